@@ -1,0 +1,231 @@
+/*
+ * tmx.h — C-ABI of libtrajopt_mi355x.so: the MI355X-native SQP inner loop of tesseract-robotics/trajopt.
+ *
+ * The reference has NO C ABI / FFI / plugin loader for this path: its extension points are C++ virtual
+ * interfaces linked at build time.  Each entry point below therefore names the reference
+ * C++ surface it stands in for (paths relative to the reference checkout); the thin C++ adapters that sit
+ * between those surfaces and this ABI are shown in INTEGRATION.md.
+ *
+ * Conventions: plain pointers and sizes only; the caller owns every host buffer; the library owns all
+ * device memory; integer status codes, never exceptions; one tmx_ctx per GPU per host thread, not
+ * re-entrant.  All floating point data is IEEE fp64; trajectories are row-major [problem][step][dof]
+ * exactly like trajopt::TrajArray / the "j_t_d" variable order (trajopt/src/problem_description.cpp:573-591).
+ */
+#ifndef TMX_H_
+#define TMX_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TMX_MAX_DOF 16
+#define TMX_API __attribute__((visibility("default")))
+
+typedef enum
+{
+  TMX_OK = 0,
+  TMX_ERR_INVALID = 1,      /* bad argument / inconsistent description                                */
+  TMX_ERR_UNSUPPORTED = 2,  /* term or QP structure the device path does not lower (never a silent CPU fallback) */
+  TMX_ERR_DEVICE = 3,       /* HIP runtime error (message in tmx_last_error)                          */
+  TMX_ERR_STATE = 4,        /* call order violated (e.g. run before upload)                           */
+  TMX_ERR_NCCL = 5
+} tmx_status;
+
+/* sco::OptStatus — trajopt_sco/include/trajopt_sco/optimizers.hpp:25-33 (same numeric values) */
+typedef enum
+{
+  TMX_OPT_CONVERGED = 0,
+  TMX_OPT_SCO_ITERATION_LIMIT = 1,
+  TMX_OPT_PENALTY_ITERATION_LIMIT = 2,
+  TMX_OPT_TIME_LIMIT = 3,
+  TMX_OPT_FAILED = 4,
+  TMX_OPT_INVALID = 5
+} tmx_opt_status;
+
+/* sco::CvxOptStatus — trajopt_sco/include/trajopt_sco/solver_interface.hpp:40-45 */
+typedef enum
+{
+  TMX_CVX_SOLVED = 0,
+  TMX_CVX_INFEASIBLE = 1,
+  TMX_CVX_FAILED = 2
+} tmx_cvx_status;
+
+/* ---- robot + scene: what trajopt reads from tesseract (kinematics JointGroup, contact managers) ------ */
+typedef struct
+{
+  int32_t type;      /* 0 revolute/continuous, 1 prismatic                                    */
+  int32_t pad_;
+  double origin[12]; /* fixed parent-link -> joint frame transform, row-major 3x4 [R | t]     */
+  double axis[3];    /* joint axis in the joint frame                                         */
+} tmx_joint;
+
+typedef struct
+{
+  int32_t link;      /* moving link index (0..n_dof-1): the child link of joint `link`        */
+  int32_t pad_;
+  double center[3];  /* sphere centre in that link's frame                                    */
+  double radius;
+} tmx_link_sphere;
+
+typedef struct
+{
+  double center[3];  /* world frame */
+  double radius;
+} tmx_obstacle_sphere;
+
+/* ---- term table: the lowered form of trajopt::TermInfo::hatch() output ------------------------------- */
+typedef enum
+{
+  /* trajopt::JointVelEqCost   trajopt/src/trajectory_costs.cpp:257-301   (squared cost, all steps in range) */
+  TMX_TERM_JOINT_VEL_COST = 1,
+  /* trajopt::JointPosEqConstraint  trajopt/src/trajectory_costs.cpp:139-183 */
+  TMX_TERM_JOINT_POS_EQ_CNT = 2,
+  /* trajopt::CartPoseTermInfo::hatch  trajopt/src/problem_description.cpp:901-987 with a static target frame:
+   * TrajOptConstraintFromErrFunc(CartPoseErrCalculator, CartPoseJacCalculator, EQ) when is_constraint != 0,
+   * TrajOptCostFromErrFunc(..., sco::ABS) otherwise; one term per timestep (first_step == last_step)        */
+  TMX_TERM_CART_POSE = 3,
+  /* trajopt::CollisionTermInfo::hatch, DISCRETE / SINGLE_TIME_STEP cost path
+   * trajopt/src/problem_description.cpp:1764-1774 -> CollisionCost trajopt/src/collision_terms.cpp:1250-1327   */
+  TMX_TERM_COLLISION_COST = 4
+} tmx_term_kind;
+
+typedef struct
+{
+  int32_t kind;        /* tmx_term_kind                                                               */
+  int32_t first_step;  /* inclusive                                                                   */
+  int32_t last_step;   /* inclusive                                                                   */
+  int32_t is_constraint;
+  double coeffs[TMX_MAX_DOF];  /* joint terms: per-DOF; cart pose: [0..5] = pos xyz, rot xyz coeffs (|c|<=1e-5 drops the row) */
+  double targets[TMX_MAX_DOF]; /* joint terms                                                         */
+  double target_pose[12];      /* cart pose: world_T_target, row-major 3x4                            */
+  double margin;               /* collision: dist_pen (contact distance threshold)                    */
+  double coeff;                /* collision: hinge coefficient                                        */
+  double buffer;               /* collision: safety_margin_buffer added to the query threshold only   */
+} tmx_term;
+
+typedef struct
+{
+  int32_t n_dof;
+  int32_t n_steps;
+  double joint_lower[TMX_MAX_DOF];
+  double joint_upper[TMX_MAX_DOF];
+  double base[12];                 /* world_T_base, row-major 3x4 */
+  tmx_joint joints[TMX_MAX_DOF];
+  double tool[12];                 /* last-link_T_tool (tcp offset) */
+  int32_t n_link_spheres;
+  int32_t n_obstacles;
+  const tmx_link_sphere* link_spheres;
+  const tmx_obstacle_sphere* obstacles;
+  int32_t n_fixed_steps;           /* BasicInfo::fixed_timesteps  trajopt/src/problem_description.cpp:485-508 */
+  int32_t n_terms;
+  const int32_t* fixed_steps;
+  const tmx_term* terms;           /* costs are hatched in list order, then constraints in list order   */
+} tmx_problem_desc;
+
+/* sco::BasicTrustRegionSQPParameters — trajopt_sco/include/trajopt_sco/optimizers.hpp:92-135 */
+typedef struct
+{
+  double improve_ratio_threshold;
+  double min_trust_box_size;
+  double min_approx_improve;
+  double min_approx_improve_frac;
+  int32_t max_iter;
+  int32_t max_qp_solver_failures;
+  double trust_shrink_ratio;
+  double trust_expand_ratio;
+  double cnt_tolerance;
+  double max_merit_coeff_increases;
+  double merit_coeff_increase_ratio;
+  double initial_merit_error_coeff;
+  int32_t inflate_constraints_individually;
+  int32_t pad_;
+  double trust_box_size;
+} tmx_sqp_params;
+
+/* OSQPSettings fields the reference touches — trajopt_sco/src/osqp_interface.cpp:78-90 (+ OSQP v1.0.0 defaults) */
+typedef struct
+{
+  double rho, sigma, alpha;
+  double eps_abs, eps_rel, eps_prim_inf, eps_dual_inf;
+  double adaptive_rho_tolerance, delta;
+  int32_t scaling, adaptive_rho, adaptive_rho_interval, max_iter;
+  int32_t polishing, polish_refine_iter, check_termination, warm_starting;
+} tmx_osqp_settings;
+
+/* per-QP record written by every batched QP solve (integer structure the parity tests compare) */
+typedef struct
+{
+  int32_t n, m, nnzP, nnzA;
+  int32_t warm_started, osqp_status, osqp_iter, rho_updates;
+  int32_t polish_status, pad_;
+  uint64_t hashP, hashA, hash_active;
+  double rho_final;
+} tmx_qp_record;
+
+typedef struct tmx_ctx tmx_ctx;
+
+/* ---- lifetime -------------------------------------------------------------------------------------- */
+TMX_API tmx_status tmx_create(int device, tmx_ctx** out);
+TMX_API void tmx_destroy(tmx_ctx* ctx);
+TMX_API const char* tmx_last_error(const tmx_ctx* ctx);
+TMX_API void tmx_default_sqp_params(tmx_sqp_params* p);       /* optimizers.hpp:92-135 defaults          */
+TMX_API void tmx_default_osqp_settings(tmx_osqp_settings* s); /* osqp_interface.cpp:78-90 defaults       */
+
+/* ---- S4: trajopt::ConstructProblem output -> device term table (problem_description.cpp:410-542) ------ */
+TMX_API tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* desc, const tmx_sqp_params* sqp,
+                                      const tmx_osqp_settings* osqp);
+
+/* ---- S3: sco::Optimizer::initialize(x) for a batch (optimizers.cpp:127-136); host or device pointers -- */
+TMX_API tmx_status tmx_batch_set_x0(tmx_ctx* ctx, const double* x0_host, int32_t batch);
+TMX_API tmx_status tmx_batch_set_x0_device(tmx_ctx* ctx, const double* x0_dev, int32_t batch);
+
+/* ---- S3: sco::BasicTrustRegionSQP::optimize() for every problem of the batch (optimizers.cpp:699-991).
+ * max_steps = 0 runs to completion; otherwise at most max_steps batched trust-region evaluations.
+ * n_active_out (optional) receives the number of problems still running.                                */
+TMX_API tmx_status tmx_sqp_run(tmx_ctx* ctx, int32_t max_steps, int32_t* n_active_out);
+
+/* sco::OptResults (optimizers.hpp:40-59) per problem; any output pointer may be NULL                    */
+TMX_API tmx_status tmx_sqp_results(tmx_ctx* ctx, double* x /*B*T*D*/, int32_t* status /*B*/, double* total_cost /*B*/,
+                                   int32_t* n_func_evals /*B*/, int32_t* n_qp_solves /*B*/);
+/* running totals over the batch since the last set_x0: {sqp trust-region evaluations, QP solves, ADMM iterations} */
+TMX_API tmx_status tmx_sqp_counters(tmx_ctx* ctx, int64_t* n_func_evals, int64_t* n_qp_solves, int64_t* n_admm_iters);
+/* per-problem QP records of the run, in solve order: out[problem*max_records + k]; counts[problem]      */
+TMX_API tmx_status tmx_sqp_qp_records(tmx_ctx* ctx, tmx_qp_record* out, int32_t max_records, int32_t* counts);
+
+/* ---- piecewise entry points (the hooks BasicTrustRegionSQP exposes "to allow overriding",
+ *      optimizers.hpp:137-194): evaluateCosts/evaluateConstraintViols, convexify*, Model::optimize ---- */
+/* exact cost values and constraint violations at the current iterate of every problem:
+ * cost_vals[B*n_costs], cnt_viols[B*n_cnts] (Cost::value / Constraint::violation)                       */
+TMX_API tmx_status tmx_term_counts(tmx_ctx* ctx, int32_t* n_costs, int32_t* n_cnts, int32_t* n_row_slots);
+TMX_API tmx_status tmx_evaluate(tmx_ctx* ctx, double* cost_vals, double* cnt_viols);
+/* convexify at the current iterate and return the linearised rows in slot order:
+ * active[B*R], coef[B*R*D], rhs[B*R] (row: coef . x_t  (op)  rhs)                                       */
+TMX_API tmx_status tmx_convexify(tmx_ctx* ctx, int32_t* active, double* coef, double* rhs);
+/* reference-layout QP of the current convexification + trust box (what OSQPModel::updateObjective /
+ * updateConstraints hand to osqp_setup, osqp_interface.cpp:170-281) for one problem.  Two-call protocol:
+ * first with all array pointers NULL to get sizes.                                                      */
+TMX_API tmx_status tmx_export_csc(tmx_ctx* ctx, int32_t problem, int32_t* n, int32_t* m, int32_t* nnzP, int32_t* nnzA,
+                                  int64_t* P_p, int64_t* P_i, double* P_x, double* q, int64_t* A_p, int64_t* A_i,
+                                  double* A_x, double* l, double* u);
+/* one batched Model::optimize() on the current convexification + trust box (osqp_interface.cpp:440-615);
+ * x_qp: B*n_max solution in reference variable order (primary vars, then aux vars); n_max from tmx_qp_dims */
+TMX_API tmx_status tmx_qp_dims(tmx_ctx* ctx, int32_t* n_max, int32_t* m_max);
+TMX_API tmx_status tmx_qp_solve(tmx_ctx* ctx, double* x_qp, int32_t* cvx_status, tmx_qp_record* rec);
+
+/* ---- K7: best-seed reduction.  Local argmin of total_cost over OPT_CONVERGED problems; when a
+ *      communicator has been attached (tmx_attach_nccl) the (cost, global index) pair is reduced over
+ *      ranks with RCCL — the only collective on the path.                               */
+TMX_API tmx_status tmx_argmin(tmx_ctx* ctx, int64_t global_offset, int64_t* best_index, double* best_cost);
+TMX_API tmx_status tmx_attach_nccl(tmx_ctx* ctx, void* nccl_comm /* ncclComm_t */);
+
+/* ---- measurement hooks (bench.py): HIP-event time and launch count of the dominant kernel ----------- */
+TMX_API tmx_status tmx_kernel_stats(tmx_ctx* ctx, double* admm_ms_total, int64_t* admm_launches, double* convexify_ms_total,
+                                    double* evaluate_ms_total);
+TMX_API tmx_status tmx_kernel_stats_reset(tmx_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TMX_H_ */

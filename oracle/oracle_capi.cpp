@@ -1,0 +1,273 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY. Not part of the shipped product path.
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use anything in oracle/.
+//
+// extern "C" surface of the CPU oracle (liborc.so) so that pytest / bench.py can drive the restated
+// reference path through ctypes.  kind = "port" for bench.py's cpu_baseline: the reference binary cannot
+// be built here (Eigen, tesseract, OSQP, Boost absent — SURVEY.md §0.1/§8c).
+#include <omp.h>
+
+#include <cstring>
+
+#include "trajprob.hpp"
+
+using namespace orc;
+
+namespace
+{
+OsqpSettings toSettings(const tmx_osqp_settings* s)
+{
+  OsqpSettings o = OsqpSettings::trajoptDefaults();
+  if (s)
+  {
+    o.rho = s->rho;
+    o.sigma = s->sigma;
+    o.alpha = s->alpha;
+    o.eps_abs = s->eps_abs;
+    o.eps_rel = s->eps_rel;
+    o.eps_prim_inf = s->eps_prim_inf;
+    o.eps_dual_inf = s->eps_dual_inf;
+    o.adaptive_rho_tolerance = s->adaptive_rho_tolerance;
+    o.delta = s->delta;
+    o.scaling = s->scaling;
+    o.adaptive_rho = s->adaptive_rho;
+    o.adaptive_rho_interval = s->adaptive_rho_interval;
+    o.max_iter = s->max_iter;
+    o.polishing = s->polishing;
+    o.polish_refine_iter = s->polish_refine_iter;
+    o.check_termination = s->check_termination;
+    o.warm_starting = s->warm_starting;
+  }
+  return o;
+}
+void toParams(const tmx_sqp_params* p, BasicTrustRegionSQPParameters& o)
+{
+  if (!p)
+    return;
+  o.improve_ratio_threshold = p->improve_ratio_threshold;
+  o.min_trust_box_size = p->min_trust_box_size;
+  o.min_approx_improve = p->min_approx_improve;
+  o.min_approx_improve_frac = p->min_approx_improve_frac;
+  o.max_iter = p->max_iter;
+  o.max_qp_solver_failures = p->max_qp_solver_failures;
+  o.trust_shrink_ratio = p->trust_shrink_ratio;
+  o.trust_expand_ratio = p->trust_expand_ratio;
+  o.cnt_tolerance = p->cnt_tolerance;
+  o.max_merit_coeff_increases = p->max_merit_coeff_increases;
+  o.merit_coeff_increase_ratio = p->merit_coeff_increase_ratio;
+  o.initial_merit_error_coeff = p->initial_merit_error_coeff;
+  o.inflate_constraints_individually = p->inflate_constraints_individually != 0;
+  o.trust_box_size = p->trust_box_size;
+}
+void toRecord(const QpTrace& t, tmx_qp_record& r)
+{
+  std::memset(&r, 0, sizeof(r));
+  r.n = static_cast<int32_t>(t.n);
+  r.m = static_cast<int32_t>(t.m);
+  r.nnzP = static_cast<int32_t>(t.nnzP);
+  r.nnzA = static_cast<int32_t>(t.nnzA);
+  r.warm_started = t.warm_started;
+  r.osqp_status = t.osqp_status;
+  r.osqp_iter = t.osqp_iter;
+  r.rho_updates = t.rho_updates;
+  r.polish_status = t.polish_status;
+  r.hashP = t.hashP;
+  r.hashA = t.hashA;
+  r.hash_active = t.hash_active;
+  r.rho_final = t.rho_final;
+}
+}  // namespace
+
+extern "C" {
+
+// BasicTrustRegionSQP::optimize() for each of B seeds, one problem per OpenMP thread.
+int orc_sqp_batch(const tmx_problem_desc* desc, const tmx_sqp_params* sqp, const tmx_osqp_settings* osqp,
+                  const double* x0, int B, int nthreads, double* x_out, int* status, double* total_cost,
+                  int* n_func_evals, int* n_qp_solves, tmx_qp_record* records, int max_records, int* rec_counts,
+                  long long* admm_iters_total)
+{
+  const int TD = desc->n_steps * desc->n_dof;
+  long long admm_total = 0;
+  int err = 0;
+#pragma omp parallel for schedule(dynamic) num_threads(nthreads > 0 ? nthreads : 1) reduction(+ : admm_total)
+  for (int b = 0; b < B; ++b)
+  {
+    try
+    {
+      TrajProblem P = constructProblem(*desc, x0 + static_cast<std::size_t>(b) * TD);
+      P.prob->getModel()->settings = toSettings(osqp);
+      std::vector<QpTrace> trace;
+      P.prob->getModel()->trace = &trace;
+      BasicTrustRegionSQP opt(P.prob);
+      toParams(sqp, opt.getParameters());
+      opt.initialize(DblVec(x0 + static_cast<std::size_t>(b) * TD, x0 + static_cast<std::size_t>(b + 1) * TD));
+      opt.optimize();
+      const OptResults& r = opt.results();
+      if (x_out)
+        std::memcpy(x_out + static_cast<std::size_t>(b) * TD, r.x.data(), sizeof(double) * TD);
+      if (status)
+        status[b] = static_cast<int>(r.status);
+      if (total_cost)
+        total_cost[b] = r.total_cost;
+      if (n_func_evals)
+        n_func_evals[b] = r.n_func_evals;
+      if (n_qp_solves)
+        n_qp_solves[b] = r.n_qp_solves;
+      for (const auto& t : trace)
+        admm_total += t.osqp_iter;
+      if (records && rec_counts)
+      {
+        const int cnt = std::min<int>(static_cast<int>(trace.size()), max_records);
+        rec_counts[b] = static_cast<int>(trace.size());
+        for (int k = 0; k < cnt; ++k)
+          toRecord(trace[k], records[static_cast<std::size_t>(b) * max_records + k]);
+      }
+    }
+    catch (...)
+    {
+#pragma omp atomic write
+      err = 1;
+    }
+  }
+  if (admm_iters_total)
+    *admm_iters_total = admm_total;
+  return err;
+}
+
+// Cost::value / Constraint::violation at x  (evaluateCosts / evaluateConstraintViols, optimizers.cpp:176-192)
+int orc_evaluate(const tmx_problem_desc* desc, const double* x0_for_fixed, const double* x, double* cost_vals,
+                 double* cnt_viols, int* n_costs, int* n_cnts)
+{
+  TrajProblem P = constructProblem(*desc, x0_for_fixed);
+  const int TD = desc->n_steps * desc->n_dof;
+  const DblVec xv(x, x + TD);
+  const auto& costs = P.prob->getCosts();
+  const auto cnts = P.prob->getConstraints();
+  if (n_costs)
+    *n_costs = static_cast<int>(costs.size());
+  if (n_cnts)
+    *n_cnts = static_cast<int>(cnts.size());
+  if (cost_vals)
+    for (std::size_t i = 0; i < costs.size(); ++i)
+      cost_vals[i] = costs[i]->value(xv);
+  if (cnt_viols)
+    for (std::size_t i = 0; i < cnts.size(); ++i)
+      cnt_viols[i] = cnts[i]->violation(xv);
+  return 0;
+}
+
+// First QP of an SQP run at x (convexify + trust box) exactly as handed to osqp_setup, plus its solution.
+// Two-call protocol: call with arrays NULL to obtain sizes.
+int orc_first_qp(const tmx_problem_desc* desc, const tmx_sqp_params* sqp, const tmx_osqp_settings* osqp,
+                 const double* x, int* n, int* m, int* nnzP, int* nnzA, long long* P_p, long long* P_i, double* P_x,
+                 double* q, long long* A_p, long long* A_i, double* A_x, double* l, double* u, double* sol_x,
+                 double* sol_y, tmx_qp_record* rec)
+{
+  TrajProblem P = constructProblem(*desc, x);
+  P.prob->getModel()->settings = toSettings(osqp);
+  std::vector<QpTrace> trace;
+  P.prob->getModel()->trace = &trace;
+  BasicTrustRegionSQP opt(P.prob);
+  toParams(sqp, opt.getParameters());
+  // one convexify + one QP: emulate by limiting the loops
+  opt.getParameters().max_iter = 1;
+  opt.getParameters().max_merit_coeff_increases = 1;
+  opt.getParameters().improve_ratio_threshold = -std::numeric_limits<double>::infinity();
+  const int TD = desc->n_steps * desc->n_dof;
+  opt.initialize(DblVec(x, x + TD));
+  // Run; the first Model::optimize() call is the one we want — capture it through the model's last CSC if only
+  // one QP was solved, otherwise re-run with a trace limit is unnecessary: exact_merit_improve<0 still shrinks.
+  // To be robust we stop after the first QP by making every step "converged": min_approx_improve = +inf.
+  opt.getParameters().min_approx_improve = std::numeric_limits<double>::infinity();
+  opt.optimize();
+  auto model = P.prob->getModel();
+  const Csc& Pm = model->P_csc;
+  const Csc& Am = model->A_csc;
+  *n = static_cast<int>(Pm.n);
+  *m = static_cast<int>(Am.m);
+  *nnzP = static_cast<int>(Pm.nnz());
+  *nnzA = static_cast<int>(Am.nnz());
+  if (P_p)
+    std::memcpy(P_p, Pm.p.data(), sizeof(long long) * Pm.p.size());
+  if (P_i)
+    std::memcpy(P_i, Pm.i.data(), sizeof(long long) * Pm.i.size());
+  if (P_x)
+    std::memcpy(P_x, Pm.x.data(), sizeof(double) * Pm.x.size());
+  if (q)
+    std::memcpy(q, model->q_.data(), sizeof(double) * model->q_.size());
+  if (A_p)
+    std::memcpy(A_p, Am.p.data(), sizeof(long long) * Am.p.size());
+  if (A_i)
+    std::memcpy(A_i, Am.i.data(), sizeof(long long) * Am.i.size());
+  if (A_x)
+    std::memcpy(A_x, Am.x.data(), sizeof(double) * Am.x.size());
+  if (l)
+    std::memcpy(l, model->l_.data(), sizeof(double) * model->l_.size());
+  if (u)
+    std::memcpy(u, model->u_.data(), sizeof(double) * model->u_.size());
+  if (sol_x && model->lastSolver())
+    std::memcpy(sol_x, model->lastSolver()->sol_x.data(), sizeof(double) * Pm.n);
+  if (sol_y && model->lastSolver())
+    std::memcpy(sol_y, model->lastSolver()->sol_y.data(), sizeof(double) * Am.m);
+  if (rec && !trace.empty())
+    toRecord(trace[0], *rec);
+  return static_cast<int>(trace.size());
+}
+
+// osqp_setup + (optional osqp_warm_start) + osqp_solve on a caller-supplied CSC QP.
+int orc_qp_solve(int n, int m, const long long* P_p, const long long* P_i, const double* P_x, const double* q,
+                 const long long* A_p, const long long* A_i, const double* A_x, const double* l, const double* u,
+                 const tmx_osqp_settings* osqp, const double* warm_x, const double* warm_y, double* x, double* y,
+                 int* status, int* iters, int* rho_updates, int* polish_status, int* active_flags, double* rho_final)
+{
+  Csc P, A;
+  P.m = n;
+  P.n = n;
+  P.p.assign(P_p, P_p + n + 1);
+  P.i.assign(P_i, P_i + P_p[n]);
+  P.x.assign(P_x, P_x + P_p[n]);
+  A.m = m;
+  A.n = n;
+  A.p.assign(A_p, A_p + n + 1);
+  A.i.assign(A_i, A_i + A_p[n]);
+  A.x.assign(A_x, A_x + A_p[n]);
+  OsqpSolver s;
+  const int ret = s.setup(P, DblVec(q, q + n), A, DblVec(l, l + m), DblVec(u, u + m), toSettings(osqp));
+  if (ret != 0)
+    return ret;
+  if (warm_x && warm_y)
+    s.warmStart(DblVec(warm_x, warm_x + n), DblVec(warm_y, warm_y + m));
+  s.solve();
+  if (x)
+    std::memcpy(x, s.sol_x.data(), sizeof(double) * n);
+  if (y)
+    std::memcpy(y, s.sol_y.data(), sizeof(double) * m);
+  if (status)
+    *status = s.info.status_val;
+  if (iters)
+    *iters = s.info.iter;
+  if (rho_updates)
+    *rho_updates = s.info.rho_updates;
+  if (polish_status)
+    *polish_status = s.info.status_polish;
+  if (active_flags)
+    std::memcpy(active_flags, s.active_flags.data(), sizeof(int) * m);
+  if (rho_final)
+    *rho_final = s.currentRho();
+  return 0;
+}
+
+// FK of the tool frame + CartPose error/Jacobian + contacts — piecewise KAT hooks for the GPU kernels
+int orc_fk_tool(const tmx_problem_desc* desc, const double* q, double* tf12)
+{
+  Chain c(*desc);
+  const Tf T = c.fkTool(q);
+  for (int r = 0; r < 3; ++r)
+  {
+    for (int k = 0; k < 3; ++k)
+      tf12[4 * r + k] = T.R[3 * r + k];
+    tf12[4 * r + 3] = T.t[r];
+  }
+  return 0;
+}
+int orc_num_threads() { return omp_get_max_threads(); }
+}

@@ -1,0 +1,106 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.  ctypes driver of oracle/_build/liborc.so (the CPU restatement of the
+reference path).  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force: bool = False):
+    so = os.path.join(_HERE, "_build", "liborc.so")
+    if force or not os.path.exists(so) or not os.path.exists(os.path.join(_HERE, "_build", "orc_kat")):
+        subprocess.check_call(["make", "-C", _HERE, "-j4"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+    return _LIB
+
+
+def _p(a, t=C.c_double):
+    return a.ctypes.data_as(C.POINTER(t)) if a is not None else None
+
+
+def sqp_batch(desc, x0, sqp=None, osqp=None, nthreads=0, max_records=64):
+    """BasicTrustRegionSQP::optimize for every seed.  Returns dict of numpy arrays (+ per-QP records)."""
+    from trajopt_amd import abi
+    x0 = np.ascontiguousarray(x0, dtype=np.float64)
+    B = x0.shape[0]
+    TD = desc.n_steps * desc.n_dof
+    x = np.zeros((B, TD))
+    status = np.zeros(B, np.int32)
+    cost = np.zeros(B)
+    nfe = np.zeros(B, np.int32)
+    nqp = np.zeros(B, np.int32)
+    recs = (abi.QpRecord * (B * max_records))()
+    cnts = np.zeros(B, np.int32)
+    admm = C.c_longlong(0)
+    if nthreads <= 0:
+        nthreads = os.cpu_count() or 1
+    rc = lib().orc_sqp_batch(C.byref(desc), C.byref(sqp) if sqp is not None else None,
+                             C.byref(osqp) if osqp is not None else None, _p(x0), B, nthreads, _p(x),
+                             _p(status, C.c_int), _p(cost), _p(nfe, C.c_int), _p(nqp, C.c_int), recs, max_records,
+                             _p(cnts, C.c_int), C.byref(admm))
+    if rc != 0:
+        raise RuntimeError("oracle sqp_batch failed")
+    return dict(x=x.reshape(B, desc.n_steps, desc.n_dof), status=status, total_cost=cost, n_func_evals=nfe,
+                n_qp_solves=nqp, records=recs, rec_counts=cnts, max_records=max_records, admm_iters=admm.value)
+
+
+def evaluate(desc, x0_fixed, x):
+    nc, nn = C.c_int(0), C.c_int(0)
+    x0_fixed = np.ascontiguousarray(x0_fixed, np.float64)
+    x = np.ascontiguousarray(x, np.float64)
+    lib().orc_evaluate(C.byref(desc), _p(x0_fixed), _p(x), None, None, C.byref(nc), C.byref(nn))
+    cv, vv = np.zeros(nc.value), np.zeros(nn.value)
+    lib().orc_evaluate(C.byref(desc), _p(x0_fixed), _p(x), _p(cv), _p(vv), C.byref(nc), C.byref(nn))
+    return cv, vv
+
+
+def first_qp(desc, x, sqp=None, osqp=None):
+    """The first QP of an SQP run at x exactly as handed to osqp_setup (+ its OSQP solution)."""
+    from trajopt_amd import abi
+    x = np.ascontiguousarray(x, np.float64)
+    n, m, nzp, nza = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
+    a = (C.byref(desc), C.byref(sqp) if sqp is not None else None, C.byref(osqp) if osqp is not None else None, _p(x),
+         C.byref(n), C.byref(m), C.byref(nzp), C.byref(nza))
+    lib().orc_first_qp(*a, *([None] * 12))
+    Pp, Pi, Px = np.zeros(n.value + 1, np.int64), np.zeros(nzp.value, np.int64), np.zeros(nzp.value)
+    Ap, Ai, Ax = np.zeros(n.value + 1, np.int64), np.zeros(nza.value, np.int64), np.zeros(nza.value)
+    q, l, u = np.zeros(n.value), np.zeros(m.value), np.zeros(m.value)
+    sx, sy = np.zeros(n.value), np.zeros(m.value)
+    rec = abi.QpRecord()
+    lib().orc_first_qp(*a, _p(Pp, C.c_longlong), _p(Pi, C.c_longlong), _p(Px), _p(q), _p(Ap, C.c_longlong),
+                       _p(Ai, C.c_longlong), _p(Ax), _p(l), _p(u), _p(sx), _p(sy), C.byref(rec))
+    return dict(n=n.value, m=m.value, P_p=Pp, P_i=Pi, P_x=Px, q=q, A_p=Ap, A_i=Ai, A_x=Ax, l=l, u=u, x=sx, y=sy, rec=rec)
+
+
+def qp_solve(qp, osqp=None, warm_x=None, warm_y=None):
+    n, m = qp["n"], qp["m"]
+    x, y = np.zeros(n), np.zeros(m)
+    st, it, ru, ps = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
+    act = np.zeros(m, np.int32)
+    rho = C.c_double(0)
+    rc = lib().orc_qp_solve(n, m, _p(qp["P_p"], C.c_longlong), _p(qp["P_i"], C.c_longlong), _p(qp["P_x"]), _p(qp["q"]),
+                            _p(qp["A_p"], C.c_longlong), _p(qp["A_i"], C.c_longlong), _p(qp["A_x"]), _p(qp["l"]),
+                            _p(qp["u"]), C.byref(osqp) if osqp is not None else None,
+                            _p(warm_x) if warm_x is not None else None, _p(warm_y) if warm_y is not None else None,
+                            _p(x), _p(y), C.byref(st), C.byref(it), C.byref(ru), C.byref(ps), _p(act, C.c_int),
+                            C.byref(rho))
+    if rc != 0:
+        raise RuntimeError(f"oracle osqp_setup failed: {rc}")
+    return dict(x=x, y=y, status=st.value, iters=it.value, rho_updates=ru.value, polish_status=ps.value, active=act,
+                rho=rho.value)
+
+
+def run_kat():
+    build()
+    out = subprocess.run([os.path.join(_HERE, "_build", "orc_kat")], capture_output=True, text=True)
+    return out.returncode, out.stdout

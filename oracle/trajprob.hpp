@@ -1,0 +1,611 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY. Not part of the shipped product path.
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use anything in oracle/.
+//
+// CPU restatement of the trajopt term layer for the hot path (paths relative to /root/reference/):
+//   trajopt/src/trajectory_costs.cpp:139-183,257-301     JointPosEqConstraint, JointVelEqCost
+//   trajopt/src/kinematic_terms.cpp:187-366              CartPoseErrCalculator / CartPoseJacCalculator (FD, eps=1e-5)
+//   trajopt/src/collision_terms.cpp:203-250,343-383,540-556,655-691,1283-1327   single-timestep CollisionCost
+//   trajopt/src/problem_description.cpp:410-592,901-987,1764-1774               ConstructProblem / hatch order
+// Third-party arithmetic NOT under /root/reference and restated from its published behaviour
+// (parity UNPINNED — tesseract is a floating dependency, .github/workflows/ubuntu.yml:50):
+//   tesseract::kinematics::JointGroup::calcFwdKin / calcJacobian     -> serial-chain FK / geometric Jacobian
+//   tesseract::common::calcTransformError / calcJacobianTransformErrorDiff / calcRotationalError
+//   tesseract contact managers (Bullet)                              -> analytic sphere-sphere signed distance
+#pragma once
+#include <array>
+#include <cmath>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../include/tmx.h"
+#include "sco.hpp"
+
+namespace orc
+{
+// ---- rigid transforms (row-major 3x4 [R|t]) ---------------------------------------------------
+struct Tf
+{
+  double R[9];
+  double t[3];
+};
+inline Tf tfIdentity()
+{
+  Tf T{};
+  T.R[0] = T.R[4] = T.R[8] = 1.0;
+  return T;
+}
+inline Tf tfFrom12(const double* a)
+{
+  Tf T;
+  for (int r = 0; r < 3; ++r)
+  {
+    for (int c = 0; c < 3; ++c)
+      T.R[3 * r + c] = a[4 * r + c];
+    T.t[r] = a[4 * r + 3];
+  }
+  return T;
+}
+inline Tf tfMul(const Tf& A, const Tf& B)
+{
+  Tf C;
+  for (int r = 0; r < 3; ++r)
+  {
+    for (int c = 0; c < 3; ++c)
+      C.R[3 * r + c] = A.R[3 * r + 0] * B.R[0 + c] + A.R[3 * r + 1] * B.R[3 + c] + A.R[3 * r + 2] * B.R[6 + c];
+    C.t[r] = A.R[3 * r + 0] * B.t[0] + A.R[3 * r + 1] * B.t[1] + A.R[3 * r + 2] * B.t[2] + A.t[r];
+  }
+  return C;
+}
+inline Tf tfInv(const Tf& A)
+{
+  Tf C;
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c)
+      C.R[3 * r + c] = A.R[3 * c + r];
+  for (int r = 0; r < 3; ++r)
+    C.t[r] = -(C.R[3 * r + 0] * A.t[0] + C.R[3 * r + 1] * A.t[1] + C.R[3 * r + 2] * A.t[2]);
+  return C;
+}
+// Rodrigues rotation about a unit axis
+inline Tf tfRotAxis(const double* ax, double ang)
+{
+  Tf T = tfIdentity();
+  const double c = std::cos(ang), s = std::sin(ang), v = 1.0 - c;
+  const double x = ax[0], y = ax[1], z = ax[2];
+  T.R[0] = c + x * x * v;
+  T.R[1] = x * y * v - z * s;
+  T.R[2] = x * z * v + y * s;
+  T.R[3] = y * x * v + z * s;
+  T.R[4] = c + y * y * v;
+  T.R[5] = y * z * v - x * s;
+  T.R[6] = z * x * v - y * s;
+  T.R[7] = z * y * v + x * s;
+  T.R[8] = c + z * z * v;
+  return T;
+}
+inline Tf tfTransAxis(const double* ax, double d)
+{
+  Tf T = tfIdentity();
+  T.t[0] = ax[0] * d;
+  T.t[1] = ax[1] * d;
+  T.t[2] = ax[2] * d;
+  return T;
+}
+
+// ---- serial chain (stands in for tesseract JointGroup) ------------------------------------------
+struct Chain
+{
+  int n_dof{ 0 };
+  Tf base, tool;
+  std::vector<Tf> origin;
+  std::vector<std::array<double, 3>> axis;
+  std::vector<int> type;
+
+  explicit Chain(const tmx_problem_desc& d) : n_dof(d.n_dof), base(tfFrom12(d.base)), tool(tfFrom12(d.tool))
+  {
+    for (int k = 0; k < n_dof; ++k)
+    {
+      origin.push_back(tfFrom12(d.joints[k].origin));
+      axis.push_back({ d.joints[k].axis[0], d.joints[k].axis[1], d.joints[k].axis[2] });
+      type.push_back(d.joints[k].type);
+    }
+  }
+  // world transforms of every moving link (link k = child of joint k); joint frames before motion in `jf`
+  void fk(const double* q, std::vector<Tf>& link, std::vector<Tf>* jf = nullptr) const
+  {
+    link.resize(n_dof);
+    if (jf)
+      jf->resize(n_dof);
+    Tf T = base;
+    for (int k = 0; k < n_dof; ++k)
+    {
+      T = tfMul(T, origin[k]);
+      if (jf)
+        (*jf)[k] = T;
+      T = tfMul(T, type[k] == 0 ? tfRotAxis(axis[k].data(), q[k]) : tfTransAxis(axis[k].data(), q[k]));
+      link[k] = T;
+    }
+  }
+  Tf fkTool(const double* q) const
+  {
+    std::vector<Tf> link;
+    fk(q, link);
+    return tfMul(link[n_dof - 1], tool);
+  }
+  // translational geometric Jacobian (3 x n_dof, row-major) of world point p rigidly attached to `link_idx`
+  void jacobianPoint(const double* q, int link_idx, const double* p, double* J) const
+  {
+    std::vector<Tf> link, jf;
+    fk(q, link, &jf);
+    for (int k = 0; k < n_dof; ++k)
+    {
+      double col[3] = { 0, 0, 0 };
+      if (k <= link_idx)
+      {
+        const Tf& F = jf[k];
+        double z[3];
+        for (int r = 0; r < 3; ++r)
+          z[r] = F.R[3 * r + 0] * axis[k][0] + F.R[3 * r + 1] * axis[k][1] + F.R[3 * r + 2] * axis[k][2];
+        if (type[k] == 0)
+        {
+          const double d[3] = { p[0] - F.t[0], p[1] - F.t[1], p[2] - F.t[2] };
+          col[0] = z[1] * d[2] - z[2] * d[1];
+          col[1] = z[2] * d[0] - z[0] * d[2];
+          col[2] = z[0] * d[1] - z[1] * d[0];
+        }
+        else
+        {
+          col[0] = z[0];
+          col[1] = z[1];
+          col[2] = z[2];
+        }
+      }
+      J[0 * n_dof + k] = col[0];
+      J[1 * n_dof + k] = col[1];
+      J[2 * n_dof + k] = col[2];
+    }
+  }
+};
+
+// ---- tesseract::common::calcRotationalErrorDecomposed / calcTransformError [NOT IN REFERENCE] ----
+// Rotation matrix -> Eigen-style quaternion -> Eigen-style angle-axis, sign fixed so the axis follows
+// the quaternion vector part, angle wrapped to [-pi, pi].
+inline void rotErrDecomposed(const double* R, double axis[3], double& angle)
+{
+  // Eigen::Quaternion(Matrix3) (Shepperd branch selection)
+  double qw, qx, qy, qz;
+  const double tr = R[0] + R[4] + R[8];
+  if (tr > 0.0)
+  {
+    double t = std::sqrt(tr + 1.0);
+    qw = 0.5 * t;
+    t = 0.5 / t;
+    qx = (R[7] - R[5]) * t;
+    qy = (R[2] - R[6]) * t;
+    qz = (R[3] - R[1]) * t;
+  }
+  else
+  {
+    int i = 0;
+    if (R[4] > R[0])
+      i = 1;
+    if (R[8] > R[4 * i])
+      i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    double t = std::sqrt(R[4 * i] - R[4 * j] - R[4 * k] + 1.0);
+    double qv[3];
+    qv[i] = 0.5 * t;
+    t = 0.5 / t;
+    qw = (R[3 * k + j] - R[3 * j + k]) * t;
+    qv[j] = (R[3 * j + i] + R[3 * i + j]) * t;
+    qv[k] = (R[3 * k + i] + R[3 * i + k]) * t;
+    qx = qv[0];
+    qy = qv[1];
+    qz = qv[2];
+  }
+  // Eigen::AngleAxis(Quaternion)
+  double n = std::sqrt(qx * qx + qy * qy + qz * qz);
+  double ang, ax[3];
+  if (n != 0.0)
+  {
+    ang = 2.0 * std::atan2(n, std::fabs(qw));
+    if (qw < 0)
+      n = -n;
+    ax[0] = qx / n;
+    ax[1] = qy / n;
+    ax[2] = qz / n;
+  }
+  else
+  {
+    ang = 0.0;
+    ax[0] = 1.0;
+    ax[1] = 0.0;
+    ax[2] = 0.0;
+  }
+  // tesseract: keep the axis aligned with the quaternion vector part, wrap angle to [-pi, pi]
+  const double s = ((qx * ax[0] + qy * ax[1] + qz * ax[2]) < 0) ? -1.0 : 1.0;
+  const double two_pi = 2.0 * M_PI;
+  double a = s * ang;
+  a = std::copysign(std::fmod(std::fabs(a), two_pi), a);
+  if (a < -M_PI)
+    a += two_pi;
+  else if (a > M_PI)
+    a -= two_pi;
+  axis[0] = s * ax[0];
+  axis[1] = s * ax[1];
+  axis[2] = s * ax[2];
+  angle = a;
+}
+// calcTransformError(t1, t2): 6-vector [translation ; axis*angle] of t1^-1 * t2
+inline void transformError(const Tf& t1, const Tf& t2, double err[6])
+{
+  const Tf pe = tfMul(tfInv(t1), t2);
+  double ax[3], ang;
+  rotErrDecomposed(pe.R, ax, ang);
+  err[0] = pe.t[0];
+  err[1] = pe.t[1];
+  err[2] = pe.t[2];
+  err[3] = ax[0] * ang;
+  err[4] = ax[1] * ang;
+  err[5] = ax[2] * ang;
+}
+// calcJacobianTransformErrorDiff(target, source, source_perturbed) with the +-pi discontinuity handling
+inline void transformErrorDiff(const Tf& target, const Tf& source, const Tf& source_pert, double diff[6])
+{
+  const Tf tinv = tfInv(target);
+  const Tf pe = tfMul(tinv, source);
+  double ax0[3], a0;
+  rotErrDecomposed(pe.R, ax0, a0);
+  const Tf pp = tfMul(tinv, source_pert);
+  double ax1[3], a1;
+  rotErrDecomposed(pp.R, ax1, a1);
+  double a1c = a1;
+  if (a1 > M_PI_2 && a0 < -M_PI_2)
+    a1c = a1 - 2.0 * M_PI;
+  else if (a1 < -M_PI_2 && a0 > M_PI_2)
+    a1c = a1 + 2.0 * M_PI;
+  for (int r = 0; r < 3; ++r)
+  {
+    diff[r] = pp.t[r] - pe.t[r];
+    diff[3 + r] = ax1[r] * a1c - ax0[r] * a0;
+  }
+}
+
+// ---- VarArray-lite ---------------------------------------------------------------------------
+struct VarArray
+{
+  int rows{ 0 }, cols{ 0 };
+  VarVector v;
+  const Var& operator()(int r, int c) const { return v[static_cast<std::size_t>(r) * cols + c]; }
+  VarVector row(int r) const { return VarVector(v.begin() + r * cols, v.begin() + (r + 1) * cols); }
+};
+
+// ---- trajopt::JointVelEqCost  trajectory_costs.cpp:257-301 --------------------------------------
+class JointVelEqCost : public Cost
+{
+public:
+  JointVelEqCost(const VarArray& vars, DblVec coeffs, DblVec targets, int first_step, int last_step)
+    : vars_(vars), coeffs_(std::move(coeffs)), targets_(std::move(targets)), first_step_(first_step), last_step_(last_step)
+  {
+    name_ = "JointVelEq";
+    for (int i = first_step_; i <= last_step_ - 1; ++i)
+      for (int j = 0; j < vars_.cols; ++j)
+      {
+        AffExpr vel;
+        exprInc(vel, exprMult(vars_(i, j), -1));
+        exprInc(vel, exprMult(vars_(i + 1, j), 1));
+        exprDec(vel, targets_[j]);
+        exprInc(expr_, exprMult(exprSquare(vel), coeffs_[j]));
+      }
+  }
+  double value(const DblVec& x) override
+  {
+    // (diff.array().square().matrix() * coeffs.asDiagonal()).sum() — Eigen reduction order is
+    // column-major over the (steps-1) x dof block
+    double s = 0;
+    for (int j = 0; j < vars_.cols; ++j)
+      for (int i = first_step_; i <= last_step_ - 1; ++i)
+      {
+        const double d = (vars_(i + 1, j).value(x) - vars_(i, j).value(x)) - targets_[j];
+        s += (d * d) * coeffs_[j];
+      }
+    return s;
+  }
+  std::shared_ptr<ConvexObjective> convex(const DblVec&, Model* model) override
+  {
+    auto out = std::make_shared<ConvexObjective>(model);
+    out->addQuadExpr(expr_);
+    return out;
+  }
+
+private:
+  VarArray vars_;
+  DblVec coeffs_, targets_;
+  int first_step_, last_step_;
+  QuadExpr expr_;
+};
+
+// ---- trajopt::JointPosEqConstraint  trajectory_costs.cpp:139-183 (quirk Q5: value() is coeff*diff^2) ----
+class JointPosEqConstraint : public Constraint
+{
+public:
+  JointPosEqConstraint(const VarArray& vars, DblVec coeffs, DblVec targets, int first_step, int last_step)
+    : vars_(vars), coeffs_(std::move(coeffs)), targets_(std::move(targets)), first_step_(first_step), last_step_(last_step)
+  {
+    name_ = "JointPosEq";
+    for (int i = first_step_; i <= last_step_; ++i)
+      for (int j = 0; j < vars_.cols; ++j)
+      {
+        AffExpr pos;
+        exprInc(pos, exprMult(vars_(i, j), 1));
+        exprDec(pos, targets_[j]);
+        expr_vec_.push_back(exprMult(pos, coeffs_[j]));
+      }
+  }
+  ConstraintType type() override { return EQ; }
+  DblVec value(const DblVec& x) override
+  {
+    // toDblVec of a (steps x dof) column-major Eigen matrix: dof-major within... the matrix is
+    // (diff^2) * diag(coeffs); toDblVec copies data() (column-major): for j, for i.
+    DblVec out;
+    for (int j = 0; j < vars_.cols; ++j)
+      for (int i = first_step_; i <= last_step_; ++i)
+      {
+        const double d = vars_(i, j).value(x) - targets_[j];
+        out.push_back((d * d) * coeffs_[j]);
+      }
+    return out;
+  }
+  std::shared_ptr<ConvexConstraints> convex(const DblVec&, Model* model) override
+  {
+    auto out = std::make_shared<ConvexConstraints>(model);
+    for (const AffExpr& e : expr_vec_)
+      out->addEqCnt(e);
+    return out;
+  }
+
+private:
+  VarArray vars_;
+  DblVec coeffs_, targets_;
+  int first_step_, last_step_;
+  AffExprVector expr_vec_;
+};
+
+// ---- CartPoseErrCalculator / CartPoseJacCalculator with a static target  kinematic_terms.cpp:250-263,348-366 ----
+struct CartPoseCalc
+{
+  std::shared_ptr<const Chain> chain;
+  Tf target;  // world_T_target
+  std::vector<int> indices;
+  DblVec err(const DblVec& q) const
+  {
+    const Tf src = chain->fkTool(q.data());
+    double e[6];
+    transformError(target, src, e);
+    DblVec out(indices.size());
+    for (std::size_t i = 0; i < indices.size(); ++i)
+      out[i] = e[indices[i]];
+    return out;
+  }
+  Mat jac(const DblVec& q) const
+  {
+    const Tf src = chain->fkTool(q.data());
+    Mat J(static_cast<int>(indices.size()), static_cast<int>(q.size()));
+    DblVec qp = q;
+    for (std::size_t i = 0; i < q.size(); ++i)
+    {
+      qp[i] = q[i] + DEFAULT_EPSILON;
+      const Tf sp = chain->fkTool(qp.data());
+      double d[6];
+      transformErrorDiff(target, src, sp, d);
+      for (std::size_t r = 0; r < indices.size(); ++r)
+        J(static_cast<int>(r), static_cast<int>(i)) = d[indices[r]] / DEFAULT_EPSILON;
+      qp[i] = q[i];
+    }
+    return J;
+  }
+};
+
+// ---- sphere-vs-sphere "contact manager" + CollisionCost (SINGLE_TIME_STEP) -------------------------
+struct Scene
+{
+  std::vector<tmx_link_sphere> link_spheres;
+  std::vector<tmx_obstacle_sphere> obstacles;
+};
+struct Contact
+{
+  int sphere, obstacle, link;
+  double distance;
+  double normal[3];         // from the link sphere towards the obstacle (object 0 -> object 1)
+  double nearest_world[3];  // nearest point on the link sphere, world frame
+};
+// stands in for SingleTimestepCollisionEvaluator::CalcCollisions  collision_terms.cpp:655-691
+inline void calcContacts(const Chain& chain, const Scene& scene, const double* q, double margin, double buffer,
+                         std::vector<Contact>& out)
+{
+  out.clear();
+  std::vector<Tf> link;
+  chain.fk(q, link);
+  for (std::size_t s = 0; s < scene.link_spheres.size(); ++s)
+  {
+    const auto& ls = scene.link_spheres[s];
+    const Tf& T = link[ls.link];
+    double c[3];
+    for (int r = 0; r < 3; ++r)
+      c[r] = T.R[3 * r + 0] * ls.center[0] + T.R[3 * r + 1] * ls.center[1] + T.R[3 * r + 2] * ls.center[2] + T.t[r];
+    for (std::size_t o = 0; o < scene.obstacles.size(); ++o)
+    {
+      const auto& ob = scene.obstacles[o];
+      const double d[3] = { ob.center[0] - c[0], ob.center[1] - c[1], ob.center[2] - c[2] };
+      const double len = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+      const double dist = len - ls.radius - ob.radius;
+      if (dist > (margin + buffer))
+        continue;  // filter at collision_terms.cpp:679-687
+      Contact ct;
+      ct.sphere = static_cast<int>(s);
+      ct.obstacle = static_cast<int>(o);
+      ct.link = ls.link;
+      ct.distance = dist;
+      for (int r = 0; r < 3; ++r)
+      {
+        ct.normal[r] = (len > 0) ? d[r] / len : (r == 2 ? 1.0 : 0.0);
+        ct.nearest_world[r] = c[r] + ls.radius * ct.normal[r];
+      }
+      out.push_back(ct);
+    }
+  }
+}
+
+class CollisionCostSingle : public Cost
+{
+public:
+  CollisionCostSingle(std::shared_ptr<const Chain> chain, std::shared_ptr<const Scene> scene, VarVector vars,
+                      double margin, double coeff, double buffer, const std::string& name)
+    : chain_(std::move(chain)), scene_(std::move(scene)), vars_(std::move(vars)), margin_(margin), coeff_(coeff), buffer_(buffer)
+  {
+    name_ = name;
+  }
+  // collision_terms.cpp:1283-1304 + :540-556 + :343-383 + :203-250
+  std::shared_ptr<ConvexObjective> convex(const DblVec& x, Model* model) override
+  {
+    auto out = std::make_shared<ConvexObjective>(model);
+    const DblVec q = getDblVec(x, vars_);
+    std::vector<Contact> cts;
+    calcContacts(*chain_, *scene_, q.data(), margin_, buffer_, cts);
+    const int D = chain_->n_dof;
+    DblVec J(3 * D);
+    for (const Contact& ct : cts)
+    {
+      chain_->jacobianPoint(q.data(), ct.link, ct.nearest_world, J.data());
+      DblVec grad(D);
+      for (int k = 0; k < D; ++k)
+        grad[k] = -1.0 * (ct.normal[0] * J[0 * D + k] + ct.normal[1] * J[1 * D + k] + ct.normal[2] * J[2 * D + k]);
+      AffExpr dist(0);
+      exprInc(dist, varDot(grad, vars_));  // scale == 1 for discrete contacts
+      double gq = 0;
+      for (int k = 0; k < D; ++k)
+        gq += grad[k] * q[k];
+      exprInc(dist, -gq);
+      exprInc(dist, ct.distance);
+      // quirk Q4: cleanupAff result discarded on the single-timestep path (collision_terms.cpp:554)
+      const AffExpr viol = exprSub(AffExpr(margin_), dist);
+      out->addHinge(viol, coeff_);
+    }
+    return out;
+  }
+  // collision_terms.cpp:1306-1327 — buffer excluded from the value
+  double value(const DblVec& x) override
+  {
+    const DblVec q = getDblVec(x, vars_);
+    std::vector<Contact> cts;
+    calcContacts(*chain_, *scene_, q.data(), margin_, buffer_, cts);
+    double out = 0;
+    for (const Contact& ct : cts)
+      out += pospart(margin_ - ct.distance) * coeff_;
+    return out;
+  }
+
+private:
+  std::shared_ptr<const Chain> chain_;
+  std::shared_ptr<const Scene> scene_;
+  VarVector vars_;
+  double margin_, coeff_, buffer_;
+};
+
+// ---- trajopt::ConstructProblem  problem_description.cpp:410-592 ------------------------------------
+struct TrajProblem
+{
+  std::shared_ptr<OptProb> prob;
+  VarArray traj_vars;
+  std::shared_ptr<Chain> chain;
+  std::shared_ptr<Scene> scene;
+  int n_costs{ 0 }, n_cnts{ 0 };
+};
+
+inline TrajProblem constructProblem(const tmx_problem_desc& d, const double* init_traj)
+{
+  TrajProblem P;
+  P.prob = std::make_shared<OptProb>();
+  P.chain = std::make_shared<Chain>(d);
+  P.scene = std::make_shared<Scene>();
+  for (int i = 0; i < d.n_link_spheres; ++i)
+    P.scene->link_spheres.push_back(d.link_spheres[i]);
+  for (int i = 0; i < d.n_obstacles; ++i)
+    P.scene->obstacles.push_back(d.obstacles[i]);
+  const int T = d.n_steps, D = d.n_dof;
+  // TrajOptProb ctor :553-592
+  std::vector<std::string> names;
+  DblVec vlower, vupper;
+  for (int i = 0; i < T; ++i)
+    for (int j = 0; j < D; ++j)
+    {
+      names.push_back("j_" + std::to_string(i) + "_" + std::to_string(j));
+      vlower.push_back(d.joint_lower[j]);
+      vupper.push_back(d.joint_upper[j]);
+    }
+  P.traj_vars.rows = T;
+  P.traj_vars.cols = D;
+  P.traj_vars.v = P.prob->createVariables(names, vlower, vupper);
+  // fixed timesteps :485-508
+  std::vector<int> fixed(d.fixed_steps, d.fixed_steps + d.n_fixed_steps);
+  for (int t_idx : fixed)
+    for (int j = 0; j < D; ++j)
+      P.prob->addLinearConstraint(exprSub(AffExpr(P.traj_vars(t_idx, j)), init_traj[t_idx * D + j]), EQ);
+  // hatch costs then constraints :532-540
+  for (int pass = 0; pass < 2; ++pass)
+    for (int k = 0; k < d.n_terms; ++k)
+    {
+      const tmx_term& tm = d.terms[k];
+      const bool is_cnt = (tm.kind == TMX_TERM_JOINT_POS_EQ_CNT) || (tm.kind == TMX_TERM_CART_POSE && tm.is_constraint);
+      if ((pass == 0) == is_cnt)
+        continue;
+      switch (tm.kind)
+      {
+        case TMX_TERM_JOINT_VEL_COST:
+          P.prob->addCost(std::make_shared<JointVelEqCost>(P.traj_vars, DblVec(tm.coeffs, tm.coeffs + D),
+                                                           DblVec(tm.targets, tm.targets + D), tm.first_step, tm.last_step));
+          break;
+        case TMX_TERM_JOINT_POS_EQ_CNT:
+          P.prob->addConstraint(std::make_shared<JointPosEqConstraint>(
+              P.traj_vars, DblVec(tm.coeffs, tm.coeffs + D), DblVec(tm.targets, tm.targets + D), tm.first_step, tm.last_step));
+          break;
+        case TMX_TERM_CART_POSE:
+        {
+          // CartPoseTermInfo::hatch :901-987 — rows with |coeff| <= 1e-5 are dropped
+          auto calc = std::make_shared<CartPoseCalc>();
+          calc->chain = P.chain;
+          calc->target = tfFrom12(tm.target_pose);
+          DblVec c;
+          for (int i = 0; i < 6; ++i)
+            if (std::fabs(tm.coeffs[i]) > 1e-5)
+            {
+              calc->indices.push_back(i);
+              c.push_back(tm.coeffs[i]);
+            }
+          VectorOfVector f = [calc](const DblVec& q) { return calc->err(q); };
+          MatrixOfVector dfdx = [calc](const DblVec& q) { return calc->jac(q); };
+          for (int t = tm.first_step; t <= tm.last_step; ++t)
+          {
+            if (tm.is_constraint)
+              P.prob->addConstraint(std::make_shared<ConstraintFromErrFunc>(f, dfdx, P.traj_vars.row(t), c, EQ, "cart_pose"));
+            else
+              P.prob->addCost(std::make_shared<CostFromErrFunc>(f, dfdx, P.traj_vars.row(t), c, ABS, "cart_pose"));
+          }
+          break;
+        }
+        case TMX_TERM_COLLISION_COST:
+          for (int i = tm.first_step; i <= tm.last_step; ++i)
+            if (std::find(fixed.begin(), fixed.end(), i) == fixed.end())
+              P.prob->addCost(std::make_shared<CollisionCostSingle>(P.chain, P.scene, P.traj_vars.row(i), tm.margin,
+                                                                    tm.coeff, tm.buffer, "collision_" + std::to_string(i)));
+          break;
+        default:
+          throw std::runtime_error("unknown term kind");
+      }
+    }
+  P.n_costs = static_cast<int>(P.prob->getCosts().size());
+  P.n_cnts = static_cast<int>(P.prob->getConstraints().size());
+  return P;
+}
+}  // namespace orc

@@ -1,0 +1,84 @@
+"""The BASELINE.json configurations restated as concrete synthetic inputs.
+
+The reference ships none of glass_upright / puzzle_piece / car_seat (README.md:40-42: the examples moved to
+tesseract_ros2); they are synthesised from the README prose + the term semantics.  Seeds: straight-line joint
+interpolation + N(0, sigma^2) per joint per interior waypoint, clipped to the joint limits, drawn from a
+counter-based Philox generator keyed by (config_id, problem index) so every consumer sees identical inputs.
+"""
+import numpy as np
+
+from .problem import (BasicInfo, CartPoseTermInfo, CollisionTermInfo, JointPosTermInfo, JointVelTermInfo,
+                      ProblemConstructionInfo, pr2_right_arm, _tf12)
+
+
+def make_seeds(config_id: int, start, goal, n_steps: int, batch: int, lower, upper, sigma: float = 0.1,
+               first: int = 0) -> np.ndarray:
+    """x0[b] = LinSpaced(start, goal) (problem_description.cpp:351-355) + N(0, sigma^2) on interior waypoints."""
+    start, goal = np.asarray(start, np.float64), np.asarray(goal, np.float64)
+    D = start.shape[0]
+    w = np.linspace(0.0, 1.0, n_steps)[:, None]
+    line = start[None, :] * (1.0 - w) + goal[None, :] * w
+    out = np.empty((batch, n_steps, D))
+    for b in range(batch):
+        rng = np.random.Generator(np.random.Philox(key=[config_id, first + b]))
+        noise = rng.standard_normal((n_steps, D)) * sigma
+        noise[0] = 0.0
+        noise[-1] = 0.0
+        out[b] = np.clip(line + noise, lower + 1e-3, upper - 1e-3)
+    return out
+
+
+# ---- config 0: planning-unit plumbing case --------------------------------------------------------------
+CFG0_START = np.array([-1.832, -0.332, -1.011, -1.437, -1.1, -1.926, 3.074])   # pr2.srdf right_start
+CFG0_GOAL = np.array([0.062, 1.287, 0.1, -1.554, -3.011, -0.268, 2.988])       # pr2.srdf right_goal / arm_around_table.json
+
+
+def config0(n_steps: int = 10):
+    """7-DOF, JointVel squared cost (coeff 1, target 0) + JointPos equality constraint at the last step +
+    fixed_timesteps=[0]; mirrors trajopt/test/joint_costs_unit.cpp:264-345 / arm_around_table.json minus collision."""
+    rob = pr2_right_arm()
+    pci = ProblemConstructionInfo(rob, BasicInfo(n_steps=n_steps, fixed_timesteps=[0]))
+    D = rob.n_dof
+    pci.cost_infos.append(JointVelTermInfo(coeffs=[1.0] * D, targets=[0.0] * D, first_step=0, last_step=n_steps - 1))
+    pci.cnt_infos.append(JointPosTermInfo(coeffs=[1.0] * D, targets=list(CFG0_GOAL), first_step=n_steps - 1,
+                                          last_step=n_steps - 1))
+    return pci, CFG0_START, CFG0_GOAL
+
+
+# ---- config 1: glass_upright ------------------------------------------------------------------------------
+CFG1_START = np.array([-1.6, 0.2, -1.0, -1.2, 0.5, -1.0, 0.3])
+CFG1_GOAL = np.array([-0.1, 0.2, -1.0, -1.2, 0.5, -1.0, 0.3])
+
+
+def config1(n_steps: int = 30, with_collision: bool = True):
+    """glass_upright: JointVel cost (coeff 1); start fixed; goal JointPos constraint at T-1; "upright" = CartPose
+    constraint on the tool frame at every non-fixed waypoint with pos_coeffs 0 and rot_coeffs (1,1,0) (2 rows per
+    waypoint); SINGLE_TIME_STEP collision cost, dist_pen 0.025, coeff 20, buffer 0.5; one sphere obstacle r=0.15.
+    The tool frame is re-oriented so that it is world-aligned at the start state; the goal differs from the start
+    by a shoulder-pan sweep, so the straight-line seed keeps the glass upright and the obstacle sits in the sweep."""
+    rob = pr2_right_arm()
+    T0 = rob.fk_tool(CFG1_START)
+    tool = np.array(rob.tool)
+    tool[:, :3] = tool[:, :3] @ T0[:3, :3].T        # tool' = tool * R_tool(start)^T  => R_tool'(start) = I
+    rob.tool = tool
+    pci = ProblemConstructionInfo(rob, BasicInfo(n_steps=n_steps, fixed_timesteps=[0]))
+    D = rob.n_dof
+    pci.cost_infos.append(JointVelTermInfo(coeffs=[1.0] * D, targets=[0.0] * D, first_step=0, last_step=n_steps - 1))
+    if with_collision:
+        pci.cost_infos.append(CollisionTermInfo(first_step=0, last_step=n_steps - 1, dist_pen=0.025, coeff=20.0,
+                                                safety_margin_buffer=0.5))
+        qmid = 0.5 * (CFG1_START + CFG1_GOAL)
+        pmid = rob.fk_tool(qmid)[:3, 3]
+        pci.obstacles.append(((float(pmid[0]) + 0.02, float(pmid[1]), float(pmid[2]) - 0.17), 0.15))
+    target = _tf12()   # identity rotation; position irrelevant (pos_coeffs = 0)
+    for t in range(1, n_steps):
+        pci.cnt_infos.append(CartPoseTermInfo(timestep=t, target_pose=target, pos_coeffs=(0, 0, 0),
+                                              rot_coeffs=(1, 1, 0), is_constraint=True))
+    pci.cnt_infos.append(JointPosTermInfo(coeffs=[1.0] * D, targets=list(CFG1_GOAL), first_step=n_steps - 1,
+                                          last_step=n_steps - 1))
+    return pci, CFG1_START, CFG1_GOAL
+
+
+def seeds_for(config_id: int, pci, start, goal, batch: int, sigma: float = 0.1, first: int = 0):
+    rob = pci.robot
+    return make_seeds(config_id, start, goal, pci.basic_info.n_steps, batch, rob.lower, rob.upper, sigma, first)

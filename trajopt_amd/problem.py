@@ -1,0 +1,224 @@
+"""Host-side mirror of trajopt::ProblemConstructionInfo for the hot path (Python, because the tests and the
+bench driver are Python; the C++ adapters for real trajopt callers are in INTEGRATION.md).
+
+Mirrors (names and argument meaning) /root/reference/trajopt/include/trajopt/problem_description.hpp:
+  BasicInfo :111-160, InitInfo :162-190, JointVelTermInfo, JointPosTermInfo, CartPoseTermInfo, CollisionTermInfo
+and lowers them to the flat `tmx_problem_desc` that both libtrajopt_mi355x.so and the CPU oracle consume.
+Robot kinematics / collision geometry, which trajopt reads from tesseract, are supplied explicitly here.
+"""
+import ctypes as C
+import json
+import math
+import os
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import abi
+
+_DATA = os.path.join(os.path.dirname(__file__), "data")
+
+
+def _tf12(R=None, t=None):
+    T = np.zeros((3, 4))
+    T[:, :3] = np.eye(3) if R is None else np.asarray(R, dtype=np.float64)
+    if t is not None:
+        T[:, 3] = t
+    return T
+
+
+def rot_axis(axis, ang):
+    """Rodrigues rotation (same formula as the oracle / device code)"""
+    x, y, z = axis
+    c, s = math.cos(ang), math.sin(ang)
+    v = 1.0 - c
+    return np.array([[c + x * x * v, x * y * v - z * s, x * z * v + y * s],
+                     [y * x * v + z * s, c + y * y * v, y * z * v - x * s],
+                     [z * x * v - y * s, z * y * v + x * s, c + z * z * v]])
+
+
+@dataclass
+class Robot:
+    """serial chain + collision spheres (what trajopt gets from tesseract JointGroup / contact managers)"""
+    joint_types: List[int]
+    origins: List[np.ndarray]        # 3x4 each
+    axes: List[np.ndarray]
+    lower: np.ndarray
+    upper: np.ndarray
+    base: np.ndarray = field(default_factory=_tf12)
+    tool: np.ndarray = field(default_factory=_tf12)
+    link_spheres: List[tuple] = field(default_factory=list)   # (link, (x,y,z), r)
+
+    @property
+    def n_dof(self):
+        return len(self.joint_types)
+
+    def fk_links(self, q):
+        T = np.vstack([self.base, [0, 0, 0, 1]])
+        out = []
+        for k in range(self.n_dof):
+            T = T @ np.vstack([self.origins[k], [0, 0, 0, 1]])
+            M = np.eye(4)
+            if self.joint_types[k] == 0:
+                M[:3, :3] = rot_axis(self.axes[k], q[k])
+            else:
+                M[:3, 3] = np.asarray(self.axes[k]) * q[k]
+            T = T @ M
+            out.append(T.copy())
+        return out
+
+    def fk_tool(self, q):
+        return self.fk_links(q)[-1] @ np.vstack([self.tool, [0, 0, 0, 1]])
+
+
+def pr2_right_arm() -> Robot:
+    """PR2 right arm (7 DOF) — the only 7-DOF model in the reference
+    (trajopt_common/data/arm_around_table.urdf:1479-1866, extracted by tools/extract_pr2_chain.py).
+    Collision geometry: 8 spheres hand-placed along upper arm / forearm / gripper (synthetic, stands in for the
+    convex meshes tesseract would load)."""
+    d = json.load(open(os.path.join(_DATA, "pr2_right_arm.json")))
+    js = d["joints"]
+    rob = Robot(
+        joint_types=[j["type"] for j in js],
+        origins=[_tf12(t=j["origin_xyz"]) for j in js],
+        axes=[np.array(j["axis"], dtype=np.float64) for j in js],
+        lower=np.array([j["lower"] for j in js], dtype=np.float64),
+        upper=np.array([j["upper"] for j in js], dtype=np.float64),
+        tool=_tf12(t=d["tool_xyz"]),
+    )
+    rob.link_spheres = [
+        (2, (0.10, 0.0, 0.0), 0.09), (2, (0.25, 0.0, 0.0), 0.09),
+        (3, (0.00, 0.0, 0.0), 0.08),
+        (4, (0.10, 0.0, 0.0), 0.07), (4, (0.22, 0.0, 0.0), 0.07),
+        (5, (0.00, 0.0, 0.0), 0.06),
+        (6, (0.08, 0.0, 0.0), 0.05), (6, (0.16, 0.0, 0.0), 0.05),
+    ]
+    return rob
+
+
+# ---- TermInfo mirrors -------------------------------------------------------------------------------
+@dataclass
+class JointVelTermInfo:
+    """trajopt::JointVelTermInfo (cost form) — hatch -> JointVelEqCost, problem_description.cpp:1197-1372"""
+    coeffs: Sequence[float]
+    targets: Sequence[float]
+    first_step: int = 0
+    last_step: int = -1
+    name: str = "joint_vel"
+
+
+@dataclass
+class JointPosTermInfo:
+    """trajopt::JointPosTermInfo (constraint form) — hatch -> JointPosEqConstraint, problem_description.cpp:1059-1176"""
+    coeffs: Sequence[float]
+    targets: Sequence[float]
+    first_step: int = 0
+    last_step: int = -1
+    name: str = "joint_pos"
+
+
+@dataclass
+class CartPoseTermInfo:
+    """trajopt::CartPoseTermInfo with a static target frame — problem_description.cpp:901-987"""
+    timestep: int
+    target_pose: np.ndarray              # 3x4 world_T_target
+    pos_coeffs: Sequence[float] = (1, 1, 1)
+    rot_coeffs: Sequence[float] = (1, 1, 1)
+    is_constraint: bool = True           # TT_CNT -> EQ constraint ; TT_COST -> ABS cost
+    name: str = "cart_pose"
+
+
+@dataclass
+class CollisionTermInfo:
+    """trajopt::CollisionTermInfo, TT_COST, evaluator_type SINGLE_TIME_STEP (DISCRETE) — problem_description.cpp:1617-1774.
+    JSON defaults: coeff 20, buffer 0.5 (quirk Q3), dist_pen given."""
+    first_step: int = 0
+    last_step: int = -1
+    dist_pen: float = 0.025
+    coeff: float = 20.0
+    safety_margin_buffer: float = 0.5
+    name: str = "collision"
+
+
+@dataclass
+class BasicInfo:
+    """trajopt::BasicInfo — problem_description.hpp:111-160"""
+    n_steps: int
+    fixed_timesteps: List[int] = field(default_factory=list)
+
+
+class ProblemConstructionInfo:
+    """trajopt::ProblemConstructionInfo mirror: costs hatch first (list order), then constraints (list order)."""
+
+    def __init__(self, robot: Robot, basic_info: BasicInfo):
+        self.robot = robot
+        self.basic_info = basic_info
+        self.cost_infos: list = []
+        self.cnt_infos: list = []
+        self.obstacles: List[tuple] = []     # ((x,y,z), r)
+        self._keep = []
+
+    # -- lowering -----------------------------------------------------------------------------------
+    def to_desc(self) -> abi.ProblemDesc:
+        rob, T, D = self.robot, self.basic_info.n_steps, self.robot.n_dof
+        if D > abi.TMX_MAX_DOF:
+            raise ValueError("n_dof exceeds TMX_MAX_DOF")
+        d = abi.ProblemDesc()
+        d.n_dof, d.n_steps = D, T
+        for j in range(D):
+            d.joint_lower[j], d.joint_upper[j] = rob.lower[j], rob.upper[j]
+            d.joints[j].type = rob.joint_types[j]
+            d.joints[j].origin[:] = list(np.asarray(rob.origins[j]).reshape(-1))
+            d.joints[j].axis[:] = list(rob.axes[j])
+        d.base[:] = list(np.asarray(rob.base).reshape(-1))
+        d.tool[:] = list(np.asarray(rob.tool).reshape(-1))
+        ls = (abi.LinkSphere * max(1, len(rob.link_spheres)))()
+        for i, (link, c, r) in enumerate(rob.link_spheres):
+            ls[i].link, ls[i].radius = link, r
+            ls[i].center[:] = list(c)
+        ob = (abi.ObstacleSphere * max(1, len(self.obstacles)))()
+        for i, (c, r) in enumerate(self.obstacles):
+            ob[i].center[:] = list(c)
+            ob[i].radius = r
+        fixed = (C.c_int32 * max(1, len(self.basic_info.fixed_timesteps)))(*self.basic_info.fixed_timesteps)
+        terms = []
+        for ti in list(self.cost_infos) + list(self.cnt_infos):
+            t = abi.Term()
+            if isinstance(ti, JointVelTermInfo):
+                t.kind = abi.TERM_JOINT_VEL_COST
+                t.first_step = ti.first_step
+                t.last_step = ti.last_step if ti.last_step >= 0 else T - 1
+                co = list(ti.coeffs) * D if len(ti.coeffs) == 1 else list(ti.coeffs)
+                t.coeffs[:D] = co
+                t.targets[:D] = list(ti.targets)
+            elif isinstance(ti, JointPosTermInfo):
+                t.kind = abi.TERM_JOINT_POS_EQ_CNT
+                t.is_constraint = 1
+                t.first_step = ti.first_step
+                t.last_step = ti.last_step if ti.last_step >= 0 else T - 1
+                co = list(ti.coeffs) * D if len(ti.coeffs) == 1 else list(ti.coeffs)
+                t.coeffs[:D] = co
+                t.targets[:D] = list(ti.targets)
+            elif isinstance(ti, CartPoseTermInfo):
+                t.kind = abi.TERM_CART_POSE
+                t.first_step = t.last_step = ti.timestep
+                t.is_constraint = 1 if ti.is_constraint else 0
+                t.coeffs[:6] = list(ti.pos_coeffs) + list(ti.rot_coeffs)
+                t.target_pose[:] = list(np.asarray(ti.target_pose).reshape(-1))
+            elif isinstance(ti, CollisionTermInfo):
+                t.kind = abi.TERM_COLLISION_COST
+                t.first_step = ti.first_step
+                t.last_step = ti.last_step if ti.last_step >= 0 else T - 1
+                t.margin, t.coeff, t.buffer = ti.dist_pen, ti.coeff, ti.safety_margin_buffer
+            else:
+                raise TypeError(f"term {type(ti).__name__} is not lowered by the device path (explicit, not silent)")
+            terms.append(t)
+        tarr = (abi.Term * max(1, len(terms)))(*terms)
+        d.n_link_spheres, d.n_obstacles = len(rob.link_spheres), len(self.obstacles)
+        d.link_spheres, d.obstacles = ls, ob
+        d.n_fixed_steps, d.n_terms = len(self.basic_info.fixed_timesteps), len(terms)
+        d.fixed_steps, d.terms = fixed, tarr
+        self._keep = [ls, ob, fixed, tarr]   # keep the pointed-to arrays alive
+        d._keep = self._keep
+        return d
