@@ -1,0 +1,163 @@
+#!/usr/bin/env python3
+"""bench.py — BASELINE.json's metric on BASELINE.json's config.
+
+A "step" is one complete pass of the hot path over one batch of synthetic input: BasicTrustRegionSQP::optimize()
+(convexify + batched QP solves + exact re-evaluation + trust-region/penalty logic) for 1024 random seeds per GPU
+of the glass_upright problem (config 1: 7-DOF, 30 waypoints, JointVel cost, upright CartPose constraints, goal
+JointPos constraint, single-timestep collision cost).  Seeds are resident in HBM before the timed region.
+  value = SQP iterations / s over all GPUs  (one SQP iteration = one trust-region evaluation = one QP solve + one
+          exact re-evaluation; the reference's counters n_func_evals-1 / n_qp_solves, optimizers.hpp:47)
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), each rank owns its own 1024 seeds (weak scaling,
+no data-path collective); the only exchange is the best-seed all_gather after every step.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_PEAK_TFLOPS = 78.6  # MI355X fp64 vector = matrix peak (spec) — the guide lists no fp64 MFMA row
+BATCH_PER_GPU = 1024
+
+
+def algorithmic_flops_per_admm_iter(T, D, n, m, nnzA):
+    """SURVEY.md §8(d) Phase B: 2 block-triangular sweeps (T*8*D^2) + 2 SpMV with A (4*nnz(A)) + ~12*(n+m) vector ops"""
+    return 8.0 * T * D * D + 4.0 * nnzA + 12.0 * (n + m)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="seeds per GPU (BASELINE: 1024)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from trajopt_amd import abi, configs, parallel, runtime
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    pci, start, goal = configs.config1()
+    desc = pci.to_desc()
+    T, D = pci.basic_info.n_steps, pci.robot.n_dof
+    B = args.batch
+    ctx = runtime.Context(local_rank)
+    ctx.upload(desc, abi.default_sqp_params(), abi.default_osqp_settings())
+
+    nsteps = args.warmup + args.steps
+    # synthetic seeds (counter-based Philox keyed by (config, global problem index)), resident in HBM before timing
+    seeds_host = configs.seeds_for(1, pci, start, goal, B * nsteps, first=rank * B * nsteps)
+    seeds = torch.from_numpy(seeds_host.reshape(nsteps, B, T, D)).to(dev)
+    torch.cuda.synchronize()
+
+    def one_step(k):
+        ctx.set_x0_device(seeds[k].data_ptr(), B)
+        ctx.run(0)
+        r = ctx.results()
+        c, i = parallel.local_best(r["status"], r["total_cost"], (rank * nsteps + k) * B)
+        best = parallel.best_seed_allgather(c, i, dev)   # the only collective (RCCL all_gather of 16 bytes / rank)
+        return r, best
+
+    for k in range(args.warmup):
+        one_step(k)
+    ctx.kernel_stats(reset=True)
+    c0 = ctx.counters()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    tot_fe = tot_qp = tot_admm = 0
+    conv = 0
+    for k in range(args.warmup, nsteps):
+        r, best = one_step(k)
+        c = ctx.counters()
+        tot_fe += int((r["n_func_evals"] - 1).sum())
+        tot_qp += int(r["n_qp_solves"].sum())
+        tot_admm += c["admm_iters"]
+        conv += int((r["status"] == abi.OPT_CONVERGED).sum())
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    stats = ctx.kernel_stats()
+    tt = torch.tensor([elapsed, float(tot_fe), float(tot_qp), float(tot_admm), float(conv)], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = tt.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = tt.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        elapsed = float(tmax[0])
+        g_fe, g_qp, g_admm, g_conv = (float(tsum[i]) for i in range(1, 5))
+    else:
+        g_fe, g_qp, g_admm, g_conv = float(tot_fe), float(tot_qp), float(tot_admm), float(conv)
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel (k_qp_solve = batched OSQP-style ADMM), rank 0, HIP-event timed ----
+        recs, cnt = ctx.qp_records(4)
+        r0 = recs[0]
+        f_iter = algorithmic_flops_per_admm_iter(T, D, r0.n, r0.m, r0.nnzA)
+        launches = max(1, stats["admm_launches"])
+        flops_per_launch = f_iter * tot_admm / launches
+        avg_ms = stats["admm_ms"] / launches
+        achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        roofline = {
+            "kernel": "k_qp_solve", "bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None,
+            "avg_launch_ms": avg_ms, "launches": launches, "algorithmic_flop_per_admm_iter": f_iter,
+            "admm_iters_per_launch": tot_admm / launches,
+            "kernel_time_share": {"admm_ms": stats["admm_ms"], "convexify_ms": stats["convexify_ms"],
+                                  "evaluate_ms": stats["evaluate_ms"], "wall_ms": (t1 - t0) * 1e3},
+        }
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import pyorc
+            cores = os.cpu_count() or 1
+            nsample = 16
+            xs = seeds_host[:nsample]
+            pyorc.build()
+            tc0 = time.perf_counter()
+            o = pyorc.sqp_batch(desc, xs, nthreads=cores)
+            tc1 = time.perf_counter()
+            cpu = {"value": float((o["n_func_evals"] - 1).sum() / (tc1 - tc0)), "unit": "SQP iters/s", "cores": cores,
+                   "kind": "port",
+                   "sample": f"first {nsample} seeds of the same workload, one problem per OpenMP thread, "
+                             f"{tc1 - tc0:.1f} s wall; restated reference CPU path (oracle/), not the upstream binary",
+                   "qp_solves_per_s": float(o["n_qp_solves"].sum() / (tc1 - tc0)),
+                   "admm_iters_per_s": float(o["admm_iters"] / (tc1 - tc0))}
+        line = {
+            "metric": "SQP iters/s (+ QP solves/s), 7-DOF x 30-wp x 1024-batch glass_upright",
+            "value": g_fe / elapsed, "unit": "SQP iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / max(1, args.steps) * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "config 1: glass_upright 7-DOF 30-waypoint, collision cost, batch=%d random seeds per GPU" % B,
+                       "n_dof": D, "n_steps": T, "batch_per_gpu": B, "qp_n": r0.n, "qp_m": r0.m, "parallelism": "seeds sharded, dp%d" % world},
+            "qp_solves_per_s": g_qp / elapsed, "admm_iters_per_s": g_admm / elapsed,
+            "converged_frac": g_conv / (B * world * max(1, args.steps)),
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -164,6 +164,26 @@ typedef struct
   double rho_final;
 } tmx_qp_record;
 
+/* Hash used in tmx_qp_record (our parity artefact, not a reference quantity): an order-sensitive but
+ * reduction-friendly position hash  H(a, salt) = sum_k mix64(a[k] + GOLD*(k+1) + salt)  (mod 2^64).
+ *   hashP = H(P colptr, 1) + H(P rowidx, 2);  hashA likewise with salts 3, 4 (int64 index arrays exactly as
+ *   handed to osqp_setup);  hash_active = H(polish active flags in reference row order, 5).               */
+#if defined(__HIPCC__)
+#define TMX_HD __host__ __device__
+#else
+#define TMX_HD
+#endif
+TMX_HD static inline uint64_t tmx_mix64(uint64_t z)
+{
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  return z ^ (z >> 31);
+}
+TMX_HD static inline uint64_t tmx_hash_term(int64_t value, uint64_t k, uint64_t salt)
+{
+  return tmx_mix64((uint64_t)value + 0x9E3779B97F4A7C15ULL * (k + 1) + salt);
+}
+
 typedef struct tmx_ctx tmx_ctx;
 
 /* ---- lifetime -------------------------------------------------------------------------------------- */

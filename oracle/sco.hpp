@@ -20,6 +20,7 @@
 #include <string>
 #include <vector>
 
+#include "../include/tmx.h"
 #include "osqp_restate.hpp"
 
 namespace orc
@@ -397,14 +398,13 @@ inline Csc upperTriangle(const Csc& M)
   return U;
 }
 
-inline uint64_t fnv1a(const void* data, std::size_t bytes, uint64_t h = 1469598103934665603ULL)
+// position hash of an integer array — definition in include/tmx.h (tmx_hash_term)
+template <typename T>
+inline uint64_t posHash(const std::vector<T>& a, uint64_t salt)
 {
-  const unsigned char* p = static_cast<const unsigned char*>(data);
-  for (std::size_t k = 0; k < bytes; ++k)
-  {
-    h ^= p[k];
-    h *= 1099511628211ULL;
-  }
+  uint64_t h = 0;
+  for (std::size_t k = 0; k < a.size(); ++k)
+    h += tmx_hash_term(static_cast<int64_t>(a[k]), k, salt);
   return h;
 }
 
@@ -426,10 +426,10 @@ enum CvxOptStatus
 struct QpTrace  // one record per Model::optimize() — the integer structure the parity tests compare
 {
   Int n, m, nnzP, nnzA;
-  uint64_t hashP, hashA;  // FNV-1a over (colptr,rowidx) int64 arrays
+  uint64_t hashP, hashA;  // position hash (include/tmx.h) over the (colptr,rowidx) int64 arrays
   int warm_started;
   int osqp_status, osqp_iter, rho_updates, polish_status;
-  uint64_t hash_active;  // FNV-1a over the polish active flags
+  uint64_t hash_active;  // position hash over the polish active flags
   double rho_final;
 };
 
@@ -573,14 +573,14 @@ public:
       t.m = A_csc.m;
       t.nnzP = P_csc.nnz();
       t.nnzA = A_csc.nnz();
-      t.hashP = fnv1a(P_csc.i.data(), P_csc.i.size() * sizeof(Int), fnv1a(P_csc.p.data(), P_csc.p.size() * sizeof(Int)));
-      t.hashA = fnv1a(A_csc.i.data(), A_csc.i.size() * sizeof(Int), fnv1a(A_csc.p.data(), A_csc.p.size() * sizeof(Int)));
+      t.hashP = posHash(P_csc.p, 1) + posHash(P_csc.i, 2);
+      t.hashA = posHash(A_csc.p, 3) + posHash(A_csc.i, 4);
       t.warm_started = warm;
       t.osqp_status = status;
       t.osqp_iter = solver_->info.iter;
       t.rho_updates = solver_->info.rho_updates;
       t.polish_status = solver_->info.status_polish;
-      t.hash_active = fnv1a(solver_->active_flags.data(), solver_->active_flags.size() * sizeof(int));
+      t.hash_active = posHash(solver_->active_flags, 5);
       t.rho_final = solver_->currentRho();
       trace->push_back(t);
     }

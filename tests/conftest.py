@@ -1,0 +1,47 @@
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HOSTEMU_DIR = os.path.join(ROOT, "tests", "hostemu")
+HOSTEMU_LIB = os.path.join(HOSTEMU_DIR, "_build", "libtmx_hostemu.so")
+PRODUCT_LIB = os.path.join(ROOT, "trajopt_amd", "_build", "libtrajopt_mi355x.so")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `pytest -m gpu` on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def orc():
+    """CPU oracle (test infrastructure)"""
+    from oracle import pyorc
+    pyorc.build()
+    return pyorc
+
+
+@pytest.fixture(scope="session")
+def hostemu_lib():
+    """kernel sources compiled for the host — CPU-tier scaffolding only (tests/hostemu/Makefile)"""
+    if not os.path.exists(HOSTEMU_LIB) or os.path.getmtime(HOSTEMU_LIB) < max(
+            os.path.getmtime(os.path.join(ROOT, "trajopt_amd", "csrc", f)) for f in os.listdir(os.path.join(ROOT, "trajopt_amd", "csrc"))):
+        subprocess.check_call(["make", "-C", HOSTEMU_DIR], stdout=subprocess.DEVNULL)
+    return HOSTEMU_LIB
+
+
+@pytest.fixture(scope="session")
+def gpu_ctx_factory():
+    """real HIP library on cuda:0; fails (does not skip) if the extension or the device is missing"""
+    import torch
+    from trajopt_amd import runtime
+    assert torch.cuda.is_available(), "gpu-marked test collected without a GPU"
+    assert os.path.exists(PRODUCT_LIB), "libtrajopt_mi355x.so missing: run __graft_entry__.build()"
+
+    def make():
+        return runtime.Context(0)
+    return make

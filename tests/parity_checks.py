@@ -1,0 +1,79 @@
+"""Step-level parity checks shared by the CPU tier (kernel sources compiled for the host) and the GPU tier (the real
+HIP library).  Every check feeds the device path and the oracle IDENTICAL inputs and compares one stage of the hot
+path: exact term values, convexified rows / reference-layout CSC, one Model::optimize(), and the SQP state machine.
+
+Why step-level: BasicTrustRegionSQP is discontinuous in its inputs (accept/reject, polish success, the 1e-7
+cleanup threshold, the byte-prefix sparsity test that gates OSQP warm starts).  The oracle itself, compiled with vs
+without FMA contraction, ends up to 3e-2 rad apart on config 1 with different QP counts, so
+end-to-end trajectories are compared statistically, and the bit-exact / 1e-5 bars apply per stage.
+"""
+import numpy as np
+
+from trajopt_amd import abi
+
+TOL_TRAJ = 1e-5      # rad — north_star tolerance for joint trajectories / QP primal solutions
+
+
+def make_ctx_inputs(ctx, pci, x0, sqp=None, osqp=None):
+    desc = pci.to_desc()
+    ctx.upload(desc, sqp or abi.default_sqp_params(), osqp or abi.default_osqp_settings())
+    ctx.set_x0(x0)
+    return desc
+
+
+def check_evaluate(ctx, orc, desc, x0, tol):
+    cv, vv = ctx.evaluate()
+    for b in range(x0.shape[0]):
+        ocv, ovv = orc.evaluate(desc, x0[b], x0[b])
+        assert cv[b].shape == ocv.shape and vv[b].shape == ovv.shape
+        assert np.abs(cv[b] - ocv).max(initial=0.0) <= tol, "cost values differ"
+        assert np.abs(vv[b] - ovv).max(initial=0.0) <= tol, "constraint violations differ"
+
+
+def check_first_qp_structure(ctx, orc, desc, x0, b, val_tol):
+    """convexify at x0[b] and compare the QP handed to osqp_setup: integer CSC arrays bit-exact, values to val_tol"""
+    ctx.convexify()
+    e = ctx.export_csc(b)
+    q = orc.first_qp(desc, x0[b])
+    assert (e["n"], e["m"]) == (q["n"], q["m"])
+    for k in ("P_p", "P_i", "A_p", "A_i"):
+        assert np.array_equal(e[k], q[k]), f"{k}: integer CSC arrays must be bit-exact"
+    for k in ("P_x", "q", "A_x", "l", "u"):
+        assert np.abs(e[k] - q[k]).max(initial=0.0) <= val_tol, f"{k} differs by {np.abs(e[k] - q[k]).max()}"
+    return q
+
+
+def check_first_qp_solve(ctx, orc, desc, x0, x_tol=TOL_TRAJ, require_same_iters=True):
+    """one cold-started Model::optimize() per problem vs the oracle's OSQP on the same QP"""
+    ctx.convexify()
+    xq, cvx, rec = ctx.qp_solve()
+    out = []
+    for b in range(x0.shape[0]):
+        q = orc.first_qp(desc, x0[b])
+        r, o = rec[b], q["rec"]
+        assert (r.n, r.m, r.nnzP, r.nnzA) == (o.n, o.m, o.nnzP, o.nnzA)
+        assert (r.hashP, r.hashA) == (o.hashP, o.hashA), "CSC index hashes differ"
+        assert r.warm_started == o.warm_started == 0
+        assert r.osqp_status == o.osqp_status
+        same = (r.osqp_iter, r.rho_updates, r.polish_status, r.hash_active) == (o.osqp_iter, o.rho_updates, o.polish_status, o.hash_active)
+        if require_same_iters:
+            assert same, f"b={b}: iters/rho_updates/polish/active-set differ: {(r.osqp_iter, r.rho_updates, r.polish_status)} vs {(o.osqp_iter, o.rho_updates, o.polish_status)}"
+        dx = np.abs(xq[b, :r.n] - q["x"]).max()
+        if same:
+            assert dx <= x_tol, f"b={b}: QP solution differs by {dx}"
+        out.append((same, dx))
+    return out
+
+
+def check_full_sqp(ctx, orc, desc, x0, x_tol=TOL_TRAJ, exact=True):
+    """whole BasicTrustRegionSQP run; `exact` demands identical integer outcomes and trajectories within x_tol"""
+    ctx.run(0)
+    r = ctx.results()
+    o = orc.sqp_batch(desc, x0, max_records=128)
+    B = x0.shape[0]
+    dx = np.abs(r["x"] - o["x"]).reshape(B, -1).max(axis=1)
+    same = (r["status"] == o["status"]) & (r["n_qp_solves"] == o["n_qp_solves"]) & (r["n_func_evals"] == o["n_func_evals"])
+    if exact:
+        assert same.all(), f"status/counters differ: {r['status']} {o['status']} {r['n_qp_solves']} {o['n_qp_solves']}"
+        assert dx.max() <= x_tol, f"trajectories differ by {dx.max()}"
+    return r, o, same, dx

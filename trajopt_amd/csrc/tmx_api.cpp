@@ -1,0 +1,958 @@
+// tmx_api.cpp — host side of libtrajopt_mi355x.so: the C-ABI of include/tmx.h.
+// Lowers the problem description to the device term table / row-slot template, owns all device memory, and drives
+// the batched SQP (convexify -> QP solve -> exact re-evaluation -> decisions) as a short chain of kernel launches per
+// trust-region evaluation on one HIP stream; the host only reads back one "problems still running" counter.
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "tmx_kernels.h"
+
+#ifdef TMX_HOST_EMU
+#include <chrono>
+thread_local tmx_emu_idx tmx_emu_threadIdx, tmx_emu_blockIdx, tmx_emu_blockDim, tmx_emu_gridDim;
+thread_local double* tmx_emu_smem = nullptr;
+double tmx_emu_now_ms()
+{
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+#else
+#include <rccl/rccl.h>
+#endif
+
+#define HIPCHK(call)                                                                                                  \
+  do                                                                                                                  \
+  {                                                                                                                   \
+    hipError_t e_ = (call);                                                                                           \
+    if (e_ != hipSuccess)                                                                                             \
+    {                                                                                                                 \
+      ctx->err = std::string(#call) + ": " + hipGetErrorString(e_);                                                   \
+      return TMX_ERR_DEVICE;                                                                                          \
+    }                                                                                                                 \
+  } while (0)
+
+struct tmx_ctx
+{
+  int device{ 0 };
+  hipStream_t stream{ nullptr };
+  std::string err;
+  bool have_problem{ false };
+  DevProblem hp{};        // host copy (device pointers inside)
+  DevProblem* dp{ nullptr };
+  DevBatch hb{};
+  DevBatch* db{ nullptr };
+  int Bcap{ 0 };
+  std::vector<void*> prob_allocs, batch_allocs;
+  long long* d_totals{ nullptr };
+  size_t smem_qp{ 0 }, smem_small{ 0 };
+  int nt_qp{ 64 }, nt_small{ 64 };
+  hipEvent_t ev0{ nullptr }, ev1{ nullptr };
+  double ms_admm{ 0 }, ms_convexify{ 0 }, ms_evaluate{ 0 };
+  long long launches_admm{ 0 };
+  bool timing{ true };
+  void* nccl{ nullptr };
+  int max_rec{ 128 };
+};
+
+template <typename T>
+static tmx_status upload(tmx_ctx* ctx, std::vector<void*>& pool, T** dst, const std::vector<T>& src)
+{
+  void* p = nullptr;
+  const size_t bytes = std::max<size_t>(1, src.size()) * sizeof(T);
+  HIPCHK(hipMalloc(&p, bytes));
+  pool.push_back(p);
+  if (!src.empty())
+    HIPCHK(hipMemcpy(p, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+  *dst = static_cast<T*>(p);
+  return TMX_OK;
+}
+template <typename T>
+static tmx_status dalloc(tmx_ctx* ctx, std::vector<void*>& pool, T** dst, size_t count)
+{
+  void* p = nullptr;
+  const size_t bytes = std::max<size_t>(1, count) * sizeof(T);
+  HIPCHK(hipMalloc(&p, bytes));
+  HIPCHK(hipMemset(p, 0, bytes));
+  pool.push_back(p);
+  *dst = static_cast<T*>(p);
+  return TMX_OK;
+}
+static void free_pool(std::vector<void*>& pool)
+{
+  for (void* p : pool)
+    (void)hipFree(p);
+  pool.clear();
+}
+
+template <typename T>
+static tmx_status d2h(tmx_ctx* ctx, T* dst, const T* src, size_t count)
+{
+  if (!dst)
+    return TMX_OK;
+  HIPCHK(hipMemcpyAsync(dst, src, sizeof(T) * count, hipMemcpyDeviceToHost, ctx->stream));
+  return TMX_OK;
+}
+
+extern "C" {
+
+void tmx_default_sqp_params(tmx_sqp_params* p)
+{
+  p->improve_ratio_threshold = 0.25;
+  p->min_trust_box_size = 1e-4;
+  p->min_approx_improve = 1e-4;
+  p->min_approx_improve_frac = -1.7976931348623157e308;  // std::numeric_limits<double>::lowest()
+  p->max_iter = 50;
+  p->max_qp_solver_failures = 3;
+  p->trust_shrink_ratio = 0.1;
+  p->trust_expand_ratio = 1.5;
+  p->cnt_tolerance = 1e-4;
+  p->max_merit_coeff_increases = 5;
+  p->merit_coeff_increase_ratio = 10;
+  p->initial_merit_error_coeff = 10;
+  p->inflate_constraints_individually = 1;
+  p->pad_ = 0;
+  p->trust_box_size = 1e-1;
+}
+
+void tmx_default_osqp_settings(tmx_osqp_settings* s)
+{
+  s->rho = 0.1;
+  s->sigma = 1e-6;
+  s->alpha = 1.6;
+  s->eps_abs = 1e-4;
+  s->eps_rel = 1e-6;
+  s->eps_prim_inf = 1e-4;
+  s->eps_dual_inf = 1e-4;
+  s->adaptive_rho_tolerance = 5.0;
+  s->delta = 1e-6;
+  s->scaling = 10;
+  s->adaptive_rho = 1;
+  s->adaptive_rho_interval = 50;
+  s->max_iter = 8192;
+  s->polishing = 1;
+  s->polish_refine_iter = 3;
+  s->check_termination = 25;
+  s->warm_starting = 1;
+}
+
+tmx_status tmx_create(int device, tmx_ctx** out)
+{
+  if (!out)
+    return TMX_ERR_INVALID;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+    return TMX_ERR_DEVICE;  // no HIP device: fail loudly, there is no CPU fallback
+  if (device < 0 || device >= count)
+    return TMX_ERR_INVALID;
+  tmx_ctx* ctx = new tmx_ctx();
+  ctx->device = device;
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&ctx->stream) != hipSuccess ||
+      hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess)
+  {
+    delete ctx;
+    return TMX_ERR_DEVICE;
+  }
+  void* p = nullptr;
+  if (hipMalloc(&p, 4 * sizeof(long long)) != hipSuccess)
+  {
+    delete ctx;
+    return TMX_ERR_DEVICE;
+  }
+  ctx->d_totals = static_cast<long long*>(p);
+  *out = ctx;
+  return TMX_OK;
+}
+
+void tmx_destroy(tmx_ctx* ctx)
+{
+  if (!ctx)
+    return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  free_pool(ctx->prob_allocs);
+  free_pool(ctx->batch_allocs);
+  if (ctx->dp)
+    (void)hipFree(ctx->dp);
+  if (ctx->db)
+    (void)hipFree(ctx->db);
+  if (ctx->d_totals)
+    (void)hipFree(ctx->d_totals);
+  (void)hipEventDestroy(ctx->ev0);
+  (void)hipEventDestroy(ctx->ev1);
+  (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char* tmx_last_error(const tmx_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx_sqp_params* sqp, const tmx_osqp_settings* osqp)
+{
+  if (!ctx || !d)
+    return TMX_ERR_INVALID;
+  HIPCHK(hipSetDevice(ctx->device));
+  const int D = d->n_dof, T = d->n_steps;
+  if (D < 1 || D > TMX_MAX_DOF || T < 2)
+  {
+    ctx->err = "n_dof must be in [1, TMX_MAX_DOF] and n_steps >= 2";
+    return TMX_ERR_INVALID;
+  }
+  free_pool(ctx->prob_allocs);
+  free_pool(ctx->batch_allocs);
+  ctx->Bcap = 0;
+  ctx->have_problem = false;
+  DevProblem& P = ctx->hp;
+  std::memset(&P, 0, sizeof(P));
+  P.D = D;
+  P.T = T;
+  P.NX = D * T;
+  P.S = d->n_link_spheres;
+  P.O = d->n_obstacles;
+  for (int j = 0; j < D; ++j)
+  {
+    P.jl[j] = d->joint_lower[j];
+    P.ju[j] = d->joint_upper[j];
+    std::memcpy(P.origin[j], d->joints[j].origin, sizeof(double) * 12);
+    std::memcpy(P.axis[j], d->joints[j].axis, sizeof(double) * 3);
+    P.jtype[j] = d->joints[j].type;
+  }
+  std::memcpy(P.base, d->base, sizeof(double) * 12);
+  std::memcpy(P.tool, d->tool, sizeof(double) * 12);
+  if (sqp)
+    P.sqp = *sqp;
+  else
+    tmx_default_sqp_params(&P.sqp);
+  if (osqp)
+    P.osqp = *osqp;
+  else
+    tmx_default_osqp_settings(&P.osqp);
+
+  // ---- slot template in reference row order ----
+  std::vector<int> kind, st, sub, sub2, owner, naux, iscnt, iseq;
+  std::vector<double> objc, scale, aux1, aux2;
+  auto add_slot = [&](int k, int t, int s1, int s2, int own, int na, int isc, int eq, double oc, double sc, double a1, double a2) {
+    kind.push_back(k);
+    st.push_back(t);
+    sub.push_back(s1);
+    sub2.push_back(s2);
+    owner.push_back(own);
+    naux.push_back(na);
+    iscnt.push_back(isc);
+    iseq.push_back(eq);
+    objc.push_back(oc);
+    scale.push_back(sc);
+    aux1.push_back(a1);
+    aux2.push_back(a2);
+  };
+  std::vector<int> fixed(d->fixed_steps, d->fixed_steps + d->n_fixed_steps);
+  for (int t : fixed)
+  {
+    if (t < 0 || t >= T)
+    {
+      ctx->err = "fixed timestep out of range";
+      return TMX_ERR_INVALID;
+    }
+    for (int j = 0; j < D; ++j)
+      add_slot(SLOT_FIXED, t, j, 0, -1, 0, 0, 1, 0.0, 1.0, 0.0, 0.0);
+  }
+  std::vector<double> pd(P.NX, 0.0), po(P.NX, 0.0), pq(P.NX, 0.0);
+  std::vector<int> vel_first, vel_last, vel_cost, cp_t, cp_owner, cp_iscnt, cp_nrows, cp_idx, cp_slot0;
+  std::vector<double> vel_coeffs, vel_targets, cp_coeff, cp_target;
+  int n_costs = 0, n_cnts = 0;
+  for (int pass = 0; pass < 2; ++pass)
+    for (int k = 0; k < d->n_terms; ++k)
+    {
+      const tmx_term& tm = d->terms[k];
+      const bool is_cnt = (tm.kind == TMX_TERM_JOINT_POS_EQ_CNT) || (tm.kind == TMX_TERM_CART_POSE && tm.is_constraint);
+      if ((pass == 0) == is_cnt)
+        continue;
+      if (tm.first_step < 0 || tm.last_step >= T || tm.first_step > tm.last_step)
+      {
+        ctx->err = "term step range invalid";
+        return TMX_ERR_INVALID;
+      }
+      switch (tm.kind)
+      {
+        case TMX_TERM_JOINT_VEL_COST:
+        {
+          if (tm.last_step - 1 - tm.first_step < 0)
+          {
+            ctx->err = "JointVelEqCost, trajectory is too short!";  // trajectory_costs.cpp:269-270
+            return TMX_ERR_INVALID;
+          }
+          vel_first.push_back(tm.first_step);
+          vel_last.push_back(tm.last_step);
+          vel_cost.push_back(n_costs++);
+          for (int j = 0; j < TMX_MAX_DOF; ++j)
+          {
+            vel_coeffs.push_back(j < D ? tm.coeffs[j] : 0.0);
+            vel_targets.push_back(j < D ? tm.targets[j] : 0.0);
+          }
+          // Hessian / linear term of sum_j c_j (x_{i+1,j} - x_{i,j} - targ_j)^2 exactly as exprSquare + exprToEigen build
+          // them (expr_ops.cpp:55-84, solver_utils.cpp:49-109 with matrix_is_halved = true)
+          for (int i = tm.first_step; i <= tm.last_step - 1; ++i)
+            for (int j = 0; j < D; ++j)
+            {
+              const double c = tm.coeffs[j];
+              const double a0 = -1.0, a1 = 1.0, cst = 0.0 - tm.targets[j];
+              const double q00 = (a0 * a0) * c, q01 = (2 * a0 * a1) * c, q11 = (a1 * a1) * c;
+              if (q00 != 0.0)
+                pd[i * D + j] += 2.0 * q00;
+              if (q11 != 0.0)
+                pd[(i + 1) * D + j] += 2.0 * q11;
+              if (q01 != 0.0)
+                po[i * D + j] += q01;
+              const double l0 = (2 * cst * a0) * c, l1 = (2 * cst * a1) * c;
+              if (l0 != 0.0)
+                pq[i * D + j] += l0;
+              if (l1 != 0.0)
+                pq[(i + 1) * D + j] += l1;
+            }
+          break;
+        }
+        case TMX_TERM_JOINT_POS_EQ_CNT:
+        {
+          const int own = n_cnts++;
+          for (int i = tm.first_step; i <= tm.last_step; ++i)
+            for (int j = 0; j < D; ++j)
+              add_slot(SLOT_JOINTPOS, i, j, 0, own, 2, 1, 1, 0.0, tm.coeffs[j], tm.targets[j], 0.0);
+          break;
+        }
+        case TMX_TERM_CART_POSE:
+        {
+          for (int t = tm.first_step; t <= tm.last_step; ++t)
+          {
+            const int own = tm.is_constraint ? n_cnts++ : n_costs++;
+            const int inst = static_cast<int>(cp_t.size());
+            cp_t.push_back(t);
+            cp_owner.push_back(own);
+            cp_iscnt.push_back(tm.is_constraint ? 1 : 0);
+            cp_slot0.push_back(static_cast<int>(kind.size()));
+            int nr = 0;
+            for (int i = 0; i < 6; ++i)
+            {
+              const bool keep = std::fabs(tm.coeffs[i]) > 1e-5;  // problem_description.cpp:910-926
+              cp_idx.push_back(0);
+              cp_coeff.push_back(0.0);
+              if (keep)
+              {
+                cp_idx[inst * 6 + nr] = i;
+                cp_coeff[inst * 6 + nr] = tm.coeffs[i];
+                add_slot(SLOT_CARTPOSE, t, nr, i, own, 2, tm.is_constraint ? 1 : 0, 1, 1.0, tm.coeffs[i], 0.0, 0.0);
+                ++nr;
+              }
+            }
+            cp_nrows.push_back(nr);
+            for (int q = 0; q < 12; ++q)
+              cp_target.push_back(tm.target_pose[q]);
+          }
+          break;
+        }
+        case TMX_TERM_COLLISION_COST:
+        {
+          for (int i = tm.first_step; i <= tm.last_step; ++i)
+          {
+            if (std::find(fixed.begin(), fixed.end(), i) != fixed.end())
+              continue;  // problem_description.cpp:1767
+            const int own = n_costs++;
+            for (int s = 0; s < d->n_link_spheres; ++s)
+              for (int o = 0; o < d->n_obstacles; ++o)
+                add_slot(SLOT_COLLISION, i, s, o, own, 1, 0, 0, tm.coeff, 1.0, tm.margin, tm.buffer);
+          }
+          break;
+        }
+        default:
+          ctx->err = "term kind not lowered by the device path";
+          return TMX_ERR_UNSUPPORTED;
+      }
+    }
+  const int R = static_cast<int>(kind.size());
+  P.R = R;
+  P.n_costs = n_costs;
+  P.n_cnts = n_cnts;
+  P.n_cp = static_cast<int>(cp_t.size());
+  P.n_vel = static_cast<int>(vel_first.size());
+  std::vector<int> aoff(R, 0);
+  int NA = 0;
+  for (int r = 0; r < R; ++r)
+  {
+    aoff[r] = NA;
+    NA += naux[r];
+  }
+  P.NA = NA;
+  P.n_max = P.NX + NA;
+  P.m_max = R + P.NX + NA;
+  int nnzP = 0;
+  for (int v = 0; v < P.NX; ++v)
+    nnzP += (pd[v] != 0.0) + (v < P.NX - D && po[v] != 0.0);
+  P.nnzP = nnzP;
+  // slots grouped by waypoint, ascending slot id inside a waypoint
+  std::vector<int> wp_start(T + 1, 0), wp_list(R, 0);
+  for (int r = 0; r < R; ++r)
+    wp_start[st[r] + 1]++;
+  for (int t = 0; t < T; ++t)
+    wp_start[t + 1] += wp_start[t];
+  {
+    std::vector<int> next(wp_start.begin(), wp_start.end() - 1);
+    for (int r = 0; r < R; ++r)
+      wp_list[next[st[r]]++] = r;
+  }
+  std::vector<int> ls_link;
+  std::vector<double> ls_center, ls_radius, ob_center, ob_radius;
+  for (int s = 0; s < d->n_link_spheres; ++s)
+  {
+    if (d->link_spheres[s].link < 0 || d->link_spheres[s].link >= D)
+    {
+      ctx->err = "link sphere attached to an invalid link";
+      return TMX_ERR_INVALID;
+    }
+    ls_link.push_back(d->link_spheres[s].link);
+    for (int q = 0; q < 3; ++q)
+      ls_center.push_back(d->link_spheres[s].center[q]);
+    ls_radius.push_back(d->link_spheres[s].radius);
+  }
+  for (int o = 0; o < d->n_obstacles; ++o)
+  {
+    for (int q = 0; q < 3; ++q)
+      ob_center.push_back(d->obstacles[o].center[q]);
+    ob_radius.push_back(d->obstacles[o].radius);
+  }
+  auto& pool = ctx->prob_allocs;
+  tmx_status rc;
+#define UP(field, vec)                                                                                                \
+  if ((rc = upload(ctx, pool, &P.field, vec)) != TMX_OK)                                                              \
+  return rc
+  UP(slot_kind, kind);
+  UP(slot_t, st);
+  UP(slot_sub, sub);
+  UP(slot_sub2, sub2);
+  UP(slot_owner, owner);
+  UP(slot_naux, naux);
+  UP(slot_aoff, aoff);
+  UP(slot_iscnt, iscnt);
+  UP(slot_eq, iseq);
+  UP(slot_objc, objc);
+  UP(slot_scale, scale);
+  UP(slot_aux1, aux1);
+  UP(slot_aux2, aux2);
+  UP(wp_start, wp_start);
+  UP(wp_list, wp_list);
+  UP(pd, pd);
+  UP(po, po);
+  UP(pq, pq);
+  UP(vel_first, vel_first);
+  UP(vel_last, vel_last);
+  UP(vel_cost, vel_cost);
+  UP(vel_coeffs, vel_coeffs);
+  UP(vel_targets, vel_targets);
+  UP(cp_t, cp_t);
+  UP(cp_owner, cp_owner);
+  UP(cp_iscnt, cp_iscnt);
+  UP(cp_nrows, cp_nrows);
+  UP(cp_idx, cp_idx);
+  UP(cp_slot0, cp_slot0);
+  UP(cp_coeff, cp_coeff);
+  UP(cp_target, cp_target);
+  UP(ls_link, ls_link);
+  UP(ls_center, ls_center);
+  UP(ls_radius, ls_radius);
+  UP(ob_center, ob_center);
+  UP(ob_radius, ob_radius);
+#undef UP
+  if (!ctx->dp)
+  {
+    void* p = nullptr;
+    HIPCHK(hipMalloc(&p, sizeof(DevProblem)));
+    ctx->dp = static_cast<DevProblem*>(p);
+  }
+  HIPCHK(hipMemcpy(ctx->dp, &P, sizeof(DevProblem), hipMemcpyHostToDevice));
+  // LDS budgets
+  ctx->smem_qp = qp_ws_doubles(D, T, R, NA) * sizeof(double);
+  const size_t small_ints = (size_t)(P.n_max + 1) + 2 * (size_t)R + 2 + 16;
+  ctx->smem_small = std::max<size_t>((size_t)(R + n_costs + n_cnts + 8) * sizeof(double), small_ints * sizeof(int) + 64);
+#ifdef TMX_HOST_EMU
+  ctx->nt_qp = 1;
+  ctx->nt_small = 1;
+#else
+  if (ctx->smem_qp > 160 * 1024)
+  {
+    ctx->err = "QP workspace of " + std::to_string(ctx->smem_qp) +
+               " bytes exceeds the 160 KiB LDS of a gfx950 CU (long-horizon streaming variant is not built yet)";
+    return TMX_ERR_UNSUPPORTED;
+  }
+  // one problem per CU when the workspace is large: use 4 waves so the data-parallel phases go 4x wider
+  ctx->nt_qp = (ctx->smem_qp > 80 * 1024) ? 256 : 64;
+  ctx->nt_small = 64;
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_qp_solve), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             static_cast<int>(ctx->smem_qp)));
+#endif
+  ctx->have_problem = true;
+  return TMX_OK;
+}
+
+static tmx_status ensure_batch(tmx_ctx* ctx, int B)
+{
+  if (B <= ctx->Bcap)
+  {
+    ctx->hb.B = B;
+    HIPCHK(hipMemcpy(ctx->db, &ctx->hb, sizeof(DevBatch), hipMemcpyHostToDevice));
+    return TMX_OK;
+  }
+  free_pool(ctx->batch_allocs);
+  const DevProblem& P = ctx->hp;
+  DevBatch& H = ctx->hb;
+  std::memset(&H, 0, sizeof(H));
+  H.B = B;
+  H.max_rec = ctx->max_rec;
+  auto& pool = ctx->batch_allocs;
+  tmx_status rc;
+  const size_t b = static_cast<size_t>(B);
+#define AL(field, count)                                                                                              \
+  if ((rc = dalloc(ctx, pool, &H.field, (count))) != TMX_OK)                                                          \
+  return rc
+  AL(x0, b * P.NX);
+  AL(x, b * P.NX);
+  AL(xnew, b * P.NX);
+  AL(cost_vals, b * P.n_costs);
+  AL(cnt_viols, b * P.n_cnts);
+  AL(new_cost_vals, b * P.n_costs);
+  AL(new_cnt_viols, b * P.n_cnts);
+  AL(merit, b * P.n_cnts);
+  AL(trust, b);
+  AL(total_cost, b);
+  AL(prev_rho, b);
+  AL(phase, b);
+  AL(iter, b);
+  AL(merit_inc, b);
+  AL(qp_fail, b);
+  AL(status, b);
+  AL(retval, b);
+  AL(n_fe, b);
+  AL(n_qp, b);
+  AL(cvx, b);
+  AL(prev_ok, b);
+  AL(active, b * P.R);
+  AL(coef, b * P.R * P.D);
+  AL(rhs, b * P.R);
+  AL(dims, b * 4);
+  AL(hashes, b * 4);
+  AL(prev_dims, b * 4);
+  AL(prev_ws, b * 2);
+  AL(xq, b * P.n_max);
+  AL(yq, b * P.m_max);
+  AL(rec_last, b);
+  AL(rec_log, b * ctx->max_rec);
+  AL(rec_count, b);
+  AL(admm_iters, b);
+  AL(n_active, 1);
+#undef AL
+  if (!ctx->db)
+  {
+    void* p = nullptr;
+    HIPCHK(hipMalloc(&p, sizeof(DevBatch)));
+    ctx->db = static_cast<DevBatch*>(p);
+  }
+  HIPCHK(hipMemcpy(ctx->db, &H, sizeof(DevBatch), hipMemcpyHostToDevice));
+  ctx->Bcap = B;
+  return TMX_OK;
+}
+
+static tmx_status prepare_batch(tmx_ctx* ctx)
+{
+  TMX_LAUNCH(k_prepare, ctx->hb.B, ctx->nt_small, ctx->smem_small, ctx->stream, ctx->dp, ctx->db);
+  HIPCHK(hipGetLastError());
+  return TMX_OK;
+}
+
+tmx_status tmx_batch_set_x0(tmx_ctx* ctx, const double* x0_host, int32_t batch)
+{
+  if (!ctx || !x0_host || batch < 1)
+    return TMX_ERR_INVALID;
+  if (!ctx->have_problem)
+    return TMX_ERR_STATE;
+  HIPCHK(hipSetDevice(ctx->device));
+  tmx_status rc = ensure_batch(ctx, batch);
+  if (rc != TMX_OK)
+    return rc;
+  HIPCHK(hipMemcpyAsync(ctx->hb.x0, x0_host, sizeof(double) * (size_t)batch * ctx->hp.NX, hipMemcpyHostToDevice, ctx->stream));
+  return prepare_batch(ctx);
+}
+
+tmx_status tmx_batch_set_x0_device(tmx_ctx* ctx, const double* x0_dev, int32_t batch)
+{
+  if (!ctx || !x0_dev || batch < 1)
+    return TMX_ERR_INVALID;
+  if (!ctx->have_problem)
+    return TMX_ERR_STATE;
+  HIPCHK(hipSetDevice(ctx->device));
+  tmx_status rc = ensure_batch(ctx, batch);
+  if (rc != TMX_OK)
+    return rc;
+  HIPCHK(hipMemcpyAsync(ctx->hb.x0, x0_dev, sizeof(double) * (size_t)batch * ctx->hp.NX, hipMemcpyDeviceToDevice, ctx->stream));
+  return prepare_batch(ctx);
+}
+
+static tmx_status read_totals(tmx_ctx* ctx, long long out[4])
+{
+  HIPCHK(hipMemsetAsync(ctx->d_totals, 0, 4 * sizeof(long long), ctx->stream));
+  TMX_LAUNCH(k_count_active, 4, 256, 0, ctx->stream, ctx->db, ctx->d_totals);
+  HIPCHK(hipMemcpyAsync(out, ctx->d_totals, 4 * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return TMX_OK;
+}
+
+#define TIMED(acc, launches, stmt)                                                                                    \
+  do                                                                                                                  \
+  {                                                                                                                   \
+    if (ctx->timing)                                                                                                  \
+      HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));                                                                  \
+    stmt;                                                                                                             \
+    if (ctx->timing)                                                                                                  \
+    {                                                                                                                 \
+      HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));                                                                  \
+      HIPCHK(hipEventSynchronize(ctx->ev1));                                                                          \
+      float ms_ = 0.f;                                                                                                \
+      HIPCHK(hipEventElapsedTime(&ms_, ctx->ev0, ctx->ev1));                                                          \
+      acc += ms_;                                                                                                     \
+      launches;                                                                                                       \
+    }                                                                                                                 \
+  } while (0)
+
+tmx_status tmx_sqp_run(tmx_ctx* ctx, int32_t max_steps, int32_t* n_active_out)
+{
+  if (!ctx)
+    return TMX_ERR_INVALID;
+  if (!ctx->have_problem || ctx->Bcap == 0)
+    return TMX_ERR_STATE;
+  HIPCHK(hipSetDevice(ctx->device));
+  const int B = ctx->hb.B;
+  long long tot[4] = { B, 0, 0, 0 };
+  int step = 0;
+  while (true)
+  {
+    tmx_status rc = read_totals(ctx, tot);
+    if (rc != TMX_OK)
+      return rc;
+    if (tot[0] == 0 || (max_steps > 0 && step >= max_steps))
+      break;
+    // safety net: a run can never need more batched steps than the nested loop bounds of optimize() allow
+    const long long cap = (long long)(ctx->hp.sqp.max_merit_coeff_increases + 1) * (ctx->hp.sqp.max_iter + 1) * 16;
+    if (step > cap)
+    {
+      ctx->err = "tmx_sqp_run exceeded the iteration bound of BasicTrustRegionSQP (internal error)";
+      return TMX_ERR_STATE;
+    }
+    TIMED(ctx->ms_convexify, (void)0,
+          TMX_LAUNCH(k_convexify, B, ctx->nt_small, ctx->smem_small, ctx->stream, ctx->dp, ctx->db, 0));
+    TIMED(ctx->ms_admm, ctx->launches_admm++,
+          TMX_LAUNCH(k_qp_solve, B, ctx->nt_qp, ctx->smem_qp, ctx->stream, ctx->dp, ctx->db, 0));
+    TIMED(ctx->ms_evaluate, (void)0,
+          TMX_LAUNCH(k_evaluate, B, ctx->nt_small, ctx->smem_small, ctx->stream, ctx->dp, ctx->db, 1));
+    TMX_LAUNCH(k_sqp_update, B, 64, (size_t)(ctx->hp.n_costs + ctx->hp.n_cnts + 8) * sizeof(double), ctx->stream, ctx->dp,
+               ctx->db);
+    HIPCHK(hipGetLastError());
+    ++step;
+  }
+  if (n_active_out)
+    *n_active_out = static_cast<int32_t>(tot[0]);
+  return TMX_OK;
+}
+
+tmx_status tmx_sqp_results(tmx_ctx* ctx, double* x, int32_t* status, double* total_cost, int32_t* n_func_evals, int32_t* n_qp_solves)
+{
+  if (!ctx)
+    return TMX_ERR_INVALID;
+  if (ctx->Bcap == 0)
+    return TMX_ERR_STATE;
+  HIPCHK(hipSetDevice(ctx->device));
+  const size_t B = ctx->hb.B;
+  tmx_status rc;
+  if ((rc = d2h(ctx, x, ctx->hb.x, B * ctx->hp.NX)) != TMX_OK || (rc = d2h(ctx, status, ctx->hb.status, B)) != TMX_OK ||
+      (rc = d2h(ctx, total_cost, ctx->hb.total_cost, B)) != TMX_OK || (rc = d2h(ctx, n_func_evals, ctx->hb.n_fe, B)) != TMX_OK ||
+      (rc = d2h(ctx, n_qp_solves, ctx->hb.n_qp, B)) != TMX_OK)
+    return rc;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return TMX_OK;
+}
+
+tmx_status tmx_sqp_counters(tmx_ctx* ctx, int64_t* n_func_evals, int64_t* n_qp_solves, int64_t* n_admm_iters)
+{
+  if (!ctx)
+    return TMX_ERR_INVALID;
+  if (ctx->Bcap == 0)
+    return TMX_ERR_STATE;
+  long long tot[4];
+  tmx_status rc = read_totals(ctx, tot);
+  if (rc != TMX_OK)
+    return rc;
+  if (n_func_evals)
+    *n_func_evals = tot[1];
+  if (n_qp_solves)
+    *n_qp_solves = tot[2];
+  if (n_admm_iters)
+    *n_admm_iters = tot[3];
+  return TMX_OK;
+}
+
+tmx_status tmx_sqp_qp_records(tmx_ctx* ctx, tmx_qp_record* out, int32_t max_records, int32_t* counts)
+{
+  if (!ctx || max_records < 0)
+    return TMX_ERR_INVALID;
+  if (ctx->Bcap == 0)
+    return TMX_ERR_STATE;
+  HIPCHK(hipSetDevice(ctx->device));
+  const int B = ctx->hb.B;
+  std::vector<tmx_qp_record> tmp((size_t)B * ctx->max_rec);
+  std::vector<int> cnt(B);
+  HIPCHK(hipMemcpy(tmp.data(), ctx->hb.rec_log, tmp.size() * sizeof(tmx_qp_record), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(cnt.data(), ctx->hb.rec_count, B * sizeof(int), hipMemcpyDeviceToHost));
+  for (int b = 0; b < B; ++b)
+  {
+    if (counts)
+      counts[b] = cnt[b];
+    if (out)
+      for (int k = 0; k < std::min({ cnt[b], (int)max_records, ctx->max_rec }); ++k)
+        out[(size_t)b * max_records + k] = tmp[(size_t)b * ctx->max_rec + k];
+  }
+  return TMX_OK;
+}
+
+tmx_status tmx_term_counts(tmx_ctx* ctx, int32_t* n_costs, int32_t* n_cnts, int32_t* n_row_slots)
+{
+  if (!ctx)
+    return TMX_ERR_INVALID;
+  if (!ctx->have_problem)
+    return TMX_ERR_STATE;
+  if (n_costs)
+    *n_costs = ctx->hp.n_costs;
+  if (n_cnts)
+    *n_cnts = ctx->hp.n_cnts;
+  if (n_row_slots)
+    *n_row_slots = ctx->hp.R;
+  return TMX_OK;
+}
+
+tmx_status tmx_evaluate(tmx_ctx* ctx, double* cost_vals, double* cnt_viols)
+{
+  if (!ctx)
+    return TMX_ERR_INVALID;
+  if (ctx->Bcap == 0)
+    return TMX_ERR_STATE;
+  HIPCHK(hipSetDevice(ctx->device));
+  const size_t B = ctx->hb.B;
+  TMX_LAUNCH(k_evaluate, ctx->hb.B, ctx->nt_small, ctx->smem_small, ctx->stream, ctx->dp, ctx->db, 0);
+  HIPCHK(hipGetLastError());
+  tmx_status rc;
+  if ((rc = d2h(ctx, cost_vals, ctx->hb.cost_vals, B * ctx->hp.n_costs)) != TMX_OK ||
+      (rc = d2h(ctx, cnt_viols, ctx->hb.cnt_viols, B * ctx->hp.n_cnts)) != TMX_OK)
+    return rc;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return TMX_OK;
+}
+
+tmx_status tmx_convexify(tmx_ctx* ctx, int32_t* active, double* coef, double* rhs)
+{
+  if (!ctx)
+    return TMX_ERR_INVALID;
+  if (ctx->Bcap == 0)
+    return TMX_ERR_STATE;
+  HIPCHK(hipSetDevice(ctx->device));
+  const size_t B = ctx->hb.B;
+  TMX_LAUNCH(k_convexify, ctx->hb.B, ctx->nt_small, ctx->smem_small, ctx->stream, ctx->dp, ctx->db, 1);
+  HIPCHK(hipGetLastError());
+  tmx_status rc;
+  if ((rc = d2h(ctx, active, ctx->hb.active, B * ctx->hp.R)) != TMX_OK ||
+      (rc = d2h(ctx, coef, ctx->hb.coef, B * ctx->hp.R * ctx->hp.D)) != TMX_OK ||
+      (rc = d2h(ctx, rhs, ctx->hb.rhs, B * ctx->hp.R)) != TMX_OK)
+    return rc;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return TMX_OK;
+}
+
+tmx_status tmx_qp_dims(tmx_ctx* ctx, int32_t* n_max, int32_t* m_max)
+{
+  if (!ctx)
+    return TMX_ERR_INVALID;
+  if (!ctx->have_problem)
+    return TMX_ERR_STATE;
+  if (n_max)
+    *n_max = ctx->hp.n_max;
+  if (m_max)
+    *m_max = ctx->hp.m_max;
+  return TMX_OK;
+}
+
+tmx_status tmx_export_csc(tmx_ctx* ctx, int32_t problem, int32_t* n, int32_t* m, int32_t* nnzP, int32_t* nnzA, int64_t* P_p,
+                          int64_t* P_i, double* P_x, double* q, int64_t* A_p, int64_t* A_i, double* A_x, double* l, double* u)
+{
+  if (!ctx || !n || !m || !nnzP || !nnzA)
+    return TMX_ERR_INVALID;
+  if (ctx->Bcap == 0)
+    return TMX_ERR_STATE;
+  if (problem < 0 || problem >= ctx->hb.B)
+    return TMX_ERR_INVALID;
+  HIPCHK(hipSetDevice(ctx->device));
+  const DevProblem& P = ctx->hp;
+  // device scratch sized for the worst case
+  const size_t nmax = P.n_max, mmax = P.m_max, nzA = (size_t)P.R * (P.D + 2) + 2 * nmax, nzP = (size_t)P.nnzP + 1;
+  std::vector<void*> pool;
+  CscOut o{};
+  int* d_dims = nullptr;
+  unsigned long long* d_hash = nullptr;
+  tmx_status rc;
+#define AL2(ptr, type, count)                                                                                         \
+  if ((rc = dalloc(ctx, pool, reinterpret_cast<type**>(&ptr), (count))) != TMX_OK)                                    \
+  {                                                                                                                   \
+    free_pool(pool);                                                                                                  \
+    return rc;                                                                                                        \
+  }
+  AL2(o.P_p, long long, nmax + 1);
+  AL2(o.P_i, long long, nzP);
+  AL2(o.P_x, double, nzP);
+  AL2(o.q, double, nmax);
+  AL2(o.A_p, long long, nmax + 1);
+  AL2(o.A_i, long long, nzA);
+  AL2(o.A_x, double, nzA);
+  AL2(o.l, double, mmax);
+  AL2(o.u, double, mmax);
+  AL2(d_dims, int, 4);
+  AL2(d_hash, unsigned long long, 4);
+#undef AL2
+  TMX_LAUNCH(k_export_csc, 1, ctx->nt_small, ctx->smem_small, ctx->stream, ctx->dp, ctx->db, (int)problem, o, d_dims, d_hash);
+  int dims[4];
+  hipError_t e = hipMemcpy(dims, d_dims, sizeof(dims), hipMemcpyDeviceToHost);
+  if (e != hipSuccess)
+  {
+    free_pool(pool);
+    ctx->err = "export copy failed";
+    return TMX_ERR_DEVICE;
+  }
+  *n = dims[0];
+  *m = dims[1];
+  *nnzP = dims[2];
+  *nnzA = dims[3];
+  auto cp = [&](void* dst, const void* src, size_t bytes) {
+    if (dst)
+      (void)hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost);
+  };
+  cp(P_p, o.P_p, sizeof(long long) * (dims[0] + 1));
+  cp(P_i, o.P_i, sizeof(long long) * dims[2]);
+  cp(P_x, o.P_x, sizeof(double) * dims[2]);
+  cp(q, o.q, sizeof(double) * dims[0]);
+  cp(A_p, o.A_p, sizeof(long long) * (dims[0] + 1));
+  cp(A_i, o.A_i, sizeof(long long) * dims[3]);
+  cp(A_x, o.A_x, sizeof(double) * dims[3]);
+  cp(l, o.l, sizeof(double) * dims[1]);
+  cp(u, o.u, sizeof(double) * dims[1]);
+  free_pool(pool);
+  return TMX_OK;
+}
+
+tmx_status tmx_qp_solve(tmx_ctx* ctx, double* x_qp, int32_t* cvx_status, tmx_qp_record* rec)
+{
+  if (!ctx)
+    return TMX_ERR_INVALID;
+  if (ctx->Bcap == 0)
+    return TMX_ERR_STATE;
+  HIPCHK(hipSetDevice(ctx->device));
+  const size_t B = ctx->hb.B;
+  TIMED(ctx->ms_admm, ctx->launches_admm++,
+        TMX_LAUNCH(k_qp_solve, ctx->hb.B, ctx->nt_qp, ctx->smem_qp, ctx->stream, ctx->dp, ctx->db, 1));
+  HIPCHK(hipGetLastError());
+  tmx_status rc;
+  if ((rc = d2h(ctx, x_qp, ctx->hb.xq, B * ctx->hp.n_max)) != TMX_OK || (rc = d2h(ctx, cvx_status, ctx->hb.cvx, B)) != TMX_OK ||
+      (rc = d2h(ctx, rec, ctx->hb.rec_last, B)) != TMX_OK)
+    return rc;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return TMX_OK;
+}
+
+tmx_status tmx_argmin(tmx_ctx* ctx, int64_t global_offset, int64_t* best_index, double* best_cost)
+{
+  if (!ctx || !best_index || !best_cost)
+    return TMX_ERR_INVALID;
+  if (ctx->Bcap == 0)
+    return TMX_ERR_STATE;
+  HIPCHK(hipSetDevice(ctx->device));
+  const int B = ctx->hb.B;
+  std::vector<double> cost(B);
+  std::vector<int> status(B);
+  HIPCHK(hipMemcpy(cost.data(), ctx->hb.total_cost, sizeof(double) * B, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(status.data(), ctx->hb.status, sizeof(int) * B, hipMemcpyDeviceToHost));
+  double bc = 1e300;
+  long long bi = -1;
+  for (int b = 0; b < B; ++b)
+    if (status[b] == TMX_OPT_CONVERGED && cost[b] < bc)
+    {
+      bc = cost[b];
+      bi = global_offset + b;
+    }
+#ifndef TMX_HOST_EMU
+  if (ctx->nccl)
+  {
+    // the only collective on the path: all-gather of one (cost, index) pair per rank, then a local argmin
+    ncclComm_t comm = static_cast<ncclComm_t>(ctx->nccl);
+    int nranks = 1, rank = 0;
+    if (ncclCommCount(comm, &nranks) != ncclSuccess || ncclCommUserRank(comm, &rank) != ncclSuccess)
+      return TMX_ERR_NCCL;
+    double pair[2] = { bc, static_cast<double>(bi) };
+    double* d_send = nullptr;
+    double* d_recv = nullptr;
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&d_send), 2 * sizeof(double)));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&d_recv), 2 * sizeof(double) * nranks));
+    HIPCHK(hipMemcpyAsync(d_send, pair, sizeof(pair), hipMemcpyHostToDevice, ctx->stream));
+    if (ncclAllGather(d_send, d_recv, 2, ncclDouble, comm, ctx->stream) != ncclSuccess)
+      return TMX_ERR_NCCL;
+    std::vector<double> all(2 * nranks);
+    HIPCHK(hipMemcpyAsync(all.data(), d_recv, sizeof(double) * 2 * nranks, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    (void)hipFree(d_send);
+    (void)hipFree(d_recv);
+    bc = 1e300;
+    bi = -1;
+    for (int r = 0; r < nranks; ++r)
+      if (all[2 * r + 1] >= 0 && all[2 * r] < bc)
+      {
+        bc = all[2 * r];
+        bi = static_cast<long long>(all[2 * r + 1]);
+      }
+  }
+#endif
+  *best_index = bi;
+  *best_cost = bc;
+  return TMX_OK;
+}
+
+tmx_status tmx_attach_nccl(tmx_ctx* ctx, void* nccl_comm)
+{
+  if (!ctx)
+    return TMX_ERR_INVALID;
+  ctx->nccl = nccl_comm;
+  return TMX_OK;
+}
+
+tmx_status tmx_kernel_stats(tmx_ctx* ctx, double* admm_ms_total, int64_t* admm_launches, double* convexify_ms_total,
+                            double* evaluate_ms_total)
+{
+  if (!ctx)
+    return TMX_ERR_INVALID;
+  if (admm_ms_total)
+    *admm_ms_total = ctx->ms_admm;
+  if (admm_launches)
+    *admm_launches = ctx->launches_admm;
+  if (convexify_ms_total)
+    *convexify_ms_total = ctx->ms_convexify;
+  if (evaluate_ms_total)
+    *evaluate_ms_total = ctx->ms_evaluate;
+  return TMX_OK;
+}
+
+tmx_status tmx_kernel_stats_reset(tmx_ctx* ctx)
+{
+  if (!ctx)
+    return TMX_ERR_INVALID;
+  ctx->ms_admm = ctx->ms_convexify = ctx->ms_evaluate = 0.0;
+  ctx->launches_admm = 0;
+  return TMX_OK;
+}
+}  // extern "C"

@@ -1,0 +1,131 @@
+// tmx_kernels.h — __global__ entry points.  Grid = one workgroup per problem of the batch (B >> 256 workgroups
+// fill the 256 CUs; problems are independent so no inter-workgroup communication exists anywhere on the path).
+#pragma once
+#include "tmx_solve.h"
+
+// Optimizer::initialize + the head of optimize(): getClosestFeasiblePoint (quirk Q1: only the upper clamp
+// survives, modeling.cpp:260-271), state reset, persistent/constant rows, first exact evaluation
+// (optimizers.cpp:725, 761-767)
+TMX_KERNEL k_prepare(const DevProblem* P, const DevBatch* Bt)
+{
+  TMX_SMEM(smem);
+  const int b = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
+  const int NX = P->NX, D = P->D, R = P->R;
+  const double* x0 = Bt->x0 + (size_t)b * NX;
+  double* x = Bt->x + (size_t)b * NX;
+  for (int v = tid; v < NX; v += NT)
+  {
+    const int j = v % D;
+    double y = fmax(P->jl[j] + 1e-6, x0[v]);
+    y = fmin(P->ju[j] - 1e-6, x0[v]);
+    x[v] = y;
+  }
+  int* act = Bt->active + (size_t)b * R;
+  for (int r = tid; r < R; r += NT)
+    act[r] = 0;
+  for (int k = tid; k < P->n_cnts; k += NT)
+    Bt->merit[(size_t)b * P->n_cnts + k] = P->sqp.initial_merit_error_coeff;
+  if (tid == 0)
+  {
+    Bt->trust[b] = P->sqp.trust_box_size;
+    Bt->phase[b] = PHASE_CONVEXIFY;
+    Bt->iter[b] = 1;
+    Bt->merit_inc[b] = 0;
+    Bt->qp_fail[b] = 0;
+    Bt->status[b] = TMX_OPT_INVALID;
+    Bt->retval[b] = TMX_OPT_INVALID;
+    Bt->n_fe[b] = 1;
+    Bt->n_qp[b] = 0;
+    Bt->cvx[b] = TMX_CVX_FAILED;
+    Bt->prev_ok[b] = 0;
+    Bt->prev_rho[b] = P->osqp.rho;
+    Bt->rec_count[b] = 0;
+    Bt->admm_iters[b] = 0;
+    Bt->total_cost[b] = 0.0;
+    for (int q = 0; q < 4; ++q)
+      Bt->prev_dims[4 * b + q] = -1;
+  }
+  TMX_SYNC();
+  init_static_rows(P, x0, act, Bt->coef + (size_t)b * R * D, Bt->rhs + (size_t)b * R, tid, NT);
+  evaluate_terms(P, x, Bt->cost_vals + (size_t)b * P->n_costs, Bt->cnt_viols + (size_t)b * P->n_cnts, smem, tid, NT);
+}
+
+// which = 0: exact costs/violations at x -> cost_vals/cnt_viols ; which = 1: at xnew -> new_* (skips DONE problems)
+TMX_KERNEL k_evaluate(const DevProblem* P, const DevBatch* Bt, int which)
+{
+  TMX_SMEM(smem);
+  const int b = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
+  if (which == 1 && Bt->phase[b] == PHASE_DONE)
+    return;
+  const double* xv = (which ? Bt->xnew : Bt->x) + (size_t)b * P->NX;
+  double* co = (which ? Bt->new_cost_vals : Bt->cost_vals) + (size_t)b * P->n_costs;
+  double* vo = (which ? Bt->new_cnt_viols : Bt->cnt_viols) + (size_t)b * P->n_cnts;
+  evaluate_terms(P, xv, co, vo, smem, tid, NT);
+}
+
+// convexify (K1, K3) + reference QP structure (K4) for problems in PHASE_CONVEXIFY (all problems if force)
+TMX_KERNEL k_convexify(const DevProblem* P, const DevBatch* Bt, int force)
+{
+  TMX_SMEM(smem);
+  const int b = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
+  if (!force && Bt->phase[b] != PHASE_CONVEXIFY)
+    return;
+  const int R = P->R, D = P->D;
+  int* act = Bt->active + (size_t)b * R;
+  double* coef = Bt->coef + (size_t)b * R * D;
+  double* rhs = Bt->rhs + (size_t)b * R;
+  const double* x = Bt->x + (size_t)b * P->NX;
+  convexify_terms(P, x, act, coef, rhs, tid, NT);
+  qp_structure(P, act, coef, rhs, x, Bt->trust[b], Bt->merit + (size_t)b * P->n_cnts, Bt->dims + 4 * b, Bt->hashes + 4 * b,
+               nullptr, reinterpret_cast<int*>(smem), tid, NT);
+}
+
+// export of one problem's QP in reference CSC layout (tests / INTEGRATION: the S1 hand-off format)
+TMX_KERNEL k_export_csc(const DevProblem* P, const DevBatch* Bt, int b, CscOut out, int* dims_out, unsigned long long* hashes_out)
+{
+  TMX_SMEM(smem);
+  const int tid = threadIdx.x, NT = blockDim.x;
+  const int R = P->R, D = P->D;
+  qp_structure(P, Bt->active + (size_t)b * R, Bt->coef + (size_t)b * R * D, Bt->rhs + (size_t)b * R,
+               Bt->x + (size_t)b * P->NX, Bt->trust[b], Bt->merit + (size_t)b * P->n_cnts, dims_out, hashes_out, &out,
+               reinterpret_cast<int*>(smem), tid, NT);
+}
+
+// K5: Model::optimize() for every running problem; also publishes new_x = first NX model vars (optimizers.cpp:396)
+TMX_KERNEL k_qp_solve(const DevProblem* P, const DevBatch* Bt, int force)
+{
+  TMX_SMEM(smem);
+  const int b = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
+  if (!force && Bt->phase[b] == PHASE_DONE)
+    return;
+  qp_solve_block(P, Bt, b, smem, tid, NT);
+  const double* xq = Bt->xq + (size_t)b * P->n_max;
+  double* xn = Bt->xnew + (size_t)b * P->NX;
+  for (int v = tid; v < P->NX; v += NT)
+    xn[v] = xq[v];
+}
+
+TMX_KERNEL k_sqp_update(const DevProblem* P, const DevBatch* Bt)
+{
+  TMX_SMEM(smem);
+  const int b = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
+  sqp_update_block(P, Bt, b, smem, tid, NT);
+}
+
+// number of problems not DONE + running totals; `totals` = {n_active, n_fe, n_qp, admm} zeroed by the host first
+TMX_KERNEL k_count_active(const DevBatch* Bt, long long* totals)
+{
+  const int tid = threadIdx.x + blockIdx.x * blockDim.x, NT = blockDim.x * gridDim.x;
+  long long na = 0, fe = 0, qp = 0, ad = 0;
+  for (int b = tid; b < Bt->B; b += NT)
+  {
+    na += (Bt->phase[b] != PHASE_DONE);
+    fe += Bt->n_fe[b];
+    qp += Bt->n_qp[b];
+    ad += Bt->admm_iters[b];
+  }
+  TMX_ATOMIC_ADD_U64(&totals[0], na);
+  TMX_ATOMIC_ADD_U64(&totals[1], fe);
+  TMX_ATOMIC_ADD_U64(&totals[2], qp);
+  TMX_ATOMIC_ADD_U64(&totals[3], ad);
+}

@@ -1,0 +1,107 @@
+// tmx_platform.h — the product is HIP for gfx950 (hipcc).  The only other mode, TMX_HOST_EMU, exists so that
+// `pytest -m "not gpu"` can exercise the HOST logic (state machine, slot tables, C-ABI plumbing) and the
+// kernel arithmetic in this GPU-less container: the same kernel sources are compiled with g++ and every
+// workgroup is executed by ONE host thread (blockDim.x == 1, barriers are no-ops).  The emulation library is
+// built under tests/hostemu/_build/ and is never loaded by the trajopt_amd runtime (trajopt_amd/runtime.py
+// refuses to run without a HIP device) — it is test scaffolding, not a CPU fallback.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#ifdef TMX_HOST_EMU
+// ------------------------------------------------------------------------------------------------
+struct tmx_emu_idx
+{
+  int x, y, z;
+};
+extern thread_local tmx_emu_idx tmx_emu_threadIdx, tmx_emu_blockIdx, tmx_emu_blockDim, tmx_emu_gridDim;
+extern thread_local double* tmx_emu_smem;
+#define threadIdx tmx_emu_threadIdx
+#define blockIdx tmx_emu_blockIdx
+#define blockDim tmx_emu_blockDim
+#define gridDim tmx_emu_gridDim
+#define TMX_DEVFN static inline
+#define TMX_HOSTDEVFN static inline
+#define TMX_KERNEL static void
+#define TMX_SMEM(name) double* name = tmx_emu_smem
+#define TMX_SYNC() ((void)0)
+#define TMX_IS_DEVICE 0
+
+typedef int hipError_t;
+typedef void* hipStream_t;
+typedef struct
+{
+  double t;
+}* hipEvent_t;
+#define hipSuccess 0
+static inline const char* hipGetErrorString(hipError_t) { return "emu"; }
+static inline hipError_t hipMalloc(void** p, size_t n)
+{
+  *p = std::calloc(1, n ? n : 1);
+  return *p ? 0 : 2;
+}
+static inline hipError_t hipFree(void* p)
+{
+  std::free(p);
+  return 0;
+}
+enum
+{
+  hipMemcpyHostToDevice,
+  hipMemcpyDeviceToHost,
+  hipMemcpyDeviceToDevice
+};
+static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, int) { return std::memcpy(d, s, n), 0; }
+static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { return std::memcpy(d, s, n), 0; }
+static inline hipError_t hipMemset(void* d, int v, size_t n) { return std::memset(d, v, n), 0; }
+static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { return std::memset(d, v, n), 0; }
+static inline hipError_t hipSetDevice(int) { return 0; }
+static inline hipError_t hipGetDeviceCount(int* c) { return *c = 1, 0; }
+static inline hipError_t hipStreamCreate(hipStream_t* s) { return *s = nullptr, 0; }
+static inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
+static inline hipError_t hipDeviceSynchronize() { return 0; }
+static inline hipError_t hipGetLastError() { return 0; }
+double tmx_emu_now_ms();
+static inline hipError_t hipEventCreate(hipEvent_t* e)
+{
+  *e = (hipEvent_t)std::calloc(1, sizeof(**e));
+  return 0;
+}
+static inline hipError_t hipEventDestroy(hipEvent_t e) { return std::free(e), 0; }
+static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { return e->t = tmx_emu_now_ms(), 0; }
+static inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
+static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { return *ms = (float)(b->t - a->t), 0; }
+
+// run every workgroup on the host, one host thread per workgroup (OpenMP over blocks)
+#define TMX_LAUNCH(kernel, grid, block, smem_bytes, stream, ...)                                                      \
+  do                                                                                                                  \
+  {                                                                                                                   \
+    const int tmx_g_ = (grid);                                                                                        \
+    _Pragma("omp parallel for schedule(dynamic)") for (int tmx_b_ = 0; tmx_b_ < tmx_g_; ++tmx_b_)                    \
+    {                                                                                                                 \
+      double* tmx_s_ = (double*)std::calloc(1, (size_t)(smem_bytes) + 16);                                            \
+      tmx_emu_smem = tmx_s_;                                                                                          \
+      tmx_emu_blockIdx = { tmx_b_, 0, 0 };                                                                            \
+      tmx_emu_threadIdx = { 0, 0, 0 };                                                                                \
+      tmx_emu_blockDim = { 1, 1, 1 };                                                                                 \
+      tmx_emu_gridDim = { tmx_g_, 1, 1 };                                                                             \
+      kernel(__VA_ARGS__);                                                                                            \
+      std::free(tmx_s_);                                                                                              \
+    }                                                                                                                 \
+  } while (0)
+#else
+// ------------------------------------------------------------------------------------------------
+#include <hip/hip_runtime.h>
+#define TMX_DEVFN __device__ static inline
+#define TMX_HOSTDEVFN __host__ __device__ static inline
+#define TMX_KERNEL __global__ void
+#define TMX_SMEM(name) extern __shared__ __attribute__((aligned(16))) double name[]
+#define TMX_SYNC() __syncthreads()
+#define TMX_IS_DEVICE 1
+#define TMX_LAUNCH(kernel, grid, block, smem_bytes, stream, ...)                                                      \
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), (size_t)(smem_bytes), stream, __VA_ARGS__)
+#endif

@@ -1,0 +1,689 @@
+// tmx_qp.h — K4 (QP structure / reference-layout export) and K5 (batched OSQP-style ADMM) device code.
+//
+// One workgroup per problem; the whole QP (scaled data, iterates, block factor) lives in LDS for the duration
+// of the solve, so the ADMM loop never touches HBM.  The QP is kept in ROW-STRUCTURED form instead of CSC:
+//   primary vars  x_p (T blocks of D)        P = per-joint tridiagonal (JointVel Hessian): pd (diag), po (t,t+1)
+//   general rows  r (slot order)             coef[r][0..D) on the primary block t(r), plus n_aux(r) in {0,1,2}
+//   aux vars      a (hinge: 1, abs: 2)       each touches exactly one general row (entry sa = -1 | +1,-1) and its
+//   bound rows    identity on every var      own bound row [0, +inf)
+// KKT solve: eliminate the constraint rows (weight rho) and then the aux vars analytically (rank-1 Sherman-Morrison
+// per row) => SPD block-tridiagonal system over the primary vars with D x D blocks and DIAGONAL coupling blocks;
+// block LDL' with explicit inverse Schur complements Sinv_t (what the ADMM loop multiplies with).
+//
+// Algorithm restated: OSQP v1.0.0 as configured by trajopt_sco/src/osqp_interface.cpp:78-90 and driven by
+// OSQPModel::createOrUpdateSolver/optimize (:283-370, :440-615) — Ruiz scaling x10, rho_eq = 1e3 rho, sigma,
+// alpha, termination test every `check_termination` iterations, adaptive rho, infeasibility certificates, polish
+// with iterative refinement, explicit warm start when the CSC sparsity is unchanged.  See oracle/osqp_restate.hpp
+// for the line-by-line CPU statement this kernel is checked against.
+#pragma once
+#include "tmx_types.h"
+
+#define TMX_OSQP_INFTY 1e30
+#define TMX_MIN_SCALING 1e-4
+#define TMX_MAX_SCALING 1e4
+#define TMX_RHO_MIN 1e-6
+#define TMX_RHO_MAX 1e6
+#define TMX_RHO_TOL 1e-4
+#define TMX_RHO_EQ_OVER_INEQ 1e3
+#define TMX_DIVISION_TOL 1e-30
+
+// ---- block reductions -------------------------------------------------------------------------------
+#if TMX_IS_DEVICE
+template <int K>
+TMX_DEVFN void block_reduce(double (&v)[K], const bool (&is_sum)[K], double* red, int tid, int NT)
+{
+  const int lane = tid & 63, wave = tid >> 6, nw = NT >> 6;
+#pragma unroll
+  for (int k = 0; k < K; ++k)
+  {
+    double x = v[k];
+    for (int off = 32; off > 0; off >>= 1)
+    {
+      const double o = __shfl_xor(x, off, 64);
+      x = is_sum[k] ? (x + o) : fmax(x, o);
+    }
+    v[k] = x;
+  }
+  if (nw > 1)
+  {
+    TMX_SYNC();
+    if (lane == 0)
+      for (int k = 0; k < K; ++k)
+        red[k * nw + wave] = v[k];
+    TMX_SYNC();
+    for (int k = 0; k < K; ++k)
+    {
+      double x = red[k * nw];
+      for (int w = 1; w < nw; ++w)
+        x = is_sum[k] ? (x + red[k * nw + w]) : fmax(x, red[k * nw + w]);
+      v[k] = x;
+    }
+  }
+}
+#else
+template <int K>
+TMX_DEVFN void block_reduce(double (&)[K], const bool (&)[K], double*, int, int)
+{
+}
+#endif
+TMX_DEVFN double block_max1(double v, double* red, int tid, int NT)
+{
+  double a[1] = { v };
+  const bool s[1] = { false };
+  block_reduce<1>(a, s, red, tid, NT);
+  return a[0];
+}
+
+// ---- LDS workspace -------------------------------------------------------------------------------------
+struct QpWs
+{
+  int D, T, NX, R, NA;
+  double sigma, alpha, rho, c, cinv;
+  // primary (NX)
+  double *xp, *zbp, *ybp, *lbp, *ubp, *qp, *Dp, *Ebp, *bbp, *tp, *pd, *po, *dxp, *dybp;
+  // general rows (R) + coefficients (R*D)
+  double *zr, *yr, *lor, *hir, *Er, *hr, *dyr, *coef;
+  // aux (NA)
+  double *xa, *zba, *yba, *qa, *Da, *Eba, *bba, *sa, *ta, *dxa, *dyba;
+  double *Sinv;  // T*D*D
+  double *gj;    // D*D Gauss-Jordan scratch
+  double *red;   // reduction scratch (64) + broadcast scalars (32)
+  // ints
+  int *act, *aoff, *naux, *slot_t, *typ_r, *typ_bp, *typ_ba, *flg_r, *flg_bp, *flg_ba, *row_ref, *aux_ref;
+};
+
+TMX_HOSTDEVFN size_t qp_ws_doubles(int D, int T, int R, int NA)
+{
+  const int NX = D * T;
+  size_t n = 14 * (size_t)NX + 7 * (size_t)R + (size_t)R * D + 11 * (size_t)NA + (size_t)T * D * D + (size_t)D * D + 96;
+  size_t ints = 8 * (size_t)R + 2 * (size_t)NX + 2 * (size_t)NA;
+  return n + (ints + 1) / 2 + 8;
+}
+
+TMX_DEVFN void qp_ws_carve(QpWs& w, double* base, int D, int T, int R, int NA)
+{
+  w.D = D;
+  w.T = T;
+  w.NX = D * T;
+  w.R = R;
+  w.NA = NA;
+  const int NX = w.NX;
+  double* p = base;
+#define TAKE(name, n)                                                                                                 \
+  w.name = p;                                                                                                         \
+  p += (n)
+  TAKE(xp, NX);
+  TAKE(zbp, NX);
+  TAKE(ybp, NX);
+  TAKE(lbp, NX);
+  TAKE(ubp, NX);
+  TAKE(qp, NX);
+  TAKE(Dp, NX);
+  TAKE(Ebp, NX);
+  TAKE(bbp, NX);
+  TAKE(tp, NX);
+  TAKE(pd, NX);
+  TAKE(po, NX);
+  TAKE(dxp, NX);
+  TAKE(dybp, NX);
+  TAKE(zr, R);
+  TAKE(yr, R);
+  TAKE(lor, R);
+  TAKE(hir, R);
+  TAKE(Er, R);
+  TAKE(hr, R);
+  TAKE(dyr, R);
+  TAKE(coef, R * D);
+  TAKE(xa, NA);
+  TAKE(zba, NA);
+  TAKE(yba, NA);
+  TAKE(qa, NA);
+  TAKE(Da, NA);
+  TAKE(Eba, NA);
+  TAKE(bba, NA);
+  TAKE(sa, NA);
+  TAKE(ta, NA);
+  TAKE(dxa, NA);
+  TAKE(dyba, NA);
+  TAKE(Sinv, T * D * D);
+  TAKE(gj, D * D);
+  TAKE(red, 96);
+#undef TAKE
+  int* ip = reinterpret_cast<int*>(p);
+#define TAKEI(name, n)                                                                                                \
+  w.name = ip;                                                                                                        \
+  ip += (n)
+  TAKEI(act, R);
+  TAKEI(aoff, R);
+  TAKEI(naux, R);
+  TAKEI(slot_t, R);
+  TAKEI(typ_r, R);
+  TAKEI(flg_r, R);
+  TAKEI(row_ref, R);
+  TAKEI(aux_ref, R);
+  TAKEI(typ_bp, NX);
+  TAKEI(flg_bp, NX);
+  TAKEI(typ_ba, NA);
+  TAKEI(flg_ba, NA);
+#undef TAKEI
+}
+
+TMX_DEVFN double limit_scaling(double v)
+{
+  v = v < TMX_MIN_SCALING ? 1.0 : v;
+  v = v > TMX_MAX_SCALING ? TMX_MAX_SCALING : v;
+  return v;
+}
+TMX_DEVFN double rho_of_type(int typ, double rho)
+{
+  return typ == 1 ? TMX_RHO_EQ_OVER_INEQ * rho : (typ == 0 ? rho : TMX_RHO_MIN);
+}
+TMX_DEVFN int constr_type(double l, double u)
+{
+  if ((l < -TMX_OSQP_INFTY * TMX_MIN_SCALING) && (u > TMX_OSQP_INFTY * TMX_MIN_SCALING))
+    return -1;
+  if (u - l < TMX_RHO_TOL)
+    return 1;
+  return 0;
+}
+TMX_DEVFN double clampd(double v, double l, double u) { return fmin(fmax(v, l), u); }
+
+// weights: per-row "rho" used by the KKT reduction.  mode 0: ADMM (rho by constraint type); mode 1: polish
+// (1/delta on active rows, 0 elsewhere)
+TMX_DEVFN double w_row(const QpWs& w, int r, int mode, double delta)
+{
+  return mode == 0 ? rho_of_type(w.typ_r[r], w.rho) : (w.flg_r[r] != 0 ? 1.0 / delta : 0.0);
+}
+TMX_DEVFN double w_bp(const QpWs& w, int i, int mode, double delta)
+{
+  return mode == 0 ? rho_of_type(w.typ_bp[i], w.rho) : (w.flg_bp[i] != 0 ? 1.0 / delta : 0.0);
+}
+TMX_DEVFN double w_ba(const QpWs& w, int a, int mode, double delta)
+{
+  return mode == 0 ? rho_of_type(w.typ_ba[a], w.rho) : (w.flg_ba[a] != 0 ? 1.0 / delta : 0.0);
+}
+
+// ---- KKT factorisation: Sinv_t for the reduced block-tridiagonal system -----------------------------------
+// sig = sigma (ADMM) or delta (polish)
+TMX_DEVFN void kkt_factor(const QpWs& w, const DevProblem* P, int mode, double sig, double delta, int tid, int NT)
+{
+  const int D = w.D, T = w.T, DD = D * D;
+  // effective row weights after eliminating the aux vars: w_eff = rho_r / (1 + rho_r * kappa_r)
+  for (int r = tid; r < w.R; r += NT)
+  {
+    double we = 0.0;
+    if (w.act[r])
+    {
+      const double rr = w_row(w, r, mode, delta);
+      double kappa = 0.0;
+      for (int k = 0; k < w.naux[r]; ++k)
+      {
+        const int a = w.aoff[r] + k;
+        const double d = sig + w_ba(w, a, mode, delta) * w.bba[a] * w.bba[a];
+        kappa += w.sa[a] * w.sa[a] / d;
+      }
+      we = rr / (1.0 + rr * kappa);
+    }
+    w.hr[r] = we;
+  }
+  TMX_SYNC();
+  // diagonal blocks A_t
+  for (int e = tid; e < T * DD; e += NT)
+  {
+    const int t = e / DD, i = (e % DD) / D, j = e % D;
+    double s = 0.0;
+    for (int q = P->wp_start[t]; q < P->wp_start[t + 1]; ++q)
+    {
+      const int r = P->wp_list[q];
+      if (w.act[r])
+        s += w.hr[r] * w.coef[r * D + i] * w.coef[r * D + j];
+    }
+    if (i == j)
+    {
+      const int v = t * D + i;
+      s += w.pd[v] + sig + w_bp(w, v, mode, delta) * w.bbp[v] * w.bbp[v];
+    }
+    w.Sinv[e] = s;
+  }
+  TMX_SYNC();
+  // sequential Schur complements + in-place Gauss-Jordan inversion (SPD, no pivoting)
+  for (int t = 0; t < T; ++t)
+  {
+    double* S = w.Sinv + t * DD;
+    if (t > 0)
+    {
+      const double* Sp = w.Sinv + (t - 1) * DD;
+      const double* c = w.po + (t - 1) * D;
+      for (int e = tid; e < DD; e += NT)
+      {
+        const int i = e / D, j = e % D;
+        S[e] -= c[i] * Sp[e] * c[j];
+      }
+      TMX_SYNC();
+    }
+    for (int k = 0; k < D; ++k)
+    {
+      const double piv = 1.0 / S[k * D + k];
+      TMX_SYNC();
+      // scale pivot row (excluding pivot), stash pivot column in red
+      for (int e = tid; e < D; e += NT)
+      {
+        w.red[32 + e] = S[e * D + k];  // column k
+      }
+      TMX_SYNC();
+      for (int e = tid; e < DD; e += NT)
+      {
+        const int i = e / D, j = e % D;
+        double v;
+        if (i == k && j == k)
+          v = piv;
+        else if (i == k)
+          v = S[e] * piv;
+        else if (j == k)
+          v = -w.red[32 + i] * piv;
+        else
+          v = S[e] - w.red[32 + i] * S[k * D + j] * piv;
+        w.gj[e] = v;
+      }
+      TMX_SYNC();
+      for (int e = tid; e < DD; e += NT)
+        S[e] = w.gj[e];
+      TMX_SYNC();
+    }
+  }
+}
+
+// ---- KKT solve: in: tp (primary rhs r1 + A'W r2 part), ta (aux rhs); out: tp = x_p, ta = x_a, hr = (A x)_r --------
+TMX_DEVFN void kkt_solve(const QpWs& w, const DevProblem* P, int mode, double sig, double delta, int tid, int NT)
+{
+  const int D = w.D, T = w.T, DD = D * D;
+  // 1. aux elimination: h_r = rho_r * (s . Maa^-1 rhs_a) ;   Maa^-1 v = v/d - rho (s/d) (s.(v/d)) / (1 + rho kappa)
+  for (int r = tid; r < w.R; r += NT)
+  {
+    double h = 0.0;
+    if (w.act[r] && w.naux[r] > 0)
+    {
+      const double rr = w_row(w, r, mode, delta);
+      double kappa = 0.0, g = 0.0;
+      for (int k = 0; k < w.naux[r]; ++k)
+      {
+        const int a = w.aoff[r] + k;
+        const double d = sig + w_ba(w, a, mode, delta) * w.bba[a] * w.bba[a];
+        kappa += w.sa[a] * w.sa[a] / d;
+        g += w.sa[a] * w.ta[a] / d;
+      }
+      h = rr * g / (1.0 + rr * kappa);
+    }
+    w.hr[r] = h;
+  }
+  TMX_SYNC();
+  for (int v = tid; v < w.NX; v += NT)
+  {
+    const int t = v / D, j = v % D;
+    double s = 0.0;
+    for (int q = P->wp_start[t]; q < P->wp_start[t + 1]; ++q)
+    {
+      const int r = P->wp_list[q];
+      if (w.act[r])
+        s += w.hr[r] * w.coef[r * D + j];
+    }
+    w.tp[v] -= s;
+  }
+  TMX_SYNC();
+  // 2. block forward / backward substitution (sequential over waypoints); row i of the block handled by thread i
+  for (int t = 1; t < T; ++t)
+  {
+    for (int i = tid; i < D; i += NT)
+    {
+      const double* S = w.Sinv + (t - 1) * DD + i * D;
+      const double* vp = w.tp + (t - 1) * D;
+      double acc = 0.0;
+      for (int j = 0; j < D; ++j)
+        acc += S[j] * vp[j];
+      w.tp[t * D + i] -= w.po[(t - 1) * D + i] * acc;
+    }
+    TMX_SYNC();
+  }
+  for (int t = T - 1; t >= 0; --t)
+  {
+    for (int i = tid; i < D; i += NT)
+    {
+      const double* S = w.Sinv + t * DD + i * D;
+      double acc = 0.0;
+      for (int j = 0; j < D; ++j)
+      {
+        double vj = w.tp[t * D + j];
+        if (t < T - 1)
+          vj -= w.po[t * D + j] * w.tp[(t + 1) * D + j];
+        acc += S[j] * vj;
+      }
+      w.gj[i] = acc;
+    }
+    TMX_SYNC();
+    for (int i = tid; i < D; i += NT)
+      w.tp[t * D + i] = w.gj[i];
+    TMX_SYNC();
+  }
+  // 3. aux recovery and (A x)_r
+  for (int r = tid; r < w.R; r += NT)
+  {
+    if (!w.act[r])
+    {
+      w.hr[r] = 0.0;
+      continue;
+    }
+    const int t = w.slot_t[r];
+    double dot = 0.0;
+    for (int j = 0; j < D; ++j)
+      dot += w.coef[r * D + j] * w.tp[t * D + j];
+    double ax = dot;
+    if (w.naux[r] > 0)
+    {
+      const double rr = w_row(w, r, mode, delta);
+      double kappa = 0.0, g = 0.0;
+      double dk[2], vk[2];
+      for (int k = 0; k < w.naux[r]; ++k)
+      {
+        const int a = w.aoff[r] + k;
+        dk[k] = sig + w_ba(w, a, mode, delta) * w.bba[a] * w.bba[a];
+        vk[k] = w.ta[a] - rr * w.sa[a] * dot;
+        kappa += w.sa[a] * w.sa[a] / dk[k];
+        g += w.sa[a] * vk[k] / dk[k];
+      }
+      const double f = rr * g / (1.0 + rr * kappa);
+      for (int k = 0; k < w.naux[r]; ++k)
+      {
+        const int a = w.aoff[r] + k;
+        const double xa = vk[k] / dk[k] - (w.sa[a] / dk[k]) * f;
+        w.ta[a] = xa;
+        ax += w.sa[a] * xa;
+      }
+    }
+    w.hr[r] = ax;
+  }
+  TMX_SYNC();
+}
+
+// (A'v)_p for primary var v given per-row values rv[R] and per-bound values handled by caller
+TMX_DEVFN double at_rows(const QpWs& w, const DevProblem* P, const double* rv, int v)
+{
+  const int D = w.D, t = v / D, j = v % D;
+  double s = 0.0;
+  for (int q = P->wp_start[t]; q < P->wp_start[t + 1]; ++q)
+  {
+    const int r = P->wp_list[q];
+    if (w.act[r])
+      s += w.coef[r * D + j] * rv[r];
+  }
+  return s;
+}
+// (P x)_v for primary var v
+TMX_DEVFN double p_times(const QpWs& w, const double* x, int v)
+{
+  const int D = w.D, t = v / D;
+  double s = w.pd[v] * x[v];
+  if (t > 0)
+    s += w.po[v - D] * x[v - D];
+  if (t < w.T - 1)
+    s += w.po[v] * x[v + D];
+  return s;
+}
+
+struct QpInfo
+{
+  int status, iter, rho_updates, polish_status;
+  double prim_res, dual_res;
+  // scaled norms for the rho estimate (from the last update_info)
+  double s_prim, s_dual, s_z, s_ax, s_q, s_aty, s_px;
+  // unscaled norms for the tolerances
+  double u_z, u_ax, u_q, u_aty, u_px;
+};
+
+// residuals at (x, z, y) given as component arrays.  z for rows/bounds passed explicitly so that the polished
+// point (z = clip(Ax)) can reuse it with zmode=1.
+TMX_DEVFN void compute_residuals(const QpWs& w, const DevProblem* P, const double* xp, const double* xa, const double* yr,
+                                 const double* ybp, const double* yba, int zmode, QpInfo& info, double& prim_res,
+                                 double& dual_res, bool store_norms, int tid, int NT)
+{
+  const int D = w.D;
+  double m[12];
+  const bool sums[12] = { false, false, false, false, false, false, false, false, false, false, false, false };
+  for (int k = 0; k < 12; ++k)
+    m[k] = 0.0;
+  double uq = 0.0, uaty = 0.0, upx = 0.0;
+  // rows
+  for (int r = tid; r < w.R; r += NT)
+  {
+    if (!w.act[r])
+      continue;
+    const int t = w.slot_t[r];
+    double ax = 0.0;
+    for (int j = 0; j < D; ++j)
+      ax += w.coef[r * D + j] * xp[t * D + j];
+    for (int k = 0; k < w.naux[r]; ++k)
+      ax += w.sa[w.aoff[r] + k] * xa[w.aoff[r] + k];
+    const double z = zmode ? clampd(ax, w.lor[r], w.hir[r]) : w.zr[r];
+    const double einv = 1.0 / w.Er[r];
+    m[0] = fmax(m[0], fabs(einv * (ax - z)));
+    m[1] = fmax(m[1], fabs(ax - z));
+    m[2] = fmax(m[2], fabs(z));
+    m[3] = fmax(m[3], fabs(ax));
+    m[4] = fmax(m[4], fabs(einv * z));
+    m[5] = fmax(m[5], fabs(einv * ax));
+  }
+  for (int v = tid; v < w.NX; v += NT)
+  {
+    const double ax = w.bbp[v] * xp[v];
+    const double z = zmode ? clampd(ax, w.lbp[v], w.ubp[v]) : w.zbp[v];
+    const double einv = 1.0 / w.Ebp[v];
+    m[0] = fmax(m[0], fabs(einv * (ax - z)));
+    m[1] = fmax(m[1], fabs(ax - z));
+    m[2] = fmax(m[2], fabs(z));
+    m[3] = fmax(m[3], fabs(ax));
+    m[4] = fmax(m[4], fabs(einv * z));
+    m[5] = fmax(m[5], fabs(einv * ax));
+    // dual residual, primary part
+    const double px = p_times(w, xp, v);
+    const double aty = at_rows(w, P, yr, v) + w.bbp[v] * ybp[v];
+    const double res = (w.qp[v] + px) + aty;
+    const double dinv = 1.0 / w.Dp[v];
+    m[6] = fmax(m[6], fabs(dinv * res));
+    m[7] = fmax(m[7], fabs(res));
+    m[8] = fmax(m[8], fabs(w.qp[v]));
+    m[9] = fmax(m[9], fabs(aty));
+    m[10] = fmax(m[10], fabs(px));
+    uq = fmax(uq, fabs(dinv * w.qp[v]));
+    uaty = fmax(uaty, fabs(dinv * aty));
+    upx = fmax(upx, fabs(dinv * px));
+  }
+  for (int r = tid; r < w.R; r += NT)
+  {
+    if (!w.act[r])
+      continue;
+    for (int k = 0; k < w.naux[r]; ++k)
+    {
+      const int a = w.aoff[r] + k;
+      // bound row of the aux var
+      const double ax = w.bba[a] * xa[a];
+      const double ua = TMX_OSQP_INFTY * w.Eba[a];
+      const double z = zmode ? clampd(ax, 0.0, ua) : w.zba[a];
+      const double einv = 1.0 / w.Eba[a];
+      m[0] = fmax(m[0], fabs(einv * (ax - z)));
+      m[1] = fmax(m[1], fabs(ax - z));
+      m[2] = fmax(m[2], fabs(z));
+      m[3] = fmax(m[3], fabs(ax));
+      m[4] = fmax(m[4], fabs(einv * z));
+      m[5] = fmax(m[5], fabs(einv * ax));
+      // dual residual, aux part (P has no aux entries)
+      const double aty = w.sa[a] * yr[r] + w.bba[a] * yba[a];
+      const double res = w.qa[a] + aty;
+      const double dinv = 1.0 / w.Da[a];
+      m[6] = fmax(m[6], fabs(dinv * res));
+      m[7] = fmax(m[7], fabs(res));
+      m[8] = fmax(m[8], fabs(w.qa[a]));
+      m[9] = fmax(m[9], fabs(aty));
+      uq = fmax(uq, fabs(dinv * w.qa[a]));
+      uaty = fmax(uaty, fabs(dinv * aty));
+    }
+  }
+  m[11] = uq;
+  double m2[2] = { uaty, upx };
+  const bool sums2[2] = { false, false };
+  block_reduce<12>(m, sums, w.red, tid, NT);
+  block_reduce<2>(m2, sums2, w.red, tid, NT);
+  prim_res = m[0];
+  dual_res = w.cinv * m[6];
+  if (store_norms)
+  {
+    info.s_prim = m[1];
+    info.s_z = m[2];
+    info.s_ax = m[3];
+    info.u_z = m[4];
+    info.u_ax = m[5];
+    info.s_dual = m[7];
+    info.s_q = m[8];
+    info.s_aty = m[9];
+    info.s_px = m[10];
+    info.u_q = m[11];
+    info.u_aty = m2[0];
+    info.u_px = m2[1];
+  }
+}
+
+TMX_DEVFN double rho_estimate(const QpWs& w, const QpInfo& info)
+{
+  double prim = info.s_prim / (fmax(info.s_z, info.s_ax) + TMX_DIVISION_TOL);
+  double dual = info.s_dual / (fmax(fmax(info.s_q, info.s_aty), info.s_px) + TMX_DIVISION_TOL);
+  double est = w.rho * sqrt(prim / dual);
+  return fmin(fmax(est, TMX_RHO_MIN), TMX_RHO_MAX);
+}
+
+// infeasibility certificates (evaluated only when a residual test fails at a check iteration)
+TMX_DEVFN bool is_primal_infeasible(const QpWs& w, const DevProblem* P, double eps, int tid, int NT)
+{
+  // project delta_y on the polar of the recession cone, norms, ineq_lhs
+  double acc[2] = { 0.0, 0.0 };  // [0] = max |E dy|, [1] = sum ineq_lhs
+  const bool sums[2] = { false, true };
+  const double BIG = TMX_OSQP_INFTY * TMX_MIN_SCALING;
+  for (int r = tid; r < w.R; r += NT)
+  {
+    if (!w.act[r])
+      continue;
+    double dy = w.dyr[r];
+    const double l = w.lor[r], u = w.hir[r];
+    if (u > BIG)
+      dy = (l < -BIG) ? 0.0 : fmin(dy, 0.0);
+    else if (l < -BIG)
+      dy = fmax(dy, 0.0);
+    w.dyr[r] = dy;
+    acc[0] = fmax(acc[0], fabs(w.Er[r] * dy));
+    acc[1] += (dy > 0) ? u * dy : ((dy < 0) ? l * dy : 0.0);
+    for (int k = 0; k < w.naux[r]; ++k)
+    {
+      const int a = w.aoff[r] + k;
+      double da = w.dyba[a];
+      const double ua = TMX_OSQP_INFTY * w.Eba[a];
+      if (ua > BIG)
+        da = fmin(da, 0.0);
+      w.dyba[a] = da;
+      acc[0] = fmax(acc[0], fabs(w.Eba[a] * da));
+      acc[1] += (da > 0) ? ua * da : ((da < 0) ? 0.0 * da : 0.0);
+    }
+  }
+  for (int v = tid; v < w.NX; v += NT)
+  {
+    double dy = w.dybp[v];
+    const double l = w.lbp[v], u = w.ubp[v];
+    if (u > BIG)
+      dy = (l < -BIG) ? 0.0 : fmin(dy, 0.0);
+    else if (l < -BIG)
+      dy = fmax(dy, 0.0);
+    w.dybp[v] = dy;
+    acc[0] = fmax(acc[0], fabs(w.Ebp[v] * dy));
+    acc[1] += (dy > 0) ? u * dy : ((dy < 0) ? l * dy : 0.0);
+  }
+  TMX_SYNC();
+  block_reduce<2>(acc, sums, w.red, tid, NT);
+  const double norm_dy = acc[0];
+  if (norm_dy > TMX_DIVISION_TOL && acc[1] < 0.0)
+  {
+    double nrm = 0.0;
+    for (int v = tid; v < w.NX; v += NT)
+      nrm = fmax(nrm, fabs((at_rows(w, P, w.dyr, v) + w.bbp[v] * w.dybp[v]) / w.Dp[v]));
+    for (int r = tid; r < w.R; r += NT)
+      if (w.act[r])
+        for (int k = 0; k < w.naux[r]; ++k)
+        {
+          const int a = w.aoff[r] + k;
+          nrm = fmax(nrm, fabs((w.sa[a] * w.dyr[r] + w.bba[a] * w.dyba[a]) / w.Da[a]));
+        }
+    nrm = block_max1(nrm, w.red, tid, NT);
+    return nrm < eps * norm_dy;
+  }
+  return false;
+}
+
+TMX_DEVFN bool is_dual_infeasible(const QpWs& w, const DevProblem* P, double eps, int tid, int NT)
+{
+  double acc[2] = { 0.0, 0.0 };  // max |D dx|, sum q.dx
+  const bool sums[2] = { false, true };
+  for (int v = tid; v < w.NX; v += NT)
+  {
+    acc[0] = fmax(acc[0], fabs(w.Dp[v] * w.dxp[v]));
+    acc[1] += w.qp[v] * w.dxp[v];
+  }
+  for (int r = tid; r < w.R; r += NT)
+    if (w.act[r])
+      for (int k = 0; k < w.naux[r]; ++k)
+      {
+        const int a = w.aoff[r] + k;
+        acc[0] = fmax(acc[0], fabs(w.Da[a] * w.dxa[a]));
+        acc[1] += w.qa[a] * w.dxa[a];
+      }
+  block_reduce<2>(acc, sums, w.red, tid, NT);
+  const double norm_dx = acc[0];
+  if (norm_dx > TMX_DIVISION_TOL && acc[1] < 0.0)
+  {
+    double nrm = 0.0;
+    for (int v = tid; v < w.NX; v += NT)
+      nrm = fmax(nrm, fabs(p_times(w, w.dxp, v) / w.Dp[v]));
+    nrm = block_max1(nrm, w.red, tid, NT);
+    if (nrm < w.c * eps * norm_dx)
+    {
+      double bad = 0.0;
+      const double BIG = TMX_OSQP_INFTY * TMX_MIN_SCALING;
+      const double thr = eps * norm_dx;
+      for (int r = tid; r < w.R; r += NT)
+      {
+        if (!w.act[r])
+          continue;
+        const int t = w.slot_t[r];
+        double adx = 0.0;
+        for (int j = 0; j < w.D; ++j)
+          adx += w.coef[r * w.D + j] * w.dxp[t * w.D + j];
+        for (int k = 0; k < w.naux[r]; ++k)
+          adx += w.sa[w.aoff[r] + k] * w.dxa[w.aoff[r] + k];
+        adx /= w.Er[r];
+        if (((w.hir[r] < BIG) && (adx > thr)) || ((w.lor[r] > -BIG) && (adx < -thr)))
+          bad = 1.0;
+        for (int k = 0; k < w.naux[r]; ++k)
+        {
+          const int a = w.aoff[r] + k;
+          const double ad = w.bba[a] * w.dxa[a] / w.Eba[a];
+          const double ua = TMX_OSQP_INFTY * w.Eba[a];
+          if (((ua < BIG) && (ad > thr)) || (ad < -thr))
+            bad = 1.0;
+        }
+      }
+      for (int v = tid; v < w.NX; v += NT)
+      {
+        const double ad = w.bbp[v] * w.dxp[v] / w.Ebp[v];
+        if (((w.ubp[v] < BIG) && (ad > thr)) || ((w.lbp[v] > -BIG) && (ad < -thr)))
+          bad = 1.0;
+      }
+      bad = block_max1(bad, w.red, tid, NT);
+      return bad == 0.0;
+    }
+  }
+  return false;
+}

@@ -1,0 +1,1250 @@
+// tmx_solve.h — K4 structure/export, the K5 ADMM driver (one Model::optimize() per workgroup) and the on-device
+// BasicTrustRegionSQP state machine (K6 decisions).  See tmx_qp.h for the KKT algebra.
+#pragma once
+#include "tmx_qp.h"
+#include "tmx_terms.h"
+
+#if TMX_IS_DEVICE
+#define TMX_ATOMIC_ADD_U64(ptr, v) atomicAdd((unsigned long long*)(ptr), (unsigned long long)(v))
+#else
+#define TMX_ATOMIC_ADD_U64(ptr, v) __atomic_fetch_add((unsigned long long*)(ptr), (unsigned long long)(v), __ATOMIC_RELAXED)
+#endif
+
+// entry sign of aux k of a row with naux aux vars: hinge: -1 ; abs: +1 (neg), -1 (pos)   (modeling.cpp:18-51)
+TMX_DEVFN double aux_sign(int naux, int k) { return (naux == 1) ? -1.0 : (k == 0 ? 1.0 : -1.0); }
+
+// ---------------------------------------------------------------------------------------------------------
+// K4: reference-layout structure of the current QP (what OSQPModel::updateObjective/updateConstraints build,
+// osqp_interface.cpp:170-281): dims, CSC index hashes, the byte-prefix hashes the reference's weak memcmp
+// sparsity test sees, and optionally the full CSC arrays (export, one problem).
+//   scratch ints (LDS): colcnt[n_max+1], rowref[R], auxref[R]
+// ---------------------------------------------------------------------------------------------------------
+struct CscOut
+{
+  long long *P_p, *P_i, *A_p, *A_i;
+  double *P_x, *q, *A_x, *l, *u;
+};
+
+TMX_DEVFN void qp_structure(const DevProblem* P, const int* active, const double* coef, const double* rhs,
+                            const double* xcur, double trust, const double* merit, int* dims, unsigned long long* hashes,
+                            const CscOut* out, int* iscratch, int tid, int NT)
+{
+  const int D = P->D, T = P->T, NX = P->NX, R = P->R;
+  int* colptr = iscratch;               // n_max + 1
+  int* rowref = colptr + P->n_max + 1;  // R
+  int* auxref = rowref + R;             // R
+  int acc_off = (P->n_max + 1) + 2 * R;
+  acc_off += (acc_off & 1);
+  unsigned long long* acc = reinterpret_cast<unsigned long long*>(iscratch + acc_off);  // 8 x u64 (8-byte aligned)
+  if (tid == 0)
+  {
+    int nr = 0, na = 0;
+    for (int r = 0; r < R; ++r)
+    {
+      rowref[r] = nr;
+      auxref[r] = NX + na;
+      if (active[r])
+      {
+        nr += 1;
+        na += P->slot_naux[r];
+      }
+    }
+    dims[0] = NX + na;       // n
+    dims[1] = nr + NX + na;  // m
+    for (int k = 0; k < 8; ++k)
+      acc[k] = 0ULL;
+  }
+  TMX_SYNC();
+  const int n = dims[0], m = dims[1], mg = m - n;
+  // column counts of A
+  for (int v = tid; v < NX; v += NT)
+  {
+    const int t = v / D, j = v % D;
+    int c = 1;
+    for (int q = P->wp_start[t]; q < P->wp_start[t + 1]; ++q)
+    {
+      const int r = P->wp_list[q];
+      if (active[r] && coef[r * D + j] != 0.0)
+        ++c;
+    }
+    colptr[v + 1] = c;
+  }
+  for (int r = tid; r < R; r += NT)
+    if (active[r])
+      for (int k = 0; k < P->slot_naux[r]; ++k)
+        colptr[auxref[r] + k + 1] = 2;
+  TMX_SYNC();
+  if (tid == 0)
+  {
+    colptr[0] = 0;
+    for (int c = 0; c < n; ++c)
+      colptr[c + 1] += colptr[c];
+    dims[3] = colptr[n];  // nnzA
+    dims[2] = P->nnzP;
+  }
+  TMX_SYNC();
+  const int nnzA = dims[3];
+  // hashes of A: colptr (salt 3) + rowidx (salt 4); prefix hashes for the weak memcmp
+  unsigned long long hA = 0ULL, wsA = 0ULL;
+  const int cp_bytes = n + 1, cp_full = cp_bytes / 8, cp_rem = cp_bytes % 8;
+  const int ri_bytes = nnzA, ri_full = ri_bytes / 8, ri_rem = ri_bytes % 8;
+  for (int c = tid; c <= n; c += NT)
+  {
+    const long long val = colptr[c];
+    hA += tmx_hash_term(val, (uint64_t)c, 3);
+    if (c < cp_full)
+      wsA += tmx_hash_term(val, (uint64_t)c, 13);
+    else if (c == cp_full && cp_rem > 0)
+      wsA += tmx_hash_term((long long)((unsigned long long)val & ((1ULL << (8 * cp_rem)) - 1ULL)), (uint64_t)c, 13);
+  }
+  // row indices: primary columns
+  for (int v = tid; v < NX; v += NT)
+  {
+    const int t = v / D, j = v % D;
+    int pos = colptr[v];
+    for (int q = P->wp_start[t]; q <= P->wp_start[t + 1]; ++q)
+    {
+      long long ri;
+      double val;
+      if (q < P->wp_start[t + 1])
+      {
+        const int r = P->wp_list[q];
+        if (!(active[r] && coef[r * D + j] != 0.0))
+          continue;
+        ri = rowref[r];
+        val = coef[r * D + j];
+      }
+      else
+      {
+        ri = mg + v;
+        val = 1.0;
+      }
+      hA += tmx_hash_term(ri, (uint64_t)pos, 4);
+      if (pos < ri_full)
+        wsA += tmx_hash_term(ri, (uint64_t)pos, 14);
+      else if (pos == ri_full && ri_rem > 0)
+        wsA += tmx_hash_term((long long)((unsigned long long)ri & ((1ULL << (8 * ri_rem)) - 1ULL)), (uint64_t)pos, 14);
+      if (out)
+      {
+        out->A_i[pos] = ri;
+        out->A_x[pos] = val;
+      }
+      ++pos;
+    }
+  }
+  for (int r = tid; r < R; r += NT)
+    if (active[r])
+      for (int k = 0; k < P->slot_naux[r]; ++k)
+      {
+        const int col = auxref[r] + k;
+        int pos = colptr[col];
+        for (int e = 0; e < 2; ++e)
+        {
+          const long long ri = (e == 0) ? rowref[r] : (mg + col);
+          hA += tmx_hash_term(ri, (uint64_t)pos, 4);
+          if (pos < ri_full)
+            wsA += tmx_hash_term(ri, (uint64_t)pos, 14);
+          else if (pos == ri_full && ri_rem > 0)
+            wsA += tmx_hash_term((long long)((unsigned long long)ri & ((1ULL << (8 * ri_rem)) - 1ULL)), (uint64_t)pos, 14);
+          if (out)
+          {
+            out->A_i[pos] = ri;
+            out->A_x[pos] = (e == 0) ? aux_sign(P->slot_naux[r], k) : 1.0;
+          }
+          ++pos;
+        }
+      }
+  // P: static pattern over the primary vars (upper triangle): (v-D, v) if po != 0 ; (v, v) if pd != 0
+  unsigned long long hP = 0ULL, wsP = 0ULL;
+  {
+    const int pp_bytes = n + 1, pp_full = pp_bytes / 8, pp_rem = pp_bytes % 8;
+    const int pi_full = P->nnzP / 8, pi_rem = P->nnzP % 8;
+    // colptr of P needs a prefix over primary columns: count = (t>0 && po[v-D]!=0) + (pd[v]!=0); sequential on thread 0
+    if (tid == 0)
+    {
+      int run = 0;
+      for (int c = 0; c <= n; ++c)
+      {
+        const long long val = run;
+        hP += tmx_hash_term(val, (uint64_t)c, 1);
+        if (c < pp_full)
+          wsP += tmx_hash_term(val, (uint64_t)c, 11);
+        else if (c == pp_full && pp_rem > 0)
+          wsP += tmx_hash_term((long long)((unsigned long long)val & ((1ULL << (8 * pp_rem)) - 1ULL)), (uint64_t)c, 11);
+        if (out)
+          out->P_p[c] = val;
+        if (c < NX)
+        {
+          const int t = c / D;
+          if (t > 0 && P->po[c - D] != 0.0)
+          {
+            hP += tmx_hash_term(c - D, (uint64_t)run, 2);
+            if (run < pi_full)
+              wsP += tmx_hash_term(c - D, (uint64_t)run, 12);
+            else if (run == pi_full && pi_rem > 0)
+              wsP += tmx_hash_term((long long)((unsigned long long)(c - D) & ((1ULL << (8 * pi_rem)) - 1ULL)), (uint64_t)run, 12);
+            if (out)
+            {
+              out->P_i[run] = c - D;
+              out->P_x[run] = P->po[c - D];
+            }
+            ++run;
+          }
+          if (P->pd[c] != 0.0)
+          {
+            hP += tmx_hash_term(c, (uint64_t)run, 2);
+            if (run < pi_full)
+              wsP += tmx_hash_term(c, (uint64_t)run, 12);
+            else if (run == pi_full && pi_rem > 0)
+              wsP += tmx_hash_term((long long)((unsigned long long)c & ((1ULL << (8 * pi_rem)) - 1ULL)), (uint64_t)run, 12);
+            if (out)
+            {
+              out->P_i[run] = c;
+              out->P_x[run] = P->pd[c];
+            }
+            ++run;
+          }
+        }
+      }
+    }
+  }
+  TMX_ATOMIC_ADD_U64(&acc[0], hP);
+  TMX_ATOMIC_ADD_U64(&acc[1], hA);
+  TMX_ATOMIC_ADD_U64(&acc[2], wsP);
+  TMX_ATOMIC_ADD_U64(&acc[3], wsA);
+  TMX_SYNC();
+  if (tid == 0)
+  {
+    hashes[0] = acc[0];
+    hashes[1] = acc[1];
+    hashes[2] = acc[2];
+    hashes[3] = acc[3];
+  }
+  if (out)
+  {
+    // q, l, u, A colptr in reference order
+    for (int c = tid; c <= n; c += NT)
+      out->A_p[c] = colptr[c];
+    for (int v = tid; v < NX; v += NT)
+    {
+      out->q[v] = P->pq[v];
+      const double xi = fmin(fmax(xcur[v], P->jl[v % D]), P->ju[v % D]);
+      const double lb = fmax(xi - trust, P->jl[v % D]), ub = fmin(xi + trust, P->ju[v % D]);
+      out->l[mg + v] = fmax(lb, -TMX_OSQP_INFTY);
+      out->u[mg + v] = fmin(ub, TMX_OSQP_INFTY);
+    }
+    for (int r = tid; r < R; r += NT)
+      if (active[r])
+      {
+        out->l[rowref[r]] = P->slot_eq[r] ? rhs[r] : -TMX_OSQP_INFTY;
+        out->u[rowref[r]] = rhs[r];
+        const double oc = P->slot_iscnt[r] ? merit[P->slot_owner[r]] : P->slot_objc[r];
+        for (int k = 0; k < P->slot_naux[r]; ++k)
+        {
+          out->q[auxref[r] + k] = oc;
+          out->l[mg + auxref[r] + k] = 0.0;
+          out->u[mg + auxref[r] + k] = TMX_OSQP_INFTY;
+        }
+      }
+  }
+  TMX_SYNC();
+  (void)T;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K5: one OSQPModel::optimize() — setup (scaling, rho vector, factor), optional explicit warm start, ADMM loop,
+// polish, solution store.  Executed by one workgroup on LDS workspace `w`.
+// ---------------------------------------------------------------------------------------------------------
+TMX_DEVFN void admm_rhs(const QpWs& w, const DevProblem* P, int tid, int NT)
+{
+  // per-row  g_r = rho_r z_r - y_r  into hr ; then tp = sigma x - q + A'g (+ bound part), ta likewise
+  for (int r = tid; r < w.R; r += NT)
+    w.hr[r] = w.act[r] ? (rho_of_type(w.typ_r[r], w.rho) * w.zr[r] - w.yr[r]) : 0.0;
+  TMX_SYNC();
+  for (int v = tid; v < w.NX; v += NT)
+  {
+    const double gb = rho_of_type(w.typ_bp[v], w.rho) * w.zbp[v] - w.ybp[v];
+    w.tp[v] = (w.sigma * w.xp[v] - w.qp[v]) + at_rows(w, P, w.hr, v) + w.bbp[v] * gb;
+  }
+  for (int r = tid; r < w.R; r += NT)
+    if (w.act[r])
+      for (int k = 0; k < w.naux[r]; ++k)
+      {
+        const int a = w.aoff[r] + k;
+        const double gb = rho_of_type(w.typ_ba[a], w.rho) * w.zba[a] - w.yba[a];
+        w.ta[a] = (w.sigma * w.xa[a] - w.qa[a]) + w.sa[a] * w.hr[r] + w.bba[a] * gb;
+      }
+  TMX_SYNC();
+}
+
+// x, z, y updates from (xtilde in tp/ta, (A xtilde)_r in hr); stores delta_x / delta_y when `keep_delta`
+TMX_DEVFN void admm_update(const QpWs& w, bool keep_delta, int tid, int NT)
+{
+  const double al = w.alpha;
+  for (int v = tid; v < w.NX; v += NT)
+  {
+    const double xn = al * w.tp[v] + (1.0 - al) * w.xp[v];
+    if (keep_delta)
+      w.dxp[v] = xn - w.xp[v];
+    w.xp[v] = xn;
+    const double rho = rho_of_type(w.typ_bp[v], w.rho), rinv = 1.0 / rho;
+    const double zt = w.bbp[v] * w.tp[v];
+    const double zr = al * zt + (1.0 - al) * w.zbp[v];
+    const double zn = clampd(zr + rinv * w.ybp[v], w.lbp[v], w.ubp[v]);
+    const double dy = rho * (zr - zn);
+    w.zbp[v] = zn;
+    w.ybp[v] += dy;
+    if (keep_delta)
+      w.dybp[v] = dy;
+  }
+  for (int r = tid; r < w.R; r += NT)
+  {
+    if (!w.act[r])
+      continue;
+    {
+      const double rho = rho_of_type(w.typ_r[r], w.rho), rinv = 1.0 / rho;
+      const double zr = al * w.hr[r] + (1.0 - al) * w.zr[r];
+      const double zn = clampd(zr + rinv * w.yr[r], w.lor[r], w.hir[r]);
+      const double dy = rho * (zr - zn);
+      w.zr[r] = zn;
+      w.yr[r] += dy;
+      if (keep_delta)
+        w.dyr[r] = dy;
+    }
+    for (int k = 0; k < w.naux[r]; ++k)
+    {
+      const int a = w.aoff[r] + k;
+      const double xn = al * w.ta[a] + (1.0 - al) * w.xa[a];
+      if (keep_delta)
+        w.dxa[a] = xn - w.xa[a];
+      w.xa[a] = xn;
+      const double rho = rho_of_type(w.typ_ba[a], w.rho), rinv = 1.0 / rho;
+      const double zt = w.bba[a] * w.ta[a];
+      const double zr = al * zt + (1.0 - al) * w.zba[a];
+      const double zn = clampd(zr + rinv * w.yba[a], 0.0, TMX_OSQP_INFTY * w.Eba[a]);
+      const double dy = rho * (zr - zn);
+      w.zba[a] = zn;
+      w.yba[a] += dy;
+      if (keep_delta)
+        w.dyba[a] = dy;
+    }
+  }
+  TMX_SYNC();
+}
+
+// returns true if terminated; sets info.status
+TMX_DEVFN bool check_termination(const QpWs& w, const DevProblem* P, QpInfo& info, bool approximate, int tid, int NT)
+{
+  const tmx_osqp_settings& s = P->osqp;
+  double eps_abs = s.eps_abs, eps_rel = s.eps_rel, eps_pinf = s.eps_prim_inf, eps_dinf = s.eps_dual_inf;
+  if (info.prim_res > TMX_OSQP_INFTY || info.dual_res > TMX_OSQP_INFTY)
+  {
+    info.status = 9;  // OSQP_NON_CVX
+    return true;
+  }
+  if (approximate)
+  {
+    eps_abs *= 10;
+    eps_rel *= 10;
+    eps_pinf *= 10;
+    eps_dinf *= 10;
+  }
+  bool prim_ok = false, dual_ok = false, prim_inf = false, dual_inf = false;
+  const double eps_prim = eps_abs + eps_rel * fmax(info.u_z, info.u_ax);
+  if (info.prim_res < eps_prim)
+    prim_ok = true;
+  else
+    prim_inf = is_primal_infeasible(w, P, eps_pinf, tid, NT);
+  const double eps_dual = eps_abs + eps_rel * (w.cinv * fmax(fmax(info.u_q, info.u_aty), info.u_px));
+  if (info.dual_res < eps_dual)
+    dual_ok = true;
+  else
+    dual_inf = is_dual_infeasible(w, P, eps_dinf, tid, NT);
+  if (prim_ok && dual_ok)
+  {
+    info.status = approximate ? 2 : 1;
+    return true;
+  }
+  if (prim_inf)
+  {
+    info.status = approximate ? 4 : 3;
+    return true;
+  }
+  if (dual_inf)
+  {
+    info.status = approximate ? 6 : 5;
+    return true;
+  }
+  return false;
+}
+
+
+#if defined(TMX_HOST_EMU) && defined(TMX_DEBUG_KKT)
+// debug: residual of the full KKT system for the ADMM step (host emulation only)
+static inline void debug_kkt_residual(const QpWs& w, const DevProblem* P, int iter)
+{
+  // nu_r = rho (ztilde - (z - y/rho)) with ztilde = hr / bb*x
+  double maxres = 0.0, maxx = 0.0;
+  std::vector<double> nu_r(w.R, 0.0);
+  for (int r = 0; r < w.R; ++r)
+    if (w.act[r])
+    {
+      const double rho = rho_of_type(w.typ_r[r], w.rho);
+      nu_r[r] = rho * (w.hr[r] - (w.zr[r] - w.yr[r] / rho));
+    }
+  for (int v = 0; v < w.NX; ++v)
+  {
+    const double rho = rho_of_type(w.typ_bp[v], w.rho);
+    const double nub = rho * (w.bbp[v] * w.tp[v] - (w.zbp[v] - w.ybp[v] / rho));
+    const double lhs = p_times(w, w.tp, v) + w.sigma * w.tp[v] + at_rows(w, P, nu_r.data(), v) + w.bbp[v] * nub;
+    const double rhs = w.sigma * w.xp[v] - w.qp[v];
+    maxres = fmax(maxres, fabs(lhs - rhs));
+    maxx = fmax(maxx, fabs(w.tp[v]));
+  }
+  for (int r = 0; r < w.R; ++r)
+    if (w.act[r])
+      for (int k = 0; k < w.naux[r]; ++k)
+      {
+        const int a = w.aoff[r] + k;
+        const double rho = rho_of_type(w.typ_ba[a], w.rho);
+        const double nub = rho * (w.bba[a] * w.ta[a] - (w.zba[a] - w.yba[a] / rho));
+        const double lhs = w.sigma * w.ta[a] + w.sa[a] * nu_r[r] + w.bba[a] * nub;
+        const double rhs = w.sigma * w.xa[a] - w.qa[a];
+        maxres = fmax(maxres, fabs(lhs - rhs));
+        maxx = fmax(maxx, fabs(w.ta[a]));
+      }
+  std::printf("[dbg] iter %d kkt residual %.3e  |xtilde| %.3e rho %.4g\n", iter, maxres, maxx, w.rho);
+}
+#endif
+
+TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, double* smem, int tid, int NT)
+{
+  const int D = P->D, T = P->T, NX = P->NX, R = P->R;
+  const tmx_osqp_settings& st = P->osqp;
+  QpWs w;
+  qp_ws_carve(w, smem, D, T, R, P->NA);
+  const int* g_act = Bt->active + (size_t)b * R;
+  const double* g_coef = Bt->coef + (size_t)b * R * D;
+  const double* g_rhs = Bt->rhs + (size_t)b * R;
+  const double* g_x = Bt->x + (size_t)b * NX;
+  const double* g_merit = Bt->merit + (size_t)b * P->n_cnts;
+  const double trust = Bt->trust[b];
+  const int* dims = Bt->dims + 4 * b;
+  const unsigned long long* hs = Bt->hashes + 4 * b;
+
+  // ---------------- load (unscaled) --------------------------------------------------------------------
+  for (int r = tid; r < R; r += NT)
+  {
+    w.act[r] = g_act[r];
+    w.naux[r] = P->slot_naux[r];
+    w.aoff[r] = P->slot_aoff[r];
+    w.slot_t[r] = P->slot_t[r];
+    w.flg_r[r] = 0;
+    w.Er[r] = 1.0;
+    w.zr[r] = 0.0;
+    w.yr[r] = 0.0;
+    w.dyr[r] = 0.0;
+    w.lor[r] = P->slot_eq[r] ? g_rhs[r] : -TMX_OSQP_INFTY;
+    w.hir[r] = g_rhs[r];
+    for (int j = 0; j < D; ++j)
+      w.coef[r * D + j] = g_act[r] ? g_coef[r * D + j] : 0.0;
+    const double oc = P->slot_iscnt[r] ? g_merit[P->slot_owner[r]] : P->slot_objc[r];
+    for (int k = 0; k < P->slot_naux[r]; ++k)
+    {
+      const int a = P->slot_aoff[r] + k;
+      w.sa[a] = aux_sign(P->slot_naux[r], k);
+      w.qa[a] = oc;
+      w.bba[a] = 1.0;
+      w.Da[a] = 1.0;
+      w.Eba[a] = 1.0;
+      w.xa[a] = 0.0;
+      w.zba[a] = 0.0;
+      w.yba[a] = 0.0;
+      w.dxa[a] = 0.0;
+      w.dyba[a] = 0.0;
+      w.flg_ba[a] = 0;
+    }
+  }
+  for (int v = tid; v < NX; v += NT)
+  {
+    const int j = v % D;
+    // setTrustBoxConstraints (optimizers.cpp:151-170) then OSQPModel bound rows (osqp_interface.cpp:245-250)
+    const double xi = fmin(fmax(g_x[v], P->jl[j]), P->ju[j]);
+    const double lb = fmax(xi - trust, P->jl[j]), ub = fmin(xi + trust, P->ju[j]);
+    w.lbp[v] = fmax(lb, -TMX_OSQP_INFTY);
+    w.ubp[v] = fmin(ub, TMX_OSQP_INFTY);
+    w.qp[v] = P->pq[v];
+    w.pd[v] = P->pd[v];
+    w.po[v] = (v < NX - D) ? P->po[v] : 0.0;
+    w.bbp[v] = 1.0;
+    w.Dp[v] = 1.0;
+    w.Ebp[v] = 1.0;
+    w.xp[v] = 0.0;
+    w.zbp[v] = 0.0;
+    w.ybp[v] = 0.0;
+    w.dxp[v] = 0.0;
+    w.dybp[v] = 0.0;
+    w.flg_bp[v] = 0;
+  }
+  if (tid == 0)
+  {
+    int nr = 0, na = 0;
+    for (int r = 0; r < R; ++r)
+    {
+      w.row_ref[r] = nr;
+      w.aux_ref[r] = NX + na;
+      if (g_act[r])
+      {
+        nr += 1;
+        na += P->slot_naux[r];
+      }
+    }
+  }
+  w.sigma = st.sigma;
+  w.alpha = st.alpha;
+  w.c = 1.0;
+  w.cinv = 1.0;
+  TMX_SYNC();
+  const int n = dims[0], m = dims[1], mg = m - n;
+
+  // ---------------- Ruiz equilibration (scale_data) ------------------------------------------------------
+  // temporaries: D_temp_p -> tp, D_temp_a -> ta, E_temp_r -> hr, E_temp_bp -> dybp, E_temp_ba -> dyba
+  for (int it = 0; it < st.scaling; ++it)
+  {
+    for (int v = tid; v < NX; v += NT)
+    {
+      const int t = v / D, j = v % D;
+      double cn = fabs(w.pd[v]);
+      if (t > 0)
+        cn = fmax(cn, fabs(w.po[v - D]));
+      if (t < T - 1)
+        cn = fmax(cn, fabs(w.po[v]));
+      for (int q = P->wp_start[t]; q < P->wp_start[t + 1]; ++q)
+      {
+        const int r = P->wp_list[q];
+        if (w.act[r])
+          cn = fmax(cn, fabs(w.coef[r * D + j]));
+      }
+      cn = fmax(cn, fabs(w.bbp[v]));
+      w.tp[v] = 1.0 / sqrt(limit_scaling(cn));
+      w.dybp[v] = 1.0 / sqrt(limit_scaling(fabs(w.bbp[v])));
+    }
+    for (int r = tid; r < R; r += NT)
+    {
+      if (!w.act[r])
+        continue;
+      double rn = 0.0;
+      for (int j = 0; j < D; ++j)
+        rn = fmax(rn, fabs(w.coef[r * D + j]));
+      for (int k = 0; k < w.naux[r]; ++k)
+      {
+        const int a = w.aoff[r] + k;
+        rn = fmax(rn, fabs(w.sa[a]));
+        w.ta[a] = 1.0 / sqrt(limit_scaling(fmax(fabs(w.sa[a]), fabs(w.bba[a]))));
+        w.dyba[a] = 1.0 / sqrt(limit_scaling(fabs(w.bba[a])));
+      }
+      w.hr[r] = 1.0 / sqrt(limit_scaling(rn));
+    }
+    TMX_SYNC();
+    for (int v = tid; v < NX; v += NT)
+    {
+      w.pd[v] = (w.tp[v] * w.pd[v]) * w.tp[v];
+      if (v < NX - D)
+        w.po[v] = (w.tp[v] * w.po[v]) * w.tp[v + D];
+      w.bbp[v] = (w.dybp[v] * w.bbp[v]) * w.tp[v];
+      w.qp[v] *= w.tp[v];
+      w.Dp[v] *= w.tp[v];
+      w.Ebp[v] *= w.dybp[v];
+    }
+    for (int r = tid; r < R; r += NT)
+    {
+      if (!w.act[r])
+        continue;
+      const int t = w.slot_t[r];
+      for (int j = 0; j < D; ++j)
+        w.coef[r * D + j] = (w.hr[r] * w.coef[r * D + j]) * w.tp[t * D + j];
+      for (int k = 0; k < w.naux[r]; ++k)
+      {
+        const int a = w.aoff[r] + k;
+        w.sa[a] = (w.hr[r] * w.sa[a]) * w.ta[a];
+        w.bba[a] = (w.dyba[a] * w.bba[a]) * w.ta[a];
+        w.qa[a] *= w.ta[a];
+        w.Da[a] *= w.ta[a];
+        w.Eba[a] *= w.dyba[a];
+      }
+      w.Er[r] *= w.hr[r];
+    }
+    TMX_SYNC();
+    // cost normalisation: mean column inf-norm of P (aux columns are empty), ||q||_inf
+    double qmax = 0.0;
+    for (int v = tid; v < NX; v += NT)
+    {
+      const int t = v / D;
+      double cn = fabs(w.pd[v]);
+      if (t > 0)
+        cn = fmax(cn, fabs(w.po[v - D]));
+      if (t < T - 1)
+        cn = fmax(cn, fabs(w.po[v]));
+      w.tp[v] = cn;
+      qmax = fmax(qmax, fabs(w.qp[v]));
+    }
+    for (int r = tid; r < R; r += NT)
+      if (w.act[r])
+        for (int k = 0; k < w.naux[r]; ++k)
+          qmax = fmax(qmax, fabs(w.qa[w.aoff[r] + k]));
+    qmax = block_max1(qmax, w.red, tid, NT);
+    TMX_SYNC();
+    if (tid == 0)
+    {
+      double sum = 0.0;  // sequential, index order (as vec_norm_1 / n upstream)
+      for (int v = 0; v < NX; ++v)
+        sum += w.tp[v];
+      double c_temp = sum / (double)n;
+      c_temp = fmax(c_temp, limit_scaling(qmax));
+      c_temp = limit_scaling(c_temp);
+      w.red[64] = 1.0 / c_temp;
+    }
+    TMX_SYNC();
+    const double ct = w.red[64];
+    for (int v = tid; v < NX; v += NT)
+    {
+      w.pd[v] *= ct;
+      w.po[v] *= ct;
+      w.qp[v] *= ct;
+    }
+    for (int r = tid; r < R; r += NT)
+      if (w.act[r])
+        for (int k = 0; k < w.naux[r]; ++k)
+          w.qa[w.aoff[r] + k] *= ct;
+    w.c *= ct;
+    TMX_SYNC();
+  }
+  w.cinv = 1.0 / w.c;
+  for (int v = tid; v < NX; v += NT)
+  {
+    w.lbp[v] *= w.Ebp[v];
+    w.ubp[v] *= w.Ebp[v];
+    w.typ_bp[v] = constr_type(w.lbp[v], w.ubp[v]);
+  }
+  for (int r = tid; r < R; r += NT)
+  {
+    if (!w.act[r])
+      continue;
+    w.lor[r] *= w.Er[r];
+    w.hir[r] *= w.Er[r];
+    w.typ_r[r] = constr_type(w.lor[r], w.hir[r]);
+    for (int k = 0; k < w.naux[r]; ++k)
+      w.typ_ba[w.aoff[r] + k] = constr_type(0.0, TMX_OSQP_INFTY * w.Eba[w.aoff[r] + k]);
+  }
+  TMX_SYNC();
+
+  // ---------------- warm start decision (createOrUpdateSolver, osqp_interface.cpp:283-370) -----------------
+  const int* pd4 = Bt->prev_dims + 4 * b;
+  const unsigned long long* pws = Bt->prev_ws + 2 * b;
+  bool warm = Bt->prev_ok[b] && st.warm_starting;
+  const bool P_eq = warm && pd4[0] == dims[0] && pd4[2] == dims[2] && pws[0] == hs[2];
+  const bool A_eq = P_eq && pd4[0] == dims[0] && pd4[1] == dims[1] && pd4[3] == dims[3] && pws[1] == hs[3];
+  warm = warm && P_eq && A_eq;
+  w.rho = warm ? Bt->prev_rho[b] : st.rho;
+  w.rho = fmin(fmax(w.rho, TMX_RHO_MIN), TMX_RHO_MAX);
+  if (warm)
+  {
+    const double* xq = Bt->xq + (size_t)b * P->n_max;
+    const double* yq = Bt->yq + (size_t)b * P->m_max;
+    for (int v = tid; v < NX; v += NT)
+    {
+      w.xp[v] = (1.0 / w.Dp[v]) * xq[v];
+      w.ybp[v] = ((1.0 / w.Ebp[v]) * yq[mg + v]) * w.c;
+    }
+    for (int r = tid; r < R; r += NT)
+      if (w.act[r])
+      {
+        w.yr[r] = ((1.0 / w.Er[r]) * yq[w.row_ref[r]]) * w.c;
+        for (int k = 0; k < w.naux[r]; ++k)
+        {
+          const int a = w.aoff[r] + k;
+          w.xa[a] = (1.0 / w.Da[a]) * xq[w.aux_ref[r] + k];
+          w.yba[a] = ((1.0 / w.Eba[a]) * yq[mg + w.aux_ref[r] + k]) * w.c;
+        }
+      }
+    TMX_SYNC();
+    for (int v = tid; v < NX; v += NT)
+      w.zbp[v] = w.bbp[v] * w.xp[v];
+    for (int r = tid; r < R; r += NT)
+      if (w.act[r])
+      {
+        const int t = w.slot_t[r];
+        double ax = 0.0;
+        for (int j = 0; j < D; ++j)
+          ax += w.coef[r * D + j] * w.xp[t * D + j];
+        for (int k = 0; k < w.naux[r]; ++k)
+        {
+          const int a = w.aoff[r] + k;
+          ax += w.sa[a] * w.xa[a];
+          w.zba[a] = w.bba[a] * w.xa[a];
+        }
+        w.zr[r] = ax;
+      }
+    TMX_SYNC();
+  }
+
+  // ---------------- factor + ADMM loop (osqp_solve) --------------------------------------------------------
+  kkt_factor(w, P, 0, w.sigma, st.delta, tid, NT);
+  QpInfo info;
+  info.status = 11;  // OSQP_UNSOLVED
+  info.iter = 0;
+  info.rho_updates = 0;
+  info.polish_status = 0;
+  info.prim_res = info.dual_res = 0.0;
+  int iter = 0;
+  bool can_check = false, terminated = false;
+  for (iter = 1; iter <= st.max_iter; ++iter)
+  {
+    can_check = st.check_termination && (iter % st.check_termination == 0);
+    const bool do_rho = st.adaptive_rho && st.adaptive_rho_interval && (iter % st.adaptive_rho_interval == 0);
+    admm_rhs(w, P, tid, NT);
+    kkt_solve(w, P, 0, w.sigma, st.delta, tid, NT);
+#if defined(TMX_HOST_EMU) && defined(TMX_DEBUG_KKT)
+    if (b == 0 && (iter <= 3 || iter % 25 == 0))
+      debug_kkt_residual(w, P, iter);
+#endif
+    admm_update(w, can_check || do_rho, tid, NT);
+    if (can_check || do_rho)
+    {
+      info.iter = iter;
+      compute_residuals(w, P, w.xp, w.xa, w.yr, w.ybp, w.yba, 0, info, info.prim_res, info.dual_res, true, tid, NT);
+    }
+#if defined(TMX_HOST_EMU) && defined(TMX_DEBUG_KKT)
+    if (b == 0 && (can_check || do_rho))
+      std::printf("[dbg] iter %d prim %.3e dual %.3e\n", iter, info.prim_res, info.dual_res);
+#endif
+    if (can_check)
+    {
+      if (check_termination(w, P, info, false, tid, NT))
+      {
+        terminated = true;
+        break;
+      }
+    }
+    if (do_rho)
+    {
+      const double rho_new = rho_estimate(w, info);
+      if ((rho_new > w.rho * st.adaptive_rho_tolerance) || (rho_new < w.rho / st.adaptive_rho_tolerance))
+      {
+        w.rho = fmin(fmax(rho_new, TMX_RHO_MIN), TMX_RHO_MAX);
+        info.rho_updates += 1;
+        kkt_factor(w, P, 0, w.sigma, st.delta, tid, NT);
+      }
+    }
+  }
+  const int exit_iter = terminated ? iter : iter - 1;
+  if (!can_check)
+  {
+    info.iter = exit_iter;
+    compute_residuals(w, P, w.xp, w.xa, w.yr, w.ybp, w.yba, 0, info, info.prim_res, info.dual_res, true, tid, NT);
+    check_termination(w, P, info, false, tid, NT);
+  }
+  if (info.status == 11)
+  {
+    if (!check_termination(w, P, info, true, tid, NT))
+      info.status = 7;  // OSQP_MAX_ITER_REACHED
+  }
+
+  // ---------------- polish (polish.c) ---------------------------------------------------------------------
+  if (st.polishing && info.status == 1)
+  {
+    const double delta = st.delta;
+    for (int v = tid; v < NX; v += NT)
+    {
+      int f = 0;
+      if (w.zbp[v] - w.lbp[v] < -w.ybp[v])
+        f = -1;
+      else if (w.ubp[v] - w.zbp[v] < w.ybp[v])
+        f = 1;
+      w.flg_bp[v] = f;
+    }
+    for (int r = tid; r < R; r += NT)
+    {
+      if (!w.act[r])
+        continue;
+      int f = 0;
+      if (w.zr[r] - w.lor[r] < -w.yr[r])
+        f = -1;
+      else if (w.hir[r] - w.zr[r] < w.yr[r])
+        f = 1;
+      w.flg_r[r] = f;
+      for (int k = 0; k < w.naux[r]; ++k)
+      {
+        const int a = w.aoff[r] + k;
+        int fa = 0;
+        if (w.zba[a] - 0.0 < -w.yba[a])
+          fa = -1;
+        else if (TMX_OSQP_INFTY * w.Eba[a] - w.zba[a] < w.yba[a])
+          fa = 1;
+        w.flg_ba[a] = fa;
+      }
+    }
+    TMX_SYNC();
+    kkt_factor(w, P, 1, delta, delta, tid, NT);
+    // polished iterate lives in (dxp, dxa | dyr, dybp, dyba)
+    for (int pass = 0; pass <= st.polish_refine_iter; ++pass)
+    {
+      // residual-form rhs: pass 0: r1 = -q, r2 = b ; pass > 0: r1 = -q - P x - Aact' y, r2 = b - Aact x
+      for (int r = tid; r < R; r += NT)
+      {
+        double g = 0.0;
+        if (w.act[r] && w.flg_r[r] != 0)
+        {
+          double r2 = (w.flg_r[r] < 0) ? w.lor[r] : w.hir[r];
+          if (pass > 0)
+          {
+            const int t = w.slot_t[r];
+            double ax = 0.0;
+            for (int j = 0; j < D; ++j)
+              ax += w.coef[r * D + j] * w.dxp[t * D + j];
+            for (int k = 0; k < w.naux[r]; ++k)
+              ax += w.sa[w.aoff[r] + k] * w.dxa[w.aoff[r] + k];
+            r2 -= ax;
+          }
+          g = r2 / delta;
+        }
+        w.hr[r] = g;
+      }
+      TMX_SYNC();
+      for (int v = tid; v < NX; v += NT)
+      {
+        double r1 = -w.qp[v];
+        double gb = 0.0;
+        if (w.flg_bp[v] != 0)
+        {
+          double r2 = (w.flg_bp[v] < 0) ? w.lbp[v] : w.ubp[v];
+          if (pass > 0)
+            r2 -= w.bbp[v] * w.dxp[v];
+          gb = r2 / delta;
+        }
+        if (pass > 0)
+          r1 -= p_times(w, w.dxp, v) + at_rows(w, P, w.dyr, v) + w.bbp[v] * w.dybp[v];
+        w.tp[v] = r1 + at_rows(w, P, w.hr, v) + w.bbp[v] * gb;
+      }
+      for (int r = tid; r < R; r += NT)
+        if (w.act[r])
+          for (int k = 0; k < w.naux[r]; ++k)
+          {
+            const int a = w.aoff[r] + k;
+            double r1 = -w.qa[a];
+            double gb = 0.0;
+            if (w.flg_ba[a] != 0)
+            {
+              double r2 = (w.flg_ba[a] < 0) ? 0.0 : TMX_OSQP_INFTY * w.Eba[a];
+              if (pass > 0)
+                r2 -= w.bba[a] * w.dxa[a];
+              gb = r2 / delta;
+            }
+            if (pass > 0)
+              r1 -= w.sa[a] * w.dyr[r] + w.bba[a] * w.dyba[a];
+            w.ta[a] = r1 + w.sa[a] * w.hr[r] + w.bba[a] * gb;
+          }
+      TMX_SYNC();
+      kkt_solve(w, P, 1, delta, delta, tid, NT);
+      // y-part of the solution: nu = (A dx - r2) / delta on active rows (r2 recomputed from the pre-update iterate)
+      for (int r = tid; r < R; r += NT)
+      {
+        if (!w.act[r])
+          continue;
+        double dy = 0.0;
+        if (w.flg_r[r] != 0)
+        {
+          double r2 = (w.flg_r[r] < 0) ? w.lor[r] : w.hir[r];
+          if (pass > 0)
+          {
+            const int t = w.slot_t[r];
+            double ax = 0.0;
+            for (int j = 0; j < D; ++j)
+              ax += w.coef[r * D + j] * w.dxp[t * D + j];
+            for (int k = 0; k < w.naux[r]; ++k)
+              ax += w.sa[w.aoff[r] + k] * w.dxa[w.aoff[r] + k];
+            r2 -= ax;
+          }
+          dy = (w.hr[r] - r2) / delta;
+        }
+        w.zr[r] = dy;  // z_r is dead after the active-set guess: reuse it to carry this pass's dy_r
+      }
+      TMX_SYNC();
+      for (int v = tid; v < NX; v += NT)
+      {
+        double dyb = 0.0;
+        if (w.flg_bp[v] != 0)
+        {
+          double r2 = (w.flg_bp[v] < 0) ? w.lbp[v] : w.ubp[v];
+          if (pass > 0)
+            r2 -= w.bbp[v] * w.dxp[v];
+          dyb = (w.bbp[v] * w.tp[v] - r2) / delta;
+        }
+        if (pass == 0)
+        {
+          w.dxp[v] = w.tp[v];
+          w.dybp[v] = dyb;
+        }
+        else
+        {
+          w.dxp[v] += w.tp[v];
+          w.dybp[v] += dyb;
+        }
+      }
+      for (int r = tid; r < R; r += NT)
+      {
+        if (!w.act[r])
+          continue;
+        for (int k = 0; k < w.naux[r]; ++k)
+        {
+          const int a = w.aoff[r] + k;
+          double dyb = 0.0;
+          if (w.flg_ba[a] != 0)
+          {
+            double r2 = (w.flg_ba[a] < 0) ? 0.0 : TMX_OSQP_INFTY * w.Eba[a];
+            if (pass > 0)
+              r2 -= w.bba[a] * w.dxa[a];
+            dyb = (w.bba[a] * w.ta[a] - r2) / delta;
+          }
+          if (pass == 0)
+          {
+            w.dxa[a] = w.ta[a];
+            w.dyba[a] = dyb;
+          }
+          else
+          {
+            w.dxa[a] += w.ta[a];
+            w.dyba[a] += dyb;
+          }
+        }
+        if (pass == 0)
+          w.dyr[r] = w.zr[r];
+        else
+          w.dyr[r] += w.zr[r];
+      }
+      TMX_SYNC();
+    }
+    // residuals at the polished point (z = clip(A x))
+    QpInfo dummy = info;
+    double pprim = 0.0, pdual = 0.0;
+    compute_residuals(w, P, w.dxp, w.dxa, w.dyr, w.dybp, w.dyba, 1, dummy, pprim, pdual, false, tid, NT);
+    const bool ok = (pprim < info.prim_res && pdual < info.dual_res) || (pprim < info.prim_res && info.dual_res < 1e-10) ||
+                    (pdual < info.dual_res && info.prim_res < 1e-10);
+    if (ok)
+    {
+      info.polish_status = 1;
+      info.prim_res = pprim;
+      info.dual_res = pdual;
+      for (int v = tid; v < NX; v += NT)
+      {
+        w.xp[v] = w.dxp[v];
+        w.ybp[v] = w.dybp[v];
+      }
+      for (int r = tid; r < R; r += NT)
+        if (w.act[r])
+        {
+          w.yr[r] = w.dyr[r];
+          for (int k = 0; k < w.naux[r]; ++k)
+          {
+            const int a = w.aoff[r] + k;
+            w.xa[a] = w.dxa[a];
+            w.yba[a] = w.dyba[a];
+          }
+        }
+    }
+    else
+      info.polish_status = -1;
+    TMX_SYNC();
+  }
+
+  // ---------------- store solution (unscaled, reference order) + record -----------------------------------
+  const bool has_sol = !(info.status == 3 || info.status == 4 || info.status == 5 || info.status == 6 || info.status == 9);
+  double* xq = Bt->xq + (size_t)b * P->n_max;
+  double* yq = Bt->yq + (size_t)b * P->m_max;
+  const double nanv = NAN;
+  unsigned long long hact = 0ULL;
+  for (int v = tid; v < NX; v += NT)
+  {
+    xq[v] = has_sol ? w.Dp[v] * w.xp[v] : nanv;
+    yq[mg + v] = has_sol ? (w.cinv * w.Ebp[v]) * w.ybp[v] : nanv;
+    hact += tmx_hash_term((long long)w.flg_bp[v], (uint64_t)(mg + v), 5);
+  }
+  for (int r = tid; r < R; r += NT)
+    if (w.act[r])
+    {
+      yq[w.row_ref[r]] = has_sol ? (w.cinv * w.Er[r]) * w.yr[r] : nanv;
+      hact += tmx_hash_term((long long)w.flg_r[r], (uint64_t)w.row_ref[r], 5);
+      for (int k = 0; k < w.naux[r]; ++k)
+      {
+        const int a = w.aoff[r] + k;
+        xq[w.aux_ref[r] + k] = has_sol ? w.Da[a] * w.xa[a] : nanv;
+        yq[mg + w.aux_ref[r] + k] = has_sol ? (w.cinv * w.Eba[a]) * w.yba[a] : nanv;
+        hact += tmx_hash_term((long long)w.flg_ba[a], (uint64_t)(mg + w.aux_ref[r] + k), 5);
+      }
+    }
+  unsigned long long* hacc = reinterpret_cast<unsigned long long*>(w.red + 70);
+  if (tid == 0)
+    *hacc = 0ULL;
+  TMX_SYNC();
+  TMX_ATOMIC_ADD_U64(hacc, hact);
+  TMX_SYNC();
+  if (tid == 0)
+  {
+    info.iter = (info.iter == 0) ? exit_iter : info.iter;
+    tmx_qp_record rec;
+    rec.n = n;
+    rec.m = m;
+    rec.nnzP = dims[2];
+    rec.nnzA = dims[3];
+    rec.warm_started = warm ? 1 : 0;
+    rec.osqp_status = info.status;
+    rec.osqp_iter = info.iter;
+    rec.rho_updates = info.rho_updates;
+    rec.polish_status = info.polish_status;
+    rec.pad_ = 0;
+    rec.hashP = hs[0];
+    rec.hashA = hs[1];
+    rec.hash_active = *hacc;
+    rec.rho_final = w.rho;
+    Bt->rec_last[b] = rec;
+    const int k = Bt->rec_count[b];
+    if (k < Bt->max_rec)
+      Bt->rec_log[(size_t)b * Bt->max_rec + k] = rec;
+    Bt->rec_count[b] = k + 1;
+    Bt->admm_iters[b] += info.iter;
+    Bt->cvx[b] = (info.status == 1 || info.status == 2) ? TMX_CVX_SOLVED : (has_sol ? TMX_CVX_FAILED : TMX_CVX_INFEASIBLE);
+    Bt->prev_ok[b] = (info.status == 1 || info.status == 2) ? 1 : 0;
+    Bt->prev_rho[b] = w.rho;
+    for (int q = 0; q < 4; ++q)
+      Bt->prev_dims[4 * b + q] = dims[q];
+    Bt->prev_ws[2 * b + 0] = hs[2];
+    Bt->prev_ws[2 * b + 1] = hs[3];
+  }
+  TMX_SYNC();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// BasicTrustRegionSQP decision step after a QP solve + exact re-evaluation at new_x
+// (BasicTrustRegionSQPResults::update + the trust-region / penalty logic, optimizers.cpp:380-426, 810-968)
+// ---------------------------------------------------------------------------------------------------------
+TMX_DEVFN void sqp_update_block(const DevProblem* P, const DevBatch* Bt, int b, double* smem, int tid, int NT)
+{
+  const int D = P->D, NX = P->NX, R = P->R;
+  const tmx_sqp_params& sp = P->sqp;
+  double* model_cost = smem;                   // n_costs
+  double* model_viol = model_cost + P->n_costs;  // n_cnts
+  const double* xq = Bt->xq + (size_t)b * P->n_max;
+  const int* act = Bt->active + (size_t)b * R;
+  const double* coef = Bt->coef + (size_t)b * R * D;
+  const double* rhs = Bt->rhs + (size_t)b * R;
+  double* cost_vals = Bt->cost_vals + (size_t)b * P->n_costs;
+  double* cnt_viols = Bt->cnt_viols + (size_t)b * P->n_cnts;
+  const double* new_cost = Bt->new_cost_vals + (size_t)b * P->n_costs;
+  const double* new_viol = Bt->new_cnt_viols + (size_t)b * P->n_cnts;
+  double* merit = Bt->merit + (size_t)b * P->n_cnts;
+  if (tid != 0)
+    return;  // decisions are serial per problem (O(terms)); the heavy parts ran in the evaluate / QP kernels
+  int phase = Bt->phase[b];
+  if (phase == PHASE_DONE)
+    return;
+  enum
+  {
+    GO_WHILE,
+    GO_AFTER_WHILE,
+    GO_PENALTY,
+    GO_CLEANUP
+  } next;
+  int retval = Bt->retval[b];
+  double box = Bt->trust[b];
+  Bt->n_qp[b] += 1;
+  if (Bt->cvx[b] != TMX_CVX_SOLVED)
+  {
+    if (Bt->qp_fail[b] < sp.max_qp_solver_failures - 1)
+    {
+      box *= sp.trust_shrink_ratio;
+      Bt->qp_fail[b] += 1;
+      next = GO_WHILE;
+    }
+    else if (Bt->qp_fail[b] == sp.max_qp_solver_failures - 1)
+    {
+      box = sp.min_trust_box_size;
+      Bt->qp_fail[b] += 1;
+      next = GO_WHILE;
+    }
+    else
+    {
+      retval = TMX_OPT_FAILED;
+      next = GO_CLEANUP;
+    }
+  }
+  else
+  {
+    // model values at the QP solution: ConvexObjective::value / ConvexConstraints::violation
+    for (int k = 0; k < P->n_costs; ++k)
+      model_cost[k] = 0.0;
+    for (int k = 0; k < P->n_cnts; ++k)
+      model_viol[k] = 0.0;
+    {
+      int na = 0;
+      for (int r = 0; r < R; ++r)
+      {
+        if (P->slot_kind[r] == SLOT_FIXED || !act[r])
+          continue;
+        const int t = P->slot_t[r];
+        if (P->slot_iscnt[r])
+        {
+          double aff = 0.0;
+          for (int j = 0; j < D; ++j)
+            aff += coef[r * D + j] * xq[t * D + j];
+          aff -= rhs[r];
+          model_viol[P->slot_owner[r]] += P->slot_eq[r] ? fabs(aff) : ((aff > 0) ? aff : 0.0);
+        }
+        else
+        {
+          // cost rows: objective coefficient times the aux values of the QP solution
+          double s = 0.0;
+          for (int k = 0; k < P->slot_naux[r]; ++k)
+            s += P->slot_objc[r] * xq[NX + na + k];
+          model_cost[P->slot_owner[r]] += s;
+        }
+        na += P->slot_naux[r];
+      }
+      for (int v = 0; v < P->n_vel; ++v)
+      {
+        double s = 0.0;
+        for (int j = 0; j < D; ++j)
+          for (int i = P->vel_first[v]; i <= P->vel_last[v] - 1; ++i)
+          {
+            const double d = (xq[(i + 1) * D + j] - xq[i * D + j]) - P->vel_targets[v * TMX_MAX_DOF + j];
+            s += (d * d) * P->vel_coeffs[v * TMX_MAX_DOF + j];
+          }
+        model_cost[P->vel_cost[v]] += s;
+      }
+    }
+    double old_merit = 0.0, model_merit = 0.0, new_merit = 0.0;
+    for (int k = 0; k < P->n_costs; ++k)
+    {
+      old_merit += cost_vals[k];
+      model_merit += model_cost[k];
+      new_merit += new_cost[k];
+    }
+    double d0 = 0.0, d1 = 0.0, d2 = 0.0;
+    for (int k = 0; k < P->n_cnts; ++k)
+    {
+      d0 += cnt_viols[k] * merit[k];
+      d1 += model_viol[k] * merit[k];
+      d2 += new_viol[k] * merit[k];
+    }
+    old_merit += d0;
+    model_merit += d1;
+    new_merit += d2;
+    const double approx = old_merit - model_merit;
+    const double exact = old_merit - new_merit;
+    const double ratio = exact / approx;
+    Bt->n_fe[b] += 1;
+    if (approx < sp.min_approx_improve)
+    {
+      retval = TMX_OPT_CONVERGED;
+      next = GO_PENALTY;
+    }
+    else if (approx / old_merit < sp.min_approx_improve_frac)
+    {
+      retval = TMX_OPT_CONVERGED;
+      next = GO_PENALTY;
+    }
+    else if (exact < 0 || ratio < sp.improve_ratio_threshold)
+    {
+      box *= sp.trust_shrink_ratio;
+      next = GO_WHILE;
+    }
+    else
+    {
+      double* x = Bt->x + (size_t)b * NX;
+      const double* xn = Bt->xnew + (size_t)b * NX;
+      for (int v = 0; v < NX; ++v)
+        x[v] = xn[v];
+      for (int k = 0; k < P->n_costs; ++k)
+        cost_vals[k] = new_cost[k];
+      for (int k = 0; k < P->n_cnts; ++k)
+        cnt_viols[k] = new_viol[k];
+      box *= sp.trust_expand_ratio;
+      next = GO_AFTER_WHILE;
+    }
+  }
+  if (next == GO_WHILE)
+  {
+    if (box >= sp.min_trust_box_size)
+    {
+      Bt->trust[b] = box;
+      Bt->phase[b] = PHASE_SOLVE;
+      Bt->retval[b] = retval;
+      return;
+    }
+    next = GO_AFTER_WHILE;
+  }
+  double vmax = -1e300;
+  for (int k = 0; k < P->n_cnts; ++k)
+    vmax = fmax(vmax, cnt_viols[k]);
+  const bool viol_ok = (P->n_cnts == 0) || (vmax < sp.cnt_tolerance);
+  if (next == GO_AFTER_WHILE)
+  {
+    if (box < sp.min_trust_box_size)
+    {
+      retval = TMX_OPT_CONVERGED;
+      next = GO_PENALTY;
+    }
+    else if (Bt->iter[b] >= sp.max_iter)
+    {
+      retval = viol_ok ? TMX_OPT_CONVERGED : TMX_OPT_SCO_ITERATION_LIMIT;
+      next = GO_CLEANUP;
+    }
+    else
+    {
+      Bt->iter[b] += 1;
+      Bt->qp_fail[b] = 0;
+      Bt->trust[b] = box;
+      Bt->phase[b] = PHASE_CONVEXIFY;
+      Bt->retval[b] = retval;
+      return;
+    }
+  }
+  if (next == GO_PENALTY)
+  {
+    if (viol_ok)
+      next = GO_CLEANUP;
+    else
+    {
+      if (sp.inflate_constraints_individually)
+      {
+        for (int k = 0; k < P->n_cnts; ++k)
+          if (cnt_viols[k] > sp.cnt_tolerance)
+            merit[k] *= sp.merit_coeff_increase_ratio;
+      }
+      else
+        for (int k = 0; k < P->n_cnts; ++k)
+          merit[k] *= sp.merit_coeff_increase_ratio;
+      box = fmax(box, sp.min_trust_box_size / sp.trust_shrink_ratio * 1.5);
+      Bt->merit_inc[b] += 1;
+      if ((double)Bt->merit_inc[b] < sp.max_merit_coeff_increases)
+      {
+        Bt->iter[b] = 1;
+        Bt->qp_fail[b] = 0;
+        Bt->trust[b] = box;
+        Bt->phase[b] = PHASE_CONVEXIFY;
+        Bt->retval[b] = retval;
+        return;
+      }
+      retval = TMX_OPT_PENALTY_ITERATION_LIMIT;
+      next = GO_CLEANUP;
+    }
+  }
+  // cleanup
+  Bt->trust[b] = box;
+  Bt->status[b] = retval;
+  Bt->retval[b] = retval;
+  double tot = 0.0;
+  for (int k = 0; k < P->n_costs; ++k)
+    tot += cost_vals[k];
+  Bt->total_cost[b] = tot;
+  Bt->phase[b] = PHASE_DONE;
+}

@@ -1,0 +1,440 @@
+// tmx_terms.h — device kinematics, exact term evaluation (K6) and convexification (K1 FD-Jacobian of the
+// Cartesian-pose error, K3 collision linearisation).  One workgroup per problem; threads stride over cart-pose
+// instances / contact slots.  The waypoint's DOF vector is read coalesced from HBM (D contiguous doubles).
+//
+// Reference behaviour restated (paths relative to the reference checkout):
+//   CartPoseErrCalculator / CartPoseJacCalculator   trajopt/src/kinematic_terms.cpp:250-263,348-366 (FD, eps 1e-5)
+//   ConstraintFromErrFunc / CostFromErrFunc::convex trajopt_sco/src/modeling_utils.cpp:168-211,247-269
+//   CollisionEvaluator::GetGradient / CollisionsToDistanceExpressions  trajopt/src/collision_terms.cpp:203-250,343-383
+//   CollisionCost::convex / value                   trajopt/src/collision_terms.cpp:1283-1327
+//   JointVelEqCost / JointPosEqConstraint           trajopt/src/trajectory_costs.cpp:139-183,257-301
+#pragma once
+#include "tmx_types.h"
+
+#define TMX_EPS_FD 1e-5       // sco DEFAULT_EPSILON, trajopt_sco/src/modeling_utils.cpp:13
+#define TMX_CLEANUP_TOL 1e-7  // sco::cleanupAff, trajopt_sco/src/expr_ops.cpp:91
+
+struct Tf3
+{
+  double R[9];
+  double t[3];
+};
+
+TMX_DEVFN void tf_from12(const double* a, Tf3& T)
+{
+  for (int r = 0; r < 3; ++r)
+  {
+    for (int c = 0; c < 3; ++c)
+      T.R[3 * r + c] = a[4 * r + c];
+    T.t[r] = a[4 * r + 3];
+  }
+}
+TMX_DEVFN void tf_mul(const Tf3& A, const Tf3& B, Tf3& C)
+{
+  for (int r = 0; r < 3; ++r)
+  {
+    for (int c = 0; c < 3; ++c)
+      C.R[3 * r + c] = A.R[3 * r + 0] * B.R[0 + c] + A.R[3 * r + 1] * B.R[3 + c] + A.R[3 * r + 2] * B.R[6 + c];
+    C.t[r] = A.R[3 * r + 0] * B.t[0] + A.R[3 * r + 1] * B.t[1] + A.R[3 * r + 2] * B.t[2] + A.t[r];
+  }
+}
+TMX_DEVFN void tf_inv(const Tf3& A, Tf3& C)
+{
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c)
+      C.R[3 * r + c] = A.R[3 * c + r];
+  for (int r = 0; r < 3; ++r)
+    C.t[r] = -(C.R[3 * r + 0] * A.t[0] + C.R[3 * r + 1] * A.t[1] + C.R[3 * r + 2] * A.t[2]);
+}
+TMX_DEVFN void tf_joint_motion(const double* ax, int type, double q, Tf3& T)
+{
+  for (int k = 0; k < 9; ++k)
+    T.R[k] = 0.0;
+  T.R[0] = T.R[4] = T.R[8] = 1.0;
+  T.t[0] = T.t[1] = T.t[2] = 0.0;
+  if (type == 0)
+  {
+    const double c = cos(q), s = sin(q), v = 1.0 - c;
+    const double x = ax[0], y = ax[1], z = ax[2];
+    T.R[0] = c + x * x * v;
+    T.R[1] = x * y * v - z * s;
+    T.R[2] = x * z * v + y * s;
+    T.R[3] = y * x * v + z * s;
+    T.R[4] = c + y * y * v;
+    T.R[5] = y * z * v - x * s;
+    T.R[6] = z * x * v - y * s;
+    T.R[7] = z * y * v + x * s;
+    T.R[8] = c + z * z * v;
+  }
+  else
+  {
+    T.t[0] = ax[0] * q;
+    T.t[1] = ax[1] * q;
+    T.t[2] = ax[2] * q;
+  }
+}
+
+// world transform of link `upto` (child of joint `upto`); optionally the joint frames before motion
+TMX_DEVFN void fk_link(const DevProblem* P, const double* q, int upto, Tf3& out, Tf3* jf)
+{
+  Tf3 T, O, M, U;
+  tf_from12(P->base, T);
+  for (int k = 0; k <= upto; ++k)
+  {
+    tf_from12(P->origin[k], O);
+    tf_mul(T, O, U);
+    if (jf)
+      jf[k] = U;
+    tf_joint_motion(P->axis[k], P->jtype[k], q[k], M);
+    tf_mul(U, M, T);
+  }
+  out = T;
+}
+TMX_DEVFN void fk_tool(const DevProblem* P, const double* q, Tf3& out)
+{
+  Tf3 L, Tl;
+  fk_link(P, q, P->D - 1, L, nullptr);
+  tf_from12(P->tool, Tl);
+  tf_mul(L, Tl, out);
+}
+
+// tesseract::common::calcRotationalErrorDecomposed [NOT IN REFERENCE] — same statement as oracle/trajprob.hpp
+TMX_DEVFN void rot_err_decomposed(const double* R, double axis[3], double& angle)
+{
+  double qw, qx, qy, qz;
+  const double tr = R[0] + R[4] + R[8];
+  if (tr > 0.0)
+  {
+    double t = sqrt(tr + 1.0);
+    qw = 0.5 * t;
+    t = 0.5 / t;
+    qx = (R[7] - R[5]) * t;
+    qy = (R[2] - R[6]) * t;
+    qz = (R[3] - R[1]) * t;
+  }
+  else
+  {
+    int i = 0;
+    if (R[4] > R[0])
+      i = 1;
+    if (R[8] > R[4 * i])
+      i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    double t = sqrt(R[4 * i] - R[4 * j] - R[4 * k] + 1.0);
+    double qv[3];
+    qv[i] = 0.5 * t;
+    t = 0.5 / t;
+    qw = (R[3 * k + j] - R[3 * j + k]) * t;
+    qv[j] = (R[3 * j + i] + R[3 * i + j]) * t;
+    qv[k] = (R[3 * k + i] + R[3 * i + k]) * t;
+    qx = qv[0];
+    qy = qv[1];
+    qz = qv[2];
+  }
+  double n = sqrt(qx * qx + qy * qy + qz * qz);
+  double ang, ax[3];
+  if (n != 0.0)
+  {
+    ang = 2.0 * atan2(n, fabs(qw));
+    if (qw < 0)
+      n = -n;
+    ax[0] = qx / n;
+    ax[1] = qy / n;
+    ax[2] = qz / n;
+  }
+  else
+  {
+    ang = 0.0;
+    ax[0] = 1.0;
+    ax[1] = 0.0;
+    ax[2] = 0.0;
+  }
+  const double s = ((qx * ax[0] + qy * ax[1] + qz * ax[2]) < 0) ? -1.0 : 1.0;
+  const double two_pi = 2.0 * M_PI;
+  double a = s * ang;
+  a = copysign(fmod(fabs(a), two_pi), a);
+  if (a < -M_PI)
+    a += two_pi;
+  else if (a > M_PI)
+    a -= two_pi;
+  axis[0] = s * ax[0];
+  axis[1] = s * ax[1];
+  axis[2] = s * ax[2];
+  angle = a;
+}
+// tesseract::common::calcTransformError(target, source)
+TMX_DEVFN void transform_error(const Tf3& tinv, const Tf3& src, double err[6], double ax[3], double& ang)
+{
+  Tf3 pe;
+  tf_mul(tinv, src, pe);
+  rot_err_decomposed(pe.R, ax, ang);
+  err[0] = pe.t[0];
+  err[1] = pe.t[1];
+  err[2] = pe.t[2];
+  err[3] = ax[0] * ang;
+  err[4] = ax[1] * ang;
+  err[5] = ax[2] * ang;
+}
+
+// sphere-vs-sphere signed distance for contact slot (link sphere s, obstacle o) at joint values q
+TMX_DEVFN double contact_distance(const DevProblem* P, const double* q, int s, int o, double n[3], double pw[3], Tf3* jf)
+{
+  Tf3 L;
+  const int link = P->ls_link[s];
+  fk_link(P, q, link, L, jf);
+  double c[3], d[3];
+  for (int r = 0; r < 3; ++r)
+    c[r] = L.R[3 * r + 0] * P->ls_center[3 * s + 0] + L.R[3 * r + 1] * P->ls_center[3 * s + 1] +
+           L.R[3 * r + 2] * P->ls_center[3 * s + 2] + L.t[r];
+  for (int r = 0; r < 3; ++r)
+    d[r] = P->ob_center[3 * o + r] - c[r];
+  const double len = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+  const double rs = P->ls_radius[s];
+  for (int r = 0; r < 3; ++r)
+  {
+    n[r] = (len > 0) ? d[r] / len : (r == 2 ? 1.0 : 0.0);
+    pw[r] = c[r] + rs * n[r];
+  }
+  return len - rs - P->ob_radius[o];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K6: exact costs / constraint violations at trajectory xv -> cost_out[n_costs], viol_out[n_cnts]
+// (BasicTrustRegionSQP::evaluateCosts / evaluateConstraintViols, trajopt_sco/src/optimizers.cpp:176-192)
+// `scratch` : LDS, >= R doubles
+// ---------------------------------------------------------------------------------------------------
+TMX_DEVFN void evaluate_terms(const DevProblem* P, const double* xv, double* cost_out, double* viol_out, double* scratch,
+                              int tid, int NT)
+{
+  const int D = P->D;
+  // per-slot scalar: collision hinge value / |cart-pose row| / joint-pos value ; fixed rows contribute nothing
+  for (int r = tid; r < P->R; r += NT)
+  {
+    const int kind = P->slot_kind[r];
+    const int t = P->slot_t[r];
+    double v = 0.0;
+    if (kind == SLOT_COLLISION)
+    {
+      double n[3], pw[3];
+      const double dist = contact_distance(P, xv + t * D, P->slot_sub[r], P->slot_sub2[r], n, pw, nullptr);
+      const double margin = P->slot_aux1[r];
+      if (!(dist > margin + P->slot_aux2[r]))
+      {
+        const double pv = margin - dist;
+        v = ((pv > 0) ? pv : 0.0) * P->slot_objc[r];
+      }
+    }
+    else if (kind == SLOT_JOINTPOS)
+    {
+      // quirk Q5: JointPosEqConstraint::value returns coeff * diff^2 (trajectory_costs.cpp:165-174)
+      const double d = xv[t * D + P->slot_sub[r]] - P->slot_aux1[r];
+      v = fabs((d * d) * P->slot_scale[r]);
+    }
+    scratch[r] = v;
+  }
+  // cart-pose instances: |coeff_i * err_i| (constraint violation) or abs cost
+  for (int c = tid; c < P->n_cp; c += NT)
+  {
+    Tf3 tgt, tinv, src;
+    tf_from12(P->cp_target + 12 * c, tgt);
+    tf_inv(tgt, tinv);
+    fk_tool(P, xv + P->cp_t[c] * D, src);
+    double err[6], ax[3], ang;
+    transform_error(tinv, src, err, ax, ang);
+    const int s0 = P->cp_slot0[c];
+    for (int i = 0; i < P->cp_nrows[c]; ++i)
+    {
+      // constraint: violation = |err*coeff| (modeling_utils.cpp:238-245, modeling.cpp:150-167);
+      // ABS cost: |err|*coeff (modeling_utils.cpp:143-167)
+      const double e = err[P->cp_idx[6 * c + i]], cc = P->cp_coeff[6 * c + i];
+      scratch[s0 + i] = P->cp_iscnt[c] ? fabs(e * cc) : fabs(e) * cc;
+    }
+  }
+  TMX_SYNC();
+  // zero the outputs, then accumulate per owner in slot order (sequential per owner => reference summation order)
+  for (int k = tid; k < P->n_costs; k += NT)
+    cost_out[k] = 0.0;
+  for (int k = tid; k < P->n_cnts; k += NT)
+    viol_out[k] = 0.0;
+  TMX_SYNC();
+  if (tid == 0)
+  {
+    for (int r = 0; r < P->R; ++r)
+    {
+      if (P->slot_kind[r] == SLOT_FIXED)
+        continue;
+      if (P->slot_iscnt[r])
+        viol_out[P->slot_owner[r]] += scratch[r];
+      else
+        cost_out[P->slot_owner[r]] += scratch[r];
+    }
+    // JointVelEqCost::value — (diff^2 * diag(coeffs)).sum(), column-major reduction order
+    for (int v = 0; v < P->n_vel; ++v)
+    {
+      double s = 0;
+      for (int j = 0; j < D; ++j)
+        for (int i = P->vel_first[v]; i <= P->vel_last[v] - 1; ++i)
+        {
+          const double d = (xv[(i + 1) * D + j] - xv[i * D + j]) - P->vel_targets[v * TMX_MAX_DOF + j];
+          s += (d * d) * P->vel_coeffs[v * TMX_MAX_DOF + j];
+        }
+      cost_out[P->vel_cost[v]] += s;
+    }
+  }
+  TMX_SYNC();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K1 + K3: convexify at xv -> rows (active, coef[R][D], rhs[R]) for the dynamic slots.
+// FIXED and JOINTPOS rows are constant (written once by init_static_rows).
+// ---------------------------------------------------------------------------------------------------
+TMX_DEVFN void init_static_rows(const DevProblem* P, const double* x0, int* active, double* coef, double* rhs, int tid, int NT)
+{
+  const int D = P->D;
+  for (int r = tid; r < P->R; r += NT)
+  {
+    const int kind = P->slot_kind[r];
+    if (kind == SLOT_FIXED || kind == SLOT_JOINTPOS)
+    {
+      for (int k = 0; k < D; ++k)
+        coef[r * D + k] = 0.0;
+      const int j = P->slot_sub[r];
+      if (kind == SLOT_FIXED)
+      {
+        // exprSub(AffExpr(var), init): x - init == 0
+        coef[r * D + j] = 1.0;
+        rhs[r] = -(0.0 - x0[P->slot_t[r] * D + j]);
+      }
+      else
+      {
+        // exprMult(pos, coeff) with pos = 1*x - target   (trajectory_costs.cpp:151-161)
+        const double c = P->slot_scale[r];
+        coef[r * D + j] = 1.0 * c;
+        rhs[r] = -((0.0 - P->slot_aux1[r]) * c);
+      }
+      active[r] = 1;
+    }
+  }
+}
+
+TMX_DEVFN void convexify_terms(const DevProblem* P, const double* xv, int* active, double* coef, double* rhs, int tid, int NT)
+{
+  const int D = P->D;
+  // ---- K1: cart-pose rows by forward finite differences over full FK
+  for (int c = tid; c < P->n_cp; c += NT)
+  {
+    const double* q = xv + P->cp_t[c] * D;
+    Tf3 tgt, tinv, src, sp, pe, pp;
+    tf_from12(P->cp_target + 12 * c, tgt);
+    tf_inv(tgt, tinv);
+    fk_tool(P, q, src);
+    double err[6], ax0[3], a0;
+    transform_error(tinv, src, err, ax0, a0);
+    tf_mul(tinv, src, pe);
+    const int s0 = P->cp_slot0[c];
+    const int nr = P->cp_nrows[c];
+    double qp[TMX_MAX_DOF];
+    for (int k = 0; k < D; ++k)
+      qp[k] = q[k];
+    double J[6][TMX_MAX_DOF];
+    for (int k = 0; k < D; ++k)
+    {
+      qp[k] = q[k] + TMX_EPS_FD;
+      fk_tool(P, qp, sp);
+      // calcJacobianTransformErrorDiff(target, source, source_perturbed)
+      tf_mul(tinv, sp, pp);
+      double ax1[3], a1;
+      rot_err_decomposed(pp.R, ax1, a1);
+      double a1c = a1;
+      if (a1 > M_PI_2 && a0 < -M_PI_2)
+        a1c = a1 - 2.0 * M_PI;
+      else if (a1 < -M_PI_2 && a0 > M_PI_2)
+        a1c = a1 + 2.0 * M_PI;
+      double diff[6];
+      for (int r = 0; r < 3; ++r)
+      {
+        diff[r] = pp.t[r] - pe.t[r];
+        diff[3 + r] = ax1[r] * a1c - ax0[r] * a0;
+      }
+      for (int i = 0; i < nr; ++i)
+        J[i][k] = diff[P->cp_idx[6 * c + i]] / TMX_EPS_FD;
+      qp[k] = q[k];
+    }
+    for (int i = 0; i < nr; ++i)
+    {
+      // affFromValGrad: constant = y - J.x ; coeffs = J with |c| <= 1e-7 dropped ; then exprScale(aff, coeff)
+      const double y = err[P->cp_idx[6 * c + i]];
+      double dot = 0.0;
+      for (int k = 0; k < D; ++k)
+        dot += J[i][k] * q[k];
+      const double cc = P->cp_coeff[6 * c + i];
+      const double constant = (y - dot) * cc;
+      const int r = s0 + i;
+      for (int k = 0; k < D; ++k)
+      {
+        const double jv = J[i][k];
+        coef[r * D + k] = (fabs(jv) > TMX_CLEANUP_TOL) ? jv * cc : 0.0;
+      }
+      rhs[r] = -constant;
+      active[r] = 1;
+    }
+  }
+  // ---- K3: collision rows
+  for (int r = tid; r < P->R; r += NT)
+  {
+    if (P->slot_kind[r] != SLOT_COLLISION)
+      continue;
+    const double* q = xv + P->slot_t[r] * D;
+    const int s = P->slot_sub[r], o = P->slot_sub2[r];
+    const int link = P->ls_link[s];
+    Tf3 jf[TMX_MAX_DOF];
+    double n[3], pw[3];
+    const double dist = contact_distance(P, q, s, o, n, pw, jf);
+    const double margin = P->slot_aux1[r];
+    if (dist > margin + P->slot_aux2[r])
+    {
+      active[r] = 0;
+      for (int k = 0; k < D; ++k)
+        coef[r * D + k] = 0.0;
+      rhs[r] = 0.0;
+      continue;
+    }
+    // gradient = -n' * J_trans(nearest point), object 0 = robot link (collision_terms.cpp:203-250)
+    double grad[TMX_MAX_DOF];
+    double gq = 0.0;
+    for (int k = 0; k < D; ++k)
+    {
+      double col[3] = { 0, 0, 0 };
+      if (k <= link)
+      {
+        const Tf3& F = jf[k];
+        double z[3];
+        for (int rr = 0; rr < 3; ++rr)
+          z[rr] = F.R[3 * rr + 0] * P->axis[k][0] + F.R[3 * rr + 1] * P->axis[k][1] + F.R[3 * rr + 2] * P->axis[k][2];
+        if (P->jtype[k] == 0)
+        {
+          const double dd[3] = { pw[0] - F.t[0], pw[1] - F.t[1], pw[2] - F.t[2] };
+          col[0] = z[1] * dd[2] - z[2] * dd[1];
+          col[1] = z[2] * dd[0] - z[0] * dd[2];
+          col[2] = z[0] * dd[1] - z[1] * dd[0];
+        }
+        else
+        {
+          col[0] = z[0];
+          col[1] = z[1];
+          col[2] = z[2];
+        }
+      }
+      grad[k] = -1.0 * (n[0] * col[0] + n[1] * col[1] + n[2] * col[2]);
+      gq += grad[k] * q[k];
+    }
+    // dist_expr = grad.x + (-(grad.q) + dist) ; viol = margin - dist_expr ; row: viol - hinge <= 0
+    const double c_dist = (0.0 + (-gq)) + dist;
+    const double viol_const = margin - c_dist;
+    for (int k = 0; k < D; ++k)
+      coef[r * D + k] = -grad[k];
+    rhs[r] = -viol_const;
+    active[r] = 1;
+  }
+  TMX_SYNC();
+}

@@ -1,0 +1,81 @@
+// tmx_types.h — device-resident problem description ("term table" + row-slot template) and batch state.
+//
+// HBM layout (all fp64 / int32, one contiguous array per field, problem-major so that a workgroup's reads of
+// its own problem are contiguous and coalesced):
+//   per batch entry b:  x[b][T][D]  (row-major trajectory, the reference's "j_t_d" order)
+//                       rows:  active[b][R], coef[b][R][D], rhs[b][R]      (the linearised QP rows, slot order)
+//                       QP solution in REFERENCE variable/row order: xq[b][n_max], yq[b][m_max]
+// Row slots: the reference's QP changes size every SQP iteration (contact count); the device keeps a static
+// per-problem-structure template of R row slots in REFERENCE ROW ORDER (persistent rows, then the rows of each
+// cost model, then the rows of each constraint-penalty model — SURVEY.md Appendix A) and masks inactive ones.
+#pragma once
+#include "../../include/tmx.h"
+#include "tmx_platform.h"
+
+enum
+{
+  SLOT_FIXED = 0,     // problem_description.cpp:485-508  x_tj - init_tj == 0       (no aux)
+  SLOT_CARTPOSE = 1,  // CartPose row (EQ constraint -> abs, or ABS cost)             (2 aux)
+  SLOT_JOINTPOS = 2,  // JointPosEqConstraint row -> abs                              (2 aux)
+  SLOT_COLLISION = 3  // CollisionCost contact -> hinge                               (1 aux)
+};
+
+enum
+{
+  PHASE_CONVEXIFY = 0,  // needs convexify + QP solve
+  PHASE_SOLVE = 1,      // same convexification, new trust box
+  PHASE_DONE = 2
+};
+
+struct DevProblem
+{
+  int D, T, NX, R, NA, n_costs, n_cnts, S, O, n_cp, n_vel;
+  int n_max, m_max;  // NX + NA, R + NX + NA
+  int nnzP;          // static
+  double jl[TMX_MAX_DOF], ju[TMX_MAX_DOF];
+  double base[12], tool[12];
+  double origin[TMX_MAX_DOF][12];
+  double axis[TMX_MAX_DOF][3];
+  int jtype[TMX_MAX_DOF];
+  tmx_sqp_params sqp;
+  tmx_osqp_settings osqp;
+  // slot template, length R
+  int *slot_kind, *slot_t, *slot_sub, *slot_sub2, *slot_owner, *slot_naux, *slot_aoff, *slot_iscnt, *slot_eq;
+  double *slot_objc;   // objective coefficient of the aux var(s) for cost rows (collision: coeff; abs cost: 1)
+  double *slot_scale;  // row scale: cart-pose / joint-pos coefficient
+  double *slot_aux1;   // collision: margin ; joint-pos: target
+  double *slot_aux2;   // collision: buffer
+  int *wp_start;       // T+1 : slots of waypoint t are wp_list[wp_start[t] .. wp_start[t+1])  (ascending slot id)
+  int *wp_list;        // R
+  // static quadratic objective over the primary vars: Hessian diagonal / (t,j)-(t+1,j) coupling, linear term
+  double *pd, *po, *pq;
+  // JointVelEqCost terms (exact value)
+  int *vel_first, *vel_last, *vel_cost;
+  double *vel_coeffs, *vel_targets;  // n_vel x TMX_MAX_DOF
+  // cart-pose instances (term, timestep)
+  int *cp_t, *cp_owner, *cp_iscnt, *cp_nrows, *cp_idx, *cp_slot0;
+  double *cp_coeff, *cp_target;  // n_cp x 6, n_cp x 12
+  // collision geometry
+  int *ls_link;
+  double *ls_center, *ls_radius, *ob_center, *ob_radius;
+};
+
+struct DevBatch
+{
+  int B, max_rec;
+  double *x0, *x, *xnew;
+  double *cost_vals, *cnt_viols, *new_cost_vals, *new_cnt_viols, *merit;
+  double *trust, *total_cost, *prev_rho;
+  int *phase, *iter, *merit_inc, *qp_fail, *status, *retval, *n_fe, *n_qp, *cvx, *prev_ok;
+  int *active;
+  double *coef, *rhs;
+  int *dims;                    // B x 4: n, m, nnzP, nnzA of the current convexification
+  unsigned long long *hashes;   // B x 4: hashP, hashA, wsP, wsA (ws* = what the reference's memcmp actually compares)
+  int *prev_dims;               // B x 4 of the previous Model::optimize()
+  unsigned long long *prev_ws;  // B x 2
+  double *xq, *yq;              // B x n_max, B x m_max (reference order, unscaled)
+  tmx_qp_record *rec_last, *rec_log;
+  int *rec_count;
+  long long *admm_iters;
+  int *n_active;  // single int: number of problems not DONE
+};

@@ -1,0 +1,227 @@
+"""ctypes binding of libtrajopt_mi355x.so + the host-side mirror of the reference optimizer surface.
+
+`BatchedTrustRegionSQP` mirrors sco::BasicTrustRegionSQP (trajopt_sco/include/trajopt_sco/optimizers.hpp:137-218:
+setParameters / initialize / optimize / results) for a BATCH of seeds of one trajopt problem; everything numerical
+happens in the HIP kernels behind the C-ABI (include/tmx.h).  There is NO CPU fallback: constructing a Context
+without a HIP device raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_DEFAULT_LIB = os.path.join(_HERE, "_build", "libtrajopt_mi355x.so")
+
+_SIGS = {
+    "tmx_create": ([C.c_int, C.POINTER(C.c_void_p)], C.c_int),
+    "tmx_destroy": ([C.c_void_p], None),
+    "tmx_last_error": ([C.c_void_p], C.c_char_p),
+    "tmx_default_sqp_params": ([C.POINTER(abi.SqpParams)], None),
+    "tmx_default_osqp_settings": ([C.POINTER(abi.OsqpSettings)], None),
+    "tmx_problem_upload": ([C.c_void_p, C.POINTER(abi.ProblemDesc), C.POINTER(abi.SqpParams), C.POINTER(abi.OsqpSettings)], C.c_int),
+    "tmx_batch_set_x0": ([C.c_void_p, C.c_void_p, C.c_int32], C.c_int),
+    "tmx_batch_set_x0_device": ([C.c_void_p, C.c_void_p, C.c_int32], C.c_int),
+    "tmx_sqp_run": ([C.c_void_p, C.c_int32, C.POINTER(C.c_int32)], C.c_int),
+    "tmx_sqp_results": ([C.c_void_p] + [C.c_void_p] * 5, C.c_int),
+    "tmx_sqp_counters": ([C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)], C.c_int),
+    "tmx_sqp_qp_records": ([C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p], C.c_int),
+    "tmx_term_counts": ([C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)], C.c_int),
+    "tmx_evaluate": ([C.c_void_p, C.c_void_p, C.c_void_p], C.c_int),
+    "tmx_convexify": ([C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p], C.c_int),
+    "tmx_export_csc": ([C.c_void_p, C.c_int32] + [C.POINTER(C.c_int32)] * 4 + [C.c_void_p] * 9, C.c_int),
+    "tmx_qp_dims": ([C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)], C.c_int),
+    "tmx_qp_solve": ([C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p], C.c_int),
+    "tmx_argmin": ([C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_double)], C.c_int),
+    "tmx_attach_nccl": ([C.c_void_p, C.c_void_p], C.c_int),
+    "tmx_kernel_stats": ([C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)], C.c_int),
+    "tmx_kernel_stats_reset": ([C.c_void_p], C.c_int),
+}
+ABI_SYMBOLS = tuple(_SIGS.keys())
+
+
+class TmxError(RuntimeError):
+    pass
+
+
+def load_library(path: str = None):
+    path = path or _DEFAULT_LIB
+    if not os.path.exists(path):
+        raise TmxError(f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(the HIP extension is required; there is no CPU fallback)")
+    lib = C.CDLL(path)
+    for name, (argt, rest) in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argt
+        fn.restype = rest
+    return lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class Context:
+    """one tmx_ctx (one GPU, one host thread)"""
+
+    def __init__(self, device: int = 0, lib_path: str = None):
+        self.lib = load_library(lib_path)
+        h = C.c_void_p()
+        rc = self.lib.tmx_create(device, C.byref(h))
+        if rc != abi.TMX_OK:
+            raise TmxError(f"tmx_create failed with status {rc}: no usable HIP device (the product path needs an MI355X)")
+        self.h = h
+        self.desc = None
+        self.B = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.tmx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != abi.TMX_OK:
+            raise TmxError(f"tmx status {rc}: {self.lib.tmx_last_error(self.h).decode()}")
+
+    # ---- S4 ----
+    def upload(self, desc: abi.ProblemDesc, sqp: abi.SqpParams = None, osqp: abi.OsqpSettings = None):
+        self.desc = desc
+        self._chk(self.lib.tmx_problem_upload(self.h, C.byref(desc), C.byref(sqp) if sqp is not None else None,
+                                              C.byref(osqp) if osqp is not None else None))
+        nc, nn, nr = C.c_int32(), C.c_int32(), C.c_int32()
+        self._chk(self.lib.tmx_term_counts(self.h, C.byref(nc), C.byref(nn), C.byref(nr)))
+        self.n_costs, self.n_cnts, self.R = nc.value, nn.value, nr.value
+        nm, mm = C.c_int32(), C.c_int32()
+        self._chk(self.lib.tmx_qp_dims(self.h, C.byref(nm), C.byref(mm)))
+        self.n_max, self.m_max = nm.value, mm.value
+        self.T, self.D = desc.n_steps, desc.n_dof
+
+    # ---- S3 ----
+    def set_x0(self, x0):
+        x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        self.B = x0.shape[0]
+        assert x0.size == self.B * self.T * self.D
+        self._chk(self.lib.tmx_batch_set_x0(self.h, _ptr(x0), self.B))
+
+    def set_x0_device(self, dev_ptr: int, batch: int):
+        self.B = batch
+        self._chk(self.lib.tmx_batch_set_x0_device(self.h, C.c_void_p(dev_ptr), batch))
+
+    def run(self, max_steps: int = 0) -> int:
+        na = C.c_int32(0)
+        self._chk(self.lib.tmx_sqp_run(self.h, max_steps, C.byref(na)))
+        return na.value
+
+    def results(self):
+        B = self.B
+        x = np.zeros((B, self.T, self.D))
+        status = np.zeros(B, np.int32)
+        cost = np.zeros(B)
+        nfe = np.zeros(B, np.int32)
+        nqp = np.zeros(B, np.int32)
+        self._chk(self.lib.tmx_sqp_results(self.h, _ptr(x), _ptr(status), _ptr(cost), _ptr(nfe), _ptr(nqp)))
+        return dict(x=x, status=status, total_cost=cost, n_func_evals=nfe, n_qp_solves=nqp)
+
+    def counters(self):
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        self._chk(self.lib.tmx_sqp_counters(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return dict(n_func_evals=a.value, n_qp_solves=b.value, admm_iters=c.value)
+
+    def qp_records(self, max_records: int = 64):
+        recs = (abi.QpRecord * (self.B * max_records))()
+        cnt = np.zeros(self.B, np.int32)
+        self._chk(self.lib.tmx_sqp_qp_records(self.h, recs, max_records, _ptr(cnt)))
+        return recs, cnt
+
+    # ---- piecewise hooks ----
+    def evaluate(self):
+        cv = np.zeros((self.B, self.n_costs))
+        vv = np.zeros((self.B, self.n_cnts))
+        self._chk(self.lib.tmx_evaluate(self.h, _ptr(cv), _ptr(vv)))
+        return cv, vv
+
+    def convexify(self):
+        act = np.zeros((self.B, self.R), np.int32)
+        coef = np.zeros((self.B, self.R, self.D))
+        rhs = np.zeros((self.B, self.R))
+        self._chk(self.lib.tmx_convexify(self.h, _ptr(act), _ptr(coef), _ptr(rhs)))
+        return act, coef, rhs
+
+    def export_csc(self, problem: int = 0):
+        n, m, nzp, nza = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        args = (self.h, problem, C.byref(n), C.byref(m), C.byref(nzp), C.byref(nza))
+        self._chk(self.lib.tmx_export_csc(*args, *([None] * 9)))
+        Pp, Pi, Px = np.zeros(n.value + 1, np.int64), np.zeros(nzp.value, np.int64), np.zeros(nzp.value)
+        Ap, Ai, Ax = np.zeros(n.value + 1, np.int64), np.zeros(nza.value, np.int64), np.zeros(nza.value)
+        q, l, u = np.zeros(n.value), np.zeros(m.value), np.zeros(m.value)
+        self._chk(self.lib.tmx_export_csc(*args, _ptr(Pp), _ptr(Pi), _ptr(Px), _ptr(q), _ptr(Ap), _ptr(Ai), _ptr(Ax),
+                                          _ptr(l), _ptr(u)))
+        return dict(n=n.value, m=m.value, P_p=Pp, P_i=Pi, P_x=Px, q=q, A_p=Ap, A_i=Ai, A_x=Ax, l=l, u=u)
+
+    def qp_solve(self):
+        xq = np.zeros((self.B, self.n_max))
+        cvx = np.zeros(self.B, np.int32)
+        rec = (abi.QpRecord * self.B)()
+        self._chk(self.lib.tmx_qp_solve(self.h, _ptr(xq), _ptr(cvx), rec))
+        return xq, cvx, rec
+
+    def argmin(self, global_offset: int = 0):
+        bi, bc = C.c_int64(), C.c_double()
+        self._chk(self.lib.tmx_argmin(self.h, global_offset, C.byref(bi), C.byref(bc)))
+        return bi.value, bc.value
+
+    def attach_nccl(self, comm_ptr: int):
+        self._chk(self.lib.tmx_attach_nccl(self.h, C.c_void_p(comm_ptr)))
+
+    def kernel_stats(self, reset: bool = False):
+        a, n, c, e = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
+        self._chk(self.lib.tmx_kernel_stats(self.h, C.byref(a), C.byref(n), C.byref(c), C.byref(e)))
+        if reset:
+            self._chk(self.lib.tmx_kernel_stats_reset(self.h))
+        return dict(admm_ms=a.value, admm_launches=n.value, convexify_ms=c.value, evaluate_ms=e.value)
+
+
+class BatchedTrustRegionSQP:
+    """sco::BasicTrustRegionSQP for a batch of seeds (optimizers.hpp:137-194): setParameters, initialize, optimize,
+    results.  `prob` is a trajopt_amd.problem.ProblemConstructionInfo (the hatched-problem description)."""
+
+    def __init__(self, pci, device: int = 0, lib_path: str = None):
+        self.pci = pci
+        self.ctx = Context(device, lib_path)
+        self.params = abi.default_sqp_params()
+        self.osqp = abi.default_osqp_settings()
+        self._uploaded = False
+
+    def setParameters(self, params: abi.SqpParams):
+        self.params = params
+        self._uploaded = False
+
+    def getParameters(self) -> abi.SqpParams:
+        return self.params
+
+    def initialize(self, x):
+        """Optimizer::initialize (optimizers.cpp:127-136): x is [batch][n_steps][n_dof]; a wrong size raises."""
+        x = np.asarray(x, dtype=np.float64)
+        T, D = self.pci.basic_info.n_steps, self.pci.robot.n_dof
+        if x.ndim != 3 or x.shape[1] != T or x.shape[2] != D:
+            raise TmxError(f"initialization vector has wrong length. expected [B,{T},{D}] got {list(x.shape)}")
+        if not self._uploaded:
+            self.desc = self.pci.to_desc()
+            self.ctx.upload(self.desc, self.params, self.osqp)
+            self._uploaded = True
+        self.ctx.set_x0(x)
+
+    def optimize(self):
+        self.ctx.run(0)
+        return self.ctx.results()["status"]
+
+    def results(self):
+        return self.ctx.results()
