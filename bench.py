@@ -129,7 +129,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             from oracle import pyorc
             cores = os.cpu_count() or 1
-            nsample = 16
+            nsample = max(16, min(cores, B))   # one problem per hardware thread: the whole host is busy
             xs = seeds_host[:nsample]
             pyorc.build()
             tc0 = time.perf_counter()

@@ -545,6 +545,7 @@ static tmx_status ensure_batch(tmx_ctx* ctx, int B)
   AL(rec_count, b);
   AL(admm_iters, b);
   AL(n_active, 1);
+  AL(prof, b * 8);
 #undef AL
   if (!ctx->db)
   {
@@ -944,6 +945,21 @@ tmx_status tmx_kernel_stats(tmx_ctx* ctx, double* admm_ms_total, int64_t* admm_l
     *convexify_ms_total = ctx->ms_convexify;
   if (evaluate_ms_total)
     *evaluate_ms_total = ctx->ms_evaluate;
+  return TMX_OK;
+}
+
+// debug/profiling hook (not part of include/tmx.h): per-phase shader-clock cycles of the last k_qp_solve, summed over problems
+__attribute__((visibility("default"))) tmx_status tmx_debug_phase_cycles(tmx_ctx* ctx, long long* out8)
+{
+  if (!ctx || !out8 || ctx->Bcap == 0)
+    return TMX_ERR_INVALID;
+  std::vector<long long> h((size_t)ctx->hb.B * 8);
+  HIPCHK(hipMemcpy(h.data(), ctx->hb.prof, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
+  for (int k = 0; k < 8; ++k)
+    out8[k] = 0;
+  for (int b = 0; b < ctx->hb.B; ++b)
+    for (int k = 0; k < 8; ++k)
+      out8[k] += h[(size_t)b * 8 + k];
   return TMX_OK;
 }
 

@@ -85,18 +85,21 @@ struct QpWs
   double *zr, *yr, *lor, *hir, *Er, *hr, *dyr, *coef;
   // aux (NA)
   double *xa, *zba, *yba, *qa, *Da, *Eba, *bba, *sa, *ta, *dxa, *dyba;
+  double *dinv;  // NA: 1 / (sigma + rho_b * bb^2) of every aux var for the current rho
+  double *fac;   // R : rho_r / (1 + rho_r * kappa_r)
   double *Sinv;  // T*D*D
   double *gj;    // D*D Gauss-Jordan scratch
   double *red;   // reduction scratch (64) + broadcast scalars (32)
   // ints
   int *act, *aoff, *naux, *slot_t, *typ_r, *typ_bp, *typ_ba, *flg_r, *flg_bp, *flg_ba, *row_ref, *aux_ref;
+  int *wp_start, *wp_list;  // LDS copies of DevProblem::wp_start / wp_list (hot in every SpMV)
 };
 
 TMX_HOSTDEVFN size_t qp_ws_doubles(int D, int T, int R, int NA)
 {
   const int NX = D * T;
-  size_t n = 14 * (size_t)NX + 7 * (size_t)R + (size_t)R * D + 11 * (size_t)NA + (size_t)T * D * D + (size_t)D * D + 96;
-  size_t ints = 8 * (size_t)R + 2 * (size_t)NX + 2 * (size_t)NA;
+  size_t n = 14 * (size_t)NX + 8 * (size_t)R + (size_t)R * D + 12 * (size_t)NA + (size_t)T * D * D + (size_t)D * D + 96;
+  size_t ints = 9 * (size_t)R + 2 * (size_t)NX + 2 * (size_t)NA + (size_t)T + 2;
   return n + (ints + 1) / 2 + 8;
 }
 
@@ -145,6 +148,8 @@ TMX_DEVFN void qp_ws_carve(QpWs& w, double* base, int D, int T, int R, int NA)
   TAKE(ta, NA);
   TAKE(dxa, NA);
   TAKE(dyba, NA);
+  TAKE(dinv, NA);
+  TAKE(fac, R);
   TAKE(Sinv, T * D * D);
   TAKE(gj, D * D);
   TAKE(red, 96);
@@ -165,6 +170,8 @@ TMX_DEVFN void qp_ws_carve(QpWs& w, double* base, int D, int T, int R, int NA)
   TAKEI(flg_bp, NX);
   TAKEI(typ_ba, NA);
   TAKEI(flg_ba, NA);
+  TAKEI(wp_start, T + 1);
+  TAKEI(wp_list, R);
 #undef TAKEI
 }
 
@@ -203,6 +210,10 @@ TMX_DEVFN double w_ba(const QpWs& w, int a, int mode, double delta)
   return mode == 0 ? rho_of_type(w.typ_ba[a], w.rho) : (w.flg_ba[a] != 0 ? 1.0 / delta : 0.0);
 }
 
+#if TMX_IS_DEVICE
+TMX_DEVFN void kkt_factor_chain_wave0(const QpWs& w, int tid);
+#endif
+
 // ---- KKT factorisation: Sinv_t for the reduced block-tridiagonal system -----------------------------------
 // sig = sigma (ADMM) or delta (polish)
 TMX_DEVFN void kkt_factor(const QpWs& w, const DevProblem* P, int mode, double sig, double delta, int tid, int NT)
@@ -232,9 +243,9 @@ TMX_DEVFN void kkt_factor(const QpWs& w, const DevProblem* P, int mode, double s
   {
     const int t = e / DD, i = (e % DD) / D, j = e % D;
     double s = 0.0;
-    for (int q = P->wp_start[t]; q < P->wp_start[t + 1]; ++q)
+    for (int q = w.wp_start[t]; q < w.wp_start[t + 1]; ++q)
     {
-      const int r = P->wp_list[q];
+      const int r = w.wp_list[q];
       if (w.act[r])
         s += w.hr[r] * w.coef[r * D + i] * w.coef[r * D + j];
     }
@@ -247,6 +258,13 @@ TMX_DEVFN void kkt_factor(const QpWs& w, const DevProblem* P, int mode, double s
   }
   TMX_SYNC();
   // sequential Schur complements + in-place Gauss-Jordan inversion (SPD, no pivoting)
+#if TMX_IS_DEVICE
+  if (DD <= 64)
+  {
+    kkt_factor_chain_wave0(w, tid);
+    return;
+  }
+#endif
   for (int t = 0; t < T; ++t)
   {
     double* S = w.Sinv + t * DD;
@@ -321,9 +339,9 @@ TMX_DEVFN void kkt_solve(const QpWs& w, const DevProblem* P, int mode, double si
   {
     const int t = v / D, j = v % D;
     double s = 0.0;
-    for (int q = P->wp_start[t]; q < P->wp_start[t + 1]; ++q)
+    for (int q = w.wp_start[t]; q < w.wp_start[t + 1]; ++q)
     {
-      const int r = P->wp_list[q];
+      const int r = w.wp_list[q];
       if (w.act[r])
         s += w.hr[r] * w.coef[r * D + j];
     }
@@ -409,9 +427,9 @@ TMX_DEVFN double at_rows(const QpWs& w, const DevProblem* P, const double* rv, i
 {
   const int D = w.D, t = v / D, j = v % D;
   double s = 0.0;
-  for (int q = P->wp_start[t]; q < P->wp_start[t + 1]; ++q)
+  for (int q = w.wp_start[t]; q < w.wp_start[t + 1]; ++q)
   {
-    const int r = P->wp_list[q];
+    const int r = w.wp_list[q];
     if (w.act[r])
       s += w.coef[r * D + j] * rv[r];
   }
@@ -687,3 +705,308 @@ TMX_DEVFN bool is_dual_infeasible(const QpWs& w, const DevProblem* P, double eps
   }
   return false;
 }
+
+// =========================================================================================================
+// Fast ADMM path (per-iteration work fused into 3 workgroup phases + a wave-0 block chain)
+// =========================================================================================================
+
+// per-rho caches: dinv[a] = 1/(sigma + rho_ba bb^2), fac[r] = rho_r / (1 + rho_r kappa_r)   (ADMM weights only)
+TMX_DEVFN void admm_cache_weights(const QpWs& w, int tid, int NT)
+{
+  for (int r = tid; r < w.R; r += NT)
+  {
+    double f = 0.0;
+    if (w.act[r])
+    {
+      const double rr = rho_of_type(w.typ_r[r], w.rho);
+      double kappa = 0.0;
+      for (int k = 0; k < w.naux[r]; ++k)
+      {
+        const int a = w.aoff[r] + k;
+        const double di = 1.0 / (w.sigma + rho_of_type(w.typ_ba[a], w.rho) * w.bba[a] * w.bba[a]);
+        w.dinv[a] = di;
+        kappa += w.sa[a] * w.sa[a] * di;
+      }
+      f = rr / (1.0 + rr * kappa);
+    }
+    w.fac[r] = f;
+  }
+  TMX_SYNC();
+}
+
+// Phase A (rows): e_r = g_r - h_r with g = rho z - y, h from the aux elimination; aux rhs -> ta
+TMX_DEVFN void admm_phase_a(const QpWs& w, int tid, int NT)
+{
+  for (int r = tid; r < w.R; r += NT)
+  {
+    double e = 0.0;
+    if (w.act[r])
+    {
+      const double rr = rho_of_type(w.typ_r[r], w.rho);
+      const double g = rr * w.zr[r] - w.yr[r];
+      double gs = 0.0;
+      for (int k = 0; k < w.naux[r]; ++k)
+      {
+        const int a = w.aoff[r] + k;
+        const double gb = rho_of_type(w.typ_ba[a], w.rho) * w.zba[a] - w.yba[a];
+        const double t = (w.sigma * w.xa[a] - w.qa[a]) + w.sa[a] * g + w.bba[a] * gb;
+        w.ta[a] = t;
+        gs += w.sa[a] * t * w.dinv[a];
+      }
+      e = g - w.fac[r] * gs;
+    }
+    w.hr[r] = e;
+  }
+  TMX_SYNC();
+}
+
+// Phase B (primary): reduced right-hand side
+TMX_DEVFN void admm_phase_b(const QpWs& w, const DevProblem* P, int tid, int NT)
+{
+  for (int v = tid; v < w.NX; v += NT)
+  {
+    const double gb = rho_of_type(w.typ_bp[v], w.rho) * w.zbp[v] - w.ybp[v];
+    w.tp[v] = (w.sigma * w.xp[v] - w.qp[v]) + at_rows(w, P, w.hr, v) + w.bbp[v] * gb;
+  }
+  TMX_SYNC();
+}
+
+#if TMX_IS_DEVICE
+typedef double tmx_v4d __attribute__((ext_vector_type(4)));
+#endif
+
+// Block forward/backward substitution  v_t = b_t - c_t o (Sinv_{t-1} v_{t-1}),  x_t = Sinv_t (v_t - c_{t+1} o x_{t+1})
+// in place on w.tp.  Device: executed by wave 0 only with v_mfma_f64_16x16x4_f64 on the D x D blocks (D <= 8): the
+// D-layout of one step (rows (lane>>4)+4r of column 0 in register r of lanes 0,16,32,48) IS the B-operand layout
+// of the next step, so the chain needs no cross-lane traffic and no LDS round trip between steps.
+TMX_DEVFN void chain_solve(const QpWs& w, int tid, int NT)
+{
+  const int D = w.D, T = w.T, DD = D * D;
+#if TMX_IS_DEVICE
+  if (D <= 8)
+  {
+    if (tid < 64)
+    {
+      const int i = tid & 15, kq = tid >> 4;
+      const bool col0 = (i == 0);
+      const bool r0 = kq < D, r1 = (kq + 4) < D;
+      const bool a0ok = (i < D) && r0, a1ok = (i < D) && r1;
+      // ---- forward (software pipelined: the operands of step t+1 are loaded before the MFMAs of step t issue,
+      //      so the LDS latency and the store of v_t are off the dependent chain)
+      double vb0 = (col0 && r0) ? w.tp[kq] : 0.0;
+      double vb1 = (col0 && r1) ? w.tp[kq + 4] : 0.0;
+      const int so0 = a0ok ? (i * D + kq) : 0, so1 = a1ok ? (i * D + kq + 4) : 0;   // clamped operand offsets
+      const int ci_off = (i < D) ? i : 0;
+      const int c0 = (col0 && r0) ? kq : 0, c1 = (col0 && r1) ? (kq + 4) : 0;
+      const double m0 = a0ok ? 1.0 : 0.0, m1 = a1ok ? 1.0 : 0.0, mc0 = (col0 && r0) ? 1.0 : 0.0, mc1 = (col0 && r1) ? 1.0 : 0.0;
+      // raw prefetched operands of the next step (multiplied only AFTER the MFMAs so that the LDS latency hides
+      // behind the matrix pipe; sched_barrier keeps the compiler from hoisting the dependent multiplies)
+      double rci = w.po[ci_off], rS0 = w.Sinv[so0], rS1 = w.Sinv[so1], rC0 = w.tp[D + c0], rC1 = w.tp[D + c1];
+      for (int t = 1; t < T; ++t)
+      {
+        const double A0 = m0 * (-rci) * rS0, A1 = m1 * (-rci) * rS1;
+        tmx_v4d acc;
+        acc[0] = mc0 * rC0;
+        acc[1] = mc1 * rC1;
+        acc[2] = 0.0;
+        acc[3] = 0.0;
+        const int tn = (t + 1 < T) ? t + 1 : t;  // clamped: the last prefetch is a harmless reload
+        rci = w.po[(tn - 1) * D + ci_off];
+        rS0 = w.Sinv[(tn - 1) * DD + so0];
+        rS1 = w.Sinv[(tn - 1) * DD + so1];
+        rC0 = w.tp[tn * D + c0];
+        rC1 = w.tp[tn * D + c1];
+        __builtin_amdgcn_sched_barrier(0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A0, vb0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A1, vb1, acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        vb0 = acc[0];
+        vb1 = acc[1];
+        if (col0 && r0)
+          w.tp[t * D + kq] = vb0;
+        if (col0 && r1)
+          w.tp[t * D + kq + 4] = vb1;
+      }
+      // ---- backward: x_t = Sinv_t (v_t - c_{t+1} o x_{t+1})
+      double xb0 = 0.0, xb1 = 0.0;
+      double pS0 = w.Sinv[(T - 1) * DD + so0], pS1 = w.Sinv[(T - 1) * DD + so1];
+      double pV0 = vb0, pV1 = vb1;  // v_{T-1} is still in registers
+      double pP0 = 0.0, pP1 = 0.0;  // c_{t+1} of the current step (0 at t = T-1)
+      for (int t = T - 1; t >= 0; --t)
+      {
+        const double A0 = m0 * pS0, A1 = m1 * pS1;
+        const double u0 = mc0 * (pV0 - pP0 * xb0), u1 = mc1 * (pV1 - pP1 * xb1);
+        const int tp_ = (t > 0) ? t - 1 : 0;
+        pS0 = w.Sinv[tp_ * DD + so0];
+        pS1 = w.Sinv[tp_ * DD + so1];
+        pV0 = w.tp[tp_ * D + c0];
+        pV1 = w.tp[tp_ * D + c1];
+        pP0 = w.po[tp_ * D + c0];
+        pP1 = w.po[tp_ * D + c1];
+        __builtin_amdgcn_sched_barrier(0);
+        tmx_v4d acc = { 0.0, 0.0, 0.0, 0.0 };
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A0, u0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A1, u1, acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        xb0 = acc[0];
+        xb1 = acc[1];
+        if (col0 && r0)
+          w.tp[t * D + kq] = xb0;
+        if (col0 && r1)
+          w.tp[t * D + kq + 4] = xb1;
+      }
+    }
+    TMX_SYNC();
+    return;
+  }
+#endif
+  for (int t = 1; t < T; ++t)
+  {
+    for (int i = tid; i < D; i += NT)
+    {
+      const double* S = w.Sinv + (t - 1) * DD + i * D;
+      const double* vp = w.tp + (t - 1) * D;
+      double acc = 0.0;
+      for (int j = 0; j < D; ++j)
+        acc += S[j] * vp[j];
+      w.tp[t * D + i] -= w.po[(t - 1) * D + i] * acc;
+    }
+    TMX_SYNC();
+  }
+  for (int t = T - 1; t >= 0; --t)
+  {
+    for (int i = tid; i < D; i += NT)
+    {
+      const double* S = w.Sinv + t * DD + i * D;
+      double acc = 0.0;
+      for (int j = 0; j < D; ++j)
+      {
+        double vj = w.tp[t * D + j];
+        if (t < T - 1)
+          vj -= w.po[t * D + j] * w.tp[(t + 1) * D + j];
+        acc += S[j] * vj;
+      }
+      w.gj[i] = acc;
+    }
+    TMX_SYNC();
+    for (int i = tid; i < D; i += NT)
+      w.tp[t * D + i] = w.gj[i];
+    TMX_SYNC();
+  }
+}
+
+// Phase C: aux recovery, ztilde, and the x / z / y updates (rows + their aux, primary vars)
+TMX_DEVFN void admm_phase_c(const QpWs& w, bool keep_delta, int tid, int NT)
+{
+  const int D = w.D;
+  const double al = w.alpha;
+  for (int r = tid; r < w.R; r += NT)
+  {
+    if (!w.act[r])
+      continue;
+    const int t = w.slot_t[r];
+    double dot = 0.0;
+    for (int j = 0; j < D; ++j)
+      dot += w.coef[r * D + j] * w.tp[t * D + j];
+    const double rr = rho_of_type(w.typ_r[r], w.rho);
+    double ax = dot;
+    const int na = w.naux[r];
+    double vk[2] = { 0.0, 0.0 };
+    double gs = 0.0;
+    for (int k = 0; k < na; ++k)
+    {
+      const int a = w.aoff[r] + k;
+      vk[k] = w.ta[a] - rr * w.sa[a] * dot;
+      gs += w.sa[a] * vk[k] * w.dinv[a];
+    }
+    const double f = w.fac[r] * gs;
+    for (int k = 0; k < na; ++k)
+    {
+      const int a = w.aoff[r] + k;
+      const double xt = (vk[k] - w.sa[a] * f) * w.dinv[a];
+      ax += w.sa[a] * xt;
+      // aux var + its bound row
+      const double xn = al * xt + (1.0 - al) * w.xa[a];
+      if (keep_delta)
+        w.dxa[a] = xn - w.xa[a];
+      w.xa[a] = xn;
+      const double rho = rho_of_type(w.typ_ba[a], w.rho), rinv = 1.0 / rho;
+      const double zt = w.bba[a] * xt;
+      const double zr = al * zt + (1.0 - al) * w.zba[a];
+      const double zn = clampd(zr + rinv * w.yba[a], 0.0, TMX_OSQP_INFTY * w.Eba[a]);
+      const double dy = rho * (zr - zn);
+      w.zba[a] = zn;
+      w.yba[a] += dy;
+      if (keep_delta)
+        w.dyba[a] = dy;
+    }
+    {
+      const double rinv = 1.0 / rr;
+      const double zr = al * ax + (1.0 - al) * w.zr[r];
+      const double zn = clampd(zr + rinv * w.yr[r], w.lor[r], w.hir[r]);
+      const double dy = rr * (zr - zn);
+      w.zr[r] = zn;
+      w.yr[r] += dy;
+      if (keep_delta)
+        w.dyr[r] = dy;
+    }
+  }
+  for (int v = tid; v < w.NX; v += NT)
+  {
+    const double xt = w.tp[v];
+    const double xn = al * xt + (1.0 - al) * w.xp[v];
+    if (keep_delta)
+      w.dxp[v] = xn - w.xp[v];
+    w.xp[v] = xn;
+    const double rho = rho_of_type(w.typ_bp[v], w.rho), rinv = 1.0 / rho;
+    const double zt = w.bbp[v] * xt;
+    const double zr = al * zt + (1.0 - al) * w.zbp[v];
+    const double zn = clampd(zr + rinv * w.ybp[v], w.lbp[v], w.ubp[v]);
+    const double dy = rho * (zr - zn);
+    w.zbp[v] = zn;
+    w.ybp[v] += dy;
+    if (keep_delta)
+      w.dybp[v] = dy;
+  }
+  TMX_SYNC();
+}
+
+#if TMX_IS_DEVICE
+// device factorisation: the T sequential Schur complements are inverted by wave 0 with one matrix entry per lane
+// (Gauss-Jordan in registers, pivots broadcast with ds_bpermute); needs D*D <= 64
+TMX_DEVFN void kkt_factor_chain_wave0(const QpWs& w, int tid)
+{
+  const int D = w.D, T = w.T, DD = D * D;
+  if (tid < 64)
+  {
+    const bool valid = tid < DD;
+    const int i = valid ? tid / D : 0, j = valid ? tid % D : 0;
+    double prev = 0.0;
+    for (int t = 0; t < T; ++t)
+    {
+      double s = valid ? w.Sinv[t * DD + tid] : 0.0;
+      if (t > 0 && valid)
+        s -= w.po[(t - 1) * D + i] * prev * w.po[(t - 1) * D + j];
+      for (int k = 0; k < D; ++k)
+      {
+        const double pkk = __shfl(s, k * D + k, 64);
+        const double rowk = __shfl(s, k * D + j, 64);
+        const double colk = __shfl(s, i * D + k, 64);
+        const double piv = 1.0 / pkk;
+        if (i == k && j == k)
+          s = piv;
+        else if (i == k)
+          s = s * piv;
+        else if (j == k)
+          s = -colk * piv;
+        else
+          s = s - colk * rowk * piv;
+      }
+      if (valid)
+        w.Sinv[t * DD + tid] = s;
+      prev = s;
+    }
+  }
+  TMX_SYNC();
+}
+#endif

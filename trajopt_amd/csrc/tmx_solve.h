@@ -417,12 +417,27 @@ static inline void debug_kkt_residual(const QpWs& w, const DevProblem* P, int it
 }
 #endif
 
+#if TMX_IS_DEVICE
+#define TMX_CLK() ((long long)__builtin_readcyclecounter())
+#else
+#define TMX_CLK() 0LL
+#endif
+#define TMX_TICK(slot)                                                                                                \
+  do                                                                                                                  \
+  {                                                                                                                   \
+    const long long now_ = TMX_CLK();                                                                                 \
+    pc[slot] += now_ - tlast;                                                                                         \
+    tlast = now_;                                                                                                     \
+  } while (0)
+
 TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, double* smem, int tid, int NT)
 {
   const int D = P->D, T = P->T, NX = P->NX, R = P->R;
   const tmx_osqp_settings& st = P->osqp;
   QpWs w;
   qp_ws_carve(w, smem, D, T, R, P->NA);
+  long long pc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+  long long tlast = TMX_CLK();
   const int* g_act = Bt->active + (size_t)b * R;
   const double* g_coef = Bt->coef + (size_t)b * R * D;
   const double* g_rhs = Bt->rhs + (size_t)b * R;
@@ -439,6 +454,7 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
     w.naux[r] = P->slot_naux[r];
     w.aoff[r] = P->slot_aoff[r];
     w.slot_t[r] = P->slot_t[r];
+    w.wp_list[r] = P->wp_list[r];
     w.flg_r[r] = 0;
     w.Er[r] = 1.0;
     w.zr[r] = 0.0;
@@ -486,6 +502,8 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
     w.dybp[v] = 0.0;
     w.flg_bp[v] = 0;
   }
+  for (int t = tid; t <= T; t += NT)
+    w.wp_start[t] = P->wp_start[t];
   if (tid == 0)
   {
     int nr = 0, na = 0;
@@ -519,9 +537,9 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
         cn = fmax(cn, fabs(w.po[v - D]));
       if (t < T - 1)
         cn = fmax(cn, fabs(w.po[v]));
-      for (int q = P->wp_start[t]; q < P->wp_start[t + 1]; ++q)
+      for (int q = w.wp_start[t]; q < w.wp_start[t + 1]; ++q)
       {
-        const int r = P->wp_list[q];
+        const int r = w.wp_list[q];
         if (w.act[r])
           cn = fmax(cn, fabs(w.coef[r * D + j]));
       }
@@ -689,7 +707,10 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
   }
 
   // ---------------- factor + ADMM loop (osqp_solve) --------------------------------------------------------
+  TMX_TICK(0);
   kkt_factor(w, P, 0, w.sigma, st.delta, tid, NT);
+  admm_cache_weights(w, tid, NT);
+  TMX_TICK(1);
   QpInfo info;
   info.status = 11;  // OSQP_UNSOLVED
   info.iter = 0;
@@ -702,13 +723,14 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
   {
     can_check = st.check_termination && (iter % st.check_termination == 0);
     const bool do_rho = st.adaptive_rho && st.adaptive_rho_interval && (iter % st.adaptive_rho_interval == 0);
-    admm_rhs(w, P, tid, NT);
-    kkt_solve(w, P, 0, w.sigma, st.delta, tid, NT);
-#if defined(TMX_HOST_EMU) && defined(TMX_DEBUG_KKT)
-    if (b == 0 && (iter <= 3 || iter % 25 == 0))
-      debug_kkt_residual(w, P, iter);
-#endif
-    admm_update(w, can_check || do_rho, tid, NT);
+    admm_phase_a(w, tid, NT);
+    TMX_TICK(2);
+    admm_phase_b(w, P, tid, NT);
+    TMX_TICK(3);
+    chain_solve(w, tid, NT);
+    TMX_TICK(4);
+    admm_phase_c(w, can_check || do_rho, tid, NT);
+    TMX_TICK(5);
     if (can_check || do_rho)
     {
       info.iter = iter;
@@ -733,9 +755,13 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
       {
         w.rho = fmin(fmax(rho_new, TMX_RHO_MIN), TMX_RHO_MAX);
         info.rho_updates += 1;
+        TMX_TICK(6);
         kkt_factor(w, P, 0, w.sigma, st.delta, tid, NT);
+        admm_cache_weights(w, tid, NT);
+        TMX_TICK(1);
       }
     }
+    TMX_TICK(6);
   }
   const int exit_iter = terminated ? iter : iter - 1;
   if (!can_check)
@@ -750,6 +776,7 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
       info.status = 7;  // OSQP_MAX_ITER_REACHED
   }
 
+  TMX_TICK(6);
   // ---------------- polish (polish.c) ---------------------------------------------------------------------
   if (st.polishing && info.status == 1)
   {
@@ -957,6 +984,7 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
     TMX_SYNC();
   }
 
+  TMX_TICK(7);
   // ---------------- store solution (unscaled, reference order) + record -----------------------------------
   const bool has_sol = !(info.status == 3 || info.status == 4 || info.status == 5 || info.status == 6 || info.status == 9);
   double* xq = Bt->xq + (size_t)b * P->n_max;
@@ -1019,6 +1047,8 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
       Bt->prev_dims[4 * b + q] = dims[q];
     Bt->prev_ws[2 * b + 0] = hs[2];
     Bt->prev_ws[2 * b + 1] = hs[3];
+    for (int q = 0; q < 8; ++q)
+      Bt->prof[(size_t)b * 8 + q] = pc[q];
   }
   TMX_SYNC();
 }

@@ -78,4 +78,5 @@ struct DevBatch
   int *rec_count;
   long long *admm_iters;
   int *n_active;  // single int: number of problems not DONE
+  long long *prof;  // B x 8 phase cycle counters of the last k_qp_solve (thread 0 view): setup, factor, A, B, chain, C, check, polish
 };
