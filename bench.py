@@ -77,7 +77,6 @@ def main():
     for k in range(args.warmup):
         one_step(k)
     ctx.kernel_stats(reset=True)
-    c0 = ctx.counters()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
