@@ -50,6 +50,7 @@ struct tmx_ctx
   double ms_admm{ 0 }, ms_convexify{ 0 }, ms_evaluate{ 0 };
   long long launches_admm{ 0 };
   bool timing{ true };
+  bool fused{ true };  // run optimize() as one persistent kernel per problem (k_sqp_fused)
   void* nccl{ nullptr };
   int max_rec{ 128 };
 };
@@ -485,6 +486,8 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
   ctx->nt_small = 64;
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_qp_solve), hipFuncAttributeMaxDynamicSharedMemorySize,
                              static_cast<int>(ctx->smem_qp)));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sqp_fused), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             static_cast<int>(ctx->smem_qp)));
 #endif
   ctx->have_problem = true;
   return TMX_OK;
@@ -629,6 +632,18 @@ tmx_status tmx_sqp_run(tmx_ctx* ctx, int32_t max_steps, int32_t* n_active_out)
   const int B = ctx->hb.B;
   long long tot[4] = { B, 0, 0, 0 };
   int step = 0;
+  if (ctx->fused)
+  {
+    TIMED(ctx->ms_admm, ctx->launches_admm++,
+          TMX_LAUNCH(k_sqp_fused, B, ctx->nt_qp, ctx->smem_qp, ctx->stream, ctx->dp, ctx->db, (int)max_steps));
+    HIPCHK(hipGetLastError());
+    tmx_status rc = read_totals(ctx, tot);
+    if (rc != TMX_OK)
+      return rc;
+    if (n_active_out)
+      *n_active_out = static_cast<int32_t>(tot[0]);
+    return TMX_OK;
+  }
   while (true)
   {
     tmx_status rc = read_totals(ctx, tot);
@@ -960,6 +975,15 @@ __attribute__((visibility("default"))) tmx_status tmx_debug_phase_cycles(tmx_ctx
   for (int b = 0; b < ctx->hb.B; ++b)
     for (int k = 0; k < 8; ++k)
       out8[k] += h[(size_t)b * 8 + k];
+  return TMX_OK;
+}
+
+// debug hook (not in include/tmx.h): 1 = fused persistent optimize() kernel (default), 0 = one launch chain per step
+__attribute__((visibility("default"))) tmx_status tmx_debug_set_fused(tmx_ctx* ctx, int fused)
+{
+  if (!ctx)
+    return TMX_ERR_INVALID;
+  ctx->fused = fused != 0;
   return TMX_OK;
 }
 

@@ -6,7 +6,7 @@
 // Optimizer::initialize + the head of optimize(): getClosestFeasiblePoint (quirk Q1: only the upper clamp
 // survives, modeling.cpp:260-271), state reset, persistent/constant rows, first exact evaluation
 // (optimizers.cpp:725, 761-767)
-TMX_KERNEL k_prepare(const DevProblem* P, const DevBatch* Bt)
+TMX_KERNEL_LB(256) k_prepare(const DevProblem* P, const DevBatch* Bt)
 {
   TMX_SMEM(smem);
   const int b = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
@@ -51,7 +51,7 @@ TMX_KERNEL k_prepare(const DevProblem* P, const DevBatch* Bt)
 }
 
 // which = 0: exact costs/violations at x -> cost_vals/cnt_viols ; which = 1: at xnew -> new_* (skips DONE problems)
-TMX_KERNEL k_evaluate(const DevProblem* P, const DevBatch* Bt, int which)
+TMX_KERNEL_LB(256) k_evaluate(const DevProblem* P, const DevBatch* Bt, int which)
 {
   TMX_SMEM(smem);
   const int b = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
@@ -64,7 +64,7 @@ TMX_KERNEL k_evaluate(const DevProblem* P, const DevBatch* Bt, int which)
 }
 
 // convexify (K1, K3) + reference QP structure (K4) for problems in PHASE_CONVEXIFY (all problems if force)
-TMX_KERNEL k_convexify(const DevProblem* P, const DevBatch* Bt, int force)
+TMX_KERNEL_LB(256) k_convexify(const DevProblem* P, const DevBatch* Bt, int force)
 {
   TMX_SMEM(smem);
   const int b = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
@@ -92,7 +92,7 @@ TMX_KERNEL k_export_csc(const DevProblem* P, const DevBatch* Bt, int b, CscOut o
 }
 
 // K5: Model::optimize() for every running problem; also publishes new_x = first NX model vars (optimizers.cpp:396)
-TMX_KERNEL k_qp_solve(const DevProblem* P, const DevBatch* Bt, int force)
+TMX_KERNEL_LB(256) k_qp_solve(const DevProblem* P, const DevBatch* Bt, int force)
 {
   TMX_SMEM(smem);
   const int b = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
@@ -110,6 +110,43 @@ TMX_KERNEL k_sqp_update(const DevProblem* P, const DevBatch* Bt)
   TMX_SMEM(smem);
   const int b = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
   sqp_update_block(P, Bt, b, smem, tid, NT);
+}
+
+// Fused optimize(): one workgroup carries its problem through the whole BasicTrustRegionSQP run (convexify -> QP
+// solve -> exact re-evaluation -> decisions, repeated) without returning to the host, so a problem never waits for
+// the slowest QP of the batch between trust-region evaluations and a CU picks up the next problem as soon as one
+// finishes.  `max_steps` bounds the number of trust-region evaluations done in this launch (0 = until DONE).
+TMX_KERNEL_LB(256) k_sqp_fused(const DevProblem* P, const DevBatch* Bt, int max_steps)
+{
+  TMX_SMEM(smem);
+  const int b = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
+  const int R = P->R, D = P->D, NX = P->NX;
+  int* act = Bt->active + (size_t)b * R;
+  double* coef = Bt->coef + (size_t)b * R * D;
+  double* rhs = Bt->rhs + (size_t)b * R;
+  double* x = Bt->x + (size_t)b * NX;
+  double* xn = Bt->xnew + (size_t)b * NX;
+  const double* xq = Bt->xq + (size_t)b * P->n_max;
+  for (int step = 0; max_steps == 0 || step < max_steps; ++step)
+  {
+    const int phase = Bt->phase[b];  // written by thread 0 before the trailing barrier of the previous round
+    if (phase == PHASE_DONE)
+      break;
+    if (phase == PHASE_CONVEXIFY)
+    {
+      convexify_terms(P, x, act, coef, rhs, tid, NT);
+      qp_structure(P, act, coef, rhs, x, Bt->trust[b], Bt->merit + (size_t)b * P->n_cnts, Bt->dims + 4 * b,
+                   Bt->hashes + 4 * b, nullptr, reinterpret_cast<int*>(smem), tid, NT);
+    }
+    TMX_SYNC();
+    qp_solve_block(P, Bt, b, smem, tid, NT);
+    for (int v = tid; v < NX; v += NT)
+      xn[v] = xq[v];
+    TMX_SYNC();
+    evaluate_terms(P, xn, Bt->new_cost_vals + (size_t)b * P->n_costs, Bt->new_cnt_viols + (size_t)b * P->n_cnts, smem, tid, NT);
+    sqp_update_block(P, Bt, b, smem, tid, NT);
+    TMX_SYNC();
+  }
 }
 
 // number of problems not DONE + running totals; `totals` = {n_active, n_fe, n_qp, admm} zeroed by the host first

@@ -78,6 +78,7 @@ TMX_DEVFN double block_max1(double v, double* red, int tid, int NT)
 struct QpWs
 {
   int D, T, NX, R, NA;
+  int DS, DDS;  // row / block stride of Sinv (rows padded to 8 doubles when D <= 8: unmasked 16-byte LDS loads)
   double sigma, alpha, rho, c, cinv;
   // primary (NX)
   double *xp, *zbp, *ybp, *lbp, *ubp, *qp, *Dp, *Ebp, *bbp, *tp, *pd, *po, *dxp, *dybp;
@@ -87,7 +88,9 @@ struct QpWs
   double *xa, *zba, *yba, *qa, *Da, *Eba, *bba, *sa, *ta, *dxa, *dyba;
   double *dinv;  // NA: 1 / (sigma + rho_b * bb^2) of every aux var for the current rho
   double *fac;   // R : rho_r / (1 + rho_r * kappa_r)
-  double *Sinv;  // T*D*D
+  double *Sinv;  // T*D*DS
+  double *WL, *WR;  // T*D*D each: spikes of the partitioned block solve (device fast path)
+  double *Zs;       // (3D)^2 inverse Schur complement on the separator blocks + 2*3D scratch
   double *gj;    // D*D Gauss-Jordan scratch
   double *red;   // reduction scratch (64) + broadcast scalars (32)
   // ints
@@ -98,7 +101,7 @@ struct QpWs
 TMX_HOSTDEVFN size_t qp_ws_doubles(int D, int T, int R, int NA)
 {
   const int NX = D * T;
-  size_t n = 14 * (size_t)NX + 8 * (size_t)R + (size_t)R * D + 12 * (size_t)NA + (size_t)T * D * D + (size_t)D * D + 96;
+  size_t n = 14 * (size_t)NX + 8 * (size_t)R + (size_t)R * D + 12 * (size_t)NA + (size_t)T * D * (D <= 8 ? 8 : D) + 2 * (size_t)T * D * D + 9 * (size_t)D * D + 6 * (size_t)D + (size_t)D * D + 98;
   size_t ints = 9 * (size_t)R + 2 * (size_t)NX + 2 * (size_t)NA + (size_t)T + 2;
   return n + (ints + 1) / 2 + 8;
 }
@@ -150,7 +153,14 @@ TMX_DEVFN void qp_ws_carve(QpWs& w, double* base, int D, int T, int R, int NA)
   TAKE(dyba, NA);
   TAKE(dinv, NA);
   TAKE(fac, R);
-  TAKE(Sinv, T * D * D);
+  w.DS = (D <= 8) ? 8 : D;
+  w.DDS = D * w.DS;
+  if ((p - base) & 1)
+    ++p;  // 16-byte alignment for the double2 row loads
+  TAKE(Sinv, T * D * w.DS);
+  TAKE(WL, T * D * D);
+  TAKE(WR, T * D * D);
+  TAKE(Zs, 9 * D * D + 6 * D);
   TAKE(gj, D * D);
   TAKE(red, 96);
 #undef TAKE
@@ -210,15 +220,11 @@ TMX_DEVFN double w_ba(const QpWs& w, int a, int mode, double delta)
   return mode == 0 ? rho_of_type(w.typ_ba[a], w.rho) : (w.flg_ba[a] != 0 ? 1.0 / delta : 0.0);
 }
 
-#if TMX_IS_DEVICE
-TMX_DEVFN void kkt_factor_chain_wave0(const QpWs& w, int tid);
-#endif
-
 // ---- KKT factorisation: Sinv_t for the reduced block-tridiagonal system -----------------------------------
 // sig = sigma (ADMM) or delta (polish)
 TMX_DEVFN void kkt_factor(const QpWs& w, const DevProblem* P, int mode, double sig, double delta, int tid, int NT)
 {
-  const int D = w.D, T = w.T, DD = D * D;
+  const int D = w.D, T = w.T, DD = D * D, DS = w.DS, DDS = w.DDS;
   // effective row weights after eliminating the aux vars: w_eff = rho_r / (1 + rho_r * kappa_r)
   for (int r = tid; r < w.R; r += NT)
   {
@@ -238,7 +244,7 @@ TMX_DEVFN void kkt_factor(const QpWs& w, const DevProblem* P, int mode, double s
     w.hr[r] = we;
   }
   TMX_SYNC();
-  // diagonal blocks A_t
+  // diagonal blocks A_t (rows padded to DS doubles)
   for (int e = tid; e < T * DD; e += NT)
   {
     const int t = e / DD, i = (e % DD) / D, j = e % D;
@@ -254,40 +260,41 @@ TMX_DEVFN void kkt_factor(const QpWs& w, const DevProblem* P, int mode, double s
       const int v = t * D + i;
       s += w.pd[v] + sig + w_bp(w, v, mode, delta) * w.bbp[v] * w.bbp[v];
     }
-    w.Sinv[e] = s;
+    w.Sinv[t * DDS + i * DS + j] = s;
+  }
+  for (int e = tid; e < T * D * (DS - D); e += NT)
+  {
+    const int t = e / (D * (DS - D)), i = (e / (DS - D)) % D, j = D + e % (DS - D);
+    w.Sinv[t * DDS + i * DS + j] = 0.0;
   }
   TMX_SYNC();
-  // sequential Schur complements + in-place Gauss-Jordan inversion (SPD, no pivoting)
-#if TMX_IS_DEVICE
-  if (DD <= 64)
+}
+
+// sequential Schur complements S_t = A_t - C_t Sinv_{t-1} C_t and in-place inversion over blocks [t0, t1]
+// (the chain restarts at t0: no coupling into block t0).  Generic (any NT) Gauss-Jordan through LDS.
+TMX_DEVFN void kkt_invert_chain_generic(const QpWs& w, int t0, int t1, int tid, int NT)
+{
+  const int D = w.D, DD = D * D, DS = w.DS, DDS = w.DDS;
+  for (int t = t0; t <= t1; ++t)
   {
-    kkt_factor_chain_wave0(w, tid);
-    return;
-  }
-#endif
-  for (int t = 0; t < T; ++t)
-  {
-    double* S = w.Sinv + t * DD;
-    if (t > 0)
+    double* S = w.Sinv + t * DDS;
+    if (t > t0)
     {
-      const double* Sp = w.Sinv + (t - 1) * DD;
+      const double* Sp = w.Sinv + (t - 1) * DDS;
       const double* c = w.po + (t - 1) * D;
       for (int e = tid; e < DD; e += NT)
       {
         const int i = e / D, j = e % D;
-        S[e] -= c[i] * Sp[e] * c[j];
+        S[i * DS + j] -= c[i] * Sp[i * DS + j] * c[j];
       }
       TMX_SYNC();
     }
     for (int k = 0; k < D; ++k)
     {
-      const double piv = 1.0 / S[k * D + k];
+      const double piv = 1.0 / S[k * DS + k];
       TMX_SYNC();
-      // scale pivot row (excluding pivot), stash pivot column in red
       for (int e = tid; e < D; e += NT)
-      {
-        w.red[32 + e] = S[e * D + k];  // column k
-      }
+        w.red[32 + e] = S[e * DS + k];  // column k
       TMX_SYNC();
       for (int e = tid; e < DD; e += NT)
       {
@@ -296,16 +303,16 @@ TMX_DEVFN void kkt_factor(const QpWs& w, const DevProblem* P, int mode, double s
         if (i == k && j == k)
           v = piv;
         else if (i == k)
-          v = S[e] * piv;
+          v = S[i * DS + j] * piv;
         else if (j == k)
           v = -w.red[32 + i] * piv;
         else
-          v = S[e] - w.red[32 + i] * S[k * D + j] * piv;
+          v = S[i * DS + j] - w.red[32 + i] * S[k * DS + j] * piv;
         w.gj[e] = v;
       }
       TMX_SYNC();
       for (int e = tid; e < DD; e += NT)
-        S[e] = w.gj[e];
+        S[(e / D) * DS + e % D] = w.gj[e];
       TMX_SYNC();
     }
   }
@@ -314,7 +321,7 @@ TMX_DEVFN void kkt_factor(const QpWs& w, const DevProblem* P, int mode, double s
 // ---- KKT solve: in: tp (primary rhs r1 + A'W r2 part), ta (aux rhs); out: tp = x_p, ta = x_a, hr = (A x)_r --------
 TMX_DEVFN void kkt_solve(const QpWs& w, const DevProblem* P, int mode, double sig, double delta, int tid, int NT)
 {
-  const int D = w.D, T = w.T, DD = D * D;
+  const int D = w.D, T = w.T, DS = w.DS, DDS = w.DDS;
   // 1. aux elimination: h_r = rho_r * (s . Maa^-1 rhs_a) ;   Maa^-1 v = v/d - rho (s/d) (s.(v/d)) / (1 + rho kappa)
   for (int r = tid; r < w.R; r += NT)
   {
@@ -353,7 +360,7 @@ TMX_DEVFN void kkt_solve(const QpWs& w, const DevProblem* P, int mode, double si
   {
     for (int i = tid; i < D; i += NT)
     {
-      const double* S = w.Sinv + (t - 1) * DD + i * D;
+      const double* S = w.Sinv + (t - 1) * DDS + i * DS;
       const double* vp = w.tp + (t - 1) * D;
       double acc = 0.0;
       for (int j = 0; j < D; ++j)
@@ -366,7 +373,7 @@ TMX_DEVFN void kkt_solve(const QpWs& w, const DevProblem* P, int mode, double si
   {
     for (int i = tid; i < D; i += NT)
     {
-      const double* S = w.Sinv + t * DD + i * D;
+      const double* S = w.Sinv + t * DDS + i * DS;
       double acc = 0.0;
       for (int j = 0; j < D; ++j)
       {
@@ -422,18 +429,31 @@ TMX_DEVFN void kkt_solve(const QpWs& w, const DevProblem* P, int mode, double si
   TMX_SYNC();
 }
 
-// (A'v)_p for primary var v given per-row values rv[R] and per-bound values handled by caller
+// (A'v)_p for primary var v given per-row values rv[R] (rv and coef are zero on inactive rows).
+// Two independent partial sums: dependent fp64 FMAs cost 40 cycles each on gfx950, so the gather is split into
+// independent chains and the loads of both rows are issued together.
 TMX_DEVFN double at_rows(const QpWs& w, const DevProblem* P, const double* rv, int v)
 {
   const int D = w.D, t = v / D, j = v % D;
-  double s = 0.0;
-  for (int q = w.wp_start[t]; q < w.wp_start[t + 1]; ++q)
+  const int q0 = w.wp_start[t], q1 = w.wp_start[t + 1];
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int q = q0;
+  for (; q + 3 < q1; q += 4)
   {
-    const int r = w.wp_list[q];
-    if (w.act[r])
-      s += w.coef[r * D + j] * rv[r];
+    const int r0 = w.wp_list[q], r1 = w.wp_list[q + 1], r2 = w.wp_list[q + 2], r3 = w.wp_list[q + 3];
+    const double c0 = w.coef[r0 * D + j], c1 = w.coef[r1 * D + j], c2 = w.coef[r2 * D + j], c3 = w.coef[r3 * D + j];
+    const double v0 = rv[r0], v1 = rv[r1], v2 = rv[r2], v3 = rv[r3];
+    s0 += c0 * v0;
+    s1 += c1 * v1;
+    s2 += c2 * v2;
+    s3 += c3 * v3;
   }
-  return s;
+  for (; q < q1; ++q)
+  {
+    const int r0 = w.wp_list[q];
+    s0 += w.coef[r0 * D + j] * rv[r0];
+  }
+  return (s0 + s1) + (s2 + s3);
 }
 // (P x)_v for primary var v
 TMX_DEVFN double p_times(const QpWs& w, const double* x, int v)
@@ -771,100 +791,16 @@ TMX_DEVFN void admm_phase_b(const QpWs& w, const DevProblem* P, int tid, int NT)
   TMX_SYNC();
 }
 
-#if TMX_IS_DEVICE
-typedef double tmx_v4d __attribute__((ext_vector_type(4)));
-#endif
-
-// Block forward/backward substitution  v_t = b_t - c_t o (Sinv_{t-1} v_{t-1}),  x_t = Sinv_t (v_t - c_{t+1} o x_{t+1})
-// in place on w.tp.  Device: executed by wave 0 only with v_mfma_f64_16x16x4_f64 on the D x D blocks (D <= 8): the
-// D-layout of one step (rows (lane>>4)+4r of column 0 in register r of lanes 0,16,32,48) IS the B-operand layout
-// of the next step, so the chain needs no cross-lane traffic and no LDS round trip between steps.
-TMX_DEVFN void chain_solve(const QpWs& w, int tid, int NT)
+// Block forward/backward substitution over blocks [t0, t1] in place on w.tp (generic, any NT):
+//   v_t = b_t - c_t o (Sinv_{t-1} v_{t-1}),   x_t = Sinv_t (v_t - c_{t+1} o x_{t+1});  the chain restarts at t0 / t1.
+TMX_DEVFN void chain_solve_range(const QpWs& w, int t0, int t1, int tid, int NT)
 {
-  const int D = w.D, T = w.T, DD = D * D;
-#if TMX_IS_DEVICE
-  if (D <= 8)
-  {
-    if (tid < 64)
-    {
-      const int i = tid & 15, kq = tid >> 4;
-      const bool col0 = (i == 0);
-      const bool r0 = kq < D, r1 = (kq + 4) < D;
-      const bool a0ok = (i < D) && r0, a1ok = (i < D) && r1;
-      // ---- forward (software pipelined: the operands of step t+1 are loaded before the MFMAs of step t issue,
-      //      so the LDS latency and the store of v_t are off the dependent chain)
-      double vb0 = (col0 && r0) ? w.tp[kq] : 0.0;
-      double vb1 = (col0 && r1) ? w.tp[kq + 4] : 0.0;
-      const int so0 = a0ok ? (i * D + kq) : 0, so1 = a1ok ? (i * D + kq + 4) : 0;   // clamped operand offsets
-      const int ci_off = (i < D) ? i : 0;
-      const int c0 = (col0 && r0) ? kq : 0, c1 = (col0 && r1) ? (kq + 4) : 0;
-      const double m0 = a0ok ? 1.0 : 0.0, m1 = a1ok ? 1.0 : 0.0, mc0 = (col0 && r0) ? 1.0 : 0.0, mc1 = (col0 && r1) ? 1.0 : 0.0;
-      // raw prefetched operands of the next step (multiplied only AFTER the MFMAs so that the LDS latency hides
-      // behind the matrix pipe; sched_barrier keeps the compiler from hoisting the dependent multiplies)
-      double rci = w.po[ci_off], rS0 = w.Sinv[so0], rS1 = w.Sinv[so1], rC0 = w.tp[D + c0], rC1 = w.tp[D + c1];
-      for (int t = 1; t < T; ++t)
-      {
-        const double A0 = m0 * (-rci) * rS0, A1 = m1 * (-rci) * rS1;
-        tmx_v4d acc;
-        acc[0] = mc0 * rC0;
-        acc[1] = mc1 * rC1;
-        acc[2] = 0.0;
-        acc[3] = 0.0;
-        const int tn = (t + 1 < T) ? t + 1 : t;  // clamped: the last prefetch is a harmless reload
-        rci = w.po[(tn - 1) * D + ci_off];
-        rS0 = w.Sinv[(tn - 1) * DD + so0];
-        rS1 = w.Sinv[(tn - 1) * DD + so1];
-        rC0 = w.tp[tn * D + c0];
-        rC1 = w.tp[tn * D + c1];
-        __builtin_amdgcn_sched_barrier(0);
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A0, vb0, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A1, vb1, acc, 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        vb0 = acc[0];
-        vb1 = acc[1];
-        if (col0 && r0)
-          w.tp[t * D + kq] = vb0;
-        if (col0 && r1)
-          w.tp[t * D + kq + 4] = vb1;
-      }
-      // ---- backward: x_t = Sinv_t (v_t - c_{t+1} o x_{t+1})
-      double xb0 = 0.0, xb1 = 0.0;
-      double pS0 = w.Sinv[(T - 1) * DD + so0], pS1 = w.Sinv[(T - 1) * DD + so1];
-      double pV0 = vb0, pV1 = vb1;  // v_{T-1} is still in registers
-      double pP0 = 0.0, pP1 = 0.0;  // c_{t+1} of the current step (0 at t = T-1)
-      for (int t = T - 1; t >= 0; --t)
-      {
-        const double A0 = m0 * pS0, A1 = m1 * pS1;
-        const double u0 = mc0 * (pV0 - pP0 * xb0), u1 = mc1 * (pV1 - pP1 * xb1);
-        const int tp_ = (t > 0) ? t - 1 : 0;
-        pS0 = w.Sinv[tp_ * DD + so0];
-        pS1 = w.Sinv[tp_ * DD + so1];
-        pV0 = w.tp[tp_ * D + c0];
-        pV1 = w.tp[tp_ * D + c1];
-        pP0 = w.po[tp_ * D + c0];
-        pP1 = w.po[tp_ * D + c1];
-        __builtin_amdgcn_sched_barrier(0);
-        tmx_v4d acc = { 0.0, 0.0, 0.0, 0.0 };
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A0, u0, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A1, u1, acc, 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        xb0 = acc[0];
-        xb1 = acc[1];
-        if (col0 && r0)
-          w.tp[t * D + kq] = xb0;
-        if (col0 && r1)
-          w.tp[t * D + kq + 4] = xb1;
-      }
-    }
-    TMX_SYNC();
-    return;
-  }
-#endif
-  for (int t = 1; t < T; ++t)
+  const int D = w.D, DS = w.DS, DDS = w.DDS;
+  for (int t = t0 + 1; t <= t1; ++t)
   {
     for (int i = tid; i < D; i += NT)
     {
-      const double* S = w.Sinv + (t - 1) * DD + i * D;
+      const double* S = w.Sinv + (t - 1) * DDS + i * DS;
       const double* vp = w.tp + (t - 1) * D;
       double acc = 0.0;
       for (int j = 0; j < D; ++j)
@@ -873,16 +809,16 @@ TMX_DEVFN void chain_solve(const QpWs& w, int tid, int NT)
     }
     TMX_SYNC();
   }
-  for (int t = T - 1; t >= 0; --t)
+  for (int t = t1; t >= t0; --t)
   {
     for (int i = tid; i < D; i += NT)
     {
-      const double* S = w.Sinv + t * DD + i * D;
+      const double* S = w.Sinv + t * DDS + i * DS;
       double acc = 0.0;
       for (int j = 0; j < D; ++j)
       {
         double vj = w.tp[t * D + j];
-        if (t < T - 1)
+        if (t < t1)
           vj -= w.po[t * D + j] * w.tp[(t + 1) * D + j];
         acc += S[j] * vj;
       }
@@ -894,6 +830,7 @@ TMX_DEVFN void chain_solve(const QpWs& w, int tid, int NT)
     TMX_SYNC();
   }
 }
+TMX_DEVFN void chain_solve(const QpWs& w, int tid, int NT) { chain_solve_range(w, 0, w.T - 1, tid, NT); }
 
 // Phase C: aux recovery, ztilde, and the x / z / y updates (rows + their aux, primary vars)
 TMX_DEVFN void admm_phase_c(const QpWs& w, bool keep_delta, int tid, int NT)
@@ -971,42 +908,7 @@ TMX_DEVFN void admm_phase_c(const QpWs& w, bool keep_delta, int tid, int NT)
   TMX_SYNC();
 }
 
+
 #if TMX_IS_DEVICE
-// device factorisation: the T sequential Schur complements are inverted by wave 0 with one matrix entry per lane
-// (Gauss-Jordan in registers, pivots broadcast with ds_bpermute); needs D*D <= 64
-TMX_DEVFN void kkt_factor_chain_wave0(const QpWs& w, int tid)
-{
-  const int D = w.D, T = w.T, DD = D * D;
-  if (tid < 64)
-  {
-    const bool valid = tid < DD;
-    const int i = valid ? tid / D : 0, j = valid ? tid % D : 0;
-    double prev = 0.0;
-    for (int t = 0; t < T; ++t)
-    {
-      double s = valid ? w.Sinv[t * DD + tid] : 0.0;
-      if (t > 0 && valid)
-        s -= w.po[(t - 1) * D + i] * prev * w.po[(t - 1) * D + j];
-      for (int k = 0; k < D; ++k)
-      {
-        const double pkk = __shfl(s, k * D + k, 64);
-        const double rowk = __shfl(s, k * D + j, 64);
-        const double colk = __shfl(s, i * D + k, 64);
-        const double piv = 1.0 / pkk;
-        if (i == k && j == k)
-          s = piv;
-        else if (i == k)
-          s = s * piv;
-        else if (j == k)
-          s = -colk * piv;
-        else
-          s = s - colk * rowk * piv;
-      }
-      if (valid)
-        w.Sinv[t * DD + tid] = s;
-      prev = s;
-    }
-  }
-  TMX_SYNC();
-}
+#include "tmx_part.h"
 #endif

@@ -255,6 +255,24 @@ TMX_DEVFN void qp_structure(const DevProblem* P, const int* active, const double
 // K5: one OSQPModel::optimize() — setup (scaling, rho vector, factor), optional explicit warm start, ADMM loop,
 // polish, solution store.  Executed by one workgroup on LDS workspace `w`.
 // ---------------------------------------------------------------------------------------------------------
+// inversion stage of the factorisation: partitioned (4 interiors + separators, fast ADMM path) or one-sided chain
+TMX_DEVFN void kkt_invert(const QpWs& w, bool partitioned, int tid, int NT)
+{
+#if TMX_IS_DEVICE
+  if (partitioned)
+  {
+    part_factor(w, tid, NT);
+    return;
+  }
+  if (w.D * w.D <= 64)
+  {
+    kkt_invert_chain_wave0(w, tid);
+    return;
+  }
+#endif
+  kkt_invert_chain_generic(w, 0, w.T - 1, tid, NT);
+}
+
 TMX_DEVFN void admm_rhs(const QpWs& w, const DevProblem* P, int tid, int NT)
 {
   // per-row  g_r = rho_r z_r - y_r  into hr ; then tp = sigma x - q + A'g (+ bound part), ta likewise
@@ -708,7 +726,13 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
 
   // ---------------- factor + ADMM loop (osqp_solve) --------------------------------------------------------
   TMX_TICK(0);
+#if TMX_IS_DEVICE
+  const bool fast = (NT == 256) && (R <= 512) && (NX <= 256) && (D <= 8) && (T >= 7);
+#else
+  const bool fast = false;
+#endif
   kkt_factor(w, P, 0, w.sigma, st.delta, tid, NT);
+  kkt_invert(w, fast, tid, NT);
   admm_cache_weights(w, tid, NT);
   TMX_TICK(1);
   QpInfo info;
@@ -721,25 +745,39 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
   bool can_check = false, terminated = false;
   for (iter = 1; iter <= st.max_iter; ++iter)
   {
+#if TMX_IS_DEVICE
+    if (fast)
+    {
+      // run up to the next iteration that needs the residuals (termination test and/or adaptive rho) in one
+      // register-resident burst
+      int next = st.max_iter;
+      if (st.check_termination)
+        next = min(next, ((iter - 1) / st.check_termination + 1) * st.check_termination);
+      if (st.adaptive_rho && st.adaptive_rho_interval)
+        next = min(next, ((iter - 1) / st.adaptive_rho_interval + 1) * st.adaptive_rho_interval);
+      admm_run_fast(w, P, next - iter + 1, true, tid);
+      iter = next;
+      TMX_TICK(4);
+    }
+#endif
     can_check = st.check_termination && (iter % st.check_termination == 0);
     const bool do_rho = st.adaptive_rho && st.adaptive_rho_interval && (iter % st.adaptive_rho_interval == 0);
-    admm_phase_a(w, tid, NT);
-    TMX_TICK(2);
-    admm_phase_b(w, P, tid, NT);
-    TMX_TICK(3);
-    chain_solve(w, tid, NT);
-    TMX_TICK(4);
-    admm_phase_c(w, can_check || do_rho, tid, NT);
-    TMX_TICK(5);
+    if (!fast)
+    {
+      admm_phase_a(w, tid, NT);
+      TMX_TICK(2);
+      admm_phase_b(w, P, tid, NT);
+      TMX_TICK(3);
+      chain_solve(w, tid, NT);
+      TMX_TICK(4);
+      admm_phase_c(w, can_check || do_rho, tid, NT);
+      TMX_TICK(5);
+    }
     if (can_check || do_rho)
     {
       info.iter = iter;
       compute_residuals(w, P, w.xp, w.xa, w.yr, w.ybp, w.yba, 0, info, info.prim_res, info.dual_res, true, tid, NT);
     }
-#if defined(TMX_HOST_EMU) && defined(TMX_DEBUG_KKT)
-    if (b == 0 && (can_check || do_rho))
-      std::printf("[dbg] iter %d prim %.3e dual %.3e\n", iter, info.prim_res, info.dual_res);
-#endif
     if (can_check)
     {
       if (check_termination(w, P, info, false, tid, NT))
@@ -757,6 +795,7 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
         info.rho_updates += 1;
         TMX_TICK(6);
         kkt_factor(w, P, 0, w.sigma, st.delta, tid, NT);
+        kkt_invert(w, fast, tid, NT);
         admm_cache_weights(w, tid, NT);
         TMX_TICK(1);
       }
@@ -813,6 +852,7 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
     }
     TMX_SYNC();
     kkt_factor(w, P, 1, delta, delta, tid, NT);
+    kkt_invert(w, false, tid, NT);
     // polished iterate lives in (dxp, dxa | dyr, dybp, dyba)
     for (int pass = 0; pass <= st.polish_refine_iter; ++pass)
     {
