@@ -17,7 +17,7 @@ out = (C.c_longlong * 8)()
 ctx.lib.tmx_debug_phase_cycles.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
 ctx.lib.tmx_debug_phase_cycles(ctx.h, out)
 iters = sum(rec[b].osqp_iter for b in range(B))
-names = ["setup", "factor", "phaseA", "phaseB", "chain", "phaseC", "check+rho", "polish"]
+names = ["setup", "factor", "phaseA+B", "int.chain", "sep+Z+corr", "phaseC", "check+rho", "polish"]
 tot = sum(out)
 print("B", B, "kernel ms", st["admm_ms"], "total admm iters", iters, "avg iters", iters / B)
 for n, c in zip(names, out):

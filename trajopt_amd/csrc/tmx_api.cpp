@@ -44,13 +44,14 @@ struct tmx_ctx
   int Bcap{ 0 };
   std::vector<void*> prob_allocs, batch_allocs;
   long long* d_totals{ nullptr };
-  size_t smem_qp{ 0 }, smem_small{ 0 };
+  size_t smem_qp{ 0 }, smem_small{ 0 }, smem_pool{ 0 };
   int nt_qp{ 64 }, nt_small{ 64 };
   hipEvent_t ev0{ nullptr }, ev1{ nullptr };
   double ms_admm{ 0 }, ms_convexify{ 0 }, ms_evaluate{ 0 };
   long long launches_admm{ 0 };
   bool timing{ true };
-  bool fused{ true };  // run optimize() as one persistent kernel per problem (k_sqp_fused)
+  int mode{ 2 };  // optimize() driver: 0 = one launch chain per step, 1 = k_sqp_fused, 2 = k_sqp_pool (default)
+  int pool_wgs{ 0 };  // resident workgroups of the pool kernel (0 = CUs x workgroups-per-CU)
   void* nccl{ nullptr };
   int max_rec{ 128 };
 };
@@ -468,12 +469,14 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
   }
   HIPCHK(hipMemcpy(ctx->dp, &P, sizeof(DevProblem), hipMemcpyHostToDevice));
   // LDS budgets
-  ctx->smem_qp = qp_ws_doubles(D, T, R, NA) * sizeof(double);
+  ctx->smem_qp = qp_smem_bytes(D, T, R, NA);
   const size_t small_ints = (size_t)(P.n_max + 1) + 2 * (size_t)R + 2 + 16;
   ctx->smem_small = std::max<size_t>((size_t)(R + n_costs + n_cnts + 8) * sizeof(double), small_ints * sizeof(int) + 64);
 #ifdef TMX_HOST_EMU
   ctx->nt_qp = 1;
   ctx->nt_small = 1;
+  ctx->smem_pool = std::max<size_t>(ctx->smem_qp, 64);
+  ctx->pool_wgs = 8;
 #else
   if (ctx->smem_qp > 160 * 1024)
   {
@@ -482,12 +485,32 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
     return TMX_ERR_UNSUPPORTED;
   }
   // one problem per CU when the workspace is large: use 4 waves so the data-parallel phases go 4x wider
-  ctx->nt_qp = (ctx->smem_qp > 80 * 1024) ? 256 : 64;
+  ctx->nt_qp = 256;  // 4 waves: one interior of the partitioned block solve each
   ctx->nt_small = 64;
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_qp_solve), hipFuncAttributeMaxDynamicSharedMemorySize,
                              static_cast<int>(ctx->smem_qp)));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sqp_fused), hipFuncAttributeMaxDynamicSharedMemorySize,
                              static_cast<int>(ctx->smem_qp)));
+  ctx->smem_pool = std::max<size_t>(ctx->smem_qp, (2 * 256 + 8) * sizeof(int));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sqp_pool), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             static_cast<int>(ctx->smem_pool)));
+  {
+    // persistent pool size = what is resident at once: CUs x workgroups per CU (LDS- and register-limited)
+    int cus = 256, per_cu = 1;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess)
+      cus = prop.multiProcessorCount;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sqp_pool, 256, ctx->smem_pool) != hipSuccess || per_cu < 1)
+      per_cu = 1;
+    per_cu = std::min(per_cu, TMX_QP_WAVES_PER_SIMD);
+    ctx->pool_wgs = cus * per_cu;
+    if (const char* e = std::getenv("TMX_POOL_WGS"))  // tuning hook
+      ctx->pool_wgs = std::max(1, std::atoi(e));
+    if (const char* e = std::getenv("TMX_SQP_MODE"))  // tuning hook: 0 stepwise launches, 1 fused in-order, 2 pool
+      ctx->mode = std::max(0, std::min(2, std::atoi(e)));
+    if (std::getenv("TMX_VERBOSE"))
+      std::fprintf(stderr, "[tmx] CUs %d, pool workgroups/CU %d, pool size %d, LDS %zu B\n", cus, per_cu, ctx->pool_wgs, ctx->smem_pool);
+  }
 #endif
   ctx->have_problem = true;
   return TMX_OK;
@@ -549,6 +572,10 @@ static tmx_status ensure_batch(tmx_ctx* ctx, int B)
   AL(admm_iters, b);
   AL(n_active, 1);
   AL(prof, b * 8);
+  AL(sched_state, b);
+  AL(sched_done, 1);
+  H.qp_scratch_stride = (long long)qp_glb_doubles(P.D, P.T, P.R, P.NA);
+  AL(qp_scratch, (TMX_QP_COLD_IN_LDS ? 1 : b) * (size_t)H.qp_scratch_stride);
 #undef AL
   if (!ctx->db)
   {
@@ -632,10 +659,17 @@ tmx_status tmx_sqp_run(tmx_ctx* ctx, int32_t max_steps, int32_t* n_active_out)
   const int B = ctx->hb.B;
   long long tot[4] = { B, 0, 0, 0 };
   int step = 0;
-  if (ctx->fused)
+  if (ctx->mode != 0)
   {
-    TIMED(ctx->ms_admm, ctx->launches_admm++,
-          TMX_LAUNCH(k_sqp_fused, B, ctx->nt_qp, ctx->smem_qp, ctx->stream, ctx->dp, ctx->db, (int)max_steps));
+    if (ctx->mode == 2 && max_steps == 0)
+    {
+      const int G = std::min(B, ctx->pool_wgs);
+      TIMED(ctx->ms_admm, ctx->launches_admm++,
+            TMX_LAUNCH(k_sqp_pool, G, ctx->nt_qp, ctx->smem_pool, ctx->stream, ctx->dp, ctx->db));
+    }
+    else
+      TIMED(ctx->ms_admm, ctx->launches_admm++,
+            TMX_LAUNCH(k_sqp_fused, B, ctx->nt_qp, ctx->smem_qp, ctx->stream, ctx->dp, ctx->db, (int)max_steps));
     HIPCHK(hipGetLastError());
     tmx_status rc = read_totals(ctx, tot);
     if (rc != TMX_OK)
@@ -978,12 +1012,23 @@ __attribute__((visibility("default"))) tmx_status tmx_debug_phase_cycles(tmx_ctx
   return TMX_OK;
 }
 
-// debug hook (not in include/tmx.h): 1 = fused persistent optimize() kernel (default), 0 = one launch chain per step
-__attribute__((visibility("default"))) tmx_status tmx_debug_set_fused(tmx_ctx* ctx, int fused)
+// debug hook (not in include/tmx.h): per-problem ADMM iteration totals of the last run (load-balance analysis)
+__attribute__((visibility("default"))) tmx_status tmx_debug_admm_iters(tmx_ctx* ctx, int64_t* out)
 {
-  if (!ctx)
+  if (!ctx || !out || ctx->hb.B <= 0)
     return TMX_ERR_INVALID;
-  ctx->fused = fused != 0;
+  static_assert(sizeof(long long) == sizeof(int64_t), "");
+  if (hipMemcpy(out, ctx->hb.admm_iters, sizeof(int64_t) * ctx->hb.B, hipMemcpyDeviceToHost) != hipSuccess)
+    return TMX_ERR_DEVICE;
+  return TMX_OK;
+}
+
+// debug hook (not in include/tmx.h): 1 = fused persistent optimize() kernel (default), 0 = one launch chain per step
+__attribute__((visibility("default"))) tmx_status tmx_debug_set_fused(tmx_ctx* ctx, int mode)
+{
+  if (!ctx || mode < 0 || mode > 2)
+    return TMX_ERR_INVALID;
+  ctx->mode = mode;
   return TMX_OK;
 }
 

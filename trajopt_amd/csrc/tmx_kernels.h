@@ -42,6 +42,9 @@ TMX_KERNEL_LB(256) k_prepare(const DevProblem* P, const DevBatch* Bt)
     Bt->rec_count[b] = 0;
     Bt->admm_iters[b] = 0;
     Bt->total_cost[b] = 0.0;
+    Bt->sched_state[b] = 0;
+    if (b == 0)
+      *Bt->sched_done = 0;
     for (int q = 0; q < 4; ++q)
       Bt->prev_dims[4 * b + q] = -1;
   }
@@ -92,7 +95,10 @@ TMX_KERNEL k_export_csc(const DevProblem* P, const DevBatch* Bt, int b, CscOut o
 }
 
 // K5: Model::optimize() for every running problem; also publishes new_x = first NX model vars (optimizers.cpp:396)
-TMX_KERNEL_LB(256) k_qp_solve(const DevProblem* P, const DevBatch* Bt, int force)
+#ifndef TMX_QP_WAVES_PER_SIMD
+#define TMX_QP_WAVES_PER_SIMD (TMX_QP_COLD_IN_LDS ? 1 : 2)  // workgroups of 256 threads per CU the register allocator must leave room for
+#endif
+TMX_KERNEL_LB2(256, TMX_QP_WAVES_PER_SIMD) k_qp_solve(const DevProblem* P, const DevBatch* Bt, int force)
 {
   TMX_SMEM(smem);
   const int b = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
@@ -112,14 +118,10 @@ TMX_KERNEL k_sqp_update(const DevProblem* P, const DevBatch* Bt)
   sqp_update_block(P, Bt, b, smem, tid, NT);
 }
 
-// Fused optimize(): one workgroup carries its problem through the whole BasicTrustRegionSQP run (convexify -> QP
-// solve -> exact re-evaluation -> decisions, repeated) without returning to the host, so a problem never waits for
-// the slowest QP of the batch between trust-region evaluations and a CU picks up the next problem as soon as one
-// finishes.  `max_steps` bounds the number of trust-region evaluations done in this launch (0 = until DONE).
-TMX_KERNEL_LB(256) k_sqp_fused(const DevProblem* P, const DevBatch* Bt, int max_steps)
+// One trust-region evaluation of problem b: [convexify + QP structure] -> Model::optimize -> exact re-evaluation ->
+// accept / shrink / penalty decisions.  All state lives in HBM between calls.
+TMX_DEVFN void sqp_step_block(const DevProblem* P, const DevBatch* Bt, int b, double* smem, int tid, int NT)
 {
-  TMX_SMEM(smem);
-  const int b = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
   const int R = P->R, D = P->D, NX = P->NX;
   int* act = Bt->active + (size_t)b * R;
   double* coef = Bt->coef + (size_t)b * R * D;
@@ -127,25 +129,133 @@ TMX_KERNEL_LB(256) k_sqp_fused(const DevProblem* P, const DevBatch* Bt, int max_
   double* x = Bt->x + (size_t)b * NX;
   double* xn = Bt->xnew + (size_t)b * NX;
   const double* xq = Bt->xq + (size_t)b * P->n_max;
+  if (Bt->phase[b] == PHASE_CONVEXIFY)
+  {
+    convexify_terms(P, x, act, coef, rhs, tid, NT);
+    qp_structure(P, act, coef, rhs, x, Bt->trust[b], Bt->merit + (size_t)b * P->n_cnts, Bt->dims + 4 * b, Bt->hashes + 4 * b,
+                 nullptr, reinterpret_cast<int*>(smem), tid, NT);
+  }
+  TMX_SYNC();
+  qp_solve_block(P, Bt, b, smem, tid, NT);
+  for (int v = tid; v < NX; v += NT)
+    xn[v] = xq[v];
+  TMX_SYNC();
+  evaluate_terms(P, xn, Bt->new_cost_vals + (size_t)b * P->n_costs, Bt->new_cnt_viols + (size_t)b * P->n_cnts, smem, tid, NT);
+  sqp_update_block(P, Bt, b, smem, tid, NT);
+  TMX_SYNC();
+}
+
+// Fused optimize(): one workgroup carries its problem through the whole BasicTrustRegionSQP run without returning to the
+// host.  `max_steps` bounds the number of trust-region evaluations done in this launch (0 = until DONE).
+TMX_KERNEL_LB2(256, TMX_QP_WAVES_PER_SIMD) k_sqp_fused(const DevProblem* P, const DevBatch* Bt, int max_steps)
+{
+  TMX_SMEM(smem);
+  const int b = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
   for (int step = 0; max_steps == 0 || step < max_steps; ++step)
   {
-    const int phase = Bt->phase[b];  // written by thread 0 before the trailing barrier of the previous round
-    if (phase == PHASE_DONE)
+    if (Bt->phase[b] == PHASE_DONE)
       break;
-    if (phase == PHASE_CONVEXIFY)
+    sqp_step_block(P, Bt, b, smem, tid, NT);
+  }
+}
+
+// Persistent pool: gridDim.x resident workgroups repeatedly CLAIM the least-advanced ready problem, advance it by one
+// trust-region evaluation and release it.  A batch of 1024 seeds on 256 CUs has only ~4 problems per CU and their run
+// lengths differ by several x, so in-order block dispatch leaves ~40 % of the CU-time idle in the tail; with fair
+// time-slicing at QP granularity every problem progresses at the same rate and the tail is one QP solve.
+// Hand-off between workgroups follows the agent-scope release / acquire recipe of the CDNA guide (G16): all problem
+// state is in HBM; publisher: stores -> __syncthreads -> lane-0 release fence -> s_waitcnt -> relaxed flag store;
+// claimer: relaxed scan -> CAS -> one acquire fence -> __syncthreads -> plain loads.
+#if TMX_IS_DEVICE
+#define TMX_LD_RELAXED(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define TMX_ST_RELAXED(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#else
+#define TMX_LD_RELAXED(p) __atomic_load_n((p), __ATOMIC_RELAXED)
+#define TMX_ST_RELAXED(p, v) __atomic_store_n((p), (v), __ATOMIC_RELAXED)
+#endif
+TMX_KERNEL_LB2(256, TMX_QP_WAVES_PER_SIMD) k_sqp_pool(const DevProblem* P, const DevBatch* Bt)
+{
+  TMX_SMEM(smem);
+  const int tid = threadIdx.x, NT = blockDim.x;
+  const int B = Bt->B;
+  int* ibuf = reinterpret_cast<int*>(smem);  // [0..NT) keys, [NT..2NT) indices, [2NT] decision
+  unsigned spins = 0;
+  while (true)
+  {
+    // ---- scan: least n_qp among the ready problems (relaxed agent-scope loads: never served from a stale L1 line)
+    int best = 0x7fffffff, bi = -1;
+    for (int b = tid; b < B; b += NT)
+      if (TMX_LD_RELAXED(&Bt->sched_state[b]) == 0)
+      {
+        const int key = TMX_LD_RELAXED(&Bt->n_qp[b]);
+        if (key < best)
+        {
+          best = key;
+          bi = b;
+        }
+      }
+    ibuf[tid] = best;
+    ibuf[NT + tid] = bi;
+    TMX_SYNC();
+    if (tid == 0)
     {
-      convexify_terms(P, x, act, coef, rhs, tid, NT);
-      qp_structure(P, act, coef, rhs, x, Bt->trust[b], Bt->merit + (size_t)b * P->n_cnts, Bt->dims + 4 * b,
-                   Bt->hashes + 4 * b, nullptr, reinterpret_cast<int*>(smem), tid, NT);
+      int kb = 0x7fffffff, kbi = -1;
+      for (int q = 0; q < NT; ++q)
+        if (ibuf[NT + q] >= 0 && ibuf[q] < kb)
+        {
+          kb = ibuf[q];
+          kbi = ibuf[NT + q];
+        }
+      int decision;
+      if (kbi < 0)
+        decision = (TMX_LD_RELAXED(Bt->sched_done) >= B) ? -1 : -2;  // all done | nothing ready right now
+      else
+      {
+#if TMX_IS_DEVICE
+        decision = (atomicCAS(&Bt->sched_state[kbi], 0, 1) == 0) ? kbi : -2;
+#else
+        int expect = 0;
+        decision = __atomic_compare_exchange_n(&Bt->sched_state[kbi], &expect, 1, false, __ATOMIC_ACQ_REL, __ATOMIC_RELAXED) ? kbi : -2;
+#endif
+      }
+      ibuf[2 * NT] = decision;
+#if TMX_IS_DEVICE
+      if (decision >= 0)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // drop this CU's stale L1 lines of the claimed problem
+#endif
     }
     TMX_SYNC();
-    qp_solve_block(P, Bt, b, smem, tid, NT);
-    for (int v = tid; v < NX; v += NT)
-      xn[v] = xq[v];
+    const int b = ibuf[2 * NT];
     TMX_SYNC();
-    evaluate_terms(P, xn, Bt->new_cost_vals + (size_t)b * P->n_costs, Bt->new_cnt_viols + (size_t)b * P->n_cnts, smem, tid, NT);
-    sqp_update_block(P, Bt, b, smem, tid, NT);
-    TMX_SYNC();
+    if (b == -1)
+      break;
+    if (b == -2)
+    {
+#if TMX_IS_DEVICE
+      __builtin_amdgcn_s_sleep(64);
+      if (++spins > (1u << 26))
+        break;  // bounded spin (never reached: every claimed problem is released)
+#endif
+      continue;
+    }
+    sqp_step_block(P, Bt, b, smem, tid, NT);  // ends with a workgroup barrier after all stores
+    if (tid == 0)
+    {
+      const bool done = Bt->phase[b] == PHASE_DONE;
+#if TMX_IS_DEVICE
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+      TMX_ST_RELAXED(&Bt->sched_state[b], done ? 2 : 0);
+      if (done)
+      {
+#if TMX_IS_DEVICE
+        atomicAdd(Bt->sched_done, 1);
+#else
+        __atomic_fetch_add(Bt->sched_done, 1, __ATOMIC_RELAXED);
+#endif
+      }
+    }
   }
 }
 

@@ -320,7 +320,7 @@ TMX_DEVFN void part_chain(const QpWs& w, int t0, int t1, int lane)
 }
 
 // ---- solve driver: rhs in w.tp, solution in w.tp ----------------------------------------------------------------
-TMX_DEVFN void part_solve(const QpWs& w, int tid, int NT)
+TMX_DEVFN void part_solve(const QpWs& w, int tid, int NT, long long* pc, long long& tlast)
 {
   const int D = w.D, DD = D * D;
   Part p;
@@ -328,6 +328,7 @@ TMX_DEVFN void part_solve(const QpWs& w, int tid, int NT)
   const int wave = tid >> 6, lane = tid & 63;
   part_chain(w, p.a[wave], p.b[wave], lane);
   TMX_SYNC();
+  TMX_TICK(3);
   const int n3 = 3 * D;
   double* rs = w.Zs + n3 * n3 + n3;  // n3 scratch: separator rhs
   if (tid < n3)
@@ -338,19 +339,18 @@ TMX_DEVFN void part_solve(const QpWs& w, int tid, int NT)
   TMX_SYNC();
   if (tid < n3)
   {
+    // 3D-term dot product as D independent partial sums of 3 (dependent depth 3 FMA + 3 add)
     const double* Zr = w.Zs + tid * n3;
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-    int n = 0;
-    for (; n + 2 < n3; n += 3)
-    {
-      s0 += Zr[n] * rs[n];
-      s1 += Zr[n + 1] * rs[n + 1];
-      s2 += Zr[n + 2] * rs[n + 2];
-    }
-    for (; n < n3; ++n)
-      s0 += Zr[n] * rs[n];
+    double ps[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      ps[q] = 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      if (q < D)
+        ps[q] = __builtin_fma(Zr[2 * D + q], rs[2 * D + q], __builtin_fma(Zr[D + q], rs[D + q], Zr[q] * rs[q]));
     const int k = tid / D, i = tid % D;
-    w.tp[p.s[k] * D + i] = (s0 + s1) + s2;
+    w.tp[p.s[k] * D + i] = ((ps[0] + ps[1]) + (ps[2] + ps[3])) + ((ps[4] + ps[5]) + (ps[6] + ps[7]));
   }
   TMX_SYNC();
   // spike correction of the interior blocks:  x_t -= WL[t] x_{s_left} + WR[t] x_{s_right}
@@ -367,24 +367,25 @@ TMX_DEVFN void part_solve(const QpWs& w, int tid, int NT)
       }
     if (!interior)
       continue;
-    double s0 = 0.0, s1 = 0.0;
-    if (k > 0)
-    {
-      const double* W = w.WL + t * DD + i * D;
-      const double* xs = w.tp + p.s[k - 1] * D;
-      for (int j = 0; j < D; ++j)
-        s0 += W[j] * xs[j];
-    }
-    if (k < 3)
-    {
-      const double* W = w.WR + t * DD + i * D;
-      const double* xs = w.tp + p.s[k] * D;
-      for (int j = 0; j < D; ++j)
-        s1 += W[j] * xs[j];
-    }
+    const double* WLr = w.WL + t * DD + i * D;
+    const double* WRr = w.WR + t * DD + i * D;
+    const double* xl = w.tp + p.s[k > 0 ? k - 1 : 0] * D;
+    const double* xr = w.tp + p.s[k < 3 ? k : 2] * D;
+    // a missing neighbour has an all-zero spike (part_spikes), so both products are always formed: 2D terms as D
+    // independent partial sums of 2
+    double ps[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      ps[q] = 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      if (q < D)
+        ps[q] = __builtin_fma(WRr[q], xr[q], WLr[q] * xl[q]);
+    const double s0 = (ps[0] + ps[1]) + (ps[2] + ps[3]), s1 = (ps[4] + ps[5]) + (ps[6] + ps[7]);
     w.tp[v] -= (s0 + s1);  // only interior rows are written; only separator rows and the own row are read
   }
   TMX_SYNC();
+  TMX_TICK(4);
 }
 
 // sequential (one-sided) inversion of the whole chain by wave 0 — used for the polish factorisation
@@ -529,7 +530,7 @@ TMX_DEVFN void row_phase_c(RowRegs& g, double alpha, double dot, const double ta
 
 // runs ADMM iterations first..last (inclusive) without any residual check; state is loaded from / stored to LDS
 // around the batch.  `keep_last` stores delta_x / delta_y of the final iteration (needed by the termination test).
-TMX_DEVFN void admm_run_fast(const QpWs& w, const DevProblem* P, int n_iter, bool keep_last, int tid)
+TMX_DEVFN void admm_run_fast(const QpWs& w, const DevProblem* P, int n_iter, bool keep_last, int tid, long long* pc, long long& tlast)
 {
   const int D = w.D;
   RowRegs g0, g1;
@@ -542,6 +543,27 @@ TMX_DEVFN void admm_run_fast(const QpWs& w, const DevProblem* P, int n_iter, boo
   const double rbp = rho_of_type(w.typ_bp[v], w.rho), rbpi = 1.0 / rbp;
   const double sigma = w.sigma, alpha = w.alpha, om = 1.0 - alpha;
   const int tb0 = g0.t * D, tb1 = g1.t * D;
+  // column v of A restricted to the rows of its waypoint, kept in registers (first 16 rows; a longer list falls back
+  // to the LDS gather for the remainder): A'e needs only the hr[] loads per iteration
+#ifndef TMX_NO_CJ
+  double cj[16];
+  int ri[16];
+  int q_rest = 0, q_end = 0;
+  {
+    const int t = v / D, j = v % D;
+    const int q0 = w.wp_start[t], q1 = w.wp_start[t + 1];
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+    {
+      const bool ok = pv && (q0 + k < q1);
+      const int r = ok ? w.wp_list[q0 + k] : 0;
+      ri[k] = r;
+      cj[k] = ok ? w.coef[r * D + j] : 0.0;
+    }
+    q_rest = q0 + 16;
+    q_end = q1;
+  }
+#endif
   for (int it = 0; it < n_iter; ++it)
   {
     const bool keep = keep_last && (it == n_iter - 1);
@@ -556,10 +578,34 @@ TMX_DEVFN void admm_run_fast(const QpWs& w, const DevProblem* P, int n_iter, boo
     if (pv)
     {
       const double gb = rbp * zb - yb;
+#ifdef TMX_NO_CJ
       w.tp[v] = (sigma * xp - qv) + at_rows(w, P, w.hr, v) + bb * gb;
+#else
+      double e[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k)
+        e[k] = w.hr[ri[k]];
+      double a0 = cj[0] * e[0], a1 = cj[1] * e[1], a2 = cj[2] * e[2], a3 = cj[3] * e[3];
+#pragma unroll
+      for (int k = 4; k < 16; k += 4)
+      {
+        a0 = __builtin_fma(cj[k], e[k], a0);
+        a1 = __builtin_fma(cj[k + 1], e[k + 1], a1);
+        a2 = __builtin_fma(cj[k + 2], e[k + 2], a2);
+        a3 = __builtin_fma(cj[k + 3], e[k + 3], a3);
+      }
+      double ate = (a0 + a1) + (a2 + a3);
+      for (int q = q_rest; q < q_end; ++q)
+      {
+        const int r = w.wp_list[q];
+        ate += w.coef[r * D + (v % D)] * w.hr[r];
+      }
+      w.tp[v] = (sigma * xp - qv) + ate + bb * gb;
+#endif
     }
     TMX_SYNC();
-    part_solve(w, tid, 256);
+    TMX_TICK(2);
+    part_solve(w, tid, 256, pc, tlast);
     // phase C
     double xt[8], xu[8];
 #pragma unroll
@@ -614,6 +660,7 @@ TMX_DEVFN void admm_run_fast(const QpWs& w, const DevProblem* P, int n_iter, boo
         }
       }
     }
+    TMX_TICK(5);
     // the next iteration's phase A only touches registers; its hr stores are ordered after every thread's tp reads by
     // the barrier that follows them, and tp is rewritten only after that barrier
   }

@@ -27,6 +27,7 @@ extern thread_local double* tmx_emu_smem;
 #define TMX_HOSTDEVFN static inline
 #define TMX_KERNEL static void
 #define TMX_KERNEL_LB(nt) static void
+#define TMX_KERNEL_LB2(nt, w) static void
 #define TMX_SMEM(name) double* name = tmx_emu_smem
 #define TMX_SYNC() ((void)0)
 #define TMX_IS_DEVICE 0
@@ -102,6 +103,7 @@ static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t
 #define TMX_KERNEL __global__ void
 // workgroup-size contract: lets the register allocator use the whole 512-VGPR file at one wave per SIMD
 #define TMX_KERNEL_LB(nt) __global__ void __launch_bounds__(nt)
+#define TMX_KERNEL_LB2(nt, w) __global__ void __launch_bounds__(nt, w)
 #define TMX_SMEM(name) extern __shared__ __attribute__((aligned(16))) double name[]
 #define TMX_SYNC() __syncthreads()
 #define TMX_IS_DEVICE 1

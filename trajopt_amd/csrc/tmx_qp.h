@@ -27,6 +27,21 @@
 #define TMX_RHO_EQ_OVER_INEQ 1e3
 #define TMX_DIVISION_TOL 1e-30
 
+// ---- phase profiler (thread-0 view, shader clock) ---
+#if TMX_IS_DEVICE && defined(TMX_PROFILE)
+#define TMX_CLK() ((long long)__builtin_readcyclecounter())
+#else
+#define TMX_CLK() 0LL  // the profiler is opt-in (-DTMX_PROFILE): s_memtime costs ~100 cycles per tick
+#endif
+#define TMX_TICK(slot)                                                                                                \
+  do                                                                                                                  \
+  {                                                                                                                   \
+    const long long now_ = TMX_CLK();                                                                                 \
+    pc[slot] += now_ - tlast;                                                                                         \
+    tlast = now_;                                                                                                     \
+  } while (0)
+
+
 // ---- block reductions -------------------------------------------------------------------------------
 #if TMX_IS_DEVICE
 template <int K>
@@ -98,15 +113,42 @@ struct QpWs
   int *wp_start, *wp_list;  // LDS copies of DevProblem::wp_start / wp_list (hot in every SpMV)
 };
 
-TMX_HOSTDEVFN size_t qp_ws_doubles(int D, int T, int R, int NA)
+// The workspace is split by access frequency:
+//   HOT  (LDS, touched every ADMM iteration): the two exchange vectors tp / hr, the coupling po, the block factor
+//        Sinv, the spikes WL / WR, the separator Schur inverse Zs and small scratch          (~47 KB for config 1)
+//   COLD (per-problem global scratch, L2 / Infinity-Cache resident): the "home" copies of the iterates and of the
+//        scaled problem data, touched only at setup (Ruiz), at the residual checks (every 25 iterations), at the
+//        burst boundaries of the register-resident loop and in the polish step                 (~110 KB)
+// which lets 2-3 workgroups share a CU so that their fp64 latency chains overlap.
+// Workspace placement.  1 (default): the whole per-problem workspace lives in LDS (~150 KB for the 7x30 problem) -> one
+// workgroup per CU with the full 512-VGPR budget: lowest latency per problem, which is what a 1024-seed batch on 256
+// CUs needs.  0: only the arrays the ADMM iteration touches stay in LDS (~48 KB), the cold ones go to a per-problem
+// HBM scratch -> 2 workgroups per CU at 256 VGPRs (measured: 1.29x CU throughput, 1.5x per-problem latency).
+#ifndef TMX_QP_COLD_IN_LDS
+#define TMX_QP_COLD_IN_LDS 1
+#endif
+TMX_HOSTDEVFN size_t qp_lds_doubles(int D, int T, int R, int NA)
 {
-  const int NX = D * T;
-  size_t n = 14 * (size_t)NX + 8 * (size_t)R + (size_t)R * D + 12 * (size_t)NA + (size_t)T * D * (D <= 8 ? 8 : D) + 2 * (size_t)T * D * D + 9 * (size_t)D * D + 6 * (size_t)D + (size_t)D * D + 98;
-  size_t ints = 9 * (size_t)R + 2 * (size_t)NX + 2 * (size_t)NA + (size_t)T + 2;
+  const size_t NX = (size_t)D * T;
+  (void)NA;
+  return 2 * NX + (size_t)R + (size_t)T * D * (D <= 8 ? 8 : D) + 2 * (size_t)T * D * D + 9 * (size_t)D * D + 6 * (size_t)D +
+         (size_t)D * D + 98 + 4;
+}
+TMX_HOSTDEVFN size_t qp_glb_doubles(int D, int T, int R, int NA);
+// dynamic LDS bytes of the QP kernels for the chosen placement
+TMX_HOSTDEVFN size_t qp_smem_bytes(int D, int T, int R, int NA)
+{
+  return (qp_lds_doubles(D, T, R, NA) + (TMX_QP_COLD_IN_LDS ? qp_glb_doubles(D, T, R, NA) : 0)) * sizeof(double);
+}
+TMX_HOSTDEVFN size_t qp_glb_doubles(int D, int T, int R, int NA)
+{
+  const size_t NX = (size_t)D * T;
+  const size_t n = 12 * NX + 7 * (size_t)R + (size_t)R * D + 12 * (size_t)NA;
+  const size_t ints = 9 * (size_t)R + 2 * NX + 2 * (size_t)NA + (size_t)T + 2;
   return n + (ints + 1) / 2 + 8;
 }
 
-TMX_DEVFN void qp_ws_carve(QpWs& w, double* base, int D, int T, int R, int NA)
+TMX_DEVFN void qp_ws_carve(QpWs& w, double* lds, double* glb, int D, int T, int R, int NA)
 {
   w.D = D;
   w.T = T;
@@ -114,10 +156,24 @@ TMX_DEVFN void qp_ws_carve(QpWs& w, double* base, int D, int T, int R, int NA)
   w.R = R;
   w.NA = NA;
   const int NX = w.NX;
-  double* p = base;
+  // ---- hot: LDS
+  double* p = lds;
 #define TAKE(name, n)                                                                                                 \
   w.name = p;                                                                                                         \
   p += (n)
+  w.DS = (D <= 8) ? 8 : D;
+  w.DDS = D * w.DS;
+  TAKE(Sinv, T * D * w.DS);  // first: 16-byte aligned for the double2 row loads
+  TAKE(WL, T * D * D);
+  TAKE(WR, T * D * D);
+  TAKE(Zs, 9 * D * D + 6 * D);
+  TAKE(tp, NX);
+  TAKE(po, NX);
+  TAKE(hr, R);
+  TAKE(gj, D * D);
+  TAKE(red, 96);
+  // ---- cold: global scratch
+  p = glb;
   TAKE(xp, NX);
   TAKE(zbp, NX);
   TAKE(ybp, NX);
@@ -127,9 +183,7 @@ TMX_DEVFN void qp_ws_carve(QpWs& w, double* base, int D, int T, int R, int NA)
   TAKE(Dp, NX);
   TAKE(Ebp, NX);
   TAKE(bbp, NX);
-  TAKE(tp, NX);
   TAKE(pd, NX);
-  TAKE(po, NX);
   TAKE(dxp, NX);
   TAKE(dybp, NX);
   TAKE(zr, R);
@@ -137,8 +191,8 @@ TMX_DEVFN void qp_ws_carve(QpWs& w, double* base, int D, int T, int R, int NA)
   TAKE(lor, R);
   TAKE(hir, R);
   TAKE(Er, R);
-  TAKE(hr, R);
   TAKE(dyr, R);
+  TAKE(fac, R);
   TAKE(coef, R * D);
   TAKE(xa, NA);
   TAKE(zba, NA);
@@ -152,17 +206,6 @@ TMX_DEVFN void qp_ws_carve(QpWs& w, double* base, int D, int T, int R, int NA)
   TAKE(dxa, NA);
   TAKE(dyba, NA);
   TAKE(dinv, NA);
-  TAKE(fac, R);
-  w.DS = (D <= 8) ? 8 : D;
-  w.DDS = D * w.DS;
-  if ((p - base) & 1)
-    ++p;  // 16-byte alignment for the double2 row loads
-  TAKE(Sinv, T * D * w.DS);
-  TAKE(WL, T * D * D);
-  TAKE(WR, T * D * D);
-  TAKE(Zs, 9 * D * D + 6 * D);
-  TAKE(gj, D * D);
-  TAKE(red, 96);
 #undef TAKE
   int* ip = reinterpret_cast<int*>(p);
 #define TAKEI(name, n)                                                                                                \

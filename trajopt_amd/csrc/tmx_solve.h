@@ -435,25 +435,16 @@ static inline void debug_kkt_residual(const QpWs& w, const DevProblem* P, int it
 }
 #endif
 
-#if TMX_IS_DEVICE
-#define TMX_CLK() ((long long)__builtin_readcyclecounter())
-#else
-#define TMX_CLK() 0LL
-#endif
-#define TMX_TICK(slot)                                                                                                \
-  do                                                                                                                  \
-  {                                                                                                                   \
-    const long long now_ = TMX_CLK();                                                                                 \
-    pc[slot] += now_ - tlast;                                                                                         \
-    tlast = now_;                                                                                                     \
-  } while (0)
-
 TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, double* smem, int tid, int NT)
 {
   const int D = P->D, T = P->T, NX = P->NX, R = P->R;
   const tmx_osqp_settings& st = P->osqp;
   QpWs w;
-  qp_ws_carve(w, smem, D, T, R, P->NA);
+#if TMX_QP_COLD_IN_LDS
+  qp_ws_carve(w, smem, smem + qp_lds_doubles(D, T, R, P->NA), D, T, R, P->NA);
+#else
+  qp_ws_carve(w, smem, Bt->qp_scratch + (size_t)b * Bt->qp_scratch_stride, D, T, R, P->NA);
+#endif
   long long pc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
   long long tlast = TMX_CLK();
   const int* g_act = Bt->active + (size_t)b * R;
@@ -755,9 +746,8 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
         next = min(next, ((iter - 1) / st.check_termination + 1) * st.check_termination);
       if (st.adaptive_rho && st.adaptive_rho_interval)
         next = min(next, ((iter - 1) / st.adaptive_rho_interval + 1) * st.adaptive_rho_interval);
-      admm_run_fast(w, P, next - iter + 1, true, tid);
+      admm_run_fast(w, P, next - iter + 1, true, tid, pc, tlast);
       iter = next;
-      TMX_TICK(4);
     }
 #endif
     can_check = st.check_termination && (iter % st.check_termination == 0);

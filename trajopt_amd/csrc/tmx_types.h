@@ -78,5 +78,9 @@ struct DevBatch
   int *rec_count;
   long long *admm_iters;
   int *n_active;  // single int: number of problems not DONE
+  int *sched_state;    // B: 0 ready, 1 claimed by a workgroup, 2 done   (k_sqp_pool)
+  int *sched_done;     // 1: number of finished problems
+  double *qp_scratch;  // B x qp_glb_doubles: cold part of the k_qp_solve workspace
+  long long qp_scratch_stride;
   long long *prof;  // B x 8 phase cycle counters of the last k_qp_solve (thread 0 view): setup, factor, A, B, chain, C, check, polish
 };
