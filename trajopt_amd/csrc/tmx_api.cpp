@@ -485,13 +485,13 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
     return TMX_ERR_UNSUPPORTED;
   }
   // one problem per CU when the workspace is large: use 4 waves so the data-parallel phases go 4x wider
-  ctx->nt_qp = 256;  // 4 waves: one interior of the partitioned block solve each
+  ctx->nt_qp = TMX_QP_NT;
   ctx->nt_small = 64;
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_qp_solve), hipFuncAttributeMaxDynamicSharedMemorySize,
                              static_cast<int>(ctx->smem_qp)));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sqp_fused), hipFuncAttributeMaxDynamicSharedMemorySize,
                              static_cast<int>(ctx->smem_qp)));
-  ctx->smem_pool = std::max<size_t>(ctx->smem_qp, (2 * 256 + 8) * sizeof(int));
+  ctx->smem_pool = std::max<size_t>(ctx->smem_qp, (2 * TMX_QP_NT + 8) * sizeof(int));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sqp_pool), hipFuncAttributeMaxDynamicSharedMemorySize,
                              static_cast<int>(ctx->smem_pool)));
   {
@@ -500,9 +500,9 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess)
       cus = prop.multiProcessorCount;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sqp_pool, 256, ctx->smem_pool) != hipSuccess || per_cu < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sqp_pool, TMX_QP_NT, ctx->smem_pool) != hipSuccess || per_cu < 1)
       per_cu = 1;
-    per_cu = std::min(per_cu, TMX_QP_WAVES_PER_SIMD);
+    per_cu = std::min(per_cu, TMX_QP_WGS_PER_CU);
     ctx->pool_wgs = cus * per_cu;
     if (const char* e = std::getenv("TMX_POOL_WGS"))  // tuning hook
       ctx->pool_wgs = std::max(1, std::atoi(e));
@@ -571,11 +571,11 @@ static tmx_status ensure_batch(tmx_ctx* ctx, int B)
   AL(rec_count, b);
   AL(admm_iters, b);
   AL(n_active, 1);
-  AL(prof, b * 8);
+  AL(prof, b * 16);
   AL(sched_state, b);
   AL(sched_done, 1);
-  H.qp_scratch_stride = (long long)qp_glb_doubles(P.D, P.T, P.R, P.NA);
-  AL(qp_scratch, (TMX_QP_COLD_IN_LDS ? 1 : b) * (size_t)H.qp_scratch_stride);
+  H.qp_scratch_stride = (long long)qp_scratch_doubles(P.D, P.T, P.R, P.NA);
+  AL(qp_scratch, b * (size_t)H.qp_scratch_stride);
 #undef AL
   if (!ctx->db)
   {
@@ -998,17 +998,17 @@ tmx_status tmx_kernel_stats(tmx_ctx* ctx, double* admm_ms_total, int64_t* admm_l
 }
 
 // debug/profiling hook (not part of include/tmx.h): per-phase shader-clock cycles of the last k_qp_solve, summed over problems
-__attribute__((visibility("default"))) tmx_status tmx_debug_phase_cycles(tmx_ctx* ctx, long long* out8)
+__attribute__((visibility("default"))) tmx_status tmx_debug_phase_cycles(tmx_ctx* ctx, long long* out16)
 {
-  if (!ctx || !out8 || ctx->Bcap == 0)
+  if (!ctx || !out16 || ctx->Bcap == 0)
     return TMX_ERR_INVALID;
-  std::vector<long long> h((size_t)ctx->hb.B * 8);
+  std::vector<long long> h((size_t)ctx->hb.B * 16);
   HIPCHK(hipMemcpy(h.data(), ctx->hb.prof, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
-  for (int k = 0; k < 8; ++k)
-    out8[k] = 0;
+  for (int k = 0; k < 16; ++k)
+    out16[k] = 0;
   for (int b = 0; b < ctx->hb.B; ++b)
-    for (int k = 0; k < 8; ++k)
-      out8[k] += h[(size_t)b * 8 + k];
+    for (int k = 0; k < 16; ++k)
+      out16[k] += h[(size_t)b * 16 + k];
   return TMX_OK;
 }
 

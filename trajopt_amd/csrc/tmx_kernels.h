@@ -42,6 +42,8 @@ TMX_KERNEL_LB(256) k_prepare(const DevProblem* P, const DevBatch* Bt)
     Bt->rec_count[b] = 0;
     Bt->admm_iters[b] = 0;
     Bt->total_cost[b] = 0.0;
+    for (int q = 0; q < 16; ++q)
+      Bt->prof[(size_t)b * 16 + q] = 0;
     Bt->sched_state[b] = 0;
     if (b == 0)
       *Bt->sched_done = 0;
@@ -95,10 +97,10 @@ TMX_KERNEL k_export_csc(const DevProblem* P, const DevBatch* Bt, int b, CscOut o
 }
 
 // K5: Model::optimize() for every running problem; also publishes new_x = first NX model vars (optimizers.cpp:396)
-#ifndef TMX_QP_WAVES_PER_SIMD
-#define TMX_QP_WAVES_PER_SIMD (TMX_QP_COLD_IN_LDS ? 1 : 2)  // workgroups of 256 threads per CU the register allocator must leave room for
+#ifndef TMX_QP_WGS_PER_CU
+#define TMX_QP_WGS_PER_CU 1  // workgroups of 256 threads per CU the register allocator must leave room for
 #endif
-TMX_KERNEL_LB2(256, TMX_QP_WAVES_PER_SIMD) k_qp_solve(const DevProblem* P, const DevBatch* Bt, int force)
+TMX_KERNEL_LB2(TMX_QP_NT, TMX_QP_WGS_PER_CU) k_qp_solve(const DevProblem* P, const DevBatch* Bt, int force)
 {
   TMX_SMEM(smem);
   const int b = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
@@ -129,6 +131,9 @@ TMX_DEVFN void sqp_step_block(const DevProblem* P, const DevBatch* Bt, int b, do
   double* x = Bt->x + (size_t)b * NX;
   double* xn = Bt->xnew + (size_t)b * NX;
   const double* xq = Bt->xq + (size_t)b * P->n_max;
+#ifdef TMX_PROFILE
+  long long tp0 = TMX_CLK();
+#endif
   if (Bt->phase[b] == PHASE_CONVEXIFY)
   {
     convexify_terms(P, x, act, coef, rhs, tid, NT);
@@ -136,18 +141,29 @@ TMX_DEVFN void sqp_step_block(const DevProblem* P, const DevBatch* Bt, int b, do
                  nullptr, reinterpret_cast<int*>(smem), tid, NT);
   }
   TMX_SYNC();
+#ifdef TMX_PROFILE
+  if (tid == 0)
+    Bt->prof[(size_t)b * 16 + 11] += TMX_CLK() - tp0;
+#endif
   qp_solve_block(P, Bt, b, smem, tid, NT);
+#ifdef TMX_PROFILE
+  tp0 = TMX_CLK();
+#endif
   for (int v = tid; v < NX; v += NT)
     xn[v] = xq[v];
   TMX_SYNC();
   evaluate_terms(P, xn, Bt->new_cost_vals + (size_t)b * P->n_costs, Bt->new_cnt_viols + (size_t)b * P->n_cnts, smem, tid, NT);
   sqp_update_block(P, Bt, b, smem, tid, NT);
   TMX_SYNC();
+#ifdef TMX_PROFILE
+  if (tid == 0)
+    Bt->prof[(size_t)b * 16 + 12] += TMX_CLK() - tp0;
+#endif
 }
 
 // Fused optimize(): one workgroup carries its problem through the whole BasicTrustRegionSQP run without returning to the
 // host.  `max_steps` bounds the number of trust-region evaluations done in this launch (0 = until DONE).
-TMX_KERNEL_LB2(256, TMX_QP_WAVES_PER_SIMD) k_sqp_fused(const DevProblem* P, const DevBatch* Bt, int max_steps)
+TMX_KERNEL_LB2(TMX_QP_NT, TMX_QP_WGS_PER_CU) k_sqp_fused(const DevProblem* P, const DevBatch* Bt, int max_steps)
 {
   TMX_SMEM(smem);
   const int b = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
@@ -173,7 +189,7 @@ TMX_KERNEL_LB2(256, TMX_QP_WAVES_PER_SIMD) k_sqp_fused(const DevProblem* P, cons
 #define TMX_LD_RELAXED(p) __atomic_load_n((p), __ATOMIC_RELAXED)
 #define TMX_ST_RELAXED(p, v) __atomic_store_n((p), (v), __ATOMIC_RELAXED)
 #endif
-TMX_KERNEL_LB2(256, TMX_QP_WAVES_PER_SIMD) k_sqp_pool(const DevProblem* P, const DevBatch* Bt)
+TMX_KERNEL_LB2(TMX_QP_NT, TMX_QP_WGS_PER_CU) k_sqp_pool(const DevProblem* P, const DevBatch* Bt)
 {
   TMX_SMEM(smem);
   const int tid = threadIdx.x, NT = blockDim.x;

@@ -1,44 +1,30 @@
 // tmx_part.h — device-only fast path of the ADMM inner loop (included by tmx_qp.h under TMX_IS_DEVICE).
 //
-// (1) PARTITIONED BLOCK SOLVE.  The reduced KKT matrix is block tridiagonal (T blocks of D x D, diagonal coupling
-//     blocks).  A lone wave running the 2T-step substitution chain exposes every fp64 / LDS latency (measured in
-//     tools/ubench: dependent v_fma_f64 40 cycles, ds_read 80, a 2-MFMA f64 16x16x4 chain step ~420), so the chain is
-//     cut by nested dissection into FOUR interiors separated by three single-block separators; each of the 4 waves of
-//     the workgroup owns one interior:
-//        factor :  per interior  Sinv_t (block LDL' with explicit inverse Schur complements, Gauss-Jordan in
-//                  registers), the spikes  WL = M_int^-1 E_left,  WR = M_int^-1 E_right  (D right-hand sides at
-//                  once: this is matmul-shaped, done with v_mfma_f64_16x16x4_f64 whose D-layout is the next step's
-//                  B-layout), then the 3D x 3D Schur complement on the separators and its dense inverse Zs.
-//        solve  :  4 interior chains in parallel (one per wave)  ->  separator rhs  ->  Zs mat-vec  ->  spike
-//                  correction.  Chain depth drops from 2T-1 = 59 to 13 block steps.
-// (2) REGISTER-RESIDENT ITERATES.  Thread `tid` owns rows tid and tid+256 (with their aux vars) and primary var tid;
-//     their iterate and data stay in registers between residual checks; LDS carries only the exchange vectors.
-// Preconditions (checked by the caller): blockDim.x == 256, R <= 512, NX <= 256, D <= 8, T >= 7.
+// (1) DENSE NESTED-DISSECTION SOLVE.  The reduced KKT matrix is block tridiagonal (T blocks of D x D, diagonal coupling
+//     blocks).  Block substitution is a chain of 2T-1 dependent D x D mat-vecs, and on one CU every link pays the
+//     fp64 / LDS latency (tools/ubench: dependent v_fma_f64 44 cycles, ds_read ~80): measured ~480 cycles per block
+//     step even after cutting the chain into 4 interiors.  The solve is therefore made DEPTH-FREE: the T blocks are
+//     split into P <= 8 interiors of <= Lmax blocks separated by P-1 single-block separators, and the factorisation
+//     stores EXPLICIT inverses
+//        G_k  = (interior diagonal sub-matrix k)^-1          (Lmax*D)^2 each, Gauss-Jordan by one wave per interior
+//        Zs   = (Schur complement on the separators)^-1      ((P-1)*D)^2, Gauss-Jordan by the workgroup
+//     so that one solve is three short, fully thread-parallel phases (one variable per thread, no chains):
+//        y_int = G_k b_int  ->  x_sep = Zs (b_sep - C y_adjacent)  ->  x_int = y_int - G_k[:, first/last block] (C x_sep)
+//     (21-, 49- and 14-term dot products for the 7-DOF / 30-waypoint problem).  All of it lives in LDS (~50 KB).
+// (2) REGISTER-RESIDENT ITERATES.  Thread `tid` owns the constraint rows tid (+ NT) with their aux vars; NX of the
+//     threads also own one primary var; their iterate and data stay in registers between residual checks; LDS carries
+//     only the exchange vectors.
+// Preconditions (checked by the caller): blockDim.x == TMX_QP_NT (256 or 512), R <= 512, NX <= 256, D <= 8, (P-1)*D <= 64.
 #pragma once
 
-typedef double tmx_v4d __attribute__((ext_vector_type(4)));
-
-struct Part
-{
-  int a[4], b[4], s[3];
-};
-TMX_DEVFN void part_make(int T, Part& p)
-{
-  const int L = T - 3, base = L / 4, rem = L % 4;
-  int t = 0;
-  for (int k = 0; k < 4; ++k)
-  {
-    const int len = base + (k < rem ? 1 : 0);
-    p.a[k] = t;
-    p.b[k] = t + len - 1;
-    t += len;
-    if (k < 3)
-    {
-      p.s[k] = t;
-      t += 1;
-    }
-  }
-}
+// wave-synchronous LDS exchange: LDS operations of one wave execute in order; the fence keeps the compiler from
+// reordering across it and waits for outstanding LDS traffic
+#define TMX_WAVE_SYNC()                                                                                               \
+  do                                                                                                                  \
+  {                                                                                                                   \
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");                                                            \
+    __builtin_amdgcn_wave_barrier();                                                                                  \
+  } while (0)
 
 // ---- factor, step 1: Schur complements of one interior inverted by one wave (one matrix entry per lane) ------------
 TMX_DEVFN void part_invert_interior(const QpWs& w, int t0, int t1, int lane)
@@ -73,319 +59,354 @@ TMX_DEVFN void part_invert_interior(const QpWs& w, int t0, int t1, int lane)
   }
 }
 
-// ---- factor, step 2: spikes of one interior with MFMA (matrix right-hand side, D columns) ---------------------------
-// register layout of v_mfma_f64_16x16x4_f64:  A[i = l&15][k = l>>4],  B[k = l>>4][j = l&15],  D[(l>>4) + 4r][l&15] in
-// register r  =>  for K-chunk c the B operand of the next product is register c of the previous result.
-TMX_DEVFN void part_spikes(const QpWs& w, int t0, int t1, bool has_left, bool has_right, int lane)
+// ---- thread roles in the dense solve --------------------------------------------------------------------------------
+//   thread m < NI              : owns interior variable m (phases 1 and 3, rhs assembly, primary update)
+//   thread NI + g, g < ns      : owns separator variable g (rhs assembly, primary update)
+//   threads 4g .. 4g+3, g < ns : the four column quarters of row g of the separator system (phase 2); thread 4g
+//                                publishes x_sep[g] and its coupling products
+struct DMap
 {
-  const int D = w.D, DD = D * D, DS = w.DS, DDS = w.DDS;
-  const int i = lane & 15, kq = lane >> 4, j = lane & 15;
-  const bool iok = i < D, jok = j < D;
-  const int k0 = kq, k1 = kq + 4;
-  const bool k0ok = k0 < D, k1ok = k1 < D;
-  // zero the spikes of this interior (a missing neighbour leaves a zero spike)
-  for (int e = lane; e < (t1 - t0 + 1) * DD; e += 64)
+  int v;      // primary variable owned by this thread (-1: none)
+  bool sep;   // owns a separator variable
+  int k;      // interior index | separator block index
+  int r, n;   // interior: local row and dimension len*D
+  int slot;   // position of the variable's right-hand side in the permuted rhs buffer ty
+  bool hasl, hasr;    // interior: has a separator on the left / right
+  bool first, last;   // interior: row lies in the first / last block of its interior
+  int qg, qq;         // separator row handled in phase 2 (-1: none) and column quarter
+  int qv;             // variable index of separator row qg
+};
+TMX_DEVFN bool dpart_supported(const QpWs& w, int NT)
+{
+  if (w.D > 8 || w.G == nullptr)
+    return false;
+  DPart p;
+  dpart_make(w.T, p);
+  return p.P >= 2 && (p.P - 1) * w.D <= 64 && w.NX <= 256 && w.NX <= NT;
+}
+TMX_DEVFN void dpart_map(const QpWs& w, const DPart& p, int tid, DMap& m)
+{
+  const int D = w.D, ns = (p.P - 1) * D, NI = w.NX - ns;
+  m.v = -1;
+  m.sep = false;
+  m.k = m.r = m.n = m.slot = 0;
+  m.hasl = m.hasr = m.first = m.last = false;
+  m.qg = (tid < 4 * ns) ? (tid >> 2) : -1;
+  m.qq = tid & 3;
+  m.qv = (m.qg >= 0) ? p.s[m.qg / D] * D + m.qg % D : D;
+  if (tid >= NI)
   {
-    w.WL[t0 * DD + e] = 0.0;
-    w.WR[t0 * DD + e] = 0.0;
+    const int g = tid - NI;
+    if (g < ns)
+    {
+      m.sep = true;
+      m.k = g / D;
+      m.v = p.s[m.k] * D + g % D;
+      m.slot = p.P * w.Gs + g;
+    }
+    return;
   }
-  if (has_left)
-  {
-    // forward: V_t0 = Cd_{t0-1} ; V_t = -diag(c_t) Sinv_{t-1} V_{t-1}
-    double v0 = (k0ok && jok && k0 == j) ? w.po[(t0 - 1) * D + j] : 0.0;
-    double v1 = (k1ok && jok && k1 == j) ? w.po[(t0 - 1) * D + j] : 0.0;
-    if (k0ok && jok)
-      w.WL[t0 * DD + k0 * D + j] = v0;
-    if (k1ok && jok)
-      w.WL[t0 * DD + k1 * D + j] = v1;
-    for (int t = t0 + 1; t <= t1; ++t)
+  int q = tid;
+  for (int k = 0; k < 8; ++k)
+    if (k < p.P)
     {
-      const double ci = iok ? -w.po[(t - 1) * D + i] : 0.0;
-      const double A0 = (iok && k0ok) ? ci * w.Sinv[(t - 1) * DDS + i * DS + k0] : 0.0;
-      const double A1 = (iok && k1ok) ? ci * w.Sinv[(t - 1) * DDS + i * DS + k1] : 0.0;
-      tmx_v4d acc = { 0.0, 0.0, 0.0, 0.0 };
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A0, v0, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A1, v1, acc, 0, 0, 0);
-      v0 = acc[0];
-      v1 = acc[1];
-      if (k0ok && jok)
-        w.WL[t * DD + k0 * D + j] = v0;
-      if (k1ok && jok)
-        w.WL[t * DD + k1 * D + j] = v1;
-    }
-    // backward: X_t1 = Sinv_t1 V_t1 ; X_t = Sinv_t (V_t - Cd_t X_{t+1})
-    double x0 = 0.0, x1 = 0.0;
-    for (int t = t1; t >= t0; --t)
-    {
-      double u0 = (k0ok && jok) ? w.WL[t * DD + k0 * D + j] : 0.0;
-      double u1 = (k1ok && jok) ? w.WL[t * DD + k1 * D + j] : 0.0;
-      if (t < t1)
+      const int n = p.len[k] * D;
+      if (q >= 0 && q < n)
       {
-        if (k0ok)
-          u0 -= w.po[t * D + k0] * x0;
-        if (k1ok)
-          u1 -= w.po[t * D + k1] * x1;
+        m.k = k;
+        m.r = q;
+        m.n = n;
+        m.v = p.a[k] * D + q;
+        m.slot = k * w.Gs + q;
+        m.hasl = k > 0;
+        m.hasr = k < p.P - 1;
+        m.first = q < D;
+        m.last = q >= n - D;
       }
-      const double A0 = (iok && k0ok) ? w.Sinv[t * DDS + i * DS + k0] : 0.0;
-      const double A1 = (iok && k1ok) ? w.Sinv[t * DDS + i * DS + k1] : 0.0;
-      tmx_v4d acc = { 0.0, 0.0, 0.0, 0.0 };
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A0, u0, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A1, u1, acc, 0, 0, 0);
-      x0 = acc[0];
-      x1 = acc[1];
-      if (k0ok && jok)
-        w.WL[t * DD + k0 * D + j] = x0;
-      if (k1ok && jok)
-        w.WL[t * DD + k1 * D + j] = x1;
+      q -= n;
     }
+}
+
+// in-place Gauss-Jordan inverse of an SPD n x n matrix (n <= 32) by one wave; entries are spread over the lanes and
+// every elimination step is two wave-synchronous LDS passes (all loads, then all stores)
+TMX_DEVFN void gj_wave(double* M, int n, int stride, int lane)
+{
+  const int nn = n * n;
+  int off[16], ii[16], jj[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q)
+  {
+    const int e = lane + 64 * q;
+    const bool ok = e < nn;
+    ii[q] = ok ? e / n : -1;
+    jj[q] = ok ? e % n : 0;
+    off[q] = ok ? ii[q] * stride + jj[q] : 0;
   }
-  if (has_right)
+  for (int k = 0; k < n; ++k)
   {
-    // V_t = 0 for t < t1, V_t1 = Cd_t1  =>  X_t1 = Sinv_t1 Cd_t1 ; X_t = -Sinv_t Cd_t X_{t+1}
-    double x0 = 0.0, x1 = 0.0;
-    for (int t = t1; t >= t0; --t)
+    const double piv = 1.0 / M[k * stride + k];
+    double nv[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
     {
-      double u0, u1;
-      if (t == t1)
+      nv[q] = 0.0;
+      if (64 * q < nn)
       {
-        u0 = (k0ok && jok && k0 == j) ? w.po[t1 * D + j] : 0.0;
-        u1 = (k1ok && jok && k1 == j) ? w.po[t1 * D + j] : 0.0;
+        const int i = ii[q] < 0 ? 0 : ii[q], j = jj[q];
+        const double mij = M[off[q]], mik = M[i * stride + k], mkj = M[k * stride + j];
+        const double upd = mij - mik * mkj * piv;
+        nv[q] = (i == k) ? ((j == k) ? piv : mij * piv) : ((j == k) ? -mik * piv : upd);
       }
-      else
-      {
-        u0 = k0ok ? -w.po[t * D + k0] * x0 : 0.0;
-        u1 = k1ok ? -w.po[t * D + k1] * x1 : 0.0;
-      }
-      const double A0 = (iok && k0ok) ? w.Sinv[t * DDS + i * DS + k0] : 0.0;
-      const double A1 = (iok && k1ok) ? w.Sinv[t * DDS + i * DS + k1] : 0.0;
-      tmx_v4d acc = { 0.0, 0.0, 0.0, 0.0 };
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A0, u0, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A1, u1, acc, 0, 0, 0);
-      x0 = acc[0];
-      x1 = acc[1];
-      if (k0ok && jok)
-        w.WR[t * DD + k0 * D + j] = x0;
-      if (k1ok && jok)
-        w.WR[t * DD + k1 * D + j] = x1;
     }
+    TMX_WAVE_SYNC();
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+    {
+      if (64 * q < nn && ii[q] >= 0)
+        M[off[q]] = nv[q];
+    }
+    TMX_WAVE_SYNC();
   }
 }
 
-// ---- factor driver (ADMM weights): call after kkt_factor() has assembled the diagonal blocks --------------------
-TMX_DEVFN void part_factor(const QpWs& w, int tid, int NT)
+// ---- factor driver (ADMM weights): call after kkt_factor() has assembled the diagonal blocks into w.Sinv ----------
+TMX_DEVFN void dpart_factor(const QpWs& w, int tid, int NT)
 {
-  const int D = w.D, DD = D * D, DS = w.DS, DDS = w.DDS;
-  Part p;
-  part_make(w.T, p);
-  const int wave = tid >> 6, lane = tid & 63;
-  part_invert_interior(w, p.a[wave], p.b[wave], lane);
-  part_spikes(w, p.a[wave], p.b[wave], wave > 0, wave < 3, lane);
-  TMX_SYNC();
-  // Schur complement on the separators: Zs is (3D x 3D), row-major, n3 = 3D
-  const int n3 = 3 * D;
-  double* Z = w.Zs;
-  for (int e = tid; e < n3 * n3; e += NT)
+  const int D = w.D, DS = w.DS, DDS = w.DDS, Gn = w.Gn, Gs = w.Gs, Zst = w.Zst;
+  DPart p;
+  dpart_make(w.T, p);
+  // 1. interior diagonal sub-matrices (block tridiagonal with diagonal coupling blocks), zero padded
+  for (int e = tid; e < p.P * Gn * Gs; e += NT)
   {
-    const int rI = e / n3, cI = e % n3;
-    const int kr = rI / D, i = rI % D, kc = cI / D, j = cI % D;
-    const int s = p.s[kr];
+    const int k = e / (Gn * Gs), rem = e % (Gn * Gs), r = rem / Gs, c = rem % Gs, n = p.len[k] * D;
     double val = 0.0;
-    if (kr == kc)
-      val = w.Sinv[s * DDS + i * DS + j] - w.po[(s - 1) * D + i] * w.WR[(s - 1) * DD + i * D + j] -
-            w.po[s * D + i] * w.WL[(s + 1) * DD + i * D + j];
-    else if (kc == kr + 1)
-      val = -w.po[s * D + i] * w.WR[(s + 1) * DD + i * D + j];
-    else if (kc + 1 == kr)
-      val = -w.po[(s - 1) * D + i] * w.WL[(s - 1) * DD + i * D + j];
-    Z[e] = val;
+    if (r < n && c < n)
+    {
+      const int tb = r / D, i = r % D, tc = c / D, j = c % D, t = p.a[k] + tb;
+      if (tb == tc)
+        val = w.Sinv[t * DDS + i * DS + j];
+      else if (tc == tb + 1 && i == j)
+        val = w.po[t * D + i];
+      else if (tb == tc + 1 && i == j)
+        val = w.po[(t - 1) * D + i];
+    }
+    w.G[e] = val;
   }
   TMX_SYNC();
-  // dense in-place Gauss-Jordan inverse (SPD)
-  double* colk = w.Zs + n3 * n3;  // n3 scratch
-  for (int k = 0; k < n3; ++k)
-  {
-    const double piv = 1.0 / Z[k * n3 + k];
-    for (int e = tid; e < n3; e += NT)
-      colk[e] = Z[e * n3 + k];
-    TMX_SYNC();
-    double nv[3];
-    int ne = 0;
-    for (int e = tid; e < n3 * n3; e += NT, ++ne)
-    {
-      const int i = e / n3, j = e % n3;
-      double v;
-      if (i == k && j == k)
-        v = piv;
-      else if (i == k)
-        v = Z[e] * piv;
-      else if (j == k)
-        v = -colk[i] * piv;
-      else
-        v = Z[e] - colk[i] * Z[k * n3 + j] * piv;
-      nv[ne] = v;
-    }
-    TMX_SYNC();
-    ne = 0;
-    for (int e = tid; e < n3 * n3; e += NT, ++ne)
-      Z[e] = nv[ne];
-    TMX_SYNC();
-  }
-}
-
-// ---- interior chain of one wave (VALU: lane i = block row, v_readlane broadcast, rows prefetched one step ahead with
-//      unmasked 16-byte loads, 4 partial sums) ----------------------------------------------------------------------
-TMX_DEVFN void part_chain(const QpWs& w, int t0, int t1, int lane)
-{
-  const int D = w.D, DS = w.DS, DDS = w.DDS;
-  const int i = (lane < D) ? lane : 0;
-  const bool live = lane < D;
-  const double2* S2 = reinterpret_cast<const double2*>(w.Sinv);  // DS == 8: rows are 64-byte aligned
-  double vcur = w.tp[t0 * D + i];
-  double2 n0, n1, n2, n3;
-  double nb = 0.0, nc = 0.0;
-  {
-    const int base = (t0 * DDS + i * DS) >> 1;
-    n0 = S2[base];
-    n1 = S2[base + 1];
-    n2 = S2[base + 2];
-    n3 = S2[base + 3];
-    const int tn = (t0 + 1 <= t1) ? t0 + 1 : t0;
-    nb = w.tp[tn * D + i];
-    nc = w.po[t0 * D + i];
-  }
-  for (int t = t0 + 1; t <= t1; ++t)
-  {
-    const double mc = -nc;
-    const double r0 = mc * n0.x, r1 = mc * n0.y, r2 = mc * n1.x, r3 = mc * n1.y;
-    const double r4 = mc * n2.x, r5 = mc * n2.y, r6 = mc * n3.x, r7 = mc * n3.y;
-    const double bt = nb;
-    {
-      const int tn = (t + 1 <= t1) ? t + 1 : t;
-      const int base = ((tn - 1) * DDS + i * DS) >> 1;
-      n0 = S2[base];
-      n1 = S2[base + 1];
-      n2 = S2[base + 2];
-      n3 = S2[base + 3];
-      nb = w.tp[tn * D + i];
-      nc = w.po[(tn - 1) * D + i];
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    const int lo = __double2loint(vcur), hi = __double2hiint(vcur);
-#define TMX_RL(j) __hiloint2double(__builtin_amdgcn_readlane(hi, j), __builtin_amdgcn_readlane(lo, j))
-    const double s0 = __builtin_fma(r4, TMX_RL(4), __builtin_fma(r0, TMX_RL(0), bt));
-    const double s1 = __builtin_fma(r5, TMX_RL(5), r1 * TMX_RL(1));
-    const double s2 = __builtin_fma(r6, TMX_RL(6), r2 * TMX_RL(2));
-    const double s3 = __builtin_fma(r7, TMX_RL(7), r3 * TMX_RL(3));
-    vcur = (s0 + s1) + (s2 + s3);
-    __builtin_amdgcn_sched_barrier(0);
-    if (live)
-      w.tp[t * D + lane] = vcur;
-  }
-  // backward
-  double xn = 0.0, cn = 0.0, nv = vcur, ncn = 0.0;
-  {
-    const int base = (t1 * DDS + i * DS) >> 1;
-    n0 = S2[base];
-    n1 = S2[base + 1];
-    n2 = S2[base + 2];
-    n3 = S2[base + 3];
-  }
-  for (int t = t1; t >= t0; --t)
-  {
-    const double r0 = n0.x, r1 = n0.y, r2 = n1.x, r3 = n1.y, r4 = n2.x, r5 = n2.y, r6 = n3.x, r7 = n3.y;
-    const double u = __builtin_fma(-cn, xn, nv);
-    {
-      const int tn = (t > t0) ? t - 1 : t0;
-      const int base = (tn * DDS + i * DS) >> 1;
-      n0 = S2[base];
-      n1 = S2[base + 1];
-      n2 = S2[base + 2];
-      n3 = S2[base + 3];
-      nv = w.tp[tn * D + i];
-      ncn = w.po[tn * D + i];
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    const int lo = __double2loint(u), hi = __double2hiint(u);
-    const double s0 = __builtin_fma(r4, TMX_RL(4), r0 * TMX_RL(0));
-    const double s1 = __builtin_fma(r5, TMX_RL(5), r1 * TMX_RL(1));
-    const double s2 = __builtin_fma(r6, TMX_RL(6), r2 * TMX_RL(2));
-    const double s3 = __builtin_fma(r7, TMX_RL(7), r3 * TMX_RL(3));
-#undef TMX_RL
-    xn = (s0 + s1) + (s2 + s3);
-    cn = ncn;
-    __builtin_amdgcn_sched_barrier(0);
-    if (live)
-      w.tp[t * D + lane] = xn;
-  }
-}
-
-// ---- solve driver: rhs in w.tp, solution in w.tp ----------------------------------------------------------------
-TMX_DEVFN void part_solve(const QpWs& w, int tid, int NT, long long* pc, long long& tlast)
-{
-  const int D = w.D, DD = D * D;
-  Part p;
-  part_make(w.T, p);
-  const int wave = tid >> 6, lane = tid & 63;
-  part_chain(w, p.a[wave], p.b[wave], lane);
+  // 2. explicit inverses, one wave per interior
+  for (int k = tid >> 6; k < p.P; k += NT >> 6)
+    gj_wave(w.G + k * Gn * Gs, p.len[k] * D, Gs, tid & 63);
   TMX_SYNC();
-  TMX_TICK(3);
-  const int n3 = 3 * D;
-  double* rs = w.Zs + n3 * n3 + n3;  // n3 scratch: separator rhs
-  if (tid < n3)
+  // 3. Schur complement on the separators (block tridiagonal, (P-1) blocks of D)
+  const int ns = (p.P - 1) * D;
+  for (int e = tid; e < ns * Zst; e += NT)
   {
-    const int k = tid / D, i = tid % D, s = p.s[k];
-    rs[tid] = w.tp[s * D + i] - w.po[(s - 1) * D + i] * w.tp[(s - 1) * D + i] - w.po[s * D + i] * w.tp[(s + 1) * D + i];
+    const int rI = e / Zst, cI = e % Zst;
+    double val = 0.0;
+    if (cI < ns)
+    {
+      const int kr = rI / D, i = rI % D, kc = cI / D, j = cI % D, sb = p.s[kr];
+      const double* GL = w.G + kr * Gn * Gs;        // interior left of separator kr
+      const double* GR = w.G + (kr + 1) * Gn * Gs;  // interior right of it
+      const int nL = p.len[kr] * D, nR = p.len[kr + 1] * D;
+      const double cl_i = w.po[(sb - 1) * D + i], cr_i = w.po[sb * D + i];
+      if (kr == kc)
+        val = w.Sinv[sb * DDS + i * DS + j] - cl_i * GL[(nL - D + i) * Gs + (nL - D + j)] * w.po[(sb - 1) * D + j] -
+              cr_i * GR[i * Gs + j] * w.po[sb * D + j];
+      else if (kc == kr + 1)
+        val = -cr_i * GR[i * Gs + (nR - D + j)] * w.po[(p.s[kc] - 1) * D + j];
+      else if (kc + 1 == kr)
+        val = -cl_i * GL[(nL - D + i) * Gs + j] * w.po[p.s[kc] * D + j];
+    }
+    w.Zs[e] = val;
   }
   TMX_SYNC();
-  if (tid < n3)
-  {
-    // 3D-term dot product as D independent partial sums of 3 (dependent depth 3 FMA + 3 add)
-    const double* Zr = w.Zs + tid * n3;
-    double ps[8];
+  // 4. its dense inverse (SPD): in-place Gauss-Jordan by the whole workgroup
+  double* colk = w.sx + 256;
+  int ei[16], ej[16], eo[16];
 #pragma unroll
-    for (int q = 0; q < 8; ++q)
-      ps[q] = 0.0;
-#pragma unroll
-    for (int q = 0; q < 8; ++q)
-      if (q < D)
-        ps[q] = __builtin_fma(Zr[2 * D + q], rs[2 * D + q], __builtin_fma(Zr[D + q], rs[D + q], Zr[q] * rs[q]));
-    const int k = tid / D, i = tid % D;
-    w.tp[p.s[k] * D + i] = ((ps[0] + ps[1]) + (ps[2] + ps[3])) + ((ps[4] + ps[5]) + (ps[6] + ps[7]));
-  }
-  TMX_SYNC();
-  // spike correction of the interior blocks:  x_t -= WL[t] x_{s_left} + WR[t] x_{s_right}
-  for (int v = tid; v < w.NX; v += NT)
+  for (int q = 0; q < 16; ++q)
   {
-    const int t = v / D, i = v % D;
-    int k = 0;
-    bool interior = false;
-    for (int q = 0; q < 4; ++q)
-      if (t >= p.a[q] && t <= p.b[q])
+    const int e = tid + NT * q;
+    const bool ok = e < ns * ns;
+    ei[q] = ok ? e / ns : -1;
+    ej[q] = ok ? e % ns : 0;
+    eo[q] = ok ? ei[q] * Zst + ej[q] : 0;
+  }
+  for (int k = 0; k < ns; ++k)
+  {
+    const double piv = 1.0 / w.Zs[k * Zst + k];
+    if (tid < ns)
+      colk[tid] = w.Zs[tid * Zst + k];
+    TMX_SYNC();
+    double nv[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+    {
+      nv[q] = 0.0;
+      if (NT * q < ns * ns)
       {
-        k = q;
-        interior = true;
+        const int i = ei[q] < 0 ? 0 : ei[q], j = ej[q];
+        const double mij = w.Zs[eo[q]], mik = colk[i], mkj = w.Zs[k * Zst + j];
+        const double upd = mij - mik * mkj * piv;
+        nv[q] = (i == k) ? ((j == k) ? piv : mij * piv) : ((j == k) ? -mik * piv : upd);
       }
-    if (!interior)
-      continue;
-    const double* WLr = w.WL + t * DD + i * D;
-    const double* WRr = w.WR + t * DD + i * D;
-    const double* xl = w.tp + p.s[k > 0 ? k - 1 : 0] * D;
-    const double* xr = w.tp + p.s[k < 3 ? k : 2] * D;
-    // a missing neighbour has an all-zero spike (part_spikes), so both products are always formed: 2D terms as D
-    // independent partial sums of 2
-    double ps[8];
+    }
+    TMX_SYNC();
 #pragma unroll
-    for (int q = 0; q < 8; ++q)
-      ps[q] = 0.0;
-#pragma unroll
-    for (int q = 0; q < 8; ++q)
-      if (q < D)
-        ps[q] = __builtin_fma(WRr[q], xr[q], WLr[q] * xl[q]);
-    const double s0 = (ps[0] + ps[1]) + (ps[2] + ps[3]), s1 = (ps[4] + ps[5]) + (ps[6] + ps[7]);
-    w.tp[v] -= (s0 + s1);  // only interior rows are written; only separator rows and the own row are read
+    for (int q = 0; q < 16; ++q)
+    {
+      if (NT * q < ns * ns && ei[q] >= 0)
+        w.Zs[eo[q]] = nv[q];
+    }
+    TMX_SYNC();
   }
-  TMX_SYNC();
-  TMX_TICK(4);
+}
+
+// ---- LDS-typed view of the arrays the iteration touches (explicit address space: ds_read / ds_write even inside the
+//      out-of-line burst function, where the generic pointers of QpWs could not be proven to point to LDS) -----------
+typedef __attribute__((address_space(3))) double tmx_lds_d;
+struct HotLds
+{
+  tmx_lds_d *hr, *ty, *tp, *G, *Zs, *sx, *po;
+  int D, Gn, Gs, Zst;
+};
+typedef double tmx_d2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) tmx_d2 tmx_lds_d2;
+
+// sum over the 4 lanes of a quad (DPP quad_perm, no LDS): every lane gets the total
+TMX_DEVFN double quad_sum(double x)
+{
+  {
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), 0xB1, 0xF, 0xF, true);
+    x += __hiloint2double(hi, lo);
+  }
+  {
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), 0x4E, 0xF, 0xF, true);  // quad_perm [2,3,0,1]
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), 0x4E, 0xF, 0xF, true);
+    x += __hiloint2double(hi, lo);
+  }
+  return x;
+}
+
+// ---- solve, phase 1 (interior thread): y = G_k[r, :] . b_int   (rhs in the permuted buffer ty) ----------------------
+// rows and right-hand sides are zero padded up to the common stride Gs (a multiple of 8): the trip count is a
+// compile-time constant per instantiation, so all loads are issued before the first FMA
+// np pairs, wave-uniform trip count, chunks of 4 pairs (8 loads in flight, then 8 FMAs into 8 independent sums)
+TMX_DEVFN double dpart_dot_pairs(const tmx_lds_d2* A, const tmx_lds_d2* B, int np)
+{
+  double s[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q)
+    s[q] = 0.0;
+  int c = 0;
+  for (; c + 4 <= np; c += 4)
+  {
+    tmx_d2 a[4], b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+    {
+      a[u] = A[c + u];
+      b[u] = B[c + u];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+    {
+      s[2 * u] = __builtin_fma(a[u].x, b[u].x, s[2 * u]);
+      s[2 * u + 1] = __builtin_fma(a[u].y, b[u].y, s[2 * u + 1]);
+    }
+  }
+  {
+    // tail: 0..3 pairs, predicated loads from the (always valid) first pair otherwise
+    tmx_d2 a[3], b[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
+    {
+      const bool ok = c + u < np;
+      a[u] = A[ok ? c + u : 0];
+      b[u] = B[ok ? c + u : 0];
+      if (!ok)
+        a[u] = tmx_d2{ 0.0, 0.0 };
+    }
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
+    {
+      s[2 * u] = __builtin_fma(a[u].x, b[u].x, s[2 * u]);
+      s[2 * u + 1] = __builtin_fma(a[u].y, b[u].y, s[2 * u + 1]);
+    }
+  }
+  return ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+}
+TMX_DEVFN double dpart_interior(const HotLds& h, const DMap& m)
+{
+  const tmx_lds_d2* Gr = reinterpret_cast<const tmx_lds_d2*>(h.G + (m.k * h.Gn + m.r) * h.Gs);
+  const tmx_lds_d2* bb = reinterpret_cast<const tmx_lds_d2*>(h.ty + m.k * h.Gs);
+  return dpart_dot_pairs(Gr, bb, h.Gs >> 1);
+}
+
+// ---- solve, phase 2 (4 lanes per separator variable): x_sep = Zs (b_sep - C y_left - C y_right) ----------------------
+// b_sep = ty[P*Gs ..], C y products in sx[0..) / sx[64..) (written by the boundary rows of the interiors in phase 1).
+// Lane quarter qq handles columns [qq*Zst/4, (qq+1)*Zst/4); returns the full dot product in every lane of the quad.
+TMX_DEVFN double dpart_separator_row(const HotLds& h, const DMap& m, const tmx_lds_d* bsep)
+{
+  const int jc = h.Zst >> 2, np = jc >> 1;  // wave-uniform
+  const int g = m.qg < 0 ? 0 : m.qg;
+  const tmx_lds_d2* Zr = reinterpret_cast<const tmx_lds_d2*>(h.Zs + g * h.Zst + m.qq * jc);
+  const tmx_lds_d2* bs = reinterpret_cast<const tmx_lds_d2*>(bsep + m.qq * jc);
+  const tmx_lds_d2* yl = reinterpret_cast<const tmx_lds_d2*>(h.sx + m.qq * jc);
+  const tmx_lds_d2* yr = reinterpret_cast<const tmx_lds_d2*>(h.sx + 64 + m.qq * jc);
+  double s[4] = { 0.0, 0.0, 0.0, 0.0 };
+  // np <= 8 pairs: two predicated chunks of 4 (Zs rows are zero padded up to Zst, the exchange vectors stay finite)
+#pragma unroll
+  for (int c0 = 0; c0 < 8; c0 += 4)
+  {
+    if (c0 < np)
+    {
+      tmx_d2 z[4], b[4], l[4], r[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+      {
+        const bool ok = c0 + u < np;
+        const int c = ok ? c0 + u : 0;
+        z[u] = Zr[c];
+        b[u] = bs[c];
+        l[u] = yl[c];
+        r[u] = yr[c];
+        if (!ok)
+          z[u] = tmx_d2{ 0.0, 0.0 };
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+      {
+        s[(2 * u) & 3] = __builtin_fma(z[u].x, (b[u].x - l[u].x) - r[u].x, s[(2 * u) & 3]);
+        s[(2 * u + 1) & 3] = __builtin_fma(z[u].y, (b[u].y - l[u].y) - r[u].y, s[(2 * u + 1) & 3]);
+      }
+    }
+  }
+  return quad_sum((s[0] + s[1]) + (s[2] + s[3]));
+}
+
+// ---- solve, phase 3 (interior thread): x = y - G_k[r, first block] (c x_sepL) - G_k[r, last block] (c x_sepR) -------
+TMX_DEVFN double dpart_correct(const HotLds& h, const DMap& m, double y)
+{
+  const int D = h.D;
+  const tmx_lds_d* Gl = h.G + (m.k * h.Gn + m.r) * h.Gs;
+  const tmx_lds_d* Gq = Gl + (m.n - D);
+  const tmx_lds_d* xl = h.sx + 192 + (m.hasl ? m.k - 1 : 0) * D;  // right-going product of the separator on the left
+  const tmx_lds_d* xr = h.sx + 128 + (m.hasr ? m.k : 0) * D;      // left-going product of the separator on the right
+  double ps[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q)
+  {
+    ps[q] = 0.0;
+    if (q < D)
+    {
+      const double gl = m.hasl ? Gl[q] : 0.0, gr = m.hasr ? Gq[q] : 0.0;
+      ps[q] = __builtin_fma(gr, xr[q], gl * xl[q]);
+    }
+  }
+  return y - (((ps[0] + ps[1]) + (ps[2] + ps[3])) + ((ps[4] + ps[5]) + (ps[6] + ps[7])));
 }
 
 // sequential (one-sided) inversion of the whole chain by wave 0 — used for the polish factorisation
@@ -528,24 +549,71 @@ TMX_DEVFN void row_phase_c(RowRegs& g, double alpha, double dot, const double ta
   }
 }
 
-// runs ADMM iterations first..last (inclusive) without any residual check; state is loaded from / stored to LDS
-// around the batch.  `keep_last` stores delta_x / delta_y of the final iteration (needed by the termination test).
-TMX_DEVFN void admm_run_fast(const QpWs& w, const DevProblem* P, int n_iter, bool keep_last, int tid, long long* pc, long long& tlast)
+// Runs n_iter ADMM iterations without any residual check; the iterate is loaded from / stored to the workspace around
+// the burst.  `keep_last` stores delta_x / delta_y of the final iteration (needed by the termination test).
+// Thread tid owns the constraint rows tid + q*NT (NROW = 512 / NT of them, with their aux vars); the primary variables
+// and the dense-solve roles are distributed by dpart_map().
+#define TMX_NROW (512 / TMX_QP_NT)
+#if defined(TMX_PROFILE) && defined(TMX_PROFILE_LOOP)
+#define TMX_LTICK(s) TMX_TICK(s)
+#else
+#define TMX_LTICK(s) ((void)0)  // per-phase ticks inside the iteration perturb it (~100 cycles each): opt-in
+#endif
+TMX_DEVFN void admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, bool keep_last, int tid, long long* pc, long long& tlast)
 {
-  const int D = w.D;
-  RowRegs g0, g1;
-  row_load(w, tid, g0);
-  row_load(w, tid + 256, g1);
-  const bool pv = tid < w.NX;
-  const int v = pv ? tid : 0;
+  const int D = __builtin_amdgcn_readfirstlane(w.D);
+#define TMX_LDS_PTR(p) ((tmx_lds_d*)(size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(p)))
+  HotLds h;
+  h.hr = TMX_LDS_PTR(w.hr);
+  h.ty = TMX_LDS_PTR(w.ty);
+  h.tp = TMX_LDS_PTR(w.tp);
+  h.G = TMX_LDS_PTR(w.G);
+  h.Zs = TMX_LDS_PTR(w.Zs);
+  h.sx = TMX_LDS_PTR(w.sx);
+  h.po = TMX_LDS_PTR(w.po);
+#undef TMX_LDS_PTR
+  h.D = D;
+  h.Gn = __builtin_amdgcn_readfirstlane(w.Gn);
+  h.Gs = __builtin_amdgcn_readfirstlane(w.Gs);
+  h.Zst = __builtin_amdgcn_readfirstlane(w.Zst);
+  RowRegs g[TMX_NROW];
+#pragma unroll
+  for (int q = 0; q < TMX_NROW; ++q)
+    row_load(w, tid + q * TMX_QP_NT, g[q]);
+  DPart dp;
+  dpart_make(w.T, dp);
+  DMap mp;
+  dpart_map(w, dp, tid, mp);
+  const bool pv = mp.v >= 0;
+  const int v = pv ? mp.v : 0;
+  const bool interior = pv && !mp.sep;
+  const tmx_lds_d* bsep = h.ty + dp.P * h.Gs;
+  // pad entries of the permuted rhs and of the separator exchange vectors are multiplied by zero matrix padding:
+  // keep them finite
+  for (int e = tid; e < dp.P * h.Gs + 64; e += TMX_QP_NT)
+    h.ty[e] = 0.0;
+  for (int e = tid; e < 6 * 64; e += TMX_QP_NT)
+    h.sx[e] = 0.0;
   double xp = w.xp[v], zb = w.zbp[v], yb = w.ybp[v];
   const double lb = w.lbp[v], ub = w.ubp[v], qv = w.qp[v], bb = w.bbp[v];
   const double rbp = rho_of_type(w.typ_bp[v], w.rho), rbpi = 1.0 / rbp;
   const double sigma = w.sigma, alpha = w.alpha, om = 1.0 - alpha;
-  const int tb0 = g0.t * D, tb1 = g1.t * D;
+  int tb[TMX_NROW];
+  bool has[TMX_NROW];
+#pragma unroll
+  for (int q = 0; q < TMX_NROW; ++q)
+  {
+    tb[q] = g[q].t * D;
+    has[q] = tid + q * TMX_QP_NT < w.R;
+  }
+  // couplings of this thread's variable / of the separator row it publishes (constant during the solve)
+  const double cprev = (pv && v >= D) ? h.po[v - D] : 0.0, cnext = pv ? h.po[v] : 0.0;
+  const double qcprev = h.po[mp.qv - D], qcnext = h.po[mp.qv];
+  const bool qlead = mp.qg >= 0 && mp.qq == 0;
+  const bool wr_yl = interior && mp.last && mp.hasr, wr_yr = interior && mp.first && mp.hasl;
+  const int i_yl = mp.k * D + (mp.r - (mp.n - D)), i_yr = 64 + (mp.k - 1) * D + mp.r;
   // column v of A restricted to the rows of its waypoint, kept in registers (first 16 rows; a longer list falls back
   // to the LDS gather for the remainder): A'e needs only the hr[] loads per iteration
-#ifndef TMX_NO_CJ
   double cj[16];
   int ri[16];
   int q_rest = 0, q_end = 0;
@@ -561,30 +629,29 @@ TMX_DEVFN void admm_run_fast(const QpWs& w, const DevProblem* P, int n_iter, boo
       cj[k] = ok ? w.coef[r * D + j] : 0.0;
     }
     q_rest = q0 + 16;
-    q_end = q1;
+    q_end = pv ? q1 : 0;
   }
-#endif
+  TMX_SYNC();
+  TMX_TICK(8);
   for (int it = 0; it < n_iter; ++it)
   {
     const bool keep = keep_last && (it == n_iter - 1);
-    double ta0[2], ta1[2];
-    const double e0 = row_phase_a(g0, sigma, ta0);
-    const double e1 = row_phase_a(g1, sigma, ta1);
-    if (tid < w.R)
-      w.hr[tid] = e0;
-    if (tid + 256 < w.R)
-      w.hr[tid + 256] = e1;
+    double ta[TMX_NROW][2];
+#pragma unroll
+    for (int q = 0; q < TMX_NROW; ++q)
+    {
+      const double e = row_phase_a(g[q], sigma, ta[q]);
+      if (has[q])
+        h.hr[tid + q * TMX_QP_NT] = e;
+    }
     TMX_SYNC();
     if (pv)
     {
       const double gb = rbp * zb - yb;
-#ifdef TMX_NO_CJ
-      w.tp[v] = (sigma * xp - qv) + at_rows(w, P, w.hr, v) + bb * gb;
-#else
       double e[16];
 #pragma unroll
       for (int k = 0; k < 16; ++k)
-        e[k] = w.hr[ri[k]];
+        e[k] = h.hr[ri[k]];
       double a0 = cj[0] * e[0], a1 = cj[1] * e[1], a2 = cj[2] * e[2], a3 = cj[3] * e[3];
 #pragma unroll
       for (int k = 4; k < 16; k += 4)
@@ -598,32 +665,65 @@ TMX_DEVFN void admm_run_fast(const QpWs& w, const DevProblem* P, int n_iter, boo
       for (int q = q_rest; q < q_end; ++q)
       {
         const int r = w.wp_list[q];
-        ate += w.coef[r * D + (v % D)] * w.hr[r];
+        ate += w.coef[r * D + (v % D)] * h.hr[r];
       }
-      w.tp[v] = (sigma * xp - qv) + ate + bb * gb;
-#endif
+      h.ty[mp.slot] = (sigma * xp - qv) + ate + bb * gb;
     }
     TMX_SYNC();
-    TMX_TICK(2);
-    part_solve(w, tid, 256, pc, tlast);
-    // phase C
-    double xt[8], xu[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j)
+    TMX_LTICK(2);
+    // dense nested-dissection solve: interiors -> separators (4 lanes per variable) -> correction
+    double yint = 0.0;
+    if (interior)
     {
-      xt[j] = (j < D) ? w.tp[tb0 + j] : 0.0;
-      xu[j] = (j < D) ? w.tp[tb1 + j] : 0.0;
+      yint = dpart_interior(h, mp);
+      if (wr_yl)
+        h.sx[i_yl] = cnext * yint;
+      if (wr_yr)
+        h.sx[i_yr] = cprev * yint;
     }
-    const double xtv = w.tp[v];
-    double d0 = (g0.c[0] * xt[0] + g0.c[4] * xt[4]) + (g0.c[1] * xt[1] + g0.c[5] * xt[5]);
-    d0 += (g0.c[2] * xt[2] + g0.c[6] * xt[6]) + (g0.c[3] * xt[3] + g0.c[7] * xt[7]);
-    double d1 = (g1.c[0] * xu[0] + g1.c[4] * xu[4]) + (g1.c[1] * xu[1] + g1.c[5] * xu[5]);
-    d1 += (g1.c[2] * xu[2] + g1.c[6] * xu[6]) + (g1.c[3] * xu[3] + g1.c[7] * xu[7]);
-    double dyr0 = 0, dyr1 = 0, dxa0[2], dya0[2], dxa1[2], dya1[2];
-    if (g0.act)
-      row_phase_c(g0, alpha, d0, ta0, keep, &dyr0, dxa0, dya0);
-    if (g1.act)
-      row_phase_c(g1, alpha, d1, ta1, keep, &dyr1, dxa1, dya1);
+    TMX_SYNC();
+    TMX_LTICK(3);
+    if (tid < 256)
+    {
+      const double xs = dpart_separator_row(h, mp, bsep);
+      if (qlead)
+      {
+        h.tp[mp.qv] = xs;
+        h.sx[128 + mp.qg] = qcprev * xs;
+        h.sx[192 + mp.qg] = qcnext * xs;
+      }
+    }
+    TMX_SYNC();
+    if (interior)
+      h.tp[v] = dpart_correct(h, mp, yint);
+    TMX_SYNC();
+    TMX_LTICK(4);
+    // phase C
+    const double xtv = h.tp[v];
+#pragma unroll
+    for (int q = 0; q < TMX_NROW; ++q)
+    {
+      RowRegs& gq = g[q];
+      double xt[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        xt[j] = (j < D) ? h.tp[tb[q] + j] : 0.0;
+      double d0 = (gq.c[0] * xt[0] + gq.c[4] * xt[4]) + (gq.c[1] * xt[1] + gq.c[5] * xt[5]);
+      d0 += (gq.c[2] * xt[2] + gq.c[6] * xt[6]) + (gq.c[3] * xt[3] + gq.c[7] * xt[7]);
+      double dyr0 = 0, dxa0[2], dya0[2];
+      if (gq.act)
+        row_phase_c(gq, alpha, d0, ta[q], keep, &dyr0, dxa0, dya0);
+      if (keep && gq.act)
+      {
+        const int r = tid + q * TMX_QP_NT;
+        w.dyr[r] = dyr0;
+        for (int k = 0; k < gq.na; ++k)
+        {
+          w.dxa[w.aoff[r] + k] = dxa0[k];
+          w.dyba[w.aoff[r] + k] = dya0[k];
+        }
+      }
+    }
     {
       const double xn = alpha * xtv + om * xp;
       const double zt = bb * xtv;
@@ -639,33 +739,14 @@ TMX_DEVFN void admm_run_fast(const QpWs& w, const DevProblem* P, int n_iter, boo
       zb = zn;
       yb += dy;
     }
-    if (keep)
-    {
-      if (g0.act)
-      {
-        w.dyr[tid] = dyr0;
-        for (int k = 0; k < g0.na; ++k)
-        {
-          w.dxa[w.aoff[tid] + k] = dxa0[k];
-          w.dyba[w.aoff[tid] + k] = dya0[k];
-        }
-      }
-      if (g1.act)
-      {
-        w.dyr[tid + 256] = dyr1;
-        for (int k = 0; k < g1.na; ++k)
-        {
-          w.dxa[w.aoff[tid + 256] + k] = dxa1[k];
-          w.dyba[w.aoff[tid + 256] + k] = dya1[k];
-        }
-      }
-    }
-    TMX_TICK(5);
+    TMX_LTICK(5);
     // the next iteration's phase A only touches registers; its hr stores are ordered after every thread's tp reads by
     // the barrier that follows them, and tp is rewritten only after that barrier
   }
-  row_store(w, tid, g0);
-  row_store(w, tid + 256, g1);
+  TMX_TICK(2);
+#pragma unroll
+  for (int q = 0; q < TMX_NROW; ++q)
+    row_store(w, tid + q * TMX_QP_NT, g[q]);
   if (pv)
   {
     w.xp[v] = xp;
@@ -673,4 +754,37 @@ TMX_DEVFN void admm_run_fast(const QpWs& w, const DevProblem* P, int n_iter, boo
     w.ybp[v] = yb;
   }
   TMX_SYNC();
+  TMX_TICK(9);
+}
+
+#ifdef TMX_BURST_NOINLINE
+// out-of-line variant: the loop is register-allocated on its own (256 architectural VGPRs); the workspace descriptor
+// is handed over through a small LDS copy
+__device__ __attribute__((noinline)) static void admm_burst_nl(const QpWs* wsh, const DevProblem* P, int n_iter_in, int keep_last_in,
+                                                              long long* pc_out, long long* tlast_p)
+{
+  const QpWs w = *wsh;
+  long long pc[16] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+  long long tlast = *tlast_p;
+  admm_burst_core(w, P, __builtin_amdgcn_readfirstlane(n_iter_in), __builtin_amdgcn_readfirstlane(keep_last_in) != 0, threadIdx.x, pc, tlast);
+#ifdef TMX_PROFILE
+#pragma unroll
+  for (int q = 0; q < 16; ++q)
+    pc_out[q] += pc[q];
+  *tlast_p = tlast;
+#endif
+}
+#endif
+
+TMX_DEVFN void admm_run_fast(const QpWs& w, const DevProblem* P, int n_iter, bool keep_last, int tid, long long* pc, long long& tlast)
+{
+#ifdef TMX_BURST_NOINLINE
+  QpWs* wsh = reinterpret_cast<QpWs*>(w.wself);
+  if (tid == 0)
+    *wsh = w;
+  TMX_SYNC();
+  admm_burst_nl(wsh, P, n_iter, keep_last ? 1 : 0, pc, &tlast);
+#else
+  admm_burst_core(w, P, n_iter, keep_last, tid, pc, tlast);
+#endif
 }

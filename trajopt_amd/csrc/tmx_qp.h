@@ -33,6 +33,7 @@
 #else
 #define TMX_CLK() 0LL  // the profiler is opt-in (-DTMX_PROFILE): s_memtime costs ~100 cycles per tick
 #endif
+#if TMX_IS_DEVICE && defined(TMX_PROFILE)
 #define TMX_TICK(slot)                                                                                                \
   do                                                                                                                  \
   {                                                                                                                   \
@@ -40,6 +41,9 @@
     pc[slot] += now_ - tlast;                                                                                         \
     tlast = now_;                                                                                                     \
   } while (0)
+#else
+#define TMX_TICK(slot) ((void)0)
+#endif
 
 
 // ---- block reductions -------------------------------------------------------------------------------
@@ -104,18 +108,24 @@ struct QpWs
   double *dinv;  // NA: 1 / (sigma + rho_b * bb^2) of every aux var for the current rho
   double *fac;   // R : rho_r / (1 + rho_r * kappa_r)
   double *Sinv;  // T*D*DS
-  double *WL, *WR;  // T*D*D each: spikes of the partitioned block solve (device fast path)
-  double *Zs;       // (3D)^2 inverse Schur complement on the separator blocks + 2*3D scratch
+  // dense nested-dissection solve (device fast path, tmx_part.h): explicit inverses of the interior diagonal
+  // sub-matrices (P slots of Gn rows, row stride Gs) and of the separator Schur complement (ns rows, stride Zst)
+  double *G, *Zs;
+  int Gn, Gs, Zst;
+  double *sx;  // 6*64: separator exchange: [0) c*y of the interior left of each separator, [64) right, [128) c*x_sep
+               // towards the left interior, [192) towards the right one, [256) Gauss-Jordan column scratch
+  double *ty;  // P*Gs + 64: right-hand side of the dense solve, permuted (interior k at k*Gs, separators after)
+  double *wself;  // LDS copy of this descriptor for the out-of-line burst function
   double *gj;    // D*D Gauss-Jordan scratch
-  double *red;   // reduction scratch (64) + broadcast scalars (32)
+  double *red;   // 256: reduction scratch [0,128) (K values x up to 8 waves), scalars / hash accumulator [128,192), GJ column [192,256)
   // ints
   int *act, *aoff, *naux, *slot_t, *typ_r, *typ_bp, *typ_ba, *flg_r, *flg_bp, *flg_ba, *row_ref, *aux_ref;
   int *wp_start, *wp_list;  // LDS copies of DevProblem::wp_start / wp_list (hot in every SpMV)
 };
 
 // The workspace is split by access frequency:
-//   HOT  (LDS, touched every ADMM iteration): the two exchange vectors tp / hr, the coupling po, the block factor
-//        Sinv, the spikes WL / WR, the separator Schur inverse Zs and small scratch          (~47 KB for config 1)
+//   HOT  (LDS, touched every ADMM iteration): the exchange vectors tp / ty / hr, the coupling po, the explicit
+//        inverses G (interiors) and Zs (separator Schur complement), the block factor Sinv   (~73 KB for config 1)
 //   COLD (per-problem global scratch, L2 / Infinity-Cache resident): the "home" copies of the iterates and of the
 //        scaled problem data, touched only at setup (Ruiz), at the residual checks (every 25 iterations), at the
 //        burst boundaries of the register-resident loop and in the polish step                 (~110 KB)
@@ -127,28 +137,91 @@ struct QpWs
 #ifndef TMX_QP_COLD_IN_LDS
 #define TMX_QP_COLD_IN_LDS 1
 #endif
+// workgroup size of the QP kernels: 256 (4 waves, 512 VGPRs each, two constraint rows per thread in the ADMM iteration)
+// or 512 (8 waves, 256 VGPRs each, one row per thread)
+#ifndef TMX_QP_NT
+#define TMX_QP_NT 256
+#endif
+// partition of the T waypoint blocks for the dense nested-dissection solve: P interiors separated by P-1 single-block
+// separators (interior k = blocks a[k] .. a[k]+len[k]-1, separator k = block s[k] between interiors k and k+1)
+struct DPart
+{
+  int P, ns, Lmax;
+  int a[8], len[8], s[8];
+};
+TMX_HOSTDEVFN void dpart_make(int T, DPart& p)
+{
+  int P = (T + 2) / 4;
+  P = P < 2 ? 2 : (P > 8 ? 8 : P);
+  if (T < 2 * P - 1)
+    P = 1;
+  p.P = P;
+  const int L = T - (P - 1), base = L / P, rem = L % P;
+  p.Lmax = base + (rem ? 1 : 0);
+  int t = 0;
+  for (int k = 0; k < 8; ++k)
+  {
+    p.a[k] = p.len[k] = p.s[k] = 0;
+    if (k >= P)
+      continue;
+    p.len[k] = base + (k < rem ? 1 : 0);
+    p.a[k] = t;
+    t += p.len[k];
+    if (k < P - 1)
+      p.s[k] = t++;
+  }
+}
+TMX_HOSTDEVFN int dpart_gn(int D, int T)
+{
+  DPart p;
+  dpart_make(T, p);
+  return p.Lmax * D;
+}
+TMX_HOSTDEVFN int dpart_even(int n) { return (n + 2) & ~1; }
+TMX_HOSTDEVFN int dpart_mult8(int n) { return (n + 8) & ~7; }
+// row stride of the interior inverses: >= n+1 (zero pad column), even (16-byte rows) and with an ODD number of
+// 16-byte chunks, so that the ds_read_b128 of 16 consecutive rows hit 16 different bank quads
+TMX_HOSTDEVFN int dpart_gstride(int n)
+{
+  int h = (n + 2) >> 1;
+  return 2 * (h | 1);
+}  // separator rows: 4 lanes x an even number of columns  // row stride: >= n+1 (zero pad column) and even (16-byte rows)
 TMX_HOSTDEVFN size_t qp_lds_doubles(int D, int T, int R, int NA)
 {
   const size_t NX = (size_t)D * T;
   (void)NA;
-  return 2 * NX + (size_t)R + (size_t)T * D * (D <= 8 ? 8 : D) + 2 * (size_t)T * D * D + 9 * (size_t)D * D + 6 * (size_t)D +
-         (size_t)D * D + 98 + 4;
-}
-TMX_HOSTDEVFN size_t qp_glb_doubles(int D, int T, int R, int NA);
-// dynamic LDS bytes of the QP kernels for the chosen placement
-TMX_HOSTDEVFN size_t qp_smem_bytes(int D, int T, int R, int NA)
-{
-  return (qp_lds_doubles(D, T, R, NA) + (TMX_QP_COLD_IN_LDS ? qp_glb_doubles(D, T, R, NA) : 0)) * sizeof(double);
+  DPart p;
+  dpart_make(T, p);
+  const size_t gn = (size_t)p.Lmax * D, nsep = (size_t)(p.P - 1) * D;
+  const size_t dense = (D <= 8) ? (size_t)p.P * gn * dpart_gstride((int)gn) + nsep * dpart_mult8((int)nsep) + 6 * 64 + (size_t)p.P * dpart_gstride((int)gn) + 64 : 0;
+  return 2 * NX + 4 + (size_t)R + (size_t)T * D * (D <= 8 ? 8 : D) + dense + (size_t)D * D + 256 + 4 + (sizeof(QpWs) + 7) / 8;
 }
 TMX_HOSTDEVFN size_t qp_glb_doubles(int D, int T, int R, int NA)
 {
   const size_t NX = (size_t)D * T;
-  const size_t n = 12 * NX + 7 * (size_t)R + (size_t)R * D + 12 * (size_t)NA;
-  const size_t ints = 9 * (size_t)R + 2 * NX + 2 * (size_t)NA + (size_t)T + 2;
+  const size_t n = 10 * NX + 6 * (size_t)R + (size_t)R * D + 8 * (size_t)NA;
+  const size_t ints = 6 * (size_t)R + (size_t)NX + (size_t)NA + (size_t)T + 2;
   return n + (ints + 1) / 2 + 8;
 }
+// arrays that are only touched at burst boundaries / in the polish step: always in the per-problem HBM scratch
+TMX_HOSTDEVFN size_t qp_far_doubles(int D, int T, int R, int NA)
+{
+  const size_t NX = (size_t)D * T;
+  const size_t n = 2 * NX + (size_t)R + 4 * (size_t)NA;
+  const size_t ints = 3 * (size_t)R + (size_t)NX + (size_t)NA;
+  return n + (ints + 1) / 2 + 8;
+}
+// dynamic LDS bytes of the QP kernels / per-problem HBM scratch doubles for the chosen placement
+TMX_HOSTDEVFN size_t qp_smem_bytes(int D, int T, int R, int NA)
+{
+  return (qp_lds_doubles(D, T, R, NA) + (TMX_QP_COLD_IN_LDS ? qp_glb_doubles(D, T, R, NA) : 0)) * sizeof(double);
+}
+TMX_HOSTDEVFN size_t qp_scratch_doubles(int D, int T, int R, int NA)
+{
+  return qp_far_doubles(D, T, R, NA) + (TMX_QP_COLD_IN_LDS ? 0 : qp_glb_doubles(D, T, R, NA));
+}
 
-TMX_DEVFN void qp_ws_carve(QpWs& w, double* lds, double* glb, int D, int T, int R, int NA)
+TMX_DEVFN void qp_ws_carve(QpWs& w, double* lds, double* glb, double* far, int D, int T, int R, int NA)
 {
   w.D = D;
   w.T = T;
@@ -164,14 +237,26 @@ TMX_DEVFN void qp_ws_carve(QpWs& w, double* lds, double* glb, int D, int T, int 
   w.DS = (D <= 8) ? 8 : D;
   w.DDS = D * w.DS;
   TAKE(Sinv, T * D * w.DS);  // first: 16-byte aligned for the double2 row loads
-  TAKE(WL, T * D * D);
-  TAKE(WR, T * D * D);
-  TAKE(Zs, 9 * D * D + 6 * D);
-  TAKE(tp, NX);
+  w.G = w.Zs = w.sx = w.ty = nullptr;
+  w.Gn = w.Gs = w.Zst = 0;
+  if (D <= 8)
+  {
+    DPart dp;
+    dpart_make(T, dp);
+    w.Gn = dp.Lmax * D;
+    w.Gs = dpart_gstride(w.Gn);
+    w.Zst = dpart_mult8((dp.P - 1) * D);
+    TAKE(G, dp.P * w.Gn * w.Gs);
+    TAKE(Zs, (dp.P - 1) * D * w.Zst);
+    TAKE(sx, 6 * 64);
+    TAKE(ty, dp.P * w.Gs + 64);
+  }
+  TAKE(tp, (NX + 3) & ~1);  // +2: the paired loads of the dense interior mat-vec may run one element past the last block
   TAKE(po, NX);
   TAKE(hr, R);
   TAKE(gj, D * D);
-  TAKE(red, 96);
+  TAKE(red, 256);
+  TAKE(wself, (sizeof(QpWs) + 7) / 8);
   // ---- cold: global scratch
   p = glb;
   TAKE(xp, NX);
@@ -184,29 +269,21 @@ TMX_DEVFN void qp_ws_carve(QpWs& w, double* lds, double* glb, int D, int T, int 
   TAKE(Ebp, NX);
   TAKE(bbp, NX);
   TAKE(pd, NX);
-  TAKE(dxp, NX);
-  TAKE(dybp, NX);
   TAKE(zr, R);
   TAKE(yr, R);
   TAKE(lor, R);
   TAKE(hir, R);
   TAKE(Er, R);
-  TAKE(dyr, R);
   TAKE(fac, R);
   TAKE(coef, R * D);
   TAKE(xa, NA);
   TAKE(zba, NA);
   TAKE(yba, NA);
   TAKE(qa, NA);
-  TAKE(Da, NA);
   TAKE(Eba, NA);
   TAKE(bba, NA);
   TAKE(sa, NA);
-  TAKE(ta, NA);
-  TAKE(dxa, NA);
-  TAKE(dyba, NA);
   TAKE(dinv, NA);
-#undef TAKE
   int* ip = reinterpret_cast<int*>(p);
 #define TAKEI(name, n)                                                                                                \
   w.name = ip;                                                                                                        \
@@ -216,15 +293,26 @@ TMX_DEVFN void qp_ws_carve(QpWs& w, double* lds, double* glb, int D, int T, int 
   TAKEI(naux, R);
   TAKEI(slot_t, R);
   TAKEI(typ_r, R);
+  TAKEI(typ_bp, NX);
+  TAKEI(typ_ba, NA);
+  TAKEI(wp_start, T + 1);
+  TAKEI(wp_list, R);
+  // ---- far: always HBM (delta vectors of the last iteration, polish bookkeeping)
+  p = far;
+  TAKE(dxp, NX);
+  TAKE(dybp, NX);
+  TAKE(dyr, R);
+  TAKE(dxa, NA);
+  TAKE(dyba, NA);
+  TAKE(ta, NA);
+  TAKE(Da, NA);
+  ip = reinterpret_cast<int*>(p);
   TAKEI(flg_r, R);
   TAKEI(row_ref, R);
   TAKEI(aux_ref, R);
-  TAKEI(typ_bp, NX);
   TAKEI(flg_bp, NX);
-  TAKEI(typ_ba, NA);
   TAKEI(flg_ba, NA);
-  TAKEI(wp_start, T + 1);
-  TAKEI(wp_list, R);
+#undef TAKE
 #undef TAKEI
 }
 
@@ -337,7 +425,7 @@ TMX_DEVFN void kkt_invert_chain_generic(const QpWs& w, int t0, int t1, int tid, 
       const double piv = 1.0 / S[k * DS + k];
       TMX_SYNC();
       for (int e = tid; e < D; e += NT)
-        w.red[32 + e] = S[e * DS + k];  // column k
+        w.red[192 + e] = S[e * DS + k];  // column k
       TMX_SYNC();
       for (int e = tid; e < DD; e += NT)
       {
@@ -348,9 +436,9 @@ TMX_DEVFN void kkt_invert_chain_generic(const QpWs& w, int t0, int t1, int tid, 
         else if (i == k)
           v = S[i * DS + j] * piv;
         else if (j == k)
-          v = -w.red[32 + i] * piv;
+          v = -w.red[192 + i] * piv;
         else
-          v = S[i * DS + j] - w.red[32 + i] * S[k * DS + j] * piv;
+          v = S[i * DS + j] - w.red[192 + i] * S[k * DS + j] * piv;
         w.gj[e] = v;
       }
       TMX_SYNC();

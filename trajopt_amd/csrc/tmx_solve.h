@@ -255,13 +255,13 @@ TMX_DEVFN void qp_structure(const DevProblem* P, const int* active, const double
 // K5: one OSQPModel::optimize() — setup (scaling, rho vector, factor), optional explicit warm start, ADMM loop,
 // polish, solution store.  Executed by one workgroup on LDS workspace `w`.
 // ---------------------------------------------------------------------------------------------------------
-// inversion stage of the factorisation: partitioned (4 interiors + separators, fast ADMM path) or one-sided chain
+// inversion stage of the factorisation: dense nested dissection (fast ADMM path) or one-sided chain
 TMX_DEVFN void kkt_invert(const QpWs& w, bool partitioned, int tid, int NT)
 {
 #if TMX_IS_DEVICE
   if (partitioned)
   {
-    part_factor(w, tid, NT);
+    dpart_factor(w, tid, NT);
     return;
   }
   if (w.D * w.D <= 64)
@@ -440,12 +440,15 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
   const int D = P->D, T = P->T, NX = P->NX, R = P->R;
   const tmx_osqp_settings& st = P->osqp;
   QpWs w;
+  {
+    double* scratch = Bt->qp_scratch + (size_t)b * Bt->qp_scratch_stride;
 #if TMX_QP_COLD_IN_LDS
-  qp_ws_carve(w, smem, smem + qp_lds_doubles(D, T, R, P->NA), D, T, R, P->NA);
+    qp_ws_carve(w, smem, smem + qp_lds_doubles(D, T, R, P->NA), scratch, D, T, R, P->NA);
 #else
-  qp_ws_carve(w, smem, Bt->qp_scratch + (size_t)b * Bt->qp_scratch_stride, D, T, R, P->NA);
+    qp_ws_carve(w, smem, scratch + qp_far_doubles(D, T, R, P->NA), scratch, D, T, R, P->NA);
 #endif
-  long long pc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+  }
+  long long pc[16] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
   long long tlast = TMX_CLK();
   const int* g_act = Bt->active + (size_t)b * R;
   const double* g_coef = Bt->coef + (size_t)b * R * D;
@@ -629,10 +632,10 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
       double c_temp = sum / (double)n;
       c_temp = fmax(c_temp, limit_scaling(qmax));
       c_temp = limit_scaling(c_temp);
-      w.red[64] = 1.0 / c_temp;
+      w.red[128] = 1.0 / c_temp;
     }
     TMX_SYNC();
-    const double ct = w.red[64];
+    const double ct = w.red[128];
     for (int v = tid; v < NX; v += NT)
     {
       w.pd[v] *= ct;
@@ -718,7 +721,7 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
   // ---------------- factor + ADMM loop (osqp_solve) --------------------------------------------------------
   TMX_TICK(0);
 #if TMX_IS_DEVICE
-  const bool fast = (NT == 256) && (R <= 512) && (NX <= 256) && (D <= 8) && (T >= 7);
+  const bool fast = (NT == TMX_QP_NT) && (R <= 512) && dpart_supported(w, NT);
 #else
   const bool fast = false;
 #endif
@@ -1040,7 +1043,7 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
         hact += tmx_hash_term((long long)w.flg_ba[a], (uint64_t)(mg + w.aux_ref[r] + k), 5);
       }
     }
-  unsigned long long* hacc = reinterpret_cast<unsigned long long*>(w.red + 70);
+  unsigned long long* hacc = reinterpret_cast<unsigned long long*>(w.red + 130);
   if (tid == 0)
     *hacc = 0ULL;
   TMX_SYNC();
@@ -1077,10 +1080,14 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
       Bt->prev_dims[4 * b + q] = dims[q];
     Bt->prev_ws[2 * b + 0] = hs[2];
     Bt->prev_ws[2 * b + 1] = hs[3];
-    for (int q = 0; q < 8; ++q)
-      Bt->prof[(size_t)b * 8 + q] = pc[q];
   }
   TMX_SYNC();
+  TMX_TICK(10);
+#ifdef TMX_PROFILE
+  if (tid == 0)
+    for (int q = 0; q < 16; ++q)
+      Bt->prof[(size_t)b * 16 + q] += pc[q];
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------

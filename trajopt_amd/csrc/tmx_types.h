@@ -82,5 +82,5 @@ struct DevBatch
   int *sched_done;     // 1: number of finished problems
   double *qp_scratch;  // B x qp_glb_doubles: cold part of the k_qp_solve workspace
   long long qp_scratch_stride;
-  long long *prof;  // B x 8 phase cycle counters of the last k_qp_solve (thread 0 view): setup, factor, A, B, chain, C, check, polish
+  long long *prof;  // B x 16 phase cycle counters (thread 0 view, -DTMX_PROFILE builds), accumulated since k_prepare
 };
