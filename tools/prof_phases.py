@@ -27,7 +27,7 @@ out = (C.c_longlong * 16)()
 ctx.lib.tmx_debug_phase_cycles.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
 ctx.lib.tmx_debug_phase_cycles(ctx.h, out)
 names = ["setup", "factor", "phaseA+B", "interior", "sep+corr", "phaseC", "resid+check", "polish", "burst entry", "burst exit",
-         "store", "convexify", "eval+update", "-", "-", "-"]
+         "store", "convexify", "eval+update", "f:assemble", "f:G inverses", "f:Schur+Zs"]
 tot = sum(out)
 print("B", B, "kernel ms", st["admm_ms"], "admm iters", iters, "qp solves", nqp, "iters/qp", iters / nqp)
 for n, c in zip(names, out):

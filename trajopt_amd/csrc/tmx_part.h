@@ -127,54 +127,121 @@ TMX_DEVFN void dpart_map(const QpWs& w, const DPart& p, int tid, DMap& m)
     }
 }
 
-// in-place Gauss-Jordan inverse of an SPD n x n matrix (n <= 32) by one wave; entries are spread over the lanes and
-// every elimination step is two wave-synchronous LDS passes (all loads, then all stores)
-TMX_DEVFN void gj_wave(double* M, int n, int stride, int lane)
+typedef double tmx_d2 __attribute__((ext_vector_type(2)));
+
+// reciprocal by v_rcp_f64 + two Newton steps (the elimination pivots are on the critical path of every step; the
+// IEEE division expands to ~40 dependent instructions)
+TMX_DEVFN double fast_rcp(double a)
 {
-  const int nn = n * n;
-  int off[16], ii[16], jj[16];
+  double x = __builtin_amdgcn_rcp(a);
+  x = __builtin_fma(__builtin_fma(-a, x, 1.0), x, x);
+  x = __builtin_fma(__builtin_fma(-a, x, 1.0), x, x);
+  return x;
+}
+
+// Register-resident Gauss-Jordan inversion of `nmat` SPD matrices held in LDS with a common row stride.
+// Thread role (m, i, seg): wn <= W consecutive entries [seg*wn, seg*wn + wn) of row i of matrix m stay in registers for
+// the whole elimination.  The sweep keeps the matrix (anti)symmetric - M[i][k] = M[k][i] for an unswept row i > k and
+// -M[k][i] for a swept row i < k - so a step only needs pivot ROW k: while step k is applied, the owner of row k+1
+// publishes its updated row (and the reciprocal of the next pivot) to a double-buffered LDS vector, and ONE workgroup
+// barrier per elimination step suffices.  The inner loop is branch-free (selects only).
+//   M   : matrix m at M + m*mslot, row stride `stride` (even, rows 16-byte aligned, wn even)
+//   n   : dimension of this thread's matrix (role inactive: active = false)
+//   buf : 2 * nmat * (stride + 2) doubles of LDS scratch, followed by >= W readable doubles
+template <int W>
+TMX_DEVFN void gj_rows(double* M, int mslot, int stride, int nmat, int nmax, bool active, int m, int i, int j0, int wn, int n, double* buf)
+{
+  // j0 (first column of this thread's segment) must be wave-uniform: the pivot-column fix-up and the next-pivot
+  // extraction then index the register array with a scalar (v_movrel) instead of a select per entry
+  const int bs = stride + 2;  // row buffer + [pivot reciprocal, pad]
+  double* Mr = M + m * mslot + i * stride + j0;
+  // loads and arithmetic run over all W register slots unconditionally (slots >= wn hold garbage that is never stored:
+  // a predicate per slot would turn into a branch + LDS round trip per entry); only the stores are predicated
+  double val[W];
 #pragma unroll
-  for (int q = 0; q < 16; ++q)
+  for (int c = 0; c < W; c += 2)
   {
-    const int e = lane + 64 * q;
-    const bool ok = e < nn;
-    ii[q] = ok ? e / n : -1;
-    jj[q] = ok ? e % n : 0;
-    off[q] = ok ? ii[q] * stride + jj[q] : 0;
+    const tmx_d2 t = *reinterpret_cast<const tmx_d2*>(Mr + c);
+    val[c] = active ? t.x : 0.0;
+    val[c + 1] = active ? t.y : 0.0;
   }
-  for (int k = 0; k < n; ++k)
+  if (active && i == 0)
   {
-    const double piv = 1.0 / M[k * stride + k];
-    double nv[16];
+    double* rb = buf + m * bs;
 #pragma unroll
-    for (int q = 0; q < 16; ++q)
+    for (int c = 0; c < W; ++c)
+      if (c < wn)
+        rb[j0 + c] = val[c];
+    if (j0 == 0)
+      rb[stride] = fast_rcp(val[0]);
+  }
+  TMX_SYNC();
+  for (int k = 0; k < nmax; ++k)
+  {
+    const int par = k & 1;
+    const int kk = __builtin_amdgcn_readfirstlane(k - j0);  // position of the pivot column in this wave's segment
+    if (active && k < n)
     {
-      nv[q] = 0.0;
-      if (64 * q < nn)
+      const double* rk = buf + (par * nmat + m) * bs;
+      const double piv = rk[stride];
+      const double rki = rk[i];
+      const double mik = (i < k) ? -rki : rki;  // column k from row k by (anti)symmetry
+      const bool prow = i == k;
+      // row k itself is scaled by the pivot reciprocal: same update formula with  a = piv - 1, b = M[k][j]  ->  val + a*val
+      const double nmp = prow ? (piv - 1.0) : -mik * piv;
+      const double pc = prow ? piv : nmp;  // value of the entry in the pivot column
+      tmx_d2 mk[W / 2];
+#pragma unroll
+      for (int c = 0; c < W / 2; ++c)
+        mk[c] = *reinterpret_cast<const tmx_d2*>(rk + j0 + 2 * c);
+#pragma unroll
+      for (int c = 0; c < W / 2; ++c)
       {
-        const int i = ii[q] < 0 ? 0 : ii[q], j = jj[q];
-        const double mij = M[off[q]], mik = M[i * stride + k], mkj = M[k * stride + j];
-        const double upd = mij - mik * mkj * piv;
-        nv[q] = (i == k) ? ((j == k) ? piv : mij * piv) : ((j == k) ? -mik * piv : upd);
+        val[2 * c] = __builtin_fma(nmp, mk[c].x, val[2 * c]);
+        val[2 * c + 1] = __builtin_fma(nmp, mk[c].y, val[2 * c + 1]);
+      }
+      {
+        // the index is clamped BEFORE use: the compiler hoists the indexed register write above the range test (it
+        // writes a copy and selects afterwards), and an out-of-range M0 index would clobber unrelated registers
+        const int kc = kk < 0 ? 0 : (kk >= W ? W - 1 : kk);
+        const double keep = val[kc];
+        val[kc] = (kk >= 0 && kk < wn) ? pc : keep;
+      }
+      if (i == k + 1)
+      {
+        double* rb = buf + ((par ^ 1) * nmat + m) * bs;
+#pragma unroll
+        for (int c = 0; c < W; ++c)
+          if (c < wn)
+            rb[j0 + c] = val[c];
+        // next pivot = M[k+1][k+1]: lives in the segment that contains column k+1
+        {
+          const int kn = kk + 1 < 0 ? 0 : (kk + 1 >= W ? W - 1 : kk + 1);
+          const double pvn = val[kn];
+          if (kk + 1 >= 0 && kk + 1 < wn)
+            rb[stride] = fast_rcp(pvn);
+        }
       }
     }
-    TMX_WAVE_SYNC();
-#pragma unroll
-    for (int q = 0; q < 16; ++q)
-    {
-      if (64 * q < nn && ii[q] >= 0)
-        M[off[q]] = nv[q];
-    }
-    TMX_WAVE_SYNC();
+    TMX_SYNC();
   }
+  if (active)
+  {
+#pragma unroll
+    for (int c = 0; c < W; ++c)
+      if (c < wn && j0 + c < n)
+        Mr[c] = val[c];
+  }
+  TMX_SYNC();
 }
 
 // ---- factor driver (ADMM weights): call after kkt_factor() has assembled the diagonal blocks into w.Sinv ----------
-TMX_DEVFN void dpart_factor(const QpWs& w, int tid, int NT)
+TMX_DEVFN void dpart_factor(const QpWs& w, int tid, int NT, long long* pc, long long& tlast)
 {
   const int D = w.D, DS = w.DS, DDS = w.DDS, Gn = w.Gn, Gs = w.Gs, Zst = w.Zst;
   DPart p;
   dpart_make(w.T, p);
+  const int ns = (p.P - 1) * D;
   // 1. interior diagonal sub-matrices (block tridiagonal with diagonal coupling blocks), zero padded
   for (int e = tid; e < p.P * Gn * Gs; e += NT)
   {
@@ -193,12 +260,20 @@ TMX_DEVFN void dpart_factor(const QpWs& w, int tid, int NT)
     w.G[e] = val;
   }
   TMX_SYNC();
-  // 2. explicit inverses, one wave per interior
-  for (int k = tid >> 6; k < p.P; k += NT >> 6)
-    gj_wave(w.G + k * Gn * Gs, p.len[k] * D, Gs, tid & 63);
-  TMX_SYNC();
+  // 2. explicit inverses of all interiors at once: one thread per matrix row (scratch: the Zs region, not yet built)
+  {
+    const int m = tid / Gn, i = tid % Gn;
+    const bool active = m < p.P && i < p.len[m < 8 ? m : 0] * D;
+    const int n = active ? p.len[m] * D : 0;
+    if (Gs <= 16)
+      gj_rows<16>(w.G, Gn * Gs, Gs, p.P, Gn, active, active ? m : 0, i, 0, Gs, n, w.Zs);
+    else if (Gs <= 24)
+      gj_rows<24>(w.G, Gn * Gs, Gs, p.P, Gn, active, active ? m : 0, i, 0, Gs, n, w.Zs);
+    else
+      gj_rows<34>(w.G, Gn * Gs, Gs, p.P, Gn, active, active ? m : 0, i, 0, Gs, n, w.Zs);
+  }
+  TMX_TICK(14);
   // 3. Schur complement on the separators (block tridiagonal, (P-1) blocks of D)
-  const int ns = (p.P - 1) * D;
   for (int e = tid; e < ns * Zst; e += NT)
   {
     const int rI = e / Zst, cI = e % Zst;
@@ -221,46 +296,16 @@ TMX_DEVFN void dpart_factor(const QpWs& w, int tid, int NT)
     w.Zs[e] = val;
   }
   TMX_SYNC();
-  // 4. its dense inverse (SPD): in-place Gauss-Jordan by the whole workgroup
-  double* colk = w.sx + 256;
-  int ei[16], ej[16], eo[16];
-#pragma unroll
-  for (int q = 0; q < 16; ++q)
+  // 4. its dense inverse (SPD): lane = row, wave = column quarter (scratch: the separator exchange vectors)
   {
-    const int e = tid + NT * q;
-    const bool ok = e < ns * ns;
-    ei[q] = ok ? e / ns : -1;
-    ej[q] = ok ? e % ns : 0;
-    eo[q] = ok ? ei[q] * Zst + ej[q] : 0;
+    const int i = tid & 63, seg = (tid >> 6) & 3;
+    const bool active = i < ns && tid < 256;
+    if (Zst <= 32)
+      gj_rows<8>(w.Zs, 0, Zst, 1, ns, active, 0, active ? i : 0, seg * (Zst >> 2), Zst >> 2, ns, w.sx);
+    else
+      gj_rows<16>(w.Zs, 0, Zst, 1, ns, active, 0, active ? i : 0, seg * (Zst >> 2), Zst >> 2, ns, w.sx);
   }
-  for (int k = 0; k < ns; ++k)
-  {
-    const double piv = 1.0 / w.Zs[k * Zst + k];
-    if (tid < ns)
-      colk[tid] = w.Zs[tid * Zst + k];
-    TMX_SYNC();
-    double nv[16];
-#pragma unroll
-    for (int q = 0; q < 16; ++q)
-    {
-      nv[q] = 0.0;
-      if (NT * q < ns * ns)
-      {
-        const int i = ei[q] < 0 ? 0 : ei[q], j = ej[q];
-        const double mij = w.Zs[eo[q]], mik = colk[i], mkj = w.Zs[k * Zst + j];
-        const double upd = mij - mik * mkj * piv;
-        nv[q] = (i == k) ? ((j == k) ? piv : mij * piv) : ((j == k) ? -mik * piv : upd);
-      }
-    }
-    TMX_SYNC();
-#pragma unroll
-    for (int q = 0; q < 16; ++q)
-    {
-      if (NT * q < ns * ns && ei[q] >= 0)
-        w.Zs[eo[q]] = nv[q];
-    }
-    TMX_SYNC();
-  }
+  TMX_TICK(15);
 }
 
 // ---- LDS-typed view of the arrays the iteration touches (explicit address space: ds_read / ds_write even inside the
@@ -271,7 +316,6 @@ struct HotLds
   tmx_lds_d *hr, *ty, *tp, *G, *Zs, *sx, *po;
   int D, Gn, Gs, Zst;
 };
-typedef double tmx_d2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) tmx_d2 tmx_lds_d2;
 
 // sum over the 4 lanes of a quad (DPP quad_perm, no LDS): every lane gets the total

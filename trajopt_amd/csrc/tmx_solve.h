@@ -256,12 +256,13 @@ TMX_DEVFN void qp_structure(const DevProblem* P, const int* active, const double
 // polish, solution store.  Executed by one workgroup on LDS workspace `w`.
 // ---------------------------------------------------------------------------------------------------------
 // inversion stage of the factorisation: dense nested dissection (fast ADMM path) or one-sided chain
-TMX_DEVFN void kkt_invert(const QpWs& w, bool partitioned, int tid, int NT)
+TMX_DEVFN void kkt_invert(const QpWs& w, bool partitioned, int tid, int NT, long long* pc, long long& tlast)
 {
 #if TMX_IS_DEVICE
   if (partitioned)
   {
-    dpart_factor(w, tid, NT);
+    TMX_TICK(13);
+    dpart_factor(w, tid, NT, pc, tlast);
     return;
   }
   if (w.D * w.D <= 64)
@@ -516,26 +517,37 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
   }
   for (int t = tid; t <= T; t += NT)
     w.wp_start[t] = P->wp_start[t];
-  if (tid == 0)
-  {
-    int nr = 0, na = 0;
-    for (int r = 0; r < R; ++r)
-    {
-      w.row_ref[r] = nr;
-      w.aux_ref[r] = NX + na;
-      if (g_act[r])
-      {
-        nr += 1;
-        na += P->slot_naux[r];
-      }
-    }
-  }
   w.sigma = st.sigma;
   w.alpha = st.alpha;
   w.c = 1.0;
   w.cinv = 1.0;
   TMX_SYNC();
+  // position of every active row / of its aux vars in the reference-order solution vectors (exclusive prefix counts)
+  for (int r = tid; r < R; r += NT)
+  {
+    int nr = 0, na = 0;
+    for (int q = 0; q < r; ++q)
+    {
+      const int aq = w.act[q];
+      nr += aq;
+      na += aq ? w.naux[q] : 0;
+    }
+    w.row_ref[r] = nr;
+    w.aux_ref[r] = NX + na;
+  }
   const int n = dims[0], m = dims[1], mg = m - n;
+  // Ruiz temporaries live in the (not yet factorised) G region of the LDS workspace when it exists
+  const bool lds_tmp = (w.G != nullptr) && ((size_t)NX + 3 * (size_t)P->NA <= (size_t)w.Gn * w.Gs);
+  double* const t_ebp = lds_tmp ? w.G : w.dybp;
+  double* const t_eba = lds_tmp ? w.G + NX : w.dyba;
+  double* const t_da = lds_tmp ? w.G + NX + P->NA : w.ta;
+  double* const acc_da = lds_tmp ? w.G + NX + 2 * P->NA : w.Da;  // running D scaling of the aux vars
+  if (lds_tmp)
+  {
+    for (int a = tid; a < P->NA; a += NT)
+      acc_da[a] = 1.0;
+    TMX_SYNC();
+  }
 
   // ---------------- Ruiz equilibration (scale_data) ------------------------------------------------------
   // temporaries: D_temp_p -> tp, D_temp_a -> ta, E_temp_r -> hr, E_temp_bp -> dybp, E_temp_ba -> dyba
@@ -557,7 +569,7 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
       }
       cn = fmax(cn, fabs(w.bbp[v]));
       w.tp[v] = 1.0 / sqrt(limit_scaling(cn));
-      w.dybp[v] = 1.0 / sqrt(limit_scaling(fabs(w.bbp[v])));
+      t_ebp[v] = 1.0 / sqrt(limit_scaling(fabs(w.bbp[v])));
     }
     for (int r = tid; r < R; r += NT)
     {
@@ -570,8 +582,8 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
       {
         const int a = w.aoff[r] + k;
         rn = fmax(rn, fabs(w.sa[a]));
-        w.ta[a] = 1.0 / sqrt(limit_scaling(fmax(fabs(w.sa[a]), fabs(w.bba[a]))));
-        w.dyba[a] = 1.0 / sqrt(limit_scaling(fabs(w.bba[a])));
+        t_da[a] = 1.0 / sqrt(limit_scaling(fmax(fabs(w.sa[a]), fabs(w.bba[a]))));
+        t_eba[a] = 1.0 / sqrt(limit_scaling(fabs(w.bba[a])));
       }
       w.hr[r] = 1.0 / sqrt(limit_scaling(rn));
     }
@@ -581,10 +593,10 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
       w.pd[v] = (w.tp[v] * w.pd[v]) * w.tp[v];
       if (v < NX - D)
         w.po[v] = (w.tp[v] * w.po[v]) * w.tp[v + D];
-      w.bbp[v] = (w.dybp[v] * w.bbp[v]) * w.tp[v];
+      w.bbp[v] = (t_ebp[v] * w.bbp[v]) * w.tp[v];
       w.qp[v] *= w.tp[v];
       w.Dp[v] *= w.tp[v];
-      w.Ebp[v] *= w.dybp[v];
+      w.Ebp[v] *= t_ebp[v];
     }
     for (int r = tid; r < R; r += NT)
     {
@@ -596,11 +608,11 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
       for (int k = 0; k < w.naux[r]; ++k)
       {
         const int a = w.aoff[r] + k;
-        w.sa[a] = (w.hr[r] * w.sa[a]) * w.ta[a];
-        w.bba[a] = (w.dyba[a] * w.bba[a]) * w.ta[a];
-        w.qa[a] *= w.ta[a];
-        w.Da[a] *= w.ta[a];
-        w.Eba[a] *= w.dyba[a];
+        w.sa[a] = (w.hr[r] * w.sa[a]) * t_da[a];
+        w.bba[a] = (t_eba[a] * w.bba[a]) * t_da[a];
+        w.qa[a] *= t_da[a];
+        acc_da[a] *= t_da[a];
+        w.Eba[a] *= t_eba[a];
       }
       w.Er[r] *= w.hr[r];
     }
@@ -624,12 +636,24 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
           qmax = fmax(qmax, fabs(w.qa[w.aoff[r] + k]));
     qmax = block_max1(qmax, w.red, tid, NT);
     TMX_SYNC();
+    double csum = 0.0;
+    for (int v = tid; v < NX; v += NT)
+      csum += w.tp[v];
+    {
+      double cs[1] = { csum };
+      const bool issum[1] = { true };
+      block_reduce<1>(cs, issum, w.red, tid, NT);
+      csum = cs[0];
+    }
+#if !TMX_IS_DEVICE
+    csum = 0.0;  // host emulation (one thread per workgroup): sequential, index order (as vec_norm_1 / n upstream)
+    for (int v = 0; v < NX; ++v)
+      csum += w.tp[v];
+#endif
+    TMX_SYNC();
     if (tid == 0)
     {
-      double sum = 0.0;  // sequential, index order (as vec_norm_1 / n upstream)
-      for (int v = 0; v < NX; ++v)
-        sum += w.tp[v];
-      double c_temp = sum / (double)n;
+      double c_temp = csum / (double)n;
       c_temp = fmax(c_temp, limit_scaling(qmax));
       c_temp = limit_scaling(c_temp);
       w.red[128] = 1.0 / c_temp;
@@ -650,6 +674,9 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
     TMX_SYNC();
   }
   w.cinv = 1.0 / w.c;
+  if (lds_tmp)
+    for (int a = tid; a < P->NA; a += NT)
+      w.Da[a] = acc_da[a];
   for (int v = tid; v < NX; v += NT)
   {
     w.lbp[v] *= w.Ebp[v];
@@ -726,7 +753,7 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
   const bool fast = false;
 #endif
   kkt_factor(w, P, 0, w.sigma, st.delta, tid, NT);
-  kkt_invert(w, fast, tid, NT);
+  kkt_invert(w, fast, tid, NT, pc, tlast);
   admm_cache_weights(w, tid, NT);
   TMX_TICK(1);
   QpInfo info;
@@ -788,7 +815,7 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
         info.rho_updates += 1;
         TMX_TICK(6);
         kkt_factor(w, P, 0, w.sigma, st.delta, tid, NT);
-        kkt_invert(w, fast, tid, NT);
+        kkt_invert(w, fast, tid, NT, pc, tlast);
         admm_cache_weights(w, tid, NT);
         TMX_TICK(1);
       }
@@ -845,7 +872,7 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
     }
     TMX_SYNC();
     kkt_factor(w, P, 1, delta, delta, tid, NT);
-    kkt_invert(w, false, tid, NT);
+    kkt_invert(w, false, tid, NT, pc, tlast);
     // polished iterate lives in (dxp, dxa | dyr, dybp, dyba)
     for (int pass = 0; pass <= st.polish_refine_iter; ++pass)
     {
@@ -1109,8 +1136,87 @@ TMX_DEVFN void sqp_update_block(const DevProblem* P, const DevBatch* Bt, int b, 
   const double* new_cost = Bt->new_cost_vals + (size_t)b * P->n_costs;
   const double* new_viol = Bt->new_cnt_viols + (size_t)b * P->n_cnts;
   double* merit = Bt->merit + (size_t)b * P->n_cnts;
+  // ---- model values at the QP solution: ConvexObjective::value / ConvexConstraints::violation, in parallel -------
+  // (per-slot values and velocity terms by all threads, then one thread per owner sums its slots in slot order)
+  const bool solved = Bt->cvx[b] == TMX_CVX_SOLVED && Bt->phase[b] != PHASE_DONE;
+  if (solved)
+  {
+    double* val = model_viol + P->n_cnts;  // R
+    int* keys = reinterpret_cast<int*>(val + R);
+    double* vterm = val + R + (R + 1) / 2;
+    double* vsum = vterm + (size_t)P->n_vel * NX;
+    QpWs wl;  // only for the layout of the per-problem scratch (aux_ref written by the QP kernel)
+    qp_ws_carve(wl, smem, smem, Bt->qp_scratch + (size_t)b * Bt->qp_scratch_stride, D, P->T, R, P->NA);
+    const int* aux_ref = wl.aux_ref;
+    for (int r = tid; r < R; r += NT)
+    {
+      double vr = 0.0;
+      int key = -1;
+      if (P->slot_kind[r] != SLOT_FIXED && act[r])
+      {
+        const int t = P->slot_t[r];
+        if (P->slot_iscnt[r])
+        {
+          double aff = 0.0;
+          for (int j = 0; j < D; ++j)
+            aff += coef[r * D + j] * xq[t * D + j];
+          aff -= rhs[r];
+          vr = P->slot_eq[r] ? fabs(aff) : ((aff > 0) ? aff : 0.0);
+          key = P->n_costs + P->slot_owner[r];
+        }
+        else
+        {
+          // cost rows: objective coefficient times the aux values of the QP solution
+          double sacc = 0.0;
+          for (int k = 0; k < P->slot_naux[r]; ++k)
+            sacc += P->slot_objc[r] * xq[aux_ref[r] + k];
+          vr = sacc;
+          key = P->slot_owner[r];
+        }
+      }
+      val[r] = vr;
+      keys[r] = key;
+    }
+    for (int v = 0; v < P->n_vel; ++v)
+    {
+      const int first = P->vel_first[v], len = P->vel_last[v] - first;
+      for (int e = tid; e < D * len; e += NT)
+      {
+        const int j = e / len, i = first + e % len;
+        const double d = (xq[(i + 1) * D + j] - xq[i * D + j]) - P->vel_targets[v * TMX_MAX_DOF + j];
+        vterm[(size_t)v * NX + e] = (d * d) * P->vel_coeffs[v * TMX_MAX_DOF + j];
+      }
+    }
+    TMX_SYNC();
+    for (int v = tid; v < P->n_vel; v += NT)
+    {
+      const int cnt = D * (P->vel_last[v] - P->vel_first[v]);
+      double sacc = 0;
+      for (int e = 0; e < cnt; ++e)
+        sacc += vterm[(size_t)v * NX + e];
+      vsum[v] = sacc;
+    }
+    TMX_SYNC();
+    for (int k = tid; k < P->n_costs + P->n_cnts; k += NT)
+    {
+      double acc = 0.0;
+      for (int r = 0; r < R; ++r)
+        if (keys[r] == k)
+          acc += val[r];
+      if (k < P->n_costs)
+      {
+        for (int v = 0; v < P->n_vel; ++v)
+          if (P->vel_cost[v] == k)
+            acc += vsum[v];
+        model_cost[k] = acc;
+      }
+      else
+        model_viol[k - P->n_costs] = acc;
+    }
+    TMX_SYNC();
+  }
   if (tid != 0)
-    return;  // decisions are serial per problem (O(terms)); the heavy parts ran in the evaluate / QP kernels
+    return;  // the decisions are serial per problem (O(terms))
   int phase = Bt->phase[b];
   if (phase == PHASE_DONE)
     return;
@@ -1146,48 +1252,6 @@ TMX_DEVFN void sqp_update_block(const DevProblem* P, const DevBatch* Bt, int b, 
   }
   else
   {
-    // model values at the QP solution: ConvexObjective::value / ConvexConstraints::violation
-    for (int k = 0; k < P->n_costs; ++k)
-      model_cost[k] = 0.0;
-    for (int k = 0; k < P->n_cnts; ++k)
-      model_viol[k] = 0.0;
-    {
-      int na = 0;
-      for (int r = 0; r < R; ++r)
-      {
-        if (P->slot_kind[r] == SLOT_FIXED || !act[r])
-          continue;
-        const int t = P->slot_t[r];
-        if (P->slot_iscnt[r])
-        {
-          double aff = 0.0;
-          for (int j = 0; j < D; ++j)
-            aff += coef[r * D + j] * xq[t * D + j];
-          aff -= rhs[r];
-          model_viol[P->slot_owner[r]] += P->slot_eq[r] ? fabs(aff) : ((aff > 0) ? aff : 0.0);
-        }
-        else
-        {
-          // cost rows: objective coefficient times the aux values of the QP solution
-          double s = 0.0;
-          for (int k = 0; k < P->slot_naux[r]; ++k)
-            s += P->slot_objc[r] * xq[NX + na + k];
-          model_cost[P->slot_owner[r]] += s;
-        }
-        na += P->slot_naux[r];
-      }
-      for (int v = 0; v < P->n_vel; ++v)
-      {
-        double s = 0.0;
-        for (int j = 0; j < D; ++j)
-          for (int i = P->vel_first[v]; i <= P->vel_last[v] - 1; ++i)
-          {
-            const double d = (xq[(i + 1) * D + j] - xq[i * D + j]) - P->vel_targets[v * TMX_MAX_DOF + j];
-            s += (d * d) * P->vel_coeffs[v * TMX_MAX_DOF + j];
-          }
-        model_cost[P->vel_cost[v]] += s;
-      }
-    }
     double old_merit = 0.0, model_merit = 0.0, new_merit = 0.0;
     for (int k = 0; k < P->n_costs; ++k)
     {

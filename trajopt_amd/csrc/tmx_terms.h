@@ -201,8 +201,13 @@ TMX_DEVFN double contact_distance(const DevProblem* P, const double* q, int s, i
 // ---------------------------------------------------------------------------------------------------
 // K6: exact costs / constraint violations at trajectory xv -> cost_out[n_costs], viol_out[n_cnts]
 // (BasicTrustRegionSQP::evaluateCosts / evaluateConstraintViols, trajopt_sco/src/optimizers.cpp:176-192)
-// `scratch` : LDS, >= R doubles
+// `scratch` : LDS, >= tmx_eval_scratch_doubles(P) doubles
 // ---------------------------------------------------------------------------------------------------
+// LDS doubles needed by evaluate_terms / sqp_update_block: slot values, slot keys, velocity terms + sums
+TMX_HOSTDEVFN size_t tmx_eval_scratch_doubles(int R, int NX, int n_vel, int n_costs, int n_cnts)
+{
+  return (size_t)R + (size_t)(R + 1) / 2 + (size_t)n_vel * NX + (size_t)n_vel + (size_t)n_costs + (size_t)n_cnts + 16;
+}
 TMX_DEVFN void evaluate_terms(const DevProblem* P, const double* xv, double* cost_out, double* viol_out, double* scratch,
                               int tid, int NT)
 {
@@ -250,36 +255,49 @@ TMX_DEVFN void evaluate_terms(const DevProblem* P, const double* xv, double* cos
       scratch[s0 + i] = P->cp_iscnt[c] ? fabs(e * cc) : fabs(e) * cc;
     }
   }
-  TMX_SYNC();
-  // zero the outputs, then accumulate per owner in slot order (sequential per owner => reference summation order)
-  for (int k = tid; k < P->n_costs; k += NT)
-    cost_out[k] = 0.0;
-  for (int k = tid; k < P->n_cnts; k += NT)
-    viol_out[k] = 0.0;
-  TMX_SYNC();
-  if (tid == 0)
+  // owner key of every slot (cost owners first, then constraint owners; -1 = contributes nothing)
+  int* keys = reinterpret_cast<int*>(scratch + P->R);
+  for (int r = tid; r < P->R; r += NT)
+    keys[r] = (P->slot_kind[r] == SLOT_FIXED) ? -1 : (P->slot_iscnt[r] ? P->n_costs + P->slot_owner[r] : P->slot_owner[r]);
+  // JointVelEqCost::value — (diff^2 * diag(coeffs)).sum(): the terms in parallel, summed below in column-major order
+  double* vterm = scratch + P->R + (P->R + 1) / 2;  // n_vel x (D * (T-1))
+  double* vsum = vterm + (size_t)P->n_vel * P->NX;
+  for (int v = 0; v < P->n_vel; ++v)
   {
+    const int first = P->vel_first[v], len = P->vel_last[v] - first;
+    for (int e = tid; e < D * len; e += NT)
+    {
+      const int j = e / len, i = first + e % len;
+      const double d = (xv[(i + 1) * D + j] - xv[i * D + j]) - P->vel_targets[v * TMX_MAX_DOF + j];
+      vterm[(size_t)v * P->NX + e] = (d * d) * P->vel_coeffs[v * TMX_MAX_DOF + j];
+    }
+  }
+  TMX_SYNC();
+  for (int v = tid; v < P->n_vel; v += NT)
+  {
+    const int cnt = D * (P->vel_last[v] - P->vel_first[v]);
+    double sacc = 0;
+    for (int e = 0; e < cnt; ++e)
+      sacc += vterm[(size_t)v * P->NX + e];
+    vsum[v] = sacc;
+  }
+  TMX_SYNC();
+  // one thread per owner accumulates its slots in slot order (sequential per owner => reference summation order)
+  for (int k = tid; k < P->n_costs + P->n_cnts; k += NT)
+  {
+    double acc = 0.0;
     for (int r = 0; r < P->R; ++r)
+      if (keys[r] == k)
+        acc += scratch[r];
+    if (k < P->n_costs)
     {
-      if (P->slot_kind[r] == SLOT_FIXED)
-        continue;
-      if (P->slot_iscnt[r])
-        viol_out[P->slot_owner[r]] += scratch[r];
-      else
-        cost_out[P->slot_owner[r]] += scratch[r];
+      for (int v = 0; v < P->n_vel; ++v)
+        if (P->vel_cost[v] == k)
+          acc += vsum[v];
+      cost_out[k] = acc;
     }
-    // JointVelEqCost::value — (diff^2 * diag(coeffs)).sum(), column-major reduction order
-    for (int v = 0; v < P->n_vel; ++v)
-    {
-      double s = 0;
-      for (int j = 0; j < D; ++j)
-        for (int i = P->vel_first[v]; i <= P->vel_last[v] - 1; ++i)
-        {
-          const double d = (xv[(i + 1) * D + j] - xv[i * D + j]) - P->vel_targets[v * TMX_MAX_DOF + j];
-          s += (d * d) * P->vel_coeffs[v * TMX_MAX_DOF + j];
-        }
-      cost_out[P->vel_cost[v]] += s;
-    }
+    else
+      viol_out[k - P->n_costs] = acc;
   }
   TMX_SYNC();
 }
