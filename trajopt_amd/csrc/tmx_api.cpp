@@ -473,6 +473,7 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
   const size_t small_ints = (size_t)(P.n_max + 1) + 2 * (size_t)R + 2 + 16;
   ctx->smem_small = std::max<size_t>((tmx_eval_scratch_doubles(R, D * T, (int)vel_first.size(), n_costs, n_cnts) + n_costs + n_cnts + 8) * sizeof(double),
                                      small_ints * sizeof(int) + 64);
+  ctx->smem_small = std::max<size_t>(ctx->smem_small, tmx_cvx_scratch_doubles(P.n_cp, D) * sizeof(double));
 #ifdef TMX_HOST_EMU
   ctx->nt_qp = 1;
   ctx->nt_small = 1;

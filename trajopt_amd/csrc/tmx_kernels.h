@@ -80,7 +80,7 @@ TMX_KERNEL_LB(256) k_convexify(const DevProblem* P, const DevBatch* Bt, int forc
   double* coef = Bt->coef + (size_t)b * R * D;
   double* rhs = Bt->rhs + (size_t)b * R;
   const double* x = Bt->x + (size_t)b * P->NX;
-  convexify_terms(P, x, act, coef, rhs, tid, NT);
+  convexify_terms(P, x, act, coef, rhs, smem, tid, NT);
   qp_structure(P, act, coef, rhs, x, Bt->trust[b], Bt->merit + (size_t)b * P->n_cnts, Bt->dims + 4 * b, Bt->hashes + 4 * b,
                nullptr, reinterpret_cast<int*>(smem), tid, NT);
 }
@@ -136,7 +136,7 @@ TMX_DEVFN void sqp_step_block(const DevProblem* P, const DevBatch* Bt, int b, do
 #endif
   if (Bt->phase[b] == PHASE_CONVEXIFY)
   {
-    convexify_terms(P, x, act, coef, rhs, tid, NT);
+    convexify_terms(P, x, act, coef, rhs, smem, tid, NT);
     qp_structure(P, act, coef, rhs, x, Bt->trust[b], Bt->merit + (size_t)b * P->n_cnts, Bt->dims + 4 * b, Bt->hashes + 4 * b,
                  nullptr, reinterpret_cast<int*>(smem), tid, NT);
   }

@@ -129,16 +129,6 @@ TMX_DEVFN void dpart_map(const QpWs& w, const DPart& p, int tid, DMap& m)
 
 typedef double tmx_d2 __attribute__((ext_vector_type(2)));
 
-// reciprocal by v_rcp_f64 + two Newton steps (the elimination pivots are on the critical path of every step; the
-// IEEE division expands to ~40 dependent instructions)
-TMX_DEVFN double fast_rcp(double a)
-{
-  double x = __builtin_amdgcn_rcp(a);
-  x = __builtin_fma(__builtin_fma(-a, x, 1.0), x, x);
-  x = __builtin_fma(__builtin_fma(-a, x, 1.0), x, x);
-  return x;
-}
-
 // Register-resident Gauss-Jordan inversion of `nmat` SPD matrices held in LDS with a common row stride.
 // Thread role (m, i, seg): wn <= W consecutive entries [seg*wn, seg*wn + wn) of row i of matrix m stay in registers for
 // the whole elimination.  The sweep keeps the matrix (anti)symmetric - M[i][k] = M[k][i] for an unswept row i > k and
@@ -148,7 +138,7 @@ TMX_DEVFN double fast_rcp(double a)
 //   M   : matrix m at M + m*mslot, row stride `stride` (even, rows 16-byte aligned, wn even)
 //   n   : dimension of this thread's matrix (role inactive: active = false)
 //   buf : 2 * nmat * (stride + 2) doubles of LDS scratch, followed by >= W readable doubles
-template <int W>
+template <int W, bool INDEXED>
 TMX_DEVFN void gj_rows(double* M, int mslot, int stride, int nmat, int nmax, bool active, int m, int i, int j0, int wn, int n, double* buf)
 {
   // j0 (first column of this thread's segment) must be wave-uniform: the pivot-column fix-up and the next-pivot
@@ -200,12 +190,19 @@ TMX_DEVFN void gj_rows(double* M, int mslot, int stride, int nmat, int nmax, boo
         val[2 * c] = __builtin_fma(nmp, mk[c].x, val[2 * c]);
         val[2 * c + 1] = __builtin_fma(nmp, mk[c].y, val[2 * c + 1]);
       }
+      if (INDEXED)
       {
         // the index is clamped BEFORE use: the compiler hoists the indexed register write above the range test (it
         // writes a copy and selects afterwards), and an out-of-range M0 index would clobber unrelated registers
         const int kc = kk < 0 ? 0 : (kk >= W ? W - 1 : kk);
         const double keep = val[kc];
         val[kc] = (kk >= 0 && kk < wn) ? pc : keep;
+      }
+      else
+      {
+#pragma unroll
+        for (int c = 0; c < W; ++c)
+          val[c] = (c == kk) ? pc : val[c];
       }
       if (i == k + 1)
       {
@@ -216,8 +213,19 @@ TMX_DEVFN void gj_rows(double* M, int mslot, int stride, int nmat, int nmax, boo
             rb[j0 + c] = val[c];
         // next pivot = M[k+1][k+1]: lives in the segment that contains column k+1
         {
-          const int kn = kk + 1 < 0 ? 0 : (kk + 1 >= W ? W - 1 : kk + 1);
-          const double pvn = val[kn];
+          double pvn;
+          if (INDEXED)
+          {
+            const int kn = kk + 1 < 0 ? 0 : (kk + 1 >= W ? W - 1 : kk + 1);
+            pvn = val[kn];
+          }
+          else
+          {
+            pvn = val[0];
+#pragma unroll
+            for (int c = 1; c < W; ++c)
+              pvn = (c == kk + 1) ? val[c] : pvn;
+          }
           if (kk + 1 >= 0 && kk + 1 < wn)
             rb[stride] = fast_rcp(pvn);
         }
@@ -266,11 +274,11 @@ TMX_DEVFN void dpart_factor(const QpWs& w, int tid, int NT, long long* pc, long 
     const bool active = m < p.P && i < p.len[m < 8 ? m : 0] * D;
     const int n = active ? p.len[m] * D : 0;
     if (Gs <= 16)
-      gj_rows<16>(w.G, Gn * Gs, Gs, p.P, Gn, active, active ? m : 0, i, 0, Gs, n, w.Zs);
+      gj_rows<16, false>(w.G, Gn * Gs, Gs, p.P, Gn, active, active ? m : 0, i, 0, Gs, n, w.Zs);
     else if (Gs <= 24)
-      gj_rows<24>(w.G, Gn * Gs, Gs, p.P, Gn, active, active ? m : 0, i, 0, Gs, n, w.Zs);
+      gj_rows<24, false>(w.G, Gn * Gs, Gs, p.P, Gn, active, active ? m : 0, i, 0, Gs, n, w.Zs);
     else
-      gj_rows<34>(w.G, Gn * Gs, Gs, p.P, Gn, active, active ? m : 0, i, 0, Gs, n, w.Zs);
+      gj_rows<34, false>(w.G, Gn * Gs, Gs, p.P, Gn, active, active ? m : 0, i, 0, Gs, n, w.Zs);
   }
   TMX_TICK(14);
   // 3. Schur complement on the separators (block tridiagonal, (P-1) blocks of D)
@@ -301,9 +309,9 @@ TMX_DEVFN void dpart_factor(const QpWs& w, int tid, int NT, long long* pc, long 
     const int i = tid & 63, seg = (tid >> 6) & 3;
     const bool active = i < ns && tid < 256;
     if (Zst <= 32)
-      gj_rows<8>(w.Zs, 0, Zst, 1, ns, active, 0, active ? i : 0, seg * (Zst >> 2), Zst >> 2, ns, w.sx);
+      gj_rows<8, true>(w.Zs, 0, Zst, 1, ns, active, 0, active ? i : 0, seg * (Zst >> 2), Zst >> 2, ns, w.sx);
     else
-      gj_rows<16>(w.Zs, 0, Zst, 1, ns, active, 0, active ? i : 0, seg * (Zst >> 2), Zst >> 2, ns, w.sx);
+      gj_rows<16, true>(w.Zs, 0, Zst, 1, ns, active, 0, active ? i : 0, seg * (Zst >> 2), Zst >> 2, ns, w.sx);
   }
   TMX_TICK(15);
 }

@@ -46,23 +46,53 @@
 #endif
 
 
+// reciprocal by v_rcp_f64 + two Newton steps (~1 ulp): the IEEE division expands to ~15 instructions with a long
+// dependent chain, which matters where a reciprocal sits on a critical path (elimination pivots, residual unscaling)
+#if TMX_IS_DEVICE
+TMX_DEVFN double fast_rcp(double a)
+{
+  double x = __builtin_amdgcn_rcp(a);
+  x = __builtin_fma(__builtin_fma(-a, x, 1.0), x, x);
+  x = __builtin_fma(__builtin_fma(-a, x, 1.0), x, x);
+  return x;
+}
+#else
+TMX_DEVFN double fast_rcp(double a) { return 1.0 / a; }
+#endif
+
 // ---- block reductions -------------------------------------------------------------------------------
 #if TMX_IS_DEVICE
+// wave-wide max / sum of a double, result in every lane: DPP inside the 16-lane rows (no LDS traffic), then the 4 row
+// totals are combined through v_readlane
+template <bool SUM>
+TMX_DEVFN double wave_allreduce(double x)
+{
+#define TMX_DPP_STEP(ctrl)                                                                                            \
+  {                                                                                                                   \
+    const int lo_ = __builtin_amdgcn_mov_dpp(__double2loint(x), ctrl, 0xF, 0xF, true);                                \
+    const int hi_ = __builtin_amdgcn_mov_dpp(__double2hiint(x), ctrl, 0xF, 0xF, true);                                \
+    const double o_ = __hiloint2double(hi_, lo_);                                                                     \
+    x = SUM ? (x + o_) : fmax(x, o_);                                                                                 \
+  }
+  TMX_DPP_STEP(0xB1)   // quad_perm [1,0,3,2]
+  TMX_DPP_STEP(0x4E)   // quad_perm [2,3,0,1]
+  TMX_DPP_STEP(0x141)  // row_half_mirror
+  TMX_DPP_STEP(0x140)  // row_mirror: every lane of a row now holds the row total
+#undef TMX_DPP_STEP
+  const int lo = __double2loint(x), hi = __double2hiint(x);
+  const double r0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+  const double r1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
+  const double r2 = __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32));
+  const double r3 = __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
+  return SUM ? ((r0 + r1) + (r2 + r3)) : fmax(fmax(r0, r1), fmax(r2, r3));
+}
 template <int K>
 TMX_DEVFN void block_reduce(double (&v)[K], const bool (&is_sum)[K], double* red, int tid, int NT)
 {
   const int lane = tid & 63, wave = tid >> 6, nw = NT >> 6;
 #pragma unroll
   for (int k = 0; k < K; ++k)
-  {
-    double x = v[k];
-    for (int off = 32; off > 0; off >>= 1)
-    {
-      const double o = __shfl_xor(x, off, 64);
-      x = is_sum[k] ? (x + o) : fmax(x, o);
-    }
-    v[k] = x;
-  }
+    v[k] = is_sum[k] ? wave_allreduce<true>(v[k]) : wave_allreduce<false>(v[k]);
   if (nw > 1)
   {
     TMX_SYNC();
@@ -632,7 +662,7 @@ TMX_DEVFN void compute_residuals(const QpWs& w, const DevProblem* P, const doubl
     for (int k = 0; k < w.naux[r]; ++k)
       ax += w.sa[w.aoff[r] + k] * xa[w.aoff[r] + k];
     const double z = zmode ? clampd(ax, w.lor[r], w.hir[r]) : w.zr[r];
-    const double einv = 1.0 / w.Er[r];
+    const double einv = fast_rcp(w.Er[r]);
     m[0] = fmax(m[0], fabs(einv * (ax - z)));
     m[1] = fmax(m[1], fabs(ax - z));
     m[2] = fmax(m[2], fabs(z));
@@ -644,7 +674,7 @@ TMX_DEVFN void compute_residuals(const QpWs& w, const DevProblem* P, const doubl
   {
     const double ax = w.bbp[v] * xp[v];
     const double z = zmode ? clampd(ax, w.lbp[v], w.ubp[v]) : w.zbp[v];
-    const double einv = 1.0 / w.Ebp[v];
+    const double einv = fast_rcp(w.Ebp[v]);
     m[0] = fmax(m[0], fabs(einv * (ax - z)));
     m[1] = fmax(m[1], fabs(ax - z));
     m[2] = fmax(m[2], fabs(z));
@@ -655,7 +685,7 @@ TMX_DEVFN void compute_residuals(const QpWs& w, const DevProblem* P, const doubl
     const double px = p_times(w, xp, v);
     const double aty = at_rows(w, P, yr, v) + w.bbp[v] * ybp[v];
     const double res = (w.qp[v] + px) + aty;
-    const double dinv = 1.0 / w.Dp[v];
+    const double dinv = fast_rcp(w.Dp[v]);
     m[6] = fmax(m[6], fabs(dinv * res));
     m[7] = fmax(m[7], fabs(res));
     m[8] = fmax(m[8], fabs(w.qp[v]));
@@ -676,7 +706,7 @@ TMX_DEVFN void compute_residuals(const QpWs& w, const DevProblem* P, const doubl
       const double ax = w.bba[a] * xa[a];
       const double ua = TMX_OSQP_INFTY * w.Eba[a];
       const double z = zmode ? clampd(ax, 0.0, ua) : w.zba[a];
-      const double einv = 1.0 / w.Eba[a];
+      const double einv = fast_rcp(w.Eba[a]);
       m[0] = fmax(m[0], fabs(einv * (ax - z)));
       m[1] = fmax(m[1], fabs(ax - z));
       m[2] = fmax(m[2], fabs(z));
@@ -686,7 +716,7 @@ TMX_DEVFN void compute_residuals(const QpWs& w, const DevProblem* P, const doubl
       // dual residual, aux part (P has no aux entries)
       const double aty = w.sa[a] * yr[r] + w.bba[a] * yba[a];
       const double res = w.qa[a] + aty;
-      const double dinv = 1.0 / w.Da[a];
+      const double dinv = fast_rcp(w.Da[a]);
       m[6] = fmax(m[6], fabs(dinv * res));
       m[7] = fmax(m[7], fabs(res));
       m[8] = fmax(m[8], fabs(w.qa[a]));

@@ -537,7 +537,9 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
   }
   const int n = dims[0], m = dims[1], mg = m - n;
   // Ruiz temporaries live in the (not yet factorised) G region of the LDS workspace when it exists
-  const bool lds_tmp = (w.G != nullptr) && ((size_t)NX + 3 * (size_t)P->NA <= (size_t)w.Gn * w.Gs);
+  DPart dpt;
+  dpart_make(T, dpt);
+  const bool lds_tmp = (w.G != nullptr) && ((size_t)NX + 3 * (size_t)P->NA <= (size_t)dpt.P * w.Gn * w.Gs);
   double* const t_ebp = lds_tmp ? w.G : w.dybp;
   double* const t_eba = lds_tmp ? w.G + NX : w.dyba;
   double* const t_da = lds_tmp ? w.G + NX + P->NA : w.ta;
@@ -797,6 +799,7 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
     {
       info.iter = iter;
       compute_residuals(w, P, w.xp, w.xa, w.yr, w.ybp, w.yba, 0, info, info.prim_res, info.dual_res, true, tid, NT);
+      TMX_TICK(6);
     }
     if (can_check)
     {
@@ -805,6 +808,7 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
         terminated = true;
         break;
       }
+      TMX_TICK(3);
     }
     if (do_rho)
     {

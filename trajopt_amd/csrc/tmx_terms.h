@@ -335,67 +335,95 @@ TMX_DEVFN void init_static_rows(const DevProblem* P, const double* x0, int* acti
   }
 }
 
-TMX_DEVFN void convexify_terms(const DevProblem* P, const double* xv, int* active, double* coef, double* rhs, int tid, int NT)
+// LDS doubles needed by convexify_terms: per cart-pose instance (D+1) pose records of 7, the error vector (6) and the
+// finite-difference Jacobian (6 x D)
+TMX_HOSTDEVFN size_t tmx_cvx_scratch_doubles(int n_cp, int D) { return (size_t)n_cp * ((size_t)(D + 1) * 7 + 6 + 6 * (size_t)D) + 8; }
+TMX_DEVFN void convexify_terms(const DevProblem* P, const double* xv, int* active, double* coef, double* rhs, double* scratch,
+                               int tid, int NT)
 {
   const int D = P->D;
-  // ---- K1: cart-pose rows by forward finite differences over full FK
-  for (int c = tid; c < P->n_cp; c += NT)
+  // ---- K1: cart-pose rows by forward finite differences over full FK.  One thread per (instance, perturbed joint | base
+  //      pose): the D+1 forward-kinematics chains of an instance run side by side instead of one after the other
+  double* rec = scratch;                                    // [n_cp][D+1][7] : translation, rotation axis, angle
+  double* errv = rec + (size_t)P->n_cp * (D + 1) * 7;        // [n_cp][6]
+  double* Jm = errv + (size_t)P->n_cp * 6;                   // [n_cp][6][D]
+  for (int item = tid; item < P->n_cp * (D + 1); item += NT)
   {
+    const int c = item / (D + 1), k = item % (D + 1);
     const double* q = xv + P->cp_t[c] * D;
-    Tf3 tgt, tinv, src, sp, pe, pp;
+    Tf3 tgt, tinv, src, pp;
     tf_from12(P->cp_target + 12 * c, tgt);
     tf_inv(tgt, tinv);
-    fk_tool(P, q, src);
-    double err[6], ax0[3], a0;
-    transform_error(tinv, src, err, ax0, a0);
-    tf_mul(tinv, src, pe);
-    const int s0 = P->cp_slot0[c];
-    const int nr = P->cp_nrows[c];
     double qp[TMX_MAX_DOF];
-    for (int k = 0; k < D; ++k)
-      qp[k] = q[k];
-    double J[6][TMX_MAX_DOF];
-    for (int k = 0; k < D; ++k)
-    {
+    for (int j = 0; j < D; ++j)
+      qp[j] = q[j];
+    if (k < D)
       qp[k] = q[k] + TMX_EPS_FD;
-      fk_tool(P, qp, sp);
-      // calcJacobianTransformErrorDiff(target, source, source_perturbed)
-      tf_mul(tinv, sp, pp);
-      double ax1[3], a1;
-      rot_err_decomposed(pp.R, ax1, a1);
-      double a1c = a1;
-      if (a1 > M_PI_2 && a0 < -M_PI_2)
-        a1c = a1 - 2.0 * M_PI;
-      else if (a1 < -M_PI_2 && a0 > M_PI_2)
-        a1c = a1 + 2.0 * M_PI;
-      double diff[6];
-      for (int r = 0; r < 3; ++r)
-      {
-        diff[r] = pp.t[r] - pe.t[r];
-        diff[3 + r] = ax1[r] * a1c - ax0[r] * a0;
-      }
-      for (int i = 0; i < nr; ++i)
-        J[i][k] = diff[P->cp_idx[6 * c + i]] / TMX_EPS_FD;
-      qp[k] = q[k];
-    }
-    for (int i = 0; i < nr; ++i)
+    fk_tool(P, qp, src);
+    tf_mul(tinv, src, pp);
+    double ax[3], ang;
+    if (k < D)
+      rot_err_decomposed(pp.R, ax, ang);
+    else
     {
-      // affFromValGrad: constant = y - J.x ; coeffs = J with |c| <= 1e-7 dropped ; then exprScale(aff, coeff)
-      const double y = err[P->cp_idx[6 * c + i]];
-      double dot = 0.0;
-      for (int k = 0; k < D; ++k)
-        dot += J[i][k] * q[k];
-      const double cc = P->cp_coeff[6 * c + i];
-      const double constant = (y - dot) * cc;
-      const int r = s0 + i;
-      for (int k = 0; k < D; ++k)
-      {
-        const double jv = J[i][k];
-        coef[r * D + k] = (fabs(jv) > TMX_CLEANUP_TOL) ? jv * cc : 0.0;
-      }
-      rhs[r] = -constant;
-      active[r] = 1;
+      double err[6];
+      transform_error(tinv, src, err, ax, ang);
+      for (int r = 0; r < 6; ++r)
+        errv[c * 6 + r] = err[r];
     }
+    double* o = rec + (size_t)item * 7;
+    for (int r = 0; r < 3; ++r)
+    {
+      o[r] = pp.t[r];
+      o[3 + r] = ax[r];
+    }
+    o[6] = ang;
+  }
+  TMX_SYNC();
+  for (int item = tid; item < P->n_cp * D; item += NT)
+  {
+    const int c = item / D, k = item % D;
+    const double* o0 = rec + ((size_t)c * (D + 1) + D) * 7;  // base pose
+    const double* o1 = rec + ((size_t)c * (D + 1) + k) * 7;
+    const double a0 = o0[6], a1 = o1[6];
+    // calcJacobianTransformErrorDiff(target, source, source_perturbed)
+    double a1c = a1;
+    if (a1 > M_PI_2 && a0 < -M_PI_2)
+      a1c = a1 - 2.0 * M_PI;
+    else if (a1 < -M_PI_2 && a0 > M_PI_2)
+      a1c = a1 + 2.0 * M_PI;
+    double diff[6];
+    for (int r = 0; r < 3; ++r)
+    {
+      diff[r] = o1[r] - o0[r];
+      diff[3 + r] = o1[3 + r] * a1c - o0[3 + r] * a0;
+    }
+    for (int i = 0; i < P->cp_nrows[c]; ++i)
+      Jm[((size_t)c * 6 + i) * D + k] = diff[P->cp_idx[6 * c + i]] / TMX_EPS_FD;
+  }
+  TMX_SYNC();
+  for (int item = tid; item < P->n_cp * 6; item += NT)
+  {
+    const int c = item / 6, i = item % 6;
+    if (i >= P->cp_nrows[c])
+      continue;
+    // affFromValGrad: constant = y - J.x ; coeffs = J with |c| <= 1e-7 dropped ; then exprScale(aff, coeff)
+    const double* q = xv + P->cp_t[c] * D;
+    const double* Jr = Jm + ((size_t)c * 6 + i) * D;
+    const double y = errv[c * 6 + P->cp_idx[6 * c + i]];
+    double dot = 0.0;
+    for (int k = 0; k < D; ++k)
+      dot += Jr[k] * q[k];
+    const double cc = P->cp_coeff[6 * c + i];
+    const double constant = (y - dot) * cc;
+    const int r = P->cp_slot0[c] + i;
+    for (int k = 0; k < D; ++k)
+    {
+      const double jv = Jr[k];
+      coef[r * D + k] = (fabs(jv) > TMX_CLEANUP_TOL) ? jv * cc : 0.0;
+    }
+    rhs[r] = -constant;
+    active[r] = 1;
   }
   // ---- K3: collision rows
   for (int r = tid; r < P->R; r += NT)
