@@ -26,8 +26,8 @@ st = ctx.kernel_stats()
 out = (C.c_longlong * 16)()
 ctx.lib.tmx_debug_phase_cycles.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
 ctx.lib.tmx_debug_phase_cycles(ctx.h, out)
-names = ["setup", "factor", "ADMM loop", "check_term", "sep+corr", "phaseC", "residuals+rho", "polish", "burst entry", "burst exit",
-         "store", "convexify", "eval+update", "f:assemble", "f:G inverses", "f:Schur+Zs"]
+names = ["setup", "factor", "ADMM loop", "check_term", "convexify_terms", "phaseC", "residuals+rho", "polish", "burst entry", "burst exit",
+         "store", "qp_structure", "eval+update", "f:assemble", "f:G inverses", "f:Schur+Zs"]
 tot = sum(out)
 print("B", B, "kernel ms", st["admm_ms"], "admm iters", iters, "qp solves", nqp, "iters/qp", iters / nqp)
 for n, c in zip(names, out):

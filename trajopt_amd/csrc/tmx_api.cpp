@@ -388,6 +388,10 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
   for (int v = 0; v < P.NX; ++v)
     nnzP += (pd[v] != 0.0) + (v < P.NX - D && po[v] != 0.0);
   P.nnzP = nnzP;
+  // column c of upper-triangular P holds (c-D, c) if po[c-D] != 0 and (c, c) if pd[c] != 0
+  std::vector<int> p_colptr(P.NX + 1, 0);
+  for (int c = 0; c < P.NX; ++c)
+    p_colptr[c + 1] = p_colptr[c] + ((c >= D && po[c - D] != 0.0) ? 1 : 0) + ((pd[c] != 0.0) ? 1 : 0);
   // slots grouped by waypoint, ascending slot id inside a waypoint
   std::vector<int> wp_start(T + 1, 0), wp_list(R, 0);
   for (int r = 0; r < R; ++r)
@@ -442,6 +446,7 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
   UP(pd, pd);
   UP(po, po);
   UP(pq, pq);
+  UP(p_colptr, p_colptr);
   UP(vel_first, vel_first);
   UP(vel_last, vel_last);
   UP(vel_cost, vel_cost);
@@ -470,7 +475,7 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
   HIPCHK(hipMemcpy(ctx->dp, &P, sizeof(DevProblem), hipMemcpyHostToDevice));
   // LDS budgets
   ctx->smem_qp = qp_smem_bytes(D, T, R, NA);
-  const size_t small_ints = (size_t)(P.n_max + 1) + 2 * (size_t)R + 2 + 16;
+  const size_t small_ints = 2 * (size_t)(P.n_max + 1) + 4 * (size_t)R + 2 + 16;
   ctx->smem_small = std::max<size_t>((tmx_eval_scratch_doubles(R, D * T, (int)vel_first.size(), n_costs, n_cnts) + n_costs + n_cnts + 8) * sizeof(double),
                                      small_ints * sizeof(int) + 64);
   ctx->smem_small = std::max<size_t>(ctx->smem_small, tmx_cvx_scratch_doubles(P.n_cp, D) * sizeof(double));

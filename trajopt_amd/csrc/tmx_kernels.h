@@ -137,6 +137,14 @@ TMX_DEVFN void sqp_step_block(const DevProblem* P, const DevBatch* Bt, int b, do
   if (Bt->phase[b] == PHASE_CONVEXIFY)
   {
     convexify_terms(P, x, act, coef, rhs, smem, tid, NT);
+#ifdef TMX_PROFILE
+    if (tid == 0)
+    {
+      const long long tnow = TMX_CLK();
+      Bt->prof[(size_t)b * 16 + 4] += tnow - tp0;
+      tp0 = tnow;
+    }
+#endif
     qp_structure(P, act, coef, rhs, x, Bt->trust[b], Bt->merit + (size_t)b * P->n_cnts, Bt->dims + 4 * b, Bt->hashes + 4 * b,
                  nullptr, reinterpret_cast<int*>(smem), tid, NT);
   }

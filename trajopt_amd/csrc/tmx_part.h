@@ -484,7 +484,7 @@ struct RowRegs
 
 TMX_DEVFN void row_load(const QpWs& w, int r, RowRegs& g)
 {
-  g.act = (r < w.R) && w.act[r];
+  g.act = (r >= 0) && (r < w.R) && w.act[r];
   g.t = 0;
   g.na = 0;
   g.rr = 1.0;
@@ -550,31 +550,32 @@ TMX_DEVFN void row_store(const QpWs& w, int r, const RowRegs& g)
     }
 }
 
-// phase A for one row: returns e_r = g - h and the aux right-hand sides
+// phase A for one row: returns e_r = g - h and the aux right-hand sides.  Explicit FMAs: the loop is instruction-issue
+// bound, and the reduction orders already differ from the reference's sparse LDL' solve
 TMX_DEVFN double row_phase_a(const RowRegs& g, double sigma, double ta[2])
 {
-  const double gg = g.rr * g.z - g.y;
+  const double gg = __builtin_fma(g.rr, g.z, -g.y);
   // both aux rhs are independent chains of depth 3
-  const double gb0 = g.rb[0] * g.za[0] - g.ya[0], gb1 = g.rb[1] * g.za[1] - g.ya[1];
-  const double b0 = sigma * g.xa[0] - g.qa[0], b1 = sigma * g.xa[1] - g.qa[1];
+  const double gb0 = __builtin_fma(g.rb[0], g.za[0], -g.ya[0]), gb1 = __builtin_fma(g.rb[1], g.za[1], -g.ya[1]);
+  const double b0 = __builtin_fma(sigma, g.xa[0], -g.qa[0]), b1 = __builtin_fma(sigma, g.xa[1], -g.qa[1]);
   ta[0] = __builtin_fma(g.bb[0], gb0, __builtin_fma(g.sa[0], gg, b0));
   ta[1] = __builtin_fma(g.bb[1], gb1, __builtin_fma(g.sa[1], gg, b1));
-  const double gs = (g.sa[0] * g.di[0]) * ta[0] + (g.sa[1] * g.di[1]) * ta[1];  // (sa*di) are loop invariants
-  return g.act ? (gg - g.fac * gs) : 0.0;
+  const double gs = __builtin_fma(g.sa[1] * g.di[1], ta[1], (g.sa[0] * g.di[0]) * ta[0]);  // (sa*di) are loop invariants
+  return g.act ? __builtin_fma(-g.fac, gs, gg) : 0.0;
 }
 
 // phase C for one row: aux recovery, ztilde, updates.  dot = coef . xtilde(block)
 TMX_DEVFN void row_phase_c(RowRegs& g, double alpha, double dot, const double ta[2], bool keep, double* dyr, double dxa[2], double dya[2])
 {
-  const double v0 = ta[0] - (g.rr * g.sa[0]) * dot, v1 = ta[1] - (g.rr * g.sa[1]) * dot;
-  const double gs = (g.sa[0] * g.di[0]) * v0 + (g.sa[1] * g.di[1]) * v1;
-  const double f = g.fac * gs;
-  const double xt0 = (v0 - g.sa[0] * f) * g.di[0], xt1 = (v1 - g.sa[1] * f) * g.di[1];
-  const double ax = dot + (g.sa[0] * xt0 + g.sa[1] * xt1);
   const double om = 1.0 - alpha;
+  const double v0 = __builtin_fma(-(g.rr * g.sa[0]), dot, ta[0]), v1 = __builtin_fma(-(g.rr * g.sa[1]), dot, ta[1]);
+  const double gs = __builtin_fma(g.sa[1] * g.di[1], v1, (g.sa[0] * g.di[0]) * v0);
+  const double f = g.fac * gs;
+  const double xt0 = __builtin_fma(-g.sa[0], f, v0) * g.di[0], xt1 = __builtin_fma(-g.sa[1], f, v1) * g.di[1];
+  const double ax = __builtin_fma(g.sa[1], xt1, __builtin_fma(g.sa[0], xt0, dot));
   {
-    const double zr = alpha * ax + om * g.z;
-    const double zn = clampd(zr + g.rri * g.y, g.lo, g.hi);
+    const double zr = __builtin_fma(alpha, ax, om * g.z);
+    const double zn = clampd(__builtin_fma(g.rri, g.y, zr), g.lo, g.hi);
     const double dy = g.rr * (zr - zn);
     g.z = zn;
     g.y += dy;
@@ -585,10 +586,9 @@ TMX_DEVFN void row_phase_c(RowRegs& g, double alpha, double dot, const double ta
   for (int k = 0; k < 2; ++k)
   {
     const double xt = k ? xt1 : xt0;
-    const double xn = alpha * xt + om * g.xa[k];
-    const double zt = g.bb[k] * xt;
-    const double zr = alpha * zt + om * g.za[k];
-    const double zn = clampd(zr + g.rbi[k] * g.ya[k], 0.0, g.ub[k]);
+    const double xn = __builtin_fma(alpha, xt, om * g.xa[k]);
+    const double zr = __builtin_fma(alpha * g.bb[k], xt, om * g.za[k]);
+    const double zn = clampd(__builtin_fma(g.rbi[k], g.ya[k], zr), 0.0, g.ub[k]);
     const double dy = g.rb[k] * (zr - zn);
     if (keep)
     {
@@ -628,10 +628,21 @@ TMX_DEVFN void admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, b
   h.Gn = __builtin_amdgcn_readfirstlane(w.Gn);
   h.Gs = __builtin_amdgcn_readfirstlane(w.Gs);
   h.Zst = __builtin_amdgcn_readfirstlane(w.Zst);
+  // rows 0 .. NT-1 go to thread r; the rows beyond NT go to the LAST threads of the workgroup, which own no primary
+  // variable and no dense-solve role: the wave that carries second rows is not the one that carries everything else
+  int rowi[TMX_NROW];
+  rowi[0] = tid;
+#pragma unroll
+  for (int q = 1; q < TMX_NROW; ++q)
+  {
+    const int extra = w.R - q * TMX_QP_NT;  // rows in this layer
+    const int first = TMX_QP_NT - extra;    // first thread that takes one
+    rowi[q] = (extra > 0 && tid >= first) ? q * TMX_QP_NT + (tid - first) : -1;
+  }
   RowRegs g[TMX_NROW];
 #pragma unroll
   for (int q = 0; q < TMX_NROW; ++q)
-    row_load(w, tid + q * TMX_QP_NT, g[q]);
+    row_load(w, rowi[q], g[q]);
   DPart dp;
   dpart_make(w.T, dp);
   DMap mp;
@@ -656,7 +667,7 @@ TMX_DEVFN void admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, b
   for (int q = 0; q < TMX_NROW; ++q)
   {
     tb[q] = g[q].t * D;
-    has[q] = tid + q * TMX_QP_NT < w.R;
+    has[q] = rowi[q] >= 0 && rowi[q] < w.R;
   }
   // couplings of this thread's variable / of the separator row it publishes (constant during the solve)
   const double cprev = (pv && v >= D) ? h.po[v - D] : 0.0, cnext = pv ? h.po[v] : 0.0;
@@ -694,12 +705,12 @@ TMX_DEVFN void admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, b
     {
       const double e = row_phase_a(g[q], sigma, ta[q]);
       if (has[q])
-        h.hr[tid + q * TMX_QP_NT] = e;
+        h.hr[rowi[q]] = e;
     }
     TMX_SYNC();
     if (pv)
     {
-      const double gb = rbp * zb - yb;
+      const double gb = __builtin_fma(rbp, zb, -yb);
       double e[16];
 #pragma unroll
       for (int k = 0; k < 16; ++k)
@@ -719,7 +730,7 @@ TMX_DEVFN void admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, b
         const int r = w.wp_list[q];
         ate += w.coef[r * D + (v % D)] * h.hr[r];
       }
-      h.ty[mp.slot] = (sigma * xp - qv) + ate + bb * gb;
+      h.ty[mp.slot] = __builtin_fma(bb, gb, __builtin_fma(sigma, xp, -qv) + ate);
     }
     TMX_SYNC();
     TMX_LTICK(2);
@@ -760,14 +771,14 @@ TMX_DEVFN void admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, b
 #pragma unroll
       for (int j = 0; j < 8; ++j)
         xt[j] = (j < D) ? h.tp[tb[q] + j] : 0.0;
-      double d0 = (gq.c[0] * xt[0] + gq.c[4] * xt[4]) + (gq.c[1] * xt[1] + gq.c[5] * xt[5]);
-      d0 += (gq.c[2] * xt[2] + gq.c[6] * xt[6]) + (gq.c[3] * xt[3] + gq.c[7] * xt[7]);
+      const double d0 = (__builtin_fma(gq.c[4], xt[4], gq.c[0] * xt[0]) + __builtin_fma(gq.c[5], xt[5], gq.c[1] * xt[1])) +
+                        (__builtin_fma(gq.c[6], xt[6], gq.c[2] * xt[2]) + __builtin_fma(gq.c[7], xt[7], gq.c[3] * xt[3]));
       double dyr0 = 0, dxa0[2], dya0[2];
       if (gq.act)
         row_phase_c(gq, alpha, d0, ta[q], keep, &dyr0, dxa0, dya0);
       if (keep && gq.act)
       {
-        const int r = tid + q * TMX_QP_NT;
+        const int r = rowi[q];
         w.dyr[r] = dyr0;
         for (int k = 0; k < gq.na; ++k)
         {
@@ -777,10 +788,9 @@ TMX_DEVFN void admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, b
       }
     }
     {
-      const double xn = alpha * xtv + om * xp;
-      const double zt = bb * xtv;
-      const double zr = alpha * zt + om * zb;
-      const double zn = clampd(zr + rbpi * yb, lb, ub);
+      const double xn = __builtin_fma(alpha, xtv, om * xp);
+      const double zr = __builtin_fma(alpha * bb, xtv, om * zb);
+      const double zn = clampd(__builtin_fma(rbpi, yb, zr), lb, ub);
       const double dy = rbp * (zr - zn);
       if (keep && pv)
       {
@@ -798,7 +808,7 @@ TMX_DEVFN void admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, b
   TMX_TICK(2);
 #pragma unroll
   for (int q = 0; q < TMX_NROW; ++q)
-    row_store(w, tid + q * TMX_QP_NT, g[q]);
+    row_store(w, rowi[q], g[q]);
   if (pv)
   {
     w.xp[v] = xp;

@@ -33,30 +33,42 @@ TMX_DEVFN void qp_structure(const DevProblem* P, const int* active, const double
   int* colptr = iscratch;               // n_max + 1
   int* rowref = colptr + P->n_max + 1;  // R
   int* auxref = rowref + R;             // R
-  int acc_off = (P->n_max + 1) + 2 * R;
+  int* lact = auxref + R;               // R     LDS copies of active / slot_naux
+  int* lnaux = lact + R;                // R
+  int* ccount = lnaux + R;              // n_max + 1  column counts of A
+  int acc_off = 2 * (P->n_max + 1) + 4 * R;
   acc_off += (acc_off & 1);
   unsigned long long* acc = reinterpret_cast<unsigned long long*>(iscratch + acc_off);  // 8 x u64 (8-byte aligned)
-  if (tid == 0)
+  // active flags / aux counts -> LDS, then exclusive prefix counts per row (every thread scans its predecessors: R^2/NT
+  // LDS reads, no serial pass and no dependent global loads)
+  for (int r = tid; r < R; r += NT)
+  {
+    lact[r] = active[r] ? 1 : 0;
+    lnaux[r] = P->slot_naux[r];
+  }
+  for (int k = tid; k < 8; k += NT)
+    acc[k] = 0ULL;
+  TMX_SYNC();
+  for (int r = tid; r < R; r += NT)
   {
     int nr = 0, na = 0;
-    for (int r = 0; r < R; ++r)
+    for (int q = 0; q < r; ++q)
     {
-      rowref[r] = nr;
-      auxref[r] = NX + na;
-      if (active[r])
-      {
-        nr += 1;
-        na += P->slot_naux[r];
-      }
+      nr += lact[q];
+      na += lact[q] ? lnaux[q] : 0;
     }
-    dims[0] = NX + na;       // n
-    dims[1] = nr + NX + na;  // m
-    for (int k = 0; k < 8; ++k)
-      acc[k] = 0ULL;
+    rowref[r] = nr;
+    auxref[r] = NX + na;
+    if (r == R - 1)
+    {
+      const int nr1 = nr + lact[r], na1 = na + (lact[r] ? lnaux[r] : 0);
+      dims[0] = NX + na1;        // n
+      dims[1] = nr1 + NX + na1;  // m
+    }
   }
   TMX_SYNC();
   const int n = dims[0], m = dims[1], mg = m - n;
-  // column counts of A
+  // column counts of A (into colptr[c + 1]), then the exclusive prefix by per-thread scans of the LDS counts
   for (int v = tid; v < NX; v += NT)
   {
     const int t = v / D, j = v % D;
@@ -64,23 +76,27 @@ TMX_DEVFN void qp_structure(const DevProblem* P, const int* active, const double
     for (int q = P->wp_start[t]; q < P->wp_start[t + 1]; ++q)
     {
       const int r = P->wp_list[q];
-      if (active[r] && coef[r * D + j] != 0.0)
+      if (lact[r] && coef[r * D + j] != 0.0)
         ++c;
     }
-    colptr[v + 1] = c;
+    ccount[v] = c;
   }
   for (int r = tid; r < R; r += NT)
-    if (active[r])
-      for (int k = 0; k < P->slot_naux[r]; ++k)
-        colptr[auxref[r] + k + 1] = 2;
+    if (lact[r])
+      for (int k = 0; k < lnaux[r]; ++k)
+        ccount[auxref[r] + k] = 2;
   TMX_SYNC();
-  if (tid == 0)
+  for (int c = tid; c <= n; c += NT)
   {
-    colptr[0] = 0;
-    for (int c = 0; c < n; ++c)
-      colptr[c + 1] += colptr[c];
-    dims[3] = colptr[n];  // nnzA
-    dims[2] = P->nnzP;
+    int run = 0;
+    for (int q = 0; q < c; ++q)
+      run += ccount[q];
+    colptr[c] = run;
+    if (c == n)
+    {
+      dims[3] = run;  // nnzA
+      dims[2] = P->nnzP;
+    }
   }
   TMX_SYNC();
   const int nnzA = dims[3];
@@ -159,51 +175,48 @@ TMX_DEVFN void qp_structure(const DevProblem* P, const int* active, const double
   {
     const int pp_bytes = n + 1, pp_full = pp_bytes / 8, pp_rem = pp_bytes % 8;
     const int pi_full = P->nnzP / 8, pi_rem = P->nnzP % 8;
-    // colptr of P needs a prefix over primary columns: count = (t>0 && po[v-D]!=0) + (pd[v]!=0); sequential on thread 0
-    if (tid == 0)
+    // the column pointers of P over the primary vars are static (DevProblem::p_colptr); aux columns are empty
+    for (int c = tid; c <= n; c += NT)
     {
-      int run = 0;
-      for (int c = 0; c <= n; ++c)
+      int run = (c <= NX) ? P->p_colptr[c] : P->nnzP;
+      const long long val = run;
+      hP += tmx_hash_term(val, (uint64_t)c, 1);
+      if (c < pp_full)
+        wsP += tmx_hash_term(val, (uint64_t)c, 11);
+      else if (c == pp_full && pp_rem > 0)
+        wsP += tmx_hash_term((long long)((unsigned long long)val & ((1ULL << (8 * pp_rem)) - 1ULL)), (uint64_t)c, 11);
+      if (out)
+        out->P_p[c] = val;
+      if (c < NX)
       {
-        const long long val = run;
-        hP += tmx_hash_term(val, (uint64_t)c, 1);
-        if (c < pp_full)
-          wsP += tmx_hash_term(val, (uint64_t)c, 11);
-        else if (c == pp_full && pp_rem > 0)
-          wsP += tmx_hash_term((long long)((unsigned long long)val & ((1ULL << (8 * pp_rem)) - 1ULL)), (uint64_t)c, 11);
-        if (out)
-          out->P_p[c] = val;
-        if (c < NX)
+        const int t = c / D;
+        if (t > 0 && P->po[c - D] != 0.0)
         {
-          const int t = c / D;
-          if (t > 0 && P->po[c - D] != 0.0)
+          hP += tmx_hash_term(c - D, (uint64_t)run, 2);
+          if (run < pi_full)
+            wsP += tmx_hash_term(c - D, (uint64_t)run, 12);
+          else if (run == pi_full && pi_rem > 0)
+            wsP += tmx_hash_term((long long)((unsigned long long)(c - D) & ((1ULL << (8 * pi_rem)) - 1ULL)), (uint64_t)run, 12);
+          if (out)
           {
-            hP += tmx_hash_term(c - D, (uint64_t)run, 2);
-            if (run < pi_full)
-              wsP += tmx_hash_term(c - D, (uint64_t)run, 12);
-            else if (run == pi_full && pi_rem > 0)
-              wsP += tmx_hash_term((long long)((unsigned long long)(c - D) & ((1ULL << (8 * pi_rem)) - 1ULL)), (uint64_t)run, 12);
-            if (out)
-            {
-              out->P_i[run] = c - D;
-              out->P_x[run] = P->po[c - D];
-            }
-            ++run;
+            out->P_i[run] = c - D;
+            out->P_x[run] = P->po[c - D];
           }
-          if (P->pd[c] != 0.0)
+          ++run;
+        }
+        if (P->pd[c] != 0.0)
+        {
+          hP += tmx_hash_term(c, (uint64_t)run, 2);
+          if (run < pi_full)
+            wsP += tmx_hash_term(c, (uint64_t)run, 12);
+          else if (run == pi_full && pi_rem > 0)
+            wsP += tmx_hash_term((long long)((unsigned long long)c & ((1ULL << (8 * pi_rem)) - 1ULL)), (uint64_t)run, 12);
+          if (out)
           {
-            hP += tmx_hash_term(c, (uint64_t)run, 2);
-            if (run < pi_full)
-              wsP += tmx_hash_term(c, (uint64_t)run, 12);
-            else if (run == pi_full && pi_rem > 0)
-              wsP += tmx_hash_term((long long)((unsigned long long)c & ((1ULL << (8 * pi_rem)) - 1ULL)), (uint64_t)run, 12);
-            if (out)
-            {
-              out->P_i[run] = c;
-              out->P_x[run] = P->pd[c];
-            }
-            ++run;
+            out->P_i[run] = c;
+            out->P_x[run] = P->pd[c];
           }
+          ++run;
         }
       }
     }

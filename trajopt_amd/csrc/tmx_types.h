@@ -49,6 +49,7 @@ struct DevProblem
   int *wp_list;        // R
   // static quadratic objective over the primary vars: Hessian diagonal / (t,j)-(t+1,j) coupling, linear term
   double *pd, *po, *pq;
+  int *p_colptr;  // NX+1: column pointers of the (static) upper-triangular CSC pattern of P over the primary vars
   // JointVelEqCost terms (exact value)
   int *vel_first, *vel_last, *vel_cost;
   double *vel_coeffs, *vel_targets;  // n_vel x TMX_MAX_DOF
