@@ -26,11 +26,13 @@ st = ctx.kernel_stats()
 out = (C.c_longlong * 16)()
 ctx.lib.tmx_debug_phase_cycles.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
 ctx.lib.tmx_debug_phase_cycles(ctx.h, out)
-names = ["setup", "factor", "ADMM loop", "check_term", "convexify_terms", "phaseC", "residuals+rho", "polish", "burst entry", "burst exit",
+names = ["setup", "WALL(10ns)", "ADMM loop", "check_term", "convexify_terms", "phaseC", "residuals+rho", "polish", "burst entry", "burst exit",
          "store", "qp_structure", "eval+update", "f:assemble", "f:G inverses", "f:Schur+Zs"]
 tot = sum(out)
 print("B", B, "kernel ms", st["admm_ms"], "admm iters", iters, "qp solves", nqp, "iters/qp", iters / nqp)
 for n, c in zip(names, out):
     if c:
         print(f"  {n:12s} {c / B:14.0f} cycles/problem  {100.0 * c / tot:5.1f}%   per-iter {c / max(1, iters):9.1f}   per-qp {c / nqp:10.0f}")
+wall = out[1]; tot -= wall
+print("  wall-clock per problem (ms)", wall / B * 1e-5, " => effective shader clock (GHz)", tot / max(1, wall) / 10.0)
 print("  total cycles/problem", tot / B, " => per ADMM iteration (all phases)", tot / iters)

@@ -133,6 +133,7 @@ TMX_DEVFN void sqp_step_block(const DevProblem* P, const DevBatch* Bt, int b, do
   const double* xq = Bt->xq + (size_t)b * P->n_max;
 #ifdef TMX_PROFILE
   long long tp0 = TMX_CLK();
+  const long long wall0 = wall_clock64();  // constant 100 MHz: s_memtime / wall = effective shader clock
 #endif
   if (Bt->phase[b] == PHASE_CONVEXIFY)
   {
@@ -165,7 +166,10 @@ TMX_DEVFN void sqp_step_block(const DevProblem* P, const DevBatch* Bt, int b, do
   TMX_SYNC();
 #ifdef TMX_PROFILE
   if (tid == 0)
+  {
     Bt->prof[(size_t)b * 16 + 12] += TMX_CLK() - tp0;
+    Bt->prof[(size_t)b * 16 + 1] += wall_clock64() - wall0;
+  }
 #endif
 }
 
@@ -202,34 +206,40 @@ TMX_KERNEL_LB2(TMX_QP_NT, TMX_QP_WGS_PER_CU) k_sqp_pool(const DevProblem* P, con
   TMX_SMEM(smem);
   const int tid = threadIdx.x, NT = blockDim.x;
   const int B = Bt->B;
-  int* ibuf = reinterpret_cast<int*>(smem);  // [0..NT) keys, [NT..2NT) indices, [2NT] decision
+  int* ibuf = reinterpret_cast<int*>(smem);  // [2NT]: decision broadcast (the reduction scratch sits at smem + 8)
   unsigned spins = 0;
   while (true)
   {
-    // ---- scan: least n_qp among the ready problems (relaxed agent-scope loads: never served from a stale L1 line)
-    int best = 0x7fffffff, bi = -1;
+    // ---- scan: least n_qp among the ready problems; ties are broken by the distance from a workgroup-specific start
+    //      index so that workgroups that finish at the same time do not all race for the same candidate.  Relaxed
+    //      agent-scope loads: never served from a stale L1 line.
+    const int pref = (int)(((long long)blockIdx.x * B) / gridDim.x);
+    double best = 1e300;  // key = n_qp * B + distance, exact in a double
     for (int b = tid; b < B; b += NT)
-      if (TMX_LD_RELAXED(&Bt->sched_state[b]) == 0)
-      {
-        const int key = TMX_LD_RELAXED(&Bt->n_qp[b]);
-        if (key < best)
-        {
-          best = key;
-          bi = b;
-        }
-      }
-    ibuf[tid] = best;
-    ibuf[NT + tid] = bi;
-    TMX_SYNC();
+    {
+      const int st = TMX_LD_RELAXED(&Bt->sched_state[b]);
+      const int nq = TMX_LD_RELAXED(&Bt->n_qp[b]);
+      int dist = b - pref;
+      dist += (dist < 0) ? B : 0;
+      const double key = (double)nq * (double)B + (double)dist;
+      best = (st == 0 && key < best) ? key : best;
+    }
+    double kred[1] = { -best };
+    const bool ksum[1] = { false };
+    block_reduce<1>(kred, ksum, smem + 8, tid, NT);  // max of -key
+#if !TMX_IS_DEVICE
+    kred[0] = -best;
+#endif
     if (tid == 0)
     {
-      int kb = 0x7fffffff, kbi = -1;
-      for (int q = 0; q < NT; ++q)
-        if (ibuf[NT + q] >= 0 && ibuf[q] < kb)
-        {
-          kb = ibuf[q];
-          kbi = ibuf[NT + q];
-        }
+      const double kmin = -kred[0];
+      int kbi = -1;
+      if (kmin < 1e299)
+      {
+        const long long kk = (long long)kmin;
+        int bi = (int)(kk % B) + pref;
+        kbi = bi >= B ? bi - B : bi;
+      }
       int decision;
       if (kbi < 0)
         decision = (TMX_LD_RELAXED(Bt->sched_done) >= B) ? -1 : -2;  // all done | nothing ready right now

@@ -770,7 +770,7 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
   kkt_factor(w, P, 0, w.sigma, st.delta, tid, NT);
   kkt_invert(w, fast, tid, NT, pc, tlast);
   admm_cache_weights(w, tid, NT);
-  TMX_TICK(1);
+  TMX_TICK(15);
   QpInfo info;
   info.status = 11;  // OSQP_UNSOLVED
   info.iter = 0;
@@ -834,7 +834,7 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
         kkt_factor(w, P, 0, w.sigma, st.delta, tid, NT);
         kkt_invert(w, fast, tid, NT, pc, tlast);
         admm_cache_weights(w, tid, NT);
-        TMX_TICK(1);
+        TMX_TICK(15);
       }
     }
     TMX_TICK(6);
