@@ -108,17 +108,31 @@ def main():
         g_fe, g_qp, g_admm, g_conv = float(tot_fe), float(tot_qp), float(tot_admm), float(conv)
 
     if rank == 0:
-        # ---- roofline of the dominant kernel (k_qp_solve = batched OSQP-style ADMM), rank 0, HIP-event timed ----
+        # ---- roofline of the dominant kernel, rank 0, HIP-event timed on the library's own stream ----
+        # optimize() is ONE persistent launch of k_sqp_pool per step (convexify + QP solves + exact re-evaluation + SQP
+        # decisions for every seed); >90 % of it is the batched OSQP-style ADMM.  The arithmetic is fp64 FMA on the
+        # vector ALUs; on MI355X the fp64 vector peak equals the fp64 matrix peak (78.6 TFLOP/s), which is the "mfma"
+        # roof the contract asks for.  The kernel is bound by dependent-issue latency, not by that roof.
         recs, cnt = ctx.qp_records(4)
         r0 = recs[0]
         f_iter = algorithmic_flops_per_admm_iter(T, D, r0.n, r0.m, r0.nnzA)
         launches = max(1, stats["admm_launches"])
+        # HBM bytes per launch from the rocprofv3 PMC passes of this same command (profiles/README.md); null if the
+        # summary is not present
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                tj = json.load(f)
+            if tj.get("batch_per_gpu") == B:
+                traffic = tj.get("hbm_bytes_per_launch")
+        except OSError:
+            pass
         flops_per_launch = f_iter * tot_admm / launches
         avg_ms = stats["admm_ms"] / launches
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         roofline = {
-            "kernel": "k_qp_solve", "bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None,
+            "kernel": "k_sqp_pool", "bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic,
             "avg_launch_ms": avg_ms, "launches": launches, "algorithmic_flop_per_admm_iter": f_iter,
             "admm_iters_per_launch": tot_admm / launches,
             "kernel_time_share": {"admm_ms": stats["admm_ms"], "convexify_ms": stats["convexify_ms"],
@@ -128,18 +142,27 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             from oracle import pyorc
             cores = os.cpu_count() or 1
-            nsample = max(16, min(cores, B))   # one problem per hardware thread: the whole host is busy
-            xs = seeds_host[:nsample]
             pyorc.build()
-            tc0 = time.perf_counter()
-            o = pyorc.sqp_batch(desc, xs, nthreads=cores)
-            tc1 = time.perf_counter()
-            cpu = {"value": float((o["n_func_evals"] - 1).sum() / (tc1 - tc0)), "unit": "SQP iters/s", "cores": cores,
-                   "kind": "port",
-                   "sample": f"first {nsample} seeds of the same workload, one problem per OpenMP thread, "
-                             f"{tc1 - tc0:.1f} s wall; restated reference CPU path (oracle/), not the upstream binary",
-                   "qp_solves_per_s": float(o["n_qp_solves"].sum() / (tc1 - tc0)),
-                   "admm_iters_per_s": float(o["admm_iters"] / (tc1 - tc0))}
+            # one problem per OpenMP thread.  Two thread counts are timed (all hardware threads, and a quarter of them:
+            # the oracle's allocator traffic makes the fully subscribed run slower on large hosts) and the FASTER one is
+            # reported, so the GPU/CPU ratio is not flattered by a badly subscribed baseline.
+            tried = []
+            for nthr in sorted({cores, max(1, cores // 4), min(cores, 16)}, reverse=True):
+                nsample = min(B, max(32, 2 * nthr))   # two problems per thread: a few seconds to ~30 s per run
+                xs = seeds_host[:nsample]
+                tc0 = time.perf_counter()
+                o = pyorc.sqp_batch(desc, xs, nthreads=nthr)
+                dt = time.perf_counter() - tc0
+                tried.append((float((o["n_func_evals"] - 1).sum() / dt), nthr, nsample, dt, o))
+            best = max(tried, key=lambda t: t[0])
+            o = best[4]
+            cpu = {"value": best[0], "unit": "SQP iters/s", "cores": best[1], "kind": "port",
+                   "sample": f"first {best[2]} seeds of the same workload, one problem per OpenMP thread on {best[1]} of "
+                             f"{cores} hardware threads, {best[3]:.1f} s wall; restated reference CPU path (oracle/), "
+                             "not the upstream binary; tried " +
+                             ", ".join(f"{t[1]} thr -> {t[0]:.0f} it/s" for t in tried),
+                   "qp_solves_per_s": float(o["n_qp_solves"].sum() / best[3]),
+                   "admm_iters_per_s": float(o["admm_iters"] / best[3])}
         line = {
             "metric": "SQP iters/s (+ QP solves/s), 7-DOF x 30-wp x 1024-batch glass_upright",
             "value": g_fe / elapsed, "unit": "SQP iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -1,0 +1,49 @@
+#!/bin/bash
+# rocprofv3 evidence for profiles/ (run on the GPU box:  gpurun -- bash tools/profile_round.sh r01b)
+# pass 1: kernel trace + stats of the default bench command; passes 2-4: PMC counters, one group per run, kernel trace only
+TAG=${1:-r01b}
+R=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$R/gpurun_out/$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d $OUT/kt -o out --output-format csv -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/kt.log
+for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_MFMA_MOPS_F64"; do
+  tag=$(echo $grp | tr ' ' '_' | cut -c1-48)
+  rocprofv3 --kernel-trace --pmc $grp -d $OUT/pmc_$tag -o out --output-format csv -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/pmc_$tag.json 2> $OUT/pmc_$tag.log
+done
+python3 - <<PY
+import csv, glob, json, collections, os
+out = "$OUT"
+lines = []
+for f in glob.glob(out + "/kt/*kernel_stats.csv"):
+    lines.append("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline")
+    lines.append(open(f).read())
+kt = glob.glob(out + "/kt/*kernel_trace.csv")
+if kt:
+    d = collections.defaultdict(list)
+    for r in csv.DictReader(open(kt[0])):
+        d[r["Kernel_Name"]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+    lines.append("# per-kernel durations from the kernel trace (ms): calls, total, avg, min, max")
+    for k, v in sorted(d.items(), key=lambda kv: -sum(kv[1])):
+        lines.append(f"{k[:70]:70s} {len(v):5d} {sum(v):12.3f} {sum(v)/len(v):10.3f} {min(v):10.3f} {max(v):10.3f}")
+tot = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.defaultdict(lambda: collections.defaultdict(int))
+for f in glob.glob(out + "/pmc_*/*counter_collection.csv"):
+    for r in csv.DictReader(open(f)):
+        tot[r["Kernel_Name"]][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[r["Kernel_Name"]][r["Counter_Name"]] += 1
+lines.append("")
+lines.append("# PMC passes (python bench.py --steps 1 --warmup 0): kernel, counter, dispatches, sum, avg per dispatch")
+for k in tot:
+    for c in sorted(tot[k]):
+        lines.append(f"{k[:60]:60s} {c:32s} {cnt[k][c]:5d} {tot[k][c]:18.1f} {tot[k][c]/cnt[k][c]:18.1f}")
+open(out + "/rocprofv3_summary.txt", "w").write("\n".join(lines) + "\n")
+pool = [k for k in tot if "k_sqp_pool" in k]
+if pool:
+    k = pool[0]
+    fetch_kib = tot[k].get("FETCH_SIZE", 0.0) / max(1, cnt[k].get("FETCH_SIZE", 1))
+    write_kib = tot[k].get("WRITE_SIZE", 0.0) / max(1, cnt[k].get("WRITE_SIZE", 1))
+    json.dump({"batch_per_gpu": 1024, "kernel": "k_sqp_pool", "fetch_size_kib_per_launch": fetch_kib, "write_size_kib_per_launch": write_kib,
+               "hbm_bytes_per_launch": (2.0 * fetch_kib + write_kib) * 1024.0,
+               "note": "FETCH_SIZE doubled per the MI355X guide's gfx950 correction for wide streaming reads (upper bound for narrow reads); WRITE_SIZE uncalibrated; "
+                       "Infinity-Cache hits are counted"}, open(out + "/pmc_traffic.json", "w"), indent=1)
+print(open(out + "/rocprofv3_summary.txt").read()[:6000])
+PY
