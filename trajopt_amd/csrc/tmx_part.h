@@ -605,6 +605,11 @@ TMX_DEVFN void row_phase_c(RowRegs& g, double alpha, double dot, const double ta
 // the burst.  `keep_last` stores delta_x / delta_y of the final iteration (needed by the termination test).
 // Thread tid owns the constraint rows tid + q*NT (NROW = 512 / NT of them, with their aux vars); the primary variables
 // and the dense-solve roles are distributed by dpart_map().
+template <bool V>
+struct TmxTag
+{
+  static constexpr bool value = V;
+};
 #define TMX_NROW (512 / TMX_QP_NT)
 #if defined(TMX_PROFILE) && defined(TMX_PROFILE_LOOP)
 #define TMX_LTICK(s) TMX_TICK(s)
@@ -696,9 +701,11 @@ TMX_DEVFN void admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, b
   }
   TMX_SYNC();
   TMX_TICK(8);
-  for (int it = 0; it < n_iter; ++it)
-  {
-    const bool keep = keep_last && (it == n_iter - 1);
+  // One ADMM iteration.  Instantiated twice: KEEP = false is the body of the hot loop and contains nothing but the
+  // iteration; KEEP = true is the peeled final iteration, which also publishes the deltas the termination test needs.
+  // (With a run-time flag the publishing code sits inside the loop and its temporaries cost the loop registers.)
+  auto iteration = [&](auto keep_tag) __attribute__((always_inline)) {
+    constexpr bool keep = decltype(keep_tag)::value;
     double ta[TMX_NROW][2];
 #pragma unroll
     for (int q = 0; q < TMX_NROW; ++q)
@@ -804,7 +811,12 @@ TMX_DEVFN void admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, b
     TMX_LTICK(5);
     // the next iteration's phase A only touches registers; its hr stores are ordered after every thread's tp reads by
     // the barrier that follows them, and tp is rewritten only after that barrier
-  }
+  };
+  const int n_plain = keep_last ? n_iter - 1 : n_iter;
+  for (int it = 0; it < n_plain; ++it)
+    iteration(TmxTag<false>{});
+  if (keep_last && n_iter > 0)
+    iteration(TmxTag<true>{});
   TMX_TICK(2);
 #pragma unroll
   for (int q = 0; q < TMX_NROW; ++q)
