@@ -857,39 +857,71 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
   if (st.polishing && info.status == 1)
   {
     const double delta = st.delta;
+    // The polished iterate (dx | dy), the aux right-hand side and the active-set flags normally live in the per-problem
+    // HBM scratch; the ADMM factors G / Zs are dead by now, so on the fast path the polish keeps them in that LDS region
+    // (every pass below would otherwise be a chain of dependent HBM round trips).
+    QpWs wp = w;
+    if (w.G != nullptr && (size_t)(2 * NX + R + 3 * P->NA) + (size_t)(R + NX + P->NA + 1) / 2 + 2 <= (size_t)dpt.P * w.Gn * w.Gs)
+    {
+      double* q = w.G;
+      wp.dxp = q;
+      q += NX;
+      wp.dybp = q;
+      q += NX;
+      wp.dyr = q;
+      q += R;
+      wp.dxa = q;
+      q += P->NA;
+      wp.dyba = q;
+      q += P->NA;
+      wp.ta = q;
+      q += P->NA;
+      int* iq = reinterpret_cast<int*>(q);
+      wp.flg_r = iq;
+      iq += R;
+      wp.flg_bp = iq;
+      iq += NX;
+      wp.flg_ba = iq;
+      // inactive rows keep flag 0 (the solution store hashes every active flag; unset entries must not be garbage)
+      for (int r = tid; r < R; r += NT)
+        wp.flg_r[r] = 0;
+      for (int a = tid; a < P->NA; a += NT)
+        wp.flg_ba[a] = 0;
+      TMX_SYNC();
+    }
     for (int v = tid; v < NX; v += NT)
     {
       int f = 0;
-      if (w.zbp[v] - w.lbp[v] < -w.ybp[v])
+      if (wp.zbp[v] - wp.lbp[v] < -wp.ybp[v])
         f = -1;
-      else if (w.ubp[v] - w.zbp[v] < w.ybp[v])
+      else if (wp.ubp[v] - wp.zbp[v] < wp.ybp[v])
         f = 1;
-      w.flg_bp[v] = f;
+      wp.flg_bp[v] = f;
     }
     for (int r = tid; r < R; r += NT)
     {
-      if (!w.act[r])
+      if (!wp.act[r])
         continue;
       int f = 0;
-      if (w.zr[r] - w.lor[r] < -w.yr[r])
+      if (wp.zr[r] - wp.lor[r] < -wp.yr[r])
         f = -1;
-      else if (w.hir[r] - w.zr[r] < w.yr[r])
+      else if (wp.hir[r] - wp.zr[r] < wp.yr[r])
         f = 1;
-      w.flg_r[r] = f;
-      for (int k = 0; k < w.naux[r]; ++k)
+      wp.flg_r[r] = f;
+      for (int k = 0; k < wp.naux[r]; ++k)
       {
-        const int a = w.aoff[r] + k;
+        const int a = wp.aoff[r] + k;
         int fa = 0;
-        if (w.zba[a] - 0.0 < -w.yba[a])
+        if (wp.zba[a] - 0.0 < -wp.yba[a])
           fa = -1;
-        else if (TMX_OSQP_INFTY * w.Eba[a] - w.zba[a] < w.yba[a])
+        else if (TMX_OSQP_INFTY * wp.Eba[a] - wp.zba[a] < wp.yba[a])
           fa = 1;
-        w.flg_ba[a] = fa;
+        wp.flg_ba[a] = fa;
       }
     }
     TMX_SYNC();
-    kkt_factor(w, P, 1, delta, delta, tid, NT);
-    kkt_invert(w, false, tid, NT, pc, tlast);
+    kkt_factor(wp, P, 1, delta, delta, tid, NT);
+    kkt_invert(wp, false, tid, NT, pc, tlast);
     // polished iterate lives in (dxp, dxa | dyr, dybp, dyba)
     for (int pass = 0; pass <= st.polish_refine_iter; ++pass)
     {
@@ -897,141 +929,141 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
       for (int r = tid; r < R; r += NT)
       {
         double g = 0.0;
-        if (w.act[r] && w.flg_r[r] != 0)
+        if (wp.act[r] && wp.flg_r[r] != 0)
         {
-          double r2 = (w.flg_r[r] < 0) ? w.lor[r] : w.hir[r];
+          double r2 = (wp.flg_r[r] < 0) ? wp.lor[r] : wp.hir[r];
           if (pass > 0)
           {
-            const int t = w.slot_t[r];
+            const int t = wp.slot_t[r];
             double ax = 0.0;
             for (int j = 0; j < D; ++j)
-              ax += w.coef[r * D + j] * w.dxp[t * D + j];
-            for (int k = 0; k < w.naux[r]; ++k)
-              ax += w.sa[w.aoff[r] + k] * w.dxa[w.aoff[r] + k];
+              ax += wp.coef[r * D + j] * wp.dxp[t * D + j];
+            for (int k = 0; k < wp.naux[r]; ++k)
+              ax += wp.sa[wp.aoff[r] + k] * wp.dxa[wp.aoff[r] + k];
             r2 -= ax;
           }
           g = r2 / delta;
         }
-        w.hr[r] = g;
+        wp.hr[r] = g;
       }
       TMX_SYNC();
       for (int v = tid; v < NX; v += NT)
       {
-        double r1 = -w.qp[v];
+        double r1 = -wp.qp[v];
         double gb = 0.0;
-        if (w.flg_bp[v] != 0)
+        if (wp.flg_bp[v] != 0)
         {
-          double r2 = (w.flg_bp[v] < 0) ? w.lbp[v] : w.ubp[v];
+          double r2 = (wp.flg_bp[v] < 0) ? wp.lbp[v] : wp.ubp[v];
           if (pass > 0)
-            r2 -= w.bbp[v] * w.dxp[v];
+            r2 -= wp.bbp[v] * wp.dxp[v];
           gb = r2 / delta;
         }
         if (pass > 0)
-          r1 -= p_times(w, w.dxp, v) + at_rows(w, P, w.dyr, v) + w.bbp[v] * w.dybp[v];
-        w.tp[v] = r1 + at_rows(w, P, w.hr, v) + w.bbp[v] * gb;
+          r1 -= p_times(wp, wp.dxp, v) + at_rows(wp, P, wp.dyr, v) + wp.bbp[v] * wp.dybp[v];
+        wp.tp[v] = r1 + at_rows(wp, P, wp.hr, v) + wp.bbp[v] * gb;
       }
       for (int r = tid; r < R; r += NT)
-        if (w.act[r])
-          for (int k = 0; k < w.naux[r]; ++k)
+        if (wp.act[r])
+          for (int k = 0; k < wp.naux[r]; ++k)
           {
-            const int a = w.aoff[r] + k;
-            double r1 = -w.qa[a];
+            const int a = wp.aoff[r] + k;
+            double r1 = -wp.qa[a];
             double gb = 0.0;
-            if (w.flg_ba[a] != 0)
+            if (wp.flg_ba[a] != 0)
             {
-              double r2 = (w.flg_ba[a] < 0) ? 0.0 : TMX_OSQP_INFTY * w.Eba[a];
+              double r2 = (wp.flg_ba[a] < 0) ? 0.0 : TMX_OSQP_INFTY * wp.Eba[a];
               if (pass > 0)
-                r2 -= w.bba[a] * w.dxa[a];
+                r2 -= wp.bba[a] * wp.dxa[a];
               gb = r2 / delta;
             }
             if (pass > 0)
-              r1 -= w.sa[a] * w.dyr[r] + w.bba[a] * w.dyba[a];
-            w.ta[a] = r1 + w.sa[a] * w.hr[r] + w.bba[a] * gb;
+              r1 -= wp.sa[a] * wp.dyr[r] + wp.bba[a] * wp.dyba[a];
+            wp.ta[a] = r1 + wp.sa[a] * wp.hr[r] + wp.bba[a] * gb;
           }
       TMX_SYNC();
-      kkt_solve(w, P, 1, delta, delta, tid, NT);
+      kkt_solve(wp, P, 1, delta, delta, tid, NT);
       // y-part of the solution: nu = (A dx - r2) / delta on active rows (r2 recomputed from the pre-update iterate)
       for (int r = tid; r < R; r += NT)
       {
-        if (!w.act[r])
+        if (!wp.act[r])
           continue;
         double dy = 0.0;
-        if (w.flg_r[r] != 0)
+        if (wp.flg_r[r] != 0)
         {
-          double r2 = (w.flg_r[r] < 0) ? w.lor[r] : w.hir[r];
+          double r2 = (wp.flg_r[r] < 0) ? wp.lor[r] : wp.hir[r];
           if (pass > 0)
           {
-            const int t = w.slot_t[r];
+            const int t = wp.slot_t[r];
             double ax = 0.0;
             for (int j = 0; j < D; ++j)
-              ax += w.coef[r * D + j] * w.dxp[t * D + j];
-            for (int k = 0; k < w.naux[r]; ++k)
-              ax += w.sa[w.aoff[r] + k] * w.dxa[w.aoff[r] + k];
+              ax += wp.coef[r * D + j] * wp.dxp[t * D + j];
+            for (int k = 0; k < wp.naux[r]; ++k)
+              ax += wp.sa[wp.aoff[r] + k] * wp.dxa[wp.aoff[r] + k];
             r2 -= ax;
           }
-          dy = (w.hr[r] - r2) / delta;
+          dy = (wp.hr[r] - r2) / delta;
         }
-        w.zr[r] = dy;  // z_r is dead after the active-set guess: reuse it to carry this pass's dy_r
+        wp.zr[r] = dy;  // z_r is dead after the active-set guess: reuse it to carry this pass's dy_r
       }
       TMX_SYNC();
       for (int v = tid; v < NX; v += NT)
       {
         double dyb = 0.0;
-        if (w.flg_bp[v] != 0)
+        if (wp.flg_bp[v] != 0)
         {
-          double r2 = (w.flg_bp[v] < 0) ? w.lbp[v] : w.ubp[v];
+          double r2 = (wp.flg_bp[v] < 0) ? wp.lbp[v] : wp.ubp[v];
           if (pass > 0)
-            r2 -= w.bbp[v] * w.dxp[v];
-          dyb = (w.bbp[v] * w.tp[v] - r2) / delta;
+            r2 -= wp.bbp[v] * wp.dxp[v];
+          dyb = (wp.bbp[v] * wp.tp[v] - r2) / delta;
         }
         if (pass == 0)
         {
-          w.dxp[v] = w.tp[v];
-          w.dybp[v] = dyb;
+          wp.dxp[v] = wp.tp[v];
+          wp.dybp[v] = dyb;
         }
         else
         {
-          w.dxp[v] += w.tp[v];
-          w.dybp[v] += dyb;
+          wp.dxp[v] += wp.tp[v];
+          wp.dybp[v] += dyb;
         }
       }
       for (int r = tid; r < R; r += NT)
       {
-        if (!w.act[r])
+        if (!wp.act[r])
           continue;
-        for (int k = 0; k < w.naux[r]; ++k)
+        for (int k = 0; k < wp.naux[r]; ++k)
         {
-          const int a = w.aoff[r] + k;
+          const int a = wp.aoff[r] + k;
           double dyb = 0.0;
-          if (w.flg_ba[a] != 0)
+          if (wp.flg_ba[a] != 0)
           {
-            double r2 = (w.flg_ba[a] < 0) ? 0.0 : TMX_OSQP_INFTY * w.Eba[a];
+            double r2 = (wp.flg_ba[a] < 0) ? 0.0 : TMX_OSQP_INFTY * wp.Eba[a];
             if (pass > 0)
-              r2 -= w.bba[a] * w.dxa[a];
-            dyb = (w.bba[a] * w.ta[a] - r2) / delta;
+              r2 -= wp.bba[a] * wp.dxa[a];
+            dyb = (wp.bba[a] * wp.ta[a] - r2) / delta;
           }
           if (pass == 0)
           {
-            w.dxa[a] = w.ta[a];
-            w.dyba[a] = dyb;
+            wp.dxa[a] = wp.ta[a];
+            wp.dyba[a] = dyb;
           }
           else
           {
-            w.dxa[a] += w.ta[a];
-            w.dyba[a] += dyb;
+            wp.dxa[a] += wp.ta[a];
+            wp.dyba[a] += dyb;
           }
         }
         if (pass == 0)
-          w.dyr[r] = w.zr[r];
+          wp.dyr[r] = wp.zr[r];
         else
-          w.dyr[r] += w.zr[r];
+          wp.dyr[r] += wp.zr[r];
       }
       TMX_SYNC();
     }
     // residuals at the polished point (z = clip(A x))
     QpInfo dummy = info;
     double pprim = 0.0, pdual = 0.0;
-    compute_residuals(w, P, w.dxp, w.dxa, w.dyr, w.dybp, w.dyba, 1, dummy, pprim, pdual, false, tid, NT);
+    compute_residuals(wp, P, wp.dxp, wp.dxa, wp.dyr, wp.dybp, wp.dyba, 1, dummy, pprim, pdual, false, tid, NT);
     const bool ok = (pprim < info.prim_res && pdual < info.dual_res) || (pprim < info.prim_res && info.dual_res < 1e-10) ||
                     (pdual < info.dual_res && info.prim_res < 1e-10);
     if (ok)
@@ -1041,23 +1073,32 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
       info.dual_res = pdual;
       for (int v = tid; v < NX; v += NT)
       {
-        w.xp[v] = w.dxp[v];
-        w.ybp[v] = w.dybp[v];
+        wp.xp[v] = wp.dxp[v];
+        wp.ybp[v] = wp.dybp[v];
       }
       for (int r = tid; r < R; r += NT)
-        if (w.act[r])
+        if (wp.act[r])
         {
-          w.yr[r] = w.dyr[r];
-          for (int k = 0; k < w.naux[r]; ++k)
+          wp.yr[r] = wp.dyr[r];
+          for (int k = 0; k < wp.naux[r]; ++k)
           {
-            const int a = w.aoff[r] + k;
-            w.xa[a] = w.dxa[a];
-            w.yba[a] = w.dyba[a];
+            const int a = wp.aoff[r] + k;
+            wp.xa[a] = wp.dxa[a];
+            wp.yba[a] = wp.dyba[a];
           }
         }
     }
     else
       info.polish_status = -1;
+    if (wp.flg_r != w.flg_r)
+    {
+      for (int r = tid; r < R; r += NT)
+        w.flg_r[r] = wp.flg_r[r];
+      for (int v = tid; v < NX; v += NT)
+        w.flg_bp[v] = wp.flg_bp[v];
+      for (int a = tid; a < P->NA; a += NT)
+        w.flg_ba[a] = wp.flg_ba[a];
+    }
     TMX_SYNC();
   }
 
