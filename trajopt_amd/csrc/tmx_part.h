@@ -43,7 +43,7 @@ TMX_DEVFN void part_invert_interior(const QpWs& w, int t0, int t1, int lane)
       const double pkk = __shfl(s, k * D + k, 64);
       const double rowk = __shfl(s, k * D + j, 64);
       const double colk = __shfl(s, i * D + k, 64);
-      const double piv = 1.0 / pkk;
+      const double piv = fast_rcp(pkk);
       if (i == k && j == k)
         s = piv;
       else if (i == k)

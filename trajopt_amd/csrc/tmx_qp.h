@@ -517,38 +517,94 @@ TMX_DEVFN void kkt_solve(const QpWs& w, const DevProblem* P, int mode, double si
   }
   TMX_SYNC();
   // 2. block forward / backward substitution (sequential over waypoints); row i of the block handled by thread i
-  for (int t = 1; t < T; ++t)
+#if TMX_IS_DEVICE
+  if (D <= 8 && NT >= 64)
   {
-    for (int i = tid; i < D; i += NT)
+    // one wave walks the chain with wave-synchronous LDS exchange: 2T-1 dependent steps without a workgroup barrier each
+    if (tid < 64)
     {
-      const double* S = w.Sinv + (t - 1) * DDS + i * DS;
-      const double* vp = w.tp + (t - 1) * D;
-      double acc = 0.0;
-      for (int j = 0; j < D; ++j)
-        acc += S[j] * vp[j];
-      w.tp[t * D + i] -= w.po[(t - 1) * D + i] * acc;
+      const int i = tid < D ? tid : 0;
+      const bool live = tid < D;
+      for (int t = 1; t < T; ++t)
+      {
+        const double* S = w.Sinv + (t - 1) * DDS + i * DS;
+        const double* vp = w.tp + (t - 1) * D;
+        double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+        for (int j = 0; j < 8; j += 2)
+        {
+          if (j < D)
+            a0 = __builtin_fma(S[j], vp[j], a0);
+          if (j + 1 < D)
+            a1 = __builtin_fma(S[j + 1], vp[j + 1], a1);
+        }
+        if (live)
+          w.tp[t * D + i] -= w.po[(t - 1) * D + i] * (a0 + a1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+      }
+      for (int t = T - 1; t >= 0; --t)
+      {
+        const double* S = w.Sinv + t * DDS + i * DS;
+        double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (j < D)
+          {
+            double vj = w.tp[t * D + j];
+            if (t < T - 1)
+              vj -= w.po[t * D + j] * w.tp[(t + 1) * D + j];
+            if (j & 1)
+              a1 = __builtin_fma(S[j], vj, a1);
+            else
+              a0 = __builtin_fma(S[j], vj, a0);
+          }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        if (live)
+          w.tp[t * D + i] = a0 + a1;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+      }
     }
     TMX_SYNC();
   }
-  for (int t = T - 1; t >= 0; --t)
+  else
+#endif
   {
-    for (int i = tid; i < D; i += NT)
+    for (int t = 1; t < T; ++t)
     {
-      const double* S = w.Sinv + t * DDS + i * DS;
-      double acc = 0.0;
-      for (int j = 0; j < D; ++j)
+      for (int i = tid; i < D; i += NT)
       {
-        double vj = w.tp[t * D + j];
-        if (t < T - 1)
-          vj -= w.po[t * D + j] * w.tp[(t + 1) * D + j];
-        acc += S[j] * vj;
+        const double* S = w.Sinv + (t - 1) * DDS + i * DS;
+        const double* vp = w.tp + (t - 1) * D;
+        double acc = 0.0;
+        for (int j = 0; j < D; ++j)
+          acc += S[j] * vp[j];
+        w.tp[t * D + i] -= w.po[(t - 1) * D + i] * acc;
       }
-      w.gj[i] = acc;
+      TMX_SYNC();
     }
-    TMX_SYNC();
-    for (int i = tid; i < D; i += NT)
-      w.tp[t * D + i] = w.gj[i];
-    TMX_SYNC();
+    for (int t = T - 1; t >= 0; --t)
+    {
+      for (int i = tid; i < D; i += NT)
+      {
+        const double* S = w.Sinv + t * DDS + i * DS;
+        double acc = 0.0;
+        for (int j = 0; j < D; ++j)
+        {
+          double vj = w.tp[t * D + j];
+          if (t < T - 1)
+            vj -= w.po[t * D + j] * w.tp[(t + 1) * D + j];
+          acc += S[j] * vj;
+        }
+        w.gj[i] = acc;
+      }
+      TMX_SYNC();
+      for (int i = tid; i < D; i += NT)
+        w.tp[t * D + i] = w.gj[i];
+      TMX_SYNC();
+    }
   }
   // 3. aux recovery and (A x)_r
   for (int r = tid; r < w.R; r += NT)
