@@ -1,0 +1,117 @@
+"""ProblemConstructionInfo JSON front end (trajopt_amd/json_io.py): the JSON fixtures under tests/golden/json are written
+in the reference's problem-description schema (problem_description.cpp:118-308) and must lower to exactly the same flat
+problem description as the programmatic configs; anything the device path does not lower must be an explicit error."""
+import copy
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from trajopt_amd import abi, configs, json_io
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _env(cfg):
+    pci, start, goal = configs.config0() if cfg == 0 else configs.config1()
+    return json_io.Environment(manipulators={"right_arm": pci.robot}, tip_links={"right_arm": "r_gripper_tool_frame"},
+                               link_frames={"base_footprint": np.hstack([np.eye(3), np.zeros((3, 1))])},
+                               joint_state={"right_arm": list(start)}, obstacles=list(pci.obstacles)), pci, start, goal
+
+
+def _terms(desc):
+    out = []
+    for i in range(desc.n_terms):
+        t = desc.terms[i]
+        out.append((t.kind, t.is_constraint, t.first_step, t.last_step, tuple(t.coeffs), tuple(t.targets), tuple(t.target_pose),
+                    t.margin, t.coeff, t.buffer))
+    return out
+
+
+@pytest.mark.parametrize("cfg,fname", [(0, "planning_unit_cfg0.json"), (1, "glass_upright_cfg1.json")])
+def test_json_lowers_like_the_programmatic_config(cfg, fname):
+    env, pci, start, goal = _env(cfg)
+    text = open(os.path.join(HERE, "golden", "json", fname)).read()
+    pp = json_io.construct_problem(text, env)
+    d_json, d_ref = pp.pci.to_desc(), pci.to_desc()
+    assert (d_json.n_dof, d_json.n_steps, d_json.n_terms, d_json.n_fixed_steps) == (d_ref.n_dof, d_ref.n_steps, d_ref.n_terms, d_ref.n_fixed_steps)
+    assert _terms(d_json) == _terms(d_ref)
+    assert [d_json.fixed_steps[i] for i in range(d_json.n_fixed_steps)] == [d_ref.fixed_steps[i] for i in range(d_ref.n_fixed_steps)]
+    assert d_json.n_obstacles == d_ref.n_obstacles
+    # generateInitTraj: joint_interpolated == LinSpaced(start, endpoint)
+    T = pci.basic_info.n_steps
+    w = np.linspace(0, 1, T)[:, None]
+    assert np.allclose(pp.init_traj, start[None, :] * (1 - w) + goal[None, :] * w, atol=0, rtol=0)
+    # opt_info overrides land in the SQP parameters
+    ref = abi.default_sqp_params()
+    assert pp.sqp_params.max_iter == ref.max_iter and pp.sqp_params.trust_box_size == ref.trust_box_size
+
+
+def test_json_problem_solves_like_the_programmatic_one(orc=None):
+    from oracle import pyorc
+    pyorc.build()
+    env, pci, start, goal = _env(0)
+    pp = json_io.construct_problem(open(os.path.join(HERE, "golden", "json", "planning_unit_cfg0.json")).read(), env)
+    x0 = pp.init_traj[None, :, :]
+    a = pyorc.sqp_batch(pp.pci.to_desc(), x0)
+    b = pyorc.sqp_batch(pci.to_desc(), x0)
+    assert (a["status"] == b["status"]).all() and (a["n_qp_solves"] == b["n_qp_solves"]).all()
+    assert np.array_equal(a["x"], b["x"])
+
+
+def test_unsupported_and_malformed_inputs_are_explicit_errors():
+    env, pci, start, goal = _env(1)
+    base = json.load(open(os.path.join(HERE, "golden", "json", "glass_upright_cfg1.json")))
+    bad = copy.deepcopy(base)
+    bad["costs"][1]["params"]["evaluator_type"] = 4        # LVS_CONTINUOUS (arm_around_table.json uses it)
+    with pytest.raises(json_io.UnsupportedTerm):
+        json_io.construct_problem(bad, env)
+    bad = copy.deepcopy(base)
+    bad["costs"][0]["params"]["bogus"] = 1                  # ensure_only_members
+    with pytest.raises(ValueError):
+        json_io.construct_problem(bad, env)
+    bad = copy.deepcopy(base)
+    bad["basic_info"]["manip"] = "left_arm"
+    with pytest.raises(ValueError):
+        json_io.construct_problem(bad, env)
+    bad = copy.deepcopy(base)
+    del bad["init_info"]
+    with pytest.raises(ValueError):
+        json_io.construct_problem(bad, env)
+    bad = copy.deepcopy(base)
+    bad["constraints"][0]["params"]["target_frame"] = "l_gripper_tool_frame"   # a moving frame
+    with pytest.raises(json_io.UnsupportedTerm):
+        json_io.construct_problem(bad, env)
+    bad = copy.deepcopy(base)
+    bad["costs"].append({"type": "joint_acc", "params": {"targets": [0] * 7}})
+    with pytest.raises(json_io.UnsupportedTerm):
+        json_io.construct_problem(bad, env)
+    bad = copy.deepcopy(base)
+    bad["basic_info"]["use_time"] = True
+    with pytest.raises(json_io.UnsupportedTerm):
+        json_io.construct_problem(bad, env)
+
+
+def test_init_info_types_and_target_offsets():
+    env, pci, start, goal = _env(1)
+    base = json.load(open(os.path.join(HERE, "golden", "json", "glass_upright_cfg1.json")))
+    st = copy.deepcopy(base)
+    st["init_info"] = {"type": "stationary"}
+    pp = json_io.construct_problem(st, env)
+    assert np.array_equal(pp.init_traj, np.tile(start, (30, 1)))
+    gv = copy.deepcopy(base)
+    traj = np.linspace(start, goal, 30)
+    gv["init_info"] = {"type": "given_traj", "data": traj.tolist()}
+    assert np.array_equal(json_io.construct_problem(gv, env).init_traj, traj)
+    gv["init_info"]["data"] = traj[:-1].tolist()
+    with pytest.raises(ValueError):
+        json_io.construct_problem(gv, env)
+    # target_frame_offset: 180 deg about y (numerical_ik1.json style wxyz = [0,0,1,0]) composes into the target pose
+    off = copy.deepcopy(base)
+    off["constraints"][0]["params"]["target_frame_offset_xyz"] = [0.4, 0, 0.8]
+    off["constraints"][0]["params"]["target_frame_offset_wxyz"] = [0, 0, 1, 0]
+    pp = json_io.construct_problem(off, env)
+    tp = np.asarray(pp.pci.cnt_infos[0].target_pose)
+    assert np.allclose(tp[:, 3], [0.4, 0, 0.8]) and np.allclose(tp[:, :3], np.diag([-1.0, 1.0, -1.0]))

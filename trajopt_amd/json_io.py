@@ -1,0 +1,216 @@
+"""ProblemConstructionInfo JSON front end for the hot path.
+
+Reads the reference's problem-description JSON — the schema parsed by `ProblemConstructionInfo::fromJson`
+(/root/reference/trajopt/src/problem_description.cpp:118-308) and the per-term `fromJson` methods
+(CartPoseTermInfo :832-899, JointPosTermInfo :1059-1076, JointVelTermInfo :1178-1194, CollisionTermInfo :1617-1700)
+— and produces the `trajopt_amd.problem.ProblemConstructionInfo` mirror that lowers to `tmx_problem_desc`.
+
+What trajopt reads from a tesseract `Environment` (kinematic groups, link frames, the current joint state, collision
+geometry) is supplied by the small `Environment` class below.  Every key or term the device path does not lower is an
+explicit error (`UnsupportedTerm`) — never a silent CPU detour, matching `TMX_ERR_UNSUPPORTED` of the C-ABI.
+"""
+import json
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import abi
+from .problem import (BasicInfo, CartPoseTermInfo, CollisionTermInfo, JointPosTermInfo, JointVelTermInfo,
+                      ProblemConstructionInfo, Robot, _tf12)
+
+
+class UnsupportedTerm(ValueError):
+    """the JSON asks for something the MI355X path does not lower (the caller may keep the reference CPU path for it)"""
+
+
+@dataclass
+class Environment:
+    """stand-in for the parts of tesseract::environment::Environment that fromJson / hatch consult"""
+    manipulators: Dict[str, Robot]                       # env->getJointGroup(manip)
+    tip_links: Dict[str, str]                            # manip -> name of the link the Robot's tool frame is attached to
+    link_frames: Dict[str, np.ndarray] = field(default_factory=dict)   # static world frames (3x4), e.g. "base_footprint"
+    joint_state: Dict[str, Sequence[float]] = field(default_factory=dict)  # manip -> current joint values (env->getState())
+    obstacles: List[Tuple[Tuple[float, float, float], float]] = field(default_factory=list)  # sphere world geometry
+
+
+# enum values of tesseract::collision::CollisionEvaluatorType (collision_terms / problem_description.cpp:1634)
+_EVAL_NONE, _EVAL_DISCRETE, _EVAL_LVS_DISCRETE, _EVAL_CONTINUOUS, _EVAL_LVS_CONTINUOUS = range(5)
+
+_OPT_INFO_KEYS = ("improve_ratio_threshold", "min_trust_box_size", "min_approx_improve", "min_approx_improve_frac", "max_iter",
+                  "trust_shrink_ratio", "trust_expand_ratio", "cnt_tolerance", "max_merit_coeff_increases",
+                  "merit_coeff_increase_ratio", "max_time", "initial_merit_error_coeff", "inflate_constraints_individually",
+                  "trust_box_size")
+
+
+def _only_members(params: dict, allowed: Sequence[str], what: str):
+    """json_marshal ensure_only_members (problem_description.cpp:66-79): unknown keys are an error"""
+    for k in params:
+        if k not in allowed:
+            raise ValueError(f"{what}: illegal field \"{k}\"")
+
+
+def _quat_to_rot(wxyz) -> np.ndarray:
+    w, x, y, z = (float(v) for v in wxyz)
+    n = math.sqrt(w * w + x * x + y * y + z * z)
+    if n == 0.0:
+        raise ValueError("zero quaternion")
+    w, x, y, z = w / n, x / n, y / n, z / n   # Eigen::Quaterniond(w,x,y,z).matrix() of the (normalised) quaternion
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def _mul34(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    out = np.zeros((3, 4))
+    out[:, :3] = a[:, :3] @ b[:, :3]
+    out[:, 3] = a[:, :3] @ b[:, 3] + a[:, 3]
+    return out
+
+
+def _vec(params: dict, key: str, n: int, default=None) -> List[float]:
+    if key not in params:
+        if default is None:
+            raise ValueError(f"missing required field \"{key}\"")
+        return list(default)
+    v = params[key]
+    v = [float(x) for x in v] if isinstance(v, (list, tuple)) else [float(v)]
+    if len(v) == 1 and n > 1 and key == "coeffs":
+        v = v * n     # arm_around_table.json style: "coeffs": [1] broadcast over the joints
+    if len(v) != n:
+        raise ValueError(f"wrong number of values in \"{key}\": expected {n} got {len(v)}")
+    return v
+
+
+@dataclass
+class ParsedProblem:
+    pci: ProblemConstructionInfo
+    sqp_params: "abi.SqpParams"          # BasicTrustRegionSQPParameters after opt_info overrides
+    init_traj: np.ndarray                # [n_steps][n_dof]  (generateInitTraj, problem_description.cpp:310-372)
+    manip: str
+    convex_solver: str
+
+
+def construct_problem(text_or_dict, env: Environment) -> ParsedProblem:
+    """ConstructProblem(json, env) (problem_description.cpp:532-550) restricted to what the device path lowers."""
+    v = json.loads(text_or_dict) if isinstance(text_or_dict, (str, bytes)) else dict(text_or_dict)
+    if "basic_info" not in v:
+        raise ValueError("Json missing required section basic_info!")
+    bi = v["basic_info"]
+    n_steps = int(bi["n_steps"])
+    manip = str(bi["manip"])
+    if manip not in env.manipulators:
+        raise ValueError(f"Manipulator does not exist: {manip}")
+    rob = env.manipulators[manip]
+    D = rob.n_dof
+    if bi.get("fixed_dofs"):
+        raise UnsupportedTerm("basic_info.fixed_dofs is not lowered by the device path")
+    if bi.get("use_time", False):
+        raise UnsupportedTerm("basic_info.use_time (time-parameterised terms) is not lowered by the device path")
+    dt_lo, dt_hi = float(bi.get("dt_lower_lim", 1.0)), float(bi.get("dt_upper_lim", 1.0))
+    if dt_lo <= 0 or dt_hi < dt_lo:
+        raise ValueError("dt limits (Basic Info) invalid")
+    convex_solver = str(bi.get("convex_solver", "AUTO_SOLVER"))
+    if convex_solver not in ("AUTO_SOLVER", "OSQP"):
+        raise UnsupportedTerm(f"convex_solver {convex_solver}: the device QP solver restates the OSQP back-end only")
+    pci = ProblemConstructionInfo(rob, BasicInfo(n_steps=n_steps, fixed_timesteps=[int(t) for t in bi.get("fixed_timesteps", [])]))
+    pci.obstacles = list(env.obstacles)
+
+    sp = abi.default_sqp_params()
+    for k, val in v.get("opt_info", {}).items():
+        if k not in _OPT_INFO_KEYS:
+            continue   # readOptInfo ignores unknown keys (childFromJson with defaults only)
+        if k == "max_time":
+            continue   # wall-clock limit: not meaningful for a batched launch
+        setattr(sp, k, type(getattr(sp, k))(val))
+
+    def read_term(it: dict, is_cost: bool):
+        typ = str(it["type"])
+        if it.get("use_time", False):
+            raise UnsupportedTerm(f"{typ}: use_time terms are not lowered by the device path")
+        if "params" not in it:
+            raise ValueError(f"{typ}: missing params")
+        p = it["params"]
+        name = str(it.get("name", typ))
+        if typ == "joint_vel":
+            _only_members(p, ("coeffs", "first_step", "last_step", "targets", "lower_tols", "upper_tols", "use_time"), typ)
+            if not is_cost:
+                raise UnsupportedTerm("joint_vel as a constraint is not lowered by the device path")
+            if any(float(x) != 0.0 for x in list(p.get("upper_tols", [])) + list(p.get("lower_tols", []))):
+                raise UnsupportedTerm("joint_vel with tolerances (hinge form) is not lowered by the device path")
+            return JointVelTermInfo(coeffs=_vec(p, "coeffs", D, [1.0] * D), targets=_vec(p, "targets", D),
+                                    first_step=int(p.get("first_step", 0)), last_step=int(p.get("last_step", n_steps - 1)), name=name)
+        if typ == "joint_pos":
+            _only_members(p, ("coeffs", "first_step", "last_step", "targets", "lower_tols", "upper_tols"), typ)
+            if is_cost:
+                raise UnsupportedTerm("joint_pos as a cost is not lowered by the device path")
+            if any(float(x) != 0.0 for x in list(p.get("upper_tols", [])) + list(p.get("lower_tols", []))):
+                raise UnsupportedTerm("joint_pos with tolerances (inequality form) is not lowered by the device path")
+            return JointPosTermInfo(coeffs=_vec(p, "coeffs", D, [1.0] * D), targets=_vec(p, "targets", D),
+                                    first_step=int(p.get("first_step", 0)), last_step=int(p.get("last_step", n_steps - 1)), name=name)
+        if typ == "cart_pose":
+            src, tgt = str(p["source_frame"]), str(p["target_frame"])
+            if src != env.tip_links.get(manip):
+                raise UnsupportedTerm(f"cart_pose source_frame {src}: only the manipulator tip link {env.tip_links.get(manip)} is lowered")
+            if tgt not in env.link_frames:
+                raise UnsupportedTerm(f"cart_pose target_frame {tgt}: only static frames of the environment are lowered "
+                                      "(DynamicCartPose is the reference's term for moving targets)")
+            s_off = _tf12(_quat_to_rot(p.get("source_frame_offset_wxyz", (1, 0, 0, 0))), _vec(p, "source_frame_offset_xyz", 3, (0, 0, 0)))
+            t_off = _tf12(_quat_to_rot(p.get("target_frame_offset_wxyz", (1, 0, 0, 0))), _vec(p, "target_frame_offset_xyz", 3, (0, 0, 0)))
+            if not np.allclose(s_off, _tf12()):
+                raise UnsupportedTerm("cart_pose source_frame_offset: fold it into the manipulator's tool frame (one tool frame per problem)")
+            target = _mul34(np.asarray(env.link_frames[tgt], dtype=np.float64), t_off)   # world_T_target * offset
+            return CartPoseTermInfo(timestep=int(p.get("timestep", n_steps - 1)), target_pose=target,
+                                    pos_coeffs=tuple(_vec(p, "pos_coeffs", 3, (1, 1, 1))), rot_coeffs=tuple(_vec(p, "rot_coeffs", 3, (1, 1, 1))),
+                                    is_constraint=not is_cost, name=name)
+        if typ == "collision":
+            if not is_cost:
+                raise UnsupportedTerm("collision as a constraint is not lowered by the device path")
+            ev = int(p.get("evaluator_type", 1))
+            if ev != _EVAL_DISCRETE:
+                raise UnsupportedTerm(f"collision evaluator_type {ev}: only DISCRETE (1, single time step) is lowered; "
+                                      "LVS / continuous evaluators are SURVEY.md §8(f) row 2")
+            if "pairs" in p:
+                raise UnsupportedTerm("collision per-pair margin overrides are not lowered by the device path")
+            first, last = int(p.get("first_step", 0)), int(p.get("last_step", n_steps - 1))
+            if not (0 <= first < n_steps and first <= last < n_steps):
+                raise ValueError("collision: invalid first_step / last_step")
+            for fs in p.get("fixed_steps", []):
+                if fs < first or fs > last:
+                    raise ValueError(f"Fixed step {fs} is not between first step {first} and last step {last}")
+            buf = float(p.get("safety_margin_buffer", 0.5))
+            if buf < 0:
+                raise ValueError("collision: negative safety_margin_buffer")
+            return CollisionTermInfo(first_step=first, last_step=last, dist_pen=float(p["dist_pen"]), coeff=float(p["coeffs"]),
+                                     safety_margin_buffer=buf, name=name)
+        raise UnsupportedTerm(f"term type \"{typ}\" is not lowered by the device path")
+
+    for it in v.get("costs", []):
+        pci.cost_infos.append(read_term(it, True))
+    for it in v.get("constraints", []):
+        pci.cnt_infos.append(read_term(it, False))
+
+    if "init_info" not in v:
+        raise ValueError("Json missing required section init_info!")
+    ii = v["init_info"]
+    typ = str(ii["type"]).lower()
+    state = np.asarray(env.joint_state.get(manip, [0.0] * D), dtype=np.float64)
+    if typ == "stationary":
+        init = np.tile(state, (n_steps, 1))
+    elif typ == "given_traj":
+        data = np.asarray(ii["data"], dtype=np.float64)
+        if data.shape[0] != n_steps:
+            raise ValueError("given initialization traj has wrong length")
+        if data.shape[1] != D:
+            raise ValueError("given initialization traj has wrong number of dof values")
+        init = data
+    elif typ == "joint_interpolated":
+        end = np.asarray(ii["endpoint"], dtype=np.float64)
+        if end.shape != (D,):
+            raise ValueError(f"wrong number of dof values in initialization. expected {D} got {end.size}")
+        w = np.linspace(0.0, 1.0, n_steps)[:, None]     # Eigen::VectorXd::LinSpaced per dof (problem_description.cpp:351-355)
+        init = state[None, :] * (1.0 - w) + end[None, :] * w
+    else:
+        raise ValueError("init_info did not have a valid type from Json. Valid types are stationary, joint_interpolated, or given_traj")
+    return ParsedProblem(pci=pci, sqp_params=sp, init_traj=np.ascontiguousarray(init), manip=manip, convex_solver=convex_solver)
