@@ -680,11 +680,28 @@ TMX_DEVFN void admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, b
   const bool qlead = mp.qg >= 0 && mp.qq == 0;
   const bool wr_yl = interior && mp.last && mp.hasr, wr_yr = interior && mp.first && mp.hasl;
   const int i_yl = mp.k * D + (mp.r - (mp.n - D)), i_yr = 64 + (mp.k - 1) * D + mp.r;
+  // e_r is exchanged GROUPED BY WAYPOINT: group t starts at the even offset wp_pst[t] (computed at QP setup) and
+  // holds the rows of waypoint t in wp_list order, so the A'e gather of a variable is a run of 16-byte loads instead of
+  // 16 indexed 8-byte loads (and needs no index registers).
+  auto pst = [&](int t) -> int { return w.wp_pst[t]; };
+  int epos[TMX_NROW];
+#pragma unroll
+  for (int q = 0; q < TMX_NROW; ++q)
+  {
+    epos[q] = 0;
+    if (has[q])
+    {
+      const int r = rowi[q], t = w.slot_t[r];
+      int k = 0;
+      for (int u = w.wp_start[t]; u < w.wp_start[t + 1]; ++u)
+        k = (w.wp_list[u] == r) ? (u - w.wp_start[t]) : k;
+      epos[q] = pst(t) + k;
+    }
+  }
   // column v of A restricted to the rows of its waypoint, kept in registers (first 16 rows; a longer list falls back
-  // to the LDS gather for the remainder): A'e needs only the hr[] loads per iteration
+  // to a loop for the remainder)
   double cj[16];
-  int ri[16];
-  int q_rest = 0, q_end = 0;
+  int e0off = 0, q_rest = 0, q_end = 0;
   {
     const int t = v / D, j = v % D;
     const int q0 = w.wp_start[t], q1 = w.wp_start[t + 1];
@@ -693,12 +710,16 @@ TMX_DEVFN void admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, b
     {
       const bool ok = pv && (q0 + k < q1);
       const int r = ok ? w.wp_list[q0 + k] : 0;
-      ri[k] = r;
       cj[k] = ok ? w.coef[r * D + j] : 0.0;
     }
+    e0off = pst(t);
     q_rest = q0 + 16;
     q_end = pv ? q1 : 0;
   }
+  const int q0v = w.wp_start[v / D];
+  // entries of the grouped buffer that no row writes (pad slots, groups of inactive rows) must stay finite
+  for (int e = tid; e < w.R + w.T + 18; e += TMX_QP_NT)
+    h.hr[e] = 0.0;
   TMX_SYNC();
   TMX_TICK(8);
   // One ADMM iteration.  Instantiated twice: KEEP = false is the body of the hot loop and contains nothing but the
@@ -712,30 +733,31 @@ TMX_DEVFN void admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, b
     {
       const double e = row_phase_a(g[q], sigma, ta[q]);
       if (has[q])
-        h.hr[rowi[q]] = e;
+        h.hr[epos[q]] = e;
     }
     TMX_SYNC();
     if (pv)
     {
       const double gb = __builtin_fma(rbp, zb, -yb);
-      double e[16];
+      tmx_d2 e2[8];
+      const tmx_lds_d2* ep = reinterpret_cast<const tmx_lds_d2*>(h.hr + e0off);
 #pragma unroll
-      for (int k = 0; k < 16; ++k)
-        e[k] = h.hr[ri[k]];
-      double a0 = cj[0] * e[0], a1 = cj[1] * e[1], a2 = cj[2] * e[2], a3 = cj[3] * e[3];
+      for (int k = 0; k < 8; ++k)
+        e2[k] = ep[k];
+      double a0 = cj[0] * e2[0].x, a1 = cj[1] * e2[0].y, a2 = cj[2] * e2[1].x, a3 = cj[3] * e2[1].y;
 #pragma unroll
-      for (int k = 4; k < 16; k += 4)
+      for (int k = 2; k < 8; k += 2)
       {
-        a0 = __builtin_fma(cj[k], e[k], a0);
-        a1 = __builtin_fma(cj[k + 1], e[k + 1], a1);
-        a2 = __builtin_fma(cj[k + 2], e[k + 2], a2);
-        a3 = __builtin_fma(cj[k + 3], e[k + 3], a3);
+        a0 = __builtin_fma(cj[2 * k], e2[k].x, a0);
+        a1 = __builtin_fma(cj[2 * k + 1], e2[k].y, a1);
+        a2 = __builtin_fma(cj[2 * k + 2], e2[k + 1].x, a2);
+        a3 = __builtin_fma(cj[2 * k + 3], e2[k + 1].y, a3);
       }
       double ate = (a0 + a1) + (a2 + a3);
       for (int q = q_rest; q < q_end; ++q)
       {
         const int r = w.wp_list[q];
-        ate += w.coef[r * D + (v % D)] * h.hr[r];
+        ate += w.coef[r * D + (v % D)] * h.hr[e0off + (q - q0v)];
       }
       h.ty[mp.slot] = __builtin_fma(bb, gb, __builtin_fma(sigma, xp, -qv) + ate);
     }

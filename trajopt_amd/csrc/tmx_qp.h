@@ -151,6 +151,7 @@ struct QpWs
   // ints
   int *act, *aoff, *naux, *slot_t, *typ_r, *typ_bp, *typ_ba, *flg_r, *flg_bp, *flg_ba, *row_ref, *aux_ref;
   int *wp_start, *wp_list;  // LDS copies of DevProblem::wp_start / wp_list (hot in every SpMV)
+  int *wp_pst;               // T+1: even-aligned start of every waypoint's group in the grouped e exchange (fast path)
 };
 
 // The workspace is split by access frequency:
@@ -224,13 +225,13 @@ TMX_HOSTDEVFN size_t qp_lds_doubles(int D, int T, int R, int NA)
   dpart_make(T, p);
   const size_t gn = (size_t)p.Lmax * D, nsep = (size_t)(p.P - 1) * D;
   const size_t dense = (D <= 8) ? (size_t)p.P * gn * dpart_gstride((int)gn) + nsep * dpart_mult8((int)nsep) + 6 * 64 + (size_t)p.P * dpart_gstride((int)gn) + 64 : 0;
-  return 2 * NX + 4 + (size_t)R + (size_t)T * D * (D <= 8 ? 8 : D) + dense + (size_t)D * D + 256 + 4 + (sizeof(QpWs) + 7) / 8;
+  return 2 * NX + 4 + (size_t)R + (size_t)T + 20 + (size_t)T * D * (D <= 8 ? 8 : D) + dense + (size_t)D * D + 256 + 4 + (sizeof(QpWs) + 7) / 8;
 }
 TMX_HOSTDEVFN size_t qp_glb_doubles(int D, int T, int R, int NA)
 {
   const size_t NX = (size_t)D * T;
   const size_t n = 10 * NX + 6 * (size_t)R + (size_t)R * D + 8 * (size_t)NA;
-  const size_t ints = 6 * (size_t)R + (size_t)NX + (size_t)NA + (size_t)T + 2;
+  const size_t ints = 6 * (size_t)R + (size_t)NX + (size_t)NA + 2 * (size_t)T + 4;
   return n + (ints + 1) / 2 + 8;
 }
 // arrays that are only touched at burst boundaries / in the polish step: always in the per-problem HBM scratch
@@ -283,7 +284,7 @@ TMX_DEVFN void qp_ws_carve(QpWs& w, double* lds, double* glb, double* far, int D
   }
   TAKE(tp, (NX + 3) & ~1);  // +2: the paired loads of the dense interior mat-vec may run one element past the last block
   TAKE(po, NX);
-  TAKE(hr, R);
+  TAKE(hr, R + T + (R + T) % 2 + 18);  // the fast path stores e grouped by waypoint (even-aligned groups) and reads 16 entries per group
   TAKE(gj, D * D);
   TAKE(red, 256);
   TAKE(wself, (sizeof(QpWs) + 7) / 8);
@@ -326,6 +327,7 @@ TMX_DEVFN void qp_ws_carve(QpWs& w, double* lds, double* glb, double* far, int D
   TAKEI(typ_bp, NX);
   TAKEI(typ_ba, NA);
   TAKEI(wp_start, T + 1);
+  TAKEI(wp_pst, T + 1);
   TAKEI(wp_list, R);
   // ---- far: always HBM (delta vectors of the last iteration, polish bookkeeping)
   p = far;

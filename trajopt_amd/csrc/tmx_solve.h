@@ -529,7 +529,16 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
     w.flg_bp[v] = 0;
   }
   for (int t = tid; t <= T; t += NT)
+  {
     w.wp_start[t] = P->wp_start[t];
+    int acc = 0;  // even-padded group starts of the grouped e exchange
+    for (int u = 0; u < t; ++u)
+    {
+      const int c = P->wp_start[u + 1] - P->wp_start[u];
+      acc += c + (c & 1);
+    }
+    w.wp_pst[t] = acc;
+  }
   w.sigma = st.sigma;
   w.alpha = st.alpha;
   w.c = 1.0;
