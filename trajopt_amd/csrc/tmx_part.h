@@ -671,13 +671,16 @@ TMX_DEVFN void admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, b
 #pragma unroll
   for (int q = 0; q < TMX_NROW; ++q)
   {
-    tb[q] = g[q].t * D;
+    tb[q] = g[q].t * 8;  // x~ is exchanged with 8 slots per waypoint
     has[q] = rowi[q] >= 0 && rowi[q] < w.R;
   }
   // couplings of this thread's variable / of the separator row it publishes (constant during the solve)
   const double cprev = (pv && v >= D) ? h.po[v - D] : 0.0, cnext = pv ? h.po[v] : 0.0;
   const double qcprev = h.po[mp.qv - D], qcnext = h.po[mp.qv];
   const bool qlead = mp.qg >= 0 && mp.qq == 0;
+  const int vp = (v / D) * 8 + v % D, qvp = (mp.qv / D) * 8 + mp.qv % D;  // positions in the padded x~ buffer
+  for (int e = tid; e < w.T * 8; e += TMX_QP_NT)
+    h.tp[e] = 0.0;
   const bool wr_yl = interior && mp.last && mp.hasr, wr_yr = interior && mp.first && mp.hasl;
   const int i_yl = mp.k * D + (mp.r - (mp.n - D)), i_yr = 64 + (mp.k - 1) * D + mp.r;
   // e_r is exchanged GROUPED BY WAYPOINT: group t starts at the even offset wp_pst[t] (computed at QP setup) and
@@ -780,26 +783,35 @@ TMX_DEVFN void admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, b
       const double xs = dpart_separator_row(h, mp, bsep);
       if (qlead)
       {
-        h.tp[mp.qv] = xs;
+        h.tp[qvp] = xs;
         h.sx[128 + mp.qg] = qcprev * xs;
         h.sx[192 + mp.qg] = qcnext * xs;
       }
     }
     TMX_SYNC();
     if (interior)
-      h.tp[v] = dpart_correct(h, mp, yint);
+      h.tp[vp] = dpart_correct(h, mp, yint);
     TMX_SYNC();
     TMX_LTICK(4);
     // phase C
-    const double xtv = h.tp[v];
+    const double xtv = h.tp[vp];
 #pragma unroll
     for (int q = 0; q < TMX_NROW; ++q)
     {
       RowRegs& gq = g[q];
+      // x~ of the row's waypoint: 8 slots per waypoint (slot 7 of a 7-dof block is never written: multiplied by c[7] = 0,
+      // kept finite by the zero fill at burst entry)
       double xt[8];
+      {
+        const tmx_lds_d2* xb = reinterpret_cast<const tmx_lds_d2*>(h.tp + tb[q]);
 #pragma unroll
-      for (int j = 0; j < 8; ++j)
-        xt[j] = (j < D) ? h.tp[tb[q] + j] : 0.0;
+        for (int j = 0; j < 4; ++j)
+        {
+          const tmx_d2 t2 = xb[j];
+          xt[2 * j] = t2.x;
+          xt[2 * j + 1] = t2.y;
+        }
+      }
       const double d0 = (__builtin_fma(gq.c[4], xt[4], gq.c[0] * xt[0]) + __builtin_fma(gq.c[5], xt[5], gq.c[1] * xt[1])) +
                         (__builtin_fma(gq.c[6], xt[6], gq.c[2] * xt[2]) + __builtin_fma(gq.c[7], xt[7], gq.c[3] * xt[3]));
       double dyr0 = 0, dxa0[2], dya0[2];

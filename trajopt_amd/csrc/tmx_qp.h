@@ -225,7 +225,7 @@ TMX_HOSTDEVFN size_t qp_lds_doubles(int D, int T, int R, int NA)
   dpart_make(T, p);
   const size_t gn = (size_t)p.Lmax * D, nsep = (size_t)(p.P - 1) * D;
   const size_t dense = (D <= 8) ? (size_t)p.P * gn * dpart_gstride((int)gn) + nsep * dpart_mult8((int)nsep) + 6 * 64 + (size_t)p.P * dpart_gstride((int)gn) + 64 : 0;
-  return 2 * NX + 4 + (size_t)R + (size_t)T + 20 + (size_t)T * D * (D <= 8 ? 8 : D) + dense + (size_t)D * D + 256 + 4 + (sizeof(QpWs) + 7) / 8;
+  return NX + 2 + (D <= 8 ? 8 * (size_t)T : NX + 2) + (size_t)R + (size_t)T + 20 + (size_t)T * D * (D <= 8 ? 8 : D) + dense + (size_t)D * D + 256 + 4 + (sizeof(QpWs) + 7) / 8;
 }
 TMX_HOSTDEVFN size_t qp_glb_doubles(int D, int T, int R, int NA)
 {
@@ -282,7 +282,7 @@ TMX_DEVFN void qp_ws_carve(QpWs& w, double* lds, double* glb, double* far, int D
     TAKE(sx, 6 * 64);
     TAKE(ty, dp.P * w.Gs + 64);
   }
-  TAKE(tp, (NX + 3) & ~1);  // +2: the paired loads of the dense interior mat-vec may run one element past the last block
+  TAKE(tp, (D <= 8) ? ((T * 8 > NX + 2) ? T * 8 : ((NX + 3) & ~1)) : ((NX + 3) & ~1));  // the burst keeps x~ with 8 slots per waypoint (aligned 16-byte loads)
   TAKE(po, NX);
   TAKE(hr, R + T + (R + T) % 2 + 18);  // the fast path stores e grouped by waypoint (even-aligned groups) and reads 16 entries per group
   TAKE(gj, D * D);
