@@ -442,23 +442,35 @@ TMX_DEVFN double dpart_separator_row(const HotLds& h, const DMap& m, const tmx_l
 // ---- solve, phase 3 (interior thread): x = y - G_k[r, first block] (c x_sepL) - G_k[r, last block] (c x_sepR) -------
 TMX_DEVFN double dpart_correct(const HotLds& h, const DMap& m, double y)
 {
-  const int D = h.D;
+  // G rows start 16-byte aligned and n - D is even; the coupling products are stored with 8 slots per separator: four
+  // 16-byte loads per operand (slot 7 of a 7-dof group is zero on both sides)
   const tmx_lds_d* Gl = h.G + (m.k * h.Gn + m.r) * h.Gs;
-  const tmx_lds_d* Gq = Gl + (m.n - D);
-  const tmx_lds_d* xl = h.sx + 192 + (m.hasl ? m.k - 1 : 0) * D;  // right-going product of the separator on the left
-  const tmx_lds_d* xr = h.sx + 128 + (m.hasr ? m.k : 0) * D;      // left-going product of the separator on the right
-  double ps[8];
+  const tmx_lds_d2* gl2 = reinterpret_cast<const tmx_lds_d2*>(Gl);
+  const tmx_lds_d2* gq2 = reinterpret_cast<const tmx_lds_d2*>(Gl + (m.n - h.D));
+  const tmx_lds_d2* xl2 = reinterpret_cast<const tmx_lds_d2*>(h.sx + 192 + (m.hasl ? m.k - 1 : 0) * 8);  // from the separator on the left
+  const tmx_lds_d2* xr2 = reinterpret_cast<const tmx_lds_d2*>(h.sx + 128 + (m.hasr ? m.k : 0) * 8);      // from the one on the right
+  const double ml = m.hasl ? 1.0 : 0.0, mr = m.hasr ? 1.0 : 0.0;
+  tmx_d2 a[4], b[4], c[4], d[4];
 #pragma unroll
-  for (int q = 0; q < 8; ++q)
+  for (int q = 0; q < 4; ++q)
   {
-    ps[q] = 0.0;
-    if (q < D)
-    {
-      const double gl = m.hasl ? Gl[q] : 0.0, gr = m.hasr ? Gq[q] : 0.0;
-      ps[q] = __builtin_fma(gr, xr[q], gl * xl[q]);
-    }
+    a[q] = gl2[q];
+    b[q] = xl2[q];
+    c[q] = gq2[q];
+    d[q] = xr2[q];
   }
-  return y - (((ps[0] + ps[1]) + (ps[2] + ps[3])) + ((ps[4] + ps[5]) + (ps[6] + ps[7])));
+  double sl[4], sr[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+  {
+    // columns >= D of the row segments belong to the next block / the pad: masked by the zero slot 7 of the products for
+    // D = 7 and by the explicit column test otherwise
+    const double ax = a[q].x, ay = (2 * q + 1 < h.D) ? a[q].y : 0.0, cx = c[q].x, cy = (2 * q + 1 < h.D) ? c[q].y : 0.0;
+    sl[q] = __builtin_fma(ay, b[q].y, ((2 * q < h.D) ? ax : 0.0) * b[q].x);
+    sr[q] = __builtin_fma(cy, d[q].y, ((2 * q < h.D) ? cx : 0.0) * d[q].x);
+  }
+  const double tl = (sl[0] + sl[1]) + (sl[2] + sl[3]), tr = (sr[0] + sr[1]) + (sr[2] + sr[3]);
+  return y - __builtin_fma(mr, tr, ml * tl);
 }
 
 // sequential (one-sided) inversion of the whole chain by wave 0 — used for the polish factorisation
@@ -678,6 +690,7 @@ TMX_DEVFN void admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, b
   const double cprev = (pv && v >= D) ? h.po[v - D] : 0.0, cnext = pv ? h.po[v] : 0.0;
   const double qcprev = h.po[mp.qv - D], qcnext = h.po[mp.qv];
   const bool qlead = mp.qg >= 0 && mp.qq == 0;
+  const int qsp = mp.qg < 0 ? 0 : (mp.qg / D) * 8 + mp.qg % D;  // slot of this quad's separator row in the 8-per-separator product buffers
   const int vp = (v / D) * 8 + v % D, qvp = (mp.qv / D) * 8 + mp.qv % D;  // positions in the padded x~ buffer
   for (int e = tid; e < w.T * 8; e += TMX_QP_NT)
     h.tp[e] = 0.0;
@@ -784,8 +797,8 @@ TMX_DEVFN void admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, b
       if (qlead)
       {
         h.tp[qvp] = xs;
-        h.sx[128 + mp.qg] = qcprev * xs;
-        h.sx[192 + mp.qg] = qcnext * xs;
+        h.sx[128 + qsp] = qcprev * xs;
+        h.sx[192 + qsp] = qcnext * xs;
       }
     }
     TMX_SYNC();
