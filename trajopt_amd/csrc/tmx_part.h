@@ -494,6 +494,13 @@ struct RowRegs
   double xa[2], za[2], ya[2], qa[2], sa[2], bb[2], di[2], rb[2], rbi[2], ub[2];
 };
 
+// 1 / rho_of_type: rho takes three values per QP, so the reciprocal is a select over three quotients instead of a
+// division per row / aux var / variable at every burst entry
+TMX_DEVFN double rcp_rho_of_type(int typ, double rho)
+{
+  const double i0 = 1.0 / rho, i1 = 1.0 / (TMX_RHO_EQ_OVER_INEQ * rho), i2 = 1.0 / TMX_RHO_MIN;
+  return typ == 1 ? i1 : (typ == 0 ? i0 : i2);
+}
 TMX_DEVFN void row_load(const QpWs& w, int r, RowRegs& g)
 {
   g.act = (r >= 0) && (r < w.R) && w.act[r];
@@ -518,7 +525,7 @@ TMX_DEVFN void row_load(const QpWs& w, int r, RowRegs& g)
   g.t = w.slot_t[r];
   g.na = w.naux[r];
   g.rr = rho_of_type(w.typ_r[r], w.rho);
-  g.rri = 1.0 / g.rr;
+  g.rri = rcp_rho_of_type(w.typ_r[r], w.rho);
   g.z = w.zr[r];
   g.y = w.yr[r];
   g.lo = w.lor[r];
@@ -540,7 +547,7 @@ TMX_DEVFN void row_load(const QpWs& w, int r, RowRegs& g)
       g.bb[k] = w.bba[a];
       g.di[k] = w.dinv[a];
       g.rb[k] = rho_of_type(w.typ_ba[a], w.rho);
-      g.rbi[k] = 1.0 / g.rb[k];
+      g.rbi[k] = rcp_rho_of_type(w.typ_ba[a], w.rho);
       g.ub[k] = TMX_OSQP_INFTY * w.Eba[a];
     }
 }
@@ -676,7 +683,7 @@ TMX_DEVFN void admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, b
     h.sx[e] = 0.0;
   double xp = w.xp[v], zb = w.zbp[v], yb = w.ybp[v];
   const double lb = w.lbp[v], ub = w.ubp[v], qv = w.qp[v], bb = w.bbp[v];
-  const double rbp = rho_of_type(w.typ_bp[v], w.rho), rbpi = 1.0 / rbp;
+  const double rbp = rho_of_type(w.typ_bp[v], w.rho), rbpi = rcp_rho_of_type(w.typ_bp[v], w.rho);
   const double sigma = w.sigma, alpha = w.alpha, om = 1.0 - alpha;
   int tb[TMX_NROW];
   bool has[TMX_NROW];
@@ -703,17 +710,7 @@ TMX_DEVFN void admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, b
   int epos[TMX_NROW];
 #pragma unroll
   for (int q = 0; q < TMX_NROW; ++q)
-  {
-    epos[q] = 0;
-    if (has[q])
-    {
-      const int r = rowi[q], t = w.slot_t[r];
-      int k = 0;
-      for (int u = w.wp_start[t]; u < w.wp_start[t + 1]; ++u)
-        k = (w.wp_list[u] == r) ? (u - w.wp_start[t]) : k;
-      epos[q] = pst(t) + k;
-    }
-  }
+    epos[q] = has[q] ? w.row_epos[rowi[q]] : 0;
   // column v of A restricted to the rows of its waypoint, kept in registers (first 16 rows; a longer list falls back
   // to a loop for the remainder)
   double cj[16];

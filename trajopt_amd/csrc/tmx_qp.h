@@ -152,6 +152,7 @@ struct QpWs
   int *act, *aoff, *naux, *slot_t, *typ_r, *typ_bp, *typ_ba, *flg_r, *flg_bp, *flg_ba, *row_ref, *aux_ref;
   int *wp_start, *wp_list;  // LDS copies of DevProblem::wp_start / wp_list (hot in every SpMV)
   int *wp_pst;               // T+1: even-aligned start of every waypoint's group in the grouped e exchange (fast path)
+  int *row_epos;             // R: position of every row in that grouped buffer
 };
 
 // The workspace is split by access frequency:
@@ -231,7 +232,7 @@ TMX_HOSTDEVFN size_t qp_glb_doubles(int D, int T, int R, int NA)
 {
   const size_t NX = (size_t)D * T;
   const size_t n = 10 * NX + 6 * (size_t)R + (size_t)R * D + 8 * (size_t)NA;
-  const size_t ints = 6 * (size_t)R + (size_t)NX + (size_t)NA + 2 * (size_t)T + 4;
+  const size_t ints = 7 * (size_t)R + (size_t)NX + (size_t)NA + 2 * (size_t)T + 4;
   return n + (ints + 1) / 2 + 8;
 }
 // arrays that are only touched at burst boundaries / in the polish step: always in the per-problem HBM scratch
@@ -328,6 +329,7 @@ TMX_DEVFN void qp_ws_carve(QpWs& w, double* lds, double* glb, double* far, int D
   TAKEI(typ_ba, NA);
   TAKEI(wp_start, T + 1);
   TAKEI(wp_pst, T + 1);
+  TAKEI(row_epos, R);
   TAKEI(wp_list, R);
   // ---- far: always HBM (delta vectors of the last iteration, polish bookkeeping)
   p = far;

@@ -538,6 +538,8 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
       acc += c + (c & 1);
     }
     w.wp_pst[t] = acc;
+    for (int u = P->wp_start[t]; t < T && u < P->wp_start[t + 1]; ++u)
+      w.row_epos[P->wp_list[u]] = acc + (u - P->wp_start[t]);
   }
   w.sigma = st.sigma;
   w.alpha = st.alpha;
