@@ -786,10 +786,18 @@ TMX_DEVFN void compute_residuals(const QpWs& w, const DevProblem* P, const doubl
     }
   }
   m[11] = uq;
-  double m2[2] = { uaty, upx };
-  const bool sums2[2] = { false, false };
-  block_reduce<12>(m, sums, w.red, tid, NT);
-  block_reduce<2>(m2, sums2, w.red, tid, NT);
+  // one reduction for all 14 maxima (two separate ones cost two extra barrier pairs per residual evaluation)
+  double mall[14];
+  const bool sall[14] = { false, false, false, false, false, false, false, false, false, false, false, false, false, false };
+  for (int k = 0; k < 12; ++k)
+    mall[k] = m[k];
+  mall[12] = uaty;
+  mall[13] = upx;
+  block_reduce<14>(mall, sall, w.red, tid, NT);
+  for (int k = 0; k < 12; ++k)
+    m[k] = mall[k];
+  double m2[2] = { mall[12], mall[13] };
+  (void)sums;
   prim_res = m[0];
   dual_res = w.cinv * m[6];
   if (store_norms)
