@@ -778,6 +778,30 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
 #else
   const bool fast = false;
 #endif
+#if TMX_IS_DEVICE
+  if (fast)
+  {
+    // The delta vectors of the last ADMM iteration are written at the end of a burst and read by the termination test
+    // that follows it.  On the dense fast path the block factor Sinv is only live inside a factorisation (which comes
+    // after that test) and during the polish (whose own iterate sits in the G region), so the deltas ALIAS Sinv in LDS
+    // instead of living in the HBM scratch.
+    const size_t polish_tmp = (size_t)(2 * NX + R + 3 * P->NA) + (size_t)(R + NX + P->NA + 1) / 2 + 2;
+    const size_t deltas = 2 * (size_t)NX + (size_t)R + 2 * (size_t)P->NA;
+    if (polish_tmp <= (size_t)dpt.P * w.Gn * w.Gs && deltas <= (size_t)T * D * w.DS)
+    {
+      double* q = w.Sinv;
+      w.dxp = q;
+      q += NX;
+      w.dybp = q;
+      q += NX;
+      w.dyr = q;
+      q += R;
+      w.dxa = q;
+      q += P->NA;
+      w.dyba = q;
+    }
+  }
+#endif
   kkt_factor(w, P, 0, w.sigma, st.delta, tid, NT);
   kkt_invert(w, fast, tid, NT, pc, tlast);
   admm_cache_weights(w, tid, NT);
