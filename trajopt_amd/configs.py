@@ -8,7 +8,7 @@ counter-based Philox generator keyed by (config_id, problem index) so every cons
 import numpy as np
 
 from .problem import (BasicInfo, CartPoseTermInfo, CollisionTermInfo, JointPosTermInfo, JointVelTermInfo,
-                      ProblemConstructionInfo, pr2_right_arm, _tf12)
+                      ProblemConstructionInfo, Robot, pr2_right_arm, _tf12)
 
 
 def make_seeds(config_id: int, start, goal, n_steps: int, batch: int, lower, upper, sigma: float = 0.1,
@@ -82,3 +82,40 @@ def config1(n_steps: int = 30, with_collision: bool = True):
 def seeds_for(config_id: int, pci, start, goal, batch: int, sigma: float = 0.1, first: int = 0):
     rob = pci.robot
     return make_seeds(config_id, start, goal, pci.basic_info.n_steps, batch, rob.lower, rob.upper, sigma, first)
+
+
+# ---- shape-coverage problem (not a BASELINE config): 4-DOF arm, 14 waypoints ---------------------------------
+# Exercises other block sizes / paddings of the device QP solver than the 7-DOF configs (D = 4, P = 4 interiors of <= 3
+# blocks, 12x12 separator system) with every lowered term class: joint-velocity cost, collision hinge cost, a
+# position-only cart-pose constraint and a joint-position goal.
+MINI_START = np.array([-0.9, 0.5, 0.4, -0.3])
+MINI_GOAL = np.array([0.8, 0.3, 0.7, 0.2])
+
+
+def mini_arm() -> Robot:
+    rob = Robot(
+        joint_types=[0, 0, 0, 0],
+        origins=[_tf12(t=(0.0, 0.0, 0.3)), _tf12(t=(0.0, 0.0, 0.1)), _tf12(t=(0.35, 0.0, 0.0)), _tf12(t=(0.3, 0.0, 0.0))],
+        axes=[np.array([0.0, 0.0, 1.0]), np.array([0.0, 1.0, 0.0]), np.array([0.0, 1.0, 0.0]), np.array([0.0, 1.0, 0.0])],
+        lower=np.array([-2.5, -1.5, -2.0, -2.0]), upper=np.array([2.5, 1.5, 2.0, 2.0]),
+        tool=_tf12(t=(0.2, 0.0, 0.0)),
+    )
+    rob.link_spheres = [(1, (0.18, 0.0, 0.0), 0.07), (2, (0.15, 0.0, 0.0), 0.06), (3, (0.1, 0.0, 0.0), 0.05)]
+    return rob
+
+
+def config_mini(n_steps: int = 14):
+    rob = mini_arm()
+    D = rob.n_dof
+    pci = ProblemConstructionInfo(rob, BasicInfo(n_steps=n_steps, fixed_timesteps=[0]))
+    pci.cost_infos.append(JointVelTermInfo(coeffs=[1.0] * D, targets=[0.0] * D, first_step=0, last_step=n_steps - 1))
+    pci.cost_infos.append(CollisionTermInfo(first_step=0, last_step=n_steps - 1, dist_pen=0.03, coeff=20.0, safety_margin_buffer=0.3))
+    qmid = 0.5 * (MINI_START + MINI_GOAL)
+    pmid = rob.fk_tool(qmid)[:3, 3]
+    pci.obstacles.append(((float(pmid[0]) + 0.05, float(pmid[1]) + 0.02, float(pmid[2]) - 0.2), 0.1))
+    # tool must pass through a via point (position only) at the middle waypoint
+    via = _tf12(t=tuple(float(x) for x in (pmid + np.array([0.0, 0.0, 0.05]))))
+    pci.cnt_infos.append(CartPoseTermInfo(timestep=n_steps // 2, target_pose=via, pos_coeffs=(1, 1, 1), rot_coeffs=(0, 0, 0),
+                                          is_constraint=True))
+    pci.cnt_infos.append(JointPosTermInfo(coeffs=[1.0] * D, targets=list(MINI_GOAL), first_step=n_steps - 1, last_step=n_steps - 1))
+    return pci, MINI_START, MINI_GOAL
