@@ -88,7 +88,11 @@ typedef enum
   TMX_TERM_CART_POSE = 3,
   /* trajopt::CollisionTermInfo::hatch, DISCRETE / SINGLE_TIME_STEP cost path
    * trajopt/src/problem_description.cpp:1764-1774 -> CollisionCost trajopt/src/collision_terms.cpp:1250-1327   */
-  TMX_TERM_COLLISION_COST = 4
+  TMX_TERM_COLLISION_COST = 4,
+  /* trajopt::JointPosIneqConstraint  trajopt/src/trajectory_costs.cpp:185-255 — JointPosTermInfo (TT_CNT) with non-zero
+   * upper_tols / lower_tols (problem_description.cpp:1150-1165): per step and joint the two rows
+   * coeff*(x - target - upper_tol) <= 0 and coeff*(lower_tol - (x - target)) <= 0                              */
+  TMX_TERM_JOINT_POS_INEQ_CNT = 5
 } tmx_term_kind;
 
 typedef struct
@@ -103,6 +107,8 @@ typedef struct
   double margin;               /* collision: dist_pen (contact distance threshold)                    */
   double coeff;                /* collision: hinge coefficient                                        */
   double buffer;               /* collision: safety_margin_buffer added to the query threshold only   */
+  double upper_tols[TMX_MAX_DOF]; /* joint_pos inequality: per-DOF tolerances around the target        */
+  double lower_tols[TMX_MAX_DOF];
 } tmx_term;
 
 typedef struct

@@ -2,7 +2,7 @@
 // Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use anything in oracle/.
 //
 // CPU restatement of the trajopt term layer for the hot path (paths relative to /root/reference/):
-//   trajopt/src/trajectory_costs.cpp:139-183,257-301     JointPosEqConstraint, JointVelEqCost
+//   trajopt/src/trajectory_costs.cpp:139-183,185-255,257-301   JointPosEqConstraint, JointPosIneqConstraint, JointVelEqCost
 //   trajopt/src/kinematic_terms.cpp:187-366              CartPoseErrCalculator / CartPoseJacCalculator (FD, eps=1e-5)
 //   trajopt/src/collision_terms.cpp:203-250,343-383,540-556,655-691,1283-1327   single-timestep CollisionCost
 //   trajopt/src/problem_description.cpp:410-592,901-987,1764-1774               ConstructProblem / hatch order
@@ -372,6 +372,67 @@ private:
   AffExprVector expr_vec_;
 };
 
+// ---- trajopt::JointPosIneqConstraint  trajectory_costs.cpp:185-255 -----------------------------------------------
+// per step i and joint j two affine rows: (x - target - upper_tol)*coeff <= 0 and (lower_tol - (x - target))*coeff <= 0
+class JointPosIneqConstraint : public Constraint
+{
+public:
+  JointPosIneqConstraint(const VarArray& vars, DblVec coeffs, DblVec targets, DblVec upper, DblVec lower, int first_step, int last_step)
+    : vars_(vars)
+    , coeffs_(std::move(coeffs))
+    , targets_(std::move(targets))
+    , upper_tols_(std::move(upper))
+    , lower_tols_(std::move(lower))
+    , first_step_(first_step)
+    , last_step_(last_step)
+  {
+    name_ = "JointPosIneq";
+    for (int i = first_step_; i <= last_step_; ++i)
+      for (int j = 0; j < vars_.cols; ++j)
+      {
+        AffExpr pos;  // pos = x - targ                                        (:206-209)
+        exprInc(pos, exprMult(vars_(i, j), 1));
+        exprDec(pos, targets_[j]);
+        AffExpr expr;  // (pos - upper_tol) * coeff                             (:211-216)
+        exprInc(expr, pos);
+        exprDec(expr, upper_tols_[j]);
+        exprScale(expr, coeffs_[j]);
+        expr_vec_.push_back(expr);
+        AffExpr expr_neg;  // (lower_tol - pos) * coeff                         (:218-223)
+        exprInc(expr_neg, lower_tols_[j]);
+        exprDec(expr_neg, pos);
+        exprScale(expr_neg, coeffs_[j]);
+        expr_vec_.push_back(expr_neg);
+      }
+  }
+  ConstraintType type() override { return INEQ; }
+  DblVec value(const DblVec& x) override
+  {
+    // out << diff1, diff2 with diff1 / diff2 (steps x dof); toDblVec copies the column-major data  (:227-242)
+    DblVec out;
+    for (int j = 0; j < vars_.cols; ++j)
+      for (int i = first_step_; i <= last_step_; ++i)
+        out.push_back(((vars_(i, j).value(x) - targets_[j]) - upper_tols_[j]) * coeffs_[j]);
+    for (int j = 0; j < vars_.cols; ++j)
+      for (int i = first_step_; i <= last_step_; ++i)
+        out.push_back((((vars_(i, j).value(x) - targets_[j]) * -1) + lower_tols_[j]) * coeffs_[j]);
+    return out;
+  }
+  std::shared_ptr<ConvexConstraints> convex(const DblVec&, Model* model) override
+  {
+    auto out = std::make_shared<ConvexConstraints>(model);
+    for (const AffExpr& e : expr_vec_)
+      out->addIneqCnt(e);
+    return out;
+  }
+
+private:
+  VarArray vars_;
+  DblVec coeffs_, targets_, upper_tols_, lower_tols_;
+  int first_step_, last_step_;
+  AffExprVector expr_vec_;
+};
+
 // ---- CartPoseErrCalculator / CartPoseJacCalculator with a static target  kinematic_terms.cpp:250-263,348-366 ----
 struct CartPoseCalc
 {
@@ -557,7 +618,8 @@ inline TrajProblem constructProblem(const tmx_problem_desc& d, const double* ini
     for (int k = 0; k < d.n_terms; ++k)
     {
       const tmx_term& tm = d.terms[k];
-      const bool is_cnt = (tm.kind == TMX_TERM_JOINT_POS_EQ_CNT) || (tm.kind == TMX_TERM_CART_POSE && tm.is_constraint);
+      const bool is_cnt = (tm.kind == TMX_TERM_JOINT_POS_EQ_CNT) || (tm.kind == TMX_TERM_JOINT_POS_INEQ_CNT) ||
+                          (tm.kind == TMX_TERM_CART_POSE && tm.is_constraint);
       if ((pass == 0) == is_cnt)
         continue;
       switch (tm.kind)
@@ -569,6 +631,13 @@ inline TrajProblem constructProblem(const tmx_problem_desc& d, const double* ini
         case TMX_TERM_JOINT_POS_EQ_CNT:
           P.prob->addConstraint(std::make_shared<JointPosEqConstraint>(
               P.traj_vars, DblVec(tm.coeffs, tm.coeffs + D), DblVec(tm.targets, tm.targets + D), tm.first_step, tm.last_step));
+          break;
+        case TMX_TERM_JOINT_POS_INEQ_CNT:
+          // JointPosTermInfo::hatch with non-zero tolerances, TT_CNT  (problem_description.cpp:1150-1165); the OptProb sorts
+          // it behind all equality constraints (modeling.cpp:234-241)
+          P.prob->addConstraint(std::make_shared<JointPosIneqConstraint>(
+              P.traj_vars, DblVec(tm.coeffs, tm.coeffs + D), DblVec(tm.targets, tm.targets + D), DblVec(tm.upper_tols, tm.upper_tols + D),
+              DblVec(tm.lower_tols, tm.lower_tols + D), tm.first_step, tm.last_step));
           break;
         case TMX_TERM_CART_POSE:
         {

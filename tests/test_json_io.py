@@ -115,3 +115,24 @@ def test_init_info_types_and_target_offsets():
     pp = json_io.construct_problem(off, env)
     tp = np.asarray(pp.pci.cnt_infos[0].target_pose)
     assert np.allclose(tp[:, 3], [0.4, 0, 0.8]) and np.allclose(tp[:, :3], np.diag([-1.0, 1.0, -1.0]))
+
+
+def test_joint_pos_tolerances_lower_to_the_inequality_constraint():
+    """JointPosTermInfo::hatch (problem_description.cpp:1150-1165): zero tolerances -> JointPosEqConstraint, otherwise
+    JointPosIneqConstraint; tolerances below doubleEquals' 1e-5 count as zero"""
+    env, pci, start, goal = _env(0)
+    base = json.load(open(os.path.join(HERE, "golden", "json", "planning_unit_cfg0.json")))
+    band = copy.deepcopy(base)
+    band["constraints"].insert(0, {"type": "joint_pos", "name": "band", "params": {
+        "targets": [0.0] * 7, "upper_tols": [0.5] * 7, "lower_tols": [-0.5, -0.4, -0.3, -0.2, -0.1, -0.6, -0.7],
+        "coeffs": [2.0] * 7, "first_step": 3, "last_step": 5}})
+    d = json_io.construct_problem(band, env).pci.to_desc()
+    kinds = [d.terms[i].kind for i in range(d.n_terms)]
+    assert kinds == [abi.TERM_JOINT_VEL_COST, abi.TERM_JOINT_POS_INEQ_CNT, abi.TERM_JOINT_POS_EQ_CNT]
+    t = d.terms[1]
+    assert (t.first_step, t.last_step) == (3, 5) and list(t.upper_tols)[:7] == [0.5] * 7 and list(t.lower_tols)[:7][1] == -0.4
+    tiny = copy.deepcopy(band)
+    tiny["constraints"][0]["params"]["upper_tols"] = [1e-6] * 7
+    tiny["constraints"][0]["params"]["lower_tols"] = [-1e-6] * 7
+    d2 = json_io.construct_problem(tiny, env).pci.to_desc()
+    assert d2.terms[1].kind == abi.TERM_JOINT_POS_EQ_CNT

@@ -15,6 +15,7 @@ TERM_JOINT_VEL_COST = 1
 TERM_JOINT_POS_EQ_CNT = 2
 TERM_CART_POSE = 3
 TERM_COLLISION_COST = 4
+TERM_JOINT_POS_INEQ_CNT = 5
 
 # OSQP v1.0.0 status values
 OSQP_SOLVED, OSQP_SOLVED_INACCURATE = 1, 2
@@ -45,6 +46,8 @@ class Term(C.Structure):
         ("margin", C.c_double),
         ("coeff", C.c_double),
         ("buffer", C.c_double),
+        ("upper_tols", C.c_double * TMX_MAX_DOF),
+        ("lower_tols", C.c_double * TMX_MAX_DOF),
     ]
 
 

@@ -104,7 +104,7 @@ def mini_arm() -> Robot:
     return rob
 
 
-def config_mini(n_steps: int = 14):
+def config_mini(n_steps: int = 14, with_joint_band: bool = True):
     rob = mini_arm()
     D = rob.n_dof
     pci = ProblemConstructionInfo(rob, BasicInfo(n_steps=n_steps, fixed_timesteps=[0]))
@@ -117,5 +117,11 @@ def config_mini(n_steps: int = 14):
     via = _tf12(t=tuple(float(x) for x in (pmid + np.array([0.0, 0.0, 0.05]))))
     pci.cnt_infos.append(CartPoseTermInfo(timestep=n_steps // 2, target_pose=via, pos_coeffs=(1, 1, 1), rot_coeffs=(0, 0, 0),
                                           is_constraint=True))
+    if with_joint_band:
+        # JointPosIneqConstraint: keep the elbow joints inside a band around the straight-line mid value over the middle
+        # third of the trajectory (listed BEFORE the goal equality on purpose: the reference orders EQ before INEQ)
+        a, b = n_steps // 3, 2 * n_steps // 3
+        pci.cnt_infos.append(JointPosTermInfo(coeffs=[1.0, 2.0, 1.0, 0.5], targets=list(qmid), first_step=a, last_step=b,
+                                              upper_tols=[0.6, 0.25, 0.3, 0.8], lower_tols=[-0.6, -0.2, -0.35, -0.8], name="band"))
     pci.cnt_infos.append(JointPosTermInfo(coeffs=[1.0] * D, targets=list(MINI_GOAL), first_step=n_steps - 1, last_step=n_steps - 1))
     return pci, MINI_START, MINI_GOAL

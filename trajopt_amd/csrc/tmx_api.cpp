@@ -261,12 +261,16 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
   std::vector<int> vel_first, vel_last, vel_cost, cp_t, cp_owner, cp_iscnt, cp_nrows, cp_idx, cp_slot0;
   std::vector<double> vel_coeffs, vel_targets, cp_coeff, cp_target;
   int n_costs = 0, n_cnts = 0;
-  for (int pass = 0; pass < 2; ++pass)
+  // hatch order: all costs in list order, then the constraints; sco::OptProb keeps equality constraints in front of the
+  // inequality constraints (modeling.cpp:234-241), which fixes both the row / aux order and the constraint numbering
+  for (int pass = 0; pass < 3; ++pass)
     for (int k = 0; k < d->n_terms; ++k)
     {
       const tmx_term& tm = d->terms[k];
-      const bool is_cnt = (tm.kind == TMX_TERM_JOINT_POS_EQ_CNT) || (tm.kind == TMX_TERM_CART_POSE && tm.is_constraint);
-      if ((pass == 0) == is_cnt)
+      const bool is_ineq = tm.kind == TMX_TERM_JOINT_POS_INEQ_CNT;
+      const bool is_cnt = is_ineq || (tm.kind == TMX_TERM_JOINT_POS_EQ_CNT) || (tm.kind == TMX_TERM_CART_POSE && tm.is_constraint);
+      const int want = !is_cnt ? 0 : (is_ineq ? 2 : 1);
+      if (pass != want)
         continue;
       if (tm.first_step < 0 || tm.last_step >= T || tm.first_step > tm.last_step)
       {
@@ -318,6 +322,19 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
           for (int i = tm.first_step; i <= tm.last_step; ++i)
             for (int j = 0; j < D; ++j)
               add_slot(SLOT_JOINTPOS, i, j, 0, own, 2, 1, 1, 0.0, tm.coeffs[j], tm.targets[j], 0.0);
+          break;
+        }
+        case TMX_TERM_JOINT_POS_INEQ_CNT:
+        {
+          // JointPosIneqConstraint (trajectory_costs.cpp:185-225): per step and joint an upper and a lower row, each an
+          // inequality constraint -> hinge penalty (1 aux).  scale = coeff, aux1 = target, aux2 = tolerance
+          const int own = n_cnts++;
+          for (int i = tm.first_step; i <= tm.last_step; ++i)
+            for (int j = 0; j < D; ++j)
+            {
+              add_slot(SLOT_JOINTPOS_INEQ, i, j, 0, own, 1, 1, 0, 0.0, tm.coeffs[j], tm.targets[j], tm.upper_tols[j]);
+              add_slot(SLOT_JOINTPOS_INEQ, i, j, 1, own, 1, 1, 0, 0.0, tm.coeffs[j], tm.targets[j], tm.lower_tols[j]);
+            }
           break;
         }
         case TMX_TERM_CART_POSE:

@@ -229,6 +229,13 @@ TMX_DEVFN void evaluate_terms(const DevProblem* P, const double* xv, double* cos
         v = ((pv > 0) ? pv : 0.0) * P->slot_objc[r];
       }
     }
+    else if (kind == SLOT_JOINTPOS_INEQ)
+    {
+      // JointPosIneqConstraint::value (trajectory_costs.cpp:227-242) then IneqConstraint::violations = pospart
+      const double pos = xv[t * D + P->slot_sub[r]] - P->slot_aux1[r];
+      const double e = (P->slot_sub2[r] == 0) ? (pos - P->slot_aux2[r]) * P->slot_scale[r] : ((pos * -1) + P->slot_aux2[r]) * P->slot_scale[r];
+      v = (e > 0) ? e : 0.0;
+    }
     else if (kind == SLOT_JOINTPOS)
     {
       // quirk Q5: JointPosEqConstraint::value returns coeff * diff^2 (trajectory_costs.cpp:165-174)
@@ -312,12 +319,28 @@ TMX_DEVFN void init_static_rows(const DevProblem* P, const double* x0, int* acti
   for (int r = tid; r < P->R; r += NT)
   {
     const int kind = P->slot_kind[r];
-    if (kind == SLOT_FIXED || kind == SLOT_JOINTPOS)
+    if (kind == SLOT_FIXED || kind == SLOT_JOINTPOS || kind == SLOT_JOINTPOS_INEQ)
     {
       for (int k = 0; k < D; ++k)
         coef[r * D + k] = 0.0;
       const int j = P->slot_sub[r];
-      if (kind == SLOT_FIXED)
+      if (kind == SLOT_JOINTPOS_INEQ)
+      {
+        // rows "aff <= 0" with aff built exactly as the reference does (trajectory_costs.cpp:206-223):
+        //   upper: ((1*x - target) - upper_tol) * coeff          lower: (lower_tol - (1*x - target)) * coeff
+        const double c = P->slot_scale[r], targ = P->slot_aux1[r], tol = P->slot_aux2[r];
+        if (P->slot_sub2[r] == 0)
+        {
+          coef[r * D + j] = 1.0 * c;
+          rhs[r] = -(((0.0 - targ) - tol) * c);
+        }
+        else
+        {
+          coef[r * D + j] = (0.0 + (1.0 * -1)) * c;   // exprDec(expr_neg, pos): pos scaled by -1 and added
+          rhs[r] = -((tol + ((0.0 - targ) * -1)) * c);
+        }
+      }
+      else if (kind == SLOT_FIXED)
       {
         // exprSub(AffExpr(var), init): x - init == 0
         coef[r * D + j] = 1.0;

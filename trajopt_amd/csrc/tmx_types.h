@@ -17,7 +17,8 @@ enum
   SLOT_FIXED = 0,     // problem_description.cpp:485-508  x_tj - init_tj == 0       (no aux)
   SLOT_CARTPOSE = 1,  // CartPose row (EQ constraint -> abs, or ABS cost)             (2 aux)
   SLOT_JOINTPOS = 2,  // JointPosEqConstraint row -> abs                              (2 aux)
-  SLOT_COLLISION = 3  // CollisionCost contact -> hinge                               (1 aux)
+  SLOT_COLLISION = 3, // CollisionCost contact -> hinge                               (1 aux)
+  SLOT_JOINTPOS_INEQ = 4  // JointPosIneqConstraint row (upper: sub2 = 0, lower: sub2 = 1) -> hinge   (1 aux)
 };
 
 enum

@@ -110,12 +110,15 @@ class JointVelTermInfo:
 
 @dataclass
 class JointPosTermInfo:
-    """trajopt::JointPosTermInfo (constraint form) — hatch -> JointPosEqConstraint, problem_description.cpp:1059-1176"""
+    """trajopt::JointPosTermInfo (constraint form), problem_description.cpp:1059-1176: hatch -> JointPosEqConstraint when
+    all tolerances are zero (doubleEquals, eps 1e-5), else JointPosIneqConstraint (trajectory_costs.cpp:185-255)"""
     coeffs: Sequence[float]
     targets: Sequence[float]
     first_step: int = 0
     last_step: int = -1
     name: str = "joint_pos"
+    upper_tols: Sequence[float] = ()
+    lower_tols: Sequence[float] = ()
 
 
 @dataclass
@@ -193,7 +196,14 @@ class ProblemConstructionInfo:
                 t.coeffs[:D] = co
                 t.targets[:D] = list(ti.targets)
             elif isinstance(ti, JointPosTermInfo):
-                t.kind = abi.TERM_JOINT_POS_EQ_CNT
+                up = list(ti.upper_tols) or [0.0] * D
+                lo = list(ti.lower_tols) or [0.0] * D
+                if len(up) != D or len(lo) != D:
+                    raise ValueError("JointPosTermInfo upper_tols / lower_tols have the wrong size")
+                zero = all(abs(x) < 1e-5 for x in up) and all(abs(x) < 1e-5 for x in lo)   # trajopt_common::doubleEquals
+                t.kind = abi.TERM_JOINT_POS_EQ_CNT if zero else abi.TERM_JOINT_POS_INEQ_CNT
+                t.upper_tols[:D] = up
+                t.lower_tols[:D] = lo
                 t.is_constraint = 1
                 t.first_step = ti.first_step
                 t.last_step = ti.last_step if ti.last_step >= 0 else T - 1
