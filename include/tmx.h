@@ -92,7 +92,13 @@ typedef enum
   /* trajopt::JointPosIneqConstraint  trajopt/src/trajectory_costs.cpp:185-255 — JointPosTermInfo (TT_CNT) with non-zero
    * upper_tols / lower_tols (problem_description.cpp:1150-1165): per step and joint the two rows
    * coeff*(x - target - upper_tol) <= 0 and coeff*(lower_tol - (x - target)) <= 0                              */
-  TMX_TERM_JOINT_POS_INEQ_CNT = 5
+  TMX_TERM_JOINT_POS_INEQ_CNT = 5,
+  /* trajopt::JointPosEqCost  trajopt/src/trajectory_costs.cpp:28-65 — JointPosTermInfo (TT_COST), zero tolerances:
+   * squared cost sum_ij coeff_j (x_ij - target_j)^2                                                              */
+  TMX_TERM_JOINT_POS_EQ_COST = 6,
+  /* trajopt::JointPosIneqCost  trajopt/src/trajectory_costs.cpp:67-137 — JointPosTermInfo (TT_COST), non-zero
+   * tolerances: the two rows of TMX_TERM_JOINT_POS_INEQ_CNT as hinge costs (addHinge(expr, 1))                   */
+  TMX_TERM_JOINT_POS_INEQ_COST = 7
 } tmx_term_kind;
 
 typedef struct

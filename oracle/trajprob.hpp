@@ -372,6 +372,114 @@ private:
   AffExprVector expr_vec_;
 };
 
+// ---- trajopt::JointPosEqCost  trajectory_costs.cpp:28-65 ----------------------------------------------------------
+class JointPosEqCost : public Cost
+{
+public:
+  JointPosEqCost(const VarArray& vars, DblVec coeffs, DblVec targets, int first_step, int last_step)
+    : vars_(vars), coeffs_(std::move(coeffs)), targets_(std::move(targets)), first_step_(first_step), last_step_(last_step)
+  {
+    name_ = "JointPosEq";
+    for (int i = first_step_; i <= last_step_; ++i)
+      for (int j = 0; j < vars_.cols; ++j)
+      {
+        AffExpr pos;
+        exprInc(pos, exprMult(vars_(i, j), 1));
+        exprDec(pos, targets_[j]);
+        exprInc(expr_, exprMult(exprSquare(pos), coeffs_[j]));
+      }
+  }
+  double value(const DblVec& x) override
+  {
+    // (diff.array().square().matrix() * coeffs.asDiagonal()).sum(): column-major reduction over the steps x dof block
+    double s = 0;
+    for (int j = 0; j < vars_.cols; ++j)
+      for (int i = first_step_; i <= last_step_; ++i)
+      {
+        const double d = vars_(i, j).value(x) - targets_[j];
+        s += (d * d) * coeffs_[j];
+      }
+    return s;
+  }
+  std::shared_ptr<ConvexObjective> convex(const DblVec&, Model* model) override
+  {
+    auto out = std::make_shared<ConvexObjective>(model);
+    out->addQuadExpr(expr_);
+    return out;
+  }
+
+private:
+  VarArray vars_;
+  DblVec coeffs_, targets_;
+  int first_step_, last_step_;
+  QuadExpr expr_;
+};
+
+// ---- trajopt::JointPosIneqCost  trajectory_costs.cpp:67-137 -------------------------------------------------------
+class JointPosIneqCost : public Cost
+{
+public:
+  JointPosIneqCost(const VarArray& vars, DblVec coeffs, DblVec targets, DblVec upper, DblVec lower, int first_step, int last_step)
+    : vars_(vars)
+    , coeffs_(std::move(coeffs))
+    , targets_(std::move(targets))
+    , upper_tols_(std::move(upper))
+    , lower_tols_(std::move(lower))
+    , first_step_(first_step)
+    , last_step_(last_step)
+  {
+    name_ = "JointPosIneq";
+    for (int i = first_step_; i <= last_step_; ++i)
+      for (int j = 0; j < vars_.cols; ++j)
+      {
+        AffExpr pos;
+        exprInc(pos, exprMult(vars_(i, j), 1));
+        exprDec(pos, targets_[j]);
+        AffExpr expr;
+        exprInc(expr, pos);
+        exprDec(expr, upper_tols_[j]);
+        exprScale(expr, coeffs_[j]);
+        expr_vec_.push_back(expr);
+        AffExpr expr_neg;
+        exprInc(expr_neg, lower_tols_[j]);
+        exprDec(expr_neg, pos);
+        exprScale(expr_neg, coeffs_[j]);
+        expr_vec_.push_back(expr_neg);
+      }
+  }
+  double value(const DblVec& x) override
+  {
+    // diff1.cwiseMax(0).sum() + diff2.cwiseMax(0).sum()   (:114-126), each a column-major reduction
+    double s1 = 0, s2 = 0;
+    for (int j = 0; j < vars_.cols; ++j)
+      for (int i = first_step_; i <= last_step_; ++i)
+      {
+        const double v = ((vars_(i, j).value(x) - targets_[j]) - upper_tols_[j]) * coeffs_[j];
+        s1 += (v > 0) ? v : 0.0;
+      }
+    for (int j = 0; j < vars_.cols; ++j)
+      for (int i = first_step_; i <= last_step_; ++i)
+      {
+        const double v = (((vars_(i, j).value(x) - targets_[j]) * -1) + lower_tols_[j]) * coeffs_[j];
+        s2 += (v > 0) ? v : 0.0;
+      }
+    return s1 + s2;
+  }
+  std::shared_ptr<ConvexObjective> convex(const DblVec&, Model* model) override
+  {
+    auto out = std::make_shared<ConvexObjective>(model);
+    for (const AffExpr& e : expr_vec_)
+      out->addHinge(e, 1);
+    return out;
+  }
+
+private:
+  VarArray vars_;
+  DblVec coeffs_, targets_, upper_tols_, lower_tols_;
+  int first_step_, last_step_;
+  AffExprVector expr_vec_;
+};
+
 // ---- trajopt::JointPosIneqConstraint  trajectory_costs.cpp:185-255 -----------------------------------------------
 // per step i and joint j two affine rows: (x - target - upper_tol)*coeff <= 0 and (lower_tol - (x - target))*coeff <= 0
 class JointPosIneqConstraint : public Constraint
@@ -631,6 +739,15 @@ inline TrajProblem constructProblem(const tmx_problem_desc& d, const double* ini
         case TMX_TERM_JOINT_POS_EQ_CNT:
           P.prob->addConstraint(std::make_shared<JointPosEqConstraint>(
               P.traj_vars, DblVec(tm.coeffs, tm.coeffs + D), DblVec(tm.targets, tm.targets + D), tm.first_step, tm.last_step));
+          break;
+        case TMX_TERM_JOINT_POS_EQ_COST:
+          P.prob->addCost(std::make_shared<JointPosEqCost>(P.traj_vars, DblVec(tm.coeffs, tm.coeffs + D),
+                                                           DblVec(tm.targets, tm.targets + D), tm.first_step, tm.last_step));
+          break;
+        case TMX_TERM_JOINT_POS_INEQ_COST:
+          P.prob->addCost(std::make_shared<JointPosIneqCost>(
+              P.traj_vars, DblVec(tm.coeffs, tm.coeffs + D), DblVec(tm.targets, tm.targets + D), DblVec(tm.upper_tols, tm.upper_tols + D),
+              DblVec(tm.lower_tols, tm.lower_tols + D), tm.first_step, tm.last_step));
           break;
         case TMX_TERM_JOINT_POS_INEQ_CNT:
           // JointPosTermInfo::hatch with non-zero tolerances, TT_CNT  (problem_description.cpp:1150-1165); the OptProb sorts

@@ -19,6 +19,8 @@ def emu(hostemu_lib):
 def _cfg(cid, T=None):
     if cid == 9:   # shape-coverage problem: 4-DOF, 14 waypoints (configs.config_mini)
         return configs.config_mini() if T is None else configs.config_mini(T)
+    if cid == 10:  # the same with JointPosEqCost + JointPosIneqCost terms
+        return configs.config_mini(with_pos_costs=True)
     if cid == 0:
         pci, s, g = configs.config0() if T is None else configs.config0(T)
     else:
@@ -26,7 +28,7 @@ def _cfg(cid, T=None):
     return pci, s, g
 
 
-@pytest.mark.parametrize("cid", [0, 1, 9])
+@pytest.mark.parametrize("cid", [0, 1, 9, 10])
 def test_evaluate_matches_oracle(emu, orc, cid):
     pci, s, g = _cfg(cid)
     x0 = configs.seeds_for(cid, pci, s, g, 3)
@@ -34,7 +36,7 @@ def test_evaluate_matches_oracle(emu, orc, cid):
     pc.check_evaluate(emu, orc, desc, x0, tol=1e-12)
 
 
-@pytest.mark.parametrize("cid", [0, 1, 9])
+@pytest.mark.parametrize("cid", [0, 1, 9, 10])
 def test_first_qp_csc_bit_exact(emu, orc, cid):
     pci, s, g = _cfg(cid)
     x0 = configs.seeds_for(cid, pci, s, g, 2)
@@ -43,7 +45,7 @@ def test_first_qp_csc_bit_exact(emu, orc, cid):
         pc.check_first_qp_structure(emu, orc, desc, x0, b, val_tol=1e-12)
 
 
-@pytest.mark.parametrize("cid", [0, 1, 9])
+@pytest.mark.parametrize("cid", [0, 1, 9, 10])
 def test_first_qp_solve_matches_oracle(emu, orc, cid):
     pci, s, g = _cfg(cid)
     x0 = configs.seeds_for(cid, pci, s, g, 2)
@@ -63,9 +65,10 @@ def test_full_sqp_config0_exact(emu, orc):
     assert np.abs(r["x"][:, 0, :] - s[None, :]).max() < 1e-6
 
 
-def test_full_sqp_mini_arm(emu, orc):
+@pytest.mark.parametrize("cid", [9, 10])
+def test_full_sqp_mini_arm(emu, orc, cid):
     """4-DOF / 14-waypoint shape-coverage problem: same status and counters, trajectories within 1e-5"""
-    pci, s, g = _cfg(9)
+    pci, s, g = _cfg(cid)
     x0 = configs.seeds_for(9, pci, s, g, 3, sigma=0.05)
     desc = pc.make_ctx_inputs(emu, pci, x0)
     r, o, same, dx = pc.check_full_sqp(emu, orc, desc, x0, exact=False)

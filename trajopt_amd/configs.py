@@ -104,7 +104,7 @@ def mini_arm() -> Robot:
     return rob
 
 
-def config_mini(n_steps: int = 14, with_joint_band: bool = True):
+def config_mini(n_steps: int = 14, with_joint_band: bool = True, with_pos_costs: bool = False):
     rob = mini_arm()
     D = rob.n_dof
     pci = ProblemConstructionInfo(rob, BasicInfo(n_steps=n_steps, fixed_timesteps=[0]))
@@ -117,6 +117,13 @@ def config_mini(n_steps: int = 14, with_joint_band: bool = True):
     via = _tf12(t=tuple(float(x) for x in (pmid + np.array([0.0, 0.0, 0.05]))))
     pci.cnt_infos.append(CartPoseTermInfo(timestep=n_steps // 2, target_pose=via, pos_coeffs=(1, 1, 1), rot_coeffs=(0, 0, 0),
                                           is_constraint=True))
+    if with_pos_costs:
+        # JointPosEqCost (pull towards the mid posture) and JointPosIneqCost (soft band) over parts of the trajectory
+        pci.cost_infos.append(JointPosTermInfo(coeffs=[0.3, 0.1, 0.2, 0.05], targets=list(qmid), first_step=2, last_step=n_steps - 3,
+                                               is_constraint=False, name="posture"))
+        pci.cost_infos.append(JointPosTermInfo(coeffs=[4.0, 3.0, 2.0, 1.0], targets=list(qmid), first_step=1, last_step=n_steps - 2,
+                                               upper_tols=[0.5, 0.15, 0.4, 0.6], lower_tols=[-0.5, -0.3, -0.2, -0.6],
+                                               is_constraint=False, name="soft_band"))
     if with_joint_band:
         # JointPosIneqConstraint: keep the elbow joints inside a band around the straight-line mid value over the middle
         # third of the trajectory (listed BEFORE the goal equality on purpose: the reference orders EQ before INEQ)

@@ -258,7 +258,7 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
       add_slot(SLOT_FIXED, t, j, 0, -1, 0, 0, 1, 0.0, 1.0, 0.0, 0.0);
   }
   std::vector<double> pd(P.NX, 0.0), po(P.NX, 0.0), pq(P.NX, 0.0);
-  std::vector<int> vel_first, vel_last, vel_cost, cp_t, cp_owner, cp_iscnt, cp_nrows, cp_idx, cp_slot0;
+  std::vector<int> vel_first, vel_last, vel_cost, vel_kind, cp_t, cp_owner, cp_iscnt, cp_nrows, cp_idx, cp_slot0;
   std::vector<double> vel_coeffs, vel_targets, cp_coeff, cp_target;
   int n_costs = 0, n_cnts = 0;
   // hatch order: all costs in list order, then the constraints; sco::OptProb keeps equality constraints in front of the
@@ -288,6 +288,7 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
           }
           vel_first.push_back(tm.first_step);
           vel_last.push_back(tm.last_step);
+          vel_kind.push_back(0);
           vel_cost.push_back(n_costs++);
           for (int j = 0; j < TMX_MAX_DOF; ++j)
           {
@@ -322,6 +323,47 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
           for (int i = tm.first_step; i <= tm.last_step; ++i)
             for (int j = 0; j < D; ++j)
               add_slot(SLOT_JOINTPOS, i, j, 0, own, 2, 1, 1, 0.0, tm.coeffs[j], tm.targets[j], 0.0);
+          break;
+        }
+        case TMX_TERM_JOINT_POS_EQ_COST:
+        {
+          // JointPosEqCost (trajectory_costs.cpp:28-65): squared cost on the joint positions; shares the device-side
+          // machinery of the velocity cost (vel_kind 1: the term is x_ij - target_j instead of a difference of steps)
+          vel_first.push_back(tm.first_step);
+          vel_last.push_back(tm.last_step);
+          vel_kind.push_back(1);
+          vel_cost.push_back(n_costs++);
+          for (int j = 0; j < TMX_MAX_DOF; ++j)
+          {
+            vel_coeffs.push_back(j < D ? tm.coeffs[j] : 0.0);
+            vel_targets.push_back(j < D ? tm.targets[j] : 0.0);
+          }
+          // exprSquare(pos) * coeff with pos = 1*x - target  ->  Hessian 2*c on the diagonal, linear term 2*(0 - target)*c
+          for (int i = tm.first_step; i <= tm.last_step; ++i)
+            for (int j = 0; j < D; ++j)
+            {
+              const double c = tm.coeffs[j];
+              const double a1 = 1.0, cst = 0.0 - tm.targets[j];
+              const double q11 = (a1 * a1) * c;
+              if (q11 != 0.0)
+                pd[i * D + j] += 2.0 * q11;
+              const double l1 = (2 * cst * a1) * c;
+              if (l1 != 0.0)
+                pq[i * D + j] += l1;
+            }
+          break;
+        }
+        case TMX_TERM_JOINT_POS_INEQ_COST:
+        {
+          // JointPosIneqCost (trajectory_costs.cpp:67-137): the rows of the inequality constraint as hinge costs with
+          // objective coefficient 1 (the per-joint coefficient already sits inside the affine expression)
+          const int own = n_costs++;
+          for (int i = tm.first_step; i <= tm.last_step; ++i)
+            for (int j = 0; j < D; ++j)
+            {
+              add_slot(SLOT_JOINTPOS_INEQ, i, j, 0, own, 1, 0, 0, 1.0, tm.coeffs[j], tm.targets[j], tm.upper_tols[j]);
+              add_slot(SLOT_JOINTPOS_INEQ, i, j, 1, own, 1, 0, 0, 1.0, tm.coeffs[j], tm.targets[j], tm.lower_tols[j]);
+            }
           break;
         }
         case TMX_TERM_JOINT_POS_INEQ_CNT:
@@ -467,6 +509,7 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
   UP(vel_first, vel_first);
   UP(vel_last, vel_last);
   UP(vel_cost, vel_cost);
+  UP(vel_kind, vel_kind);
   UP(vel_coeffs, vel_coeffs);
   UP(vel_targets, vel_targets);
   UP(cp_t, cp_t);

@@ -1272,18 +1272,19 @@ TMX_DEVFN void sqp_update_block(const DevProblem* P, const DevBatch* Bt, int b, 
     }
     for (int v = 0; v < P->n_vel; ++v)
     {
-      const int first = P->vel_first[v], len = P->vel_last[v] - first;
+      const int pk = P->vel_kind[v];  // 0: difference of consecutive steps (JointVelEqCost), 1: position (JointPosEqCost)
+      const int first = P->vel_first[v], len = P->vel_last[v] - first + pk;
       for (int e = tid; e < D * len; e += NT)
       {
         const int j = e / len, i = first + e % len;
-        const double d = (xq[(i + 1) * D + j] - xq[i * D + j]) - P->vel_targets[v * TMX_MAX_DOF + j];
+        const double d = (pk ? xq[i * D + j] : (xq[(i + 1) * D + j] - xq[i * D + j])) - P->vel_targets[v * TMX_MAX_DOF + j];
         vterm[(size_t)v * NX + e] = (d * d) * P->vel_coeffs[v * TMX_MAX_DOF + j];
       }
     }
     TMX_SYNC();
     for (int v = tid; v < P->n_vel; v += NT)
     {
-      const int cnt = D * (P->vel_last[v] - P->vel_first[v]);
+      const int cnt = D * (P->vel_last[v] - P->vel_first[v] + P->vel_kind[v]);
       double sacc = 0;
       for (int e = 0; e < cnt; ++e)
         sacc += vterm[(size_t)v * NX + e];

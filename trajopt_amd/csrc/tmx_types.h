@@ -52,7 +52,7 @@ struct DevProblem
   double *pd, *po, *pq;
   int *p_colptr;  // NX+1: column pointers of the (static) upper-triangular CSC pattern of P over the primary vars
   // JointVelEqCost terms (exact value)
-  int *vel_first, *vel_last, *vel_cost;
+  int *vel_first, *vel_last, *vel_cost, *vel_kind;  // vel_kind 0: JointVelEqCost, 1: JointPosEqCost (same machinery)
   double *vel_coeffs, *vel_targets;  // n_vel x TMX_MAX_DOF
   // cart-pose instances (term, timestep)
   int *cp_t, *cp_owner, *cp_iscnt, *cp_nrows, *cp_idx, *cp_slot0;

@@ -143,11 +143,10 @@ def construct_problem(text_or_dict, env: Environment) -> ParsedProblem:
                                     first_step=int(p.get("first_step", 0)), last_step=int(p.get("last_step", n_steps - 1)), name=name)
         if typ == "joint_pos":
             _only_members(p, ("coeffs", "first_step", "last_step", "targets", "lower_tols", "upper_tols"), typ)
-            if is_cost:
-                raise UnsupportedTerm("joint_pos as a cost is not lowered by the device path")
             return JointPosTermInfo(coeffs=_vec(p, "coeffs", D, [1.0] * D), targets=_vec(p, "targets", D),
                                     first_step=int(p.get("first_step", 0)), last_step=int(p.get("last_step", n_steps - 1)), name=name,
-                                    upper_tols=_vec(p, "upper_tols", D, [0.0] * D), lower_tols=_vec(p, "lower_tols", D, [0.0] * D))
+                                    upper_tols=_vec(p, "upper_tols", D, [0.0] * D), lower_tols=_vec(p, "lower_tols", D, [0.0] * D),
+                                    is_constraint=not is_cost)
         if typ == "cart_pose":
             src, tgt = str(p["source_frame"]), str(p["target_frame"])
             if src != env.tip_links.get(manip):

@@ -119,6 +119,7 @@ class JointPosTermInfo:
     name: str = "joint_pos"
     upper_tols: Sequence[float] = ()
     lower_tols: Sequence[float] = ()
+    is_constraint: bool = True        # TT_CNT (default) | TT_COST: JointPosEqCost / JointPosIneqCost (:1128-1149)
 
 
 @dataclass
@@ -201,10 +202,13 @@ class ProblemConstructionInfo:
                 if len(up) != D or len(lo) != D:
                     raise ValueError("JointPosTermInfo upper_tols / lower_tols have the wrong size")
                 zero = all(abs(x) < 1e-5 for x in up) and all(abs(x) < 1e-5 for x in lo)   # trajopt_common::doubleEquals
-                t.kind = abi.TERM_JOINT_POS_EQ_CNT if zero else abi.TERM_JOINT_POS_INEQ_CNT
+                if ti.is_constraint:
+                    t.kind = abi.TERM_JOINT_POS_EQ_CNT if zero else abi.TERM_JOINT_POS_INEQ_CNT
+                else:
+                    t.kind = abi.TERM_JOINT_POS_EQ_COST if zero else abi.TERM_JOINT_POS_INEQ_COST
                 t.upper_tols[:D] = up
                 t.lower_tols[:D] = lo
-                t.is_constraint = 1
+                t.is_constraint = 1 if ti.is_constraint else 0
                 t.first_step = ti.first_step
                 t.last_step = ti.last_step if ti.last_step >= 0 else T - 1
                 co = list(ti.coeffs) * D if len(ti.coeffs) == 1 else list(ti.coeffs)
