@@ -98,7 +98,11 @@ typedef enum
   TMX_TERM_JOINT_POS_EQ_COST = 6,
   /* trajopt::JointPosIneqCost  trajopt/src/trajectory_costs.cpp:67-137 — JointPosTermInfo (TT_COST), non-zero
    * tolerances: the two rows of TMX_TERM_JOINT_POS_INEQ_CNT as hinge costs (addHinge(expr, 1))                   */
-  TMX_TERM_JOINT_POS_INEQ_COST = 7
+  TMX_TERM_JOINT_POS_INEQ_COST = 7,
+  /* trajopt::CollisionTermInfo::hatch, TT_CNT, DISCRETE / SINGLE_TIME_STEP: one CollisionConstraint per non-fixed step
+   * (problem_description.cpp:1821-1835; collision_terms.cpp:1369-1420): per contact the inequality row
+   * (margin - dist_expr) * coeff <= 0, violation pospart(margin - dist) * coeff                                  */
+  TMX_TERM_COLLISION_CNT = 8
 } tmx_term_kind;
 
 typedef struct

@@ -682,6 +682,63 @@ private:
   double margin_, coeff_, buffer_;
 };
 
+// ---- trajopt::CollisionConstraint, SingleTimestepCollisionEvaluator  collision_terms.cpp:1335-1420 -------------------
+// "ALMOST EXACTLY COPIED FROM CollisionCost" upstream: same distance expressions, but every contact becomes the
+// inequality row (margin - dist_expr) * coeff <= 0 and the violation is pospart(margin - dist) * coeff
+class CollisionConstraintSingle : public Constraint
+{
+public:
+  CollisionConstraintSingle(std::shared_ptr<const Chain> chain, std::shared_ptr<const Scene> scene, VarVector vars, double margin,
+                            double coeff, double buffer, const std::string& name)
+    : chain_(std::move(chain)), scene_(std::move(scene)), vars_(std::move(vars)), margin_(margin), coeff_(coeff), buffer_(buffer)
+  {
+    name_ = name;
+  }
+  ConstraintType type() override { return INEQ; }
+  std::shared_ptr<ConvexConstraints> convex(const DblVec& x, Model* model) override
+  {
+    auto out = std::make_shared<ConvexConstraints>(model);
+    const DblVec q = getDblVec(x, vars_);
+    std::vector<Contact> cts;
+    calcContacts(*chain_, *scene_, q.data(), margin_, buffer_, cts);
+    const int D = chain_->n_dof;
+    DblVec J(3 * D);
+    for (const Contact& ct : cts)
+    {
+      chain_->jacobianPoint(q.data(), ct.link, ct.nearest_world, J.data());
+      DblVec grad(D);
+      for (int k = 0; k < D; ++k)
+        grad[k] = -1.0 * (ct.normal[0] * J[0 * D + k] + ct.normal[1] * J[1 * D + k] + ct.normal[2] * J[2 * D + k]);
+      AffExpr dist(0);
+      exprInc(dist, varDot(grad, vars_));
+      double gq = 0;
+      for (int k = 0; k < D; ++k)
+        gq += grad[k] * q[k];
+      exprInc(dist, -gq);
+      exprInc(dist, ct.distance);
+      const AffExpr viol = exprSub(AffExpr(margin_), dist);
+      out->addIneqCnt(exprMult(viol, coeff_));  // :1387-1391
+    }
+    return out;
+  }
+  DblVec value(const DblVec& x) override
+  {
+    const DblVec q = getDblVec(x, vars_);
+    std::vector<Contact> cts;
+    calcContacts(*chain_, *scene_, q.data(), margin_, buffer_, cts);
+    DblVec out;
+    for (const Contact& ct : cts)
+      out.push_back(pospart(margin_ - ct.distance) * coeff_);  // :1404-1417 (buffer not used for the error)
+    return out;
+  }
+
+private:
+  std::shared_ptr<const Chain> chain_;
+  std::shared_ptr<const Scene> scene_;
+  VarVector vars_;
+  double margin_, coeff_, buffer_;
+};
+
 // ---- trajopt::ConstructProblem  problem_description.cpp:410-592 ------------------------------------
 struct TrajProblem
 {
@@ -726,7 +783,7 @@ inline TrajProblem constructProblem(const tmx_problem_desc& d, const double* ini
     for (int k = 0; k < d.n_terms; ++k)
     {
       const tmx_term& tm = d.terms[k];
-      const bool is_cnt = (tm.kind == TMX_TERM_JOINT_POS_EQ_CNT) || (tm.kind == TMX_TERM_JOINT_POS_INEQ_CNT) ||
+      const bool is_cnt = (tm.kind == TMX_TERM_JOINT_POS_EQ_CNT) || (tm.kind == TMX_TERM_JOINT_POS_INEQ_CNT) || (tm.kind == TMX_TERM_COLLISION_CNT) ||
                           (tm.kind == TMX_TERM_CART_POSE && tm.is_constraint);
       if ((pass == 0) == is_cnt)
         continue;
@@ -785,6 +842,12 @@ inline TrajProblem constructProblem(const tmx_problem_desc& d, const double* ini
             if (std::find(fixed.begin(), fixed.end(), i) == fixed.end())
               P.prob->addCost(std::make_shared<CollisionCostSingle>(P.chain, P.scene, P.traj_vars.row(i), tm.margin,
                                                                     tm.coeff, tm.buffer, "collision_" + std::to_string(i)));
+          break;
+        case TMX_TERM_COLLISION_CNT:
+          for (int i = tm.first_step; i <= tm.last_step; ++i)
+            if (std::find(fixed.begin(), fixed.end(), i) == fixed.end())
+              P.prob->addConstraint(std::make_shared<CollisionConstraintSingle>(P.chain, P.scene, P.traj_vars.row(i), tm.margin, tm.coeff,
+                                                                                tm.buffer, "collision_" + std::to_string(i)));
           break;
         default:
           throw std::runtime_error("unknown term kind");

@@ -18,6 +18,7 @@ TERM_COLLISION_COST = 4
 TERM_JOINT_POS_INEQ_CNT = 5
 TERM_JOINT_POS_EQ_COST = 6
 TERM_JOINT_POS_INEQ_COST = 7
+TERM_COLLISION_CNT = 8
 
 # OSQP v1.0.0 status values
 OSQP_SOLVED, OSQP_SOLVED_INACCURATE = 1, 2

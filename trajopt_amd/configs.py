@@ -104,12 +104,15 @@ def mini_arm() -> Robot:
     return rob
 
 
-def config_mini(n_steps: int = 14, with_joint_band: bool = True, with_pos_costs: bool = False):
+def config_mini(n_steps: int = 14, with_joint_band: bool = True, with_pos_costs: bool = False, collision_cnt: bool = False):
     rob = mini_arm()
     D = rob.n_dof
     pci = ProblemConstructionInfo(rob, BasicInfo(n_steps=n_steps, fixed_timesteps=[0]))
     pci.cost_infos.append(JointVelTermInfo(coeffs=[1.0] * D, targets=[0.0] * D, first_step=0, last_step=n_steps - 1))
-    pci.cost_infos.append(CollisionTermInfo(first_step=0, last_step=n_steps - 1, dist_pen=0.03, coeff=20.0, safety_margin_buffer=0.3))
+    coll = CollisionTermInfo(first_step=0, last_step=n_steps - 1, dist_pen=0.03, coeff=20.0 if not collision_cnt else 3.0,
+                             safety_margin_buffer=0.3, is_constraint=collision_cnt)
+    if not collision_cnt:
+        pci.cost_infos.append(coll)
     qmid = 0.5 * (MINI_START + MINI_GOAL)
     pmid = rob.fk_tool(qmid)[:3, 3]
     pci.obstacles.append(((float(pmid[0]) + 0.05, float(pmid[1]) + 0.02, float(pmid[2]) - 0.2), 0.1))
@@ -124,6 +127,8 @@ def config_mini(n_steps: int = 14, with_joint_band: bool = True, with_pos_costs:
         pci.cost_infos.append(JointPosTermInfo(coeffs=[4.0, 3.0, 2.0, 1.0], targets=list(qmid), first_step=1, last_step=n_steps - 2,
                                                upper_tols=[0.5, 0.15, 0.4, 0.6], lower_tols=[-0.5, -0.3, -0.2, -0.6],
                                                is_constraint=False, name="soft_band"))
+    if collision_cnt:
+        pci.cnt_infos.append(coll)   # listed first among the constraints; still sorted behind the equalities
     if with_joint_band:
         # JointPosIneqConstraint: keep the elbow joints inside a band around the straight-line mid value over the middle
         # third of the trajectory (listed BEFORE the goal equality on purpose: the reference orders EQ before INEQ)

@@ -267,7 +267,7 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
     for (int k = 0; k < d->n_terms; ++k)
     {
       const tmx_term& tm = d->terms[k];
-      const bool is_ineq = tm.kind == TMX_TERM_JOINT_POS_INEQ_CNT;
+      const bool is_ineq = tm.kind == TMX_TERM_JOINT_POS_INEQ_CNT || tm.kind == TMX_TERM_COLLISION_CNT;
       const bool is_cnt = is_ineq || (tm.kind == TMX_TERM_JOINT_POS_EQ_CNT) || (tm.kind == TMX_TERM_CART_POSE && tm.is_constraint);
       const int want = !is_cnt ? 0 : (is_ineq ? 2 : 1);
       if (pass != want)
@@ -419,6 +419,21 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
             for (int s = 0; s < d->n_link_spheres; ++s)
               for (int o = 0; o < d->n_obstacles; ++o)
                 add_slot(SLOT_COLLISION, i, s, o, own, 1, 0, 0, tm.coeff, 1.0, tm.margin, tm.buffer);
+          }
+          break;
+        }
+        case TMX_TERM_COLLISION_CNT:
+        {
+          // CollisionConstraint per non-fixed step (problem_description.cpp:1821-1835): inequality rows, hinge penalty with
+          // the merit coefficient; the collision coefficient scales the row itself (slot_scale)
+          for (int i = tm.first_step; i <= tm.last_step; ++i)
+          {
+            if (std::find(fixed.begin(), fixed.end(), i) != fixed.end())
+              continue;
+            const int own = n_cnts++;
+            for (int s = 0; s < d->n_link_spheres; ++s)
+              for (int o = 0; o < d->n_obstacles; ++o)
+                add_slot(SLOT_COLLISION, i, s, o, own, 1, 1, 0, tm.coeff, tm.coeff, tm.margin, tm.buffer);
           }
           break;
         }

@@ -501,9 +501,20 @@ TMX_DEVFN void convexify_terms(const DevProblem* P, const double* xv, int* activ
     // dist_expr = grad.x + (-(grad.q) + dist) ; viol = margin - dist_expr ; row: viol - hinge <= 0
     const double c_dist = (0.0 + (-gq)) + dist;
     const double viol_const = margin - c_dist;
-    for (int k = 0; k < D; ++k)
-      coef[r * D + k] = -grad[k];
-    rhs[r] = -viol_const;
+    if (P->slot_iscnt[r])
+    {
+      // CollisionConstraint: exprMult(viol, coeff)  (collision_terms.cpp:1387-1391)
+      const double cc = P->slot_scale[r];
+      for (int k = 0; k < D; ++k)
+        coef[r * D + k] = (-grad[k]) * cc;
+      rhs[r] = -(viol_const * cc);
+    }
+    else
+    {
+      for (int k = 0; k < D; ++k)
+        coef[r * D + k] = -grad[k];
+      rhs[r] = -viol_const;
+    }
     active[r] = 1;
   }
   TMX_SYNC();

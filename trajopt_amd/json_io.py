@@ -163,8 +163,6 @@ def construct_problem(text_or_dict, env: Environment) -> ParsedProblem:
                                     pos_coeffs=tuple(_vec(p, "pos_coeffs", 3, (1, 1, 1))), rot_coeffs=tuple(_vec(p, "rot_coeffs", 3, (1, 1, 1))),
                                     is_constraint=not is_cost, name=name)
         if typ == "collision":
-            if not is_cost:
-                raise UnsupportedTerm("collision as a constraint is not lowered by the device path")
             ev = int(p.get("evaluator_type", 1))
             if ev != _EVAL_DISCRETE:
                 raise UnsupportedTerm(f"collision evaluator_type {ev}: only DISCRETE (1, single time step) is lowered; "
@@ -181,7 +179,7 @@ def construct_problem(text_or_dict, env: Environment) -> ParsedProblem:
             if buf < 0:
                 raise ValueError("collision: negative safety_margin_buffer")
             return CollisionTermInfo(first_step=first, last_step=last, dist_pen=float(p["dist_pen"]), coeff=float(p["coeffs"]),
-                                     safety_margin_buffer=buf, name=name)
+                                     safety_margin_buffer=buf, name=name, is_constraint=not is_cost)
         raise UnsupportedTerm(f"term type \"{typ}\" is not lowered by the device path")
 
     for it in v.get("costs", []):

@@ -143,6 +143,7 @@ class CollisionTermInfo:
     coeff: float = 20.0
     safety_margin_buffer: float = 0.5
     name: str = "collision"
+    is_constraint: bool = False       # TT_CNT: one CollisionConstraint per step (problem_description.cpp:1821-1835)
 
 
 @dataclass
@@ -221,7 +222,8 @@ class ProblemConstructionInfo:
                 t.coeffs[:6] = list(ti.pos_coeffs) + list(ti.rot_coeffs)
                 t.target_pose[:] = list(np.asarray(ti.target_pose).reshape(-1))
             elif isinstance(ti, CollisionTermInfo):
-                t.kind = abi.TERM_COLLISION_COST
+                t.kind = abi.TERM_COLLISION_CNT if ti.is_constraint else abi.TERM_COLLISION_COST
+                t.is_constraint = 1 if ti.is_constraint else 0
                 t.first_step = ti.first_step
                 t.last_step = ti.last_step if ti.last_step >= 0 else T - 1
                 t.margin, t.coeff, t.buffer = ti.dist_pen, ti.coeff, ti.safety_margin_buffer
