@@ -138,6 +138,9 @@ typedef struct
   int32_t n_terms;
   const int32_t* fixed_steps;
   const tmx_term* terms;           /* costs are hatched in list order, then constraints in list order   */
+  int32_t n_fixed_dofs;            /* BasicInfo::fixed_dofs  trajopt/src/problem_description.cpp:510-530: the joint keeps its */
+  int32_t pad_;                    /* initial value at every timestep that is not already a fixed timestep              */
+  const int32_t* fixed_dofs;
 } tmx_problem_desc;
 
 /* sco::BasicTrustRegionSQPParameters — trajopt_sco/include/trajopt_sco/optimizers.hpp:92-135 */

@@ -778,6 +778,17 @@ inline TrajProblem constructProblem(const tmx_problem_desc& d, const double* ini
   for (int t_idx : fixed)
     for (int j = 0; j < D; ++j)
       P.prob->addLinearConstraint(exprSub(AffExpr(P.traj_vars(t_idx, j)), init_traj[t_idx * D + j]), EQ);
+  // fixed dofs :510-530 — every timestep that is not already fixed
+  for (int q = 0; q < d.n_fixed_dofs; ++q)
+  {
+    const int dof = d.fixed_dofs[q];
+    for (int i = 0; i < T; ++i)
+    {
+      if (std::find(fixed.begin(), fixed.end(), i) != fixed.end())
+        continue;
+      P.prob->addLinearConstraint(exprSub(AffExpr(P.traj_vars(i, dof)), AffExpr(init_traj[i * D + dof])), EQ);
+    }
+  }
   // hatch costs then constraints :532-540
   for (int pass = 0; pass < 2; ++pass)
     for (int k = 0; k < d.n_terms; ++k)

@@ -71,6 +71,9 @@ class ProblemDesc(C.Structure):
         ("n_terms", C.c_int32),
         ("fixed_steps", C.POINTER(C.c_int32)),
         ("terms", C.POINTER(Term)),
+        ("n_fixed_dofs", C.c_int32),
+        ("pad_", C.c_int32),
+        ("fixed_dofs", C.POINTER(C.c_int32)),
     ]
 
 

@@ -104,10 +104,11 @@ def mini_arm() -> Robot:
     return rob
 
 
-def config_mini(n_steps: int = 14, with_joint_band: bool = True, with_pos_costs: bool = False, collision_cnt: bool = False):
+def config_mini(n_steps: int = 14, with_joint_band: bool = True, with_pos_costs: bool = False, collision_cnt: bool = False,
+                fixed_dofs=()):
     rob = mini_arm()
     D = rob.n_dof
-    pci = ProblemConstructionInfo(rob, BasicInfo(n_steps=n_steps, fixed_timesteps=[0]))
+    pci = ProblemConstructionInfo(rob, BasicInfo(n_steps=n_steps, fixed_timesteps=[0], fixed_dofs=list(fixed_dofs)))
     pci.cost_infos.append(JointVelTermInfo(coeffs=[1.0] * D, targets=[0.0] * D, first_step=0, last_step=n_steps - 1))
     coll = CollisionTermInfo(first_step=0, last_step=n_steps - 1, dist_pen=0.03, coeff=20.0 if not collision_cnt else 3.0,
                              safety_margin_buffer=0.3, is_constraint=collision_cnt)

@@ -257,6 +257,20 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
     for (int j = 0; j < D; ++j)
       add_slot(SLOT_FIXED, t, j, 0, -1, 0, 0, 1, 0.0, 1.0, 0.0, 0.0);
   }
+  // BasicInfo::fixed_dofs (problem_description.cpp:510-530): the joint keeps its initial value at every timestep that is not
+  // already a fixed timestep
+  for (int q = 0; q < d->n_fixed_dofs; ++q)
+  {
+    const int dof = d->fixed_dofs[q];
+    if (dof < 0 || dof >= D)
+    {
+      ctx->err = "DOF(aka Joint) indice is greater than the number of DOF available.";
+      return TMX_ERR_INVALID;
+    }
+    for (int i = 0; i < T; ++i)
+      if (std::find(fixed.begin(), fixed.end(), i) == fixed.end())
+        add_slot(SLOT_FIXED, i, dof, 0, -1, 0, 0, 1, 0.0, 1.0, 0.0, 0.0);
+  }
   std::vector<double> pd(P.NX, 0.0), po(P.NX, 0.0), pq(P.NX, 0.0);
   std::vector<int> vel_first, vel_last, vel_cost, vel_kind, cp_t, cp_owner, cp_iscnt, cp_nrows, cp_idx, cp_slot0;
   std::vector<double> vel_coeffs, vel_targets, cp_coeff, cp_target;

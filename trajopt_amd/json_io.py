@@ -104,8 +104,6 @@ def construct_problem(text_or_dict, env: Environment) -> ParsedProblem:
         raise ValueError(f"Manipulator does not exist: {manip}")
     rob = env.manipulators[manip]
     D = rob.n_dof
-    if bi.get("fixed_dofs"):
-        raise UnsupportedTerm("basic_info.fixed_dofs is not lowered by the device path")
     if bi.get("use_time", False):
         raise UnsupportedTerm("basic_info.use_time (time-parameterised terms) is not lowered by the device path")
     dt_lo, dt_hi = float(bi.get("dt_lower_lim", 1.0)), float(bi.get("dt_upper_lim", 1.0))
@@ -114,7 +112,8 @@ def construct_problem(text_or_dict, env: Environment) -> ParsedProblem:
     convex_solver = str(bi.get("convex_solver", "AUTO_SOLVER"))
     if convex_solver not in ("AUTO_SOLVER", "OSQP"):
         raise UnsupportedTerm(f"convex_solver {convex_solver}: the device QP solver restates the OSQP back-end only")
-    pci = ProblemConstructionInfo(rob, BasicInfo(n_steps=n_steps, fixed_timesteps=[int(t) for t in bi.get("fixed_timesteps", [])]))
+    pci = ProblemConstructionInfo(rob, BasicInfo(n_steps=n_steps, fixed_timesteps=[int(t) for t in bi.get("fixed_timesteps", [])],
+                                                   fixed_dofs=[int(t) for t in bi.get("fixed_dofs", [])]))
     pci.obstacles = list(env.obstacles)
 
     sp = abi.default_sqp_params()

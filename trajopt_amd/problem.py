@@ -151,6 +151,7 @@ class BasicInfo:
     """trajopt::BasicInfo — problem_description.hpp:111-160"""
     n_steps: int
     fixed_timesteps: List[int] = field(default_factory=list)
+    fixed_dofs: List[int] = field(default_factory=list)
 
 
 class ProblemConstructionInfo:
@@ -235,6 +236,8 @@ class ProblemConstructionInfo:
         d.link_spheres, d.obstacles = ls, ob
         d.n_fixed_steps, d.n_terms = len(self.basic_info.fixed_timesteps), len(terms)
         d.fixed_steps, d.terms = fixed, tarr
-        self._keep = [ls, ob, fixed, tarr]   # keep the pointed-to arrays alive
+        fdofs = (C.c_int32 * max(1, len(self.basic_info.fixed_dofs)))(*self.basic_info.fixed_dofs)
+        d.n_fixed_dofs, d.fixed_dofs = len(self.basic_info.fixed_dofs), fdofs
+        self._keep = [ls, ob, fixed, tarr, fdofs]   # keep the pointed-to arrays alive
         d._keep = self._keep
         return d
