@@ -23,6 +23,8 @@ def _cfg(cid, T=None):
         return configs.config_mini(with_pos_costs=True)
     if cid == 11:  # collision as a constraint (CollisionConstraint per step)
         return configs.config_mini(collision_cnt=True)
+    if cid == 13:  # 10-DOF chain: outside the dense fast path -> generic block-chain path of the kernels
+        return configs.config_wide()
     if cid == 12:  # BasicInfo::fixed_dofs: the wrist joint keeps its seed value at every step
         return configs.config_mini(with_joint_band=False, fixed_dofs=[3])
     if cid == 0:
@@ -32,7 +34,7 @@ def _cfg(cid, T=None):
     return pci, s, g
 
 
-@pytest.mark.parametrize("cid", [0, 1, 9, 10, 11, 12])
+@pytest.mark.parametrize("cid", [0, 1, 9, 10, 11, 12, 13])
 def test_evaluate_matches_oracle(emu, orc, cid):
     pci, s, g = _cfg(cid)
     x0 = configs.seeds_for(cid, pci, s, g, 3)
@@ -40,7 +42,7 @@ def test_evaluate_matches_oracle(emu, orc, cid):
     pc.check_evaluate(emu, orc, desc, x0, tol=1e-12)
 
 
-@pytest.mark.parametrize("cid", [0, 1, 9, 10, 11, 12])
+@pytest.mark.parametrize("cid", [0, 1, 9, 10, 11, 12, 13])
 def test_first_qp_csc_bit_exact(emu, orc, cid):
     pci, s, g = _cfg(cid)
     x0 = configs.seeds_for(cid, pci, s, g, 2)
@@ -49,7 +51,7 @@ def test_first_qp_csc_bit_exact(emu, orc, cid):
         pc.check_first_qp_structure(emu, orc, desc, x0, b, val_tol=1e-12)
 
 
-@pytest.mark.parametrize("cid", [0, 1, 9, 10, 11, 12])
+@pytest.mark.parametrize("cid", [0, 1, 9, 10, 11, 12, 13])
 def test_first_qp_solve_matches_oracle(emu, orc, cid):
     pci, s, g = _cfg(cid)
     x0 = configs.seeds_for(cid, pci, s, g, 2)
@@ -69,7 +71,7 @@ def test_full_sqp_config0_exact(emu, orc):
     assert np.abs(r["x"][:, 0, :] - s[None, :]).max() < 1e-6
 
 
-@pytest.mark.parametrize("cid", [9, 10, 11, 12])
+@pytest.mark.parametrize("cid", [9, 10, 11, 12, 13])
 def test_full_sqp_mini_arm(emu, orc, cid):
     """4-DOF / 14-waypoint shape-coverage problem: same status and counters, trajectories within 1e-5"""
     pci, s, g = _cfg(cid)

@@ -138,3 +138,31 @@ def config_mini(n_steps: int = 14, with_joint_band: bool = True, with_pos_costs:
                                               upper_tols=[0.6, 0.25, 0.3, 0.8], lower_tols=[-0.6, -0.2, -0.35, -0.8], name="band"))
     pci.cnt_infos.append(JointPosTermInfo(coeffs=[1.0] * D, targets=list(MINI_GOAL), first_step=n_steps - 1, last_step=n_steps - 1))
     return pci, MINI_START, MINI_GOAL
+
+
+# ---- generic-path coverage problem (not a BASELINE config): 10-DOF chain, 8 waypoints ------------------------------
+# n_dof > 8 is outside the dense fast path of the device QP solver, so this problem runs the generic
+# block-chain path of the kernels - the one the host emulation exercises - on the real GPU as well.
+WIDE_START = np.array([0.3, -0.4, 0.2, 0.5, -0.3, 0.4, -0.2, 0.3, 0.1, -0.2])
+WIDE_GOAL = np.array([-0.5, 0.3, -0.3, 0.2, 0.4, -0.5, 0.3, -0.2, 0.4, 0.3])
+
+
+def wide_arm() -> Robot:
+    ax = [(0, 0, 1), (0, 1, 0), (1, 0, 0), (0, 1, 0), (0, 0, 1), (0, 1, 0), (1, 0, 0), (0, 1, 0), (0, 0, 1), (0, 1, 0)]
+    off = [(0, 0, 0.2), (0, 0, 0.1), (0.15, 0, 0), (0.15, 0, 0), (0.1, 0, 0.05), (0.12, 0, 0), (0.1, 0, 0), (0.1, 0, 0), (0.08, 0, 0), (0.08, 0, 0)]
+    rob = Robot(joint_types=[0] * 10, origins=[_tf12(t=o) for o in off], axes=[np.array(a, dtype=np.float64) for a in ax],
+                lower=np.full(10, -2.0), upper=np.full(10, 2.0), tool=_tf12(t=(0.1, 0.0, 0.0)))
+    rob.link_spheres = [(3, (0.05, 0.0, 0.0), 0.05), (6, (0.05, 0.0, 0.0), 0.04), (9, (0.04, 0.0, 0.0), 0.04)]
+    return rob
+
+
+def config_wide(n_steps: int = 8):
+    rob = wide_arm()
+    D = rob.n_dof
+    pci = ProblemConstructionInfo(rob, BasicInfo(n_steps=n_steps, fixed_timesteps=[0]))
+    pci.cost_infos.append(JointVelTermInfo(coeffs=[1.0] * D, targets=[0.0] * D, first_step=0, last_step=n_steps - 1))
+    pci.cost_infos.append(CollisionTermInfo(first_step=0, last_step=n_steps - 1, dist_pen=0.03, coeff=20.0, safety_margin_buffer=0.3))
+    pmid = rob.fk_tool(0.5 * (WIDE_START + WIDE_GOAL))[:3, 3]
+    pci.obstacles.append(((float(pmid[0]) + 0.03, float(pmid[1]) - 0.02, float(pmid[2]) - 0.15), 0.08))
+    pci.cnt_infos.append(JointPosTermInfo(coeffs=[1.0] * D, targets=list(WIDE_GOAL), first_step=n_steps - 1, last_step=n_steps - 1))
+    return pci, WIDE_START, WIDE_GOAL
