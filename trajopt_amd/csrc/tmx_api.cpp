@@ -194,9 +194,9 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
     return TMX_ERR_INVALID;
   HIPCHK(hipSetDevice(ctx->device));
   const int D = d->n_dof, T = d->n_steps;
-  if (D < 1 || D > TMX_MAX_DOF || T < 2)
+  if (D < 1 || D > TMX_MAX_DOF || T < 1)
   {
-    ctx->err = "n_dof must be in [1, TMX_MAX_DOF] and n_steps >= 2";
+    ctx->err = "n_dof must be in [1, TMX_MAX_DOF] and n_steps >= 1";
     return TMX_ERR_INVALID;
   }
   free_pool(ctx->prob_allocs);
