@@ -119,6 +119,12 @@ typedef struct
   double buffer;               /* collision: safety_margin_buffer added to the query threshold only   */
   double upper_tols[TMX_MAX_DOF]; /* joint_pos inequality: per-DOF tolerances around the target        */
   double lower_tols[TMX_MAX_DOF];
+  /* collision: CollisionTermInfo::fixed_steps (trajopt/include/trajopt/problem_description.hpp:603) — steps in
+     [first_step, last_step] that get NO collision term (problem_description.cpp:1641-1649 validation, :1767 / :1827
+     skip).  Independent of tmx_problem_desc.fixed_steps, exactly as in the reference.  May be NULL when n == 0. */
+  int32_t n_fixed_steps;
+  int32_t pad_;
+  const int32_t* fixed_steps;
 } tmx_term;
 
 typedef struct

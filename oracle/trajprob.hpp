@@ -850,13 +850,13 @@ inline TrajProblem constructProblem(const tmx_problem_desc& d, const double* ini
         }
         case TMX_TERM_COLLISION_COST:
           for (int i = tm.first_step; i <= tm.last_step; ++i)
-            if (std::find(fixed.begin(), fixed.end(), i) == fixed.end())
+            if (std::find(tm.fixed_steps, tm.fixed_steps + tm.n_fixed_steps, i) == tm.fixed_steps + tm.n_fixed_steps)  // :1767, :1827
               P.prob->addCost(std::make_shared<CollisionCostSingle>(P.chain, P.scene, P.traj_vars.row(i), tm.margin,
                                                                     tm.coeff, tm.buffer, "collision_" + std::to_string(i)));
           break;
         case TMX_TERM_COLLISION_CNT:
           for (int i = tm.first_step; i <= tm.last_step; ++i)
-            if (std::find(fixed.begin(), fixed.end(), i) == fixed.end())
+            if (std::find(tm.fixed_steps, tm.fixed_steps + tm.n_fixed_steps, i) == tm.fixed_steps + tm.n_fixed_steps)  // :1767, :1827
               P.prob->addConstraint(std::make_shared<CollisionConstraintSingle>(P.chain, P.scene, P.traj_vars.row(i), tm.margin, tm.coeff,
                                                                                 tm.buffer, "collision_" + std::to_string(i)));
           break;

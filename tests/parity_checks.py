@@ -9,9 +9,30 @@ end-to-end trajectories are compared statistically, and the bit-exact / 1e-5 bar
 """
 import numpy as np
 
-from trajopt_amd import abi
+from trajopt_amd import abi, configs
 
 TOL_TRAJ = 1e-5      # rad — north_star tolerance for joint trajectories / QP primal solutions
+
+
+def cfg(cid, T=None):
+    """config id -> (pci, start, goal); shared by the CPU (host build) and GPU tiers so both run the same problems"""
+    if cid == 9:   # shape-coverage problem: 4-DOF, 14 waypoints (configs.config_mini)
+        return configs.config_mini() if T is None else configs.config_mini(T)
+    if cid == 10:  # the same with JointPosEqCost + JointPosIneqCost terms
+        return configs.config_mini(with_pos_costs=True)
+    if cid == 11:  # collision as a constraint (CollisionConstraint per step)
+        return configs.config_mini(collision_cnt=True)
+    if cid == 13:  # 10-DOF chain: outside the dense fast path -> generic block-chain path of the kernels
+        return configs.config_wide()
+    if cid == 14:  # CollisionTermInfo::fixed_steps independent of BasicInfo::fixed_timesteps: contacts AT the fixed
+        return configs.config_mini(collision_fixed_steps=(5,))   # waypoint 0 (constant rows), none at waypoint 5
+    if cid == 12:  # BasicInfo::fixed_dofs: the wrist joint keeps its seed value at every step
+        return configs.config_mini(with_joint_band=False, fixed_dofs=[3])
+    if cid == 0:
+        pci, s, g = configs.config0() if T is None else configs.config0(T)
+    else:
+        pci, s, g = configs.config1() if T is None else configs.config1(T)
+    return pci, s, g
 
 
 def make_ctx_inputs(ctx, pci, x0, sqp=None, osqp=None):

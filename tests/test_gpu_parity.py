@@ -16,12 +16,10 @@ def gpu(gpu_ctx_factory):
     ctx.close()
 
 
-def _cfg(cid, T=None):
-    f = configs.config0 if cid == 0 else configs.config1
-    return f() if T is None else f(T)
+_cfg = pc.cfg
 
 
-@pytest.mark.parametrize("cid", [0, 1, 9, 10, 11, 12, 13])
+@pytest.mark.parametrize("cid", [0, 1, 9, 10, 11, 12, 13, 14])
 def test_evaluate_matches_oracle(gpu, orc, cid):
     pci, s, g = _cfg(cid)
     x0 = configs.seeds_for(cid, pci, s, g, 4)
@@ -39,7 +37,7 @@ def test_first_qp_csc_integers_bit_exact(gpu, orc, cid):
         pc.check_first_qp_structure(gpu, orc, desc, x0, b, val_tol=1e-9, strict=(cid == 0))
 
 
-@pytest.mark.parametrize("cid", [0, 1, 9, 10, 11, 12, 13])
+@pytest.mark.parametrize("cid", [0, 1, 9, 10, 11, 12, 13, 14])
 def test_first_qp_solve_matches_oracle(gpu, orc, cid):
     pci, s, g = _cfg(cid)
     x0 = configs.seeds_for(cid, pci, s, g, 6)
@@ -60,7 +58,7 @@ def test_full_sqp_config0_exact(gpu, orc):
     assert np.abs(r["x"][:, 0, :] - s[None, :]).max() < 1e-6
 
 
-@pytest.mark.parametrize("cid", [9, 10, 11, 12, 13])
+@pytest.mark.parametrize("cid", [9, 10, 11, 12, 13, 14])
 def test_full_sqp_mini_arm(gpu, orc, cid):
     """4-DOF / 14-waypoint shape-coverage problem (other block size, partition and paddings of the dense KKT solve)"""
     pci, s, g = _cfg(cid)

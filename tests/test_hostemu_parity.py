@@ -16,25 +16,10 @@ def emu(hostemu_lib):
     ctx.close()
 
 
-def _cfg(cid, T=None):
-    if cid == 9:   # shape-coverage problem: 4-DOF, 14 waypoints (configs.config_mini)
-        return configs.config_mini() if T is None else configs.config_mini(T)
-    if cid == 10:  # the same with JointPosEqCost + JointPosIneqCost terms
-        return configs.config_mini(with_pos_costs=True)
-    if cid == 11:  # collision as a constraint (CollisionConstraint per step)
-        return configs.config_mini(collision_cnt=True)
-    if cid == 13:  # 10-DOF chain: outside the dense fast path -> generic block-chain path of the kernels
-        return configs.config_wide()
-    if cid == 12:  # BasicInfo::fixed_dofs: the wrist joint keeps its seed value at every step
-        return configs.config_mini(with_joint_band=False, fixed_dofs=[3])
-    if cid == 0:
-        pci, s, g = configs.config0() if T is None else configs.config0(T)
-    else:
-        pci, s, g = configs.config1() if T is None else configs.config1(T)
-    return pci, s, g
+_cfg = pc.cfg
 
 
-@pytest.mark.parametrize("cid", [0, 1, 9, 10, 11, 12, 13])
+@pytest.mark.parametrize("cid", [0, 1, 9, 10, 11, 12, 13, 14])
 def test_evaluate_matches_oracle(emu, orc, cid):
     pci, s, g = _cfg(cid)
     x0 = configs.seeds_for(cid, pci, s, g, 3)
@@ -42,7 +27,7 @@ def test_evaluate_matches_oracle(emu, orc, cid):
     pc.check_evaluate(emu, orc, desc, x0, tol=1e-12)
 
 
-@pytest.mark.parametrize("cid", [0, 1, 9, 10, 11, 12, 13])
+@pytest.mark.parametrize("cid", [0, 1, 9, 10, 11, 12, 13, 14])
 def test_first_qp_csc_bit_exact(emu, orc, cid):
     pci, s, g = _cfg(cid)
     x0 = configs.seeds_for(cid, pci, s, g, 2)
@@ -51,7 +36,7 @@ def test_first_qp_csc_bit_exact(emu, orc, cid):
         pc.check_first_qp_structure(emu, orc, desc, x0, b, val_tol=1e-12)
 
 
-@pytest.mark.parametrize("cid", [0, 1, 9, 10, 11, 12, 13])
+@pytest.mark.parametrize("cid", [0, 1, 9, 10, 11, 12, 13, 14])
 def test_first_qp_solve_matches_oracle(emu, orc, cid):
     pci, s, g = _cfg(cid)
     x0 = configs.seeds_for(cid, pci, s, g, 2)
@@ -71,7 +56,7 @@ def test_full_sqp_config0_exact(emu, orc):
     assert np.abs(r["x"][:, 0, :] - s[None, :]).max() < 1e-6
 
 
-@pytest.mark.parametrize("cid", [9, 10, 11, 12, 13])
+@pytest.mark.parametrize("cid", [9, 10, 11, 12, 13, 14])
 def test_full_sqp_mini_arm(emu, orc, cid):
     """4-DOF / 14-waypoint shape-coverage problem: same status and counters, trajectories within 1e-5"""
     pci, s, g = _cfg(cid)

@@ -26,7 +26,7 @@ def _terms(desc):
     for i in range(desc.n_terms):
         t = desc.terms[i]
         out.append((t.kind, t.is_constraint, t.first_step, t.last_step, tuple(t.coeffs), tuple(t.targets), tuple(t.target_pose),
-                    t.margin, t.coeff, t.buffer))
+                    t.margin, t.coeff, t.buffer, tuple(t.fixed_steps[k] for k in range(t.n_fixed_steps))))
     return out
 
 
@@ -136,3 +136,24 @@ def test_joint_pos_tolerances_lower_to_the_inequality_constraint():
     tiny["constraints"][0]["params"]["lower_tols"] = [-1e-6] * 7
     d2 = json_io.construct_problem(tiny, env).pci.to_desc()
     assert d2.terms[1].kind == abi.TERM_JOINT_POS_EQ_CNT
+
+
+def test_collision_fixed_steps_are_the_terms_own(orc):
+    """CollisionTermInfo::fixed_steps (problem_description.cpp:1641-1649, :1767): steps without a collision term are the
+    TERM's list, not BasicInfo::fixed_timesteps — without "fixed_steps" the fixed waypoint 0 keeps its (constant)
+    collision cost, which shows up as one more cost term; an out-of-range entry is an error"""
+    env, pci, start, goal = _env(1)
+    base = json.load(open(os.path.join(HERE, "golden", "json", "glass_upright_cfg1.json")))
+    coll = next(c for c in base["costs"] if c["type"] == "collision")
+    assert coll["params"]["fixed_steps"] == [0]
+    pp = json_io.construct_problem(base, env)
+    x = pp.init_traj
+    n_with = len(orc.evaluate(pp.pci.to_desc(), x, x)[0])
+    nofix = copy.deepcopy(base)
+    del next(c for c in nofix["costs"] if c["type"] == "collision")["params"]["fixed_steps"]
+    pp2 = json_io.construct_problem(nofix, env)
+    assert len(orc.evaluate(pp2.pci.to_desc(), x, x)[0]) == n_with + 1
+    bad = copy.deepcopy(base)
+    next(c for c in bad["costs"] if c["type"] == "collision")["params"]["first_step"] = 2
+    with pytest.raises(ValueError, match="Fixed step 0 is not between"):
+        json_io.construct_problem(bad, env)

@@ -1,19 +1,23 @@
 #!/usr/bin/env python3
-"""Extract the PR2 `right_arm` serial chain (torso_lift_link -> r_gripper_tool_frame) from the reference's
-URDF fixture into a small JSON data file.
+"""Extract a PR2 arm serial chain (`right_arm`: torso_lift_link -> r_gripper_tool_frame, or `left_arm`:
+torso_lift_link -> l_gripper_tool_frame) from the reference's URDF fixture into a small JSON data file.
+Usage: extract_pr2_chain.py [r|l] [out.json]
 
 Source (read-only, only available in the build container):
   /root/reference/trajopt_common/data/arm_around_table.urdf:1479-1866   (joint origins / axes / limits)
-  /root/reference/trajopt_common/data/pr2.srdf:15-17                   (group right_arm = chain torso_lift_link..r_gripper_tool_frame)
-Output: trajopt_amd/data/pr2_right_arm.json (numbers only — kinematic DATA, no reference code).
+  /root/reference/trajopt_common/data/pr2.srdf:12-17                   (groups left_arm / right_arm = chains from torso_lift_link)
+  /root/reference/trajopt_common/data/arm_around_table.urdf:121-125, 735-745  (base_footprint -> base_link -> torso_lift_link)
+Output: trajopt_amd/data/pr2_{right,left}_arm.json (numbers only — kinematic DATA, no reference code).
+`base_footprint_xyz` is the static frame base_footprint expressed in the chain base (torso_lift_joint at its default 0).
 Continuous joints have no URDF limits; they get +-2*pi here [NOT IN REFERENCE: tesseract's choice is not pinned].
 """
 import json, math, re, sys
 
 URDF = "/root/reference/trajopt_common/data/arm_around_table.urdf"
-BASE, TIP = "torso_lift_link", "r_gripper_tool_frame"
+BASE = "torso_lift_link"
 
-def main(out):
+def main(side, out):
+    TIP = side + "_gripper_tool_frame"
     s = open(URDF).read()
     J = {}
     for m in re.finditer(r'<joint name="([^"]+)" type="([^"]+)">(.*?)</joint>', s, re.S):
@@ -50,10 +54,17 @@ def main(out):
         joints.append(dict(name=j["name"], type=1 if j["type"] == "prismatic" else 0, origin_xyz=pend,
                            axis=j["axis"], lower=lo, upper=hi, child=j["child"]))
         pend = [0.0, 0.0, 0.0]
-    data = dict(source="arm_around_table.urdf (PR2), group right_arm", base_link=BASE, tip_link=TIP,
-                joints=joints, tool_xyz=pend)
+    # base_footprint in the chain base frame: walk torso_lift_link up to base_footprint (pure translations, prismatic at 0)
+    up, l = [0.0, 0.0, 0.0], BASE
+    while l != "base_footprint":
+        assert all(abs(v) < 1e-12 for v in J[l]["rpy"]) and J[l]["type"] in ("fixed", "prismatic")
+        up = [up[k] + J[l]["xyz"][k] for k in range(3)]; l = J[l]["parent"]
+    data = dict(source="arm_around_table.urdf (PR2), group %s_arm" % ("right" if side == "r" else "left"), base_link=BASE,
+                tip_link=TIP, joints=joints, tool_xyz=pend, base_footprint_xyz=[0.0 - v for v in up])
     json.dump(data, open(out, "w"), indent=1)
     print("wrote", out, "with", len(joints), "joints; tool offset", pend)
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "trajopt_amd/data/pr2_right_arm.json")
+    side = sys.argv[1] if len(sys.argv) > 1 else "r"
+    assert side in ("r", "l")
+    main(side, sys.argv[2] if len(sys.argv) > 2 else "trajopt_amd/data/pr2_%s_arm.json" % ("right" if side == "r" else "left"))

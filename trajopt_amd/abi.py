@@ -51,6 +51,9 @@ class Term(C.Structure):
         ("buffer", C.c_double),
         ("upper_tols", C.c_double * TMX_MAX_DOF),
         ("lower_tols", C.c_double * TMX_MAX_DOF),
+        ("n_fixed_steps", C.c_int32),
+        ("pad_", C.c_int32),
+        ("fixed_steps", C.POINTER(C.c_int32)),
     ]
 
 

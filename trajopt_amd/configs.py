@@ -66,7 +66,7 @@ def config1(n_steps: int = 30, with_collision: bool = True):
     pci.cost_infos.append(JointVelTermInfo(coeffs=[1.0] * D, targets=[0.0] * D, first_step=0, last_step=n_steps - 1))
     if with_collision:
         pci.cost_infos.append(CollisionTermInfo(first_step=0, last_step=n_steps - 1, dist_pen=0.025, coeff=20.0,
-                                                safety_margin_buffer=0.5))
+                                                safety_margin_buffer=0.5, fixed_steps=[0]))
         qmid = 0.5 * (CFG1_START + CFG1_GOAL)
         pmid = rob.fk_tool(qmid)[:3, 3]
         pci.obstacles.append(((float(pmid[0]) + 0.02, float(pmid[1]), float(pmid[2]) - 0.17), 0.15))
@@ -105,13 +105,13 @@ def mini_arm() -> Robot:
 
 
 def config_mini(n_steps: int = 14, with_joint_band: bool = True, with_pos_costs: bool = False, collision_cnt: bool = False,
-                fixed_dofs=()):
+                fixed_dofs=(), collision_fixed_steps=(0,)):
     rob = mini_arm()
     D = rob.n_dof
     pci = ProblemConstructionInfo(rob, BasicInfo(n_steps=n_steps, fixed_timesteps=[0], fixed_dofs=list(fixed_dofs)))
     pci.cost_infos.append(JointVelTermInfo(coeffs=[1.0] * D, targets=[0.0] * D, first_step=0, last_step=n_steps - 1))
     coll = CollisionTermInfo(first_step=0, last_step=n_steps - 1, dist_pen=0.03, coeff=20.0 if not collision_cnt else 3.0,
-                             safety_margin_buffer=0.3, is_constraint=collision_cnt)
+                             safety_margin_buffer=0.3, is_constraint=collision_cnt, fixed_steps=list(collision_fixed_steps))
     if not collision_cnt:
         pci.cost_infos.append(coll)
     qmid = 0.5 * (MINI_START + MINI_GOAL)
@@ -161,7 +161,8 @@ def config_wide(n_steps: int = 8):
     D = rob.n_dof
     pci = ProblemConstructionInfo(rob, BasicInfo(n_steps=n_steps, fixed_timesteps=[0]))
     pci.cost_infos.append(JointVelTermInfo(coeffs=[1.0] * D, targets=[0.0] * D, first_step=0, last_step=n_steps - 1))
-    pci.cost_infos.append(CollisionTermInfo(first_step=0, last_step=n_steps - 1, dist_pen=0.03, coeff=20.0, safety_margin_buffer=0.3))
+    pci.cost_infos.append(CollisionTermInfo(first_step=0, last_step=n_steps - 1, dist_pen=0.03, coeff=20.0, safety_margin_buffer=0.3,
+                                            fixed_steps=[0]))
     pmid = rob.fk_tool(0.5 * (WIDE_START + WIDE_GOAL))[:3, 3]
     pci.obstacles.append(((float(pmid[0]) + 0.03, float(pmid[1]) - 0.02, float(pmid[2]) - 0.15), 0.08))
     pci.cnt_infos.append(JointPosTermInfo(coeffs=[1.0] * D, targets=list(WIDE_GOAL), first_step=n_steps - 1, last_step=n_steps - 1))

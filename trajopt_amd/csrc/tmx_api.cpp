@@ -291,6 +291,18 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
         ctx->err = "term step range invalid";
         return TMX_ERR_INVALID;
       }
+      if (tm.n_fixed_steps < 0 || (tm.n_fixed_steps > 0 && tm.fixed_steps == nullptr) ||
+          (tm.n_fixed_steps > 0 && tm.kind != TMX_TERM_COLLISION_COST && tm.kind != TMX_TERM_COLLISION_CNT))
+      {
+        ctx->err = "tmx_term.fixed_steps: only collision terms carry fixed steps";
+        return TMX_ERR_INVALID;
+      }
+      for (int q = 0; q < tm.n_fixed_steps; ++q)
+        if (tm.fixed_steps[q] < tm.first_step || tm.fixed_steps[q] > tm.last_step)
+        {
+          ctx->err = "Fixed step is not between first step and last step";  // problem_description.cpp:1641-1649
+          return TMX_ERR_INVALID;
+        }
       switch (tm.kind)
       {
         case TMX_TERM_JOINT_VEL_COST:
@@ -427,8 +439,8 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
         {
           for (int i = tm.first_step; i <= tm.last_step; ++i)
           {
-            if (std::find(fixed.begin(), fixed.end(), i) != fixed.end())
-              continue;  // problem_description.cpp:1767
+            if (std::find(tm.fixed_steps, tm.fixed_steps + tm.n_fixed_steps, i) != tm.fixed_steps + tm.n_fixed_steps)
+              continue;  // the term's own fixed_steps, problem_description.cpp:1767
             const int own = n_costs++;
             for (int s = 0; s < d->n_link_spheres; ++s)
               for (int o = 0; o < d->n_obstacles; ++o)
@@ -442,8 +454,8 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
           // the merit coefficient; the collision coefficient scales the row itself (slot_scale)
           for (int i = tm.first_step; i <= tm.last_step; ++i)
           {
-            if (std::find(fixed.begin(), fixed.end(), i) != fixed.end())
-              continue;
+            if (std::find(tm.fixed_steps, tm.fixed_steps + tm.n_fixed_steps, i) != tm.fixed_steps + tm.n_fixed_steps)
+              continue;  // :1827
             const int own = n_cnts++;
             for (int s = 0; s < d->n_link_spheres; ++s)
               for (int o = 0; o < d->n_obstacles; ++o)

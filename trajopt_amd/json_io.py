@@ -171,14 +171,15 @@ def construct_problem(text_or_dict, env: Environment) -> ParsedProblem:
             first, last = int(p.get("first_step", 0)), int(p.get("last_step", n_steps - 1))
             if not (0 <= first < n_steps and first <= last < n_steps):
                 raise ValueError("collision: invalid first_step / last_step")
-            for fs in p.get("fixed_steps", []):
+            fixed_steps = [int(fs) for fs in p.get("fixed_steps", [])]
+            for fs in fixed_steps:
                 if fs < first or fs > last:
                     raise ValueError(f"Fixed step {fs} is not between first step {first} and last step {last}")
             buf = float(p.get("safety_margin_buffer", 0.5))
             if buf < 0:
                 raise ValueError("collision: negative safety_margin_buffer")
             return CollisionTermInfo(first_step=first, last_step=last, dist_pen=float(p["dist_pen"]), coeff=float(p["coeffs"]),
-                                     safety_margin_buffer=buf, name=name, is_constraint=not is_cost)
+                                     safety_margin_buffer=buf, name=name, is_constraint=not is_cost, fixed_steps=fixed_steps)
         raise UnsupportedTerm(f"term type \"{typ}\" is not lowered by the device path")
 
     for it in v.get("costs", []):

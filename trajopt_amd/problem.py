@@ -72,14 +72,10 @@ class Robot:
         return self.fk_links(q)[-1] @ np.vstack([self.tool, [0, 0, 0, 1]])
 
 
-def pr2_right_arm() -> Robot:
-    """PR2 right arm (7 DOF) — the only 7-DOF model in the reference
-    (trajopt_common/data/arm_around_table.urdf:1479-1866, extracted by tools/extract_pr2_chain.py).
-    Collision geometry: 8 spheres hand-placed along upper arm / forearm / gripper (synthetic, stands in for the
-    convex meshes tesseract would load)."""
-    d = json.load(open(os.path.join(_DATA, "pr2_right_arm.json")))
+def _pr2_chain(fname: str) -> Robot:
+    d = json.load(open(os.path.join(_DATA, fname)))
     js = d["joints"]
-    rob = Robot(
+    return Robot(
         joint_types=[j["type"] for j in js],
         origins=[_tf12(t=j["origin_xyz"]) for j in js],
         axes=[np.array(j["axis"], dtype=np.float64) for j in js],
@@ -87,6 +83,29 @@ def pr2_right_arm() -> Robot:
         upper=np.array([j["upper"] for j in js], dtype=np.float64),
         tool=_tf12(t=d["tool_xyz"]),
     )
+
+
+def pr2_base_footprint() -> np.ndarray:
+    """static frame `base_footprint` expressed in the arm chains' base (torso_lift_link, torso_lift_joint at 0) —
+    arm_around_table.urdf:121-125, 735-745 via tools/extract_pr2_chain.py; 3x4 [R|t]"""
+    d = json.load(open(os.path.join(_DATA, "pr2_right_arm.json")))
+    return np.hstack([np.eye(3), np.array(d["base_footprint_xyz"], dtype=np.float64).reshape(3, 1)])
+
+
+def pr2_left_arm() -> Robot:
+    """PR2 left arm (7 DOF; pr2.srdf:12-14 group left_arm), the manipulator of trajopt/test/numerical_ik_unit.cpp.
+    No collision spheres (the numerical-IK problem has no collision term)."""
+    rob = _pr2_chain("pr2_left_arm.json")
+    rob.link_spheres = []
+    return rob
+
+
+def pr2_right_arm() -> Robot:
+    """PR2 right arm (7 DOF) — the only 7-DOF model in the reference
+    (trajopt_common/data/arm_around_table.urdf:1479-1866, extracted by tools/extract_pr2_chain.py).
+    Collision geometry: 8 spheres hand-placed along upper arm / forearm / gripper (synthetic, stands in for the
+    convex meshes tesseract would load)."""
+    rob = _pr2_chain("pr2_right_arm.json")
     rob.link_spheres = [
         (2, (0.10, 0.0, 0.0), 0.09), (2, (0.25, 0.0, 0.0), 0.09),
         (3, (0.00, 0.0, 0.0), 0.08),
@@ -144,6 +163,8 @@ class CollisionTermInfo:
     safety_margin_buffer: float = 0.5
     name: str = "collision"
     is_constraint: bool = False       # TT_CNT: one CollisionConstraint per step (problem_description.cpp:1821-1835)
+    fixed_steps: Sequence[int] = ()   # steps that get no collision term (:1641-1649, :1767, :1827); independent of
+                                      # BasicInfo.fixed_timesteps, as in the reference
 
 
 @dataclass
@@ -189,6 +210,7 @@ class ProblemConstructionInfo:
             ob[i].radius = r
         fixed = (C.c_int32 * max(1, len(self.basic_info.fixed_timesteps)))(*self.basic_info.fixed_timesteps)
         terms = []
+        keep_fixed = []
         for ti in list(self.cost_infos) + list(self.cnt_infos):
             t = abi.Term()
             if isinstance(ti, JointVelTermInfo):
@@ -228,6 +250,13 @@ class ProblemConstructionInfo:
                 t.first_step = ti.first_step
                 t.last_step = ti.last_step if ti.last_step >= 0 else T - 1
                 t.margin, t.coeff, t.buffer = ti.dist_pen, ti.coeff, ti.safety_margin_buffer
+                for fs in ti.fixed_steps:
+                    if fs < t.first_step or fs > t.last_step:
+                        raise ValueError(f"Fixed step {fs} is not between first step {t.first_step} and last step {t.last_step}")
+                if len(ti.fixed_steps):
+                    fa = (C.c_int32 * len(ti.fixed_steps))(*[int(v) for v in ti.fixed_steps])
+                    keep_fixed.append(fa)
+                    t.n_fixed_steps, t.fixed_steps = len(ti.fixed_steps), fa
             else:
                 raise TypeError(f"term {type(ti).__name__} is not lowered by the device path (explicit, not silent)")
             terms.append(t)
@@ -238,6 +267,6 @@ class ProblemConstructionInfo:
         d.fixed_steps, d.terms = fixed, tarr
         fdofs = (C.c_int32 * max(1, len(self.basic_info.fixed_dofs)))(*self.basic_info.fixed_dofs)
         d.n_fixed_dofs, d.fixed_dofs = len(self.basic_info.fixed_dofs), fdofs
-        self._keep = [ls, ob, fixed, tarr, fdofs]   # keep the pointed-to arrays alive
+        self._keep = [ls, ob, fixed, tarr, fdofs, keep_fixed]   # keep the pointed-to arrays alive
         d._keep = self._keep
         return d
