@@ -1,0 +1,871 @@
+// tmx_trajopt.hpp — C++ host side above the C-ABI of libtrajopt_mi355x.so (include/tmx.h).
+//
+// Header-only mirror of the reference's caller-facing interface for the SQP hot path, so that a trajopt user finds
+// the same names, argument meaning and error behaviour (std::runtime_error where the reference PRINT_AND_THROWs):
+//
+//   tmx::trajopt::  TermType, BasicInfo, InitInfo, TermInfo, JointPosTermInfo, JointVelTermInfo, CartPoseTermInfo,
+//                   CollisionTermInfo, ProblemConstructionInfo, TrajOptProb, ConstructProblem
+//                     <- trajopt/include/trajopt/problem_description.hpp:29-66, 68-107, 123-160, 162-186, 199-230,
+//                        235-262, 352-392, 421-514, 597-617, 661-663 ; trajopt/src/problem_description.cpp:410-592
+//   tmx::sco::      OptStatus, BasicTrustRegionSQPParameters, OptResults, BasicTrustRegionSQPBatchedHip
+//                     <- trajopt_sco/include/trajopt_sco/optimizers.hpp:25-33, 40-59, 92-135, 137-218 ;
+//                        trajopt_sco/src/optimizers.cpp:120-136, 699-991
+//
+// What differs from the reference, on purpose:
+//   * tesseract is not a dependency: `JointGroup` / `Environment` below are plain-data stand-ins for the few things
+//     ConstructProblem and the TermInfo::hatch functions read from tesseract (chain description, joint limits, current
+//     state, static link frames, sphere collision geometry).  Inside the trajopt tree the adapter of INTEGRATION.md §1
+//     fills them from the real tesseract objects.
+//   * matrices are plain row-major arrays (`TrajArray`), no Eigen.
+//   * hatch() lowers a term to the flat `tmx_term` of the C-ABI instead of creating sco::Cost / sco::Constraint objects;
+//     a term (or option) the device path does not lower throws — there is NO CPU fallback behind this interface.
+//   * the optimizer runs a BATCH of seeds (one trajectory problem per workgroup); the single-seed calls of the reference
+//     (`initialize(DblVec)`, `x()`, `results()`) are the batch-of-one case and report the best seed otherwise.
+//   * JSON (`ProblemConstructionInfo::fromJson`) is handled by trajopt_amd/json_io.py in this repository (no JSON library
+//     in the C++ toolchain here); inside the trajopt tree the reference's own fromJson fills these structs.
+// This file contains no arithmetic of the hot path: everything numerical happens behind tmx_sqp_run().
+#ifndef TMX_TRAJOPT_HPP_
+#define TMX_TRAJOPT_HPP_
+
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <functional>
+#include <limits>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "tmx.h"
+
+namespace tmx
+{
+using DblVec = std::vector<double>;
+using IntVec = std::vector<int>;
+
+[[noreturn]] inline void printAndThrow(const std::string& msg) { throw std::runtime_error(msg); }  // macros.h:90-98
+
+/** row-major dense matrix: trajopt::TrajArray (trajopt/include/trajopt/typedefs.hpp) without Eigen */
+struct TrajArray
+{
+  int rows_{ 0 }, cols_{ 0 };
+  DblVec data;
+  TrajArray() = default;
+  TrajArray(int r, int c, double v = 0.0) : rows_(r), cols_(c), data(static_cast<std::size_t>(r) * static_cast<std::size_t>(c), v) {}
+  int rows() const { return rows_; }
+  int cols() const { return cols_; }
+  double& operator()(int r, int c) { return data[static_cast<std::size_t>(r) * static_cast<std::size_t>(cols_) + static_cast<std::size_t>(c)]; }
+  double operator()(int r, int c) const { return data[static_cast<std::size_t>(r) * static_cast<std::size_t>(cols_) + static_cast<std::size_t>(c)]; }
+};
+
+/** rigid transform, row-major 3x4 [R | t] (the layout of tmx_joint::origin / tmx_term::target_pose) */
+struct Transform
+{
+  std::array<double, 12> m{ { 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0 } };
+  static Transform Identity() { return Transform(); }
+  static Transform Translation(double x, double y, double z)
+  {
+    Transform t;
+    t.m[3] = x;
+    t.m[7] = y;
+    t.m[11] = z;
+    return t;
+  }
+  /** Eigen::Quaterniond(w,x,y,z) (normalised) + translation */
+  static Transform FromQuaternion(double w, double x, double y, double z, double tx = 0, double ty = 0, double tz = 0)
+  {
+    const double n = std::sqrt(w * w + x * x + y * y + z * z);
+    if (n == 0.0)
+      printAndThrow("zero quaternion");
+    w /= n, x /= n, y /= n, z /= n;
+    Transform t;
+    t.m = { { 1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w), tx,  //
+              2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w), ty,  //
+              2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y), tz } };
+    return t;
+  }
+  Transform operator*(const Transform& b) const
+  {
+    Transform o;
+    for (int r = 0; r < 3; ++r)
+    {
+      for (int c = 0; c < 3; ++c)
+        o.m[r * 4 + c] = m[r * 4 + 0] * b.m[0 + c] + m[r * 4 + 1] * b.m[4 + c] + m[r * 4 + 2] * b.m[8 + c];
+      o.m[r * 4 + 3] = m[r * 4 + 0] * b.m[3] + m[r * 4 + 1] * b.m[7] + m[r * 4 + 2] * b.m[11] + m[r * 4 + 3];
+    }
+    return o;
+  }
+  bool isIdentity(double eps = 1e-12) const
+  {
+    const Transform i;
+    for (std::size_t k = 0; k < 12; ++k)
+      if (std::fabs(m[k] - i.m[k]) > eps)
+        return false;
+    return true;
+  }
+};
+
+namespace trajopt
+{
+/** problem_description.hpp:29-66 */
+enum class TermType : char
+{
+  TT_INVALID = 0,
+  TT_COST = 0x1,
+  TT_CNT = 0x2,
+  TT_USE_TIME = 0x4
+};
+inline TermType operator|(TermType a, TermType b) { return static_cast<TermType>(static_cast<char>(a) | static_cast<char>(b)); }
+inline TermType operator&(TermType a, TermType b) { return static_cast<TermType>(static_cast<char>(a) & static_cast<char>(b)); }
+inline TermType operator~(TermType a) { return static_cast<TermType>(~static_cast<char>(a)); }
+
+/** stand-in for tesseract::kinematics::JointGroup: a serial chain with sphere collision geometry */
+struct JointGroup
+{
+  using ConstPtr = std::shared_ptr<const JointGroup>;
+  std::vector<std::string> joint_names;
+  std::vector<tmx_joint> joints;  // type, fixed parent->joint origin, axis
+  DblVec lower, upper;            // getLimits().joint_limits
+  Transform base;                 // world_T_base
+  Transform tool;                 // last link -> tip_link frame (tcp)
+  std::string tip_link;           // the link the tool frame is attached to
+  std::vector<tmx_link_sphere> link_spheres;
+  std::size_t numJoints() const { return joints.size(); }
+};
+
+/** stand-in for the parts of tesseract::environment::Environment the problem construction consults */
+struct Environment
+{
+  using ConstPtr = std::shared_ptr<const Environment>;
+  std::map<std::string, std::shared_ptr<const JointGroup>> manipulators;  // getJointGroup(manip)
+  std::map<std::string, DblVec> state;                                    // getState(): manip -> current joint values
+  std::map<std::string, Transform> link_frames;                           // static links: world_T_link
+  std::vector<tmx_obstacle_sphere> obstacles;                             // world collision geometry (spheres)
+  std::shared_ptr<const JointGroup> getJointGroup(const std::string& manip) const
+  {
+    auto it = manipulators.find(manip);
+    if (it == manipulators.end())
+      printAndThrow("Manipulator does not exist: " + manip);  // problem_description.cpp:292
+    return it->second;
+  }
+};
+
+/** problem_description.hpp:123-160 */
+struct BasicInfo
+{
+  int n_steps{ -1 };
+  std::string manip;
+  IntVec fixed_timesteps;
+  IntVec fixed_dofs;
+  bool use_time{ false };  // time-parameterised problems are not lowered: ConstructProblem throws when set
+  double dt_upper_lim{ 1.0 };
+  double dt_lower_lim{ 1.0 };
+};
+
+/** problem_description.hpp:162-186 */
+struct InitInfo
+{
+  enum Type : std::uint8_t
+  {
+    STATIONARY,
+    JOINT_INTERPOLATED,
+    GIVEN_TRAJ
+  };
+  Type type{ STATIONARY };
+  TrajArray data;
+  double dt{ 1.0 };
+};
+
+class TrajOptProb;
+
+/** problem_description.hpp:199-230 */
+struct TermInfo
+{
+  using Ptr = std::shared_ptr<TermInfo>;
+  std::string name;
+  TermType term_type{ TermType::TT_INVALID };
+  explicit TermInfo(TermType supported) : supported_term_types_(supported) {}
+  virtual ~TermInfo() = default;
+  TermType getSupportedTypes() const { return supported_term_types_; }
+  /** lowers the term into the problem's flat term table (the reference creates sco::Cost / sco::Constraint objects) */
+  virtual void hatch(TrajOptProb& prob) = 0;
+
+private:
+  TermType supported_term_types_;
+};
+
+}  // namespace trajopt
+
+namespace sco
+{
+/** optimizers.hpp:25-33 — same integer values as tmx_opt_status */
+enum class OptStatus : std::uint8_t
+{
+  OPT_CONVERGED = TMX_OPT_CONVERGED,
+  OPT_SCO_ITERATION_LIMIT = TMX_OPT_SCO_ITERATION_LIMIT,
+  OPT_PENALTY_ITERATION_LIMIT = TMX_OPT_PENALTY_ITERATION_LIMIT,
+  OPT_TIME_LIMIT = TMX_OPT_TIME_LIMIT,
+  OPT_FAILED = TMX_OPT_FAILED,
+  INVALID = TMX_OPT_INVALID
+};
+inline const char* statusToString(OptStatus s)  // optimizers.cpp:33-50
+{
+  static const char* const names[] = { "CONVERGED", "SCO_ITERATION_LIMIT", "PENALTY_ITERATION_LIMIT", "TIME_LIMIT", "FAILED", "INVALID" };
+  return names[std::min<std::size_t>(static_cast<std::size_t>(s), 5)];
+}
+
+/** optimizers.hpp:92-135 (same defaults).  max_time / log_results / num_threads have no meaning for a batched launch
+    and are not mirrored. */
+struct BasicTrustRegionSQPParameters
+{
+  double improve_ratio_threshold{ 0.25 };
+  double min_trust_box_size{ 1e-4 };
+  double min_approx_improve{ 1e-4 };
+  double min_approx_improve_frac{ std::numeric_limits<double>::lowest() };
+  double max_iter{ 50 };
+  double trust_shrink_ratio{ 0.1 };
+  double trust_expand_ratio{ 1.5 };
+  double cnt_tolerance{ 1e-4 };
+  double max_merit_coeff_increases{ 5 };
+  int max_qp_solver_failures{ 3 };
+  double merit_coeff_increase_ratio{ 10 };
+  double initial_merit_error_coeff{ 10 };
+  bool inflate_constraints_individually{ true };
+  double trust_box_size{ 1e-1 };
+
+  tmx_sqp_params toTmx() const
+  {
+    tmx_sqp_params p{};
+    p.improve_ratio_threshold = improve_ratio_threshold;
+    p.min_trust_box_size = min_trust_box_size;
+    p.min_approx_improve = min_approx_improve;
+    p.min_approx_improve_frac = min_approx_improve_frac;
+    p.max_iter = static_cast<int32_t>(max_iter);
+    p.max_qp_solver_failures = max_qp_solver_failures;
+    p.trust_shrink_ratio = trust_shrink_ratio;
+    p.trust_expand_ratio = trust_expand_ratio;
+    p.cnt_tolerance = cnt_tolerance;
+    p.max_merit_coeff_increases = max_merit_coeff_increases;
+    p.merit_coeff_increase_ratio = merit_coeff_increase_ratio;
+    p.initial_merit_error_coeff = initial_merit_error_coeff;
+    p.inflate_constraints_individually = inflate_constraints_individually ? 1 : 0;
+    p.trust_box_size = trust_box_size;
+    return p;
+  }
+};
+
+/** optimizers.hpp:40-59 */
+struct OptResults
+{
+  DblVec x;
+  OptStatus status{ OptStatus::INVALID };
+  double total_cost{ 0 };
+  DblVec cost_vals;
+  DblVec cnt_viols;
+  int n_func_evals{ 0 };
+  int n_qp_solves{ 0 };
+  void clear()
+  {
+    x.clear();
+    status = OptStatus::INVALID;
+    cost_vals.clear();
+    cnt_viols.clear();
+    n_func_evals = 0;
+    n_qp_solves = 0;
+    total_cost = 0;
+  }
+};
+}  // namespace sco
+
+namespace trajopt
+{
+/** problem_description.hpp:235-262 */
+struct ProblemConstructionInfo
+{
+  BasicInfo basic_info;
+  sco::BasicTrustRegionSQPParameters opt_info;  // quirk Q6: unused by the reference's own ConstructProblem, same here
+  std::vector<TermInfo::Ptr> cost_infos;
+  std::vector<TermInfo::Ptr> cnt_infos;
+  InitInfo init_info;
+  std::shared_ptr<const Environment> env;
+  std::shared_ptr<const JointGroup> kin;
+
+  explicit ProblemConstructionInfo(std::shared_ptr<const Environment> env_) : env(std::move(env_)) {}
+  /** readBasicInfo's tail (problem_description.cpp:288-293): resolve `kin` from basic_info.manip */
+  void resolveKin() { kin = env->getJointGroup(basic_info.manip); }
+};
+
+/** problem_description.hpp:68-107: the hatched problem.  Holds the flat description the C-ABI consumes. */
+class TrajOptProb
+{
+public:
+  using Ptr = std::shared_ptr<TrajOptProb>;
+  TrajOptProb(int n_steps, const ProblemConstructionInfo& pci) : n_steps_(n_steps), kin_(pci.kin), env_(pci.env)
+  {
+    if (!kin_)
+      printAndThrow("ProblemConstructionInfo.kin is not set (call resolveKin())");
+    if (kin_->numJoints() > TMX_MAX_DOF)
+      printAndThrow("n_dof exceeds TMX_MAX_DOF");
+  }
+  int GetNumSteps() const { return n_steps_; }
+  int GetNumDOF() const { return static_cast<int>(kin_->numJoints()); }
+  bool GetHasTime() const { return false; }
+  std::shared_ptr<const JointGroup> GetKin() const { return kin_; }
+  std::shared_ptr<const Environment> GetEnv() const { return env_; }
+  const TrajArray& GetInitTraj() const { return init_traj_; }
+  void SetInitTraj(const TrajArray& t) { init_traj_ = t; }
+  std::size_t getNumCosts() const { return n_cost_terms_; }
+  std::size_t getNumConstraints() const { return terms_.size() - n_cost_terms_; }
+
+  /** used by TermInfo::hatch: costs are hatched before constraints (problem_description.cpp:560-571) */
+  void addTerm(const tmx_term& t, const IntVec& fixed_steps = {})
+  {
+    terms_.push_back(t);
+    term_fixed_.push_back(fixed_steps);
+    if (!t.is_constraint)
+    {
+      if (n_cost_terms_ + 1 != terms_.size())
+        printAndThrow("costs must be hatched before constraints");
+      ++n_cost_terms_;
+    }
+  }
+  void setFixed(const IntVec& steps, const IntVec& dofs)
+  {
+    fixed_steps_.assign(steps.begin(), steps.end());
+    fixed_dofs_.assign(dofs.begin(), dofs.end());
+  }
+
+  /** the flat description; pointers stay valid as long as this object lives and is not modified */
+  const tmx_problem_desc& desc()
+  {
+    tmx_problem_desc d{};
+    const int D = GetNumDOF();
+    d.n_dof = D;
+    d.n_steps = n_steps_;
+    for (int j = 0; j < D; ++j)
+    {
+      d.joint_lower[j] = kin_->lower[static_cast<std::size_t>(j)];
+      d.joint_upper[j] = kin_->upper[static_cast<std::size_t>(j)];
+      d.joints[j] = kin_->joints[static_cast<std::size_t>(j)];
+    }
+    std::copy(kin_->base.m.begin(), kin_->base.m.end(), d.base);
+    std::copy(kin_->tool.m.begin(), kin_->tool.m.end(), d.tool);
+    d.n_link_spheres = static_cast<int32_t>(kin_->link_spheres.size());
+    d.link_spheres = kin_->link_spheres.data();
+    d.n_obstacles = static_cast<int32_t>(env_ ? env_->obstacles.size() : 0);
+    d.obstacles = env_ ? env_->obstacles.data() : nullptr;
+    d.n_fixed_steps = static_cast<int32_t>(fixed_steps_.size());
+    d.fixed_steps = fixed_steps_.data();
+    d.n_fixed_dofs = static_cast<int32_t>(fixed_dofs_.size());
+    d.fixed_dofs = fixed_dofs_.data();
+    for (std::size_t k = 0; k < terms_.size(); ++k)
+    {
+      term_fixed32_.resize(terms_.size());
+      term_fixed32_[k].assign(term_fixed_[k].begin(), term_fixed_[k].end());
+      terms_[k].n_fixed_steps = static_cast<int32_t>(term_fixed32_[k].size());
+      terms_[k].fixed_steps = term_fixed32_[k].empty() ? nullptr : term_fixed32_[k].data();
+    }
+    d.n_terms = static_cast<int32_t>(terms_.size());
+    d.terms = terms_.data();
+    desc_ = d;
+    return desc_;
+  }
+
+private:
+  int n_steps_;
+  std::shared_ptr<const JointGroup> kin_;
+  std::shared_ptr<const Environment> env_;
+  TrajArray init_traj_;
+  std::vector<tmx_term> terms_;
+  std::vector<IntVec> term_fixed_;
+  std::vector<std::vector<int32_t>> term_fixed32_;
+  std::size_t n_cost_terms_{ 0 };
+  std::vector<int32_t> fixed_steps_, fixed_dofs_;
+  tmx_problem_desc desc_{};
+};
+
+namespace detail
+{
+/** checkParameterSize (problem_description.cpp:70-89): a single value is broadcast, anything else must match */
+inline void checkParameterSize(DblVec& parameter, std::size_t expected_size, const std::string& name, bool apply_first = true)
+{
+  if (apply_first && parameter.size() == 1)
+    parameter = DblVec(expected_size, parameter[0]);
+  else if (parameter.size() != expected_size)
+    printAndThrow("wrong number of " + name + ". expected " + std::to_string(expected_size) + " got " + std::to_string(parameter.size()));
+}
+inline bool doubleEquals(double a, double b, double eps = 1e-5) { return std::fabs(a - b) < eps; }  // trajopt_common/utils.hpp
+inline bool allZero(const DblVec& v)
+{
+  return std::all_of(v.begin(), v.end(), [](double x) { return doubleEquals(x, 0.); });
+}
+inline tmx_term blankTerm()
+{
+  tmx_term t{};
+  return t;
+}
+}  // namespace detail
+
+/** problem_description.hpp:421-469 ; hatch: problem_description.cpp:1073-1176 */
+struct JointPosTermInfo : public TermInfo
+{
+  DblVec coeffs;
+  DblVec targets;
+  DblVec upper_tols;
+  DblVec lower_tols;
+  int first_step = 0;
+  int last_step = -1;
+  JointPosTermInfo() : TermInfo(TermType::TT_COST | TermType::TT_CNT | TermType::TT_USE_TIME) {}
+  void hatch(TrajOptProb& prob) override
+  {
+    const std::size_t n_dof = prob.GetKin()->numJoints();
+    if (coeffs.empty())
+      coeffs = DblVec(n_dof, 1);
+    if (upper_tols.empty())
+      upper_tols = DblVec(n_dof, 0);
+    if (lower_tols.empty())
+      lower_tols = DblVec(n_dof, 0);
+    if (last_step <= -1)
+      last_step = prob.GetNumSteps() - 1;
+    // step range handling as problem_description.cpp:1092-1108: clamp to the last step, reversed ranges are swapped
+    if ((prob.GetNumSteps() - 1) <= first_step)
+      first_step = prob.GetNumSteps() - 1;
+    if ((prob.GetNumSteps() - 1) <= last_step)
+      last_step = prob.GetNumSteps() - 1;
+    if (last_step < first_step)
+      std::swap(first_step, last_step);
+    detail::checkParameterSize(coeffs, n_dof, "JointPosTermInfo coeffs");
+    detail::checkParameterSize(targets, n_dof, "JointPosTermInfo targets");
+    detail::checkParameterSize(upper_tols, n_dof, "JointPosTermInfo upper_tols");
+    detail::checkParameterSize(lower_tols, n_dof, "JointPosTermInfo lower_tols");
+    const bool zero = detail::allZero(upper_tols) && detail::allZero(lower_tols);
+    tmx_term t = detail::blankTerm();
+    t.first_step = first_step;
+    t.last_step = last_step;
+    for (std::size_t j = 0; j < n_dof; ++j)
+    {
+      t.coeffs[j] = coeffs[j];
+      t.targets[j] = targets[j];
+      t.upper_tols[j] = upper_tols[j];
+      t.lower_tols[j] = lower_tols[j];
+    }
+    if (static_cast<bool>(term_type & TermType::TT_COST))
+    {
+      t.kind = zero ? TMX_TERM_JOINT_POS_EQ_COST : TMX_TERM_JOINT_POS_INEQ_COST;  // :1128-1149
+      t.is_constraint = 0;
+    }
+    else if (static_cast<bool>(term_type & TermType::TT_CNT))
+    {
+      t.kind = zero ? TMX_TERM_JOINT_POS_EQ_CNT : TMX_TERM_JOINT_POS_INEQ_CNT;  // :1150-1171
+      t.is_constraint = 1;
+    }
+    else
+      return;  // "JointPosTermInfo does not have a valid term_type defined. No cost/constraint applied" (:1172-1175)
+    prob.addTerm(t);
+  }
+};
+
+/** problem_description.hpp:471-514 ; hatch: problem_description.cpp:1197-1372.  Lowered: the squared cost with zero
+    tolerances (JointVelEqCost).  Constraint form, hinge form and the time-parameterised forms throw. */
+struct JointVelTermInfo : public TermInfo
+{
+  DblVec coeffs;
+  DblVec targets;
+  DblVec upper_tols;
+  DblVec lower_tols;
+  int first_step = 0;
+  int last_step = -1;
+  JointVelTermInfo() : TermInfo(TermType::TT_COST | TermType::TT_CNT | TermType::TT_USE_TIME) {}
+  void hatch(TrajOptProb& prob) override
+  {
+    const std::size_t n_dof = prob.GetKin()->numJoints();
+    if (coeffs.empty())
+      coeffs = DblVec(n_dof, 1);
+    if (upper_tols.empty())
+      upper_tols = DblVec(n_dof, 0);
+    if (lower_tols.empty())
+      lower_tols = DblVec(n_dof, 0);
+    if (last_step <= -1)
+      last_step = prob.GetNumSteps() - 1;
+    if ((prob.GetNumSteps() - 2) <= first_step)  // :1212-1226
+      first_step = prob.GetNumSteps() - 2;
+    if ((prob.GetNumSteps() - 1) <= last_step)
+      last_step = prob.GetNumSteps() - 1;
+    if (last_step == first_step)
+      last_step += 1;
+    if (last_step < first_step)
+      std::swap(first_step, last_step);
+    detail::checkParameterSize(coeffs, n_dof, "JointVelTermInfo coeffs");
+    detail::checkParameterSize(targets, n_dof, "JointVelTermInfo targets");
+    detail::checkParameterSize(upper_tols, n_dof, "JointVelTermInfo upper_tols");
+    detail::checkParameterSize(lower_tols, n_dof, "JointVelTermInfo lower_tols");
+    if (first_step < 0)
+      printAndThrow("JointVelEqCost, trajectory is too short!");  // trajectory_costs.cpp:269-270
+    if (term_type != TermType::TT_COST)
+      printAndThrow("JointVelTermInfo: only the TT_COST form is lowered by the device path (constraint / use_time forms are not)");
+    if (!(detail::allZero(upper_tols) && detail::allZero(lower_tols)))
+      printAndThrow("JointVelTermInfo with tolerances (hinge form, JointVelIneqCost) is not lowered by the device path");
+    tmx_term t = detail::blankTerm();
+    t.kind = TMX_TERM_JOINT_VEL_COST;
+    t.first_step = first_step;
+    t.last_step = last_step;
+    for (std::size_t j = 0; j < n_dof; ++j)
+    {
+      t.coeffs[j] = coeffs[j];
+      t.targets[j] = targets[j];
+    }
+    prob.addTerm(t);
+  }
+};
+
+/** problem_description.hpp:352-392 ; hatch: problem_description.cpp:857-987.  Lowered: source = the manipulator's tip link
+    (active), target = a static link of the environment, no tolerances. */
+struct CartPoseTermInfo : public TermInfo
+{
+  int timestep{ 0 };
+  std::string source_frame;
+  std::string target_frame;
+  Transform source_frame_offset;
+  Transform target_frame_offset;
+  std::array<double, 3> pos_coeffs{ { 1, 1, 1 } };
+  std::array<double, 3> rot_coeffs{ { 1, 1, 1 } };
+  DblVec lower_tolerance;
+  DblVec upper_tolerance;
+  CartPoseTermInfo() : TermInfo(TermType::TT_COST | TermType::TT_CNT) {}
+  void hatch(TrajOptProb& prob) override
+  {
+    const auto kin = prob.GetKin();
+    const auto env = prob.GetEnv();
+    const bool src_active = (source_frame == kin->tip_link);
+    const bool tgt_static = env && env->link_frames.count(target_frame) != 0;
+    if (!src_active && !(env && env->link_frames.count(source_frame)))
+      printAndThrow("invalid source frame: " + source_frame);  // :869
+    if (!tgt_static && target_frame != kin->tip_link)
+      printAndThrow("invalid target frame: " + target_frame);  // :874
+    if (src_active && !tgt_static)
+      printAndThrow("source '" + source_frame + "' and target '" + target_frame + "' are both active");  // :881
+    if (!src_active && tgt_static)
+      printAndThrow("source '" + source_frame + "' and target '" + target_frame + "' are both static");  // :886
+    if (!detail::allZero(lower_tolerance) || !detail::allZero(upper_tolerance))
+      printAndThrow("CartPoseTermInfo tolerances are not lowered by the device path");
+    if (!source_frame_offset.isIdentity())
+      printAndThrow("CartPoseTermInfo source_frame_offset: fold it into JointGroup::tool (one tool frame per problem)");
+    if (timestep < 0 || timestep >= prob.GetNumSteps())
+      printAndThrow("CartPoseTermInfo timestep out of range");
+    tmx_term t = detail::blankTerm();
+    t.kind = TMX_TERM_CART_POSE;
+    t.first_step = t.last_step = timestep;
+    for (std::size_t k = 0; k < 3; ++k)
+    {
+      t.coeffs[k] = pos_coeffs[k];
+      t.coeffs[3 + k] = rot_coeffs[k];
+    }
+    const Transform target = env->link_frames.at(target_frame) * target_frame_offset;  // world_T_target * offset
+    std::copy(target.m.begin(), target.m.end(), t.target_pose);
+    if (static_cast<bool>(term_type & TermType::TT_COST))
+      t.is_constraint = 0;  // ABS cost (:946-960)
+    else if (static_cast<bool>(term_type & TermType::TT_CNT))
+      t.is_constraint = 1;  // EQ constraint (:961-976)
+    else
+      return;
+    prob.addTerm(t);
+  }
+};
+
+/** the members of trajopt_common::TrajOptCollisionConfig (trajopt_common/include/trajopt_common/collision_types.h:119-162)
+    that the single-timestep path reads */
+struct TrajOptCollisionConfig
+{
+  enum class CollisionEvaluatorType  // tesseract::collision::CollisionEvaluatorType
+  {
+    NONE = 0,
+    DISCRETE = 1,
+    LVS_DISCRETE = 2,
+    CONTINUOUS = 3,
+    LVS_CONTINUOUS = 4
+  };
+  bool enabled{ true };
+  double default_margin{ 0.0 };           // contact_manager_config.default_margin (JSON "dist_pen")
+  double default_collision_coeff{ 1.0 };  // collision_coeff_data default (JSON "coeffs")
+  double collision_margin_buffer{ 0.01 };
+  CollisionEvaluatorType type{ CollisionEvaluatorType::DISCRETE };  // collision_check_config.type
+  TrajOptCollisionConfig() = default;
+  TrajOptCollisionConfig(double margin, double coeff) : default_margin(margin), default_collision_coeff(coeff) {}
+};
+
+/** problem_description.hpp:597-617 ; hatch: problem_description.cpp:1716-1837.  Lowered: DISCRETE evaluator (one term per
+    non-fixed step: SINGLE_TIME_STEP expressions), cost and constraint form. */
+struct CollisionTermInfo : public TermInfo
+{
+  int first_step{ -1 }, last_step{ -1 };
+  std::vector<int> fixed_steps;
+  TrajOptCollisionConfig config;
+  CollisionTermInfo() : TermInfo(TermType::TT_COST | TermType::TT_CNT) {}
+  void hatch(TrajOptProb& prob) override
+  {
+    if (!config.enabled)
+      return;
+    if (config.type != TrajOptCollisionConfig::CollisionEvaluatorType::DISCRETE)
+      printAndThrow("CollisionTermInfo: only the DISCRETE evaluator (single time step) is lowered by the device path");
+    if (first_step < 0 || last_step < first_step || last_step >= prob.GetNumSteps())
+      printAndThrow("CollisionTermInfo: invalid first_step / last_step");
+    for (int fs : fixed_steps)
+      if (fs < first_step || fs > last_step)
+        printAndThrow("Fixed step " + std::to_string(fs) + " is not between first step " + std::to_string(first_step) + " and last step " +
+                      std::to_string(last_step));  // :1645
+    tmx_term t = detail::blankTerm();
+    t.first_step = first_step;
+    t.last_step = last_step;
+    t.margin = config.default_margin;
+    t.coeff = config.default_collision_coeff;
+    t.buffer = config.collision_margin_buffer;
+    if (static_cast<bool>(term_type & TermType::TT_COST))
+    {
+      t.kind = TMX_TERM_COLLISION_COST;
+      t.is_constraint = 0;
+    }
+    else
+    {
+      t.kind = TMX_TERM_COLLISION_CNT;
+      t.is_constraint = 1;
+    }
+    prob.addTerm(t, fixed_steps);
+  }
+};
+
+namespace detail
+{
+/** generateInitTraj, problem_description.cpp:310-366 */
+inline TrajArray generateInitTraj(const ProblemConstructionInfo& pci)
+{
+  const InitInfo& init_info = pci.init_info;
+  const int n_steps = pci.basic_info.n_steps;
+  const int D = static_cast<int>(pci.kin->numJoints());
+  auto current = [&]() {
+    auto it = pci.env->state.find(pci.basic_info.manip);
+    DblVec s = (it == pci.env->state.end()) ? DblVec(static_cast<std::size_t>(D), 0.0) : it->second;
+    if (static_cast<int>(s.size()) != D)
+      printAndThrow("environment state has the wrong number of joint values for " + pci.basic_info.manip);
+    return s;
+  };
+  TrajArray init;
+  if (init_info.type == InitInfo::STATIONARY)
+  {
+    const DblVec s = current();
+    init = TrajArray(n_steps, D);
+    for (int t = 0; t < n_steps; ++t)
+      for (int j = 0; j < D; ++j)
+        init(t, j) = s[static_cast<std::size_t>(j)];
+  }
+  else if (init_info.type == InitInfo::JOINT_INTERPOLATED)
+  {
+    const DblVec s = current();
+    const TrajArray& d = init_info.data;
+    if (!((d.rows() == 1 && d.cols() == D) || (d.rows() == D && d.cols() == 1)))
+      printAndThrow("JOINT_INTERPOLATED selected, but init_info.data is the wrong size. It should be 1 x pci.kin->numJoints()");
+    init = TrajArray(n_steps, D);
+    for (int j = 0; j < D; ++j)
+    {
+      // Eigen::VectorXd::LinSpaced(n_steps, start, end): start + i*step, the last entry exactly `end`
+      const double a = s[static_cast<std::size_t>(j)], b = d.data[static_cast<std::size_t>(j)];
+      const double step = n_steps > 1 ? (b - a) / (n_steps - 1) : 0.0;
+      for (int t = 0; t < n_steps; ++t)
+        init(t, j) = (t == n_steps - 1 && n_steps > 1) ? b : a + t * step;
+    }
+  }
+  else if (init_info.type == InitInfo::GIVEN_TRAJ)
+    init = init_info.data;
+  else
+    printAndThrow("Init Info did not have a valid type. Valid types are STATIONARY, JOINT_INTERPOLATED, or GIVEN_TRAJ");
+  return init;
+}
+}  // namespace detail
+
+/** ConstructProblem(const ProblemConstructionInfo&), problem_description.cpp:410-592 */
+inline TrajOptProb::Ptr ConstructProblem(const ProblemConstructionInfo& pci)
+{
+  const BasicInfo& bi = pci.basic_info;
+  const int n_steps = bi.n_steps;
+  if (!pci.env || !pci.kin)
+    printAndThrow("ProblemConstructionInfo needs env and kin");
+  if (n_steps < 1)
+    printAndThrow("basic_info.n_steps must be positive");
+  // term-type checks, :417-453
+  for (const TermInfo::Ptr& cost : pci.cost_infos)
+  {
+    if (!static_cast<bool>(cost->getSupportedTypes() & TermType::TT_COST))
+      printAndThrow(cost->name + " is only a constraint, but you listed it as a cost");
+    if (static_cast<bool>(cost->term_type & TermType::TT_USE_TIME))
+      printAndThrow(cost->name + ": time-parameterised terms (TT_USE_TIME) are not lowered by the device path");
+  }
+  for (const TermInfo::Ptr& cnt : pci.cnt_infos)
+  {
+    if (!static_cast<bool>(cnt->getSupportedTypes() & TermType::TT_CNT))
+      printAndThrow(cnt->name + " is only a cost, but you listed it as a constraint");
+    if (static_cast<bool>(cnt->term_type & TermType::TT_USE_TIME))
+      printAndThrow(cnt->name + ": time-parameterised terms (TT_USE_TIME) are not lowered by the device path");
+  }
+  if (bi.use_time)
+    printAndThrow("basic_info.use_time: time-parameterised problems are not lowered by the device path");
+
+  auto prob = std::make_shared<TrajOptProb>(n_steps, pci);
+  const int n_dof = prob->GetNumDOF();
+  const TrajArray init_traj = detail::generateInitTraj(pci);
+  if (init_traj.rows() != n_steps || init_traj.cols() != n_dof)  // :471-479
+    printAndThrow("Initial trajectory is not the right size matrix\nExpected " + std::to_string(n_steps) + " rows (time steps) x " +
+                  std::to_string(n_dof) + " columns\nGot " + std::to_string(init_traj.rows()) + " rows and " +
+                  std::to_string(init_traj.cols()) + " columns");
+  prob->SetInitTraj(init_traj);
+  for (const int t_idx : bi.fixed_timesteps)  // :485-508
+    if (t_idx < 0 || t_idx >= init_traj.rows())
+      printAndThrow("Fixed timestep index is outside the bounds of the initial trajectory.");
+  for (const int dof_ind : bi.fixed_dofs)  // :510-530
+    if (dof_ind < 0 || dof_ind >= n_dof)
+      printAndThrow("DOF(aka Joint) indice is greater than the number of DOF available.");
+  prob->setFixed(bi.fixed_timesteps, bi.fixed_dofs);
+  // costs first, then constraints (:560-571).  A TermInfo listed under cost_infos / cnt_infos is hatched as that kind,
+  // whatever its term_type says (the reference only warns, :420-421 / :434-435).
+  for (const TermInfo::Ptr& ci : pci.cost_infos)
+  {
+    ci->term_type = TermType::TT_COST;
+    ci->hatch(*prob);
+  }
+  for (const TermInfo::Ptr& ci : pci.cnt_infos)
+  {
+    ci->term_type = TermType::TT_CNT;
+    ci->hatch(*prob);
+  }
+  return prob;
+}
+}  // namespace trajopt
+
+namespace sco
+{
+/** Sibling of sco::BasicTrustRegionSQPMultiThreaded (optimizers.hpp:196-218): BasicTrustRegionSQP::optimize() for a batch
+    of seeds on one MI355X.  Throws if no device is available — there is no CPU path behind it. */
+class BasicTrustRegionSQPBatchedHip
+{
+public:
+  using Callback = std::function<void(trajopt::TrajOptProb*, OptResults&)>;  // optimizers.hpp:83-84
+
+  explicit BasicTrustRegionSQPBatchedHip(trajopt::TrajOptProb::Ptr prob, int device = 0) : prob_(std::move(prob))
+  {
+    if (!prob_)
+      printAndThrow("need to set the problem before initializing");
+    const tmx_status rc = tmx_create(device, &ctx_);
+    if (rc != TMX_OK || !ctx_)
+      printAndThrow("tmx_create failed: no MI355X device available (libtrajopt_mi355x has no CPU fallback)");
+    tmx_default_osqp_settings(&osqp_);
+  }
+  ~BasicTrustRegionSQPBatchedHip()
+  {
+    if (ctx_)
+      tmx_destroy(ctx_);
+  }
+  BasicTrustRegionSQPBatchedHip(const BasicTrustRegionSQPBatchedHip&) = delete;
+  BasicTrustRegionSQPBatchedHip& operator=(const BasicTrustRegionSQPBatchedHip&) = delete;
+
+  void setParameters(const BasicTrustRegionSQPParameters& param) { param_ = param; }
+  const BasicTrustRegionSQPParameters& getParameters() const { return param_; }
+  BasicTrustRegionSQPParameters& getParameters() { return param_; }
+  /** OSQPModelConfig::settings (osqp_interface.cpp:78-90 defaults) */
+  tmx_osqp_settings& getOSQPSettings() { return osqp_; }
+  void addCallback(const Callback& cb) { callbacks_.push_back(cb); }  // invoked once per optimize(), on the best seed
+
+  /** Optimizer::initialize (optimizers.cpp:127-136): one seed, x in j_t_d order (row-major n_steps x n_dof) */
+  void initialize(const DblVec& x) { initialize(std::vector<DblVec>{ x }); }
+  /** a batch of seeds */
+  void initialize(const std::vector<DblVec>& seeds)
+  {
+    const std::size_t nv = numVars();
+    if (seeds.empty())
+      printAndThrow("initialize: empty batch");
+    for (const DblVec& x : seeds)
+      if (x.size() != nv)
+        printAndThrow("initialization vector has wrong length. expected " + std::to_string(nv) + " got " + std::to_string(x.size()));
+    seeds_.clear();
+    seeds_.reserve(seeds.size() * nv);
+    for (const DblVec& x : seeds)
+      seeds_.insert(seeds_.end(), x.begin(), x.end());
+    batch_ = static_cast<int32_t>(seeds.size());
+    results_.clear();
+    results_.x = seeds[0];
+    batch_results_.clear();
+  }
+
+  /** BasicTrustRegionSQP::optimize() (optimizers.cpp:699-991) for every seed; returns the status of the best seed */
+  OptStatus optimize()
+  {
+    if (batch_ == 0)
+      printAndThrow("must initialize before optimizing");
+    const tmx_sqp_params p = param_.toTmx();
+    check(tmx_problem_upload(ctx_, &prob_->desc(), &p, &osqp_));
+    check(tmx_batch_set_x0(ctx_, seeds_.data(), batch_));
+    check(tmx_sqp_run(ctx_, 0, nullptr));
+    const std::size_t B = static_cast<std::size_t>(batch_), nv = numVars();
+    std::vector<double> x(B * nv), cost(B);
+    std::vector<int32_t> status(B), nfe(B), nqp(B);
+    check(tmx_sqp_results(ctx_, x.data(), status.data(), cost.data(), nfe.data(), nqp.data()));
+    int32_t n_costs = 0, n_cnts = 0, n_slots = 0;
+    check(tmx_term_counts(ctx_, &n_costs, &n_cnts, &n_slots));
+    std::vector<double> cv(B * static_cast<std::size_t>(n_costs)), vv(B * static_cast<std::size_t>(n_cnts));
+    check(tmx_evaluate(ctx_, cv.data(), vv.data()));  // cost values / constraint violations at the final iterates
+    batch_results_.assign(B, OptResults());
+    for (std::size_t b = 0; b < B; ++b)
+    {
+      OptResults& r = batch_results_[b];
+      r.x.assign(x.begin() + static_cast<std::ptrdiff_t>(b * nv), x.begin() + static_cast<std::ptrdiff_t>((b + 1) * nv));
+      r.status = static_cast<OptStatus>(status[b]);
+      r.total_cost = cost[b];
+      r.n_func_evals = nfe[b];
+      r.n_qp_solves = nqp[b];
+      r.cost_vals.assign(cv.begin() + static_cast<std::ptrdiff_t>(b * static_cast<std::size_t>(n_costs)),
+                         cv.begin() + static_cast<std::ptrdiff_t>((b + 1) * static_cast<std::size_t>(n_costs)));
+      r.cnt_viols.assign(vv.begin() + static_cast<std::ptrdiff_t>(b * static_cast<std::size_t>(n_cnts)),
+                         vv.begin() + static_cast<std::ptrdiff_t>((b + 1) * static_cast<std::size_t>(n_cnts)));
+    }
+    int64_t best = -1;
+    double best_cost = 0;
+    check(tmx_argmin(ctx_, 0, &best, &best_cost));  // lowest total_cost among the converged seeds
+    best_ = best < 0 ? 0 : static_cast<std::size_t>(best);
+    results_ = batch_results_[best_];
+    for (auto& cb : callbacks_)
+      cb(prob_.get(), results_);
+    return results_.status;
+  }
+
+  DblVec& x() { return results_.x; }
+  OptResults& results() { return results_; }
+  const std::vector<OptResults>& batchResults() const { return batch_results_; }
+  std::size_t bestSeed() const { return best_; }
+  tmx_ctx* context() { return ctx_; }
+
+private:
+  std::size_t numVars() const { return static_cast<std::size_t>(prob_->GetNumSteps()) * static_cast<std::size_t>(prob_->GetNumDOF()); }
+  void check(tmx_status s)
+  {
+    if (s != TMX_OK)
+      printAndThrow(std::string("libtrajopt_mi355x: ") + tmx_last_error(ctx_));
+  }
+  trajopt::TrajOptProb::Ptr prob_;
+  tmx_ctx* ctx_{ nullptr };
+  BasicTrustRegionSQPParameters param_;
+  tmx_osqp_settings osqp_{};
+  std::vector<double> seeds_;
+  int32_t batch_{ 0 };
+  OptResults results_;
+  std::vector<OptResults> batch_results_;
+  std::size_t best_{ 0 };
+  std::vector<Callback> callbacks_;
+};
+
+/** trajToDblVec (trajopt/include/trajopt/utils.hpp:18): row-major flattening of a TrajArray */
+inline DblVec trajToDblVec(const TrajArray& t) { return t.data; }
+}  // namespace sco
+}  // namespace tmx
+
+#endif  // TMX_TRAJOPT_HPP_

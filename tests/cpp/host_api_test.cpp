@@ -1,0 +1,608 @@
+// Test program for the C++ host layer include/tmx_trajopt.hpp (TEST CODE; built and driven by tests/test_cpp_host_api.py).
+// Reads kinematic data / seeds from a text file written by the Python test, builds the problems through the C++ mirror of
+// the reference interface exactly the way the reference's own tests do
+//   (trajopt/test/joint_costs_unit.cpp:63-253, trajopt/test/numerical_ik_unit.cpp:59-124, trajopt/test/planning_unit.cpp:66-130)
+// and prints one line per optimised seed (hex floats, so the Python side can compare bit-for-bit with its own ctypes path).
+// Linked against the kernel sources built for the host (CPU tier) or against libtrajopt_mi355x.so (GPU tier).
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+
+#include "tmx_trajopt.hpp"
+
+using namespace tmx;
+using namespace tmx::trajopt;
+using tmx::sco::BasicTrustRegionSQPBatchedHip;
+using tmx::sco::OptStatus;
+
+static int g_fail = 0;
+#define EXPECT_TRUE(c)                                                                  \
+  do                                                                                    \
+  {                                                                                     \
+    if (!(c))                                                                           \
+    {                                                                                   \
+      std::fprintf(stderr, "EXPECT failed %s:%d: %s\n", __FILE__, __LINE__, #c);        \
+      ++g_fail;                                                                         \
+    }                                                                                   \
+  } while (0)
+#define EXPECT_NEAR(a, b, tol) EXPECT_TRUE(std::fabs((a) - (b)) <= (tol))
+#define EXPECT_THROW_MSG(stmt, needle)                                                  \
+  do                                                                                    \
+  {                                                                                     \
+    bool thrown = false;                                                                \
+    try                                                                                 \
+    {                                                                                   \
+      stmt;                                                                             \
+    }                                                                                   \
+    catch (const std::runtime_error& e)                                                 \
+    {                                                                                   \
+      thrown = std::string(e.what()).find(needle) != std::string::npos;                 \
+      if (!thrown)                                                                      \
+        std::fprintf(stderr, "unexpected message: %s\n", e.what());                     \
+    }                                                                                   \
+    EXPECT_TRUE(thrown);                                                                \
+  } while (0)
+
+struct Input
+{
+  std::map<std::string, std::shared_ptr<JointGroup>> robots;
+  std::map<std::string, Transform> frames;
+  std::vector<tmx_obstacle_sphere> obstacles;
+  std::map<std::string, DblVec> vectors;
+};
+
+// numbers are written as C99 hex floats (exact); operator>> does not parse those, strtod does
+static double rd(std::istream& f)
+{
+  std::string t;
+  if (!(f >> t))
+    throw std::runtime_error("unexpected end of input");
+  return std::strtod(t.c_str(), nullptr);
+}
+
+static Input readInput(const char* path)
+{
+  Input in;
+  std::ifstream f(path);
+  if (!f)
+    throw std::runtime_error("cannot open input file");
+  std::string tok;
+  while (f >> tok)
+  {
+    if (tok == "robot")
+    {
+      auto r = std::make_shared<JointGroup>();
+      std::string name;
+      int D = 0;
+      f >> name >> D >> r->tip_link;
+      r->joints.resize(static_cast<std::size_t>(D));
+      r->lower.resize(static_cast<std::size_t>(D));
+      r->upper.resize(static_cast<std::size_t>(D));
+      for (int j = 0; j < D; ++j)
+      {
+        tmx_joint& jt = r->joints[static_cast<std::size_t>(j)];
+        jt = tmx_joint{};
+        f >> jt.type;
+        for (double& v : jt.origin)
+          v = rd(f);
+        for (double& v : jt.axis)
+          v = rd(f);
+        r->lower[static_cast<std::size_t>(j)] = rd(f);
+        r->upper[static_cast<std::size_t>(j)] = rd(f);
+        r->joint_names.push_back("j" + std::to_string(j));
+      }
+      for (double& v : r->base.m)
+        v = rd(f);
+      for (double& v : r->tool.m)
+        v = rd(f);
+      int ns = 0;
+      f >> ns;
+      r->link_spheres.resize(static_cast<std::size_t>(ns));
+      for (auto& s : r->link_spheres)
+      {
+        s = tmx_link_sphere{};
+        f >> s.link;
+        for (double& v : s.center)
+          v = rd(f);
+        s.radius = rd(f);
+      }
+      in.robots[name] = r;
+    }
+    else if (tok == "frame")
+    {
+      std::string name;
+      f >> name;
+      Transform t;
+      for (double& v : t.m)
+        v = rd(f);
+      in.frames[name] = t;
+    }
+    else if (tok == "obstacles")
+    {
+      int n = 0;
+      f >> n;
+      in.obstacles.resize(static_cast<std::size_t>(n));
+      for (auto& o : in.obstacles)
+      {
+        for (double& v : o.center)
+          v = rd(f);
+        o.radius = rd(f);
+      }
+    }
+    else if (tok == "vector")
+    {
+      std::string name;
+      std::size_t n = 0;
+      f >> name >> n;
+      DblVec v(n);
+      for (double& x : v)
+        x = rd(f);
+      in.vectors[name] = v;
+    }
+    else
+      throw std::runtime_error("bad token in input: " + tok);
+  }
+  return in;
+}
+
+static std::vector<DblVec> splitSeeds(const DblVec& flat, std::size_t nv)
+{
+  std::vector<DblVec> out;
+  for (std::size_t o = 0; o + nv <= flat.size(); o += nv)
+    out.emplace_back(flat.begin() + static_cast<std::ptrdiff_t>(o), flat.begin() + static_cast<std::ptrdiff_t>(o + nv));
+  return out;
+}
+
+static void printResults(const char* name, const BasicTrustRegionSQPBatchedHip& opt)
+{
+  const auto& rs = opt.batchResults();
+  for (std::size_t b = 0; b < rs.size(); ++b)
+  {
+    std::printf("RESULT %s %zu %d %d %d %a", name, b, static_cast<int>(rs[b].status), rs[b].n_func_evals, rs[b].n_qp_solves, rs[b].total_cost);
+    for (double v : rs[b].x)
+      std::printf(" %a", v);
+    std::printf("\n");
+  }
+  std::printf("BEST %s %zu\n", name, opt.bestSeed());
+}
+
+static std::shared_ptr<Environment> makeEnv(const Input& in, const std::string& manip, const std::string& robot, const DblVec& state,
+                                            bool with_obstacles)
+{
+  auto env = std::make_shared<Environment>();
+  env->manipulators[manip] = in.robots.at(robot);
+  env->state[manip] = state;
+  env->link_frames = in.frames;
+  if (with_obstacles)
+    env->obstacles = in.obstacles;
+  return env;
+}
+
+// ---- config 0: joint-velocity cost + goal joint-position constraint, start fixed (SURVEY.md §8d cfg 0) ----------------
+static void caseCfg0(const Input& in)
+{
+  const DblVec& start = in.vectors.at("cfg0_start");
+  const DblVec& goal = in.vectors.at("cfg0_goal");
+  const int steps = 10;
+  auto env = makeEnv(in, "right_arm", "pr2_right_arm", start, false);
+  ProblemConstructionInfo pci(env);
+  pci.basic_info.n_steps = steps;
+  pci.basic_info.manip = "right_arm";
+  pci.basic_info.fixed_timesteps = { 0 };
+  pci.resolveKin();
+  pci.init_info.type = InitInfo::JOINT_INTERPOLATED;
+  pci.init_info.data = TrajArray(1, 7);
+  pci.init_info.data.data = goal;
+  auto jv = std::make_shared<JointVelTermInfo>();
+  jv->coeffs = DblVec(7, 1.0);
+  jv->targets = DblVec(7, 0.0);
+  jv->first_step = 0;
+  jv->last_step = steps - 1;
+  jv->name = "joint_vel";
+  jv->term_type = TermType::TT_COST;
+  pci.cost_infos.push_back(jv);
+  auto jp = std::make_shared<JointPosTermInfo>();
+  jp->coeffs = DblVec(7, 1.0);
+  jp->targets = goal;
+  jp->first_step = steps - 1;
+  jp->last_step = steps - 1;
+  jp->name = "joint_pos";
+  jp->term_type = TermType::TT_CNT;
+  pci.cnt_infos.push_back(jp);
+  auto prob = ConstructProblem(pci);
+  EXPECT_TRUE(prob->GetNumSteps() == steps && prob->GetNumDOF() == 7);
+  EXPECT_TRUE(prob->getNumCosts() == 1 && prob->getNumConstraints() == 1);
+  // the straight-line init trajectory: first row = current state, last row = endpoint exactly
+  for (int j = 0; j < 7; ++j)
+  {
+    EXPECT_TRUE(prob->GetInitTraj()(0, j) == start[static_cast<std::size_t>(j)]);
+    EXPECT_TRUE(prob->GetInitTraj()(steps - 1, j) == goal[static_cast<std::size_t>(j)]);
+  }
+  std::printf("INIT cfg0");
+  for (double v : prob->GetInitTraj().data)
+    std::printf(" %a", v);
+  std::printf("\n");
+  BasicTrustRegionSQPBatchedHip opt(prob);
+  std::vector<DblVec> seeds = splitSeeds(in.vectors.at("cfg0_seeds"), 70);
+  opt.initialize(seeds);
+  int calls = 0;
+  opt.addCallback([&](TrajOptProb*, tmx::sco::OptResults& r) {
+    ++calls;
+    EXPECT_TRUE(r.x.size() == 70);
+  });
+  const OptStatus st = opt.optimize();
+  EXPECT_TRUE(calls == 1);
+  EXPECT_TRUE(st == opt.results().status);
+  EXPECT_TRUE(opt.x() == opt.batchResults()[opt.bestSeed()].x);
+  for (const auto& r : opt.batchResults())
+  {
+    EXPECT_TRUE(r.status == OptStatus::OPT_CONVERGED);
+    EXPECT_TRUE(r.cost_vals.size() == 1 && r.cnt_viols.size() == 1);
+    EXPECT_TRUE(r.cnt_viols[0] <= 1e-4);  // cnt_tolerance
+    for (int j = 0; j < 7; ++j)
+    {
+      EXPECT_NEAR(r.x[static_cast<std::size_t>(j)], seeds[0][static_cast<std::size_t>(j)], 1e-6);               // fixed timestep 0 (a QP row)
+      EXPECT_NEAR(r.x[static_cast<std::size_t>(63 + j)], goal[static_cast<std::size_t>(j)], 1e-4);               // goal constraint
+    }
+  }
+  printResults("cfg0", opt);
+}
+
+// ---- config 1: glass_upright (SURVEY.md §8d cfg 1) with a handful of seeds -------------------------------------------
+static void caseCfg1(const Input& in)
+{
+  const DblVec& start = in.vectors.at("cfg1_start");
+  const DblVec& goal = in.vectors.at("cfg1_goal");
+  const int steps = 30;
+  auto env = makeEnv(in, "right_arm", "pr2_right_arm_upright", start, true);
+  ProblemConstructionInfo pci(env);
+  pci.basic_info.n_steps = steps;
+  pci.basic_info.manip = "right_arm";
+  pci.basic_info.fixed_timesteps = { 0 };
+  pci.resolveKin();
+  pci.init_info.type = InitInfo::STATIONARY;
+  auto jv = std::make_shared<JointVelTermInfo>();
+  jv->coeffs = DblVec(1, 1.0);  // single value: broadcast by checkParameterSize
+  jv->targets = DblVec(7, 0.0);
+  jv->name = "joint_vel";
+  jv->term_type = TermType::TT_COST;
+  pci.cost_infos.push_back(jv);
+  auto col = std::make_shared<CollisionTermInfo>();
+  col->first_step = 0;
+  col->last_step = steps - 1;
+  col->fixed_steps = { 0 };
+  col->config = TrajOptCollisionConfig(0.025, 20.0);
+  col->config.collision_margin_buffer = 0.5;
+  col->name = "collision";
+  col->term_type = TermType::TT_COST;
+  pci.cost_infos.push_back(col);
+  for (int t = 1; t < steps; ++t)
+  {
+    auto cp = std::make_shared<CartPoseTermInfo>();
+    cp->timestep = t;
+    cp->source_frame = pci.kin->tip_link;
+    cp->target_frame = "world";
+    cp->pos_coeffs = { { 0, 0, 0 } };
+    cp->rot_coeffs = { { 1, 1, 0 } };
+    cp->name = "upright_" + std::to_string(t);
+    cp->term_type = TermType::TT_CNT;
+    pci.cnt_infos.push_back(cp);
+  }
+  auto jp = std::make_shared<JointPosTermInfo>();
+  jp->targets = goal;  // coeffs empty -> ones
+  jp->first_step = steps - 1;
+  jp->last_step = steps - 1;
+  jp->name = "goal";
+  jp->term_type = TermType::TT_CNT;
+  pci.cnt_infos.push_back(jp);
+  auto prob = ConstructProblem(pci);
+  BasicTrustRegionSQPBatchedHip opt(prob);
+  opt.initialize(splitSeeds(in.vectors.at("cfg1_seeds"), 210));
+  opt.optimize();
+  printResults("cfg1", opt);
+}
+
+// ---- trajopt/test/joint_costs_unit.cpp:63-141 (equality_jointPos) and :152-253 (inequality_jointPos) -------------------
+static void caseJointCosts(const Input& in)
+{
+  const int steps = 10;
+  {
+    auto env = makeEnv(in, "right_arm", "pr2_right_arm", DblVec(7, 0.0), false);
+    ProblemConstructionInfo pci(env);
+    pci.basic_info.n_steps = steps;
+    pci.basic_info.manip = "right_arm";
+    pci.resolveKin();
+    pci.init_info.type = InitInfo::STATIONARY;
+    const double cnt_targ = 0.0, cost_targ = -0.1;
+    auto jv = std::make_shared<JointPosTermInfo>();
+    jv->coeffs = DblVec(7, 10.0);
+    jv->targets = DblVec(7, cnt_targ);
+    jv->first_step = 0;
+    jv->last_step = 0;
+    jv->name = "joint_pos_single";
+    jv->term_type = TermType::TT_CNT;
+    pci.cnt_infos.push_back(jv);
+    auto jv2 = std::make_shared<JointPosTermInfo>();
+    jv2->coeffs = DblVec(7, 10.0);
+    jv2->targets = DblVec(7, cost_targ);
+    jv2->first_step = 0;
+    jv2->last_step = steps - 1;
+    jv2->name = "joint_pos_all";
+    jv2->term_type = TermType::TT_COST;
+    pci.cost_infos.push_back(jv2);
+    auto prob = ConstructProblem(pci);
+    BasicTrustRegionSQPBatchedHip opt(prob);
+    opt.initialize(tmx::sco::trajToDblVec(prob->GetInitTraj()));
+    opt.optimize();
+    const DblVec& x = opt.x();
+    for (int j = 0; j < 7; ++j)
+      EXPECT_NEAR(x[static_cast<std::size_t>(j)], cnt_targ, 1e-4);
+    for (int i = 1; i < steps; ++i)
+      for (int j = 0; j < 7; ++j)
+        EXPECT_NEAR(x[static_cast<std::size_t>(i * 7 + j)], cost_targ, 0.01);
+    printResults("equality_jointPos", opt);
+  }
+  {
+    auto env = makeEnv(in, "right_arm", "pr2_right_arm", DblVec(7, 0.0), false);
+    ProblemConstructionInfo pci(env);
+    pci.basic_info.n_steps = steps;
+    pci.basic_info.manip = "right_arm";
+    pci.resolveKin();
+    pci.init_info.type = InitInfo::STATIONARY;
+    const double lower_tol = -0.1, upper_tol = 0.2;
+    auto jv = std::make_shared<JointPosTermInfo>();
+    jv->coeffs = DblVec(7, 1.0);
+    jv->targets = DblVec(7, 0.0);
+    jv->lower_tols = DblVec(7, lower_tol);
+    jv->upper_tols = DblVec(7, upper_tol);
+    jv->first_step = 0;
+    jv->last_step = steps - 1;
+    jv->name = "joint_pos_limits";
+    jv->term_type = TermType::TT_CNT;
+    pci.cnt_infos.push_back(jv);
+    auto jv2 = std::make_shared<JointPosTermInfo>();
+    jv2->coeffs = DblVec(7, 1.0);
+    jv2->targets = DblVec(7, 0.5);
+    jv2->lower_tols = DblVec(7, -0.01);
+    jv2->upper_tols = DblVec(7, 0.01);
+    jv2->first_step = 0;
+    jv2->last_step = (steps - 1) / 2;
+    jv2->name = "joint_pos_targ_1";
+    jv2->term_type = TermType::TT_COST;
+    pci.cost_infos.push_back(jv2);
+    auto jv3 = std::make_shared<JointPosTermInfo>();
+    jv3->coeffs = DblVec(7, 1.0);
+    jv3->targets = DblVec(7, -0.5);
+    jv3->lower_tols = DblVec(7, -0.01);
+    jv3->upper_tols = DblVec(7, 0.01);
+    jv3->first_step = (steps - 1) / 2 + 1;
+    jv3->last_step = steps - 1;
+    jv3->name = "joint_pos_targ_2";
+    jv3->term_type = TermType::TT_COST;
+    pci.cost_infos.push_back(jv3);
+    auto prob = ConstructProblem(pci);
+    BasicTrustRegionSQPBatchedHip opt(prob);
+    opt.initialize(tmx::sco::trajToDblVec(prob->GetInitTraj()));
+    opt.optimize();
+    const double cnt_tol = opt.getParameters().cnt_tolerance;
+    for (double v : opt.x())
+    {
+      EXPECT_TRUE(v < upper_tol + cnt_tol);
+      EXPECT_TRUE(v > lower_tol - cnt_tol);
+    }
+    printResults("inequality_jointPos", opt);
+  }
+}
+
+// ---- trajopt/test/numerical_ik_unit.cpp:59-124 ------------------------------------------------------------------------
+static Transform fkTool(const JointGroup& kin, const DblVec& q)
+{
+  Transform T = kin.base;
+  for (std::size_t k = 0; k < kin.numJoints(); ++k)
+  {
+    Transform o;
+    std::copy(kin.joints[k].origin, kin.joints[k].origin + 12, o.m.begin());
+    T = T * o;
+    Transform m;
+    const double* a = kin.joints[k].axis;
+    if (kin.joints[k].type == 0)
+    {
+      const double c = std::cos(q[k]), s = std::sin(q[k]), v = 1 - c, x = a[0], y = a[1], z = a[2];
+      m.m = { { c + x * x * v, x * y * v - z * s, x * z * v + y * s, 0, y * x * v + z * s, c + y * y * v, y * z * v - x * s, 0,
+                z * x * v - y * s, z * y * v + x * s, c + z * z * v, 0 } };
+    }
+    else
+      m = Transform::Translation(a[0] * q[k], a[1] * q[k], a[2] * q[k]);
+    T = T * m;
+  }
+  return T * kin.tool;
+}
+
+static void caseNumericalIk(const Input& in)
+{
+  auto env = makeEnv(in, "left_arm", "pr2_left_arm", DblVec(7, 0.0), false);
+  ProblemConstructionInfo pci(env);
+  pci.basic_info.n_steps = 1;
+  pci.basic_info.manip = "left_arm";
+  pci.resolveKin();
+  pci.init_info.type = InitInfo::STATIONARY;
+  auto cp = std::make_shared<CartPoseTermInfo>();
+  cp->timestep = 0;
+  cp->source_frame = "l_gripper_tool_frame";
+  cp->target_frame = "base_footprint";
+  cp->target_frame_offset = Transform::FromQuaternion(0, 0, 1, 0, 0.4, 0, 0.8);
+  cp->name = "cart_pose";
+  cp->term_type = TermType::TT_CNT;
+  pci.cnt_infos.push_back(cp);
+  auto prob = ConstructProblem(pci);
+  BasicTrustRegionSQPBatchedHip opt(prob);
+  opt.initialize(DblVec(static_cast<std::size_t>(prob->GetNumDOF()), 0));
+  const OptStatus st = opt.optimize();
+  EXPECT_TRUE(st == OptStatus::OPT_CONVERGED);
+  // final pose in the base_footprint frame: change_base * fk  (:108-109), goal (:111-114)
+  const Transform bf = in.frames.at("base_footprint");
+  Transform inv = bf;  // pure translation in this model
+  inv.m[3] = -bf.m[3], inv.m[7] = -bf.m[7], inv.m[11] = -bf.m[11];
+  const Transform final_pose = inv * fkTool(*pci.kin, opt.x());
+  const Transform goal = Transform::FromQuaternion(0, 0, 1, 0, 0.4, 0, 0.8);
+  for (std::size_t k = 0; k < 12; ++k)
+    EXPECT_NEAR(goal.m[k], final_pose.m[k], 1e-3);
+  printResults("numerical_ik1", opt);
+}
+
+// ---- error behaviour: where the reference PRINT_AND_THROWs, this layer throws std::runtime_error -----------------------
+static void caseErrors(const Input& in, bool have_device)
+{
+  auto env = makeEnv(in, "right_arm", "pr2_right_arm", DblVec(7, 0.0), false);
+  auto base = [&]() {
+    ProblemConstructionInfo pci(env);
+    pci.basic_info.n_steps = 5;
+    pci.basic_info.manip = "right_arm";
+    pci.resolveKin();
+    return pci;
+  };
+  {
+    ProblemConstructionInfo pci(env);
+    pci.basic_info.manip = "no_such_arm";
+    EXPECT_THROW_MSG(pci.resolveKin(), "Manipulator does not exist: no_such_arm");
+  }
+  {
+    auto pci = base();
+    auto jp = std::make_shared<JointPosTermInfo>();
+    jp->targets = DblVec(3, 0.0);
+    pci.cnt_infos.push_back(jp);
+    EXPECT_THROW_MSG(ConstructProblem(pci), "wrong number of JointPosTermInfo targets. expected 7 got 3");
+  }
+  {
+    auto pci = base();
+    pci.init_info.type = InitInfo::GIVEN_TRAJ;
+    pci.init_info.data = TrajArray(4, 7);
+    EXPECT_THROW_MSG(ConstructProblem(pci), "Initial trajectory is not the right size matrix");
+  }
+  {
+    auto pci = base();
+    pci.init_info.type = InitInfo::JOINT_INTERPOLATED;
+    pci.init_info.data = TrajArray(1, 6);
+    EXPECT_THROW_MSG(ConstructProblem(pci), "JOINT_INTERPOLATED selected, but init_info.data is the wrong size");
+  }
+  {
+    auto pci = base();
+    pci.basic_info.fixed_timesteps = { 7 };
+    EXPECT_THROW_MSG(ConstructProblem(pci), "Fixed timestep index is outside the bounds");
+  }
+  {
+    auto pci = base();
+    pci.basic_info.fixed_dofs = { 9 };
+    EXPECT_THROW_MSG(ConstructProblem(pci), "DOF(aka Joint) indice is greater than the number of DOF available.");
+  }
+  {
+    auto pci = base();
+    auto col = std::make_shared<CollisionTermInfo>();
+    col->first_step = 1;
+    col->last_step = 4;
+    col->fixed_steps = { 0 };
+    pci.cost_infos.push_back(col);
+    EXPECT_THROW_MSG(ConstructProblem(pci), "Fixed step 0 is not between first step 1 and last step 4");
+  }
+  {
+    auto pci = base();
+    auto col = std::make_shared<CollisionTermInfo>();
+    col->first_step = 0;
+    col->last_step = 4;
+    col->config.type = TrajOptCollisionConfig::CollisionEvaluatorType::LVS_CONTINUOUS;
+    pci.cost_infos.push_back(col);
+    EXPECT_THROW_MSG(ConstructProblem(pci), "only the DISCRETE evaluator");  // unsupported is explicit, never a CPU detour
+  }
+  {
+    auto pci = base();
+    auto jv = std::make_shared<JointVelTermInfo>();
+    jv->targets = DblVec(7, 0.0);
+    pci.cnt_infos.push_back(jv);
+    EXPECT_THROW_MSG(ConstructProblem(pci), "only the TT_COST form is lowered");
+  }
+  {
+    auto pci = base();
+    auto cp = std::make_shared<CartPoseTermInfo>();
+    cp->source_frame = "nowhere";
+    cp->target_frame = "base_footprint";
+    pci.cnt_infos.push_back(cp);
+    EXPECT_THROW_MSG(ConstructProblem(pci), "invalid source frame: nowhere");
+  }
+  {
+    auto pci = base();
+    auto cp = std::make_shared<CartPoseTermInfo>();
+    cp->source_frame = pci.kin->tip_link;
+    cp->target_frame = pci.kin->tip_link;
+    pci.cnt_infos.push_back(cp);
+    EXPECT_THROW_MSG(ConstructProblem(pci), "are both active");
+  }
+  {
+    // step ranges are clamped / swapped as in JointPosTermInfo::hatch (:1092-1108)
+    auto pci = base();
+    auto jp = std::make_shared<JointPosTermInfo>();
+    jp->targets = DblVec(7, 0.0);
+    jp->first_step = 9;
+    jp->last_step = 2;
+    pci.cnt_infos.push_back(jp);
+    auto prob = ConstructProblem(pci);
+    const tmx_problem_desc& d = prob->desc();
+    EXPECT_TRUE(d.n_terms == 1 && d.terms[0].first_step == 2 && d.terms[0].last_step == 4);
+    EXPECT_TRUE(d.terms[0].kind == TMX_TERM_JOINT_POS_EQ_CNT && d.terms[0].coeffs[6] == 1.0);
+  }
+  if (have_device)
+  {
+    auto pci = base();
+    auto prob = ConstructProblem(pci);
+    BasicTrustRegionSQPBatchedHip opt(prob);
+    EXPECT_THROW_MSG(opt.initialize(DblVec(34, 0.0)), "initialization vector has wrong length. expected 35 got 34");
+    EXPECT_THROW_MSG(opt.optimize(), "must initialize before optimizing");
+  }
+  else
+  {
+    // no device and no CPU fallback: constructing the optimizer must fail loudly
+    auto pci = base();
+    auto prob = ConstructProblem(pci);
+    EXPECT_THROW_MSG(BasicTrustRegionSQPBatchedHip opt(prob), "no MI355X device available");
+  }
+  std::printf("ERRORS done\n");
+}
+
+int main(int argc, char** argv)
+{
+  if (argc < 3)
+  {
+    std::fprintf(stderr, "usage: %s <input.txt> <case>[,<case>...]\n", argv[0]);
+    return 2;
+  }
+  try
+  {
+    const Input in = readInput(argv[1]);
+    std::stringstream ss(argv[2]);
+    std::string c;
+    while (std::getline(ss, c, ','))
+    {
+      if (c == "cfg0")
+        caseCfg0(in);
+      else if (c == "cfg1")
+        caseCfg1(in);
+      else if (c == "joint_costs")
+        caseJointCosts(in);
+      else if (c == "numerical_ik")
+        caseNumericalIk(in);
+      else if (c == "errors")
+        caseErrors(in, true);
+      else if (c == "errors_nodevice")
+        caseErrors(in, false);
+      else
+        throw std::runtime_error("unknown case " + c);
+    }
+  }
+  catch (const std::exception& e)
+  {
+    std::fprintf(stderr, "uncaught exception: %s\n", e.what());
+    return 3;
+  }
+  return g_fail ? 1 : 0;
+}

@@ -1,0 +1,145 @@
+"""C++ host layer (include/tmx_trajopt.hpp: the reference's ProblemConstructionInfo / TermInfo / ConstructProblem /
+BasicTrustRegionSQP interface above the C-ABI) driven by tests/cpp/host_api_test.cpp.
+
+The C++ program builds the problems the way the reference's own C++ tests do and checks their assertions itself
+(joint_costs_unit.cpp equality_jointPos / inequality_jointPos, numerical_ik_unit.cpp, error behaviour).  Here we
+additionally require that the C++ lowering and the Python lowering (trajopt_amd/problem.py) are THE SAME problem:
+both front ends on the same library must return bit-identical trajectories, statuses and counters.
+CPU tier: linked against the kernel sources built for the host (tests/hostemu).  GPU tier: libtrajopt_mi355x.so."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from trajopt_amd import configs, runtime
+from trajopt_amd.problem import pr2_base_footprint, pr2_left_arm, pr2_right_arm
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+BUILD = os.path.join(HERE, "cpp", "_build")
+SRC = os.path.join(HERE, "cpp", "host_api_test.cpp")
+HDRS = [os.path.join(ROOT, "include", "tmx_trajopt.hpp"), os.path.join(ROOT, "include", "tmx.h")]
+PRODUCT_LIB = os.path.join(ROOT, "trajopt_amd", "_build", "libtrajopt_mi355x.so")
+N0, N1 = 3, 3     # seeds per config
+
+
+def _build(lib_path, tag):
+    os.makedirs(BUILD, exist_ok=True)
+    exe = os.path.join(BUILD, "host_api_test_" + tag)
+    newest = max(os.path.getmtime(p) for p in [SRC, lib_path] + HDRS)
+    if not os.path.exists(exe) or os.path.getmtime(exe) < newest:
+        libdir, libname = os.path.dirname(lib_path), os.path.basename(lib_path)
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"), SRC,
+                               "-o", exe, "-L" + libdir, "-l:" + libname, "-Wl,-rpath," + libdir, "-fopenmp"])
+    return exe
+
+
+def _fmt(v):
+    return " ".join(float(x).hex() for x in np.asarray(v, dtype=np.float64).reshape(-1))
+
+
+def _robot_block(name, rob, tip):
+    out = [f"robot {name} {rob.n_dof} {tip}"]
+    for j in range(rob.n_dof):
+        out.append(f"{rob.joint_types[j]} {_fmt(rob.origins[j])} {_fmt(rob.axes[j])} {_fmt(rob.lower[j])} {_fmt(rob.upper[j])}")
+    out.append(_fmt(rob.base))
+    out.append(_fmt(rob.tool))
+    out.append(str(len(rob.link_spheres)))
+    for link, c, r in rob.link_spheres:
+        out.append(f"{link} {_fmt(c)} {_fmt(r)}")
+    return out
+
+
+@pytest.fixture(scope="module")
+def inputs(tmp_path_factory):
+    pci0, s0, g0 = configs.config0()
+    pci1, s1, g1 = configs.config1()
+    x0 = configs.seeds_for(0, pci0, s0, g0, N0)
+    x1 = configs.seeds_for(1, pci1, s1, g1, N1)
+    lines = []
+    lines += _robot_block("pr2_right_arm", pr2_right_arm(), "r_gripper_tool_frame")
+    lines += _robot_block("pr2_right_arm_upright", pci1.robot, "r_gripper_tool_frame")
+    lines += _robot_block("pr2_left_arm", pr2_left_arm(), "l_gripper_tool_frame")
+    lines.append("frame world " + _fmt(np.hstack([np.eye(3), np.zeros((3, 1))])))
+    lines.append("frame base_footprint " + _fmt(pr2_base_footprint()))
+    lines.append(f"obstacles {len(pci1.obstacles)}")
+    for c, r in pci1.obstacles:
+        lines.append(f"{_fmt(c)} {_fmt(r)}")
+    for name, v in (("cfg0_start", s0), ("cfg0_goal", g0), ("cfg1_start", s1), ("cfg1_goal", g1), ("cfg0_seeds", x0), ("cfg1_seeds", x1)):
+        lines.append(f"vector {name} {np.asarray(v).size} {_fmt(v)}")
+    path = tmp_path_factory.mktemp("cpp") / "input.txt"
+    path.write_text("\n".join(lines) + "\n")
+    return dict(path=str(path), pci0=pci0, pci1=pci1, x0=x0, x1=x1, s0=s0, g0=g0)
+
+
+def _run(exe, inp, cases, timeout=600):
+    p = subprocess.run([exe, inp, cases], capture_output=True, text=True, timeout=timeout)
+    assert p.returncode == 0, f"{cases}: rc={p.returncode}\n{p.stdout[-2000:]}\n{p.stderr[-4000:]}"
+    res, init = {}, {}
+    for ln in p.stdout.splitlines():
+        tok = ln.split()
+        if tok and tok[0] == "RESULT":
+            res.setdefault(tok[1], []).append(dict(status=int(tok[3]), nfe=int(tok[4]), nqp=int(tok[5]), cost=float.fromhex(tok[6]),
+                                                   x=np.array([float.fromhex(t) for t in tok[7:]])))
+        elif tok and tok[0] == "INIT":
+            init[tok[1]] = np.array([float.fromhex(t) for t in tok[2:]])
+    return res, init, p.stdout
+
+
+def _python_path(pci, x0, lib_path):
+    opt = runtime.BatchedTrustRegionSQP(pci, lib_path=lib_path)
+    opt.initialize(x0)
+    opt.optimize()
+    r = opt.results()
+    opt.ctx.close()
+    return r
+
+
+def _same(cpp, py):
+    assert len(cpp) == py["x"].shape[0]
+    for b, c in enumerate(cpp):
+        assert c["status"] == py["status"][b] and c["nfe"] == py["n_func_evals"][b] and c["nqp"] == py["n_qp_solves"][b]
+        assert c["cost"] == py["total_cost"][b]
+        assert np.array_equal(c["x"], py["x"][b].reshape(-1)), "C++ and Python front ends must describe the same problem"
+
+
+def _check_front_ends(exe, inputs, lib_path):
+    res, init, _ = _run(exe, inputs["path"], "cfg0,cfg1")
+    _same(res["cfg0"], _python_path(inputs["pci0"], inputs["x0"], lib_path))
+    _same(res["cfg1"], _python_path(inputs["pci1"], inputs["x1"], lib_path))
+    # JOINT_INTERPOLATED init trajectory: LinSpaced(start, goal) per joint
+    line = np.linspace(inputs["s0"], inputs["g0"], 10)
+    assert np.abs(init["cfg0"].reshape(10, 7) - line).max() < 1e-14
+
+
+def test_cpp_front_end_equals_python_front_end_on_host_build(hostemu_lib, inputs):
+    _check_front_ends(_build(hostemu_lib, "hostemu"), inputs, hostemu_lib)
+
+
+def test_cpp_reference_kats_on_host_build(hostemu_lib, inputs, orc):
+    exe = _build(hostemu_lib, "hostemu")
+    res, _, out = _run(exe, inputs["path"], "joint_costs,numerical_ik,errors")
+    assert "ERRORS done" in out
+    assert set(res) == {"equality_jointPos", "inequality_jointPos", "numerical_ik1"}
+    assert all(r[0]["status"] == 0 for r in res.values())
+
+
+def test_cpp_optimizer_fails_loudly_without_a_device(inputs):
+    """linked against the PRODUCT library on a machine without a GPU: no CPU path may take over"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    assert os.path.exists(PRODUCT_LIB), "libtrajopt_mi355x.so missing: run __graft_entry__.build()"
+    exe = _build(PRODUCT_LIB, "product")
+    _, _, out = _run(exe, inputs["path"], "errors_nodevice")
+    assert "ERRORS done" in out
+
+
+@pytest.mark.gpu
+def test_cpp_front_end_on_device(inputs):
+    assert os.path.exists(PRODUCT_LIB), "libtrajopt_mi355x.so missing: run __graft_entry__.build()"
+    exe = _build(PRODUCT_LIB, "product")
+    _check_front_ends(exe, inputs, None)
+    res, _, out = _run(exe, inputs["path"], "joint_costs,numerical_ik,errors")
+    assert "ERRORS done" in out and all(r[0]["status"] == 0 for r in res.values())

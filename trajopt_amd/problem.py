@@ -1,5 +1,6 @@
-"""Host-side mirror of trajopt::ProblemConstructionInfo for the hot path (Python, because the tests and the
-bench driver are Python; the C++ adapters for real trajopt callers are in INTEGRATION.md).
+"""Host-side mirror of trajopt::ProblemConstructionInfo for the hot path (the Python twin of the C++ host
+layer include/tmx_trajopt.hpp; tests and bench driver are Python.  tests/test_cpp_host_api.py holds the two to
+bit-identical results).
 
 Mirrors (names and argument meaning) /root/reference/trajopt/include/trajopt/problem_description.hpp:
   BasicInfo :111-160, InitInfo :162-190, JointVelTermInfo, JointPosTermInfo, CartPoseTermInfo, CollisionTermInfo
