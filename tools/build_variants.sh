@@ -1,5 +1,7 @@
 #!/bin/bash
 # builds timing-experiment variants of the library: tools/build_variants.sh name1:"-DFLAGS" name2:"..."
+# (base flags = the Makefile's without CODEGEN, so that scheduler / allocator options can be varied; compare against a
+#  variant built with the Makefile's CODEGEN flags, and time them with tools/bench_libs.py)
 cd "$(dirname "$0")/../trajopt_amd/csrc"
 for spec in "$@"; do
   name="${spec%%:*}"; flags="${spec#*:}"
