@@ -1,5 +1,5 @@
 """Phase profile (needs a -DTMX_PROFILE build: make -C trajopt_amd/csrc EXTRA=-DTMX_PROFILE).
-   python tools/prof_phases.py [B] [full]   - first QP solve only (default) or the whole optimize() run ("full")"""
+   python tools/prof_phases.py [B] [full|first] [lib.so]   - first QP solve only (default) or the whole optimize() run ("full")"""
 import sys, os, ctypes as C, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -9,7 +9,7 @@ desc = pci.to_desc()
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 full = len(sys.argv) > 2 and sys.argv[2] == "full"
 x0 = configs.seeds_for(1, pci, s, g, B)
-ctx = runtime.Context(0)
+ctx = runtime.Context(0, sys.argv[3] if len(sys.argv) > 3 else None)
 ctx.upload(desc, abi.default_sqp_params(), abi.default_osqp_settings())
 ctx.set_x0(x0)
 ctx.kernel_stats(reset=True)

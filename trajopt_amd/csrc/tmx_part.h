@@ -64,6 +64,11 @@ TMX_DEVFN void part_invert_interior(const QpWs& w, int t0, int t1, int lane)
 //   thread NI + g, g < ns      : owns separator variable g (rhs assembly, primary update)
 //   threads 4g .. 4g+3, g < ns : the four column quarters of row g of the separator system (phase 2); thread 4g
 //                                publishes x_sep[g] and its coupling products
+// x / d and x % d for 0 <= x < 2^20, 1 <= d <= 64 through one float multiply (rd = 1.0f / d): (x + 0.5) / d is at
+// least 0.5 / d away from every integer, far more than the float rounding error, so the truncation is exact.  The
+// generic 32-bit division expands to ~30 dependent instructions, and the burst prologue needs a dozen of them.
+TMX_DEVFN int tmx_fdiv(int x, float rd) { return (int)(((float)x + 0.5f) * rd); }
+
 struct DMap
 {
   int v;      // primary variable owned by this thread (-1: none)
@@ -87,21 +92,25 @@ TMX_DEVFN bool dpart_supported(const QpWs& w, int NT)
 TMX_DEVFN void dpart_map(const QpWs& w, const DPart& p, int tid, DMap& m)
 {
   const int D = w.D, ns = (p.P - 1) * D, NI = w.NX - ns;
+  const float rD = 1.0f / (float)D;
   m.v = -1;
   m.sep = false;
   m.k = m.r = m.n = m.slot = 0;
   m.hasl = m.hasr = m.first = m.last = false;
   m.qg = (tid < 4 * ns) ? (tid >> 2) : -1;
   m.qq = tid & 3;
-  m.qv = (m.qg >= 0) ? p.s[m.qg / D] * D + m.qg % D : D;
+  {
+    const int qb = tmx_fdiv(m.qg < 0 ? 0 : m.qg, rD);
+    m.qv = (m.qg >= 0) ? p.s[qb] * D + (m.qg - qb * D) : D;
+  }
   if (tid >= NI)
   {
     const int g = tid - NI;
     if (g < ns)
     {
       m.sep = true;
-      m.k = g / D;
-      m.v = p.s[m.k] * D + g % D;
+      m.k = tmx_fdiv(g, rD);
+      m.v = p.s[m.k] * D + (g - m.k * D);
       m.slot = p.P * w.Gs + g;
     }
     return;
@@ -491,7 +500,7 @@ struct RowRegs
   double rr, rri, z, y, lo, hi, fac;
   double c[8];
   // aux vars (k = 0, 1)
-  double xa[2], za[2], ya[2], qa[2], sa[2], bb[2], di[2], rb[2], rbi[2], ub[2];
+  double xa[2], za[2], ya[2], qa[2], sa[2], bb[2], di[2], ub[2];
 };
 
 // 1 / rho_of_type: rho takes three values per QP, so the reciprocal is a select over three quotients instead of a
@@ -516,8 +525,6 @@ TMX_DEVFN void row_load(const QpWs& w, int r, RowRegs& g)
   for (int k = 0; k < 2; ++k)
   {
     g.xa[k] = g.za[k] = g.ya[k] = g.qa[k] = g.sa[k] = g.bb[k] = g.di[k] = 0.0;
-    g.rb[k] = 1.0;
-    g.rbi[k] = 1.0;
     g.ub[k] = 0.0;
   }
   if (!g.act)
@@ -546,8 +553,6 @@ TMX_DEVFN void row_load(const QpWs& w, int r, RowRegs& g)
       g.sa[k] = w.sa[a];
       g.bb[k] = w.bba[a];
       g.di[k] = w.dinv[a];
-      g.rb[k] = rho_of_type(w.typ_ba[a], w.rho);
-      g.rbi[k] = rcp_rho_of_type(w.typ_ba[a], w.rho);
       g.ub[k] = TMX_OSQP_INFTY * w.Eba[a];
     }
 }
@@ -571,11 +576,14 @@ TMX_DEVFN void row_store(const QpWs& w, int r, const RowRegs& g)
 
 // phase A for one row: returns e_r = g - h and the aux right-hand sides.  Explicit FMAs: the loop is instruction-issue
 // bound, and the reduction orders already differ from the reference's sparse LDL' solve
-TMX_DEVFN double row_phase_a(const RowRegs& g, double sigma, double ta[2])
+// rho of the aux bound rows is one value for the whole QP: an aux var has bounds [0, OSQP_INFTY * E] with
+// E >= MIN_SCALING, so constr_type() is 0 for every one of them and rho_of_type(typ_ba) == rho.  Kept out of the per-row
+// registers (8 VGPRs per row; the loop reloaded 6 spilled doubles from scratch per iteration with them, 2 without)
+TMX_DEVFN double row_phase_a(const RowRegs& g, double sigma, double rho_b, double ta[2])
 {
   const double gg = __builtin_fma(g.rr, g.z, -g.y);
   // both aux rhs are independent chains of depth 3
-  const double gb0 = __builtin_fma(g.rb[0], g.za[0], -g.ya[0]), gb1 = __builtin_fma(g.rb[1], g.za[1], -g.ya[1]);
+  const double gb0 = __builtin_fma(rho_b, g.za[0], -g.ya[0]), gb1 = __builtin_fma(rho_b, g.za[1], -g.ya[1]);
   const double b0 = __builtin_fma(sigma, g.xa[0], -g.qa[0]), b1 = __builtin_fma(sigma, g.xa[1], -g.qa[1]);
   ta[0] = __builtin_fma(g.bb[0], gb0, __builtin_fma(g.sa[0], gg, b0));
   ta[1] = __builtin_fma(g.bb[1], gb1, __builtin_fma(g.sa[1], gg, b1));
@@ -584,7 +592,8 @@ TMX_DEVFN double row_phase_a(const RowRegs& g, double sigma, double ta[2])
 }
 
 // phase C for one row: aux recovery, ztilde, updates.  dot = coef . xtilde(block)
-TMX_DEVFN void row_phase_c(RowRegs& g, double alpha, double dot, const double ta[2], bool keep, double* dyr, double dxa[2], double dya[2])
+TMX_DEVFN void row_phase_c(RowRegs& g, double alpha, double rho_b, double rhoi_b, double dot, const double ta[2], bool keep, double* dyr,
+                           double dxa[2], double dya[2])
 {
   const double om = 1.0 - alpha;
   const double v0 = __builtin_fma(-(g.rr * g.sa[0]), dot, ta[0]), v1 = __builtin_fma(-(g.rr * g.sa[1]), dot, ta[1]);
@@ -607,8 +616,8 @@ TMX_DEVFN void row_phase_c(RowRegs& g, double alpha, double dot, const double ta
     const double xt = k ? xt1 : xt0;
     const double xn = __builtin_fma(alpha, xt, om * g.xa[k]);
     const double zr = __builtin_fma(alpha * g.bb[k], xt, om * g.za[k]);
-    const double zn = clampd(__builtin_fma(g.rbi[k], g.ya[k], zr), 0.0, g.ub[k]);
-    const double dy = g.rb[k] * (zr - zn);
+    const double zn = clampd(__builtin_fma(rhoi_b, g.ya[k], zr), 0.0, g.ub[k]);
+    const double dy = rho_b * (zr - zn);
     if (keep)
     {
       dxa[k] = xn - g.xa[k];
@@ -667,6 +676,7 @@ TMX_DEVFN void admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, b
 #pragma unroll
   for (int q = 0; q < TMX_NROW; ++q)
     row_load(w, rowi[q], g[q]);
+  TMX_PTICK(1);
   DPart dp;
   dpart_make(w.T, dp);
   DMap mp;
@@ -685,6 +695,8 @@ TMX_DEVFN void admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, b
   const double lb = w.lbp[v], ub = w.ubp[v], qv = w.qp[v], bb = w.bbp[v];
   const double rbp = rho_of_type(w.typ_bp[v], w.rho), rbpi = rcp_rho_of_type(w.typ_bp[v], w.rho);
   const double sigma = w.sigma, alpha = w.alpha, om = 1.0 - alpha;
+  // (moving these, sigma and alpha to scalar registers with readfirstlane was measured: -1 .. -2 %)
+  const double rho_b = rho_of_type(0, w.rho), rhoi_b = rcp_rho_of_type(0, w.rho);
   int tb[TMX_NROW];
   bool has[TMX_NROW];
 #pragma unroll
@@ -693,12 +705,16 @@ TMX_DEVFN void admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, b
     tb[q] = g[q].t * 8;  // x~ is exchanged with 8 slots per waypoint
     has[q] = rowi[q] >= 0 && rowi[q] < w.R;
   }
+  TMX_PTICK(2);
   // couplings of this thread's variable / of the separator row it publishes (constant during the solve)
   const double cprev = (pv && v >= D) ? h.po[v - D] : 0.0, cnext = pv ? h.po[v] : 0.0;
   const double qcprev = h.po[mp.qv - D], qcnext = h.po[mp.qv];
   const bool qlead = mp.qg >= 0 && mp.qq == 0;
-  const int qsp = mp.qg < 0 ? 0 : (mp.qg / D) * 8 + mp.qg % D;  // slot of this quad's separator row in the 8-per-separator product buffers
-  const int vp = (v / D) * 8 + v % D, qvp = (mp.qv / D) * 8 + mp.qv % D;  // positions in the padded x~ buffer
+  const float rD = 1.0f / (float)D;
+  const int vt = tmx_fdiv(v, rD), vj = v - vt * D;  // waypoint and joint of this thread's variable
+  const int qgb = tmx_fdiv(mp.qg < 0 ? 0 : mp.qg, rD), qvt = tmx_fdiv(mp.qv, rD);
+  const int qsp = mp.qg < 0 ? 0 : qgb * 8 + (mp.qg - qgb * D);  // slot of this quad's separator row in the 8-per-separator product buffers
+  const int vp = vt * 8 + vj, qvp = qvt * 8 + (mp.qv - qvt * D);  // positions in the padded x~ buffer
   for (int e = tid; e < w.T * 8; e += TMX_QP_NT)
     h.tp[e] = 0.0;
   const bool wr_yl = interior && mp.last && mp.hasr, wr_yr = interior && mp.first && mp.hasl;
@@ -716,7 +732,7 @@ TMX_DEVFN void admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, b
   double cj[16];
   int e0off = 0, q_rest = 0, q_end = 0;
   {
-    const int t = v / D, j = v % D;
+    const int t = vt, j = vj;
     const int q0 = w.wp_start[t], q1 = w.wp_start[t + 1];
 #pragma unroll
     for (int k = 0; k < 16; ++k)
@@ -729,7 +745,8 @@ TMX_DEVFN void admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, b
     q_rest = q0 + 16;
     q_end = pv ? q1 : 0;
   }
-  const int q0v = w.wp_start[v / D];
+  const int q0v = w.wp_start[vt];
+  TMX_PTICK(3);
   // entries of the grouped buffer that no row writes (pad slots, groups of inactive rows) must stay finite
   for (int e = tid; e < w.R + w.T + 18; e += TMX_QP_NT)
     h.hr[e] = 0.0;
@@ -744,7 +761,7 @@ TMX_DEVFN void admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, b
 #pragma unroll
     for (int q = 0; q < TMX_NROW; ++q)
     {
-      const double e = row_phase_a(g[q], sigma, ta[q]);
+      const double e = row_phase_a(g[q], sigma, rho_b, ta[q]);
       if (has[q])
         h.hr[epos[q]] = e;
     }
@@ -770,7 +787,7 @@ TMX_DEVFN void admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, b
       for (int q = q_rest; q < q_end; ++q)
       {
         const int r = w.wp_list[q];
-        ate += w.coef[r * D + (v % D)] * h.hr[e0off + (q - q0v)];
+        ate += w.coef[r * D + (v - tmx_fdiv(v, 1.0f / (float)D) * D)] * h.hr[e0off + (q - q0v)];  // rare path: keeps no extra register live
       }
       h.ty[mp.slot] = __builtin_fma(bb, gb, __builtin_fma(sigma, xp, -qv) + ate);
     }
@@ -826,7 +843,7 @@ TMX_DEVFN void admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, b
                         (__builtin_fma(gq.c[6], xt[6], gq.c[2] * xt[2]) + __builtin_fma(gq.c[7], xt[7], gq.c[3] * xt[3]));
       double dyr0 = 0, dxa0[2], dya0[2];
       if (gq.act)
-        row_phase_c(gq, alpha, d0, ta[q], keep, &dyr0, dxa0, dya0);
+        row_phase_c(gq, alpha, rho_b, rhoi_b, d0, ta[q], keep, &dyr0, dxa0, dya0);
       if (keep && gq.act)
       {
         const int r = rowi[q];

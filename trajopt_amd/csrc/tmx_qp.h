@@ -44,6 +44,17 @@
 #else
 #define TMX_TICK(slot) ((void)0)
 #endif
+// one extra split point inside a phase (slot 5 is unused on the fast path): -DTMX_PROFILE -DTMX_PROFILE_POINT=<n>
+#if TMX_IS_DEVICE && defined(TMX_PROFILE) && defined(TMX_PROFILE_POINT)
+#define TMX_PTICK(n)                                                                                                  \
+  do                                                                                                                  \
+  {                                                                                                                   \
+    if (TMX_PROFILE_POINT == (n))                                                                                     \
+      TMX_TICK(5);                                                                                                    \
+  } while (0)
+#else
+#define TMX_PTICK(n) ((void)0)
+#endif
 
 
 // reciprocal by v_rcp_f64 + two Newton steps (~1 ulp): the IEEE division expands to ~15 instructions with a long
