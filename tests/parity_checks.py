@@ -28,6 +28,8 @@ def cfg(cid, T=None):
         return configs.config_mini(collision_fixed_steps=(5,))   # waypoint 0 (constant rows), none at waypoint 5
     if cid == 12:  # BasicInfo::fixed_dofs: the wrist joint keeps its seed value at every step
         return configs.config_mini(with_joint_band=False, fixed_dofs=[3])
+    if cid == 2:   # puzzle_piece: 300 waypoints, the QP workspace lives in HBM on the device (generic block-chain path)
+        return configs.config2() if T is None else configs.config2(T)
     if cid == 0:
         pci, s, g = configs.config0() if T is None else configs.config0(T)
     else:
@@ -128,3 +130,13 @@ def check_full_sqp(ctx, orc, desc, x0, x_tol=TOL_TRAJ, exact=True):
         assert same.all(), f"status/counters differ: {r['status']} {o['status']} {r['n_qp_solves']} {o['n_qp_solves']}"
         assert dx.max() <= x_tol, f"trajectories differ by {dx.max()}"
     return r, o, same, dx
+
+
+def check_config2_toolpath(pci, x, tol=1e-3):
+    """size-independent property of config 2: every waypoint's tool pose is on the prescribed tool path (the 6-row
+    CartPose constraints hold to the SQP's cnt_tolerance 1e-4 per row) and the fixed first waypoint did not move"""
+    rob = pci.robot
+    for b in range(x.shape[0]):
+        for t, ci in enumerate(pci.cnt_infos):
+            got = rob.fk_tool(x[b, ci.timestep])[:3, :]
+            assert np.abs(got - np.asarray(ci.target_pose)).max() < tol, (b, t)

@@ -19,7 +19,7 @@ def gpu(gpu_ctx_factory):
 _cfg = pc.cfg
 
 
-@pytest.mark.parametrize("cid", [0, 1, 9, 10, 11, 12, 13, 14])
+@pytest.mark.parametrize("cid", [0, 1, 2, 9, 10, 11, 12, 13, 14])
 def test_evaluate_matches_oracle(gpu, orc, cid):
     pci, s, g = _cfg(cid)
     x0 = configs.seeds_for(cid, pci, s, g, 4)
@@ -27,7 +27,7 @@ def test_evaluate_matches_oracle(gpu, orc, cid):
     pc.check_evaluate(gpu, orc, desc, x0, tol=1e-10)   # device libm (sin/cos/atan2) vs glibc: rounding level
 
 
-@pytest.mark.parametrize("cid", [0, 1])
+@pytest.mark.parametrize("cid", [0, 1, 2])
 def test_first_qp_csc_integers_bit_exact(gpu, orc, cid):
     pci, s, g = _cfg(cid)
     x0 = configs.seeds_for(cid, pci, s, g, 3)
@@ -37,7 +37,7 @@ def test_first_qp_csc_integers_bit_exact(gpu, orc, cid):
         pc.check_first_qp_structure(gpu, orc, desc, x0, b, val_tol=1e-9, strict=(cid == 0))
 
 
-@pytest.mark.parametrize("cid", [0, 1, 9, 10, 11, 12, 13, 14])
+@pytest.mark.parametrize("cid", [0, 1, 2, 9, 10, 11, 12, 13, 14])
 def test_first_qp_solve_matches_oracle(gpu, orc, cid):
     pci, s, g = _cfg(cid)
     x0 = configs.seeds_for(cid, pci, s, g, 6)
@@ -85,6 +85,34 @@ def test_full_sqp_config1_statistical(gpu, orc):
     cv, vv = gpu.evaluate()
     assert vv.max() < 1e-3
     assert np.abs(r["total_cost"] - o["total_cost"]).max() < 0.05 * max(1.0, np.abs(o["total_cost"]).max())
+
+
+def test_full_sqp_config2_long_horizon(gpu, orc):
+    """puzzle_piece with all 300 waypoints (QP workspace in HBM, generic block-chain path): identical status and
+    counters, trajectories within 1e-5, tool path followed"""
+    pci, curve, _ = _cfg(2)
+    x0 = configs.seeds_for(2, pci, curve, None, 4)
+    desc = pc.make_ctx_inputs(gpu, pci, x0)
+    r, o, same, dx = pc.check_full_sqp(gpu, orc, desc, x0, exact=False)
+    assert (r["status"] == o["status"]).all() and (r["status"] == abi.OPT_CONVERGED).all()
+    assert same.sum() >= 3 and (dx[same] <= pc.TOL_TRAJ).all()
+    pc.check_config2_toolpath(pci, r["x"])
+
+
+def test_full_batch_properties_config2(gpu):
+    """BASELINE config 2 at its full batch (256 seeds x 300 waypoints): properties that do not need the oracle"""
+    pci, curve, _ = _cfg(2)
+    B = 256
+    x0 = configs.seeds_for(2, pci, curve, None, B)
+    pc.make_ctx_inputs(gpu, pci, x0)
+    gpu.run(0)
+    r = gpu.results()
+    assert (r["status"] == abi.OPT_CONVERGED).all()
+    assert np.abs(r["x"][:, 0, :] - x0[:, 0, :]).max() < 1e-6          # fixed first waypoint
+    assert (r["n_func_evals"] == r["n_qp_solves"] + 1).all()
+    pc.check_config2_toolpath(pci, r["x"][::32])
+    rob = pci.robot
+    assert (r["x"] >= rob.lower - 1e-6).all() and (r["x"] <= rob.upper + 1e-6).all()
 
 
 def test_full_batch_properties(gpu):

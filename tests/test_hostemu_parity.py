@@ -19,7 +19,7 @@ def emu(hostemu_lib):
 _cfg = pc.cfg
 
 
-@pytest.mark.parametrize("cid", [0, 1, 9, 10, 11, 12, 13, 14])
+@pytest.mark.parametrize("cid", [0, 1, 2, 9, 10, 11, 12, 13, 14])
 def test_evaluate_matches_oracle(emu, orc, cid):
     pci, s, g = _cfg(cid)
     x0 = configs.seeds_for(cid, pci, s, g, 3)
@@ -27,7 +27,7 @@ def test_evaluate_matches_oracle(emu, orc, cid):
     pc.check_evaluate(emu, orc, desc, x0, tol=1e-12)
 
 
-@pytest.mark.parametrize("cid", [0, 1, 9, 10, 11, 12, 13, 14])
+@pytest.mark.parametrize("cid", [0, 1, 2, 9, 10, 11, 12, 13, 14])
 def test_first_qp_csc_bit_exact(emu, orc, cid):
     pci, s, g = _cfg(cid)
     x0 = configs.seeds_for(cid, pci, s, g, 2)
@@ -36,7 +36,7 @@ def test_first_qp_csc_bit_exact(emu, orc, cid):
         pc.check_first_qp_structure(emu, orc, desc, x0, b, val_tol=1e-12)
 
 
-@pytest.mark.parametrize("cid", [0, 1, 9, 10, 11, 12, 13, 14])
+@pytest.mark.parametrize("cid", [0, 1, 2, 9, 10, 11, 12, 13, 14])
 def test_first_qp_solve_matches_oracle(emu, orc, cid):
     pci, s, g = _cfg(cid)
     x0 = configs.seeds_for(cid, pci, s, g, 2)
@@ -78,6 +78,17 @@ def test_full_sqp_config1_short_horizon(emu, orc):
     assert (dx[same] <= pc.TOL_TRAJ).all()
     assert same.any()
     assert (r["status"] == o["status"]).all()
+
+
+def test_full_sqp_config2_long_horizon(emu, orc):
+    """puzzle_piece, all 300 waypoints: identical status / counters, trajectories within 1e-5, tool path followed"""
+    pci, curve, _ = _cfg(2)
+    x0 = configs.seeds_for(2, pci, curve, None, 2)
+    desc = pc.make_ctx_inputs(emu, pci, x0)
+    r, o, same, dx = pc.check_full_sqp(emu, orc, desc, x0, exact=False)
+    assert same.all() and (dx <= pc.TOL_TRAJ).all()
+    assert (r["status"] == abi.OPT_CONVERGED).all()
+    pc.check_config2_toolpath(pci, r["x"])
 
 
 def test_error_paths(emu):

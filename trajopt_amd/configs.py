@@ -80,6 +80,8 @@ def config1(n_steps: int = 30, with_collision: bool = True):
 
 
 def seeds_for(config_id: int, pci, start, goal, batch: int, sigma: float = 0.1, first: int = 0):
+    if goal is None:      # config 2: `start` is the whole joint-space curve of the tool path
+        return seeds_config2(pci, start, batch, first=first)
     rob = pci.robot
     return make_seeds(config_id, start, goal, pci.basic_info.n_steps, batch, rob.lower, rob.upper, sigma, first)
 
@@ -167,3 +169,44 @@ def config_wide(n_steps: int = 8):
     pci.obstacles.append(((float(pmid[0]) + 0.03, float(pmid[1]) - 0.02, float(pmid[2]) - 0.15), 0.08))
     pci.cnt_infos.append(JointPosTermInfo(coeffs=[1.0] * D, targets=list(WIDE_GOAL), first_step=n_steps - 1, last_step=n_steps - 1))
     return pci, WIDE_START, WIDE_GOAL
+
+
+# ---- config 2: puzzle_piece ---------------------------------------------------------------------------------
+# 7-DOF, ~300 waypoints, a 6-row CartPose constraint at EVERY waypoint (tool path on a smooth closed curve), JointVel
+# cost, start fixed, no collision (SURVEY.md §8d cfg 2: n = 2100 + 2*1800 = 5700, m = 7 + 1800 + n).  The tool path is
+# the forward kinematics of a smooth closed joint-space curve, so every pose is exactly reachable; seeds are that curve
+# plus noise.
+CFG2_CENTER = np.array([-0.8, 0.3, -1.0, -1.3, 0.4, -0.9, 0.2])
+CFG2_AMPL = np.array([0.35, 0.2, 0.25, 0.3, 0.3, 0.25, 0.4])
+CFG2_PHASE = np.array([0.0, 0.7, 1.4, 2.1, 2.8, 3.5, 4.2])
+
+
+def config2_curve(n_steps: int = 300) -> np.ndarray:
+    s = np.arange(n_steps)[:, None] / float(n_steps)
+    return CFG2_CENTER[None, :] + CFG2_AMPL[None, :] * np.sin(2.0 * np.pi * s + CFG2_PHASE[None, :])
+
+
+def config2(n_steps: int = 300):
+    rob = pr2_right_arm()
+    rob.link_spheres = []
+    D = rob.n_dof
+    curve = config2_curve(n_steps)
+    pci = ProblemConstructionInfo(rob, BasicInfo(n_steps=n_steps, fixed_timesteps=[0]))
+    pci.cost_infos.append(JointVelTermInfo(coeffs=[1.0] * D, targets=[0.0] * D, first_step=0, last_step=n_steps - 1))
+    for t in range(n_steps):
+        pose = rob.fk_tool(curve[t])[:3, :]
+        pci.cnt_infos.append(CartPoseTermInfo(timestep=t, target_pose=pose, pos_coeffs=(1, 1, 1), rot_coeffs=(1, 1, 1),
+                                              is_constraint=True, name=f"toolpath_{t}"))
+    return pci, curve, None
+
+
+def seeds_config2(pci, curve, batch: int, sigma: float = 0.02, first: int = 0) -> np.ndarray:
+    """the joint-space curve + N(0, sigma^2) on every waypoint but the (fixed) first, clipped to the joint limits"""
+    rob = pci.robot
+    out = np.empty((batch,) + curve.shape)
+    for b in range(batch):
+        rng = np.random.Generator(np.random.Philox(key=[2, first + b]))
+        noise = rng.standard_normal(curve.shape) * sigma
+        noise[0] = 0.0
+        out[b] = np.clip(curve + noise, rob.lower + 1e-3, rob.upper - 1e-3)
+    return out

@@ -44,12 +44,13 @@ struct tmx_ctx
   int Bcap{ 0 };
   std::vector<void*> prob_allocs, batch_allocs;
   long long* d_totals{ nullptr };
-  size_t smem_qp{ 0 }, smem_small{ 0 }, smem_pool{ 0 };
+  size_t smem_qp{ 0 }, smem_small{ 0 }, smem_pool{ 0 }, ws_bytes{ 0 };
   int nt_qp{ 64 }, nt_small{ 64 };
   hipEvent_t ev0{ nullptr }, ev1{ nullptr };
   double ms_admm{ 0 }, ms_convexify{ 0 }, ms_evaluate{ 0 };
   long long launches_admm{ 0 };
   bool timing{ true };
+  bool ws_in_hbm{ false };  // QP workspace > 160 KB of LDS: k_*_hbm kernels, workspace carved in HBM (long horizons)
   int mode{ 2 };  // optimize() driver: 0 = one launch chain per step, 1 = k_sqp_fused, 2 = k_sqp_pool (default)
   int pool_wgs{ 0 };  // resident workgroups of the pool kernel (0 = CUs x workgroups-per-CU)
   void* nccl{ nullptr };
@@ -586,22 +587,34 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
   ctx->smem_pool = std::max<size_t>(ctx->smem_qp, 64);
   ctx->pool_wgs = 8;
 #else
-  if (ctx->smem_qp > 160 * 1024)
-  {
-    ctx->err = "QP workspace of " + std::to_string(ctx->smem_qp) +
-               " bytes exceeds the 160 KiB LDS of a gfx950 CU (long-horizon streaming variant is not built yet)";
-    return TMX_ERR_UNSUPPORTED;
-  }
+  // long-horizon problems (config 2: T = 300): neither the QP workspace nor the term scratch fits the 160 KB of LDS;
+  // every kernel then carves its scratch from a per-workgroup HBM slice (k_*_hbm for the QP / fused kernels)
+  ctx->ws_in_hbm = ctx->smem_qp > 160 * 1024;
+  ctx->ws_bytes = ctx->ws_in_hbm ? std::max({ ctx->smem_qp, ctx->smem_small, (size_t)(n_costs + n_cnts + 8) * sizeof(double) }) : 0;
+  if (ctx->ws_in_hbm)
+    ctx->smem_small = 64;
   // one problem per CU when the workspace is large: use 4 waves so the data-parallel phases go 4x wider
   ctx->nt_qp = TMX_QP_NT;
   ctx->nt_small = 64;
-  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_qp_solve), hipFuncAttributeMaxDynamicSharedMemorySize,
-                             static_cast<int>(ctx->smem_qp)));
-  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sqp_fused), hipFuncAttributeMaxDynamicSharedMemorySize,
-                             static_cast<int>(ctx->smem_qp)));
-  ctx->smem_pool = std::max<size_t>(ctx->smem_qp, (2 * TMX_QP_NT + 8) * sizeof(int));
-  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sqp_pool), hipFuncAttributeMaxDynamicSharedMemorySize,
-                             static_cast<int>(ctx->smem_pool)));
+  if (!ctx->ws_in_hbm)
+  {
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_qp_solve), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               static_cast<int>(ctx->smem_qp)));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sqp_fused), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               static_cast<int>(ctx->smem_qp)));
+  }
+  ctx->smem_pool = ctx->ws_in_hbm ? 64 : std::max<size_t>(ctx->smem_qp, (2 * TMX_QP_NT + 8) * sizeof(int));
+  if (!ctx->ws_in_hbm)
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sqp_pool), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               static_cast<int>(ctx->smem_pool)));
+  if (ctx->smem_small > 64 * 1024)
+  {
+    // the term / structure kernels of a long-horizon problem need more than the default 64 KB of dynamic LDS
+    const void* small_kernels[] = { reinterpret_cast<const void*>(k_prepare), reinterpret_cast<const void*>(k_evaluate),
+                                    reinterpret_cast<const void*>(k_convexify), reinterpret_cast<const void*>(k_export_csc) };
+    for (const void* k : small_kernels)
+      HIPCHK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(ctx->smem_small)));
+  }
   {
     // persistent pool size = what is resident at once: CUs x workgroups per CU (LDS- and register-limited)
     int cus = 256, per_cu = 1;
@@ -684,6 +697,9 @@ static tmx_status ensure_batch(tmx_ctx* ctx, int B)
   AL(sched_done, 1);
   H.qp_scratch_stride = (long long)qp_scratch_doubles(P.D, P.T, P.R, P.NA);
   AL(qp_scratch, b * (size_t)H.qp_scratch_stride);
+  H.ws_hbm_stride = ctx->ws_in_hbm ? (long long)((ctx->ws_bytes + 15) / 16 * 2) : 0;  // doubles, 16-byte aligned slices
+  if (ctx->ws_in_hbm)  // stays nullptr otherwise: the kernels test the pointer
+    AL(ws_hbm, b * (size_t)H.ws_hbm_stride);
 #undef AL
   if (!ctx->db)
   {
@@ -769,7 +785,10 @@ tmx_status tmx_sqp_run(tmx_ctx* ctx, int32_t max_steps, int32_t* n_active_out)
   int step = 0;
   if (ctx->mode != 0)
   {
-    if (ctx->mode == 2 && max_steps == 0)
+    if (ctx->ws_in_hbm)
+      TIMED(ctx->ms_admm, ctx->launches_admm++,
+            TMX_LAUNCH(k_sqp_fused_hbm, B, ctx->nt_qp, 0, ctx->stream, ctx->dp, ctx->db, (int)max_steps));
+    else if (ctx->mode == 2 && max_steps == 0)
     {
       const int G = std::min(B, ctx->pool_wgs);
       TIMED(ctx->ms_admm, ctx->launches_admm++,
@@ -802,8 +821,11 @@ tmx_status tmx_sqp_run(tmx_ctx* ctx, int32_t max_steps, int32_t* n_active_out)
     }
     TIMED(ctx->ms_convexify, (void)0,
           TMX_LAUNCH(k_convexify, B, ctx->nt_small, ctx->smem_small, ctx->stream, ctx->dp, ctx->db, 0));
-    TIMED(ctx->ms_admm, ctx->launches_admm++,
-          TMX_LAUNCH(k_qp_solve, B, ctx->nt_qp, ctx->smem_qp, ctx->stream, ctx->dp, ctx->db, 0));
+    if (ctx->ws_in_hbm)
+      TIMED(ctx->ms_admm, ctx->launches_admm++, TMX_LAUNCH(k_qp_solve_hbm, B, ctx->nt_qp, 0, ctx->stream, ctx->dp, ctx->db, 0));
+    else
+      TIMED(ctx->ms_admm, ctx->launches_admm++,
+            TMX_LAUNCH(k_qp_solve, B, ctx->nt_qp, ctx->smem_qp, ctx->stream, ctx->dp, ctx->db, 0));
     TIMED(ctx->ms_evaluate, (void)0,
           TMX_LAUNCH(k_evaluate, B, ctx->nt_small, ctx->smem_small, ctx->stream, ctx->dp, ctx->db, 1));
     TMX_LAUNCH(k_sqp_update, B, 64, (size_t)(ctx->hp.n_costs + ctx->hp.n_cnts + 8) * sizeof(double), ctx->stream, ctx->dp,
@@ -1014,8 +1036,11 @@ tmx_status tmx_qp_solve(tmx_ctx* ctx, double* x_qp, int32_t* cvx_status, tmx_qp_
     return TMX_ERR_STATE;
   HIPCHK(hipSetDevice(ctx->device));
   const size_t B = ctx->hb.B;
-  TIMED(ctx->ms_admm, ctx->launches_admm++,
-        TMX_LAUNCH(k_qp_solve, ctx->hb.B, ctx->nt_qp, ctx->smem_qp, ctx->stream, ctx->dp, ctx->db, 1));
+  if (ctx->ws_in_hbm)
+    TIMED(ctx->ms_admm, ctx->launches_admm++, TMX_LAUNCH(k_qp_solve_hbm, ctx->hb.B, ctx->nt_qp, 0, ctx->stream, ctx->dp, ctx->db, 1));
+  else
+    TIMED(ctx->ms_admm, ctx->launches_admm++,
+          TMX_LAUNCH(k_qp_solve, ctx->hb.B, ctx->nt_qp, ctx->smem_qp, ctx->stream, ctx->dp, ctx->db, 1));
   HIPCHK(hipGetLastError());
   tmx_status rc;
   if ((rc = d2h(ctx, x_qp, ctx->hb.xq, B * ctx->hp.n_max)) != TMX_OK || (rc = d2h(ctx, cvx_status, ctx->hb.cvx, B)) != TMX_OK ||

@@ -3,6 +3,10 @@
 #pragma once
 #include "tmx_solve.h"
 
+// scratch of the term / structure kernels: dynamic LDS, or this workgroup's slice of Bt->ws_hbm for long-horizon
+// problems whose scratch exceeds the LDS (the LDS-resident QP kernels never take this branch: they use smem directly)
+#define TMX_WORK(smem, Bt) ((Bt)->ws_hbm ? (Bt)->ws_hbm + (size_t)blockIdx.x * (size_t)(Bt)->ws_hbm_stride : (smem))
+
 // Optimizer::initialize + the head of optimize(): getClosestFeasiblePoint (quirk Q1: only the upper clamp
 // survives, modeling.cpp:260-271), state reset, persistent/constant rows, first exact evaluation
 // (optimizers.cpp:725, 761-767)
@@ -52,13 +56,19 @@ TMX_KERNEL_LB(256) k_prepare(const DevProblem* P, const DevBatch* Bt)
   }
   TMX_SYNC();
   init_static_rows(P, x0, act, Bt->coef + (size_t)b * R * D, Bt->rhs + (size_t)b * R, tid, NT);
-  evaluate_terms(P, x, Bt->cost_vals + (size_t)b * P->n_costs, Bt->cnt_viols + (size_t)b * P->n_cnts, smem, tid, NT);
+  // (two call sites instead of a pointer select: the select crashes the register allocator of this ROCm 7.2 clang)
+  if (Bt->ws_hbm)
+    evaluate_terms(P, x, Bt->cost_vals + (size_t)b * P->n_costs, Bt->cnt_viols + (size_t)b * P->n_cnts,
+                   Bt->ws_hbm + (size_t)b * (size_t)Bt->ws_hbm_stride, tid, NT);
+  else
+    evaluate_terms(P, x, Bt->cost_vals + (size_t)b * P->n_costs, Bt->cnt_viols + (size_t)b * P->n_cnts, smem, tid, NT);
 }
 
 // which = 0: exact costs/violations at x -> cost_vals/cnt_viols ; which = 1: at xnew -> new_* (skips DONE problems)
 TMX_KERNEL_LB(256) k_evaluate(const DevProblem* P, const DevBatch* Bt, int which)
 {
-  TMX_SMEM(smem);
+  TMX_SMEM(smem_lds);
+  double* smem = TMX_WORK(smem_lds, Bt);
   const int b = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
   if (which == 1 && Bt->phase[b] == PHASE_DONE)
     return;
@@ -71,7 +81,8 @@ TMX_KERNEL_LB(256) k_evaluate(const DevProblem* P, const DevBatch* Bt, int which
 // convexify (K1, K3) + reference QP structure (K4) for problems in PHASE_CONVEXIFY (all problems if force)
 TMX_KERNEL_LB(256) k_convexify(const DevProblem* P, const DevBatch* Bt, int force)
 {
-  TMX_SMEM(smem);
+  TMX_SMEM(smem_lds);
+  double* smem = TMX_WORK(smem_lds, Bt);
   const int b = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
   if (!force && Bt->phase[b] != PHASE_CONVEXIFY)
     return;
@@ -88,7 +99,8 @@ TMX_KERNEL_LB(256) k_convexify(const DevProblem* P, const DevBatch* Bt, int forc
 // export of one problem's QP in reference CSC layout (tests / INTEGRATION: the S1 hand-off format)
 TMX_KERNEL k_export_csc(const DevProblem* P, const DevBatch* Bt, int b, CscOut out, int* dims_out, unsigned long long* hashes_out)
 {
-  TMX_SMEM(smem);
+  TMX_SMEM(smem_lds);
+  double* smem = TMX_WORK(smem_lds, Bt);
   const int tid = threadIdx.x, NT = blockDim.x;
   const int R = P->R, D = P->D;
   qp_structure(P, Bt->active + (size_t)b * R, Bt->coef + (size_t)b * R * D, Bt->rhs + (size_t)b * R,
@@ -115,7 +127,8 @@ TMX_KERNEL_LB2(TMX_QP_NT, TMX_QP_WGS_PER_CU) k_qp_solve(const DevProblem* P, con
 
 TMX_KERNEL k_sqp_update(const DevProblem* P, const DevBatch* Bt)
 {
-  TMX_SMEM(smem);
+  TMX_SMEM(smem_lds);
+  double* smem = TMX_WORK(smem_lds, Bt);
   const int b = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
   sqp_update_block(P, Bt, b, smem, tid, NT);
 }
@@ -184,6 +197,34 @@ TMX_KERNEL_LB2(TMX_QP_NT, TMX_QP_WGS_PER_CU) k_sqp_fused(const DevProblem* P, co
     if (Bt->phase[b] == PHASE_DONE)
       break;
     sqp_step_block(P, Bt, b, smem, tid, NT);
+  }
+}
+
+// Long-horizon variants: the QP workspace does not fit the 160 KB of LDS, so each workgroup carves it in HBM
+// (Bt->ws_hbm) and runs the generic block-chain path of the solver on it.  Same device functions, same results; the
+// workgroup barrier orders the HBM accesses of one workgroup just as it orders LDS.  Separate kernels so that the code
+// generation of the LDS-resident kernels (k_sqp_pool) is untouched.
+TMX_KERNEL_LB2(TMX_QP_NT, 1) k_qp_solve_hbm(const DevProblem* P, const DevBatch* Bt, int force)
+{
+  const int b = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
+  if (!force && Bt->phase[b] == PHASE_DONE)
+    return;
+  double* work = Bt->ws_hbm + (size_t)b * (size_t)Bt->ws_hbm_stride;
+  qp_solve_block(P, Bt, b, work, tid, NT);
+  const double* xq = Bt->xq + (size_t)b * P->n_max;
+  double* xn = Bt->xnew + (size_t)b * P->NX;
+  for (int v = tid; v < P->NX; v += NT)
+    xn[v] = xq[v];
+}
+TMX_KERNEL_LB2(TMX_QP_NT, 1) k_sqp_fused_hbm(const DevProblem* P, const DevBatch* Bt, int max_steps)
+{
+  const int b = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
+  double* work = Bt->ws_hbm + (size_t)b * (size_t)Bt->ws_hbm_stride;
+  for (int step = 0; max_steps == 0 || step < max_steps; ++step)
+  {
+    if (Bt->phase[b] == PHASE_DONE)
+      break;
+    sqp_step_block(P, Bt, b, work, tid, NT);
   }
 }
 

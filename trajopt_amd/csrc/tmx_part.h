@@ -730,6 +730,12 @@ TMX_DEVFN void admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, b
   // column v of A restricted to the rows of its waypoint, kept in registers (first 16 rows; a longer list falls back
   // to a loop for the remainder)
   double cj[16];
+#ifndef TMX_CJX
+#define TMX_CJX 0  // extra cached pairs beyond 16 (config 1's goal waypoint has 17 rows: 7 goal + 2 upright + 8 collision)
+#endif
+#if TMX_CJX
+  double cjx[2 * TMX_CJX];
+#endif
   int e0off = 0, q_rest = 0, q_end = 0;
   {
     const int t = vt, j = vj;
@@ -741,8 +747,17 @@ TMX_DEVFN void admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, b
       const int r = ok ? w.wp_list[q0 + k] : 0;
       cj[k] = ok ? w.coef[r * D + j] : 0.0;
     }
+#if TMX_CJX
+#pragma unroll
+    for (int k = 0; k < 2 * TMX_CJX; ++k)
+    {
+      const bool ok = pv && (q0 + 16 + k < q1);
+      const int r = ok ? w.wp_list[q0 + 16 + k] : 0;
+      cjx[k] = ok ? w.coef[r * D + j] : 0.0;
+    }
+#endif
     e0off = pst(t);
-    q_rest = q0 + 16;
+    q_rest = q0 + 16 + 2 * TMX_CJX;
     q_end = pv ? q1 : 0;
   }
   const int q0v = w.wp_start[vt];
@@ -784,6 +799,16 @@ TMX_DEVFN void admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, b
         a3 = __builtin_fma(cj[2 * k + 3], e2[k + 1].y, a3);
       }
       double ate = (a0 + a1) + (a2 + a3);
+#if TMX_CJX
+      // same order and rounding as the remainder loop below (product, then sum)
+#pragma unroll
+      for (int k = 0; k < TMX_CJX; ++k)
+      {
+        const tmx_d2 ex = ep[8 + k];
+        ate += cjx[2 * k] * ex.x;
+        ate += cjx[2 * k + 1] * ex.y;
+      }
+#endif
       for (int q = q_rest; q < q_end; ++q)
       {
         const int r = w.wp_list[q];

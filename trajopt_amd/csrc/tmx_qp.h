@@ -229,6 +229,16 @@ TMX_HOSTDEVFN int dpart_gstride(int n)
   int h = (n + 2) >> 1;
   return 2 * (h | 1);
 }  // separator rows: 4 lanes x an even number of columns  // row stride: >= n+1 (zero pad column) and even (16-byte rows)
+// the dense nested-dissection solve (tmx_part.h) needs one thread per primary variable and a separator system of at
+// most 64 rows; its LDS region is only reserved for problems it can take (dpart_supported() re-checks at run time)
+TMX_HOSTDEVFN bool dpart_fits(int D, int T)
+{
+  if (D > 8 || D * T > 256)
+    return false;
+  DPart p;
+  dpart_make(T, p);
+  return p.P >= 2 && (p.P - 1) * D <= 64;
+}
 TMX_HOSTDEVFN size_t qp_lds_doubles(int D, int T, int R, int NA)
 {
   const size_t NX = (size_t)D * T;
@@ -236,7 +246,7 @@ TMX_HOSTDEVFN size_t qp_lds_doubles(int D, int T, int R, int NA)
   DPart p;
   dpart_make(T, p);
   const size_t gn = (size_t)p.Lmax * D, nsep = (size_t)(p.P - 1) * D;
-  const size_t dense = (D <= 8) ? (size_t)p.P * gn * dpart_gstride((int)gn) + nsep * dpart_mult8((int)nsep) + 6 * 64 + (size_t)p.P * dpart_gstride((int)gn) + 64 : 0;
+  const size_t dense = dpart_fits(D, T) ? (size_t)p.P * gn * dpart_gstride((int)gn) + nsep * dpart_mult8((int)nsep) + 6 * 64 + (size_t)p.P * dpart_gstride((int)gn) + 64 : 0;
   return NX + 2 + (D <= 8 ? 8 * (size_t)T : NX + 2) + (size_t)R + (size_t)T + 20 + (size_t)T * D * (D <= 8 ? 8 : D) + dense + (size_t)D * D + 256 + 4 + (sizeof(QpWs) + 7) / 8;
 }
 TMX_HOSTDEVFN size_t qp_glb_doubles(int D, int T, int R, int NA)
@@ -282,7 +292,7 @@ TMX_DEVFN void qp_ws_carve(QpWs& w, double* lds, double* glb, double* far, int D
   TAKE(Sinv, T * D * w.DS);  // first: 16-byte aligned for the double2 row loads
   w.G = w.Zs = w.sx = w.ty = nullptr;
   w.Gn = w.Gs = w.Zst = 0;
-  if (D <= 8)
+  if (dpart_fits(D, T))
   {
     DPart dp;
     dpart_make(T, dp);

@@ -85,4 +85,8 @@ struct DevBatch
   double *qp_scratch;  // B x qp_glb_doubles: cold part of the k_qp_solve workspace
   long long qp_scratch_stride;
   long long *prof;  // B x 16 phase cycle counters (thread 0 view, -DTMX_PROFILE builds), accumulated since k_prepare
+  // long-horizon problems whose QP workspace exceeds the 160 KB of LDS (config 2: T = 300): B x ws_hbm_stride doubles, the
+  // k_*_hbm kernels carve the workspace here instead of in LDS (nullptr / 0 otherwise)
+  double *ws_hbm;
+  long long ws_hbm_stride;
 };
