@@ -30,6 +30,8 @@ def cfg(cid, T=None):
         return configs.config_mini(with_joint_band=False, fixed_dofs=[3])
     if cid == 2:   # puzzle_piece: 300 waypoints, the QP workspace lives in HBM on the device (generic block-chain path)
         return configs.config2() if T is None else configs.config2(T)
+    if cid == 3:   # car_seat shape: 10-DOF, 50 waypoints, 20 obstacles (DISCRETE collision variant; workspace in HBM)
+        return configs.config3() if T is None else configs.config3(T)
     if cid == 0:
         pci, s, g = configs.config0() if T is None else configs.config0(T)
     else:

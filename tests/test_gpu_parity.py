@@ -19,7 +19,7 @@ def gpu(gpu_ctx_factory):
 _cfg = pc.cfg
 
 
-@pytest.mark.parametrize("cid", [0, 1, 2, 9, 10, 11, 12, 13, 14])
+@pytest.mark.parametrize("cid", [0, 1, 2, 3, 9, 10, 11, 12, 13, 14])
 def test_evaluate_matches_oracle(gpu, orc, cid):
     pci, s, g = _cfg(cid)
     x0 = configs.seeds_for(cid, pci, s, g, 4)
@@ -37,7 +37,7 @@ def test_first_qp_csc_integers_bit_exact(gpu, orc, cid):
         pc.check_first_qp_structure(gpu, orc, desc, x0, b, val_tol=1e-9, strict=(cid == 0))
 
 
-@pytest.mark.parametrize("cid", [0, 1, 2, 9, 10, 11, 12, 13, 14])
+@pytest.mark.parametrize("cid", [0, 1, 2, 3, 9, 10, 11, 12, 13, 14])
 def test_first_qp_solve_matches_oracle(gpu, orc, cid):
     pci, s, g = _cfg(cid)
     x0 = configs.seeds_for(cid, pci, s, g, 6)
@@ -97,6 +97,20 @@ def test_full_sqp_config2_long_horizon(gpu, orc):
     assert (r["status"] == o["status"]).all() and (r["status"] == abi.OPT_CONVERGED).all()
     assert same.sum() >= 3 and (dx[same] <= pc.TOL_TRAJ).all()
     pc.check_config2_toolpath(pci, r["x"])
+
+
+def test_full_sqp_config3_car_seat_shape(gpu, orc):
+    """10-DOF x 50 waypoints x 20 obstacles (single-time-step collision variant of config 3; workspace in HBM)"""
+    pci, s, g = _cfg(3)
+    B = 8
+    x0 = configs.seeds_for(3, pci, s, g, B, sigma=0.05)
+    desc = pc.make_ctx_inputs(gpu, pci, x0)
+    r, o, same, dx = pc.check_full_sqp(gpu, orc, desc, x0, exact=False)
+    assert (r["status"] == o["status"]).all()
+    assert same.sum() >= B // 2 and (dx[same] <= pc.TOL_TRAJ).all()
+    conv = r["status"] == abi.OPT_CONVERGED
+    assert conv.mean() >= 0.75
+    assert np.abs(r["x"][conv, 0, :] - s[None, :]).max() < 1e-3 and np.abs(r["x"][conv, -1, :] - g[None, :]).max() < 1e-3
 
 
 def test_full_batch_properties_config2(gpu):

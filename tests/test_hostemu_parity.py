@@ -19,7 +19,7 @@ def emu(hostemu_lib):
 _cfg = pc.cfg
 
 
-@pytest.mark.parametrize("cid", [0, 1, 2, 9, 10, 11, 12, 13, 14])
+@pytest.mark.parametrize("cid", [0, 1, 2, 3, 9, 10, 11, 12, 13, 14])
 def test_evaluate_matches_oracle(emu, orc, cid):
     pci, s, g = _cfg(cid)
     x0 = configs.seeds_for(cid, pci, s, g, 3)
@@ -27,7 +27,7 @@ def test_evaluate_matches_oracle(emu, orc, cid):
     pc.check_evaluate(emu, orc, desc, x0, tol=1e-12)
 
 
-@pytest.mark.parametrize("cid", [0, 1, 2, 9, 10, 11, 12, 13, 14])
+@pytest.mark.parametrize("cid", [0, 1, 2, 3, 9, 10, 11, 12, 13, 14])
 def test_first_qp_csc_bit_exact(emu, orc, cid):
     pci, s, g = _cfg(cid)
     x0 = configs.seeds_for(cid, pci, s, g, 2)
@@ -36,7 +36,7 @@ def test_first_qp_csc_bit_exact(emu, orc, cid):
         pc.check_first_qp_structure(emu, orc, desc, x0, b, val_tol=1e-12)
 
 
-@pytest.mark.parametrize("cid", [0, 1, 2, 9, 10, 11, 12, 13, 14])
+@pytest.mark.parametrize("cid", [0, 1, 2, 3, 9, 10, 11, 12, 13, 14])
 def test_first_qp_solve_matches_oracle(emu, orc, cid):
     pci, s, g = _cfg(cid)
     x0 = configs.seeds_for(cid, pci, s, g, 2)
@@ -89,6 +89,16 @@ def test_full_sqp_config2_long_horizon(emu, orc):
     assert same.all() and (dx <= pc.TOL_TRAJ).all()
     assert (r["status"] == abi.OPT_CONVERGED).all()
     pc.check_config2_toolpath(pci, r["x"])
+
+
+def test_full_sqp_config3_car_seat_shape(emu, orc):
+    """10-DOF x 50 waypoints x 20 obstacles (single-time-step collision variant of config 3)"""
+    pci, s, g = _cfg(3)
+    x0 = configs.seeds_for(3, pci, s, g, 2, sigma=0.05)
+    desc = pc.make_ctx_inputs(emu, pci, x0)
+    r, o, same, dx = pc.check_full_sqp(emu, orc, desc, x0, exact=False)
+    assert (r["status"] == o["status"]).all() and (r["status"] == abi.OPT_CONVERGED).all()
+    assert same.any() and (dx[same] <= pc.TOL_TRAJ).all()
 
 
 def test_error_paths(emu):

@@ -210,3 +210,57 @@ def seeds_config2(pci, curve, batch: int, sigma: float = 0.02, first: int = 0) -
         noise[0] = 0.0
         out[b] = np.clip(curve + noise, rob.lower + 1e-3, rob.upper - 1e-3)
     return out
+
+
+# ---- config 3: car_seat (discrete-collision variant) ------------------------------------------------------------
+# 10-DOF = three prismatic positioner axes carrying the 7-DOF arm, 50 waypoints, JointVel cost, start and goal JointPos
+# constraints, a dense collision scene of 20 sphere obstacles.  SURVEY.md §8d cfg 3 asks for the LVS_CONTINUOUS
+# evaluator; the device path lowers the DISCRETE (single time step) evaluator only, so this is the same problem shape
+# (10-DOF blocks, 50 waypoints, ~8000 collision row slots) with single-time-step collision costs — stated wherever it is
+# reported.
+CFG3_START = np.array([0.0, 0.0, 0.0, -1.4, 0.3, -1.0, -1.2, 0.5, -1.0, 0.3])
+CFG3_GOAL = np.array([0.25, -0.2, 0.15, -0.2, 0.25, -0.9, -1.3, 0.4, -1.1, 0.2])
+
+
+def car_seat_robot() -> Robot:
+    arm = pr2_right_arm()
+    types = [1, 1, 1] + list(arm.joint_types)
+    origins = [_tf12(), _tf12(), _tf12()] + list(arm.origins)
+    axes = [np.array([1.0, 0, 0]), np.array([0, 1.0, 0]), np.array([0, 0, 1.0])] + list(arm.axes)
+    rob = Robot(joint_types=types, origins=origins, axes=axes,
+                lower=np.concatenate([[-0.5, -0.5, -0.3], arm.lower]), upper=np.concatenate([[0.5, 0.5, 0.3], arm.upper]),
+                tool=arm.tool)
+    rob.link_spheres = [(link + 3, c, r) for (link, c, r) in arm.link_spheres]
+    return rob
+
+
+def config3(n_steps: int = 50, n_obstacles: int = 20):
+    rob = car_seat_robot()
+    D = rob.n_dof
+    pci = ProblemConstructionInfo(rob, BasicInfo(n_steps=n_steps))
+    pci.cost_infos.append(JointVelTermInfo(coeffs=[1.0] * D, targets=[0.0] * D, first_step=0, last_step=n_steps - 1))
+    pci.cost_infos.append(CollisionTermInfo(first_step=0, last_step=n_steps - 1, dist_pen=0.025, coeff=20.0,
+                                            safety_margin_buffer=0.05))
+    # obstacles scattered (deterministically) around the swept tool path; candidates closer than 0.15 m to the arm in
+    # the start or the goal state are rejected (with a contact at a constrained end point the reference's penalty loop
+    # gives up: the trust region has collapsed by the time the merit coefficient is large enough)
+    def sphere_centres(q):
+        fr = rob.fk_links(q)
+        return [(fr[link] @ np.array([c[0], c[1], c[2], 1.0]))[:3] for (link, c, r) in rob.link_spheres], [r for (_, _, r) in rob.link_spheres]
+    ends = [sphere_centres(CFG3_START), sphere_centres(CFG3_GOAL)]
+    line = np.linspace(CFG3_START, CFG3_GOAL, 11)[2:9]
+    rng = np.random.Generator(np.random.Philox(key=[3, 12345]))
+    k = 0
+    while len(pci.obstacles) < n_obstacles:
+        p = rob.fk_tool(line[k % 7])[:3, 3]
+        k += 1
+        off = rng.standard_normal(3)
+        off = off / np.linalg.norm(off) * (0.14 + 0.12 * rng.random())
+        c, rad = p + off, 0.05 + 0.03 * float(rng.random())
+        if min(np.linalg.norm(c - sc) - sr - rad for cs, rs in ends for sc, sr in zip(cs, rs)) < 0.15:
+            continue
+        pci.obstacles.append(((float(c[0]), float(c[1]), float(c[2])), rad))
+    pci.cnt_infos.append(JointPosTermInfo(coeffs=[1.0] * D, targets=list(CFG3_START), first_step=0, last_step=0, name="start"))
+    pci.cnt_infos.append(JointPosTermInfo(coeffs=[1.0] * D, targets=list(CFG3_GOAL), first_step=n_steps - 1, last_step=n_steps - 1,
+                                          name="goal"))
+    return pci, CFG3_START, CFG3_GOAL
