@@ -1,14 +1,16 @@
 """Phase profile (needs a -DTMX_PROFILE build: make -C trajopt_amd/csrc EXTRA=-DTMX_PROFILE).
-   python tools/prof_phases.py [B] [full|first] [lib.so]   - first QP solve only (default) or the whole optimize() run ("full")"""
+   python tools/prof_phases.py [B] [full|first] [lib.so] [config]   - first QP solve only (default) or the whole optimize() run
+   ("full"); config 1 (default), 2 or 3"""
 import sys, os, ctypes as C, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from trajopt_amd import configs, abi, runtime
-pci, s, g = configs.config1()
+cid = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+pci, s, g = {1: configs.config1, 2: configs.config2, 3: configs.config3}[cid]()
 desc = pci.to_desc()
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 full = len(sys.argv) > 2 and sys.argv[2] == "full"
-x0 = configs.seeds_for(1, pci, s, g, B)
+x0 = configs.seeds_for(cid, pci, s, g, B)
 ctx = runtime.Context(0, sys.argv[3] if len(sys.argv) > 3 else None)
 ctx.upload(desc, abi.default_sqp_params(), abi.default_osqp_settings())
 ctx.set_x0(x0)
@@ -26,7 +28,7 @@ st = ctx.kernel_stats()
 out = (C.c_longlong * 16)()
 ctx.lib.tmx_debug_phase_cycles.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
 ctx.lib.tmx_debug_phase_cycles(ctx.h, out)
-names = ["setup", "WALL(10ns)", "ADMM loop", "check_term", "convexify_terms", "phaseC", "residuals+rho", "polish", "burst entry", "burst exit",
+names = ["setup", "WALL(10ns)", "ADMM loop | generic: phase A", "check_term | generic: phase B", "convexify_terms | generic: chain", "generic: phase C", "residuals+rho", "polish", "burst entry", "burst exit",
          "store", "qp_structure", "eval+update", "f:assemble", "f:G inverses", "f:Schur+Zs"]
 tot = sum(out)
 print("B", B, "kernel ms", st["admm_ms"], "admm iters", iters, "qp solves", nqp, "iters/qp", iters / nqp)

@@ -44,7 +44,7 @@ struct tmx_ctx
   int Bcap{ 0 };
   std::vector<void*> prob_allocs, batch_allocs;
   long long* d_totals{ nullptr };
-  size_t smem_qp{ 0 }, smem_small{ 0 }, smem_pool{ 0 }, ws_bytes{ 0 };
+  size_t smem_qp{ 0 }, smem_small{ 0 }, smem_pool{ 0 }, ws_bytes{ 0 }, smem_chain{ 0 };
   int nt_qp{ 64 }, nt_small{ 64 };
   hipEvent_t ev0{ nullptr }, ev1{ nullptr };
   double ms_admm{ 0 }, ms_convexify{ 0 }, ms_evaluate{ 0 };
@@ -593,6 +593,15 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
   ctx->ws_bytes = ctx->ws_in_hbm ? std::max({ ctx->smem_qp, ctx->smem_small, (size_t)(n_costs + n_cnts + 8) * sizeof(double) }) : 0;
   if (ctx->ws_in_hbm)
     ctx->smem_small = 64;
+  ctx->smem_chain = 0;
+  if (ctx->ws_in_hbm && qp_chain_lds_doubles(D, T) * sizeof(double) <= 160 * 1024)
+  {
+    ctx->smem_chain = qp_chain_lds_doubles(D, T) * sizeof(double);
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_qp_solve_hbm), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               static_cast<int>(ctx->smem_chain)));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sqp_fused_hbm), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               static_cast<int>(ctx->smem_chain)));
+  }
   // one problem per CU when the workspace is large: use 4 waves so the data-parallel phases go 4x wider
   ctx->nt_qp = TMX_QP_NT;
   ctx->nt_small = 64;
@@ -700,6 +709,7 @@ static tmx_status ensure_batch(tmx_ctx* ctx, int B)
   H.ws_hbm_stride = ctx->ws_in_hbm ? (long long)((ctx->ws_bytes + 15) / 16 * 2) : 0;  // doubles, 16-byte aligned slices
   if (ctx->ws_in_hbm)  // stays nullptr otherwise: the kernels test the pointer
     AL(ws_hbm, b * (size_t)H.ws_hbm_stride);
+  H.ws_chain_in_lds = ctx->smem_chain > 0 ? 1 : 0;
 #undef AL
   if (!ctx->db)
   {
@@ -787,7 +797,7 @@ tmx_status tmx_sqp_run(tmx_ctx* ctx, int32_t max_steps, int32_t* n_active_out)
   {
     if (ctx->ws_in_hbm)
       TIMED(ctx->ms_admm, ctx->launches_admm++,
-            TMX_LAUNCH(k_sqp_fused_hbm, B, ctx->nt_qp, 0, ctx->stream, ctx->dp, ctx->db, (int)max_steps));
+            TMX_LAUNCH(k_sqp_fused_hbm, B, ctx->nt_qp, ctx->smem_chain, ctx->stream, ctx->dp, ctx->db, (int)max_steps));
     else if (ctx->mode == 2 && max_steps == 0)
     {
       const int G = std::min(B, ctx->pool_wgs);
@@ -822,7 +832,7 @@ tmx_status tmx_sqp_run(tmx_ctx* ctx, int32_t max_steps, int32_t* n_active_out)
     TIMED(ctx->ms_convexify, (void)0,
           TMX_LAUNCH(k_convexify, B, ctx->nt_small, ctx->smem_small, ctx->stream, ctx->dp, ctx->db, 0));
     if (ctx->ws_in_hbm)
-      TIMED(ctx->ms_admm, ctx->launches_admm++, TMX_LAUNCH(k_qp_solve_hbm, B, ctx->nt_qp, 0, ctx->stream, ctx->dp, ctx->db, 0));
+      TIMED(ctx->ms_admm, ctx->launches_admm++, TMX_LAUNCH(k_qp_solve_hbm, B, ctx->nt_qp, ctx->smem_chain, ctx->stream, ctx->dp, ctx->db, 0));
     else
       TIMED(ctx->ms_admm, ctx->launches_admm++,
             TMX_LAUNCH(k_qp_solve, B, ctx->nt_qp, ctx->smem_qp, ctx->stream, ctx->dp, ctx->db, 0));
@@ -1037,7 +1047,7 @@ tmx_status tmx_qp_solve(tmx_ctx* ctx, double* x_qp, int32_t* cvx_status, tmx_qp_
   HIPCHK(hipSetDevice(ctx->device));
   const size_t B = ctx->hb.B;
   if (ctx->ws_in_hbm)
-    TIMED(ctx->ms_admm, ctx->launches_admm++, TMX_LAUNCH(k_qp_solve_hbm, ctx->hb.B, ctx->nt_qp, 0, ctx->stream, ctx->dp, ctx->db, 1));
+    TIMED(ctx->ms_admm, ctx->launches_admm++, TMX_LAUNCH(k_qp_solve_hbm, ctx->hb.B, ctx->nt_qp, ctx->smem_chain, ctx->stream, ctx->dp, ctx->db, 1));
   else
     TIMED(ctx->ms_admm, ctx->launches_admm++,
           TMX_LAUNCH(k_qp_solve, ctx->hb.B, ctx->nt_qp, ctx->smem_qp, ctx->stream, ctx->dp, ctx->db, 1));

@@ -135,7 +135,7 @@ TMX_KERNEL k_sqp_update(const DevProblem* P, const DevBatch* Bt)
 
 // One trust-region evaluation of problem b: [convexify + QP structure] -> Model::optimize -> exact re-evaluation ->
 // accept / shrink / penalty decisions.  All state lives in HBM between calls.
-TMX_DEVFN void sqp_step_block(const DevProblem* P, const DevBatch* Bt, int b, double* smem, int tid, int NT)
+TMX_DEVFN void sqp_step_block(const DevProblem* P, const DevBatch* Bt, int b, double* smem, int tid, int NT, double* chain_lds = nullptr)
 {
   const int R = P->R, D = P->D, NX = P->NX;
   int* act = Bt->active + (size_t)b * R;
@@ -167,7 +167,7 @@ TMX_DEVFN void sqp_step_block(const DevProblem* P, const DevBatch* Bt, int b, do
   if (tid == 0)
     Bt->prof[(size_t)b * 16 + 11] += TMX_CLK() - tp0;
 #endif
-  qp_solve_block(P, Bt, b, smem, tid, NT);
+  qp_solve_block(P, Bt, b, smem, tid, NT, chain_lds);
 #ifdef TMX_PROFILE
   tp0 = TMX_CLK();
 #endif
@@ -210,7 +210,8 @@ TMX_KERNEL_LB2(TMX_QP_NT, 1) k_qp_solve_hbm(const DevProblem* P, const DevBatch*
   if (!force && Bt->phase[b] == PHASE_DONE)
     return;
   double* work = Bt->ws_hbm + (size_t)b * (size_t)Bt->ws_hbm_stride;
-  qp_solve_block(P, Bt, b, work, tid, NT);
+  TMX_SMEM(lds);
+  qp_solve_block(P, Bt, b, work, tid, NT, Bt->ws_chain_in_lds ? lds : nullptr);
   const double* xq = Bt->xq + (size_t)b * P->n_max;
   double* xn = Bt->xnew + (size_t)b * P->NX;
   for (int v = tid; v < P->NX; v += NT)
@@ -220,11 +221,13 @@ TMX_KERNEL_LB2(TMX_QP_NT, 1) k_sqp_fused_hbm(const DevProblem* P, const DevBatch
 {
   const int b = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
   double* work = Bt->ws_hbm + (size_t)b * (size_t)Bt->ws_hbm_stride;
+  TMX_SMEM(lds);
+  double* chain_lds = Bt->ws_chain_in_lds ? lds : nullptr;
   for (int step = 0; max_steps == 0 || step < max_steps; ++step)
   {
     if (Bt->phase[b] == PHASE_DONE)
       break;
-    sqp_step_block(P, Bt, b, work, tid, NT);
+    sqp_step_block(P, Bt, b, work, tid, NT, chain_lds);
   }
 }
 

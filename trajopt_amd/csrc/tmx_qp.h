@@ -274,6 +274,31 @@ TMX_HOSTDEVFN size_t qp_scratch_doubles(int D, int T, int R, int NA)
   return qp_far_doubles(D, T, R, NA) + (TMX_QP_COLD_IN_LDS ? 0 : qp_glb_doubles(D, T, R, NA));
 }
 
+// long-horizon problems keep their workspace in HBM (k_*_hbm kernels); the arrays the sequential block chain walks -
+// the block factor (stored compactly, DS = D), the coupling, the chain vector and the reduction scratch - are moved into
+// LDS when they fit (T = 300, D = 7: 154 KB), otherwise every chain step is a dependent HBM round trip
+TMX_HOSTDEVFN size_t qp_chain_lds_doubles(int D, int T)
+{
+  const size_t NX = (size_t)D * T;
+  return (size_t)T * D * D + ((D <= 8 && (size_t)T * 8 > NX + 2) ? (size_t)T * 8 : ((NX + 3) & ~(size_t)1)) + NX + (size_t)D * D + 256 + 8;
+}
+TMX_DEVFN void qp_ws_chain_to_lds(QpWs& w, double* lds)
+{
+  const int D = w.D, T = w.T, NX = w.NX;
+  double* p = lds;
+  w.DS = D;
+  w.DDS = D * D;
+  w.Sinv = p;
+  p += (size_t)T * D * D + ((size_t)T * D * D) % 2;
+  w.tp = p;
+  p += (D <= 8 && T * 8 > NX + 2) ? T * 8 : ((NX + 3) & ~1);
+  w.po = p;
+  p += NX + NX % 2;
+  w.gj = p;
+  p += D * D + (D * D) % 2;
+  w.red = p;
+}
+
 TMX_DEVFN void qp_ws_carve(QpWs& w, double* lds, double* glb, double* far, int D, int T, int R, int NA)
 {
   w.D = D;

@@ -449,7 +449,7 @@ static inline void debug_kkt_residual(const QpWs& w, const DevProblem* P, int it
 }
 #endif
 
-TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, double* smem, int tid, int NT)
+TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, double* smem, int tid, int NT, double* chain_lds = nullptr)
 {
   const int D = P->D, T = P->T, NX = P->NX, R = P->R;
   const tmx_osqp_settings& st = P->osqp;
@@ -461,6 +461,8 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
 #else
     qp_ws_carve(w, smem, scratch + qp_far_doubles(D, T, R, P->NA), scratch, D, T, R, P->NA);
 #endif
+    if (chain_lds)  // k_*_hbm kernels only (a constant nullptr everywhere else)
+      qp_ws_chain_to_lds(w, chain_lds);
   }
   long long pc[16] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
   long long tlast = TMX_CLK();

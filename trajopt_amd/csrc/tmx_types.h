@@ -89,4 +89,5 @@ struct DevBatch
   // k_*_hbm kernels carve the workspace here instead of in LDS (nullptr / 0 otherwise)
   double *ws_hbm;
   long long ws_hbm_stride;
+  int ws_chain_in_lds;  // the k_*_hbm launch carries qp_chain_lds_doubles() of dynamic LDS for the block chain
 };
