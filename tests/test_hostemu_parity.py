@@ -110,8 +110,50 @@ def test_error_paths(emu):
     desc.n_dof = 99
     with pytest.raises(runtime.TmxError):
         fresh.upload(desc)      # invalid description
-    sqp = runtime.BatchedTrustRegionSQP(pci, lib_path=None) if False else None
-    assert sqp is None
+
+
+def test_invalid_descriptions_are_rejected_with_the_reference_messages(emu):
+    """C-ABI validation of the flat description (the checks ConstructProblem / TermInfo::hatch make in the reference)"""
+    import ctypes as C
+
+    def expect(mutate, needle, cid=9):
+        pci, s, g = _cfg(cid)
+        desc = pci.to_desc()
+        keep = mutate(desc)
+        with pytest.raises(runtime.TmxError, match=needle):
+            emu.upload(desc)
+        return keep
+
+    def coll_term(desc):
+        return next(desc.terms[k] for k in range(desc.n_terms) if desc.terms[k].kind in (abi.TERM_COLLISION_COST, abi.TERM_COLLISION_CNT))
+
+    def bad_fixed_step(desc):            # problem_description.cpp:1641-1649
+        arr = (C.c_int32 * 1)(desc.n_steps + 3)
+        t = coll_term(desc)
+        t.n_fixed_steps, t.fixed_steps = 1, arr
+        return arr
+    expect(bad_fixed_step, "Fixed step is not between first step and last step")
+
+    def fixed_steps_on_a_joint_term(desc):
+        arr = (C.c_int32 * 1)(0)
+        t = next(desc.terms[k] for k in range(desc.n_terms) if desc.terms[k].kind == abi.TERM_JOINT_VEL_COST)
+        t.n_fixed_steps, t.fixed_steps = 1, arr
+        return arr
+    expect(fixed_steps_on_a_joint_term, "only collision terms carry fixed steps")
+
+    def bad_step_range(desc):
+        coll_term(desc).last_step = desc.n_steps
+    expect(bad_step_range, "term step range invalid")
+
+    def bad_fixed_dof(desc):             # problem_description.cpp:515
+        arr = (C.c_int32 * 1)(desc.n_dof)
+        desc.n_fixed_dofs, desc.fixed_dofs = 1, arr
+        return arr
+    expect(bad_fixed_dof, "DOF\\(aka Joint\\) indice is greater than the number of DOF available")
+
+    def unknown_kind(desc):
+        desc.terms[0].kind = 77
+    expect(unknown_kind, "term kind not lowered by the device path")
 
 
 def test_initialize_rejects_wrong_length(hostemu_lib):

@@ -251,7 +251,7 @@ TMX_KERNEL_LB2(TMX_QP_NT, TMX_QP_WGS_PER_CU) k_sqp_pool(const DevProblem* P, con
   const int tid = threadIdx.x, NT = blockDim.x;
   const int B = Bt->B;
   int* ibuf = reinterpret_cast<int*>(smem);  // [2NT]: decision broadcast (the reduction scratch sits at smem + 8)
-  unsigned spins = 0;
+  [[maybe_unused]] unsigned spins = 0;
   while (true)
   {
     // ---- scan: least n_qp among the ready problems; ties are broken by the distance from a workgroup-specific start
