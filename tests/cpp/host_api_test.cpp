@@ -452,6 +452,90 @@ static void caseNumericalIk(const Input& in)
   printResults("numerical_ik1", opt);
 }
 
+// ---- trajopt/test/cart_position_optimization_unit.cpp:55-141 ----------------------------------------------------------
+static void caseCartPosition(const Input& in)
+{
+  auto env = makeEnv(in, "right_arm", "pr2_right_arm", DblVec(7, 0.0), false);
+  ProblemConstructionInfo pci(env);
+  pci.basic_info.n_steps = 1;
+  pci.basic_info.manip = "right_arm";
+  pci.basic_info.use_time = false;
+  pci.resolveKin();
+  const DblVec start_pos = { 0, 0, 0, -1.0, 0, -1, 0.0 };
+  pci.init_info.type = InitInfo::GIVEN_TRAJ;
+  pci.init_info.data = TrajArray(1, 7, 0.0);
+  const Transform target_pose = fkTool(*pci.kin, start_pos);
+  auto pose = std::make_shared<CartPoseTermInfo>();
+  pose->term_type = TermType::TT_CNT;
+  pose->name = "waypoint_cart_0";
+  pose->timestep = 0;
+  pose->source_frame = "r_gripper_tool_frame";
+  pose->target_frame = "world";  // the stand-in's FK is expressed in the chain base = world here
+  pose->target_frame_offset = target_pose;
+  pose->pos_coeffs = { { 1, 1, 1 } };
+  pose->rot_coeffs = { { 1, 1, 1 } };
+  pci.cnt_infos.push_back(pose);
+  auto prob = ConstructProblem(pci);
+  BasicTrustRegionSQPBatchedHip opt(prob);
+  opt.initialize(tmx::sco::trajToDblVec(prob->GetInitTraj()));
+  opt.optimize();
+  const Transform optimized_pose = fkTool(*pci.kin, opt.x());
+  // Eigen isApprox(a, b, p): ||a - b|| <= p * min(||a||, ||b||)  (:137-140)
+  double dn = 0, na = 0, nb = 0;
+  for (std::size_t r = 0; r < 3; ++r)
+  {
+    const double a = target_pose.m[r * 4 + 3], b = optimized_pose.m[r * 4 + 3];
+    dn += (a - b) * (a - b);
+    na += a * a;
+    nb += b * b;
+  }
+  EXPECT_TRUE(std::sqrt(dn) <= 1e-4 * std::sqrt(std::min(na, nb)));
+  for (std::size_t r = 0; r < 3; ++r)
+    for (std::size_t c = 0; c < 3; ++c)
+      EXPECT_NEAR(target_pose.m[r * 4 + c], optimized_pose.m[r * 4 + c], 2e-5);  // quaternion isApprox 1e-5
+  printResults("cart_position", opt);
+}
+
+// ---- trajopt/test/interface_unit.cpp:50-90 (initial trajectory through the C++ interface) and :236-262 (bitmask) --------
+static void caseInterface(const Input& in)
+{
+  const int steps = 13;
+  auto env = makeEnv(in, "right_arm", "pr2_right_arm", DblVec(7, 0.25), false);
+  ProblemConstructionInfo pci(env);
+  pci.basic_info.n_steps = steps;
+  pci.basic_info.manip = "right_arm";
+  pci.basic_info.use_time = false;
+  pci.resolveKin();
+  pci.init_info.type = InitInfo::STATIONARY;
+  auto jv = std::make_shared<JointPosTermInfo>();
+  jv->coeffs = DblVec(7, 10.0);
+  jv->targets = DblVec(7, 0.0);
+  jv->first_step = 0;
+  jv->last_step = pci.basic_info.n_steps - 1;
+  jv->name = "joint_pos_all";
+  jv->term_type = TermType::TT_COST;
+  pci.cost_infos.push_back(jv);
+  const TrajOptProb::Ptr prob = ConstructProblem(pci);
+  EXPECT_TRUE(!!prob);
+  const TrajArray initial_trajectory = prob->GetInitTraj();
+  EXPECT_TRUE(initial_trajectory.cols() == static_cast<int>(prob->GetKin()->numJoints()));
+  EXPECT_TRUE(steps == initial_trajectory.rows());
+  for (double v : initial_trajectory.data)
+    EXPECT_TRUE(v == 0.25);  // STATIONARY: the environment's current state in every row
+  // bitmask_test
+  const TermType types[] = { TermType::TT_CNT, TermType::TT_COST, TermType::TT_CNT | TermType::TT_USE_TIME,
+                             TermType::TT_COST | TermType::TT_USE_TIME };
+  const bool cost[] = { false, true, false, true }, cnt[] = { true, false, true, false }, time[] = { false, false, true, true };
+  for (std::size_t i = 0; i < 4; ++i)
+  {
+    EXPECT_TRUE(static_cast<bool>(types[i] & TermType::TT_COST) == cost[i]);
+    EXPECT_TRUE(static_cast<bool>(types[i] & TermType::TT_CNT) == cnt[i]);
+    EXPECT_TRUE(static_cast<bool>(types[i] & TermType::TT_USE_TIME) == time[i]);
+    EXPECT_TRUE(static_cast<bool>(~(types[i] | ~TermType::TT_USE_TIME)) == !time[i]);
+  }
+  std::printf("INTERFACE done\n");
+}
+
 // ---- error behaviour: where the reference PRINT_AND_THROWs, this layer throws std::runtime_error -----------------------
 static void caseErrors(const Input& in, bool have_device)
 {
@@ -591,6 +675,10 @@ int main(int argc, char** argv)
         caseJointCosts(in);
       else if (c == "numerical_ik")
         caseNumericalIk(in);
+      else if (c == "cart_position")
+        caseCartPosition(in);
+      else if (c == "interface")
+        caseInterface(in);
       else if (c == "errors")
         caseErrors(in, true);
       else if (c == "errors_nodevice")

@@ -2,7 +2,8 @@
 BasicTrustRegionSQP interface above the C-ABI) driven by tests/cpp/host_api_test.cpp.
 
 The C++ program builds the problems the way the reference's own C++ tests do and checks their assertions itself
-(joint_costs_unit.cpp equality_jointPos / inequality_jointPos, numerical_ik_unit.cpp, error behaviour).  Here we
+(joint_costs_unit.cpp equality_jointPos / inequality_jointPos, numerical_ik_unit.cpp, cart_position_optimization_unit.cpp,
+interface_unit.cpp initial trajectory + bitmask, error behaviour).  Here we
 additionally require that the C++ lowering and the Python lowering (trajopt_amd/problem.py) are THE SAME problem:
 both front ends on the same library must return bit-identical trajectories, statuses and counters.
 CPU tier: linked against the kernel sources built for the host (tests/hostemu).  GPU tier: libtrajopt_mi355x.so."""
@@ -119,9 +120,9 @@ def test_cpp_front_end_equals_python_front_end_on_host_build(hostemu_lib, inputs
 
 def test_cpp_reference_kats_on_host_build(hostemu_lib, inputs, orc):
     exe = _build(hostemu_lib, "hostemu")
-    res, _, out = _run(exe, inputs["path"], "joint_costs,numerical_ik,errors")
-    assert "ERRORS done" in out
-    assert set(res) == {"equality_jointPos", "inequality_jointPos", "numerical_ik1"}
+    res, _, out = _run(exe, inputs["path"], "joint_costs,numerical_ik,cart_position,interface,errors")
+    assert "ERRORS done" in out and "INTERFACE done" in out
+    assert set(res) == {"equality_jointPos", "inequality_jointPos", "numerical_ik1", "cart_position"}
     assert all(r[0]["status"] == 0 for r in res.values())
 
 
@@ -141,5 +142,5 @@ def test_cpp_front_end_on_device(inputs):
     assert os.path.exists(PRODUCT_LIB), "libtrajopt_mi355x.so missing: run __graft_entry__.build()"
     exe = _build(PRODUCT_LIB, "product")
     _check_front_ends(exe, inputs, None)
-    res, _, out = _run(exe, inputs["path"], "joint_costs,numerical_ik,errors")
-    assert "ERRORS done" in out and all(r[0]["status"] == 0 for r in res.values())
+    res, _, out = _run(exe, inputs["path"], "joint_costs,numerical_ik,cart_position,interface,errors")
+    assert "ERRORS done" in out and "INTERFACE done" in out and all(r[0]["status"] == 0 for r in res.values())

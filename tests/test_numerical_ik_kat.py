@@ -1,4 +1,4 @@
-"""Reference KAT for a single-waypoint problem: trajopt/test/numerical_ik_unit.cpp ("numerical_ik1") with the fixture
+"""Reference KATs for single-waypoint problems (numerical IK and cart_position_optimization_unit.cpp, further below): trajopt/test/numerical_ik_unit.cpp ("numerical_ik1") with the fixture
 trajopt_common/data/config/numerical_ik1.json — PR2 left arm, n_steps = 1, one 6-row cart_pose CONSTRAINT on
 l_gripper_tool_frame with target base_footprint * (xyz 0.4 0 0.8, wxyz 0 0 1 0), stationary init, the optimizer started
 from all-zero joints (:95).  The reference asserts (:112-124) that every entry of the final tool pose (in the world /
@@ -102,3 +102,61 @@ def test_numerical_ik_device(orc):
     assert np.abs(r["x"] - r["x"][:1]).max() == 0.0      # identical seeds -> bit-identical results within one run
     opt.ctx.close()
     _first_iteration_parity(orc, pp, None)
+
+
+# ---- trajopt/test/cart_position_optimization_unit.cpp:55-141 -------------------------------------------------------------
+# PR2 right arm, n_steps = 1, GIVEN_TRAJ init at zero, one 6-row cart_pose CONSTRAINT whose target is the forward
+# kinematics of the joint state (0, 0, 0, -1, 0, -1, 0).  The reference expects the optimised tool position within 1e-4
+# (relative, Eigen isApprox) and the orientation quaternion within 1e-5 of the target.  Same degenerate structure as the
+# numerical-IK problem (7 joints, 6 rows, no cost), so the same parity statement applies.
+def _cart_position_problem():
+    from trajopt_amd.problem import BasicInfo, CartPoseTermInfo, ProblemConstructionInfo, pr2_right_arm
+    rob = pr2_right_arm()
+    rob.link_spheres = []
+    target = rob.fk_tool(np.array([0.0, 0.0, 0.0, -1.0, 0.0, -1.0, 0.0]))
+    pci = ProblemConstructionInfo(rob, BasicInfo(n_steps=1))
+    pci.cnt_infos.append(CartPoseTermInfo(timestep=0, target_pose=target[:3, :], pos_coeffs=(1, 1, 1), rot_coeffs=(1, 1, 1),
+                                          is_constraint=True, name="waypoint_cart_0"))
+    return pci, rob, target
+
+
+def _quat(Rm):
+    w = 0.5 * np.sqrt(max(0.0, 1.0 + Rm[0, 0] + Rm[1, 1] + Rm[2, 2]))
+    return np.array([w, (Rm[2, 1] - Rm[1, 2]) / (4 * w), (Rm[0, 2] - Rm[2, 0]) / (4 * w), (Rm[1, 0] - Rm[0, 1]) / (4 * w)])
+
+
+def _check_cart_position(rob, target, q, status):
+    assert status == abi.OPT_CONVERGED
+    got = rob.fk_tool(np.asarray(q))
+    # Eigen isApprox(a, b, p): ||a - b|| <= p * min(||a||, ||b||)
+    assert np.linalg.norm(got[:3, 3] - target[:3, 3]) <= 1e-4 * min(np.linalg.norm(got[:3, 3]), np.linalg.norm(target[:3, 3]))
+    qa, qb = _quat(target[:3, :3]), _quat(got[:3, :3])
+    assert min(np.linalg.norm(qa - qb), np.linalg.norm(qa + qb)) <= 1e-5
+
+
+def test_cart_position_oracle(orc):
+    pci, rob, target = _cart_position_problem()
+    o = orc.sqp_batch(pci.to_desc(), np.zeros((1, 1, 7)))
+    _check_cart_position(rob, target, o["x"][0, 0], o["status"][0])
+
+
+def test_cart_position_kernel_sources_on_host(hostemu_lib):
+    pci, rob, target = _cart_position_problem()
+    opt = runtime.BatchedTrustRegionSQP(pci, lib_path=hostemu_lib)
+    opt.initialize(np.zeros((1, 1, 7)))
+    opt.optimize()
+    r = opt.results()
+    _check_cart_position(rob, target, r["x"][0, 0], r["status"][0])
+    opt.ctx.close()
+
+
+@pytest.mark.gpu
+def test_cart_position_device():
+    pci, rob, target = _cart_position_problem()
+    opt = runtime.BatchedTrustRegionSQP(pci)
+    opt.initialize(np.zeros((2, 1, 7)))
+    opt.optimize()
+    r = opt.results()
+    for b in range(2):
+        _check_cart_position(rob, target, r["x"][b, 0], r["status"][b])
+    opt.ctx.close()
