@@ -238,6 +238,13 @@ TMX_API tmx_status tmx_sqp_results(tmx_ctx* ctx, double* x /*B*T*D*/, int32_t* s
 TMX_API tmx_status tmx_sqp_counters(tmx_ctx* ctx, int64_t* n_func_evals, int64_t* n_qp_solves, int64_t* n_admm_iters);
 /* per-problem QP records of the run, in solve order: out[problem*max_records + k]; counts[problem]      */
 TMX_API tmx_status tmx_sqp_qp_records(tmx_ctx* ctx, tmx_qp_record* out, int32_t max_records, int32_t* counts);
+/* Per-problem optimizer state between bounded tmx_sqp_run(ctx, max_steps > 0, ...) calls: the loop variables of
+   BasicTrustRegionSQP::optimize (trajopt_sco/src/optimizers.cpp:742-760: merit_increases, iter, trust_box_size_) that its
+   per-iteration log table (:428-647, :708-718) and its callbacks (:754, invoked before every SQP iteration) observe.
+   A host that wants the reference's per-iteration callbacks / logs steps the batch with max_steps = 1 and reads this
+   together with tmx_sqp_results / tmx_evaluate.  Any output pointer may be NULL.  done[b] = 1 once problem b finished. */
+TMX_API tmx_status tmx_sqp_state(tmx_ctx* ctx, int32_t* sqp_iter /*B*/, int32_t* merit_increases /*B*/,
+                                 double* trust_box_size /*B*/, int32_t* done /*B*/);
 
 /* ---- piecewise entry points (the hooks BasicTrustRegionSQP exposes "to allow overriding",
  *      optimizers.hpp:137-194): evaluateCosts/evaluateConstraintViols, convexify*, Model::optimize ---- */

@@ -775,6 +775,21 @@ public:
   /** OSQPModelConfig::settings (osqp_interface.cpp:78-90 defaults) */
   tmx_osqp_settings& getOSQPSettings() { return osqp_; }
   void addCallback(const Callback& cb) { callbacks_.push_back(cb); }  // invoked once per optimize(), on the best seed
+  /** the loop variables the reference's per-iteration log shows (optimizers.cpp:742-760) */
+  struct IterationInfo
+  {
+    std::size_t seed{ 0 };
+    int sqp_iter{ 0 };
+    int merit_increases{ 0 };
+    double trust_box_size{ 0 };
+    bool at_exit{ false };
+  };
+  using IterationCallback = std::function<void(const IterationInfo&, OptResults&)>;
+  /** Per-iteration observability: the callback runs before every SQP iteration of every seed and once when the seed
+      finishes, as Optimizer callbacks do in the reference (optimizers.cpp:754, :978).  With such a callback the batch
+      is stepped one trust-region evaluation per launch (tmx_sqp_run(max_steps = 1)) instead of running in the
+      persistent kernel; the results are identical. */
+  void addIterationCallback(const IterationCallback& cb) { iteration_callbacks_.push_back(cb); }
 
   /** Optimizer::initialize (optimizers.cpp:127-136): one seed, x in j_t_d order (row-major n_steps x n_dof) */
   void initialize(const DblVec& x) { initialize(std::vector<DblVec>{ x }); }
@@ -805,7 +820,10 @@ public:
     const tmx_sqp_params p = param_.toTmx();
     check(tmx_problem_upload(ctx_, &prob_->desc(), &p, &osqp_));
     check(tmx_batch_set_x0(ctx_, seeds_.data(), batch_));
-    check(tmx_sqp_run(ctx_, 0, nullptr));
+    if (iteration_callbacks_.empty())
+      check(tmx_sqp_run(ctx_, 0, nullptr));
+    else
+      runStepwise();
     const std::size_t B = static_cast<std::size_t>(batch_), nv = numVars();
     std::vector<double> x(B * nv), cost(B);
     std::vector<int32_t> status(B), nfe(B), nqp(B);
@@ -845,6 +863,61 @@ public:
   tmx_ctx* context() { return ctx_; }
 
 private:
+  void runStepwise()
+  {
+    const std::size_t B = static_cast<std::size_t>(batch_), nv = numVars();
+    int32_t n_costs = 0, n_cnts = 0, n_slots = 0;
+    std::vector<long long> seen(B, -1);
+    std::vector<char> finished(B, 0);
+    std::vector<double> x(B * nv), cost(B), trust(B);
+    std::vector<int32_t> status(B), nfe(B), nqp(B), it(B), mi(B), done(B);
+    while (true)
+    {
+      check(tmx_sqp_results(ctx_, x.data(), status.data(), cost.data(), nfe.data(), nqp.data()));
+      check(tmx_sqp_state(ctx_, it.data(), mi.data(), trust.data(), done.data()));
+      check(tmx_term_counts(ctx_, &n_costs, &n_cnts, &n_slots));
+      std::vector<double> cv(B * static_cast<std::size_t>(n_costs)), vv(B * static_cast<std::size_t>(n_cnts));
+      check(tmx_evaluate(ctx_, cv.data(), vv.data()));
+      bool all = true;
+      for (std::size_t b = 0; b < B; ++b)
+      {
+        if (finished[b])
+          continue;
+        const long long key = static_cast<long long>(mi[b]) * 100000 + it[b];
+        const bool fire = done[b] || key != seen[b];
+        if (done[b])
+          finished[b] = 1;
+        else
+        {
+          seen[b] = key;
+          all = false;
+        }
+        if (!fire)
+          continue;
+        OptResults r;
+        r.x.assign(x.begin() + static_cast<std::ptrdiff_t>(b * nv), x.begin() + static_cast<std::ptrdiff_t>((b + 1) * nv));
+        r.status = static_cast<OptStatus>(status[b]);
+        r.total_cost = cost[b];
+        r.n_func_evals = nfe[b];
+        r.n_qp_solves = nqp[b];
+        r.cost_vals.assign(cv.begin() + static_cast<std::ptrdiff_t>(b * static_cast<std::size_t>(n_costs)),
+                           cv.begin() + static_cast<std::ptrdiff_t>((b + 1) * static_cast<std::size_t>(n_costs)));
+        r.cnt_viols.assign(vv.begin() + static_cast<std::ptrdiff_t>(b * static_cast<std::size_t>(n_cnts)),
+                           vv.begin() + static_cast<std::ptrdiff_t>((b + 1) * static_cast<std::size_t>(n_cnts)));
+        IterationInfo info;
+        info.seed = b;
+        info.sqp_iter = it[b];
+        info.merit_increases = mi[b];
+        info.trust_box_size = trust[b];
+        info.at_exit = done[b] != 0;
+        for (auto& cb : iteration_callbacks_)
+          cb(info, r);
+      }
+      if (all)
+        break;
+      check(tmx_sqp_run(ctx_, 1, nullptr));
+    }
+  }
   std::size_t numVars() const { return static_cast<std::size_t>(prob_->GetNumSteps()) * static_cast<std::size_t>(prob_->GetNumDOF()); }
   void check(tmx_status s)
   {
@@ -861,6 +934,7 @@ private:
   std::vector<OptResults> batch_results_;
   std::size_t best_{ 0 };
   std::vector<Callback> callbacks_;
+  std::vector<IterationCallback> iteration_callbacks_;
 };
 
 /** trajToDblVec (trajopt/include/trajopt/utils.hpp:18): row-major flattening of a TrajArray */

@@ -248,6 +248,25 @@ static void caseCfg0(const Input& in)
     }
   }
   printResults("cfg0", opt);
+  // the same batch with per-iteration callbacks (stepped launches): identical results, one call per SQP iteration + exit
+  BasicTrustRegionSQPBatchedHip stepped(prob);
+  std::vector<int> n_calls(seeds.size(), 0), n_exit(seeds.size(), 0);
+  stepped.addIterationCallback([&](const BasicTrustRegionSQPBatchedHip::IterationInfo& info, tmx::sco::OptResults& r) {
+    ++n_calls[info.seed];
+    if (info.at_exit)
+      ++n_exit[info.seed];
+    else if (n_calls[info.seed] == 1)
+      EXPECT_TRUE(info.sqp_iter == 1 && info.merit_increases == 0 && r.n_qp_solves == 0 && info.trust_box_size == 0.1);
+    EXPECT_TRUE(r.x.size() == 70 && r.cost_vals.size() == 1 && r.cnt_viols.size() == 1);
+  });
+  stepped.initialize(seeds);
+  stepped.optimize();
+  for (std::size_t b = 0; b < seeds.size(); ++b)
+  {
+    EXPECT_TRUE(n_exit[b] == 1 && n_calls[b] >= 2);
+    EXPECT_TRUE(stepped.batchResults()[b].x == opt.batchResults()[b].x);
+    EXPECT_TRUE(stepped.batchResults()[b].n_qp_solves == opt.batchResults()[b].n_qp_solves);
+  }
 }
 
 // ---- config 1: glass_upright (SURVEY.md §8d cfg 1) with a handful of seeds -------------------------------------------

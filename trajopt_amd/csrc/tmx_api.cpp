@@ -884,6 +884,28 @@ tmx_status tmx_sqp_counters(tmx_ctx* ctx, int64_t* n_func_evals, int64_t* n_qp_s
   return TMX_OK;
 }
 
+tmx_status tmx_sqp_state(tmx_ctx* ctx, int32_t* sqp_iter, int32_t* merit_increases, double* trust_box_size, int32_t* done)
+{
+  if (!ctx)
+    return TMX_ERR_INVALID;
+  if (ctx->Bcap == 0)
+    return TMX_ERR_STATE;
+  HIPCHK(hipSetDevice(ctx->device));
+  const size_t B = ctx->hb.B;
+  tmx_status rc;
+  std::vector<int> phase(done ? B : 0);
+  if ((sqp_iter && (rc = d2h(ctx, sqp_iter, ctx->hb.iter, B)) != TMX_OK) ||
+      (merit_increases && (rc = d2h(ctx, merit_increases, ctx->hb.merit_inc, B)) != TMX_OK) ||
+      (trust_box_size && (rc = d2h(ctx, trust_box_size, ctx->hb.trust, B)) != TMX_OK) ||
+      (done && (rc = d2h(ctx, phase.data(), ctx->hb.phase, B)) != TMX_OK))
+    return rc;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (done)
+    for (size_t b = 0; b < B; ++b)
+      done[b] = phase[b] == PHASE_DONE ? 1 : 0;
+  return TMX_OK;
+}
+
 tmx_status tmx_sqp_qp_records(tmx_ctx* ctx, tmx_qp_record* out, int32_t max_records, int32_t* counts)
 {
   if (!ctx || max_records < 0)

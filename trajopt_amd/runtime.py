@@ -38,6 +38,7 @@ _SIGS = {
     "tmx_attach_nccl": ([C.c_void_p, C.c_void_p], C.c_int),
     "tmx_kernel_stats": ([C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)], C.c_int),
     "tmx_kernel_stats_reset": ([C.c_void_p], C.c_int),
+    "tmx_sqp_state": ([C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p], C.c_int),
 }
 ABI_SYMBOLS = tuple(_SIGS.keys())
 
@@ -130,6 +131,14 @@ class Context:
         self._chk(self.lib.tmx_sqp_results(self.h, _ptr(x), _ptr(status), _ptr(cost), _ptr(nfe), _ptr(nqp)))
         return dict(x=x, status=status, total_cost=cost, n_func_evals=nfe, n_qp_solves=nqp)
 
+    def state(self):
+        """loop variables of BasicTrustRegionSQP::optimize per problem (between bounded run() calls)"""
+        B = self.B
+        it, mi, done = np.zeros(B, np.int32), np.zeros(B, np.int32), np.zeros(B, np.int32)
+        trust = np.zeros(B)
+        self._chk(self.lib.tmx_sqp_state(self.h, _ptr(it), _ptr(mi), _ptr(trust), _ptr(done)))
+        return dict(sqp_iter=it, merit_increases=mi, trust_box_size=trust, done=done.astype(bool))
+
     def counters(self):
         a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
         self._chk(self.lib.tmx_sqp_counters(self.h, C.byref(a), C.byref(b), C.byref(c)))
@@ -199,6 +208,7 @@ class BatchedTrustRegionSQP:
         self.params = abi.default_sqp_params()
         self.osqp = abi.default_osqp_settings()
         self._uploaded = False
+        self._callbacks = []
 
     def setParameters(self, params: abi.SqpParams):
         self.params = params
@@ -219,8 +229,43 @@ class BatchedTrustRegionSQP:
             self._uploaded = True
         self.ctx.set_x0(x)
 
+    def addCallback(self, cb):
+        """Optimizer::addCallback (optimizers.hpp:83-84).  cb(problem_index, results) with results = dict(x, status,
+        total_cost, cost_vals, cnt_viols, n_func_evals, n_qp_solves, sqp_iter, merit_increases, trust_box_size): called
+        before every SQP iteration of every seed and once more when the seed finishes, like the reference
+        (optimizers.cpp:754, :978).  With callbacks the batch is stepped one trust-region evaluation per launch instead of
+        running in the persistent kernel - an observability mode, not the fast path."""
+        self._callbacks.append(cb)
+
+    def _fire(self, b, r, cv, vv, st):
+        res = dict(x=r["x"][b], status=int(r["status"][b]), total_cost=float(r["total_cost"][b]), cost_vals=cv[b], cnt_viols=vv[b],
+                   n_func_evals=int(r["n_func_evals"][b]), n_qp_solves=int(r["n_qp_solves"][b]), sqp_iter=int(st["sqp_iter"][b]),
+                   merit_increases=int(st["merit_increases"][b]), trust_box_size=float(st["trust_box_size"][b]))
+        for cb in self._callbacks:
+            cb(b, res)
+
     def optimize(self):
-        self.ctx.run(0)
+        if not self._callbacks:
+            self.ctx.run(0)
+            return self.ctx.results()["status"]
+        B = self.ctx.B
+        seen_iter = np.full(B, -1, np.int64)       # last (merit_increases, sqp_iter) whose start was reported
+        finished = np.zeros(B, bool)
+        while True:
+            r, st = self.ctx.results(), self.ctx.state()
+            cv, vv = self.ctx.evaluate()
+            for b in range(B):
+                if finished[b]:
+                    continue
+                if st["done"][b]:
+                    finished[b] = True
+                    self._fire(b, r, cv, vv, st)        # "at exit"
+                elif st["merit_increases"][b] * 100000 + st["sqp_iter"][b] != seen_iter[b]:
+                    seen_iter[b] = st["merit_increases"][b] * 100000 + st["sqp_iter"][b]
+                    self._fire(b, r, cv, vv, st)        # before this SQP iteration starts
+            if finished.all():
+                break
+            self.ctx.run(1)
         return self.ctx.results()["status"]
 
     def results(self):
