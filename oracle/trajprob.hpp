@@ -2,10 +2,13 @@
 // Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use anything in oracle/.
 //
 // CPU restatement of the trajopt term layer for the hot path (paths relative to /root/reference/):
-//   trajopt/src/trajectory_costs.cpp:139-183,185-255,257-301   JointPosEqConstraint, JointPosIneqConstraint, JointVelEqCost
+//   trajopt/src/trajectory_costs.cpp:28-137,139-183,185-255,257-301   JointPosEqCost, JointPosIneqCost, JointPosEqConstraint,
+//                                                                     JointPosIneqConstraint, JointVelEqCost
 //   trajopt/src/kinematic_terms.cpp:187-366              CartPoseErrCalculator / CartPoseJacCalculator (FD, eps=1e-5)
-//   trajopt/src/collision_terms.cpp:203-250,343-383,540-556,655-691,1283-1327   single-timestep CollisionCost
-//   trajopt/src/problem_description.cpp:410-592,901-987,1764-1774               ConstructProblem / hatch order
+//   trajopt/src/collision_terms.cpp:203-250,343-383,540-556,655-691,1283-1327,1335-1420   single-timestep CollisionCost /
+//                                                                     CollisionConstraint
+//   trajopt/src/problem_description.cpp:410-592,901-987,1641-1649,1764-1774,1821-1835   ConstructProblem (fixed timesteps,
+//                                                                     fixed dofs), hatch order, collision fixed_steps
 // Third-party arithmetic NOT under /root/reference and restated from its published behaviour
 // (parity UNPINNED — tesseract is a floating dependency, .github/workflows/ubuntu.yml:50):
 //   tesseract::kinematics::JointGroup::calcFwdKin / calcJacobian     -> serial-chain FK / geometric Jacobian
