@@ -530,42 +530,95 @@ TMX_DEVFN void kkt_invert_chain_generic(const QpWs& w, int t0, int t1, int tid, 
 }
 
 // ---- KKT solve: in: tp (primary rhs r1 + A'W r2 part), ta (aux rhs); out: tp = x_p, ta = x_a, hr = (A x)_r --------
+// (mode 1, polish: other conventions for the row terms, see the first branch)
 TMX_DEVFN void kkt_solve(const QpWs& w, const DevProblem* P, int mode, double sig, double delta, int tid, int NT)
 {
   const int D = w.D, T = w.T, DS = w.DS, DDS = w.DDS;
-  // 1. aux elimination: h_r = rho_r * (s . Maa^-1 rhs_a) ;   Maa^-1 v = v/d - rho (s/d) (s.(v/d)) / (1 + rho kappa)
-  for (int r = tid; r < w.R; r += NT)
+  if (mode == 1)
   {
-    double h = 0.0;
-    if (w.act[r] && w.naux[r] > 0)
+    // POLISH (row weights 1/delta = 1e6): in: hr = r2 of the active rows (UNSCALED), ta = aux rhs WITHOUT the row term,
+    // tp = primary rhs WITHOUT the A' W r2 term.  With W r2 folded into the right-hand sides (as in the ADMM form below)
+    // a row whose aux var is free (d = delta) contributes rho r2 - rho g / (1 + rho kappa): two numbers of size 1e6 |r2|
+    // whose difference is 1e-6 |r2| - 12 digits gone, 1e-4 errors in the polished point, polish rejected where the
+    // reference's quasi-definite LDL' accepts it.  Stable form of the same elimination: with the aux block
+    //   d_k x_k + s_k nu = ta_k ,   sum_k s_k x_k + a.dx - delta nu = r2
+    // the row acts on dx through  c_r = (r2 - sum s_k ta_k / d_k) / (delta + sum s_k^2 / d_k), evaluated with numerator
+    // and denominator scaled by d_min (all ratios d_min / d_k <= 1).
+    for (int r = tid; r < w.R; r += NT)
     {
-      const double rr = w_row(w, r, mode, delta);
-      double kappa = 0.0, g = 0.0;
-      for (int k = 0; k < w.naux[r]; ++k)
+      double c = 0.0;
+      if (w.act[r] && w_row(w, r, 1, delta) > 0.0)
       {
-        const int a = w.aoff[r] + k;
-        const double d = sig + w_ba(w, a, mode, delta) * w.bba[a] * w.bba[a];
-        kappa += w.sa[a] * w.sa[a] / d;
-        g += w.sa[a] * w.ta[a] / d;
+        double dk[2] = { 1.0, 1.0 }, dmin = 1.0;
+        for (int k = 0; k < w.naux[r]; ++k)
+        {
+          const int a = w.aoff[r] + k;
+          dk[k] = sig + w_ba(w, a, 1, delta) * w.bba[a] * w.bba[a];
+          dmin = (k == 0) ? dk[k] : fmin(dmin, dk[k]);
+        }
+        double num = dmin * w.hr[r], den = dmin * delta;
+        for (int k = 0; k < w.naux[r]; ++k)
+        {
+          const int a = w.aoff[r] + k;
+          const double ratio = dmin / dk[k];
+          num -= w.sa[a] * w.ta[a] * ratio;
+          den += w.sa[a] * w.sa[a] * ratio;
+        }
+        c = num / den;
       }
-      h = rr * g / (1.0 + rr * kappa);
+      w.hr[r] = c;
     }
-    w.hr[r] = h;
-  }
-  TMX_SYNC();
-  for (int v = tid; v < w.NX; v += NT)
-  {
-    const int t = v / D, j = v % D;
-    double s = 0.0;
-    for (int q = w.wp_start[t]; q < w.wp_start[t + 1]; ++q)
+    TMX_SYNC();
+    for (int v = tid; v < w.NX; v += NT)
     {
-      const int r = w.wp_list[q];
-      if (w.act[r])
-        s += w.hr[r] * w.coef[r * D + j];
+      const int t = v / D, j = v % D;
+      double s = 0.0;
+      for (int q = w.wp_start[t]; q < w.wp_start[t + 1]; ++q)
+      {
+        const int r = w.wp_list[q];
+        if (w.act[r])
+          s += w.hr[r] * w.coef[r * D + j];
+      }
+      w.tp[v] += s;
     }
-    w.tp[v] -= s;
+    TMX_SYNC();
   }
-  TMX_SYNC();
+  else
+  {
+  // 1. aux elimination: h_r = rho_r * (s . Maa^-1 rhs_a) ;   Maa^-1 v = v/d - rho (s/d) (s.(v/d)) / (1 + rho kappa)
+    for (int r = tid; r < w.R; r += NT)
+    {
+      double h = 0.0;
+      if (w.act[r] && w.naux[r] > 0)
+      {
+        const double rr = w_row(w, r, mode, delta);
+        double kappa = 0.0, g = 0.0;
+        for (int k = 0; k < w.naux[r]; ++k)
+        {
+          const int a = w.aoff[r] + k;
+          const double d = sig + w_ba(w, a, mode, delta) * w.bba[a] * w.bba[a];
+          kappa += w.sa[a] * w.sa[a] / d;
+          g += w.sa[a] * w.ta[a] / d;
+        }
+        h = rr * g / (1.0 + rr * kappa);
+      }
+      w.hr[r] = h;
+    }
+    TMX_SYNC();
+    for (int v = tid; v < w.NX; v += NT)
+    {
+      const int t = v / D, j = v % D;
+      double s = 0.0;
+      for (int q = w.wp_start[t]; q < w.wp_start[t + 1]; ++q)
+      {
+        const int r = w.wp_list[q];
+        if (w.act[r])
+          s += w.hr[r] * w.coef[r * D + j];
+      }
+      w.tp[v] -= s;
+    }
+    TMX_SYNC();
+  }
   // 2. block forward / backward substitution (sequential over waypoints); row i of the block handled by thread i
 #if TMX_IS_DEVICE
   if (D <= 8 && NT >= 64)
@@ -655,6 +708,45 @@ TMX_DEVFN void kkt_solve(const QpWs& w, const DevProblem* P, int mode, double si
         w.tp[t * D + i] = w.gj[i];
       TMX_SYNC();
     }
+  }
+  // 3. aux recovery and (A x)_r   (polish: hr = nu_r, the multiplier itself - (A dx - r2) / delta would cancel again)
+  if (mode == 1)
+  {
+    for (int r = tid; r < w.R; r += NT)
+    {
+      if (!w.act[r])
+      {
+        w.hr[r] = 0.0;
+        continue;
+      }
+      const int t = w.slot_t[r];
+      double dot = 0.0;
+      for (int j = 0; j < D; ++j)
+        dot += w.coef[r * D + j] * w.tp[t * D + j];
+      double dk[2] = { 1.0, 1.0 }, dmin = 1.0;
+      for (int k = 0; k < w.naux[r]; ++k)
+      {
+        const int a = w.aoff[r] + k;
+        dk[k] = sig + w_ba(w, a, 1, delta) * w.bba[a] * w.bba[a];
+        dmin = (k == 0) ? dk[k] : fmin(dmin, dk[k]);
+      }
+      double nu = 0.0;
+      if (w_row(w, r, 1, delta) > 0.0)
+      {
+        double den = dmin * delta;
+        for (int k = 0; k < w.naux[r]; ++k)
+          den += w.sa[w.aoff[r] + k] * w.sa[w.aoff[r] + k] * (dmin / dk[k]);
+        nu = dot * (dmin / den) - w.hr[r];  // hr holds c_r from step 1
+      }
+      for (int k = 0; k < w.naux[r]; ++k)
+      {
+        const int a = w.aoff[r] + k;
+        w.ta[a] = (w.ta[a] - w.sa[a] * nu) / dk[k];
+      }
+      w.hr[r] = nu;
+    }
+    TMX_SYNC();
+    return;
   }
   // 3. aux recovery and (A x)_r
   for (int r = tid; r < w.R; r += NT)

@@ -66,6 +66,11 @@ TMX_DEVFN void qp_structure(const DevProblem* P, const int* active, const double
       dims[1] = nr1 + NX + na1;  // m
     }
   }
+  if (R == 0 && tid == 0)  // a problem without any row slot (costs only, nothing fixed): the QP is the box-constrained objective
+  {
+    dims[0] = NX;
+    dims[1] = NX;
+  }
   TMX_SYNC();
   const int n = dims[0], m = dims[1], mg = m - n;
   // column counts of A (into colptr[c + 1]), then the exclusive prefix by per-thread scans of the LDS counts
@@ -979,7 +984,7 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
               ax += wp.sa[wp.aoff[r] + k] * wp.dxa[wp.aoff[r] + k];
             r2 -= ax;
           }
-          g = r2 / delta;
+          g = r2;  // unscaled: kkt_solve(mode 1) applies the 1/delta weight in its cancellation-free form
         }
         wp.hr[r] = g;
       }
@@ -997,7 +1002,7 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
         }
         if (pass > 0)
           r1 -= p_times(wp, wp.dxp, v) + at_rows(wp, P, wp.dyr, v) + wp.bbp[v] * wp.dybp[v];
-        wp.tp[v] = r1 + at_rows(wp, P, wp.hr, v) + wp.bbp[v] * gb;
+        wp.tp[v] = r1 + wp.bbp[v] * gb;
       }
       for (int r = tid; r < R; r += NT)
         if (wp.act[r])
@@ -1015,31 +1020,16 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
             }
             if (pass > 0)
               r1 -= wp.sa[a] * wp.dyr[r] + wp.bba[a] * wp.dyba[a];
-            wp.ta[a] = r1 + wp.sa[a] * wp.hr[r] + wp.bba[a] * gb;
+            wp.ta[a] = r1 + wp.bba[a] * gb;
           }
       TMX_SYNC();
       kkt_solve(wp, P, 1, delta, delta, tid, NT);
-      // y-part of the solution: nu = (A dx - r2) / delta on active rows (r2 recomputed from the pre-update iterate)
+      // y-part of the solution: kkt_solve(mode 1) left nu_r in hr
       for (int r = tid; r < R; r += NT)
       {
         if (!wp.act[r])
           continue;
-        double dy = 0.0;
-        if (wp.flg_r[r] != 0)
-        {
-          double r2 = (wp.flg_r[r] < 0) ? wp.lor[r] : wp.hir[r];
-          if (pass > 0)
-          {
-            const int t = wp.slot_t[r];
-            double ax = 0.0;
-            for (int j = 0; j < D; ++j)
-              ax += wp.coef[r * D + j] * wp.dxp[t * D + j];
-            for (int k = 0; k < wp.naux[r]; ++k)
-              ax += wp.sa[wp.aoff[r] + k] * wp.dxa[wp.aoff[r] + k];
-            r2 -= ax;
-          }
-          dy = (wp.hr[r] - r2) / delta;
-        }
+        const double dy = (wp.flg_r[r] != 0) ? wp.hr[r] : 0.0;
         wp.zr[r] = dy;  // z_r is dead after the active-set guess: reuse it to carry this pass's dy_r
       }
       TMX_SYNC();
