@@ -81,7 +81,7 @@ def test_full_sqp_config1_statistical(gpu, orc):
     r, o, same, dx = pc.check_full_sqp(gpu, orc, desc, x0, exact=False)
     assert (r["status"] == o["status"]).all()
     tight = dx <= pc.TOL_TRAJ
-    assert tight.sum() >= B // 2, f"only {tight.sum()} of {B} seeds agree to 1e-5: {dx}"
+    assert tight.sum() >= (3 * B) // 4, f"only {tight.sum()} of {B} seeds agree to 1e-5: {dx}"   # measured: 62 of 64
     cv, vv = gpu.evaluate()
     assert vv.max() < 1e-3
     assert np.abs(r["total_cost"] - o["total_cost"]).max() < 0.05 * max(1.0, np.abs(o["total_cost"]).max())
