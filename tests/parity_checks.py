@@ -26,6 +26,13 @@ def cfg(cid, T=None):
         return configs.config_wide()
     if cid == 14:  # CollisionTermInfo::fixed_steps independent of BasicInfo::fixed_timesteps: contacts AT the fixed
         return configs.config_mini(collision_fixed_steps=(5,))   # waypoint 0 (constant rows), none at waypoint 5
+    if cid == 15:  # no row slot at all: a joint-velocity cost and nothing else (R = 0, the QP is the box-constrained objective)
+        from trajopt_amd.problem import BasicInfo, JointVelTermInfo, ProblemConstructionInfo
+        rob = configs.mini_arm()
+        rob.link_spheres = []
+        pci = ProblemConstructionInfo(rob, BasicInfo(n_steps=6 if T is None else T))
+        pci.cost_infos.append(JointVelTermInfo(coeffs=[1.0, 2.0, 0.5, 1.5], targets=[0.0] * 4, first_step=0, last_step=pci.basic_info.n_steps - 1))
+        return pci, configs.MINI_START, configs.MINI_GOAL
     if cid == 12:  # BasicInfo::fixed_dofs: the wrist joint keeps its seed value at every step
         return configs.config_mini(with_joint_band=False, fixed_dofs=[3])
     if cid == 2:   # puzzle_piece: 300 waypoints, the QP workspace lives in HBM on the device (generic block-chain path)
