@@ -1,5 +1,5 @@
 """Oracle (rebuilt wherever the tests run) vs the committed golden fixtures of tests/golden (oracle-generated in the
-build container by tools/make_golden.py — the reference cannot be built here, so parity vs the real reference is
+build container by tests/tools/make_golden.py — the reference cannot be built here, so parity vs the real reference is
 UNPINNED; these pins guard the restatement against drift and against host/compiler differences)."""
 import os
 

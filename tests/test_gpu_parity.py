@@ -164,7 +164,7 @@ def test_full_batch_properties(gpu):
 
 
 def test_golden_fixture_first_qp(gpu, orc):
-    """the committed golden fixture (tests/golden, generated by tools/make_golden.py from the oracle in the build
+    """the committed golden fixture (tests/golden, generated by tests/tools/make_golden.py from the oracle in the build
     container) is reproduced by the device path"""
     import os
     path = os.path.join(os.path.dirname(__file__), "golden", "cfg1_first_qp.npz")

@@ -1,6 +1,6 @@
 """config 1 end-to-end agreement of the device path (or the host build) with the oracle: python tools/c1_parity_stat.py [B] [lib.so]"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from trajopt_amd import configs, abi, runtime
 from oracle import pyorc as orc

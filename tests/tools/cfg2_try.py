@@ -1,4 +1,4 @@
-import sys, time; sys.path.insert(0,'.')
+import os, sys, time; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from trajopt_amd import configs, abi, runtime
 from oracle import pyorc as orc

@@ -4,8 +4,8 @@ Checks per case: exact term values, first-QP CSC (integer arrays bit-exact modul
 (same OSQP status / iteration count / rho updates / polish status, |dx| <= 1e-5), whole SQP (same status and counters ->
 |dx| <= 1e-5).  Prints one line per failing case and a summary; exit code 1 if anything failed."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
 import numpy as np
 from trajopt_amd import abi, runtime
 from trajopt_amd.problem import (BasicInfo, CartPoseTermInfo, CollisionTermInfo, JointPosTermInfo, JointVelTermInfo,
@@ -76,7 +76,7 @@ def random_problem(rng):
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 50
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-    lib = sys.argv[3] if len(sys.argv) > 3 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "hostemu", "_build", "libtmx_hostemu.so")
+    lib = sys.argv[3] if len(sys.argv) > 3 else os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests", "hostemu", "_build", "libtmx_hostemu.so")
     on_gpu = lib == "gpu"
     fails, soft, diverged = 0, 0, 0
     for k in range(n):
