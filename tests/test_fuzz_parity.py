@@ -1,0 +1,26 @@
+"""A slice of the randomised parity sweep (tests/tools/fuzz_parity.py) in the regular tiers: random serial chains
+(2-8 DOF, revolute and prismatic), horizons and term sets, every stage of the hot path against the oracle.  The sweep
+found the R = 0 structure bug and the polish cancellation; the full sweep is run by hand."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+TOOL = os.path.join(HERE, "tools", "fuzz_parity.py")
+
+
+def _sweep(n, seed, target):
+    p = subprocess.run([sys.executable, TOOL, str(n), str(seed), target], capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
+    assert f"{n} cases, 0 failures" in p.stdout
+
+
+def test_random_problems_on_host_build(hostemu_lib, orc):
+    _sweep(40, 7, hostemu_lib)
+
+
+@pytest.mark.gpu
+def test_random_problems_on_device(orc):
+    _sweep(20, 5, "gpu")     # D <= 8 and n_steps * D <= 256: the dense fast path of the QP solver
