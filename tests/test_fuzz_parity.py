@@ -11,14 +11,19 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 TOOL = os.path.join(HERE, "tools", "fuzz_parity.py")
 
 
-def _sweep(n, seed, target):
-    p = subprocess.run([sys.executable, TOOL, str(n), str(seed), target], capture_output=True, text=True, timeout=900)
+def _sweep(n, seed, target, *extra):
+    p = subprocess.run([sys.executable, TOOL, str(n), str(seed), target, *extra], capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
     assert f"{n} cases, 0 failures" in p.stdout
 
 
 def test_random_problems_on_host_build(hostemu_lib, orc):
     _sweep(40, 7, hostemu_lib)
+
+
+def test_random_wide_problems_on_host_build(hostemu_lib, orc):
+    """9-11 DOF chains, longer horizons, single-waypoint problems: the generic block-chain path"""
+    _sweep(40, 21, hostemu_lib, "wide")
 
 
 @pytest.mark.gpu

@@ -1,5 +1,5 @@
 """Randomised stage-by-stage parity sweep: random serial chains, term sets and seeds -> device path (or the kernel sources
-built for the host) vs the oracle.   python tools/fuzz_parity.py [n_cases] [seed] [lib.so|gpu]
+built for the host) vs the oracle.   python tests/tools/fuzz_parity.py [n_cases] [seed] [lib.so|gpu] [wide]
 Checks per case: exact term values, first-QP CSC (integer arrays bit-exact modulo noise entries), first Model::optimize
 (same OSQP status / iteration count / rho updates / polish status, |dx| <= 1e-5), whole SQP (same status and counters ->
 |dx| <= 1e-5).  Prints one line per failing case and a summary; exit code 1 if anything failed."""
@@ -14,9 +14,15 @@ from oracle import pyorc as orc
 import parity_checks as pc
 
 
-def random_problem(rng):
-    D = int(rng.integers(2, 9))
-    T = int(rng.integers(2, min(24, 256 // D) + 1))
+def random_problem(rng, wide=False):
+    """wide=False: D <= 8 and T * D <= 256 (the dense fast path on the device); wide=True also draws 9-11 DOF chains,
+    longer horizons (T * D up to ~400) and single-waypoint problems: the generic block-chain path"""
+    if wide:
+        D = int(rng.integers(2, 12))
+        T = 1 if rng.random() < 0.08 else int(rng.integers(2, max(3, min(40, 400 // D)) + 1))
+    else:
+        D = int(rng.integers(2, 9))
+        T = int(rng.integers(2, min(24, 256 // D) + 1))
     types = [int(rng.random() < 0.2) for _ in range(D)]
     axes = []
     for _ in range(D):
@@ -28,12 +34,16 @@ def random_problem(rng):
     rob = Robot(joint_types=types, origins=origins, axes=axes, lower=lower, upper=upper, tool=_tf12(t=rng.uniform(0.0, 0.2, 3)))
     n_sph = int(rng.integers(0, 4))
     rob.link_spheres = [(int(rng.integers(0, D)), tuple(rng.uniform(-0.05, 0.1, 3)), float(rng.uniform(0.03, 0.08))) for _ in range(n_sph)]
-    fixed_t = [0] if rng.random() < 0.7 else []
+    fixed_t = [0] if (rng.random() < 0.7 and T > 1) else []
     fixed_d = [int(rng.integers(0, D))] if rng.random() < 0.2 else []
     pci = ProblemConstructionInfo(rob, BasicInfo(n_steps=T, fixed_timesteps=fixed_t, fixed_dofs=fixed_d))
     start = rng.uniform(0.6 * lower, 0.6 * upper)
     goal = rng.uniform(0.6 * lower, 0.6 * upper)
-    pci.cost_infos.append(JointVelTermInfo(coeffs=list(rng.uniform(0.5, 2.0, D)), targets=[0.0] * D, first_step=0, last_step=T - 1))
+    if T > 1:
+        pci.cost_infos.append(JointVelTermInfo(coeffs=list(rng.uniform(0.5, 2.0, D)), targets=[0.0] * D, first_step=0, last_step=T - 1))
+    else:
+        pci.cost_infos.append(JointPosTermInfo(coeffs=list(rng.uniform(0.1, 1.0, D)), targets=list(start), first_step=0, last_step=0,
+                                               is_constraint=False))
     if n_sph and rng.random() < 0.8:
         for _ in range(int(rng.integers(1, 3))):
             q = start + rng.random() * (goal - start)
@@ -51,7 +61,7 @@ def random_problem(rng):
                                                upper_tols=list(rng.uniform(0.05, 0.5, D)) if rng.random() < 0.5 else [],
                                                lower_tols=list(-rng.uniform(0.05, 0.5, D)) if rng.random() < 0.5 else []))
     for _ in range(int(rng.integers(0, 3))):
-        t = int(rng.integers(1, T))
+        t = int(rng.integers(1, T)) if T > 1 else 0
         q = start + (t / max(1, T - 1)) * (goal - start) + 0.05 * rng.standard_normal(D)
         pose = rob.fk_tool(np.clip(q, lower, upper))[:3, :]
         pc_ = tuple(float(v) for v in (rng.random(3) < 0.7))
@@ -74,6 +84,9 @@ def random_problem(rng):
 
 
 def main():
+    wide = "wide" in sys.argv
+    if wide:
+        sys.argv.remove("wide")
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 50
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     lib = sys.argv[3] if len(sys.argv) > 3 else os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests", "hostemu", "_build", "libtmx_hostemu.so")
@@ -81,7 +94,7 @@ def main():
     fails, soft, diverged = 0, 0, 0
     for k in range(n):
         rng = np.random.default_rng([seed, k])
-        pci, x0 = random_problem(rng)
+        pci, x0 = random_problem(rng, wide)
         tag = f"case {seed}/{k}: D={pci.robot.n_dof} T={pci.basic_info.n_steps} costs={len(pci.cost_infos)} cnts={len(pci.cnt_infos)}"
         ctx = runtime.Context(0, None if on_gpu else lib)
         try:
@@ -101,8 +114,12 @@ def main():
             recs, cnt = ctx.qp_records(128)
             for b in range(x0.shape[0]):
                 nq = int(cnt[b])
+                # ... and the same rho after every solve: the adaptive-rho estimates are continuous functions of the iterates, so
+                # a relative difference above 1e-9 means the two ADMM runs are already drifting apart (unpolished solutions)
                 hist = same[b] and nq == int(o["rec_counts"][b]) and nq <= 128 and all(
-                    recs[b * 128 + q].key() == o["records"][b * o["max_records"] + q].key() for q in range(nq))
+                    recs[b * 128 + q].key() == o["records"][b * o["max_records"] + q].key() and
+                    abs(recs[b * 128 + q].rho_final - o["records"][b * o["max_records"] + q].rho_final) <=
+                    1e-9 * abs(o["records"][b * o["max_records"] + q].rho_final) for q in range(nq))
                 if hist and dx[b] > pc.TOL_TRAJ:
                     raise AssertionError(f"full SQP: identical QP history but |dx| = {dx[b]}")
                 if not hist:
