@@ -69,3 +69,30 @@ def test_state_requires_a_batch(hostemu_lib):
 @pytest.mark.gpu
 def test_callbacks_on_device():
     _check(*_run_pair(None, B=5))
+
+
+def test_iteration_log_table_and_csv(hostemu_lib):
+    import io
+    from trajopt_amd.iteration_log import IterationLog
+    pci, s, g = configs.config0()
+    x0 = configs.seeds_for(0, pci, s, g, 2)
+    log = IterationLog(cost_names=["joint_vel"], cnt_names=["joint_pos_goal"])
+    opt = runtime.BatchedTrustRegionSQP(pci, lib_path=hostemu_lib)
+    opt.addCallback(log)
+    opt.initialize(x0)
+    opt.optimize()
+    res = opt.results()
+    opt.ctx.close()
+    rows0 = [r for r in log.rows if r["seed"] == 0]
+    assert rows0[0]["dexact_costs"] is None and rows0[-1]["status"] == abi.OPT_CONVERGED
+    assert rows0[-1]["n_qp_solves"] == res["n_qp_solves"][0]
+    # the exact improvements telescope to first - last
+    tot = sum(r["dexact_costs"][0] for r in rows0[1:])
+    assert abs(tot - (rows0[0]["cost_vals"][0] - rows0[-1]["cost_vals"][0])) < 1e-9
+    table = log.format_table(0)
+    assert "joint_vel" in table and "joint_pos_goal" in table and "TOTAL COST" in table and table.count("SQP iteration") == len(rows0)
+    buf = io.StringIO()
+    log.write_csv(buf)
+    lines = buf.getvalue().strip().splitlines()
+    assert lines[0].startswith("seed,merit_increases,sqp_iter,trust_box_size") and lines[0].endswith("joint_vel,joint_pos_goal")
+    assert len(lines) == 1 + len(log.rows)
