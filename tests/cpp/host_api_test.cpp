@@ -10,7 +10,7 @@
 #include <iostream>
 #include <sstream>
 
-#include "tmx_trajopt.hpp"
+#include "tmx_trajopt_json.hpp"
 
 using namespace tmx;
 using namespace tmx::trajopt;
@@ -51,6 +51,7 @@ struct Input
   std::map<std::string, Transform> frames;
   std::vector<tmx_obstacle_sphere> obstacles;
   std::map<std::string, DblVec> vectors;
+  std::map<std::string, std::string> files;
 };
 
 // numbers are written as C99 hex floats (exact); operator>> does not parse those, strtod does
@@ -130,6 +131,12 @@ static Input readInput(const char* path)
           v = rd(f);
         o.radius = rd(f);
       }
+    }
+    else if (tok == "file")
+    {
+      std::string name, path;
+      f >> name >> path;
+      in.files[name] = path;
     }
     else if (tok == "vector")
     {
@@ -555,6 +562,75 @@ static void caseInterface(const Input& in)
   std::printf("INTERFACE done\n");
 }
 
+// ---- ProblemConstructionInfo JSON through the C++ front end (include/tmx_trajopt_json.hpp) ------------------------------
+static std::string slurp(const std::string& path)
+{
+  std::ifstream f(path);
+  if (!f)
+    throw std::runtime_error("cannot open " + path);
+  std::stringstream ss;
+  ss << f.rdbuf();
+  return ss.str();
+}
+
+static void caseJson(const Input& in)
+{
+  struct Case
+  {
+    const char* name;
+    const char* file;
+    const char* robot;
+    const char* state;
+    const char* seeds;
+    std::size_t nv;
+    bool obstacles;
+  };
+  const Case cases[] = { { "json_cfg0", "planning_unit_cfg0", "pr2_right_arm", "cfg0_start", "cfg0_seeds", 70, false },
+                         { "json_cfg1", "glass_upright_cfg1", "pr2_right_arm_upright", "cfg1_start", "cfg1_seeds", 210, true } };
+  for (const Case& c : cases)
+  {
+    auto env = makeEnv(in, "right_arm", c.robot, in.vectors.at(c.state), c.obstacles);
+    env->link_frames["base_footprint"] = Transform::Identity();  // as tests/test_json_io.py::_env
+    tmx::sco::BasicTrustRegionSQPParameters opt_info;
+    auto prob = ConstructProblem(slurp(in.files.at(c.file)), env, &opt_info);
+    BasicTrustRegionSQPBatchedHip opt(prob);
+    opt.setParameters(opt_info);
+    opt.initialize(splitSeeds(in.vectors.at(c.seeds), c.nv));
+    opt.optimize();
+    printResults(c.name, opt);
+  }
+  {
+    // numerical_ik1.json: the init trajectory comes from the JSON (stationary at the environment state)
+    auto env = makeEnv(in, "left_arm", "pr2_left_arm", DblVec(7, 0.0), false);
+    auto prob = ConstructProblem(slurp(in.files.at("numerical_ik1")), env);
+    EXPECT_TRUE(prob->GetNumSteps() == 1 && prob->getNumConstraints() == 1 && prob->getNumCosts() == 0);
+    BasicTrustRegionSQPBatchedHip opt(prob);
+    opt.initialize(tmx::sco::trajToDblVec(prob->GetInitTraj()));
+    EXPECT_TRUE(opt.optimize() == OptStatus::OPT_CONVERGED);
+    printResults("json_numerical_ik1", opt);
+  }
+  {
+    // malformed / unsupported inputs are explicit errors with the reference's wording
+    auto env = makeEnv(in, "right_arm", "pr2_right_arm", DblVec(7, 0.0), false);
+    env->link_frames["base_footprint"] = Transform::Identity();
+    const std::string head = "{\"basic_info\": {\"n_steps\": 5, \"manip\": \"right_arm\"}, ";
+    const std::string init = "\"init_info\": {\"type\": \"stationary\"}}";
+    EXPECT_THROW_MSG(ConstructProblem("{\"init_info\": {\"type\": \"stationary\"}}", env), "Json missing required section basic_info!");
+    EXPECT_THROW_MSG(ConstructProblem(head + "\"costs\": []}", env), "Json missing required section init_info!");
+    EXPECT_THROW_MSG(ConstructProblem("{\"basic_info\": {\"n_steps\": 5, \"manip\": \"nope\"}, " + init, env), "Manipulator does not exist: nope");
+    EXPECT_THROW_MSG(ConstructProblem(head + "\"costs\": [{\"type\": \"joint_acc\", \"params\": {}}], " + init, env), "is not lowered by the device path");
+    EXPECT_THROW_MSG(ConstructProblem(head + "\"costs\": [{\"type\": \"joint_pos\", \"params\": {\"targets\": [0,0,0,0,0,0,0], \"bogus\": 1}}], " + init, env),
+                     "illegal field \"bogus\"");
+    EXPECT_THROW_MSG(ConstructProblem(head + "\"costs\": [{\"type\": \"joint_pos\", \"params\": {\"targets\": [0,0,0]}}], " + init, env),
+                     "wrong number of values in \"targets\": expected 7 got 3");
+    EXPECT_THROW_MSG(ConstructProblem(head + "\"costs\": [{\"type\": \"collision\", \"params\": {\"evaluator_type\": 4, \"coeffs\": 20, \"dist_pen\": 0.02}}], " + init, env),
+                     "only DISCRETE");
+    EXPECT_THROW_MSG(ConstructProblem(head + "\"costs\": [], \"init_info\": {\"type\": \"spline\"}}", env), "init_info did not have a valid type from Json");
+    EXPECT_THROW_MSG(ConstructProblem(head + "\"costs\": [, " + init, env), "JSON parse error");
+  }
+  std::printf("JSON done\n");
+}
+
 // ---- error behaviour: where the reference PRINT_AND_THROWs, this layer throws std::runtime_error -----------------------
 static void caseErrors(const Input& in, bool have_device)
 {
@@ -698,6 +774,8 @@ int main(int argc, char** argv)
         caseCartPosition(in);
       else if (c == "interface")
         caseInterface(in);
+      else if (c == "json")
+        caseJson(in);
       else if (c == "errors")
         caseErrors(in, true);
       else if (c == "errors_nodevice")

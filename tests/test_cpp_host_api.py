@@ -20,7 +20,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 BUILD = os.path.join(HERE, "cpp", "_build")
 SRC = os.path.join(HERE, "cpp", "host_api_test.cpp")
-HDRS = [os.path.join(ROOT, "include", "tmx_trajopt.hpp"), os.path.join(ROOT, "include", "tmx.h")]
+HDRS = [os.path.join(ROOT, "include", "tmx_trajopt.hpp"), os.path.join(ROOT, "include", "tmx_trajopt_json.hpp"),
+        os.path.join(ROOT, "include", "tmx.h")]
 PRODUCT_LIB = os.path.join(ROOT, "trajopt_amd", "_build", "libtrajopt_mi355x.so")
 N0, N1 = 3, 3     # seeds per config
 
@@ -67,11 +68,13 @@ def inputs(tmp_path_factory):
     lines.append(f"obstacles {len(pci1.obstacles)}")
     for c, r in pci1.obstacles:
         lines.append(f"{_fmt(c)} {_fmt(r)}")
+    for name in ("planning_unit_cfg0", "glass_upright_cfg1", "numerical_ik1"):
+        lines.append(f"file {name} {os.path.join(HERE, 'golden', 'json', name + '.json')}")
     for name, v in (("cfg0_start", s0), ("cfg0_goal", g0), ("cfg1_start", s1), ("cfg1_goal", g1), ("cfg0_seeds", x0), ("cfg1_seeds", x1)):
         lines.append(f"vector {name} {np.asarray(v).size} {_fmt(v)}")
     path = tmp_path_factory.mktemp("cpp") / "input.txt"
     path.write_text("\n".join(lines) + "\n")
-    return dict(path=str(path), pci0=pci0, pci1=pci1, x0=x0, x1=x1, s0=s0, g0=g0)
+    return dict(path=str(path), pci0=pci0, pci1=pci1, x0=x0, x1=x1, s0=s0, g0=g0, s1=s1)
 
 
 def _run(exe, inp, cases, timeout=600):
@@ -118,6 +121,31 @@ def test_cpp_front_end_equals_python_front_end_on_host_build(hostemu_lib, inputs
     _check_front_ends(_build(hostemu_lib, "hostemu"), inputs, hostemu_lib)
 
 
+def _check_json_front_ends(exe, inputs, lib_path):
+    """the reference's problem-description JSON through include/tmx_trajopt_json.hpp and through trajopt_amd/json_io.py"""
+    from trajopt_amd import json_io
+    res, _, out = _run(exe, inputs["path"], "json")
+    assert "JSON done" in out
+    ident = np.hstack([np.eye(3), np.zeros((3, 1))])
+    for name, fname, pci, x0, start in (("json_cfg0", "planning_unit_cfg0.json", inputs["pci0"], inputs["x0"], inputs["s0"]),
+                                        ("json_cfg1", "glass_upright_cfg1.json", inputs["pci1"], inputs["x1"], inputs["s1"])):
+        env = json_io.Environment(manipulators={"right_arm": pci.robot}, tip_links={"right_arm": "r_gripper_tool_frame"},
+                                  link_frames={"base_footprint": ident}, joint_state={"right_arm": list(start)},
+                                  obstacles=list(pci.obstacles))
+        pp = json_io.construct_problem(open(os.path.join(HERE, "golden", "json", fname)).read(), env)
+        opt = runtime.BatchedTrustRegionSQP(pp.pci, lib_path=lib_path)
+        opt.setParameters(pp.sqp_params)
+        opt.initialize(x0)
+        opt.optimize()
+        _same(res[name], opt.results())
+        opt.ctx.close()
+    assert res["json_numerical_ik1"][0]["status"] == 0
+
+
+def test_cpp_json_front_end_equals_python_json_front_end_on_host_build(hostemu_lib, inputs):
+    _check_json_front_ends(_build(hostemu_lib, "hostemu"), inputs, hostemu_lib)
+
+
 def test_cpp_reference_kats_on_host_build(hostemu_lib, inputs, orc):
     exe = _build(hostemu_lib, "hostemu")
     res, _, out = _run(exe, inputs["path"], "joint_costs,numerical_ik,cart_position,interface,errors")
@@ -142,5 +170,6 @@ def test_cpp_front_end_on_device(inputs):
     assert os.path.exists(PRODUCT_LIB), "libtrajopt_mi355x.so missing: run __graft_entry__.build()"
     exe = _build(PRODUCT_LIB, "product")
     _check_front_ends(exe, inputs, None)
+    _check_json_front_ends(exe, inputs, None)
     res, _, out = _run(exe, inputs["path"], "joint_costs,numerical_ik,cart_position,interface,errors")
     assert "ERRORS done" in out and "INTERFACE done" in out and all(r[0]["status"] == 0 for r in res.values())
