@@ -321,9 +321,32 @@ public:
   std::size_t getNumCosts() const { return n_cost_terms_; }
   std::size_t getNumConstraints() const { return terms_.size() - n_cost_terms_; }
 
-  /** used by TermInfo::hatch: costs are hatched before constraints (problem_description.cpp:560-571) */
-  void addTerm(const tmx_term& t, const IntVec& fixed_steps = {})
+  /** names of the costs / constraints the terms expand to, in the order of OptResults::cost_vals / cnt_viols: costs in
+      hatch order; constraints with all equalities in front of the inequalities (sco::OptProb, modeling.cpp:234-241) */
+  const std::vector<std::string>& getCostNames() const { return cost_names_; }
+  std::vector<std::string> getCntNames() const
   {
+    std::vector<std::string> out(eq_cnt_names_);
+    out.insert(out.end(), ineq_cnt_names_.begin(), ineq_cnt_names_.end());
+    return out;
+  }
+
+  /** used by TermInfo::hatch: costs are hatched before constraints (problem_description.cpp:560-571).  `name` is the
+      TermInfo name; collision terms expand to one cost / constraint "name_<step>" per non-fixed step (:1773, :1833) */
+  void addTerm(const tmx_term& t, const IntVec& fixed_steps = {}, const std::string& name = std::string())
+  {
+    std::vector<std::string> names;
+    if (t.kind == TMX_TERM_COLLISION_COST || t.kind == TMX_TERM_COLLISION_CNT)
+    {
+      for (int i = t.first_step; i <= t.last_step; ++i)
+        if (std::find(fixed_steps.begin(), fixed_steps.end(), i) == fixed_steps.end())
+          names.push_back(name + "_" + std::to_string(i));
+    }
+    else
+      names.push_back(name);
+    const bool ineq = t.kind == TMX_TERM_JOINT_POS_INEQ_CNT || t.kind == TMX_TERM_COLLISION_CNT;
+    std::vector<std::string>& dst = !t.is_constraint ? cost_names_ : (ineq ? ineq_cnt_names_ : eq_cnt_names_);
+    dst.insert(dst.end(), names.begin(), names.end());
     terms_.push_back(t);
     term_fixed_.push_back(fixed_steps);
     if (!t.is_constraint)
@@ -385,6 +408,7 @@ private:
   std::vector<std::vector<int32_t>> term_fixed32_;
   std::size_t n_cost_terms_{ 0 };
   std::vector<int32_t> fixed_steps_, fixed_dofs_;
+  std::vector<std::string> cost_names_, eq_cnt_names_, ineq_cnt_names_;
   tmx_problem_desc desc_{};
 };
 
@@ -465,7 +489,7 @@ struct JointPosTermInfo : public TermInfo
     }
     else
       return;  // "JointPosTermInfo does not have a valid term_type defined. No cost/constraint applied" (:1172-1175)
-    prob.addTerm(t);
+    prob.addTerm(t, {}, name);
   }
 };
 
@@ -518,7 +542,7 @@ struct JointVelTermInfo : public TermInfo
       t.coeffs[j] = coeffs[j];
       t.targets[j] = targets[j];
     }
-    prob.addTerm(t);
+    prob.addTerm(t, {}, name);
   }
 };
 
@@ -572,7 +596,7 @@ struct CartPoseTermInfo : public TermInfo
       t.is_constraint = 1;  // EQ constraint (:961-976)
     else
       return;
-    prob.addTerm(t);
+    prob.addTerm(t, {}, name);
   }
 };
 
@@ -633,7 +657,7 @@ struct CollisionTermInfo : public TermInfo
       t.kind = TMX_TERM_COLLISION_CNT;
       t.is_constraint = 1;
     }
-    prob.addTerm(t, fixed_steps);
+    prob.addTerm(t, fixed_steps, name);
   }
 };
 
@@ -940,6 +964,40 @@ private:
 /** trajToDblVec (trajopt/include/trajopt/utils.hpp:18): row-major flattening of a TrajArray */
 inline DblVec trajToDblVec(const TrajArray& t) { return t.data; }
 }  // namespace sco
+
+namespace trajopt
+{
+/** problem_description.hpp:112-121, problem_description.cpp:380-394 */
+struct TrajOptResult
+{
+  using Ptr = std::shared_ptr<TrajOptResult>;
+  std::vector<std::string> cost_names, cnt_names;
+  DblVec cost_vals, cnt_viols;
+  TrajArray traj;
+  sco::OptStatus status;
+  TrajOptResult(const sco::OptResults& opt, const TrajOptProb& prob)
+    : cost_names(prob.getCostNames()), cnt_names(prob.getCntNames()), cost_vals(opt.cost_vals), cnt_viols(opt.cnt_viols), status(opt.status)
+  {
+    traj = TrajArray(prob.GetNumSteps(), prob.GetNumDOF());
+    traj.data = opt.x;  // getTraj: the vars are laid out row-major (j_t_d)
+  }
+};
+
+/** OptimizeProblem (problem_description.cpp:396-408): BasicTrustRegionSQP with the reference's planner-style parameters
+    on the problem's own initial trajectory */
+inline TrajOptResult::Ptr OptimizeProblem(const TrajOptProb::Ptr& prob, int device = 0)
+{
+  sco::BasicTrustRegionSQPBatchedHip opt(prob, device);
+  sco::BasicTrustRegionSQPParameters& param = opt.getParameters();
+  param.max_iter = 40;
+  param.min_approx_improve_frac = .001;
+  param.improve_ratio_threshold = .2;
+  param.initial_merit_error_coeff = 20;
+  opt.initialize(sco::trajToDblVec(prob->GetInitTraj()));
+  opt.optimize();
+  return std::make_shared<TrajOptResult>(opt.results(), *prob);
+}
+}  // namespace trajopt
 }  // namespace tmx
 
 #endif  // TMX_TRAJOPT_HPP_

@@ -328,6 +328,13 @@ static void caseCfg1(const Input& in)
   opt.initialize(splitSeeds(in.vectors.at("cfg1_seeds"), 210));
   opt.optimize();
   printResults("cfg1", opt);
+  // names of the expanded costs / constraints line up with the values (TrajOptResult, problem_description.cpp:380-394)
+  const TrajOptResult res(opt.results(), *prob);
+  EXPECT_TRUE(res.cost_names.size() == res.cost_vals.size() && res.cnt_names.size() == res.cnt_viols.size());
+  EXPECT_TRUE(res.cost_names.size() == 1 + 29 && res.cost_names[0] == "joint_vel" && res.cost_names[1] == "collision_1" &&
+              res.cost_names.back() == "collision_29");
+  EXPECT_TRUE(res.cnt_names.size() == 29 + 1 && res.cnt_names[0] == "upright_1" && res.cnt_names.back() == "goal");
+  EXPECT_TRUE(res.traj.rows() == 30 && res.traj.cols() == 7 && res.traj.data == opt.x());
 }
 
 // ---- trajopt/test/joint_costs_unit.cpp:63-141 (equality_jointPos) and :152-253 (inequality_jointPos) -------------------
@@ -520,6 +527,10 @@ static void caseCartPosition(const Input& in)
     for (std::size_t c = 0; c < 3; ++c)
       EXPECT_NEAR(target_pose.m[r * 4 + c], optimized_pose.m[r * 4 + c], 2e-5);  // quaternion isApprox 1e-5
   printResults("cart_position", opt);
+  // the same through OptimizeProblem (problem_description.cpp:396-408: planner-style parameters, own initial trajectory)
+  const TrajOptResult::Ptr res = OptimizeProblem(prob);
+  EXPECT_TRUE(res->status == OptStatus::OPT_CONVERGED && res->cnt_names.size() == 1 && res->cnt_names[0] == "waypoint_cart_0");
+  EXPECT_TRUE(res->cnt_viols.size() == 1 && res->cnt_viols[0] < 1e-4 && res->cost_names.empty());
 }
 
 // ---- trajopt/test/interface_unit.cpp:50-90 (initial trajectory through the C++ interface) and :236-262 (bitmask) --------

@@ -157,3 +157,15 @@ def test_collision_fixed_steps_are_the_terms_own(orc):
     next(c for c in bad["costs"] if c["type"] == "collision")["params"]["first_step"] = 2
     with pytest.raises(ValueError, match="Fixed step 0 is not between"):
         json_io.construct_problem(bad, env)
+
+
+def test_optimize_problem_and_names(hostemu_lib):
+    """trajopt::OptimizeProblem / TrajOptResult (problem_description.cpp:380-408): names line up with the values"""
+    from trajopt_amd import runtime
+    env, pci, start, goal = _env(1)
+    pp = json_io.construct_problem(open(os.path.join(HERE, "golden", "json", "glass_upright_cfg1.json")).read(), env)
+    res = runtime.OptimizeProblem(pp.pci, pp.init_traj, lib_path=hostemu_lib)
+    assert len(res["cost_names"]) == len(res["cost_vals"]) == 30 and len(res["cnt_names"]) == len(res["cnt_viols"]) == 30
+    assert res["cost_names"][0] == "joint_vel" and res["cost_names"][1] == "collision_1" and res["cost_names"][-1] == "collision_29"
+    assert res["cnt_names"][0].startswith("upright") and res["traj"].shape == (30, 7)
+    assert res["status"] in (0, 1, 2) and res["cnt_viols"].max() < 1e-3

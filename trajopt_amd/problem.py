@@ -187,6 +187,28 @@ class ProblemConstructionInfo:
         self.obstacles: List[tuple] = []     # ((x,y,z), r)
         self._keep = []
 
+    # -- names of the expanded costs / constraints (TrajOptResult::cost_names / cnt_names, problem_description.cpp:380-394)
+    def _expand_names(self, ti):
+        T = self.basic_info.n_steps
+        if isinstance(ti, CollisionTermInfo):     # one CollisionCost / CollisionConstraint "name_<step>" per non-fixed step
+            last = ti.last_step if ti.last_step >= 0 else T - 1
+            return [f"{ti.name}_{i}" for i in range(ti.first_step, last + 1) if i not in list(ti.fixed_steps)]
+        return [ti.name]
+
+    def cost_names(self) -> List[str]:
+        return [n for ti in self.cost_infos for n in self._expand_names(ti)]
+
+    def cnt_names(self) -> List[str]:
+        """equalities in front of the inequalities, as sco::OptProb orders them (modeling.cpp:234-241)"""
+        def is_ineq(ti):
+            if isinstance(ti, CollisionTermInfo):
+                return True
+            if isinstance(ti, JointPosTermInfo):
+                return any(abs(x) >= 1e-5 for x in list(ti.upper_tols) + list(ti.lower_tols))
+            return False
+        eq = [n for ti in self.cnt_infos if not is_ineq(ti) for n in self._expand_names(ti)]
+        return eq + [n for ti in self.cnt_infos if is_ineq(ti) for n in self._expand_names(ti)]
+
     # -- lowering -----------------------------------------------------------------------------------
     def to_desc(self) -> abi.ProblemDesc:
         rob, T, D = self.robot, self.basic_info.n_steps, self.robot.n_dof

@@ -270,3 +270,18 @@ class BatchedTrustRegionSQP:
 
     def results(self):
         return self.ctx.results()
+
+
+def OptimizeProblem(pci, init_traj, device: int = 0, lib_path: str = None):
+    """trajopt::OptimizeProblem (problem_description.cpp:396-408): BasicTrustRegionSQP with the reference's planner-style
+    parameters on the given initial trajectory [n_steps][n_dof]; returns the fields of trajopt::TrajOptResult"""
+    opt = BatchedTrustRegionSQP(pci, device=device, lib_path=lib_path)
+    p = opt.getParameters()
+    p.max_iter, p.min_approx_improve_frac, p.improve_ratio_threshold, p.initial_merit_error_coeff = 40, 0.001, 0.2, 20.0
+    opt.initialize(np.asarray(init_traj, dtype=np.float64)[None, :, :])
+    opt.optimize()
+    r = opt.results()
+    cv, vv = opt.ctx.evaluate()
+    opt.ctx.close()
+    return dict(cost_names=pci.cost_names(), cnt_names=pci.cnt_names(), cost_vals=cv[0], cnt_viols=vv[0], traj=r["x"][0],
+                status=int(r["status"][0]))
