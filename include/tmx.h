@@ -102,7 +102,16 @@ typedef enum
   /* trajopt::CollisionTermInfo::hatch, TT_CNT, DISCRETE / SINGLE_TIME_STEP: one CollisionConstraint per non-fixed step
    * (problem_description.cpp:1821-1835; collision_terms.cpp:1369-1420): per contact the inequality row
    * (margin - dist_expr) * coeff <= 0, violation pospart(margin - dist) * coeff                                  */
-  TMX_TERM_COLLISION_CNT = 8
+  TMX_TERM_COLLISION_CNT = 8,
+  /* trajopt::JointVelEqConstraint  trajopt/src/trajectory_costs.cpp:376-424 — JointVelTermInfo (TT_CNT), zero tolerances:
+     per step i in [first_step, last_step - 1] and joint j the equality row coeff_j * (x[i+1][j] - x[i][j] - target_j) == 0.
+     Rows of the three JointVel kinds below touch TWO consecutive waypoints (one joint each). */
+  TMX_TERM_JOINT_VEL_EQ_CNT = 9,
+  /* trajopt::JointVelIneqCost  trajectory_costs.cpp:303-374 — JointVelTermInfo (TT_COST), non-zero tolerances: two hinge
+     rows per (step, joint), -(upper_tol - vel) * coeff and (lower_tol - vel) * coeff with vel = x[i+1][j] - x[i][j] - target_j */
+  TMX_TERM_JOINT_VEL_INEQ_COST = 10,
+  /* trajopt::JointVelIneqConstraint  trajectory_costs.cpp:426-499 — the same two rows as inequality constraints */
+  TMX_TERM_JOINT_VEL_INEQ_CNT = 11
 } tmx_term_kind;
 
 typedef struct

@@ -329,6 +329,184 @@ private:
   QuadExpr expr_;
 };
 
+// ---- trajopt::JointVelEqConstraint  trajectory_costs.cpp:376-424 (value() is coeff*diff^2, convex() coeff*diff) ----
+class JointVelEqConstraint : public Constraint
+{
+public:
+  JointVelEqConstraint(const VarArray& vars, DblVec coeffs, DblVec targets, int first_step, int last_step)
+    : vars_(vars), coeffs_(std::move(coeffs)), targets_(std::move(targets)), first_step_(first_step), last_step_(last_step)
+  {
+    name_ = "JointVelEq";
+    if (((last_step_ - 1) - first_step_) < 0)
+      throw std::runtime_error("JointVelEqConstraint, trajectory is too short!");
+    for (int i = first_step_; i <= last_step_ - 1; ++i)
+      for (int j = 0; j < vars_.cols; ++j)
+      {
+        AffExpr vel;  // vel = (x2 - x1) - targ                                (:392-397)
+        exprInc(vel, exprMult(vars_(i, j), -1));
+        exprInc(vel, exprMult(vars_(i + 1, j), 1));
+        exprDec(vel, targets_[j]);
+        expr_vec_.push_back(exprMult(vel, coeffs_[j]));  // :399
+      }
+  }
+  ConstraintType type() override { return EQ; }
+  DblVec value(const DblVec& x) override
+  {
+    // toDblVec((diff.array().square()).matrix() * coeffs.asDiagonal()): column-major copy of the (steps-1) x dof block
+    DblVec out;
+    for (int j = 0; j < vars_.cols; ++j)
+      for (int i = first_step_; i <= last_step_ - 1; ++i)
+      {
+        const double d = (vars_(i + 1, j).value(x) - vars_(i, j).value(x)) - targets_[j];
+        out.push_back((d * d) * coeffs_[j]);
+      }
+    return out;
+  }
+  std::shared_ptr<ConvexConstraints> convex(const DblVec&, Model* model) override
+  {
+    auto out = std::make_shared<ConvexConstraints>(model);
+    for (const AffExpr& e : expr_vec_)
+      out->addEqCnt(e);
+    return out;
+  }
+
+private:
+  VarArray vars_;
+  DblVec coeffs_, targets_;
+  int first_step_, last_step_;
+  AffExprVector expr_vec_;
+};
+
+// the two hinge rows per (step, joint) shared by JointVelIneqCost (:303-374) and JointVelIneqConstraint (:426-499):
+//   -(upper_tol - (vel - targ)) * coeff   and   (lower_tol - (vel - targ)) * coeff
+inline AffExprVector jointVelIneqExprs(const VarArray& vars, const DblVec& coeffs, const DblVec& targets, const DblVec& upper,
+                                       const DblVec& lower, int first_step, int last_step)
+{
+  AffExprVector out;
+  for (int i = first_step; i <= last_step - 1; ++i)
+    for (int j = 0; j < vars.cols; ++j)
+    {
+      AffExpr vel;
+      exprInc(vel, exprMult(vars(i, j), -1));
+      exprInc(vel, exprMult(vars(i + 1, j), 1));
+      exprDec(vel, targets[j]);
+      AffExpr expr;
+      exprInc(expr, upper[j]);
+      exprDec(expr, vel);
+      exprScale(expr, -coeffs[j]);
+      out.push_back(expr);
+      AffExpr expr_neg;
+      exprInc(expr_neg, lower[j]);
+      exprDec(expr_neg, vel);
+      exprScale(expr_neg, coeffs[j]);
+      out.push_back(expr_neg);
+    }
+  return out;
+}
+
+// ---- trajopt::JointVelIneqCost  trajectory_costs.cpp:303-374 ----
+class JointVelIneqCost : public Cost
+{
+public:
+  JointVelIneqCost(const VarArray& vars, DblVec coeffs, DblVec targets, DblVec upper, DblVec lower, int first_step, int last_step)
+    : vars_(vars)
+    , coeffs_(std::move(coeffs))
+    , targets_(std::move(targets))
+    , upper_tols_(std::move(upper))
+    , lower_tols_(std::move(lower))
+    , first_step_(first_step)
+    , last_step_(last_step)
+  {
+    name_ = "JointVelIneq";
+    if (((last_step_ - 1) - first_step_) < 0)
+      throw std::runtime_error("JointVelIneqCost, trajectory is too short!");
+    expr_vec_ = jointVelIneqExprs(vars_, coeffs_, targets_, upper_tols_, lower_tols_, first_step_, last_step_);
+  }
+  double value(const DblVec& x) override
+  {
+    // diff1.cwiseMax(0).sum() + diff2.cwiseMax(0).sum(), each a column-major reduction over (steps-1) x dof  (:349-361)
+    double s1 = 0, s2 = 0;
+    for (int j = 0; j < vars_.cols; ++j)
+      for (int i = first_step_; i <= last_step_ - 1; ++i)
+      {
+        const double d0 = (vars_(i + 1, j).value(x) - vars_(i, j).value(x)) - targets_[j];
+        s1 += std::fmax((d0 - upper_tols_[j]) * coeffs_[j], 0.0);
+      }
+    for (int j = 0; j < vars_.cols; ++j)
+      for (int i = first_step_; i <= last_step_ - 1; ++i)
+      {
+        const double d0 = (vars_(i + 1, j).value(x) - vars_(i, j).value(x)) - targets_[j];
+        s2 += std::fmax(((d0 * -1) + lower_tols_[j]) * coeffs_[j], 0.0);
+      }
+    return s1 + s2;
+  }
+  std::shared_ptr<ConvexObjective> convex(const DblVec&, Model* model) override
+  {
+    auto out = std::make_shared<ConvexObjective>(model);
+    for (const AffExpr& e : expr_vec_)
+      out->addHinge(e, 1);  // the coefficient is already in the AffExpr (:364-373)
+    return out;
+  }
+
+private:
+  VarArray vars_;
+  DblVec coeffs_, targets_, upper_tols_, lower_tols_;
+  int first_step_, last_step_;
+  AffExprVector expr_vec_;
+};
+
+// ---- trajopt::JointVelIneqConstraint  trajectory_costs.cpp:426-499 ----
+class JointVelIneqConstraint : public Constraint
+{
+public:
+  JointVelIneqConstraint(const VarArray& vars, DblVec coeffs, DblVec targets, DblVec upper, DblVec lower, int first_step, int last_step)
+    : vars_(vars)
+    , coeffs_(std::move(coeffs))
+    , targets_(std::move(targets))
+    , upper_tols_(std::move(upper))
+    , lower_tols_(std::move(lower))
+    , first_step_(first_step)
+    , last_step_(last_step)
+  {
+    name_ = "JointVelIneq";
+    if (((last_step_ - 1) - first_step_) < 0)
+      throw std::runtime_error("JointVelIneqConstraint, trajectory is too short!");
+    expr_vec_ = jointVelIneqExprs(vars_, coeffs_, targets_, upper_tols_, lower_tols_, first_step_, last_step_);
+  }
+  ConstraintType type() override { return INEQ; }
+  DblVec value(const DblVec& x) override
+  {
+    // out << diff1, diff2 ; toDblVec(out.cwiseMax(0)): column-major copy  (:472-487)
+    DblVec out;
+    for (int j = 0; j < vars_.cols; ++j)
+      for (int i = first_step_; i <= last_step_ - 1; ++i)
+      {
+        const double d0 = (vars_(i + 1, j).value(x) - vars_(i, j).value(x)) - targets_[j];
+        out.push_back(std::fmax((d0 - upper_tols_[j]) * coeffs_[j], 0.0));
+      }
+    for (int j = 0; j < vars_.cols; ++j)
+      for (int i = first_step_; i <= last_step_ - 1; ++i)
+      {
+        const double d0 = (vars_(i + 1, j).value(x) - vars_(i, j).value(x)) - targets_[j];
+        out.push_back(std::fmax(((d0 * -1) + lower_tols_[j]) * coeffs_[j], 0.0));
+      }
+    return out;
+  }
+  std::shared_ptr<ConvexConstraints> convex(const DblVec&, Model* model) override
+  {
+    auto out = std::make_shared<ConvexConstraints>(model);
+    for (const AffExpr& e : expr_vec_)
+      out->addIneqCnt(e);
+    return out;
+  }
+
+private:
+  VarArray vars_;
+  DblVec coeffs_, targets_, upper_tols_, lower_tols_;
+  int first_step_, last_step_;
+  AffExprVector expr_vec_;
+};
+
 // ---- trajopt::JointPosEqConstraint  trajectory_costs.cpp:139-183 (quirk Q5: value() is coeff*diff^2) ----
 class JointPosEqConstraint : public Constraint
 {
@@ -798,6 +976,7 @@ inline TrajProblem constructProblem(const tmx_problem_desc& d, const double* ini
     {
       const tmx_term& tm = d.terms[k];
       const bool is_cnt = (tm.kind == TMX_TERM_JOINT_POS_EQ_CNT) || (tm.kind == TMX_TERM_JOINT_POS_INEQ_CNT) || (tm.kind == TMX_TERM_COLLISION_CNT) ||
+                          (tm.kind == TMX_TERM_JOINT_VEL_EQ_CNT) || (tm.kind == TMX_TERM_JOINT_VEL_INEQ_CNT) ||
                           (tm.kind == TMX_TERM_CART_POSE && tm.is_constraint);
       if ((pass == 0) == is_cnt)
         continue;
@@ -806,6 +985,20 @@ inline TrajProblem constructProblem(const tmx_problem_desc& d, const double* ini
         case TMX_TERM_JOINT_VEL_COST:
           P.prob->addCost(std::make_shared<JointVelEqCost>(P.traj_vars, DblVec(tm.coeffs, tm.coeffs + D),
                                                            DblVec(tm.targets, tm.targets + D), tm.first_step, tm.last_step));
+          break;
+        case TMX_TERM_JOINT_VEL_EQ_CNT:
+          P.prob->addConstraint(std::make_shared<JointVelEqConstraint>(
+              P.traj_vars, DblVec(tm.coeffs, tm.coeffs + D), DblVec(tm.targets, tm.targets + D), tm.first_step, tm.last_step));
+          break;
+        case TMX_TERM_JOINT_VEL_INEQ_COST:
+          P.prob->addCost(std::make_shared<JointVelIneqCost>(P.traj_vars, DblVec(tm.coeffs, tm.coeffs + D), DblVec(tm.targets, tm.targets + D),
+                                                             DblVec(tm.upper_tols, tm.upper_tols + D),
+                                                             DblVec(tm.lower_tols, tm.lower_tols + D), tm.first_step, tm.last_step));
+          break;
+        case TMX_TERM_JOINT_VEL_INEQ_CNT:
+          P.prob->addConstraint(std::make_shared<JointVelIneqConstraint>(
+              P.traj_vars, DblVec(tm.coeffs, tm.coeffs + D), DblVec(tm.targets, tm.targets + D), DblVec(tm.upper_tols, tm.upper_tols + D),
+              DblVec(tm.lower_tols, tm.lower_tols + D), tm.first_step, tm.last_step));
           break;
         case TMX_TERM_JOINT_POS_EQ_CNT:
           P.prob->addConstraint(std::make_shared<JointPosEqConstraint>(

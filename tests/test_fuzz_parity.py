@@ -21,6 +21,11 @@ def test_random_problems_on_host_build(hostemu_lib, orc):
     _sweep(40, 7, hostemu_lib)
 
 
+def test_random_problems_with_two_waypoint_rows_on_host_build(hostemu_lib, orc):
+    """JointVelEqConstraint / JointVelIneqCost / JointVelIneqConstraint rows (TMX_LINK_ROWS builds: the host build)"""
+    _sweep(40, 31, hostemu_lib, "links")
+
+
 def test_random_wide_problems_on_host_build(hostemu_lib, orc):
     """9-11 DOF chains, longer horizons, single-waypoint problems: the generic block-chain path"""
     _sweep(40, 21, hostemu_lib, "wide")

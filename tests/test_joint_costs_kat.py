@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 from trajopt_amd import abi, runtime
-from trajopt_amd.problem import BasicInfo, JointPosTermInfo, ProblemConstructionInfo, pr2_right_arm
+from trajopt_amd.problem import BasicInfo, JointPosTermInfo, JointVelTermInfo, ProblemConstructionInfo, pr2_right_arm
 
 STEPS = 10
 
@@ -88,3 +88,82 @@ def test_joint_pos_kat_device(orc, name, make, check):
     assert (r["status"] == o["status"][0]).all()
     assert np.abs(r["x"] - o["x"][0][None]).max() < 1e-5
     opt.ctx.close()
+
+
+# ---- joint_costs_unit.cpp:264-345 (equality_jointVel) and :354-463 (inequality_jointVel) -----------------------------------
+# JointVelEqConstraint / JointVelIneqCost / JointVelIneqConstraint put rows on TWO consecutive waypoints.  The kernel
+# sources handle them (generic block-chain path, -DTMX_LINK_ROWS=1: the host build of the CPU tier); the product library is
+# still compiled without them until that path has been validated on the GPU, and rejects these terms explicitly.
+def _equality_vel():
+    rob = pr2_right_arm()
+    pci = ProblemConstructionInfo(rob, BasicInfo(n_steps=STEPS))
+    pci.cnt_infos.append(JointVelTermInfo(coeffs=[10.0] * 7, targets=[0.0] * 7, first_step=0, last_step=0, is_constraint=True,
+                                          name="joint_vel_single"))
+    pci.cost_infos.append(JointVelTermInfo(coeffs=[10.0] * 7, targets=[0.1] * 7, first_step=0, last_step=STEPS - 1, name="joint_vel_all"))
+    return pci
+
+
+def _inequality_vel():
+    rob = pr2_right_arm()
+    pci = ProblemConstructionInfo(rob, BasicInfo(n_steps=STEPS))
+    pci.cnt_infos.append(JointVelTermInfo(coeffs=[1.0] * 7, targets=[0.0] * 7, lower_tols=[-0.1] * 7, upper_tols=[0.2] * 7, first_step=0,
+                                          last_step=STEPS - 1, is_constraint=True, name="joint_vel_limits"))
+    half = (STEPS - 1) // 2
+    pci.cost_infos.append(JointVelTermInfo(coeffs=[1.0] * 7, targets=[0.5] * 7, lower_tols=[-0.01] * 7, upper_tols=[0.0] * 7, first_step=0,
+                                           last_step=half, name="joint_vel_targ_1"))
+    pci.cost_infos.append(JointVelTermInfo(coeffs=[1.0] * 7, targets=[-0.5] * 7, lower_tols=[-0.01] * 7, upper_tols=[0.01] * 7,
+                                           first_step=half + 1, last_step=STEPS - 1, name="joint_vel_targ_2"))
+    return pci
+
+
+def _check_equality_vel(x):
+    v = np.diff(x, axis=0)
+    assert np.abs(v[0] - 0.0).max() <= 1e-4          # :325-330
+    assert np.abs(v[1:] - 0.1).max() <= 0.01          # :331-339
+
+
+def _check_inequality_vel(x):
+    v = np.diff(x, axis=0)
+    assert (v < 0.2 + 1e-4).all() and (v > -0.1 - 1e-4).all()   # :435-461
+
+
+VEL_CASES = [("equality_vel", _equality_vel, _check_equality_vel), ("inequality_vel", _inequality_vel, _check_inequality_vel)]
+
+
+@pytest.mark.parametrize("name,make,check", VEL_CASES)
+def test_joint_vel_kat_oracle(orc, name, make, check):
+    o = orc.sqp_batch(make().to_desc(), np.zeros((1, STEPS, 7)))
+    assert o["status"][0] == abi.OPT_CONVERGED
+    check(o["x"][0])
+
+
+@pytest.mark.parametrize("name,make,check", VEL_CASES)
+def test_joint_vel_kat_kernel_sources_on_host(hostemu_lib, orc, name, make, check):
+    import parity_checks as pc
+    pci = make()
+    rob = pci.robot
+    x0 = np.zeros((2, STEPS, 7))
+    x0[1] = np.clip(0.05 * np.random.default_rng(1).standard_normal((STEPS, 7)), rob.lower + 1e-3, rob.upper - 1e-3)
+    ctx = runtime.Context(0, hostemu_lib)
+    desc = pc.make_ctx_inputs(ctx, pci, x0)
+    pc.check_evaluate(ctx, orc, desc, x0, tol=1e-12)
+    for b in range(2):
+        pc.check_first_qp_structure(ctx, orc, desc, x0, b, val_tol=1e-12)     # incl. the merged two-waypoint columns of A
+    assert all(same for same, _ in pc.check_first_qp_solve(ctx, orc, desc, x0))
+    ctx.set_x0(x0)
+    r, o, same, dx = pc.check_full_sqp(ctx, orc, desc, x0, exact=False)
+    assert same.all() and (r["status"] == abi.OPT_CONVERGED).all()
+    for b in range(2):
+        check(r["x"][b])
+        # without a fixed waypoint the problem is translation invariant: compare the velocities
+        assert np.abs(np.diff(r["x"][b], axis=0) - np.diff(o["x"][b], axis=0)).max() < 1e-5
+    ctx.close()
+
+
+def test_product_library_rejects_two_waypoint_rows_explicitly():
+    """until the link-row path is validated on the GPU the product build says so instead of computing something else"""
+    import os, subprocess
+    lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "trajopt_amd", "_build", "libtrajopt_mi355x.so")
+    assert os.path.exists(lib)
+    out = subprocess.run(["strings", lib], capture_output=True, text=True).stdout
+    assert "JointVel constraint / hinge forms (rows on two consecutive waypoints) are not enabled in this build" in out

@@ -1,5 +1,5 @@
 """Randomised stage-by-stage parity sweep: random serial chains, term sets and seeds -> device path (or the kernel sources
-built for the host) vs the oracle.   python tests/tools/fuzz_parity.py [n_cases] [seed] [lib.so|gpu] [wide]
+built for the host) vs the oracle.   python tests/tools/fuzz_parity.py [n_cases] [seed] [lib.so|gpu] [wide] [links]
 Checks per case: exact term values, first-QP CSC (integer arrays bit-exact modulo noise entries), first Model::optimize
 (same OSQP status / iteration count / rho updates / polish status, |dx| <= 1e-5), whole SQP (same status and counters ->
 |dx| <= 1e-5).  Prints one line per failing case and a summary; exit code 1 if anything failed."""
@@ -14,7 +14,7 @@ from oracle import pyorc as orc
 import parity_checks as pc
 
 
-def random_problem(rng, wide=False):
+def random_problem(rng, wide=False, links=False):
     """wide=False: D <= 8 and T * D <= 256 (the dense fast path on the device); wide=True also draws 9-11 DOF chains,
     longer horizons (T * D up to ~400) and single-waypoint problems: the generic block-chain path"""
     if wide:
@@ -74,6 +74,23 @@ def random_problem(rng, wide=False):
         a, b = sorted(int(v) for v in rng.integers(1, T - 1, 2))
         pci.cnt_infos.append(JointPosTermInfo(coeffs=list(rng.uniform(0.5, 2.0, D)), targets=list(0.5 * (start + goal)), first_step=a,
                                               last_step=b, upper_tols=list(rng.uniform(0.4, 1.0, D)), lower_tols=list(-rng.uniform(0.4, 1.0, D))))
+    if links and T > 2:
+        # rows on two consecutive waypoints (JointVelEqConstraint / JointVelIneqCost / JointVelIneqConstraint): host build only
+        vmax = float(np.abs(goal - start).max()) / (T - 1)
+        if rng.random() < 0.6:
+            a, b = sorted(int(v) for v in rng.integers(0, T, 2))
+            pci.cnt_infos.append(JointVelTermInfo(coeffs=list(rng.uniform(0.5, 2.0, D)), targets=[0.0] * D, first_step=a, last_step=b,
+                                                  upper_tols=[1.5 * vmax + 0.05] * D, lower_tols=[-(1.5 * vmax + 0.05)] * D, is_constraint=True,
+                                                  name="vel_limits"))
+        if rng.random() < 0.4:
+            a, b = sorted(int(v) for v in rng.integers(0, T, 2))
+            pci.cost_infos.append(JointVelTermInfo(coeffs=list(rng.uniform(0.5, 2.0, D)), targets=list((goal - start) / (T - 1)), first_step=a,
+                                                   last_step=b, upper_tols=list(rng.uniform(0.01, 0.1, D)), lower_tols=list(-rng.uniform(0.01, 0.1, D)),
+                                                   name="vel_band"))
+        if rng.random() < 0.3:
+            a = int(rng.integers(0, T - 1))
+            pci.cnt_infos.append(JointVelTermInfo(coeffs=list(rng.uniform(0.5, 5.0, D)), targets=list((goal - start) / (T - 1)), first_step=a,
+                                                  last_step=a, is_constraint=True, name="vel_eq"))
     if rng.random() < 0.8:
         pci.cnt_infos.append(JointPosTermInfo(coeffs=[1.0] * D, targets=list(goal), first_step=T - 1, last_step=T - 1))
     w = np.linspace(0.0, 1.0, T)[:, None]
@@ -87,6 +104,9 @@ def main():
     wide = "wide" in sys.argv
     if wide:
         sys.argv.remove("wide")
+    links = "links" in sys.argv      # two-waypoint rows: kernel sources built with -DTMX_LINK_ROWS=1 (the host build) only
+    if links:
+        sys.argv.remove("links")
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 50
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     lib = sys.argv[3] if len(sys.argv) > 3 else os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests", "hostemu", "_build", "libtmx_hostemu.so")
@@ -94,7 +114,7 @@ def main():
     fails, soft, diverged = 0, 0, 0
     for k in range(n):
         rng = np.random.default_rng([seed, k])
-        pci, x0 = random_problem(rng, wide)
+        pci, x0 = random_problem(rng, wide, links)
         tag = f"case {seed}/{k}: D={pci.robot.n_dof} T={pci.basic_info.n_steps} costs={len(pci.cost_infos)} cnts={len(pci.cnt_infos)}"
         ctx = runtime.Context(0, None if on_gpu else lib)
         try:

@@ -233,6 +233,8 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
   // ---- slot template in reference row order ----
   std::vector<int> kind, st, sub, sub2, owner, naux, iscnt, iseq;
   std::vector<double> objc, scale, aux1, aux2;
+  std::vector<int> lkj;
+  std::vector<double> lkc;
   auto add_slot = [&](int k, int t, int s1, int s2, int own, int na, int isc, int eq, double oc, double sc, double a1, double a2) {
     kind.push_back(k);
     st.push_back(t);
@@ -246,6 +248,8 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
     scale.push_back(sc);
     aux1.push_back(a1);
     aux2.push_back(a2);
+    lkj.push_back(-1);
+    lkc.push_back(0.0);
   };
   std::vector<int> fixed(d->fixed_steps, d->fixed_steps + d->n_fixed_steps);
   for (int t : fixed)
@@ -282,8 +286,9 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
     for (int k = 0; k < d->n_terms; ++k)
     {
       const tmx_term& tm = d->terms[k];
-      const bool is_ineq = tm.kind == TMX_TERM_JOINT_POS_INEQ_CNT || tm.kind == TMX_TERM_COLLISION_CNT;
-      const bool is_cnt = is_ineq || (tm.kind == TMX_TERM_JOINT_POS_EQ_CNT) || (tm.kind == TMX_TERM_CART_POSE && tm.is_constraint);
+      const bool is_ineq = tm.kind == TMX_TERM_JOINT_POS_INEQ_CNT || tm.kind == TMX_TERM_COLLISION_CNT || tm.kind == TMX_TERM_JOINT_VEL_INEQ_CNT;
+      const bool is_cnt = is_ineq || (tm.kind == TMX_TERM_JOINT_POS_EQ_CNT) || (tm.kind == TMX_TERM_JOINT_VEL_EQ_CNT) ||
+                          (tm.kind == TMX_TERM_CART_POSE && tm.is_constraint);
       const int want = !is_cnt ? 0 : (is_ineq ? 2 : 1);
       if (pass != want)
         continue;
@@ -351,6 +356,46 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
             for (int j = 0; j < D; ++j)
               add_slot(SLOT_JOINTPOS, i, j, 0, own, 2, 1, 1, 0.0, tm.coeffs[j], tm.targets[j], 0.0);
           break;
+        }
+        case TMX_TERM_JOINT_VEL_EQ_CNT:
+        case TMX_TERM_JOINT_VEL_INEQ_COST:
+        case TMX_TERM_JOINT_VEL_INEQ_CNT:
+        {
+#if !TMX_LINK_ROWS
+          ctx->err = "JointVel constraint / hinge forms (rows on two consecutive waypoints) are not enabled in this build";
+          return TMX_ERR_UNSUPPORTED;
+#else
+          if (tm.last_step - 1 - tm.first_step < 0)
+          {
+            ctx->err = "JointVel term, trajectory is too short!";  // trajectory_costs.cpp:320, :390, :444
+            return TMX_ERR_INVALID;
+          }
+          // one row (EQ) or an upper and a lower row (INEQ) per step i in [first, last - 1] and joint j, in the order of the
+          // reference's expr_vec_ (trajectory_costs.cpp:322-346, 392-400, 446-470): home coefficient on x[i][j], link on x[i+1][j]
+          const bool is_cnt = tm.kind != TMX_TERM_JOINT_VEL_INEQ_COST;
+          const int own = is_cnt ? n_cnts++ : n_costs++;
+          for (int i = tm.first_step; i <= tm.last_step - 1; ++i)
+            for (int j = 0; j < D; ++j)
+            {
+              const double c = tm.coeffs[j];
+              if (tm.kind == TMX_TERM_JOINT_VEL_EQ_CNT)
+              {
+                add_slot(SLOT_JOINTVEL, i, j, 0, own, 2, 1, 1, 0.0, c, tm.targets[j], 0.0);
+                lkj.back() = j;
+                lkc.back() = (0.0 + (1.0 * 1)) * c;  // exprMult(vel, coeff): coefficient of x[i+1][j]
+              }
+              else
+              {
+                add_slot(SLOT_JOINTVEL_INEQ, i, j, 0, own, 1, is_cnt ? 1 : 0, 0, is_cnt ? 0.0 : 1.0, c, tm.targets[j], tm.upper_tols[j]);
+                lkj.back() = j;
+                lkc.back() = (0.0 - (1.0 * 1)) * -c;  // -(upper_tol - vel) * coeff: +coeff on x[i+1][j]
+                add_slot(SLOT_JOINTVEL_INEQ, i, j, 1, own, 1, is_cnt ? 1 : 0, 0, is_cnt ? 0.0 : 1.0, c, tm.targets[j], tm.lower_tols[j]);
+                lkj.back() = j;
+                lkc.back() = (0.0 - (1.0 * 1)) * c;  // (lower_tol - vel) * coeff: -coeff on x[i+1][j]
+              }
+            }
+          break;
+#endif
         }
         case TMX_TERM_JOINT_POS_EQ_COST:
         {
@@ -542,6 +587,9 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
   UP(slot_scale, scale);
   UP(slot_aux1, aux1);
   UP(slot_aux2, aux2);
+  UP(slot_lkj, lkj);
+  UP(slot_lkc, lkc);
+  P.n_link = static_cast<int>(std::count_if(lkj.begin(), lkj.end(), [](int j) { return j >= 0; }));
   UP(wp_start, wp_start);
   UP(wp_list, wp_list);
   UP(pd, pd);

@@ -37,7 +37,7 @@ TMX_DEVFN void part_invert_interior(const QpWs& w, int t0, int t1, int lane)
   {
     double s = valid ? w.Sinv[t * DDS + i * DS + j] : 0.0;
     if (t > t0 && valid)
-      s -= w.po[(t - 1) * D + i] * prev * w.po[(t - 1) * D + j];
+      s -= TMX_PC(w)[(t - 1) * D + i] * prev * TMX_PC(w)[(t - 1) * D + j];
     for (int k = 0; k < D; ++k)
     {
       const double pkk = __shfl(s, k * D + k, 64);

@@ -164,7 +164,40 @@ struct QpWs
   int *wp_start, *wp_list;  // LDS copies of DevProblem::wp_start / wp_list (hot in every SpMV)
   int *wp_pst;               // T+1: even-aligned start of every waypoint's group in the grouped e exchange (fast path)
   int *row_epos;             // R: position of every row in that grouped buffer
+#if TMX_LINK_ROWS
+  // rows with a link to the next waypoint (JointVel constraint / hinge forms): row r of waypoint t carries ONE more
+  // coefficient lkc[r] on variable (t + 1, lkj[r]); the reduced KKT stays block-tridiagonal with diagonal couplings
+  const int *lkj;  // R (DevProblem::slot_lkj): joint of the linked variable, -1 = none
+  double *lkc;     // R: the (scaled) link coefficient
+  double *pc;      // NX: chain coupling = objective coupling po + the rows' contribution (rebuilt by kkt_factor)
+  int n_link;
+#endif
 };
+
+#if TMX_LINK_ROWS
+#define TMX_PC(w) ((w).pc)
+// x-part of row r (home waypoint t) on the next waypoint
+TMX_DEVFN double link_dot(const QpWs& w, int r, int t, const double* x)
+{
+  const int j = w.lkj[r];
+  return (j >= 0) ? w.lkc[r] * x[(t + 1) * w.D + j] : 0.0;
+}
+// (A'rv) contribution to variable (t, j) of the rows of waypoint t-1 that link to it
+TMX_DEVFN double link_gather(const QpWs& w, const double* rv, int t, int j)
+{
+  double s = 0.0;
+  if (w.n_link > 0 && t > 0)
+    for (int q = w.wp_start[t - 1]; q < w.wp_start[t]; ++q)
+    {
+      const int r = w.wp_list[q];
+      if (w.act[r] && w.lkj[r] == j)
+        s += rv[r] * w.lkc[r];
+    }
+  return s;
+}
+#else
+#define TMX_PC(w) ((w).po)
+#endif
 
 // The workspace is split by access frequency:
 //   HOT  (LDS, touched every ADMM iteration): the exchange vectors tp / ty / hr, the coupling po, the explicit
@@ -252,7 +285,7 @@ TMX_HOSTDEVFN size_t qp_lds_doubles(int D, int T, int R, int NA)
 TMX_HOSTDEVFN size_t qp_glb_doubles(int D, int T, int R, int NA)
 {
   const size_t NX = (size_t)D * T;
-  const size_t n = 10 * NX + 6 * (size_t)R + (size_t)R * D + 8 * (size_t)NA;
+  const size_t n = 10 * NX + 6 * (size_t)R + (size_t)R * D + 8 * (size_t)NA + (TMX_LINK_ROWS ? (size_t)R + NX : 0);
   const size_t ints = 7 * (size_t)R + (size_t)NX + (size_t)NA + 2 * (size_t)T + 4;
   return n + (ints + 1) / 2 + 8;
 }
@@ -362,6 +395,10 @@ TMX_DEVFN void qp_ws_carve(QpWs& w, double* lds, double* glb, double* far, int D
   TAKE(bba, NA);
   TAKE(sa, NA);
   TAKE(dinv, NA);
+#if TMX_LINK_ROWS
+  TAKE(lkc, R);
+  TAKE(pc, NX);
+#endif
   int* ip = reinterpret_cast<int*>(p);
 #define TAKEI(name, n)                                                                                                \
   w.name = ip;                                                                                                        \
@@ -470,6 +507,30 @@ TMX_DEVFN void kkt_factor(const QpWs& w, const DevProblem* P, int mode, double s
     {
       const int v = t * D + i;
       s += w.pd[v] + sig + w_bp(w, v, mode, delta) * w.bbp[v] * w.bbp[v];
+#if TMX_LINK_ROWS
+      // rows of waypoint t-1 linked to (t, i): we * lkc^2 on the diagonal; rows of waypoint t linked to (t+1, i): their
+      // product with the home coefficient is the coupling of the chain
+      if (w.n_link > 0)
+      {
+        if (t > 0)
+          for (int q = w.wp_start[t - 1]; q < w.wp_start[t]; ++q)
+          {
+            const int r = w.wp_list[q];
+            if (w.act[r] && w.lkj[r] == i)
+              s += w.hr[r] * w.lkc[r] * w.lkc[r];
+          }
+        double c = w.po[v];
+        for (int q = w.wp_start[t]; q < w.wp_start[t + 1]; ++q)
+        {
+          const int r = w.wp_list[q];
+          if (w.act[r] && w.lkj[r] == i)
+            c += w.hr[r] * w.coef[r * D + i] * w.lkc[r];
+        }
+        w.pc[v] = c;
+      }
+      else
+        w.pc[v] = w.po[v];
+#endif
     }
     w.Sinv[t * DDS + i * DS + j] = s;
   }
@@ -492,7 +553,7 @@ TMX_DEVFN void kkt_invert_chain_generic(const QpWs& w, int t0, int t1, int tid, 
     if (t > t0)
     {
       const double* Sp = w.Sinv + (t - 1) * DDS;
-      const double* c = w.po + (t - 1) * D;
+      const double* c = TMX_PC(w) + (t - 1) * D;
       for (int e = tid; e < DD; e += NT)
       {
         const int i = e / D, j = e % D;
@@ -579,6 +640,9 @@ TMX_DEVFN void kkt_solve(const QpWs& w, const DevProblem* P, int mode, double si
         if (w.act[r])
           s += w.hr[r] * w.coef[r * D + j];
       }
+#if TMX_LINK_ROWS
+      s += link_gather(w, w.hr, t, j);
+#endif
       w.tp[v] += s;
     }
     TMX_SYNC();
@@ -615,6 +679,9 @@ TMX_DEVFN void kkt_solve(const QpWs& w, const DevProblem* P, int mode, double si
         if (w.act[r])
           s += w.hr[r] * w.coef[r * D + j];
       }
+#if TMX_LINK_ROWS
+      s += link_gather(w, w.hr, t, j);
+#endif
       w.tp[v] -= s;
     }
     TMX_SYNC();
@@ -642,7 +709,7 @@ TMX_DEVFN void kkt_solve(const QpWs& w, const DevProblem* P, int mode, double si
             a1 = __builtin_fma(S[j + 1], vp[j + 1], a1);
         }
         if (live)
-          w.tp[t * D + i] -= w.po[(t - 1) * D + i] * (a0 + a1);
+          w.tp[t * D + i] -= TMX_PC(w)[(t - 1) * D + i] * (a0 + a1);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
       }
@@ -656,7 +723,7 @@ TMX_DEVFN void kkt_solve(const QpWs& w, const DevProblem* P, int mode, double si
           {
             double vj = w.tp[t * D + j];
             if (t < T - 1)
-              vj -= w.po[t * D + j] * w.tp[(t + 1) * D + j];
+              vj -= TMX_PC(w)[t * D + j] * w.tp[(t + 1) * D + j];
             if (j & 1)
               a1 = __builtin_fma(S[j], vj, a1);
             else
@@ -684,7 +751,7 @@ TMX_DEVFN void kkt_solve(const QpWs& w, const DevProblem* P, int mode, double si
         double acc = 0.0;
         for (int j = 0; j < D; ++j)
           acc += S[j] * vp[j];
-        w.tp[t * D + i] -= w.po[(t - 1) * D + i] * acc;
+        w.tp[t * D + i] -= TMX_PC(w)[(t - 1) * D + i] * acc;
       }
       TMX_SYNC();
     }
@@ -698,7 +765,7 @@ TMX_DEVFN void kkt_solve(const QpWs& w, const DevProblem* P, int mode, double si
         {
           double vj = w.tp[t * D + j];
           if (t < T - 1)
-            vj -= w.po[t * D + j] * w.tp[(t + 1) * D + j];
+            vj -= TMX_PC(w)[t * D + j] * w.tp[(t + 1) * D + j];
           acc += S[j] * vj;
         }
         w.gj[i] = acc;
@@ -723,6 +790,9 @@ TMX_DEVFN void kkt_solve(const QpWs& w, const DevProblem* P, int mode, double si
       double dot = 0.0;
       for (int j = 0; j < D; ++j)
         dot += w.coef[r * D + j] * w.tp[t * D + j];
+#if TMX_LINK_ROWS
+      dot += link_dot(w, r, t, w.tp);
+#endif
       double dk[2] = { 1.0, 1.0 }, dmin = 1.0;
       for (int k = 0; k < w.naux[r]; ++k)
       {
@@ -760,6 +830,9 @@ TMX_DEVFN void kkt_solve(const QpWs& w, const DevProblem* P, int mode, double si
     double dot = 0.0;
     for (int j = 0; j < D; ++j)
       dot += w.coef[r * D + j] * w.tp[t * D + j];
+#if TMX_LINK_ROWS
+    dot += link_dot(w, r, t, w.tp);
+#endif
     double ax = dot;
     if (w.naux[r] > 0)
     {
@@ -812,7 +885,11 @@ TMX_DEVFN double at_rows(const QpWs& w, const DevProblem* P, const double* rv, i
     const int r0 = w.wp_list[q];
     s0 += w.coef[r0 * D + j] * rv[r0];
   }
+#if TMX_LINK_ROWS
+  return ((s0 + s1) + (s2 + s3)) + link_gather(w, rv, t, j);
+#else
   return (s0 + s1) + (s2 + s3);
+#endif
 }
 // (P x)_v for primary var v
 TMX_DEVFN double p_times(const QpWs& w, const double* x, int v)
@@ -857,6 +934,9 @@ TMX_DEVFN void compute_residuals(const QpWs& w, const DevProblem* P, const doubl
     double ax = 0.0;
     for (int j = 0; j < D; ++j)
       ax += w.coef[r * D + j] * xp[t * D + j];
+#if TMX_LINK_ROWS
+    ax += link_dot(w, r, t, xp);
+#endif
     for (int k = 0; k < w.naux[r]; ++k)
       ax += w.sa[w.aoff[r] + k] * xa[w.aoff[r] + k];
     const double z = zmode ? clampd(ax, w.lor[r], w.hir[r]) : w.zr[r];
@@ -1066,6 +1146,9 @@ TMX_DEVFN bool is_dual_infeasible(const QpWs& w, const DevProblem* P, double eps
         double adx = 0.0;
         for (int j = 0; j < w.D; ++j)
           adx += w.coef[r * w.D + j] * w.dxp[t * w.D + j];
+#if TMX_LINK_ROWS
+        adx += link_dot(w, r, t, w.dxp);
+#endif
         for (int k = 0; k < w.naux[r]; ++k)
           adx += w.sa[w.aoff[r] + k] * w.dxa[w.aoff[r] + k];
         adx /= w.Er[r];
@@ -1172,7 +1255,7 @@ TMX_DEVFN void chain_solve_range(const QpWs& w, int t0, int t1, int tid, int NT)
       double acc = 0.0;
       for (int j = 0; j < D; ++j)
         acc += S[j] * vp[j];
-      w.tp[t * D + i] -= w.po[(t - 1) * D + i] * acc;
+      w.tp[t * D + i] -= TMX_PC(w)[(t - 1) * D + i] * acc;
     }
     TMX_SYNC();
   }
@@ -1186,7 +1269,7 @@ TMX_DEVFN void chain_solve_range(const QpWs& w, int t0, int t1, int tid, int NT)
       {
         double vj = w.tp[t * D + j];
         if (t < t1)
-          vj -= w.po[t * D + j] * w.tp[(t + 1) * D + j];
+          vj -= TMX_PC(w)[t * D + j] * w.tp[(t + 1) * D + j];
         acc += S[j] * vj;
       }
       w.gj[i] = acc;
@@ -1212,6 +1295,9 @@ TMX_DEVFN void admm_phase_c(const QpWs& w, bool keep_delta, int tid, int NT)
     double dot = 0.0;
     for (int j = 0; j < D; ++j)
       dot += w.coef[r * D + j] * w.tp[t * D + j];
+#if TMX_LINK_ROWS
+    dot += link_dot(w, r, t, w.tp);
+#endif
     const double rr = rho_of_type(w.typ_r[r], w.rho);
     double ax = dot;
     const int na = w.naux[r];

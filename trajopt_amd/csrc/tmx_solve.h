@@ -84,6 +84,15 @@ TMX_DEVFN void qp_structure(const DevProblem* P, const int* active, const double
       if (lact[r] && coef[r * D + j] != 0.0)
         ++c;
     }
+#if TMX_LINK_ROWS
+    if (P->n_link > 0 && t > 0)  // rows of the previous waypoint linked to this variable
+      for (int q = P->wp_start[t - 1]; q < P->wp_start[t]; ++q)
+      {
+        const int r = P->wp_list[q];
+        if (lact[r] && P->slot_lkj[r] == j)
+          ++c;
+      }
+#endif
     ccount[v] = c;
   }
   for (int r = tid; r < R; r += NT)
@@ -123,6 +132,16 @@ TMX_DEVFN void qp_structure(const DevProblem* P, const int* active, const double
   {
     const int t = v / D, j = v % D;
     int pos = colptr[v];
+#if TMX_LINK_ROWS
+    // entries of the rows of waypoint t-1 that link to this variable, merged by ascending reference row index
+    int ql = (P->n_link > 0 && t > 0) ? P->wp_start[t - 1] : 0;
+    const int ql_end = (P->n_link > 0 && t > 0) ? P->wp_start[t] : 0;
+    auto next_link = [&]() {
+      while (ql < ql_end && !(active[P->wp_list[ql]] && P->slot_lkj[P->wp_list[ql]] == j))
+        ++ql;
+    };
+    next_link();
+#endif
     for (int q = P->wp_start[t]; q <= P->wp_start[t + 1]; ++q)
     {
       long long ri;
@@ -140,6 +159,25 @@ TMX_DEVFN void qp_structure(const DevProblem* P, const int* active, const double
         ri = mg + v;
         val = 1.0;
       }
+#if TMX_LINK_ROWS
+      while (ql < ql_end && rowref[P->wp_list[ql]] < ri)
+      {
+        const long long rl = rowref[P->wp_list[ql]];
+        hA += tmx_hash_term(rl, (uint64_t)pos, 4);
+        if (pos < ri_full)
+          wsA += tmx_hash_term(rl, (uint64_t)pos, 14);
+        else if (pos == ri_full && ri_rem > 0)
+          wsA += tmx_hash_term((long long)((unsigned long long)rl & ((1ULL << (8 * ri_rem)) - 1ULL)), (uint64_t)pos, 14);
+        if (out)
+        {
+          out->A_i[pos] = rl;
+          out->A_x[pos] = P->slot_lkc[P->wp_list[ql]];
+        }
+        ++pos;
+        ++ql;
+        next_link();
+      }
+#endif
       hA += tmx_hash_term(ri, (uint64_t)pos, 4);
       if (pos < ri_full)
         wsA += tmx_hash_term(ri, (uint64_t)pos, 14);
@@ -497,6 +535,9 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
     w.hir[r] = g_rhs[r];
     for (int j = 0; j < D; ++j)
       w.coef[r * D + j] = g_act[r] ? g_coef[r * D + j] : 0.0;
+#if TMX_LINK_ROWS
+    w.lkc[r] = (g_act[r] && P->slot_lkj[r] >= 0) ? P->slot_lkc[r] : 0.0;
+#endif
     const double oc = P->slot_iscnt[r] ? g_merit[P->slot_owner[r]] : P->slot_objc[r];
     for (int k = 0; k < P->slot_naux[r]; ++k)
     {
@@ -548,6 +589,10 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
     for (int u = P->wp_start[t]; t < T && u < P->wp_start[t + 1]; ++u)
       w.row_epos[P->wp_list[u]] = acc + (u - P->wp_start[t]);
   }
+#if TMX_LINK_ROWS
+  w.lkj = P->slot_lkj;
+  w.n_link = P->n_link;
+#endif
   w.sigma = st.sigma;
   w.alpha = st.alpha;
   w.c = 1.0;
@@ -600,6 +645,15 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
         if (w.act[r])
           cn = fmax(cn, fabs(w.coef[r * D + j]));
       }
+#if TMX_LINK_ROWS
+      if (w.n_link > 0 && t > 0)
+        for (int q = w.wp_start[t - 1]; q < w.wp_start[t]; ++q)
+        {
+          const int r = w.wp_list[q];
+          if (w.act[r] && w.lkj[r] == j)
+            cn = fmax(cn, fabs(w.lkc[r]));
+        }
+#endif
       cn = fmax(cn, fabs(w.bbp[v]));
       w.tp[v] = 1.0 / sqrt(limit_scaling(cn));
       t_ebp[v] = 1.0 / sqrt(limit_scaling(fabs(w.bbp[v])));
@@ -611,6 +665,9 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
       double rn = 0.0;
       for (int j = 0; j < D; ++j)
         rn = fmax(rn, fabs(w.coef[r * D + j]));
+#if TMX_LINK_ROWS
+      rn = fmax(rn, fabs(w.lkc[r]));
+#endif
       for (int k = 0; k < w.naux[r]; ++k)
       {
         const int a = w.aoff[r] + k;
@@ -638,6 +695,10 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
       const int t = w.slot_t[r];
       for (int j = 0; j < D; ++j)
         w.coef[r * D + j] = (w.hr[r] * w.coef[r * D + j]) * w.tp[t * D + j];
+#if TMX_LINK_ROWS
+      if (w.lkj[r] >= 0)
+        w.lkc[r] = (w.hr[r] * w.lkc[r]) * w.tp[(t + 1) * D + w.lkj[r]];
+#endif
       for (int k = 0; k < w.naux[r]; ++k)
       {
         const int a = w.aoff[r] + k;
@@ -767,6 +828,9 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
         double ax = 0.0;
         for (int j = 0; j < D; ++j)
           ax += w.coef[r * D + j] * w.xp[t * D + j];
+#if TMX_LINK_ROWS
+        ax += link_dot(w, r, t, w.xp);
+#endif
         for (int k = 0; k < w.naux[r]; ++k)
         {
           const int a = w.aoff[r] + k;
@@ -781,7 +845,7 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
   // ---------------- factor + ADMM loop (osqp_solve) --------------------------------------------------------
   TMX_TICK(0);
 #if TMX_IS_DEVICE
-  const bool fast = (NT == TMX_QP_NT) && (R <= 512) && dpart_supported(w, NT);
+  const bool fast = (NT == TMX_QP_NT) && (R <= 512) && dpart_supported(w, NT) && (!TMX_LINK_ROWS || P->n_link == 0);
 #else
   const bool fast = false;
 #endif
@@ -980,6 +1044,9 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
             double ax = 0.0;
             for (int j = 0; j < D; ++j)
               ax += wp.coef[r * D + j] * wp.dxp[t * D + j];
+#if TMX_LINK_ROWS
+            ax += link_dot(wp, r, t, wp.dxp);
+#endif
             for (int k = 0; k < wp.naux[r]; ++k)
               ax += wp.sa[wp.aoff[r] + k] * wp.dxa[wp.aoff[r] + k];
             r2 -= ax;
@@ -1245,6 +1312,10 @@ TMX_DEVFN void sqp_update_block(const DevProblem* P, const DevBatch* Bt, int b, 
           double aff = 0.0;
           for (int j = 0; j < D; ++j)
             aff += coef[r * D + j] * xq[t * D + j];
+#if TMX_LINK_ROWS
+          if (P->slot_lkj[r] >= 0)
+            aff += P->slot_lkc[r] * xq[(t + 1) * D + P->slot_lkj[r]];
+#endif
           aff -= rhs[r];
           vr = P->slot_eq[r] ? fabs(aff) : ((aff > 0) ? aff : 0.0);
           key = P->n_costs + P->slot_owner[r];

@@ -242,6 +242,23 @@ TMX_DEVFN void evaluate_terms(const DevProblem* P, const double* xv, double* cos
       const double d = xv[t * D + P->slot_sub[r]] - P->slot_aux1[r];
       v = fabs((d * d) * P->slot_scale[r]);
     }
+#if TMX_LINK_ROWS
+    else if (kind == SLOT_JOINTVEL)
+    {
+      // JointVelEqConstraint::value: coeff * diff^2 as well (trajectory_costs.cpp:403-413)
+      const int j = P->slot_sub[r];
+      const double d = (xv[(t + 1) * D + j] - xv[t * D + j]) - P->slot_aux1[r];
+      v = fabs((d * d) * P->slot_scale[r]);
+    }
+    else if (kind == SLOT_JOINTVEL_INEQ)
+    {
+      // JointVelIneqCost::value / JointVelIneqConstraint::value (trajectory_costs.cpp:349-361, 472-487)
+      const int j = P->slot_sub[r];
+      const double d0 = (xv[(t + 1) * D + j] - xv[t * D + j]) - P->slot_aux1[r];
+      const double e = (P->slot_sub2[r] == 0) ? (d0 - P->slot_aux2[r]) * P->slot_scale[r] : ((d0 * -1) + P->slot_aux2[r]) * P->slot_scale[r];
+      v = (e > 0) ? e : 0.0;
+    }
+#endif
     scratch[r] = v;
   }
   // cart-pose instances: |coeff_i * err_i| (constraint violation) or abs cost
@@ -320,6 +337,36 @@ TMX_DEVFN void init_static_rows(const DevProblem* P, const double* x0, int* acti
   for (int r = tid; r < P->R; r += NT)
   {
     const int kind = P->slot_kind[r];
+#if TMX_LINK_ROWS
+    if (kind == SLOT_JOINTVEL || kind == SLOT_JOINTVEL_INEQ)
+    {
+      // home coefficient on x[t][j]; the coefficient on x[t+1][j] is the static link slot_lkc (built the same way at upload)
+      for (int k = 0; k < D; ++k)
+        coef[r * D + k] = 0.0;
+      const int j = P->slot_sub[r];
+      const double c = P->slot_scale[r], targ = P->slot_aux1[r], tol = P->slot_aux2[r];
+      if (kind == SLOT_JOINTVEL)
+      {
+        // exprMult(vel, coeff), vel = -1*x[t] + 1*x[t+1] - target   (trajectory_costs.cpp:392-400)
+        coef[r * D + j] = (1.0 * -1) * c;
+        rhs[r] = -((0.0 - targ) * c);
+      }
+      else if (P->slot_sub2[r] == 0)
+      {
+        // expr = upper_tol - vel, scaled by -coeff   (:334-338, :458-462)
+        coef[r * D + j] = (0.0 - (1.0 * -1)) * -c;
+        rhs[r] = -((tol - (0.0 - targ)) * -c);
+      }
+      else
+      {
+        // expr_neg = lower_tol - vel, scaled by coeff   (:340-344, :464-468)
+        coef[r * D + j] = (0.0 - (1.0 * -1)) * c;
+        rhs[r] = -((tol - (0.0 - targ)) * c);
+      }
+      active[r] = 1;
+      continue;
+    }
+#endif
     if (kind == SLOT_FIXED || kind == SLOT_JOINTPOS || kind == SLOT_JOINTPOS_INEQ)
     {
       for (int k = 0; k < D; ++k)

@@ -18,8 +18,15 @@ enum
   SLOT_CARTPOSE = 1,  // CartPose row (EQ constraint -> abs, or ABS cost)             (2 aux)
   SLOT_JOINTPOS = 2,  // JointPosEqConstraint row -> abs                              (2 aux)
   SLOT_COLLISION = 3, // CollisionCost contact -> hinge                               (1 aux)
-  SLOT_JOINTPOS_INEQ = 4  // JointPosIneqConstraint row (upper: sub2 = 0, lower: sub2 = 1) -> hinge   (1 aux)
+  SLOT_JOINTPOS_INEQ = 4,  // JointPosIneqConstraint row (upper: sub2 = 0, lower: sub2 = 1) -> hinge   (1 aux)
+  // rows on TWO consecutive waypoints (only in TMX_LINK_ROWS builds): home coefficient on (t, sub), link coefficient
+  // slot_lkc on (t + 1, slot_lkj = sub)
+  SLOT_JOINTVEL = 5,       // JointVelEqConstraint row  coeff * (x[t+1][j] - x[t][j] - target) == 0 -> abs (2 aux)
+  SLOT_JOINTVEL_INEQ = 6   // JointVelIneqCost / JointVelIneqConstraint row (upper: sub2 = 0, lower: sub2 = 1) -> hinge (1 aux)
 };
+#ifndef TMX_LINK_ROWS
+#define TMX_LINK_ROWS 0  // 1: the QP kernels understand rows with a link to the next waypoint (JointVel constraint / hinge forms)
+#endif
 
 enum
 {
@@ -60,6 +67,10 @@ struct DevProblem
   // collision geometry
   int *ls_link;
   double *ls_center, *ls_radius, *ob_center, *ob_radius;
+  // link of a row to the next waypoint (appended last: the layout of everything above is that of builds without links)
+  int *slot_lkj;      // R: joint of the linked variable (t + 1, lkj), -1 = none
+  double *slot_lkc;   // R: its coefficient
+  int n_link;         // number of slots with a link (0: every row sits on one waypoint)
 };
 
 struct DevBatch

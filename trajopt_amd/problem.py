@@ -120,12 +120,17 @@ def pr2_right_arm() -> Robot:
 # ---- TermInfo mirrors -------------------------------------------------------------------------------
 @dataclass
 class JointVelTermInfo:
-    """trajopt::JointVelTermInfo (cost form) — hatch -> JointVelEqCost, problem_description.cpp:1197-1372"""
+    """trajopt::JointVelTermInfo without time parameterisation — hatch (problem_description.cpp:1197-1372): zero tolerances
+    -> JointVelEqCost (TT_COST) / JointVelEqConstraint (TT_CNT); otherwise JointVelIneqCost / JointVelIneqConstraint.
+    The constraint and hinge forms put rows on TWO consecutive waypoints."""
     coeffs: Sequence[float]
     targets: Sequence[float]
     first_step: int = 0
     last_step: int = -1
     name: str = "joint_vel"
+    upper_tols: Sequence[float] = ()
+    lower_tols: Sequence[float] = ()
+    is_constraint: bool = False
 
 
 @dataclass
@@ -203,7 +208,7 @@ class ProblemConstructionInfo:
         def is_ineq(ti):
             if isinstance(ti, CollisionTermInfo):
                 return True
-            if isinstance(ti, JointPosTermInfo):
+            if isinstance(ti, (JointPosTermInfo, JointVelTermInfo)):
                 return any(abs(x) >= 1e-5 for x in list(ti.upper_tols) + list(ti.lower_tols))
             return False
         eq = [n for ti in self.cnt_infos if not is_ineq(ti) for n in self._expand_names(ti)]
@@ -237,9 +242,29 @@ class ProblemConstructionInfo:
         for ti in list(self.cost_infos) + list(self.cnt_infos):
             t = abi.Term()
             if isinstance(ti, JointVelTermInfo):
-                t.kind = abi.TERM_JOINT_VEL_COST
-                t.first_step = ti.first_step
-                t.last_step = ti.last_step if ti.last_step >= 0 else T - 1
+                up = list(ti.upper_tols) or [0.0] * D
+                lo = list(ti.lower_tols) or [0.0] * D
+                if len(up) != D or len(lo) != D:
+                    raise ValueError("JointVelTermInfo upper_tols / lower_tols have the wrong size")
+                zero = all(abs(x) < 1e-5 for x in up) and all(abs(x) < 1e-5 for x in lo)   # trajopt_common::doubleEquals
+                if ti.is_constraint:
+                    t.kind = abi.TERM_JOINT_VEL_EQ_CNT if zero else abi.TERM_JOINT_VEL_INEQ_CNT
+                else:
+                    t.kind = abi.TERM_JOINT_VEL_COST if zero else abi.TERM_JOINT_VEL_INEQ_COST
+                t.is_constraint = 1 if ti.is_constraint else 0
+                t.upper_tols[:D] = up
+                t.lower_tols[:D] = lo
+                # step handling of JointVelTermInfo::hatch (:1212-1226): a velocity needs two steps
+                first, last = ti.first_step, (ti.last_step if ti.last_step >= 0 else T - 1)
+                if (T - 2) <= first:
+                    first = T - 2
+                if (T - 1) <= last:
+                    last = T - 1
+                if last == first:
+                    last += 1
+                if last < first:
+                    first, last = last, first
+                t.first_step, t.last_step = first, last
                 co = list(ti.coeffs) * D if len(ti.coeffs) == 1 else list(ti.coeffs)
                 t.coeffs[:D] = co
                 t.targets[:D] = list(ti.targets)
