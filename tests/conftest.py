@@ -35,6 +35,15 @@ def hostemu_lib():
 
 
 @pytest.fixture(scope="session")
+def hostemu_lib_nolink(hostemu_lib):
+    """the same kernel sources in the PRODUCT's configuration (rows on two waypoints compiled out)"""
+    path = os.path.join(HOSTEMU_DIR, "_build", "libtmx_hostemu_nolink.so")
+    if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(hostemu_lib):
+        subprocess.check_call(["make", "-C", HOSTEMU_DIR], stdout=subprocess.DEVNULL)
+    return path
+
+
+@pytest.fixture(scope="session")
 def gpu_ctx_factory():
     """real HIP library on cuda:0; fails (does not skip) if the extension or the device is missing"""
     import torch

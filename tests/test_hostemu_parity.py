@@ -101,6 +101,32 @@ def test_full_sqp_config3_car_seat_shape(emu, orc):
     assert same.any() and (dx[same] <= pc.TOL_TRAJ).all()
 
 
+def test_product_configuration_of_the_kernel_sources(hostemu_lib_nolink, hostemu_lib, orc):
+    """The host build used above has the two-waypoint rows compiled in; the product library has not.  Same sources with the
+    product's configuration: bit-identical results on problems without such rows, and an explicit refusal of problems with."""
+    from trajopt_amd.problem import BasicInfo, JointVelTermInfo, ProblemConstructionInfo
+    for cid in (0, 1, 9, 13):
+        pci, s, g = _cfg(cid) if cid != 1 else _cfg(1, T=8)
+        x0 = configs.seeds_for(cid, pci, s, g, 2)
+        out = []
+        for lib in (hostemu_lib_nolink, hostemu_lib):
+            ctx = runtime.Context(0, lib)
+            pc.make_ctx_inputs(ctx, pci, x0)
+            ctx.run(0)
+            out.append(ctx.results())
+            ctx.close()
+        assert np.array_equal(out[0]["x"], out[1]["x"]) and np.array_equal(out[0]["n_qp_solves"], out[1]["n_qp_solves"])
+    o = orc.sqp_batch(pci.to_desc(), x0)
+    assert (out[0]["status"] == o["status"]).all()
+    rob = configs.mini_arm()
+    pci = ProblemConstructionInfo(rob, BasicInfo(n_steps=6))
+    pci.cnt_infos.append(JointVelTermInfo(coeffs=[1.0] * 4, targets=[0.0] * 4, first_step=0, last_step=5, is_constraint=True))
+    ctx = runtime.Context(0, hostemu_lib_nolink)
+    with pytest.raises(runtime.TmxError, match="not enabled in this build"):
+        ctx.upload(pci.to_desc())
+    ctx.close()
+
+
 def test_error_paths(emu):
     pci, s, g = _cfg(0)
     desc = pci.to_desc()
