@@ -344,7 +344,7 @@ public:
     }
     else
       names.push_back(name);
-    const bool ineq = t.kind == TMX_TERM_JOINT_POS_INEQ_CNT || t.kind == TMX_TERM_COLLISION_CNT;
+    const bool ineq = t.kind == TMX_TERM_JOINT_POS_INEQ_CNT || t.kind == TMX_TERM_COLLISION_CNT || t.kind == TMX_TERM_JOINT_VEL_INEQ_CNT;
     std::vector<std::string>& dst = !t.is_constraint ? cost_names_ : (ineq ? ineq_cnt_names_ : eq_cnt_names_);
     dst.insert(dst.end(), names.begin(), names.end());
     terms_.push_back(t);
@@ -493,8 +493,8 @@ struct JointPosTermInfo : public TermInfo
   }
 };
 
-/** problem_description.hpp:471-514 ; hatch: problem_description.cpp:1197-1372.  Lowered: the squared cost with zero
-    tolerances (JointVelEqCost).  Constraint form, hinge form and the time-parameterised forms throw. */
+/** problem_description.hpp:471-514 ; hatch: problem_description.cpp:1197-1372 without time parameterisation: the squared
+    cost (JointVelEqCost), the equality constraint and the hinge cost / inequality constraint forms. */
 struct JointVelTermInfo : public TermInfo
 {
   DblVec coeffs;
@@ -529,18 +529,33 @@ struct JointVelTermInfo : public TermInfo
     detail::checkParameterSize(lower_tols, n_dof, "JointVelTermInfo lower_tols");
     if (first_step < 0)
       printAndThrow("JointVelEqCost, trajectory is too short!");  // trajectory_costs.cpp:269-270
-    if (term_type != TermType::TT_COST)
-      printAndThrow("JointVelTermInfo: only the TT_COST form is lowered by the device path (constraint / use_time forms are not)");
-    if (!(detail::allZero(upper_tols) && detail::allZero(lower_tols)))
-      printAndThrow("JointVelTermInfo with tolerances (hinge form, JointVelIneqCost) is not lowered by the device path");
+    if (static_cast<bool>(term_type & TermType::TT_USE_TIME))
+      printAndThrow("JointVelTermInfo: the time-parameterised forms are not lowered by the device path");
+    const bool zero = detail::allZero(upper_tols) && detail::allZero(lower_tols);
     tmx_term t = detail::blankTerm();
-    t.kind = TMX_TERM_JOINT_VEL_COST;
+    // :1246-1372 without use_time: zero tolerances -> JointVelEqCost / JointVelEqConstraint, else JointVelIneqCost /
+    // JointVelIneqConstraint.  The constraint and hinge forms put rows on two consecutive waypoints; a library built without
+    // TMX_LINK_ROWS refuses them at upload (TMX_ERR_UNSUPPORTED), which optimize() reports as an exception.
+    if (static_cast<bool>(term_type & TermType::TT_COST))
+    {
+      t.kind = zero ? TMX_TERM_JOINT_VEL_COST : TMX_TERM_JOINT_VEL_INEQ_COST;
+      t.is_constraint = 0;
+    }
+    else if (static_cast<bool>(term_type & TermType::TT_CNT))
+    {
+      t.kind = zero ? TMX_TERM_JOINT_VEL_EQ_CNT : TMX_TERM_JOINT_VEL_INEQ_CNT;
+      t.is_constraint = 1;
+    }
+    else
+      return;
     t.first_step = first_step;
     t.last_step = last_step;
     for (std::size_t j = 0; j < n_dof; ++j)
     {
       t.coeffs[j] = coeffs[j];
       t.targets[j] = targets[j];
+      t.upper_tols[j] = upper_tols[j];
+      t.lower_tols[j] = lower_tols[j];
     }
     prob.addTerm(t, {}, name);
   }

@@ -260,16 +260,11 @@ inline TermInfo::Ptr readTerm(const json::Value& it, bool is_cost, const Problem
   if (typ == "joint_vel")
   {
     ensureOnlyMembers(p, { "coeffs", "first_step", "last_step", "targets", "lower_tols", "upper_tols", "use_time" }, typ);
-    if (!is_cost)
-      printAndThrow("joint_vel as a constraint is not lowered by the device path");
     auto t = std::make_shared<JointVelTermInfo>();
     t->coeffs = jsonVec(p, "coeffs", D, &ones);
     t->targets = jsonVec(p, "targets", D, nullptr);
     t->upper_tols = jsonVec(p, "upper_tols", D, &zeros);
     t->lower_tols = jsonVec(p, "lower_tols", D, &zeros);
-    for (std::size_t j = 0; j < D; ++j)
-      if (t->upper_tols[j] != 0.0 || t->lower_tols[j] != 0.0)
-        printAndThrow("joint_vel with tolerances (hinge form) is not lowered by the device path");
     t->first_step = jsonInt(p, "first_step", 0);
     t->last_step = jsonInt(p, "last_step", n_steps - 1);
     t->name = name;

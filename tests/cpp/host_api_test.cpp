@@ -429,6 +429,112 @@ static void caseJointCosts(const Input& in)
   }
 }
 
+// ---- trajopt/test/joint_costs_unit.cpp:264-345 (equality_jointVel) and :354-463 (inequality_jointVel) ------------------------
+// Rows on two consecutive waypoints: a library built with TMX_LINK_ROWS (the host build of the CPU tier) runs them, this
+// round's product library refuses them explicitly at upload - both outcomes are checked.
+static void caseJointVel(const Input& in)
+{
+  const int steps = 10;
+  auto run = [&](ProblemConstructionInfo& pci, const char* name, const std::function<void(const DblVec&)>& check) {
+    auto prob = ConstructProblem(pci);
+    BasicTrustRegionSQPBatchedHip opt(prob);
+    opt.initialize(tmx::sco::trajToDblVec(prob->GetInitTraj()));
+    try
+    {
+      opt.optimize();
+    }
+    catch (const std::runtime_error& e)
+    {
+      EXPECT_TRUE(std::string(e.what()).find("not enabled in this build") != std::string::npos);
+      std::printf("LINKROWS refused %s\n", name);
+      return;
+    }
+    EXPECT_TRUE(opt.results().status == OptStatus::OPT_CONVERGED);
+    check(opt.x());
+    printResults(name, opt);
+  };
+  {
+    auto env = makeEnv(in, "right_arm", "pr2_right_arm", DblVec(7, 0.0), false);
+    ProblemConstructionInfo pci(env);
+    pci.basic_info.n_steps = steps;
+    pci.basic_info.manip = "right_arm";
+    pci.resolveKin();
+    pci.init_info.type = InitInfo::STATIONARY;
+    const double cnt_targ = 0.0, cost_targ = 0.1;
+    auto jv = std::make_shared<JointVelTermInfo>();
+    jv->coeffs = DblVec(7, 10.0);
+    jv->targets = DblVec(7, cnt_targ);
+    jv->first_step = 0;
+    jv->last_step = 0;
+    jv->name = "joint_vel_single";
+    jv->term_type = TermType::TT_CNT;
+    pci.cnt_infos.push_back(jv);
+    auto jv2 = std::make_shared<JointVelTermInfo>();
+    jv2->coeffs = DblVec(7, 10.0);
+    jv2->targets = DblVec(7, cost_targ);
+    jv2->first_step = 0;
+    jv2->last_step = steps - 1;
+    jv2->name = "joint_vel_all";
+    jv2->term_type = TermType::TT_COST;
+    pci.cost_infos.push_back(jv2);
+    run(pci, "equality_jointVel", [&](const DblVec& x) {
+      for (int j = 0; j < 7; ++j)
+        EXPECT_NEAR(x[static_cast<std::size_t>(7 + j)] - x[static_cast<std::size_t>(j)], cnt_targ, 1e-4);
+      for (int i = 1; i < steps - 1; ++i)
+        for (int j = 0; j < 7; ++j)
+          EXPECT_NEAR(x[static_cast<std::size_t>((i + 1) * 7 + j)] - x[static_cast<std::size_t>(i * 7 + j)], cost_targ, 0.01);
+    });
+  }
+  {
+    auto env = makeEnv(in, "right_arm", "pr2_right_arm", DblVec(7, 0.0), false);
+    ProblemConstructionInfo pci(env);
+    pci.basic_info.n_steps = steps;
+    pci.basic_info.manip = "right_arm";
+    pci.resolveKin();
+    pci.init_info.type = InitInfo::STATIONARY;
+    const double lower_tol = -0.1, upper_tol = 0.2;
+    auto jv = std::make_shared<JointVelTermInfo>();
+    jv->coeffs = DblVec(7, 1.0);
+    jv->targets = DblVec(7, 0.0);
+    jv->lower_tols = DblVec(7, lower_tol);
+    jv->upper_tols = DblVec(7, upper_tol);
+    jv->first_step = 0;
+    jv->last_step = steps - 1;
+    jv->name = "joint_vel_limits";
+    jv->term_type = TermType::TT_CNT;
+    pci.cnt_infos.push_back(jv);
+    auto jv2 = std::make_shared<JointVelTermInfo>();
+    jv2->coeffs = DblVec(7, 1.0);
+    jv2->targets = DblVec(7, 0.5);
+    jv2->lower_tols = DblVec(7, -0.01);
+    jv2->upper_tols = DblVec(7, 0.0);
+    jv2->first_step = 0;
+    jv2->last_step = (steps - 1) / 2;
+    jv2->name = "joint_vel_targ_1";
+    jv2->term_type = TermType::TT_COST;
+    pci.cost_infos.push_back(jv2);
+    auto jv3 = std::make_shared<JointVelTermInfo>();
+    jv3->coeffs = DblVec(7, 1.0);
+    jv3->targets = DblVec(7, -0.5);
+    jv3->lower_tols = DblVec(7, -0.01);
+    jv3->upper_tols = DblVec(7, 0.01);
+    jv3->first_step = (steps - 1) / 2 + 1;
+    jv3->last_step = steps - 1;
+    jv3->name = "joint_vel_targ_2";
+    jv3->term_type = TermType::TT_COST;
+    pci.cost_infos.push_back(jv3);
+    run(pci, "inequality_jointVel", [&](const DblVec& x) {
+      for (int i = 0; i < steps - 1; ++i)
+        for (int j = 0; j < 7; ++j)
+        {
+          const double v = x[static_cast<std::size_t>((i + 1) * 7 + j)] - x[static_cast<std::size_t>(i * 7 + j)];
+          EXPECT_TRUE(v < upper_tol + 1e-4 && v > lower_tol - 1e-4);
+        }
+    });
+  }
+  std::printf("JOINTVEL done\n");
+}
+
 // ---- trajopt/test/numerical_ik_unit.cpp:59-124 ------------------------------------------------------------------------
 static Transform fkTool(const JointGroup& kin, const DblVec& q)
 {
@@ -707,13 +813,6 @@ static void caseErrors(const Input& in, bool have_device)
   }
   {
     auto pci = base();
-    auto jv = std::make_shared<JointVelTermInfo>();
-    jv->targets = DblVec(7, 0.0);
-    pci.cnt_infos.push_back(jv);
-    EXPECT_THROW_MSG(ConstructProblem(pci), "only the TT_COST form is lowered");
-  }
-  {
-    auto pci = base();
     auto cp = std::make_shared<CartPoseTermInfo>();
     cp->source_frame = "nowhere";
     cp->target_frame = "base_footprint";
@@ -781,6 +880,8 @@ int main(int argc, char** argv)
         caseJointCosts(in);
       else if (c == "numerical_ik")
         caseNumericalIk(in);
+      else if (c == "joint_vel")
+        caseJointVel(in);
       else if (c == "cart_position")
         caseCartPosition(in);
       else if (c == "interface")

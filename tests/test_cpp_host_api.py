@@ -148,10 +148,19 @@ def test_cpp_json_front_end_equals_python_json_front_end_on_host_build(hostemu_l
 
 def test_cpp_reference_kats_on_host_build(hostemu_lib, inputs, orc):
     exe = _build(hostemu_lib, "hostemu")
-    res, _, out = _run(exe, inputs["path"], "joint_costs,numerical_ik,cart_position,interface,errors")
-    assert "ERRORS done" in out and "INTERFACE done" in out
-    assert set(res) == {"equality_jointPos", "inequality_jointPos", "numerical_ik1", "cart_position"}
+    res, _, out = _run(exe, inputs["path"], "joint_costs,numerical_ik,cart_position,interface,joint_vel,errors")
+    assert "ERRORS done" in out and "INTERFACE done" in out and "JOINTVEL done" in out and "LINKROWS refused" not in out
+    assert set(res) == {"equality_jointPos", "inequality_jointPos", "numerical_ik1", "cart_position", "equality_jointVel",
+                        "inequality_jointVel"}      # the host build has the two-waypoint rows (TMX_LINK_ROWS=1)
     assert all(r[0]["status"] == 0 for r in res.values())
+
+
+def test_cpp_two_waypoint_terms_are_refused_by_the_product_configuration(hostemu_lib_nolink, inputs):
+    """kernel sources in the product's configuration (TMX_LINK_ROWS=0): the JointVel constraint / hinge KATs end in the
+    library's explicit refusal, exactly what the GPU tier expects from libtrajopt_mi355x.so this round"""
+    exe = _build(hostemu_lib_nolink, "hostemu_nolink")
+    res, _, out = _run(exe, inputs["path"], "joint_vel")
+    assert out.count("LINKROWS refused") == 2 and "JOINTVEL done" in out and not res
 
 
 def test_cpp_optimizer_fails_loudly_without_a_device(inputs):
@@ -171,5 +180,7 @@ def test_cpp_front_end_on_device(inputs):
     exe = _build(PRODUCT_LIB, "product")
     _check_front_ends(exe, inputs, None)
     _check_json_front_ends(exe, inputs, None)
-    res, _, out = _run(exe, inputs["path"], "joint_costs,numerical_ik,cart_position,interface,errors")
+    res, _, out = _run(exe, inputs["path"], "joint_costs,numerical_ik,cart_position,interface,joint_vel,errors")
     assert "ERRORS done" in out and "INTERFACE done" in out and all(r[0]["status"] == 0 for r in res.values())
+    # this round's product library is built without the two-waypoint rows and must say so
+    assert out.count("LINKROWS refused") == 2 and "equality_jointVel" not in res

@@ -169,3 +169,36 @@ def test_optimize_problem_and_names(hostemu_lib):
     assert res["cost_names"][0] == "joint_vel" and res["cost_names"][1] == "collision_1" and res["cost_names"][-1] == "collision_29"
     assert res["cnt_names"][0].startswith("upright") and res["traj"].shape == (30, 7)
     assert res["status"] in (0, 1, 2) and res["cnt_viols"].max() < 1e-3
+
+
+def test_joint_vel_constraint_and_hinge_forms_from_json(hostemu_lib, orc):
+    """joint_vel as a constraint / with tolerances lowers to the two-waypoint kinds (JointVelEqConstraint, JointVelIneqCost,
+    JointVelIneqConstraint); the host build (TMX_LINK_ROWS=1) runs them like the oracle"""
+    from trajopt_amd import abi, runtime
+    env, pci, start, goal = _env(0)
+    base = json.load(open(os.path.join(HERE, "golden", "json", "planning_unit_cfg0.json")))
+    v = copy.deepcopy(base)
+    v["constraints"].append({"type": "joint_vel", "name": "vel_limits",
+                             "params": {"targets": [0.0] * 7, "upper_tols": [0.6] * 7, "lower_tols": [-0.6] * 7}})
+    v["constraints"].append({"type": "joint_vel", "name": "vel_start", "params": {"targets": [0.0] * 7, "first_step": 0, "last_step": 0}})
+    v["costs"].append({"type": "joint_vel", "name": "vel_band",
+                       "params": {"targets": [0.1] * 7, "upper_tols": [0.05] * 7, "lower_tols": [-0.05] * 7, "first_step": 2, "last_step": 6}})
+    pp = json_io.construct_problem(v, env)
+    d = pp.pci.to_desc()
+    kinds = [d.terms[i].kind for i in range(d.n_terms)]
+    assert abi.TERM_JOINT_VEL_INEQ_COST in kinds and abi.TERM_JOINT_VEL_INEQ_CNT in kinds and abi.TERM_JOINT_VEL_EQ_CNT in kinds
+    eqt = next(d.terms[i] for i in range(d.n_terms) if d.terms[i].kind == abi.TERM_JOINT_VEL_EQ_CNT)
+    assert (eqt.first_step, eqt.last_step) == (0, 1)          # JointVelTermInfo::hatch: a velocity needs two steps
+    assert pp.pci.cnt_names()[-1] == "vel_limits"               # the inequality goes behind every equality
+    x0 = pp.init_traj[None, :, :]
+    opt = runtime.BatchedTrustRegionSQP(pp.pci, lib_path=hostemu_lib)
+    opt.initialize(x0)
+    opt.optimize()
+    r = opt.results()
+    opt.ctx.close()
+    o = orc.sqp_batch(d, x0)
+    assert r["status"][0] == o["status"][0] and r["n_qp_solves"][0] == o["n_qp_solves"][0]
+    assert np.abs(r["x"] - o["x"]).max() < 1e-5
+    if r["status"][0] == abi.OPT_CONVERGED:
+        v_ = np.diff(r["x"][0], axis=0)
+        assert np.abs(v_).max() < 0.6 + 1e-3 and np.abs(v_[0]).max() < 1e-3

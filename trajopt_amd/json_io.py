@@ -134,12 +134,13 @@ def construct_problem(text_or_dict, env: Environment) -> ParsedProblem:
         name = str(it.get("name", typ))
         if typ == "joint_vel":
             _only_members(p, ("coeffs", "first_step", "last_step", "targets", "lower_tols", "upper_tols", "use_time"), typ)
-            if not is_cost:
-                raise UnsupportedTerm("joint_vel as a constraint is not lowered by the device path")
-            if any(float(x) != 0.0 for x in list(p.get("upper_tols", [])) + list(p.get("lower_tols", []))):
-                raise UnsupportedTerm("joint_vel with tolerances (hinge form) is not lowered by the device path")
+            # cost / constraint, with or without tolerances: JointVelEqCost, JointVelEqConstraint, JointVelIneqCost,
+            # JointVelIneqConstraint (problem_description.cpp:1246-1372 without use_time).  The constraint and hinge forms put
+            # rows on two consecutive waypoints; a library built without TMX_LINK_ROWS refuses them at upload.
             return JointVelTermInfo(coeffs=_vec(p, "coeffs", D, [1.0] * D), targets=_vec(p, "targets", D),
-                                    first_step=int(p.get("first_step", 0)), last_step=int(p.get("last_step", n_steps - 1)), name=name)
+                                    first_step=int(p.get("first_step", 0)), last_step=int(p.get("last_step", n_steps - 1)), name=name,
+                                    upper_tols=_vec(p, "upper_tols", D, [0.0] * D), lower_tols=_vec(p, "lower_tols", D, [0.0] * D),
+                                    is_constraint=not is_cost)
         if typ == "joint_pos":
             _only_members(p, ("coeffs", "first_step", "last_step", "targets", "lower_tols", "upper_tols"), typ)
             return JointPosTermInfo(coeffs=_vec(p, "coeffs", D, [1.0] * D), targets=_vec(p, "targets", D),
