@@ -34,3 +34,25 @@ def test_random_wide_problems_on_host_build(hostemu_lib, orc):
 @pytest.mark.gpu
 def test_random_problems_on_device(orc):
     _sweep(20, 5, "gpu")     # D <= 8 and n_steps * D <= 256: the dense fast path of the QP solver
+
+
+@pytest.mark.parametrize("seed,case", [(2, 26), (2, 50), (2, 78), (2, 59), (2, 68), (2, 91)])
+def test_polish_regression_cases(hostemu_lib, orc, seed, case):
+    """Random QPs on which the first device polish (1/delta row weights folded into the right-hand sides) lost 12 digits
+    and was rejected while the reference's KKT solve accepts it: the polish status must equal the
+    oracle's and the polished points must agree to round-off."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(HERE, "tools"))
+    import fuzz_parity as fz
+    import parity_checks as pc
+    from trajopt_amd import runtime
+    pci, x0 = fz.random_problem(np.random.default_rng([seed, case]))
+    ctx = runtime.Context(0, hostemu_lib)
+    desc = pc.make_ctx_inputs(ctx, pci, x0[:1])
+    ctx.convexify()
+    xq, cvx, rec = ctx.qp_solve()
+    q = orc.first_qp(desc, x0[0])
+    ctx.close()
+    assert rec[0].polish_status == q["rec"].polish_status == 1
+    assert rec[0].osqp_iter == q["rec"].osqp_iter
+    assert np.abs(xq[0][:q["n"]] - q["x"]).max() < 1e-10
