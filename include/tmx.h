@@ -149,6 +149,10 @@ typedef struct
   int32_t n_obstacles;
   const tmx_link_sphere* link_spheres;
   const tmx_obstacle_sphere* obstacles;
+  /* Fixed timesteps / dofs pin the variable to the value of EACH SEED's own initial trajectory (the x0 handed to
+     tmx_batch_set_x0 for that problem of the batch).  In the reference the pinned value is TrajOptProb's init_traj
+     (problem_description.cpp:485-530) and callers initialise the optimizer with that same trajectory
+     (OptimizeProblem, :394-408: opt.initialize(trajToDblVec(prob->GetInitTraj()))), so one seed == one reference problem. */
   int32_t n_fixed_steps;           /* BasicInfo::fixed_timesteps  trajopt/src/problem_description.cpp:485-508 */
   int32_t n_terms;
   const int32_t* fixed_steps;
@@ -274,6 +278,16 @@ TMX_API tmx_status tmx_export_csc(tmx_ctx* ctx, int32_t problem, int32_t* n, int
  * x_qp: B*n_max solution in reference variable order (primary vars, then aux vars); n_max from tmx_qp_dims */
 TMX_API tmx_status tmx_qp_dims(tmx_ctx* ctx, int32_t* n_max, int32_t* m_max);
 TMX_API tmx_status tmx_qp_solve(tmx_ctx* ctx, double* x_qp, int32_t* cvx_status, tmx_qp_record* rec);
+
+/* dual solution (OSQP solution->y, unscaled) of the last batched Model::optimize(): y_qp[problem * m_max + i], reference
+ * row order; the reference reads it back for its explicit warm start (osqp_interface.cpp:346-348, 514-515)            */
+TMX_API tmx_status tmx_qp_duals(tmx_ctx* ctx, double* y_qp /* B * m_max */);
+/* Polish active-set guess of the last batched Model::optimize() (OSQP polish.c: A_low = {i : z_i - l_i < -y_i},
+ * A_upp = {i : u_i - z_i < y_i}) in REFERENCE ROW ORDER (constraint rows, then the n identity bound rows):
+ * flags[problem * m_max + i] = -1 (lower bound active), +1 (upper), 0 (inactive or i >= m).  These are the integer
+ * active-set indices the parity tests compare bit-exactly with the oracle; tmx_qp_record.hash_active is their hash.
+ * All zero when the solve did not reach the polish (status != OSQP_SOLVED).                                   */
+TMX_API tmx_status tmx_qp_active_set(tmx_ctx* ctx, int32_t* flags /* B * m_max */);
 
 /* ---- K7: best-seed reduction.  Local argmin of total_cost over OPT_CONVERGED problems; when a
  *      communicator has been attached (tmx_attach_nccl) the (cost, global index) pair is reduced over

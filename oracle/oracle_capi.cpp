@@ -133,6 +133,45 @@ int orc_sqp_batch(const tmx_problem_desc* desc, const tmx_sqp_params* sqp, const
   return err;
 }
 
+// One seed: the polish active-set flags (-1 lower / +1 upper / 0) and the unscaled duals of EVERY Model::optimize() of the
+// SQP run, reference row order; flags[k * m_cap + i], y[k * m_cap + i], m_out[k] rows in QP k.
+int orc_sqp_active_sets(const tmx_problem_desc* desc, const tmx_sqp_params* sqp, const tmx_osqp_settings* osqp, const double* x0,
+                        int max_qp, int m_cap, int* flags, double* y, int* m_out, int* n_qp_out)
+{
+  try
+  {
+    const int TD = desc->n_steps * desc->n_dof;
+    TrajProblem P = constructProblem(*desc, x0);
+    P.prob->getModel()->settings = toSettings(osqp);
+    std::vector<QpTrace> trace;
+    std::vector<std::vector<int>> act;
+    std::vector<DblVec> duals;
+    P.prob->getModel()->trace = &trace;
+    P.prob->getModel()->trace_active = &act;
+    P.prob->getModel()->trace_duals = &duals;
+    BasicTrustRegionSQP opt(P.prob);
+    toParams(sqp, opt.getParameters());
+    opt.initialize(DblVec(x0, x0 + TD));
+    opt.optimize();
+    *n_qp_out = static_cast<int>(act.size());
+    for (int k = 0; k < std::min<int>(max_qp, static_cast<int>(act.size())); ++k)
+    {
+      const int m = std::min<int>(m_cap, static_cast<int>(act[k].size()));
+      m_out[k] = static_cast<int>(act[k].size());
+      for (int i = 0; i < m; ++i)
+      {
+        flags[static_cast<std::size_t>(k) * m_cap + i] = act[k][i];
+        y[static_cast<std::size_t>(k) * m_cap + i] = duals[k][i];
+      }
+    }
+    return 0;
+  }
+  catch (...)
+  {
+    return 1;
+  }
+}
+
 // Cost::value / Constraint::violation at x  (evaluateCosts / evaluateConstraintViols, optimizers.cpp:176-192)
 int orc_evaluate(const tmx_problem_desc* desc, const double* x0_for_fixed, const double* x, double* cost_vals,
                  double* cnt_viols, int* n_costs, int* n_cnts)
@@ -270,4 +309,11 @@ int orc_fk_tool(const tmx_problem_desc* desc, const double* q, double* tf12)
   return 0;
 }
 int orc_num_threads() { return omp_get_max_threads(); }
+// the shared libm stand-in (include/tmx_detmath.h) as compiled into the oracle: op 0 sin, 1 cos, 2 atan2(a, b)
+int orc_detmath(int op, int n, const double* a, const double* b, double* out)
+{
+  for (int i = 0; i < n; ++i)
+    out[i] = (op == 0) ? tmx_sin(a[i]) : (op == 1) ? tmx_cos(a[i]) : tmx_atan2(a[i], b[i]);
+  return 0;
+}
 }

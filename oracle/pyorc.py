@@ -54,6 +54,21 @@ def sqp_batch(desc, x0, sqp=None, osqp=None, nthreads=0, max_records=64):
                 n_qp_solves=nqp, records=recs, rec_counts=cnts, max_records=max_records, admm_iters=admm.value)
 
 
+def sqp_active_sets(desc, x0, m_cap, sqp=None, osqp=None, max_qp=256):
+    """one seed: per-QP polish active flags and duals of the whole SQP run -> list of (flags[m], y[m])"""
+    x0 = np.ascontiguousarray(x0, np.float64)
+    flags = np.zeros((max_qp, m_cap), np.int32)
+    y = np.zeros((max_qp, m_cap))
+    ms = np.zeros(max_qp, np.int32)
+    nq = C.c_int(0)
+    rc = lib().orc_sqp_active_sets(C.byref(desc), C.byref(sqp) if sqp is not None else None,
+                                   C.byref(osqp) if osqp is not None else None, _p(x0), max_qp, m_cap, _p(flags, C.c_int), _p(y),
+                                   _p(ms, C.c_int), C.byref(nq))
+    if rc != 0:
+        raise RuntimeError("oracle sqp_active_sets failed")
+    return [(flags[k, :ms[k]].copy(), y[k, :ms[k]].copy()) for k in range(min(nq.value, max_qp))]
+
+
 def evaluate(desc, x0_fixed, x):
     nc, nn = C.c_int(0), C.c_int(0)
     x0_fixed = np.ascontiguousarray(x0_fixed, np.float64)

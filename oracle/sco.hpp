@@ -438,6 +438,8 @@ class Model
 public:
   OsqpSettings settings = OsqpSettings::trajoptDefaults();
   std::vector<QpTrace>* trace{ nullptr };
+  std::vector<std::vector<int>>* trace_active{ nullptr };
+  std::vector<DblVec>* trace_duals{ nullptr };
   // last CSC handed to OSQP (kept for KATs / export)
   Csc P_csc, A_csc;
   DblVec q_, l_, u_;
@@ -583,6 +585,11 @@ public:
       t.hash_active = posHash(solver_->active_flags, 5);
       t.rho_final = solver_->currentRho();
       trace->push_back(t);
+      if (trace_active)  // per-QP polish active flags + unscaled duals (parity tests compare active sets row by row)
+      {
+        trace_active->push_back(solver_->active_flags);
+        trace_duals->push_back(solver_->sol_y);
+      }
     }
     if (status == OSQP_SOLVED || status == OSQP_SOLVED_INACCURATE)
       return CVX_SOLVED;

@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "../include/tmx.h"
+#include "../include/tmx_detmath.h"  // the libm stand-in shared with the device kernels (fixed IEEE operation sequence)
 #include "sco.hpp"
 
 namespace orc
@@ -74,7 +75,9 @@ inline Tf tfInv(const Tf& A)
 inline Tf tfRotAxis(const double* ax, double ang)
 {
   Tf T = tfIdentity();
-  const double c = std::cos(ang), s = std::sin(ang), v = 1.0 - c;
+  double c, s;
+  tmx_sincos(ang, &s, &c);
+  const double v = 1.0 - c;
   const double x = ax[0], y = ax[1], z = ax[2];
   T.R[0] = c + x * x * v;
   T.R[1] = x * y * v - z * s;
@@ -212,7 +215,7 @@ inline void rotErrDecomposed(const double* R, double axis[3], double& angle)
   double ang, ax[3];
   if (n != 0.0)
   {
-    ang = 2.0 * std::atan2(n, std::fabs(qw));
+    ang = 2.0 * tmx_atan2(n, std::fabs(qw));
     if (qw < 0)
       n = -n;
     ax[0] = qx / n;

@@ -191,3 +191,51 @@ def test_initialize_rejects_wrong_length(hostemu_lib):
     opt.initialize(configs.seeds_for(0, pci, s, g, 2))
     st = opt.optimize()
     assert (st == abi.OPT_CONVERGED).all()
+
+
+def _set_mode(ctx, mode):
+    import ctypes as C
+    fn = ctx.lib.tmx_debug_set_fused
+    fn.argtypes = [C.c_void_p, C.c_int]
+    fn.restype = C.c_int
+    assert fn(ctx.h, mode) == 0
+
+
+@pytest.mark.parametrize("cid", [0, 9])
+def test_stepwise_driver_matches_the_pool(emu, cid):
+    """mode 0 (one launch chain per trust-region evaluation: k_convexify / k_qp_solve / k_evaluate / k_sqp_update) gives the
+    results of the persistent pool kernel bit for bit.  Regression: k_sqp_update used to be launched with too little
+    scratch for the model values + per-slot terms (out-of-range accesses, wrong merits on a GPU)."""
+    pci, s, g = _cfg(cid)
+    x0 = configs.seeds_for(cid, pci, s, g, 3, sigma=0.05)
+    pc.make_ctx_inputs(emu, pci, x0)
+    emu.run(0)
+    ref = emu.results()
+    _set_mode(emu, 0)
+    emu.set_x0(x0)
+    emu.run(0)
+    r = emu.results()
+    _set_mode(emu, 2)
+    for k in ("x", "status", "total_cost", "n_func_evals", "n_qp_solves"):
+        assert np.array_equal(r[k], ref[k]), k
+
+
+def test_pool_after_bounded_steps_does_not_resolve_finished_problems(emu):
+    """bounded tmx_sqp_run(k > 0) calls (k_sqp_fused) followed by tmx_sqp_run(0) (the pool): the pool's scheduler words
+    follow the problem phases, so finished seeds are not claimed again (regression: one extra QP record per finished seed)"""
+    pci, s, g = _cfg(0)
+    x0 = configs.seeds_for(0, pci, s, g, 4)
+    pc.make_ctx_inputs(emu, pci, x0)
+    emu.run(0)
+    ref = emu.results()
+    _, ref_cnt = emu.qp_records(64)
+    ref_admm = emu.counters()["admm_iters"]
+    emu.set_x0(x0)
+    for _ in range(3):
+        emu.run(1)
+    emu.run(0)
+    r = emu.results()
+    _, cnt = emu.qp_records(64)
+    assert np.array_equal(r["x"], ref["x"]) and np.array_equal(r["n_qp_solves"], ref["n_qp_solves"])
+    assert np.array_equal(cnt, ref_cnt) and np.array_equal(cnt, r["n_qp_solves"])
+    assert emu.counters()["admm_iters"] == ref_admm

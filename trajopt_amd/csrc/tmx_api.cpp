@@ -200,6 +200,13 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
     ctx->err = "n_dof must be in [1, TMX_MAX_DOF] and n_steps >= 1";
     return TMX_ERR_INVALID;
   }
+  if (d->n_fixed_steps < 0 || d->n_fixed_dofs < 0 || d->n_terms < 0 || d->n_link_spheres < 0 || d->n_obstacles < 0 ||
+      (d->n_fixed_steps > 0 && !d->fixed_steps) || (d->n_fixed_dofs > 0 && !d->fixed_dofs) || (d->n_terms > 0 && !d->terms) ||
+      (d->n_link_spheres > 0 && !d->link_spheres) || (d->n_obstacles > 0 && !d->obstacles))
+  {
+    ctx->err = "tmx_problem_desc: negative count or NULL array with a positive count";
+    return TMX_ERR_INVALID;
+  }
   free_pool(ctx->prob_allocs);
   free_pool(ctx->batch_allocs);
   ctx->Bcap = 0;
@@ -668,7 +675,8 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
   {
     // the term / structure kernels of a long-horizon problem need more than the default 64 KB of dynamic LDS
     const void* small_kernels[] = { reinterpret_cast<const void*>(k_prepare), reinterpret_cast<const void*>(k_evaluate),
-                                    reinterpret_cast<const void*>(k_convexify), reinterpret_cast<const void*>(k_export_csc) };
+                                    reinterpret_cast<const void*>(k_convexify), reinterpret_cast<const void*>(k_export_csc),
+                                    reinterpret_cast<const void*>(k_sqp_update) };
     for (const void* k : small_kernels)
       HIPCHK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(ctx->smem_small)));
   }
@@ -849,6 +857,8 @@ tmx_status tmx_sqp_run(tmx_ctx* ctx, int32_t max_steps, int32_t* n_active_out)
     else if (ctx->mode == 2 && max_steps == 0)
     {
       const int G = std::min(B, ctx->pool_wgs);
+      // the scheduler words follow the problem phases (bounded k_sqp_fused calls before this one do not maintain them)
+      TMX_LAUNCH(k_pool_sync, 1, 256, 0, ctx->stream, ctx->db);
       TIMED(ctx->ms_admm, ctx->launches_admm++,
             TMX_LAUNCH(k_sqp_pool, G, ctx->nt_qp, ctx->smem_pool, ctx->stream, ctx->dp, ctx->db));
     }
@@ -886,8 +896,8 @@ tmx_status tmx_sqp_run(tmx_ctx* ctx, int32_t max_steps, int32_t* n_active_out)
             TMX_LAUNCH(k_qp_solve, B, ctx->nt_qp, ctx->smem_qp, ctx->stream, ctx->dp, ctx->db, 0));
     TIMED(ctx->ms_evaluate, (void)0,
           TMX_LAUNCH(k_evaluate, B, ctx->nt_small, ctx->smem_small, ctx->stream, ctx->dp, ctx->db, 1));
-    TMX_LAUNCH(k_sqp_update, B, 64, (size_t)(ctx->hp.n_costs + ctx->hp.n_cnts + 8) * sizeof(double), ctx->stream, ctx->dp,
-               ctx->db);
+    // sqp_update_block carves the model values AND the per-slot / velocity-term scratch of evaluate_terms behind them
+    TMX_LAUNCH(k_sqp_update, B, 64, ctx->smem_small, ctx->stream, ctx->dp, ctx->db);
     HIPCHK(hipGetLastError());
     ++step;
   }
@@ -1130,6 +1140,46 @@ tmx_status tmx_qp_solve(tmx_ctx* ctx, double* x_qp, int32_t* cvx_status, tmx_qp_
   return TMX_OK;
 }
 
+tmx_status tmx_qp_duals(tmx_ctx* ctx, double* y_qp)
+{
+  if (!ctx || !y_qp)
+    return TMX_ERR_INVALID;
+  if (ctx->Bcap == 0)
+    return TMX_ERR_STATE;
+  HIPCHK(hipSetDevice(ctx->device));
+  tmx_status rc = d2h(ctx, y_qp, ctx->hb.yq, (size_t)ctx->hb.B * ctx->hp.m_max);
+  if (rc != TMX_OK)
+    return rc;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return TMX_OK;
+}
+
+tmx_status tmx_qp_active_set(tmx_ctx* ctx, int32_t* flags)
+{
+  if (!ctx || !flags)
+    return TMX_ERR_INVALID;
+  if (ctx->Bcap == 0)
+    return TMX_ERR_STATE;
+  HIPCHK(hipSetDevice(ctx->device));
+  const size_t count = (size_t)ctx->hb.B * ctx->hp.m_max;
+  std::vector<void*> pool;
+  int* d_out = nullptr;
+  tmx_status rc = dalloc(ctx, pool, &d_out, count);
+  if (rc != TMX_OK)
+    return rc;
+  TMX_LAUNCH(k_export_active, ctx->hb.B, 256, 0, ctx->stream, ctx->dp, ctx->db, d_out);
+  hipError_t e = hipStreamSynchronize(ctx->stream);
+  if (e == hipSuccess)
+    e = hipMemcpy(flags, d_out, sizeof(int) * count, hipMemcpyDeviceToHost);
+  free_pool(pool);
+  if (e != hipSuccess)
+  {
+    ctx->err = std::string("tmx_qp_active_set: ") + hipGetErrorString(e);
+    return TMX_ERR_DEVICE;
+  }
+  return TMX_OK;
+}
+
 tmx_status tmx_argmin(tmx_ctx* ctx, int64_t global_offset, int64_t* best_index, double* best_cost)
 {
   if (!ctx || !best_index || !best_cost)
@@ -1222,6 +1272,41 @@ __attribute__((visibility("default"))) tmx_status tmx_debug_phase_cycles(tmx_ctx
   for (int b = 0; b < ctx->hb.B; ++b)
     for (int k = 0; k < 16; ++k)
       out16[k] += h[(size_t)b * 16 + k];
+  return TMX_OK;
+}
+
+// debug hook (not in include/tmx.h): the device build of include/tmx_detmath.h on host arrays (parity test: the same
+// bits as the oracle's build of the same header)
+__attribute__((visibility("default"))) tmx_status tmx_debug_detmath(tmx_ctx* ctx, int op, int n, const double* a, const double* b, double* out)
+{
+  if (!ctx || !a || !b || !out || n < 1 || op < 0 || op > 2)
+    return TMX_ERR_INVALID;
+  HIPCHK(hipSetDevice(ctx->device));
+  std::vector<void*> pool;
+  double *da = nullptr, *db = nullptr, *dout = nullptr;
+  tmx_status rc;
+  if ((rc = dalloc(ctx, pool, &da, (size_t)n)) != TMX_OK || (rc = dalloc(ctx, pool, &db, (size_t)n)) != TMX_OK ||
+      (rc = dalloc(ctx, pool, &dout, (size_t)n)) != TMX_OK)
+  {
+    free_pool(pool);
+    return rc;
+  }
+  hipError_t e = hipMemcpy(da, a, sizeof(double) * n, hipMemcpyHostToDevice);
+  if (e == hipSuccess)
+    e = hipMemcpy(db, b, sizeof(double) * n, hipMemcpyHostToDevice);
+  if (e == hipSuccess)
+  {
+    TMX_LAUNCH(k_detmath, 64, 256, 0, ctx->stream, op, n, da, db, dout);
+    e = hipStreamSynchronize(ctx->stream);
+  }
+  if (e == hipSuccess)
+    e = hipMemcpy(out, dout, sizeof(double) * n, hipMemcpyDeviceToHost);
+  free_pool(pool);
+  if (e != hipSuccess)
+  {
+    ctx->err = std::string("tmx_debug_detmath: ") + hipGetErrorString(e);
+    return TMX_ERR_DEVICE;
+  }
   return TMX_OK;
 }
 

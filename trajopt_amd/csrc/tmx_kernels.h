@@ -337,6 +337,68 @@ TMX_KERNEL_LB2(TMX_QP_NT, TMX_QP_WGS_PER_CU) k_sqp_pool(const DevProblem* P, con
   }
 }
 
+// polish active-set flags of the last Model::optimize() of every problem, reference row order (tmx_qp_active_set)
+TMX_KERNEL k_export_active(const DevProblem* P, const DevBatch* Bt, int* out)
+{
+  const int b = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
+  const int R = P->R, NX = P->NX;
+  QpWs w;  // only the layout of the far (HBM) part is used
+  double* scratch = Bt->qp_scratch + (size_t)b * Bt->qp_scratch_stride;
+  qp_ws_carve(w, scratch, scratch, scratch, P->D, P->T, R, P->NA);
+  int* o = out + (size_t)b * P->m_max;
+  const int* rec = Bt->prev_dims + 4 * b;  // dims of the last solve
+  const int n = rec[0], m = rec[1], mg = m - n;
+  for (int i = tid; i < P->m_max; i += NT)
+    o[i] = 0;
+  TMX_SYNC();
+  if (n < 0)
+    return;
+  const int* act = Bt->active + (size_t)b * R;
+  for (int v = tid; v < NX; v += NT)
+    o[mg + v] = w.flg_bp[v];
+  for (int r = tid; r < R; r += NT)
+    if (act[r])
+    {
+      o[w.row_ref[r]] = w.flg_r[r];
+      for (int k = 0; k < P->slot_naux[r]; ++k)
+        o[mg + w.aux_ref[r] + k] = w.flg_ba[P->slot_aoff[r] + k];
+    }
+}
+
+// the shared libm stand-in (include/tmx_detmath.h) as compiled for the device: op 0 sin, 1 cos, 2 atan2(a, b)
+TMX_KERNEL k_detmath(int op, int n, const double* a, const double* b, double* out)
+{
+  const int i0 = threadIdx.x + blockIdx.x * blockDim.x, stride = blockDim.x * gridDim.x;
+  for (int i = i0; i < n; i += stride)
+    out[i] = (op == 0) ? tmx_sin(a[i]) : (op == 1) ? tmx_cos(a[i]) : tmx_atan2(a[i], b[i]);
+}
+
+// scheduler words of the pool from the problem phases (one workgroup): ready unless DONE
+TMX_KERNEL k_pool_sync(const DevBatch* Bt)
+{
+  TMX_SMEM(smem);
+  (void)smem;
+  const int tid = threadIdx.x, NT = blockDim.x;
+  if (tid == 0)
+    *Bt->sched_done = 0;
+  TMX_SYNC();
+  int nd = 0;
+  for (int b = tid; b < Bt->B; b += NT)
+  {
+    const bool done = Bt->phase[b] == PHASE_DONE;
+    Bt->sched_state[b] = done ? 2 : 0;
+    nd += done ? 1 : 0;
+  }
+  if (nd)
+  {
+#if TMX_IS_DEVICE
+    atomicAdd(Bt->sched_done, nd);
+#else
+    __atomic_fetch_add(Bt->sched_done, nd, __ATOMIC_RELAXED);
+#endif
+  }
+}
+
 // number of problems not DONE + running totals; `totals` = {n_active, n_fe, n_qp, admm} zeroed by the host first
 TMX_KERNEL k_count_active(const DevBatch* Bt, long long* totals)
 {

@@ -10,6 +10,7 @@
 //   JointVelEqCost / JointPosEqConstraint           trajopt/src/trajectory_costs.cpp:139-183,257-301
 #pragma once
 #include "tmx_types.h"
+#include "../../include/tmx_detmath.h"  // sin / cos / atan2 with a fixed IEEE operation sequence, shared with the oracle
 
 #define TMX_EPS_FD 1e-5       // sco DEFAULT_EPSILON, trajopt_sco/src/modeling_utils.cpp:13
 #define TMX_CLEANUP_TOL 1e-7  // sco::cleanupAff, trajopt_sco/src/expr_ops.cpp:91
@@ -54,7 +55,9 @@ TMX_DEVFN void tf_joint_motion(const double* ax, int type, double q, Tf3& T)
   T.t[0] = T.t[1] = T.t[2] = 0.0;
   if (type == 0)
   {
-    const double c = cos(q), s = sin(q), v = 1.0 - c;
+    double c, s;
+    tmx_sincos(q, &s, &c);
+    const double v = 1.0 - c;
     const double x = ax[0], y = ax[1], z = ax[2];
     T.R[0] = c + x * x * v;
     T.R[1] = x * y * v - z * s;
@@ -135,7 +138,7 @@ TMX_DEVFN void rot_err_decomposed(const double* R, double axis[3], double& angle
   double ang, ax[3];
   if (n != 0.0)
   {
-    ang = 2.0 * atan2(n, fabs(qw));
+    ang = 2.0 * tmx_atan2(n, fabs(qw));
     if (qw < 0)
       n = -n;
     ax[0] = qx / n;
@@ -259,7 +262,9 @@ TMX_DEVFN void evaluate_terms(const DevProblem* P, const double* xv, double* cos
       v = (e > 0) ? e : 0.0;
     }
 #endif
-    scratch[r] = v;
+    // cart-pose slots are written by the instance loop below (another thread, no barrier in between): never store here
+    if (kind != SLOT_CARTPOSE)
+      scratch[r] = v;
   }
   // cart-pose instances: |coeff_i * err_i| (constraint violation) or abs cost
   for (int c = tid; c < P->n_cp; c += NT)

@@ -34,6 +34,8 @@ _SIGS = {
     "tmx_export_csc": ([C.c_void_p, C.c_int32] + [C.POINTER(C.c_int32)] * 4 + [C.c_void_p] * 9, C.c_int),
     "tmx_qp_dims": ([C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)], C.c_int),
     "tmx_qp_solve": ([C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p], C.c_int),
+    "tmx_qp_active_set": ([C.c_void_p, C.c_void_p], C.c_int),
+    "tmx_qp_duals": ([C.c_void_p, C.c_void_p], C.c_int),
     "tmx_argmin": ([C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_double)], C.c_int),
     "tmx_attach_nccl": ([C.c_void_p, C.c_void_p], C.c_int),
     "tmx_kernel_stats": ([C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)], C.c_int),
@@ -181,6 +183,18 @@ class Context:
         rec = (abi.QpRecord * self.B)()
         self._chk(self.lib.tmx_qp_solve(self.h, _ptr(xq), _ptr(cvx), rec))
         return xq, cvx, rec
+
+    def qp_duals(self):
+        """dual solution of the last qp_solve() / SQP step, reference row order: [B][m_max]"""
+        y = np.zeros((self.B, self.m_max))
+        self._chk(self.lib.tmx_qp_duals(self.h, _ptr(y)))
+        return y
+
+    def qp_active_set(self):
+        """polish active-set flags of the last qp_solve() / SQP step, reference row order: [B][m_max] of -1 / 0 / +1"""
+        f = np.zeros((self.B, self.m_max), np.int32)
+        self._chk(self.lib.tmx_qp_active_set(self.h, _ptr(f)))
+        return f
 
     def argmin(self, global_offset: int = 0):
         bi, bc = C.c_int64(), C.c_double()
