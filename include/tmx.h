@@ -132,8 +132,19 @@ typedef struct
      [first_step, last_step] that get NO collision term (problem_description.cpp:1641-1649 validation, :1767 / :1827
      skip).  Independent of tmx_problem_desc.fixed_steps, exactly as in the reference.  May be NULL when n == 0. */
   int32_t n_fixed_steps;
-  int32_t pad_;
+  /* collision: tesseract::collision::CollisionEvaluatorType of the term's collision_check_config (the JSON key
+     "evaluator_type", problem_description.cpp:1627): 0 / 1 DISCRETE -> one SingleTimestep term per non-fixed step;
+     2 LVS_DISCRETE -> DiscreteCollisionEvaluator, 3 CONTINUOUS / 4 LVS_CONTINUOUS -> CastCollisionEvaluator: one term per
+     SEGMENT (i, i+1), i in [first_step, last_step) (problem_description.cpp:1720-1761, :1779-1819), whose rows touch both
+     waypoints.  fixed_steps then select START_FIXED_END_FREE / START_FREE_END_FIXED (contacts at the fixed state are
+     dropped, its variables carry no gradient).                                                                  */
+  int32_t evaluator_type;
   const int32_t* fixed_steps;
+  double longest_valid_segment_length; /* collision, evaluator types 2..4: sub-states are inserted while the joint distance of
+                                          a segment exceeds it (collision_terms.cpp:823-905, :1071-1173)          */
+  int32_t max_substates;   /* collision, evaluator types 2..4: row-slot capacity per (segment, link sphere, obstacle); the number
+                              of sub-states ceil(dist / lvs) + 1 is clamped to it on the device AND in the oracle (0 = 2)   */
+  int32_t pad2_;
 } tmx_term;
 
 typedef struct

@@ -338,9 +338,13 @@ public:
     std::vector<std::string> names;
     if (t.kind == TMX_TERM_COLLISION_COST || t.kind == TMX_TERM_COLLISION_CNT)
     {
-      for (int i = t.first_step; i <= t.last_step; ++i)
-        if (std::find(fixed_steps.begin(), fixed_steps.end(), i) == fixed_steps.end())
+      if (t.evaluator_type >= 2)  // one term per segment (problem_description.cpp:1723, :1781)
+        for (int i = t.first_step; i < t.last_step; ++i)
           names.push_back(name + "_" + std::to_string(i));
+      else
+        for (int i = t.first_step; i <= t.last_step; ++i)
+          if (std::find(fixed_steps.begin(), fixed_steps.end(), i) == fixed_steps.end())
+            names.push_back(name + "_" + std::to_string(i));
     }
     else
       names.push_back(name);
@@ -616,7 +620,7 @@ struct CartPoseTermInfo : public TermInfo
 };
 
 /** the members of trajopt_common::TrajOptCollisionConfig (trajopt_common/include/trajopt_common/collision_types.h:119-162)
-    that the single-timestep path reads */
+    that the collision terms read */
 struct TrajOptCollisionConfig
 {
   enum class CollisionEvaluatorType  // tesseract::collision::CollisionEvaluatorType
@@ -632,12 +636,17 @@ struct TrajOptCollisionConfig
   double default_collision_coeff{ 1.0 };  // collision_coeff_data default (JSON "coeffs")
   double collision_margin_buffer{ 0.01 };
   CollisionEvaluatorType type{ CollisionEvaluatorType::DISCRETE };  // collision_check_config.type
+  double longest_valid_segment_length{ 0.005 };                     // collision_check_config.longest_valid_segment_length
+  /** row-slot capacity per (segment, link sphere, obstacle) of the device path for the LVS / continuous evaluators: the
+      number of sub-states ceil(dist / lvs) + 1 is clamped to it (not a reference member) */
+  int max_substates{ 2 };
   TrajOptCollisionConfig() = default;
   TrajOptCollisionConfig(double margin, double coeff) : default_margin(margin), default_collision_coeff(coeff) {}
 };
 
-/** problem_description.hpp:597-617 ; hatch: problem_description.cpp:1716-1837.  Lowered: DISCRETE evaluator (one term per
-    non-fixed step: SINGLE_TIME_STEP expressions), cost and constraint form. */
+/** problem_description.hpp:597-617 ; hatch: problem_description.cpp:1716-1837.  DISCRETE evaluator: one term per non-fixed
+    step (SINGLE_TIME_STEP expressions); LVS_DISCRETE / CONTINUOUS / LVS_CONTINUOUS: one term per segment (i, i+1) with
+    START_FREE_END_FREE / START_FIXED_END_FREE / START_FREE_END_FIXED expressions; cost and constraint form. */
 struct CollisionTermInfo : public TermInfo
 {
   int first_step{ -1 }, last_step{ -1 };
@@ -648,8 +657,8 @@ struct CollisionTermInfo : public TermInfo
   {
     if (!config.enabled)
       return;
-    if (config.type != TrajOptCollisionConfig::CollisionEvaluatorType::DISCRETE)
-      printAndThrow("CollisionTermInfo: only the DISCRETE evaluator (single time step) is lowered by the device path");
+    if (config.type == TrajOptCollisionConfig::CollisionEvaluatorType::NONE)
+      printAndThrow("CollisionTermInfo: evaluator type NONE");
     if (first_step < 0 || last_step < first_step || last_step >= prob.GetNumSteps())
       printAndThrow("CollisionTermInfo: invalid first_step / last_step");
     for (int fs : fixed_steps)
@@ -662,6 +671,24 @@ struct CollisionTermInfo : public TermInfo
     t.margin = config.default_margin;
     t.coeff = config.default_collision_coeff;
     t.buffer = config.collision_margin_buffer;
+    t.evaluator_type = static_cast<int32_t>(config.type);
+    t.longest_valid_segment_length = config.longest_valid_segment_length;
+    t.max_substates = config.max_substates;
+    if (t.evaluator_type >= 2 && t.max_substates <= 0)
+    {
+      // capacity from the initial trajectory: 1.5 x the longest segment, at most 64 sub-states
+      const TrajArray& it = prob.GetInitTraj();
+      double dmax = 0.0;
+      for (int i = 0; i + 1 < it.rows(); ++i)
+      {
+        double d2 = 0.0;
+        for (int j = 0; j < it.cols(); ++j)
+          d2 += (it(i + 1, j) - it(i, j)) * (it(i + 1, j) - it(i, j));
+        dmax = std::max(dmax, std::sqrt(d2));
+      }
+      const double lv = std::max(config.longest_valid_segment_length, 1e-9);
+      t.max_substates = static_cast<int32_t>(std::min(64.0, std::max(2.0, std::ceil(1.5 * dmax / lv) + 1.0)));
+    }
     if (static_cast<bool>(term_type & TermType::TT_COST))
     {
       t.kind = TMX_TERM_COLLISION_COST;

@@ -309,9 +309,11 @@ inline TermInfo::Ptr readTerm(const json::Value& it, bool is_cost, const Problem
   if (typ == "collision")
   {
     const int ev = jsonInt(p, "evaluator_type", 1);
-    if (ev != 1)
-      printAndThrow("collision evaluator_type " + std::to_string(ev) +
-                    ": only DISCRETE (1, single time step) is lowered; LVS / continuous evaluators are not");
+    if (ev < 1 || ev > 4)
+      printAndThrow("collision evaluator_type " + std::to_string(ev) + ": must be 1 .. 4");  // FAIL_IF_FALSE(<= 4), :1637; 0 = NONE
+    const double lvs = jsonDouble(p, "longest_valid_segment_length", 0.5);
+    if (!(lvs >= 0))
+      printAndThrow("collision: longest_valid_segment_length must be >= 0");  // :1634
     if (p.isMember("pairs"))
       printAndThrow("collision per-pair margin overrides are not lowered by the device path");
     auto t = std::make_shared<CollisionTermInfo>();
@@ -329,8 +331,15 @@ inline TermInfo::Ptr readTerm(const json::Value& it, bool is_cost, const Problem
     const double buf = jsonDouble(p, "safety_margin_buffer", 0.5);  // quirk Q3: the JSON default is 0.5
     if (buf < 0)
       printAndThrow("collision: negative safety_margin_buffer");
+    // ... and the reference's list of allowed fields (:1701-1711) does not contain "safety_margin_buffer": a JSON file that
+    // supplies the key is rejected, the effective JSON-path buffer is always the default
+    ensureOnlyMembers(p, { "type", "first_step", "last_step", "evaluator_type", "fixed_steps", "contact_test_type",
+                           "longest_valid_segment_length", "coeffs", "dist_pen", "pairs" }, typ);
     t->config = TrajOptCollisionConfig(p["dist_pen"].asDouble(), p["coeffs"].asDouble());
     t->config.collision_margin_buffer = buf;
+    t->config.type = static_cast<TrajOptCollisionConfig::CollisionEvaluatorType>(ev);
+    t->config.longest_valid_segment_length = lvs;
+    t->config.max_substates = 0;  // resolved from the initial trajectory by ProblemConstructionInfoFromJson
     t->name = name;
     t->term_type = tt;
     return t;

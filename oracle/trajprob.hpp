@@ -923,6 +923,271 @@ private:
   double margin_, coeff_, buffer_;
 };
 
+// ---- DiscreteCollisionEvaluator (LVS_DISCRETE) / CastCollisionEvaluator (CONTINUOUS, LVS_CONTINUOUS) on sphere geometry --
+// trajopt/src/collision_terms.cpp:742-905 (discrete LVS), :975-1173 (cast), GetGradient :203-250, CollisionsToDistanceExpressions
+// :343-383, CalcDistExpressionsStartFree / EndFree / BothFree :468-538, trajopt_common::removeInvalidContactResults
+// (trajopt_common/src/collision_utils.cpp:71-114).  The contact managers are tesseract / Bullet [NOT IN REFERENCE]; stand-in:
+//   discrete sub-state i : sphere-sphere contact at q_i; cc_time = i * dt, cc_type Time0 (i == 0) / Time1 (i == last) / Between,
+//                          transform = cc_transform = link pose at q_i   (ContactResultMap::addInterpolatedCollisionResults)
+//   cast sub-segment i   : the link sphere swept from q_i to q_{i+1} is the capsule between its two centres; closest point of
+//                          that segment to the obstacle centre at parameter tau; cc_time = (i + tau) * dt; transform = pose at q_i,
+//                          cc_transform = pose at q_{i+1}; cc_type of the raw cast test: Time0 (tau == 0) / Time1 (tau == 1) /
+//                          Between, then retyped by addInterpolatedCollisionResults exactly as upstream does (a sub-segment index
+//                          never equals the last STATE index, so Time1 only survives on the un-split path)
+//   nearest_points_local : the contact point on the sphere in the link frame of `transform`
+// The number of sub-states is clamped to the row-slot capacity max_substates (device and oracle alike; documented deviation).
+enum CcType { CC_NONE = 0, CC_TIME0 = 1, CC_TIME1 = 2, CC_BETWEEN = 3 };
+struct Contact2
+{
+  int sphere, obstacle, link, sub;
+  double distance;
+  double normal[3];
+  double p_local[3];
+  Tf tf0, tf1;  // transform / cc_transform of the link
+  double cc_time;
+  int cc_type;
+};
+// Eigen::VectorXd::LinSpaced(size, low, high)(i) for size >= 2 (Eigen linspaced_op, non-integer scalar)
+inline double linSpacedAt(long size, double low, double high, long i)
+{
+  const long size1 = size - 1;
+  const double step = (high - low) / static_cast<double>(size1);
+  const bool flip = std::fabs(high) < std::fabs(low);
+  if (flip)
+    return (i == 0) ? low : (high - static_cast<double>(size1 - i) * step);
+  return (i == size1) ? high : (low + static_cast<double>(i) * step);
+}
+struct LvsEvaluator
+{
+  std::shared_ptr<const Chain> chain;
+  std::shared_ptr<const Scene> scene;
+  VarVector vars0, vars1;
+  double margin, coeff, buffer, lvs;
+  bool cast, fixed0, fixed1;
+  int kmax;
+
+  bool keep(const Contact2& c) const  // removeInvalidContactResults with link 1 static (cc_type[1] == None)
+  {
+    if (c.distance > (margin + buffer))
+      return false;
+    if (!fixed0 && !fixed1)
+      return true;
+    if (fixed0 && c.cc_type != CC_NONE && c.cc_type != CC_TIME0)
+      return true;
+    if (fixed1 && c.cc_type != CC_NONE && c.cc_type != CC_TIME1)
+      return true;
+    return false;
+  }
+  void sphereCentre(const Tf& T, const tmx_link_sphere& ls, double c[3]) const
+  {
+    for (int r = 0; r < 3; ++r)
+      c[r] = T.R[3 * r + 0] * ls.center[0] + T.R[3 * r + 1] * ls.center[1] + T.R[3 * r + 2] * ls.center[2] + T.t[r];
+  }
+  void calc(const double* q0, const double* q1, std::vector<Contact2>& out) const
+  {
+    out.clear();
+    const int D = chain->n_dof;
+    double d2 = 0;
+    for (int j = 0; j < D; ++j)
+      d2 += (q1[j] - q0[j]) * (q1[j] - q0[j]);
+    const double dist = std::sqrt(d2);
+    long cnt = 2;
+    if (dist > lvs)
+      cnt = static_cast<long>(std::ceil(dist / lvs)) + 1;
+    if (cnt > kmax)
+      cnt = kmax;
+    const bool split = dist > lvs;
+    // link poses at every sub-state
+    std::vector<std::vector<Tf>> poses(static_cast<std::size_t>(cnt));
+    DblVec qi(D);
+    for (long i = 0; i < cnt; ++i)
+    {
+      for (int j = 0; j < D; ++j)
+        qi[j] = linSpacedAt(cnt, q0[j], q1[j], i);
+      if (!split && cast)  // the un-split cast test uses the two end states themselves
+        for (int j = 0; j < D; ++j)
+          qi[j] = (i == 0) ? q0[j] : q1[j];
+      chain->fk(qi.data(), poses[static_cast<std::size_t>(i)]);
+    }
+    const long last = cnt - 1;
+    const double dt = 1.0 / static_cast<double>(last);
+    for (std::size_t s = 0; s < scene->link_spheres.size(); ++s)
+      for (std::size_t o = 0; o < scene->obstacles.size(); ++o)
+      {
+        const auto& ls = scene->link_spheres[s];
+        const auto& ob = scene->obstacles[o];
+        const long n_sub = cast ? last : cnt;
+        for (long i = 0; i < n_sub; ++i)
+        {
+          Contact2 c;
+          c.sphere = static_cast<int>(s);
+          c.obstacle = static_cast<int>(o);
+          c.link = ls.link;
+          c.sub = static_cast<int>(i);
+          const Tf& Ta = poses[static_cast<std::size_t>(i)][ls.link];
+          double ca[3], p[3];
+          sphereCentre(Ta, ls, ca);
+          double tau = 0.0;
+          if (cast)
+          {
+            const Tf& Tb = poses[static_cast<std::size_t>(i + 1)][ls.link];
+            double cb[3];
+            sphereCentre(Tb, ls, cb);
+            const double e[3] = { cb[0] - ca[0], cb[1] - ca[1], cb[2] - ca[2] };
+            const double ee = e[0] * e[0] + e[1] * e[1] + e[2] * e[2];
+            const double eo = e[0] * (ob.center[0] - ca[0]) + e[1] * (ob.center[1] - ca[1]) + e[2] * (ob.center[2] - ca[2]);
+            tau = (ee > 0) ? eo / ee : 0.0;
+            tau = tau < 0.0 ? 0.0 : (tau > 1.0 ? 1.0 : tau);
+            for (int r = 0; r < 3; ++r)
+              p[r] = ca[r] + tau * e[r];
+            c.tf0 = Ta;
+            c.tf1 = Tb;
+          }
+          else
+          {
+            for (int r = 0; r < 3; ++r)
+              p[r] = ca[r];
+            c.tf0 = Ta;
+            c.tf1 = Ta;
+          }
+          const double d[3] = { ob.center[0] - p[0], ob.center[1] - p[1], ob.center[2] - p[2] };
+          const double len = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+          c.distance = len - ls.radius - ob.radius;
+          double pw[3];
+          for (int r = 0; r < 3; ++r)
+          {
+            c.normal[r] = (len > 0) ? d[r] / len : (r == 2 ? 1.0 : 0.0);
+            pw[r] = p[r] + ls.radius * c.normal[r];
+          }
+          // contact point in the link frame of `transform`
+          for (int r = 0; r < 3; ++r)
+            c.p_local[r] = c.tf0.R[0 + r] * (pw[0] - c.tf0.t[0]) + c.tf0.R[3 + r] * (pw[1] - c.tf0.t[1]) + c.tf0.R[6 + r] * (pw[2] - c.tf0.t[2]);
+          int raw = CC_NONE;
+          if (cast)
+            raw = (tau == 0.0) ? CC_TIME0 : ((tau == 1.0) ? CC_TIME1 : CC_BETWEEN);
+          if (!cast || split)
+          {
+            // addInterpolatedCollisionResults: cc_time and cc_type of an active link
+            c.cc_time = cast ? (static_cast<double>(i) * dt) + (tau * dt) : (static_cast<double>(i) * dt);
+            if (i == 0 && (raw == CC_NONE || raw == CC_TIME0))
+              c.cc_type = CC_TIME0;
+            else if (i == last && (raw == CC_NONE || raw == CC_TIME1))
+              c.cc_type = CC_TIME1;
+            else
+              c.cc_type = CC_BETWEEN;
+          }
+          else
+          {
+            c.cc_time = tau;
+            c.cc_type = raw;
+          }
+          if (keep(c))
+            out.push_back(c);
+        }
+      }
+  }
+  // GetGradient(dofvals, contact, isTimestep1) for the (only) active link 0 + its share of the distance expression
+  void addEnd(AffExpr& dist, const Contact2& c, const DblVec& q, const VarVector& vars, bool isTimestep1) const
+  {
+    const int D = chain->n_dof;
+    const double scale = isTimestep1 ? c.cc_time : (1 - c.cc_time);
+    const Tf& lt = isTimestep1 ? c.tf1 : c.tf0;
+    // jacobianChangeRefPoint(jac, link_transform.linear() * nearest_points_local): the point rigidly attached to the link AT q
+    std::vector<Tf> link;
+    chain->fk(q.data(), link);
+    double p[3];
+    for (int r = 0; r < 3; ++r)
+      p[r] = link[c.link].t[r] + (lt.R[3 * r + 0] * c.p_local[0] + lt.R[3 * r + 1] * c.p_local[1] + lt.R[3 * r + 2] * c.p_local[2]);
+    DblVec J(3 * D);
+    chain->jacobianPoint(q.data(), c.link, p, J.data());
+    DblVec sg(D);
+    double gq = 0;
+    for (int k = 0; k < D; ++k)
+    {
+      const double g = -1.0 * (c.normal[0] * J[0 * D + k] + c.normal[1] * J[1 * D + k] + c.normal[2] * J[2 * D + k]);
+      sg[k] = scale * g;
+      gq += g * q[k];
+    }
+    exprInc(dist, varDot(sg, vars));
+    exprInc(dist, scale * -gq);
+  }
+  AffExprVector distExpressions(const DblVec& x, std::vector<Contact2>& cts) const
+  {
+    const DblVec q0 = getDblVec(x, vars0), q1 = getDblVec(x, vars1);
+    calc(q0.data(), q1.data(), cts);
+    AffExprVector exprs;
+    for (const Contact2& c : cts)
+    {
+      AffExpr e0(0), e1(0);
+      if (!fixed0)
+        addEnd(e0, c, q0, vars0, false);
+      if (!fixed1)
+        addEnd(e1, c, q1, vars1, true);
+      AffExpr e(c.distance);
+      if (!fixed0)
+        exprInc(e, e0);
+      if (!fixed1)
+        exprInc(e, e1);
+      exprs.push_back(cleanupAff(e));
+    }
+    return exprs;
+  }
+};
+
+class CollisionCostLvs : public Cost
+{
+public:
+  CollisionCostLvs(LvsEvaluator ev, const std::string& name) : ev_(std::move(ev)) { name_ = name; }
+  std::shared_ptr<ConvexObjective> convex(const DblVec& x, Model* model) override
+  {
+    auto out = std::make_shared<ConvexObjective>(model);
+    std::vector<Contact2> cts;
+    for (const AffExpr& e : ev_.distExpressions(x, cts))
+      out->addHinge(exprSub(AffExpr(ev_.margin), e), ev_.coeff);  // collision_terms.cpp:1298-1302
+    return out;
+  }
+  double value(const DblVec& x) override
+  {
+    std::vector<Contact2> cts;
+    const DblVec q0 = getDblVec(x, ev_.vars0), q1 = getDblVec(x, ev_.vars1);
+    ev_.calc(q0.data(), q1.data(), cts);
+    double out = 0;
+    for (const Contact2& c : cts)
+      out += pospart(ev_.margin - c.distance) * ev_.coeff;
+    return out;
+  }
+
+private:
+  LvsEvaluator ev_;
+};
+class CollisionConstraintLvs : public Constraint
+{
+public:
+  CollisionConstraintLvs(LvsEvaluator ev, const std::string& name) : ev_(std::move(ev)) { name_ = name; }
+  ConstraintType type() override { return INEQ; }
+  std::shared_ptr<ConvexConstraints> convex(const DblVec& x, Model* model) override
+  {
+    auto out = std::make_shared<ConvexConstraints>(model);
+    std::vector<Contact2> cts;
+    for (const AffExpr& e : ev_.distExpressions(x, cts))
+      out->addIneqCnt(exprMult(exprSub(AffExpr(ev_.margin), e), ev_.coeff));  // :1387-1391
+    return out;
+  }
+  DblVec value(const DblVec& x) override
+  {
+    std::vector<Contact2> cts;
+    const DblVec q0 = getDblVec(x, ev_.vars0), q1 = getDblVec(x, ev_.vars1);
+    ev_.calc(q0.data(), q1.data(), cts);
+    DblVec out;
+    for (const Contact2& c : cts)
+      out.push_back(pospart(ev_.margin - c.distance) * ev_.coeff);
+    return out;
+  }
+
+private:
+  LvsEvaluator ev_;
+};
+
 // ---- trajopt::ConstructProblem  problem_description.cpp:410-592 ------------------------------------
 struct TrajProblem
 {
@@ -1048,16 +1313,46 @@ inline TrajProblem constructProblem(const tmx_problem_desc& d, const double* ini
           break;
         }
         case TMX_TERM_COLLISION_COST:
+        case TMX_TERM_COLLISION_CNT:
+          if (tm.evaluator_type >= 2)
+          {
+            // one term per SEGMENT (problem_description.cpp:1720-1761, :1779-1819)
+            for (int i = tm.first_step; i < tm.last_step; ++i)
+            {
+              const bool cur = std::find(tm.fixed_steps, tm.fixed_steps + tm.n_fixed_steps, i) != tm.fixed_steps + tm.n_fixed_steps;
+              const bool nxt = std::find(tm.fixed_steps, tm.fixed_steps + tm.n_fixed_steps, i + 1) != tm.fixed_steps + tm.n_fixed_steps;
+              LvsEvaluator ev;
+              ev.chain = P.chain;
+              ev.scene = P.scene;
+              ev.vars0 = P.traj_vars.row(i);
+              ev.vars1 = P.traj_vars.row(i + 1);
+              ev.margin = tm.margin;
+              ev.coeff = tm.coeff;
+              ev.buffer = tm.buffer;
+              ev.lvs = tm.longest_valid_segment_length;
+              ev.cast = tm.evaluator_type != 2;
+              ev.fixed0 = cur;            // START_FIXED_END_FREE also when both are fixed (the :1745 branch is unreachable)
+              ev.fixed1 = !cur && nxt;    // START_FREE_END_FIXED
+              ev.kmax = tm.max_substates < 2 ? 2 : tm.max_substates;
+              if (tm.kind == TMX_TERM_COLLISION_COST)
+                P.prob->addCost(std::make_shared<CollisionCostLvs>(ev, "collision_" + std::to_string(i)));
+              else
+                P.prob->addConstraint(std::make_shared<CollisionConstraintLvs>(ev, "collision_" + std::to_string(i)));
+            }
+            break;
+          }
+          if (tm.kind == TMX_TERM_COLLISION_CNT)
+          {
+            for (int i = tm.first_step; i <= tm.last_step; ++i)
+              if (std::find(tm.fixed_steps, tm.fixed_steps + tm.n_fixed_steps, i) == tm.fixed_steps + tm.n_fixed_steps)  // :1767, :1827
+                P.prob->addConstraint(std::make_shared<CollisionConstraintSingle>(P.chain, P.scene, P.traj_vars.row(i), tm.margin, tm.coeff,
+                                                                                  tm.buffer, "collision_" + std::to_string(i)));
+            break;
+          }
           for (int i = tm.first_step; i <= tm.last_step; ++i)
             if (std::find(tm.fixed_steps, tm.fixed_steps + tm.n_fixed_steps, i) == tm.fixed_steps + tm.n_fixed_steps)  // :1767, :1827
               P.prob->addCost(std::make_shared<CollisionCostSingle>(P.chain, P.scene, P.traj_vars.row(i), tm.margin,
                                                                     tm.coeff, tm.buffer, "collision_" + std::to_string(i)));
-          break;
-        case TMX_TERM_COLLISION_CNT:
-          for (int i = tm.first_step; i <= tm.last_step; ++i)
-            if (std::find(tm.fixed_steps, tm.fixed_steps + tm.n_fixed_steps, i) == tm.fixed_steps + tm.n_fixed_steps)  // :1767, :1827
-              P.prob->addConstraint(std::make_shared<CollisionConstraintSingle>(P.chain, P.scene, P.traj_vars.row(i), tm.margin, tm.coeff,
-                                                                                tm.buffer, "collision_" + std::to_string(i)));
           break;
         default:
           throw std::runtime_error("unknown term kind");

@@ -740,8 +740,11 @@ static void caseJson(const Input& in)
                      "illegal field \"bogus\"");
     EXPECT_THROW_MSG(ConstructProblem(head + "\"costs\": [{\"type\": \"joint_pos\", \"params\": {\"targets\": [0,0,0]}}], " + init, env),
                      "wrong number of values in \"targets\": expected 7 got 3");
-    EXPECT_THROW_MSG(ConstructProblem(head + "\"costs\": [{\"type\": \"collision\", \"params\": {\"evaluator_type\": 4, \"coeffs\": 20, \"dist_pen\": 0.02}}], " + init, env),
-                     "only DISCRETE");
+    EXPECT_THROW_MSG(ConstructProblem(head + "\"costs\": [{\"type\": \"collision\", \"params\": {\"evaluator_type\": 5, \"coeffs\": 20, \"dist_pen\": 0.02}}], " + init, env),
+                     "must be 1 .. 4");
+    // quirk Q3 (problem_description.cpp:1630 vs :1701-1711): "safety_margin_buffer" is read but not an allowed field
+    EXPECT_THROW_MSG(ConstructProblem(head + "\"costs\": [{\"type\": \"collision\", \"params\": {\"coeffs\": 20, \"dist_pen\": 0.02, \"safety_margin_buffer\": 0.1}}], " + init, env),
+                     "illegal field \"safety_margin_buffer\"");
     EXPECT_THROW_MSG(ConstructProblem(head + "\"costs\": [], \"init_info\": {\"type\": \"spline\"}}", env), "init_info did not have a valid type from Json");
     EXPECT_THROW_MSG(ConstructProblem(head + "\"costs\": [, " + init, env), "JSON parse error");
   }
@@ -807,9 +810,9 @@ static void caseErrors(const Input& in, bool have_device)
     auto col = std::make_shared<CollisionTermInfo>();
     col->first_step = 0;
     col->last_step = 4;
-    col->config.type = TrajOptCollisionConfig::CollisionEvaluatorType::LVS_CONTINUOUS;
+    col->config.type = TrajOptCollisionConfig::CollisionEvaluatorType::NONE;
     pci.cost_infos.push_back(col);
-    EXPECT_THROW_MSG(ConstructProblem(pci), "only the DISCRETE evaluator");  // unsupported is explicit, never a CPU detour
+    EXPECT_THROW_MSG(ConstructProblem(pci), "evaluator type NONE");
   }
   {
     auto pci = base();

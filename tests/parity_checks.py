@@ -33,11 +33,22 @@ def cfg(cid, T=None):
         pci = ProblemConstructionInfo(rob, BasicInfo(n_steps=6 if T is None else T))
         pci.cost_infos.append(JointVelTermInfo(coeffs=[1.0, 2.0, 0.5, 1.5], targets=[0.0] * 4, first_step=0, last_step=pci.basic_info.n_steps - 1))
         return pci, configs.MINI_START, configs.MINI_GOAL
+    if cid in (16, 17, 18, 19):
+        # segment collision evaluators (pair rows, dense coupling blocks): 16 LVS_DISCRETE cost, 17 LVS_CONTINUOUS (cast) cost,
+        # 18 LVS_CONTINUOUS constraint, 19 CONTINUOUS cost whose segments are never split (lvs larger than any step)
+        from trajopt_amd.problem import CollisionTermInfo
+        pci, s, g = configs.config_mini(collision_cnt=(cid == 18)) if T is None else configs.config_mini(T, collision_cnt=(cid == 18))
+        for ti in pci.cost_infos + pci.cnt_infos:
+            if isinstance(ti, CollisionTermInfo):
+                ti.evaluator_type = {16: 2, 17: 4, 18: 4, 19: 3}[cid]
+                ti.longest_valid_segment_length = 10.0 if cid == 19 else 0.12
+                ti.max_substates = 2 if cid == 19 else 4
+        return pci, s, g
     if cid == 12:  # BasicInfo::fixed_dofs: the wrist joint keeps its seed value at every step
         return configs.config_mini(with_joint_band=False, fixed_dofs=[3])
     if cid == 2:   # puzzle_piece: 300 waypoints, the QP workspace lives in HBM on the device (generic block-chain path)
         return configs.config2() if T is None else configs.config2(T)
-    if cid == 3:   # car_seat shape: 10-DOF, 50 waypoints, 20 obstacles (DISCRETE collision variant; workspace in HBM)
+    if cid == 3:   # car_seat: 10-DOF, 50 waypoints, 20 obstacles, LVS_CONTINUOUS collision (pair rows; workspace in HBM)
         return configs.config3() if T is None else configs.config3(T)
     if cid == 0:
         pci, s, g = configs.config0() if T is None else configs.config0(T)
@@ -176,7 +187,11 @@ def sqp_history_classes(ctx, orc, desc, x0, max_qp=128, detail=None):
                    amplifies the 1e-16 differences between QDLDL's and the device's linear solves into 1e-9 ... 1e-2
                    relative differences of rho (visible in tmx_qp_record.rho_final from the first QPs on, with identical
                    iteration counts), and eventually a "5x" update decision or a termination check falls on the other side;
-      "other":     anything else (a structural difference: sizes, CSC index hashes, warm-start decision).
+      "csc-noise": the FIRST difference is nnz(A) / the index hash of A (sizes, P and everything before identical): the
+                   reference keeps every coefficient that is not EXACTLY 0.0 (solver_utils.cpp:111-144), and a gradient
+                   entry that is mathematically zero (a contact point exactly on a roll-joint axis) comes out as 0.0 or
+                   1e-17 depending on the last bits of x - which differ between the two runs from the second QP on;
+      "other":     anything else (sizes, P structure, warm-start decision with identical structure).
     Returns (classes, dx, results)."""
     B = x0.shape[0]
     dev = [[] for _ in range(B)]   # per problem: list of (record key without hash_active, flags, y)
@@ -205,9 +220,15 @@ def sqp_history_classes(ctx, orc, desc, x0, max_qp=128, detail=None):
                 break
             r, f, y = dev[b][k]
             o = ob["records"][k]
-            struct = lambda t: (t.n, t.m, t.nnzP, t.nnzA, t.hashP, t.hashA, t.warm_started)
+            struct = lambda t: (t.n, t.m, t.nnzP, t.hashP)
             admm = lambda t: (t.osqp_status, t.osqp_iter, t.rho_updates, t.polish_status)
             if struct(r) != struct(o):
+                cls = "other"
+                break
+            if (r.nnzA, r.hashA) != (o.nnzA, o.hashA):
+                cls = "csc-noise" if k > 0 and abs(r.nnzA - o.nnzA) <= 16 else "other"
+                break
+            if r.warm_started != o.warm_started:
                 cls = "other"
                 break
             if admm(r) != admm(o):

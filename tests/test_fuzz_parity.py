@@ -31,6 +31,16 @@ def test_random_wide_problems_on_host_build(hostemu_lib, orc):
     _sweep(40, 21, hostemu_lib, "wide")
 
 
+def test_random_problems_with_segment_collision_on_host_build(hostemu_lib, orc):
+    """LVS_DISCRETE / CONTINUOUS / LVS_CONTINUOUS collision terms (pair rows with dense coupling blocks)"""
+    _sweep(30, 41, hostemu_lib, "lvs")
+
+
+@pytest.mark.gpu
+def test_random_problems_with_pair_rows_on_device(orc):
+    _sweep(12, 43, "gpu", "lvs", "links")
+
+
 @pytest.mark.gpu
 def test_random_problems_on_device(orc):
     _sweep(20, 5, "gpu")     # D <= 8 and n_steps * D <= 256: the dense fast path of the QP solver

@@ -65,12 +65,16 @@ def test_unsupported_and_malformed_inputs_are_explicit_errors():
     env, pci, start, goal = _env(1)
     base = json.load(open(os.path.join(HERE, "golden", "json", "glass_upright_cfg1.json")))
     bad = copy.deepcopy(base)
-    bad["costs"][1]["params"]["evaluator_type"] = 4        # LVS_CONTINUOUS (arm_around_table.json uses it)
-    with pytest.raises(json_io.UnsupportedTerm):
+    bad["costs"][1]["params"]["evaluator_type"] = 5        # FAIL_IF_FALSE(collision_evaluator_type <= 4), :1637
+    with pytest.raises(ValueError):
         json_io.construct_problem(bad, env)
     bad = copy.deepcopy(base)
     bad["costs"][0]["params"]["bogus"] = 1                  # ensure_only_members
     with pytest.raises(ValueError):
+        json_io.construct_problem(bad, env)
+    bad = copy.deepcopy(base)
+    bad["costs"][1]["params"]["safety_margin_buffer"] = 0.1   # quirk Q3: read (:1630) but not an allowed field (:1701-1711)
+    with pytest.raises(ValueError, match="safety_margin_buffer"):
         json_io.construct_problem(bad, env)
     bad = copy.deepcopy(base)
     bad["basic_info"]["manip"] = "left_arm"
@@ -202,3 +206,47 @@ def test_joint_vel_constraint_and_hinge_forms_from_json(hostemu_lib, orc):
     if r["status"][0] == abi.OPT_CONVERGED:
         v_ = np.diff(r["x"][0], axis=0)
         assert np.abs(v_).max() < 0.6 + 1e-3 and np.abs(v_[0]).max() < 1e-3
+
+
+def _table_env():
+    """PR2 right arm + a 'table' edge made of spheres in the sweep of the given trajectory (the reference's scene is the
+    arm_around_table URDF with a box table; tesseract / Bullet are absent, so the obstacle is a synthetic stand-in)"""
+    pci, start, goal = configs.config0()
+    rob = pci.robot
+    init = np.array(json.load(open(os.path.join(HERE, "golden", "json", "arm_around_table.json")))["init_info"]["data"])
+    tool = rob.fk_tool(init[2])[:3, 3]
+    obstacles = [((float(tool[0]) + 0.03, float(tool[1]) + 0.10 * k, float(tool[2]) - 0.16), 0.10) for k in (-1, 0, 1)]
+    env = json_io.Environment(manipulators={"right_arm": rob}, tip_links={"right_arm": "r_gripper_tool_frame"},
+                              link_frames={"base_footprint": np.hstack([np.eye(3), np.zeros((3, 1))])},
+                              joint_state={"right_arm": list(init[0])}, obstacles=obstacles)
+    return env, init
+
+
+def test_reference_fixture_arm_around_table_runs_unchanged(hostemu_lib, orc):
+    """trajopt_common/data/config/arm_around_table.json - the reference's only 7-DOF planning fixture (evaluator_type 4 =
+    LVS_CONTINUOUS, longest_valid_segment_length 0.02, fixed_steps [0, 5]) - lowers unchanged and runs on the kernel
+    sources exactly as on the oracle; planning_unit.cpp:101-147 asserts: the initial trajectory is in collision, the
+    result is not, status converged."""
+    import parity_checks as pc
+    from trajopt_amd import runtime
+    env, init = _table_env()
+    pp = json_io.construct_problem(open(os.path.join(HERE, "golden", "json", "arm_around_table.json")).read(), env)
+    coll = pp.pci.cost_infos[1]
+    assert coll.evaluator_type == 4 and coll.longest_valid_segment_length == 0.02 and list(coll.fixed_steps) == [0, 5]
+    assert 2 < coll.max_substates <= 64 and np.array_equal(pp.init_traj, init)
+    desc = pp.pci.to_desc()
+    cv0, _ = orc.evaluate(desc, init, init)
+    assert cv0[1:].sum() > 0.0, "the given trajectory must start in collision"
+    ctx = runtime.Context(0, hostemu_lib)
+    x0 = init[None]
+    pc.make_ctx_inputs(ctx, pp.pci, x0, sqp=pp.sqp_params)
+    pc.check_evaluate(ctx, orc, desc, x0, tol=1e-12)
+    pc.check_first_qp_structure(ctx, orc, desc, x0, 0, val_tol=1e-12)
+    ctx.run(0)
+    r = ctx.results()
+    o = orc.sqp_batch(desc, x0, sqp=pp.sqp_params)
+    assert r["status"][0] == o["status"][0] == abi.OPT_CONVERGED
+    assert np.abs(r["x"] - o["x"]).max() < 1e-5
+    cv, vv = ctx.evaluate()
+    assert cv[0, 1:].sum() == 0.0 and vv.max() < 1e-4, "collision-free and at the goal"
+    ctx.close()

@@ -1,5 +1,5 @@
 """Randomised stage-by-stage parity sweep: random serial chains, term sets and seeds -> device path (or the kernel sources
-built for the host) vs the oracle.   python tests/tools/fuzz_parity.py [n_cases] [seed] [lib.so|gpu] [wide] [links]
+built for the host) vs the oracle.   python tests/tools/fuzz_parity.py [n_cases] [seed] [lib.so|gpu] [wide] [links] [lvs]
 Checks per case: exact term values (1e-12), first-QP CSC (integer arrays bit-exact), first Model::optimize (same OSQP
 status / iteration count / rho updates / polish status / active set row by row, |dx| <= 1e-5, numpy KKT certificate), whole
 SQP QP by QP (parity_checks.sqp_history_classes: identical integer history -> |dx| <= 1e-5; runs that part at a degenerate
@@ -16,7 +16,7 @@ from oracle import pyorc as orc
 import parity_checks as pc
 
 
-def random_problem(rng, wide=False, links=False):
+def random_problem(rng, wide=False, links=False, lvs=False):
     """wide=False: D <= 8 and T * D <= 256 (the dense fast path on the device); wide=True also draws 9-11 DOF chains,
     longer horizons (T * D up to ~400) and single-waypoint problems: the generic block-chain path"""
     if wide:
@@ -55,6 +55,13 @@ def random_problem(rng, wide=False, links=False):
         ci = CollisionTermInfo(first_step=0, last_step=T - 1, dist_pen=float(rng.uniform(0.02, 0.06)), coeff=float(rng.uniform(2, 20)),
                                safety_margin_buffer=float(rng.uniform(0.02, 0.3)), is_constraint=cnt,
                                fixed_steps=list(fixed_t) if rng.random() < 0.7 else [])
+        if lvs and T > 1:
+            # segment evaluators: LVS_DISCRETE / CONTINUOUS / LVS_CONTINUOUS (pair rows; generic block-chain path)
+            ci.evaluator_type = int(rng.integers(2, 5))
+            ci.longest_valid_segment_length = float(rng.uniform(0.05, 0.4))
+            ci.max_substates = int(rng.integers(2, 6))
+            if rng.random() < 0.3:
+                ci.fixed_steps = sorted(set(list(ci.fixed_steps) + [T - 1]))
         (pci.cnt_infos if cnt else pci.cost_infos).append(ci)
     if rng.random() < 0.5 and T > 2:
         a, b = sorted(int(v) for v in rng.integers(1, T, 2))
@@ -106,19 +113,22 @@ def main():
     wide = "wide" in sys.argv
     if wide:
         sys.argv.remove("wide")
-    links = "links" in sys.argv      # two-waypoint rows: kernel sources built with -DTMX_LINK_ROWS=1 (the host build) only
+    links = "links" in sys.argv      # JointVel constraint / hinge forms (pair rows)
     if links:
         sys.argv.remove("links")
+    lvs = "lvs" in sys.argv          # segment collision evaluators (pair rows with gradients on both waypoints)
+    if lvs:
+        sys.argv.remove("lvs")
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 50
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     lib = sys.argv[3] if len(sys.argv) > 3 else os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests", "hostemu", "_build", "libtmx_hostemu.so")
     on_gpu = lib == "gpu"
     fails, soft = 0, 0
-    counts = dict(identical=0, tie=0, admm=0, other=0)
-    worst = dict(identical=0.0, tie=0.0, admm=0.0, other=0.0)
+    counts = {"identical": 0, "tie": 0, "admm": 0, "csc-noise": 0, "other": 0}
+    worst = {k: 0.0 for k in counts}
     for k in range(n):
         rng = np.random.default_rng([seed, k])
-        pci, x0 = random_problem(rng, wide, links)
+        pci, x0 = random_problem(rng, wide, links, lvs)
         tag = f"case {seed}/{k}: D={pci.robot.n_dof} T={pci.basic_info.n_steps} costs={len(pci.cost_infos)} cnts={len(pci.cnt_infos)}"
         ctx = runtime.Context(0, None if on_gpu else lib)
         try:
@@ -151,7 +161,8 @@ def main():
             ctx.close()
     print(f"{n} cases, {fails} failures, {soft} first QPs with differing history; SQP runs: {counts['identical']} identical integer history "
           f"(max |dx| {worst['identical']:.1e}), {counts['tie']} parted at a degenerate polish tie (max |dx| {worst['tie']:.1e}), "
-          f"{counts['admm']} at an ADMM-level integer after rho drift (max |dx| {worst['admm']:.1e}), {counts['other']} other")
+          f"{counts['admm']} at an ADMM-level integer after rho drift (max |dx| {worst['admm']:.1e}), {counts['csc-noise']} at a round-off entry of A "
+          f"(max |dx| {worst['csc-noise']:.1e}), {counts['other']} other")
     sys.exit(1 if fails else 0)
 
 

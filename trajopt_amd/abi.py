@@ -55,8 +55,11 @@ class Term(C.Structure):
         ("upper_tols", C.c_double * TMX_MAX_DOF),
         ("lower_tols", C.c_double * TMX_MAX_DOF),
         ("n_fixed_steps", C.c_int32),
-        ("pad_", C.c_int32),
+        ("evaluator_type", C.c_int32),
         ("fixed_steps", C.POINTER(C.c_int32)),
+        ("longest_valid_segment_length", C.c_double),
+        ("max_substates", C.c_int32),
+        ("pad2_", C.c_int32),
     ]
 
 

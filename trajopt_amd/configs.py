@@ -212,12 +212,11 @@ def seeds_config2(pci, curve, batch: int, sigma: float = 0.02, first: int = 0) -
     return out
 
 
-# ---- config 3: car_seat (discrete-collision variant) ------------------------------------------------------------
+# ---- config 3: car_seat ------------------------------------------------------------------------------------------
 # 10-DOF = three prismatic positioner axes carrying the 7-DOF arm, 50 waypoints, JointVel cost, start and goal JointPos
-# constraints, a dense collision scene of 20 sphere obstacles.  SURVEY.md §8d cfg 3 asks for the LVS_CONTINUOUS
-# evaluator; the device path lowers the DISCRETE (single time step) evaluator only, so this is the same problem shape
-# (10-DOF blocks, 50 waypoints, ~8000 collision row slots) with single-time-step collision costs — stated wherever it is
-# reported.
+# constraints, a dense collision scene of 20 sphere obstacles checked with the LVS_CONTINUOUS evaluator (SURVEY.md §8d cfg 3:
+# evaluator_type 4): one CastCollisionEvaluator term per segment, longest valid segment 0.15 rad, up to 2 sub-segments
+# per (segment, link sphere, obstacle) => 49 x 8 x 20 x 2 = 15 680 pair-row slots with gradients on both waypoints.
 CFG3_START = np.array([0.0, 0.0, 0.0, -1.4, 0.3, -1.0, -1.2, 0.5, -1.0, 0.3])
 CFG3_GOAL = np.array([0.25, -0.2, 0.15, -0.2, 0.25, -0.9, -1.3, 0.4, -1.1, 0.2])
 
@@ -234,13 +233,14 @@ def car_seat_robot() -> Robot:
     return rob
 
 
-def config3(n_steps: int = 50, n_obstacles: int = 20):
+def config3(n_steps: int = 50, n_obstacles: int = 20, evaluator_type: int = 4):
     rob = car_seat_robot()
     D = rob.n_dof
     pci = ProblemConstructionInfo(rob, BasicInfo(n_steps=n_steps))
     pci.cost_infos.append(JointVelTermInfo(coeffs=[1.0] * D, targets=[0.0] * D, first_step=0, last_step=n_steps - 1))
     pci.cost_infos.append(CollisionTermInfo(first_step=0, last_step=n_steps - 1, dist_pen=0.025, coeff=20.0,
-                                            safety_margin_buffer=0.05))
+                                            safety_margin_buffer=0.05, evaluator_type=evaluator_type,
+                                            longest_valid_segment_length=0.15, max_substates=3))
     # obstacles scattered (deterministically) around the swept tool path; candidates closer than 0.15 m to the arm in
     # the start or the goal state are rejected (with a contact at a constrained end point the reference's penalty loop
     # gives up: the trust region has collapsed by the time the merit coefficient is large enough)

@@ -240,8 +240,9 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
   // ---- slot template in reference row order ----
   std::vector<int> kind, st, sub, sub2, owner, naux, iscnt, iseq;
   std::vector<double> objc, scale, aux1, aux2;
-  std::vector<int> lkj;
-  std::vector<double> lkc;
+  std::vector<int> c2, sub3;   // pair rows: index of the second coefficient block; LVS flags
+  std::vector<double> aux3;
+  int R2 = 0, lvs_kmax = 2;
   auto add_slot = [&](int k, int t, int s1, int s2, int own, int na, int isc, int eq, double oc, double sc, double a1, double a2) {
     kind.push_back(k);
     st.push_back(t);
@@ -255,8 +256,9 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
     scale.push_back(sc);
     aux1.push_back(a1);
     aux2.push_back(a2);
-    lkj.push_back(-1);
-    lkc.push_back(0.0);
+    c2.push_back(-1);
+    sub3.push_back(0);
+    aux3.push_back(0.0);
   };
   std::vector<int> fixed(d->fixed_steps, d->fixed_steps + d->n_fixed_steps);
   for (int t : fixed)
@@ -369,7 +371,7 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
         case TMX_TERM_JOINT_VEL_INEQ_CNT:
         {
 #if !TMX_LINK_ROWS
-          ctx->err = "JointVel constraint / hinge forms (rows on two consecutive waypoints) are not enabled in this build";
+          ctx->err = "rows on two consecutive waypoints (JointVel constraint / hinge forms) are not enabled in this build";
           return TMX_ERR_UNSUPPORTED;
 #else
           if (tm.last_step - 1 - tm.first_step < 0)
@@ -388,17 +390,14 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
               if (tm.kind == TMX_TERM_JOINT_VEL_EQ_CNT)
               {
                 add_slot(SLOT_JOINTVEL, i, j, 0, own, 2, 1, 1, 0.0, c, tm.targets[j], 0.0);
-                lkj.back() = j;
-                lkc.back() = (0.0 + (1.0 * 1)) * c;  // exprMult(vel, coeff): coefficient of x[i+1][j]
+                c2.back() = R2++;
               }
               else
               {
                 add_slot(SLOT_JOINTVEL_INEQ, i, j, 0, own, 1, is_cnt ? 1 : 0, 0, is_cnt ? 0.0 : 1.0, c, tm.targets[j], tm.upper_tols[j]);
-                lkj.back() = j;
-                lkc.back() = (0.0 - (1.0 * 1)) * -c;  // -(upper_tol - vel) * coeff: +coeff on x[i+1][j]
+                c2.back() = R2++;
                 add_slot(SLOT_JOINTVEL_INEQ, i, j, 1, own, 1, is_cnt ? 1 : 0, 0, is_cnt ? 0.0 : 1.0, c, tm.targets[j], tm.lower_tols[j]);
-                lkj.back() = j;
-                lkc.back() = (0.0 - (1.0 * 1)) * c;  // (lower_tol - vel) * coeff: -coeff on x[i+1][j]
+                c2.back() = R2++;
               }
             }
           break;
@@ -490,6 +489,53 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
         }
         case TMX_TERM_COLLISION_COST:
         {
+          if (tm.evaluator_type < 0 || tm.evaluator_type > 4)
+          {
+            ctx->err = "collision evaluator_type must be <= 4";  // FAIL_IF_FALSE, problem_description.cpp:1637
+            return TMX_ERR_INVALID;
+          }
+          if (tm.evaluator_type >= 2)
+          {
+#if !TMX_LINK_ROWS
+            ctx->err = "rows on two consecutive waypoints (LVS / continuous collision) are not enabled in this build";
+            return TMX_ERR_UNSUPPORTED;
+#else
+            // DiscreteCollisionEvaluator (2) / CastCollisionEvaluator (3, 4): one term per SEGMENT (i, i+1)
+            // (problem_description.cpp:1720-1761, :1779-1819); per (link sphere, obstacle) max_substates row slots in the order
+            // of the flattened contact map (pair-major, sub-state ascending)
+            if (!(tm.longest_valid_segment_length >= 0))
+            {
+              ctx->err = "collision: longest_valid_segment_length must be >= 0";  // :1634
+              return TMX_ERR_INVALID;
+            }
+            const int kmax = tm.max_substates < 2 ? 2 : tm.max_substates;
+            if (lvs_kmax != 2 && lvs_kmax != kmax && kmax != 2)
+            {
+              ctx->err = "collision terms of one problem must share max_substates";
+              return TMX_ERR_UNSUPPORTED;
+            }
+            lvs_kmax = std::max(lvs_kmax, kmax);
+            const bool cast = tm.evaluator_type != 2, is_cnt_c = tm.kind == TMX_TERM_COLLISION_CNT;
+            for (int i = tm.first_step; i < tm.last_step; ++i)
+            {
+              const bool cur = std::find(tm.fixed_steps, tm.fixed_steps + tm.n_fixed_steps, i) != tm.fixed_steps + tm.n_fixed_steps;
+              const bool nxt = std::find(tm.fixed_steps, tm.fixed_steps + tm.n_fixed_steps, i + 1) != tm.fixed_steps + tm.n_fixed_steps;
+              const int fl = (cur ? 1 : 0) | ((!cur && nxt) ? 2 : 0) | (cast ? 4 : 0);
+              const int own = is_cnt_c ? n_cnts++ : n_costs++;
+              const int nsub = cast ? kmax - 1 : kmax;
+              for (int sp = 0; sp < d->n_link_spheres; ++sp)
+                for (int o = 0; o < d->n_obstacles; ++o)
+                  for (int q = 0; q < nsub; ++q)
+                  {
+                    add_slot(SLOT_COLLISION_LVS, i, sp, o, own, 1, is_cnt_c ? 1 : 0, 0, tm.coeff, is_cnt_c ? tm.coeff : 1.0, tm.margin, tm.buffer);
+                    c2.back() = R2++;
+                    sub3.back() = fl | (q << 3);
+                    aux3.back() = tm.longest_valid_segment_length;
+                  }
+            }
+            break;
+#endif
+          }
           for (int i = tm.first_step; i <= tm.last_step; ++i)
           {
             if (std::find(tm.fixed_steps, tm.fixed_steps + tm.n_fixed_steps, i) != tm.fixed_steps + tm.n_fixed_steps)
@@ -503,6 +549,53 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
         }
         case TMX_TERM_COLLISION_CNT:
         {
+          if (tm.evaluator_type < 0 || tm.evaluator_type > 4)
+          {
+            ctx->err = "collision evaluator_type must be <= 4";  // FAIL_IF_FALSE, problem_description.cpp:1637
+            return TMX_ERR_INVALID;
+          }
+          if (tm.evaluator_type >= 2)
+          {
+#if !TMX_LINK_ROWS
+            ctx->err = "rows on two consecutive waypoints (LVS / continuous collision) are not enabled in this build";
+            return TMX_ERR_UNSUPPORTED;
+#else
+            // DiscreteCollisionEvaluator (2) / CastCollisionEvaluator (3, 4): one term per SEGMENT (i, i+1)
+            // (problem_description.cpp:1720-1761, :1779-1819); per (link sphere, obstacle) max_substates row slots in the order
+            // of the flattened contact map (pair-major, sub-state ascending)
+            if (!(tm.longest_valid_segment_length >= 0))
+            {
+              ctx->err = "collision: longest_valid_segment_length must be >= 0";  // :1634
+              return TMX_ERR_INVALID;
+            }
+            const int kmax = tm.max_substates < 2 ? 2 : tm.max_substates;
+            if (lvs_kmax != 2 && lvs_kmax != kmax && kmax != 2)
+            {
+              ctx->err = "collision terms of one problem must share max_substates";
+              return TMX_ERR_UNSUPPORTED;
+            }
+            lvs_kmax = std::max(lvs_kmax, kmax);
+            const bool cast = tm.evaluator_type != 2, is_cnt_c = tm.kind == TMX_TERM_COLLISION_CNT;
+            for (int i = tm.first_step; i < tm.last_step; ++i)
+            {
+              const bool cur = std::find(tm.fixed_steps, tm.fixed_steps + tm.n_fixed_steps, i) != tm.fixed_steps + tm.n_fixed_steps;
+              const bool nxt = std::find(tm.fixed_steps, tm.fixed_steps + tm.n_fixed_steps, i + 1) != tm.fixed_steps + tm.n_fixed_steps;
+              const int fl = (cur ? 1 : 0) | ((!cur && nxt) ? 2 : 0) | (cast ? 4 : 0);
+              const int own = is_cnt_c ? n_cnts++ : n_costs++;
+              const int nsub = cast ? kmax - 1 : kmax;
+              for (int sp = 0; sp < d->n_link_spheres; ++sp)
+                for (int o = 0; o < d->n_obstacles; ++o)
+                  for (int q = 0; q < nsub; ++q)
+                  {
+                    add_slot(SLOT_COLLISION_LVS, i, sp, o, own, 1, is_cnt_c ? 1 : 0, 0, tm.coeff, is_cnt_c ? tm.coeff : 1.0, tm.margin, tm.buffer);
+                    c2.back() = R2++;
+                    sub3.back() = fl | (q << 3);
+                    aux3.back() = tm.longest_valid_segment_length;
+                  }
+            }
+            break;
+#endif
+          }
           // CollisionConstraint per non-fixed step (problem_description.cpp:1821-1835): inequality rows, hinge penalty with
           // the merit coefficient; the collision coefficient scales the row itself (slot_scale)
           for (int i = tm.first_step; i <= tm.last_step; ++i)
@@ -594,9 +687,11 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
   UP(slot_scale, scale);
   UP(slot_aux1, aux1);
   UP(slot_aux2, aux2);
-  UP(slot_lkj, lkj);
-  UP(slot_lkc, lkc);
-  P.n_link = static_cast<int>(std::count_if(lkj.begin(), lkj.end(), [](int j) { return j >= 0; }));
+  UP(slot_c2, c2);
+  UP(slot_sub3, sub3);
+  UP(slot_aux3, aux3);
+  P.n_link = R2;
+  P.lvs_kmax = lvs_kmax;
   UP(wp_start, wp_start);
   UP(wp_list, wp_list);
   UP(pd, pd);
@@ -631,7 +726,7 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
   }
   HIPCHK(hipMemcpy(ctx->dp, &P, sizeof(DevProblem), hipMemcpyHostToDevice));
   // LDS budgets
-  ctx->smem_qp = qp_smem_bytes(D, T, R, NA);
+  ctx->smem_qp = qp_smem_bytes(D, T, R, NA, R2);
   const size_t small_ints = 2 * (size_t)(P.n_max + 1) + 4 * (size_t)R + 2 + 16;
   ctx->smem_small = std::max<size_t>((tmx_eval_scratch_doubles(R, D * T, (int)vel_first.size(), n_costs, n_cnts) + n_costs + n_cnts + 8) * sizeof(double),
                                      small_ints * sizeof(int) + 64);
@@ -745,6 +840,7 @@ static tmx_status ensure_batch(tmx_ctx* ctx, int B)
   AL(prev_ok, b);
   AL(active, b * P.R);
   AL(coef, b * P.R * P.D);
+  AL(coef2, b * P.n_link * P.D);
   AL(rhs, b * P.R);
   AL(dims, b * 4);
   AL(hashes, b * 4);
@@ -760,7 +856,7 @@ static tmx_status ensure_batch(tmx_ctx* ctx, int B)
   AL(prof, b * 16);
   AL(sched_state, b);
   AL(sched_done, 1);
-  H.qp_scratch_stride = (long long)qp_scratch_doubles(P.D, P.T, P.R, P.NA);
+  H.qp_scratch_stride = (long long)qp_scratch_doubles(P.D, P.T, P.R, P.NA, P.n_link);
   AL(qp_scratch, b * (size_t)H.qp_scratch_stride);
   H.ws_hbm_stride = ctx->ws_in_hbm ? (long long)((ctx->ws_bytes + 15) / 16 * 2) : 0;  // doubles, 16-byte aligned slices
   if (ctx->ws_in_hbm)  // stays nullptr otherwise: the kernels test the pointer
@@ -1064,7 +1160,7 @@ tmx_status tmx_export_csc(tmx_ctx* ctx, int32_t problem, int32_t* n, int32_t* m,
   HIPCHK(hipSetDevice(ctx->device));
   const DevProblem& P = ctx->hp;
   // device scratch sized for the worst case
-  const size_t nmax = P.n_max, mmax = P.m_max, nzA = (size_t)P.R * (P.D + 2) + 2 * nmax, nzP = (size_t)P.nnzP + 1;
+  const size_t nmax = P.n_max, mmax = P.m_max, nzA = (size_t)P.R * (2 * P.D + 2) + 2 * nmax, nzP = (size_t)P.nnzP + 1;
   std::vector<void*> pool;
   CscOut o{};
   int* d_dims = nullptr;

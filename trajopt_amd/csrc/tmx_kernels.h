@@ -55,7 +55,7 @@ TMX_KERNEL_LB(256) k_prepare(const DevProblem* P, const DevBatch* Bt)
       Bt->prev_dims[4 * b + q] = -1;
   }
   TMX_SYNC();
-  init_static_rows(P, x0, act, Bt->coef + (size_t)b * R * D, Bt->rhs + (size_t)b * R, tid, NT);
+  init_static_rows(P, x0, act, Bt->coef + (size_t)b * R * D, Bt->coef2 + (size_t)b * P->n_link * D, Bt->rhs + (size_t)b * R, tid, NT);
   // (two call sites instead of a pointer select: the select crashes the register allocator of this ROCm 7.2 clang)
   if (Bt->ws_hbm)
     evaluate_terms(P, x, Bt->cost_vals + (size_t)b * P->n_costs, Bt->cnt_viols + (size_t)b * P->n_cnts,
@@ -91,9 +91,9 @@ TMX_KERNEL_LB(256) k_convexify(const DevProblem* P, const DevBatch* Bt, int forc
   double* coef = Bt->coef + (size_t)b * R * D;
   double* rhs = Bt->rhs + (size_t)b * R;
   const double* x = Bt->x + (size_t)b * P->NX;
-  convexify_terms(P, x, act, coef, rhs, smem, tid, NT);
-  qp_structure(P, act, coef, rhs, x, Bt->trust[b], Bt->merit + (size_t)b * P->n_cnts, Bt->dims + 4 * b, Bt->hashes + 4 * b,
-               nullptr, reinterpret_cast<int*>(smem), tid, NT);
+  convexify_terms(P, x, act, coef, Bt->coef2 + (size_t)b * P->n_link * D, rhs, smem, tid, NT);
+  qp_structure(P, act, coef, Bt->coef2 + (size_t)b * P->n_link * D, rhs, x, Bt->trust[b], Bt->merit + (size_t)b * P->n_cnts, Bt->dims + 4 * b,
+               Bt->hashes + 4 * b, nullptr, reinterpret_cast<int*>(smem), tid, NT);
 }
 
 // export of one problem's QP in reference CSC layout (tests / INTEGRATION: the S1 hand-off format)
@@ -103,7 +103,7 @@ TMX_KERNEL k_export_csc(const DevProblem* P, const DevBatch* Bt, int b, CscOut o
   double* smem = TMX_WORK(smem_lds, Bt);
   const int tid = threadIdx.x, NT = blockDim.x;
   const int R = P->R, D = P->D;
-  qp_structure(P, Bt->active + (size_t)b * R, Bt->coef + (size_t)b * R * D, Bt->rhs + (size_t)b * R,
+  qp_structure(P, Bt->active + (size_t)b * R, Bt->coef + (size_t)b * R * D, Bt->coef2 + (size_t)b * P->n_link * D, Bt->rhs + (size_t)b * R,
                Bt->x + (size_t)b * P->NX, Bt->trust[b], Bt->merit + (size_t)b * P->n_cnts, dims_out, hashes_out, &out,
                reinterpret_cast<int*>(smem), tid, NT);
 }
@@ -150,7 +150,7 @@ TMX_DEVFN void sqp_step_block(const DevProblem* P, const DevBatch* Bt, int b, do
 #endif
   if (Bt->phase[b] == PHASE_CONVEXIFY)
   {
-    convexify_terms(P, x, act, coef, rhs, smem, tid, NT);
+    convexify_terms(P, x, act, coef, Bt->coef2 + (size_t)b * P->n_link * D, rhs, smem, tid, NT);
 #ifdef TMX_PROFILE
     if (tid == 0)
     {
@@ -159,8 +159,8 @@ TMX_DEVFN void sqp_step_block(const DevProblem* P, const DevBatch* Bt, int b, do
       tp0 = tnow;
     }
 #endif
-    qp_structure(P, act, coef, rhs, x, Bt->trust[b], Bt->merit + (size_t)b * P->n_cnts, Bt->dims + 4 * b, Bt->hashes + 4 * b,
-                 nullptr, reinterpret_cast<int*>(smem), tid, NT);
+    qp_structure(P, act, coef, Bt->coef2 + (size_t)b * P->n_link * D, rhs, x, Bt->trust[b], Bt->merit + (size_t)b * P->n_cnts, Bt->dims + 4 * b,
+                 Bt->hashes + 4 * b, nullptr, reinterpret_cast<int*>(smem), tid, NT);
   }
   TMX_SYNC();
 #ifdef TMX_PROFILE
@@ -344,7 +344,7 @@ TMX_KERNEL k_export_active(const DevProblem* P, const DevBatch* Bt, int* out)
   const int R = P->R, NX = P->NX;
   QpWs w;  // only the layout of the far (HBM) part is used
   double* scratch = Bt->qp_scratch + (size_t)b * Bt->qp_scratch_stride;
-  qp_ws_carve(w, scratch, scratch, scratch, P->D, P->T, R, P->NA);
+  qp_ws_carve(w, scratch, scratch, scratch, P->D, P->T, R, P->NA, P->n_link);
   int* o = out + (size_t)b * P->m_max;
   const int* rec = Bt->prev_dims + 4 * b;  // dims of the last solve
   const int n = rec[0], m = rec[1], mg = m - n;

@@ -165,24 +165,33 @@ struct QpWs
   int *wp_pst;               // T+1: even-aligned start of every waypoint's group in the grouped e exchange (fast path)
   int *row_epos;             // R: position of every row in that grouped buffer
 #if TMX_LINK_ROWS
-  // rows with a link to the next waypoint (JointVel constraint / hinge forms): row r of waypoint t carries ONE more
-  // coefficient lkc[r] on variable (t + 1, lkj[r]); the reduced KKT stays block-tridiagonal with diagonal couplings
-  const int *lkj;  // R (DevProblem::slot_lkj): joint of the linked variable, -1 = none
-  double *lkc;     // R: the (scaled) link coefficient
-  double *pc;      // NX: chain coupling = objective coupling po + the rows' contribution (rebuilt by kkt_factor)
-  int n_link;
+  // PAIR ROWS (JointVel constraint / hinge forms, LVS / cast collision): row r of waypoint t carries D more coefficients
+  // c2[c2i[r]][.] on waypoint t + 1.  The reduced KKT stays block tridiagonal, but its coupling blocks become DENSE:
+  // C_t = diag(po_t) + sum_r w_r coef_r c2_r'  (Cd, rebuilt by kkt_factor); problems with pair rows take the generic
+  // block-chain path.
+  const int *c2i;  // R (DevProblem::slot_c2): index of the row's second block, -1 = none
+  double *c2;      // R2 * D: the (scaled) second-block coefficients
+  double *Cd;      // (T-1) * D * D: dense coupling blocks (row = variable of waypoint t, column = variable of t + 1)
+  int n_link;      // R2
 #endif
 };
 
+// the chains of problems WITHOUT pair rows couple consecutive blocks through the diagonal of the objective only
+#define TMX_PC(w) ((w).po)
 #if TMX_LINK_ROWS
-#define TMX_PC(w) ((w).pc)
+#define TMX_HAS_PAIRS(w) ((w).n_link > 0)
 // x-part of row r (home waypoint t) on the next waypoint
 TMX_DEVFN double link_dot(const QpWs& w, int r, int t, const double* x)
 {
-  const int j = w.lkj[r];
-  return (j >= 0) ? w.lkc[r] * x[(t + 1) * w.D + j] : 0.0;
+  const int i = w.c2i[r];
+  if (i < 0)
+    return 0.0;
+  double s = 0.0;
+  for (int j = 0; j < w.D; ++j)
+    s += w.c2[i * w.D + j] * x[(t + 1) * w.D + j];
+  return s;
 }
-// (A'rv) contribution to variable (t, j) of the rows of waypoint t-1 that link to it
+// (A'rv) contribution to variable (t, j) of the pair rows of waypoint t-1
 TMX_DEVFN double link_gather(const QpWs& w, const double* rv, int t, int j)
 {
   double s = 0.0;
@@ -190,13 +199,14 @@ TMX_DEVFN double link_gather(const QpWs& w, const double* rv, int t, int j)
     for (int q = w.wp_start[t - 1]; q < w.wp_start[t]; ++q)
     {
       const int r = w.wp_list[q];
-      if (w.act[r] && w.lkj[r] == j)
-        s += rv[r] * w.lkc[r];
+      const int i = w.c2i[r];
+      if (w.act[r] && i >= 0)
+        s += rv[r] * w.c2[i * w.D + j];
     }
   return s;
 }
 #else
-#define TMX_PC(w) ((w).po)
+#define TMX_HAS_PAIRS(w) false
 #endif
 
 // The workspace is split by access frequency:
@@ -272,20 +282,21 @@ TMX_HOSTDEVFN bool dpart_fits(int D, int T)
   dpart_make(T, p);
   return p.P >= 2 && (p.P - 1) * D <= 64;
 }
-TMX_HOSTDEVFN size_t qp_lds_doubles(int D, int T, int R, int NA)
+TMX_HOSTDEVFN size_t qp_lds_doubles(int D, int T, int R, int NA, int R2 = 0)
 {
   const size_t NX = (size_t)D * T;
   (void)NA;
   DPart p;
   dpart_make(T, p);
   const size_t gn = (size_t)p.Lmax * D, nsep = (size_t)(p.P - 1) * D;
-  const size_t dense = dpart_fits(D, T) ? (size_t)p.P * gn * dpart_gstride((int)gn) + nsep * dpart_mult8((int)nsep) + 6 * 64 + (size_t)p.P * dpart_gstride((int)gn) + 64 : 0;
+  // the dense nested-dissection region is only reserved for problems that can take the fast path (no pair rows)
+  const size_t dense = (dpart_fits(D, T) && R2 == 0) ? (size_t)p.P * gn * dpart_gstride((int)gn) + nsep * dpart_mult8((int)nsep) + 6 * 64 + (size_t)p.P * dpart_gstride((int)gn) + 64 : 0;
   return NX + 2 + (D <= 8 ? 8 * (size_t)T : NX + 2) + (size_t)R + (size_t)T + 20 + (size_t)T * D * (D <= 8 ? 8 : D) + dense + (size_t)D * D + 256 + 4 + (sizeof(QpWs) + 7) / 8;
 }
-TMX_HOSTDEVFN size_t qp_glb_doubles(int D, int T, int R, int NA)
+TMX_HOSTDEVFN size_t qp_glb_doubles(int D, int T, int R, int NA, int R2 = 0)
 {
   const size_t NX = (size_t)D * T;
-  const size_t n = 10 * NX + 6 * (size_t)R + (size_t)R * D + 8 * (size_t)NA + (TMX_LINK_ROWS ? (size_t)R + NX : 0);
+  const size_t n = 10 * NX + 6 * (size_t)R + (size_t)R * D + 8 * (size_t)NA + (R2 > 0 ? (size_t)R2 * D + (size_t)T * D * D : 0);
   const size_t ints = 7 * (size_t)R + (size_t)NX + (size_t)NA + 2 * (size_t)T + 4;
   return n + (ints + 1) / 2 + 8;
 }
@@ -298,13 +309,13 @@ TMX_HOSTDEVFN size_t qp_far_doubles(int D, int T, int R, int NA)
   return n + (ints + 1) / 2 + 8;
 }
 // dynamic LDS bytes of the QP kernels / per-problem HBM scratch doubles for the chosen placement
-TMX_HOSTDEVFN size_t qp_smem_bytes(int D, int T, int R, int NA)
+TMX_HOSTDEVFN size_t qp_smem_bytes(int D, int T, int R, int NA, int R2 = 0)
 {
-  return (qp_lds_doubles(D, T, R, NA) + (TMX_QP_COLD_IN_LDS ? qp_glb_doubles(D, T, R, NA) : 0)) * sizeof(double);
+  return (qp_lds_doubles(D, T, R, NA, R2) + (TMX_QP_COLD_IN_LDS ? qp_glb_doubles(D, T, R, NA, R2) : 0)) * sizeof(double);
 }
-TMX_HOSTDEVFN size_t qp_scratch_doubles(int D, int T, int R, int NA)
+TMX_HOSTDEVFN size_t qp_scratch_doubles(int D, int T, int R, int NA, int R2 = 0)
 {
-  return qp_far_doubles(D, T, R, NA) + (TMX_QP_COLD_IN_LDS ? 0 : qp_glb_doubles(D, T, R, NA));
+  return qp_far_doubles(D, T, R, NA) + (TMX_QP_COLD_IN_LDS ? 0 : qp_glb_doubles(D, T, R, NA, R2));
 }
 
 // long-horizon problems keep their workspace in HBM (k_*_hbm kernels); the arrays the sequential block chain walks -
@@ -332,7 +343,7 @@ TMX_DEVFN void qp_ws_chain_to_lds(QpWs& w, double* lds)
   w.red = p;
 }
 
-TMX_DEVFN void qp_ws_carve(QpWs& w, double* lds, double* glb, double* far, int D, int T, int R, int NA)
+TMX_DEVFN void qp_ws_carve(QpWs& w, double* lds, double* glb, double* far, int D, int T, int R, int NA, int R2 = 0)
 {
   w.D = D;
   w.T = T;
@@ -350,7 +361,7 @@ TMX_DEVFN void qp_ws_carve(QpWs& w, double* lds, double* glb, double* far, int D
   TAKE(Sinv, T * D * w.DS);  // first: 16-byte aligned for the double2 row loads
   w.G = w.Zs = w.sx = w.ty = nullptr;
   w.Gn = w.Gs = w.Zst = 0;
-  if (dpart_fits(D, T))
+  if (dpart_fits(D, T) && R2 == 0)
   {
     DPart dp;
     dpart_make(T, dp);
@@ -396,8 +407,14 @@ TMX_DEVFN void qp_ws_carve(QpWs& w, double* lds, double* glb, double* far, int D
   TAKE(sa, NA);
   TAKE(dinv, NA);
 #if TMX_LINK_ROWS
-  TAKE(lkc, R);
-  TAKE(pc, NX);
+  w.c2 = w.Cd = nullptr;
+  w.c2i = nullptr;
+  w.n_link = R2;
+  if (R2 > 0)
+  {
+    TAKE(c2, R2 * D);
+    TAKE(Cd, T * D * D);
+  }
 #endif
   int* ip = reinterpret_cast<int*>(p);
 #define TAKEI(name, n)                                                                                                \
@@ -503,37 +520,41 @@ TMX_DEVFN void kkt_factor(const QpWs& w, const DevProblem* P, int mode, double s
       if (w.act[r])
         s += w.hr[r] * w.coef[r * D + i] * w.coef[r * D + j];
     }
+#if TMX_LINK_ROWS
+    // pair rows of waypoint t-1: their second block lands on this diagonal block
+    if (w.n_link > 0 && t > 0)
+      for (int q = w.wp_start[t - 1]; q < w.wp_start[t]; ++q)
+      {
+        const int r = w.wp_list[q];
+        const int ci = w.c2i[r];
+        if (w.act[r] && ci >= 0)
+          s += w.hr[r] * w.c2[ci * D + i] * w.c2[ci * D + j];
+      }
+#endif
     if (i == j)
     {
       const int v = t * D + i;
       s += w.pd[v] + sig + w_bp(w, v, mode, delta) * w.bbp[v] * w.bbp[v];
-#if TMX_LINK_ROWS
-      // rows of waypoint t-1 linked to (t, i): we * lkc^2 on the diagonal; rows of waypoint t linked to (t+1, i): their
-      // product with the home coefficient is the coupling of the chain
-      if (w.n_link > 0)
-      {
-        if (t > 0)
-          for (int q = w.wp_start[t - 1]; q < w.wp_start[t]; ++q)
-          {
-            const int r = w.wp_list[q];
-            if (w.act[r] && w.lkj[r] == i)
-              s += w.hr[r] * w.lkc[r] * w.lkc[r];
-          }
-        double c = w.po[v];
-        for (int q = w.wp_start[t]; q < w.wp_start[t + 1]; ++q)
-        {
-          const int r = w.wp_list[q];
-          if (w.act[r] && w.lkj[r] == i)
-            c += w.hr[r] * w.coef[r * D + i] * w.lkc[r];
-        }
-        w.pc[v] = c;
-      }
-      else
-        w.pc[v] = w.po[v];
-#endif
     }
     w.Sinv[t * DDS + i * DS + j] = s;
   }
+#if TMX_LINK_ROWS
+  // dense coupling blocks C_t = diag(po_t) + sum over the pair rows of waypoint t of  w_r coef_r c2_r'
+  if (w.n_link > 0)
+    for (int e = tid; e < (T - 1) * DD; e += NT)
+    {
+      const int t = e / DD, i = (e % DD) / D, j = e % D;
+      double c = (i == j) ? w.po[t * D + i] : 0.0;
+      for (int q = w.wp_start[t]; q < w.wp_start[t + 1]; ++q)
+      {
+        const int r = w.wp_list[q];
+        const int ci = w.c2i[r];
+        if (w.act[r] && ci >= 0)
+          c += w.hr[r] * w.coef[r * D + i] * w.c2[ci * D + j];
+      }
+      w.Cd[e] = c;
+    }
+#endif
   for (int e = tid; e < T * D * (DS - D); e += NT)
   {
     const int t = e / (D * (DS - D)), i = (e / (DS - D)) % D, j = D + e % (DS - D);
@@ -553,13 +574,41 @@ TMX_DEVFN void kkt_invert_chain_generic(const QpWs& w, int t0, int t1, int tid, 
     if (t > t0)
     {
       const double* Sp = w.Sinv + (t - 1) * DDS;
-      const double* c = TMX_PC(w) + (t - 1) * D;
-      for (int e = tid; e < DD; e += NT)
+#if TMX_LINK_ROWS
+      if (TMX_HAS_PAIRS(w))
       {
-        const int i = e / D, j = e % D;
-        S[i * DS + j] -= c[i] * Sp[i * DS + j] * c[j];
+        // S_t -= C' Sinv_{t-1} C  with the dense coupling block C = Cd[t-1]
+        const double* Cm = w.Cd + (size_t)(t - 1) * DD;
+        for (int e = tid; e < DD; e += NT)
+        {
+          const int i = e / D, j = e % D;
+          double m = 0.0;
+          for (int k = 0; k < D; ++k)
+            m += Sp[i * DS + k] * Cm[k * D + j];
+          w.gj[e] = m;
+        }
+        TMX_SYNC();
+        for (int e = tid; e < DD; e += NT)
+        {
+          const int i = e / D, j = e % D;
+          double m = 0.0;
+          for (int k = 0; k < D; ++k)
+            m += Cm[k * D + i] * w.gj[k * D + j];
+          S[i * DS + j] -= m;
+        }
+        TMX_SYNC();
       }
-      TMX_SYNC();
+      else
+#endif
+      {
+        const double* c = TMX_PC(w) + (t - 1) * D;
+        for (int e = tid; e < DD; e += NT)
+        {
+          const int i = e / D, j = e % D;
+          S[i * DS + j] -= c[i] * Sp[i * DS + j] * c[j];
+        }
+        TMX_SYNC();
+      }
     }
     for (int k = 0; k < D; ++k)
     {
@@ -589,6 +638,8 @@ TMX_DEVFN void kkt_invert_chain_generic(const QpWs& w, int t0, int t1, int tid, 
     }
   }
 }
+
+TMX_DEVFN void chain_solve_range(const QpWs& w, int t0, int t1, int tid, int NT);
 
 // ---- KKT solve: in: tp (primary rhs r1 + A'W r2 part), ta (aux rhs); out: tp = x_p, ta = x_a, hr = (A x)_r --------
 // (mode 1, polish: other conventions for the row terms, see the first branch)
@@ -687,6 +738,9 @@ TMX_DEVFN void kkt_solve(const QpWs& w, const DevProblem* P, int mode, double si
     TMX_SYNC();
   }
   // 2. block forward / backward substitution (sequential over waypoints); row i of the block handled by thread i
+  if (TMX_HAS_PAIRS(w))
+    chain_solve_range(w, 0, T - 1, tid, NT);  // dense coupling blocks
+  else
 #if TMX_IS_DEVICE
   if (D <= 8 && NT >= 64)
   {
@@ -1246,6 +1300,64 @@ TMX_DEVFN void admm_phase_b(const QpWs& w, const DevProblem* P, int tid, int NT)
 TMX_DEVFN void chain_solve_range(const QpWs& w, int t0, int t1, int tid, int NT)
 {
   const int D = w.D, DS = w.DS, DDS = w.DDS;
+#if TMX_LINK_ROWS
+  if (TMX_HAS_PAIRS(w))
+  {
+    // dense coupling blocks: v_t = b_t - C_{t-1}' (Sinv_{t-1} v_{t-1}),  x_t = Sinv_t (v_t - C_t x_{t+1})
+    double* tmp = w.red + 192;  // 2 D <= 64 doubles
+    const int DD = D * D;
+    for (int t = t0 + 1; t <= t1; ++t)
+    {
+      for (int i = tid; i < D; i += NT)
+      {
+        const double* S = w.Sinv + (t - 1) * DDS + i * DS;
+        const double* vp = w.tp + (t - 1) * D;
+        double acc = 0.0;
+        for (int j = 0; j < D; ++j)
+          acc += S[j] * vp[j];
+        tmp[i] = acc;
+      }
+      TMX_SYNC();
+      const double* Cm = w.Cd + (size_t)(t - 1) * DD;
+      for (int i = tid; i < D; i += NT)
+      {
+        double acc = 0.0;
+        for (int k = 0; k < D; ++k)
+          acc += Cm[k * D + i] * tmp[k];
+        w.tp[t * D + i] -= acc;
+      }
+      TMX_SYNC();
+    }
+    for (int t = t1; t >= t0; --t)
+    {
+      for (int j = tid; j < D; j += NT)
+      {
+        double vj = w.tp[t * D + j];
+        if (t < t1)
+        {
+          const double* Cm = w.Cd + (size_t)t * DD + j * D;
+          for (int k = 0; k < D; ++k)
+            vj -= Cm[k] * w.tp[(t + 1) * D + k];
+        }
+        tmp[D + j] = vj;
+      }
+      TMX_SYNC();
+      for (int i = tid; i < D; i += NT)
+      {
+        const double* S = w.Sinv + t * DDS + i * DS;
+        double acc = 0.0;
+        for (int j = 0; j < D; ++j)
+          acc += S[j] * tmp[D + j];
+        tmp[i] = acc;
+      }
+      TMX_SYNC();
+      for (int i = tid; i < D; i += NT)
+        w.tp[t * D + i] = tmp[i];
+      TMX_SYNC();
+    }
+    return;
+  }
+#endif
   for (int t = t0 + 1; t <= t1; ++t)
   {
     for (int i = tid; i < D; i += NT)

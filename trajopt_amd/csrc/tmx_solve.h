@@ -25,10 +25,11 @@ struct CscOut
   double *P_x, *q, *A_x, *l, *u;
 };
 
-TMX_DEVFN void qp_structure(const DevProblem* P, const int* active, const double* coef, const double* rhs,
+TMX_DEVFN void qp_structure(const DevProblem* P, const int* active, const double* coef, const double* coef2, const double* rhs,
                             const double* xcur, double trust, const double* merit, int* dims, unsigned long long* hashes,
                             const CscOut* out, int* iscratch, int tid, int NT)
 {
+  (void)coef2;
   const int D = P->D, T = P->T, NX = P->NX, R = P->R;
   int* colptr = iscratch;               // n_max + 1
   int* rowref = colptr + P->n_max + 1;  // R
@@ -85,11 +86,11 @@ TMX_DEVFN void qp_structure(const DevProblem* P, const int* active, const double
         ++c;
     }
 #if TMX_LINK_ROWS
-    if (P->n_link > 0 && t > 0)  // rows of the previous waypoint linked to this variable
+    if (P->n_link > 0 && t > 0)  // pair rows of the previous waypoint with an entry on this variable
       for (int q = P->wp_start[t - 1]; q < P->wp_start[t]; ++q)
       {
         const int r = P->wp_list[q];
-        if (lact[r] && P->slot_lkj[r] == j)
+        if (lact[r] && P->slot_c2[r] >= 0 && coef2[P->slot_c2[r] * D + j] != 0.0)
           ++c;
       }
 #endif
@@ -136,8 +137,12 @@ TMX_DEVFN void qp_structure(const DevProblem* P, const int* active, const double
     // entries of the rows of waypoint t-1 that link to this variable, merged by ascending reference row index
     int ql = (P->n_link > 0 && t > 0) ? P->wp_start[t - 1] : 0;
     const int ql_end = (P->n_link > 0 && t > 0) ? P->wp_start[t] : 0;
+    auto link_val = [&](int qq) -> double {
+      const int rr = P->wp_list[qq];
+      return (active[rr] && P->slot_c2[rr] >= 0) ? coef2[P->slot_c2[rr] * D + j] : 0.0;
+    };
     auto next_link = [&]() {
-      while (ql < ql_end && !(active[P->wp_list[ql]] && P->slot_lkj[P->wp_list[ql]] == j))
+      while (ql < ql_end && link_val(ql) == 0.0)
         ++ql;
     };
     next_link();
@@ -171,7 +176,7 @@ TMX_DEVFN void qp_structure(const DevProblem* P, const int* active, const double
         if (out)
         {
           out->A_i[pos] = rl;
-          out->A_x[pos] = P->slot_lkc[P->wp_list[ql]];
+          out->A_x[pos] = link_val(ql);
         }
         ++pos;
         ++ql;
@@ -321,7 +326,7 @@ TMX_DEVFN void kkt_invert(const QpWs& w, bool partitioned, int tid, int NT, long
     dpart_factor(w, tid, NT, pc, tlast);
     return;
   }
-  if (w.D * w.D <= 64)
+  if (w.D * w.D <= 64 && !TMX_HAS_PAIRS(w))
   {
     kkt_invert_chain_wave0(w, tid);
     return;
@@ -500,9 +505,9 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
   {
     double* scratch = Bt->qp_scratch + (size_t)b * Bt->qp_scratch_stride;
 #if TMX_QP_COLD_IN_LDS
-    qp_ws_carve(w, smem, smem + qp_lds_doubles(D, T, R, P->NA), scratch, D, T, R, P->NA);
+    qp_ws_carve(w, smem, smem + qp_lds_doubles(D, T, R, P->NA, P->n_link), scratch, D, T, R, P->NA, P->n_link);
 #else
-    qp_ws_carve(w, smem, scratch + qp_far_doubles(D, T, R, P->NA), scratch, D, T, R, P->NA);
+    qp_ws_carve(w, smem, scratch + qp_far_doubles(D, T, R, P->NA), scratch, D, T, R, P->NA, P->n_link);
 #endif
     if (chain_lds)  // k_*_hbm kernels only (a constant nullptr everywhere else)
       qp_ws_chain_to_lds(w, chain_lds);
@@ -512,6 +517,7 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
   const int* g_act = Bt->active + (size_t)b * R;
   const double* g_coef = Bt->coef + (size_t)b * R * D;
   const double* g_rhs = Bt->rhs + (size_t)b * R;
+  [[maybe_unused]] const double* g_coef2 = Bt->coef2 + (size_t)b * P->n_link * D;
   const double* g_x = Bt->x + (size_t)b * NX;
   const double* g_merit = Bt->merit + (size_t)b * P->n_cnts;
   const double trust = Bt->trust[b];
@@ -536,7 +542,9 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
     for (int j = 0; j < D; ++j)
       w.coef[r * D + j] = g_act[r] ? g_coef[r * D + j] : 0.0;
 #if TMX_LINK_ROWS
-    w.lkc[r] = (g_act[r] && P->slot_lkj[r] >= 0) ? P->slot_lkc[r] : 0.0;
+    if (P->n_link > 0 && P->slot_c2[r] >= 0)
+      for (int j = 0; j < D; ++j)
+        w.c2[P->slot_c2[r] * D + j] = g_act[r] ? g_coef2[P->slot_c2[r] * D + j] : 0.0;
 #endif
     const double oc = P->slot_iscnt[r] ? g_merit[P->slot_owner[r]] : P->slot_objc[r];
     for (int k = 0; k < P->slot_naux[r]; ++k)
@@ -590,8 +598,7 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
       w.row_epos[P->wp_list[u]] = acc + (u - P->wp_start[t]);
   }
 #if TMX_LINK_ROWS
-  w.lkj = P->slot_lkj;
-  w.n_link = P->n_link;
+  w.c2i = P->slot_c2;
 #endif
   w.sigma = st.sigma;
   w.alpha = st.alpha;
@@ -650,8 +657,8 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
         for (int q = w.wp_start[t - 1]; q < w.wp_start[t]; ++q)
         {
           const int r = w.wp_list[q];
-          if (w.act[r] && w.lkj[r] == j)
-            cn = fmax(cn, fabs(w.lkc[r]));
+          if (w.act[r] && w.c2i[r] >= 0)
+            cn = fmax(cn, fabs(w.c2[w.c2i[r] * D + j]));
         }
 #endif
       cn = fmax(cn, fabs(w.bbp[v]));
@@ -666,7 +673,9 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
       for (int j = 0; j < D; ++j)
         rn = fmax(rn, fabs(w.coef[r * D + j]));
 #if TMX_LINK_ROWS
-      rn = fmax(rn, fabs(w.lkc[r]));
+      if (w.n_link > 0 && w.c2i[r] >= 0)
+        for (int j = 0; j < D; ++j)
+          rn = fmax(rn, fabs(w.c2[w.c2i[r] * D + j]));
 #endif
       for (int k = 0; k < w.naux[r]; ++k)
       {
@@ -696,8 +705,9 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
       for (int j = 0; j < D; ++j)
         w.coef[r * D + j] = (w.hr[r] * w.coef[r * D + j]) * w.tp[t * D + j];
 #if TMX_LINK_ROWS
-      if (w.lkj[r] >= 0)
-        w.lkc[r] = (w.hr[r] * w.lkc[r]) * w.tp[(t + 1) * D + w.lkj[r]];
+      if (w.n_link > 0 && w.c2i[r] >= 0)
+        for (int j = 0; j < D; ++j)
+          w.c2[w.c2i[r] * D + j] = (w.hr[r] * w.c2[w.c2i[r] * D + j]) * w.tp[(t + 1) * D + j];
 #endif
       for (int k = 0; k < w.naux[r]; ++k)
       {
@@ -845,7 +855,7 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
   // ---------------- factor + ADMM loop (osqp_solve) --------------------------------------------------------
   TMX_TICK(0);
 #if TMX_IS_DEVICE
-  const bool fast = (NT == TMX_QP_NT) && (R <= 512) && dpart_supported(w, NT) && (!TMX_LINK_ROWS || P->n_link == 0);
+  const bool fast = (NT == TMX_QP_NT) && (R <= 512) && dpart_supported(w, NT) && !TMX_HAS_PAIRS(w);
 #else
   const bool fast = false;
 #endif
@@ -1298,7 +1308,7 @@ TMX_DEVFN void sqp_update_block(const DevProblem* P, const DevBatch* Bt, int b, 
     double* vterm = val + R + (R + 1) / 2;
     double* vsum = vterm + (size_t)P->n_vel * NX;
     QpWs wl;  // only for the layout of the per-problem scratch (aux_ref written by the QP kernel)
-    qp_ws_carve(wl, smem, smem, Bt->qp_scratch + (size_t)b * Bt->qp_scratch_stride, D, P->T, R, P->NA);
+    qp_ws_carve(wl, smem, smem, Bt->qp_scratch + (size_t)b * Bt->qp_scratch_stride, D, P->T, R, P->NA, P->n_link);
     const int* aux_ref = wl.aux_ref;
     for (int r = tid; r < R; r += NT)
     {
@@ -1313,8 +1323,12 @@ TMX_DEVFN void sqp_update_block(const DevProblem* P, const DevBatch* Bt, int b, 
           for (int j = 0; j < D; ++j)
             aff += coef[r * D + j] * xq[t * D + j];
 #if TMX_LINK_ROWS
-          if (P->slot_lkj[r] >= 0)
-            aff += P->slot_lkc[r] * xq[(t + 1) * D + P->slot_lkj[r]];
+          if (P->n_link > 0 && P->slot_c2[r] >= 0)
+          {
+            const double* c2r = Bt->coef2 + ((size_t)b * P->n_link + P->slot_c2[r]) * D;
+            for (int j = 0; j < D; ++j)
+              aff += c2r[j] * xq[(t + 1) * D + j];
+          }
 #endif
           aff -= rhs[r];
           vr = P->slot_eq[r] ? fabs(aff) : ((aff > 0) ? aff : 0.0);

@@ -201,6 +201,175 @@ TMX_DEVFN double contact_distance(const DevProblem* P, const double* q, int s, i
   return len - rs - P->ob_radius[o];
 }
 
+// ---- LVS_DISCRETE / (LVS_)CONTINUOUS collision on a segment (q0 = x[t], q1 = x[t+1]) --------------------------------
+// Same statement, operation by operation, as oracle/trajprob.hpp LvsEvaluator (DiscreteCollisionEvaluator /
+// CastCollisionEvaluator::CalcCollisions trajopt/src/collision_terms.cpp:823-905, :1071-1173 on sphere geometry).
+// Slot (t, sphere s, obstacle o, sub-state / sub-segment index i).
+struct LvsContact
+{
+  double distance, n[3], p_local[3], cc_time;
+  double R0[9], R1[9];  // rotation of the link in `transform` / `cc_transform`
+};
+TMX_DEVFN double lin_spaced_at(int size, double low, double high, int i)
+{
+  const int size1 = size - 1;
+  const double step = (high - low) / (double)size1;
+  const bool flip = fabs(high) < fabs(low);
+  if (flip)
+    return (i == 0) ? low : (high - (double)(size1 - i) * step);
+  return (i == size1) ? high : (low + (double)i * step);
+}
+// returns true if the slot holds a contact of the (filtered) result vector
+TMX_DEVFN bool lvs_contact(const DevProblem* P, const double* q0, const double* q1, int r, LvsContact& c)
+{
+  const int D = P->D;
+  const int s = P->slot_sub[r], o = P->slot_sub2[r], flags = P->slot_sub3[r];
+  const int i = flags >> 3;
+  const bool fixed0 = flags & 1, fixed1 = flags & 2, cast = flags & 4;
+  const double lvs = P->slot_aux3[r], margin = P->slot_aux1[r], buffer = P->slot_aux2[r];
+  double d2 = 0.0;
+  for (int j = 0; j < D; ++j)
+    d2 += (q1[j] - q0[j]) * (q1[j] - q0[j]);
+  const double dist = sqrt(d2);
+  int cnt = 2;
+  if (dist > lvs)
+    cnt = (int)ceil(dist / lvs) + 1;
+  if (cnt > P->lvs_kmax)
+    cnt = P->lvs_kmax;
+  const bool split = dist > lvs;
+  const int last = cnt - 1;
+  const int n_sub = cast ? last : cnt;
+  if (i >= n_sub)
+    return false;
+  const double dt = 1.0 / (double)last;
+  const int link = P->ls_link[s];
+  double qa[TMX_MAX_DOF], qb[TMX_MAX_DOF];
+  for (int j = 0; j < D; ++j)
+  {
+    qa[j] = lin_spaced_at(cnt, q0[j], q1[j], i);
+    qb[j] = cast ? lin_spaced_at(cnt, q0[j], q1[j], i + 1) : qa[j];
+    if (!split && cast)
+    {
+      qa[j] = q0[j];
+      qb[j] = q1[j];
+    }
+  }
+  Tf3 Ta, Tb;
+  fk_link(P, qa, link, Ta, nullptr);
+  double ca[3], p[3];
+  for (int rr = 0; rr < 3; ++rr)
+    ca[rr] = Ta.R[3 * rr + 0] * P->ls_center[3 * s + 0] + Ta.R[3 * rr + 1] * P->ls_center[3 * s + 1] + Ta.R[3 * rr + 2] * P->ls_center[3 * s + 2] + Ta.t[rr];
+  double tau = 0.0;
+  if (cast)
+  {
+    fk_link(P, qb, link, Tb, nullptr);
+    double cb[3];
+    for (int rr = 0; rr < 3; ++rr)
+      cb[rr] = Tb.R[3 * rr + 0] * P->ls_center[3 * s + 0] + Tb.R[3 * rr + 1] * P->ls_center[3 * s + 1] + Tb.R[3 * rr + 2] * P->ls_center[3 * s + 2] + Tb.t[rr];
+    const double e[3] = { cb[0] - ca[0], cb[1] - ca[1], cb[2] - ca[2] };
+    const double ee = e[0] * e[0] + e[1] * e[1] + e[2] * e[2];
+    const double eo = e[0] * (P->ob_center[3 * o + 0] - ca[0]) + e[1] * (P->ob_center[3 * o + 1] - ca[1]) + e[2] * (P->ob_center[3 * o + 2] - ca[2]);
+    tau = (ee > 0) ? eo / ee : 0.0;
+    tau = tau < 0.0 ? 0.0 : (tau > 1.0 ? 1.0 : tau);
+    for (int rr = 0; rr < 3; ++rr)
+      p[rr] = ca[rr] + tau * e[rr];
+  }
+  else
+  {
+    Tb = Ta;
+    for (int rr = 0; rr < 3; ++rr)
+      p[rr] = ca[rr];
+  }
+  const double d[3] = { P->ob_center[3 * o + 0] - p[0], P->ob_center[3 * o + 1] - p[1], P->ob_center[3 * o + 2] - p[2] };
+  const double len = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+  const double rs = P->ls_radius[s];
+  c.distance = len - rs - P->ob_radius[o];
+  double pw[3];
+  for (int rr = 0; rr < 3; ++rr)
+  {
+    c.n[rr] = (len > 0) ? d[rr] / len : (rr == 2 ? 1.0 : 0.0);
+    pw[rr] = p[rr] + rs * c.n[rr];
+  }
+  for (int rr = 0; rr < 3; ++rr)
+    c.p_local[rr] = Ta.R[0 + rr] * (pw[0] - Ta.t[0]) + Ta.R[3 + rr] * (pw[1] - Ta.t[1]) + Ta.R[6 + rr] * (pw[2] - Ta.t[2]);
+  for (int k = 0; k < 9; ++k)
+  {
+    c.R0[k] = Ta.R[k];
+    c.R1[k] = Tb.R[k];
+  }
+  // cc_type: 0 none, 1 Time0, 2 Time1, 3 Between (ContactResultMap::addInterpolatedCollisionResults)
+  int raw = 0, type;
+  if (cast)
+    raw = (tau == 0.0) ? 1 : ((tau == 1.0) ? 2 : 3);
+  if (!cast || split)
+  {
+    c.cc_time = cast ? ((double)i * dt) + (tau * dt) : ((double)i * dt);
+    if (i == 0 && (raw == 0 || raw == 1))
+      type = 1;
+    else if (i == last && (raw == 0 || raw == 2))
+      type = 2;
+    else
+      type = 3;
+  }
+  else
+  {
+    c.cc_time = tau;
+    type = raw;
+  }
+  // trajopt_common::removeInvalidContactResults (collision_utils.cpp:71-114), link 1 static
+  if (c.distance > (margin + buffer))
+    return false;
+  if (!fixed0 && !fixed1)
+    return true;
+  if (fixed0 && type != 0 && type != 1)
+    return true;
+  if (fixed1 && type != 0 && type != 2)
+    return true;
+  return false;
+}
+// GetGradient(dofvals, contact, isTimestep1) of the link sphere at end state q: scale * grad and scale * -(grad . q)
+TMX_DEVFN void lvs_end_gradient(const DevProblem* P, const double* q, int s, const LvsContact& c, bool is1, double* sg, double& sconst)
+{
+  const int D = P->D, link = P->ls_link[s];
+  const double scale = is1 ? c.cc_time : (1 - c.cc_time);
+  const double* Rl = is1 ? c.R1 : c.R0;
+  Tf3 L;
+  Tf3 jf[TMX_MAX_DOF];
+  fk_link(P, q, link, L, jf);
+  double p[3];
+  for (int rr = 0; rr < 3; ++rr)
+    p[rr] = L.t[rr] + (Rl[3 * rr + 0] * c.p_local[0] + Rl[3 * rr + 1] * c.p_local[1] + Rl[3 * rr + 2] * c.p_local[2]);
+  double gq = 0.0;
+  for (int k = 0; k < D; ++k)
+  {
+    double col[3] = { 0, 0, 0 };
+    if (k <= link)
+    {
+      const Tf3& F = jf[k];
+      double z[3];
+      for (int rr = 0; rr < 3; ++rr)
+        z[rr] = F.R[3 * rr + 0] * P->axis[k][0] + F.R[3 * rr + 1] * P->axis[k][1] + F.R[3 * rr + 2] * P->axis[k][2];
+      if (P->jtype[k] == 0)
+      {
+        const double dd[3] = { p[0] - F.t[0], p[1] - F.t[1], p[2] - F.t[2] };
+        col[0] = z[1] * dd[2] - z[2] * dd[1];
+        col[1] = z[2] * dd[0] - z[0] * dd[2];
+        col[2] = z[0] * dd[1] - z[1] * dd[0];
+      }
+      else
+      {
+        col[0] = z[0];
+        col[1] = z[1];
+        col[2] = z[2];
+      }
+    }
+    const double g = -1.0 * (c.n[0] * col[0] + c.n[1] * col[1] + c.n[2] * col[2]);
+    sg[k] = scale * g;
+    gq += g * q[k];
+  }
+  sconst = scale * -gq;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // K6: exact costs / constraint violations at trajectory xv -> cost_out[n_costs], viol_out[n_cnts]
 // (BasicTrustRegionSQP::evaluateCosts / evaluateConstraintViols, trajopt_sco/src/optimizers.cpp:176-192)
@@ -232,6 +401,18 @@ TMX_DEVFN void evaluate_terms(const DevProblem* P, const double* xv, double* cos
         v = ((pv > 0) ? pv : 0.0) * P->slot_objc[r];
       }
     }
+#if TMX_LINK_ROWS
+    else if (kind == SLOT_COLLISION_LVS)
+    {
+      // CollisionCost::value / CollisionConstraint::value over the segment's filtered contacts (collision_terms.cpp:1306-1327)
+      LvsContact c;
+      if (lvs_contact(P, xv + t * D, xv + (t + 1) * D, r, c))
+      {
+        const double pv = P->slot_aux1[r] - c.distance;
+        v = ((pv > 0) ? pv : 0.0) * P->slot_objc[r];
+      }
+    }
+#endif
     else if (kind == SLOT_JOINTPOS_INEQ)
     {
       // JointPosIneqConstraint::value (trajectory_costs.cpp:227-242) then IneqConstraint::violations = pospart
@@ -336,8 +517,9 @@ TMX_DEVFN void evaluate_terms(const DevProblem* P, const double* xv, double* cos
 // K1 + K3: convexify at xv -> rows (active, coef[R][D], rhs[R]) for the dynamic slots.
 // FIXED and JOINTPOS rows are constant (written once by init_static_rows).
 // ---------------------------------------------------------------------------------------------------
-TMX_DEVFN void init_static_rows(const DevProblem* P, const double* x0, int* active, double* coef, double* rhs, int tid, int NT)
+TMX_DEVFN void init_static_rows(const DevProblem* P, const double* x0, int* active, double* coef, double* coef2, double* rhs, int tid, int NT)
 {
+  (void)coef2;
   const int D = P->D;
   for (int r = tid; r < P->R; r += NT)
   {
@@ -345,27 +527,34 @@ TMX_DEVFN void init_static_rows(const DevProblem* P, const double* x0, int* acti
 #if TMX_LINK_ROWS
     if (kind == SLOT_JOINTVEL || kind == SLOT_JOINTVEL_INEQ)
     {
-      // home coefficient on x[t][j]; the coefficient on x[t+1][j] is the static link slot_lkc (built the same way at upload)
+      // home coefficient on x[t][j], second-block coefficient on x[t+1][j]
+      double* c2r = coef2 + (size_t)P->slot_c2[r] * D;
       for (int k = 0; k < D; ++k)
+      {
         coef[r * D + k] = 0.0;
+        c2r[k] = 0.0;
+      }
       const int j = P->slot_sub[r];
       const double c = P->slot_scale[r], targ = P->slot_aux1[r], tol = P->slot_aux2[r];
       if (kind == SLOT_JOINTVEL)
       {
         // exprMult(vel, coeff), vel = -1*x[t] + 1*x[t+1] - target   (trajectory_costs.cpp:392-400)
         coef[r * D + j] = (1.0 * -1) * c;
+        c2r[j] = (0.0 + (1.0 * 1)) * c;
         rhs[r] = -((0.0 - targ) * c);
       }
       else if (P->slot_sub2[r] == 0)
       {
         // expr = upper_tol - vel, scaled by -coeff   (:334-338, :458-462)
         coef[r * D + j] = (0.0 - (1.0 * -1)) * -c;
+        c2r[j] = (0.0 - (1.0 * 1)) * -c;
         rhs[r] = -((tol - (0.0 - targ)) * -c);
       }
       else
       {
         // expr_neg = lower_tol - vel, scaled by coeff   (:340-344, :464-468)
         coef[r * D + j] = (0.0 - (1.0 * -1)) * c;
+        c2r[j] = (0.0 - (1.0 * 1)) * c;
         rhs[r] = -((tol - (0.0 - targ)) * c);
       }
       active[r] = 1;
@@ -414,9 +603,10 @@ TMX_DEVFN void init_static_rows(const DevProblem* P, const double* x0, int* acti
 // LDS doubles needed by convexify_terms: per cart-pose instance (D+1) pose records of 7, the error vector (6) and the
 // finite-difference Jacobian (6 x D)
 TMX_HOSTDEVFN size_t tmx_cvx_scratch_doubles(int n_cp, int D) { return (size_t)n_cp * ((size_t)(D + 1) * 7 + 6 + 6 * (size_t)D) + 8; }
-TMX_DEVFN void convexify_terms(const DevProblem* P, const double* xv, int* active, double* coef, double* rhs, double* scratch,
+TMX_DEVFN void convexify_terms(const DevProblem* P, const double* xv, int* active, double* coef, double* coef2, double* rhs, double* scratch,
                                int tid, int NT)
 {
+  (void)coef2;
   const int D = P->D;
   // ---- K1: cart-pose rows by forward finite differences over full FK.  One thread per (instance, perturbed joint | base
   //      pose): the D+1 forward-kinematics chains of an instance run side by side instead of one after the other
@@ -501,6 +691,56 @@ TMX_DEVFN void convexify_terms(const DevProblem* P, const double* xv, int* activ
     rhs[r] = -constant;
     active[r] = 1;
   }
+#if TMX_LINK_ROWS
+  // ---- K3': collision rows of the segment evaluators (pair rows: gradient on both waypoints)
+  for (int r = tid; r < P->R; r += NT)
+  {
+    if (P->slot_kind[r] != SLOT_COLLISION_LVS)
+      continue;
+    const int t = P->slot_t[r], s = P->slot_sub[r], flags = P->slot_sub3[r];
+    const bool fixed0 = flags & 1, fixed1 = flags & 2;
+    const double* q0 = xv + t * D;
+    const double* q1 = xv + (t + 1) * D;
+    double* c2r = coef2 + (size_t)P->slot_c2[r] * D;
+    LvsContact c;
+    if (!lvs_contact(P, q0, q1, r, c))
+    {
+      active[r] = 0;
+      for (int k = 0; k < D; ++k)
+      {
+        coef[r * D + k] = 0.0;
+        c2r[k] = 0.0;
+      }
+      rhs[r] = 0.0;
+      continue;
+    }
+    // dist_expr = distance + [scale0 (grad0 . x0 - grad0 . q0)] + [scale1 (grad1 . x1 - grad1 . q1)], cleanupAff (1e-7)
+    double g0[TMX_MAX_DOF], g1[TMX_MAX_DOF], k0 = 0.0, k1 = 0.0;
+    for (int k = 0; k < D; ++k)
+      g0[k] = g1[k] = 0.0;
+    if (!fixed0)
+      lvs_end_gradient(P, q0, s, c, false, g0, k0);
+    if (!fixed1)
+      lvs_end_gradient(P, q1, s, c, true, g1, k1);
+    double cst = c.distance;
+    if (!fixed0)
+      cst += (0.0 + k0);
+    if (!fixed1)
+      cst += (0.0 + k1);
+    const double margin = P->slot_aux1[r];
+    const double viol_const = margin - cst;
+    const double cc = P->slot_iscnt[r] ? P->slot_scale[r] : 1.0;
+    for (int k = 0; k < D; ++k)
+    {
+      const double a0 = (fabs(g0[k]) > TMX_CLEANUP_TOL) ? g0[k] : 0.0, a1 = (fabs(g1[k]) > TMX_CLEANUP_TOL) ? g1[k] : 0.0;
+      // viol = margin - dist_expr: coefficients -a; CollisionConstraint scales the row by the collision coefficient
+      coef[r * D + k] = P->slot_iscnt[r] ? (-a0) * cc : -a0;
+      c2r[k] = P->slot_iscnt[r] ? (-a1) * cc : -a1;
+    }
+    rhs[r] = P->slot_iscnt[r] ? -(viol_const * cc) : -viol_const;
+    active[r] = 1;
+  }
+#endif
   // ---- K3: collision rows
   for (int r = tid; r < P->R; r += NT)
   {

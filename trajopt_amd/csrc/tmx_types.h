@@ -19,13 +19,14 @@ enum
   SLOT_JOINTPOS = 2,  // JointPosEqConstraint row -> abs                              (2 aux)
   SLOT_COLLISION = 3, // CollisionCost contact -> hinge                               (1 aux)
   SLOT_JOINTPOS_INEQ = 4,  // JointPosIneqConstraint row (upper: sub2 = 0, lower: sub2 = 1) -> hinge   (1 aux)
-  // rows on TWO consecutive waypoints (only in TMX_LINK_ROWS builds): home coefficient on (t, sub), link coefficient
-  // slot_lkc on (t + 1, slot_lkj = sub)
+  // PAIR ROWS - rows on TWO consecutive waypoints (TMX_LINK_ROWS builds): D home coefficients coef[r][.] on waypoint t and D
+  // more, coef2[slot_c2[r]][.], on waypoint t + 1
   SLOT_JOINTVEL = 5,       // JointVelEqConstraint row  coeff * (x[t+1][j] - x[t][j] - target) == 0 -> abs (2 aux)
-  SLOT_JOINTVEL_INEQ = 6   // JointVelIneqCost / JointVelIneqConstraint row (upper: sub2 = 0, lower: sub2 = 1) -> hinge (1 aux)
+  SLOT_JOINTVEL_INEQ = 6,  // JointVelIneqCost / JointVelIneqConstraint row (upper: sub2 = 0, lower: sub2 = 1) -> hinge (1 aux)
+  SLOT_COLLISION_LVS = 7   // contact of a link sphere with an obstacle on the segment (t, t+1): LVS_DISCRETE / LVS_CONTINUOUS -> hinge
 };
 #ifndef TMX_LINK_ROWS
-#define TMX_LINK_ROWS 0  // 1: the QP kernels understand rows with a link to the next waypoint (JointVel constraint / hinge forms)
+#define TMX_LINK_ROWS 1  // 1: the QP kernels understand pair rows (generic block-chain path with dense coupling blocks)
 #endif
 
 enum
@@ -67,10 +68,13 @@ struct DevProblem
   // collision geometry
   int *ls_link;
   double *ls_center, *ls_radius, *ob_center, *ob_radius;
-  // link of a row to the next waypoint (appended last: the layout of everything above is that of builds without links)
-  int *slot_lkj;      // R: joint of the linked variable (t + 1, lkj), -1 = none
-  double *slot_lkc;   // R: its coefficient
-  int n_link;         // number of slots with a link (0: every row sits on one waypoint)
+  // pair rows (rows that also touch waypoint t + 1)
+  int *slot_c2;       // R: index of the row's second coefficient block in DevBatch::coef2 (-1: the row sits on one waypoint)
+  int n_link;         // number of pair rows R2 (0: every row sits on one waypoint)
+  // collision evaluator of the LVS slots: longest valid segment length; fixed-state flags per slot in slot_sub3
+  int *slot_sub3;     // R: collision LVS: bit 0 = state t is fixed (START_FIXED_END_FREE), bit 1 = state t+1 is fixed
+  double *slot_aux3;  // R: collision LVS: longest_valid_segment_length
+  int lvs_kmax;       // sub-state capacity of the LVS evaluators (tmx_term.max_substates)
 };
 
 struct DevBatch
@@ -82,6 +86,7 @@ struct DevBatch
   int *phase, *iter, *merit_inc, *qp_fail, *status, *retval, *n_fe, *n_qp, *cvx, *prev_ok;
   int *active;
   double *coef, *rhs;
+  double *coef2;                // B x R2 x D: coefficients of the pair rows on waypoint t + 1 (slot order of the pair rows)
   int *dims;                    // B x 4: n, m, nnzP, nnzA of the current convexification
   unsigned long long *hashes;   // B x 4: hashP, hashA, wsP, wsA (ws* = what the reference's memcmp actually compares)
   int *prev_dims;               // B x 4 of the previous Model::optimize()

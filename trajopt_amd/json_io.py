@@ -164,9 +164,11 @@ def construct_problem(text_or_dict, env: Environment) -> ParsedProblem:
                                     is_constraint=not is_cost, name=name)
         if typ == "collision":
             ev = int(p.get("evaluator_type", 1))
-            if ev != _EVAL_DISCRETE:
-                raise UnsupportedTerm(f"collision evaluator_type {ev}: only DISCRETE (1, single time step) is lowered; "
-                                      "LVS / continuous evaluators are SURVEY.md §8(f) row 2")
+            if ev < 1 or ev > 4:
+                raise ValueError(f"collision evaluator_type {ev}: must be 1 .. 4")     # FAIL_IF_FALSE(<= 4), :1637; 0 = NONE
+            lvs = float(p.get("longest_valid_segment_length", 0.5))
+            if not lvs >= 0:
+                raise ValueError("collision: longest_valid_segment_length must be >= 0")   # :1634
             if "pairs" in p:
                 raise UnsupportedTerm("collision per-pair margin overrides are not lowered by the device path")
             first, last = int(p.get("first_step", 0)), int(p.get("last_step", n_steps - 1))
@@ -179,8 +181,14 @@ def construct_problem(text_or_dict, env: Environment) -> ParsedProblem:
             buf = float(p.get("safety_margin_buffer", 0.5))
             if buf < 0:
                 raise ValueError("collision: negative safety_margin_buffer")
+            # quirk Q3: the reference reads "safety_margin_buffer" (problem_description.cpp:1630) but its list of allowed fields
+            # (:1701-1711) does not contain it, so a JSON file that supplies the key is rejected by ensure_only_members and
+            # the effective JSON-path buffer is always the 0.5 default
+            _only_members(p, ("type", "first_step", "last_step", "evaluator_type", "fixed_steps", "contact_test_type",
+                              "longest_valid_segment_length", "coeffs", "dist_pen", "pairs"), typ)
             return CollisionTermInfo(first_step=first, last_step=last, dist_pen=float(p["dist_pen"]), coeff=float(p["coeffs"]),
-                                     safety_margin_buffer=buf, name=name, is_constraint=not is_cost, fixed_steps=fixed_steps)
+                                     safety_margin_buffer=buf, name=name, is_constraint=not is_cost, fixed_steps=fixed_steps,
+                                     evaluator_type=ev, longest_valid_segment_length=lvs, max_substates=0)
         raise UnsupportedTerm(f"term type \"{typ}\" is not lowered by the device path")
 
     for it in v.get("costs", []):
@@ -210,4 +218,9 @@ def construct_problem(text_or_dict, env: Environment) -> ParsedProblem:
         init = state[None, :] * (1.0 - w) + end[None, :] * w
     else:
         raise ValueError("init_info did not have a valid type from Json. Valid types are stationary, joint_interpolated, or given_traj")
+    # row-slot capacity of the segment collision evaluators from the initial trajectory: 1.5 x the longest segment, <= 64
+    for ti in pci.cost_infos + pci.cnt_infos:
+        if isinstance(ti, CollisionTermInfo) and ti.evaluator_type >= 2 and ti.max_substates <= 0:
+            dmax = float(np.sqrt(((init[1:] - init[:-1]) ** 2).sum(axis=1)).max()) if n_steps > 1 else 0.0
+            ti.max_substates = int(min(64.0, max(2.0, np.ceil(1.5 * dmax / max(ti.longest_valid_segment_length, 1e-9)) + 1.0)))
     return ParsedProblem(pci=pci, sqp_params=sp, init_traj=np.ascontiguousarray(init), manip=manip, convex_solver=convex_solver)

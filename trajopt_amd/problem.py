@@ -105,14 +105,17 @@ def pr2_right_arm() -> Robot:
     """PR2 right arm (7 DOF) — the only 7-DOF model in the reference
     (trajopt_common/data/arm_around_table.urdf:1479-1866, extracted by tools/extract_pr2_chain.py).
     Collision geometry: 8 spheres hand-placed along upper arm / forearm / gripper (synthetic, stands in for the
-    convex meshes tesseract would load)."""
+    convex meshes tesseract would load).  The centres sit slightly OFF the roll-joint axes, like the real link meshes: a
+    centre exactly on an axis makes the gradient entry n . (z x d) a mathematical zero that comes out as 0.0 or 1e-17
+    depending on the last bits of x, and the reference keeps every entry that is not exactly 0.0
+    (trajopt_sco/src/solver_utils.cpp:111-144) - nnz(A) of such a problem is decided by round-off in the reference itself."""
     rob = _pr2_chain("pr2_right_arm.json")
     rob.link_spheres = [
-        (2, (0.10, 0.0, 0.0), 0.09), (2, (0.25, 0.0, 0.0), 0.09),
-        (3, (0.00, 0.0, 0.0), 0.08),
-        (4, (0.10, 0.0, 0.0), 0.07), (4, (0.22, 0.0, 0.0), 0.07),
-        (5, (0.00, 0.0, 0.0), 0.06),
-        (6, (0.08, 0.0, 0.0), 0.05), (6, (0.16, 0.0, 0.0), 0.05),
+        (2, (0.10, 0.012, -0.008), 0.09), (2, (0.25, -0.010, 0.006), 0.09),
+        (3, (0.00, 0.015, 0.010), 0.08),
+        (4, (0.10, -0.008, 0.012), 0.07), (4, (0.22, 0.010, -0.006), 0.07),
+        (5, (0.00, 0.012, -0.009), 0.06),
+        (6, (0.08, 0.007, 0.005), 0.05), (6, (0.16, -0.006, 0.008), 0.05),
     ]
     return rob
 
@@ -160,8 +163,10 @@ class CartPoseTermInfo:
 
 @dataclass
 class CollisionTermInfo:
-    """trajopt::CollisionTermInfo, TT_COST, evaluator_type SINGLE_TIME_STEP (DISCRETE) — problem_description.cpp:1617-1774.
-    JSON defaults: coeff 20, buffer 0.5 (quirk Q3), dist_pen given."""
+    """trajopt::CollisionTermInfo — problem_description.cpp:1617-1837.  evaluator_type (tesseract CollisionEvaluatorType):
+    1 DISCRETE -> one single-time-step term per non-fixed step; 2 LVS_DISCRETE / 3 CONTINUOUS / 4 LVS_CONTINUOUS -> one term
+    per segment (i, i+1) whose rows touch both waypoints (:1720-1761).  JSON defaults: coeff 20, buffer 0.5 (quirk Q3),
+    longest_valid_segment_length 0.5."""
     first_step: int = 0
     last_step: int = -1
     dist_pen: float = 0.025
@@ -171,6 +176,9 @@ class CollisionTermInfo:
     is_constraint: bool = False       # TT_CNT: one CollisionConstraint per step (problem_description.cpp:1821-1835)
     fixed_steps: Sequence[int] = ()   # steps that get no collision term (:1641-1649, :1767, :1827); independent of
                                       # BasicInfo.fixed_timesteps, as in the reference
+    evaluator_type: int = 1
+    longest_valid_segment_length: float = 0.5
+    max_substates: int = 2            # row-slot capacity per (segment, link sphere, obstacle) of the device path
 
 
 @dataclass
@@ -197,6 +205,8 @@ class ProblemConstructionInfo:
         T = self.basic_info.n_steps
         if isinstance(ti, CollisionTermInfo):     # one CollisionCost / CollisionConstraint "name_<step>" per non-fixed step
             last = ti.last_step if ti.last_step >= 0 else T - 1
+            if ti.evaluator_type >= 2:             # one term per segment (:1723, :1781)
+                return [f"{ti.name}_{i}" for i in range(ti.first_step, last)]
             return [f"{ti.name}_{i}" for i in range(ti.first_step, last + 1) if i not in list(ti.fixed_steps)]
         return [ti.name]
 
@@ -298,6 +308,11 @@ class ProblemConstructionInfo:
                 t.first_step = ti.first_step
                 t.last_step = ti.last_step if ti.last_step >= 0 else T - 1
                 t.margin, t.coeff, t.buffer = ti.dist_pen, ti.coeff, ti.safety_margin_buffer
+                if ti.evaluator_type not in (0, 1, 2, 3, 4):
+                    raise ValueError("collision evaluator_type must be <= 4")          # FAIL_IF_FALSE, :1637
+                t.evaluator_type = ti.evaluator_type
+                t.longest_valid_segment_length = ti.longest_valid_segment_length
+                t.max_substates = ti.max_substates
                 for fs in ti.fixed_steps:
                     if fs < t.first_step or fs > t.last_step:
                         raise ValueError(f"Fixed step {fs} is not between first step {t.first_step} and last step {t.last_step}")
