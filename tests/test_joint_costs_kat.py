@@ -160,10 +160,26 @@ def test_joint_vel_kat_kernel_sources_on_host(hostemu_lib, orc, name, make, chec
     ctx.close()
 
 
-def test_product_library_rejects_two_waypoint_rows_explicitly():
-    """until the link-row path is validated on the GPU the product build says so instead of computing something else"""
-    import os, subprocess
-    lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "trajopt_amd", "_build", "libtrajopt_mi355x.so")
-    assert os.path.exists(lib)
-    out = subprocess.run(["strings", lib], capture_output=True, text=True).stdout
-    assert "JointVel constraint / hinge forms (rows on two consecutive waypoints) are not enabled in this build" in out
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,make,check", VEL_CASES)
+def test_joint_vel_kat_device(orc, gpu_ctx_factory, name, make, check):
+    """equality_jointVel / inequality_jointVel (trajopt/test/joint_costs_unit.cpp) on the HIP library: rows on two
+    consecutive waypoints (JointVelEqConstraint, JointVelIneqCost, JointVelIneqConstraint) through the generic block-chain
+    path with dense coupling blocks"""
+    import parity_checks as pc
+    pci = make()
+    rob = pci.robot
+    x0 = np.zeros((2, STEPS, 7))
+    x0[1] = np.clip(0.05 * np.random.default_rng(1).standard_normal((STEPS, 7)), rob.lower + 1e-3, rob.upper - 1e-3)
+    ctx = gpu_ctx_factory()
+    desc = pc.make_ctx_inputs(ctx, pci, x0)
+    pc.check_evaluate(ctx, orc, desc, x0, tol=1e-12)
+    for b in range(2):
+        pc.check_first_qp_structure(ctx, orc, desc, x0, b, val_tol=1e-12)
+    assert all(same for same, _ in pc.check_first_qp_solve(ctx, orc, desc, x0))
+    ctx.set_x0(x0)
+    r, o, same, dx = pc.check_full_sqp(ctx, orc, desc, x0, exact=False)
+    assert (r["status"] == abi.OPT_CONVERGED).all()
+    for b in range(2):
+        check(r["x"][b])
+    ctx.close()
