@@ -290,6 +290,42 @@ TMX_API tmx_status tmx_export_csc(tmx_ctx* ctx, int32_t problem, int32_t* n, int
 TMX_API tmx_status tmx_qp_dims(tmx_ctx* ctx, int32_t* n_max, int32_t* m_max);
 TMX_API tmx_status tmx_qp_solve(tmx_ctx* ctx, double* x_qp, int32_t* cvx_status, tmx_qp_record* rec);
 
+/* ---- S1 / S5: QPs handed over in CSC form ------------------------------------------------------------------------------
+ * sco::Model (trajopt_sco/include/trajopt_sco/solver_interface.hpp:54-104: addVar / addEqCnt / addIneqCnt / setObjective /
+ * optimize, as OSQPModel implements it, trajopt_sco/src/osqp_interface.cpp:283-370, :440-615) and trajopt_sqp::QPSolver
+ * (trajopt_optimizers/trajopt_sqp/include/trajopt_sqp/qp_solver.h:67-170: init / updateHessianMatrix / updateGradient /
+ * updateLinearConstraintsMatrix / updateBounds / setWarmStart / solve / getSolution) callers build their QP themselves;
+ * the adapters (adapters/) convert it to the arrays OSQP's own osqp_setup takes and call this entry point: one OSQP-style
+ * ADMM solve per QP of the batch, one workgroup per QP, arbitrary sparsity (dense internally; n + m up to a few thousand).
+ *   minimize 1/2 x'Px + q'x   subject to  l <= Ax <= u ;  P: upper triangle, CSC ; A: CSC ; |bounds| >= 1e30 = infinite  */
+typedef struct
+{
+  int32_t n, m;
+  const int64_t* P_p; /* n + 1 */
+  const int64_t* P_i;
+  const double* P_x;
+  const double* q;    /* n */
+  const int64_t* A_p; /* n + 1 */
+  const int64_t* A_i;
+  const double* A_x;
+  const double* l;    /* m */
+  const double* u;    /* m */
+  const double* x_warm; /* osqp_warm_start(x, y): both or neither; NULL = cold start */
+  const double* y_warm;
+} tmx_qp_csc;
+typedef struct
+{
+  int32_t osqp_status;   /* OSQP status_val: 1 solved, 2 solved inaccurate, 3/4 primal infeasible (inaccurate), 5/6 dual
+                            infeasible (inaccurate), 7 max iter reached, 9 non convex */
+  int32_t iter, rho_updates, polish_status;
+  double rho_final, prim_res, dual_res;
+} tmx_qp_info;
+/* x: concatenated primal solutions (sum of n), y: concatenated duals (sum of m), cvx_status: sco::CvxOptStatus per QP as
+ * OSQPModel::optimize maps it (osqp_interface.cpp:565-614), info / active_flags (polish active set, sum of m; -1 lower, +1
+ * upper) optional.  settings NULL = trajopt's defaults.                                                                 */
+TMX_API tmx_status tmx_qp_solve_batched(tmx_ctx* ctx, const tmx_qp_csc* qps, int32_t batch, const tmx_osqp_settings* settings,
+                                        double* x, double* y, int32_t* cvx_status, tmx_qp_info* info, int32_t* active_flags);
+
 /* dual solution (OSQP solution->y, unscaled) of the last batched Model::optimize(): y_qp[problem * m_max + i], reference
  * row order; the reference reads it back for its explicit warm start (osqp_interface.cpp:346-348, 514-515)            */
 TMX_API tmx_status tmx_qp_duals(tmx_ctx* ctx, double* y_qp /* B * m_max */);

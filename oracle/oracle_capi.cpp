@@ -309,6 +309,97 @@ int orc_fk_tool(const tmx_problem_desc* desc, const double* q, double* tf12)
   return 0;
 }
 int orc_num_threads() { return omp_get_max_threads(); }
+// S1 demonstration: the reference's trajopt_sco/test/small-problems-unit.cpp:48-172 (separable / non-separable quadratics,
+// Hock-Schittkowski TP1 / TP3 / TP6 / TP7 with CostFromFunc / ConstraintFromErrFunc callbacks on the HOST, as in the
+// reference) run by the restated BasicTrustRegionSQP with every Model::optimize() handed to `backend` (NULL = the restated
+// OSQP).  x_out: 6 problems x 3 doubles, status_out / n_qp_out: 6 ints.  Returns the number of QPs solved.
+int orc_small_problems(ExternalQpFn backend, void* user, double* x_out, int* status_out, int* n_qp_out)
+{
+  externalQp() = backend;
+  externalQpUser() = user;
+  int total = 0, k = 0;
+  auto finish = [&](BasicTrustRegionSQP& solver) {
+    const OptResults& r = solver.results();
+    for (std::size_t i = 0; i < 3; ++i)
+      x_out[3 * k + static_cast<int>(i)] = i < r.x.size() ? r.x[i] : 0.0;
+    status_out[k] = static_cast<int>(r.status);
+    n_qp_out[k] = r.n_qp_solves;
+    total += r.n_qp_solves;
+    ++k;
+  };
+  auto setup = [](std::size_t n_vars) {
+    auto prob = std::make_shared<OptProb>();
+    std::vector<std::string> names;
+    for (std::size_t i = 0; i < n_vars; ++i)
+      names.push_back("x_" + std::to_string(i));
+    const double inf = std::numeric_limits<double>::infinity();
+    prob->createVariables(names, DblVec(n_vars, -inf), DblVec(n_vars, inf));
+    return prob;
+  };
+  auto sq = [](double v) { return v * v; };
+  try
+  {
+    {
+      auto prob = setup(3);
+      prob->addCost(std::make_shared<CostFromFunc>([sq](const DblVec& x) { return x[0] * x[0] + sq(x[1] - 1) + sq(x[2] - 2); },
+                                                   prob->getVars(), "f"));
+      BasicTrustRegionSQP solver(prob);
+      solver.getParameters().trust_box_size = 100;
+      solver.initialize({ 3, 4, 5 });
+      solver.optimize();
+      finish(solver);
+    }
+    {
+      auto prob = setup(3);
+      prob->addCost(std::make_shared<CostFromFunc>(
+          [sq](const DblVec& x) { return sq(x[0] - x[1] + 3 * x[2]) + sq(x[0] - 1) + sq(x[2] - 2); }, prob->getVars(), "f", true));
+      BasicTrustRegionSQP solver(prob);
+      solver.getParameters().trust_box_size = 100;
+      solver.getParameters().min_trust_box_size = 1e-5;
+      solver.getParameters().min_approx_improve = 1e-6;
+      solver.initialize({ 3, 4, 5 });
+      solver.optimize();
+      finish(solver);
+    }
+    struct TP
+    {
+      ScalarOfVector f;
+      VectorOfVector g;
+      ConstraintType type;
+      DblVec init;
+    };
+    std::vector<TP> tps = {
+      { [sq](const DblVec& x) { return 1 * sq(x[1] - sq(x[0])) + sq(1 - x[0]); }, [](const DblVec& x) { return DblVec{ -1.5 - x[1] }; }, INEQ, { -2, 1 } },
+      { [sq](const DblVec& x) { return (x[1] + 1e-5 * sq(x[1] - x[0])); }, [](const DblVec& x) { return DblVec{ 0 - x[1] }; }, INEQ, { 10, 1 } },
+      { [sq](const DblVec& x) { return sq(1 - x[0]); }, [sq](const DblVec& x) { return DblVec{ 10 * (x[1] - sq(x[0])) }; }, EQ, { 10, 1 } },
+      { [sq](const DblVec& x) { return std::log(1 + sq(x[0])) - x[1]; },
+        [sq](const DblVec& x) { return DblVec{ sq(1 + sq(x[0])) + sq(x[1]) - 4 }; }, EQ, { 2, 2 } },
+    };
+    for (auto& tp : tps)
+    {
+      auto prob = setup(tp.init.size());
+      prob->addCost(std::make_shared<CostFromFunc>(tp.f, prob->getVars(), "f", true));
+      prob->addConstraint(std::make_shared<ConstraintFromErrFunc>(tp.g, MatrixOfVector(), prob->getVars(), DblVec(), tp.type, "g"));
+      BasicTrustRegionSQP solver(prob);
+      auto& params = solver.getParameters();
+      params.max_iter = 1000;
+      params.min_trust_box_size = 1e-5;
+      params.min_approx_improve = 1e-10;
+      params.initial_merit_error_coeff = 1;
+      solver.initialize(tp.init);
+      solver.optimize();
+      finish(solver);
+    }
+  }
+  catch (...)
+  {
+    externalQp() = nullptr;
+    return -1;
+  }
+  externalQp() = nullptr;
+  return total;
+}
+
 // the shared libm stand-in (include/tmx_detmath.h) as compiled into the oracle: op 0 sin, 1 cos, 2 atan2(a, b)
 int orc_detmath(int op, int n, const double* a, const double* b, double* out)
 {

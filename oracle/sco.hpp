@@ -433,6 +433,25 @@ struct QpTrace  // one record per Model::optimize() — the integer structure th
   double rho_final;
 };
 
+// S1 test hook: when set, Model::optimize() hands the QP it has just built (exactly what it would pass to osqp_setup, plus the
+// explicit warm start and rho the reference re-applies, osqp_interface.cpp:338-369) to an EXTERNAL solver instead of the
+// restated OSQP.  tests/ point it at tmx_qp_solve_batched: the restated sco SQP then runs with every QP solved on the device,
+// which is what the reference-side adapter HipBatchedAdmmModel : sco::Model does.  Returns the OSQP status value.
+typedef int (*ExternalQpFn)(int n, int m, const long long* P_p, const long long* P_i, const double* P_x, const double* q,
+                            const long long* A_p, const long long* A_i, const double* A_x, const double* l, const double* u,
+                            const double* x_warm, const double* y_warm, double rho, double* x, double* y, double* rho_final,
+                            void* user);
+inline ExternalQpFn& externalQp()
+{
+  static ExternalQpFn fn = nullptr;
+  return fn;
+}
+inline void*& externalQpUser()
+{
+  static void* u = nullptr;
+  return u;
+}
+
 class Model
 {
 public:
@@ -564,7 +583,21 @@ public:
     {
       return CVX_FAILED;
     }
-    solver_->solve();
+    if (externalQp())
+    {
+      const bool ws = warm != 0;
+      std::vector<long long> Pp(P_csc.p.begin(), P_csc.p.end()), Pi(P_csc.i.begin(), P_csc.i.end()), Ap(A_csc.p.begin(), A_csc.p.end()),
+          Ai(A_csc.i.begin(), A_csc.i.end());
+      double rho_final = solver_->currentRho();
+      const int st = externalQp()(static_cast<int>(P_csc.n), static_cast<int>(A_csc.m), Pp.data(), Pi.data(), P_csc.x.data(), q_.data(),
+                                  Ap.data(), Ai.data(), A_csc.x.data(), l_.data(), u_.data(), ws ? warm_x_.data() : nullptr,
+                                  ws ? warm_y_.data() : nullptr, solver_->currentRho(), solver_->sol_x.data(), solver_->sol_y.data(),
+                                  &rho_final, externalQpUser());
+      solver_->info.status_val = st;
+      solver_->settings.rho = rho_final;
+    }
+    else
+      solver_->solve();
     solution_.assign(solver_->sol_x.begin(), solver_->sol_x.begin() + static_cast<long>(vars_.size()));
     last_y_ = solver_->sol_y;
     const int status = solver_->info.status_val;
@@ -731,10 +764,13 @@ private:
     if (!prev_x.empty() && !prev_y.empty())
     {
       solver_->warmStart(prev_x, prev_y);
+      warm_x_ = prev_x;
+      warm_y_ = prev_y;
       return 1;
     }
     return 0;
   }
+  DblVec warm_x_, warm_y_;
 };
 
 // ---------------------------------------------------------------------------------------------

@@ -1036,7 +1036,7 @@ struct LvsEvaluator
             const double e[3] = { cb[0] - ca[0], cb[1] - ca[1], cb[2] - ca[2] };
             const double ee = e[0] * e[0] + e[1] * e[1] + e[2] * e[2];
             const double eo = e[0] * (ob.center[0] - ca[0]) + e[1] * (ob.center[1] - ca[1]) + e[2] * (ob.center[2] - ca[2]);
-            tau = (ee > 0) ? eo / ee : 0.0;
+            tau = (ee > 1e-24) ? eo / ee : 0.0;  // a link that does not move over the sub-segment: contact at its start
             tau = tau < 0.0 ? 0.0 : (tau > 1.0 ? 1.0 : tau);
             for (int r = 0; r < 3; ++r)
               p[r] = ca[r] + tau * e[r];

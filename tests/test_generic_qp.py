@@ -1,0 +1,188 @@
+"""tmx_qp_solve_batched — the sco::Model / trajopt_sqp::QPSolver boundary for QPs handed over in CSC form (SURVEY.md §8b S1,
+S5).  CPU tier: the kernel sources on the host against the oracle's OSQP restatement and a numpy KKT certificate; GPU tier:
+the HIP library on the same QPs."""
+import numpy as np
+import pytest
+
+import parity_checks as pc
+from trajopt_amd import abi, configs, runtime
+
+
+def _random_qp(rng, n, m, infeasible=False):
+    """strictly convex random QP with box + general rows, a few equalities and infinite bounds, in OSQP's CSC form"""
+    import scipy.sparse as sp
+    M = rng.standard_normal((n, n)) * (rng.random((n, n)) < 0.4)
+    P = M @ M.T + 0.1 * np.eye(n)
+    Pu = sp.csc_matrix(np.triu(P))
+    G = rng.standard_normal((m - n, n)) * (rng.random((m - n, n)) < 0.5)
+    A = sp.csc_matrix(np.vstack([G, np.eye(n)]))
+    x_feas = rng.standard_normal(n)
+    mid = A @ x_feas
+    l, u = mid - rng.uniform(0.1, 2.0, m), mid + rng.uniform(0.1, 2.0, m)
+    eq = rng.random(m) < 0.15
+    eq[m - n:] = False
+    l[eq] = u[eq] = mid[eq]
+    l[rng.random(m) < 0.2] = -1e30
+    u[rng.random(m) < 0.2] = 1e30
+    if infeasible:   # two contradicting rows
+        A = sp.vstack([A, sp.csc_matrix(np.eye(n)[:1])]).tocsc()
+        l, u = np.append(l, u[m - n] + 5.0), np.append(u, u[m - n] + 6.0)
+    A.sort_indices()
+    Pu.sort_indices()
+    return dict(n=n, m=A.shape[0], P_p=Pu.indptr.astype(np.int64), P_i=Pu.indices.astype(np.int64), P_x=Pu.data.copy(),
+                q=rng.standard_normal(n), A_p=A.indptr.astype(np.int64), A_i=A.indices.astype(np.int64), A_x=A.data.copy(), l=l, u=u)
+
+
+def _check_batch(ctx, orc, qps, x_tol=1e-6):
+    res = ctx.qp_solve_batched(qps)
+    n_same = 0
+    for q, r in zip(qps, res):
+        o = orc.qp_solve(q, warm_x=q.get("x_warm"), warm_y=q.get("y_warm"))
+        assert r["info"].osqp_status == o["status"], (r["info"].osqp_status, o["status"])
+        if o["status"] in (3, 4, 5, 6):
+            assert r["cvx_status"] == abi.CVX_INFEASIBLE and np.isnan(r["x"]).all()
+            continue
+        assert r["cvx_status"] == abi.CVX_SOLVED
+        same = (r["info"].iter, r["info"].rho_updates, r["info"].polish_status) == (o["iters"], o["rho_updates"], o["polish_status"])
+        n_same += same
+        if same and np.array_equal(r["active"], o["active"]):
+            assert np.abs(r["x"] - o["x"]).max() <= x_tol
+        if r["info"].polish_status == 1:
+            st, pr, su = pc.kkt_certificate(q, r["x"], r["y"])
+            assert st <= 1e-8 and pr <= pc.KKT_PRIM_TOL and su <= pc.KKT_PRIM_TOL, (st, pr, su)
+        # both are minimisers of the same strictly convex QP to OSQP's tolerance
+        assert np.abs(r["x"] - o["x"]).max() <= 1e-3
+    return n_same, len(qps)
+
+
+def _qps(seed, count=12):
+    rng = np.random.default_rng(seed)
+    out = []
+    for k in range(count):
+        n = int(rng.integers(2, 24))
+        out.append(_random_qp(rng, n, n + int(rng.integers(1, 20)), infeasible=(k % 6 == 5)))
+    return out
+
+
+def test_generic_qp_matches_oracle_on_host_build(hostemu_lib, orc):
+    ctx = runtime.Context(0, hostemu_lib)
+    same, tot = _check_batch(ctx, orc, _qps(3))
+    assert same >= tot - 4        # identical ADMM history for (nearly) all: different linear algebra, same algorithm
+    ctx.close()
+
+
+def test_generic_qp_warm_start_and_trajectory_qp(hostemu_lib, orc):
+    """(i) osqp_warm_start through the boundary; (ii) a real trajectory QP (config 0's first QP, exported by the device path
+    in reference layout) solved through the generic entry gives the term-structured solver's answer"""
+    ctx = runtime.Context(0, hostemu_lib)
+    q = _qps(5, 1)[0]
+    first = ctx.qp_solve_batched([q])[0]
+    q2 = dict(q, x_warm=first["x"], y_warm=first["y"])
+    r2 = ctx.qp_solve_batched([q2])[0]
+    o2 = orc.qp_solve(q, warm_x=first["x"], warm_y=first["y"])
+    assert r2["info"].iter == o2["iters"] <= first["info"].iter and np.abs(r2["x"] - first["x"]).max() < 1e-6
+    pci, s, g = configs.config0()
+    x0 = configs.seeds_for(0, pci, s, g, 1)
+    pc.make_ctx_inputs(ctx, pci, x0)
+    ctx.convexify()
+    xq, cvx, rec = ctx.qp_solve()
+    e = ctx.export_csc(0)
+    r = ctx.qp_solve_batched([e])[0]
+    assert r["cvx_status"] == abi.CVX_SOLVED and r["info"].iter == rec[0].osqp_iter
+    assert np.abs(r["x"] - xq[0, :e["n"]]).max() < 1e-9
+    ctx.close()
+
+
+def test_generic_qp_rejects_malformed_input(hostemu_lib):
+    ctx = runtime.Context(0, hostemu_lib)
+    q = _qps(7, 1)[0]
+    bad = dict(q, l=q["u"] + 1.0)
+    with pytest.raises(runtime.TmxError, match="lower bound above upper bound"):
+        ctx.qp_solve_batched([bad])
+    bad = dict(q, A_i=q["A_i"] + 1000)
+    with pytest.raises(runtime.TmxError, match="row index out of range"):
+        ctx.qp_solve_batched([bad])
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_generic_qp_matches_oracle_on_device(gpu_ctx_factory, orc):
+    ctx = gpu_ctx_factory()
+    same, tot = _check_batch(ctx, orc, _qps(3) + _qps(11, 20))
+    assert same >= tot - 8
+    pci, s, g = configs.config1()
+    x0 = configs.seeds_for(1, pci, s, g, 1)
+    pc.make_ctx_inputs(ctx, pci, x0)
+    ctx.convexify()
+    xq, cvx, rec = ctx.qp_solve()
+    e = ctx.export_csc(0)                     # n = 572, m = 876: the glass_upright trajectory QP through the dense generic path
+    r = ctx.qp_solve_batched([e])[0]
+    assert r["cvx_status"] == abi.CVX_SOLVED and np.abs(r["x"] - xq[0, :e["n"]]).max() < 1e-5
+    ctx.close()
+
+
+def _small_problems(orc, ctx):
+    """trajopt_sco/test/small-problems-unit.cpp:48-172 on the restated sco SQP; with a context every Model::optimize() is
+    solved by tmx_qp_solve_batched (the S1 boundary: host callbacks convexify, the device solves the QP)"""
+    import ctypes as C
+    FN = C.CFUNCTYPE(C.c_int, C.c_int, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                     C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                     C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                     C.POINTER(C.c_double), C.c_void_p)
+    calls = []
+
+    def backend(n, m, Pp, Pi, Px, q, Ap, Ai, Ax, l, u, xw, yw, rho, x, y, rho_final, user):
+        a = lambda p, k, dt: (np.ctypeslib.as_array(p, shape=(k,)).astype(dt) if k > 0 else np.zeros(0, dt))
+        nzP, nzA = int(Pp[n]), int(Ap[n])
+        qp = dict(n=n, m=m, P_p=a(Pp, n + 1, np.int64), P_i=a(Pi, nzP, np.int64), P_x=a(Px, nzP, np.float64), q=a(q, n, np.float64),
+                  A_p=a(Ap, n + 1, np.int64), A_i=a(Ai, nzA, np.int64), A_x=a(Ax, nzA, np.float64), l=a(l, m, np.float64), u=a(u, m, np.float64))
+        if bool(xw):
+            qp["x_warm"], qp["y_warm"] = a(xw, n, np.float64), a(yw, m, np.float64)
+        st = abi.default_osqp_settings()
+        st.rho = rho
+        r = ctx.qp_solve_batched([qp], st)[0]
+        for j in range(n):
+            x[j] = r["x"][j]
+        for i in range(m):
+            y[i] = r["y"][i]
+        rho_final[0] = r["info"].rho_final
+        calls.append(r["info"].osqp_status)
+        return r["info"].osqp_status
+
+    cb = FN(backend)
+    x = np.zeros((6, 3))
+    status, nqp = np.zeros(6, np.int32), np.zeros(6, np.int32)
+    fn = orc.lib().orc_small_problems
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    total = fn(C.cast(cb, C.c_void_p) if ctx is not None else None, None, x.ctypes.data_as(C.c_void_p), status.ctypes.data_as(C.c_void_p),
+               nqp.ctypes.data_as(C.c_void_p))
+    assert total > 0 and (ctx is None or len(calls) == total)
+    return x, status, nqp
+
+
+SMALL_EXPECT = [((0, 1, 2), 1e-3), ((1, 7, 2), 1e-2), ((1, 1), 1e-2), ((0, 0), 1e-2), ((1, 1), 1e-2), ((0, float(np.float32(3) ** 0.5)), 1e-2)]
+
+
+def _check_small(x, status):
+    for k, (sol, tol) in enumerate(SMALL_EXPECT):
+        assert status[k] == abi.OPT_CONVERGED, (k, status[k])
+        assert np.abs(x[k, :len(sol)] - np.array(sol)).max() < tol, (k, x[k])
+
+
+def test_small_problems_unit_with_the_generic_qp_backend_on_host_build(hostemu_lib, orc):
+    xo, so, no = _small_problems(orc, None)           # restated OSQP: the KAT itself
+    _check_small(xo, so)
+    ctx = runtime.Context(0, hostemu_lib)
+    xd, sd, nd = _small_problems(orc, ctx)            # every QP through tmx_qp_solve_batched
+    _check_small(xd, sd)
+    assert np.array_equal(sd, so) and np.abs(xd - xo).max() < 1e-5
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_small_problems_unit_with_the_generic_qp_backend_on_device(gpu_ctx_factory, orc):
+    ctx = gpu_ctx_factory()
+    xd, sd, nd = _small_problems(orc, ctx)
+    _check_small(xd, sd)
+    ctx.close()

@@ -63,6 +63,23 @@ class Term(C.Structure):
     ]
 
 
+class QpCsc(C.Structure):
+    """tmx_qp_csc — a QP in the CSC form OSQP's osqp_setup takes (include/tmx.h)"""
+    _fields_ = [
+        ("n", C.c_int32), ("m", C.c_int32),
+        ("P_p", C.POINTER(C.c_int64)), ("P_i", C.POINTER(C.c_int64)), ("P_x", C.POINTER(C.c_double)),
+        ("q", C.POINTER(C.c_double)),
+        ("A_p", C.POINTER(C.c_int64)), ("A_i", C.POINTER(C.c_int64)), ("A_x", C.POINTER(C.c_double)),
+        ("l", C.POINTER(C.c_double)), ("u", C.POINTER(C.c_double)),
+        ("x_warm", C.POINTER(C.c_double)), ("y_warm", C.POINTER(C.c_double)),
+    ]
+
+
+class QpInfo(C.Structure):
+    _fields_ = [("osqp_status", C.c_int32), ("iter", C.c_int32), ("rho_updates", C.c_int32), ("polish_status", C.c_int32),
+                ("rho_final", C.c_double), ("prim_res", C.c_double), ("dual_res", C.c_double)]
+
+
 class ProblemDesc(C.Structure):
     _fields_ = [
         ("n_dof", C.c_int32),

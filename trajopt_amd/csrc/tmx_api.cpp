@@ -1236,6 +1236,167 @@ tmx_status tmx_qp_solve(tmx_ctx* ctx, double* x_qp, int32_t* cvx_status, tmx_qp_
   return TMX_OK;
 }
 
+tmx_status tmx_qp_solve_batched(tmx_ctx* ctx, const tmx_qp_csc* qps, int32_t batch, const tmx_osqp_settings* settings, double* x,
+                                double* y, int32_t* cvx_status, tmx_qp_info* info, int32_t* active_flags)
+{
+  if (!ctx || !qps || batch < 1 || !x || !y)
+    return TMX_ERR_INVALID;
+  HIPCHK(hipSetDevice(ctx->device));
+  tmx_osqp_settings st;
+  if (settings)
+    st = *settings;
+  else
+    tmx_default_osqp_settings(&st);
+  // pack the batch: one contiguous host image per array kind, offsets per problem
+  std::vector<GenQp> g((size_t)batch);
+  std::vector<long long> Pp, Pi, Ap, Ai;
+  std::vector<double> Px, Ax, q, l, u, xw, yw;
+  long long ows = 0;
+  for (int b = 0; b < batch; ++b)
+  {
+    const tmx_qp_csc& Q = qps[b];
+    if (Q.n < 1 || Q.m < 0 || !Q.P_p || !Q.q || !Q.A_p || (Q.m > 0 && (!Q.l || !Q.u)) || ((Q.x_warm == nullptr) != (Q.y_warm == nullptr)))
+    {
+      ctx->err = "tmx_qp_solve_batched: malformed tmx_qp_csc";
+      return TMX_ERR_INVALID;
+    }
+    if (Q.n > 4096 || Q.m > 16384)
+    {
+      ctx->err = "tmx_qp_solve_batched: QP too large for the generic (dense) path";
+      return TMX_ERR_UNSUPPORTED;
+    }
+    const long long nzP = Q.P_p[Q.n], nzA = Q.A_p[Q.n];
+    if (nzP < 0 || nzA < 0 || (nzP > 0 && (!Q.P_i || !Q.P_x)) || (nzA > 0 && (!Q.A_i || !Q.A_x)))
+    {
+      ctx->err = "tmx_qp_solve_batched: malformed CSC arrays";
+      return TMX_ERR_INVALID;
+    }
+    for (long long p = 0; p < nzP; ++p)
+      if (Q.P_i[p] < 0 || Q.P_i[p] >= Q.n)
+      {
+        ctx->err = "tmx_qp_solve_batched: P row index out of range";
+        return TMX_ERR_INVALID;
+      }
+    for (long long p = 0; p < nzA; ++p)
+      if (Q.A_i[p] < 0 || Q.A_i[p] >= Q.m)
+      {
+        ctx->err = "tmx_qp_solve_batched: A row index out of range";
+        return TMX_ERR_INVALID;
+      }
+    for (int i = 0; i < Q.m; ++i)
+      if (Q.l[i] > Q.u[i])
+      {
+        ctx->err = "tmx_qp_solve_batched: lower bound above upper bound (OSQP_DATA_VALIDATION_ERROR)";
+        return TMX_ERR_INVALID;
+      }
+    GenQp& gq = g[(size_t)b];
+    gq.n = Q.n;
+    gq.m = Q.m;
+    gq.oP = (long long)Pi.size();
+    gq.oA = (long long)Ai.size();
+    gq.oPp = (long long)Pp.size();
+    gq.oAp = (long long)Ap.size();
+    gq.ov_n = (long long)q.size();
+    gq.ov_m = (long long)l.size();
+    gq.ows = ows;
+    gq.warm = (Q.x_warm != nullptr && st.warm_starting) ? 1 : 0;
+    ows += (long long)((gen_ws_doubles(Q.n, Q.m) + 1) & ~(size_t)1);
+    Pp.insert(Pp.end(), Q.P_p, Q.P_p + Q.n + 1);
+    Ap.insert(Ap.end(), Q.A_p, Q.A_p + Q.n + 1);
+    Pi.insert(Pi.end(), Q.P_i, Q.P_i + nzP);
+    Px.insert(Px.end(), Q.P_x, Q.P_x + nzP);
+    Ai.insert(Ai.end(), Q.A_i, Q.A_i + nzA);
+    Ax.insert(Ax.end(), Q.A_x, Q.A_x + nzA);
+    q.insert(q.end(), Q.q, Q.q + Q.n);
+    l.insert(l.end(), Q.l, Q.l + Q.m);
+    u.insert(u.end(), Q.u, Q.u + Q.m);
+    for (int j = 0; j < Q.n; ++j)
+      xw.push_back(Q.x_warm ? Q.x_warm[j] : 0.0);
+    for (int i = 0; i < Q.m; ++i)
+      yw.push_back(Q.y_warm ? Q.y_warm[i] : 0.0);
+  }
+  if ((size_t)ows * sizeof(double) > ((size_t)16 << 30))
+  {
+    ctx->err = "tmx_qp_solve_batched: dense workspace of the batch exceeds 16 GiB";
+    return TMX_ERR_UNSUPPORTED;
+  }
+  std::vector<void*> pool;
+  GenData D{};
+  GenQp* d_g = nullptr;
+  tmx_status rc = TMX_OK;
+  auto up = [&](auto** dst, const auto& vec) { return rc == TMX_OK ? (rc = upload(ctx, pool, dst, vec)) : rc; };
+  long long *dPp = nullptr, *dPi = nullptr, *dAp = nullptr, *dAi = nullptr;
+  double *dPx = nullptr, *dAx = nullptr, *dq = nullptr, *dl = nullptr, *du = nullptr, *dxw = nullptr, *dyw = nullptr;
+  up(&d_g, g);
+  up(&dPp, Pp);
+  up(&dPi, Pi);
+  up(&dAp, Ap);
+  up(&dAi, Ai);
+  up(&dPx, Px);
+  up(&dAx, Ax);
+  up(&dq, q);
+  up(&dl, l);
+  up(&du, u);
+  up(&dxw, xw);
+  up(&dyw, yw);
+  int* d_flags = nullptr;
+  if (rc == TMX_OK)
+    rc = dalloc(ctx, pool, &D.x_out, q.size());
+  if (rc == TMX_OK)
+    rc = dalloc(ctx, pool, &D.y_out, l.size());
+  if (rc == TMX_OK)
+    rc = dalloc(ctx, pool, &d_flags, l.size());
+  if (rc == TMX_OK)
+    rc = dalloc(ctx, pool, &D.info, (size_t)batch);
+  if (rc == TMX_OK)
+    rc = dalloc(ctx, pool, &D.ws, (size_t)ows);
+  if (rc != TMX_OK)
+  {
+    free_pool(pool);
+    return rc;
+  }
+  D.P_p = dPp;
+  D.P_i = dPi;
+  D.A_p = dAp;
+  D.A_i = dAi;
+  D.P_x = dPx;
+  D.A_x = dAx;
+  D.q = dq;
+  D.l = dl;
+  D.u = du;
+  D.xw = dxw;
+  D.yw = dyw;
+  D.flags_out = d_flags;
+  TMX_LAUNCH(k_qp_generic, batch, ctx->nt_qp > 1 ? 256 : 1, 320 * sizeof(double), ctx->stream, d_g, D, st);
+  hipError_t e = hipStreamSynchronize(ctx->stream);
+  if (e == hipSuccess)
+    e = hipGetLastError();
+  std::vector<tmx_qp_info> hinfo((size_t)batch);
+  if (e == hipSuccess)
+    e = hipMemcpy(x, D.x_out, sizeof(double) * q.size(), hipMemcpyDeviceToHost);
+  if (e == hipSuccess && !l.empty())
+    e = hipMemcpy(y, D.y_out, sizeof(double) * l.size(), hipMemcpyDeviceToHost);
+  if (e == hipSuccess)
+    e = hipMemcpy(hinfo.data(), D.info, sizeof(tmx_qp_info) * batch, hipMemcpyDeviceToHost);
+  if (e == hipSuccess && active_flags && !l.empty())
+    e = hipMemcpy(active_flags, d_flags, sizeof(int) * l.size(), hipMemcpyDeviceToHost);
+  free_pool(pool);
+  if (e != hipSuccess)
+  {
+    ctx->err = std::string("tmx_qp_solve_batched: ") + hipGetErrorString(e);
+    return TMX_ERR_DEVICE;
+  }
+  for (int b = 0; b < batch; ++b)
+  {
+    const int s = hinfo[(size_t)b].osqp_status;
+    if (info)
+      info[b] = hinfo[(size_t)b];
+    if (cvx_status)  // OSQPModel::optimize, osqp_interface.cpp:565-614
+      cvx_status[b] = (s == 1 || s == 2) ? TMX_CVX_SOLVED : ((s == 3 || s == 4 || s == 5 || s == 6) ? TMX_CVX_INFEASIBLE : TMX_CVX_FAILED);
+  }
+  return TMX_OK;
+}
+
 tmx_status tmx_qp_duals(tmx_ctx* ctx, double* y_qp)
 {
   if (!ctx || !y_qp)

@@ -2,6 +2,7 @@
 // fill the 256 CUs; problems are independent so no inter-workgroup communication exists anywhere on the path).
 #pragma once
 #include "tmx_solve.h"
+#include "tmx_generic.h"
 
 // scratch of the term / structure kernels: dynamic LDS, or this workgroup's slice of Bt->ws_hbm for long-horizon
 // problems whose scratch exceeds the LDS (the LDS-resident QP kernels never take this branch: they use smem directly)

@@ -269,7 +269,7 @@ TMX_DEVFN bool lvs_contact(const DevProblem* P, const double* q0, const double* 
     const double e[3] = { cb[0] - ca[0], cb[1] - ca[1], cb[2] - ca[2] };
     const double ee = e[0] * e[0] + e[1] * e[1] + e[2] * e[2];
     const double eo = e[0] * (P->ob_center[3 * o + 0] - ca[0]) + e[1] * (P->ob_center[3 * o + 1] - ca[1]) + e[2] * (P->ob_center[3 * o + 2] - ca[2]);
-    tau = (ee > 0) ? eo / ee : 0.0;
+    tau = (ee > 1e-24) ? eo / ee : 0.0;  // a link that does not move over the sub-segment: contact at its start
     tau = tau < 0.0 ? 0.0 : (tau > 1.0 ? 1.0 : tau);
     for (int rr = 0; rr < 3; ++rr)
       p[rr] = ca[rr] + tau * e[rr];

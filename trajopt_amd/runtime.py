@@ -34,6 +34,8 @@ _SIGS = {
     "tmx_export_csc": ([C.c_void_p, C.c_int32] + [C.POINTER(C.c_int32)] * 4 + [C.c_void_p] * 9, C.c_int),
     "tmx_qp_dims": ([C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)], C.c_int),
     "tmx_qp_solve": ([C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p], C.c_int),
+    "tmx_qp_solve_batched": ([C.c_void_p, C.POINTER(abi.QpCsc), C.c_int32, C.POINTER(abi.OsqpSettings), C.c_void_p, C.c_void_p,
+                              C.c_void_p, C.POINTER(abi.QpInfo), C.c_void_p], C.c_int),
     "tmx_qp_active_set": ([C.c_void_p, C.c_void_p], C.c_int),
     "tmx_qp_duals": ([C.c_void_p, C.c_void_p], C.c_int),
     "tmx_argmin": ([C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_double)], C.c_int),
@@ -183,6 +185,44 @@ class Context:
         rec = (abi.QpRecord * self.B)()
         self._chk(self.lib.tmx_qp_solve(self.h, _ptr(xq), _ptr(cvx), rec))
         return xq, cvx, rec
+
+    def qp_solve_batched(self, qps, settings: abi.OsqpSettings = None):
+        """sco::Model::optimize / trajopt_sqp::QPSolver::solve for a batch of QPs in CSC form (tmx_qp_solve_batched).
+        qps: list of dicts with n, m, P_p, P_i, P_x, q, A_p, A_i, A_x, l, u and optionally x_warm, y_warm.
+        Returns a list of dicts x, y, cvx_status, info (abi.QpInfo), active."""
+        B = len(qps)
+        arr = (abi.QpCsc * B)()
+        keep = []
+
+        def _a(v, dt):
+            a = np.ascontiguousarray(v, dtype=dt)
+            keep.append(a)
+            return a
+
+        for b, q in enumerate(qps):
+            c = arr[b]
+            c.n, c.m = int(q["n"]), int(q["m"])
+            for k, dt, ct in (("P_p", np.int64, C.c_int64), ("P_i", np.int64, C.c_int64), ("P_x", np.float64, C.c_double),
+                              ("q", np.float64, C.c_double), ("A_p", np.int64, C.c_int64), ("A_i", np.int64, C.c_int64),
+                              ("A_x", np.float64, C.c_double), ("l", np.float64, C.c_double), ("u", np.float64, C.c_double)):
+                setattr(c, k, _a(q[k], dt).ctypes.data_as(C.POINTER(ct)))
+            if q.get("x_warm") is not None:
+                c.x_warm = _a(q["x_warm"], np.float64).ctypes.data_as(C.POINTER(C.c_double))
+                c.y_warm = _a(q["y_warm"], np.float64).ctypes.data_as(C.POINTER(C.c_double))
+        ns, ms = [int(q["n"]) for q in qps], [int(q["m"]) for q in qps]
+        x, y = np.zeros(max(1, sum(ns))), np.zeros(max(1, sum(ms)))
+        act = np.zeros(max(1, sum(ms)), np.int32)
+        cvx = np.zeros(B, np.int32)
+        info = (abi.QpInfo * B)()
+        self._chk(self.lib.tmx_qp_solve_batched(self.h, arr, B, C.byref(settings) if settings is not None else None, _ptr(x), _ptr(y),
+                                                _ptr(cvx), info, _ptr(act)))
+        out, on, om = [], 0, 0
+        for b in range(B):
+            out.append(dict(x=x[on:on + ns[b]].copy(), y=y[om:om + ms[b]].copy(), cvx_status=int(cvx[b]), info=info[b],
+                            active=act[om:om + ms[b]].copy()))
+            on += ns[b]
+            om += ms[b]
+        return out
 
     def qp_duals(self):
         """dual solution of the last qp_solve() / SQP step, reference row order: [B][m_max]"""
