@@ -1,0 +1,389 @@
+#include "optimizers_mi355x.hpp"
+
+#include <trajopt_common/macros.h>
+#include <tesseract/environment/environment.h>
+#include <tesseract/kinematics/joint_group.h>
+#include <tesseract/scene_graph/graph.h>
+#include <tesseract/scene_graph/joint.h>
+#include <tesseract/scene_graph/link.h>
+#include <tesseract/geometry/impl/sphere.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace trajopt
+{
+namespace
+{
+void toRowMajor34(const Eigen::Isometry3d& T, double out[12])
+{
+  for (int r = 0; r < 3; ++r)
+  {
+    for (int c = 0; c < 3; ++c)
+      out[4 * r + c] = T.linear()(r, c);
+    out[4 * r + 3] = T.translation()(r);
+  }
+}
+tmx_term blankTerm()
+{
+  tmx_term t;
+  std::memset(&t, 0, sizeof(t));
+  return t;
+}
+bool allZero(const DblVec& v) { return std::all_of(v.begin(), v.end(), [](double x) { return std::abs(x) < 1e-5; }); }
+void fill(double* dst, const DblVec& src, std::size_t n, const char* what)
+{
+  if (src.size() != n)
+    PRINT_AND_THROW(std::string("wrong number of values in ") + what);
+  std::copy(src.begin(), src.end(), dst);
+}
+
+// serial chain of the manipulator from the scene graph: per active joint the fixed transform from the previous moving link
+// to the joint frame (folding the fixed joints in between), its axis and type
+void lowerKinematics(const ProblemConstructionInfo& pci, LoweredProblem& out)
+{
+  const auto& kin = *pci.kin;
+  const auto graph = pci.env->getSceneGraph();
+  const std::vector<std::string> joint_names = kin.getJointNames();
+  const auto n_dof = static_cast<int>(kin.numJoints());
+  if (n_dof > TMX_MAX_DOF)
+    PRINT_AND_THROW("manipulator has more joints than TMX_MAX_DOF");
+  tmx_problem_desc& d = out.desc;
+  d.n_dof = n_dof;
+  const Eigen::MatrixX2d limits = kin.getLimits().joint_limits;
+  const Eigen::VectorXd zeros = Eigen::VectorXd::Zero(n_dof);
+  const tesseract::common::TransformMap tf0 = pci.env->getState(joint_names, zeros).link_transforms;
+  Eigen::Isometry3d prev_link = Eigen::Isometry3d::Identity();  // world
+  for (int k = 0; k < n_dof; ++k)
+  {
+    const auto joint = graph->getJoint(joint_names[static_cast<std::size_t>(k)]);
+    tmx_joint& j = d.joints[k];
+    switch (joint->type)
+    {
+      case tesseract::scene_graph::JointType::REVOLUTE:
+      case tesseract::scene_graph::JointType::CONTINUOUS:
+        j.type = 0;
+        break;
+      case tesseract::scene_graph::JointType::PRISMATIC:
+        j.type = 1;
+        break;
+      default:
+        PRINT_AND_THROW("joint type of " + joint->getName() + " is not lowered by the device path");
+    }
+    // at q = 0 the child link frame coincides with the joint frame
+    const Eigen::Isometry3d joint_frame = tf0.at(joint->parent_link_name) * joint->parent_to_joint_origin_transform;
+    toRowMajor34(prev_link.inverse() * joint_frame, j.origin);
+    for (int a = 0; a < 3; ++a)
+      j.axis[a] = joint->axis(a);
+    d.joint_lower[k] = limits(k, 0);
+    d.joint_upper[k] = limits(k, 1);
+    prev_link = tf0.at(joint->child_link_name);
+    // link spheres: sphere collision geometry of every link rigidly attached to this moving link
+    for (const auto& link_name : kin.getActiveLinkNames())
+    {
+      // the closest moving ancestor of link_name is joint k's child iff no later active joint lies on its path to the root
+      const auto link = graph->getLink(link_name);
+      std::string cur = link_name;
+      int owner = -1;
+      while (owner < 0)
+      {
+        const auto in = graph->getInboundJoints(cur);
+        if (in.empty())
+          break;
+        const auto it = std::find(joint_names.begin(), joint_names.end(), in.front()->getName());
+        if (it != joint_names.end())
+          owner = static_cast<int>(it - joint_names.begin());
+        else
+          cur = in.front()->parent_link_name;
+      }
+      if (owner != k)
+        continue;
+      for (const auto& col : link->collision)
+      {
+        if (col->geometry->getType() != tesseract::geometry::GeometryType::SPHERE)
+          PRINT_AND_THROW("collision geometry of link " + link_name + " is not a sphere: not lowered by the device path");
+        const auto sphere = std::static_pointer_cast<const tesseract::geometry::Sphere>(col->geometry);
+        const Eigen::Vector3d c = (prev_link.inverse() * tf0.at(link_name) * col->origin).translation();
+        tmx_link_sphere s{};
+        s.link = k;
+        s.center[0] = c.x();
+        s.center[1] = c.y();
+        s.center[2] = c.z();
+        s.radius = sphere->getRadius();
+        out.link_spheres.push_back(s);
+      }
+    }
+  }
+  toRowMajor34(Eigen::Isometry3d::Identity(), d.base);
+  toRowMajor34(Eigen::Isometry3d::Identity(), d.tool);
+  // static obstacles: sphere collision geometry of the links the manipulator does not move
+  const std::vector<std::string> active = kin.getActiveLinkNames();
+  for (const auto& link : graph->getLinks())
+  {
+    if (std::find(active.begin(), active.end(), link->getName()) != active.end())
+      continue;
+    for (const auto& col : link->collision)
+    {
+      if (col->geometry->getType() != tesseract::geometry::GeometryType::SPHERE)
+        PRINT_AND_THROW("collision geometry of link " + link->getName() + " is not a sphere: not lowered by the device path");
+      const auto sphere = std::static_pointer_cast<const tesseract::geometry::Sphere>(col->geometry);
+      const Eigen::Vector3d c = (tf0.at(link->getName()) * col->origin).translation();
+      tmx_obstacle_sphere o{};
+      o.center[0] = c.x();
+      o.center[1] = c.y();
+      o.center[2] = c.z();
+      o.radius = sphere->getRadius();
+      out.obstacles.push_back(o);
+    }
+  }
+}
+
+void lowerTerm(const ProblemConstructionInfo& pci, const TermInfo& ti, bool is_cost, const TrajArray& init_traj, int max_substates,
+               LoweredProblem& out)
+{
+  const int n_steps = pci.basic_info.n_steps;
+  const auto D = static_cast<std::size_t>(pci.kin->numJoints());
+  auto clampSteps = [n_steps](int& first, int& last) {  // JointVelTermInfo::hatch, problem_description.cpp:1212-1226
+    if ((n_steps - 2) <= first)
+      first = n_steps - 2;
+    if ((n_steps - 1) <= last)
+      last = n_steps - 1;
+    if (last == first)
+      last += 1;
+    if (last < first)
+      std::swap(first, last);
+  };
+  tmx_term t = blankTerm();
+  t.is_constraint = is_cost ? 0 : 1;
+  std::vector<int32_t> fixed;
+  std::vector<std::string> names{ ti.name };
+  if (static_cast<bool>(ti.term_type & TermType::TT_USE_TIME))
+    PRINT_AND_THROW(ti.name + ": time-parameterised terms (TT_USE_TIME) are not lowered by the device path");
+  if (const auto* jp = dynamic_cast<const JointPosTermInfo*>(&ti))
+  {
+    DblVec up = jp->upper_tols.empty() ? DblVec(D, 0) : jp->upper_tols, lo = jp->lower_tols.empty() ? DblVec(D, 0) : jp->lower_tols;
+    const bool zero = allZero(up) && allZero(lo);  // :1113-1116
+    t.kind = is_cost ? (zero ? TMX_TERM_JOINT_POS_EQ_COST : TMX_TERM_JOINT_POS_INEQ_COST) :
+                       (zero ? TMX_TERM_JOINT_POS_EQ_CNT : TMX_TERM_JOINT_POS_INEQ_CNT);
+    t.first_step = jp->first_step;
+    t.last_step = jp->last_step;
+    fill(t.coeffs, jp->coeffs.size() == 1 ? DblVec(D, jp->coeffs[0]) : jp->coeffs, D, "coeffs");
+    fill(t.targets, jp->targets, D, "targets");
+    fill(t.upper_tols, up, D, "upper_tols");
+    fill(t.lower_tols, lo, D, "lower_tols");
+  }
+  else if (const auto* jv = dynamic_cast<const JointVelTermInfo*>(&ti))
+  {
+    DblVec up = jv->upper_tols.empty() ? DblVec(D, 0) : jv->upper_tols, lo = jv->lower_tols.empty() ? DblVec(D, 0) : jv->lower_tols;
+    const bool zero = allZero(up) && allZero(lo);
+    t.kind = is_cost ? (zero ? TMX_TERM_JOINT_VEL_COST : TMX_TERM_JOINT_VEL_INEQ_COST) :
+                       (zero ? TMX_TERM_JOINT_VEL_EQ_CNT : TMX_TERM_JOINT_VEL_INEQ_CNT);
+    int first = jv->first_step, last = jv->last_step;
+    clampSteps(first, last);
+    t.first_step = first;
+    t.last_step = last;
+    fill(t.coeffs, jv->coeffs.size() == 1 ? DblVec(D, jv->coeffs[0]) : jv->coeffs, D, "coeffs");
+    fill(t.targets, jv->targets, D, "targets");
+    fill(t.upper_tols, up, D, "upper_tols");
+    fill(t.lower_tols, lo, D, "lower_tols");
+  }
+  else if (const auto* cp = dynamic_cast<const CartPoseTermInfo*>(&ti))
+  {
+    if (cp->error_function != nullptr || cp->lower_tolerance.size() != 0 || cp->upper_tolerance.size() != 0)
+      PRINT_AND_THROW(ti.name + ": CartPose tolerances / custom error functions are not lowered by the device path");
+    const auto tip = pci.kin->getActiveLinkNames().back();
+    if (cp->source_frame != tip)
+      PRINT_AND_THROW(ti.name + ": the source frame must be the manipulator's tip link (one tool frame per problem)");
+    if (pci.kin->isActiveLinkName(cp->target_frame))
+      PRINT_AND_THROW(ti.name + ": a moving target frame is the reference's DynamicCartPose term: not lowered");
+    t.kind = TMX_TERM_CART_POSE;
+    t.first_step = t.last_step = cp->timestep;
+    for (int i = 0; i < 3; ++i)
+    {
+      t.coeffs[i] = cp->pos_coeffs(i);
+      t.coeffs[3 + i] = cp->rot_coeffs(i);
+    }
+    toRowMajor34(pci.env->getLinkTransform(cp->target_frame) * cp->target_frame_offset, t.target_pose);
+    toRowMajor34(cp->source_frame_offset, out.desc.tool);  // tcp offset on the tip link
+  }
+  else if (const auto* col = dynamic_cast<const CollisionTermInfo*>(&ti))
+  {
+    if (!col->config.enabled)
+      return;
+    const auto type = col->config.collision_check_config.type;
+    t.kind = is_cost ? TMX_TERM_COLLISION_COST : TMX_TERM_COLLISION_CNT;
+    t.first_step = col->first_step;
+    t.last_step = col->last_step;
+    t.margin = col->config.contact_manager_config.default_margin.value_or(0.0);
+    t.coeff = col->config.collision_coeff_data.getCollisionCoeff("", "");  // default coefficient; per-pair overrides throw below
+    if (!col->config.collision_coeff_data.getPairsWithZeroCoeff().empty())
+      PRINT_AND_THROW(ti.name + ": per-pair collision coefficients are not lowered by the device path");
+    t.buffer = col->config.collision_margin_buffer;
+    t.evaluator_type = static_cast<int32_t>(type);
+    t.longest_valid_segment_length = col->config.collision_check_config.longest_valid_segment_length;
+    t.max_substates = max_substates;
+    if (t.evaluator_type >= 2 && t.max_substates <= 0)
+    {
+      double dmax = 0.0;
+      for (Eigen::Index i = 0; i + 1 < init_traj.rows(); ++i)
+        dmax = std::max(dmax, (init_traj.row(i + 1) - init_traj.row(i)).norm());
+      t.max_substates = static_cast<int32_t>(
+          std::min(64.0, std::max(2.0, std::ceil(1.5 * dmax / std::max(t.longest_valid_segment_length, 1e-9)) + 1.0)));
+    }
+    fixed.assign(col->fixed_steps.begin(), col->fixed_steps.end());
+    names.clear();
+    if (t.evaluator_type >= 2)
+      for (int i = t.first_step; i < t.last_step; ++i)
+        names.push_back(ti.name + "_" + std::to_string(i));
+    else
+      for (int i = t.first_step; i <= t.last_step; ++i)
+        if (std::find(fixed.begin(), fixed.end(), i) == fixed.end())
+          names.push_back(ti.name + "_" + std::to_string(i));
+  }
+  else
+    PRINT_AND_THROW("term \"" + ti.name + "\" has a TermInfo class the device path does not lower (UserDefinedTermInfo, "
+                    "DynamicCartPose, CartVel, JointAcc, JointJerk, TotalTime, AvoidSingularity): solve it with the reference's "
+                    "BasicTrustRegionSQP, or with its QPs on the device through HipBatchedAdmmModel");
+  auto& dst = is_cost ? out.cost_names : out.cnt_names;
+  dst.insert(dst.end(), names.begin(), names.end());
+  out.terms.push_back(t);
+  out.term_fixed_steps.push_back(fixed);
+}
+}  // namespace
+
+void LoweredProblem::finalize()
+{
+  for (std::size_t k = 0; k < terms.size(); ++k)
+  {
+    terms[k].n_fixed_steps = static_cast<int32_t>(term_fixed_steps[k].size());
+    terms[k].fixed_steps = term_fixed_steps[k].empty() ? nullptr : term_fixed_steps[k].data();
+  }
+  desc.n_link_spheres = static_cast<int32_t>(link_spheres.size());
+  desc.link_spheres = link_spheres.data();
+  desc.n_obstacles = static_cast<int32_t>(obstacles.size());
+  desc.obstacles = obstacles.data();
+  desc.n_fixed_steps = static_cast<int32_t>(fixed_steps.size());
+  desc.fixed_steps = fixed_steps.data();
+  desc.n_fixed_dofs = static_cast<int32_t>(fixed_dofs.size());
+  desc.fixed_dofs = fixed_dofs.data();
+  desc.n_terms = static_cast<int32_t>(terms.size());
+  desc.terms = terms.data();
+}
+
+LoweredProblem lowerProblem(const ProblemConstructionInfo& pci, const TrajArray& init_traj, int max_substates)
+{
+  if (pci.basic_info.use_time)
+    PRINT_AND_THROW("basic_info.use_time: time-parameterised problems are not lowered by the device path");
+  LoweredProblem out;
+  out.desc.n_steps = pci.basic_info.n_steps;
+  lowerKinematics(pci, out);
+  out.fixed_steps.assign(pci.basic_info.fixed_timesteps.begin(), pci.basic_info.fixed_timesteps.end());
+  out.fixed_dofs.assign(pci.basic_info.fixed_dofs.begin(), pci.basic_info.fixed_dofs.end());
+  for (const auto& ci : pci.cost_infos)
+    lowerTerm(pci, *ci, true, init_traj, max_substates, out);
+  for (const auto& ci : pci.cnt_infos)
+    lowerTerm(pci, *ci, false, init_traj, max_substates, out);
+  out.finalize();
+  return out;
+}
+}  // namespace trajopt
+
+namespace sco
+{
+namespace
+{
+tmx_sqp_params toParams(const BasicTrustRegionSQPParameters& p)
+{
+  tmx_sqp_params o;
+  tmx_default_sqp_params(&o);
+  o.improve_ratio_threshold = p.improve_ratio_threshold;
+  o.min_trust_box_size = p.min_trust_box_size;
+  o.min_approx_improve = p.min_approx_improve;
+  o.min_approx_improve_frac = p.min_approx_improve_frac;
+  o.max_iter = static_cast<int32_t>(p.max_iter);
+  o.max_qp_solver_failures = static_cast<int32_t>(p.max_qp_solver_failures);
+  o.trust_shrink_ratio = p.trust_shrink_ratio;
+  o.trust_expand_ratio = p.trust_expand_ratio;
+  o.cnt_tolerance = p.cnt_tolerance;
+  o.max_merit_coeff_increases = p.max_merit_coeff_increases;
+  o.merit_coeff_increase_ratio = p.merit_coeff_increase_ratio;
+  o.initial_merit_error_coeff = p.initial_merit_error_coeff;
+  o.inflate_constraints_individually = p.inflate_constraints_individually ? 1 : 0;
+  o.trust_box_size = p.trust_box_size;
+  return o;
+}
+}  // namespace
+
+BasicTrustRegionSQPBatchedHip::BasicTrustRegionSQPBatchedHip(const std::shared_ptr<trajopt::TrajOptProb>& prob,
+                                                             const trajopt::ProblemConstructionInfo& pci, int device)
+  : BasicTrustRegionSQP(prob), lowered_(trajopt::lowerProblem(pci, prob->GetInitTraj()))
+{
+  if (tmx_create(device, &ctx_) != TMX_OK)
+    PRINT_AND_THROW("BasicTrustRegionSQPBatchedHip: no usable HIP device (there is no CPU fallback behind this optimizer)");
+}
+
+BasicTrustRegionSQPBatchedHip::~BasicTrustRegionSQPBatchedHip() { tmx_destroy(ctx_); }
+
+void BasicTrustRegionSQPBatchedHip::initializeBatch(const std::vector<DblVec>& seeds)
+{
+  const auto n = static_cast<std::size_t>(lowered_.desc.n_steps) * static_cast<std::size_t>(lowered_.desc.n_dof);
+  for (const DblVec& s : seeds)
+    if (s.size() != n)
+      PRINT_AND_THROW("initialization vector has wrong length");  // Optimizer::initialize, optimizers.cpp:127-136
+  seeds_ = seeds;
+  if (!seeds_.empty())
+    initialize(seeds_.front());
+}
+
+void BasicTrustRegionSQPBatchedHip::attachCommunicator(void* nccl_comm, long global_offset)
+{
+  global_offset_ = global_offset;
+  if (tmx_attach_nccl(ctx_, nccl_comm) != TMX_OK)
+    PRINT_AND_THROW(tmx_last_error(ctx_));
+}
+
+OptStatus BasicTrustRegionSQPBatchedHip::optimize()
+{
+  if (seeds_.empty())
+    seeds_.push_back(results_.x);  // initialize(x) of the base class
+  const auto B = static_cast<int32_t>(seeds_.size());
+  const std::size_t n = seeds_.front().size();
+  const tmx_sqp_params sp = toParams(param_);
+  if (tmx_problem_upload(ctx_, &lowered_.desc, &sp, nullptr) != TMX_OK)
+    PRINT_AND_THROW(tmx_last_error(ctx_));
+  DblVec flat(static_cast<std::size_t>(B) * n);
+  for (int32_t b = 0; b < B; ++b)
+    std::copy(seeds_[static_cast<std::size_t>(b)].begin(), seeds_[static_cast<std::size_t>(b)].end(), flat.begin() + b * static_cast<long>(n));
+  if (tmx_batch_set_x0(ctx_, flat.data(), B) != TMX_OK || tmx_sqp_run(ctx_, 0, nullptr) != TMX_OK)
+    PRINT_AND_THROW(tmx_last_error(ctx_));
+  std::vector<int32_t> status(static_cast<std::size_t>(B)), nfe(status.size()), nqp(status.size());
+  DblVec cost(status.size());
+  int32_t n_costs = 0, n_cnts = 0;
+  tmx_term_counts(ctx_, &n_costs, &n_cnts, nullptr);
+  DblVec cost_vals(status.size() * static_cast<std::size_t>(n_costs)), cnt_viols(status.size() * static_cast<std::size_t>(n_cnts));
+  if (tmx_sqp_results(ctx_, flat.data(), status.data(), cost.data(), nfe.data(), nqp.data()) != TMX_OK ||
+      tmx_evaluate(ctx_, cost_vals.data(), cnt_viols.data()) != TMX_OK)
+    PRINT_AND_THROW(tmx_last_error(ctx_));
+  batch_results_.assign(status.size(), OptResults());
+  for (std::size_t b = 0; b < status.size(); ++b)
+  {
+    OptResults& r = batch_results_[b];
+    r.x.assign(flat.begin() + static_cast<long>(b * n), flat.begin() + static_cast<long>((b + 1) * n));
+    r.status = static_cast<OptStatus>(status[b]);
+    r.total_cost = cost[b];
+    r.cost_vals.assign(cost_vals.begin() + static_cast<long>(b) * n_costs, cost_vals.begin() + static_cast<long>(b + 1) * n_costs);
+    r.cnt_viols.assign(cnt_viols.begin() + static_cast<long>(b) * n_cnts, cnt_viols.begin() + static_cast<long>(b + 1) * n_cnts);
+    r.n_func_evals = nfe[b];
+    r.n_qp_solves = nqp[b];
+  }
+  int64_t best = -1;
+  double best_cost = 0;
+  if (tmx_argmin(ctx_, global_offset_, &best, &best_cost) != TMX_OK)
+    PRINT_AND_THROW(tmx_last_error(ctx_));
+  best_ = (best >= global_offset_ && best < global_offset_ + B) ? static_cast<long>(best - global_offset_) : -1;
+  results_ = batch_results_[static_cast<std::size_t>(best_ >= 0 ? best_ : 0)];
+  callCallbacks();  // "at exit" call of the reference (optimizers.cpp:978) on the reported seed
+  return results_.status;
+}
+}  // namespace sco
