@@ -169,9 +169,39 @@ typedef struct
   const int32_t* fixed_steps;
   const tmx_term* terms;           /* costs are hatched in list order, then constraints in list order   */
   int32_t n_fixed_dofs;            /* BasicInfo::fixed_dofs  trajopt/src/problem_description.cpp:510-530: the joint keeps its */
-  int32_t pad_;                    /* initial value at every timestep that is not already a fixed timestep              */
+  /* initial value at every timestep that is not already a fixed timestep                                         */
+  /* Which of the reference's two stacks the problem is run as (tmx_flavor): TMX_FLAVOR_SCO = trajopt + trajopt_sco
+     (BasicTrustRegionSQP, OSQPModel; everything above), TMX_FLAVOR_SQP = trajopt_ifopt + trajopt_sqp (BASELINE config 4):
+     TrajOptQPProblem's slack-column QP layout (trajopt_optimizers/trajopt_sqp/src/trajopt_qp_problem.cpp:29-36, 720-973),
+     TrustRegionSQPSolver (trust_region_sqp_solver.cpp:87-439), OSQPEigenSolver's call protocol (osqp_eigen_solver.cpp:50-326).
+     Term table in that flavour: TMX_TERM_JOINT_VEL_COST = trajopt_ifopt::JointVelConstraint as a kSquared cost set,
+     TMX_TERM_JOINT_POS_EQ_CNT = one JointPosConstraint per step as a constraint set, TMX_TERM_JOINT_POS_EQ_COST = the same as a
+     kAbsolute cost set, TMX_TERM_COLLISION_COST / _CNT with evaluator_type 2..4 = one segment collision constraint set per
+     segment as a kHinge cost / a constraint set (coefficient = collision coefficient).  fixed_steps / fixed_dofs and the other
+     term kinds are refused.  tmx_sqp_params: max_iter = SQPParameters::max_iterations (counts QP solves), trust_box_size =
+     initial_trust_box_size (trajopt_sqp/include/trajopt_sqp/types.h:99-141).                                      */
+  int32_t flavor;
   const int32_t* fixed_dofs;
 } tmx_problem_desc;
+
+typedef enum
+{
+  TMX_FLAVOR_SCO = 0,
+  TMX_FLAVOR_SQP = 1
+} tmx_flavor;
+
+/* trajopt_sqp::SQPStatus — trajopt_optimizers/trajopt_sqp/include/trajopt_sqp/types.h:216-225 (same numeric values); the
+   status array of tmx_sqp_results holds these for TMX_FLAVOR_SQP problems */
+typedef enum
+{
+  TMX_SQP_RUNNING = 0,
+  TMX_SQP_CONVERGED = 1,
+  TMX_SQP_ITERATION_LIMIT = 2,
+  TMX_SQP_PENALTY_ITERATION_LIMIT = 3,
+  TMX_SQP_TIME_LIMIT = 4,
+  TMX_SQP_QP_SOLVE_FAILED = 5,
+  TMX_SQP_STOPPED_BY_CALLBACK = 6
+} tmx_sqp_status;
 
 /* sco::BasicTrustRegionSQPParameters — trajopt_sco/include/trajopt_sco/optimizers.hpp:92-135 */
 typedef struct

@@ -9,6 +9,7 @@
 #include <cstring>
 
 #include "trajprob.hpp"
+#include "sqp_ifopt.hpp"
 
 using namespace orc;
 
@@ -309,6 +310,227 @@ int orc_fk_tool(const tmx_problem_desc* desc, const double* q, double* tf12)
   return 0;
 }
 int orc_num_threads() { return omp_get_max_threads(); }
+// ---- trajopt_ifopt / trajopt_sqp flavour (BASELINE config 4) -----------------------------------------------------------------
+namespace
+{
+struct Sqp2Problem
+{
+  std::shared_ptr<ifopt::Variables> vars;
+  std::shared_ptr<ifopt::TrajOptQPProblem> qp;
+};
+// the term table of a TMX_FLAVOR_SQP description as trajopt_ifopt constraint sets (include/tmx.h: tmx_problem_desc.flavor)
+Sqp2Problem buildSqp2(const tmx_problem_desc& d, const double* x0)
+{
+  const int T = d.n_steps, D = d.n_dof;
+  if (d.n_fixed_steps > 0 || d.n_fixed_dofs > 0)
+    throw std::runtime_error("fixed steps / dofs are not part of the trajopt_sqp flavour");
+  Sqp2Problem P;
+  P.vars = std::make_shared<ifopt::Variables>();
+  P.vars->x.assign(x0, x0 + T * D);
+  for (int i = 0; i < T; ++i)
+    for (int j = 0; j < D; ++j)
+      P.vars->bounds.emplace_back(d.joint_lower[j], d.joint_upper[j]);
+  auto var = [&](int t) {
+    ifopt::Var v;
+    v.vars = P.vars;
+    v.index = t * D;
+    v.n = D;
+    return v;
+  };
+  P.qp = std::make_shared<ifopt::TrajOptQPProblem>(P.vars);
+  auto chain = std::make_shared<Chain>(d);
+  auto scene = std::make_shared<Scene>();
+  for (int i = 0; i < d.n_link_spheres; ++i)
+    scene->link_spheres.push_back(d.link_spheres[i]);
+  for (int i = 0; i < d.n_obstacles; ++i)
+    scene->obstacles.push_back(d.obstacles[i]);
+  for (int k = 0; k < d.n_terms; ++k)
+  {
+    const tmx_term& tm = d.terms[k];
+    const ifopt::Vec coeffs(tm.coeffs, tm.coeffs + D), targets(tm.targets, tm.targets + D);
+    switch (tm.kind)
+    {
+      case TMX_TERM_JOINT_VEL_COST:
+      {
+        std::vector<ifopt::Var> vs;
+        for (int t = tm.first_step; t <= tm.last_step; ++t)
+          vs.push_back(var(t));
+        P.qp->addCostSet(std::make_shared<ifopt::JointVelConstraint>(targets, vs, coeffs, "joint_vel"), ifopt::CostPenaltyType::kSquared);
+        break;
+      }
+      case TMX_TERM_JOINT_POS_EQ_CNT:
+        for (int t = tm.first_step; t <= tm.last_step; ++t)
+          P.qp->addConstraintSet(std::make_shared<ifopt::JointPosConstraint>(targets, var(t), coeffs, "joint_pos_" + std::to_string(t)));
+        break;
+      case TMX_TERM_JOINT_POS_EQ_COST:
+        for (int t = tm.first_step; t <= tm.last_step; ++t)
+          P.qp->addCostSet(std::make_shared<ifopt::JointPosConstraint>(targets, var(t), coeffs, "joint_pos_" + std::to_string(t)),
+                           ifopt::CostPenaltyType::kAbsolute);
+        break;
+      case TMX_TERM_COLLISION_COST:
+      case TMX_TERM_COLLISION_CNT:
+      {
+        if (tm.evaluator_type < 2)
+          throw std::runtime_error("the trajopt_sqp flavour lowers the segment collision evaluators (evaluator_type 2..4) only");
+        for (int i = tm.first_step; i < tm.last_step; ++i)
+        {
+          const bool cur = std::find(tm.fixed_steps, tm.fixed_steps + tm.n_fixed_steps, i) != tm.fixed_steps + tm.n_fixed_steps;
+          const bool nxt = std::find(tm.fixed_steps, tm.fixed_steps + tm.n_fixed_steps, i + 1) != tm.fixed_steps + tm.n_fixed_steps;
+          LvsEvaluatorData ev;
+          ev.chain = chain;
+          ev.scene = scene;
+          ev.margin = tm.margin;
+          ev.coeff = tm.coeff;
+          ev.buffer = tm.buffer;
+          ev.lvs = tm.longest_valid_segment_length;
+          ev.cast = tm.evaluator_type != 2;
+          ev.fixed0 = cur;
+          ev.fixed1 = !cur && nxt;
+          ev.kmax = tm.max_substates < 2 ? 2 : tm.max_substates;
+          auto set = std::make_shared<ifopt::SegmentCollisionConstraint>(ev, var(i), var(i + 1), "collision_" + std::to_string(i));
+          if (tm.kind == TMX_TERM_COLLISION_COST)
+            P.qp->addCostSet(set, ifopt::CostPenaltyType::kHinge);
+          else
+            P.qp->addConstraintSet(set);
+        }
+        break;
+      }
+      default:
+        throw std::runtime_error("term kind not part of the trajopt_sqp flavour");
+    }
+  }
+  P.qp->setup();
+  return P;
+}
+void toSqpParams(const tmx_sqp_params* p, ifopt::SQPParameters& o)
+{
+  if (!p)
+    return;
+  o.improve_ratio_threshold = p->improve_ratio_threshold;
+  o.min_trust_box_size = p->min_trust_box_size;
+  o.min_approx_improve = p->min_approx_improve;
+  o.min_approx_improve_frac = p->min_approx_improve_frac;
+  o.max_iterations = p->max_iter;
+  o.max_qp_solver_failures = p->max_qp_solver_failures;
+  o.trust_shrink_ratio = p->trust_shrink_ratio;
+  o.trust_expand_ratio = p->trust_expand_ratio;
+  o.cnt_tolerance = p->cnt_tolerance;
+  o.max_merit_coeff_increases = p->max_merit_coeff_increases;
+  o.merit_coeff_increase_ratio = p->merit_coeff_increase_ratio;
+  o.initial_merit_error_coeff = p->initial_merit_error_coeff;
+  o.inflate_constraints_individually = p->inflate_constraints_individually != 0;
+  o.initial_trust_box_size = p->trust_box_size;
+}
+}  // namespace
+
+// TrustRegionSQPSolver::solve for each of B seeds; status = trajopt_sqp::SQPStatus, n_qp = overall_iteration
+int orc_sqp2_batch(const tmx_problem_desc* desc, const tmx_sqp_params* sqp, const tmx_osqp_settings* osqp, const double* x0, int B,
+                   int nthreads, double* x_out, int* status, double* total_cost, int* n_qp_solves, tmx_qp_record* records,
+                   int max_records, int* rec_counts, double* cost_vals, double* cnt_viols)
+{
+  const int TD = desc->n_steps * desc->n_dof;
+  int err = 0;
+#pragma omp parallel for schedule(dynamic) num_threads(nthreads > 0 ? nthreads : 1)
+  for (int b = 0; b < B; ++b)
+  {
+    try
+    {
+      Sqp2Problem P = buildSqp2(*desc, x0 + static_cast<std::size_t>(b) * TD);
+      ifopt::TrustRegionSQPSolver solver;
+      toSqpParams(sqp, solver.params);
+      solver.qp_solver.settings = toSettings(osqp);
+      std::vector<QpTrace> trace;
+      solver.qp_solver.trace = &trace;
+      solver.solve(*P.qp);
+      if (x_out)
+        std::memcpy(x_out + static_cast<std::size_t>(b) * TD, P.vars->x.data(), sizeof(double) * TD);
+      if (status)
+        status[b] = static_cast<int>(solver.status);
+      const ifopt::Vec costs = P.qp->getExactCosts(), viols = P.qp->getExactConstraintViolations();
+      if (total_cost)
+      {
+        double s = 0;
+        for (double c : costs)
+          s += c;
+        total_cost[b] = s;
+      }
+      if (cost_vals)
+        std::memcpy(cost_vals + static_cast<std::size_t>(b) * costs.size(), costs.data(), sizeof(double) * costs.size());
+      if (cnt_viols)
+        std::memcpy(cnt_viols + static_cast<std::size_t>(b) * viols.size(), viols.data(), sizeof(double) * viols.size());
+      if (n_qp_solves)
+        n_qp_solves[b] = solver.overall_iteration;
+      if (records && rec_counts)
+      {
+        rec_counts[b] = static_cast<int>(trace.size());
+        for (int k = 0; k < std::min<int>(static_cast<int>(trace.size()), max_records); ++k)
+          toRecord(trace[k], records[static_cast<std::size_t>(b) * max_records + k]);
+      }
+    }
+    catch (...)
+    {
+#pragma omp atomic write
+      err = 1;
+    }
+  }
+  return err;
+}
+// the first convexified QP of the trajopt_sqp flavour at x: sizes + dense-free CSC-like export for parity tests
+// (hessian / gradient / constraint matrix in row-major triplets, bounds), two-call protocol
+int orc_sqp2_first_qp(const tmx_problem_desc* desc, const tmx_sqp_params* sqp, const double* x, int* nv, int* nc, int* nnzH, int* nnzA,
+                      int* H_r, int* H_c, double* H_x, double* grad, int* A_r, int* A_c, double* A_x, double* lo, double* up,
+                      double* exact_costs, double* exact_viols, int* n_costs, int* n_cnts)
+{
+  try
+  {
+    Sqp2Problem P = buildSqp2(*desc, x);
+    ifopt::SQPParameters prm;
+    toSqpParams(sqp, prm);
+    P.qp->constraint_merit_coeff.assign(P.qp->merit_constraints.size(), prm.initial_merit_error_coeff);
+    P.qp->setBoxSize(ifopt::Vec(static_cast<std::size_t>(P.qp->getNumNLPVars()), prm.initial_trust_box_size));
+    P.qp->convexify();
+    *nv = P.qp->num_qp_vars;
+    *nc = P.qp->num_qp_cnts;
+    *nnzH = static_cast<int>(P.qp->hessian.nonZeros());
+    *nnzA = static_cast<int>(P.qp->constraint_matrix.nonZeros());
+    const ifopt::Vec costs = P.qp->getExactCosts(), viols = P.qp->getExactConstraintViolations();
+    if (n_costs)
+      *n_costs = static_cast<int>(costs.size());
+    if (n_cnts)
+      *n_cnts = static_cast<int>(viols.size());
+    if (exact_costs)
+      std::memcpy(exact_costs, costs.data(), sizeof(double) * costs.size());
+    if (exact_viols)
+      std::memcpy(exact_viols, viols.data(), sizeof(double) * viols.size());
+    if (!H_r)
+      return 0;
+    int k = 0;
+    for (int r = 0; r < P.qp->hessian.rows; ++r)
+      for (const auto& e : P.qp->hessian.r[static_cast<std::size_t>(r)])
+      {
+        H_r[k] = r;
+        H_c[k] = e.first;
+        H_x[k++] = e.second;
+      }
+    k = 0;
+    for (int r = 0; r < P.qp->constraint_matrix.rows; ++r)
+      for (const auto& e : P.qp->constraint_matrix.r[static_cast<std::size_t>(r)])
+      {
+        A_r[k] = r;
+        A_c[k] = e.first;
+        A_x[k++] = e.second;
+      }
+    std::memcpy(grad, P.qp->gradient.data(), sizeof(double) * P.qp->gradient.size());
+    std::memcpy(lo, P.qp->bounds_lower.data(), sizeof(double) * P.qp->bounds_lower.size());
+    std::memcpy(up, P.qp->bounds_upper.data(), sizeof(double) * P.qp->bounds_upper.size());
+    return 0;
+  }
+  catch (...)
+  {
+    return 1;
+  }
+}
+
 // S1 demonstration: the reference's trajopt_sco/test/small-problems-unit.cpp:48-172 (separable / non-separable quadratics,
 // Hock-Schittkowski TP1 / TP3 / TP6 / TP7 with CostFromFunc / ConstraintFromErrFunc callbacks on the HOST, as in the
 // reference) run by the restated BasicTrustRegionSQP with every Model::optimize() handed to `backend` (NULL = the restated

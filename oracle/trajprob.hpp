@@ -957,11 +957,10 @@ inline double linSpacedAt(long size, double low, double high, long i)
     return (i == 0) ? low : (high - static_cast<double>(size1 - i) * step);
   return (i == size1) ? high : (low + static_cast<double>(i) * step);
 }
-struct LvsEvaluator
+struct LvsEvaluatorData  // the contact model itself (shared by the sco terms below and the trajopt_ifopt constraint set)
 {
   std::shared_ptr<const Chain> chain;
   std::shared_ptr<const Scene> scene;
-  VarVector vars0, vars1;
   double margin, coeff, buffer, lvs;
   bool cast, fixed0, fixed1;
   int kmax;
@@ -1086,8 +1085,8 @@ struct LvsEvaluator
         }
       }
   }
-  // GetGradient(dofvals, contact, isTimestep1) for the (only) active link 0 + its share of the distance expression
-  void addEnd(AffExpr& dist, const Contact2& c, const DblVec& q, const VarVector& vars, bool isTimestep1) const
+  // GetGradient(dofvals, contact, isTimestep1) for the (only) active link 0: sg = scale * grad, sconst = scale * -(grad . q)
+  void endGradient(const Contact2& c, const DblVec& q, bool isTimestep1, DblVec& sg, double& sconst) const
   {
     const int D = chain->n_dof;
     const double scale = isTimestep1 ? c.cc_time : (1 - c.cc_time);
@@ -1100,7 +1099,7 @@ struct LvsEvaluator
       p[r] = link[c.link].t[r] + (lt.R[3 * r + 0] * c.p_local[0] + lt.R[3 * r + 1] * c.p_local[1] + lt.R[3 * r + 2] * c.p_local[2]);
     DblVec J(3 * D);
     chain->jacobianPoint(q.data(), c.link, p, J.data());
-    DblVec sg(D);
+    sg.assign(D, 0.0);
     double gq = 0;
     for (int k = 0; k < D; ++k)
     {
@@ -1108,8 +1107,19 @@ struct LvsEvaluator
       sg[k] = scale * g;
       gq += g * q[k];
     }
+    sconst = scale * -gq;
+  }
+};
+struct LvsEvaluator : public LvsEvaluatorData
+{
+  VarVector vars0, vars1;
+  void addEnd(AffExpr& dist, const Contact2& c, const DblVec& q, const VarVector& vars, bool isTimestep1) const
+  {
+    DblVec sg;
+    double sconst = 0;
+    endGradient(c, q, isTimestep1, sg, sconst);
     exprInc(dist, varDot(sg, vars));
-    exprInc(dist, scale * -gq);
+    exprInc(dist, sconst);
   }
   AffExprVector distExpressions(const DblVec& x, std::vector<Contact2>& cts) const
   {

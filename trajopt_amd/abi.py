@@ -98,7 +98,7 @@ class ProblemDesc(C.Structure):
         ("fixed_steps", C.POINTER(C.c_int32)),
         ("terms", C.POINTER(Term)),
         ("n_fixed_dofs", C.c_int32),
-        ("pad_", C.c_int32),
+        ("flavor", C.c_int32),
         ("fixed_dofs", C.POINTER(C.c_int32)),
     ]
 
