@@ -69,6 +69,48 @@ def sqp_active_sets(desc, x0, m_cap, sqp=None, osqp=None, max_qp=256):
     return [(flags[k, :ms[k]].copy(), y[k, :ms[k]].copy()) for k in range(min(nq.value, max_qp))]
 
 
+def sqp2_batch(desc, x0, sqp=None, osqp=None, nthreads=0, max_records=64):
+    """TrustRegionSQPSolver::solve (trajopt_sqp flavour) for every seed"""
+    from trajopt_amd import abi
+    x0 = np.ascontiguousarray(x0, dtype=np.float64)
+    B, TD = x0.shape[0], desc.n_steps * desc.n_dof
+    q = sqp2_first_qp(desc, x0[0], sqp)
+    nc, nn = len(q["exact_costs"]), len(q["exact_viols"])
+    x = np.zeros((B, TD))
+    status, nqp, cnts = np.zeros(B, np.int32), np.zeros(B, np.int32), np.zeros(B, np.int32)
+    cost, cv, vv = np.zeros(B), np.zeros((B, nc)), np.zeros((B, nn))
+    recs = (abi.QpRecord * (B * max_records))()
+    rc = lib().orc_sqp2_batch(C.byref(desc), C.byref(sqp) if sqp is not None else None, C.byref(osqp) if osqp is not None else None,
+                              _p(x0), B, nthreads if nthreads > 0 else (os.cpu_count() or 1), _p(x), _p(status, C.c_int), _p(cost),
+                              _p(nqp, C.c_int), recs, max_records, _p(cnts, C.c_int), _p(cv), _p(vv))
+    if rc != 0:
+        raise RuntimeError("oracle sqp2_batch failed")
+    return dict(x=x.reshape(B, desc.n_steps, desc.n_dof), status=status, total_cost=cost, n_qp_solves=nqp, records=recs, rec_counts=cnts,
+                max_records=max_records, cost_vals=cv, cnt_viols=vv)
+
+
+def sqp2_first_qp(desc, x, sqp=None):
+    """the first convexified QP of the trajopt_sqp flavour at x (TrajOptQPProblem::convexify): dense Hessian / constraint matrix,
+    gradient, bounds, exact costs and violations"""
+    x = np.ascontiguousarray(x, np.float64)
+    nv, nc, nzh, nza, ncost, ncnt = (C.c_int(0) for _ in range(6))
+    a = (C.byref(desc), C.byref(sqp) if sqp is not None else None, _p(x), C.byref(nv), C.byref(nc), C.byref(nzh), C.byref(nza))
+    lib().orc_sqp2_first_qp(*a, *([None] * 11), C.byref(ncost), C.byref(ncnt))
+    Hr, Hc, Hx = np.zeros(nzh.value, np.int32), np.zeros(nzh.value, np.int32), np.zeros(nzh.value)
+    Ar, Ac, Ax = np.zeros(nza.value, np.int32), np.zeros(nza.value, np.int32), np.zeros(nza.value)
+    g, lo, up = np.zeros(nv.value), np.zeros(nc.value), np.zeros(nc.value)
+    ec, ev = np.zeros(ncost.value), np.zeros(ncnt.value)
+    rc = lib().orc_sqp2_first_qp(*a, _p(Hr, C.c_int), _p(Hc, C.c_int), _p(Hx), _p(g), _p(Ar, C.c_int), _p(Ac, C.c_int), _p(Ax), _p(lo), _p(up),
+                                 _p(ec), _p(ev), C.byref(ncost), C.byref(ncnt))
+    if rc != 0:
+        raise RuntimeError("oracle sqp2_first_qp failed")
+    H = np.zeros((nv.value, nv.value))
+    H[Hr, Hc] = Hx
+    A = np.zeros((nc.value, nv.value))
+    A[Ar, Ac] = Ax
+    return dict(nv=nv.value, nc=nc.value, H=H, gradient=g, A=A, lower=lo, upper=up, exact_costs=ec, exact_viols=ev)
+
+
 def evaluate(desc, x0_fixed, x):
     nc, nn = C.c_int(0), C.c_int(0)
     x0_fixed = np.ascontiguousarray(x0_fixed, np.float64)

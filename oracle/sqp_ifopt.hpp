@@ -1075,13 +1075,17 @@ public:
       t.rho_final = solver->currentRho();
       trace->push_back(t);
     }
+    // OSQP keeps its iterates and rho inside the workspace whatever the status; after an infeasibility / non-convexity
+    // verdict it cold-starts them (osqp_solve: solution NaN + cold start)
+    const bool has_sol = !(st == OSQP_PRIMAL_INFEASIBLE || st == OSQP_PRIMAL_INFEASIBLE_INACCURATE || st == OSQP_DUAL_INFEASIBLE ||
+                           st == OSQP_DUAL_INFEASIBLE_INACCURATE || st == OSQP_NON_CVX);
+    prev_x = has_sol ? solver->sol_x : Vec(static_cast<std::size_t>(num_vars), 0.0);
+    prev_y = has_sol ? solver->sol_y : Vec(static_cast<std::size_t>(num_cnts), 0.0);
+    prev_rho = solver->currentRho();
+    have_prev = true;
     if (st == OSQP_SOLVED || st == OSQP_SOLVED_INACCURATE)
     {
       solution = solver->sol_x;
-      prev_x = solver->sol_x;
-      prev_y = solver->sol_y;
-      prev_rho = solver->currentRho();
-      have_prev = true;
       return true;
     }
     return false;

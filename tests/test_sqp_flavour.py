@@ -1,0 +1,125 @@
+"""BASELINE config 4: the trajopt_ifopt / trajopt_sqp path (TMX_FLAVOR_SQP).  Oracle: oracle/sqp_ifopt.hpp, pinned by the
+reference's tesseract-free white-box tests (oracle/kat_sqp.cpp replays expressions_unit, hessian_gradient_unit,
+trust_box_floor_unit and joint_velocity_optimization_unit).  Device: TrajOptQPProblem's slack-column QP, OSQPEigenSolver's call
+protocol and TrustRegionSQPSolver's loops inside the same kernels as the trajopt_sco path."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from trajopt_amd import abi, configs, runtime
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_reference_kats_of_the_trajopt_sqp_restatement(orc):
+    orc.build()
+    exe = os.path.join(ROOT, "oracle", "_build", "orc_kat_sqp")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and "KAT_OK 0 failures" in out.stdout, out.stdout
+    assert out.stdout.count("PASS") == 19
+
+
+def _dense_from_export(e):
+    import scipy.sparse as sp
+    A = sp.csc_matrix((e["A_x"], e["A_i"], e["A_p"]), shape=(e["m"], e["n"])).toarray()
+    Pu = sp.csc_matrix((e["P_x"], e["P_i"], e["P_p"]), shape=(e["n"], e["n"])).toarray()
+    return Pu + np.triu(Pu, 1).T, A
+
+
+def _check_flavour(ctx, orc, n_steps, B, with_collision=True, x_tol=1e-5):
+    pci, s, g = configs.config4(n_steps, with_collision=with_collision)
+    desc = pci.to_desc()
+    x0 = configs.seeds_for(4, pci, s, g, B, sigma=0.05)
+    st = configs.osqp_settings_config4()
+    ctx.upload(desc, abi.default_sqp_params(), st)
+    ctx.set_x0(x0)
+    # exact costs / constraint violations (getExactCosts / getExactConstraintViolations) and the first convexified QP in
+    # TrajOptQPProblem's layout: [NLP vars | slack], rows [hinge costs ; abs costs ; constraints ; identity], P = 2 H
+    cv, vv = ctx.evaluate()
+    ctx.convexify()
+    for b in range(min(B, 2)):
+        q = orc.sqp2_first_qp(desc, x0[b])
+        assert np.abs(cv[b] - q["exact_costs"]).max(initial=0.0) <= 1e-12 and np.abs(vv[b] - q["exact_viols"]).max(initial=0.0) <= 1e-12
+        e = ctx.export_csc(b)
+        assert (e["n"], e["m"]) == (q["nv"], q["nc"])
+        P, A = _dense_from_export(e)
+        assert np.array_equal(A != 0, q["A"] != 0), "sparsity of the constraint matrix"
+        assert np.abs(A - q["A"]).max() <= 1e-12 and np.abs(P - 2.0 * q["H"]).max() <= 1e-12
+        assert np.abs(e["q"] - np.where(np.abs(q["gradient"]) < 1e-7, 0.0, q["gradient"])).max() <= 1e-12
+        assert np.abs(np.clip(q["lower"], -1e30, 1e30) - e["l"]).max() <= 1e-12 and np.abs(np.clip(q["upper"], -1e30, 1e30) - e["u"]).max() <= 1e-12
+    # the whole TrustRegionSQPSolver::solve
+    ctx.set_x0(x0)
+    ctx.run(0)
+    r = ctx.results()
+    o = orc.sqp2_batch(desc, x0, osqp=st)
+    assert np.array_equal(r["status"], o["status"]), (r["status"], o["status"])
+    same = r["n_qp_solves"] == o["n_qp_solves"]
+    dx = np.abs(r["x"] - o["x"]).reshape(B, -1).max(axis=1)
+    assert (dx[same] <= x_tol).all(), dx
+    recs, cnt = ctx.qp_records(64)
+    for b in np.nonzero(same)[0]:
+        for k in range(min(int(cnt[b]), 64)):
+            a, c = recs[b * 64 + k], o["records"][b * o["max_records"] + k]
+            if (a.osqp_iter, a.osqp_status) != (c.osqp_iter, c.osqp_status):
+                break   # histories may part at an ADMM-level integer (parity_checks.sqp_history_classes); counted, not required
+            assert (a.n, a.m, a.warm_started) == (c.n, c.m, c.warm_started)
+    return r, o, same, dx
+
+
+@pytest.mark.parametrize("n_steps,coll", [(10, True), (30, True), (12, False)])
+def test_trajopt_sqp_flavour_on_host_build(hostemu_lib, orc, n_steps, coll):
+    ctx = runtime.Context(0, hostemu_lib)
+    r, o, same, dx = _check_flavour(ctx, orc, n_steps, 3, with_collision=coll)
+    assert (r["status"] == abi.SQP_CONVERGED).all() and same.all()
+    cv, vv = ctx.evaluate()
+    assert vv.max() < 1e-4            # start and goal reached (cnt_tolerance)
+    ctx.close()
+
+
+def test_trajopt_sqp_flavour_refuses_what_it_does_not_lower(hostemu_lib):
+    pci, s, g = configs.config4(8)
+    pci.basic_info.fixed_timesteps = [0]
+    ctx = runtime.Context(0, hostemu_lib)
+    with pytest.raises(runtime.TmxError, match="fixed_steps"):
+        ctx.upload(pci.to_desc(), abi.default_sqp_params(), abi.default_osqp_settings())
+    pci, s, g = configs.config1(8)
+    pci.flavor = 1
+    pci.basic_info.fixed_timesteps = []
+    with pytest.raises(runtime.TmxError, match="not part of the trajopt_sqp path|segment collision"):
+        ctx.upload(pci.to_desc(), abi.default_sqp_params(), abi.default_osqp_settings())
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_trajopt_sqp_flavour_on_device(gpu_ctx_factory, orc):
+    """config 4 at its real size (7-DOF x 30 waypoints, continuous collision hinge cost per segment) on the HIP library"""
+    ctx = gpu_ctx_factory()
+    r, o, same, dx = _check_flavour(ctx, orc, 30, 16)
+    assert (r["status"] == abi.SQP_CONVERGED).mean() >= 0.9 and same.sum() >= 12
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_trajopt_sqp_flavour_full_batch_properties(gpu_ctx_factory):
+    """1024 problems of config 4 on one GPU (the 8192 of BASELINE.json are 8 such shards): properties that need no oracle"""
+    ctx = gpu_ctx_factory()
+    pci, s, g = configs.config4(30)
+    x0 = configs.seeds_for(4, pci, s, g, 1024, sigma=0.05)
+    ctx.upload(pci.to_desc(), abi.default_sqp_params(), configs.osqp_settings_config4())
+    ctx.set_x0(x0)
+    ctx.run(0)
+    r = ctx.results()
+    conv = r["status"] == abi.SQP_CONVERGED
+    assert conv.mean() > 0.9
+    assert np.abs(r["x"][conv, 0, :] - s[None, :]).max() < 1e-3 and np.abs(r["x"][conv, -1, :] - g[None, :]).max() < 1e-3
+    rob = pci.robot
+    assert (r["x"] >= rob.lower - 1e-6).all() and (r["x"] <= rob.upper + 1e-6).all()
+    perm = np.random.default_rng(1).permutation(32)
+    ctx.set_x0(x0[:32][perm])
+    ctx.run(0)
+    assert np.array_equal(ctx.results()["x"], r["x"][:32][perm]), "result depends on batch position / not deterministic"
+    ctx.close()

@@ -10,6 +10,10 @@ TMX_MAX_DOF = 16
 TMX_OK, TMX_ERR_INVALID, TMX_ERR_UNSUPPORTED, TMX_ERR_DEVICE, TMX_ERR_STATE, TMX_ERR_NCCL = range(6)
 (OPT_CONVERGED, OPT_SCO_ITERATION_LIMIT, OPT_PENALTY_ITERATION_LIMIT, OPT_TIME_LIMIT, OPT_FAILED, OPT_INVALID) = range(6)
 CVX_SOLVED, CVX_INFEASIBLE, CVX_FAILED = range(3)
+FLAVOR_SCO, FLAVOR_SQP = 0, 1
+# trajopt_sqp::SQPStatus (types.h:216-225): the status values of FLAVOR_SQP problems
+(SQP_RUNNING, SQP_CONVERGED, SQP_ITERATION_LIMIT, SQP_PENALTY_ITERATION_LIMIT, SQP_TIME_LIMIT, SQP_QP_SOLVE_FAILED,
+ SQP_STOPPED_BY_CALLBACK) = range(7)
 
 TERM_JOINT_VEL_COST = 1
 TERM_JOINT_POS_EQ_CNT = 2

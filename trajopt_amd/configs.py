@@ -264,3 +264,32 @@ def config3(n_steps: int = 50, n_obstacles: int = 20, evaluator_type: int = 4):
     pci.cnt_infos.append(JointPosTermInfo(coeffs=[1.0] * D, targets=list(CFG3_GOAL), first_step=n_steps - 1, last_step=n_steps - 1,
                                           name="goal"))
     return pci, CFG3_START, CFG3_GOAL
+
+
+# ---- config 4: the trajopt_ifopt / trajopt_sqp path ---------------------------------------------------------------------
+# 7-DOF, 30 waypoints (SURVEY.md §8d cfg 4, trajopt_optimizers/trajopt_sqp/test/planning_unit.cpp:87-218): JointVelConstraint as a
+# squared cost, JointPosConstraint sets at the first and the last waypoint (coefficient 5, :149-159), a continuous collision
+# hinge cost per segment (LVS_CONTINUOUS, margin 0.025, coefficient 20, :161-184), OSQP with adaptive_rho off (:186-194).
+def config4(n_steps: int = 30, with_collision: bool = True):
+    rob = pr2_right_arm()
+    pci = ProblemConstructionInfo(rob, BasicInfo(n_steps=n_steps))
+    pci.flavor = 1
+    D = rob.n_dof
+    pci.cost_infos.append(JointVelTermInfo(coeffs=[1.0] * D, targets=[0.0] * D, first_step=0, last_step=n_steps - 1))
+    if with_collision:
+        pci.cost_infos.append(CollisionTermInfo(first_step=0, last_step=n_steps - 1, dist_pen=0.025, coeff=20.0, safety_margin_buffer=0.05,
+                                                evaluator_type=4, longest_valid_segment_length=0.15, max_substates=3))
+        qmid = 0.5 * (CFG1_START + CFG1_GOAL)
+        pmid = rob.fk_tool(qmid)[:3, 3]
+        pci.obstacles.append(((float(pmid[0]) + 0.02, float(pmid[1]), float(pmid[2]) - 0.17), 0.15))
+    pci.cnt_infos.append(JointPosTermInfo(coeffs=[5.0] * D, targets=list(CFG1_START), first_step=0, last_step=0, name="start"))
+    pci.cnt_infos.append(JointPosTermInfo(coeffs=[5.0] * D, targets=list(CFG1_GOAL), first_step=n_steps - 1, last_step=n_steps - 1, name="goal"))
+    return pci, CFG1_START, CFG1_GOAL
+
+
+def osqp_settings_config4():
+    """OSQPEigenSolver defaults (osqp_eigen_solver.cpp:50-61) with adaptive_rho = false as planning_unit.cpp:186-194 sets it"""
+    from . import abi
+    st = abi.default_osqp_settings()
+    st.adaptive_rho = 0
+    return st

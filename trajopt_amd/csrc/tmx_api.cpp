@@ -260,6 +260,25 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
     sub3.push_back(0);
     aux3.push_back(0.0);
   };
+  const int flavor = d->flavor;
+  if (flavor != TMX_FLAVOR_SCO && flavor != TMX_FLAVOR_SQP)
+  {
+    ctx->err = "tmx_problem_desc.flavor must be TMX_FLAVOR_SCO or TMX_FLAVOR_SQP";
+    return TMX_ERR_INVALID;
+  }
+  if (flavor == TMX_FLAVOR_SQP && (d->n_fixed_steps > 0 || d->n_fixed_dofs > 0))
+  {
+    ctx->err = "TMX_FLAVOR_SQP: fixed_steps / fixed_dofs are not part of the trajopt_sqp path (use JointPos constraint sets)";
+    return TMX_ERR_UNSUPPORTED;
+  }
+#if !TMX_LINK_ROWS
+  if (flavor == TMX_FLAVOR_SQP)
+  {
+    ctx->err = "TMX_FLAVOR_SQP needs a build with pair rows";
+    return TMX_ERR_UNSUPPORTED;
+  }
+#endif
+  P.flavor = flavor;
   std::vector<int> fixed(d->fixed_steps, d->fixed_steps + d->n_fixed_steps);
   for (int t : fixed)
   {
@@ -291,14 +310,46 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
   int n_costs = 0, n_cnts = 0;
   // hatch order: all costs in list order, then the constraints; sco::OptProb keeps equality constraints in front of the
   // inequality constraints (modeling.cpp:234-241), which fixes both the row / aux order and the constraint numbering
-  for (int pass = 0; pass < 3; ++pass)
+  int n_sq = 0;
+  for (int pass = 0; pass < 5; ++pass)
     for (int k = 0; k < d->n_terms; ++k)
     {
       const tmx_term& tm = d->terms[k];
       const bool is_ineq = tm.kind == TMX_TERM_JOINT_POS_INEQ_CNT || tm.kind == TMX_TERM_COLLISION_CNT || tm.kind == TMX_TERM_JOINT_VEL_INEQ_CNT;
       const bool is_cnt = is_ineq || (tm.kind == TMX_TERM_JOINT_POS_EQ_CNT) || (tm.kind == TMX_TERM_JOINT_VEL_EQ_CNT) ||
                           (tm.kind == TMX_TERM_CART_POSE && tm.is_constraint);
-      const int want = !is_cnt ? 0 : (is_ineq ? 2 : 1);
+      int want = !is_cnt ? 0 : (is_ineq ? 2 : 1);
+      if (flavor == TMX_FLAVOR_SQP)
+      {
+        // TrajOptQPProblem::setup (trajopt_qp_problem.cpp:568-600): objective terms (squared), penalty constraints = hinge costs
+        // (static, dynamic) then abs costs, merit constraints = static constraint sets then the dynamic ones
+        switch (tm.kind)
+        {
+          case TMX_TERM_JOINT_VEL_COST:
+            want = 0;
+            break;
+          case TMX_TERM_COLLISION_COST:
+            want = 1;
+            break;
+          case TMX_TERM_JOINT_POS_EQ_COST:
+            want = 2;
+            break;
+          case TMX_TERM_JOINT_POS_EQ_CNT:
+            want = 3;
+            break;
+          case TMX_TERM_COLLISION_CNT:
+            want = 4;
+            break;
+          default:
+            ctx->err = "TMX_FLAVOR_SQP: term kind not part of the trajopt_sqp path";
+            return TMX_ERR_UNSUPPORTED;
+        }
+        if ((tm.kind == TMX_TERM_COLLISION_COST || tm.kind == TMX_TERM_COLLISION_CNT) && tm.evaluator_type < 2)
+        {
+          ctx->err = "TMX_FLAVOR_SQP lowers the segment collision evaluators (evaluator_type 2..4) only";
+          return TMX_ERR_UNSUPPORTED;
+        }
+      }
       if (pass != want)
         continue;
       if (tm.first_step < 0 || tm.last_step >= T || tm.first_step > tm.last_step)
@@ -336,6 +387,29 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
             vel_coeffs.push_back(j < D ? tm.coeffs[j] : 0.0);
             vel_targets.push_back(j < D ? tm.targets[j] : 0.0);
           }
+          if (flavor == TMX_FLAVOR_SQP)
+          {
+            // JointVelConstraint as a kSquared cost set: H = Bw' Bw with Bw = diag(sqrt(w)) B, B rows (-1 at x[i][j], +1 at
+            // x[i+1][j]) accumulated over the rows in row order (AffExprs::square, expressions.cpp:43-112); the 1e-7 zeroing and
+            // the factor 2 of OSQPEigenSolver::updateHessianMatrix are applied after all sets are summed (below)
+            ++n_sq;
+            for (int j = 0; j < D; ++j)
+              if (!(tm.coeffs[j] > 0))
+              {
+                ctx->err = "JointVelConstraint, coeff must be greater than zero.";  // joint_velocity_constraint.cpp:66
+                return TMX_ERR_INVALID;
+              }
+            for (int i = tm.first_step; i <= tm.last_step - 1; ++i)
+              for (int j = 0; j < D; ++j)
+              {
+                const double sw = std::sqrt(tm.coeffs[j]);
+                const double b0 = -1 * sw, b1 = 1 * sw;
+                pd[i * D + j] += b0 * b0;
+                po[i * D + j] += b0 * b1;
+                pd[(i + 1) * D + j] += b1 * b1;
+              }
+            break;
+          }
           // Hessian / linear term of sum_j c_j (x_{i+1,j} - x_{i,j} - targ_j)^2 exactly as exprSquare + exprToEigen build
           // them (expr_ops.cpp:55-84, solver_utils.cpp:49-109 with matrix_is_halved = true)
           for (int i = tm.first_step; i <= tm.last_step - 1; ++i)
@@ -360,6 +434,25 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
         }
         case TMX_TERM_JOINT_POS_EQ_CNT:
         {
+          if (flavor == TMX_FLAVOR_SQP)
+          {
+            // one JointPosConstraint set per step (joint_position_constraint.cpp:36-75): unscaled identity rows with equality
+            // bounds; the coefficient weighs the slack pair in the objective (trajopt_qp_problem.cpp:799-812)
+            for (int i = tm.first_step; i <= tm.last_step; ++i)
+            {
+              const int own = n_cnts++;
+              for (int j = 0; j < D; ++j)
+              {
+                if (!(tm.coeffs[j] > 0))
+                {
+                  ctx->err = "JointPosConstraint, coeff must be greater than zero.";
+                  return TMX_ERR_INVALID;
+                }
+                add_slot(SLOT_JOINTPOS, i, j, 0, own, 2, 1, 1, 0.0, tm.coeffs[j], tm.targets[j], 0.0);
+              }
+            }
+            break;
+          }
           const int own = n_cnts++;
           for (int i = tm.first_step; i <= tm.last_step; ++i)
             for (int j = 0; j < D; ++j)
@@ -405,6 +498,24 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
         }
         case TMX_TERM_JOINT_POS_EQ_COST:
         {
+          if (flavor == TMX_FLAVOR_SQP)
+          {
+            // JointPosConstraint per step as a kAbsolute cost set: the same rows, slack pair weighted by the coefficient
+            for (int i = tm.first_step; i <= tm.last_step; ++i)
+            {
+              const int own = n_costs++;
+              for (int j = 0; j < D; ++j)
+              {
+                if (!(tm.coeffs[j] > 0))
+                {
+                  ctx->err = "JointPosConstraint, coeff must be greater than zero.";
+                  return TMX_ERR_INVALID;
+                }
+                add_slot(SLOT_JOINTPOS, i, j, 0, own, 2, 0, 1, tm.coeffs[j], tm.coeffs[j], tm.targets[j], 0.0);
+              }
+            }
+            break;
+          }
           // JointPosEqCost (trajectory_costs.cpp:28-65): squared cost on the joint positions; shares the device-side
           // machinery of the velocity cost (vel_kind 1: the term is x_ij - target_j instead of a difference of steps)
           vel_first.push_back(tm.first_step);
@@ -614,6 +725,16 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
           return TMX_ERR_UNSUPPORTED;
       }
     }
+  if (flavor == TMX_FLAVOR_SQP)
+    for (int v = 0; v < P.NX; ++v)
+    {
+      // "originally it pruned these but it changes sparsity so we now set to zero" (trajopt_qp_problem.cpp:938-942), then
+      // OSQPEigenSolver::updateHessianMatrix: 2 H (osqp_eigen_solver.cpp:220-229).  A zeroed entry stays in the pattern
+      // upstream; it does not contribute to any product here.
+      pd[v] = 2.0 * ((std::fabs(pd[v]) < 1e-7) ? 0.0 : pd[v]);
+      po[v] = 2.0 * ((std::fabs(po[v]) < 1e-7) ? 0.0 : po[v]);
+    }
+  P.n_sq = n_sq;
   const int R = static_cast<int>(kind.size());
   P.R = R;
   P.n_costs = n_costs;
@@ -841,6 +962,9 @@ static tmx_status ensure_batch(tmx_ctx* ctx, int B)
   AL(active, b * P.R);
   AL(coef, b * P.R * P.D);
   AL(coef2, b * P.n_link * P.D);
+  AL(qdyn, b * P.NX);
+  AL(rowc, b * P.R);
+  AL(solver_init, b);
   AL(rhs, b * P.R);
   AL(dims, b * 4);
   AL(hashes, b * 4);

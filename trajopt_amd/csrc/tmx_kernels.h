@@ -23,7 +23,7 @@ TMX_KERNEL_LB(256) k_prepare(const DevProblem* P, const DevBatch* Bt)
     const int j = v % D;
     double y = fmax(P->jl[j] + 1e-6, x0[v]);
     y = fmin(P->ju[j] - 1e-6, x0[v]);
-    x[v] = y;
+    x[v] = (P->flavor == 1) ? x0[v] : y;  // getClosestFeasiblePoint belongs to sco::BasicTrustRegionSQP only
   }
   int* act = Bt->active + (size_t)b * R;
   for (int r = tid; r < R; r += NT)
@@ -49,6 +49,14 @@ TMX_KERNEL_LB(256) k_prepare(const DevProblem* P, const DevBatch* Bt)
     Bt->total_cost[b] = 0.0;
     for (int q = 0; q < 16; ++q)
       Bt->prof[(size_t)b * 16 + q] = 0;
+    Bt->solver_init[b] = 0;
+    if (P->flavor == 1)
+    {
+      // TrustRegionSQPSolver::init (trust_region_sqp_solver.cpp:45-64): no feasibility projection of the start point, box =
+      // initial_trust_box_size, status running; overall_iteration counts QP solves
+      Bt->status[b] = TMX_SQP_RUNNING;
+      Bt->retval[b] = TMX_SQP_RUNNING;
+    }
     Bt->sched_state[b] = 0;
     if (b == 0)
       *Bt->sched_done = 0;
@@ -92,9 +100,13 @@ TMX_KERNEL_LB(256) k_convexify(const DevProblem* P, const DevBatch* Bt, int forc
   double* coef = Bt->coef + (size_t)b * R * D;
   double* rhs = Bt->rhs + (size_t)b * R;
   const double* x = Bt->x + (size_t)b * P->NX;
-  convexify_terms(P, x, act, coef, Bt->coef2 + (size_t)b * P->n_link * D, rhs, smem, tid, NT);
+  convexify_terms(P, x, act, coef, Bt->coef2 + (size_t)b * P->n_link * D, rhs, smem, tid, NT, Bt->rowc + (size_t)b * R, Bt->qdyn + (size_t)b * P->NX);
   qp_structure(P, act, coef, Bt->coef2 + (size_t)b * P->n_link * D, rhs, x, Bt->trust[b], Bt->merit + (size_t)b * P->n_cnts, Bt->dims + 4 * b,
-               Bt->hashes + 4 * b, nullptr, reinterpret_cast<int*>(smem), tid, NT);
+               Bt->hashes + 4 * b, nullptr, reinterpret_cast<int*>(smem), tid, NT, Bt->qdyn + (size_t)b * P->NX);
+#if TMX_LINK_ROWS
+  if (P->flavor == 1 && !force)
+    sqp2_begin_qp(P, Bt, b, smem, tid, NT);
+#endif
 }
 
 // export of one problem's QP in reference CSC layout (tests / INTEGRATION: the S1 hand-off format)
@@ -106,7 +118,7 @@ TMX_KERNEL k_export_csc(const DevProblem* P, const DevBatch* Bt, int b, CscOut o
   const int R = P->R, D = P->D;
   qp_structure(P, Bt->active + (size_t)b * R, Bt->coef + (size_t)b * R * D, Bt->coef2 + (size_t)b * P->n_link * D, Bt->rhs + (size_t)b * R,
                Bt->x + (size_t)b * P->NX, Bt->trust[b], Bt->merit + (size_t)b * P->n_cnts, dims_out, hashes_out, &out,
-               reinterpret_cast<int*>(smem), tid, NT);
+               reinterpret_cast<int*>(smem), tid, NT, Bt->qdyn + (size_t)b * P->NX);
 }
 
 // K5: Model::optimize() for every running problem; also publishes new_x = first NX model vars (optimizers.cpp:396)
@@ -131,6 +143,13 @@ TMX_KERNEL k_sqp_update(const DevProblem* P, const DevBatch* Bt)
   TMX_SMEM(smem_lds);
   double* smem = TMX_WORK(smem_lds, Bt);
   const int b = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
+#if TMX_LINK_ROWS
+  if (P->flavor == 1)
+  {
+    sqp2_update_block(P, Bt, b, smem, tid, NT);
+    return;
+  }
+#endif
   sqp_update_block(P, Bt, b, smem, tid, NT);
 }
 
@@ -151,7 +170,7 @@ TMX_DEVFN void sqp_step_block(const DevProblem* P, const DevBatch* Bt, int b, do
 #endif
   if (Bt->phase[b] == PHASE_CONVEXIFY)
   {
-    convexify_terms(P, x, act, coef, Bt->coef2 + (size_t)b * P->n_link * D, rhs, smem, tid, NT);
+    convexify_terms(P, x, act, coef, Bt->coef2 + (size_t)b * P->n_link * D, rhs, smem, tid, NT, Bt->rowc + (size_t)b * R, Bt->qdyn + (size_t)b * NX);
 #ifdef TMX_PROFILE
     if (tid == 0)
     {
@@ -161,7 +180,11 @@ TMX_DEVFN void sqp_step_block(const DevProblem* P, const DevBatch* Bt, int b, do
     }
 #endif
     qp_structure(P, act, coef, Bt->coef2 + (size_t)b * P->n_link * D, rhs, x, Bt->trust[b], Bt->merit + (size_t)b * P->n_cnts, Bt->dims + 4 * b,
-                 Bt->hashes + 4 * b, nullptr, reinterpret_cast<int*>(smem), tid, NT);
+                 Bt->hashes + 4 * b, nullptr, reinterpret_cast<int*>(smem), tid, NT, Bt->qdyn + (size_t)b * NX);
+#if TMX_LINK_ROWS
+    if (P->flavor == 1)
+      sqp2_begin_qp(P, Bt, b, smem, tid, NT);
+#endif
   }
   TMX_SYNC();
 #ifdef TMX_PROFILE
@@ -176,7 +199,12 @@ TMX_DEVFN void sqp_step_block(const DevProblem* P, const DevBatch* Bt, int b, do
     xn[v] = xq[v];
   TMX_SYNC();
   evaluate_terms(P, xn, Bt->new_cost_vals + (size_t)b * P->n_costs, Bt->new_cnt_viols + (size_t)b * P->n_cnts, smem, tid, NT);
-  sqp_update_block(P, Bt, b, smem, tid, NT);
+#if TMX_LINK_ROWS
+  if (P->flavor == 1)
+    sqp2_update_block(P, Bt, b, smem, tid, NT);
+  else
+#endif
+    sqp_update_block(P, Bt, b, smem, tid, NT);
   TMX_SYNC();
 #ifdef TMX_PROFILE
   if (tid == 0)

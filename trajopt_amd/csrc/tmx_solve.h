@@ -10,6 +10,27 @@
 #define TMX_ATOMIC_ADD_U64(ptr, v) __atomic_fetch_add((unsigned long long*)(ptr), (unsigned long long)(v), __ATOMIC_RELAXED)
 #endif
 
+// objective coefficient of the aux (slack) variable(s) of row r:
+//   trajopt_sco : cost rows slot_objc, constraint rows their merit coefficient (cntsToCosts, optimizers.cpp:59-81)
+//   trajopt_sqp : merit_coeff * coefficient of the set, merit_coeff = 1 for the penalty cost sets (trajopt_qp_problem.cpp:771-798)
+TMX_DEVFN double aux_cost(const DevProblem* P, const double* merit, int r)
+{
+  if (P->flavor == 1)
+  {
+    const double cf = (P->slot_kind[r] == SLOT_COLLISION_LVS) ? P->slot_objc[r] : P->slot_scale[r];
+    return (P->slot_iscnt[r] ? merit[P->slot_owner[r]] : 1.0) * cf;
+  }
+  return P->slot_iscnt[r] ? merit[P->slot_owner[r]] : P->slot_objc[r];
+}
+// linear objective entry of primary variable v: static for trajopt_sco; for trajopt_sqp the per-convexification gradient of
+// the squared costs with OSQPEigenSolver::updateGradient's zeroing (osqp_eigen_solver.cpp:233)
+TMX_DEVFN double primary_q(const DevProblem* P, const double* qdyn, int v)
+{
+  if (P->flavor == 1)
+    return (fabs(qdyn[v]) < 1e-7) ? 0.0 : qdyn[v];
+  return P->pq[v];
+}
+
 // entry sign of aux k of a row with naux aux vars: hinge: -1 ; abs: +1 (neg), -1 (pos)   (modeling.cpp:18-51)
 TMX_DEVFN double aux_sign(int naux, int k) { return (naux == 1) ? -1.0 : (k == 0 ? 1.0 : -1.0); }
 
@@ -27,7 +48,7 @@ struct CscOut
 
 TMX_DEVFN void qp_structure(const DevProblem* P, const int* active, const double* coef, const double* coef2, const double* rhs,
                             const double* xcur, double trust, const double* merit, int* dims, unsigned long long* hashes,
-                            const CscOut* out, int* iscratch, int tid, int NT)
+                            const CscOut* out, int* iscratch, int tid, int NT, const double* qdyn = nullptr)
 {
   (void)coef2;
   const int D = P->D, T = P->T, NX = P->NX, R = P->R;
@@ -288,7 +309,7 @@ TMX_DEVFN void qp_structure(const DevProblem* P, const int* active, const double
       out->A_p[c] = colptr[c];
     for (int v = tid; v < NX; v += NT)
     {
-      out->q[v] = P->pq[v];
+      out->q[v] = primary_q(P, qdyn, v);
       const double xi = fmin(fmax(xcur[v], P->jl[v % D]), P->ju[v % D]);
       const double lb = fmax(xi - trust, P->jl[v % D]), ub = fmin(xi + trust, P->ju[v % D]);
       out->l[mg + v] = fmax(lb, -TMX_OSQP_INFTY);
@@ -299,7 +320,7 @@ TMX_DEVFN void qp_structure(const DevProblem* P, const int* active, const double
       {
         out->l[rowref[r]] = P->slot_eq[r] ? rhs[r] : -TMX_OSQP_INFTY;
         out->u[rowref[r]] = rhs[r];
-        const double oc = P->slot_iscnt[r] ? merit[P->slot_owner[r]] : P->slot_objc[r];
+        const double oc = aux_cost(P, merit, r);
         for (int k = 0; k < P->slot_naux[r]; ++k)
         {
           out->q[auxref[r] + k] = oc;
@@ -546,7 +567,7 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
       for (int j = 0; j < D; ++j)
         w.c2[P->slot_c2[r] * D + j] = g_act[r] ? g_coef2[P->slot_c2[r] * D + j] : 0.0;
 #endif
-    const double oc = P->slot_iscnt[r] ? g_merit[P->slot_owner[r]] : P->slot_objc[r];
+    const double oc = aux_cost(P, g_merit, r);
     for (int k = 0; k < P->slot_naux[r]; ++k)
     {
       const int a = P->slot_aoff[r] + k;
@@ -571,7 +592,7 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
     const double lb = fmax(xi - trust, P->jl[j]), ub = fmin(xi + trust, P->ju[j]);
     w.lbp[v] = fmax(lb, -TMX_OSQP_INFTY);
     w.ubp[v] = fmin(ub, TMX_OSQP_INFTY);
-    w.qp[v] = P->pq[v];
+    w.qp[v] = primary_q(P, Bt->qdyn + (size_t)b * NX, v);
     w.pd[v] = P->pd[v];
     w.po[v] = (v < NX - D) ? P->po[v] : 0.0;
     w.bbp[v] = 1.0;
@@ -806,7 +827,16 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
   const bool P_eq = warm && pd4[0] == dims[0] && pd4[2] == dims[2] && pws[0] == hs[2];
   const bool A_eq = P_eq && pd4[0] == dims[0] && pd4[1] == dims[1] && pd4[3] == dims[3] && pws[1] == hs[3];
   warm = warm && P_eq && A_eq;
-  w.rho = warm ? Bt->prev_rho[b] : st.rho;
+  if (P->flavor == 1)
+  {
+    // OSQPEigenSolver protocol (osqp_eigen_solver.cpp:96-109, :277-326; trust_region_sqp_solver.cpp:214-244): with warm
+    // starting on, EVERY solve starts from a point - the slack warm start written by sqp2_begin_qp after a (re)build
+    // (prev_ok = 0: xq / yq hold x0 / y0 = 0, rho = settings) or the previous solve's iterates and rho (prev_ok = 1)
+    warm = st.warm_starting != 0;
+    w.rho = Bt->prev_ok[b] ? Bt->prev_rho[b] : st.rho;
+  }
+  else
+    w.rho = warm ? Bt->prev_rho[b] : st.rho;
   w.rho = fmin(fmax(w.rho, TMX_RHO_MIN), TMX_RHO_MAX);
   if (warm)
   {
@@ -1211,7 +1241,7 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
   const bool has_sol = !(info.status == 3 || info.status == 4 || info.status == 5 || info.status == 6 || info.status == 9);
   double* xq = Bt->xq + (size_t)b * P->n_max;
   double* yq = Bt->yq + (size_t)b * P->m_max;
-  const double nanv = NAN;
+  const double nanv = (P->flavor == 1) ? 0.0 : NAN;  // flavour 1: OSQP cold-starts its persistent iterates after an infeasible verdict
   unsigned long long hact = 0ULL;
   for (int v = tid; v < NX; v += NT)
   {
@@ -1263,7 +1293,7 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
     Bt->rec_count[b] = k + 1;
     Bt->admm_iters[b] += info.iter;
     Bt->cvx[b] = (info.status == 1 || info.status == 2) ? TMX_CVX_SOLVED : (has_sol ? TMX_CVX_FAILED : TMX_CVX_INFEASIBLE);
-    Bt->prev_ok[b] = (info.status == 1 || info.status == 2) ? 1 : 0;
+    Bt->prev_ok[b] = (P->flavor == 1) ? 1 : ((info.status == 1 || info.status == 2) ? 1 : 0);
     Bt->prev_rho[b] = w.rho;
     for (int q = 0; q < 4; ++q)
       Bt->prev_dims[4 * b + q] = dims[q];
@@ -1550,3 +1580,332 @@ TMX_DEVFN void sqp_update_block(const DevProblem* P, const DevBatch* Bt, int b, 
   Bt->total_cost[b] = tot;
   Bt->phase[b] = PHASE_DONE;
 }
+
+
+// =========================================================================================================
+// trajopt_sqp flavour (TMX_FLAVOR_SQP, BASELINE config 4): TrajOptQPProblem + TrustRegionSQPSolver on the device
+// =========================================================================================================
+#if TMX_LINK_ROWS
+// value of row r of the convexified constraint matrix at the QP variables xq (reference order): constant + J x (+ slack part)
+TMX_DEVFN double sqp2_row_value(const DevProblem* P, const DevBatch* Bt, int b, int r, const double* xq, const int* aux_ref, bool with_slack)
+{
+  const int D = P->D, t = P->slot_t[r];
+  const double* coef = Bt->coef + ((size_t)b * P->R + r) * D;
+  double a = 0.0;
+  for (int j = 0; j < D; ++j)
+    a += coef[j] * xq[t * D + j];
+  if (P->n_link > 0 && P->slot_c2[r] >= 0)
+  {
+    const double* c2r = Bt->coef2 + ((size_t)b * P->n_link + P->slot_c2[r]) * D;
+    for (int j = 0; j < D; ++j)
+      a += c2r[j] * xq[(t + 1) * D + j];
+  }
+  if (with_slack)
+    for (int k = 0; k < P->slot_naux[r]; ++k)
+      a += aux_sign(P->slot_naux[r], k) * xq[aux_ref[r] + k];
+  return Bt->rowc[(size_t)b * P->R + r] + a;
+}
+// calcBoundsViolations of a row value against the ORIGINAL bounds of its constraint set (ifopt_utils.cpp:122-145)
+TMX_DEVFN double sqp2_row_violation(const DevProblem* P, int r, double val)
+{
+  if (P->slot_kind[r] == SLOT_COLLISION_LVS)  // (-inf, 0]
+    return (val > 0.0) ? fabs(val - 0.0) : 0.0;
+  const double t = P->slot_aux1[r];  // equality bounds (target, target)
+  return (val < t) ? fabs(val - t) : ((val > t) ? fabs(val - t) : 0.0);
+}
+
+// TrustRegionSQPSolver::stepSQPSolver head (trust_region_sqp_solver.cpp:202-244) after convexify(): first QP of the solver
+// or changed dimensions -> clear / init / update* / setWarmStart: the slack warm start of OSQPEigenSolver::setWarmStart
+// (osqp_eigen_solver.cpp:277-326) goes to xq / yq and the solver starts from settings.rho; otherwise the solver keeps
+// its iterates (xq / yq / prev_rho of the previous solve).  `scratch`: >= n_cnts doubles.
+TMX_DEVFN void sqp2_begin_qp(const DevProblem* P, const DevBatch* Bt, int b, double* scratch, int tid, int NT)
+{
+  const int NX = P->NX, R = P->R;
+  const int* dims = Bt->dims + 4 * b;
+  const int* pd4 = Bt->prev_dims + 4 * b;
+  const bool rebuild = !Bt->solver_init[b] || pd4[0] != dims[0] || pd4[1] != dims[1];
+  TMX_SYNC();
+  if (!rebuild)
+    return;
+  const int* act = Bt->active + (size_t)b * R;
+  const double* x = Bt->x + (size_t)b * NX;
+  double* xq = Bt->xq + (size_t)b * P->n_max;
+  double* yq = Bt->yq + (size_t)b * P->m_max;
+  for (int v = tid; v < P->n_max; v += NT)
+    xq[v] = (v < NX) ? x[v] : 0.0;
+  for (int i = tid; i < P->m_max; i += NT)
+    yq[i] = 0.0;
+  // evaluateConvexConstraintViolations(nlp values) per merit constraint SET (trajopt_qp_problem.cpp:205-244)
+  for (int k = tid; k < P->n_cnts; k += NT)
+  {
+    double s = 0.0;
+    for (int r = 0; r < R; ++r)
+      if (act[r] && P->slot_iscnt[r] && P->slot_owner[r] == k)
+        s += sqp2_row_violation(P, r, sqp2_row_value(P, Bt, b, r, x, nullptr, false));
+    scratch[k] = s;
+  }
+  TMX_SYNC();
+  // quirk: the loop over the violations indexes the ROWS of the constraint matrix with the index of the merit-constraint
+  // SET (osqp_eigen_solver.cpp:300-318): row k (k-th active row in reference order) gets slack = violation[k] / coefficient
+  if (tid == 0)
+  {
+    int k = 0, na = 0;
+    for (int r = 0; r < R && k < P->n_cnts; ++r)
+    {
+      if (!act[r])
+        continue;
+      for (int q = 0; q < P->slot_naux[r]; ++q)
+      {
+        const double sl = scratch[k] / aux_sign(P->slot_naux[r], q);
+        xq[NX + na + q] = (0.0 > sl) ? 0.0 : sl;  // std::max(0.0, slack)
+      }
+      na += P->slot_naux[r];
+      ++k;
+    }
+    Bt->solver_init[b] = 1;
+    Bt->prev_ok[b] = 0;  // the next solve starts from (x0, y0) with settings.rho
+  }
+  TMX_SYNC();
+}
+
+// TrustRegionSQPSolver after one qp_solver->solve(): solveQPProblem's merits (trust_region_sqp_solver.cpp:373-439), the body of
+// runTrustRegionLoop (:262-371), the tail of stepSQPSolver (:246-259), the convexification / penalty loops of solve()
+// (:99-152), verifySQPSolverConvergence (:161-177) and adjustPenalty (:179-200).  smem: n_costs + n_cnts + R + (R+1)/2 doubles.
+TMX_DEVFN void sqp2_update_block(const DevProblem* P, const DevBatch* Bt, int b, double* smem, int tid, int NT)
+{
+  const int D = P->D, NX = P->NX, R = P->R;
+  const tmx_sqp_params& sp = P->sqp;
+  double* model_cost = smem;                     // n_costs
+  double* model_viol = model_cost + P->n_costs;  // n_cnts
+  double* val = model_viol + P->n_cnts;          // R
+  int* keys = reinterpret_cast<int*>(val + R);
+  const double* xq = Bt->xq + (size_t)b * P->n_max;
+  const int* act = Bt->active + (size_t)b * R;
+  double* cost_vals = Bt->cost_vals + (size_t)b * P->n_costs;
+  double* cnt_viols = Bt->cnt_viols + (size_t)b * P->n_cnts;
+  const double* new_cost = Bt->new_cost_vals + (size_t)b * P->n_costs;
+  const double* new_viol = Bt->new_cnt_viols + (size_t)b * P->n_cnts;
+  double* merit = Bt->merit + (size_t)b * P->n_cnts;
+  const bool solved = Bt->cvx[b] == TMX_CVX_SOLVED && Bt->phase[b] != PHASE_DONE;
+  if (solved)
+  {
+    // evaluateConvexCosts / evaluateConvexConstraintViolations at the FULL QP solution (trajopt_qp_problem.cpp:131-244)
+    QpWs wl;
+    qp_ws_carve(wl, smem, smem, Bt->qp_scratch + (size_t)b * Bt->qp_scratch_stride, D, P->T, R, P->NA, P->n_link);
+    const int* aux_ref = wl.aux_ref;
+    for (int r = tid; r < R; r += NT)
+    {
+      double vr = 0.0;
+      int key = -1;
+      if (act[r])
+      {
+        const bool cnt = P->slot_iscnt[r] != 0;
+        vr = sqp2_row_violation(P, r, sqp2_row_value(P, Bt, b, r, xq, aux_ref, !cnt));  // penalty costs: ALL variables
+        key = cnt ? P->n_costs + P->slot_owner[r] : P->slot_owner[r];
+      }
+      val[r] = vr;
+      keys[r] = key;
+    }
+    TMX_SYNC();
+    const double* x0 = Bt->x + (size_t)b * NX;  // the convexification point
+    for (int k = tid; k < P->n_costs + P->n_cnts; k += NT)
+    {
+      double acc = 0.0;
+      bool squared = false;
+      if (k < P->n_costs)
+        for (int v = 0; v < P->n_vel; ++v)
+          if (P->vel_cost[v] == k && P->vel_kind[v] == 0)
+          {
+            // QuadExprs::values of the squared set, rows in order (expressions.cpp:123-170 on the output of AffExprs::square)
+            squared = true;
+            for (int i = P->vel_first[v]; i <= P->vel_last[v] - 1; ++i)
+              for (int j = 0; j < D; ++j)
+              {
+                const double w = P->vel_coeffs[v * TMX_MAX_DOF + j], targ = P->vel_targets[v * TMX_MAX_DOF + j];
+                const double a0 = x0[i * D + j], a1 = x0[(i + 1) * D + j];
+                double cst = a1 - a0;
+                cst += -1.0 * ((-1 * a0) + (1 * a1));
+                const double a = targ - cst;
+                const double sr = 2.0 * (a * w), sw = sqrt(w);
+                double out = (a * a) * w;
+                out += 1.0 * (((-1.0 * -1) * sr) * xq[i * D + j] + ((1.0 * -1) * sr) * xq[(i + 1) * D + j]);
+                const double tq = ((-1.0 * -1) * sw) * xq[i * D + j] + ((1.0 * -1) * sw) * xq[(i + 1) * D + j];
+                out += tq * tq;
+                acc += out;
+              }
+          }
+      if (!squared)
+        for (int r = 0; r < R; ++r)
+          if (keys[r] == k)
+            acc += val[r];
+      if (k < P->n_costs)
+        model_cost[k] = acc;
+      else
+        model_viol[k - P->n_costs] = acc;
+    }
+    TMX_SYNC();
+  }
+  if (tid != 0)
+    return;
+  if (Bt->phase[b] == PHASE_DONE)
+    return;
+  double box = Bt->trust[b];
+  int st = TMX_SQP_RUNNING;
+  Bt->n_qp[b] += 1;  // overall_iteration
+  bool to_after_loop = false;
+  auto finish = [&](int status) {
+    Bt->trust[b] = box;
+    Bt->status[b] = status;
+    Bt->retval[b] = status;
+    double tot = 0.0;
+    for (int k = 0; k < P->n_costs; ++k)
+      tot += cost_vals[k];
+    Bt->total_cost[b] = tot;
+    Bt->phase[b] = PHASE_DONE;
+  };
+  if (Bt->cvx[b] != TMX_CVX_SOLVED)
+  {
+    Bt->qp_fail[b] += 1;
+    st = TMX_SQP_QP_SOLVE_FAILED;
+    if (Bt->qp_fail[b] < sp.max_qp_solver_failures)
+      box *= sp.trust_shrink_ratio;
+    else if (Bt->qp_fail[b] == sp.max_qp_solver_failures)
+      box = sp.min_trust_box_size;
+    else
+      to_after_loop = true;  // "the convex solver failed you one too many times": return from the trust-region loop
+  }
+  else
+  {
+    double best_exact = 0.0, new_approx = 0.0, new_exact = 0.0;
+    for (int k = 0; k < P->n_costs; ++k)
+    {
+      best_exact += cost_vals[k];
+      new_approx += model_cost[k];
+      new_exact += new_cost[k];
+    }
+    double d0 = 0.0, d1 = 0.0, d2 = 0.0;
+    for (int k = 0; k < P->n_cnts; ++k)
+    {
+      d0 += cnt_viols[k] * merit[k];
+      d1 += model_viol[k] * merit[k];
+      d2 += new_viol[k] * merit[k];
+    }
+    best_exact += d0;
+    new_approx += d1;
+    new_exact += d2;
+    const double approx = best_exact - new_approx, exact = best_exact - new_exact;
+    const double ratio = (fabs(approx) < 1e-12) ? 0.0 : exact / approx;
+    Bt->n_fe[b] += 1;
+    if (approx < sp.min_approx_improve)
+    {
+      st = TMX_SQP_CONVERGED;
+      to_after_loop = true;
+    }
+    else if (approx / fmax(fabs(best_exact), 1e-12) < sp.min_approx_improve_frac)
+    {
+      st = TMX_SQP_CONVERGED;
+      to_after_loop = true;
+    }
+    else if (exact < 0 || ratio < sp.improve_ratio_threshold)
+      box *= sp.trust_shrink_ratio;
+    else
+    {
+      double* x = Bt->x + (size_t)b * NX;
+      const double* xn = Bt->xnew + (size_t)b * NX;
+      for (int v = 0; v < NX; ++v)
+        x[v] = xn[v];
+      for (int k = 0; k < P->n_costs; ++k)
+        cost_vals[k] = new_cost[k];
+      for (int k = 0; k < P->n_cnts; ++k)
+        cnt_viols[k] = new_viol[k];
+      box *= sp.trust_expand_ratio;
+      to_after_loop = true;  // accepted: return from the trust-region loop (status running)
+    }
+  }
+  if (!to_after_loop)
+  {
+    // `while (box_size.maxCoeff() >= min_trust_box_size)`: another solve of the same convexification with the new box
+    if (box >= sp.min_trust_box_size)
+    {
+      Bt->trust[b] = box;
+      Bt->phase[b] = PHASE_SOLVE;
+      return;
+    }
+  }
+  // ---- tail of stepSQPSolver
+  bool step_converged = (st == TMX_SQP_CONVERGED);
+  if (!step_converged && box < sp.min_trust_box_size)
+  {
+    st = TMX_SQP_CONVERGED;
+    step_converged = true;
+  }
+  auto viol_ok = [&]() {
+    if (P->n_cnts == 0)
+      return true;
+    double vmax = cnt_viols[0];
+    for (int k = 1; k < P->n_cnts; ++k)
+      vmax = fmax(vmax, cnt_viols[k]);
+    return vmax < sp.cnt_tolerance;
+  };
+  bool convex_loop_done = step_converged;
+  if (!step_converged)
+  {
+    // next convexification iteration of `for (convex_iteration = 1; convex_iteration < 100; ...)`
+    Bt->iter[b] += 1;
+    if (Bt->iter[b] >= 100)
+      convex_loop_done = true;  // the loop runs out with the current status
+    else if (Bt->n_qp[b] >= sp.max_iter)
+    {
+      st = TMX_SQP_ITERATION_LIMIT;
+      convex_loop_done = true;
+    }
+  }
+  while (true)
+  {
+    if (!convex_loop_done)
+    {
+      Bt->qp_fail[b] = 0;
+      Bt->trust[b] = box;
+      Bt->phase[b] = PHASE_CONVEXIFY;
+      return;
+    }
+    // ---- after the convexification loop (solve(), :126-152)
+    if (viol_ok())
+    {
+      finish(TMX_SQP_CONVERGED);
+      return;
+    }
+    if (st == TMX_SQP_ITERATION_LIMIT || st == TMX_SQP_TIME_LIMIT)
+    {
+      finish(st);
+      return;
+    }
+    st = TMX_SQP_RUNNING;
+    // adjustPenalty
+    if (sp.inflate_constraints_individually)
+    {
+      for (int k = 0; k < P->n_cnts; ++k)
+        if (cnt_viols[k] > sp.cnt_tolerance)
+          merit[k] *= sp.merit_coeff_increase_ratio;
+    }
+    else
+      for (int k = 0; k < P->n_cnts; ++k)
+        merit[k] *= sp.merit_coeff_increase_ratio;
+    box = fmax(box, sp.min_trust_box_size / sp.trust_shrink_ratio * 1.5);
+    Bt->merit_inc[b] += 1;
+    if (!((double)Bt->merit_inc[b] < sp.max_merit_coeff_increases))
+    {
+      finish(TMX_SQP_PENALTY_ITERATION_LIMIT);
+      return;
+    }
+    // next penalty iteration: convex_iteration = 1, iteration-limit check at the top of the convexification loop
+    Bt->iter[b] = 1;
+    convex_loop_done = false;
+    if (Bt->n_qp[b] >= sp.max_iter)
+    {
+      st = TMX_SQP_ITERATION_LIMIT;
+      convex_loop_done = true;
+    }
+  }
+}
+#endif

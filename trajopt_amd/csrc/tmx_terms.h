@@ -409,7 +409,9 @@ TMX_DEVFN void evaluate_terms(const DevProblem* P, const double* xv, double* cos
       if (lvs_contact(P, xv + t * D, xv + (t + 1) * D, r, c))
       {
         const double pv = P->slot_aux1[r] - c.distance;
-        v = ((pv > 0) ? pv : 0.0) * P->slot_objc[r];
+        // flavour 1: calcBoundsViolations of the value margin - distance against (-inf, 0], UNWEIGHTED (the exact penalty
+        // costs / constraint violations of TrajOptQPProblem are plain sums, trajopt_qp_problem.cpp:1003-1019, :1030-1046)
+        v = (P->flavor == 1) ? ((pv > 0.0) ? fabs(pv - 0.0) : 0.0) : ((pv > 0) ? pv : 0.0) * P->slot_objc[r];
       }
     }
 #endif
@@ -424,7 +426,8 @@ TMX_DEVFN void evaluate_terms(const DevProblem* P, const double* xv, double* cos
     {
       // quirk Q5: JointPosEqConstraint::value returns coeff * diff^2 (trajectory_costs.cpp:165-174)
       const double d = xv[t * D + P->slot_sub[r]] - P->slot_aux1[r];
-      v = fabs((d * d) * P->slot_scale[r]);
+      // flavour 1: |x - target| (calcBoundsViolations with equality bounds, ifopt_utils.cpp:122-145)
+      v = (P->flavor == 1) ? ((d != 0.0) ? fabs(d) : 0.0) : fabs((d * d) * P->slot_scale[r]);
     }
 #if TMX_LINK_ROWS
     else if (kind == SLOT_JOINTVEL)
@@ -478,7 +481,9 @@ TMX_DEVFN void evaluate_terms(const DevProblem* P, const double* xv, double* cos
     const int first = P->vel_first[v], len = P->vel_last[v] - first + pk;
     for (int e = tid; e < D * len; e += NT)
     {
-      const int j = e / len, i = first + e % len;
+      // summation order: the reference's column-major Eigen array (joint-major) for trajopt_sco; row order of the constraint
+      // set (segment-major) for the trajopt_sqp flavour (getExactCosts, trajopt_qp_problem.cpp:986-1001)
+      const int j = (P->flavor == 1) ? e % D : e / len, i = first + ((P->flavor == 1) ? e / D : e % len);
       const double d = (pk ? xv[i * D + j] : (xv[(i + 1) * D + j] - xv[i * D + j])) - P->vel_targets[v * TMX_MAX_DOF + j];
       vterm[(size_t)v * P->NX + e] = (d * d) * P->vel_coeffs[v * TMX_MAX_DOF + j];
     }
@@ -588,6 +593,13 @@ TMX_DEVFN void init_static_rows(const DevProblem* P, const double* x0, int* acti
         coef[r * D + j] = 1.0;
         rhs[r] = -(0.0 - x0[P->slot_t[r] * D + j]);
       }
+      else if (P->flavor == 1)
+      {
+        // JointPosConstraint row of TrajOptQPProblem::convexify (trajopt_qp_problem.cpp:752-792): Jacobian entry 1, constant
+        // value - J x0 = x - 1 x = 0, bounds target - constant
+        coef[r * D + j] = 1.0;
+        rhs[r] = P->slot_aux1[r] - 0.0;
+      }
       else
       {
         // exprMult(pos, coeff) with pos = 1*x - target   (trajectory_costs.cpp:151-161)
@@ -604,9 +616,46 @@ TMX_DEVFN void init_static_rows(const DevProblem* P, const double* x0, int* acti
 // finite-difference Jacobian (6 x D)
 TMX_HOSTDEVFN size_t tmx_cvx_scratch_doubles(int n_cp, int D) { return (size_t)n_cp * ((size_t)(D + 1) * 7 + 6 + 6 * (size_t)D) + 8; }
 TMX_DEVFN void convexify_terms(const DevProblem* P, const double* xv, int* active, double* coef, double* coef2, double* rhs, double* scratch,
-                               int tid, int NT)
+                               int tid, int NT, double* rowc = nullptr, double* qdyn = nullptr)
 {
   (void)coef2;
+  (void)rowc;
+#if TMX_LINK_ROWS
+  if (P->flavor == 1)
+  {
+    // trajopt_sqp flavour: linear objective of the squared cost sets at the convexification point
+    // (TrajOptQPProblem::convexify, trajopt_qp_problem.cpp:861-927 with AffExprs::create / square, expressions.cpp:28-112):
+    //   per row r = (segment i, joint j):  constants = (x1 - x0) - ((-1) x0 + (1) x1) ;  a = target - constants ;
+    //   flipped Jacobian entries (+1 at x0, -1 at x1) ;  sr = 2 (a w) ;  objective_linear[col] += entry * sr   (row order)
+    const int D = P->D;
+    for (int v = tid; v < P->NX; v += NT)
+    {
+      const int t = v / D, j = v % D;
+      double acc = 0.0;
+      for (int k = 0; k < P->n_vel; ++k)
+      {
+        if (P->vel_kind[k] != 0)
+          continue;
+        double part = 0.0;  // objective_linear_coeffs of this set, accumulated over its rows in row order
+        const double w = P->vel_coeffs[k * TMX_MAX_DOF + j], targ = P->vel_targets[k * TMX_MAX_DOF + j];
+        for (int side = 1; side >= 0; --side)  // the row of segment t-1 (entry -1 at x1 = this var) comes before segment t's
+        {
+          const int i = side ? t - 1 : t;      // segment index
+          if (i < P->vel_first[k] || i > P->vel_last[k] - 1)
+            continue;
+          const double x0 = xv[i * D + j], x1 = xv[(i + 1) * D + j];
+          double cst = x1 - x0;
+          cst += -1.0 * ((-1 * x0) + (1 * x1));
+          const double a = targ - cst;
+          const double sr = 2.0 * (a * w);
+          part += (side ? (1.0 * -1) : (-1.0 * -1)) * sr;
+        }
+        acc += part;
+      }
+      qdyn[v] = acc;
+    }
+  }
+#endif
   const int D = P->D;
   // ---- K1: cart-pose rows by forward finite differences over full FK.  One thread per (instance, perturbed joint | base
   //      pose): the D+1 forward-kinematics chains of an instance run side by side instead of one after the other
@@ -722,12 +771,36 @@ TMX_DEVFN void convexify_terms(const DevProblem* P, const double* xv, int* activ
       lvs_end_gradient(P, q0, s, c, false, g0, k0);
     if (!fixed1)
       lvs_end_gradient(P, q1, s, c, true, g1, k1);
+    const double margin = P->slot_aux1[r];
+    if (P->flavor == 1)
+    {
+      // SegmentCollisionConstraint row in TrajOptQPProblem::convexify: value = margin - distance, Jacobian = -(scaled
+      // gradients) on both waypoints, constant = value - J x0, entries with |v| < 1e-7 stored as 0, upper bound 0 - constant
+      double sdot = 0.0;
+      for (int k = 0; k < D; ++k)
+        if (!fixed0)
+          sdot += (-g0[k]) * q0[k];
+      for (int k = 0; k < D; ++k)
+        if (!fixed1)
+          sdot += (-g1[k]) * q1[k];
+      double cc = margin - c.distance;
+      cc += -1.0 * sdot;
+      for (int k = 0; k < D; ++k)
+      {
+        const double a0 = -g0[k], a1 = -g1[k];
+        coef[r * D + k] = (fabs(a0) < TMX_CLEANUP_TOL) ? 0.0 : a0;
+        c2r[k] = (fabs(a1) < TMX_CLEANUP_TOL) ? 0.0 : a1;
+      }
+      rhs[r] = 0.0 - cc;
+      rowc[r] = cc;
+      active[r] = 1;
+      continue;
+    }
     double cst = c.distance;
     if (!fixed0)
       cst += (0.0 + k0);
     if (!fixed1)
       cst += (0.0 + k1);
-    const double margin = P->slot_aux1[r];
     const double viol_const = margin - cst;
     const double cc = P->slot_iscnt[r] ? P->slot_scale[r] : 1.0;
     for (int k = 0; k < D; ++k)

@@ -75,6 +75,8 @@ struct DevProblem
   int *slot_sub3;     // R: collision LVS: bit 0 = state t is fixed (START_FIXED_END_FREE), bit 1 = state t+1 is fixed
   double *slot_aux3;  // R: collision LVS: longest_valid_segment_length
   int lvs_kmax;       // sub-state capacity of the LVS evaluators (tmx_term.max_substates)
+  int flavor;         // tmx_flavor: 0 trajopt_sco (BasicTrustRegionSQP / OSQPModel), 1 trajopt_sqp (TrajOptQPProblem / TrustRegionSQPSolver)
+  int n_sq;           // flavour 1: number of squared cost sets (their exact / model costs come first in cost_vals)
 };
 
 struct DevBatch
@@ -86,6 +88,9 @@ struct DevBatch
   int *phase, *iter, *merit_inc, *qp_fail, *status, *retval, *n_fe, *n_qp, *cvx, *prev_ok;
   int *active;
   double *coef, *rhs;
+  double *qdyn;                 // B x NX: flavour 1: linear objective of the squared costs at the convexification point
+  double *rowc;                 // B x R : flavour 1: constraint_constant of every row (value - J x0)
+  int *solver_init;             // B: flavour 1: OSQPEigenSolver is initialised (dims of its QP in prev_dims)
   double *coef2;                // B x R2 x D: coefficients of the pair rows on waypoint t + 1 (slot order of the pair rows)
   int *dims;                    // B x 4: n, m, nnzP, nnzA of the current convexification
   unsigned long long *hashes;   // B x 4: hashP, hashA, wsP, wsA (ws* = what the reference's memcmp actually compares)

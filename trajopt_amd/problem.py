@@ -198,6 +198,7 @@ class ProblemConstructionInfo:
         self.cost_infos: list = []
         self.cnt_infos: list = []
         self.obstacles: List[tuple] = []     # ((x,y,z), r)
+        self.flavor = 0                      # abi.FLAVOR_SCO (trajopt + trajopt_sco) | abi.FLAVOR_SQP (trajopt_ifopt + trajopt_sqp)
         self._keep = []
 
     # -- names of the expanded costs / constraints (TrajOptResult::cost_names / cnt_names, problem_description.cpp:380-394)
@@ -330,6 +331,7 @@ class ProblemConstructionInfo:
         d.fixed_steps, d.terms = fixed, tarr
         fdofs = (C.c_int32 * max(1, len(self.basic_info.fixed_dofs)))(*self.basic_info.fixed_dofs)
         d.n_fixed_dofs, d.fixed_dofs = len(self.basic_info.fixed_dofs), fdofs
+        d.flavor = int(self.flavor)
         self._keep = [ls, ob, fixed, tarr, fdofs, keep_fixed]   # keep the pointed-to arrays alive
         d._keep = self._keep
         return d
