@@ -7,8 +7,13 @@ of the glass_upright problem (config 1: 7-DOF, 30 waypoints, JointVel cost, upri
 JointPos constraint, single-timestep collision cost).  Seeds are resident in HBM before the timed region.
   value = SQP iterations / s over all GPUs  (one SQP iteration = one trust-region evaluation = one QP solve + one
           exact re-evaluation; the reference's counters n_func_evals-1 / n_qp_solves, optimizers.hpp:47)
-N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), each rank owns its own 1024 seeds (weak scaling,
-no data-path collective); the only exchange is the best-seed all_gather after every step.
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL, for the launcher's barrier / timing reductions), each rank
+owns its own 1024 seeds (weak scaling, no data-path collective); the only exchange on the path is the best-seed reduction
+after every step, done by the library itself over its own RCCL communicator (tmx_nccl_init / tmx_argmin: an all-gather of
+one 16-byte (cost, index) pair per rank).  The communicator is created at N = 1 too, so the collective is exercised by
+every bench run.
+`--config 2|3|4` benches the other BASELINE configurations (puzzle_piece, car_seat, trajopt_sqp path) with their own
+roofline object; the default and the headline is config 1.
 """
 import argparse
 import json
@@ -35,13 +40,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="seeds per GPU (BASELINE: 1024)")
+    ap.add_argument("--batch", type=int, default=0, help="seeds per GPU (default: the configuration's BASELINE batch per GPU)")
+    ap.add_argument("--config", type=int, default=1, choices=[1, 2, 3, 4], help="BASELINE.json configuration (default 1 = the metric's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
-    from trajopt_amd import abi, configs, parallel, runtime
+    from trajopt_amd import abi, configs, runtime
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -53,16 +59,34 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
 
-    pci, start, goal = configs.config1()
+    cid = args.config
+    # (constructor, BASELINE batch per GPU, seed sigma, workload text)
+    spec = {1: (configs.config1, 1024, 0.1, "config 1: glass_upright 7-DOF 30-waypoint, collision cost, batch=%d random seeds per GPU"),
+            2: (configs.config2, 256, None, "config 2: puzzle_piece 7-DOF 300-waypoint, 6-row CartPose constraint per waypoint, batch=%d per GPU"),
+            3: (configs.config3, 128, 0.05, "config 3: car_seat 10-DOF 50-waypoint, 20 obstacles, LVS_CONTINUOUS collision, batch=%d per GPU "
+                                            "(BASELINE: 512 over 4 GPUs)"),
+            4: (configs.config4, 1024, 0.05, "config 4: trajopt_ifopt/trajopt_sqp path 7-DOF 30-waypoint, continuous collision hinge cost, "
+                                             "batch=%d problems per GPU (BASELINE: 8192 over 8 GPUs)")}[cid]
+    pci, start, goal = spec[0]()
     desc = pci.to_desc()
     T, D = pci.basic_info.n_steps, pci.robot.n_dof
-    B = args.batch
+    B = args.batch or spec[1]
+    conv_code = abi.SQP_CONVERGED if cid == 4 else abi.OPT_CONVERGED
+    osqp_st = configs.osqp_settings_config4() if cid == 4 else abi.default_osqp_settings()
     ctx = runtime.Context(local_rank)
-    ctx.upload(desc, abi.default_sqp_params(), abi.default_osqp_settings())
+    ctx.upload(desc, abi.default_sqp_params(), osqp_st)
+    # the library's own RCCL communicator for the best-seed reduction (also with one rank: the collective always runs)
+    uid = torch.zeros(128, dtype=torch.uint8, device=dev)
+    if rank == 0:
+        uid = torch.tensor(list(ctx.nccl_unique_id()), dtype=torch.uint8, device=dev)
+    if world > 1:
+        dist.broadcast(uid, src=0)
+    ctx.nccl_init(bytes(uid.cpu().tolist()), world, rank)
 
     nsteps = args.warmup + args.steps
     # synthetic seeds (counter-based Philox keyed by (config, global problem index)), resident in HBM before timing
-    seeds_host = configs.seeds_for(1, pci, start, goal, B * nsteps, first=rank * B * nsteps)
+    kw = {} if spec[2] is None else {"sigma": spec[2]}
+    seeds_host = configs.seeds_for(cid, pci, start, goal, B * nsteps, first=rank * B * nsteps, **kw)
     seeds = torch.from_numpy(seeds_host.reshape(nsteps, B, T, D)).to(dev)
     torch.cuda.synchronize()
 
@@ -70,8 +94,7 @@ def main():
         ctx.set_x0_device(seeds[k].data_ptr(), B)
         ctx.run(0)
         r = ctx.results()
-        c, i = parallel.local_best(r["status"], r["total_cost"], (rank * nsteps + k) * B)
-        best = parallel.best_seed_allgather(c, i, dev)   # the only collective (RCCL all_gather of 16 bytes / rank)
+        best = ctx.argmin((rank * nsteps + k) * B)   # the only collective: RCCL all-gather of 16 bytes per rank inside the library
         return r, best
 
     for k in range(args.warmup):
@@ -86,10 +109,11 @@ def main():
     for k in range(args.warmup, nsteps):
         r, best = one_step(k)
         c = ctx.counters()
-        tot_fe += int((r["n_func_evals"] - 1).sum())
+        # trajopt_sqp counts QP solves only (SQPResults::overall_iteration): one trust-region evaluation each
+        tot_fe += int(r["n_qp_solves"].sum()) if cid == 4 else int((r["n_func_evals"] - 1).sum())
         tot_qp += int(r["n_qp_solves"].sum())
         tot_admm += c["admm_iters"]
-        conv += int((r["status"] == abi.OPT_CONVERGED).sum())
+        conv += int((r["status"] == conv_code).sum())
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -132,14 +156,25 @@ def main():
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         roofline = {
             "kernel": "k_sqp_pool", "bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic,
+            "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic if cid == 1 else None,
             "avg_launch_ms": avg_ms, "launches": launches, "algorithmic_flop_per_admm_iter": f_iter,
             "admm_iters_per_launch": tot_admm / launches,
             "kernel_time_share": {"admm_ms": stats["admm_ms"], "convexify_ms": stats["convexify_ms"],
                                   "evaluate_ms": stats["evaluate_ms"], "wall_ms": (t1 - t0) * 1e3},
         }
+        if cid != 1:
+            # QP workspace in HBM (k_sqp_fused_hbm) or the generic LDS path inside k_sqp_pool: the block factor and the rows are
+            # streamed every ADMM iteration - SURVEY.md section 8(d): B_admm = 2 * 12 * (nnz(L) + nnz(A)) bytes per iteration,
+            # nnz(L) ~ T * 1.5 * D^2 + the slack couplings (one per aux variable)
+            nnzL = 1.5 * T * D * D + (r0.n - T * D)
+            b_iter = 24.0 * (nnzL + r0.nnzA)
+            ach = b_iter * tot_admm / launches / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+            roofline = {"kernel": "k_sqp_fused_hbm" if r0.n * 8 * 30 > 160 * 1024 else "k_sqp_pool", "bound": "hbm", "achieved": ach, "peak": 8000.0,
+                        "unit": "GB/s", "frac": ach / 8000.0, "traffic": None, "avg_launch_ms": avg_ms, "launches": launches,
+                        "algorithmic_bytes_per_admm_iter": b_iter, "admm_iters_per_launch": tot_admm / launches,
+                        "flop_view": {"achieved_tflops": achieved, "frac_of_fp64_peak": achieved / FP64_PEAK_TFLOPS}}
         cpu = None
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and cid == 1:
             from oracle import pyorc
             cores = os.cpu_count() or 1
             pyorc.build()
@@ -164,11 +199,12 @@ def main():
                    "qp_solves_per_s": float(o["n_qp_solves"].sum() / best[3]),
                    "admm_iters_per_s": float(o["admm_iters"] / best[3])}
         line = {
-            "metric": "SQP iters/s (+ QP solves/s), 7-DOF x 30-wp x 1024-batch glass_upright",
+            "metric": "SQP iters/s (+ QP solves/s), 7-DOF x 30-wp x 1024-batch glass_upright" if cid == 1 else
+                      "SQP iters/s (+ QP solves/s), BASELINE config %d" % cid,
             "value": g_fe / elapsed, "unit": "SQP iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / max(1, args.steps) * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "config 1: glass_upright 7-DOF 30-waypoint, collision cost, batch=%d random seeds per GPU" % B,
+            "config": {"workload": spec[3] % B,
                        "n_dof": D, "n_steps": T, "batch_per_gpu": B, "qp_n": r0.n, "qp_m": r0.m, "parallelism": "seeds sharded, dp%d" % world},
             "qp_solves_per_s": g_qp / elapsed, "admm_iters_per_s": g_admm / elapsed,
             "converged_frac": g_conv / (B * world * max(1, args.steps)),

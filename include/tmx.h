@@ -371,6 +371,12 @@ TMX_API tmx_status tmx_qp_active_set(tmx_ctx* ctx, int32_t* flags /* B * m_max *
  *      ranks with RCCL — the only collective on the path.                               */
 TMX_API tmx_status tmx_argmin(tmx_ctx* ctx, int64_t global_offset, int64_t* best_index, double* best_cost);
 TMX_API tmx_status tmx_attach_nccl(tmx_ctx* ctx, void* nccl_comm /* ncclComm_t */);
+/* ... or let the library own its communicator: rank 0 calls tmx_nccl_unique_id and ships the 128 bytes to the other ranks by
+ * any means (bench.py: torch.distributed broadcast); every rank then calls tmx_nccl_init (ncclCommInitRank on the context's
+ * device and stream).  The communicator is destroyed with the context.                                           */
+#define TMX_NCCL_UNIQUE_ID_BYTES 128
+TMX_API tmx_status tmx_nccl_unique_id(uint8_t id[TMX_NCCL_UNIQUE_ID_BYTES]);
+TMX_API tmx_status tmx_nccl_init(tmx_ctx* ctx, const uint8_t id[TMX_NCCL_UNIQUE_ID_BYTES], int32_t n_ranks, int32_t rank);
 
 /* ---- measurement hooks (bench.py): HIP-event time and launch count of the dominant kernel ----------- */
 TMX_API tmx_status tmx_kernel_stats(tmx_ctx* ctx, double* admm_ms_total, int64_t* admm_launches, double* convexify_ms_total,

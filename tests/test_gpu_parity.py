@@ -163,6 +163,10 @@ def test_full_batch_properties(gpu):
     ok = r3["status"] == abi.OPT_CONVERGED
     ref = np.where(ok, r3["total_cost"], np.inf)
     assert bi == 1000 + int(np.argmin(ref)) and abs(bc - ref.min()) == 0.0
+    # the same reduction through the library's own RCCL communicator (one rank: the all-gather of the (cost, index) pair
+    # still runs - it is the only collective on the path, tmx_nccl_init / tmx_argmin)
+    gpu.nccl_init(gpu.nccl_unique_id(), 1, 0)
+    assert gpu.argmin(1000) == (bi, bc)
 
 
 def test_golden_fixture_first_qp(gpu, orc):

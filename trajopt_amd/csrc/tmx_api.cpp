@@ -54,6 +54,9 @@ struct tmx_ctx
   int mode{ 2 };  // optimize() driver: 0 = one launch chain per step, 1 = k_sqp_fused, 2 = k_sqp_pool (default)
   int pool_wgs{ 0 };  // resident workgroups of the pool kernel (0 = CUs x workgroups-per-CU)
   void* nccl{ nullptr };
+  bool nccl_owned{ false };
+  double* d_pair{ nullptr };   // K7: [2] local (cost, index) + [2 * n_ranks] gathered pairs
+  int pair_cap{ 0 };
   int max_rec{ 128 };
 };
 
@@ -181,6 +184,12 @@ void tmx_destroy(tmx_ctx* ctx)
     (void)hipFree(ctx->db);
   if (ctx->d_totals)
     (void)hipFree(ctx->d_totals);
+  if (ctx->d_pair)
+    (void)hipFree(ctx->d_pair);
+#ifndef TMX_HOST_EMU
+  if (ctx->nccl && ctx->nccl_owned)
+    (void)ncclCommDestroy(static_cast<ncclComm_t>(ctx->nccl));
+#endif
   (void)hipEventDestroy(ctx->ev0);
   (void)hipEventDestroy(ctx->ev1);
   (void)hipStreamDestroy(ctx->stream);
@@ -1561,6 +1570,20 @@ tmx_status tmx_qp_active_set(tmx_ctx* ctx, int32_t* flags)
   return TMX_OK;
 }
 
+static tmx_status ensure_pairs(tmx_ctx* ctx, int n_ranks)
+{
+  if (ctx->d_pair && ctx->pair_cap >= n_ranks)
+    return TMX_OK;
+  if (ctx->d_pair)
+    (void)hipFree(ctx->d_pair);
+  ctx->d_pair = nullptr;
+  void* p = nullptr;
+  HIPCHK(hipMalloc(&p, sizeof(double) * (2 + 2 * (size_t)n_ranks)));
+  ctx->d_pair = static_cast<double*>(p);
+  ctx->pair_cap = n_ranks;
+  return TMX_OK;
+}
+
 tmx_status tmx_argmin(tmx_ctx* ctx, int64_t global_offset, int64_t* best_index, double* best_cost)
 {
   if (!ctx || !best_index || !best_cost)
@@ -1568,60 +1591,102 @@ tmx_status tmx_argmin(tmx_ctx* ctx, int64_t global_offset, int64_t* best_index, 
   if (ctx->Bcap == 0)
     return TMX_ERR_STATE;
   HIPCHK(hipSetDevice(ctx->device));
-  const int B = ctx->hb.B;
-  std::vector<double> cost(B);
-  std::vector<int> status(B);
-  HIPCHK(hipMemcpy(cost.data(), ctx->hb.total_cost, sizeof(double) * B, hipMemcpyDeviceToHost));
-  HIPCHK(hipMemcpy(status.data(), ctx->hb.status, sizeof(int) * B, hipMemcpyDeviceToHost));
+  int nranks = 1;
+#ifndef TMX_HOST_EMU
+  ncclComm_t comm = static_cast<ncclComm_t>(ctx->nccl);
+  if (comm && ncclCommCount(comm, &nranks) != ncclSuccess)
+    return TMX_ERR_NCCL;
+#endif
+  tmx_status rc = ensure_pairs(ctx, nranks);
+  if (rc != TMX_OK)
+    return rc;
+  // local argmin on the device (one workgroup), then - with a communicator - the only collective on the path: an
+  // all-gather of one (cost, index) pair per rank (16 bytes each) and an argmin over the n_ranks pairs
+  const int conv = ctx->hp.flavor == TMX_FLAVOR_SQP ? (int)TMX_SQP_CONVERGED : (int)TMX_OPT_CONVERGED;
+  const int nt = ctx->nt_qp > 1 ? 256 : 1;
+  TMX_LAUNCH(k_argmin, 1, nt, (size_t)nt * 16, ctx->stream, ctx->db, conv, (long long)global_offset, ctx->d_pair);
+  HIPCHK(hipGetLastError());
+  std::vector<double> all(2 * (size_t)nranks);
+#ifndef TMX_HOST_EMU
+  if (comm)
+  {
+    if (ncclAllGather(ctx->d_pair, ctx->d_pair + 2, 2, ncclDouble, comm, ctx->stream) != ncclSuccess)
+    {
+      ctx->err = "ncclAllGather failed";
+      return TMX_ERR_NCCL;
+    }
+    HIPCHK(hipMemcpyAsync(all.data(), ctx->d_pair + 2, sizeof(double) * 2 * nranks, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  else
+#endif
+    HIPCHK(hipMemcpyAsync(all.data(), ctx->d_pair, sizeof(double) * 2, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
   double bc = 1e300;
   long long bi = -1;
-  for (int b = 0; b < B; ++b)
-    if (status[b] == TMX_OPT_CONVERGED && cost[b] < bc)
+  for (int r = 0; r < nranks; ++r)
+    if (all[2 * r + 1] >= 0 && (all[2 * r] < bc || (all[2 * r] == bc && (bi < 0 || (long long)all[2 * r + 1] < bi))))
     {
-      bc = cost[b];
-      bi = global_offset + b;
+      bc = all[2 * r];
+      bi = static_cast<long long>(all[2 * r + 1]);
     }
-#ifndef TMX_HOST_EMU
-  if (ctx->nccl)
-  {
-    // the only collective on the path: all-gather of one (cost, index) pair per rank, then a local argmin
-    ncclComm_t comm = static_cast<ncclComm_t>(ctx->nccl);
-    int nranks = 1, rank = 0;
-    if (ncclCommCount(comm, &nranks) != ncclSuccess || ncclCommUserRank(comm, &rank) != ncclSuccess)
-      return TMX_ERR_NCCL;
-    double pair[2] = { bc, static_cast<double>(bi) };
-    double* d_send = nullptr;
-    double* d_recv = nullptr;
-    HIPCHK(hipMalloc(reinterpret_cast<void**>(&d_send), 2 * sizeof(double)));
-    HIPCHK(hipMalloc(reinterpret_cast<void**>(&d_recv), 2 * sizeof(double) * nranks));
-    HIPCHK(hipMemcpyAsync(d_send, pair, sizeof(pair), hipMemcpyHostToDevice, ctx->stream));
-    if (ncclAllGather(d_send, d_recv, 2, ncclDouble, comm, ctx->stream) != ncclSuccess)
-      return TMX_ERR_NCCL;
-    std::vector<double> all(2 * nranks);
-    HIPCHK(hipMemcpyAsync(all.data(), d_recv, sizeof(double) * 2 * nranks, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    (void)hipFree(d_send);
-    (void)hipFree(d_recv);
-    bc = 1e300;
-    bi = -1;
-    for (int r = 0; r < nranks; ++r)
-      if (all[2 * r + 1] >= 0 && all[2 * r] < bc)
-      {
-        bc = all[2 * r];
-        bi = static_cast<long long>(all[2 * r + 1]);
-      }
-  }
-#endif
   *best_index = bi;
   *best_cost = bc;
   return TMX_OK;
+}
+
+tmx_status tmx_nccl_unique_id(uint8_t id[TMX_NCCL_UNIQUE_ID_BYTES])
+{
+  if (!id)
+    return TMX_ERR_INVALID;
+#ifdef TMX_HOST_EMU
+  std::memset(id, 0, TMX_NCCL_UNIQUE_ID_BYTES);
+  return TMX_OK;
+#else
+  static_assert(sizeof(ncclUniqueId) <= TMX_NCCL_UNIQUE_ID_BYTES, "ncclUniqueId larger than the ABI buffer");
+  ncclUniqueId u;
+  if (ncclGetUniqueId(&u) != ncclSuccess)
+    return TMX_ERR_NCCL;
+  std::memset(id, 0, TMX_NCCL_UNIQUE_ID_BYTES);
+  std::memcpy(id, &u, sizeof(u));
+  return TMX_OK;
+#endif
+}
+
+tmx_status tmx_nccl_init(tmx_ctx* ctx, const uint8_t id[TMX_NCCL_UNIQUE_ID_BYTES], int32_t n_ranks, int32_t rank)
+{
+  if (!ctx || !id || n_ranks < 1 || rank < 0 || rank >= n_ranks)
+    return TMX_ERR_INVALID;
+#ifdef TMX_HOST_EMU
+  return TMX_OK;  // no collective in the host emulation (tests use gloo above the C-ABI)
+#else
+  HIPCHK(hipSetDevice(ctx->device));
+  if (ctx->nccl && ctx->nccl_owned)
+    (void)ncclCommDestroy(static_cast<ncclComm_t>(ctx->nccl));
+  ctx->nccl = nullptr;
+  ncclUniqueId u;
+  std::memcpy(&u, id, sizeof(u));
+  ncclComm_t comm = nullptr;
+  if (ncclCommInitRank(&comm, n_ranks, u, rank) != ncclSuccess)
+  {
+    ctx->err = "ncclCommInitRank failed";
+    return TMX_ERR_NCCL;
+  }
+  ctx->nccl = comm;
+  ctx->nccl_owned = true;
+  return TMX_OK;
+#endif
 }
 
 tmx_status tmx_attach_nccl(tmx_ctx* ctx, void* nccl_comm)
 {
   if (!ctx)
     return TMX_ERR_INVALID;
+#ifndef TMX_HOST_EMU
+  if (ctx->nccl && ctx->nccl_owned)
+    (void)ncclCommDestroy(static_cast<ncclComm_t>(ctx->nccl));
+#endif
   ctx->nccl = nccl_comm;
+  ctx->nccl_owned = false;
   return TMX_OK;
 }
 

@@ -428,6 +428,38 @@ TMX_KERNEL k_pool_sync(const DevBatch* Bt)
   }
 }
 
+// K7: local best seed - argmin of total_cost over the converged problems (ties: lowest index), one workgroup.
+// out[0] = cost (1e300: none), out[1] = global index as a double (-1: none)
+TMX_KERNEL k_argmin(const DevBatch* Bt, int converged_code, long long global_offset, double* out)
+{
+  TMX_SMEM(smem);
+  const int tid = threadIdx.x, NT = blockDim.x;
+  double bc = 1e300;
+  long long bi = -1;
+  for (int b = tid; b < Bt->B; b += NT)
+    if (Bt->status[b] == converged_code && Bt->total_cost[b] < bc)
+    {
+      bc = Bt->total_cost[b];
+      bi = b;
+    }
+  double* sc = smem;                                            // NT costs
+  long long* si = reinterpret_cast<long long*>(smem + NT);     // NT indices
+  sc[tid] = bc;
+  si[tid] = bi;
+  TMX_SYNC();
+  if (tid == 0)
+  {
+    for (int k = 1; k < NT; ++k)
+      if (si[k] >= 0 && (sc[k] < bc || (sc[k] == bc && (bi < 0 || si[k] < bi))))
+      {
+        bc = sc[k];
+        bi = si[k];
+      }
+    out[0] = bc;
+    out[1] = (bi >= 0) ? (double)(global_offset + bi) : -1.0;
+  }
+}
+
 // number of problems not DONE + running totals; `totals` = {n_active, n_fe, n_qp, admm} zeroed by the host first
 TMX_KERNEL k_count_active(const DevBatch* Bt, long long* totals)
 {

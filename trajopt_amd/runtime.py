@@ -40,6 +40,8 @@ _SIGS = {
     "tmx_qp_duals": ([C.c_void_p, C.c_void_p], C.c_int),
     "tmx_argmin": ([C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_double)], C.c_int),
     "tmx_attach_nccl": ([C.c_void_p, C.c_void_p], C.c_int),
+    "tmx_nccl_unique_id": ([C.c_void_p], C.c_int),
+    "tmx_nccl_init": ([C.c_void_p, C.c_void_p, C.c_int32, C.c_int32], C.c_int),
     "tmx_kernel_stats": ([C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)], C.c_int),
     "tmx_kernel_stats_reset": ([C.c_void_p], C.c_int),
     "tmx_sqp_state": ([C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p], C.c_int),
@@ -240,6 +242,16 @@ class Context:
         bi, bc = C.c_int64(), C.c_double()
         self._chk(self.lib.tmx_argmin(self.h, global_offset, C.byref(bi), C.byref(bc)))
         return bi.value, bc.value
+
+    def nccl_unique_id(self) -> bytes:
+        buf = (C.c_uint8 * 128)()
+        self._chk(self.lib.tmx_nccl_unique_id(buf))
+        return bytes(buf)
+
+    def nccl_init(self, unique_id: bytes, n_ranks: int, rank: int):
+        """the library's own RCCL communicator for the best-seed reduction (tmx_argmin then spans all ranks)"""
+        buf = (C.c_uint8 * 128)(*unique_id)
+        self._chk(self.lib.tmx_nccl_init(self.h, buf, n_ranks, rank))
 
     def attach_nccl(self, comm_ptr: int):
         self._chk(self.lib.tmx_attach_nccl(self.h, C.c_void_p(comm_ptr)))
