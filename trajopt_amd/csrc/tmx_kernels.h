@@ -155,6 +155,7 @@ TMX_KERNEL k_sqp_update(const DevProblem* P, const DevBatch* Bt)
 
 // One trust-region evaluation of problem b: [convexify + QP structure] -> Model::optimize -> exact re-evaluation ->
 // accept / shrink / penalty decisions.  All state lives in HBM between calls.
+template <bool HBM = false>
 TMX_DEVFN void sqp_step_block(const DevProblem* P, const DevBatch* Bt, int b, double* smem, int tid, int NT, double* chain_lds = nullptr)
 {
   const int R = P->R, D = P->D, NX = P->NX;
@@ -191,7 +192,7 @@ TMX_DEVFN void sqp_step_block(const DevProblem* P, const DevBatch* Bt, int b, do
   if (tid == 0)
     Bt->prof[(size_t)b * 16 + 11] += TMX_CLK() - tp0;
 #endif
-  qp_solve_block(P, Bt, b, smem, tid, NT, chain_lds);
+  qp_solve_block<HBM>(P, Bt, b, smem, tid, NT, chain_lds);
 #ifdef TMX_PROFILE
   tp0 = TMX_CLK();
 #endif
@@ -240,7 +241,7 @@ TMX_KERNEL_LB2(TMX_QP_NT, 1) k_qp_solve_hbm(const DevProblem* P, const DevBatch*
     return;
   double* work = Bt->ws_hbm + (size_t)b * (size_t)Bt->ws_hbm_stride;
   TMX_SMEM(lds);
-  qp_solve_block(P, Bt, b, work, tid, NT, Bt->ws_chain_in_lds ? lds : nullptr);
+  qp_solve_block<true>(P, Bt, b, work, tid, NT, Bt->ws_chain_in_lds ? lds : nullptr);
   const double* xq = Bt->xq + (size_t)b * P->n_max;
   double* xn = Bt->xnew + (size_t)b * P->NX;
   for (int v = tid; v < P->NX; v += NT)
@@ -256,7 +257,7 @@ TMX_KERNEL_LB2(TMX_QP_NT, 1) k_sqp_fused_hbm(const DevProblem* P, const DevBatch
   {
     if (Bt->phase[b] == PHASE_DONE)
       break;
-    sqp_step_block(P, Bt, b, work, tid, NT, chain_lds);
+    sqp_step_block<true>(P, Bt, b, work, tid, NT, chain_lds);
   }
 }
 

@@ -482,6 +482,82 @@ TMX_DEVFN double dpart_correct(const HotLds& h, const DMap& m, double y)
   return y - __builtin_fma(mr, tr, ml * tl);
 }
 
+// ---- register-resident variants (RC = true instantiation of the burst): the matrix operands of the three phases are
+//      constants of a factorisation, so each thread keeps ITS rows in registers for the whole burst - its row of G_k
+//      (phase 1 and the first-block columns of phase 3), the last-block columns of that row (phase 3) and its quarter of
+//      a Zs row (phase 2) - and LDS only carries the vectors.  The loop is LDS-throughput bound (44 % of its cycles are
+//      ds_read_b128 data beats): this removes 34 of the 80 16-byte reads per thread and iteration.  Same products, same
+//      summation order as the LDS variants above (results bit-identical).
+#define TMX_RC_GP 12  // pairs of a G row held in registers (Gs <= 24)
+#define TMX_RC_ZP 8   // pairs of a Zs row quarter (Zst <= 64)
+TMX_DEVFN double dpart_interior_rc(const HotLds& h, const DMap& m, const double (&gr)[2 * TMX_RC_GP])
+{
+  const tmx_lds_d2* bb = reinterpret_cast<const tmx_lds_d2*>(h.ty + m.k * h.Gs);
+  tmx_d2 b[TMX_RC_GP];
+#pragma unroll
+  for (int p = 0; p < TMX_RC_GP; ++p)
+    b[p] = bb[p];  // reads past Gs stay inside ty (finite) and meet zero matrix entries
+  double s[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q)
+    s[q] = 0.0;
+#pragma unroll
+  for (int p = 0; p < TMX_RC_GP; ++p)
+  {
+    const int u = p & 3;
+    s[2 * u] = __builtin_fma(gr[2 * p], b[p].x, s[2 * u]);
+    s[2 * u + 1] = __builtin_fma(gr[2 * p + 1], b[p].y, s[2 * u + 1]);
+  }
+  return ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+}
+// bl = b_sep - C y_left is formed by the interior thread that produces C y_left (sx[0..)), so this phase reads two
+// vectors instead of three:  z * ((b - l) - r)  with the same roundings
+TMX_DEVFN double dpart_separator_row_rc(const HotLds& h, const DMap& m, const double (&zq)[2 * TMX_RC_ZP])
+{
+  const int jc = h.Zst >> 2;
+  const tmx_lds_d2* bl = reinterpret_cast<const tmx_lds_d2*>(h.sx + m.qq * jc);
+  const tmx_lds_d2* yr = reinterpret_cast<const tmx_lds_d2*>(h.sx + 64 + m.qq * jc);
+  tmx_d2 l[TMX_RC_ZP], r[TMX_RC_ZP];
+#pragma unroll
+  for (int p = 0; p < TMX_RC_ZP; ++p)
+  {
+    l[p] = bl[p];  // entries past the quarter belong to the next quarter / the next vector: finite, times zero
+    r[p] = yr[p];
+  }
+  double s[4] = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+  for (int p = 0; p < TMX_RC_ZP; ++p)
+  {
+    const int u = p & 3;
+    s[(2 * u) & 3] = __builtin_fma(zq[2 * p], l[p].x - r[p].x, s[(2 * u) & 3]);
+    s[(2 * u + 1) & 3] = __builtin_fma(zq[2 * p + 1], l[p].y - r[p].y, s[(2 * u + 1) & 3]);
+  }
+  return quad_sum((s[0] + s[1]) + (s[2] + s[3]));
+}
+TMX_DEVFN double dpart_correct_rc(const HotLds& h, const DMap& m, double y, const double (&gr)[2 * TMX_RC_GP], const double (&gc)[8])
+{
+  const tmx_lds_d2* xl2 = reinterpret_cast<const tmx_lds_d2*>(h.sx + 192 + (m.hasl ? m.k - 1 : 0) * 8);
+  const tmx_lds_d2* xr2 = reinterpret_cast<const tmx_lds_d2*>(h.sx + 128 + (m.hasr ? m.k : 0) * 8);
+  const double ml = m.hasl ? 1.0 : 0.0, mr = m.hasr ? 1.0 : 0.0;
+  tmx_d2 b[4], d[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+  {
+    b[q] = xl2[q];
+    d[q] = xr2[q];
+  }
+  double sl[4], sr[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+  {
+    // gr / gc hold zeros in the columns >= D (masked when they were loaded)
+    sl[q] = __builtin_fma(gr[2 * q + 1], b[q].y, gr[2 * q] * b[q].x);
+    sr[q] = __builtin_fma(gc[2 * q + 1], d[q].y, gc[2 * q] * d[q].x);
+  }
+  const double tl = (sl[0] + sl[1]) + (sl[2] + sl[3]), tr = (sr[0] + sr[1]) + (sr[2] + sr[3]);
+  return y - __builtin_fma(mr, tr, ml * tl);
+}
+
 // sequential (one-sided) inversion of the whole chain by wave 0 — used for the polish factorisation
 TMX_DEVFN void kkt_invert_chain_wave0(const QpWs& w, int tid)
 {
@@ -644,6 +720,13 @@ struct TmxTag
 #else
 #define TMX_LTICK(s) ((void)0)  // per-phase ticks inside the iteration perturb it (~100 cycles each): opt-in
 #endif
+// RC  : matrix rows of the dense solve in registers (workgroup-uniform: it also selects the b_sep - C y_left exchange)
+// NR  : constraint rows per thread compiled in (1 or NR); wave-uniform - only the waves that really carry rows
+//       beyond NT run the two-row instantiation
+// INTW: the wave has interior variables (else no G-row registers and no phase 1 / 3 code)
+// The instantiations differ per WAVE, not per thread: every wave executes the same five barriers per iteration, and the
+// register allocation of the kernel is the maximum over the instantiations instead of the union of all roles.
+template <bool RC, int NR, bool INTW>
 TMX_DEVFN void admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, bool keep_last, int tid, long long* pc, long long& tlast)
 {
   const int D = __builtin_amdgcn_readfirstlane(w.D);
@@ -663,18 +746,18 @@ TMX_DEVFN void admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, b
   h.Zst = __builtin_amdgcn_readfirstlane(w.Zst);
   // rows 0 .. NT-1 go to thread r; the rows beyond NT go to the LAST threads of the workgroup, which own no primary
   // variable and no dense-solve role: the wave that carries second rows is not the one that carries everything else
-  int rowi[TMX_NROW];
+  int rowi[NR];
   rowi[0] = tid;
 #pragma unroll
-  for (int q = 1; q < TMX_NROW; ++q)
+  for (int q = 1; q < NR; ++q)
   {
     const int extra = w.R - q * TMX_QP_NT;  // rows in this layer
     const int first = TMX_QP_NT - extra;    // first thread that takes one
     rowi[q] = (extra > 0 && tid >= first) ? q * TMX_QP_NT + (tid - first) : -1;
   }
-  RowRegs g[TMX_NROW];
+  RowRegs g[NR];
 #pragma unroll
-  for (int q = 0; q < TMX_NROW; ++q)
+  for (int q = 0; q < NR; ++q)
     row_load(w, rowi[q], g[q]);
   TMX_PTICK(1);
   DPart dp;
@@ -683,7 +766,7 @@ TMX_DEVFN void admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, b
   dpart_map(w, dp, tid, mp);
   const bool pv = mp.v >= 0;
   const int v = pv ? mp.v : 0;
-  const bool interior = pv && !mp.sep;
+  const bool interior = INTW && pv && !mp.sep;
   const tmx_lds_d* bsep = h.ty + dp.P * h.Gs;
   // pad entries of the permuted rhs and of the separator exchange vectors are multiplied by zero matrix padding:
   // keep them finite
@@ -697,10 +780,10 @@ TMX_DEVFN void admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, b
   const double sigma = w.sigma, alpha = w.alpha, om = 1.0 - alpha;
   // (moving these, sigma and alpha to scalar registers with readfirstlane was measured: -1 .. -2 %)
   const double rho_b = rho_of_type(0, w.rho), rhoi_b = rcp_rho_of_type(0, w.rho);
-  int tb[TMX_NROW];
-  bool has[TMX_NROW];
+  int tb[NR];
+  bool has[NR];
 #pragma unroll
-  for (int q = 0; q < TMX_NROW; ++q)
+  for (int q = 0; q < NR; ++q)
   {
     tb[q] = g[q].t * 8;  // x~ is exchanged with 8 slots per waypoint
     has[q] = rowi[q] >= 0 && rowi[q] < w.R;
@@ -723,9 +806,9 @@ TMX_DEVFN void admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, b
   // holds the rows of waypoint t in wp_list order, so the A'e gather of a variable is a run of 16-byte loads instead of
   // 16 indexed 8-byte loads (and needs no index registers).
   auto pst = [&](int t) -> int { return w.wp_pst[t]; };
-  int epos[TMX_NROW];
+  int epos[NR];
 #pragma unroll
-  for (int q = 0; q < TMX_NROW; ++q)
+  for (int q = 0; q < NR; ++q)
     epos[q] = has[q] ? w.row_epos[rowi[q]] : 0;
   // column v of A restricted to the rows of its waypoint, kept in registers (first 16 rows; a longer list falls back
   // to a loop for the remainder)
@@ -761,6 +844,38 @@ TMX_DEVFN void admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, b
     q_end = pv ? q1 : 0;
   }
   const int q0v = w.wp_start[vt];
+  // RC: this thread's matrix rows of the dense solve (constants of the factorisation) in registers
+  double gr[(RC && INTW) ? 2 * TMX_RC_GP : 2], gc[(RC && INTW) ? 8 : 2], zq[RC ? 2 * TMX_RC_ZP : 2];
+  if constexpr (RC && INTW)
+  {
+    // 16-byte loads (rows start 16-byte aligned, Gs and Zst / 4 are even); entries past the row end are replaced by zeros
+    const tmx_lds_d* Grow = h.G + (interior ? (mp.k * h.Gn + mp.r) * h.Gs : 0);
+    const tmx_lds_d2* Grow2 = reinterpret_cast<const tmx_lds_d2*>(Grow);
+#pragma unroll
+    for (int c = 0; c < TMX_RC_GP; ++c)
+    {
+      const bool ok = interior && 2 * c < h.Gs;
+      const tmx_d2 t = Grow2[ok ? c : 0];
+      gr[2 * c] = ok ? t.x : 0.0;
+      gr[2 * c + 1] = ok ? t.y : 0.0;
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+      gc[c] = (interior && c < D) ? Grow[mp.n - D + c] : 0.0;
+  }
+  if constexpr (RC)
+  {
+    const int jc = h.Zst >> 2;
+    const tmx_lds_d2* Zrow2 = reinterpret_cast<const tmx_lds_d2*>(h.Zs + (mp.qg < 0 ? 0 : mp.qg) * h.Zst + mp.qq * jc);
+#pragma unroll
+    for (int c = 0; c < TMX_RC_ZP; ++c)
+    {
+      const bool ok = mp.qg >= 0 && 2 * c < jc;
+      const tmx_d2 t = Zrow2[ok ? c : 0];
+      zq[2 * c] = ok ? t.x : 0.0;
+      zq[2 * c + 1] = ok ? t.y : 0.0;
+    }
+  }
   TMX_PTICK(3);
   // entries of the grouped buffer that no row writes (pad slots, groups of inactive rows) must stay finite
   for (int e = tid; e < w.R + w.T + 18; e += TMX_QP_NT)
@@ -772,9 +887,9 @@ TMX_DEVFN void admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, b
   // (With a run-time flag the publishing code sits inside the loop and its temporaries cost the loop registers.)
   auto iteration = [&](auto keep_tag) __attribute__((always_inline)) {
     constexpr bool keep = decltype(keep_tag)::value;
-    double ta[TMX_NROW][2];
+    double ta[NR][2];
 #pragma unroll
-    for (int q = 0; q < TMX_NROW; ++q)
+    for (int q = 0; q < NR; ++q)
     {
       const double e = row_phase_a(g[q], sigma, rho_b, ta[q]);
       if (has[q])
@@ -820,11 +935,14 @@ TMX_DEVFN void admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, b
     TMX_LTICK(2);
     // dense nested-dissection solve: interiors -> separators (4 lanes per variable) -> correction
     double yint = 0.0;
-    if (interior)
+    if (INTW && interior)
     {
-      yint = dpart_interior(h, mp);
+      if constexpr (RC && INTW)
+        yint = dpart_interior_rc(h, mp, gr);
+      else
+        yint = dpart_interior(h, mp);
       if (wr_yl)
-        h.sx[i_yl] = cnext * yint;
+        h.sx[i_yl] = RC ? bsep[i_yl] - cnext * yint : cnext * yint;  // RC: b_sep - C y_left in one slot
       if (wr_yr)
         h.sx[i_yr] = cprev * yint;
     }
@@ -832,7 +950,11 @@ TMX_DEVFN void admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, b
     TMX_LTICK(3);
     if (tid < 256)
     {
-      const double xs = dpart_separator_row(h, mp, bsep);
+      double xs;
+      if constexpr (RC)
+        xs = dpart_separator_row_rc(h, mp, zq);
+      else
+        xs = dpart_separator_row(h, mp, bsep);
       if (qlead)
       {
         h.tp[qvp] = xs;
@@ -841,14 +963,19 @@ TMX_DEVFN void admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, b
       }
     }
     TMX_SYNC();
-    if (interior)
-      h.tp[vp] = dpart_correct(h, mp, yint);
+    if (INTW && interior)
+    {
+      if constexpr (RC && INTW)
+        h.tp[vp] = dpart_correct_rc(h, mp, yint, gr, gc);
+      else
+        h.tp[vp] = dpart_correct(h, mp, yint);
+    }
     TMX_SYNC();
     TMX_LTICK(4);
     // phase C
     const double xtv = h.tp[vp];
 #pragma unroll
-    for (int q = 0; q < TMX_NROW; ++q)
+    for (int q = 0; q < NR; ++q)
     {
       RowRegs& gq = g[q];
       // x~ of the row's waypoint: 8 slots per waypoint (slot 7 of a 7-dof block is never written: multiplied by c[7] = 0,
@@ -905,7 +1032,7 @@ TMX_DEVFN void admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, b
     iteration(TmxTag<true>{});
   TMX_TICK(2);
 #pragma unroll
-  for (int q = 0; q < TMX_NROW; ++q)
+  for (int q = 0; q < NR; ++q)
     row_store(w, rowi[q], g[q]);
   if (pv)
   {
@@ -920,13 +1047,14 @@ TMX_DEVFN void admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, b
 #ifdef TMX_BURST_NOINLINE
 // out-of-line variant: the loop is register-allocated on its own (256 architectural VGPRs); the workspace descriptor
 // is handed over through a small LDS copy
+template <bool RC, int NR, bool INTW>
 __device__ __attribute__((noinline)) static void admm_burst_nl(const QpWs* wsh, const DevProblem* P, int n_iter_in, int keep_last_in,
                                                               long long* pc_out, long long* tlast_p)
 {
   const QpWs w = *wsh;
   long long pc[16] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
   long long tlast = *tlast_p;
-  admm_burst_core(w, P, __builtin_amdgcn_readfirstlane(n_iter_in), __builtin_amdgcn_readfirstlane(keep_last_in) != 0, threadIdx.x, pc, tlast);
+  admm_burst_core<RC, NR, INTW>(w, P, __builtin_amdgcn_readfirstlane(n_iter_in), __builtin_amdgcn_readfirstlane(keep_last_in) != 0, threadIdx.x, pc, tlast);
 #ifdef TMX_PROFILE
 #pragma unroll
   for (int q = 0; q < 16; ++q)
@@ -936,15 +1064,44 @@ __device__ __attribute__((noinline)) static void admm_burst_nl(const QpWs* wsh, 
 }
 #endif
 
+#ifndef TMX_BURST_RC
+#define TMX_BURST_RC 1
+#endif
 TMX_DEVFN void admm_run_fast(const QpWs& w, const DevProblem* P, int n_iter, bool keep_last, int tid, long long* pc, long long& tlast)
 {
+  // matrix rows of the dense solve in registers when they fit the fixed register arrays (7-DOF / 30 waypoints: Gs = 22, Zst = 56)
+  const bool rc = TMX_BURST_RC && w.Gs <= 2 * TMX_RC_GP && w.Zst <= 8 * TMX_RC_ZP;
+  // wave roles (all wave-uniform): rows beyond NT sit on the last threads, interior variables on the first NI
+  const int wave0 = __builtin_amdgcn_readfirstlane(tid) & ~63;
+  const int extra = w.R - TMX_QP_NT;
+  const bool two = TMX_NROW > 1 && extra > 0 && wave0 + 63 >= TMX_QP_NT - extra;
+  DPart dp;
+  dpart_make(w.T, dp);
+  const bool intw = wave0 < w.NX - (dp.P - 1) * w.D;
 #ifdef TMX_BURST_NOINLINE
   QpWs* wsh = reinterpret_cast<QpWs*>(w.wself);
   if (tid == 0)
     *wsh = w;
   TMX_SYNC();
-  admm_burst_nl(wsh, P, n_iter, keep_last ? 1 : 0, pc, &tlast);
+#define TMX_BURST_CALL(RCv, NRv, INTv) admm_burst_nl<RCv, NRv, INTv>(wsh, P, n_iter, keep_last ? 1 : 0, pc, &tlast)
 #else
-  admm_burst_core(w, P, n_iter, keep_last, tid, pc, tlast);
+#define TMX_BURST_CALL(RCv, NRv, INTv) admm_burst_core<RCv, NRv, INTv>(w, P, n_iter, keep_last, tid, pc, tlast)
 #endif
+  if (!rc)
+    TMX_BURST_CALL(false, TMX_NROW, true);
+  else if (two)
+  {
+    if (intw)
+      TMX_BURST_CALL(true, TMX_NROW, true);
+    else
+      TMX_BURST_CALL(true, TMX_NROW, false);
+  }
+  else
+  {
+    if (intw)
+      TMX_BURST_CALL(true, 1, true);
+    else
+      TMX_BURST_CALL(true, 1, false);
+  }
+#undef TMX_BURST_CALL
 }

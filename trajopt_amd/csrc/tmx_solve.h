@@ -518,6 +518,175 @@ static inline void debug_kkt_residual(const QpWs& w, const DevProblem* P, int it
 }
 #endif
 
+
+#if TMX_IS_DEVICE
+// The delta vectors of the last ADMM iteration are written at the end of a burst and read by the termination test
+// that follows it.  On the dense fast path the block factor Sinv is only live inside a factorisation (which comes
+// after that test) and during the polish (whose own iterate sits in the G region), so the deltas ALIAS Sinv in LDS
+// instead of living in the HBM scratch.
+TMX_DEVFN void qp_ws_alias_deltas(QpWs& w, const DevProblem* P, const DPart& dpt)
+{
+  const int NX = w.NX, R = w.R, D = w.D, T = w.T;
+  const size_t polish_tmp = (size_t)(2 * NX + R + 3 * P->NA) + (size_t)(R + NX + P->NA + 1) / 2 + 2;
+  const size_t deltas = 2 * (size_t)NX + (size_t)R + 2 * (size_t)P->NA;
+  if (polish_tmp <= (size_t)dpt.P * w.Gn * w.Gs && deltas <= (size_t)T * D * w.DS)
+  {
+    double* q = w.Sinv;
+    w.dxp = q;
+    q += NX;
+    w.dybp = q;
+    q += NX;
+    w.dyr = q;
+    q += R;
+    w.dxa = q;
+    q += P->NA;
+    w.dyba = q;
+  }
+}
+
+#if TMX_ADMM_OUTLINED
+// ---- the ADMM loop of the dense fast path as separately compiled functions ---------------------------------------------
+// The register-resident burst needs ~460 registers.  Compiled inline it shares one allocation with 50 k instructions of
+// cold code (the kernel is one function) and both suffer; compiled as a callee of its own it saves / restores ~340
+// callee-saved registers per call, i.e. per 25 iterations (measured: +10 % throughput but 400 GiB of scratch write-back per
+// launch).  So the nesting is: the whole ADMM loop of one QP is ONE out-of-line function (qp_admm_fast_nl: entered once
+// per QP solve, contains the bursts inline and nothing else that is hot), and what runs between two bursts - residuals,
+// termination test, rho update with re-factorisation - is a second out-of-line function called from it (qp_check_nl:
+// uses few registers, so it saves few).  State crosses the calls through a small LDS record; the workspace descriptor
+// is rebuilt in each function from the LDS / scratch base pointers (pure address arithmetic, and it keeps the address
+// spaces visible to the compiler: ds_* / global_* instead of flat_*).
+struct QpShared
+{
+  double rho, sigma, alpha, c, cinv;
+  QpInfo info;
+  int terminated, can_check, iter, pad_;
+};
+TMX_DEVFN QpShared* qp_ws_rebuild(QpWs& w, const DevProblem* P, const DevBatch* Bt, int b, double* smem)
+{
+  const int D = P->D, T = P->T, R = P->R;
+  double* scratch = Bt->qp_scratch + (size_t)b * Bt->qp_scratch_stride;
+#if TMX_QP_COLD_IN_LDS
+  qp_ws_carve(w, smem, smem + qp_lds_doubles(D, T, R, P->NA, P->n_link), scratch, D, T, R, P->NA, P->n_link);
+#else
+  qp_ws_carve(w, smem, scratch + qp_far_doubles(D, T, R, P->NA), scratch, D, T, R, P->NA, P->n_link);
+#endif
+#if TMX_LINK_ROWS
+  w.c2i = P->slot_c2;
+#endif
+  DPart dpt;
+  dpart_make(T, dpt);
+  qp_ws_alias_deltas(w, P, dpt);
+  QpShared* sh = reinterpret_cast<QpShared*>(w.wself);  // the descriptor copy slot is free: the burst is inline in qp_admm_fast_nl
+  w.rho = sh->rho;
+  w.sigma = sh->sigma;
+  w.alpha = sh->alpha;
+  w.c = sh->c;
+  w.cinv = sh->cinv;
+  return sh;
+}
+static_assert(sizeof(QpShared) <= sizeof(QpWs), "QpShared must fit the descriptor slot");
+template <class T>
+TMX_DEVFN T* tmx_uniform_ptr(T* p)
+{
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return (T*)(((unsigned long long)hi << 32) | lo);
+}
+// between two bursts (iteration `iter` just done): returns 1 when the loop ends
+// (the workgroup's dynamic LDS base travels as a 32-bit LDS offset: no extern __shared__ lookup inside the callees)
+__device__ __attribute__((noinline)) static int qp_check_nl(const DevProblem* P_in, const DevBatch* Bt_in, int b_in, int iter_in, unsigned lds_in)
+{
+  const DevProblem* P = tmx_uniform_ptr(P_in);
+  const DevBatch* Bt = tmx_uniform_ptr(Bt_in);
+  const int b = __builtin_amdgcn_readfirstlane(b_in), iter = __builtin_amdgcn_readfirstlane(iter_in);
+  const int tid = threadIdx.x, NT = TMX_QP_NT;
+  double* smem = (double*)(tmx_lds_d*)(size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)lds_in);
+  const tmx_osqp_settings& st = P->osqp;
+  QpWs w;
+  QpShared* sh = qp_ws_rebuild(w, P, Bt, b, smem);
+  QpInfo info = sh->info;
+  long long pc[16];
+  long long tlast = 0;
+  (void)pc;
+  (void)tlast;
+  const bool can_check = st.check_termination && (iter % st.check_termination == 0);
+  const bool do_rho = st.adaptive_rho && st.adaptive_rho_interval && (iter % st.adaptive_rho_interval == 0);
+  int ended = 0;
+  if (can_check || do_rho)
+  {
+    info.iter = iter;
+    compute_residuals(w, P, w.xp, w.xa, w.yr, w.ybp, w.yba, 0, info, info.prim_res, info.dual_res, true, tid, NT);
+  }
+  if (can_check && check_termination(w, P, info, false, tid, NT))
+    ended = 1;
+  double rho = w.rho;
+  if (!ended && do_rho)
+  {
+    const double rho_new = rho_estimate(w, info);
+    if ((rho_new > w.rho * st.adaptive_rho_tolerance) || (rho_new < w.rho / st.adaptive_rho_tolerance))
+    {
+      w.rho = fmin(fmax(rho_new, TMX_RHO_MIN), TMX_RHO_MAX);
+      rho = w.rho;
+      info.rho_updates += 1;
+      kkt_factor(w, P, 0, w.sigma, st.delta, tid, NT);
+      kkt_invert(w, true, tid, NT, pc, tlast);
+      admm_cache_weights(w, tid, NT);
+    }
+  }
+  TMX_SYNC();
+  if (tid == 0)
+  {
+    sh->info = info;
+    sh->rho = rho;
+    sh->can_check = can_check ? 1 : 0;
+  }
+  TMX_SYNC();
+  return ended;
+}
+// the whole ADMM loop of one QP on the dense fast path (osqp_solve): in / out through the LDS record
+__device__ __attribute__((noinline)) static void qp_admm_fast_nl(const DevProblem* P_in, const DevBatch* Bt_in, int b_in, unsigned lds_in)
+{
+  const DevProblem* P = tmx_uniform_ptr(P_in);
+  const DevBatch* Bt = tmx_uniform_ptr(Bt_in);
+  const int b = __builtin_amdgcn_readfirstlane(b_in);
+  const int tid = threadIdx.x;
+  const unsigned lds_off = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_in);
+  double* smem = (double*)(tmx_lds_d*)(size_t)lds_off;
+  const tmx_osqp_settings& st = P->osqp;
+  QpShared* sh = nullptr;
+  long long pc[16];
+  long long tlast = 0;
+  (void)pc;
+  int iter = 0, ended = 0;
+  for (iter = 1; iter <= st.max_iter; ++iter)
+  {
+    int next = st.max_iter;
+    if (st.check_termination)
+      next = min(next, ((iter - 1) / st.check_termination + 1) * st.check_termination);
+    if (st.adaptive_rho && st.adaptive_rho_interval)
+      next = min(next, ((iter - 1) / st.adaptive_rho_interval + 1) * st.adaptive_rho_interval);
+    {
+      QpWs w;
+      sh = qp_ws_rebuild(w, P, Bt, b, smem);
+      admm_run_fast(w, P, next - iter + 1, true, tid, pc, tlast);
+    }
+    iter = next;
+    ended = qp_check_nl(P, Bt, b, iter, lds_off);
+    if (ended)
+      break;
+  }
+  if (tid == 0)
+  {
+    sh->terminated = ended;
+    sh->iter = iter;
+  }
+  TMX_SYNC();
+}
+#endif
+#endif
+
+// HBM = true: the k_*_hbm kernels (workspace in HBM): the dense fast path (LDS-resident by construction) is compiled out
+template <bool HBM = false>
 TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, double* smem, int tid, int NT, double* chain_lds = nullptr)
 {
   const int D = P->D, T = P->T, NX = P->NX, R = P->R;
@@ -885,33 +1054,13 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
   // ---------------- factor + ADMM loop (osqp_solve) --------------------------------------------------------
   TMX_TICK(0);
 #if TMX_IS_DEVICE
-  const bool fast = (NT == TMX_QP_NT) && (R <= 512) && dpart_supported(w, NT) && !TMX_HAS_PAIRS(w);
+  const bool fast = !HBM && (NT == TMX_QP_NT) && (R <= 512) && dpart_supported(w, NT) && !TMX_HAS_PAIRS(w);
 #else
   const bool fast = false;
 #endif
 #if TMX_IS_DEVICE
   if (fast)
-  {
-    // The delta vectors of the last ADMM iteration are written at the end of a burst and read by the termination test
-    // that follows it.  On the dense fast path the block factor Sinv is only live inside a factorisation (which comes
-    // after that test) and during the polish (whose own iterate sits in the G region), so the deltas ALIAS Sinv in LDS
-    // instead of living in the HBM scratch.
-    const size_t polish_tmp = (size_t)(2 * NX + R + 3 * P->NA) + (size_t)(R + NX + P->NA + 1) / 2 + 2;
-    const size_t deltas = 2 * (size_t)NX + (size_t)R + 2 * (size_t)P->NA;
-    if (polish_tmp <= (size_t)dpt.P * w.Gn * w.Gs && deltas <= (size_t)T * D * w.DS)
-    {
-      double* q = w.Sinv;
-      w.dxp = q;
-      q += NX;
-      w.dybp = q;
-      q += NX;
-      w.dyr = q;
-      q += R;
-      w.dxa = q;
-      q += P->NA;
-      w.dyba = q;
-    }
-  }
+    qp_ws_alias_deltas(w, P, dpt);
 #endif
   kkt_factor(w, P, 0, w.sigma, st.delta, tid, NT);
   kkt_invert(w, fast, tid, NT, pc, tlast);
@@ -925,6 +1074,33 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
   info.prim_res = info.dual_res = 0.0;
   int iter = 0;
   bool can_check = false, terminated = false;
+#if TMX_ADMM_OUTLINED
+  if (fast)
+  {
+    QpShared* sh = reinterpret_cast<QpShared*>(w.wself);
+    if (tid == 0)
+    {
+      sh->rho = w.rho;
+      sh->sigma = w.sigma;
+      sh->alpha = w.alpha;
+      sh->c = w.c;
+      sh->cinv = w.cinv;
+      sh->info = info;
+      sh->terminated = 0;
+      sh->can_check = 0;
+      sh->iter = 0;
+    }
+    TMX_SYNC();
+    qp_admm_fast_nl(P, Bt, b, (unsigned)(size_t)smem);
+    info = sh->info;
+    w.rho = sh->rho;
+    terminated = sh->terminated != 0;
+    can_check = sh->can_check != 0;
+    iter = sh->iter;
+    TMX_SYNC();
+  }
+  else
+#endif
   for (iter = 1; iter <= st.max_iter; ++iter)
   {
 #if TMX_IS_DEVICE

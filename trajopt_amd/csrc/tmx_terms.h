@@ -77,8 +77,11 @@ TMX_DEVFN void tf_joint_motion(const double* ax, int type, double q, Tf3& T)
   }
 }
 
-// world transform of link `upto` (child of joint `upto`); optionally the joint frames before motion
-TMX_DEVFN void fk_link(const DevProblem* P, const double* q, int upto, Tf3& out, Tf3* jf)
+// world transform of link `upto` (child of joint `upto`).  The joint values come from a callable (joint index -> value)
+// and the joint frames before motion go to a visitor: no per-thread array is ever indexed with a run-time subscript,
+// so nothing of the kinematics lives in scratch memory (a Tf3 jf[TMX_MAX_DOF] alone was 1.5 KB per lane).
+template <class QAt, class Visit>
+TMX_DEVFN void fk_link_visit(const DevProblem* P, QAt&& qat, int upto, Tf3& out, Visit&& visit)
 {
   Tf3 T, O, M, U;
   tf_from12(P->base, T);
@@ -86,19 +89,55 @@ TMX_DEVFN void fk_link(const DevProblem* P, const double* q, int upto, Tf3& out,
   {
     tf_from12(P->origin[k], O);
     tf_mul(T, O, U);
-    if (jf)
-      jf[k] = U;
-    tf_joint_motion(P->axis[k], P->jtype[k], q[k], M);
+    visit(k, U);
+    tf_joint_motion(P->axis[k], P->jtype[k], qat(k), M);
     tf_mul(U, M, T);
   }
   out = T;
 }
-TMX_DEVFN void fk_tool(const DevProblem* P, const double* q, Tf3& out)
+template <class QAt>
+TMX_DEVFN void fk_link_at(const DevProblem* P, QAt&& qat, int upto, Tf3& out)
+{
+  fk_link_visit(P, qat, upto, out, [](int, const Tf3&) {});
+}
+TMX_DEVFN void fk_link(const DevProblem* P, const double* q, int upto, Tf3& out)
+{
+  fk_link_at(P, [q](int k) { return q[k]; }, upto, out);
+}
+template <class QAt>
+TMX_DEVFN void fk_tool_at(const DevProblem* P, QAt&& qat, Tf3& out)
 {
   Tf3 L, Tl;
-  fk_link(P, q, P->D - 1, L, nullptr);
+  fk_link_at(P, qat, P->D - 1, L);
   tf_from12(P->tool, Tl);
   tf_mul(L, Tl, out);
+}
+TMX_DEVFN void fk_tool(const DevProblem* P, const double* q, Tf3& out)
+{
+  fk_tool_at(P, [q](int k) { return q[k]; }, out);
+}
+// -n . (translational Jacobian column of joint k at world point p), joint frame F before motion
+// (trajopt_common::getGradient: gradient of the signed distance w.r.t. joint k, collision_utils.cpp:116-221)
+TMX_DEVFN double contact_grad_col(const DevProblem* P, int k, const Tf3& F, const double p[3], const double n[3])
+{
+  double z[3];
+  for (int rr = 0; rr < 3; ++rr)
+    z[rr] = F.R[3 * rr + 0] * P->axis[k][0] + F.R[3 * rr + 1] * P->axis[k][1] + F.R[3 * rr + 2] * P->axis[k][2];
+  double col[3];
+  if (P->jtype[k] == 0)
+  {
+    const double dd[3] = { p[0] - F.t[0], p[1] - F.t[1], p[2] - F.t[2] };
+    col[0] = z[1] * dd[2] - z[2] * dd[1];
+    col[1] = z[2] * dd[0] - z[0] * dd[2];
+    col[2] = z[0] * dd[1] - z[1] * dd[0];
+  }
+  else
+  {
+    col[0] = z[0];
+    col[1] = z[1];
+    col[2] = z[2];
+  }
+  return -1.0 * (n[0] * col[0] + n[1] * col[1] + n[2] * col[2]);
 }
 
 // tesseract::common::calcRotationalErrorDecomposed [NOT IN REFERENCE] — same statement as oracle/trajprob.hpp
@@ -117,22 +156,39 @@ TMX_DEVFN void rot_err_decomposed(const double* R, double axis[3], double& angle
   }
   else
   {
+    // largest diagonal entry i, then (i, j, k) cyclic: spelled out per case so that R is only indexed with constants
     int i = 0;
     if (R[4] > R[0])
       i = 1;
-    if (R[8] > R[4 * i])
+    if (R[8] > (i == 1 ? R[4] : R[0]))
       i = 2;
-    const int j = (i + 1) % 3, k = (j + 1) % 3;
-    double t = sqrt(R[4 * i] - R[4 * j] - R[4 * k] + 1.0);
-    double qv[3];
-    qv[i] = 0.5 * t;
-    t = 0.5 / t;
-    qw = (R[3 * k + j] - R[3 * j + k]) * t;
-    qv[j] = (R[3 * j + i] + R[3 * i + j]) * t;
-    qv[k] = (R[3 * k + i] + R[3 * i + k]) * t;
-    qx = qv[0];
-    qy = qv[1];
-    qz = qv[2];
+    if (i == 0)
+    {
+      double t = sqrt(R[0] - R[4] - R[8] + 1.0);
+      qx = 0.5 * t;
+      t = 0.5 / t;
+      qw = (R[7] - R[5]) * t;
+      qy = (R[3] + R[1]) * t;
+      qz = (R[6] + R[2]) * t;
+    }
+    else if (i == 1)
+    {
+      double t = sqrt(R[4] - R[8] - R[0] + 1.0);
+      qy = 0.5 * t;
+      t = 0.5 / t;
+      qw = (R[2] - R[6]) * t;
+      qz = (R[7] + R[5]) * t;
+      qx = (R[1] + R[3]) * t;
+    }
+    else
+    {
+      double t = sqrt(R[8] - R[0] - R[4] + 1.0);
+      qz = 0.5 * t;
+      t = 0.5 / t;
+      qw = (R[3] - R[1]) * t;
+      qx = (R[2] + R[6]) * t;
+      qy = (R[5] + R[7]) * t;
+    }
   }
   double n = sqrt(qx * qx + qy * qy + qz * qz);
   double ang, ax[3];
@@ -180,11 +236,11 @@ TMX_DEVFN void transform_error(const Tf3& tinv, const Tf3& src, double err[6], d
 }
 
 // sphere-vs-sphere signed distance for contact slot (link sphere s, obstacle o) at joint values q
-TMX_DEVFN double contact_distance(const DevProblem* P, const double* q, int s, int o, double n[3], double pw[3], Tf3* jf)
+TMX_DEVFN double contact_distance(const DevProblem* P, const double* q, int s, int o, double n[3], double pw[3])
 {
   Tf3 L;
   const int link = P->ls_link[s];
-  fk_link(P, q, link, L, jf);
+  fk_link(P, q, link, L);
   double c[3], d[3];
   for (int r = 0; r < 3; ++r)
     c[r] = L.R[3 * r + 0] * P->ls_center[3 * s + 0] + L.R[3 * r + 1] * P->ls_center[3 * s + 1] +
@@ -243,26 +299,18 @@ TMX_DEVFN bool lvs_contact(const DevProblem* P, const double* q0, const double* 
     return false;
   const double dt = 1.0 / (double)last;
   const int link = P->ls_link[s];
-  double qa[TMX_MAX_DOF], qb[TMX_MAX_DOF];
-  for (int j = 0; j < D; ++j)
-  {
-    qa[j] = lin_spaced_at(cnt, q0[j], q1[j], i);
-    qb[j] = cast ? lin_spaced_at(cnt, q0[j], q1[j], i + 1) : qa[j];
-    if (!split && cast)
-    {
-      qa[j] = q0[j];
-      qb[j] = q1[j];
-    }
-  }
+  // sub-state joint values on the fly (no per-thread arrays): start and end state of sub-segment i
+  auto qa = [=](int j) { return (!split && cast) ? q0[j] : lin_spaced_at(cnt, q0[j], q1[j], i); };
+  auto qb = [=](int j) { return (!split && cast) ? q1[j] : lin_spaced_at(cnt, q0[j], q1[j], cast ? i + 1 : i); };
   Tf3 Ta, Tb;
-  fk_link(P, qa, link, Ta, nullptr);
+  fk_link_at(P, qa, link, Ta);
   double ca[3], p[3];
   for (int rr = 0; rr < 3; ++rr)
     ca[rr] = Ta.R[3 * rr + 0] * P->ls_center[3 * s + 0] + Ta.R[3 * rr + 1] * P->ls_center[3 * s + 1] + Ta.R[3 * rr + 2] * P->ls_center[3 * s + 2] + Ta.t[rr];
   double tau = 0.0;
   if (cast)
   {
-    fk_link(P, qb, link, Tb, nullptr);
+    fk_link_at(P, qb, link, Tb);
     double cb[3];
     for (int rr = 0; rr < 3; ++rr)
       cb[rr] = Tb.R[3 * rr + 0] * P->ls_center[3 * s + 0] + Tb.R[3 * rr + 1] * P->ls_center[3 * s + 1] + Tb.R[3 * rr + 2] * P->ls_center[3 * s + 2] + Tb.t[rr];
@@ -327,43 +375,28 @@ TMX_DEVFN bool lvs_contact(const DevProblem* P, const double* q0, const double* 
     return true;
   return false;
 }
-// GetGradient(dofvals, contact, isTimestep1) of the link sphere at end state q: scale * grad and scale * -(grad . q)
+// GetGradient(dofvals, contact, isTimestep1) of the link sphere at end state q: scale * grad goes to sg[k * stride]
+// (the caller's row in HBM: the raw gradient is staged there and post-processed in place) and scale * -(grad . q) is returned
 TMX_DEVFN void lvs_end_gradient(const DevProblem* P, const double* q, int s, const LvsContact& c, bool is1, double* sg, double& sconst)
 {
   const int D = P->D, link = P->ls_link[s];
   const double scale = is1 ? c.cc_time : (1 - c.cc_time);
   const double* Rl = is1 ? c.R1 : c.R0;
+  // pass 1: the link frame -> world position of the contact point; pass 2: the joint frames again, one gradient entry each
   Tf3 L;
-  Tf3 jf[TMX_MAX_DOF];
-  fk_link(P, q, link, L, jf);
+  fk_link(P, q, link, L);
   double p[3];
   for (int rr = 0; rr < 3; ++rr)
     p[rr] = L.t[rr] + (Rl[3 * rr + 0] * c.p_local[0] + Rl[3 * rr + 1] * c.p_local[1] + Rl[3 * rr + 2] * c.p_local[2]);
   double gq = 0.0;
-  for (int k = 0; k < D; ++k)
+  fk_link_visit(P, [q](int k) { return q[k]; }, link, L, [&](int k, const Tf3& F) {
+    const double g = contact_grad_col(P, k, F, p, c.n);
+    sg[k] = scale * g;
+    gq += g * q[k];
+  });
+  for (int k = link + 1; k < D; ++k)
   {
-    double col[3] = { 0, 0, 0 };
-    if (k <= link)
-    {
-      const Tf3& F = jf[k];
-      double z[3];
-      for (int rr = 0; rr < 3; ++rr)
-        z[rr] = F.R[3 * rr + 0] * P->axis[k][0] + F.R[3 * rr + 1] * P->axis[k][1] + F.R[3 * rr + 2] * P->axis[k][2];
-      if (P->jtype[k] == 0)
-      {
-        const double dd[3] = { p[0] - F.t[0], p[1] - F.t[1], p[2] - F.t[2] };
-        col[0] = z[1] * dd[2] - z[2] * dd[1];
-        col[1] = z[2] * dd[0] - z[0] * dd[2];
-        col[2] = z[0] * dd[1] - z[1] * dd[0];
-      }
-      else
-      {
-        col[0] = z[0];
-        col[1] = z[1];
-        col[2] = z[2];
-      }
-    }
-    const double g = -1.0 * (c.n[0] * col[0] + c.n[1] * col[1] + c.n[2] * col[2]);
+    const double g = -1.0 * (c.n[0] * 0.0 + c.n[1] * 0.0 + c.n[2] * 0.0);
     sg[k] = scale * g;
     gq += g * q[k];
   }
@@ -393,7 +426,7 @@ TMX_DEVFN void evaluate_terms(const DevProblem* P, const double* xv, double* cos
     if (kind == SLOT_COLLISION)
     {
       double n[3], pw[3];
-      const double dist = contact_distance(P, xv + t * D, P->slot_sub[r], P->slot_sub2[r], n, pw, nullptr);
+      const double dist = contact_distance(P, xv + t * D, P->slot_sub[r], P->slot_sub2[r], n, pw);
       const double margin = P->slot_aux1[r];
       if (!(dist > margin + P->slot_aux2[r]))
       {
@@ -669,12 +702,7 @@ TMX_DEVFN void convexify_terms(const DevProblem* P, const double* xv, int* activ
     Tf3 tgt, tinv, src, pp;
     tf_from12(P->cp_target + 12 * c, tgt);
     tf_inv(tgt, tinv);
-    double qp[TMX_MAX_DOF];
-    for (int j = 0; j < D; ++j)
-      qp[j] = q[j];
-    if (k < D)
-      qp[k] = q[k] + TMX_EPS_FD;
-    fk_tool(P, qp, src);
+    fk_tool_at(P, [q, k](int j) { return (j == k) ? q[j] + TMX_EPS_FD : q[j]; }, src);  // k == D: the unperturbed pose
     tf_mul(tinv, src, pp);
     double ax[3], ang;
     if (k < D)
@@ -707,14 +735,12 @@ TMX_DEVFN void convexify_terms(const DevProblem* P, const double* xv, int* activ
       a1c = a1 - 2.0 * M_PI;
     else if (a1 < -M_PI_2 && a0 > M_PI_2)
       a1c = a1 + 2.0 * M_PI;
-    double diff[6];
-    for (int r = 0; r < 3; ++r)
-    {
-      diff[r] = o1[r] - o0[r];
-      diff[3 + r] = o1[3 + r] * a1c - o0[3 + r] * a0;
-    }
     for (int i = 0; i < P->cp_nrows[c]; ++i)
-      Jm[((size_t)c * 6 + i) * D + k] = diff[P->cp_idx[6 * c + i]] / TMX_EPS_FD;
+    {
+      const int r = P->cp_idx[6 * c + i];
+      const double diff = (r < 3) ? o1[r] - o0[r] : o1[r] * a1c - o0[r] * a0;
+      Jm[((size_t)c * 6 + i) * D + k] = diff / TMX_EPS_FD;
+    }
   }
   TMX_SYNC();
   for (int item = tid; item < P->n_cp * 6; item += NT)
@@ -764,7 +790,8 @@ TMX_DEVFN void convexify_terms(const DevProblem* P, const double* xv, int* activ
       continue;
     }
     // dist_expr = distance + [scale0 (grad0 . x0 - grad0 . q0)] + [scale1 (grad1 . x1 - grad1 . q1)], cleanupAff (1e-7)
-    double g0[TMX_MAX_DOF], g1[TMX_MAX_DOF], k0 = 0.0, k1 = 0.0;
+    // the raw scaled gradients are staged in the row's own coefficient arrays and post-processed in place
+    double *g0 = coef + (size_t)r * D, *g1 = c2r, k0 = 0.0, k1 = 0.0;
     for (int k = 0; k < D; ++k)
       g0[k] = g1[k] = 0.0;
     if (!fixed0)
@@ -822,9 +849,8 @@ TMX_DEVFN void convexify_terms(const DevProblem* P, const double* xv, int* activ
     const double* q = xv + P->slot_t[r] * D;
     const int s = P->slot_sub[r], o = P->slot_sub2[r];
     const int link = P->ls_link[s];
-    Tf3 jf[TMX_MAX_DOF];
     double n[3], pw[3];
-    const double dist = contact_distance(P, q, s, o, n, pw, jf);
+    const double dist = contact_distance(P, q, s, o, n, pw);
     const double margin = P->slot_aux1[r];
     if (dist > margin + P->slot_aux2[r])
     {
@@ -834,34 +860,24 @@ TMX_DEVFN void convexify_terms(const DevProblem* P, const double* xv, int* activ
       rhs[r] = 0.0;
       continue;
     }
-    // gradient = -n' * J_trans(nearest point), object 0 = robot link (collision_terms.cpp:203-250)
-    double grad[TMX_MAX_DOF];
+    // gradient = -n' * J_trans(nearest point), object 0 = robot link (collision_terms.cpp:203-250).  Second pass over the
+    // chain (the joint frames are recomputed instead of being kept in a per-thread array); the raw gradient is staged in
+    // the row's coefficient array
+    double* grad = coef + (size_t)r * D;
     double gq = 0.0;
-    for (int k = 0; k < D; ++k)
     {
-      double col[3] = { 0, 0, 0 };
-      if (k <= link)
+      Tf3 L;
+      fk_link_visit(P, [q](int k) { return q[k]; }, link, L, [&](int k, const Tf3& F) {
+        const double g = contact_grad_col(P, k, F, pw, n);
+        grad[k] = g;
+        gq += g * q[k];
+      });
+      for (int k = link + 1; k < D; ++k)
       {
-        const Tf3& F = jf[k];
-        double z[3];
-        for (int rr = 0; rr < 3; ++rr)
-          z[rr] = F.R[3 * rr + 0] * P->axis[k][0] + F.R[3 * rr + 1] * P->axis[k][1] + F.R[3 * rr + 2] * P->axis[k][2];
-        if (P->jtype[k] == 0)
-        {
-          const double dd[3] = { pw[0] - F.t[0], pw[1] - F.t[1], pw[2] - F.t[2] };
-          col[0] = z[1] * dd[2] - z[2] * dd[1];
-          col[1] = z[2] * dd[0] - z[0] * dd[2];
-          col[2] = z[0] * dd[1] - z[1] * dd[0];
-        }
-        else
-        {
-          col[0] = z[0];
-          col[1] = z[1];
-          col[2] = z[2];
-        }
+        const double g = -1.0 * (n[0] * 0.0 + n[1] * 0.0 + n[2] * 0.0);
+        grad[k] = g;
+        gq += g * q[k];
       }
-      grad[k] = -1.0 * (n[0] * col[0] + n[1] * col[1] + n[2] * col[2]);
-      gq += grad[k] * q[k];
     }
     // dist_expr = grad.x + (-(grad.q) + dist) ; viol = margin - dist_expr ; row: viol - hinge <= 0
     const double c_dist = (0.0 + (-gq)) + dist;

@@ -112,3 +112,13 @@ struct DevBatch
   long long ws_hbm_stride;
   int ws_chain_in_lds;  // the k_*_hbm launch carries qp_chain_lds_doubles() of dynamic LDS for the block chain
 };
+
+// The ADMM loop of the dense fast path as separately compiled device functions (tmx_solve.h: qp_admm_fast_nl /
+// qp_check_nl).  Default on for the product build; the phase profiler (-DTMX_PROFILE) keeps everything inline.
+#ifndef TMX_ADMM_OUTLINED
+#if defined(TMX_PROFILE) || defined(TMX_BURST_NOINLINE) || defined(TMX_HOST_EMU)
+#define TMX_ADMM_OUTLINED 0
+#else
+#define TMX_ADMM_OUTLINED 1
+#endif
+#endif
