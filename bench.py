@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=0, help="seeds per GPU (default: the configuration's BASELINE batch per GPU)")
+    ap.add_argument("--depth", type=int, default=2, help="batches in flight (1 = strictly sequential steps, 2 = double-buffered contexts)")
     ap.add_argument("--config", type=int, default=1, choices=[1, 2, 3, 4], help="BASELINE.json configuration (default 1 = the metric's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -73,15 +74,25 @@ def main():
     B = args.batch or spec[1]
     conv_code = abi.SQP_CONVERGED if cid == 4 else abi.OPT_CONVERGED
     osqp_st = configs.osqp_settings_config4() if cid == 4 else abi.default_osqp_settings()
-    ctx = runtime.Context(local_rank)
-    ctx.upload(desc, abi.default_sqp_params(), osqp_st)
-    # the library's own RCCL communicator for the best-seed reduction (also with one rank: the collective always runs)
-    uid = torch.zeros(128, dtype=torch.uint8, device=dev)
-    if rank == 0:
-        uid = torch.tensor(list(ctx.nccl_unique_id()), dtype=torch.uint8, device=dev)
-    if world > 1:
-        dist.broadcast(uid, src=0)
-    ctx.nccl_init(bytes(uid.cpu().tolist()), world, rank)
+    # Two contexts = two batches in flight (double buffering): the kernel time of a batch is set by its longest chain of QP
+    # solves (one straggler seed with 104 instead of 61 solves stretches the launch from 475 to 604 ms, tools/tail_probe.py),
+    # the persistent workgroups retire when nothing is left for them, and the next batch's kernel - enqueued on the other
+    # context's stream - takes over their CUs.  Every step still is one complete optimize() of one batch; all of them start
+    # and end inside the timed region.  --depth 1 runs them strictly one after the other.
+    depth = max(1, min(2, args.depth))
+    ctxs = []
+    for _ in range(depth):
+        c = runtime.Context(local_rank)
+        c.upload(desc, abi.default_sqp_params(), osqp_st)
+        # the library's own RCCL communicator for the best-seed reduction (also with one rank: the collective always runs)
+        uid = torch.zeros(128, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            uid = torch.tensor(list(c.nccl_unique_id()), dtype=torch.uint8, device=dev)
+        if world > 1:
+            dist.broadcast(uid, src=0)
+        c.nccl_init(bytes(uid.cpu().tolist()), world, rank)
+        ctxs.append(c)
+    ctx = ctxs[0]
 
     nsteps = args.warmup + args.steps
     # synthetic seeds (counter-based Philox keyed by (config, global problem index)), resident in HBM before timing
@@ -90,25 +101,35 @@ def main():
     seeds = torch.from_numpy(seeds_host.reshape(nsteps, B, T, D)).to(dev)
     torch.cuda.synchronize()
 
-    def one_step(k):
-        ctx.set_x0_device(seeds[k].data_ptr(), B)
-        ctx.run(0)
-        r = ctx.results()
-        best = ctx.argmin((rank * nsteps + k) * B)   # the only collective: RCCL all-gather of 16 bytes per rank inside the library
-        return r, best
+    def issue(k):
+        c = ctxs[k % depth]
+        c.set_x0_device(seeds[k].data_ptr(), B)
+        c.launch()
 
-    for k in range(args.warmup):
-        one_step(k)
-    ctx.kernel_stats(reset=True)
+    def finish(k):
+        c = ctxs[k % depth]
+        c.wait()
+        r = c.results()
+        best = c.argmin((rank * nsteps + k) * B)   # the only collective: RCCL all-gather of 16 bytes per rank inside the library
+        return r, best, c.counters()
+
+    for k in range(args.warmup):   # warm-up steps run one at a time
+        issue(k)
+        finish(k)
+    for c in ctxs:
+        c.kernel_stats(reset=True)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     tot_fe = tot_qp = tot_admm = 0
     conv = 0
+    for k in range(args.warmup, min(nsteps, args.warmup + depth - 1)):
+        issue(k)
     for k in range(args.warmup, nsteps):
-        r, best = one_step(k)
-        c = ctx.counters()
+        if k + depth - 1 < nsteps:
+            issue(k + depth - 1)
+        r, best, c = finish(k)
         # trajopt_sqp counts QP solves only (SQPResults::overall_iteration): one trust-region evaluation each
         tot_fe += int(r["n_qp_solves"].sum()) if cid == 4 else int((r["n_func_evals"] - 1).sum())
         tot_qp += int(r["n_qp_solves"].sum())
@@ -119,7 +140,11 @@ def main():
         dist.barrier()
     t1 = time.perf_counter()
     elapsed = t1 - t0
-    stats = ctx.kernel_stats()
+    stats = {"admm_ms": 0.0, "convexify_ms": 0.0, "evaluate_ms": 0.0, "admm_launches": 0}
+    for c in ctxs:
+        st_c = c.kernel_stats()
+        for key in stats:
+            stats[key] += st_c[key]
     tt = torch.tensor([elapsed, float(tot_fe), float(tot_qp), float(tot_admm), float(conv)], dtype=torch.float64, device=dev)
     if world > 1:
         tmax = tt.clone()
@@ -145,11 +170,12 @@ def main():
         # summary is not present
         traffic = None
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            import glob
+            with open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]) as f:   # latest round
                 tj = json.load(f)
             if tj.get("batch_per_gpu") == B:
                 traffic = tj.get("hbm_bytes_per_launch")
-        except OSError:
+        except (OSError, IndexError):
             pass
         flops_per_launch = f_iter * tot_admm / launches
         avg_ms = stats["admm_ms"] / launches
@@ -159,6 +185,10 @@ def main():
             "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic if cid == 1 else None,
             "avg_launch_ms": avg_ms, "launches": launches, "algorithmic_flop_per_admm_iter": f_iter,
             "admm_iters_per_launch": tot_admm / launches,
+            # with two batches in flight the launches overlap (the tail of one under the bulk of the next): a launch still lasts
+            # avg_launch_ms from its first to its last workgroup, but one completes every ms_per_step
+            "batches_in_flight": depth,
+            "achieved_at_step_rate": flops_per_launch / (elapsed / max(1, args.steps)) / 1e12,
             "kernel_time_share": {"admm_ms": stats["admm_ms"], "convexify_ms": stats["convexify_ms"],
                                   "evaluate_ms": stats["evaluate_ms"], "wall_ms": (t1 - t0) * 1e3},
         }
@@ -178,12 +208,22 @@ def main():
             from oracle import pyorc
             cores = os.cpu_count() or 1
             pyorc.build()
-            # one problem per OpenMP thread.  Two thread counts are timed (all hardware threads, and a quarter of them:
-            # the oracle's allocator traffic makes the fully subscribed run slower on large hosts) and the FASTER one is
-            # reported, so the GPU/CPU ratio is not flattered by a badly subscribed baseline.
+            # one problem per OpenMP thread.  Several thread counts are timed and the FASTEST is reported, so the GPU/CPU
+            # ratio is not flattered by a badly subscribed baseline.  (Round-2 probe on the GPU box, tools/cpu_scaling.py:
+            # 16 threads 1.57 k, 64 threads 1.64 k, 256 threads 0.84 k SQP it/s, and 4 x 64 / 8 x 32 / 16 x 16 processes x
+            # threads 0.84-0.86 k: the box gives the container about 16 cores' worth of CPU time whatever the thread or
+            # process count - it is a CPU quota, not the oracle's allocator, that bounds this leg.)
+            quota = None
+            try:
+                with open("/sys/fs/cgroup/cpu.max") as f:
+                    q = f.read().split()
+                if q[0] != "max":
+                    quota = float(q[0]) / float(q[1])
+            except (OSError, ValueError, IndexError):
+                pass
             tried = []
-            for nthr in sorted({cores, max(1, cores // 4), min(cores, 16)}, reverse=True):
-                nsample = min(B, max(32, 2 * nthr))   # two problems per thread: a few seconds to ~30 s per run
+            for nthr in sorted({min(cores, 64), min(cores, 32), min(cores, 16), min(cores, 8)}, reverse=True):
+                nsample = min(B, max(32, 2 * nthr))   # two problems per thread: a few seconds per run
                 xs = seeds_host[:nsample]
                 tc0 = time.perf_counter()
                 o = pyorc.sqp_batch(desc, xs, nthreads=nthr)
@@ -196,6 +236,7 @@ def main():
                              f"{cores} hardware threads, {best[3]:.1f} s wall; restated reference CPU path (oracle/), "
                              "not the upstream binary; tried " +
                              ", ".join(f"{t[1]} thr -> {t[0]:.0f} it/s" for t in tried),
+                   "per_thread_value": best[0] / best[1], "host_threads": cores, "cgroup_cpu_quota_cores": quota,
                    "qp_solves_per_s": float(o["n_qp_solves"].sum() / best[3]),
                    "admm_iters_per_s": float(o["admm_iters"] / best[3])}
         line = {
@@ -204,6 +245,7 @@ def main():
             "value": g_fe / elapsed, "unit": "SQP iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / max(1, args.steps) * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "batches_in_flight": depth,
             "config": {"workload": spec[3] % B,
                        "n_dof": D, "n_steps": T, "batch_per_gpu": B, "qp_n": r0.n, "qp_m": r0.m, "parallelism": "seeds sharded, dp%d" % world},
             "qp_solves_per_s": g_qp / elapsed, "admm_iters_per_s": g_admm / elapsed,
@@ -214,7 +256,8 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    ctx.close()
+    for c in ctxs:
+        c.close()
 
 
 if __name__ == "__main__":

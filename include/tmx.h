@@ -284,6 +284,13 @@ TMX_API tmx_status tmx_batch_set_x0_device(tmx_ctx* ctx, const double* x0_dev, i
  * max_steps = 0 runs to completion; otherwise at most max_steps batched trust-region evaluations.
  * n_active_out (optional) receives the number of problems still running.                                */
 TMX_API tmx_status tmx_sqp_run(tmx_ctx* ctx, int32_t max_steps, int32_t* n_active_out);
+/* The two halves of tmx_sqp_run(ctx, 0, ...): tmx_sqp_launch enqueues the whole batched optimize() on the context's own
+ * stream and returns at once; tmx_sqp_wait blocks until it is done (then the results / counters / argmin calls apply).
+ * With two contexts on one device (double-buffered batches of a stream of planning requests) the straggler tail of one
+ * batch - the kernel time is set by the longest chain of QP solves of a batch - overlaps the bulk of the next one.
+ * TMX_ERR_STATE: launch while one is pending, wait without one; TMX_ERR_UNSUPPORTED in the piecewise mode. */
+TMX_API tmx_status tmx_sqp_launch(tmx_ctx* ctx);
+TMX_API tmx_status tmx_sqp_wait(tmx_ctx* ctx, int32_t* n_active_out);
 
 /* sco::OptResults (optimizers.hpp:40-59) per problem; any output pointer may be NULL                    */
 TMX_API tmx_status tmx_sqp_results(tmx_ctx* ctx, double* x /*B*T*D*/, int32_t* status /*B*/, double* total_cost /*B*/,

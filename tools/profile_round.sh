@@ -6,10 +6,11 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $OUT/kt -o out --output-format csv -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/kt.log
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/kt -o out --output-format csv -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/kt.log
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_MFMA_MOPS_F64"; do
+  [ -n "$QUICK" ] && [ "$grp" != "FETCH_SIZE" ] && [ "$grp" != "WRITE_SIZE" ] && continue
   tag=$(echo $grp | tr ' ' '_' | cut -c1-48)
-  rocprofv3 --kernel-trace --pmc $grp -d $OUT/pmc_$tag -o out --output-format csv -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/pmc_$tag.json 2> $OUT/pmc_$tag.log
+  timeout 200 rocprofv3 --kernel-trace --pmc $grp -d $OUT/pmc_$tag -o out --output-format csv -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/pmc_$tag.json 2> $OUT/pmc_$tag.log
 done
 python3 - <<PY
 import csv, glob, json, collections, os

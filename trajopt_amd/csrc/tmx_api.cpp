@@ -50,6 +50,7 @@ struct tmx_ctx
   double ms_admm{ 0 }, ms_convexify{ 0 }, ms_evaluate{ 0 };
   long long launches_admm{ 0 };
   bool timing{ true };
+  int pending{ 0 };  // a tmx_sqp_launch() not yet collected by tmx_sqp_wait()
   bool ws_in_hbm{ false };  // QP workspace > 160 KB of LDS: k_*_hbm kernels, workspace carved in HBM (long horizons)
   int mode{ 2 };  // optimize() driver: 0 = one launch chain per step, 1 = k_sqp_fused, 2 = k_sqp_pool (default)
   int pool_wgs{ 0 };  // resident workgroups of the pool kernel (0 = CUs x workgroups-per-CU)
@@ -931,8 +932,14 @@ static tmx_status ensure_batch(tmx_ctx* ctx, int B)
 {
   if (B <= ctx->Bcap)
   {
-    ctx->hb.B = B;
-    HIPCHK(hipMemcpy(ctx->db, &ctx->hb, sizeof(DevBatch), hipMemcpyHostToDevice));
+    // (stream-ordered and only when the batch size changes: a synchronous copy is a null-stream operation, which waits for
+    //  every other blocking stream of the device - i.e. for the other context's batch still in flight)
+    if (ctx->hb.B != B)
+    {
+      ctx->hb.B = B;
+      HIPCHK(hipMemcpyAsync(ctx->db, &ctx->hb, sizeof(DevBatch), hipMemcpyHostToDevice, ctx->stream));
+      HIPCHK(hipStreamSynchronize(ctx->stream));  // hb is host memory that the next call may modify
+    }
     return TMX_OK;
   }
   free_pool(ctx->batch_allocs);
@@ -1068,11 +1075,70 @@ static tmx_status read_totals(tmx_ctx* ctx, long long out[4])
     }                                                                                                                 \
   } while (0)
 
+// Asynchronous half of tmx_sqp_run(ctx, 0, ...): enqueues the whole optimize() of the batch on the context's stream and
+// returns.  Two contexts on one device (double-buffered batches) overlap the straggler tail of one batch - the kernel
+// time of a batch is set by its longest chain of QP solves, and the persistent workgroups retire as soon as nothing is
+// left for them - with the bulk of the next one.
+tmx_status tmx_sqp_launch(tmx_ctx* ctx)
+{
+  if (!ctx)
+    return TMX_ERR_INVALID;
+  if (!ctx->have_problem || ctx->Bcap == 0 || ctx->pending)
+    return TMX_ERR_STATE;
+  HIPCHK(hipSetDevice(ctx->device));
+  const int B = ctx->hb.B;
+  if (ctx->mode == 0)
+    return TMX_ERR_UNSUPPORTED;  // the piecewise mode runs the loop on the host
+  if (ctx->timing)
+    HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+  if (ctx->ws_in_hbm)
+    TMX_LAUNCH(k_sqp_fused_hbm, B, ctx->nt_qp, ctx->smem_chain, ctx->stream, ctx->dp, ctx->db, 0);
+  else if (ctx->mode == 2)
+  {
+    const int G = std::min(B, ctx->pool_wgs);
+    // the scheduler words follow the problem phases (bounded k_sqp_fused calls before this one do not maintain them)
+    TMX_LAUNCH(k_pool_sync, 1, 256, 0, ctx->stream, ctx->db);
+    TMX_LAUNCH(k_sqp_pool, G, ctx->nt_qp, ctx->smem_pool, ctx->stream, ctx->dp, ctx->db);
+  }
+  else
+    TMX_LAUNCH(k_sqp_fused, B, ctx->nt_qp, ctx->smem_qp, ctx->stream, ctx->dp, ctx->db, 0);
+  HIPCHK(hipGetLastError());
+  if (ctx->timing)
+    HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+  ctx->pending = 1;
+  return TMX_OK;
+}
+
+tmx_status tmx_sqp_wait(tmx_ctx* ctx, int32_t* n_active_out)
+{
+  if (!ctx)
+    return TMX_ERR_INVALID;
+  if (!ctx->pending)
+    return TMX_ERR_STATE;
+  HIPCHK(hipSetDevice(ctx->device));
+  ctx->pending = 0;
+  if (ctx->timing)
+  {
+    HIPCHK(hipEventSynchronize(ctx->ev1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    ctx->ms_admm += ms;
+    ctx->launches_admm++;
+  }
+  long long tot[4] = { 0, 0, 0, 0 };
+  tmx_status rc = read_totals(ctx, tot);
+  if (rc != TMX_OK)
+    return rc;
+  if (n_active_out)
+    *n_active_out = static_cast<int32_t>(tot[0]);
+  return TMX_OK;
+}
+
 tmx_status tmx_sqp_run(tmx_ctx* ctx, int32_t max_steps, int32_t* n_active_out)
 {
   if (!ctx)
     return TMX_ERR_INVALID;
-  if (!ctx->have_problem || ctx->Bcap == 0)
+  if (!ctx->have_problem || ctx->Bcap == 0 || ctx->pending)
     return TMX_ERR_STATE;
   HIPCHK(hipSetDevice(ctx->device));
   const int B = ctx->hb.B;
@@ -1080,17 +1146,14 @@ tmx_status tmx_sqp_run(tmx_ctx* ctx, int32_t max_steps, int32_t* n_active_out)
   int step = 0;
   if (ctx->mode != 0)
   {
+    if (max_steps == 0)
+    {
+      tmx_status rc = tmx_sqp_launch(ctx);
+      return rc != TMX_OK ? rc : tmx_sqp_wait(ctx, n_active_out);
+    }
     if (ctx->ws_in_hbm)
       TIMED(ctx->ms_admm, ctx->launches_admm++,
             TMX_LAUNCH(k_sqp_fused_hbm, B, ctx->nt_qp, ctx->smem_chain, ctx->stream, ctx->dp, ctx->db, (int)max_steps));
-    else if (ctx->mode == 2 && max_steps == 0)
-    {
-      const int G = std::min(B, ctx->pool_wgs);
-      // the scheduler words follow the problem phases (bounded k_sqp_fused calls before this one do not maintain them)
-      TMX_LAUNCH(k_pool_sync, 1, 256, 0, ctx->stream, ctx->db);
-      TIMED(ctx->ms_admm, ctx->launches_admm++,
-            TMX_LAUNCH(k_sqp_pool, G, ctx->nt_qp, ctx->smem_pool, ctx->stream, ctx->dp, ctx->db));
-    }
     else
       TIMED(ctx->ms_admm, ctx->launches_admm++,
             TMX_LAUNCH(k_sqp_fused, B, ctx->nt_qp, ctx->smem_qp, ctx->stream, ctx->dp, ctx->db, (int)max_steps));

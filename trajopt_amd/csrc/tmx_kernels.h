@@ -316,7 +316,11 @@ TMX_KERNEL_LB2(TMX_QP_NT, TMX_QP_WGS_PER_CU) k_sqp_pool(const DevProblem* P, con
       }
       int decision;
       if (kbi < 0)
-        decision = (TMX_LD_RELAXED(Bt->sched_done) >= B) ? -1 : -2;  // all done | nothing ready right now
+        // Nothing ready: every unfinished problem is in the hands of another workgroup, which will rescan the moment it
+        // releases it - so this workgroup is surplus from now on (the number of unfinished problems only falls) and
+        // RETIRES instead of spinning to the end of the straggler tail: its CU (all of its LDS) goes to whatever is queued
+        // behind this launch, e.g. the next batch's kernel on another stream (tmx_sqp_launch).
+        decision = -1;
       else
       {
 #if TMX_IS_DEVICE

@@ -560,7 +560,32 @@ struct QpShared
   double rho, sigma, alpha, c, cinv;
   QpInfo info;
   int terminated, can_check, iter, pad_;
+#ifdef TMX_PROFILE
+  long long pc[16], tlast;  // phase profiler: the callee continues the caller's timeline (thread 0)
+#endif
 };
+#ifdef TMX_PROFILE
+#define TMX_PROF_ENTER(sh)                                                                                            \
+  long long pc[16] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };                                             \
+  long long tlast = (sh)->tlast
+#define TMX_PROF_LEAVE(sh)                                                                                            \
+  do                                                                                                                  \
+  {                                                                                                                   \
+    if (threadIdx.x == 0)                                                                                             \
+    {                                                                                                                 \
+      for (int q_ = 0; q_ < 16; ++q_)                                                                                 \
+        (sh)->pc[q_] += pc[q_];                                                                                       \
+      (sh)->tlast = tlast;                                                                                            \
+    }                                                                                                                 \
+  } while (0)
+#else
+#define TMX_PROF_ENTER(sh)                                                                                            \
+  long long pc[16];                                                                                                   \
+  long long tlast = 0;                                                                                                \
+  (void)pc;                                                                                                           \
+  (void)tlast
+#define TMX_PROF_LEAVE(sh) ((void)0)
+#endif
 TMX_DEVFN QpShared* qp_ws_rebuild(QpWs& w, const DevProblem* P, const DevBatch* Bt, int b, double* smem)
 {
   const int D = P->D, T = P->T, R = P->R;
@@ -605,10 +630,7 @@ __device__ __attribute__((noinline)) static int qp_check_nl(const DevProblem* P_
   QpWs w;
   QpShared* sh = qp_ws_rebuild(w, P, Bt, b, smem);
   QpInfo info = sh->info;
-  long long pc[16];
-  long long tlast = 0;
-  (void)pc;
-  (void)tlast;
+  TMX_PROF_ENTER(sh);
   const bool can_check = st.check_termination && (iter % st.check_termination == 0);
   const bool do_rho = st.adaptive_rho && st.adaptive_rho_interval && (iter % st.adaptive_rho_interval == 0);
   int ended = 0;
@@ -616,9 +638,11 @@ __device__ __attribute__((noinline)) static int qp_check_nl(const DevProblem* P_
   {
     info.iter = iter;
     compute_residuals(w, P, w.xp, w.xa, w.yr, w.ybp, w.yba, 0, info, info.prim_res, info.dual_res, true, tid, NT);
+    TMX_TICK(6);
   }
   if (can_check && check_termination(w, P, info, false, tid, NT))
     ended = 1;
+  TMX_TICK(3);
   double rho = w.rho;
   if (!ended && do_rho)
   {
@@ -628,18 +652,22 @@ __device__ __attribute__((noinline)) static int qp_check_nl(const DevProblem* P_
       w.rho = fmin(fmax(rho_new, TMX_RHO_MIN), TMX_RHO_MAX);
       rho = w.rho;
       info.rho_updates += 1;
+      TMX_TICK(6);
       kkt_factor(w, P, 0, w.sigma, st.delta, tid, NT);
       kkt_invert(w, true, tid, NT, pc, tlast);
       admm_cache_weights(w, tid, NT);
+      TMX_TICK(15);
     }
   }
   TMX_SYNC();
+  TMX_TICK(6);
   if (tid == 0)
   {
     sh->info = info;
     sh->rho = rho;
     sh->can_check = can_check ? 1 : 0;
   }
+  TMX_PROF_LEAVE(sh);
   TMX_SYNC();
   return ended;
 }
@@ -653,10 +681,12 @@ __device__ __attribute__((noinline)) static void qp_admm_fast_nl(const DevProble
   const unsigned lds_off = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_in);
   double* smem = (double*)(tmx_lds_d*)(size_t)lds_off;
   const tmx_osqp_settings& st = P->osqp;
-  QpShared* sh = nullptr;
-  long long pc[16];
-  long long tlast = 0;
-  (void)pc;
+  QpShared* sh;
+  {
+    QpWs w0;
+    sh = qp_ws_rebuild(w0, P, Bt, b, smem);
+  }
+  TMX_PROF_ENTER(sh);
   int iter = 0, ended = 0;
   for (iter = 1; iter <= st.max_iter; ++iter)
   {
@@ -671,7 +701,16 @@ __device__ __attribute__((noinline)) static void qp_admm_fast_nl(const DevProble
       admm_run_fast(w, P, next - iter + 1, true, tid, pc, tlast);
     }
     iter = next;
+    TMX_PROF_LEAVE(sh);
+#ifdef TMX_PROFILE
+    for (int q_ = 0; q_ < 16; ++q_)
+      pc[q_] = 0;
+    TMX_SYNC();
+#endif
     ended = qp_check_nl(P, Bt, b, iter, lds_off);
+#ifdef TMX_PROFILE
+    tlast = sh->tlast;
+#endif
     if (ended)
       break;
   }
@@ -680,6 +719,7 @@ __device__ __attribute__((noinline)) static void qp_admm_fast_nl(const DevProble
     sh->terminated = ended;
     sh->iter = iter;
   }
+  TMX_PROF_LEAVE(sh);
   TMX_SYNC();
 }
 #endif
@@ -1089,9 +1129,26 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
       sh->terminated = 0;
       sh->can_check = 0;
       sh->iter = 0;
+#ifdef TMX_PROFILE
+      for (int q_ = 0; q_ < 16; ++q_)
+        sh->pc[q_] = 0;
+      sh->tlast = tlast;
+#endif
     }
     TMX_SYNC();
-    qp_admm_fast_nl(P, Bt, b, (unsigned)(size_t)smem);
+    {
+      // the LDS offset is made opaque: with a visible constant (the address of the dynamic LDS symbol) interprocedural
+      // constant propagation re-materialises the symbol inside the callees, whose per-kernel dynamic-LDS lookup
+      // (llvm.amdgcn.dynlds.offset.table) then faulted on this toolchain
+      unsigned lds_off = (unsigned)(size_t)smem;
+      asm volatile("" : "+s"(lds_off));
+      qp_admm_fast_nl(P, Bt, b, lds_off);
+    }
+#ifdef TMX_PROFILE
+    for (int q_ = 0; q_ < 16; ++q_)
+      pc[q_] += sh->pc[q_];
+    tlast = sh->tlast;
+#endif
     info = sh->info;
     w.rho = sh->rho;
     terminated = sh->terminated != 0;

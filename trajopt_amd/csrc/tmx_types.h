@@ -114,9 +114,9 @@ struct DevBatch
 };
 
 // The ADMM loop of the dense fast path as separately compiled device functions (tmx_solve.h: qp_admm_fast_nl /
-// qp_check_nl).  Default on for the product build; the phase profiler (-DTMX_PROFILE) keeps everything inline.
+// qp_check_nl).  Default on for the device build.
 #ifndef TMX_ADMM_OUTLINED
-#if defined(TMX_PROFILE) || defined(TMX_BURST_NOINLINE) || defined(TMX_HOST_EMU)
+#if defined(TMX_BURST_NOINLINE) || defined(TMX_HOST_EMU)
 #define TMX_ADMM_OUTLINED 0
 #else
 #define TMX_ADMM_OUTLINED 1

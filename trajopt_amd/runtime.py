@@ -25,6 +25,8 @@ _SIGS = {
     "tmx_batch_set_x0": ([C.c_void_p, C.c_void_p, C.c_int32], C.c_int),
     "tmx_batch_set_x0_device": ([C.c_void_p, C.c_void_p, C.c_int32], C.c_int),
     "tmx_sqp_run": ([C.c_void_p, C.c_int32, C.POINTER(C.c_int32)], C.c_int),
+    "tmx_sqp_launch": ([C.c_void_p], C.c_int),
+    "tmx_sqp_wait": ([C.c_void_p, C.POINTER(C.c_int32)], C.c_int),
     "tmx_sqp_results": ([C.c_void_p] + [C.c_void_p] * 5, C.c_int),
     "tmx_sqp_counters": ([C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)], C.c_int),
     "tmx_sqp_qp_records": ([C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p], C.c_int),
@@ -125,6 +127,15 @@ class Context:
     def run(self, max_steps: int = 0) -> int:
         na = C.c_int32(0)
         self._chk(self.lib.tmx_sqp_run(self.h, max_steps, C.byref(na)))
+        return na.value
+
+    def launch(self):
+        """asynchronous half of run(0): the whole optimize() of the batch is enqueued on the context's stream"""
+        self._chk(self.lib.tmx_sqp_launch(self.h))
+
+    def wait(self) -> int:
+        na = C.c_int32(0)
+        self._chk(self.lib.tmx_sqp_wait(self.h, C.byref(na)))
         return na.value
 
     def results(self):
