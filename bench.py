@@ -128,6 +128,13 @@ def main():
         issue(k)
     for k in range(args.warmup, nsteps):
         if k + depth - 1 < nsteps:
+            if depth > 1:
+                # the next batch is enqueued when this one begins to retire workgroups (a pinned word the kernel sets): its
+                # launch then lasts from about its first to its last workgroup, as an isolated launch does, instead of
+                # sitting in the queue behind this batch's bulk with its start event already recorded
+                cur = ctxs[k % depth]
+                while not cur.tail_started():
+                    time.sleep(0.0002)
             issue(k + depth - 1)
         r, best, c = finish(k)
         # trajopt_sqp counts QP solves only (SQPResults::overall_iteration): one trust-region evaluation each

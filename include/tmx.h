@@ -291,6 +291,10 @@ TMX_API tmx_status tmx_sqp_run(tmx_ctx* ctx, int32_t max_steps, int32_t* n_activ
  * TMX_ERR_STATE: launch while one is pending, wait without one; TMX_ERR_UNSUPPORTED in the piecewise mode. */
 TMX_API tmx_status tmx_sqp_launch(tmx_ctx* ctx);
 TMX_API tmx_status tmx_sqp_wait(tmx_ctx* ctx, int32_t* n_active_out);
+/* 1 once the pending launch has begun to retire workgroups (its straggler tail has started: CUs are free for the next
+ * batch's launch on another context), or when nothing is pending; 0 while every workgroup is still busy.  A host-side
+ * poll of one pinned word, no device call. */
+TMX_API int32_t tmx_sqp_tail_started(const tmx_ctx* ctx);
 
 /* sco::OptResults (optimizers.hpp:40-59) per problem; any output pointer may be NULL                    */
 TMX_API tmx_status tmx_sqp_results(tmx_ctx* ctx, double* x /*B*T*D*/, int32_t* status /*B*/, double* total_cost /*B*/,

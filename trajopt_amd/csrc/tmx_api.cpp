@@ -51,6 +51,7 @@ struct tmx_ctx
   long long launches_admm{ 0 };
   bool timing{ true };
   int pending{ 0 };  // a tmx_sqp_launch() not yet collected by tmx_sqp_wait()
+  int* h_tail{ nullptr };  // pinned, device-mapped word: 1 once the pool kernel of the pending launch has begun to retire workgroups
   bool ws_in_hbm{ false };  // QP workspace > 160 KB of LDS: k_*_hbm kernels, workspace carved in HBM (long horizons)
   int mode{ 2 };  // optimize() driver: 0 = one launch chain per step, 1 = k_sqp_fused, 2 = k_sqp_pool (default)
   int pool_wgs{ 0 };  // resident workgroups of the pool kernel (0 = CUs x workgroups-per-CU)
@@ -160,6 +161,20 @@ tmx_status tmx_create(int device, tmx_ctx** out)
     delete ctx;
     return TMX_ERR_DEVICE;
   }
+#ifdef TMX_HOST_EMU
+  ctx->h_tail = new int(0);
+#else
+  {
+    void* hp = nullptr;
+    if (hipHostMalloc(&hp, sizeof(int), hipHostMallocMapped) != hipSuccess)
+    {
+      delete ctx;
+      return TMX_ERR_DEVICE;
+    }
+    ctx->h_tail = static_cast<int*>(hp);
+    *ctx->h_tail = 0;
+  }
+#endif
   void* p = nullptr;
   if (hipMalloc(&p, 4 * sizeof(long long)) != hipSuccess)
   {
@@ -187,6 +202,12 @@ void tmx_destroy(tmx_ctx* ctx)
     (void)hipFree(ctx->d_totals);
   if (ctx->d_pair)
     (void)hipFree(ctx->d_pair);
+#ifdef TMX_HOST_EMU
+  delete ctx->h_tail;
+#else
+  if (ctx->h_tail)
+    (void)hipHostFree(ctx->h_tail);
+#endif
 #ifndef TMX_HOST_EMU
   if (ctx->nccl && ctx->nccl_owned)
     (void)ncclCommDestroy(static_cast<ncclComm_t>(ctx->nccl));
@@ -996,6 +1017,7 @@ static tmx_status ensure_batch(tmx_ctx* ctx, int B)
   AL(prof, b * 16);
   AL(sched_state, b);
   AL(sched_done, 1);
+  H.tail_flag = ctx->h_tail;  // pinned host memory is device-accessible at the same address (unified addressing)
   H.qp_scratch_stride = (long long)qp_scratch_doubles(P.D, P.T, P.R, P.NA, P.n_link);
   AL(qp_scratch, b * (size_t)H.qp_scratch_stride);
   H.ws_hbm_stride = ctx->ws_in_hbm ? (long long)((ctx->ws_bytes + 15) / 16 * 2) : 0;  // doubles, 16-byte aligned slices
@@ -1089,6 +1111,7 @@ tmx_status tmx_sqp_launch(tmx_ctx* ctx)
   const int B = ctx->hb.B;
   if (ctx->mode == 0)
     return TMX_ERR_UNSUPPORTED;  // the piecewise mode runs the loop on the host
+  *ctx->h_tail = 0;
   if (ctx->timing)
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
   if (ctx->ws_in_hbm)
@@ -1109,6 +1132,13 @@ tmx_status tmx_sqp_launch(tmx_ctx* ctx)
   return TMX_OK;
 }
 
+int32_t tmx_sqp_tail_started(const tmx_ctx* ctx)
+{
+  if (!ctx || !ctx->pending)
+    return 1;
+  return *static_cast<volatile int*>(ctx->h_tail) != 0 ? 1 : 0;
+}
+
 tmx_status tmx_sqp_wait(tmx_ctx* ctx, int32_t* n_active_out)
 {
   if (!ctx)
@@ -1117,6 +1147,7 @@ tmx_status tmx_sqp_wait(tmx_ctx* ctx, int32_t* n_active_out)
     return TMX_ERR_STATE;
   HIPCHK(hipSetDevice(ctx->device));
   ctx->pending = 0;
+  *ctx->h_tail = 1;
   if (ctx->timing)
   {
     HIPCHK(hipEventSynchronize(ctx->ev1));

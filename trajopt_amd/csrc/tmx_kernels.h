@@ -320,7 +320,14 @@ TMX_KERNEL_LB2(TMX_QP_NT, TMX_QP_WGS_PER_CU) k_sqp_pool(const DevProblem* P, con
         // releases it - so this workgroup is surplus from now on (the number of unfinished problems only falls) and
         // RETIRES instead of spinning to the end of the straggler tail: its CU (all of its LDS) goes to whatever is queued
         // behind this launch, e.g. the next batch's kernel on another stream (tmx_sqp_launch).
+      {
         decision = -1;
+#if TMX_IS_DEVICE
+        __hip_atomic_store(Bt->tail_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // tmx_sqp_tail_started
+#else
+        *Bt->tail_flag = 1;
+#endif
+      }
       else
       {
 #if TMX_IS_DEVICE

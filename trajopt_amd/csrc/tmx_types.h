@@ -103,6 +103,7 @@ struct DevBatch
   int *n_active;  // single int: number of problems not DONE
   int *sched_state;    // B: 0 ready, 1 claimed by a workgroup, 2 done   (k_sqp_pool)
   int *sched_done;     // 1: number of finished problems
+  int *tail_flag;      // 1, host-visible (pinned): set by the first pool workgroup that retires (tmx_sqp_tail_started)
   double *qp_scratch;  // B x qp_glb_doubles: cold part of the k_qp_solve workspace
   long long qp_scratch_stride;
   long long *prof;  // B x 16 phase cycle counters (thread 0 view, -DTMX_PROFILE builds), accumulated since k_prepare

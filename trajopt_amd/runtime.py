@@ -27,6 +27,7 @@ _SIGS = {
     "tmx_sqp_run": ([C.c_void_p, C.c_int32, C.POINTER(C.c_int32)], C.c_int),
     "tmx_sqp_launch": ([C.c_void_p], C.c_int),
     "tmx_sqp_wait": ([C.c_void_p, C.POINTER(C.c_int32)], C.c_int),
+    "tmx_sqp_tail_started": ([C.c_void_p], C.c_int32),
     "tmx_sqp_results": ([C.c_void_p] + [C.c_void_p] * 5, C.c_int),
     "tmx_sqp_counters": ([C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)], C.c_int),
     "tmx_sqp_qp_records": ([C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p], C.c_int),
@@ -132,6 +133,10 @@ class Context:
     def launch(self):
         """asynchronous half of run(0): the whole optimize() of the batch is enqueued on the context's stream"""
         self._chk(self.lib.tmx_sqp_launch(self.h))
+
+    def tail_started(self) -> bool:
+        """the pending launch has begun to retire workgroups (host-side poll of one pinned word)"""
+        return bool(self.lib.tmx_sqp_tail_started(self.h))
 
     def wait(self) -> int:
         na = C.c_int32(0)
