@@ -214,9 +214,11 @@ def sqp_history_classes(ctx, orc, desc, x0, max_qp=128, detail=None):
         oq = orc.sqp_active_sets(desc, x0[b], ctx.m_max, max_qp=max_qp)
         ob = orc.sqp_batch(desc, x0[b:b + 1], max_records=max_qp, nthreads=1)
         cls = "identical"
+        why = ""
         for k in range(max(len(dev[b]), len(oq))):
             if k >= len(dev[b]) or k >= len(oq):
                 cls = "other"
+                why = f"history lengths {len(dev[b])} vs {len(oq)}"
                 break
             r, f, y = dev[b][k]
             o = ob["records"][k]
@@ -224,12 +226,15 @@ def sqp_history_classes(ctx, orc, desc, x0, max_qp=128, detail=None):
             admm = lambda t: (t.osqp_status, t.osqp_iter, t.rho_updates, t.polish_status)
             if struct(r) != struct(o):
                 cls = "other"
+                why = f"QP structure {struct(r)} vs {struct(o)}"
                 break
             if (r.nnzA, r.hashA) != (o.nnzA, o.hashA):
                 cls = "csc-noise" if k > 0 and abs(r.nnzA - o.nnzA) <= 16 else "other"
+                why = f"A: nnz {r.nnzA} vs {o.nnzA}"
                 break
             if r.warm_started != o.warm_started:
                 cls = "other"
+                why = f"warm start {r.warm_started} vs {o.warm_started}"
                 break
             if admm(r) != admm(o):
                 cls = "admm"
@@ -237,13 +242,15 @@ def sqp_history_classes(ctx, orc, desc, x0, max_qp=128, detail=None):
             same, only_ties = compare_active_sets(f, y, oq[k][0], oq[k][1])
             if not same:
                 # a non-degenerate active-set difference is only explained when the two ADMM runs already used different rho
-                drift = abs(r.rho_final - o.rho_final) > 1e-6 * abs(o.rho_final)
+                drift = abs(r.rho_final - o.rho_final) > 1e-9 * abs(o.rho_final)   # round-off alone leaves rho equal to ~1e-13
                 cls = "tie" if only_ties else ("admm" if drift else "other")
+                why = f"non-degenerate active-set difference, rho {r.rho_final!r} vs {o.rho_final!r}, records {admm(r)}"
                 break
         if cls == "identical" and (res["status"][b] != ob["status"][0] or res["n_qp_solves"][b] != ob["n_qp_solves"][0]):
             cls = "other"
+            why = f"final status / counters {res['status'][b]},{res['n_qp_solves'][b]} vs {ob['status'][0]},{ob['n_qp_solves'][0]}"
         if cls == "other" and detail is not None:
-            detail.append((b, k if k < min(len(dev[b]), len(oq)) else -1, len(dev[b]), len(oq)))
+            detail.append((b, k if k < min(len(dev[b]), len(oq)) else -1, len(dev[b]), len(oq), why))
         classes.append(cls)
         dxs.append(float(np.abs(res["x"][b] - ob["x"][0]).max()))
     return classes, np.array(dxs), res

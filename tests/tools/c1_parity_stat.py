@@ -15,7 +15,10 @@ pci, s, g = configs.config1()
 x0 = configs.seeds_for(1, pci, s, g, B)
 ctx = runtime.Context(0, lib)
 desc = pc.make_ctx_inputs(ctx, pci, x0)
-classes, dx, r = pc.sqp_history_classes(ctx, orc, desc, x0)
+detail = []
+classes, dx, r = pc.sqp_history_classes(ctx, orc, desc, x0, detail=detail)
+for d in detail:
+    print('  other:', d)
 o = orc.sqp_batch(desc, x0)
 same = (r["status"] == o["status"]) & (r["n_qp_solves"] == o["n_qp_solves"])
 print(f"B={B}: classes {dict(Counter(classes))}; same status+QP count {same.sum()}/{B}; same status {(r['status'] == o['status']).sum()}/{B}; "
