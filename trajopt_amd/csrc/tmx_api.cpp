@@ -896,9 +896,9 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
   if (ctx->ws_in_hbm)
     ctx->smem_small = 64;
   ctx->smem_chain = 0;
-  if (ctx->ws_in_hbm && qp_chain_lds_doubles(D, T) * sizeof(double) <= 160 * 1024)
+  if (ctx->ws_in_hbm && qp_chain_lds_doubles(D, T, R2) * sizeof(double) <= 160 * 1024)
   {
-    ctx->smem_chain = qp_chain_lds_doubles(D, T) * sizeof(double);
+    ctx->smem_chain = qp_chain_lds_doubles(D, T, R2) * sizeof(double);
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_qp_solve_hbm), hipFuncAttributeMaxDynamicSharedMemorySize,
                                static_cast<int>(ctx->smem_chain)));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sqp_fused_hbm), hipFuncAttributeMaxDynamicSharedMemorySize,

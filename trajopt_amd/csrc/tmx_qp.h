@@ -172,6 +172,9 @@ struct QpWs
   const int *c2i;  // R (DevProblem::slot_c2): index of the row's second block, -1 = none
   double *c2;      // R2 * D: the (scaled) second-block coefficients
   double *Cd;      // (T-1) * D * D: dense coupling blocks (row = variable of waypoint t, column = variable of t + 1)
+  // the chain with dense couplings walks ONE mat-vec per step: Mf_t = C_t' S_t^-1 (forward), Nb_t = S_t^-1 C_t (backward),
+  // both rebuilt after every chain inversion; yb = S_t^-1 v_t of all blocks (one parallel pass between the two sweeps)
+  double *Mf, *Nb, *yb;
   int n_link;      // R2
 #endif
 };
@@ -296,7 +299,7 @@ TMX_HOSTDEVFN size_t qp_lds_doubles(int D, int T, int R, int NA, int R2 = 0)
 TMX_HOSTDEVFN size_t qp_glb_doubles(int D, int T, int R, int NA, int R2 = 0)
 {
   const size_t NX = (size_t)D * T;
-  const size_t n = 10 * NX + 6 * (size_t)R + (size_t)R * D + 8 * (size_t)NA + (R2 > 0 ? (size_t)R2 * D + (size_t)T * D * D : 0);
+  const size_t n = 10 * NX + 6 * (size_t)R + (size_t)R * D + 8 * (size_t)NA + (R2 > 0 ? (size_t)R2 * D + 3 * (size_t)T * D * D + NX : 0);
   const size_t ints = 7 * (size_t)R + (size_t)NX + (size_t)NA + 2 * (size_t)T + 4;
   return n + (ints + 1) / 2 + 8;
 }
@@ -321,10 +324,11 @@ TMX_HOSTDEVFN size_t qp_scratch_doubles(int D, int T, int R, int NA, int R2 = 0)
 // long-horizon problems keep their workspace in HBM (k_*_hbm kernels); the arrays the sequential block chain walks -
 // the block factor (stored compactly, DS = D), the coupling, the chain vector and the reduction scratch - are moved into
 // LDS when they fit (T = 300, D = 7: 154 KB), otherwise every chain step is a dependent HBM round trip
-TMX_HOSTDEVFN size_t qp_chain_lds_doubles(int D, int T)
+TMX_HOSTDEVFN size_t qp_chain_lds_doubles(int D, int T, int R2 = 0)
 {
   const size_t NX = (size_t)D * T;
-  return (size_t)T * D * D + ((D <= 8 && (size_t)T * 8 > NX + 2) ? (size_t)T * 8 : ((NX + 3) & ~(size_t)1)) + NX + (size_t)D * D + 256 + 8;
+  const size_t pairs = R2 > 0 ? 2 * (size_t)T * D * D + NX + 4 : 0;  // Mf, Nb, yb of the dense-coupling chain
+  return (size_t)T * D * D + ((D <= 8 && (size_t)T * 8 > NX + 2) ? (size_t)T * 8 : ((NX + 3) & ~(size_t)1)) + NX + (size_t)D * D + 256 + 8 + pairs;
 }
 TMX_DEVFN void qp_ws_chain_to_lds(QpWs& w, double* lds)
 {
@@ -341,6 +345,17 @@ TMX_DEVFN void qp_ws_chain_to_lds(QpWs& w, double* lds)
   w.gj = p;
   p += D * D + (D * D) % 2;
   w.red = p;
+  p += 256;
+#if TMX_LINK_ROWS
+  if (w.n_link > 0)
+  {
+    w.Mf = p;
+    p += (size_t)T * D * D + ((size_t)T * D * D) % 2;
+    w.Nb = p;
+    p += (size_t)T * D * D + ((size_t)T * D * D) % 2;
+    w.yb = p;
+  }
+#endif
 }
 
 TMX_DEVFN void qp_ws_carve(QpWs& w, double* lds, double* glb, double* far, int D, int T, int R, int NA, int R2 = 0)
@@ -407,13 +422,16 @@ TMX_DEVFN void qp_ws_carve(QpWs& w, double* lds, double* glb, double* far, int D
   TAKE(sa, NA);
   TAKE(dinv, NA);
 #if TMX_LINK_ROWS
-  w.c2 = w.Cd = nullptr;
+  w.c2 = w.Cd = w.Mf = w.Nb = w.yb = nullptr;
   w.c2i = nullptr;
   w.n_link = R2;
   if (R2 > 0)
   {
     TAKE(c2, R2 * D);
     TAKE(Cd, T * D * D);
+    TAKE(Mf, T * D * D);
+    TAKE(Nb, T * D * D);
+    TAKE(yb, NX);
   }
 #endif
   int* ip = reinterpret_cast<int*>(p);
@@ -639,6 +657,30 @@ TMX_DEVFN void kkt_invert_chain_generic(const QpWs& w, int t0, int t1, int tid, 
   }
 }
 
+#if TMX_LINK_ROWS
+// after a chain inversion with dense couplings: Mf_t = C_t' S_t^-1 and Nb_t = S_t^-1 C_t, so that every step of the two
+// substitution sweeps is ONE D x D mat-vec (as with diagonal couplings) and the sweep can be walked by one wave without
+// workgroup barriers.  Fully parallel: (T-1) D^2 entries of D-term dot products each.
+TMX_DEVFN void chain_pair_products(const QpWs& w, int tid, int NT)
+{
+  const int D = w.D, DD = D * D, DS = w.DS, DDS = w.DDS;
+  for (int e = tid; e < (w.T - 1) * DD; e += NT)
+  {
+    const int t = e / DD, i = (e / D) % D, j = e % D;
+    const double* Cm = w.Cd + (size_t)t * DD;
+    const double* S = w.Sinv + (size_t)t * DDS;
+    double m = 0.0, n = 0.0;
+    for (int k = 0; k < D; ++k)
+    {
+      m += Cm[k * D + i] * S[k * DS + j];
+      n += S[i * DS + k] * Cm[k * D + j];
+    }
+    w.Mf[e] = m;
+    w.Nb[e] = n;
+  }
+  TMX_SYNC();
+}
+#endif
 TMX_DEVFN void chain_solve_range(const QpWs& w, int t0, int t1, int tid, int NT);
 
 // ---- KKT solve: in: tp (primary rhs r1 + A'W r2 part), ta (aux rhs); out: tp = x_p, ta = x_a, hr = (A x)_r --------
@@ -1303,57 +1345,107 @@ TMX_DEVFN void chain_solve_range(const QpWs& w, int t0, int t1, int tid, int NT)
 #if TMX_LINK_ROWS
   if (TMX_HAS_PAIRS(w))
   {
-    // dense coupling blocks: v_t = b_t - C_{t-1}' (Sinv_{t-1} v_{t-1}),  x_t = Sinv_t (v_t - C_t x_{t+1})
-    double* tmp = w.red + 192;  // 2 D <= 64 doubles
+    // dense coupling blocks: v_t = b_t - Mf_{t-1} v_{t-1}  |  y_t = S_t^-1 v_t (all t at once)  |  x_t = y_t - Nb_t x_{t+1}
+    // (Mf = C' S^-1, Nb = S^-1 C from chain_pair_products).  Same operation order in both variants below.
     const int DD = D * D;
-    for (int t = t0 + 1; t <= t1; ++t)
+#if TMX_IS_DEVICE
+    const bool wave_walk = D <= 16 && NT >= 64;
+#else
+    const bool wave_walk = false;
+#endif
+    if (wave_walk)
     {
-      for (int i = tid; i < D; i += NT)
+#if TMX_IS_DEVICE
+      // one wave walks the sweep with wave-synchronous exchange: no workgroup barrier per block
+      if (tid < 64)
       {
-        const double* S = w.Sinv + (t - 1) * DDS + i * DS;
-        const double* vp = w.tp + (t - 1) * D;
-        double acc = 0.0;
-        for (int j = 0; j < D; ++j)
-          acc += S[j] * vp[j];
-        tmp[i] = acc;
-      }
-      TMX_SYNC();
-      const double* Cm = w.Cd + (size_t)(t - 1) * DD;
-      for (int i = tid; i < D; i += NT)
-      {
-        double acc = 0.0;
-        for (int k = 0; k < D; ++k)
-          acc += Cm[k * D + i] * tmp[k];
-        w.tp[t * D + i] -= acc;
-      }
-      TMX_SYNC();
-    }
-    for (int t = t1; t >= t0; --t)
-    {
-      for (int j = tid; j < D; j += NT)
-      {
-        double vj = w.tp[t * D + j];
-        if (t < t1)
+        const int i = tid < D ? tid : 0;
+        const bool live = tid < D;
+        for (int t = t0 + 1; t <= t1; ++t)
         {
-          const double* Cm = w.Cd + (size_t)t * DD + j * D;
-          for (int k = 0; k < D; ++k)
-            vj -= Cm[k] * w.tp[(t + 1) * D + k];
+          const double* M = w.Mf + (size_t)(t - 1) * DD + i * D;
+          const double* vp = w.tp + (t - 1) * D;
+          double acc = 0.0;
+          for (int j = 0; j < D; ++j)
+            acc += M[j] * vp[j];
+          if (live)
+            w.tp[t * D + i] -= acc;
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+          __builtin_amdgcn_wave_barrier();
         }
-        tmp[D + j] = vj;
       }
       TMX_SYNC();
-      for (int i = tid; i < D; i += NT)
+#endif
+    }
+    else
+      for (int t = t0 + 1; t <= t1; ++t)
       {
-        const double* S = w.Sinv + t * DDS + i * DS;
-        double acc = 0.0;
-        for (int j = 0; j < D; ++j)
-          acc += S[j] * tmp[D + j];
-        tmp[i] = acc;
+        for (int i = tid; i < D; i += NT)
+        {
+          const double* M = w.Mf + (size_t)(t - 1) * DD + i * D;
+          const double* vp = w.tp + (t - 1) * D;
+          double acc = 0.0;
+          for (int j = 0; j < D; ++j)
+            acc += M[j] * vp[j];
+          w.tp[t * D + i] -= acc;
+        }
+        TMX_SYNC();
+      }
+    for (int e = tid + t0 * D; e < (t1 + 1) * D; e += NT)
+    {
+      const int t = e / D, i = e % D;
+      const double* S = w.Sinv + t * DDS + i * DS;
+      double acc = 0.0;
+      for (int j = 0; j < D; ++j)
+        acc += S[j] * w.tp[t * D + j];
+      w.yb[e] = acc;
+    }
+    TMX_SYNC();
+    if (wave_walk)
+    {
+#if TMX_IS_DEVICE
+      if (tid < 64)
+      {
+        const int i = tid < D ? tid : 0;
+        const bool live = tid < D;
+        if (live)
+          w.tp[t1 * D + i] = w.yb[t1 * D + i];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        for (int t = t1 - 1; t >= t0; --t)
+        {
+          const double* N = w.Nb + (size_t)t * DD + i * D;
+          const double* xn = w.tp + (t + 1) * D;
+          double acc = 0.0;
+          for (int k = 0; k < D; ++k)
+            acc += N[k] * xn[k];
+          if (live)
+            w.tp[t * D + i] = w.yb[t * D + i] - acc;
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+          __builtin_amdgcn_wave_barrier();
+        }
       }
       TMX_SYNC();
+#endif
+    }
+    else
+    {
       for (int i = tid; i < D; i += NT)
-        w.tp[t * D + i] = tmp[i];
+        w.tp[t1 * D + i] = w.yb[t1 * D + i];
       TMX_SYNC();
+      for (int t = t1 - 1; t >= t0; --t)
+      {
+        for (int i = tid; i < D; i += NT)
+        {
+          const double* N = w.Nb + (size_t)t * DD + i * D;
+          const double* xn = w.tp + (t + 1) * D;
+          double acc = 0.0;
+          for (int k = 0; k < D; ++k)
+            acc += N[k] * xn[k];
+          w.tp[t * D + i] = w.yb[t * D + i] - acc;
+        }
+        TMX_SYNC();
+      }
     }
     return;
   }

@@ -354,6 +354,10 @@ TMX_DEVFN void kkt_invert(const QpWs& w, bool partitioned, int tid, int NT, long
   }
 #endif
   kkt_invert_chain_generic(w, 0, w.T - 1, tid, NT);
+#if TMX_LINK_ROWS
+  if (TMX_HAS_PAIRS(w))
+    chain_pair_products(w, tid, NT);
+#endif
 }
 
 TMX_DEVFN void admm_rhs(const QpWs& w, const DevProblem* P, int tid, int NT)
