@@ -157,6 +157,8 @@ struct QpWs
                // towards the left interior, [192) towards the right one, [256) Gauss-Jordan column scratch
   double *ty;  // P*Gs + 64: right-hand side of the dense solve, permuted (interior k at k*Gs, separators after)
   double *wself;  // LDS copy of this descriptor for the out-of-line burst function
+  // long-horizon partitioned chain (tmx_long.h): spikes of the 4 interiors (T*D*D each) and the separator system
+  double *WL, *WR, *Zp;
   double *gj;    // D*D Gauss-Jordan scratch
   double *red;   // 256: reduction scratch [0,128) (K values x up to 8 waves), scalars / hash accumulator [128,192), GJ column [192,256)
   // ints
@@ -303,13 +305,17 @@ TMX_HOSTDEVFN size_t qp_glb_doubles(int D, int T, int R, int NA, int R2 = 0)
   const size_t ints = 7 * (size_t)R + (size_t)NX + (size_t)NA + 2 * (size_t)T + 4;
   return n + (ints + 1) / 2 + 8;
 }
+// long horizons without pair rows: the block chain is cut into 4 interiors + 3 separator blocks (tmx_long.h)
+TMX_HOSTDEVFN bool lpart_fits(int D, int T, int R2) { return D <= 8 && R2 == 0 && T >= 64; }
+TMX_HOSTDEVFN size_t lpart_zp_doubles(int D) { return 9 * (size_t)D * D + 6 * (size_t)D + 2; }
 // arrays that are only touched at burst boundaries / in the polish step: always in the per-problem HBM scratch
-TMX_HOSTDEVFN size_t qp_far_doubles(int D, int T, int R, int NA)
+TMX_HOSTDEVFN size_t qp_far_doubles(int D, int T, int R, int NA, int R2 = 0)
 {
   const size_t NX = (size_t)D * T;
   const size_t n = 2 * NX + (size_t)R + 4 * (size_t)NA;
   const size_t ints = 3 * (size_t)R + (size_t)NX + (size_t)NA;
-  return n + (ints + 1) / 2 + 8;
+  const size_t lp = lpart_fits(D, T, R2) ? 2 * (size_t)T * D * D + lpart_zp_doubles(D) + 2 : 0;
+  return n + (ints + 1) / 2 + 8 + lp;
 }
 // dynamic LDS bytes of the QP kernels / per-problem HBM scratch doubles for the chosen placement
 TMX_HOSTDEVFN size_t qp_smem_bytes(int D, int T, int R, int NA, int R2 = 0)
@@ -318,7 +324,7 @@ TMX_HOSTDEVFN size_t qp_smem_bytes(int D, int T, int R, int NA, int R2 = 0)
 }
 TMX_HOSTDEVFN size_t qp_scratch_doubles(int D, int T, int R, int NA, int R2 = 0)
 {
-  return qp_far_doubles(D, T, R, NA) + (TMX_QP_COLD_IN_LDS ? 0 : qp_glb_doubles(D, T, R, NA, R2));
+  return qp_far_doubles(D, T, R, NA, R2) + (TMX_QP_COLD_IN_LDS ? 0 : qp_glb_doubles(D, T, R, NA, R2));
 }
 
 // long-horizon problems keep their workspace in HBM (k_*_hbm kernels); the arrays the sequential block chain walks -
@@ -328,7 +334,8 @@ TMX_HOSTDEVFN size_t qp_chain_lds_doubles(int D, int T, int R2 = 0)
 {
   const size_t NX = (size_t)D * T;
   const size_t pairs = R2 > 0 ? 2 * (size_t)T * D * D + NX + 4 : 0;  // Mf, Nb, yb of the dense-coupling chain
-  return (size_t)T * D * D + ((D <= 8 && (size_t)T * 8 > NX + 2) ? (size_t)T * 8 : ((NX + 3) & ~(size_t)1)) + NX + (size_t)D * D + 256 + 8 + pairs;
+  const size_t lp = lpart_fits(D, T, R2) ? lpart_zp_doubles(D) + 2 : 0;  // separator system of the partitioned chain
+  return (size_t)T * D * D + ((D <= 8 && (size_t)T * 8 > NX + 2) ? (size_t)T * 8 : ((NX + 3) & ~(size_t)1)) + NX + (size_t)D * D + 256 + 8 + pairs + lp;
 }
 TMX_DEVFN void qp_ws_chain_to_lds(QpWs& w, double* lds)
 {
@@ -354,8 +361,11 @@ TMX_DEVFN void qp_ws_chain_to_lds(QpWs& w, double* lds)
     w.Nb = p;
     p += (size_t)T * D * D + ((size_t)T * D * D) % 2;
     w.yb = p;
+    p += NX + NX % 2;
   }
 #endif
+  if (w.Zp != nullptr)
+    w.Zp = p;
 }
 
 TMX_DEVFN void qp_ws_carve(QpWs& w, double* lds, double* glb, double* far, int D, int T, int R, int NA, int R2 = 0)
@@ -464,6 +474,14 @@ TMX_DEVFN void qp_ws_carve(QpWs& w, double* lds, double* glb, double* far, int D
   TAKEI(aux_ref, R);
   TAKEI(flg_bp, NX);
   TAKEI(flg_ba, NA);
+  w.WL = w.WR = w.Zp = nullptr;
+  if (lpart_fits(D, T, R2))
+  {
+    p = reinterpret_cast<double*>((reinterpret_cast<size_t>(ip) + 15) & ~(size_t)15);
+    TAKE(WL, T * D * D);
+    TAKE(WR, T * D * D);
+    TAKE(Zp, (int)lpart_zp_doubles(D));
+  }
 #undef TAKE
 #undef TAKEI
 }
@@ -657,6 +675,11 @@ TMX_DEVFN void kkt_invert_chain_generic(const QpWs& w, int t0, int t1, int tid, 
   }
 }
 
+#if TMX_IS_DEVICE
+TMX_DEVFN bool lpart_active(const QpWs& w, int NT);
+TMX_DEVFN void lpart_factor(const QpWs& w, int tid, int NT);
+TMX_DEVFN void lpart_solve(const QpWs& w, int tid, int NT);
+#endif
 #if TMX_LINK_ROWS
 // after a chain inversion with dense couplings: Mf_t = C_t' S_t^-1 and Nb_t = S_t^-1 C_t, so that every step of the two
 // substitution sweeps is ONE D x D mat-vec (as with diagonal couplings) and the sweep can be walked by one wave without
@@ -784,7 +807,9 @@ TMX_DEVFN void kkt_solve(const QpWs& w, const DevProblem* P, int mode, double si
     chain_solve_range(w, 0, T - 1, tid, NT);  // dense coupling blocks
   else
 #if TMX_IS_DEVICE
-  if (D <= 8 && NT >= 64)
+  if (lpart_active(w, NT))
+    lpart_solve(w, tid, NT);  // long horizon: 4 interior chains side by side + separator system + spike correction
+  else if (D <= 8 && NT >= 64)
   {
     // one wave walks the chain with wave-synchronous LDS exchange: 2T-1 dependent steps without a workgroup barrier each
     if (tid < 64)
@@ -1484,7 +1509,17 @@ TMX_DEVFN void chain_solve_range(const QpWs& w, int t0, int t1, int tid, int NT)
     TMX_SYNC();
   }
 }
-TMX_DEVFN void chain_solve(const QpWs& w, int tid, int NT) { chain_solve_range(w, 0, w.T - 1, tid, NT); }
+TMX_DEVFN void chain_solve(const QpWs& w, int tid, int NT)
+{
+#if TMX_IS_DEVICE
+  if (lpart_active(w, NT))
+  {
+    lpart_solve(w, tid, NT);  // long horizon: the factorisation is the partitioned one (kkt_invert)
+    return;
+  }
+#endif
+  chain_solve_range(w, 0, w.T - 1, tid, NT);
+}
 
 // Phase C: aux recovery, ztilde, and the x / z / y updates (rows + their aux, primary vars)
 TMX_DEVFN void admm_phase_c(const QpWs& w, bool keep_delta, int tid, int NT)
@@ -1568,4 +1603,5 @@ TMX_DEVFN void admm_phase_c(const QpWs& w, bool keep_delta, int tid, int NT)
 
 #if TMX_IS_DEVICE
 #include "tmx_part.h"
+#include "tmx_long.h"
 #endif

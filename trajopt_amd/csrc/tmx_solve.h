@@ -347,6 +347,11 @@ TMX_DEVFN void kkt_invert(const QpWs& w, bool partitioned, int tid, int NT, long
     dpart_factor(w, tid, NT, pc, tlast);
     return;
   }
+  if (lpart_active(w, NT))
+  {
+    lpart_factor(w, tid, NT);
+    return;
+  }
   if (w.D * w.D <= 64 && !TMX_HAS_PAIRS(w))
   {
     kkt_invert_chain_wave0(w, tid);
@@ -597,7 +602,7 @@ TMX_DEVFN QpShared* qp_ws_rebuild(QpWs& w, const DevProblem* P, const DevBatch* 
 #if TMX_QP_COLD_IN_LDS
   qp_ws_carve(w, smem, smem + qp_lds_doubles(D, T, R, P->NA, P->n_link), scratch, D, T, R, P->NA, P->n_link);
 #else
-  qp_ws_carve(w, smem, scratch + qp_far_doubles(D, T, R, P->NA), scratch, D, T, R, P->NA, P->n_link);
+  qp_ws_carve(w, smem, scratch + qp_far_doubles(D, T, R, P->NA, P->n_link), scratch, D, T, R, P->NA, P->n_link);
 #endif
 #if TMX_LINK_ROWS
   w.c2i = P->slot_c2;
@@ -741,7 +746,7 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
 #if TMX_QP_COLD_IN_LDS
     qp_ws_carve(w, smem, smem + qp_lds_doubles(D, T, R, P->NA, P->n_link), scratch, D, T, R, P->NA, P->n_link);
 #else
-    qp_ws_carve(w, smem, scratch + qp_far_doubles(D, T, R, P->NA), scratch, D, T, R, P->NA, P->n_link);
+    qp_ws_carve(w, smem, scratch + qp_far_doubles(D, T, R, P->NA, P->n_link), scratch, D, T, R, P->NA, P->n_link);
 #endif
     if (chain_lds)  // k_*_hbm kernels only (a constant nullptr everywhere else)
       qp_ws_chain_to_lds(w, chain_lds);
