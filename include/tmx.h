@@ -182,6 +182,10 @@ typedef struct
      initial_trust_box_size (trajopt_sqp/include/trajopt_sqp/types.h:99-141).                                      */
   int32_t flavor;
   const int32_t* fixed_dofs;
+  /* optional, 3 doubles per obstacle (NULL: all obstacles are spheres): obstacle o is the CAPSULE swept by its sphere from
+     `center` to `center + axis`; a zero vector leaves it a sphere.  Contact data of link spheres against capsules:
+     include/tmx_geom.h (closest point on the segment; swept link sphere vs capsule = closest points of two segments).   */
+  const double* obstacle_axes;
 } tmx_problem_desc;
 
 typedef enum

@@ -344,6 +344,8 @@ Sqp2Problem buildSqp2(const tmx_problem_desc& d, const double* x0)
     scene->link_spheres.push_back(d.link_spheres[i]);
   for (int i = 0; i < d.n_obstacles; ++i)
     scene->obstacles.push_back(d.obstacles[i]);
+  if (d.obstacle_axes)
+    scene->obstacle_axes.assign(d.obstacle_axes, d.obstacle_axes + 3 * d.n_obstacles);
   for (int k = 0; k < d.n_terms; ++k)
   {
     const tmx_term& tm = d.terms[k];

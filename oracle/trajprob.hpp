@@ -22,7 +22,9 @@
 #include <vector>
 
 #include "../include/tmx.h"
-#include "../include/tmx_detmath.h"  // the libm stand-in shared with the device kernels (fixed IEEE operation sequence)
+#include "../include/tmx_detmath.h"
+#include "../include/tmx_geom.h"  // sphere / capsule obstacle contacts, shared with the kernels
+// ^ tmx_detmath.h: the libm stand-in shared with the device kernels (fixed IEEE operation sequence)
 #include "sco.hpp"
 
 namespace orc
@@ -765,6 +767,8 @@ struct Scene
 {
   std::vector<tmx_link_sphere> link_spheres;
   std::vector<tmx_obstacle_sphere> obstacles;
+  std::vector<double> obstacle_axes;  // 3 per obstacle (capsule = sphere swept from centre to centre + axis); empty: spheres
+  const double* axisOf(std::size_t o) const { return obstacle_axes.empty() ? nullptr : obstacle_axes.data() + 3 * o; }
 };
 struct Contact
 {
@@ -790,7 +794,9 @@ inline void calcContacts(const Chain& chain, const Scene& scene, const double* q
     for (std::size_t o = 0; o < scene.obstacles.size(); ++o)
     {
       const auto& ob = scene.obstacles[o];
-      const double d[3] = { ob.center[0] - c[0], ob.center[1] - c[1], ob.center[2] - c[2] };
+      double oq[3];  // closest point of the obstacle primitive to the sphere centre (the centre itself for a sphere)
+      tmx_obstacle_closest_to_point(ob.center, scene.axisOf(o), c, oq);
+      const double d[3] = { oq[0] - c[0], oq[1] - c[1], oq[2] - c[2] };
       const double len = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
       const double dist = len - ls.radius - ob.radius;
       if (dist > (margin + buffer))
@@ -1027,16 +1033,14 @@ struct LvsEvaluatorData  // the contact model itself (shared by the sco terms be
           double ca[3], p[3];
           sphereCentre(Ta, ls, ca);
           double tau = 0.0;
+          double oq[3];  // closest point of the obstacle primitive (include/tmx_geom.h)
           if (cast)
           {
             const Tf& Tb = poses[static_cast<std::size_t>(i + 1)][ls.link];
             double cb[3];
             sphereCentre(Tb, ls, cb);
             const double e[3] = { cb[0] - ca[0], cb[1] - ca[1], cb[2] - ca[2] };
-            const double ee = e[0] * e[0] + e[1] * e[1] + e[2] * e[2];
-            const double eo = e[0] * (ob.center[0] - ca[0]) + e[1] * (ob.center[1] - ca[1]) + e[2] * (ob.center[2] - ca[2]);
-            tau = (ee > 1e-24) ? eo / ee : 0.0;  // a link that does not move over the sub-segment: contact at its start
-            tau = tau < 0.0 ? 0.0 : (tau > 1.0 ? 1.0 : tau);
+            tau = tmx_swept_closest_to_obstacle(ca, e, ob.center, scene->axisOf(o), oq);
             for (int r = 0; r < 3; ++r)
               p[r] = ca[r] + tau * e[r];
             c.tf0 = Ta;
@@ -1046,10 +1050,11 @@ struct LvsEvaluatorData  // the contact model itself (shared by the sco terms be
           {
             for (int r = 0; r < 3; ++r)
               p[r] = ca[r];
+            tmx_obstacle_closest_to_point(ob.center, scene->axisOf(o), p, oq);
             c.tf0 = Ta;
             c.tf1 = Ta;
           }
-          const double d[3] = { ob.center[0] - p[0], ob.center[1] - p[1], ob.center[2] - p[2] };
+          const double d[3] = { oq[0] - p[0], oq[1] - p[1], oq[2] - p[2] };
           const double len = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
           c.distance = len - ls.radius - ob.radius;
           double pw[3];
@@ -1218,6 +1223,8 @@ inline TrajProblem constructProblem(const tmx_problem_desc& d, const double* ini
     P.scene->link_spheres.push_back(d.link_spheres[i]);
   for (int i = 0; i < d.n_obstacles; ++i)
     P.scene->obstacles.push_back(d.obstacles[i]);
+  if (d.obstacle_axes)
+    P.scene->obstacle_axes.assign(d.obstacle_axes, d.obstacle_axes + 3 * d.n_obstacles);
   const int T = d.n_steps, D = d.n_dof;
   // TrajOptProb ctor :553-592
   std::vector<std::string> names;

@@ -44,6 +44,19 @@ def cfg(cid, T=None):
                 ti.longest_valid_segment_length = 10.0 if cid == 19 else 0.12
                 ti.max_substates = 2 if cid == 19 else 4
         return pci, s, g
+    if cid in (20, 21, 22):
+        # CAPSULE obstacles (include/tmx_geom.h): 20 single-time-step cost, 21 LVS_CONTINUOUS (swept link sphere vs capsule =
+        # closest points of two segments) cost, 22 LVS_DISCRETE constraint; one capsule across the path + the original sphere
+        from trajopt_amd.problem import CollisionTermInfo
+        pci, s, g = configs.config_mini(collision_cnt=(cid == 22)) if T is None else configs.config_mini(T, collision_cnt=(cid == 22))
+        (c0, r0) = pci.obstacles[0]
+        pci.obstacles = [((c0[0] - 0.25, c0[1] - 0.1, c0[2] + 0.05), 0.06, (0.5, 0.15, -0.1)), (c0, r0)]
+        for ti in pci.cost_infos + pci.cnt_infos:
+            if isinstance(ti, CollisionTermInfo) and cid != 20:
+                ti.evaluator_type = 4 if cid == 21 else 2
+                ti.longest_valid_segment_length = 0.12
+                ti.max_substates = 4
+        return pci, s, g
     if cid == 12:  # BasicInfo::fixed_dofs: the wrist joint keeps its seed value at every step
         return configs.config_mini(with_joint_band=False, fixed_dofs=[3])
     if cid == 2:   # puzzle_piece: 300 waypoints, the QP workspace lives in HBM on the device (generic block-chain path)

@@ -1,0 +1,91 @@
+"""Capsule obstacles (include/tmx_geom.h): the exact collision-cost value of the oracle (and of the kernel sources, which
+include the same header) against a brute-force numpy distance - link-sphere centre to a densely sampled capsule axis.
+The reference gets these contacts from tesseract / Bullet; sphere-vs-capsule has this closed form."""
+import numpy as np
+import pytest
+
+import parity_checks as pc
+from trajopt_amd import configs, runtime
+from trajopt_amd.problem import CollisionTermInfo
+
+
+def _brute_force_cost(pci, x, term):
+    rob = pci.robot
+    total = 0.0
+    for t in range(term.first_step, term.last_step + 1):
+        links = rob.fk_links(x[t])
+        for (link, c, r) in rob.link_spheres:
+            T = links[link]
+            cw = T[:3, :3] @ np.asarray(c) + T[:3, 3]
+            for ob in pci.obstacles:
+                oc, orad = np.asarray(ob[0]), ob[1]
+                ax = np.asarray(ob[2]) if len(ob) > 2 else np.zeros(3)
+                ss = np.linspace(0.0, 1.0, 20001)
+                pts = oc[None, :] + ss[:, None] * ax[None, :]
+                dist = np.sqrt(((pts - cw[None, :]) ** 2).sum(axis=1)).min() - r - orad
+                if dist <= term.dist_pen + term.safety_margin_buffer:
+                    total += term.coeff * max(term.dist_pen - dist, 0.0)
+    return total
+
+
+def test_single_time_step_cost_against_brute_force(hostemu_lib, orc):
+    pci, s, g = pc.cfg(20)
+    # a wider penalty distance so that several contacts are in violation
+    term = [ti for ti in pci.cost_infos if isinstance(ti, CollisionTermInfo)][0]
+    term.dist_pen = 0.25
+    x0 = configs.seeds_for(20, pci, s, g, 2, sigma=0.05)
+    desc = pci.to_desc()
+    assert pci.cost_infos[0] is not term and len(pci.cost_infos) == 2   # [JointVel, collision]: one cost per step follows the first
+    for b in range(2):
+        ref = _brute_force_cost(pci, x0[b], term)
+        cvo, _ = orc.evaluate(desc, x0[b], x0[b])
+        assert ref > 0.01, "the test geometry must produce violations"
+        assert abs(cvo[1:].sum() - ref) <= 1e-7 * max(1.0, ref)
+    ctx = runtime.Context(0, hostemu_lib)
+    pc.make_ctx_inputs(ctx, pci, x0)
+    cv, _ = ctx.evaluate()
+    ctx.close()
+    for b in range(2):
+        assert np.array_equal(cv[b], orc.evaluate(desc, x0[b], x0[b])[0])   # same header, same bits
+
+
+def test_segment_segment_closest_points_against_brute_force(tmp_path):
+    """tmx_swept_closest_to_obstacle (swept link-sphere centre vs capsule axis) on random segments, incl. parallel and
+    degenerate ones: the distance at the returned parameters equals the brute-force minimum over a 401 x 401 grid refined
+    around its argmin"""
+    import ctypes as C
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "g.c"
+    src.write_text('#include "tmx_geom.h"\n'
+                   'double swept(const double* ca, const double* e, const double* oc, const double* oa, double* q)\n'
+                   '{ return tmx_swept_closest_to_obstacle(ca, e, oc, oa, q); }\n'
+                   'void point(const double* oc, const double* oa, const double* c, double* q) { tmx_obstacle_closest_to_point(oc, oa, c, q); }\n')
+    so = tmp_path / "g.so"
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-shared", "-fPIC", "-I", os.path.join(root, "include"), "-o", str(so), str(src)])
+    lib = C.CDLL(str(so))
+    lib.swept.restype = C.c_double
+    P = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    rng = np.random.default_rng(5)
+    for case in range(300):
+        ca, e, oc, oa = (rng.normal(size=3) for _ in range(4))
+        if case % 7 == 0:
+            oa = e * rng.uniform(-2, 2)          # parallel axes
+        if case % 11 == 0:
+            e = np.zeros(3)                       # link that does not move
+        if case % 13 == 0:
+            oa = np.zeros(3)                      # sphere obstacle
+        q = np.zeros(3)
+        tau = lib.swept(P(ca), P(e), P(oc), P(oa), P(q))
+        assert 0.0 <= tau <= 1.0
+        d = np.linalg.norm(ca + tau * e - q)
+        ss = np.linspace(0, 1, 401)
+        A = ca[None, :] + ss[:, None] * e[None, :]
+        Bp = oc[None, :] + ss[:, None] * oa[None, :]
+        D2 = ((A[:, None, :] - Bp[None, :, :]) ** 2).sum(axis=2)
+        assert d <= np.sqrt(D2.min()) + 1e-9, (case, d, np.sqrt(D2.min()))
+        # and q is on the capsule axis
+        if np.dot(oa, oa) > 0:
+            t = np.dot(q - oc, oa) / np.dot(oa, oa)
+            assert -1e-12 <= t <= 1 + 1e-12 and np.linalg.norm(oc + t * oa - q) < 1e-12

@@ -104,6 +104,7 @@ class ProblemDesc(C.Structure):
         ("n_fixed_dofs", C.c_int32),
         ("flavor", C.c_int32),
         ("fixed_dofs", C.POINTER(C.c_int32)),
+        ("obstacle_axes", C.POINTER(C.c_double)),
     ]
 
 

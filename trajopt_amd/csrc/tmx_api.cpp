@@ -802,7 +802,7 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
       wp_list[next[st[r]]++] = r;
   }
   std::vector<int> ls_link;
-  std::vector<double> ls_center, ls_radius, ob_center, ob_radius;
+  std::vector<double> ls_center, ls_radius, ob_center, ob_radius, ob_axis;
   for (int s = 0; s < d->n_link_spheres; ++s)
   {
     if (d->link_spheres[s].link < 0 || d->link_spheres[s].link >= D)
@@ -820,6 +820,8 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
     for (int q = 0; q < 3; ++q)
       ob_center.push_back(d->obstacles[o].center[q]);
     ob_radius.push_back(d->obstacles[o].radius);
+    for (int q = 0; q < 3; ++q)
+      ob_axis.push_back(d->obstacle_axes ? d->obstacle_axes[3 * o + q] : 0.0);
   }
   auto& pool = ctx->prob_allocs;
   tmx_status rc;
@@ -869,6 +871,7 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
   UP(ls_radius, ls_radius);
   UP(ob_center, ob_center);
   UP(ob_radius, ob_radius);
+  UP(ob_axis, ob_axis);
 #undef UP
   if (!ctx->dp)
   {

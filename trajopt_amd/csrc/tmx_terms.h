@@ -10,7 +10,8 @@
 //   JointVelEqCost / JointPosEqConstraint           trajopt/src/trajectory_costs.cpp:139-183,257-301
 #pragma once
 #include "tmx_types.h"
-#include "../../include/tmx_detmath.h"  // sin / cos / atan2 with a fixed IEEE operation sequence, shared with the oracle
+#include "../../include/tmx_detmath.h"
+#include "../../include/tmx_geom.h"     // sphere / capsule obstacle contacts, shared with the oracle  // sin / cos / atan2 with a fixed IEEE operation sequence, shared with the oracle
 
 #define TMX_EPS_FD 1e-5       // sco DEFAULT_EPSILON, trajopt_sco/src/modeling_utils.cpp:13
 #define TMX_CLEANUP_TOL 1e-7  // sco::cleanupAff, trajopt_sco/src/expr_ops.cpp:91
@@ -245,8 +246,10 @@ TMX_DEVFN double contact_distance(const DevProblem* P, const double* q, int s, i
   for (int r = 0; r < 3; ++r)
     c[r] = L.R[3 * r + 0] * P->ls_center[3 * s + 0] + L.R[3 * r + 1] * P->ls_center[3 * s + 1] +
            L.R[3 * r + 2] * P->ls_center[3 * s + 2] + L.t[r];
+  double oq[3];  // closest point of the obstacle primitive to the sphere centre (the centre itself for a sphere)
+  tmx_obstacle_closest_to_point(P->ob_center + 3 * o, P->ob_axis + 3 * o, c, oq);
   for (int r = 0; r < 3; ++r)
-    d[r] = P->ob_center[3 * o + r] - c[r];
+    d[r] = oq[r] - c[r];
   const double len = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
   const double rs = P->ls_radius[s];
   for (int r = 0; r < 3; ++r)
@@ -308,6 +311,7 @@ TMX_DEVFN bool lvs_contact(const DevProblem* P, const double* q0, const double* 
   for (int rr = 0; rr < 3; ++rr)
     ca[rr] = Ta.R[3 * rr + 0] * P->ls_center[3 * s + 0] + Ta.R[3 * rr + 1] * P->ls_center[3 * s + 1] + Ta.R[3 * rr + 2] * P->ls_center[3 * s + 2] + Ta.t[rr];
   double tau = 0.0;
+  double oq[3];  // closest point of the obstacle primitive (include/tmx_geom.h)
   if (cast)
   {
     fk_link_at(P, qb, link, Tb);
@@ -315,10 +319,7 @@ TMX_DEVFN bool lvs_contact(const DevProblem* P, const double* q0, const double* 
     for (int rr = 0; rr < 3; ++rr)
       cb[rr] = Tb.R[3 * rr + 0] * P->ls_center[3 * s + 0] + Tb.R[3 * rr + 1] * P->ls_center[3 * s + 1] + Tb.R[3 * rr + 2] * P->ls_center[3 * s + 2] + Tb.t[rr];
     const double e[3] = { cb[0] - ca[0], cb[1] - ca[1], cb[2] - ca[2] };
-    const double ee = e[0] * e[0] + e[1] * e[1] + e[2] * e[2];
-    const double eo = e[0] * (P->ob_center[3 * o + 0] - ca[0]) + e[1] * (P->ob_center[3 * o + 1] - ca[1]) + e[2] * (P->ob_center[3 * o + 2] - ca[2]);
-    tau = (ee > 1e-24) ? eo / ee : 0.0;  // a link that does not move over the sub-segment: contact at its start
-    tau = tau < 0.0 ? 0.0 : (tau > 1.0 ? 1.0 : tau);
+    tau = tmx_swept_closest_to_obstacle(ca, e, P->ob_center + 3 * o, P->ob_axis + 3 * o, oq);
     for (int rr = 0; rr < 3; ++rr)
       p[rr] = ca[rr] + tau * e[rr];
   }
@@ -327,8 +328,9 @@ TMX_DEVFN bool lvs_contact(const DevProblem* P, const double* q0, const double* 
     Tb = Ta;
     for (int rr = 0; rr < 3; ++rr)
       p[rr] = ca[rr];
+    tmx_obstacle_closest_to_point(P->ob_center + 3 * o, P->ob_axis + 3 * o, p, oq);
   }
-  const double d[3] = { P->ob_center[3 * o + 0] - p[0], P->ob_center[3 * o + 1] - p[1], P->ob_center[3 * o + 2] - p[2] };
+  const double d[3] = { oq[0] - p[0], oq[1] - p[1], oq[2] - p[2] };
   const double len = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
   const double rs = P->ls_radius[s];
   c.distance = len - rs - P->ob_radius[o];

@@ -68,6 +68,7 @@ struct DevProblem
   // collision geometry
   int *ls_link;
   double *ls_center, *ls_radius, *ob_center, *ob_radius;
+  double *ob_axis;  // 3 per obstacle: capsule = sphere swept from ob_center to ob_center + ob_axis (zero: sphere)
   // pair rows (rows that also touch waypoint t + 1)
   int *slot_c2;       // R: index of the row's second coefficient block in DevBatch::coef2 (-1: the row sits on one waypoint)
   int n_link;         // number of pair rows R2 (0: every row sits on one waypoint)

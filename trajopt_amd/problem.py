@@ -243,10 +243,14 @@ class ProblemConstructionInfo:
         for i, (link, c, r) in enumerate(rob.link_spheres):
             ls[i].link, ls[i].radius = link, r
             ls[i].center[:] = list(c)
+        # an obstacle is ((x, y, z), r) - a sphere - or ((x, y, z), r, (ax, ay, az)) - the capsule swept from centre to centre + axis
         ob = (abi.ObstacleSphere * max(1, len(self.obstacles)))()
-        for i, (c, r) in enumerate(self.obstacles):
-            ob[i].center[:] = list(c)
-            ob[i].radius = r
+        ob_axes = (C.c_double * (3 * max(1, len(self.obstacles))))()
+        for i, o in enumerate(self.obstacles):
+            ob[i].center[:] = list(o[0])
+            ob[i].radius = o[1]
+            if len(o) > 2:
+                ob_axes[3 * i:3 * i + 3] = list(o[2])
         fixed = (C.c_int32 * max(1, len(self.basic_info.fixed_timesteps)))(*self.basic_info.fixed_timesteps)
         terms = []
         keep_fixed = []
@@ -327,11 +331,13 @@ class ProblemConstructionInfo:
         tarr = (abi.Term * max(1, len(terms)))(*terms)
         d.n_link_spheres, d.n_obstacles = len(rob.link_spheres), len(self.obstacles)
         d.link_spheres, d.obstacles = ls, ob
+        if any(len(o) > 2 for o in self.obstacles):
+            d.obstacle_axes = C.cast(ob_axes, C.POINTER(C.c_double))
         d.n_fixed_steps, d.n_terms = len(self.basic_info.fixed_timesteps), len(terms)
         d.fixed_steps, d.terms = fixed, tarr
         fdofs = (C.c_int32 * max(1, len(self.basic_info.fixed_dofs)))(*self.basic_info.fixed_dofs)
         d.n_fixed_dofs, d.fixed_dofs = len(self.basic_info.fixed_dofs), fdofs
         d.flavor = int(self.flavor)
-        self._keep = [ls, ob, fixed, tarr, fdofs, keep_fixed]   # keep the pointed-to arrays alive
+        self._keep = [ls, ob, ob_axes, fixed, tarr, fdofs, keep_fixed]   # keep the pointed-to arrays alive
         d._keep = self._keep
         return d
