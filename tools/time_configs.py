@@ -1,4 +1,4 @@
-"""Wall time of one batched optimize() per BASELINE config on the device: python tools/time_configs.py [cfg ...]
+"""Wall time of one batched optimize() per BASELINE config on the device: python tools/time_configs.py [cfg ...] [lib.so]
 prints SQP iterations / QP solves / ADMM iterations per second per config (used for the per-config lines of DESIGN.md)."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -6,12 +6,13 @@ import numpy as np
 from trajopt_amd import configs, abi, runtime
 
 SPEC = {1: (configs.config1, 1024, 0.1), 2: (configs.config2, 256, None), 3: (configs.config3, 128, 0.05), 4: (configs.config4, 1024, 0.05)}
-for cid in [int(a) for a in sys.argv[1:]] or [1, 2, 3, 4]:
+LIB = next((a for a in sys.argv[1:] if not a.isdigit()), None)
+for cid in [int(a) for a in sys.argv[1:] if a.isdigit()] or [1, 2, 3, 4]:
     make, B, sigma = SPEC[cid]
     pci, s, g = make()
     desc = pci.to_desc()
     x0 = configs.seeds_for(cid, pci, s, g, B) if sigma is None else configs.seeds_for(cid, pci, s, g, B, sigma=sigma)
-    ctx = runtime.Context(0)
+    ctx = runtime.Context(0, LIB)
     ctx.upload(desc, abi.default_sqp_params(), configs.osqp_settings_config4() if cid == 4 else abi.default_osqp_settings())
     best = None
     for rep in range(2):

@@ -1118,7 +1118,7 @@ tmx_status tmx_sqp_launch(tmx_ctx* ctx)
   if (ctx->timing)
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
   if (ctx->ws_in_hbm)
-    TMX_LAUNCH(k_sqp_fused_hbm, B, ctx->nt_qp, ctx->smem_chain, ctx->stream, ctx->dp, ctx->db, 0);
+    TMX_LAUNCH(k_sqp_fused_hbm, B, ctx->nt_qp > 1 ? TMX_HBM_NT : 1, ctx->smem_chain, ctx->stream, ctx->dp, ctx->db, 0);
   else if (ctx->mode == 2)
   {
     const int G = std::min(B, ctx->pool_wgs);
@@ -1187,7 +1187,7 @@ tmx_status tmx_sqp_run(tmx_ctx* ctx, int32_t max_steps, int32_t* n_active_out)
     }
     if (ctx->ws_in_hbm)
       TIMED(ctx->ms_admm, ctx->launches_admm++,
-            TMX_LAUNCH(k_sqp_fused_hbm, B, ctx->nt_qp, ctx->smem_chain, ctx->stream, ctx->dp, ctx->db, (int)max_steps));
+            TMX_LAUNCH(k_sqp_fused_hbm, B, ctx->nt_qp > 1 ? TMX_HBM_NT : 1, ctx->smem_chain, ctx->stream, ctx->dp, ctx->db, (int)max_steps));
     else
       TIMED(ctx->ms_admm, ctx->launches_admm++,
             TMX_LAUNCH(k_sqp_fused, B, ctx->nt_qp, ctx->smem_qp, ctx->stream, ctx->dp, ctx->db, (int)max_steps));
@@ -1216,7 +1216,7 @@ tmx_status tmx_sqp_run(tmx_ctx* ctx, int32_t max_steps, int32_t* n_active_out)
     TIMED(ctx->ms_convexify, (void)0,
           TMX_LAUNCH(k_convexify, B, ctx->nt_small, ctx->smem_small, ctx->stream, ctx->dp, ctx->db, 0));
     if (ctx->ws_in_hbm)
-      TIMED(ctx->ms_admm, ctx->launches_admm++, TMX_LAUNCH(k_qp_solve_hbm, B, ctx->nt_qp, ctx->smem_chain, ctx->stream, ctx->dp, ctx->db, 0));
+      TIMED(ctx->ms_admm, ctx->launches_admm++, TMX_LAUNCH(k_qp_solve_hbm, B, ctx->nt_qp > 1 ? TMX_HBM_NT : 1, ctx->smem_chain, ctx->stream, ctx->dp, ctx->db, 0));
     else
       TIMED(ctx->ms_admm, ctx->launches_admm++,
             TMX_LAUNCH(k_qp_solve, B, ctx->nt_qp, ctx->smem_qp, ctx->stream, ctx->dp, ctx->db, 0));
@@ -1453,7 +1453,7 @@ tmx_status tmx_qp_solve(tmx_ctx* ctx, double* x_qp, int32_t* cvx_status, tmx_qp_
   HIPCHK(hipSetDevice(ctx->device));
   const size_t B = ctx->hb.B;
   if (ctx->ws_in_hbm)
-    TIMED(ctx->ms_admm, ctx->launches_admm++, TMX_LAUNCH(k_qp_solve_hbm, ctx->hb.B, ctx->nt_qp, ctx->smem_chain, ctx->stream, ctx->dp, ctx->db, 1));
+    TIMED(ctx->ms_admm, ctx->launches_admm++, TMX_LAUNCH(k_qp_solve_hbm, ctx->hb.B, ctx->nt_qp > 1 ? TMX_HBM_NT : 1, ctx->smem_chain, ctx->stream, ctx->dp, ctx->db, 1));
   else
     TIMED(ctx->ms_admm, ctx->launches_admm++,
           TMX_LAUNCH(k_qp_solve, ctx->hb.B, ctx->nt_qp, ctx->smem_qp, ctx->stream, ctx->dp, ctx->db, 1));

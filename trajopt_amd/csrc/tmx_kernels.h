@@ -230,11 +230,16 @@ TMX_KERNEL_LB2(TMX_QP_NT, TMX_QP_WGS_PER_CU) k_sqp_fused(const DevProblem* P, co
   }
 }
 
+#ifndef TMX_HBM_NT
+#define TMX_HBM_NT 512  // threads per workgroup of the HBM-workspace kernels: their row / variable sweeps are chains of
+                        // dependent HBM round trips, so two waves per SIMD hide more than the halved register budget costs
+                        // (256 -> 512 threads: config 2 2.16 -> 1.62 s, config 3 3.68 -> 2.60 s per batch)
+#endif
 // Long-horizon variants: the QP workspace does not fit the 160 KB of LDS, so each workgroup carves it in HBM
 // (Bt->ws_hbm) and runs the generic block-chain path of the solver on it.  Same device functions, same results; the
 // workgroup barrier orders the HBM accesses of one workgroup just as it orders LDS.  Separate kernels so that the code
 // generation of the LDS-resident kernels (k_sqp_pool) is untouched.
-TMX_KERNEL_LB2(TMX_QP_NT, 1) k_qp_solve_hbm(const DevProblem* P, const DevBatch* Bt, int force)
+TMX_KERNEL_LB2(TMX_HBM_NT, 1) k_qp_solve_hbm(const DevProblem* P, const DevBatch* Bt, int force)
 {
   const int b = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
   if (!force && Bt->phase[b] == PHASE_DONE)
@@ -247,7 +252,7 @@ TMX_KERNEL_LB2(TMX_QP_NT, 1) k_qp_solve_hbm(const DevProblem* P, const DevBatch*
   for (int v = tid; v < P->NX; v += NT)
     xn[v] = xq[v];
 }
-TMX_KERNEL_LB2(TMX_QP_NT, 1) k_sqp_fused_hbm(const DevProblem* P, const DevBatch* Bt, int max_steps)
+TMX_KERNEL_LB2(TMX_HBM_NT, 1) k_sqp_fused_hbm(const DevProblem* P, const DevBatch* Bt, int max_steps)
 {
   const int b = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
   double* work = Bt->ws_hbm + (size_t)b * (size_t)Bt->ws_hbm_stride;

@@ -3,7 +3,8 @@
 // The generic path solves the block-tridiagonal reduced KKT system (T blocks of D x D, diagonal couplings) by block
 // substitution: 2T-1 dependent D x D mat-vecs walked by ONE wave.  For config 2 (puzzle_piece, T = 300) that chain was 75 %
 // of the ADMM iteration (599 steps x ~1400 cycles, tools/prof_phases.py 256 full <lib> 2) with three waves idle.  Here the
-// chain is cut by nested dissection into FOUR interiors separated by three single-block separators, one interior per wave:
+// chain is cut by nested dissection into P interiors (P = waves of the workgroup, 4 or 8) separated by P-1 single-block
+// separators, one interior per wave:
 //   factor :  per interior the explicit inverse Schur complements Sinv_t (part_invert_interior, one matrix entry per lane)
 //             and the two SPIKES  WL = M_int^-1 E_first C_left,  WR = M_int^-1 E_last C_right  - D right-hand sides at once,
 //             i.e. matmul-shaped: v_mfma_f64_16x16x4_f64, whose D-layout is the next step's B-layout; then the 3D x 3D
@@ -19,26 +20,34 @@ typedef double tmx_v4d __attribute__((ext_vector_type(4)));
 
 struct LPart
 {
-  int a[4], b[4], s[3];
+  int P;  // interiors = waves of the workgroup, at most 8
+  int a[8], b[8], s[8];
 };
-TMX_DEVFN void lpart_make(int T, LPart& p)
+TMX_DEVFN void lpart_make(int T, int NT, LPart& p)
 {
-  const int L = T - 3, base = L / 4, rem = L % 4;
+  // measured on config 2 with 512 threads: 8 interiors 1.69 s per batch, 4 interiors 1.62 s - the 49 x 49 separator system
+  // (in the HBM scratch) costs more than the shorter chains save
+  const int P = (NT >> 6) < 4 ? (NT >> 6) : 4;
+  p.P = P;
+  const int L = T - (P - 1), base = L / P, rem = L % P;
   int t = 0;
-  for (int k = 0; k < 4; ++k)
+  for (int k = 0; k < 8; ++k)
   {
+    p.a[k] = p.b[k] = p.s[k] = 0;
+    if (k >= P)
+      continue;
     const int len = base + (k < rem ? 1 : 0);
     p.a[k] = t;
     p.b[k] = t + len - 1;
     t += len;
-    if (k < 3)
+    if (k < P - 1)
     {
       p.s[k] = t;
       t += 1;
     }
   }
 }
-TMX_DEVFN bool lpart_active(const QpWs& w, int NT) { return NT == 256 && w.WL != nullptr && !TMX_HAS_PAIRS(w) && w.D <= 8; }
+TMX_DEVFN bool lpart_active(const QpWs& w, int NT) { return NT >= 256 && w.WL != nullptr && !TMX_HAS_PAIRS(w) && w.D <= 8; }
 
 // ---- factor: spikes of one interior with MFMA (matrix right-hand side, D columns) ------------------------------------
 // register layout of v_mfma_f64_16x16x4_f64:  A[i = l&15][k = l>>4],  B[k = l>>4][j = l&15],  D[(l>>4) + 4r][l&15] in
@@ -145,16 +154,19 @@ TMX_DEVFN void lpart_factor(const QpWs& w, int tid, int NT)
   const int D = w.D, DD = D * D, DS = w.DS, DDS = w.DDS;
   const double* po = TMX_PC(w);
   LPart p;
-  lpart_make(w.T, p);
+  lpart_make(w.T, NT, p);
   const int wave = tid >> 6, lane = tid & 63;
-  // the interiors are inverted in place, block by block; the three separator blocks keep their assembled diagonal block
-  part_invert_interior(w, p.a[wave], p.b[wave], lane);
-  // the spikes read Sinv of their own interior only (written by this wave): wave-level visibility of the LDS stores
-  TMX_WAVE_SYNC();
-  lpart_spikes(w, p.a[wave], p.b[wave], wave > 0, wave < 3, lane);
+  // the interiors are inverted in place, block by block; the separator blocks keep their assembled diagonal block
+  if (wave < p.P)
+  {
+    part_invert_interior(w, p.a[wave], p.b[wave], lane);
+    // the spikes read Sinv of their own interior only (written by this wave): wave-level visibility of the LDS stores
+    TMX_WAVE_SYNC();
+    lpart_spikes(w, p.a[wave], p.b[wave], wave > 0, wave < p.P - 1, lane);
+  }
   TMX_SYNC();
-  // Schur complement on the separators: Z is (3D x 3D), row-major
-  const int n3 = 3 * D;
+  // Schur complement on the separators: Z is ((P-1) D)^2, row-major
+  const int n3 = (p.P - 1) * D;
   double* Z = w.Zp;
   for (int e = tid; e < n3 * n3; e += NT)
   {
@@ -172,34 +184,28 @@ TMX_DEVFN void lpart_factor(const QpWs& w, int tid, int NT)
     Z[e] = val;
   }
   TMX_SYNC();
-  // dense in-place Gauss-Jordan inverse (SPD, n3 <= 24)
-  double* colk = Z + n3 * n3;  // n3 scratch
+  // dense Gauss-Jordan inverse (SPD, n3 <= 56), ping-pong between two buffers: step k reads one and writes the other, so no
+  // per-thread staging array (a run-time indexed private array would live in scratch); the result ends in buffer n3 & 1
+  double* Zb = Z + n3 * n3;
   for (int k = 0; k < n3; ++k)
   {
-    const double piv = 1.0 / Z[k * n3 + k];
-    for (int e = tid; e < n3; e += NT)
-      colk[e] = Z[e * n3 + k];
-    TMX_SYNC();
-    double nv[3] = { 0.0, 0.0, 0.0 };
-    int ne = 0;
-    for (int e = tid; e < n3 * n3; e += NT, ++ne)
+    const double* src = (k & 1) ? Zb : Z;
+    double* dst = (k & 1) ? Z : Zb;
+    const double piv = 1.0 / src[k * n3 + k];
+    for (int e = tid; e < n3 * n3; e += NT)
     {
       const int i = e / n3, j = e % n3;
       double v;
       if (i == k && j == k)
         v = piv;
       else if (i == k)
-        v = Z[e] * piv;
+        v = src[e] * piv;
       else if (j == k)
-        v = -colk[i] * piv;
+        v = -src[i * n3 + k] * piv;
       else
-        v = Z[e] - colk[i] * Z[k * n3 + j] * piv;
-      nv[ne] = v;
+        v = src[e] - src[i * n3 + k] * src[k * n3 + j] * piv;
+      dst[e] = v;
     }
-    TMX_SYNC();
-    ne = 0;
-    for (int e = tid; e < n3 * n3; e += NT, ++ne)
-      Z[e] = nv[ne];
     TMX_SYNC();
   }
 }
@@ -294,12 +300,14 @@ TMX_DEVFN void lpart_solve(const QpWs& w, int tid, int NT)
   const int D = w.D, DD = D * D;
   const double* po = TMX_PC(w);
   LPart p;
-  lpart_make(w.T, p);
+  lpart_make(w.T, NT, p);
   const int wave = tid >> 6, lane = tid & 63;
-  lpart_chain(w, p.a[wave], p.b[wave], lane);
+  if (wave < p.P)
+    lpart_chain(w, p.a[wave], p.b[wave], lane);
   TMX_SYNC();
-  const int n3 = 3 * D;
-  double* rs = w.Zp + n3 * n3 + n3;  // n3: separator right-hand sides
+  const int n3 = (p.P - 1) * D;
+  const double* Zinv = w.Zp + ((n3 & 1) ? n3 * n3 : 0);  // where the ping-pong inversion ended
+  double* rs = w.Zp + 2 * n3 * n3;                        // n3: separator right-hand sides
   if (tid < n3)
   {
     const int k = tid / D, i = tid % D, s = p.s[k];
@@ -308,7 +316,7 @@ TMX_DEVFN void lpart_solve(const QpWs& w, int tid, int NT)
   TMX_SYNC();
   if (tid < n3)
   {
-    const double* Zr = w.Zp + tid * n3;
+    const double* Zr = Zinv + tid * n3;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0;
     int n = 0;
     for (; n + 2 < n3; n += 3)
@@ -329,8 +337,8 @@ TMX_DEVFN void lpart_solve(const QpWs& w, int tid, int NT)
     const int t = v / D, i = v % D;
     int k = 0;
     bool interior = false;
-    for (int q = 0; q < 4; ++q)
-      if (t >= p.a[q] && t <= p.b[q])
+    for (int q = 0; q < 8; ++q)
+      if (q < p.P && t >= p.a[q] && t <= p.b[q])
       {
         k = q;
         interior = true;
@@ -345,7 +353,7 @@ TMX_DEVFN void lpart_solve(const QpWs& w, int tid, int NT)
       for (int j = 0; j < D; ++j)
         s0 += W[j] * xs[j];
     }
-    if (k < 3)
+    if (k < p.P - 1)
     {
       const double* W = w.WR + (size_t)t * DD + i * D;
       const double* xs = w.tp + p.s[k] * D;

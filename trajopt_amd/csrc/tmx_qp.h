@@ -307,7 +307,7 @@ TMX_HOSTDEVFN size_t qp_glb_doubles(int D, int T, int R, int NA, int R2 = 0)
 }
 // long horizons without pair rows: the block chain is cut into 4 interiors + 3 separator blocks (tmx_long.h)
 TMX_HOSTDEVFN bool lpart_fits(int D, int T, int R2) { return D <= 8 && R2 == 0 && T >= 64; }
-TMX_HOSTDEVFN size_t lpart_zp_doubles(int D) { return 9 * (size_t)D * D + 6 * (size_t)D + 2; }
+TMX_HOSTDEVFN size_t lpart_zp_doubles(int D) { return 18 * (size_t)D * D + 6 * (size_t)D + 2; }  // 4 interiors: 2 x (3 D)^2 (ping-pong inversion) + 2 x 3 D
 // arrays that are only touched at burst boundaries / in the polish step: always in the per-problem HBM scratch
 TMX_HOSTDEVFN size_t qp_far_doubles(int D, int T, int R, int NA, int R2 = 0)
 {
