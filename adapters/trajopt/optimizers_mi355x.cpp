@@ -241,9 +241,23 @@ void lowerTerm(const ProblemConstructionInfo& pci, const TermInfo& ti, bool is_c
         if (std::find(fixed.begin(), fixed.end(), i) == fixed.end())
           names.push_back(ti.name + "_" + std::to_string(i));
   }
+  else if (const auto* cv = dynamic_cast<const CartVelTermInfo*>(&ti))
+  {
+    // CartVelTermInfo::hatch (problem_description.cpp:1011-1057): one cost (named after the term) / one constraint "CartVel"
+    // per step i in [first_step, last_step] over waypoints i and i + 1
+    if (static_cast<bool>(ti.term_type & TermType::TT_USE_TIME))
+      PRINT_AND_THROW(ti.name + ": Use time version of this term has not been defined.");
+    if (cv->link != pci.kin->getActiveLinkNames().back())
+      PRINT_AND_THROW(ti.name + ": the link must be the manipulator's tip link (one tool frame per problem)");
+    t.kind = TMX_TERM_CART_VEL;
+    t.first_step = cv->first_step;
+    t.last_step = cv->last_step;
+    t.margin = cv->max_displacement;
+    names.assign(static_cast<std::size_t>(cv->last_step - cv->first_step + 1), is_cost ? ti.name : std::string("CartVel"));
+  }
   else
     PRINT_AND_THROW("term \"" + ti.name + "\" has a TermInfo class the device path does not lower (UserDefinedTermInfo, "
-                    "DynamicCartPose, CartVel, JointAcc, JointJerk, TotalTime, AvoidSingularity): solve it with the reference's "
+                    "DynamicCartPose, JointAcc, JointJerk, TotalTime, AvoidSingularity): solve it with the reference's "
                     "BasicTrustRegionSQP, or with its QPs on the device through HipBatchedAdmmModel");
   auto& dst = is_cost ? out.cost_names : out.cnt_names;
   dst.insert(dst.end(), names.begin(), names.end());

@@ -111,7 +111,13 @@ typedef enum
      rows per (step, joint), -(upper_tol - vel) * coeff and (lower_tol - vel) * coeff with vel = x[i+1][j] - x[i][j] - target_j */
   TMX_TERM_JOINT_VEL_INEQ_COST = 10,
   /* trajopt::JointVelIneqConstraint  trajectory_costs.cpp:426-499 — the same two rows as inequality constraints */
-  TMX_TERM_JOINT_VEL_INEQ_CNT = 11
+  TMX_TERM_JOINT_VEL_INEQ_CNT = 11,
+  /* trajopt::CartVelTermInfo::hatch  trajopt/src/problem_description.cpp:1011-1057: per step i in [first_step, last_step] one
+     TrajOptCostFromErrFunc (sco::ABS, no coefficients) or TrajOptConstraintFromErrFunc (sco::INEQ) over the variables of
+     waypoints i and i + 1 (so last_step <= n_steps - 2) with CartVelErrCalculator / CartVelJacCalculator
+     (trajopt/src/kinematic_terms.cpp:376-426): the six rows  +-(p[i+1] - p[i]) - max_displacement  of the tool-frame origin,
+     analytic translational Jacobians -J(x[i]) / +J(x[i+1]).  `margin` = max_displacement; the link is the chain's tool frame. */
+  TMX_TERM_CART_VEL = 12
 } tmx_term_kind;
 
 typedef struct

@@ -347,9 +347,13 @@ public:
           if (std::find(fixed_steps.begin(), fixed_steps.end(), i) == fixed_steps.end())
             names.push_back(name + "_" + std::to_string(i));
     }
+    else if (t.kind == TMX_TERM_CART_VEL)  // one cost named after the term / one constraint "CartVel" per step (:1029-1050)
+      for (int i = t.first_step; i <= t.last_step; ++i)
+        names.push_back(t.is_constraint ? std::string("CartVel") : name);
     else
       names.push_back(name);
-    const bool ineq = t.kind == TMX_TERM_JOINT_POS_INEQ_CNT || t.kind == TMX_TERM_COLLISION_CNT || t.kind == TMX_TERM_JOINT_VEL_INEQ_CNT;
+    const bool ineq = t.kind == TMX_TERM_JOINT_POS_INEQ_CNT || t.kind == TMX_TERM_COLLISION_CNT || t.kind == TMX_TERM_JOINT_VEL_INEQ_CNT ||
+                      t.kind == TMX_TERM_CART_VEL;
     std::vector<std::string>& dst = !t.is_constraint ? cost_names_ : (ineq ? ineq_cnt_names_ : eq_cnt_names_);
     dst.insert(dst.end(), names.begin(), names.end());
     terms_.push_back(t);
@@ -615,6 +619,42 @@ struct CartPoseTermInfo : public TermInfo
       t.is_constraint = 0;  // ABS cost (:946-960)
     else if (static_cast<bool>(term_type & TermType::TT_CNT))
       t.is_constraint = 1;  // EQ constraint (:961-976)
+    else
+      return;
+    prob.addTerm(t, {}, name);
+  }
+};
+
+/** trajopt::CartVelTermInfo (problem_description.hpp:394-420, problem_description.cpp:989-1057): the tool-frame origin may move at
+    most max_displacement per axis between waypoints i and i + 1, i in [first_step, last_step] */
+struct CartVelTermInfo : public TermInfo
+{
+  int first_step{ 0 };
+  int last_step{ 0 };
+  double max_displacement{ 0.0 };
+  std::string link;
+  CartVelTermInfo() : TermInfo(TermType::TT_COST | TermType::TT_CNT) {}
+  void hatch(TrajOptProb& prob) override
+  {
+    const auto kin = prob.GetKin();
+    const int n_steps = prob.GetNumSteps();
+    if (link != kin->tip_link)
+      printAndThrow("invalid link name: " + link);  // :1003 (only the tip link carries the tool frame here)
+    if (!((first_step >= 0) && (first_step <= n_steps - 1) && (first_step < last_step)) || !((last_step > 0) && (last_step <= n_steps - 1)))
+      printAndThrow("cart_vel: first_step / last_step out of range");  // FAIL_IF_FALSE :997-998
+    if (last_step + 1 > n_steps - 1)
+      printAndThrow("cart_vel: last_step + 1 must be a waypoint of the trajectory (the term couples steps i and i + 1)");
+    if (static_cast<bool>(term_type & TermType::TT_USE_TIME))
+      printAndThrow("Use time version of this term has not been defined.");  // :1015-1022
+    tmx_term t = detail::blankTerm();
+    t.kind = TMX_TERM_CART_VEL;
+    t.first_step = first_step;
+    t.last_step = last_step;
+    t.margin = max_displacement;
+    if (static_cast<bool>(term_type & TermType::TT_COST))
+      t.is_constraint = 0;  // ABS cost (:1023-1036)
+    else if (static_cast<bool>(term_type & TermType::TT_CNT))
+      t.is_constraint = 1;  // INEQ constraint (:1038-1052)
     else
       return;
     prob.addTerm(t, {}, name);

@@ -306,6 +306,22 @@ inline TermInfo::Ptr readTerm(const json::Value& it, bool is_cost, const Problem
     t->term_type = tt;
     return t;
   }
+  if (typ == "cart_vel")
+  {
+    // CartVelTermInfo::fromJson (problem_description.cpp:989-1009): all four fields are required
+    for (const char* f : { "first_step", "last_step", "max_displacement", "link" })
+      if (!p.isMember(f))
+        printAndThrow(std::string("cart_vel: missing required field ") + f);
+    ensureOnlyMembers(p, { "first_step", "last_step", "max_displacement", "link" }, typ);
+    auto t = std::make_shared<CartVelTermInfo>();
+    t->first_step = jsonInt(p, "first_step", 0);
+    t->last_step = jsonInt(p, "last_step", 0);
+    t->max_displacement = jsonDouble(p, "max_displacement", 0.0);
+    t->link = p["link"].asString();
+    t->name = name;
+    t->term_type = tt;
+    return t;
+  }
   if (typ == "collision")
   {
     const int ev = jsonInt(p, "evaluator_type", 1);

@@ -1262,7 +1262,7 @@ inline TrajProblem constructProblem(const tmx_problem_desc& d, const double* ini
       const tmx_term& tm = d.terms[k];
       const bool is_cnt = (tm.kind == TMX_TERM_JOINT_POS_EQ_CNT) || (tm.kind == TMX_TERM_JOINT_POS_INEQ_CNT) || (tm.kind == TMX_TERM_COLLISION_CNT) ||
                           (tm.kind == TMX_TERM_JOINT_VEL_EQ_CNT) || (tm.kind == TMX_TERM_JOINT_VEL_INEQ_CNT) ||
-                          (tm.kind == TMX_TERM_CART_POSE && tm.is_constraint);
+                          ((tm.kind == TMX_TERM_CART_POSE || tm.kind == TMX_TERM_CART_VEL) && tm.is_constraint);
       if ((pass == 0) == is_cnt)
         continue;
       switch (tm.kind)
@@ -1326,6 +1326,51 @@ inline TrajProblem constructProblem(const tmx_problem_desc& d, const double* ini
               P.prob->addConstraint(std::make_shared<ConstraintFromErrFunc>(f, dfdx, P.traj_vars.row(t), c, EQ, "cart_pose"));
             else
               P.prob->addCost(std::make_shared<CostFromErrFunc>(f, dfdx, P.traj_vars.row(t), c, ABS, "cart_pose"));
+          }
+          break;
+        }
+        case TMX_TERM_CART_VEL:
+        {
+          // CartVelTermInfo::hatch  problem_description.cpp:1011-1057; CartVelErrCalculator / CartVelJacCalculator
+          // kinematic_terms.cpp:376-426 (tool-frame origin; tcp = the chain's tool offset)
+          auto chain = P.chain;
+          const double limit = tm.margin;
+          const int Dn = D;
+          VectorOfVector f = [chain, limit, Dn](const DblVec& x) {
+            const Tf p0 = chain->fkTool(x.data()), p1 = chain->fkTool(x.data() + Dn);
+            DblVec out(6);
+            for (int r = 0; r < 3; ++r)
+            {
+              out[r] = (p1.t[r] - p0.t[r]) - limit;
+              out[3 + r] = (p0.t[r] - p1.t[r]) - limit;
+            }
+            return out;
+          };
+          MatrixOfVector dfdx = [chain, Dn](const DblVec& x) {
+            const Tf p0 = chain->fkTool(x.data()), p1 = chain->fkTool(x.data() + Dn);
+            DblVec j0(3 * Dn), j1(3 * Dn);
+            chain->jacobianPoint(x.data(), Dn - 1, p0.t, j0.data());
+            chain->jacobianPoint(x.data() + Dn, Dn - 1, p1.t, j1.data());
+            Mat out(6, 2 * Dn);
+            for (int r = 0; r < 3; ++r)
+              for (int k = 0; k < Dn; ++k)
+              {
+                out(r, k) = -j0[r * Dn + k];
+                out(r, Dn + k) = j1[r * Dn + k];
+                out(3 + r, k) = j0[r * Dn + k];
+                out(3 + r, Dn + k) = -j1[r * Dn + k];
+              }
+            return out;
+          };
+          for (int t = tm.first_step; t <= tm.last_step; ++t)
+          {
+            VarVector vars = P.traj_vars.row(t);
+            const VarVector v1 = P.traj_vars.row(t + 1);
+            vars.insert(vars.end(), v1.begin(), v1.end());
+            if (tm.is_constraint)
+              P.prob->addConstraint(std::make_shared<ConstraintFromErrFunc>(f, dfdx, vars, DblVec(), INEQ, "CartVel"));
+            else
+              P.prob->addCost(std::make_shared<CostFromErrFunc>(f, dfdx, vars, DblVec(), ABS, "cart_vel"));
           }
           break;
         }

@@ -57,6 +57,15 @@ def cfg(cid, T=None):
                 ti.longest_valid_segment_length = 0.12
                 ti.max_substates = 4
         return pci, s, g
+    if cid in (23, 24):
+        # CartVelTermInfo (rows on two waypoints with analytic Jacobians): 23 INEQ constraint, 24 ABS cost; the limit is tighter
+        # than the straight-line tool motion per step, so the rows are active
+        from trajopt_amd.problem import CartVelTermInfo
+        pci, s, g = configs.config_mini(with_joint_band=False) if T is None else configs.config_mini(T, with_joint_band=False)
+        n = pci.basic_info.n_steps
+        ti = CartVelTermInfo(first_step=1, last_step=n - 2, max_displacement=0.07, is_constraint=(cid == 23))
+        (pci.cnt_infos if cid == 23 else pci.cost_infos).append(ti)
+        return pci, s, g
     if cid == 12:  # BasicInfo::fixed_dofs: the wrist joint keeps its seed value at every step
         return configs.config_mini(with_joint_band=False, fixed_dofs=[3])
     if cid == 2:   # puzzle_piece: 300 waypoints, the QP workspace lives in HBM on the device (generic block-chain path)

@@ -250,3 +250,42 @@ def test_reference_fixture_arm_around_table_runs_unchanged(hostemu_lib, orc):
     cv, vv = ctx.evaluate()
     assert cv[0, 1:].sum() == 0.0 and vv.max() < 1e-4, "collision-free and at the goal"
     ctx.close()
+
+
+def test_cart_vel_from_json(hostemu_lib, orc):
+    """cart_vel (CartVelTermInfo, problem_description.cpp:989-1057) as a constraint and as a cost: required fields, unknown
+    members, the tip-link restriction, the per-step names, and the run against the oracle on the host build"""
+    from trajopt_amd import abi, runtime
+    env, pci, start, goal = _env(0)
+    base = json.load(open(os.path.join(HERE, "golden", "json", "planning_unit_cfg0.json")))
+    n = base["basic_info"]["n_steps"]
+    v = copy.deepcopy(base)
+    v["constraints"].append({"type": "cart_vel", "name": "tool_speed",
+                             "params": {"first_step": 0, "last_step": n - 2, "max_displacement": 0.12, "link": "r_gripper_tool_frame"}})
+    v["costs"].append({"type": "cart_vel", "name": "tool_speed_soft",
+                       "params": {"first_step": 1, "last_step": 3, "max_displacement": 0.05, "link": "r_gripper_tool_frame"}})
+    pp = json_io.construct_problem(v, env)
+    d = pp.pci.to_desc()
+    cv = [d.terms[i] for i in range(d.n_terms) if d.terms[i].kind == abi.TERM_CART_VEL]
+    assert len(cv) == 2 and {(t.first_step, t.last_step, t.is_constraint) for t in cv} == {(0, n - 2, 1), (1, 3, 0)}
+    assert pp.pci.cnt_names()[-(n - 1):] == ["CartVel"] * (n - 1) and pp.pci.cost_names()[-3:] == ["tool_speed_soft"] * 3
+    for bad, exc in (({"first_step": 0, "last_step": n - 2, "max_displacement": 0.1}, ValueError),                       # link missing
+                     ({"first_step": 0, "last_step": n - 2, "max_displacement": 0.1, "link": "r_gripper_tool_frame", "coeffs": [1]}, ValueError),
+                     ({"first_step": 0, "last_step": n - 1, "max_displacement": 0.1, "link": "r_gripper_tool_frame"}, ValueError),  # i + 1 off the end
+                     ({"first_step": 0, "last_step": n - 2, "max_displacement": 0.1, "link": "r_elbow_flex_link"}, json_io.UnsupportedTerm)):
+        w = copy.deepcopy(base)
+        w["constraints"].append({"type": "cart_vel", "params": bad})
+        with pytest.raises(exc):
+            json_io.construct_problem(w, env).pci.to_desc()
+    x0 = pp.init_traj[None, :, :]
+    opt = runtime.BatchedTrustRegionSQP(pp.pci, lib_path=hostemu_lib)
+    opt.initialize(x0)
+    opt.optimize()
+    r = opt.results()
+    opt.ctx.close()
+    o = orc.sqp_batch(d, x0)
+    assert r["status"][0] == o["status"][0] and r["n_qp_solves"][0] == o["n_qp_solves"][0]
+    assert np.abs(r["x"] - o["x"]).max() < 1e-5
+    if r["status"][0] == abi.OPT_CONVERGED:
+        p = np.array([pp.pci.robot.fk_tool(q)[:3, 3] for q in r["x"][0]])
+        assert np.abs(np.diff(p, axis=0)).max() <= 0.12 + 1e-3

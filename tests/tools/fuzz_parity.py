@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
 import numpy as np
 from trajopt_amd import abi, runtime
-from trajopt_amd.problem import (BasicInfo, CartPoseTermInfo, CollisionTermInfo, JointPosTermInfo, JointVelTermInfo,
+from trajopt_amd.problem import (BasicInfo, CartPoseTermInfo, CartVelTermInfo, CollisionTermInfo, JointPosTermInfo, JointVelTermInfo,
                                  ProblemConstructionInfo, Robot, _tf12, rot_axis)
 from oracle import pyorc as orc
 import parity_checks as pc
@@ -100,6 +100,15 @@ def random_problem(rng, wide=False, links=False, lvs=False):
             a = int(rng.integers(0, T - 1))
             pci.cnt_infos.append(JointVelTermInfo(coeffs=list(rng.uniform(0.5, 5.0, D)), targets=list((goal - start) / (T - 1)), first_step=a,
                                                   last_step=a, is_constraint=True, name="vel_eq"))
+    if links and T > 3 and rng.random() < 0.4:
+        # CartVelTermInfo: pair rows with analytic Jacobians, as a constraint or as an ABS cost; limit around the straight-line motion
+        w0 = np.linspace(0.0, 1.0, T)[:, None]
+        tool = np.array([rob.fk_tool(q)[:3, 3] for q in (start[None, :] * (1 - w0) + goal[None, :] * w0)])
+        step = float(np.abs(np.diff(tool, axis=0)).max())
+        a = int(rng.integers(0, T - 2))
+        b = int(rng.integers(a + 1, T - 1))
+        ti = CartVelTermInfo(first_step=a, last_step=b, max_displacement=float(rng.uniform(0.7, 1.6)) * step + 1e-3, is_constraint=bool(rng.random() < 0.6))
+        (pci.cnt_infos if ti.is_constraint else pci.cost_infos).append(ti)
     if rng.random() < 0.8:
         pci.cnt_infos.append(JointPosTermInfo(coeffs=[1.0] * D, targets=list(goal), first_step=T - 1, last_step=T - 1))
     w = np.linspace(0.0, 1.0, T)[:, None]

@@ -26,6 +26,7 @@ TERM_COLLISION_CNT = 8
 TERM_JOINT_VEL_EQ_CNT = 9
 TERM_JOINT_VEL_INEQ_COST = 10
 TERM_JOINT_VEL_INEQ_CNT = 11
+TERM_CART_VEL = 12
 
 # OSQP v1.0.0 status values
 OSQP_SOLVED, OSQP_SOLVED_INACCURATE = 1, 2

@@ -346,7 +346,8 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
     for (int k = 0; k < d->n_terms; ++k)
     {
       const tmx_term& tm = d->terms[k];
-      const bool is_ineq = tm.kind == TMX_TERM_JOINT_POS_INEQ_CNT || tm.kind == TMX_TERM_COLLISION_CNT || tm.kind == TMX_TERM_JOINT_VEL_INEQ_CNT;
+      const bool is_ineq = tm.kind == TMX_TERM_JOINT_POS_INEQ_CNT || tm.kind == TMX_TERM_COLLISION_CNT || tm.kind == TMX_TERM_JOINT_VEL_INEQ_CNT ||
+                           (tm.kind == TMX_TERM_CART_VEL && tm.is_constraint);
       const bool is_cnt = is_ineq || (tm.kind == TMX_TERM_JOINT_POS_EQ_CNT) || (tm.kind == TMX_TERM_JOINT_VEL_EQ_CNT) ||
                           (tm.kind == TMX_TERM_CART_POSE && tm.is_constraint);
       int want = !is_cnt ? 0 : (is_ineq ? 2 : 1);
@@ -628,6 +629,36 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
               cp_target.push_back(tm.target_pose[q]);
           }
           break;
+        }
+        case TMX_TERM_CART_VEL:
+        {
+#if !TMX_LINK_ROWS
+          ctx->err = "rows on two consecutive waypoints (CartVel) are not enabled in this build";
+          return TMX_ERR_UNSUPPORTED;
+#else
+          if (tm.last_step + 1 >= T)
+          {
+            ctx->err = "cart_vel: last_step + 1 must be a waypoint of the trajectory (the term couples steps i and i + 1)";
+            return TMX_ERR_INVALID;
+          }
+          if (flavor == TMX_FLAVOR_SQP)
+          {
+            ctx->err = "TMX_FLAVOR_SQP: cart_vel is not part of the trajopt_sqp path";
+            return TMX_ERR_UNSUPPORTED;
+          }
+          // CartVelTermInfo::hatch (problem_description.cpp:1011-1057): one cost / constraint per step i in [first, last] over
+          // waypoints i and i + 1, six rows each
+          for (int t = tm.first_step; t <= tm.last_step; ++t)
+          {
+            const int own = tm.is_constraint ? n_cnts++ : n_costs++;
+            for (int i = 0; i < 6; ++i)
+            {
+              add_slot(SLOT_CARTVEL, t, i, 0, own, tm.is_constraint ? 1 : 2, tm.is_constraint ? 1 : 0, tm.is_constraint ? 0 : 1, 1.0, 1.0, tm.margin, 0.0);
+              c2.back() = R2++;
+            }
+          }
+          break;
+#endif
         }
         case TMX_TERM_COLLISION_COST:
         {

@@ -236,6 +236,39 @@ TMX_DEVFN void transform_error(const Tf3& tinv, const Tf3& src, double err[6], d
   err[5] = ax[2] * ang;
 }
 
+// column k of the translational geometric Jacobian of world point p (rigidly attached to a link behind joint k), joint frame F
+// before motion: z x (p - o) for a revolute joint, z for a prismatic one (same statement as oracle Chain::jacobianPoint)
+TMX_DEVFN void jac_point_col(const DevProblem* P, int k, const Tf3& F, const double p[3], double col[3])
+{
+  double z[3];
+  for (int rr = 0; rr < 3; ++rr)
+    z[rr] = F.R[3 * rr + 0] * P->axis[k][0] + F.R[3 * rr + 1] * P->axis[k][1] + F.R[3 * rr + 2] * P->axis[k][2];
+  if (P->jtype[k] == 0)
+  {
+    const double dd[3] = { p[0] - F.t[0], p[1] - F.t[1], p[2] - F.t[2] };
+    col[0] = z[1] * dd[2] - z[2] * dd[1];
+    col[1] = z[2] * dd[0] - z[0] * dd[2];
+    col[2] = z[0] * dd[1] - z[1] * dd[0];
+  }
+  else
+  {
+    col[0] = z[0];
+    col[1] = z[1];
+    col[2] = z[2];
+  }
+}
+#if TMX_LINK_ROWS
+// CartVelErrCalculator (trajopt/src/kinematic_terms.cpp:411-426), row i of segment (q0, q1):
+//   i < 3: (p1 - p0)[i] - limit      i >= 3: (p0 - p1)[i - 3] - limit      (p = origin of the tool frame)
+TMX_DEVFN double cart_vel_value(const DevProblem* P, const double* q0, const double* q1, int i, double limit, Tf3& s0, Tf3& s1)
+{
+  fk_tool(P, q0, s0);
+  fk_tool(P, q1, s1);
+  const int c = i < 3 ? i : i - 3;
+  return (i < 3) ? (s1.t[c] - s0.t[c]) - limit : (s0.t[c] - s1.t[c]) - limit;
+}
+#endif
+
 // sphere-vs-sphere signed distance for contact slot (link sphere s, obstacle o) at joint values q
 TMX_DEVFN double contact_distance(const DevProblem* P, const double* q, int s, int o, double n[3], double pw[3])
 {
@@ -479,6 +512,15 @@ TMX_DEVFN void evaluate_terms(const DevProblem* P, const double* xv, double* cos
       const double d0 = (xv[(t + 1) * D + j] - xv[t * D + j]) - P->slot_aux1[r];
       const double e = (P->slot_sub2[r] == 0) ? (d0 - P->slot_aux2[r]) * P->slot_scale[r] : ((d0 * -1) + P->slot_aux2[r]) * P->slot_scale[r];
       v = (e > 0) ? e : 0.0;
+    }
+#endif
+#if TMX_LINK_ROWS
+    else if (kind == SLOT_CARTVEL)
+    {
+      // ABS cost without coefficients: |err_i| (modeling_utils.cpp:143-167); INEQ constraint: pospart(err_i)
+      Tf3 s0, s1;
+      const double e = cart_vel_value(P, xv + t * D, xv + (t + 1) * D, P->slot_sub[r], P->slot_aux1[r], s0, s1);
+      v = P->slot_iscnt[r] ? ((e > 0) ? e : 0.0) : fabs(e);
     }
 #endif
     // cart-pose slots are written by the instance loop below (another thread, no barrier in between): never store here
@@ -768,6 +810,52 @@ TMX_DEVFN void convexify_terms(const DevProblem* P, const double* xv, int* activ
     rhs[r] = -constant;
     active[r] = 1;
   }
+#if TMX_LINK_ROWS
+  // ---- CartVel rows (pair rows, analytic Jacobian): CartVelJacCalculator kinematic_terms.cpp:376-401, affFromValGrad
+  for (int r = tid; r < P->R; r += NT)
+  {
+    if (P->slot_kind[r] != SLOT_CARTVEL)
+      continue;
+    const int t = P->slot_t[r], i = P->slot_sub[r], c = i < 3 ? i : i - 3;
+    const double* q0 = xv + t * D;
+    const double* q1 = xv + (t + 1) * D;
+    double* a0 = coef + (size_t)r * D;
+    double* a1 = coef2 + (size_t)P->slot_c2[r] * D;
+    Tf3 s0, s1, L;
+    const double y = cart_vel_value(P, q0, q1, i, P->slot_aux1[r], s0, s1);
+    // component c of the Jacobian columns at both waypoints, staged in the row's own coefficient arrays
+    fk_link_visit(P, [q0](int k) { return q0[k]; }, D - 1, L, [&](int k, const Tf3& F) {
+      double col[3];
+      jac_point_col(P, k, F, s0.t, col);
+      a0[k] = col[c];
+    });
+    fk_link_visit(P, [q1](int k) { return q1[k]; }, D - 1, L, [&](int k, const Tf3& F) {
+      double col[3];
+      jac_point_col(P, k, F, s1.t, col);
+      a1[k] = col[c];
+    });
+    // out.block(0, 0) = -jac0, out.block(0, n) = jac1, out.block(3, 0) = jac0, out.block(3, n) = -jac1
+    double dot = 0.0;
+    for (int k = 0; k < D; ++k)
+    {
+      a0[k] = (i < 3) ? -a0[k] : a0[k];
+      dot += a0[k] * q0[k];
+    }
+    for (int k = 0; k < D; ++k)
+    {
+      a1[k] = (i < 3) ? a1[k] : -a1[k];
+      dot += a1[k] * q1[k];
+    }
+    const double constant = y - dot;
+    for (int k = 0; k < D; ++k)
+    {
+      a0[k] = (fabs(a0[k]) > TMX_CLEANUP_TOL) ? a0[k] : 0.0;
+      a1[k] = (fabs(a1[k]) > TMX_CLEANUP_TOL) ? a1[k] : 0.0;
+    }
+    rhs[r] = -constant;
+    active[r] = 1;
+  }
+#endif
 #if TMX_LINK_ROWS
   // ---- K3': collision rows of the segment evaluators (pair rows: gradient on both waypoints)
   for (int r = tid; r < P->R; r += NT)

@@ -23,7 +23,8 @@ enum
   // more, coef2[slot_c2[r]][.], on waypoint t + 1
   SLOT_JOINTVEL = 5,       // JointVelEqConstraint row  coeff * (x[t+1][j] - x[t][j] - target) == 0 -> abs (2 aux)
   SLOT_JOINTVEL_INEQ = 6,  // JointVelIneqCost / JointVelIneqConstraint row (upper: sub2 = 0, lower: sub2 = 1) -> hinge (1 aux)
-  SLOT_COLLISION_LVS = 7   // contact of a link sphere with an obstacle on the segment (t, t+1): LVS_DISCRETE / LVS_CONTINUOUS -> hinge
+  SLOT_COLLISION_LVS = 7,  // contact of a link sphere with an obstacle on the segment (t, t+1): LVS_DISCRETE / LVS_CONTINUOUS -> hinge
+  SLOT_CARTVEL = 8         // CartVel row i (0..5) of segment (t, t+1): +-(p[t+1] - p[t]) - max_displacement; ABS cost (2 aux) or INEQ constraint -> hinge (1 aux)
 };
 #ifndef TMX_LINK_ROWS
 #define TMX_LINK_ROWS 1  // 1: the QP kernels understand pair rows (generic block-chain path with dense coupling blocks)

@@ -17,7 +17,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import numpy as np
 
 from . import abi
-from .problem import (BasicInfo, CartPoseTermInfo, CollisionTermInfo, JointPosTermInfo, JointVelTermInfo,
+from .problem import (BasicInfo, CartPoseTermInfo, CartVelTermInfo, CollisionTermInfo, JointPosTermInfo, JointVelTermInfo,
                       ProblemConstructionInfo, Robot, _tf12)
 
 
@@ -162,6 +162,17 @@ def construct_problem(text_or_dict, env: Environment) -> ParsedProblem:
             return CartPoseTermInfo(timestep=int(p.get("timestep", n_steps - 1)), target_pose=target,
                                     pos_coeffs=tuple(_vec(p, "pos_coeffs", 3, (1, 1, 1))), rot_coeffs=tuple(_vec(p, "rot_coeffs", 3, (1, 1, 1))),
                                     is_constraint=not is_cost, name=name)
+        if typ == "cart_vel":
+            # CartVelTermInfo::fromJson (problem_description.cpp:989-1009)
+            _only_members(p, ("first_step", "last_step", "max_displacement", "link"), typ)
+            for key in ("first_step", "last_step", "max_displacement", "link"):
+                if key not in p:
+                    raise ValueError(f"cart_vel: missing required field {key}")      # childFromJson without a default
+            link = str(p["link"])
+            if link != env.tip_links.get(manip):
+                raise UnsupportedTerm(f"cart_vel link {link}: only the manipulator tip link {env.tip_links.get(manip)} is lowered")
+            return CartVelTermInfo(first_step=int(p["first_step"]), last_step=int(p["last_step"]), max_displacement=float(p["max_displacement"]),
+                                   is_constraint=not is_cost, name=name)
         if typ == "collision":
             ev = int(p.get("evaluator_type", 1))
             if ev < 1 or ev > 4:

@@ -162,6 +162,18 @@ class CartPoseTermInfo:
 
 
 @dataclass
+class CartVelTermInfo:
+    """trajopt::CartVelTermInfo — problem_description.cpp:989-1057: the tool-frame origin may move at most `max_displacement`
+    per axis between consecutive waypoints i, i + 1 for i in [first_step, last_step] (so last_step <= n_steps - 2); ABS cost
+    (TT_COST) or INEQ constraint (TT_CNT) through CartVelErrCalculator / CartVelJacCalculator (kinematic_terms.cpp:376-426)"""
+    first_step: int
+    last_step: int
+    max_displacement: float
+    is_constraint: bool = True
+    name: str = "cart_vel"
+
+
+@dataclass
 class CollisionTermInfo:
     """trajopt::CollisionTermInfo — problem_description.cpp:1617-1837.  evaluator_type (tesseract CollisionEvaluatorType):
     1 DISCRETE -> one single-time-step term per non-fixed step; 2 LVS_DISCRETE / 3 CONTINUOUS / 4 LVS_CONTINUOUS -> one term
@@ -209,6 +221,8 @@ class ProblemConstructionInfo:
             if ti.evaluator_type >= 2:             # one term per segment (:1723, :1781)
                 return [f"{ti.name}_{i}" for i in range(ti.first_step, last)]
             return [f"{ti.name}_{i}" for i in range(ti.first_step, last + 1) if i not in list(ti.fixed_steps)]
+        if isinstance(ti, CartVelTermInfo):       # one cost named after the term / one constraint "CartVel" per step (:1029-1050)
+            return ["CartVel" if ti.is_constraint else ti.name] * (ti.last_step - ti.first_step + 1)
         return [ti.name]
 
     def cost_names(self) -> List[str]:
@@ -217,7 +231,7 @@ class ProblemConstructionInfo:
     def cnt_names(self) -> List[str]:
         """equalities in front of the inequalities, as sco::OptProb orders them (modeling.cpp:234-241)"""
         def is_ineq(ti):
-            if isinstance(ti, CollisionTermInfo):
+            if isinstance(ti, (CollisionTermInfo, CartVelTermInfo)):
                 return True
             if isinstance(ti, (JointPosTermInfo, JointVelTermInfo)):
                 return any(abs(x) >= 1e-5 for x in list(ti.upper_tols) + list(ti.lower_tols))
@@ -307,6 +321,16 @@ class ProblemConstructionInfo:
                 t.is_constraint = 1 if ti.is_constraint else 0
                 t.coeffs[:6] = list(ti.pos_coeffs) + list(ti.rot_coeffs)
                 t.target_pose[:] = list(np.asarray(ti.target_pose).reshape(-1))
+            elif isinstance(ti, CartVelTermInfo):
+                # FAIL_IF_FALSE checks of CartVelTermInfo::fromJson (:997-998)
+                if not (0 <= ti.first_step <= T - 1 and ti.first_step < ti.last_step and 0 < ti.last_step <= T - 1):
+                    raise ValueError("cart_vel: first_step / last_step out of range")
+                if ti.last_step + 1 > T - 1:
+                    raise ValueError("cart_vel: last_step + 1 must be a waypoint of the trajectory (the term couples steps i and i + 1)")
+                t.kind = abi.TERM_CART_VEL
+                t.first_step, t.last_step = ti.first_step, ti.last_step
+                t.is_constraint = 1 if ti.is_constraint else 0
+                t.margin = ti.max_displacement
             elif isinstance(ti, CollisionTermInfo):
                 t.kind = abi.TERM_COLLISION_CNT if ti.is_constraint else abi.TERM_COLLISION_COST
                 t.is_constraint = 1 if ti.is_constraint else 0
