@@ -38,8 +38,8 @@ def algorithmic_flops_per_admm_iter(T, D, n, m, nnzA):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=0, help="seeds per GPU (default: the configuration's BASELINE batch per GPU)")
     ap.add_argument("--depth", type=int, default=2, help="batches in flight (1 = strictly sequential steps, 2 = double-buffered contexts)")
     ap.add_argument("--config", type=int, default=1, choices=[1, 2, 3, 4], help="BASELINE.json configuration (default 1 = the metric's)")
@@ -133,7 +133,8 @@ def main():
                 # launch then lasts from about its first to its last workgroup, as an isolated launch does, instead of
                 # sitting in the queue behind this batch's bulk with its start event already recorded
                 cur = ctxs[k % depth]
-                while not cur.tail_started():
+                t_poll = time.perf_counter()
+                while not cur.tail_started() and time.perf_counter() - t_poll < 120.0:
                     time.sleep(0.0002)
             issue(k + depth - 1)
         r, best, c = finish(k)

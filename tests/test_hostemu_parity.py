@@ -239,3 +239,24 @@ def test_pool_after_bounded_steps_does_not_resolve_finished_problems(emu):
     assert np.array_equal(r["x"], ref["x"]) and np.array_equal(r["n_qp_solves"], ref["n_qp_solves"])
     assert np.array_equal(cnt, ref_cnt) and np.array_equal(cnt, r["n_qp_solves"])
     assert emu.counters()["admm_iters"] == ref_admm
+
+
+def test_launch_wait_and_tail_word(emu, orc):
+    """tmx_sqp_launch / tmx_sqp_wait are the two halves of tmx_sqp_run(0); tmx_sqp_tail_started must turn 1 without a wait()
+    (the bench polls it before enqueuing the next batch) and launching twice without a wait is a state error"""
+    pci, s, g = pc.cfg(0)
+    x0 = configs.seeds_for(0, pci, s, g, 3)
+    desc = pc.make_ctx_inputs(emu, pci, x0)
+    emu.run(0)
+    ref = emu.results()
+    emu.set_x0(x0)
+    assert emu.tail_started()          # nothing pending
+    emu.launch()
+    assert emu.tail_started()          # the host build runs the kernel inside launch(): every workgroup has retired
+    with pytest.raises(RuntimeError):
+        emu.launch()
+    assert emu.wait() == 0
+    r = emu.results()
+    assert np.array_equal(r["x"], ref["x"]) and np.array_equal(r["n_qp_solves"], ref["n_qp_solves"])
+    with pytest.raises(RuntimeError):
+        emu.wait()

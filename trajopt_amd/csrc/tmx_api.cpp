@@ -1145,7 +1145,9 @@ tmx_status tmx_sqp_launch(tmx_ctx* ctx)
   const int B = ctx->hb.B;
   if (ctx->mode == 0)
     return TMX_ERR_UNSUPPORTED;  // the piecewise mode runs the loop on the host
-  *ctx->h_tail = 0;
+  // only the pool kernel reports the start of its tail; the one-workgroup-per-problem kernels free CUs from their first
+  // finished problem on, so for them the next batch may be enqueued at once
+  *ctx->h_tail = (!ctx->ws_in_hbm && ctx->mode == 2) ? 0 : 1;
   if (ctx->timing)
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
   if (ctx->ws_in_hbm)
