@@ -101,7 +101,7 @@ TMX_DEVFN void dpart_map(const QpWs& w, const DPart& p, int tid, DMap& m)
   m.qq = tid & 3;
   {
     const int qb = tmx_fdiv(m.qg < 0 ? 0 : m.qg, rD);
-    m.qv = (m.qg >= 0) ? p.s[qb] * D + (m.qg - qb * D) : D;
+    m.qv = (m.qg >= 0) ? dpart_sep(w.T, p.P, qb) * D + (m.qg - qb * D) : D;
   }
   if (tid >= NI)
   {
@@ -110,13 +110,14 @@ TMX_DEVFN void dpart_map(const QpWs& w, const DPart& p, int tid, DMap& m)
     {
       m.sep = true;
       m.k = tmx_fdiv(g, rD);
-      m.v = p.s[m.k] * D + (g - m.k * D);
+      m.v = dpart_sep(w.T, p.P, m.k) * D + (g - m.k * D);
       m.slot = p.P * w.Gs + g;
     }
     return;
   }
   int q = tid;
-  for (int k = 0; k < 8; ++k)
+#pragma unroll
+  for (int k = 0; k < 8; ++k)  // unrolled: p.len[k] / p.a[k] with constant subscripts
     if (k < p.P)
     {
       const int n = p.len[k] * D;
@@ -262,11 +263,11 @@ TMX_DEVFN void dpart_factor(const QpWs& w, int tid, int NT, long long* pc, long 
   // 1. interior diagonal sub-matrices (block tridiagonal with diagonal coupling blocks), zero padded
   for (int e = tid; e < p.P * Gn * Gs; e += NT)
   {
-    const int k = e / (Gn * Gs), rem = e % (Gn * Gs), r = rem / Gs, c = rem % Gs, n = p.len[k] * D;
+    const int k = e / (Gn * Gs), rem = e % (Gn * Gs), r = rem / Gs, c = rem % Gs, n = dpart_len(w.T, p.P, k) * D;
     double val = 0.0;
     if (r < n && c < n)
     {
-      const int tb = r / D, i = r % D, tc = c / D, j = c % D, t = p.a[k] + tb;
+      const int tb = r / D, i = r % D, tc = c / D, j = c % D, t = dpart_first(w.T, p.P, k) + tb;
       if (tb == tc)
         val = w.Sinv[t * DDS + i * DS + j];
       else if (tc == tb + 1 && i == j)
@@ -280,8 +281,8 @@ TMX_DEVFN void dpart_factor(const QpWs& w, int tid, int NT, long long* pc, long 
   // 2. explicit inverses of all interiors at once: one thread per matrix row (scratch: the Zs region, not yet built)
   {
     const int m = tid / Gn, i = tid % Gn;
-    const bool active = m < p.P && i < p.len[m < 8 ? m : 0] * D;
-    const int n = active ? p.len[m] * D : 0;
+    const bool active = m < p.P && i < dpart_len(w.T, p.P, m) * D;
+    const int n = active ? dpart_len(w.T, p.P, m) * D : 0;
     if (Gs <= 16)
       gj_rows<16, false>(w.G, Gn * Gs, Gs, p.P, Gn, active, active ? m : 0, i, 0, Gs, n, w.Zs);
     else if (Gs <= 24)
@@ -297,18 +298,18 @@ TMX_DEVFN void dpart_factor(const QpWs& w, int tid, int NT, long long* pc, long 
     double val = 0.0;
     if (cI < ns)
     {
-      const int kr = rI / D, i = rI % D, kc = cI / D, j = cI % D, sb = p.s[kr];
+      const int kr = rI / D, i = rI % D, kc = cI / D, j = cI % D, sb = dpart_sep(w.T, p.P, kr);
       const double* GL = w.G + kr * Gn * Gs;        // interior left of separator kr
       const double* GR = w.G + (kr + 1) * Gn * Gs;  // interior right of it
-      const int nL = p.len[kr] * D, nR = p.len[kr + 1] * D;
+      const int nL = dpart_len(w.T, p.P, kr) * D, nR = dpart_len(w.T, p.P, kr + 1) * D;
       const double cl_i = w.po[(sb - 1) * D + i], cr_i = w.po[sb * D + i];
       if (kr == kc)
         val = w.Sinv[sb * DDS + i * DS + j] - cl_i * GL[(nL - D + i) * Gs + (nL - D + j)] * w.po[(sb - 1) * D + j] -
               cr_i * GR[i * Gs + j] * w.po[sb * D + j];
       else if (kc == kr + 1)
-        val = -cr_i * GR[i * Gs + (nR - D + j)] * w.po[(p.s[kc] - 1) * D + j];
+        val = -cr_i * GR[i * Gs + (nR - D + j)] * w.po[(dpart_sep(w.T, p.P, kc) - 1) * D + j];
       else if (kc + 1 == kr)
-        val = -cl_i * GL[(nL - D + i) * Gs + j] * w.po[p.s[kc] * D + j];
+        val = -cl_i * GL[(nL - D + i) * Gs + j] * w.po[dpart_sep(w.T, p.P, kc) * D + j];
     }
     w.Zs[e] = val;
   }
@@ -569,14 +570,17 @@ TMX_DEVFN void kkt_invert_chain_wave0(const QpWs& w, int tid)
 // =========================================================================================================
 // Register-resident ADMM iterations
 // =========================================================================================================
-struct RowRegs
+// NA = aux slots compiled in (1: rows with at most one aux var - hinge rows; 2: abs rows).  With one slot the formulas below
+// are the two-slot ones minus terms that are exactly zero for a missing aux var (x + 0, fma(0, ., c) = c): same bits.
+template <int NA>
+struct RowRegsT
 {
   bool act;
   int t, na;
   double rr, rri, z, y, lo, hi, fac;
   double c[8];
-  // aux vars (k = 0, 1)
-  double xa[2], za[2], ya[2], qa[2], sa[2], bb[2], di[2], ub[2];
+  // aux vars (k = 0 .. NA-1)
+  double xa[NA], za[NA], ya[NA], qa[NA], sa[NA], bb[NA], di[NA], ub[NA];
 };
 
 // 1 / rho_of_type: rho takes three values per QP, so the reciprocal is a select over three quotients instead of a
@@ -586,7 +590,8 @@ TMX_DEVFN double rcp_rho_of_type(int typ, double rho)
   const double i0 = 1.0 / rho, i1 = 1.0 / (TMX_RHO_EQ_OVER_INEQ * rho), i2 = 1.0 / TMX_RHO_MIN;
   return typ == 1 ? i1 : (typ == 0 ? i0 : i2);
 }
-TMX_DEVFN void row_load(const QpWs& w, int r, RowRegs& g)
+template <int NA>
+TMX_DEVFN void row_load(const QpWs& w, int r, RowRegsT<NA>& g)
 {
   g.act = (r >= 0) && (r < w.R) && w.act[r];
   g.t = 0;
@@ -598,7 +603,7 @@ TMX_DEVFN void row_load(const QpWs& w, int r, RowRegs& g)
   for (int j = 0; j < 8; ++j)
     g.c[j] = 0.0;
 #pragma unroll
-  for (int k = 0; k < 2; ++k)
+  for (int k = 0; k < NA; ++k)
   {
     g.xa[k] = g.za[k] = g.ya[k] = g.qa[k] = g.sa[k] = g.bb[k] = g.di[k] = 0.0;
     g.ub[k] = 0.0;
@@ -618,7 +623,7 @@ TMX_DEVFN void row_load(const QpWs& w, int r, RowRegs& g)
   for (int j = 0; j < 8; ++j)
     g.c[j] = (j < w.D) ? w.coef[r * w.D + j] : 0.0;
 #pragma unroll
-  for (int k = 0; k < 2; ++k)
+  for (int k = 0; k < NA; ++k)
     if (k < g.na)
     {
       const int a = w.aoff[r] + k;
@@ -633,14 +638,15 @@ TMX_DEVFN void row_load(const QpWs& w, int r, RowRegs& g)
     }
 }
 
-TMX_DEVFN void row_store(const QpWs& w, int r, const RowRegs& g)
+template <int NA>
+TMX_DEVFN void row_store(const QpWs& w, int r, const RowRegsT<NA>& g)
 {
   if (!g.act)
     return;
   w.zr[r] = g.z;
   w.yr[r] = g.y;
 #pragma unroll
-  for (int k = 0; k < 2; ++k)
+  for (int k = 0; k < NA; ++k)
     if (k < g.na)
     {
       const int a = w.aoff[r] + k;
@@ -655,28 +661,47 @@ TMX_DEVFN void row_store(const QpWs& w, int r, const RowRegs& g)
 // rho of the aux bound rows is one value for the whole QP: an aux var has bounds [0, OSQP_INFTY * E] with
 // E >= MIN_SCALING, so constr_type() is 0 for every one of them and rho_of_type(typ_ba) == rho.  Kept out of the per-row
 // registers (8 VGPRs per row; the loop reloaded 6 spilled doubles from scratch per iteration with them, 2 without)
-TMX_DEVFN double row_phase_a(const RowRegs& g, double sigma, double rho_b, double ta[2])
+template <int NA>
+TMX_DEVFN double row_phase_a(const RowRegsT<NA>& g, double sigma, double rho_b, double (&ta)[NA])
 {
   const double gg = __builtin_fma(g.rr, g.z, -g.y);
-  // both aux rhs are independent chains of depth 3
-  const double gb0 = __builtin_fma(rho_b, g.za[0], -g.ya[0]), gb1 = __builtin_fma(rho_b, g.za[1], -g.ya[1]);
-  const double b0 = __builtin_fma(sigma, g.xa[0], -g.qa[0]), b1 = __builtin_fma(sigma, g.xa[1], -g.qa[1]);
+  // the aux rhs are independent chains of depth 3
+  const double gb0 = __builtin_fma(rho_b, g.za[0], -g.ya[0]);
+  const double b0 = __builtin_fma(sigma, g.xa[0], -g.qa[0]);
   ta[0] = __builtin_fma(g.bb[0], gb0, __builtin_fma(g.sa[0], gg, b0));
-  ta[1] = __builtin_fma(g.bb[1], gb1, __builtin_fma(g.sa[1], gg, b1));
-  const double gs = __builtin_fma(g.sa[1] * g.di[1], ta[1], (g.sa[0] * g.di[0]) * ta[0]);  // (sa*di) are loop invariants
+  double gs = (g.sa[0] * g.di[0]) * ta[0];  // (sa*di) are loop invariants
+  if constexpr (NA > 1)
+  {
+    const double gb1 = __builtin_fma(rho_b, g.za[1], -g.ya[1]);
+    const double b1 = __builtin_fma(sigma, g.xa[1], -g.qa[1]);
+    ta[1] = __builtin_fma(g.bb[1], gb1, __builtin_fma(g.sa[1], gg, b1));
+    gs = __builtin_fma(g.sa[1] * g.di[1], ta[1], gs);
+  }
   return g.act ? __builtin_fma(-g.fac, gs, gg) : 0.0;
 }
 
 // phase C for one row: aux recovery, ztilde, updates.  dot = coef . xtilde(block)
-TMX_DEVFN void row_phase_c(RowRegs& g, double alpha, double rho_b, double rhoi_b, double dot, const double ta[2], bool keep, double* dyr,
-                           double dxa[2], double dya[2])
+template <int NA>
+TMX_DEVFN void row_phase_c(RowRegsT<NA>& g, double alpha, double rho_b, double rhoi_b, double dot, const double (&ta)[NA], bool keep, double* dyr,
+                           double (&dxa)[NA], double (&dya)[NA])
 {
   const double om = 1.0 - alpha;
-  const double v0 = __builtin_fma(-(g.rr * g.sa[0]), dot, ta[0]), v1 = __builtin_fma(-(g.rr * g.sa[1]), dot, ta[1]);
-  const double gs = __builtin_fma(g.sa[1] * g.di[1], v1, (g.sa[0] * g.di[0]) * v0);
+  double v[NA], xt[NA];
+  v[0] = __builtin_fma(-(g.rr * g.sa[0]), dot, ta[0]);
+  double gs = (g.sa[0] * g.di[0]) * v[0];
+  if constexpr (NA > 1)
+  {
+    v[1] = __builtin_fma(-(g.rr * g.sa[1]), dot, ta[1]);
+    gs = __builtin_fma(g.sa[1] * g.di[1], v[1], gs);
+  }
   const double f = g.fac * gs;
-  const double xt0 = __builtin_fma(-g.sa[0], f, v0) * g.di[0], xt1 = __builtin_fma(-g.sa[1], f, v1) * g.di[1];
-  const double ax = __builtin_fma(g.sa[1], xt1, __builtin_fma(g.sa[0], xt0, dot));
+  xt[0] = __builtin_fma(-g.sa[0], f, v[0]) * g.di[0];
+  double ax = __builtin_fma(g.sa[0], xt[0], dot);
+  if constexpr (NA > 1)
+  {
+    xt[1] = __builtin_fma(-g.sa[1], f, v[1]) * g.di[1];
+    ax = __builtin_fma(g.sa[1], xt[1], ax);
+  }
   {
     const double zr = __builtin_fma(alpha, ax, om * g.z);
     const double zn = clampd(__builtin_fma(g.rri, g.y, zr), g.lo, g.hi);
@@ -687,11 +712,10 @@ TMX_DEVFN void row_phase_c(RowRegs& g, double alpha, double rho_b, double rhoi_b
       *dyr = dy;
   }
 #pragma unroll
-  for (int k = 0; k < 2; ++k)
+  for (int k = 0; k < NA; ++k)
   {
-    const double xt = k ? xt1 : xt0;
-    const double xn = __builtin_fma(alpha, xt, om * g.xa[k]);
-    const double zr = __builtin_fma(alpha * g.bb[k], xt, om * g.za[k]);
+    const double xn = __builtin_fma(alpha, xt[k], om * g.xa[k]);
+    const double zr = __builtin_fma(alpha * g.bb[k], xt[k], om * g.za[k]);
     const double zn = clampd(__builtin_fma(rhoi_b, g.ya[k], zr), 0.0, g.ub[k]);
     const double dy = rho_b * (zr - zn);
     if (keep)
@@ -726,9 +750,14 @@ struct TmxTag
 // INTW: the wave has interior variables (else no G-row registers and no phase 1 / 3 code)
 // The instantiations differ per WAVE, not per thread: every wave executes the same five barriers per iteration, and the
 // register allocation of the kernel is the maximum over the instantiations instead of the union of all roles.
-template <bool RC, int NR, bool INTW>
+// NAX : aux slots per row compiled in (1 when no row of the wave has two aux vars - the hinge rows; else 2)
+template <bool RC, int NR, bool INTW, int NAX = 2>
 TMX_DEVFN void admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, bool keep_last, int tid, long long* pc, long long& tlast)
 {
+  // The instantiations sit in the arms of one wave-uniform dispatch and begin with the same prologue; left alone, the optimiser
+  // hoists that common code above the dispatch, and the ~50 values it defines then have to survive the branching - they were
+  // spilled to scratch at every burst entry of even the smallest instantiation.  A distinct volatile marker per arm stops it.
+  asm volatile("; admm_burst_core<%0, %1, %2, %3>" ::"n"((int)RC), "n"(NR), "n"((int)INTW), "n"(NAX));
   const int D = __builtin_amdgcn_readfirstlane(w.D);
 #define TMX_LDS_PTR(p) ((tmx_lds_d*)(size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(p)))
   HotLds h;
@@ -755,7 +784,7 @@ TMX_DEVFN void admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, b
     const int first = TMX_QP_NT - extra;    // first thread that takes one
     rowi[q] = (extra > 0 && tid >= first) ? q * TMX_QP_NT + (tid - first) : -1;
   }
-  RowRegs g[NR];
+  RowRegsT<NAX> g[NR];
 #pragma unroll
   for (int q = 0; q < NR; ++q)
     row_load(w, rowi[q], g[q]);
@@ -887,7 +916,7 @@ TMX_DEVFN void admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, b
   // (With a run-time flag the publishing code sits inside the loop and its temporaries cost the loop registers.)
   auto iteration = [&](auto keep_tag) __attribute__((always_inline)) {
     constexpr bool keep = decltype(keep_tag)::value;
-    double ta[NR][2];
+    double ta[NR][NAX];
 #pragma unroll
     for (int q = 0; q < NR; ++q)
     {
@@ -977,7 +1006,7 @@ TMX_DEVFN void admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, b
 #pragma unroll
     for (int q = 0; q < NR; ++q)
     {
-      RowRegs& gq = g[q];
+      RowRegsT<NAX>& gq = g[q];
       // x~ of the row's waypoint: 8 slots per waypoint (slot 7 of a 7-dof block is never written: multiplied by c[7] = 0,
       // kept finite by the zero fill at burst entry)
       double xt[8];
@@ -993,7 +1022,7 @@ TMX_DEVFN void admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, b
       }
       const double d0 = (__builtin_fma(gq.c[4], xt[4], gq.c[0] * xt[0]) + __builtin_fma(gq.c[5], xt[5], gq.c[1] * xt[1])) +
                         (__builtin_fma(gq.c[6], xt[6], gq.c[2] * xt[2]) + __builtin_fma(gq.c[7], xt[7], gq.c[3] * xt[3]));
-      double dyr0 = 0, dxa0[2], dya0[2];
+      double dyr0 = 0, dxa0[NAX], dya0[NAX];
       if (gq.act)
         row_phase_c(gq, alpha, rho_b, rhoi_b, d0, ta[q], keep, &dyr0, dxa0, dya0);
       if (keep && gq.act)
@@ -1078,14 +1107,24 @@ TMX_DEVFN void admm_run_fast(const QpWs& w, const DevProblem* P, int n_iter, boo
   DPart dp;
   dpart_make(w.T, dp);
   const bool intw = wave0 < w.NX - (dp.P - 1) * w.D;
+  // does any row of this wave carry two aux vars (abs rows)?  Hinge-only waves run the one-slot instantiation
+  bool my2 = false;
+  {
+    const int r0 = tid;
+    if (r0 < w.R && w.act[r0] && w.naux[r0] > 1)
+      my2 = true;
+  }
+  const bool aux2 = two || __builtin_amdgcn_ballot_w64(my2) != 0ULL;
 #ifdef TMX_BURST_NOINLINE
   QpWs* wsh = reinterpret_cast<QpWs*>(w.wself);
   if (tid == 0)
     *wsh = w;
   TMX_SYNC();
 #define TMX_BURST_CALL(RCv, NRv, INTv) admm_burst_nl<RCv, NRv, INTv>(wsh, P, n_iter, keep_last ? 1 : 0, pc, &tlast)
+#define TMX_BURST_CALL1(RCv, NRv, INTv) TMX_BURST_CALL(RCv, NRv, INTv)
 #else
-#define TMX_BURST_CALL(RCv, NRv, INTv) admm_burst_core<RCv, NRv, INTv>(w, P, n_iter, keep_last, tid, pc, tlast)
+#define TMX_BURST_CALL(RCv, NRv, INTv) admm_burst_core<RCv, NRv, INTv, 2>(w, P, n_iter, keep_last, tid, pc, tlast)
+#define TMX_BURST_CALL1(RCv, NRv, INTv) admm_burst_core<RCv, NRv, INTv, 1>(w, P, n_iter, keep_last, tid, pc, tlast)
 #endif
   if (!rc)
     TMX_BURST_CALL(false, TMX_NROW, true);
@@ -1096,12 +1135,20 @@ TMX_DEVFN void admm_run_fast(const QpWs& w, const DevProblem* P, int n_iter, boo
     else
       TMX_BURST_CALL(true, TMX_NROW, false);
   }
-  else
+  else if (aux2)
   {
     if (intw)
       TMX_BURST_CALL(true, 1, true);
     else
       TMX_BURST_CALL(true, 1, false);
   }
+  else
+  {
+    if (intw)
+      TMX_BURST_CALL1(true, 1, true);
+    else
+      TMX_BURST_CALL1(true, 1, false);
+  }
 #undef TMX_BURST_CALL
+#undef TMX_BURST_CALL1
 }

@@ -240,6 +240,23 @@ struct DPart
   int P, ns, Lmax;
   int a[8], len[8], s[8];
 };
+// separator block index s[k] in closed form: a run-time subscript into DPart::s would put the whole struct in scratch memory
+// (27 dwords stored at every burst entry, read back through a scratch pointer)
+TMX_HOSTDEVFN int dpart_sep(int T, int P, int k)
+{
+  const int L = T - (P - 1), base = L / P, rem = L % P;
+  return k * (base + 1) + (k < rem ? k : rem) + base + (k < rem ? 1 : 0);
+}
+TMX_HOSTDEVFN int dpart_len(int T, int P, int k)
+{
+  const int L = T - (P - 1), base = L / P, rem = L % P;
+  return base + (k < rem ? 1 : 0);
+}
+TMX_HOSTDEVFN int dpart_first(int T, int P, int k)
+{
+  const int L = T - (P - 1), base = L / P, rem = L % P;
+  return k * (base + 1) + (k < rem ? k : rem);
+}
 TMX_HOSTDEVFN void dpart_make(int T, DPart& p)
 {
   int P = (T + 2) / 4;
