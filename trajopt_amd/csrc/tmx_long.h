@@ -18,35 +18,30 @@
 
 typedef double tmx_v4d __attribute__((ext_vector_type(4)));
 
+// interiors = waves of the workgroup (at most 4): interior k covers blocks [lpart_a, lpart_b], separator k is block lpart_s.
+// Closed forms instead of a table: a run-time subscript (p.a[wave]) would put the table in scratch memory.
+// (measured on config 2 with 512 threads: 8 interiors 1.69 s per batch, 4 interiors 1.62 s - the 49 x 49 separator system
+//  costs more than the shorter chains save)
 struct LPart
 {
-  int P;  // interiors = waves of the workgroup, at most 8
-  int a[8], b[8], s[8];
+  int P, T;
 };
 TMX_DEVFN void lpart_make(int T, int NT, LPart& p)
 {
-  // measured on config 2 with 512 threads: 8 interiors 1.69 s per batch, 4 interiors 1.62 s - the 49 x 49 separator system
-  // (in the HBM scratch) costs more than the shorter chains save
-  const int P = (NT >> 6) < 4 ? (NT >> 6) : 4;
-  p.P = P;
-  const int L = T - (P - 1), base = L / P, rem = L % P;
-  int t = 0;
-  for (int k = 0; k < 8; ++k)
-  {
-    p.a[k] = p.b[k] = p.s[k] = 0;
-    if (k >= P)
-      continue;
-    const int len = base + (k < rem ? 1 : 0);
-    p.a[k] = t;
-    p.b[k] = t + len - 1;
-    t += len;
-    if (k < P - 1)
-    {
-      p.s[k] = t;
-      t += 1;
-    }
-  }
+  p.P = (NT >> 6) < 4 ? (NT >> 6) : 4;
+  p.T = T;
 }
+TMX_DEVFN int lpart_a(const LPart& p, int k)
+{
+  const int L = p.T - (p.P - 1), base = L / p.P, rem = L % p.P;
+  return k * (base + 1) + (k < rem ? k : rem);
+}
+TMX_DEVFN int lpart_b(const LPart& p, int k)
+{
+  const int L = p.T - (p.P - 1), base = L / p.P, rem = L % p.P;
+  return lpart_a(p, k) + base + (k < rem ? 1 : 0) - 1;
+}
+TMX_DEVFN int lpart_s(const LPart& p, int k) { return lpart_b(p, k) + 1; }
 TMX_DEVFN bool lpart_active(const QpWs& w, int NT) { return NT >= 256 && w.WL != nullptr && !TMX_HAS_PAIRS(w) && w.D <= 8; }
 
 // ---- factor: spikes of one interior with MFMA (matrix right-hand side, D columns) ------------------------------------
@@ -159,10 +154,10 @@ TMX_DEVFN void lpart_factor(const QpWs& w, int tid, int NT)
   // the interiors are inverted in place, block by block; the separator blocks keep their assembled diagonal block
   if (wave < p.P)
   {
-    part_invert_interior(w, p.a[wave], p.b[wave], lane);
+    part_invert_interior(w, lpart_a(p, wave), lpart_b(p, wave), lane);
     // the spikes read Sinv of their own interior only (written by this wave): wave-level visibility of the LDS stores
     TMX_WAVE_SYNC();
-    lpart_spikes(w, p.a[wave], p.b[wave], wave > 0, wave < p.P - 1, lane);
+    lpart_spikes(w, lpart_a(p, wave), lpart_b(p, wave), wave > 0, wave < p.P - 1, lane);
   }
   TMX_SYNC();
   // Schur complement on the separators: Z is ((P-1) D)^2, row-major
@@ -172,7 +167,7 @@ TMX_DEVFN void lpart_factor(const QpWs& w, int tid, int NT)
   {
     const int rI = e / n3, cI = e % n3;
     const int kr = rI / D, i = rI % D, kc = cI / D, j = cI % D;
-    const int s = p.s[kr];
+    const int s = lpart_s(p, kr);
     double val = 0.0;
     if (kr == kc)
       val = w.Sinv[s * DDS + i * DS + j] - po[(s - 1) * D + i] * w.WR[(size_t)(s - 1) * DD + i * D + j] -
@@ -303,14 +298,14 @@ TMX_DEVFN void lpart_solve(const QpWs& w, int tid, int NT)
   lpart_make(w.T, NT, p);
   const int wave = tid >> 6, lane = tid & 63;
   if (wave < p.P)
-    lpart_chain(w, p.a[wave], p.b[wave], lane);
+    lpart_chain(w, lpart_a(p, wave), lpart_b(p, wave), lane);
   TMX_SYNC();
   const int n3 = (p.P - 1) * D;
   const double* Zinv = w.Zp + ((n3 & 1) ? n3 * n3 : 0);  // where the ping-pong inversion ended
   double* rs = w.Zp + 2 * n3 * n3;                        // n3: separator right-hand sides
   if (tid < n3)
   {
-    const int k = tid / D, i = tid % D, s = p.s[k];
+    const int k = tid / D, i = tid % D, s = lpart_s(p, k);
     rs[tid] = w.tp[s * D + i] - po[(s - 1) * D + i] * w.tp[(s - 1) * D + i] - po[s * D + i] * w.tp[(s + 1) * D + i];
   }
   TMX_SYNC();
@@ -328,7 +323,7 @@ TMX_DEVFN void lpart_solve(const QpWs& w, int tid, int NT)
     for (; n < n3; ++n)
       s0 += Zr[n] * rs[n];
     const int k = tid / D, i = tid % D;
-    w.tp[p.s[k] * D + i] = (s0 + s1) + s2;
+    w.tp[lpart_s(p, k) * D + i] = (s0 + s1) + s2;
   }
   TMX_SYNC();
   // spike correction of the interior blocks:  x_t -= WL[t] x_{s_left} + WR[t] x_{s_right}
@@ -337,8 +332,9 @@ TMX_DEVFN void lpart_solve(const QpWs& w, int tid, int NT)
     const int t = v / D, i = v % D;
     int k = 0;
     bool interior = false;
-    for (int q = 0; q < 8; ++q)
-      if (q < p.P && t >= p.a[q] && t <= p.b[q])
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (q < p.P && t >= lpart_a(p, q) && t <= lpart_b(p, q))
       {
         k = q;
         interior = true;
@@ -349,14 +345,14 @@ TMX_DEVFN void lpart_solve(const QpWs& w, int tid, int NT)
     if (k > 0)
     {
       const double* W = w.WL + (size_t)t * DD + i * D;
-      const double* xs = w.tp + p.s[k - 1] * D;
+      const double* xs = w.tp + lpart_s(p, k - 1) * D;
       for (int j = 0; j < D; ++j)
         s0 += W[j] * xs[j];
     }
     if (k < p.P - 1)
     {
       const double* W = w.WR + (size_t)t * DD + i * D;
-      const double* xs = w.tp + p.s[k] * D;
+      const double* xs = w.tp + lpart_s(p, k) * D;
       for (int j = 0; j < D; ++j)
         s1 += W[j] * xs[j];
     }

@@ -744,14 +744,18 @@ TMX_DEVFN void kkt_solve(const QpWs& w, const DevProblem* P, int mode, double si
       if (w.act[r] && w_row(w, r, 1, delta) > 0.0)
       {
         double dk[2] = { 1.0, 1.0 }, dmin = 1.0;
-        for (int k = 0; k < w.naux[r]; ++k)
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+          if (k < w.naux[r])
         {
           const int a = w.aoff[r] + k;
           dk[k] = sig + w_ba(w, a, 1, delta) * w.bba[a] * w.bba[a];
           dmin = (k == 0) ? dk[k] : fmin(dmin, dk[k]);
         }
         double num = dmin * w.hr[r], den = dmin * delta;
-        for (int k = 0; k < w.naux[r]; ++k)
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+          if (k < w.naux[r])
         {
           const int a = w.aoff[r] + k;
           const double ratio = dmin / dk[k];
@@ -790,7 +794,9 @@ TMX_DEVFN void kkt_solve(const QpWs& w, const DevProblem* P, int mode, double si
       {
         const double rr = w_row(w, r, mode, delta);
         double kappa = 0.0, g = 0.0;
-        for (int k = 0; k < w.naux[r]; ++k)
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+          if (k < w.naux[r])
         {
           const int a = w.aoff[r] + k;
           const double d = sig + w_ba(w, a, mode, delta) * w.bba[a] * w.bba[a];
@@ -932,7 +938,9 @@ TMX_DEVFN void kkt_solve(const QpWs& w, const DevProblem* P, int mode, double si
       dot += link_dot(w, r, t, w.tp);
 #endif
       double dk[2] = { 1.0, 1.0 }, dmin = 1.0;
-      for (int k = 0; k < w.naux[r]; ++k)
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+        if (k < w.naux[r])
       {
         const int a = w.aoff[r] + k;
         dk[k] = sig + w_ba(w, a, 1, delta) * w.bba[a] * w.bba[a];
@@ -942,11 +950,15 @@ TMX_DEVFN void kkt_solve(const QpWs& w, const DevProblem* P, int mode, double si
       if (w_row(w, r, 1, delta) > 0.0)
       {
         double den = dmin * delta;
-        for (int k = 0; k < w.naux[r]; ++k)
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+          if (k < w.naux[r])
           den += w.sa[w.aoff[r] + k] * w.sa[w.aoff[r] + k] * (dmin / dk[k]);
         nu = dot * (dmin / den) - w.hr[r];  // hr holds c_r from step 1
       }
-      for (int k = 0; k < w.naux[r]; ++k)
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+        if (k < w.naux[r])
       {
         const int a = w.aoff[r] + k;
         w.ta[a] = (w.ta[a] - w.sa[a] * nu) / dk[k];
@@ -977,7 +989,9 @@ TMX_DEVFN void kkt_solve(const QpWs& w, const DevProblem* P, int mode, double si
       const double rr = w_row(w, r, mode, delta);
       double kappa = 0.0, g = 0.0;
       double dk[2], vk[2];
-      for (int k = 0; k < w.naux[r]; ++k)
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+        if (k < w.naux[r])
       {
         const int a = w.aoff[r] + k;
         dk[k] = sig + w_ba(w, a, mode, delta) * w.bba[a] * w.bba[a];
@@ -986,7 +1000,9 @@ TMX_DEVFN void kkt_solve(const QpWs& w, const DevProblem* P, int mode, double si
         g += w.sa[a] * vk[k] / dk[k];
       }
       const double f = rr * g / (1.0 + rr * kappa);
-      for (int k = 0; k < w.naux[r]; ++k)
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+        if (k < w.naux[r])
       {
         const int a = w.aoff[r] + k;
         const double xa = vk[k] / dk[k] - (w.sa[a] / dk[k]) * f;

@@ -264,8 +264,11 @@ TMX_DEVFN double cart_vel_value(const DevProblem* P, const double* q0, const dou
 {
   fk_tool(P, q0, s0);
   fk_tool(P, q1, s1);
+  // (select chains, not t[c]: a run-time subscript would put both transforms in scratch memory)
   const int c = i < 3 ? i : i - 3;
-  return (i < 3) ? (s1.t[c] - s0.t[c]) - limit : (s0.t[c] - s1.t[c]) - limit;
+  const double p0 = (c == 0) ? s0.t[0] : (c == 1) ? s0.t[1] : s0.t[2];
+  const double p1 = (c == 0) ? s1.t[0] : (c == 1) ? s1.t[1] : s1.t[2];
+  return (i < 3) ? (p1 - p0) - limit : (p0 - p1) - limit;
 }
 #endif
 
@@ -541,7 +544,10 @@ TMX_DEVFN void evaluate_terms(const DevProblem* P, const double* xv, double* cos
     {
       // constraint: violation = |err*coeff| (modeling_utils.cpp:238-245, modeling.cpp:150-167);
       // ABS cost: |err|*coeff (modeling_utils.cpp:143-167)
-      const double e = err[P->cp_idx[6 * c + i]], cc = P->cp_coeff[6 * c + i];
+      // (select chain, not err[idx]: a run-time subscript would put err[] in scratch memory)
+      const int ix = P->cp_idx[6 * c + i];
+      const double e = (ix == 0) ? err[0] : (ix == 1) ? err[1] : (ix == 2) ? err[2] : (ix == 3) ? err[3] : (ix == 4) ? err[4] : err[5];
+      const double cc = P->cp_coeff[6 * c + i];
       scratch[s0 + i] = P->cp_iscnt[c] ? fabs(e * cc) : fabs(e) * cc;
     }
   }
@@ -827,12 +833,12 @@ TMX_DEVFN void convexify_terms(const DevProblem* P, const double* xv, int* activ
     fk_link_visit(P, [q0](int k) { return q0[k]; }, D - 1, L, [&](int k, const Tf3& F) {
       double col[3];
       jac_point_col(P, k, F, s0.t, col);
-      a0[k] = col[c];
+      a0[k] = (c == 0) ? col[0] : (c == 1) ? col[1] : col[2];
     });
     fk_link_visit(P, [q1](int k) { return q1[k]; }, D - 1, L, [&](int k, const Tf3& F) {
       double col[3];
       jac_point_col(P, k, F, s1.t, col);
-      a1[k] = col[c];
+      a1[k] = (c == 0) ? col[0] : (c == 1) ? col[1] : col[2];
     });
     // out.block(0, 0) = -jac0, out.block(0, n) = jac1, out.block(3, 0) = jac0, out.block(3, n) = -jac1
     double dot = 0.0;
