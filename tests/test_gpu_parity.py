@@ -214,3 +214,34 @@ def test_json_problem_runs_on_device_like_the_programmatic_one():
         opt.ctx.close()
     assert (res[0]["status"] == res[1]["status"]).all() and (res[0]["n_qp_solves"] == res[1]["n_qp_solves"]).all()
     assert _np.array_equal(res[0]["x"], res[1]["x"])
+
+
+def test_two_batches_in_flight_give_the_sequential_results(orc):
+    """tmx_sqp_launch / tmx_sqp_wait on two contexts of one device (the bench's double buffering): the second batch is
+    enqueued while the first is still running, the pool workgroups of the first retire into it, and both end with exactly
+    the results of running them one after the other"""
+    from trajopt_amd import runtime
+    pci, s, g = pc.cfg(1)
+    xa = configs.seeds_for(1, pci, s, g, 256)
+    xb = configs.seeds_for(1, pci, s, g, 256, first=256)
+    desc = pci.to_desc()
+    ctxs = [runtime.Context(0), runtime.Context(0)]
+    try:
+        for c in ctxs:
+            c.upload(desc, abi.default_sqp_params(), abi.default_osqp_settings())
+        ref = []
+        for c, x in zip(ctxs, (xa, xb)):
+            c.set_x0(x)
+            c.run(0)
+            ref.append(c.results())
+        for c, x in zip(ctxs, (xa, xb)):
+            c.set_x0(x)
+            c.launch()
+        assert ctxs[1].wait() == 0 and ctxs[0].wait() == 0
+        for c, r0 in zip(ctxs, ref):
+            r = c.results()
+            assert np.array_equal(r["x"], r0["x"]) and np.array_equal(r["status"], r0["status"]) and np.array_equal(r["n_qp_solves"], r0["n_qp_solves"])
+            assert c.tail_started()
+    finally:
+        for c in ctxs:
+            c.close()

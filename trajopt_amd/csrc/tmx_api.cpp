@@ -904,6 +904,15 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
   UP(ob_radius, ob_radius);
   UP(ob_axis, ob_axis);
 #undef UP
+  // workspace placement: everything in LDS if it fits; else everything but the row coefficient arrays (they move to the HBM
+  // scratch: config 4, 177 -> 125 KB); else the HBM-workspace kernels
+  P.coef_far = 0;
+  {
+    const char* force = std::getenv("TMX_FORCE_COEF_FAR");  // test hook: exercise the placement on small problems / the host build
+    if ((force && force[0] == '1') ||
+        (qp_smem_bytes(D, T, R, NA, R2, 0) > 160 * 1024 && qp_smem_bytes(D, T, R, NA, R2, 1) <= 160 * 1024))
+      P.coef_far = 1;
+  }
   if (!ctx->dp)
   {
     void* p = nullptr;
@@ -912,7 +921,7 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
   }
   HIPCHK(hipMemcpy(ctx->dp, &P, sizeof(DevProblem), hipMemcpyHostToDevice));
   // LDS budgets
-  ctx->smem_qp = qp_smem_bytes(D, T, R, NA, R2);
+  ctx->smem_qp = qp_smem_bytes(D, T, R, NA, R2, P.coef_far);
   const size_t small_ints = 2 * (size_t)(P.n_max + 1) + 4 * (size_t)R + 2 + 16;
   ctx->smem_small = std::max<size_t>((tmx_eval_scratch_doubles(R, D * T, (int)vel_first.size(), n_costs, n_cnts) + n_costs + n_cnts + 8) * sizeof(double),
                                      small_ints * sizeof(int) + 64);
@@ -1052,7 +1061,7 @@ static tmx_status ensure_batch(tmx_ctx* ctx, int B)
   AL(sched_state, b);
   AL(sched_done, 1);
   H.tail_flag = ctx->h_tail;  // pinned host memory is device-accessible at the same address (unified addressing)
-  H.qp_scratch_stride = (long long)qp_scratch_doubles(P.D, P.T, P.R, P.NA, P.n_link);
+  H.qp_scratch_stride = (long long)qp_scratch_doubles(P.D, P.T, P.R, P.NA, P.n_link, P.coef_far);
   AL(qp_scratch, b * (size_t)H.qp_scratch_stride);
   H.ws_hbm_stride = ctx->ws_in_hbm ? (long long)((ctx->ws_bytes + 15) / 16 * 2) : 0;  // doubles, 16-byte aligned slices
   if (ctx->ws_in_hbm)  // stays nullptr otherwise: the kernels test the pointer

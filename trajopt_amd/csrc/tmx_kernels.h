@@ -390,7 +390,7 @@ TMX_KERNEL k_export_active(const DevProblem* P, const DevBatch* Bt, int* out)
   const int R = P->R, NX = P->NX;
   QpWs w;  // only the layout of the far (HBM) part is used
   double* scratch = Bt->qp_scratch + (size_t)b * Bt->qp_scratch_stride;
-  qp_ws_carve(w, scratch, scratch, scratch, P->D, P->T, R, P->NA, P->n_link);
+  qp_ws_carve(w, scratch, scratch, scratch, P->D, P->T, R, P->NA, P->n_link, P->coef_far);
   int* o = out + (size_t)b * P->m_max;
   const int* rec = Bt->prev_dims + 4 * b;  // dims of the last solve
   const int n = rec[0], m = rec[1], mg = m - n;

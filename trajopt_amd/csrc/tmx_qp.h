@@ -315,10 +315,15 @@ TMX_HOSTDEVFN size_t qp_lds_doubles(int D, int T, int R, int NA, int R2 = 0)
   const size_t dense = (dpart_fits(D, T) && R2 == 0) ? (size_t)p.P * gn * dpart_gstride((int)gn) + nsep * dpart_mult8((int)nsep) + 6 * 64 + (size_t)p.P * dpart_gstride((int)gn) + 64 : 0;
   return NX + 2 + (D <= 8 ? 8 * (size_t)T : NX + 2) + (size_t)R + (size_t)T + 20 + (size_t)T * D * (D <= 8 ? 8 : D) + dense + (size_t)D * D + 256 + 4 + (sizeof(QpWs) + 7) / 8;
 }
-TMX_HOSTDEVFN size_t qp_glb_doubles(int D, int T, int R, int NA, int R2 = 0)
+// cf ("coefficients far"): the row coefficient arrays coef / c2 live in the per-problem HBM scratch instead of the cold part.
+// They are the largest cold arrays (config 4: 52 of 177 KB) and only read by row sweeps, so a problem whose workspace
+// exceeds the LDS by less than that still runs LDS-resident (on the pool kernel) instead of out of an HBM workspace.
+TMX_HOSTDEVFN size_t qp_coef_doubles(int D, int R, int R2) { return (size_t)R * D + (size_t)(R2 > 0 ? R2 : 0) * D; }
+TMX_HOSTDEVFN size_t qp_glb_doubles(int D, int T, int R, int NA, int R2 = 0, int cf = 0)
 {
   const size_t NX = (size_t)D * T;
-  const size_t n = 10 * NX + 6 * (size_t)R + (size_t)R * D + 8 * (size_t)NA + (R2 > 0 ? (size_t)R2 * D + 3 * (size_t)T * D * D + NX : 0);
+  const size_t n = 10 * NX + 6 * (size_t)R + (cf ? 0 : (size_t)R * D) + 8 * (size_t)NA +
+                   (R2 > 0 ? (cf ? 0 : (size_t)R2 * D) + 3 * (size_t)T * D * D + NX : 0);
   const size_t ints = 7 * (size_t)R + (size_t)NX + (size_t)NA + 2 * (size_t)T + 4;
   return n + (ints + 1) / 2 + 8;
 }
@@ -326,22 +331,22 @@ TMX_HOSTDEVFN size_t qp_glb_doubles(int D, int T, int R, int NA, int R2 = 0)
 TMX_HOSTDEVFN bool lpart_fits(int D, int T, int R2) { return D <= 8 && R2 == 0 && T >= 64; }
 TMX_HOSTDEVFN size_t lpart_zp_doubles(int D) { return 18 * (size_t)D * D + 6 * (size_t)D + 2; }  // 4 interiors: 2 x (3 D)^2 (ping-pong inversion) + 2 x 3 D
 // arrays that are only touched at burst boundaries / in the polish step: always in the per-problem HBM scratch
-TMX_HOSTDEVFN size_t qp_far_doubles(int D, int T, int R, int NA, int R2 = 0)
+TMX_HOSTDEVFN size_t qp_far_doubles(int D, int T, int R, int NA, int R2 = 0, int cf = 0)
 {
   const size_t NX = (size_t)D * T;
   const size_t n = 2 * NX + (size_t)R + 4 * (size_t)NA;
   const size_t ints = 3 * (size_t)R + (size_t)NX + (size_t)NA;
   const size_t lp = lpart_fits(D, T, R2) ? 2 * (size_t)T * D * D + lpart_zp_doubles(D) + 2 : 0;
-  return n + (ints + 1) / 2 + 8 + lp;
+  return n + (ints + 1) / 2 + 8 + lp + (cf ? qp_coef_doubles(D, R, R2) + 2 : 0);
 }
 // dynamic LDS bytes of the QP kernels / per-problem HBM scratch doubles for the chosen placement
-TMX_HOSTDEVFN size_t qp_smem_bytes(int D, int T, int R, int NA, int R2 = 0)
+TMX_HOSTDEVFN size_t qp_smem_bytes(int D, int T, int R, int NA, int R2 = 0, int cf = 0)
 {
-  return (qp_lds_doubles(D, T, R, NA, R2) + (TMX_QP_COLD_IN_LDS ? qp_glb_doubles(D, T, R, NA, R2) : 0)) * sizeof(double);
+  return (qp_lds_doubles(D, T, R, NA, R2) + (TMX_QP_COLD_IN_LDS ? qp_glb_doubles(D, T, R, NA, R2, cf) : 0)) * sizeof(double);
 }
-TMX_HOSTDEVFN size_t qp_scratch_doubles(int D, int T, int R, int NA, int R2 = 0)
+TMX_HOSTDEVFN size_t qp_scratch_doubles(int D, int T, int R, int NA, int R2 = 0, int cf = 0)
 {
-  return qp_far_doubles(D, T, R, NA, R2) + (TMX_QP_COLD_IN_LDS ? 0 : qp_glb_doubles(D, T, R, NA, R2));
+  return qp_far_doubles(D, T, R, NA, R2, cf) + (TMX_QP_COLD_IN_LDS ? 0 : qp_glb_doubles(D, T, R, NA, R2, cf));
 }
 
 // long-horizon problems keep their workspace in HBM (k_*_hbm kernels); the arrays the sequential block chain walks -
@@ -385,7 +390,7 @@ TMX_DEVFN void qp_ws_chain_to_lds(QpWs& w, double* lds)
     w.Zp = p;
 }
 
-TMX_DEVFN void qp_ws_carve(QpWs& w, double* lds, double* glb, double* far, int D, int T, int R, int NA, int R2 = 0)
+TMX_DEVFN void qp_ws_carve(QpWs& w, double* lds, double* glb, double* far, int D, int T, int R, int NA, int R2 = 0, int cf = 0)
 {
   w.D = D;
   w.T = T;
@@ -439,7 +444,10 @@ TMX_DEVFN void qp_ws_carve(QpWs& w, double* lds, double* glb, double* far, int D
   TAKE(hir, R);
   TAKE(Er, R);
   TAKE(fac, R);
-  TAKE(coef, R * D);
+  if (!cf)
+  {
+    TAKE(coef, R * D);
+  }
   TAKE(xa, NA);
   TAKE(zba, NA);
   TAKE(yba, NA);
@@ -454,7 +462,10 @@ TMX_DEVFN void qp_ws_carve(QpWs& w, double* lds, double* glb, double* far, int D
   w.n_link = R2;
   if (R2 > 0)
   {
-    TAKE(c2, R2 * D);
+    if (!cf)
+    {
+      TAKE(c2, R2 * D);
+    }
     TAKE(Cd, T * D * D);
     TAKE(Mf, T * D * D);
     TAKE(Nb, T * D * D);
@@ -498,6 +509,19 @@ TMX_DEVFN void qp_ws_carve(QpWs& w, double* lds, double* glb, double* far, int D
     TAKE(WL, T * D * D);
     TAKE(WR, T * D * D);
     TAKE(Zp, (int)lpart_zp_doubles(D));
+  }
+  if (cf)
+  {
+    // coefficient arrays in the HBM scratch (behind everything else of the far region)
+    if (!lpart_fits(D, T, R2))
+      p = reinterpret_cast<double*>((reinterpret_cast<size_t>(ip) + 15) & ~(size_t)15);
+    TAKE(coef, R * D);
+#if TMX_LINK_ROWS
+    if (R2 > 0)
+    {
+      TAKE(c2, R2 * D);
+    }
+#endif
   }
 #undef TAKE
 #undef TAKEI

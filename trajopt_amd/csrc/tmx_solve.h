@@ -600,9 +600,9 @@ TMX_DEVFN QpShared* qp_ws_rebuild(QpWs& w, const DevProblem* P, const DevBatch* 
   const int D = P->D, T = P->T, R = P->R;
   double* scratch = Bt->qp_scratch + (size_t)b * Bt->qp_scratch_stride;
 #if TMX_QP_COLD_IN_LDS
-  qp_ws_carve(w, smem, smem + qp_lds_doubles(D, T, R, P->NA, P->n_link), scratch, D, T, R, P->NA, P->n_link);
+  qp_ws_carve(w, smem, smem + qp_lds_doubles(D, T, R, P->NA, P->n_link), scratch, D, T, R, P->NA, P->n_link, P->coef_far);
 #else
-  qp_ws_carve(w, smem, scratch + qp_far_doubles(D, T, R, P->NA, P->n_link), scratch, D, T, R, P->NA, P->n_link);
+  qp_ws_carve(w, smem, scratch + qp_far_doubles(D, T, R, P->NA, P->n_link, P->coef_far), scratch, D, T, R, P->NA, P->n_link, P->coef_far);
 #endif
 #if TMX_LINK_ROWS
   w.c2i = P->slot_c2;
@@ -744,9 +744,9 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
   {
     double* scratch = Bt->qp_scratch + (size_t)b * Bt->qp_scratch_stride;
 #if TMX_QP_COLD_IN_LDS
-    qp_ws_carve(w, smem, smem + qp_lds_doubles(D, T, R, P->NA, P->n_link), scratch, D, T, R, P->NA, P->n_link);
+    qp_ws_carve(w, smem, smem + qp_lds_doubles(D, T, R, P->NA, P->n_link), scratch, D, T, R, P->NA, P->n_link, P->coef_far);
 #else
-    qp_ws_carve(w, smem, scratch + qp_far_doubles(D, T, R, P->NA, P->n_link), scratch, D, T, R, P->NA, P->n_link);
+    qp_ws_carve(w, smem, scratch + qp_far_doubles(D, T, R, P->NA, P->n_link, P->coef_far), scratch, D, T, R, P->NA, P->n_link, P->coef_far);
 #endif
     if (chain_lds)  // k_*_hbm kernels only (a constant nullptr everywhere else)
       qp_ws_chain_to_lds(w, chain_lds);
@@ -1580,7 +1580,7 @@ TMX_DEVFN void sqp_update_block(const DevProblem* P, const DevBatch* Bt, int b, 
     double* vterm = val + R + (R + 1) / 2;
     double* vsum = vterm + (size_t)P->n_vel * NX;
     QpWs wl;  // only for the layout of the per-problem scratch (aux_ref written by the QP kernel)
-    qp_ws_carve(wl, smem, smem, Bt->qp_scratch + (size_t)b * Bt->qp_scratch_stride, D, P->T, R, P->NA, P->n_link);
+    qp_ws_carve(wl, smem, smem, Bt->qp_scratch + (size_t)b * Bt->qp_scratch_stride, D, P->T, R, P->NA, P->n_link, P->coef_far);
     const int* aux_ref = wl.aux_ref;
     for (int r = tid; r < R; r += NT)
     {
@@ -1933,7 +1933,7 @@ TMX_DEVFN void sqp2_update_block(const DevProblem* P, const DevBatch* Bt, int b,
   {
     // evaluateConvexCosts / evaluateConvexConstraintViolations at the FULL QP solution (trajopt_qp_problem.cpp:131-244)
     QpWs wl;
-    qp_ws_carve(wl, smem, smem, Bt->qp_scratch + (size_t)b * Bt->qp_scratch_stride, D, P->T, R, P->NA, P->n_link);
+    qp_ws_carve(wl, smem, smem, Bt->qp_scratch + (size_t)b * Bt->qp_scratch_stride, D, P->T, R, P->NA, P->n_link, P->coef_far);
     const int* aux_ref = wl.aux_ref;
     for (int r = tid; r < R; r += NT)
     {

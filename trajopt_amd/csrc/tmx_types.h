@@ -69,6 +69,7 @@ struct DevProblem
   // collision geometry
   int *ls_link;
   double *ls_center, *ls_radius, *ob_center, *ob_radius;
+  int coef_far;     // row coefficient arrays of the QP workspace in the HBM scratch (the rest of the workspace fits the LDS then)
   double *ob_axis;  // 3 per obstacle: capsule = sphere swept from ob_center to ob_center + ob_axis (zero: sphere)
   // pair rows (rows that also touch waypoint t + 1)
   int *slot_c2;       // R: index of the row's second coefficient block in DevBatch::coef2 (-1: the row sits on one waypoint)
