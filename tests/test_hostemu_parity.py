@@ -260,3 +260,23 @@ def test_launch_wait_and_tail_word(emu, orc):
     assert np.array_equal(r["x"], ref["x"]) and np.array_equal(r["n_qp_solves"], ref["n_qp_solves"])
     with pytest.raises(RuntimeError):
         emu.wait()
+
+
+@pytest.mark.parametrize("cid", [9, 17, 23])
+def test_coefficient_arrays_in_the_hbm_scratch(hostemu_lib, orc, monkeypatch, cid):
+    """DevProblem::coef_far (the placement config 4 gets on the device: coef / c2 in the per-problem HBM scratch, the rest of the
+    workspace resident), forced on small problems: same stage-by-stage agreement with the oracle"""
+    monkeypatch.setenv("TMX_FORCE_COEF_FAR", "1")
+    from trajopt_amd import runtime
+    ctx = runtime.Context(0, hostemu_lib)
+    try:
+        pci, s, g = pc.cfg(cid)
+        x0 = configs.seeds_for(cid, pci, s, g, 3)
+        desc = pc.make_ctx_inputs(ctx, pci, x0)
+        for b in range(2):
+            pc.check_first_qp_structure(ctx, orc, desc, x0, b, val_tol=1e-12)
+        assert all(same for same, _ in pc.check_first_qp_solve(ctx, orc, desc, x0))
+        r, o, same, dx = pc.check_full_sqp(ctx, orc, desc, x0, exact=False)
+        assert same.any() and (dx[same] <= pc.TOL_TRAJ).all()
+    finally:
+        ctx.close()
