@@ -569,23 +569,22 @@ struct QpShared
   double rho, sigma, alpha, c, cinv;
   QpInfo info;
   int terminated, can_check, iter, pad_;
-#ifdef TMX_PROFILE
-  long long pc[16], tlast;  // phase profiler: the callee continues the caller's timeline (thread 0)
-#endif
 };
 #ifdef TMX_PROFILE
+// phase profiler inside the out-of-line functions: each function keeps its own phase counters from a fresh time stamp and adds
+// them to the problem's counters in HBM when it leaves (thread 0); the few cycles of the call / return themselves are not counted
 #define TMX_PROF_ENTER(sh)                                                                                            \
   long long pc[16] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };                                             \
-  long long tlast = (sh)->tlast
+  long long tlast = TMX_CLK()
 #define TMX_PROF_LEAVE(sh)                                                                                            \
   do                                                                                                                  \
   {                                                                                                                   \
     if (threadIdx.x == 0)                                                                                             \
-    {                                                                                                                 \
       for (int q_ = 0; q_ < 16; ++q_)                                                                                 \
-        (sh)->pc[q_] += pc[q_];                                                                                       \
-      (sh)->tlast = tlast;                                                                                            \
-    }                                                                                                                 \
+      {                                                                                                               \
+        Bt->prof[(size_t)b * 16 + q_] += pc[q_];                                                                      \
+        pc[q_] = 0;                                                                                                   \
+      }                                                                                                               \
   } while (0)
 #else
 #define TMX_PROF_ENTER(sh)                                                                                            \
@@ -711,14 +710,9 @@ __device__ __attribute__((noinline)) static void qp_admm_fast_nl(const DevProble
     }
     iter = next;
     TMX_PROF_LEAVE(sh);
-#ifdef TMX_PROFILE
-    for (int q_ = 0; q_ < 16; ++q_)
-      pc[q_] = 0;
-    TMX_SYNC();
-#endif
     ended = qp_check_nl(P, Bt, b, iter, lds_off);
 #ifdef TMX_PROFILE
-    tlast = sh->tlast;
+    tlast = TMX_CLK();
 #endif
     if (ended)
       break;
@@ -1138,11 +1132,6 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
       sh->terminated = 0;
       sh->can_check = 0;
       sh->iter = 0;
-#ifdef TMX_PROFILE
-      for (int q_ = 0; q_ < 16; ++q_)
-        sh->pc[q_] = 0;
-      sh->tlast = tlast;
-#endif
     }
     TMX_SYNC();
     {
@@ -1154,9 +1143,7 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
       qp_admm_fast_nl(P, Bt, b, lds_off);
     }
 #ifdef TMX_PROFILE
-    for (int q_ = 0; q_ < 16; ++q_)
-      pc[q_] += sh->pc[q_];
-    tlast = sh->tlast;
+    tlast = TMX_CLK();
 #endif
     info = sh->info;
     w.rho = sh->rho;
