@@ -752,7 +752,8 @@ struct TmxTag
 // register allocation of the kernel is the maximum over the instantiations instead of the union of all roles.
 // NAX : aux slots per row compiled in (1 when no row of the wave has two aux vars - the hinge rows; else 2)
 template <bool RC, int NR, bool INTW, int NAX = 2>
-TMX_DEVFN void admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, bool keep_last, int tid, long long* pc, long long& tlast)
+TMX_DEVFN void admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, bool keep_last, int tid, long long* pc, long long& tlast,
+                                double* res14 = nullptr)
 {
   // The instantiations sit in the arms of one wave-uniform dispatch and begin with the same prologue; left alone, the optimiser
   // hoists that common code above the dispatch, and the ~50 values it defines then have to survive the branching - they were
@@ -1071,6 +1072,165 @@ TMX_DEVFN void admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, b
   }
   TMX_SYNC();
   TMX_TICK(9);
+  if (res14 != nullptr)
+  {
+    // ---- RESIDUALS FROM REGISTERS (update_info / compute_residuals, zmode 0): the iterate, the row coefficients and the
+    // column cache are still in registers, so the 14 norms of the termination test cost two exchanges (y of the rows grouped by
+    // waypoint as e was; x with 8 slots per waypoint) and one block reduction instead of a sweep over index lists in LDS.
+    // Every per-element value is formed with the operations and in the order of compute_residuals / at_rows / p_times
+    // (products and sums, no FMA; four partial sums over the waypoint's row list, remainder into the first): same bits.
+    // (the barrier above: every thread is past phase C of the last iteration - tp and hr are free)
+#pragma unroll
+    for (int q = 0; q < NR; ++q)
+      if (has[q])
+        h.hr[epos[q]] = g[q].y;  // 0 for an inactive row
+    if (pv)
+      h.tp[vp] = xp;
+    TMX_SYNC();
+    double m[14];
+#pragma unroll
+    for (int k = 0; k < 14; ++k)
+      m[k] = 0.0;
+#pragma unroll
+    for (int q = 0; q < NR; ++q)
+    {
+      const RowRegsT<NAX>& gq = g[q];
+      if (gq.act)
+      {
+        const int r = rowi[q];
+        double xb[8];
+        {
+          const tmx_lds_d2* xb2 = reinterpret_cast<const tmx_lds_d2*>(h.tp + tb[q]);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+          {
+            const tmx_d2 t2 = xb2[j];
+            xb[2 * j] = t2.x;
+            xb[2 * j + 1] = t2.y;
+          }
+        }
+        double ax = 0.0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (j < D)
+            ax = ax + gq.c[j] * xb[j];
+#pragma unroll
+        for (int k = 0; k < NAX; ++k)
+          if (k < gq.na)
+            ax = ax + gq.sa[k] * gq.xa[k];
+        {
+          const double z = gq.z, einv = fast_rcp(w.Er[r]);
+          m[0] = fmax(m[0], fabs(einv * (ax - z)));
+          m[1] = fmax(m[1], fabs(ax - z));
+          m[2] = fmax(m[2], fabs(z));
+          m[3] = fmax(m[3], fabs(ax));
+          m[4] = fmax(m[4], fabs(einv * z));
+          m[5] = fmax(m[5], fabs(einv * ax));
+        }
+#pragma unroll
+        for (int k = 0; k < NAX; ++k)
+          if (k < gq.na)
+          {
+            const int a = w.aoff[r] + k;
+            const double axa = gq.bb[k] * gq.xa[k], z = gq.za[k], einv = fast_rcp(w.Eba[a]);
+            m[0] = fmax(m[0], fabs(einv * (axa - z)));
+            m[1] = fmax(m[1], fabs(axa - z));
+            m[2] = fmax(m[2], fabs(z));
+            m[3] = fmax(m[3], fabs(axa));
+            m[4] = fmax(m[4], fabs(einv * z));
+            m[5] = fmax(m[5], fabs(einv * axa));
+            const double aty = gq.sa[k] * gq.y + gq.bb[k] * gq.ya[k];
+            const double res = gq.qa[k] + aty;
+            const double dinv = fast_rcp(w.Da[a]);
+            m[6] = fmax(m[6], fabs(dinv * res));
+            m[7] = fmax(m[7], fabs(res));
+            m[8] = fmax(m[8], fabs(gq.qa[k]));
+            m[9] = fmax(m[9], fabs(aty));
+            m[11] = fmax(m[11], fabs(dinv * gq.qa[k]));
+            m[12] = fmax(m[12], fabs(dinv * aty));
+          }
+      }
+    }
+    if (pv)
+    {
+      {
+        const double ax = bb * xp, z = zb, einv = fast_rcp(w.Ebp[v]);
+        m[0] = fmax(m[0], fabs(einv * (ax - z)));
+        m[1] = fmax(m[1], fabs(ax - z));
+        m[2] = fmax(m[2], fabs(z));
+        m[3] = fmax(m[3], fabs(ax));
+        m[4] = fmax(m[4], fabs(einv * z));
+        m[5] = fmax(m[5], fabs(einv * ax));
+      }
+      // (P x)_v: p_times
+      double px = w.pd[v] * xp;
+      if (vt > 0)
+        px = px + w.po[v - D] * h.tp[vp - 8];
+      if (vt < w.T - 1)
+        px = px + w.po[v] * h.tp[vp + 8];
+      // (A' y)_v: at_rows over the waypoint's row list (n entries): groups of four into four partial sums, remainder into the first
+      const int n = q_end > 0 ? q_end - q0v : 0, n4 = n & ~3;
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+      {
+        const tmx_lds_d2* ep = reinterpret_cast<const tmx_lds_d2*>(h.hr + e0off);
+#pragma unroll
+        for (int k2 = 0; k2 < 8; ++k2)
+        {
+          const tmx_d2 e2 = ep[k2];
+          const double p0 = cj[2 * k2] * e2.x, p1 = cj[2 * k2 + 1] * e2.y;
+          // entries 2 k2 and 2 k2 + 1: partial sum (k & 3) inside the groups of four, the first one in the remainder
+          const int ka = 2 * k2, kb = 2 * k2 + 1;
+          if ((ka & 3) == 0)
+          {
+            s0 = (ka < n) ? s0 + p0 : s0;
+            if (kb < n4)
+              s1 = s1 + p1;
+            else if (kb < n)
+              s0 = s0 + p1;
+          }
+          else
+          {
+            if (ka < n4)
+              s2 = s2 + p0;
+            else if (ka < n)
+              s0 = s0 + p0;
+            if (kb < n4)
+              s3 = s3 + p1;
+            else if (kb < n)
+              s0 = s0 + p1;
+          }
+        }
+      }
+      for (int q = q_rest; q < q_end; ++q)
+      {
+        const int k = q - q0v, r = w.wp_list[q];
+        const double pr = w.coef[r * D + vj] * h.hr[e0off + k];
+        const int u = (k < n4) ? (k & 3) : 0;
+        s0 = (u == 0) ? s0 + pr : s0;
+        s1 = (u == 1) ? s1 + pr : s1;
+        s2 = (u == 2) ? s2 + pr : s2;
+        s3 = (u == 3) ? s3 + pr : s3;
+      }
+      const double aty = ((s0 + s1) + (s2 + s3)) + bb * yb;
+      const double res = (qv + px) + aty;
+      const double dinv = fast_rcp(w.Dp[v]);
+      m[6] = fmax(m[6], fabs(dinv * res));
+      m[7] = fmax(m[7], fabs(res));
+      m[8] = fmax(m[8], fabs(qv));
+      m[9] = fmax(m[9], fabs(aty));
+      m[10] = fmax(m[10], fabs(px));
+      m[11] = fmax(m[11], fabs(dinv * qv));
+      m[12] = fmax(m[12], fabs(dinv * aty));
+      m[13] = fmax(m[13], fabs(dinv * px));
+    }
+    const bool sall[14] = { false, false, false, false, false, false, false, false, false, false, false, false, false, false };
+    block_reduce<14>(m, sall, w.red, tid, TMX_QP_NT);
+    if (tid == 0)
+#pragma unroll
+      for (int k = 0; k < 14; ++k)
+        res14[k] = m[k];
+    TMX_SYNC();
+  }
 }
 
 #ifdef TMX_BURST_NOINLINE
@@ -1096,7 +1256,8 @@ __device__ __attribute__((noinline)) static void admm_burst_nl(const QpWs* wsh, 
 #ifndef TMX_BURST_RC
 #define TMX_BURST_RC 1
 #endif
-TMX_DEVFN void admm_run_fast(const QpWs& w, const DevProblem* P, int n_iter, bool keep_last, int tid, long long* pc, long long& tlast)
+TMX_DEVFN void admm_run_fast(const QpWs& w, const DevProblem* P, int n_iter, bool keep_last, int tid, long long* pc, long long& tlast,
+                              double* res14 = nullptr)
 {
   // matrix rows of the dense solve in registers when they fit the fixed register arrays (7-DOF / 30 waypoints: Gs = 22, Zst = 56)
   const bool rc = TMX_BURST_RC && w.Gs <= 2 * TMX_RC_GP && w.Zst <= 8 * TMX_RC_ZP;
@@ -1123,8 +1284,8 @@ TMX_DEVFN void admm_run_fast(const QpWs& w, const DevProblem* P, int n_iter, boo
 #define TMX_BURST_CALL(RCv, NRv, INTv) admm_burst_nl<RCv, NRv, INTv>(wsh, P, n_iter, keep_last ? 1 : 0, pc, &tlast)
 #define TMX_BURST_CALL1(RCv, NRv, INTv) TMX_BURST_CALL(RCv, NRv, INTv)
 #else
-#define TMX_BURST_CALL(RCv, NRv, INTv) admm_burst_core<RCv, NRv, INTv, 2>(w, P, n_iter, keep_last, tid, pc, tlast)
-#define TMX_BURST_CALL1(RCv, NRv, INTv) admm_burst_core<RCv, NRv, INTv, 1>(w, P, n_iter, keep_last, tid, pc, tlast)
+#define TMX_BURST_CALL(RCv, NRv, INTv) admm_burst_core<RCv, NRv, INTv, 2>(w, P, n_iter, keep_last, tid, pc, tlast, res14)
+#define TMX_BURST_CALL1(RCv, NRv, INTv) admm_burst_core<RCv, NRv, INTv, 1>(w, P, n_iter, keep_last, tid, pc, tlast, res14)
 #endif
   if (!rc)
     TMX_BURST_CALL(false, TMX_NROW, true);

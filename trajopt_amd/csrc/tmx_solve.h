@@ -568,7 +568,8 @@ struct QpShared
 {
   double rho, sigma, alpha, c, cinv;
   QpInfo info;
-  int terminated, can_check, iter, pad_;
+  int terminated, can_check, iter, have_res;
+  double res[14];  // the 14 norms of update_info, left by the burst that just ended (have_res = 1): compute_residuals' output
 };
 #ifdef TMX_PROFILE
 // phase profiler inside the out-of-line functions: each function keeps its own phase counters from a fresh time stamp and adds
@@ -645,7 +646,27 @@ __device__ __attribute__((noinline)) static int qp_check_nl(const DevProblem* P_
   if (can_check || do_rho)
   {
     info.iter = iter;
-    compute_residuals(w, P, w.xp, w.xa, w.yr, w.ybp, w.yba, 0, info, info.prim_res, info.dual_res, true, tid, NT);
+    if (sh->have_res)
+    {
+      // the burst left the norms (admm_burst_core, "residuals from registers"): the assignments of compute_residuals
+      const double* m = sh->res;
+      info.prim_res = m[0];
+      info.dual_res = w.cinv * m[6];
+      info.s_prim = m[1];
+      info.s_z = m[2];
+      info.s_ax = m[3];
+      info.u_z = m[4];
+      info.u_ax = m[5];
+      info.s_dual = m[7];
+      info.s_q = m[8];
+      info.s_aty = m[9];
+      info.s_px = m[10];
+      info.u_q = m[11];
+      info.u_aty = m[12];
+      info.u_px = m[13];
+    }
+    else
+      compute_residuals(w, P, w.xp, w.xa, w.yr, w.ybp, w.yba, 0, info, info.prim_res, info.dual_res, true, tid, NT);
     TMX_TICK(6);
   }
   if (can_check && check_termination(w, P, info, false, tid, NT))
@@ -674,6 +695,7 @@ __device__ __attribute__((noinline)) static int qp_check_nl(const DevProblem* P_
     sh->info = info;
     sh->rho = rho;
     sh->can_check = can_check ? 1 : 0;
+    sh->have_res = 0;
   }
   TMX_PROF_LEAVE(sh);
   TMX_SYNC();
@@ -706,7 +728,13 @@ __device__ __attribute__((noinline)) static void qp_admm_fast_nl(const DevProble
     {
       QpWs w;
       sh = qp_ws_rebuild(w, P, Bt, b, smem);
-      admm_run_fast(w, P, next - iter + 1, true, tid, pc, tlast);
+#ifndef TMX_RES_FROM_REGS
+#define TMX_RES_FROM_REGS 1
+#endif
+      admm_run_fast(w, P, next - iter + 1, true, tid, pc, tlast, TMX_RES_FROM_REGS ? sh->res : nullptr);
+      if (TMX_RES_FROM_REGS && tid == 0)
+        sh->have_res = 1;  // ordered before qp_check_nl's reads by the barrier at its entry (qp_ws_rebuild + first block sync)
+      TMX_SYNC();
     }
     iter = next;
     TMX_PROF_LEAVE(sh);
@@ -1132,6 +1160,7 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
       sh->terminated = 0;
       sh->can_check = 0;
       sh->iter = 0;
+      sh->have_res = 0;
     }
     TMX_SYNC();
     {
