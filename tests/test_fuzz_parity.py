@@ -38,12 +38,12 @@ def test_random_problems_with_segment_collision_on_host_build(hostemu_lib, orc):
 
 @pytest.mark.gpu
 def test_random_problems_with_pair_rows_on_device(orc):
-    _sweep(12, 43, "gpu", "lvs", "links")
+    _sweep(24, 43, "gpu", "lvs", "links")
 
 
 @pytest.mark.gpu
 def test_random_problems_on_device(orc):
-    _sweep(20, 5, "gpu")     # D <= 8 and n_steps * D <= 256: the dense fast path of the QP solver
+    _sweep(40, 5, "gpu")     # D <= 8 and n_steps * D <= 256: the dense fast path of the QP solver
 
 
 @pytest.mark.parametrize("seed,case", [(2, 26), (2, 50), (2, 78), (2, 59), (2, 68), (2, 91)])
