@@ -24,6 +24,21 @@ def lib():
     return _LIB
 
 
+def variant(name="fma"):
+    """a second instance of this module bound to another build of the same source (oracle/Makefile: liborc_fma.so, the
+    restatement compiled with FMA contraction) - the yardstick of the end-to-end comparisons"""
+    import importlib.util
+    build()
+    so = os.path.join(_HERE, "_build", f"liborc_{name}.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-C", _HERE, "-j4"], stdout=subprocess.DEVNULL)
+    spec = importlib.util.spec_from_file_location(f"pyorc_{name}", os.path.join(_HERE, "pyorc.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    m._LIB = C.CDLL(so)
+    return m
+
+
 def _p(a, t=C.c_double):
     return a.ctypes.data_as(C.POINTER(t)) if a is not None else None
 

@@ -26,6 +26,12 @@ def orc():
 
 
 @pytest.fixture(scope="session")
+def orc_fma(orc):
+    """the same oracle source built with FMA contraction (oracle/Makefile): how far two correct builds of one restatement part"""
+    return orc.variant("fma")
+
+
+@pytest.fixture(scope="session")
 def hostemu_lib():
     """kernel sources compiled for the host — CPU-tier scaffolding only (tests/hostemu/Makefile)"""
     if not os.path.exists(HOSTEMU_LIB) or os.path.getmtime(HOSTEMU_LIB) < max(

@@ -195,14 +195,15 @@ def compare_active_sets(dev_flags, dev_y, orc_flags, orc_y):
     return False, bool(ties.all())
 
 
-def sqp_history_classes(ctx, orc, desc, x0, max_qp=128, detail=None):
+def sqp_history_classes(ctx, orc, desc, x0, max_qp=128, detail=None, trace=None):
     """Whole SQP runs compared QP by QP.  The device batch is stepped one trust-region evaluation per launch and after
     every step the integer record, the polish active set and the duals of every problem are read back; the oracle returns
     the same per QP.  Per seed the result is one of
       "identical": every QP record (sizes, CSC hashes, warm-start flag, OSQP status, iteration count, rho updates, polish
                    status) and every polish active set agree, row by row, for the whole run;
-      "tie":       the FIRST difference is a polish active set that differs only on degenerate rows (compare_active_sets);
-                   from there on the two runs solve different (warm-started) QPs and may legitimately part ways;
+      "tie":       the ONLY differences of the whole run are polish active sets that differ on degenerate rows
+                   (compare_active_sets): both choices give the same polished point, so the run must end within 1e-5 rad
+                   like an identical one (a run that parts at a tie and LATER at something else is classified by that);
       "admm":      the FIRST difference is an ADMM-level integer (OSQP iteration count, number of rho updates, polish
                    status, OSQP status) of a QP with identical structure and warm-start decision.  OSQP's adaptive rho is
                    rho * sqrt(prim_res / dual_res): whenever one of the residuals sits near round-off, the estimate
@@ -232,11 +233,21 @@ def sqp_history_classes(ctx, orc, desc, x0, max_qp=128, detail=None):
             break
     res = ctx.results()
     classes, dxs = [], []
+    # the oracle side of every seed (two serial runs each) on a thread pool: ctypes releases the GIL
+    from concurrent.futures import ThreadPoolExecutor
+    import os as _os
+
+    def _oracle(b):
+        return (orc.sqp_active_sets(desc, x0[b], ctx.m_max, max_qp=max_qp), orc.sqp_batch(desc, x0[b:b + 1], max_records=max_qp, nthreads=1))
+    with ThreadPoolExecutor(max_workers=min(16, _os.cpu_count() or 1)) as ex:
+        oracle_runs = list(ex.map(_oracle, range(B)))
     for b in range(B):
-        oq = orc.sqp_active_sets(desc, x0[b], ctx.m_max, max_qp=max_qp)
-        ob = orc.sqp_batch(desc, x0[b:b + 1], max_records=max_qp, nthreads=1)
+        oq, ob = oracle_runs[b]
         cls = "identical"
         why = ""
+        k = -1
+        struct = lambda t: (t.n, t.m, t.nnzP, t.hashP)
+        admm = lambda t: (t.osqp_status, t.osqp_iter, t.rho_updates, t.polish_status)
         for k in range(max(len(dev[b]), len(oq))):
             if k >= len(dev[b]) or k >= len(oq):
                 cls = "other"
@@ -244,8 +255,6 @@ def sqp_history_classes(ctx, orc, desc, x0, max_qp=128, detail=None):
                 break
             r, f, y = dev[b][k]
             o = ob["records"][k]
-            struct = lambda t: (t.n, t.m, t.nnzP, t.hashP)
-            admm = lambda t: (t.osqp_status, t.osqp_iter, t.rho_updates, t.polish_status)
             if struct(r) != struct(o):
                 cls = "other"
                 why = f"QP structure {struct(r)} vs {struct(o)}"
@@ -263,16 +272,26 @@ def sqp_history_classes(ctx, orc, desc, x0, max_qp=128, detail=None):
                 break
             same, only_ties = compare_active_sets(f, y, oq[k][0], oq[k][1])
             if not same:
+                if only_ties:
+                    # a degenerate tie gives the same polished point: the comparison goes on, and the seed stays in this class
+                    # only if NOTHING but ties ever differs (then |dx| <= 1e-5 is required of it like of an identical history)
+                    cls = "tie"
+                    continue
                 # a non-degenerate active-set difference is only explained when the two ADMM runs already used different rho
                 drift = abs(r.rho_final - o.rho_final) > 1e-9 * abs(o.rho_final)   # round-off alone leaves rho equal to ~1e-13
-                cls = "tie" if only_ties else ("admm" if drift else "other")
+                cls = "admm" if drift else "other"
                 why = f"non-degenerate active-set difference, rho {r.rho_final!r} vs {o.rho_final!r}, records {admm(r)}"
                 break
-        if cls == "identical" and (res["status"][b] != ob["status"][0] or res["n_qp_solves"][b] != ob["n_qp_solves"][0]):
+        if cls in ("identical", "tie") and (res["status"][b] != ob["status"][0] or res["n_qp_solves"][b] != ob["n_qp_solves"][0]):
             cls = "other"
             why = f"final status / counters {res['status'][b]},{res['n_qp_solves'][b]} vs {ob['status'][0]},{ob['n_qp_solves'][0]}"
         if cls == "other" and detail is not None:
             detail.append((b, k if k < min(len(dev[b]), len(oq)) else -1, len(dev[b]), len(oq), why))
+        if cls != "identical" and trace is not None:
+            kk = k if k < min(len(dev[b]), len(oq)) else -1
+            rd = admm(dev[b][kk][0]) + (dev[b][kk][0].rho_final,) if kk >= 0 else None
+            ro = admm(ob["records"][kk]) + (ob["records"][kk].rho_final,) if kk >= 0 else None
+            trace.append(dict(seed=b, cls=cls, first_qp=kk, n_qp_dev=len(dev[b]), n_qp_orc=len(oq), dev=rd, orc=ro, why=why))
         classes.append(cls)
         dxs.append(float(np.abs(res["x"][b] - ob["x"][0]).max()))
     return classes, np.array(dxs), res

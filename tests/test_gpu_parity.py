@@ -67,6 +67,7 @@ def test_full_sqp_mini_arm(gpu, orc, cid):
     x0 = configs.seeds_for(9, pci, s, g, B, sigma=0.05)
     desc = pc.make_ctx_inputs(gpu, pci, x0)
     r, o, same, dx = pc.check_full_sqp(gpu, orc, desc, x0, exact=False)
+    print(f"cid {cid}: same history {same.sum()}/{B}, within 1e-5: {(dx <= pc.TOL_TRAJ).sum()}/{B}, worst {dx.max():.2e}")
     assert (r["status"] == o["status"]).all()
     assert (dx[same] <= pc.TOL_TRAJ).all() and same.sum() >= B // 2
 
@@ -82,10 +83,45 @@ def test_full_sqp_config1_statistical(gpu, orc):
     r, o, same, dx = pc.check_full_sqp(gpu, orc, desc, x0, exact=False)
     assert (r["status"] == o["status"]).all()
     tight = dx <= pc.TOL_TRAJ
-    assert tight.sum() >= (3 * B) // 4, f"only {tight.sum()} of {B} seeds agree to 1e-5: {dx}"   # measured: 62 of 64
+    assert tight.sum() >= B - 1, f"only {tight.sum()} of {B} seeds agree to 1e-5: {dx}"   # measured: 16 of 16 (62 of 64, next test)
     cv, vv = gpu.evaluate()
     assert vv.max() < 1e-3
     assert np.abs(r["total_cost"] - o["total_cost"]).max() < 0.05 * max(1.0, np.abs(o["total_cost"]).max())
+
+
+def test_config1_history_classes_64_seeds(gpu, orc, orc_fma):
+    """The north-star bar on the headline configuration: 64 seeds of config 1, whole SQP runs compared QP by QP
+    (parity_checks.sqp_history_classes).  Required: no unexplained difference (class "other"); every seed whose integer history
+    is identical - or differs only by degenerate polish ties - ends within 1e-5 rad of the oracle; the seeds that leave the
+    1e-5 ball all parted at an ADMM-level integer (adaptive-rho round-off) and are no more than the oracle loses against
+    ITSELF when the same source is built with FMA contraction (measured: device 2 of 64 - seeds 23 and 55, parting at QP 34 /
+    QP 14; oracle vs oracle-with-FMA 3 of 64 - seeds 23, 24, 55, parting at the SAME QPs 34 / 18 / 14)."""
+    from collections import Counter
+    pci, s, g = _cfg(1)
+    B = 64
+    x0 = configs.seeds_for(1, pci, s, g, B)
+    desc = pc.make_ctx_inputs(gpu, pci, x0)
+    trace = []
+    classes, dx, res = pc.sqp_history_classes(gpu, orc, desc, x0, trace=trace)
+    cnt = Counter(classes)
+    cl = np.array(classes)
+    for c in cnt:
+        print(f"config 1 x {B}: {c}: {cnt[c]} seeds, worst |dx| {dx[cl == c].max():.2e}")
+    assert cnt["other"] == 0, [t for t in trace if t["cls"] == "other"]
+    for c in ("identical", "tie"):
+        if cnt[c]:
+            assert dx[cl == c].max() <= pc.TOL_TRAJ, f"{c} history but |dx| = {dx[cl == c].max()}"
+    out = set(np.nonzero(dx > pc.TOL_TRAJ)[0].tolist())
+    assert all(cl[b] in ("admm", "csc-noise") for b in out)
+    # the yardstick: the same seeds on two builds of the oracle itself
+    a = orc.sqp_batch(desc, x0)
+    f = orc_fma.sqp_batch(desc, x0)
+    dself = np.abs(a["x"] - f["x"]).reshape(B, -1).max(axis=1)
+    fragile = set(np.nonzero(dself > pc.TOL_TRAJ)[0].tolist())
+    print(f"outside 1e-5 rad: device vs oracle {sorted(out)}, oracle vs oracle-with-FMA {sorted(fragile)}")
+    assert len(out) <= max(len(fragile), 2), (sorted(out), sorted(fragile))
+    assert (dx <= pc.TOL_TRAJ).sum() >= 60     # measured: 62
+    assert cnt["identical"] + cnt["tie"] >= 48  # measured: 47 + 8
 
 
 def test_full_sqp_config2_long_horizon(gpu, orc):
@@ -95,6 +131,7 @@ def test_full_sqp_config2_long_horizon(gpu, orc):
     x0 = configs.seeds_for(2, pci, curve, None, 4)
     desc = pc.make_ctx_inputs(gpu, pci, x0)
     r, o, same, dx = pc.check_full_sqp(gpu, orc, desc, x0, exact=False)
+    print(f"config 2: same history {same.sum()}/4, within 1e-5: {(dx <= pc.TOL_TRAJ).sum()}/4, worst {dx.max():.2e}")
     assert (r["status"] == o["status"]).all() and (r["status"] == abi.OPT_CONVERGED).all()
     assert same.sum() >= 3 and (dx[same] <= pc.TOL_TRAJ).all()
     pc.check_config2_toolpath(pci, r["x"])
@@ -108,6 +145,7 @@ def test_full_sqp_config3_car_seat_shape(gpu, orc):
     x0 = configs.seeds_for(3, pci, s, g, B, sigma=0.05)
     desc = pc.make_ctx_inputs(gpu, pci, x0)
     r, o, same, dx = pc.check_full_sqp(gpu, orc, desc, x0, exact=False)
+    print(f"config 3: same history {same.sum()}/{B}, within 1e-5: {(dx <= pc.TOL_TRAJ).sum()}/{B}, worst {dx.max():.2e}")
     assert (r["status"] == o["status"]).all()
     assert same.sum() >= B // 2 and (dx[same] <= pc.TOL_TRAJ).all()
     conv = r["status"] == abi.OPT_CONVERGED

@@ -99,8 +99,26 @@ def test_trajopt_sqp_flavour_on_device(gpu_ctx_factory, orc):
     """config 4 at its real size (7-DOF x 30 waypoints, continuous collision hinge cost per segment) on the HIP library"""
     ctx = gpu_ctx_factory()
     r, o, same, dx = _check_flavour(ctx, orc, 30, 16)
-    assert (r["status"] == abi.SQP_CONVERGED).mean() >= 0.9 and same.sum() >= 12
+    assert (r["status"] == abi.SQP_CONVERGED).mean() >= 0.9 and same.sum() >= 15   # measured: 16 of 16 (32 of 32 in the next test)
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_trajopt_sqp_flavour_history_classes_32_seeds(gpu_ctx_factory, orc):
+    """config 4, 32 seeds, QP by QP against the oracle (tests/tools/c4_parity_stat.py): no structural / warm-start / final
+    difference, and every seed within 1e-5 rad (measured: 20 identical histories, 12 that differ in a polish active-set hash
+    only, worst |dx| 1.3e-10; adaptive rho is off on this path, so there is no ADMM-level class to part at)"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
+    import c4_parity_stat as c4
+    ctx = gpu_ctx_factory()
+    out, dx, r, o = c4.classes_config4(ctx, 32)
+    ctx.close()
+    cl = [c for c, _ in out]
+    print({c: cl.count(c) for c in set(cl)}, "worst |dx|", dx.max())
+    assert cl.count("other") == 0, out
+    assert np.array_equal(r["status"], o["status"]) and np.array_equal(r["n_qp_solves"], o["n_qp_solves"])
+    assert dx.max() <= 1e-5
 
 
 @pytest.mark.gpu

@@ -15,10 +15,14 @@ pci, s, g = configs.config1()
 x0 = configs.seeds_for(1, pci, s, g, B)
 ctx = runtime.Context(0, lib)
 desc = pc.make_ctx_inputs(ctx, pci, x0)
-detail = []
-classes, dx, r = pc.sqp_history_classes(ctx, orc, desc, x0, detail=detail)
+detail, trace = [], []
+classes, dx, r = pc.sqp_history_classes(ctx, orc, desc, x0, detail=detail, trace=trace)
 for d in detail:
     print('  other:', d)
+for t in trace:
+    if t["cls"] != "tie" or dx[t["seed"]] > 1e-5:
+        print(f"  seed {t['seed']}: {t['cls']}, |dx| {dx[t['seed']]:.2e}, first differing QP {t['first_qp']} of {t['n_qp_dev']} / {t['n_qp_orc']}: "
+              f"(status, iters, rho updates, polish, rho) device {t['dev']} oracle {t['orc']} {t['why']}")
 o = orc.sqp_batch(desc, x0)
 same = (r["status"] == o["status"]) & (r["n_qp_solves"] == o["n_qp_solves"])
 print(f"B={B}: classes {dict(Counter(classes))}; same status+QP count {same.sum()}/{B}; same status {(r['status'] == o['status']).sum()}/{B}; "

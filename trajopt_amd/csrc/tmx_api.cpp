@@ -51,6 +51,7 @@ struct tmx_ctx
   long long launches_admm{ 0 };
   bool timing{ true };
   int pending{ 0 };  // a tmx_sqp_launch() not yet collected by tmx_sqp_wait()
+  long long pool_relaunches{ 0 };  // times tmx_sqp_wait had to restart the pool (expected: 0)
   int* h_tail{ nullptr };  // pinned, device-mapped word: 1 once the pool kernel of the pending launch has begun to retire workgroups
   bool ws_in_hbm{ false };  // QP workspace > 160 KB of LDS: k_*_hbm kernels, workspace carved in HBM (long horizons)
   int mode{ 2 };  // optimize() driver: 0 = one launch chain per step, 1 = k_sqp_fused, 2 = k_sqp_pool (default)
@@ -1191,8 +1192,7 @@ tmx_status tmx_sqp_wait(tmx_ctx* ctx, int32_t* n_active_out)
   if (!ctx->pending)
     return TMX_ERR_STATE;
   HIPCHK(hipSetDevice(ctx->device));
-  ctx->pending = 0;
-  *ctx->h_tail = 1;
+  // (pending is cleared only once the launch has been collected: a device error leaves the context in the pending state)
   if (ctx->timing)
   {
     HIPCHK(hipEventSynchronize(ctx->ev1));
@@ -1202,11 +1202,31 @@ tmx_status tmx_sqp_wait(tmx_ctx* ctx, int32_t* n_active_out)
     ctx->launches_admm++;
   }
   long long tot[4] = { 0, 0, 0, 0 };
-  tmx_status rc = read_totals(ctx, tot);
+  tmx_status rc = read_totals(ctx, tot);  // synchronises the stream
   if (rc != TMX_OK)
     return rc;
+  // A run-to-completion launch must leave no problem unfinished.  The pool kernel retires workgroups that find nothing
+  // ready; should the last workgroups ever leave with work undone, the scheduler words are rebuilt from the problem phases
+  // (k_pool_sync) and the pool is started again - problems are independent, so the results do not depend on it.
+  for (int again = 0; tot[0] > 0 && again < 4 && !ctx->ws_in_hbm && ctx->mode == 2; ++again)
+  {
+    const int G = std::min(ctx->hb.B, ctx->pool_wgs);
+    TMX_LAUNCH(k_pool_sync, 1, 256, 0, ctx->stream, ctx->db);
+    TMX_LAUNCH(k_sqp_pool, G, ctx->nt_qp, ctx->smem_pool, ctx->stream, ctx->dp, ctx->db);
+    HIPCHK(hipGetLastError());
+    ctx->pool_relaunches++;
+    if ((rc = read_totals(ctx, tot)) != TMX_OK)
+      return rc;
+  }
+  ctx->pending = 0;
+  *ctx->h_tail = 1;
   if (n_active_out)
     *n_active_out = static_cast<int32_t>(tot[0]);
+  if (tot[0] > 0)
+  {
+    ctx->err = "tmx_sqp_wait: the launch ended with unfinished problems (internal error)";
+    return TMX_ERR_STATE;
+  }
   return TMX_OK;
 }
 
@@ -1543,22 +1563,55 @@ tmx_status tmx_qp_solve_batched(tmx_ctx* ctx, const tmx_qp_csc* qps, int32_t bat
       ctx->err = "tmx_qp_solve_batched: malformed CSC arrays";
       return TMX_ERR_INVALID;
     }
-    for (long long p = 0; p < nzP; ++p)
-      if (Q.P_i[p] < 0 || Q.P_i[p] >= Q.n)
+    // what osqp_setup's validate_data rejects (OSQP_DATA_VALIDATION_ERROR): column pointers that do not start at 0 or decrease
+    // (the kernel walks p = P_p[j] .. P_p[j+1] over device memory), row indices out of range, a P that is not upper
+    // triangular (the kernel mirrors the strict upper triangle: a full symmetric P would be counted twice), l > u, NaN
+    if (Q.P_p[0] != 0 || Q.A_p[0] != 0)
+    {
+      ctx->err = "tmx_qp_solve_batched: CSC column pointers must start at 0";
+      return TMX_ERR_INVALID;
+    }
+    for (int j = 0; j < Q.n; ++j)
+    {
+      if (Q.P_p[j] > Q.P_p[j + 1] || Q.P_p[j + 1] > nzP || Q.A_p[j] > Q.A_p[j + 1] || Q.A_p[j + 1] > nzA)
       {
-        ctx->err = "tmx_qp_solve_batched: P row index out of range";
+        ctx->err = "tmx_qp_solve_batched: CSC column pointers must be non-decreasing and end at nnz";
         return TMX_ERR_INVALID;
       }
-    for (long long p = 0; p < nzA; ++p)
-      if (Q.A_i[p] < 0 || Q.A_i[p] >= Q.m)
+      for (long long p = Q.P_p[j]; p < Q.P_p[j + 1]; ++p)
       {
-        ctx->err = "tmx_qp_solve_batched: A row index out of range";
+        if (Q.P_i[p] < 0 || Q.P_i[p] >= Q.n)
+        {
+          ctx->err = "tmx_qp_solve_batched: P row index out of range";
+          return TMX_ERR_INVALID;
+        }
+        if (Q.P_i[p] > j)
+        {
+          ctx->err = "tmx_qp_solve_batched: P must be given by its upper triangle (OSQP_DATA_VALIDATION_ERROR)";
+          return TMX_ERR_INVALID;
+        }
+        if (std::isnan(Q.P_x[p]))
+        {
+          ctx->err = "tmx_qp_solve_batched: NaN in P";
+          return TMX_ERR_INVALID;
+        }
+      }
+      if (std::isnan(Q.q[j]))
+      {
+        ctx->err = "tmx_qp_solve_batched: NaN in q";
+        return TMX_ERR_INVALID;
+      }
+    }
+    for (long long p = 0; p < nzA; ++p)
+      if (Q.A_i[p] < 0 || Q.A_i[p] >= Q.m || std::isnan(Q.A_x[p]))
+      {
+        ctx->err = "tmx_qp_solve_batched: A row index out of range (or NaN entry)";
         return TMX_ERR_INVALID;
       }
     for (int i = 0; i < Q.m; ++i)
-      if (Q.l[i] > Q.u[i])
+      if (!(Q.l[i] <= Q.u[i]))  // also false for a NaN bound
       {
-        ctx->err = "tmx_qp_solve_batched: lower bound above upper bound (OSQP_DATA_VALIDATION_ERROR)";
+        ctx->err = "tmx_qp_solve_batched: lower bound above upper bound or NaN bound (OSQP_DATA_VALIDATION_ERROR)";
         return TMX_ERR_INVALID;
       }
     GenQp& gq = g[(size_t)b];

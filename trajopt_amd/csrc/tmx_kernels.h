@@ -287,6 +287,7 @@ TMX_KERNEL_LB2(TMX_QP_NT, TMX_QP_WGS_PER_CU) k_sqp_pool(const DevProblem* P, con
   const int B = Bt->B;
   int* ibuf = reinterpret_cast<int*>(smem);  // [2NT]: decision broadcast (the reduction scratch sits at smem + 8)
   [[maybe_unused]] unsigned spins = 0;
+  bool released_open = false;  // thread 0: this workgroup's last step released a problem that is not DONE
   while (true)
   {
     // ---- scan: least n_qp among the ready problems; ties are broken by the distance from a workgroup-specific start
@@ -320,7 +321,16 @@ TMX_KERNEL_LB2(TMX_QP_NT, TMX_QP_WGS_PER_CU) k_sqp_pool(const DevProblem* P, con
         kbi = bi >= B ? bi - B : bi;
       }
       int decision;
-      if (kbi < 0)
+      if (kbi < 0 && released_open)
+      {
+        // The scan saw nothing ready right after this workgroup released an unfinished problem itself: either another
+        // workgroup claimed it in between (then it is in that workgroup's hands) or the scan ran ahead of the release.  The
+        // invariant below ("every unfinished problem is held by a workgroup that will rescan") only holds in the first
+        // case, so scan once more before retiring - by then the release is visible (barrier + s_waitcnt after the store).
+        decision = -2;
+        released_open = false;
+      }
+      else if (kbi < 0)
         // Nothing ready: every unfinished problem is in the hands of another workgroup, which will rescan the moment it
         // releases it - so this workgroup is surplus from now on (the number of unfinished problems only falls) and
         // RETIRES instead of spinning to the end of the straggler tail: its CU (all of its LDS) goes to whatever is queued
@@ -371,6 +381,7 @@ TMX_KERNEL_LB2(TMX_QP_NT, TMX_QP_WGS_PER_CU) k_sqp_pool(const DevProblem* P, con
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
       TMX_ST_RELAXED(&Bt->sched_state[b], done ? 2 : 0);
+      released_open = !done;
       if (done)
       {
 #if TMX_IS_DEVICE
@@ -379,7 +390,11 @@ TMX_KERNEL_LB2(TMX_QP_NT, TMX_QP_WGS_PER_CU) k_sqp_pool(const DevProblem* P, con
         __atomic_fetch_add(Bt->sched_done, 1, __ATOMIC_RELAXED);
 #endif
       }
+#if TMX_IS_DEVICE
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the release store has left the CU before any wave rescans
+#endif
     }
+    TMX_SYNC();  // no wave scans sched_state before thread 0 has published the release
   }
 }
 
