@@ -6,6 +6,7 @@
 #include <Eigen/SparseCore>
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <fstream>
 
 namespace sco
@@ -235,8 +236,17 @@ CvxOptStatus HipBatchedAdmmModel::optimize()
   toInt64(P_i, Pi);
   toInt64(A_p, Ap);
   toInt64(A_i, Ai);
-  // explicit warm start only when the previous solve succeeded and the sparsity is unchanged (:186-201, :338-369)
-  const bool warm = prev_solved_ && settings_.warm_starting && Pp == prev_P_p_ && Pi == prev_P_i_ && Ap == prev_A_p_ && Ai == prev_A_i_;
+  // explicit warm start only when the previous solve succeeded and the sparsity is "unchanged" (:186-201, :256-271, :338-369).
+  // The reference's test is weaker than it looks and is reproduced as written, so that this path warm-starts exactly when
+  // OSQPModel (and the in-library term path, tmx_solve.h qp_structure `wsP` / `wsA`) does: same dimensions and nnz, then
+  // memcmp over the first n + 1 BYTES of the column pointers and the first nnz BYTES of the row indices - not elements.
+  auto same_prefix = [](const std::vector<int64_t>& a, const std::vector<int64_t>& b, std::size_t bytes) {
+    return a.size() * sizeof(int64_t) >= bytes && b.size() * sizeof(int64_t) >= bytes && std::memcmp(a.data(), b.data(), bytes) == 0;
+  };
+  const bool P_eq = prev_n_ == n && prev_P_i_.size() == Pi.size() && same_prefix(prev_P_p_, Pp, n + 1) && same_prefix(prev_P_i_, Pi, Pi.size());
+  const bool A_eq = prev_n_ == n && prev_m_ == n_cnt + n && prev_A_i_.size() == Ai.size() && same_prefix(prev_A_p_, Ap, n + 1) &&
+                    same_prefix(prev_A_i_, Ai, Ai.size());
+  const bool warm = prev_solved_ && settings_.warm_starting && P_eq && A_eq;
   tmx_qp_csc qp{};
   qp.n = static_cast<int32_t>(n);
   qp.m = static_cast<int32_t>(n_cnt + n);
@@ -267,6 +277,8 @@ CvxOptStatus HipBatchedAdmmModel::optimize()
   prev_x_ = x;
   prev_y_ = y;
   prev_rho_ = info.rho_final;
+  prev_n_ = n;
+  prev_m_ = n_cnt + n;
   prev_P_p_ = Pp;
   prev_P_i_ = Pi;
   prev_A_p_ = Ap;

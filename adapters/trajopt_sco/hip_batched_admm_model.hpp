@@ -61,6 +61,7 @@ private:
   DblVec solution_;
   // previous solve: the reference re-applies x, y and rho when the sparsity is unchanged (osqp_interface.cpp:338-369)
   std::vector<int64_t> prev_P_p_, prev_P_i_, prev_A_p_, prev_A_i_;
+  std::size_t prev_n_{ 0 }, prev_m_{ 0 };  // dimensions of the previous QP (the reference compares them before the byte prefixes)
   DblVec prev_x_, prev_y_;
   double prev_rho_{ 0 };
   bool prev_solved_{ false };

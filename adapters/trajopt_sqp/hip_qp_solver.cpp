@@ -143,8 +143,29 @@ bool HipQPSolver::solve()
   Eigen::VectorXd x(num_vars_), y(num_cnts_);
   int32_t cvx = TMX_CVX_FAILED;
   tmx_qp_info info{};
-  if (tmx_qp_solve_batched(ctx_, &qp, 1, &st, x.data(), y.data(), &cvx, &info, nullptr) != TMX_OK || cvx != TMX_CVX_SOLVED)
+  if (tmx_qp_solve_batched(ctx_, &qp, 1, &st, x.data(), y.data(), &cvx, &info, nullptr) != TMX_OK)
   {
+    have_solution_ = false;  // nothing was solved: the next solve starts from (x0, y0) with settings.rho again
+    solver_status_ = QPSolverStatus::kFailed;
+    return false;
+  }
+  if (cvx != TMX_CVX_SOLVED)
+  {
+    // an initialised OSQP solver keeps going from where the failed solve left it: after an infeasibility verdict it cold-starts
+    // its iterates (osqp_solve resets x, z, y when the previous status was an infeasible one), after max_iter it continues from
+    // the last iterates; rho stays what the failed solve ended with - never the state of an OLDER successful solve
+    if (cvx == TMX_CVX_INFEASIBLE)
+    {
+      solution_ = Eigen::VectorXd::Zero(num_vars_);
+      duals_ = Eigen::VectorXd::Zero(num_cnts_);
+    }
+    else
+    {
+      solution_ = x;
+      duals_ = y;
+    }
+    rho_ = info.rho_final;
+    have_solution_ = true;
     solver_status_ = QPSolverStatus::kFailed;
     return false;
   }

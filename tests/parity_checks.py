@@ -13,6 +13,10 @@ from trajopt_amd import abi, configs
 
 TOL_TRAJ = 1e-5      # rad — north_star tolerance for joint trajectories / QP primal solutions
 
+# configuration ids of cfg() below: every id runs the stage checks on both tiers; MINI_CIDS also the whole SQP
+MINI_CIDS = [9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25]
+STAGE_CIDS = [0, 1, 2, 3] + MINI_CIDS
+
 
 def cfg(cid, T=None):
     """config id -> (pci, start, goal); shared by the CPU (host build) and GPU tiers so both run the same problems"""
@@ -43,6 +47,19 @@ def cfg(cid, T=None):
                 ti.evaluator_type = {16: 2, 17: 4, 18: 4, 19: 3}[cid]
                 ti.longest_valid_segment_length = 10.0 if cid == 19 else 0.12
                 ti.max_substates = 2 if cid == 19 else 4
+        return pci, s, g
+    if cid == 25:
+        # two segment collision terms with DIFFERENT max_substates (every row slot carries its term's capacity): an LVS_DISCRETE
+        # cost that never splits its segments (capacity 2) next to an LVS_CONTINUOUS constraint with capacity 5
+        from trajopt_amd.problem import CollisionTermInfo
+        pci, s, g = configs.config_mini() if T is None else configs.config_mini(T)
+        n = pci.basic_info.n_steps
+        for ti in pci.cost_infos:
+            if isinstance(ti, CollisionTermInfo):
+                ti.evaluator_type, ti.longest_valid_segment_length, ti.max_substates = 2, 0.12, 2
+        pci.cnt_infos.insert(0, CollisionTermInfo(first_step=0, last_step=n - 1, dist_pen=0.02, coeff=3.0, safety_margin_buffer=0.2,
+                                                  is_constraint=True, fixed_steps=[0], evaluator_type=4,
+                                                  longest_valid_segment_length=0.1, max_substates=5))
         return pci, s, g
     if cid in (20, 21, 22):
         # CAPSULE obstacles (include/tmx_geom.h): 20 single-time-step cost, 21 LVS_CONTINUOUS (swept link sphere vs capsule =

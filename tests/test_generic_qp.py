@@ -102,6 +102,51 @@ def test_generic_qp_rejects_malformed_input(hostemu_lib):
     bad = dict(q, A_i=q["A_i"] + 1000)
     with pytest.raises(runtime.TmxError, match="row index out of range"):
         ctx.qp_solve_batched([bad])
+    # what osqp_setup's validate_data rejects as well: column pointers that do not start at 0 / decrease / overrun nnz (the
+    # kernel walks them over device memory), a P given with its lower triangle (it would be counted twice), NaN bounds
+    Pp = q["P_p"].copy()
+    Pp[0] = 1
+    with pytest.raises(runtime.TmxError, match="must start at 0"):
+        ctx.qp_solve_batched([dict(q, P_p=Pp)])
+    Ap = q["A_p"].copy()
+    Ap[1], Ap[2] = Ap[2] + 1, Ap[1]
+    with pytest.raises(runtime.TmxError, match="non-decreasing"):
+        ctx.qp_solve_batched([dict(q, A_p=Ap)])
+    Ap = q["A_p"].copy()
+    Ap[3] = Ap[-1] + 5
+    with pytest.raises(runtime.TmxError, match="non-decreasing and end at nnz"):
+        ctx.qp_solve_batched([dict(q, A_p=Ap)])
+    import scipy.sparse as sp
+    n = q["n"]
+    Pu = sp.csc_matrix((q["P_x"], q["P_i"], q["P_p"]), shape=(n, n))
+    Pfull = sp.csc_matrix(Pu + sp.triu(Pu, 1).T)
+    Pfull.sort_indices()
+    if Pfull.nnz > Pu.nnz:
+        with pytest.raises(runtime.TmxError, match="upper triangle"):
+            ctx.qp_solve_batched([dict(q, P_p=Pfull.indptr.astype(np.int64), P_i=Pfull.indices.astype(np.int64), P_x=Pfull.data)])
+    lnan = q["l"].copy()
+    lnan[0] = np.nan
+    with pytest.raises(runtime.TmxError, match="NaN bound"):
+        ctx.qp_solve_batched([dict(q, l=lnan)])
+    ctx.close()
+
+
+def test_entry_points_refuse_while_a_launch_is_pending(hostemu_lib):
+    """tmx_sqp_launch / tmx_sqp_wait: until the launch is collected, everything that would re-prepare, reallocate or read the
+    batch returns TMX_ERR_STATE"""
+    ctx = runtime.Context(0, hostemu_lib)
+    pci, s, g = configs.config0()
+    x0 = configs.seeds_for(0, pci, s, g, 2)
+    pc.make_ctx_inputs(ctx, pci, x0)
+    ctx.launch()
+    for call in (lambda: ctx.set_x0(x0), ctx.results, ctx.evaluate, ctx.convexify, lambda: ctx.argmin(0), ctx.launch,
+                 lambda: ctx.upload(pci.to_desc(), abi.default_sqp_params(), abi.default_osqp_settings()),
+                 lambda: ctx.qp_solve_batched(_qps(7, 1))):
+        with pytest.raises(runtime.TmxError):
+            call()
+    assert ctx.wait() == 0
+    r = ctx.results()
+    assert (r["status"] == abi.OPT_CONVERGED).all()
     ctx.close()
 
 

@@ -19,7 +19,7 @@ def gpu(gpu_ctx_factory):
 _cfg = pc.cfg
 
 
-@pytest.mark.parametrize("cid", [0, 1, 2, 3, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24])
+@pytest.mark.parametrize("cid", pc.STAGE_CIDS)
 def test_evaluate_matches_oracle(gpu, orc, cid):
     pci, s, g = _cfg(cid)
     x0 = configs.seeds_for(cid, pci, s, g, 4)
@@ -38,7 +38,7 @@ def test_first_qp_csc_integers_bit_exact(gpu, orc, cid):
         pc.check_first_qp_structure(gpu, orc, desc, x0, b, val_tol=1e-10)
 
 
-@pytest.mark.parametrize("cid", [0, 1, 2, 3, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24])
+@pytest.mark.parametrize("cid", pc.STAGE_CIDS)
 def test_first_qp_solve_matches_oracle(gpu, orc, cid):
     pci, s, g = _cfg(cid)
     x0 = configs.seeds_for(cid, pci, s, g, 6)
@@ -59,7 +59,7 @@ def test_full_sqp_config0_exact(gpu, orc):
     assert np.abs(r["x"][:, 0, :] - s[None, :]).max() < 1e-6
 
 
-@pytest.mark.parametrize("cid", [9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24])
+@pytest.mark.parametrize("cid", pc.MINI_CIDS)
 def test_full_sqp_mini_arm(gpu, orc, cid):
     """4-DOF / 14-waypoint shape-coverage problem (other block size, partition and paddings of the dense KKT solve)"""
     pci, s, g = _cfg(cid)

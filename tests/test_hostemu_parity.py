@@ -19,7 +19,7 @@ def emu(hostemu_lib):
 _cfg = pc.cfg
 
 
-@pytest.mark.parametrize("cid", [0, 1, 2, 3, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24])
+@pytest.mark.parametrize("cid", pc.STAGE_CIDS)
 def test_evaluate_matches_oracle(emu, orc, cid):
     pci, s, g = _cfg(cid)
     x0 = configs.seeds_for(cid, pci, s, g, 3)
@@ -27,7 +27,7 @@ def test_evaluate_matches_oracle(emu, orc, cid):
     pc.check_evaluate(emu, orc, desc, x0, tol=1e-12)
 
 
-@pytest.mark.parametrize("cid", [0, 1, 2, 3, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24])
+@pytest.mark.parametrize("cid", pc.STAGE_CIDS)
 def test_first_qp_csc_bit_exact(emu, orc, cid):
     pci, s, g = _cfg(cid)
     x0 = configs.seeds_for(cid, pci, s, g, 2)
@@ -36,7 +36,7 @@ def test_first_qp_csc_bit_exact(emu, orc, cid):
         pc.check_first_qp_structure(emu, orc, desc, x0, b, val_tol=1e-12)
 
 
-@pytest.mark.parametrize("cid", [0, 1, 2, 3, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24])
+@pytest.mark.parametrize("cid", pc.STAGE_CIDS)
 def test_first_qp_solve_matches_oracle(emu, orc, cid):
     pci, s, g = _cfg(cid)
     x0 = configs.seeds_for(cid, pci, s, g, 2)
@@ -56,7 +56,7 @@ def test_full_sqp_config0_exact(emu, orc):
     assert np.abs(r["x"][:, 0, :] - s[None, :]).max() < 1e-6
 
 
-@pytest.mark.parametrize("cid", [9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24])
+@pytest.mark.parametrize("cid", pc.MINI_CIDS)
 def test_full_sqp_mini_arm(emu, orc, cid):
     """4-DOF / 14-waypoint shape-coverage problem: same status and counters, trajectories within 1e-5"""
     pci, s, g = _cfg(cid)

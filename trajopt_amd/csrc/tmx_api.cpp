@@ -76,16 +76,30 @@ static tmx_status upload(tmx_ctx* ctx, std::vector<void*>& pool, T** dst, const 
   return TMX_OK;
 }
 template <typename T>
-static tmx_status dalloc(tmx_ctx* ctx, std::vector<void*>& pool, T** dst, size_t count)
+static tmx_status dalloc(tmx_ctx* ctx, std::vector<void*>& pool, T** dst, size_t count, bool zero = true)
 {
   void* p = nullptr;
   const size_t bytes = std::max<size_t>(1, count) * sizeof(T);
   HIPCHK(hipMalloc(&p, bytes));
-  HIPCHK(hipMemset(p, 0, bytes));
+  // zero fill ordered on the context's stream (a null-stream hipMemset would wait for every blocking stream of the device,
+  // i.e. for the other context's batch in flight)
+  if (zero)
+    HIPCHK(hipMemsetAsync(p, 0, bytes, ctx->stream));
   pool.push_back(p);
   *dst = static_cast<T*>(p);
   return TMX_OK;
 }
+// Entry points that modify or read the batch refuse while a tmx_sqp_launch() is pending: they would re-prepare, reallocate
+// or read a batch that is still running (tmx_sqp_wait() collects it first).
+#define TMX_REFUSE_WHILE_PENDING(ctx)                                                                                 \
+  do                                                                                                                  \
+  {                                                                                                                   \
+    if ((ctx)->pending)                                                                                               \
+    {                                                                                                                 \
+      (ctx)->err = "a tmx_sqp_launch() is pending on this context: call tmx_sqp_wait() first";                        \
+      return TMX_ERR_STATE;                                                                                           \
+    }                                                                                                                 \
+  } while (0)
 static void free_pool(std::vector<void*>& pool)
 {
   for (void* p : pool)
@@ -225,6 +239,7 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
 {
   if (!ctx || !d)
     return TMX_ERR_INVALID;
+  TMX_REFUSE_WHILE_PENDING(ctx);
   HIPCHK(hipSetDevice(ctx->device));
   const int D = d->n_dof, T = d->n_steps;
   if (D < 1 || D > TMX_MAX_DOF || T < 1)
@@ -292,6 +307,51 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
     sub3.push_back(0);
     aux3.push_back(0.0);
   };
+  // DiscreteCollisionEvaluator (evaluator_type 2) / CastCollisionEvaluator (3, 4): one term per SEGMENT (i, i+1)
+  // (problem_description.cpp:1720-1761, :1779-1819); per (link sphere, obstacle) max_substates row slots in the order of the
+  // flattened contact map (pair-major, sub-state ascending).  Cost and constraint forms share this construction.
+  int n_costs = 0, n_cnts = 0;
+  auto add_lvs_segments = [&](const tmx_term& tm) -> tmx_status {
+#if !TMX_LINK_ROWS
+    (void)tm;
+    ctx->err = "rows on two consecutive waypoints (LVS / continuous collision) are not enabled in this build";
+    return TMX_ERR_UNSUPPORTED;
+#else
+    if (!(tm.longest_valid_segment_length >= 0))
+    {
+      ctx->err = "collision: longest_valid_segment_length must be >= 0";  // :1634
+      return TMX_ERR_INVALID;
+    }
+    const int kmax = tm.max_substates < 2 ? 2 : tm.max_substates;
+    // every slot carries its term's sub-state capacity (bits 16.. of slot_sub3: it fixes the LinSpaced grid the slot's sub-state
+    // index refers to), so terms with different max_substates coexist
+    if (kmax > 0x7FFF)
+    {
+      ctx->err = "collision: max_substates too large";
+      return TMX_ERR_UNSUPPORTED;
+    }
+    lvs_kmax = std::max(lvs_kmax, kmax);
+    const bool cast = tm.evaluator_type != 2, is_cnt_c = tm.kind == TMX_TERM_COLLISION_CNT;
+    for (int i = tm.first_step; i < tm.last_step; ++i)
+    {
+      const bool cur = std::find(tm.fixed_steps, tm.fixed_steps + tm.n_fixed_steps, i) != tm.fixed_steps + tm.n_fixed_steps;
+      const bool nxt = std::find(tm.fixed_steps, tm.fixed_steps + tm.n_fixed_steps, i + 1) != tm.fixed_steps + tm.n_fixed_steps;
+      const int fl = (cur ? 1 : 0) | ((!cur && nxt) ? 2 : 0) | (cast ? 4 : 0);
+      const int own = is_cnt_c ? n_cnts++ : n_costs++;
+      const int nsub = cast ? kmax - 1 : kmax;
+      for (int sp = 0; sp < d->n_link_spheres; ++sp)
+        for (int o = 0; o < d->n_obstacles; ++o)
+          for (int q = 0; q < nsub; ++q)
+          {
+            add_slot(SLOT_COLLISION_LVS, i, sp, o, own, 1, is_cnt_c ? 1 : 0, 0, tm.coeff, is_cnt_c ? tm.coeff : 1.0, tm.margin, tm.buffer);
+            c2.back() = R2++;
+            sub3.back() = fl | (q << 3) | (kmax << 16);
+            aux3.back() = tm.longest_valid_segment_length;
+          }
+    }
+    return TMX_OK;
+#endif
+  };
   const int flavor = d->flavor;
   if (flavor != TMX_FLAVOR_SCO && flavor != TMX_FLAVOR_SQP)
   {
@@ -339,7 +399,6 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
   std::vector<double> pd(P.NX, 0.0), po(P.NX, 0.0), pq(P.NX, 0.0);
   std::vector<int> vel_first, vel_last, vel_cost, vel_kind, cp_t, cp_owner, cp_iscnt, cp_nrows, cp_idx, cp_slot0;
   std::vector<double> vel_coeffs, vel_targets, cp_coeff, cp_target;
-  int n_costs = 0, n_cnts = 0;
   // hatch order: all costs in list order, then the constraints; sco::OptProb keeps equality constraints in front of the
   // inequality constraints (modeling.cpp:234-241), which fixes both the row / aux order and the constraint numbering
   int n_sq = 0;
@@ -670,45 +729,10 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
           }
           if (tm.evaluator_type >= 2)
           {
-#if !TMX_LINK_ROWS
-            ctx->err = "rows on two consecutive waypoints (LVS / continuous collision) are not enabled in this build";
-            return TMX_ERR_UNSUPPORTED;
-#else
-            // DiscreteCollisionEvaluator (2) / CastCollisionEvaluator (3, 4): one term per SEGMENT (i, i+1)
-            // (problem_description.cpp:1720-1761, :1779-1819); per (link sphere, obstacle) max_substates row slots in the order
-            // of the flattened contact map (pair-major, sub-state ascending)
-            if (!(tm.longest_valid_segment_length >= 0))
-            {
-              ctx->err = "collision: longest_valid_segment_length must be >= 0";  // :1634
-              return TMX_ERR_INVALID;
-            }
-            const int kmax = tm.max_substates < 2 ? 2 : tm.max_substates;
-            if (lvs_kmax != 2 && lvs_kmax != kmax && kmax != 2)
-            {
-              ctx->err = "collision terms of one problem must share max_substates";
-              return TMX_ERR_UNSUPPORTED;
-            }
-            lvs_kmax = std::max(lvs_kmax, kmax);
-            const bool cast = tm.evaluator_type != 2, is_cnt_c = tm.kind == TMX_TERM_COLLISION_CNT;
-            for (int i = tm.first_step; i < tm.last_step; ++i)
-            {
-              const bool cur = std::find(tm.fixed_steps, tm.fixed_steps + tm.n_fixed_steps, i) != tm.fixed_steps + tm.n_fixed_steps;
-              const bool nxt = std::find(tm.fixed_steps, tm.fixed_steps + tm.n_fixed_steps, i + 1) != tm.fixed_steps + tm.n_fixed_steps;
-              const int fl = (cur ? 1 : 0) | ((!cur && nxt) ? 2 : 0) | (cast ? 4 : 0);
-              const int own = is_cnt_c ? n_cnts++ : n_costs++;
-              const int nsub = cast ? kmax - 1 : kmax;
-              for (int sp = 0; sp < d->n_link_spheres; ++sp)
-                for (int o = 0; o < d->n_obstacles; ++o)
-                  for (int q = 0; q < nsub; ++q)
-                  {
-                    add_slot(SLOT_COLLISION_LVS, i, sp, o, own, 1, is_cnt_c ? 1 : 0, 0, tm.coeff, is_cnt_c ? tm.coeff : 1.0, tm.margin, tm.buffer);
-                    c2.back() = R2++;
-                    sub3.back() = fl | (q << 3);
-                    aux3.back() = tm.longest_valid_segment_length;
-                  }
-            }
+            const tmx_status rc_lvs = add_lvs_segments(tm);
+            if (rc_lvs != TMX_OK)
+              return rc_lvs;
             break;
-#endif
           }
           for (int i = tm.first_step; i <= tm.last_step; ++i)
           {
@@ -730,45 +754,10 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
           }
           if (tm.evaluator_type >= 2)
           {
-#if !TMX_LINK_ROWS
-            ctx->err = "rows on two consecutive waypoints (LVS / continuous collision) are not enabled in this build";
-            return TMX_ERR_UNSUPPORTED;
-#else
-            // DiscreteCollisionEvaluator (2) / CastCollisionEvaluator (3, 4): one term per SEGMENT (i, i+1)
-            // (problem_description.cpp:1720-1761, :1779-1819); per (link sphere, obstacle) max_substates row slots in the order
-            // of the flattened contact map (pair-major, sub-state ascending)
-            if (!(tm.longest_valid_segment_length >= 0))
-            {
-              ctx->err = "collision: longest_valid_segment_length must be >= 0";  // :1634
-              return TMX_ERR_INVALID;
-            }
-            const int kmax = tm.max_substates < 2 ? 2 : tm.max_substates;
-            if (lvs_kmax != 2 && lvs_kmax != kmax && kmax != 2)
-            {
-              ctx->err = "collision terms of one problem must share max_substates";
-              return TMX_ERR_UNSUPPORTED;
-            }
-            lvs_kmax = std::max(lvs_kmax, kmax);
-            const bool cast = tm.evaluator_type != 2, is_cnt_c = tm.kind == TMX_TERM_COLLISION_CNT;
-            for (int i = tm.first_step; i < tm.last_step; ++i)
-            {
-              const bool cur = std::find(tm.fixed_steps, tm.fixed_steps + tm.n_fixed_steps, i) != tm.fixed_steps + tm.n_fixed_steps;
-              const bool nxt = std::find(tm.fixed_steps, tm.fixed_steps + tm.n_fixed_steps, i + 1) != tm.fixed_steps + tm.n_fixed_steps;
-              const int fl = (cur ? 1 : 0) | ((!cur && nxt) ? 2 : 0) | (cast ? 4 : 0);
-              const int own = is_cnt_c ? n_cnts++ : n_costs++;
-              const int nsub = cast ? kmax - 1 : kmax;
-              for (int sp = 0; sp < d->n_link_spheres; ++sp)
-                for (int o = 0; o < d->n_obstacles; ++o)
-                  for (int q = 0; q < nsub; ++q)
-                  {
-                    add_slot(SLOT_COLLISION_LVS, i, sp, o, own, 1, is_cnt_c ? 1 : 0, 0, tm.coeff, is_cnt_c ? tm.coeff : 1.0, tm.margin, tm.buffer);
-                    c2.back() = R2++;
-                    sub3.back() = fl | (q << 3);
-                    aux3.back() = tm.longest_valid_segment_length;
-                  }
-            }
+            const tmx_status rc_lvs = add_lvs_segments(tm);
+            if (rc_lvs != TMX_OK)
+              return rc_lvs;
             break;
-#endif
           }
           // CollisionConstraint per non-fixed step (problem_description.cpp:1821-1835): inequality rows, hinge penalty with
           // the merit coefficient; the collision coefficient scales the row itself (slot_scale)
@@ -1093,6 +1082,7 @@ tmx_status tmx_batch_set_x0(tmx_ctx* ctx, const double* x0_host, int32_t batch)
     return TMX_ERR_INVALID;
   if (!ctx->have_problem)
     return TMX_ERR_STATE;
+  TMX_REFUSE_WHILE_PENDING(ctx);
   HIPCHK(hipSetDevice(ctx->device));
   tmx_status rc = ensure_batch(ctx, batch);
   if (rc != TMX_OK)
@@ -1107,6 +1097,7 @@ tmx_status tmx_batch_set_x0_device(tmx_ctx* ctx, const double* x0_dev, int32_t b
     return TMX_ERR_INVALID;
   if (!ctx->have_problem)
     return TMX_ERR_STATE;
+  TMX_REFUSE_WHILE_PENDING(ctx);
   HIPCHK(hipSetDevice(ctx->device));
   tmx_status rc = ensure_batch(ctx, batch);
   if (rc != TMX_OK)
@@ -1300,6 +1291,7 @@ tmx_status tmx_sqp_results(tmx_ctx* ctx, double* x, int32_t* status, double* tot
     return TMX_ERR_INVALID;
   if (ctx->Bcap == 0)
     return TMX_ERR_STATE;
+  TMX_REFUSE_WHILE_PENDING(ctx);
   HIPCHK(hipSetDevice(ctx->device));
   const size_t B = ctx->hb.B;
   tmx_status rc;
@@ -1317,6 +1309,7 @@ tmx_status tmx_sqp_counters(tmx_ctx* ctx, int64_t* n_func_evals, int64_t* n_qp_s
     return TMX_ERR_INVALID;
   if (ctx->Bcap == 0)
     return TMX_ERR_STATE;
+  TMX_REFUSE_WHILE_PENDING(ctx);
   long long tot[4];
   tmx_status rc = read_totals(ctx, tot);
   if (rc != TMX_OK)
@@ -1336,6 +1329,7 @@ tmx_status tmx_sqp_state(tmx_ctx* ctx, int32_t* sqp_iter, int32_t* merit_increas
     return TMX_ERR_INVALID;
   if (ctx->Bcap == 0)
     return TMX_ERR_STATE;
+  TMX_REFUSE_WHILE_PENDING(ctx);
   HIPCHK(hipSetDevice(ctx->device));
   const size_t B = ctx->hb.B;
   tmx_status rc;
@@ -1358,6 +1352,7 @@ tmx_status tmx_sqp_qp_records(tmx_ctx* ctx, tmx_qp_record* out, int32_t max_reco
     return TMX_ERR_INVALID;
   if (ctx->Bcap == 0)
     return TMX_ERR_STATE;
+  TMX_REFUSE_WHILE_PENDING(ctx);
   HIPCHK(hipSetDevice(ctx->device));
   const int B = ctx->hb.B;
   std::vector<tmx_qp_record> tmp((size_t)B * ctx->max_rec);
@@ -1396,6 +1391,7 @@ tmx_status tmx_evaluate(tmx_ctx* ctx, double* cost_vals, double* cnt_viols)
     return TMX_ERR_INVALID;
   if (ctx->Bcap == 0)
     return TMX_ERR_STATE;
+  TMX_REFUSE_WHILE_PENDING(ctx);
   HIPCHK(hipSetDevice(ctx->device));
   const size_t B = ctx->hb.B;
   TMX_LAUNCH(k_evaluate, ctx->hb.B, ctx->nt_small, ctx->smem_small, ctx->stream, ctx->dp, ctx->db, 0);
@@ -1414,6 +1410,7 @@ tmx_status tmx_convexify(tmx_ctx* ctx, int32_t* active, double* coef, double* rh
     return TMX_ERR_INVALID;
   if (ctx->Bcap == 0)
     return TMX_ERR_STATE;
+  TMX_REFUSE_WHILE_PENDING(ctx);
   HIPCHK(hipSetDevice(ctx->device));
   const size_t B = ctx->hb.B;
   TMX_LAUNCH(k_convexify, ctx->hb.B, ctx->nt_small, ctx->smem_small, ctx->stream, ctx->dp, ctx->db, 1);
@@ -1447,6 +1444,7 @@ tmx_status tmx_export_csc(tmx_ctx* ctx, int32_t problem, int32_t* n, int32_t* m,
     return TMX_ERR_INVALID;
   if (ctx->Bcap == 0)
     return TMX_ERR_STATE;
+  TMX_REFUSE_WHILE_PENDING(ctx);
   if (problem < 0 || problem >= ctx->hb.B)
     return TMX_ERR_INVALID;
   HIPCHK(hipSetDevice(ctx->device));
@@ -1512,6 +1510,7 @@ tmx_status tmx_qp_solve(tmx_ctx* ctx, double* x_qp, int32_t* cvx_status, tmx_qp_
     return TMX_ERR_INVALID;
   if (ctx->Bcap == 0)
     return TMX_ERR_STATE;
+  TMX_REFUSE_WHILE_PENDING(ctx);
   HIPCHK(hipSetDevice(ctx->device));
   const size_t B = ctx->hb.B;
   if (ctx->ws_in_hbm)
@@ -1533,6 +1532,7 @@ tmx_status tmx_qp_solve_batched(tmx_ctx* ctx, const tmx_qp_csc* qps, int32_t bat
 {
   if (!ctx || !qps || batch < 1 || !x || !y)
     return TMX_ERR_INVALID;
+  TMX_REFUSE_WHILE_PENDING(ctx);
   HIPCHK(hipSetDevice(ctx->device));
   tmx_osqp_settings st;
   if (settings)
@@ -1674,7 +1674,7 @@ tmx_status tmx_qp_solve_batched(tmx_ctx* ctx, const tmx_qp_csc* qps, int32_t bat
   if (rc == TMX_OK)
     rc = dalloc(ctx, pool, &D.info, (size_t)batch);
   if (rc == TMX_OK)
-    rc = dalloc(ctx, pool, &D.ws, (size_t)ows);
+    rc = dalloc(ctx, pool, &D.ws, (size_t)ows, /*zero=*/false);  // k_qp_generic zero-fills the dense P / A it builds itself
   if (rc != TMX_OK)
   {
     free_pool(pool);
@@ -1728,6 +1728,7 @@ tmx_status tmx_qp_duals(tmx_ctx* ctx, double* y_qp)
     return TMX_ERR_INVALID;
   if (ctx->Bcap == 0)
     return TMX_ERR_STATE;
+  TMX_REFUSE_WHILE_PENDING(ctx);
   HIPCHK(hipSetDevice(ctx->device));
   tmx_status rc = d2h(ctx, y_qp, ctx->hb.yq, (size_t)ctx->hb.B * ctx->hp.m_max);
   if (rc != TMX_OK)
@@ -1742,6 +1743,7 @@ tmx_status tmx_qp_active_set(tmx_ctx* ctx, int32_t* flags)
     return TMX_ERR_INVALID;
   if (ctx->Bcap == 0)
     return TMX_ERR_STATE;
+  TMX_REFUSE_WHILE_PENDING(ctx);
   HIPCHK(hipSetDevice(ctx->device));
   const size_t count = (size_t)ctx->hb.B * ctx->hp.m_max;
   std::vector<void*> pool;
@@ -1782,6 +1784,7 @@ tmx_status tmx_argmin(tmx_ctx* ctx, int64_t global_offset, int64_t* best_index, 
     return TMX_ERR_INVALID;
   if (ctx->Bcap == 0)
     return TMX_ERR_STATE;
+  TMX_REFUSE_WHILE_PENDING(ctx);
   HIPCHK(hipSetDevice(ctx->device));
   int nranks = 1;
 #ifndef TMX_HOST_EMU

@@ -319,7 +319,7 @@ TMX_DEVFN bool lvs_contact(const DevProblem* P, const double* q0, const double* 
 {
   const int D = P->D;
   const int s = P->slot_sub[r], o = P->slot_sub2[r], flags = P->slot_sub3[r];
-  const int i = flags >> 3;
+  const int i = (flags >> 3) & 0x1FFF, kmax = flags >> 16;  // sub-state index; sub-state capacity of the slot's term
   const bool fixed0 = flags & 1, fixed1 = flags & 2, cast = flags & 4;
   const double lvs = P->slot_aux3[r], margin = P->slot_aux1[r], buffer = P->slot_aux2[r];
   double d2 = 0.0;
@@ -329,8 +329,8 @@ TMX_DEVFN bool lvs_contact(const DevProblem* P, const double* q0, const double* 
   int cnt = 2;
   if (dist > lvs)
     cnt = (int)ceil(dist / lvs) + 1;
-  if (cnt > P->lvs_kmax)
-    cnt = P->lvs_kmax;
+  if (cnt > kmax)
+    cnt = kmax;
   const bool split = dist > lvs;
   const int last = cnt - 1;
   const int n_sub = cast ? last : cnt;

@@ -75,7 +75,8 @@ struct DevProblem
   int *slot_c2;       // R: index of the row's second coefficient block in DevBatch::coef2 (-1: the row sits on one waypoint)
   int n_link;         // number of pair rows R2 (0: every row sits on one waypoint)
   // collision evaluator of the LVS slots: longest valid segment length; fixed-state flags per slot in slot_sub3
-  int *slot_sub3;     // R: collision LVS: bit 0 = state t is fixed (START_FIXED_END_FREE), bit 1 = state t+1 is fixed
+  int *slot_sub3;     // R: collision LVS: bit 0 = state t is fixed (START_FIXED_END_FREE), bit 1 = state t+1 is fixed,
+                      //    bit 2 = cast, bits 3..15 = sub-state index, bits 16.. = max_substates of the slot's term
   double *slot_aux3;  // R: collision LVS: longest_valid_segment_length
   int lvs_kmax;       // sub-state capacity of the LVS evaluators (tmx_term.max_substates)
   int flavor;         // tmx_flavor: 0 trajopt_sco (BasicTrustRegionSQP / OSQPModel), 1 trajopt_sqp (TrajOptQPProblem / TrustRegionSQPSolver)
