@@ -231,6 +231,10 @@ typedef struct
   int32_t inflate_constraints_individually;
   int32_t pad_;
   double trust_box_size;
+  /* wall-clock limit in seconds, tested at the top of every SQP iteration (optimizers.cpp:738-753: OPT_TIME_LIMIT, or
+     OPT_CONVERGED when the constraints are satisfied).  On the device the clock is the constant-rate counter of the GPU and
+     starts at the first tmx_sqp_run / tmx_sqp_launch after tmx_batch_set_x0.  Default: no limit (DBL_MAX). */
+  double max_time;
 } tmx_sqp_params;
 
 /* OSQPSettings fields the reference touches — trajopt_sco/src/osqp_interface.cpp:78-90 (+ OSQP v1.0.0 defaults) */
@@ -320,6 +324,18 @@ TMX_API tmx_status tmx_sqp_qp_records(tmx_ctx* ctx, tmx_qp_record* out, int32_t 
    together with tmx_sqp_results / tmx_evaluate.  Any output pointer may be NULL.  done[b] = 1 once problem b finished. */
 TMX_API tmx_status tmx_sqp_state(tmx_ctx* ctx, int32_t* sqp_iter /*B*/, int32_t* merit_increases /*B*/,
                                  double* trust_box_size /*B*/, int32_t* done /*B*/);
+
+/* BasicTrustRegionSQPResults (trajopt_sco/include/trajopt_sco/optimizers.hpp:159-218; ::update optimizers.cpp:380-426): what the LAST
+   trust-region evaluation of every problem left for the reference's per-iteration table (::print :428-531) and log files
+   (:533-647).  out[b * stride + k], stride = TMX_STEP_LOG_HEAD + 3 * n_costs + 4 * n_cnts (returned in *stride_out):
+     k = 0 merit_increases, 1 sqp_iter, 2 trust box the QP was solved with, 3 old_merit, 4 model_merit, 5 new_merit,
+         6 approx_merit_improve, 7 exact_merit_improve, 8 merit_improve_ratio, 9 valid (1: a QP was solved and evaluated in that
+         step; 0: no step yet, or the QP solver failed), 10 .. TMX_STEP_LOG_HEAD-1 reserved;
+     then old_cost_vals[n_costs], model_cost_vals[n_costs], new_cost_vals[n_costs], old_cnt_viols[n_cnts],
+     model_cnt_viols[n_cnts], new_cnt_viols[n_cnts], merit_error_coeffs[n_cnts].
+   With tmx_sqp_run(max_steps = 1) between reads this is the reference's table, step by step.  out may be NULL (stride only). */
+#define TMX_STEP_LOG_HEAD 16
+TMX_API tmx_status tmx_sqp_step_log(tmx_ctx* ctx, double* out, int32_t* stride_out);
 
 /* ---- piecewise entry points (the hooks BasicTrustRegionSQP exposes "to allow overriding",
  *      optimizers.hpp:137-194): evaluateCosts/evaluateConstraintViols, convexify*, Model::optimize ---- */

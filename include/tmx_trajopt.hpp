@@ -219,8 +219,9 @@ inline const char* statusToString(OptStatus s)  // optimizers.cpp:33-50
   return names[std::min<std::size_t>(static_cast<std::size_t>(s), 5)];
 }
 
-/** optimizers.hpp:92-135 (same defaults).  max_time / log_results / num_threads have no meaning for a batched launch
-    and are not mirrored. */
+/** optimizers.hpp:92-135 (same defaults).  log_results / log_dir / num_threads have no meaning for a batched launch and are
+    not mirrored; max_time is the wall-clock limit of optimize() in seconds (optimizers.cpp:738-753), tested on the device
+    at the top of every SQP iteration. */
 struct BasicTrustRegionSQPParameters
 {
   double improve_ratio_threshold{ 0.25 };
@@ -237,6 +238,7 @@ struct BasicTrustRegionSQPParameters
   double initial_merit_error_coeff{ 10 };
   bool inflate_constraints_individually{ true };
   double trust_box_size{ 1e-1 };
+  double max_time{ std::numeric_limits<double>::max() };
 
   tmx_sqp_params toTmx() const
   {
@@ -255,6 +257,7 @@ struct BasicTrustRegionSQPParameters
     p.initial_merit_error_coeff = initial_merit_error_coeff;
     p.inflate_constraints_individually = inflate_constraints_individually ? 1 : 0;
     p.trust_box_size = trust_box_size;
+    p.max_time = max_time;
     return p;
   }
 };
@@ -853,6 +856,77 @@ inline TrajOptProb::Ptr ConstructProblem(const ProblemConstructionInfo& pci)
 
 namespace sco
 {
+/** optimizers.hpp:230-316 BasicTrustRegionSQPResults: what one trust-region evaluation (Model::optimize + exact re-evaluation)
+    leaves for the per-iteration table and the log writers.  Filled from tmx_sqp_step_log; model_var_vals / new_x are not
+    carried (new_x is OptResults::x after an accepted step). */
+struct BasicTrustRegionSQPResults
+{
+  std::size_t seed{ 0 };
+  int merit_increases{ 0 }, sqp_iter{ 0 };
+  double trust_box_size{ 0 };  ///< the box the QP of this evaluation was solved with
+  DblVec model_cost_vals, model_cnt_viols, new_cost_vals, old_cost_vals, new_cnt_viols, old_cnt_viols;
+  double old_merit{ 0 }, model_merit{ 0 }, new_merit{ 0 };
+  double approx_merit_improve{ 0 }, exact_merit_improve{ 0 }, merit_improve_ratio{ 0 };
+  std::vector<double> merit_error_coeffs;
+  std::vector<std::string> cost_names, cnt_names;
+
+  /** BasicTrustRegionSQPResults::print (optimizers.cpp:428-531), same columns and formats, into a stream */
+  void print(std::FILE* out = stdout) const
+  {
+    const std::string bar(88, '='), dash(88, '-');
+    std::fprintf(out, "\n| %s |\n", bar.c_str());
+    std::fprintf(out, "| %10s | %10s | %10s | %10s | %10s | %10s | %10s |\n", "merit", "oldexact", "new_exact", "new_approx", "dapprox", "dexact",
+                 "ratio");
+    std::fprintf(out, "| %s | COSTS\n", dash.c_str());
+    auto name = [](const std::vector<std::string>& n, std::size_t i) { return i < n.size() ? n[i].c_str() : ""; };
+    auto sum = [](const DblVec& v) {
+      double o = 0;
+      for (double x : v)
+        o += x;
+      return o;
+    };
+    for (std::size_t i = 0; i < old_cost_vals.size(); ++i)
+    {
+      const double approx_improve = old_cost_vals[i] - model_cost_vals[i];
+      const double exact_improve = old_cost_vals[i] - new_cost_vals[i];
+      if (std::fabs(approx_improve) > 1e-8)
+        std::fprintf(out, "| %10s | %10.3e | %10.3e | %10.3e | %10.3e | %10.3e | %10.3e | %-15s \n", "----------", old_cost_vals[i],
+                     new_cost_vals[i], model_cost_vals[i], approx_improve, exact_improve, exact_improve / approx_improve, name(cost_names, i));
+      else
+        std::fprintf(out, "| %10s | %10.3e | %10.3e | %10.3e | %10.3e | %10.3e | %10s | %-15s \n", "----------", old_cost_vals[i],
+                     new_cost_vals[i], model_cost_vals[i], approx_improve, exact_improve, "----------", name(cost_names, i));
+    }
+    std::fprintf(out, "| %s |\n", bar.c_str());
+    std::fprintf(out, "| %10s | %10.3e | %10.3e | %10.3e | %10s | %10s | %10s | SUM COSTS\n", "----------", sum(old_cost_vals),
+                 sum(new_cost_vals), sum(model_cost_vals), "----------", "----------", "----------");
+    std::fprintf(out, "| %s |\n", bar.c_str());
+    if (!old_cnt_viols.empty())
+    {
+      std::fprintf(out, "| %s | CONSTRAINTS\n", dash.c_str());
+      for (std::size_t i = 0; i < old_cnt_viols.size(); ++i)
+      {
+        const double approx_improve = old_cnt_viols[i] - model_cnt_viols[i];
+        const double exact_improve = old_cnt_viols[i] - new_cnt_viols[i];
+        const double mc = merit_error_coeffs[i];
+        if (std::fabs(approx_improve) > 1e-8)
+          std::fprintf(out, "| %10.3e | %10.3e | %10.3e | %10.3e | %10.3e | %10.3e | %10.3e | %-15s \n", mc, mc * old_cnt_viols[i],
+                       mc * new_cnt_viols[i], mc * model_cnt_viols[i], mc * approx_improve, mc * exact_improve, exact_improve / approx_improve,
+                       name(cnt_names, i));
+        else
+          std::fprintf(out, "| %10.3e | %10.3e | %10.3e | %10.3e | %10.3e | %10.3e | %10s | %-15s \n", mc, mc * old_cnt_viols[i],
+                       mc * new_cnt_viols[i], mc * model_cnt_viols[i], mc * approx_improve, mc * exact_improve, "----------", name(cnt_names, i));
+      }
+    }
+    std::fprintf(out, "| %s |\n", bar.c_str());
+    std::fprintf(out, "| %10s | %10.3e | %10.3e | %10.3e | %10s | %10s | %10s | SUM CONSTRAINTS (WITHOUT MERIT) \n", "----------",
+                 sum(old_cnt_viols), sum(new_cnt_viols), sum(model_cnt_viols), "----------", "----------", "----------");
+    std::fprintf(out, "| %s |\n", bar.c_str());
+    std::fprintf(out, "| %10s | %10.3e | %10.3e | %10s | %10.3e | %10.3e | %10.3e | TOTAL = SUM COSTS + SUM CONSTRAINTS (WITH MERIT)\n",
+                 "----------", old_merit, new_merit, "----------", approx_merit_improve, exact_merit_improve, merit_improve_ratio);
+    std::fprintf(out, "| %s |\n", bar.c_str());
+  }
+};
+
 /** Sibling of sco::BasicTrustRegionSQPMultiThreaded (optimizers.hpp:196-218): BasicTrustRegionSQP::optimize() for a batch
     of seeds on one MI355X.  Throws if no device is available — there is no CPU path behind it. */
 class BasicTrustRegionSQPBatchedHip
@@ -898,6 +972,10 @@ public:
       is stepped one trust-region evaluation per launch (tmx_sqp_run(max_steps = 1)) instead of running in the
       persistent kernel; the results are identical. */
   void addIterationCallback(const IterationCallback& cb) { iteration_callbacks_.push_back(cb); }
+  /** After EVERY trust-region evaluation of every seed: the BasicTrustRegionSQPResults the reference prints / logs per
+      iteration (optimizers.cpp:380-647).  Also puts the optimizer into the stepped mode. */
+  using ResultsCallback = std::function<void(const BasicTrustRegionSQPResults&)>;
+  void addResultsCallback(const ResultsCallback& cb) { results_callbacks_.push_back(cb); }
 
   /** Optimizer::initialize (optimizers.cpp:127-136): one seed, x in j_t_d order (row-major n_steps x n_dof) */
   void initialize(const DblVec& x) { initialize(std::vector<DblVec>{ x }); }
@@ -928,7 +1006,7 @@ public:
     const tmx_sqp_params p = param_.toTmx();
     check(tmx_problem_upload(ctx_, &prob_->desc(), &p, &osqp_));
     check(tmx_batch_set_x0(ctx_, seeds_.data(), batch_));
-    if (iteration_callbacks_.empty())
+    if (iteration_callbacks_.empty() && results_callbacks_.empty())
       check(tmx_sqp_run(ctx_, 0, nullptr));
     else
       runStepwise();
@@ -978,12 +1056,54 @@ private:
     std::vector<long long> seen(B, -1);
     std::vector<char> finished(B, 0);
     std::vector<double> x(B * nv), cost(B), trust(B);
-    std::vector<int32_t> status(B), nfe(B), nqp(B), it(B), mi(B), done(B);
+    std::vector<int32_t> status(B), nfe(B), nqp(B), it(B), mi(B), done(B), nqp_seen(B, 0);
     while (true)
     {
       check(tmx_sqp_results(ctx_, x.data(), status.data(), cost.data(), nfe.data(), nqp.data()));
       check(tmx_sqp_state(ctx_, it.data(), mi.data(), trust.data(), done.data()));
       check(tmx_term_counts(ctx_, &n_costs, &n_cnts, &n_slots));
+      if (!results_callbacks_.empty())
+      {
+        int32_t stride = 0;
+        check(tmx_sqp_step_log(ctx_, nullptr, &stride));
+        std::vector<double> lg(B * static_cast<std::size_t>(stride));
+        check(tmx_sqp_step_log(ctx_, lg.data(), &stride));
+        const std::size_t nc = static_cast<std::size_t>(n_costs), nv2 = static_cast<std::size_t>(n_cnts);
+        for (std::size_t b = 0; b < B; ++b)
+        {
+          const double* o = lg.data() + b * static_cast<std::size_t>(stride);
+          if (nqp[b] <= nqp_seen[b] || o[9] == 0.0)
+          {
+            nqp_seen[b] = nqp[b];
+            continue;
+          }
+          nqp_seen[b] = nqp[b];
+          BasicTrustRegionSQPResults r;
+          r.seed = b;
+          r.merit_increases = static_cast<int>(o[0]);
+          r.sqp_iter = static_cast<int>(o[1]);
+          r.trust_box_size = o[2];
+          r.old_merit = o[3];
+          r.model_merit = o[4];
+          r.new_merit = o[5];
+          r.approx_merit_improve = o[6];
+          r.exact_merit_improve = o[7];
+          r.merit_improve_ratio = o[8];
+          const double* q = o + TMX_STEP_LOG_HEAD;
+          r.old_cost_vals.assign(q, q + nc);
+          r.model_cost_vals.assign(q + nc, q + 2 * nc);
+          r.new_cost_vals.assign(q + 2 * nc, q + 3 * nc);
+          q += 3 * nc;
+          r.old_cnt_viols.assign(q, q + nv2);
+          r.model_cnt_viols.assign(q + nv2, q + 2 * nv2);
+          r.new_cnt_viols.assign(q + 2 * nv2, q + 3 * nv2);
+          r.merit_error_coeffs.assign(q + 3 * nv2, q + 4 * nv2);
+          r.cost_names = prob_->getCostNames();
+          r.cnt_names = prob_->getCntNames();
+          for (auto& cb : results_callbacks_)
+            cb(r);
+        }
+      }
       std::vector<double> cv(B * static_cast<std::size_t>(n_costs)), vv(B * static_cast<std::size_t>(n_cnts));
       check(tmx_evaluate(ctx_, cv.data(), vv.data()));
       bool all = true;
@@ -1043,6 +1163,7 @@ private:
   std::size_t best_{ 0 };
   std::vector<Callback> callbacks_;
   std::vector<IterationCallback> iteration_callbacks_;
+  std::vector<ResultsCallback> results_callbacks_;
 };
 
 /** trajToDblVec (trajopt/include/trajopt/utils.hpp:18): row-major flattening of a TrajArray */

@@ -389,7 +389,7 @@ inline ProblemConstructionInfo ProblemConstructionInfoFromJson(const json::Value
   if (bi.isMember("fixed_dofs"))
     for (const auto& e : bi["fixed_dofs"].arr)
       pci.basic_info.fixed_dofs.push_back(e.asInt());
-  // readOptInfo (:147-166): known keys override the defaults, unknown keys are ignored; max_time has no meaning here
+  // readOptInfo (:147-166): known keys override the defaults, unknown keys are ignored
   if (v.isMember("opt_info"))
   {
     sco::BasicTrustRegionSQPParameters& o = pci.opt_info;
@@ -423,6 +423,8 @@ inline ProblemConstructionInfo ProblemConstructionInfoFromJson(const json::Value
         o.inflate_constraints_individually = (val.kind == json::Value::BOOL) ? val.asBool() : (val.asDouble() != 0.0);
       else if (k == "trust_box_size")
         o.trust_box_size = val.asDouble();
+      else if (k == "max_time")
+        o.max_time = val.asDouble();
     }
   }
   if (v.isMember("costs"))

@@ -58,6 +58,7 @@ void toParams(const tmx_sqp_params* p, BasicTrustRegionSQPParameters& o)
   o.initial_merit_error_coeff = p->initial_merit_error_coeff;
   o.inflate_constraints_individually = p->inflate_constraints_individually != 0;
   o.trust_box_size = p->trust_box_size;
+  o.max_time = p->max_time;
 }
 void toRecord(const QpTrace& t, tmx_qp_record& r)
 {
@@ -132,6 +133,70 @@ int orc_sqp_batch(const tmx_problem_desc* desc, const tmx_sqp_params* sqp, const
   if (admm_iters_total)
     *admm_iters_total = admm_total;
   return err;
+}
+
+// One seed: BasicTrustRegionSQPResults of every trust-region evaluation of the run (sco.hpp StepLog), in the layout of
+// tmx_sqp_step_log (include/tmx.h): out[k * stride + ...], stride = TMX_STEP_LOG_HEAD + 3 n_costs + 4 n_cnts
+int orc_sqp_step_logs(const tmx_problem_desc* desc, const tmx_sqp_params* sqp, const tmx_osqp_settings* osqp, const double* x0,
+                      int max_steps, int stride, double* out, int* n_steps_out, int* n_costs_out, int* n_cnts_out, int* status_out)
+{
+  try
+  {
+    const int TD = desc->n_steps * desc->n_dof;
+    TrajProblem P = constructProblem(*desc, x0);
+    P.prob->getModel()->settings = toSettings(osqp);
+    BasicTrustRegionSQP opt(P.prob);
+    toParams(sqp, opt.getParameters());
+    const int nc = static_cast<int>(P.prob->getCosts().size()), nv = static_cast<int>(P.prob->getConstraints().size());
+    if (n_costs_out)
+      *n_costs_out = nc;
+    if (n_cnts_out)
+      *n_cnts_out = nv;
+    int k = 0;
+    opt.on_step = [&](const StepLog& lg) {
+      if (out && k < max_steps && stride >= TMX_STEP_LOG_HEAD + 3 * nc + 4 * nv)
+      {
+        double* o = out + static_cast<std::size_t>(k) * stride;
+        o[0] = lg.merit_increases;
+        o[1] = lg.sqp_iter;
+        o[2] = lg.box_size;
+        o[3] = lg.old_merit;
+        o[4] = lg.model_merit;
+        o[5] = lg.new_merit;
+        o[6] = lg.approx_merit_improve;
+        o[7] = lg.exact_merit_improve;
+        o[8] = lg.merit_improve_ratio;
+        o[9] = 1.0;
+        double* q = o + TMX_STEP_LOG_HEAD;
+        for (int i = 0; i < nc; ++i)
+        {
+          q[i] = lg.old_cost_vals[i];
+          q[nc + i] = lg.model_cost_vals[i];
+          q[2 * nc + i] = lg.new_cost_vals[i];
+        }
+        q += 3 * nc;
+        for (int i = 0; i < nv; ++i)
+        {
+          q[i] = lg.old_cnt_viols[i];
+          q[nv + i] = lg.model_cnt_viols[i];
+          q[2 * nv + i] = lg.new_cnt_viols[i];
+          q[3 * nv + i] = lg.merit_error_coeffs[i];
+        }
+      }
+      ++k;
+    };
+    opt.initialize(DblVec(x0, x0 + TD));
+    opt.optimize();
+    if (n_steps_out)
+      *n_steps_out = k;
+    if (status_out)
+      *status_out = static_cast<int>(opt.results().status);
+    return 0;
+  }
+  catch (...)
+  {
+    return 1;
+  }
 }
 
 // One seed: the polish active-set flags (-1 lower / +1 upper / 0) and the unscaled duals of EVERY Model::optimize() of the

@@ -69,6 +69,36 @@ def sqp_batch(desc, x0, sqp=None, osqp=None, nthreads=0, max_records=64):
                 n_qp_solves=nqp, records=recs, rec_counts=cnts, max_records=max_records, admm_iters=admm.value)
 
 
+def sqp_step_logs(desc, x0, sqp=None, osqp=None, max_steps=256):
+    """one seed: BasicTrustRegionSQPResults of every trust-region evaluation (optimizers.cpp:380-426), as a list of dicts
+    with the keys of trajopt_amd.runtime.Context.step_log()"""
+    from trajopt_amd import abi
+    x0 = np.ascontiguousarray(x0, np.float64)
+    nc, nv, n, st = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
+    rc = lib().orc_sqp_step_logs(C.byref(desc), C.byref(sqp) if sqp is not None else None, C.byref(osqp) if osqp is not None else None,
+                                 _p(x0), 0, 0, None, C.byref(n), C.byref(nc), C.byref(nv), C.byref(st))
+    if rc != 0:
+        raise RuntimeError("oracle sqp_step_logs failed")
+    nc, nv, H = nc.value, nv.value, abi.STEP_LOG_HEAD
+    stride = H + 3 * nc + 4 * nv
+    out = np.zeros((max_steps, stride))
+    rc = lib().orc_sqp_step_logs(C.byref(desc), C.byref(sqp) if sqp is not None else None, C.byref(osqp) if osqp is not None else None,
+                                 _p(x0), max_steps, stride, _p(out), C.byref(n), None, None, C.byref(st))
+    if rc != 0:
+        raise RuntimeError("oracle sqp_step_logs failed")
+    logs = []
+    for k in range(min(n.value, max_steps)):
+        o = out[k]
+        q = o[H:]
+        logs.append(dict(merit_increases=int(o[0]), sqp_iter=int(o[1]), box_size=float(o[2]), old_merit=float(o[3]), model_merit=float(o[4]),
+                         new_merit=float(o[5]), approx_merit_improve=float(o[6]), exact_merit_improve=float(o[7]),
+                         merit_improve_ratio=float(o[8]), valid=True,
+                         old_cost_vals=q[0:nc].copy(), model_cost_vals=q[nc:2 * nc].copy(), new_cost_vals=q[2 * nc:3 * nc].copy(),
+                         old_cnt_viols=q[3 * nc:3 * nc + nv].copy(), model_cnt_viols=q[3 * nc + nv:3 * nc + 2 * nv].copy(),
+                         new_cnt_viols=q[3 * nc + 2 * nv:3 * nc + 3 * nv].copy(), merit_error_coeffs=q[3 * nc + 3 * nv:3 * nc + 4 * nv].copy()))
+    return logs, n.value, st.value
+
+
 def sqp_active_sets(desc, x0, m_cap, sqp=None, osqp=None, max_qp=256):
     """one seed: per-QP polish active flags and duals of the whole SQP run -> list of (flags[m], y[m])"""
     x0 = np.ascontiguousarray(x0, np.float64)

@@ -10,6 +10,7 @@
 #pragma once
 #include <algorithm>
 #include <cassert>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -1393,6 +1394,17 @@ struct BasicTrustRegionSQPParameters
   double initial_merit_error_coeff = 10;
   bool inflate_constraints_individually = true;
   double trust_box_size = 1e-1;
+  double max_time = std::numeric_limits<double>::max();  // seconds (optimizers.hpp:117)
+};
+
+// BasicTrustRegionSQPResults (optimizers.hpp:159-218, filled by ::update optimizers.cpp:380-426): what one trust-region
+// evaluation leaves for the per-iteration table (::print :428-531) and the log files (:533-647)
+struct StepLog
+{
+  int merit_increases{ 0 }, sqp_iter{ 0 };
+  double box_size{ 0 };  // trust box the QP was solved with
+  DblVec old_cost_vals, model_cost_vals, new_cost_vals, old_cnt_viols, model_cnt_viols, new_cnt_viols, merit_error_coeffs;
+  double old_merit{ 0 }, model_merit{ 0 }, new_merit{ 0 }, approx_merit_improve{ 0 }, exact_merit_improve{ 0 }, merit_improve_ratio{ 0 };
 };
 
 struct OptResults
@@ -1435,8 +1447,9 @@ public:
   const OptResults& results() const { return results_; }
   const DblVec& x() const { return results_.x; }
   std::vector<double> merit_error_coeffs_final;
+  std::function<void(const StepLog&)> on_step;  // after every BasicTrustRegionSQPResults::update (what print() / the writers see)
 
-  // optimizers.cpp:699-991 (logging, callbacks and the wall-clock limit omitted)
+  // optimizers.cpp:699-991 (file logging and callbacks omitted; on_step receives what they would see)
   OptStatus optimize()
   {
     const auto constraints = prob_->getConstraints();
@@ -1446,12 +1459,25 @@ public:
       throw std::runtime_error("you forgot to initialize!");
     results_.x = prob_->getClosestFeasiblePoint(results_.x);
     OptStatus retval = INVALID;
+    using Clock = std::chrono::high_resolution_clock;
+    const auto start_time = Clock::now();
 
     for (int merit_increases = 0; merit_increases < param_.max_merit_coeff_increases; ++merit_increases)
     {
       bool goto_cleanup = false;
       for (int iter = 1;; ++iter)
       {
+        // wall-clock limit, tested at the top of every SQP iteration (:738-753).  On the very first pass cnt_viols is still
+        // empty (the first evaluation follows below), so an expired clock reports OPT_CONVERGED there - kept as written.
+        const double elapsed_time = std::chrono::duration<double, std::milli>(Clock::now() - start_time).count() / 1000.0;
+        if (elapsed_time > param_.max_time)
+        {
+          retval = OPT_TIME_LIMIT;
+          if (results_.cnt_viols.empty() || vecMax(results_.cnt_viols) < param_.cnt_tolerance)
+            retval = OPT_CONVERGED;
+          goto_cleanup = true;
+          break;
+        }
         if (results_.cost_vals.empty() && results_.cnt_viols.empty())
         {
           results_.cnt_viols = evaluateConstraintViols(constraints, results_.x);
@@ -1522,6 +1548,27 @@ public:
           const double exact_merit_improve = old_merit - new_merit;
           const double merit_improve_ratio = exact_merit_improve / approx_merit_improve;
           ++results_.n_func_evals;
+          if (on_step)
+          {
+            StepLog lg;
+            lg.merit_increases = merit_increases;
+            lg.sqp_iter = iter;
+            lg.box_size = param_.trust_box_size;
+            lg.old_cost_vals = results_.cost_vals;
+            lg.model_cost_vals = model_cost_vals;
+            lg.new_cost_vals = new_cost_vals;
+            lg.old_cnt_viols = results_.cnt_viols;
+            lg.model_cnt_viols = model_cnt_viols;
+            lg.new_cnt_viols = new_cnt_viols;
+            lg.merit_error_coeffs = merit_error_coeffs;
+            lg.old_merit = old_merit;
+            lg.model_merit = model_merit;
+            lg.new_merit = new_merit;
+            lg.approx_merit_improve = approx_merit_improve;
+            lg.exact_merit_improve = exact_merit_improve;
+            lg.merit_improve_ratio = merit_improve_ratio;
+            on_step(lg);
+          }
 
           if (approx_merit_improve < param_.min_approx_improve)
           {

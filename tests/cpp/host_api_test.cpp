@@ -274,6 +274,36 @@ static void caseCfg0(const Input& in)
     EXPECT_TRUE(stepped.batchResults()[b].x == opt.batchResults()[b].x);
     EXPECT_TRUE(stepped.batchResults()[b].n_qp_solves == opt.batchResults()[b].n_qp_solves);
   }
+  // BasicTrustRegionSQPResults after every trust-region evaluation (optimizers.cpp:380-531): one per QP solve, the identities
+  // of ::update hold, and print() writes the reference's table
+  BasicTrustRegionSQPBatchedHip logged(prob);
+  std::vector<int> n_steps(seeds.size(), 0);
+  std::string first_table;
+  logged.addResultsCallback([&](const tmx::sco::BasicTrustRegionSQPResults& r) {
+    ++n_steps[r.seed];
+    EXPECT_TRUE(r.old_cost_vals.size() == 1 && r.model_cost_vals.size() == 1 && r.new_cnt_viols.size() == 1 && r.merit_error_coeffs.size() == 1);
+    EXPECT_TRUE(std::fabs(r.approx_merit_improve - (r.old_merit - r.model_merit)) < 1e-12);
+    EXPECT_TRUE(std::fabs(r.exact_merit_improve - (r.old_merit - r.new_merit)) < 1e-12);
+    EXPECT_TRUE(std::fabs(r.old_merit - (r.old_cost_vals[0] + r.merit_error_coeffs[0] * r.old_cnt_viols[0])) < 1e-9 * std::max(1.0, std::fabs(r.old_merit)));
+    if (first_table.empty())
+    {
+      char* buf = nullptr;
+      std::size_t len = 0;
+      std::FILE* mem = open_memstream(&buf, &len);
+      r.print(mem);
+      std::fclose(mem);
+      first_table.assign(buf, len);
+      std::free(buf);
+    }
+  });
+  logged.initialize(seeds);
+  logged.optimize();
+  for (std::size_t b = 0; b < seeds.size(); ++b)
+  {
+    EXPECT_TRUE(n_steps[b] == logged.batchResults()[b].n_qp_solves);
+    EXPECT_TRUE(logged.batchResults()[b].x == opt.batchResults()[b].x);
+  }
+  EXPECT_TRUE(first_table.find("dapprox") != std::string::npos && first_table.find("TOTAL = SUM COSTS + SUM CONSTRAINTS (WITH MERIT)") != std::string::npos);
 }
 
 // ---- config 1: glass_upright (SURVEY.md §8d cfg 1) with a handful of seeds -------------------------------------------

@@ -96,3 +96,107 @@ def test_iteration_log_table_and_csv(hostemu_lib):
     lines = buf.getvalue().strip().splitlines()
     assert lines[0].startswith("seed,merit_increases,sqp_iter,trust_box_size") and lines[0].endswith("joint_vel,joint_pos_goal")
     assert len(lines) == 1 + len(log.rows)
+
+
+# ---- the per-iteration table against the ORACLE (BasicTrustRegionSQPResults::update / ::print, optimizers.cpp:380-531) ------------
+def _step_tables(lib_path, orc, cid, B, tol):
+    """device: one step per launch, tmx_sqp_step_log after each; oracle: the same record from its own optimize().  Every
+    evaluation of every seed must show the reference's columns: old / model / new values per cost and constraint, the merit
+    coefficients, the three merits, dapprox, dexact and ratio - and in the same (merit_increases, sqp_iter, trust box) slots."""
+    import parity_checks as pc
+    from trajopt_amd.iteration_log import StepTable
+    pci, s, g = pc.cfg(cid)
+    x0 = configs.seeds_for(cid, pci, s, g, B)
+    opt = runtime.BatchedTrustRegionSQP(pci, lib_path=lib_path)
+    tab = StepTable(pci.cost_names(), pci.cnt_names())
+    opt.addStepCallback(tab)
+    opt.initialize(x0)
+    opt.optimize()
+    res = opt.results()
+    desc = opt.desc
+    worst = 0.0
+    for b in range(B):
+        dev = tab.of(b)
+        ol, n_steps, st = orc.sqp_step_logs(desc, x0[b])
+        assert st == res["status"][b]
+        n = min(len(dev), len(ol))
+        assert n >= 1
+        if res["n_qp_solves"][b] == n_steps:
+            assert len(dev) == n_steps, (len(dev), n_steps)
+        for k in range(n):
+            d, o = dev[k], ol[k]
+            if (d["merit_increases"], d["sqp_iter"]) != (o["merit_increases"], o["sqp_iter"]) or abs(d["box_size"] - o["box_size"]) > 1e-12:
+                assert cid != 0, "config 0 follows the oracle exactly"
+                break   # the two runs parted (an accept / reject decision on round-off): histories are compared elsewhere
+            for key in ("old_cost_vals", "model_cost_vals", "new_cost_vals", "old_cnt_viols", "model_cnt_viols", "new_cnt_viols", "merit_error_coeffs"):
+                assert d[key].shape == o[key].shape
+                scale = max(1.0, float(np.abs(o[key]).max(initial=0.0)))
+                worst = max(worst, float(np.abs(d[key] - o[key]).max(initial=0.0)) / scale)
+            for key in ("old_merit", "model_merit", "new_merit", "approx_merit_improve", "exact_merit_improve"):
+                worst = max(worst, abs(d[key] - o[key]) / max(1.0, abs(o[key])))
+            if abs(o["approx_merit_improve"]) > 1e-6:
+                worst = max(worst, abs(d["merit_improve_ratio"] - o["merit_improve_ratio"]) / max(1.0, abs(o["merit_improve_ratio"])))
+            assert worst <= tol, (b, k, worst)
+        # the table itself: the reference's layout
+        txt = StepTable.format_step(dev[0], pci.cost_names(), pci.cnt_names())
+        assert "dapprox" in txt and "ratio" in txt and "TOTAL = SUM COSTS + SUM CONSTRAINTS (WITH MERIT)" in txt
+        assert txt == StepTable.format_step(ol[0], pci.cost_names(), pci.cnt_names()) or worst > 0.0
+    opt.ctx.close()
+    return worst
+
+
+@pytest.mark.parametrize("cid", [0, 1, 9])
+def test_step_table_matches_oracle_on_host_build(hostemu_lib, orc, cid):
+    _step_tables(hostemu_lib, orc, cid, 2, 1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cid", [0, 1])
+def test_step_table_matches_oracle_on_device(orc, cid):
+    worst = _step_tables(None, orc, cid, 4, 1e-6)
+    print("worst relative difference of a table entry:", worst)
+
+
+def _max_time(lib_path, orc):
+    """sqp.max_time (optimizers.cpp:738-753).  max_time = 0 is deterministic: the clock has expired at the first test, where
+    the reference's cnt_viols is still empty - OPT_CONVERGED, no QP solved, total_cost = sum of nothing, x = the feasibility-
+    clamped seed; the oracle does the same.  A limit of 2 ms stops a config-1 batch early with TIME_LIMIT / CONVERGED only."""
+    pci, s, g = configs.config1()
+    x0 = configs.seeds_for(1, pci, s, g, 4)
+    sp = abi.default_sqp_params()
+    sp.max_time = 0.0
+    ctx = runtime.Context(0, lib_path)
+    desc = pci.to_desc()
+    ctx.upload(desc, sp, abi.default_osqp_settings())
+    ctx.set_x0(x0)
+    assert ctx.run(0) == 0
+    r = ctx.results()
+    o = orc.sqp_batch(desc, x0, sqp=sp)
+    assert (r["status"] == abi.OPT_CONVERGED).all() and (o["status"] == abi.OPT_CONVERGED).all()
+    assert (r["n_qp_solves"] == 0).all() and (o["n_qp_solves"] == 0).all()
+    assert (r["total_cost"] == 0.0).all() and (o["total_cost"] == 0.0).all()
+    assert np.array_equal(r["x"], o["x"])
+    full = abi.default_sqp_params()
+    ctx.upload(desc, full, abi.default_osqp_settings())
+    ctx.set_x0(x0)
+    ctx.run(0)
+    nq_full = ctx.results()["n_qp_solves"]
+    sp.max_time = 2e-3
+    ctx.upload(desc, sp, abi.default_osqp_settings())
+    ctx.set_x0(x0)
+    assert ctx.run(0) == 0
+    r2 = ctx.results()
+    assert set(np.unique(r2["status"])) <= {abi.OPT_TIME_LIMIT, abi.OPT_CONVERGED}
+    assert (r2["n_qp_solves"] <= nq_full).all()
+    ctx.close()
+    return r2, nq_full
+
+
+def test_max_time_on_host_build(hostemu_lib, orc):
+    _max_time(hostemu_lib, orc)
+
+
+@pytest.mark.gpu
+def test_max_time_on_device(orc):
+    r2, nq_full = _max_time(None, orc)
+    assert (r2["status"] == abi.OPT_TIME_LIMIT).any() and (r2["n_qp_solves"] < nq_full).any()   # 2 ms: nothing of config 1 finishes

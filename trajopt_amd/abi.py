@@ -109,6 +109,9 @@ class ProblemDesc(C.Structure):
     ]
 
 
+STEP_LOG_HEAD = 16   # TMX_STEP_LOG_HEAD (include/tmx.h, tmx_sqp_step_log)
+
+
 class SqpParams(C.Structure):
     _fields_ = [
         ("improve_ratio_threshold", C.c_double),
@@ -126,6 +129,7 @@ class SqpParams(C.Structure):
         ("inflate_constraints_individually", C.c_int32),
         ("pad_", C.c_int32),
         ("trust_box_size", C.c_double),
+        ("max_time", C.c_double),
     ]
 
 
@@ -173,6 +177,7 @@ def default_sqp_params():
     p.initial_merit_error_coeff = 10
     p.inflate_constraints_individually = 1
     p.trust_box_size = 1e-1
+    p.max_time = 1.7976931348623157e308   # std::numeric_limits<double>::max(): no wall-clock limit (optimizers.hpp:117)
     return p
 
 

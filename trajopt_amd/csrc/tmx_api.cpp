@@ -3,6 +3,7 @@
 // the batched SQP (convexify -> QP solve -> exact re-evaluation -> decisions) as a short chain of kernel launches per
 // trust-region evaluation on one HIP stream; the host only reads back one "problems still running" counter.
 #include <algorithm>
+#include <limits>
 #include <string>
 #include <vector>
 
@@ -51,6 +52,7 @@ struct tmx_ctx
   long long launches_admm{ 0 };
   bool timing{ true };
   int pending{ 0 };  // a tmx_sqp_launch() not yet collected by tmx_sqp_wait()
+  bool clock_started{ false };  // k_mark_start ran since the last tmx_batch_set_x0 (start of optimize(): sqp.max_time)
   long long pool_relaunches{ 0 };  // times tmx_sqp_wait had to restart the pool (expected: 0)
   int* h_tail{ nullptr };  // pinned, device-mapped word: 1 once the pool kernel of the pending launch has begun to retire workgroups
   bool ws_in_hbm{ false };  // QP workspace > 160 KB of LDS: k_*_hbm kernels, workspace carved in HBM (long horizons)
@@ -135,6 +137,7 @@ void tmx_default_sqp_params(tmx_sqp_params* p)
   p->inflate_constraints_individually = 1;
   p->pad_ = 0;
   p->trust_box_size = 1e-1;
+  p->max_time = std::numeric_limits<double>::max();
 }
 
 void tmx_default_osqp_settings(tmx_osqp_settings* s)
@@ -1050,6 +1053,9 @@ static tmx_status ensure_batch(tmx_ctx* ctx, int B)
   AL(prof, b * 16);
   AL(sched_state, b);
   AL(sched_done, 1);
+  H.step_log_stride = TMX_STEP_LOG_HEAD + 3 * P.n_costs + 4 * P.n_cnts;
+  AL(step_log, b * (size_t)H.step_log_stride);
+  AL(t_start, 1);
   H.tail_flag = ctx->h_tail;  // pinned host memory is device-accessible at the same address (unified addressing)
   H.qp_scratch_stride = (long long)qp_scratch_doubles(P.D, P.T, P.R, P.NA, P.n_link, P.coef_far);
   AL(qp_scratch, b * (size_t)H.qp_scratch_stride);
@@ -1071,6 +1077,7 @@ static tmx_status ensure_batch(tmx_ctx* ctx, int B)
 
 static tmx_status prepare_batch(tmx_ctx* ctx)
 {
+  ctx->clock_started = false;  // Optimizer::initialize: the next run / launch starts optimize() and its clock
   TMX_LAUNCH(k_prepare, ctx->hb.B, ctx->nt_small, ctx->smem_small, ctx->stream, ctx->dp, ctx->db);
   HIPCHK(hipGetLastError());
   return TMX_OK;
@@ -1149,6 +1156,11 @@ tmx_status tmx_sqp_launch(tmx_ctx* ctx)
   // only the pool kernel reports the start of its tail; the one-workgroup-per-problem kernels free CUs from their first
   // finished problem on, so for them the next batch may be enqueued at once
   *ctx->h_tail = (!ctx->ws_in_hbm && ctx->mode == 2) ? 0 : 1;
+  if (!ctx->clock_started)
+  {
+    TMX_LAUNCH(k_mark_start, 1, 64, 0, ctx->stream, ctx->db);
+    ctx->clock_started = true;
+  }
   if (ctx->timing)
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
   if (ctx->ws_in_hbm)
@@ -1238,6 +1250,14 @@ tmx_status tmx_sqp_run(tmx_ctx* ctx, int32_t max_steps, int32_t* n_active_out)
       tmx_status rc = tmx_sqp_launch(ctx);
       return rc != TMX_OK ? rc : tmx_sqp_wait(ctx, n_active_out);
     }
+  }
+  if (!ctx->clock_started)
+  {
+    TMX_LAUNCH(k_mark_start, 1, 64, 0, ctx->stream, ctx->db);
+    ctx->clock_started = true;
+  }
+  if (ctx->mode != 0)
+  {
     if (ctx->ws_in_hbm)
       TIMED(ctx->ms_admm, ctx->launches_admm++,
             TMX_LAUNCH(k_sqp_fused_hbm, B, ctx->nt_qp > 1 ? TMX_HBM_NT : 1, ctx->smem_chain, ctx->stream, ctx->dp, ctx->db, (int)max_steps));
@@ -1343,6 +1363,23 @@ tmx_status tmx_sqp_state(tmx_ctx* ctx, int32_t* sqp_iter, int32_t* merit_increas
   if (done)
     for (size_t b = 0; b < B; ++b)
       done[b] = phase[b] == PHASE_DONE ? 1 : 0;
+  return TMX_OK;
+}
+
+tmx_status tmx_sqp_step_log(tmx_ctx* ctx, double* out, int32_t* stride_out)
+{
+  if (!ctx)
+    return TMX_ERR_INVALID;
+  if (ctx->Bcap == 0)
+    return TMX_ERR_STATE;
+  TMX_REFUSE_WHILE_PENDING(ctx);
+  HIPCHK(hipSetDevice(ctx->device));
+  if (stride_out)
+    *stride_out = ctx->hb.step_log_stride;
+  tmx_status rc = d2h(ctx, out, ctx->hb.step_log, (size_t)ctx->hb.B * (size_t)ctx->hb.step_log_stride);
+  if (rc != TMX_OK)
+    return rc;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
   return TMX_OK;
 }
 

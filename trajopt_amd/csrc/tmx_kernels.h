@@ -50,6 +50,8 @@ TMX_KERNEL_LB(256) k_prepare(const DevProblem* P, const DevBatch* Bt)
     for (int q = 0; q < 16; ++q)
       Bt->prof[(size_t)b * 16 + q] = 0;
     Bt->solver_init[b] = 0;
+    for (int q = 0; q < TMX_STEP_LOG_HEAD; ++q)
+      Bt->step_log[(size_t)b * Bt->step_log_stride + q] = 0.0;
     if (P->flavor == 1)
     {
       // TrustRegionSQPSolver::init (trust_region_sqp_solver.cpp:45-64): no feasibility projection of the start point, box =
@@ -93,6 +95,12 @@ TMX_KERNEL_LB(256) k_convexify(const DevProblem* P, const DevBatch* Bt, int forc
   TMX_SMEM(smem_lds);
   double* smem = TMX_WORK(smem_lds, Bt);
   const int b = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
+  if (!force && P->sqp.max_time < 1e300)
+  {
+    if (tid == 0)
+      sqp_time_limit_check(P, Bt, b);
+    TMX_SYNC();
+  }
   if (!force && Bt->phase[b] != PHASE_CONVEXIFY)
     return;
   const int R = P->R, D = P->D;
@@ -169,6 +177,14 @@ TMX_DEVFN void sqp_step_block(const DevProblem* P, const DevBatch* Bt, int b, do
   long long tp0 = TMX_CLK();
   const long long wall0 = wall_clock64();  // constant 100 MHz: s_memtime / wall = effective shader clock
 #endif
+  if (P->sqp.max_time < 1e300)  // (uniform; the default is no limit)
+  {
+    if (tid == 0)
+      sqp_time_limit_check(P, Bt, b);
+    TMX_SYNC();
+    if (Bt->phase[b] == PHASE_DONE)
+      return;
+  }
   if (Bt->phase[b] == PHASE_CONVEXIFY)
   {
     convexify_terms(P, x, act, coef, Bt->coef2 + (size_t)b * P->n_link * D, rhs, smem, tid, NT, Bt->rowc + (size_t)b * R, Bt->qdyn + (size_t)b * NX);
@@ -432,6 +448,13 @@ TMX_KERNEL k_detmath(int op, int n, const double* a, const double* b, double* ou
   const int i0 = threadIdx.x + blockIdx.x * blockDim.x, stride = blockDim.x * gridDim.x;
   for (int i = i0; i < n; i += stride)
     out[i] = (op == 0) ? tmx_sin(a[i]) : (op == 1) ? tmx_cos(a[i]) : tmx_atan2(a[i], b[i]);
+}
+
+// start of optimize(): reference point of the wall-clock limit sqp.max_time
+TMX_KERNEL k_mark_start(const DevBatch* Bt)
+{
+  if (threadIdx.x == 0 && blockIdx.x == 0)
+    *Bt->t_start = tmx_wall_ticks();
 }
 
 // scheduler words of the pool from the problem phases (one workgroup): ready unless DONE

@@ -31,6 +31,12 @@ extern thread_local double* tmx_emu_smem;
 #define TMX_SMEM(name) double* name = tmx_emu_smem
 #define TMX_SYNC() ((void)0)
 #define TMX_IS_DEVICE 0
+#include <chrono>
+// constant-rate clock in 10 ns ticks (the device's wall_clock64 counts at 100 MHz)
+static inline long long tmx_wall_ticks()
+{
+  return (long long)(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() / 10);
+}
 
 typedef int hipError_t;
 typedef void* hipStream_t;
@@ -107,6 +113,8 @@ static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t
 #define TMX_SMEM(name) extern __shared__ __attribute__((aligned(16))) double name[]
 #define TMX_SYNC() __syncthreads()
 #define TMX_IS_DEVICE 1
+// constant-rate clock in 10 ns ticks (s_memrealtime: 100 MHz on gfx950, independent of the shader clock)
+__device__ static inline long long tmx_wall_ticks() { return (long long)wall_clock64(); }
 #define TMX_LAUNCH(kernel, grid, block, smem_bytes, stream, ...)                                                      \
   hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), (size_t)(smem_bytes), stream, __VA_ARGS__)
 #endif

@@ -1568,28 +1568,87 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// BasicTrustRegionSQPResults of one trust-region evaluation -> Bt->step_log (thread 0; layout: include/tmx.h tmx_sqp_step_log)
+// ---------------------------------------------------------------------------------------------------------
+TMX_DEVFN void step_log_write(const DevProblem* P, const DevBatch* Bt, int b, int valid, double box, const double* old_cost,
+                              const double* model_cost, const double* new_cost, const double* old_viol, const double* model_viol,
+                              const double* new_viol, const double* merit, double old_merit, double model_merit, double new_merit,
+                              double approx, double exact, double ratio)
+{
+  double* o = Bt->step_log + (size_t)b * Bt->step_log_stride;
+  o[0] = (double)Bt->merit_inc[b];
+  o[1] = (double)Bt->iter[b];
+  o[2] = box;
+  o[3] = old_merit;
+  o[4] = model_merit;
+  o[5] = new_merit;
+  o[6] = approx;
+  o[7] = exact;
+  o[8] = ratio;
+  o[9] = (double)valid;
+  if (!valid)
+    return;
+  double* q = o + TMX_STEP_LOG_HEAD;
+  const int nc = P->n_costs, nv = P->n_cnts;
+  for (int k = 0; k < nc; ++k)
+  {
+    q[k] = old_cost[k];
+    q[nc + k] = model_cost[k];
+    q[2 * nc + k] = new_cost[k];
+  }
+  q += 3 * nc;
+  for (int k = 0; k < nv; ++k)
+  {
+    q[k] = old_viol[k];
+    q[nv + k] = model_viol[k];
+    q[2 * nv + k] = new_viol[k];
+    q[3 * nv + k] = merit[k];
+  }
+}
+
+// Wall-clock limit of BasicTrustRegionSQP::optimize (optimizers.cpp:738-753), tested by thread 0 at the top of an SQP
+// iteration (phase CONVEXIFY): OPT_TIME_LIMIT, or OPT_CONVERGED when the constraint violations are within tolerance - and, as
+// in the reference, also on the very first pass, where results_.cnt_viols is still EMPTY (the first evaluation comes after the
+// test) and total_cost is the sum of an empty vector.
+TMX_DEVFN void sqp_time_limit_check(const DevProblem* P, const DevBatch* Bt, int b)
+{
+  if (Bt->phase[b] != PHASE_CONVEXIFY || P->flavor == 1)
+    return;
+  const double elapsed = (double)(tmx_wall_ticks() - *Bt->t_start) * 1e-8;
+  if (!(elapsed > P->sqp.max_time))
+    return;
+  const bool first = Bt->n_qp[b] == 0 && Bt->iter[b] == 1 && Bt->merit_inc[b] == 0;
+  const double* cnt_viols = Bt->cnt_viols + (size_t)b * P->n_cnts;
+  const double* cost_vals = Bt->cost_vals + (size_t)b * P->n_costs;
+  double vmax = -1e300, tot = 0.0;
+  for (int k = 0; k < P->n_cnts; ++k)
+    vmax = fmax(vmax, cnt_viols[k]);
+  for (int k = 0; k < P->n_costs; ++k)
+    tot += cost_vals[k];
+  const bool ok = first || P->n_cnts == 0 || vmax < P->sqp.cnt_tolerance;
+  const int retval = ok ? TMX_OPT_CONVERGED : TMX_OPT_TIME_LIMIT;
+  Bt->status[b] = retval;
+  Bt->retval[b] = retval;
+  Bt->total_cost[b] = first ? 0.0 : tot;
+  Bt->phase[b] = PHASE_DONE;
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // BasicTrustRegionSQP decision step after a QP solve + exact re-evaluation at new_x
 // (BasicTrustRegionSQPResults::update + the trust-region / penalty logic, optimizers.cpp:380-426, 810-968)
 // ---------------------------------------------------------------------------------------------------------
-TMX_DEVFN void sqp_update_block(const DevProblem* P, const DevBatch* Bt, int b, double* smem, int tid, int NT)
+// Model values at QP variables xq (reference order): ConvexObjective::value / ConvexConstraints::violation of every cost /
+// constraint of the current convexification (BasicTrustRegionSQP::evaluateModelCosts / evaluateModelCntViols,
+// optimizers.hpp:176-178; ::update optimizers.cpp:391-396), in parallel: per-slot values and velocity terms by all threads, then
+// one thread per owner sums its slots in slot order.  Results: smem[0 .. n_costs) costs, smem[n_costs .. n_costs + n_cnts) violations.
+TMX_DEVFN void sqp_model_values(const DevProblem* P, const DevBatch* Bt, int b, const double* xq, double* smem, int tid, int NT)
 {
   const int D = P->D, NX = P->NX, R = P->R;
-  const tmx_sqp_params& sp = P->sqp;
   double* model_cost = smem;                   // n_costs
   double* model_viol = model_cost + P->n_costs;  // n_cnts
-  const double* xq = Bt->xq + (size_t)b * P->n_max;
   const int* act = Bt->active + (size_t)b * R;
   const double* coef = Bt->coef + (size_t)b * R * D;
   const double* rhs = Bt->rhs + (size_t)b * R;
-  double* cost_vals = Bt->cost_vals + (size_t)b * P->n_costs;
-  double* cnt_viols = Bt->cnt_viols + (size_t)b * P->n_cnts;
-  const double* new_cost = Bt->new_cost_vals + (size_t)b * P->n_costs;
-  const double* new_viol = Bt->new_cnt_viols + (size_t)b * P->n_cnts;
-  double* merit = Bt->merit + (size_t)b * P->n_cnts;
-  // ---- model values at the QP solution: ConvexObjective::value / ConvexConstraints::violation, in parallel -------
-  // (per-slot values and velocity terms by all threads, then one thread per owner sums its slots in slot order)
-  const bool solved = Bt->cvx[b] == TMX_CVX_SOLVED && Bt->phase[b] != PHASE_DONE;
-  if (solved)
   {
     double* val = model_viol + P->n_cnts;  // R
     int* keys = reinterpret_cast<int*>(val + R);
@@ -1674,6 +1733,23 @@ TMX_DEVFN void sqp_update_block(const DevProblem* P, const DevBatch* Bt, int b, 
     }
     TMX_SYNC();
   }
+}
+
+TMX_DEVFN void sqp_update_block(const DevProblem* P, const DevBatch* Bt, int b, double* smem, int tid, int NT)
+{
+  const int NX = P->NX;
+  const tmx_sqp_params& sp = P->sqp;
+  double* model_cost = smem;                   // n_costs
+  double* model_viol = model_cost + P->n_costs;  // n_cnts
+  double* cost_vals = Bt->cost_vals + (size_t)b * P->n_costs;
+  double* cnt_viols = Bt->cnt_viols + (size_t)b * P->n_cnts;
+  const double* new_cost = Bt->new_cost_vals + (size_t)b * P->n_costs;
+  const double* new_viol = Bt->new_cnt_viols + (size_t)b * P->n_cnts;
+  double* merit = Bt->merit + (size_t)b * P->n_cnts;
+  // ---- model values at the QP solution
+  const bool solved = Bt->cvx[b] == TMX_CVX_SOLVED && Bt->phase[b] != PHASE_DONE;
+  if (solved)
+    sqp_model_values(P, Bt, b, Bt->xq + (size_t)b * P->n_max, smem, tid, NT);
   if (tid != 0)
     return;  // the decisions are serial per problem (O(terms))
   int phase = Bt->phase[b];
@@ -1691,6 +1767,7 @@ TMX_DEVFN void sqp_update_block(const DevProblem* P, const DevBatch* Bt, int b, 
   Bt->n_qp[b] += 1;
   if (Bt->cvx[b] != TMX_CVX_SOLVED)
   {
+    step_log_write(P, Bt, b, 0, box, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0);
     if (Bt->qp_fail[b] < sp.max_qp_solver_failures - 1)
     {
       box *= sp.trust_shrink_ratio;
@@ -1732,6 +1809,8 @@ TMX_DEVFN void sqp_update_block(const DevProblem* P, const DevBatch* Bt, int b, 
     const double exact = old_merit - new_merit;
     const double ratio = exact / approx;
     Bt->n_fe[b] += 1;
+    step_log_write(P, Bt, b, 1, box, cost_vals, model_cost, new_cost, cnt_viols, model_viol, new_viol, merit, old_merit, model_merit, new_merit,
+                   approx, exact, ratio);
     if (approx < sp.min_approx_improve)
     {
       retval = TMX_OPT_CONVERGED;
@@ -2054,6 +2133,8 @@ TMX_DEVFN void sqp2_update_block(const DevProblem* P, const DevBatch* Bt, int b,
     const double approx = best_exact - new_approx, exact = best_exact - new_exact;
     const double ratio = (fabs(approx) < 1e-12) ? 0.0 : exact / approx;
     Bt->n_fe[b] += 1;
+    step_log_write(P, Bt, b, 1, box, cost_vals, model_cost, new_cost, cnt_viols, model_viol, new_viol, merit, best_exact, new_approx, new_exact,
+                   approx, exact, ratio);
     if (approx < sp.min_approx_improve)
     {
       st = TMX_SQP_CONVERGED;

@@ -116,6 +116,10 @@ struct DevBatch
   double *ws_hbm;
   long long ws_hbm_stride;
   int ws_chain_in_lds;  // the k_*_hbm launch carries qp_chain_lds_doubles() of dynamic LDS for the block chain
+  // BasicTrustRegionSQPResults of the last trust-region evaluation of every problem (tmx_sqp_step_log, layout in include/tmx.h)
+  double *step_log;
+  int step_log_stride;
+  long long *t_start;  // 1: constant-rate clock (100 MHz ticks) at the start of optimize(): reference point of sqp.max_time
 };
 
 // The ADMM loop of the dense fast path as separately compiled device functions (tmx_solve.h: qp_admm_fast_nl /

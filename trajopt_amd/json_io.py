@@ -120,8 +120,6 @@ def construct_problem(text_or_dict, env: Environment) -> ParsedProblem:
     for k, val in v.get("opt_info", {}).items():
         if k not in _OPT_INFO_KEYS:
             continue   # readOptInfo ignores unknown keys (childFromJson with defaults only)
-        if k == "max_time":
-            continue   # wall-clock limit: not meaningful for a batched launch
         setattr(sp, k, type(getattr(sp, k))(val))
 
     def read_term(it: dict, is_cost: bool):

@@ -48,6 +48,7 @@ _SIGS = {
     "tmx_kernel_stats": ([C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)], C.c_int),
     "tmx_kernel_stats_reset": ([C.c_void_p], C.c_int),
     "tmx_sqp_state": ([C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p], C.c_int),
+    "tmx_sqp_step_log": ([C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)], C.c_int),
 }
 ABI_SYMBOLS = tuple(_SIGS.keys())
 
@@ -160,6 +161,26 @@ class Context:
         trust = np.zeros(B)
         self._chk(self.lib.tmx_sqp_state(self.h, _ptr(it), _ptr(mi), _ptr(trust), _ptr(done)))
         return dict(sqp_iter=it, merit_increases=mi, trust_box_size=trust, done=done.astype(bool))
+
+    def step_log(self):
+        """BasicTrustRegionSQPResults of the last trust-region evaluation of every problem (tmx_sqp_step_log): the columns of
+        the reference's per-iteration table (optimizers.cpp:428-531).  Returns a list of dicts, one per problem."""
+        stride = C.c_int32(0)
+        self._chk(self.lib.tmx_sqp_step_log(self.h, None, C.byref(stride)))
+        out = np.zeros((self.B, stride.value))
+        self._chk(self.lib.tmx_sqp_step_log(self.h, _ptr(out), C.byref(stride)))
+        nc, nv, H = self.n_costs, self.n_cnts, abi.STEP_LOG_HEAD
+        logs = []
+        for b in range(self.B):
+            o = out[b]
+            q = o[H:]
+            logs.append(dict(merit_increases=int(o[0]), sqp_iter=int(o[1]), box_size=float(o[2]), old_merit=float(o[3]), model_merit=float(o[4]),
+                             new_merit=float(o[5]), approx_merit_improve=float(o[6]), exact_merit_improve=float(o[7]),
+                             merit_improve_ratio=float(o[8]), valid=bool(o[9]),
+                             old_cost_vals=q[0:nc].copy(), model_cost_vals=q[nc:2 * nc].copy(), new_cost_vals=q[2 * nc:3 * nc].copy(),
+                             old_cnt_viols=q[3 * nc:3 * nc + nv].copy(), model_cnt_viols=q[3 * nc + nv:3 * nc + 2 * nv].copy(),
+                             new_cnt_viols=q[3 * nc + 2 * nv:3 * nc + 3 * nv].copy(), merit_error_coeffs=q[3 * nc + 3 * nv:3 * nc + 4 * nv].copy()))
+        return logs
 
     def counters(self):
         a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
@@ -291,6 +312,7 @@ class BatchedTrustRegionSQP:
         self.osqp = abi.default_osqp_settings()
         self._uploaded = False
         self._callbacks = []
+        self._step_callbacks = []
 
     def setParameters(self, params: abi.SqpParams):
         self.params = params
@@ -319,6 +341,13 @@ class BatchedTrustRegionSQP:
         running in the persistent kernel - an observability mode, not the fast path."""
         self._callbacks.append(cb)
 
+    def addStepCallback(self, cb):
+        """cb(problem_index, step) after EVERY trust-region evaluation (QP solve + exact re-evaluation) of every seed, with
+        step = Context.step_log()[problem_index]: what BasicTrustRegionSQPResults::update leaves for ::print and the log writers
+        (optimizers.cpp:380-647) - old / model / new values per cost and constraint, merit coefficients, the merits, dapprox,
+        dexact, ratio.  Like addCallback it puts the optimizer into the stepped mode."""
+        self._step_callbacks.append(cb)
+
     def _fire(self, b, r, cv, vv, st):
         res = dict(x=r["x"][b], status=int(r["status"][b]), total_cost=float(r["total_cost"][b]), cost_vals=cv[b], cnt_viols=vv[b],
                    n_func_evals=int(r["n_func_evals"][b]), n_qp_solves=int(r["n_qp_solves"][b]), sqp_iter=int(st["sqp_iter"][b]),
@@ -327,14 +356,22 @@ class BatchedTrustRegionSQP:
             cb(b, res)
 
     def optimize(self):
-        if not self._callbacks:
+        if not self._callbacks and not self._step_callbacks:
             self.ctx.run(0)
             return self.ctx.results()["status"]
         B = self.ctx.B
         seen_iter = np.full(B, -1, np.int64)       # last (merit_increases, sqp_iter) whose start was reported
         finished = np.zeros(B, bool)
+        n_qp_seen = np.zeros(B, np.int64)
         while True:
             r, st = self.ctx.results(), self.ctx.state()
+            if self._step_callbacks:
+                logs = self.ctx.step_log()
+                for b in range(B):
+                    if r["n_qp_solves"][b] > n_qp_seen[b]:
+                        n_qp_seen[b] = r["n_qp_solves"][b]
+                        for cb in self._step_callbacks:
+                            cb(b, logs[b])
             cv, vv = self.ctx.evaluate()
             for b in range(B):
                 if finished[b]:
