@@ -1,0 +1,220 @@
+#include "hip_qp_problem.hpp"
+
+#include <trajopt_ifopt/core/constraint_set.h>
+
+#include <cmath>
+#include <iostream>
+#include <stdexcept>
+
+namespace trajopt_sqp
+{
+HipQPProblem::HipQPProblem(const tmx_problem_desc& desc, const Eigen::Ref<const Eigen::VectorXd>& x0, int device) : desc_(&desc), x_(x0)
+{
+  if (desc.flavor != TMX_FLAVOR_SQP)
+    throw std::runtime_error("HipQPProblem: the problem description must be lowered with flavor TMX_FLAVOR_SQP");
+  if (x0.size() != static_cast<Eigen::Index>(desc.n_steps) * desc.n_dof)
+    throw std::runtime_error("HipQPProblem: x0 has the wrong size");
+  if (tmx_create(device, &ctx_) != TMX_OK)
+    throw std::runtime_error("HipQPProblem: no usable HIP device (there is no CPU fallback behind this problem)");
+  n_nlp_vars_ = x0.size();
+}
+
+HipQPProblem::~HipQPProblem() { tmx_destroy(ctx_); }
+
+void HipQPProblem::check(tmx_status s, const char* what) const
+{
+  if (s != TMX_OK)
+    throw std::runtime_error(std::string("HipQPProblem::") + what + ": " + tmx_last_error(ctx_));
+}
+
+// The sets themselves stay on the host for their names; their arithmetic was lowered into the term table (class comment).
+void HipQPProblem::addConstraintSet(std::shared_ptr<trajopt_ifopt::ConstraintSet> constraint_set)
+{
+  if (set_up_)
+    throw std::runtime_error("HipQPProblem: addConstraintSet after setup()");
+  cnt_names_.push_back(constraint_set->getName());
+  rows_added_cnt_ += constraint_set->getRows();
+}
+
+void HipQPProblem::addCostSet(std::shared_ptr<trajopt_ifopt::ConstraintSet> constraint_set, CostPenaltyType /*penalty_type*/)
+{
+  if (set_up_)
+    throw std::runtime_error("HipQPProblem: addCostSet after setup()");
+  cost_names_.push_back(constraint_set->getName());
+  rows_added_cost_ += constraint_set->getRows();
+}
+
+void HipQPProblem::setup()
+{
+  tmx_sqp_params sp;
+  tmx_default_sqp_params(&sp);
+  tmx_osqp_settings st;
+  tmx_default_osqp_settings(&st);
+  check(tmx_problem_upload(ctx_, desc_, &sp, &st), "setup");
+  check(tmx_batch_set_x0(ctx_, x_.data(), 1), "setup");
+  int32_t nc = 0, nv = 0, nslots = 0;
+  check(tmx_term_counts(ctx_, &nc, &nv, &nslots), "setup");
+  check(tmx_qp_dims(ctx_, &n_max_, &m_max_), "setup");
+  n_costs_ = nc;
+  n_cnts_ = nv;
+  if (!cnt_names_.empty() && static_cast<Eigen::Index>(cnt_names_.size()) != n_cnts_)
+    throw std::runtime_error("HipQPProblem: the constraint sets handed to addConstraintSet do not match the lowered terms");
+  if (!cost_names_.empty() && static_cast<Eigen::Index>(cost_names_.size()) != n_costs_)
+    throw std::runtime_error("HipQPProblem: the cost sets handed to addCostSet do not match the lowered terms");
+  if (cnt_names_.empty())
+    for (Eigen::Index i = 0; i < n_cnts_; ++i)
+      cnt_names_.push_back("cnt_" + std::to_string(i));
+  if (cost_names_.empty())
+    for (Eigen::Index i = 0; i < n_costs_; ++i)
+      cost_names_.push_back("cost_" + std::to_string(i));
+  // TrajOptQPProblem::setup (trajopt_qp_problem.cpp:660-672): box 1e-1 per variable, merit coefficient 10 per constraint set
+  box_size_ = Eigen::VectorXd::Constant(n_nlp_vars_, 1e-1);
+  merit_coeff_ = Eigen::VectorXd::Constant(n_cnts_, 10.0);
+  set_up_ = true;
+  convexify();
+}
+
+void HipQPProblem::pushLoopVars() const
+{
+  // the device keeps ONE trust box size per problem (TrustRegionSQPSolver only ever sets constant vectors,
+  // trust_region_sqp_solver.cpp:68, :298)
+  const double box = box_size_.size() > 0 ? box_size_(0) : 0.0;
+  check(tmx_sqp_set_loop_vars(ctx_, &box, n_cnts_ > 0 ? merit_coeff_.data() : nullptr), "pushLoopVars");
+}
+
+void HipQPProblem::setVariables(const double* x)
+{
+  x_ = Eigen::Map<const Eigen::VectorXd>(x, n_nlp_vars_);
+  if (!set_up_)
+    return;
+  check(tmx_batch_set_x0(ctx_, x_.data(), 1), "setVariables");  // Optimizer::initialize resets the loop variables ...
+  pushLoopVars();                                                // ... which belong to the caller here
+}
+
+Eigen::VectorXd HipQPProblem::getVariableValues() const { return x_; }
+
+void HipQPProblem::convexify()
+{
+  pushLoopVars();
+  check(tmx_convexify(ctx_, nullptr, nullptr, nullptr), "convexify");
+  exportQP();
+}
+
+void HipQPProblem::exportQP()
+{
+  int32_t n = 0, m = 0, nnzP = 0, nnzA = 0;
+  std::vector<int64_t> Pp(static_cast<std::size_t>(n_max_) + 1), Ap(static_cast<std::size_t>(n_max_) + 1);
+  std::vector<int64_t> Pi(static_cast<std::size_t>(n_max_) * 3 + 8), Ai;
+  std::vector<double> Px(Pi.size()), q(static_cast<std::size_t>(n_max_)), l(static_cast<std::size_t>(m_max_)), u(static_cast<std::size_t>(m_max_)), Ax;
+  // sizes first (the index / value arrays may be NULL), then the arrays
+  check(tmx_export_csc(ctx_, 0, &n, &m, &nnzP, &nnzA, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr), "exportQP");
+  Pi.resize(static_cast<std::size_t>(nnzP) + 1);
+  Px.resize(static_cast<std::size_t>(nnzP) + 1);
+  Ai.resize(static_cast<std::size_t>(nnzA) + 1);
+  Ax.resize(static_cast<std::size_t>(nnzA) + 1);
+  check(tmx_export_csc(ctx_, 0, &n, &m, &nnzP, &nnzA, Pp.data(), Pi.data(), Px.data(), q.data(), Ap.data(), Ai.data(), Ax.data(), l.data(), u.data()),
+        "exportQP");
+  n_qp_vars_ = n;
+  n_qp_cnts_ = m;
+  // QPProblem::getHessian is H with objective x'Hx + g'x (OSQPEigenSolver doubles it, osqp_eigen_solver.cpp:220-229); the device
+  // exports the upper triangle of P = 2H
+  std::vector<Eigen::Triplet<double>> th, ta;
+  for (int32_t j = 0; j < n; ++j)
+    for (int64_t p = Pp[static_cast<std::size_t>(j)]; p < Pp[static_cast<std::size_t>(j) + 1]; ++p)
+    {
+      const auto i = static_cast<Eigen::Index>(Pi[static_cast<std::size_t>(p)]);
+      th.emplace_back(i, j, 0.5 * Px[static_cast<std::size_t>(p)]);
+      if (i != j)
+        th.emplace_back(j, i, 0.5 * Px[static_cast<std::size_t>(p)]);
+    }
+  for (int32_t j = 0; j < n; ++j)
+    for (int64_t p = Ap[static_cast<std::size_t>(j)]; p < Ap[static_cast<std::size_t>(j) + 1]; ++p)
+      ta.emplace_back(static_cast<Eigen::Index>(Ai[static_cast<std::size_t>(p)]), j, Ax[static_cast<std::size_t>(p)]);
+  hessian_.resize(n, n);
+  hessian_.setFromTriplets(th.begin(), th.end());
+  constraint_matrix_.resize(m, n);
+  constraint_matrix_.setFromTriplets(ta.begin(), ta.end());
+  gradient_ = Eigen::Map<const Eigen::VectorXd>(q.data(), n);
+  bounds_lower_ = Eigen::Map<const Eigen::VectorXd>(l.data(), m);
+  bounds_upper_ = Eigen::Map<const Eigen::VectorXd>(u.data(), m);
+}
+
+void HipQPProblem::modelValues(const Eigen::Ref<const Eigen::VectorXd>& var_vals, Eigen::VectorXd& costs, Eigen::VectorXd& viols) const
+{
+  std::vector<double> xq(static_cast<std::size_t>(n_max_), 0.0);
+  for (Eigen::Index i = 0; i < var_vals.size() && i < n_max_; ++i)
+    xq[static_cast<std::size_t>(i)] = var_vals(i);
+  costs.resize(n_costs_);
+  viols.resize(n_cnts_);
+  check(tmx_model_values(ctx_, xq.data(), costs.data(), viols.data()), "modelValues");
+}
+
+double HipQPProblem::evaluateTotalConvexCost(const Eigen::Ref<const Eigen::VectorXd>& var_vals) const { return evaluateConvexCosts(var_vals).sum(); }
+
+Eigen::VectorXd HipQPProblem::evaluateConvexCosts(const Eigen::Ref<const Eigen::VectorXd>& var_vals) const
+{
+  Eigen::VectorXd c, v;
+  modelValues(var_vals, c, v);
+  return c;
+}
+
+Eigen::VectorXd HipQPProblem::evaluateConvexConstraintViolations(const Eigen::Ref<const Eigen::VectorXd>& var_vals) const
+{
+  Eigen::VectorXd c, v;
+  modelValues(var_vals, c, v);
+  return v;
+}
+
+double HipQPProblem::getTotalExactCost() const { return getExactCosts().sum(); }
+
+Eigen::VectorXd HipQPProblem::getExactCosts() const
+{
+  Eigen::VectorXd c(n_costs_), v(n_cnts_);
+  check(tmx_evaluate(ctx_, c.data(), v.data()), "getExactCosts");
+  return c;
+}
+
+Eigen::VectorXd HipQPProblem::getExactConstraintViolations() const
+{
+  Eigen::VectorXd c(n_costs_), v(n_cnts_);
+  check(tmx_evaluate(ctx_, c.data(), v.data()), "getExactConstraintViolations");
+  return v;
+}
+
+// trajopt_qp_problem.cpp:1040-1057: the box changes the variable-bound rows of the QP only (no re-convexification)
+void HipQPProblem::scaleBoxSize(double& scale)
+{
+  box_size_ = box_size_ * scale;
+  pushLoopVars();
+  exportQP();
+}
+
+void HipQPProblem::setBoxSize(const Eigen::Ref<const Eigen::VectorXd>& box_size)
+{
+  if (box_size.size() != n_nlp_vars_)
+    throw std::runtime_error("HipQPProblem::setBoxSize: wrong size");
+  for (Eigen::Index i = 1; i < box_size.size(); ++i)
+    if (box_size(i) != box_size(0))
+      throw std::runtime_error("HipQPProblem::setBoxSize: the device path keeps one trust box size per problem");
+  box_size_ = box_size;
+  pushLoopVars();
+  exportQP();
+}
+
+void HipQPProblem::setConstraintMeritCoeff(const Eigen::Ref<const Eigen::VectorXd>& merit_coeff)
+{
+  if (merit_coeff.size() != n_cnts_)
+    throw std::runtime_error("HipQPProblem::setConstraintMeritCoeff: wrong size");
+  merit_coeff_ = merit_coeff;
+  pushLoopVars();
+  exportQP();  // the slack gradients carry the merit coefficients (trajopt_qp_problem.cpp:771-799)
+}
+
+void HipQPProblem::print() const
+{
+  std::cout << "-------------- HipQPProblem::print() --------------\n";
+  std::cout << "Num NLP Vars: " << n_nlp_vars_ << "\nNum QP Vars: " << n_qp_vars_ << "\nNum NLP Constraints: " << n_qp_cnts_ << '\n';
+  std::cout << "Box Size: " << (box_size_.size() > 0 ? box_size_(0) : 0.0) << "\nConstraint Merit Coeff: " << merit_coeff_.transpose() << '\n';
+  std::cout << "Gradient: " << gradient_.transpose() << "\nbounds_lower: " << bounds_lower_.transpose() << "\nbounds_upper: " << bounds_upper_.transpose() << '\n';
+}
+}  // namespace trajopt_sqp

@@ -337,6 +337,18 @@ TMX_API tmx_status tmx_sqp_state(tmx_ctx* ctx, int32_t* sqp_iter /*B*/, int32_t*
 #define TMX_STEP_LOG_HEAD 16
 TMX_API tmx_status tmx_sqp_step_log(tmx_ctx* ctx, double* out, int32_t* stride_out);
 
+/* sco::BasicTrustRegionSQP::evaluateModelCosts / evaluateModelCntViols (optimizers.hpp:176-178; ::update optimizers.cpp:391-396) and
+   trajopt_sqp::QPProblem::evaluateConvexCosts / evaluateConvexConstraintViolations (qp_problem.h:56-88): values of the convex
+   models of the CURRENT convexification (after tmx_convexify or a run step) at caller-supplied QP variables x_qp[B][n_max]
+   (reference variable order: NLP variables, then the slack / aux variables) -> model_cost_vals[B][n_costs],
+   model_cnt_viols[B][n_cnts]. */
+TMX_API tmx_status tmx_model_values(tmx_ctx* ctx, const double* x_qp, double* model_cost_vals, double* model_cnt_viols);
+/* The loop variables an outer optimizer owns when it drives the piecewise hooks itself (sco::BasicTrustRegionSQP::
+   setTrustRegionSize optimizers.hpp:190, trajopt_sqp::QPProblem::setBoxSize / scaleBoxSize / setConstraintMeritCoeff
+   qp_problem.h:96-110): trust box size per problem [B] and merit (penalty) coefficient per constraint [B][n_cnts].  They take
+   effect at the next tmx_convexify / tmx_export_csc / tmx_qp_solve.  Either pointer may be NULL. */
+TMX_API tmx_status tmx_sqp_set_loop_vars(tmx_ctx* ctx, const double* trust_box_size, const double* merit_error_coeffs);
+
 /* ---- piecewise entry points (the hooks BasicTrustRegionSQP exposes "to allow overriding",
  *      optimizers.hpp:137-194): evaluateCosts/evaluateConstraintViols, convexify*, Model::optimize ---- */
 /* exact cost values and constraint violations at the current iterate of every problem:

@@ -200,3 +200,54 @@ def test_max_time_on_host_build(hostemu_lib, orc):
 def test_max_time_on_device(orc):
     r2, nq_full = _max_time(None, orc)
     assert (r2["status"] == abi.OPT_TIME_LIMIT).any() and (r2["n_qp_solves"] < nq_full).any()   # 2 ms: nothing of config 1 finishes
+
+
+# ---- the piecewise hooks are enough to drive the reference's own loop from outside ------------------------
+def _outer_loop_with_hooks(lib_path, orc, cid=0, B=2):
+    """BasicTrustRegionSQP::optimize written on the HOST over the hooks a reference optimizer overrides - evaluateCosts /
+    evaluateConstraintViols (tmx_evaluate), convexify (tmx_convexify), Model::optimize (tmx_qp_solve), evaluateModelCosts /
+    evaluateModelCntViols (tmx_model_values), setTrustBoxConstraints + merit coefficients (tmx_sqp_set_loop_vars).  One trust-
+    region evaluation of it must reproduce the fused device step: same model values as tmx_sqp_step_log and as the oracle."""
+    import parity_checks as pc
+    pci, s, g = pc.cfg(cid)
+    x0 = configs.seeds_for(cid, pci, s, g, B)
+    ctx = runtime.Context(0, lib_path)
+    desc = pc.make_ctx_inputs(ctx, pci, x0)
+    # fused: one step, read the record
+    ctx.run(1)
+    fused = ctx.step_log()
+    # piecewise: the same step from the hooks, with loop variables set from outside
+    ctx.set_x0(x0)
+    sp = abi.default_sqp_params()
+    ctx.set_loop_vars(trust_box_size=sp.trust_box_size, merit_error_coeffs=sp.initial_merit_error_coeff)
+    old_c, old_v = ctx.evaluate()
+    ctx.convexify()
+    xq, cvx, rec = ctx.qp_solve()
+    assert (cvx == abi.CVX_SOLVED).all()
+    mc, mv = ctx.model_values(xq)
+    for b in range(B):
+        assert fused[b]["valid"]
+        assert np.array_equal(mc[b], fused[b]["model_cost_vals"]) and np.array_equal(mv[b], fused[b]["model_cnt_viols"])
+        assert np.array_equal(old_c[b], fused[b]["old_cost_vals"]) and np.array_equal(old_v[b], fused[b]["old_cnt_viols"])
+        ol, _, _ = orc.sqp_step_logs(desc, x0[b], max_steps=1)
+        assert np.abs(mc[b] - ol[0]["model_cost_vals"]).max(initial=0.0) <= 1e-8 * max(1.0, np.abs(ol[0]["model_cost_vals"]).max(initial=0.0))
+        assert np.abs(mv[b] - ol[0]["model_cnt_viols"]).max(initial=0.0) <= 1e-8 * max(1.0, np.abs(ol[0]["model_cnt_viols"]).max(initial=0.0))
+    # a smaller box from outside changes the QP bounds of the next export
+    ctx.set_loop_vars(trust_box_size=0.01)
+    e = ctx.export_csc(0)
+    mg = e["m"] - e["n"]
+    NX = pci.basic_info.n_steps * pci.robot.n_dof
+    width = (e["u"][mg:mg + NX] - e["l"][mg:mg + NX])
+    assert width.max() <= 0.02 + 1e-12
+    ctx.close()
+
+
+@pytest.mark.parametrize("cid", [0, 9])
+def test_outer_loop_with_hooks_on_host_build(hostemu_lib, orc, cid):
+    _outer_loop_with_hooks(hostemu_lib, orc, cid)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cid", [0, 1])
+def test_outer_loop_with_hooks_on_device(orc, cid):
+    _outer_loop_with_hooks(None, orc, cid, B=4)

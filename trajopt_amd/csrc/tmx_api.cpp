@@ -1383,6 +1383,51 @@ tmx_status tmx_sqp_step_log(tmx_ctx* ctx, double* out, int32_t* stride_out)
   return TMX_OK;
 }
 
+tmx_status tmx_model_values(tmx_ctx* ctx, const double* x_qp, double* model_cost_vals, double* model_cnt_viols)
+{
+  if (!ctx || !x_qp)
+    return TMX_ERR_INVALID;
+  if (ctx->Bcap == 0)
+    return TMX_ERR_STATE;
+  TMX_REFUSE_WHILE_PENDING(ctx);
+  HIPCHK(hipSetDevice(ctx->device));
+  const size_t B = ctx->hb.B;
+  std::vector<void*> pool;
+  double *d_x = nullptr, *d_c = nullptr, *d_v = nullptr;
+  tmx_status rc;
+  if ((rc = dalloc(ctx, pool, &d_x, B * ctx->hp.n_max, false)) != TMX_OK || (rc = dalloc(ctx, pool, &d_c, B * ctx->hp.n_costs)) != TMX_OK ||
+      (rc = dalloc(ctx, pool, &d_v, B * ctx->hp.n_cnts)) != TMX_OK)
+  {
+    free_pool(pool);
+    return rc;
+  }
+  HIPCHK(hipMemcpyAsync(d_x, x_qp, sizeof(double) * B * ctx->hp.n_max, hipMemcpyHostToDevice, ctx->stream));
+  TMX_LAUNCH(k_model_values, ctx->hb.B, ctx->nt_small, ctx->smem_small, ctx->stream, ctx->dp, ctx->db, d_x, d_c, d_v);
+  HIPCHK(hipGetLastError());
+  if ((rc = d2h(ctx, model_cost_vals, d_c, B * ctx->hp.n_costs)) == TMX_OK)
+    rc = d2h(ctx, model_cnt_viols, d_v, B * ctx->hp.n_cnts);
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  free_pool(pool);
+  return rc;
+}
+
+tmx_status tmx_sqp_set_loop_vars(tmx_ctx* ctx, const double* trust_box_size, const double* merit_error_coeffs)
+{
+  if (!ctx)
+    return TMX_ERR_INVALID;
+  if (ctx->Bcap == 0)
+    return TMX_ERR_STATE;
+  TMX_REFUSE_WHILE_PENDING(ctx);
+  HIPCHK(hipSetDevice(ctx->device));
+  const size_t B = ctx->hb.B;
+  if (trust_box_size)
+    HIPCHK(hipMemcpyAsync(ctx->hb.trust, trust_box_size, sizeof(double) * B, hipMemcpyHostToDevice, ctx->stream));
+  if (merit_error_coeffs && ctx->hp.n_cnts > 0)
+    HIPCHK(hipMemcpyAsync(ctx->hb.merit, merit_error_coeffs, sizeof(double) * B * ctx->hp.n_cnts, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return TMX_OK;
+}
+
 tmx_status tmx_sqp_qp_records(tmx_ctx* ctx, tmx_qp_record* out, int32_t max_records, int32_t* counts)
 {
   if (!ctx || max_records < 0)

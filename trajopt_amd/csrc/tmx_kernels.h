@@ -450,6 +450,42 @@ TMX_KERNEL k_detmath(int op, int n, const double* a, const double* b, double* ou
     out[i] = (op == 0) ? tmx_sin(a[i]) : (op == 1) ? tmx_cos(a[i]) : tmx_atan2(a[i], b[i]);
 }
 
+// BasicTrustRegionSQP::evaluateModelCosts / evaluateModelCntViols (optimizers.hpp:176-178) and trajopt_sqp::QPProblem::
+// evaluateConvexCosts / evaluateConvexConstraintViolations (qp_problem.h:56-88) for caller-supplied QP variable values
+// xq[b][n_max] (reference order): model values of the CURRENT convexification -> out_cost[b][n_costs], out_viol[b][n_cnts]
+TMX_KERNEL k_model_values(const DevProblem* P, const DevBatch* Bt, const double* xq, double* out_cost, double* out_viol)
+{
+  TMX_SMEM(smem_lds);
+  double* smem = TMX_WORK(smem_lds, Bt);
+  const int b = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
+  const int R = P->R;
+  {
+    // position of the aux variables of every active row in the reference-order variable vector (what qp_solve_block leaves in
+    // the per-problem scratch; rebuilt here so that the call does not depend on an earlier solve)
+    QpWs wl;
+    qp_ws_carve(wl, smem, smem, Bt->qp_scratch + (size_t)b * Bt->qp_scratch_stride, P->D, P->T, R, P->NA, P->n_link, P->coef_far);
+    const int* act = Bt->active + (size_t)b * R;
+    for (int r = tid; r < R; r += NT)
+    {
+      int na = 0;
+      for (int q = 0; q < r; ++q)
+        na += act[q] ? P->slot_naux[q] : 0;
+      wl.aux_ref[r] = P->NX + na;
+    }
+    TMX_SYNC();
+  }
+#if TMX_LINK_ROWS
+  if (P->flavor == 1)
+    sqp2_model_values(P, Bt, b, xq + (size_t)b * P->n_max, smem, tid, NT);
+  else
+#endif
+    sqp_model_values(P, Bt, b, xq + (size_t)b * P->n_max, smem, tid, NT);
+  for (int k = tid; k < P->n_costs; k += NT)
+    out_cost[(size_t)b * P->n_costs + k] = smem[k];
+  for (int k = tid; k < P->n_cnts; k += NT)
+    out_viol[(size_t)b * P->n_cnts + k] = smem[P->n_costs + k];
+}
+
 // start of optimize(): reference point of the wall-clock limit sqp.max_time
 TMX_KERNEL k_mark_start(const DevBatch* Bt)
 {

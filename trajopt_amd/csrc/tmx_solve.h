@@ -2008,25 +2008,17 @@ TMX_DEVFN void sqp2_begin_qp(const DevProblem* P, const DevBatch* Bt, int b, dou
 // TrustRegionSQPSolver after one qp_solver->solve(): solveQPProblem's merits (trust_region_sqp_solver.cpp:373-439), the body of
 // runTrustRegionLoop (:262-371), the tail of stepSQPSolver (:246-259), the convexification / penalty loops of solve()
 // (:99-152), verifySQPSolverConvergence (:161-177) and adjustPenalty (:179-200).  smem: n_costs + n_cnts + R + (R+1)/2 doubles.
-TMX_DEVFN void sqp2_update_block(const DevProblem* P, const DevBatch* Bt, int b, double* smem, int tid, int NT)
+// evaluateConvexCosts / evaluateConvexConstraintViolations (trajopt_qp_problem.cpp:131-244) at QP variables xq -> smem[0 .. n_costs),
+// smem[n_costs .. n_costs + n_cnts)
+TMX_DEVFN void sqp2_model_values(const DevProblem* P, const DevBatch* Bt, int b, const double* xq, double* smem, int tid, int NT)
 {
   const int D = P->D, NX = P->NX, R = P->R;
-  const tmx_sqp_params& sp = P->sqp;
   double* model_cost = smem;                     // n_costs
   double* model_viol = model_cost + P->n_costs;  // n_cnts
   double* val = model_viol + P->n_cnts;          // R
   int* keys = reinterpret_cast<int*>(val + R);
-  const double* xq = Bt->xq + (size_t)b * P->n_max;
   const int* act = Bt->active + (size_t)b * R;
-  double* cost_vals = Bt->cost_vals + (size_t)b * P->n_costs;
-  double* cnt_viols = Bt->cnt_viols + (size_t)b * P->n_cnts;
-  const double* new_cost = Bt->new_cost_vals + (size_t)b * P->n_costs;
-  const double* new_viol = Bt->new_cnt_viols + (size_t)b * P->n_cnts;
-  double* merit = Bt->merit + (size_t)b * P->n_cnts;
-  const bool solved = Bt->cvx[b] == TMX_CVX_SOLVED && Bt->phase[b] != PHASE_DONE;
-  if (solved)
   {
-    // evaluateConvexCosts / evaluateConvexConstraintViolations at the FULL QP solution (trajopt_qp_problem.cpp:131-244)
     QpWs wl;
     qp_ws_carve(wl, smem, smem, Bt->qp_scratch + (size_t)b * Bt->qp_scratch_stride, D, P->T, R, P->NA, P->n_link, P->coef_far);
     const int* aux_ref = wl.aux_ref;
@@ -2082,6 +2074,22 @@ TMX_DEVFN void sqp2_update_block(const DevProblem* P, const DevBatch* Bt, int b,
     }
     TMX_SYNC();
   }
+}
+
+TMX_DEVFN void sqp2_update_block(const DevProblem* P, const DevBatch* Bt, int b, double* smem, int tid, int NT)
+{
+  const int NX = P->NX;
+  const tmx_sqp_params& sp = P->sqp;
+  double* model_cost = smem;                     // n_costs
+  double* model_viol = model_cost + P->n_costs;  // n_cnts
+  double* cost_vals = Bt->cost_vals + (size_t)b * P->n_costs;
+  double* cnt_viols = Bt->cnt_viols + (size_t)b * P->n_cnts;
+  const double* new_cost = Bt->new_cost_vals + (size_t)b * P->n_costs;
+  const double* new_viol = Bt->new_cnt_viols + (size_t)b * P->n_cnts;
+  double* merit = Bt->merit + (size_t)b * P->n_cnts;
+  const bool solved = Bt->cvx[b] == TMX_CVX_SOLVED && Bt->phase[b] != PHASE_DONE;
+  if (solved)
+    sqp2_model_values(P, Bt, b, Bt->xq + (size_t)b * P->n_max, smem, tid, NT);
   if (tid != 0)
     return;
   if (Bt->phase[b] == PHASE_DONE)

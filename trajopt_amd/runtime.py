@@ -49,6 +49,8 @@ _SIGS = {
     "tmx_kernel_stats_reset": ([C.c_void_p], C.c_int),
     "tmx_sqp_state": ([C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p], C.c_int),
     "tmx_sqp_step_log": ([C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)], C.c_int),
+    "tmx_model_values": ([C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p], C.c_int),
+    "tmx_sqp_set_loop_vars": ([C.c_void_p, C.c_void_p, C.c_void_p], C.c_int),
 }
 ABI_SYMBOLS = tuple(_SIGS.keys())
 
@@ -181,6 +183,21 @@ class Context:
                              old_cnt_viols=q[3 * nc:3 * nc + nv].copy(), model_cnt_viols=q[3 * nc + nv:3 * nc + 2 * nv].copy(),
                              new_cnt_viols=q[3 * nc + 2 * nv:3 * nc + 3 * nv].copy(), merit_error_coeffs=q[3 * nc + 3 * nv:3 * nc + 4 * nv].copy()))
         return logs
+
+    def model_values(self, x_qp):
+        """evaluateModelCosts / evaluateModelCntViols (trajopt_sqp: evaluateConvexCosts / evaluateConvexConstraintViolations) of
+        the current convexification at QP variables x_qp[B][n_max] (reference order)"""
+        x_qp = np.ascontiguousarray(x_qp, np.float64)
+        assert x_qp.shape == (self.B, self.n_max)
+        mc, mv = np.zeros((self.B, self.n_costs)), np.zeros((self.B, self.n_cnts))
+        self._chk(self.lib.tmx_model_values(self.h, _ptr(x_qp), _ptr(mc), _ptr(mv)))
+        return mc, mv
+
+    def set_loop_vars(self, trust_box_size=None, merit_error_coeffs=None):
+        """trust box size [B] / merit coefficients [B][n_cnts] of an outer optimizer that drives the piecewise hooks itself"""
+        t = None if trust_box_size is None else np.ascontiguousarray(np.broadcast_to(np.asarray(trust_box_size, np.float64), (self.B,)))
+        m = None if merit_error_coeffs is None else np.ascontiguousarray(np.broadcast_to(np.asarray(merit_error_coeffs, np.float64), (self.B, self.n_cnts)))
+        self._chk(self.lib.tmx_sqp_set_loop_vars(self.h, _ptr(t), _ptr(m)))
 
     def counters(self):
         a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
