@@ -114,14 +114,23 @@ def _step_tables(lib_path, orc, cid, B, tol):
     opt.optimize()
     res = opt.results()
     desc = opt.desc
+    recs, cnt = opt.ctx.qp_records(128)
     worst = 0.0
     for b in range(B):
         dev = tab.of(b)
         ol, n_steps, st = orc.sqp_step_logs(desc, x0[b])
+        ob = orc.sqp_batch(desc, x0[b:b + 1], max_records=128, nthreads=1)
+        # the two runs are compared while their QP solves have the same integer history (OSQP status, iterations, rho updates,
+        # polish): beyond an ADMM-level difference the QP solutions - and with them the table - legitimately differ
+        # (parity_checks.sqp_history_classes, class "admm")
+        adm = lambda t: (t.osqp_status, t.osqp_iter, t.rho_updates, t.polish_status)
+        n_same = 0
+        while n_same < min(int(cnt[b]), int(ob["rec_counts"][0]), 128) and adm(recs[b * 128 + n_same]) == adm(ob["records"][n_same]):
+            n_same += 1
         assert st == res["status"][b]
-        n = min(len(dev), len(ol))
+        n = min(len(dev), len(ol), n_same)
         assert n >= 1
-        if res["n_qp_solves"][b] == n_steps:
+        if res["n_qp_solves"][b] == n_steps and n_same == n_steps:
             assert len(dev) == n_steps, (len(dev), n_steps)
         for k in range(n):
             d, o = dev[k], ol[k]
@@ -153,7 +162,10 @@ def test_step_table_matches_oracle_on_host_build(hostemu_lib, orc, cid):
 @pytest.mark.gpu
 @pytest.mark.parametrize("cid", [0, 1])
 def test_step_table_matches_oracle_on_device(orc, cid):
-    worst = _step_tables(None, orc, cid, 4, 1e-6)
+    # config 0: every QP is polished - the table agrees to round-off.  config 1: a QP whose polish is rejected is returned at
+    # ADMM accuracy (eps_rel = 1e-4 of OSQP's scaled residuals), on both sides, by two different linear solvers: the model / new
+    # values of that step agree to that accuracy only (measured 3.9e-5 relative on 4 seeds)
+    worst = _step_tables(None, orc, cid, 4, 1e-6 if cid == 0 else 5e-4)
     print("worst relative difference of a table entry:", worst)
 
 

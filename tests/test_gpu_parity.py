@@ -69,7 +69,7 @@ def test_full_sqp_mini_arm(gpu, orc, cid):
     r, o, same, dx = pc.check_full_sqp(gpu, orc, desc, x0, exact=False)
     print(f"cid {cid}: same history {same.sum()}/{B}, within 1e-5: {(dx <= pc.TOL_TRAJ).sum()}/{B}, worst {dx.max():.2e}")
     assert (r["status"] == o["status"]).all()
-    assert (dx[same] <= pc.TOL_TRAJ).all() and same.sum() >= B // 2
+    assert (dx[same] <= pc.TOL_TRAJ).all() and same.sum() >= B - 1   # measured: 16 of 16 for every configuration id
 
 
 def test_full_sqp_config1_statistical(gpu, orc):
@@ -133,7 +133,7 @@ def test_full_sqp_config2_long_horizon(gpu, orc):
     r, o, same, dx = pc.check_full_sqp(gpu, orc, desc, x0, exact=False)
     print(f"config 2: same history {same.sum()}/4, within 1e-5: {(dx <= pc.TOL_TRAJ).sum()}/4, worst {dx.max():.2e}")
     assert (r["status"] == o["status"]).all() and (r["status"] == abi.OPT_CONVERGED).all()
-    assert same.sum() >= 3 and (dx[same] <= pc.TOL_TRAJ).all()
+    assert same.sum() == 4 and (dx <= pc.TOL_TRAJ).all()   # measured: 4 of 4, worst 7e-10
     pc.check_config2_toolpath(pci, r["x"])
 
 
@@ -147,7 +147,7 @@ def test_full_sqp_config3_car_seat_shape(gpu, orc):
     r, o, same, dx = pc.check_full_sqp(gpu, orc, desc, x0, exact=False)
     print(f"config 3: same history {same.sum()}/{B}, within 1e-5: {(dx <= pc.TOL_TRAJ).sum()}/{B}, worst {dx.max():.2e}")
     assert (r["status"] == o["status"]).all()
-    assert same.sum() >= B // 2 and (dx[same] <= pc.TOL_TRAJ).all()
+    assert same.sum() >= B - 1 and (dx[same] <= pc.TOL_TRAJ).all()   # measured: 8 of 8, worst 2e-15
     conv = r["status"] == abi.OPT_CONVERGED
     assert conv.mean() >= 0.75
     assert np.abs(r["x"][conv, 0, :] - s[None, :]).max() < 1e-3 and np.abs(r["x"][conv, -1, :] - g[None, :]).max() < 1e-3

@@ -751,9 +751,23 @@ struct TmxTag
 // The instantiations differ per WAVE, not per thread: every wave executes the same five barriers per iteration, and the
 // register allocation of the kernel is the maximum over the instantiations instead of the union of all roles.
 // NAX : aux slots per row compiled in (1 when no row of the wave has two aux vars - the hinge rows; else 2)
+// EPOCH MODE (ctl != nullptr): the burst does not return at every residual check.  After the 14 norms of update_info it also
+// forms, from registers, what the termination test and the adaptive-rho rule would do with them - including the two
+// infeasibility certificates of check_termination - and goes on iterating when NOTHING would happen: no termination, certificates
+// certainly negative, no rho update, iterations left.  Otherwise it stores the iterate and returns, and qp_check_nl repeats the
+// test in full on the stored data, exactly as after a single burst: the in-register test is a FILTER with safety margins (a sum
+// is "certainly positive" if it exceeds 1e-10 of the sum of its magnitudes, a norm "certainly above" a threshold if it exceeds
+// twice the threshold), never the authority, so every decision and every number is the one the check-per-burst structure made.
+// What it saves: the burst entry (row / column / matrix registers: ~15 k cycles) and exit, the call of qp_check_nl with its
+// callee-saved registers, and the certificate sweeps over index lists in LDS, 26 times per QP solve -> ~4 times.
+struct BurstCtl
+{
+  int iter;  // in: ADMM iterations done so far
+  int n_checks{ 0 }, n_continued{ 0 };
+};
 template <bool RC, int NR, bool INTW, int NAX = 2>
-TMX_DEVFN void admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, bool keep_last, int tid, long long* pc, long long& tlast,
-                                double* res14 = nullptr)
+TMX_DEVFN int admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, bool keep_last, int tid, long long* pc, long long& tlast,
+                               double* res14 = nullptr, BurstCtl* ctl = nullptr)
 {
   // The instantiations sit in the arms of one wave-uniform dispatch and begin with the same prologue; left alone, the optimiser
   // hoists that common code above the dispatch, and the ~50 values it defines then have to survive the branching - they were
@@ -915,6 +929,8 @@ TMX_DEVFN void admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, b
   // One ADMM iteration.  Instantiated twice: KEEP = false is the body of the hot loop and contains nothing but the
   // iteration; KEEP = true is the peeled final iteration, which also publishes the deltas the termination test needs.
   // (With a run-time flag the publishing code sits inside the loop and its temporaries cost the loop registers.)
+  // deltas of the last (KEEP) iteration, kept in registers for the in-register certificates of the epoch mode
+  [[maybe_unused]] double kd_dyr[NR], kd_dya[NR][NAX], kd_dxa[NR][NAX], kd_dxp = 0.0, kd_dybp = 0.0;
   auto iteration = [&](auto keep_tag) __attribute__((always_inline)) {
     constexpr bool keep = decltype(keep_tag)::value;
     double ta[NR][NAX];
@@ -1036,6 +1052,17 @@ TMX_DEVFN void admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, b
           w.dyba[w.aoff[r] + k] = dya0[k];
         }
       }
+      if constexpr (keep)
+      {
+        kd_dyr[q] = gq.act ? dyr0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < NAX; ++k)
+        {
+          const bool ok = gq.act && k < gq.na;
+          kd_dya[q][k] = ok ? dya0[k] : 0.0;
+          kd_dxa[q][k] = ok ? dxa0[k] : 0.0;
+        }
+      }
     }
     {
       const double xn = __builtin_fma(alpha, xtv, om * xp);
@@ -1046,6 +1073,11 @@ TMX_DEVFN void admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, b
       {
         w.dxp[v] = xn - xp;
         w.dybp[v] = dy;
+      }
+      if constexpr (keep)
+      {
+        kd_dxp = pv ? xn - xp : 0.0;
+        kd_dybp = pv ? dy : 0.0;
       }
       xp = xn;
       zb = zn;
