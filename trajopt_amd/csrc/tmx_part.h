@@ -890,36 +890,42 @@ TMX_DEVFN int admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, bo
   const int q0v = w.wp_start[vt];
   // RC: this thread's matrix rows of the dense solve (constants of the factorisation) in registers
   double gr[(RC && INTW) ? 2 * TMX_RC_GP : 2], gc[(RC && INTW) ? 8 : 2], zq[RC ? 2 * TMX_RC_ZP : 2];
-  if constexpr (RC && INTW)
-  {
-    // 16-byte loads (rows start 16-byte aligned, Gs and Zst / 4 are even); entries past the row end are replaced by zeros
-    const tmx_lds_d* Grow = h.G + (interior ? (mp.k * h.Gn + mp.r) * h.Gs : 0);
-    const tmx_lds_d2* Grow2 = reinterpret_cast<const tmx_lds_d2*>(Grow);
-#pragma unroll
-    for (int c = 0; c < TMX_RC_GP; ++c)
+  // (a lambda: the epoch mode reloads them after every in-register check instead of keeping ~100 registers alive across the
+  //  check's own code - kept alive, they pushed the loop's invariants into AGPRs: +100 copy instructions per iteration)
+  auto load_matrix_rows = [&]() __attribute__((always_inline)) {
+    if constexpr (RC && INTW)
     {
-      const bool ok = interior && 2 * c < h.Gs;
-      const tmx_d2 t = Grow2[ok ? c : 0];
-      gr[2 * c] = ok ? t.x : 0.0;
-      gr[2 * c + 1] = ok ? t.y : 0.0;
+      // 16-byte loads (rows start 16-byte aligned, Gs and Zst / 4 are even); entries past the row end are replaced by zeros
+      const tmx_lds_d* Grow = h.G + (interior ? (mp.k * h.Gn + mp.r) * h.Gs : 0);
+      const tmx_lds_d2* Grow2 = reinterpret_cast<const tmx_lds_d2*>(Grow);
+  #pragma unroll
+      for (int c = 0; c < TMX_RC_GP; ++c)
+      {
+        const bool ok = interior && 2 * c < h.Gs;
+        const tmx_d2 t = Grow2[ok ? c : 0];
+        gr[2 * c] = ok ? t.x : 0.0;
+        gr[2 * c + 1] = ok ? t.y : 0.0;
+      }
+  #pragma unroll
+      for (int c = 0; c < 8; ++c)
+        gc[c] = (interior && c < D) ? Grow[mp.n - D + c] : 0.0;
     }
-#pragma unroll
-    for (int c = 0; c < 8; ++c)
-      gc[c] = (interior && c < D) ? Grow[mp.n - D + c] : 0.0;
-  }
-  if constexpr (RC)
-  {
-    const int jc = h.Zst >> 2;
-    const tmx_lds_d2* Zrow2 = reinterpret_cast<const tmx_lds_d2*>(h.Zs + (mp.qg < 0 ? 0 : mp.qg) * h.Zst + mp.qq * jc);
-#pragma unroll
-    for (int c = 0; c < TMX_RC_ZP; ++c)
+    if constexpr (RC)
     {
-      const bool ok = mp.qg >= 0 && 2 * c < jc;
-      const tmx_d2 t = Zrow2[ok ? c : 0];
-      zq[2 * c] = ok ? t.x : 0.0;
-      zq[2 * c + 1] = ok ? t.y : 0.0;
+      const int jc = h.Zst >> 2;
+      const tmx_lds_d2* Zrow2 = reinterpret_cast<const tmx_lds_d2*>(h.Zs + (mp.qg < 0 ? 0 : mp.qg) * h.Zst + mp.qq * jc);
+  #pragma unroll
+      for (int c = 0; c < TMX_RC_ZP; ++c)
+      {
+        const bool ok = mp.qg >= 0 && 2 * c < jc;
+        const tmx_d2 t = Zrow2[ok ? c : 0];
+        zq[2 * c] = ok ? t.x : 0.0;
+        zq[2 * c + 1] = ok ? t.y : 0.0;
+      }
     }
-  }
+};
+  if (ctl == nullptr)
+    load_matrix_rows();
   TMX_PTICK(3);
   // entries of the grouped buffer that no row writes (pad slots, groups of inactive rows) must stay finite
   for (int e = tid; e < w.R + w.T + 18; e += TMX_QP_NT)
@@ -1087,43 +1093,21 @@ TMX_DEVFN int admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, bo
     // the next iteration's phase A only touches registers; its hr stores are ordered after every thread's tp reads by
     // the barrier that follows them, and tp is rewritten only after that barrier
   };
-  const int n_plain = keep_last ? n_iter - 1 : n_iter;
-  for (int it = 0; it < n_plain; ++it)
-    iteration(TmxTag<false>{});
-  if (keep_last && n_iter > 0)
-    iteration(TmxTag<true>{});
-  TMX_TICK(2);
-#pragma unroll
-  for (int q = 0; q < NR; ++q)
-    row_store(w, rowi[q], g[q]);
-  if (pv)
-  {
-    w.xp[v] = xp;
-    w.zbp[v] = zb;
-    w.ybp[v] = yb;
-  }
-  TMX_SYNC();
-  TMX_TICK(9);
-  if (res14 != nullptr)
-  {
-    // ---- RESIDUALS FROM REGISTERS (update_info / compute_residuals, zmode 0): the iterate, the row coefficients and the
-    // column cache are still in registers, so the 14 norms of the termination test cost two exchanges (y of the rows grouped by
-    // waypoint as e was; x with 8 slots per waypoint) and one block reduction instead of a sweep over index lists in LDS.
-    // Every per-element value is formed with the operations and in the order of compute_residuals / at_rows / p_times
-    // (products and sums, no FMA; four partial sums over the waypoint's row list, remainder into the first): same bits.
-    // (the barrier above: every thread is past phase C of the last iteration - tp and hr are free)
+  // ---- RESIDUALS FROM REGISTERS (update_info / compute_residuals, zmode 0): the iterate, the row coefficients and the column
+  // cache are still in registers, so the 14 norms of the termination test cost two exchanges (y of the rows grouped by waypoint
+  // as e was; x with 8 slots per waypoint) and one block reduction instead of a sweep over index lists in LDS.  Every per-element
+  // value is formed with the operations and in the order of compute_residuals / at_rows / p_times (products and sums, no FMA;
+  // four partial sums over the waypoint's row list, remainder into the first): same bits.
+  auto publish_xy = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int q = 0; q < NR; ++q)
       if (has[q])
         h.hr[epos[q]] = g[q].y;  // 0 for an inactive row
     if (pv)
       h.tp[vp] = xp;
-    TMX_SYNC();
-    double m[14];
-#pragma unroll
-    for (int k = 0; k < 14; ++k)
-      m[k] = 0.0;
-#pragma unroll
+  };
+  auto norms14 = [&](double (&m)[22]) __attribute__((always_inline)) {
+  #pragma unroll
     for (int q = 0; q < NR; ++q)
     {
       const RowRegsT<NAX>& gq = g[q];
@@ -1133,7 +1117,7 @@ TMX_DEVFN int admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, bo
         double xb[8];
         {
           const tmx_lds_d2* xb2 = reinterpret_cast<const tmx_lds_d2*>(h.tp + tb[q]);
-#pragma unroll
+  #pragma unroll
           for (int j = 0; j < 4; ++j)
           {
             const tmx_d2 t2 = xb2[j];
@@ -1142,11 +1126,11 @@ TMX_DEVFN int admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, bo
           }
         }
         double ax = 0.0;
-#pragma unroll
+  #pragma unroll
         for (int j = 0; j < 8; ++j)
           if (j < D)
             ax = ax + gq.c[j] * xb[j];
-#pragma unroll
+  #pragma unroll
         for (int k = 0; k < NAX; ++k)
           if (k < gq.na)
             ax = ax + gq.sa[k] * gq.xa[k];
@@ -1159,7 +1143,7 @@ TMX_DEVFN int admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, bo
           m[4] = fmax(m[4], fabs(einv * z));
           m[5] = fmax(m[5], fabs(einv * ax));
         }
-#pragma unroll
+  #pragma unroll
         for (int k = 0; k < NAX; ++k)
           if (k < gq.na)
           {
@@ -1205,7 +1189,7 @@ TMX_DEVFN int admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, bo
       double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
       {
         const tmx_lds_d2* ep = reinterpret_cast<const tmx_lds_d2*>(h.hr + e0off);
-#pragma unroll
+  #pragma unroll
         for (int k2 = 0; k2 < 8; ++k2)
         {
           const tmx_d2 e2 = ep[k2];
@@ -1255,14 +1239,259 @@ TMX_DEVFN int admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, bo
       m[12] = fmax(m[12], fabs(dinv * aty));
       m[13] = fmax(m[13], fabs(dinv * px));
     }
-    const bool sall[14] = { false, false, false, false, false, false, false, false, false, false, false, false, false, false };
-    block_reduce<14>(m, sall, w.red, tid, TMX_QP_NT);
-    if (tid == 0)
+  };
+  // ---- INFEASIBILITY CERTIFICATES FROM REGISTERS (epoch mode; is_primal_infeasible / is_dual_infeasible of check_termination):
+  // deltas of the KEEP iteration.  Exchanges: the projected delta_y of the rows grouped by waypoint -> sx, delta_x with 8 slots per
+  // waypoint -> ty (both free between iterations; values finite, so the zero matrix padding of the loop still annihilates them).
+  //   m[14] max |E dy_proj|   m[15] max |(A' dy_proj) / D|   m[16] max |D dx|   m[17] max |(P dx) / D|
+  // (the sign tests `sum ineq_lhs < 0` / `q.dx < 0` of the certificates are not evaluated: a certificate counts as "certainly
+  //  negative" on its norm test alone, which costs four reduced values instead of eight)
+  const bool certs_ok = ctl != nullptr && w.wp_pst[w.T] <= 6 * 64 && w.T * 8 <= dp.P * h.Gs + 64;
+  [[maybe_unused]] double kp_dyr[NR], kp_dya[NR][NAX], kp_dyb = 0.0;  // projected deltas
+  auto publish_deltas = [&]() __attribute__((always_inline)) {
+    const double BIG = TMX_OSQP_INFTY * TMX_MIN_SCALING;
+#pragma unroll
+    for (int q = 0; q < NR; ++q)
+    {
+      const RowRegsT<NAX>& gq = g[q];
+      double dy = kd_dyr[q];
+      if (gq.hi > BIG)
+        dy = (gq.lo < -BIG) ? 0.0 : fmin(dy, 0.0);
+      else if (gq.lo < -BIG)
+        dy = fmax(dy, 0.0);
+      kp_dyr[q] = gq.act ? dy : 0.0;
+#pragma unroll
+      for (int k = 0; k < NAX; ++k)
+      {
+        double da = kd_dya[q][k];
+        if (gq.ub[k] > BIG)
+          da = fmin(da, 0.0);
+        kp_dya[q][k] = (gq.act && k < gq.na) ? da : 0.0;
+      }
+      if (has[q])
+        h.sx[epos[q]] = kp_dyr[q];
+    }
+    {
+      double dy = kd_dybp;
+      if (ub > BIG)
+        dy = (lb < -BIG) ? 0.0 : fmin(dy, 0.0);
+      else if (lb < -BIG)
+        dy = fmax(dy, 0.0);
+      kp_dyb = pv ? dy : 0.0;
+    }
+    if (pv)
+      h.ty[vp] = kd_dxp;
+  };
+  auto certs8 = [&](double (&m)[22]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < NR; ++q)
+    {
+      const RowRegsT<NAX>& gq = g[q];
+      if (gq.act)
+      {
+        const int r = rowi[q];
+        const double dy = kp_dyr[q];
+        m[14] = fmax(m[14], fabs(w.Er[r] * dy));
+#pragma unroll
+        for (int k = 0; k < NAX; ++k)
+          if (k < gq.na)
+          {
+            const int a = w.aoff[r] + k;
+            const double da = kp_dya[q][k];
+            m[14] = fmax(m[14], fabs(w.Eba[a] * da));
+            const double dinv = fast_rcp(w.Da[a]);
+            m[15] = fmax(m[15], fabs((gq.sa[k] * dy + gq.bb[k] * da) * dinv));
+            m[16] = fmax(m[16], fabs(w.Da[a] * kd_dxa[q][k]));
+          }
+      }
+    }
+    if (pv)
+    {
+      const double dy = kp_dyb;
+      m[14] = fmax(m[14], fabs(w.Ebp[v] * dy));
+      // (A' dy)_v over the waypoint's row list from the grouped buffer (any summation order: the result is only compared with
+      // a threshold it must exceed twofold)
+      double s0 = 0.0, s1 = 0.0;
+      {
+        const tmx_lds_d2* ep = reinterpret_cast<const tmx_lds_d2*>(h.sx + e0off);
+#pragma unroll
+        for (int k2 = 0; k2 < 8; ++k2)
+        {
+          const tmx_d2 e2 = ep[k2];
+          s0 = __builtin_fma(cj[2 * k2], e2.x, s0);
+          s1 = __builtin_fma(cj[2 * k2 + 1], e2.y, s1);
+        }
+      }
+      for (int q = q_rest; q < q_end; ++q)
+        s0 += w.coef[w.wp_list[q] * D + vj] * h.sx[e0off + (q - q0v)];
+      const double dinv = fast_rcp(w.Dp[v]);
+      m[15] = fmax(m[15], fabs(((s0 + s1) + bb * dy) * dinv));
+      m[16] = fmax(m[16], fabs(w.Dp[v] * kd_dxp));
+      double px = w.pd[v] * kd_dxp;
+      if (vt > 0)
+        px += w.po[v - D] * h.ty[vp - 8];
+      if (vt < w.T - 1)
+        px += w.po[v] * h.ty[vp + 8];
+      m[17] = fmax(m[17], fabs(px * dinv));
+    }
+  };
+  int iter_done = 0;
+  if (ctl == nullptr)
+  {
+    const int n_plain = keep_last ? n_iter - 1 : n_iter;
+    for (int it = 0; it < n_plain; ++it)
+      iteration(TmxTag<false>{});
+    if (keep_last && n_iter > 0)
+      iteration(TmxTag<true>{});
+    iter_done = n_iter;
+    TMX_TICK(2);
+#pragma unroll
+    for (int q = 0; q < NR; ++q)
+      row_store(w, rowi[q], g[q]);
+    if (pv)
+    {
+      w.xp[v] = xp;
+      w.zbp[v] = zb;
+      w.ybp[v] = yb;
+    }
+    TMX_SYNC();
+    TMX_TICK(9);
+    if (res14 != nullptr)
+    {
+      // (the barrier above: every thread is past phase C of the last iteration - tp and hr are free)
+      publish_xy();
+      TMX_SYNC();
+      double m[22];
+#pragma unroll
+      for (int k = 0; k < 22; ++k)
+        m[k] = 0.0;
+      norms14(m);
+      double m14[14];
 #pragma unroll
       for (int k = 0; k < 14; ++k)
-        res14[k] = m[k];
-    TMX_SYNC();
+        m14[k] = m[k];
+      const bool sall[14] = { false, false, false, false, false, false, false, false, false, false, false, false, false, false };
+      block_reduce<14>(m14, sall, w.red, tid, TMX_QP_NT);
+      if (tid == 0)
+#pragma unroll
+        for (int k = 0; k < 14; ++k)
+          res14[k] = m14[k];
+      TMX_SYNC();
+    }
+    return iter_done;
   }
+  // ---- EPOCH MODE --------------------------------------------------------------------------------------------------------------
+  const tmx_osqp_settings& st = P->osqp;
+  const int max_iter = st.max_iter, chk = st.check_termination, rint = (st.adaptive_rho && st.adaptive_rho_interval) ? st.adaptive_rho_interval : 0;
+  const double eps_abs = st.eps_abs, eps_rel = st.eps_rel, eps_pinf = st.eps_prim_inf, eps_dinf = st.eps_dual_inf, rtol = st.adaptive_rho_tolerance;
+  const double cinv = w.cinv, cc = w.c, rho0 = w.rho;
+  iter_done = ctl->iter;
+  double m[22];
+  while (true)
+  {
+    int next = max_iter;
+    if (chk)
+      next = min(next, (iter_done / chk + 1) * chk);
+    if (rint)
+      next = min(next, (iter_done / rint + 1) * rint);
+    const int n = next - iter_done;
+    load_matrix_rows();
+    for (int it = 0; it < n - 1; ++it)
+      iteration(TmxTag<false>{});
+    if (n > 0)
+      iteration(TmxTag<true>{});
+    iter_done = next;
+    TMX_TICK(2);
+    TMX_SYNC();  // every thread is past phase C of the last iteration: tp / hr / sx / ty are free
+    publish_xy();
+    if (certs_ok)
+      publish_deltas();
+    TMX_SYNC();
+#pragma unroll
+    for (int k = 0; k < 22; ++k)
+      m[k] = 0.0;
+    norms14(m);
+    if (certs_ok)
+      certs8(m);
+    double m18[18];
+#pragma unroll
+    for (int k = 0; k < 18; ++k)
+      m18[k] = m[k];
+    const bool sall[18] = { false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false };
+    block_reduce<18>(m18, sall, w.red, tid, TMX_QP_NT);  // ends with every thread holding all values; its barriers free the buffers
+#pragma unroll
+    for (int k = 0; k < 18; ++k)
+      m[k] = m18[k];
+    if (certs_ok)
+    {
+      // back to the state of a burst entry: the loop relies on EXACT zeros in the never-written slots of sx (slot 7 of the 8-slot
+      // coupling products meets a non-zero matrix column in dpart_correct_rc) and of ty.  Ordered before the first use in the
+      // next iteration by the barriers of its phases A and B.
+      for (int e = tid; e < dp.P * h.Gs + 64; e += TMX_QP_NT)
+        h.ty[e] = 0.0;
+      for (int e = tid; e < 6 * 64; e += TMX_QP_NT)
+        h.sx[e] = 0.0;
+    }
+    // ---- would qp_check_nl do anything?  (the same tests in the same order; anything not CERTAINLY a no-op leaves the loop)
+    bool go_on = certs_ok && iter_done < max_iter;
+    const bool can_check = chk && (iter_done % chk == 0);
+    const bool do_rho = rint && (iter_done % rint == 0);
+    if (go_on && can_check)
+    {
+      const double prim_res = m[0], dual_res = cinv * m[6];
+      if (prim_res > TMX_OSQP_INFTY || dual_res > TMX_OSQP_INFTY)
+        go_on = false;
+      const bool prim_ok = prim_res < eps_abs + eps_rel * fmax(m[4], m[5]);
+      const bool dual_ok = dual_res < eps_abs + eps_rel * (cinv * fmax(fmax(m[11], m[12]), m[13]));
+      if (prim_ok && dual_ok)
+        go_on = false;  // solved
+      if (!prim_ok)
+      {
+        // is_primal_infeasible returns false unless norm_dy > DIVISION_TOL and sum < 0 and |A' dy| < eps norm_dy
+        const bool surely_not = !(m[14] > TMX_DIVISION_TOL) || m[15] > 2.0 * eps_pinf * m[14];
+        go_on = go_on && surely_not;
+      }
+      if (!dual_ok)
+      {
+        // is_dual_infeasible returns false unless norm_dx > DIVISION_TOL and q.dx < 0 and |P dx| < c eps norm_dx (and the row tests)
+        const bool surely_not = !(m[16] > TMX_DIVISION_TOL) || m[17] > 2.0 * cc * eps_dinf * m[16];
+        go_on = go_on && surely_not;
+      }
+    }
+    if (go_on && do_rho)
+    {
+      // rho_estimate + the update rule of osqp_solve, from the same norms
+      const double prim = m[1] / (fmax(m[2], m[3]) + TMX_DIVISION_TOL);
+      const double dual = m[7] / (fmax(fmax(m[8], m[9]), m[10]) + TMX_DIVISION_TOL);
+      const double rho_new = fmin(fmax(rho0 * sqrt(prim / dual), TMX_RHO_MIN), TMX_RHO_MAX);
+      if ((rho_new > rho0 * rtol) || (rho_new < rho0 / rtol))
+        go_on = false;
+    }
+    go_on = __builtin_amdgcn_readfirstlane(go_on ? 1 : 0) != 0;
+    TMX_TICK(9);
+#ifdef TMX_PROFILE
+    pc[5] += 1 + (go_on ? (1LL << 20) : 0);  // diagnostic: checks, and checks after which the burst went on (slot 5 is unused on this path)
+#endif
+    if (!go_on)
+      break;
+  }
+  TMX_TICK(2);
+#pragma unroll
+  for (int q = 0; q < NR; ++q)
+    row_store(w, rowi[q], g[q]);
+  if (pv)
+  {
+    w.xp[v] = xp;
+    w.zbp[v] = zb;
+    w.ybp[v] = yb;
+  }
+  if (tid == 0 && res14 != nullptr)
+#pragma unroll
+    for (int k = 0; k < 14; ++k)
+      res14[k] = m[k];
+  TMX_SYNC();
+  TMX_TICK(9);
+  return iter_done;
 }
 
 #ifdef TMX_BURST_NOINLINE
@@ -1288,8 +1517,8 @@ __device__ __attribute__((noinline)) static void admm_burst_nl(const QpWs* wsh, 
 #ifndef TMX_BURST_RC
 #define TMX_BURST_RC 1
 #endif
-TMX_DEVFN void admm_run_fast(const QpWs& w, const DevProblem* P, int n_iter, bool keep_last, int tid, long long* pc, long long& tlast,
-                              double* res14 = nullptr)
+TMX_DEVFN int admm_run_fast(const QpWs& w, const DevProblem* P, int n_iter, bool keep_last, int tid, long long* pc, long long& tlast,
+                             double* res14 = nullptr, BurstCtl* ctl = nullptr)
 {
   // matrix rows of the dense solve in registers when they fit the fixed register arrays (7-DOF / 30 waypoints: Gs = 22, Zst = 56)
   const bool rc = TMX_BURST_RC && w.Gs <= 2 * TMX_RC_GP && w.Zst <= 8 * TMX_RC_ZP;
@@ -1313,35 +1542,38 @@ TMX_DEVFN void admm_run_fast(const QpWs& w, const DevProblem* P, int n_iter, boo
   if (tid == 0)
     *wsh = w;
   TMX_SYNC();
-#define TMX_BURST_CALL(RCv, NRv, INTv) admm_burst_nl<RCv, NRv, INTv>(wsh, P, n_iter, keep_last ? 1 : 0, pc, &tlast)
+#define TMX_BURST_CALL(RCv, NRv, INTv) (admm_burst_nl<RCv, NRv, INTv>(wsh, P, n_iter, keep_last ? 1 : 0, pc, &tlast), n_iter)
 #define TMX_BURST_CALL1(RCv, NRv, INTv) TMX_BURST_CALL(RCv, NRv, INTv)
 #else
-#define TMX_BURST_CALL(RCv, NRv, INTv) admm_burst_core<RCv, NRv, INTv, 2>(w, P, n_iter, keep_last, tid, pc, tlast, res14)
-#define TMX_BURST_CALL1(RCv, NRv, INTv) admm_burst_core<RCv, NRv, INTv, 1>(w, P, n_iter, keep_last, tid, pc, tlast, res14)
+#define TMX_BURST_CALL(RCv, NRv, INTv) admm_burst_core<RCv, NRv, INTv, 2>(w, P, n_iter, keep_last, tid, pc, tlast, res14, ctl)
+#define TMX_BURST_CALL1(RCv, NRv, INTv) admm_burst_core<RCv, NRv, INTv, 1>(w, P, n_iter, keep_last, tid, pc, tlast, res14, ctl)
 #endif
+  // (every wave runs the same number of iterations: the epoch-mode decision is made from workgroup-wide reductions)
+  int done;
   if (!rc)
-    TMX_BURST_CALL(false, TMX_NROW, true);
+    done = TMX_BURST_CALL(false, TMX_NROW, true);
   else if (two)
   {
     if (intw)
-      TMX_BURST_CALL(true, TMX_NROW, true);
+      done = TMX_BURST_CALL(true, TMX_NROW, true);
     else
-      TMX_BURST_CALL(true, TMX_NROW, false);
+      done = TMX_BURST_CALL(true, TMX_NROW, false);
   }
   else if (aux2)
   {
     if (intw)
-      TMX_BURST_CALL(true, 1, true);
+      done = TMX_BURST_CALL(true, 1, true);
     else
-      TMX_BURST_CALL(true, 1, false);
+      done = TMX_BURST_CALL(true, 1, false);
   }
   else
   {
     if (intw)
-      TMX_BURST_CALL1(true, 1, true);
+      done = TMX_BURST_CALL1(true, 1, true);
     else
-      TMX_BURST_CALL1(true, 1, false);
+      done = TMX_BURST_CALL1(true, 1, false);
   }
 #undef TMX_BURST_CALL
 #undef TMX_BURST_CALL1
+  return done;
 }

@@ -717,7 +717,44 @@ __device__ __attribute__((noinline)) static void qp_admm_fast_nl(const DevProble
     sh = qp_ws_rebuild(w0, P, Bt, b, smem);
   }
   TMX_PROF_ENTER(sh);
+#ifndef TMX_RES_FROM_REGS
+#define TMX_RES_FROM_REGS 1
+#endif
+#ifndef TMX_BURST_EPOCHS
+#define TMX_BURST_EPOCHS 1  // the burst keeps iterating across residual checks that change nothing (tmx_part.h, BurstCtl)
+#endif
   int iter = 0, ended = 0;
+#if TMX_BURST_EPOCHS && TMX_RES_FROM_REGS
+  {
+    int done = 0;
+    while (true)
+    {
+      {
+        QpWs w;
+        sh = qp_ws_rebuild(w, P, Bt, b, smem);
+        BurstCtl ctl;
+        ctl.iter = done;
+        done = admm_run_fast(w, P, 0, true, tid, pc, tlast, sh->res, &ctl);
+        if (tid == 0)
+          sh->have_res = 1;  // ordered before qp_check_nl's reads by the barrier at its entry (qp_ws_rebuild + first block sync)
+        TMX_SYNC();
+      }
+      iter = done;
+      TMX_PROF_LEAVE(sh);
+      ended = qp_check_nl(P, Bt, b, iter, lds_off);
+#ifdef TMX_PROFILE
+      tlast = TMX_CLK();
+#endif
+      if (ended)
+        break;
+      if (done >= st.max_iter)
+      {
+        iter = st.max_iter + 1;  // the loop `for (iter = 1; iter <= max_iter; ++iter)` ran out
+        break;
+      }
+    }
+  }
+#else
   for (iter = 1; iter <= st.max_iter; ++iter)
   {
     int next = st.max_iter;
@@ -728,9 +765,6 @@ __device__ __attribute__((noinline)) static void qp_admm_fast_nl(const DevProble
     {
       QpWs w;
       sh = qp_ws_rebuild(w, P, Bt, b, smem);
-#ifndef TMX_RES_FROM_REGS
-#define TMX_RES_FROM_REGS 1
-#endif
       admm_run_fast(w, P, next - iter + 1, true, tid, pc, tlast, TMX_RES_FROM_REGS ? sh->res : nullptr);
       if (TMX_RES_FROM_REGS && tid == 0)
         sh->have_res = 1;  // ordered before qp_check_nl's reads by the barrier at its entry (qp_ws_rebuild + first block sync)
@@ -745,6 +779,7 @@ __device__ __attribute__((noinline)) static void qp_admm_fast_nl(const DevProble
     if (ended)
       break;
   }
+#endif
   if (tid == 0)
   {
     sh->terminated = ended;
