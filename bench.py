@@ -108,7 +108,8 @@ def main():
 
     def finish(k):
         c = ctxs[k % depth]
-        c.wait()
+        n_active = c.wait()
+        assert n_active == 0, f"step {k}: {n_active} problems left unfinished by a run-to-completion launch"
         r = c.results()
         best = c.argmin((rank * nsteps + k) * B)   # the only collective: RCCL all-gather of 16 bytes per rank inside the library
         return r, best, c.counters()
@@ -179,7 +180,8 @@ def main():
         traffic = None
         try:
             import glob
-            with open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]) as f:   # latest round
+            pat = "r*_pmc_traffic.json" if cid == 1 else "r*_pmc_traffic_cfg%d.json" % cid
+            with open(sorted(glob.glob(os.path.join(ROOT, "profiles", pat)))[-1]) as f:   # latest round
                 tj = json.load(f)
             if tj.get("batch_per_gpu") == B:
                 traffic = tj.get("hbm_bytes_per_launch")
@@ -190,7 +192,7 @@ def main():
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         roofline = {
             "kernel": "k_sqp_pool", "bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic if cid == 1 else None,
+            "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic,
             "avg_launch_ms": avg_ms, "launches": launches, "algorithmic_flop_per_admm_iter": f_iter,
             "admm_iters_per_launch": tot_admm / launches,
             # with two batches in flight the launches overlap (the tail of one under the bulk of the next): a launch still lasts
@@ -200,19 +202,25 @@ def main():
             "kernel_time_share": {"admm_ms": stats["admm_ms"], "convexify_ms": stats["convexify_ms"],
                                   "evaluate_ms": stats["evaluate_ms"], "wall_ms": (t1 - t0) * 1e3},
         }
-        if cid != 1:
-            # QP workspace in HBM (k_sqp_fused_hbm) or the generic LDS path inside k_sqp_pool: the block factor and the rows are
-            # streamed every ADMM iteration - SURVEY.md section 8(d): B_admm = 2 * 12 * (nnz(L) + nnz(A)) bytes per iteration,
-            # nnz(L) ~ T * 1.5 * D^2 + the slack couplings (one per aux variable)
+        kernel_name = "k_sqp_fused_hbm" if ctx.workspace_in_hbm() else "k_sqp_pool"
+        roofline["kernel"] = kernel_name
+        if kernel_name == "k_sqp_fused_hbm":
+            # QP workspace in HBM (configs 2 and 3): the rows and the block factor are streamed from the workgroup's HBM slice every
+            # ADMM iteration - SURVEY.md section 8(d): B_admm = 2 * 12 * (nnz(L) + nnz(A)) bytes per iteration,
+            # nnz(L) ~ T * 1.5 * D^2 + the slack couplings (one per aux variable).  `traffic` is the counter measurement of the same
+            # launch (profiles/r*_pmc_traffic_cfgN.json): what the kernel really moved, against these algorithmic bytes.
             nnzL = 1.5 * T * D * D + (r0.n - T * D)
             b_iter = 24.0 * (nnzL + r0.nnzA)
             ach = b_iter * tot_admm / launches / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-            roofline = {"kernel": "k_sqp_fused_hbm" if r0.n * 8 * 30 > 160 * 1024 else "k_sqp_pool", "bound": "hbm", "achieved": ach, "peak": 8000.0,
-                        "unit": "GB/s", "frac": ach / 8000.0, "traffic": None, "avg_launch_ms": avg_ms, "launches": launches,
+            roofline = {"kernel": kernel_name, "bound": "hbm", "achieved": ach, "peak": 8000.0,
+                        "unit": "GB/s", "frac": ach / 8000.0, "traffic": traffic, "avg_launch_ms": avg_ms, "launches": launches,
                         "algorithmic_bytes_per_admm_iter": b_iter, "admm_iters_per_launch": tot_admm / launches,
+                        "measured_traffic_gbps": (traffic / (avg_ms * 1e-3) / 1e9) if (traffic and avg_ms > 0) else None,
                         "flop_view": {"achieved_tflops": achieved, "frac_of_fp64_peak": achieved / FP64_PEAK_TFLOPS}}
+        # (config 4 runs LDS-resident on k_sqp_pool's generic path: like config 1 it is priced against the fp64 roof - it is
+        #  bound by dependent-issue latency, not by HBM)
         cpu = None
-        if world == 1 and not args.no_cpu_baseline and cid == 1:
+        if world == 1 and not args.no_cpu_baseline:
             from oracle import pyorc
             cores = os.cpu_count() or 1
             pyorc.build()
@@ -230,13 +238,17 @@ def main():
             except (OSError, ValueError, IndexError):
                 pass
             tried = []
-            for nthr in sorted({min(cores, 64), min(cores, 32), min(cores, 16), min(cores, 8)}, reverse=True):
-                nsample = min(B, max(32, 2 * nthr))   # two problems per thread: a few seconds per run
+            # bounded: config 1 takes a few seconds per thread count; the long-horizon / pair-row configurations are timed on
+            # fewer thread counts and one problem per thread so that the whole leg stays within ~30 s
+            thread_counts = sorted({min(cores, 64), min(cores, 32), min(cores, 16), min(cores, 8)}, reverse=True) if cid == 1 else [min(cores, 32), min(cores, 16)]
+            for nthr in thread_counts:
+                nsample = min(B, max(32, 2 * nthr)) if cid == 1 else min(B, nthr)
                 xs = seeds_host[:nsample]
                 tc0 = time.perf_counter()
-                o = pyorc.sqp_batch(desc, xs, nthreads=nthr)
+                o = pyorc.sqp2_batch(desc, xs, osqp=osqp_st, nthreads=nthr) if cid == 4 else pyorc.sqp_batch(desc, xs, nthreads=nthr)
                 dt = time.perf_counter() - tc0
-                tried.append((float((o["n_func_evals"] - 1).sum() / dt), nthr, nsample, dt, o))
+                nit = o["n_qp_solves"].sum() if cid == 4 else (o["n_func_evals"] - 1).sum()
+                tried.append((float(nit / dt), nthr, nsample, dt, o))
             best = max(tried, key=lambda t: t[0])
             o = best[4]
             cpu = {"value": best[0], "unit": "SQP iters/s", "cores": best[1], "kind": "port",
@@ -246,7 +258,7 @@ def main():
                              ", ".join(f"{t[1]} thr -> {t[0]:.0f} it/s" for t in tried),
                    "per_thread_value": best[0] / best[1], "host_threads": cores, "cgroup_cpu_quota_cores": quota,
                    "qp_solves_per_s": float(o["n_qp_solves"].sum() / best[3]),
-                   "admm_iters_per_s": float(o["admm_iters"] / best[3])}
+                   "admm_iters_per_s": (float(o["admm_iters"] / best[3]) if "admm_iters" in o else None)}
         line = {
             "metric": "SQP iters/s (+ QP solves/s), 7-DOF x 30-wp x 1024-batch glass_upright" if cid == 1 else
                       "SQP iters/s (+ QP solves/s), BASELINE config %d" % cid,

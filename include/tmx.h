@@ -366,6 +366,10 @@ TMX_API tmx_status tmx_export_csc(tmx_ctx* ctx, int32_t problem, int32_t* n, int
                                   double* A_x, double* l, double* u);
 /* one batched Model::optimize() on the current convexification + trust box (osqp_interface.cpp:440-615);
  * x_qp: B*n_max solution in reference variable order (primary vars, then aux vars); n_max from tmx_qp_dims */
+/* where the QP workspace of the uploaded problem lives: *in_hbm = 1 for the k_*_hbm kernels (workspace carved from HBM: long
+ * horizons / large row counts), 0 when it is LDS-resident (k_sqp_pool); *lds_bytes = dynamic LDS of the QP kernels;
+ * *hbm_bytes_per_problem = per-problem HBM scratch + HBM workspace.  Any pointer may be NULL. */
+TMX_API tmx_status tmx_workspace_info(tmx_ctx* ctx, int32_t* in_hbm, int64_t* lds_bytes, int64_t* hbm_bytes_per_problem);
 TMX_API tmx_status tmx_qp_dims(tmx_ctx* ctx, int32_t* n_max, int32_t* m_max);
 TMX_API tmx_status tmx_qp_solve(tmx_ctx* ctx, double* x_qp, int32_t* cvx_status, tmx_qp_record* rec);
 

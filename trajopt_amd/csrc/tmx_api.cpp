@@ -1056,6 +1056,7 @@ static tmx_status ensure_batch(tmx_ctx* ctx, int B)
   H.step_log_stride = TMX_STEP_LOG_HEAD + 3 * P.n_costs + 4 * P.n_cnts;
   AL(step_log, b * (size_t)H.step_log_stride);
   AL(t_start, 1);
+  AL(accept_flag, b);
   H.tail_flag = ctx->h_tail;  // pinned host memory is device-accessible at the same address (unified addressing)
   H.qp_scratch_stride = (long long)qp_scratch_doubles(P.D, P.T, P.R, P.NA, P.n_link, P.coef_far);
   AL(qp_scratch, b * (size_t)H.qp_scratch_stride);
@@ -1503,6 +1504,22 @@ tmx_status tmx_convexify(tmx_ctx* ctx, int32_t* active, double* coef, double* rh
       (rc = d2h(ctx, rhs, ctx->hb.rhs, B * ctx->hp.R)) != TMX_OK)
     return rc;
   HIPCHK(hipStreamSynchronize(ctx->stream));
+  return TMX_OK;
+}
+
+tmx_status tmx_workspace_info(tmx_ctx* ctx, int32_t* in_hbm, int64_t* lds_bytes, int64_t* hbm_bytes_per_problem)
+{
+  if (!ctx)
+    return TMX_ERR_INVALID;
+  if (!ctx->have_problem)
+    return TMX_ERR_STATE;
+  const DevProblem& P = ctx->hp;
+  if (in_hbm)
+    *in_hbm = ctx->ws_in_hbm ? 1 : 0;
+  if (lds_bytes)
+    *lds_bytes = static_cast<int64_t>(ctx->ws_in_hbm ? ctx->smem_chain : ctx->smem_pool);
+  if (hbm_bytes_per_problem)
+    *hbm_bytes_per_problem = static_cast<int64_t>(qp_scratch_doubles(P.D, P.T, P.R, P.NA, P.n_link, P.coef_far) * sizeof(double) + ctx->ws_bytes);
   return TMX_OK;
 }
 

@@ -1770,23 +1770,53 @@ TMX_DEVFN void sqp_model_values(const DevProblem* P, const DevBatch* Bt, int b, 
   }
 }
 
+TMX_DEVFN void sqp_decide(const DevProblem* P, const DevBatch* Bt, int b, const double* model_cost, const double* model_viol);
 TMX_DEVFN void sqp_update_block(const DevProblem* P, const DevBatch* Bt, int b, double* smem, int tid, int NT)
 {
   const int NX = P->NX;
-  const tmx_sqp_params& sp = P->sqp;
   double* model_cost = smem;                   // n_costs
   double* model_viol = model_cost + P->n_costs;  // n_cnts
   double* cost_vals = Bt->cost_vals + (size_t)b * P->n_costs;
   double* cnt_viols = Bt->cnt_viols + (size_t)b * P->n_cnts;
   const double* new_cost = Bt->new_cost_vals + (size_t)b * P->n_costs;
   const double* new_viol = Bt->new_cnt_viols + (size_t)b * P->n_cnts;
-  double* merit = Bt->merit + (size_t)b * P->n_cnts;
   // ---- model values at the QP solution
   const bool solved = Bt->cvx[b] == TMX_CVX_SOLVED && Bt->phase[b] != PHASE_DONE;
   if (solved)
     sqp_model_values(P, Bt, b, Bt->xq + (size_t)b * P->n_max, smem, tid, NT);
-  if (tid != 0)
-    return;  // the decisions are serial per problem (O(terms))
+  // the decisions are serial per problem (O(terms)): thread 0; an accepted point is then copied by the whole workgroup
+  if (tid == 0)
+  {
+    Bt->accept_flag[b] = 0;
+    sqp_decide(P, Bt, b, model_cost, model_viol);
+  }
+  TMX_SYNC();
+  if (Bt->accept_flag[b])
+  {
+    double* x = Bt->x + (size_t)b * NX;
+    const double* xn = Bt->xnew + (size_t)b * NX;
+    for (int v = tid; v < NX; v += NT)
+      x[v] = xn[v];
+    for (int k = tid; k < P->n_costs; k += NT)
+      cost_vals[k] = new_cost[k];
+    for (int k = tid; k < P->n_cnts; k += NT)
+      cnt_viols[k] = new_viol[k];
+  }
+}
+
+// thread 0: BasicTrustRegionSQPResults::update's merits and the trust-region / penalty decisions (optimizers.cpp:380-426, 810-968).
+// An accepted step only raises Bt->accept_flag: the copy of (new_x, new costs, new violations) is done by the caller in parallel,
+// and this function reads the accepted values through cur_cost / cur_viol.
+TMX_DEVFN void sqp_decide(const DevProblem* P, const DevBatch* Bt, int b, const double* model_cost, const double* model_viol)
+{
+  const tmx_sqp_params& sp = P->sqp;
+  const double* cost_vals = Bt->cost_vals + (size_t)b * P->n_costs;
+  const double* cnt_viols = Bt->cnt_viols + (size_t)b * P->n_cnts;
+  const double* new_cost = Bt->new_cost_vals + (size_t)b * P->n_costs;
+  const double* new_viol = Bt->new_cnt_viols + (size_t)b * P->n_cnts;
+  double* merit = Bt->merit + (size_t)b * P->n_cnts;
+  const double* cur_cost = cost_vals;  // results_.cost_vals / cnt_viols as the decisions below see them
+  const double* cur_viol = cnt_viols;
   int phase = Bt->phase[b];
   if (phase == PHASE_DONE)
     return;
@@ -1863,14 +1893,9 @@ TMX_DEVFN void sqp_update_block(const DevProblem* P, const DevBatch* Bt, int b, 
     }
     else
     {
-      double* x = Bt->x + (size_t)b * NX;
-      const double* xn = Bt->xnew + (size_t)b * NX;
-      for (int v = 0; v < NX; ++v)
-        x[v] = xn[v];
-      for (int k = 0; k < P->n_costs; ++k)
-        cost_vals[k] = new_cost[k];
-      for (int k = 0; k < P->n_cnts; ++k)
-        cnt_viols[k] = new_viol[k];
+      Bt->accept_flag[b] = 1;  // results_.x = new_x, cost_vals = new_cost_vals, cnt_viols = new_cnt_viols: copied by the workgroup
+      cur_cost = new_cost;
+      cur_viol = new_viol;
       box *= sp.trust_expand_ratio;
       next = GO_AFTER_WHILE;
     }
@@ -1888,7 +1913,7 @@ TMX_DEVFN void sqp_update_block(const DevProblem* P, const DevBatch* Bt, int b, 
   }
   double vmax = -1e300;
   for (int k = 0; k < P->n_cnts; ++k)
-    vmax = fmax(vmax, cnt_viols[k]);
+    vmax = fmax(vmax, cur_viol[k]);
   const bool viol_ok = (P->n_cnts == 0) || (vmax < sp.cnt_tolerance);
   if (next == GO_AFTER_WHILE)
   {
@@ -1921,7 +1946,7 @@ TMX_DEVFN void sqp_update_block(const DevProblem* P, const DevBatch* Bt, int b, 
       if (sp.inflate_constraints_individually)
       {
         for (int k = 0; k < P->n_cnts; ++k)
-          if (cnt_viols[k] > sp.cnt_tolerance)
+          if (cur_viol[k] > sp.cnt_tolerance)
             merit[k] *= sp.merit_coeff_increase_ratio;
       }
       else
@@ -1948,7 +1973,7 @@ TMX_DEVFN void sqp_update_block(const DevProblem* P, const DevBatch* Bt, int b, 
   Bt->retval[b] = retval;
   double tot = 0.0;
   for (int k = 0; k < P->n_costs; ++k)
-    tot += cost_vals[k];
+    tot += cur_cost[k];
   Bt->total_cost[b] = tot;
   Bt->phase[b] = PHASE_DONE;
 }
@@ -2125,169 +2150,184 @@ TMX_DEVFN void sqp2_update_block(const DevProblem* P, const DevBatch* Bt, int b,
   const bool solved = Bt->cvx[b] == TMX_CVX_SOLVED && Bt->phase[b] != PHASE_DONE;
   if (solved)
     sqp2_model_values(P, Bt, b, Bt->xq + (size_t)b * P->n_max, smem, tid, NT);
-  if (tid != 0)
-    return;
-  if (Bt->phase[b] == PHASE_DONE)
-    return;
-  double box = Bt->trust[b];
-  int st = TMX_SQP_RUNNING;
-  Bt->n_qp[b] += 1;  // overall_iteration
-  bool to_after_loop = false;
-  auto finish = [&](int status) {
-    Bt->trust[b] = box;
-    Bt->status[b] = status;
-    Bt->retval[b] = status;
-    double tot = 0.0;
-    for (int k = 0; k < P->n_costs; ++k)
-      tot += cost_vals[k];
-    Bt->total_cost[b] = tot;
-    Bt->phase[b] = PHASE_DONE;
-  };
-  if (Bt->cvx[b] != TMX_CVX_SOLVED)
+  // thread 0 decides; an accepted point is copied by the whole workgroup afterwards (cur_cost / cur_viol: the values the
+  // decisions after an acceptance see)
+  if (tid == 0)
   {
-    Bt->qp_fail[b] += 1;
-    st = TMX_SQP_QP_SOLVE_FAILED;
-    if (Bt->qp_fail[b] < sp.max_qp_solver_failures)
-      box *= sp.trust_shrink_ratio;
-    else if (Bt->qp_fail[b] == sp.max_qp_solver_failures)
-      box = sp.min_trust_box_size;
-    else
-      to_after_loop = true;  // "the convex solver failed you one too many times": return from the trust-region loop
+    Bt->accept_flag[b] = 0;
+    const double* cur_cost = cost_vals;
+    const double* cur_viol = cnt_viols;
+    [&]() {
+      if (Bt->phase[b] == PHASE_DONE)
+        return;
+      double box = Bt->trust[b];
+      int st = TMX_SQP_RUNNING;
+      Bt->n_qp[b] += 1;  // overall_iteration
+      bool to_after_loop = false;
+      auto finish = [&](int status) {
+        Bt->trust[b] = box;
+        Bt->status[b] = status;
+        Bt->retval[b] = status;
+        double tot = 0.0;
+        for (int k = 0; k < P->n_costs; ++k)
+          tot += cur_cost[k];
+        Bt->total_cost[b] = tot;
+        Bt->phase[b] = PHASE_DONE;
+      };
+      if (Bt->cvx[b] != TMX_CVX_SOLVED)
+      {
+        Bt->qp_fail[b] += 1;
+        st = TMX_SQP_QP_SOLVE_FAILED;
+        if (Bt->qp_fail[b] < sp.max_qp_solver_failures)
+          box *= sp.trust_shrink_ratio;
+        else if (Bt->qp_fail[b] == sp.max_qp_solver_failures)
+          box = sp.min_trust_box_size;
+        else
+          to_after_loop = true;  // "the convex solver failed you one too many times": return from the trust-region loop
+      }
+      else
+      {
+        double best_exact = 0.0, new_approx = 0.0, new_exact = 0.0;
+        for (int k = 0; k < P->n_costs; ++k)
+        {
+          best_exact += cost_vals[k];
+          new_approx += model_cost[k];
+          new_exact += new_cost[k];
+        }
+        double d0 = 0.0, d1 = 0.0, d2 = 0.0;
+        for (int k = 0; k < P->n_cnts; ++k)
+        {
+          d0 += cnt_viols[k] * merit[k];
+          d1 += model_viol[k] * merit[k];
+          d2 += new_viol[k] * merit[k];
+        }
+        best_exact += d0;
+        new_approx += d1;
+        new_exact += d2;
+        const double approx = best_exact - new_approx, exact = best_exact - new_exact;
+        const double ratio = (fabs(approx) < 1e-12) ? 0.0 : exact / approx;
+        Bt->n_fe[b] += 1;
+        step_log_write(P, Bt, b, 1, box, cost_vals, model_cost, new_cost, cnt_viols, model_viol, new_viol, merit, best_exact, new_approx, new_exact,
+                       approx, exact, ratio);
+        if (approx < sp.min_approx_improve)
+        {
+          st = TMX_SQP_CONVERGED;
+          to_after_loop = true;
+        }
+        else if (approx / fmax(fabs(best_exact), 1e-12) < sp.min_approx_improve_frac)
+        {
+          st = TMX_SQP_CONVERGED;
+          to_after_loop = true;
+        }
+        else if (exact < 0 || ratio < sp.improve_ratio_threshold)
+          box *= sp.trust_shrink_ratio;
+        else
+        {
+          Bt->accept_flag[b] = 1;  // best_var_vals / best costs / violations = the new ones: copied by the workgroup below
+          cur_cost = new_cost;
+          cur_viol = new_viol;
+          box *= sp.trust_expand_ratio;
+          to_after_loop = true;  // accepted: return from the trust-region loop (status running)
+        }
+      }
+      if (!to_after_loop)
+      {
+        // `while (box_size.maxCoeff() >= min_trust_box_size)`: another solve of the same convexification with the new box
+        if (box >= sp.min_trust_box_size)
+        {
+          Bt->trust[b] = box;
+          Bt->phase[b] = PHASE_SOLVE;
+          return;
+        }
+      }
+      // ---- tail of stepSQPSolver
+      bool step_converged = (st == TMX_SQP_CONVERGED);
+      if (!step_converged && box < sp.min_trust_box_size)
+      {
+        st = TMX_SQP_CONVERGED;
+        step_converged = true;
+      }
+      auto viol_ok = [&]() {
+        if (P->n_cnts == 0)
+          return true;
+        double vmax = cur_viol[0];
+        for (int k = 1; k < P->n_cnts; ++k)
+          vmax = fmax(vmax, cur_viol[k]);
+        return vmax < sp.cnt_tolerance;
+      };
+      bool convex_loop_done = step_converged;
+      if (!step_converged)
+      {
+        // next convexification iteration of `for (convex_iteration = 1; convex_iteration < 100; ...)`
+        Bt->iter[b] += 1;
+        if (Bt->iter[b] >= 100)
+          convex_loop_done = true;  // the loop runs out with the current status
+        else if (Bt->n_qp[b] >= sp.max_iter)
+        {
+          st = TMX_SQP_ITERATION_LIMIT;
+          convex_loop_done = true;
+        }
+      }
+      while (true)
+      {
+        if (!convex_loop_done)
+        {
+          Bt->qp_fail[b] = 0;
+          Bt->trust[b] = box;
+          Bt->phase[b] = PHASE_CONVEXIFY;
+          return;
+        }
+        // ---- after the convexification loop (solve(), :126-152)
+        if (viol_ok())
+        {
+          finish(TMX_SQP_CONVERGED);
+          return;
+        }
+        if (st == TMX_SQP_ITERATION_LIMIT || st == TMX_SQP_TIME_LIMIT)
+        {
+          finish(st);
+          return;
+        }
+        st = TMX_SQP_RUNNING;
+        // adjustPenalty
+        if (sp.inflate_constraints_individually)
+        {
+          for (int k = 0; k < P->n_cnts; ++k)
+            if (cur_viol[k] > sp.cnt_tolerance)
+              merit[k] *= sp.merit_coeff_increase_ratio;
+        }
+        else
+          for (int k = 0; k < P->n_cnts; ++k)
+            merit[k] *= sp.merit_coeff_increase_ratio;
+        box = fmax(box, sp.min_trust_box_size / sp.trust_shrink_ratio * 1.5);
+        Bt->merit_inc[b] += 1;
+        if (!((double)Bt->merit_inc[b] < sp.max_merit_coeff_increases))
+        {
+          finish(TMX_SQP_PENALTY_ITERATION_LIMIT);
+          return;
+        }
+        // next penalty iteration: convex_iteration = 1, iteration-limit check at the top of the convexification loop
+        Bt->iter[b] = 1;
+        convex_loop_done = false;
+        if (Bt->n_qp[b] >= sp.max_iter)
+        {
+          st = TMX_SQP_ITERATION_LIMIT;
+          convex_loop_done = true;
+        }
+      }
+    }();
   }
-  else
+  TMX_SYNC();
+  if (Bt->accept_flag[b])
   {
-    double best_exact = 0.0, new_approx = 0.0, new_exact = 0.0;
-    for (int k = 0; k < P->n_costs; ++k)
-    {
-      best_exact += cost_vals[k];
-      new_approx += model_cost[k];
-      new_exact += new_cost[k];
-    }
-    double d0 = 0.0, d1 = 0.0, d2 = 0.0;
-    for (int k = 0; k < P->n_cnts; ++k)
-    {
-      d0 += cnt_viols[k] * merit[k];
-      d1 += model_viol[k] * merit[k];
-      d2 += new_viol[k] * merit[k];
-    }
-    best_exact += d0;
-    new_approx += d1;
-    new_exact += d2;
-    const double approx = best_exact - new_approx, exact = best_exact - new_exact;
-    const double ratio = (fabs(approx) < 1e-12) ? 0.0 : exact / approx;
-    Bt->n_fe[b] += 1;
-    step_log_write(P, Bt, b, 1, box, cost_vals, model_cost, new_cost, cnt_viols, model_viol, new_viol, merit, best_exact, new_approx, new_exact,
-                   approx, exact, ratio);
-    if (approx < sp.min_approx_improve)
-    {
-      st = TMX_SQP_CONVERGED;
-      to_after_loop = true;
-    }
-    else if (approx / fmax(fabs(best_exact), 1e-12) < sp.min_approx_improve_frac)
-    {
-      st = TMX_SQP_CONVERGED;
-      to_after_loop = true;
-    }
-    else if (exact < 0 || ratio < sp.improve_ratio_threshold)
-      box *= sp.trust_shrink_ratio;
-    else
-    {
-      double* x = Bt->x + (size_t)b * NX;
-      const double* xn = Bt->xnew + (size_t)b * NX;
-      for (int v = 0; v < NX; ++v)
-        x[v] = xn[v];
-      for (int k = 0; k < P->n_costs; ++k)
-        cost_vals[k] = new_cost[k];
-      for (int k = 0; k < P->n_cnts; ++k)
-        cnt_viols[k] = new_viol[k];
-      box *= sp.trust_expand_ratio;
-      to_after_loop = true;  // accepted: return from the trust-region loop (status running)
-    }
-  }
-  if (!to_after_loop)
-  {
-    // `while (box_size.maxCoeff() >= min_trust_box_size)`: another solve of the same convexification with the new box
-    if (box >= sp.min_trust_box_size)
-    {
-      Bt->trust[b] = box;
-      Bt->phase[b] = PHASE_SOLVE;
-      return;
-    }
-  }
-  // ---- tail of stepSQPSolver
-  bool step_converged = (st == TMX_SQP_CONVERGED);
-  if (!step_converged && box < sp.min_trust_box_size)
-  {
-    st = TMX_SQP_CONVERGED;
-    step_converged = true;
-  }
-  auto viol_ok = [&]() {
-    if (P->n_cnts == 0)
-      return true;
-    double vmax = cnt_viols[0];
-    for (int k = 1; k < P->n_cnts; ++k)
-      vmax = fmax(vmax, cnt_viols[k]);
-    return vmax < sp.cnt_tolerance;
-  };
-  bool convex_loop_done = step_converged;
-  if (!step_converged)
-  {
-    // next convexification iteration of `for (convex_iteration = 1; convex_iteration < 100; ...)`
-    Bt->iter[b] += 1;
-    if (Bt->iter[b] >= 100)
-      convex_loop_done = true;  // the loop runs out with the current status
-    else if (Bt->n_qp[b] >= sp.max_iter)
-    {
-      st = TMX_SQP_ITERATION_LIMIT;
-      convex_loop_done = true;
-    }
-  }
-  while (true)
-  {
-    if (!convex_loop_done)
-    {
-      Bt->qp_fail[b] = 0;
-      Bt->trust[b] = box;
-      Bt->phase[b] = PHASE_CONVEXIFY;
-      return;
-    }
-    // ---- after the convexification loop (solve(), :126-152)
-    if (viol_ok())
-    {
-      finish(TMX_SQP_CONVERGED);
-      return;
-    }
-    if (st == TMX_SQP_ITERATION_LIMIT || st == TMX_SQP_TIME_LIMIT)
-    {
-      finish(st);
-      return;
-    }
-    st = TMX_SQP_RUNNING;
-    // adjustPenalty
-    if (sp.inflate_constraints_individually)
-    {
-      for (int k = 0; k < P->n_cnts; ++k)
-        if (cnt_viols[k] > sp.cnt_tolerance)
-          merit[k] *= sp.merit_coeff_increase_ratio;
-    }
-    else
-      for (int k = 0; k < P->n_cnts; ++k)
-        merit[k] *= sp.merit_coeff_increase_ratio;
-    box = fmax(box, sp.min_trust_box_size / sp.trust_shrink_ratio * 1.5);
-    Bt->merit_inc[b] += 1;
-    if (!((double)Bt->merit_inc[b] < sp.max_merit_coeff_increases))
-    {
-      finish(TMX_SQP_PENALTY_ITERATION_LIMIT);
-      return;
-    }
-    // next penalty iteration: convex_iteration = 1, iteration-limit check at the top of the convexification loop
-    Bt->iter[b] = 1;
-    convex_loop_done = false;
-    if (Bt->n_qp[b] >= sp.max_iter)
-    {
-      st = TMX_SQP_ITERATION_LIMIT;
-      convex_loop_done = true;
-    }
+    double* x = Bt->x + (size_t)b * NX;
+    const double* xn = Bt->xnew + (size_t)b * NX;
+    for (int v = tid; v < NX; v += NT)
+      x[v] = xn[v];
+    for (int k = tid; k < P->n_costs; k += NT)
+      cost_vals[k] = new_cost[k];
+    for (int k = tid; k < P->n_cnts; k += NT)
+      cnt_viols[k] = new_viol[k];
   }
 }
 #endif

@@ -119,6 +119,7 @@ struct DevBatch
   // BasicTrustRegionSQPResults of the last trust-region evaluation of every problem (tmx_sqp_step_log, layout in include/tmx.h)
   double *step_log;
   int step_log_stride;
+  int *accept_flag;    // B: the decision step accepted new_x (thread 0 -> the workgroup's parallel copy of the accepted point)
   long long *t_start;  // 1: constant-rate clock (100 MHz ticks) at the start of optimize(): reference point of sqp.max_time
 };
 

@@ -49,6 +49,7 @@ _SIGS = {
     "tmx_kernel_stats_reset": ([C.c_void_p], C.c_int),
     "tmx_sqp_state": ([C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p], C.c_int),
     "tmx_sqp_step_log": ([C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)], C.c_int),
+    "tmx_workspace_info": ([C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64)], C.c_int),
     "tmx_model_values": ([C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p], C.c_int),
     "tmx_sqp_set_loop_vars": ([C.c_void_p, C.c_void_p, C.c_void_p], C.c_int),
 }
@@ -183,6 +184,14 @@ class Context:
                              old_cnt_viols=q[3 * nc:3 * nc + nv].copy(), model_cnt_viols=q[3 * nc + nv:3 * nc + 2 * nv].copy(),
                              new_cnt_viols=q[3 * nc + 2 * nv:3 * nc + 3 * nv].copy(), merit_error_coeffs=q[3 * nc + 3 * nv:3 * nc + 4 * nv].copy()))
         return logs
+
+    def workspace_info(self):
+        a, b, c = C.c_int32(0), C.c_int64(0), C.c_int64(0)
+        self._chk(self.lib.tmx_workspace_info(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return dict(in_hbm=bool(a.value), lds_bytes=b.value, hbm_bytes_per_problem=c.value)
+
+    def workspace_in_hbm(self) -> bool:
+        return self.workspace_info()["in_hbm"]
 
     def model_values(self, x_qp):
         """evaluateModelCosts / evaluateModelCntViols (trajopt_sqp: evaluateConvexCosts / evaluateConvexConstraintViolations) of
