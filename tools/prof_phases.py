@@ -1,18 +1,18 @@
 """Phase profile (needs a -DTMX_PROFILE build: make -C trajopt_amd/csrc EXTRA=-DTMX_PROFILE).
    python tools/prof_phases.py [B] [full|first] [lib.so] [config]   - first QP solve only (default) or the whole optimize() run
-   ("full"); config 1 (default), 2 or 3"""
+   ("full"); config 1 (default), 2, 3 or 4"""
 import sys, os, ctypes as C, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from trajopt_amd import configs, abi, runtime
 cid = int(sys.argv[4]) if len(sys.argv) > 4 else 1
-pci, s, g = {1: configs.config1, 2: configs.config2, 3: configs.config3}[cid]()
+pci, s, g = {1: configs.config1, 2: configs.config2, 3: configs.config3, 4: configs.config4}[cid]()
 desc = pci.to_desc()
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 full = len(sys.argv) > 2 and sys.argv[2] == "full"
-x0 = configs.seeds_for(cid, pci, s, g, B)
+x0 = configs.seeds_for(cid, pci, s, g, B, **({"sigma": 0.05} if cid in (3, 4) else {}))
 ctx = runtime.Context(0, sys.argv[3] if len(sys.argv) > 3 else None)
-ctx.upload(desc, abi.default_sqp_params(), abi.default_osqp_settings())
+ctx.upload(desc, abi.default_sqp_params(), configs.osqp_settings_config4() if cid == 4 else abi.default_osqp_settings())
 ctx.set_x0(x0)
 ctx.kernel_stats(reset=True)
 if full:

@@ -868,6 +868,27 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
   UP(slot_c2, c2);
   UP(slot_sub3, sub3);
   UP(slot_aux3, aux3);
+  {
+    // slot range of every cost / constraint (key = cost index, or n_costs + constraint index)
+    std::vector<int> lo((size_t)(n_costs + n_cnts), 1), hi((size_t)(n_costs + n_cnts), 0);
+    std::vector<char> seen((size_t)(n_costs + n_cnts), 0);
+    for (int r = 0; r < static_cast<int>(kind.size()); ++r)
+    {
+      if (kind[(size_t)r] == SLOT_FIXED)
+        continue;
+      const int k = iscnt[(size_t)r] ? n_costs + owner[(size_t)r] : owner[(size_t)r];
+      if (k < 0 || k >= n_costs + n_cnts)
+        continue;
+      if (!seen[(size_t)k])
+      {
+        lo[(size_t)k] = r;
+        seen[(size_t)k] = 1;
+      }
+      hi[(size_t)k] = r;
+    }
+    UP(own_lo, lo);
+    UP(own_hi, hi);
+  }
   P.n_link = R2;
   P.lvs_kmax = lvs_kmax;
   UP(wp_start, wp_start);
@@ -906,6 +927,18 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
         (qp_smem_bytes(D, T, R, NA, R2, 0) > 160 * 1024 && qp_smem_bytes(D, T, R, NA, R2, 1) <= 160 * 1024))
       P.coef_far = 1;
   }
+  {
+    // compact row lists (bit 1 of the flag word): problems whose row slots are mostly collision slots - thousands of slots, a
+    // few hundred contacts at any time (config 3: 15.7 k slots, ~370 active rows).  Such problems never take the dense fast
+    // path (R <= 512), which rebuilds its workspace descriptor without the lists.
+    int n_coll = 0;
+    for (int k : kind)
+      n_coll += (k == SLOT_COLLISION || k == SLOT_COLLISION_LVS) ? 1 : 0;
+    const char* force = std::getenv("TMX_FORCE_COMPACT");  // test hook: "1" on (any size > 512 is not required on the host build), "0" off
+    const bool on = (force && force[0] == '1') || (!(force && force[0] == '0') && R >= 1024 && 2 * n_coll > R);
+    if (on)
+      P.coef_far |= 2;
+  }
   if (!ctx->dp)
   {
     void* p = nullptr;
@@ -915,7 +948,7 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
   HIPCHK(hipMemcpy(ctx->dp, &P, sizeof(DevProblem), hipMemcpyHostToDevice));
   // LDS budgets
   ctx->smem_qp = qp_smem_bytes(D, T, R, NA, R2, P.coef_far);
-  const size_t small_ints = 2 * (size_t)(P.n_max + 1) + 4 * (size_t)R + 2 + 16;
+  const size_t small_ints = 2 * (size_t)(P.n_max + 1) + 4 * (size_t)R + 2 + 16 + 16 + 512;  // qp_structure: tables, hash accumulators, chunk totals
   ctx->smem_small = std::max<size_t>((tmx_eval_scratch_doubles(R, D * T, (int)vel_first.size(), n_costs, n_cnts) + n_costs + n_cnts + 8) * sizeof(double),
                                      small_ints * sizeof(int) + 64);
   ctx->smem_small = std::max<size_t>(ctx->smem_small, tmx_cvx_scratch_doubles(P.n_cp, D) * sizeof(double));

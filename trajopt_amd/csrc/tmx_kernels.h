@@ -75,6 +75,16 @@ TMX_KERNEL_LB(256) k_prepare(const DevProblem* P, const DevBatch* Bt)
     evaluate_terms(P, x, Bt->cost_vals + (size_t)b * P->n_costs, Bt->cnt_viols + (size_t)b * P->n_cnts, smem, tid, NT);
 }
 
+// descriptor of the compact row lists of problem b (per-problem scratch; nullptr members unless the problem carries them)
+TMX_DEVFN QpWs* compact_lists_of(QpWs& cw, const DevProblem* P, const DevBatch* Bt, int b)
+{
+  if (!(P->coef_far & 2))
+    return nullptr;
+  double* scratch = Bt->qp_scratch + (size_t)b * Bt->qp_scratch_stride;
+  qp_ws_carve(cw, scratch, scratch, scratch, P->D, P->T, P->R, P->NA, P->n_link, P->coef_far);  // only the far layout is used
+  return &cw;
+}
+
 // which = 0: exact costs/violations at x -> cost_vals/cnt_viols ; which = 1: at xnew -> new_* (skips DONE problems)
 TMX_KERNEL_LB(256) k_evaluate(const DevProblem* P, const DevBatch* Bt, int which)
 {
@@ -109,8 +119,9 @@ TMX_KERNEL_LB(256) k_convexify(const DevProblem* P, const DevBatch* Bt, int forc
   double* rhs = Bt->rhs + (size_t)b * R;
   const double* x = Bt->x + (size_t)b * P->NX;
   convexify_terms(P, x, act, coef, Bt->coef2 + (size_t)b * P->n_link * D, rhs, smem, tid, NT, Bt->rowc + (size_t)b * R, Bt->qdyn + (size_t)b * P->NX);
+  QpWs cwd;
   qp_structure(P, act, coef, Bt->coef2 + (size_t)b * P->n_link * D, rhs, x, Bt->trust[b], Bt->merit + (size_t)b * P->n_cnts, Bt->dims + 4 * b,
-               Bt->hashes + 4 * b, nullptr, reinterpret_cast<int*>(smem), tid, NT, Bt->qdyn + (size_t)b * P->NX);
+               Bt->hashes + 4 * b, nullptr, reinterpret_cast<int*>(smem), tid, NT, Bt->qdyn + (size_t)b * P->NX, compact_lists_of(cwd, P, Bt, b));
 #if TMX_LINK_ROWS
   if (P->flavor == 1 && !force)
     sqp2_begin_qp(P, Bt, b, smem, tid, NT);
@@ -124,9 +135,10 @@ TMX_KERNEL k_export_csc(const DevProblem* P, const DevBatch* Bt, int b, CscOut o
   double* smem = TMX_WORK(smem_lds, Bt);
   const int tid = threadIdx.x, NT = blockDim.x;
   const int R = P->R, D = P->D;
+  QpWs cwd;
   qp_structure(P, Bt->active + (size_t)b * R, Bt->coef + (size_t)b * R * D, Bt->coef2 + (size_t)b * P->n_link * D, Bt->rhs + (size_t)b * R,
                Bt->x + (size_t)b * P->NX, Bt->trust[b], Bt->merit + (size_t)b * P->n_cnts, dims_out, hashes_out, &out,
-               reinterpret_cast<int*>(smem), tid, NT, Bt->qdyn + (size_t)b * P->NX);
+               reinterpret_cast<int*>(smem), tid, NT, Bt->qdyn + (size_t)b * P->NX, compact_lists_of(cwd, P, Bt, b));
 }
 
 // K5: Model::optimize() for every running problem; also publishes new_x = first NX model vars (optimizers.cpp:396)
@@ -196,8 +208,9 @@ TMX_DEVFN void sqp_step_block(const DevProblem* P, const DevBatch* Bt, int b, do
       tp0 = tnow;
     }
 #endif
+    QpWs cwd;
     qp_structure(P, act, coef, Bt->coef2 + (size_t)b * P->n_link * D, rhs, x, Bt->trust[b], Bt->merit + (size_t)b * P->n_cnts, Bt->dims + 4 * b,
-                 Bt->hashes + 4 * b, nullptr, reinterpret_cast<int*>(smem), tid, NT, Bt->qdyn + (size_t)b * NX);
+                 Bt->hashes + 4 * b, nullptr, reinterpret_cast<int*>(smem), tid, NT, Bt->qdyn + (size_t)b * NX, compact_lists_of(cwd, P, Bt, b));
 #if TMX_LINK_ROWS
     if (P->flavor == 1)
       sqp2_begin_qp(P, Bt, b, smem, tid, NT);

@@ -164,6 +164,17 @@ struct QpWs
   // ints
   int *act, *aoff, *naux, *slot_t, *typ_r, *typ_bp, *typ_ba, *flg_r, *flg_bp, *flg_ba, *row_ref, *aux_ref;
   int *wp_start, *wp_list;  // LDS copies of DevProblem::wp_start / wp_list (hot in every SpMV)
+  // COMPACT ROW LISTS (problems whose row slots are mostly inactive: thousands of collision slots, a few hundred contacts): the
+  // row sweeps visit the active rows only and the per-waypoint gathers walk the active rows of the waypoint.  Every sum keeps
+  // the summands and the order it had over all slots (an inactive slot contributed an exact 0.0), so results are bit-identical.
+  //   n_rows_iter : trip count of the row sweeps (R, or the number of active rows)
+  //   alist       : nullptr, or the active rows in slot order
+  //   wl_start / wl_list : per-waypoint row lists the gathers walk (all slots, or the active ones); wl_pos: nullptr, or the
+  //                        position of every listed row in the waypoint's FULL slot list (at_rows assigns its four partial sums by it)
+  int n_rows_iter;
+  const int* alist;
+  const int *wl_start, *wl_list, *wl_pos;
+  int *c_alist, *c_start, *c_list, *c_pos, *c_count;  // storage of the compact lists in the per-problem HBM scratch (c_count: n_act)
   int *wp_pst;               // T+1: even-aligned start of every waypoint's group in the grouped e exchange (fast path)
   int *row_epos;             // R: position of every row in that grouped buffer
 #if TMX_LINK_ROWS
@@ -201,9 +212,9 @@ TMX_DEVFN double link_gather(const QpWs& w, const double* rv, int t, int j)
 {
   double s = 0.0;
   if (w.n_link > 0 && t > 0)
-    for (int q = w.wp_start[t - 1]; q < w.wp_start[t]; ++q)
+    for (int q = w.wl_start[t - 1]; q < w.wl_start[t]; ++q)
     {
-      const int r = w.wp_list[q];
+      const int r = w.wl_list[q];
       const int i = w.c2i[r];
       if (w.act[r] && i >= 0)
         s += rv[r] * w.c2[i * w.D + j];
@@ -319,8 +330,10 @@ TMX_HOSTDEVFN size_t qp_lds_doubles(int D, int T, int R, int NA, int R2 = 0)
 // They are the largest cold arrays (config 4: 52 of 177 KB) and only read by row sweeps, so a problem whose workspace
 // exceeds the LDS by less than that still runs LDS-resident (on the pool kernel) instead of out of an HBM workspace.
 TMX_HOSTDEVFN size_t qp_coef_doubles(int D, int R, int R2) { return (size_t)R * D + (size_t)(R2 > 0 ? R2 : 0) * D; }
-TMX_HOSTDEVFN size_t qp_glb_doubles(int D, int T, int R, int NA, int R2 = 0, int cf = 0)
+// (`cf` is a flag word: bit 0 = the row coefficient arrays live in the HBM scratch, bit 1 = compact row lists)
+TMX_HOSTDEVFN size_t qp_glb_doubles(int D, int T, int R, int NA, int R2 = 0, int cf_flags = 0)
 {
+  const int cf = cf_flags & 1;
   const size_t NX = (size_t)D * T;
   const size_t n = 10 * NX + 6 * (size_t)R + (cf ? 0 : (size_t)R * D) + 8 * (size_t)NA +
                    (R2 > 0 ? (cf ? 0 : (size_t)R2 * D) + 3 * (size_t)T * D * D + NX : 0);
@@ -331,13 +344,15 @@ TMX_HOSTDEVFN size_t qp_glb_doubles(int D, int T, int R, int NA, int R2 = 0, int
 TMX_HOSTDEVFN bool lpart_fits(int D, int T, int R2) { return D <= 8 && R2 == 0 && T >= 64; }
 TMX_HOSTDEVFN size_t lpart_zp_doubles(int D) { return 18 * (size_t)D * D + 6 * (size_t)D + 2; }  // 4 interiors: 2 x (3 D)^2 (ping-pong inversion) + 2 x 3 D
 // arrays that are only touched at burst boundaries / in the polish step: always in the per-problem HBM scratch
-TMX_HOSTDEVFN size_t qp_far_doubles(int D, int T, int R, int NA, int R2 = 0, int cf = 0)
+TMX_HOSTDEVFN size_t qp_far_doubles(int D, int T, int R, int NA, int R2 = 0, int cf_flags = 0)
 {
+  const int cf = cf_flags & 1;
   const size_t NX = (size_t)D * T;
   const size_t n = 2 * NX + (size_t)R + 4 * (size_t)NA;
   const size_t ints = 3 * (size_t)R + (size_t)NX + (size_t)NA;
   const size_t lp = lpart_fits(D, T, R2) ? 2 * (size_t)T * D * D + lpart_zp_doubles(D) + 2 : 0;
-  return n + (ints + 1) / 2 + 8 + lp + (cf ? qp_coef_doubles(D, R, R2) + 2 : 0);
+  const size_t cmp = (cf_flags & 2) ? (3 * (size_t)R + (size_t)T + 1 + 2 + 1) / 2 + 2 : 0;  // alist, list, pos, start, count
+  return n + (ints + 1) / 2 + 8 + lp + (cf ? qp_coef_doubles(D, R, R2) + 2 : 0) + cmp;
 }
 // dynamic LDS bytes of the QP kernels / per-problem HBM scratch doubles for the chosen placement
 TMX_HOSTDEVFN size_t qp_smem_bytes(int D, int T, int R, int NA, int R2 = 0, int cf = 0)
@@ -390,8 +405,9 @@ TMX_DEVFN void qp_ws_chain_to_lds(QpWs& w, double* lds)
     w.Zp = p;
 }
 
-TMX_DEVFN void qp_ws_carve(QpWs& w, double* lds, double* glb, double* far, int D, int T, int R, int NA, int R2 = 0, int cf = 0)
+TMX_DEVFN void qp_ws_carve(QpWs& w, double* lds, double* glb, double* far, int D, int T, int R, int NA, int R2 = 0, int cf_flags = 0)
 {
+  const int cf = cf_flags & 1;
   w.D = D;
   w.T = T;
   w.NX = D * T;
@@ -523,8 +539,106 @@ TMX_DEVFN void qp_ws_carve(QpWs& w, double* lds, double* glb, double* far, int D
     }
 #endif
   }
+  // compact row lists: always the last thing in the far region; until rows_compact_build() fills them the sweeps see all slots
+  w.n_rows_iter = R;
+  w.alist = nullptr;
+  w.wl_start = w.wp_start;
+  w.wl_list = w.wp_list;
+  w.wl_pos = nullptr;
+  w.c_alist = w.c_start = w.c_list = w.c_pos = w.c_count = nullptr;
+  if (cf_flags & 2)
+  {
+    ip = reinterpret_cast<int*>((reinterpret_cast<size_t>(reinterpret_cast<int*>(p) > ip ? reinterpret_cast<int*>(p) : ip) + 7) & ~(size_t)7);
+    TAKEI(c_count, 2);
+    TAKEI(c_start, T + 1);
+    TAKEI(c_alist, R);
+    TAKEI(c_list, R);
+    TAKEI(c_pos, R);
+  }
 #undef TAKE
 #undef TAKEI
+}
+
+// row sweep over the slots the workspace says exist: `for r in rows` visits all R slots, or only the active rows when the
+// problem carries compact lists (then every `if (!act[r]) continue` inside the body is a no-op)
+#define TMX_ROWS(w, r)                                                                                               \
+  for (int rq_ = tid; rq_ < (w).n_rows_iter; rq_ += NT)                                                               \
+    if (const int r = (w).alist ? (w).alist[rq_] : rq_; true)
+
+// Builds the compact lists from the active flags (w.act) into the per-problem scratch and switches the workspace to them.
+// Two chunked prefix counts (one contiguous chunk of slots per thread, chunk totals exchanged through `scan`: NT ints of LDS):
+// the active rows in slot order, and the active rows of every waypoint in wp_list order with their position in the full list.
+TMX_DEVFN void rows_compact_build(QpWs& w, const DevProblem* P, int* scan, int tid, int NT, const int* act_in = nullptr)
+{
+  if (w.c_alist == nullptr)
+    return;
+  const int R = w.R, T = w.T;
+  const int* act = act_in ? act_in : w.act;
+  const int C = (R + NT - 1) / NT;
+  const int r0 = tid * C < R ? tid * C : R, r1 = (tid + 1) * C < R ? (tid + 1) * C : R;
+  for (int pass = 0; pass < 2; ++pass)
+  {
+    int cnt = 0;
+    for (int q = r0; q < r1; ++q)
+      cnt += act[pass == 0 ? q : P->wp_list[q]] ? 1 : 0;
+    TMX_SYNC();
+    scan[tid] = cnt;
+    TMX_SYNC();
+    int off = 0;
+    for (int u = 0; u < tid; ++u)
+      off += scan[u];
+    if (pass == 0)
+    {
+      if (tid == NT - 1)
+        w.c_count[0] = off + cnt;
+      for (int q = r0; q < r1; ++q)
+        if (act[q])
+          w.c_alist[off++] = q;
+    }
+    else
+    {
+      // starts of the waypoint groups: active entries before wp_start[t] = totals of the chunks before it + the part of its chunk
+      for (int t = tid; t <= T; t += NT)
+      {
+        const int qs = P->wp_start[t], ch = qs / C;
+        int a = 0;
+        for (int u = 0; u < ch && u < NT; ++u)
+          a += scan[u];
+        for (int q = ch * C; q < qs; ++q)
+          a += act[P->wp_list[q]] ? 1 : 0;
+        w.c_start[t] = a;
+      }
+      for (int q = r0; q < r1; ++q)
+      {
+        const int r = P->wp_list[q];
+        if (act[r])
+        {
+          w.c_list[off] = r;
+          w.c_pos[off] = q - P->wp_start[P->slot_t[r]];
+          ++off;
+        }
+      }
+    }
+  }
+  if (tid == 0)
+    w.c_count[1] = 1;  // lists valid (rows_compact_attach)
+  TMX_SYNC();
+  w.n_rows_iter = w.c_count[0];
+  w.alist = w.c_alist;
+  w.wl_start = w.c_start;
+  w.wl_list = w.c_list;
+  w.wl_pos = w.c_pos;
+}
+// a freshly carved descriptor of a problem whose lists were built by rows_compact_build() earlier in this QP solve
+TMX_DEVFN void rows_compact_attach(QpWs& w)
+{
+  if (w.c_alist == nullptr || w.c_count[1] != 1)
+    return;
+  w.n_rows_iter = w.c_count[0];
+  w.alist = w.c_alist;
+  w.wl_start = w.c_start;
+  w.wl_list = w.c_list;
+  w.wl_pos = w.c_pos;
 }
 
 TMX_DEVFN double limit_scaling(double v)
@@ -568,7 +682,7 @@ TMX_DEVFN void kkt_factor(const QpWs& w, const DevProblem* P, int mode, double s
 {
   const int D = w.D, T = w.T, DD = D * D, DS = w.DS, DDS = w.DDS;
   // effective row weights after eliminating the aux vars: w_eff = rho_r / (1 + rho_r * kappa_r)
-  for (int r = tid; r < w.R; r += NT)
+  TMX_ROWS(w, r)
   {
     double we = 0.0;
     if (w.act[r])
@@ -591,18 +705,18 @@ TMX_DEVFN void kkt_factor(const QpWs& w, const DevProblem* P, int mode, double s
   {
     const int t = e / DD, i = (e % DD) / D, j = e % D;
     double s = 0.0;
-    for (int q = w.wp_start[t]; q < w.wp_start[t + 1]; ++q)
+    for (int q = w.wl_start[t]; q < w.wl_start[t + 1]; ++q)
     {
-      const int r = w.wp_list[q];
+      const int r = w.wl_list[q];
       if (w.act[r])
         s += w.hr[r] * w.coef[r * D + i] * w.coef[r * D + j];
     }
 #if TMX_LINK_ROWS
     // pair rows of waypoint t-1: their second block lands on this diagonal block
     if (w.n_link > 0 && t > 0)
-      for (int q = w.wp_start[t - 1]; q < w.wp_start[t]; ++q)
+      for (int q = w.wl_start[t - 1]; q < w.wl_start[t]; ++q)
       {
-        const int r = w.wp_list[q];
+        const int r = w.wl_list[q];
         const int ci = w.c2i[r];
         if (w.act[r] && ci >= 0)
           s += w.hr[r] * w.c2[ci * D + i] * w.c2[ci * D + j];
@@ -622,9 +736,9 @@ TMX_DEVFN void kkt_factor(const QpWs& w, const DevProblem* P, int mode, double s
     {
       const int t = e / DD, i = (e % DD) / D, j = e % D;
       double c = (i == j) ? w.po[t * D + i] : 0.0;
-      for (int q = w.wp_start[t]; q < w.wp_start[t + 1]; ++q)
+      for (int q = w.wl_start[t]; q < w.wl_start[t + 1]; ++q)
       {
-        const int r = w.wp_list[q];
+        const int r = w.wl_list[q];
         const int ci = w.c2i[r];
         if (w.act[r] && ci >= 0)
           c += w.hr[r] * w.coef[r * D + i] * w.c2[ci * D + j];
@@ -762,7 +876,7 @@ TMX_DEVFN void kkt_solve(const QpWs& w, const DevProblem* P, int mode, double si
     //   d_k x_k + s_k nu = ta_k ,   sum_k s_k x_k + a.dx - delta nu = r2
     // the row acts on dx through  c_r = (r2 - sum s_k ta_k / d_k) / (delta + sum s_k^2 / d_k), evaluated with numerator
     // and denominator scaled by d_min (all ratios d_min / d_k <= 1).
-    for (int r = tid; r < w.R; r += NT)
+    TMX_ROWS(w, r)
     {
       double c = 0.0;
       if (w.act[r] && w_row(w, r, 1, delta) > 0.0)
@@ -795,9 +909,9 @@ TMX_DEVFN void kkt_solve(const QpWs& w, const DevProblem* P, int mode, double si
     {
       const int t = v / D, j = v % D;
       double s = 0.0;
-      for (int q = w.wp_start[t]; q < w.wp_start[t + 1]; ++q)
+      for (int q = w.wl_start[t]; q < w.wl_start[t + 1]; ++q)
       {
-        const int r = w.wp_list[q];
+        const int r = w.wl_list[q];
         if (w.act[r])
           s += w.hr[r] * w.coef[r * D + j];
       }
@@ -811,7 +925,7 @@ TMX_DEVFN void kkt_solve(const QpWs& w, const DevProblem* P, int mode, double si
   else
   {
   // 1. aux elimination: h_r = rho_r * (s . Maa^-1 rhs_a) ;   Maa^-1 v = v/d - rho (s/d) (s.(v/d)) / (1 + rho kappa)
-    for (int r = tid; r < w.R; r += NT)
+    TMX_ROWS(w, r)
     {
       double h = 0.0;
       if (w.act[r] && w.naux[r] > 0)
@@ -836,9 +950,9 @@ TMX_DEVFN void kkt_solve(const QpWs& w, const DevProblem* P, int mode, double si
     {
       const int t = v / D, j = v % D;
       double s = 0.0;
-      for (int q = w.wp_start[t]; q < w.wp_start[t + 1]; ++q)
+      for (int q = w.wl_start[t]; q < w.wl_start[t + 1]; ++q)
       {
-        const int r = w.wp_list[q];
+        const int r = w.wl_list[q];
         if (w.act[r])
           s += w.hr[r] * w.coef[r * D + j];
       }
@@ -947,7 +1061,7 @@ TMX_DEVFN void kkt_solve(const QpWs& w, const DevProblem* P, int mode, double si
   // 3. aux recovery and (A x)_r   (polish: hr = nu_r, the multiplier itself - (A dx - r2) / delta would cancel again)
   if (mode == 1)
   {
-    for (int r = tid; r < w.R; r += NT)
+    TMX_ROWS(w, r)
     {
       if (!w.act[r])
       {
@@ -993,7 +1107,7 @@ TMX_DEVFN void kkt_solve(const QpWs& w, const DevProblem* P, int mode, double si
     return;
   }
   // 3. aux recovery and (A x)_r
-  for (int r = tid; r < w.R; r += NT)
+  TMX_ROWS(w, r)
   {
     if (!w.act[r])
     {
@@ -1045,6 +1159,28 @@ TMX_DEVFN void kkt_solve(const QpWs& w, const DevProblem* P, int mode, double si
 TMX_DEVFN double at_rows(const QpWs& w, const DevProblem* P, const double* rv, int v)
 {
   const int D = w.D, t = v / D, j = v % D;
+  if (w.wl_pos != nullptr)
+  {
+    // compact lists: only the active rows of the waypoint, each added to the partial sum its position in the FULL slot list
+    // selects (groups of four into s0..s3, the remainder into s0): the sums an all-slot walk forms, minus exact zeros
+    const int n4 = (w.wp_start[t + 1] - w.wp_start[t]) & ~3;
+    double c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0;
+    for (int q = w.wl_start[t]; q < w.wl_start[t + 1]; ++q)
+    {
+      const int r = w.wl_list[q], k = w.wl_pos[q];
+      const double pv = w.coef[r * D + j] * rv[r];
+      const int u = (k < n4) ? (k & 3) : 0;
+      c0 = (u == 0) ? c0 + pv : c0;
+      c1 = (u == 1) ? c1 + pv : c1;
+      c2 = (u == 2) ? c2 + pv : c2;
+      c3 = (u == 3) ? c3 + pv : c3;
+    }
+#if TMX_LINK_ROWS
+    return ((c0 + c1) + (c2 + c3)) + link_gather(w, rv, t, j);
+#else
+    return (c0 + c1) + (c2 + c3);
+#endif
+  }
   const int q0 = w.wp_start[t], q1 = w.wp_start[t + 1];
   double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
   int q = q0;
@@ -1104,7 +1240,7 @@ TMX_DEVFN void compute_residuals(const QpWs& w, const DevProblem* P, const doubl
     m[k] = 0.0;
   double uq = 0.0, uaty = 0.0, upx = 0.0;
   // rows
-  for (int r = tid; r < w.R; r += NT)
+  TMX_ROWS(w, r)
   {
     if (!w.act[r])
       continue;
@@ -1151,7 +1287,7 @@ TMX_DEVFN void compute_residuals(const QpWs& w, const DevProblem* P, const doubl
     uaty = fmax(uaty, fabs(dinv * aty));
     upx = fmax(upx, fabs(dinv * px));
   }
-  for (int r = tid; r < w.R; r += NT)
+  TMX_ROWS(w, r)
   {
     if (!w.act[r])
       continue;
@@ -1228,7 +1364,7 @@ TMX_DEVFN bool is_primal_infeasible(const QpWs& w, const DevProblem* P, double e
   double acc[2] = { 0.0, 0.0 };  // [0] = max |E dy|, [1] = sum ineq_lhs
   const bool sums[2] = { false, true };
   const double BIG = TMX_OSQP_INFTY * TMX_MIN_SCALING;
-  for (int r = tid; r < w.R; r += NT)
+  TMX_ROWS(w, r)
   {
     if (!w.act[r])
       continue;
@@ -1273,7 +1409,7 @@ TMX_DEVFN bool is_primal_infeasible(const QpWs& w, const DevProblem* P, double e
     double nrm = 0.0;
     for (int v = tid; v < w.NX; v += NT)
       nrm = fmax(nrm, fabs((at_rows(w, P, w.dyr, v) + w.bbp[v] * w.dybp[v]) / w.Dp[v]));
-    for (int r = tid; r < w.R; r += NT)
+    TMX_ROWS(w, r)
       if (w.act[r])
         for (int k = 0; k < w.naux[r]; ++k)
         {
@@ -1295,7 +1431,7 @@ TMX_DEVFN bool is_dual_infeasible(const QpWs& w, const DevProblem* P, double eps
     acc[0] = fmax(acc[0], fabs(w.Dp[v] * w.dxp[v]));
     acc[1] += w.qp[v] * w.dxp[v];
   }
-  for (int r = tid; r < w.R; r += NT)
+  TMX_ROWS(w, r)
     if (w.act[r])
       for (int k = 0; k < w.naux[r]; ++k)
       {
@@ -1316,7 +1452,7 @@ TMX_DEVFN bool is_dual_infeasible(const QpWs& w, const DevProblem* P, double eps
       double bad = 0.0;
       const double BIG = TMX_OSQP_INFTY * TMX_MIN_SCALING;
       const double thr = eps * norm_dx;
-      for (int r = tid; r < w.R; r += NT)
+      TMX_ROWS(w, r)
       {
         if (!w.act[r])
           continue;
@@ -1361,7 +1497,7 @@ TMX_DEVFN bool is_dual_infeasible(const QpWs& w, const DevProblem* P, double eps
 // per-rho caches: dinv[a] = 1/(sigma + rho_ba bb^2), fac[r] = rho_r / (1 + rho_r kappa_r)   (ADMM weights only)
 TMX_DEVFN void admm_cache_weights(const QpWs& w, int tid, int NT)
 {
-  for (int r = tid; r < w.R; r += NT)
+  TMX_ROWS(w, r)
   {
     double f = 0.0;
     if (w.act[r])
@@ -1385,7 +1521,7 @@ TMX_DEVFN void admm_cache_weights(const QpWs& w, int tid, int NT)
 // Phase A (rows): e_r = g_r - h_r with g = rho z - y, h from the aux elimination; aux rhs -> ta
 TMX_DEVFN void admm_phase_a(const QpWs& w, int tid, int NT)
 {
-  for (int r = tid; r < w.R; r += NT)
+  TMX_ROWS(w, r)
   {
     double e = 0.0;
     if (w.act[r])
@@ -1583,7 +1719,7 @@ TMX_DEVFN void admm_phase_c(const QpWs& w, bool keep_delta, int tid, int NT)
 {
   const int D = w.D;
   const double al = w.alpha;
-  for (int r = tid; r < w.R; r += NT)
+  TMX_ROWS(w, r)
   {
     if (!w.act[r])
       continue;

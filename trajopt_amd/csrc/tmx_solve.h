@@ -48,7 +48,7 @@ struct CscOut
 
 TMX_DEVFN void qp_structure(const DevProblem* P, const int* active, const double* coef, const double* coef2, const double* rhs,
                             const double* xcur, double trust, const double* merit, int* dims, unsigned long long* hashes,
-                            const CscOut* out, int* iscratch, int tid, int NT, const double* qdyn = nullptr)
+                            const CscOut* out, int* iscratch, int tid, int NT, const double* qdyn = nullptr, QpWs* cw = nullptr)
 {
   (void)coef2;
   const int D = P->D, T = P->T, NX = P->NX, R = P->R;
@@ -61,6 +61,7 @@ TMX_DEVFN void qp_structure(const DevProblem* P, const int* active, const double
   int acc_off = 2 * (P->n_max + 1) + 4 * R;
   acc_off += (acc_off & 1);
   unsigned long long* acc = reinterpret_cast<unsigned long long*>(iscratch + acc_off);  // 8 x u64 (8-byte aligned)
+  int* scan = iscratch + acc_off + 16;  // NT ints: chunk totals of the prefix counts
   // active flags / aux counts -> LDS, then exclusive prefix counts per row (every thread scans its predecessors: R^2/NT
   // LDS reads, no serial pass and no dependent global loads)
   for (int r = tid; r < R; r += NT)
@@ -71,22 +72,44 @@ TMX_DEVFN void qp_structure(const DevProblem* P, const int* active, const double
   for (int k = tid; k < 8; k += NT)
     acc[k] = 0ULL;
   TMX_SYNC();
-  for (int r = tid; r < R; r += NT)
+  // exclusive prefix counts by chunks (one contiguous chunk of slots per thread, chunk totals through `scan`)
   {
-    int nr = 0, na = 0;
-    for (int q = 0; q < r; ++q)
+    const int C = (R + NT - 1) / NT;
+    const int r0 = tid * C < R ? tid * C : R, r1 = (tid + 1) * C < R ? (tid + 1) * C : R;
+    int tot_r = 0;
+    for (int pass = 0; pass < 2; ++pass)
     {
-      nr += lact[q];
-      na += lact[q] ? lnaux[q] : 0;
+      int cnt = 0;
+      for (int r = r0; r < r1; ++r)
+        cnt += lact[r] ? (pass == 0 ? 1 : lnaux[r]) : 0;
+      TMX_SYNC();
+      scan[tid] = cnt;
+      TMX_SYNC();
+      int off = 0;
+      for (int u = 0; u < tid; ++u)
+        off += scan[u];
+      for (int r = r0; r < r1; ++r)
+      {
+        if (pass == 0)
+          rowref[r] = off;
+        else
+          auxref[r] = NX + off;
+        off += lact[r] ? (pass == 0 ? 1 : lnaux[r]) : 0;
+      }
+      if (tid == NT - 1)
+      {
+        if (pass == 0)
+          tot_r = off;
+        else if (R > 0)
+        {
+          dims[0] = NX + off;          // n
+          dims[1] = tot_r + NX + off;  // m
+        }
+      }
     }
-    rowref[r] = nr;
-    auxref[r] = NX + na;
-    if (r == R - 1)
-    {
-      const int nr1 = nr + lact[r], na1 = na + (lact[r] ? lnaux[r] : 0);
-      dims[0] = NX + na1;        // n
-      dims[1] = nr1 + NX + na1;  // m
-    }
+    TMX_SYNC();
+    if (cw != nullptr)
+      rows_compact_build(*cw, P, scan, tid, NT, lact);  // compact row lists of this convexification (per-problem scratch)
   }
   if (R == 0 && tid == 0)  // a problem without any row slot (costs only, nothing fixed): the QP is the box-constrained objective
   {
@@ -95,32 +118,41 @@ TMX_DEVFN void qp_structure(const DevProblem* P, const int* active, const double
   }
   TMX_SYNC();
   const int n = dims[0], m = dims[1], mg = m - n;
+  // the per-waypoint row lists the column walks use: all slots, or the active rows only (same order, inactive slots skipped)
+  const bool cmp = cw != nullptr && cw->wl_pos != nullptr;
+  const int* const wls = cmp ? cw->wl_start : P->wp_start;
+  const int* const wll = cmp ? cw->wl_list : P->wp_list;
+  const int* const ali = cmp ? cw->alist : nullptr;
+  const int n_it = cmp ? cw->n_rows_iter : R;
   // column counts of A (into colptr[c + 1]), then the exclusive prefix by per-thread scans of the LDS counts
   for (int v = tid; v < NX; v += NT)
   {
     const int t = v / D, j = v % D;
     int c = 1;
-    for (int q = P->wp_start[t]; q < P->wp_start[t + 1]; ++q)
+    for (int q = wls[t]; q < wls[t + 1]; ++q)
     {
-      const int r = P->wp_list[q];
+      const int r = wll[q];
       if (lact[r] && coef[r * D + j] != 0.0)
         ++c;
     }
 #if TMX_LINK_ROWS
     if (P->n_link > 0 && t > 0)  // pair rows of the previous waypoint with an entry on this variable
-      for (int q = P->wp_start[t - 1]; q < P->wp_start[t]; ++q)
+      for (int q = wls[t - 1]; q < wls[t]; ++q)
       {
-        const int r = P->wp_list[q];
+        const int r = wll[q];
         if (lact[r] && P->slot_c2[r] >= 0 && coef2[P->slot_c2[r] * D + j] != 0.0)
           ++c;
       }
 #endif
     ccount[v] = c;
   }
-  for (int r = tid; r < R; r += NT)
+  for (int rq = tid; rq < n_it; rq += NT)
+  {
+    const int r = ali ? ali[rq] : rq;
     if (lact[r])
       for (int k = 0; k < lnaux[r]; ++k)
         ccount[auxref[r] + k] = 2;
+  }
   TMX_SYNC();
   for (int c = tid; c <= n; c += NT)
   {
@@ -156,10 +188,10 @@ TMX_DEVFN void qp_structure(const DevProblem* P, const int* active, const double
     int pos = colptr[v];
 #if TMX_LINK_ROWS
     // entries of the rows of waypoint t-1 that link to this variable, merged by ascending reference row index
-    int ql = (P->n_link > 0 && t > 0) ? P->wp_start[t - 1] : 0;
-    const int ql_end = (P->n_link > 0 && t > 0) ? P->wp_start[t] : 0;
+    int ql = (P->n_link > 0 && t > 0) ? wls[t - 1] : 0;
+    const int ql_end = (P->n_link > 0 && t > 0) ? wls[t] : 0;
     auto link_val = [&](int qq) -> double {
-      const int rr = P->wp_list[qq];
+      const int rr = wll[qq];
       return (active[rr] && P->slot_c2[rr] >= 0) ? coef2[P->slot_c2[rr] * D + j] : 0.0;
     };
     auto next_link = [&]() {
@@ -168,13 +200,13 @@ TMX_DEVFN void qp_structure(const DevProblem* P, const int* active, const double
     };
     next_link();
 #endif
-    for (int q = P->wp_start[t]; q <= P->wp_start[t + 1]; ++q)
+    for (int q = wls[t]; q <= wls[t + 1]; ++q)
     {
       long long ri;
       double val;
-      if (q < P->wp_start[t + 1])
+      if (q < wls[t + 1])
       {
-        const int r = P->wp_list[q];
+        const int r = wll[q];
         if (!(active[r] && coef[r * D + j] != 0.0))
           continue;
         ri = rowref[r];
@@ -186,9 +218,9 @@ TMX_DEVFN void qp_structure(const DevProblem* P, const int* active, const double
         val = 1.0;
       }
 #if TMX_LINK_ROWS
-      while (ql < ql_end && rowref[P->wp_list[ql]] < ri)
+      while (ql < ql_end && rowref[wll[ql]] < ri)
       {
-        const long long rl = rowref[P->wp_list[ql]];
+        const long long rl = rowref[wll[ql]];
         hA += tmx_hash_term(rl, (uint64_t)pos, 4);
         if (pos < ri_full)
           wsA += tmx_hash_term(rl, (uint64_t)pos, 14);
@@ -217,7 +249,9 @@ TMX_DEVFN void qp_structure(const DevProblem* P, const int* active, const double
       ++pos;
     }
   }
-  for (int r = tid; r < R; r += NT)
+  for (int rq = tid; rq < n_it; rq += NT)
+  {
+    const int r = ali ? ali[rq] : rq;
     if (active[r])
       for (int k = 0; k < P->slot_naux[r]; ++k)
       {
@@ -239,6 +273,7 @@ TMX_DEVFN void qp_structure(const DevProblem* P, const int* active, const double
           ++pos;
         }
       }
+  }
   // P: static pattern over the primary vars (upper triangle): (v-D, v) if po != 0 ; (v, v) if pd != 0
   unsigned long long hP = 0ULL, wsP = 0ULL;
   {
@@ -315,8 +350,8 @@ TMX_DEVFN void qp_structure(const DevProblem* P, const int* active, const double
       out->l[mg + v] = fmax(lb, -TMX_OSQP_INFTY);
       out->u[mg + v] = fmin(ub, TMX_OSQP_INFTY);
     }
-    for (int r = tid; r < R; r += NT)
-      if (active[r])
+    for (int rq = tid; rq < n_it; rq += NT)
+      if (const int r = ali ? ali[rq] : rq; active[r])
       {
         out->l[rowref[r]] = P->slot_eq[r] ? rhs[r] : -TMX_OSQP_INFTY;
         out->u[rowref[r]] = rhs[r];
@@ -368,7 +403,7 @@ TMX_DEVFN void kkt_invert(const QpWs& w, bool partitioned, int tid, int NT, long
 TMX_DEVFN void admm_rhs(const QpWs& w, const DevProblem* P, int tid, int NT)
 {
   // per-row  g_r = rho_r z_r - y_r  into hr ; then tp = sigma x - q + A'g (+ bound part), ta likewise
-  for (int r = tid; r < w.R; r += NT)
+  TMX_ROWS(w, r)
     w.hr[r] = w.act[r] ? (rho_of_type(w.typ_r[r], w.rho) * w.zr[r] - w.yr[r]) : 0.0;
   TMX_SYNC();
   for (int v = tid; v < w.NX; v += NT)
@@ -376,7 +411,7 @@ TMX_DEVFN void admm_rhs(const QpWs& w, const DevProblem* P, int tid, int NT)
     const double gb = rho_of_type(w.typ_bp[v], w.rho) * w.zbp[v] - w.ybp[v];
     w.tp[v] = (w.sigma * w.xp[v] - w.qp[v]) + at_rows(w, P, w.hr, v) + w.bbp[v] * gb;
   }
-  for (int r = tid; r < w.R; r += NT)
+  TMX_ROWS(w, r)
     if (w.act[r])
       for (int k = 0; k < w.naux[r]; ++k)
       {
@@ -407,7 +442,7 @@ TMX_DEVFN void admm_update(const QpWs& w, bool keep_delta, int tid, int NT)
     if (keep_delta)
       w.dybp[v] = dy;
   }
-  for (int r = tid; r < w.R; r += NT)
+  TMX_ROWS(w, r)
   {
     if (!w.act[r])
       continue;
@@ -791,6 +826,121 @@ __device__ __attribute__((noinline)) static void qp_admm_fast_nl(const DevProble
 #endif
 #endif
 
+// The ADMM loop of the generic path (osqp_solve without the register-resident bursts): phases A / B, block chain, phase C, the
+// residual checks and the adaptive-rho refactorisations.  In / out: info, iter, can_check, terminated (and w.rho).
+TMX_DEVFN void qp_admm_generic_loop(QpWs& w, const DevProblem* P, QpInfo& info, int& iter, bool& can_check, bool& terminated, int tid, int NT,
+                                    long long* pc, long long& tlast)
+{
+  const tmx_osqp_settings& st = P->osqp;
+  for (iter = 1; iter <= st.max_iter; ++iter)
+  {
+    can_check = st.check_termination && (iter % st.check_termination == 0);
+    const bool do_rho = st.adaptive_rho && st.adaptive_rho_interval && (iter % st.adaptive_rho_interval == 0);
+    {
+      admm_phase_a(w, tid, NT);
+      TMX_TICK(2);
+      admm_phase_b(w, P, tid, NT);
+      TMX_TICK(3);
+      chain_solve(w, tid, NT);
+      TMX_TICK(4);
+      admm_phase_c(w, can_check || do_rho, tid, NT);
+      TMX_TICK(5);
+    }
+    if (can_check || do_rho)
+    {
+      info.iter = iter;
+      compute_residuals(w, P, w.xp, w.xa, w.yr, w.ybp, w.yba, 0, info, info.prim_res, info.dual_res, true, tid, NT);
+      TMX_TICK(6);
+    }
+    if (can_check)
+    {
+      if (check_termination(w, P, info, false, tid, NT))
+      {
+        terminated = true;
+        break;
+      }
+      TMX_TICK(3);
+    }
+    if (do_rho)
+    {
+      const double rho_new = rho_estimate(w, info);
+      if ((rho_new > w.rho * st.adaptive_rho_tolerance) || (rho_new < w.rho / st.adaptive_rho_tolerance))
+      {
+        w.rho = fmin(fmax(rho_new, TMX_RHO_MIN), TMX_RHO_MAX);
+        info.rho_updates += 1;
+        TMX_TICK(6);
+        kkt_factor(w, P, 0, w.sigma, st.delta, tid, NT);
+        kkt_invert(w, false, tid, NT, pc, tlast);
+        admm_cache_weights(w, tid, NT);
+        TMX_TICK(15);
+      }
+    }
+    TMX_TICK(6);
+  }
+}
+
+#if TMX_IS_DEVICE && TMX_ADMM_OUTLINED
+// ... as a function of its own.  Inlined into the kernels, this loop shared one register allocation with everything around it;
+// in k_sqp_pool that includes the call of qp_admm_fast_nl, and the ~70 pointers of the workspace descriptor that live across
+// that call were spilled and reloaded INSIDE this loop (346 scratch instructions per iteration, 518 once the callee used every
+// AGPR).  Out of line it rebuilds the descriptor from the base pointers like the fast-path functions do; state crosses the call
+// through the same QpShared record.  HBM: the workspace is the workgroup's HBM slice `work` (k_*_hbm kernels), with the chain
+// arrays in LDS at lds_off when the launch carries them; otherwise the whole workspace sits in LDS at lds_off.
+template <bool HBM>
+__device__ __attribute__((noinline)) static void qp_admm_generic_nl(const DevProblem* P_in, const DevBatch* Bt_in, int b_in, unsigned lds_in,
+                                                                  double* work_in, int chain_in_lds)
+{
+  const DevProblem* P = tmx_uniform_ptr(P_in);
+  const DevBatch* Bt = tmx_uniform_ptr(Bt_in);
+  const int b = __builtin_amdgcn_readfirstlane(b_in);
+  const int tid = threadIdx.x, NT = blockDim.x;
+  double* lds = (double*)(tmx_lds_d*)(size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)lds_in);
+  double* smem = HBM ? tmx_uniform_ptr(work_in) : lds;
+  const int D = P->D, T = P->T, R = P->R;
+  QpWs w;
+  {
+    double* scratch = Bt->qp_scratch + (size_t)b * Bt->qp_scratch_stride;
+#if TMX_QP_COLD_IN_LDS
+    qp_ws_carve(w, smem, smem + qp_lds_doubles(D, T, R, P->NA, P->n_link), scratch, D, T, R, P->NA, P->n_link, P->coef_far);
+#else
+    qp_ws_carve(w, smem, scratch + qp_far_doubles(D, T, R, P->NA, P->n_link, P->coef_far), scratch, D, T, R, P->NA, P->n_link, P->coef_far);
+#endif
+    if (HBM && __builtin_amdgcn_readfirstlane(chain_in_lds) != 0)
+      qp_ws_chain_to_lds(w, lds);
+  }
+#if TMX_LINK_ROWS
+  w.c2i = P->slot_c2;
+#endif
+  rows_compact_attach(w);
+  QpShared* sh = reinterpret_cast<QpShared*>(w.wself);
+  w.rho = sh->rho;
+  w.sigma = sh->sigma;
+  w.alpha = sh->alpha;
+  w.c = sh->c;
+  w.cinv = sh->cinv;
+  QpInfo info = sh->info;
+  int iter = 0;
+  bool can_check = false, terminated = false;
+  long long pc[16] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+  long long tlast = TMX_CLK();
+  TMX_SYNC();
+  qp_admm_generic_loop(w, P, info, iter, can_check, terminated, tid, NT, pc, tlast);
+  if (tid == 0)
+  {
+    sh->info = info;
+    sh->rho = w.rho;
+    sh->terminated = terminated ? 1 : 0;
+    sh->can_check = can_check ? 1 : 0;
+    sh->iter = iter;
+#ifdef TMX_PROFILE
+    for (int q_ = 0; q_ < 16; ++q_)
+      Bt->prof[(size_t)b * 16 + q_] += pc[q_];
+#endif
+  }
+  TMX_SYNC();
+}
+#endif
+
 // HBM = true: the k_*_hbm kernels (workspace in HBM): the dense fast path (LDS-resident by construction) is compiled out
 template <bool HBM = false>
 TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, double* smem, int tid, int NT, double* chain_lds = nullptr)
@@ -835,13 +985,17 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
     w.dyr[r] = 0.0;
     w.lor[r] = P->slot_eq[r] ? g_rhs[r] : -TMX_OSQP_INFTY;
     w.hir[r] = g_rhs[r];
-    for (int j = 0; j < D; ++j)
-      w.coef[r * D + j] = g_act[r] ? g_coef[r * D + j] : 0.0;
-#if TMX_LINK_ROWS
-    if (P->n_link > 0 && P->slot_c2[r] >= 0)
+    // (with compact row lists nothing ever reads the coefficients of an inactive slot: they are not copied)
+    if (g_act[r] || w.c_alist == nullptr)
+    {
       for (int j = 0; j < D; ++j)
-        w.c2[P->slot_c2[r] * D + j] = g_act[r] ? g_coef2[P->slot_c2[r] * D + j] : 0.0;
+        w.coef[r * D + j] = g_act[r] ? g_coef[r * D + j] : 0.0;
+#if TMX_LINK_ROWS
+      if (P->n_link > 0 && P->slot_c2[r] >= 0)
+        for (int j = 0; j < D; ++j)
+          w.c2[P->slot_c2[r] * D + j] = g_act[r] ? g_coef2[P->slot_c2[r] * D + j] : 0.0;
 #endif
+    }
     const double oc = aux_cost(P, g_merit, r);
     for (int k = 0; k < P->slot_naux[r]; ++k)
     {
@@ -901,18 +1055,34 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
   w.c = 1.0;
   w.cinv = 1.0;
   TMX_SYNC();
-  // position of every active row / of its aux vars in the reference-order solution vectors (exclusive prefix counts)
-  for (int r = tid; r < R; r += NT)
+  // position of every active row / of its aux vars in the reference-order solution vectors: exclusive prefix counts by chunks
+  // (one contiguous chunk of slots per thread, chunk totals through the reduction scratch), then the compact row lists
   {
-    int nr = 0, na = 0;
-    for (int q = 0; q < r; ++q)
+    int* scan = reinterpret_cast<int*>(w.red);  // NT ints (NT <= 512)
+    const int C = (R + NT - 1) / NT;
+    const int r0 = tid * C < R ? tid * C : R, r1 = (tid + 1) * C < R ? (tid + 1) * C : R;
+    for (int pass = 0; pass < 2; ++pass)
     {
-      const int aq = w.act[q];
-      nr += aq;
-      na += aq ? w.naux[q] : 0;
+      int cnt = 0;
+      for (int r = r0; r < r1; ++r)
+        cnt += w.act[r] ? (pass == 0 ? 1 : w.naux[r]) : 0;
+      TMX_SYNC();
+      scan[tid] = cnt;
+      TMX_SYNC();
+      int off = 0;
+      for (int u = 0; u < tid; ++u)
+        off += scan[u];
+      for (int r = r0; r < r1; ++r)
+      {
+        if (pass == 0)
+          w.row_ref[r] = off;
+        else
+          w.aux_ref[r] = NX + off;
+        off += w.act[r] ? (pass == 0 ? 1 : w.naux[r]) : 0;
+      }
     }
-    w.row_ref[r] = nr;
-    w.aux_ref[r] = NX + na;
+    TMX_SYNC();
+    rows_compact_build(w, P, scan, tid, NT);
   }
   const int n = dims[0], m = dims[1], mg = m - n;
   // Ruiz temporaries live in the (not yet factorised) G region of the LDS workspace when it exists
@@ -942,17 +1112,17 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
         cn = fmax(cn, fabs(w.po[v - D]));
       if (t < T - 1)
         cn = fmax(cn, fabs(w.po[v]));
-      for (int q = w.wp_start[t]; q < w.wp_start[t + 1]; ++q)
+      for (int q = w.wl_start[t]; q < w.wl_start[t + 1]; ++q)
       {
-        const int r = w.wp_list[q];
+        const int r = w.wl_list[q];
         if (w.act[r])
           cn = fmax(cn, fabs(w.coef[r * D + j]));
       }
 #if TMX_LINK_ROWS
       if (w.n_link > 0 && t > 0)
-        for (int q = w.wp_start[t - 1]; q < w.wp_start[t]; ++q)
+        for (int q = w.wl_start[t - 1]; q < w.wl_start[t]; ++q)
         {
-          const int r = w.wp_list[q];
+          const int r = w.wl_list[q];
           if (w.act[r] && w.c2i[r] >= 0)
             cn = fmax(cn, fabs(w.c2[w.c2i[r] * D + j]));
         }
@@ -961,7 +1131,7 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
       w.tp[v] = 1.0 / sqrt(limit_scaling(cn));
       t_ebp[v] = 1.0 / sqrt(limit_scaling(fabs(w.bbp[v])));
     }
-    for (int r = tid; r < R; r += NT)
+    TMX_ROWS(w, r)
     {
       if (!w.act[r])
         continue;
@@ -993,7 +1163,7 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
       w.Dp[v] *= w.tp[v];
       w.Ebp[v] *= t_ebp[v];
     }
-    for (int r = tid; r < R; r += NT)
+    TMX_ROWS(w, r)
     {
       if (!w.act[r])
         continue;
@@ -1030,7 +1200,7 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
       w.tp[v] = cn;
       qmax = fmax(qmax, fabs(w.qp[v]));
     }
-    for (int r = tid; r < R; r += NT)
+    TMX_ROWS(w, r)
       if (w.act[r])
         for (int k = 0; k < w.naux[r]; ++k)
           qmax = fmax(qmax, fabs(w.qa[w.aoff[r] + k]));
@@ -1066,7 +1236,7 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
       w.po[v] *= ct;
       w.qp[v] *= ct;
     }
-    for (int r = tid; r < R; r += NT)
+    TMX_ROWS(w, r)
       if (w.act[r])
         for (int k = 0; k < w.naux[r]; ++k)
           w.qa[w.aoff[r] + k] *= ct;
@@ -1083,7 +1253,7 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
     w.ubp[v] *= w.Ebp[v];
     w.typ_bp[v] = constr_type(w.lbp[v], w.ubp[v]);
   }
-  for (int r = tid; r < R; r += NT)
+  TMX_ROWS(w, r)
   {
     if (!w.act[r])
       continue;
@@ -1122,7 +1292,7 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
       w.xp[v] = (1.0 / w.Dp[v]) * xq[v];
       w.ybp[v] = ((1.0 / w.Ebp[v]) * yq[mg + v]) * w.c;
     }
-    for (int r = tid; r < R; r += NT)
+    TMX_ROWS(w, r)
       if (w.act[r])
       {
         w.yr[r] = ((1.0 / w.Er[r]) * yq[w.row_ref[r]]) * w.c;
@@ -1136,7 +1306,7 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
     TMX_SYNC();
     for (int v = tid; v < NX; v += NT)
       w.zbp[v] = w.bbp[v] * w.xp[v];
-    for (int r = tid; r < R; r += NT)
+    TMX_ROWS(w, r)
       if (w.act[r])
       {
         const int t = w.slot_t[r];
@@ -1160,7 +1330,7 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
   // ---------------- factor + ADMM loop (osqp_solve) --------------------------------------------------------
   TMX_TICK(0);
 #if TMX_IS_DEVICE
-  const bool fast = !HBM && (NT == TMX_QP_NT) && (R <= 512) && dpart_supported(w, NT) && !TMX_HAS_PAIRS(w);
+  const bool fast = !HBM && (NT == TMX_QP_NT) && (R <= 512) && dpart_supported(w, NT) && !TMX_HAS_PAIRS(w) && w.c_alist == nullptr;
 #else
   const bool fast = false;
 #endif
@@ -1218,65 +1388,41 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
   }
   else
 #endif
-  for (iter = 1; iter <= st.max_iter; ++iter)
   {
-#if TMX_IS_DEVICE
-    if (fast)
+#if TMX_IS_DEVICE && TMX_ADMM_OUTLINED
+    // generic path: the same hand-over as above, to qp_admm_generic_nl
+    QpShared* sh = reinterpret_cast<QpShared*>(w.wself);
+    if (tid == 0)
     {
-      // run up to the next iteration that needs the residuals (termination test and/or adaptive rho) in one
-      // register-resident burst
-      int next = st.max_iter;
-      if (st.check_termination)
-        next = min(next, ((iter - 1) / st.check_termination + 1) * st.check_termination);
-      if (st.adaptive_rho && st.adaptive_rho_interval)
-        next = min(next, ((iter - 1) / st.adaptive_rho_interval + 1) * st.adaptive_rho_interval);
-      admm_run_fast(w, P, next - iter + 1, true, tid, pc, tlast);
-      iter = next;
+      sh->rho = w.rho;
+      sh->sigma = w.sigma;
+      sh->alpha = w.alpha;
+      sh->c = w.c;
+      sh->cinv = w.cinv;
+      sh->info = info;
+      sh->terminated = 0;
+      sh->can_check = 0;
+      sh->iter = 0;
+      sh->have_res = 0;
     }
+    TMX_SYNC();
+    {
+      unsigned lds_off = (unsigned)(size_t)(HBM ? chain_lds : smem);
+      asm volatile("" : "+s"(lds_off));
+      qp_admm_generic_nl<HBM>(P, Bt, b, lds_off, HBM ? smem : nullptr, chain_lds != nullptr ? 1 : 0);
+    }
+#ifdef TMX_PROFILE
+    tlast = TMX_CLK();
 #endif
-    can_check = st.check_termination && (iter % st.check_termination == 0);
-    const bool do_rho = st.adaptive_rho && st.adaptive_rho_interval && (iter % st.adaptive_rho_interval == 0);
-    if (!fast)
-    {
-      admm_phase_a(w, tid, NT);
-      TMX_TICK(2);
-      admm_phase_b(w, P, tid, NT);
-      TMX_TICK(3);
-      chain_solve(w, tid, NT);
-      TMX_TICK(4);
-      admm_phase_c(w, can_check || do_rho, tid, NT);
-      TMX_TICK(5);
-    }
-    if (can_check || do_rho)
-    {
-      info.iter = iter;
-      compute_residuals(w, P, w.xp, w.xa, w.yr, w.ybp, w.yba, 0, info, info.prim_res, info.dual_res, true, tid, NT);
-      TMX_TICK(6);
-    }
-    if (can_check)
-    {
-      if (check_termination(w, P, info, false, tid, NT))
-      {
-        terminated = true;
-        break;
-      }
-      TMX_TICK(3);
-    }
-    if (do_rho)
-    {
-      const double rho_new = rho_estimate(w, info);
-      if ((rho_new > w.rho * st.adaptive_rho_tolerance) || (rho_new < w.rho / st.adaptive_rho_tolerance))
-      {
-        w.rho = fmin(fmax(rho_new, TMX_RHO_MIN), TMX_RHO_MAX);
-        info.rho_updates += 1;
-        TMX_TICK(6);
-        kkt_factor(w, P, 0, w.sigma, st.delta, tid, NT);
-        kkt_invert(w, fast, tid, NT, pc, tlast);
-        admm_cache_weights(w, tid, NT);
-        TMX_TICK(15);
-      }
-    }
-    TMX_TICK(6);
+    info = sh->info;
+    w.rho = sh->rho;
+    terminated = sh->terminated != 0;
+    can_check = sh->can_check != 0;
+    iter = sh->iter;
+    TMX_SYNC();
+#else
+    qp_admm_generic_loop(w, P, info, iter, can_check, terminated, tid, NT, pc, tlast);
+#endif
   }
   const int exit_iter = terminated ? iter : iter - 1;
   if (!can_check)
@@ -1337,7 +1483,7 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
         f = 1;
       wp.flg_bp[v] = f;
     }
-    for (int r = tid; r < R; r += NT)
+    TMX_ROWS(wp, r)
     {
       if (!wp.act[r])
         continue;
@@ -1365,7 +1511,7 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
     for (int pass = 0; pass <= st.polish_refine_iter; ++pass)
     {
       // residual-form rhs: pass 0: r1 = -q, r2 = b ; pass > 0: r1 = -q - P x - Aact' y, r2 = b - Aact x
-      for (int r = tid; r < R; r += NT)
+      TMX_ROWS(wp, r)
       {
         double g = 0.0;
         if (wp.act[r] && wp.flg_r[r] != 0)
@@ -1404,7 +1550,7 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
           r1 -= p_times(wp, wp.dxp, v) + at_rows(wp, P, wp.dyr, v) + wp.bbp[v] * wp.dybp[v];
         wp.tp[v] = r1 + wp.bbp[v] * gb;
       }
-      for (int r = tid; r < R; r += NT)
+      TMX_ROWS(wp, r)
         if (wp.act[r])
           for (int k = 0; k < wp.naux[r]; ++k)
           {
@@ -1425,7 +1571,7 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
       TMX_SYNC();
       kkt_solve(wp, P, 1, delta, delta, tid, NT);
       // y-part of the solution: kkt_solve(mode 1) left nu_r in hr
-      for (int r = tid; r < R; r += NT)
+      TMX_ROWS(wp, r)
       {
         if (!wp.act[r])
           continue;
@@ -1454,7 +1600,7 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
           wp.dybp[v] += dyb;
         }
       }
-      for (int r = tid; r < R; r += NT)
+      TMX_ROWS(wp, r)
       {
         if (!wp.act[r])
           continue;
@@ -1503,7 +1649,7 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
         wp.xp[v] = wp.dxp[v];
         wp.ybp[v] = wp.dybp[v];
       }
-      for (int r = tid; r < R; r += NT)
+      TMX_ROWS(wp, r)
         if (wp.act[r])
         {
           wp.yr[r] = wp.dyr[r];
@@ -1542,7 +1688,7 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
     yq[mg + v] = has_sol ? (w.cinv * w.Ebp[v]) * w.ybp[v] : nanv;
     hact += tmx_hash_term((long long)w.flg_bp[v], (uint64_t)(mg + v), 5);
   }
-  for (int r = tid; r < R; r += NT)
+  TMX_ROWS(w, r)
     if (w.act[r])
     {
       yq[w.row_ref[r]] = has_sol ? (w.cinv * w.Er[r]) * w.yr[r] : nanv;
@@ -1753,7 +1899,7 @@ TMX_DEVFN void sqp_model_values(const DevProblem* P, const DevBatch* Bt, int b, 
     for (int k = tid; k < P->n_costs + P->n_cnts; k += NT)
     {
       double acc = 0.0;
-      for (int r = 0; r < R; ++r)
+      for (int r = P->own_lo[k]; r <= P->own_hi[k]; ++r)
         if (keys[r] == k)
           acc += val[r];
       if (k < P->n_costs)
@@ -2124,7 +2270,7 @@ TMX_DEVFN void sqp2_model_values(const DevProblem* P, const DevBatch* Bt, int b,
               }
           }
       if (!squared)
-        for (int r = 0; r < R; ++r)
+        for (int r = P->own_lo[k]; r <= P->own_hi[k]; ++r)
           if (keys[r] == k)
             acc += val[r];
       if (k < P->n_costs)

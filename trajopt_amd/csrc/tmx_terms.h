@@ -585,7 +585,7 @@ TMX_DEVFN void evaluate_terms(const DevProblem* P, const double* xv, double* cos
   for (int k = tid; k < P->n_costs + P->n_cnts; k += NT)
   {
     double acc = 0.0;
-    for (int r = 0; r < P->R; ++r)
+    for (int r = P->own_lo[k]; r <= P->own_hi[k]; ++r)
       if (keys[r] == k)
         acc += scratch[r];
     if (k < P->n_costs)

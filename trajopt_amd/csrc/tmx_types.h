@@ -69,6 +69,8 @@ struct DevProblem
   // collision geometry
   int *ls_link;
   double *ls_center, *ls_radius, *ob_center, *ob_radius;
+  int *own_lo, *own_hi;  // n_costs + n_cnts: first / last row slot of every cost (key k) and constraint (key n_costs + k): the owner
+                         // sums of the evaluation / model-value passes walk only their own slot range (hi < lo: no slot)
   int coef_far;     // row coefficient arrays of the QP workspace in the HBM scratch (the rest of the workspace fits the LDS then)
   double *ob_axis;  // 3 per obstacle: capsule = sphere swept from ob_center to ob_center + ob_axis (zero: sphere)
   // pair rows (rows that also touch waypoint t + 1)
