@@ -189,6 +189,43 @@ void lowerTerm(const ProblemConstructionInfo& pci, const TermInfo& ti, bool is_c
     fill(t.upper_tols, up, D, "upper_tols");
     fill(t.lower_tols, lo, D, "lower_tols");
   }
+  else if (dynamic_cast<const JointAccTermInfo*>(&ti) != nullptr || dynamic_cast<const JointJerkTermInfo*>(&ti) != nullptr)
+  {
+    // JointAccTermInfo::hatch / JointJerkTermInfo::hatch (problem_description.cpp:1393-1493, :1515-1615): the same fields as
+    // JointVelTermInfo, second / third difference; the library solves these problems with its dense QP engine
+    const auto* ja = dynamic_cast<const JointAccTermInfo*>(&ti);
+    const auto* jj = dynamic_cast<const JointJerkTermInfo*>(&ti);
+    const int ord = ja != nullptr ? 2 : 3;
+    const DblVec& c_in = ja ? ja->coeffs : jj->coeffs;
+    const DblVec& t_in = ja ? ja->targets : jj->targets;
+    const DblVec& u_in = ja ? ja->upper_tols : jj->upper_tols;
+    const DblVec& l_in = ja ? ja->lower_tols : jj->lower_tols;
+    DblVec up = u_in.empty() ? DblVec(D, 0) : u_in, lo = l_in.empty() ? DblVec(D, 0) : l_in;
+    const bool zero = allZero(up) && allZero(lo);
+    if (ord == 2)
+      t.kind = is_cost ? (zero ? TMX_TERM_JOINT_ACC_EQ_COST : TMX_TERM_JOINT_ACC_INEQ_COST) :
+                         (zero ? TMX_TERM_JOINT_ACC_EQ_CNT : TMX_TERM_JOINT_ACC_INEQ_CNT);
+    else
+      t.kind = is_cost ? (zero ? TMX_TERM_JOINT_JERK_EQ_COST : TMX_TERM_JOINT_JERK_INEQ_COST) :
+                         (zero ? TMX_TERM_JOINT_JERK_EQ_CNT : TMX_TERM_JOINT_JERK_INEQ_CNT);
+    int first = ja ? ja->first_step : jj->first_step, last = ja ? ja->last_step : jj->last_step;
+    if (last <= -1)
+      last = n_steps - 1;
+    if ((n_steps - 1 - ord) <= first)  // :1407-1421 / :1529-1543
+      first = n_steps - 1 - ord;
+    if ((n_steps - 1) <= last)
+      last = n_steps - 1;
+    if (last == first)
+      last += (ord == 2 ? 2 : 4);
+    if (last < first)
+      std::swap(first, last);
+    t.first_step = first;
+    t.last_step = last;
+    fill(t.coeffs, c_in.empty() ? DblVec(D, 1) : (c_in.size() == 1 ? DblVec(D, c_in[0]) : c_in), D, "coeffs");
+    fill(t.targets, t_in, D, "targets");
+    fill(t.upper_tols, up, D, "upper_tols");
+    fill(t.lower_tols, lo, D, "lower_tols");
+  }
   else if (const auto* cp = dynamic_cast<const CartPoseTermInfo*>(&ti))
   {
     if (cp->error_function != nullptr || cp->lower_tolerance.size() != 0 || cp->upper_tolerance.size() != 0)

@@ -117,7 +117,22 @@ typedef enum
      waypoints i and i + 1 (so last_step <= n_steps - 2) with CartVelErrCalculator / CartVelJacCalculator
      (trajopt/src/kinematic_terms.cpp:376-426): the six rows  +-(p[i+1] - p[i]) - max_displacement  of the tool-frame origin,
      analytic translational Jacobians -J(x[i]) / +J(x[i+1]).  `margin` = max_displacement; the link is the chain's tool frame. */
-  TMX_TERM_CART_VEL = 12
+  TMX_TERM_CART_VEL = 12,
+  /* trajopt::JointAccTermInfo::hatch  problem_description.cpp:1393-1493 -> the four acceleration classes of
+     trajectory_costs.cpp:502-754, acc = x[i] - 2 x[i+1] + x[i+2] - target_j for i in [first_step, last_step - 2]:
+     JointAccEqCost (squared cost, zero tolerances), JointAccIneqCost (two hinge rows per step and joint), JointAccEqConstraint,
+     JointAccIneqConstraint.  Rows touch THREE consecutive waypoints and the squared cost couples waypoints i and i + 2: the QP
+     is no longer block tridiagonal, such problems are solved by the dense batched engine.                     */
+  TMX_TERM_JOINT_ACC_EQ_COST = 13,
+  TMX_TERM_JOINT_ACC_INEQ_COST = 14,
+  TMX_TERM_JOINT_ACC_EQ_CNT = 15,
+  TMX_TERM_JOINT_ACC_INEQ_CNT = 16,
+  /* trajopt::JointJerkTermInfo::hatch  problem_description.cpp:1515-1615 -> trajectory_costs.cpp:756-1016,
+     jerk = -x[i] + 3 x[i+1] - 3 x[i+2] + x[i+3] - target_j for i in [first_step, last_step - 3]; four waypoints per row      */
+  TMX_TERM_JOINT_JERK_EQ_COST = 17,
+  TMX_TERM_JOINT_JERK_INEQ_COST = 18,
+  TMX_TERM_JOINT_JERK_EQ_CNT = 19,
+  TMX_TERM_JOINT_JERK_INEQ_CNT = 20
 } tmx_term_kind;
 
 typedef struct

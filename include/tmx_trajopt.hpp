@@ -3,7 +3,7 @@
 // Header-only mirror of the reference's caller-facing interface for the SQP hot path, so that a trajopt user finds
 // the same names, argument meaning and error behaviour (std::runtime_error where the reference PRINT_AND_THROWs):
 //
-//   tmx::trajopt::  TermType, BasicInfo, InitInfo, TermInfo, JointPosTermInfo, JointVelTermInfo, CartPoseTermInfo,
+//   tmx::trajopt::  TermType, BasicInfo, InitInfo, TermInfo, JointPosTermInfo, JointVelTermInfo, JointAccTermInfo, JointJerkTermInfo, CartPoseTermInfo,
 //                   CollisionTermInfo, ProblemConstructionInfo, TrajOptProb, ConstructProblem
 //                     <- trajopt/include/trajopt/problem_description.hpp:29-66, 68-107, 123-160, 162-186, 199-230,
 //                        235-262, 352-392, 421-514, 597-617, 661-663 ; trajopt/src/problem_description.cpp:410-592
@@ -356,7 +356,7 @@ public:
     else
       names.push_back(name);
     const bool ineq = t.kind == TMX_TERM_JOINT_POS_INEQ_CNT || t.kind == TMX_TERM_COLLISION_CNT || t.kind == TMX_TERM_JOINT_VEL_INEQ_CNT ||
-                      t.kind == TMX_TERM_CART_VEL;
+                      t.kind == TMX_TERM_JOINT_ACC_INEQ_CNT || t.kind == TMX_TERM_JOINT_JERK_INEQ_CNT || t.kind == TMX_TERM_CART_VEL;
     std::vector<std::string>& dst = !t.is_constraint ? cost_names_ : (ineq ? ineq_cnt_names_ : eq_cnt_names_);
     dst.insert(dst.end(), names.begin(), names.end());
     terms_.push_back(t);
@@ -573,6 +573,78 @@ struct JointVelTermInfo : public TermInfo
     prob.addTerm(t, {}, name);
   }
 };
+
+/** JointAccTermInfo (problem_description.hpp:516-538 ; hatch: problem_description.cpp:1393-1493) and JointJerkTermInfo
+    (:546-568 ; hatch :1515-1615): the four Eq / Ineq cost / constraint classes over the second / third difference
+    (trajectory_costs.cpp:502-1016).  ORDER = 2 | 3. */
+template <int ORDER>
+struct JointDiffTermInfo : public TermInfo
+{
+  DblVec coeffs;
+  DblVec targets;
+  DblVec upper_tols;
+  DblVec lower_tols;
+  int first_step = 0;
+  int last_step = -1;
+  JointDiffTermInfo() : TermInfo(TermType::TT_COST | TermType::TT_CNT) {}
+  void hatch(TrajOptProb& prob) override
+  {
+    const char* cls = ORDER == 2 ? "JointAccTermInfo" : "JointJerkTermInfo";
+    const std::size_t n_dof = prob.GetKin()->numJoints();
+    if (coeffs.empty())
+      coeffs = DblVec(n_dof, 1);
+    if (upper_tols.empty())
+      upper_tols = DblVec(n_dof, 0);
+    if (lower_tols.empty())
+      lower_tols = DblVec(n_dof, 0);
+    if (last_step <= -1)
+      last_step = prob.GetNumSteps() - 1;
+    if ((prob.GetNumSteps() - 1 - ORDER) <= first_step)  // :1407-1421 / :1529-1543
+      first_step = prob.GetNumSteps() - 1 - ORDER;
+    if ((prob.GetNumSteps() - 1) <= last_step)
+      last_step = prob.GetNumSteps() - 1;
+    if (last_step == first_step)
+      last_step += (ORDER == 2 ? 2 : 4);  // (jerk: += 4 as the reference writes it, :1535)
+    if (last_step < first_step)
+      std::swap(first_step, last_step);
+    detail::checkParameterSize(coeffs, n_dof, std::string(cls) + " coeffs");
+    detail::checkParameterSize(targets, n_dof, std::string(cls) + " targets");
+    detail::checkParameterSize(upper_tols, n_dof, std::string(cls) + " upper_tols");
+    detail::checkParameterSize(lower_tols, n_dof, std::string(cls) + " lower_tols");
+    if (first_step < 0 || last_step - ORDER - first_step < 0)
+      printAndThrow(std::string(ORDER == 2 ? "JointAcc" : "JointJerk") + " term, trajectory is too short!");  // trajectory_costs.cpp:515, :768
+    const bool zero = detail::allZero(upper_tols) && detail::allZero(lower_tols);
+    tmx_term t = detail::blankTerm();
+    if (static_cast<bool>(term_type & TermType::TT_USE_TIME))
+      return;  // "Use time version of this term has not been defined." (:1439-1446): no term
+    if (static_cast<bool>(term_type & TermType::TT_COST))
+    {
+      t.kind = ORDER == 2 ? (zero ? TMX_TERM_JOINT_ACC_EQ_COST : TMX_TERM_JOINT_ACC_INEQ_COST) :
+                            (zero ? TMX_TERM_JOINT_JERK_EQ_COST : TMX_TERM_JOINT_JERK_INEQ_COST);
+      t.is_constraint = 0;
+    }
+    else if (static_cast<bool>(term_type & TermType::TT_CNT))
+    {
+      t.kind = ORDER == 2 ? (zero ? TMX_TERM_JOINT_ACC_EQ_CNT : TMX_TERM_JOINT_ACC_INEQ_CNT) :
+                            (zero ? TMX_TERM_JOINT_JERK_EQ_CNT : TMX_TERM_JOINT_JERK_INEQ_CNT);
+      t.is_constraint = 1;
+    }
+    else
+      return;
+    t.first_step = first_step;
+    t.last_step = last_step;
+    for (std::size_t j = 0; j < n_dof; ++j)
+    {
+      t.coeffs[j] = coeffs[j];
+      t.targets[j] = targets[j];
+      t.upper_tols[j] = upper_tols[j];
+      t.lower_tols[j] = lower_tols[j];
+    }
+    prob.addTerm(t, {}, name);
+  }
+};
+using JointAccTermInfo = JointDiffTermInfo<2>;
+using JointJerkTermInfo = JointDiffTermInfo<3>;
 
 /** problem_description.hpp:352-392 ; hatch: problem_description.cpp:857-987.  Lowered: source = the manipulator's tip link
     (active), target = a static link of the environment, no tolerances. */

@@ -271,6 +271,25 @@ inline TermInfo::Ptr readTerm(const json::Value& it, bool is_cost, const Problem
     t->term_type = tt;
     return t;
   }
+  if (typ == "joint_acc" || typ == "joint_jerk")
+  {
+    // JointAccTermInfo::fromJson / JointJerkTermInfo::fromJson (problem_description.cpp:1374-1391, :1495-1513)
+    ensureOnlyMembers(p, { "coeffs", "first_step", "last_step", "targets", "lower_tols", "upper_tols", "use_time" }, typ);
+    auto fill = [&](auto t) {
+      t->coeffs = jsonVec(p, "coeffs", D, &ones);
+      t->targets = jsonVec(p, "targets", D, nullptr);
+      t->upper_tols = jsonVec(p, "upper_tols", D, &zeros);
+      t->lower_tols = jsonVec(p, "lower_tols", D, &zeros);
+      t->first_step = jsonInt(p, "first_step", 0);
+      t->last_step = jsonInt(p, "last_step", n_steps - 1);
+      t->name = name;
+      t->term_type = tt;
+      return std::static_pointer_cast<TermInfo>(t);
+    };
+    if (typ == "joint_acc")
+      return fill(std::make_shared<JointAccTermInfo>());
+    return fill(std::make_shared<JointJerkTermInfo>());
+  }
   if (typ == "joint_pos")
   {
     ensureOnlyMembers(p, { "coeffs", "first_step", "last_step", "targets", "lower_tols", "upper_tols" }, typ);

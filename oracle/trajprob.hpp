@@ -289,33 +289,65 @@ struct VarArray
   VarVector row(int r) const { return VarVector(v.begin() + r * cols, v.begin() + (r + 1) * cols); }
 };
 
-// ---- trajopt::JointVelEqCost  trajectory_costs.cpp:257-301 --------------------------------------
+// ---- finite-difference joint terms: velocity (order 1, trajectory_costs.cpp:257-499), acceleration (order 2, :502-754) and
+// jerk (order 3, :756-1016).  The three families are the same twelve classes up to the stencil, the range of the step loop
+// (i <= last_step - order) and the nesting depth of diffAxis0 in value() (:17-20): one restatement with the order as a
+// constructor argument (names and error texts per order as in the reference).
+inline const double* diffStencil(int ord)
+{
+  static const double s1[] = { -1.0, 1.0 };             // vel  = x2 - x1                (:277-279)
+  static const double s2[] = { 1.0, -2.0, 1.0 };        // acc  = x3 - 2*x2 + x1         (:522-525)
+  static const double s3[] = { -1.0, 3.0, -3.0, 1.0 };  // jerk = -x1 + 3*x2 - 3*x3 + x4 (:775-779)
+  return ord == 1 ? s1 : (ord == 2 ? s2 : s3);
+}
+inline const char* diffFamily(int ord) { return ord == 1 ? "JointVel" : (ord == 2 ? "JointAcc" : "JointJerk"); }
+// the AffExpr "stencil . x - target" with the terms added in waypoint order
+inline AffExpr diffExpr(const VarArray& vars, int i, int j, int ord, double target)
+{
+  AffExpr e;
+  const double* s = diffStencil(ord);
+  for (int k = 0; k <= ord; ++k)
+    exprInc(e, exprMult(vars(i + k, j), s[k]));
+  exprDec(e, target);
+  return e;
+}
+// entry (i - first_step, j) of diffAxis0 applied `ord` times to the block of rows first_step..last_step: differences of
+// differences, NOT the stencil (the roundings differ)
+inline double diffValue(const VarArray& vars, const DblVec& x, int i, int j, int ord)
+{
+  if (ord == 1)
+    return vars(i + 1, j).value(x) - vars(i, j).value(x);
+  return diffValue(vars, x, i + 1, j, ord - 1) - diffValue(vars, x, i, j, ord - 1);
+}
+inline void diffCheckLength(int first_step, int last_step, int ord, const char* cls)
+{
+  if (((last_step - ord) - first_step) < 0)
+    throw std::runtime_error(std::string(diffFamily(ord)) + cls + ", trajectory is too short!");
+}
+
+// ---- trajopt::JointVelEqCost :257-301 / JointAccEqCost :502-552 / JointJerkEqCost :756-809 ----------------------------
 class JointVelEqCost : public Cost
 {
 public:
-  JointVelEqCost(const VarArray& vars, DblVec coeffs, DblVec targets, int first_step, int last_step)
-    : vars_(vars), coeffs_(std::move(coeffs)), targets_(std::move(targets)), first_step_(first_step), last_step_(last_step)
+  JointVelEqCost(const VarArray& vars, DblVec coeffs, DblVec targets, int first_step, int last_step, int ord = 1)
+    : vars_(vars), coeffs_(std::move(coeffs)), targets_(std::move(targets)), first_step_(first_step), last_step_(last_step), ord_(ord)
   {
-    name_ = "JointVelEq";
-    for (int i = first_step_; i <= last_step_ - 1; ++i)
+    name_ = std::string(diffFamily(ord_)) + "Eq";
+    if (ord_ > 1)  // (JointVelEqCost has no length check, :257-286)
+      diffCheckLength(first_step_, last_step_, ord_, "EqCost");
+    for (int i = first_step_; i <= last_step_ - ord_; ++i)
       for (int j = 0; j < vars_.cols; ++j)
-      {
-        AffExpr vel;
-        exprInc(vel, exprMult(vars_(i, j), -1));
-        exprInc(vel, exprMult(vars_(i + 1, j), 1));
-        exprDec(vel, targets_[j]);
-        exprInc(expr_, exprMult(exprSquare(vel), coeffs_[j]));
-      }
+        exprInc(expr_, exprMult(exprSquare(diffExpr(vars_, i, j, ord_, targets_[j])), coeffs_[j]));
   }
   double value(const DblVec& x) override
   {
     // (diff.array().square().matrix() * coeffs.asDiagonal()).sum() — Eigen reduction order is
-    // column-major over the (steps-1) x dof block
+    // column-major over the (steps-ord) x dof block
     double s = 0;
     for (int j = 0; j < vars_.cols; ++j)
-      for (int i = first_step_; i <= last_step_ - 1; ++i)
+      for (int i = first_step_; i <= last_step_ - ord_; ++i)
       {
-        const double d = (vars_(i + 1, j).value(x) - vars_(i, j).value(x)) - targets_[j];
+        const double d = diffValue(vars_, x, i, j, ord_) - targets_[j];
         s += (d * d) * coeffs_[j];
       }
     return s;
@@ -330,39 +362,33 @@ public:
 private:
   VarArray vars_;
   DblVec coeffs_, targets_;
-  int first_step_, last_step_;
+  int first_step_, last_step_, ord_;
   QuadExpr expr_;
 };
 
-// ---- trajopt::JointVelEqConstraint  trajectory_costs.cpp:376-424 (value() is coeff*diff^2, convex() coeff*diff) ----
+// ---- trajopt::JointVelEqConstraint :376-424 / JointAccEqConstraint :628-676 / JointJerkEqConstraint :886-935
+// (value() is coeff*diff^2, convex() coeff*diff) ----
 class JointVelEqConstraint : public Constraint
 {
 public:
-  JointVelEqConstraint(const VarArray& vars, DblVec coeffs, DblVec targets, int first_step, int last_step)
-    : vars_(vars), coeffs_(std::move(coeffs)), targets_(std::move(targets)), first_step_(first_step), last_step_(last_step)
+  JointVelEqConstraint(const VarArray& vars, DblVec coeffs, DblVec targets, int first_step, int last_step, int ord = 1)
+    : vars_(vars), coeffs_(std::move(coeffs)), targets_(std::move(targets)), first_step_(first_step), last_step_(last_step), ord_(ord)
   {
-    name_ = "JointVelEq";
-    if (((last_step_ - 1) - first_step_) < 0)
-      throw std::runtime_error("JointVelEqConstraint, trajectory is too short!");
-    for (int i = first_step_; i <= last_step_ - 1; ++i)
+    name_ = std::string(diffFamily(ord_)) + "Eq";
+    diffCheckLength(first_step_, last_step_, ord_, "EqConstraint");
+    for (int i = first_step_; i <= last_step_ - ord_; ++i)
       for (int j = 0; j < vars_.cols; ++j)
-      {
-        AffExpr vel;  // vel = (x2 - x1) - targ                                (:392-397)
-        exprInc(vel, exprMult(vars_(i, j), -1));
-        exprInc(vel, exprMult(vars_(i + 1, j), 1));
-        exprDec(vel, targets_[j]);
-        expr_vec_.push_back(exprMult(vel, coeffs_[j]));  // :399
-      }
+        expr_vec_.push_back(exprMult(diffExpr(vars_, i, j, ord_, targets_[j]), coeffs_[j]));  // :399, :651, :910
   }
   ConstraintType type() override { return EQ; }
   DblVec value(const DblVec& x) override
   {
-    // toDblVec((diff.array().square()).matrix() * coeffs.asDiagonal()): column-major copy of the (steps-1) x dof block
+    // toDblVec((diff.array().square()).matrix() * coeffs.asDiagonal()): column-major copy of the (steps-ord) x dof block
     DblVec out;
     for (int j = 0; j < vars_.cols; ++j)
-      for (int i = first_step_; i <= last_step_ - 1; ++i)
+      for (int i = first_step_; i <= last_step_ - ord_; ++i)
       {
-        const double d = (vars_(i + 1, j).value(x) - vars_(i, j).value(x)) - targets_[j];
+        const double d = diffValue(vars_, x, i, j, ord_) - targets_[j];
         out.push_back((d * d) * coeffs_[j]);
       }
     return out;
@@ -378,23 +404,20 @@ public:
 private:
   VarArray vars_;
   DblVec coeffs_, targets_;
-  int first_step_, last_step_;
+  int first_step_, last_step_, ord_;
   AffExprVector expr_vec_;
 };
 
-// the two hinge rows per (step, joint) shared by JointVelIneqCost (:303-374) and JointVelIneqConstraint (:426-499):
-//   -(upper_tol - (vel - targ)) * coeff   and   (lower_tol - (vel - targ)) * coeff
+// the two hinge rows per (step, joint) shared by the IneqCost (:303-374, :554-626, :811-884) and IneqConstraint (:426-499,
+// :678-754, :937-1016) classes:   -(upper_tol - (diff - targ)) * coeff   and   (lower_tol - (diff - targ)) * coeff
 inline AffExprVector jointVelIneqExprs(const VarArray& vars, const DblVec& coeffs, const DblVec& targets, const DblVec& upper,
-                                       const DblVec& lower, int first_step, int last_step)
+                                       const DblVec& lower, int first_step, int last_step, int ord = 1)
 {
   AffExprVector out;
-  for (int i = first_step; i <= last_step - 1; ++i)
+  for (int i = first_step; i <= last_step - ord; ++i)
     for (int j = 0; j < vars.cols; ++j)
     {
-      AffExpr vel;
-      exprInc(vel, exprMult(vars(i, j), -1));
-      exprInc(vel, exprMult(vars(i + 1, j), 1));
-      exprDec(vel, targets[j]);
+      const AffExpr vel = diffExpr(vars, i, j, ord, targets[j]);
       AffExpr expr;
       exprInc(expr, upper[j]);
       exprDec(expr, vel);
@@ -409,11 +432,11 @@ inline AffExprVector jointVelIneqExprs(const VarArray& vars, const DblVec& coeff
   return out;
 }
 
-// ---- trajopt::JointVelIneqCost  trajectory_costs.cpp:303-374 ----
 class JointVelIneqCost : public Cost
 {
 public:
-  JointVelIneqCost(const VarArray& vars, DblVec coeffs, DblVec targets, DblVec upper, DblVec lower, int first_step, int last_step)
+  JointVelIneqCost(const VarArray& vars, DblVec coeffs, DblVec targets, DblVec upper, DblVec lower, int first_step, int last_step,
+                   int ord = 1)
     : vars_(vars)
     , coeffs_(std::move(coeffs))
     , targets_(std::move(targets))
@@ -421,26 +444,26 @@ public:
     , lower_tols_(std::move(lower))
     , first_step_(first_step)
     , last_step_(last_step)
+    , ord_(ord)
   {
-    name_ = "JointVelIneq";
-    if (((last_step_ - 1) - first_step_) < 0)
-      throw std::runtime_error("JointVelIneqCost, trajectory is too short!");
-    expr_vec_ = jointVelIneqExprs(vars_, coeffs_, targets_, upper_tols_, lower_tols_, first_step_, last_step_);
+    name_ = std::string(diffFamily(ord_)) + "Ineq";
+    diffCheckLength(first_step_, last_step_, ord_, "IneqCost");
+    expr_vec_ = jointVelIneqExprs(vars_, coeffs_, targets_, upper_tols_, lower_tols_, first_step_, last_step_, ord_);
   }
   double value(const DblVec& x) override
   {
-    // diff1.cwiseMax(0).sum() + diff2.cwiseMax(0).sum(), each a column-major reduction over (steps-1) x dof  (:349-361)
+    // diff1.cwiseMax(0).sum() + diff2.cwiseMax(0).sum(), each a column-major reduction over (steps-ord) x dof  (:349-361)
     double s1 = 0, s2 = 0;
     for (int j = 0; j < vars_.cols; ++j)
-      for (int i = first_step_; i <= last_step_ - 1; ++i)
+      for (int i = first_step_; i <= last_step_ - ord_; ++i)
       {
-        const double d0 = (vars_(i + 1, j).value(x) - vars_(i, j).value(x)) - targets_[j];
+        const double d0 = diffValue(vars_, x, i, j, ord_) - targets_[j];
         s1 += std::fmax((d0 - upper_tols_[j]) * coeffs_[j], 0.0);
       }
     for (int j = 0; j < vars_.cols; ++j)
-      for (int i = first_step_; i <= last_step_ - 1; ++i)
+      for (int i = first_step_; i <= last_step_ - ord_; ++i)
       {
-        const double d0 = (vars_(i + 1, j).value(x) - vars_(i, j).value(x)) - targets_[j];
+        const double d0 = diffValue(vars_, x, i, j, ord_) - targets_[j];
         s2 += std::fmax(((d0 * -1) + lower_tols_[j]) * coeffs_[j], 0.0);
       }
     return s1 + s2;
@@ -456,15 +479,15 @@ public:
 private:
   VarArray vars_;
   DblVec coeffs_, targets_, upper_tols_, lower_tols_;
-  int first_step_, last_step_;
+  int first_step_, last_step_, ord_;
   AffExprVector expr_vec_;
 };
 
-// ---- trajopt::JointVelIneqConstraint  trajectory_costs.cpp:426-499 ----
 class JointVelIneqConstraint : public Constraint
 {
 public:
-  JointVelIneqConstraint(const VarArray& vars, DblVec coeffs, DblVec targets, DblVec upper, DblVec lower, int first_step, int last_step)
+  JointVelIneqConstraint(const VarArray& vars, DblVec coeffs, DblVec targets, DblVec upper, DblVec lower, int first_step, int last_step,
+                         int ord = 1)
     : vars_(vars)
     , coeffs_(std::move(coeffs))
     , targets_(std::move(targets))
@@ -472,11 +495,11 @@ public:
     , lower_tols_(std::move(lower))
     , first_step_(first_step)
     , last_step_(last_step)
+    , ord_(ord)
   {
-    name_ = "JointVelIneq";
-    if (((last_step_ - 1) - first_step_) < 0)
-      throw std::runtime_error("JointVelIneqConstraint, trajectory is too short!");
-    expr_vec_ = jointVelIneqExprs(vars_, coeffs_, targets_, upper_tols_, lower_tols_, first_step_, last_step_);
+    name_ = std::string(diffFamily(ord_)) + "Ineq";
+    diffCheckLength(first_step_, last_step_, ord_, "IneqConstraint");
+    expr_vec_ = jointVelIneqExprs(vars_, coeffs_, targets_, upper_tols_, lower_tols_, first_step_, last_step_, ord_);
   }
   ConstraintType type() override { return INEQ; }
   DblVec value(const DblVec& x) override
@@ -484,15 +507,15 @@ public:
     // out << diff1, diff2 ; toDblVec(out.cwiseMax(0)): column-major copy  (:472-487)
     DblVec out;
     for (int j = 0; j < vars_.cols; ++j)
-      for (int i = first_step_; i <= last_step_ - 1; ++i)
+      for (int i = first_step_; i <= last_step_ - ord_; ++i)
       {
-        const double d0 = (vars_(i + 1, j).value(x) - vars_(i, j).value(x)) - targets_[j];
+        const double d0 = diffValue(vars_, x, i, j, ord_) - targets_[j];
         out.push_back(std::fmax((d0 - upper_tols_[j]) * coeffs_[j], 0.0));
       }
     for (int j = 0; j < vars_.cols; ++j)
-      for (int i = first_step_; i <= last_step_ - 1; ++i)
+      for (int i = first_step_; i <= last_step_ - ord_; ++i)
       {
-        const double d0 = (vars_(i + 1, j).value(x) - vars_(i, j).value(x)) - targets_[j];
+        const double d0 = diffValue(vars_, x, i, j, ord_) - targets_[j];
         out.push_back(std::fmax(((d0 * -1) + lower_tols_[j]) * coeffs_[j], 0.0));
       }
     return out;
@@ -508,7 +531,7 @@ public:
 private:
   VarArray vars_;
   DblVec coeffs_, targets_, upper_tols_, lower_tols_;
-  int first_step_, last_step_;
+  int first_step_, last_step_, ord_;
   AffExprVector expr_vec_;
 };
 
@@ -1262,6 +1285,8 @@ inline TrajProblem constructProblem(const tmx_problem_desc& d, const double* ini
       const tmx_term& tm = d.terms[k];
       const bool is_cnt = (tm.kind == TMX_TERM_JOINT_POS_EQ_CNT) || (tm.kind == TMX_TERM_JOINT_POS_INEQ_CNT) || (tm.kind == TMX_TERM_COLLISION_CNT) ||
                           (tm.kind == TMX_TERM_JOINT_VEL_EQ_CNT) || (tm.kind == TMX_TERM_JOINT_VEL_INEQ_CNT) ||
+                          (tm.kind == TMX_TERM_JOINT_ACC_EQ_CNT) || (tm.kind == TMX_TERM_JOINT_ACC_INEQ_CNT) ||
+                          (tm.kind == TMX_TERM_JOINT_JERK_EQ_CNT) || (tm.kind == TMX_TERM_JOINT_JERK_INEQ_CNT) ||
                           ((tm.kind == TMX_TERM_CART_POSE || tm.kind == TMX_TERM_CART_VEL) && tm.is_constraint);
       if ((pass == 0) == is_cnt)
         continue;
@@ -1284,6 +1309,31 @@ inline TrajProblem constructProblem(const tmx_problem_desc& d, const double* ini
           P.prob->addConstraint(std::make_shared<JointVelIneqConstraint>(
               P.traj_vars, DblVec(tm.coeffs, tm.coeffs + D), DblVec(tm.targets, tm.targets + D), DblVec(tm.upper_tols, tm.upper_tols + D),
               DblVec(tm.lower_tols, tm.lower_tols + D), tm.first_step, tm.last_step));
+          break;
+        // JointAccTermInfo::hatch / JointJerkTermInfo::hatch (problem_description.cpp:1393-1493, :1530-1631): the four classes of
+        // the velocity family with the second / third difference
+        case TMX_TERM_JOINT_ACC_EQ_COST:
+        case TMX_TERM_JOINT_JERK_EQ_COST:
+          P.prob->addCost(std::make_shared<JointVelEqCost>(P.traj_vars, DblVec(tm.coeffs, tm.coeffs + D), DblVec(tm.targets, tm.targets + D),
+                                                           tm.first_step, tm.last_step, tm.kind == TMX_TERM_JOINT_ACC_EQ_COST ? 2 : 3));
+          break;
+        case TMX_TERM_JOINT_ACC_EQ_CNT:
+        case TMX_TERM_JOINT_JERK_EQ_CNT:
+          P.prob->addConstraint(std::make_shared<JointVelEqConstraint>(P.traj_vars, DblVec(tm.coeffs, tm.coeffs + D),
+                                                                       DblVec(tm.targets, tm.targets + D), tm.first_step, tm.last_step,
+                                                                       tm.kind == TMX_TERM_JOINT_ACC_EQ_CNT ? 2 : 3));
+          break;
+        case TMX_TERM_JOINT_ACC_INEQ_COST:
+        case TMX_TERM_JOINT_JERK_INEQ_COST:
+          P.prob->addCost(std::make_shared<JointVelIneqCost>(P.traj_vars, DblVec(tm.coeffs, tm.coeffs + D), DblVec(tm.targets, tm.targets + D),
+                                                             DblVec(tm.upper_tols, tm.upper_tols + D), DblVec(tm.lower_tols, tm.lower_tols + D),
+                                                             tm.first_step, tm.last_step, tm.kind == TMX_TERM_JOINT_ACC_INEQ_COST ? 2 : 3));
+          break;
+        case TMX_TERM_JOINT_ACC_INEQ_CNT:
+        case TMX_TERM_JOINT_JERK_INEQ_CNT:
+          P.prob->addConstraint(std::make_shared<JointVelIneqConstraint>(
+              P.traj_vars, DblVec(tm.coeffs, tm.coeffs + D), DblVec(tm.targets, tm.targets + D), DblVec(tm.upper_tols, tm.upper_tols + D),
+              DblVec(tm.lower_tols, tm.lower_tols + D), tm.first_step, tm.last_step, tm.kind == TMX_TERM_JOINT_ACC_INEQ_CNT ? 2 : 3));
           break;
         case TMX_TERM_JOINT_POS_EQ_CNT:
           P.prob->addConstraint(std::make_shared<JointPosEqConstraint>(

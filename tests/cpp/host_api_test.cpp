@@ -765,7 +765,15 @@ static void caseJson(const Input& in)
     EXPECT_THROW_MSG(ConstructProblem("{\"init_info\": {\"type\": \"stationary\"}}", env), "Json missing required section basic_info!");
     EXPECT_THROW_MSG(ConstructProblem(head + "\"costs\": []}", env), "Json missing required section init_info!");
     EXPECT_THROW_MSG(ConstructProblem("{\"basic_info\": {\"n_steps\": 5, \"manip\": \"nope\"}, " + init, env), "Manipulator does not exist: nope");
-    EXPECT_THROW_MSG(ConstructProblem(head + "\"costs\": [{\"type\": \"joint_acc\", \"params\": {}}], " + init, env), "is not lowered by the device path");
+    EXPECT_THROW_MSG(ConstructProblem(head + "\"costs\": [{\"type\": \"total_time\", \"params\": {}}], " + init, env), "is not lowered by the device path");
+    EXPECT_THROW_MSG(ConstructProblem(head + "\"costs\": [{\"type\": \"joint_acc\", \"params\": {}}], " + init, env), "missing required field \"targets\"");
+    {
+      // joint_acc / joint_jerk (problem_description.cpp:1374-1391, :1495-1513) are lowered: one cost, one inequality constraint
+      auto prob = ConstructProblem(head + "\"costs\": [{\"type\": \"joint_acc\", \"params\": {\"targets\": [0,0,0,0,0,0,0]}}], "
+                                          "\"constraints\": [{\"type\": \"joint_jerk\", \"params\": {\"targets\": [0,0,0,0,0,0,0], "
+                                          "\"upper_tols\": [0.1,0.1,0.1,0.1,0.1,0.1,0.1], \"lower_tols\": [-0.1,-0.1,-0.1,-0.1,-0.1,-0.1,-0.1]}}], " + init, env);
+      EXPECT_TRUE(prob->getNumCosts() == 1 && prob->getNumConstraints() == 1);
+    }
     EXPECT_THROW_MSG(ConstructProblem(head + "\"costs\": [{\"type\": \"joint_pos\", \"params\": {\"targets\": [0,0,0,0,0,0,0], \"bogus\": 1}}], " + init, env),
                      "illegal field \"bogus\"");
     EXPECT_THROW_MSG(ConstructProblem(head + "\"costs\": [{\"type\": \"joint_pos\", \"params\": {\"targets\": [0,0,0]}}], " + init, env),

@@ -14,7 +14,7 @@ from trajopt_amd import abi, configs
 TOL_TRAJ = 1e-5      # rad — north_star tolerance for joint trajectories / QP primal solutions
 
 # configuration ids of cfg() below: every id runs the stage checks on both tiers; MINI_CIDS also the whole SQP
-MINI_CIDS = [9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25]
+MINI_CIDS = [9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28]
 STAGE_CIDS = [0, 1, 2, 3] + MINI_CIDS
 
 
@@ -82,6 +82,33 @@ def cfg(cid, T=None):
         n = pci.basic_info.n_steps
         ti = CartVelTermInfo(first_step=1, last_step=n - 2, max_displacement=0.07, is_constraint=(cid == 23))
         (pci.cnt_infos if cid == 23 else pci.cost_infos).append(ti)
+        return pci, s, g
+    if cid in (26, 27, 28):
+        # JointAcc / JointJerk terms (rows on 3 / 4 waypoints, banded objective -> dense QP engine) next to the mini arm's collision
+        # cost, via-point constraint and joint band: 26 acceleration smoothing cost + acceleration limits (INEQ constraint),
+        # 27 jerk smoothing cost + a jerk EQ constraint over the first steps + jerk hinge cost, 28 all three difference orders
+        # (velocity EQ constraint, acceleration hinge cost, jerk limits) interleaved in one problem
+        from trajopt_amd.problem import JointAccTermInfo, JointJerkTermInfo, JointVelTermInfo
+        pci, s, g = configs.config_mini() if T is None else configs.config_mini(T)
+        n, D = pci.basic_info.n_steps, 4
+        if cid == 26:
+            pci.cost_infos.append(JointAccTermInfo(coeffs=[2.0, 1.0, 0.5, 1.5], targets=[0.0] * D, first_step=0, last_step=n - 1, name="acc_smooth"))
+            pci.cnt_infos.insert(0, JointAccTermInfo(coeffs=[1.0, 2.0, 1.0, 0.5], targets=[0.0] * D, first_step=1, last_step=n - 2,
+                                                     upper_tols=[0.05, 0.04, 0.06, 0.05], lower_tols=[-0.05, -0.03, -0.06, -0.04],
+                                                     is_constraint=True, name="acc_limits"))
+        elif cid == 27:
+            pci.cost_infos.insert(1, JointJerkTermInfo(coeffs=[1.0, 0.5, 2.0, 1.0], targets=[0.0] * D, first_step=0, last_step=n - 1, name="jerk_smooth"))
+            pci.cost_infos.append(JointJerkTermInfo(coeffs=[3.0, 2.0, 1.0, 1.0], targets=[0.01, 0.0, -0.01, 0.0], first_step=2, last_step=n - 2,
+                                                    upper_tols=[0.02] * D, lower_tols=[-0.02, -0.01, -0.02, -0.03], name="jerk_hinge"))
+            pci.cnt_infos.append(JointJerkTermInfo(coeffs=[1.0] * D, targets=[0.0] * D, first_step=0, last_step=4, is_constraint=True, name="jerk_eq"))
+        else:
+            pci.cnt_infos.append(JointVelTermInfo(coeffs=[1.0] * D, targets=[0.0] * D, first_step=n - 2, last_step=n - 1, is_constraint=True,
+                                                  name="stop"))
+            pci.cost_infos.append(JointAccTermInfo(coeffs=[2.0, 2.0, 1.0, 1.0], targets=[0.0] * D, first_step=0, last_step=n - 1,
+                                                   upper_tols=[0.03] * D, lower_tols=[-0.03] * D, name="acc_hinge"))
+            pci.cnt_infos.insert(0, JointJerkTermInfo(coeffs=[1.0] * D, targets=[0.0] * D, first_step=0, last_step=n - 1,
+                                                      upper_tols=[0.08] * D, lower_tols=[-0.08] * D, is_constraint=True, name="jerk_limits"))
+            pci.cost_infos.append(JointJerkTermInfo(coeffs=[0.5] * D, targets=[0.0] * D, first_step=0, last_step=n - 1, name="jerk_smooth"))
         return pci, s, g
     if cid == 12:  # BasicInfo::fixed_dofs: the wrist joint keeps its seed value at every step
         return configs.config_mini(with_joint_band=False, fixed_dofs=[3])

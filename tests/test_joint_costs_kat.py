@@ -11,7 +11,8 @@ import numpy as np
 import pytest
 
 from trajopt_amd import abi, runtime
-from trajopt_amd.problem import BasicInfo, JointPosTermInfo, JointVelTermInfo, ProblemConstructionInfo, pr2_right_arm
+from trajopt_amd.problem import (BasicInfo, JointAccTermInfo, JointJerkTermInfo, JointPosTermInfo, JointVelTermInfo,
+                                 ProblemConstructionInfo, pr2_right_arm)
 
 STEPS = 10
 
@@ -183,3 +184,126 @@ def test_joint_vel_kat_device(orc, gpu_ctx_factory, name, make, check):
     for b in range(2):
         check(r["x"][b])
     ctx.close()
+
+
+# ---- joint_costs_unit.cpp:677-757 (equality_jointAcc), :768-868 (inequality_jointAcc) and their jerk twins ---------------------
+# JointAcc / JointJerk terms (trajectory_costs.cpp:502-1016): rows on three / four waypoints and a squared cost that couples
+# waypoints i and i + 2 / i + 3.  The QP is no longer block tridiagonal; the library solves it with the dense batched engine
+# (DevProblem::qp_dense).  The reference has no jerk test of this kind: the jerk cases restate the acceleration ones.
+def _equality_diff(cls):
+    rob = pr2_right_arm()
+    pci = ProblemConstructionInfo(rob, BasicInfo(n_steps=STEPS))
+    pci.cnt_infos.append(cls(coeffs=[10.0] * 7, targets=[0.0] * 7, first_step=0, last_step=0, is_constraint=True, name="single"))
+    pci.cost_infos.append(cls(coeffs=[10.0] * 7, targets=[0.1] * 7, first_step=0, last_step=STEPS - 1, name="all"))
+    return pci
+
+
+def _inequality_diff(cls):
+    rob = pr2_right_arm()
+    pci = ProblemConstructionInfo(rob, BasicInfo(n_steps=STEPS))
+    pci.cnt_infos.append(cls(coeffs=[1.0] * 7, targets=[0.0] * 7, lower_tols=[-0.1] * 7, upper_tols=[0.2] * 7, first_step=0,
+                             last_step=STEPS - 1, is_constraint=True, name="limits"))
+    half = (STEPS - 1) // 2
+    pci.cost_infos.append(cls(coeffs=[1.0] * 7, targets=[0.5] * 7, lower_tols=[-0.01] * 7, upper_tols=[0.01] * 7, first_step=0,
+                              last_step=half, name="targ_1"))
+    pci.cost_infos.append(cls(coeffs=[1.0] * 7, targets=[-0.5] * 7, lower_tols=[-0.01] * 7, upper_tols=[0.01] * 7, first_step=half + 1,
+                              last_step=STEPS - 1, name="targ_2"))
+    return pci
+
+
+def _check_equality_diff(order):
+    def check(x):
+        d = np.diff(x, n=order, axis=0)
+        n_cnt = 1 if order == 2 else 2       # a single-step jerk term gets last_step += 4: two rows (problem_description.cpp:1535)
+        assert np.abs(d[:n_cnt] - 0.0).max() <= 1e-4     # :735-741
+        assert np.abs(d[n_cnt:] - 0.1).max() <= 0.01     # :742-750
+    return check
+
+
+def _check_inequality_diff(order):
+    def check(x):
+        d = np.diff(x, n=order, axis=0)
+        assert (d < 0.2 + 1e-4).all() and (d > -0.1 - 1e-4).all()   # :846-866
+    return check
+
+
+DIFF_CASES = [("equality_acc", lambda: _equality_diff(JointAccTermInfo), _check_equality_diff(2)),
+              ("inequality_acc", lambda: _inequality_diff(JointAccTermInfo), _check_inequality_diff(2)),
+              ("equality_jerk", lambda: _equality_diff(JointJerkTermInfo), _check_equality_diff(3)),
+              ("inequality_jerk", lambda: _inequality_diff(JointJerkTermInfo), _check_inequality_diff(3))]
+
+
+def _diff_seeds(pci):
+    rob = pci.robot
+    x0 = np.zeros((2, STEPS, 7))
+    x0[1] = np.clip(0.05 * np.random.default_rng(1).standard_normal((STEPS, 7)), rob.lower + 1e-3, rob.upper - 1e-3)
+    return x0
+
+
+@pytest.mark.parametrize("name,make,check", DIFF_CASES)
+def test_joint_acc_jerk_kat_oracle(orc, name, make, check):
+    o = orc.sqp_batch(make().to_desc(), np.zeros((1, STEPS, 7)))
+    assert o["status"][0] == abi.OPT_CONVERGED
+    check(o["x"][0])
+
+
+def _run_diff_case(ctx, orc, pci, check):
+    import parity_checks as pc
+    x0 = _diff_seeds(pci)
+    desc = pc.make_ctx_inputs(ctx, pci, x0)
+    pc.check_evaluate(ctx, orc, desc, x0, tol=1e-12)
+    for b in range(2):
+        pc.check_first_qp_structure(ctx, orc, desc, x0, b, val_tol=1e-12)     # banded P, columns of A merged over four waypoints
+    assert all(same for same, _ in pc.check_first_qp_solve(ctx, orc, desc, x0))
+    ctx.set_x0(x0)
+    r, o, same, dx = pc.check_full_sqp(ctx, orc, desc, x0, exact=False)
+    assert same.all() and (r["status"] == abi.OPT_CONVERGED).all()
+    order = 2 if "acc" in pci.cost_infos[0].__class__.__name__.lower() else 3
+    for b in range(2):
+        check(r["x"][b])
+        # no fixed waypoint: the problem is invariant under the polynomials the difference annihilates - compare the differences
+        assert np.abs(np.diff(r["x"][b], n=order, axis=0) - np.diff(o["x"][b], n=order, axis=0)).max() < 1e-5
+
+
+@pytest.mark.parametrize("name,make,check", DIFF_CASES)
+def test_joint_acc_jerk_kat_kernel_sources_on_host(hostemu_lib, orc, name, make, check):
+    ctx = runtime.Context(0, hostemu_lib)
+    _run_diff_case(ctx, orc, make(), check)
+    ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,make,check", DIFF_CASES)
+def test_joint_acc_jerk_kat_device(orc, gpu_ctx_factory, name, make, check):
+    """equality_jointAcc / inequality_jointAcc (trajopt/test/joint_costs_unit.cpp:677-868) and jerk twins on the HIP library"""
+    ctx = gpu_ctx_factory()
+    _run_diff_case(ctx, orc, make(), check)
+    ctx.close()
+
+
+def test_finite_difference_derivatives(orc, hostemu_lib):
+    """joint_costs_unit.cpp:883-942: on x(t) = t^3 sampled at dt the first / second / third differences divided by dt^k are the
+    derivatives 3 t^2 + ..., 6 t + ..., 6 up to the known truncation terms; here through value() of the three squared costs with
+    the analytic difference as target (cost 0) - oracle and kernel sources"""
+    import parity_checks as pc
+    rob = pr2_right_arm()
+    n, dt = 8, 0.1
+    t = dt * np.arange(n)
+    # (offset to the middle of the joint ranges: the optimizer projects its start point into the limits, modeling.cpp:264-269)
+    x = 0.5 * (rob.lower + rob.upper)[None, :] + np.repeat((t ** 3)[:, None], 7, axis=1)
+    d1, d2, d3 = 3 * t[0] ** 2, 6 * t[0], 6.0
+    # forward differences of t^3 at t0 = 0: x1 - x0 = dt^3, second difference at i: 6 t_i dt^2 + 6 dt^3, third: 6 dt^3
+    cases = [(JointVelTermInfo, 0, 1, dt ** 3), (JointAccTermInfo, 0, 2, 6 * t[0] * dt ** 2 + 6 * dt ** 3), (JointJerkTermInfo, 0, 3, 6 * dt ** 3)]
+    for cls, first, order, target in cases:
+        pci = ProblemConstructionInfo(rob, BasicInfo(n_steps=n))
+        pci.cost_infos.append(cls(coeffs=[1.0] * 7, targets=[target] * 7, first_step=first, last_step=first + order, name="d"))
+        pci.cost_infos.append(cls(coeffs=[1.0] * 7, targets=[0.0] * 7, first_step=first, last_step=first + order, name="d0"))
+        desc = pci.to_desc()
+        cv, _ = orc.evaluate(desc, x, x)
+        assert abs(cv[0]) < 1e-28 and abs(cv[1] - 7 * target ** 2) < 1e-15, (cls.__name__, cv)   # rounding of the offset sums
+        ctx = runtime.Context(0, hostemu_lib)
+        pc.make_ctx_inputs(ctx, pci, x[None])
+        dv, _ = ctx.evaluate()
+        assert np.abs(dv[0] - cv).max() < 1e-30    # the same differences of differences, bit for bit
+        ctx.close()
+    assert abs(d3 - 6.0) == 0 and d1 == 0 and d2 == 0

@@ -27,6 +27,8 @@ TERM_JOINT_VEL_EQ_CNT = 9
 TERM_JOINT_VEL_INEQ_COST = 10
 TERM_JOINT_VEL_INEQ_CNT = 11
 TERM_CART_VEL = 12
+TERM_JOINT_ACC_EQ_COST, TERM_JOINT_ACC_INEQ_COST, TERM_JOINT_ACC_EQ_CNT, TERM_JOINT_ACC_INEQ_CNT = 13, 14, 15, 16
+TERM_JOINT_JERK_EQ_COST, TERM_JOINT_JERK_INEQ_COST, TERM_JOINT_JERK_EQ_CNT, TERM_JOINT_JERK_INEQ_CNT = 17, 18, 19, 20
 
 # OSQP v1.0.0 status values
 OSQP_SOLVED, OSQP_SOLVED_INACCURATE = 1, 2

@@ -55,6 +55,7 @@ struct tmx_ctx
   bool clock_started{ false };  // k_mark_start ran since the last tmx_batch_set_x0 (start of optimize(): sqp.max_time)
   long long pool_relaunches{ 0 };  // times tmx_sqp_wait had to restart the pool (expected: 0)
   int* h_tail{ nullptr };  // pinned, device-mapped word: 1 once the pool kernel of the pending launch has begun to retire workgroups
+  bool dense{ false };      // DevProblem::qp_dense: the piecewise driver with k_qp_solve_dense runs optimize() (host loop)
   bool ws_in_hbm{ false };  // QP workspace > 160 KB of LDS: k_*_hbm kernels, workspace carved in HBM (long horizons)
   int mode{ 2 };  // optimize() driver: 0 = one launch chain per step, 1 = k_sqp_fused, 2 = k_sqp_pool (default)
   int pool_wgs{ 0 };  // resident workgroups of the pool kernel (0 = CUs x workgroups-per-CU)
@@ -399,7 +400,9 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
       if (std::find(fixed.begin(), fixed.end(), i) == fixed.end())
         add_slot(SLOT_FIXED, i, dof, 0, -1, 0, 0, 1, 0.0, 1.0, 0.0, 0.0);
   }
-  std::vector<double> pd(P.NX, 0.0), po(P.NX, 0.0), pq(P.NX, 0.0);
+  std::vector<double> pd(P.NX, 0.0), po(P.NX, 0.0), pq(P.NX, 0.0), po2(P.NX, 0.0), po3(P.NX, 0.0);
+  int n_stencil = 0;      // rows of difference order 2 / 3
+  bool qp_dense = false;  // an acceleration / jerk term is present: banded objective and / or rows on 3 - 4 waypoints
   std::vector<int> vel_first, vel_last, vel_cost, vel_kind, cp_t, cp_owner, cp_iscnt, cp_nrows, cp_idx, cp_slot0;
   std::vector<double> vel_coeffs, vel_targets, cp_coeff, cp_target;
   // hatch order: all costs in list order, then the constraints; sco::OptProb keeps equality constraints in front of the
@@ -410,8 +413,10 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
     {
       const tmx_term& tm = d->terms[k];
       const bool is_ineq = tm.kind == TMX_TERM_JOINT_POS_INEQ_CNT || tm.kind == TMX_TERM_COLLISION_CNT || tm.kind == TMX_TERM_JOINT_VEL_INEQ_CNT ||
+                           tm.kind == TMX_TERM_JOINT_ACC_INEQ_CNT || tm.kind == TMX_TERM_JOINT_JERK_INEQ_CNT ||
                            (tm.kind == TMX_TERM_CART_VEL && tm.is_constraint);
       const bool is_cnt = is_ineq || (tm.kind == TMX_TERM_JOINT_POS_EQ_CNT) || (tm.kind == TMX_TERM_JOINT_VEL_EQ_CNT) ||
+                          (tm.kind == TMX_TERM_JOINT_ACC_EQ_CNT) || (tm.kind == TMX_TERM_JOINT_JERK_EQ_CNT) ||
                           (tm.kind == TMX_TERM_CART_POSE && tm.is_constraint);
       int want = !is_cnt ? 0 : (is_ineq ? 2 : 1);
       if (flavor == TMX_FLAVOR_SQP)
@@ -586,6 +591,113 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
                 c2.back() = R2++;
                 add_slot(SLOT_JOINTVEL_INEQ, i, j, 1, own, 1, is_cnt ? 1 : 0, 0, is_cnt ? 0.0 : 1.0, c, tm.targets[j], tm.lower_tols[j]);
                 c2.back() = R2++;
+              }
+            }
+          break;
+#endif
+        }
+        case TMX_TERM_JOINT_ACC_EQ_COST:
+        case TMX_TERM_JOINT_JERK_EQ_COST:
+        {
+          // JointAccEqCost / JointJerkEqCost (trajectory_costs.cpp:502-552, :756-809): sum_ij c_j (stencil . x[i..i+ord][j] - targ_j)^2
+          // built once as a QuadExpr; Hessian / linear term exactly as exprSquare + exprToEigen build them (expr_ops.cpp:55-84,
+          // solver_utils.cpp:49-109 with matrix_is_halved = true): diagonal 2 a_k^2 c, off-diagonal (2 a_k a_l) c, linear (2 cst a_k) c
+          const int ord = tm.kind == TMX_TERM_JOINT_ACC_EQ_COST ? 2 : 3;
+          if (flavor == TMX_FLAVOR_SQP || !TMX_LINK_ROWS)
+          {
+            ctx->err = "joint acceleration / jerk terms: not available in this flavour / build";
+            return TMX_ERR_UNSUPPORTED;
+          }
+          if (tm.last_step - ord - tm.first_step < 0)
+          {
+            ctx->err = ord == 2 ? "JointAccEqCost, trajectory is too short!" : "JointJerkEqCost, trajectory is too short!";  // :515, :768
+            return TMX_ERR_INVALID;
+          }
+          qp_dense = true;
+          vel_first.push_back(tm.first_step);
+          vel_last.push_back(tm.last_step);
+          vel_kind.push_back(ord);
+          vel_cost.push_back(n_costs++);
+          for (int j = 0; j < TMX_MAX_DOF; ++j)
+          {
+            vel_coeffs.push_back(j < D ? tm.coeffs[j] : 0.0);
+            vel_targets.push_back(j < D ? tm.targets[j] : 0.0);
+          }
+          static const double S2[3] = { 1.0, -2.0, 1.0 }, S3[4] = { -1.0, 3.0, -3.0, 1.0 };
+          const double* a = ord == 2 ? S2 : S3;
+          for (int i = tm.first_step; i <= tm.last_step - ord; ++i)
+            for (int j = 0; j < D; ++j)
+            {
+              const double c = tm.coeffs[j], cst = 0.0 - tm.targets[j];
+              for (int k = 0; k <= ord; ++k)
+              {
+                const double qkk = (a[k] * a[k]) * c;
+                if (qkk != 0.0)
+                  pd[(i + k) * D + j] += 2.0 * qkk;
+                const double lk = (2 * cst * a[k]) * c;
+                if (lk != 0.0)
+                  pq[(i + k) * D + j] += lk;
+                for (int l = k + 1; l <= ord; ++l)
+                {
+                  const double qkl = (2 * a[k] * a[l]) * c;
+                  if (qkl == 0.0)
+                    continue;
+                  std::vector<double>& band = (l - k == 1) ? po : ((l - k == 2) ? po2 : po3);
+                  band[(i + k) * D + j] += qkl;
+                }
+              }
+            }
+          break;
+        }
+        case TMX_TERM_JOINT_ACC_EQ_CNT:
+        case TMX_TERM_JOINT_ACC_INEQ_COST:
+        case TMX_TERM_JOINT_ACC_INEQ_CNT:
+        case TMX_TERM_JOINT_JERK_EQ_CNT:
+        case TMX_TERM_JOINT_JERK_INEQ_COST:
+        case TMX_TERM_JOINT_JERK_INEQ_CNT:
+        {
+#if !TMX_LINK_ROWS
+          ctx->err = "rows on several waypoints (joint acceleration / jerk terms) are not enabled in this build";
+          return TMX_ERR_UNSUPPORTED;
+#else
+          const bool acc = tm.kind == TMX_TERM_JOINT_ACC_EQ_CNT || tm.kind == TMX_TERM_JOINT_ACC_INEQ_COST || tm.kind == TMX_TERM_JOINT_ACC_INEQ_CNT;
+          const int ord = acc ? 2 : 3;
+          const bool is_eq = tm.kind == TMX_TERM_JOINT_ACC_EQ_CNT || tm.kind == TMX_TERM_JOINT_JERK_EQ_CNT;
+          const bool is_cost = tm.kind == TMX_TERM_JOINT_ACC_INEQ_COST || tm.kind == TMX_TERM_JOINT_JERK_INEQ_COST;
+          if (flavor == TMX_FLAVOR_SQP)
+          {
+            ctx->err = "TMX_FLAVOR_SQP: joint acceleration / jerk terms are not part of the trajopt_sqp path";
+            return TMX_ERR_UNSUPPORTED;
+          }
+          if (tm.last_step - ord - tm.first_step < 0)
+          {
+            ctx->err = acc ? "JointAcc term, trajectory is too short!" : "JointJerk term, trajectory is too short!";  // :575, :642, :699, ...
+            return TMX_ERR_INVALID;
+          }
+          qp_dense = true;
+          // rows in the order of the reference's expr_vec_ (:577-601, :644-652, :703-727 and the jerk twins): one row (EQ) or an
+          // upper and a lower row (INEQ) per step i in [first, last - ord] and joint j over x[i .. i + ord][j]
+          const int own = is_cost ? n_costs++ : n_cnts++;
+          for (int i = tm.first_step; i <= tm.last_step - ord; ++i)
+            for (int j = 0; j < D; ++j)
+            {
+              const double c = tm.coeffs[j];
+              if (is_eq)
+              {
+                add_slot(SLOT_JOINTVEL, i, j, 0, own, 2, 1, 1, 0.0, c, tm.targets[j], 0.0);
+                c2.back() = R2++;
+                sub3.back() = ord;
+                ++n_stencil;
+              }
+              else
+              {
+                add_slot(SLOT_JOINTVEL_INEQ, i, j, 0, own, 1, is_cost ? 0 : 1, 0, is_cost ? 1.0 : 0.0, c, tm.targets[j], tm.upper_tols[j]);
+                c2.back() = R2++;
+                sub3.back() = ord;
+                add_slot(SLOT_JOINTVEL_INEQ, i, j, 1, own, 1, is_cost ? 0 : 1, 0, is_cost ? 1.0 : 0.0, c, tm.targets[j], tm.lower_tols[j]);
+                c2.back() = R2++;
+                sub3.back() = ord;
+                n_stencil += 2;
               }
             }
           break;
@@ -808,12 +920,16 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
   P.m_max = R + P.NX + NA;
   int nnzP = 0;
   for (int v = 0; v < P.NX; ++v)
-    nnzP += (pd[v] != 0.0) + (v < P.NX - D && po[v] != 0.0);
+    nnzP += (pd[v] != 0.0) + (v < P.NX - D && po[v] != 0.0) + (v < P.NX - 2 * D && po2[v] != 0.0) + (v < P.NX - 3 * D && po3[v] != 0.0);
   P.nnzP = nnzP;
-  // column c of upper-triangular P holds (c-D, c) if po[c-D] != 0 and (c, c) if pd[c] != 0
+  // column c of upper-triangular P holds (c-3D, c) / (c-2D, c) if po3 / po2 are set there (jerk / acceleration costs), (c-D, c) if
+  // po[c-D] != 0 and (c, c) if pd[c] != 0
   std::vector<int> p_colptr(P.NX + 1, 0);
   for (int c = 0; c < P.NX; ++c)
-    p_colptr[c + 1] = p_colptr[c] + ((c >= D && po[c - D] != 0.0) ? 1 : 0) + ((pd[c] != 0.0) ? 1 : 0);
+    p_colptr[c + 1] = p_colptr[c] + ((c >= 3 * D && po3[c - 3 * D] != 0.0) ? 1 : 0) + ((c >= 2 * D && po2[c - 2 * D] != 0.0) ? 1 : 0) +
+                      ((c >= D && po[c - D] != 0.0) ? 1 : 0) + ((pd[c] != 0.0) ? 1 : 0);
+  P.n_stencil = n_stencil;
+  P.qp_dense = qp_dense ? 1 : 0;
   // slots grouped by waypoint, ascending slot id inside a waypoint
   std::vector<int> wp_start(T + 1, 0), wp_list(R, 0);
   for (int r = 0; r < R; ++r)
@@ -896,6 +1012,8 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
   UP(pd, pd);
   UP(po, po);
   UP(pq, pq);
+  UP(po2, po2);
+  UP(po3, po3);
   UP(p_colptr, p_colptr);
   UP(vel_first, vel_first);
   UP(vel_last, vel_last);
@@ -952,6 +1070,9 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
   ctx->smem_small = std::max<size_t>((tmx_eval_scratch_doubles(R, D * T, (int)vel_first.size(), n_costs, n_cnts) + n_costs + n_cnts + 8) * sizeof(double),
                                      small_ints * sizeof(int) + 64);
   ctx->smem_small = std::max<size_t>(ctx->smem_small, tmx_cvx_scratch_doubles(P.n_cp, D) * sizeof(double));
+  ctx->dense = P.qp_dense != 0;
+  if (ctx->dense)
+    ctx->smem_small = std::max<size_t>(ctx->smem_small, 320 * sizeof(double));  // reduction scratch of qp_generic_block
 #ifdef TMX_HOST_EMU
   ctx->nt_qp = 1;
   ctx->nt_small = 1;
@@ -992,7 +1113,8 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
     // the term / structure kernels of a long-horizon problem need more than the default 64 KB of dynamic LDS
     const void* small_kernels[] = { reinterpret_cast<const void*>(k_prepare), reinterpret_cast<const void*>(k_evaluate),
                                     reinterpret_cast<const void*>(k_convexify), reinterpret_cast<const void*>(k_export_csc),
-                                    reinterpret_cast<const void*>(k_sqp_update) };
+                                    reinterpret_cast<const void*>(k_sqp_update), reinterpret_cast<const void*>(k_qp_solve_dense),
+                                    reinterpret_cast<const void*>(k_model_values) };
     for (const void* k : small_kernels)
       HIPCHK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(ctx->smem_small)));
   }
@@ -1090,6 +1212,44 @@ static tmx_status ensure_batch(tmx_ctx* ctx, int B)
   AL(step_log, b * (size_t)H.step_log_stride);
   AL(t_start, 1);
   AL(accept_flag, b);
+  if (P.qp_dense)
+  {
+    // dense engine: the QP in CSC form + dense workspace per problem (tmx_generic.h).  Capacity of A: every row slot with all the
+    // entries its kind can have, two entries per aux column, one identity entry per variable.
+    size_t cap = (size_t)P.n_max + 2 * (size_t)P.NA;
+    for (int r = 0; r < P.R; ++r)
+      cap += (size_t)2 * P.D;
+    if (P.n_max > 4096 || P.m_max > 16384)
+    {
+      ctx->err = "joint acceleration / jerk terms: the QP is too large for the dense engine (n <= 4096, m <= 16384)";
+      return TMX_ERR_UNSUPPORTED;
+    }
+    H.dq_nnzA = (int)cap;
+    const size_t nzp = (size_t)std::max(1, P.nnzP);
+    AL(dq_Pp, b * (size_t)(P.n_max + 1));
+    AL(dq_Pi, b * nzp);
+    AL(dq_Px, b * nzp);
+    AL(dq_Ap, b * (size_t)(P.n_max + 1));
+    AL(dq_Ai, b * cap);
+    AL(dq_Ax, b * cap);
+    AL(dq_q, b * (size_t)P.n_max);
+    AL(dq_l, b * (size_t)P.m_max);
+    AL(dq_u, b * (size_t)P.m_max);
+    AL(dq_x, b * (size_t)P.n_max);
+    AL(dq_y, b * (size_t)P.m_max);
+    AL(dq_xw, b * (size_t)P.n_max);
+    AL(dq_yw, b * (size_t)P.m_max);
+    AL(dq_flags, b * (size_t)P.m_max);
+    AL(dq_info, b);
+    H.dq_ws_stride = (long long)((gen_ws_doubles(P.n_max, P.m_max) + 1) & ~(size_t)1);
+    if (b * (size_t)H.dq_ws_stride * sizeof(double) > ((size_t)200 << 30))
+    {
+      ctx->err = "joint acceleration / jerk terms: dense workspace of the batch exceeds 200 GiB (reduce the batch)";
+      return TMX_ERR_UNSUPPORTED;
+    }
+    if ((rc = dalloc(ctx, pool, &H.dq_ws, b * (size_t)H.dq_ws_stride, /*zero=*/false)) != TMX_OK)
+      return rc;
+  }
   H.tail_flag = ctx->h_tail;  // pinned host memory is device-accessible at the same address (unified addressing)
   H.qp_scratch_stride = (long long)qp_scratch_doubles(P.D, P.T, P.R, P.NA, P.n_link, P.coef_far);
   AL(qp_scratch, b * (size_t)H.qp_scratch_stride);
@@ -1177,6 +1337,7 @@ static tmx_status read_totals(tmx_ctx* ctx, long long out[4])
 // returns.  Two contexts on one device (double-buffered batches) overlap the straggler tail of one batch - the kernel
 // time of a batch is set by its longest chain of QP solves, and the persistent workgroups retire as soon as nothing is
 // left for them - with the bulk of the next one.
+static tmx_status sqp_run_piecewise(tmx_ctx* ctx, int32_t max_steps, int32_t* n_active_out);
 tmx_status tmx_sqp_launch(tmx_ctx* ctx)
 {
   if (!ctx)
@@ -1185,6 +1346,16 @@ tmx_status tmx_sqp_launch(tmx_ctx* ctx)
     return TMX_ERR_STATE;
   HIPCHK(hipSetDevice(ctx->device));
   const int B = ctx->hb.B;
+  if (ctx->dense)
+  {
+    // the piecewise driver is a host loop: the whole optimize() runs here, tmx_sqp_wait() only collects it
+    int32_t left = 0;
+    const tmx_status rc = sqp_run_piecewise(ctx, 0, &left);
+    if (rc != TMX_OK)
+      return rc;
+    ctx->pending = 2;
+    return TMX_OK;
+  }
   if (ctx->mode == 0)
     return TMX_ERR_UNSUPPORTED;  // the piecewise mode runs the loop on the host
   // only the pool kernel reports the start of its tail; the one-workgroup-per-problem kernels free CUs from their first
@@ -1229,6 +1400,17 @@ tmx_status tmx_sqp_wait(tmx_ctx* ctx, int32_t* n_active_out)
   if (!ctx->pending)
     return TMX_ERR_STATE;
   HIPCHK(hipSetDevice(ctx->device));
+  if (ctx->pending == 2)  // qp_dense problem: tmx_sqp_launch ran the loop
+  {
+    long long tot2[4] = { 0, 0, 0, 0 };
+    const tmx_status rc2 = read_totals(ctx, tot2);
+    if (rc2 != TMX_OK)
+      return rc2;
+    ctx->pending = 0;
+    if (n_active_out)
+      *n_active_out = static_cast<int32_t>(tot2[0]);
+    return TMX_OK;
+  }
   // (pending is cleared only once the launch has been collected: a device error leaves the context in the pending state)
   if (ctx->timing)
   {
@@ -1274,9 +1456,10 @@ tmx_status tmx_sqp_run(tmx_ctx* ctx, int32_t max_steps, int32_t* n_active_out)
   if (!ctx->have_problem || ctx->Bcap == 0 || ctx->pending)
     return TMX_ERR_STATE;
   HIPCHK(hipSetDevice(ctx->device));
+  if (ctx->dense)
+    return sqp_run_piecewise(ctx, max_steps, n_active_out);
   const int B = ctx->hb.B;
   long long tot[4] = { B, 0, 0, 0 };
-  int step = 0;
   if (ctx->mode != 0)
   {
     if (max_steps == 0)
@@ -1306,6 +1489,21 @@ tmx_status tmx_sqp_run(tmx_ctx* ctx, int32_t max_steps, int32_t* n_active_out)
       *n_active_out = static_cast<int32_t>(tot[0]);
     return TMX_OK;
   }
+  return sqp_run_piecewise(ctx, max_steps, n_active_out);
+}
+
+// optimize() as one launch chain per trust-region evaluation (k_convexify -> QP solve -> k_evaluate -> k_sqp_update), the loop on
+// the host: driver mode 0, and the only driver of qp_dense problems (k_qp_solve_dense)
+static tmx_status sqp_run_piecewise(tmx_ctx* ctx, int32_t max_steps, int32_t* n_active_out)
+{
+  const int B = ctx->hb.B;
+  long long tot[4] = { B, 0, 0, 0 };
+  int step = 0;
+  if (!ctx->clock_started)
+  {
+    TMX_LAUNCH(k_mark_start, 1, 64, 0, ctx->stream, ctx->db);
+    ctx->clock_started = true;
+  }
   while (true)
   {
     tmx_status rc = read_totals(ctx, tot);
@@ -1322,7 +1520,10 @@ tmx_status tmx_sqp_run(tmx_ctx* ctx, int32_t max_steps, int32_t* n_active_out)
     }
     TIMED(ctx->ms_convexify, (void)0,
           TMX_LAUNCH(k_convexify, B, ctx->nt_small, ctx->smem_small, ctx->stream, ctx->dp, ctx->db, 0));
-    if (ctx->ws_in_hbm)
+    if (ctx->dense)
+      TIMED(ctx->ms_admm, ctx->launches_admm++,
+            TMX_LAUNCH(k_qp_solve_dense, B, ctx->nt_qp > 1 ? 256 : 1, ctx->smem_small, ctx->stream, ctx->dp, ctx->db, 0));
+    else if (ctx->ws_in_hbm)
       TIMED(ctx->ms_admm, ctx->launches_admm++, TMX_LAUNCH(k_qp_solve_hbm, B, ctx->nt_qp > 1 ? TMX_HBM_NT : 1, ctx->smem_chain, ctx->stream, ctx->dp, ctx->db, 0));
     else
       TIMED(ctx->ms_admm, ctx->launches_admm++,
@@ -1645,7 +1846,10 @@ tmx_status tmx_qp_solve(tmx_ctx* ctx, double* x_qp, int32_t* cvx_status, tmx_qp_
   TMX_REFUSE_WHILE_PENDING(ctx);
   HIPCHK(hipSetDevice(ctx->device));
   const size_t B = ctx->hb.B;
-  if (ctx->ws_in_hbm)
+  if (ctx->dense)
+    TIMED(ctx->ms_admm, ctx->launches_admm++,
+          TMX_LAUNCH(k_qp_solve_dense, ctx->hb.B, ctx->nt_qp > 1 ? 256 : 1, ctx->smem_small, ctx->stream, ctx->dp, ctx->db, 1));
+  else if (ctx->ws_in_hbm)
     TIMED(ctx->ms_admm, ctx->launches_admm++, TMX_LAUNCH(k_qp_solve_hbm, ctx->hb.B, ctx->nt_qp > 1 ? TMX_HBM_NT : 1, ctx->smem_chain, ctx->stream, ctx->dp, ctx->db, 1));
   else
     TIMED(ctx->ms_admm, ctx->launches_admm++,

@@ -68,7 +68,15 @@ TMX_KERNEL_LB(256) k_prepare(const DevProblem* P, const DevBatch* Bt)
   TMX_SYNC();
   init_static_rows(P, x0, act, Bt->coef + (size_t)b * R * D, Bt->coef2 + (size_t)b * P->n_link * D, Bt->rhs + (size_t)b * R, tid, NT);
   // (two call sites instead of a pointer select: the select crashes the register allocator of this ROCm 7.2 clang)
-  if (Bt->ws_hbm)
+  if (P->qp_dense)  // difference terms of order 2 / 3 (the ST instantiations live in the piecewise kernels only)
+  {
+    if (Bt->ws_hbm)
+      evaluate_terms<true>(P, x, Bt->cost_vals + (size_t)b * P->n_costs, Bt->cnt_viols + (size_t)b * P->n_cnts,
+                           Bt->ws_hbm + (size_t)b * (size_t)Bt->ws_hbm_stride, tid, NT);
+    else
+      evaluate_terms<true>(P, x, Bt->cost_vals + (size_t)b * P->n_costs, Bt->cnt_viols + (size_t)b * P->n_cnts, smem, tid, NT);
+  }
+  else if (Bt->ws_hbm)
     evaluate_terms(P, x, Bt->cost_vals + (size_t)b * P->n_costs, Bt->cnt_viols + (size_t)b * P->n_cnts,
                    Bt->ws_hbm + (size_t)b * (size_t)Bt->ws_hbm_stride, tid, NT);
   else
@@ -96,7 +104,10 @@ TMX_KERNEL_LB(256) k_evaluate(const DevProblem* P, const DevBatch* Bt, int which
   const double* xv = (which ? Bt->xnew : Bt->x) + (size_t)b * P->NX;
   double* co = (which ? Bt->new_cost_vals : Bt->cost_vals) + (size_t)b * P->n_costs;
   double* vo = (which ? Bt->new_cnt_viols : Bt->cnt_viols) + (size_t)b * P->n_cnts;
-  evaluate_terms(P, xv, co, vo, smem, tid, NT);
+  if (P->qp_dense)
+    evaluate_terms<true>(P, xv, co, vo, smem, tid, NT);
+  else
+    evaluate_terms(P, xv, co, vo, smem, tid, NT);
 }
 
 // convexify (K1, K3) + reference QP structure (K4) for problems in PHASE_CONVEXIFY (all problems if force)
@@ -120,8 +131,12 @@ TMX_KERNEL_LB(256) k_convexify(const DevProblem* P, const DevBatch* Bt, int forc
   const double* x = Bt->x + (size_t)b * P->NX;
   convexify_terms(P, x, act, coef, Bt->coef2 + (size_t)b * P->n_link * D, rhs, smem, tid, NT, Bt->rowc + (size_t)b * R, Bt->qdyn + (size_t)b * P->NX);
   QpWs cwd;
-  qp_structure(P, act, coef, Bt->coef2 + (size_t)b * P->n_link * D, rhs, x, Bt->trust[b], Bt->merit + (size_t)b * P->n_cnts, Bt->dims + 4 * b,
-               Bt->hashes + 4 * b, nullptr, reinterpret_cast<int*>(smem), tid, NT, Bt->qdyn + (size_t)b * P->NX, compact_lists_of(cwd, P, Bt, b));
+  if (P->qp_dense)
+    qp_structure<true>(P, act, coef, Bt->coef2 + (size_t)b * P->n_link * D, rhs, x, Bt->trust[b], Bt->merit + (size_t)b * P->n_cnts,
+                       Bt->dims + 4 * b, Bt->hashes + 4 * b, nullptr, reinterpret_cast<int*>(smem), tid, NT, Bt->qdyn + (size_t)b * P->NX, nullptr);
+  else
+    qp_structure(P, act, coef, Bt->coef2 + (size_t)b * P->n_link * D, rhs, x, Bt->trust[b], Bt->merit + (size_t)b * P->n_cnts, Bt->dims + 4 * b,
+                 Bt->hashes + 4 * b, nullptr, reinterpret_cast<int*>(smem), tid, NT, Bt->qdyn + (size_t)b * P->NX, compact_lists_of(cwd, P, Bt, b));
 #if TMX_LINK_ROWS
   if (P->flavor == 1 && !force)
     sqp2_begin_qp(P, Bt, b, smem, tid, NT);
@@ -136,9 +151,179 @@ TMX_KERNEL k_export_csc(const DevProblem* P, const DevBatch* Bt, int b, CscOut o
   const int tid = threadIdx.x, NT = blockDim.x;
   const int R = P->R, D = P->D;
   QpWs cwd;
-  qp_structure(P, Bt->active + (size_t)b * R, Bt->coef + (size_t)b * R * D, Bt->coef2 + (size_t)b * P->n_link * D, Bt->rhs + (size_t)b * R,
-               Bt->x + (size_t)b * P->NX, Bt->trust[b], Bt->merit + (size_t)b * P->n_cnts, dims_out, hashes_out, &out,
-               reinterpret_cast<int*>(smem), tid, NT, Bt->qdyn + (size_t)b * P->NX, compact_lists_of(cwd, P, Bt, b));
+  if (P->qp_dense)
+    qp_structure<true>(P, Bt->active + (size_t)b * R, Bt->coef + (size_t)b * R * D, Bt->coef2 + (size_t)b * P->n_link * D,
+                       Bt->rhs + (size_t)b * R, Bt->x + (size_t)b * P->NX, Bt->trust[b], Bt->merit + (size_t)b * P->n_cnts, dims_out, hashes_out,
+                       &out, reinterpret_cast<int*>(smem), tid, NT, Bt->qdyn + (size_t)b * P->NX, nullptr);
+  else
+    qp_structure(P, Bt->active + (size_t)b * R, Bt->coef + (size_t)b * R * D, Bt->coef2 + (size_t)b * P->n_link * D, Bt->rhs + (size_t)b * R,
+                 Bt->x + (size_t)b * P->NX, Bt->trust[b], Bt->merit + (size_t)b * P->n_cnts, dims_out, hashes_out, &out,
+                 reinterpret_cast<int*>(smem), tid, NT, Bt->qdyn + (size_t)b * P->NX, compact_lists_of(cwd, P, Bt, b));
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Model::optimize() of a problem whose QP is not block tridiagonal (DevProblem::qp_dense: acceleration / jerk terms): the QP of
+// the current convexification and trust box is written in the reference's CSC layout (qp_structure, the same arrays
+// tmx_export_csc hands out) and solved by the dense batched engine (qp_generic_block, tmx_generic.h) under the call protocol of
+// OSQPModel (osqp_interface.cpp:283-370: warm start with the previous x, y, rho when the sparsity is unchanged under the
+// reference's own comparison).  Results land where qp_solve_block leaves them: xq / yq in reference order, the QP record, the
+// polish active-set flags in the per-problem scratch (k_export_active), the position of every row's aux variables (aux_ref).
+// ---------------------------------------------------------------------------------------------------------------------------
+TMX_DEVFN void qp_solve_dense_block(const DevProblem* P, const DevBatch* Bt, int b, double* smem, int tid, int NT)
+{
+  const int R = P->R, D = P->D, NX = P->NX, n_max = P->n_max, m_max = P->m_max;
+  CscOut out;
+  out.P_p = Bt->dq_Pp + (size_t)b * (n_max + 1);
+  out.P_i = Bt->dq_Pi + (size_t)b * (P->nnzP > 0 ? P->nnzP : 1);
+  out.P_x = Bt->dq_Px + (size_t)b * (P->nnzP > 0 ? P->nnzP : 1);
+  out.A_p = Bt->dq_Ap + (size_t)b * (n_max + 1);
+  out.A_i = Bt->dq_Ai + (size_t)b * Bt->dq_nnzA;
+  out.A_x = Bt->dq_Ax + (size_t)b * Bt->dq_nnzA;
+  out.q = Bt->dq_q + (size_t)b * n_max;
+  out.l = Bt->dq_l + (size_t)b * m_max;
+  out.u = Bt->dq_u + (size_t)b * m_max;
+  int* dims = Bt->dims + 4 * b;
+  unsigned long long* hs = Bt->hashes + 4 * b;
+  const int* act = Bt->active + (size_t)b * R;
+  qp_structure<true>(P, act, Bt->coef + (size_t)b * R * D, Bt->coef2 + (size_t)b * P->n_link * D, Bt->rhs + (size_t)b * R,
+                     Bt->x + (size_t)b * NX, Bt->trust[b], Bt->merit + (size_t)b * P->n_cnts, dims, hs, &out, reinterpret_cast<int*>(smem), tid,
+                     NT, Bt->qdyn + (size_t)b * NX, nullptr);
+  // reference positions of rows / aux variables (LDS, layout of qp_structure) -> per-problem scratch
+  QpWs w;
+  double* scratch = Bt->qp_scratch + (size_t)b * Bt->qp_scratch_stride;
+  qp_ws_carve(w, scratch, scratch, scratch, D, P->T, R, P->NA, P->n_link, P->coef_far);  // only the far layout is used
+  {
+    const int* rowref = reinterpret_cast<int*>(smem) + (n_max + 1);
+    const int* auxref = rowref + R;
+    for (int r = tid; r < R; r += NT)
+    {
+      w.row_ref[r] = rowref[r];
+      w.aux_ref[r] = auxref[r];
+    }
+  }
+  TMX_SYNC();
+  const int n = dims[0], m = dims[1], mg = m - n;
+  // warm start decision (createOrUpdateSolver, osqp_interface.cpp:283-370), as in qp_solve_block
+  const int* pd4 = Bt->prev_dims + 4 * b;
+  const unsigned long long* pws = Bt->prev_ws + 2 * b;
+  bool warm = Bt->prev_ok[b] && P->osqp.warm_starting;
+  const bool P_eq = warm && pd4[0] == dims[0] && pd4[2] == dims[2] && pws[0] == hs[2];
+  const bool A_eq = P_eq && pd4[1] == dims[1] && pd4[3] == dims[3] && pws[1] == hs[3];
+  warm = warm && P_eq && A_eq;
+  tmx_osqp_settings st = P->osqp;
+  st.rho = warm ? Bt->prev_rho[b] : st.rho;
+  double* xq = Bt->xq + (size_t)b * n_max;
+  double* yq = Bt->yq + (size_t)b * m_max;
+  double* xw = Bt->dq_xw + (size_t)b * n_max;
+  double* yw = Bt->dq_yw + (size_t)b * m_max;
+  if (warm)
+  {
+    for (int v = tid; v < n; v += NT)
+      xw[v] = xq[v];
+    for (int i = tid; i < m; i += NT)
+      yw[i] = yq[i];
+  }
+  TMX_SYNC();
+  GenQp g;
+  g.n = n;
+  g.m = m;
+  g.oP = g.oA = g.oPp = g.oAp = 0;
+  g.ov_n = g.ov_m = 0;
+  g.ows = 0;
+  g.warm = warm ? 1 : 0;
+  GenData d;
+  d.P_p = out.P_p;
+  d.P_i = out.P_i;
+  d.A_p = out.A_p;
+  d.A_i = out.A_i;
+  d.P_x = out.P_x;
+  d.A_x = out.A_x;
+  d.q = out.q;
+  d.l = out.l;
+  d.u = out.u;
+  d.xw = xw;
+  d.yw = yw;
+  d.x_out = Bt->dq_x + (size_t)b * n_max;
+  d.y_out = Bt->dq_y + (size_t)b * m_max;
+  d.flags_out = Bt->dq_flags + (size_t)b * m_max;
+  d.info = Bt->dq_info + b;
+  d.ws = Bt->dq_ws + (size_t)b * (size_t)Bt->dq_ws_stride;
+  qp_generic_block(g, d, st, smem, tid, NT);
+  TMX_SYNC();
+  const tmx_qp_info info = Bt->dq_info[b];
+  const bool has_sol = !(info.osqp_status == 3 || info.osqp_status == 4 || info.osqp_status == 5 || info.osqp_status == 6 || info.osqp_status == 9);
+  unsigned long long hact = 0ULL;
+  for (int v = tid; v < n; v += NT)
+    xq[v] = d.x_out[v];
+  for (int i = tid; i < m; i += NT)
+  {
+    yq[i] = d.y_out[i];
+    hact += tmx_hash_term((long long)d.flags_out[i], (uint64_t)i, 5);
+  }
+  // active-set flags in the layout k_export_active reads
+  for (int v = tid; v < NX; v += NT)
+    w.flg_bp[v] = d.flags_out[mg + v];
+  for (int r = tid; r < R; r += NT)
+    if (act[r])
+    {
+      w.flg_r[r] = d.flags_out[w.row_ref[r]];
+      for (int k = 0; k < P->slot_naux[r]; ++k)
+        w.flg_ba[P->slot_aoff[r] + k] = d.flags_out[mg + w.aux_ref[r] + k];
+    }
+  unsigned long long* hacc = reinterpret_cast<unsigned long long*>(smem);
+  TMX_SYNC();
+  if (tid == 0)
+    *hacc = 0ULL;
+  TMX_SYNC();
+  TMX_ATOMIC_ADD_U64(hacc, hact);
+  TMX_SYNC();
+  if (tid == 0)
+  {
+    tmx_qp_record rec;
+    rec.n = n;
+    rec.m = m;
+    rec.nnzP = dims[2];
+    rec.nnzA = dims[3];
+    rec.warm_started = warm ? 1 : 0;
+    rec.osqp_status = info.osqp_status;
+    rec.osqp_iter = info.iter;
+    rec.rho_updates = info.rho_updates;
+    rec.polish_status = info.polish_status;
+    rec.pad_ = 0;
+    rec.hashP = hs[0];
+    rec.hashA = hs[1];
+    rec.hash_active = *hacc;
+    rec.rho_final = info.rho_final;
+    Bt->rec_last[b] = rec;
+    const int k = Bt->rec_count[b];
+    if (k < Bt->max_rec)
+      Bt->rec_log[(size_t)b * Bt->max_rec + k] = rec;
+    Bt->rec_count[b] = k + 1;
+    Bt->admm_iters[b] += info.iter;
+    Bt->cvx[b] = (info.osqp_status == 1 || info.osqp_status == 2) ? TMX_CVX_SOLVED : (has_sol ? TMX_CVX_FAILED : TMX_CVX_INFEASIBLE);
+    Bt->prev_ok[b] = (info.osqp_status == 1 || info.osqp_status == 2) ? 1 : 0;
+    Bt->prev_rho[b] = info.rho_final;
+    for (int q = 0; q < 4; ++q)
+      Bt->prev_dims[4 * b + q] = dims[q];
+    Bt->prev_ws[2 * b + 0] = hs[2];
+    Bt->prev_ws[2 * b + 1] = hs[3];
+  }
+  TMX_SYNC();
+}
+
+// K5 for qp_dense problems (piecewise driver: k_convexify -> k_qp_solve_dense -> k_evaluate -> k_sqp_update)
+TMX_KERNEL_LB(256) k_qp_solve_dense(const DevProblem* P, const DevBatch* Bt, int force)
+{
+  TMX_SMEM(smem_lds);
+  double* smem = TMX_WORK(smem_lds, Bt);
+  const int b = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
+  if (!force && Bt->phase[b] == PHASE_DONE)
+    return;
+  qp_solve_dense_block(P, Bt, b, smem, tid, NT);
+  const double* xq = Bt->xq + (size_t)b * P->n_max;
+  double* xn = Bt->xnew + (size_t)b * P->NX;
+  for (int v = tid; v < P->NX; v += NT)
+    xn[v] = xq[v];
 }
 
 // K5: Model::optimize() for every running problem; also publishes new_x = first NX model vars (optimizers.cpp:396)
@@ -170,7 +355,10 @@ TMX_KERNEL k_sqp_update(const DevProblem* P, const DevBatch* Bt)
     return;
   }
 #endif
-  sqp_update_block(P, Bt, b, smem, tid, NT);
+  if (P->qp_dense)
+    sqp_update_block<true>(P, Bt, b, smem, tid, NT);
+  else
+    sqp_update_block(P, Bt, b, smem, tid, NT);
 }
 
 // One trust-region evaluation of problem b: [convexify + QP structure] -> Model::optimize -> exact re-evaluation ->
@@ -492,7 +680,12 @@ TMX_KERNEL k_model_values(const DevProblem* P, const DevBatch* Bt, const double*
     sqp2_model_values(P, Bt, b, xq + (size_t)b * P->n_max, smem, tid, NT);
   else
 #endif
-    sqp_model_values(P, Bt, b, xq + (size_t)b * P->n_max, smem, tid, NT);
+  {
+    if (P->qp_dense)
+      sqp_model_values<true>(P, Bt, b, xq + (size_t)b * P->n_max, smem, tid, NT);
+    else
+      sqp_model_values(P, Bt, b, xq + (size_t)b * P->n_max, smem, tid, NT);
+  }
   for (int k = tid; k < P->n_costs; k += NT)
     out_cost[(size_t)b * P->n_costs + k] = smem[k];
   for (int k = tid; k < P->n_cnts; k += NT)

@@ -46,6 +46,10 @@ struct CscOut
   double *P_x, *q, *A_x, *l, *u;
 };
 
+// ST: the problem may hold difference rows of order 2 / 3 (entries on waypoints t + 2, t + 3: diff_row_coef) and the banded
+// objective of the acceleration / jerk costs (DevProblem::po2 / po3).  The ST = false instantiation is the code of the
+// block-tridiagonal problems, unchanged.
+template <bool ST = false>
 TMX_DEVFN void qp_structure(const DevProblem* P, const int* active, const double* coef, const double* coef2, const double* rhs,
                             const double* xcur, double trust, const double* merit, int* dims, unsigned long long* hashes,
                             const CscOut* out, int* iscratch, int tid, int NT, const double* qdyn = nullptr, QpWs* cw = nullptr)
@@ -144,6 +148,15 @@ TMX_DEVFN void qp_structure(const DevProblem* P, const int* active, const double
           ++c;
       }
 #endif
+    if constexpr (ST)
+      for (int back = 2; back <= 3; ++back)  // rows of order >= back at waypoint t - back, same joint
+        if (P->n_stencil > 0 && t >= back)
+          for (int q = wls[t - back]; q < wls[t - back + 1]; ++q)
+          {
+            const int r = wll[q];
+            if (lact[r] && slot_is_diff(P->slot_kind[r]) && P->slot_sub3[r] >= back && P->slot_sub[r] == j && diff_row_coef(P, r, back) != 0.0)
+              ++c;
+          }
     ccount[v] = c;
   }
   for (int rq = tid; rq < n_it; rq += NT)
@@ -199,6 +212,25 @@ TMX_DEVFN void qp_structure(const DevProblem* P, const int* active, const double
         ++ql;
     };
     next_link();
+    // cursors over the rows of waypoints t-2 / t-3 with an entry on this variable (ST only)
+    int qf[2] = { 0, 0 }, qf_end[2] = { 0, 0 };
+    auto far_hit = [&](int qq, int back) -> bool {
+      const int rr = wll[qq];
+      return active[rr] && slot_is_diff(P->slot_kind[rr]) && P->slot_sub3[rr] >= back && P->slot_sub[rr] == j && diff_row_coef(P, rr, back) != 0.0;
+    };
+    auto next_far = [&](int back) {
+      while (qf[back - 2] < qf_end[back - 2] && !far_hit(qf[back - 2], back))
+        ++qf[back - 2];
+    };
+    if constexpr (ST)
+      for (int back = 2; back <= 3; ++back)
+        if (P->n_stencil > 0 && t >= back)
+        {
+          qf[back - 2] = wls[t - back];
+          qf_end[back - 2] = wls[t - back + 1];
+          next_far(back);
+        }
+    (void)qf_end;
 #endif
     for (int q = wls[t]; q <= wls[t + 1]; ++q)
     {
@@ -218,6 +250,51 @@ TMX_DEVFN void qp_structure(const DevProblem* P, const int* active, const double
         val = 1.0;
       }
 #if TMX_LINK_ROWS
+      if constexpr (ST)
+      {
+        // entries of the rows of waypoints t-1 (coef2), t-2 and t-3 (difference rows of order 2 / 3) in front of row `ri`, merged
+        // by ascending reference row index (every per-waypoint list is ascending)
+        while (true)
+        {
+          int best = -1;
+          long long rbest = ri;
+          if (ql < ql_end && rowref[wll[ql]] < rbest)
+          {
+            best = 1;
+            rbest = rowref[wll[ql]];
+          }
+          for (int back = 2; back <= 3; ++back)
+            if (qf[back - 2] < qf_end[back - 2] && rowref[wll[qf[back - 2]]] < rbest)
+            {
+              best = back;
+              rbest = rowref[wll[qf[back - 2]]];
+            }
+          if (best < 0)
+            break;
+          hA += tmx_hash_term(rbest, (uint64_t)pos, 4);
+          if (pos < ri_full)
+            wsA += tmx_hash_term(rbest, (uint64_t)pos, 14);
+          else if (pos == ri_full && ri_rem > 0)
+            wsA += tmx_hash_term((long long)((unsigned long long)rbest & ((1ULL << (8 * ri_rem)) - 1ULL)), (uint64_t)pos, 14);
+          if (out)
+          {
+            out->A_i[pos] = rbest;
+            out->A_x[pos] = (best == 1) ? link_val(ql) : diff_row_coef(P, wll[qf[best - 2]], best);
+          }
+          ++pos;
+          if (best == 1)
+          {
+            ++ql;
+            next_link();
+          }
+          else
+          {
+            ++qf[best - 2];
+            next_far(best);
+          }
+        }
+      }
+      else
       while (ql < ql_end && rowref[wll[ql]] < ri)
       {
         const long long rl = rowref[wll[ql]];
@@ -294,6 +371,26 @@ TMX_DEVFN void qp_structure(const DevProblem* P, const int* active, const double
       if (c < NX)
       {
         const int t = c / D;
+        if constexpr (ST)
+          for (int back = 3; back >= 2; --back)  // (c - 3D, c), (c - 2D, c): couplings of the jerk / acceleration costs
+          {
+            const double* pb = (back == 3) ? P->po3 : P->po2;
+            if (t >= back && pb[c - back * D] != 0.0)
+            {
+              const int row = c - back * D;
+              hP += tmx_hash_term(row, (uint64_t)run, 2);
+              if (run < pi_full)
+                wsP += tmx_hash_term(row, (uint64_t)run, 12);
+              else if (run == pi_full && pi_rem > 0)
+                wsP += tmx_hash_term((long long)((unsigned long long)row & ((1ULL << (8 * pi_rem)) - 1ULL)), (uint64_t)run, 12);
+              if (out)
+              {
+                out->P_i[run] = row;
+                out->P_x[run] = pb[row];
+              }
+              ++run;
+            }
+          }
         if (t > 0 && P->po[c - D] != 0.0)
         {
           hP += tmx_hash_term(c - D, (uint64_t)run, 2);
@@ -1822,6 +1919,7 @@ TMX_DEVFN void sqp_time_limit_check(const DevProblem* P, const DevBatch* Bt, int
 // constraint of the current convexification (BasicTrustRegionSQP::evaluateModelCosts / evaluateModelCntViols,
 // optimizers.hpp:176-178; ::update optimizers.cpp:391-396), in parallel: per-slot values and velocity terms by all threads, then
 // one thread per owner sums its slots in slot order.  Results: smem[0 .. n_costs) costs, smem[n_costs .. n_costs + n_cnts) violations.
+template <bool ST = false>
 TMX_DEVFN void sqp_model_values(const DevProblem* P, const DevBatch* Bt, int b, const double* xq, double* smem, int tid, int NT)
 {
   const int D = P->D, NX = P->NX, R = P->R;
@@ -1858,6 +1956,10 @@ TMX_DEVFN void sqp_model_values(const DevProblem* P, const DevBatch* Bt, int b, 
               aff += c2r[j] * xq[(t + 1) * D + j];
           }
 #endif
+          if constexpr (ST)
+            if (slot_is_diff(P->slot_kind[r]))
+              for (int k = 2; k <= P->slot_sub3[r]; ++k)
+                aff += diff_row_coef(P, r, k) * xq[(t + k) * D + P->slot_sub[r]];
           aff -= rhs[r];
           vr = P->slot_eq[r] ? fabs(aff) : ((aff > 0) ? aff : 0.0);
           key = P->n_costs + P->slot_owner[r];
@@ -1877,19 +1979,20 @@ TMX_DEVFN void sqp_model_values(const DevProblem* P, const DevBatch* Bt, int b, 
     }
     for (int v = 0; v < P->n_vel; ++v)
     {
-      const int pk = P->vel_kind[v];  // 0: difference of consecutive steps (JointVelEqCost), 1: position (JointPosEqCost)
-      const int first = P->vel_first[v], len = P->vel_last[v] - first + pk;
+      const int pk = P->vel_kind[v];  // 0: difference of consecutive steps (JointVelEqCost), 1: position (JointPosEqCost); ST: 2 / 3
+      const int first = P->vel_first[v], len = P->vel_last[v] - first + vel_len_adj<ST>(pk);
       for (int e = tid; e < D * len; e += NT)
       {
         const int j = e / len, i = first + e % len;
-        const double d = (pk ? xq[i * D + j] : (xq[(i + 1) * D + j] - xq[i * D + j])) - P->vel_targets[v * TMX_MAX_DOF + j];
+        const double dv = (ST && pk >= 2) ? diff_value(xq, D, i, j, pk) : (pk ? xq[i * D + j] : (xq[(i + 1) * D + j] - xq[i * D + j]));
+        const double d = dv - P->vel_targets[v * TMX_MAX_DOF + j];
         vterm[(size_t)v * NX + e] = (d * d) * P->vel_coeffs[v * TMX_MAX_DOF + j];
       }
     }
     TMX_SYNC();
     for (int v = tid; v < P->n_vel; v += NT)
     {
-      const int cnt = D * (P->vel_last[v] - P->vel_first[v] + P->vel_kind[v]);
+      const int cnt = D * (P->vel_last[v] - P->vel_first[v] + vel_len_adj<ST>(P->vel_kind[v]));
       double sacc = 0;
       for (int e = 0; e < cnt; ++e)
         sacc += vterm[(size_t)v * NX + e];
@@ -1917,6 +2020,7 @@ TMX_DEVFN void sqp_model_values(const DevProblem* P, const DevBatch* Bt, int b, 
 }
 
 TMX_DEVFN void sqp_decide(const DevProblem* P, const DevBatch* Bt, int b, const double* model_cost, const double* model_viol);
+template <bool ST = false>
 TMX_DEVFN void sqp_update_block(const DevProblem* P, const DevBatch* Bt, int b, double* smem, int tid, int NT)
 {
   const int NX = P->NX;
@@ -1929,7 +2033,7 @@ TMX_DEVFN void sqp_update_block(const DevProblem* P, const DevBatch* Bt, int b, 
   // ---- model values at the QP solution
   const bool solved = Bt->cvx[b] == TMX_CVX_SOLVED && Bt->phase[b] != PHASE_DONE;
   if (solved)
-    sqp_model_values(P, Bt, b, Bt->xq + (size_t)b * P->n_max, smem, tid, NT);
+    sqp_model_values<ST>(P, Bt, b, Bt->xq + (size_t)b * P->n_max, smem, tid, NT);
   // the decisions are serial per problem (O(terms)): thread 0; an accepted point is then copied by the whole workgroup
   if (tid == 0)
   {

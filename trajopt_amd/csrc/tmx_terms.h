@@ -441,6 +441,45 @@ TMX_DEVFN void lvs_end_gradient(const DevProblem* P, const double* q, int s, con
   sconst = scale * -gq;
 }
 
+// number of entries per joint of a squared joint cost minus (last_step - first_step): position 1, velocity 0, acc -1, jerk -2
+template <bool ST>
+TMX_DEVFN int vel_len_adj(int pk)
+{
+  return (ST && pk >= 2) ? 1 - pk : pk;
+}
+// ---- finite-difference rows of order 2 / 3 (JointAcc / JointJerk, trajectory_costs.cpp:502-1016) ------------------------
+// order of a SLOT_JOINTVEL / SLOT_JOINTVEL_INEQ row: 1 (velocity: x[t], x[t+1]) unless slot_sub3 says 2 or 3
+TMX_DEVFN int diff_row_order(const DevProblem* P, int r) { return P->slot_sub3[r] >= 2 ? P->slot_sub3[r] : 1; }
+// stencil entry k of the order's difference expression as the reference writes it (:277-279, :522-525, :775-779)
+TMX_DEVFN double diff_stencil(int ord, int k)
+{
+  if (ord == 1)
+    return k == 0 ? -1.0 : 1.0;
+  if (ord == 2)
+    return k == 1 ? -2.0 : 1.0;
+  return (k == 0) ? -1.0 : (k == 1) ? 3.0 : (k == 2) ? -3.0 : 1.0;
+}
+// coefficient of row r on x[t + k][j]: exprMult(diff, coeff) (EQ), (upper_tol - diff) * -coeff, (lower_tol - diff) * coeff
+TMX_DEVFN double diff_row_coef(const DevProblem* P, int r, int k)
+{
+  const double s = diff_stencil(diff_row_order(P, r), k), c = P->slot_scale[r];
+  if (P->slot_kind[r] == SLOT_JOINTVEL)
+    return (1.0 * s) * c;
+  return (P->slot_sub2[r] == 0) ? (0.0 - (1.0 * s)) * -c : (0.0 - (1.0 * s)) * c;
+}
+// entry (i, j) of diffAxis0 applied `ord` times (trajectory_costs.cpp:17-20): differences of differences, in that order
+TMX_DEVFN double diff_value(const double* xv, int D, int i, int j, int ord)
+{
+  const double d0 = xv[(i + 1) * D + j] - xv[i * D + j];
+  if (ord == 1)
+    return d0;
+  const double d1 = xv[(i + 2) * D + j] - xv[(i + 1) * D + j];
+  if (ord == 2)
+    return d1 - d0;
+  const double d2 = xv[(i + 3) * D + j] - xv[(i + 2) * D + j];
+  return (d2 - d1) - (d1 - d0);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // K6: exact costs / constraint violations at trajectory xv -> cost_out[n_costs], viol_out[n_cnts]
 // (BasicTrustRegionSQP::evaluateCosts / evaluateConstraintViols, trajopt_sco/src/optimizers.cpp:176-192)
@@ -451,6 +490,8 @@ TMX_HOSTDEVFN size_t tmx_eval_scratch_doubles(int R, int NX, int n_vel, int n_co
 {
   return (size_t)R + (size_t)(R + 1) / 2 + (size_t)n_vel * NX + (size_t)n_vel + (size_t)n_costs + (size_t)n_cnts + 16;
 }
+// ST: the problem may hold rows / costs of difference order 2 and 3 (DevProblem::n_stencil, vel_kind 2 / 3)
+template <bool ST = false>
 TMX_DEVFN void evaluate_terms(const DevProblem* P, const double* xv, double* cost_out, double* viol_out, double* scratch,
                               int tid, int NT)
 {
@@ -505,14 +546,14 @@ TMX_DEVFN void evaluate_terms(const DevProblem* P, const double* xv, double* cos
     {
       // JointVelEqConstraint::value: coeff * diff^2 as well (trajectory_costs.cpp:403-413)
       const int j = P->slot_sub[r];
-      const double d = (xv[(t + 1) * D + j] - xv[t * D + j]) - P->slot_aux1[r];
+      const double d = (ST ? diff_value(xv, D, t, j, diff_row_order(P, r)) : (xv[(t + 1) * D + j] - xv[t * D + j])) - P->slot_aux1[r];
       v = fabs((d * d) * P->slot_scale[r]);
     }
     else if (kind == SLOT_JOINTVEL_INEQ)
     {
       // JointVelIneqCost::value / JointVelIneqConstraint::value (trajectory_costs.cpp:349-361, 472-487)
       const int j = P->slot_sub[r];
-      const double d0 = (xv[(t + 1) * D + j] - xv[t * D + j]) - P->slot_aux1[r];
+      const double d0 = (ST ? diff_value(xv, D, t, j, diff_row_order(P, r)) : (xv[(t + 1) * D + j] - xv[t * D + j])) - P->slot_aux1[r];
       const double e = (P->slot_sub2[r] == 0) ? (d0 - P->slot_aux2[r]) * P->slot_scale[r] : ((d0 * -1) + P->slot_aux2[r]) * P->slot_scale[r];
       v = (e > 0) ? e : 0.0;
     }
@@ -560,21 +601,24 @@ TMX_DEVFN void evaluate_terms(const DevProblem* P, const double* xv, double* cos
   double* vsum = vterm + (size_t)P->n_vel * P->NX;
   for (int v = 0; v < P->n_vel; ++v)
   {
-    const int pk = P->vel_kind[v];  // 0: difference of consecutive steps (JointVelEqCost), 1: position (JointPosEqCost)
-    const int first = P->vel_first[v], len = P->vel_last[v] - first + pk;
+    // 0: difference of consecutive steps (JointVelEqCost), 1: position (JointPosEqCost); ST: 2 / 3 = second / third difference
+    // (JointAccEqCost / JointJerkEqCost, trajectory_costs.cpp:532-545, :786-801)
+    const int pk = P->vel_kind[v];
+    const int first = P->vel_first[v], len = P->vel_last[v] - first + vel_len_adj<ST>(pk);
     for (int e = tid; e < D * len; e += NT)
     {
       // summation order: the reference's column-major Eigen array (joint-major) for trajopt_sco; row order of the constraint
       // set (segment-major) for the trajopt_sqp flavour (getExactCosts, trajopt_qp_problem.cpp:986-1001)
       const int j = (P->flavor == 1) ? e % D : e / len, i = first + ((P->flavor == 1) ? e / D : e % len);
-      const double d = (pk ? xv[i * D + j] : (xv[(i + 1) * D + j] - xv[i * D + j])) - P->vel_targets[v * TMX_MAX_DOF + j];
+      const double dv = (ST && pk >= 2) ? diff_value(xv, D, i, j, pk) : (pk ? xv[i * D + j] : (xv[(i + 1) * D + j] - xv[i * D + j]));
+      const double d = dv - P->vel_targets[v * TMX_MAX_DOF + j];
       vterm[(size_t)v * P->NX + e] = (d * d) * P->vel_coeffs[v * TMX_MAX_DOF + j];
     }
   }
   TMX_SYNC();
   for (int v = tid; v < P->n_vel; v += NT)
   {
-    const int cnt = D * (P->vel_last[v] - P->vel_first[v] + P->vel_kind[v]);
+    const int cnt = D * (P->vel_last[v] - P->vel_first[v] + vel_len_adj<ST>(P->vel_kind[v]));
     double sacc = 0;
     for (int e = 0; e < cnt; ++e)
       sacc += vterm[(size_t)v * P->NX + e];
@@ -644,6 +688,13 @@ TMX_DEVFN void init_static_rows(const DevProblem* P, const double* x0, int* acti
         coef[r * D + j] = (0.0 - (1.0 * -1)) * c;
         c2r[j] = (0.0 - (1.0 * 1)) * c;
         rhs[r] = -((tol - (0.0 - targ)) * c);
+      }
+      if (P->slot_sub3[r] >= 2)
+      {
+        // acceleration / jerk rows: the same three forms over the longer stencil; the coefficients beyond waypoint t + 1 are
+        // not stored (diff_row_coef)
+        coef[r * D + j] = diff_row_coef(P, r, 0);
+        c2r[j] = diff_row_coef(P, r, 1);
       }
       active[r] = 1;
       continue;

@@ -83,7 +83,16 @@ struct DevProblem
   int lvs_kmax;       // sub-state capacity of the LVS evaluators (tmx_term.max_substates)
   int flavor;         // tmx_flavor: 0 trajopt_sco (BasicTrustRegionSQP / OSQPModel), 1 trajopt_sqp (TrajOptQPProblem / TrustRegionSQPSolver)
   int n_sq;           // flavour 1: number of squared cost sets (their exact / model costs come first in cost_vals)
+  // STENCIL ROWS / BANDED OBJECTIVE (JointAcc / JointJerk terms, trajectory_costs.cpp:502-1016).  SLOT_JOINTVEL(_INEQ) rows with
+  // slot_sub3[r] = order 2 | 3 carry, besides the home coefficient (coef) and the one on waypoint t + 1 (coef2), the fixed
+  // coefficients diff_row_coef(P, r, k) on x[t + k][j], k = 2 .. order; the squared costs couple x[t][j] with x[t + 2][j]
+  // (po2) and x[t + 3][j] (po3).  Such a QP is not block tridiagonal: qp_dense = 1 routes every Model::optimize() of the
+  // problem to the dense batched engine (qp_solve_dense_block, tmx_generic.h) instead of the block-chain solvers.
+  double *po2, *po3;  // NX each (zero where absent)
+  int n_stencil;      // number of rows of order >= 2
+  int qp_dense;
 };
+TMX_HOSTDEVFN int slot_is_diff(int kind) { return kind == SLOT_JOINTVEL || kind == SLOT_JOINTVEL_INEQ; }
 
 struct DevBatch
 {
@@ -123,6 +132,16 @@ struct DevBatch
   int step_log_stride;
   int *accept_flag;    // B: the decision step accepted new_x (thread 0 -> the workgroup's parallel copy of the accepted point)
   long long *t_start;  // 1: constant-rate clock (100 MHz ticks) at the start of optimize(): reference point of sqp.max_time
+  // dense engine (DevProblem::qp_dense): per problem the QP in the reference's CSC layout (written by qp_structure), the
+  // engine's outputs and its dense workspace
+  long long *dq_Pp, *dq_Pi, *dq_Ap, *dq_Ai;   // B x (n_max + 1), B x nnzP, B x (n_max + 1), B x dq_nnzA
+  double *dq_Px, *dq_Ax, *dq_q, *dq_l, *dq_u;  // B x nnzP, B x dq_nnzA, B x n_max, B x m_max, B x m_max
+  double *dq_x, *dq_y, *dq_xw, *dq_yw;         // B x n_max, B x m_max (solution / warm start in reference order)
+  int *dq_flags;                               // B x m_max: polish active-set flags of the rows
+  double *dq_ws;                               // B x dq_ws_stride doubles
+  long long dq_ws_stride;
+  int dq_nnzA;                                 // capacity of A per problem
+  tmx_qp_info* dq_info;                        // B
 };
 
 // The ADMM loop of the dense fast path as separately compiled device functions (tmx_solve.h: qp_admm_fast_nl /

@@ -17,7 +17,8 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import numpy as np
 
 from . import abi
-from .problem import (BasicInfo, CartPoseTermInfo, CartVelTermInfo, CollisionTermInfo, JointPosTermInfo, JointVelTermInfo,
+from .problem import (BasicInfo, CartPoseTermInfo, CartVelTermInfo, CollisionTermInfo, JointAccTermInfo, JointJerkTermInfo, JointPosTermInfo,
+                      JointVelTermInfo,
                       ProblemConstructionInfo, Robot, _tf12)
 
 
@@ -139,6 +140,14 @@ def construct_problem(text_or_dict, env: Environment) -> ParsedProblem:
                                     first_step=int(p.get("first_step", 0)), last_step=int(p.get("last_step", n_steps - 1)), name=name,
                                     upper_tols=_vec(p, "upper_tols", D, [0.0] * D), lower_tols=_vec(p, "lower_tols", D, [0.0] * D),
                                     is_constraint=not is_cost)
+        if typ in ("joint_acc", "joint_jerk"):
+            # JointAccTermInfo::fromJson / JointJerkTermInfo::fromJson (problem_description.cpp:1374-1391, :1495-1513): the fields
+            # of joint_vel; hatch -> the Eq / Ineq cost / constraint classes over the second / third difference
+            _only_members(p, ("coeffs", "first_step", "last_step", "targets", "lower_tols", "upper_tols", "use_time"), typ)
+            cls = JointAccTermInfo if typ == "joint_acc" else JointJerkTermInfo
+            return cls(coeffs=_vec(p, "coeffs", D, [1.0] * D), targets=_vec(p, "targets", D), first_step=int(p.get("first_step", 0)),
+                       last_step=int(p.get("last_step", n_steps - 1)), name=name, upper_tols=_vec(p, "upper_tols", D, [0.0] * D),
+                       lower_tols=_vec(p, "lower_tols", D, [0.0] * D), is_constraint=not is_cost)
         if typ == "joint_pos":
             _only_members(p, ("coeffs", "first_step", "last_step", "targets", "lower_tols", "upper_tols"), typ)
             return JointPosTermInfo(coeffs=_vec(p, "coeffs", D, [1.0] * D), targets=_vec(p, "targets", D),

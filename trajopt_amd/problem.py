@@ -137,6 +137,22 @@ class JointVelTermInfo:
 
 
 @dataclass
+class JointAccTermInfo(JointVelTermInfo):
+    """trajopt::JointAccTermInfo — hatch (problem_description.cpp:1393-1493): the four classes of the velocity family over
+    acc = x[i] - 2 x[i+1] + x[i+2] (trajectory_costs.cpp:502-754); three steps are needed for one acceleration"""
+    name: str = "joint_acc"
+    ORDER = 2
+
+
+@dataclass
+class JointJerkTermInfo(JointVelTermInfo):
+    """trajopt::JointJerkTermInfo — hatch (problem_description.cpp:1515-1615): jerk = -x[i] + 3 x[i+1] - 3 x[i+2] + x[i+3]
+    (trajectory_costs.cpp:756-1016)"""
+    name: str = "joint_jerk"
+    ORDER = 3
+
+
+@dataclass
 class JointPosTermInfo:
     """trajopt::JointPosTermInfo (constraint form), problem_description.cpp:1059-1176: hatch -> JointPosEqConstraint when
     all tolerances are zero (doubleEquals, eps 1e-5), else JointPosIneqConstraint (trajectory_costs.cpp:185-255)"""
@@ -276,21 +292,24 @@ class ProblemConstructionInfo:
                 if len(up) != D or len(lo) != D:
                     raise ValueError("JointVelTermInfo upper_tols / lower_tols have the wrong size")
                 zero = all(abs(x) < 1e-5 for x in up) and all(abs(x) < 1e-5 for x in lo)   # trajopt_common::doubleEquals
-                if ti.is_constraint:
-                    t.kind = abi.TERM_JOINT_VEL_EQ_CNT if zero else abi.TERM_JOINT_VEL_INEQ_CNT
-                else:
-                    t.kind = abi.TERM_JOINT_VEL_COST if zero else abi.TERM_JOINT_VEL_INEQ_COST
+                order = getattr(ti, "ORDER", 1)
+                kinds = {1: (abi.TERM_JOINT_VEL_COST, abi.TERM_JOINT_VEL_INEQ_COST, abi.TERM_JOINT_VEL_EQ_CNT, abi.TERM_JOINT_VEL_INEQ_CNT),
+                         2: (abi.TERM_JOINT_ACC_EQ_COST, abi.TERM_JOINT_ACC_INEQ_COST, abi.TERM_JOINT_ACC_EQ_CNT, abi.TERM_JOINT_ACC_INEQ_CNT),
+                         3: (abi.TERM_JOINT_JERK_EQ_COST, abi.TERM_JOINT_JERK_INEQ_COST, abi.TERM_JOINT_JERK_EQ_CNT,
+                             abi.TERM_JOINT_JERK_INEQ_CNT)}[order]
+                t.kind = kinds[(2 if ti.is_constraint else 0) + (0 if zero else 1)]
                 t.is_constraint = 1 if ti.is_constraint else 0
                 t.upper_tols[:D] = up
                 t.lower_tols[:D] = lo
-                # step handling of JointVelTermInfo::hatch (:1212-1226): a velocity needs two steps
+                # step handling of JointVelTermInfo::hatch (:1212-1226; acc :1407-1421, jerk :1529-1543): a velocity needs two
+                # steps, an acceleration three, a jerk four - and a single-step jerk term gets last_step += 4 (sic, :1535)
                 first, last = ti.first_step, (ti.last_step if ti.last_step >= 0 else T - 1)
-                if (T - 2) <= first:
-                    first = T - 2
+                if (T - 1 - order) <= first:
+                    first = T - 1 - order
                 if (T - 1) <= last:
                     last = T - 1
                 if last == first:
-                    last += 1
+                    last += {1: 1, 2: 2, 3: 4}[order]
                 if last < first:
                     first, last = last, first
                 t.first_step, t.last_step = first, last
