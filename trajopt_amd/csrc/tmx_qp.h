@@ -189,6 +189,7 @@ struct QpWs
   // both rebuilt after every chain inversion; yb = S_t^-1 v_t of all blocks (one parallel pass between the two sweeps)
   double *Mf, *Nb, *yb;
   int n_link;      // R2
+  bool sweep_regs; // the dense-coupling chain sweeps keep their running vector in registers (set by qp_admm_generic_nl<., true> only)
 #endif
 };
 
@@ -476,6 +477,7 @@ TMX_DEVFN void qp_ws_carve(QpWs& w, double* lds, double* glb, double* far, int D
   w.c2 = w.Cd = w.Mf = w.Nb = w.yb = nullptr;
   w.c2i = nullptr;
   w.n_link = R2;
+  w.sweep_regs = false;
   if (R2 > 0)
   {
     if (!cf)
@@ -1555,6 +1557,141 @@ TMX_DEVFN void admm_phase_b(const QpWs& w, const DevProblem* P, int tid, int NT)
   TMX_SYNC();
 }
 
+#if TMX_IS_DEVICE && TMX_LINK_ROWS
+// ---- one wave walks the sweeps of the dense-coupling chain ---------------------------------------------------------------
+// v_t = b_t - Mf_{t-1} v_{t-1} (forward) and x_t = y_t - Nb_t x_{t+1} (backward): 2 (T - 1) dependent D x D mat-vecs.  Lane i < D
+// owns component i of the running vector and keeps it in a REGISTER; the D-term dot reads the other components with
+// v_readlane (no LDS round trip, no fence per block) and the matrix row / right-hand side of the NEXT block are loaded while
+// the current one is summed (they do not depend on the chain).  Products and the order of the additions are those of the
+// loop `acc = 0; for j: acc += M[j] * v[j]`: results are bit-identical to the LDS-exchange walk this replaces (which paid a
+// load + s_waitcnt per term: ~1 k cycles per block, 60 % of the iteration of configs 3 / 4).
+TMX_DEVFN double tmx_readlane_d(double v, int lane)
+{
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+// the chain arrays live either in LDS or in the HBM workspace; typed pointers keep the loads ds_read_b64 / global_load (a
+// flat access merged to 16 bytes faults on an 8-byte aligned LDS address)
+typedef __attribute__((address_space(3))) const double tmx_clds_d;
+typedef __attribute__((address_space(1))) const double tmx_cglb_d;
+template <int DC, class MP>
+TMX_DEVFN void chain_row_load(MP row, int D, double (&m)[16])
+{
+#pragma unroll
+  for (int j = 0; j < 16; ++j)
+    m[j] = (j < (DC ? DC : D)) ? row[j] : 0.0;
+}
+template <int DC>
+TMX_DEVFN double chain_row_dot(const double (&m)[16], double v, int D)
+{
+  double acc = 0.0;
+#pragma unroll
+  for (int j = 0; j < 16; ++j)
+    if (j < (DC ? DC : D))
+      acc += m[j] * tmx_readlane_d(v, j);
+  return acc;
+}
+// forward (dir = +1: rows of Mf, tp updated in place) or backward (dir = -1: rows of Nb, tp = yb - ...) sweep by lanes 0 .. 63 of
+// one wave; MP / VP: pointer types of the matrix array and of the vectors (tp, yb)
+template <int DC, class MP, class VP, class VW>
+TMX_DEVFN void chain_wave_sweep(MP mat, VP rhs, VW out, int D_in, int t0, int t1, int dir, int lane)
+{
+  const int D = DC ? DC : D_in, DD = D * D;
+  const bool live = lane < D;
+  const int i = live ? lane : 0;
+  if (t1 <= t0)
+  {
+    if (dir < 0 && live)
+      out[t1 * D + i] = rhs[t1 * D + i];
+    return;
+  }
+  double m[16], mn[16];
+  double v, bn;
+  if (dir > 0)
+  {
+    v = rhs[t0 * D + i];                 // v_{t0} = b_{t0}
+    chain_row_load<DC>(mat + (size_t)t0 * DD + i * D, D, m);
+    bn = rhs[(t0 + 1) * D + i];
+    for (int t = t0 + 1; t <= t1; ++t)
+    {
+      const bool more = t < t1;
+      const int tn = more ? t : t - 1;   // (clamped prefetch: the last pass reloads a valid row)
+      chain_row_load<DC>(mat + (size_t)tn * DD + i * D, D, mn);
+      const double bnn = rhs[(tn + 1) * D + i];
+      const double acc = chain_row_dot<DC>(m, v, D);
+      v = bn - acc;
+      if (live)
+        out[t * D + i] = v;
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        m[j] = mn[j];
+      bn = bnn;
+    }
+  }
+  else
+  {
+    v = rhs[t1 * D + i];                 // x_{t1} = y_{t1}
+    if (live)
+      out[t1 * D + i] = v;
+    chain_row_load<DC>(mat + (size_t)(t1 - 1) * DD + i * D, D, m);
+    bn = rhs[(t1 - 1) * D + i];
+    for (int t = t1 - 1; t >= t0; --t)
+    {
+      const bool more = t > t0;
+      const int tn = more ? t - 1 : t;
+      chain_row_load<DC>(mat + (size_t)tn * DD + i * D, D, mn);
+      const double bnn = rhs[tn * D + i];
+      const double acc = chain_row_dot<DC>(m, v, D);
+      v = bn - acc;
+      if (live)
+        out[t * D + i] = v;
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        m[j] = mn[j];
+      bn = bnn;
+    }
+  }
+}
+// dispatch on the block size (compile-time trip counts for the common ones) and on the address space of the chain arrays
+template <class MP, class VP, class VW>
+TMX_DEVFN void chain_wave_sweep_d(MP mat, VP rhs, VW out, int D, int t0, int t1, int dir, int lane)
+{
+  if (D == 7)
+    chain_wave_sweep<7>(mat, rhs, out, D, t0, t1, dir, lane);
+  else if (D == 10)
+    chain_wave_sweep<10>(mat, rhs, out, D, t0, t1, dir, lane);
+  else
+    chain_wave_sweep<0>(mat, rhs, out, D, t0, t1, dir, lane);
+}
+TMX_DEVFN bool tmx_in_lds(const void* p)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_is_shared(p);
+#else
+  (void)p;
+  return false;  // (host pass of hipcc: never executed)
+#endif
+}
+// (out of line: the sweep's 32 matrix registers stay out of the register allocation of the iteration loop around it - inlined, the
+//  512-thread HBM kernels of a problem WITHOUT pair rows, config 2, lost 16 %)
+__device__ __attribute__((noinline)) static void chain_wave_sweep_any(const double* mat, const double* rhs, double* out, int D, int t0, int t1,
+                                                                      int dir, int lane)
+{
+  typedef __attribute__((address_space(3))) double lds_w;
+  typedef __attribute__((address_space(1))) double glb_w;
+  const bool ml = tmx_in_lds(mat), vl = tmx_in_lds(rhs) && tmx_in_lds(out);
+  if (ml && vl)
+    chain_wave_sweep_d((tmx_clds_d*)mat, (tmx_clds_d*)rhs, (lds_w*)out, D, t0, t1, dir, lane);
+  else if (!ml && vl)
+    chain_wave_sweep_d((tmx_cglb_d*)mat, (tmx_clds_d*)rhs, (lds_w*)out, D, t0, t1, dir, lane);
+  else if (!ml && !tmx_in_lds(rhs) && !tmx_in_lds(out))
+    chain_wave_sweep_d((tmx_cglb_d*)mat, (tmx_cglb_d*)rhs, (glb_w*)out, D, t0, t1, dir, lane);
+  else
+    chain_wave_sweep_d(mat, rhs, out, D, t0, t1, dir, lane);   // mixed placement: generic pointers
+}
+#endif
+
 // Block forward/backward substitution over blocks [t0, t1] in place on w.tp (generic, any NT):
 //   v_t = b_t - c_t o (Sinv_{t-1} v_{t-1}),   x_t = Sinv_t (v_t - c_{t+1} o x_{t+1});  the chain restarts at t0 / t1.
 TMX_DEVFN void chain_solve_range(const QpWs& w, int t0, int t1, int tid, int NT)
@@ -1574,8 +1711,15 @@ TMX_DEVFN void chain_solve_range(const QpWs& w, int t0, int t1, int tid, int NT)
     if (wave_walk)
     {
 #if TMX_IS_DEVICE
-      // one wave walks the sweep with wave-synchronous exchange: no workgroup barrier per block
-      if (tid < 64)
+      // one wave walks the sweep: the running vector in registers (chain_wave_sweep, no barrier and no LDS exchange per block) in
+      // the ADMM loop of pair-row problems (w.sweep_regs, a compile-time constant after inlining); the few solves outside that
+      // loop (polish, first factorisation) keep the LDS-exchange walk, so the kernels' own code is what it was
+      if (w.sweep_regs)
+      {
+        if (tid < 64)
+          chain_wave_sweep_any(w.Mf, w.tp, w.tp, D, t0, t1, +1, tid);
+      }
+      else if (tid < 64)
       {
         const int i = tid < D ? tid : 0;
         const bool live = tid < D;
@@ -1622,7 +1766,12 @@ TMX_DEVFN void chain_solve_range(const QpWs& w, int t0, int t1, int tid, int NT)
     if (wave_walk)
     {
 #if TMX_IS_DEVICE
-      if (tid < 64)
+      if (w.sweep_regs)
+      {
+        if (tid < 64)
+          chain_wave_sweep_any(w.Nb, w.yb, w.tp, D, t0, t1, -1, tid);
+      }
+      else if (tid < 64)
       {
         const int i = tid < D ? tid : 0;
         const bool live = tid < D;

@@ -983,7 +983,10 @@ TMX_DEVFN void qp_admm_generic_loop(QpWs& w, const DevProblem* P, QpInfo& info, 
 // AGPR).  Out of line it rebuilds the descriptor from the base pointers like the fast-path functions do; state crosses the call
 // through the same QpShared record.  HBM: the workspace is the workgroup's HBM slice `work` (k_*_hbm kernels), with the chain
 // arrays in LDS at lds_off when the launch carries them; otherwise the whole workspace sits in LDS at lds_off.
-template <bool HBM>
+// PAIRS = false: the problem has no row on two waypoints (n_link == 0, checked by the caller): the literal 0 below folds every
+// TMX_HAS_PAIRS(w) of the inlined solver code, so the dense-coupling chain (and its register-resident sweep) is not part of the
+// instantiation that configs 1 / 2 run.
+template <bool HBM, bool PAIRS>
 __device__ __attribute__((noinline)) static void qp_admm_generic_nl(const DevProblem* P_in, const DevBatch* Bt_in, int b_in, unsigned lds_in,
                                                                   double* work_in, int chain_in_lds)
 {
@@ -994,13 +997,14 @@ __device__ __attribute__((noinline)) static void qp_admm_generic_nl(const DevPro
   double* lds = (double*)(tmx_lds_d*)(size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)lds_in);
   double* smem = HBM ? tmx_uniform_ptr(work_in) : lds;
   const int D = P->D, T = P->T, R = P->R;
+  const int n_link = PAIRS ? P->n_link : 0;
   QpWs w;
   {
     double* scratch = Bt->qp_scratch + (size_t)b * Bt->qp_scratch_stride;
 #if TMX_QP_COLD_IN_LDS
-    qp_ws_carve(w, smem, smem + qp_lds_doubles(D, T, R, P->NA, P->n_link), scratch, D, T, R, P->NA, P->n_link, P->coef_far);
+    qp_ws_carve(w, smem, smem + qp_lds_doubles(D, T, R, P->NA, n_link), scratch, D, T, R, P->NA, n_link, P->coef_far);
 #else
-    qp_ws_carve(w, smem, scratch + qp_far_doubles(D, T, R, P->NA, P->n_link, P->coef_far), scratch, D, T, R, P->NA, P->n_link, P->coef_far);
+    qp_ws_carve(w, smem, scratch + qp_far_doubles(D, T, R, P->NA, n_link, P->coef_far), scratch, D, T, R, P->NA, n_link, P->coef_far);
 #endif
     if (HBM && __builtin_amdgcn_readfirstlane(chain_in_lds) != 0)
       qp_ws_chain_to_lds(w, lds);
@@ -1009,6 +1013,7 @@ __device__ __attribute__((noinline)) static void qp_admm_generic_nl(const DevPro
   w.c2i = P->slot_c2;
 #endif
   rows_compact_attach(w);
+  w.sweep_regs = PAIRS;
   QpShared* sh = reinterpret_cast<QpShared*>(w.wself);
   w.rho = sh->rho;
   w.sigma = sh->sigma;
@@ -1506,7 +1511,12 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
     {
       unsigned lds_off = (unsigned)(size_t)(HBM ? chain_lds : smem);
       asm volatile("" : "+s"(lds_off));
-      qp_admm_generic_nl<HBM>(P, Bt, b, lds_off, HBM ? smem : nullptr, chain_lds != nullptr ? 1 : 0);
+    {
+      if (P->n_link > 0)
+        qp_admm_generic_nl<HBM, true>(P, Bt, b, lds_off, HBM ? smem : nullptr, chain_lds != nullptr ? 1 : 0);
+      else
+        qp_admm_generic_nl<HBM, false>(P, Bt, b, lds_off, HBM ? smem : nullptr, chain_lds != nullptr ? 1 : 0);
+    }
     }
 #ifdef TMX_PROFILE
     tlast = TMX_CLK();
