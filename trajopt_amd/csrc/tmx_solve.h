@@ -986,7 +986,10 @@ TMX_DEVFN void qp_admm_generic_loop(QpWs& w, const DevProblem* P, QpInfo& info, 
 // PAIRS = false: the problem has no row on two waypoints (n_link == 0, checked by the caller): the literal 0 below folds every
 // TMX_HAS_PAIRS(w) of the inlined solver code, so the dense-coupling chain (and its register-resident sweep) is not part of the
 // instantiation that configs 1 / 2 run.
-template <bool HBM, bool PAIRS>
+// DC > 0: the block size D is the compile-time constant DC (checked by the caller): the literal reaches every `for (j < w.D)` of
+// the inlined solver code, which then unrolls completely - all loads of a D-term dot are issued before the first wait instead of
+// one load + wait per term - with the additions in the same order (results bit-identical).
+template <bool HBM, bool PAIRS, int DC>
 __device__ __attribute__((noinline)) static void qp_admm_generic_nl(const DevProblem* P_in, const DevBatch* Bt_in, int b_in, unsigned lds_in,
                                                                   double* work_in, int chain_in_lds)
 {
@@ -996,7 +999,7 @@ __device__ __attribute__((noinline)) static void qp_admm_generic_nl(const DevPro
   const int tid = threadIdx.x, NT = blockDim.x;
   double* lds = (double*)(tmx_lds_d*)(size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)lds_in);
   double* smem = HBM ? tmx_uniform_ptr(work_in) : lds;
-  const int D = P->D, T = P->T, R = P->R;
+  const int D = DC ? DC : P->D, T = P->T, R = P->R;
   const int n_link = PAIRS ? P->n_link : 0;
   QpWs w;
   {
@@ -1512,10 +1515,18 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
       unsigned lds_off = (unsigned)(size_t)(HBM ? chain_lds : smem);
       asm volatile("" : "+s"(lds_off));
     {
+      // instantiations: with / without pair rows; block size 7 (7-DOF arms: config 4) as a compile-time constant.  (A D = 10
+      // instantiation for config 3 faulted in the 512-thread HBM kernel - memory access fault at address 0, not understood - and is
+      // not built.)
       if (P->n_link > 0)
-        qp_admm_generic_nl<HBM, true>(P, Bt, b, lds_off, HBM ? smem : nullptr, chain_lds != nullptr ? 1 : 0);
+      {
+        if (!HBM && P->D == 7)
+          qp_admm_generic_nl<HBM, true, 7>(P, Bt, b, lds_off, HBM ? smem : nullptr, chain_lds != nullptr ? 1 : 0);
+        else
+          qp_admm_generic_nl<HBM, true, 0>(P, Bt, b, lds_off, HBM ? smem : nullptr, chain_lds != nullptr ? 1 : 0);
+      }
       else
-        qp_admm_generic_nl<HBM, false>(P, Bt, b, lds_off, HBM ? smem : nullptr, chain_lds != nullptr ? 1 : 0);
+        qp_admm_generic_nl<HBM, false, 0>(P, Bt, b, lds_off, HBM ? smem : nullptr, chain_lds != nullptr ? 1 : 0);
     }
     }
 #ifdef TMX_PROFILE
