@@ -213,6 +213,34 @@ TMX_DEVFN double link_gather(const QpWs& w, const double* rv, int t, int j)
 {
   double s = 0.0;
   if (w.n_link > 0 && t > 0)
+  {
+#if TMX_IS_DEVICE
+    // groups of four entries: the three dependent load levels (list entry -> row attributes -> coefficient) are issued four wide,
+    // the products are added in list order (same sums as the one-by-one walk of the host build)
+    const int q0 = w.wl_start[t - 1], q1 = w.wl_start[t];
+    for (int q = q0; q < q1; q += 4)
+    {
+      int r[4], ci[4], ac[4];
+      double rr[4], cc[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        r[u] = w.wl_list[(q + u < q1) ? q + u : q0];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+      {
+        ci[u] = w.c2i[r[u]];
+        ac[u] = w.act[r[u]];
+        rr[u] = rv[r[u]];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        cc[u] = w.c2[(ci[u] >= 0 ? ci[u] : 0) * w.D + j];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (q + u < q1 && ac[u] && ci[u] >= 0)
+          s += rr[u] * cc[u];
+    }
+#else
     for (int q = w.wl_start[t - 1]; q < w.wl_start[t]; ++q)
     {
       const int r = w.wl_list[q];
@@ -220,6 +248,8 @@ TMX_DEVFN double link_gather(const QpWs& w, const double* rv, int t, int j)
       if (w.act[r] && i >= 0)
         s += rv[r] * w.c2[i * w.D + j];
     }
+#endif
+  }
   return s;
 }
 #else
@@ -1167,6 +1197,35 @@ TMX_DEVFN double at_rows(const QpWs& w, const DevProblem* P, const double* rv, i
     // selects (groups of four into s0..s3, the remainder into s0): the sums an all-slot walk forms, minus exact zeros
     const int n4 = (w.wp_start[t + 1] - w.wp_start[t]) & ~3;
     double c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0;
+#if TMX_IS_DEVICE
+    // (groups of four entries: list entries, then coefficients / row values, issued four wide; applied in list order)
+    const int qa = w.wl_start[t], qb = w.wl_start[t + 1];
+    for (int q = qa; q < qb; q += 4)
+    {
+      int r[4], k[4];
+      double pv[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+      {
+        const int qq = (q + e < qb) ? q + e : qa;
+        r[e] = w.wl_list[qq];
+        k[e] = w.wl_pos[qq];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        pv[e] = w.coef[r[e] * D + j] * rv[r[e]];
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (q + e < qb)
+        {
+          const int u = (k[e] < n4) ? (k[e] & 3) : 0;
+          c0 = (u == 0) ? c0 + pv[e] : c0;
+          c1 = (u == 1) ? c1 + pv[e] : c1;
+          c2 = (u == 2) ? c2 + pv[e] : c2;
+          c3 = (u == 3) ? c3 + pv[e] : c3;
+        }
+    }
+#else
     for (int q = w.wl_start[t]; q < w.wl_start[t + 1]; ++q)
     {
       const int r = w.wl_list[q], k = w.wl_pos[q];
@@ -1177,6 +1236,7 @@ TMX_DEVFN double at_rows(const QpWs& w, const DevProblem* P, const double* rv, i
       c2 = (u == 2) ? c2 + pv : c2;
       c3 = (u == 3) ? c3 + pv : c3;
     }
+#endif
 #if TMX_LINK_ROWS
     return ((c0 + c1) + (c2 + c3)) + link_gather(w, rv, t, j);
 #else
