@@ -132,8 +132,46 @@ typedef enum
   TMX_TERM_JOINT_JERK_EQ_COST = 17,
   TMX_TERM_JOINT_JERK_INEQ_COST = 18,
   TMX_TERM_JOINT_JERK_EQ_CNT = 19,
-  TMX_TERM_JOINT_JERK_INEQ_CNT = 20
+  TMX_TERM_JOINT_JERK_INEQ_CNT = 20,
+  /* sco::CostFromFunc  trajopt_sco/src/modeling_utils.cpp:41-113 — a cost given as a FUNCTION of the variables of one waypoint:
+     value() = f(x_t); convex(): numerical gradient and diagonal Hessian (calcGradAndDiagHess, num_diff.cpp:70-91, negative
+     curvature clipped) or, with full_hessian != 0, the full numerical Hessian (calcGradHess, :93-105) projected on its positive
+     eigenspace.  One cost per step in [first_step, last_step].  The function is a device-evaluable tmx_expr program (below): the
+     host callbacks of the reference (sco::ScalarOfVector) cannot run inside a kernel.                                     */
+  TMX_TERM_FUNC_COST = 21,
+  /* sco::ConstraintFromErrFunc without an analytic Jacobian  modeling_utils.cpp:213-269 — a vector-valued tmx_expr program
+     g(x_t) with n_outputs rows per step: EQ (cnt_type 0: g = 0) or INEQ (1: g <= 0); Jacobian by forward differences
+     (calcForwardNumJac, num_diff.cpp:55-68); rows scaled by coeffs[i] when has_coeffs != 0 (a zero coefficient drops the row). */
+  TMX_TERM_FUNC_CNT = 22
 } tmx_term_kind;
+
+/* ---- device-evaluable functions: a stack program over the n_dof values x[0..n_dof) of one waypoint -----------------------
+   ops = n_ops pairs (opcode, argument); evaluation order = program order; TMX_OP_OUT pops the top of the stack into
+   out[argument].  sin / cos are the shared implementations of include/tmx_detmath.h (oracle and kernels round alike).
+   Interpreter: include/tmx_expr.h (one header for the oracle, the host front ends and the kernels).                      */
+typedef enum
+{
+  TMX_OP_VAR = 1,   /* push x[arg]                 */
+  TMX_OP_CONST = 2, /* push consts[arg]            */
+  TMX_OP_ADD = 3,   /* b = pop, a = pop, push a + b */
+  TMX_OP_SUB = 4,   /* a - b                       */
+  TMX_OP_MUL = 5,   /* a * b                       */
+  TMX_OP_DIV = 6,   /* a / b                       */
+  TMX_OP_NEG = 7,   /* -a                          */
+  TMX_OP_SQ = 8,    /* a * a   (trajopt_common sq) */
+  TMX_OP_SIN = 9,
+  TMX_OP_COS = 10,
+  TMX_OP_SQRT = 11,
+  TMX_OP_OUT = 12   /* out[arg] = pop              */
+} tmx_expr_op;
+#define TMX_EXPR_STACK 16
+#define TMX_EXPR_MAX_OUT 8
+typedef struct
+{
+  int32_t n_ops, n_consts, n_outputs, pad_;
+  const int32_t* ops;   /* 2 * n_ops */
+  const double* consts; /* n_consts  */
+} tmx_expr;
 
 typedef struct
 {
@@ -166,6 +204,13 @@ typedef struct
   int32_t max_substates;   /* collision, evaluator types 2..4: row-slot capacity per (segment, link sphere, obstacle); the number
                               of sub-states ceil(dist / lvs) + 1 is clamped to it on the device AND in the oracle (0 = 2)   */
   int32_t pad2_;
+  /* TMX_TERM_FUNC_COST / TMX_TERM_FUNC_CNT: the function, and the constructor arguments of CostFromFunc (full_hessian) /
+     ConstraintFromErrFunc (type, optional coefficients in coeffs[0 .. n_outputs))                                       */
+  const tmx_expr* expr;
+  int32_t full_hessian;
+  int32_t cnt_type;    /* 0 EQ, 1 INEQ */
+  int32_t has_coeffs;
+  int32_t pad3_;
 } tmx_term;
 
 typedef struct

@@ -337,6 +337,21 @@ public:
 
   /** used by TermInfo::hatch: costs are hatched before constraints (problem_description.cpp:560-571).  `name` is the
       TermInfo name; collision terms expand to one cost / constraint "name_<step>" per non-fixed step (:1773, :1833) */
+  /** a function term: the program is copied into the problem (the descriptor points at the copy) */
+  void addFuncTerm(tmx_term t, const std::vector<int32_t>& ops, const DblVec& consts, int n_outputs, const std::string& name)
+  {
+    auto prog = std::make_shared<FuncProgram>();
+    prog->ops = ops;
+    prog->consts = consts;
+    prog->e.n_ops = static_cast<int32_t>(ops.size() / 2);
+    prog->e.n_consts = static_cast<int32_t>(consts.size());
+    prog->e.n_outputs = n_outputs;
+    prog->e.ops = prog->ops.data();
+    prog->e.consts = prog->consts.data();
+    programs_.push_back(prog);
+    t.expr = &prog->e;
+    addTerm(t, {}, name);
+  }
   void addTerm(const tmx_term& t, const IntVec& fixed_steps = {}, const std::string& name = std::string())
   {
     std::vector<std::string> names;
@@ -353,10 +368,14 @@ public:
     else if (t.kind == TMX_TERM_CART_VEL)  // one cost named after the term / one constraint "CartVel" per step (:1029-1050)
       for (int i = t.first_step; i <= t.last_step; ++i)
         names.push_back(t.is_constraint ? std::string("CartVel") : name);
+    else if (t.kind == TMX_TERM_FUNC_COST || t.kind == TMX_TERM_FUNC_CNT)  // one sco cost / constraint per step
+      for (int i = t.first_step; i <= t.last_step; ++i)
+        names.push_back(name);
     else
       names.push_back(name);
     const bool ineq = t.kind == TMX_TERM_JOINT_POS_INEQ_CNT || t.kind == TMX_TERM_COLLISION_CNT || t.kind == TMX_TERM_JOINT_VEL_INEQ_CNT ||
-                      t.kind == TMX_TERM_JOINT_ACC_INEQ_CNT || t.kind == TMX_TERM_JOINT_JERK_INEQ_CNT || t.kind == TMX_TERM_CART_VEL;
+                      t.kind == TMX_TERM_JOINT_ACC_INEQ_CNT || t.kind == TMX_TERM_JOINT_JERK_INEQ_CNT || t.kind == TMX_TERM_CART_VEL ||
+                      (t.kind == TMX_TERM_FUNC_CNT && t.cnt_type == 1);
     std::vector<std::string>& dst = !t.is_constraint ? cost_names_ : (ineq ? ineq_cnt_names_ : eq_cnt_names_);
     dst.insert(dst.end(), names.begin(), names.end());
     terms_.push_back(t);
@@ -422,6 +441,13 @@ private:
   std::size_t n_cost_terms_{ 0 };
   std::vector<int32_t> fixed_steps_, fixed_dofs_;
   std::vector<std::string> cost_names_, eq_cnt_names_, ineq_cnt_names_;
+  struct FuncProgram
+  {
+    std::vector<int32_t> ops;
+    DblVec consts;
+    tmx_expr e{};
+  };
+  std::vector<std::shared_ptr<FuncProgram>> programs_;
   tmx_problem_desc desc_{};
 };
 
@@ -571,6 +597,119 @@ struct JointVelTermInfo : public TermInfo
       t.lower_tols[j] = lower_tols[j];
     }
     prob.addTerm(t, {}, name);
+  }
+};
+
+/** A function of the variables x[0 .. n_dof) of one waypoint as a tmx_expr stack program (include/tmx.h, interpreter
+    include/tmx_expr.h): the device-evaluable stand-in for the reference's host callbacks sco::ScalarOfVector / VectorOfVector
+    (trajopt_sco/include/trajopt_sco/num_diff.hpp:14-57), which cannot run inside a kernel.
+        Expr x0 = Expr::var(0), x1 = Expr::var(1);   Expr f = sq(x1 - sq(x0)) + sq(1.0 - x0); */
+class Expr
+{
+public:
+  static Expr var(int i) { return Expr({ { TMX_OP_VAR, i } }, {}); }
+  static Expr constant(double c) { return Expr({ { TMX_OP_CONST, 0 } }, { c }); }
+  Expr(double c) : Expr(constant(c)) {}  // NOLINT(google-explicit-constructor): numbers mix with expressions
+  friend Expr operator+(const Expr& a, const Expr& b) { return bin(a, b, TMX_OP_ADD); }
+  friend Expr operator-(const Expr& a, const Expr& b) { return bin(a, b, TMX_OP_SUB); }
+  friend Expr operator*(const Expr& a, const Expr& b) { return bin(a, b, TMX_OP_MUL); }
+  friend Expr operator/(const Expr& a, const Expr& b) { return bin(a, b, TMX_OP_DIV); }
+  Expr operator-() const { return un(*this, TMX_OP_NEG); }
+  friend Expr sq(const Expr& a) { return un(a, TMX_OP_SQ); }
+  friend Expr sin(const Expr& a) { return un(a, TMX_OP_SIN); }
+  friend Expr cos(const Expr& a) { return un(a, TMX_OP_COS); }
+  friend Expr sqrt(const Expr& a) { return un(a, TMX_OP_SQRT); }
+  /** appends this expression followed by OUT(output) to a program */
+  void emit(std::vector<int32_t>& ops, DblVec& consts, int output) const
+  {
+    std::size_t next_c = 0;
+    for (const auto& oc : code_)
+    {
+      ops.push_back(oc.first);
+      if (oc.first == TMX_OP_CONST)
+      {
+        consts.push_back(consts_[next_c++]);
+        ops.push_back(static_cast<int32_t>(consts.size() - 1));
+      }
+      else
+        ops.push_back(oc.second);
+    }
+    ops.push_back(TMX_OP_OUT);
+    ops.push_back(output);
+  }
+
+private:
+  using Code = std::vector<std::pair<int32_t, int32_t>>;
+  Expr(Code code, DblVec consts) : code_(std::move(code)), consts_(std::move(consts)) {}
+  static Expr bin(const Expr& a, const Expr& b, int32_t op)
+  {
+    Expr r = a;
+    r.code_.insert(r.code_.end(), b.code_.begin(), b.code_.end());
+    r.consts_.insert(r.consts_.end(), b.consts_.begin(), b.consts_.end());
+    r.code_.emplace_back(op, 0);
+    return r;
+  }
+  static Expr un(const Expr& a, int32_t op)
+  {
+    Expr r = a;
+    r.code_.emplace_back(op, 0);
+    return r;
+  }
+  Code code_;
+  DblVec consts_;  // in the order of the CONST ops of code_
+};
+
+/** sco::CostFromFunc (trajopt_sco/src/modeling_utils.cpp:41-113) on the variables of every step in [first_step, last_step]; what a
+    reference user writes as prob->addCost(std::make_shared<sco::CostFromFunc>(f, vars, name, full_hessian)) per step */
+struct FuncCostTermInfo : public TermInfo
+{
+  Expr f{ 0.0 };
+  int first_step = 0;
+  int last_step = -1;
+  bool full_hessian = false;
+  FuncCostTermInfo() : TermInfo(TermType::TT_COST) {}
+  void hatch(TrajOptProb& prob) override
+  {
+    tmx_term t = detail::blankTerm();
+    t.kind = TMX_TERM_FUNC_COST;
+    t.first_step = first_step;
+    t.last_step = last_step <= -1 ? prob.GetNumSteps() - 1 : last_step;
+    t.full_hessian = full_hessian ? 1 : 0;
+    std::vector<int32_t> ops;
+    DblVec consts;
+    f.emit(ops, consts, 0);
+    prob.addFuncTerm(t, ops, consts, 1, name);
+  }
+};
+
+/** sco::ConstraintFromErrFunc without an analytic Jacobian (modeling_utils.cpp:213-269): g(x_t) == 0 (EQ) or <= 0 (INEQ), optional
+    row coefficients */
+struct FuncConstraintTermInfo : public TermInfo
+{
+  std::vector<Expr> g;
+  int first_step = 0;
+  int last_step = -1;
+  bool ineq = false;
+  DblVec coeffs;
+  FuncConstraintTermInfo() : TermInfo(TermType::TT_CNT) {}
+  void hatch(TrajOptProb& prob) override
+  {
+    if (g.empty() || g.size() > TMX_EXPR_MAX_OUT || (!coeffs.empty() && coeffs.size() != g.size()))
+      printAndThrow("FuncConstraintTermInfo: 1 .. TMX_EXPR_MAX_OUT outputs, one coefficient per output if any");
+    tmx_term t = detail::blankTerm();
+    t.kind = TMX_TERM_FUNC_CNT;
+    t.is_constraint = 1;
+    t.first_step = first_step;
+    t.last_step = last_step <= -1 ? prob.GetNumSteps() - 1 : last_step;
+    t.cnt_type = ineq ? 1 : 0;
+    t.has_coeffs = coeffs.empty() ? 0 : 1;
+    for (std::size_t i = 0; i < coeffs.size(); ++i)
+      t.coeffs[i] = coeffs[i];
+    std::vector<int32_t> ops;
+    DblVec consts;
+    for (std::size_t i = 0; i < g.size(); ++i)
+      g[i].emit(ops, consts, static_cast<int>(i));
+    prob.addFuncTerm(t, ops, consts, static_cast<int>(g.size()), name);
   }
 };
 

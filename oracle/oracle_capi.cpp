@@ -137,6 +137,14 @@ int orc_sqp_batch(const tmx_problem_desc* desc, const tmx_sqp_params* sqp, const
 
 // One seed: BasicTrustRegionSQPResults of every trust-region evaluation of the run (sco.hpp StepLog), in the layout of
 // tmx_sqp_step_log (include/tmx.h): out[k * stride + ...], stride = TMX_STEP_LOG_HEAD + 3 n_costs + 4 n_cnts
+// tmx_expr programs (include/tmx_expr.h): static check + one evaluation (tests)
+int orc_expr_eval(const tmx_expr* e, int32_t n_vars, const double* x, double* out)
+{
+  if (tmx_expr_check(e, n_vars) != 0)
+    return -1;
+  return tmx_expr_eval(e->ops, e->n_ops, e->consts, x, out);
+}
+
 int orc_sqp_step_logs(const tmx_problem_desc* desc, const tmx_sqp_params* sqp, const tmx_osqp_settings* osqp, const double* x0,
                       int max_steps, int stride, double* out, int* n_steps_out, int* n_costs_out, int* n_cnts_out, int* status_out)
 {

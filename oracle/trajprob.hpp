@@ -23,6 +23,7 @@
 
 #include "../include/tmx.h"
 #include "../include/tmx_detmath.h"
+#include "../include/tmx_expr.h"  // tmx_expr programs (function terms), shared with the kernels
 #include "../include/tmx_geom.h"  // sphere / capsule obstacle contacts, shared with the kernels
 // ^ tmx_detmath.h: the libm stand-in shared with the device kernels (fixed IEEE operation sequence)
 #include "sco.hpp"
@@ -1285,7 +1286,7 @@ inline TrajProblem constructProblem(const tmx_problem_desc& d, const double* ini
       const tmx_term& tm = d.terms[k];
       const bool is_cnt = (tm.kind == TMX_TERM_JOINT_POS_EQ_CNT) || (tm.kind == TMX_TERM_JOINT_POS_INEQ_CNT) || (tm.kind == TMX_TERM_COLLISION_CNT) ||
                           (tm.kind == TMX_TERM_JOINT_VEL_EQ_CNT) || (tm.kind == TMX_TERM_JOINT_VEL_INEQ_CNT) ||
-                          (tm.kind == TMX_TERM_JOINT_ACC_EQ_CNT) || (tm.kind == TMX_TERM_JOINT_ACC_INEQ_CNT) ||
+                          (tm.kind == TMX_TERM_JOINT_ACC_EQ_CNT) || (tm.kind == TMX_TERM_JOINT_ACC_INEQ_CNT) || (tm.kind == TMX_TERM_FUNC_CNT) ||
                           (tm.kind == TMX_TERM_JOINT_JERK_EQ_CNT) || (tm.kind == TMX_TERM_JOINT_JERK_INEQ_CNT) ||
                           ((tm.kind == TMX_TERM_CART_POSE || tm.kind == TMX_TERM_CART_VEL) && tm.is_constraint);
       if ((pass == 0) == is_cnt)
@@ -1310,6 +1311,43 @@ inline TrajProblem constructProblem(const tmx_problem_desc& d, const double* ini
               P.traj_vars, DblVec(tm.coeffs, tm.coeffs + D), DblVec(tm.targets, tm.targets + D), DblVec(tm.upper_tols, tm.upper_tols + D),
               DblVec(tm.lower_tols, tm.lower_tols + D), tm.first_step, tm.last_step));
           break;
+        // user functions as tmx_expr programs over the variables of one waypoint: sco::CostFromFunc (numerical gradient and
+        // Hessian) / sco::ConstraintFromErrFunc with a forward-difference Jacobian, one per step (include/tmx.h)
+        case TMX_TERM_FUNC_COST:
+        case TMX_TERM_FUNC_CNT:
+        {
+          if (tmx_expr_check(tm.expr, D) != 0)
+            throw std::runtime_error("function term: malformed tmx_expr program");
+          const std::vector<int32_t> ops(tm.expr->ops, tm.expr->ops + 2 * tm.expr->n_ops);
+          const DblVec consts(tm.expr->consts, tm.expr->consts + tm.expr->n_consts);
+          const int n_out = tm.expr->n_outputs;
+          for (int t = tm.first_step; t <= tm.last_step; ++t)
+          {
+            if (tm.kind == TMX_TERM_FUNC_COST)
+            {
+              ScalarOfVector f = [ops, consts](const DblVec& q) {
+                double o[TMX_EXPR_MAX_OUT];
+                tmx_expr_eval(ops.data(), static_cast<int32_t>(ops.size() / 2), consts.data(), q.data(), o);
+                return o[0];
+              };
+              P.prob->addCost(std::make_shared<CostFromFunc>(f, P.traj_vars.row(t), "func_cost", tm.full_hessian != 0));
+            }
+            else
+            {
+              VectorOfVector g = [ops, consts, n_out](const DblVec& q) {
+                double o[TMX_EXPR_MAX_OUT];
+                tmx_expr_eval(ops.data(), static_cast<int32_t>(ops.size() / 2), consts.data(), q.data(), o);
+                return DblVec(o, o + n_out);
+              };
+              DblVec c;
+              if (tm.has_coeffs)
+                c.assign(tm.coeffs, tm.coeffs + n_out);
+              P.prob->addConstraint(std::make_shared<ConstraintFromErrFunc>(g, MatrixOfVector(), P.traj_vars.row(t), c,
+                                                                            tm.cnt_type == 1 ? INEQ : EQ, "func_cnt"));
+            }
+          }
+          break;
+        }
         // JointAccTermInfo::hatch / JointJerkTermInfo::hatch (problem_description.cpp:1393-1493, :1530-1631): the four classes of
         // the velocity family with the second / third difference
         case TMX_TERM_JOINT_ACC_EQ_COST:

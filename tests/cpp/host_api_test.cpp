@@ -484,6 +484,45 @@ static void caseJointVel(const Input& in)
     printResults(name, opt);
   };
   {
+    // function terms (sco::CostFromFunc / ConstraintFromErrFunc as tmx_expr programs) next to an acceleration smoothing cost:
+    // Rosenbrock-like bowl on joints 0 / 1 of every step (TP1 of trajopt_sco/test/small-problems-unit.cpp:116-122, full
+    // Hessian), joint 2 tied to joint 3 at the last step by an equality g = x2 - 0.5 x3 - 0.1
+    using tmx::trajopt::Expr;
+    auto env = makeEnv(in, "right_arm", "pr2_right_arm", DblVec(7, 0.0), false);
+    ProblemConstructionInfo pci(env);
+    pci.basic_info.n_steps = steps;
+    pci.basic_info.manip = "right_arm";
+    pci.resolveKin();
+    pci.init_info.type = InitInfo::STATIONARY;
+    auto ja = std::make_shared<JointAccTermInfo>();
+    ja->coeffs = DblVec(7, 1.0);
+    ja->targets = DblVec(7, 0.0);
+    ja->name = "smooth";
+    ja->term_type = TermType::TT_COST;
+    pci.cost_infos.push_back(ja);
+    auto fc = std::make_shared<FuncCostTermInfo>();
+    const Expr x0 = Expr::var(0), x1 = Expr::var(1);
+    fc->f = 0.5 * sq(x1 - sq(x0)) + sq(0.3 - x0);
+    fc->full_hessian = true;
+    fc->name = "bowl";
+    pci.cost_infos.push_back(fc);
+    auto fg = std::make_shared<FuncConstraintTermInfo>();
+    fg->g = { Expr::var(2) - 0.5 * Expr::var(3) - 0.1 };
+    fg->first_step = steps - 1;
+    fg->last_step = steps - 1;
+    fg->name = "tie";
+    pci.cnt_infos.push_back(fg);
+    run(pci, "function_terms", [&](const DblVec& x) {
+      const std::size_t last = static_cast<std::size_t>((steps - 1) * 7);
+      EXPECT_NEAR(x[last + 2] - 0.5 * x[last + 3] - 0.1, 0.0, 1e-4);
+      for (int i = 0; i < steps; ++i)  // the bowl's minimiser (0.3, 0.09) at every step (the smoothing cost vanishes on constants)
+      {
+        EXPECT_NEAR(x[static_cast<std::size_t>(i * 7)], 0.3, 0.01);
+        EXPECT_NEAR(x[static_cast<std::size_t>(i * 7 + 1)], 0.09, 0.01);
+      }
+    });
+  }
+  {
     auto env = makeEnv(in, "right_arm", "pr2_right_arm", DblVec(7, 0.0), false);
     ProblemConstructionInfo pci(env);
     pci.basic_info.n_steps = steps;

@@ -151,7 +151,7 @@ def test_cpp_reference_kats_on_host_build(hostemu_lib, inputs, orc):
     res, _, out = _run(exe, inputs["path"], "joint_costs,numerical_ik,cart_position,interface,joint_vel,errors")
     assert "ERRORS done" in out and "INTERFACE done" in out and "JOINTVEL done" in out and "LINKROWS refused" not in out
     assert set(res) == {"equality_jointPos", "inequality_jointPos", "numerical_ik1", "cart_position", "equality_jointVel",
-                        "inequality_jointVel"}      # the host build has the two-waypoint rows (TMX_LINK_ROWS=1)
+                        "inequality_jointVel", "function_terms"}      # the host build has the two-waypoint rows (TMX_LINK_ROWS=1)
     assert all(r[0]["status"] == 0 for r in res.values())
 
 
@@ -160,7 +160,7 @@ def test_cpp_two_waypoint_terms_are_refused_by_the_product_configuration(hostemu
     library's explicit refusal, exactly what the GPU tier expects from libtrajopt_mi355x.so this round"""
     exe = _build(hostemu_lib_nolink, "hostemu_nolink")
     res, _, out = _run(exe, inputs["path"], "joint_vel")
-    assert out.count("LINKROWS refused") == 2 and "JOINTVEL done" in out and not res
+    assert out.count("LINKROWS refused") == 3 and "JOINTVEL done" in out and not res   # + the acceleration cost of function_terms
 
 
 def test_cpp_optimizer_fails_loudly_without_a_device(inputs):

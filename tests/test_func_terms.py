@@ -1,0 +1,171 @@
+"""sco::CostFromFunc / sco::ConstraintFromErrFunc over device-evaluable functions:
+  * trajopt_sco/src/modeling_utils.cpp:41-113 (numerical gradient, diagonal or full Hessian, positive part), :213-269
+  * trajopt_sco/src/num_diff.cpp:41-105 (forward / central differences)
+The reference takes host callbacks (sco::ScalarOfVector / VectorOfVector); a kernel cannot call them, so the device path takes
+the function as a tmx_expr stack program (include/tmx.h, interpreter include/tmx_expr.h - ONE header for oracle and kernels).
+KATs: trajopt_sco/test/small-problems-unit.cpp (QuadraticSeparable :47-65, QuadraticNonseparable :66-86, TP1 / TP3 / TP6
+:88-166; TP7 needs log) - the reference runs them with every solver EXCEPT OSQP (:176-186); with the OSQP restatement they reach the
+same solutions."""
+import numpy as np
+import pytest
+
+import parity_checks as pc
+from trajopt_amd import abi, runtime
+from trajopt_amd.problem import (BasicInfo, Ex, FuncConstraintTermInfo, FuncCostTermInfo, JointVelTermInfo, ProblemConstructionInfo,
+                                 Robot, _tf12, compile_program, ex_cos, ex_sin, ex_sqrt, sq)
+
+
+def free_vars(n):
+    """setupProblem (small-problems-unit.cpp:27-38): n unbounded variables; as a one-waypoint 'trajectory' of an n-joint chain"""
+    rob = Robot(joint_types=[0] * n, origins=[_tf12(t=(0, 0, 0.1))] * n, axes=[np.array([0, 0, 1.0])] * n, lower=np.full(n, -1e30),
+                upper=np.full(n, 1e30), tool=_tf12())
+    rob.link_spheres = []
+    return rob
+
+
+def _case(name):
+    x = [Ex.var(i) for i in range(3)]
+    sp = abi.default_sqp_params()
+    if name == "QuadraticSeparable":       # :46-65: exactly a QP (diagonal Hessian path)
+        sp.trust_box_size = 100
+        return 3, sq(x[0]) + sq(x[1] - 1) + sq(x[2] - 2), False, None, False, [3, 4, 5], [0, 1, 2], 1e-3, sp
+    if name == "QuadraticNonseparable":    # :66-86: full Hessian path
+        sp.trust_box_size, sp.min_trust_box_size, sp.min_approx_improve = 100, 1e-5, 1e-6
+        return 3, sq(x[0] - x[1] + 3 * x[2]) + sq(x[0] - 1) + sq(x[2] - 2), True, None, False, [3, 4, 5], [1, 7, 2], .01, sp
+    sp.max_iter, sp.min_trust_box_size, sp.min_approx_improve, sp.initial_merit_error_coeff = 1000, 1e-5, 1e-10, 1   # testProblem :88-114
+    if name == "TP1":
+        return 2, 1 * sq(x[1] - sq(x[0])) + sq(1 - x[0]), True, [-1.5 - x[1]], True, [-2, 1], [1, 1], .01, sp
+    if name == "TP3":
+        return 2, x[1] + 1e-5 * sq(x[1] - x[0]), True, [0 - x[1]], True, [10, 1], [0, 0], .01, sp
+    if name == "TP6":
+        return 2, sq(1 - x[0]), True, [10 * (x[1] - sq(x[0]))], False, [10, 1], [1, 1], .01, sp
+    raise KeyError(name)
+
+
+NAMES = ["QuadraticSeparable", "QuadraticNonseparable", "TP1", "TP3", "TP6"]
+
+
+def _problem(name):
+    n, f, full, g, ineq, init, sol, tol, sp = _case(name)
+    pci = ProblemConstructionInfo(free_vars(n), BasicInfo(n_steps=1))
+    pci.cost_infos.append(FuncCostTermInfo(f=f, full_hessian=full, name="f"))
+    if g is not None:
+        pci.cnt_infos.append(FuncConstraintTermInfo(g=g, ineq=ineq, name="g"))
+    return pci, np.array(init, float).reshape(1, 1, n), np.array(sol, float), tol, sp
+
+
+def test_interpreter_and_program_check(orc):
+    """the interpreter against numpy, and the static check of malformed programs"""
+    import ctypes as C
+    x = [Ex.var(i) for i in range(3)]
+    prog, keep = compile_program([sq(x[0] - 2 * x[1]) / (1 + sq(x[2])) + ex_sin(x[0]) * ex_cos(x[1]) - ex_sqrt(sq(x[2]) + 1), -x[0] + 3])
+    lib = orc.lib()
+    lib.orc_expr_eval.argtypes = [C.POINTER(abi.Expr), C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    lib.orc_expr_eval.restype = C.c_int32
+    rng = np.random.default_rng(0)
+    for _ in range(20):
+        v = rng.standard_normal(3)
+        out = (C.c_double * 2)()
+        assert lib.orc_expr_eval(C.byref(prog), 3, (C.c_double * 3)(*v), out) == 0
+        want = (v[0] - 2 * v[1]) ** 2 / (1 + v[2] ** 2) + np.sin(v[0]) * np.cos(v[1]) - np.sqrt(v[2] ** 2 + 1)
+        assert abs(out[0] - want) < 1e-14 and out[1] == -v[0] + 3
+    bad, keep2 = compile_program([x[0] + x[1]])
+    bad.ops[0] = 99                                                   # unknown opcode
+    assert lib.orc_expr_eval(C.byref(bad), 3, (C.c_double * 3)(), (C.c_double * 2)()) != 0
+    bad, keep3 = compile_program([x[2]])
+    assert lib.orc_expr_eval(C.byref(bad), 2, (C.c_double * 3)(), (C.c_double * 2)()) != 0    # variable index out of range
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_small_problems_kat_oracle(orc, name):
+    pci, x0, sol, tol, sp = _problem(name)
+    o = orc.sqp_batch(pci.to_desc(), x0, sqp=sp)
+    assert o["status"][0] == abi.OPT_CONVERGED
+    assert np.abs(o["x"].ravel() - sol).max() <= tol
+
+
+def _stage_and_sqp(ctx, orc, name):
+    pci, x0, sol, tol, sp = _problem(name)
+    # a second seed off the reference's start point
+    x0 = np.concatenate([x0, x0 + 0.3 * np.random.default_rng(3).standard_normal(x0.shape)])
+    desc = pc.make_ctx_inputs(ctx, pci, x0)                                   # (stage checks at the default parameters)
+    pc.check_evaluate(ctx, orc, desc, x0, tol=1e-12)
+    for b in range(2):
+        pc.check_first_qp_structure(ctx, orc, desc, x0, b, val_tol=1e-9)     # P carries the dynamic Hessian block of the model
+    ctx.upload(desc, sp, abi.default_osqp_settings())
+    ctx.set_x0(x0)
+    ctx.run(0)
+    r = ctx.results()
+    o = orc.sqp_batch(desc, x0, sqp=sp)
+    assert (r["status"] == o["status"]).all() and r["status"][0] == abi.OPT_CONVERGED
+    assert np.abs(r["x"][0].ravel() - sol).max() <= tol
+    assert np.abs(r["x"] - o["x"]).max() < 1e-5
+    assert (np.abs(r["n_qp_solves"] - o["n_qp_solves"]) <= 2).all()
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_small_problems_kat_kernel_sources_on_host(hostemu_lib, orc, name):
+    ctx = runtime.Context(0, hostemu_lib)
+    _stage_and_sqp(ctx, orc, name)
+    ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", NAMES)
+def test_small_problems_kat_device(gpu_ctx_factory, orc, name):
+    ctx = gpu_ctx_factory()
+    _stage_and_sqp(ctx, orc, name)
+    ctx.close()
+
+
+def _mixed():
+    """a function cost and a function constraint per waypoint next to the terms of the 4-DOF test arm: a quadratic bowl around the
+    mid posture (full Hessian), a trigonometric inequality on two joints and a coupled equality at one step"""
+    from trajopt_amd import configs
+    pci, s, g = configs.config_mini(with_joint_band=False)
+    n = pci.basic_info.n_steps
+    x = [Ex.var(i) for i in range(4)]
+    pci.cost_infos.append(FuncCostTermInfo(f=0.2 * sq(x[0] - 0.3 * x[1]) + 0.1 * sq(x[2] + x[3]) + 0.05 * ex_cos(x[1]), first_step=1, last_step=n - 2,
+                                           full_hessian=True, name="bowl"))
+    pci.cost_infos.append(FuncCostTermInfo(f=0.3 * sq(x[3] - 0.1) + 0.01 * sq(sq(x[2])), first_step=2, last_step=4, name="diag"))
+    pci.cnt_infos.append(FuncConstraintTermInfo(g=[ex_sin(x[1]) + 0.5 * x[2] - 1.2, -x[0] - 2.0], first_step=3, last_step=n - 3, ineq=True,
+                                                coeffs=[2.0, 0.5], name="trig"))
+    pci.cnt_infos.insert(0, FuncConstraintTermInfo(g=[x[2] - 0.8 * x[3] + 0.1 * sq(x[1])], first_step=n // 2 + 2, last_step=n // 2 + 2, name="couple"))
+    return pci, s, g
+
+
+def _run_mixed(ctx, orc, B):
+    from trajopt_amd import configs
+    pci, s, g = _mixed()
+    x0 = configs.seeds_for(9, pci, s, g, B)
+    desc = pc.make_ctx_inputs(ctx, pci, x0)
+    pc.check_evaluate(ctx, orc, desc, x0, tol=1e-12)
+    for b in range(min(B, 2)):
+        pc.check_first_qp_structure(ctx, orc, desc, x0, b, val_tol=1e-9)
+    assert all(same for same, _ in pc.check_first_qp_solve(ctx, orc, desc, x0))
+    ctx.set_x0(x0)
+    r, o, same, dx = pc.check_full_sqp(ctx, orc, desc, x0, exact=False)
+    assert (r["status"] == o["status"]).all()
+    assert (dx < 1e-5).sum() >= B - 1, dx
+
+
+def test_function_terms_next_to_trajectory_terms_on_host(hostemu_lib, orc):
+    ctx = runtime.Context(0, hostemu_lib)
+    _run_mixed(ctx, orc, 3)
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_function_terms_next_to_trajectory_terms_on_device(gpu_ctx_factory, orc):
+    ctx = gpu_ctx_factory()
+    _run_mixed(ctx, orc, 8)
+    ctx.close()
+
+
+def test_malformed_programs_are_refused(hostemu_lib):
+    pci = ProblemConstructionInfo(free_vars(2), BasicInfo(n_steps=1))
+    pci.cost_infos.append(FuncCostTermInfo(f=Ex.var(5)))          # variable index out of range
+    ctx = runtime.Context(0, hostemu_lib)
+    with pytest.raises(RuntimeError, match="tmx_expr"):
+        ctx.upload(pci.to_desc(), abi.default_sqp_params(), abi.default_osqp_settings())
+    ctx.close()

@@ -47,6 +47,16 @@ class ObstacleSphere(C.Structure):
     _fields_ = [("center", C.c_double * 3), ("radius", C.c_double)]
 
 
+class Expr(C.Structure):
+    """tmx_expr — a stack program over the variables of one waypoint (include/tmx.h, interpreter include/tmx_expr.h)"""
+    _fields_ = [("n_ops", C.c_int32), ("n_consts", C.c_int32), ("n_outputs", C.c_int32), ("pad_", C.c_int32),
+                ("ops", C.POINTER(C.c_int32)), ("consts", C.POINTER(C.c_double))]
+
+
+OP_VAR, OP_CONST, OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_NEG, OP_SQ, OP_SIN, OP_COS, OP_SQRT, OP_OUT = range(1, 13)
+TERM_FUNC_COST, TERM_FUNC_CNT = 21, 22
+
+
 class Term(C.Structure):
     _fields_ = [
         ("kind", C.c_int32),
@@ -67,6 +77,11 @@ class Term(C.Structure):
         ("longest_valid_segment_length", C.c_double),
         ("max_substates", C.c_int32),
         ("pad2_", C.c_int32),
+        ("expr", C.POINTER(Expr)),
+        ("full_hessian", C.c_int32),
+        ("cnt_type", C.c_int32),
+        ("has_coeffs", C.c_int32),
+        ("pad3_", C.c_int32),
     ]
 
 

@@ -401,6 +401,9 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
         add_slot(SLOT_FIXED, i, dof, 0, -1, 0, 0, 1, 0.0, 1.0, 0.0, 0.0);
   }
   std::vector<double> pd(P.NX, 0.0), po(P.NX, 0.0), pq(P.NX, 0.0), po2(P.NX, 0.0), po3(P.NX, 0.0);
+  std::vector<int> fx_t, fx_kind, fx_owner, fx_op0, fx_nops, fx_c0, fx_nout, fx_slot0, fx_ci, fx_ops;  // function-term instances
+  std::vector<double> fx_consts;
+  int n_fx_cost = 0;
   int n_stencil = 0;      // rows of difference order 2 / 3
   bool qp_dense = false;  // an acceleration / jerk term is present: banded objective and / or rows on 3 - 4 waypoints
   std::vector<int> vel_first, vel_last, vel_cost, vel_kind, cp_t, cp_owner, cp_iscnt, cp_nrows, cp_idx, cp_slot0;
@@ -414,9 +417,9 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
       const tmx_term& tm = d->terms[k];
       const bool is_ineq = tm.kind == TMX_TERM_JOINT_POS_INEQ_CNT || tm.kind == TMX_TERM_COLLISION_CNT || tm.kind == TMX_TERM_JOINT_VEL_INEQ_CNT ||
                            tm.kind == TMX_TERM_JOINT_ACC_INEQ_CNT || tm.kind == TMX_TERM_JOINT_JERK_INEQ_CNT ||
-                           (tm.kind == TMX_TERM_CART_VEL && tm.is_constraint);
+                           (tm.kind == TMX_TERM_FUNC_CNT && tm.cnt_type == 1) || (tm.kind == TMX_TERM_CART_VEL && tm.is_constraint);
       const bool is_cnt = is_ineq || (tm.kind == TMX_TERM_JOINT_POS_EQ_CNT) || (tm.kind == TMX_TERM_JOINT_VEL_EQ_CNT) ||
-                          (tm.kind == TMX_TERM_JOINT_ACC_EQ_CNT) || (tm.kind == TMX_TERM_JOINT_JERK_EQ_CNT) ||
+                          (tm.kind == TMX_TERM_JOINT_ACC_EQ_CNT) || (tm.kind == TMX_TERM_JOINT_JERK_EQ_CNT) || (tm.kind == TMX_TERM_FUNC_CNT) ||
                           (tm.kind == TMX_TERM_CART_POSE && tm.is_constraint);
       int want = !is_cnt ? 0 : (is_ineq ? 2 : 1);
       if (flavor == TMX_FLAVOR_SQP)
@@ -596,6 +599,60 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
           break;
 #endif
         }
+        case TMX_TERM_FUNC_COST:
+        case TMX_TERM_FUNC_CNT:
+        {
+          // sco::CostFromFunc / sco::ConstraintFromErrFunc over a tmx_expr program of the waypoint's variables: one cost /
+          // constraint per step (include/tmx.h).  The cost model is a dynamic quadratic: dense QP engine.
+          if (flavor == TMX_FLAVOR_SQP)
+          {
+            ctx->err = "TMX_FLAVOR_SQP: function terms are not part of the trajopt_sqp path";
+            return TMX_ERR_UNSUPPORTED;
+          }
+          if (tmx_expr_check(tm.expr, D) != 0)
+          {
+            ctx->err = "function term: malformed tmx_expr program (opcode, index, stack discipline or outputs)";
+            return TMX_ERR_INVALID;
+          }
+          const bool is_cost = tm.kind == TMX_TERM_FUNC_COST;
+          if (is_cost && tm.expr->n_outputs != 1)
+          {
+            ctx->err = "TMX_TERM_FUNC_COST: the program of a cost has one output";
+            return TMX_ERR_INVALID;
+          }
+          if (!is_cost && tm.cnt_type != 0 && tm.cnt_type != 1)
+          {
+            ctx->err = "TMX_TERM_FUNC_CNT: cnt_type must be 0 (EQ) or 1 (INEQ)";
+            return TMX_ERR_INVALID;
+          }
+          qp_dense = true;
+          const int op0 = (int)fx_ops.size() / 2, c0 = (int)fx_consts.size();
+          fx_ops.insert(fx_ops.end(), tm.expr->ops, tm.expr->ops + 2 * tm.expr->n_ops);
+          fx_consts.insert(fx_consts.end(), tm.expr->consts, tm.expr->consts + tm.expr->n_consts);
+          for (int t = tm.first_step; t <= tm.last_step; ++t)
+          {
+            const int inst = (int)fx_t.size();
+            const int own = is_cost ? n_costs++ : n_cnts++;
+            fx_t.push_back(t);
+            fx_kind.push_back(is_cost ? (tm.full_hessian ? 1 : 0) : 2);
+            fx_owner.push_back(own);
+            fx_op0.push_back(op0);
+            fx_nops.push_back(tm.expr->n_ops);
+            fx_c0.push_back(c0);
+            fx_nout.push_back(tm.expr->n_outputs);
+            fx_slot0.push_back((int)kind.size());
+            fx_ci.push_back(is_cost ? n_fx_cost++ : -1);
+            if (!is_cost)
+              for (int i = 0; i < tm.expr->n_outputs; ++i)
+              {
+                const double cc = tm.has_coeffs ? tm.coeffs[i] : 1.0;
+                if (tm.has_coeffs && cc == 0)
+                  continue;  // modeling_utils.cpp:258-259
+                add_slot(SLOT_FUNC, t, i, inst, own, tm.cnt_type == 0 ? 2 : 1, 1, tm.cnt_type == 0 ? 1 : 0, 0.0, cc, 0.0, 0.0);
+              }
+          }
+          break;
+        }
         case TMX_TERM_JOINT_ACC_EQ_COST:
         case TMX_TERM_JOINT_JERK_EQ_COST:
         {
@@ -603,9 +660,14 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
           // built once as a QuadExpr; Hessian / linear term exactly as exprSquare + exprToEigen build them (expr_ops.cpp:55-84,
           // solver_utils.cpp:49-109 with matrix_is_halved = true): diagonal 2 a_k^2 c, off-diagonal (2 a_k a_l) c, linear (2 cst a_k) c
           const int ord = tm.kind == TMX_TERM_JOINT_ACC_EQ_COST ? 2 : 3;
-          if (flavor == TMX_FLAVOR_SQP || !TMX_LINK_ROWS)
+          if (!TMX_LINK_ROWS)
           {
-            ctx->err = "joint acceleration / jerk terms: not available in this flavour / build";
+            ctx->err = "rows on several waypoints (joint acceleration / jerk terms) are not enabled in this build";
+            return TMX_ERR_UNSUPPORTED;
+          }
+          if (flavor == TMX_FLAVOR_SQP)
+          {
+            ctx->err = "TMX_FLAVOR_SQP: joint acceleration / jerk terms are not part of the trajopt_sqp path";
             return TMX_ERR_UNSUPPORTED;
           }
           if (tm.last_step - ord - tm.first_step < 0)
@@ -930,6 +992,8 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
                       ((c >= D && po[c - D] != 0.0) ? 1 : 0) + ((pd[c] != 0.0) ? 1 : 0);
   P.n_stencil = n_stencil;
   P.qp_dense = qp_dense ? 1 : 0;
+  P.n_fx = (int)fx_t.size();
+  P.n_fx_cost = n_fx_cost;
   // slots grouped by waypoint, ascending slot id inside a waypoint
   std::vector<int> wp_start(T + 1, 0), wp_list(R, 0);
   for (int r = 0; r < R; ++r)
@@ -1014,6 +1078,17 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
   UP(pq, pq);
   UP(po2, po2);
   UP(po3, po3);
+  UP(fx_t, fx_t);
+  UP(fx_kind, fx_kind);
+  UP(fx_owner, fx_owner);
+  UP(fx_op0, fx_op0);
+  UP(fx_nops, fx_nops);
+  UP(fx_c0, fx_c0);
+  UP(fx_nout, fx_nout);
+  UP(fx_slot0, fx_slot0);
+  UP(fx_ci, fx_ci);
+  UP(fx_ops, fx_ops);
+  UP(fx_consts, fx_consts);
   UP(p_colptr, p_colptr);
   UP(vel_first, vel_first);
   UP(vel_last, vel_last);
@@ -1225,7 +1300,13 @@ static tmx_status ensure_batch(tmx_ctx* ctx, int B)
       return TMX_ERR_UNSUPPORTED;
     }
     H.dq_nnzA = (int)cap;
-    const size_t nzp = (size_t)std::max(1, P.nnzP);
+    const size_t nzp = (size_t)std::max(1, P.nnzP) + (size_t)P.n_fx_cost * P.D * (P.D + 1) / 2;
+    H.dq_nnzP = (int)nzp;
+    const size_t nfc = (size_t)std::max(1, P.n_fx_cost), dd = (size_t)P.D * P.D;
+    AL(fx_H, b * nfc * dd);
+    AL(fx_g, b * nfc * (size_t)P.D);
+    AL(fx_c, b * nfc);
+    AL(fx_W, b * nfc * 2 * dd);
     AL(dq_Pp, b * (size_t)(P.n_max + 1));
     AL(dq_Pi, b * nzp);
     AL(dq_Px, b * nzp);
@@ -1783,7 +1864,7 @@ tmx_status tmx_export_csc(tmx_ctx* ctx, int32_t problem, int32_t* n, int32_t* m,
   HIPCHK(hipSetDevice(ctx->device));
   const DevProblem& P = ctx->hp;
   // device scratch sized for the worst case
-  const size_t nmax = P.n_max, mmax = P.m_max, nzA = (size_t)P.R * (2 * P.D + 2) + 2 * nmax, nzP = (size_t)P.nnzP + 1;
+  const size_t nmax = P.n_max, mmax = P.m_max, nzA = (size_t)P.R * (2 * P.D + 2) + 2 * nmax, nzP = (size_t)P.nnzP + 1 + (size_t)P.n_fx_cost * P.D * (P.D + 1) / 2;
   std::vector<void*> pool;
   CscOut o{};
   int* d_dims = nullptr;

@@ -132,8 +132,14 @@ TMX_KERNEL_LB(256) k_convexify(const DevProblem* P, const DevBatch* Bt, int forc
   convexify_terms(P, x, act, coef, Bt->coef2 + (size_t)b * P->n_link * D, rhs, smem, tid, NT, Bt->rowc + (size_t)b * R, Bt->qdyn + (size_t)b * P->NX);
   QpWs cwd;
   if (P->qp_dense)
+  {
+    const size_t fo = (size_t)b * P->n_fx_cost;
+    if (P->n_fx > 0)
+      convexify_func_terms(P, x, act, coef, rhs, Bt->fx_H + fo * D * D, Bt->fx_g + fo * D, Bt->fx_c + fo, Bt->fx_W + fo * 2 * D * D, tid, NT);
     qp_structure<true>(P, act, coef, Bt->coef2 + (size_t)b * P->n_link * D, rhs, x, Bt->trust[b], Bt->merit + (size_t)b * P->n_cnts,
-                       Bt->dims + 4 * b, Bt->hashes + 4 * b, nullptr, reinterpret_cast<int*>(smem), tid, NT, Bt->qdyn + (size_t)b * P->NX, nullptr);
+                       Bt->dims + 4 * b, Bt->hashes + 4 * b, nullptr, reinterpret_cast<int*>(smem), tid, NT, Bt->qdyn + (size_t)b * P->NX, nullptr,
+                       Bt->fx_H + fo * D * D, Bt->fx_g + fo * D);
+  }
   else
     qp_structure(P, act, coef, Bt->coef2 + (size_t)b * P->n_link * D, rhs, x, Bt->trust[b], Bt->merit + (size_t)b * P->n_cnts, Bt->dims + 4 * b,
                  Bt->hashes + 4 * b, nullptr, reinterpret_cast<int*>(smem), tid, NT, Bt->qdyn + (size_t)b * P->NX, compact_lists_of(cwd, P, Bt, b));
@@ -154,7 +160,8 @@ TMX_KERNEL k_export_csc(const DevProblem* P, const DevBatch* Bt, int b, CscOut o
   if (P->qp_dense)
     qp_structure<true>(P, Bt->active + (size_t)b * R, Bt->coef + (size_t)b * R * D, Bt->coef2 + (size_t)b * P->n_link * D,
                        Bt->rhs + (size_t)b * R, Bt->x + (size_t)b * P->NX, Bt->trust[b], Bt->merit + (size_t)b * P->n_cnts, dims_out, hashes_out,
-                       &out, reinterpret_cast<int*>(smem), tid, NT, Bt->qdyn + (size_t)b * P->NX, nullptr);
+                       &out, reinterpret_cast<int*>(smem), tid, NT, Bt->qdyn + (size_t)b * P->NX, nullptr,
+                       Bt->fx_H + (size_t)b * P->n_fx_cost * D * D, Bt->fx_g + (size_t)b * P->n_fx_cost * D);
   else
     qp_structure(P, Bt->active + (size_t)b * R, Bt->coef + (size_t)b * R * D, Bt->coef2 + (size_t)b * P->n_link * D, Bt->rhs + (size_t)b * R,
                  Bt->x + (size_t)b * P->NX, Bt->trust[b], Bt->merit + (size_t)b * P->n_cnts, dims_out, hashes_out, &out,
@@ -174,8 +181,8 @@ TMX_DEVFN void qp_solve_dense_block(const DevProblem* P, const DevBatch* Bt, int
   const int R = P->R, D = P->D, NX = P->NX, n_max = P->n_max, m_max = P->m_max;
   CscOut out;
   out.P_p = Bt->dq_Pp + (size_t)b * (n_max + 1);
-  out.P_i = Bt->dq_Pi + (size_t)b * (P->nnzP > 0 ? P->nnzP : 1);
-  out.P_x = Bt->dq_Px + (size_t)b * (P->nnzP > 0 ? P->nnzP : 1);
+  out.P_i = Bt->dq_Pi + (size_t)b * Bt->dq_nnzP;
+  out.P_x = Bt->dq_Px + (size_t)b * Bt->dq_nnzP;
   out.A_p = Bt->dq_Ap + (size_t)b * (n_max + 1);
   out.A_i = Bt->dq_Ai + (size_t)b * Bt->dq_nnzA;
   out.A_x = Bt->dq_Ax + (size_t)b * Bt->dq_nnzA;
@@ -187,7 +194,7 @@ TMX_DEVFN void qp_solve_dense_block(const DevProblem* P, const DevBatch* Bt, int
   const int* act = Bt->active + (size_t)b * R;
   qp_structure<true>(P, act, Bt->coef + (size_t)b * R * D, Bt->coef2 + (size_t)b * P->n_link * D, Bt->rhs + (size_t)b * R,
                      Bt->x + (size_t)b * NX, Bt->trust[b], Bt->merit + (size_t)b * P->n_cnts, dims, hs, &out, reinterpret_cast<int*>(smem), tid,
-                     NT, Bt->qdyn + (size_t)b * NX, nullptr);
+                     NT, Bt->qdyn + (size_t)b * NX, nullptr, Bt->fx_H + (size_t)b * P->n_fx_cost * D * D, Bt->fx_g + (size_t)b * P->n_fx_cost * D);
   // reference positions of rows / aux variables (LDS, layout of qp_structure) -> per-problem scratch
   QpWs w;
   double* scratch = Bt->qp_scratch + (size_t)b * Bt->qp_scratch_stride;

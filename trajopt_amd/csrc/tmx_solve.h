@@ -52,9 +52,12 @@ struct CscOut
 template <bool ST = false>
 TMX_DEVFN void qp_structure(const DevProblem* P, const int* active, const double* coef, const double* coef2, const double* rhs,
                             const double* xcur, double trust, const double* merit, int* dims, unsigned long long* hashes,
-                            const CscOut* out, int* iscratch, int tid, int NT, const double* qdyn = nullptr, QpWs* cw = nullptr)
+                            const CscOut* out, int* iscratch, int tid, int NT, const double* qdyn = nullptr, QpWs* cw = nullptr,
+                            const double* fxH = nullptr, const double* fxg = nullptr)
 {
   (void)coef2;
+  (void)fxH;
+  (void)fxg;
   const int D = P->D, T = P->T, NX = P->NX, R = P->R;
   int* colptr = iscratch;               // n_max + 1
   int* rowref = colptr + P->n_max + 1;  // R
@@ -353,6 +356,106 @@ TMX_DEVFN void qp_structure(const DevProblem* P, const int* active, const double
   }
   // P: static pattern over the primary vars (upper triangle): (v-D, v) if po != 0 ; (v, v) if pd != 0
   unsigned long long hP = 0ULL, wsP = 0ULL;
+  bool p_done = false;
+  if constexpr (ST)
+    if (fxH != nullptr && P->n_fx_cost > 0)
+    {
+      // DYNAMIC objective blocks of the CostFromFunc models (exprToEigen of their QuadExprs, solver_utils.cpp:49-109): for the
+      // variables (t, i <= j) of a waypoint with cost instances, P(i, j) += H_ij (i < j) and P(j, j) += 2 (H_jj / 2); a triplet exists
+      // where the coefficient is not exactly zero.  Column pointers = static ones + the dynamic entries in front.
+      p_done = true;
+      TMX_SYNC();
+      int* pextra = ccount;  // (the column counts of A are no longer needed)
+      auto dyn_val = [&](int t, int i, int j, bool& any) -> double {
+        double v = 0.0;
+        any = false;
+        for (int c = 0; c < P->n_fx; ++c)
+          if (P->fx_kind[c] != 2 && P->fx_t[c] == t)
+          {
+            const double h = fxH[(size_t)P->fx_ci[c] * D * D + i * D + j];
+            const double coeff = (i == j) ? h / 2 : h;  // the QuadExpr coefficient (modeling_utils.cpp:62, :100-106)
+            if (coeff != 0.0)
+            {
+              v += (i == j) ? 2.0 * coeff : coeff;
+              any = true;
+            }
+          }
+        return v;
+      };
+      for (int c = tid; c < NX; c += NT)
+      {
+        const int t = c / D, j = c % D;
+        int extra = 0;
+        bool any;
+        for (int i = 0; i < j; ++i)
+        {
+          dyn_val(t, i, j, any);
+          extra += any ? 1 : 0;
+        }
+        dyn_val(t, j, j, any);
+        if (any && P->pd[c] == 0.0)
+          ++extra;
+        pextra[c] = extra;
+      }
+      TMX_SYNC();
+      int tot_extra = 0;
+      for (int c = 0; c < NX; ++c)
+        tot_extra += pextra[c];
+      const int nnzP_dyn = P->nnzP + tot_extra;
+      const int pp_bytes = n + 1, pp_full = pp_bytes / 8, pp_rem = pp_bytes % 8;
+      const int pi_full = nnzP_dyn / 8, pi_rem = nnzP_dyn % 8;
+      auto emitP = [&](int row, double val, int& run) {
+        hP += tmx_hash_term(row, (uint64_t)run, 2);
+        if (run < pi_full)
+          wsP += tmx_hash_term(row, (uint64_t)run, 12);
+        else if (run == pi_full && pi_rem > 0)
+          wsP += tmx_hash_term((long long)((unsigned long long)row & ((1ULL << (8 * pi_rem)) - 1ULL)), (uint64_t)run, 12);
+        if (out)
+        {
+          out->P_i[run] = row;
+          out->P_x[run] = val;
+        }
+        ++run;
+      };
+      for (int c = tid; c <= n; c += NT)
+      {
+        int before = 0;
+        for (int q = 0; q < (c < NX ? c : NX); ++q)
+          before += pextra[q];
+        int run = ((c <= NX) ? P->p_colptr[c] : P->nnzP) + before;
+        const long long val = run;
+        hP += tmx_hash_term(val, (uint64_t)c, 1);
+        if (c < pp_full)
+          wsP += tmx_hash_term(val, (uint64_t)c, 11);
+        else if (c == pp_full && pp_rem > 0)
+          wsP += tmx_hash_term((long long)((unsigned long long)val & ((1ULL << (8 * pp_rem)) - 1ULL)), (uint64_t)c, 11);
+        if (out)
+          out->P_p[c] = val;
+        if (c == n)
+          dims[2] = nnzP_dyn;
+        if (c < NX)
+        {
+          const int t = c / D, j = c % D;
+          for (int back = 3; back >= 1; --back)
+          {
+            const double* pb = (back == 3) ? P->po3 : ((back == 2) ? P->po2 : P->po);
+            if (t >= back && pb[c - back * D] != 0.0)
+              emitP(c - back * D, pb[c - back * D], run);
+          }
+          bool any;
+          for (int i = 0; i < j; ++i)
+          {
+            const double v = dyn_val(t, i, j, any);
+            if (any)
+              emitP(c - j + i, v, run);
+          }
+          const double dv = dyn_val(t, j, j, any);
+          if (P->pd[c] != 0.0 || any)
+            emitP(c, P->pd[c] + dv, run);
+        }
+      }
+    }
+  if (!p_done)
   {
     const int pp_bytes = n + 1, pp_full = pp_bytes / 8, pp_rem = pp_bytes % 8;
     const int pi_full = P->nnzP / 8, pi_rem = P->nnzP % 8;
@@ -441,7 +544,13 @@ TMX_DEVFN void qp_structure(const DevProblem* P, const int* active, const double
       out->A_p[c] = colptr[c];
     for (int v = tid; v < NX; v += NT)
     {
-      out->q[v] = primary_q(P, qdyn, v);
+      double qv = primary_q(P, qdyn, v);
+      if constexpr (ST)
+        if (fxg != nullptr)
+          for (int c = 0; c < P->n_fx; ++c)
+            if (P->fx_kind[c] != 2 && P->fx_t[c] == v / D)
+              qv += fxg[(size_t)P->fx_ci[c] * D + v % D];  // affexpr.coeffs of the CostFromFunc model
+      out->q[v] = qv;
       const double xi = fmin(fmax(xcur[v], P->jl[v % D]), P->ju[v % D]);
       const double lb = fmax(xi - trust, P->jl[v % D]), ub = fmin(xi + trust, P->ju[v % D]);
       out->l[mg + v] = fmax(lb, -TMX_OSQP_INFTY);
@@ -2031,6 +2140,15 @@ TMX_DEVFN void sqp_model_values(const DevProblem* P, const DevBatch* Bt, int b, 
         for (int v = 0; v < P->n_vel; ++v)
           if (P->vel_cost[v] == k)
             acc += vsum[v];
+        if constexpr (ST)
+          for (int c = 0; c < P->n_fx; ++c)
+            if (P->fx_kind[c] != 2 && P->fx_owner[c] == k)
+            {
+              // ConvexObjective::value of the CostFromFunc model: QuadExpr::value at the QP solution
+              const int ci = P->fx_ci[c];
+              const size_t o = (size_t)b * P->n_fx_cost + ci;
+              acc += fx_model_value(Bt->fx_H + o * D * D, Bt->fx_g + o * D, Bt->fx_c[o], xq + P->fx_t[c] * D, D);
+            }
         model_cost[k] = acc;
       }
       else

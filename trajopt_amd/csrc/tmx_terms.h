@@ -11,6 +11,7 @@
 #pragma once
 #include "tmx_types.h"
 #include "../../include/tmx_detmath.h"
+#include "../../include/tmx_expr.h"     // tmx_expr programs (function terms), shared with the oracle
 #include "../../include/tmx_geom.h"     // sphere / capsule obstacle contacts, shared with the oracle  // sin / cos / atan2 with a fixed IEEE operation sequence, shared with the oracle
 
 #define TMX_EPS_FD 1e-5       // sco DEFAULT_EPSILON, trajopt_sco/src/modeling_utils.cpp:13
@@ -441,6 +442,178 @@ TMX_DEVFN void lvs_end_gradient(const DevProblem* P, const double* q, int s, con
   sconst = scale * -gq;
 }
 
+// ---- function terms (tmx_expr programs): sco::CostFromFunc / ConstraintFromErrFunc, trajopt_sco/src/modeling_utils.cpp ----------
+TMX_DEVFN void fx_eval(const DevProblem* P, int inst, const double* x, double* out)
+{
+  tmx_expr_eval(P->fx_ops + 2 * P->fx_op0[inst], P->fx_nops[inst], P->fx_consts + P->fx_c0[inst], x, out);
+}
+TMX_DEVFN double fx_eval1(const DevProblem* P, int inst, const double* x)
+{
+  double o[TMX_EXPR_MAX_OUT];
+  fx_eval(P, inst, x, o);
+  return o[0];
+}
+// forwardNumGrad(f, eps)(x)  (num_diff.cpp:41-54, sco/num_diff.hpp): g_i = (f(x + eps e_i) - f(x)) / eps; x is restored
+TMX_DEVFN void fx_forward_grad(const DevProblem* P, int inst, double* x, int k, double* g)
+{
+  const double y = fx_eval1(P, inst, x);
+  for (int i = 0; i < k; ++i)
+  {
+    const double xi = x[i];
+    x[i] = xi + TMX_EPS_FD;
+    const double yp = fx_eval1(P, inst, x);
+    g[i] = (yp - y) / TMX_EPS_FD;
+    x[i] = xi;
+  }
+}
+// eigen-decomposition of the symmetric k x k matrix A (row-major, overwritten by its diagonal form), eigenvectors in the columns
+// of V: cyclic Jacobi rotations.  Stands in for Eigen::SelfAdjointEigenSolver (modeling_utils.cpp:77): the projection on the
+// positive eigenspace computed from it is a matrix function of A and does not depend on the method beyond rounding.
+TMX_DEVFN void sym_eig_jacobi(double* A, double* V, int k)
+{
+  for (int i = 0; i < k; ++i)
+    for (int j = 0; j < k; ++j)
+      V[i * k + j] = (i == j) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 60; ++sweep)
+  {
+    double off = 0.0, diag = 0.0;
+    for (int i = 0; i < k; ++i)
+      for (int j = 0; j < k; ++j)
+        if (i != j)
+          off += A[i * k + j] * A[i * k + j];
+        else
+          diag += A[i * k + j] * A[i * k + j];
+    if (!(off > 1e-32 * (diag + off)) || off == 0.0)
+      break;
+    for (int p = 0; p < k - 1; ++p)
+      for (int q = p + 1; q < k; ++q)
+      {
+        const double apq = A[p * k + q];
+        if (apq == 0.0)
+          continue;
+        const double theta = (A[q * k + q] - A[p * k + p]) / (2.0 * apq);
+        const double t = ((theta >= 0.0) ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+        for (int r = 0; r < k; ++r)  // A <- A J
+        {
+          const double arp = A[r * k + p], arq = A[r * k + q];
+          A[r * k + p] = c * arp - sn * arq;
+          A[r * k + q] = sn * arp + c * arq;
+        }
+        for (int r = 0; r < k; ++r)  // A <- J' A
+        {
+          const double apr = A[p * k + r], aqr = A[q * k + r];
+          A[p * k + r] = c * apr - sn * aqr;
+          A[q * k + r] = sn * apr + c * aqr;
+        }
+        for (int r = 0; r < k; ++r)
+        {
+          const double vrp = V[r * k + p], vrq = V[r * k + q];
+          V[r * k + p] = c * vrp - sn * vrq;
+          V[r * k + q] = sn * vrp + c * vrq;
+        }
+      }
+  }
+}
+// CostFromFunc::convex (modeling_utils.cpp:52-113) for cost instance `inst` at the waypoint values q: quadratic model
+//   c + g . x + sum_i (H_ii / 2) x_i^2 + sum_{i<j} H_ij x_i x_j   ->  H (k x k, diagonal form: off-diagonals zero), g, c
+TMX_DEVFN void fx_convexify_cost(const DevProblem* P, int inst, const double* q, int k, double* H, double* g, double* cst, double* W)
+{
+  double x[TMX_MAX_DOF];
+  for (int i = 0; i < k; ++i)
+    x[i] = q[i];
+  if (P->fx_kind[inst] == 0)
+  {
+    // calcGradAndDiagHess (num_diff.cpp:70-91), hess = max(hess, 0)
+    const double y = fx_eval1(P, inst, x);
+    double gx = 0.0, xhx = 0.0;
+    for (int i = 0; i < k * k; ++i)
+      H[i] = 0.0;
+    for (int i = 0; i < k; ++i)
+    {
+      const double xi = x[i];
+      x[i] = xi + TMX_EPS_FD / 2;
+      const double yplus = fx_eval1(P, inst, x);
+      x[i] = xi - TMX_EPS_FD / 2;
+      const double yminus = fx_eval1(P, inst, x);
+      x[i] = xi;
+      const double gi = (yplus - yminus) / TMX_EPS_FD;
+      double hi = (yplus + yminus - 2 * y) / (TMX_EPS_FD * TMX_EPS_FD / 4);
+      hi = fmax(hi, 0.0);
+      H[i * k + i] = hi;
+      g[i] = gi;
+    }
+    for (int i = 0; i < k; ++i)
+    {
+      gx += g[i] * x[i];
+      xhx += x[i] * (H[i * k + i] * x[i]);
+    }
+    *cst = y - gx + .5 * xhx;
+    for (int i = 0; i < k; ++i)
+      g[i] = g[i] - H[i * k + i] * x[i];
+    return;
+  }
+  // calcGradHess (num_diff.cpp:93-105): grad = forward gradient, hess = forward Jacobian of the forward gradient, symmetrised
+  double* Hn = W;          // k x k
+  double* V = W + k * k;   // k x k
+  double g0[TMX_MAX_DOF], g1[TMX_MAX_DOF];
+  const double y = fx_eval1(P, inst, x);
+  fx_forward_grad(P, inst, x, k, g0);
+  for (int i = 0; i < k; ++i)
+  {
+    const double xi = x[i];
+    x[i] = xi + TMX_EPS_FD;
+    fx_forward_grad(P, inst, x, k, g1);
+    for (int r = 0; r < k; ++r)
+      Hn[r * k + i] = (g1[r] - g0[r]) / TMX_EPS_FD;
+    x[i] = xi;
+  }
+  for (int i = 0; i < k; ++i)
+    for (int j = i; j < k; ++j)
+    {
+      const double sy = (Hn[i * k + j] + Hn[j * k + i]) / 2;
+      H[i * k + j] = sy;  // (H as scratch for the symmetric matrix; rebuilt below)
+      H[j * k + i] = sy;
+    }
+  for (int i = 0; i < k * k; ++i)
+    Hn[i] = H[i];
+  sym_eig_jacobi(Hn, V, k);
+  for (int i = 0; i < k * k; ++i)
+    H[i] = 0.0;
+  for (int e = 0; e < k; ++e)
+    if (Hn[e * k + e] > 0)
+      for (int i = 0; i < k; ++i)
+        for (int j = 0; j < k; ++j)
+          H[i * k + j] += Hn[e * k + e] * V[i * k + e] * V[j * k + e];
+  double gx = 0.0, xhx = 0.0;
+  for (int i = 0; i < k; ++i)
+  {
+    double hx = 0.0;
+    for (int j = 0; j < k; ++j)
+      hx += H[i * k + j] * x[j];
+    g1[i] = hx;
+    gx += g0[i] * x[i];
+    xhx += x[i] * hx;
+  }
+  *cst = y - gx + .5 * xhx;
+  for (int i = 0; i < k; ++i)
+    g[i] = g0[i] - g1[i];
+}
+// QuadExpr::value of that model at the waypoint values xq (the (i, i) terms carry H_ii / 2, the (i < j) terms H_ij)
+TMX_DEVFN double fx_model_value(const double* H, const double* g, double cst, const double* xq, int k)
+{
+  double v = cst;
+  for (int i = 0; i < k; ++i)
+    v += g[i] * xq[i];
+  for (int i = 0; i < k; ++i)
+  {
+    v += (H[i * k + i] / 2) * xq[i] * xq[i];
+    for (int j = i + 1; j < k; ++j)
+      v += H[i * k + j] * xq[i] * xq[j];
+  }
+  return v;
+}
+
 // number of entries per joint of a squared joint cost minus (last_step - first_step): position 1, velocity 0, acc -1, jerk -2
 template <bool ST>
 TMX_DEVFN int vel_len_adj(int pk)
@@ -567,8 +740,8 @@ TMX_DEVFN void evaluate_terms(const DevProblem* P, const double* xv, double* cos
       v = P->slot_iscnt[r] ? ((e > 0) ? e : 0.0) : fabs(e);
     }
 #endif
-    // cart-pose slots are written by the instance loop below (another thread, no barrier in between): never store here
-    if (kind != SLOT_CARTPOSE)
+    // cart-pose (and function) slots are written by the instance loops below (another thread, no barrier in between): never store here
+    if (kind != SLOT_CARTPOSE && kind != SLOT_FUNC)
       scratch[r] = v;
   }
   // cart-pose instances: |coeff_i * err_i| (constraint violation) or abs cost
@@ -592,6 +765,22 @@ TMX_DEVFN void evaluate_terms(const DevProblem* P, const double* xv, double* cos
       scratch[s0 + i] = P->cp_iscnt[c] ? fabs(e * cc) : fabs(e) * cc;
     }
   }
+  if constexpr (ST)
+    for (int c = tid; c < P->n_fx; c += NT)
+      if (P->fx_kind[c] == 2)
+      {
+        // ConstraintFromErrFunc::value (modeling_utils.cpp:238-245): err * coeffs; violation |.| (EQ) / pospart (INEQ)
+        double o[TMX_EXPR_MAX_OUT];
+        fx_eval(P, c, xv + P->fx_t[c] * D, o);
+        int r = P->fx_slot0[c];
+        for (int i = 0; i < P->fx_nout[c] && r < P->R; ++i)
+          if (P->slot_kind[r] == SLOT_FUNC && P->slot_sub2[r] == c && P->slot_sub[r] == i)
+          {
+            const double e = o[i] * P->slot_scale[r];
+            scratch[r] = P->slot_eq[r] ? fabs(e) : ((e > 0) ? e : 0.0);
+            ++r;
+          }
+      }
   // owner key of every slot (cost owners first, then constraint owners; -1 = contributes nothing)
   int* keys = reinterpret_cast<int*>(scratch + P->R);
   for (int r = tid; r < P->R; r += NT)
@@ -637,10 +826,66 @@ TMX_DEVFN void evaluate_terms(const DevProblem* P, const double* xv, double* cos
       for (int v = 0; v < P->n_vel; ++v)
         if (P->vel_cost[v] == k)
           acc += vsum[v];
+      if constexpr (ST)
+        for (int c = 0; c < P->n_fx; ++c)
+          if (P->fx_kind[c] != 2 && P->fx_owner[c] == k)
+            acc += fx_eval1(P, c, xv + P->fx_t[c] * D);  // CostFromFunc::value (modeling_utils.cpp:46-50)
       cost_out[k] = acc;
     }
     else
       viol_out[k - P->n_costs] = acc;
+  }
+  TMX_SYNC();
+}
+
+// Function terms at the convexification point (piecewise kernels of qp_dense problems only): ConstraintFromErrFunc::convex rows
+// (modeling_utils.cpp:247-269: forward-difference Jacobian, affFromValGrad, optional row scale) and the quadratic models of the
+// CostFromFunc instances.  One thread per instance: the evaluations of an instance are sequential by definition
+// (x is perturbed in place), the instances are independent.
+TMX_DEVFN void convexify_func_terms(const DevProblem* P, const double* xv, int* active, double* coef, double* rhs, double* fxH, double* fxg,
+                                    double* fxc, double* fxW, int tid, int NT)
+{
+  const int D = P->D;
+  for (int c = tid; c < P->n_fx; c += NT)
+  {
+    const double* q = xv + P->fx_t[c] * D;
+    if (P->fx_kind[c] != 2)
+    {
+      const int ci = P->fx_ci[c];
+      fx_convexify_cost(P, c, q, D, fxH + (size_t)ci * D * D, fxg + (size_t)ci * D, fxc + ci, fxW + (size_t)ci * 2 * D * D);
+      continue;
+    }
+    double x[TMX_MAX_DOF], y[TMX_EXPR_MAX_OUT], yp[TMX_EXPR_MAX_OUT];
+    double J[TMX_EXPR_MAX_OUT][TMX_MAX_DOF];
+    for (int i = 0; i < D; ++i)
+      x[i] = q[i];
+    const int no = P->fx_nout[c];
+    fx_eval(P, c, x, y);  // calcForwardNumJac evaluates f(x) first (num_diff.cpp:57), convex() once more for y (:252): same value
+    for (int i = 0; i < D; ++i)
+    {
+      const double xi = x[i];
+      x[i] = xi + TMX_EPS_FD;
+      fx_eval(P, c, x, yp);
+      for (int o = 0; o < no; ++o)
+        J[o][i] = (yp[o] - y[o]) / TMX_EPS_FD;
+      x[i] = xi;
+    }
+    int r = P->fx_slot0[c];
+    for (int o = 0; o < no && r < P->R; ++o)
+    {
+      if (!(P->slot_kind[r] == SLOT_FUNC && P->slot_sub2[r] == c && P->slot_sub[r] == o))
+        continue;  // row dropped at upload (zero coefficient, :258-259)
+      double dot = 0.0;
+      for (int k = 0; k < D; ++k)
+        dot += J[o][k] * x[k];
+      const double cc = P->slot_scale[r];
+      const double constant = (y[o] - dot) * cc;
+      for (int k = 0; k < D; ++k)
+        coef[r * D + k] = (fabs(J[o][k]) > TMX_CLEANUP_TOL) ? J[o][k] * cc : 0.0;
+      rhs[r] = -constant;
+      active[r] = 1;
+      ++r;
+    }
   }
   TMX_SYNC();
 }

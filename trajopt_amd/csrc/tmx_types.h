@@ -24,6 +24,7 @@ enum
   SLOT_JOINTVEL = 5,       // JointVelEqConstraint row  coeff * (x[t+1][j] - x[t][j] - target) == 0 -> abs (2 aux)
   SLOT_JOINTVEL_INEQ = 6,  // JointVelIneqCost / JointVelIneqConstraint row (upper: sub2 = 0, lower: sub2 = 1) -> hinge (1 aux)
   SLOT_COLLISION_LVS = 7,  // contact of a link sphere with an obstacle on the segment (t, t+1): LVS_DISCRETE / LVS_CONTINUOUS -> hinge
+  SLOT_FUNC = 9,           // row i (slot_sub) of a ConstraintFromErrFunc over a tmx_expr program, instance slot_sub2: EQ -> abs (2 aux) | INEQ -> hinge (1 aux)
   SLOT_CARTVEL = 8         // CartVel row i (0..5) of segment (t, t+1): +-(p[t+1] - p[t]) - max_displacement; ABS cost (2 aux) or INEQ constraint -> hinge (1 aux)
 };
 #ifndef TMX_LINK_ROWS
@@ -91,6 +92,13 @@ struct DevProblem
   double *po2, *po3;  // NX each (zero where absent)
   int n_stencil;      // number of rows of order >= 2
   int qp_dense;
+  // FUNCTION TERMS (sco::CostFromFunc / ConstraintFromErrFunc over tmx_expr programs, include/tmx_expr.h): one instance per (term,
+  // step).  Cost instances own a DYNAMIC quadratic model (DevBatch::fx_H / fx_g / fx_c, rebuilt by every convexification), so
+  // P changes with the iterate: qp_dense problems only.
+  int n_fx, n_fx_cost;
+  int *fx_t, *fx_kind, *fx_owner, *fx_op0, *fx_nops, *fx_c0, *fx_nout, *fx_slot0, *fx_ci;  // fx_kind: 0 cost (diag Hessian), 1 cost (full), 2 constraint
+  int *fx_ops;        // all programs, (opcode, argument) pairs
+  double *fx_consts;
 };
 TMX_HOSTDEVFN int slot_is_diff(int kind) { return kind == SLOT_JOINTVEL || kind == SLOT_JOINTVEL_INEQ; }
 
@@ -141,7 +149,10 @@ struct DevBatch
   double *dq_ws;                               // B x dq_ws_stride doubles
   long long dq_ws_stride;
   int dq_nnzA;                                 // capacity of A per problem
+  int dq_nnzP;                                 // capacity of P per problem (static pattern + the dynamic blocks of the function costs)
   tmx_qp_info* dq_info;                        // B
+  // dynamic quadratic models of the function costs: B x n_fx_cost x (D*D | D | 1); fx_W: B x n_fx_cost x 2 D*D of work space
+  double *fx_H, *fx_g, *fx_c, *fx_W;
 };
 
 // The ADMM loop of the dense fast path as separately compiled device functions (tmx_solve.h: qp_admm_fast_nl /

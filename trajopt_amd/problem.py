@@ -152,6 +152,90 @@ class JointJerkTermInfo(JointVelTermInfo):
     ORDER = 3
 
 
+class Ex:
+    """Expression over the variables x[0 .. n_dof) of one waypoint, compiled to a tmx_expr stack program (include/tmx.h): the
+    device-evaluable stand-in for the reference's host callbacks sco::ScalarOfVector / VectorOfVector.
+        f = sq(Ex.var(0)) + sq(Ex.var(1) - 1)"""
+
+    def __init__(self, code, consts):
+        self.code, self.consts = code, consts    # code: list of (opcode, argument | float for constants)
+
+    @staticmethod
+    def var(i):
+        return Ex([(abi.OP_VAR, int(i))], [])
+
+    @staticmethod
+    def const(c):
+        return Ex([(abi.OP_CONST, float(c))], [])
+
+    @staticmethod
+    def _lift(v):
+        return v if isinstance(v, Ex) else Ex.const(v)
+
+    def _bin(self, other, op, swap=False):
+        a, b = (Ex._lift(other), self) if swap else (self, Ex._lift(other))
+        return Ex(a.code + b.code + [(op, 0)], [])
+
+    def __add__(self, o): return self._bin(o, abi.OP_ADD)
+    def __radd__(self, o): return self._bin(o, abi.OP_ADD, True)
+    def __sub__(self, o): return self._bin(o, abi.OP_SUB)
+    def __rsub__(self, o): return self._bin(o, abi.OP_SUB, True)
+    def __mul__(self, o): return self._bin(o, abi.OP_MUL)
+    def __rmul__(self, o): return self._bin(o, abi.OP_MUL, True)
+    def __truediv__(self, o): return self._bin(o, abi.OP_DIV)
+    def __rtruediv__(self, o): return self._bin(o, abi.OP_DIV, True)
+    def __neg__(self): return Ex(self.code + [(abi.OP_NEG, 0)], [])
+    def _un(self, op): return Ex(self.code + [(op, 0)], [])
+
+
+def sq(e): return Ex._lift(e)._un(abi.OP_SQ)
+def ex_sin(e): return Ex._lift(e)._un(abi.OP_SIN)
+def ex_cos(e): return Ex._lift(e)._un(abi.OP_COS)
+def ex_sqrt(e): return Ex._lift(e)._un(abi.OP_SQRT)
+
+
+def compile_program(outputs):
+    """[Ex, ...] -> (abi.Expr, keep-alive objects)"""
+    ops, consts = [], []
+    for k, e in enumerate(outputs):
+        for op, arg in Ex._lift(e).code:
+            if op == abi.OP_CONST:
+                consts.append(float(arg))
+                ops += [op, len(consts) - 1]
+            else:
+                ops += [op, int(arg)]
+        ops += [abi.OP_OUT, k]
+    a_ops = (C.c_int32 * len(ops))(*ops)
+    a_c = (C.c_double * max(1, len(consts)))(*consts)
+    e = abi.Expr()
+    e.n_ops, e.n_consts, e.n_outputs = len(ops) // 2, len(consts), len(outputs)
+    e.ops = C.cast(a_ops, C.POINTER(C.c_int32))
+    e.consts = C.cast(a_c, C.POINTER(C.c_double))
+    return e, (a_ops, a_c)
+
+
+@dataclass
+class FuncCostTermInfo:
+    """sco::CostFromFunc (trajopt_sco/src/modeling_utils.cpp:41-113) over the variables of every step in [first_step, last_step]:
+    numerical gradient + diagonal Hessian, or the full numerical Hessian projected on its positive eigenspace"""
+    f: Ex
+    first_step: int = 0
+    last_step: int = -1
+    full_hessian: bool = False
+    name: str = "func_cost"
+
+
+@dataclass
+class FuncConstraintTermInfo:
+    """sco::ConstraintFromErrFunc without an analytic Jacobian (modeling_utils.cpp:213-269): g(x_t) == 0 (EQ) or <= 0 (INEQ)"""
+    g: Sequence[Ex]
+    first_step: int = 0
+    last_step: int = -1
+    ineq: bool = False
+    coeffs: Sequence[float] = ()
+    name: str = "func_cnt"
+
+
 @dataclass
 class JointPosTermInfo:
     """trajopt::JointPosTermInfo (constraint form), problem_description.cpp:1059-1176: hatch -> JointPosEqConstraint when
@@ -239,6 +323,9 @@ class ProblemConstructionInfo:
             return [f"{ti.name}_{i}" for i in range(ti.first_step, last + 1) if i not in list(ti.fixed_steps)]
         if isinstance(ti, CartVelTermInfo):       # one cost named after the term / one constraint "CartVel" per step (:1029-1050)
             return ["CartVel" if ti.is_constraint else ti.name] * (ti.last_step - ti.first_step + 1)
+        if isinstance(ti, (FuncCostTermInfo, FuncConstraintTermInfo)):   # one sco cost / constraint per step
+            last = ti.last_step if ti.last_step >= 0 else T - 1
+            return [ti.name] * (last - ti.first_step + 1)
         return [ti.name]
 
     def cost_names(self) -> List[str]:
@@ -249,6 +336,8 @@ class ProblemConstructionInfo:
         def is_ineq(ti):
             if isinstance(ti, (CollisionTermInfo, CartVelTermInfo)):
                 return True
+            if isinstance(ti, FuncConstraintTermInfo):
+                return ti.ineq
             if isinstance(ti, (JointPosTermInfo, JointVelTermInfo)):
                 return any(abs(x) >= 1e-5 for x in list(ti.upper_tols) + list(ti.lower_tols))
             return False
@@ -334,6 +423,22 @@ class ProblemConstructionInfo:
                 co = list(ti.coeffs) * D if len(ti.coeffs) == 1 else list(ti.coeffs)
                 t.coeffs[:D] = co
                 t.targets[:D] = list(ti.targets)
+            elif isinstance(ti, (FuncCostTermInfo, FuncConstraintTermInfo)):
+                is_cost = isinstance(ti, FuncCostTermInfo)
+                t.kind = abi.TERM_FUNC_COST if is_cost else abi.TERM_FUNC_CNT
+                t.is_constraint = 0 if is_cost else 1
+                t.first_step = ti.first_step
+                t.last_step = ti.last_step if ti.last_step >= 0 else T - 1
+                prog, keep = compile_program([ti.f] if is_cost else list(ti.g))
+                self._keep.append((prog, keep))
+                t.expr = C.pointer(prog)
+                if is_cost:
+                    t.full_hessian = 1 if ti.full_hessian else 0
+                else:
+                    t.cnt_type = 1 if ti.ineq else 0
+                    if len(ti.coeffs):
+                        t.has_coeffs = 1
+                        t.coeffs[:len(ti.coeffs)] = list(ti.coeffs)
             elif isinstance(ti, CartPoseTermInfo):
                 t.kind = abi.TERM_CART_POSE
                 t.first_step = t.last_step = ti.timestep
