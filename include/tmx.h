@@ -142,7 +142,13 @@ typedef enum
   /* sco::ConstraintFromErrFunc without an analytic Jacobian  modeling_utils.cpp:213-269 — a vector-valued tmx_expr program
      g(x_t) with n_outputs rows per step: EQ (cnt_type 0: g = 0) or INEQ (1: g <= 0); Jacobian by forward differences
      (calcForwardNumJac, num_diff.cpp:55-68); rows scaled by coeffs[i] when has_coeffs != 0 (a zero coefficient drops the row). */
-  TMX_TERM_FUNC_CNT = 22
+  TMX_TERM_FUNC_CNT = 22,
+  /* sco::CostFromErrFunc without an analytic Jacobian  modeling_utils.cpp:115-211 — the cost form of the same vector-valued
+     program: penalty_type 0 SQUARED (sum_i coeff_i err_i^2; convex(): exprSquare of the linearised rows), 1 ABS, 2 HINGE (rows
+     scaled by the coefficient, addAbs / addHinge with weight 1).  Together with TMX_TERM_FUNC_CNT this is what
+     trajopt::UserDefinedTermInfo::hatch builds (trajopt/src/problem_description.cpp:599-675), one per step in
+     [first_step, last_step] that is not in the term's fixed_steps.                                                        */
+  TMX_TERM_FUNC_ERR_COST = 23
 } tmx_term_kind;
 
 /* ---- device-evaluable functions: a stack program over the n_dof values x[0..n_dof) of one waypoint -----------------------
@@ -210,7 +216,7 @@ typedef struct
   int32_t full_hessian;
   int32_t cnt_type;    /* 0 EQ, 1 INEQ */
   int32_t has_coeffs;
-  int32_t pad3_;
+  int32_t penalty_type; /* TMX_TERM_FUNC_ERR_COST: sco::PenaltyType 0 SQUARED, 1 ABS, 2 HINGE (sco_common.hpp)               */
 } tmx_term;
 
 typedef struct

@@ -338,7 +338,8 @@ public:
   /** used by TermInfo::hatch: costs are hatched before constraints (problem_description.cpp:560-571).  `name` is the
       TermInfo name; collision terms expand to one cost / constraint "name_<step>" per non-fixed step (:1773, :1833) */
   /** a function term: the program is copied into the problem (the descriptor points at the copy) */
-  void addFuncTerm(tmx_term t, const std::vector<int32_t>& ops, const DblVec& consts, int n_outputs, const std::string& name)
+  void addFuncTerm(tmx_term t, const std::vector<int32_t>& ops, const DblVec& consts, int n_outputs, const std::string& name,
+                   const IntVec& fixed_steps = {})
   {
     auto prog = std::make_shared<FuncProgram>();
     prog->ops = ops;
@@ -350,7 +351,7 @@ public:
     prog->e.consts = prog->consts.data();
     programs_.push_back(prog);
     t.expr = &prog->e;
-    addTerm(t, {}, name);
+    addTerm(t, fixed_steps, name);
   }
   void addTerm(const tmx_term& t, const IntVec& fixed_steps = {}, const std::string& name = std::string())
   {
@@ -368,9 +369,13 @@ public:
     else if (t.kind == TMX_TERM_CART_VEL)  // one cost named after the term / one constraint "CartVel" per step (:1029-1050)
       for (int i = t.first_step; i <= t.last_step; ++i)
         names.push_back(t.is_constraint ? std::string("CartVel") : name);
-    else if (t.kind == TMX_TERM_FUNC_COST || t.kind == TMX_TERM_FUNC_CNT)  // one sco cost / constraint per step
+    else if (t.kind == TMX_TERM_FUNC_COST || t.kind == TMX_TERM_FUNC_CNT || t.kind == TMX_TERM_FUNC_ERR_COST)
+    {
+      // one sco cost / constraint per step; UserDefinedTermInfo appends the step (problem_description.cpp:611-630)
       for (int i = t.first_step; i <= t.last_step; ++i)
-        names.push_back(name);
+        if (std::find(fixed_steps.begin(), fixed_steps.end(), i) == fixed_steps.end())
+          names.push_back(t.kind == TMX_TERM_FUNC_COST ? name : name + "_" + std::to_string(i));
+    }
     else
       names.push_back(name);
     const bool ineq = t.kind == TMX_TERM_JOINT_POS_INEQ_CNT || t.kind == TMX_TERM_COLLISION_CNT || t.kind == TMX_TERM_JOINT_VEL_INEQ_CNT ||
@@ -710,6 +715,50 @@ struct FuncConstraintTermInfo : public TermInfo
     for (std::size_t i = 0; i < g.size(); ++i)
       g[i].emit(ops, consts, static_cast<int>(i));
     prob.addFuncTerm(t, ops, consts, static_cast<int>(g.size()), name);
+  }
+};
+
+/** trajopt::UserDefinedTermInfo (problem_description.hpp:570-600 ; hatch: problem_description.cpp:599-675) with the error function
+    given as Expr outputs instead of a host callback (numerical Jacobian, as the reference does without a jacobian_function):
+    TT_COST -> TrajOptCostFromErrFunc with cost_penalty_type, TT_CNT -> TrajOptConstraintFromErrFunc with constraint_type; one term
+    "name_<TYPE>_<step>" per step in [first_step, last_step] that is not in fixed_steps. */
+struct UserDefinedTermInfo : public TermInfo
+{
+  enum PenaltyType
+  {
+    SQUARED = 0,
+    ABS = 1,
+    HINGE = 2
+  };
+  std::vector<Expr> error_function;
+  int first_step = 0;
+  int last_step = -1;
+  DblVec coeff;
+  PenaltyType cost_penalty_type = SQUARED;
+  bool constraint_ineq = false;  // sco::ConstraintType: EQ (false) | INEQ
+  IntVec fixed_steps;
+  UserDefinedTermInfo() : TermInfo(TermType::TT_COST | TermType::TT_CNT) {}
+  void hatch(TrajOptProb& prob) override
+  {
+    if (error_function.empty() || error_function.size() > TMX_EXPR_MAX_OUT || (!coeff.empty() && coeff.size() != error_function.size()))
+      printAndThrow("UserDefinedTermInfo: 1 .. TMX_EXPR_MAX_OUT error outputs, one coefficient per output if any");
+    tmx_term t = detail::blankTerm();
+    const bool cnt = static_cast<bool>(term_type & TermType::TT_CNT) && !static_cast<bool>(term_type & TermType::TT_COST);
+    t.kind = cnt ? TMX_TERM_FUNC_CNT : TMX_TERM_FUNC_ERR_COST;
+    t.is_constraint = cnt ? 1 : 0;
+    t.first_step = first_step;
+    t.last_step = last_step <= -1 ? prob.GetNumSteps() - 1 : last_step;
+    t.cnt_type = constraint_ineq ? 1 : 0;
+    t.penalty_type = static_cast<int32_t>(cost_penalty_type);
+    t.has_coeffs = coeff.empty() ? 0 : 1;
+    for (std::size_t i = 0; i < coeff.size(); ++i)
+      t.coeffs[i] = coeff[i];
+    std::vector<int32_t> ops;
+    DblVec consts;
+    for (std::size_t i = 0; i < error_function.size(); ++i)
+      error_function[i].emit(ops, consts, static_cast<int>(i));
+    const std::string typ = cnt ? (constraint_ineq ? "INEQ" : "EQ") : (cost_penalty_type == ABS ? "ABS" : (cost_penalty_type == HINGE ? "HING" : "SQUARED"));
+    prob.addFuncTerm(t, ops, consts, static_cast<int>(error_function.size()), name + "_" + typ, fixed_steps);
   }
 };
 

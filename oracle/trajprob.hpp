@@ -1315,6 +1315,7 @@ inline TrajProblem constructProblem(const tmx_problem_desc& d, const double* ini
         // Hessian) / sco::ConstraintFromErrFunc with a forward-difference Jacobian, one per step (include/tmx.h)
         case TMX_TERM_FUNC_COST:
         case TMX_TERM_FUNC_CNT:
+        case TMX_TERM_FUNC_ERR_COST:
         {
           if (tmx_expr_check(tm.expr, D) != 0)
             throw std::runtime_error("function term: malformed tmx_expr program");
@@ -1323,6 +1324,8 @@ inline TrajProblem constructProblem(const tmx_problem_desc& d, const double* ini
           const int n_out = tm.expr->n_outputs;
           for (int t = tm.first_step; t <= tm.last_step; ++t)
           {
+            if (std::find(tm.fixed_steps, tm.fixed_steps + tm.n_fixed_steps, t) != tm.fixed_steps + tm.n_fixed_steps)
+              continue;  // UserDefinedTermInfo::fixed_steps (problem_description.cpp:608, :645)
             if (tm.kind == TMX_TERM_FUNC_COST)
             {
               ScalarOfVector f = [ops, consts](const DblVec& q) {
@@ -1342,6 +1345,13 @@ inline TrajProblem constructProblem(const tmx_problem_desc& d, const double* ini
               DblVec c;
               if (tm.has_coeffs)
                 c.assign(tm.coeffs, tm.coeffs + n_out);
+              if (tm.kind == TMX_TERM_FUNC_ERR_COST)
+              {
+                // TrajOptCostFromErrFunc without a Jacobian (UserDefinedTermInfo::hatch, problem_description.cpp:622-630)
+                const PenaltyType pt = tm.penalty_type == 0 ? SQUARED : (tm.penalty_type == 1 ? ABS : HINGE);
+                P.prob->addCost(std::make_shared<CostFromErrFunc>(g, MatrixOfVector(), P.traj_vars.row(t), c, pt, "func_err_cost"));
+                continue;
+              }
               P.prob->addConstraint(std::make_shared<ConstraintFromErrFunc>(g, MatrixOfVector(), P.traj_vars.row(t), c,
                                                                             tm.cnt_type == 1 ? INEQ : EQ, "func_cnt"));
             }

@@ -12,7 +12,7 @@ import pytest
 import parity_checks as pc
 from trajopt_amd import abi, runtime
 from trajopt_amd.problem import (BasicInfo, Ex, FuncConstraintTermInfo, FuncCostTermInfo, JointVelTermInfo, ProblemConstructionInfo,
-                                 Robot, _tf12, compile_program, ex_cos, ex_sin, ex_sqrt, sq)
+                                 Robot, UserDefinedTermInfo, _tf12, compile_program, ex_cos, ex_sin, ex_sqrt, sq)
 
 
 def free_vars(n):
@@ -168,4 +168,53 @@ def test_malformed_programs_are_refused(hostemu_lib):
     ctx = runtime.Context(0, hostemu_lib)
     with pytest.raises(RuntimeError, match="tmx_expr"):
         ctx.upload(pci.to_desc(), abi.default_sqp_params(), abi.default_osqp_settings())
+    ctx.close()
+
+
+# ---- trajopt::UserDefinedTermInfo (problem_description.cpp:599-675): TrajOptCostFromErrFunc with SQUARED / ABS / HINGE penalties and
+# TrajOptConstraintFromErrFunc, numerical Jacobians, coefficient vector, fixed_steps - the error function as tmx_expr expressions
+def _user_defined(penalty):
+    from trajopt_amd import configs
+    pci, s, g = configs.config_mini(with_joint_band=False)
+    n = pci.basic_info.n_steps
+    x = [Ex.var(i) for i in range(4)]
+    err = [ex_sin(x[0]) * x[1] - 0.2, x[2] + 0.5 * sq(x[3]) - 0.4, x[1] - x[2]]
+    pci.cost_infos.append(UserDefinedTermInfo(error_function=err, first_step=1, last_step=n - 2, coeff=[2.0, 0.0, 0.5],
+                                              cost_penalty_type=penalty, fixed_steps=[3, 4], name="user_cost"))
+    pci.cnt_infos.append(UserDefinedTermInfo(error_function=[x[0] + x[3] - 0.3], first_step=n // 2, last_step=n // 2 + 1, is_constraint=True,
+                                             constraint_ineq=True, name="user_cnt"))
+    return pci, s, g
+
+
+def _run_user_defined(ctx, orc, penalty, B):
+    from trajopt_amd import configs
+    pci, s, g = _user_defined(penalty)
+    n = pci.basic_info.n_steps
+    typ = {0: "SQUARED", 1: "ABS", 2: "HING"}[penalty]
+    user = [c for c in pci.cost_names() if c.startswith("user_cost_")]
+    assert user == [f"user_cost_{typ}_{i}" for i in range(1, n - 1) if i not in (3, 4)] and pci.cnt_names()[-1] == f"user_cnt_INEQ_{n // 2 + 1}"
+    x0 = configs.seeds_for(9, pci, s, g, B)
+    desc = pc.make_ctx_inputs(ctx, pci, x0)
+    pc.check_evaluate(ctx, orc, desc, x0, tol=1e-12)
+    for b in range(min(B, 2)):
+        pc.check_first_qp_structure(ctx, orc, desc, x0, b, val_tol=1e-9)
+    assert all(same for same, _ in pc.check_first_qp_solve(ctx, orc, desc, x0))
+    ctx.set_x0(x0)
+    r, o, same, dx = pc.check_full_sqp(ctx, orc, desc, x0, exact=False)
+    assert (r["status"] == o["status"]).all()
+    assert (dx < 1e-5).sum() >= B - 1, dx
+
+
+@pytest.mark.parametrize("penalty", [abi.PENALTY_SQUARED, abi.PENALTY_ABS, abi.PENALTY_HINGE])
+def test_user_defined_term_on_host(hostemu_lib, orc, penalty):
+    ctx = runtime.Context(0, hostemu_lib)
+    _run_user_defined(ctx, orc, penalty, 3)
+    ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("penalty", [abi.PENALTY_SQUARED, abi.PENALTY_ABS, abi.PENALTY_HINGE])
+def test_user_defined_term_on_device(gpu_ctx_factory, orc, penalty):
+    ctx = gpu_ctx_factory()
+    _run_user_defined(ctx, orc, penalty, 6)
     ctx.close()

@@ -165,7 +165,7 @@ def test_invalid_descriptions_are_rejected_with_the_reference_messages(emu):
         t = next(desc.terms[k] for k in range(desc.n_terms) if desc.terms[k].kind == abi.TERM_JOINT_VEL_COST)
         t.n_fixed_steps, t.fixed_steps = 1, arr
         return arr
-    expect(fixed_steps_on_a_joint_term, "only collision terms carry fixed steps")
+    expect(fixed_steps_on_a_joint_term, "only collision and function terms carry fixed steps")
 
     def bad_step_range(desc):
         coll_term(desc).last_step = desc.n_steps

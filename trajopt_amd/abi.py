@@ -54,7 +54,8 @@ class Expr(C.Structure):
 
 
 OP_VAR, OP_CONST, OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_NEG, OP_SQ, OP_SIN, OP_COS, OP_SQRT, OP_OUT = range(1, 13)
-TERM_FUNC_COST, TERM_FUNC_CNT = 21, 22
+TERM_FUNC_COST, TERM_FUNC_CNT, TERM_FUNC_ERR_COST = 21, 22, 23
+PENALTY_SQUARED, PENALTY_ABS, PENALTY_HINGE = 0, 1, 2     # sco::PenaltyType
 
 
 class Term(C.Structure):
@@ -81,7 +82,7 @@ class Term(C.Structure):
         ("full_hessian", C.c_int32),
         ("cnt_type", C.c_int32),
         ("has_coeffs", C.c_int32),
-        ("pad3_", C.c_int32),
+        ("penalty_type", C.c_int32),
     ]
 
 

@@ -461,9 +461,10 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
         return TMX_ERR_INVALID;
       }
       if (tm.n_fixed_steps < 0 || (tm.n_fixed_steps > 0 && tm.fixed_steps == nullptr) ||
-          (tm.n_fixed_steps > 0 && tm.kind != TMX_TERM_COLLISION_COST && tm.kind != TMX_TERM_COLLISION_CNT))
+          (tm.n_fixed_steps > 0 && tm.kind != TMX_TERM_COLLISION_COST && tm.kind != TMX_TERM_COLLISION_CNT && tm.kind != TMX_TERM_FUNC_COST &&
+           tm.kind != TMX_TERM_FUNC_CNT && tm.kind != TMX_TERM_FUNC_ERR_COST))
       {
-        ctx->err = "tmx_term.fixed_steps: only collision terms carry fixed steps";
+        ctx->err = "tmx_term.fixed_steps: only collision and function terms carry fixed steps";
         return TMX_ERR_INVALID;
       }
       for (int q = 0; q < tm.n_fixed_steps; ++q)
@@ -601,6 +602,7 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
         }
         case TMX_TERM_FUNC_COST:
         case TMX_TERM_FUNC_CNT:
+        case TMX_TERM_FUNC_ERR_COST:
         {
           // sco::CostFromFunc / sco::ConstraintFromErrFunc over a tmx_expr program of the waypoint's variables: one cost /
           // constraint per step (include/tmx.h).  The cost model is a dynamic quadratic: dense QP engine.
@@ -614,41 +616,57 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
             ctx->err = "function term: malformed tmx_expr program (opcode, index, stack discipline or outputs)";
             return TMX_ERR_INVALID;
           }
-          const bool is_cost = tm.kind == TMX_TERM_FUNC_COST;
-          if (is_cost && tm.expr->n_outputs != 1)
+          const bool is_cnt = tm.kind == TMX_TERM_FUNC_CNT;
+          if (tm.kind == TMX_TERM_FUNC_COST && tm.expr->n_outputs != 1)
           {
             ctx->err = "TMX_TERM_FUNC_COST: the program of a cost has one output";
             return TMX_ERR_INVALID;
           }
-          if (!is_cost && tm.cnt_type != 0 && tm.cnt_type != 1)
+          if (is_cnt && tm.cnt_type != 0 && tm.cnt_type != 1)
           {
             ctx->err = "TMX_TERM_FUNC_CNT: cnt_type must be 0 (EQ) or 1 (INEQ)";
             return TMX_ERR_INVALID;
           }
+          if (tm.kind == TMX_TERM_FUNC_ERR_COST && (tm.penalty_type < 0 || tm.penalty_type > 2))
+          {
+            ctx->err = "TMX_TERM_FUNC_ERR_COST: penalty_type must be 0 (SQUARED), 1 (ABS) or 2 (HINGE)";
+            return TMX_ERR_INVALID;
+          }
+          // instance kind: 0 / 1 CostFromFunc (diagonal / full Hessian), 2 constraint rows, 3 squared error cost, 4 abs / hinge cost rows
+          const int fk = tm.kind == TMX_TERM_FUNC_COST ? (tm.full_hessian ? 1 : 0) : (is_cnt ? 2 : (tm.penalty_type == 0 ? 3 : 4));
+          const bool quad = fk == 0 || fk == 1 || fk == 3;
           qp_dense = true;
+          // the row weights (coeffs, 1 when absent) sit in front of the program's constants
+          for (int i = 0; i < TMX_EXPR_MAX_OUT; ++i)
+            fx_consts.push_back((tm.has_coeffs && i < tm.expr->n_outputs) ? tm.coeffs[i] : 1.0);
           const int op0 = (int)fx_ops.size() / 2, c0 = (int)fx_consts.size();
           fx_ops.insert(fx_ops.end(), tm.expr->ops, tm.expr->ops + 2 * tm.expr->n_ops);
           fx_consts.insert(fx_consts.end(), tm.expr->consts, tm.expr->consts + tm.expr->n_consts);
           for (int t = tm.first_step; t <= tm.last_step; ++t)
           {
+            if (std::find(tm.fixed_steps, tm.fixed_steps + tm.n_fixed_steps, t) != tm.fixed_steps + tm.n_fixed_steps)
+              continue;  // UserDefinedTermInfo::fixed_steps (problem_description.cpp:608, :645)
             const int inst = (int)fx_t.size();
-            const int own = is_cost ? n_costs++ : n_cnts++;
+            const int own = is_cnt ? n_cnts++ : n_costs++;
             fx_t.push_back(t);
-            fx_kind.push_back(is_cost ? (tm.full_hessian ? 1 : 0) : 2);
+            fx_kind.push_back(fk);
             fx_owner.push_back(own);
             fx_op0.push_back(op0);
             fx_nops.push_back(tm.expr->n_ops);
             fx_c0.push_back(c0);
             fx_nout.push_back(tm.expr->n_outputs);
             fx_slot0.push_back((int)kind.size());
-            fx_ci.push_back(is_cost ? n_fx_cost++ : -1);
-            if (!is_cost)
+            fx_ci.push_back(quad ? n_fx_cost++ : -1);
+            if (!quad)
               for (int i = 0; i < tm.expr->n_outputs; ++i)
               {
                 const double cc = tm.has_coeffs ? tm.coeffs[i] : 1.0;
                 if (tm.has_coeffs && cc == 0)
-                  continue;  // modeling_utils.cpp:258-259
-                add_slot(SLOT_FUNC, t, i, inst, own, tm.cnt_type == 0 ? 2 : 1, 1, tm.cnt_type == 0 ? 1 : 0, 0.0, cc, 0.0, 0.0);
+                  continue;  // modeling_utils.cpp:175-176, :258-259
+                if (is_cnt)
+                  add_slot(SLOT_FUNC, t, i, inst, own, tm.cnt_type == 0 ? 2 : 1, 1, tm.cnt_type == 0 ? 1 : 0, 0.0, cc, 0.0, 0.0);
+                else  // ABS: exprScale(aff, weight); addAbs(aff, 1) -> two aux with objective 1; HINGE: one aux
+                  add_slot(SLOT_FUNC, t, i, inst, own, tm.penalty_type == 1 ? 2 : 1, 0, tm.penalty_type == 1 ? 1 : 0, 1.0, cc, 0.0, 0.0);
               }
           }
           break;

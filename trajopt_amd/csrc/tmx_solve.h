@@ -370,7 +370,7 @@ TMX_DEVFN void qp_structure(const DevProblem* P, const int* active, const double
         double v = 0.0;
         any = false;
         for (int c = 0; c < P->n_fx; ++c)
-          if (P->fx_kind[c] != 2 && P->fx_t[c] == t)
+          if (fx_is_quad(P->fx_kind[c]) && P->fx_t[c] == t)
           {
             const double h = fxH[(size_t)P->fx_ci[c] * D * D + i * D + j];
             const double coeff = (i == j) ? h / 2 : h;  // the QuadExpr coefficient (modeling_utils.cpp:62, :100-106)
@@ -548,7 +548,7 @@ TMX_DEVFN void qp_structure(const DevProblem* P, const int* active, const double
       if constexpr (ST)
         if (fxg != nullptr)
           for (int c = 0; c < P->n_fx; ++c)
-            if (P->fx_kind[c] != 2 && P->fx_t[c] == v / D)
+            if (fx_is_quad(P->fx_kind[c]) && P->fx_t[c] == v / D)
               qv += fxg[(size_t)P->fx_ci[c] * D + v % D];  // affexpr.coeffs of the CostFromFunc model
       out->q[v] = qv;
       const double xi = fmin(fmax(xcur[v], P->jl[v % D]), P->ju[v % D]);
@@ -2142,7 +2142,7 @@ TMX_DEVFN void sqp_model_values(const DevProblem* P, const DevBatch* Bt, int b, 
             acc += vsum[v];
         if constexpr (ST)
           for (int c = 0; c < P->n_fx; ++c)
-            if (P->fx_kind[c] != 2 && P->fx_owner[c] == k)
+            if (fx_is_quad(P->fx_kind[c]) && P->fx_owner[c] == k)
             {
               // ConvexObjective::value of the CostFromFunc model: QuadExpr::value at the QP solution
               const int ci = P->fx_ci[c];

@@ -522,6 +522,57 @@ TMX_DEVFN void fx_convexify_cost(const DevProblem* P, int inst, const double* q,
   double x[TMX_MAX_DOF];
   for (int i = 0; i < k; ++i)
     x[i] = q[i];
+  if (P->fx_kind[inst] == 3)
+  {
+    // CostFromErrFunc::convex, SQUARED (modeling_utils.cpp:166-190): per output i the linearised row aff = k + a . x
+    // (affFromValGrad with the 1e-7 clean-up), quad = exprSquare(aff) scaled by the weight: constant w k^2, linear 2 w k a_j,
+    // (j, j) coefficient w a_j^2, (j < l) coefficient 2 w a_j a_l - accumulated in the (H, g, c) form of this model
+    double y[TMX_EXPR_MAX_OUT], yp[TMX_EXPR_MAX_OUT];
+    double* J = W;  // n_out x k
+    const int no = P->fx_nout[inst];
+    fx_eval(P, inst, x, y);
+    for (int i = 0; i < k; ++i)
+    {
+      const double xi = x[i];
+      x[i] = xi + TMX_EPS_FD;
+      fx_eval(P, inst, x, yp);
+      for (int o = 0; o < no; ++o)
+        J[o * k + i] = (yp[o] - y[o]) / TMX_EPS_FD;
+      x[i] = xi;
+    }
+    for (int i = 0; i < k * k; ++i)
+      H[i] = 0.0;
+    for (int i = 0; i < k; ++i)
+      g[i] = 0.0;
+    double cacc = 0.0;
+    const double* wts = P->fx_consts + P->fx_c0[inst] - TMX_EXPR_MAX_OUT;  // the instance's weights sit in front of its constants
+    for (int o = 0; o < no; ++o)
+    {
+      const double w = wts[o];
+      if (w == 0)
+        continue;  // :175-176
+      double dot = 0.0;
+      for (int j = 0; j < k; ++j)
+        dot += J[o * k + j] * x[j];
+      const double kc = y[o] - dot;
+      cacc += (kc * kc) * w;
+      for (int j = 0; j < k; ++j)
+      {
+        const double aj = (fabs(J[o * k + j]) > TMX_CLEANUP_TOL) ? J[o * k + j] : 0.0;
+        g[j] += (2 * kc * aj) * w;
+        H[j * k + j] += 2.0 * ((aj * aj) * w);
+        for (int l = j + 1; l < k; ++l)
+        {
+          const double al = (fabs(J[o * k + l]) > TMX_CLEANUP_TOL) ? J[o * k + l] : 0.0;
+          const double v = (2 * aj * al) * w;
+          H[j * k + l] += v;
+          H[l * k + j] += v;
+        }
+      }
+    }
+    *cst = cacc;
+    return;
+  }
   if (P->fx_kind[inst] == 0)
   {
     // calcGradAndDiagHess (num_diff.cpp:70-91), hess = max(hess, 0)
@@ -767,17 +818,23 @@ TMX_DEVFN void evaluate_terms(const DevProblem* P, const double* xv, double* cos
   }
   if constexpr (ST)
     for (int c = tid; c < P->n_fx; c += NT)
-      if (P->fx_kind[c] == 2)
+      if (fx_is_rows(P->fx_kind[c]))
       {
-        // ConstraintFromErrFunc::value (modeling_utils.cpp:238-245): err * coeffs; violation |.| (EQ) / pospart (INEQ)
+        // ConstraintFromErrFunc::value (modeling_utils.cpp:238-245): err * coeffs; violation |.| (EQ) / pospart (INEQ).
+        // CostFromErrFunc::value, ABS / HINGE (:143-165): |err| or pospart(err), THEN times the coefficient
         double o[TMX_EXPR_MAX_OUT];
         fx_eval(P, c, xv + P->fx_t[c] * D, o);
         int r = P->fx_slot0[c];
         for (int i = 0; i < P->fx_nout[c] && r < P->R; ++i)
           if (P->slot_kind[r] == SLOT_FUNC && P->slot_sub2[r] == c && P->slot_sub[r] == i)
           {
-            const double e = o[i] * P->slot_scale[r];
-            scratch[r] = P->slot_eq[r] ? fabs(e) : ((e > 0) ? e : 0.0);
+            if (P->slot_iscnt[r])
+            {
+              const double e = o[i] * P->slot_scale[r];
+              scratch[r] = P->slot_eq[r] ? fabs(e) : ((e > 0) ? e : 0.0);
+            }
+            else
+              scratch[r] = (P->slot_eq[r] ? fabs(o[i]) : ((o[i] > 0) ? o[i] : 0.0)) * P->slot_scale[r];
             ++r;
           }
       }
@@ -828,8 +885,22 @@ TMX_DEVFN void evaluate_terms(const DevProblem* P, const double* xv, double* cos
           acc += vsum[v];
       if constexpr (ST)
         for (int c = 0; c < P->n_fx; ++c)
-          if (P->fx_kind[c] != 2 && P->fx_owner[c] == k)
-            acc += fx_eval1(P, c, xv + P->fx_t[c] * D);  // CostFromFunc::value (modeling_utils.cpp:46-50)
+          if (fx_is_quad(P->fx_kind[c]) && P->fx_owner[c] == k)
+          {
+            if (P->fx_kind[c] != 3)
+              acc += fx_eval1(P, c, xv + P->fx_t[c] * D);  // CostFromFunc::value (modeling_utils.cpp:46-50)
+            else
+            {
+              // CostFromErrFunc::value, SQUARED: (err^2 * coeffs).sum()  (:143-165)
+              double o[TMX_EXPR_MAX_OUT];
+              fx_eval(P, c, xv + P->fx_t[c] * D, o);
+              const double* wts = P->fx_consts + P->fx_c0[c] - TMX_EXPR_MAX_OUT;
+              double sacc = 0.0;
+              for (int i = 0; i < P->fx_nout[c]; ++i)
+                sacc += (o[i] * o[i]) * wts[i];
+              acc += sacc;
+            }
+          }
       cost_out[k] = acc;
     }
     else
@@ -849,7 +920,7 @@ TMX_DEVFN void convexify_func_terms(const DevProblem* P, const double* xv, int* 
   for (int c = tid; c < P->n_fx; c += NT)
   {
     const double* q = xv + P->fx_t[c] * D;
-    if (P->fx_kind[c] != 2)
+    if (fx_is_quad(P->fx_kind[c]))
     {
       const int ci = P->fx_ci[c];
       fx_convexify_cost(P, c, q, D, fxH + (size_t)ci * D * D, fxg + (size_t)ci * D, fxc + ci, fxW + (size_t)ci * 2 * D * D);

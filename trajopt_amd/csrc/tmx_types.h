@@ -96,11 +96,13 @@ struct DevProblem
   // step).  Cost instances own a DYNAMIC quadratic model (DevBatch::fx_H / fx_g / fx_c, rebuilt by every convexification), so
   // P changes with the iterate: qp_dense problems only.
   int n_fx, n_fx_cost;
-  int *fx_t, *fx_kind, *fx_owner, *fx_op0, *fx_nops, *fx_c0, *fx_nout, *fx_slot0, *fx_ci;  // fx_kind: 0 cost (diag Hessian), 1 cost (full), 2 constraint
+  int *fx_t, *fx_kind, *fx_owner, *fx_op0, *fx_nops, *fx_c0, *fx_nout, *fx_slot0, *fx_ci;  // fx_kind: 0 cost (diag Hessian), 1 cost (full), 2 constraint rows, 3 squared error cost, 4 abs / hinge error-cost rows
   int *fx_ops;        // all programs, (opcode, argument) pairs
   double *fx_consts;
 };
 TMX_HOSTDEVFN int slot_is_diff(int kind) { return kind == SLOT_JOINTVEL || kind == SLOT_JOINTVEL_INEQ; }
+TMX_HOSTDEVFN int fx_is_quad(int kind) { return kind == 0 || kind == 1 || kind == 3; }  // instance owns a dynamic quadratic model
+TMX_HOSTDEVFN int fx_is_rows(int kind) { return kind == 2 || kind == 4; }               // instance owns SLOT_FUNC rows
 
 struct DevBatch
 {

@@ -237,6 +237,22 @@ class FuncConstraintTermInfo:
 
 
 @dataclass
+class UserDefinedTermInfo:
+    """trajopt::UserDefinedTermInfo (problem_description.hpp:570-600; hatch problem_description.cpp:599-675) with the error function
+    as tmx_expr expressions instead of a host callback: TT_COST -> TrajOptCostFromErrFunc with cost_penalty_type (SQUARED / ABS /
+    HINGE), TT_CNT -> TrajOptConstraintFromErrFunc (EQ / INEQ); numerical Jacobian; one term per step that is not in fixed_steps"""
+    error_function: Sequence[Ex]
+    first_step: int = 0
+    last_step: int = -1
+    coeff: Sequence[float] = ()
+    is_constraint: bool = False
+    cost_penalty_type: int = 0            # abi.PENALTY_SQUARED | PENALTY_ABS | PENALTY_HINGE
+    constraint_ineq: bool = False
+    fixed_steps: Sequence[int] = ()
+    name: str = "user_defined"
+
+
+@dataclass
 class JointPosTermInfo:
     """trajopt::JointPosTermInfo (constraint form), problem_description.cpp:1059-1176: hatch -> JointPosEqConstraint when
     all tolerances are zero (doubleEquals, eps 1e-5), else JointPosIneqConstraint (trajectory_costs.cpp:185-255)"""
@@ -325,7 +341,13 @@ class ProblemConstructionInfo:
             return ["CartVel" if ti.is_constraint else ti.name] * (ti.last_step - ti.first_step + 1)
         if isinstance(ti, (FuncCostTermInfo, FuncConstraintTermInfo)):   # one sco cost / constraint per step
             last = ti.last_step if ti.last_step >= 0 else T - 1
+            if isinstance(ti, FuncConstraintTermInfo):
+                return [f"{ti.name}_{i}" for i in range(ti.first_step, last + 1)]
             return [ti.name] * (last - ti.first_step + 1)
+        if isinstance(ti, UserDefinedTermInfo):      # name_<TYPE>_<step> (problem_description.cpp:611-630, :648-656)
+            last = ti.last_step if ti.last_step >= 0 else T - 1
+            typ = ("INEQ" if ti.constraint_ineq else "EQ") if ti.is_constraint else {0: "SQUARED", 1: "ABS", 2: "HING"}[int(ti.cost_penalty_type)]
+            return [f"{ti.name}_{typ}_{i}" for i in range(ti.first_step, last + 1) if i not in list(ti.fixed_steps)]
         return [ti.name]
 
     def cost_names(self) -> List[str]:
@@ -338,6 +360,8 @@ class ProblemConstructionInfo:
                 return True
             if isinstance(ti, FuncConstraintTermInfo):
                 return ti.ineq
+            if isinstance(ti, UserDefinedTermInfo):
+                return ti.constraint_ineq
             if isinstance(ti, (JointPosTermInfo, JointVelTermInfo)):
                 return any(abs(x) >= 1e-5 for x in list(ti.upper_tols) + list(ti.lower_tols))
             return False
@@ -423,6 +447,24 @@ class ProblemConstructionInfo:
                 co = list(ti.coeffs) * D if len(ti.coeffs) == 1 else list(ti.coeffs)
                 t.coeffs[:D] = co
                 t.targets[:D] = list(ti.targets)
+            elif isinstance(ti, UserDefinedTermInfo):
+                t.kind = abi.TERM_FUNC_CNT if ti.is_constraint else abi.TERM_FUNC_ERR_COST
+                t.is_constraint = 1 if ti.is_constraint else 0
+                t.first_step = ti.first_step
+                t.last_step = ti.last_step if ti.last_step >= 0 else T - 1
+                prog, keep = compile_program(list(ti.error_function))
+                self._keep.append((prog, keep))
+                t.expr = C.pointer(prog)
+                t.cnt_type = 1 if ti.constraint_ineq else 0
+                t.penalty_type = int(ti.cost_penalty_type)
+                if len(ti.coeff):
+                    t.has_coeffs = 1
+                    t.coeffs[:len(ti.coeff)] = list(ti.coeff)
+                if len(ti.fixed_steps):
+                    fs = (C.c_int32 * len(ti.fixed_steps))(*[int(v) for v in ti.fixed_steps])
+                    self._keep.append(fs)
+                    t.n_fixed_steps = len(ti.fixed_steps)
+                    t.fixed_steps = C.cast(fs, C.POINTER(C.c_int32))
             elif isinstance(ti, (FuncCostTermInfo, FuncConstraintTermInfo)):
                 is_cost = isinstance(ti, FuncCostTermInfo)
                 t.kind = abi.TERM_FUNC_COST if is_cost else abi.TERM_FUNC_CNT
