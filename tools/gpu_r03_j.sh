@@ -2,5 +2,6 @@
 set -x
 O=gpurun_out/r03j; mkdir -p $O; rm -f $O/ab.log
 export TMPDIR=/tmp
-for c in 4 3; do timeout 600 python tools/time_configs_ab.py $c trajopt_amd/_build_prev/libtrajopt_mi355x.so trajopt_amd/_build_dc7/libtrajopt_mi355x.so trajopt_amd/_build/libtrajopt_mi355x.so >> $O/ab.log 2>&1; done
+for c in 4 3; do timeout 600 python tools/time_configs_ab.py $c trajopt_amd/_build_prev/libtrajopt_mi355x.so trajopt_amd/_build/libtrajopt_mi355x.so >> $O/ab.log 2>&1; done
+timeout 300 python tools/bench_libs.py 1024 trajopt_amd/_build_prev/libtrajopt_mi355x.so trajopt_amd/_build/libtrajopt_mi355x.so >> $O/ab.log 2>&1
 cat $O/ab.log

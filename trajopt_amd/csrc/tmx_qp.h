@@ -190,6 +190,7 @@ struct QpWs
   double *Mf, *Nb, *yb;
   int n_link;      // R2
   bool sweep_regs; // the dense-coupling chain sweeps keep their running vector in registers (set by qp_admm_generic_nl<., true> only)
+  bool sweep_inline; // ... and are inlined into the loop (LDS-resident kernels)
 #endif
 };
 
@@ -508,6 +509,7 @@ TMX_DEVFN void qp_ws_carve(QpWs& w, double* lds, double* glb, double* far, int D
   w.c2i = nullptr;
   w.n_link = R2;
   w.sweep_regs = false;
+  w.sweep_inline = false;
   if (R2 > 0)
   {
     if (!cf)
@@ -1735,8 +1737,15 @@ TMX_DEVFN bool tmx_in_lds(const void* p)
 }
 // (out of line: the sweep's 32 matrix registers stay out of the register allocation of the iteration loop around it - inlined, the
 //  512-thread HBM kernels of a problem WITHOUT pair rows, config 2, lost 16 %)
+TMX_DEVFN void chain_wave_sweep_body(const double* mat, const double* rhs, double* out, int D, int t0, int t1, int dir, int lane);
 __device__ __attribute__((noinline)) static void chain_wave_sweep_any(const double* mat, const double* rhs, double* out, int D, int t0, int t1,
                                                                       int dir, int lane)
+{
+  chain_wave_sweep_body(mat, rhs, out, D, t0, t1, dir, lane);
+}
+// (inlined where the caller has registers to spare: the LDS-resident kernels at one wave per SIMD - no save / restore of callee-saved
+//  registers around the two sweeps of every iteration)
+TMX_DEVFN void chain_wave_sweep_body(const double* mat, const double* rhs, double* out, int D, int t0, int t1, int dir, int lane)
 {
   typedef __attribute__((address_space(3))) double lds_w;
   typedef __attribute__((address_space(1))) double glb_w;
@@ -1777,7 +1786,12 @@ TMX_DEVFN void chain_solve_range(const QpWs& w, int t0, int t1, int tid, int NT)
       if (w.sweep_regs)
       {
         if (tid < 64)
-          chain_wave_sweep_any(w.Mf, w.tp, w.tp, D, t0, t1, +1, tid);
+        {
+          if (w.sweep_inline)
+            chain_wave_sweep_body(w.Mf, w.tp, w.tp, D, t0, t1, +1, tid);
+          else
+            chain_wave_sweep_any(w.Mf, w.tp, w.tp, D, t0, t1, +1, tid);
+        }
       }
       else if (tid < 64)
       {
@@ -1829,7 +1843,12 @@ TMX_DEVFN void chain_solve_range(const QpWs& w, int t0, int t1, int tid, int NT)
       if (w.sweep_regs)
       {
         if (tid < 64)
-          chain_wave_sweep_any(w.Nb, w.yb, w.tp, D, t0, t1, -1, tid);
+        {
+          if (w.sweep_inline)
+            chain_wave_sweep_body(w.Nb, w.yb, w.tp, D, t0, t1, -1, tid);
+          else
+            chain_wave_sweep_any(w.Nb, w.yb, w.tp, D, t0, t1, -1, tid);
+        }
       }
       else if (tid < 64)
       {

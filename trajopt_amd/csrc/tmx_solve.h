@@ -1126,6 +1126,7 @@ __device__ __attribute__((noinline)) static void qp_admm_generic_nl(const DevPro
 #endif
   rows_compact_attach(w);
   w.sweep_regs = PAIRS;
+  w.sweep_inline = PAIRS && !HBM;
   QpShared* sh = reinterpret_cast<QpShared*>(w.wself);
   w.rho = sh->rho;
   w.sigma = sh->sigma;
