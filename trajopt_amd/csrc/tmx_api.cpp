@@ -1146,7 +1146,8 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
     for (int k : kind)
       n_coll += (k == SLOT_COLLISION || k == SLOT_COLLISION_LVS) ? 1 : 0;
     const char* force = std::getenv("TMX_FORCE_COMPACT");  // test hook: "1" on (any size > 512 is not required on the host build), "0" off
-    const bool on = (force && force[0] == '1') || (!(force && force[0] == '0') && R >= 1024 && 2 * n_coll > R);
+    // (pair-row problems never take the dense fast path, so the lists pay at any size: config 4 - 478 slots, ~195 active rows - 17 %)
+    const bool on = (force && force[0] == '1') || (!(force && force[0] == '0') && (R >= 1024 || R2 > 0) && 2 * n_coll > R);
     if (on)
       P.coef_far |= 2;
   }
