@@ -1625,16 +1625,18 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
       unsigned lds_off = (unsigned)(size_t)(HBM ? chain_lds : smem);
       asm volatile("" : "+s"(lds_off));
     {
-      // instantiations: with / without pair rows; block size 7 (7-DOF arms: config 4) as a compile-time constant.  (A D = 10
+      // instantiations: with / without pair rows; block size 7 (7-DOF arms: configs 2 and 4) as a compile-time constant.  (A D = 10
       // instantiation for config 3 faulted in the 512-thread HBM kernel - memory access fault at address 0, not understood - and is
       // not built.)
       if (P->n_link > 0)
       {
-        if (!HBM && P->D == 7)
+        if (P->D == 7)
           qp_admm_generic_nl<HBM, true, 7>(P, Bt, b, lds_off, HBM ? smem : nullptr, chain_lds != nullptr ? 1 : 0);
         else
           qp_admm_generic_nl<HBM, true, 0>(P, Bt, b, lds_off, HBM ? smem : nullptr, chain_lds != nullptr ? 1 : 0);
       }
+      else if (HBM && P->D == 7)  // long horizons of 7-DOF arms (config 2)
+        qp_admm_generic_nl<HBM, false, 7>(P, Bt, b, lds_off, HBM ? smem : nullptr, chain_lds != nullptr ? 1 : 0);
       else
         qp_admm_generic_nl<HBM, false, 0>(P, Bt, b, lds_off, HBM ? smem : nullptr, chain_lds != nullptr ? 1 : 0);
     }
