@@ -102,17 +102,32 @@ void lowerKinematics(const ProblemConstructionInfo& pci, LoweredProblem& out)
         continue;
       for (const auto& col : link->collision)
       {
-        if (col->geometry->getType() != tesseract::geometry::GeometryType::SPHERE)
-          PRINT_AND_THROW("collision geometry of link " + link_name + " is not a sphere: not lowered by the device path");
-        const auto sphere = std::static_pointer_cast<const tesseract::geometry::Sphere>(col->geometry);
-        const Eigen::Vector3d c = (prev_link.inverse() * tf0.at(link_name) * col->origin).translation();
+        // spheres, and capsules (tesseract: a cylinder of `length` along the local z axis with hemispherical caps) as the sphere
+        // swept from one cap centre to the other (tmx_problem_desc::link_sphere_axes; discrete evaluators only)
+        const auto type = col->geometry->getType();
+        if (type != tesseract::geometry::GeometryType::SPHERE && type != tesseract::geometry::GeometryType::CAPSULE)
+          PRINT_AND_THROW("collision geometry of link " + link_name + " is neither a sphere nor a capsule: not lowered by the device path");
+        const Eigen::Isometry3d g = prev_link.inverse() * tf0.at(link_name) * col->origin;
+        double radius = 0.0, half = 0.0;
+        if (type == tesseract::geometry::GeometryType::SPHERE)
+          radius = std::static_pointer_cast<const tesseract::geometry::Sphere>(col->geometry)->getRadius();
+        else
+        {
+          const auto cap = std::static_pointer_cast<const tesseract::geometry::Capsule>(col->geometry);
+          radius = cap->getRadius();
+          half = 0.5 * cap->getLength();
+        }
+        const Eigen::Vector3d c = g * Eigen::Vector3d(0, 0, -half);
+        const Eigen::Vector3d a = g * Eigen::Vector3d(0, 0, half) - c;  // cap centre to cap centre
         tmx_link_sphere s{};
         s.link = k;
         s.center[0] = c.x();
         s.center[1] = c.y();
         s.center[2] = c.z();
-        s.radius = sphere->getRadius();
+        s.radius = radius;
         out.link_spheres.push_back(s);
+        for (int q = 0; q < 3; ++q)
+          out.link_sphere_axes.push_back(a[q]);
       }
     }
   }
@@ -126,16 +141,29 @@ void lowerKinematics(const ProblemConstructionInfo& pci, LoweredProblem& out)
       continue;
     for (const auto& col : link->collision)
     {
-      if (col->geometry->getType() != tesseract::geometry::GeometryType::SPHERE)
-        PRINT_AND_THROW("collision geometry of link " + link->getName() + " is not a sphere: not lowered by the device path");
-      const auto sphere = std::static_pointer_cast<const tesseract::geometry::Sphere>(col->geometry);
-      const Eigen::Vector3d c = (tf0.at(link->getName()) * col->origin).translation();
+      const auto type = col->geometry->getType();
+      if (type != tesseract::geometry::GeometryType::SPHERE && type != tesseract::geometry::GeometryType::CAPSULE)
+        PRINT_AND_THROW("collision geometry of link " + link->getName() + " is neither a sphere nor a capsule: not lowered by the device path");
+      const Eigen::Isometry3d g = tf0.at(link->getName()) * col->origin;
+      double radius = 0.0, half = 0.0;
+      if (type == tesseract::geometry::GeometryType::SPHERE)
+        radius = std::static_pointer_cast<const tesseract::geometry::Sphere>(col->geometry)->getRadius();
+      else
+      {
+        const auto cap = std::static_pointer_cast<const tesseract::geometry::Capsule>(col->geometry);
+        radius = cap->getRadius();
+        half = 0.5 * cap->getLength();
+      }
+      const Eigen::Vector3d c = g * Eigen::Vector3d(0, 0, -half);
+      const Eigen::Vector3d a = g * Eigen::Vector3d(0, 0, half) - c;  // cap centre to cap centre
       tmx_obstacle_sphere o{};
       o.center[0] = c.x();
       o.center[1] = c.y();
       o.center[2] = c.z();
-      o.radius = sphere->getRadius();
+      o.radius = radius;
       out.obstacles.push_back(o);
+      for (int q = 0; q < 3; ++q)
+        out.obstacle_axes.push_back(a[q]);
     }
   }
 }
@@ -313,6 +341,8 @@ void LoweredProblem::finalize()
   }
   desc.n_link_spheres = static_cast<int32_t>(link_spheres.size());
   desc.link_spheres = link_spheres.data();
+  desc.link_sphere_axes = (link_sphere_axes.size() == 3 * link_spheres.size() && !link_spheres.empty()) ? link_sphere_axes.data() : nullptr;
+  desc.obstacle_axes = (obstacle_axes.size() == 3 * obstacles.size() && !obstacles.empty()) ? obstacle_axes.data() : nullptr;
   desc.n_obstacles = static_cast<int32_t>(obstacles.size());
   desc.obstacles = obstacles.data();
   desc.n_fixed_steps = static_cast<int32_t>(fixed_steps.size());

@@ -258,6 +258,11 @@ typedef struct
      `center` to `center + axis`; a zero vector leaves it a sphere.  Contact data of link spheres against capsules:
      include/tmx_geom.h (closest point on the segment; swept link sphere vs capsule = closest points of two segments).   */
   const double* obstacle_axes;
+  /* optional, 3 doubles per link sphere in the LINK frame (NULL: all link primitives are spheres): link primitive s is the CAPSULE
+     swept by its sphere from `center` to `center + axis`; a zero vector leaves it a sphere.  Discrete evaluators only
+     (evaluator_type 0 / 1 / 2): the cast evaluators sweep link SPHERES between two states (the swept volume of a capsule is not a
+     capsule) and refuse capsule links at upload.                                                                        */
+  const double* link_sphere_axes;
 } tmx_problem_desc;
 
 typedef enum

@@ -95,4 +95,27 @@ TMX_GM_FN double tmx_swept_closest_to_obstacle(const double ca[3], const double 
   return s;
 }
 
+/* a LINK primitive against an obstacle primitive at one configuration: the link sphere (centre c, world frame) or, with a non-zero
+ * world axis e, the link CAPSULE swept by that sphere from c to c + e.  p = the point of the link's core (centre / segment) closest
+ * to the obstacle's core, q = the obstacle's closest core point; the caller subtracts both radii.  (A capsule link against a capsule
+ * obstacle is the two-segment problem of tmx_swept_closest_to_obstacle with the link's own axis in place of the sweep.) */
+TMX_GM_FN void tmx_link_closest_to_obstacle(const double c[3], const double* e, const double oc[3], const double* oa, double p[3], double q[3])
+{
+  double ee = 0.0;
+  if (e)
+    ee = e[0] * e[0] + e[1] * e[1] + e[2] * e[2];
+  if (!(ee > TMX_GM_EPS))
+  {
+    p[0] = c[0];
+    p[1] = c[1];
+    p[2] = c[2];
+    tmx_obstacle_closest_to_point(oc, oa, c, q);
+    return;
+  }
+  const double s = tmx_swept_closest_to_obstacle(c, e, oc, oa, q);
+  p[0] = c[0] + s * e[0];
+  p[1] = c[1] + s * e[1];
+  p[2] = c[2] + s * e[2];
+}
+
 #endif /* TMX_GEOM_H_ */

@@ -134,6 +134,7 @@ struct JointGroup
   Transform tool;                 // last link -> tip_link frame (tcp)
   std::string tip_link;           // the link the tool frame is attached to
   std::vector<tmx_link_sphere> link_spheres;
+  std::vector<double> link_sphere_axes;  // ... or capsules: 3 per link sphere, link frame (swept from centre to centre + axis); empty = all spheres
   std::size_t numJoints() const { return joints.size(); }
 };
 
@@ -415,6 +416,7 @@ public:
     std::copy(kin_->tool.m.begin(), kin_->tool.m.end(), d.tool);
     d.n_link_spheres = static_cast<int32_t>(kin_->link_spheres.size());
     d.link_spheres = kin_->link_spheres.data();
+    d.link_sphere_axes = (kin_->link_sphere_axes.size() == 3 * kin_->link_spheres.size() && !kin_->link_spheres.empty()) ? kin_->link_sphere_axes.data() : nullptr;
     d.n_obstacles = static_cast<int32_t>(env_ ? env_->obstacles.size() : 0);
     d.obstacles = env_ ? env_->obstacles.data() : nullptr;
     d.obstacle_axes = (env_ && env_->obstacle_axes.size() == 3 * env_->obstacles.size() && !env_->obstacles.empty()) ? env_->obstacle_axes.data() : nullptr;

@@ -793,6 +793,20 @@ struct Scene
   std::vector<tmx_obstacle_sphere> obstacles;
   std::vector<double> obstacle_axes;  // 3 per obstacle (capsule = sphere swept from centre to centre + axis); empty: spheres
   const double* axisOf(std::size_t o) const { return obstacle_axes.empty() ? nullptr : obstacle_axes.data() + 3 * o; }
+  std::vector<double> link_axes;  // 3 per link sphere, link frame (capsule link = sphere swept from centre to centre + axis); empty: spheres
+  // world axis of link primitive s under the link pose T (false: a sphere)
+  template <class TF>
+  bool linkAxisWorld(std::size_t s, const TF& T, double e[3]) const
+  {
+    if (link_axes.empty())
+      return false;
+    const double* a = link_axes.data() + 3 * s;
+    if (a[0] == 0.0 && a[1] == 0.0 && a[2] == 0.0)
+      return false;
+    for (int r = 0; r < 3; ++r)
+      e[r] = T.R[3 * r + 0] * a[0] + T.R[3 * r + 1] * a[1] + T.R[3 * r + 2] * a[2];
+    return true;
+  }
 };
 struct Contact
 {
@@ -818,9 +832,11 @@ inline void calcContacts(const Chain& chain, const Scene& scene, const double* q
     for (std::size_t o = 0; o < scene.obstacles.size(); ++o)
     {
       const auto& ob = scene.obstacles[o];
-      double oq[3];  // closest point of the obstacle primitive to the sphere centre (the centre itself for a sphere)
-      tmx_obstacle_closest_to_point(ob.center, scene.axisOf(o), c, oq);
-      const double d[3] = { oq[0] - c[0], oq[1] - c[1], oq[2] - c[2] };
+      double oq[3];  // closest point of the obstacle primitive to the link primitive's core (sphere centre / capsule segment)
+      double e[3], pc[3];
+      const bool capsule = scene.linkAxisWorld(s, T, e);
+      tmx_link_closest_to_obstacle(c, capsule ? e : nullptr, ob.center, scene.axisOf(o), pc, oq);
+      const double d[3] = { oq[0] - pc[0], oq[1] - pc[1], oq[2] - pc[2] };
       const double len = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
       const double dist = len - ls.radius - ob.radius;
       if (dist > (margin + buffer))
@@ -833,7 +849,7 @@ inline void calcContacts(const Chain& chain, const Scene& scene, const double* q
       for (int r = 0; r < 3; ++r)
       {
         ct.normal[r] = (len > 0) ? d[r] / len : (r == 2 ? 1.0 : 0.0);
-        ct.nearest_world[r] = c[r] + ls.radius * ct.normal[r];
+        ct.nearest_world[r] = pc[r] + ls.radius * ct.normal[r];
       }
       out.push_back(ct);
     }
@@ -1072,9 +1088,9 @@ struct LvsEvaluatorData  // the contact model itself (shared by the sco terms be
           }
           else
           {
-            for (int r = 0; r < 3; ++r)
-              p[r] = ca[r];
-            tmx_obstacle_closest_to_point(ob.center, scene->axisOf(o), p, oq);
+            double ea[3];
+            const bool capsule = scene->linkAxisWorld(s, Ta, ea);
+            tmx_link_closest_to_obstacle(ca, capsule ? ea : nullptr, ob.center, scene->axisOf(o), p, oq);
             c.tf0 = Ta;
             c.tf1 = Ta;
           }
@@ -1249,6 +1265,8 @@ inline TrajProblem constructProblem(const tmx_problem_desc& d, const double* ini
     P.scene->obstacles.push_back(d.obstacles[i]);
   if (d.obstacle_axes)
     P.scene->obstacle_axes.assign(d.obstacle_axes, d.obstacle_axes + 3 * d.n_obstacles);
+  if (d.link_sphere_axes)
+    P.scene->link_axes.assign(d.link_sphere_axes, d.link_sphere_axes + 3 * d.n_link_spheres);
   const int T = d.n_steps, D = d.n_dof;
   // TrajOptProb ctor :553-592
   std::vector<std::string> names;
@@ -1491,6 +1509,10 @@ inline TrajProblem constructProblem(const tmx_problem_desc& d, const double* ini
               ev.buffer = tm.buffer;
               ev.lvs = tm.longest_valid_segment_length;
               ev.cast = tm.evaluator_type != 2;
+              if (ev.cast && !P.scene->link_axes.empty())
+                for (double a : P.scene->link_axes)
+                  if (a != 0.0)
+                    throw std::runtime_error("capsule links: the cast evaluators (evaluator_type 3 / 4) sweep link spheres only");
               ev.fixed0 = cur;            // START_FIXED_END_FREE also when both are fixed (the :1745 branch is unreachable)
               ev.fixed1 = !cur && nxt;    // START_FREE_END_FIXED
               ev.kmax = tm.max_substates < 2 ? 2 : tm.max_substates;

@@ -14,7 +14,7 @@ from trajopt_amd import abi, configs
 TOL_TRAJ = 1e-5      # rad — north_star tolerance for joint trajectories / QP primal solutions
 
 # configuration ids of cfg() below: every id runs the stage checks on both tiers; MINI_CIDS also the whole SQP
-MINI_CIDS = [9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28]
+MINI_CIDS = [9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30]
 STAGE_CIDS = [0, 1, 2, 3] + MINI_CIDS
 
 
@@ -82,6 +82,20 @@ def cfg(cid, T=None):
         n = pci.basic_info.n_steps
         ti = CartVelTermInfo(first_step=1, last_step=n - 2, max_displacement=0.07, is_constraint=(cid == 23))
         (pci.cnt_infos if cid == 23 else pci.cost_infos).append(ti)
+        return pci, s, g
+    if cid in (29, 30):
+        # CAPSULE LINKS (tmx_problem_desc::link_sphere_axes): the three link primitives of the test arm become capsules along their
+        # links; 29 single-time-step cost against the sphere + a capsule obstacle, 30 LVS_DISCRETE constraint
+        from trajopt_amd.problem import CollisionTermInfo
+        pci, s, g = configs.config_mini(collision_cnt=(cid == 30)) if T is None else configs.config_mini(T, collision_cnt=(cid == 30))
+        rob = pci.robot
+        rob.link_spheres = [(1, (0.08, 0.0, 0.0), 0.06, (0.2, 0.0, 0.0)), (2, (0.06, 0.0, 0.0), 0.05, (0.18, 0.0, 0.01)), (3, (0.1, 0.0, 0.0), 0.05)]
+        (c0, r0) = pci.obstacles[0]
+        pci.obstacles = [((c0[0] - 0.25, c0[1] - 0.1, c0[2] + 0.05), 0.05, (0.5, 0.15, -0.1)), (c0, r0)]
+        if cid == 30:
+            for ti in pci.cost_infos + pci.cnt_infos:
+                if isinstance(ti, CollisionTermInfo):
+                    ti.evaluator_type, ti.longest_valid_segment_length, ti.max_substates = 2, 0.12, 4
         return pci, s, g
     if cid in (26, 27, 28):
         # JointAcc / JointJerk terms (rows on 3 / 4 waypoints, banded objective -> dense QP engine) next to the mini arm's collision

@@ -14,12 +14,29 @@ def _brute_force_cost(pci, x, term):
     total = 0.0
     for t in range(term.first_step, term.last_step + 1):
         links = rob.fk_links(x[t])
-        for (link, c, r) in rob.link_spheres:
+        for prim in rob.link_spheres:
+            link, c, r = prim[0], prim[1], prim[2]
             T = links[link]
             cw = T[:3, :3] @ np.asarray(c) + T[:3, 3]
+            lax = T[:3, :3] @ np.asarray(prim[3]) if len(prim) > 3 else np.zeros(3)     # capsule link: world axis
             for ob in pci.obstacles:
                 oc, orad = np.asarray(ob[0]), ob[1]
                 ax = np.asarray(ob[2]) if len(ob) > 2 else np.zeros(3)
+                if len(prim) > 3:
+                    # segment against segment (or point): coarse grid, then a fine grid around its argmin
+                    s0 = np.linspace(0.0, 1.0, 401)
+                    A = cw[None, :] + s0[:, None] * lax[None, :]
+                    Bp = oc[None, :] + s0[:, None] * ax[None, :]
+                    dd = np.sqrt(((A[:, None, :] - Bp[None, :, :]) ** 2).sum(axis=2))
+                    ia, ib = np.unravel_index(dd.argmin(), dd.shape)
+                    sa = np.clip(s0[ia] + np.linspace(-1, 1, 801) / 400.0, 0, 1)
+                    sb = np.clip(s0[ib] + np.linspace(-1, 1, 801) / 400.0, 0, 1)
+                    A = cw[None, :] + sa[:, None] * lax[None, :]
+                    Bp = oc[None, :] + sb[:, None] * ax[None, :]
+                    dist = np.sqrt(((A[:, None, :] - Bp[None, :, :]) ** 2).sum(axis=2)).min() - r - orad
+                    if dist <= term.dist_pen + term.safety_margin_buffer:
+                        total += term.coeff * max(term.dist_pen - dist, 0.0)
+                    continue
                 ss = np.linspace(0.0, 1.0, 20001)
                 pts = oc[None, :] + ss[:, None] * ax[None, :]
                 dist = np.sqrt(((pts - cw[None, :]) ** 2).sum(axis=1)).min() - r - orad
@@ -47,6 +64,39 @@ def test_single_time_step_cost_against_brute_force(hostemu_lib, orc):
     ctx.close()
     for b in range(2):
         assert np.array_equal(cv[b], orc.evaluate(desc, x0[b], x0[b])[0])   # same header, same bits
+
+
+def test_capsule_links_cost_against_brute_force(hostemu_lib, orc):
+    """capsule LINKS (tmx_problem_desc::link_sphere_axes) against sphere and capsule obstacles, single-time-step cost: the oracle's
+    exact cost against a brute-force segment-segment distance; kernel sources give the same bits as the oracle"""
+    pci, s, g = pc.cfg(29)
+    term = [ti for ti in pci.cost_infos if isinstance(ti, CollisionTermInfo)][0]
+    term.dist_pen = 0.25
+    x0 = configs.seeds_for(29, pci, s, g, 2, sigma=0.05)
+    desc = pci.to_desc()
+    for b in range(2):
+        ref = _brute_force_cost(pci, x0[b], term)
+        cvo, _ = orc.evaluate(desc, x0[b], x0[b])
+        assert ref > 0.01, "the test geometry must produce violations"
+        assert abs(cvo[1:].sum() - ref) <= 2e-5 * max(1.0, ref)      # (grid resolution of the brute force)
+    ctx = runtime.Context(0, hostemu_lib)
+    pc.make_ctx_inputs(ctx, pci, x0)
+    cv, _ = ctx.evaluate()
+    ctx.close()
+    for b in range(2):
+        assert np.array_equal(cv[b], orc.evaluate(desc, x0[b], x0[b])[0])
+
+
+def test_capsule_links_are_refused_by_the_cast_evaluators(hostemu_lib):
+    pci, s, g = pc.cfg(29)
+    for ti in pci.cost_infos:
+        if isinstance(ti, CollisionTermInfo):
+            ti.evaluator_type, ti.longest_valid_segment_length = 4, 0.1
+    ctx = runtime.Context(0, hostemu_lib)
+    from trajopt_amd import abi
+    with pytest.raises(runtime.TmxError, match="capsule links"):
+        ctx.upload(pci.to_desc(), abi.default_sqp_params(), abi.default_osqp_settings())
+    ctx.close()
 
 
 def test_segment_segment_closest_points_against_brute_force(tmp_path):

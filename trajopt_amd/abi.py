@@ -124,6 +124,7 @@ class ProblemDesc(C.Structure):
         ("flavor", C.c_int32),
         ("fixed_dofs", C.POINTER(C.c_int32)),
         ("obstacle_axes", C.POINTER(C.c_double)),
+        ("link_sphere_axes", C.POINTER(C.c_double)),
     ]
 
 

@@ -1024,7 +1024,8 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
       wp_list[next[st[r]]++] = r;
   }
   std::vector<int> ls_link;
-  std::vector<double> ls_center, ls_radius, ob_center, ob_radius, ob_axis;
+  std::vector<double> ls_center, ls_radius, ob_center, ob_radius, ob_axis, ls_axis;
+  int n_ls_capsule = 0;
   for (int s = 0; s < d->n_link_spheres; ++s)
   {
     if (d->link_spheres[s].link < 0 || d->link_spheres[s].link >= D)
@@ -1036,7 +1037,23 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
     for (int q = 0; q < 3; ++q)
       ls_center.push_back(d->link_spheres[s].center[q]);
     ls_radius.push_back(d->link_spheres[s].radius);
+    bool cap = false;
+    for (int q = 0; q < 3; ++q)
+    {
+      const double a = d->link_sphere_axes ? d->link_sphere_axes[3 * s + q] : 0.0;
+      ls_axis.push_back(a);
+      cap = cap || a != 0.0;
+    }
+    n_ls_capsule += cap ? 1 : 0;
   }
+  if (n_ls_capsule > 0)
+    for (int k = 0; k < d->n_terms; ++k)
+      if ((d->terms[k].kind == TMX_TERM_COLLISION_COST || d->terms[k].kind == TMX_TERM_COLLISION_CNT) && d->terms[k].evaluator_type >= 3)
+      {
+        ctx->err = "capsule links: the cast evaluators (evaluator_type 3 / 4) sweep link spheres only";
+        return TMX_ERR_UNSUPPORTED;
+      }
+  P.n_ls_capsule = n_ls_capsule;
   for (int o = 0; o < d->n_obstacles; ++o)
   {
     for (int q = 0; q < 3; ++q)
@@ -1094,6 +1111,7 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
   UP(pd, pd);
   UP(po, po);
   UP(pq, pq);
+  UP(ls_axis, ls_axis);
   UP(po2, po2);
   UP(po3, po3);
   UP(fx_t, fx_t);

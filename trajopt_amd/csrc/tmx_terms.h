@@ -284,7 +284,19 @@ TMX_DEVFN double contact_distance(const DevProblem* P, const double* q, int s, i
     c[r] = L.R[3 * r + 0] * P->ls_center[3 * s + 0] + L.R[3 * r + 1] * P->ls_center[3 * s + 1] +
            L.R[3 * r + 2] * P->ls_center[3 * s + 2] + L.t[r];
   double oq[3];  // closest point of the obstacle primitive to the sphere centre (the centre itself for a sphere)
-  tmx_obstacle_closest_to_point(P->ob_center + 3 * o, P->ob_axis + 3 * o, c, oq);
+  if (P->n_ls_capsule > 0)
+  {
+    // capsule link: the point of the link's segment closest to the obstacle takes the place of the centre (include/tmx_geom.h)
+    double e[3], pc[3];
+    for (int r = 0; r < 3; ++r)
+      e[r] = L.R[3 * r + 0] * P->ls_axis[3 * s + 0] + L.R[3 * r + 1] * P->ls_axis[3 * s + 1] + L.R[3 * r + 2] * P->ls_axis[3 * s + 2];
+    const bool capsule = P->ls_axis[3 * s + 0] != 0.0 || P->ls_axis[3 * s + 1] != 0.0 || P->ls_axis[3 * s + 2] != 0.0;
+    tmx_link_closest_to_obstacle(c, capsule ? e : nullptr, P->ob_center + 3 * o, P->ob_axis + 3 * o, pc, oq);
+    for (int r = 0; r < 3; ++r)
+      c[r] = pc[r];
+  }
+  else
+    tmx_obstacle_closest_to_point(P->ob_center + 3 * o, P->ob_axis + 3 * o, c, oq);
   for (int r = 0; r < 3; ++r)
     d[r] = oq[r] - c[r];
   const double len = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
@@ -363,9 +375,20 @@ TMX_DEVFN bool lvs_contact(const DevProblem* P, const double* q0, const double* 
   else
   {
     Tb = Ta;
-    for (int rr = 0; rr < 3; ++rr)
-      p[rr] = ca[rr];
-    tmx_obstacle_closest_to_point(P->ob_center + 3 * o, P->ob_axis + 3 * o, p, oq);
+    if (P->n_ls_capsule > 0)
+    {
+      double ea[3];
+      for (int rr = 0; rr < 3; ++rr)
+        ea[rr] = Ta.R[3 * rr + 0] * P->ls_axis[3 * s + 0] + Ta.R[3 * rr + 1] * P->ls_axis[3 * s + 1] + Ta.R[3 * rr + 2] * P->ls_axis[3 * s + 2];
+      const bool capsule = P->ls_axis[3 * s + 0] != 0.0 || P->ls_axis[3 * s + 1] != 0.0 || P->ls_axis[3 * s + 2] != 0.0;
+      tmx_link_closest_to_obstacle(ca, capsule ? ea : nullptr, P->ob_center + 3 * o, P->ob_axis + 3 * o, p, oq);
+    }
+    else
+    {
+      for (int rr = 0; rr < 3; ++rr)
+        p[rr] = ca[rr];
+      tmx_obstacle_closest_to_point(P->ob_center + 3 * o, P->ob_axis + 3 * o, p, oq);
+    }
   }
   const double d[3] = { oq[0] - p[0], oq[1] - p[1], oq[2] - p[2] };
   const double len = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);

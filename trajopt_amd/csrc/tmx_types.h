@@ -99,6 +99,8 @@ struct DevProblem
   int *fx_t, *fx_kind, *fx_owner, *fx_op0, *fx_nops, *fx_c0, *fx_nout, *fx_slot0, *fx_ci;  // fx_kind: 0 cost (diag Hessian), 1 cost (full), 2 constraint rows, 3 squared error cost, 4 abs / hinge error-cost rows
   int *fx_ops;        // all programs, (opcode, argument) pairs
   double *fx_consts;
+  double *ls_axis;    // 3 per link sphere, link frame: capsule link = sphere swept from ls_center to ls_center + ls_axis (zero: sphere)
+  int n_ls_capsule;   // number of link primitives with a non-zero axis
 };
 TMX_HOSTDEVFN int slot_is_diff(int kind) { return kind == SLOT_JOINTVEL || kind == SLOT_JOINTVEL_INEQ; }
 TMX_HOSTDEVFN int fx_is_quad(int kind) { return kind == 0 || kind == 1 || kind == 3; }  // instance owns a dynamic quadratic model

@@ -382,10 +382,16 @@ class ProblemConstructionInfo:
             d.joints[j].axis[:] = list(rob.axes[j])
         d.base[:] = list(np.asarray(rob.base).reshape(-1))
         d.tool[:] = list(np.asarray(rob.tool).reshape(-1))
+        # a link primitive is (link, centre, radius) - a sphere - or (link, centre, radius, axis) - the capsule swept from centre to
+        # centre + axis (link frame)
         ls = (abi.LinkSphere * max(1, len(rob.link_spheres)))()
-        for i, (link, c, r) in enumerate(rob.link_spheres):
+        ls_axes = (C.c_double * (3 * max(1, len(rob.link_spheres))))()
+        for i, prim in enumerate(rob.link_spheres):
+            link, c, r = prim[0], prim[1], prim[2]
             ls[i].link, ls[i].radius = link, r
             ls[i].center[:] = list(c)
+            if len(prim) > 3:
+                ls_axes[3 * i:3 * i + 3] = list(prim[3])
         # an obstacle is ((x, y, z), r) - a sphere - or ((x, y, z), r, (ax, ay, az)) - the capsule swept from centre to centre + axis
         ob = (abi.ObstacleSphere * max(1, len(self.obstacles)))()
         ob_axes = (C.c_double * (3 * max(1, len(self.obstacles))))()
@@ -453,7 +459,7 @@ class ProblemConstructionInfo:
                 t.first_step = ti.first_step
                 t.last_step = ti.last_step if ti.last_step >= 0 else T - 1
                 prog, keep = compile_program(list(ti.error_function))
-                self._keep.append((prog, keep))
+                keep_fixed.append((prog, keep))
                 t.expr = C.pointer(prog)
                 t.cnt_type = 1 if ti.constraint_ineq else 0
                 t.penalty_type = int(ti.cost_penalty_type)
@@ -462,7 +468,7 @@ class ProblemConstructionInfo:
                     t.coeffs[:len(ti.coeff)] = list(ti.coeff)
                 if len(ti.fixed_steps):
                     fs = (C.c_int32 * len(ti.fixed_steps))(*[int(v) for v in ti.fixed_steps])
-                    self._keep.append(fs)
+                    keep_fixed.append(fs)
                     t.n_fixed_steps = len(ti.fixed_steps)
                     t.fixed_steps = C.cast(fs, C.POINTER(C.c_int32))
             elif isinstance(ti, (FuncCostTermInfo, FuncConstraintTermInfo)):
@@ -472,7 +478,7 @@ class ProblemConstructionInfo:
                 t.first_step = ti.first_step
                 t.last_step = ti.last_step if ti.last_step >= 0 else T - 1
                 prog, keep = compile_program([ti.f] if is_cost else list(ti.g))
-                self._keep.append((prog, keep))
+                keep_fixed.append((prog, keep))
                 t.expr = C.pointer(prog)
                 if is_cost:
                     t.full_hessian = 1 if ti.full_hessian else 0
@@ -523,11 +529,13 @@ class ProblemConstructionInfo:
         d.link_spheres, d.obstacles = ls, ob
         if any(len(o) > 2 for o in self.obstacles):
             d.obstacle_axes = C.cast(ob_axes, C.POINTER(C.c_double))
+        if any(len(prim) > 3 for prim in rob.link_spheres):
+            d.link_sphere_axes = C.cast(ls_axes, C.POINTER(C.c_double))
         d.n_fixed_steps, d.n_terms = len(self.basic_info.fixed_timesteps), len(terms)
         d.fixed_steps, d.terms = fixed, tarr
         fdofs = (C.c_int32 * max(1, len(self.basic_info.fixed_dofs)))(*self.basic_info.fixed_dofs)
         d.n_fixed_dofs, d.fixed_dofs = len(self.basic_info.fixed_dofs), fdofs
         d.flavor = int(self.flavor)
-        self._keep = [ls, ob, ob_axes, fixed, tarr, fdofs, keep_fixed]   # keep the pointed-to arrays alive
+        self._keep = [ls, ls_axes, ob, ob_axes, fixed, tarr, fdofs, keep_fixed]   # keep the pointed-to arrays alive
         d._keep = self._keep
         return d
