@@ -142,10 +142,38 @@ void lowerKinematics(const ProblemConstructionInfo& pci, LoweredProblem& out)
     for (const auto& col : link->collision)
     {
       const auto type = col->geometry->getType();
-      if (type != tesseract::geometry::GeometryType::SPHERE && type != tesseract::geometry::GeometryType::CAPSULE)
-        PRINT_AND_THROW("collision geometry of link " + link->getName() + " is neither a sphere nor a capsule: not lowered by the device path");
+      if (type != tesseract::geometry::GeometryType::SPHERE && type != tesseract::geometry::GeometryType::CAPSULE &&
+          type != tesseract::geometry::GeometryType::BOX)
+        PRINT_AND_THROW("collision geometry of link " + link->getName() + " is not a sphere, capsule or box: not lowered by the device path");
       const Eigen::Isometry3d g = tf0.at(link->getName()) * col->origin;
       double radius = 0.0, half = 0.0;
+      if (type == tesseract::geometry::GeometryType::BOX)
+      {
+        // tesseract::geometry::Box: full side lengths x, y, z about the geometry origin -> tmx_problem_desc::obstacle_boxes
+        const auto box = std::static_pointer_cast<const tesseract::geometry::Box>(col->geometry);
+        const Eigen::Vector3d c0 = g.translation();
+        tmx_obstacle_sphere o{};
+        o.center[0] = c0.x();
+        o.center[1] = c0.y();
+        o.center[2] = c0.z();
+        o.radius = 0.0;
+        out.obstacles.push_back(o);
+        for (int q = 0; q < 3; ++q)
+          out.obstacle_axes.push_back(0.0);
+        out.obstacle_boxes.push_back(0.5 * box->getX());
+        out.obstacle_boxes.push_back(0.5 * box->getY());
+        out.obstacle_boxes.push_back(0.5 * box->getZ());
+        for (int r = 0; r < 3; ++r)  // world_R_box row-major: row r = (ex[r], ey[r], ez[r]), the images of the box axes
+        {
+          const Eigen::Vector3d ex = g * Eigen::Vector3d(1, 0, 0) - c0, ey = g * Eigen::Vector3d(0, 1, 0) - c0, ez = g * Eigen::Vector3d(0, 0, 1) - c0;
+          out.obstacle_boxes.push_back(ex[r]);
+          out.obstacle_boxes.push_back(ey[r]);
+          out.obstacle_boxes.push_back(ez[r]);
+        }
+        continue;
+      }
+      for (int q = 0; q < 12; ++q)
+        out.obstacle_boxes.push_back(0.0);
       if (type == tesseract::geometry::GeometryType::SPHERE)
         radius = std::static_pointer_cast<const tesseract::geometry::Sphere>(col->geometry)->getRadius();
       else
@@ -343,6 +371,7 @@ void LoweredProblem::finalize()
   desc.link_spheres = link_spheres.data();
   desc.link_sphere_axes = (link_sphere_axes.size() == 3 * link_spheres.size() && !link_spheres.empty()) ? link_sphere_axes.data() : nullptr;
   desc.obstacle_axes = (obstacle_axes.size() == 3 * obstacles.size() && !obstacles.empty()) ? obstacle_axes.data() : nullptr;
+  desc.obstacle_boxes = (obstacle_boxes.size() == 12 * obstacles.size() && !obstacles.empty()) ? obstacle_boxes.data() : nullptr;
   desc.n_obstacles = static_cast<int32_t>(obstacles.size());
   desc.obstacles = obstacles.data();
   desc.n_fixed_steps = static_cast<int32_t>(fixed_steps.size());

@@ -34,13 +34,14 @@ struct LoweredProblem
   std::vector<tmx_link_sphere> link_spheres;
   std::vector<tmx_obstacle_sphere> obstacles;
   std::vector<double> link_sphere_axes, obstacle_axes;  // capsules: 3 per primitive (zero = sphere); empty when every primitive is a sphere
+  std::vector<double> obstacle_boxes;                    // boxes: 12 per obstacle (half extents, rotation; zero = not a box)
   std::vector<std::string> cost_names, cnt_names;
   void finalize();  // wires the pointers of `desc`
 };
 
 /** TermInfo::hatch for the device: throws std::runtime_error for every term class / option the device path does not lower
     (UserDefinedTermInfo with opaque callbacks, DynamicCartPoseTermInfo, TotalTime, AvoidSingularity, use_time, tolerances on
-    CartPose, collision geometry other than spheres and capsules) - explicit, never a silent CPU detour.
+    CartPose, link geometry other than spheres and capsules, obstacle geometry other than spheres, capsules and boxes) - explicit, never a silent CPU detour.
     `max_substates`: row-slot capacity of the LVS / continuous collision evaluators (0 = from the initial trajectory). */
 LoweredProblem lowerProblem(const ProblemConstructionInfo& pci, const TrajArray& init_traj, int max_substates = 0);
 }  // namespace trajopt

@@ -263,6 +263,11 @@ typedef struct
      (evaluator_type 0 / 1 / 2): the cast evaluators sweep link SPHERES between two states (the swept volume of a capsule is not a
      capsule) and refuse capsule links at upload.                                                                        */
   const double* link_sphere_axes;
+  /* optional, 12 doubles per obstacle (NULL: no boxes): half extents hx hy hz (> 0 marks a box) and the rotation world_R_box
+     row-major; the obstacle is the box centred at `center`, rounded by `radius` (>= 0).  All evaluators: the closest point of a
+     link-core segment (capsule link, swept sphere) to the box is found by a fixed-length golden-section search on the box's convex
+     signed-distance function, penetration included (include/tmx_geom.h).  obstacle_axes of a box obstacle must be zero.        */
+  const double* obstacle_boxes;
 } tmx_problem_desc;
 
 typedef enum

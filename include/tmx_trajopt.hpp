@@ -147,6 +147,7 @@ struct Environment
   std::map<std::string, Transform> link_frames;                           // static links: world_T_link
   std::vector<tmx_obstacle_sphere> obstacles;                             // world collision geometry: spheres ...
   std::vector<double> obstacle_axes;  // ... or capsules: 3 per obstacle (swept from centre to centre + axis); empty = all spheres
+  std::vector<double> obstacle_boxes;  // ... or rounded boxes: 12 per obstacle (half extents, rotation world_R_box row-major); empty = none
   std::shared_ptr<const JointGroup> getJointGroup(const std::string& manip) const
   {
     auto it = manipulators.find(manip);
@@ -420,6 +421,7 @@ public:
     d.n_obstacles = static_cast<int32_t>(env_ ? env_->obstacles.size() : 0);
     d.obstacles = env_ ? env_->obstacles.data() : nullptr;
     d.obstacle_axes = (env_ && env_->obstacle_axes.size() == 3 * env_->obstacles.size() && !env_->obstacles.empty()) ? env_->obstacle_axes.data() : nullptr;
+    d.obstacle_boxes = (env_ && env_->obstacle_boxes.size() == 12 * env_->obstacles.size() && !env_->obstacles.empty()) ? env_->obstacle_boxes.data() : nullptr;
     d.n_fixed_steps = static_cast<int32_t>(fixed_steps_.size());
     d.fixed_steps = fixed_steps_.data();
     d.n_fixed_dofs = static_cast<int32_t>(fixed_dofs_.size());

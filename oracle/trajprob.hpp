@@ -793,6 +793,8 @@ struct Scene
   std::vector<tmx_obstacle_sphere> obstacles;
   std::vector<double> obstacle_axes;  // 3 per obstacle (capsule = sphere swept from centre to centre + axis); empty: spheres
   const double* axisOf(std::size_t o) const { return obstacle_axes.empty() ? nullptr : obstacle_axes.data() + 3 * o; }
+  std::vector<double> obstacle_boxes;  // 12 per obstacle (half extents, rotation): rounded box obstacles (include/tmx_geom.h); empty: none
+  const double* boxOf(std::size_t o) const { return obstacle_boxes.empty() ? nullptr : obstacle_boxes.data() + 12 * o; }
   std::vector<double> link_axes;  // 3 per link sphere, link frame (capsule link = sphere swept from centre to centre + axis); empty: spheres
   // world axis of link primitive s under the link pose T (false: a sphere)
   template <class TF>
@@ -835,9 +837,9 @@ inline void calcContacts(const Chain& chain, const Scene& scene, const double* q
       double oq[3];  // closest point of the obstacle primitive to the link primitive's core (sphere centre / capsule segment)
       double e[3], pc[3];
       const bool capsule = scene.linkAxisWorld(s, T, e);
-      tmx_link_closest_to_obstacle(c, capsule ? e : nullptr, ob.center, scene.axisOf(o), pc, oq);
-      const double d[3] = { oq[0] - pc[0], oq[1] - pc[1], oq[2] - pc[2] };
-      const double len = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+      const int inside = tmx_link_closest_to_obstacle_b(c, capsule ? e : nullptr, ob.center, scene.axisOf(o), scene.boxOf(o), pc, oq);
+      double nrm[3];
+      const double len = tmx_contact_normal(pc, oq, inside, nrm);
       const double dist = len - ls.radius - ob.radius;
       if (dist > (margin + buffer))
         continue;  // filter at collision_terms.cpp:679-687
@@ -848,7 +850,7 @@ inline void calcContacts(const Chain& chain, const Scene& scene, const double* q
       ct.distance = dist;
       for (int r = 0; r < 3; ++r)
       {
-        ct.normal[r] = (len > 0) ? d[r] / len : (r == 2 ? 1.0 : 0.0);
+        ct.normal[r] = nrm[r];
         ct.nearest_world[r] = pc[r] + ls.radius * ct.normal[r];
       }
       out.push_back(ct);
@@ -1074,13 +1076,14 @@ struct LvsEvaluatorData  // the contact model itself (shared by the sco terms be
           sphereCentre(Ta, ls, ca);
           double tau = 0.0;
           double oq[3];  // closest point of the obstacle primitive (include/tmx_geom.h)
+          int inside = 0;  // the link core point lies inside a box obstacle's core
           if (cast)
           {
             const Tf& Tb = poses[static_cast<std::size_t>(i + 1)][ls.link];
             double cb[3];
             sphereCentre(Tb, ls, cb);
             const double e[3] = { cb[0] - ca[0], cb[1] - ca[1], cb[2] - ca[2] };
-            tau = tmx_swept_closest_to_obstacle(ca, e, ob.center, scene->axisOf(o), oq);
+            tau = tmx_swept_closest_to_obstacle_b(ca, e, ob.center, scene->axisOf(o), scene->boxOf(o), oq, &inside);
             for (int r = 0; r < 3; ++r)
               p[r] = ca[r] + tau * e[r];
             c.tf0 = Ta;
@@ -1090,19 +1093,15 @@ struct LvsEvaluatorData  // the contact model itself (shared by the sco terms be
           {
             double ea[3];
             const bool capsule = scene->linkAxisWorld(s, Ta, ea);
-            tmx_link_closest_to_obstacle(ca, capsule ? ea : nullptr, ob.center, scene->axisOf(o), p, oq);
+            inside = tmx_link_closest_to_obstacle_b(ca, capsule ? ea : nullptr, ob.center, scene->axisOf(o), scene->boxOf(o), p, oq);
             c.tf0 = Ta;
             c.tf1 = Ta;
           }
-          const double d[3] = { oq[0] - p[0], oq[1] - p[1], oq[2] - p[2] };
-          const double len = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+          const double len = tmx_contact_normal(p, oq, inside, c.normal);
           c.distance = len - ls.radius - ob.radius;
           double pw[3];
           for (int r = 0; r < 3; ++r)
-          {
-            c.normal[r] = (len > 0) ? d[r] / len : (r == 2 ? 1.0 : 0.0);
             pw[r] = p[r] + ls.radius * c.normal[r];
-          }
           // contact point in the link frame of `transform`
           for (int r = 0; r < 3; ++r)
             c.p_local[r] = c.tf0.R[0 + r] * (pw[0] - c.tf0.t[0]) + c.tf0.R[3 + r] * (pw[1] - c.tf0.t[1]) + c.tf0.R[6 + r] * (pw[2] - c.tf0.t[2]);
@@ -1265,6 +1264,8 @@ inline TrajProblem constructProblem(const tmx_problem_desc& d, const double* ini
     P.scene->obstacles.push_back(d.obstacles[i]);
   if (d.obstacle_axes)
     P.scene->obstacle_axes.assign(d.obstacle_axes, d.obstacle_axes + 3 * d.n_obstacles);
+  if (d.obstacle_boxes)
+    P.scene->obstacle_boxes.assign(d.obstacle_boxes, d.obstacle_boxes + 12 * d.n_obstacles);
   if (d.link_sphere_axes)
     P.scene->link_axes.assign(d.link_sphere_axes, d.link_sphere_axes + 3 * d.n_link_spheres);
   const int T = d.n_steps, D = d.n_dof;

@@ -14,7 +14,7 @@ from trajopt_amd import abi, configs
 TOL_TRAJ = 1e-5      # rad — north_star tolerance for joint trajectories / QP primal solutions
 
 # configuration ids of cfg() below: every id runs the stage checks on both tiers; MINI_CIDS also the whole SQP
-MINI_CIDS = [9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30]
+MINI_CIDS = [9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33]
 STAGE_CIDS = [0, 1, 2, 3] + MINI_CIDS
 
 
@@ -82,6 +82,23 @@ def cfg(cid, T=None):
         n = pci.basic_info.n_steps
         ti = CartVelTermInfo(first_step=1, last_step=n - 2, max_displacement=0.07, is_constraint=(cid == 23))
         (pci.cnt_infos if cid == 23 else pci.cost_infos).append(ti)
+        return pci, s, g
+    if cid in (31, 32, 33):
+        # BOX obstacles (tmx_problem_desc::obstacle_boxes): a rotated, rounded box across the path next to the original sphere;
+        # 31 single-time-step cost with sphere links, 32 LVS_CONTINUOUS (cast: swept link spheres against the box by the golden-section
+        # search on the box's signed distance) cost, 33 capsule links + LVS_DISCRETE constraint
+        from trajopt_amd.problem import CollisionTermInfo, rot_axis
+        pci, s, g = configs.config_mini(collision_cnt=(cid == 33)) if T is None else configs.config_mini(T, collision_cnt=(cid == 33))
+        (c0, r0) = pci.obstacles[0]
+        Rb = rot_axis(np.array([0.0, 0.0, 1.0]), 0.4) @ rot_axis(np.array([1.0, 0.0, 0.0]), 0.25)
+        pci.obstacles = [((c0[0] - 0.05, c0[1] + 0.02, c0[2] + 0.1), 0.02, ("box", (0.12, 0.2, 0.05), Rb)), (c0, r0)]
+        if cid == 33:
+            pci.robot.link_spheres = [(1, (0.08, 0.0, 0.0), 0.06, (0.2, 0.0, 0.0)), (2, (0.06, 0.0, 0.0), 0.05, (0.18, 0.0, 0.01)), (3, (0.1, 0.0, 0.0), 0.05)]
+        for ti in pci.cost_infos + pci.cnt_infos:
+            if isinstance(ti, CollisionTermInfo) and cid != 31:
+                ti.evaluator_type = 4 if cid == 32 else 2
+                ti.longest_valid_segment_length = 0.12
+                ti.max_substates = 4
         return pci, s, g
     if cid in (29, 30):
         # CAPSULE LINKS (tmx_problem_desc::link_sphere_axes): the three link primitives of the test arm become capsules along their

@@ -87,6 +87,92 @@ def test_capsule_links_cost_against_brute_force(hostemu_lib, orc):
         assert np.array_equal(cv[b], orc.evaluate(desc, x0[b], x0[b])[0])
 
 
+def test_box_signed_distance_against_brute_force(tmp_path):
+    """tmx_box_sdf / tmx_swept_closest_to_obstacle_b (include/tmx_geom.h): point and segment against a rotated box - outside against
+    a dense sampling of the box surface, inside against the nearest face, along segments against a fine scan of tau"""
+    import ctypes as C
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "b.c"
+    src.write_text('#include "tmx_geom.h"\n'
+                   'double sdf(const double* oc, const double* ob, const double* c, double* q) { return tmx_box_sdf(oc, ob, c, q); }\n'
+                   'double swept(const double* ca, const double* e, const double* oc, const double* ob, double* q, int* inside)'
+                   '{ return tmx_swept_closest_to_obstacle_b(ca, e, oc, 0, ob, q, inside); }\n')
+    so = tmp_path / "b.so"
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-shared", "-fPIC", "-I", os.path.join(root, "include"), str(src), "-o", str(so), "-lm"])
+    lib = C.CDLL(str(so))
+    lib.sdf.restype = C.c_double
+    lib.swept.restype = C.c_double
+    D3 = C.c_double * 3
+    rng = np.random.default_rng(5)
+    from trajopt_amd.problem import rot_axis
+    for trial in range(30):
+        h = rng.uniform(0.05, 0.4, 3)
+        ax = rng.standard_normal(3)
+        R = rot_axis(ax / np.linalg.norm(ax), rng.uniform(-2, 2)) if trial else np.eye(3)
+        oc = rng.uniform(-0.3, 0.3, 3)
+        ob = (C.c_double * 12)(*list(h), *list(R.reshape(-1)))
+
+        def sdf_np(p):
+            l = R.T @ (p - oc)
+            qd = np.abs(l) - h
+            return np.linalg.norm(np.maximum(qd, 0.0)) + min(qd.max(), 0.0)
+        for _ in range(40):
+            p = oc + R @ (rng.uniform(-1.5, 1.5, 3) * h)
+            q = D3()
+            sd = lib.sdf(D3(*oc), ob, D3(*p), q)
+            assert abs(sd - sdf_np(p)) < 1e-12
+            assert abs(np.linalg.norm(np.array(q[:]) - p) - abs(sd)) < 1e-12      # q is the surface point the distance is measured to
+            lq = R.T @ (np.array(q[:]) - oc)
+            assert (np.abs(lq) <= h + 1e-12).all() and np.isclose(np.abs(lq), h, atol=1e-12).any() or sd > 0
+        for _ in range(10):
+            a = oc + R @ (rng.uniform(-2.5, 2.5, 3) * h)
+            e = rng.uniform(-0.6, 0.6, 3)
+            q = D3()
+            inside = C.c_int(0)
+            tau = lib.swept(D3(*a), D3(*e), D3(*oc), ob, q, C.byref(inside))
+            taus = np.linspace(0, 1, 4001)
+            vals = np.array([sdf_np(a + t * e) for t in taus])
+            assert 0.0 <= tau <= 1.0
+            assert sdf_np(a + tau * e) <= vals.min() + 1e-9
+            assert (inside.value == 1) == (sdf_np(a + tau * e) < 0)
+
+
+def test_box_obstacles_cost_against_brute_force(hostemu_lib, orc):
+    """single-time-step collision cost with a rounded, rotated box obstacle: the oracle against the numpy signed distance; kernel
+    sources give the same bits as the oracle"""
+    pci, s, g = pc.cfg(31)
+    term = [ti for ti in pci.cost_infos if isinstance(ti, CollisionTermInfo)][0]
+    term.dist_pen = 0.25
+    x0 = configs.seeds_for(31, pci, s, g, 2, sigma=0.05)
+    desc = pci.to_desc()
+    rob = pci.robot
+    for b in range(2):
+        total = 0.0
+        for t in range(term.first_step, term.last_step + 1):
+            links = rob.fk_links(x0[b][t])
+            for (link, c, r) in rob.link_spheres:
+                cw = links[link][:3, :3] @ np.asarray(c) + links[link][:3, 3]
+                for ob in pci.obstacles:
+                    if len(ob) > 2:
+                        h, R = np.asarray(ob[2][1]), np.asarray(ob[2][2])
+                        qd = np.abs(R.T @ (cw - np.asarray(ob[0]))) - h
+                        dist = np.linalg.norm(np.maximum(qd, 0.0)) + min(qd.max(), 0.0) - r - ob[1]
+                    else:
+                        dist = np.linalg.norm(cw - np.asarray(ob[0])) - r - ob[1]
+                    if dist <= term.dist_pen + term.safety_margin_buffer:
+                        total += term.coeff * max(term.dist_pen - dist, 0.0)
+        cvo, _ = orc.evaluate(desc, x0[b], x0[b])
+        assert total > 0.01 and abs(cvo[1:].sum() - total) <= 1e-10 * max(1.0, total)
+    ctx = runtime.Context(0, hostemu_lib)
+    pc.make_ctx_inputs(ctx, pci, x0)
+    cv, _ = ctx.evaluate()
+    ctx.close()
+    for b in range(2):
+        assert np.array_equal(cv[b], orc.evaluate(desc, x0[b], x0[b])[0])
+
+
 def test_capsule_links_are_refused_by_the_cast_evaluators(hostemu_lib):
     pci, s, g = pc.cfg(29)
     for ti in pci.cost_infos:

@@ -125,6 +125,7 @@ class ProblemDesc(C.Structure):
         ("fixed_dofs", C.POINTER(C.c_int32)),
         ("obstacle_axes", C.POINTER(C.c_double)),
         ("link_sphere_axes", C.POINTER(C.c_double)),
+        ("obstacle_boxes", C.POINTER(C.c_double)),
     ]
 
 

@@ -1024,8 +1024,8 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
       wp_list[next[st[r]]++] = r;
   }
   std::vector<int> ls_link;
-  std::vector<double> ls_center, ls_radius, ob_center, ob_radius, ob_axis, ls_axis;
-  int n_ls_capsule = 0;
+  std::vector<double> ls_center, ls_radius, ob_center, ob_radius, ob_axis, ls_axis, ob_box;
+  int n_ls_capsule = 0, n_ob_box = 0;
   for (int s = 0; s < d->n_link_spheres; ++s)
   {
     if (d->link_spheres[s].link < 0 || d->link_spheres[s].link >= D)
@@ -1061,7 +1061,26 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
     ob_radius.push_back(d->obstacles[o].radius);
     for (int q = 0; q < 3; ++q)
       ob_axis.push_back(d->obstacle_axes ? d->obstacle_axes[3 * o + q] : 0.0);
+    bool box = false;
+    for (int q = 0; q < 12; ++q)
+    {
+      const double v = d->obstacle_boxes ? d->obstacle_boxes[12 * o + q] : 0.0;
+      ob_box.push_back(v);
+      box = box || (q < 3 && v > 0.0);
+      if (q < 3 && v < 0.0)
+      {
+        ctx->err = "obstacle_boxes: negative half extent";
+        return TMX_ERR_INVALID;
+      }
+    }
+    if (box && d->obstacle_axes && (d->obstacle_axes[3 * o] != 0.0 || d->obstacle_axes[3 * o + 1] != 0.0 || d->obstacle_axes[3 * o + 2] != 0.0))
+    {
+      ctx->err = "an obstacle is a capsule (obstacle_axes) or a box (obstacle_boxes), not both";
+      return TMX_ERR_INVALID;
+    }
+    n_ob_box += box ? 1 : 0;
   }
+  P.n_ob_box = n_ob_box;
   auto& pool = ctx->prob_allocs;
   tmx_status rc;
 #define UP(field, vec)                                                                                                \
@@ -1112,6 +1131,7 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
   UP(po, po);
   UP(pq, pq);
   UP(ls_axis, ls_axis);
+  UP(ob_box, ob_box);
   UP(po2, po2);
   UP(po3, po3);
   UP(fx_t, fx_t);

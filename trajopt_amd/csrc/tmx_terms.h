@@ -273,6 +273,24 @@ TMX_DEVFN double cart_vel_value(const DevProblem* P, const double* q0, const dou
 }
 #endif
 
+// the capsule-link / box-obstacle contact functions of include/tmx_geom.h out of line on the device: they are cold, and inlined
+// their golden-section search grows the persistent kernel's collision code for every problem (config 1 -1 % with it inline)
+#if TMX_IS_DEVICE
+__device__ __attribute__((noinline)) static int link_closest_b_nl(const double* c, const double* e, const double* oc, const double* oa, const double* ob,
+                                                                  double* p, double* q)
+{
+  return tmx_link_closest_to_obstacle_b(c, e, oc, oa, ob, p, q);
+}
+__device__ __attribute__((noinline)) static double swept_closest_b_nl(const double* ca, const double* e, const double* oc, const double* oa,
+                                                                      const double* ob, double* q, int* inside)
+{
+  return tmx_swept_closest_to_obstacle_b(ca, e, oc, oa, ob, q, inside);
+}
+#else
+#define link_closest_b_nl tmx_link_closest_to_obstacle_b
+#define swept_closest_b_nl tmx_swept_closest_to_obstacle_b
+#endif
+
 // sphere-vs-sphere signed distance for contact slot (link sphere s, obstacle o) at joint values q
 TMX_DEVFN double contact_distance(const DevProblem* P, const double* q, int s, int o, double n[3], double pw[3])
 {
@@ -284,28 +302,31 @@ TMX_DEVFN double contact_distance(const DevProblem* P, const double* q, int s, i
     c[r] = L.R[3 * r + 0] * P->ls_center[3 * s + 0] + L.R[3 * r + 1] * P->ls_center[3 * s + 1] +
            L.R[3 * r + 2] * P->ls_center[3 * s + 2] + L.t[r];
   double oq[3];  // closest point of the obstacle primitive to the sphere centre (the centre itself for a sphere)
-  if (P->n_ls_capsule > 0)
+  int inside = 0;  // the link core point lies inside a box obstacle's core
+  if (P->n_ls_capsule > 0 || P->n_ob_box > 0)
   {
-    // capsule link: the point of the link's segment closest to the obstacle takes the place of the centre (include/tmx_geom.h)
+    // capsule link: the point of the link's segment closest to the obstacle takes the place of the centre; box obstacles: signed
+    // distance with penetration (include/tmx_geom.h)
     double e[3], pc[3];
-    for (int r = 0; r < 3; ++r)
-      e[r] = L.R[3 * r + 0] * P->ls_axis[3 * s + 0] + L.R[3 * r + 1] * P->ls_axis[3 * s + 1] + L.R[3 * r + 2] * P->ls_axis[3 * s + 2];
-    const bool capsule = P->ls_axis[3 * s + 0] != 0.0 || P->ls_axis[3 * s + 1] != 0.0 || P->ls_axis[3 * s + 2] != 0.0;
-    tmx_link_closest_to_obstacle(c, capsule ? e : nullptr, P->ob_center + 3 * o, P->ob_axis + 3 * o, pc, oq);
+    bool capsule = false;
+    if (P->n_ls_capsule > 0)
+    {
+      for (int r = 0; r < 3; ++r)
+        e[r] = L.R[3 * r + 0] * P->ls_axis[3 * s + 0] + L.R[3 * r + 1] * P->ls_axis[3 * s + 1] + L.R[3 * r + 2] * P->ls_axis[3 * s + 2];
+      capsule = P->ls_axis[3 * s + 0] != 0.0 || P->ls_axis[3 * s + 1] != 0.0 || P->ls_axis[3 * s + 2] != 0.0;
+    }
+    inside = link_closest_b_nl(c, capsule ? e : nullptr, P->ob_center + 3 * o, P->ob_axis + 3 * o,
+                                            P->n_ob_box > 0 ? P->ob_box + 12 * o : nullptr, pc, oq);
     for (int r = 0; r < 3; ++r)
       c[r] = pc[r];
   }
   else
     tmx_obstacle_closest_to_point(P->ob_center + 3 * o, P->ob_axis + 3 * o, c, oq);
-  for (int r = 0; r < 3; ++r)
-    d[r] = oq[r] - c[r];
-  const double len = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+  (void)d;
+  const double len = tmx_contact_normal(c, oq, inside, n);
   const double rs = P->ls_radius[s];
   for (int r = 0; r < 3; ++r)
-  {
-    n[r] = (len > 0) ? d[r] / len : (r == 2 ? 1.0 : 0.0);
     pw[r] = c[r] + rs * n[r];
-  }
   return len - rs - P->ob_radius[o];
 }
 
@@ -361,6 +382,7 @@ TMX_DEVFN bool lvs_contact(const DevProblem* P, const double* q0, const double* 
     ca[rr] = Ta.R[3 * rr + 0] * P->ls_center[3 * s + 0] + Ta.R[3 * rr + 1] * P->ls_center[3 * s + 1] + Ta.R[3 * rr + 2] * P->ls_center[3 * s + 2] + Ta.t[rr];
   double tau = 0.0;
   double oq[3];  // closest point of the obstacle primitive (include/tmx_geom.h)
+  int inside = 0;  // the link core point lies inside a box obstacle's core
   if (cast)
   {
     fk_link_at(P, qb, link, Tb);
@@ -368,20 +390,28 @@ TMX_DEVFN bool lvs_contact(const DevProblem* P, const double* q0, const double* 
     for (int rr = 0; rr < 3; ++rr)
       cb[rr] = Tb.R[3 * rr + 0] * P->ls_center[3 * s + 0] + Tb.R[3 * rr + 1] * P->ls_center[3 * s + 1] + Tb.R[3 * rr + 2] * P->ls_center[3 * s + 2] + Tb.t[rr];
     const double e[3] = { cb[0] - ca[0], cb[1] - ca[1], cb[2] - ca[2] };
-    tau = tmx_swept_closest_to_obstacle(ca, e, P->ob_center + 3 * o, P->ob_axis + 3 * o, oq);
+    if (P->n_ob_box > 0)
+      tau = swept_closest_b_nl(ca, e, P->ob_center + 3 * o, P->ob_axis + 3 * o, P->ob_box + 12 * o, oq, &inside);
+    else
+      tau = tmx_swept_closest_to_obstacle(ca, e, P->ob_center + 3 * o, P->ob_axis + 3 * o, oq);
     for (int rr = 0; rr < 3; ++rr)
       p[rr] = ca[rr] + tau * e[rr];
   }
   else
   {
     Tb = Ta;
-    if (P->n_ls_capsule > 0)
+    if (P->n_ls_capsule > 0 || P->n_ob_box > 0)
     {
       double ea[3];
-      for (int rr = 0; rr < 3; ++rr)
-        ea[rr] = Ta.R[3 * rr + 0] * P->ls_axis[3 * s + 0] + Ta.R[3 * rr + 1] * P->ls_axis[3 * s + 1] + Ta.R[3 * rr + 2] * P->ls_axis[3 * s + 2];
-      const bool capsule = P->ls_axis[3 * s + 0] != 0.0 || P->ls_axis[3 * s + 1] != 0.0 || P->ls_axis[3 * s + 2] != 0.0;
-      tmx_link_closest_to_obstacle(ca, capsule ? ea : nullptr, P->ob_center + 3 * o, P->ob_axis + 3 * o, p, oq);
+      bool capsule = false;
+      if (P->n_ls_capsule > 0)
+      {
+        for (int rr = 0; rr < 3; ++rr)
+          ea[rr] = Ta.R[3 * rr + 0] * P->ls_axis[3 * s + 0] + Ta.R[3 * rr + 1] * P->ls_axis[3 * s + 1] + Ta.R[3 * rr + 2] * P->ls_axis[3 * s + 2];
+        capsule = P->ls_axis[3 * s + 0] != 0.0 || P->ls_axis[3 * s + 1] != 0.0 || P->ls_axis[3 * s + 2] != 0.0;
+      }
+      inside = link_closest_b_nl(ca, capsule ? ea : nullptr, P->ob_center + 3 * o, P->ob_axis + 3 * o,
+                                              P->n_ob_box > 0 ? P->ob_box + 12 * o : nullptr, p, oq);
     }
     else
     {
@@ -390,16 +420,12 @@ TMX_DEVFN bool lvs_contact(const DevProblem* P, const double* q0, const double* 
       tmx_obstacle_closest_to_point(P->ob_center + 3 * o, P->ob_axis + 3 * o, p, oq);
     }
   }
-  const double d[3] = { oq[0] - p[0], oq[1] - p[1], oq[2] - p[2] };
-  const double len = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+  const double len = tmx_contact_normal(p, oq, inside, c.n);
   const double rs = P->ls_radius[s];
   c.distance = len - rs - P->ob_radius[o];
   double pw[3];
   for (int rr = 0; rr < 3; ++rr)
-  {
-    c.n[rr] = (len > 0) ? d[rr] / len : (rr == 2 ? 1.0 : 0.0);
     pw[rr] = p[rr] + rs * c.n[rr];
-  }
   for (int rr = 0; rr < 3; ++rr)
     c.p_local[rr] = Ta.R[0 + rr] * (pw[0] - Ta.t[0]) + Ta.R[3 + rr] * (pw[1] - Ta.t[1]) + Ta.R[6 + rr] * (pw[2] - Ta.t[2]);
   for (int k = 0; k < 9; ++k)
