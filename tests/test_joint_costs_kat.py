@@ -307,3 +307,21 @@ def test_finite_difference_derivatives(orc, hostemu_lib):
         assert np.abs(dv[0] - cv).max() < 1e-30    # the same differences of differences, bit for bit
         ctx.close()
     assert abs(d3 - 6.0) == 0 and d1 == 0 and d2 == 0
+
+
+def test_large_smoothing_problems_are_refused_not_hung(hostemu_lib):
+    """BASELINE config 1 with acceleration + jerk smoothing costs: 572 QP variables, beyond what the dense engine solves in practical
+    time - an explicit refusal at upload, and the documented override"""
+    import os
+    from trajopt_amd import configs
+    pci, s, g = configs.config1()
+    pci.cost_infos.append(JointAccTermInfo(coeffs=[1.0] * 7, targets=[0.0] * 7, first_step=0, last_step=29, name="acc"))
+    ctx = runtime.Context(0, hostemu_lib)
+    with pytest.raises(runtime.TmxError, match="dense engine"):
+        ctx.upload(pci.to_desc(), abi.default_sqp_params(), abi.default_osqp_settings())
+    os.environ["TMX_DENSE_QP_MAX_N"] = "4096"
+    try:
+        ctx.upload(pci.to_desc(), abi.default_sqp_params(), abi.default_osqp_settings())     # accepted (not run here)
+    finally:
+        del os.environ["TMX_DENSE_QP_MAX_N"]
+    ctx.close()

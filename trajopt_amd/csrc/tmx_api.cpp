@@ -1204,6 +1204,24 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
   ctx->smem_small = std::max<size_t>(ctx->smem_small, tmx_cvx_scratch_doubles(P.n_cp, D) * sizeof(double));
   ctx->dense = P.qp_dense != 0;
   if (ctx->dense)
+  {
+    // The dense engine inverts n x n (every rho update) and (n + active rows)^2 (polish) matrices by Gauss-Jordan, one workgroup per
+    // problem on an HBM-resident matrix: fine for the few-hundred-variable QPs of the reference's KATs, minutes per batch at the
+    // size of BASELINE config 1 with smoothing costs (n = 572: a 64-seed batch did not finish in 800 s).  Refuse instead of hanging;
+    // TMX_DENSE_QP_MAX_N lifts the limit for callers who accept the time.
+    int max_n = 448;
+    if (const char* e = std::getenv("TMX_DENSE_QP_MAX_N"))
+      max_n = std::max(1, std::atoi(e));
+    if (P.n_max > max_n)
+    {
+      ctx->err = "acceleration / jerk / function terms: the QP of this problem has too many variables for the dense engine to solve in "
+                 "practical time (limit 448 incl. penalty variables; TMX_DENSE_QP_MAX_N overrides); a banded solver for such problems "
+                 "is not built yet";
+      ctx->have_problem = false;
+      return TMX_ERR_UNSUPPORTED;
+    }
+  }
+  if (ctx->dense)
     ctx->smem_small = std::max<size_t>(ctx->smem_small, 320 * sizeof(double));  // reduction scratch of qp_generic_block
 #ifdef TMX_HOST_EMU
   ctx->nt_qp = 1;
