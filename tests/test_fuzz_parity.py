@@ -36,6 +36,18 @@ def test_random_problems_with_segment_collision_on_host_build(hostemu_lib, orc):
     _sweep(30, 41, hostemu_lib, "lvs")
 
 
+def test_random_problems_with_round3_features_on_host_build(hostemu_lib, orc):
+    """capsule links, capsule / rounded-box obstacles, JointAcc / JointJerk terms (dense QP engine), function terms (tmx_expr programs:
+    CostFromFunc, CostFromErrFunc, ConstraintFromErrFunc) drawn next to the older term families"""
+    _sweep(24, 11, hostemu_lib, "new", "lvs")
+
+
+@pytest.mark.gpu
+def test_random_problems_with_round3_features_on_device(orc):
+    """(problems above the dense engine's size limit are drawn rarely at these sizes; the sweep counts a refusal as a failure)"""
+    _sweep(16, 13, "gpu", "new", "lvs")
+
+
 @pytest.mark.gpu
 def test_random_problems_with_pair_rows_on_device(orc):
     _sweep(24, 43, "gpu", "lvs", "links")
