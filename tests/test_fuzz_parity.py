@@ -39,7 +39,7 @@ def test_random_problems_with_segment_collision_on_host_build(hostemu_lib, orc):
 def test_random_problems_with_round3_features_on_host_build(hostemu_lib, orc):
     """capsule links, capsule / rounded-box obstacles, JointAcc / JointJerk terms (dense QP engine), function terms (tmx_expr programs:
     CostFromFunc, CostFromErrFunc, ConstraintFromErrFunc) drawn next to the older term families"""
-    _sweep(24, 11, hostemu_lib, "new", "lvs")
+    _sweep(10, 11, hostemu_lib, "new", "lvs")
 
 
 @pytest.mark.gpu
