@@ -144,6 +144,8 @@ void lowerKinematics(const ProblemConstructionInfo& pci, LoweredProblem& out)
       const auto type = col->geometry->getType();
       if (type != tesseract::geometry::GeometryType::SPHERE && type != tesseract::geometry::GeometryType::CAPSULE &&
           type != tesseract::geometry::GeometryType::BOX)
+        // (the C-ABI also takes convex triangle meshes - tmx_problem_desc::obstacle_mesh - for tesseract::geometry::ConvexMesh; that
+        //  class is not part of the trajopt tree this adapter is type-checked against, so its flattening is left to the integrator)
         PRINT_AND_THROW("collision geometry of link " + link->getName() + " is not a sphere, capsule or box: not lowered by the device path");
       const Eigen::Isometry3d g = tf0.at(link->getName()) * col->origin;
       double radius = 0.0, half = 0.0;

@@ -268,6 +268,15 @@ typedef struct
      link-core segment (capsule link, swept sphere) to the box is found by a fixed-length golden-section search on the box's convex
      signed-distance function, penetration included (include/tmx_geom.h).  obstacle_axes of a box obstacle must be zero.        */
   const double* obstacle_boxes;
+  /* optional CONVEX TRIANGLE-MESH obstacles (convex hulls): obstacle_mesh = 2 ints per obstacle (first triangle, number of triangles;
+     0 triangles: not a mesh) into mesh_triangles, 9 doubles per triangle = three WORLD-frame vertices, counter-clockwise seen from
+     outside; `center` of such an obstacle is not used, `radius` (>= 0) rounds the hull.  Signed distance with penetration: closest
+     point over the triangles outside, nearest face plane inside; segments by the golden-section search of the boxes
+     (include/tmx_geom.h).  An obstacle is at most one of capsule / box / mesh.                                            */
+  const int32_t* obstacle_mesh;
+  const double* mesh_triangles;
+  int32_t n_mesh_triangles;
+  int32_t pad4_;
 } tmx_problem_desc;
 
 typedef enum

@@ -5,7 +5,8 @@
  * normal, nearest point, cc_time - are bit-identical on both sides (no FMA contraction in either build).
  *
  * Obstacle primitives: SPHERE (centre, radius), CAPSULE = the sphere swept from `centre` to `centre + axis` and (round 3) the
- * rounded BOX (tmx_problem_desc::obstacle_boxes, signed distance with penetration); link primitives: sphere and capsule.
+ * rounded BOX (tmx_problem_desc::obstacle_boxes) and CONVEX TRIANGLE MESH (obstacle_mesh / mesh_triangles), both with signed
+ * distance and penetration; link primitives: sphere and capsule.
  * (tmx_problem_desc::obstacle_axes; a zero axis is a sphere).  In the reference these contacts come from
  * tesseract / Bullet (trajopt/src/collision_terms.cpp:655-691 discrete, :1064-1173 cast); for sphere-vs-sphere and
  * sphere-vs-capsule the signed distance, the normal and the nearest points have the closed forms below.
@@ -143,12 +144,132 @@ TMX_GM_FN double tmx_box_sdf(const double oc[3], const double* ob, const double 
   return sd;
 }
 
+/* ---- CONVEX TRIANGLE-MESH obstacles: nt triangles of 9 doubles (three world-frame vertices, counter-clockwise seen from
+ * outside), the boundary of a convex polytope (a convex hull).  Internally a mesh obstacle is a 12-double record like a box with the
+ * tag ob[0] = -1, ob[1] = number of triangles, ob[2] = offset (in doubles) into the mesh array. ---- */
+TMX_GM_FN int tmx_is_mesh(const double* ob) { return ob != 0 && ob[0] == -1.0; }
+
+/* closest point of the triangle (a, b, c) to p (Voronoi-region walk: vertices, edges, face) */
+TMX_GM_FN void tmx_tri_closest(const double* a, const double* b, const double* c, const double p[3], double q[3])
+{
+  const double ab[3] = { b[0] - a[0], b[1] - a[1], b[2] - a[2] }, ac[3] = { c[0] - a[0], c[1] - a[1], c[2] - a[2] };
+  const double ap[3] = { p[0] - a[0], p[1] - a[1], p[2] - a[2] };
+  const double d1 = ab[0] * ap[0] + ab[1] * ap[1] + ab[2] * ap[2], d2 = ac[0] * ap[0] + ac[1] * ap[1] + ac[2] * ap[2];
+  double u = 0.0, v = 0.0; /* q = a + u ab + v ac */
+  if (d1 <= 0.0 && d2 <= 0.0)
+  {
+    u = 0.0;
+    v = 0.0;
+  }
+  else
+  {
+    const double bp[3] = { p[0] - b[0], p[1] - b[1], p[2] - b[2] };
+    const double d3 = ab[0] * bp[0] + ab[1] * bp[1] + ab[2] * bp[2], d4 = ac[0] * bp[0] + ac[1] * bp[1] + ac[2] * bp[2];
+    const double cp[3] = { p[0] - c[0], p[1] - c[1], p[2] - c[2] };
+    const double d5 = ab[0] * cp[0] + ab[1] * cp[1] + ab[2] * cp[2], d6 = ac[0] * cp[0] + ac[1] * cp[1] + ac[2] * cp[2];
+    const double vc = d1 * d4 - d3 * d2, vb = d5 * d2 - d1 * d6, va = d3 * d6 - d5 * d4;
+    if (d3 >= 0.0 && d4 <= d3)
+    {
+      u = 1.0; /* vertex b */
+      v = 0.0;
+    }
+    else if (vc <= 0.0 && d1 >= 0.0 && d3 <= 0.0)
+    {
+      u = d1 / (d1 - d3); /* edge ab */
+      v = 0.0;
+    }
+    else if (d6 >= 0.0 && d5 <= d6)
+    {
+      u = 0.0; /* vertex c */
+      v = 1.0;
+    }
+    else if (vb <= 0.0 && d2 >= 0.0 && d6 <= 0.0)
+    {
+      u = 0.0; /* edge ac */
+      v = d2 / (d2 - d6);
+    }
+    else if (va <= 0.0 && (d4 - d3) >= 0.0 && (d5 - d6) >= 0.0)
+    {
+      const double w = (d4 - d3) / ((d4 - d3) + (d5 - d6)); /* edge bc */
+      u = 1.0 - w;
+      v = w;
+    }
+    else
+    {
+      const double denom = 1.0 / (va + vb + vc); /* inside the face */
+      u = vb * denom;
+      v = vc * denom;
+    }
+  }
+  for (int i = 0; i < 3; ++i)
+    q[i] = a[i] + u * ab[i] + v * ac[i];
+}
+
+/* signed distance of p to the convex mesh (negative inside) and the surface point q it is measured to: outside the closest point
+ * over all triangles (first minimum), inside the projection on the nearest face plane */
+TMX_GM_FN double tmx_mesh_sdf(const double* tri, int nt, const double p[3], double q[3])
+{
+  double best_plane = -1e300, best_d2 = 1e300;
+  int kin = 0;
+  double qb[3] = { p[0], p[1], p[2] };
+  for (int k = 0; k < nt; ++k)
+  {
+    const double *a = tri + 9 * k, *b = a + 3, *c = a + 6;
+    const double ab[3] = { b[0] - a[0], b[1] - a[1], b[2] - a[2] }, ac[3] = { c[0] - a[0], c[1] - a[1], c[2] - a[2] };
+    double n[3] = { ab[1] * ac[2] - ab[2] * ac[1], ab[2] * ac[0] - ab[0] * ac[2], ab[0] * ac[1] - ab[1] * ac[0] };
+    const double nl = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+    if (!(nl > 0.0))
+      continue; /* degenerate triangle */
+    const double pd = (n[0] * (p[0] - a[0]) + n[1] * (p[1] - a[1]) + n[2] * (p[2] - a[2])) / nl;
+    if (pd > best_plane)
+    {
+      best_plane = pd;
+      kin = k;
+    }
+    double qq[3];
+    tmx_tri_closest(a, b, c, p, qq);
+    const double dx = p[0] - qq[0], dy = p[1] - qq[1], dz = p[2] - qq[2];
+    const double d2 = dx * dx + dy * dy + dz * dz;
+    if (d2 < best_d2)
+    {
+      best_d2 = d2;
+      qb[0] = qq[0];
+      qb[1] = qq[1];
+      qb[2] = qq[2];
+    }
+  }
+  if (best_plane <= 0.0 && nt > 0)
+  {
+    /* inside (or on) every face plane: the nearest boundary point is the projection on the plane of face kin */
+    const double *a = tri + 9 * kin, *b = a + 3, *c = a + 6;
+    const double ab[3] = { b[0] - a[0], b[1] - a[1], b[2] - a[2] }, ac[3] = { c[0] - a[0], c[1] - a[1], c[2] - a[2] };
+    double n[3] = { ab[1] * ac[2] - ab[2] * ac[1], ab[2] * ac[0] - ab[0] * ac[2], ab[0] * ac[1] - ab[1] * ac[0] };
+    const double nl = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+    for (int i = 0; i < 3; ++i)
+      q[i] = p[i] - best_plane * (n[i] / nl);
+    return best_plane;
+  }
+  q[0] = qb[0];
+  q[1] = qb[1];
+  q[2] = qb[2];
+  return sqrt(best_d2);
+}
+
+/* signed distance to a box or mesh core */
+TMX_GM_FN double tmx_shape_sdf(const double oc[3], const double* ob, const double* mesh, const double p[3], double q[3])
+{
+  if (tmx_is_mesh(ob))
+    return tmx_mesh_sdf(mesh + (long long)ob[2], (int)ob[1], p, q);
+  return tmx_box_sdf(oc, ob, p, q);
+}
+
 /* point of the obstacle core closest to c for any primitive; returns 1 when c lies inside a box core (q is then the nearest face
  * point: the caller's distance is negative and its normal points from q to c) */
-TMX_GM_FN int tmx_obstacle_closest_to_point_b(const double oc[3], const double* oa, const double* ob, const double c[3], double q[3])
+TMX_GM_FN int tmx_obstacle_closest_to_point_b(const double oc[3], const double* oa, const double* ob, const double* mesh, const double c[3],
+                                              double q[3])
 {
-  if (tmx_is_box(ob))
-    return tmx_box_sdf(oc, ob, c, q) < 0.0 ? 1 : 0;
+  if (tmx_is_box(ob) || tmx_is_mesh(ob))
+    return tmx_shape_sdf(oc, ob, mesh, c, q) < 0.0 ? 1 : 0;
   tmx_obstacle_closest_to_point(oc, oa, c, q);
   return 0;
 }
@@ -158,15 +279,15 @@ TMX_GM_FN int tmx_obstacle_closest_to_point_b(const double oc[3], const double* 
  * the kernels), then the end points take over when they are at least as close (tau is exactly 0 or 1 there, as the evaluators'
  * cc_type tests expect; a tie goes to the start of the sweep). */
 TMX_GM_FN double tmx_swept_closest_to_obstacle_b(const double ca[3], const double e[3], const double oc[3], const double* oa, const double* ob,
-                                                 double q[3], int* inside)
+                                                 const double* mesh, double q[3], int* inside)
 {
   *inside = 0;
-  if (!tmx_is_box(ob))
+  if (!tmx_is_box(ob) && !tmx_is_mesh(ob))
     return tmx_swept_closest_to_obstacle(ca, e, oc, oa, q);
   const double ee = e[0] * e[0] + e[1] * e[1] + e[2] * e[2];
   double p[3], qq[3];
   double tau = 0.0;
-  double f0 = tmx_box_sdf(oc, ob, ca, q);
+  double f0 = tmx_shape_sdf(oc, ob, mesh, ca, q);
   if (ee > TMX_GM_EPS)
   {
     const double gr = 0.6180339887498949; /* (sqrt(5) - 1) / 2 */
@@ -174,10 +295,10 @@ TMX_GM_FN double tmx_swept_closest_to_obstacle_b(const double ca[3], const doubl
     double x1 = b - gr * (b - a), x2 = a + gr * (b - a);
     for (int i = 0; i < 3; ++i)
       p[i] = ca[i] + x1 * e[i];
-    double f1 = tmx_box_sdf(oc, ob, p, qq);
+    double f1 = tmx_shape_sdf(oc, ob, mesh, p, qq);
     for (int i = 0; i < 3; ++i)
       p[i] = ca[i] + x2 * e[i];
-    double f2 = tmx_box_sdf(oc, ob, p, qq);
+    double f2 = tmx_shape_sdf(oc, ob, mesh, p, qq);
     for (int it = 0; it < 64; ++it)
     {
       if (f1 <= f2)
@@ -188,7 +309,7 @@ TMX_GM_FN double tmx_swept_closest_to_obstacle_b(const double ca[3], const doubl
         x1 = b - gr * (b - a);
         for (int i = 0; i < 3; ++i)
           p[i] = ca[i] + x1 * e[i];
-        f1 = tmx_box_sdf(oc, ob, p, qq);
+        f1 = tmx_shape_sdf(oc, ob, mesh, p, qq);
       }
       else
       {
@@ -198,17 +319,17 @@ TMX_GM_FN double tmx_swept_closest_to_obstacle_b(const double ca[3], const doubl
         x2 = a + gr * (b - a);
         for (int i = 0; i < 3; ++i)
           p[i] = ca[i] + x2 * e[i];
-        f2 = tmx_box_sdf(oc, ob, p, qq);
+        f2 = tmx_shape_sdf(oc, ob, mesh, p, qq);
       }
     }
     const double tm = 0.5 * (a + b);
     for (int i = 0; i < 3; ++i)
       p[i] = ca[i] + tm * e[i];
-    const double fm = tmx_box_sdf(oc, ob, p, qq);
+    const double fm = tmx_shape_sdf(oc, ob, mesh, p, qq);
     for (int i = 0; i < 3; ++i)
       p[i] = ca[i] + e[i];
     double q1[3];
-    const double fe = tmx_box_sdf(oc, ob, p, q1);
+    const double fe = tmx_shape_sdf(oc, ob, mesh, p, q1);
     if (f0 <= fm && f0 <= fe)
       tau = 0.0; /* q already holds the start point's contact */
     else if (fe <= fm)
@@ -247,7 +368,7 @@ TMX_GM_FN double tmx_contact_normal(const double p[3], const double q[3], int in
  * to the obstacle's core, q = the obstacle's closest core point; the caller subtracts both radii.  (A capsule link against a capsule
  * obstacle is the two-segment problem of tmx_swept_closest_to_obstacle with the link's own axis in place of the sweep.) */
 TMX_GM_FN int tmx_link_closest_to_obstacle_b(const double c[3], const double* e, const double oc[3], const double* oa, const double* ob,
-                                             double p[3], double q[3])
+                                             const double* mesh, double p[3], double q[3])
 {
   double ee = 0.0;
   if (e)
@@ -257,10 +378,10 @@ TMX_GM_FN int tmx_link_closest_to_obstacle_b(const double c[3], const double* e,
     p[0] = c[0];
     p[1] = c[1];
     p[2] = c[2];
-    return tmx_obstacle_closest_to_point_b(oc, oa, ob, c, q);
+    return tmx_obstacle_closest_to_point_b(oc, oa, ob, mesh, c, q);
   }
   int inside = 0;
-  const double s = tmx_swept_closest_to_obstacle_b(c, e, oc, oa, ob, q, &inside);
+  const double s = tmx_swept_closest_to_obstacle_b(c, e, oc, oa, ob, mesh, q, &inside);
   p[0] = c[0] + s * e[0];
   p[1] = c[1] + s * e[1];
   p[2] = c[2] + s * e[2];

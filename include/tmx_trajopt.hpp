@@ -148,6 +148,8 @@ struct Environment
   std::vector<tmx_obstacle_sphere> obstacles;                             // world collision geometry: spheres ...
   std::vector<double> obstacle_axes;  // ... or capsules: 3 per obstacle (swept from centre to centre + axis); empty = all spheres
   std::vector<double> obstacle_boxes;  // ... or rounded boxes: 12 per obstacle (half extents, rotation world_R_box row-major); empty = none
+  std::vector<int32_t> obstacle_mesh;  // ... or convex triangle meshes: 2 per obstacle (first triangle, number of triangles); empty = none
+  std::vector<double> mesh_triangles;  // 9 per triangle: three world-frame vertices, counter-clockwise seen from outside
   std::shared_ptr<const JointGroup> getJointGroup(const std::string& manip) const
   {
     auto it = manipulators.find(manip);
@@ -422,6 +424,12 @@ public:
     d.obstacles = env_ ? env_->obstacles.data() : nullptr;
     d.obstacle_axes = (env_ && env_->obstacle_axes.size() == 3 * env_->obstacles.size() && !env_->obstacles.empty()) ? env_->obstacle_axes.data() : nullptr;
     d.obstacle_boxes = (env_ && env_->obstacle_boxes.size() == 12 * env_->obstacles.size() && !env_->obstacles.empty()) ? env_->obstacle_boxes.data() : nullptr;
+    if (env_ && env_->obstacle_mesh.size() == 2 * env_->obstacles.size() && !env_->mesh_triangles.empty())
+    {
+      d.obstacle_mesh = env_->obstacle_mesh.data();
+      d.mesh_triangles = env_->mesh_triangles.data();
+      d.n_mesh_triangles = static_cast<int32_t>(env_->mesh_triangles.size() / 9);
+    }
     d.n_fixed_steps = static_cast<int32_t>(fixed_steps_.size());
     d.fixed_steps = fixed_steps_.data();
     d.n_fixed_dofs = static_cast<int32_t>(fixed_dofs_.size());

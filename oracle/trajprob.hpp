@@ -795,6 +795,7 @@ struct Scene
   const double* axisOf(std::size_t o) const { return obstacle_axes.empty() ? nullptr : obstacle_axes.data() + 3 * o; }
   std::vector<double> obstacle_boxes;  // 12 per obstacle (half extents, rotation): rounded box obstacles (include/tmx_geom.h); empty: none
   const double* boxOf(std::size_t o) const { return obstacle_boxes.empty() ? nullptr : obstacle_boxes.data() + 12 * o; }
+  std::vector<double> mesh;  // triangle soup of the convex-mesh obstacles (their 12-double records carry the tag -1, count, offset)
   std::vector<double> link_axes;  // 3 per link sphere, link frame (capsule link = sphere swept from centre to centre + axis); empty: spheres
   // world axis of link primitive s under the link pose T (false: a sphere)
   template <class TF>
@@ -837,7 +838,7 @@ inline void calcContacts(const Chain& chain, const Scene& scene, const double* q
       double oq[3];  // closest point of the obstacle primitive to the link primitive's core (sphere centre / capsule segment)
       double e[3], pc[3];
       const bool capsule = scene.linkAxisWorld(s, T, e);
-      const int inside = tmx_link_closest_to_obstacle_b(c, capsule ? e : nullptr, ob.center, scene.axisOf(o), scene.boxOf(o), pc, oq);
+      const int inside = tmx_link_closest_to_obstacle_b(c, capsule ? e : nullptr, ob.center, scene.axisOf(o), scene.boxOf(o), scene.mesh.data(), pc, oq);
       double nrm[3];
       const double len = tmx_contact_normal(pc, oq, inside, nrm);
       const double dist = len - ls.radius - ob.radius;
@@ -1083,7 +1084,7 @@ struct LvsEvaluatorData  // the contact model itself (shared by the sco terms be
             double cb[3];
             sphereCentre(Tb, ls, cb);
             const double e[3] = { cb[0] - ca[0], cb[1] - ca[1], cb[2] - ca[2] };
-            tau = tmx_swept_closest_to_obstacle_b(ca, e, ob.center, scene->axisOf(o), scene->boxOf(o), oq, &inside);
+            tau = tmx_swept_closest_to_obstacle_b(ca, e, ob.center, scene->axisOf(o), scene->boxOf(o), scene->mesh.data(), oq, &inside);
             for (int r = 0; r < 3; ++r)
               p[r] = ca[r] + tau * e[r];
             c.tf0 = Ta;
@@ -1093,7 +1094,7 @@ struct LvsEvaluatorData  // the contact model itself (shared by the sco terms be
           {
             double ea[3];
             const bool capsule = scene->linkAxisWorld(s, Ta, ea);
-            inside = tmx_link_closest_to_obstacle_b(ca, capsule ? ea : nullptr, ob.center, scene->axisOf(o), scene->boxOf(o), p, oq);
+            inside = tmx_link_closest_to_obstacle_b(ca, capsule ? ea : nullptr, ob.center, scene->axisOf(o), scene->boxOf(o), scene->mesh.data(), p, oq);
             c.tf0 = Ta;
             c.tf1 = Ta;
           }
@@ -1266,6 +1267,20 @@ inline TrajProblem constructProblem(const tmx_problem_desc& d, const double* ini
     P.scene->obstacle_axes.assign(d.obstacle_axes, d.obstacle_axes + 3 * d.n_obstacles);
   if (d.obstacle_boxes)
     P.scene->obstacle_boxes.assign(d.obstacle_boxes, d.obstacle_boxes + 12 * d.n_obstacles);
+  if (d.obstacle_mesh && d.mesh_triangles)
+  {
+    if (P.scene->obstacle_boxes.empty())
+      P.scene->obstacle_boxes.assign(static_cast<std::size_t>(12) * d.n_obstacles, 0.0);
+    P.scene->mesh.assign(d.mesh_triangles, d.mesh_triangles + static_cast<std::size_t>(9) * d.n_mesh_triangles);
+    for (int o = 0; o < d.n_obstacles; ++o)
+      if (d.obstacle_mesh[2 * o + 1] > 0)
+      {
+        double* rec = P.scene->obstacle_boxes.data() + 12 * o;
+        rec[0] = -1.0;
+        rec[1] = d.obstacle_mesh[2 * o + 1];
+        rec[2] = 9.0 * d.obstacle_mesh[2 * o];
+      }
+  }
   if (d.link_sphere_axes)
     P.scene->link_axes.assign(d.link_sphere_axes, d.link_sphere_axes + 3 * d.n_link_spheres);
   const int T = d.n_steps, D = d.n_dof;

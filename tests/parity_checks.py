@@ -14,8 +14,23 @@ from trajopt_amd import abi, configs
 TOL_TRAJ = 1e-5      # rad — north_star tolerance for joint trajectories / QP primal solutions
 
 # configuration ids of cfg() below: every id runs the stage checks on both tiers; MINI_CIDS also the whole SQP
-MINI_CIDS = [9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33]
+MINI_CIDS = [9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35]
 STAGE_CIDS = [0, 1, 2, 3] + MINI_CIDS
+
+
+def convex_hull_triangles(points):
+    """triangles [nt][3][3] of the convex hull of `points`, counter-clockwise seen from outside (scipy's Qhull facets re-oriented)"""
+    from scipy.spatial import ConvexHull
+    pts = np.asarray(points, dtype=np.float64)
+    hull = ConvexHull(pts)
+    mid = pts[hull.vertices].mean(axis=0)
+    tris = []
+    for simplex in hull.simplices:
+        a, b, c = pts[simplex]
+        if np.dot(np.cross(b - a, c - a), a - mid) < 0:
+            b, c = c, b
+        tris.append([a, b, c])
+    return np.asarray(tris)
 
 
 def cfg(cid, T=None):
@@ -82,6 +97,18 @@ def cfg(cid, T=None):
         n = pci.basic_info.n_steps
         ti = CartVelTermInfo(first_step=1, last_step=n - 2, max_displacement=0.07, is_constraint=(cid == 23))
         (pci.cnt_infos if cid == 23 else pci.cost_infos).append(ti)
+        return pci, s, g
+    if cid in (34, 35):
+        # CONVEX-MESH obstacles (tmx_problem_desc::obstacle_mesh / mesh_triangles): the convex hull of 14 points across the path, rounded
+        # by 1 cm, next to the original sphere; 34 single-time-step cost, 35 LVS_CONTINUOUS (cast) constraint
+        from trajopt_amd.problem import CollisionTermInfo
+        pci, s, g = configs.config_mini(collision_cnt=(cid == 35)) if T is None else configs.config_mini(T, collision_cnt=(cid == 35))
+        (c0, r0) = pci.obstacles[0]
+        pts = np.asarray(c0)[None, :] + np.array([-0.05, 0.02, 0.12])[None, :] + np.random.default_rng(7).uniform(-1, 1, (14, 3)) * np.array([0.14, 0.18, 0.06])
+        pci.obstacles = [(tuple(pts.mean(axis=0)), 0.01, ("mesh", convex_hull_triangles(pts))), (c0, r0)]
+        for ti in pci.cost_infos + pci.cnt_infos:
+            if isinstance(ti, CollisionTermInfo) and cid == 35:
+                ti.evaluator_type, ti.longest_valid_segment_length, ti.max_substates = 4, 0.12, 4
         return pci, s, g
     if cid in (31, 32, 33):
         # BOX obstacles (tmx_problem_desc::obstacle_boxes): a rotated, rounded box across the path next to the original sphere;

@@ -98,7 +98,7 @@ def test_box_signed_distance_against_brute_force(tmp_path):
     src.write_text('#include "tmx_geom.h"\n'
                    'double sdf(const double* oc, const double* ob, const double* c, double* q) { return tmx_box_sdf(oc, ob, c, q); }\n'
                    'double swept(const double* ca, const double* e, const double* oc, const double* ob, double* q, int* inside)'
-                   '{ return tmx_swept_closest_to_obstacle_b(ca, e, oc, 0, ob, q, inside); }\n')
+                   '{ return tmx_swept_closest_to_obstacle_b(ca, e, oc, 0, ob, 0, q, inside); }\n')
     so = tmp_path / "b.so"
     subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-shared", "-fPIC", "-I", os.path.join(root, "include"), str(src), "-o", str(so), "-lm"])
     lib = C.CDLL(str(so))
@@ -171,6 +171,44 @@ def test_box_obstacles_cost_against_brute_force(hostemu_lib, orc):
     ctx.close()
     for b in range(2):
         assert np.array_equal(cv[b], orc.evaluate(desc, x0[b], x0[b])[0])
+
+
+def test_convex_mesh_signed_distance_against_brute_force(tmp_path):
+    """tmx_mesh_sdf (include/tmx_geom.h) on random convex hulls: outside against the minimum over densely sampled triangles, inside
+    against the hull's half-space equations (scipy / Qhull)"""
+    import ctypes as C
+    import os
+    import subprocess
+    from scipy.spatial import ConvexHull
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "m.c"
+    src.write_text('#include "tmx_geom.h"\ndouble sdf(const double* tri, int nt, const double* p, double* q) { return tmx_mesh_sdf(tri, nt, p, q); }\n')
+    so = tmp_path / "m.so"
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-shared", "-fPIC", "-I", os.path.join(root, "include"), str(src), "-o", str(so), "-lm"])
+    lib = C.CDLL(str(so))
+    lib.sdf.restype = C.c_double
+    rng = np.random.default_rng(9)
+    w = np.linspace(0, 1, 41)
+    bary = np.array([(a, b, 1 - a - b) for a in w for b in w if a + b <= 1 + 1e-12])
+    for trial in range(12):
+        pts = rng.uniform(-1, 1, (int(rng.integers(6, 20)), 3)) * rng.uniform(0.1, 0.5, 3)
+        tris = pc.convex_hull_triangles(pts)
+        hull = ConvexHull(pts)
+        arr = (C.c_double * tris.size)(*tris.reshape(-1))
+        for _ in range(30):
+            p = rng.uniform(-1.3, 1.3, 3) * np.abs(pts).max(axis=0)
+            q = (C.c_double * 3)()
+            sd = lib.sdf(arr, len(tris), (C.c_double * 3)(*p), q)
+            plane = (hull.equations[:, :3] @ p + hull.equations[:, 3]).max()
+            if plane <= 0:
+                assert abs(sd - plane) < 1e-9                        # inside: distance to the nearest face plane
+            else:
+                samp = (bary[None, :, :, None] * tris[:, None, :, :]).sum(axis=2)      # [nt][n_bary][3]
+                ref = np.sqrt(((samp - p[None, None, :]) ** 2).sum(axis=2)).min()
+                edge = np.abs(tris - np.roll(tris, 1, axis=1)).max()
+                # the samples bound the distance from above; their lateral offset from the true closest point is at most one grid cell
+                assert sd > 0 and sd <= ref + 1e-12 and np.sqrt(max(ref * ref - sd * sd, 0.0)) < 0.04 * edge
+            assert abs(np.linalg.norm(np.array(q[:]) - p) - abs(sd)) < 1e-9
 
 
 def test_capsule_links_are_refused_by_the_cast_evaluators(hostemu_lib):

@@ -126,6 +126,10 @@ class ProblemDesc(C.Structure):
         ("obstacle_axes", C.POINTER(C.c_double)),
         ("link_sphere_axes", C.POINTER(C.c_double)),
         ("obstacle_boxes", C.POINTER(C.c_double)),
+        ("obstacle_mesh", C.POINTER(C.c_int32)),
+        ("mesh_triangles", C.POINTER(C.c_double)),
+        ("n_mesh_triangles", C.c_int32),
+        ("pad4_", C.c_int32),
     ]
 
 

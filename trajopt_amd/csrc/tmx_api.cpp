@@ -1078,9 +1078,31 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
       ctx->err = "an obstacle is a capsule (obstacle_axes) or a box (obstacle_boxes), not both";
       return TMX_ERR_INVALID;
     }
+    const int nt = (d->obstacle_mesh && d->mesh_triangles) ? d->obstacle_mesh[2 * o + 1] : 0;
+    if (nt < 0 || (nt > 0 && (d->obstacle_mesh[2 * o] < 0 || d->obstacle_mesh[2 * o] + nt > d->n_mesh_triangles)))
+    {
+      ctx->err = "obstacle_mesh: triangle range outside mesh_triangles";
+      return TMX_ERR_INVALID;
+    }
+    if (nt > 0)
+    {
+      if (box || (d->obstacle_axes && (d->obstacle_axes[3 * o] != 0.0 || d->obstacle_axes[3 * o + 1] != 0.0 || d->obstacle_axes[3 * o + 2] != 0.0)))
+      {
+        ctx->err = "an obstacle is at most one of capsule (obstacle_axes), box (obstacle_boxes) and mesh (obstacle_mesh)";
+        return TMX_ERR_INVALID;
+      }
+      double* rec = ob_box.data() + 12 * (size_t)o;
+      rec[0] = -1.0;
+      rec[1] = nt;
+      rec[2] = 9.0 * d->obstacle_mesh[2 * o];
+      box = true;  // (counted with the boxes: the same code path)
+    }
     n_ob_box += box ? 1 : 0;
   }
   P.n_ob_box = n_ob_box;
+  std::vector<double> mesh;
+  if (d->obstacle_mesh && d->mesh_triangles && d->n_mesh_triangles > 0)
+    mesh.assign(d->mesh_triangles, d->mesh_triangles + (size_t)9 * d->n_mesh_triangles);
   auto& pool = ctx->prob_allocs;
   tmx_status rc;
 #define UP(field, vec)                                                                                                \
@@ -1132,6 +1154,7 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
   UP(pq, pq);
   UP(ls_axis, ls_axis);
   UP(ob_box, ob_box);
+  UP(mesh, mesh);
   UP(po2, po2);
   UP(po3, po3);
   UP(fx_t, fx_t);

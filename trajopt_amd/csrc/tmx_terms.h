@@ -277,14 +277,14 @@ TMX_DEVFN double cart_vel_value(const DevProblem* P, const double* q0, const dou
 // their golden-section search grows the persistent kernel's collision code for every problem (config 1 -1 % with it inline)
 #if TMX_IS_DEVICE
 __device__ __attribute__((noinline)) static int link_closest_b_nl(const double* c, const double* e, const double* oc, const double* oa, const double* ob,
-                                                                  double* p, double* q)
+                                                                  const double* mesh, double* p, double* q)
 {
-  return tmx_link_closest_to_obstacle_b(c, e, oc, oa, ob, p, q);
+  return tmx_link_closest_to_obstacle_b(c, e, oc, oa, ob, mesh, p, q);
 }
 __device__ __attribute__((noinline)) static double swept_closest_b_nl(const double* ca, const double* e, const double* oc, const double* oa,
-                                                                      const double* ob, double* q, int* inside)
+                                                                      const double* ob, const double* mesh, double* q, int* inside)
 {
-  return tmx_swept_closest_to_obstacle_b(ca, e, oc, oa, ob, q, inside);
+  return tmx_swept_closest_to_obstacle_b(ca, e, oc, oa, ob, mesh, q, inside);
 }
 #else
 #define link_closest_b_nl tmx_link_closest_to_obstacle_b
@@ -316,7 +316,7 @@ TMX_DEVFN double contact_distance(const DevProblem* P, const double* q, int s, i
       capsule = P->ls_axis[3 * s + 0] != 0.0 || P->ls_axis[3 * s + 1] != 0.0 || P->ls_axis[3 * s + 2] != 0.0;
     }
     inside = link_closest_b_nl(c, capsule ? e : nullptr, P->ob_center + 3 * o, P->ob_axis + 3 * o,
-                                            P->n_ob_box > 0 ? P->ob_box + 12 * o : nullptr, pc, oq);
+                                            P->n_ob_box > 0 ? P->ob_box + 12 * o : nullptr, P->mesh, pc, oq);
     for (int r = 0; r < 3; ++r)
       c[r] = pc[r];
   }
@@ -391,7 +391,7 @@ TMX_DEVFN bool lvs_contact(const DevProblem* P, const double* q0, const double* 
       cb[rr] = Tb.R[3 * rr + 0] * P->ls_center[3 * s + 0] + Tb.R[3 * rr + 1] * P->ls_center[3 * s + 1] + Tb.R[3 * rr + 2] * P->ls_center[3 * s + 2] + Tb.t[rr];
     const double e[3] = { cb[0] - ca[0], cb[1] - ca[1], cb[2] - ca[2] };
     if (P->n_ob_box > 0)
-      tau = swept_closest_b_nl(ca, e, P->ob_center + 3 * o, P->ob_axis + 3 * o, P->ob_box + 12 * o, oq, &inside);
+      tau = swept_closest_b_nl(ca, e, P->ob_center + 3 * o, P->ob_axis + 3 * o, P->ob_box + 12 * o, P->mesh, oq, &inside);
     else
       tau = tmx_swept_closest_to_obstacle(ca, e, P->ob_center + 3 * o, P->ob_axis + 3 * o, oq);
     for (int rr = 0; rr < 3; ++rr)
@@ -411,7 +411,7 @@ TMX_DEVFN bool lvs_contact(const DevProblem* P, const double* q0, const double* 
         capsule = P->ls_axis[3 * s + 0] != 0.0 || P->ls_axis[3 * s + 1] != 0.0 || P->ls_axis[3 * s + 2] != 0.0;
       }
       inside = link_closest_b_nl(ca, capsule ? ea : nullptr, P->ob_center + 3 * o, P->ob_axis + 3 * o,
-                                              P->n_ob_box > 0 ? P->ob_box + 12 * o : nullptr, p, oq);
+                                              P->n_ob_box > 0 ? P->ob_box + 12 * o : nullptr, P->mesh, p, oq);
     }
     else
     {

@@ -102,7 +102,8 @@ struct DevProblem
   double *ls_axis;    // 3 per link sphere, link frame: capsule link = sphere swept from ls_center to ls_center + ls_axis (zero: sphere)
   int n_ls_capsule;   // number of link primitives with a non-zero axis
   double *ob_box;     // 12 per obstacle: half extents + rotation of a (rounded) box obstacle, zeros otherwise (include/tmx_geom.h)
-  int n_ob_box;       // number of box obstacles
+  int n_ob_box;       // number of box AND convex-mesh obstacles (a mesh obstacle's record: tag -1, triangle count, offset into `mesh`)
+  double *mesh;       // triangle soup of the convex-mesh obstacles, 9 doubles per triangle (world frame)
 };
 TMX_HOSTDEVFN int slot_is_diff(int kind) { return kind == SLOT_JOINTVEL || kind == SLOT_JOINTVEL_INEQ; }
 TMX_HOSTDEVFN int fx_is_quad(int kind) { return kind == 0 || kind == 1 || kind == 3; }  // instance owns a dynamic quadratic model

@@ -395,13 +395,21 @@ class ProblemConstructionInfo:
         # an obstacle is ((x, y, z), r) - a sphere - or ((x, y, z), r, (ax, ay, az)) - the capsule swept from centre to centre + axis
         # ... or ((x, y, z), r, ("box", (hx, hy, hz), R)) - the box of half extents h and rotation R (3x3, world_R_box; None = identity)
         # centred there and rounded by r
+        # ... or ((x, y, z), r, ("mesh", triangles)) - a convex triangle mesh, triangles = array [nt][3][3] of world-frame vertices
+        # (counter-clockwise seen from outside), rounded by r
         ob = (abi.ObstacleSphere * max(1, len(self.obstacles)))()
         ob_axes = (C.c_double * (3 * max(1, len(self.obstacles))))()
         ob_boxes = (C.c_double * (12 * max(1, len(self.obstacles))))()
+        ob_mesh = (C.c_int32 * (2 * max(1, len(self.obstacles))))()
+        tris = []
         for i, o in enumerate(self.obstacles):
             ob[i].center[:] = list(o[0])
             ob[i].radius = o[1]
-            if len(o) > 2 and isinstance(o[2], tuple) and len(o[2]) == 3 and o[2][0] == "box":
+            if len(o) > 2 and isinstance(o[2], tuple) and len(o[2]) == 2 and o[2][0] == "mesh":
+                tr = np.asarray(o[2][1], dtype=np.float64).reshape(-1, 9)
+                ob_mesh[2 * i], ob_mesh[2 * i + 1] = len(tris), len(tr)
+                tris += [list(row) for row in tr]
+            elif len(o) > 2 and isinstance(o[2], tuple) and len(o[2]) == 3 and o[2][0] == "box":
                 Rb = np.eye(3) if o[2][2] is None else np.asarray(o[2][2], dtype=np.float64).reshape(3, 3)
                 ob_boxes[12 * i:12 * i + 12] = list(o[2][1]) + list(Rb.reshape(-1))
             elif len(o) > 2:
@@ -537,6 +545,11 @@ class ProblemConstructionInfo:
             d.obstacle_axes = C.cast(ob_axes, C.POINTER(C.c_double))
         if any(len(o) > 2 and isinstance(o[2], tuple) and len(o[2]) == 3 and o[2][0] == "box" for o in self.obstacles):
             d.obstacle_boxes = C.cast(ob_boxes, C.POINTER(C.c_double))
+        mesh_arr = (C.c_double * max(1, 9 * len(tris)))(*[v for row in tris for v in row])
+        if tris:
+            d.obstacle_mesh = C.cast(ob_mesh, C.POINTER(C.c_int32))
+            d.mesh_triangles = C.cast(mesh_arr, C.POINTER(C.c_double))
+            d.n_mesh_triangles = len(tris)
         if any(len(prim) > 3 for prim in rob.link_spheres):
             d.link_sphere_axes = C.cast(ls_axes, C.POINTER(C.c_double))
         d.n_fixed_steps, d.n_terms = len(self.basic_info.fixed_timesteps), len(terms)
@@ -544,6 +557,6 @@ class ProblemConstructionInfo:
         fdofs = (C.c_int32 * max(1, len(self.basic_info.fixed_dofs)))(*self.basic_info.fixed_dofs)
         d.n_fixed_dofs, d.fixed_dofs = len(self.basic_info.fixed_dofs), fdofs
         d.flavor = int(self.flavor)
-        self._keep = [ls, ls_axes, ob, ob_axes, ob_boxes, fixed, tarr, fdofs, keep_fixed]   # keep the pointed-to arrays alive
+        self._keep = [ls, ls_axes, ob, ob_axes, ob_boxes, ob_mesh, mesh_arr, fixed, tarr, fdofs, keep_fixed]   # keep the pointed-to arrays alive
         d._keep = self._keep
         return d
