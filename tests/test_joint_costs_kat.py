@@ -309,14 +309,28 @@ def test_finite_difference_derivatives(orc, hostemu_lib):
     assert abs(d3 - 6.0) == 0 and d1 == 0 and d2 == 0
 
 
-def test_large_smoothing_problems_are_refused_not_hung(hostemu_lib):
-    """BASELINE config 1 with acceleration + jerk smoothing costs: 572 QP variables, beyond what the dense engine solves in practical
-    time - an explicit refusal at upload, and the documented override"""
+def test_smoothing_costs_at_baseline_size(hostemu_lib, orc):
+    """BASELINE config 1 with acceleration + jerk SMOOTHING COSTS (the defaults of tesseract's planning profiles): banded objective
+    on the structured solver (DevProblem::band) - whole SQP against the oracle on two seeds.  With a difference ROW of order >= 2 on
+    top (here acceleration limits) the problem needs the dense engine, which refuses 572 QP variables explicitly instead of running
+    for minutes; TMX_DENSE_QP_MAX_N is the documented override."""
     import os
+    import parity_checks as pc
     from trajopt_amd import configs
     pci, s, g = configs.config1()
     pci.cost_infos.append(JointAccTermInfo(coeffs=[1.0] * 7, targets=[0.0] * 7, first_step=0, last_step=29, name="acc"))
+    pci.cost_infos.append(JointJerkTermInfo(coeffs=[0.5] * 7, targets=[0.0] * 7, first_step=0, last_step=29, name="jerk"))
+    x0 = configs.seeds_for(1, pci, s, g, 2)
     ctx = runtime.Context(0, hostemu_lib)
+    desc = pc.make_ctx_inputs(ctx, pci, x0)
+    pc.check_evaluate(ctx, orc, desc, x0, tol=1e-12)
+    pc.check_first_qp_structure(ctx, orc, desc, x0, 0, val_tol=1e-12)
+    assert all(same for same, _ in pc.check_first_qp_solve(ctx, orc, desc, x0))
+    ctx.set_x0(x0)
+    r, o, same, dx = pc.check_full_sqp(ctx, orc, desc, x0, exact=False)
+    assert (r["status"] == o["status"]).all() and (dx < 1e-5).all(), (r["status"], o["status"], dx)
+    pci.cnt_infos.append(JointAccTermInfo(coeffs=[1.0] * 7, targets=[0.0] * 7, first_step=0, last_step=29, upper_tols=[0.3] * 7, lower_tols=[-0.3] * 7,
+                                          is_constraint=True, name="acc_limits"))
     with pytest.raises(runtime.TmxError, match="dense engine"):
         ctx.upload(pci.to_desc(), abi.default_sqp_params(), abi.default_osqp_settings())
     os.environ["TMX_DENSE_QP_MAX_N"] = "4096"

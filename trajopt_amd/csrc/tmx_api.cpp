@@ -405,7 +405,8 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
   std::vector<double> fx_consts;
   int n_fx_cost = 0;
   int n_stencil = 0;      // rows of difference order 2 / 3
-  bool qp_dense = false;  // an acceleration / jerk term is present: banded objective and / or rows on 3 - 4 waypoints
+  bool qp_dense = false;  // rows on 3 - 4 waypoints or function terms: dense QP engine
+  int band = 0;           // acceleration (2) / jerk (3) squared costs: banded objective
   std::vector<int> vel_first, vel_last, vel_cost, vel_kind, cp_t, cp_owner, cp_iscnt, cp_nrows, cp_idx, cp_slot0;
   std::vector<double> vel_coeffs, vel_targets, cp_coeff, cp_target;
   // hatch order: all costs in list order, then the constraints; sco::OptProb keeps equality constraints in front of the
@@ -693,7 +694,7 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
             ctx->err = ord == 2 ? "JointAccEqCost, trajectory is too short!" : "JointJerkEqCost, trajectory is too short!";  // :515, :768
             return TMX_ERR_INVALID;
           }
-          qp_dense = true;
+          band = std::max(band, ord);
           vel_first.push_back(tm.first_step);
           vel_last.push_back(tm.last_step);
           vel_kind.push_back(ord);
@@ -1008,6 +1009,14 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
   for (int c = 0; c < P.NX; ++c)
     p_colptr[c + 1] = p_colptr[c] + ((c >= 3 * D && po3[c - 3 * D] != 0.0) ? 1 : 0) + ((c >= 2 * D && po2[c - 2 * D] != 0.0) ? 1 : 0) +
                       ((c >= D && po[c - D] != 0.0) ? 1 : 0) + ((pd[c] != 0.0) ? 1 : 0);
+  // squared acceleration / jerk costs alone keep the structured solver (banded block factorisation of the generic path); together
+  // with pair rows (the dense-coupling chain has no banded variant) or with difference rows / function terms: dense engine
+  if (band && (qp_dense || R2 > 0))
+  {
+    qp_dense = true;
+    band = 0;
+  }
+  P.band = band;
   P.n_stencil = n_stencil;
   P.qp_dense = qp_dense ? 1 : 0;
   P.n_fx = (int)fx_t.size();
@@ -1385,6 +1394,11 @@ static tmx_status ensure_batch(tmx_ctx* ctx, int B)
   AL(step_log, b * (size_t)H.step_log_stride);
   AL(t_start, 1);
   AL(accept_flag, b);
+  if (P.band)
+  {
+    H.band_stride = (long long)qp_band_doubles(P.D, P.T);
+    AL(band_ws, b * (size_t)H.band_stride);
+  }
   if (P.qp_dense)
   {
     // dense engine: the QP in CSC form + dense workspace per problem (tmx_generic.h).  Capacity of A: every row slot with all the

@@ -42,7 +42,7 @@ TMX_DEVFN int lpart_b(const LPart& p, int k)
   return lpart_a(p, k) + base + (k < rem ? 1 : 0) - 1;
 }
 TMX_DEVFN int lpart_s(const LPart& p, int k) { return lpart_b(p, k) + 1; }
-TMX_DEVFN bool lpart_active(const QpWs& w, int NT) { return NT >= 256 && w.WL != nullptr && !TMX_HAS_PAIRS(w) && w.D <= 8; }
+TMX_DEVFN bool lpart_active(const QpWs& w, int NT) { return NT >= 256 && w.WL != nullptr && !TMX_HAS_PAIRS(w) && w.D <= 8 && w.band == 0; }
 
 // ---- factor: spikes of one interior with MFMA (matrix right-hand side, D columns) ------------------------------------
 // register layout of v_mfma_f64_16x16x4_f64:  A[i = l&15][k = l>>4],  B[k = l>>4][j = l&15],  D[(l>>4) + 4r][l&15] in

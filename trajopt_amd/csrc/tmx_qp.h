@@ -142,6 +142,11 @@ struct QpWs
   double sigma, alpha, rho, c, cinv;
   // primary (NX)
   double *xp, *zbp, *ybp, *lbp, *ubp, *qp, *Dp, *Ebp, *bbp, *tp, *pd, *po, *dxp, *dybp;
+  // banded objective (DevProblem::band = 2 | 3; 0 otherwise): couplings (t, j)-(t+2, j) / (t+3, j) and the block factors of
+  // band_factor: Wb[(k-1) T + t] = L_{t+k,t} (D x D, unit block lower banded LDL'), Mb the same times S_t (needed while factoring;
+  // its first NX doubles serve band_solve as the intermediate vector)
+  double *po2, *po3, *Wb, *Mb;
+  int band;
   // general rows (R) + coefficients (R*D)
   double *zr, *yr, *lor, *hir, *Er, *hr, *dyr, *coef;
   // aux (NA)
@@ -347,6 +352,10 @@ TMX_HOSTDEVFN bool dpart_fits(int D, int T)
   dpart_make(T, p);
   return p.P >= 2 && (p.P - 1) * D <= 64;
 }
+// LDS doubles of the descriptor copy: an EVEN count, so that everything carved behind it keeps the 16-byte alignment the double2
+// accesses of the cold arrays rely on (a descriptor of an odd number of 8-byte words once shifted them by 8 bytes: memory aperture
+// violations on every configuration)
+#define QPWS_DOUBLES (((sizeof(QpWs) + 15) / 16) * 2)
 TMX_HOSTDEVFN size_t qp_lds_doubles(int D, int T, int R, int NA, int R2 = 0)
 {
   const size_t NX = (size_t)D * T;
@@ -356,7 +365,7 @@ TMX_HOSTDEVFN size_t qp_lds_doubles(int D, int T, int R, int NA, int R2 = 0)
   const size_t gn = (size_t)p.Lmax * D, nsep = (size_t)(p.P - 1) * D;
   // the dense nested-dissection region is only reserved for problems that can take the fast path (no pair rows)
   const size_t dense = (dpart_fits(D, T) && R2 == 0) ? (size_t)p.P * gn * dpart_gstride((int)gn) + nsep * dpart_mult8((int)nsep) + 6 * 64 + (size_t)p.P * dpart_gstride((int)gn) + 64 : 0;
-  return NX + 2 + (D <= 8 ? 8 * (size_t)T : NX + 2) + (size_t)R + (size_t)T + 20 + (size_t)T * D * (D <= 8 ? 8 : D) + dense + (size_t)D * D + 256 + 4 + (sizeof(QpWs) + 7) / 8;
+  return NX + 2 + (D <= 8 ? 8 * (size_t)T : NX + 2) + (size_t)R + (size_t)T + 20 + (size_t)T * D * (D <= 8 ? 8 : D) + dense + (size_t)D * D + 256 + 4 + QPWS_DOUBLES;
 }
 // cf ("coefficients far"): the row coefficient arrays coef / c2 live in the per-problem HBM scratch instead of the cold part.
 // They are the largest cold arrays (config 4: 52 of 177 KB) and only read by row sweeps, so a problem whose workspace
@@ -445,6 +454,8 @@ TMX_DEVFN void qp_ws_carve(QpWs& w, double* lds, double* glb, double* far, int D
   w.NX = D * T;
   w.R = R;
   w.NA = NA;
+  w.band = 0;
+  w.po2 = w.po3 = w.Wb = w.Mb = nullptr;
   const int NX = w.NX;
   // ---- hot: LDS
   double* p = lds;
@@ -473,7 +484,7 @@ TMX_DEVFN void qp_ws_carve(QpWs& w, double* lds, double* glb, double* far, int D
   TAKE(hr, R + T + (R + T) % 2 + 18);  // the fast path stores e grouped by waypoint (even-aligned groups) and reads 16 entries per group
   TAKE(gj, D * D);
   TAKE(red, 256);
-  TAKE(wself, (sizeof(QpWs) + 7) / 8);
+  TAKE(wself, QPWS_DOUBLES);
   // ---- cold: global scratch
   p = glb;
   TAKE(xp, NX);
@@ -895,6 +906,225 @@ TMX_DEVFN void chain_pair_products(const QpWs& w, int tid, int NT)
 #endif
 TMX_DEVFN void chain_solve_range(const QpWs& w, int t0, int t1, int tid, int NT);
 
+// largest |entry| of the far couplings in column v of P (Ruiz column norms)
+TMX_DEVFN double band_col_norm(const QpWs& w, int v)
+{
+  const int D = w.D, t = v / D;
+  double cn = 0.0;
+  if (t > 1)
+    cn = fmax(cn, fabs(w.po2[v - 2 * D]));
+  if (t < w.T - 2)
+    cn = fmax(cn, fabs(w.po2[v]));
+  if (t > 2)
+    cn = fmax(cn, fabs(w.po3[v - 3 * D]));
+  if (t < w.T - 3)
+    cn = fmax(cn, fabs(w.po3[v]));
+  return cn;
+}
+// banded problems: the far couplings and the block factors live in their own per-problem HBM slice (DevBatch::band_ws)
+TMX_DEVFN void qp_ws_attach_band(QpWs& w, int band, double* slice)
+{
+  w.band = band;
+  if (band == 0)
+    return;
+  const size_t NX = (size_t)w.NX, TDD = (size_t)w.T * w.D * w.D;
+  w.po2 = slice;
+  w.po3 = slice + NX;
+  w.Wb = slice + 2 * NX;
+  w.Mb = w.Wb + 3 * TDD;
+}
+TMX_HOSTDEVFN size_t qp_band_doubles(int D, int T) { return 2 * (size_t)D * T + 6 * (size_t)T * D * D + 8; }
+
+// ---- BANDED block factorisation (DevProblem::band): K = L S L' with block bandwidth `band`, the off-diagonal blocks of K diagonal
+// matrices (po: t <-> t+1, po2: t <-> t+2, po3: t <-> t+3), the blocks of L dense (fill-in inside the band).
+//   S_t      = K_tt - sum_k M_k[t-k] W_k[t-k]'                          M_a[s] = L_{s+a,s} S_s ,  W_a[s] = L_{s+a,s}
+//   M_j[t]   = K_{t+j,t} - sum_{k >= 1, j+k <= band} M_{j+k}[t-k] W_k[t-k]' ;   W_j[t] = M_j[t] S_t^-1
+// In: the diagonal blocks K_tt in w.Sinv (kkt_factor).  Out: S_t^-1 in w.Sinv, W in w.Wb.  Sequential over t, block operations by the
+// workgroup.  Generic (any NT); not a hot path yet: it serves the smoothing-cost problems that used to need the dense engine.
+// the fields of the workspace the banded routines touch, by value: on the device they are separate functions (cold code: inlined
+// into the kernels - even unexecuted - they doubled the kernels' private segment and every configuration faulted with a memory
+// aperture violation on the MI355X; found by bisecting builds, not understood further)
+struct BandWs
+{
+  double *Sinv, *Wb, *Mb, *po, *po2, *po3, *gj, *red, *tp;
+  int D, DS, DDS, T, band;
+};
+TMX_DEVFN BandWs band_ws_of(const QpWs& w)
+{
+  BandWs b;
+  b.Sinv = w.Sinv;
+  b.Wb = w.Wb;
+  b.Mb = w.Mb;
+  b.po = w.po;
+  b.po2 = w.po2;
+  b.po3 = w.po3;
+  b.gj = w.gj;
+  b.red = w.red;
+  b.tp = w.tp;
+  b.D = w.D;
+  b.DS = w.DS;
+  b.DDS = w.DDS;
+  b.T = w.T;
+  b.band = w.band;
+  return b;
+}
+TMX_DEVFN double band_coupling(const BandWs& w, int k, int t, int i)
+{
+  return k == 1 ? w.po[t * w.D + i] : (k == 2 ? w.po2[t * w.D + i] : w.po3[t * w.D + i]);
+}
+TMX_DEVFN void band_factor_impl(const BandWs& w, int tid, int NT)
+{
+  const int D = w.D, DD = D * D, DS = w.DS, DDS = w.DDS, T = w.T, nb = w.band;
+  for (int t = 0; t < T; ++t)
+  {
+    double* S = w.Sinv + t * DDS;
+    for (int e = tid; e < DD; e += NT)
+    {
+      const int i = e / D, j = e % D;
+      double acc = 0.0;
+      for (int k = 1; k <= nb && k <= t; ++k)
+      {
+        const double* Mk = w.Mb + ((size_t)(k - 1) * T + (t - k)) * DD;
+        const double* Wk = w.Wb + ((size_t)(k - 1) * T + (t - k)) * DD;
+        for (int l = 0; l < D; ++l)
+          acc += Mk[i * D + l] * Wk[j * D + l];
+      }
+      w.gj[e] = S[i * DS + j] - acc;
+    }
+    TMX_SYNC();
+    for (int e = tid; e < DD; e += NT)
+      S[(e / D) * DS + e % D] = w.gj[e];
+    TMX_SYNC();
+    for (int k = 0; k < D; ++k)  // Gauss-Jordan inversion in place (as kkt_invert_chain_generic)
+    {
+      const double piv = 1.0 / S[k * DS + k];
+      TMX_SYNC();
+      for (int e = tid; e < D; e += NT)
+        w.red[192 + e] = S[e * DS + k];
+      TMX_SYNC();
+      for (int e = tid; e < DD; e += NT)
+      {
+        const int i = e / D, j = e % D;
+        double v;
+        if (i == k && j == k)
+          v = piv;
+        else if (i == k)
+          v = S[i * DS + j] * piv;
+        else if (j == k)
+          v = -w.red[192 + i] * piv;
+        else
+          v = S[i * DS + j] - w.red[192 + i] * S[k * DS + j] * piv;
+        w.gj[e] = v;
+      }
+      TMX_SYNC();
+      for (int e = tid; e < DD; e += NT)
+        S[(e / D) * DS + e % D] = w.gj[e];
+      TMX_SYNC();
+    }
+    for (int jj = 1; jj <= nb; ++jj)
+      if (t + jj < T)
+      {
+        double* Mj = w.Mb + ((size_t)(jj - 1) * T + t) * DD;
+        for (int e = tid; e < DD; e += NT)
+        {
+          const int i = e / D, c = e % D;
+          double val = (i == c) ? band_coupling(w, jj, t, i) : 0.0;
+          for (int k = 1; jj + k <= nb && k <= t; ++k)
+          {
+            const double* A = w.Mb + ((size_t)(jj + k - 1) * T + (t - k)) * DD;
+            const double* Bm = w.Wb + ((size_t)(k - 1) * T + (t - k)) * DD;
+            for (int l = 0; l < D; ++l)
+              val -= A[i * D + l] * Bm[c * D + l];
+          }
+          Mj[e] = val;
+        }
+      }
+    TMX_SYNC();
+    for (int jj = 1; jj <= nb; ++jj)
+      if (t + jj < T)
+      {
+        const double* Mj = w.Mb + ((size_t)(jj - 1) * T + t) * DD;
+        double* Wj = w.Wb + ((size_t)(jj - 1) * T + t) * DD;
+        for (int e = tid; e < DD; e += NT)
+        {
+          const int i = e / D, c = e % D;
+          double acc = 0.0;
+          for (int l = 0; l < D; ++l)
+            acc += Mj[i * D + l] * S[l * DS + c];
+          Wj[e] = acc;
+        }
+      }
+    TMX_SYNC();
+  }
+}
+// K x = b in place on w.tp:  v_t = b_t - sum_k W_k[t-k] v_{t-k} ;  y_t = S_t^-1 v_t ;  x_t = y_t - sum_k W_k[t]' x_{t+k}
+TMX_DEVFN void band_solve_impl(const BandWs& w, int tid, int NT)
+{
+  const int D = w.D, DD = D * D, DS = w.DS, DDS = w.DDS, T = w.T, nb = w.band;
+  for (int t = 1; t < T; ++t)
+  {
+    for (int i = tid; i < D; i += NT)
+    {
+      double acc = 0.0;
+      for (int k = 1; k <= nb && k <= t; ++k)
+      {
+        const double* Wk = w.Wb + ((size_t)(k - 1) * T + (t - k)) * DD + i * D;
+        const double* vp = w.tp + (t - k) * D;
+        for (int l = 0; l < D; ++l)
+          acc += Wk[l] * vp[l];
+      }
+      w.gj[i] = w.tp[t * D + i] - acc;
+    }
+    TMX_SYNC();
+    for (int i = tid; i < D; i += NT)
+      w.tp[t * D + i] = w.gj[i];
+    TMX_SYNC();
+  }
+  double* y = w.Mb;  // (the M blocks are dead after the factorisation)
+  for (int e = tid; e < T * D; e += NT)
+  {
+    const int t = e / D, i = e % D;
+    const double* S = w.Sinv + t * DDS + i * DS;
+    double acc = 0.0;
+    for (int l = 0; l < D; ++l)
+      acc += S[l] * w.tp[t * D + l];
+    y[e] = acc;
+  }
+  TMX_SYNC();
+  for (int i = tid; i < D; i += NT)
+    w.tp[(T - 1) * D + i] = y[(T - 1) * D + i];
+  TMX_SYNC();
+  for (int t = T - 2; t >= 0; --t)
+  {
+    for (int i = tid; i < D; i += NT)
+    {
+      double acc = 0.0;
+      for (int k = 1; k <= nb && t + k < T; ++k)
+      {
+        const double* Wk = w.Wb + ((size_t)(k - 1) * T + t) * DD;  // W_k[t]' : column i
+        const double* xn = w.tp + (t + k) * D;
+        for (int l = 0; l < D; ++l)
+          acc += Wk[l * D + i] * xn[l];
+      }
+      w.gj[i] = y[t * D + i] - acc;
+    }
+    TMX_SYNC();
+    for (int i = tid; i < D; i += NT)
+      w.tp[t * D + i] = w.gj[i];
+    TMX_SYNC();
+  }
+}
+
+#if TMX_IS_DEVICE
+__device__ __attribute__((noinline)) static void band_factor_nl(BandWs b) { band_factor_impl(b, threadIdx.x, blockDim.x); }
+__device__ __attribute__((noinline)) static void band_solve_nl(BandWs b) { band_solve_impl(b, threadIdx.x, blockDim.x); }
+TMX_DEVFN void band_factor(const QpWs& w, int, int) { band_factor_nl(band_ws_of(w)); }
+TMX_DEVFN void band_solve(const QpWs& w, int, int) { band_solve_nl(band_ws_of(w)); }
+#else
+TMX_DEVFN void band_factor(const QpWs& w, int tid, int NT) { band_factor_impl(band_ws_of(w), tid, NT); }
+TMX_DEVFN void band_solve(const QpWs& w, int tid, int NT) { band_solve_impl(band_ws_of(w), tid, NT); }
+#endif
+
 // ---- KKT solve: in: tp (primary rhs r1 + A'W r2 part), ta (aux rhs); out: tp = x_p, ta = x_a, hr = (A x)_r --------
 // (mode 1, polish: other conventions for the row terms, see the first branch)
 TMX_DEVFN void kkt_solve(const QpWs& w, const DevProblem* P, int mode, double sig, double delta, int tid, int NT)
@@ -998,7 +1228,9 @@ TMX_DEVFN void kkt_solve(const QpWs& w, const DevProblem* P, int mode, double si
     TMX_SYNC();
   }
   // 2. block forward / backward substitution (sequential over waypoints); row i of the block handled by thread i
-  if (TMX_HAS_PAIRS(w))
+  if (w.band)
+    band_solve(w, tid, NT);  // banded objective (acceleration / jerk costs)
+  else if (TMX_HAS_PAIRS(w))
     chain_solve_range(w, 0, T - 1, tid, NT);  // dense coupling blocks
   else
 #if TMX_IS_DEVICE
@@ -1278,6 +1510,21 @@ TMX_DEVFN double p_times(const QpWs& w, const double* x, int v)
     s += w.po[v - D] * x[v - D];
   if (t < w.T - 1)
     s += w.po[v] * x[v + D];
+  if (w.band)
+  {
+    // (exprToEigen's column order is irrelevant for a product; the far couplings follow the near ones)
+    if (t > 1)
+      s += w.po2[v - 2 * D] * x[v - 2 * D];
+    if (t < w.T - 2)
+      s += w.po2[v] * x[v + 2 * D];
+    if (w.band > 2)
+    {
+      if (t > 2)
+        s += w.po3[v - 3 * D] * x[v - 3 * D];
+      if (t < w.T - 3)
+        s += w.po3[v] * x[v + 3 * D];
+    }
+  }
   return s;
 }
 
@@ -1932,6 +2179,11 @@ TMX_DEVFN void chain_solve_range(const QpWs& w, int t0, int t1, int tid, int NT)
 }
 TMX_DEVFN void chain_solve(const QpWs& w, int tid, int NT)
 {
+  if (w.band)
+  {
+    band_solve(w, tid, NT);
+    return;
+  }
 #if TMX_IS_DEVICE
   if (lpart_active(w, NT))
   {

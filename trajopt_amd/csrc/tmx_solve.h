@@ -474,7 +474,7 @@ TMX_DEVFN void qp_structure(const DevProblem* P, const int* active, const double
       if (c < NX)
       {
         const int t = c / D;
-        if constexpr (ST)
+        if (ST || P->band)
           for (int back = 3; back >= 2; --back)  // (c - 3D, c), (c - 2D, c): couplings of the jerk / acceleration costs
           {
             const double* pb = (back == 3) ? P->po3 : P->po2;
@@ -581,6 +581,11 @@ TMX_DEVFN void qp_structure(const DevProblem* P, const int* active, const double
 // inversion stage of the factorisation: dense nested dissection (fast ADMM path) or one-sided chain
 TMX_DEVFN void kkt_invert(const QpWs& w, bool partitioned, int tid, int NT, long long* pc, long long& tlast)
 {
+  if (w.band)
+  {
+    band_factor(w, tid, NT);  // banded objective: acceleration / jerk costs (never `partitioned`: the fast path is off)
+    return;
+  }
 #if TMX_IS_DEVICE
   if (partitioned)
   {
@@ -1098,7 +1103,9 @@ TMX_DEVFN void qp_admm_generic_loop(QpWs& w, const DevProblem* P, QpInfo& info, 
 // DC > 0: the block size D is the compile-time constant DC (checked by the caller): the literal reaches every `for (j < w.D)` of
 // the inlined solver code, which then unrolls completely - all loads of a D-term dot are issued before the first wait instead of
 // one load + wait per term - with the additions in the same order (results bit-identical).
-template <bool HBM, bool PAIRS, int DC>
+// BAND = true: the instantiation for banded objectives (acceleration / jerk costs; never with pair rows).  Every other
+// instantiation keeps the literal band = 0 of qp_ws_carve: no banded code, no calls in the loops of configs 1 - 4.
+template <bool HBM, bool PAIRS, int DC, bool BAND = false>
 __device__ __attribute__((noinline)) static void qp_admm_generic_nl(const DevProblem* P_in, const DevBatch* Bt_in, int b_in, unsigned lds_in,
                                                                   double* work_in, int chain_in_lds)
 {
@@ -1127,6 +1134,8 @@ __device__ __attribute__((noinline)) static void qp_admm_generic_nl(const DevPro
   rows_compact_attach(w);
   w.sweep_regs = PAIRS;
   w.sweep_inline = PAIRS && !HBM;
+  if (BAND)  // (banded objectives are never combined with pair rows: tmx_problem_upload)
+    qp_ws_attach_band(w, P->band, Bt->band_ws + (size_t)b * (size_t)Bt->band_stride);
   QpShared* sh = reinterpret_cast<QpShared*>(w.wself);
   w.rho = sh->rho;
   w.sigma = sh->sigma;
@@ -1173,6 +1182,7 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
     if (chain_lds)  // k_*_hbm kernels only (a constant nullptr everywhere else)
       qp_ws_chain_to_lds(w, chain_lds);
   }
+  qp_ws_attach_band(w, P->band, Bt->band_ws + (size_t)b * (size_t)Bt->band_stride);
   long long pc[16] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
   long long tlast = TMX_CLK();
   const int* g_act = Bt->active + (size_t)b * R;
@@ -1239,6 +1249,11 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
     w.qp[v] = primary_q(P, Bt->qdyn + (size_t)b * NX, v);
     w.pd[v] = P->pd[v];
     w.po[v] = (v < NX - D) ? P->po[v] : 0.0;
+    if (w.band)
+    {
+      w.po2[v] = (v < NX - 2 * D) ? P->po2[v] : 0.0;
+      w.po3[v] = (v < NX - 3 * D) ? P->po3[v] : 0.0;
+    }
     w.bbp[v] = 1.0;
     w.Dp[v] = 1.0;
     w.Ebp[v] = 1.0;
@@ -1327,6 +1342,8 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
         cn = fmax(cn, fabs(w.po[v - D]));
       if (t < T - 1)
         cn = fmax(cn, fabs(w.po[v]));
+      if (w.band)
+        cn = fmax(cn, band_col_norm(w, v));
       for (int q = w.wl_start[t]; q < w.wl_start[t + 1]; ++q)
       {
         const int r = w.wl_list[q];
@@ -1373,6 +1390,13 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
       w.pd[v] = (w.tp[v] * w.pd[v]) * w.tp[v];
       if (v < NX - D)
         w.po[v] = (w.tp[v] * w.po[v]) * w.tp[v + D];
+      if (w.band)
+      {
+        if (v < NX - 2 * D)
+          w.po2[v] = (w.tp[v] * w.po2[v]) * w.tp[v + 2 * D];
+        if (v < NX - 3 * D)
+          w.po3[v] = (w.tp[v] * w.po3[v]) * w.tp[v + 3 * D];
+      }
       w.bbp[v] = (t_ebp[v] * w.bbp[v]) * w.tp[v];
       w.qp[v] *= w.tp[v];
       w.Dp[v] *= w.tp[v];
@@ -1412,6 +1436,8 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
         cn = fmax(cn, fabs(w.po[v - D]));
       if (t < T - 1)
         cn = fmax(cn, fabs(w.po[v]));
+      if (w.band)
+        cn = fmax(cn, band_col_norm(w, v));
       w.tp[v] = cn;
       qmax = fmax(qmax, fabs(w.qp[v]));
     }
@@ -1449,6 +1475,11 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
     {
       w.pd[v] *= ct;
       w.po[v] *= ct;
+      if (w.band)
+      {
+        w.po2[v] *= ct;
+        w.po3[v] *= ct;
+      }
       w.qp[v] *= ct;
     }
     TMX_ROWS(w, r)
@@ -1545,7 +1576,7 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
   // ---------------- factor + ADMM loop (osqp_solve) --------------------------------------------------------
   TMX_TICK(0);
 #if TMX_IS_DEVICE
-  const bool fast = !HBM && (NT == TMX_QP_NT) && (R <= 512) && dpart_supported(w, NT) && !TMX_HAS_PAIRS(w) && w.c_alist == nullptr;
+  const bool fast = !HBM && (NT == TMX_QP_NT) && (R <= 512) && dpart_supported(w, NT) && !TMX_HAS_PAIRS(w) && w.c_alist == nullptr && w.band == 0;
 #else
   const bool fast = false;
 #endif
@@ -1635,6 +1666,8 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
         else
           qp_admm_generic_nl<HBM, true, 0>(P, Bt, b, lds_off, HBM ? smem : nullptr, chain_lds != nullptr ? 1 : 0);
       }
+      else if (P->band)
+        qp_admm_generic_nl<HBM, false, 0, true>(P, Bt, b, lds_off, HBM ? smem : nullptr, chain_lds != nullptr ? 1 : 0);
       else if (HBM && P->D == 7)  // long horizons of 7-DOF arms (config 2)
         qp_admm_generic_nl<HBM, false, 7>(P, Bt, b, lds_off, HBM ? smem : nullptr, chain_lds != nullptr ? 1 : 0);
       else
@@ -2117,7 +2150,7 @@ TMX_DEVFN void sqp_model_values(const DevProblem* P, const DevBatch* Bt, int b, 
       for (int e = tid; e < D * len; e += NT)
       {
         const int j = e / len, i = first + e % len;
-        const double dv = (ST && pk >= 2) ? diff_value(xq, D, i, j, pk) : (pk ? xq[i * D + j] : (xq[(i + 1) * D + j] - xq[i * D + j]));
+        const double dv = (pk >= 2) ? diff_value(xq, D, i, j, pk) : (pk ? xq[i * D + j] : (xq[(i + 1) * D + j] - xq[i * D + j]));
         const double d = dv - P->vel_targets[v * TMX_MAX_DOF + j];
         vterm[(size_t)v * NX + e] = (d * d) * P->vel_coeffs[v * TMX_MAX_DOF + j];
       }

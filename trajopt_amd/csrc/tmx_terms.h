@@ -715,10 +715,11 @@ TMX_DEVFN double fx_model_value(const double* H, const double* g, double cst, co
 }
 
 // number of entries per joint of a squared joint cost minus (last_step - first_step): position 1, velocity 0, acc -1, jerk -2
+// (run-time in every instantiation: the banded structured path evaluates acceleration / jerk COSTS in the fused kernels too)
 template <bool ST>
 TMX_DEVFN int vel_len_adj(int pk)
 {
-  return (ST && pk >= 2) ? 1 - pk : pk;
+  return (pk >= 2) ? 1 - pk : pk;
 }
 // ---- finite-difference rows of order 2 / 3 (JointAcc / JointJerk, trajectory_costs.cpp:502-1016) ------------------------
 // order of a SLOT_JOINTVEL / SLOT_JOINTVEL_INEQ row: 1 (velocity: x[t], x[t+1]) unless slot_sub3 says 2 or 3
@@ -905,7 +906,7 @@ TMX_DEVFN void evaluate_terms(const DevProblem* P, const double* xv, double* cos
       // summation order: the reference's column-major Eigen array (joint-major) for trajopt_sco; row order of the constraint
       // set (segment-major) for the trajopt_sqp flavour (getExactCosts, trajopt_qp_problem.cpp:986-1001)
       const int j = (P->flavor == 1) ? e % D : e / len, i = first + ((P->flavor == 1) ? e / D : e % len);
-      const double dv = (ST && pk >= 2) ? diff_value(xv, D, i, j, pk) : (pk ? xv[i * D + j] : (xv[(i + 1) * D + j] - xv[i * D + j]));
+      const double dv = (pk >= 2) ? diff_value(xv, D, i, j, pk) : (pk ? xv[i * D + j] : (xv[(i + 1) * D + j] - xv[i * D + j]));
       const double d = dv - P->vel_targets[v * TMX_MAX_DOF + j];
       vterm[(size_t)v * P->NX + e] = (d * d) * P->vel_coeffs[v * TMX_MAX_DOF + j];
     }

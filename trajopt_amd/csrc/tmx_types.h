@@ -104,6 +104,10 @@ struct DevProblem
   double *ob_box;     // 12 per obstacle: half extents + rotation of a (rounded) box obstacle, zeros otherwise (include/tmx_geom.h)
   int n_ob_box;       // number of box AND convex-mesh obstacles (a mesh obstacle's record: tag -1, triangle count, offset into `mesh`)
   double *mesh;       // triangle soup of the convex-mesh obstacles, 9 doubles per triangle (world frame)
+  // BANDED OBJECTIVE on the structured path: acceleration / jerk squared costs ONLY (no difference rows of order >= 2, no function
+  // terms, no pair rows): the reduced KKT matrix is block banded with DIAGONAL off-diagonal blocks (po, po2, po3) - band = 2 | 3
+  // selects the banded block factorisation of the generic path (band_factor / band_solve, tmx_qp.h) instead of the dense engine
+  int band;
 };
 TMX_HOSTDEVFN int slot_is_diff(int kind) { return kind == SLOT_JOINTVEL || kind == SLOT_JOINTVEL_INEQ; }
 TMX_HOSTDEVFN int fx_is_quad(int kind) { return kind == 0 || kind == 1 || kind == 3; }  // instance owns a dynamic quadratic model
@@ -160,6 +164,9 @@ struct DevBatch
   tmx_qp_info* dq_info;                        // B
   // dynamic quadratic models of the function costs: B x n_fx_cost x (D*D | D | 1); fx_W: B x n_fx_cost x 2 D*D of work space
   double *fx_H, *fx_g, *fx_c, *fx_W;
+  // banded problems (DevProblem::band): B x band_stride doubles: scaled po2 / po3 (NX each) and the block factors W / M (3 T D^2 each)
+  double *band_ws;
+  long long band_stride;
 };
 
 // The ADMM loop of the dense fast path as separately compiled device functions (tmx_solve.h: qp_admm_fast_nl /
