@@ -1,12 +1,18 @@
 """Phase profile (needs a -DTMX_PROFILE build: make -C trajopt_amd/csrc EXTRA=-DTMX_PROFILE).
-   python tools/prof_phases.py [B] [full|first] [lib.so] [config]   - first QP solve only (default) or the whole optimize() run
+   python tools/prof_phases.py [B] [full|first] [lib.so] [config[s]]   - first QP solve only (default) or the whole optimize() run
    ("full"); config 1 (default), 2, 3 or 4"""
 import sys, os, ctypes as C, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from trajopt_amd import configs, abi, runtime
-cid = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+smooth = len(sys.argv) > 4 and sys.argv[4].endswith("s")  # "1s": config 1 + acceleration and jerk smoothing costs (banded path)
+cid = int(sys.argv[4].rstrip("s")) if len(sys.argv) > 4 else 1
 pci, s, g = {1: configs.config1, 2: configs.config2, 3: configs.config3, 4: configs.config4}[cid]()
+if smooth:
+    from trajopt_amd.problem import JointAccTermInfo, JointJerkTermInfo
+    nj = len(pci.cost_infos[0].coeffs) if hasattr(pci.cost_infos[0], "coeffs") else 7
+    pci.cost_infos.append(JointAccTermInfo(coeffs=[1.0] * nj, targets=[0.0] * nj, first_step=0, last_step=pci.basic_info.n_steps - 1, name="acc"))
+    pci.cost_infos.append(JointJerkTermInfo(coeffs=[0.5] * nj, targets=[0.0] * nj, first_step=0, last_step=pci.basic_info.n_steps - 1, name="jerk"))
 desc = pci.to_desc()
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 full = len(sys.argv) > 2 and sys.argv[2] == "full"

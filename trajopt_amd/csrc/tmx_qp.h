@@ -932,6 +932,10 @@ TMX_DEVFN void qp_ws_attach_band(QpWs& w, int band, double* slice)
   w.po3 = slice + NX;
   w.Wb = slice + 2 * NX;
   w.Mb = w.Wb + 3 * TDD;
+  // the fast path is off for these problems: its LDS region (G up to Zs) is free - the block factors W go there when they fit, so
+  // that the sweeps of band_solve do not wait for HBM at every block
+  if (w.G != nullptr && w.Zs != nullptr && (size_t)(w.Zs - w.G) >= 3 * TDD)
+    w.Wb = w.G;
 }
 TMX_HOSTDEVFN size_t qp_band_doubles(int D, int T) { return 2 * (size_t)D * T + 6 * (size_t)T * D * D + 8; }
 
@@ -941,12 +945,16 @@ TMX_HOSTDEVFN size_t qp_band_doubles(int D, int T) { return 2 * (size_t)D * T + 
 //   M_j[t]   = K_{t+j,t} - sum_{k >= 1, j+k <= band} M_{j+k}[t-k] W_k[t-k]' ;   W_j[t] = M_j[t] S_t^-1
 // In: the diagonal blocks K_tt in w.Sinv (kkt_factor).  Out: S_t^-1 in w.Sinv, W in w.Wb.  Sequential over t, block operations by the
 // workgroup.  Generic (any NT); not a hot path yet: it serves the smoothing-cost problems that used to need the dense engine.
+#if TMX_IS_DEVICE
+TMX_DEVFN double tmx_readlane_d(double v, int lane);
+#endif
 // the fields of the workspace the banded routines touch, by value: on the device they are separate functions (cold code: inlined
 // into the kernels - even unexecuted - they doubled the kernels' private segment and every configuration faulted with a memory
 // aperture violation on the MI355X; found by bisecting builds, not understood further)
 struct BandWs
 {
   double *Sinv, *Wb, *Mb, *po, *po2, *po3, *gj, *red, *tp;
+  double *y;  // T D doubles between the sweeps of band_solve: behind W in LDS when there is room, else the (dead) head of Mb in HBM
   int D, DS, DDS, T, band;
 };
 TMX_DEVFN BandWs band_ws_of(const QpWs& w)
@@ -966,6 +974,8 @@ TMX_DEVFN BandWs band_ws_of(const QpWs& w)
   b.DDS = w.DDS;
   b.T = w.T;
   b.band = w.band;
+  const size_t TDD3 = 3 * (size_t)w.T * w.D * w.D;
+  b.y = (w.Wb != nullptr && w.Wb == w.G && (size_t)(w.Zs - w.G) >= TDD3 + (size_t)w.NX) ? w.G + TDD3 : w.Mb;
   return b;
 }
 TMX_DEVFN double band_coupling(const BandWs& w, int k, int t, int i)
@@ -1080,7 +1090,7 @@ TMX_DEVFN void band_solve_impl(const BandWs& w, int tid, int NT)
       w.tp[t * D + i] = w.gj[i];
     TMX_SYNC();
   }
-  double* y = w.Mb;  // (the M blocks are dead after the factorisation)
+  double* y = w.y;  // (LDS behind W, or the head of the M blocks, dead after the factorisation)
   for (int e = tid; e < T * D; e += NT)
   {
     const int t = e / D, i = e % D;
@@ -1117,7 +1127,112 @@ TMX_DEVFN void band_solve_impl(const BandWs& w, int tid, int NT)
 
 #if TMX_IS_DEVICE
 __device__ __attribute__((noinline)) static void band_factor_nl(BandWs b) { band_factor_impl(b, threadIdx.x, blockDim.x); }
-__device__ __attribute__((noinline)) static void band_solve_nl(BandWs b) { band_solve_impl(b, threadIdx.x, blockDim.x); }
+// band_solve with the two sweeps walked by ONE wave (lane i = component i of the running vectors, which stay in registers; the other
+// components by v_readlane; no barrier per block) - the treatment of the dense-coupling chain (chain_wave_sweep).  Same products,
+// same order of additions as band_solve_impl: bit-identical.  The factors W should sit in LDS (qp_ws_attach_band) - from the HBM
+// slice every block waits for a memory round trip.
+template <int DC>
+TMX_DEVFN double band_rows_dot(const double* W0, size_t kstride, size_t row_off, size_t lstride, int nk, const double (&v)[3], int D)
+{
+  double m[3][16];
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int l = 0; l < 16; ++l)
+      m[k][l] = (k < nk && l < (DC ? DC : D)) ? W0[k * kstride + row_off + l * lstride] : 0.0;
+  double acc = 0.0;
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+    if (k < nk)
+    {
+#pragma unroll
+      for (int l = 0; l < 16; ++l)
+        if (l < (DC ? DC : D))
+          acc += m[k][l] * tmx_readlane_d(v[k], l);
+    }
+  return acc;
+}
+template <int DC>
+TMX_DEVFN void band_sweeps_wave(const BandWs& w, int lane, bool forward)
+{
+  const int D = DC ? DC : w.D, DD = D * D, T = w.T, nb = w.band;
+  const bool live = lane < D;
+  const int i = live ? lane : 0;
+  const size_t kstride = (size_t)T * DD;
+  double v[3] = { 0.0, 0.0, 0.0 };  // the three most recent vectors of the sweep (this lane's component)
+  if (forward)
+  {
+    v[0] = w.tp[i];
+    for (int t = 1; t < T; ++t)
+    {
+      const int nk = (t < nb) ? t : nb;
+      // W_k[t-k] row i, k = 1..nk : base of k = 1 is block (t-1) of band 1; band k, block t-k = base + (k-1) (kstride - DD)
+      const double acc = band_rows_dot<DC>(w.Wb + (size_t)(t - 1) * DD, kstride - DD, (size_t)i * D, 1, nk, v, D);
+      const double vt = w.tp[t * D + i] - acc;
+      if (live)
+        w.tp[t * D + i] = vt;
+      v[2] = v[1];
+      v[1] = v[0];
+      v[0] = vt;
+    }
+  }
+  else
+  {
+    const double* y = w.y;
+    v[0] = y[(T - 1) * D + i];
+    if (live)
+      w.tp[(T - 1) * D + i] = v[0];
+    for (int t = T - 2; t >= 0; --t)
+    {
+      const int nk = (T - 1 - t < nb) ? T - 1 - t : nb;
+      // W_k[t] column i, k = 1..nk : band k, block t = base + (k-1) kstride
+      const double acc = band_rows_dot<DC>(w.Wb + (size_t)t * DD, kstride, (size_t)i, (size_t)D, nk, v, D);
+      const double xt = y[t * D + i] - acc;
+      if (live)
+        w.tp[t * D + i] = xt;
+      v[2] = v[1];
+      v[1] = v[0];
+      v[0] = xt;
+    }
+  }
+}
+__device__ __attribute__((noinline)) static void band_solve_nl(BandWs w)
+{
+  const int tid = threadIdx.x, NT = blockDim.x;
+  if (NT < 64 || w.D > 16)
+  {
+    band_solve_impl(w, tid, NT);
+    return;
+  }
+  const int D = w.D, DS = w.DS, DDS = w.DDS, T = w.T;
+  if (tid < 64)
+  {
+    if (D == 7)
+      band_sweeps_wave<7>(w, tid, true);
+    else
+      band_sweeps_wave<0>(w, tid, true);
+  }
+  TMX_SYNC();
+  double* y = w.y;
+  for (int e = tid; e < T * D; e += NT)
+  {
+    const int t = e / D, i = e % D;
+    const double* S = w.Sinv + t * DDS + i * DS;
+    double acc = 0.0;
+    for (int l = 0; l < D; ++l)
+      acc += S[l] * w.tp[t * D + l];
+    y[e] = acc;
+  }
+  TMX_SYNC();
+  if (tid < 64)
+  {
+    if (D == 7)
+      band_sweeps_wave<7>(w, tid, false);
+    else
+      band_sweeps_wave<0>(w, tid, false);
+  }
+  TMX_SYNC();
+}
 TMX_DEVFN void band_factor(const QpWs& w, int, int) { band_factor_nl(band_ws_of(w)); }
 TMX_DEVFN void band_solve(const QpWs& w, int, int) { band_solve_nl(band_ws_of(w)); }
 #else

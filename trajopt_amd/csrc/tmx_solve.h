@@ -1667,7 +1667,12 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
           qp_admm_generic_nl<HBM, true, 0>(P, Bt, b, lds_off, HBM ? smem : nullptr, chain_lds != nullptr ? 1 : 0);
       }
       else if (P->band)
-        qp_admm_generic_nl<HBM, false, 0, true>(P, Bt, b, lds_off, HBM ? smem : nullptr, chain_lds != nullptr ? 1 : 0);
+      {
+        if (P->D == 7)
+          qp_admm_generic_nl<HBM, false, 7, true>(P, Bt, b, lds_off, HBM ? smem : nullptr, chain_lds != nullptr ? 1 : 0);
+        else
+          qp_admm_generic_nl<HBM, false, 0, true>(P, Bt, b, lds_off, HBM ? smem : nullptr, chain_lds != nullptr ? 1 : 0);
+      }
       else if (HBM && P->D == 7)  // long horizons of 7-DOF arms (config 2)
         qp_admm_generic_nl<HBM, false, 7>(P, Bt, b, lds_off, HBM ? smem : nullptr, chain_lds != nullptr ? 1 : 0);
       else
@@ -1709,7 +1714,8 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
     // HBM scratch; the ADMM factors G / Zs are dead by now, so on the fast path the polish keeps them in that LDS region
     // (every pass below would otherwise be a chain of dependent HBM round trips).
     QpWs wp = w;
-    if (w.G != nullptr && (size_t)(2 * NX + R + 3 * P->NA) + (size_t)(R + NX + P->NA + 1) / 2 + 2 <= (size_t)dpt.P * w.Gn * w.Gs)
+    if (w.G != nullptr && w.band == 0 /* (banded problems keep their block factors there) */ &&
+        (size_t)(2 * NX + R + 3 * P->NA) + (size_t)(R + NX + P->NA + 1) / 2 + 2 <= (size_t)dpt.P * w.Gn * w.Gs)
     {
       double* q = w.G;
       wp.dxp = q;
