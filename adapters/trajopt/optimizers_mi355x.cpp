@@ -40,6 +40,17 @@ void fill(double* dst, const DblVec& src, std::size_t n, const char* what)
   std::copy(src.begin(), src.end(), dst);
 }
 
+// index k of the moving link `name` = child link of joint k of the manipulator (-1: not one)
+int movingLinkIndex(const ProblemConstructionInfo& pci, const std::string& name)
+{
+  const auto graph = pci.env->getSceneGraph();
+  const std::vector<std::string> joint_names = pci.kin->getJointNames();
+  for (std::size_t k = 0; k < joint_names.size(); ++k)
+    if (graph->getJoint(joint_names[k])->child_link_name == name)
+      return static_cast<int>(k);
+  return -1;
+}
+
 // serial chain of the manipulator from the scene graph: per active joint the fixed transform from the previous moving link
 // to the joint frame (folding the fixed joints in between), its axis and type
 void lowerKinematics(const ProblemConstructionInfo& pci, LoweredProblem& out)
@@ -337,6 +348,49 @@ void lowerTerm(const ProblemConstructionInfo& pci, const TermInfo& ti, bool is_c
         if (std::find(fixed.begin(), fixed.end(), i) == fixed.end())
           names.push_back(ti.name + "_" + std::to_string(i));
   }
+  else if (const auto* dcp = dynamic_cast<const DynamicCartPoseTermInfo*>(&ti))
+  {
+    // DynamicCartPoseTermInfo::hatch (problem_description.cpp:752-822): source = the tool frame, target = a moving link of the chain
+    if (dcp->lower_tolerance.size() != 0 || dcp->upper_tolerance.size() != 0)
+      PRINT_AND_THROW(ti.name + ": DynamicCartPose tolerances are not lowered by the device path");
+    if (static_cast<bool>(ti.term_type & TermType::TT_USE_TIME))
+      PRINT_AND_THROW(ti.name + ": Use time version of this term has not been defined.");
+    if (dcp->source_frame != pci.kin->getActiveLinkNames().back())
+      PRINT_AND_THROW(ti.name + ": the source frame must be the manipulator's tip link (one tool frame per problem)");
+    const int target = movingLinkIndex(pci, dcp->target_frame);
+    if (target < 0)
+      PRINT_AND_THROW(ti.name + ": the target frame must be the child link of one of the manipulator's joints");
+    t.kind = TMX_TERM_DYN_CART_POSE;
+    t.first_step = t.last_step = dcp->timestep;
+    for (int i = 0; i < 3; ++i)
+    {
+      t.coeffs[i] = dcp->pos_coeffs(i);
+      t.coeffs[3 + i] = dcp->rot_coeffs(i);
+    }
+    t.link = target;
+    toRowMajor34(dcp->target_frame_offset, t.target_pose);
+    toRowMajor34(dcp->source_frame_offset, out.desc.tool);  // tcp offset on the tip link
+  }
+  else if (const auto* avs = dynamic_cast<const AvoidSingularityTermInfo*>(&ti))
+  {
+    // AvoidSingularityTermInfo::hatch (problem_description.cpp:1900-1940), the problem's full joint set; names name_<step>
+    if (avs->subset_kin_ != nullptr)
+      PRINT_AND_THROW(ti.name + ": AvoidSingularity over a subset of the joints is not lowered by the device path");
+    const int link = movingLinkIndex(pci, avs->link);
+    if (link < 0)
+      PRINT_AND_THROW(ti.name + ": the link must be the child link of one of the manipulator's joints");
+    if (avs->coeffs.size() != 1)
+      PRINT_AND_THROW(ti.name + ": one coefficient (the error has one row)");
+    t.kind = TMX_TERM_AVOID_SINGULARITY;
+    t.first_step = avs->first_step;
+    t.last_step = avs->last_step;
+    t.coeffs[0] = avs->coeffs[0];
+    t.link = link;
+    t.lambda = avs->lambda;
+    names.clear();
+    for (int i = t.first_step; i <= t.last_step; ++i)
+      names.push_back(ti.name + "_" + std::to_string(i));
+  }
   else if (const auto* cv = dynamic_cast<const CartVelTermInfo*>(&ti))
   {
     // CartVelTermInfo::hatch (problem_description.cpp:1011-1057): one cost (named after the term) / one constraint "CartVel"
@@ -352,8 +406,8 @@ void lowerTerm(const ProblemConstructionInfo& pci, const TermInfo& ti, bool is_c
     names.assign(static_cast<std::size_t>(cv->last_step - cv->first_step + 1), is_cost ? ti.name : std::string("CartVel"));
   }
   else
-    PRINT_AND_THROW("term \"" + ti.name + "\" has a TermInfo class the device path does not lower (UserDefinedTermInfo, "
-                    "DynamicCartPose, JointAcc, JointJerk, TotalTime, AvoidSingularity): solve it with the reference's "
+    PRINT_AND_THROW("term \"" + ti.name + "\" has a TermInfo class the device path does not lower (UserDefinedTermInfo with "
+                    "opaque callbacks, TotalTime): solve it with the reference's "
                     "BasicTrustRegionSQP, or with its QPs on the device through HipBatchedAdmmModel");
   auto& dst = is_cost ? out.cost_names : out.cnt_names;
   dst.insert(dst.end(), names.begin(), names.end());

@@ -148,7 +148,20 @@ typedef enum
      scaled by the coefficient, addAbs / addHinge with weight 1).  Together with TMX_TERM_FUNC_CNT this is what
      trajopt::UserDefinedTermInfo::hatch builds (trajopt/src/problem_description.cpp:599-675), one per step in
      [first_step, last_step] that is not in the term's fixed_steps.                                                        */
-  TMX_TERM_FUNC_ERR_COST = 23
+  TMX_TERM_FUNC_ERR_COST = 23,
+  /* trajopt::AvoidSingularityTermInfo::hatch  trajopt/src/problem_description.cpp:1900-1940 (full joint set): per step in
+     [first_step, last_step] a TrajOptCostFromErrFunc (sco::ABS, coeffs[0]) or TrajOptConstraintFromErrFunc (sco::INEQ) over
+     AvoidSingularityErrCalculator / AvoidSingularityJacCalculator (trajopt/src/kinematic_terms.cpp:586-635):
+     err = 1 / (s_min + lambda) - 1 / (0.1 + lambda), s_min = smallest singular value of the 6 x n_dof geometric Jacobian of
+     link `link` (origin of the link frame, base coordinates); gradient -(u' dJ/dq_k v) / (s_min + lambda)^2 with the Jacobian
+     differenced forward by 1e-6.  A built-in function of the function-term machinery (dense QP engine).                   */
+  TMX_TERM_AVOID_SINGULARITY = 24,
+  /* trajopt::DynamicCartPoseTermInfo::hatch  problem_description.cpp:752-822: BOTH frames move with the joints - the source
+     is the chain's tool frame, the target is link `link` times target_pose (= target_frame_offset, link_T_target).  EQ
+     constraint (is_constraint) or ABS cost per step over DynamicCartPoseErrCalculator / DynamicCartPoseJacCalculator
+     (kinematic_terms.cpp:59-185): err = calcTransformError(target(q), source(q)) rows with |coeff| > 1e-5, forward-difference
+     Jacobian through calcJacobianTransformErrorDiff(target, target', source, source').  Built-in function, dense QP engine. */
+  TMX_TERM_DYN_CART_POSE = 25
 } tmx_term_kind;
 
 /* ---- device-evaluable functions: a stack program over the n_dof values x[0..n_dof) of one waypoint -----------------------
@@ -217,6 +230,10 @@ typedef struct
   int32_t cnt_type;    /* 0 EQ, 1 INEQ */
   int32_t has_coeffs;
   int32_t penalty_type; /* TMX_TERM_FUNC_ERR_COST: sco::PenaltyType 0 SQUARED, 1 ABS, 2 HINGE (sco_common.hpp)               */
+  /* TMX_TERM_AVOID_SINGULARITY / TMX_TERM_DYN_CART_POSE: moving link k = child of joint k (0 .. n_dof - 1)                   */
+  int32_t link;
+  int32_t pad3_;
+  double lambda;        /* AvoidSingularityTermInfo::lambda (problem_description.hpp:643, default 0.1)                        */
 } tmx_term;
 
 typedef struct

@@ -3,7 +3,7 @@
 // Header-only mirror of the reference's caller-facing interface for the SQP hot path, so that a trajopt user finds
 // the same names, argument meaning and error behaviour (std::runtime_error where the reference PRINT_AND_THROWs):
 //
-//   tmx::trajopt::  TermType, BasicInfo, InitInfo, TermInfo, JointPosTermInfo, JointVelTermInfo, JointAccTermInfo, JointJerkTermInfo, CartPoseTermInfo,
+//   tmx::trajopt::  TermType, BasicInfo, InitInfo, TermInfo, JointPosTermInfo, JointVelTermInfo, JointAccTermInfo, JointJerkTermInfo, CartPoseTermInfo, DynamicCartPoseTermInfo, AvoidSingularityTermInfo,
 //                   CollisionTermInfo, ProblemConstructionInfo, TrajOptProb, ConstructProblem
 //                     <- trajopt/include/trajopt/problem_description.hpp:29-66, 68-107, 123-160, 162-186, 199-230,
 //                        235-262, 352-392, 421-514, 597-617, 661-663 ; trajopt/src/problem_description.cpp:410-592
@@ -133,6 +133,15 @@ struct JointGroup
   Transform base;                 // world_T_base
   Transform tool;                 // last link -> tip_link frame (tcp)
   std::string tip_link;           // the link the tool frame is attached to
+  std::vector<std::string> link_names;  // optional: child link of every joint (DynamicCartPose / AvoidSingularity name moving links)
+  /** index of a moving link (child of joint k), -1 when the name is not one */
+  int linkIndex(const std::string& link) const
+  {
+    for (std::size_t k = 0; k < link_names.size() && k < joints.size(); ++k)
+      if (link_names[k] == link)
+        return static_cast<int>(k);
+    return link == tip_link ? static_cast<int>(joints.size()) - 1 : -1;
+  }
   std::vector<tmx_link_sphere> link_spheres;
   std::vector<double> link_sphere_axes;  // ... or capsules: 3 per link sphere, link frame (swept from centre to centre + axis); empty = all spheres
   std::size_t numJoints() const { return joints.size(); }
@@ -373,6 +382,9 @@ public:
     else if (t.kind == TMX_TERM_CART_VEL)  // one cost named after the term / one constraint "CartVel" per step (:1029-1050)
       for (int i = t.first_step; i <= t.last_step; ++i)
         names.push_back(t.is_constraint ? std::string("CartVel") : name);
+    else if (t.kind == TMX_TERM_AVOID_SINGULARITY)  // name_<step> (problem_description.cpp:1924)
+      for (int i = t.first_step; i <= t.last_step; ++i)
+        names.push_back(name + "_" + std::to_string(i));
     else if (t.kind == TMX_TERM_FUNC_COST || t.kind == TMX_TERM_FUNC_CNT || t.kind == TMX_TERM_FUNC_ERR_COST)
     {
       // one sco cost / constraint per step; UserDefinedTermInfo appends the step (problem_description.cpp:611-630)
@@ -384,7 +396,7 @@ public:
       names.push_back(name);
     const bool ineq = t.kind == TMX_TERM_JOINT_POS_INEQ_CNT || t.kind == TMX_TERM_COLLISION_CNT || t.kind == TMX_TERM_JOINT_VEL_INEQ_CNT ||
                       t.kind == TMX_TERM_JOINT_ACC_INEQ_CNT || t.kind == TMX_TERM_JOINT_JERK_INEQ_CNT || t.kind == TMX_TERM_CART_VEL ||
-                      (t.kind == TMX_TERM_FUNC_CNT && t.cnt_type == 1);
+                      (t.kind == TMX_TERM_FUNC_CNT && t.cnt_type == 1) || t.kind == TMX_TERM_AVOID_SINGULARITY;
     std::vector<std::string>& dst = !t.is_constraint ? cost_names_ : (ineq ? ineq_cnt_names_ : eq_cnt_names_);
     dst.insert(dst.end(), names.begin(), names.end());
     terms_.push_back(t);
@@ -894,6 +906,92 @@ struct CartPoseTermInfo : public TermInfo
       t.is_constraint = 0;  // ABS cost (:946-960)
     else if (static_cast<bool>(term_type & TermType::TT_CNT))
       t.is_constraint = 1;  // EQ constraint (:961-976)
+    else
+      return;
+    prob.addTerm(t, {}, name);
+  }
+};
+
+/** trajopt::DynamicCartPoseTermInfo (problem_description.hpp:310-350; hatch problem_description.cpp:752-822): source and target are
+    BOTH links of the manipulator.  Lowered: source = the tip link (tool frame), target = any moving link times
+    target_frame_offset; no tolerances. */
+struct DynamicCartPoseTermInfo : public TermInfo
+{
+  int timestep{ 0 };
+  std::string source_frame;
+  std::string target_frame;
+  Transform source_frame_offset;
+  Transform target_frame_offset;
+  std::array<double, 3> pos_coeffs{ { 1, 1, 1 } };
+  std::array<double, 3> rot_coeffs{ { 1, 1, 1 } };
+  DblVec lower_tolerance;
+  DblVec upper_tolerance;
+  DynamicCartPoseTermInfo() : TermInfo(TermType::TT_COST | TermType::TT_CNT) {}
+  void hatch(TrajOptProb& prob) override
+  {
+    const auto kin = prob.GetKin();
+    const int target = kin->linkIndex(target_frame);
+    if (source_frame != kin->tip_link || target < 0)
+      printAndThrow("source '" + source_frame + "' and target '" + target_frame + "' are not both active links");  // :735
+    if (!detail::allZero(lower_tolerance) || !detail::allZero(upper_tolerance))
+      printAndThrow("DynamicCartPoseTermInfo tolerances are not lowered by the device path");
+    if (!source_frame_offset.isIdentity())
+      printAndThrow("DynamicCartPoseTermInfo source_frame_offset: fold it into JointGroup::tool (one tool frame per problem)");
+    if (timestep < 0 || timestep >= prob.GetNumSteps())
+      printAndThrow("DynamicCartPoseTermInfo timestep out of range");
+    if (static_cast<bool>(term_type & TermType::TT_USE_TIME))
+      printAndThrow("Use time version of this term has not been defined.");  // :781-784
+    tmx_term t = detail::blankTerm();
+    t.kind = TMX_TERM_DYN_CART_POSE;
+    t.first_step = t.last_step = timestep;
+    for (std::size_t k = 0; k < 3; ++k)
+    {
+      t.coeffs[k] = pos_coeffs[k];
+      t.coeffs[3 + k] = rot_coeffs[k];
+    }
+    t.link = target;
+    std::copy(target_frame_offset.m.begin(), target_frame_offset.m.end(), t.target_pose);
+    if (static_cast<bool>(term_type & TermType::TT_COST))
+      t.is_constraint = 0;  // ABS cost (:806-810)
+    else if (static_cast<bool>(term_type & TermType::TT_CNT))
+      t.is_constraint = 1;  // EQ constraint (:811-815)
+    else
+      return;
+    prob.addTerm(t, {}, name);
+  }
+};
+
+/** trajopt::AvoidSingularityTermInfo (problem_description.hpp:637-659; hatch problem_description.cpp:1900-1940) over the problem's
+    full joint set (no subset kinematics): one ABS cost / INEQ constraint per step in [first_step, last_step] */
+struct AvoidSingularityTermInfo : public TermInfo
+{
+  double lambda{ 0.1 };
+  std::string link;
+  int first_step{ -1 };
+  int last_step{ -1 };
+  DblVec coeffs;
+  explicit AvoidSingularityTermInfo(double lambda_ = 0.1) : TermInfo(TermType::TT_COST | TermType::TT_CNT), lambda(lambda_) {}
+  void hatch(TrajOptProb& prob) override
+  {
+    const auto kin = prob.GetKin();
+    const int idx = kin->linkIndex(link);
+    if (idx < 0)
+      printAndThrow("invalid link name: " + link);
+    if (first_step < 0 || last_step >= prob.GetNumSteps() || first_step > last_step)
+      printAndThrow("avoid_singularity: first_step / last_step out of range");
+    if (coeffs.size() != 1)
+      printAndThrow("avoid_singularity: one coefficient (the error has one row)");
+    tmx_term t = detail::blankTerm();
+    t.kind = TMX_TERM_AVOID_SINGULARITY;
+    t.first_step = first_step;
+    t.last_step = last_step;
+    t.coeffs[0] = coeffs[0];
+    t.link = idx;
+    t.lambda = lambda;
+    if (static_cast<bool>(term_type & TermType::TT_COST))
+      t.is_constraint = 0;  // ABS cost (:1925-1929)
+    else if (static_cast<bool>(term_type & TermType::TT_CNT))
+      t.is_constraint = 1;  // INEQ constraint (:1930-1934)
     else
       return;
     prob.addTerm(t, {}, name);

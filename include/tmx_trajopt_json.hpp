@@ -325,6 +325,33 @@ inline TermInfo::Ptr readTerm(const json::Value& it, bool is_cost, const Problem
     t->term_type = tt;
     return t;
   }
+  if (typ == "dynamic_cart_pose")
+  {
+    // DynamicCartPoseTermInfo::fromJson (problem_description.cpp:685-750): both frames are active links of the manipulator
+    ensureOnlyMembers(p, { "timestep", "pos_coeffs", "rot_coeffs", "source_frame", "target_frame", "source_frame_offset_xyz",
+                           "source_frame_offset_wxyz", "target_frame_offset_xyz", "target_frame_offset_wxyz" }, typ);
+    auto t = std::make_shared<DynamicCartPoseTermInfo>();
+    t->source_frame = p["source_frame"].asString();
+    t->target_frame = p["target_frame"].asString();
+    if (t->source_frame != pci.kin->tip_link)
+      printAndThrow("dynamic_cart_pose source_frame " + t->source_frame + ": only the manipulator tip link " + pci.kin->tip_link + " is lowered");
+    if (pci.kin->linkIndex(t->target_frame) < 0)
+    {
+      if (pci.env->link_frames.count(t->target_frame))
+        printAndThrow("source '" + t->source_frame + "' and target '" + t->target_frame + "' are not both active links");  // :733-737
+      printAndThrow("invalid target frame: " + t->target_frame);                                                          // :726-729
+    }
+    t->source_frame_offset = jsonOffset(p, "source_frame_offset_xyz", "source_frame_offset_wxyz");
+    t->target_frame_offset = jsonOffset(p, "target_frame_offset_xyz", "target_frame_offset_wxyz");
+    const DblVec one3(3, 1.0);
+    const DblVec pc = jsonVec(p, "pos_coeffs", 3, &one3), rc = jsonVec(p, "rot_coeffs", 3, &one3);
+    t->pos_coeffs = { { pc[0], pc[1], pc[2] } };
+    t->rot_coeffs = { { rc[0], rc[1], rc[2] } };
+    t->timestep = jsonInt(p, "timestep", n_steps - 1);
+    t->name = name;
+    t->term_type = tt;
+    return t;
+  }
   if (typ == "cart_vel")
   {
     // CartVelTermInfo::fromJson (problem_description.cpp:989-1009): all four fields are required

@@ -382,6 +382,44 @@ int orc_fk_tool(const tmx_problem_desc* desc, const double* q, double* tf12)
   }
   return 0;
 }
+// AvoidSingularity / DynamicCartPose calculators at one joint vector (tests): error rows and Jacobian (row-major n_rows x n_dof)
+int orc_avoid_singularity(const tmx_problem_desc* desc, const double* q, int link, double lambda, double* err, double* jac, double* sv)
+{
+  AvoidSingularityCalc c;
+  c.chain = std::make_shared<Chain>(*desc);
+  c.link = link;
+  c.lambda = lambda;
+  const DblVec qv(q, q + desc->n_dof);
+  err[0] = c.err(qv)[0];
+  const Mat J = c.jac(qv);
+  for (int k = 0; k < desc->n_dof; ++k)
+    jac[k] = J(0, k);
+  if (sv)
+  {
+    const ThinSvd svd = thinSvd(chainJacobian6(*c.chain, q, link));
+    for (std::size_t i = 0; i < svd.s.size(); ++i)
+      sv[i] = svd.s[i];
+  }
+  return 0;
+}
+int orc_dyn_cart_pose(const tmx_problem_desc* desc, const double* q, int link, const double* offset12, double* err6, double* jac)
+{
+  DynCartPoseCalc c;
+  c.chain = std::make_shared<Chain>(*desc);
+  c.link = link;
+  c.target_offset = tfFrom12(offset12);
+  c.indices = { 0, 1, 2, 3, 4, 5 };
+  const DblVec qv(q, q + desc->n_dof);
+  const DblVec e = c.err(qv);
+  const Mat J = c.jac(qv);
+  for (int r = 0; r < 6; ++r)
+  {
+    err6[r] = e[static_cast<std::size_t>(r)];
+    for (int k = 0; k < desc->n_dof; ++k)
+      jac[r * desc->n_dof + k] = J(r, k);
+  }
+  return 0;
+}
 int orc_num_threads() { return omp_get_max_threads(); }
 // ---- trajopt_ifopt / trajopt_sqp flavour (BASELINE config 4) -----------------------------------------------------------------
 namespace

@@ -786,6 +786,226 @@ struct CartPoseCalc
   }
 };
 
+// ---- AvoidSingularity  trajopt/src/kinematic_terms.cpp:586-635 ------------------------------------------------
+// 6 x n geometric Jacobian of moving link `link` (linear rows on top, angular below; reference point = origin of the link
+// frame, base coordinates): stands in for tesseract JointGroup::calcJacobian(q, link_name) [NOT IN REFERENCE]
+inline Mat chainJacobian6(const Chain& c, const double* q, int link)
+{
+  std::vector<Tf> lk, jf;
+  c.fk(q, lk, &jf);
+  const double* p = lk[static_cast<std::size_t>(link)].t;
+  Mat J(6, c.n_dof);
+  for (int k = 0; k <= link; ++k)
+  {
+    const Tf& F = jf[static_cast<std::size_t>(k)];
+    double z[3];
+    for (int r = 0; r < 3; ++r)
+      z[r] = F.R[3 * r + 0] * c.axis[k][0] + F.R[3 * r + 1] * c.axis[k][1] + F.R[3 * r + 2] * c.axis[k][2];
+    if (c.type[static_cast<std::size_t>(k)] == 0)
+    {
+      const double d[3] = { p[0] - F.t[0], p[1] - F.t[1], p[2] - F.t[2] };
+      J(0, k) = z[1] * d[2] - z[2] * d[1];
+      J(1, k) = z[2] * d[0] - z[0] * d[2];
+      J(2, k) = z[0] * d[1] - z[1] * d[0];
+      for (int r = 0; r < 3; ++r)
+        J(3 + r, k) = z[r];
+    }
+    else
+      for (int r = 0; r < 3; ++r)
+        J(r, k) = z[r];
+  }
+  return J;
+}
+// thin SVD A = U diag(s) V' by one-sided Jacobi rotations (Hestenes), singular values in decreasing order - stands in for
+// Eigen::JacobiSVD(A, ComputeThinU | ComputeThinV) (kinematic_terms.cpp:589-593, :625-631)
+struct ThinSvd
+{
+  DblVec s;
+  Mat U, V;
+};
+inline ThinSvd thinSvd(const Mat& A)
+{
+  const bool flip = A.rows < A.cols;  // work on the tall orientation
+  const int m = flip ? A.cols : A.rows, n = flip ? A.rows : A.cols;
+  Mat G(m, n), W(n, n);
+  for (int i = 0; i < m; ++i)
+    for (int j = 0; j < n; ++j)
+      G(i, j) = flip ? A(j, i) : A(i, j);
+  for (int j = 0; j < n; ++j)
+    W(j, j) = 1.0;
+  for (int sweep = 0; sweep < 80; ++sweep)
+  {
+    bool rotated = false;
+    for (int p = 0; p < n - 1; ++p)
+      for (int q = p + 1; q < n; ++q)
+      {
+        double alpha = 0.0, beta = 0.0, gamma = 0.0;
+        for (int i = 0; i < m; ++i)
+        {
+          alpha += G(i, p) * G(i, p);
+          beta += G(i, q) * G(i, q);
+          gamma += G(i, p) * G(i, q);
+        }
+        if (gamma == 0.0 || std::fabs(gamma) <= 1e-17 * std::sqrt(alpha * beta))
+          continue;
+        rotated = true;
+        const double zeta = (beta - alpha) / (2.0 * gamma);
+        const double t = ((zeta >= 0.0) ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
+        const double c = 1.0 / std::sqrt(1.0 + t * t), sn = c * t;
+        for (int i = 0; i < m; ++i)
+        {
+          const double gp = G(i, p), gq = G(i, q);
+          G(i, p) = c * gp - sn * gq;
+          G(i, q) = sn * gp + c * gq;
+        }
+        for (int i = 0; i < n; ++i)
+        {
+          const double wp = W(i, p), wq = W(i, q);
+          W(i, p) = c * wp - sn * wq;
+          W(i, q) = sn * wp + c * wq;
+        }
+      }
+    if (!rotated)
+      break;
+  }
+  std::vector<int> order(static_cast<std::size_t>(n));
+  DblVec norms(static_cast<std::size_t>(n));
+  for (int j = 0; j < n; ++j)
+  {
+    double nn = 0.0;
+    for (int i = 0; i < m; ++i)
+      nn += G(i, j) * G(i, j);
+    norms[static_cast<std::size_t>(j)] = std::sqrt(nn);
+    order[static_cast<std::size_t>(j)] = j;
+  }
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return norms[static_cast<std::size_t>(a)] > norms[static_cast<std::size_t>(b)]; });
+  ThinSvd out;
+  Mat L(m, n), R(n, n);  // left / right factors of the tall orientation
+  for (int jj = 0; jj < n; ++jj)
+  {
+    const int j = order[static_cast<std::size_t>(jj)];
+    const double sv = norms[static_cast<std::size_t>(j)];
+    out.s.push_back(sv);
+    for (int i = 0; i < m; ++i)
+      L(i, jj) = (sv > 0.0) ? G(i, j) / sv : 0.0;
+    for (int i = 0; i < n; ++i)
+      R(i, jj) = W(i, j);
+  }
+  out.U = flip ? R : L;
+  out.V = flip ? L : R;
+  return out;
+}
+struct AvoidSingularityCalc
+{
+  std::shared_ptr<const Chain> chain;
+  int link{ 0 };
+  double lambda{ 0.1 };
+  double eps{ 1.0e-6 };  // AvoidSingularityJacCalculator::eps_ (kinematic_terms.hpp:371)
+  // AvoidSingularityErrCalculator::operator()  kinematic_terms.cpp:586-603
+  DblVec err(const DblVec& q) const
+  {
+    const ThinSvd svd = thinSvd(chainJacobian6(*chain, q.data(), link));
+    const double smallest_sv = svd.s.back();
+    const double cost = 1.0 / (smallest_sv + lambda);
+    const double smallest_allowable_sv = 0.1;
+    const double threshold = 1.0 / (smallest_allowable_sv + lambda);
+    return DblVec{ cost - threshold };
+  }
+  // AvoidSingularityJacCalculator::operator() / jacobianPartialDerivative  kinematic_terms.cpp:605-642
+  Mat jac(const DblVec& q) const
+  {
+    const int n = static_cast<int>(q.size());
+    const Mat J = chainJacobian6(*chain, q.data(), link);
+    const ThinSvd svd = thinSvd(J);
+    const int last = static_cast<int>(svd.s.size()) - 1;
+    const double smallest_sv = svd.s.back();
+    Mat out(1, n);
+    for (int k = 0; k < n; ++k)
+    {
+      DblVec joints = q;
+      joints[static_cast<std::size_t>(k)] += eps;
+      const Mat Jp = chainJacobian6(*chain, joints.data(), link);
+      // (u' * dJ) * v, left to right
+      double acc = 0.0;
+      for (int c = 0; c < n; ++c)
+      {
+        double uc = 0.0;
+        for (int r = 0; r < 6; ++r)
+          uc += svd.U(r, last) * ((Jp(r, c) - J(r, c)) / eps);
+        acc += uc * svd.V(c, last);
+      }
+      out(0, k) = acc;
+    }
+    const double scale = -1.0 / std::pow(smallest_sv + lambda, 2.0);
+    for (int k = 0; k < n; ++k)
+      out(0, k) *= scale;
+    return out;
+  }
+};
+
+// ---- DynamicCartPose  trajopt/src/kinematic_terms.cpp:59-185: source = tool frame, target = link * offset, both move ---------
+struct DynCartPoseCalc
+{
+  std::shared_ptr<const Chain> chain;
+  int link{ 0 };
+  Tf target_offset;  // link_T_target
+  std::vector<int> indices;
+  void frames(const double* q, Tf& target, Tf& source) const
+  {
+    std::vector<Tf> lk;
+    chain->fk(q, lk);
+    target = tfMul(lk[static_cast<std::size_t>(link)], target_offset);
+    source = tfMul(lk[static_cast<std::size_t>(chain->n_dof - 1)], chain->tool);
+  }
+  DblVec err(const DblVec& q) const
+  {
+    Tf tgt, src;
+    frames(q.data(), tgt, src);
+    double e[6];
+    transformError(tgt, src, e);
+    DblVec out(indices.size());
+    for (std::size_t i = 0; i < indices.size(); ++i)
+      out[i] = e[indices[i]];
+    return out;
+  }
+  // calcJacobianTransformErrorDiff(target, target_perturbed, source, source_perturbed) [tesseract, NOT IN REFERENCE]: the
+  // three-argument form (transformErrorDiff above) with the perturbed error taken against the perturbed target
+  Mat jac(const DblVec& q) const
+  {
+    Tf tgt, src;
+    frames(q.data(), tgt, src);
+    const Tf pe = tfMul(tfInv(tgt), src);
+    double ax0[3], a0;
+    rotErrDecomposed(pe.R, ax0, a0);
+    Mat J(static_cast<int>(indices.size()), static_cast<int>(q.size()));
+    DblVec qp = q;
+    for (std::size_t i = 0; i < q.size(); ++i)
+    {
+      qp[i] = q[i] + DEFAULT_EPSILON;
+      Tf tp, sp;
+      frames(qp.data(), tp, sp);
+      const Tf pp = tfMul(tfInv(tp), sp);
+      double ax1[3], a1;
+      rotErrDecomposed(pp.R, ax1, a1);
+      double a1c = a1;
+      if (a1 > M_PI_2 && a0 < -M_PI_2)
+        a1c = a1 - 2.0 * M_PI;
+      else if (a1 < -M_PI_2 && a0 > M_PI_2)
+        a1c = a1 + 2.0 * M_PI;
+      double d[6];
+      for (int r = 0; r < 3; ++r)
+      {
+        d[r] = pp.t[r] - pe.t[r];
+        d[3 + r] = ax1[r] * a1c - ax0[r] * a0;
+      }
+      for (std::size_t r = 0; r < indices.size(); ++r)
+        J(static_cast<int>(r), static_cast<int>(i)) = d[indices[r]] / DEFAULT_EPSILON;
+      qp[i] = q[i];
+    }
+    return J;
+  }
+};
+
 // ---- sphere-vs-sphere "contact manager" + CollisionCost (SINGLE_TIME_STEP) -------------------------
 struct Scene
 {
@@ -1322,7 +1542,9 @@ inline TrajProblem constructProblem(const tmx_problem_desc& d, const double* ini
                           (tm.kind == TMX_TERM_JOINT_VEL_EQ_CNT) || (tm.kind == TMX_TERM_JOINT_VEL_INEQ_CNT) ||
                           (tm.kind == TMX_TERM_JOINT_ACC_EQ_CNT) || (tm.kind == TMX_TERM_JOINT_ACC_INEQ_CNT) || (tm.kind == TMX_TERM_FUNC_CNT) ||
                           (tm.kind == TMX_TERM_JOINT_JERK_EQ_CNT) || (tm.kind == TMX_TERM_JOINT_JERK_INEQ_CNT) ||
-                          ((tm.kind == TMX_TERM_CART_POSE || tm.kind == TMX_TERM_CART_VEL) && tm.is_constraint);
+                          ((tm.kind == TMX_TERM_CART_POSE || tm.kind == TMX_TERM_CART_VEL || tm.kind == TMX_TERM_AVOID_SINGULARITY ||
+                            tm.kind == TMX_TERM_DYN_CART_POSE) &&
+                           tm.is_constraint);
       if ((pass == 0) == is_cnt)
         continue;
       switch (tm.kind)
@@ -1458,6 +1680,50 @@ inline TrajProblem constructProblem(const tmx_problem_desc& d, const double* ini
               P.prob->addConstraint(std::make_shared<ConstraintFromErrFunc>(f, dfdx, P.traj_vars.row(t), c, EQ, "cart_pose"));
             else
               P.prob->addCost(std::make_shared<CostFromErrFunc>(f, dfdx, P.traj_vars.row(t), c, ABS, "cart_pose"));
+          }
+          break;
+        }
+        case TMX_TERM_AVOID_SINGULARITY:
+        {
+          // AvoidSingularityTermInfo::hatch  problem_description.cpp:1900-1940 (problem's full joint set)
+          auto calc = std::make_shared<AvoidSingularityCalc>();
+          calc->chain = P.chain;
+          calc->link = tm.link;
+          calc->lambda = tm.lambda;
+          VectorOfVector f = [calc](const DblVec& q) { return calc->err(q); };
+          MatrixOfVector dfdx = [calc](const DblVec& q) { return calc->jac(q); };
+          const DblVec c{ tm.coeffs[0] };
+          for (int t = tm.first_step; t <= tm.last_step; ++t)
+          {
+            if (tm.is_constraint)
+              P.prob->addConstraint(std::make_shared<ConstraintFromErrFunc>(f, dfdx, P.traj_vars.row(t), c, INEQ, "avoid_singularity"));
+            else
+              P.prob->addCost(std::make_shared<CostFromErrFunc>(f, dfdx, P.traj_vars.row(t), c, ABS, "avoid_singularity"));
+          }
+          break;
+        }
+        case TMX_TERM_DYN_CART_POSE:
+        {
+          // DynamicCartPoseTermInfo::hatch  problem_description.cpp:752-822 - rows with |coeff| <= 1e-5 are dropped
+          auto calc = std::make_shared<DynCartPoseCalc>();
+          calc->chain = P.chain;
+          calc->link = tm.link;
+          calc->target_offset = tfFrom12(tm.target_pose);
+          DblVec c;
+          for (int i = 0; i < 6; ++i)
+            if (std::fabs(tm.coeffs[i]) > 1e-5)
+            {
+              calc->indices.push_back(i);
+              c.push_back(tm.coeffs[i]);
+            }
+          VectorOfVector f = [calc](const DblVec& q) { return calc->err(q); };
+          MatrixOfVector dfdx = [calc](const DblVec& q) { return calc->jac(q); };
+          for (int t = tm.first_step; t <= tm.last_step; ++t)
+          {
+            if (tm.is_constraint)
+              P.prob->addConstraint(std::make_shared<ConstraintFromErrFunc>(f, dfdx, P.traj_vars.row(t), c, EQ, "dyn_cart_pose"));
+            else
+              P.prob->addCost(std::make_shared<CostFromErrFunc>(f, dfdx, P.traj_vars.row(t), c, ABS, "dyn_cart_pose"));
           }
           break;
         }

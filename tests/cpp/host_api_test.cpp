@@ -523,6 +523,34 @@ static void caseJointVel(const Input& in)
     });
   }
   {
+    // AvoidSingularityTermInfo (ABS cost on the tip link's Jacobian, problem_description.cpp:1900-1940) next to a JointVel cost, from
+    // a posture away from the arm's singular configurations; the Python front end builds the same problem (test_cpp_host_api.py)
+    const DblVec start{ 0.3, -0.2, 0.4, -1.0, 0.3, -0.5, 0.2 };
+    auto env = makeEnv(in, "right_arm", "pr2_right_arm", start, false);
+    ProblemConstructionInfo pci(env);
+    pci.basic_info.n_steps = steps;
+    pci.basic_info.manip = "right_arm";
+    pci.resolveKin();
+    pci.init_info.type = InitInfo::STATIONARY;
+    auto jv = std::make_shared<JointVelTermInfo>();
+    jv->coeffs = DblVec(7, 1.0);
+    jv->targets = DblVec(7, 0.0);
+    jv->first_step = 0;
+    jv->last_step = steps - 1;
+    jv->name = "joint_vel";
+    jv->term_type = TermType::TT_COST;
+    pci.cost_infos.push_back(jv);
+    auto as = std::make_shared<tmx::trajopt::AvoidSingularityTermInfo>(0.1);
+    as->link = "r_gripper_tool_frame";
+    as->first_step = 0;
+    as->last_step = steps - 1;
+    as->coeffs = { 5.0 };
+    as->name = "sing";
+    as->term_type = TermType::TT_COST;
+    pci.cost_infos.push_back(as);
+    run(pci, "kinematic_terms", [&](const DblVec&) {});
+  }
+  {
     auto env = makeEnv(in, "right_arm", "pr2_right_arm", DblVec(7, 0.0), false);
     ProblemConstructionInfo pci(env);
     pci.basic_info.n_steps = steps;

@@ -14,7 +14,7 @@ from trajopt_amd import abi, configs
 TOL_TRAJ = 1e-5      # rad — north_star tolerance for joint trajectories / QP primal solutions
 
 # configuration ids of cfg() below: every id runs the stage checks on both tiers; MINI_CIDS also the whole SQP
-MINI_CIDS = [9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 36, 37]
+MINI_CIDS = [9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 36, 37, 38, 39, 40, 41]
 STAGE_CIDS = [0, 1, 2, 3] + MINI_CIDS
 
 
@@ -97,6 +97,33 @@ def cfg(cid, T=None):
         n = pci.basic_info.n_steps
         ti = CartVelTermInfo(first_step=1, last_step=n - 2, max_displacement=0.07, is_constraint=(cid == 23))
         (pci.cnt_infos if cid == 23 else pci.cost_infos).append(ti)
+        return pci, s, g
+    if cid in (38, 39):
+        # AvoidSingularityTermInfo (built-in kinematic function of the function-term machinery, dense QP engine): 38 ABS cost on the
+        # 4-DOF test arm (fewer joints than Jacobian rows: the singular triplet comes from J'J), 39 INEQ constraint on a 10-waypoint
+        # glass_upright (7 joints: from JJ')
+        from trajopt_amd.problem import AvoidSingularityTermInfo
+        if cid == 38:
+            pci, s, g = configs.config_mini() if T is None else configs.config_mini(T)
+        else:
+            pci, s, g = configs.config1(10 if T is None else T)
+        D, n = pci.robot.n_dof, pci.basic_info.n_steps
+        ti = AvoidSingularityTermInfo(link=D - 1, first_step=1, last_step=n - 2, coeffs=[2.0 if cid == 38 else 1.0], lambda_=0.1 if cid == 38 else 0.05,
+                                      is_constraint=(cid == 39), name="sing")
+        (pci.cnt_infos if cid == 39 else pci.cost_infos).append(ti)
+        return pci, s, g
+    if cid in (40, 41):
+        # DynamicCartPoseTermInfo (both frames move): the tool relative to link 1 of the 4-DOF test arm at the middle waypoint, in
+        # place of the static via point; 40 EQ constraint on the position rows, 41 ABS cost on all six rows
+        from trajopt_amd.problem import CartPoseTermInfo, DynamicCartPoseTermInfo
+        pci, s, g = configs.config_mini() if T is None else configs.config_mini(T)
+        n = pci.basic_info.n_steps
+        pci.cnt_infos = [ti for ti in pci.cnt_infos if not isinstance(ti, CartPoseTermInfo)]
+        qv = 0.5 * (s + g) + np.array([0.1, -0.15, 0.2, 0.1])
+        off = (np.linalg.inv(pci.robot.fk_links(qv)[1]) @ pci.robot.fk_tool(qv))[:3, :]
+        ti = DynamicCartPoseTermInfo(timestep=n // 2, target_link=1, target_frame_offset=off, pos_coeffs=(1, 1, 1) if cid == 40 else (2, 1, 1.5),
+                                     rot_coeffs=(0, 0, 0) if cid == 40 else (0.5, 0.25, 1.0), is_constraint=(cid == 40))
+        (pci.cnt_infos if cid == 40 else pci.cost_infos).insert(0, ti)
         return pci, s, g
     if cid in (36, 37):
         # acceleration + jerk SMOOTHING COSTS alone (banded objective, no rows on 3 - 4 waypoints): the structured solver's banded block

@@ -151,8 +151,15 @@ def test_cpp_reference_kats_on_host_build(hostemu_lib, inputs, orc):
     res, _, out = _run(exe, inputs["path"], "joint_costs,numerical_ik,cart_position,interface,joint_vel,errors")
     assert "ERRORS done" in out and "INTERFACE done" in out and "JOINTVEL done" in out and "LINKROWS refused" not in out
     assert set(res) == {"equality_jointPos", "inequality_jointPos", "numerical_ik1", "cart_position", "equality_jointVel",
-                        "inequality_jointVel", "function_terms"}      # the host build has the two-waypoint rows (TMX_LINK_ROWS=1)
+                        "inequality_jointVel", "function_terms", "kinematic_terms"}   # the host build has the two-waypoint rows (TMX_LINK_ROWS=1)
     assert all(r[0]["status"] == 0 for r in res.values())
+    # the AvoidSingularity problem of the C++ program through the Python front end: the same lowering
+    from trajopt_amd.problem import AvoidSingularityTermInfo, BasicInfo, JointVelTermInfo, ProblemConstructionInfo
+    pci = ProblemConstructionInfo(pr2_right_arm(), BasicInfo(n_steps=10))
+    pci.cost_infos.append(JointVelTermInfo(coeffs=[1.0] * 7, targets=[0.0] * 7, first_step=0, last_step=9))
+    pci.cost_infos.append(AvoidSingularityTermInfo(link=6, first_step=0, last_step=9, coeffs=[5.0], lambda_=0.1, name="sing"))
+    start = np.array([0.3, -0.2, 0.4, -1.0, 0.3, -0.5, 0.2])
+    _same(res["kinematic_terms"], _python_path(pci, np.tile(start, (1, 10, 1)), hostemu_lib))
 
 
 def test_cpp_two_waypoint_terms_are_refused_by_the_product_configuration(hostemu_lib_nolink, inputs):
@@ -160,7 +167,7 @@ def test_cpp_two_waypoint_terms_are_refused_by_the_product_configuration(hostemu
     library's explicit refusal, exactly what the GPU tier expects from libtrajopt_mi355x.so this round"""
     exe = _build(hostemu_lib_nolink, "hostemu_nolink")
     res, _, out = _run(exe, inputs["path"], "joint_vel")
-    assert out.count("LINKROWS refused") == 3 and "JOINTVEL done" in out and not res   # + the acceleration cost of function_terms
+    assert out.count("LINKROWS refused") == 3 and "JOINTVEL done" in out and set(res) == {"kinematic_terms"}   # + the acceleration cost of function_terms
 
 
 def test_cpp_optimizer_fails_loudly_without_a_device(inputs):

@@ -306,3 +306,47 @@ def test_cart_vel_from_json(hostemu_lib, orc):
     if r["status"][0] == abi.OPT_CONVERGED:
         p = np.array([pp.pci.robot.fk_tool(q)[:3, 3] for q in r["x"][0]])
         assert np.abs(np.diff(p, axis=0)).max() <= 0.12 + 1e-3
+
+
+def test_dynamic_cart_pose_from_json(hostemu_lib, orc):
+    """dynamic_cart_pose (DynamicCartPoseTermInfo::fromJson, problem_description.cpp:685-750): both frames are active links of the
+    manipulator; unknown members, inactive targets and unknown links are errors with the reference's texts; the run against the oracle"""
+    from trajopt_amd import abi, runtime
+    env, pci, start, goal = _env(0)
+    links = [f"link_{k}" for k in range(6)] + ["r_gripper_tool_frame"]
+    env.link_names = {"right_arm": links}
+    base = json.load(open(os.path.join(HERE, "golden", "json", "planning_unit_cfg0.json")))
+    n = base["basic_info"]["n_steps"]
+    v = copy.deepcopy(base)
+    rob = pci.robot
+    qv = 0.5 * (np.asarray(start) + np.asarray(goal)) + 0.1
+    rel = np.linalg.inv(rob.fk_links(qv)[2]) @ rob.fk_tool(qv)
+    v["constraints"].append({"type": "dynamic_cart_pose", "name": "wrist_to_shoulder",
+                             "params": {"timestep": n // 2, "source_frame": "r_gripper_tool_frame", "target_frame": "link_2",
+                                        "target_frame_offset_xyz": [float(x) for x in rel[:3, 3]], "pos_coeffs": [1, 1, 1], "rot_coeffs": [0, 0, 0]}})
+    pp = json_io.construct_problem(v, env)
+    d = pp.pci.to_desc()
+    dc = [d.terms[i] for i in range(d.n_terms) if d.terms[i].kind == abi.TERM_DYN_CART_POSE]
+    assert len(dc) == 1 and dc[0].link == 2 and dc[0].is_constraint == 1 and dc[0].first_step == n // 2
+    assert np.allclose(np.array(dc[0].target_pose[:]).reshape(3, 4)[:, 3], rel[:3, 3])
+    for bad, exc, text in (({"source_frame": "r_gripper_tool_frame", "target_frame": "base_footprint"}, ValueError, "are not both active links"),
+                           ({"source_frame": "r_gripper_tool_frame", "target_frame": "nowhere"}, ValueError, "invalid target frame"),
+                           ({"source_frame": "r_gripper_tool_frame", "target_frame": "link_2", "tolerance": 1}, ValueError, "illegal field"),
+                           ({"source_frame": "link_3", "target_frame": "link_2"}, json_io.UnsupportedTerm, "tip link")):
+        w = copy.deepcopy(base)
+        w["constraints"].append({"type": "dynamic_cart_pose", "params": bad})
+        with pytest.raises(exc, match=text):
+            json_io.construct_problem(w, env)
+    x0 = pp.init_traj[None, :, :]
+    opt = runtime.BatchedTrustRegionSQP(pp.pci, lib_path=hostemu_lib)
+    opt.initialize(x0)
+    opt.optimize()
+    r = opt.results()
+    opt.ctx.close()
+    o = orc.sqp_batch(d, x0)
+    assert r["status"][0] == o["status"][0] and abs(int(r["n_qp_solves"][0]) - int(o["n_qp_solves"][0])) <= 1
+    assert np.abs(r["x"] - o["x"]).max() < 1e-4
+    if r["status"][0] == abi.OPT_CONVERGED:
+        q = r["x"][0][n // 2]
+        got = (np.linalg.inv(rob.fk_links(q)[2]) @ rob.fk_tool(q))[:3, 3]
+        assert np.abs(got - rel[:3, 3]).max() < 2e-4

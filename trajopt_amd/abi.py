@@ -55,6 +55,7 @@ class Expr(C.Structure):
 
 OP_VAR, OP_CONST, OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_NEG, OP_SQ, OP_SIN, OP_COS, OP_SQRT, OP_OUT = range(1, 13)
 TERM_FUNC_COST, TERM_FUNC_CNT, TERM_FUNC_ERR_COST = 21, 22, 23
+TERM_AVOID_SINGULARITY, TERM_DYN_CART_POSE = 24, 25
 PENALTY_SQUARED, PENALTY_ABS, PENALTY_HINGE = 0, 1, 2     # sco::PenaltyType
 
 
@@ -83,6 +84,9 @@ class Term(C.Structure):
         ("cnt_type", C.c_int32),
         ("has_coeffs", C.c_int32),
         ("penalty_type", C.c_int32),
+        ("link", C.c_int32),
+        ("pad3_", C.c_int32),
+        ("lambda_", C.c_double),
     ]
 
 

@@ -418,10 +418,11 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
       const tmx_term& tm = d->terms[k];
       const bool is_ineq = tm.kind == TMX_TERM_JOINT_POS_INEQ_CNT || tm.kind == TMX_TERM_COLLISION_CNT || tm.kind == TMX_TERM_JOINT_VEL_INEQ_CNT ||
                            tm.kind == TMX_TERM_JOINT_ACC_INEQ_CNT || tm.kind == TMX_TERM_JOINT_JERK_INEQ_CNT ||
-                           (tm.kind == TMX_TERM_FUNC_CNT && tm.cnt_type == 1) || (tm.kind == TMX_TERM_CART_VEL && tm.is_constraint);
+                           (tm.kind == TMX_TERM_FUNC_CNT && tm.cnt_type == 1) || (tm.kind == TMX_TERM_CART_VEL && tm.is_constraint) ||
+                           (tm.kind == TMX_TERM_AVOID_SINGULARITY && tm.is_constraint);
       const bool is_cnt = is_ineq || (tm.kind == TMX_TERM_JOINT_POS_EQ_CNT) || (tm.kind == TMX_TERM_JOINT_VEL_EQ_CNT) ||
                           (tm.kind == TMX_TERM_JOINT_ACC_EQ_CNT) || (tm.kind == TMX_TERM_JOINT_JERK_EQ_CNT) || (tm.kind == TMX_TERM_FUNC_CNT) ||
-                          (tm.kind == TMX_TERM_CART_POSE && tm.is_constraint);
+                          (tm.kind == TMX_TERM_CART_POSE && tm.is_constraint) || (tm.kind == TMX_TERM_DYN_CART_POSE && tm.is_constraint);
       int want = !is_cnt ? 0 : (is_ineq ? 2 : 1);
       if (flavor == TMX_FLAVOR_SQP)
       {
@@ -604,48 +605,99 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
         case TMX_TERM_FUNC_COST:
         case TMX_TERM_FUNC_CNT:
         case TMX_TERM_FUNC_ERR_COST:
+        case TMX_TERM_AVOID_SINGULARITY:
+        case TMX_TERM_DYN_CART_POSE:
         {
           // sco::CostFromFunc / sco::ConstraintFromErrFunc over a tmx_expr program of the waypoint's variables: one cost /
           // constraint per step (include/tmx.h).  The cost model is a dynamic quadratic: dense QP engine.
+          // AvoidSingularity / DynamicCartPose: the same Cost / ConstraintFromErrFunc rows over a BUILT-IN kinematic function
+          // with its own Jacobian (fx_nops < 0: -1 / -2, fx_op0 = link, parameters in the constants; tmx_terms.h).
+          const bool builtin = tm.kind == TMX_TERM_AVOID_SINGULARITY || tm.kind == TMX_TERM_DYN_CART_POSE;
           if (flavor == TMX_FLAVOR_SQP)
           {
             ctx->err = "TMX_FLAVOR_SQP: function terms are not part of the trajopt_sqp path";
             return TMX_ERR_UNSUPPORTED;
           }
-          if (tmx_expr_check(tm.expr, D) != 0)
+          if (!builtin && tmx_expr_check(tm.expr, D) != 0)
           {
             ctx->err = "function term: malformed tmx_expr program (opcode, index, stack discipline or outputs)";
             return TMX_ERR_INVALID;
           }
-          const bool is_cnt = tm.kind == TMX_TERM_FUNC_CNT;
-          if (tm.kind == TMX_TERM_FUNC_COST && tm.expr->n_outputs != 1)
+          if (builtin && (tm.link < 0 || tm.link >= D))
+          {
+            ctx->err = "AvoidSingularity / DynamicCartPose: link is the index of a moving link, 0 .. n_dof - 1";
+            return TMX_ERR_INVALID;
+          }
+          const bool is_cnt = builtin ? tm.is_constraint != 0 : tm.kind == TMX_TERM_FUNC_CNT;
+          // AvoidSingularity: ABS cost / INEQ constraint (problem_description.cpp:1925-1934); DynamicCartPose: ABS cost / EQ
+          // constraint (:808-816)
+          const int cnt_type = tm.kind == TMX_TERM_AVOID_SINGULARITY ? 1 : (tm.kind == TMX_TERM_DYN_CART_POSE ? 0 : tm.cnt_type);
+          const int penalty_type = builtin ? 1 : tm.penalty_type;
+          double weights[TMX_EXPR_MAX_OUT];
+          int n_out = builtin ? 0 : tm.expr->n_outputs;
+          bool has_coeffs = builtin ? true : tm.has_coeffs != 0;
+          for (int i = 0; i < TMX_EXPR_MAX_OUT; ++i)
+            weights[i] = (!builtin && tm.has_coeffs && i < n_out) ? tm.coeffs[i] : 1.0;
+          int pose_idx[6] = { 0, 0, 0, 0, 0, 0 };
+          if (tm.kind == TMX_TERM_AVOID_SINGULARITY)
+          {
+            n_out = 1;
+            weights[0] = tm.coeffs[0];
+          }
+          else if (tm.kind == TMX_TERM_DYN_CART_POSE)
+            for (int i = 0; i < 6; ++i)  // rows with |coeff| <= 1e-5 are dropped (problem_description.cpp:756-775)
+              if (std::fabs(tm.coeffs[i]) > 1e-5)
+              {
+                pose_idx[n_out] = i;
+                weights[n_out++] = tm.coeffs[i];
+              }
+          if (tm.kind == TMX_TERM_FUNC_COST && n_out != 1)
           {
             ctx->err = "TMX_TERM_FUNC_COST: the program of a cost has one output";
             return TMX_ERR_INVALID;
           }
-          if (is_cnt && tm.cnt_type != 0 && tm.cnt_type != 1)
+          if (is_cnt && cnt_type != 0 && cnt_type != 1)
           {
             ctx->err = "TMX_TERM_FUNC_CNT: cnt_type must be 0 (EQ) or 1 (INEQ)";
             return TMX_ERR_INVALID;
           }
-          if (tm.kind == TMX_TERM_FUNC_ERR_COST && (tm.penalty_type < 0 || tm.penalty_type > 2))
+          if (tm.kind == TMX_TERM_FUNC_ERR_COST && (penalty_type < 0 || penalty_type > 2))
           {
             ctx->err = "TMX_TERM_FUNC_ERR_COST: penalty_type must be 0 (SQUARED), 1 (ABS) or 2 (HINGE)";
             return TMX_ERR_INVALID;
           }
           // instance kind: 0 / 1 CostFromFunc (diagonal / full Hessian), 2 constraint rows, 3 squared error cost, 4 abs / hinge cost rows
-          const int fk = tm.kind == TMX_TERM_FUNC_COST ? (tm.full_hessian ? 1 : 0) : (is_cnt ? 2 : (tm.penalty_type == 0 ? 3 : 4));
+          const int fk = tm.kind == TMX_TERM_FUNC_COST ? (tm.full_hessian ? 1 : 0) : (is_cnt ? 2 : (penalty_type == 0 ? 3 : 4));
           const bool quad = fk == 0 || fk == 1 || fk == 3;
           qp_dense = true;
           // the row weights (coeffs, 1 when absent) sit in front of the program's constants
           for (int i = 0; i < TMX_EXPR_MAX_OUT; ++i)
-            fx_consts.push_back((tm.has_coeffs && i < tm.expr->n_outputs) ? tm.coeffs[i] : 1.0);
-          const int op0 = (int)fx_ops.size() / 2, c0 = (int)fx_consts.size();
-          fx_ops.insert(fx_ops.end(), tm.expr->ops, tm.expr->ops + 2 * tm.expr->n_ops);
-          fx_consts.insert(fx_consts.end(), tm.expr->consts, tm.expr->consts + tm.expr->n_consts);
+            fx_consts.push_back(weights[i]);
+          int op0 = (int)fx_ops.size() / 2, n_ops = 0;
+          const int c0 = (int)fx_consts.size();
+          if (!builtin)
+          {
+            n_ops = tm.expr->n_ops;
+            fx_ops.insert(fx_ops.end(), tm.expr->ops, tm.expr->ops + 2 * tm.expr->n_ops);
+            fx_consts.insert(fx_consts.end(), tm.expr->consts, tm.expr->consts + tm.expr->n_consts);
+          }
+          else if (tm.kind == TMX_TERM_AVOID_SINGULARITY)
+          {
+            op0 = tm.link;
+            n_ops = -1;
+            fx_consts.push_back(tm.lambda);
+          }
+          else
+          {
+            op0 = tm.link;
+            n_ops = -2;
+            fx_consts.insert(fx_consts.end(), tm.target_pose, tm.target_pose + 12);  // link_T_target
+            for (int i = 0; i < 6; ++i)
+              fx_consts.push_back((double)pose_idx[i]);
+          }
           for (int t = tm.first_step; t <= tm.last_step; ++t)
           {
-            if (std::find(tm.fixed_steps, tm.fixed_steps + tm.n_fixed_steps, t) != tm.fixed_steps + tm.n_fixed_steps)
+            if (!builtin && std::find(tm.fixed_steps, tm.fixed_steps + tm.n_fixed_steps, t) != tm.fixed_steps + tm.n_fixed_steps)
               continue;  // UserDefinedTermInfo::fixed_steps (problem_description.cpp:608, :645)
             const int inst = (int)fx_t.size();
             const int own = is_cnt ? n_cnts++ : n_costs++;
@@ -653,21 +705,21 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
             fx_kind.push_back(fk);
             fx_owner.push_back(own);
             fx_op0.push_back(op0);
-            fx_nops.push_back(tm.expr->n_ops);
+            fx_nops.push_back(n_ops);
             fx_c0.push_back(c0);
-            fx_nout.push_back(tm.expr->n_outputs);
+            fx_nout.push_back(n_out);
             fx_slot0.push_back((int)kind.size());
             fx_ci.push_back(quad ? n_fx_cost++ : -1);
             if (!quad)
-              for (int i = 0; i < tm.expr->n_outputs; ++i)
+              for (int i = 0; i < n_out; ++i)
               {
-                const double cc = tm.has_coeffs ? tm.coeffs[i] : 1.0;
-                if (tm.has_coeffs && cc == 0)
+                const double cc = has_coeffs ? weights[i] : 1.0;
+                if (has_coeffs && cc == 0)
                   continue;  // modeling_utils.cpp:175-176, :258-259
                 if (is_cnt)
-                  add_slot(SLOT_FUNC, t, i, inst, own, tm.cnt_type == 0 ? 2 : 1, 1, tm.cnt_type == 0 ? 1 : 0, 0.0, cc, 0.0, 0.0);
+                  add_slot(SLOT_FUNC, t, i, inst, own, cnt_type == 0 ? 2 : 1, 1, cnt_type == 0 ? 1 : 0, 0.0, cc, 0.0, 0.0);
                 else  // ABS: exprScale(aff, weight); addAbs(aff, 1) -> two aux with objective 1; HINGE: one aux
-                  add_slot(SLOT_FUNC, t, i, inst, own, tm.penalty_type == 1 ? 2 : 1, 0, tm.penalty_type == 1 ? 1 : 0, 1.0, cc, 0.0, 0.0);
+                  add_slot(SLOT_FUNC, t, i, inst, own, penalty_type == 1 ? 2 : 1, 0, penalty_type == 1 ? 1 : 0, 1.0, cc, 0.0, 0.0);
               }
           }
           break;

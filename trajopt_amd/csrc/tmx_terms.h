@@ -492,8 +492,17 @@ TMX_DEVFN void lvs_end_gradient(const DevProblem* P, const double* q, int s, con
 }
 
 // ---- function terms (tmx_expr programs): sco::CostFromFunc / ConstraintFromErrFunc, trajopt_sco/src/modeling_utils.cpp ----------
+// fx_nops[inst] < 0: a built-in kinematic function instead of a program (fx_op0 = link, parameters behind the row weights)
+#define FX_AVOID_SINGULARITY (-1)  // consts: lambda
+#define FX_DYN_CART_POSE (-2)      // consts: link_T_target (12), row indices (6)
+TMX_DEVFN void fx_builtin_eval(const DevProblem* P, int inst, const double* x, double* out);
 TMX_DEVFN void fx_eval(const DevProblem* P, int inst, const double* x, double* out)
 {
+  if (P->fx_nops[inst] < 0)
+  {
+    fx_builtin_eval(P, inst, x, out);
+    return;
+  }
   tmx_expr_eval(P->fx_ops + 2 * P->fx_op0[inst], P->fx_nops[inst], P->fx_consts + P->fx_c0[inst], x, out);
 }
 TMX_DEVFN double fx_eval1(const DevProblem* P, int inst, const double* x)
@@ -564,6 +573,175 @@ TMX_DEVFN void sym_eig_jacobi(double* A, double* V, int k)
       }
   }
 }
+// ---- built-in kinematic functions of the function-term machinery -----------------------------------------------------------
+// 6 x D geometric Jacobian (row-major; linear rows on top, angular below; reference point = origin of the link frame, base
+// coordinates) of moving link `link`: what tesseract's JointGroup::calcJacobian(q, link_name) returns for a serial chain
+TMX_DEVFN void link_jacobian6(const DevProblem* P, const double* q, int link, double* J)
+{
+  const int D = P->D;
+  Tf3 L;
+  fk_link(P, q, link, L);
+  const double p[3] = { L.t[0], L.t[1], L.t[2] };
+  for (int e = 0; e < 6 * D; ++e)
+    J[e] = 0.0;
+  fk_link_visit(P, [q](int k) { return q[k]; }, link, L, [&](int k, const Tf3& F) {
+    double col[3];
+    jac_point_col(P, k, F, p, col);
+    for (int r = 0; r < 3; ++r)
+      J[r * D + k] = col[r];
+    if (P->jtype[k] == 0)
+      for (int r = 0; r < 3; ++r)
+        J[(3 + r) * D + k] = F.R[3 * r + 0] * P->axis[k][0] + F.R[3 * r + 1] * P->axis[k][1] + F.R[3 * r + 2] * P->axis[k][2];
+  });
+}
+// smallest singular value of the 6 x D matrix J with its left / right singular vectors u (6), v (D) - the last triplet of
+// Eigen::JacobiSVD(J, ComputeThinU | ComputeThinV) (kinematic_terms.cpp:589-593): eigen-decomposition of the smaller Gram
+// matrix (J J' for D >= 6, J' J below), the other vector from J v = s u.  u' dJ v does not depend on the common sign.
+TMX_DEVFN double smallest_singular(const double* J, int D, double* u, double* v)
+{
+  double A[36], V[36];  // the smaller Gram matrix is at most 6 x 6
+  const bool wide = D >= 6;
+  const int k = wide ? 6 : D;
+  for (int i = 0; i < k; ++i)
+    for (int j = 0; j < k; ++j)
+    {
+      double acc = 0.0;
+      if (wide)
+        for (int c = 0; c < D; ++c)
+          acc += J[i * D + c] * J[j * D + c];
+      else
+        for (int r = 0; r < 6; ++r)
+          acc += J[r * D + i] * J[r * D + j];
+      A[i * k + j] = acc;
+    }
+  sym_eig_jacobi(A, V, k);
+  int im = 0;
+  for (int i = 1; i < k; ++i)
+    if (A[i * k + i] < A[im * k + im])
+      im = i;
+  const double lam = A[im * k + im];
+  const double sv = (lam > 0.0) ? sqrt(lam) : 0.0;
+  if (wide)
+  {
+    for (int r = 0; r < 6; ++r)
+      u[r] = V[r * k + im];
+    for (int c = 0; c < D; ++c)
+    {
+      double acc = 0.0;
+      for (int r = 0; r < 6; ++r)
+        acc += J[r * D + c] * u[r];
+      v[c] = (sv > 0.0) ? acc / sv : 0.0;
+    }
+  }
+  else
+  {
+    for (int c = 0; c < D; ++c)
+      v[c] = V[c * k + im];
+    for (int r = 0; r < 6; ++r)
+    {
+      double acc = 0.0;
+      for (int c = 0; c < D; ++c)
+        acc += J[r * D + c] * v[c];
+      u[r] = (sv > 0.0) ? acc / sv : 0.0;
+    }
+  }
+  return sv;
+}
+// target and source frames of a DynamicCartPose instance at q: link * offset, tool
+TMX_DEVFN void dyn_pose_frames(const DevProblem* P, int inst, const double* q, Tf3& tinv, Tf3& src)
+{
+  Tf3 L, off, tgt;
+  fk_link(P, q, P->fx_op0[inst], L);
+  tf_from12(P->fx_consts + P->fx_c0[inst], off);
+  tf_mul(L, off, tgt);
+  tf_inv(tgt, tinv);
+  fk_tool(P, q, src);
+}
+TMX_DEVFN void fx_builtin_eval(const DevProblem* P, int inst, const double* x, double* out)
+{
+  const double* par = P->fx_consts + P->fx_c0[inst];
+  if (P->fx_nops[inst] == FX_AVOID_SINGULARITY)
+  {
+    // AvoidSingularityErrCalculator::operator()  kinematic_terms.cpp:586-603
+    double J[6 * TMX_MAX_DOF], u[6], v[TMX_MAX_DOF];
+    link_jacobian6(P, x, P->fx_op0[inst], J);
+    const double sv = smallest_singular(J, P->D, u, v);
+    const double lambda = par[0];
+    out[0] = 1.0 / (sv + lambda) - 1.0 / (0.1 + lambda);
+    return;
+  }
+  // DynamicCartPoseErrCalculator::operator()  kinematic_terms.cpp:98-111
+  Tf3 tinv, src;
+  dyn_pose_frames(P, inst, x, tinv, src);
+  double err[6], ax[3], ang;
+  transform_error(tinv, src, err, ax, ang);
+  for (int i = 0; i < P->fx_nout[inst]; ++i)
+    out[i] = err[(int)par[12 + i]];
+}
+// Jacobian of a built-in at x (perturbed in place and restored), rows J[o][.]
+TMX_DEVFN void fx_builtin_jac(const DevProblem* P, int inst, double* x, double (*Jo)[TMX_MAX_DOF])
+{
+  const int D = P->D;
+  const double* par = P->fx_consts + P->fx_c0[inst];
+  if (P->fx_nops[inst] == FX_AVOID_SINGULARITY)
+  {
+    // AvoidSingularityJacCalculator::operator() / jacobianPartialDerivative  kinematic_terms.cpp:605-642 (eps_ = 1e-6,
+    // kinematic_terms.hpp:371): d s_min / d q_k = u' (dJ / dq_k) v, Jacobian differenced forward
+    const double eps = 1.0e-6;
+    double J0[6 * TMX_MAX_DOF], J1[6 * TMX_MAX_DOF], u[6], v[TMX_MAX_DOF];
+    const int link = P->fx_op0[inst];
+    link_jacobian6(P, x, link, J0);
+    const double sv = smallest_singular(J0, D, u, v);
+    const double lambda = par[0];
+    const double scale = -1.0 / ((sv + lambda) * (sv + lambda));
+    for (int k = 0; k < D; ++k)
+    {
+      const double xk = x[k];
+      x[k] = xk + eps;
+      link_jacobian6(P, x, link, J1);
+      x[k] = xk;
+      double acc = 0.0;
+      for (int c = 0; c < D; ++c)
+      {
+        double uc = 0.0;
+        for (int r = 0; r < 6; ++r)
+          uc += u[r] * ((J1[r * D + c] - J0[r * D + c]) / eps);
+        acc += uc * v[c];
+      }
+      Jo[0][k] = acc * scale;
+    }
+    return;
+  }
+  // DynamicCartPoseJacCalculator::operator()  kinematic_terms.cpp:158-185: calcJacobianTransformErrorDiff(target, target',
+  // source, source') / eps - both frames perturbed, the +-pi handling of the static CartPose Jacobian (convexify_terms)
+  Tf3 tinv, src, pe, pp;
+  dyn_pose_frames(P, inst, x, tinv, src);
+  tf_mul(tinv, src, pe);
+  double ax0[3], a0;
+  rot_err_decomposed(pe.R, ax0, a0);
+  for (int k = 0; k < D; ++k)
+  {
+    const double xk = x[k];
+    x[k] = xk + TMX_EPS_FD;
+    dyn_pose_frames(P, inst, x, tinv, src);
+    x[k] = xk;
+    tf_mul(tinv, src, pp);
+    double ax1[3], a1;
+    rot_err_decomposed(pp.R, ax1, a1);
+    double a1c = a1;
+    if (a1 > M_PI_2 && a0 < -M_PI_2)
+      a1c = a1 - 2.0 * M_PI;
+    else if (a1 < -M_PI_2 && a0 > M_PI_2)
+      a1c = a1 + 2.0 * M_PI;
+    for (int i = 0; i < P->fx_nout[inst]; ++i)
+    {
+      const int r = (int)par[12 + i];
+      const double diff = (r < 3) ? pp.t[r] - pe.t[r] : ax1[r - 3] * a1c - ax0[r - 3] * a0;
+      Jo[i][k] = diff / TMX_EPS_FD;
+    }
+  }
+}
+
 // CostFromFunc::convex (modeling_utils.cpp:52-113) for cost instance `inst` at the waypoint values q: quadratic model
 //   c + g . x + sum_i (H_ii / 2) x_i^2 + sum_{i<j} H_ij x_i x_j   ->  H (k x k, diagonal form: off-diagonals zero), g, c
 TMX_DEVFN void fx_convexify_cost(const DevProblem* P, int inst, const double* q, int k, double* H, double* g, double* cst, double* W)
@@ -982,15 +1160,18 @@ TMX_DEVFN void convexify_func_terms(const DevProblem* P, const double* xv, int* 
       x[i] = q[i];
     const int no = P->fx_nout[c];
     fx_eval(P, c, x, y);  // calcForwardNumJac evaluates f(x) first (num_diff.cpp:57), convex() once more for y (:252): same value
-    for (int i = 0; i < D; ++i)
-    {
-      const double xi = x[i];
-      x[i] = xi + TMX_EPS_FD;
-      fx_eval(P, c, x, yp);
-      for (int o = 0; o < no; ++o)
-        J[o][i] = (yp[o] - y[o]) / TMX_EPS_FD;
-      x[i] = xi;
-    }
+    if (P->fx_nops[c] < 0)
+      fx_builtin_jac(P, c, x, J);  // the calculators' own dfdx (modeling_utils.cpp:171, :250)
+    else
+      for (int i = 0; i < D; ++i)
+      {
+        const double xi = x[i];
+        x[i] = xi + TMX_EPS_FD;
+        fx_eval(P, c, x, yp);
+        for (int o = 0; o < no; ++o)
+          J[o][i] = (yp[o] - y[o]) / TMX_EPS_FD;
+        x[i] = xi;
+      }
     int r = P->fx_slot0[c];
     for (int o = 0; o < no && r < P->R; ++o)
     {

@@ -17,7 +17,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import numpy as np
 
 from . import abi
-from .problem import (BasicInfo, CartPoseTermInfo, CartVelTermInfo, CollisionTermInfo, JointAccTermInfo, JointJerkTermInfo, JointPosTermInfo,
+from .problem import (BasicInfo, CartPoseTermInfo, CartVelTermInfo, CollisionTermInfo, DynamicCartPoseTermInfo, JointAccTermInfo, JointJerkTermInfo, JointPosTermInfo,
                       JointVelTermInfo,
                       ProblemConstructionInfo, Robot, _tf12)
 
@@ -34,6 +34,7 @@ class Environment:
     link_frames: Dict[str, np.ndarray] = field(default_factory=dict)   # static world frames (3x4), e.g. "base_footprint"
     joint_state: Dict[str, Sequence[float]] = field(default_factory=dict)  # manip -> current joint values (env->getState())
     obstacles: List[Tuple[Tuple[float, float, float], float]] = field(default_factory=list)  # sphere world geometry
+    link_names: Dict[str, Sequence[str]] = field(default_factory=dict)   # manip -> child link of every joint (dynamic_cart_pose targets)
 
 
 # enum values of tesseract::collision::CollisionEvaluatorType (collision_terms / problem_description.cpp:1634)
@@ -169,6 +170,25 @@ def construct_problem(text_or_dict, env: Environment) -> ParsedProblem:
             return CartPoseTermInfo(timestep=int(p.get("timestep", n_steps - 1)), target_pose=target,
                                     pos_coeffs=tuple(_vec(p, "pos_coeffs", 3, (1, 1, 1))), rot_coeffs=tuple(_vec(p, "rot_coeffs", 3, (1, 1, 1))),
                                     is_constraint=not is_cost, name=name)
+        if typ == "dynamic_cart_pose":
+            # DynamicCartPoseTermInfo::fromJson (problem_description.cpp:685-750): both frames are ACTIVE links of the manipulator
+            _only_members(p, ("timestep", "pos_coeffs", "rot_coeffs", "source_frame", "target_frame", "source_frame_offset_xyz",
+                              "source_frame_offset_wxyz", "target_frame_offset_xyz", "target_frame_offset_wxyz"), typ)
+            src, tgt = str(p["source_frame"]), str(p["target_frame"])
+            links = list(env.link_names.get(manip, ()))
+            if src != env.tip_links.get(manip):
+                raise UnsupportedTerm(f"dynamic_cart_pose source_frame {src}: only the manipulator tip link {env.tip_links.get(manip)} is lowered")
+            if tgt not in links:
+                if tgt in env.link_frames:
+                    raise ValueError(f"source '{src}' and target '{tgt}' are not both active links")     # :733-737
+                raise ValueError(f"invalid target frame: {tgt}")                                         # :726-729
+            s_off = _tf12(_quat_to_rot(p.get("source_frame_offset_wxyz", (1, 0, 0, 0))), _vec(p, "source_frame_offset_xyz", 3, (0, 0, 0)))
+            t_off = _tf12(_quat_to_rot(p.get("target_frame_offset_wxyz", (1, 0, 0, 0))), _vec(p, "target_frame_offset_xyz", 3, (0, 0, 0)))
+            if not np.allclose(s_off, _tf12()):
+                raise UnsupportedTerm("dynamic_cart_pose source_frame_offset: fold it into the manipulator's tool frame (one tool frame per problem)")
+            return DynamicCartPoseTermInfo(timestep=int(p.get("timestep", n_steps - 1)), target_link=links.index(tgt), target_frame_offset=t_off,
+                                           pos_coeffs=tuple(_vec(p, "pos_coeffs", 3, (1, 1, 1))), rot_coeffs=tuple(_vec(p, "rot_coeffs", 3, (1, 1, 1))),
+                                           is_constraint=not is_cost, name=name)
         if typ == "cart_vel":
             # CartVelTermInfo::fromJson (problem_description.cpp:989-1009)
             _only_members(p, ("first_step", "last_step", "max_displacement", "link"), typ)

@@ -278,6 +278,35 @@ class CartPoseTermInfo:
 
 
 @dataclass
+class DynamicCartPoseTermInfo:
+    """trajopt::DynamicCartPoseTermInfo — problem_description.cpp:677-822: BOTH frames move with the joints.  The source frame
+    is the chain's tool frame, the target frame is moving link `target_link` (child of joint `target_link`) times
+    target_frame_offset (3x4 link_T_target); EQ constraint (TT_CNT) or ABS cost (TT_COST) at one timestep"""
+    timestep: int
+    target_link: int
+    target_frame_offset: np.ndarray = field(default_factory=lambda: np.hstack([np.eye(3), np.zeros((3, 1))]))
+    pos_coeffs: Sequence[float] = (1, 1, 1)
+    rot_coeffs: Sequence[float] = (1, 1, 1)
+    is_constraint: bool = True
+    name: str = "dynamic_cart_pose"
+
+
+@dataclass
+class AvoidSingularityTermInfo:
+    """trajopt::AvoidSingularityTermInfo — problem_description.hpp:637-659, hatch problem_description.cpp:1900-1940 (the
+    problem's full joint set): per step in [first_step, last_step] the error 1 / (s_min + lambda) - 1 / (0.1 + lambda) of the
+    smallest singular value of link `link`'s Jacobian, as an ABS cost (TT_COST) or an INEQ constraint (TT_CNT); names
+    name_<step>"""
+    link: int
+    first_step: int = 0
+    last_step: int = -1
+    coeffs: Sequence[float] = (1.0,)
+    lambda_: float = 0.1
+    is_constraint: bool = False
+    name: str = "avoid_singularity"
+
+
+@dataclass
 class CartVelTermInfo:
     """trajopt::CartVelTermInfo — problem_description.cpp:989-1057: the tool-frame origin may move at most `max_displacement`
     per axis between consecutive waypoints i, i + 1 for i in [first_step, last_step] (so last_step <= n_steps - 2); ABS cost
@@ -344,6 +373,9 @@ class ProblemConstructionInfo:
             if isinstance(ti, FuncConstraintTermInfo):
                 return [f"{ti.name}_{i}" for i in range(ti.first_step, last + 1)]
             return [ti.name] * (last - ti.first_step + 1)
+        if isinstance(ti, AvoidSingularityTermInfo):  # name_<step> (problem_description.cpp:1924)
+            last = ti.last_step if ti.last_step >= 0 else T - 1
+            return [f"{ti.name}_{i}" for i in range(ti.first_step, last + 1)]
         if isinstance(ti, UserDefinedTermInfo):      # name_<TYPE>_<step> (problem_description.cpp:611-630, :648-656)
             last = ti.last_step if ti.last_step >= 0 else T - 1
             typ = ("INEQ" if ti.constraint_ineq else "EQ") if ti.is_constraint else {0: "SQUARED", 1: "ABS", 2: "HING"}[int(ti.cost_penalty_type)]
@@ -360,6 +392,8 @@ class ProblemConstructionInfo:
                 return True
             if isinstance(ti, FuncConstraintTermInfo):
                 return ti.ineq
+            if isinstance(ti, AvoidSingularityTermInfo):
+                return True
             if isinstance(ti, UserDefinedTermInfo):
                 return ti.constraint_ineq
             if isinstance(ti, (JointPosTermInfo, JointVelTermInfo)):
@@ -507,6 +541,23 @@ class ProblemConstructionInfo:
                 t.is_constraint = 1 if ti.is_constraint else 0
                 t.coeffs[:6] = list(ti.pos_coeffs) + list(ti.rot_coeffs)
                 t.target_pose[:] = list(np.asarray(ti.target_pose).reshape(-1))
+            elif isinstance(ti, DynamicCartPoseTermInfo):
+                t.kind = abi.TERM_DYN_CART_POSE
+                t.first_step = t.last_step = ti.timestep
+                t.is_constraint = 1 if ti.is_constraint else 0
+                t.coeffs[:6] = list(ti.pos_coeffs) + list(ti.rot_coeffs)
+                t.target_pose[:] = list(np.asarray(ti.target_frame_offset, dtype=float).reshape(-1))
+                t.link = int(ti.target_link)
+            elif isinstance(ti, AvoidSingularityTermInfo):
+                t.kind = abi.TERM_AVOID_SINGULARITY
+                t.first_step = ti.first_step
+                t.last_step = ti.last_step if ti.last_step >= 0 else T - 1
+                t.is_constraint = 1 if ti.is_constraint else 0
+                if len(ti.coeffs) != 1:
+                    raise ValueError("AvoidSingularityTermInfo: one coefficient (the error has one row)")
+                t.coeffs[0] = float(ti.coeffs[0])
+                t.link = int(ti.link)
+                t.lambda_ = float(ti.lambda_)
             elif isinstance(ti, CartVelTermInfo):
                 # FAIL_IF_FALSE checks of CartVelTermInfo::fromJson (:997-998)
                 if not (0 <= ti.first_step <= T - 1 and ti.first_step < ti.last_step and 0 < ti.last_step <= T - 1):
