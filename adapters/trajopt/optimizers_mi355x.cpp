@@ -40,6 +40,25 @@ void fill(double* dst, const DblVec& src, std::size_t n, const char* what)
   std::copy(src.begin(), src.end(), dst);
 }
 
+// CartPoseTermInfo / DynamicCartPoseTermInfo tolerance bands (validateTolerances, kinematic_terms.cpp:41-55) -> tmx_term::lower_tols /
+// upper_tols [0..5]
+void fillPoseTolerances(tmx_term& t, const Eigen::VectorXd& lower, const Eigen::VectorXd& upper, const std::string& name)
+{
+  if (lower.size() != upper.size())
+    PRINT_AND_THROW(name + ": Mismatched tolerance sizes.");
+  if (lower.size() == 0)
+    return;
+  if (lower.size() != 6)
+    PRINT_AND_THROW(name + ": pose tolerances have six values (the rows of calcTransformError)");
+  for (Eigen::Index i = 0; i < 6; ++i)
+  {
+    if (lower(i) > upper(i))
+      PRINT_AND_THROW(name + ": Inverted tolerance band - lower > upper at one or more indices.");
+    t.lower_tols[i] = lower(i);
+    t.upper_tols[i] = upper(i);
+  }
+}
+
 // index k of the moving link `name` = child link of joint k of the manipulator (-1: not one)
 int movingLinkIndex(const ProblemConstructionInfo& pci, const std::string& name)
 {
@@ -297,8 +316,9 @@ void lowerTerm(const ProblemConstructionInfo& pci, const TermInfo& ti, bool is_c
   }
   else if (const auto* cp = dynamic_cast<const CartPoseTermInfo*>(&ti))
   {
-    if (cp->error_function != nullptr || cp->lower_tolerance.size() != 0 || cp->upper_tolerance.size() != 0)
-      PRINT_AND_THROW(ti.name + ": CartPose tolerances / custom error functions are not lowered by the device path");
+    if (cp->error_function != nullptr)
+      PRINT_AND_THROW(ti.name + ": custom CartPose error functions are not lowered by the device path");
+    fillPoseTolerances(t, cp->lower_tolerance, cp->upper_tolerance, ti.name);
     const auto tip = pci.kin->getActiveLinkNames().back();
     if (cp->source_frame != tip)
       PRINT_AND_THROW(ti.name + ": the source frame must be the manipulator's tip link (one tool frame per problem)");
@@ -351,8 +371,7 @@ void lowerTerm(const ProblemConstructionInfo& pci, const TermInfo& ti, bool is_c
   else if (const auto* dcp = dynamic_cast<const DynamicCartPoseTermInfo*>(&ti))
   {
     // DynamicCartPoseTermInfo::hatch (problem_description.cpp:752-822): source = the tool frame, target = a moving link of the chain
-    if (dcp->lower_tolerance.size() != 0 || dcp->upper_tolerance.size() != 0)
-      PRINT_AND_THROW(ti.name + ": DynamicCartPose tolerances are not lowered by the device path");
+    fillPoseTolerances(t, dcp->lower_tolerance, dcp->upper_tolerance, ti.name);
     if (static_cast<bool>(ti.term_type & TermType::TT_USE_TIME))
       PRINT_AND_THROW(ti.name + ": Use time version of this term has not been defined.");
     if (dcp->source_frame != pci.kin->getActiveLinkNames().back())

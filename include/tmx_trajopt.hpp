@@ -500,6 +500,25 @@ inline tmx_term blankTerm()
   tmx_term t{};
   return t;
 }
+/** validateTolerances (trajopt/src/kinematic_terms.cpp:41-55); six values each (the rows of calcTransformError) or none */
+inline void validateTolerances(const std::string& who, const DblVec& lower, const DblVec& upper)
+{
+  if (lower.size() != upper.size())
+    printAndThrow(who + ": Mismatched tolerance sizes. lower: " + std::to_string(lower.size()) + ", upper: " + std::to_string(upper.size()));
+  if (!lower.empty() && lower.size() != 6)
+    printAndThrow(who + ": pose tolerances have six values");
+  for (std::size_t i = 0; i < lower.size(); ++i)
+    if (lower[i] > upper[i])
+      printAndThrow(who + ": Inverted tolerance band - lower > upper at one or more indices.");
+}
+inline void fillTolerances(tmx_term& t, const DblVec& lower, const DblVec& upper)
+{
+  for (std::size_t i = 0; i < lower.size() && i < 6; ++i)
+  {
+    t.lower_tols[i] = lower[i];
+    t.upper_tols[i] = upper[i];
+  }
+}
 }  // namespace detail
 
 /** problem_description.hpp:421-469 ; hatch: problem_description.cpp:1073-1176 */
@@ -859,7 +878,7 @@ using JointAccTermInfo = JointDiffTermInfo<2>;
 using JointJerkTermInfo = JointDiffTermInfo<3>;
 
 /** problem_description.hpp:352-392 ; hatch: problem_description.cpp:857-987.  Lowered: source = the manipulator's tip link
-    (active), target = a static link of the environment, no tolerances. */
+    (active), target = a static link of the environment; with a tolerance band the term runs on the dense QP engine. */
 struct CartPoseTermInfo : public TermInfo
 {
   int timestep{ 0 };
@@ -886,8 +905,7 @@ struct CartPoseTermInfo : public TermInfo
       printAndThrow("source '" + source_frame + "' and target '" + target_frame + "' are both active");  // :881
     if (!src_active && tgt_static)
       printAndThrow("source '" + source_frame + "' and target '" + target_frame + "' are both static");  // :886
-    if (!detail::allZero(lower_tolerance) || !detail::allZero(upper_tolerance))
-      printAndThrow("CartPoseTermInfo tolerances are not lowered by the device path");
+    detail::validateTolerances("CartPoseErrCalculator", lower_tolerance, upper_tolerance);
     if (!source_frame_offset.isIdentity())
       printAndThrow("CartPoseTermInfo source_frame_offset: fold it into JointGroup::tool (one tool frame per problem)");
     if (timestep < 0 || timestep >= prob.GetNumSteps())
@@ -902,6 +920,7 @@ struct CartPoseTermInfo : public TermInfo
     }
     const Transform target = env->link_frames.at(target_frame) * target_frame_offset;  // world_T_target * offset
     std::copy(target.m.begin(), target.m.end(), t.target_pose);
+    detail::fillTolerances(t, lower_tolerance, upper_tolerance);
     if (static_cast<bool>(term_type & TermType::TT_COST))
       t.is_constraint = 0;  // ABS cost (:946-960)
     else if (static_cast<bool>(term_type & TermType::TT_CNT))
@@ -914,7 +933,7 @@ struct CartPoseTermInfo : public TermInfo
 
 /** trajopt::DynamicCartPoseTermInfo (problem_description.hpp:310-350; hatch problem_description.cpp:752-822): source and target are
     BOTH links of the manipulator.  Lowered: source = the tip link (tool frame), target = any moving link times
-    target_frame_offset; no tolerances. */
+    target_frame_offset. */
 struct DynamicCartPoseTermInfo : public TermInfo
 {
   int timestep{ 0 };
@@ -933,8 +952,7 @@ struct DynamicCartPoseTermInfo : public TermInfo
     const int target = kin->linkIndex(target_frame);
     if (source_frame != kin->tip_link || target < 0)
       printAndThrow("source '" + source_frame + "' and target '" + target_frame + "' are not both active links");  // :735
-    if (!detail::allZero(lower_tolerance) || !detail::allZero(upper_tolerance))
-      printAndThrow("DynamicCartPoseTermInfo tolerances are not lowered by the device path");
+    detail::validateTolerances("DynamicCartPoseErrCalculator", lower_tolerance, upper_tolerance);
     if (!source_frame_offset.isIdentity())
       printAndThrow("DynamicCartPoseTermInfo source_frame_offset: fold it into JointGroup::tool (one tool frame per problem)");
     if (timestep < 0 || timestep >= prob.GetNumSteps())
@@ -951,6 +969,7 @@ struct DynamicCartPoseTermInfo : public TermInfo
     }
     t.link = target;
     std::copy(target_frame_offset.m.begin(), target_frame_offset.m.end(), t.target_pose);
+    detail::fillTolerances(t, lower_tolerance, upper_tolerance);
     if (static_cast<bool>(term_type & TermType::TT_COST))
       t.is_constraint = 0;  // ABS cost (:806-810)
     else if (static_cast<bool>(term_type & TermType::TT_CNT))

@@ -260,7 +260,11 @@ inline void transformError(const Tf& t1, const Tf& t2, double err[6])
   err[5] = ax[2] * ang;
 }
 // calcJacobianTransformErrorDiff(target, source, source_perturbed) with the +-pi discontinuity handling
-inline void transformErrorDiff(const Tf& target, const Tf& source, const Tf& source_pert, double diff[6])
+inline void applyTolerances(double err[6], const DblVec& lower, const DblVec& upper);
+// (with a tolerance band - the five-argument overload the reference calls, kinematic_terms.cpp:318, :336 - both errors pass
+//  through applyTolerances before the difference)
+inline void transformErrorDiff(const Tf& target, const Tf& source, const Tf& source_pert, double diff[6], const DblVec& lower = DblVec(),
+                               const DblVec& upper = DblVec())
 {
   const Tf tinv = tfInv(target);
   const Tf pe = tfMul(tinv, source);
@@ -274,11 +278,15 @@ inline void transformErrorDiff(const Tf& target, const Tf& source, const Tf& sou
     a1c = a1 - 2.0 * M_PI;
   else if (a1 < -M_PI_2 && a0 > M_PI_2)
     a1c = a1 + 2.0 * M_PI;
-  for (int r = 0; r < 3; ++r)
+  double e0[6] = { pe.t[0], pe.t[1], pe.t[2], ax0[0] * a0, ax0[1] * a0, ax0[2] * a0 };
+  double e1[6] = { pp.t[0], pp.t[1], pp.t[2], ax1[0] * a1c, ax1[1] * a1c, ax1[2] * a1c };
+  if (!lower.empty())
   {
-    diff[r] = pp.t[r] - pe.t[r];
-    diff[3 + r] = ax1[r] * a1c - ax0[r] * a0;
+    applyTolerances(e0, lower, upper);
+    applyTolerances(e1, lower, upper);
   }
+  for (int r = 0; r < 6; ++r)
+    diff[r] = e1[r] - e0[r];
 }
 
 // ---- VarArray-lite ---------------------------------------------------------------------------
@@ -752,16 +760,51 @@ private:
 };
 
 // ---- CartPoseErrCalculator / CartPoseJacCalculator with a static target  kinematic_terms.cpp:250-263,348-366 ----
+// tesseract::common::applyTolerances [NOT IN REFERENCE; call sites kinematic_terms.cpp:92, :234, :243]: what is left of the error
+// outside the band [lower, upper] (zero inside).  Restated from its use in the reference: "parity unpinned".
+inline void applyTolerances(double err[6], const DblVec& lower, const DblVec& upper)
+{
+  for (std::size_t i = 0; i < 6 && i < lower.size(); ++i)
+  {
+    if (err[i] < lower[i])
+      err[i] = err[i] - lower[i];
+    else if (err[i] > upper[i])
+      err[i] = err[i] - upper[i];
+    else
+      err[i] = 0.0;
+  }
+}
+// (lower, upper) of a pose term: empty unless the band is a band (CartPoseErrCalculator ctor, kinematic_terms.cpp:206-247:
+// validateTolerances, then toleranced unless the vectors are empty or almostEqualRelativeAndAbs(lower, upper))
+inline void poseTolerances(const tmx_term& tm, DblVec& lower, DblVec& upper)
+{
+  bool band = false;
+  for (int i = 0; i < 6; ++i)
+  {
+    if (tm.lower_tols[i] > tm.upper_tols[i])
+      throw std::runtime_error("CartPoseErrCalculator: Inverted tolerance band — lower > upper at one or more indices.");
+    band = band || std::fabs(tm.lower_tols[i] - tm.upper_tols[i]) > 1e-6;
+  }
+  lower.clear();
+  upper.clear();
+  if (band)
+  {
+    lower.assign(tm.lower_tols, tm.lower_tols + 6);
+    upper.assign(tm.upper_tols, tm.upper_tols + 6);
+  }
+}
 struct CartPoseCalc
 {
   std::shared_ptr<const Chain> chain;
   Tf target;  // world_T_target
   std::vector<int> indices;
+  DblVec lower_tolerance, upper_tolerance;  // empty: no band
   DblVec err(const DblVec& q) const
   {
     const Tf src = chain->fkTool(q.data());
     double e[6];
     transformError(target, src, e);
+    applyTolerances(e, lower_tolerance, upper_tolerance);
     DblVec out(indices.size());
     for (std::size_t i = 0; i < indices.size(); ++i)
       out[i] = e[indices[i]];
@@ -777,7 +820,7 @@ struct CartPoseCalc
       qp[i] = q[i] + DEFAULT_EPSILON;
       const Tf sp = chain->fkTool(qp.data());
       double d[6];
-      transformErrorDiff(target, src, sp, d);
+      transformErrorDiff(target, src, sp, d, lower_tolerance, upper_tolerance);
       for (std::size_t r = 0; r < indices.size(); ++r)
         J(static_cast<int>(r), static_cast<int>(i)) = d[indices[r]] / DEFAULT_EPSILON;
       qp[i] = q[i];
@@ -950,6 +993,7 @@ struct DynCartPoseCalc
   int link{ 0 };
   Tf target_offset;  // link_T_target
   std::vector<int> indices;
+  DblVec lower_tolerance, upper_tolerance;  // empty: no band
   void frames(const double* q, Tf& target, Tf& source) const
   {
     std::vector<Tf> lk;
@@ -963,12 +1007,13 @@ struct DynCartPoseCalc
     frames(q.data(), tgt, src);
     double e[6];
     transformError(tgt, src, e);
+    applyTolerances(e, lower_tolerance, upper_tolerance);
     DblVec out(indices.size());
     for (std::size_t i = 0; i < indices.size(); ++i)
       out[i] = e[indices[i]];
     return out;
   }
-  // calcJacobianTransformErrorDiff(target, target_perturbed, source, source_perturbed) [tesseract, NOT IN REFERENCE]: the
+  // calcJacobianTransformErrorDiff(target, target_perturbed, source, source_perturbed, lower, upper) [tesseract, NOT IN REFERENCE]: the
   // three-argument form (transformErrorDiff above) with the perturbed error taken against the perturbed target
   Mat jac(const DblVec& q) const
   {
@@ -992,14 +1037,12 @@ struct DynCartPoseCalc
         a1c = a1 - 2.0 * M_PI;
       else if (a1 < -M_PI_2 && a0 > M_PI_2)
         a1c = a1 + 2.0 * M_PI;
-      double d[6];
-      for (int r = 0; r < 3; ++r)
-      {
-        d[r] = pp.t[r] - pe.t[r];
-        d[3 + r] = ax1[r] * a1c - ax0[r] * a0;
-      }
+      double e0[6] = { pe.t[0], pe.t[1], pe.t[2], ax0[0] * a0, ax0[1] * a0, ax0[2] * a0 };
+      double e1[6] = { pp.t[0], pp.t[1], pp.t[2], ax1[0] * a1c, ax1[1] * a1c, ax1[2] * a1c };
+      applyTolerances(e0, lower_tolerance, upper_tolerance);
+      applyTolerances(e1, lower_tolerance, upper_tolerance);
       for (std::size_t r = 0; r < indices.size(); ++r)
-        J(static_cast<int>(r), static_cast<int>(i)) = d[indices[r]] / DEFAULT_EPSILON;
+        J(static_cast<int>(r), static_cast<int>(i)) = (e1[indices[r]] - e0[indices[r]]) / DEFAULT_EPSILON;
       qp[i] = q[i];
     }
     return J;
@@ -1665,6 +1708,7 @@ inline TrajProblem constructProblem(const tmx_problem_desc& d, const double* ini
           auto calc = std::make_shared<CartPoseCalc>();
           calc->chain = P.chain;
           calc->target = tfFrom12(tm.target_pose);
+          poseTolerances(tm, calc->lower_tolerance, calc->upper_tolerance);
           DblVec c;
           for (int i = 0; i < 6; ++i)
             if (std::fabs(tm.coeffs[i]) > 1e-5)
@@ -1709,6 +1753,7 @@ inline TrajProblem constructProblem(const tmx_problem_desc& d, const double* ini
           calc->chain = P.chain;
           calc->link = tm.link;
           calc->target_offset = tfFrom12(tm.target_pose);
+          poseTolerances(tm, calc->lower_tolerance, calc->upper_tolerance);
           DblVec c;
           for (int i = 0; i < 6; ++i)
             if (std::fabs(tm.coeffs[i]) > 1e-5)

@@ -132,7 +132,7 @@ def _check_terms_matter(pci, desc, orc, x0, r, o, cid):
     """the new term is not a bystander: its cost / violation is non-zero at the seeds and the run ends where the oracle's does"""
     cv0, vv0 = orc.evaluate(desc, x0[0], x0[0])
     names_c, names_v = pci.cost_names(), pci.cnt_names()
-    if cid in (38, 41):
+    if cid in (38, 41, 43):
         idx = [i for i, n in enumerate(names_c) if n.startswith("sing_") or n == "dynamic_cart_pose"]
         assert idx and cv0[idx].sum() > 1e-3
     if cid == 40:
@@ -144,7 +144,7 @@ def _check_terms_matter(pci, desc, orc, x0, r, o, cid):
     assert (close | ~same).mean() >= 0.75 and close.sum() >= 1
 
 
-@pytest.mark.parametrize("cid", [38, 39, 40, 41])
+@pytest.mark.parametrize("cid", [38, 39, 40, 41, 42, 43])
 def test_kinematic_terms_kernel_sources_on_host(hostemu_lib, orc, cid):
     ctx = runtime.Context(0, hostemu_lib)
     pci, desc, x0, r, o = _run(ctx, orc, cid, 2)
@@ -153,7 +153,7 @@ def test_kinematic_terms_kernel_sources_on_host(hostemu_lib, orc, cid):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cid", [38, 39, 40, 41])
+@pytest.mark.parametrize("cid", [38, 39, 40, 41, 42, 43])
 def test_kinematic_terms_on_device(gpu_ctx_factory, orc, cid):
     ctx = gpu_ctx_factory()
     pci, desc, x0, r, o = _run(ctx, orc, cid, 8)
@@ -169,3 +169,27 @@ def test_constraint_order_and_names():
     assert names[-(n - 2):] == [f"sing_{i}" for i in range(1, n - 1)]
     pci, s, g = pc.cfg(38)
     assert [x for x in pci.cost_names() if x.startswith("sing_")] == [f"sing_{i}" for i in range(1, pci.basic_info.n_steps - 1)]
+
+
+def test_pose_tolerance_band(orc):
+    """tesseract::common::applyTolerances as the reference uses it (kinematic_terms.cpp:229-246): the violation of a toleranced CartPose
+    row is what is left of the plain error outside [lower, upper], zero inside; lower == upper is no band; inverted bands are errors"""
+    from trajopt_amd.problem import CartPoseTermInfo
+    pci, s, g = configs.config_mini()
+    cp = [ti for ti in pci.cnt_infos if isinstance(ti, CartPoseTermInfo)][0]
+    x = np.linspace(s, g, pci.basic_info.n_steps)
+    names = pci.cnt_names()
+    k = names.index(cp.name)
+    plain = orc.evaluate(pci.to_desc(), x, x)[1][k]
+    tool = pci.robot.fk_tool(x[cp.timestep])[:3, 3]
+    e = tool - np.asarray(cp.target_pose).reshape(3, 4)[:, 3]            # identity target rotation: the error is the offset
+    assert abs(plain - np.abs(e).sum()) < 1e-12
+    lo, up = np.array([-1.0, e[1] + 0.004, -1.0]), np.array([e[0] - 0.003, 1.0, 1.0])   # row 0 above its band, row 1 below, row 2 inside
+    cp.lower_tolerance, cp.upper_tolerance = list(lo) + [0, 0, 0], list(up) + [0, 0, 0]
+    banded = orc.evaluate(pci.to_desc(), x, x)[1][k]
+    assert abs(banded - (0.003 + 0.004)) < 1e-12
+    cp.lower_tolerance = cp.upper_tolerance = [0.01] * 6                                  # lower == upper: the plain error
+    assert orc.evaluate(pci.to_desc(), x, x)[1][k] == plain
+    cp.lower_tolerance, cp.upper_tolerance = [0.1] * 6, [0.0] * 6
+    with pytest.raises(ValueError, match="Inverted tolerance band"):
+        pci.to_desc()

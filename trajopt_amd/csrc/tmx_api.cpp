@@ -475,7 +475,21 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
           ctx->err = "Fixed step is not between first step and last step";  // problem_description.cpp:1641-1649
           return TMX_ERR_INVALID;
         }
-      switch (tm.kind)
+      // CartPose / DynamicCartPose with a tolerance band (CartPoseErrCalculator, kinematic_terms.cpp:206-247: toleranced unless the
+      // vectors are empty or lower == upper): the band is applied to the six error rows before the row selection
+      bool pose_tol = false;
+      if (tm.kind == TMX_TERM_CART_POSE || tm.kind == TMX_TERM_DYN_CART_POSE)
+        for (int i = 0; i < 6; ++i)
+        {
+          if (tm.lower_tols[i] > tm.upper_tols[i])
+          {
+            ctx->err = "CartPoseErrCalculator: Inverted tolerance band - lower > upper at one or more indices";  // kinematic_terms.cpp:47-54
+            return TMX_ERR_INVALID;
+          }
+          pose_tol = pose_tol || std::fabs(tm.lower_tols[i] - tm.upper_tols[i]) > 1e-6;
+        }
+      const int kind_eff = (tm.kind == TMX_TERM_CART_POSE && pose_tol) ? TMX_TERM_DYN_CART_POSE : tm.kind;
+      switch (kind_eff)
       {
         case TMX_TERM_JOINT_VEL_COST:
         {
@@ -612,7 +626,8 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
           // constraint per step (include/tmx.h).  The cost model is a dynamic quadratic: dense QP engine.
           // AvoidSingularity / DynamicCartPose: the same Cost / ConstraintFromErrFunc rows over a BUILT-IN kinematic function
           // with its own Jacobian (fx_nops < 0: -1 / -2, fx_op0 = link, parameters in the constants; tmx_terms.h).
-          const bool builtin = tm.kind == TMX_TERM_AVOID_SINGULARITY || tm.kind == TMX_TERM_DYN_CART_POSE;
+          const bool pose = tm.kind == TMX_TERM_DYN_CART_POSE || tm.kind == TMX_TERM_CART_POSE;  // (a static target only with tolerances)
+          const bool builtin = tm.kind == TMX_TERM_AVOID_SINGULARITY || pose;
           if (flavor == TMX_FLAVOR_SQP)
           {
             ctx->err = "TMX_FLAVOR_SQP: function terms are not part of the trajopt_sqp path";
@@ -623,7 +638,7 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
             ctx->err = "function term: malformed tmx_expr program (opcode, index, stack discipline or outputs)";
             return TMX_ERR_INVALID;
           }
-          if (builtin && (tm.link < 0 || tm.link >= D))
+          if (builtin && tm.kind != TMX_TERM_CART_POSE && (tm.link < 0 || tm.link >= D))
           {
             ctx->err = "AvoidSingularity / DynamicCartPose: link is the index of a moving link, 0 .. n_dof - 1";
             return TMX_ERR_INVALID;
@@ -631,7 +646,7 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
           const bool is_cnt = builtin ? tm.is_constraint != 0 : tm.kind == TMX_TERM_FUNC_CNT;
           // AvoidSingularity: ABS cost / INEQ constraint (problem_description.cpp:1925-1934); DynamicCartPose: ABS cost / EQ
           // constraint (:808-816)
-          const int cnt_type = tm.kind == TMX_TERM_AVOID_SINGULARITY ? 1 : (tm.kind == TMX_TERM_DYN_CART_POSE ? 0 : tm.cnt_type);
+          const int cnt_type = tm.kind == TMX_TERM_AVOID_SINGULARITY ? 1 : (pose ? 0 : tm.cnt_type);
           const int penalty_type = builtin ? 1 : tm.penalty_type;
           double weights[TMX_EXPR_MAX_OUT];
           int n_out = builtin ? 0 : tm.expr->n_outputs;
@@ -644,7 +659,7 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
             n_out = 1;
             weights[0] = tm.coeffs[0];
           }
-          else if (tm.kind == TMX_TERM_DYN_CART_POSE)
+          else if (pose)
             for (int i = 0; i < 6; ++i)  // rows with |coeff| <= 1e-5 are dropped (problem_description.cpp:756-775)
               if (std::fabs(tm.coeffs[i]) > 1e-5)
               {
@@ -689,11 +704,14 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
           }
           else
           {
-            op0 = tm.link;
+            op0 = tm.kind == TMX_TERM_CART_POSE ? -1 : tm.link;  // -1: the frame is world_T_target itself
             n_ops = -2;
-            fx_consts.insert(fx_consts.end(), tm.target_pose, tm.target_pose + 12);  // link_T_target
+            fx_consts.insert(fx_consts.end(), tm.target_pose, tm.target_pose + 12);  // link_T_target (world_T_target)
             for (int i = 0; i < 6; ++i)
               fx_consts.push_back((double)pose_idx[i]);
+            fx_consts.push_back(pose_tol ? 1.0 : 0.0);
+            fx_consts.insert(fx_consts.end(), tm.lower_tols, tm.lower_tols + 6);
+            fx_consts.insert(fx_consts.end(), tm.upper_tols, tm.upper_tols + 6);
           }
           for (int t = tm.first_step; t <= tm.last_step; ++t)
           {

@@ -494,7 +494,7 @@ TMX_DEVFN void lvs_end_gradient(const DevProblem* P, const double* q, int s, con
 // ---- function terms (tmx_expr programs): sco::CostFromFunc / ConstraintFromErrFunc, trajopt_sco/src/modeling_utils.cpp ----------
 // fx_nops[inst] < 0: a built-in kinematic function instead of a program (fx_op0 = link, parameters behind the row weights)
 #define FX_AVOID_SINGULARITY (-1)  // consts: lambda
-#define FX_DYN_CART_POSE (-2)      // consts: link_T_target (12), row indices (6)
+#define FX_DYN_CART_POSE (-2)      // consts: link_T_target (12; world_T_target when fx_op0 < 0), row indices (6), tolerance flag, lower (6), upper (6)
 TMX_DEVFN void fx_builtin_eval(const DevProblem* P, int inst, const double* x, double* out);
 TMX_DEVFN void fx_eval(const DevProblem* P, int inst, const double* x, double* out)
 {
@@ -647,15 +647,32 @@ TMX_DEVFN double smallest_singular(const double* J, int D, double* u, double* v)
   }
   return sv;
 }
-// target and source frames of a DynamicCartPose instance at q: link * offset, tool
+// target and source frames of a pose instance at q: link * offset (or the static world frame), tool
 TMX_DEVFN void dyn_pose_frames(const DevProblem* P, int inst, const double* q, Tf3& tinv, Tf3& src)
 {
   Tf3 L, off, tgt;
-  fk_link(P, q, P->fx_op0[inst], L);
   tf_from12(P->fx_consts + P->fx_c0[inst], off);
-  tf_mul(L, off, tgt);
-  tf_inv(tgt, tinv);
+  if (P->fx_op0[inst] >= 0)
+  {
+    fk_link(P, q, P->fx_op0[inst], L);
+    tf_mul(L, off, tgt);
+    tf_inv(tgt, tinv);
+  }
+  else
+    tf_inv(off, tinv);
   fk_tool(P, q, src);
+}
+// tesseract::common::applyTolerances [NOT IN REFERENCE; call sites kinematic_terms.cpp:92, :234, :243]: the part of the error
+// outside the band [lower, upper], zero inside
+TMX_DEVFN void pose_apply_tolerances(const double* par, double err[6])
+{
+  if (par[18] == 0.0)
+    return;
+  for (int i = 0; i < 6; ++i)
+  {
+    const double lo = par[19 + i], up = par[25 + i];
+    err[i] = (err[i] < lo) ? err[i] - lo : ((err[i] > up) ? err[i] - up : 0.0);
+  }
 }
 TMX_DEVFN void fx_builtin_eval(const DevProblem* P, int inst, const double* x, double* out)
 {
@@ -675,6 +692,7 @@ TMX_DEVFN void fx_builtin_eval(const DevProblem* P, int inst, const double* x, d
   dyn_pose_frames(P, inst, x, tinv, src);
   double err[6], ax[3], ang;
   transform_error(tinv, src, err, ax, ang);
+  pose_apply_tolerances(par, err);
   for (int i = 0; i < P->fx_nout[inst]; ++i)
     out[i] = err[(int)par[12 + i]];
 }
@@ -713,12 +731,15 @@ TMX_DEVFN void fx_builtin_jac(const DevProblem* P, int inst, double* x, double (
     return;
   }
   // DynamicCartPoseJacCalculator::operator()  kinematic_terms.cpp:158-185: calcJacobianTransformErrorDiff(target, target',
-  // source, source') / eps - both frames perturbed, the +-pi handling of the static CartPose Jacobian (convexify_terms)
+  // source, source', lower, upper) / eps - both frames perturbed, the +-pi handling of the static CartPose Jacobian
+  // (convexify_terms); with a tolerance band both errors pass through it before the difference
   Tf3 tinv, src, pe, pp;
   dyn_pose_frames(P, inst, x, tinv, src);
   tf_mul(tinv, src, pe);
   double ax0[3], a0;
   rot_err_decomposed(pe.R, ax0, a0);
+  double e0[6] = { pe.t[0], pe.t[1], pe.t[2], ax0[0] * a0, ax0[1] * a0, ax0[2] * a0 };
+  pose_apply_tolerances(par, e0);
   for (int k = 0; k < D; ++k)
   {
     const double xk = x[k];
@@ -733,11 +754,12 @@ TMX_DEVFN void fx_builtin_jac(const DevProblem* P, int inst, double* x, double (
       a1c = a1 - 2.0 * M_PI;
     else if (a1 < -M_PI_2 && a0 > M_PI_2)
       a1c = a1 + 2.0 * M_PI;
+    double e1[6] = { pp.t[0], pp.t[1], pp.t[2], ax1[0] * a1c, ax1[1] * a1c, ax1[2] * a1c };
+    pose_apply_tolerances(par, e1);
     for (int i = 0; i < P->fx_nout[inst]; ++i)
     {
       const int r = (int)par[12 + i];
-      const double diff = (r < 3) ? pp.t[r] - pe.t[r] : ax1[r - 3] * a1c - ax0[r - 3] * a0;
-      Jo[i][k] = diff / TMX_EPS_FD;
+      Jo[i][k] = (e1[r] - e0[r]) / TMX_EPS_FD;
     }
   }
 }

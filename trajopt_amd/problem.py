@@ -275,6 +275,25 @@ class CartPoseTermInfo:
     rot_coeffs: Sequence[float] = (1, 1, 1)
     is_constraint: bool = True           # TT_CNT -> EQ constraint ; TT_COST -> ABS cost
     name: str = "cart_pose"
+    # CartPoseTermInfo::lower_tolerance / upper_tolerance (problem_description.hpp:370-373): six values each; the error inside the
+    # band [lower, upper] counts as zero (toleranced terms run on the dense QP engine)
+    lower_tolerance: Sequence[float] = ()
+    upper_tolerance: Sequence[float] = ()
+
+
+def _pose_tolerances(t, ti):
+    """validateTolerances (kinematic_terms.cpp:41-55)"""
+    lo, up = list(ti.lower_tolerance), list(ti.upper_tolerance)
+    if len(lo) != len(up):
+        raise ValueError(f"CartPoseErrCalculator: Mismatched tolerance sizes. lower: {len(lo)}, upper: {len(up)}")
+    if not lo:
+        return
+    if len(lo) != 6:
+        raise ValueError("pose tolerances have six values (the rows of calcTransformError)")
+    if any(a > b for a, b in zip(lo, up)):
+        raise ValueError("CartPoseErrCalculator: Inverted tolerance band - lower > upper at one or more indices")
+    t.lower_tols[:6] = lo
+    t.upper_tols[:6] = up
 
 
 @dataclass
@@ -289,6 +308,8 @@ class DynamicCartPoseTermInfo:
     rot_coeffs: Sequence[float] = (1, 1, 1)
     is_constraint: bool = True
     name: str = "dynamic_cart_pose"
+    lower_tolerance: Sequence[float] = ()     # problem_description.hpp:330-333
+    upper_tolerance: Sequence[float] = ()
 
 
 @dataclass
@@ -541,6 +562,7 @@ class ProblemConstructionInfo:
                 t.is_constraint = 1 if ti.is_constraint else 0
                 t.coeffs[:6] = list(ti.pos_coeffs) + list(ti.rot_coeffs)
                 t.target_pose[:] = list(np.asarray(ti.target_pose).reshape(-1))
+                _pose_tolerances(t, ti)
             elif isinstance(ti, DynamicCartPoseTermInfo):
                 t.kind = abi.TERM_DYN_CART_POSE
                 t.first_step = t.last_step = ti.timestep
@@ -548,6 +570,7 @@ class ProblemConstructionInfo:
                 t.coeffs[:6] = list(ti.pos_coeffs) + list(ti.rot_coeffs)
                 t.target_pose[:] = list(np.asarray(ti.target_frame_offset, dtype=float).reshape(-1))
                 t.link = int(ti.target_link)
+                _pose_tolerances(t, ti)
             elif isinstance(ti, AvoidSingularityTermInfo):
                 t.kind = abi.TERM_AVOID_SINGULARITY
                 t.first_step = ti.first_step
