@@ -1131,15 +1131,21 @@ __device__ __attribute__((noinline)) static void band_factor_nl(BandWs b) { band
 // components by v_readlane; no barrier per block) - the treatment of the dense-coupling chain (chain_wave_sweep).  Same products,
 // same order of additions as band_solve_impl: bit-identical.  The factors W should sit in LDS (qp_ws_attach_band) - from the HBM
 // slice every block waits for a memory round trip.
-template <int DC>
-TMX_DEVFN double band_rows_dot(const double* W0, size_t kstride, size_t row_off, size_t lstride, int nk, const double (&v)[3], int D)
+TMX_DEVFN bool tmx_in_lds(const void* p);
+typedef __attribute__((address_space(3))) const double tmx_band_clds_d;
+typedef __attribute__((address_space(3))) double tmx_band_lds_d;
+template <int DC, class MP>
+TMX_DEVFN void band_rows_load(MP W0, size_t kstride, size_t row_off, size_t lstride, int nk, int D, double (&m)[3][16])
 {
-  double m[3][16];
 #pragma unroll
   for (int k = 0; k < 3; ++k)
 #pragma unroll
     for (int l = 0; l < 16; ++l)
       m[k][l] = (k < nk && l < (DC ? DC : D)) ? W0[k * kstride + row_off + l * lstride] : 0.0;
+}
+template <int DC>
+TMX_DEVFN double band_rows_dot(const double (&m)[3][16], int nk, const double (&v)[3], int D)
+{
   double acc = 0.0;
 #pragma unroll
   for (int k = 0; k < 3; ++k)
@@ -1152,49 +1158,91 @@ TMX_DEVFN double band_rows_dot(const double* W0, size_t kstride, size_t row_off,
     }
   return acc;
 }
-template <int DC>
-TMX_DEVFN void band_sweeps_wave(const BandWs& w, int lane, bool forward)
+// MP: pointer type of the factors W, VP / VW: of the vectors (tp read / written, y) - typed LDS pointers keep the loads ds_read_b64
+// (flat loads cost a memory round trip per block); the rows of block t + 1 are fetched while block t is summed
+template <int DC, class MP, class VP, class VW>
+TMX_DEVFN void band_sweeps_wave_t(MP Wb, VP tpr, VW tpw, VP y, int D_in, int T, int nb, int lane, bool forward)
 {
-  const int D = DC ? DC : w.D, DD = D * D, T = w.T, nb = w.band;
+  const int D = DC ? DC : D_in, DD = D * D;
   const bool live = lane < D;
   const int i = live ? lane : 0;
   const size_t kstride = (size_t)T * DD;
   double v[3] = { 0.0, 0.0, 0.0 };  // the three most recent vectors of the sweep (this lane's component)
+  double mc[3][16], mn[3][16];
+  if (T < 2)
+  {
+    if (!forward && live)
+      tpw[i] = y[i];
+    return;
+  }
   if (forward)
   {
-    v[0] = w.tp[i];
+    v[0] = tpr[i];
+    int nk = (1 < nb) ? 1 : nb;
+    // W_k[t-k] row i, k = 1..nk : base of k = 1 is block (t-1) of band 1; band k, block t-k = base + (k-1) (kstride - DD)
+    band_rows_load<DC>(Wb, kstride - DD, (size_t)i * D, 1, nk, D, mc);
+    double bn = tpr[D + i];
     for (int t = 1; t < T; ++t)
     {
-      const int nk = (t < nb) ? t : nb;
-      // W_k[t-k] row i, k = 1..nk : base of k = 1 is block (t-1) of band 1; band k, block t-k = base + (k-1) (kstride - DD)
-      const double acc = band_rows_dot<DC>(w.Wb + (size_t)(t - 1) * DD, kstride - DD, (size_t)i * D, 1, nk, v, D);
-      const double vt = w.tp[t * D + i] - acc;
+      const int tn = (t + 1 < T) ? t + 1 : t;  // (clamped prefetch: the last pass reloads a valid block)
+      const int nkn = (tn < nb) ? tn : nb;
+      band_rows_load<DC>(Wb + (size_t)(tn - 1) * DD, kstride - DD, (size_t)i * D, 1, nkn, D, mn);
+      const double bnn = tpr[tn * D + i];
+      const double acc = band_rows_dot<DC>(mc, nk, v, D);
+      const double vt = bn - acc;
       if (live)
-        w.tp[t * D + i] = vt;
+        tpw[t * D + i] = vt;
       v[2] = v[1];
       v[1] = v[0];
       v[0] = vt;
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int l = 0; l < 16; ++l)
+          mc[k][l] = mn[k][l];
+      bn = bnn;
+      nk = nkn;
     }
   }
   else
   {
-    const double* y = w.y;
     v[0] = y[(T - 1) * D + i];
     if (live)
-      w.tp[(T - 1) * D + i] = v[0];
+      tpw[(T - 1) * D + i] = v[0];
+    int nk = (1 < nb) ? 1 : nb;
+    // W_k[t]' column i, k = 1..nk : band k, block t = base + (k-1) kstride
+    band_rows_load<DC>(Wb + (size_t)(T - 2) * DD, kstride, (size_t)i, (size_t)D, nk, D, mc);
+    double bn = y[(T - 2) * D + i];
     for (int t = T - 2; t >= 0; --t)
     {
-      const int nk = (T - 1 - t < nb) ? T - 1 - t : nb;
-      // W_k[t] column i, k = 1..nk : band k, block t = base + (k-1) kstride
-      const double acc = band_rows_dot<DC>(w.Wb + (size_t)t * DD, kstride, (size_t)i, (size_t)D, nk, v, D);
-      const double xt = y[t * D + i] - acc;
+      const int tn = (t > 0) ? t - 1 : t;
+      const int nkn = (T - 1 - tn < nb) ? T - 1 - tn : nb;
+      band_rows_load<DC>(Wb + (size_t)tn * DD, kstride, (size_t)i, (size_t)D, nkn, D, mn);
+      const double bnn = y[tn * D + i];
+      const double acc = band_rows_dot<DC>(mc, nk, v, D);
+      const double xt = bn - acc;
       if (live)
-        w.tp[t * D + i] = xt;
+        tpw[t * D + i] = xt;
       v[2] = v[1];
       v[1] = v[0];
       v[0] = xt;
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int l = 0; l < 16; ++l)
+          mc[k][l] = mn[k][l];
+      bn = bnn;
+      nk = nkn;
     }
   }
+}
+template <int DC>
+TMX_DEVFN void band_sweeps_wave(const BandWs& w, int lane, bool forward)
+{
+  if (tmx_in_lds(w.Wb) && tmx_in_lds(w.tp) && tmx_in_lds(w.y))
+    band_sweeps_wave_t<DC>((tmx_band_clds_d*)w.Wb, (tmx_band_clds_d*)w.tp, (tmx_band_lds_d*)w.tp, (tmx_band_clds_d*)w.y, w.D, w.T, w.band, lane, forward);
+  else
+    band_sweeps_wave_t<DC>((const double*)w.Wb, (const double*)w.tp, w.tp, (const double*)w.y, w.D, w.T, w.band, lane, forward);
 }
 __device__ __attribute__((noinline)) static void band_solve_nl(BandWs w)
 {
