@@ -42,6 +42,16 @@ def test_random_problems_with_round3_features_on_host_build(hostemu_lib, orc):
     _sweep(10, 11, hostemu_lib, "new", "lvs")
 
 
+def test_random_problems_with_kinematic_builtins_on_host_build(hostemu_lib, orc):
+    """AvoidSingularity, DynamicCartPose and tolerance bands on the pose terms drawn next to the older term families"""
+    _sweep(8, 17, hostemu_lib, "kin")
+
+
+@pytest.mark.gpu
+def test_random_problems_with_kinematic_builtins_on_device(orc):
+    _sweep(12, 19, "gpu", "kin")
+
+
 @pytest.mark.gpu
 def test_random_problems_with_round3_features_on_device(orc):
     """(problems above the dense engine's size limit are drawn rarely at these sizes; the sweep counts a refusal as a failure)"""

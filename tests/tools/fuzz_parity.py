@@ -17,7 +17,7 @@ from oracle import pyorc as orc
 import parity_checks as pc
 
 
-def random_problem(rng, wide=False, links=False, lvs=False, new=False):
+def random_problem(rng, wide=False, links=False, lvs=False, new=False, kin=False):
     """wide=False: D <= 8 and T * D <= 256 (the dense fast path on the device); wide=True also draws 9-11 DOF chains,
     longer horizons (T * D up to ~400) and single-waypoint problems: the generic block-chain path"""
     if wide:
@@ -163,6 +163,31 @@ def random_problem(rng, wide=False, links=False, lvs=False, new=False):
             t = int(rng.integers(0, T))
             pci.cnt_infos.append(FuncConstraintTermInfo(g=[x[i0] + 0.5 * x[i1] - float(rng.uniform(-0.5, 0.5))], first_step=t, last_step=t,
                                                         ineq=bool(rng.random() < 0.5), name="fcnt"))
+    if kin:
+        # kinematic built-ins (dense QP engine): AvoidSingularity, DynamicCartPose, tolerance bands on the pose terms
+        from trajopt_amd.problem import AvoidSingularityTermInfo, DynamicCartPoseTermInfo
+        if rng.random() < 0.5:
+            a, b = sorted(int(v) for v in rng.integers(0, T, 2))
+            cnt = bool(rng.random() < 0.4)
+            ti = AvoidSingularityTermInfo(link=int(rng.integers(max(D - 2, 0), D)), first_step=a, last_step=b, coeffs=[float(rng.uniform(0.2, 2.0))],
+                                          lambda_=float(rng.choice([0.1, 0.05, 0.3])), is_constraint=cnt, name="sing")
+            (pci.cnt_infos if cnt else pci.cost_infos).append(ti)
+        if D >= 3 and rng.random() < 0.5:
+            qv = start + (goal - start) * rng.uniform(0.2, 0.8) + 0.1 * rng.standard_normal(D)
+            link = int(rng.integers(0, D - 1))
+            off = (np.linalg.inv(rob.fk_links(qv)[link]) @ rob.fk_tool(qv))[:3, :]
+            cnt = bool(rng.random() < 0.5)
+            ti = DynamicCartPoseTermInfo(timestep=int(rng.integers(1, T)) if T > 1 else 0, target_link=link, target_frame_offset=off,
+                                         pos_coeffs=tuple(rng.uniform(0.5, 2.0, 3)), rot_coeffs=tuple(rng.uniform(0.1, 1.0, 3) * (rng.random(3) < 0.5)),
+                                         is_constraint=cnt)
+            if rng.random() < 0.5:
+                ti.lower_tolerance = list(-rng.uniform(0.005, 0.05, 6))
+                ti.upper_tolerance = list(rng.uniform(0.005, 0.05, 6))
+            (pci.cnt_infos if cnt else pci.cost_infos).append(ti)
+        for ti in pci.cost_infos + pci.cnt_infos:
+            if isinstance(ti, CartPoseTermInfo) and rng.random() < 0.5:
+                ti.lower_tolerance = list(-rng.uniform(0.0, 0.03, 6))
+                ti.upper_tolerance = list(rng.uniform(0.0, 0.03, 6))
     if rng.random() < 0.8:
         pci.cnt_infos.append(JointPosTermInfo(coeffs=[1.0] * D, targets=list(goal), first_step=T - 1, last_step=T - 1))
     w = np.linspace(0.0, 1.0, T)[:, None]
@@ -185,18 +210,21 @@ def main():
     new = "new" in sys.argv          # round 3: capsule links, capsule / box obstacles, acceleration / jerk terms, function terms
     if new:
         sys.argv.remove("new")
+    kin = "kin" in sys.argv          # round 3: AvoidSingularity, DynamicCartPose, pose tolerance bands (built-in kinematic functions)
+    if kin:
+        sys.argv.remove("kin")
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 50
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     lib = sys.argv[3] if len(sys.argv) > 3 else os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests", "hostemu", "_build", "libtmx_hostemu.so")
     on_gpu = lib == "gpu"
-    if new and not on_gpu:
+    if (new or kin) and not on_gpu:
         os.environ.setdefault("TMX_DENSE_QP_MAX_N", "2000")   # the host build has the time; on the GPU the library's limit stays
     fails, soft, refused = 0, 0, 0
     counts = {"identical": 0, "tie": 0, "admm": 0, "csc-noise": 0, "other": 0}
     worst = {k: 0.0 for k in counts}
     for k in range(n):
         rng = np.random.default_rng([seed, k])
-        pci, x0 = random_problem(rng, wide, links, lvs, new)
+        pci, x0 = random_problem(rng, wide, links, lvs, new, kin)
         tag = f"case {seed}/{k}: D={pci.robot.n_dof} T={pci.basic_info.n_steps} costs={len(pci.cost_infos)} cnts={len(pci.cnt_infos)}"
         ctx = runtime.Context(0, None if on_gpu else lib)
         try:

@@ -595,56 +595,76 @@ TMX_DEVFN void link_jacobian6(const DevProblem* P, const double* q, int link, do
   });
 }
 // smallest singular value of the 6 x D matrix J with its left / right singular vectors u (6), v (D) - the last triplet of
-// Eigen::JacobiSVD(J, ComputeThinU | ComputeThinV) (kinematic_terms.cpp:589-593): eigen-decomposition of the smaller Gram
-// matrix (J J' for D >= 6, J' J below), the other vector from J v = s u.  u' dJ v does not depend on the common sign.
+// Eigen::JacobiSVD(J, ComputeThinU | ComputeThinV) (kinematic_terms.cpp:589-593): one-sided Jacobi rotations (Hestenes) on the
+// columns of the tall orientation, the same sequence of rotations as the oracle's thinSvd (a Gram-matrix eigen-solve would lose
+// s_max^2 / s_min digits exactly where the term matters, near a singular posture).  u' dJ v does not depend on the common sign.
 TMX_DEVFN double smallest_singular(const double* J, int D, double* u, double* v)
 {
-  double A[36], V[36];  // the smaller Gram matrix is at most 6 x 6
-  const bool wide = D >= 6;
-  const int k = wide ? 6 : D;
-  for (int i = 0; i < k; ++i)
-    for (int j = 0; j < k; ++j)
-    {
-      double acc = 0.0;
-      if (wide)
-        for (int c = 0; c < D; ++c)
-          acc += J[i * D + c] * J[j * D + c];
-      else
-        for (int r = 0; r < 6; ++r)
-          acc += J[r * D + i] * J[r * D + j];
-      A[i * k + j] = acc;
-    }
-  sym_eig_jacobi(A, V, k);
-  int im = 0;
-  for (int i = 1; i < k; ++i)
-    if (A[i * k + i] < A[im * k + im])
-      im = i;
-  const double lam = A[im * k + im];
-  const double sv = (lam > 0.0) ? sqrt(lam) : 0.0;
-  if (wide)
+  const bool flip = 6 < D;  // tall orientation: m >= n
+  const int m = flip ? D : 6, n = flip ? 6 : D;
+  double G[TMX_MAX_DOF * 6], W[36];
+  for (int i = 0; i < m; ++i)
+    for (int j = 0; j < n; ++j)
+      G[i * n + j] = flip ? J[j * D + i] : J[i * D + j];
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j)
+      W[i * n + j] = (i == j) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 80; ++sweep)
   {
-    for (int r = 0; r < 6; ++r)
-      u[r] = V[r * k + im];
-    for (int c = 0; c < D; ++c)
+    bool rotated = false;
+    for (int p = 0; p < n - 1; ++p)
+      for (int q = p + 1; q < n; ++q)
+      {
+        double alpha = 0.0, beta = 0.0, gamma = 0.0;
+        for (int i = 0; i < m; ++i)
+        {
+          alpha += G[i * n + p] * G[i * n + p];
+          beta += G[i * n + q] * G[i * n + q];
+          gamma += G[i * n + p] * G[i * n + q];
+        }
+        if (gamma == 0.0 || fabs(gamma) <= 1e-17 * sqrt(alpha * beta))
+          continue;
+        rotated = true;
+        const double zeta = (beta - alpha) / (2.0 * gamma);
+        const double t = ((zeta >= 0.0) ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+        const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
+        for (int i = 0; i < m; ++i)
+        {
+          const double gp = G[i * n + p], gq = G[i * n + q];
+          G[i * n + p] = c * gp - sn * gq;
+          G[i * n + q] = sn * gp + c * gq;
+        }
+        for (int i = 0; i < n; ++i)
+        {
+          const double wp = W[i * n + p], wq = W[i * n + q];
+          W[i * n + p] = c * wp - sn * wq;
+          W[i * n + q] = sn * wp + c * wq;
+        }
+      }
+    if (!rotated)
+      break;
+  }
+  int jm = 0;
+  double sv = 0.0;
+  for (int j = 0; j < n; ++j)
+  {
+    double nn = 0.0;
+    for (int i = 0; i < m; ++i)
+      nn += G[i * n + j] * G[i * n + j];
+    nn = sqrt(nn);
+    if (j == 0 || nn <= sv)  // (the last of equal minima: where a stable descending sort leaves it)
     {
-      double acc = 0.0;
-      for (int r = 0; r < 6; ++r)
-        acc += J[r * D + c] * u[r];
-      v[c] = (sv > 0.0) ? acc / sv : 0.0;
+      sv = nn;
+      jm = j;
     }
   }
-  else
-  {
-    for (int c = 0; c < D; ++c)
-      v[c] = V[c * k + im];
-    for (int r = 0; r < 6; ++r)
-    {
-      double acc = 0.0;
-      for (int c = 0; c < D; ++c)
-        acc += J[r * D + c] * v[c];
-      u[r] = (sv > 0.0) ? acc / sv : 0.0;
-    }
-  }
+  // J' = L S R' (flip) or J = L S R': left factor of the tall orientation = normalised column of G, right factor = column of W
+  double* lv = flip ? v : u;  // m values
+  double* rv = flip ? u : v;  // n values
+  for (int i = 0; i < m; ++i)
+    lv[i] = (sv > 0.0) ? G[i * n + jm] / sv : 0.0;
+  for (int i = 0; i < n; ++i)
+    rv[i] = W[i * n + jm];
   return sv;
 }
 // target and source frames of a pose instance at q: link * offset (or the static world frame), tool
