@@ -393,11 +393,26 @@ void lowerTerm(const ProblemConstructionInfo& pci, const TermInfo& ti, bool is_c
   else if (const auto* avs = dynamic_cast<const AvoidSingularityTermInfo*>(&ti))
   {
     // AvoidSingularityTermInfo::hatch (problem_description.cpp:1900-1940), the problem's full joint set; names name_<step>
-    if (avs->subset_kin_ != nullptr)
-      PRINT_AND_THROW(ti.name + ": AvoidSingularity over a subset of the joints is not lowered by the device path");
     const int link = movingLinkIndex(pci, avs->link);
     if (link < 0)
       PRINT_AND_THROW(ti.name + ": the link must be the child link of one of the manipulator's joints");
+    if (avs->subset_kin_ != nullptr)
+    {
+      // the subset form is used when the subset's joints are joints of the problem (isSuperset, :1907); lowered when they are the run
+      // of joints first .. link of the chain
+      const std::vector<std::string> all = pci.kin->getJointNames(), sub = avs->subset_kin_->getJointNames();
+      bool subset = !sub.empty();
+      for (const auto& n : sub)
+        subset = subset && std::find(all.begin(), all.end(), n) != all.end();
+      if (subset)
+      {
+        const auto first = std::find(all.begin(), all.end(), sub.front());
+        const int j0 = static_cast<int>(first - all.begin());
+        if (j0 + static_cast<int>(sub.size()) != link + 1 || !std::equal(sub.begin(), sub.end(), first))
+          PRINT_AND_THROW(ti.name + ": the joint subset must be a run of the manipulator's joints that ends at the link's joint");
+        t.subset_first = j0 + 1;
+      }
+    }
     if (avs->coeffs.size() != 1)
       PRINT_AND_THROW(ti.name + ": one coefficient (the error has one row)");
     t.kind = TMX_TERM_AVOID_SINGULARITY;

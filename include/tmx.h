@@ -154,7 +154,7 @@ typedef enum
      AvoidSingularityErrCalculator / AvoidSingularityJacCalculator (trajopt/src/kinematic_terms.cpp:586-635):
      err = 1 / (s_min + lambda) - 1 / (0.1 + lambda), s_min = smallest singular value of the 6 x n_dof geometric Jacobian of
      link `link` (origin of the link frame, base coordinates); gradient -(u' dJ/dq_k v) / (s_min + lambda)^2 with the Jacobian
-     differenced forward by 1e-6.  A built-in function of the function-term machinery (dense QP engine).                   */
+     differenced forward by 1e-6.  subset_first selects the subset form.  A built-in function (dense QP engine).             */
   TMX_TERM_AVOID_SINGULARITY = 24,
   /* trajopt::DynamicCartPoseTermInfo::hatch  problem_description.cpp:752-822: BOTH frames move with the joints - the source
      is the chain's tool frame, the target is link `link` times target_pose (= target_frame_offset, link_T_target).  EQ
@@ -232,7 +232,10 @@ typedef struct
   int32_t penalty_type; /* TMX_TERM_FUNC_ERR_COST: sco::PenaltyType 0 SQUARED, 1 ABS, 2 HINGE (sco_common.hpp)               */
   /* TMX_TERM_AVOID_SINGULARITY / TMX_TERM_DYN_CART_POSE: moving link k = child of joint k (0 .. n_dof - 1)                   */
   int32_t link;
-  int32_t pad3_;
+  /* TMX_TERM_AVOID_SINGULARITY: 0 = the Jacobian of the problem's whole joint group; j0 + 1 = AvoidSingularitySubset*Calculator
+     (kinematic_terms.cpp:644-680) for the subset group of joints j0 .. link (a chain that ends at the link): its Jacobian has
+     those columns only, the gradient is zero for the other joints                                                         */
+  int32_t subset_first;
   double lambda;        /* AvoidSingularityTermInfo::lambda (problem_description.hpp:643, default 0.1)                        */
 } tmx_term;
 

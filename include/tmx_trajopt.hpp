@@ -981,9 +981,12 @@ struct DynamicCartPoseTermInfo : public TermInfo
 };
 
 /** trajopt::AvoidSingularityTermInfo (problem_description.hpp:637-659; hatch problem_description.cpp:1900-1940) over the problem's
-    full joint set (no subset kinematics): one ABS cost / INEQ constraint per step in [first_step, last_step] */
+    joint set or a subset of it: one ABS cost / INEQ constraint per step in [first_step, last_step] */
 struct AvoidSingularityTermInfo : public TermInfo
 {
+  /** optional joint subset (problem_description.hpp:640): a group whose joints are a run of the manipulator's joints ending at the
+      joint of `link`; used when its joint names are a subset of the problem's (problem_description.cpp:1907) */
+  std::shared_ptr<const JointGroup> subset_kin_;
   double lambda{ 0.1 };
   std::string link;
   int first_step{ -1 };
@@ -1007,6 +1010,23 @@ struct AvoidSingularityTermInfo : public TermInfo
     t.coeffs[0] = coeffs[0];
     t.link = idx;
     t.lambda = lambda;
+    if (subset_kin_ && !subset_kin_->joint_names.empty())
+    {
+      // isSuperset(subset names, problem names) (:1907); lowered when the subset is the run of joints first .. link
+      const auto& all = kin->joint_names;
+      const auto first = std::find(all.begin(), all.end(), subset_kin_->joint_names.front());
+      bool subset = true;
+      for (const auto& n : subset_kin_->joint_names)
+        subset = subset && std::find(all.begin(), all.end(), n) != all.end();
+      if (subset)
+      {
+        const int j0 = static_cast<int>(first - all.begin());
+        if (j0 + static_cast<int>(subset_kin_->joint_names.size()) != idx + 1 ||
+            !std::equal(subset_kin_->joint_names.begin(), subset_kin_->joint_names.end(), first))
+          printAndThrow("avoid_singularity: the joint subset must be a run of the manipulator's joints that ends at the link's joint");
+        t.subset_first = j0 + 1;
+      }
+    }
     if (static_cast<bool>(term_type & TermType::TT_COST))
       t.is_constraint = 0;  // ABS cost (:1925-1929)
     else if (static_cast<bool>(term_type & TermType::TT_CNT))

@@ -383,12 +383,14 @@ int orc_fk_tool(const tmx_problem_desc* desc, const double* q, double* tf12)
   return 0;
 }
 // AvoidSingularity / DynamicCartPose calculators at one joint vector (tests): error rows and Jacobian (row-major n_rows x n_dof)
-int orc_avoid_singularity(const tmx_problem_desc* desc, const double* q, int link, double lambda, double* err, double* jac, double* sv)
+int orc_avoid_singularity(const tmx_problem_desc* desc, const double* q, int link, double lambda, int subset_first, double* err, double* jac,
+                          double* sv)
 {
   AvoidSingularityCalc c;
   c.chain = std::make_shared<Chain>(*desc);
   c.link = link;
   c.lambda = lambda;
+  c.subset_first = subset_first;
   const DblVec qv(q, q + desc->n_dof);
   err[0] = c.err(qv)[0];
   const Mat J = c.jac(qv);
@@ -396,7 +398,7 @@ int orc_avoid_singularity(const tmx_problem_desc* desc, const double* q, int lin
     jac[k] = J(0, k);
   if (sv)
   {
-    const ThinSvd svd = thinSvd(chainJacobian6(*c.chain, q, link));
+    const ThinSvd svd = thinSvd(c.jacobian(q));
     for (std::size_t i = 0; i < svd.s.size(); ++i)
       sv[i] = svd.s[i];
   }

@@ -942,12 +942,25 @@ struct AvoidSingularityCalc
 {
   std::shared_ptr<const Chain> chain;
   int link{ 0 };
+  int subset_first{ -1 };  // >= 0: AvoidSingularitySubset*Calculator (kinematic_terms.cpp:644-680) for the subset group of joints
+                           // subset_first .. link - fwd_kin_->calcJacobian of that group has those columns only
+  Mat jacobian(const double* q) const
+  {
+    const Mat J = chainJacobian6(*chain, q, link);
+    if (subset_first < 0)
+      return J;
+    Mat S(6, link - subset_first + 1);
+    for (int r = 0; r < 6; ++r)
+      for (int c = 0; c < S.cols; ++c)
+        S(r, c) = J(r, subset_first + c);
+    return S;
+  }
   double lambda{ 0.1 };
   double eps{ 1.0e-6 };  // AvoidSingularityJacCalculator::eps_ (kinematic_terms.hpp:371)
   // AvoidSingularityErrCalculator::operator()  kinematic_terms.cpp:586-603
   DblVec err(const DblVec& q) const
   {
-    const ThinSvd svd = thinSvd(chainJacobian6(*chain, q.data(), link));
+    const ThinSvd svd = thinSvd(jacobian(q.data()));
     const double smallest_sv = svd.s.back();
     const double cost = 1.0 / (smallest_sv + lambda);
     const double smallest_allowable_sv = 0.1;
@@ -958,19 +971,21 @@ struct AvoidSingularityCalc
   Mat jac(const DblVec& q) const
   {
     const int n = static_cast<int>(q.size());
-    const Mat J = chainJacobian6(*chain, q.data(), link);
+    const Mat J = jacobian(q.data());
     const ThinSvd svd = thinSvd(J);
     const int last = static_cast<int>(svd.s.size()) - 1;
     const double smallest_sv = svd.s.back();
-    Mat out(1, n);
+    Mat out(1, n);  // (subset form: the superset gradient, zero outside the subset, :662-676)
     for (int k = 0; k < n; ++k)
     {
+      if (subset_first >= 0 && (k < subset_first || k > link))
+        continue;
       DblVec joints = q;
       joints[static_cast<std::size_t>(k)] += eps;
-      const Mat Jp = chainJacobian6(*chain, joints.data(), link);
+      const Mat Jp = jacobian(joints.data());
       // (u' * dJ) * v, left to right
       double acc = 0.0;
-      for (int c = 0; c < n; ++c)
+      for (int c = 0; c < J.cols; ++c)
       {
         double uc = 0.0;
         for (int r = 0; r < 6; ++r)
@@ -1734,6 +1749,7 @@ inline TrajProblem constructProblem(const tmx_problem_desc& d, const double* ini
           calc->chain = P.chain;
           calc->link = tm.link;
           calc->lambda = tm.lambda;
+          calc->subset_first = tm.subset_first - 1;
           VectorOfVector f = [calc](const DblVec& q) { return calc->err(q); };
           MatrixOfVector dfdx = [calc](const DblVec& q) { return calc->jac(q); };
           const DblVec c{ tm.coeffs[0] };

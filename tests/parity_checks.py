@@ -14,7 +14,7 @@ from trajopt_amd import abi, configs
 TOL_TRAJ = 1e-5      # rad — north_star tolerance for joint trajectories / QP primal solutions
 
 # configuration ids of cfg() below: every id runs the stage checks on both tiers; MINI_CIDS also the whole SQP
-MINI_CIDS = [9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 36, 37, 38, 39, 40, 41, 42, 43]
+MINI_CIDS = [9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 36, 37, 38, 39, 40, 41, 42, 43, 44]
 STAGE_CIDS = [0, 1, 2, 3] + MINI_CIDS
 
 
@@ -97,6 +97,13 @@ def cfg(cid, T=None):
         n = pci.basic_info.n_steps
         ti = CartVelTermInfo(first_step=1, last_step=n - 2, max_displacement=0.07, is_constraint=(cid == 23))
         (pci.cnt_infos if cid == 23 else pci.cost_infos).append(ti)
+        return pci, s, g
+    if cid == 44:
+        # AvoidSingularity over a joint SUBSET (subset_kin_): joints 1 .. 6 of the PR2 arm on an 8-waypoint glass_upright, ABS cost
+        from trajopt_amd.problem import AvoidSingularityTermInfo
+        pci, s, g = configs.config1(8 if T is None else T)
+        n = pci.basic_info.n_steps
+        pci.cost_infos.append(AvoidSingularityTermInfo(link=6, first_step=1, last_step=n - 2, coeffs=[1.5], lambda_=0.1, subset_first=1, name="sing"))
         return pci, s, g
     if cid in (38, 39):
         # AvoidSingularityTermInfo (built-in kinematic function of the function-term machinery, dense QP engine): 38 ABS cost on the

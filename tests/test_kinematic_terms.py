@@ -39,14 +39,15 @@ def _geometric_jacobian(rob, q, link):
     return J
 
 
-def _orc_sing(orc, desc, q, link, lam):
+def _orc_sing(orc, desc, q, link, lam, subset_first=-1):
     lib = orc.lib()
     D = desc.n_dof
     err, jac, sv = (C.c_double * 1)(), (C.c_double * D)(), (C.c_double * 8)()
-    lib.orc_avoid_singularity.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double),
-                                          C.POINTER(C.c_double)]
-    assert lib.orc_avoid_singularity(C.byref(desc), (C.c_double * D)(*q), link, lam, err, jac, sv) == 0
-    return err[0], np.array(jac[:]), np.array(sv[:min(6, D)])
+    lib.orc_avoid_singularity.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_double, C.c_int, C.POINTER(C.c_double),
+                                          C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    assert lib.orc_avoid_singularity(C.byref(desc), (C.c_double * D)(*q), link, lam, subset_first, err, jac, sv) == 0
+    n = D if subset_first < 0 else link - subset_first + 1
+    return err[0], np.array(jac[:]), np.array(sv[:min(6, n)])
 
 
 @pytest.mark.parametrize("which", ["mini", "pr2", "wide"])
@@ -75,6 +76,33 @@ def test_avoid_singularity_calculators(orc, which):
                 fd[k] = (_orc_sing(orc, desc, qp, link, lam)[0] - _orc_sing(orc, desc, qm, link, lam)[0]) / (2 * h)
             if np.sort(ref_sv[:min(6, D)])[1] - smin > 1e-3:     # a simple smallest singular value
                 assert np.abs(grad - fd).max() < 2e-4 * max(1.0, np.abs(fd).max()), (link, lam, grad, fd)
+
+
+def test_avoid_singularity_subset_calculators(orc):
+    """AvoidSingularitySubset*Calculator (kinematic_terms.cpp:644-680): the singular values are those of the subset group's own Jacobian
+    (columns of joints j0 .. link; independent of the joints upstream, which move everything rigidly), the superset gradient is zero
+    outside the subset and matches central differences inside"""
+    pci, s, g = configs.config_wide()                 # 10 joints
+    desc = pci.to_desc()
+    rob, D = pci.robot, pci.robot.n_dof
+    rng = np.random.default_rng(9)
+    for j0, link in [(3, 9), (2, 8), (4, 9)]:
+        q = s + (g - s) * rng.uniform(0, 1) + 0.2 * rng.standard_normal(D)
+        err, grad, sv = _orc_sing(orc, desc, q, link, 0.1, j0)
+        ref = np.linalg.svd(_geometric_jacobian(rob, q, link)[:, j0:link + 1], compute_uv=False)
+        assert np.abs(sv - ref[:len(sv)]).max() < 1e-12
+        q2 = q.copy()
+        q2[:j0] += rng.standard_normal(j0)          # upstream joints: a rigid motion
+        q2[link + 1:] += rng.standard_normal(D - link - 1)
+        assert abs(_orc_sing(orc, desc, q2, link, 0.1, j0)[0] - err) < 1e-9
+        assert np.all(grad[:j0] == 0.0) and np.all(grad[link + 1:] == 0.0)
+        h, fd = 1e-6, np.zeros(D)
+        for k in range(j0, link + 1):
+            qp, qm = q.copy(), q.copy()
+            qp[k] += h
+            qm[k] -= h
+            fd[k] = (_orc_sing(orc, desc, qp, link, 0.1, j0)[0] - _orc_sing(orc, desc, qm, link, 0.1, j0)[0]) / (2 * h)
+        assert np.abs(grad - fd).max() < 2e-4 * max(1.0, np.abs(fd).max())
 
 
 def test_dynamic_cart_pose_calculators(orc):
@@ -132,7 +160,7 @@ def _check_terms_matter(pci, desc, orc, x0, r, o, cid):
     """the new term is not a bystander: its cost / violation is non-zero at the seeds and the run ends where the oracle's does"""
     cv0, vv0 = orc.evaluate(desc, x0[0], x0[0])
     names_c, names_v = pci.cost_names(), pci.cnt_names()
-    if cid in (38, 41, 43):
+    if cid in (38, 41, 43, 44):
         idx = [i for i, n in enumerate(names_c) if n.startswith("sing_") or n == "dynamic_cart_pose"]
         assert idx and cv0[idx].sum() > 1e-3
     if cid == 40:
@@ -144,7 +172,7 @@ def _check_terms_matter(pci, desc, orc, x0, r, o, cid):
     assert (close | ~same).mean() >= 0.75 and close.sum() >= 1
 
 
-@pytest.mark.parametrize("cid", [38, 39, 40, 41, 42, 43])
+@pytest.mark.parametrize("cid", [38, 39, 40, 41, 42, 43, 44])
 def test_kinematic_terms_kernel_sources_on_host(hostemu_lib, orc, cid):
     ctx = runtime.Context(0, hostemu_lib)
     pci, desc, x0, r, o = _run(ctx, orc, cid, 2)
@@ -153,7 +181,7 @@ def test_kinematic_terms_kernel_sources_on_host(hostemu_lib, orc, cid):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cid", [38, 39, 40, 41, 42, 43])
+@pytest.mark.parametrize("cid", [38, 39, 40, 41, 42, 43, 44])
 def test_kinematic_terms_on_device(gpu_ctx_factory, orc, cid):
     ctx = gpu_ctx_factory()
     pci, desc, x0, r, o = _run(ctx, orc, cid, 8)

@@ -85,7 +85,7 @@ class Term(C.Structure):
         ("has_coeffs", C.c_int32),
         ("penalty_type", C.c_int32),
         ("link", C.c_int32),
-        ("pad3_", C.c_int32),
+        ("subset_first", C.c_int32),
         ("lambda_", C.c_double),
     ]
 

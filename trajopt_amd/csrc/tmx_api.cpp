@@ -698,9 +698,15 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
           }
           else if (tm.kind == TMX_TERM_AVOID_SINGULARITY)
           {
+            if (tm.subset_first < 0 || tm.subset_first > tm.link + 1)
+            {
+              ctx->err = "AvoidSingularity: subset_first is 0 (all joints) or 1 + the first joint of a subset that ends at `link`";
+              return TMX_ERR_INVALID;
+            }
             op0 = tm.link;
             n_ops = -1;
             fx_consts.push_back(tm.lambda);
+            fx_consts.push_back((double)tm.subset_first);
           }
           else
           {

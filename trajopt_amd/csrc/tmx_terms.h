@@ -493,7 +493,7 @@ TMX_DEVFN void lvs_end_gradient(const DevProblem* P, const double* q, int s, con
 
 // ---- function terms (tmx_expr programs): sco::CostFromFunc / ConstraintFromErrFunc, trajopt_sco/src/modeling_utils.cpp ----------
 // fx_nops[inst] < 0: a built-in kinematic function instead of a program (fx_op0 = link, parameters behind the row weights)
-#define FX_AVOID_SINGULARITY (-1)  // consts: lambda
+#define FX_AVOID_SINGULARITY (-1)  // consts: lambda, first joint of the subset + 1 (0: all joints)
 #define FX_DYN_CART_POSE (-2)      // consts: link_T_target (12; world_T_target when fx_op0 < 0), row indices (6), tolerance flag, lower (6), upper (6)
 TMX_DEVFN void fx_builtin_eval(const DevProblem* P, int inst, const double* x, double* out);
 TMX_DEVFN void fx_eval(const DevProblem* P, int inst, const double* x, double* out)
@@ -667,6 +667,21 @@ TMX_DEVFN double smallest_singular(const double* J, int D, double* u, double* v)
     rv[i] = W[i * n + jm];
   return sv;
 }
+// the Jacobian AvoidSingularity decomposes: all n_dof columns (j0p1 == 0, the problem's joint group) or the columns of joints
+// j0 .. link, j0 = j0p1 - 1 (the subset group of AvoidSingularitySubsetErrCalculator: a rigid motion of everything upstream does not
+// change the singular values, joints downstream of the link do not move it); returns the number of columns
+TMX_DEVFN int sing_jacobian(const DevProblem* P, const double* q, int link, int j0p1, double* J)
+{
+  const int D = P->D;
+  link_jacobian6(P, q, link, J);
+  if (j0p1 == 0)
+    return D;
+  const int j0 = j0p1 - 1, nc = link - j0 + 1;
+  for (int r = 0; r < 6; ++r)  // compaction in place: (r, c) moves down to a smaller index
+    for (int c = 0; c < nc; ++c)
+      J[r * nc + c] = J[r * D + j0 + c];
+  return nc;
+}
 // target and source frames of a pose instance at q: link * offset (or the static world frame), tool
 TMX_DEVFN void dyn_pose_frames(const DevProblem* P, int inst, const double* q, Tf3& tinv, Tf3& src)
 {
@@ -699,10 +714,10 @@ TMX_DEVFN void fx_builtin_eval(const DevProblem* P, int inst, const double* x, d
   const double* par = P->fx_consts + P->fx_c0[inst];
   if (P->fx_nops[inst] == FX_AVOID_SINGULARITY)
   {
-    // AvoidSingularityErrCalculator::operator()  kinematic_terms.cpp:586-603
+    // AvoidSingularityErrCalculator::operator()  kinematic_terms.cpp:586-603 (subset form :644-653: the Jacobian of the joint subset)
     double J[6 * TMX_MAX_DOF], u[6], v[TMX_MAX_DOF];
-    link_jacobian6(P, x, P->fx_op0[inst], J);
-    const double sv = smallest_singular(J, P->D, u, v);
+    const int nc = sing_jacobian(P, x, P->fx_op0[inst], (int)par[1], J);
+    const double sv = smallest_singular(J, nc, u, v);
     const double lambda = par[0];
     out[0] = 1.0 / (sv + lambda) - 1.0 / (0.1 + lambda);
     return;
@@ -725,25 +740,32 @@ TMX_DEVFN void fx_builtin_jac(const DevProblem* P, int inst, double* x, double (
   {
     // AvoidSingularityJacCalculator::operator() / jacobianPartialDerivative  kinematic_terms.cpp:605-642 (eps_ = 1e-6,
     // kinematic_terms.hpp:371): d s_min / d q_k = u' (dJ / dq_k) v, Jacobian differenced forward
+    // Subset form (:655-680): the gradient of the subset's joints, zero for the others.
     const double eps = 1.0e-6;
     double J0[6 * TMX_MAX_DOF], J1[6 * TMX_MAX_DOF], u[6], v[TMX_MAX_DOF];
-    const int link = P->fx_op0[inst];
-    link_jacobian6(P, x, link, J0);
-    const double sv = smallest_singular(J0, D, u, v);
+    const int link = P->fx_op0[inst], j0p1 = (int)par[1];
+    const int nc = sing_jacobian(P, x, link, j0p1, J0);
+    const double sv = smallest_singular(J0, nc, u, v);
     const double lambda = par[0];
     const double scale = -1.0 / ((sv + lambda) * (sv + lambda));
+    const int k0 = j0p1 ? j0p1 - 1 : 0, k1 = j0p1 ? link : D - 1;
     for (int k = 0; k < D; ++k)
     {
+      if (k < k0 || k > k1)
+      {
+        Jo[0][k] = 0.0;
+        continue;
+      }
       const double xk = x[k];
       x[k] = xk + eps;
-      link_jacobian6(P, x, link, J1);
+      sing_jacobian(P, x, link, j0p1, J1);
       x[k] = xk;
       double acc = 0.0;
-      for (int c = 0; c < D; ++c)
+      for (int c = 0; c < nc; ++c)
       {
         double uc = 0.0;
         for (int r = 0; r < 6; ++r)
-          uc += u[r] * ((J1[r * D + c] - J0[r * D + c]) / eps);
+          uc += u[r] * ((J1[r * nc + c] - J0[r * nc + c]) / eps);
         acc += uc * v[c];
       }
       Jo[0][k] = acc * scale;

@@ -325,6 +325,7 @@ class AvoidSingularityTermInfo:
     lambda_: float = 0.1
     is_constraint: bool = False
     name: str = "avoid_singularity"
+    subset_first: Optional[int] = None     # subset_kin_: the joint subset subset_first .. link (None: the problem's joint group)
 
 
 @dataclass
@@ -581,6 +582,7 @@ class ProblemConstructionInfo:
                 t.coeffs[0] = float(ti.coeffs[0])
                 t.link = int(ti.link)
                 t.lambda_ = float(ti.lambda_)
+                t.subset_first = 0 if ti.subset_first is None else int(ti.subset_first) + 1
             elif isinstance(ti, CartVelTermInfo):
                 # FAIL_IF_FALSE checks of CartVelTermInfo::fromJson (:997-998)
                 if not (0 <= ti.first_step <= T - 1 and ti.first_step < ti.last_step and 0 < ti.last_step <= T - 1):
