@@ -221,3 +221,37 @@ def test_pose_tolerance_band(orc):
     cp.lower_tolerance, cp.upper_tolerance = [0.1] * 6, [0.0] * 6
     with pytest.raises(ValueError, match="Inverted tolerance band"):
         pci.to_desc()
+
+
+@pytest.mark.gpu
+def test_kinematic_terms_at_baseline_size(gpu_ctx_factory, orc):
+    """BASELINE config 1 (30 waypoints, 7 joints: 600 QP variables - beyond the dense engine) with an AvoidSingularity cost on every
+    interior waypoint and a toleranced DynamicCartPose constraint: row-only function terms keep the structured QP solvers (DevProblem::st
+    without qp_dense), so there is no size limit; four seeds against the oracle, 16 seeds for status and feasibility"""
+    pci, s, g = configs.config1()
+    n = pci.basic_info.n_steps
+    pci.cost_infos.append(AvoidSingularityTermInfo(link=6, first_step=1, last_step=n - 2, coeffs=[0.5], lambda_=0.1, name="sing"))
+    qv = 0.5 * (s + g)
+    off = (np.linalg.inv(pci.robot.fk_links(qv)[2]) @ pci.robot.fk_tool(qv))[:3, :]
+    pci.cnt_infos.insert(0, DynamicCartPoseTermInfo(timestep=n // 2, target_link=2, target_frame_offset=off, pos_coeffs=(1, 1, 1), rot_coeffs=(0, 0, 0),
+                                                    lower_tolerance=[-0.02] * 6, upper_tolerance=[0.02] * 6, is_constraint=True))
+    x0 = configs.seeds_for(1, pci, s, g, 16)
+    ctx = gpu_ctx_factory()
+    # four seeds QP by QP against the oracle (parity_checks.sqp_history_classes): every run either keeps the oracle's integer history
+    # (then |dx| <= 1e-5) or parts from it at a degenerate comparison (polish tie, ADMM-level integer after a rho drift) - never "other"
+    sub = pc.make_ctx_inputs(ctx, pci, x0[:4])
+    res = pc.check_first_qp_solve(ctx, orc, sub, x0[:4], require_same_iters=False)
+    assert all(same for same, _ in res)
+    classes, dx, r4 = pc.sqp_history_classes(ctx, orc, sub, x0[:4])
+    assert "other" not in classes, classes
+    assert all(d <= pc.TOL_TRAJ for c, d in zip(classes, dx) if c == "identical") and max(dx) < 5e-2, (classes, dx)
+    desc = pc.make_ctx_inputs(ctx, pci, x0)
+    ctx.upload(desc, abi.default_sqp_params(), abi.default_osqp_settings())
+    ctx.set_x0(x0)
+    ctx.run(0)
+    r = ctx.results()
+    conv = r["status"] == abi.OPT_CONVERGED
+    assert conv.mean() >= 0.75
+    cv, vv = ctx.evaluate()
+    assert vv[conv].max() <= 1e-3
+    ctx.close()

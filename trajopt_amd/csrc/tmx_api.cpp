@@ -55,7 +55,8 @@ struct tmx_ctx
   bool clock_started{ false };  // k_mark_start ran since the last tmx_batch_set_x0 (start of optimize(): sqp.max_time)
   long long pool_relaunches{ 0 };  // times tmx_sqp_wait had to restart the pool (expected: 0)
   int* h_tail{ nullptr };  // pinned, device-mapped word: 1 once the pool kernel of the pending launch has begun to retire workgroups
-  bool dense{ false };      // DevProblem::qp_dense: the piecewise driver with k_qp_solve_dense runs optimize() (host loop)
+  bool dense{ false };      // DevProblem::qp_dense: Model::optimize() by k_qp_solve_dense
+  bool piecewise{ false };  // DevProblem::st: the piecewise driver runs optimize() (host loop) - dense problems and row-only function terms
   bool ws_in_hbm{ false };  // QP workspace > 160 KB of LDS: k_*_hbm kernels, workspace carved in HBM (long horizons)
   int mode{ 2 };  // optimize() driver: 0 = one launch chain per step, 1 = k_sqp_fused, 2 = k_sqp_pool (default)
   int pool_wgs{ 0 };  // resident workgroups of the pool kernel (0 = CUs x workgroups-per-CU)
@@ -405,7 +406,8 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
   std::vector<double> fx_consts;
   int n_fx_cost = 0;
   int n_stencil = 0;      // rows of difference order 2 / 3
-  bool qp_dense = false;  // rows on 3 - 4 waypoints or function terms: dense QP engine
+  bool qp_dense = false;  // rows on 3 - 4 waypoints or function COSTS with a dynamic quadratic model: dense QP engine
+  bool st_terms = false;  // function terms (any): the ST instantiations of the term code, piecewise driver
   int band = 0;           // acceleration (2) / jerk (3) squared costs: banded objective
   std::vector<int> vel_first, vel_last, vel_cost, vel_kind, cp_t, cp_owner, cp_iscnt, cp_nrows, cp_idx, cp_slot0;
   std::vector<double> vel_coeffs, vel_targets, cp_coeff, cp_target;
@@ -684,7 +686,9 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
           // instance kind: 0 / 1 CostFromFunc (diagonal / full Hessian), 2 constraint rows, 3 squared error cost, 4 abs / hinge cost rows
           const int fk = tm.kind == TMX_TERM_FUNC_COST ? (tm.full_hessian ? 1 : 0) : (is_cnt ? 2 : (penalty_type == 0 ? 3 : 4));
           const bool quad = fk == 0 || fk == 1 || fk == 3;
-          qp_dense = true;
+          st_terms = true;
+          if (quad)
+            qp_dense = true;  // P changes with the iterate; row-only function terms leave the QP an ordinary block chain
           // the row weights (coeffs, 1 when absent) sit in front of the program's constants
           for (int i = 0; i < TMX_EXPR_MAX_OUT; ++i)
             fx_consts.push_back(weights[i]);
@@ -1095,6 +1099,7 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
   P.band = band;
   P.n_stencil = n_stencil;
   P.qp_dense = qp_dense ? 1 : 0;
+  P.st = (qp_dense || st_terms) ? 1 : 0;
   P.n_fx = (int)fx_t.size();
   P.n_fx_cost = n_fx_cost;
   // slots grouped by waypoint, ascending slot id inside a waypoint
@@ -1311,6 +1316,7 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
                                      small_ints * sizeof(int) + 64);
   ctx->smem_small = std::max<size_t>(ctx->smem_small, tmx_cvx_scratch_doubles(P.n_cp, D) * sizeof(double));
   ctx->dense = P.qp_dense != 0;
+  ctx->piecewise = P.st != 0;
   if (ctx->dense)
   {
     // The dense engine inverts n x n (every rho update) and (n + active rows)^2 (polish) matrices by Gauss-Jordan, one workgroup per
@@ -1322,9 +1328,9 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
       max_n = std::max(1, std::atoi(e));
     if (P.n_max > max_n)
     {
-      ctx->err = "acceleration / jerk / function terms: the QP of this problem has too many variables for the dense engine to solve in "
-                 "practical time (limit 448 incl. penalty variables; TMX_DENSE_QP_MAX_N overrides); a banded solver for such problems "
-                 "is not built yet";
+      ctx->err = "acceleration / jerk rows or function costs: the QP of this problem has too many variables for the dense engine to "
+                 "solve in practical time (limit 448 incl. penalty variables; TMX_DENSE_QP_MAX_N overrides); smoothing costs alone and "
+                 "function terms that are rows only (constraints, ABS / HINGE costs, AvoidSingularity, DynamicCartPose) have no such limit";
       ctx->have_problem = false;
       return TMX_ERR_UNSUPPORTED;
     }
@@ -1615,7 +1621,7 @@ tmx_status tmx_sqp_launch(tmx_ctx* ctx)
     return TMX_ERR_STATE;
   HIPCHK(hipSetDevice(ctx->device));
   const int B = ctx->hb.B;
-  if (ctx->dense)
+  if (ctx->piecewise)
   {
     // the piecewise driver is a host loop: the whole optimize() runs here, tmx_sqp_wait() only collects it
     int32_t left = 0;
@@ -1669,7 +1675,7 @@ tmx_status tmx_sqp_wait(tmx_ctx* ctx, int32_t* n_active_out)
   if (!ctx->pending)
     return TMX_ERR_STATE;
   HIPCHK(hipSetDevice(ctx->device));
-  if (ctx->pending == 2)  // qp_dense problem: tmx_sqp_launch ran the loop
+  if (ctx->pending == 2)  // piecewise problem (DevProblem::st): tmx_sqp_launch ran the loop
   {
     long long tot2[4] = { 0, 0, 0, 0 };
     const tmx_status rc2 = read_totals(ctx, tot2);
@@ -1725,7 +1731,7 @@ tmx_status tmx_sqp_run(tmx_ctx* ctx, int32_t max_steps, int32_t* n_active_out)
   if (!ctx->have_problem || ctx->Bcap == 0 || ctx->pending)
     return TMX_ERR_STATE;
   HIPCHK(hipSetDevice(ctx->device));
-  if (ctx->dense)
+  if (ctx->piecewise)
     return sqp_run_piecewise(ctx, max_steps, n_active_out);
   const int B = ctx->hb.B;
   long long tot[4] = { B, 0, 0, 0 };

@@ -68,7 +68,7 @@ TMX_KERNEL_LB(256) k_prepare(const DevProblem* P, const DevBatch* Bt)
   TMX_SYNC();
   init_static_rows(P, x0, act, Bt->coef + (size_t)b * R * D, Bt->coef2 + (size_t)b * P->n_link * D, Bt->rhs + (size_t)b * R, tid, NT);
   // (two call sites instead of a pointer select: the select crashes the register allocator of this ROCm 7.2 clang)
-  if (P->qp_dense)  // difference terms of order 2 / 3 (the ST instantiations live in the piecewise kernels only)
+  if (P->st)  // difference terms of order 2 / 3 (the ST instantiations live in the piecewise kernels only)
   {
     if (Bt->ws_hbm)
       evaluate_terms<true>(P, x, Bt->cost_vals + (size_t)b * P->n_costs, Bt->cnt_viols + (size_t)b * P->n_cnts,
@@ -104,7 +104,7 @@ TMX_KERNEL_LB(256) k_evaluate(const DevProblem* P, const DevBatch* Bt, int which
   const double* xv = (which ? Bt->xnew : Bt->x) + (size_t)b * P->NX;
   double* co = (which ? Bt->new_cost_vals : Bt->cost_vals) + (size_t)b * P->n_costs;
   double* vo = (which ? Bt->new_cnt_viols : Bt->cnt_viols) + (size_t)b * P->n_cnts;
-  if (P->qp_dense)
+  if (P->st)
     evaluate_terms<true>(P, xv, co, vo, smem, tid, NT);
   else
     evaluate_terms(P, xv, co, vo, smem, tid, NT);
@@ -131,7 +131,7 @@ TMX_KERNEL_LB(256) k_convexify(const DevProblem* P, const DevBatch* Bt, int forc
   const double* x = Bt->x + (size_t)b * P->NX;
   convexify_terms(P, x, act, coef, Bt->coef2 + (size_t)b * P->n_link * D, rhs, smem, tid, NT, Bt->rowc + (size_t)b * R, Bt->qdyn + (size_t)b * P->NX);
   QpWs cwd;
-  if (P->qp_dense)
+  if (P->st)
   {
     const size_t fo = (size_t)b * P->n_fx_cost;
     if (P->n_fx > 0)
@@ -157,7 +157,7 @@ TMX_KERNEL k_export_csc(const DevProblem* P, const DevBatch* Bt, int b, CscOut o
   const int tid = threadIdx.x, NT = blockDim.x;
   const int R = P->R, D = P->D;
   QpWs cwd;
-  if (P->qp_dense)
+  if (P->st)
     qp_structure<true>(P, Bt->active + (size_t)b * R, Bt->coef + (size_t)b * R * D, Bt->coef2 + (size_t)b * P->n_link * D,
                        Bt->rhs + (size_t)b * R, Bt->x + (size_t)b * P->NX, Bt->trust[b], Bt->merit + (size_t)b * P->n_cnts, dims_out, hashes_out,
                        &out, reinterpret_cast<int*>(smem), tid, NT, Bt->qdyn + (size_t)b * P->NX, nullptr,
@@ -362,7 +362,7 @@ TMX_KERNEL k_sqp_update(const DevProblem* P, const DevBatch* Bt)
     return;
   }
 #endif
-  if (P->qp_dense)
+  if (P->st)
     sqp_update_block<true>(P, Bt, b, smem, tid, NT);
   else
     sqp_update_block(P, Bt, b, smem, tid, NT);
@@ -688,7 +688,7 @@ TMX_KERNEL k_model_values(const DevProblem* P, const DevBatch* Bt, const double*
   else
 #endif
   {
-    if (P->qp_dense)
+    if (P->st)
       sqp_model_values<true>(P, Bt, b, xq + (size_t)b * P->n_max, smem, tid, NT);
     else
       sqp_model_values(P, Bt, b, xq + (size_t)b * P->n_max, smem, tid, NT);

@@ -92,6 +92,10 @@ struct DevProblem
   double *po2, *po3;  // NX each (zero where absent)
   int n_stencil;      // number of rows of order >= 2
   int qp_dense;
+  // the term code of stencil rows / function terms is instantiated in the piecewise kernels only (template flag ST): st = 1 runs
+  // optimize() on the piecewise driver.  qp_dense implies st; st alone (function terms that are ROWS only: constraints, ABS / HINGE
+  // error costs, the kinematic built-ins) keeps the structured QP solvers - the QP of such a problem is an ordinary block chain.
+  int st;
   // FUNCTION TERMS (sco::CostFromFunc / ConstraintFromErrFunc over tmx_expr programs, include/tmx_expr.h): one instance per (term,
   // step).  Cost instances own a DYNAMIC quadratic model (DevBatch::fx_H / fx_g / fx_c, rebuilt by every convexification), so
   // P changes with the iterate: qp_dense problems only.
