@@ -56,6 +56,7 @@ struct tmx_ctx
   long long pool_relaunches{ 0 };  // times tmx_sqp_wait had to restart the pool (expected: 0)
   int* h_tail{ nullptr };  // pinned, device-mapped word: 1 once the pool kernel of the pending launch has begun to retire workgroups
   bool dense{ false };      // DevProblem::qp_dense: Model::optimize() by k_qp_solve_dense
+  bool band{ false };       // DevProblem::band: the pool driver launches k_sqp_pool_band
   bool piecewise{ false };  // DevProblem::st: the piecewise driver runs optimize() (host loop) - dense problems and row-only function terms
   bool ws_in_hbm{ false };  // QP workspace > 160 KB of LDS: k_*_hbm kernels, workspace carved in HBM (long horizons)
   int mode{ 2 };  // optimize() driver: 0 = one launch chain per step, 1 = k_sqp_fused, 2 = k_sqp_pool (default)
@@ -1369,9 +1370,10 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
                                static_cast<int>(ctx->smem_qp)));
   }
   ctx->smem_pool = ctx->ws_in_hbm ? 64 : std::max<size_t>(ctx->smem_qp, (2 * TMX_QP_NT + 8) * sizeof(int));
+  ctx->band = P.band != 0;
   if (!ctx->ws_in_hbm)
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sqp_pool), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               static_cast<int>(ctx->smem_pool)));
+    HIPCHK(hipFuncSetAttribute(ctx->band ? reinterpret_cast<const void*>(k_sqp_pool_band) : reinterpret_cast<const void*>(k_sqp_pool),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(ctx->smem_pool)));
   if (ctx->smem_small > 64 * 1024)
   {
     // the term / structure kernels of a long-horizon problem need more than the default 64 KB of dynamic LDS
@@ -1388,7 +1390,9 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess)
       cus = prop.multiProcessorCount;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sqp_pool, TMX_QP_NT, ctx->smem_pool) != hipSuccess || per_cu < 1)
+    const hipError_t occ = ctx->band ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sqp_pool_band, TMX_QP_NT, ctx->smem_pool)
+                                     : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sqp_pool, TMX_QP_NT, ctx->smem_pool);
+    if (occ != hipSuccess || per_cu < 1)
       per_cu = 1;
     per_cu = std::min(per_cu, TMX_QP_WGS_PER_CU);
     ctx->pool_wgs = cus * per_cu;
@@ -1650,7 +1654,10 @@ tmx_status tmx_sqp_launch(tmx_ctx* ctx)
     const int G = std::min(B, ctx->pool_wgs);
     // the scheduler words follow the problem phases (bounded k_sqp_fused calls before this one do not maintain them)
     TMX_LAUNCH(k_pool_sync, 1, 256, 0, ctx->stream, ctx->db);
-    TMX_LAUNCH(k_sqp_pool, G, ctx->nt_qp, ctx->smem_pool, ctx->stream, ctx->dp, ctx->db);
+    if (ctx->band)  // (k_sqp_pool carries no code for banded objectives: qp_solve_block<.., BANDK>)
+      TMX_LAUNCH(k_sqp_pool_band, G, ctx->nt_qp, ctx->smem_pool, ctx->stream, ctx->dp, ctx->db);
+    else
+      TMX_LAUNCH(k_sqp_pool, G, ctx->nt_qp, ctx->smem_pool, ctx->stream, ctx->dp, ctx->db);
   }
   else
     TMX_LAUNCH(k_sqp_fused, B, ctx->nt_qp, ctx->smem_qp, ctx->stream, ctx->dp, ctx->db, 0);
@@ -1706,7 +1713,10 @@ tmx_status tmx_sqp_wait(tmx_ctx* ctx, int32_t* n_active_out)
   {
     const int G = std::min(ctx->hb.B, ctx->pool_wgs);
     TMX_LAUNCH(k_pool_sync, 1, 256, 0, ctx->stream, ctx->db);
-    TMX_LAUNCH(k_sqp_pool, G, ctx->nt_qp, ctx->smem_pool, ctx->stream, ctx->dp, ctx->db);
+    if (ctx->band)
+      TMX_LAUNCH(k_sqp_pool_band, G, ctx->nt_qp, ctx->smem_pool, ctx->stream, ctx->dp, ctx->db);
+    else
+      TMX_LAUNCH(k_sqp_pool, G, ctx->nt_qp, ctx->smem_pool, ctx->stream, ctx->dp, ctx->db);
     HIPCHK(hipGetLastError());
     ctx->pool_relaunches++;
     if ((rc = read_totals(ctx, tot)) != TMX_OK)

@@ -370,7 +370,7 @@ TMX_KERNEL k_sqp_update(const DevProblem* P, const DevBatch* Bt)
 
 // One trust-region evaluation of problem b: [convexify + QP structure] -> Model::optimize -> exact re-evaluation ->
 // accept / shrink / penalty decisions.  All state lives in HBM between calls.
-template <bool HBM = false>
+template <bool HBM = false, bool BANDK = true>
 TMX_DEVFN void sqp_step_block(const DevProblem* P, const DevBatch* Bt, int b, double* smem, int tid, int NT, double* chain_lds = nullptr)
 {
   const int R = P->R, D = P->D, NX = P->NX;
@@ -416,7 +416,7 @@ TMX_DEVFN void sqp_step_block(const DevProblem* P, const DevBatch* Bt, int b, do
   if (tid == 0)
     Bt->prof[(size_t)b * 16 + 11] += TMX_CLK() - tp0;
 #endif
-  qp_solve_block<HBM>(P, Bt, b, smem, tid, NT, chain_lds);
+  qp_solve_block<HBM, BANDK>(P, Bt, b, smem, tid, NT, chain_lds);
 #ifdef TMX_PROFILE
   tp0 = TMX_CLK();
 #endif
@@ -476,6 +476,8 @@ TMX_KERNEL_LB2(TMX_HBM_NT, 1) k_qp_solve_hbm(const DevProblem* P, const DevBatch
   for (int v = tid; v < P->NX; v += NT)
     xn[v] = xq[v];
 }
+// (one kernel for problems with and without a banded objective: the split that pays for k_sqp_pool - qp_solve_block<.., BANDK> -
+//  cost config 3 4.5 % here on one box, the register allocation of the pair-row instantiations moves with it)
 TMX_KERNEL_LB2(TMX_HBM_NT, 1) k_sqp_fused_hbm(const DevProblem* P, const DevBatch* Bt, int max_steps)
 {
   const int b = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
@@ -504,7 +506,8 @@ TMX_KERNEL_LB2(TMX_HBM_NT, 1) k_sqp_fused_hbm(const DevProblem* P, const DevBatc
 #define TMX_LD_RELAXED(p) __atomic_load_n((p), __ATOMIC_RELAXED)
 #define TMX_ST_RELAXED(p, v) __atomic_store_n((p), (v), __ATOMIC_RELAXED)
 #endif
-TMX_KERNEL_LB2(TMX_QP_NT, TMX_QP_WGS_PER_CU) k_sqp_pool(const DevProblem* P, const DevBatch* Bt)
+template <bool BANDK>
+TMX_DEVFN void sqp_pool_body(const DevProblem* P, const DevBatch* Bt)
 {
   TMX_SMEM(smem);
   const int tid = threadIdx.x, NT = blockDim.x;
@@ -596,7 +599,7 @@ TMX_KERNEL_LB2(TMX_QP_NT, TMX_QP_WGS_PER_CU) k_sqp_pool(const DevProblem* P, con
 #endif
       continue;
     }
-    sqp_step_block(P, Bt, b, smem, tid, NT);  // ends with a workgroup barrier after all stores
+    sqp_step_block<false, BANDK>(P, Bt, b, smem, tid, NT);  // ends with a workgroup barrier after all stores
     if (tid == 0)
     {
       const bool done = Bt->phase[b] == PHASE_DONE;
@@ -621,6 +624,9 @@ TMX_KERNEL_LB2(TMX_QP_NT, TMX_QP_WGS_PER_CU) k_sqp_pool(const DevProblem* P, con
     TMX_SYNC();  // no wave scans sched_state before thread 0 has published the release
   }
 }
+TMX_KERNEL_LB2(TMX_QP_NT, TMX_QP_WGS_PER_CU) k_sqp_pool(const DevProblem* P, const DevBatch* Bt) { sqp_pool_body<false>(P, Bt); }
+// the same kernel for problems with a banded objective (DevProblem::band: acceleration / jerk smoothing costs)
+TMX_KERNEL_LB2(TMX_QP_NT, TMX_QP_WGS_PER_CU) k_sqp_pool_band(const DevProblem* P, const DevBatch* Bt) { sqp_pool_body<true>(P, Bt); }
 
 // polish active-set flags of the last Model::optimize() of every problem, reference row order (tmx_qp_active_set)
 TMX_KERNEL k_export_active(const DevProblem* P, const DevBatch* Bt, int* out)

@@ -1165,8 +1165,12 @@ __device__ __attribute__((noinline)) static void qp_admm_generic_nl(const DevPro
 }
 #endif
 
-// HBM = true: the k_*_hbm kernels (workspace in HBM): the dense fast path (LDS-resident by construction) is compiled out
-template <bool HBM = false>
+// HBM = true: the k_*_hbm kernels (workspace in HBM): the dense fast path (LDS-resident by construction) is compiled out.
+// BANDK = false: a kernel that is never launched for banded objectives (k_sqp_pool; such problems get k_sqp_pool_band): w.band stays
+// the literal 0 of qp_ws_carve, every banded branch folds away and band_factor_nl / band_solve_nl leave the kernel's call graph - their
+// frames (callee-saved registers of the one-wave sweeps) grew the private segment of k_sqp_pool from 2.9 to 4.0 KB per lane and cost
+// BASELINE config 1 4.5 % on one box (same results), although it never executes them.
+template <bool HBM = false, bool BANDK = true>
 TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, double* smem, int tid, int NT, double* chain_lds = nullptr)
 {
   const int D = P->D, T = P->T, NX = P->NX, R = P->R;
@@ -1182,7 +1186,8 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
     if (chain_lds)  // k_*_hbm kernels only (a constant nullptr everywhere else)
       qp_ws_chain_to_lds(w, chain_lds);
   }
-  qp_ws_attach_band(w, P->band, Bt->band_ws + (size_t)b * (size_t)Bt->band_stride);
+  if constexpr (BANDK)
+    qp_ws_attach_band(w, P->band, Bt->band_ws + (size_t)b * (size_t)Bt->band_stride);
   long long pc[16] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
   long long tlast = TMX_CLK();
   const int* g_act = Bt->active + (size_t)b * R;
@@ -1666,7 +1671,7 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
         else
           qp_admm_generic_nl<HBM, true, 0>(P, Bt, b, lds_off, HBM ? smem : nullptr, chain_lds != nullptr ? 1 : 0);
       }
-      else if (P->band)
+      else if (BANDK && P->band)
       {
         if (P->D == 7)
           qp_admm_generic_nl<HBM, false, 7, true>(P, Bt, b, lds_off, HBM ? smem : nullptr, chain_lds != nullptr ? 1 : 0);
