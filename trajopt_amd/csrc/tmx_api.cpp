@@ -1318,6 +1318,7 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
   ctx->smem_small = std::max<size_t>(ctx->smem_small, tmx_cvx_scratch_doubles(P.n_cp, D) * sizeof(double));
   ctx->dense = P.qp_dense != 0;
   ctx->piecewise = P.st != 0;
+  ctx->band = P.band != 0;
   if (ctx->dense)
   {
     // The dense engine inverts n x n (every rho update) and (n + active rows)^2 (polish) matrices by Gauss-Jordan, one workgroup per
@@ -1370,7 +1371,6 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
                                static_cast<int>(ctx->smem_qp)));
   }
   ctx->smem_pool = ctx->ws_in_hbm ? 64 : std::max<size_t>(ctx->smem_qp, (2 * TMX_QP_NT + 8) * sizeof(int));
-  ctx->band = P.band != 0;
   if (!ctx->ws_in_hbm)
     HIPCHK(hipFuncSetAttribute(ctx->band ? reinterpret_cast<const void*>(k_sqp_pool_band) : reinterpret_cast<const void*>(k_sqp_pool),
                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(ctx->smem_pool)));
