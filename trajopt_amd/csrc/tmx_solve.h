@@ -1167,9 +1167,9 @@ __device__ __attribute__((noinline)) static void qp_admm_generic_nl(const DevPro
 
 // HBM = true: the k_*_hbm kernels (workspace in HBM): the dense fast path (LDS-resident by construction) is compiled out.
 // BANDK = false: a kernel that is never launched for banded objectives (k_sqp_pool; such problems get k_sqp_pool_band): w.band stays
-// the literal 0 of qp_ws_carve, every banded branch folds away and band_factor_nl / band_solve_nl leave the kernel's call graph - their
-// frames (callee-saved registers of the one-wave sweeps) grew the private segment of k_sqp_pool from 2.9 to 4.0 KB per lane and cost
-// BASELINE config 1 4.5 % on one box (same results), although it never executes them.
+// the literal 0 of qp_ws_carve, every banded branch folds away and the banded instantiations leave the kernel - with them the inlined
+// body of k_sqp_pool spilled 132 more dwords per lane (own frame 1200 -> 1728 B) and BASELINE config 1 lost 4.5 % on one box (same
+// results), although it never executes them.
 template <bool HBM = false, bool BANDK = true>
 TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, double* smem, int tid, int NT, double* chain_lds = nullptr)
 {
