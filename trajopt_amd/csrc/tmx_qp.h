@@ -946,7 +946,22 @@ TMX_HOSTDEVFN size_t qp_band_doubles(int D, int T) { return 2 * (size_t)D * T + 
 // In: the diagonal blocks K_tt in w.Sinv (kkt_factor).  Out: S_t^-1 in w.Sinv, W in w.Wb.  Sequential over t, block operations by the
 // workgroup.  Generic (any NT); not a hot path yet: it serves the smoothing-cost problems that used to need the dense engine.
 #if TMX_IS_DEVICE
-TMX_DEVFN double tmx_readlane_d(double v, int lane);
+// lane `lane`'s value of v, uniform (two v_readlane_b32); is p an LDS address (typed-pointer dispatch of the one-wave sweeps)
+TMX_DEVFN double tmx_readlane_d(double v, int lane)
+{
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+TMX_DEVFN bool tmx_in_lds(const void* p)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_is_shared(p);
+#else
+  (void)p;
+  return false;  // (host pass of hipcc: never executed)
+#endif
+}
 #endif
 // the fields of the workspace the banded routines touch, by value: on the device they are separate functions (cold code: inlined
 // into the kernels - even unexecuted - they doubled the kernels' private segment and every configuration faulted with a memory
@@ -1131,7 +1146,6 @@ __device__ __attribute__((noinline)) static void band_factor_nl(BandWs b) { band
 // components by v_readlane; no barrier per block) - the treatment of the dense-coupling chain (chain_wave_sweep).  Same products,
 // same order of additions as band_solve_impl: bit-identical.  The factors W should sit in LDS (qp_ws_attach_band) - from the HBM
 // slice every block waits for a memory round trip.
-TMX_DEVFN bool tmx_in_lds(const void* p);
 typedef __attribute__((address_space(3))) const double tmx_band_clds_d;
 typedef __attribute__((address_space(3))) double tmx_band_lds_d;
 template <int DC, class MP>
@@ -2037,12 +2051,6 @@ TMX_DEVFN void admm_phase_b(const QpWs& w, const DevProblem* P, int tid, int NT)
 // the current one is summed (they do not depend on the chain).  Products and the order of the additions are those of the
 // loop `acc = 0; for j: acc += M[j] * v[j]`: results are bit-identical to the LDS-exchange walk this replaces (which paid a
 // load + s_waitcnt per term: ~1 k cycles per block, 60 % of the iteration of configs 3 / 4).
-TMX_DEVFN double tmx_readlane_d(double v, int lane)
-{
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-  return __hiloint2double(hi, lo);
-}
 // the chain arrays live either in LDS or in the HBM workspace; typed pointers keep the loads ds_read_b64 / global_load (a
 // flat access merged to 16 bytes faults on an 8-byte aligned LDS address)
 typedef __attribute__((address_space(3))) const double tmx_clds_d;
@@ -2135,15 +2143,6 @@ TMX_DEVFN void chain_wave_sweep_d(MP mat, VP rhs, VW out, int D, int t0, int t1,
     chain_wave_sweep<10>(mat, rhs, out, D, t0, t1, dir, lane);
   else
     chain_wave_sweep<0>(mat, rhs, out, D, t0, t1, dir, lane);
-}
-TMX_DEVFN bool tmx_in_lds(const void* p)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-  return __builtin_amdgcn_is_shared(p);
-#else
-  (void)p;
-  return false;  // (host pass of hipcc: never executed)
-#endif
 }
 // (out of line: the sweep's 32 matrix registers stay out of the register allocation of the iteration loop around it - inlined, the
 //  512-thread HBM kernels of a problem WITHOUT pair rows, config 2, lost 16 %)

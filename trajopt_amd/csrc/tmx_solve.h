@@ -1132,8 +1132,10 @@ __device__ __attribute__((noinline)) static void qp_admm_generic_nl(const DevPro
   w.c2i = P->slot_c2;
 #endif
   rows_compact_attach(w);
+#if TMX_LINK_ROWS
   w.sweep_regs = PAIRS;
   w.sweep_inline = PAIRS && !HBM;
+#endif
   if (BAND)  // (banded objectives are never combined with pair rows: tmx_problem_upload)
     qp_ws_attach_band(w, P->band, Bt->band_ws + (size_t)b * (size_t)Bt->band_stride);
   QpShared* sh = reinterpret_cast<QpShared*>(w.wself);
