@@ -420,6 +420,7 @@ def sqp_history_classes(ctx, orc, desc, x0, max_qp=128, detail=None, trace=None)
         oq, ob = oracle_runs[b]
         cls = "identical"
         why = ""
+        dual_tie = False
         k = -1
         struct = lambda t: (t.n, t.m, t.nnzP, t.hashP)
         admm = lambda t: (t.osqp_status, t.osqp_iter, t.rho_updates, t.polish_status)
@@ -452,14 +453,25 @@ def sqp_history_classes(ctx, orc, desc, x0, max_qp=128, detail=None, trace=None)
                     # only if NOTHING but ties ever differs (then |dx| <= 1e-5 is required of it like of an identical history)
                     cls = "tie"
                     continue
-                # a non-degenerate active-set difference is only explained when the two ADMM runs already used different rho
+                # a non-degenerate active-set difference is only explained when the two ADMM runs already used different rho ...
                 drift = abs(r.rho_final - o.rho_final) > 1e-9 * abs(o.rho_final)   # round-off alone leaves rho equal to ~1e-13
-                cls = "admm" if drift else "other"
                 why = f"non-degenerate active-set difference, rho {r.rho_final!r} vs {o.rho_final!r}, records {admm(r)}"
+                if not drift:
+                    # ... or when the DUALS are not unique: the row of a pose error inside its tolerance band has no data at all
+                    # (zero Jacobian, zero constant), its two penalty variables sit at their bounds, and the multipliers of the row
+                    # and of those bounds can be traded against each other - two polishes return the same primal point with
+                    # different (non-vanishing) multipliers and flags.  Accepted as a tie only if NOTHING else ever differs and
+                    # the run ends on the oracle's trajectory (checked below).
+                    cls = "tie"
+                    dual_tie = True
+                    continue
+                cls = "admm"
                 break
         if cls in ("identical", "tie") and (res["status"][b] != ob["status"][0] or res["n_qp_solves"][b] != ob["n_qp_solves"][0]):
             cls = "other"
             why = f"final status / counters {res['status'][b]},{res['n_qp_solves'][b]} vs {ob['status'][0]},{ob['n_qp_solves'][0]}"
+        if cls == "tie" and dual_tie and float(np.abs(res["x"][b] - ob["x"][0]).max()) > TOL_TRAJ:
+            cls = "other"   # (why: the non-degenerate active-set difference recorded above)
         if cls == "other" and detail is not None:
             detail.append((b, k if k < min(len(dev[b]), len(oq)) else -1, len(dev[b]), len(oq), why))
         if cls != "identical" and trace is not None:
