@@ -332,7 +332,7 @@ void lowerTerm(const ProblemConstructionInfo& pci, const TermInfo& ti, bool is_c
       t.coeffs[3 + i] = cp->rot_coeffs(i);
     }
     toRowMajor34(pci.env->getLinkTransform(cp->target_frame) * cp->target_frame_offset, t.target_pose);
-    toRowMajor34(cp->source_frame_offset, out.desc.tool);  // tcp offset on the tip link
+    out.setTool(cp->source_frame_offset, ti.name);  // tcp offset on the tip link
   }
   else if (const auto* col = dynamic_cast<const CollisionTermInfo*>(&ti))
   {
@@ -388,7 +388,7 @@ void lowerTerm(const ProblemConstructionInfo& pci, const TermInfo& ti, bool is_c
     }
     t.link = target;
     toRowMajor34(dcp->target_frame_offset, t.target_pose);
-    toRowMajor34(dcp->source_frame_offset, out.desc.tool);  // tcp offset on the tip link
+    out.setTool(dcp->source_frame_offset, ti.name);  // tcp offset on the tip link
   }
   else if (const auto* avs = dynamic_cast<const AvoidSingularityTermInfo*>(&ti))
   {
@@ -449,6 +449,25 @@ void lowerTerm(const ProblemConstructionInfo& pci, const TermInfo& ti, bool is_c
   out.term_fixed_steps.push_back(fixed);
 }
 }  // namespace
+
+// The reference keeps source_frame_offset per term (CartPoseTermInfo / DynamicCartPoseTermInfo); the device keeps one tool offset
+// per problem.  Two pose terms with different offsets must not silently share the last writer's: explicit error.
+void LoweredProblem::setTool(const Eigen::Isometry3d& source_frame_offset, const std::string& term_name)
+{
+  double m[12];
+  toRowMajor34(source_frame_offset, m);
+  if (have_tool)
+  {
+    for (int q = 0; q < 12; ++q)
+      if (m[q] != desc.tool[q])
+        PRINT_AND_THROW(term_name + ": pose terms with different source_frame_offset in one problem are not lowered by the device path "
+                                    "(one tool frame per problem)");
+    return;
+  }
+  for (int q = 0; q < 12; ++q)
+    desc.tool[q] = m[q];
+  have_tool = true;
+}
 
 void LoweredProblem::finalize()
 {

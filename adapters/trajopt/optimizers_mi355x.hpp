@@ -36,6 +36,8 @@ struct LoweredProblem
   std::vector<double> link_sphere_axes, obstacle_axes;  // capsules: 3 per primitive (zero = sphere); empty when every primitive is a sphere
   std::vector<double> obstacle_boxes;                    // boxes: 12 per obstacle (half extents, rotation; zero = not a box)
   std::vector<std::string> cost_names, cnt_names;
+  bool have_tool{ false };  // a pose term has written desc.tool (the device keeps ONE tool offset per problem; the reference one per term)
+  void setTool(const Eigen::Isometry3d& source_frame_offset, const std::string& term_name);
   void finalize();  // wires the pointers of `desc`
 };
 

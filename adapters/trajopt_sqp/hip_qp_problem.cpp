@@ -71,6 +71,7 @@ void HipQPProblem::setup()
   box_size_ = Eigen::VectorXd::Constant(n_nlp_vars_, 1e-1);
   merit_coeff_ = Eigen::VectorXd::Constant(n_cnts_, 10.0);
   set_up_ = true;
+  exact_valid_ = false;
   convexify();
 }
 
@@ -82,19 +83,24 @@ void HipQPProblem::pushLoopVars() const
   check(tmx_sqp_set_loop_vars(ctx_, &box, n_cnts_ > 0 ? merit_coeff_.data() : nullptr), "pushLoopVars");
 }
 
+// TrustRegionSQPSolver calls setVariables(new_var_vals) before the exact evaluation and setVariables(best_var_vals) before
+// scaleBoxSize() -> the QP re-exported around the best point (trust_region_sqp_solver.cpp:262-371).  Only the iterate moves: the
+// stored convexification (dynamic rows included) must survive, so this is tmx_sqp_set_x, NOT tmx_batch_set_x0 (which is
+// Optimizer::initialize: every dynamic row inactive until the next convexification).
 void HipQPProblem::setVariables(const double* x)
 {
   x_ = Eigen::Map<const Eigen::VectorXd>(x, n_nlp_vars_);
+  exact_valid_ = false;
   if (!set_up_)
     return;
-  check(tmx_batch_set_x0(ctx_, x_.data(), 1), "setVariables");  // Optimizer::initialize resets the loop variables ...
-  pushLoopVars();                                                // ... which belong to the caller here
+  check(tmx_sqp_set_x(ctx_, x_.data()), "setVariables");
 }
 
 Eigen::VectorXd HipQPProblem::getVariableValues() const { return x_; }
 
 void HipQPProblem::convexify()
 {
+  model_valid_ = false;  // new convex models
   pushLoopVars();
   check(tmx_convexify(ctx_, nullptr, nullptr, nullptr), "convexify");
   exportQP();
@@ -139,14 +145,26 @@ void HipQPProblem::exportQP()
   bounds_upper_ = Eigen::Map<const Eigen::VectorXd>(u.data(), m);
 }
 
+// One kernel pass gives both vectors; TrustRegionSQPSolver asks for them one after the other at the same point
+// (evaluateConvexCosts then evaluateConvexConstraintViolations), so the pair is cached per var_vals until the model changes.
 void HipQPProblem::modelValues(const Eigen::Ref<const Eigen::VectorXd>& var_vals, Eigen::VectorXd& costs, Eigen::VectorXd& viols) const
 {
-  std::vector<double> xq(static_cast<std::size_t>(n_max_), 0.0);
-  for (Eigen::Index i = 0; i < var_vals.size() && i < n_max_; ++i)
-    xq[static_cast<std::size_t>(i)] = var_vals(i);
-  costs.resize(n_costs_);
-  viols.resize(n_cnts_);
-  check(tmx_model_values(ctx_, xq.data(), costs.data(), viols.data()), "modelValues");
+  bool cached = model_valid_ && model_at_.size() == var_vals.size();
+  for (Eigen::Index i = 0; cached && i < var_vals.size(); ++i)
+    cached = model_at_(i) == var_vals(i);
+  if (!cached)
+  {
+    std::vector<double> xq(static_cast<std::size_t>(n_max_), 0.0);
+    for (Eigen::Index i = 0; i < var_vals.size() && i < n_max_; ++i)
+      xq[static_cast<std::size_t>(i)] = var_vals(i);
+    model_costs_.resize(n_costs_);
+    model_viols_.resize(n_cnts_);
+    check(tmx_model_values(ctx_, xq.data(), model_costs_.data(), model_viols_.data()), "modelValues");
+    model_at_ = var_vals;
+    model_valid_ = true;
+  }
+  costs = model_costs_;
+  viols = model_viols_;
 }
 
 double HipQPProblem::evaluateTotalConvexCost(const Eigen::Ref<const Eigen::VectorXd>& var_vals) const { return evaluateConvexCosts(var_vals).sum(); }
@@ -165,20 +183,29 @@ Eigen::VectorXd HipQPProblem::evaluateConvexConstraintViolations(const Eigen::Re
   return v;
 }
 
+// exact costs and violations at the current variables: one kernel pass for both, cached until setVariables
+void HipQPProblem::exactValues() const
+{
+  if (exact_valid_)
+    return;
+  exact_costs_.resize(n_costs_);
+  exact_viols_.resize(n_cnts_);
+  check(tmx_evaluate(ctx_, exact_costs_.data(), exact_viols_.data()), "exactValues");
+  exact_valid_ = true;
+}
+
 double HipQPProblem::getTotalExactCost() const { return getExactCosts().sum(); }
 
 Eigen::VectorXd HipQPProblem::getExactCosts() const
 {
-  Eigen::VectorXd c(n_costs_), v(n_cnts_);
-  check(tmx_evaluate(ctx_, c.data(), v.data()), "getExactCosts");
-  return c;
+  exactValues();
+  return exact_costs_;
 }
 
 Eigen::VectorXd HipQPProblem::getExactConstraintViolations() const
 {
-  Eigen::VectorXd c(n_costs_), v(n_cnts_);
-  check(tmx_evaluate(ctx_, c.data(), v.data()), "getExactConstraintViolations");
-  return v;
+  exactValues();
+  return exact_viols_;
 }
 
 // trajopt_qp_problem.cpp:1040-1057: the box changes the variable-bound rows of the QP only (no re-convexification)
@@ -206,6 +233,7 @@ void HipQPProblem::setConstraintMeritCoeff(const Eigen::Ref<const Eigen::VectorX
   if (merit_coeff.size() != n_cnts_)
     throw std::runtime_error("HipQPProblem::setConstraintMeritCoeff: wrong size");
   merit_coeff_ = merit_coeff;
+  model_valid_ = false;
   pushLoopVars();
   exportQP();  // the slack gradients carry the merit coefficients (trajopt_qp_problem.cpp:771-799)
 }

@@ -67,6 +67,7 @@ private:
   void pushLoopVars() const;
   void exportQP();
   void modelValues(const Eigen::Ref<const Eigen::VectorXd>& var_vals, Eigen::VectorXd& costs, Eigen::VectorXd& viols) const;
+  void exactValues() const;
 
   const tmx_problem_desc* desc_;
   tmx_ctx* ctx_{ nullptr };
@@ -78,5 +79,8 @@ private:
   std::vector<std::string> cost_names_, cnt_names_;
   trajopt_ifopt::Jacobian hessian_, constraint_matrix_;
   Eigen::VectorXd gradient_, bounds_lower_, bounds_upper_;
+  // one kernel pass yields (costs, violations) together: cached per evaluation point / per iterate
+  mutable bool model_valid_{ false }, exact_valid_{ false };
+  mutable Eigen::VectorXd model_at_, model_costs_, model_viols_, exact_costs_, exact_viols_;
 };
 }  // namespace trajopt_sqp

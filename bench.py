@@ -112,6 +112,8 @@ def main():
         assert n_active == 0, f"step {k}: {n_active} problems left unfinished by a run-to-completion launch"
         r = c.results()
         best = c.argmin((rank * nsteps + k) * B)   # the only collective: RCCL all-gather of 16 bytes per rank inside the library
+        if best[0] >= 0:
+            c.best_trajectory()   # ... and its optional last step: the winning T x D trajectory broadcast from its owner rank
         return r, best, c.counters()
 
     for k in range(args.warmup):   # warm-up steps run one at a time
@@ -178,13 +180,21 @@ def main():
         # HBM bytes per launch from the rocprofv3 PMC passes of this same command (profiles/README.md); null if the
         # summary is not present
         traffic = None
+        traffic_source = None
+        mfma_ops = None
         try:
             import glob
             pat = "r*_pmc_traffic.json" if cid == 1 else "r*_pmc_traffic_cfg%d.json" % cid
-            with open(sorted(glob.glob(os.path.join(ROOT, "profiles", pat)))[-1]) as f:   # latest round
+            tfile = sorted(glob.glob(os.path.join(ROOT, "profiles", pat)))[-1]   # latest round
+            with open(tfile) as f:
                 tj = json.load(f)
             if tj.get("batch_per_gpu") == B:
                 traffic = tj.get("hbm_bytes_per_launch")
+                # the counters are NOT collected in this run (rocprofv3 --pmc needs its own passes, tools/pmc_traffic.sh): the number is
+                # read from the committed summary of the latest collection of this same command
+                traffic_source = "committed counter summary profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command " \
+                                 "on an earlier run; not measured in this run)" % os.path.basename(tfile)
+                mfma_ops = tj.get("mfma_mops_f64_per_launch")   # SQ_INSTS_VALU_MFMA_MOPS_F64 of the same collection (None: not collected)
         except (OSError, IndexError):
             pass
         flops_per_launch = f_iter * tot_admm / launches
@@ -192,7 +202,10 @@ def main():
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         roofline = {
             "kernel": "k_sqp_pool", "bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic,
+            "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
+            # "bound": "mfma" is the contract's label for the flop roof (fp64 vector peak = fp64 matrix peak on this part); how many
+            # MFMA operations the kernel really issues is this counter (per launch, same collection as `traffic`)
+            "mfma_ops": mfma_ops,
             "avg_launch_ms": avg_ms, "launches": launches, "algorithmic_flop_per_admm_iter": f_iter,
             "admm_iters_per_launch": tot_admm / launches,
             # with two batches in flight the launches overlap (the tail of one under the bulk of the next): a launch still lasts
@@ -213,7 +226,8 @@ def main():
             b_iter = 24.0 * (nnzL + r0.nnzA)
             ach = b_iter * tot_admm / launches / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
             roofline = {"kernel": kernel_name, "bound": "hbm", "achieved": ach, "peak": 8000.0,
-                        "unit": "GB/s", "frac": ach / 8000.0, "traffic": traffic, "avg_launch_ms": avg_ms, "launches": launches,
+                        "unit": "GB/s", "frac": ach / 8000.0, "traffic": traffic, "traffic_source": traffic_source,
+                        "mfma_ops": mfma_ops, "avg_launch_ms": avg_ms, "launches": launches,
                         "algorithmic_bytes_per_admm_iter": b_iter, "admm_iters_per_launch": tot_admm / launches,
                         "measured_traffic_gbps": (traffic / (avg_ms * 1e-3) / 1e9) if (traffic and avg_ms > 0) else None,
                         "flop_view": {"achieved_tflops": achieved, "frac_of_fp64_peak": achieved / FP64_PEAK_TFLOPS}}
@@ -242,23 +256,32 @@ def main():
             # fewer thread counts and one problem per thread so that the whole leg stays within ~30 s
             thread_counts = sorted({min(cores, 64), min(cores, 32), min(cores, 16), min(cores, 8)}, reverse=True) if cid == 1 else [min(cores, 32), min(cores, 16)]
             for nthr in thread_counts:
-                nsample = min(B, max(32, 2 * nthr)) if cid == 1 else min(B, nthr)
-                xs = seeds_host[:nsample]
-                tc0 = time.perf_counter()
-                o = pyorc.sqp2_batch(desc, xs, osqp=osqp_st, nthreads=nthr) if cid == 4 else pyorc.sqp_batch(desc, xs, nthreads=nthr)
-                dt = time.perf_counter() - tc0
-                nit = o["n_qp_solves"].sum() if cid == 4 else (o["n_func_evals"] - 1).sum()
-                tried.append((float(nit / dt), nthr, nsample, dt, o))
+                # configs 2 / 3 / 4: at least 64 problems per thread count and at least 2 s of wall (a 0.1 s sample of 32 problems moved
+                # by 25 % between two runs): the sample is repeated until both hold, every repetition on fresh seeds of the workload
+                nsample = min(B, max(32, 2 * nthr)) if cid == 1 else min(B, max(64, 2 * nthr))
+                nit, nqp, nadmm, dt, done = 0.0, 0.0, 0.0, 0.0, 0
+                while True:
+                    lo = done % max(1, len(seeds_host) - nsample + 1)
+                    xs = seeds_host[lo:lo + nsample]
+                    tc0 = time.perf_counter()
+                    o = pyorc.sqp2_batch(desc, xs, osqp=osqp_st, nthreads=nthr) if cid == 4 else pyorc.sqp_batch(desc, xs, nthreads=nthr)
+                    dt += time.perf_counter() - tc0
+                    nit += float(o["n_qp_solves"].sum() if cid == 4 else (o["n_func_evals"] - 1).sum())
+                    nqp += float(o["n_qp_solves"].sum())
+                    nadmm += float(o["admm_iters"]) if "admm_iters" in o else float("nan")
+                    done += nsample
+                    if cid == 1 or dt >= 2.0 or dt > 20.0:
+                        break
+                tried.append((float(nit / dt), nthr, done, dt, nqp, nadmm))
             best = max(tried, key=lambda t: t[0])
-            o = best[4]
             cpu = {"value": best[0], "unit": "SQP iters/s", "cores": best[1], "kind": "port",
-                   "sample": f"first {best[2]} seeds of the same workload, one problem per OpenMP thread on {best[1]} of "
+                   "sample": f"{best[2]} seeds of the same workload, one problem per OpenMP thread on {best[1]} of "
                              f"{cores} hardware threads, {best[3]:.1f} s wall; restated reference CPU path (oracle/), "
                              "not the upstream binary; tried " +
                              ", ".join(f"{t[1]} thr -> {t[0]:.0f} it/s" for t in tried),
                    "per_thread_value": best[0] / best[1], "host_threads": cores, "cgroup_cpu_quota_cores": quota,
-                   "qp_solves_per_s": float(o["n_qp_solves"].sum() / best[3]),
-                   "admm_iters_per_s": (float(o["admm_iters"] / best[3]) if "admm_iters" in o else None)}
+                   "qp_solves_per_s": best[4] / best[3],
+                   "admm_iters_per_s": (best[5] / best[3] if best[5] == best[5] else None)}
         line = {
             "metric": "SQP iters/s (+ QP solves/s), 7-DOF x 30-wp x 1024-batch glass_upright" if cid == 1 else
                       "SQP iters/s (+ QP solves/s), BASELINE config %d" % cid,

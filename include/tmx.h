@@ -453,6 +453,14 @@ TMX_API tmx_status tmx_model_values(tmx_ctx* ctx, const double* x_qp, double* mo
    qp_problem.h:96-110): trust box size per problem [B] and merit (penalty) coefficient per constraint [B][n_cnts].  They take
    effect at the next tmx_convexify / tmx_export_csc / tmx_qp_solve.  Either pointer may be NULL. */
 TMX_API tmx_status tmx_sqp_set_loop_vars(tmx_ctx* ctx, const double* trust_box_size, const double* merit_error_coeffs);
+/* trajopt_sqp::QPProblem::setVariables (trajopt_optimizers/trajopt_sqp/include/trajopt_sqp/qp_problem.h:44; called by
+   TrustRegionSQPSolver::stepSQPSolver, trust_region_sqp_solver.cpp:262-371, with the QP's candidate before the exact evaluation and
+   with the best point before the box is shrunk): overwrite the iterate x[B][T*D] of every problem and NOTHING else.  Unlike
+   tmx_batch_set_x0 (= Optimizer::initialize: state reset, every dynamic row inactive until the next convexification) the stored
+   convexification, the loop variables, warm-start state and records are kept: tmx_evaluate then gives the exact values at x,
+   tmx_model_values the values of the convex models built at the point of the last tmx_convexify, and tmx_export_csc the same
+   rows with the trust box centred on the new x. */
+TMX_API tmx_status tmx_sqp_set_x(tmx_ctx* ctx, const double* x_host);
 
 /* ---- piecewise entry points (the hooks BasicTrustRegionSQP exposes "to allow overriding",
  *      optimizers.hpp:137-194): evaluateCosts/evaluateConstraintViols, convexify*, Model::optimize ---- */
@@ -469,13 +477,14 @@ TMX_API tmx_status tmx_convexify(tmx_ctx* ctx, int32_t* active, double* coef, do
 TMX_API tmx_status tmx_export_csc(tmx_ctx* ctx, int32_t problem, int32_t* n, int32_t* m, int32_t* nnzP, int32_t* nnzA,
                                   int64_t* P_p, int64_t* P_i, double* P_x, double* q, int64_t* A_p, int64_t* A_i,
                                   double* A_x, double* l, double* u);
-/* one batched Model::optimize() on the current convexification + trust box (osqp_interface.cpp:440-615);
- * x_qp: B*n_max solution in reference variable order (primary vars, then aux vars); n_max from tmx_qp_dims */
 /* where the QP workspace of the uploaded problem lives: *in_hbm = 1 for the k_*_hbm kernels (workspace carved from HBM: long
  * horizons / large row counts), 0 when it is LDS-resident (k_sqp_pool); *lds_bytes = dynamic LDS of the QP kernels;
  * *hbm_bytes_per_problem = per-problem HBM scratch + HBM workspace.  Any pointer may be NULL. */
 TMX_API tmx_status tmx_workspace_info(tmx_ctx* ctx, int32_t* in_hbm, int64_t* lds_bytes, int64_t* hbm_bytes_per_problem);
+/* capacity of the QP of the uploaded problem: n_max variables / m_max rows (every row slot active) */
 TMX_API tmx_status tmx_qp_dims(tmx_ctx* ctx, int32_t* n_max, int32_t* m_max);
+/* one batched Model::optimize() on the current convexification + trust box (osqp_interface.cpp:440-615);
+ * x_qp: B*n_max solution in reference variable order (primary vars, then aux vars); n_max from tmx_qp_dims */
 TMX_API tmx_status tmx_qp_solve(tmx_ctx* ctx, double* x_qp, int32_t* cvx_status, tmx_qp_record* rec);
 
 /* ---- S1 / S5: QPs handed over in CSC form ------------------------------------------------------------------------------
@@ -529,6 +538,11 @@ TMX_API tmx_status tmx_qp_active_set(tmx_ctx* ctx, int32_t* flags /* B * m_max *
  *      ranks with RCCL — the only collective on the path.                               */
 TMX_API tmx_status tmx_argmin(tmx_ctx* ctx, int64_t global_offset, int64_t* best_index, double* best_cost);
 TMX_API tmx_status tmx_attach_nccl(tmx_ctx* ctx, void* nccl_comm /* ncclComm_t */);
+/* The winning trajectory of the LAST tmx_argmin on every rank: x_out[T*D] (row-major, the j_t_d order of
+ * trajopt::TrajOptProb::GetVars, problem_description.cpp:573-591); with a communicator one ncclBroadcast of T*D doubles from the
+ * owner rank (the rank whose shard holds the winning global index), otherwise a copy.  *owner_rank (optional) = that rank.
+ * TMX_ERR_STATE when no seed converged anywhere.  Collective: every rank of the communicator must call it.              */
+TMX_API tmx_status tmx_best_trajectory(tmx_ctx* ctx, double* x_out, int32_t* owner_rank);
 /* ... or let the library own its communicator: rank 0 calls tmx_nccl_unique_id and ships the 128 bytes to the other ranks by
  * any means (bench.py: torch.distributed broadcast); every rank then calls tmx_nccl_init (ncclCommInitRank on the context's
  * device and stream).  The communicator is destroyed with the context.                                           */

@@ -392,8 +392,40 @@ def sqp_history_classes(ctx, orc, desc, x0, max_qp=128, detail=None, trace=None)
       "other":     anything else (sizes, P structure, warm-start decision with identical structure).
     Returns (classes, dx, results)."""
     B = x0.shape[0]
-    dev = [[] for _ in range(B)]   # per problem: list of (record key without hash_active, flags, y)
+    # the oracle side of every seed (two serial runs each) first, on a thread pool: ctypes releases the GIL
+    from concurrent.futures import ThreadPoolExecutor
+    import os as _os
+
+    def _oracle(b):
+        return (orc.sqp_active_sets(desc, x0[b], ctx.m_max, max_qp=max_qp), orc.sqp_batch(desc, x0[b:b + 1], max_records=max_qp, nthreads=1))
     ctx.set_x0(x0)
+    with ThreadPoolExecutor(max_workers=min(16, _os.cpu_count() or 1)) as ex:
+        oracle_runs = list(ex.map(_oracle, range(B)))
+    n_traj = desc.n_steps * desc.n_dof
+
+    def _dataless_rows(b, rows):
+        """True if every row of `rows` of problem b's CURRENT QP belongs to an equality row WITHOUT DATA: l = u = 0 and no
+        coefficient on a trajectory variable (the row of a pose error inside its tolerance band) - either that row itself or the
+        bound row of one of its two penalty variables.  These are the only rows whose multipliers are not unique."""
+        e = ctx.export_csc(b)
+        _, A = csc_dense_ops(e)
+        n, m = e["n"], e["m"]
+        Ar, Ac = A.tocsr(), A.tocsc()
+
+        def dataless(i):
+            return e["l"][i] == 0.0 and e["u"][i] == 0.0 and Ar[i, :n_traj].nnz == 0
+
+        def ok(i):
+            if i < m - n:
+                return dataless(i)
+            col = i - (m - n)   # identity block: the bound row of variable `col`
+            if col < n_traj:
+                return False
+            owners = [g for g in Ac[:, col].nonzero()[0] if g < m - n]
+            return len(owners) == 1 and dataless(owners[0])
+        return all(ok(int(i)) for i in rows)
+
+    dev = [[] for _ in range(B)]   # per problem: list of (record, flags, y, differing rows are data-less equality rows)
     seen = np.zeros(B, np.int64)
     while True:
         na = ctx.run(1)
@@ -401,21 +433,22 @@ def sqp_history_classes(ctx, orc, desc, x0, max_qp=128, detail=None, trace=None)
         fl, yq = ctx.qp_active_set(), ctx.qp_duals()
         for b in range(B):
             if cnt[b] > seen[b] and cnt[b] <= max_qp:
-                r = recs[b * max_qp + int(cnt[b]) - 1]
-                dev[b].append((r, fl[b, :r.m].copy(), yq[b, :r.m].copy()))
+                k = int(cnt[b]) - 1
+                r = recs[b * max_qp + k]
+                f, y = fl[b, :r.m].copy(), yq[b, :r.m].copy()
+                dataless = None
+                oq = oracle_runs[b][0]
+                if k < len(oq) and len(oq[k][0]) == r.m:
+                    same, only_ties = compare_active_sets(f, y, oq[k][0], oq[k][1])
+                    if not same and not only_ties:
+                        # (the QP of this step is still the one in HBM: the next convexification has not run yet)
+                        dataless = _dataless_rows(b, np.nonzero(f != oq[k][0])[0])
+                dev[b].append((r, f, y, dataless))
                 seen[b] = cnt[b]
         if na == 0:
             break
     res = ctx.results()
     classes, dxs = [], []
-    # the oracle side of every seed (two serial runs each) on a thread pool: ctypes releases the GIL
-    from concurrent.futures import ThreadPoolExecutor
-    import os as _os
-
-    def _oracle(b):
-        return (orc.sqp_active_sets(desc, x0[b], ctx.m_max, max_qp=max_qp), orc.sqp_batch(desc, x0[b:b + 1], max_records=max_qp, nthreads=1))
-    with ThreadPoolExecutor(max_workers=min(16, _os.cpu_count() or 1)) as ex:
-        oracle_runs = list(ex.map(_oracle, range(B)))
     for b in range(B):
         oq, ob = oracle_runs[b]
         cls = "identical"
@@ -429,7 +462,7 @@ def sqp_history_classes(ctx, orc, desc, x0, max_qp=128, detail=None, trace=None)
                 cls = "other"
                 why = f"history lengths {len(dev[b])} vs {len(oq)}"
                 break
-            r, f, y = dev[b][k]
+            r, f, y, dataless = dev[b][k]
             o = ob["records"][k]
             if struct(r) != struct(o):
                 cls = "other"
@@ -456,16 +489,17 @@ def sqp_history_classes(ctx, orc, desc, x0, max_qp=128, detail=None, trace=None)
                 # a non-degenerate active-set difference is only explained when the two ADMM runs already used different rho ...
                 drift = abs(r.rho_final - o.rho_final) > 1e-9 * abs(o.rho_final)   # round-off alone leaves rho equal to ~1e-13
                 why = f"non-degenerate active-set difference, rho {r.rho_final!r} vs {o.rho_final!r}, records {admm(r)}"
-                if not drift:
+                if not drift and dataless:
                     # ... or when the DUALS are not unique: the row of a pose error inside its tolerance band has no data at all
-                    # (zero Jacobian, zero constant), its two penalty variables sit at their bounds, and the multipliers of the row
-                    # and of those bounds can be traded against each other - two polishes return the same primal point with
-                    # different (non-vanishing) multipliers and flags.  Accepted as a tie only if NOTHING else ever differs and
-                    # the run ends on the oracle's trajectory (checked below).
+                    # (zero Jacobian, zero constant, l = u = 0: the only rows this rule applies to, as in check_first_qp_solve), its
+                    # two penalty variables sit at their bounds, and the multipliers of the row and of those bounds can be traded
+                    # against each other - two polishes return the same primal point with different (non-vanishing) multipliers and
+                    # flags.  Accepted as a tie only if NOTHING else ever differs and the run ends on the oracle's trajectory
+                    # (checked below).  The same difference on a row WITH data and without rho drift is class "other".
                     cls = "tie"
                     dual_tie = True
                     continue
-                cls = "admm"
+                cls = "admm" if drift else "other"
                 break
         if cls in ("identical", "tie") and (res["status"][b] != ob["status"][0] or res["n_qp_solves"][b] != ob["n_qp_solves"][0]):
             cls = "other"

@@ -268,3 +268,65 @@ def test_outer_loop_with_hooks_on_host_build(hostemu_lib, orc, cid):
 @pytest.mark.parametrize("cid", [0, 1])
 def test_outer_loop_with_hooks_on_device(orc, cid):
     _outer_loop_with_hooks(None, orc, cid, B=4)
+
+
+# ---- QPProblem::setVariables between convexify and the model values / the re-exported QP (tmx_sqp_set_x) -------------------------
+def _set_variables_keeps_the_convexification(lib_path, orc, cid, B=2):
+    """trajopt_sqp::TrustRegionSQPSolver::stepSQPSolver (trust_region_sqp_solver.cpp:262-371) moves the iterate WITHOUT re-
+    convexifying: setVariables(new_var_vals) before the exact evaluation, setVariables(best_var_vals) before scaleBoxSize() re-exports
+    the same QP with a smaller box.  tmx_sqp_set_x must leave every dynamic row (collision hinges, pose rows) of the stored
+    convexification in place: model values and the re-exported QP are those of the fused step."""
+    import parity_checks as pc
+    pci, s, g = pc.cfg(cid)
+    x0 = configs.seeds_for(cid, pci, s, g, B)
+    ctx = runtime.Context(0, lib_path)
+    desc = pc.make_ctx_inputs(ctx, pci, x0)
+    NX = pci.basic_info.n_steps * pci.robot.n_dof
+    x_start = ctx.results()["x"].reshape(B, NX).copy()   # the iterate after Optimizer::initialize (feasibility clamp, quirk Q1)
+    ctx.convexify()
+    e0 = [ctx.export_csc(b) for b in range(B)]
+    assert any(e["m"] - e["n"] > desc.n_dof for e in e0), "the problem has no dynamic rows: the test would prove nothing"
+    xq, cvx, rec = ctx.qp_solve()
+    mc0, mv0 = ctx.model_values(xq)
+    # 1. the candidate: exact values there = the oracle's Cost::value / Constraint::violation at that point
+    cand = np.ascontiguousarray(xq[:, :NX])
+    ctx.set_x(cand)
+    c_new, v_new = ctx.evaluate()
+    for b in range(B):
+        oc, ov = orc.evaluate(desc, x0[b], cand[b])
+        assert np.abs(c_new[b] - oc).max(initial=0.0) <= 1e-9 * max(1.0, np.abs(oc).max(initial=0.0))
+        assert np.abs(v_new[b] - ov).max(initial=0.0) <= 1e-9 * max(1.0, np.abs(ov).max(initial=0.0))
+    # ... and the convex models are still the ones built at the start point: bit for bit
+    mc1, mv1 = ctx.model_values(xq)
+    assert np.array_equal(mc0, mc1) and np.array_equal(mv0, mv1)
+    # 2. back to the best point, smaller box: the same rows, only the variable bounds move
+    ctx.set_x(x_start)
+    for b in range(B):
+        e1 = ctx.export_csc(b)
+        for k in ("n", "m"):
+            assert e1[k] == e0[b][k]
+        for k in ("P_p", "P_i", "P_x", "q", "A_p", "A_i", "A_x", "l", "u"):
+            assert np.array_equal(e1[k], e0[b][k]), k
+    ctx.set_loop_vars(trust_box_size=0.5 * abi.default_sqp_params().trust_box_size)
+    for b in range(B):
+        e2 = ctx.export_csc(b)
+        mg = e2["m"] - e2["n"]
+        assert e2["m"] == e0[b]["m"] and np.array_equal(e2["A_x"], e0[b]["A_x"]) and np.array_equal(e2["A_i"], e0[b]["A_i"])
+        assert np.array_equal(e2["l"][:mg], e0[b]["l"][:mg]) and np.array_equal(e2["u"][:mg], e0[b]["u"][:mg])
+        w2, w0 = e2["u"][mg:mg + NX] - e2["l"][mg:mg + NX], e0[b]["u"][mg:mg + NX] - e0[b]["l"][mg:mg + NX]
+        assert (w2 <= w0 + 1e-15).all() and (w2 < w0).any()
+    # (what the adapter did before: Optimizer::initialize at the same point drops every dynamic row until the next convexification)
+    ctx.set_x0(x_start.reshape(x0.shape))
+    assert ctx.export_csc(0)["m"] < e0[0]["m"]
+    ctx.close()
+
+
+@pytest.mark.parametrize("cid", [1, 9])
+def test_set_variables_keeps_the_convexification_on_host_build(hostemu_lib, orc, cid):
+    _set_variables_keeps_the_convexification(hostemu_lib, orc, cid)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cid", [1, 4])
+def test_set_variables_keeps_the_convexification_on_device(orc, cid):
+    _set_variables_keeps_the_convexification(None, orc, cid, B=3)

@@ -153,6 +153,39 @@ def test_full_sqp_config3_car_seat_shape(gpu, orc):
     assert np.abs(r["x"][conv, 0, :] - s[None, :]).max() < 1e-3 and np.abs(r["x"][conv, -1, :] - g[None, :]).max() < 1e-3
 
 
+def _history_classes(gpu, orc, cid, B, sigma=None):
+    """sqp_history_classes on a BASELINE configuration: no unexplained difference; identical and tie histories end within 1e-5 rad;
+    whatever leaves the 1e-5 ball parted at an ADMM-level integer (class admm / csc-noise)"""
+    from collections import Counter
+    pci, s, g = _cfg(cid)
+    x0 = configs.seeds_for(cid, pci, s, g, B, **({} if sigma is None else {"sigma": sigma}))
+    desc = pc.make_ctx_inputs(gpu, pci, x0)
+    trace = []
+    classes, dx, res = pc.sqp_history_classes(gpu, orc, desc, x0, trace=trace)
+    cnt, cl = Counter(classes), np.array(classes)
+    for c in cnt:
+        print(f"config {cid} x {B}: {c}: {cnt[c]} seeds, worst |dx| {dx[cl == c].max():.2e}")
+    assert cnt["other"] == 0, [t for t in trace if t["cls"] == "other"]
+    for c in ("identical", "tie"):
+        if cnt[c]:
+            assert dx[cl == c].max() <= pc.TOL_TRAJ, f"{c} history but |dx| = {dx[cl == c].max()}"
+    out = set(np.nonzero(dx > pc.TOL_TRAJ)[0].tolist())
+    assert all(cl[b] in ("admm", "csc-noise") for b in out), (sorted(out), [cl[b] for b in sorted(out)])
+    return cnt, dx
+
+
+def test_config2_history_classes_16_seeds(gpu, orc):
+    """puzzle_piece (300 waypoints, workspace in HBM, partitioned chain) QP by QP against the oracle"""
+    cnt, dx = _history_classes(gpu, orc, 2, 16)
+    assert cnt["identical"] + cnt["tie"] >= 12 and (dx <= pc.TOL_TRAJ).sum() >= 14
+
+
+def test_config3_history_classes_32_seeds(gpu, orc):
+    """car_seat (10-DOF x 50 waypoints x 20 obstacles, LVS_CONTINUOUS pair rows, compact row lists) QP by QP against the oracle"""
+    cnt, dx = _history_classes(gpu, orc, 3, 32, sigma=0.05)
+    assert cnt["identical"] + cnt["tie"] >= 24 and (dx <= pc.TOL_TRAJ).sum() >= 28
+
+
 def test_full_batch_properties_config2(gpu):
     """BASELINE config 2 at its full batch (256 seeds x 300 waypoints): properties that do not need the oracle"""
     pci, curve, _ = _cfg(2)
@@ -203,8 +236,12 @@ def test_full_batch_properties(gpu):
     assert bi == 1000 + int(np.argmin(ref)) and abs(bc - ref.min()) == 0.0
     # the same reduction through the library's own RCCL communicator (one rank: the all-gather of the (cost, index) pair
     # still runs - it is the only collective on the path, tmx_nccl_init / tmx_argmin)
+    xb0, owner0 = gpu.best_trajectory()   # without a communicator: a copy of the winner
+    assert owner0 == 0 and np.array_equal(xb0, r3["x"][bi - 1000])
     gpu.nccl_init(gpu.nccl_unique_id(), 1, 0)
     assert gpu.argmin(1000) == (bi, bc)
+    xb1, owner1 = gpu.best_trajectory()   # with the one-rank communicator (no broadcast needed, same result)
+    assert owner1 == 0 and np.array_equal(xb1, xb0)
 
 
 def test_golden_fixture_first_qp(gpu, orc):

@@ -309,28 +309,53 @@ def test_finite_difference_derivatives(orc, hostemu_lib):
     assert abs(d3 - 6.0) == 0 and d1 == 0 and d2 == 0
 
 
-def test_smoothing_costs_at_baseline_size(hostemu_lib, orc):
+def _smoothing_costs_at_baseline_size(lib_path, orc, B):
     """BASELINE config 1 with acceleration + jerk SMOOTHING COSTS (the defaults of tesseract's planning profiles): banded objective
-    on the structured solver (DevProblem::band) - whole SQP against the oracle on two seeds.  With a difference ROW of order >= 2 on
-    top (here acceleration limits) the problem needs the dense engine, which refuses 572 QP variables explicitly instead of running
-    for minutes; TMX_DENSE_QP_MAX_N is the documented override."""
-    import os
+    on the structured solver (DevProblem::band) - first QP strictly, then the whole SQP against the oracle"""
     import parity_checks as pc
     from trajopt_amd import configs
     pci, s, g = configs.config1()
     pci.cost_infos.append(JointAccTermInfo(coeffs=[1.0] * 7, targets=[0.0] * 7, first_step=0, last_step=29, name="acc"))
     pci.cost_infos.append(JointJerkTermInfo(coeffs=[0.5] * 7, targets=[0.0] * 7, first_step=0, last_step=29, name="jerk"))
-    x0 = configs.seeds_for(1, pci, s, g, 2)
-    ctx = runtime.Context(0, hostemu_lib)
+    x0 = configs.seeds_for(1, pci, s, g, B)
+    ctx = runtime.Context(0, lib_path)
     desc = pc.make_ctx_inputs(ctx, pci, x0)
     pc.check_evaluate(ctx, orc, desc, x0, tol=1e-12)
     pc.check_first_qp_structure(ctx, orc, desc, x0, 0, val_tol=1e-12)
     assert all(same for same, _ in pc.check_first_qp_solve(ctx, orc, desc, x0))
     ctx.set_x0(x0)
     r, o, same, dx = pc.check_full_sqp(ctx, orc, desc, x0, exact=False)
+    return ctx, pci, r, o, same, dx
+
+
+def test_smoothing_costs_at_baseline_size(hostemu_lib, orc):
+    ctx, pci, r, o, same, dx = _smoothing_costs_at_baseline_size(hostemu_lib, orc, 2)
     assert (r["status"] == o["status"]).all() and (dx < 1e-5).all(), (r["status"], o["status"], dx)
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_smoothing_costs_at_baseline_size_on_device(orc):
+    """the same on the GPU: the only test that runs band_solve_nl (the one-wave walk of the band recurrence) and k_sqp_pool_band at
+    BASELINE size (the device tests of configs 36 / 37 are 4-DOF x 14 and 7-DOF x 12 waypoints)"""
+    B = 8
+    ctx, pci, r, o, same, dx = _smoothing_costs_at_baseline_size(None, orc, B)
+    print(f"config 1 + acc + jerk costs: same history {same.sum()}/{B}, within 1e-5: {(dx <= 1e-5).sum()}/{B}, worst {dx.max():.2e}")
+    assert (r["status"] == o["status"]).all()
+    assert (dx[same] <= 1e-5).all() and same.sum() >= B - 1
+    ctx.close()
+
+
+def test_difference_rows_need_the_dense_engine_above_its_size_limit(hostemu_lib):
+    """With a difference ROW of order >= 2 on top of config 1 (here acceleration limits) the problem needs the dense engine, which
+    refuses 572 QP variables explicitly instead of running for minutes; TMX_DENSE_QP_MAX_N is the
+    documented override."""
+    import os
+    from trajopt_amd import configs
+    pci, s, g = configs.config1()
     pci.cnt_infos.append(JointAccTermInfo(coeffs=[1.0] * 7, targets=[0.0] * 7, first_step=0, last_step=29, upper_tols=[0.3] * 7, lower_tols=[-0.3] * 7,
                                           is_constraint=True, name="acc_limits"))
+    ctx = runtime.Context(0, hostemu_lib)
     with pytest.raises(runtime.TmxError, match="dense engine"):
         ctx.upload(pci.to_desc(), abi.default_sqp_params(), abi.default_osqp_settings())
     os.environ["TMX_DENSE_QP_MAX_N"] = "4096"

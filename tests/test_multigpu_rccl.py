@@ -32,7 +32,9 @@ def _worker(rank, world, port, total, q):
     ctx.run(0)
     r = ctx.results()
     bi, bc = ctx.argmin(lo)
-    q.put((rank, bc, bi, np.where(r["status"] == abi.OPT_CONVERGED, r["total_cost"], np.inf).tolist(), lo))
+    xb, owner = ctx.best_trajectory()   # ncclBroadcast of the winning T x D doubles from the owner rank
+    mine = r["x"][bi - lo].tolist() if lo <= bi < hi else None
+    q.put((rank, bc, bi, np.where(r["status"] == abi.OPT_CONVERGED, r["total_cost"], np.inf).tolist(), lo, xb.tolist(), owner, mine))
     dist.barrier()
     ctx.close()
     dist.destroy_process_group()
@@ -54,7 +56,10 @@ def test_two_rank_best_seed_over_library_communicator():
         p.join(timeout=120)
         assert p.exitcode == 0
     costs = np.full(total, np.inf)
-    for rank, bc, bi, local, lo in res:
+    for rank, bc, bi, local, lo, xb, owner, mine in res:
         costs[lo:lo + len(local)] = local
-    for rank, bc, bi, local, lo in res:
+    owner_x = [mine for (*_, mine) in res if mine is not None]
+    for rank, bc, bi, local, lo, xb, owner, mine in res:
         assert bi == int(np.argmin(costs)) and bc == costs.min()
+        assert owner == (0 if bi < total // 2 else 1)
+        assert len(owner_x) == 1 and xb == owner_x[0]   # every rank holds the owner's trajectory, bit for bit

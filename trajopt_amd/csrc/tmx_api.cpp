@@ -65,6 +65,12 @@ struct tmx_ctx
   bool nccl_owned{ false };
   double* d_pair{ nullptr };   // K7: [2] local (cost, index) + [2 * n_ranks] gathered pairs
   int pair_cap{ 0 };
+  // result of the last tmx_argmin: owner rank of the winning pair (-1: no converged seed anywhere), its LOCAL problem index on the
+  // owner (global index - the owner's global_offset; valid on the owner only), the rank count it was reduced over
+  int best_owner{ -1 }, best_nranks{ 1 };
+  long long best_local{ -1 }, best_global{ -1 };
+  double* d_best{ nullptr };   // T * D doubles: the broadcast buffer of tmx_best_trajectory
+  size_t best_cap{ 0 };
   int max_rec{ 128 };
 };
 
@@ -223,6 +229,8 @@ void tmx_destroy(tmx_ctx* ctx)
     (void)hipFree(ctx->d_totals);
   if (ctx->d_pair)
     (void)hipFree(ctx->d_pair);
+  if (ctx->d_best)
+    (void)hipFree(ctx->d_best);
 #ifdef TMX_HOST_EMU
   delete ctx->h_tail;
 #else
@@ -1488,10 +1496,11 @@ static tmx_status ensure_batch(tmx_ctx* ctx, int B)
   if (P.qp_dense)
   {
     // dense engine: the QP in CSC form + dense workspace per problem (tmx_generic.h).  Capacity of A: every row slot with all the
-    // entries its kind can have, two entries per aux column, one identity entry per variable.
+    // entries its kind can have (a row on two waypoints: 2 D; a difference row of order 2 / 3 on one joint: 3 / 4 entries, which
+    // exceeds 2 D on a one-joint chain), two entries per aux column, one identity entry per variable.
     size_t cap = (size_t)P.n_max + 2 * (size_t)P.NA;
     for (int r = 0; r < P.R; ++r)
-      cap += (size_t)2 * P.D;
+      cap += (size_t)std::max(2 * P.D, 4);
     if (P.n_max > 4096 || P.m_max > 16384)
     {
       ctx->err = "joint acceleration / jerk terms: the QP is too large for the dense engine (n <= 4096, m <= 16384)";
@@ -1912,23 +1921,42 @@ tmx_status tmx_model_values(tmx_ctx* ctx, const double* x_qp, double* model_cost
   TMX_REFUSE_WHILE_PENDING(ctx);
   HIPCHK(hipSetDevice(ctx->device));
   const size_t B = ctx->hb.B;
-  std::vector<void*> pool;
+  // the three staging buffers are released on EVERY exit path (HIPCHK returns early on a device error)
+  struct PoolGuard
+  {
+    std::vector<void*> pool;
+    ~PoolGuard() { free_pool(pool); }
+  } guard;
   double *d_x = nullptr, *d_c = nullptr, *d_v = nullptr;
   tmx_status rc;
-  if ((rc = dalloc(ctx, pool, &d_x, B * ctx->hp.n_max, false)) != TMX_OK || (rc = dalloc(ctx, pool, &d_c, B * ctx->hp.n_costs)) != TMX_OK ||
-      (rc = dalloc(ctx, pool, &d_v, B * ctx->hp.n_cnts)) != TMX_OK)
-  {
-    free_pool(pool);
+  if ((rc = dalloc(ctx, guard.pool, &d_x, B * ctx->hp.n_max, false)) != TMX_OK || (rc = dalloc(ctx, guard.pool, &d_c, B * ctx->hp.n_costs)) != TMX_OK ||
+      (rc = dalloc(ctx, guard.pool, &d_v, B * ctx->hp.n_cnts)) != TMX_OK)
     return rc;
-  }
   HIPCHK(hipMemcpyAsync(d_x, x_qp, sizeof(double) * B * ctx->hp.n_max, hipMemcpyHostToDevice, ctx->stream));
   TMX_LAUNCH(k_model_values, ctx->hb.B, ctx->nt_small, ctx->smem_small, ctx->stream, ctx->dp, ctx->db, d_x, d_c, d_v);
   HIPCHK(hipGetLastError());
   if ((rc = d2h(ctx, model_cost_vals, d_c, B * ctx->hp.n_costs)) == TMX_OK)
     rc = d2h(ctx, model_cnt_viols, d_v, B * ctx->hp.n_cnts);
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  free_pool(pool);
   return rc;
+}
+
+// The iterate alone: x of every problem is overwritten, NOTHING else changes - the convexification (active rows, coefficients,
+// right-hand sides), the loop variables, the warm-start state and the records stay as they are (tmx_batch_set_x0 is
+// Optimizer::initialize: it resets all of them).  trajopt_sqp::QPProblem::setVariables (qp_problem.h:44) is this operation:
+// TrustRegionSQPSolver calls it with the QP's candidate before the exact evaluation and with the best point before it shrinks the
+// box and re-exports the SAME convexification around it (trust_region_sqp_solver.cpp:262-371).
+tmx_status tmx_sqp_set_x(tmx_ctx* ctx, const double* x_host)
+{
+  if (!ctx || !x_host)
+    return TMX_ERR_INVALID;
+  if (ctx->Bcap == 0)
+    return TMX_ERR_STATE;
+  TMX_REFUSE_WHILE_PENDING(ctx);
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipMemcpyAsync(ctx->hb.x, x_host, sizeof(double) * (size_t)ctx->hb.B * ctx->hp.NX, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return TMX_OK;
 }
 
 tmx_status tmx_sqp_set_loop_vars(tmx_ctx* ctx, const double* trust_box_size, const double* merit_error_coeffs)
@@ -2068,7 +2096,7 @@ tmx_status tmx_export_csc(tmx_ctx* ctx, int32_t problem, int32_t* n, int32_t* m,
   HIPCHK(hipSetDevice(ctx->device));
   const DevProblem& P = ctx->hp;
   // device scratch sized for the worst case
-  const size_t nmax = P.n_max, mmax = P.m_max, nzA = (size_t)P.R * (2 * P.D + 2) + 2 * nmax, nzP = (size_t)P.nnzP + 1 + (size_t)P.n_fx_cost * P.D * (P.D + 1) / 2;
+  const size_t nmax = P.n_max, mmax = P.m_max, nzA = (size_t)P.R * (std::max(2 * P.D, 4) + 2) + 2 * nmax, nzP = (size_t)P.nnzP + 1 + (size_t)P.n_fx_cost * P.D * (P.D + 1) / 2;
   std::vector<void*> pool;
   CscOut o{};
   int* d_dims = nullptr;
@@ -2439,14 +2467,76 @@ tmx_status tmx_argmin(tmx_ctx* ctx, int64_t global_offset, int64_t* best_index, 
   HIPCHK(hipStreamSynchronize(ctx->stream));
   double bc = 1e300;
   long long bi = -1;
+  int owner = -1;
   for (int r = 0; r < nranks; ++r)
     if (all[2 * r + 1] >= 0 && (all[2 * r] < bc || (all[2 * r] == bc && (bi < 0 || (long long)all[2 * r + 1] < bi))))
     {
       bc = all[2 * r];
       bi = static_cast<long long>(all[2 * r + 1]);
+      owner = r;
     }
   *best_index = bi;
   *best_cost = bc;
+  ctx->best_owner = owner;
+  ctx->best_nranks = nranks;
+  ctx->best_global = bi;
+  ctx->best_local = bi >= 0 ? bi - (long long)global_offset : -1;  // meaningful on the owner rank only
+  return TMX_OK;
+}
+
+// The optional last step of SURVEY.md section 8(e): the winning trajectory (T x D doubles, 1.7 KB for config 1) goes from its owner
+// rank to every rank - one ncclBroadcast on the library's communicator, latency-bound; without a communicator (one rank) a copy.
+tmx_status tmx_best_trajectory(tmx_ctx* ctx, double* x_out, int32_t* owner_rank)
+{
+  if (!ctx || !x_out)
+    return TMX_ERR_INVALID;
+  if (ctx->Bcap == 0)
+    return TMX_ERR_STATE;
+  TMX_REFUSE_WHILE_PENDING(ctx);
+  if (owner_rank)
+    *owner_rank = ctx->best_owner;
+  if (ctx->best_owner < 0)
+  {
+    ctx->err = "tmx_best_trajectory: the last tmx_argmin found no converged seed on any rank (or tmx_argmin was not called)";
+    return TMX_ERR_STATE;
+  }
+  HIPCHK(hipSetDevice(ctx->device));
+  const size_t NX = (size_t)ctx->hp.NX;
+  if (ctx->best_cap < NX)
+  {
+    if (ctx->d_best)
+      (void)hipFree(ctx->d_best);
+    ctx->d_best = nullptr;
+    void* p = nullptr;
+    HIPCHK(hipMalloc(&p, sizeof(double) * NX));
+    ctx->d_best = static_cast<double*>(p);
+    ctx->best_cap = NX;
+  }
+  int my_rank = 0;
+#ifndef TMX_HOST_EMU
+  ncclComm_t comm = static_cast<ncclComm_t>(ctx->nccl);
+  if (comm && ncclCommUserRank(comm, &my_rank) != ncclSuccess)
+    return TMX_ERR_NCCL;
+#endif
+  if (my_rank == ctx->best_owner)
+  {
+    if (ctx->best_local < 0 || ctx->best_local >= (long long)ctx->hb.B)
+    {
+      ctx->err = "tmx_best_trajectory: the winning index is not in this rank's shard (global_offset of tmx_argmin inconsistent across ranks)";
+      return TMX_ERR_STATE;
+    }
+    HIPCHK(hipMemcpyAsync(ctx->d_best, ctx->hb.x + (size_t)ctx->best_local * NX, sizeof(double) * NX, hipMemcpyDeviceToDevice, ctx->stream));
+  }
+#ifndef TMX_HOST_EMU
+  if (comm && ctx->best_nranks > 1 &&
+      ncclBroadcast(ctx->d_best, ctx->d_best, NX, ncclDouble, ctx->best_owner, comm, ctx->stream) != ncclSuccess)
+  {
+    ctx->err = "ncclBroadcast failed";
+    return TMX_ERR_NCCL;
+  }
+#endif
+  HIPCHK(hipMemcpyAsync(x_out, ctx->d_best, sizeof(double) * NX, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
   return TMX_OK;
 }
 

@@ -26,7 +26,7 @@ def best_seed_allgather(cost: float, index: int, device=None):
     import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return cost, index, 0
+        return cost, index, (0 if index >= 0 else -1)
     t = torch.tensor([cost, float(index)], dtype=torch.float64, device=device)
     out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
     dist.all_gather(out, t)
@@ -37,3 +37,20 @@ def best_seed_allgather(cost: float, index: int, device=None):
     c = np.where(valid, pairs[:, 0], np.inf)
     r = int(np.argmin(c))
     return float(pairs[r, 0]), int(pairs[r, 1]), r
+
+
+def best_trajectory_broadcast(x_local, owner: int, n_values: int, device=None):
+    """the optional last step of SURVEY.md section 8(e): the winning trajectory goes from its owner rank to every rank (one
+    broadcast of T*D doubles).  `x_local`: the trajectory on the owner (ignored elsewhere); owner < 0 (no converged seed on any
+    rank) returns None everywhere."""
+    import torch
+    import torch.distributed as dist
+    if owner < 0:
+        return None
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return np.asarray(x_local, np.float64).reshape(-1).copy()
+    t = torch.zeros(n_values, dtype=torch.float64, device=device)
+    if dist.get_rank() == owner:
+        t.copy_(torch.from_numpy(np.ascontiguousarray(x_local, np.float64).reshape(-1)))
+    dist.broadcast(t, src=owner)
+    return t.cpu().numpy()

@@ -276,7 +276,7 @@ class CartPoseTermInfo:
     is_constraint: bool = True           # TT_CNT -> EQ constraint ; TT_COST -> ABS cost
     name: str = "cart_pose"
     # CartPoseTermInfo::lower_tolerance / upper_tolerance (problem_description.hpp:370-373): six values each; the error inside the
-    # band [lower, upper] counts as zero (toleranced terms run on the dense QP engine)
+    # band [lower, upper] counts as zero (toleranced terms are row-only function terms: structured QP solvers, no size limit)
     lower_tolerance: Sequence[float] = ()
     upper_tolerance: Sequence[float] = ()
 

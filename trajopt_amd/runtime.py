@@ -24,6 +24,8 @@ _SIGS = {
     "tmx_problem_upload": ([C.c_void_p, C.POINTER(abi.ProblemDesc), C.POINTER(abi.SqpParams), C.POINTER(abi.OsqpSettings)], C.c_int),
     "tmx_batch_set_x0": ([C.c_void_p, C.c_void_p, C.c_int32], C.c_int),
     "tmx_batch_set_x0_device": ([C.c_void_p, C.c_void_p, C.c_int32], C.c_int),
+    "tmx_sqp_set_x": ([C.c_void_p, C.c_void_p], C.c_int),
+    "tmx_best_trajectory": ([C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)], C.c_int),
     "tmx_sqp_run": ([C.c_void_p, C.c_int32, C.POINTER(C.c_int32)], C.c_int),
     "tmx_sqp_launch": ([C.c_void_p], C.c_int),
     "tmx_sqp_wait": ([C.c_void_p, C.POINTER(C.c_int32)], C.c_int),
@@ -124,6 +126,12 @@ class Context:
         self.B = x0.shape[0]
         assert x0.size == self.B * self.T * self.D
         self._chk(self.lib.tmx_batch_set_x0(self.h, _ptr(x0), self.B))
+
+    def set_x(self, x):
+        """QPProblem::setVariables: overwrite the iterate of every problem, keep the convexification and all loop state"""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        assert x.size == self.B * self.T * self.D
+        self._chk(self.lib.tmx_sqp_set_x(self.h, _ptr(x)))
 
     def set_x0_device(self, dev_ptr: int, batch: int):
         self.B = batch
@@ -305,6 +313,13 @@ class Context:
         bi, bc = C.c_int64(), C.c_double()
         self._chk(self.lib.tmx_argmin(self.h, global_offset, C.byref(bi), C.byref(bc)))
         return bi.value, bc.value
+
+    def best_trajectory(self):
+        """the winning trajectory of the last argmin() on every rank (one broadcast from the owner rank): (x[T][D], owner rank)"""
+        x = np.zeros((self.T, self.D))
+        owner = C.c_int32(-1)
+        self._chk(self.lib.tmx_best_trajectory(self.h, _ptr(x), C.byref(owner)))
+        return x, owner.value
 
     def nccl_unique_id(self) -> bytes:
         buf = (C.c_uint8 * 128)()
