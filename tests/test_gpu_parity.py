@@ -120,8 +120,8 @@ def test_config1_history_classes_64_seeds(gpu, orc, orc_fma):
     fragile = set(np.nonzero(dself > pc.TOL_TRAJ)[0].tolist())
     print(f"outside 1e-5 rad: device vs oracle {sorted(out)}, oracle vs oracle-with-FMA {sorted(fragile)}")
     assert len(out) <= max(len(fragile), 2), (sorted(out), sorted(fragile))
-    assert (dx <= pc.TOL_TRAJ).sum() >= 60     # measured: 62
-    assert cnt["identical"] + cnt["tie"] >= 48  # measured: 47 + 8
+    assert (dx <= pc.TOL_TRAJ).sum() >= 60     # measured: 61 (round 4; round 3: 62)
+    assert cnt["identical"] + cnt["tie"] >= 52  # measured: 50 + 8 (round 4, diagonal blocks assembled on the matrix cores; round 3: 47 + 8)
 
 
 def test_full_sqp_config2_long_horizon(gpu, orc):
@@ -177,13 +177,13 @@ def _history_classes(gpu, orc, cid, B, sigma=None):
 def test_config2_history_classes_16_seeds(gpu, orc):
     """puzzle_piece (300 waypoints, workspace in HBM, partitioned chain) QP by QP against the oracle"""
     cnt, dx = _history_classes(gpu, orc, 2, 16)
-    assert cnt["identical"] + cnt["tie"] >= 12 and (dx <= pc.TOL_TRAJ).sum() >= 14
+    assert cnt["identical"] + cnt["tie"] >= 15 and (dx <= pc.TOL_TRAJ).sum() >= 15   # measured: 16 identical, worst 7.0e-10
 
 
 def test_config3_history_classes_32_seeds(gpu, orc):
     """car_seat (10-DOF x 50 waypoints x 20 obstacles, LVS_CONTINUOUS pair rows, compact row lists) QP by QP against the oracle"""
     cnt, dx = _history_classes(gpu, orc, 3, 32, sigma=0.05)
-    assert cnt["identical"] + cnt["tie"] >= 24 and (dx <= pc.TOL_TRAJ).sum() >= 28
+    assert cnt["identical"] + cnt["tie"] >= 31 and (dx <= pc.TOL_TRAJ).sum() >= 31   # measured: 32 identical, worst 1.6e-15
 
 
 def test_full_batch_properties_config2(gpu):

@@ -745,6 +745,49 @@ TMX_DEVFN void kkt_factor(const QpWs& w, const DevProblem* P, int mode, double s
     w.hr[r] = we;
   }
   TMX_SYNC();
+#if TMX_IS_DEVICE
+  // The D x D diagonal blocks  A_t = sum_r w_r coef_r coef_r'  over the rows of waypoint t are products (D x n_t)(n_t x D): on the
+  // f64 matrix cores, one waypoint per wave and four rows per v_mfma_f64_16x16x4_f64 (A operand: lane l = w_r coef_r[l & 15] of
+  // row r = list entry q + (l >> 4); B operand: coef_r[l & 15] of the same row; the rows enter in list order, as in the scalar
+  // loop below, which problems with rows on two waypoints and the host build keep).  D layout: lane l, register q = entry
+  // ((l >> 4) + 4 q, l & 15).
+  const bool mfma_blocks = D <= 16 && (NT & 63) == 0 && !TMX_HAS_PAIRS(w);
+  if (mfma_blocks)
+  {
+    typedef double tmx_kf_v4d __attribute__((ext_vector_type(4)));
+    const int lane = tid & 63, wv = tid >> 6, nw = NT >> 6, li = lane & 15, lk = lane >> 4;
+    for (int t = wv; t < T; t += nw)
+    {
+      const int q0 = w.wl_start[t], q1 = w.wl_start[t + 1];
+      tmx_kf_v4d acc = { 0.0, 0.0, 0.0, 0.0 };
+      for (int q = q0; q < q1; q += 4)
+      {
+        const bool ok = q + lk < q1;
+        const int r = w.wl_list[ok ? q + lk : q0];
+        const bool on = ok && w.act[r] != 0 && li < D;
+        const double cf = on ? w.coef[r * D + li] : 0.0;
+        const double wc = on ? w.hr[r] * cf : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wc, cf, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int qr = 0; qr < 4; ++qr)
+      {
+        const int i = lk + 4 * qr, j = li;
+        if (i < D && j < D)
+        {
+          double sblk = acc[qr];
+          if (i == j)
+          {
+            const int v = t * D + i;
+            sblk += w.pd[v] + sig + w_bp(w, v, mode, delta) * w.bbp[v] * w.bbp[v];
+          }
+          w.Sinv[t * DDS + i * DS + j] = sblk;
+        }
+      }
+    }
+  }
+  else
+#endif
   // diagonal blocks A_t (rows padded to DS doubles)
   for (int e = tid; e < T * DD; e += NT)
   {
