@@ -60,3 +60,14 @@ def gpu_ctx_factory():
     def make():
         return runtime.Context(0)
     return make
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _torch_sees_the_device_first(request):
+    """PyTorch-ROCm brings its own HIP runtime; when the product library (system ROCm) initialises the device first, torch in the same
+    process no longer finds it (torch.cuda.is_available() -> False: seen when a -m gpu selection started with a test that builds its
+    runtime.Context directly).  Any session that contains a gpu-marked test therefore lets torch look first."""
+    if any(item.get_closest_marker("gpu") is not None for item in request.session.items):
+        import torch
+        torch.cuda.is_available()
+    yield

@@ -346,19 +346,73 @@ def test_smoothing_costs_at_baseline_size_on_device(orc):
     ctx.close()
 
 
-def test_difference_rows_need_the_dense_engine_above_its_size_limit(hostemu_lib):
-    """With a difference ROW of order >= 2 on top of config 1 (here acceleration limits) the problem needs the dense engine, which
-    refuses 572 QP variables explicitly instead of running for minutes; TMX_DENSE_QP_MAX_N is the
-    documented override."""
-    import os
+def _difference_rows_at_baseline_size(lib_path, orc, B):
+    """BASELINE config 1 with acceleration LIMITS (JointAccIneqConstraint, trajectory_costs.cpp:690-754) and a jerk HINGE cost
+    (JointJerkIneqCost, :811-878) on top: 572 + 392 + 378 QP variables.  Round 3 refused this problem (dense engine, 448-variable cap);
+    the rows now run on the banded structured path (DevProblem::band_rows): every block a single-joint difference row adds to the
+    reduced KKT matrix is diagonal.  First QP strictly (CSC integers bit-exact, iteration count / rho updates / polish / active set
+    row by row), then whole SQP runs QP by QP against the oracle (parity_checks.sqp_history_classes)."""
+    from collections import Counter
+    import parity_checks as pc
     from trajopt_amd import configs
     pci, s, g = configs.config1()
+    pci.cnt_infos.append(JointAccTermInfo(coeffs=[1.0] * 7, targets=[0.0] * 7, first_step=0, last_step=29, upper_tols=[0.05] * 7, lower_tols=[-0.05] * 7,
+                                          is_constraint=True, name="acc_limits"))
+    pci.cost_infos.append(JointJerkTermInfo(coeffs=[2.0] * 7, targets=[0.0] * 7, first_step=0, last_step=29, upper_tols=[0.02] * 7, lower_tols=[-0.02] * 7,
+                                            name="jerk_hinge"))
+    x0 = configs.seeds_for(1, pci, s, g, B)
+    ctx = runtime.Context(0, lib_path)
+    desc = pc.make_ctx_inputs(ctx, pci, x0)
+    assert ctx.n_max > 448   # beyond the dense engine's size limit
+    pc.check_evaluate(ctx, orc, desc, x0, tol=1e-12)
+    pc.check_first_qp_structure(ctx, orc, desc, x0, 0, val_tol=1e-12)
+    first = pc.check_first_qp_solve(ctx, orc, desc, x0)
+    assert all(same for same, _ in first), first
+    trace = []
+    classes, dx, res = pc.sqp_history_classes(ctx, orc, desc, x0, trace=trace)
+    ctx.close()
+    cnt, cl = Counter(classes), np.array(classes)
+    print(f"config 1 + acc limits + jerk hinge x {B}: {dict(cnt)}, worst |dx| of the identical / tie histories "
+          f"{max([dx[i] for i in range(B) if classes[i] in ('identical', 'tie')], default=0.0):.2e}")
+    assert cnt["other"] == 0, [t for t in trace if t["cls"] == "other"]
+    for c in ("identical", "tie"):
+        if cnt[c]:
+            assert dx[cl == c].max() <= 1e-5, f"{c} history but |dx| = {dx[cl == c].max()}"
+    return cnt, dx
+
+
+def test_difference_rows_at_baseline_size(hostemu_lib, orc):
+    cnt, dx = _difference_rows_at_baseline_size(hostemu_lib, orc, 4)
+    assert cnt["identical"] + cnt["tie"] >= 2   # measured: 3 identical, 1 admm (parting at QP 11 of 60)
+
+
+@pytest.mark.gpu
+def test_difference_rows_at_baseline_size_on_device(orc):
+    # measured on the MI355X: 7 identical, 7 admm, 2 csc-noise of 16 (worst |dx| of the identical histories 9.2e-8).  The yardstick -
+    # the oracle against ITSELF built with FMA contraction on the same 16 seeds (tests/tools/oracle_self_parity.py) - keeps 5 of 16
+    # integer histories: hinge costs with tolerance bands make rank-deficient polish active sets, and the reference's own outcome
+    # there is decided by round-off.
+    cnt, dx = _difference_rows_at_baseline_size(None, orc, 16)
+    assert cnt["identical"] + cnt["tie"] >= 5
+
+
+def test_difference_rows_next_to_general_pair_rows_keep_the_dense_engine(hostemu_lib):
+    """Next to rows on two waypoints with DENSE coupling blocks (here an LVS collision cost) the difference rows of order 2 / 3 stay on
+    the dense engine, which refuses 600+ QP variables explicitly instead of running for minutes (DESIGN.md section 2.7);
+    TMX_DENSE_QP_MAX_N is the documented override."""
+    import os
+    from trajopt_amd import configs
+    from trajopt_amd.problem import CollisionTermInfo
+    pci, s, g = configs.config1()
+    for ti in pci.cost_infos:
+        if isinstance(ti, CollisionTermInfo):
+            ti.evaluator_type, ti.longest_valid_segment_length, ti.max_substates = 2, 0.2, 2
     pci.cnt_infos.append(JointAccTermInfo(coeffs=[1.0] * 7, targets=[0.0] * 7, first_step=0, last_step=29, upper_tols=[0.3] * 7, lower_tols=[-0.3] * 7,
                                           is_constraint=True, name="acc_limits"))
     ctx = runtime.Context(0, hostemu_lib)
     with pytest.raises(runtime.TmxError, match="dense engine"):
         ctx.upload(pci.to_desc(), abi.default_sqp_params(), abi.default_osqp_settings())
-    os.environ["TMX_DENSE_QP_MAX_N"] = "4096"
+    os.environ["TMX_DENSE_QP_MAX_N"] = "8192"
     try:
         ctx.upload(pci.to_desc(), abi.default_sqp_params(), abi.default_osqp_settings())     # accepted (not run here)
     finally:

@@ -415,7 +415,9 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
   std::vector<double> fx_consts;
   int n_fx_cost = 0;
   int n_stencil = 0;      // rows of difference order 2 / 3
-  bool qp_dense = false;  // rows on 3 - 4 waypoints or function COSTS with a dynamic quadratic model: dense QP engine
+  bool qp_dense = false;  // function COSTS with a dynamic quadratic model (or difference rows next to general pair rows): dense QP engine
+  bool stencil_rows = false;  // difference rows of order 2 / 3 (JointAcc / JointJerk Ineq costs, Eq / Ineq constraints)
+  int max_row_order = 0;
   bool st_terms = false;  // function terms (any): the ST instantiations of the term code, piecewise driver
   int band = 0;           // acceleration (2) / jerk (3) squared costs: banded objective
   std::vector<int> vel_first, vel_last, vel_cost, vel_kind, cp_t, cp_owner, cp_iscnt, cp_nrows, cp_idx, cp_slot0;
@@ -844,7 +846,8 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
             ctx->err = acc ? "JointAcc term, trajectory is too short!" : "JointJerk term, trajectory is too short!";  // :575, :642, :699, ...
             return TMX_ERR_INVALID;
           }
-          qp_dense = true;
+          stencil_rows = true;  // (structured banded path or dense engine: decided below, when every term is known)
+          max_row_order = std::max(max_row_order, ord);
           // rows in the order of the reference's expr_vec_ (:577-601, :644-652, :703-727 and the jerk twins): one row (EQ) or an
           // upper and a lower row (INEQ) per step i in [first, last - ord] and joint j over x[i .. i + ord][j]
           const int own = is_cost ? n_costs++ : n_cnts++;
@@ -1098,14 +1101,35 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
   for (int c = 0; c < P.NX; ++c)
     p_colptr[c + 1] = p_colptr[c] + ((c >= 3 * D && po3[c - 3 * D] != 0.0) ? 1 : 0) + ((c >= 2 * D && po2[c - 2 * D] != 0.0) ? 1 : 0) +
                       ((c >= D && po[c - D] != 0.0) ? 1 : 0) + ((pd[c] != 0.0) ? 1 : 0);
+  // Difference ROWS of order 2 / 3 touch one joint each: as long as every row on several waypoints is such a single-joint row (no
+  // LVS / cast collision rows, no CartVel rows) all the blocks they add to the reduced KKT matrix are diagonal, and the problem runs
+  // on the banded structured path at any size (band = max of the orders of costs and rows; DevProblem::band_rows).  Next to general
+  // pair rows (dense coupling blocks) or to function costs (dynamic P) they keep the dense engine.
+  bool band_rows = false;
+  if (stencil_rows)
+  {
+    int other_pairs = 0;
+    for (int r = 0; r < R; ++r)
+      if (c2[r] >= 0 && !slot_is_diff(kind[r]))
+        ++other_pairs;
+    if (!qp_dense && other_pairs == 0 && D <= 255)
+    {
+      band_rows = true;
+      st_terms = true;  // the term code of these rows is instantiated in the piecewise kernels (template flag ST)
+      band = std::max(band, max_row_order);
+    }
+    else
+      qp_dense = true;
+  }
   // squared acceleration / jerk costs alone keep the structured solver (banded block factorisation of the generic path); together
-  // with pair rows (the dense-coupling chain has no banded variant) or with difference rows / function terms: dense engine
-  if (band && (qp_dense || R2 > 0))
+  // with general pair rows (the dense-coupling chain has no banded variant) or function costs: dense engine
+  if (band && !band_rows && (qp_dense || R2 > 0))
   {
     qp_dense = true;
     band = 0;
   }
   P.band = band;
+  P.band_rows = band_rows ? 1 : 0;
   P.n_stencil = n_stencil;
   P.qp_dense = qp_dense ? 1 : 0;
   P.st = (qp_dense || st_terms) ? 1 : 0;
@@ -1338,9 +1362,10 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
       max_n = std::max(1, std::atoi(e));
     if (P.n_max > max_n)
     {
-      ctx->err = "acceleration / jerk rows or function costs: the QP of this problem has too many variables for the dense engine to "
-                 "solve in practical time (limit 448 incl. penalty variables; TMX_DENSE_QP_MAX_N overrides); smoothing costs alone and "
-                 "function terms that are rows only (constraints, ABS / HINGE costs, AvoidSingularity, DynamicCartPose) have no such limit";
+      ctx->err = "function costs (or acceleration / jerk rows next to collision / CartVel rows on two waypoints): the QP of this problem has "
+                 "too many variables for the dense engine to solve in practical time (limit 448 incl. penalty variables; "
+                 "TMX_DENSE_QP_MAX_N overrides); smoothing costs, acceleration / jerk limits and function terms that are rows only "
+                 "(constraints, ABS / HINGE costs, AvoidSingularity, DynamicCartPose) have no such limit";
       ctx->have_problem = false;
       return TMX_ERR_UNSUPPORTED;
     }
@@ -1490,7 +1515,7 @@ static tmx_status ensure_batch(tmx_ctx* ctx, int B)
   AL(accept_flag, b);
   if (P.band)
   {
-    H.band_stride = (long long)qp_band_doubles(P.D, P.T);
+    H.band_stride = (long long)qp_band_doubles(P.D, P.T, P.band_rows ? P.n_link : 0);
     AL(band_ws, b * (size_t)H.band_stride);
   }
   if (P.qp_dense)

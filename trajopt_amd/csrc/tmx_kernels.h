@@ -416,7 +416,7 @@ TMX_DEVFN void sqp_step_block(const DevProblem* P, const DevBatch* Bt, int b, do
   if (tid == 0)
     Bt->prof[(size_t)b * 16 + 11] += TMX_CLK() - tp0;
 #endif
-  qp_solve_block<HBM, BANDK>(P, Bt, b, smem, tid, NT, chain_lds);
+  qp_solve_block<HBM, BANDK, false>(P, Bt, b, smem, tid, NT, chain_lds);  // (fused step: never a band_rows problem)
 #ifdef TMX_PROFILE
   tp0 = TMX_CLK();
 #endif

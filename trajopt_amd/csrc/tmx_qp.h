@@ -16,6 +16,9 @@
 // with iterative refinement, explicit warm start when the CSC sparsity is unchanged.  See oracle/osqp_restate.hpp
 // for the line-by-line CPU statement this kernel is checked against.
 #pragma once
+#if defined(TMX_HOST_EMU) && defined(TMX_DEBUG_KKT)
+#include <vector>
+#endif
 #include "tmx_types.h"
 
 #define TMX_OSQP_INFTY 1e30
@@ -147,6 +150,16 @@ struct QpWs
   // its first NX doubles serve band_solve as the intermediate vector)
   double *po2, *po3, *Wb, *Mb;
   int band;
+  // DIFFERENCE ROWS of order 2 / 3 on the banded structured path (DevProblem::band_rows: JointAcc / JointJerk Ineq costs and
+  // constraints, trajectory_costs.cpp:556-754, :811-1016): such a row touches ONE joint j on waypoints t .. t + order.  coef / c2
+  // hold its entries on t and t + 1 (D-vectors that are zero off joint j), cf[2 i], cf[2 i + 1] (i = the row's c2 index) the
+  // entries on t + 2 / t + 3, fo[i] = order << 8 | j (0: not such a row).  Every block these rows add to the reduced KKT matrix is
+  // DIAGONAL (w_r a_k a_l on entry (j, j) of block (t + k, t + l)): with the objective's bands the matrix stays block banded with
+  // diagonal couplings - bk1 / bk2 / bk3 (NX each: objective coupling + row terms, rebuilt by kkt_factor) feed band_factor.
+  // All of it lives in the per-problem band slice (qp_ws_attach_band).  band_rows = 0: none of this is touched.
+  double* bk;     // bk1 | bk2 | bk3 | cf | fo | double-double workspace (accessors ws_bk1 .. ws_dd below: ONE pointer in the descriptor)
+  int band_rows;
+  int polish_dd;  // 1: factor / solve the banded system in double-double arithmetic (polish of problems with difference rows of order 2 / 3)
   // general rows (R) + coefficients (R*D)
   double *zr, *yr, *lor, *hir, *Er, *hr, *dyr, *coef;
   // aux (NA)
@@ -199,6 +212,16 @@ struct QpWs
 #endif
 };
 
+// layout of the far-row region QpWs::bk (band slice; band_rows = number of c2 slots of the problem)
+TMX_DEVFN double* ws_bk1(const QpWs& w) { return w.bk; }
+TMX_DEVFN double* ws_bk2(const QpWs& w) { return w.bk + w.NX; }
+TMX_DEVFN double* ws_bk3(const QpWs& w) { return w.bk + 2 * w.NX; }
+TMX_DEVFN double* ws_cf(const QpWs& w) { return w.bk + 3 * w.NX; }
+TMX_DEVFN int* ws_fo(const QpWs& w) { return reinterpret_cast<int*>(w.bk + 3 * w.NX + 2 * (size_t)w.band_rows); }
+TMX_DEVFN double* ws_dd(const QpWs& w)  // (even offset: 16-byte aligned pairs)
+{
+  return w.bk + 3 * w.NX + 3 * (size_t)w.band_rows + 8 - ((3 * (size_t)w.NX + 3 * (size_t)w.band_rows) & 1);
+}
 // the chains of problems WITHOUT pair rows couple consecutive blocks through the diagonal of the objective only
 #define TMX_PC(w) ((w).po)
 #if TMX_LINK_ROWS
@@ -212,6 +235,34 @@ TMX_DEVFN double link_dot(const QpWs& w, int r, int t, const double* x)
   double s = 0.0;
   for (int j = 0; j < w.D; ++j)
     s += w.c2[i * w.D + j] * x[(t + 1) * w.D + j];
+  if (w.band_rows)  // difference row of order 2 / 3: its entries on waypoints t + 2, t + 3 (joint j only)
+  {
+    const int f = ws_fo(w)[i];
+    if (f != 0)
+    {
+      const int j = f & 0xff;
+      s += ws_cf(w)[2 * i] * x[(t + 2) * w.D + j];
+      if ((f >> 8) >= 3)
+        s += ws_cf(w)[2 * i + 1] * x[(t + 3) * w.D + j];
+    }
+  }
+  return s;
+}
+// (A'rv) contribution to variable (t, j) of the difference rows of order >= 2 at home waypoints t-2 and t-3
+TMX_DEVFN double far_gather(const QpWs& w, const double* rv, int t, int j)
+{
+  double s = 0.0;
+  for (int k = 2; k <= 3 && k <= t; ++k)
+    for (int q = w.wl_start[t - k]; q < w.wl_start[t - k + 1]; ++q)
+    {
+      const int r = w.wl_list[q];
+      const int i = w.c2i[r];
+      if (!w.act[r] || i < 0)
+        continue;
+      const int f = ws_fo(w)[i];
+      if (f != 0 && (f & 0xff) == j && (f >> 8) >= k)
+        s += rv[r] * ws_cf(w)[2 * i + (k - 2)];
+    }
   return s;
 }
 // (A'rv) contribution to variable (t, j) of the pair rows of waypoint t-1
@@ -256,6 +307,8 @@ TMX_DEVFN double link_gather(const QpWs& w, const double* rv, int t, int j)
     }
 #endif
   }
+  if (w.band_rows)
+    s += far_gather(w, rv, t, j);
   return s;
 }
 #else
@@ -456,6 +509,9 @@ TMX_DEVFN void qp_ws_carve(QpWs& w, double* lds, double* glb, double* far, int D
   w.NA = NA;
   w.band = 0;
   w.po2 = w.po3 = w.Wb = w.Mb = nullptr;
+  w.bk = nullptr;
+  w.band_rows = 0;
+  w.polish_dd = 0;
   const int NX = w.NX;
   // ---- hot: LDS
   double* p = lds;
@@ -791,7 +847,12 @@ TMX_DEVFN void kkt_factor(const QpWs& w, const DevProblem* P, int mode, double s
   // diagonal blocks A_t (rows padded to DS doubles)
   for (int e = tid; e < T * DD; e += NT)
   {
-    const int t = e / DD, i = (e % DD) / D, j = e % D;
+    const int t = e / DD, i0 = (e % DD) / D, j0 = e % D;
+    // Problems with difference rows of order 2 / 3 get bit-SYMMETRIC diagonal blocks (entry (i, j) and (j, i) from the same
+    // operations): (w c_i) c_j and (w c_j) c_i round differently, and the banded elimination of their polish system has factors L of
+    // size 1e6 - 1e8 that amplify an asymmetry of 3e-11 in K_tt into O(1) differences between L S L' and K above the diagonal
+    // (found on config 1 + jerk hinge costs: the polish solve was off by 0.5 rad near the goal waypoint, in exact arithmetic).
+    const int i = (w.band_rows && j0 < i0) ? j0 : i0, j = (w.band_rows && j0 < i0) ? i0 : j0;
     double s = 0.0;
     for (int q = w.wl_start[t]; q < w.wl_start[t + 1]; ++q)
     {
@@ -809,17 +870,60 @@ TMX_DEVFN void kkt_factor(const QpWs& w, const DevProblem* P, int mode, double s
         if (w.act[r] && ci >= 0)
           s += w.hr[r] * w.c2[ci * D + i] * w.c2[ci * D + j];
       }
+    // difference rows of order 2 / 3 at home waypoints t-2, t-3: w_r a_k^2 on the diagonal entry of their joint
+    if (w.band_rows && i == j)
+      for (int k = 2; k <= 3 && k <= t; ++k)
+        for (int q = w.wl_start[t - k]; q < w.wl_start[t - k + 1]; ++q)
+        {
+          const int r = w.wl_list[q];
+          const int ci = w.c2i[r];
+          if (!w.act[r] || ci < 0)
+            continue;
+          const int f = ws_fo(w)[ci];
+          if (f != 0 && (f & 0xff) == i && (f >> 8) >= k)
+            s += w.hr[r] * ws_cf(w)[2 * ci + (k - 2)] * ws_cf(w)[2 * ci + (k - 2)];
+        }
 #endif
     if (i == j)
     {
       const int v = t * D + i;
       s += w.pd[v] + sig + w_bp(w, v, mode, delta) * w.bbp[v] * w.bbp[v];
     }
-    w.Sinv[t * DDS + i * DS + j] = s;
+    w.Sinv[t * DDS + i0 * DS + j0] = s;
   }
 #if TMX_LINK_ROWS
+  // banded path with difference rows: the couplings (t, j) - (t + k, j), k = 1 .. 3, of the reduced KKT matrix = the objective's
+  // band + sum over the rows r of joint j at home waypoints t - m of  w_r a_m a_{m+k}  (a_0 = coef, a_1 = c2, a_2 / a_3 = cf)
+  if (w.band_rows)
+    for (int v = tid; v < T * D; v += NT)
+    {
+      const int t = v / D, j = v % D;
+      double b1 = (t < T - 1) ? w.po[v] : 0.0, b2 = (t < T - 2) ? w.po2[v] : 0.0, b3 = (t < T - 3) ? w.po3[v] : 0.0;
+      for (int m = 0; m <= 2 && m <= t; ++m)
+        for (int q = w.wl_start[t - m]; q < w.wl_start[t - m + 1]; ++q)
+        {
+          const int r = w.wl_list[q];
+          const int ci = w.c2i[r];
+          if (!w.act[r] || ci < 0)
+            continue;
+          const int f = ws_fo(w)[ci];
+          const int ord = f != 0 ? (f >> 8) : 1;
+          const double a[4] = { w.coef[r * D + j], w.c2[ci * D + j], (f != 0 && (f & 0xff) == j) ? ws_cf(w)[2 * ci] : 0.0,
+                                (f != 0 && (f & 0xff) == j && ord >= 3) ? ws_cf(w)[2 * ci + 1] : 0.0 };
+          const double wr = w.hr[r];
+          if (m + 1 <= 3)
+            b1 += wr * a[m] * a[m + 1];
+          if (m + 2 <= 3)
+            b2 += wr * a[m] * a[m + 2];
+          if (m + 3 <= 3)
+            b3 += wr * a[m] * a[m + 3];
+        }
+      ws_bk1(w)[v] = b1;
+      ws_bk2(w)[v] = b2;
+      ws_bk3(w)[v] = b3;
+    }
   // dense coupling blocks C_t = diag(po_t) + sum over the pair rows of waypoint t of  w_r coef_r c2_r'
-  if (w.n_link > 0)
+  if (w.n_link > 0 && !w.band_rows)
     for (int e = tid; e < (T - 1) * DD; e += NT)
     {
       const int t = e / DD, i = (e % DD) / D, j = e % D;
@@ -840,6 +944,62 @@ TMX_DEVFN void kkt_factor(const QpWs& w, const DevProblem* P, int mode, double s
     w.Sinv[t * DDS + i * DS + j] = 0.0;
   }
   TMX_SYNC();
+#if defined(TMX_HOST_EMU) && defined(TMX_DEBUG_KKT)
+  if (mode == 1 && w.band_rows)
+  {
+    // assembled blocks against the operator  K = diag + bands + sum_r w_r a_r a_r'  applied to unit vectors
+    const int NX = w.NX;
+    double worst = 0.0;
+    int wi = -1, wj = -1;
+    std::vector<double> x(NX), rv(w.R);
+    for (int c = 0; c < NX; ++c)
+    {
+      std::fill(x.begin(), x.end(), 0.0);
+      x[c] = 1.0;
+      for (int r = 0; r < w.R; ++r)
+      {
+        rv[r] = 0.0;
+        if (!w.act[r])
+          continue;
+        double dot = 0.0;
+        for (int j = 0; j < D; ++j)
+          dot += w.coef[r * D + j] * x[w.slot_t[r] * D + j];
+        dot += link_dot(w, r, w.slot_t[r], x.data());
+        rv[r] = w.hr[r] * dot;
+      }
+      for (int v = 0; v < NX; ++v)
+      {
+        const int t = v / D, j = v % D, tc = c / D, jc = c % D;
+        double op = (v == c) ? (w.pd[v] + sig + w_bp(w, v, mode, delta) * w.bbp[v] * w.bbp[v]) : 0.0;
+        if (jc == j && tc == t + 1) op += w.po[v];
+        if (jc == j && tc == t - 1) op += w.po[c];
+        if (jc == j && tc == t + 2) op += w.po2[v];
+        if (jc == j && tc == t - 2) op += w.po2[c];
+        if (jc == j && tc == t + 3) op += w.po3[v];
+        if (jc == j && tc == t - 3) op += w.po3[c];
+        for (int q = w.wl_start[t]; q < w.wl_start[t + 1]; ++q)
+          if (w.act[w.wl_list[q]])
+            op += rv[w.wl_list[q]] * w.coef[w.wl_list[q] * D + j];
+        op += link_gather(w, rv.data(), t, j);
+        double as = 0.0;
+        if (tc == t)
+          as = w.Sinv[t * DDS + j * DS + jc];
+        else if (jc == j && abs(tc - t) <= 3)
+        {
+          const int lo = tc < t ? c : v, k = abs(tc - t);
+          as = k == 1 ? ws_bk1(w)[lo] : (k == 2 ? ws_bk2(w)[lo] : ws_bk3(w)[lo]);
+        }
+        if (fabs(op - as) > worst)
+        {
+          worst = fabs(op - as);
+          wi = v;
+          wj = c;
+        }
+      }
+    }
+    std::printf("[dbg] polish assembly vs operator: worst |diff| %.3e at (%d = wp %d joint %d, %d = wp %d joint %d)\n", worst, wi, wi / D, wi % D, wj, wj / D, wj % D);
+  }
+#endif
 }
 
 // sequential Schur complements S_t = A_t - C_t Sinv_{t-1} C_t and in-place inversion over blocks [t0, t1]
@@ -965,7 +1125,7 @@ TMX_DEVFN double band_col_norm(const QpWs& w, int v)
   return cn;
 }
 // banded problems: the far couplings and the block factors live in their own per-problem HBM slice (DevBatch::band_ws)
-TMX_DEVFN void qp_ws_attach_band(QpWs& w, int band, double* slice)
+TMX_DEVFN void qp_ws_attach_band(QpWs& w, int band, double* slice, int band_rows = 0)
 {
   w.band = band;
   if (band == 0)
@@ -975,12 +1135,25 @@ TMX_DEVFN void qp_ws_attach_band(QpWs& w, int band, double* slice)
   w.po3 = slice + NX;
   w.Wb = slice + 2 * NX;
   w.Mb = w.Wb + 3 * TDD;
+#if TMX_LINK_ROWS
+  if (band_rows > 0)  // difference rows of order 2 / 3 (QpWs::cf ...): behind the block factors
+  {
+    w.bk = w.Mb + 3 * TDD + 8;
+    w.band_rows = band_rows;
+  }
+#else
+  (void)band_rows;
+#endif
   // the fast path is off for these problems: its LDS region (G up to Zs) is free - the block factors W go there when they fit, so
   // that the sweeps of band_solve do not wait for HBM at every block
   if (w.G != nullptr && w.Zs != nullptr && (size_t)(w.Zs - w.G) >= 3 * TDD)
     w.Wb = w.G;
 }
-TMX_HOSTDEVFN size_t qp_band_doubles(int D, int T) { return 2 * (size_t)D * T + 6 * (size_t)T * D * D + 8; }
+TMX_HOSTDEVFN size_t qp_band_doubles(int D, int T, int band_rows = 0)
+{
+  return 2 * (size_t)D * T + 6 * (size_t)T * D * D + 8 +
+         (band_rows > 0 ? 3 * (size_t)D * T + 3 * (size_t)band_rows + 16 + 2 * (7 * (size_t)T * D * D + 2 * (size_t)T * D + (size_t)D * D + D) + 8 : 0);
+}
 
 // ---- BANDED block factorisation (DevProblem::band): K = L S L' with block bandwidth `band`, the off-diagonal blocks of K diagonal
 // matrices (po: t <-> t+1, po2: t <-> t+2, po3: t <-> t+3), the blocks of L dense (fill-in inside the band).
@@ -1021,9 +1194,10 @@ TMX_DEVFN BandWs band_ws_of(const QpWs& w)
   b.Sinv = w.Sinv;
   b.Wb = w.Wb;
   b.Mb = w.Mb;
-  b.po = w.po;
-  b.po2 = w.po2;
-  b.po3 = w.po3;
+  // (with difference rows of order 2 / 3 the couplings of the reduced KKT matrix are the objective's plus the rows' terms: kkt_factor)
+  b.po = w.band_rows ? ws_bk1(w) : w.po;
+  b.po2 = w.band_rows ? ws_bk2(w) : w.po2;
+  b.po3 = w.band_rows ? ws_bk3(w) : w.po3;
   b.gj = w.gj;
   b.red = w.red;
   b.tp = w.tp;
@@ -1183,6 +1357,215 @@ TMX_DEVFN void band_solve_impl(const BandWs& w, int tid, int NT)
   }
 }
 
+// ---- the banded factorisation / solve in DOUBLE-DOUBLE arithmetic (polish of problems with difference rows of order 2 / 3) ---------
+// OSQP's polish solves the quasi-definite KKT system of the active set, regularised by +-delta = 1e-6, and refines towards the
+// unregularised solution.  The reduced form squares the regularisation into row weights 1 / delta = 1e6; with second / third
+// differences pinned over stretches of waypoints the reduced matrix of the RUIZ-SCALED problem reaches condition numbers of 1e13 and
+// more, and the fp64 block elimination loses what the refinement needs: measured on config 1 + jerk hinge costs, the device's
+// refinement contracted by 0.2 - 0.8 per pass (or diverged) where the reference's LDL' of the UNsquared system contracts by 1e-3,
+// and its polish was rejected where the reference's is accepted - on every seed, from the second or third QP on (the same QPs
+// without Ruiz scaling agree).  A numpy model of the elimination order on the exported QP shows the reduced form itself is sound
+// when its recurrences are carried accurately; so the polish of these problems carries them in double-double (~32 digits: error-free
+// sums and FMA products): S_t, M, W of band_factor and the three sweeps of band_solve, inputs and outputs fp64.  Cold code: once
+// per QP solve, a 30-block chain of 7 x 7 blocks.
+#ifndef TMX_POLISH_DD
+#define TMX_POLISH_DD 1  // 0: the polish of these problems in plain fp64 (host build, 16 runs: 9 instead of 11 identical histories)
+#endif
+struct tdd
+{
+  double h, l;
+};
+TMX_DEVFN tdd dd_of(double a) { return tdd{ a, 0.0 }; }
+TMX_DEVFN tdd dd_quick(double a, double b)
+{
+  const double s = a + b;
+  return tdd{ s, b - (s - a) };
+}
+TMX_DEVFN tdd dd_add(tdd a, tdd b)
+{
+  const double s = a.h + b.h, bb = s - a.h;
+  double e = (a.h - (s - bb)) + (b.h - bb);
+  e += a.l + b.l;
+  return dd_quick(s, e);
+}
+TMX_DEVFN tdd dd_neg(tdd a) { return tdd{ -a.h, -a.l }; }
+TMX_DEVFN tdd dd_sub(tdd a, tdd b) { return dd_add(a, dd_neg(b)); }
+TMX_DEVFN tdd dd_mul(tdd a, tdd b)
+{
+  const double p = a.h * b.h;
+  double e = __builtin_fma(a.h, b.h, -p);
+  e += a.h * b.l + a.l * b.h;
+  return dd_quick(p, e);
+}
+TMX_DEVFN tdd dd_div(tdd a, tdd b)
+{
+  const double q1 = a.h / b.h;
+  tdd r = dd_sub(a, dd_mul(b, dd_of(q1)));
+  const double q2 = r.h / b.h;
+  r = dd_sub(r, dd_mul(b, dd_of(q2)));
+  const double q3 = r.h / b.h;
+  return dd_add(dd_quick(q1, q2), dd_of(q3));
+}
+// doubles of the double-double workspace behind the far-row arrays of the band slice: S (T D D), W and M (3 T D D each), two
+// vectors (T D), Gauss-Jordan scratch (D D + D), all as (hi, lo) pairs
+TMX_HOSTDEVFN size_t qp_band_dd_doubles(int D, int T) { return 2 * (7 * (size_t)T * D * D + 2 * (size_t)T * D + (size_t)D * D + D) + 8; }
+struct BandDd
+{
+  tdd *S, *W, *M, *v, *y, *gj, *col;
+};
+TMX_DEVFN BandDd band_dd_of(double* base, int D, int T)
+{
+  BandDd b;
+  const size_t TDD = (size_t)T * D * D, NX = (size_t)T * D;
+  tdd* p = reinterpret_cast<tdd*>(base);
+  b.S = p;
+  b.W = b.S + TDD;
+  b.M = b.W + 3 * TDD;
+  b.v = b.M + 3 * TDD;
+  b.y = b.v + NX;
+  b.gj = b.y + NX;
+  b.col = b.gj + (size_t)D * D;
+  return b;
+}
+// as band_factor_impl: in K_tt in w.Sinv (fp64) and the couplings; out S_t^-1, W in double-double (dd)
+TMX_DEVFN void band_factor_dd_impl(const BandWs& w, double* ddbase, int tid, int NT)
+{
+  const int D = w.D, DD = D * D, DS = w.DS, DDS = w.DDS, T = w.T, nb = w.band;
+  const BandDd d = band_dd_of(ddbase, D, T);
+  for (int t = 0; t < T; ++t)
+  {
+    tdd* S = d.S + (size_t)t * DD;
+    for (int e = tid; e < DD; e += NT)
+    {
+      const int i = e / D, j = e % D;
+      tdd acc = dd_of(w.Sinv[t * DDS + i * DS + j]);
+      for (int k = 1; k <= nb && k <= t; ++k)
+      {
+        const tdd* Mk = d.M + ((size_t)(k - 1) * T + (t - k)) * DD;
+        const tdd* Wk = d.W + ((size_t)(k - 1) * T + (t - k)) * DD;
+        for (int l = 0; l < D; ++l)
+          acc = dd_sub(acc, dd_mul(Mk[i * D + l], Wk[j * D + l]));
+      }
+      S[e] = acc;
+    }
+    TMX_SYNC();
+    for (int k = 0; k < D; ++k)  // Gauss-Jordan inversion in place
+    {
+      const tdd piv = dd_div(dd_of(1.0), S[k * D + k]);
+      TMX_SYNC();
+      for (int e = tid; e < D; e += NT)
+        d.col[e] = S[e * D + k];
+      TMX_SYNC();
+      for (int e = tid; e < DD; e += NT)
+      {
+        const int i = e / D, j = e % D;
+        tdd v;
+        if (i == k && j == k)
+          v = piv;
+        else if (i == k)
+          v = dd_mul(S[e], piv);
+        else if (j == k)
+          v = dd_neg(dd_mul(d.col[i], piv));
+        else
+          v = dd_sub(S[e], dd_mul(dd_mul(d.col[i], S[k * D + j]), piv));
+        d.gj[e] = v;
+      }
+      TMX_SYNC();
+      for (int e = tid; e < DD; e += NT)
+        S[e] = d.gj[e];
+      TMX_SYNC();
+    }
+    for (int jj = 1; jj <= nb; ++jj)
+      if (t + jj < T)
+      {
+        tdd* Mj = d.M + ((size_t)(jj - 1) * T + t) * DD;
+        for (int e = tid; e < DD; e += NT)
+        {
+          const int i = e / D, c = e % D;
+          tdd val = dd_of((i == c) ? band_coupling(w, jj, t, i) : 0.0);
+          for (int k = 1; jj + k <= nb && k <= t; ++k)
+          {
+            const tdd* A = d.M + ((size_t)(jj + k - 1) * T + (t - k)) * DD;
+            const tdd* Bm = d.W + ((size_t)(k - 1) * T + (t - k)) * DD;
+            for (int l = 0; l < D; ++l)
+              val = dd_sub(val, dd_mul(A[i * D + l], Bm[c * D + l]));
+          }
+          Mj[e] = val;
+        }
+      }
+    TMX_SYNC();
+    for (int jj = 1; jj <= nb; ++jj)
+      if (t + jj < T)
+      {
+        const tdd* Mj = d.M + ((size_t)(jj - 1) * T + t) * DD;
+        tdd* Wj = d.W + ((size_t)(jj - 1) * T + t) * DD;
+        for (int e = tid; e < DD; e += NT)
+        {
+          const int i = e / D, c = e % D;
+          tdd acc = dd_of(0.0);
+          for (int l = 0; l < D; ++l)
+            acc = dd_add(acc, dd_mul(Mj[i * D + l], S[l * D + c]));
+          Wj[e] = acc;
+        }
+      }
+    TMX_SYNC();
+  }
+}
+// K x = b in place on w.tp (fp64 in, fp64 out), the three sweeps of band_solve_impl carried in double-double
+TMX_DEVFN void band_solve_dd_impl(const BandWs& w, double* ddbase, int tid, int NT)
+{
+  const int D = w.D, DD = D * D, T = w.T, nb = w.band;
+  const BandDd d = band_dd_of(ddbase, D, T);
+  for (int e = tid; e < T * D; e += NT)
+    d.v[e] = dd_of(w.tp[e]);
+  TMX_SYNC();
+  for (int t = 1; t < T; ++t)
+  {
+    for (int i = tid; i < D; i += NT)
+    {
+      tdd acc = d.v[t * D + i];
+      for (int k = 1; k <= nb && k <= t; ++k)
+      {
+        const tdd* Wk = d.W + ((size_t)(k - 1) * T + (t - k)) * DD + i * D;
+        const tdd* vp = d.v + (t - k) * D;
+        for (int l = 0; l < D; ++l)
+          acc = dd_sub(acc, dd_mul(Wk[l], vp[l]));
+      }
+      d.v[t * D + i] = acc;  // (row i of block t only: no other thread reads it in this step)
+    }
+    TMX_SYNC();
+  }
+  for (int e = tid; e < T * D; e += NT)
+  {
+    const int t = e / D, i = e % D;
+    const tdd* S = d.S + (size_t)t * DD + i * D;
+    tdd acc = dd_of(0.0);
+    for (int l = 0; l < D; ++l)
+      acc = dd_add(acc, dd_mul(S[l], d.v[t * D + l]));
+    d.y[e] = acc;
+  }
+  TMX_SYNC();
+  for (int t = T - 2; t >= 0; --t)
+  {
+    for (int i = tid; i < D; i += NT)
+    {
+      tdd acc = d.y[t * D + i];
+      for (int k = 1; k <= nb && t + k < T; ++k)
+      {
+        const tdd* Wk = d.W + ((size_t)(k - 1) * T + t) * DD;  // W_k[t]' : column i
+        const tdd* xn = d.y + (t + k) * D;                      // (y is overwritten by x from the end)
+        for (int l = 0; l < D; ++l)
+          acc = dd_sub(acc, dd_mul(Wk[l * D + i], xn[l]));
+      }
+      d.y[t * D + i] = acc;
+    }
+    TMX_SYNC();
+  }
+  for (int e = tid; e < T * D; e += NT)
+    w.tp[e] = d.y[e].h + d.y[e].l;
+  TMX_SYNC();
+}
+
 #if TMX_IS_DEVICE
 __device__ __attribute__((noinline)) static void band_factor_nl(BandWs b) { band_factor_impl(b, threadIdx.x, blockDim.x); }
 // band_solve with the two sweeps walked by ONE wave (lane i = component i of the running vectors, which stay in registers; the other
@@ -1338,11 +1721,37 @@ __device__ __attribute__((noinline)) static void band_solve_nl(BandWs w)
   }
   TMX_SYNC();
 }
-TMX_DEVFN void band_factor(const QpWs& w, int, int) { band_factor_nl(band_ws_of(w)); }
-TMX_DEVFN void band_solve(const QpWs& w, int, int) { band_solve_nl(band_ws_of(w)); }
+__device__ __attribute__((noinline)) static void band_factor_dd_nl(BandWs b, double* ddbase) { band_factor_dd_impl(b, ddbase, threadIdx.x, blockDim.x); }
+__device__ __attribute__((noinline)) static void band_solve_dd_nl(BandWs b, double* ddbase) { band_solve_dd_impl(b, ddbase, threadIdx.x, blockDim.x); }
+TMX_DEVFN void band_factor(const QpWs& w, int, int)
+{
+  if (w.polish_dd)
+    band_factor_dd_nl(band_ws_of(w), ws_dd(w));
+  else
+    band_factor_nl(band_ws_of(w));
+}
+TMX_DEVFN void band_solve(const QpWs& w, int, int)
+{
+  if (w.polish_dd)
+    band_solve_dd_nl(band_ws_of(w), ws_dd(w));
+  else
+    band_solve_nl(band_ws_of(w));
+}
 #else
-TMX_DEVFN void band_factor(const QpWs& w, int tid, int NT) { band_factor_impl(band_ws_of(w), tid, NT); }
-TMX_DEVFN void band_solve(const QpWs& w, int tid, int NT) { band_solve_impl(band_ws_of(w), tid, NT); }
+TMX_DEVFN void band_factor(const QpWs& w, int tid, int NT)
+{
+  if (w.polish_dd)
+    band_factor_dd_impl(band_ws_of(w), ws_dd(w), tid, NT);
+  else
+    band_factor_impl(band_ws_of(w), tid, NT);
+}
+TMX_DEVFN void band_solve(const QpWs& w, int tid, int NT)
+{
+  if (w.polish_dd)
+    band_solve_dd_impl(band_ws_of(w), ws_dd(w), tid, NT);
+  else
+    band_solve_impl(band_ws_of(w), tid, NT);
+}
 #endif
 
 // ---- KKT solve: in: tp (primary rhs r1 + A'W r2 part), ta (aux rhs); out: tp = x_p, ta = x_a, hr = (A x)_r --------
@@ -1448,6 +1857,9 @@ TMX_DEVFN void kkt_solve(const QpWs& w, const DevProblem* P, int mode, double si
     TMX_SYNC();
   }
   // 2. block forward / backward substitution (sequential over waypoints); row i of the block handled by thread i
+#if defined(TMX_HOST_EMU) && defined(TMX_DEBUG_KKT)
+  std::vector<double> dbg_rhs(w.tp, w.tp + w.NX);
+#endif
   if (w.band)
     band_solve(w, tid, NT);  // banded objective (acceleration / jerk costs)
   else if (TMX_HAS_PAIRS(w))
@@ -1544,6 +1956,49 @@ TMX_DEVFN void kkt_solve(const QpWs& w, const DevProblem* P, int mode, double si
       TMX_SYNC();
     }
   }
+#if defined(TMX_HOST_EMU) && defined(TMX_DEBUG_KKT)
+  if (mode == 1 && w.band)
+  {
+    // residual of the reduced solve against the OPERATOR form of the reduced matrix (weights recomputed as in kkt_factor)
+    std::vector<double> weff(w.R, 0.0), rv(w.R, 0.0), kx(w.NX, 0.0);
+    for (int r = 0; r < w.R; ++r)
+      if (w.act[r])
+      {
+        const double rr = w_row(w, r, mode, delta);
+        double kappa = 0.0;
+        for (int k = 0; k < w.naux[r]; ++k)
+        {
+          const int a = w.aoff[r] + k;
+          kappa += w.sa[a] * w.sa[a] / (sig + w_ba(w, a, mode, delta) * w.bba[a] * w.bba[a]);
+        }
+        weff[r] = rr / (1.0 + rr * kappa);
+        double dot = 0.0;
+        for (int j = 0; j < D; ++j)
+          dot += w.coef[r * D + j] * w.tp[w.slot_t[r] * D + j];
+        dot += link_dot(w, r, w.slot_t[r], w.tp);
+        rv[r] = weff[r] * dot;
+      }
+    double rmax = 0.0, bmax = 0.0;
+    for (int v = 0; v < w.NX; ++v)
+    {
+      const int t = v / D, j = v % D;
+      double sacc = (w.pd[v] + sig + w_bp(w, v, mode, delta) * w.bbp[v] * w.bbp[v]) * w.tp[v];
+      if (t > 0) sacc += w.po[v - D] * w.tp[v - D];
+      if (t < T - 1) sacc += w.po[v] * w.tp[v + D];
+      if (t > 1) sacc += w.po2[v - 2 * D] * w.tp[v - 2 * D];
+      if (t < T - 2) sacc += w.po2[v] * w.tp[v + 2 * D];
+      if (t > 2) sacc += w.po3[v - 3 * D] * w.tp[v - 3 * D];
+      if (t < T - 3) sacc += w.po3[v] * w.tp[v + 3 * D];
+      for (int q = w.wl_start[t]; q < w.wl_start[t + 1]; ++q)
+        if (w.act[w.wl_list[q]])
+          sacc += rv[w.wl_list[q]] * w.coef[w.wl_list[q] * D + j];
+      sacc += link_gather(w, rv.data(), t, j);
+      rmax = fmax(rmax, fabs(sacc - dbg_rhs[v]));
+      bmax = fmax(bmax, fabs(dbg_rhs[v]));
+    }
+    std::printf("[dbg] reduced solve: |K x - b| %.3e  |b| %.3e  polish_dd %d\n", rmax, bmax, w.polish_dd);
+  }
+#endif
   // 3. aux recovery and (A x)_r   (polish: hr = nu_r, the multiplier itself - (A dx - r2) / delta would cancel again)
   if (mode == 1)
   {

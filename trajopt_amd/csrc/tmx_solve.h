@@ -1136,8 +1136,8 @@ __device__ __attribute__((noinline)) static void qp_admm_generic_nl(const DevPro
   w.sweep_regs = PAIRS;
   w.sweep_inline = PAIRS && !HBM;
 #endif
-  if (BAND)  // (banded objectives are never combined with pair rows: tmx_problem_upload)
-    qp_ws_attach_band(w, P->band, Bt->band_ws + (size_t)b * (size_t)Bt->band_stride);
+  if (BAND)  // (banded objectives go with single-joint difference rows only, never with general pair rows: tmx_problem_upload)
+    qp_ws_attach_band(w, P->band, Bt->band_ws + (size_t)b * (size_t)Bt->band_stride, (PAIRS && P->band_rows) ? P->n_link : 0);
   QpShared* sh = reinterpret_cast<QpShared*>(w.wself);
   w.rho = sh->rho;
   w.sigma = sh->sigma;
@@ -1172,7 +1172,10 @@ __device__ __attribute__((noinline)) static void qp_admm_generic_nl(const DevPro
 // the literal 0 of qp_ws_carve, every banded branch folds away and the banded instantiations leave the kernel - with them the inlined
 // body of k_sqp_pool spilled 132 more dwords per lane (own frame 1200 -> 1728 B) and BASELINE config 1 lost 4.5 % on one box (same
 // results), although it never executes them.
-template <bool HBM = false, bool BANDK = true>
+// ROWSK = false: a kernel that is never launched for problems with difference rows of order 2 / 3 on the banded path (DevProblem::
+// band_rows: such problems are ST problems and run on the piecewise driver, i.e. k_qp_solve / k_qp_solve_hbm): w.band_rows stays the
+// literal 0 and the far-row code folds out of the fused kernels (with it in k_sqp_fused_hbm config 2 lost 3 %, same results).
+template <bool HBM = false, bool BANDK = true, bool ROWSK = true>
 TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, double* smem, int tid, int NT, double* chain_lds = nullptr)
 {
   const int D = P->D, T = P->T, NX = P->NX, R = P->R;
@@ -1189,7 +1192,7 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
       qp_ws_chain_to_lds(w, chain_lds);
   }
   if constexpr (BANDK)
-    qp_ws_attach_band(w, P->band, Bt->band_ws + (size_t)b * (size_t)Bt->band_stride);
+    qp_ws_attach_band(w, P->band, Bt->band_ws + (size_t)b * (size_t)Bt->band_stride, (ROWSK && P->band_rows) ? P->n_link : 0);
   long long pc[16] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
   long long tlast = TMX_CLK();
   const int* g_act = Bt->active + (size_t)b * R;
@@ -1228,6 +1231,17 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
           w.c2[P->slot_c2[r] * D + j] = g_act[r] ? g_coef2[P->slot_c2[r] * D + j] : 0.0;
 #endif
     }
+#if TMX_LINK_ROWS
+    if (w.band_rows && P->slot_c2[r] >= 0)
+    {
+      // difference row of order 2 / 3: the fixed entries on waypoints t + 2, t + 3 (diff_row_coef), its joint and order
+      const int ci = P->slot_c2[r];
+      const int ord = slot_is_diff(P->slot_kind[r]) ? diff_row_order(P, r) : 1;
+      ws_fo(w)[ci] = ord >= 2 ? (ord << 8 | P->slot_sub[r]) : 0;
+      ws_cf(w)[2 * ci] = (ord >= 2 && g_act[r]) ? diff_row_coef(P, r, 2) : 0.0;
+      ws_cf(w)[2 * ci + 1] = (ord >= 3 && g_act[r]) ? diff_row_coef(P, r, 3) : 0.0;
+    }
+#endif
     const double oc = aux_cost(P, g_merit, r);
     for (int k = 0; k < P->slot_naux[r]; ++k)
     {
@@ -1365,6 +1379,18 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
           if (w.act[r] && w.c2i[r] >= 0)
             cn = fmax(cn, fabs(w.c2[w.c2i[r] * D + j]));
         }
+      if (w.band_rows)  // entries of the difference rows of order 2 / 3 at home waypoints t-2, t-3 in this column
+        for (int k = 2; k <= 3 && k <= t; ++k)
+          for (int q = w.wl_start[t - k]; q < w.wl_start[t - k + 1]; ++q)
+          {
+            const int r = w.wl_list[q];
+            const int ci = w.c2i[r];
+            if (!w.act[r] || ci < 0)
+              continue;
+            const int f = ws_fo(w)[ci];
+            if (f != 0 && (f & 0xff) == j && (f >> 8) >= k)
+              cn = fmax(cn, fabs(ws_cf(w)[2 * ci + (k - 2)]));
+          }
 #endif
       cn = fmax(cn, fabs(w.bbp[v]));
       w.tp[v] = 1.0 / sqrt(limit_scaling(cn));
@@ -1381,6 +1407,8 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
       if (w.n_link > 0 && w.c2i[r] >= 0)
         for (int j = 0; j < D; ++j)
           rn = fmax(rn, fabs(w.c2[w.c2i[r] * D + j]));
+      if (w.band_rows && w.c2i[r] >= 0 && ws_fo(w)[w.c2i[r]] != 0)
+        rn = fmax(rn, fmax(fabs(ws_cf(w)[2 * w.c2i[r]]), fabs(ws_cf(w)[2 * w.c2i[r] + 1])));
 #endif
       for (int k = 0; k < w.naux[r]; ++k)
       {
@@ -1420,6 +1448,13 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
       if (w.n_link > 0 && w.c2i[r] >= 0)
         for (int j = 0; j < D; ++j)
           w.c2[w.c2i[r] * D + j] = (w.hr[r] * w.c2[w.c2i[r] * D + j]) * w.tp[(t + 1) * D + j];
+      if (w.band_rows && w.c2i[r] >= 0 && ws_fo(w)[w.c2i[r]] != 0)
+      {
+        const int ci = w.c2i[r], f = ws_fo(w)[ci], jj = f & 0xff;
+        ws_cf(w)[2 * ci] = (w.hr[r] * ws_cf(w)[2 * ci]) * w.tp[(t + 2) * D + jj];
+        if ((f >> 8) >= 3)
+          ws_cf(w)[2 * ci + 1] = (w.hr[r] * ws_cf(w)[2 * ci + 1]) * w.tp[(t + 3) * D + jj];
+      }
 #endif
       for (int k = 0; k < w.naux[r]; ++k)
       {
@@ -1666,7 +1701,9 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
       // instantiations: with / without pair rows; block size 7 (7-DOF arms: configs 2 and 4) as a compile-time constant.  (A D = 10
       // instantiation for config 3 faulted in the 512-thread HBM kernel - memory access fault at address 0, not understood - and is
       // not built.)
-      if (P->n_link > 0)
+      if (ROWSK && BANDK && P->band && P->n_link > 0)  // banded path with difference rows of order 2 / 3 (DevProblem::band_rows)
+        qp_admm_generic_nl<HBM, true, 0, true>(P, Bt, b, lds_off, HBM ? smem : nullptr, chain_lds != nullptr ? 1 : 0);
+      else if (P->n_link > 0)
       {
         if (P->D == 7)
           qp_admm_generic_nl<HBM, true, 7>(P, Bt, b, lds_off, HBM ? smem : nullptr, chain_lds != nullptr ? 1 : 0);
@@ -1781,6 +1818,8 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
       }
     }
     TMX_SYNC();
+    // (difference rows of order 2 / 3: the banded factorisation and its solves in double-double arithmetic, tmx_qp.h)
+    wp.polish_dd = (TMX_POLISH_DD && wp.band_rows > 0 && wp.bk != nullptr) ? 1 : 0;
     kkt_factor(wp, P, 1, delta, delta, tid, NT);
     kkt_invert(wp, false, tid, NT, pc, tlast);
     // polished iterate lives in (dxp, dxa | dyr, dybp, dyba)
@@ -1846,6 +1885,14 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
           }
       TMX_SYNC();
       kkt_solve(wp, P, 1, delta, delta, tid, NT);
+#if defined(TMX_HOST_EMU) && defined(TMX_DEBUG_KKT)
+      {
+        double mx = 0.0;
+        for (int v = 0; v < NX; ++v)
+          mx = fmax(mx, fabs(wp.tp[v]));
+        std::printf("[dbg] polish pass %d: max |correction of x| %.3e\n", pass, mx);
+      }
+#endif
       // y-part of the solution: kkt_solve(mode 1) left nu_r in hr
       TMX_ROWS(wp, r)
       {
@@ -1913,6 +1960,9 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
     QpInfo dummy = info;
     double pprim = 0.0, pdual = 0.0;
     compute_residuals(wp, P, wp.dxp, wp.dxa, wp.dyr, wp.dybp, wp.dyba, 1, dummy, pprim, pdual, false, tid, NT);
+#if defined(TMX_HOST_EMU) && defined(TMX_DEBUG_KKT)
+    std::printf("[dbg] polish: prim %.3e (admm %.3e)  dual %.3e (admm %.3e)\n", pprim, info.prim_res, pdual, info.dual_res);
+#endif
     const bool ok = (pprim < info.prim_res && pdual < info.dual_res) || (pprim < info.prim_res && info.dual_res < 1e-10) ||
                     (pdual < info.dual_res && info.prim_res < 1e-10);
     if (ok)

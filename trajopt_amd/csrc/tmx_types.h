@@ -112,6 +112,10 @@ struct DevProblem
   // terms, no pair rows): the reduced KKT matrix is block banded with DIAGONAL off-diagonal blocks (po, po2, po3) - band = 2 | 3
   // selects the banded block factorisation of the generic path (band_factor / band_solve, tmx_qp.h) instead of the dense engine
   int band;
+  // ... and (round 4) the same path with DIFFERENCE ROWS of order 2 / 3 (JointAcc / JointJerk Ineq costs, Eq / Ineq constraints,
+  // trajectory_costs.cpp:556-754, :811-1016) when every row on several waypoints is such a single-joint row: all blocks they add
+  // to the reduced KKT matrix are diagonal (QpWs::cf / bk1..3, tmx_qp.h).  band = max(order of the costs, order of the rows).
+  int band_rows;
 };
 TMX_HOSTDEVFN int slot_is_diff(int kind) { return kind == SLOT_JOINTVEL || kind == SLOT_JOINTVEL_INEQ; }
 TMX_HOSTDEVFN int fx_is_quad(int kind) { return kind == 0 || kind == 1 || kind == 3; }  // instance owns a dynamic quadratic model
