@@ -1,6 +1,15 @@
 #include "hip_qp_problem.hpp"
 
 #include <trajopt_ifopt/core/constraint_set.h>
+#include <trajopt_ifopt/core/bounds.h>
+#include <trajopt_ifopt/constraints/joint_position_constraint.h>
+#include <trajopt_ifopt/constraints/joint_velocity_constraint.h>
+#include <trajopt_ifopt/constraints/collision/discrete_collision_constraint.h>
+#include <trajopt_ifopt/constraints/collision/discrete_collision_evaluators.h>
+#include <trajopt_ifopt/constraints/collision/continuous_collision_constraint.h>
+#include <trajopt_ifopt/constraints/collision/continuous_collision_evaluators.h>
+#include <trajopt_common/collision_types.h>
+#include <trajopt_sqp/types.h>
 
 #include <cmath>
 #include <iostream>
@@ -17,7 +26,134 @@ HipQPProblem::HipQPProblem(const tmx_problem_desc& desc, const Eigen::Ref<const 
   if (tmx_create(device, &ctx_) != TMX_OK)
     throw std::runtime_error("HipQPProblem: no usable HIP device (there is no CPU fallback behind this problem)");
   n_nlp_vars_ = x0.size();
+  lower_from_sets_ = desc.n_terms == 0;  // (b) of the class comment: the sets describe the terms
 }
+
+void HipQPProblem::setCollisionSubstates(double longest_valid_segment_length, int max_substates)
+{
+  if (set_up_)
+    throw std::runtime_error("HipQPProblem: setCollisionSubstates after setup()");
+  lvs_length_ = longest_valid_segment_length;
+  max_substates_ = max_substates;
+}
+
+namespace
+{
+tmx_term blankTerm()
+{
+  tmx_term t{};
+  t.max_substates = 0;
+  return t;
+}
+// the first decision variable a set touches = the smallest column of its (row-major, sparse) Jacobian; -1: no entry
+Eigen::Index firstColumn(const trajopt_ifopt::Jacobian& jac)
+{
+  Eigen::Index first = -1;
+  for (Eigen::Index k = 0; k < jac.outerSize(); ++k)
+    for (trajopt_ifopt::Jacobian::InnerIterator it(jac, k); it; ++it)
+      if (first < 0 || it.col() < first)
+        first = it.col();
+  return first;
+}
+}  // namespace
+
+// TrajOptQPProblem keeps the sets and calls their virtuals every convexification (trajopt_qp_problem.cpp:479-698); the device needs
+// what they compute as DATA.  Everything read here is public interface of the reference classes.
+void HipQPProblem::lowerSet(const trajopt_ifopt::ConstraintSet& set, bool is_cost, CostPenaltyType penalty_type)
+{
+  const Eigen::Index D = desc_->n_dof;
+  const std::string who = "HipQPProblem: set \"" + set.getName() + "\": ";
+  tmx_term t = blankTerm();
+  t.is_constraint = is_cost ? 0 : 1;
+  auto equalityTargets = [&](Eigen::Index rows_per_step) {
+    const std::vector<trajopt_ifopt::Bounds> b = set.getBounds();
+    const Eigen::VectorXd c = set.getCoefficients();
+    if (static_cast<Eigen::Index>(b.size()) != set.getRows() || c.size() != set.getRows() || set.getRows() % rows_per_step != 0)
+      throw std::runtime_error(who + "bounds / coefficients do not match the rows of the set");
+    for (Eigen::Index i = 0; i < set.getRows(); ++i)
+    {
+      if (b[static_cast<std::size_t>(i)].getLower() != b[static_cast<std::size_t>(i)].getUpper())
+        throw std::runtime_error(who + "only equality bounds (target == lower == upper) are lowered by the device path");
+      // one coefficient / target per joint, the same at every step the set covers (JointVelConstraint repeats them per step)
+      if (i >= D && (c(i) != c(i % D) || b[static_cast<std::size_t>(i)].getLower() != b[static_cast<std::size_t>(i % D)].getLower()))
+        throw std::runtime_error(who + "coefficients / targets that change from step to step are not lowered by the device path");
+    }
+    for (Eigen::Index j = 0; j < D; ++j)
+    {
+      t.coeffs[j] = c(j);
+      t.targets[j] = b[static_cast<std::size_t>(j)].getLower();
+    }
+  };
+  if (dynamic_cast<const trajopt_ifopt::JointPosConstraint*>(&set) != nullptr)
+  {
+    if (set.getRows() != D)
+      throw std::runtime_error(who + "a JointPosConstraint of one waypoint with one row per joint is expected (no split range bounds)");
+    if (is_cost && penalty_type != CostPenaltyType::kAbsolute)
+      throw std::runtime_error(who + "JointPosConstraint as a cost is lowered with CostPenaltyType::kAbsolute only");
+    equalityTargets(D);
+    const Eigen::Index col = firstColumn(set.getJacobian());
+    if (col < 0 || col % D != 0)
+      throw std::runtime_error(who + "cannot read the waypoint of the set off its Jacobian");
+    t.kind = is_cost ? TMX_TERM_JOINT_POS_EQ_COST : TMX_TERM_JOINT_POS_EQ_CNT;
+    t.first_step = t.last_step = static_cast<int32_t>(col / D);
+  }
+  else if (dynamic_cast<const trajopt_ifopt::JointVelConstraint*>(&set) != nullptr)
+  {
+    if (!is_cost || penalty_type != CostPenaltyType::kSquared)
+      throw std::runtime_error(who + "JointVelConstraint is lowered as a CostPenaltyType::kSquared cost set only");
+    equalityTargets(D);
+    const Eigen::Index col = firstColumn(set.getJacobian());
+    if (col < 0 || col % D != 0)
+      throw std::runtime_error(who + "cannot read the first waypoint of the set off its Jacobian");
+    t.kind = TMX_TERM_JOINT_VEL_COST;
+    t.first_step = static_cast<int32_t>(col / D);
+    t.last_step = t.first_step + static_cast<int32_t>(set.getRows() / D);  // rows = n_dof * (n_vars - 1)
+  }
+  else
+  {
+    const auto* dc = dynamic_cast<const trajopt_ifopt::DiscreteCollisionConstraint*>(&set);
+    const auto* cc = dynamic_cast<const trajopt_ifopt::ContinuousCollisionConstraint*>(&set);
+    if (dc == nullptr && cc == nullptr)
+      throw std::runtime_error(who + "this ConstraintSet class is not lowered by the device path (JointPosConstraint, JointVelConstraint, "
+                                     "Discrete / ContinuousCollisionConstraint are); describe the problem with a lowered term table instead");
+    if (is_cost && penalty_type != CostPenaltyType::kHinge)
+      throw std::runtime_error(who + "collision sets as costs are lowered with CostPenaltyType::kHinge only");
+    double margin = 0.0, coeff = 0.0, buffer = 0.0;
+    if (dc != nullptr)
+    {
+      const auto ev = dc->getCollisionEvaluator();
+      margin = ev->getCollisionMarginData().getMaxCollisionMargin();
+      coeff = ev->getCollisionCoeffData().getDefaultCollisionCoeff();
+      buffer = ev->getCollisionMarginBuffer();
+    }
+    else
+    {
+      const auto ev = cc->getCollisionEvaluator();
+      margin = ev->getCollisionMarginData().getMaxCollisionMargin();
+      coeff = ev->getCollisionCoeffData().getDefaultCollisionCoeff();
+      buffer = ev->getCollisionMarginBuffer();
+    }
+    t.kind = is_cost ? TMX_TERM_COLLISION_COST : TMX_TERM_COLLISION_CNT;
+    t.margin = margin;
+    t.coeff = coeff;
+    t.buffer = buffer;
+    // a segment set: LVS_DISCRETE (DiscreteCollisionConstraint of the trajopt_sqp examples works on one state; the segment form
+    // is the continuous one) / LVS_CONTINUOUS.  The segment = the waypoint of the first variable with a Jacobian entry when the
+    // set is in contact at the start point, otherwise the position of the set among the collision sets (one per segment, in order).
+    t.evaluator_type = dc != nullptr ? 2 : 4;
+    const Eigen::Index col = firstColumn(set.getJacobian());
+    const int32_t seg = col >= 0 ? static_cast<int32_t>(col / D) : n_collision_sets_;
+    if (seg != n_collision_sets_)
+      throw std::runtime_error(who + "collision sets must be added one per segment, in segment order");
+    ++n_collision_sets_;
+    t.first_step = seg;
+    t.last_step = seg + 1;
+    t.longest_valid_segment_length = lvs_length_;
+    t.max_substates = max_substates_;
+  }
+  (is_cost ? cost_terms_ : cnt_terms_).push_back(t);
+}
+
 
 HipQPProblem::~HipQPProblem() { tmx_destroy(ctx_); }
 
@@ -34,14 +170,18 @@ void HipQPProblem::addConstraintSet(std::shared_ptr<trajopt_ifopt::ConstraintSet
     throw std::runtime_error("HipQPProblem: addConstraintSet after setup()");
   cnt_names_.push_back(constraint_set->getName());
   rows_added_cnt_ += constraint_set->getRows();
+  if (lower_from_sets_)
+    lowerSet(*constraint_set, false, CostPenaltyType::kSquared);
 }
 
-void HipQPProblem::addCostSet(std::shared_ptr<trajopt_ifopt::ConstraintSet> constraint_set, CostPenaltyType /*penalty_type*/)
+void HipQPProblem::addCostSet(std::shared_ptr<trajopt_ifopt::ConstraintSet> constraint_set, CostPenaltyType penalty_type)
 {
   if (set_up_)
     throw std::runtime_error("HipQPProblem: addCostSet after setup()");
   cost_names_.push_back(constraint_set->getName());
   rows_added_cost_ += constraint_set->getRows();
+  if (lower_from_sets_)
+    lowerSet(*constraint_set, true, penalty_type);
 }
 
 void HipQPProblem::setup()
@@ -50,6 +190,19 @@ void HipQPProblem::setup()
   tmx_default_sqp_params(&sp);
   tmx_osqp_settings st;
   tmx_default_osqp_settings(&st);
+  if (lower_from_sets_)
+  {
+    if (cost_terms_.empty() && cnt_terms_.empty())
+      throw std::runtime_error("HipQPProblem: the description has no term table and no set was added");
+    // one segment collision term per set -> merge consecutive segments of equal parameters into one term per run is not needed:
+    // the device hatches one cost / constraint set per segment of a term either way
+    terms_ = cost_terms_;
+    terms_.insert(terms_.end(), cnt_terms_.begin(), cnt_terms_.end());
+    desc_lowered_ = *desc_;
+    desc_lowered_.terms = terms_.data();
+    desc_lowered_.n_terms = static_cast<int32_t>(terms_.size());
+    desc_ = &desc_lowered_;
+  }
   check(tmx_problem_upload(ctx_, desc_, &sp, &st), "setup");
   check(tmx_batch_set_x0(ctx_, x_.data(), 1), "setup");
   int32_t nc = 0, nv = 0, nslots = 0;

@@ -4,10 +4,14 @@
  * TrajOptQPProblem's slack-column QP layout, trajopt_qp_problem.cpp:479-698).  A reference trust_region_sqp_solver.cpp:87-159
  * `TrustRegionSQPSolver::solve(qp_problem)` drives it unchanged, with any QPSolver (OSQPEigenSolver or HipQPSolver).
  *
- * The ifopt constraint / cost sets of the reference keep their targets and coefficients private (joint_position_constraint.h:
- * 60-75), so the problem is LOWERED where the term tables exist: construct it from a tmx_problem_desc (flavor TMX_FLAVOR_SQP;
- * adapters/trajopt `lowerProblem`, or filled by hand as include/tmx_trajopt.hpp does).  addConstraintSet / addCostSet keep the
- * sets the caller still hands over for their NAMES and check that the row counts agree with the lowered terms.
+ * Two ways to describe the problem.  (a) A tmx_problem_desc WITH its term table (adapters/trajopt `lowerProblem`, or filled by hand
+ * as include/tmx_trajopt.hpp does): addConstraintSet / addCostSet then only take the NAMES of the sets and check the counts.
+ * (b) A description of the robot and the scene WITHOUT terms (n_terms = 0): the term table is LOWERED FROM THE SETS the caller
+ * hands to addConstraintSet / addCostSet, through their public interface - getBounds() / getCoefficients() / getJacobian()
+ * (sparsity = which waypoint) of trajopt_ifopt::JointPosConstraint (joint_position_constraint.h:77-92) and JointVelConstraint
+ * (joint_velocity_constraint.h:81-93), getCollisionEvaluator() of the discrete / continuous collision constraints
+ * (collision/discrete_collision_constraint.h:93, continuous_collision_constraint.h:100).  Any other set class, bound shape or
+ * penalty type throws: explicit, never a silent approximation.  A reference TrustRegionSQPSolver user describes the problem once.
  * Compiled inside a trajopt checkout (needs trajopt_sqp, trajopt_ifopt, Eigen); see adapters/README.md.
  */
 #pragma once
@@ -27,6 +31,10 @@ public:
   using Ptr = std::shared_ptr<HipQPProblem>;
   /** `desc` must outlive setup(); `x0`: the NLP variables (n_steps * n_dof, row-major) */
   HipQPProblem(const tmx_problem_desc& desc, const Eigen::Ref<const Eigen::VectorXd>& x0, int device = 0);
+  /** Sub-state capacity of the segment collision sets lowered from ifopt constraints (the evaluators keep their
+      CollisionCheckConfig private): longest_valid_segment_length and the row-slot capacity per (segment, link primitive, obstacle).
+      Defaults: no sub-states between two waypoints (capacity 2 = the two end states). */
+  void setCollisionSubstates(double longest_valid_segment_length, int max_substates);
   ~HipQPProblem() override;
   HipQPProblem(const HipQPProblem&) = delete;
   HipQPProblem& operator=(const HipQPProblem&) = delete;
@@ -68,8 +76,16 @@ private:
   void exportQP();
   void modelValues(const Eigen::Ref<const Eigen::VectorXd>& var_vals, Eigen::VectorXd& costs, Eigen::VectorXd& viols) const;
   void exactValues() const;
+  void lowerSet(const trajopt_ifopt::ConstraintSet& set, bool is_cost, CostPenaltyType penalty_type);
 
   const tmx_problem_desc* desc_;
+  // (b): the term table lowered from the ifopt sets, costs first then constraints (the device hatches them in that order)
+  bool lower_from_sets_{ false };
+  std::vector<tmx_term> cost_terms_, cnt_terms_, terms_;
+  tmx_problem_desc desc_lowered_{};
+  int n_collision_sets_{ 0 };
+  double lvs_length_{ 1e9 };
+  int max_substates_{ 2 };
   tmx_ctx* ctx_{ nullptr };
   bool set_up_{ false };
   Eigen::Index n_nlp_vars_{ 0 }, n_costs_{ 0 }, n_cnts_{ 0 }, n_qp_vars_{ 0 }, n_qp_cnts_{ 0 };

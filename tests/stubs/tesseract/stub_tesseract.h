@@ -25,7 +25,11 @@ using VectorIsometry3d = std::vector<Eigen::Isometry3d>;
 template <typename T>
 using AlignedVector = std::vector<T>;
 using TrajArray = Eigen::MatrixXd;
-struct CollisionMarginData;
+struct CollisionMarginData  // tesseract/common/collision_margin_data.h: the two accessors the adapters read
+{
+  double getDefaultCollisionMargin() const;
+  double getMaxCollisionMargin() const;
+};
 Eigen::VectorXd calcTransformError(const Eigen::Isometry3d& t1, const Eigen::Isometry3d& t2);
 }  // namespace common
 }  // namespace tesseract
@@ -162,6 +166,8 @@ class Visualization;
 }
 namespace collision
 {
+class DiscreteContactManager;    // tesseract/collision/fwd.h
+class ContinuousContactManager;
 enum class ContinuousCollisionType : std::uint8_t
 {
   CCType_None,
