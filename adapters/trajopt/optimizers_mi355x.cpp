@@ -135,9 +135,37 @@ void lowerKinematics(const ProblemConstructionInfo& pci, LoweredProblem& out)
         // spheres, and capsules (tesseract: a cylinder of `length` along the local z axis with hemispherical caps) as the sphere
         // swept from one cap centre to the other (tmx_problem_desc::link_sphere_axes; discrete evaluators only)
         const auto type = col->geometry->getType();
-        if (type != tesseract::geometry::GeometryType::SPHERE && type != tesseract::geometry::GeometryType::CAPSULE)
-          PRINT_AND_THROW("collision geometry of link " + link_name + " is neither a sphere nor a capsule: not lowered by the device path");
+        if (type != tesseract::geometry::GeometryType::SPHERE && type != tesseract::geometry::GeometryType::CAPSULE &&
+            type != tesseract::geometry::GeometryType::BOX)
+          // (convex meshes - tesseract::geometry::ConvexMesh, e.g. URDFs with tesseract:make_convex - go the same way as boxes: their
+          //  vertices as a hull; the class is not part of the trajopt tree this adapter is type-checked against)
+          PRINT_AND_THROW("collision geometry of link " + link_name + " is not a sphere, capsule or box: not lowered by the device path");
         const Eigen::Isometry3d g = prev_link.inverse() * tf0.at(link_name) * col->origin;
+        if (type == tesseract::geometry::GeometryType::BOX)
+        {
+          // a box LINK is a convex hull of its eight corners in the moving link's frame (tmx_problem_desc::link_hull; contacts by
+          // GJK / EPA, include/tmx_gjk.h) - boxbot.urdf of trajopt/test/cast_cost_unit.cpp
+          const auto box = std::static_pointer_cast<const tesseract::geometry::Box>(col->geometry);
+          tmx_link_sphere hs{};
+          hs.link = k;
+          hs.radius = 0.0;
+          while (out.link_hull.size() < 2 * out.link_spheres.size())
+            out.link_hull.push_back(0);
+          out.link_hull.push_back(static_cast<int32_t>(out.hull_vertices.size() / 3));
+          out.link_hull.push_back(8);
+          for (int sx = -1; sx <= 1; sx += 2)
+            for (int sy = -1; sy <= 1; sy += 2)
+              for (int sz = -1; sz <= 1; sz += 2)
+              {
+                const Eigen::Vector3d v = g * Eigen::Vector3d(0.5 * sx * box->getX(), 0.5 * sy * box->getY(), 0.5 * sz * box->getZ());
+                for (int q = 0; q < 3; ++q)
+                  out.hull_vertices.push_back(v[q]);
+              }
+          out.link_spheres.push_back(hs);
+          for (int q = 0; q < 3; ++q)
+            out.link_sphere_axes.push_back(0.0);
+          continue;
+        }
         double radius = 0.0, half = 0.0;
         if (type == tesseract::geometry::GeometryType::SPHERE)
           radius = std::static_pointer_cast<const tesseract::geometry::Sphere>(col->geometry)->getRadius();
@@ -478,6 +506,13 @@ void LoweredProblem::finalize()
   }
   desc.n_link_spheres = static_cast<int32_t>(link_spheres.size());
   desc.link_spheres = link_spheres.data();
+  if (!hull_vertices.empty())
+  {
+    link_hull.resize(2 * link_spheres.size(), 0);
+    desc.link_hull = link_hull.data();
+    desc.hull_vertices = hull_vertices.data();
+    desc.n_hull_vertices = static_cast<int32_t>(hull_vertices.size() / 3);
+  }
   desc.link_sphere_axes = (link_sphere_axes.size() == 3 * link_spheres.size() && !link_spheres.empty()) ? link_sphere_axes.data() : nullptr;
   desc.obstacle_axes = (obstacle_axes.size() == 3 * obstacles.size() && !obstacles.empty()) ? obstacle_axes.data() : nullptr;
   desc.obstacle_boxes = (obstacle_boxes.size() == 12 * obstacles.size() && !obstacles.empty()) ? obstacle_boxes.data() : nullptr;

@@ -35,6 +35,8 @@ struct LoweredProblem
   std::vector<tmx_obstacle_sphere> obstacles;
   std::vector<double> link_sphere_axes, obstacle_axes;  // capsules: 3 per primitive (zero = sphere); empty when every primitive is a sphere
   std::vector<double> obstacle_boxes;                    // boxes: 12 per obstacle (half extents, rotation; zero = not a box)
+  std::vector<int32_t> link_hull;                        // convex-hull links: 2 per link primitive (first vertex, count; 0 = sphere / capsule)
+  std::vector<double> hull_vertices;                     // 3 per vertex, link frame
   std::vector<std::string> cost_names, cnt_names;
   bool have_tool{ false };  // a pose term has written desc.tool (the device keeps ONE tool offset per problem; the reference one per term)
   void setTool(const Eigen::Isometry3d& source_frame_offset, const std::string& term_name);

@@ -297,6 +297,16 @@ typedef struct
   const double* mesh_triangles;
   int32_t n_mesh_triangles;
   int32_t pad4_;
+  /* optional CONVEX-HULL LINKS (round 4): link_hull = 2 ints per link primitive (first vertex, number of vertices; 0 vertices: the
+     primitive stays a sphere / capsule) into hull_vertices, 3 doubles per vertex in the LINK frame.  Such a primitive is the convex
+     hull of its vertices, rounded by the primitive's `radius` (>= 0; `center` unused); the cast evaluators sweep it between the two
+     states of a sub-segment (the convex hull of both placements, as tesseract's cast shapes).  Contacts against every obstacle
+     primitive by GJK / EPA on support functions (include/tmx_gjk.h): trajopt/src/collision_terms.cpp:655-691, :1064-1173 get them
+     from tesseract / Bullet.  Problems with hull links run on the piecewise driver (like function terms).                    */
+  const int32_t* link_hull;
+  const double* hull_vertices;
+  int32_t n_hull_vertices;
+  int32_t pad5_;
 } tmx_problem_desc;
 
 typedef enum

@@ -406,4 +406,83 @@ TMX_GM_FN void tmx_link_closest_to_obstacle(const double c[3], const double* e, 
   p[2] = c[2] + s * e[2];
 }
 
+/* ---- CONVEX-HULL LINKS (round 4): a link primitive given as a vertex cloud hv[nv][3] in the LINK frame, placed at (R0, t0) -
+ * or, for the cast evaluators, swept from (R0, t0) to (R1, t1): the convex hull of both placements, as tesseract's cast shapes are
+ * (trajopt/src/collision_terms.cpp:1064-1173; trajopt/test/cast_cost_unit.cpp:64-117 sweeps a box link) - against any obstacle
+ * primitive, by GJK / EPA on support functions (tmx_gjk.h).  Same outputs as tmx_link_closest_to_obstacle_b: p on the link's core,
+ * q on the obstacle's core, return 1 when the cores overlap (q - p then has the length of the penetration and points back out of the
+ * obstacle).  *tau (swept only) = the fraction of the sweep the contact belongs to, by the rule of tesseract's cast contacts: the
+ * support vertices v0, v1 of the link at the two poses in the contact direction n; the pose with the larger support owns the contact
+ * (tau = 0 / 1), equal supports (a contact on a face spanned between the poses) interpolate by the distances of p to v0 and v1. */
+#include "tmx_gjk.h"
+#define TMX_GM_SUP_TOL 1e-9
+TMX_GM_FN void tmx_obstacle_cvx(const double oc[3], const double* oa, const double* ob, const double* mesh, tmx_cvx* B)
+{
+  B->a = oc;
+  B->b = 0;
+  B->n = 0;
+  if (tmx_is_mesh(ob))
+  {
+    B->kind = 3;
+    B->a = mesh + (long)ob[2];
+    B->n = 3 * (int)ob[1];
+  }
+  else if (tmx_is_box(ob))
+  {
+    B->kind = 2;
+    B->b = ob;
+  }
+  else if (oa && (oa[0] * oa[0] + oa[1] * oa[1] + oa[2] * oa[2]) > TMX_GM_EPS)
+  {
+    B->kind = 1;
+    B->b = oa;
+  }
+  else
+    B->kind = 0;
+}
+TMX_GM_FN int tmx_hull_closest_to_obstacle(const double* hv, int nv, const double* R0, const double* t0, const double* R1, const double* t1,
+                                           const double oc[3], const double* oa, const double* ob, const double* mesh, double p[3], double q[3],
+                                           double* tau)
+{
+  tmx_cvx A, B;
+  A.kind = R1 ? 5 : 4;
+  A.a = hv;
+  A.b = 0;
+  A.n = nv;
+  for (int k = 0; k < 9; ++k)
+  {
+    A.R[k] = R0[k];
+    A.R2[k] = R1 ? R1[k] : R0[k];
+  }
+  for (int k = 0; k < 3; ++k)
+  {
+    A.t[k] = t0[k];
+    A.t2[k] = R1 ? t1[k] : t0[k];
+  }
+  tmx_obstacle_cvx(oc, oa, ob, mesh, &B);
+  const int inside = tmx_gjk_epa(&A, &B, p, q);
+  if (tau)
+  {
+    *tau = 0.0;
+    if (R1)
+    {
+      double n[3];
+      tmx_contact_normal(p, q, inside, n);
+      double v0[3], v1[3];
+      const double s0 = tmx_gjk_cloud_support(hv, nv, R0, t0, n, v0), s1 = tmx_gjk_cloud_support(hv, nv, R1, t1, n, v1);
+      if (s0 - s1 > TMX_GM_SUP_TOL)
+        *tau = 0.0;
+      else if (s1 - s0 > TMX_GM_SUP_TOL)
+        *tau = 1.0;
+      else
+      {
+        const double d0[3] = { p[0] - v0[0], p[1] - v0[1], p[2] - v0[2] }, d1[3] = { p[0] - v1[0], p[1] - v1[1], p[2] - v1[2] };
+        const double l0 = sqrt(d0[0] * d0[0] + d0[1] * d0[1] + d0[2] * d0[2]), l1 = sqrt(d1[0] * d1[0] + d1[1] * d1[1] + d1[2] * d1[2]);
+        *tau = (l0 + l1 > 0.0) ? l0 / (l0 + l1) : 0.5;
+      }
+    }
+  }
+  return inside;
+}
+
 #endif /* TMX_GEOM_H_ */

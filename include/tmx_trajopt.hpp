@@ -144,6 +144,10 @@ struct JointGroup
   }
   std::vector<tmx_link_sphere> link_spheres;
   std::vector<double> link_sphere_axes;  // ... or capsules: 3 per link sphere, link frame (swept from centre to centre + axis); empty = all spheres
+  // ... or convex hulls (round 4): 2 per link primitive (first vertex, number of vertices; 0 = sphere / capsule) into hull_vertices,
+  // 3 doubles per vertex in the link frame; the primitive's radius rounds the hull (tmx_problem_desc::link_hull; GJK / EPA contacts)
+  std::vector<int32_t> link_hull;
+  std::vector<double> hull_vertices;
   std::size_t numJoints() const { return joints.size(); }
 };
 
@@ -432,6 +436,12 @@ public:
     d.n_link_spheres = static_cast<int32_t>(kin_->link_spheres.size());
     d.link_spheres = kin_->link_spheres.data();
     d.link_sphere_axes = (kin_->link_sphere_axes.size() == 3 * kin_->link_spheres.size() && !kin_->link_spheres.empty()) ? kin_->link_sphere_axes.data() : nullptr;
+    if (kin_->link_hull.size() == 2 * kin_->link_spheres.size() && !kin_->hull_vertices.empty())
+    {
+      d.link_hull = kin_->link_hull.data();
+      d.hull_vertices = kin_->hull_vertices.data();
+      d.n_hull_vertices = static_cast<int32_t>(kin_->hull_vertices.size() / 3);
+    }
     d.n_obstacles = static_cast<int32_t>(env_ ? env_->obstacles.size() : 0);
     d.obstacles = env_ ? env_->obstacles.data() : nullptr;
     d.obstacle_axes = (env_ && env_->obstacle_axes.size() == 3 * env_->obstacles.size() && !env_->obstacles.empty()) ? env_->obstacle_axes.data() : nullptr;

@@ -745,3 +745,11 @@ int orc_detmath(int op, int n, const double* a, const double* b, double* out)
   return 0;
 }
 }
+
+// include/tmx_gjk.h / tmx_geom.h through the oracle build (tests/test_hull_geometry.py pins them against brute-force geometry): a
+// convex-hull link hv[nv][3] at (R0, t0) - swept to (R1, t1) when R1 is given - against one obstacle primitive
+extern "C" int orc_hull_contact(const double* hv, int nv, const double* R0, const double* t0, const double* R1, const double* t1, const double* oc,
+                                const double* oa, const double* ob, const double* mesh, double* p, double* q, double* tau)
+{
+  return tmx_hull_closest_to_obstacle(hv, nv, R0, t0, R1, t1, oc, oa, ob, mesh, p, q, tau);
+}

@@ -206,3 +206,19 @@ def run_kat():
     build()
     out = subprocess.run([os.path.join(_HERE, "_build", "orc_kat")], capture_output=True, text=True)
     return out.returncode, out.stdout
+
+
+def hull_contact(hv, R0, t0, oc, R1=None, t1=None, axis=None, box=None, mesh=None):
+    """tmx_hull_closest_to_obstacle (include/tmx_geom.h, tmx_gjk.h) as the oracle build compiles it: a convex-hull link at (R0, t0),
+    swept to (R1, t1) when given, against a point / segment (axis) / box (12-double record) / mesh obstacle ->
+    (inside, p on the link, q on the obstacle, tau)"""
+    f = lambda a: None if a is None else np.ascontiguousarray(a, np.float64)
+    hv, R0, t0, oc, R1, t1, axis, box, mesh = (f(a) for a in (hv, R0, t0, oc, R1, t1, axis, box, mesh))
+    p, q, tau = np.zeros(3), np.zeros(3), C.c_double(0.0)
+    g = lambda a: None if a is None else _p(a)
+    rec = box
+    if mesh is not None:
+        rec = np.array([-1.0, len(mesh.reshape(-1, 9)), 0.0] + [0.0] * 9)
+    ins = lib().orc_hull_contact(_p(hv), len(hv.reshape(-1, 3)), _p(R0), _p(t0), g(R1), g(t1), _p(oc), g(axis), g(rec), g(mesh), _p(p), _p(q),
+                                 C.byref(tau))
+    return ins, p, q, tau.value

@@ -1075,6 +1075,11 @@ struct Scene
   const double* boxOf(std::size_t o) const { return obstacle_boxes.empty() ? nullptr : obstacle_boxes.data() + 12 * o; }
   std::vector<double> mesh;  // triangle soup of the convex-mesh obstacles (their 12-double records carry the tag -1, count, offset)
   std::vector<double> link_axes;  // 3 per link sphere, link frame (capsule link = sphere swept from centre to centre + axis); empty: spheres
+  // convex-hull links (tmx_problem_desc::link_hull): per link primitive (first vertex, count; 0 = sphere / capsule) into hull_vertices
+  std::vector<int> link_hull;
+  std::vector<double> hull_vertices;
+  int hullCount(std::size_t s) const { return link_hull.empty() ? 0 : link_hull[2 * s + 1]; }
+  const double* hullOf(std::size_t s) const { return hull_vertices.data() + 3 * static_cast<std::size_t>(link_hull[2 * s]); }
   // world axis of link primitive s under the link pose T (false: a sphere)
   template <class TF>
   bool linkAxisWorld(std::size_t s, const TF& T, double e[3]) const
@@ -1116,7 +1121,11 @@ inline void calcContacts(const Chain& chain, const Scene& scene, const double* q
       double oq[3];  // closest point of the obstacle primitive to the link primitive's core (sphere centre / capsule segment)
       double e[3], pc[3];
       const bool capsule = scene.linkAxisWorld(s, T, e);
-      const int inside = tmx_link_closest_to_obstacle_b(c, capsule ? e : nullptr, ob.center, scene.axisOf(o), scene.boxOf(o), scene.mesh.data(), pc, oq);
+      // (convex-hull link: GJK / EPA on support functions, include/tmx_gjk.h - the same call as the kernels')
+      const int inside = scene.hullCount(s) > 0 ?
+                             tmx_hull_closest_to_obstacle(scene.hullOf(s), scene.hullCount(s), T.R, T.t, nullptr, nullptr, ob.center, scene.axisOf(o),
+                                                          scene.boxOf(o), scene.mesh.data(), pc, oq, nullptr) :
+                             tmx_link_closest_to_obstacle_b(c, capsule ? e : nullptr, ob.center, scene.axisOf(o), scene.boxOf(o), scene.mesh.data(), pc, oq);
       double nrm[3];
       const double len = tmx_contact_normal(pc, oq, inside, nrm);
       const double dist = len - ls.radius - ob.radius;
@@ -1356,7 +1365,16 @@ struct LvsEvaluatorData  // the contact model itself (shared by the sco terms be
           double tau = 0.0;
           double oq[3];  // closest point of the obstacle primitive (include/tmx_geom.h)
           int inside = 0;  // the link core point lies inside a box obstacle's core
-          if (cast)
+          if (scene->hullCount(s) > 0)
+          {
+            // convex-hull link at the sub-state, or swept over the sub-segment (the convex hull of both placements)
+            const Tf& Tb = cast ? poses[static_cast<std::size_t>(i + 1)][ls.link] : Ta;
+            inside = tmx_hull_closest_to_obstacle(scene->hullOf(s), scene->hullCount(s), Ta.R, Ta.t, cast ? Tb.R : nullptr, cast ? Tb.t : nullptr,
+                                                  ob.center, scene->axisOf(o), scene->boxOf(o), scene->mesh.data(), p, oq, cast ? &tau : nullptr);
+            c.tf0 = Ta;
+            c.tf1 = Tb;
+          }
+          else if (cast)
           {
             const Tf& Tb = poses[static_cast<std::size_t>(i + 1)][ls.link];
             double cb[3];
@@ -1561,6 +1579,33 @@ inline TrajProblem constructProblem(const tmx_problem_desc& d, const double* ini
   }
   if (d.link_sphere_axes)
     P.scene->link_axes.assign(d.link_sphere_axes, d.link_sphere_axes + 3 * d.n_link_spheres);
+  if (d.link_hull && d.hull_vertices)
+  {
+    P.scene->link_hull.assign(d.link_hull, d.link_hull + 2 * d.n_link_spheres);
+    P.scene->hull_vertices.assign(d.hull_vertices, d.hull_vertices + static_cast<std::size_t>(3) * d.n_hull_vertices);
+  }
+  // capsule links under a cast evaluator become two-vertex hulls rounded by their radius (the rule of tmx_problem_upload)
+  {
+    bool cast_term = false;
+    for (int k = 0; k < d.n_terms; ++k)
+      cast_term = cast_term || ((d.terms[k].kind == TMX_TERM_COLLISION_COST || d.terms[k].kind == TMX_TERM_COLLISION_CNT) && d.terms[k].evaluator_type >= 3);
+    if (cast_term && !P.scene->link_axes.empty())
+      for (int sp = 0; sp < d.n_link_spheres; ++sp)
+      {
+        double* a = P.scene->link_axes.data() + 3 * sp;
+        if (a[0] == 0.0 && a[1] == 0.0 && a[2] == 0.0)
+          continue;
+        if (P.scene->link_hull.empty())
+          P.scene->link_hull.assign(static_cast<std::size_t>(2) * d.n_link_spheres, 0);
+        P.scene->link_hull[2 * sp] = static_cast<int>(P.scene->hull_vertices.size() / 3);
+        P.scene->link_hull[2 * sp + 1] = 2;
+        for (int q = 0; q < 3; ++q)
+          P.scene->hull_vertices.push_back(d.link_spheres[sp].center[q]);
+        for (int q = 0; q < 3; ++q)
+          P.scene->hull_vertices.push_back(d.link_spheres[sp].center[q] + a[q]);
+        a[0] = a[1] = a[2] = 0.0;
+      }
+  }
   const int T = d.n_steps, D = d.n_dof;
   // TrajOptProb ctor :553-592
   std::vector<std::string> names;

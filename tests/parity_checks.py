@@ -98,6 +98,35 @@ def cfg(cid, T=None):
         ti = CartVelTermInfo(first_step=1, last_step=n - 2, max_displacement=0.07, is_constraint=(cid == 23))
         (pci.cnt_infos if cid == 23 else pci.cost_infos).append(ti)
         return pci, s, g
+    if cid in (45, 46, 47):
+        # CONVEX-HULL LINKS (include/tmx_gjk.h): the last two link spheres of the test arm become a box hull (rounded by 1 cm) and a
+        # wedge hull; 45 single-time-step cost against the sphere + a box obstacle, 46 LVS_CONTINUOUS (cast: hulls swept over the
+        # sub-segments) cost, 47 LVS_DISCRETE constraint with a convex-mesh obstacle on top
+        from trajopt_amd.problem import CollisionTermInfo
+        pci, s, g = configs.config_mini(collision_cnt=(cid == 47)) if T is None else configs.config_mini(T, collision_cnt=(cid == 47))
+        rob = pci.robot
+        box = np.array([[sx * 0.09, sy * 0.04, sz * 0.03] for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)]) + np.array([0.15, 0.0, 0.0])
+        wedge = np.array([[0.02, -0.03, -0.03], [0.02, 0.03, -0.03], [0.02, 0.0, 0.04], [0.2, -0.02, -0.02], [0.2, 0.02, -0.02], [0.2, 0.0, 0.02]])
+        rob.link_spheres = [rob.link_spheres[0], (2, (0.0, 0.0, 0.0), 0.01, ("hull", box)), (3, (0.0, 0.0, 0.0), 0.0, ("hull", wedge))]
+        (c0, r0) = pci.obstacles[0]
+        pci.obstacles = [(c0, r0), ((c0[0] - 0.2, c0[1] + 0.1, c0[2] + 0.12), 0.01, ("box", (0.06, 0.1, 0.05), None))]
+        if cid == 47:
+            from scipy.spatial import ConvexHull
+            V = np.array([[0.0, 0.0, 0.0], [0.12, 0.0, 0.0], [0.0, 0.12, 0.0], [0.0, 0.0, 0.12], [0.1, 0.1, 0.1]]) + np.array([c0[0] + 0.1, c0[1] - 0.25, c0[2] + 0.15])
+            H = ConvexHull(V)
+            tris = []
+            for simp, eq in zip(H.simplices, H.equations):
+                a, b, c = V[simp]
+                if np.cross(b - a, c - a) @ eq[:3] < 0:
+                    b, c = c, b
+                tris.append([a, b, c])
+            pci.obstacles.append(((0.0, 0.0, 0.0), 0.0, ("mesh", np.array(tris))))
+        for ti in pci.cost_infos + pci.cnt_infos:
+            if isinstance(ti, CollisionTermInfo) and cid != 45:
+                ti.evaluator_type = 4 if cid == 46 else 2
+                ti.longest_valid_segment_length = 0.12
+                ti.max_substates = 4
+        return pci, s, g
     if cid == 44:
         # AvoidSingularity over a joint SUBSET (subset_kin_): joints 1 .. 6 of the PR2 arm on an 8-waypoint glass_upright, ABS cost
         from trajopt_amd.problem import AvoidSingularityTermInfo

@@ -211,15 +211,28 @@ def test_convex_mesh_signed_distance_against_brute_force(tmp_path):
             assert abs(np.linalg.norm(np.array(q[:]) - p) - abs(sd)) < 1e-9
 
 
-def test_capsule_links_are_refused_by_the_cast_evaluators(hostemu_lib):
+def test_capsule_links_under_the_cast_evaluators(hostemu_lib, orc):
+    """Round 3 refused capsule links for evaluator types 3 / 4 (the swept volume of a capsule is not a capsule).  A capsule is the
+    convex hull of its two cap centres rounded by its radius: under a cast evaluator such links become two-vertex hulls
+    (tmx_problem_upload and the oracle apply the same rule) and go through GJK / EPA - stage by stage against the oracle."""
+    from trajopt_amd import abi, configs
     pci, s, g = pc.cfg(29)
     for ti in pci.cost_infos:
         if isinstance(ti, CollisionTermInfo):
-            ti.evaluator_type, ti.longest_valid_segment_length = 4, 0.1
+            ti.evaluator_type, ti.longest_valid_segment_length, ti.max_substates = 4, 0.12, 4
+    x0 = configs.seeds_for(9, pci, s, g, 3, sigma=0.05)
     ctx = runtime.Context(0, hostemu_lib)
-    from trajopt_amd import abi
-    with pytest.raises(runtime.TmxError, match="capsule links"):
-        ctx.upload(pci.to_desc(), abi.default_sqp_params(), abi.default_osqp_settings())
+    desc = pc.make_ctx_inputs(ctx, pci, x0)
+    pc.check_evaluate(ctx, orc, desc, x0, tol=1e-12)
+    pc.check_first_qp_structure(ctx, orc, desc, x0, 0, val_tol=1e-12)
+    assert all(same for same, _ in pc.check_first_qp_solve(ctx, orc, desc, x0))
+    ctx.set_x0(x0)
+    r, o, same, dx = pc.check_full_sqp(ctx, orc, desc, x0, exact=False)
+    assert (r["status"] == o["status"]).all() and (dx[same] <= 1e-5).all() and same.sum() >= 2
+    # the swept capsule against a sphere obstacle, by hand: a link capsule that only translates sweeps a rounded parallelogram
+    ins, p, q, tau = orc.hull_contact(np.array([[0.0, 0, 0], [0.0, 0.4, 0]]), np.eye(3), np.zeros(3), np.array([0.5, 0.2, 0.3]), R1=np.eye(3),
+                                      t1=np.array([1.0, 0.0, 0.0]))
+    assert not ins and abs(np.linalg.norm(q - p) - 0.3) < 1e-12 and 0.0 < tau < 1.0
     ctx.close()
 
 

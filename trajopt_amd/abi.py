@@ -134,6 +134,10 @@ class ProblemDesc(C.Structure):
         ("mesh_triangles", C.POINTER(C.c_double)),
         ("n_mesh_triangles", C.c_int32),
         ("pad4_", C.c_int32),
+        ("link_hull", C.POINTER(C.c_int32)),
+        ("hull_vertices", C.POINTER(C.c_double)),
+        ("n_hull_vertices", C.c_int32),
+        ("pad5_", C.c_int32),
     ]
 
 

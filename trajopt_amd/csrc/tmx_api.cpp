@@ -57,6 +57,7 @@ struct tmx_ctx
   int* h_tail{ nullptr };  // pinned, device-mapped word: 1 once the pool kernel of the pending launch has begun to retire workgroups
   bool dense{ false };      // DevProblem::qp_dense: Model::optimize() by k_qp_solve_dense
   bool band{ false };       // DevProblem::band: the pool driver launches k_sqp_pool_band
+  bool hull{ false };       // DevProblem::n_ls_hull > 0: the term kernels are the *_hull instantiations (GJK / EPA contacts)
   bool piecewise{ false };  // DevProblem::st: the piecewise driver runs optimize() (host loop) - dense problems and row-only function terms
   bool ws_in_hbm{ false };  // QP workspace > 160 KB of LDS: k_*_hbm kernels, workspace carved in HBM (long horizons)
   int mode{ 2 };  // optimize() driver: 0 = one launch chain per step, 1 = k_sqp_fused, 2 = k_sqp_pool (default)
@@ -1133,6 +1134,15 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
   P.n_stencil = n_stencil;
   P.qp_dense = qp_dense ? 1 : 0;
   P.st = (qp_dense || st_terms) ? 1 : 0;
+  // convex-hull links: their contact code (GJK / EPA) is instantiated in the piecewise kernels only (template flag HULL)
+  {
+    int n_hull = 0;
+    if (d->link_hull && d->hull_vertices)
+      for (int sp = 0; sp < d->n_link_spheres; ++sp)
+        n_hull += d->link_hull[2 * sp + 1] > 0 ? 1 : 0;
+    if (n_hull > 0)
+      P.st = 1;
+  }
   P.n_fx = (int)fx_t.size();
   P.n_fx_cost = n_fx_cost;
   // slots grouped by waypoint, ascending slot id inside a waypoint
@@ -1147,7 +1157,9 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
       wp_list[next[st[r]]++] = r;
   }
   std::vector<int> ls_link;
-  std::vector<double> ls_center, ls_radius, ob_center, ob_radius, ob_axis, ls_axis, ob_box;
+  std::vector<double> ls_center, ls_radius, ob_center, ob_radius, ob_axis, ls_axis, ob_box, hullv;
+  std::vector<int> ls_hull;
+  int n_ls_hull = 0;
   int n_ls_capsule = 0, n_ob_box = 0;
   for (int s = 0; s < d->n_link_spheres; ++s)
   {
@@ -1168,14 +1180,52 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
       cap = cap || a != 0.0;
     }
     n_ls_capsule += cap ? 1 : 0;
+    const int hn = (d->link_hull && d->hull_vertices) ? d->link_hull[2 * s + 1] : 0;
+    if (hn < 0 || (hn > 0 && (d->link_hull[2 * s] < 0 || d->link_hull[2 * s] + hn > d->n_hull_vertices)))
+    {
+      ctx->err = "link_hull: vertex range outside hull_vertices";
+      return TMX_ERR_INVALID;
+    }
+    if (hn > 0 && cap)
+    {
+      ctx->err = "a link primitive is at most one of capsule (link_sphere_axes) and convex hull (link_hull)";
+      return TMX_ERR_INVALID;
+    }
+    ls_hull.push_back(hn > 0 ? d->link_hull[2 * s] : 0);
+    ls_hull.push_back(hn);
+    n_ls_hull += hn > 0 ? 1 : 0;
   }
-  if (n_ls_capsule > 0)
+  P.n_ls_hull = n_ls_hull;
+  if (n_ls_hull > 0)
+    hullv.assign(d->hull_vertices, d->hull_vertices + (size_t)3 * d->n_hull_vertices);
+  // Capsule links under a cast evaluator (evaluator_type 3 / 4): the swept volume of a capsule is not a capsule, but a capsule IS the
+  // convex hull of its two cap centres rounded by its radius - such links become two-vertex hulls (every evaluator of the problem
+  // then sees them through GJK / EPA; the oracle applies the same rule, oracle/trajprob.hpp constructProblem)
+  {
+    bool cast_term = false;
     for (int k = 0; k < d->n_terms; ++k)
-      if ((d->terms[k].kind == TMX_TERM_COLLISION_COST || d->terms[k].kind == TMX_TERM_COLLISION_CNT) && d->terms[k].evaluator_type >= 3)
+      cast_term = cast_term || ((d->terms[k].kind == TMX_TERM_COLLISION_COST || d->terms[k].kind == TMX_TERM_COLLISION_CNT) && d->terms[k].evaluator_type >= 3);
+    if (cast_term && n_ls_capsule > 0)
+    {
+      for (int sp = 0; sp < d->n_link_spheres; ++sp)
       {
-        ctx->err = "capsule links: the cast evaluators (evaluator_type 3 / 4) sweep link spheres only";
-        return TMX_ERR_UNSUPPORTED;
+        const double* a = &ls_axis[3 * (size_t)sp];
+        if (a[0] == 0.0 && a[1] == 0.0 && a[2] == 0.0)
+          continue;
+        ls_hull[2 * (size_t)sp] = (int)(hullv.size() / 3);
+        ls_hull[2 * (size_t)sp + 1] = 2;
+        for (int q = 0; q < 3; ++q)
+          hullv.push_back(ls_center[3 * (size_t)sp + q]);
+        for (int q = 0; q < 3; ++q)
+          hullv.push_back(ls_center[3 * (size_t)sp + q] + a[q]);
+        ls_axis[3 * (size_t)sp] = ls_axis[3 * (size_t)sp + 1] = ls_axis[3 * (size_t)sp + 2] = 0.0;
+        ++n_ls_hull;
+        --n_ls_capsule;
       }
+      P.n_ls_hull = n_ls_hull;
+      P.st = 1;
+    }
+  }
   P.n_ls_capsule = n_ls_capsule;
   for (int o = 0; o < d->n_obstacles; ++o)
   {
@@ -1276,6 +1326,8 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
   UP(po, po);
   UP(pq, pq);
   UP(ls_axis, ls_axis);
+  UP(ls_hull, ls_hull);
+  UP(hull, hullv);
   UP(ob_box, ob_box);
   UP(mesh, mesh);
   UP(po2, po2);
@@ -1351,6 +1403,7 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
   ctx->dense = P.qp_dense != 0;
   ctx->piecewise = P.st != 0;
   ctx->band = P.band != 0;
+  ctx->hull = P.n_ls_hull > 0;
   if (ctx->dense)
   {
     // The dense engine inverts n x n (every rho update) and (n + active rows)^2 (polish) matrices by Gauss-Jordan, one workgroup per
@@ -1411,7 +1464,8 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
   {
     // the term / structure kernels of a long-horizon problem need more than the default 64 KB of dynamic LDS
     const void* small_kernels[] = { reinterpret_cast<const void*>(k_prepare), reinterpret_cast<const void*>(k_evaluate),
-                                    reinterpret_cast<const void*>(k_convexify), reinterpret_cast<const void*>(k_export_csc),
+                                    reinterpret_cast<const void*>(k_convexify), reinterpret_cast<const void*>(k_prepare_hull),
+                                    reinterpret_cast<const void*>(k_evaluate_hull), reinterpret_cast<const void*>(k_convexify_hull), reinterpret_cast<const void*>(k_export_csc),
                                     reinterpret_cast<const void*>(k_sqp_update), reinterpret_cast<const void*>(k_qp_solve_dense),
                                     reinterpret_cast<const void*>(k_model_values) };
     for (const void* k : small_kernels)
@@ -1585,7 +1639,10 @@ static tmx_status ensure_batch(tmx_ctx* ctx, int B)
 static tmx_status prepare_batch(tmx_ctx* ctx)
 {
   ctx->clock_started = false;  // Optimizer::initialize: the next run / launch starts optimize() and its clock
-  TMX_LAUNCH(k_prepare, ctx->hb.B, ctx->nt_small, ctx->smem_small, ctx->stream, ctx->dp, ctx->db);
+  if (ctx->hull)
+    TMX_LAUNCH(k_prepare_hull, ctx->hb.B, ctx->nt_small, ctx->smem_small, ctx->stream, ctx->dp, ctx->db);
+  else
+    TMX_LAUNCH(k_prepare, ctx->hb.B, ctx->nt_small, ctx->smem_small, ctx->stream, ctx->dp, ctx->db);
   HIPCHK(hipGetLastError());
   return TMX_OK;
 }
@@ -1838,7 +1895,8 @@ static tmx_status sqp_run_piecewise(tmx_ctx* ctx, int32_t max_steps, int32_t* n_
       return TMX_ERR_STATE;
     }
     TIMED(ctx->ms_convexify, (void)0,
-          TMX_LAUNCH(k_convexify, B, ctx->nt_small, ctx->smem_small, ctx->stream, ctx->dp, ctx->db, 0));
+          if (ctx->hull) TMX_LAUNCH(k_convexify_hull, B, ctx->nt_small, ctx->smem_small, ctx->stream, ctx->dp, ctx->db, 0);
+          else TMX_LAUNCH(k_convexify, B, ctx->nt_small, ctx->smem_small, ctx->stream, ctx->dp, ctx->db, 0));
     if (ctx->dense)
       TIMED(ctx->ms_admm, ctx->launches_admm++,
             TMX_LAUNCH(k_qp_solve_dense, B, ctx->nt_qp > 1 ? 256 : 1, ctx->smem_small, ctx->stream, ctx->dp, ctx->db, 0));
@@ -1848,7 +1906,8 @@ static tmx_status sqp_run_piecewise(tmx_ctx* ctx, int32_t max_steps, int32_t* n_
       TIMED(ctx->ms_admm, ctx->launches_admm++,
             TMX_LAUNCH(k_qp_solve, B, ctx->nt_qp, ctx->smem_qp, ctx->stream, ctx->dp, ctx->db, 0));
     TIMED(ctx->ms_evaluate, (void)0,
-          TMX_LAUNCH(k_evaluate, B, ctx->nt_small, ctx->smem_small, ctx->stream, ctx->dp, ctx->db, 1));
+          if (ctx->hull) TMX_LAUNCH(k_evaluate_hull, B, ctx->nt_small, ctx->smem_small, ctx->stream, ctx->dp, ctx->db, 1);
+          else TMX_LAUNCH(k_evaluate, B, ctx->nt_small, ctx->smem_small, ctx->stream, ctx->dp, ctx->db, 1));
     // sqp_update_block carves the model values AND the per-slot / velocity-term scratch of evaluate_terms behind them
     TMX_LAUNCH(k_sqp_update, B, 64, ctx->smem_small, ctx->stream, ctx->dp, ctx->db);
     HIPCHK(hipGetLastError());
@@ -2049,7 +2108,10 @@ tmx_status tmx_evaluate(tmx_ctx* ctx, double* cost_vals, double* cnt_viols)
   TMX_REFUSE_WHILE_PENDING(ctx);
   HIPCHK(hipSetDevice(ctx->device));
   const size_t B = ctx->hb.B;
-  TMX_LAUNCH(k_evaluate, ctx->hb.B, ctx->nt_small, ctx->smem_small, ctx->stream, ctx->dp, ctx->db, 0);
+  if (ctx->hull)
+    TMX_LAUNCH(k_evaluate_hull, ctx->hb.B, ctx->nt_small, ctx->smem_small, ctx->stream, ctx->dp, ctx->db, 0);
+  else
+    TMX_LAUNCH(k_evaluate, ctx->hb.B, ctx->nt_small, ctx->smem_small, ctx->stream, ctx->dp, ctx->db, 0);
   HIPCHK(hipGetLastError());
   tmx_status rc;
   if ((rc = d2h(ctx, cost_vals, ctx->hb.cost_vals, B * ctx->hp.n_costs)) != TMX_OK ||
@@ -2068,7 +2130,10 @@ tmx_status tmx_convexify(tmx_ctx* ctx, int32_t* active, double* coef, double* rh
   TMX_REFUSE_WHILE_PENDING(ctx);
   HIPCHK(hipSetDevice(ctx->device));
   const size_t B = ctx->hb.B;
-  TMX_LAUNCH(k_convexify, ctx->hb.B, ctx->nt_small, ctx->smem_small, ctx->stream, ctx->dp, ctx->db, 1);
+  if (ctx->hull)
+    TMX_LAUNCH(k_convexify_hull, ctx->hb.B, ctx->nt_small, ctx->smem_small, ctx->stream, ctx->dp, ctx->db, 1);
+  else
+    TMX_LAUNCH(k_convexify, ctx->hb.B, ctx->nt_small, ctx->smem_small, ctx->stream, ctx->dp, ctx->db, 1);
   HIPCHK(hipGetLastError());
   tmx_status rc;
   if ((rc = d2h(ctx, active, ctx->hb.active, B * ctx->hp.R)) != TMX_OK ||

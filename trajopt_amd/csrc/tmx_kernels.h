@@ -11,7 +11,10 @@
 // Optimizer::initialize + the head of optimize(): getClosestFeasiblePoint (quirk Q1: only the upper clamp
 // survives, modeling.cpp:260-271), state reset, persistent/constant rows, first exact evaluation
 // (optimizers.cpp:725, 761-767)
-TMX_KERNEL_LB(256) k_prepare(const DevProblem* P, const DevBatch* Bt)
+// HULL: the kernels of problems with convex-hull links (GJK / EPA contacts: ~10 KB of private arrays per lane) are instantiations of
+// their own - k_prepare_hull / k_evaluate_hull / k_convexify_hull - so that every other problem keeps kernels without that frame
+template <bool HULL>
+TMX_DEVFN void prepare_body(const DevProblem* P, const DevBatch* Bt)
 {
   TMX_SMEM(smem);
   const int b = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
@@ -71,10 +74,10 @@ TMX_KERNEL_LB(256) k_prepare(const DevProblem* P, const DevBatch* Bt)
   if (P->st)  // difference terms of order 2 / 3 (the ST instantiations live in the piecewise kernels only)
   {
     if (Bt->ws_hbm)
-      evaluate_terms<true>(P, x, Bt->cost_vals + (size_t)b * P->n_costs, Bt->cnt_viols + (size_t)b * P->n_cnts,
-                           Bt->ws_hbm + (size_t)b * (size_t)Bt->ws_hbm_stride, tid, NT);
+      evaluate_terms<true, HULL>(P, x, Bt->cost_vals + (size_t)b * P->n_costs, Bt->cnt_viols + (size_t)b * P->n_cnts,
+                                 Bt->ws_hbm + (size_t)b * (size_t)Bt->ws_hbm_stride, tid, NT);
     else
-      evaluate_terms<true>(P, x, Bt->cost_vals + (size_t)b * P->n_costs, Bt->cnt_viols + (size_t)b * P->n_cnts, smem, tid, NT);
+      evaluate_terms<true, HULL>(P, x, Bt->cost_vals + (size_t)b * P->n_costs, Bt->cnt_viols + (size_t)b * P->n_cnts, smem, tid, NT);
   }
   else if (Bt->ws_hbm)
     evaluate_terms(P, x, Bt->cost_vals + (size_t)b * P->n_costs, Bt->cnt_viols + (size_t)b * P->n_cnts,
@@ -82,6 +85,9 @@ TMX_KERNEL_LB(256) k_prepare(const DevProblem* P, const DevBatch* Bt)
   else
     evaluate_terms(P, x, Bt->cost_vals + (size_t)b * P->n_costs, Bt->cnt_viols + (size_t)b * P->n_cnts, smem, tid, NT);
 }
+
+TMX_KERNEL_LB(256) k_prepare(const DevProblem* P, const DevBatch* Bt) { prepare_body<false>(P, Bt); }
+TMX_KERNEL_LB(256) k_prepare_hull(const DevProblem* P, const DevBatch* Bt) { prepare_body<true>(P, Bt); }
 
 // descriptor of the compact row lists of problem b (per-problem scratch; nullptr members unless the problem carries them)
 TMX_DEVFN QpWs* compact_lists_of(QpWs& cw, const DevProblem* P, const DevBatch* Bt, int b)
@@ -94,7 +100,8 @@ TMX_DEVFN QpWs* compact_lists_of(QpWs& cw, const DevProblem* P, const DevBatch* 
 }
 
 // which = 0: exact costs/violations at x -> cost_vals/cnt_viols ; which = 1: at xnew -> new_* (skips DONE problems)
-TMX_KERNEL_LB(256) k_evaluate(const DevProblem* P, const DevBatch* Bt, int which)
+template <bool HULL>
+TMX_DEVFN void evaluate_body(const DevProblem* P, const DevBatch* Bt, int which)
 {
   TMX_SMEM(smem_lds);
   double* smem = TMX_WORK(smem_lds, Bt);
@@ -105,13 +112,16 @@ TMX_KERNEL_LB(256) k_evaluate(const DevProblem* P, const DevBatch* Bt, int which
   double* co = (which ? Bt->new_cost_vals : Bt->cost_vals) + (size_t)b * P->n_costs;
   double* vo = (which ? Bt->new_cnt_viols : Bt->cnt_viols) + (size_t)b * P->n_cnts;
   if (P->st)
-    evaluate_terms<true>(P, xv, co, vo, smem, tid, NT);
+    evaluate_terms<true, HULL>(P, xv, co, vo, smem, tid, NT);
   else
     evaluate_terms(P, xv, co, vo, smem, tid, NT);
 }
+TMX_KERNEL_LB(256) k_evaluate(const DevProblem* P, const DevBatch* Bt, int which) { evaluate_body<false>(P, Bt, which); }
+TMX_KERNEL_LB(256) k_evaluate_hull(const DevProblem* P, const DevBatch* Bt, int which) { evaluate_body<true>(P, Bt, which); }
 
 // convexify (K1, K3) + reference QP structure (K4) for problems in PHASE_CONVEXIFY (all problems if force)
-TMX_KERNEL_LB(256) k_convexify(const DevProblem* P, const DevBatch* Bt, int force)
+template <bool HULL>
+TMX_DEVFN void convexify_body(const DevProblem* P, const DevBatch* Bt, int force)
 {
   TMX_SMEM(smem_lds);
   double* smem = TMX_WORK(smem_lds, Bt);
@@ -129,7 +139,10 @@ TMX_KERNEL_LB(256) k_convexify(const DevProblem* P, const DevBatch* Bt, int forc
   double* coef = Bt->coef + (size_t)b * R * D;
   double* rhs = Bt->rhs + (size_t)b * R;
   const double* x = Bt->x + (size_t)b * P->NX;
-  convexify_terms(P, x, act, coef, Bt->coef2 + (size_t)b * P->n_link * D, rhs, smem, tid, NT, Bt->rowc + (size_t)b * R, Bt->qdyn + (size_t)b * P->NX);
+  if (HULL)  // (the instantiation with the convex-hull link contacts)
+    convexify_terms<true>(P, x, act, coef, Bt->coef2 + (size_t)b * P->n_link * D, rhs, smem, tid, NT, Bt->rowc + (size_t)b * R, Bt->qdyn + (size_t)b * P->NX);
+  else
+    convexify_terms(P, x, act, coef, Bt->coef2 + (size_t)b * P->n_link * D, rhs, smem, tid, NT, Bt->rowc + (size_t)b * R, Bt->qdyn + (size_t)b * P->NX);
   QpWs cwd;
   if (P->st)
   {
@@ -148,6 +161,8 @@ TMX_KERNEL_LB(256) k_convexify(const DevProblem* P, const DevBatch* Bt, int forc
     sqp2_begin_qp(P, Bt, b, smem, tid, NT);
 #endif
 }
+TMX_KERNEL_LB(256) k_convexify(const DevProblem* P, const DevBatch* Bt, int force) { convexify_body<false>(P, Bt, force); }
+TMX_KERNEL_LB(256) k_convexify_hull(const DevProblem* P, const DevBatch* Bt, int force) { convexify_body<true>(P, Bt, force); }
 
 // export of one problem's QP in reference CSC layout (tests / INTEGRATION: the S1 hand-off format)
 TMX_KERNEL k_export_csc(const DevProblem* P, const DevBatch* Bt, int b, CscOut out, int* dims_out, unsigned long long* hashes_out)

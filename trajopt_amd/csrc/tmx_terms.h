@@ -286,17 +286,39 @@ __device__ __attribute__((noinline)) static double swept_closest_b_nl(const doub
 {
   return tmx_swept_closest_to_obstacle_b(ca, e, oc, oa, ob, mesh, q, inside);
 }
+// convex-hull link against an obstacle primitive (GJK / EPA, include/tmx_gjk.h): cold, a few KB of private arrays
+__device__ __attribute__((noinline)) static int hull_closest_nl(const double* hv, int nv, const double* R0, const double* t0, const double* R1,
+                                                                const double* t1, const double* oc, const double* oa, const double* ob,
+                                                                const double* mesh, double* p, double* q, double* tau)
+{
+  return tmx_hull_closest_to_obstacle(hv, nv, R0, t0, R1, t1, oc, oa, ob, mesh, p, q, tau);
+}
 #else
 #define link_closest_b_nl tmx_link_closest_to_obstacle_b
 #define swept_closest_b_nl tmx_swept_closest_to_obstacle_b
+#define hull_closest_nl tmx_hull_closest_to_obstacle
 #endif
 
 // sphere-vs-sphere signed distance for contact slot (link sphere s, obstacle o) at joint values q
+// HULL: the instantiation carries the convex-hull link code (piecewise kernels of ST problems only)
+template <bool HULL = false>
 TMX_DEVFN double contact_distance(const DevProblem* P, const double* q, int s, int o, double n[3], double pw[3])
 {
   Tf3 L;
   const int link = P->ls_link[s];
   fk_link(P, q, link, L);
+  if constexpr (HULL)
+    if (P->n_ls_hull > 0 && P->ls_hull[2 * s + 1] > 0)
+    {
+      double pc[3], oq[3];
+      const int inside = hull_closest_nl(P->hull + 3 * P->ls_hull[2 * s], P->ls_hull[2 * s + 1], L.R, L.t, nullptr, nullptr, P->ob_center + 3 * o,
+                                         P->ob_axis + 3 * o, P->n_ob_box > 0 ? P->ob_box + 12 * o : nullptr, P->mesh, pc, oq, nullptr);
+      const double len = tmx_contact_normal(pc, oq, inside, n);
+      const double rs = P->ls_radius[s];
+      for (int r = 0; r < 3; ++r)
+        pw[r] = pc[r] + rs * n[r];
+      return len - rs - P->ob_radius[o];
+    }
   double c[3], d[3];
   for (int r = 0; r < 3; ++r)
     c[r] = L.R[3 * r + 0] * P->ls_center[3 * s + 0] + L.R[3 * r + 1] * P->ls_center[3 * s + 1] +
@@ -349,6 +371,7 @@ TMX_DEVFN double lin_spaced_at(int size, double low, double high, int i)
   return (i == size1) ? high : (low + (double)i * step);
 }
 // returns true if the slot holds a contact of the (filtered) result vector
+template <bool HULL = false>
 TMX_DEVFN bool lvs_contact(const DevProblem* P, const double* q0, const double* q1, int r, LvsContact& c)
 {
   const int D = P->D;
@@ -383,7 +406,21 @@ TMX_DEVFN bool lvs_contact(const DevProblem* P, const double* q0, const double* 
   double tau = 0.0;
   double oq[3];  // closest point of the obstacle primitive (include/tmx_geom.h)
   int inside = 0;  // the link core point lies inside a box obstacle's core
-  if (cast)
+  bool hull = false;
+  if constexpr (HULL)
+    hull = P->n_ls_hull > 0 && P->ls_hull[2 * s + 1] > 0;
+  if (hull)
+  {
+    // convex-hull link: at the sub-state (discrete) or swept over the sub-segment (cast: the convex hull of both placements)
+    if (cast)
+      fk_link_at(P, qb, link, Tb);
+    else
+      Tb = Ta;
+    inside = hull_closest_nl(P->hull + 3 * P->ls_hull[2 * s], P->ls_hull[2 * s + 1], Ta.R, Ta.t, cast ? Tb.R : nullptr, cast ? Tb.t : nullptr,
+                             P->ob_center + 3 * o, P->ob_axis + 3 * o, P->n_ob_box > 0 ? P->ob_box + 12 * o : nullptr, P->mesh, p, oq,
+                             cast ? &tau : nullptr);
+  }
+  else if (cast)
   {
     fk_link_at(P, qb, link, Tb);
     double cb[3];
@@ -1007,7 +1044,7 @@ TMX_HOSTDEVFN size_t tmx_eval_scratch_doubles(int R, int NX, int n_vel, int n_co
   return (size_t)R + (size_t)(R + 1) / 2 + (size_t)n_vel * NX + (size_t)n_vel + (size_t)n_costs + (size_t)n_cnts + 16;
 }
 // ST: the problem may hold rows / costs of difference order 2 and 3 (DevProblem::n_stencil, vel_kind 2 / 3)
-template <bool ST = false>
+template <bool ST = false, bool HULL = false>
 TMX_DEVFN void evaluate_terms(const DevProblem* P, const double* xv, double* cost_out, double* viol_out, double* scratch,
                               int tid, int NT)
 {
@@ -1021,7 +1058,7 @@ TMX_DEVFN void evaluate_terms(const DevProblem* P, const double* xv, double* cos
     if (kind == SLOT_COLLISION)
     {
       double n[3], pw[3];
-      const double dist = contact_distance(P, xv + t * D, P->slot_sub[r], P->slot_sub2[r], n, pw);
+      const double dist = contact_distance<HULL>(P, xv + t * D, P->slot_sub[r], P->slot_sub2[r], n, pw);
       const double margin = P->slot_aux1[r];
       if (!(dist > margin + P->slot_aux2[r]))
       {
@@ -1034,7 +1071,7 @@ TMX_DEVFN void evaluate_terms(const DevProblem* P, const double* xv, double* cos
     {
       // CollisionCost::value / CollisionConstraint::value over the segment's filtered contacts (collision_terms.cpp:1306-1327)
       LvsContact c;
-      if (lvs_contact(P, xv + t * D, xv + (t + 1) * D, r, c))
+      if (lvs_contact<HULL>(P, xv + t * D, xv + (t + 1) * D, r, c))
       {
         const double pv = P->slot_aux1[r] - c.distance;
         // flavour 1: calcBoundsViolations of the value margin - distance against (-inf, 0], UNWEIGHTED (the exact penalty
@@ -1360,6 +1397,8 @@ TMX_DEVFN void init_static_rows(const DevProblem* P, const double* x0, int* acti
 // LDS doubles needed by convexify_terms: per cart-pose instance (D+1) pose records of 7, the error vector (6) and the
 // finite-difference Jacobian (6 x D)
 TMX_HOSTDEVFN size_t tmx_cvx_scratch_doubles(int n_cp, int D) { return (size_t)n_cp * ((size_t)(D + 1) * 7 + 6 + 6 * (size_t)D) + 8; }
+// HULL: the instantiation carries the convex-hull link contacts (k_convexify of ST problems only)
+template <bool HULL = false>
 TMX_DEVFN void convexify_terms(const DevProblem* P, const double* xv, int* active, double* coef, double* coef2, double* rhs, double* scratch,
                                int tid, int NT, double* rowc = nullptr, double* qdyn = nullptr)
 {
@@ -1536,7 +1575,7 @@ TMX_DEVFN void convexify_terms(const DevProblem* P, const double* xv, int* activ
     const double* q1 = xv + (t + 1) * D;
     double* c2r = coef2 + (size_t)P->slot_c2[r] * D;
     LvsContact c;
-    if (!lvs_contact(P, q0, q1, r, c))
+    if (!lvs_contact<HULL>(P, q0, q1, r, c))
     {
       active[r] = 0;
       for (int k = 0; k < D; ++k)
@@ -1608,7 +1647,7 @@ TMX_DEVFN void convexify_terms(const DevProblem* P, const double* xv, int* activ
     const int s = P->slot_sub[r], o = P->slot_sub2[r];
     const int link = P->ls_link[s];
     double n[3], pw[3];
-    const double dist = contact_distance(P, q, s, o, n, pw);
+    const double dist = contact_distance<HULL>(P, q, s, o, n, pw);
     const double margin = P->slot_aux1[r];
     if (dist > margin + P->slot_aux2[r])
     {

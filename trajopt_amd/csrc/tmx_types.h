@@ -116,6 +116,12 @@ struct DevProblem
   // trajectory_costs.cpp:556-754, :811-1016) when every row on several waypoints is such a single-joint row: all blocks they add
   // to the reduced KKT matrix are diagonal (QpWs::cf / bk1..3, tmx_qp.h).  band = max(order of the costs, order of the rows).
   int band_rows;
+  // CONVEX-HULL LINKS (tmx_problem_desc::link_hull): per link primitive (first vertex, number of vertices; 0: sphere / capsule) into
+  // `hull` (3 doubles per vertex, link frame); n_ls_hull = number of hull primitives.  Their contacts (GJK / EPA, include/tmx_gjk.h)
+  // are compiled into the piecewise kernels only (template flag HULL of the term code): such problems set st.
+  int* ls_hull;
+  double* hull;
+  int n_ls_hull;
 };
 TMX_HOSTDEVFN int slot_is_diff(int kind) { return kind == SLOT_JOINTVEL || kind == SLOT_JOINTVEL_INEQ; }
 TMX_HOSTDEVFN int fx_is_quad(int kind) { return kind == 0 || kind == 1 || kind == 3; }  // instance owns a dynamic quadratic model

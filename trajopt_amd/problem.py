@@ -442,11 +442,19 @@ class ProblemConstructionInfo:
         # centre + axis (link frame)
         ls = (abi.LinkSphere * max(1, len(rob.link_spheres)))()
         ls_axes = (C.c_double * (3 * max(1, len(rob.link_spheres))))()
+        # ... or (link, centre, radius, ("hull", vertices[nv][3])) - the convex hull of the vertices (link frame) rounded by radius;
+        # contacts by GJK / EPA (include/tmx_gjk.h), the centre is unused
+        ls_hull = (C.c_int32 * (2 * max(1, len(rob.link_spheres))))()
+        hull_v = []
         for i, prim in enumerate(rob.link_spheres):
             link, c, r = prim[0], prim[1], prim[2]
             ls[i].link, ls[i].radius = link, r
             ls[i].center[:] = list(c)
-            if len(prim) > 3:
+            if len(prim) > 3 and isinstance(prim[3], tuple) and len(prim[3]) == 2 and prim[3][0] == "hull":
+                hv = np.asarray(prim[3][1], dtype=np.float64).reshape(-1, 3)
+                ls_hull[2 * i], ls_hull[2 * i + 1] = len(hull_v), len(hv)
+                hull_v += [list(row) for row in hv]
+            elif len(prim) > 3:
                 ls_axes[3 * i:3 * i + 3] = list(prim[3])
         # an obstacle is ((x, y, z), r) - a sphere - or ((x, y, z), r, (ax, ay, az)) - the capsule swept from centre to centre + axis
         # ... or ((x, y, z), r, ("box", (hx, hy, hz), R)) - the box of half extents h and rotation R (3x3, world_R_box; None = identity)
@@ -626,13 +634,19 @@ class ProblemConstructionInfo:
             d.obstacle_mesh = C.cast(ob_mesh, C.POINTER(C.c_int32))
             d.mesh_triangles = C.cast(mesh_arr, C.POINTER(C.c_double))
             d.n_mesh_triangles = len(tris)
-        if any(len(prim) > 3 for prim in rob.link_spheres):
+        is_hull = lambda prim: len(prim) > 3 and isinstance(prim[3], tuple) and len(prim[3]) == 2 and prim[3][0] == "hull"
+        if any(len(prim) > 3 and not is_hull(prim) for prim in rob.link_spheres):
             d.link_sphere_axes = C.cast(ls_axes, C.POINTER(C.c_double))
+        hull_arr = (C.c_double * max(1, 3 * len(hull_v)))(*[v for row in hull_v for v in row])
+        if hull_v:
+            d.link_hull = C.cast(ls_hull, C.POINTER(C.c_int32))
+            d.hull_vertices = C.cast(hull_arr, C.POINTER(C.c_double))
+            d.n_hull_vertices = len(hull_v)
         d.n_fixed_steps, d.n_terms = len(self.basic_info.fixed_timesteps), len(terms)
         d.fixed_steps, d.terms = fixed, tarr
         fdofs = (C.c_int32 * max(1, len(self.basic_info.fixed_dofs)))(*self.basic_info.fixed_dofs)
         d.n_fixed_dofs, d.fixed_dofs = len(self.basic_info.fixed_dofs), fdofs
         d.flavor = int(self.flavor)
-        self._keep = [ls, ls_axes, ob, ob_axes, ob_boxes, ob_mesh, mesh_arr, fixed, tarr, fdofs, keep_fixed]   # keep the pointed-to arrays alive
+        self._keep = [ls, ls_axes, ls_hull, hull_arr, ob, ob_axes, ob_boxes, ob_mesh, mesh_arr, fixed, tarr, fdofs, keep_fixed]   # keep the pointed-to arrays alive
         d._keep = self._keep
         return d
