@@ -275,9 +275,23 @@ void lowerTerm(const ProblemConstructionInfo& pci, const TermInfo& ti, bool is_c
   t.is_constraint = is_cost ? 0 : 1;
   std::vector<int32_t> fixed;
   std::vector<std::string> names{ ti.name };
-  if (static_cast<bool>(ti.term_type & TermType::TT_USE_TIME))
-    PRINT_AND_THROW(ti.name + ": time-parameterised terms (TT_USE_TIME) are not lowered by the device path");
-  if (const auto* jp = dynamic_cast<const JointPosTermInfo*>(&ti))
+  const bool with_time = static_cast<bool>(ti.term_type & TermType::TT_USE_TIME);
+  if (with_time && !pci.basic_info.use_time)  // ConstructProblem, problem_description.cpp:447-448
+    PRINT_AND_THROW("A term is using time and basic_info is not set correctly. Try basic_info.use_time = true");
+  if (with_time && !static_cast<bool>(ti.getSupportedTypes() & TermType::TT_USE_TIME))  // :427-428, :441-442
+    PRINT_AND_THROW(ti.name + " does not support time, but you listed it as a using time");
+  if (const auto* tt = dynamic_cast<const TotalTimeTermInfo*>(&ti))
+  {
+    // TotalTimeTermInfo::hatch  problem_description.cpp:1852-1890
+    if (!pci.basic_info.use_time)
+      PRINT_AND_THROW(ti.name + ": TotalTime needs the time variables (basic_info.use_time)");
+    t.kind = TMX_TERM_TOTAL_TIME;
+    t.first_step = 1;
+    t.last_step = n_steps - 1;
+    t.coeff = tt->coeff;
+    t.margin = tt->limit;
+  }
+  else if (const auto* jp = dynamic_cast<const JointPosTermInfo*>(&ti))
   {
     DblVec up = jp->upper_tols.empty() ? DblVec(D, 0) : jp->upper_tols, lo = jp->lower_tols.empty() ? DblVec(D, 0) : jp->lower_tols;
     const bool zero = allZero(up) && allZero(lo);  // :1113-1116
@@ -296,6 +310,14 @@ void lowerTerm(const ProblemConstructionInfo& pci, const TermInfo& ti, bool is_c
     const bool zero = allZero(up) && allZero(lo);
     t.kind = is_cost ? (zero ? TMX_TERM_JOINT_VEL_COST : TMX_TERM_JOINT_VEL_INEQ_COST) :
                        (zero ? TMX_TERM_JOINT_VEL_EQ_CNT : TMX_TERM_JOINT_VEL_INEQ_CNT);
+    if (with_time)
+    {
+      // :1244-1325: one TrajOptCostFromErrFunc / TrajOptConstraintFromErrFunc per joint, "name_j<j>"; expanded by the library
+      t.kind = TMX_TERM_JOINT_VEL_TIME;
+      names.clear();
+      for (std::size_t j = 0; j < D; ++j)
+        names.push_back(ti.name + "_j" + std::to_string(j));
+    }
     int first = jv->first_step, last = jv->last_step;
     clampSteps(first, last);
     t.first_step = first;
@@ -469,7 +491,7 @@ void lowerTerm(const ProblemConstructionInfo& pci, const TermInfo& ti, bool is_c
   }
   else
     PRINT_AND_THROW("term \"" + ti.name + "\" has a TermInfo class the device path does not lower (UserDefinedTermInfo with "
-                    "opaque callbacks, TotalTime): solve it with the reference's "
+                    "opaque callbacks): solve it with the reference's "
                     "BasicTrustRegionSQP, or with its QPs on the device through HipBatchedAdmmModel");
   auto& dst = is_cost ? out.cost_names : out.cnt_names;
   dst.insert(dst.end(), names.begin(), names.end());
@@ -528,10 +550,21 @@ void LoweredProblem::finalize()
 
 LoweredProblem lowerProblem(const ProblemConstructionInfo& pci, const TrajArray& init_traj, int max_substates)
 {
-  if (pci.basic_info.use_time)
-    PRINT_AND_THROW("basic_info.use_time: time-parameterised problems are not lowered by the device path");
   LoweredProblem out;
   out.desc.n_steps = pci.basic_info.n_steps;
+  // time-parameterised problems: the caller's init_traj carries the time column (generateInitTraj, problem_description.cpp:367-376)
+  out.desc.use_time = pci.basic_info.use_time ? 1 : 0;
+  out.desc.dt_lower_lim = pci.basic_info.dt_lower_lim;
+  out.desc.dt_upper_lim = pci.basic_info.dt_upper_lim;
+  if (pci.basic_info.use_time)
+  {
+    bool any = false;  // (:451-452)
+    for (const auto& lst : { pci.cost_infos, pci.cnt_infos })
+      for (const auto& ci : lst)
+        any = any || static_cast<bool>(ci->term_type & TermType::TT_USE_TIME);
+    if (!any)
+      PRINT_AND_THROW("No terms use time and basic_info is not set correctly. Try basic_info.use_time = false");
+  }
   lowerKinematics(pci, out);
   out.fixed_steps.assign(pci.basic_info.fixed_timesteps.begin(), pci.basic_info.fixed_timesteps.end());
   out.fixed_dofs.assign(pci.basic_info.fixed_dofs.begin(), pci.basic_info.fixed_dofs.end());

@@ -44,7 +44,7 @@ struct LoweredProblem
 };
 
 /** TermInfo::hatch for the device: throws std::runtime_error for every term class / option the device path does not lower
-    (UserDefinedTermInfo with opaque callbacks, TotalTime, use_time, custom CartPose error functions, link geometry other than spheres and capsules, obstacle geometry other than spheres, capsules and boxes) - explicit, never a silent CPU detour.
+    (UserDefinedTermInfo with opaque callbacks, custom CartPose error functions, link geometry other than spheres and capsules, obstacle geometry other than spheres, capsules and boxes) - explicit, never a silent CPU detour.
     `max_substates`: row-slot capacity of the LVS / continuous collision evaluators (0 = from the initial trajectory). */
 LoweredProblem lowerProblem(const ProblemConstructionInfo& pci, const TrajArray& init_traj, int max_substates = 0);
 }  // namespace trajopt

@@ -161,7 +161,20 @@ typedef enum
      constraint (is_constraint) or ABS cost per step over DynamicCartPoseErrCalculator / DynamicCartPoseJacCalculator
      (kinematic_terms.cpp:59-185): err = calcTransformError(target(q), source(q)) rows with |coeff| > 1e-5, forward-difference
      Jacobian through calcJacobianTransformErrorDiff(target, target', source, source').  Built-in function, dense QP engine. */
-  TMX_TERM_DYN_CART_POSE = 25
+  TMX_TERM_DYN_CART_POSE = 25,
+  /* TIME-PARAMETERISED PROBLEMS (tmx_problem_desc.use_time).  trajopt::JointVelTermInfo::hatch with TT_USE_TIME
+     (problem_description.cpp:1244-1325): PER JOINT j one TrajOptCostFromErrFunc / TrajOptConstraintFromErrFunc over the joint's
+     column and the time column of steps first_step .. last_step with JointVelErrCalculator / JointVelJacCalculator
+     (trajopt/src/kinematic_terms.cpp:427-470): vel_i = (x[i+1][j] - x[i][j]) * tau[i+1] (the time variable IS 1/dt); 2 (last - first)
+     error rows, first the upper ones  vel_i - target_j - upper_tol_j,  then the lower ones  lower_tol_j - (vel_i - target_j),  every
+     row with the coefficient coeffs[j].  Zero tolerances: sco::SQUARED cost / sco::EQ constraint, otherwise sco::HINGE / sco::INEQ.
+     is_constraint selects the constraint form.  n_dof costs (constraints) per term: the reference's "name_j<j>".           */
+  TMX_TERM_JOINT_VEL_TIME = 26,
+  /* trajopt::TotalTimeTermInfo::hatch  problem_description.cpp:1852-1890: ONE cost / constraint over the time variables of steps
+     1 .. n_steps - 1 with TimeCostCalculator / TimeCostJacCalculator (kinematic_terms.cpp:572-584): err = sum_t 1 / tau[t] - limit,
+     gradient -1 / tau[t]^2; coefficient `coeff`, limit `margin`; limit == 0: sco::SQUARED cost / sco::EQ constraint, otherwise
+     sco::HINGE / sco::INEQ.  The row touches every waypoint: dense QP engine.                                              */
+  TMX_TERM_TOTAL_TIME = 27
 } tmx_term_kind;
 
 /* ---- device-evaluable functions: a stack program over the n_dof values x[0..n_dof) of one waypoint -----------------------
@@ -306,7 +319,17 @@ typedef struct
   const int32_t* link_hull;
   const double* hull_vertices;
   int32_t n_hull_vertices;
-  int32_t pad5_;
+  /* BasicInfo::use_time (trajopt/include/trajopt/problem_description.hpp:150; TrajOptProb ctor problem_description.cpp:553-592):
+     every waypoint carries ONE more variable behind its n_dof joint values, the time variable tau = 1 / dt ("dt_<t>", bounds
+     dt_lower_lim / dt_upper_lim).  Trajectories handed to / returned by the library then have n_dof + 1 columns (variable index
+     t (n_dof + 1) + j), fixed_steps pin the joint columns only (:485-508), the trust box covers the time column like any other
+     variable.  A TMX_TERM_JOINT_VEL_TIME / TMX_TERM_TOTAL_TIME term needs it (:447-448); the converse check of the reference
+     (:451-452) is on TermInfo flags and is made by the front ends.  Problems whose time terms are ROWS only (velocity limits, hinge
+     costs) stay on the structured solvers; a TotalTime term or a squared velocity cost with time selects the dense QP engine
+     (<= 448 QP variables).  n_dof stays the number of JOINTS.                                                          */
+  int32_t use_time;
+  double dt_lower_lim;
+  double dt_upper_lim;
 } tmx_problem_desc;
 
 typedef enum

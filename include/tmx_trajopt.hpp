@@ -179,7 +179,7 @@ struct BasicInfo
   std::string manip;
   IntVec fixed_timesteps;
   IntVec fixed_dofs;
-  bool use_time{ false };  // time-parameterised problems are not lowered: ConstructProblem throws when set
+  bool use_time{ false };  // one (1/dt) variable per step behind the joints (problem_description.hpp:150); dense QP engine when a TotalTime term or a squared velocity cost uses it
   double dt_upper_lim{ 1.0 };
   double dt_lower_lim{ 1.0 };
 };
@@ -334,7 +334,16 @@ public:
   }
   int GetNumSteps() const { return n_steps_; }
   int GetNumDOF() const { return static_cast<int>(kin_->numJoints()); }
-  bool GetHasTime() const { return false; }
+  bool GetHasTime() const { return has_time_; }
+  void SetHasTime(bool tmp) { has_time_ = tmp; }
+  void setTimeLimits(double lower, double upper)
+  {
+    dt_lower_lim_ = lower;
+    dt_upper_lim_ = upper;
+  }
+  /** number of variables per step: the joints, plus the time column of a time-parameterised problem (TrajOptProb::GetNumDOF of the
+      reference counts the same, problem_description.hpp:300) */
+  int GetNumVarsPerStep() const { return GetNumDOF() + (has_time_ ? 1 : 0); }
   std::shared_ptr<const JointGroup> GetKin() const { return kin_; }
   std::shared_ptr<const Environment> GetEnv() const { return env_; }
   const TrajArray& GetInitTraj() const { return init_traj_; }
@@ -386,6 +395,9 @@ public:
     else if (t.kind == TMX_TERM_CART_VEL)  // one cost named after the term / one constraint "CartVel" per step (:1029-1050)
       for (int i = t.first_step; i <= t.last_step; ++i)
         names.push_back(t.is_constraint ? std::string("CartVel") : name);
+    else if (t.kind == TMX_TERM_JOINT_VEL_TIME)  // one cost / constraint per joint, name_j<j> (problem_description.cpp:1267-1283)
+      for (int j = 0; j < GetNumDOF(); ++j)
+        names.push_back(name + "_j" + std::to_string(j));
     else if (t.kind == TMX_TERM_AVOID_SINGULARITY)  // name_<step> (problem_description.cpp:1924)
       for (int i = t.first_step; i <= t.last_step; ++i)
         names.push_back(name + "_" + std::to_string(i));
@@ -400,7 +412,9 @@ public:
       names.push_back(name);
     const bool ineq = t.kind == TMX_TERM_JOINT_POS_INEQ_CNT || t.kind == TMX_TERM_COLLISION_CNT || t.kind == TMX_TERM_JOINT_VEL_INEQ_CNT ||
                       t.kind == TMX_TERM_JOINT_ACC_INEQ_CNT || t.kind == TMX_TERM_JOINT_JERK_INEQ_CNT || t.kind == TMX_TERM_CART_VEL ||
-                      (t.kind == TMX_TERM_FUNC_CNT && t.cnt_type == 1) || t.kind == TMX_TERM_AVOID_SINGULARITY;
+                      (t.kind == TMX_TERM_FUNC_CNT && t.cnt_type == 1) || t.kind == TMX_TERM_AVOID_SINGULARITY ||
+                      (t.kind == TMX_TERM_TOTAL_TIME && !(std::fabs(t.margin) < 1e-5)) || (t.kind == TMX_TERM_JOINT_VEL_TIME && time_ineq_);
+    time_ineq_ = false;
     std::vector<std::string>& dst = !t.is_constraint ? cost_names_ : (ineq ? ineq_cnt_names_ : eq_cnt_names_);
     dst.insert(dst.end(), names.begin(), names.end());
     terms_.push_back(t);
@@ -412,6 +426,8 @@ public:
       ++n_cost_terms_;
     }
   }
+  /** the next TMX_TERM_JOINT_VEL_TIME constraint handed to addTerm has non-zero tolerances (an inequality: its names go behind the equalities) */
+  void nextTimeTermIsIneq() { time_ineq_ = true; }
   void setFixed(const IntVec& steps, const IntVec& dofs)
   {
     fixed_steps_.assign(steps.begin(), steps.end());
@@ -465,6 +481,9 @@ public:
     }
     d.n_terms = static_cast<int32_t>(terms_.size());
     d.terms = terms_.data();
+    d.use_time = has_time_ ? 1 : 0;
+    d.dt_lower_lim = dt_lower_lim_;
+    d.dt_upper_lim = dt_upper_lim_;
     desc_ = d;
     return desc_;
   }
@@ -479,6 +498,8 @@ private:
   std::vector<std::vector<int32_t>> term_fixed32_;
   std::size_t n_cost_terms_{ 0 };
   std::vector<int32_t> fixed_steps_, fixed_dofs_;
+  bool has_time_{ false }, time_ineq_{ false };
+  double dt_lower_lim_{ 1.0 }, dt_upper_lim_{ 1.0 };
   std::vector<std::string> cost_names_, eq_cnt_names_, ineq_cnt_names_;
   struct FuncProgram
   {
@@ -626,10 +647,30 @@ struct JointVelTermInfo : public TermInfo
     detail::checkParameterSize(lower_tols, n_dof, "JointVelTermInfo lower_tols");
     if (first_step < 0)
       printAndThrow("JointVelEqCost, trajectory is too short!");  // trajectory_costs.cpp:269-270
-    if (static_cast<bool>(term_type & TermType::TT_USE_TIME))
-      printAndThrow("JointVelTermInfo: the time-parameterised forms are not lowered by the device path");
     const bool zero = detail::allZero(upper_tols) && detail::allZero(lower_tols);
     tmx_term t = detail::blankTerm();
+    if (static_cast<bool>(term_type & TermType::TT_USE_TIME))
+    {
+      // :1244-1325: per joint one TrajOptCostFromErrFunc (SQUARED / HINGE) or TrajOptConstraintFromErrFunc (EQ / INEQ) over
+      // JointVelErrCalculator / JointVelJacCalculator (kinematic_terms.cpp:427-470); lowered as one term, expanded per joint at upload
+      if (!prob.GetHasTime())
+        printAndThrow(name + " uses time but the problem has no time variables (basic_info.use_time)");
+      t.kind = TMX_TERM_JOINT_VEL_TIME;
+      t.is_constraint = static_cast<bool>(term_type & TermType::TT_COST) ? 0 : 1;
+      t.first_step = first_step;
+      t.last_step = last_step;
+      for (std::size_t j = 0; j < n_dof; ++j)
+      {
+        t.coeffs[j] = coeffs[j];
+        t.targets[j] = targets[j];
+        t.upper_tols[j] = upper_tols[j];
+        t.lower_tols[j] = lower_tols[j];
+      }
+      if (t.is_constraint && !zero)
+        prob.nextTimeTermIsIneq();
+      prob.addTerm(t, {}, name);
+      return;
+    }
     // :1246-1372 without use_time: zero tolerances -> JointVelEqCost / JointVelEqConstraint, else JointVelIneqCost /
     // JointVelIneqConstraint.  The constraint and hinge forms put rows on two consecutive waypoints; a library built without
     // TMX_LINK_ROWS refuses them at upload (TMX_ERR_UNSUPPORTED), which optimize() reports as an exception.
@@ -654,6 +695,34 @@ struct JointVelTermInfo : public TermInfo
       t.upper_tols[j] = upper_tols[j];
       t.lower_tols[j] = lower_tols[j];
     }
+    prob.addTerm(t, {}, name);
+  }
+};
+
+/** problem_description.hpp:617-640 ; hatch: problem_description.cpp:1852-1890 - penalises sum_t dt_t - limit over the time variables of
+    steps 1 .. n_steps - 1 (TimeCostCalculator / TimeCostJacCalculator, kinematic_terms.cpp:572-584); limit == 0 selects the SQUARED
+    cost / EQ constraint, otherwise HINGE / INEQ */
+struct TotalTimeTermInfo : public TermInfo
+{
+  double coeff{ 1.0 };
+  double limit{ 1.0 };
+  TotalTimeTermInfo() : TermInfo(TermType::TT_COST | TermType::TT_CNT | TermType::TT_USE_TIME) {}
+  void hatch(TrajOptProb& prob) override
+  {
+    if (!prob.GetHasTime())
+      printAndThrow(name + " uses time but the problem has no time variables (basic_info.use_time)");
+    tmx_term t = detail::blankTerm();
+    t.kind = TMX_TERM_TOTAL_TIME;
+    t.first_step = 1;
+    t.last_step = prob.GetNumSteps() - 1;
+    t.coeff = coeff;
+    t.margin = limit;
+    if (static_cast<bool>(term_type & TermType::TT_COST))
+      t.is_constraint = 0;
+    else if (static_cast<bool>(term_type & TermType::TT_CNT))
+      t.is_constraint = 1;
+    else
+      printAndThrow("A valid term type was not specified in TotalTimeTermInfo");  // :1886-1889
     prob.addTerm(t, {}, name);
   }
 };
@@ -1225,29 +1294,59 @@ inline TrajOptProb::Ptr ConstructProblem(const ProblemConstructionInfo& pci)
   if (n_steps < 1)
     printAndThrow("basic_info.n_steps must be positive");
   // term-type checks, :417-453
+  bool use_time = false;
   for (const TermInfo::Ptr& cost : pci.cost_infos)
   {
     if (!static_cast<bool>(cost->getSupportedTypes() & TermType::TT_COST))
       printAndThrow(cost->name + " is only a constraint, but you listed it as a cost");
     if (static_cast<bool>(cost->term_type & TermType::TT_USE_TIME))
-      printAndThrow(cost->name + ": time-parameterised terms (TT_USE_TIME) are not lowered by the device path");
+    {
+      use_time = true;
+      if (!static_cast<bool>(cost->getSupportedTypes() & TermType::TT_USE_TIME))
+        printAndThrow(cost->name + " does not support time, but you listed it as a using time");
+    }
   }
   for (const TermInfo::Ptr& cnt : pci.cnt_infos)
   {
     if (!static_cast<bool>(cnt->getSupportedTypes() & TermType::TT_CNT))
       printAndThrow(cnt->name + " is only a cost, but you listed it as a constraint");
     if (static_cast<bool>(cnt->term_type & TermType::TT_USE_TIME))
-      printAndThrow(cnt->name + ": time-parameterised terms (TT_USE_TIME) are not lowered by the device path");
+    {
+      use_time = true;
+      if (!static_cast<bool>(cnt->getSupportedTypes() & TermType::TT_USE_TIME))
+        printAndThrow(cnt->name + " does not support time, but you listed it as a using time");
+    }
   }
-  if (bi.use_time)
-    printAndThrow("basic_info.use_time: time-parameterised problems are not lowered by the device path");
+  if (use_time && !bi.use_time)  // :447-452
+    printAndThrow("A term is using time and basic_info is not set correctly. Try basic_info.use_time = true");
+  if (!use_time && bi.use_time)
+    printAndThrow("No terms use time and basic_info is not set correctly. Try basic_info.use_time = false");
+  if (bi.dt_lower_lim <= 0 || bi.dt_upper_lim < bi.dt_lower_lim)  // readBasicInfo :129-133
+    printAndThrow("dt limits (Basic Info) invalid. The lower limit must be positive, and the minimum upper limit is equal to the lower limit.");
 
   auto prob = std::make_shared<TrajOptProb>(n_steps, pci);
   const int n_dof = prob->GetNumDOF();
-  const TrajArray init_traj = detail::generateInitTraj(pci);
-  if (init_traj.rows() != n_steps || init_traj.cols() != n_dof)  // :471-479
+  TrajArray init_traj = detail::generateInitTraj(pci);
+  if (bi.use_time)
+  {
+    // "Currently all trajectories are generated without time then appended here" (:367-376): the time column is init_info.dt
+    if (n_dof + 1 > TMX_MAX_DOF)
+      printAndThrow("n_dof + 1 (time column) exceeds TMX_MAX_DOF");
+    prob->SetHasTime(true);
+    prob->setTimeLimits(bi.dt_lower_lim, bi.dt_upper_lim);
+    TrajArray with_time(init_traj.rows(), init_traj.cols() + 1);
+    for (int t = 0; t < init_traj.rows(); ++t)
+    {
+      for (int j = 0; j < init_traj.cols(); ++j)
+        with_time(t, j) = init_traj(t, j);
+      with_time(t, init_traj.cols()) = pci.init_info.dt;
+    }
+    init_traj = with_time;
+  }
+  const int n_cols = n_dof + (bi.use_time ? 1 : 0);
+  if (init_traj.rows() != n_steps || init_traj.cols() != n_cols)  // :460-481
     printAndThrow("Initial trajectory is not the right size matrix\nExpected " + std::to_string(n_steps) + " rows (time steps) x " +
-                  std::to_string(n_dof) + " columns\nGot " + std::to_string(init_traj.rows()) + " rows and " +
+                  std::to_string(n_cols) + " columns\nGot " + std::to_string(init_traj.rows()) + " rows and " +
                   std::to_string(init_traj.cols()) + " columns");
   prob->SetInitTraj(init_traj);
   for (const int t_idx : bi.fixed_timesteps)  // :485-508
@@ -1261,12 +1360,12 @@ inline TrajOptProb::Ptr ConstructProblem(const ProblemConstructionInfo& pci)
   // whatever its term_type says (the reference only warns, :420-421 / :434-435).
   for (const TermInfo::Ptr& ci : pci.cost_infos)
   {
-    ci->term_type = TermType::TT_COST;
+    ci->term_type = static_cast<bool>(ci->term_type & TermType::TT_USE_TIME) ? (TermType::TT_COST | TermType::TT_USE_TIME) : TermType::TT_COST;
     ci->hatch(*prob);
   }
   for (const TermInfo::Ptr& ci : pci.cnt_infos)
   {
-    ci->term_type = TermType::TT_CNT;
+    ci->term_type = static_cast<bool>(ci->term_type & TermType::TT_USE_TIME) ? (TermType::TT_CNT | TermType::TT_USE_TIME) : TermType::TT_CNT;
     ci->hatch(*prob);
   }
   return prob;
@@ -1565,7 +1664,7 @@ private:
       check(tmx_sqp_run(ctx_, 1, nullptr));
     }
   }
-  std::size_t numVars() const { return static_cast<std::size_t>(prob_->GetNumSteps()) * static_cast<std::size_t>(prob_->GetNumDOF()); }
+  std::size_t numVars() const { return static_cast<std::size_t>(prob_->GetNumSteps()) * static_cast<std::size_t>(prob_->GetNumVarsPerStep()); }
   void check(tmx_status s)
   {
     if (s != TMX_OK)
@@ -1602,7 +1701,7 @@ struct TrajOptResult
   TrajOptResult(const sco::OptResults& opt, const TrajOptProb& prob)
     : cost_names(prob.getCostNames()), cnt_names(prob.getCntNames()), cost_vals(opt.cost_vals), cnt_viols(opt.cnt_viols), status(opt.status)
   {
-    traj = TrajArray(prob.GetNumSteps(), prob.GetNumDOF());
+    traj = TrajArray(prob.GetNumSteps(), prob.GetNumVarsPerStep());
     traj.data = opt.x;  // getTraj: the vars are laid out row-major (j_t_d)
   }
 };

@@ -59,10 +59,14 @@ struct Value
     return num;
   }
   int asInt() const { return static_cast<int>(asDouble()); }
+  /** Json::Value::asBool(): booleans and numbers convert; a STRING does not ("Value is not convertible to bool") - which is what
+      "use_time" : "false" of trajopt_common/data/config/arm_around_table_time.json runs into in the reference (json_marshal.cpp:10-20) */
   bool asBool() const
   {
+    if (kind == NUMBER)
+      return num != 0.0;
     if (kind != BOOL)
-      printAndThrow("JSON value is not a bool");
+      printAndThrow("expected: bool, got a value that is not convertible to bool");
     return b;
   }
   const std::string& asString() const
@@ -247,8 +251,9 @@ inline Transform jsonOffset(const json::Value& p, const std::string& xyz_key, co
 inline TermInfo::Ptr readTerm(const json::Value& it, bool is_cost, const ProblemConstructionInfo& pci)
 {
   const std::string typ = it["type"].asString();
-  if (it.isMember("use_time") && it["use_time"].asBool())
-    printAndThrow(typ + ": use_time terms are not lowered by the device path");
+  // readCosts / readConstraints (problem_description.cpp:162-216): a term-level "use_time" sets TT_USE_TIME (and basic_info.use_time,
+  // done by the caller)
+  const bool term_time = it.isMember("use_time") && it["use_time"].asBool();
   if (!it.isMember("params"))
     printAndThrow(typ + ": missing params");
   const json::Value& p = it["params"];
@@ -256,7 +261,18 @@ inline TermInfo::Ptr readTerm(const json::Value& it, bool is_cost, const Problem
   const std::size_t D = pci.kin->numJoints();
   const int n_steps = pci.basic_info.n_steps;
   const DblVec ones(D, 1.0), zeros(D, 0.0);
-  const TermType tt = is_cost ? TermType::TT_COST : TermType::TT_CNT;
+  const TermType tt = term_time ? ((is_cost ? TermType::TT_COST : TermType::TT_CNT) | TermType::TT_USE_TIME) : (is_cost ? TermType::TT_COST : TermType::TT_CNT);
+  if (typ == "total_time")
+  {
+    // TotalTimeTermInfo::fromJson (problem_description.cpp:1839-1850)
+    ensureOnlyMembers(p, { "coeff", "limit" }, typ);
+    auto t = std::make_shared<TotalTimeTermInfo>();
+    t->coeff = jsonDouble(p, "coeff", 1.0);
+    t->limit = jsonDouble(p, "limit", 1.0);
+    t->name = name;
+    t->term_type = tt;
+    return t;
+  }
   if (typ == "joint_vel")
   {
     ensureOnlyMembers(p, { "coeffs", "first_step", "last_step", "targets", "lower_tols", "upper_tols", "use_time" }, typ);
@@ -292,7 +308,7 @@ inline TermInfo::Ptr readTerm(const json::Value& it, bool is_cost, const Problem
   }
   if (typ == "joint_pos")
   {
-    ensureOnlyMembers(p, { "coeffs", "first_step", "last_step", "targets", "lower_tols", "upper_tols" }, typ);
+    ensureOnlyMembers(p, { "coeffs", "first_step", "last_step", "targets", "lower_tols", "upper_tols", "use_time" }, typ);
     auto t = std::make_shared<JointPosTermInfo>();
     t->coeffs = jsonVec(p, "coeffs", D, &ones);
     t->targets = jsonVec(p, "targets", D, nullptr);
@@ -420,8 +436,7 @@ inline ProblemConstructionInfo ProblemConstructionInfoFromJson(const json::Value
   pci.basic_info.n_steps = bi["n_steps"].asInt();
   pci.basic_info.manip = bi["manip"].asString();
   pci.resolveKin();  // "Manipulator does not exist: ..." (:292)
-  if (bi.isMember("use_time") && bi["use_time"].asBool())
-    printAndThrow("basic_info.use_time (time-parameterised terms) is not lowered by the device path");
+  pci.basic_info.use_time = bi.isMember("use_time") && bi["use_time"].asBool();
   pci.basic_info.dt_lower_lim = detail::jsonDouble(bi, "dt_lower_lim", 1.0);
   pci.basic_info.dt_upper_lim = detail::jsonDouble(bi, "dt_upper_lim", 1.0);
   if (pci.basic_info.dt_lower_lim <= 0 || pci.basic_info.dt_upper_lim < pci.basic_info.dt_lower_lim)
@@ -479,10 +494,15 @@ inline ProblemConstructionInfo ProblemConstructionInfoFromJson(const json::Value
   if (v.isMember("constraints"))
     for (const auto& it : v["constraints"].arr)
       pci.cnt_infos.push_back(detail::readTerm(it, false, pci));
+  for (const auto& lst : { pci.cost_infos, pci.cnt_infos })  // (:178-181, :208-211)
+    for (const TermInfo::Ptr& ti : lst)
+      if (static_cast<bool>(ti->term_type & TermType::TT_USE_TIME))
+        pci.basic_info.use_time = true;
   // readInitInfo (:208-268)
   if (!v.isMember("init_info"))
     printAndThrow("Json missing required section init_info!");  // :306
   const json::Value& ii = v["init_info"];
+  pci.init_info.dt = detail::jsonDouble(ii, "dt", 1.0);  // :226
   std::string typ = ii["type"].asString();
   std::transform(typ.begin(), typ.end(), typ.begin(), [](unsigned char c) { return static_cast<char>(std::tolower(c)); });
   const int D = static_cast<int>(pci.kin->numJoints());

@@ -87,7 +87,7 @@ int orc_sqp_batch(const tmx_problem_desc* desc, const tmx_sqp_params* sqp, const
                   int* n_func_evals, int* n_qp_solves, tmx_qp_record* records, int max_records, int* rec_counts,
                   long long* admm_iters_total)
 {
-  const int TD = desc->n_steps * desc->n_dof;
+  const int TD = desc->n_steps * (desc->n_dof + (desc->use_time ? 1 : 0));
   long long admm_total = 0;
   int err = 0;
 #pragma omp parallel for schedule(dynamic) num_threads(nthreads > 0 ? nthreads : 1) reduction(+ : admm_total)
@@ -150,7 +150,7 @@ int orc_sqp_step_logs(const tmx_problem_desc* desc, const tmx_sqp_params* sqp, c
 {
   try
   {
-    const int TD = desc->n_steps * desc->n_dof;
+    const int TD = desc->n_steps * (desc->n_dof + (desc->use_time ? 1 : 0));
     TrajProblem P = constructProblem(*desc, x0);
     P.prob->getModel()->settings = toSettings(osqp);
     BasicTrustRegionSQP opt(P.prob);
@@ -214,7 +214,7 @@ int orc_sqp_active_sets(const tmx_problem_desc* desc, const tmx_sqp_params* sqp,
 {
   try
   {
-    const int TD = desc->n_steps * desc->n_dof;
+    const int TD = desc->n_steps * (desc->n_dof + (desc->use_time ? 1 : 0));
     TrajProblem P = constructProblem(*desc, x0);
     P.prob->getModel()->settings = toSettings(osqp);
     std::vector<QpTrace> trace;
@@ -251,7 +251,7 @@ int orc_evaluate(const tmx_problem_desc* desc, const double* x0_for_fixed, const
                  double* cnt_viols, int* n_costs, int* n_cnts)
 {
   TrajProblem P = constructProblem(*desc, x0_for_fixed);
-  const int TD = desc->n_steps * desc->n_dof;
+  const int TD = desc->n_steps * (desc->n_dof + (desc->use_time ? 1 : 0));
   const DblVec xv(x, x + TD);
   const auto& costs = P.prob->getCosts();
   const auto cnts = P.prob->getConstraints();
@@ -285,7 +285,7 @@ int orc_first_qp(const tmx_problem_desc* desc, const tmx_sqp_params* sqp, const 
   opt.getParameters().max_iter = 1;
   opt.getParameters().max_merit_coeff_increases = 1;
   opt.getParameters().improve_ratio_threshold = -std::numeric_limits<double>::infinity();
-  const int TD = desc->n_steps * desc->n_dof;
+  const int TD = desc->n_steps * (desc->n_dof + (desc->use_time ? 1 : 0));
   opt.initialize(DblVec(x, x + TD));
   // Run; the first Model::optimize() call is the one we want — capture it through the model's last CSC if only
   // one QP was solved, otherwise re-run with a trace limit is unnecessary: exact_merit_improve<0 still shrinks.
@@ -437,6 +437,8 @@ Sqp2Problem buildSqp2(const tmx_problem_desc& d, const double* x0)
   const int T = d.n_steps, D = d.n_dof;
   if (d.n_fixed_steps > 0 || d.n_fixed_dofs > 0)
     throw std::runtime_error("fixed steps / dofs are not part of the trajopt_sqp flavour");
+  if (d.use_time)
+    throw std::runtime_error("use_time is not part of the trajopt_sqp flavour (trajopt_ifopt has no time-parameterised sets)");
   Sqp2Problem P;
   P.vars = std::make_shared<ifopt::Variables>();
   P.vars->x.assign(x0, x0 + T * D);
@@ -543,7 +545,7 @@ int orc_sqp2_batch(const tmx_problem_desc* desc, const tmx_sqp_params* sqp, cons
                    int nthreads, double* x_out, int* status, double* total_cost, int* n_qp_solves, tmx_qp_record* records,
                    int max_records, int* rec_counts, double* cost_vals, double* cnt_viols)
 {
-  const int TD = desc->n_steps * desc->n_dof;
+  const int TD = desc->n_steps * (desc->n_dof + (desc->use_time ? 1 : 0));
   int err = 0;
 #pragma omp parallel for schedule(dynamic) num_threads(nthreads > 0 ? nthreads : 1)
   for (int b = 0; b < B; ++b)

@@ -48,7 +48,7 @@ def sqp_batch(desc, x0, sqp=None, osqp=None, nthreads=0, max_records=64):
     from trajopt_amd import abi
     x0 = np.ascontiguousarray(x0, dtype=np.float64)
     B = x0.shape[0]
-    TD = desc.n_steps * desc.n_dof
+    TD = desc.n_steps * (desc.n_dof + (1 if desc.use_time else 0))
     x = np.zeros((B, TD))
     status = np.zeros(B, np.int32)
     cost = np.zeros(B)
@@ -65,7 +65,7 @@ def sqp_batch(desc, x0, sqp=None, osqp=None, nthreads=0, max_records=64):
                              _p(cnts, C.c_int), C.byref(admm))
     if rc != 0:
         raise RuntimeError("oracle sqp_batch failed")
-    return dict(x=x.reshape(B, desc.n_steps, desc.n_dof), status=status, total_cost=cost, n_func_evals=nfe,
+    return dict(x=x.reshape(B, desc.n_steps, -1), status=status, total_cost=cost, n_func_evals=nfe,
                 n_qp_solves=nqp, records=recs, rec_counts=cnts, max_records=max_records, admm_iters=admm.value)
 
 
@@ -118,7 +118,7 @@ def sqp2_batch(desc, x0, sqp=None, osqp=None, nthreads=0, max_records=64):
     """TrustRegionSQPSolver::solve (trajopt_sqp flavour) for every seed"""
     from trajopt_amd import abi
     x0 = np.ascontiguousarray(x0, dtype=np.float64)
-    B, TD = x0.shape[0], desc.n_steps * desc.n_dof
+    B, TD = x0.shape[0], desc.n_steps * (desc.n_dof + (1 if desc.use_time else 0))
     q = sqp2_first_qp(desc, x0[0], sqp)
     nc, nn = len(q["exact_costs"]), len(q["exact_viols"])
     x = np.zeros((B, TD))
@@ -130,7 +130,7 @@ def sqp2_batch(desc, x0, sqp=None, osqp=None, nthreads=0, max_records=64):
                               _p(nqp, C.c_int), recs, max_records, _p(cnts, C.c_int), _p(cv), _p(vv))
     if rc != 0:
         raise RuntimeError("oracle sqp2_batch failed")
-    return dict(x=x.reshape(B, desc.n_steps, desc.n_dof), status=status, total_cost=cost, n_qp_solves=nqp, records=recs, rec_counts=cnts,
+    return dict(x=x.reshape(B, desc.n_steps, -1), status=status, total_cost=cost, n_qp_solves=nqp, records=recs, rec_counts=cnts,
                 max_records=max_records, cost_vals=cv, cnt_viols=vv)
 
 

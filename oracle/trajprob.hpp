@@ -1540,10 +1540,57 @@ private:
 };
 
 // ---- trajopt::ConstructProblem  problem_description.cpp:410-592 ------------------------------------
+// Eigen's `var_vals.cwiseInverse().sum()` (TimeCostCalculator, kinematic_terms.cpp:572-577) for a dynamic double vector: the
+// unvectorised default traversal is a plain left-to-right sum; with SSE2 packets (Eigen's default build on x86-64) the linear
+// vectorised reduction keeps two lanes (four from 8 elements on, unrolled by two) and adds them at the end.  The restatement
+// uses the packet order of a default x86-64 build (packet size 2); the kernels follow the same order (tmx_terms.h).
+inline double timeInverseSum(const DblVec& v)
+{
+  const std::size_t n = v.size();
+  auto inv = [&](std::size_t k) { return 1.0 / v[k]; };
+  const std::size_t ps = 2, aligned2 = (n / (2 * ps)) * (2 * ps), aligned = (n / ps) * ps;
+  if (n == 0)
+    return 0.0;
+  double res;
+  if (aligned)
+  {
+    double p0[2] = { inv(0), inv(1) };
+    if (aligned > ps)
+    {
+      double p1[2] = { inv(2), inv(3) };
+      for (std::size_t k = 2 * ps; k < aligned2; k += 2 * ps)
+      {
+        p0[0] += inv(k);
+        p0[1] += inv(k + 1);
+        p1[0] += inv(k + 2);
+        p1[1] += inv(k + 3);
+      }
+      p0[0] += p1[0];
+      p0[1] += p1[1];
+      if (aligned > aligned2)
+      {
+        p0[0] += inv(aligned2);
+        p0[1] += inv(aligned2 + 1);
+      }
+    }
+    res = p0[0] + p0[1];
+    for (std::size_t k = aligned; k < n; ++k)
+      res += inv(k);
+  }
+  else
+  {
+    res = inv(0);
+    for (std::size_t k = 1; k < n; ++k)
+      res += inv(k);
+  }
+  return res;
+}
+
 struct TrajProblem
 {
   std::shared_ptr<OptProb> prob;
-  VarArray traj_vars;
+  VarArray traj_vars;   // T x (n_dof + use_time): all problem variables (TrajOptProb::m_traj_vars)
+  VarArray joint_vars;  // T x n_dof: the joint columns (`vars.block(0, 0, vars.rows(), n_dof)` of every TermInfo::hatch)
   std::shared_ptr<Chain> chain;
   std::shared_ptr<Scene> scene;
   int n_costs{ 0 }, n_cnts{ 0 };
@@ -1606,25 +1653,48 @@ inline TrajProblem constructProblem(const tmx_problem_desc& d, const double* ini
         a[0] = a[1] = a[2] = 0.0;
       }
   }
-  const int T = d.n_steps, D = d.n_dof;
-  // TrajOptProb ctor :553-592
+  const int T = d.n_steps, D = d.n_dof, DV = d.n_dof + (d.use_time ? 1 : 0);
+  // TrajOptProb ctor :553-592 (with use_time: one "dt_<i>" variable per step behind the joints, bounds dt_lower_lim / dt_upper_lim)
+  if (d.use_time && (d.dt_lower_lim <= 0 || d.dt_upper_lim < d.dt_lower_lim))
+    throw std::runtime_error("dt limits (Basic Info) invalid. The lower limit must be positive, and the minimum upper limit is equal to the lower limit.");  // :129-133
+  {
+    // ConstructProblem :415-452: a term that uses time <=> basic_info.use_time
+    bool term_time = false;
+    for (int k = 0; k < d.n_terms; ++k)
+      term_time = term_time || d.terms[k].kind == TMX_TERM_JOINT_VEL_TIME || d.terms[k].kind == TMX_TERM_TOTAL_TIME;
+    if (term_time && !d.use_time)
+      throw std::runtime_error("A term is using time and basic_info is not set correctly. Try basic_info.use_time = true");
+  }
   std::vector<std::string> names;
   DblVec vlower, vupper;
   for (int i = 0; i < T; ++i)
+  {
     for (int j = 0; j < D; ++j)
     {
       names.push_back("j_" + std::to_string(i) + "_" + std::to_string(j));
       vlower.push_back(d.joint_lower[j]);
       vupper.push_back(d.joint_upper[j]);
     }
+    if (d.use_time)
+    {
+      names.push_back("dt_" + std::to_string(i));
+      vlower.push_back(d.dt_lower_lim);
+      vupper.push_back(d.dt_upper_lim);
+    }
+  }
   P.traj_vars.rows = T;
-  P.traj_vars.cols = D;
+  P.traj_vars.cols = DV;
   P.traj_vars.v = P.prob->createVariables(names, vlower, vupper);
-  // fixed timesteps :485-508
+  P.joint_vars.rows = T;
+  P.joint_vars.cols = D;
+  for (int i = 0; i < T; ++i)
+    for (int j = 0; j < D; ++j)
+      P.joint_vars.v.push_back(P.traj_vars(i, j));
+  // fixed timesteps :485-508 (the joint columns only)
   std::vector<int> fixed(d.fixed_steps, d.fixed_steps + d.n_fixed_steps);
   for (int t_idx : fixed)
     for (int j = 0; j < D; ++j)
-      P.prob->addLinearConstraint(exprSub(AffExpr(P.traj_vars(t_idx, j)), init_traj[t_idx * D + j]), EQ);
+      P.prob->addLinearConstraint(exprSub(AffExpr(P.traj_vars(t_idx, j)), init_traj[t_idx * DV + j]), EQ);
   // fixed dofs :510-530 — every timestep that is not already fixed
   for (int q = 0; q < d.n_fixed_dofs; ++q)
   {
@@ -1633,7 +1703,7 @@ inline TrajProblem constructProblem(const tmx_problem_desc& d, const double* ini
     {
       if (std::find(fixed.begin(), fixed.end(), i) != fixed.end())
         continue;
-      P.prob->addLinearConstraint(exprSub(AffExpr(P.traj_vars(i, dof)), AffExpr(init_traj[i * D + dof])), EQ);
+      P.prob->addLinearConstraint(exprSub(AffExpr(P.traj_vars(i, dof)), AffExpr(init_traj[i * DV + dof])), EQ);
     }
   }
   // hatch costs then constraints :532-540
@@ -1645,6 +1715,7 @@ inline TrajProblem constructProblem(const tmx_problem_desc& d, const double* ini
                           (tm.kind == TMX_TERM_JOINT_VEL_EQ_CNT) || (tm.kind == TMX_TERM_JOINT_VEL_INEQ_CNT) ||
                           (tm.kind == TMX_TERM_JOINT_ACC_EQ_CNT) || (tm.kind == TMX_TERM_JOINT_ACC_INEQ_CNT) || (tm.kind == TMX_TERM_FUNC_CNT) ||
                           (tm.kind == TMX_TERM_JOINT_JERK_EQ_CNT) || (tm.kind == TMX_TERM_JOINT_JERK_INEQ_CNT) ||
+                          ((tm.kind == TMX_TERM_JOINT_VEL_TIME || tm.kind == TMX_TERM_TOTAL_TIME) && tm.is_constraint) ||
                           ((tm.kind == TMX_TERM_CART_POSE || tm.kind == TMX_TERM_CART_VEL || tm.kind == TMX_TERM_AVOID_SINGULARITY ||
                             tm.kind == TMX_TERM_DYN_CART_POSE) &&
                            tm.is_constraint);
@@ -1653,21 +1724,21 @@ inline TrajProblem constructProblem(const tmx_problem_desc& d, const double* ini
       switch (tm.kind)
       {
         case TMX_TERM_JOINT_VEL_COST:
-          P.prob->addCost(std::make_shared<JointVelEqCost>(P.traj_vars, DblVec(tm.coeffs, tm.coeffs + D),
+          P.prob->addCost(std::make_shared<JointVelEqCost>(P.joint_vars, DblVec(tm.coeffs, tm.coeffs + D),
                                                            DblVec(tm.targets, tm.targets + D), tm.first_step, tm.last_step));
           break;
         case TMX_TERM_JOINT_VEL_EQ_CNT:
           P.prob->addConstraint(std::make_shared<JointVelEqConstraint>(
-              P.traj_vars, DblVec(tm.coeffs, tm.coeffs + D), DblVec(tm.targets, tm.targets + D), tm.first_step, tm.last_step));
+              P.joint_vars, DblVec(tm.coeffs, tm.coeffs + D), DblVec(tm.targets, tm.targets + D), tm.first_step, tm.last_step));
           break;
         case TMX_TERM_JOINT_VEL_INEQ_COST:
-          P.prob->addCost(std::make_shared<JointVelIneqCost>(P.traj_vars, DblVec(tm.coeffs, tm.coeffs + D), DblVec(tm.targets, tm.targets + D),
+          P.prob->addCost(std::make_shared<JointVelIneqCost>(P.joint_vars, DblVec(tm.coeffs, tm.coeffs + D), DblVec(tm.targets, tm.targets + D),
                                                              DblVec(tm.upper_tols, tm.upper_tols + D),
                                                              DblVec(tm.lower_tols, tm.lower_tols + D), tm.first_step, tm.last_step));
           break;
         case TMX_TERM_JOINT_VEL_INEQ_CNT:
           P.prob->addConstraint(std::make_shared<JointVelIneqConstraint>(
-              P.traj_vars, DblVec(tm.coeffs, tm.coeffs + D), DblVec(tm.targets, tm.targets + D), DblVec(tm.upper_tols, tm.upper_tols + D),
+              P.joint_vars, DblVec(tm.coeffs, tm.coeffs + D), DblVec(tm.targets, tm.targets + D), DblVec(tm.upper_tols, tm.upper_tols + D),
               DblVec(tm.lower_tols, tm.lower_tols + D), tm.first_step, tm.last_step));
           break;
         // user functions as tmx_expr programs over the variables of one waypoint: sco::CostFromFunc (numerical gradient and
@@ -1692,7 +1763,7 @@ inline TrajProblem constructProblem(const tmx_problem_desc& d, const double* ini
                 tmx_expr_eval(ops.data(), static_cast<int32_t>(ops.size() / 2), consts.data(), q.data(), o);
                 return o[0];
               };
-              P.prob->addCost(std::make_shared<CostFromFunc>(f, P.traj_vars.row(t), "func_cost", tm.full_hessian != 0));
+              P.prob->addCost(std::make_shared<CostFromFunc>(f, P.joint_vars.row(t), "func_cost", tm.full_hessian != 0));
             }
             else
             {
@@ -1708,10 +1779,10 @@ inline TrajProblem constructProblem(const tmx_problem_desc& d, const double* ini
               {
                 // TrajOptCostFromErrFunc without a Jacobian (UserDefinedTermInfo::hatch, problem_description.cpp:622-630)
                 const PenaltyType pt = tm.penalty_type == 0 ? SQUARED : (tm.penalty_type == 1 ? ABS : HINGE);
-                P.prob->addCost(std::make_shared<CostFromErrFunc>(g, MatrixOfVector(), P.traj_vars.row(t), c, pt, "func_err_cost"));
+                P.prob->addCost(std::make_shared<CostFromErrFunc>(g, MatrixOfVector(), P.joint_vars.row(t), c, pt, "func_err_cost"));
                 continue;
               }
-              P.prob->addConstraint(std::make_shared<ConstraintFromErrFunc>(g, MatrixOfVector(), P.traj_vars.row(t), c,
+              P.prob->addConstraint(std::make_shared<ConstraintFromErrFunc>(g, MatrixOfVector(), P.joint_vars.row(t), c,
                                                                             tm.cnt_type == 1 ? INEQ : EQ, "func_cnt"));
             }
           }
@@ -1721,45 +1792,45 @@ inline TrajProblem constructProblem(const tmx_problem_desc& d, const double* ini
         // the velocity family with the second / third difference
         case TMX_TERM_JOINT_ACC_EQ_COST:
         case TMX_TERM_JOINT_JERK_EQ_COST:
-          P.prob->addCost(std::make_shared<JointVelEqCost>(P.traj_vars, DblVec(tm.coeffs, tm.coeffs + D), DblVec(tm.targets, tm.targets + D),
+          P.prob->addCost(std::make_shared<JointVelEqCost>(P.joint_vars, DblVec(tm.coeffs, tm.coeffs + D), DblVec(tm.targets, tm.targets + D),
                                                            tm.first_step, tm.last_step, tm.kind == TMX_TERM_JOINT_ACC_EQ_COST ? 2 : 3));
           break;
         case TMX_TERM_JOINT_ACC_EQ_CNT:
         case TMX_TERM_JOINT_JERK_EQ_CNT:
-          P.prob->addConstraint(std::make_shared<JointVelEqConstraint>(P.traj_vars, DblVec(tm.coeffs, tm.coeffs + D),
+          P.prob->addConstraint(std::make_shared<JointVelEqConstraint>(P.joint_vars, DblVec(tm.coeffs, tm.coeffs + D),
                                                                        DblVec(tm.targets, tm.targets + D), tm.first_step, tm.last_step,
                                                                        tm.kind == TMX_TERM_JOINT_ACC_EQ_CNT ? 2 : 3));
           break;
         case TMX_TERM_JOINT_ACC_INEQ_COST:
         case TMX_TERM_JOINT_JERK_INEQ_COST:
-          P.prob->addCost(std::make_shared<JointVelIneqCost>(P.traj_vars, DblVec(tm.coeffs, tm.coeffs + D), DblVec(tm.targets, tm.targets + D),
+          P.prob->addCost(std::make_shared<JointVelIneqCost>(P.joint_vars, DblVec(tm.coeffs, tm.coeffs + D), DblVec(tm.targets, tm.targets + D),
                                                              DblVec(tm.upper_tols, tm.upper_tols + D), DblVec(tm.lower_tols, tm.lower_tols + D),
                                                              tm.first_step, tm.last_step, tm.kind == TMX_TERM_JOINT_ACC_INEQ_COST ? 2 : 3));
           break;
         case TMX_TERM_JOINT_ACC_INEQ_CNT:
         case TMX_TERM_JOINT_JERK_INEQ_CNT:
           P.prob->addConstraint(std::make_shared<JointVelIneqConstraint>(
-              P.traj_vars, DblVec(tm.coeffs, tm.coeffs + D), DblVec(tm.targets, tm.targets + D), DblVec(tm.upper_tols, tm.upper_tols + D),
+              P.joint_vars, DblVec(tm.coeffs, tm.coeffs + D), DblVec(tm.targets, tm.targets + D), DblVec(tm.upper_tols, tm.upper_tols + D),
               DblVec(tm.lower_tols, tm.lower_tols + D), tm.first_step, tm.last_step, tm.kind == TMX_TERM_JOINT_ACC_INEQ_CNT ? 2 : 3));
           break;
         case TMX_TERM_JOINT_POS_EQ_CNT:
           P.prob->addConstraint(std::make_shared<JointPosEqConstraint>(
-              P.traj_vars, DblVec(tm.coeffs, tm.coeffs + D), DblVec(tm.targets, tm.targets + D), tm.first_step, tm.last_step));
+              P.joint_vars, DblVec(tm.coeffs, tm.coeffs + D), DblVec(tm.targets, tm.targets + D), tm.first_step, tm.last_step));
           break;
         case TMX_TERM_JOINT_POS_EQ_COST:
-          P.prob->addCost(std::make_shared<JointPosEqCost>(P.traj_vars, DblVec(tm.coeffs, tm.coeffs + D),
+          P.prob->addCost(std::make_shared<JointPosEqCost>(P.joint_vars, DblVec(tm.coeffs, tm.coeffs + D),
                                                            DblVec(tm.targets, tm.targets + D), tm.first_step, tm.last_step));
           break;
         case TMX_TERM_JOINT_POS_INEQ_COST:
           P.prob->addCost(std::make_shared<JointPosIneqCost>(
-              P.traj_vars, DblVec(tm.coeffs, tm.coeffs + D), DblVec(tm.targets, tm.targets + D), DblVec(tm.upper_tols, tm.upper_tols + D),
+              P.joint_vars, DblVec(tm.coeffs, tm.coeffs + D), DblVec(tm.targets, tm.targets + D), DblVec(tm.upper_tols, tm.upper_tols + D),
               DblVec(tm.lower_tols, tm.lower_tols + D), tm.first_step, tm.last_step));
           break;
         case TMX_TERM_JOINT_POS_INEQ_CNT:
           // JointPosTermInfo::hatch with non-zero tolerances, TT_CNT  (problem_description.cpp:1150-1165); the OptProb sorts
           // it behind all equality constraints (modeling.cpp:234-241)
           P.prob->addConstraint(std::make_shared<JointPosIneqConstraint>(
-              P.traj_vars, DblVec(tm.coeffs, tm.coeffs + D), DblVec(tm.targets, tm.targets + D), DblVec(tm.upper_tols, tm.upper_tols + D),
+              P.joint_vars, DblVec(tm.coeffs, tm.coeffs + D), DblVec(tm.targets, tm.targets + D), DblVec(tm.upper_tols, tm.upper_tols + D),
               DblVec(tm.lower_tols, tm.lower_tols + D), tm.first_step, tm.last_step));
           break;
         case TMX_TERM_CART_POSE:
@@ -1781,9 +1852,9 @@ inline TrajProblem constructProblem(const tmx_problem_desc& d, const double* ini
           for (int t = tm.first_step; t <= tm.last_step; ++t)
           {
             if (tm.is_constraint)
-              P.prob->addConstraint(std::make_shared<ConstraintFromErrFunc>(f, dfdx, P.traj_vars.row(t), c, EQ, "cart_pose"));
+              P.prob->addConstraint(std::make_shared<ConstraintFromErrFunc>(f, dfdx, P.joint_vars.row(t), c, EQ, "cart_pose"));
             else
-              P.prob->addCost(std::make_shared<CostFromErrFunc>(f, dfdx, P.traj_vars.row(t), c, ABS, "cart_pose"));
+              P.prob->addCost(std::make_shared<CostFromErrFunc>(f, dfdx, P.joint_vars.row(t), c, ABS, "cart_pose"));
           }
           break;
         }
@@ -1801,9 +1872,9 @@ inline TrajProblem constructProblem(const tmx_problem_desc& d, const double* ini
           for (int t = tm.first_step; t <= tm.last_step; ++t)
           {
             if (tm.is_constraint)
-              P.prob->addConstraint(std::make_shared<ConstraintFromErrFunc>(f, dfdx, P.traj_vars.row(t), c, INEQ, "avoid_singularity"));
+              P.prob->addConstraint(std::make_shared<ConstraintFromErrFunc>(f, dfdx, P.joint_vars.row(t), c, INEQ, "avoid_singularity"));
             else
-              P.prob->addCost(std::make_shared<CostFromErrFunc>(f, dfdx, P.traj_vars.row(t), c, ABS, "avoid_singularity"));
+              P.prob->addCost(std::make_shared<CostFromErrFunc>(f, dfdx, P.joint_vars.row(t), c, ABS, "avoid_singularity"));
           }
           break;
         }
@@ -1827,9 +1898,9 @@ inline TrajProblem constructProblem(const tmx_problem_desc& d, const double* ini
           for (int t = tm.first_step; t <= tm.last_step; ++t)
           {
             if (tm.is_constraint)
-              P.prob->addConstraint(std::make_shared<ConstraintFromErrFunc>(f, dfdx, P.traj_vars.row(t), c, EQ, "dyn_cart_pose"));
+              P.prob->addConstraint(std::make_shared<ConstraintFromErrFunc>(f, dfdx, P.joint_vars.row(t), c, EQ, "dyn_cart_pose"));
             else
-              P.prob->addCost(std::make_shared<CostFromErrFunc>(f, dfdx, P.traj_vars.row(t), c, ABS, "dyn_cart_pose"));
+              P.prob->addCost(std::make_shared<CostFromErrFunc>(f, dfdx, P.joint_vars.row(t), c, ABS, "dyn_cart_pose"));
           }
           break;
         }
@@ -1868,8 +1939,8 @@ inline TrajProblem constructProblem(const tmx_problem_desc& d, const double* ini
           };
           for (int t = tm.first_step; t <= tm.last_step; ++t)
           {
-            VarVector vars = P.traj_vars.row(t);
-            const VarVector v1 = P.traj_vars.row(t + 1);
+            VarVector vars = P.joint_vars.row(t);
+            const VarVector v1 = P.joint_vars.row(t + 1);
             vars.insert(vars.end(), v1.begin(), v1.end());
             if (tm.is_constraint)
               P.prob->addConstraint(std::make_shared<ConstraintFromErrFunc>(f, dfdx, vars, DblVec(), INEQ, "CartVel"));
@@ -1890,8 +1961,8 @@ inline TrajProblem constructProblem(const tmx_problem_desc& d, const double* ini
               LvsEvaluator ev;
               ev.chain = P.chain;
               ev.scene = P.scene;
-              ev.vars0 = P.traj_vars.row(i);
-              ev.vars1 = P.traj_vars.row(i + 1);
+              ev.vars0 = P.joint_vars.row(i);
+              ev.vars1 = P.joint_vars.row(i + 1);
               ev.margin = tm.margin;
               ev.coeff = tm.coeff;
               ev.buffer = tm.buffer;
@@ -1915,15 +1986,94 @@ inline TrajProblem constructProblem(const tmx_problem_desc& d, const double* ini
           {
             for (int i = tm.first_step; i <= tm.last_step; ++i)
               if (std::find(tm.fixed_steps, tm.fixed_steps + tm.n_fixed_steps, i) == tm.fixed_steps + tm.n_fixed_steps)  // :1767, :1827
-                P.prob->addConstraint(std::make_shared<CollisionConstraintSingle>(P.chain, P.scene, P.traj_vars.row(i), tm.margin, tm.coeff,
+                P.prob->addConstraint(std::make_shared<CollisionConstraintSingle>(P.chain, P.scene, P.joint_vars.row(i), tm.margin, tm.coeff,
                                                                                   tm.buffer, "collision_" + std::to_string(i)));
             break;
           }
           for (int i = tm.first_step; i <= tm.last_step; ++i)
             if (std::find(tm.fixed_steps, tm.fixed_steps + tm.n_fixed_steps, i) == tm.fixed_steps + tm.n_fixed_steps)  // :1767, :1827
-              P.prob->addCost(std::make_shared<CollisionCostSingle>(P.chain, P.scene, P.traj_vars.row(i), tm.margin,
+              P.prob->addCost(std::make_shared<CollisionCostSingle>(P.chain, P.scene, P.joint_vars.row(i), tm.margin,
                                                                     tm.coeff, tm.buffer, "collision_" + std::to_string(i)));
           break;
+        case TMX_TERM_JOINT_VEL_TIME:
+        {
+          // JointVelTermInfo::hatch, TT_USE_TIME  problem_description.cpp:1244-1325
+          if (!d.use_time)
+            throw std::runtime_error("joint_vel with use_time: basic_info.use_time is not set");
+          bool zero_tols = true;
+          for (int j = 0; j < D; ++j)
+            zero_tols = zero_tols && std::fabs(tm.upper_tols[j]) < 1e-5 && std::fabs(tm.lower_tols[j]) < 1e-5;  // doubleEquals (trajopt_common/vector_ops.hpp:17)
+          const int n = tm.last_step - tm.first_step + 1, nv = n - 1;
+          for (int j = 0; j < D; ++j)
+          {
+            VarVector vars;
+            for (int i = tm.first_step; i <= tm.last_step; ++i)
+              vars.push_back(P.traj_vars(i, j));
+            for (int i = tm.first_step; i <= tm.last_step; ++i)
+              vars.push_back(P.traj_vars(i, DV - 1));
+            const double target = tm.targets[j], up = tm.upper_tols[j], lo = tm.lower_tols[j];
+            // JointVelErrCalculator / JointVelJacCalculator  kinematic_terms.cpp:427-470
+            VectorOfVector f = [target, up, lo](const DblVec& v) {
+              const int half = static_cast<int>(v.size() / 2), num = half - 1;
+              DblVec out(static_cast<std::size_t>(2 * num));
+              for (int i = 0; i < num; ++i)
+              {
+                const double vel = (v[i + 1] - v[i]) * v[half + 1 + i];
+                out[i] = -(up - (vel - target));
+                out[num + i] = lo - (vel - target);
+              }
+              return out;
+            };
+            MatrixOfVector dfdx = [](const DblVec& v) {
+              const int nvals = static_cast<int>(v.size()), half = nvals / 2, num = half - 1;
+              Mat jac(2 * num, nvals);
+              for (int i = 0; i < num; ++i)
+              {
+                const int ti = i + half + 1;
+                jac(i, i) = -1.0 * v[ti];
+                jac(i, i + 1) = 1.0 * v[ti];
+                jac(i, ti) = v[i + 1] - v[i];
+              }
+              for (int i = 0; i < num; ++i)
+                for (int k = 0; k < nvals; ++k)
+                  jac(num + i, k) = -jac(i, k);
+              return jac;
+            };
+            const DblVec c(static_cast<std::size_t>(2 * nv), tm.coeffs[j]);
+            const std::string name = "joint_vel_j" + std::to_string(j);
+            if (tm.is_constraint)
+              P.prob->addConstraint(std::make_shared<ConstraintFromErrFunc>(f, dfdx, vars, c, zero_tols ? EQ : INEQ, name));
+            else
+              P.prob->addCost(std::make_shared<CostFromErrFunc>(f, dfdx, vars, c, zero_tols ? SQUARED : HINGE, name));
+          }
+          break;
+        }
+        case TMX_TERM_TOTAL_TIME:
+        {
+          // TotalTimeTermInfo::hatch  problem_description.cpp:1852-1890; TimeCostCalculator / TimeCostJacCalculator kinematic_terms.cpp:572-584
+          if (!d.use_time)
+            throw std::runtime_error("total_time: basic_info.use_time is not set");
+          VarVector vars;
+          for (int i = 1; i < T; ++i)
+            vars.push_back(P.traj_vars(i, DV - 1));
+          const double limit = tm.margin;
+          const bool zero_limit = std::fabs(limit) < 1e-5;
+          VectorOfVector f = [limit](const DblVec& v) {
+            return DblVec{ timeInverseSum(v) - limit };
+          };
+          MatrixOfVector dfdx = [](const DblVec& v) {
+            Mat jac(1, static_cast<int>(v.size()));
+            for (std::size_t k = 0; k < v.size(); ++k)
+              jac(0, static_cast<int>(k)) = -1 * (1.0 / (v[k] * v[k]));
+            return jac;
+          };
+          const DblVec c{ tm.coeff };
+          if (tm.is_constraint)
+            P.prob->addConstraint(std::make_shared<ConstraintFromErrFunc>(f, dfdx, vars, c, zero_limit ? EQ : INEQ, "total_time"));
+          else
+            P.prob->addCost(std::make_shared<CostFromErrFunc>(f, dfdx, vars, c, zero_limit ? SQUARED : HINGE, "total_time"));
+          break;
+        }
         default:
           throw std::runtime_error("unknown term kind");
       }

@@ -832,7 +832,7 @@ static void caseJson(const Input& in)
     EXPECT_THROW_MSG(ConstructProblem("{\"init_info\": {\"type\": \"stationary\"}}", env), "Json missing required section basic_info!");
     EXPECT_THROW_MSG(ConstructProblem(head + "\"costs\": []}", env), "Json missing required section init_info!");
     EXPECT_THROW_MSG(ConstructProblem("{\"basic_info\": {\"n_steps\": 5, \"manip\": \"nope\"}, " + init, env), "Manipulator does not exist: nope");
-    EXPECT_THROW_MSG(ConstructProblem(head + "\"costs\": [{\"type\": \"total_time\", \"params\": {}}], " + init, env), "is not lowered by the device path");
+    EXPECT_THROW_MSG(ConstructProblem(head + "\"costs\": [{\"type\": \"total_time\", \"params\": {}}], " + init, env), "uses time but the problem has no time variables");
     EXPECT_THROW_MSG(ConstructProblem(head + "\"costs\": [{\"type\": \"joint_acc\", \"params\": {}}], " + init, env), "missing required field \"targets\"");
     {
       // joint_acc / joint_jerk (problem_description.cpp:1374-1391, :1495-1513) are lowered: one cost, one inequality constraint
@@ -854,6 +854,66 @@ static void caseJson(const Input& in)
     EXPECT_THROW_MSG(ConstructProblem(head + "\"costs\": [, " + init, env), "JSON parse error");
   }
   std::printf("JSON done\n");
+}
+
+// ---- time-parameterised problems (BasicInfo::use_time, problem_description.cpp:127, :162-216, :367-376, :415-452, :553-592) -------
+static void caseTime(const Input& in)
+{
+  auto env = makeEnv(in, "right_arm", "pr2_right_arm", in.vectors.at("cfg0_start"), true);
+  env->link_frames["base_footprint"] = Transform::Identity();
+  {
+    // trajopt_common/data/config/arm_around_table_time.json AS IT IS: "use_time" : "false" is a STRING, which Json::Value::asBool()
+    // does not convert - the reference throws while reading the costs (json_marshal.cpp:10-20)
+    EXPECT_THROW_MSG(ConstructProblem(slurp(in.files.at("arm_around_table_time")), env), "expected: bool");
+  }
+  {
+    // the same file with its two strings written as booleans (tests/test_time_terms.py writes it): joint_pos with use_time switches
+    // the time column on (and "does not differ based on setting of TermType::TT_USE_TIME", problem_description.cpp:1124-1125)
+    tmx::sco::BasicTrustRegionSQPParameters opt_info;
+    auto prob = ConstructProblem(slurp(in.files.at("arm_around_table_time_bool")), env, &opt_info);
+    EXPECT_TRUE(prob->GetHasTime() && prob->GetNumVarsPerStep() == 8 && prob->GetNumSteps() == 10);
+    const tmx_problem_desc& d = prob->desc();
+    EXPECT_TRUE(d.use_time == 1 && d.n_dof == 7 && d.dt_lower_lim == 1.0 && d.dt_upper_lim == 1.0);
+    const TrajArray& init = prob->GetInitTraj();
+    EXPECT_TRUE(init.rows() == 10 && init.cols() == 8 && init(0, 7) == 0.12341234 && init(9, 7) == 0.12341234);
+    std::printf("INIT time_fixture");
+    for (double v : init.data)
+      std::printf(" %a", v);
+    std::printf("\n");
+    BasicTrustRegionSQPBatchedHip opt(prob);
+    opt.setParameters(opt_info);
+    opt.initialize(tmx::sco::trajToDblVec(init));
+    opt.optimize();
+    printResults("time_fixture", opt);
+  }
+  {
+    // a problem whose terms do use the time column: squared velocity cost with time, TotalTime hinge cost, velocity limits with time
+    auto prob = ConstructProblem(slurp(in.files.at("time_terms")), env);
+    EXPECT_TRUE(prob->GetHasTime() && prob->getNumCosts() == 2 && prob->getNumConstraints() == 2);
+    const std::vector<std::string>& cn = prob->getCostNames();
+    EXPECT_TRUE(cn.size() == 8 && cn[0] == "vel_t_j0" && cn[6] == "vel_t_j6" && cn[7] == "total_time");
+    const std::vector<std::string> nn = prob->getCntNames();
+    EXPECT_TRUE(nn.size() == 8 && nn[0] == "joint_pos" && nn[1] == "vel_lim_j0" && nn[7] == "vel_lim_j6");
+    std::printf("INIT time_terms");
+    for (double v : prob->GetInitTraj().data)
+      std::printf(" %a", v);
+    std::printf("\n");
+    BasicTrustRegionSQPBatchedHip opt(prob);
+    opt.initialize(tmx::sco::trajToDblVec(prob->GetInitTraj()));
+    opt.optimize();
+    printResults("time_terms", opt);
+  }
+  {
+    const std::string head = "{\"basic_info\": {\"n_steps\": 5, \"manip\": \"right_arm\", \"use_time\": true}, ";
+    const std::string init = "\"init_info\": {\"type\": \"stationary\"}}";
+    EXPECT_THROW_MSG(ConstructProblem(head + "\"costs\": [{\"type\": \"joint_vel\", \"params\": {\"targets\": [0,0,0,0,0,0,0]}}], " + init, env),
+                     "No terms use time and basic_info is not set correctly");
+    EXPECT_THROW_MSG(ConstructProblem(head + "\"costs\": [{\"type\": \"joint_acc\", \"use_time\": true, \"params\": {\"targets\": [0,0,0,0,0,0,0]}}], " + init, env),
+                     "does not support time");
+    EXPECT_THROW_MSG(ConstructProblem("{\"basic_info\": {\"n_steps\": 5, \"manip\": \"right_arm\", \"dt_lower_lim\": 2.0, \"dt_upper_lim\": 1.0}, \"costs\": [], " + init, env),
+                     "dt limits (Basic Info) invalid");
+  }
+  std::printf("TIME done\n");
 }
 
 // ---- error behaviour: where the reference PRINT_AND_THROWs, this layer throws std::runtime_error -----------------------
@@ -996,6 +1056,8 @@ int main(int argc, char** argv)
         caseInterface(in);
       else if (c == "json")
         caseJson(in);
+      else if (c == "time")
+        caseTime(in);
       else if (c == "errors")
         caseErrors(in, true);
       else if (c == "errors_nodevice")

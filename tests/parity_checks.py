@@ -98,6 +98,42 @@ def cfg(cid, T=None):
         ti = CartVelTermInfo(first_step=1, last_step=n - 2, max_displacement=0.07, is_constraint=(cid == 23))
         (pci.cnt_infos if cid == 23 else pci.cost_infos).append(ti)
         return pci, s, g
+    if cid in (48, 49, 50, 51, 52, 53):
+        # TIME-PARAMETERISED problems (BasicInfo::use_time: one 1/dt variable per waypoint; problem_description.cpp:1244-1325, :1852-1890)
+        # on the 4-DOF test arm (53: glass_upright): 48 JointVel-with-time SQUARED cost + TotalTime HINGE cost; 49 velocity limits as a
+        # HINGE cost + TotalTime INEQ constraint; 50 the time-optimal shape: velocity limits as INEQ constraints, TotalTime cost; 51 velocity
+        # EQ constraints on two segments + TotalTime SQUARED cost (limit 0); 52 = 48 without a TotalTime term (time enters through the
+        # velocity cost only); 53 ROWS ONLY - velocity limits as INEQ constraints and a HINGE velocity cost, no TotalTime: the QP stays a
+        # block chain with pair rows and runs on the structured solvers (no dense engine, no size limit)
+        from trajopt_amd.problem import JointVelTermInfo, TotalTimeTermInfo
+        pci, s, g = configs.config_mini() if T is None else configs.config_mini(T)
+        D, n = pci.robot.n_dof, pci.basic_info.n_steps
+        pci.basic_info.use_time = True
+        pci.basic_info.dt_lower_lim, pci.basic_info.dt_upper_lim = 0.4, 6.0
+        plain = pci.cost_infos[0]
+        assert isinstance(plain, JointVelTermInfo)
+        if cid in (48, 52):
+            pci.cost_infos[0] = JointVelTermInfo(coeffs=[1.0, 2.0, 0.5, 1.5], targets=[0.0] * D, first_step=0, last_step=n - 1, use_time=True, name="vel_t")
+            if cid == 48:
+                pci.cost_infos.append(TotalTimeTermInfo(coeff=0.3, limit=0.5 * (n - 1), name="total_time"))
+        elif cid == 49:
+            pci.cost_infos.insert(1, JointVelTermInfo(coeffs=[2.0, 1.0, 3.0, 1.5], targets=[0.0] * D, first_step=1, last_step=n - 2, use_time=True,
+                                                      upper_tols=[0.08, 0.1, 0.06, 0.12], lower_tols=[-0.08, -0.1, -0.06, -0.12], name="vel_lim"))
+            pci.cnt_infos.insert(0, TotalTimeTermInfo(coeff=1.0, limit=0.7 * (n - 1), is_constraint=True, name="total_time"))
+        elif cid == 53:
+            pci.cnt_infos.insert(0, JointVelTermInfo(coeffs=[1.0] * D, targets=[0.0] * D, first_step=0, last_step=n - 1, use_time=True, is_constraint=True,
+                                                     upper_tols=[0.2] * D, lower_tols=[-0.2] * D, name="vel_lim"))
+            pci.cost_infos.insert(1, JointVelTermInfo(coeffs=[2.0, 1.0, 3.0, 1.5], targets=[0.0] * D, first_step=1, last_step=n - 2, use_time=True,
+                                                      upper_tols=[0.08, 0.1, 0.06, 0.12], lower_tols=[-0.08, -0.1, -0.06, -0.12], name="vel_soft"))
+        elif cid == 50:
+            pci.cnt_infos.insert(0, JointVelTermInfo(coeffs=[1.0] * D, targets=[0.0] * D, first_step=0, last_step=n - 1, use_time=True, is_constraint=True,
+                                                     upper_tols=[0.25] * D, lower_tols=[-0.25] * D, name="vel_lim"))
+            pci.cost_infos.append(TotalTimeTermInfo(coeff=2.0, limit=0.2 * (n - 1), name="total_time"))
+        else:
+            pci.cnt_infos.insert(0, JointVelTermInfo(coeffs=[1.0, 0.5, 2.0, 1.0], targets=list((g - s) / (n - 1)), first_step=2, last_step=4, use_time=True,
+                                                     is_constraint=True, name="vel_eq"))
+            pci.cost_infos.append(TotalTimeTermInfo(coeff=0.01, limit=0.0, name="total_time"))
+        return pci, s, g
     if cid in (45, 46, 47):
         # CONVEX-HULL LINKS (include/tmx_gjk.h): the last two link spheres of the test arm become a box hull (rounded by 1 cm) and a
         # wedge hull; 45 single-time-step cost against the sphere + a box obstacle, 46 LVS_CONTINUOUS (cast: hulls swept over the
@@ -430,7 +466,7 @@ def sqp_history_classes(ctx, orc, desc, x0, max_qp=128, detail=None, trace=None)
     ctx.set_x0(x0)
     with ThreadPoolExecutor(max_workers=min(16, _os.cpu_count() or 1)) as ex:
         oracle_runs = list(ex.map(_oracle, range(B)))
-    n_traj = desc.n_steps * desc.n_dof
+    n_traj = desc.n_steps * (desc.n_dof + (1 if desc.use_time else 0))
 
     def _dataless_rows(b, rows):
         """True if every row of `rows` of problem b's CURRENT QP belongs to an equality row WITHOUT DATA: l = u = 0 and no

@@ -53,6 +53,29 @@ def _robot_block(name, rob, tip):
     return out
 
 
+def time_json_texts():
+    """time-parameterised problem descriptions for both JSON readers: (1) the reference's arm_around_table_time.json with its two
+    string-valued "use_time" members written as booleans (as a string they make the reference throw, json_marshal.cpp:10-20);
+    (2) a problem whose terms use the time column - squared velocity cost with time, TotalTime hinge cost, velocity limits with time"""
+    import json
+    fx = json.load(open(os.path.join(HERE, "golden", "json", "arm_around_table_time.json")))
+    for it in fx["costs"] + fx["constraints"]:
+        if isinstance(it.get("use_time"), str):
+            it["use_time"] = it["use_time"].lower() == "true"
+    terms = {
+        "basic_info": {"n_steps": 8, "manip": "right_arm", "fixed_timesteps": [0], "use_time": True, "dt_lower_lim": 0.5, "dt_upper_lim": 5.0},
+        "costs": [{"type": "joint_vel", "name": "vel_t", "use_time": True, "params": {"coeffs": [1], "targets": [0, 0, 0, 0, 0, 0, 0]}},
+                  {"type": "total_time", "name": "total_time", "use_time": True, "params": {"coeff": 0.5, "limit": 3.0}}],
+        "constraints": [{"type": "joint_pos", "name": "joint_pos", "params": {"coeffs": [1, 1, 1, 1, 1, 1, 1],
+                                                                                "targets": [0.062, 1.287, 0.1, -1.554, -3.011, -0.268, 2.988],
+                                                                                "first_step": 7, "last_step": 7}},
+                        {"type": "joint_vel", "name": "vel_lim", "use_time": True,
+                         "params": {"targets": [0, 0, 0, 0, 0, 0, 0], "upper_tols": [0.9] * 7, "lower_tols": [-0.9] * 7}}],
+        "init_info": {"type": "joint_interpolated", "dt": 1.5, "endpoint": [0.062, 1.287, 0.1, -1.554, -3.011, -0.268, 2.988]},
+    }
+    return {"arm_around_table_time_bool": json.dumps(fx, indent=1), "time_terms": json.dumps(terms, indent=1)}
+
+
 @pytest.fixture(scope="module")
 def inputs(tmp_path_factory):
     pci0, s0, g0 = configs.config0()
@@ -68,8 +91,12 @@ def inputs(tmp_path_factory):
     lines.append(f"obstacles {len(pci1.obstacles)}")
     for c, r in pci1.obstacles:
         lines.append(f"{_fmt(c)} {_fmt(r)}")
-    for name in ("planning_unit_cfg0", "glass_upright_cfg1", "numerical_ik1"):
+    for name in ("planning_unit_cfg0", "glass_upright_cfg1", "numerical_ik1", "arm_around_table_time"):
         lines.append(f"file {name} {os.path.join(HERE, 'golden', 'json', name + '.json')}")
+    tdir = tmp_path_factory.mktemp("time_json")
+    for name, text in time_json_texts().items():
+        (tdir / (name + ".json")).write_text(text)
+        lines.append(f"file {name} {tdir / (name + '.json')}")
     for name, v in (("cfg0_start", s0), ("cfg0_goal", g0), ("cfg1_start", s1), ("cfg1_goal", g1), ("cfg0_seeds", x0), ("cfg1_seeds", x1)):
         lines.append(f"vector {name} {np.asarray(v).size} {_fmt(v)}")
     path = tmp_path_factory.mktemp("cpp") / "input.txt"
@@ -146,6 +173,39 @@ def test_cpp_json_front_end_equals_python_json_front_end_on_host_build(hostemu_l
     _check_json_front_ends(_build(hostemu_lib, "hostemu"), inputs, hostemu_lib)
 
 
+def _check_time_front_ends(exe, inputs, lib_path):
+    """time-parameterised problems (basic_info.use_time) through both JSON readers: same description, same run"""
+    from trajopt_amd import json_io
+    res, init, out = _run(exe, inputs["path"], "time")
+    assert "TIME done" in out
+    pci1 = inputs["pci1"]
+    env = json_io.Environment(manipulators={"right_arm": pr2_right_arm()}, tip_links={"right_arm": "r_gripper_tool_frame"},
+                              link_frames={"base_footprint": np.hstack([np.eye(3), np.zeros((3, 1))])},
+                              joint_state={"right_arm": list(inputs["s0"])}, obstacles=list(pci1.obstacles))
+    texts = time_json_texts()
+    with pytest.raises(ValueError, match="expected: bool"):
+        json_io.construct_problem(open(os.path.join(HERE, "golden", "json", "arm_around_table_time.json")).read(), env)
+    for name, key in (("time_fixture", "arm_around_table_time_bool"), ("time_terms", "time_terms")):
+        pp = json_io.construct_problem(texts[key], env)
+        assert pp.pci.basic_info.use_time and pp.init_traj.shape[1] == 8
+        # (the two readers restate Eigen's LinSpaced differently in the last bit: both runs start from the C++ reader's trajectory)
+        x_init = init[name].reshape(pp.init_traj.shape)
+        assert np.abs(x_init - pp.init_traj).max() < 1e-14 and np.array_equal(x_init[:, 7], pp.init_traj[:, 7])
+        opt = runtime.BatchedTrustRegionSQP(pp.pci, lib_path=lib_path)
+        opt.setParameters(pp.sqp_params)
+        opt.initialize(x_init[None])
+        opt.optimize()
+        _same(res[name], opt.results())
+        if name == "time_terms":
+            assert pp.pci.cost_names() == [f"vel_t_j{j}" for j in range(7)] + ["total_time"]
+            assert pp.pci.cnt_names() == ["joint_pos"] + [f"vel_lim_j{j}" for j in range(7)]
+        opt.ctx.close()
+
+
+def test_cpp_time_problems_equal_python_time_problems_on_host_build(hostemu_lib, inputs):
+    _check_time_front_ends(_build(hostemu_lib, "hostemu"), inputs, hostemu_lib)
+
+
 def test_cpp_reference_kats_on_host_build(hostemu_lib, inputs, orc):
     exe = _build(hostemu_lib, "hostemu")
     res, _, out = _run(exe, inputs["path"], "joint_costs,numerical_ik,cart_position,interface,joint_vel,errors")
@@ -187,6 +247,7 @@ def test_cpp_front_end_on_device(inputs):
     exe = _build(PRODUCT_LIB, "product")
     _check_front_ends(exe, inputs, None)
     _check_json_front_ends(exe, inputs, None)
+    _check_time_front_ends(exe, inputs, None)
     res, _, out = _run(exe, inputs["path"], "joint_costs,numerical_ik,cart_position,interface,joint_vel,errors")
     assert "ERRORS done" in out and "INTERFACE done" in out and all(r[0]["status"] == 0 for r in res.values())
     # the product lowers the rows on two consecutive waypoints: the reference's jointVel tests run on the device

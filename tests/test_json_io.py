@@ -89,8 +89,8 @@ def test_unsupported_and_malformed_inputs_are_explicit_errors():
     with pytest.raises(json_io.UnsupportedTerm):
         json_io.construct_problem(bad, env)
     bad = copy.deepcopy(base)
-    bad["costs"].append({"type": "total_time", "params": {"coeff": 1.0}})
-    with pytest.raises(json_io.UnsupportedTerm):
+    bad["costs"].append({"type": "total_time", "params": {"coeff": 1.0}})   # a time term without basic_info.use_time (:447-448)
+    with pytest.raises(ValueError, match="A term is using time"):
         json_io.construct_problem(bad, env)
     # joint_acc / joint_jerk (problem_description.cpp:1374-1391, :1495-1513) are lowered: Eq cost without tolerances, Ineq
     # constraint with them; unknown parameter fields are refused as ensure_only_members does
@@ -110,8 +110,12 @@ def test_unsupported_and_malformed_inputs_are_explicit_errors():
     with pytest.raises(ValueError, match="max_acc"):
         json_io.construct_problem(bad, env)
     bad = copy.deepcopy(base)
-    bad["basic_info"]["use_time"] = True
-    with pytest.raises(json_io.UnsupportedTerm):
+    bad["basic_info"]["use_time"] = True     # ConstructProblem, problem_description.cpp:451-452
+    with pytest.raises(ValueError, match="No terms use time"):
+        json_io.construct_problem(bad, env)
+    bad = copy.deepcopy(good)
+    bad["costs"][-1]["use_time"] = True       # joint_acc has no TT_USE_TIME in its supported types (:427-428)
+    with pytest.raises(ValueError, match="does not support time"):
         json_io.construct_problem(bad, env)
 
 

@@ -1,0 +1,217 @@
+"""Time-parameterised problems: BasicInfo::use_time puts one variable tau = 1/dt behind the joints of every waypoint
+(TrajOptProb ctor, /root/reference/trajopt/src/problem_description.cpp:553-592); JointVelTermInfo with TT_USE_TIME hatches per joint
+a TrajOptCostFromErrFunc / TrajOptConstraintFromErrFunc over JointVelErrCalculator / JointVelJacCalculator (:1244-1325,
+trajopt/src/kinematic_terms.cpp:427-470); TotalTimeTermInfo one term over TimeCostCalculator (:1852-1890, kinematic_terms.cpp:572-584).
+The reference has no test or golden vector for any of them (JointAcc / JointJerk with time are "not defined", :1439-1446), so the
+oracle is pinned on the calculators' closed forms here, and the kernels are compared with the oracle stage by stage:
+exact values, the QP handed to OSQP (integer CSC arrays bit-exact), the first QP solve, whole SQP histories."""
+import numpy as np
+import pytest
+
+import parity_checks as pc
+from trajopt_amd import abi, configs, runtime
+
+TIME_CIDS = (48, 49, 50, 51, 52, 53)
+
+
+def seeds_time(cid, pci, s, g, B, dt0=1.3):
+    """joint seeds of the 4-DOF test arm + a time column around dt0 (inside the dt limits of the configurations)"""
+    x = configs.seeds_for(9, pci, s, g, B)
+    rng = np.random.default_rng(1234 + cid)
+    tau = dt0 + 0.3 * rng.standard_normal((B, x.shape[1], 1))
+    return np.concatenate([x, np.clip(tau, 0.5, 4.0)], axis=2)
+
+
+def _expected_values(pci, x):
+    """closed forms of kinematic_terms.cpp:427-441 and :572-577 with CostFromErrFunc::value / ConstraintFromErrFunc::value +
+    violations (trajopt_sco/src/modeling_utils.cpp:143-165, :238-245; modeling.cpp:150-167) for the time terms of a configuration"""
+    from trajopt_amd.problem import JointVelTermInfo, TotalTimeTermInfo
+    D = pci.robot.n_dof
+    costs, cnts = {}, {}
+    for ti in pci.cost_infos + pci.cnt_infos:
+        if isinstance(ti, JointVelTermInfo) and ti.use_time:
+            up = list(ti.upper_tols) or [0.0] * D
+            lo = list(ti.lower_tols) or [0.0] * D
+            zero = all(abs(v) < 1e-5 for v in up + lo)
+            first, last = ti.first_step, ti.last_step
+            for j in range(D):
+                vel = (x[first + 1:last + 1, j] - x[first:last, j]) * x[first + 1:last + 1, D]
+                err = np.concatenate([-(up[j] - (vel - ti.targets[j])), lo[j] - (vel - ti.targets[j])])
+                c = ti.coeffs[j]
+                if ti.is_constraint:
+                    cnts[f"{ti.name}_j{j}"] = np.abs(err * c).sum() if zero else np.maximum(err * c, 0).sum()
+                else:
+                    costs[f"{ti.name}_j{j}"] = (err ** 2 * c).sum() if zero else (np.maximum(err, 0) * c).sum()
+        elif isinstance(ti, TotalTimeTermInfo):
+            err = (1.0 / x[1:, D]).sum() - ti.limit
+            zero = abs(ti.limit) < 1e-5
+            if ti.is_constraint:
+                cnts[ti.name] = abs(err * ti.coeff) if zero else max(err * ti.coeff, 0.0)
+            else:
+                costs[ti.name] = err ** 2 * ti.coeff if zero else max(err, 0.0) * ti.coeff
+    return costs, cnts
+
+
+@pytest.mark.parametrize("cid", TIME_CIDS)
+def test_oracle_time_terms_against_the_calculators_closed_forms(orc, cid):
+    pci, s, g = pc.cfg(cid)
+    desc = pci.to_desc()
+    x0 = seeds_time(cid, pci, s, g, 3)
+    cn, vn = pci.cost_names(), pci.cnt_names()
+    for b in range(3):
+        cv, vv = orc.evaluate(desc, x0[b], x0[b])
+        assert len(cv) == len(cn) and len(vv) == len(vn)
+        ec, ev = _expected_values(pci, x0[b])
+        assert ec or ev
+        for name, val in ec.items():
+            assert abs(cv[cn.index(name)] - val) <= 1e-12 * max(1.0, abs(val)), name
+        for name, val in ev.items():
+            assert abs(vv[vn.index(name)] - val) <= 1e-12 * max(1.0, abs(val)), name
+
+
+def test_oracle_first_qp_rows_are_the_linearised_calculators(orc):
+    """configuration 50 (velocity limits as INEQ constraints): every velocity row of the first QP is the affine model
+    coeff * (err(x0) + J (x - x0)) with JointVelJacCalculator's three entries (-tau, +tau, x[i+1] - x[i]), checked against central
+    differences of the error; the TotalTime row of configuration 49 likewise (-1 / tau^2)"""
+    for cid in (50, 49):
+        pci, s, g = pc.cfg(cid)
+        desc = pci.to_desc()
+        D, T = pci.robot.n_dof, pci.basic_info.n_steps
+        x0 = seeds_time(cid, pci, s, g, 1)[0]
+        q = orc.first_qp(desc, x0)
+        A = pc.csc_dense_ops(q)[1].toarray()
+        nx = T * (D + 1)
+        xf = x0.reshape(-1)
+        hits = 0
+        for r in range(q["m"] - q["n"]):
+            row = A[r, :nx]
+            tcols = [c for c in np.nonzero(row)[0] if c % (D + 1) == D]
+            if not tcols:
+                continue
+            if len(tcols) == T - 1:                     # the TotalTime row
+                tau = x0[1:, D]
+                w = [ti for ti in pci.cnt_infos + pci.cost_infos if type(ti).__name__ == "TotalTimeTermInfo"][0].coeff
+                assert np.allclose(row[tcols], -w / tau ** 2, rtol=1e-13, atol=0)
+                hits += 1
+                continue
+            assert len(tcols) == 1                      # a velocity row: x[i][j], x[i+1][j], tau[i+1]
+            ct = tcols[0]
+            i1, nz = ct // (D + 1), np.nonzero(row)[0]
+            assert len(nz) == 3
+            j = nz[0] % (D + 1)
+            assert list(nz) == [(i1 - 1) * (D + 1) + j, i1 * (D + 1) + j, ct]
+            tau, dx = xf[ct], xf[nz[1]] - xf[nz[0]]
+            sgn = np.sign(row[nz[1]])
+            scale = abs(row[nz[1]]) / tau               # the row's coefficient
+            assert np.allclose(row[nz], sgn * scale * np.array([-tau, tau, dx]), rtol=1e-13, atol=1e-15)
+            hits += 1
+        assert hits > 0
+
+
+@pytest.mark.parametrize("cid", TIME_CIDS)
+def test_time_terms_stage_by_stage_on_host_build(hostemu_lib, orc, cid):
+    pci, s, g = pc.cfg(cid)
+    x0 = seeds_time(cid, pci, s, g, 2)
+    ctx = runtime.Context(0, hostemu_lib)
+    desc = pc.make_ctx_inputs(ctx, pci, x0)
+    pc.check_evaluate(ctx, orc, desc, x0, 1e-12)
+    for b in range(2):
+        pc.check_first_qp_structure(ctx, orc, desc, x0, b, 1e-12)
+    ctx.close()
+    ctx = runtime.Context(0, hostemu_lib)
+    desc = pc.make_ctx_inputs(ctx, pci, x0)
+    pc.check_first_qp_solve(ctx, orc, desc, x0)
+    ctx.close()
+
+
+def _history_check(ctx, orc, orc_fma, cid, B):
+    """whole SQP runs QP by QP.  The yardstick for these (bilinear, badly conditioned) problems is how often two correct builds of
+    the ORACLE itself - the same source with and without FMA contraction - keep the same history: the kernels may part from the
+    oracle on at most one seed more than that, never in class "other" (a structural difference)."""
+    pci, s, g = pc.cfg(cid)
+    x0 = seeds_time(cid, pci, s, g, B)
+    desc = pc.make_ctx_inputs(ctx, pci, x0)
+    classes, dx, _ = pc.sqp_history_classes(ctx, orc, desc, x0)
+    r0, r1 = orc.sqp_batch(desc, x0), orc_fma.sqp_batch(desc, x0)
+    same_builds = int(((r0["n_qp_solves"] == r1["n_qp_solves"]) & (np.abs(r0["x"] - r1["x"]).reshape(B, -1).max(axis=1) < 1e-5)).sum())
+    good = sum(c in ("identical", "tie") for c in classes)
+    print(f"config {cid}: classes {classes}, |dx| {np.round(dx, 7)}, oracle vs FMA oracle same on {same_builds}/{B}")
+    assert "other" not in classes and "csc-noise" not in classes
+    assert good >= max(1, same_builds - 1)
+    return classes
+
+
+@pytest.mark.parametrize("cid", TIME_CIDS)
+def test_time_problems_whole_sqp_on_host_build(hostemu_lib, orc, orc_fma, cid):
+    ctx = runtime.Context(0, hostemu_lib)
+    _history_check(ctx, orc, orc_fma, cid, 4)
+    ctx.close()
+
+
+def test_rows_only_time_problem_stays_on_the_structured_solver(hostemu_lib):
+    """configuration 53 has no TotalTime term and no squared velocity cost: its QP is a block chain with pair rows and the upload does
+    not select the dense engine (so there is no 448-variable limit) - a 40-waypoint version of it uploads and runs"""
+    pci, s, g = pc.cfg(53, T=40)
+    x0 = seeds_time(53, pci, s, g, 1)
+    ctx = runtime.Context(0, hostemu_lib)
+    pc.make_ctx_inputs(ctx, pci, x0)
+    assert ctx.n_max > 448
+    ctx.run(0)
+    assert ctx.results()["status"][0] in (abi.OPT_CONVERGED, abi.OPT_SCO_ITERATION_LIMIT, abi.OPT_PENALTY_ITERATION_LIMIT)
+    ctx.close()
+    # ... while a TotalTime term at that size is refused with the dense engine's explicit limit
+    pci, s, g = pc.cfg(48, T=120)
+    ctx = runtime.Context(0, hostemu_lib)
+    with pytest.raises(runtime.TmxError, match="dense engine"):
+        pc.make_ctx_inputs(ctx, pci, seeds_time(48, pci, s, g, 1))
+    ctx.close()
+
+
+def test_time_terms_need_the_time_column_and_the_sco_flavour(hostemu_lib):
+    from trajopt_amd.problem import TotalTimeTermInfo
+    pci, s, g = pc.cfg(9)
+    pci.cost_infos.append(TotalTimeTermInfo())
+    ctx = runtime.Context(0, hostemu_lib)
+    with pytest.raises(runtime.TmxError, match="A term is using time"):
+        pc.make_ctx_inputs(ctx, pci, configs.seeds_for(9, pci, s, g, 1))
+    pci, s, g = pc.cfg(52)
+    pci.flavor = abi.FLAVOR_SQP
+    with pytest.raises(runtime.TmxError):
+        pc.make_ctx_inputs(ctx, pci, seeds_time(52, pci, s, g, 1))
+    pci, s, g = pc.cfg(52)
+    pci.basic_info.dt_lower_lim, pci.basic_info.dt_upper_lim = 2.0, 1.0
+    with pytest.raises(runtime.TmxError, match="dt limits"):
+        pc.make_ctx_inputs(ctx, pci, seeds_time(52, pci, s, g, 1))
+    # wrong trajectory width: the time column is part of every trajectory handed over
+    pci, s, g = pc.cfg(52)
+    opt = runtime.BatchedTrustRegionSQP(pci, lib_path=hostemu_lib)
+    with pytest.raises(runtime.TmxError, match="wrong length"):
+        opt.initialize(configs.seeds_for(9, pci, s, g, 1))
+    opt.ctx.close()
+    ctx.close()
+
+
+# ---- GPU tier ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("cid", TIME_CIDS)
+def test_time_terms_stage_by_stage_on_device(gpu_ctx_factory, orc, cid):
+    pci, s, g = pc.cfg(cid)
+    x0 = seeds_time(cid, pci, s, g, 4)
+    ctx = gpu_ctx_factory()
+    desc = pc.make_ctx_inputs(ctx, pci, x0)
+    pc.check_evaluate(ctx, orc, desc, x0, 1e-12)
+    for b in range(4):
+        pc.check_first_qp_structure(ctx, orc, desc, x0, b, 1e-12)
+    ctx.close()
+    ctx = gpu_ctx_factory()
+    desc = pc.make_ctx_inputs(ctx, pci, x0)
+    pc.check_first_qp_solve(ctx, orc, desc, x0)
+    ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cid", TIME_CIDS)
+def test_time_problems_whole_sqp_on_device(gpu_ctx_factory, orc, orc_fma, cid):
+    ctx = gpu_ctx_factory()
+    _history_check(ctx, orc, orc_fma, cid, 8)
+    ctx.close()

@@ -56,6 +56,7 @@ class Expr(C.Structure):
 OP_VAR, OP_CONST, OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_NEG, OP_SQ, OP_SIN, OP_COS, OP_SQRT, OP_OUT = range(1, 13)
 TERM_FUNC_COST, TERM_FUNC_CNT, TERM_FUNC_ERR_COST = 21, 22, 23
 TERM_AVOID_SINGULARITY, TERM_DYN_CART_POSE = 24, 25
+TERM_JOINT_VEL_TIME, TERM_TOTAL_TIME = 26, 27
 PENALTY_SQUARED, PENALTY_ABS, PENALTY_HINGE = 0, 1, 2     # sco::PenaltyType
 
 
@@ -137,7 +138,9 @@ class ProblemDesc(C.Structure):
         ("link_hull", C.POINTER(C.c_int32)),
         ("hull_vertices", C.POINTER(C.c_double)),
         ("n_hull_vertices", C.c_int32),
-        ("pad5_", C.c_int32),
+        ("use_time", C.c_int32),
+        ("dt_lower_lim", C.c_double),
+        ("dt_upper_lim", C.c_double),
     ]
 
 

@@ -57,6 +57,7 @@ struct tmx_ctx
   int* h_tail{ nullptr };  // pinned, device-mapped word: 1 once the pool kernel of the pending launch has begun to retire workgroups
   bool dense{ false };      // DevProblem::qp_dense: Model::optimize() by k_qp_solve_dense
   bool band{ false };       // DevProblem::band: the pool driver launches k_sqp_pool_band
+  bool tt_squared{ false }; // a TotalTime cost in its squared form (dense objective block over the time variables)
   bool hull{ false };       // DevProblem::n_ls_hull > 0: the term kernels are the *_hull instantiations (GJK / EPA contacts)
   bool piecewise{ false };  // DevProblem::st: the piecewise driver runs optimize() (host loop) - dense problems and row-only function terms
   bool ws_in_hbm{ false };  // QP workspace > 160 KB of LDS: k_*_hbm kernels, workspace carved in HBM (long horizons)
@@ -256,11 +257,33 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
     return TMX_ERR_INVALID;
   TMX_REFUSE_WHILE_PENDING(ctx);
   HIPCHK(hipSetDevice(ctx->device));
-  const int D = d->n_dof, T = d->n_steps;
-  if (D < 1 || D > TMX_MAX_DOF || T < 1)
+  // DK joints; D variables per waypoint (time-parameterised problems carry the time variable 1 / dt behind the joints)
+  const int DK = d->n_dof, T = d->n_steps;
+  const int D = DK + (d->use_time ? 1 : 0);
+  if (DK < 1 || D > TMX_MAX_DOF || T < 1)
   {
-    ctx->err = "n_dof must be in [1, TMX_MAX_DOF] and n_steps >= 1";
+    ctx->err = "n_dof (+ 1 with use_time) must be in [1, TMX_MAX_DOF] and n_steps >= 1";
     return TMX_ERR_INVALID;
+  }
+  if (d->use_time && (d->dt_lower_lim <= 0 || d->dt_upper_lim < d->dt_lower_lim))
+  {
+    // ProblemConstructionInfo::readBasicInfo  problem_description.cpp:129-133
+    ctx->err = "dt limits (Basic Info) invalid. The lower limit must be positive, and the minimum upper limit is equal to the lower limit.";
+    return TMX_ERR_INVALID;
+  }
+  {
+    // ConstructProblem  problem_description.cpp:415-452: a term that uses time <=> basic_info.use_time
+    bool term_time = false;
+    for (int k = 0; k < d->n_terms && d->terms; ++k)
+      term_time = term_time || d->terms[k].kind == TMX_TERM_JOINT_VEL_TIME || d->terms[k].kind == TMX_TERM_TOTAL_TIME;
+    if (term_time && !d->use_time)
+    {
+      ctx->err = "A term is using time and basic_info is not set correctly. Try basic_info.use_time = true";
+      return TMX_ERR_INVALID;
+    }
+    // (the converse - "No terms use time and basic_info is not set correctly" - is a check on the TermInfo FLAGS in the reference: a
+    //  joint_pos term listed with use_time switches the time column on without ever touching it, problem_description.cpp:1124-1125;
+    //  the front ends make that check, the term table cannot)
   }
   if (d->n_fixed_steps < 0 || d->n_fixed_dofs < 0 || d->n_terms < 0 || d->n_link_spheres < 0 || d->n_obstacles < 0 ||
       (d->n_fixed_steps > 0 && !d->fixed_steps) || (d->n_fixed_dofs > 0 && !d->fixed_dofs) || (d->n_terms > 0 && !d->terms) ||
@@ -276,17 +299,30 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
   DevProblem& P = ctx->hp;
   std::memset(&P, 0, sizeof(P));
   P.D = D;
+  P.DK = DK;
+  P.use_time = d->use_time ? 1 : 0;
   P.T = T;
   P.NX = D * T;
   P.S = d->n_link_spheres;
   P.O = d->n_obstacles;
-  for (int j = 0; j < D; ++j)
+  for (int j = 0; j < DK; ++j)
   {
     P.jl[j] = d->joint_lower[j];
     P.ju[j] = d->joint_upper[j];
     std::memcpy(P.origin[j], d->joints[j].origin, sizeof(double) * 12);
     std::memcpy(P.axis[j], d->joints[j].axis, sizeof(double) * 3);
     P.jtype[j] = d->joints[j].type;
+  }
+  if (d->use_time)
+  {
+    // the time column as seen by the kinematic code: a prismatic joint with a zero axis behind the last link - no motion, a zero
+    // Jacobian column; its variable bounds are the dt limits (TrajOptProb ctor, problem_description.cpp:583-588)
+    P.jl[DK] = d->dt_lower_lim;
+    P.ju[DK] = d->dt_upper_lim;
+    const double ident[12] = { 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0 };
+    std::memcpy(P.origin[DK], ident, sizeof(ident));
+    P.axis[DK][0] = P.axis[DK][1] = P.axis[DK][2] = 0.0;
+    P.jtype[DK] = 1;
   }
   std::memcpy(P.base, d->base, sizeof(double) * 12);
   std::memcpy(P.tool, d->tool, sizeof(double) * 12);
@@ -385,6 +421,11 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
     return TMX_ERR_UNSUPPORTED;
   }
 #endif
+  if (flavor == TMX_FLAVOR_SQP && d->use_time)
+  {
+    ctx->err = "TMX_FLAVOR_SQP: time-parameterised problems are not part of the trajopt_sqp path (trajopt_ifopt has no such sets)";
+    return TMX_ERR_UNSUPPORTED;
+  }
   P.flavor = flavor;
   std::vector<int> fixed(d->fixed_steps, d->fixed_steps + d->n_fixed_steps);
   for (int t : fixed)
@@ -394,7 +435,7 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
       ctx->err = "fixed timestep out of range";
       return TMX_ERR_INVALID;
     }
-    for (int j = 0; j < D; ++j)
+    for (int j = 0; j < DK; ++j)  // (the joint columns only, problem_description.cpp:499-503)
       add_slot(SLOT_FIXED, t, j, 0, -1, 0, 0, 1, 0.0, 1.0, 0.0, 0.0);
   }
   // BasicInfo::fixed_dofs (problem_description.cpp:510-530): the joint keeps its initial value at every timestep that is not
@@ -402,7 +443,7 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
   for (int q = 0; q < d->n_fixed_dofs; ++q)
   {
     const int dof = d->fixed_dofs[q];
-    if (dof < 0 || dof >= D)
+    if (dof < 0 || dof >= DK)
     {
       ctx->err = "DOF(aka Joint) indice is greater than the number of DOF available.";
       return TMX_ERR_INVALID;
@@ -426,6 +467,15 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
   // hatch order: all costs in list order, then the constraints; sco::OptProb keeps equality constraints in front of the
   // inequality constraints (modeling.cpp:234-241), which fixes both the row / aux order and the constraint numbering
   int n_sq = 0;
+  // time-parameterised terms
+  std::vector<int> tv_owner, tv_joint, tv_first, tv_last, tt_owner, tt_form, tt_slot;
+  std::vector<double> tv_coeff, tv_target, tv_up, tv_lo, tt_coeff, tt_limit;
+  auto time_zero_tols = [](const tmx_term& tm, int nj) {
+    bool z = true;
+    for (int j = 0; j < nj; ++j)
+      z = z && std::fabs(tm.upper_tols[j]) < 1e-5 && std::fabs(tm.lower_tols[j]) < 1e-5;  // trajopt_common::doubleEquals (vector_ops.hpp:17)
+    return z;
+  };
   for (int pass = 0; pass < 5; ++pass)
     for (int k = 0; k < d->n_terms; ++k)
     {
@@ -433,10 +483,13 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
       const bool is_ineq = tm.kind == TMX_TERM_JOINT_POS_INEQ_CNT || tm.kind == TMX_TERM_COLLISION_CNT || tm.kind == TMX_TERM_JOINT_VEL_INEQ_CNT ||
                            tm.kind == TMX_TERM_JOINT_ACC_INEQ_CNT || tm.kind == TMX_TERM_JOINT_JERK_INEQ_CNT ||
                            (tm.kind == TMX_TERM_FUNC_CNT && tm.cnt_type == 1) || (tm.kind == TMX_TERM_CART_VEL && tm.is_constraint) ||
-                           (tm.kind == TMX_TERM_AVOID_SINGULARITY && tm.is_constraint);
+                           (tm.kind == TMX_TERM_AVOID_SINGULARITY && tm.is_constraint) ||
+                           (tm.kind == TMX_TERM_JOINT_VEL_TIME && tm.is_constraint && !time_zero_tols(tm, DK)) ||
+                           (tm.kind == TMX_TERM_TOTAL_TIME && tm.is_constraint && !(std::fabs(tm.margin) < 1e-5));
       const bool is_cnt = is_ineq || (tm.kind == TMX_TERM_JOINT_POS_EQ_CNT) || (tm.kind == TMX_TERM_JOINT_VEL_EQ_CNT) ||
                           (tm.kind == TMX_TERM_JOINT_ACC_EQ_CNT) || (tm.kind == TMX_TERM_JOINT_JERK_EQ_CNT) || (tm.kind == TMX_TERM_FUNC_CNT) ||
-                          (tm.kind == TMX_TERM_CART_POSE && tm.is_constraint) || (tm.kind == TMX_TERM_DYN_CART_POSE && tm.is_constraint);
+                          (tm.kind == TMX_TERM_CART_POSE && tm.is_constraint) || (tm.kind == TMX_TERM_DYN_CART_POSE && tm.is_constraint) ||
+                          ((tm.kind == TMX_TERM_JOINT_VEL_TIME || tm.kind == TMX_TERM_TOTAL_TIME) && tm.is_constraint);
       int want = !is_cnt ? 0 : (is_ineq ? 2 : 1);
       if (flavor == TMX_FLAVOR_SQP)
       {
@@ -471,7 +524,7 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
       }
       if (pass != want)
         continue;
-      if (tm.first_step < 0 || tm.last_step >= T || tm.first_step > tm.last_step)
+      if (tm.kind != TMX_TERM_TOTAL_TIME && (tm.first_step < 0 || tm.last_step >= T || tm.first_step > tm.last_step))
       {
         ctx->err = "term step range invalid";
         return TMX_ERR_INVALID;
@@ -518,8 +571,8 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
           vel_cost.push_back(n_costs++);
           for (int j = 0; j < TMX_MAX_DOF; ++j)
           {
-            vel_coeffs.push_back(j < D ? tm.coeffs[j] : 0.0);
-            vel_targets.push_back(j < D ? tm.targets[j] : 0.0);
+            vel_coeffs.push_back(j < DK ? tm.coeffs[j] : 0.0);
+            vel_targets.push_back(j < DK ? tm.targets[j] : 0.0);
           }
           if (flavor == TMX_FLAVOR_SQP)
           {
@@ -527,14 +580,14 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
             // x[i+1][j]) accumulated over the rows in row order (AffExprs::square, expressions.cpp:43-112); the 1e-7 zeroing and
             // the factor 2 of OSQPEigenSolver::updateHessianMatrix are applied after all sets are summed (below)
             ++n_sq;
-            for (int j = 0; j < D; ++j)
+            for (int j = 0; j < DK; ++j)
               if (!(tm.coeffs[j] > 0))
               {
                 ctx->err = "JointVelConstraint, coeff must be greater than zero.";  // joint_velocity_constraint.cpp:66
                 return TMX_ERR_INVALID;
               }
             for (int i = tm.first_step; i <= tm.last_step - 1; ++i)
-              for (int j = 0; j < D; ++j)
+              for (int j = 0; j < DK; ++j)
               {
                 const double sw = std::sqrt(tm.coeffs[j]);
                 const double b0 = -1 * sw, b1 = 1 * sw;
@@ -547,7 +600,7 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
           // Hessian / linear term of sum_j c_j (x_{i+1,j} - x_{i,j} - targ_j)^2 exactly as exprSquare + exprToEigen build
           // them (expr_ops.cpp:55-84, solver_utils.cpp:49-109 with matrix_is_halved = true)
           for (int i = tm.first_step; i <= tm.last_step - 1; ++i)
-            for (int j = 0; j < D; ++j)
+            for (int j = 0; j < DK; ++j)
             {
               const double c = tm.coeffs[j];
               const double a0 = -1.0, a1 = 1.0, cst = 0.0 - tm.targets[j];
@@ -575,7 +628,7 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
             for (int i = tm.first_step; i <= tm.last_step; ++i)
             {
               const int own = n_cnts++;
-              for (int j = 0; j < D; ++j)
+              for (int j = 0; j < DK; ++j)
               {
                 if (!(tm.coeffs[j] > 0))
                 {
@@ -589,7 +642,7 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
           }
           const int own = n_cnts++;
           for (int i = tm.first_step; i <= tm.last_step; ++i)
-            for (int j = 0; j < D; ++j)
+            for (int j = 0; j < DK; ++j)
               add_slot(SLOT_JOINTPOS, i, j, 0, own, 2, 1, 1, 0.0, tm.coeffs[j], tm.targets[j], 0.0);
           break;
         }
@@ -611,7 +664,7 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
           const bool is_cnt = tm.kind != TMX_TERM_JOINT_VEL_INEQ_COST;
           const int own = is_cnt ? n_cnts++ : n_costs++;
           for (int i = tm.first_step; i <= tm.last_step - 1; ++i)
-            for (int j = 0; j < D; ++j)
+            for (int j = 0; j < DK; ++j)
             {
               const double c = tm.coeffs[j];
               if (tm.kind == TMX_TERM_JOINT_VEL_EQ_CNT)
@@ -647,12 +700,18 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
             ctx->err = "TMX_FLAVOR_SQP: function terms are not part of the trajopt_sqp path";
             return TMX_ERR_UNSUPPORTED;
           }
-          if (!builtin && tmx_expr_check(tm.expr, D) != 0)
+          if (d->use_time)
+          {
+            ctx->err = "function terms (user-defined functions, AvoidSingularity, DynamicCartPose, CartPose with a tolerance band) are not lowered "
+                       "for time-parameterised problems";
+            return TMX_ERR_UNSUPPORTED;
+          }
+          if (!builtin && tmx_expr_check(tm.expr, DK) != 0)
           {
             ctx->err = "function term: malformed tmx_expr program (opcode, index, stack discipline or outputs)";
             return TMX_ERR_INVALID;
           }
-          if (builtin && tm.kind != TMX_TERM_CART_POSE && (tm.link < 0 || tm.link >= D))
+          if (builtin && tm.kind != TMX_TERM_CART_POSE && (tm.link < 0 || tm.link >= DK))
           {
             ctx->err = "AvoidSingularity / DynamicCartPose: link is the index of a moving link, 0 .. n_dof - 1";
             return TMX_ERR_INVALID;
@@ -793,13 +852,13 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
           vel_cost.push_back(n_costs++);
           for (int j = 0; j < TMX_MAX_DOF; ++j)
           {
-            vel_coeffs.push_back(j < D ? tm.coeffs[j] : 0.0);
-            vel_targets.push_back(j < D ? tm.targets[j] : 0.0);
+            vel_coeffs.push_back(j < DK ? tm.coeffs[j] : 0.0);
+            vel_targets.push_back(j < DK ? tm.targets[j] : 0.0);
           }
           static const double S2[3] = { 1.0, -2.0, 1.0 }, S3[4] = { -1.0, 3.0, -3.0, 1.0 };
           const double* a = ord == 2 ? S2 : S3;
           for (int i = tm.first_step; i <= tm.last_step - ord; ++i)
-            for (int j = 0; j < D; ++j)
+            for (int j = 0; j < DK; ++j)
             {
               const double c = tm.coeffs[j], cst = 0.0 - tm.targets[j];
               for (int k = 0; k <= ord; ++k)
@@ -853,7 +912,7 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
           // upper and a lower row (INEQ) per step i in [first, last - ord] and joint j over x[i .. i + ord][j]
           const int own = is_cost ? n_costs++ : n_cnts++;
           for (int i = tm.first_step; i <= tm.last_step - ord; ++i)
-            for (int j = 0; j < D; ++j)
+            for (int j = 0; j < DK; ++j)
             {
               const double c = tm.coeffs[j];
               if (is_eq)
@@ -885,7 +944,7 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
             for (int i = tm.first_step; i <= tm.last_step; ++i)
             {
               const int own = n_costs++;
-              for (int j = 0; j < D; ++j)
+              for (int j = 0; j < DK; ++j)
               {
                 if (!(tm.coeffs[j] > 0))
                 {
@@ -905,12 +964,12 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
           vel_cost.push_back(n_costs++);
           for (int j = 0; j < TMX_MAX_DOF; ++j)
           {
-            vel_coeffs.push_back(j < D ? tm.coeffs[j] : 0.0);
-            vel_targets.push_back(j < D ? tm.targets[j] : 0.0);
+            vel_coeffs.push_back(j < DK ? tm.coeffs[j] : 0.0);
+            vel_targets.push_back(j < DK ? tm.targets[j] : 0.0);
           }
           // exprSquare(pos) * coeff with pos = 1*x - target  ->  Hessian 2*c on the diagonal, linear term 2*(0 - target)*c
           for (int i = tm.first_step; i <= tm.last_step; ++i)
-            for (int j = 0; j < D; ++j)
+            for (int j = 0; j < DK; ++j)
             {
               const double c = tm.coeffs[j];
               const double a1 = 1.0, cst = 0.0 - tm.targets[j];
@@ -929,7 +988,7 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
           // objective coefficient 1 (the per-joint coefficient already sits inside the affine expression)
           const int own = n_costs++;
           for (int i = tm.first_step; i <= tm.last_step; ++i)
-            for (int j = 0; j < D; ++j)
+            for (int j = 0; j < DK; ++j)
             {
               add_slot(SLOT_JOINTPOS_INEQ, i, j, 0, own, 1, 0, 0, 1.0, tm.coeffs[j], tm.targets[j], tm.upper_tols[j]);
               add_slot(SLOT_JOINTPOS_INEQ, i, j, 1, own, 1, 0, 0, 1.0, tm.coeffs[j], tm.targets[j], tm.lower_tols[j]);
@@ -942,7 +1001,7 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
           // inequality constraint -> hinge penalty (1 aux).  scale = coeff, aux1 = target, aux2 = tolerance
           const int own = n_cnts++;
           for (int i = tm.first_step; i <= tm.last_step; ++i)
-            for (int j = 0; j < D; ++j)
+            for (int j = 0; j < DK; ++j)
             {
               add_slot(SLOT_JOINTPOS_INEQ, i, j, 0, own, 1, 1, 0, 0.0, tm.coeffs[j], tm.targets[j], tm.upper_tols[j]);
               add_slot(SLOT_JOINTPOS_INEQ, i, j, 1, own, 1, 1, 0, 0.0, tm.coeffs[j], tm.targets[j], tm.lower_tols[j]);
@@ -1059,6 +1118,90 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
               for (int o = 0; o < d->n_obstacles; ++o)
                 add_slot(SLOT_COLLISION, i, s, o, own, 1, 1, 0, tm.coeff, tm.coeff, tm.margin, tm.buffer);
           }
+          break;
+        }
+        case TMX_TERM_JOINT_VEL_TIME:
+        {
+          // JointVelTermInfo::hatch with TT_USE_TIME (problem_description.cpp:1244-1325): per joint one TrajOptCostFromErrFunc /
+          // TrajOptConstraintFromErrFunc over 2 (last - first) rows - the upper rows, then the lower rows - with the coefficient
+          // coeffs[j] on every row (a zero coefficient drops the rows, modeling_utils.cpp:175-176, :258-259; the cost stays)
+#if !TMX_LINK_ROWS
+          ctx->err = "rows on two consecutive waypoints (time-parameterised joint velocities) are not enabled in this build";
+          return TMX_ERR_UNSUPPORTED;
+#else
+          if (tm.last_step - tm.first_step < 1)
+          {
+            ctx->err = "joint_vel with use_time: the term needs two steps";
+            return TMX_ERR_INVALID;
+          }
+          const bool zero = time_zero_tols(tm, DK);
+          for (int j = 0; j < DK; ++j)
+          {
+            const int own = tm.is_constraint ? n_cnts++ : n_costs++;
+            const double c = tm.coeffs[j];
+            if (!tm.is_constraint && zero)
+            {
+              // sco::SQUARED: a dynamic quadratic model over (x[i][j], x[i+1][j], tau[i+1]) of every segment
+              if (c != 0.0)
+              {
+                tv_owner.push_back(own);
+                tv_joint.push_back(j);
+                tv_first.push_back(tm.first_step);
+                tv_last.push_back(tm.last_step);
+                tv_coeff.push_back(c);
+                tv_target.push_back(tm.targets[j]);
+                tv_up.push_back(tm.upper_tols[j]);
+                tv_lo.push_back(tm.lower_tols[j]);
+                qp_dense = true;  // P changes with the iterate and couples a joint with the NEXT waypoint's time variable
+              }
+              continue;
+            }
+            if (c == 0.0)
+              continue;
+            for (int half = 0; half < 2; ++half)
+              for (int i = tm.first_step; i < tm.last_step; ++i)
+              {
+                const double tol = half ? tm.lower_tols[j] : tm.upper_tols[j];
+                if (tm.is_constraint)  // EQ -> abs penalty (2 aux), INEQ -> hinge (1 aux); objective = merit coefficient
+                  add_slot(SLOT_JOINTVEL_TIME, i, j, half, own, zero ? 2 : 1, 1, zero ? 1 : 0, 0.0, c, tm.targets[j], tol);
+                else                   // sco::HINGE: exprScale(aff, coeff); addHinge(aff, 1)
+                  add_slot(SLOT_JOINTVEL_TIME, i, j, half, own, 1, 0, 0, 1.0, c, tm.targets[j], tol);
+                c2.back() = R2++;
+              }
+          }
+          st_terms = true;  // (rows only: the QP stays a block chain with pair rows - structured solvers, piecewise driver)
+          break;
+#endif
+        }
+        case TMX_TERM_TOTAL_TIME:
+        {
+          // TotalTimeTermInfo::hatch (problem_description.cpp:1852-1890): one cost / constraint over tau[1 .. T-1]
+          if (T < 2)
+          {
+            ctx->err = "total_time: the problem needs two steps";
+            return TMX_ERR_INVALID;
+          }
+          const bool zero = std::fabs(tm.margin) < 1e-5;
+          const int own = tm.is_constraint ? n_cnts++ : n_costs++;
+          const int form = tm.is_constraint ? (zero ? 2 : 3) : (zero ? 0 : 1);
+          int slot = -1;
+          if (form != 0 && tm.coeff != 0.0)
+          {
+            slot = (int)kind.size();
+            if (form == 1)
+              add_slot(SLOT_TOTAL_TIME, 1, (int)tt_owner.size(), 0, own, 1, 0, 0, 1.0, tm.coeff, 0.0, 0.0);
+            else
+              add_slot(SLOT_TOTAL_TIME, 1, (int)tt_owner.size(), 0, own, form == 2 ? 2 : 1, 1, form == 2 ? 1 : 0, 0.0, tm.coeff, 0.0, 0.0);
+          }
+          if (form == 0 && tm.coeff == 0.0)
+            break;  // (no model, the value is zero: nothing to carry)
+          tt_owner.push_back(own);
+          tt_form.push_back(form);
+          tt_slot.push_back(slot);
+          tt_coeff.push_back(tm.coeff);
+          tt_limit.push_back(tm.margin);
+          st_terms = true;
+          qp_dense = true;
           break;
         }
         default:
@@ -1364,6 +1507,21 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
   UP(ob_center, ob_center);
   UP(ob_radius, ob_radius);
   UP(ob_axis, ob_axis);
+  P.n_tv = (int)tv_owner.size();
+  P.n_tt = (int)tt_owner.size();
+  UP(tv_owner, tv_owner);
+  UP(tv_joint, tv_joint);
+  UP(tv_first, tv_first);
+  UP(tv_last, tv_last);
+  UP(tv_coeff, tv_coeff);
+  UP(tv_target, tv_target);
+  UP(tv_up, tv_up);
+  UP(tv_lo, tv_lo);
+  UP(tt_owner, tt_owner);
+  UP(tt_form, tt_form);
+  UP(tt_slot, tt_slot);
+  UP(tt_coeff, tt_coeff);
+  UP(tt_limit, tt_limit);
 #undef UP
   // workspace placement: everything in LDS if it fits; else everything but the row coefficient arrays (they move to the HBM
   // scratch: config 4, 177 -> 125 KB); else the HBM-workspace kernels
@@ -1404,6 +1562,7 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
   ctx->piecewise = P.st != 0;
   ctx->band = P.band != 0;
   ctx->hull = P.n_ls_hull > 0;
+  ctx->tt_squared = std::find(tt_form.begin(), tt_form.end(), 0) != tt_form.end();
   if (ctx->dense)
   {
     // The dense engine inverts n x n (every rho update) and (n + active rows)^2 (polish) matrices by Gauss-Jordan, one workgroup per
@@ -1580,13 +1739,24 @@ static tmx_status ensure_batch(tmx_ctx* ctx, int B)
     size_t cap = (size_t)P.n_max + 2 * (size_t)P.NA;
     for (int r = 0; r < P.R; ++r)
       cap += (size_t)std::max(2 * P.D, 4);
+    cap += (size_t)P.n_tt * P.T;  // global rows of the TotalTime terms
     if (P.n_max > 4096 || P.m_max > 16384)
     {
       ctx->err = "joint acceleration / jerk terms: the QP is too large for the dense engine (n <= 4096, m <= 16384)";
       return TMX_ERR_UNSUPPORTED;
     }
     H.dq_nnzA = (int)cap;
-    const size_t nzp = (size_t)std::max(1, P.nnzP) + (size_t)P.n_fx_cost * P.D * (P.D + 1) / 2;
+    // (+ the squared time-parameterised costs: per waypoint the joint diagonals and couplings, two columns of entries in the time
+    //  column, its diagonal; a squared TotalTime cost couples all time variables)
+    size_t nzp = (size_t)std::max(1, P.nnzP) + (size_t)P.n_fx_cost * P.D * (P.D + 1) / 2;
+    if (P.n_tv > 0)
+      nzp += (size_t)P.T * (4 * (size_t)P.D + 1);
+    for (int k = 0; k < P.n_tt; ++k)
+      if (ctx->tt_squared)
+      {
+        nzp += (size_t)P.T * (P.T + 1) / 2;
+        break;
+      }
     H.dq_nnzP = (int)nzp;
     const size_t nfc = (size_t)std::max(1, P.n_fx_cost), dd = (size_t)P.D * P.D;
     AL(fx_H, b * nfc * dd);
@@ -1617,6 +1787,10 @@ static tmx_status ensure_batch(tmx_ctx* ctx, int B)
     if ((rc = dalloc(ctx, pool, &H.dq_ws, b * (size_t)H.dq_ws_stride, /*zero=*/false)) != TMX_OK)
       return rc;
   }
+  if (P.n_tv > 0)
+    AL(tv_aff, b * (size_t)P.n_tv * P.T * TMX_TV_REC);
+  if (P.n_tt > 0)
+    AL(tt_aff, b * (size_t)P.n_tt * (P.T + 1));
   H.tail_flag = ctx->h_tail;  // pinned host memory is device-accessible at the same address (unified addressing)
   H.qp_scratch_stride = (long long)qp_scratch_doubles(P.D, P.T, P.R, P.NA, P.n_link, P.coef_far);
   AL(qp_scratch, b * (size_t)H.qp_scratch_stride);
@@ -2186,7 +2360,9 @@ tmx_status tmx_export_csc(tmx_ctx* ctx, int32_t problem, int32_t* n, int32_t* m,
   HIPCHK(hipSetDevice(ctx->device));
   const DevProblem& P = ctx->hp;
   // device scratch sized for the worst case
-  const size_t nmax = P.n_max, mmax = P.m_max, nzA = (size_t)P.R * (std::max(2 * P.D, 4) + 2) + 2 * nmax, nzP = (size_t)P.nnzP + 1 + (size_t)P.n_fx_cost * P.D * (P.D + 1) / 2;
+  const size_t nmax = P.n_max, mmax = P.m_max, nzA = (size_t)P.R * (std::max(2 * P.D, 4) + 2) + 2 * nmax + (size_t)P.n_tt * P.T,
+               nzP = (size_t)P.nnzP + 1 + (size_t)P.n_fx_cost * P.D * (P.D + 1) / 2 + (P.n_tv > 0 ? (size_t)P.T * (4 * (size_t)P.D + 1) : 0) +
+                     (ctx->tt_squared ? (size_t)P.T * (P.T + 1) / 2 : 0);
   std::vector<void*> pool;
   CscOut o{};
   int* d_dims = nullptr;

@@ -119,6 +119,16 @@ TMX_DEVFN void evaluate_body(const DevProblem* P, const DevBatch* Bt, int which)
 TMX_KERNEL_LB(256) k_evaluate(const DevProblem* P, const DevBatch* Bt, int which) { evaluate_body<false>(P, Bt, which); }
 TMX_KERNEL_LB(256) k_evaluate_hull(const DevProblem* P, const DevBatch* Bt, int which) { evaluate_body<true>(P, Bt, which); }
 
+// per-problem slices of the time-parameterised terms' linearisations (DevBatch::tv_aff / tt_aff; nullptr without such terms)
+TMX_DEVFN double* tv_aff_of(const DevProblem* P, const DevBatch* Bt, int b)
+{
+  return (P->n_tv > 0 && Bt->tv_aff) ? Bt->tv_aff + (size_t)b * P->n_tv * P->T * TMX_TV_REC : nullptr;
+}
+TMX_DEVFN double* tt_aff_of(const DevProblem* P, const DevBatch* Bt, int b)
+{
+  return (P->n_tt > 0 && Bt->tt_aff) ? Bt->tt_aff + (size_t)b * P->n_tt * (P->T + 1) : nullptr;
+}
+
 // convexify (K1, K3) + reference QP structure (K4) for problems in PHASE_CONVEXIFY (all problems if force)
 template <bool HULL>
 TMX_DEVFN void convexify_body(const DevProblem* P, const DevBatch* Bt, int force)
@@ -149,9 +159,14 @@ TMX_DEVFN void convexify_body(const DevProblem* P, const DevBatch* Bt, int force
     const size_t fo = (size_t)b * P->n_fx_cost;
     if (P->n_fx > 0)
       convexify_func_terms(P, x, act, coef, rhs, Bt->fx_H + fo * D * D, Bt->fx_g + fo * D, Bt->fx_c + fo, Bt->fx_W + fo * 2 * D * D, tid, NT);
+    if (P->use_time)
+    {
+      convexify_time_terms(P, x, act, coef, Bt->coef2 + (size_t)b * P->n_link * D, rhs, tv_aff_of(P, Bt, b), tt_aff_of(P, Bt, b), tid, NT);
+      TMX_SYNC();
+    }
     qp_structure<true>(P, act, coef, Bt->coef2 + (size_t)b * P->n_link * D, rhs, x, Bt->trust[b], Bt->merit + (size_t)b * P->n_cnts,
                        Bt->dims + 4 * b, Bt->hashes + 4 * b, nullptr, reinterpret_cast<int*>(smem), tid, NT, Bt->qdyn + (size_t)b * P->NX, nullptr,
-                       Bt->fx_H + fo * D * D, Bt->fx_g + fo * D);
+                       Bt->fx_H + fo * D * D, Bt->fx_g + fo * D, tv_aff_of(P, Bt, b), tt_aff_of(P, Bt, b));
   }
   else
     qp_structure(P, act, coef, Bt->coef2 + (size_t)b * P->n_link * D, rhs, x, Bt->trust[b], Bt->merit + (size_t)b * P->n_cnts, Bt->dims + 4 * b,
@@ -176,7 +191,7 @@ TMX_KERNEL k_export_csc(const DevProblem* P, const DevBatch* Bt, int b, CscOut o
     qp_structure<true>(P, Bt->active + (size_t)b * R, Bt->coef + (size_t)b * R * D, Bt->coef2 + (size_t)b * P->n_link * D,
                        Bt->rhs + (size_t)b * R, Bt->x + (size_t)b * P->NX, Bt->trust[b], Bt->merit + (size_t)b * P->n_cnts, dims_out, hashes_out,
                        &out, reinterpret_cast<int*>(smem), tid, NT, Bt->qdyn + (size_t)b * P->NX, nullptr,
-                       Bt->fx_H + (size_t)b * P->n_fx_cost * D * D, Bt->fx_g + (size_t)b * P->n_fx_cost * D);
+                       Bt->fx_H + (size_t)b * P->n_fx_cost * D * D, Bt->fx_g + (size_t)b * P->n_fx_cost * D, tv_aff_of(P, Bt, b), tt_aff_of(P, Bt, b));
   else
     qp_structure(P, Bt->active + (size_t)b * R, Bt->coef + (size_t)b * R * D, Bt->coef2 + (size_t)b * P->n_link * D, Bt->rhs + (size_t)b * R,
                  Bt->x + (size_t)b * P->NX, Bt->trust[b], Bt->merit + (size_t)b * P->n_cnts, dims_out, hashes_out, &out,
@@ -209,7 +224,8 @@ TMX_DEVFN void qp_solve_dense_block(const DevProblem* P, const DevBatch* Bt, int
   const int* act = Bt->active + (size_t)b * R;
   qp_structure<true>(P, act, Bt->coef + (size_t)b * R * D, Bt->coef2 + (size_t)b * P->n_link * D, Bt->rhs + (size_t)b * R,
                      Bt->x + (size_t)b * NX, Bt->trust[b], Bt->merit + (size_t)b * P->n_cnts, dims, hs, &out, reinterpret_cast<int*>(smem), tid,
-                     NT, Bt->qdyn + (size_t)b * NX, nullptr, Bt->fx_H + (size_t)b * P->n_fx_cost * D * D, Bt->fx_g + (size_t)b * P->n_fx_cost * D);
+                     NT, Bt->qdyn + (size_t)b * NX, nullptr, Bt->fx_H + (size_t)b * P->n_fx_cost * D * D, Bt->fx_g + (size_t)b * P->n_fx_cost * D,
+                     tv_aff_of(P, Bt, b), tt_aff_of(P, Bt, b));
   // reference positions of rows / aux variables (LDS, layout of qp_structure) -> per-problem scratch
   QpWs w;
   double* scratch = Bt->qp_scratch + (size_t)b * Bt->qp_scratch_stride;

@@ -53,11 +53,13 @@ template <bool ST = false>
 TMX_DEVFN void qp_structure(const DevProblem* P, const int* active, const double* coef, const double* coef2, const double* rhs,
                             const double* xcur, double trust, const double* merit, int* dims, unsigned long long* hashes,
                             const CscOut* out, int* iscratch, int tid, int NT, const double* qdyn = nullptr, QpWs* cw = nullptr,
-                            const double* fxH = nullptr, const double* fxg = nullptr)
+                            const double* fxH = nullptr, const double* fxg = nullptr, const double* tv_aff = nullptr, const double* tt_aff = nullptr)
 {
   (void)coef2;
   (void)fxH;
   (void)fxg;
+  (void)tv_aff;
+  (void)tt_aff;
   const int D = P->D, T = P->T, NX = P->NX, R = P->R;
   int* colptr = iscratch;               // n_max + 1
   int* rowref = colptr + P->n_max + 1;  // R
@@ -160,6 +162,11 @@ TMX_DEVFN void qp_structure(const DevProblem* P, const int* active, const double
             if (lact[r] && slot_is_diff(P->slot_kind[r]) && P->slot_sub3[r] >= back && P->slot_sub[r] == j && diff_row_coef(P, r, back) != 0.0)
               ++c;
           }
+    if constexpr (ST)
+      if (P->n_tt > 0 && tt_aff != nullptr && j == D - 1 && t >= 1)  // global rows of the TotalTime terms on this time variable
+        for (int k = 0; k < P->n_tt; ++k)
+          if (P->tt_slot[k] >= 0 && lact[P->tt_slot[k]] && tt_row_entry(P, tt_aff, k, t) != 0.0)
+            ++c;
     ccount[v] = c;
   }
   for (int rq = tid; rq < n_it; rq += NT)
@@ -234,6 +241,19 @@ TMX_DEVFN void qp_structure(const DevProblem* P, const int* active, const double
           next_far(back);
         }
     (void)qf_end;
+    // cursor over the global rows (TotalTime terms, ascending slot = ascending reference row) with an entry on this variable
+    int qg = 0;
+    auto glob_hit = [&](int k) -> bool {
+      if constexpr (ST)
+        return tt_aff != nullptr && j == D - 1 && t >= 1 && P->tt_slot[k] >= 0 && active[P->tt_slot[k]] && tt_row_entry(P, tt_aff, k, t) != 0.0;
+      return false;
+    };
+    const int qg_end = (ST && tt_aff != nullptr) ? P->n_tt : 0;
+    auto next_glob = [&]() {
+      while (qg < qg_end && !glob_hit(qg))
+        ++qg;
+    };
+    next_glob();
 #endif
     for (int q = wls[t]; q <= wls[t + 1]; ++q)
     {
@@ -272,6 +292,11 @@ TMX_DEVFN void qp_structure(const DevProblem* P, const int* active, const double
               best = back;
               rbest = rowref[wll[qf[back - 2]]];
             }
+          if (qg < qg_end && rowref[P->tt_slot[qg]] < rbest)
+          {
+            best = 4;
+            rbest = rowref[P->tt_slot[qg]];
+          }
           if (best < 0)
             break;
           hA += tmx_hash_term(rbest, (uint64_t)pos, 4);
@@ -282,13 +307,18 @@ TMX_DEVFN void qp_structure(const DevProblem* P, const int* active, const double
           if (out)
           {
             out->A_i[pos] = rbest;
-            out->A_x[pos] = (best == 1) ? link_val(ql) : diff_row_coef(P, wll[qf[best - 2]], best);
+            out->A_x[pos] = (best == 1) ? link_val(ql) : ((best == 4) ? tt_row_entry(P, tt_aff, qg, t) : diff_row_coef(P, wll[qf[best - 2]], best));
           }
           ++pos;
           if (best == 1)
           {
             ++ql;
             next_link();
+          }
+          else if (best == 4)
+          {
+            ++qg;
+            next_glob();
           }
           else
           {
@@ -358,17 +388,25 @@ TMX_DEVFN void qp_structure(const DevProblem* P, const int* active, const double
   unsigned long long hP = 0ULL, wsP = 0ULL;
   bool p_done = false;
   if constexpr (ST)
-    if (fxH != nullptr && P->n_fx_cost > 0)
+    if ((fxH != nullptr && P->n_fx_cost > 0) || (tv_aff != nullptr && P->n_tv > 0) || (tt_aff != nullptr && P->n_tt > 0))
     {
-      // DYNAMIC objective blocks of the CostFromFunc models (exprToEigen of their QuadExprs, solver_utils.cpp:49-109): for the
-      // variables (t, i <= j) of a waypoint with cost instances, P(i, j) += H_ij (i < j) and P(j, j) += 2 (H_jj / 2); a triplet exists
-      // where the coefficient is not exactly zero.  Column pointers = static ones + the dynamic entries in front.
+      // DYNAMIC objective entries (exprToEigen of the costs' QuadExprs, solver_utils.cpp:49-109): a triplet exists where a
+      // coefficient is not exactly zero; P(i, j) = sum of the triplets (i < j), P(j, j) = 2 x sum.
+      //  * CostFromFunc / squared CostFromErrFunc models of one waypoint (fxH): the block of that waypoint
+      //  * squared JointVel-with-time costs (tv_aff): exprSquare of the rows a x[t][j] + b x[t+1][j] + c tau[t+1] + k, scaled by the
+      //    coefficient - entries (x_t, x_t), (x_t, x_t+1), (x_t, tau_t+1), (x_t+1, x_t+1), (x_t+1, tau_t+1), (tau_t+1, tau_t+1); the upper
+      //    rows of a cost come before its lower rows, costs in instance order
+      //  * squared TotalTime costs (tt_aff): all pairs of time variables
+      // Column pointers = counts of the walk below.
       p_done = true;
       TMX_SYNC();
-      int* pextra = ccount;  // (the column counts of A are no longer needed)
-      auto dyn_val = [&](int t, int i, int j, bool& any) -> double {
+      int* pcnt = ccount;  // (the column counts of A are no longer needed)
+      const int T1 = P->T + 1;
+      auto fx_val = [&](int t, int i, int j, bool& any) -> double {
         double v = 0.0;
         any = false;
+        if (fxH == nullptr)
+          return v;
         for (int c = 0; c < P->n_fx; ++c)
           if (fx_is_quad(P->fx_kind[c]) && P->fx_t[c] == t)
           {
@@ -382,47 +420,152 @@ TMX_DEVFN void qp_structure(const DevProblem* P, const int* active, const double
           }
         return v;
       };
+      // role of the two Jacobian entries of a velocity-cost record: ia, ib in {0: x[t][j], 1: x[t+1][j], 2: tau[t+1]} of segment sgm of
+      // joint jj; the upper and the lower row of every instance contribute (the lower row's entries are the negated ones)
+      auto tv_val = [&](int sgm, int jj, int ia, int ib, bool& any) -> double {
+        double v = 0.0;
+        any = false;
+        if (tv_aff == nullptr || sgm < 0 || sgm >= P->T - 1)
+          return v;
+        for (int c = 0; c < P->n_tv; ++c)
+          if ((jj < 0 || P->tv_joint[c] == jj) && sgm >= P->tv_first[c] && sgm < P->tv_last[c])
+          {
+            const double* rec = tv_aff + ((size_t)c * P->T + sgm) * TMX_TV_REC;
+            for (int half = 0; half < 2; ++half)
+            {
+              const double ca = half ? -rec[ia] : rec[ia], cb = half ? -rec[ib] : rec[ib];
+              const double coeff = ((ia == ib) ? ca * ca : 2 * ca * cb) * P->tv_coeff[c];
+              if (coeff != 0.0)
+              {
+                v += (ia == ib) ? 2.0 * coeff : coeff;
+                any = true;
+              }
+            }
+          }
+        return v;
+      };
+      auto tt_val = [&](int s_, int t_, bool& any) -> double {  // time variables of waypoints s_ <= t_
+        double v = 0.0;
+        any = false;
+        if (tt_aff == nullptr || s_ < 1)
+          return v;
+        for (int c = 0; c < P->n_tt; ++c)
+          if (P->tt_form[c] == 0)
+          {
+            const double ga = tt_aff[(size_t)c * T1 + s_], gb = tt_aff[(size_t)c * T1 + t_];
+            const double coeff = ((s_ == t_) ? ga * ga : 2 * ga * gb) * P->tt_coeff[c];
+            if (coeff != 0.0)
+            {
+              v += (s_ == t_) ? 2.0 * coeff : coeff;
+              any = true;
+            }
+          }
+        return v;
+      };
+      // entries of column c in ascending row order: f(row, value)
+      auto walk = [&](int c, auto&& f) {
+        const int t = c / D, j = c % D;
+        const bool tcol = P->use_time && j == D - 1;
+        bool any, any2;
+        if (!tcol)
+        {
+          for (int back = 3; back >= 2; --back)
+          {
+            const double* pb = (back == 3) ? P->po3 : P->po2;
+            if (t >= back && pb[c - back * D] != 0.0)
+              f(c - back * D, pb[c - back * D]);
+          }
+          if (t >= 1)
+          {
+            const double dv = P->use_time ? tv_val(t - 1, j, 0, 1, any) : (any = false, 0.0);
+            if (P->po[c - D] != 0.0 || any)
+              f(c - D, P->po[c - D] + dv);
+          }
+          for (int i = 0; i < j; ++i)
+          {
+            const double v = fx_val(t, i, j, any);
+            if (any)
+              f(c - j + i, v);
+          }
+          const double dv = fx_val(t, j, j, any);
+          double tvd = 0.0;
+          any2 = false;
+          if (P->use_time && tv_aff != nullptr)
+          {
+            // insertion order within a cost: its upper rows by ascending segment - segment t-1 (this variable is x[t+1] of it) before
+            // segment t - then its lower rows the same way; duplicates are summed in that order (tripletsToCsc)
+            for (int c2_ = 0; c2_ < P->n_tv; ++c2_)
+              if (P->tv_joint[c2_] == j)
+                for (int half = 0; half < 2; ++half)
+                  for (int side = 1; side >= 0; --side)
+                  {
+                    const int sgm = side ? t - 1 : t;
+                    if (sgm < P->tv_first[c2_] || sgm >= P->tv_last[c2_])
+                      continue;
+                    const double cfv = tv_aff[((size_t)c2_ * P->T + sgm) * TMX_TV_REC + (side ? 1 : 0)];
+                    const double coeff = (cfv * cfv) * P->tv_coeff[c2_];  // (the lower row's entry is the negated one: same square)
+                    if (coeff != 0.0)
+                    {
+                      tvd += 2.0 * coeff;
+                      any2 = true;
+                    }
+                  }
+          }
+          if (P->pd[c] != 0.0 || any || any2)
+            f(c, (P->pd[c] + dv) + tvd);
+          return;
+        }
+        if (t < 1)
+        {
+          if (P->pd[c] != 0.0)
+            f(c, P->pd[c]);
+          return;
+        }
+        for (int s_ = 1; s_ <= t - 2; ++s_)
+        {
+          const double v = tt_val(s_, t, any);
+          if (any)
+            f(s_ * D + D - 1, v);
+        }
+        for (int jj = 0; jj < D - 1; ++jj)
+        {
+          const double v = tv_val(t - 1, jj, 0, 2, any);
+          if (any)
+            f((t - 1) * D + jj, v);
+        }
+        if (t >= 2)
+        {
+          const double v = tt_val(t - 1, t, any);
+          if (any)
+            f((t - 1) * D + D - 1, v);
+        }
+        for (int jj = 0; jj < D - 1; ++jj)
+        {
+          const double v = tv_val(t - 1, jj, 1, 2, any);
+          if (any)
+            f(t * D + jj, v);
+        }
+        const double v1 = tv_val(t - 1, -1, 2, 2, any), v2 = tt_val(t, t, any2);
+        if (P->pd[c] != 0.0 || any || any2)
+          f(c, (P->pd[c] + v1) + v2);
+      };
       for (int c = tid; c < NX; c += NT)
       {
-        const int t = c / D, j = c % D;
-        int extra = 0;
-        bool any;
-        for (int i = 0; i < j; ++i)
-        {
-          dyn_val(t, i, j, any);
-          extra += any ? 1 : 0;
-        }
-        dyn_val(t, j, j, any);
-        if (any && P->pd[c] == 0.0)
-          ++extra;
-        pextra[c] = extra;
+        int cnt = 0;
+        walk(c, [&](int, double) { ++cnt; });
+        pcnt[c] = cnt;
       }
       TMX_SYNC();
-      int tot_extra = 0;
+      int nnzP_dyn = 0;
       for (int c = 0; c < NX; ++c)
-        tot_extra += pextra[c];
-      const int nnzP_dyn = P->nnzP + tot_extra;
+        nnzP_dyn += pcnt[c];
       const int pp_bytes = n + 1, pp_full = pp_bytes / 8, pp_rem = pp_bytes % 8;
       const int pi_full = nnzP_dyn / 8, pi_rem = nnzP_dyn % 8;
-      auto emitP = [&](int row, double val, int& run) {
-        hP += tmx_hash_term(row, (uint64_t)run, 2);
-        if (run < pi_full)
-          wsP += tmx_hash_term(row, (uint64_t)run, 12);
-        else if (run == pi_full && pi_rem > 0)
-          wsP += tmx_hash_term((long long)((unsigned long long)row & ((1ULL << (8 * pi_rem)) - 1ULL)), (uint64_t)run, 12);
-        if (out)
-        {
-          out->P_i[run] = row;
-          out->P_x[run] = val;
-        }
-        ++run;
-      };
       for (int c = tid; c <= n; c += NT)
       {
-        int before = 0;
+        int run = 0;
         for (int q = 0; q < (c < NX ? c : NX); ++q)
-          before += pextra[q];
-        int run = ((c <= NX) ? P->p_colptr[c] : P->nnzP) + before;
+          run += pcnt[q];
         const long long val = run;
         hP += tmx_hash_term(val, (uint64_t)c, 1);
         if (c < pp_full)
@@ -434,25 +577,19 @@ TMX_DEVFN void qp_structure(const DevProblem* P, const int* active, const double
         if (c == n)
           dims[2] = nnzP_dyn;
         if (c < NX)
-        {
-          const int t = c / D, j = c % D;
-          for (int back = 3; back >= 1; --back)
-          {
-            const double* pb = (back == 3) ? P->po3 : ((back == 2) ? P->po2 : P->po);
-            if (t >= back && pb[c - back * D] != 0.0)
-              emitP(c - back * D, pb[c - back * D], run);
-          }
-          bool any;
-          for (int i = 0; i < j; ++i)
-          {
-            const double v = dyn_val(t, i, j, any);
-            if (any)
-              emitP(c - j + i, v, run);
-          }
-          const double dv = dyn_val(t, j, j, any);
-          if (P->pd[c] != 0.0 || any)
-            emitP(c, P->pd[c] + dv, run);
-        }
+          walk(c, [&](int row, double v) {
+            hP += tmx_hash_term(row, (uint64_t)run, 2);
+            if (run < pi_full)
+              wsP += tmx_hash_term(row, (uint64_t)run, 12);
+            else if (run == pi_full && pi_rem > 0)
+              wsP += tmx_hash_term((long long)((unsigned long long)row & ((1ULL << (8 * pi_rem)) - 1ULL)), (uint64_t)run, 12);
+            if (out)
+            {
+              out->P_i[run] = row;
+              out->P_x[run] = v;
+            }
+            ++run;
+          });
       }
     }
   if (!p_done)
@@ -550,6 +687,42 @@ TMX_DEVFN void qp_structure(const DevProblem* P, const int* active, const double
           for (int c = 0; c < P->n_fx; ++c)
             if (fx_is_quad(P->fx_kind[c]) && P->fx_t[c] == v / D)
               qv += fxg[(size_t)P->fx_ci[c] * D + v % D];  // affexpr.coeffs of the CostFromFunc model
+      if constexpr (ST)
+        if (P->use_time)
+        {
+          // affexpr of exprSquare (expr_ops.cpp:55-84): 2 * constant * coefficient, scaled by the cost coefficient; exprToVector adds
+          // the non-zero ones in insertion order (upper rows of a cost, then its lower rows)
+          const int t = v / D, j = v % D;
+          if (tv_aff != nullptr)
+            for (int c = 0; c < P->n_tv; ++c)
+              for (int half = 0; half < 2; ++half)
+                for (int side = 1; side >= 0; --side)  // segment t-1 (this variable is its x[t+1] / tau[t+1]), then segment t
+                {
+                  const int sgm = side ? t - 1 : t;
+                  if (sgm < P->tv_first[c] || sgm >= P->tv_last[c])
+                    continue;
+                  const double* rec = tv_aff + ((size_t)c * P->T + sgm) * TMX_TV_REC;
+                  double cf = 0.0;
+                  if (j == D - 1)
+                    cf = side ? rec[2] : 0.0;
+                  else if (j == P->tv_joint[c])
+                    cf = side ? rec[1] : rec[0];
+                  if (half)
+                    cf = -cf;
+                  const double lin = ((2 * rec[3 + half]) * cf) * P->tv_coeff[c];
+                  if (lin != 0.0)
+                    qv += lin;
+                }
+          if (tt_aff != nullptr && j == D - 1 && t >= 1)
+            for (int c = 0; c < P->n_tt; ++c)
+              if (P->tt_form[c] == 0)
+              {
+                const double* g = tt_aff + (size_t)c * (P->T + 1);
+                const double lin = ((2 * g[P->T]) * g[t]) * P->tt_coeff[c];
+                if (lin != 0.0)
+                  qv += lin;
+              }
+        }
       out->q[v] = qv;
       const double xi = fmin(fmax(xcur[v], P->jl[v % D]), P->ju[v % D]);
       const double lb = fmax(xi - trust, P->jl[v % D]), ub = fmin(xi + trust, P->ju[v % D]);
@@ -2189,6 +2362,10 @@ TMX_DEVFN void sqp_model_values(const DevProblem* P, const DevBatch* Bt, int b, 
             if (slot_is_diff(P->slot_kind[r]))
               for (int k = 2; k <= P->slot_sub3[r]; ++k)
                 aff += diff_row_coef(P, r, k) * xq[(t + k) * D + P->slot_sub[r]];
+          if constexpr (ST)
+            if (P->slot_kind[r] == SLOT_TOTAL_TIME && Bt->tt_aff)  // global row: its entries on tau[1 .. T-1]
+              for (int tt = 1; tt < P->T; ++tt)
+                aff += tt_row_entry(P, Bt->tt_aff + (size_t)b * P->n_tt * (P->T + 1), P->slot_sub[r], tt) * xq[tt * D + D - 1];
           aff -= rhs[r];
           vr = P->slot_eq[r] ? fabs(aff) : ((aff > 0) ? aff : 0.0);
           key = P->n_costs + P->slot_owner[r];
@@ -2248,6 +2425,79 @@ TMX_DEVFN void sqp_model_values(const DevProblem* P, const DevBatch* Bt, int b, 
               const size_t o = (size_t)b * P->n_fx_cost + ci;
               acc += fx_model_value(Bt->fx_H + o * D * D, Bt->fx_g + o * D, Bt->fx_c[o], xq + P->fx_t[c] * D, D);
             }
+        if constexpr (ST)
+          if (P->use_time)
+          {
+            // ConvexObjective::value of the squared time-parameterised costs: QuadExpr::value at the QP solution - the constants, the
+            // affine part in insertion order, then the quadratic triplets in insertion order (exprSquare, expr_ops.cpp:55-84; the
+            // QuadExprs of a cost's rows are concatenated by exprInc)
+            for (int c = 0; c < P->n_tv; ++c)
+              if (P->tv_owner[c] == k && Bt->tv_aff)
+              {
+                const double* base = Bt->tv_aff + ((size_t)b * P->n_tv + c) * P->T * TMX_TV_REC;
+                const int j = P->tv_joint[c];
+                const double w = P->tv_coeff[c];
+                double cst = 0.0;
+                for (int half = 0; half < 2; ++half)
+                  for (int sg = P->tv_first[c]; sg < P->tv_last[c]; ++sg)
+                    cst += (base[sg * TMX_TV_REC + 3 + half] * base[sg * TMX_TV_REC + 3 + half]) * w;
+                double val = cst;
+                for (int half = 0; half < 2; ++half)
+                  for (int sg = P->tv_first[c]; sg < P->tv_last[c]; ++sg)
+                  {
+                    const double* rec = base + sg * TMX_TV_REC;
+                    const double kk = rec[3 + half];
+                    const double xs[3] = { xq[sg * D + j], xq[(sg + 1) * D + j], xq[(sg + 1) * D + D - 1] };
+                    for (int q = 0; q < 3; ++q)
+                    {
+                      const double cf = half ? -rec[q] : rec[q];
+                      if (rec[q] != 0.0)  // (cleanupAff dropped the variable otherwise)
+                        val += (((2 * kk) * cf) * w) * xs[q];
+                    }
+                  }
+                for (int half = 0; half < 2; ++half)
+                  for (int sg = P->tv_first[c]; sg < P->tv_last[c]; ++sg)
+                  {
+                    const double* rec = base + sg * TMX_TV_REC;
+                    const double xs[3] = { xq[sg * D + j], xq[(sg + 1) * D + j], xq[(sg + 1) * D + D - 1] };
+                    for (int q = 0; q < 3; ++q)
+                    {
+                      if (rec[q] == 0.0)
+                        continue;
+                      const double cq = half ? -rec[q] : rec[q];
+                      val += (((cq * cq) * w) * xs[q]) * xs[q];
+                      for (int q2 = q + 1; q2 < 3; ++q2)
+                      {
+                        if (rec[q2] == 0.0)
+                          continue;
+                        const double cq2 = half ? -rec[q2] : rec[q2];
+                        val += (((2 * cq * cq2) * w) * xs[q]) * xs[q2];
+                      }
+                    }
+                  }
+                acc += val;
+              }
+            for (int c = 0; c < P->n_tt; ++c)
+              if (P->tt_form[c] == 0 && P->tt_owner[c] == k && Bt->tt_aff)
+              {
+                const double* g = Bt->tt_aff + ((size_t)b * P->n_tt + c) * (P->T + 1);
+                const double w = P->tt_coeff[c], kk = g[P->T];
+                double val = (kk * kk) * w;
+                for (int tt = 1; tt < P->T; ++tt)
+                  if (g[tt] != 0.0)
+                    val += (((2 * kk) * g[tt]) * w) * xq[tt * D + D - 1];
+                for (int tt = 1; tt < P->T; ++tt)
+                {
+                  if (g[tt] == 0.0)
+                    continue;
+                  val += (((g[tt] * g[tt]) * w) * xq[tt * D + D - 1]) * xq[tt * D + D - 1];
+                  for (int t2 = tt + 1; t2 < P->T; ++t2)
+                    if (g[t2] != 0.0)
+                      val += (((2 * g[tt] * g[t2]) * w) * xq[tt * D + D - 1]) * xq[t2 * D + D - 1];
+                }
+                acc += val;
+              }
+          }
         model_cost[k] = acc;
       }
       else

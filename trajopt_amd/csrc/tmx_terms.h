@@ -374,13 +374,12 @@ TMX_DEVFN double lin_spaced_at(int size, double low, double high, int i)
 template <bool HULL = false>
 TMX_DEVFN bool lvs_contact(const DevProblem* P, const double* q0, const double* q1, int r, LvsContact& c)
 {
-  const int D = P->D;
   const int s = P->slot_sub[r], o = P->slot_sub2[r], flags = P->slot_sub3[r];
   const int i = (flags >> 3) & 0x1FFF, kmax = flags >> 16;  // sub-state index; sub-state capacity of the slot's term
   const bool fixed0 = flags & 1, fixed1 = flags & 2, cast = flags & 4;
   const double lvs = P->slot_aux3[r], margin = P->slot_aux1[r], buffer = P->slot_aux2[r];
   double d2 = 0.0;
-  for (int j = 0; j < D; ++j)
+  for (int j = 0; j < P->DK; ++j)  // the joints (a time-parameterised problem's time column is not part of the state distance)
     d2 += (q1[j] - q0[j]) * (q1[j] - q0[j]);
   const double dist = sqrt(d2);
   int cnt = 2;
@@ -1033,6 +1032,159 @@ TMX_DEVFN double diff_value(const double* xv, int D, int i, int j, int ord)
   return (d2 - d1) - (d1 - d0);
 }
 
+
+// ---- TIME-PARAMETERISED TERMS (DevProblem::use_time) ---------------------------------------------------------------------------
+// JointVelErrCalculator / JointVelJacCalculator (trajopt/src/kinematic_terms.cpp:427-470) for segment (t, t+1) of joint j:
+//   vel = (x[t+1][j] - x[t][j]) * tau[t+1];  upper error -(upper_tol - (vel - target)),  lower error lower_tol - (vel - target);
+//   Jacobian of the upper row: -tau on x[t][j], +tau on x[t+1][j], x[t+1][j] - x[t][j] on tau[t+1]; the lower row is its negative.
+// affFromValGrad (trajopt_sco/src/modeling_utils.cpp:31-39): constant = y - sum_k J_k x_k over the term's variables in their order
+// (the joint's column, then the time column: x[t][j], x[t+1][j], tau[t+1]), coefficients with |J| <= 1e-7 dropped (cleanupAff).
+struct TvSeg
+{
+  double ja, jb, jc;    // cleaned Jacobian of the UPPER row
+  double y_up, y_lo;    // error values
+  double k_up, k_lo;    // constants of the two affine rows
+};
+TMX_DEVFN void tv_segment(const double* xv, int D, int t, int j, double target, double up, double lo, TvSeg& s)
+{
+  const double x0 = xv[t * D + j], x1 = xv[(t + 1) * D + j], tau = xv[(t + 1) * D + D - 1];
+  const double vel = (x1 - x0) * tau;
+  s.y_up = -(up - (vel - target));
+  s.y_lo = lo - (vel - target);
+  const double ja = -1.0 * tau, jb = 1.0 * tau, jc = x1 - x0;
+  double du = 0.0, dl = 0.0;
+  du += ja * x0;
+  du += jb * x1;
+  du += jc * tau;
+  dl += (-ja) * x0;
+  dl += (-jb) * x1;
+  dl += (-jc) * tau;
+  s.k_up = s.y_up - du;
+  s.k_lo = s.y_lo - dl;
+  s.ja = (fabs(ja) > TMX_CLEANUP_TOL) ? ja : 0.0;
+  s.jb = (fabs(jb) > TMX_CLEANUP_TOL) ? jb : 0.0;
+  s.jc = (fabs(jc) > TMX_CLEANUP_TOL) ? jc : 0.0;
+}
+// TimeCostCalculator (kinematic_terms.cpp:572-577): var_vals.cwiseInverse().sum() over tau[1 .. T-1] in the order of Eigen's
+// vectorised linear reduction with two-lane packets (oracle/trajprob.hpp timeInverseSum: the same statement)
+TMX_DEVFN double time_inverse_sum(const double* xv, int D, int T)
+{
+  const int n = T - 1;
+  auto inv = [&](int k) { return 1.0 / xv[(k + 1) * D + D - 1]; };
+  if (n <= 0)
+    return 0.0;
+  const int aligned2 = (n / 4) * 4, aligned = (n / 2) * 2;
+  double res;
+  if (aligned)
+  {
+    double p00 = inv(0), p01 = inv(1);
+    if (aligned > 2)
+    {
+      double p10 = inv(2), p11 = inv(3);
+      for (int k = 4; k < aligned2; k += 4)
+      {
+        p00 += inv(k);
+        p01 += inv(k + 1);
+        p10 += inv(k + 2);
+        p11 += inv(k + 3);
+      }
+      p00 += p10;
+      p01 += p11;
+      if (aligned > aligned2)
+      {
+        p00 += inv(aligned2);
+        p01 += inv(aligned2 + 1);
+      }
+    }
+    res = p00 + p01;
+    for (int k = aligned; k < n; ++k)
+      res += inv(k);
+  }
+  else
+  {
+    res = inv(0);
+    for (int k = 1; k < n; ++k)
+      res += inv(k);
+  }
+  return res;
+}
+// Convexification of the time-parameterised terms at xv (piecewise kernels; one thread per row / record):
+//   SLOT_JOINTVEL_TIME rows: coefficients on both waypoints + right-hand side (exprScale(aff, coeff), modeling_utils.cpp:175-204, :258-268)
+//   tv_aff: the linearised rows of the SQUARED velocity costs;  tt_aff: gradient and constant of every TotalTime term
+//   SLOT_TOTAL_TIME rows: right-hand side (their entries live in tt_aff)
+TMX_DEVFN void convexify_time_terms(const DevProblem* P, const double* xv, int* active, double* coef, double* coef2, double* rhs, double* tv_aff,
+                                    double* tt_aff, int tid, int NT)
+{
+  const int D = P->D, T = P->T;
+  for (int r = tid; r < P->R; r += NT)
+  {
+    const int kind = P->slot_kind[r];
+    if (kind == SLOT_JOINTVEL_TIME)
+    {
+      const int t = P->slot_t[r], j = P->slot_sub[r];
+      const double w = P->slot_scale[r];
+      TvSeg sg;
+      // slot_aux1 = target; slot_aux2 = the row's own tolerance (upper or lower): the other one does not enter this row
+      tv_segment(xv, D, t, j, P->slot_aux1[r], P->slot_aux2[r], P->slot_aux2[r], sg);
+      double* a0 = coef + (size_t)r * D;
+      double* a1 = coef2 + (size_t)P->slot_c2[r] * D;
+      for (int k = 0; k < D; ++k)
+        a0[k] = a1[k] = 0.0;
+      const bool upper = P->slot_sub2[r] == 0;
+      // (the lower row's Jacobian is the negated upper one: jac.bottomRows = -jac.topRows, kinematic_terms.cpp:466)
+      a0[j] = (upper ? sg.ja : -sg.ja) * w;
+      a1[j] = (upper ? sg.jb : -sg.jb) * w;
+      a1[D - 1] = (upper ? sg.jc : -sg.jc) * w;
+      rhs[r] = -((upper ? sg.k_up : sg.k_lo) * w);
+      active[r] = 1;
+    }
+  }
+  for (int item = tid; item < P->n_tv * (T - 1); item += NT)
+  {
+    const int k = item / (T - 1), t = item % (T - 1);
+    double* rec = tv_aff + ((size_t)k * T + t) * TMX_TV_REC;
+    if (t < P->tv_first[k] || t >= P->tv_last[k])
+    {
+      for (int q = 0; q < TMX_TV_REC; ++q)
+        rec[q] = 0.0;
+      continue;
+    }
+    TvSeg sg;
+    tv_segment(xv, D, t, P->tv_joint[k], P->tv_target[k], P->tv_up[k], P->tv_lo[k], sg);
+    rec[0] = sg.ja;
+    rec[1] = sg.jb;
+    rec[2] = sg.jc;
+    rec[3] = sg.k_up;
+    rec[4] = sg.k_lo;
+  }
+  for (int k = tid; k < P->n_tt; k += NT)
+  {
+    // TimeCostJacCalculator (kinematic_terms.cpp:579-584): -1 / tau^2; affFromValGrad over tau[1 .. T-1]
+    double* g = tt_aff + (size_t)k * (T + 1);
+    double dot = 0.0;
+    g[0] = 0.0;
+    for (int t = 1; t < T; ++t)
+    {
+      const double tau = xv[t * D + D - 1];
+      const double jv = -1 * (1.0 / (tau * tau));
+      dot += jv * tau;
+      g[t] = (fabs(jv) > TMX_CLEANUP_TOL) ? jv : 0.0;
+    }
+    const double y = time_inverse_sum(xv, D, T) - P->tt_limit[k];
+    g[T] = y - dot;
+    const int r = P->tt_slot[k];
+    if (r >= 0)
+    {
+      for (int q = 0; q < D; ++q)
+        coef[(size_t)r * D + q] = 0.0;
+      rhs[r] = -(g[T] * P->tt_coeff[k]);
+      active[r] = 1;
+    }
+  }
+}
+// entry of the global row of TotalTime term k on tau[t] (exprScale(aff, coeff))
+TMX_DEVFN double tt_row_entry(const DevProblem* P, const double* tt_aff, int k, int t) { return tt_aff[(size_t)k * (P->T + 1) + t] * P->tt_coeff[k]; }
+
 // ---------------------------------------------------------------------------------------------------
 // K6: exact costs / constraint violations at trajectory xv -> cost_out[n_costs], viol_out[n_cnts]
 // (BasicTrustRegionSQP::evaluateCosts / evaluateConstraintViols, trajopt_sco/src/optimizers.cpp:176-192)
@@ -1120,6 +1272,36 @@ TMX_DEVFN void evaluate_terms(const DevProblem* P, const double* xv, double* cos
       v = P->slot_iscnt[r] ? ((e > 0) ? e : 0.0) : fabs(e);
     }
 #endif
+    if constexpr (ST)
+    {
+      if (kind == SLOT_JOINTVEL_TIME)
+      {
+        // CostFromErrFunc::value, HINGE: pospart(err) * coeff; ConstraintFromErrFunc::value: err * coeff, violation |.| (EQ) / pospart
+        // (INEQ)  (modeling_utils.cpp:143-165, :238-245)
+        TvSeg sg;
+        tv_segment(xv, D, t, P->slot_sub[r], P->slot_aux1[r], P->slot_aux2[r], P->slot_aux2[r], sg);
+        const double e = (P->slot_sub2[r] == 0) ? sg.y_up : sg.y_lo;
+        if (P->slot_iscnt[r])
+        {
+          const double ec = e * P->slot_scale[r];
+          v = P->slot_eq[r] ? fabs(ec) : ((ec > 0) ? ec : 0.0);
+        }
+        else
+          v = ((e > 0) ? e : 0.0) * P->slot_scale[r];
+      }
+      else if (kind == SLOT_TOTAL_TIME)
+      {
+        const int k = P->slot_sub[r];
+        const double e = time_inverse_sum(xv, D, P->T) - P->tt_limit[k];
+        if (P->slot_iscnt[r])
+        {
+          const double ec = e * P->tt_coeff[k];
+          v = P->slot_eq[r] ? fabs(ec) : ((ec > 0) ? ec : 0.0);
+        }
+        else
+          v = ((e > 0) ? e : 0.0) * P->tt_coeff[k];
+      }
+    }
     // cart-pose (and function) slots are written by the instance loops below (another thread, no barrier in between): never store here
     if (kind != SLOT_CARTPOSE && kind != SLOT_FUNC)
       scratch[r] = v;
@@ -1230,6 +1412,30 @@ TMX_DEVFN void evaluate_terms(const DevProblem* P, const double* xv, double* cos
               acc += sacc;
             }
           }
+      if constexpr (ST)
+      {
+        // SQUARED time-parameterised costs, CostFromErrFunc::value (:143-165): err^2, times the coefficient, summed in row order
+        for (int c = 0; c < P->n_tv; ++c)
+          if (P->tv_owner[c] == k)
+          {
+            double sacc = 0.0;
+            for (int half = 0; half < 2; ++half)  // the upper rows, then the lower rows
+              for (int t = P->tv_first[c]; t < P->tv_last[c]; ++t)
+              {
+                TvSeg sg;
+                tv_segment(xv, D, t, P->tv_joint[c], P->tv_target[c], P->tv_up[c], P->tv_lo[c], sg);
+                const double e = half ? sg.y_lo : sg.y_up;
+                sacc += (e * e) * P->tv_coeff[c];
+              }
+            acc += sacc;
+          }
+        for (int c = 0; c < P->n_tt; ++c)
+          if (P->tt_form[c] == 0 && P->tt_owner[c] == k)
+          {
+            const double e = time_inverse_sum(xv, D, P->T) - P->tt_limit[c];
+            acc += (e * e) * P->tt_coeff[c];
+          }
+      }
       cost_out[k] = acc;
     }
     else

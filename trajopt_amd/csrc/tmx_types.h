@@ -25,7 +25,11 @@ enum
   SLOT_JOINTVEL_INEQ = 6,  // JointVelIneqCost / JointVelIneqConstraint row (upper: sub2 = 0, lower: sub2 = 1) -> hinge (1 aux)
   SLOT_COLLISION_LVS = 7,  // contact of a link sphere with an obstacle on the segment (t, t+1): LVS_DISCRETE / LVS_CONTINUOUS -> hinge
   SLOT_FUNC = 9,           // row i (slot_sub) of a ConstraintFromErrFunc over a tmx_expr program, instance slot_sub2: EQ -> abs (2 aux) | INEQ -> hinge (1 aux)
-  SLOT_CARTVEL = 8         // CartVel row i (0..5) of segment (t, t+1): +-(p[t+1] - p[t]) - max_displacement; ABS cost (2 aux) or INEQ constraint -> hinge (1 aux)
+  SLOT_CARTVEL = 8,        // CartVel row i (0..5) of segment (t, t+1): +-(p[t+1] - p[t]) - max_displacement; ABS cost (2 aux) or INEQ constraint -> hinge (1 aux)
+  // TIME-PARAMETERISED problems (DevProblem::use_time; the last variable of every waypoint is tau = 1 / dt)
+  SLOT_JOINTVEL_TIME = 10,  // PAIR ROW: JointVelErrCalculator row of segment (t, t+1), joint slot_sub (upper: sub2 = 0, lower: sub2 = 1):
+                            // HINGE cost / INEQ constraint -> hinge (1 aux), EQ constraint -> abs (2 aux).  Entries on x[t][j], x[t+1][j], tau[t+1]
+  SLOT_TOTAL_TIME = 11      // GLOBAL ROW of TotalTime term slot_sub: entries on tau[1 .. T-1] (DevBatch::tt_aff); listed under waypoint 0
 };
 #ifndef TMX_LINK_ROWS
 #define TMX_LINK_ROWS 1  // 1: the QP kernels understand pair rows (generic block-chain path with dense coupling blocks)
@@ -122,8 +126,22 @@ struct DevProblem
   int* ls_hull;
   double* hull;
   int n_ls_hull;
+  // TIME-PARAMETERISED PROBLEMS (tmx_problem_desc::use_time): D = DK + 1 - the block of a waypoint is its DK joint values and the
+  // time variable tau = 1 / dt; the kinematic chain sees the time column as a prismatic joint with a zero axis (no motion, zero
+  // Jacobian column).  Dense QP engine (qp_dense).
+  int DK;        // number of JOINTS (= D without use_time)
+  int use_time;
+  // JointVel-with-time SQUARED costs: one instance per (term, joint) = one cost of the reference ("name_j<j>")
+  int n_tv;
+  int *tv_owner, *tv_joint, *tv_first, *tv_last;   // segments first .. last - 1
+  double *tv_coeff, *tv_target, *tv_up, *tv_lo;
+  // TotalTime terms: tt_form 0 SQUARED cost, 1 HINGE cost, 2 EQ constraint, 3 INEQ constraint; tt_slot = row slot (forms 1 .. 3), -1 otherwise
+  int n_tt;
+  int *tt_owner, *tt_form, *tt_slot;
+  double *tt_coeff, *tt_limit;
 };
 TMX_HOSTDEVFN int slot_is_diff(int kind) { return kind == SLOT_JOINTVEL || kind == SLOT_JOINTVEL_INEQ; }
+#define TMX_TV_REC 5  // DevBatch::tv_aff record of one segment: cleaned Jacobian entries on x[t][j], x[t+1][j], tau[t+1] (upper row), constants of the upper / lower row
 TMX_HOSTDEVFN int fx_is_quad(int kind) { return kind == 0 || kind == 1 || kind == 3; }  // instance owns a dynamic quadratic model
 TMX_HOSTDEVFN int fx_is_rows(int kind) { return kind == 2 || kind == 4; }               // instance owns SLOT_FUNC rows
 
@@ -181,6 +199,10 @@ struct DevBatch
   // banded problems (DevProblem::band): B x band_stride doubles: scaled po2 / po3 (NX each) and the block factors W / M (3 T D^2 each)
   double *band_ws;
   long long band_stride;
+  // time-parameterised problems, written by every convexification (tmx_terms.h: convexify_time_terms):
+  //   tv_aff: B x n_tv x T x TMX_TV_REC  - linearised rows of the squared velocity costs (record of segment t at [t])
+  //   tt_aff: B x n_tt x (T + 1)         - cleaned gradient of sum_t 1 / tau[t] on tau[t] at [t] (t = 1 .. T-1), the constant at [T]
+  double *tv_aff, *tt_aff;
 };
 
 // The ADMM loop of the dense fast path as separately compiled device functions (tmx_solve.h: qp_admm_fast_nl /

@@ -17,7 +17,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import numpy as np
 
 from . import abi
-from .problem import (BasicInfo, CartPoseTermInfo, CartVelTermInfo, CollisionTermInfo, DynamicCartPoseTermInfo, JointAccTermInfo, JointJerkTermInfo, JointPosTermInfo,
+from .problem import (TotalTimeTermInfo, BasicInfo, CartPoseTermInfo, CartVelTermInfo, CollisionTermInfo, DynamicCartPoseTermInfo, JointAccTermInfo, JointJerkTermInfo, JointPosTermInfo,
                       JointVelTermInfo,
                       ProblemConstructionInfo, Robot, _tf12)
 
@@ -51,6 +51,19 @@ def _only_members(params: dict, allowed: Sequence[str], what: str):
     for k in params:
         if k not in allowed:
             raise ValueError(f"{what}: illegal field \"{k}\"")
+
+
+def _as_bool(v) -> bool:
+    """json_marshal::fromJson(bool) = Json::Value::asBool() (trajopt/src/json_marshal.cpp:10-20): numbers and booleans convert, a
+    STRING does not - JsonCpp throws ("Value is not convertible to bool"), which is what happens to "use_time" : "false" of
+    trajopt_common/data/config/arm_around_table_time.json in the reference"""
+    if isinstance(v, bool):
+        return v
+    if isinstance(v, (int, float)):
+        return v != 0
+    if v is None:
+        return False
+    raise ValueError(f"expected: bool, got {v!r}")
 
 
 def _quat_to_rot(wxyz) -> np.ndarray:
@@ -89,7 +102,7 @@ def _vec(params: dict, key: str, n: int, default=None) -> List[float]:
 class ParsedProblem:
     pci: ProblemConstructionInfo
     sqp_params: "abi.SqpParams"          # BasicTrustRegionSQPParameters after opt_info overrides
-    init_traj: np.ndarray                # [n_steps][n_dof]  (generateInitTraj, problem_description.cpp:310-372)
+    init_traj: np.ndarray                # [n_steps][n_dof (+ 1 with use_time)]  (generateInitTraj, problem_description.cpp:310-376)
     manip: str
     convex_solver: str
 
@@ -106,16 +119,16 @@ def construct_problem(text_or_dict, env: Environment) -> ParsedProblem:
         raise ValueError(f"Manipulator does not exist: {manip}")
     rob = env.manipulators[manip]
     D = rob.n_dof
-    if bi.get("use_time", False):
-        raise UnsupportedTerm("basic_info.use_time (time-parameterised terms) is not lowered by the device path")
+    use_time = _as_bool(bi.get("use_time", False))
     dt_lo, dt_hi = float(bi.get("dt_lower_lim", 1.0)), float(bi.get("dt_upper_lim", 1.0))
     if dt_lo <= 0 or dt_hi < dt_lo:
-        raise ValueError("dt limits (Basic Info) invalid")
+        raise ValueError("dt limits (Basic Info) invalid. The lower limit must be positive, and the minimum upper limit is equal to the lower limit.")
     convex_solver = str(bi.get("convex_solver", "AUTO_SOLVER"))
     if convex_solver not in ("AUTO_SOLVER", "OSQP"):
         raise UnsupportedTerm(f"convex_solver {convex_solver}: the device QP solver restates the OSQP back-end only")
     pci = ProblemConstructionInfo(rob, BasicInfo(n_steps=n_steps, fixed_timesteps=[int(t) for t in bi.get("fixed_timesteps", [])],
-                                                   fixed_dofs=[int(t) for t in bi.get("fixed_dofs", [])]))
+                                                   fixed_dofs=[int(t) for t in bi.get("fixed_dofs", [])], use_time=use_time,
+                                                   dt_lower_lim=dt_lo, dt_upper_lim=dt_hi))
     pci.obstacles = list(env.obstacles)
 
     sp = abi.default_sqp_params()
@@ -126,8 +139,13 @@ def construct_problem(text_or_dict, env: Environment) -> ParsedProblem:
 
     def read_term(it: dict, is_cost: bool):
         typ = str(it["type"])
-        if it.get("use_time", False):
-            raise UnsupportedTerm(f"{typ}: use_time terms are not lowered by the device path")
+        # readCosts / readConstraints (problem_description.cpp:162-216): a term-level "use_time" switches basic_info.use_time on
+        term_time = _as_bool(it.get("use_time", False))
+        if term_time:
+            pci.basic_info.use_time = True
+            if typ not in ("joint_pos", "joint_vel", "total_time"):
+                # ConstructProblem :424-443 (getSupportedTypes() & TT_USE_TIME)
+                raise ValueError(f"{it.get('name', typ)} does not support time, but you listed it as a using time")
         if "params" not in it:
             raise ValueError(f"{typ}: missing params")
         p = it["params"]
@@ -140,17 +158,26 @@ def construct_problem(text_or_dict, env: Environment) -> ParsedProblem:
             return JointVelTermInfo(coeffs=_vec(p, "coeffs", D, [1.0] * D), targets=_vec(p, "targets", D),
                                     first_step=int(p.get("first_step", 0)), last_step=int(p.get("last_step", n_steps - 1)), name=name,
                                     upper_tols=_vec(p, "upper_tols", D, [0.0] * D), lower_tols=_vec(p, "lower_tols", D, [0.0] * D),
-                                    is_constraint=not is_cost)
+                                    is_constraint=not is_cost, use_time=term_time)
+        if typ == "total_time":
+            # TotalTimeTermInfo::fromJson (problem_description.cpp:1839-1850)
+            _only_members(p, ("coeff", "limit"), typ)
+            return TotalTimeTermInfo(coeff=float(p.get("coeff", 1.0)), limit=float(p.get("limit", 1.0)), is_constraint=not is_cost, name=name)
         if typ in ("joint_acc", "joint_jerk"):
             # JointAccTermInfo::fromJson / JointJerkTermInfo::fromJson (problem_description.cpp:1374-1391, :1495-1513): the fields
             # of joint_vel; hatch -> the Eq / Ineq cost / constraint classes over the second / third difference
             _only_members(p, ("coeffs", "first_step", "last_step", "targets", "lower_tols", "upper_tols", "use_time"), typ)
             cls = JointAccTermInfo if typ == "joint_acc" else JointJerkTermInfo
+            if term_time:
+                # the reference logs "Use time version of this term has not been defined." and hatches NOTHING (:1439-1446,
+                # :1561-1568) - and ConstructProblem has already refused the term (no TT_USE_TIME in its supported types)
+                raise ValueError(f"{name} does not support time, but you listed it as a using time")
             return cls(coeffs=_vec(p, "coeffs", D, [1.0] * D), targets=_vec(p, "targets", D), first_step=int(p.get("first_step", 0)),
                        last_step=int(p.get("last_step", n_steps - 1)), name=name, upper_tols=_vec(p, "upper_tols", D, [0.0] * D),
                        lower_tols=_vec(p, "lower_tols", D, [0.0] * D), is_constraint=not is_cost)
         if typ == "joint_pos":
-            _only_members(p, ("coeffs", "first_step", "last_step", "targets", "lower_tols", "upper_tols"), typ)
+            # "JointPosTermInfo does not differ based on setting of TermType::TT_USE_TIME" (problem_description.cpp:1124-1125)
+            _only_members(p, ("coeffs", "first_step", "last_step", "targets", "lower_tols", "upper_tols", "use_time"), typ)
             return JointPosTermInfo(coeffs=_vec(p, "coeffs", D, [1.0] * D), targets=_vec(p, "targets", D),
                                     first_step=int(p.get("first_step", 0)), last_step=int(p.get("last_step", n_steps - 1)), name=name,
                                     upper_tols=_vec(p, "upper_tols", D, [0.0] * D), lower_tols=_vec(p, "lower_tols", D, [0.0] * D),
@@ -233,6 +260,13 @@ def construct_problem(text_or_dict, env: Environment) -> ParsedProblem:
         pci.cost_infos.append(read_term(it, True))
     for it in v.get("constraints", []):
         pci.cnt_infos.append(read_term(it, False))
+    # ConstructProblem :415-452: a term uses time <=> basic_info.use_time
+    any_time = any((isinstance(ti, JointVelTermInfo) and ti.use_time) or isinstance(ti, TotalTimeTermInfo) for ti in pci.cost_infos + pci.cnt_infos) \
+        or any(_as_bool(it.get("use_time", False)) for it in list(v.get("costs", [])) + list(v.get("constraints", [])))
+    if any_time and not pci.basic_info.use_time:
+        raise ValueError("A term is using time and basic_info is not set correctly. Try basic_info.use_time = true")
+    if not any_time and pci.basic_info.use_time:
+        raise ValueError("No terms use time and basic_info is not set correctly. Try basic_info.use_time = false")
 
     if "init_info" not in v:
         raise ValueError("Json missing required section init_info!")
@@ -256,9 +290,14 @@ def construct_problem(text_or_dict, env: Environment) -> ParsedProblem:
         init = state[None, :] * (1.0 - w) + end[None, :] * w
     else:
         raise ValueError("init_info did not have a valid type from Json. Valid types are stationary, joint_interpolated, or given_traj")
+    joint_init = init
+    if pci.basic_info.use_time:
+        # "Currently all trajectories are generated without time then appended here" (problem_description.cpp:367-376): the time
+        # column is init_info.dt (default 1.0, :266)
+        init = np.concatenate([init, np.full((n_steps, 1), float(ii.get("dt", 1.0)))], axis=1)
     # row-slot capacity of the segment collision evaluators from the initial trajectory: 1.5 x the longest segment, <= 64
     for ti in pci.cost_infos + pci.cnt_infos:
         if isinstance(ti, CollisionTermInfo) and ti.evaluator_type >= 2 and ti.max_substates <= 0:
-            dmax = float(np.sqrt(((init[1:] - init[:-1]) ** 2).sum(axis=1)).max()) if n_steps > 1 else 0.0
+            dmax = float(np.sqrt(((joint_init[1:] - joint_init[:-1]) ** 2).sum(axis=1)).max()) if n_steps > 1 else 0.0
             ti.max_substates = int(min(64.0, max(2.0, np.ceil(1.5 * dmax / max(ti.longest_valid_segment_length, 1e-9)) + 1.0)))
     return ParsedProblem(pci=pci, sqp_params=sp, init_traj=np.ascontiguousarray(init), manip=manip, convex_solver=convex_solver)

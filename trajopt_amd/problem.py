@@ -134,6 +134,20 @@ class JointVelTermInfo:
     upper_tols: Sequence[float] = ()
     lower_tols: Sequence[float] = ()
     is_constraint: bool = False
+    # TermType::TT_USE_TIME (problem_description.cpp:1244-1325): per joint one TrajOptCostFromErrFunc / ConstraintFromErrFunc over
+    # vel = (x[i+1][j] - x[i][j]) * (1/dt)[i+1]; needs BasicInfo.use_time.  JointAcc / JointJerk have no such form (the reference
+    # logs "Use time version of this term has not been defined" and adds nothing, :1439-1446, :1561-1568)
+    use_time: bool = False
+
+
+@dataclass
+class TotalTimeTermInfo:
+    """trajopt::TotalTimeTermInfo (problem_description.hpp:617-640; hatch problem_description.cpp:1852-1890): penalises
+    sum_t dt_t - limit over the time variables of steps 1 .. n_steps - 1 (the variable is 1/dt)"""
+    coeff: float = 1.0
+    limit: float = 1.0
+    is_constraint: bool = False
+    name: str = "total_time"
 
 
 @dataclass
@@ -366,6 +380,9 @@ class BasicInfo:
     n_steps: int
     fixed_timesteps: List[int] = field(default_factory=list)
     fixed_dofs: List[int] = field(default_factory=list)
+    use_time: bool = False      # one (1/dt) variable per step behind the joints (problem_description.hpp:150)
+    dt_lower_lim: float = 1.0   # (:146-148)
+    dt_upper_lim: float = 1.0
 
 
 class ProblemConstructionInfo:
@@ -398,6 +415,8 @@ class ProblemConstructionInfo:
         if isinstance(ti, AvoidSingularityTermInfo):  # name_<step> (problem_description.cpp:1924)
             last = ti.last_step if ti.last_step >= 0 else T - 1
             return [f"{ti.name}_{i}" for i in range(ti.first_step, last + 1)]
+        if isinstance(ti, JointVelTermInfo) and ti.use_time:   # one cost / constraint per joint (problem_description.cpp:1267-1283)
+            return [f"{ti.name}_j{j}" for j in range(self.robot.n_dof)]
         if isinstance(ti, UserDefinedTermInfo):      # name_<TYPE>_<step> (problem_description.cpp:611-630, :648-656)
             last = ti.last_step if ti.last_step >= 0 else T - 1
             typ = ("INEQ" if ti.constraint_ineq else "EQ") if ti.is_constraint else {0: "SQUARED", 1: "ABS", 2: "HING"}[int(ti.cost_penalty_type)]
@@ -420,6 +439,8 @@ class ProblemConstructionInfo:
                 return ti.constraint_ineq
             if isinstance(ti, (JointPosTermInfo, JointVelTermInfo)):
                 return any(abs(x) >= 1e-5 for x in list(ti.upper_tols) + list(ti.lower_tols))
+            if isinstance(ti, TotalTimeTermInfo):
+                return abs(ti.limit) >= 1e-5
             return False
         eq = [n for ti in self.cnt_infos if not is_ineq(ti) for n in self._expand_names(ti)]
         return eq + [n for ti in self.cnt_infos if is_ineq(ti) for n in self._expand_names(ti)]
@@ -431,6 +452,10 @@ class ProblemConstructionInfo:
             raise ValueError("n_dof exceeds TMX_MAX_DOF")
         d = abi.ProblemDesc()
         d.n_dof, d.n_steps = D, T
+        d.use_time = 1 if self.basic_info.use_time else 0
+        d.dt_lower_lim, d.dt_upper_lim = float(self.basic_info.dt_lower_lim), float(self.basic_info.dt_upper_lim)
+        if self.basic_info.use_time and D + 1 > abi.TMX_MAX_DOF:
+            raise ValueError("n_dof + 1 (time column) exceeds TMX_MAX_DOF")
         for j in range(D):
             d.joint_lower[j], d.joint_upper[j] = rob.lower[j], rob.upper[j]
             d.joints[j].type = rob.joint_types[j]
@@ -483,7 +508,12 @@ class ProblemConstructionInfo:
         keep_fixed = []
         for ti in list(self.cost_infos) + list(self.cnt_infos):
             t = abi.Term()
-            if isinstance(ti, JointVelTermInfo):
+            if isinstance(ti, TotalTimeTermInfo):
+                t.kind = abi.TERM_TOTAL_TIME
+                t.is_constraint = 1 if ti.is_constraint else 0
+                t.coeff, t.margin = float(ti.coeff), float(ti.limit)
+                t.first_step, t.last_step = 1, T - 1
+            elif isinstance(ti, JointVelTermInfo):
                 up = list(ti.upper_tols) or [0.0] * D
                 lo = list(ti.lower_tols) or [0.0] * D
                 if len(up) != D or len(lo) != D:
@@ -495,6 +525,10 @@ class ProblemConstructionInfo:
                          3: (abi.TERM_JOINT_JERK_EQ_COST, abi.TERM_JOINT_JERK_INEQ_COST, abi.TERM_JOINT_JERK_EQ_CNT,
                              abi.TERM_JOINT_JERK_INEQ_CNT)}[order]
                 t.kind = kinds[(2 if ti.is_constraint else 0) + (0 if zero else 1)]
+                if ti.use_time:
+                    if order != 1:
+                        raise ValueError("Use time version of this term has not been defined.")   # (:1439-1446, :1561-1568: the reference adds no term)
+                    t.kind = abi.TERM_JOINT_VEL_TIME
                 t.is_constraint = 1 if ti.is_constraint else 0
                 t.upper_tols[:D] = up
                 t.lower_tols[:D] = lo

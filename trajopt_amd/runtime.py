@@ -118,7 +118,7 @@ class Context:
         nm, mm = C.c_int32(), C.c_int32()
         self._chk(self.lib.tmx_qp_dims(self.h, C.byref(nm), C.byref(mm)))
         self.n_max, self.m_max = nm.value, mm.value
-        self.T, self.D = desc.n_steps, desc.n_dof
+        self.T, self.D = desc.n_steps, desc.n_dof + (1 if desc.use_time else 0)   # columns of a trajectory (joints + the time column)
 
     # ---- S3 ----
     def set_x0(self, x0):
@@ -365,7 +365,7 @@ class BatchedTrustRegionSQP:
     def initialize(self, x):
         """Optimizer::initialize (optimizers.cpp:127-136): x is [batch][n_steps][n_dof]; a wrong size raises."""
         x = np.asarray(x, dtype=np.float64)
-        T, D = self.pci.basic_info.n_steps, self.pci.robot.n_dof
+        T, D = self.pci.basic_info.n_steps, self.pci.robot.n_dof + (1 if self.pci.basic_info.use_time else 0)
         if x.ndim != 3 or x.shape[1] != T or x.shape[2] != D:
             raise TmxError(f"initialization vector has wrong length. expected [B,{T},{D}] got {list(x.shape)}")
         if not self._uploaded:
