@@ -436,6 +436,10 @@ TMX_HOSTDEVFN size_t qp_glb_doubles(int D, int T, int R, int NA, int R2 = 0, int
 }
 // long horizons without pair rows: the block chain is cut into 4 interiors + 3 separator blocks (tmx_long.h)
 TMX_HOSTDEVFN bool lpart_fits(int D, int T, int R2) { return D <= 8 && R2 == 0 && T >= 64; }
+// chains WITH pair rows (dense couplings): the two substitution sweeps are cut into up to 4 segments walked side by side, joined
+// through precomputed SPIKES (chain_pair_spikes: T D^2 doubles per sweep direction, kept where WL / WR of the long-horizon scheme
+// would be - the two schemes exclude each other)
+TMX_HOSTDEVFN bool pspk_fits(int D, int T, int R2) { return R2 > 0 && D <= 16 && T >= 10; }
 TMX_HOSTDEVFN size_t lpart_zp_doubles(int D) { return 18 * (size_t)D * D + 6 * (size_t)D + 2; }  // 4 interiors: 2 x (3 D)^2 (ping-pong inversion) + 2 x 3 D
 // arrays that are only touched at burst boundaries / in the polish step: always in the per-problem HBM scratch
 TMX_HOSTDEVFN size_t qp_far_doubles(int D, int T, int R, int NA, int R2 = 0, int cf_flags = 0)
@@ -444,7 +448,7 @@ TMX_HOSTDEVFN size_t qp_far_doubles(int D, int T, int R, int NA, int R2 = 0, int
   const size_t NX = (size_t)D * T;
   const size_t n = 2 * NX + (size_t)R + 4 * (size_t)NA;
   const size_t ints = 3 * (size_t)R + (size_t)NX + (size_t)NA;
-  const size_t lp = lpart_fits(D, T, R2) ? 2 * (size_t)T * D * D + lpart_zp_doubles(D) + 2 : 0;
+  const size_t lp = lpart_fits(D, T, R2) ? 2 * (size_t)T * D * D + lpart_zp_doubles(D) + 2 : (pspk_fits(D, T, R2) ? 2 * (size_t)T * D * D + 2 : 0);
   const size_t cmp = (cf_flags & 2) ? (3 * (size_t)R + (size_t)T + 1 + 2 + 1) / 2 + 2 : 0;  // alist, list, pos, start, count
   return n + (ints + 1) / 2 + 8 + lp + (cf ? qp_coef_doubles(D, R, R2) + 2 : 0) + cmp;
 }
@@ -627,10 +631,16 @@ TMX_DEVFN void qp_ws_carve(QpWs& w, double* lds, double* glb, double* far, int D
     TAKE(WR, T * D * D);
     TAKE(Zp, (int)lpart_zp_doubles(D));
   }
+  else if (pspk_fits(D, T, R2))
+  {
+    p = reinterpret_cast<double*>((reinterpret_cast<size_t>(ip) + 15) & ~(size_t)15);
+    TAKE(WL, T * D * D);  // forward spikes of the segmented dense-coupling chain
+    TAKE(WR, T * D * D);  // backward spikes
+  }
   if (cf)
   {
     // coefficient arrays in the HBM scratch (behind everything else of the far region)
-    if (!lpart_fits(D, T, R2))
+    if (!lpart_fits(D, T, R2) && !pspk_fits(D, T, R2))
       p = reinterpret_cast<double*>((reinterpret_cast<size_t>(ip) + 15) & ~(size_t)15);
     TAKE(coef, R * D);
 #if TMX_LINK_ROWS
@@ -1105,6 +1115,69 @@ TMX_DEVFN void chain_pair_products(const QpWs& w, int tid, int NT)
     w.Nb[e] = n;
   }
   TMX_SYNC();
+}
+// SEGMENTED SWEEPS of the dense-coupling chain.  The forward sweep v_t = b_t - Mf_{t-1} v_{t-1} restarted at the first block a of a
+// segment gives u_t with  v_t = u_t + Wf_t v_{a-1},  Wf_a = -Mf_{a-1},  Wf_t = -Mf_{t-1} Wf_{t-1};  the backward sweep
+// x_t = y_t - Nb_t x_{t+1} restarted at the last block b of a segment gives u_t with  x_t = u_t + Wb_t x_{b+1},  Wb_b = -Nb_b,
+// Wb_t = -Nb_t Wb_{t+1}.  With the spikes Wf (w.WL) / Wb (w.WR) known from the factorisation, the P segments of a sweep are walked
+// by P waves at once, the P - 1 true boundary vectors follow from P - 1 dependent mat-vecs, and the correction of every block is one
+// independent mat-vec: 2 (T - 1) dependent block steps become 2 (T / P + P) (config 4, T = 30: 58 -> 24; config 3, T = 50: 98 -> 34).
+TMX_DEVFN int pspk_segments(const QpWs& w, int NT)
+{
+  const int P = (NT >> 6) < 4 ? (NT >> 6) : 4;
+  return (w.WL != nullptr && TMX_HAS_PAIRS(w) && P >= 2 && w.T >= 2 * P + 2 && P * w.D <= 64) ? P : 0;
+}
+TMX_DEVFN int pspk_a(int T, int P, int p) { return p * ((T + P - 1) / P); }
+TMX_DEVFN int pspk_b(int T, int P, int p)
+{
+  const int e = (p + 1) * ((T + P - 1) / P) - 1;
+  return e < T - 1 ? e : T - 1;
+}
+TMX_DEVFN void chain_pair_spikes(const QpWs& w, int tid, int NT)
+{
+  const int P = pspk_segments(w, NT);
+  if (P == 0)
+    return;
+  const int D = w.D, DD = D * D, T = w.T, L = (T + P - 1) / P;
+  for (int s_ = 0; s_ < L; ++s_)
+  {
+    for (int e = tid; e < 2 * P * DD; e += NT)
+    {
+      const int dir = e / (P * DD), p = (e / DD) % P, i = (e / D) % D, j = e % D;
+      const int a = pspk_a(T, P, p), b = pspk_b(T, P, p);
+      if (a > b)
+        continue;
+      if (dir == 0)
+      {
+        const int t = a + s_;
+        if (p == 0 || t > b)
+          continue;
+        const double* M = w.Mf + (size_t)(t - 1) * DD + i * D;
+        double acc = 0.0;
+        if (s_ == 0)
+          acc = M[j];
+        else
+          for (int k = 0; k < D; ++k)
+            acc += M[k] * w.WL[(size_t)(t - 1) * DD + k * D + j];
+        w.WL[(size_t)t * DD + i * D + j] = -acc;
+      }
+      else
+      {
+        const int t = b - s_;
+        if (p == P - 1 || t < a)
+          continue;
+        const double* N = w.Nb + (size_t)t * DD + i * D;
+        double acc = 0.0;
+        if (s_ == 0)
+          acc = N[j];
+        else
+          for (int k = 0; k < D; ++k)
+            acc += N[k] * w.WR[(size_t)(t + 1) * DD + k * D + j];
+        w.WR[(size_t)t * DD + i * D + j] = -acc;
+      }
+    }
+    TMX_SYNC();
+  }
 }
 #endif
 TMX_DEVFN void chain_solve_range(const QpWs& w, int t0, int t1, int tid, int NT);
@@ -2666,6 +2739,84 @@ TMX_DEVFN void chain_wave_sweep_body(const double* mat, const double* rhs, doubl
   else
     chain_wave_sweep_d(mat, rhs, out, D, t0, t1, dir, lane);   // mixed placement: generic pointers
 }
+// one sweep of the dense-coupling chain in PS segments (see chain_pair_spikes): local sweeps by PS waves, boundary vectors by wave 0,
+// spike correction by all threads.  dir = +1: w.tp -> w.tp; dir = -1: w.yb -> w.tp.  The boundary vectors live in w.red[192 .. 256).
+TMX_DEVFN void chain_segmented_sweep(const QpWs& w, int PS, int dir, int tid, int NT)
+{
+  const int D = w.D, DD = D * D, T = w.T;
+  const int wave = tid >> 6, lane = tid & 63;
+  double* bnd = w.red + 192;
+  if (wave < PS)
+  {
+    const int a = pspk_a(T, PS, wave), b = pspk_b(T, PS, wave);
+    if (dir > 0)
+    {
+      if (w.sweep_inline)
+        chain_wave_sweep_body(w.Mf, w.tp, w.tp, D, a, b, +1, lane);
+      else
+        chain_wave_sweep_any(w.Mf, w.tp, w.tp, D, a, b, +1, lane);
+    }
+    else
+    {
+      if (w.sweep_inline)
+        chain_wave_sweep_body(w.Nb, w.yb, w.tp, D, a, b, -1, lane);
+      else
+        chain_wave_sweep_any(w.Nb, w.yb, w.tp, D, a, b, -1, lane);
+    }
+  }
+  TMX_SYNC();
+  if (tid < 64)
+  {
+    const bool live = lane < D;
+    const int i = live ? lane : 0;
+    double m[16];
+    if (dir > 0)
+    {
+      double v = w.tp[pspk_b(T, PS, 0) * D + i];  // true end of segment 0
+      if (live)
+        bnd[i] = v;
+      for (int p = 1; p < PS - 1; ++p)  // (the end of the last segment is nobody's boundary)
+      {
+        const int b = pspk_b(T, PS, p);
+        chain_row_load<0>(w.WL + (size_t)b * DD + i * D, D, m);
+        const double acc = chain_row_dot<0>(m, v, D);
+        v = w.tp[b * D + i] + acc;
+        if (live)
+          bnd[p * D + i] = v;
+      }
+    }
+    else
+    {
+      double v = w.tp[pspk_a(T, PS, PS - 1) * D + i];  // true start of the last segment
+      if (live)
+        bnd[(PS - 1) * D + i] = v;
+      for (int p = PS - 2; p >= 1; --p)
+      {
+        const int a = pspk_a(T, PS, p);
+        chain_row_load<0>(w.WR + (size_t)a * DD + i * D, D, m);
+        const double acc = chain_row_dot<0>(m, v, D);
+        v = w.tp[a * D + i] + acc;
+        if (live)
+          bnd[p * D + i] = v;
+      }
+    }
+  }
+  TMX_SYNC();
+  const int L = (T + PS - 1) / PS;
+  for (int e = tid; e < T * D; e += NT)
+  {
+    const int t = e / D, i = e % D, p = t / L;
+    if (dir > 0 ? p == 0 : p == PS - 1)
+      continue;
+    const double* W = (dir > 0 ? w.WL : w.WR) + (size_t)t * DD + i * D;
+    const double* bv = bnd + (dir > 0 ? p - 1 : p + 1) * D;
+    double acc = 0.0;
+    for (int j = 0; j < D; ++j)
+      acc += W[j] * bv[j];
+    w.tp[e] += acc;
+  }
+  TMX_SYNC();
+}
 #endif
 
 // Block forward/backward substitution over blocks [t0, t1] in place on w.tp (generic, any NT):
@@ -2690,7 +2841,10 @@ TMX_DEVFN void chain_solve_range(const QpWs& w, int t0, int t1, int tid, int NT)
       // one wave walks the sweep: the running vector in registers (chain_wave_sweep, no barrier and no LDS exchange per block) in
       // the ADMM loop of pair-row problems (w.sweep_regs, a compile-time constant after inlining); the few solves outside that
       // loop (polish, first factorisation) keep the LDS-exchange walk, so the kernels' own code is what it was
-      if (w.sweep_regs)
+      const int PS = (w.sweep_regs && t0 == 0 && t1 == w.T - 1) ? pspk_segments(w, NT) : 0;
+      if (PS > 0)
+        chain_segmented_sweep(w, PS, +1, tid, NT);
+      else if (w.sweep_regs)
       {
         if (tid < 64)
         {
@@ -2747,7 +2901,10 @@ TMX_DEVFN void chain_solve_range(const QpWs& w, int t0, int t1, int tid, int NT)
     if (wave_walk)
     {
 #if TMX_IS_DEVICE
-      if (w.sweep_regs)
+      const int PS = (w.sweep_regs && t0 == 0 && t1 == w.T - 1) ? pspk_segments(w, NT) : 0;
+      if (PS > 0)
+        chain_segmented_sweep(w, PS, -1, tid, NT);
+      else if (w.sweep_regs)
       {
         if (tid < 64)
         {

@@ -780,7 +780,10 @@ TMX_DEVFN void kkt_invert(const QpWs& w, bool partitioned, int tid, int NT, long
   kkt_invert_chain_generic(w, 0, w.T - 1, tid, NT);
 #if TMX_LINK_ROWS
   if (TMX_HAS_PAIRS(w))
+  {
     chain_pair_products(w, tid, NT);
+    chain_pair_spikes(w, tid, NT);  // segmented sweeps of the ADMM loop (no-op without the spike arrays / below 2 waves)
+  }
 #endif
 }
 
