@@ -455,6 +455,13 @@ TMX_API tmx_status tmx_sqp_results(tmx_ctx* ctx, double* x /*B*T*D*/, int32_t* s
 TMX_API tmx_status tmx_sqp_counters(tmx_ctx* ctx, int64_t* n_func_evals, int64_t* n_qp_solves, int64_t* n_admm_iters);
 /* per-problem QP records of the run, in solve order: out[problem*max_records + k]; counts[problem]      */
 TMX_API tmx_status tmx_sqp_qp_records(tmx_ctx* ctx, tmx_qp_record* out, int32_t max_records, int32_t* counts);
+/* Ends the optimisation of ONE problem of the batch between bounded tmx_sqp_run(ctx, max_steps > 0, ...) calls: what a callback
+   that returns false does to the reference's solver - trajopt_sqp::SQPCallback::execute (trajopt_optimizers/trajopt_sqp/include/
+   trajopt_sqp/sqp_callback.h:36-51), TrustRegionSQPSolver::stepSQPSolver / callCallbacks (src/trust_region_sqp_solver.cpp:421-446:
+   the solver returns SQPStatus::kStoppedByCallback and solve() leaves, :277-278).  The problem keeps its current iterate (the best
+   point so far), takes `status` (TMX_SQP_STOPPED_BY_CALLBACK for the trajopt_sqp flavour) and is skipped by every later run step;
+   the other problems of the batch go on. */
+TMX_API tmx_status tmx_sqp_stop(tmx_ctx* ctx, int32_t problem, int32_t status);
 /* Per-problem optimizer state between bounded tmx_sqp_run(ctx, max_steps > 0, ...) calls: the loop variables of
    BasicTrustRegionSQP::optimize (trajopt_sco/src/optimizers.cpp:742-760: merit_increases, iter, trust_box_size_) that its
    per-iteration log table (:428-647, :708-718) and its callbacks (:754, invoked before every SQP iteration) observe.

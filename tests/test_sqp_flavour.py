@@ -163,3 +163,63 @@ def test_trajopt_sqp_flavour_full_batch_properties(gpu_ctx_factory):
     ctx.run(0)
     assert np.array_equal(ctx.results()["x"], r["x"][:32][perm]), "result depends on batch position / not deterministic"
     ctx.close()
+
+
+# ---- trajopt_sqp::SQPCallback (sqp_callback.h:36-51) on the batched solver ----------------------------------------------------------
+def _callback_checks(lib_path):
+    """registerCallback: one call per trust-region evaluation of every seed with the SQPResults of that step; stepping does not
+    change the run; a callback that returns False ends ITS seed with kStoppedByCallback at the best point so far."""
+    pci, s, g = configs.config4(10)
+    x0 = configs.seeds_for(4, pci, s, g, 3, sigma=0.05)
+
+    def make():
+        opt = runtime.BatchedTrustRegionSQPSolver(pci, lib_path=lib_path)
+        opt.osqp = configs.osqp_settings_config4()
+        opt.initialize(x0)
+        return opt
+    ref = make()
+    st_ref = ref.solve().copy()
+    r_ref = ref.results()
+    ref.ctx.close()
+    # 1. observing callbacks
+    seen = {b: [] for b in range(3)}
+    opt = make()
+    opt.registerCallback(lambda b, res: seen[b].append(res) or True)
+    st = opt.solve()
+    r = opt.results()
+    opt.ctx.close()
+    assert np.array_equal(st, st_ref) and np.array_equal(r["x"], r_ref["x"]) and np.array_equal(r["n_qp_solves"], r_ref["n_qp_solves"])
+    for b in range(3):
+        assert len(seen[b]) == r_ref["n_qp_solves"][b] and [e["n_qp_solves"] for e in seen[b]] == list(range(1, len(seen[b]) + 1))
+        for e in seen[b]:
+            # stepSQPSolver (trust_region_sqp_solver.cpp:380-411): the merits are sums of the vectors the callback sees
+            assert abs(e["new_exact_merit"] - (e["new_costs"].sum() + e["new_constraint_violations"] @ e["merit_error_coeffs"])) <= 1e-9 * max(1.0, abs(e["new_exact_merit"]))
+            assert abs(e["approx_merit_improve"] - (e["best_exact_merit"] - e["new_approx_merit"])) <= 1e-9 * max(1.0, abs(e["best_exact_merit"]))
+            assert abs(e["exact_merit_improve"] - (e["best_exact_merit"] - e["new_exact_merit"])) <= 1e-9 * max(1.0, abs(e["best_exact_merit"]))
+            assert e["box_size"] > 0 and e["best_var_vals"].shape == (x0.shape[1] * x0.shape[2],)
+        assert seen[b][-1]["best_costs"].shape == seen[b][-1]["new_costs"].shape
+    # 2. a callback that stops seed 1 after its second evaluation; a second callback still runs (success &= ..., :444-445)
+    calls = []
+    opt = make()
+    opt.registerCallback(lambda b, res: not (b == 1 and res["n_qp_solves"] >= 2))
+    opt.registerCallback(lambda b, res: calls.append((b, res["n_qp_solves"])) or True)
+    st2 = opt.solve()
+    r2 = opt.results()
+    opt.ctx.close()
+    assert st2[1] == abi.SQP_STOPPED_BY_CALLBACK and r2["n_qp_solves"][1] == 2 and (1, 2) in calls and (1, 3) not in calls
+    assert np.array_equal(r2["x"][1].reshape(-1), seen[1][1]["best_var_vals"]) or np.array_equal(r2["x"][1].reshape(-1), seen[1][2]["best_var_vals"])
+    for b in (0, 2):
+        assert st2[b] == st_ref[b] and np.array_equal(r2["x"][b], r_ref["x"][b])
+    # the sco flavour has its own optimizer class
+    pci0, _, _ = configs.config0()
+    with pytest.raises(runtime.TmxError, match="trajopt_sqp flavour"):
+        runtime.BatchedTrustRegionSQPSolver(pci0, lib_path=lib_path)
+
+
+def test_sqp_callbacks_on_host_build(hostemu_lib):
+    _callback_checks(hostemu_lib)
+
+
+@pytest.mark.gpu
+def test_sqp_callbacks_on_device(gpu_ctx_factory):
+    _callback_checks(None)

@@ -42,8 +42,12 @@ if pool:
     k = pool[0]
     fetch_kib = tot[k].get("FETCH_SIZE", 0.0) / max(1, cnt[k].get("FETCH_SIZE", 1))
     write_kib = tot[k].get("WRITE_SIZE", 0.0) / max(1, cnt[k].get("WRITE_SIZE", 1))
+    mfma = tot[k].get("SQ_INSTS_VALU_MFMA_MOPS_F64", None)
     json.dump({"batch_per_gpu": 1024, "kernel": "k_sqp_pool", "fetch_size_kib_per_launch": fetch_kib, "write_size_kib_per_launch": write_kib,
                "hbm_bytes_per_launch": (2.0 * fetch_kib + write_kib) * 1024.0,
+               "fetch_bytes_per_launch_doubled": 2.0 * fetch_kib * 1024.0, "write_bytes_per_launch": write_kib * 1024.0,
+               "mfma_mops_f64_per_launch": (mfma / max(1, cnt[k].get("SQ_INSTS_VALU_MFMA_MOPS_F64", 1))) if mfma is not None else None,
+               "valu_insts_per_launch": tot[k].get("SQ_INSTS_VALU", 0.0) / max(1, cnt[k].get("SQ_INSTS_VALU", 1)),
                "note": "FETCH_SIZE doubled per the MI355X guide's gfx950 correction for wide streaming reads (upper bound for narrow reads); WRITE_SIZE uncalibrated; "
                        "Infinity-Cache hits are counted"}, open(out + "/pmc_traffic.json", "w"), indent=1)
 print(open(out + "/rocprofv3_summary.txt").read()[:6000])

@@ -2153,6 +2153,27 @@ tmx_status tmx_sqp_state(tmx_ctx* ctx, int32_t* sqp_iter, int32_t* merit_increas
   return TMX_OK;
 }
 
+tmx_status tmx_sqp_stop(tmx_ctx* ctx, int32_t problem, int32_t status)
+{
+  if (!ctx)
+    return TMX_ERR_INVALID;
+  if (ctx->Bcap == 0)
+    return TMX_ERR_STATE;
+  TMX_REFUSE_WHILE_PENDING(ctx);
+  if (problem < 0 || problem >= ctx->hb.B)
+  {
+    ctx->err = "tmx_sqp_stop: problem index outside the batch";
+    return TMX_ERR_INVALID;
+  }
+  HIPCHK(hipSetDevice(ctx->device));
+  // (between launches: the next run step reads phase / status from HBM; k_pool_sync derives the scheduler state from the phase)
+  const int done = PHASE_DONE, st = status;
+  HIPCHK(hipMemcpyAsync(ctx->hb.phase + problem, &done, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->hb.status + problem, &st, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return TMX_OK;
+}
+
 tmx_status tmx_sqp_step_log(tmx_ctx* ctx, double* out, int32_t* stride_out)
 {
   if (!ctx)

@@ -25,6 +25,7 @@ _SIGS = {
     "tmx_batch_set_x0": ([C.c_void_p, C.c_void_p, C.c_int32], C.c_int),
     "tmx_batch_set_x0_device": ([C.c_void_p, C.c_void_p, C.c_int32], C.c_int),
     "tmx_sqp_set_x": ([C.c_void_p, C.c_void_p], C.c_int),
+    "tmx_sqp_stop": ([C.c_void_p, C.c_int32, C.c_int32], C.c_int),
     "tmx_best_trajectory": ([C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)], C.c_int),
     "tmx_sqp_run": ([C.c_void_p, C.c_int32, C.POINTER(C.c_int32)], C.c_int),
     "tmx_sqp_launch": ([C.c_void_p], C.c_int),
@@ -164,6 +165,10 @@ class Context:
         nqp = np.zeros(B, np.int32)
         self._chk(self.lib.tmx_sqp_results(self.h, _ptr(x), _ptr(status), _ptr(cost), _ptr(nfe), _ptr(nqp)))
         return dict(x=x, status=status, total_cost=cost, n_func_evals=nfe, n_qp_solves=nqp)
+
+    def stop(self, problem: int, status: int):
+        """finish one problem of the batch between bounded run() calls (tmx_sqp_stop: a callback returned false)"""
+        self._chk(self.lib.tmx_sqp_stop(self.h, int(problem), int(status)))
 
     def state(self):
         """loop variables of BasicTrustRegionSQP::optimize per problem (between bounded run() calls)"""
@@ -430,6 +435,59 @@ class BatchedTrustRegionSQP:
 
     def results(self):
         return self.ctx.results()
+
+
+class BatchedTrustRegionSQPSolver(BatchedTrustRegionSQP):
+    """trajopt_sqp::TrustRegionSQPSolver (trajopt_optimizers/trajopt_sqp/src/trust_region_sqp_solver.cpp:87-439) for a batch of seeds:
+    the problem description must be of the trajopt_sqp flavour (pci.flavor = abi.FLAVOR_SQP).  registerCallback mirrors
+    TrustRegionSQPSolver::registerCallback (:81): cb(problem_index, sqp_results) -> bool runs after every trust-region evaluation of
+    every seed (stepSQPSolver, :421-422) with sqp_results = the fields of trajopt_sqp::SQPResults the step leaves (types.h:143-209):
+    best_var_vals, best_costs / new_costs / new_approx_costs, best / new / new_approx constraint violations, merit_error_coeffs,
+    box_size, best_exact_merit / new_approx_merit / new_exact_merit, approx / exact merit improvement and their ratio,
+    penalty_iteration, convexify_iteration.  A callback that returns False ends THAT seed with SQPStatus::kStoppedByCallback
+    (:432-436); the rest of the batch goes on.  With callbacks the batch is stepped one trust-region evaluation per launch."""
+
+    def __init__(self, pci, device: int = 0, lib_path: str = None):
+        if int(getattr(pci, "flavor", 0)) != abi.FLAVOR_SQP:
+            raise TmxError("BatchedTrustRegionSQPSolver drives problems of the trajopt_sqp flavour (pci.flavor = abi.FLAVOR_SQP)")
+        super().__init__(pci, device=device, lib_path=lib_path)
+        self._sqp_callbacks = []
+
+    def registerCallback(self, cb):
+        self._sqp_callbacks.append(cb)
+
+    def solve(self):
+        """TrustRegionSQPSolver::solve (:87-159); returns the SQPStatus of every seed"""
+        if not self._sqp_callbacks:
+            self.ctx.run(0)
+            return self.ctx.results()["status"]
+        B = self.ctx.B
+        n_qp_seen = np.zeros(B, np.int64)
+        stopped = np.zeros(B, bool)
+        while True:
+            self.ctx.run(1)
+            r, st, logs = self.ctx.results(), self.ctx.state(), self.ctx.step_log()
+            for b in range(B):
+                if stopped[b] or r["n_qp_solves"][b] <= n_qp_seen[b] or not logs[b]["valid"]:
+                    continue
+                n_qp_seen[b] = r["n_qp_solves"][b]
+                lg = logs[b]
+                res = dict(best_var_vals=r["x"][b].reshape(-1), best_costs=lg["old_cost_vals"], new_costs=lg["new_cost_vals"],
+                           new_approx_costs=lg["model_cost_vals"], best_constraint_violations=lg["old_cnt_viols"],
+                           new_constraint_violations=lg["new_cnt_viols"], new_approx_constraint_violations=lg["model_cnt_viols"],
+                           merit_error_coeffs=lg["merit_error_coeffs"], box_size=lg["box_size"], best_exact_merit=lg["old_merit"],
+                           new_approx_merit=lg["model_merit"], new_exact_merit=lg["new_merit"], approx_merit_improve=lg["approx_merit_improve"],
+                           exact_merit_improve=lg["exact_merit_improve"], merit_improve_ratio=lg["merit_improve_ratio"],
+                           penalty_iteration=lg["merit_increases"], convexify_iteration=lg["sqp_iter"], n_qp_solves=int(r["n_qp_solves"][b]))
+                ok = True
+                for cb in self._sqp_callbacks:
+                    ok = bool(cb(b, res)) and ok       # (every callback runs: success &= callback->execute(...), :444-445)
+                if not ok and not st["done"][b]:
+                    self.ctx.stop(b, abi.SQP_STOPPED_BY_CALLBACK)
+                    stopped[b] = True
+            if (st["done"] | stopped).all():
+                break
+        return self.ctx.results()["status"]
 
 
 def OptimizeProblem(pci, init_traj, device: int = 0, lib_path: str = None):
