@@ -481,7 +481,12 @@ TMX_KERNEL_LB2(TMX_QP_NT, TMX_QP_WGS_PER_CU) k_sqp_fused(const DevProblem* P, co
   {
     if (Bt->phase[b] == PHASE_DONE)
       break;
-    sqp_step_block(P, Bt, b, smem, tid, NT);
+    // (the instantiation without banded code for every problem that has no banded objective, as in k_sqp_pool: the banded one faulted
+    //  - memory access fault at address 0 on the first step - for problems of the trajopt_sqp flavour, which the pool kernel runs)
+    if (P->band)
+      sqp_step_block<false, true>(P, Bt, b, smem, tid, NT);
+    else
+      sqp_step_block<false, false>(P, Bt, b, smem, tid, NT);
   }
 }
 
