@@ -61,3 +61,11 @@ wall = out[1]; tot -= wall
 # effective shader clock, and the rows above sum to wall x clock by construction of the ticks
 print("  wall-clock per problem (ms)", wall / B * 1e-5, " => effective shader clock (GHz)", tot / max(1, wall) / 10.0)
 print("  total cycles/problem", tot / B, " => per ADMM iteration (all phases)", tot / iters)
+if hasattr(ctx.lib, "tmx_debug_pspk"):
+    # segmented sweeps of the dense-coupling chain (pair-row problems): thread-0 cycles of their three parts, per sweep
+    sp = (C.c_longlong * 8)()
+    ctx.lib.tmx_debug_pspk.argtypes = [C.POINTER(C.c_longlong)]
+    if ctx.lib.tmx_debug_pspk(sp) == 0 and sp[3] > 0:
+        n = sp[3]
+        print(f"  segmented sweeps: {n} sweeps; cycles per sweep: local sweeps {sp[0] / n:.0f}, boundary vectors {sp[1] / n:.0f}, spike correction {sp[2] / n:.0f}"
+              f"  (two sweeps per ADMM iteration: {2 * (sp[0] + sp[1] + sp[2]) / n:.0f} cycles)")

@@ -2153,6 +2153,14 @@ tmx_status tmx_sqp_state(tmx_ctx* ctx, int32_t* sqp_iter, int32_t* merit_increas
   return TMX_OK;
 }
 
+#if defined(TMX_PROFILE) && !defined(TMX_HOST_EMU)
+// profile builds only: cycles of thread 0 in the three parts of the segmented chain sweeps (local sweeps, boundary vectors, spike
+// correction) and the number of sweeps, summed over all workgroups since the library was loaded (tools/prof_phases.py)
+extern "C" __attribute__((visibility("default"))) int tmx_debug_pspk(long long* out)
+{
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pspk_prof), 8 * sizeof(long long)) == hipSuccess ? 0 : 1;
+}
+#endif
 tmx_status tmx_sqp_stop(tmx_ctx* ctx, int32_t problem, int32_t status)
 {
   if (!ctx)

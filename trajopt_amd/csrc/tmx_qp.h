@@ -206,6 +206,8 @@ struct QpWs
   // the chain with dense couplings walks ONE mat-vec per step: Mf_t = C_t' S_t^-1 (forward), Nb_t = S_t^-1 C_t (backward),
   // both rebuilt after every chain inversion; yb = S_t^-1 v_t of all blocks (one parallel pass between the two sweeps)
   double *Mf, *Nb, *yb;
+  double *bsp;     // 4 D^2 (LDS): the spike blocks of the segment boundaries (forward b_1, b_2; backward a_{P-2}, a_{P-3}) - the
+                   // boundary vectors of a segmented sweep are chained through them, a dependent path that must not wait on HBM
   int n_link;      // R2
   bool sweep_regs; // the dense-coupling chain sweeps keep their running vector in registers (set by qp_admm_generic_nl<., true> only)
   bool sweep_inline; // ... and are inlined into the loop (LDS-resident kernels)
@@ -409,6 +411,11 @@ TMX_HOSTDEVFN bool dpart_fits(int D, int T)
 // accesses of the cold arrays rely on (a descriptor of an odd number of 8-byte words once shifted them by 8 bytes: memory aperture
 // violations on every configuration)
 #define QPWS_DOUBLES (((sizeof(QpWs) + 15) / 16) * 2)
+// chains WITH pair rows (dense couplings): the two substitution sweeps are cut into up to 4 segments walked side by side, joined
+// through precomputed SPIKES (chain_pair_spikes: T D^2 doubles per sweep direction, kept where WL / WR of the long-horizon scheme
+// would be - the two schemes exclude each other; the four boundary blocks also in LDS: QpWs::bsp)
+TMX_HOSTDEVFN bool pspk_fits(int D, int T, int R2) { return R2 > 0 && D <= 16 && T >= 10; }
+TMX_HOSTDEVFN size_t pspk_lds_doubles(int D, int T, int R2) { return pspk_fits(D, T, R2) ? 4 * (size_t)D * D : 0; }
 TMX_HOSTDEVFN size_t qp_lds_doubles(int D, int T, int R, int NA, int R2 = 0)
 {
   const size_t NX = (size_t)D * T;
@@ -418,7 +425,8 @@ TMX_HOSTDEVFN size_t qp_lds_doubles(int D, int T, int R, int NA, int R2 = 0)
   const size_t gn = (size_t)p.Lmax * D, nsep = (size_t)(p.P - 1) * D;
   // the dense nested-dissection region is only reserved for problems that can take the fast path (no pair rows)
   const size_t dense = (dpart_fits(D, T) && R2 == 0) ? (size_t)p.P * gn * dpart_gstride((int)gn) + nsep * dpart_mult8((int)nsep) + 6 * 64 + (size_t)p.P * dpart_gstride((int)gn) + 64 : 0;
-  return NX + 2 + (D <= 8 ? 8 * (size_t)T : NX + 2) + (size_t)R + (size_t)T + 20 + (size_t)T * D * (D <= 8 ? 8 : D) + dense + (size_t)D * D + 256 + 4 + QPWS_DOUBLES;
+  return NX + 2 + (D <= 8 ? 8 * (size_t)T : NX + 2) + (size_t)R + (size_t)T + 20 + (size_t)T * D * (D <= 8 ? 8 : D) + dense + (size_t)D * D + 256 + 4 + QPWS_DOUBLES +
+         pspk_lds_doubles(D, T, R2);
 }
 // cf ("coefficients far"): the row coefficient arrays coef / c2 live in the per-problem HBM scratch instead of the cold part.
 // They are the largest cold arrays (config 4: 52 of 177 KB) and only read by row sweeps, so a problem whose workspace
@@ -436,10 +444,7 @@ TMX_HOSTDEVFN size_t qp_glb_doubles(int D, int T, int R, int NA, int R2 = 0, int
 }
 // long horizons without pair rows: the block chain is cut into 4 interiors + 3 separator blocks (tmx_long.h)
 TMX_HOSTDEVFN bool lpart_fits(int D, int T, int R2) { return D <= 8 && R2 == 0 && T >= 64; }
-// chains WITH pair rows (dense couplings): the two substitution sweeps are cut into up to 4 segments walked side by side, joined
-// through precomputed SPIKES (chain_pair_spikes: T D^2 doubles per sweep direction, kept where WL / WR of the long-horizon scheme
-// would be - the two schemes exclude each other)
-TMX_HOSTDEVFN bool pspk_fits(int D, int T, int R2) { return R2 > 0 && D <= 16 && T >= 10; }
+
 TMX_HOSTDEVFN size_t lpart_zp_doubles(int D) { return 18 * (size_t)D * D + 6 * (size_t)D + 2; }  // 4 interiors: 2 x (3 D)^2 (ping-pong inversion) + 2 x 3 D
 // arrays that are only touched at burst boundaries / in the polish step: always in the per-problem HBM scratch
 TMX_HOSTDEVFN size_t qp_far_doubles(int D, int T, int R, int NA, int R2 = 0, int cf_flags = 0)
@@ -468,7 +473,7 @@ TMX_HOSTDEVFN size_t qp_scratch_doubles(int D, int T, int R, int NA, int R2 = 0,
 TMX_HOSTDEVFN size_t qp_chain_lds_doubles(int D, int T, int R2 = 0)
 {
   const size_t NX = (size_t)D * T;
-  const size_t pairs = R2 > 0 ? 2 * (size_t)T * D * D + NX + 4 : 0;  // Mf, Nb, yb of the dense-coupling chain
+  const size_t pairs = R2 > 0 ? 2 * (size_t)T * D * D + NX + 4 + pspk_lds_doubles(D, T, R2) : 0;  // Mf, Nb, yb of the dense-coupling chain, boundary spikes
   const size_t lp = lpart_fits(D, T, R2) ? lpart_zp_doubles(D) + 2 : 0;  // separator system of the partitioned chain
   return (size_t)T * D * D + ((D <= 8 && (size_t)T * 8 > NX + 2) ? (size_t)T * 8 : ((NX + 3) & ~(size_t)1)) + NX + (size_t)D * D + 256 + 8 + pairs + lp;
 }
@@ -497,6 +502,11 @@ TMX_DEVFN void qp_ws_chain_to_lds(QpWs& w, double* lds)
     p += (size_t)T * D * D + ((size_t)T * D * D) % 2;
     w.yb = p;
     p += NX + NX % 2;
+    if (w.bsp != nullptr)
+    {
+      w.bsp = p;
+      p += 4 * D * D;
+    }
   }
 #endif
   if (w.Zp != nullptr)
@@ -545,6 +555,13 @@ TMX_DEVFN void qp_ws_carve(QpWs& w, double* lds, double* glb, double* far, int D
   TAKE(gj, D * D);
   TAKE(red, 256);
   TAKE(wself, QPWS_DOUBLES);
+#if TMX_LINK_ROWS
+  w.bsp = nullptr;
+  if (pspk_fits(D, T, R2))
+  {
+    TAKE(bsp, 4 * D * D);
+  }
+#endif
   // ---- cold: global scratch
   p = glb;
   TAKE(xp, NX);
@@ -1175,6 +1192,20 @@ TMX_DEVFN void chain_pair_spikes(const QpWs& w, int tid, int NT)
             acc += N[k] * w.WR[(size_t)(t + 1) * DD + k * D + j];
         w.WR[(size_t)t * DD + i * D + j] = -acc;
       }
+    }
+    TMX_SYNC();
+  }
+  if (w.bsp != nullptr)
+  {
+    // boundary blocks into LDS: slot 0 / 1 = Wf at b_1 / b_2, slot 2 / 3 = Wb at a_{P-2} / a_{P-3}
+    for (int e = tid; e < 4 * DD; e += NT)
+    {
+      const int k = e / DD, q = e % DD;
+      const int p = (k < 2) ? 1 + k : P - 2 - (k - 2);
+      double v = 0.0;
+      if (p >= 1 && p <= P - 2)
+        v = (k < 2) ? w.WL[(size_t)pspk_b(T, P, p) * DD + q] : w.WR[(size_t)pspk_a(T, P, p) * DD + q];
+      w.bsp[e] = v;
     }
     TMX_SYNC();
   }
@@ -2741,11 +2772,29 @@ TMX_DEVFN void chain_wave_sweep_body(const double* mat, const double* rhs, doubl
 }
 // one sweep of the dense-coupling chain in PS segments (see chain_pair_spikes): local sweeps by PS waves, boundary vectors by wave 0,
 // spike correction by all threads.  dir = +1: w.tp -> w.tp; dir = -1: w.yb -> w.tp.  The boundary vectors live in w.red[192 .. 256).
+#ifdef TMX_PROFILE
+__device__ long long g_pspk_prof[8];  // cycles of thread 0 in the three parts of a segmented sweep (+ calls), all workgroups
+#define TMX_PSPK_T0 long long pt_ = TMX_CLK()
+#define TMX_PSPK_TICK(k)                                                                                              \
+  do                                                                                                                  \
+  {                                                                                                                   \
+    if (tid == 0)                                                                                                     \
+    {                                                                                                                 \
+      const long long now_ = TMX_CLK();                                                                               \
+      atomicAdd((unsigned long long*)&g_pspk_prof[k], (unsigned long long)(now_ - pt_));                              \
+      pt_ = now_;                                                                                                     \
+    }                                                                                                                 \
+  } while (0)
+#else
+#define TMX_PSPK_T0 ((void)0)
+#define TMX_PSPK_TICK(k) ((void)0)
+#endif
 TMX_DEVFN void chain_segmented_sweep(const QpWs& w, int PS, int dir, int tid, int NT)
 {
   const int D = w.D, DD = D * D, T = w.T;
   const int wave = tid >> 6, lane = tid & 63;
   double* bnd = w.red + 192;
+  TMX_PSPK_T0;
   if (wave < PS)
   {
     const int a = pspk_a(T, PS, wave), b = pspk_b(T, PS, wave);
@@ -2765,6 +2814,7 @@ TMX_DEVFN void chain_segmented_sweep(const QpWs& w, int PS, int dir, int tid, in
     }
   }
   TMX_SYNC();
+  TMX_PSPK_TICK(0);
   if (tid < 64)
   {
     const bool live = lane < D;
@@ -2778,7 +2828,10 @@ TMX_DEVFN void chain_segmented_sweep(const QpWs& w, int PS, int dir, int tid, in
       for (int p = 1; p < PS - 1; ++p)  // (the end of the last segment is nobody's boundary)
       {
         const int b = pspk_b(T, PS, p);
-        chain_row_load<0>(w.WL + (size_t)b * DD + i * D, D, m);
+        if (w.bsp != nullptr)
+          chain_row_load<0>(w.bsp + (size_t)(p - 1) * DD + i * D, D, m);
+        else
+          chain_row_load<0>(w.WL + (size_t)b * DD + i * D, D, m);
         const double acc = chain_row_dot<0>(m, v, D);
         v = w.tp[b * D + i] + acc;
         if (live)
@@ -2793,7 +2846,10 @@ TMX_DEVFN void chain_segmented_sweep(const QpWs& w, int PS, int dir, int tid, in
       for (int p = PS - 2; p >= 1; --p)
       {
         const int a = pspk_a(T, PS, p);
-        chain_row_load<0>(w.WR + (size_t)a * DD + i * D, D, m);
+        if (w.bsp != nullptr)
+          chain_row_load<0>(w.bsp + (size_t)(2 + (PS - 2 - p)) * DD + i * D, D, m);
+        else
+          chain_row_load<0>(w.WR + (size_t)a * DD + i * D, D, m);
         const double acc = chain_row_dot<0>(m, v, D);
         v = w.tp[a * D + i] + acc;
         if (live)
@@ -2802,6 +2858,7 @@ TMX_DEVFN void chain_segmented_sweep(const QpWs& w, int PS, int dir, int tid, in
     }
   }
   TMX_SYNC();
+  TMX_PSPK_TICK(1);
   const int L = (T + PS - 1) / PS;
   for (int e = tid; e < T * D; e += NT)
   {
@@ -2810,12 +2867,30 @@ TMX_DEVFN void chain_segmented_sweep(const QpWs& w, int PS, int dir, int tid, in
       continue;
     const double* W = (dir > 0 ? w.WL : w.WR) + (size_t)t * DD + i * D;
     const double* bv = bnd + (dir > 0 ? p - 1 : p + 1) * D;
+    // sixteen predicated loads of the spike row and of the boundary vector, all in flight before the first product (a loop with the
+    // run-time trip count D pays one memory round trip per term).  Measured and NOT kept: requesting these rows (and wave 0's boundary
+    // rows) before the local sweeps so that their latency passes under them - the registers they hold across the sweep cost more
+    // than the latency (config 3 -24 %, config 4 -2.6 %, profiles/r04/r04_segmented_sweep_parts.log).
+    double m[16], bb[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+    {
+      m[j] = (j < D) ? W[j] : 0.0;
+      bb[j] = (j < D) ? bv[j] : 0.0;
+    }
     double acc = 0.0;
-    for (int j = 0; j < D; ++j)
-      acc += W[j] * bv[j];
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      if (j < D)
+        acc += m[j] * bb[j];
     w.tp[e] += acc;
   }
   TMX_SYNC();
+  TMX_PSPK_TICK(2);
+#ifdef TMX_PROFILE
+  if (tid == 0)
+    atomicAdd((unsigned long long*)&g_pspk_prof[3], 1ULL);
+#endif
 }
 #endif
 
