@@ -579,7 +579,15 @@ def sqp_history_classes(ctx, orc, desc, x0, max_qp=128, detail=None, trace=None)
             ro = admm(ob["records"][kk]) + (ob["records"][kk].rho_final,) if kk >= 0 else None
             trace.append(dict(seed=b, cls=cls, first_qp=kk, n_qp_dev=len(dev[b]), n_qp_orc=len(oq), dev=rd, orc=ro, why=why))
         classes.append(cls)
-        dxs.append(float(np.abs(res["x"][b] - ob["x"][0]).max()))
+        # the bar is on JOINT trajectories (north_star: "within 1e-5 rad").  The time column of a time-parameterised problem often lies
+        # on a flat direction of the QP (a TotalTime hinge that is not active, velocity rows inside their band): where no polish
+        # succeeds the ADMM iterate keeps whatever round-off put there - identical integer histories end with joints 4e-8 and time
+        # variables 1e-4 apart (tests/tools/fuzz_parity.py 24 71 <host build> r4 lvs, case 15) - so it is compared at 1e-3
+        dj = np.abs(res["x"][b] - ob["x"][0])
+        if desc.use_time:
+            assert dj[:, desc.n_dof:].max() <= 1e-3 or cls not in ("identical", "tie"), f"time column of an identical history differs by {dj[:, desc.n_dof:].max()}"
+            dj = dj[:, :desc.n_dof]
+        dxs.append(float(dj.max()))
     return classes, np.array(dxs), res
 
 

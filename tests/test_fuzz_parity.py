@@ -47,6 +47,12 @@ def test_random_problems_with_kinematic_builtins_on_host_build(hostemu_lib, orc)
     _sweep(8, 17, hostemu_lib, "kin")
 
 
+def test_random_problems_with_round4_features_on_host_build(hostemu_lib, orc):
+    """convex-hull links (GJK / EPA) and capsule links under every evaluator incl. the cast ones, time-parameterised problems (JointVel
+    with time in its four forms, TotalTime as cost / constraint / squared cost) drawn next to the older term families"""
+    _sweep(10, 71, hostemu_lib, "r4", "lvs")
+
+
 @pytest.mark.gpu
 def test_random_problems_with_kinematic_builtins_on_device(orc):
     _sweep(12, 19, "gpu", "kin")

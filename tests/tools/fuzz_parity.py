@@ -17,7 +17,7 @@ from oracle import pyorc as orc
 import parity_checks as pc
 
 
-def random_problem(rng, wide=False, links=False, lvs=False, new=False, kin=False):
+def random_problem(rng, wide=False, links=False, lvs=False, new=False, kin=False, r4=False):
     """wide=False: D <= 8 and T * D <= 256 (the dense fast path on the device); wide=True also draws 9-11 DOF chains,
     longer horizons (T * D up to ~400) and single-waypoint problems: the generic block-chain path"""
     if wide:
@@ -40,6 +40,20 @@ def random_problem(rng, wide=False, links=False, lvs=False, new=False, kin=False
     if new and n_sph:
         # capsule links (discrete evaluators only: the caller keeps evaluator_type <= 2 then)
         rob.link_spheres = [prim + ((tuple(rng.uniform(-0.1, 0.15, 3)),) if rng.random() < 0.5 else ()) for prim in rob.link_spheres]
+    if r4 and n_sph:
+        # round 4: convex-hull links (4 - 9 random vertices around the primitive's centre, rounded by a small radius) and capsule
+        # links, under ANY evaluator (the cast evaluators sweep hulls; capsules become two-vertex hulls there)
+        prims = []
+        for link, c, r in [prim[:3] for prim in rob.link_spheres]:
+            u = rng.random()
+            if u < 0.45:
+                verts = np.asarray(c)[None, :] + rng.uniform(-0.09, 0.09, (int(rng.integers(4, 10)), 3))
+                prims.append((link, c, float(rng.uniform(0.0, 0.03)), ("hull", verts)))
+            elif u < 0.7:
+                prims.append((link, c, r, tuple(rng.uniform(-0.1, 0.15, 3))))
+            else:
+                prims.append((link, c, r))
+        rob.link_spheres = prims
     fixed_t = [0] if (rng.random() < 0.7 and T > 1) else []
     fixed_d = [int(rng.integers(0, D))] if rng.random() < 0.2 else []
     pci = ProblemConstructionInfo(rob, BasicInfo(n_steps=T, fixed_timesteps=fixed_t, fixed_dofs=fixed_d))
@@ -70,8 +84,8 @@ def random_problem(rng, wide=False, links=False, lvs=False, new=False, kin=False
         if lvs and T > 1:
             # segment evaluators: LVS_DISCRETE / CONTINUOUS / LVS_CONTINUOUS (pair rows; generic block-chain path)
             ci.evaluator_type = int(rng.integers(2, 5))
-            if any(len(prim) > 3 for prim in rob.link_spheres):
-                ci.evaluator_type = 2        # capsule links: discrete evaluators
+            if any(len(prim) > 3 for prim in rob.link_spheres) and not r4:
+                ci.evaluator_type = 2        # capsule links: discrete evaluators (round 3; round 4 sweeps them as two-vertex hulls)
             ci.longest_valid_segment_length = float(rng.uniform(0.05, 0.4))
             ci.max_substates = int(rng.integers(2, 6))
             if rng.random() < 0.3:
@@ -190,10 +204,41 @@ def random_problem(rng, wide=False, links=False, lvs=False, new=False, kin=False
                 ti.upper_tolerance = list(rng.uniform(0.0, 0.03, 6))
     if rng.random() < 0.8:
         pci.cnt_infos.append(JointPosTermInfo(coeffs=[1.0] * D, targets=list(goal), first_step=T - 1, last_step=T - 1))
+    use_time = r4 and not new and not kin and T > 2 and D + 1 <= abi.TMX_MAX_DOF and rng.random() < 0.6
+    if use_time:
+        # round 4: time-parameterised problems - JointVel with time in one or two of its four forms, TotalTime as cost or constraint
+        from trajopt_amd.problem import TotalTimeTermInfo
+        pci.basic_info.use_time = True
+        pci.basic_info.dt_lower_lim, pci.basic_info.dt_upper_lim = 0.3, 5.0
+        vmax = float(np.abs(goal - start).max()) / (T - 1)
+        forms = rng.permutation(4)[:int(rng.integers(1, 3))]
+        for f in forms:
+            a, b = sorted(int(v) for v in rng.integers(0, T, 2))
+            if f == 0:    # SQUARED cost (dense engine)
+                pci.cost_infos.append(JointVelTermInfo(coeffs=list(rng.uniform(0.3, 2.0, D)), targets=[0.0] * D, first_step=a, last_step=b, use_time=True, name="vt_sq"))
+            elif f == 1:  # HINGE cost
+                pci.cost_infos.append(JointVelTermInfo(coeffs=list(rng.uniform(0.5, 3.0, D)), targets=[0.0] * D, first_step=a, last_step=b, use_time=True,
+                                                       upper_tols=list(rng.uniform(0.5, 1.5, D) * vmax + 0.02), lower_tols=list(-(rng.uniform(0.5, 1.5, D) * vmax + 0.02)), name="vt_hinge"))
+            elif f == 2:  # INEQ constraint
+                pci.cnt_infos.append(JointVelTermInfo(coeffs=list(rng.uniform(0.5, 2.0, D)), targets=[0.0] * D, first_step=a, last_step=b, use_time=True, is_constraint=True,
+                                                      upper_tols=[2.5 * vmax + 0.05] * D, lower_tols=[-(2.5 * vmax + 0.05)] * D, name="vt_lim"))
+            else:         # EQ constraint on one segment
+                a = int(rng.integers(0, T - 1))
+                pci.cnt_infos.append(JointVelTermInfo(coeffs=list(rng.uniform(0.5, 2.0, D)), targets=list((goal - start) / (T - 1)), first_step=a, last_step=a, use_time=True,
+                                                      is_constraint=True, name="vt_eq"))
+        u = rng.random()
+        if u < 0.4:
+            pci.cost_infos.append(TotalTimeTermInfo(coeff=float(rng.uniform(0.05, 1.0)), limit=float(rng.uniform(0.3, 0.9)) * (T - 1), name="total_time"))
+        elif u < 0.6:
+            pci.cnt_infos.append(TotalTimeTermInfo(coeff=float(rng.uniform(0.5, 2.0)), limit=float(rng.uniform(0.6, 1.2)) * (T - 1), is_constraint=True, name="total_time"))
+        elif u < 0.7:
+            pci.cost_infos.append(TotalTimeTermInfo(coeff=float(rng.uniform(0.005, 0.05)), limit=0.0, name="total_time"))
     w = np.linspace(0.0, 1.0, T)[:, None]
     line = start[None, :] * (1 - w) + goal[None, :] * w
     B = 2
     x0 = np.clip(line[None] + 0.05 * rng.standard_normal((B, T, D)) * (np.arange(T)[None, :, None] > 0), lower + 1e-3, upper - 1e-3)
+    if use_time:
+        x0 = np.concatenate([x0, np.clip(1.2 + 0.3 * rng.standard_normal((B, T, 1)), 0.4, 4.0)], axis=2)
     return pci, x0
 
 
@@ -213,19 +258,26 @@ def main():
     kin = "kin" in sys.argv          # round 3: AvoidSingularity, DynamicCartPose, pose tolerance bands (built-in kinematic functions)
     if kin:
         sys.argv.remove("kin")
+    r4 = "r4" in sys.argv            # round 4: convex-hull links (GJK / EPA) and capsule links under any evaluator, time-parameterised problems
+    if r4:
+        sys.argv.remove("r4")
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 50
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     lib = sys.argv[3] if len(sys.argv) > 3 else os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests", "hostemu", "_build", "libtmx_hostemu.so")
     on_gpu = lib == "gpu"
-    if (new or kin) and not on_gpu:
+    if (new or kin or r4) and not on_gpu:
         os.environ.setdefault("TMX_DENSE_QP_MAX_N", "2000")   # the host build has the time; on the GPU the library's limit stays
     fails, soft, refused = 0, 0, 0
     counts = {"identical": 0, "tie": 0, "admm": 0, "csc-noise": 0, "other": 0}
     worst = {k: 0.0 for k in counts}
     for k in range(n):
         rng = np.random.default_rng([seed, k])
-        pci, x0 = random_problem(rng, wide, links, lvs, new, kin)
-        tag = f"case {seed}/{k}: D={pci.robot.n_dof} T={pci.basic_info.n_steps} costs={len(pci.cost_infos)} cnts={len(pci.cnt_infos)}"
+        pci, x0 = random_problem(rng, wide, links, lvs, new, kin, r4)
+        if os.environ.get("FUZZ_VERBOSE"):
+            print(f"start case {seed}/{k}: D={pci.robot.n_dof} T={pci.basic_info.n_steps} time={pci.basic_info.use_time} "
+                  f"prims={[('hull' if (len(p_) > 3 and isinstance(p_[3], tuple) and p_[3][0] == 'hull') else ('capsule' if len(p_) > 3 else 'sphere')) for p_ in pci.robot.link_spheres]} "
+                  f"terms={[type(t_).__name__ + str(getattr(t_, 'evaluator_type', '')) for t_ in pci.cost_infos + pci.cnt_infos]}", flush=True)
+        tag = f"case {seed}/{k}: D={pci.robot.n_dof} T={pci.basic_info.n_steps} costs={len(pci.cost_infos)} cnts={len(pci.cnt_infos)}" + (" +time" if pci.basic_info.use_time else "")
         ctx = runtime.Context(0, None if on_gpu else lib)
         try:
             desc = pc.make_ctx_inputs(ctx, pci, x0)
