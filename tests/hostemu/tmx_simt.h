@@ -1,0 +1,515 @@
+// tmx_simt.h — TEST SCAFFOLDING (included by trajopt_amd/csrc/tmx_platform.h under -DTMX_HOST_EMU -DTMX_EMU_SIMT only).
+//
+// The plain host build runs every workgroup as ONE thread: barriers are no-ops and the device-only branches of the kernels
+// (`#if TMX_IS_DEVICE`: wave sweeps through v_readlane, DPP reductions, the register-resident ADMM burst, MFMA assemblies) are not
+// compiled at all.  This layer closes that gap on the CPU: the SAME sources are compiled with TMX_IS_DEVICE = 1 and a workgroup
+// is executed as blockDim.x cooperative fibers with the synchronisation semantics of the hardware
+//   __syncthreads                        every live fiber of the workgroup arrives before any leaves
+//   wave barrier / cross-lane operation  every live fiber of the 64-lane wave arrives (v_readlane, DPP, __shfl, ballot, MFMA
+//                                        exchange their operands through a per-workgroup buffer)
+// Between two synchronisation points the fibers of a workgroup run one after the other, in an order TMX_SIMT_ORDER selects
+// (0 ascending, 1 descending, 2 waves descending / lanes ascending, 3 a fresh random permutation per pass), so that a missing
+// barrier shows up as a result that depends on the order.  A wave whose lanes wait at different kinds of barrier, or a barrier
+// some lanes never reach, ends the process with a report of where every fiber waits (the device would hang or read garbage).
+// What it cannot reproduce: instruction-level lockstep inside a wave (code relying on it without a wave barrier fails here
+// although it works on the device), hardware rounding of v_rcp_f64 / the MFMA accumulation order, memory-model effects.
+// The emulated LDS is mapped below 4 GB so that the kernels' 32-bit LDS offsets round-trip through pointers.
+#pragma once
+#include <execinfo.h>
+#include <fenv.h>
+#include <signal.h>
+#include <sys/mman.h>
+#include <unistd.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <random>
+#include <vector>
+
+enum
+{
+  TMX_SIMT_READY = 0,
+  TMX_SIMT_WAVE = 1,
+  TMX_SIMT_BLOCK = 2,
+  TMX_SIMT_DONE = 3
+};
+struct tmx_simt_fiber
+{
+  void* sp;  // saved stack pointer of the suspended fiber (tmx_simt_switch)
+  int state;
+  const char* where;
+  int line;
+};
+struct tmx_simt_block
+{
+  int NT{ 0 }, cur{ 0 }, block_id{ 0 };
+  std::vector<tmx_simt_fiber> f;
+  std::vector<char*> stacks;
+  void* sched_sp{ nullptr };
+  std::vector<uint64_t> xa, xb;  // cross-lane exchange (one slot per fiber each)
+  char *lds{ nullptr }, *lds_map{ nullptr }, *guard{ nullptr };
+  size_t lds_cap{ 0 }, lds_bytes{ 0 };
+  const std::function<void()>* fn{ nullptr };
+  std::mt19937 rng{ 12345u };
+  unsigned long long n_switch{ 0 };
+};
+static constexpr size_t TMX_SIMT_STACK = (size_t)1 << 20;
+static thread_local tmx_simt_block* tmx_simt_cur = nullptr;
+
+static inline int tmx_simt_order()
+{
+  static const int v = [] {
+    const char* e = std::getenv("TMX_SIMT_ORDER");
+    return e ? std::atoi(e) : 0;
+  }();
+  return v;
+}
+static void tmx_simt_report(tmx_simt_block* b, const char* what)
+{
+  std::fprintf(stderr, "[tmx simt] %s in workgroup %d (NT %d)\n", what, b->block_id, b->NT);
+  static const char* names[] = { "ready", "wave-barrier", "block-barrier", "done" };
+  int last_state = -1, last_line = -1, first = 0;
+  for (int i = 0; i <= b->NT; ++i)
+  {
+    const bool brk = i == b->NT || b->f[i].state != last_state || b->f[i].line != last_line;
+    if (brk && i > 0)
+      std::fprintf(stderr, "  threads %d..%d: %s at %s:%d\n", first, i - 1, names[last_state], b->f[first].where ? b->f[first].where : "?", last_line);
+    if (brk && i < b->NT)
+    {
+      first = i;
+      last_state = b->f[i].state;
+      last_line = b->f[i].line;
+    }
+  }
+  std::abort();
+}
+// Context switch between fibers of one host thread: callee-saved registers, MXCSR and the x87 control word on the outgoing stack,
+// stack pointers exchanged.  (swapcontext would do, but it saves the signal mask with a system call per switch - a QP solve of the
+// 7 x 30 problem is ~10^7 switches.)
+extern "C" void tmx_simt_switch(void** save_sp, void* load_sp);
+asm(R"(
+.text
+.hidden tmx_simt_switch
+.globl tmx_simt_switch
+.type tmx_simt_switch,@function
+tmx_simt_switch:
+  pushq %rbp
+  pushq %rbx
+  pushq %r12
+  pushq %r13
+  pushq %r14
+  pushq %r15
+  subq $8, %rsp
+  stmxcsr (%rsp)
+  fnstcw 4(%rsp)
+  movq %rsp, (%rdi)
+  movq %rsi, %rsp
+  ldmxcsr (%rsp)
+  fldcw 4(%rsp)
+  addq $8, %rsp
+  popq %r15
+  popq %r14
+  popq %r13
+  popq %r12
+  popq %rbx
+  popq %rbp
+  ret
+.size tmx_simt_switch,.-tmx_simt_switch
+)");
+// called by a fiber: wait at a barrier of the given kind
+static __attribute__((noinline)) void tmx_simt_wait(int kind, const char* where, int line)
+{
+  tmx_simt_block* b = tmx_simt_cur;
+  tmx_simt_fiber& me = b->f[b->cur];
+  me.state = kind;
+  me.where = where;
+  me.line = line;
+  tmx_simt_switch(&me.sp, b->sched_sp);
+}
+static void tmx_simt_entry()
+{
+  tmx_simt_block* b = tmx_simt_cur;
+  (*b->fn)();
+  b = tmx_simt_cur;
+  b->f[b->cur].state = TMX_SIMT_DONE;
+  b->f[b->cur].line = 0;
+  tmx_simt_switch(&b->f[b->cur].sp, b->sched_sp);
+  std::abort();  // a finished fiber is never resumed
+}
+extern thread_local struct tmx_emu_idx tmx_emu_threadIdx, tmx_emu_blockIdx, tmx_emu_blockDim, tmx_emu_gridDim;
+extern thread_local double* tmx_emu_smem;
+
+static void tmx_simt_run_block(int block_id, int grid, int NT, size_t smem_bytes, const std::function<void()>& fn);
+
+// ---- cross-lane primitives (called by fibers) -----------------------------------------------------------------------------
+#define TMX_SIMT_WAVE_SYNC() tmx_simt_wait(TMX_SIMT_WAVE, __FILE__, __LINE__)
+static inline uint64_t tmx_simt_xchg(uint64_t v, int src_lane, const char* where, int line)
+{
+  tmx_simt_block* b = tmx_simt_cur;
+  const int tid = b->cur, base = tid & ~63;
+  b->xa[tid] = v;
+  tmx_simt_wait(TMX_SIMT_WAVE, where, line);
+  int s = base + (src_lane & 63);
+  if (s >= b->NT)
+    s = tid;
+  const uint64_t r = b->xa[s];
+  tmx_simt_wait(TMX_SIMT_WAVE, where, line);
+  return r;
+}
+static inline int tmx_simt_readlane_i(int v, int lane, const char* where, int line) { return (int)(uint32_t)tmx_simt_xchg((uint32_t)v, lane, where, line); }
+static inline int tmx_simt_dpp_src(int lane, int ctrl)
+{
+  if (ctrl >= 0 && ctrl <= 0xFF)  // quad_perm
+    return (lane & ~3) | ((ctrl >> (2 * (lane & 3))) & 3);
+  if (ctrl == 0x140)  // row_mirror
+    return (lane & ~15) | (15 - (lane & 15));
+  if (ctrl == 0x141)  // row_half_mirror
+    return (lane & ~7) | (7 - (lane & 7));
+  if (ctrl >= 0x101 && ctrl <= 0x10F)  // row_shl n: lane reads lane + n of its row (bound_ctrl: 0 outside)
+    return ((lane & 15) + (ctrl & 15) <= 15) ? lane + (ctrl & 15) : -1;
+  if (ctrl >= 0x111 && ctrl <= 0x11F)  // row_shr n
+    return ((lane & 15) >= (ctrl & 15)) ? lane - (ctrl & 15) : -1;
+  std::fprintf(stderr, "[tmx simt] DPP control 0x%x is not emulated\n", ctrl);
+  std::abort();
+}
+static inline int tmx_simt_mov_dpp(int v, int ctrl, const char* where, int line)
+{
+  tmx_simt_block* b = tmx_simt_cur;
+  const int tid = b->cur, base = tid & ~63;
+  b->xa[tid] = (uint32_t)v;
+  tmx_simt_wait(TMX_SIMT_WAVE, where, line);
+  const int s = tmx_simt_dpp_src(tid & 63, ctrl);
+  const int r = (s < 0 || base + s >= b->NT) ? 0 : (int)(uint32_t)b->xa[base + s];
+  tmx_simt_wait(TMX_SIMT_WAVE, where, line);
+  return r;
+}
+static inline unsigned long long tmx_simt_ballot(bool p, const char* where, int line)
+{
+  tmx_simt_block* b = tmx_simt_cur;
+  const int tid = b->cur, base = tid & ~63;
+  b->xa[tid] = p ? 1u : 0u;
+  tmx_simt_wait(TMX_SIMT_WAVE, where, line);
+  unsigned long long m = 0;
+  for (int l = 0; l < 64 && base + l < b->NT; ++l)
+    if (b->f[base + l].state != TMX_SIMT_DONE && b->xa[base + l])
+      m |= 1ULL << l;
+  tmx_simt_wait(TMX_SIMT_WAVE, where, line);
+  return m;
+}
+template <class T>
+static inline T tmx_simt_shfl(T v, int src, const char* where, int line)
+{
+  static_assert(sizeof(T) <= 8, "shfl operand");
+  uint64_t u = 0;
+  std::memcpy(&u, &v, sizeof(T));
+  u = tmx_simt_xchg(u, src, where, line);
+  T r;
+  std::memcpy(&r, &u, sizeof(T));
+  return r;
+}
+typedef double tmx_simt_v4d __attribute__((ext_vector_type(4)));  // clang (the ROCm toolchain's host compiler): .x/.y members, numbered address spaces
+// v_mfma_f64_16x16x4_f64: D (16 x 16) += A (16 x 4) B (4 x 16); lane l holds A[l & 15][l >> 4], B[l >> 4][l & 15] and the four
+// entries D[(l >> 4) + 4 q][l & 15], q = 0..3, of the accumulator (the f64 form's own map)
+static inline tmx_simt_v4d tmx_simt_mfma_f64_16x16x4(double a, double bv, tmx_simt_v4d c, const char* where, int line)
+{
+  tmx_simt_block* b = tmx_simt_cur;
+  const int tid = b->cur, base = tid & ~63, lane = tid & 63;
+  std::memcpy(&b->xa[tid], &a, 8);
+  std::memcpy(&b->xb[tid], &bv, 8);
+  tmx_simt_wait(TMX_SIMT_WAVE, where, line);
+  const int j = lane & 15;
+  for (int q = 0; q < 4; ++q)
+  {
+    const int i = (lane >> 4) + 4 * q;
+    double acc = c[q];
+    for (int k = 0; k < 4; ++k)
+    {
+      double av, bb;
+      std::memcpy(&av, &b->xa[base + 16 * k + i], 8);
+      std::memcpy(&bb, &b->xb[base + 16 * k + j], 8);
+      acc = __builtin_fma(av, bb, acc);
+    }
+    c[q] = acc;
+  }
+  tmx_simt_wait(TMX_SIMT_WAVE, where, line);
+  return c;
+}
+
+// ---- the scheduler --------------------------------------------------------------------------------------------------------
+static tmx_simt_block* tmx_simt_block_of_thread()
+{
+  static thread_local tmx_simt_block* blk = nullptr;
+  if (!blk)
+    blk = new tmx_simt_block();
+  return blk;
+}
+// TMX_SIMT_FPE=1: trap the first invalid floating-point operation (with TMX_EMU_POISON_WORD=7FF4DEAD7FF4DEAD, a signalling NaN, the
+// first ARITHMETIC use of memory nothing has written) and the first access beyond the workgroup's LDS, and say where
+static void tmx_simt_fault(int sig, siginfo_t* si, void*)
+{
+  tmx_simt_block* b = tmx_simt_cur;
+  char msg[256];
+  const int n = std::snprintf(msg, sizeof msg, "[tmx simt] signal %d (code %d, address %p) in workgroup %d, thread %d; last barrier %s:%d; LDS %p + %zu\n", sig, si->si_code,
+                              si->si_addr, b ? b->block_id : -1, b ? b->cur : -1, (b && b->f[b->cur].where) ? b->f[b->cur].where : "-", b ? b->f[b->cur].line : 0,
+                              b ? (void*)b->lds : nullptr, b ? b->lds_bytes : (size_t)0);
+  (void)!write(2, msg, n);
+  void* bt[48];
+  backtrace_symbols_fd(bt, backtrace(bt, 48), 2);
+  _exit(99);
+}
+static void tmx_simt_install_traps()
+{
+  static const bool once = [] {
+    if (const char* e = std::getenv("TMX_SIMT_FPE"))
+      if (e[0] == '1')
+      {
+        struct sigaction sa;
+        std::memset(&sa, 0, sizeof sa);
+        sa.sa_sigaction = tmx_simt_fault;
+        sa.sa_flags = SA_SIGINFO;
+        sigaction(SIGFPE, &sa, nullptr);
+        sigaction(SIGSEGV, &sa, nullptr);
+      }
+    return true;
+  }();
+  (void)once;
+}
+static void tmx_simt_run_block(int block_id, int grid, int NT, size_t smem_bytes, const std::function<void()>& fn)
+{
+  tmx_simt_install_traps();
+  const bool fpe = std::getenv("TMX_SIMT_FPE") != nullptr;
+  if (fpe)
+    feenableexcept(FE_INVALID);
+  tmx_simt_block* b = tmx_simt_block_of_thread();
+  b->NT = NT;
+  b->block_id = block_id;
+  b->fn = &fn;
+  if ((int)b->stacks.size() < NT)
+  {
+    const size_t old = b->stacks.size();
+    b->stacks.resize(NT);
+    for (size_t i = old; i < (size_t)NT; ++i)
+    {
+      void* p = mmap(nullptr, TMX_SIMT_STACK, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE | MAP_STACK, -1, 0);
+      if (p == MAP_FAILED)
+      {
+        std::perror("[tmx simt] mmap stack");
+        std::abort();
+      }
+      b->stacks[i] = (char*)p;
+    }
+  }
+  b->f.resize(NT);
+  b->xa.assign(NT + 64, 0);
+  b->xb.assign(NT + 64, 0);
+  // The workgroup's LDS ends at a page boundary followed by an inaccessible page: the device neither faults nor stores beyond the
+  // allocation (reads return 0, writes vanish), which no comparison of results on the host would show - here it is a SIGSEGV.
+  const size_t need = (smem_bytes + 15) & ~(size_t)15;
+  const size_t pages = ((need + 4095) & ~(size_t)4095) + 4096;
+  if (b->lds_cap < pages)
+  {
+    if (b->lds_map)
+      munmap(b->lds_map, b->lds_cap);
+    b->lds_cap = (pages + 0xFFFFF) & ~(size_t)0xFFFFF;
+    void* p = mmap(nullptr, b->lds_cap, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_32BIT, -1, 0);
+    if (p == MAP_FAILED)
+    {
+      std::perror("[tmx simt] mmap LDS below 4 GB");
+      std::abort();
+    }
+    b->lds_map = (char*)p;
+    b->guard = nullptr;
+  }
+  if (b->guard)
+    mprotect(b->guard, 4096, PROT_READ | PROT_WRITE);
+  b->guard = b->lds_map + (pages - 4096);
+  b->lds = b->guard - need;
+  b->lds_bytes = need;
+  // the device does not clear LDS between workgroups: hand out a signalling pattern (NaNs / huge negative ints)
+  tmx_emu_fill(b->lds, need);
+  mprotect(b->guard, 4096, PROT_NONE);
+  tmx_simt_cur = b;
+  tmx_emu_smem = (double*)b->lds;
+  tmx_emu_blockIdx = { block_id, 0, 0 };
+  tmx_emu_blockDim = { NT, 1, 1 };
+  tmx_emu_gridDim = { grid, 1, 1 };
+  for (int i = 0; i < NT; ++i)
+  {
+    tmx_simt_fiber& f = b->f[i];
+    // initial frame: what tmx_simt_switch pops (control words, six registers) and the entry point as its return address; the entry
+    // then sees the stack alignment of a called function
+    uint64_t* top = reinterpret_cast<uint64_t*>(b->stacks[i] + TMX_SIMT_STACK);
+    top -= 2;           // 16 bytes above the return address stay unused
+    *--top = 0;         // keeps (rsp + 8) a multiple of 16 at the entry
+    *--top = reinterpret_cast<uint64_t>(&tmx_simt_entry);
+    for (int r = 0; r < 6; ++r)
+      *--top = 0;       // rbp, rbx, r12 - r15
+    {
+      uint32_t cw[2] = { 0, 0 };
+      asm volatile("stmxcsr %0" : "=m"(cw[0]));
+      uint16_t fcw;
+      asm volatile("fnstcw %0" : "=m"(fcw));
+      cw[1] = fcw;
+      uint64_t both;
+      std::memcpy(&both, cw, 8);
+      *--top = both;
+    }
+    f.sp = top;
+    f.state = TMX_SIMT_READY;
+    f.where = nullptr;
+    f.line = 0;
+  }
+  std::vector<int> order(NT);
+  const int mode = tmx_simt_order();
+  for (int i = 0; i < NT; ++i)
+    order[i] = mode == 1 ? NT - 1 - i : mode == 2 ? (((NT - 1 - i) & ~63) | (i & 63)) : i;
+  if (mode == 2)
+    for (int i = 0; i < NT; ++i)
+      if (order[i] >= NT)
+        order[i] = i;  // ragged last wave: keep it simple
+  int n_done = 0;
+  while (n_done < NT)
+  {
+    if (mode == 3)
+      std::shuffle(order.begin(), order.end(), b->rng);
+    bool ran = false;
+    for (int k = 0; k < NT; ++k)
+    {
+      const int i = order[k];
+      if (b->f[i].state != TMX_SIMT_READY)
+        continue;
+      b->cur = i;
+      tmx_emu_threadIdx = { i, 0, 0 };
+      ++b->n_switch;
+      tmx_simt_switch(&b->sched_sp, b->f[i].sp);
+      ran = true;
+      if (b->f[i].state == TMX_SIMT_DONE)
+        ++n_done;
+    }
+    if (n_done == NT)
+      break;
+    // release: complete waves first, then the workgroup
+    bool released = false;
+    int n_block = 0;
+    for (int w0 = 0; w0 < NT; w0 += 64)
+    {
+      int live = 0, at_wave = 0;
+      for (int l = w0; l < w0 + 64 && l < NT; ++l)
+      {
+        live += b->f[l].state != TMX_SIMT_DONE;
+        at_wave += b->f[l].state == TMX_SIMT_WAVE;
+        n_block += b->f[l].state == TMX_SIMT_BLOCK;
+      }
+      if (live > 0 && at_wave == live)
+      {
+        if (std::getenv("TMX_SIMT_CHECK_SITES"))
+        {
+          int f0 = -1;
+          for (int l = w0; l < w0 + 64 && l < NT; ++l)
+            if (b->f[l].state == TMX_SIMT_WAVE)
+            {
+              if (f0 < 0)
+                f0 = l;
+              else if (b->f[l].line != b->f[f0].line || b->f[l].where != b->f[f0].where)
+              {
+                std::fprintf(stderr, "[tmx simt] wave %d: lane %d waits at %s:%d, lane %d at %s:%d\n", w0 / 64, f0 - w0, b->f[f0].where, b->f[f0].line, l - w0,
+                             b->f[l].where, b->f[l].line);
+                break;
+              }
+            }
+        }
+        for (int l = w0; l < w0 + 64 && l < NT; ++l)
+          if (b->f[l].state == TMX_SIMT_WAVE)
+            b->f[l].state = TMX_SIMT_READY;
+        released = true;
+      }
+    }
+    if (!released && n_block == NT - n_done)
+    {
+      for (int l = 0; l < NT; ++l)
+        if (b->f[l].state == TMX_SIMT_BLOCK)
+          b->f[l].state = TMX_SIMT_READY;
+      released = true;
+    }
+    if (!released)
+      tmx_simt_report(b, ran ? "divergent barrier (lanes of a wave wait at different barriers, or some never arrive)" : "deadlock");
+  }
+  if (fpe)
+    fedisableexcept(FE_INVALID);
+  if (std::getenv("TMX_SIMT_VERBOSE"))
+    std::fprintf(stderr, "[tmx simt] workgroup %d/%d: %d threads, %zu B of LDS, %llu fiber switches so far\n", block_id, grid, NT, smem_bytes, b->n_switch);
+  tmx_simt_cur = nullptr;
+}
+
+// ---- the device vocabulary the kernels use --------------------------------------------------------------------------------
+#define __device__
+#define __global__
+#define __host__
+#define __builtin_amdgcn_readfirstlane(x) (x) /* a uniformity hint wherever the kernels use it */
+#define __builtin_amdgcn_readlane(v, l) tmx_simt_readlane_i((v), (l), __FILE__, __LINE__)
+#define __builtin_amdgcn_mov_dpp(v, ctrl, rm, bm, bc) tmx_simt_mov_dpp((v), (ctrl), __FILE__, __LINE__)
+#define __builtin_amdgcn_ballot_w64(p) tmx_simt_ballot((p), __FILE__, __LINE__)
+#define __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, x, y, z) tmx_simt_mfma_f64_16x16x4((a), (b), (c), __FILE__, __LINE__)
+#define __builtin_amdgcn_rcp(a) (1.0 / (a))
+#define __builtin_amdgcn_fence(order, scope) __atomic_thread_fence(order)
+#define __builtin_amdgcn_wave_barrier() TMX_SIMT_WAVE_SYNC()
+#define __builtin_amdgcn_s_sleep(n) ((void)0)
+#define __shfl(v, src, width) tmx_simt_shfl((v), (src), __FILE__, __LINE__)
+static inline bool tmx_simt_is_shared(const void* p)
+{
+  const tmx_simt_block* b = tmx_simt_cur;
+  return b && (const char*)p >= b->lds_map && (const char*)p < b->lds_map + b->lds_cap;
+}
+#define __builtin_amdgcn_is_shared(p) tmx_simt_is_shared((const void*)(p))
+static inline int __double2loint(double x)
+{
+  uint64_t u;
+  std::memcpy(&u, &x, 8);
+  return (int)(uint32_t)u;
+}
+static inline int __double2hiint(double x)
+{
+  uint64_t u;
+  std::memcpy(&u, &x, 8);
+  return (int)(uint32_t)(u >> 32);
+}
+static inline double __hiloint2double(int hi, int lo)
+{
+  const uint64_t u = ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
+  double x;
+  std::memcpy(&x, &u, 8);
+  return x;
+}
+#define __HIP_MEMORY_SCOPE_AGENT 0
+#define __HIP_MEMORY_SCOPE_SYSTEM 0
+#define __HIP_MEMORY_SCOPE_WORKGROUP 0
+#define __hip_atomic_load(p, order, scope) __atomic_load_n((p), (order))
+#define __hip_atomic_store(p, v, order, scope) __atomic_store_n((p), (v), (order))
+template <class T>
+static inline T atomicCAS(T* p, T cmp, T val)
+{
+  __atomic_compare_exchange_n(p, &cmp, val, false, __ATOMIC_ACQ_REL, __ATOMIC_RELAXED);
+  return cmp;
+}
+template <class T, class U>
+static inline T atomicAdd(T* p, U v)
+{
+  return __atomic_fetch_add(p, (T)v, __ATOMIC_RELAXED);
+}
+struct hipDeviceProp_t
+{
+  int multiProcessorCount;
+};
+static inline int hipGetDeviceProperties(hipDeviceProp_t* p, int) { return p->multiProcessorCount = 8, 0; }
+enum
+{
+  hipFuncAttributeMaxDynamicSharedMemorySize = 8
+};
+static inline int hipFuncSetAttribute(const void*, int, int) { return 0; }
+template <class K>
+static inline int hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, K, int, size_t) { return *n = 1, 0; }
+static inline int min(int a, int b) { return a < b ? a : b; }
+static inline int max(int a, int b) { return a > b ? a : b; }

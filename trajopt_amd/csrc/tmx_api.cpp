@@ -1554,6 +1554,9 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
   HIPCHK(hipMemcpy(ctx->dp, &P, sizeof(DevProblem), hipMemcpyHostToDevice));
   // LDS budgets
   ctx->smem_qp = qp_smem_bytes(D, T, R, NA, R2, P.coef_far);
+  if (std::getenv("TMX_VERBOSE"))
+    std::fprintf(stderr, "[tmx] problem: D %d (joints %d), T %d, row slots %d, aux %d, pair rows %d, workspace flags %d, band %d, dense %d, QP workspace %zu B\n", D, P.DK, T, R, NA, R2,
+                 P.coef_far, P.band, (int)P.qp_dense, ctx->smem_qp);
   const size_t small_ints = 2 * (size_t)(P.n_max + 1) + 4 * (size_t)R + 2 + 16 + 16 + 512;  // qp_structure: tables, hash accumulators, chunk totals
   ctx->smem_small = std::max<size_t>((tmx_eval_scratch_doubles(R, D * T, (int)vel_first.size(), n_costs, n_cnts) + n_costs + n_cnts + 8) * sizeof(double),
                                      small_ints * sizeof(int) + 64);
@@ -1584,7 +1587,7 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
   }
   if (ctx->dense)
     ctx->smem_small = std::max<size_t>(ctx->smem_small, 320 * sizeof(double));  // reduction scratch of qp_generic_block
-#ifdef TMX_HOST_EMU
+#if defined(TMX_HOST_EMU) && !defined(TMX_EMU_SIMT)
   ctx->nt_qp = 1;
   ctx->nt_small = 1;
   ctx->smem_pool = std::max<size_t>(ctx->smem_qp, 64);

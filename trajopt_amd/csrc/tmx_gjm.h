@@ -26,7 +26,7 @@
 #pragma once
 
 typedef double tmx_v4d __attribute__((ext_vector_type(4)));
-typedef double tmx_gjm_d2 __attribute__((ext_vector_type(2)));
+typedef double tmx_gjm_d2 __attribute__((ext_vector_type(2) TMX_D2_MEM_ALIGN));
 typedef __attribute__((address_space(3))) double tmx_gjm_lds;
 typedef __attribute__((address_space(3))) tmx_gjm_d2 tmx_gjm_lds2;
 

@@ -641,7 +641,7 @@ TMX_DEVFN void sqp_pool_body(const DevProblem* P, const DevBatch* Bt)
       const bool done = Bt->phase[b] == PHASE_DONE;
 #if TMX_IS_DEVICE
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      TMX_ASM_WAIT_VM();
 #endif
       TMX_ST_RELAXED(&Bt->sched_state[b], done ? 2 : 0);
       released_open = !done;
@@ -654,7 +654,7 @@ TMX_DEVFN void sqp_pool_body(const DevProblem* P, const DevBatch* Bt)
 #endif
       }
 #if TMX_IS_DEVICE
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the release store has left the CU before any wave rescans
+      TMX_ASM_WAIT_VM();  // the release store has left the CU before any wave rescans
 #endif
     }
     TMX_SYNC();  // no wave scans sched_state before thread 0 has published the release

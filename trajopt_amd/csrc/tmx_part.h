@@ -137,7 +137,7 @@ TMX_DEVFN void dpart_map(const QpWs& w, const DPart& p, int tid, DMap& m)
     }
 }
 
-typedef double tmx_d2 __attribute__((ext_vector_type(2)));
+typedef double tmx_d2 __attribute__((ext_vector_type(2) TMX_D2_MEM_ALIGN));
 #include "tmx_gjm.h"
 // block Gauss-Jordan on the f64 matrix cores (tmx_gjm.h) for the two inversion stages of dpart_factor; 0: the row versions below
 #ifndef TMX_GJM
@@ -798,7 +798,9 @@ TMX_DEVFN int admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, bo
   // The instantiations sit in the arms of one wave-uniform dispatch and begin with the same prologue; left alone, the optimiser
   // hoists that common code above the dispatch, and the ~50 values it defines then have to survive the branching - they were
   // spilled to scratch at every burst entry of even the smallest instantiation.  A distinct volatile marker per arm stops it.
+#if TMX_IS_GCN
   asm volatile("; admm_burst_core<%0, %1, %2, %3>" ::"n"((int)RC), "n"(NR), "n"((int)INTW), "n"(NAX));
+#endif
   const int D = __builtin_amdgcn_readfirstlane(w.D);
 #define TMX_LDS_PTR(p) ((tmx_lds_d*)(size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(p)))
   HotLds h;

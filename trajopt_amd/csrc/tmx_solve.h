@@ -1794,7 +1794,7 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
   // ---------------- factor + ADMM loop (osqp_solve) --------------------------------------------------------
   TMX_TICK(0);
 #if TMX_IS_DEVICE
-  const bool fast = !HBM && (NT == TMX_QP_NT) && (R <= 512) && dpart_supported(w, NT) && !TMX_HAS_PAIRS(w) && w.c_alist == nullptr && w.band == 0;
+  const bool fast = !HBM && (NT == TMX_QP_NT) && (R <= 512) && dpart_supported(w, NT) && !TMX_HAS_PAIRS(w) && w.c_alist == nullptr && w.band == 0 && TMX_FAST_ALLOWED;
 #else
   const bool fast = false;
 #endif
@@ -1837,7 +1837,7 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
       // constant propagation re-materialises the symbol inside the callees, whose per-kernel dynamic-LDS lookup
       // (llvm.amdgcn.dynlds.offset.table) then faulted on this toolchain
       unsigned lds_off = (unsigned)(size_t)smem;
-      asm volatile("" : "+s"(lds_off));
+      TMX_ASM_OPAQUE_SGPR(lds_off);
       qp_admm_fast_nl(P, Bt, b, lds_off);
     }
 #ifdef TMX_PROFILE
@@ -1872,7 +1872,7 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
     TMX_SYNC();
     {
       unsigned lds_off = (unsigned)(size_t)(HBM ? chain_lds : smem);
-      asm volatile("" : "+s"(lds_off));
+      TMX_ASM_OPAQUE_SGPR(lds_off);
     {
       // instantiations: with / without pair rows; block size 7 (7-DOF arms: configs 2 and 4) as a compile-time constant.  (A D = 10
       // instantiation for config 3 faulted in the 512-thread HBM kernel - memory access fault at address 0, not understood - and is
