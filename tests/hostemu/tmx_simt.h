@@ -429,6 +429,17 @@ static void tmx_simt_run_block(int block_id, int grid, int NT, size_t smem_bytes
     }
     if (!released && n_block == NT - n_done)
     {
+      // every live thread waits at a workgroup barrier: it has to be the SAME one (s_barrier only counts arrivals - threads that took
+      // different branches to different __syncthreads would pass each other on the device and compute garbage)
+      int f0 = -1;
+      for (int l = 0; l < NT; ++l)
+        if (b->f[l].state == TMX_SIMT_BLOCK)
+        {
+          if (f0 < 0)
+            f0 = l;
+          else if (b->f[l].line != b->f[f0].line || b->f[l].where != b->f[f0].where)
+            tmx_simt_report(b, "threads of one workgroup wait at DIFFERENT __syncthreads");
+        }
       for (int l = 0; l < NT; ++l)
         if (b->f[l].state == TMX_SIMT_BLOCK)
           b->f[l].state = TMX_SIMT_READY;

@@ -61,6 +61,37 @@ def test_full_sqp_config1_short_horizon(simt, orc):
     assert (r["status"] == o["status"]).all()
 
 
+def test_full_sqp_baseline_config1(simt, orc):
+    """BASELINE config 1 at its real size (glass_upright, 7 joints x 30 waypoints; two seeds): the headline kernel's device code -
+    k_sqp_pool with the fast path's burst, 8 interiors / 7 separators, MFMA factorisations - QP by QP the oracle's run (about sixty
+    Model::optimize() calls per seed)"""
+    pci, s, g = pc.cfg(1)
+    x0 = configs.seeds_for(1, pci, s, g, 2, sigma=0.05)
+    desc = pc.make_ctx_inputs(simt, pci, x0)
+    r, o, same, dx = pc.check_full_sqp(simt, orc, desc, x0, exact=False)
+    assert same.all() and (dx <= pc.TOL_TRAJ).all()
+    assert (r["status"] == o["status"]).all()
+
+
+def test_trajopt_sqp_flavour_config4(simt, orc):
+    """BASELINE config 4 (trajopt_sqp flavour, 7 joints, continuous collision per segment) on 14 waypoints, two seeds: pair rows through
+    the register-resident and SEGMENTED chain sweeps of this round (T >= 10), whole TrustRegionSQPSolver::solve.  (At its real size -
+    30 waypoints, four seeds - the emulation returns the oracle's run to 5e-13 as well; most of that minute is the oracle's.)"""
+    from test_sqp_flavour import _check_flavour
+    r, o, same, dx = _check_flavour(simt, orc, 14, 2)
+    assert same.all() and (dx <= 1e-9).all()
+
+
+def test_first_qp_of_config3_in_the_hbm_workspace(simt, orc):
+    """BASELINE config 3 (car_seat: 10 joints x 50 waypoints, pair rows): k_qp_solve_hbm - 512 threads, workspace in HBM, the chain
+    arrays in LDS"""
+    pci, s, g = pc.cfg(3)
+    x0 = configs.seeds_for(3, pci, s, g, 1)
+    desc = pc.make_ctx_inputs(simt, pci, x0)
+    res = pc.check_first_qp_solve(simt, orc, desc, x0)
+    assert all(same for same, _ in res)
+
+
 @pytest.mark.parametrize("cid", [9, 11, 13, 16, 18, 20, 26, 48])
 def test_first_qp_solve_matches_oracle(simt, orc, cid):
     """one Model::optimize() through the device branches: 9 / 11 mini arm (fast path), 13 ten joints (generic chain, MFMA block
@@ -125,3 +156,16 @@ np.save(sys.argv[1], np.concatenate(out))
             subprocess.check_call([sys.executable, "-c", code, path], env=env)
             res[o] = np.load(path)
     assert np.array_equal(res["0"], res[order])
+
+
+def test_random_problems_of_the_failing_device_sweep(simt_lib, orc):
+    """the first four problems of `fuzz_parity.py 20 73 gpu r4 lvs` (case 3 is one of the device's two failures; all twenty pass here,
+    profiles/r04/r04_simt_fuzz_sweeps.log) - every stage and the whole SQP against the oracle, on the emulation"""
+    from test_fuzz_parity import _sweep
+    _sweep(4, 73, simt_lib, "r4", "lvs")
+
+
+def test_random_problems_on_the_fast_path(simt_lib, orc):
+    """a slice of the device tier's own sweep (seed 5: D <= 8, n_steps * D <= 256)"""
+    from test_fuzz_parity import _sweep
+    _sweep(5, 5, simt_lib)
