@@ -56,6 +56,14 @@ struct tmx_simt_block
   std::mt19937 rng{ 12345u };
   unsigned long long n_switch{ 0 };
 };
+// bookkeeping of the v_readfirstlane check (below, with the device vocabulary)
+#include <unordered_map>
+struct tmx_simt_rfl_table
+{
+  std::unordered_map<uint64_t, std::pair<int, int>> first;   // (wave, site, call index) -> (value, thread) of the first lane that got there
+  std::vector<std::unordered_map<uint32_t, uint32_t>> calls;  // per thread: site -> number of calls so far
+};
+static thread_local tmx_simt_rfl_table tmx_simt_rfl;
 static constexpr size_t TMX_SIMT_STACK = (size_t)1 << 20;
 static thread_local tmx_simt_block* tmx_simt_cur = nullptr;
 
@@ -331,6 +339,9 @@ static void tmx_simt_run_block(int block_id, int grid, int NT, size_t smem_bytes
   // the device does not clear LDS between workgroups: hand out a signalling pattern (NaNs / huge negative ints)
   tmx_emu_fill(b->lds, need);
   mprotect(b->guard, 4096, PROT_NONE);
+  tmx_simt_rfl.first.clear();
+  for (auto& m : tmx_simt_rfl.calls)
+    m.clear();
   tmx_simt_cur = b;
   tmx_emu_smem = (double*)b->lds;
   tmx_emu_blockIdx = { block_id, 0, 0 };
@@ -459,7 +470,35 @@ static void tmx_simt_run_block(int block_id, int grid, int NT, size_t smem_bytes
 #define __device__
 #define __global__
 #define __host__
-#define __builtin_amdgcn_readfirstlane(x) (x) /* a uniformity hint wherever the kernels use it */
+// v_readfirstlane: the kernels use it as a uniformity hint (the value is the same in every lane; the compiler is told so), also in
+// places only some lanes of the wave reach - so it cannot be a collective here.  It returns the lane's own value and CHECKS the claim:
+// the k-th call of a lane at a source line must see the value the first lane of its wave saw at its k-th call there (the device
+// would silently hand every lane the first active lane's value)
+static inline int tmx_simt_readfirstlane(int v, const char* where, int line)
+{
+  tmx_simt_block* b = tmx_simt_cur;
+  if (!b)
+    return v;
+  if ((int)tmx_simt_rfl.calls.size() < b->NT)
+    tmx_simt_rfl.calls.resize(b->NT);
+  const uint32_t site = (uint32_t)line ^ ((uint32_t)(uintptr_t)where * 2654435761u);
+  const uint32_t k = tmx_simt_rfl.calls[b->cur][site]++;
+  const uint64_t key = ((uint64_t)(b->cur >> 6) << 56) ^ ((uint64_t)site << 24) ^ k;
+  auto it = tmx_simt_rfl.first.find(key);
+  if (it == tmx_simt_rfl.first.end())
+    tmx_simt_rfl.first.emplace(key, std::make_pair(v, b->cur));
+  else if (it->second.first != v)
+  {
+    // the one legitimate non-uniform operand: the thread index itself (`readfirstlane(tid) & ~63` = first thread of the wave)
+    if (v == b->cur && it->second.first == it->second.second)
+      return b->cur & ~63;
+    std::fprintf(stderr, "[tmx simt] v_readfirstlane of a NON-UNIFORM value at %s:%d (workgroup %d, thread %d: %d, first lane of the wave: %d)\n", where, line, b->block_id, b->cur,
+                 v, it->second.first);
+    std::abort();
+  }
+  return v;
+}
+#define __builtin_amdgcn_readfirstlane(x) tmx_simt_readfirstlane((int)(x), __FILE__, __LINE__)
 #define __builtin_amdgcn_readlane(v, l) tmx_simt_readlane_i((v), (l), __FILE__, __LINE__)
 #define __builtin_amdgcn_mov_dpp(v, ctrl, rm, bm, bc) tmx_simt_mov_dpp((v), (ctrl), __FILE__, __LINE__)
 #define __builtin_amdgcn_ballot_w64(p) tmx_simt_ballot((p), __FILE__, __LINE__)
