@@ -1531,6 +1531,13 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
     if ((force && force[0] == '1') ||
         (qp_smem_bytes(D, T, R, NA, R2, 0) > 160 * 1024 && qp_smem_bytes(D, T, R, NA, R2, 1) <= 160 * 1024))
       P.coef_far = 1;
+    // Odd block sizes above 8: every other row of coef / c2 starts on an 8-byte boundary, and the stepping kernel's row dots
+    // (compute_residuals, the activity pass at load, link_dot) are compiled eight wide with 16-byte FLAT loads of those rows
+    // (profiles/r04/r04_defect_offline_analysis.md).  A misaligned 16-byte flat access is legal in HBM and is what has faulted in LDS
+    // before, so such problems keep their coefficient rows in the HBM scratch - the placement config 4 runs with.  (Host-side
+    // mitigation of the round-4 device defect, case 3; not yet confirmed on the device: no GPU budget was left.)
+    if (D > 8 && (D & 1) && !(force && force[0] == '0'))
+      P.coef_far = 1;
   }
   {
     // compact row lists (bit 1 of the flag word): problems whose row slots are mostly collision slots - thousands of slots, a
