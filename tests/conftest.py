@@ -33,7 +33,11 @@ def orc_fma(orc):
 
 @pytest.fixture(scope="session")
 def hostemu_lib():
-    """kernel sources compiled for the host — CPU-tier scaffolding only (tests/hostemu/Makefile)"""
+    """kernel sources compiled for the host — CPU-tier scaffolding only (tests/hostemu/Makefile).
+    TMX_HOSTEMU_LIB=<path>: run the tier on another build of the same sources (by hand: the SIMT emulation libtmx_simt.so, a
+    sanitizer build)"""
+    if os.environ.get("TMX_HOSTEMU_LIB"):
+        return os.environ["TMX_HOSTEMU_LIB"]
     if not os.path.exists(HOSTEMU_LIB) or os.path.getmtime(HOSTEMU_LIB) < max(
             os.path.getmtime(os.path.join(ROOT, "trajopt_amd", "csrc", f)) for f in os.listdir(os.path.join(ROOT, "trajopt_amd", "csrc"))):
         subprocess.check_call(["make", "-C", HOSTEMU_DIR], stdout=subprocess.DEVNULL)
