@@ -55,6 +55,7 @@ struct tmx_simt_block
   const std::function<void()>* fn{ nullptr };
   std::mt19937 rng{ 12345u };
   unsigned long long n_switch{ 0 };
+  unsigned long long n_sync[2]{ 0, 0 };  // synchronisation points thread 0 went through in this launch: workgroup barriers, wave-level ones
 };
 // bookkeeping of the v_readfirstlane check (below, with the device vocabulary)
 #include <unordered_map>
@@ -132,6 +133,8 @@ static __attribute__((noinline)) void tmx_simt_wait(int kind, const char* where,
 {
   tmx_simt_block* b = tmx_simt_cur;
   tmx_simt_fiber& me = b->f[b->cur];
+  if (b->cur == 0)
+    ++b->n_sync[kind == TMX_SIMT_BLOCK ? 0 : 1];
   me.state = kind;
   me.where = where;
   me.line = line;
@@ -339,6 +342,7 @@ static void tmx_simt_run_block(int block_id, int grid, int NT, size_t smem_bytes
   // the device does not clear LDS between workgroups: hand out a signalling pattern (NaNs / huge negative ints)
   tmx_emu_fill(b->lds, need);
   mprotect(b->guard, 4096, PROT_NONE);
+  b->n_sync[0] = b->n_sync[1] = 0;
   tmx_simt_rfl.first.clear();
   for (auto& m : tmx_simt_rfl.calls)
     m.clear();
@@ -462,7 +466,8 @@ static void tmx_simt_run_block(int block_id, int grid, int NT, size_t smem_bytes
   if (fpe)
     fedisableexcept(FE_INVALID);
   if (std::getenv("TMX_SIMT_VERBOSE"))
-    std::fprintf(stderr, "[tmx simt] workgroup %d/%d: %d threads, %zu B of LDS, %llu fiber switches so far\n", block_id, grid, NT, smem_bytes, b->n_switch);
+    std::fprintf(stderr, "[tmx simt] workgroup %d/%d: %d threads, %zu B of LDS; thread 0 passed %llu workgroup barriers and %llu wave-level synchronisation points\n", block_id,
+                 grid, NT, smem_bytes, b->n_sync[0], b->n_sync[1]);
   tmx_simt_cur = nullptr;
 }
 
