@@ -28,7 +28,9 @@ N0, N1 = 3, 3     # seeds per config
 
 def _build(lib_path, tag):
     os.makedirs(BUILD, exist_ok=True)
-    exe = os.path.join(BUILD, "host_api_test_" + tag)
+    # (the executable is bound to ONE library by name and rpath: another build of the sources handed in through TMX_HOSTEMU_LIB gets
+    # its own)
+    exe = os.path.join(BUILD, "host_api_test_" + tag + "_" + os.path.splitext(os.path.basename(lib_path))[0])
     newest = max(os.path.getmtime(p) for p in [SRC, lib_path] + HDRS)
     if not os.path.exists(exe) or os.path.getmtime(exe) < newest:
         libdir, libname = os.path.dirname(lib_path), os.path.basename(lib_path)
