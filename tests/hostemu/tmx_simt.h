@@ -21,6 +21,7 @@
 #include <sys/mman.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -65,7 +66,7 @@ struct tmx_simt_rfl_table
   std::vector<std::unordered_map<uint32_t, uint32_t>> calls;  // per thread: site -> number of calls so far
 };
 static thread_local tmx_simt_rfl_table tmx_simt_rfl;
-static constexpr size_t TMX_SIMT_STACK = (size_t)1 << 20;
+static constexpr size_t TMX_SIMT_STACK = (size_t)256 << 10;  // measured high-water mark of the kernels at -O2: 11 KB (TMX_SIMT_STACK_REPORT=1)
 static thread_local tmx_simt_block* tmx_simt_cur = nullptr;
 
 static inline int tmx_simt_order()
@@ -465,6 +466,25 @@ static void tmx_simt_run_block(int block_id, int grid, int NT, size_t smem_bytes
   }
   if (fpe)
     fedisableexcept(FE_INVALID);
+  if (std::getenv("TMX_SIMT_STACK_REPORT"))
+  {
+    // high-water mark of the fiber stacks (fresh anonymous pages read as zero)
+    size_t deepest = 0;
+    for (int i = 0; i < NT; ++i)
+    {
+      const uint64_t* q = reinterpret_cast<const uint64_t*>(b->stacks[i]);
+      size_t k = 0;
+      while (k < TMX_SIMT_STACK / 8 && q[k] == 0)
+        ++k;
+      deepest = std::max(deepest, TMX_SIMT_STACK - k * 8);
+    }
+    static thread_local size_t worst = 0;
+    if (deepest > worst)
+    {
+      worst = deepest;
+      std::fprintf(stderr, "[tmx simt] deepest fiber stack so far: %zu KB of %zu\n", worst >> 10, TMX_SIMT_STACK >> 10);
+    }
+  }
   if (std::getenv("TMX_SIMT_VERBOSE"))
     std::fprintf(stderr, "[tmx simt] workgroup %d/%d: %d threads, %zu B of LDS; thread 0 passed %llu workgroup barriers and %llu wave-level synchronisation points\n", block_id,
                  grid, NT, smem_bytes, b->n_sync[0], b->n_sync[1]);
