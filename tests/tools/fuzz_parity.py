@@ -264,7 +264,8 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 50
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     lib = sys.argv[3] if len(sys.argv) > 3 else os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests", "hostemu", "_build", "libtmx_hostemu.so")
-    on_gpu = lib == "gpu"
+    on_gpu = lib == "gpu" or lib.startswith("gpu:")   # gpu:<path> = a code-generation variant of the device library (diagnosis)
+    gpu_lib = lib[4:] if lib.startswith("gpu:") else None
     if (new or kin or r4) and not on_gpu:
         os.environ.setdefault("TMX_DENSE_QP_MAX_N", "2000")   # the host build has the time; on the GPU the library's limit stays
     fails, soft, refused = 0, 0, 0
@@ -278,7 +279,7 @@ def main():
                   f"prims={[('hull' if (len(p_) > 3 and isinstance(p_[3], tuple) and p_[3][0] == 'hull') else ('capsule' if len(p_) > 3 else 'sphere')) for p_ in pci.robot.link_spheres]} "
                   f"terms={[type(t_).__name__ + str(getattr(t_, 'evaluator_type', '')) for t_ in pci.cost_infos + pci.cnt_infos]}", flush=True)
         tag = f"case {seed}/{k}: D={pci.robot.n_dof} T={pci.basic_info.n_steps} costs={len(pci.cost_infos)} cnts={len(pci.cnt_infos)}" + (" +time" if pci.basic_info.use_time else "")
-        ctx = runtime.Context(0, None if on_gpu else lib)
+        ctx = runtime.Context(0, gpu_lib if on_gpu else lib)
         try:
             desc = pc.make_ctx_inputs(ctx, pci, x0)
             pc.check_evaluate(ctx, orc, desc, x0, tol=1e-12)

@@ -1309,8 +1309,11 @@ __device__ __attribute__((noinline)) static void qp_admm_generic_nl(const DevPro
 #endif
   rows_compact_attach(w);
 #if TMX_LINK_ROWS
-  w.sweep_regs = PAIRS;
-  w.sweep_inline = PAIRS && !HBM;
+#ifndef TMX_DBG_SWEEP_REGS
+#define TMX_DBG_SWEEP_REGS 1  // (diagnostic builds: 0 = the LDS-exchange walk of the dense-coupling chain everywhere)
+#endif
+  w.sweep_regs = PAIRS && TMX_DBG_SWEEP_REGS;
+  w.sweep_inline = PAIRS && !HBM && TMX_DBG_SWEEP_REGS;
 #endif
   if (BAND)  // (banded objectives go with single-joint difference rows only, never with general pair rows: tmx_problem_upload)
     qp_ws_attach_band(w, P->band, Bt->band_ws + (size_t)b * (size_t)Bt->band_stride, (PAIRS && P->band_rows) ? P->n_link : 0);
