@@ -17,6 +17,24 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `pytest -m gpu` on the GPU box)")
 
 
+# GPU tier order: the BASELINE-configuration parity tests first, the randomised sweeps last - a failure late in the collection
+# order must not hide the headline configurations (round 4: 178 tests behind one failing sweep never ran)
+_GPU_ORDER = ["test_gpu_parity", "test_sqp_flavour", "test_time_terms", "test_hull_geometry", "test_joint_costs_kat", "test_kinematic_terms",
+              "test_spherebot_kat", "test_numerical_ik_kat", "test_generic_qp", "test_golden", "test_callbacks", "test_cpp_host_api",
+              "test_func_terms", "test_detmath", "test_multigpu_rccl"]
+
+
+def pytest_collection_modifyitems(config, items):
+    def key(item):
+        mod = os.path.splitext(os.path.basename(str(item.fspath)))[0]
+        if item.get_closest_marker("gpu") is None:
+            return (0, 0)
+        if mod == "test_fuzz_parity":
+            return (2, 0)
+        return (1, _GPU_ORDER.index(mod) if mod in _GPU_ORDER else len(_GPU_ORDER))
+    items.sort(key=key)   # stable: the order inside a module stays
+
+
 @pytest.fixture(scope="session")
 def orc():
     """CPU oracle (test infrastructure)"""

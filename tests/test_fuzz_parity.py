@@ -11,10 +11,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 TOOL = os.path.join(HERE, "tools", "fuzz_parity.py")
 
 
-def _sweep(n, seed, target, *extra):
-    p = subprocess.run([sys.executable, TOOL, str(n), str(seed), target, *extra], capture_output=True, text=True, timeout=900)
+def _sweep(n, seed, target, *extra, timeout=900):
+    p = subprocess.run([sys.executable, TOOL, str(n), str(seed), target, *extra], capture_output=True, text=True, timeout=timeout)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
     assert f"{n} cases, 0 failures" in p.stdout
+    return p.stdout
 
 
 def test_random_problems_on_host_build(hostemu_lib, orc):
@@ -60,8 +61,22 @@ def test_random_problems_with_kinematic_builtins_on_device(orc):
 
 @pytest.mark.gpu
 def test_random_problems_with_round3_features_on_device(orc):
-    """(problems above the dense engine's size limit are drawn rarely at these sizes; the sweep counts a refusal as a failure)"""
+    """round 4's driver run failed here (case 13/11, device only): the out-of-line ADMM loop of pair-row problems as compiled with
+    -amdgpu-sched-strategy=iterative-ilp ("the device-only defect").  Problems above the dense engine's size
+    limit are refused with an explicit error; the tool reports them as notes, the sweep's verdict is over the cases that ran."""
     _sweep(16, 13, "gpu", "new", "lvs")
+
+
+@pytest.mark.gpu
+def test_random_problems_with_round4_features_on_device(orc):
+    """convex-hull / capsule links under every evaluator, time-parameterised problems - the family that returned diverging first QPs
+    (cases 73/3, 73/6) and faulted the GPU in round 4; back in the tier with the code-generation fix of round 5"""
+    _sweep(20, 73, "gpu", "r4", "lvs")
+
+
+@pytest.mark.gpu
+def test_random_problems_with_round4_features_and_pair_rows_on_device(orc):
+    _sweep(12, 79, "gpu", "r4", "lvs", "links")
 
 
 @pytest.mark.gpu

@@ -271,8 +271,11 @@ def main():
     fails, soft, refused = 0, 0, 0
     counts = {"identical": 0, "tie": 0, "admm": 0, "csc-noise": 0, "other": 0}
     worst = {k: 0.0 for k in counts}
-    for k in range(n):
-        rng = np.random.default_rng([seed, k])
+    redraw = {}   # case -> attempt: a case the library refuses (dense-engine size limit) is drawn again, so n cases test n problems
+    k = -1
+    while k + 1 < n:
+        k += 1
+        rng = np.random.default_rng([seed, k] + ([redraw[k]] if k in redraw else []))
         pci, x0 = random_problem(rng, wide, links, lvs, new, kin, r4)
         if os.environ.get("FUZZ_VERBOSE"):
             print(f"start case {seed}/{k}: D={pci.robot.n_dof} T={pci.basic_info.n_steps} time={pci.basic_info.use_time} "
@@ -306,14 +309,20 @@ def main():
         except (AssertionError, runtime.TmxError) as e:
             if isinstance(e, runtime.TmxError) and "dense engine" in str(e):
                 refused += 1    # above the dense engine's size limit: an explicit refusal, not a parity failure
-                print("  note (refused: beyond the dense engine's size limit):", tag)
+                print("  note (refused: beyond the dense engine's size limit; drawn again):", tag)
+                if redraw.get(k, 0) < 8:
+                    redraw[k] = redraw.get(k, 0) + 1
+                    k -= 1
+                else:
+                    fails += 1
+                    print("FAIL", tag, "-> refused in 9 draws")
             else:
                 fails += 1
                 print("FAIL", tag, "->", str(e)[:300])
         finally:
             ctx.close()
     if refused:
-        print(f"{refused} cases refused (dense-engine size limit)")
+        print(f"{refused} draws refused (dense-engine size limit) and drawn again")
     print(f"{n} cases, {fails} failures, {soft} first QPs with differing history; SQP runs: {counts['identical']} identical integer history "
           f"(max |dx| {worst['identical']:.1e}), {counts['tie']} parted at a degenerate polish tie (max |dx| {worst['tie']:.1e}), "
           f"{counts['admm']} at an ADMM-level integer after rho drift (max |dx| {worst['admm']:.1e}), {counts['csc-noise']} at a round-off entry of A "

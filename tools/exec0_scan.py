@@ -65,6 +65,10 @@ def scan(path):
             i = index[t]
             if i > 0 and ins[i - 1][1] not in ("s_branch", "s_endpgm", "s_setpc_b64"):
                 continue  # fall-through predecessor: EXEC may be non-zero
+            # branch relaxation: `s_cbranch_execnz FAR` becomes `s_cbranch_execz L; s_getpc / s_add / s_addc / s_setpc FAR; L:` - L is
+            # the EXEC = 0 side of an edge block (spill code of a split critical edge: nothing to save, nothing lost)
+            if i >= 5 and [x[1] for x in ins[i - 5:i]] == ["s_cbranch_execz", "s_getpc_b64", "s_add_u32", "s_addc_u32", "s_setpc_b64"] and len(ops) == 1:
+                continue
             j = i
             while j < len(ins):
                 a, op, args, ln = ins[j]
