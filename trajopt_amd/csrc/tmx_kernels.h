@@ -622,7 +622,7 @@ TMX_DEVFN void sqp_pool_body(const DevProblem* P, const DevBatch* Bt)
 #endif
     }
     TMX_SYNC();
-    const int b = ibuf[2 * NT];
+    const int b = TMX_UNI_I(ibuf[2 * NT]);  // (one value for the workgroup: a scalar)
     TMX_SYNC();
     if (b == -1)
       break;

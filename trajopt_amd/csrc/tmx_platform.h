@@ -45,6 +45,8 @@ extern thread_local double* tmx_emu_smem;
 #define TMX_FAST_ALLOWED (std::getenv("TMX_SIMT_NO_FAST") == nullptr)  // test hook of the SIMT build: the dense fast path on / off
 #define TMX_ASM_WAIT_VM() __atomic_thread_fence(__ATOMIC_SEQ_CST)
 #define TMX_ASM_OPAQUE_SGPR(x) asm volatile("" : "+r"(x))
+#define TMX_UNI_I(x) (x)
+#define TMX_UNI_B(x) (x)
 #include <chrono>
 // constant-rate clock in 10 ns ticks (the device's wall_clock64 counts at 100 MHz)
 static inline long long tmx_wall_ticks()
@@ -180,6 +182,12 @@ static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t
 #define TMX_FAST_ALLOWED true
 #define TMX_ASM_WAIT_VM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #define TMX_ASM_OPAQUE_SGPR(x) asm volatile("" : "+s"(x))  // the value stays in a scalar register and becomes opaque to the optimiser
+// WORKGROUP-UNIFORM values the compiler cannot prove uniform (read from LDS / HBM by every lane: the claimed problem index of the pool
+// kernel, `warm`, the status of a QP solve) are handed back to it as scalars: conditions on them become s_cbranch_scc branches instead
+// of EXEC-masked regions - regions that hold workgroup barriers (round 5: a register copy stranded at EXEC = 0 at the end of such a
+// region, trajopt_amd/csrc/Makefile) - and the address arithmetic on them moves to the scalar unit.
+#define TMX_UNI_I(x) __builtin_amdgcn_readfirstlane((int)(x))
+#define TMX_UNI_B(x) (__builtin_amdgcn_readfirstlane((int)(bool)(x)) != 0)
 // constant-rate clock in 10 ns ticks (s_memrealtime: 100 MHz on gfx950, independent of the shader clock)
 __device__ static inline long long tmx_wall_ticks() { return (long long)wall_clock64(); }
 #define TMX_LAUNCH(kernel, grid, block, smem_bytes, stream, ...)                                                      \

@@ -1091,14 +1091,14 @@ __device__ __attribute__((noinline)) static int qp_check_nl(const DevProblem* P_
       compute_residuals(w, P, w.xp, w.xa, w.yr, w.ybp, w.yba, 0, info, info.prim_res, info.dual_res, true, tid, NT);
     TMX_TICK(6);
   }
-  if (can_check && check_termination(w, P, info, false, tid, NT))
+  if (can_check && TMX_UNI_B(check_termination(w, P, info, false, tid, NT)))
     ended = 1;
   TMX_TICK(3);
   double rho = w.rho;
   if (!ended && do_rho)
   {
     const double rho_new = rho_estimate(w, info);
-    if ((rho_new > w.rho * st.adaptive_rho_tolerance) || (rho_new < w.rho / st.adaptive_rho_tolerance))
+    if (TMX_UNI_B((rho_new > w.rho * st.adaptive_rho_tolerance) || (rho_new < w.rho / st.adaptive_rho_tolerance)))
     {
       w.rho = fmin(fmax(rho_new, TMX_RHO_MIN), TMX_RHO_MAX);
       rho = w.rho;
@@ -1241,7 +1241,7 @@ TMX_DEVFN void qp_admm_generic_loop(QpWs& w, const DevProblem* P, QpInfo& info, 
     }
     if (can_check)
     {
-      if (check_termination(w, P, info, false, tid, NT))
+      if (TMX_UNI_B(check_termination(w, P, info, false, tid, NT)))
       {
         terminated = true;
         break;
@@ -1251,7 +1251,7 @@ TMX_DEVFN void qp_admm_generic_loop(QpWs& w, const DevProblem* P, QpInfo& info, 
     if (do_rho)
     {
       const double rho_new = rho_estimate(w, info);
-      if ((rho_new > w.rho * st.adaptive_rho_tolerance) || (rho_new < w.rho / st.adaptive_rho_tolerance))
+      if (TMX_UNI_B((rho_new > w.rho * st.adaptive_rho_tolerance) || (rho_new < w.rho / st.adaptive_rho_tolerance)))
       {
         w.rho = fmin(fmax(rho_new, TMX_RHO_MIN), TMX_RHO_MAX);
         info.rho_updates += 1;
@@ -1738,13 +1738,13 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
   bool warm = Bt->prev_ok[b] && st.warm_starting;
   const bool P_eq = warm && pd4[0] == dims[0] && pd4[2] == dims[2] && pws[0] == hs[2];
   const bool A_eq = P_eq && pd4[0] == dims[0] && pd4[1] == dims[1] && pd4[3] == dims[3] && pws[1] == hs[3];
-  warm = warm && P_eq && A_eq;
+  warm = TMX_UNI_B(warm && P_eq && A_eq);
   if (P->flavor == 1)
   {
     // OSQPEigenSolver protocol (osqp_eigen_solver.cpp:96-109, :277-326; trust_region_sqp_solver.cpp:214-244): with warm
     // starting on, EVERY solve starts from a point - the slack warm start written by sqp2_begin_qp after a (re)build
     // (prev_ok = 0: xq / yq hold x0 / y0 = 0, rho = settings) or the previous solve's iterates and rho (prev_ok = 1)
-    warm = st.warm_starting != 0;
+    warm = TMX_UNI_B(st.warm_starting != 0);
     w.rho = Bt->prev_ok[b] ? Bt->prev_rho[b] : st.rho;
   }
   else
@@ -1797,7 +1797,7 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
   // ---------------- factor + ADMM loop (osqp_solve) --------------------------------------------------------
   TMX_TICK(0);
 #if TMX_IS_DEVICE
-  const bool fast = !HBM && (NT == TMX_QP_NT) && (R <= 512) && dpart_supported(w, NT) && !TMX_HAS_PAIRS(w) && w.c_alist == nullptr && w.band == 0 && TMX_FAST_ALLOWED;
+  const bool fast = TMX_UNI_B(!HBM && (NT == TMX_QP_NT) && (R <= 512) && dpart_supported(w, NT) && !TMX_HAS_PAIRS(w) && w.c_alist == nullptr && w.band == 0 && TMX_FAST_ALLOWED);
 #else
   const bool fast = false;
 #endif
@@ -1930,7 +1930,7 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
 
   TMX_TICK(6);
   // ---------------- polish (polish.c) ---------------------------------------------------------------------
-  if (st.polishing && info.status == 1)
+  if (TMX_UNI_B(st.polishing && info.status == 1))
   {
     const double delta = st.delta;
     // The polished iterate (dx | dy), the aux right-hand side and the active-set flags normally live in the per-problem
