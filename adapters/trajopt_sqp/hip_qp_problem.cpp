@@ -4,6 +4,8 @@
 #include <trajopt_ifopt/core/bounds.h>
 #include <trajopt_ifopt/constraints/joint_position_constraint.h>
 #include <trajopt_ifopt/constraints/joint_velocity_constraint.h>
+#include <trajopt_ifopt/constraints/joint_acceleration_constraint.h>
+#include <trajopt_ifopt/constraints/joint_jerk_constraint.h>
 #include <trajopt_ifopt/constraints/collision/discrete_collision_constraint.h>
 #include <trajopt_ifopt/constraints/collision/discrete_collision_evaluators.h>
 #include <trajopt_ifopt/constraints/collision/continuous_collision_constraint.h>
@@ -109,13 +111,30 @@ void HipQPProblem::lowerSet(const trajopt_ifopt::ConstraintSet& set, bool is_cos
     t.first_step = static_cast<int32_t>(col / D);
     t.last_step = t.first_step + static_cast<int32_t>(set.getRows() / D);  // rows = n_dof * (n_vars - 1)
   }
+  else if (dynamic_cast<const trajopt_ifopt::JointAccelConstraint*>(&set) != nullptr ||
+           dynamic_cast<const trajopt_ifopt::JointJerkConstraint*>(&set) != nullptr)
+  {
+    // (round 5) rows = n_dof * n_vars: one row per step and joint, the last two / three of them backward stencils
+    // (joint_acceleration_constraint.cpp:90-175, joint_jerk_constraint.cpp:90-180); the device lowers them as kSquared cost sets, the
+    // use trajopt_sqp's own tests make of them (joint_acceleration_optimization_unit.cpp:110, joint_jerk_optimization_unit.cpp:111)
+    const bool acc = dynamic_cast<const trajopt_ifopt::JointAccelConstraint*>(&set) != nullptr;
+    if (!is_cost || penalty_type != CostPenaltyType::kSquared)
+      throw std::runtime_error(who + (acc ? "JointAccelConstraint" : "JointJerkConstraint") + " is lowered as a CostPenaltyType::kSquared cost set only");
+    equalityTargets(D);
+    const Eigen::Index col = firstColumn(set.getJacobian());
+    if (col < 0 || col % D != 0)
+      throw std::runtime_error(who + "cannot read the first waypoint of the set off its Jacobian");
+    t.kind = acc ? TMX_TERM_JOINT_ACC_EQ_COST : TMX_TERM_JOINT_JERK_EQ_COST;
+    t.first_step = static_cast<int32_t>(col / D);
+    t.last_step = t.first_step + static_cast<int32_t>(set.getRows() / D) - 1;  // rows = n_dof * n_vars
+  }
   else
   {
     const auto* dc = dynamic_cast<const trajopt_ifopt::DiscreteCollisionConstraint*>(&set);
     const auto* cc = dynamic_cast<const trajopt_ifopt::ContinuousCollisionConstraint*>(&set);
     if (dc == nullptr && cc == nullptr)
       throw std::runtime_error(who + "this ConstraintSet class is not lowered by the device path (JointPosConstraint, JointVelConstraint, "
-                                     "Discrete / ContinuousCollisionConstraint are); describe the problem with a lowered term table instead");
+                                     "JointAccelConstraint, JointJerkConstraint, Discrete / ContinuousCollisionConstraint are); describe the problem with a lowered term table instead");
     if (is_cost && penalty_type != CostPenaltyType::kHinge)
       throw std::runtime_error(who + "collision sets as costs are lowered with CostPenaltyType::kHinge only");
     double margin = 0.0, coeff = 0.0, buffer = 0.0;

@@ -127,6 +127,7 @@ def main():
     t0 = time.perf_counter()
     tot_fe = tot_qp = tot_admm = 0
     conv = 0
+    last_r = None
     for k in range(args.warmup, min(nsteps, args.warmup + depth - 1)):
         issue(k)
     for k in range(args.warmup, nsteps):
@@ -141,6 +142,7 @@ def main():
                     time.sleep(0.0002)
             issue(k + depth - 1)
         r, best, c = finish(k)
+        last_r = r
         # trajopt_sqp counts QP solves only (SQPResults::overall_iteration): one trust-region evaluation each
         tot_fe += int(r["n_qp_solves"].sum()) if cid == 4 else int((r["n_func_evals"] - 1).sum())
         tot_qp += int(r["n_qp_solves"].sum())
@@ -282,6 +284,24 @@ def main():
                    "per_thread_value": best[0] / best[1], "host_threads": cores, "cgroup_cpu_quota_cores": quota,
                    "qp_solves_per_s": best[4] / best[3],
                    "admm_iters_per_s": (best[5] / best[3] if best[5] == best[5] else None)}
+        # parity of THIS run's results (after the timed region; the oracle is the checker, never the thing measured): the first 64 problems
+        # of the last timed batch against the restated reference CPU path on the same seeds - north_star: "joint trajectories within
+        # 1e-5 rad".  (SQP outcomes are discontinuous in rounding: the seeds outside the ball are the ones on which the oracle parts from
+        # its own FMA build as well, tests/test_gpu_parity.py.)
+        parity = None
+        if world == 1 and not args.no_cpu_baseline and last_r is not None:
+            from oracle import pyorc
+            npar = min(64, B)
+            k_last = nsteps - 1
+            xs = seeds_host[k_last * B:k_last * B + npar]
+            o = pyorc.sqp2_batch(desc, xs, osqp=osqp_st, nthreads=min(os.cpu_count() or 1, 32)) if cid == 4 else \
+                pyorc.sqp_batch(desc, xs, nthreads=min(os.cpu_count() or 1, 32))
+            dxp = np.abs(last_r["x"][:npar] - o["x"]).reshape(npar, -1).max(axis=1)
+            parity = {"seeds_compared": int(npar), "parity_frac_within_1e-5": float((dxp <= 1e-5).mean()),
+                      "same_status_frac": float((last_r["status"][:npar] == o["status"]).mean()),
+                      "same_n_qp_solves_frac": float((last_r["n_qp_solves"][:npar] == o["n_qp_solves"]).mean()),
+                      "median_abs_dx": float(np.median(dxp)), "max_abs_dx": float(dxp.max()),
+                      "what": "first %d problems of the last timed batch vs the oracle (oracle/, restated reference CPU path) on the same seeds" % npar}
         line = {
             "metric": "SQP iters/s (+ QP solves/s), 7-DOF x 30-wp x 1024-batch glass_upright" if cid == 1 else
                       "SQP iters/s (+ QP solves/s), BASELINE config %d" % cid,
@@ -293,7 +313,7 @@ def main():
                        "n_dof": D, "n_steps": T, "batch_per_gpu": B, "qp_n": r0.n, "qp_m": r0.m, "parallelism": "seeds sharded, dp%d" % world},
             "qp_solves_per_s": g_qp / elapsed, "admm_iters_per_s": g_admm / elapsed,
             "converged_frac": g_conv / (B * world * max(1, args.steps)),
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
         }
         print(json.dumps(line))
     if world > 1:

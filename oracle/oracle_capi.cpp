@@ -475,6 +475,20 @@ Sqp2Problem buildSqp2(const tmx_problem_desc& d, const double* x0)
         P.qp->addCostSet(std::make_shared<ifopt::JointVelConstraint>(targets, vs, coeffs, "joint_vel"), ifopt::CostPenaltyType::kSquared);
         break;
       }
+      case TMX_TERM_JOINT_ACC_EQ_COST:
+      case TMX_TERM_JOINT_JERK_EQ_COST:
+      {
+        // JointAccelConstraint / JointJerkConstraint over the steps of the term as a kSquared cost set - the use the reference's
+        // trajopt_sqp tests make of them (joint_acceleration_optimization_unit.cpp:110, joint_jerk_optimization_unit.cpp:111)
+        std::vector<ifopt::Var> vs;
+        for (int t = tm.first_step; t <= tm.last_step; ++t)
+          vs.push_back(var(t));
+        if (tm.kind == TMX_TERM_JOINT_ACC_EQ_COST)
+          P.qp->addCostSet(std::make_shared<ifopt::JointAccelConstraint>(targets, vs, coeffs, "joint_accel"), ifopt::CostPenaltyType::kSquared);
+        else
+          P.qp->addCostSet(std::make_shared<ifopt::JointJerkConstraint>(targets, vs, coeffs, "joint_jerk"), ifopt::CostPenaltyType::kSquared);
+        break;
+      }
       case TMX_TERM_JOINT_POS_EQ_CNT:
         for (int t = tm.first_step; t <= tm.last_step; ++t)
           P.qp->addConstraintSet(std::make_shared<ifopt::JointPosConstraint>(targets, var(t), coeffs, "joint_pos_" + std::to_string(t)));

@@ -331,6 +331,70 @@ private:
   std::vector<Bounds> bounds_;
 };
 
+// joint_jerk_constraint.cpp:37-180 - forward stencil (-1, 3, -3, 1) on [0, n-4], backward on the last three; one row per (step, joint)
+class JointJerkConstraint : public ConstraintSet
+{
+public:
+  JointJerkConstraint(const Vec& targets, std::vector<Var> position_vars, const Vec& coeffs, const std::string& name)
+    : ConstraintSet(name), vars_(std::move(position_vars)), n_dof_(static_cast<int>(targets.size()))
+  {
+    if (vars_.size() < 6)
+      throw std::runtime_error("JointJerkConstraint requires a minimum of six position variables!");  // joint_jerk_constraint.cpp:45-46
+    for (double c : coeffs)
+      if (!(c > 0))
+        throw std::runtime_error("JointJerkConstraint, coeff must be greater than zero.");
+    const auto n = vars_.size();
+    coeffs_.assign(static_cast<std::size_t>(n_dof_) * n, coeffs.size() == 1 ? coeffs[0] : 1.0);
+    if (static_cast<int>(coeffs.size()) == n_dof_)
+      for (std::size_t i = 0; i < n; ++i)
+        std::copy(coeffs.begin(), coeffs.end(), coeffs_.begin() + static_cast<long>(i) * n_dof_);
+    for (std::size_t i = 0; i < n; ++i)
+      for (int k = 0; k < n_dof_; ++k)
+        bounds_.emplace_back(targets[static_cast<std::size_t>(k)], targets[static_cast<std::size_t>(k)]);
+  }
+  Vec getValues() const override
+  {
+    Vec v;
+    const auto n = vars_.size();
+    for (std::size_t i = 0; i < n; ++i)
+      for (int k = 0; k < n_dof_; ++k)
+      {
+        if (i < n - 3)  // -q0 + 3.0 * q1 - 3.0 * q2 + q3
+          v.push_back(((-vars_[i].at(k) + 3.0 * vars_[i + 1].at(k)) - 3.0 * vars_[i + 2].at(k)) + vars_[i + 3].at(k));
+        else  // q0 - 3.0 * q1 + 3.0 * q2 - q3 with q0 = q_i
+          v.push_back(((vars_[i].at(k) - 3.0 * vars_[i - 1].at(k)) + 3.0 * vars_[i - 2].at(k)) - vars_[i - 3].at(k));
+      }
+    return v;
+  }
+  Jac getJacobian() const override
+  {
+    Jac j(getRows(), variables_->getRows());
+    const auto n = vars_.size();
+    for (std::size_t i = 0; i < n; ++i)
+    {
+      const std::size_t a = i < n - 3 ? i : i - 3;  // first waypoint of the stencil: ascending columns in both branches
+      for (int k = 0; k < n_dof_; ++k)
+      {
+        const int row = static_cast<int>(i) * n_dof_ + k;
+        j.insertBack(row, vars_[a].index + k, -1);
+        j.insertBack(row, vars_[a + 1].index + k, 3.0);
+        j.insertBack(row, vars_[a + 2].index + k, -3.0);
+        j.insertBack(row, vars_[a + 3].index + k, 1);
+      }
+    }
+    return j;
+  }
+  std::vector<Bounds> getBounds() const override { return bounds_; }
+  Vec getCoefficients() const override { return coeffs_; }
+  int getRows() const override { return static_cast<int>(bounds_.size()); }
+
+private:
+  std::vector<Var> vars_;
+  int n_dof_;
+  Vec coeffs_;
+  std::vector<Bounds> bounds_;
+};
+
 // Segment collision as a DYNAMIC constraint set (one row per filtered contact, "D" variants of trajopt_ifopt's collision
 // constraints): value = margin - distance (<= 0 wanted: kUpperBound 0), Jacobian = -(cc_time-weighted gradients on both
 // waypoints), coefficient = collision coefficient.  The contact model is oracle/trajprob.hpp LvsEvaluator (the same

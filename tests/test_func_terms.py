@@ -218,3 +218,48 @@ def test_user_defined_term_on_device(gpu_ctx_factory, orc, penalty):
     ctx = gpu_ctx_factory()
     _run_user_defined(ctx, orc, penalty, 6)
     ctx.close()
+
+
+# ---- function costs at BASELINE size (round 5): config 1 (7 DOF x 30 waypoints, collision cost, n = 572 + the hinge variables) with a
+# CostFromFunc on every waypoint (full numerical Hessian, modeling_utils.cpp:52-113) and a squared CostFromErrFunc.  Until round 4 such a
+# problem went to the dense QP engine and was refused above 448 variables; now the models' D x D Hessians are dynamic diagonal blocks of
+# the structured solver's objective (QpWs::pb).
+def _config1_with_function_costs():
+    from trajopt_amd import configs
+    pci, s, g = configs.config1()
+    n = pci.basic_info.n_steps
+    x = [Ex.var(i) for i in range(7)]
+    f = 0.3 * sq(x[1] - 0.4 * x[3]) + 0.05 * ex_cos(x[2] + x[4]) + 0.1 * sq(x[5]) + 0.02 * x[0] * x[6]
+    pci.cost_infos.append(FuncCostTermInfo(f=f, first_step=1, last_step=n - 2, full_hessian=True, name="posture"))
+    pci.cost_infos.append(UserDefinedTermInfo(error_function=[ex_sin(x[0]) - 0.2 * x[1], x[2] * x[3] - 0.1], first_step=n // 3, last_step=2 * n // 3,
+                                              coeff=[0.5, 0.25], cost_penalty_type=abi.PENALTY_SQUARED, name="shape"))
+    return pci, s, g
+
+
+def _run_config1_with_function_costs(ctx, orc, B):
+    from trajopt_amd import configs
+    pci, s, g = _config1_with_function_costs()
+    x0 = configs.seeds_for(1, pci, s, g, B)
+    desc = pc.make_ctx_inputs(ctx, pci, x0)
+    assert ctx.n_max > 448                      # (beyond the old limit of the dense engine)
+    pc.check_evaluate(ctx, orc, desc, x0, tol=1e-12)
+    pc.check_first_qp_structure(ctx, orc, desc, x0, 0, val_tol=1e-9)
+    assert all(same for same, _ in pc.check_first_qp_solve(ctx, orc, desc, x0))
+    ctx.set_x0(x0)
+    r, o, same, dx = pc.check_full_sqp(ctx, orc, desc, x0, exact=False)
+    print(f"config 1 + function costs: same history {same.sum()}/{B}, within 1e-5: {(dx <= pc.TOL_TRAJ).sum()}/{B}, worst {dx.max():.2e}")
+    assert (r["status"] == o["status"]).all()
+    assert (dx <= pc.TOL_TRAJ).sum() >= B - 1, dx
+
+
+def test_function_costs_at_baseline_size_on_host(hostemu_lib, orc):
+    ctx = runtime.Context(0, hostemu_lib)
+    _run_config1_with_function_costs(ctx, orc, 2)
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_function_costs_at_baseline_size_on_device(gpu_ctx_factory, orc):
+    ctx = gpu_ctx_factory()
+    _run_config1_with_function_costs(ctx, orc, 8)
+    ctx.close()

@@ -85,6 +85,12 @@ def test_random_problems_with_pair_rows_on_device(orc):
 
 
 @pytest.mark.gpu
+def test_random_wide_problems_on_device(orc):
+    """9-11 DOF chains (odd block sizes above 8 keep their coefficient rows in LDS again, round 5), longer horizons, one waypoint"""
+    _sweep(16, 21, "gpu", "wide")
+
+
+@pytest.mark.gpu
 def test_random_problems_on_device(orc):
     _sweep(40, 5, "gpu")     # D <= 8 and n_steps * D <= 256: the dense fast path of the QP solver
 

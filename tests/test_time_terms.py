@@ -213,5 +213,5 @@ def test_time_terms_stage_by_stage_on_device(gpu_ctx_factory, orc, cid):
 @pytest.mark.parametrize("cid", TIME_CIDS)
 def test_time_problems_whole_sqp_on_device(gpu_ctx_factory, orc, orc_fma, cid):
     ctx = gpu_ctx_factory()
-    _history_check(ctx, orc, orc_fma, cid, 8)
+    _history_check(ctx, orc, orc_fma, cid, 32 if cid == 50 else 8)   # (config 50 = the reference's arm_around_table with time: 32 seeds)
     ctx.close()

@@ -457,7 +457,8 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
   std::vector<double> fx_consts;
   int n_fx_cost = 0;
   int n_stencil = 0;      // rows of difference order 2 / 3
-  bool qp_dense = false;  // function COSTS with a dynamic quadratic model (or difference rows next to general pair rows): dense QP engine
+  bool qp_dense = false;  // time-squared costs, difference rows next to general pair rows: dense QP engine
+  bool dyn_p = false;     // function COSTS (CostFromFunc / squared CostFromErrFunc): dynamic D x D objective blocks on the structured solver (round 5)
   bool stencil_rows = false;  // difference rows of order 2 / 3 (JointAcc / JointJerk Ineq costs, Eq / Ineq constraints)
   int max_row_order = 0;
   bool st_terms = false;  // function terms (any): the ST instantiations of the term code, piecewise driver
@@ -498,6 +499,8 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
         switch (tm.kind)
         {
           case TMX_TERM_JOINT_VEL_COST:
+          case TMX_TERM_JOINT_ACC_EQ_COST:
+          case TMX_TERM_JOINT_JERK_EQ_COST:
             want = 0;
             break;
           case TMX_TERM_COLLISION_COST:
@@ -759,7 +762,7 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
           const bool quad = fk == 0 || fk == 1 || fk == 3;
           st_terms = true;
           if (quad)
-            qp_dense = true;  // P changes with the iterate; row-only function terms leave the QP an ordinary block chain
+            dyn_p = true;  // P changes with the iterate, but only inside the waypoint's diagonal block: QpWs::pb (row-only function terms leave the QP as it is)
           // the row weights (coeffs, 1 when absent) sit in front of the program's constants
           for (int i = 0; i < TMX_EXPR_MAX_OUT; ++i)
             fx_consts.push_back(weights[i]);
@@ -837,8 +840,57 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
           }
           if (flavor == TMX_FLAVOR_SQP)
           {
-            ctx->err = "TMX_FLAVOR_SQP: joint acceleration / jerk terms are not part of the trajopt_sqp path";
-            return TMX_ERR_UNSUPPORTED;
+            // trajopt_ifopt::JointAccelConstraint / JointJerkConstraint over the steps of the term as a kSquared cost set (round 5; the use
+            // joint_acceleration_optimization_unit.cpp:110 / joint_jerk_optimization_unit.cpp:111 make of them): n rows per joint, the
+            // last `ord` of them backward stencils (joint_acceleration_constraint.cpp:90-175, joint_jerk_constraint.cpp:90-180).
+            // H = Bw' Bw with Bw = diag(sqrt(w)) B accumulated in row order (AffExprs::square, expressions.cpp:43-112), like the
+            // JointVelConstraint set above; the 1e-7 zeroing and the factor 2 are applied after all sets are summed.
+            const int n = tm.last_step - tm.first_step + 1;
+            if (n < (ord == 2 ? 4 : 6))
+            {
+              ctx->err = ord == 2 ? "JointAccelConstraint requires a minimum of four position variables!"   // joint_acceleration_constraint.cpp:45-46
+                                  : "JointJerkConstraint requires a minimum of six position variables!";    // joint_jerk_constraint.cpp:45-46
+              return TMX_ERR_INVALID;
+            }
+            for (int j = 0; j < DK; ++j)
+              if (!(tm.coeffs[j] > 0))
+              {
+                ctx->err = ord == 2 ? "JointAccelConstraint, coeff must be greater than zero." : "JointJerkConstraint, coeff must be greater than zero.";
+                return TMX_ERR_INVALID;
+              }
+            ++n_sq;
+            band = std::max(band, ord);
+            st_terms = true;  // (the squared-set code of these kinds is instantiated in the piecewise kernels)
+            vel_first.push_back(tm.first_step);
+            vel_last.push_back(tm.last_step);
+            vel_kind.push_back(ord + 2);  // 4: ifopt accel, 5: ifopt jerk (tmx_terms.h: vel_is_ifopt_kind)
+            vel_cost.push_back(n_costs++);
+            for (int j = 0; j < TMX_MAX_DOF; ++j)
+            {
+              vel_coeffs.push_back(j < DK ? tm.coeffs[j] : 0.0);
+              vel_targets.push_back(j < DK ? tm.targets[j] : 0.0);
+            }
+            static const double E2[3] = { 1.0, -2.0, 1.0 }, E3[4] = { -1.0, 3.0, -3.0, 1.0 };
+            const double* e = ord == 2 ? E2 : E3;
+            for (int i = 0; i < n; ++i)
+            {
+              const int a0 = tm.first_step + ((i < n - ord) ? i : i - ord);
+              for (int j = 0; j < DK; ++j)
+              {
+                const double sw = std::sqrt(tm.coeffs[j]);
+                for (int k = 0; k <= ord; ++k)
+                {
+                  const double bk = e[k] * sw;
+                  pd[(a0 + k) * D + j] += bk * bk;
+                  for (int l = k + 1; l <= ord; ++l)
+                  {
+                    std::vector<double>& bnd = (l - k == 1) ? po : ((l - k == 2) ? po2 : po3);
+                    bnd[(a0 + k) * D + j] += bk * (e[l] * sw);
+                  }
+                }
+              }
+            }
+            break;
           }
           if (tm.last_step - ord - tm.first_step < 0)
           {
@@ -1217,6 +1269,8 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
       // upstream; it does not contribute to any product here.
       pd[v] = 2.0 * ((std::fabs(pd[v]) < 1e-7) ? 0.0 : pd[v]);
       po[v] = 2.0 * ((std::fabs(po[v]) < 1e-7) ? 0.0 : po[v]);
+      po2[v] = 2.0 * ((std::fabs(po2[v]) < 1e-7) ? 0.0 : po2[v]);   // (JointAccelConstraint / JointJerkConstraint squared sets)
+      po3[v] = 2.0 * ((std::fabs(po3[v]) < 1e-7) ? 0.0 : po3[v]);
     }
   P.n_sq = n_sq;
   const int R = static_cast<int>(kind.size());
@@ -1531,13 +1585,8 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
     if ((force && force[0] == '1') ||
         (qp_smem_bytes(D, T, R, NA, R2, 0) > 160 * 1024 && qp_smem_bytes(D, T, R, NA, R2, 1) <= 160 * 1024))
       P.coef_far = 1;
-    // Odd block sizes above 8: every other row of coef / c2 starts on an 8-byte boundary, and the stepping kernel's row dots
-    // (compute_residuals, the activity pass at load, link_dot) are compiled eight wide with 16-byte FLAT loads of those rows
-    // (profiles/r04/r04_defect_offline_analysis.md).  A misaligned 16-byte flat access is legal in HBM and is what has faulted in LDS
-    // before, so such problems keep their coefficient rows in the HBM scratch - the placement config 4 runs with.  (Host-side
-    // mitigation of the round-4 device defect, case 3; not yet confirmed on the device: no GPU budget was left.)
-    if (D > 8 && (D & 1) && !(force && force[0] == '0'))
-      P.coef_far = 1;
+    // (round 4 also moved the rows of odd block sizes above 8 there, on the hypothesis that 16-byte flat accesses at 8-byte aligned LDS
+    //  addresses fault; the hardware accepts them - tools/ubench/align_probe.hip, profiles/r05/r05a_align_probe.log - and the placement is gone)
   }
   {
     // compact row lists (bit 1 of the flag word): problems whose row slots are mostly collision slots - thousands of slots, a
@@ -1552,6 +1601,8 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
     if (on)
       P.coef_far |= 2;
   }
+  if (dyn_p && !qp_dense)
+    P.coef_far |= 4;  // dynamic objective blocks behind the far region of the per-problem scratch (qp_dynp_offset)
   if (!ctx->dp)
   {
     void* p = nullptr;
@@ -1584,9 +1635,9 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
       max_n = std::max(1, std::atoi(e));
     if (P.n_max > max_n)
     {
-      ctx->err = "function costs (or acceleration / jerk rows next to collision / CartVel rows on two waypoints): the QP of this problem has "
-                 "too many variables for the dense engine to solve in practical time (limit 448 incl. penalty variables; "
-                 "TMX_DENSE_QP_MAX_N overrides); smoothing costs, acceleration / jerk limits and function terms that are rows only "
+      ctx->err = "squared time-parameterised costs (or acceleration / jerk rows next to collision / CartVel rows on two waypoints): the QP of "
+                 "this problem has too many variables for the dense engine to solve in practical time (limit 448 incl. penalty variables; "
+                 "TMX_DENSE_QP_MAX_N overrides); function costs, smoothing costs, acceleration / jerk limits and function terms that are rows "
                  "(constraints, ABS / HINGE costs, AvoidSingularity, DynamicCartPose) have no such limit";
       ctx->have_problem = false;
       return TMX_ERR_UNSUPPORTED;
@@ -1741,6 +1792,16 @@ static tmx_status ensure_batch(tmx_ctx* ctx, int B)
     H.band_stride = (long long)qp_band_doubles(P.D, P.T, P.band_rows ? P.n_link : 0);
     AL(band_ws, b * (size_t)H.band_stride);
   }
+  if (P.qp_dense || P.n_fx_cost > 0)
+  {
+    // quadratic models of the function costs (rebuilt by every convexification): dense engine, or the dynamic objective blocks of the
+    // structured solver (QpWs::pb)
+    const size_t nfc = (size_t)std::max(1, P.n_fx_cost), dd = (size_t)P.D * P.D;
+    AL(fx_H, b * nfc * dd);
+    AL(fx_g, b * nfc * (size_t)P.D);
+    AL(fx_c, b * nfc);
+    AL(fx_W, b * nfc * 2 * dd);
+  }
   if (P.qp_dense)
   {
     // dense engine: the QP in CSC form + dense workspace per problem (tmx_generic.h).  Capacity of A: every row slot with all the
@@ -1768,11 +1829,6 @@ static tmx_status ensure_batch(tmx_ctx* ctx, int B)
         break;
       }
     H.dq_nnzP = (int)nzp;
-    const size_t nfc = (size_t)std::max(1, P.n_fx_cost), dd = (size_t)P.D * P.D;
-    AL(fx_H, b * nfc * dd);
-    AL(fx_g, b * nfc * (size_t)P.D);
-    AL(fx_c, b * nfc);
-    AL(fx_W, b * nfc * 2 * dd);
     AL(dq_Pp, b * (size_t)(P.n_max + 1));
     AL(dq_Pi, b * nzp);
     AL(dq_Px, b * nzp);

@@ -150,6 +150,11 @@ struct QpWs
   // its first NX doubles serve band_solve as the intermediate vector)
   double *po2, *po3, *Wb, *Mb;
   int band;
+  // DYNAMIC OBJECTIVE BLOCKS (round 5): the off-diagonal entries of the D x D diagonal blocks of P of a problem with function costs
+  // (sco::CostFromFunc / squared CostFromErrFunc models of one waypoint, modeling_utils.cpp:52-113): pb[t D D + i D + j], symmetric,
+  // zero diagonal (the diagonal entries are part of pd).  nullptr everywhere else - a literal in every instantiation but the piecewise
+  // QP kernels (qp_solve_block<., ., ROWSK = true>), so the pool / fused kernels and the out-of-line loops carry none of this code.
+  double* pb;
   // DIFFERENCE ROWS of order 2 / 3 on the banded structured path (DevProblem::band_rows: JointAcc / JointJerk Ineq costs and
   // constraints, trajectory_costs.cpp:556-754, :811-1016): such a row touches ONE joint j on waypoints t .. t + order.  coef / c2
   // hold its entries on t and t + 1 (D-vectors that are zero off joint j), cf[2 i], cf[2 i + 1] (i = the row's c2 index) the
@@ -455,7 +460,13 @@ TMX_HOSTDEVFN size_t qp_far_doubles(int D, int T, int R, int NA, int R2 = 0, int
   const size_t ints = 3 * (size_t)R + (size_t)NX + (size_t)NA;
   const size_t lp = lpart_fits(D, T, R2) ? 2 * (size_t)T * D * D + lpart_zp_doubles(D) + 2 : (pspk_fits(D, T, R2) ? 2 * (size_t)T * D * D + 2 : 0);
   const size_t cmp = (cf_flags & 2) ? (3 * (size_t)R + (size_t)T + 1 + 2 + 1) / 2 + 2 : 0;  // alist, list, pos, start, count
-  return n + (ints + 1) / 2 + 8 + lp + (cf ? qp_coef_doubles(D, R, R2) + 2 : 0) + cmp;
+  const size_t base = n + (ints + 1) / 2 + 8 + lp + (cf ? qp_coef_doubles(D, R, R2) + 2 : 0) + cmp;
+  // (bit 2 of the flag word: dynamic objective blocks QpWs::pb, T D^2 doubles BEHIND everything else of the far region)
+  return (cf_flags & 4) ? ((base + 1) & ~(size_t)1) + (size_t)T * D * D + 2 : base;
+}
+TMX_HOSTDEVFN size_t qp_dynp_offset(int D, int T, int R, int NA, int R2, int cf_flags)
+{
+  return (qp_far_doubles(D, T, R, NA, R2, cf_flags & 3) + 1) & ~(size_t)1;
 }
 // dynamic LDS bytes of the QP kernels / per-problem HBM scratch doubles for the chosen placement
 TMX_HOSTDEVFN size_t qp_smem_bytes(int D, int T, int R, int NA, int R2 = 0, int cf = 0)
@@ -523,6 +534,7 @@ TMX_DEVFN void qp_ws_carve(QpWs& w, double* lds, double* glb, double* far, int D
   w.NA = NA;
   w.band = 0;
   w.po2 = w.po3 = w.Wb = w.Mb = nullptr;
+  w.pb = nullptr;
   w.bk = nullptr;
   w.band_rows = 0;
   w.polish_dd = 0;
@@ -864,6 +876,8 @@ TMX_DEVFN void kkt_factor(const QpWs& w, const DevProblem* P, int mode, double s
             const int v = t * D + i;
             sblk += w.pd[v] + sig + w_bp(w, v, mode, delta) * w.bbp[v] * w.bbp[v];
           }
+          else if (w.pb != nullptr)
+            sblk += w.pb[t * DD + i * D + j];
           w.Sinv[t * DDS + i * DS + j] = sblk;
         }
       }
@@ -916,6 +930,8 @@ TMX_DEVFN void kkt_factor(const QpWs& w, const DevProblem* P, int mode, double s
       const int v = t * D + i;
       s += w.pd[v] + sig + w_bp(w, v, mode, delta) * w.bbp[v] * w.bbp[v];
     }
+    else if (w.pb != nullptr)
+      s += w.pb[t * DD + i * D + j];
     w.Sinv[t * DDS + i0 * DS + j0] = s;
   }
 #if TMX_LINK_ROWS
@@ -2285,6 +2301,13 @@ TMX_DEVFN double p_times(const QpWs& w, const double* x, int v)
 {
   const int D = w.D, t = v / D;
   double s = w.pd[v] * x[v];
+  if (w.pb != nullptr)  // function costs: the other entries of this variable's row inside its waypoint's block
+  {
+    const double* row = w.pb + (size_t)t * D * D + (size_t)(v % D) * D;
+    for (int i = 0; i < D; ++i)
+      if (i != v % D)
+        s += row[i] * x[t * D + i];
+  }
   if (t > 0)
     s += w.po[v - D] * x[v - D];
   if (t < w.T - 1)

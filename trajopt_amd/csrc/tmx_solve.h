@@ -1372,6 +1372,17 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
   }
   if constexpr (BANDK)
     qp_ws_attach_band(w, P->band, Bt->band_ws + (size_t)b * (size_t)Bt->band_stride, (ROWSK && P->band_rows) ? P->n_link : 0);
+  // function costs on the structured solver (round 5; piecewise kernels only): the dynamic D x D objective blocks of the waypoints
+  // live behind the far region of the per-problem scratch
+  [[maybe_unused]] const double* dyn_H = nullptr;
+  [[maybe_unused]] const double* dyn_g = nullptr;
+  if constexpr (ROWSK)
+    if (P->coef_far & 4)
+    {
+      w.pb = Bt->qp_scratch + (size_t)b * Bt->qp_scratch_stride + qp_dynp_offset(D, T, R, P->NA, P->n_link, P->coef_far);
+      dyn_H = Bt->fx_H + (size_t)b * P->n_fx_cost * D * D;
+      dyn_g = Bt->fx_g + (size_t)b * P->n_fx_cost * D;
+    }
   long long pc[16] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
   long long tlast = TMX_CLK();
   const int* g_act = Bt->active + (size_t)b * R;
@@ -1448,6 +1459,24 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
     w.ubp[v] = fmin(ub, TMX_OSQP_INFTY);
     w.qp[v] = primary_q(P, Bt->qdyn + (size_t)b * NX, v);
     w.pd[v] = P->pd[v];
+    if constexpr (ROWSK)
+      if (w.pb != nullptr)
+      {
+        // objective of the CostFromFunc / squared CostFromErrFunc models of this variable's waypoint, with the operations of
+        // qp_structure's export (exprToEigen, solver_utils.cpp:49-109): a triplet exists where the QuadExpr coefficient (h / 2 on the
+        // diagonal, modeling_utils.cpp:62, :100-106) is not exactly zero; the diagonal entry of P is twice the sum, added to the static one
+        double dv = 0.0, qv = w.qp[v];
+        for (int c = 0; c < P->n_fx; ++c)
+          if (fx_is_quad(P->fx_kind[c]) && P->fx_t[c] == v / D)
+          {
+            const double coeff = dyn_H[(size_t)P->fx_ci[c] * D * D + (v % D) * D + (v % D)] / 2;
+            if (coeff != 0.0)
+              dv += 2.0 * coeff;
+            qv += dyn_g[(size_t)P->fx_ci[c] * D + v % D];
+          }
+        w.pd[v] = P->pd[v] + dv;
+        w.qp[v] = qv;
+      }
     w.po[v] = (v < NX - D) ? P->po[v] : 0.0;
     if (w.band)
     {
@@ -1464,6 +1493,22 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
     w.dybp[v] = 0.0;
     w.flg_bp[v] = 0;
   }
+  if constexpr (ROWSK)
+    if (w.pb != nullptr)
+      for (int e = tid; e < T * D * D; e += NT)
+      {
+        const int t = e / (D * D), i = (e / D) % D, j = e % D;
+        double v = 0.0;
+        if (i != j)
+          for (int c = 0; c < P->n_fx; ++c)
+            if (fx_is_quad(P->fx_kind[c]) && P->fx_t[c] == t)
+            {
+              const double h = dyn_H[(size_t)P->fx_ci[c] * D * D + (i < j ? i : j) * D + (i < j ? j : i)];  // (upper triangle, as the export)
+              if (h != 0.0)
+                v += h;
+            }
+        w.pb[e] = v;
+      }
   for (int t = tid; t <= T; t += NT)
   {
     w.wp_start[t] = P->wp_start[t];
@@ -1544,6 +1589,9 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
         cn = fmax(cn, fabs(w.po[v]));
       if (w.band)
         cn = fmax(cn, band_col_norm(w, v));
+      if (w.pb != nullptr)
+        for (int i = 0; i < D; ++i)
+          cn = fmax(cn, fabs(w.pb[(size_t)t * D * D + i * D + j]));
       for (int q = w.wl_start[t]; q < w.wl_start[t + 1]; ++q)
       {
         const int r = w.wl_list[q];
@@ -1616,6 +1664,12 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
       w.Dp[v] *= w.tp[v];
       w.Ebp[v] *= t_ebp[v];
     }
+    if (w.pb != nullptr)
+      for (int e = tid; e < T * D * D; e += NT)
+      {
+        const int t = e / (D * D), i = (e / D) % D, j = e % D;
+        w.pb[e] = (w.tp[t * D + i] * w.pb[e]) * w.tp[t * D + j];
+      }
     TMX_ROWS(w, r)
     {
       if (!w.act[r])
@@ -1659,6 +1713,9 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
         cn = fmax(cn, fabs(w.po[v]));
       if (w.band)
         cn = fmax(cn, band_col_norm(w, v));
+      if (w.pb != nullptr)
+        for (int i = 0; i < D; ++i)
+          cn = fmax(cn, fabs(w.pb[(size_t)t * D * D + i * D + v % D]));
       w.tp[v] = cn;
       qmax = fmax(qmax, fabs(w.qp[v]));
     }
@@ -1703,6 +1760,9 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
       }
       w.qp[v] *= ct;
     }
+    if (w.pb != nullptr)
+      for (int e = tid; e < T * D * D; e += NT)
+        w.pb[e] *= ct;
     TMX_ROWS(w, r)
       if (w.act[r])
         for (int k = 0; k < w.naux[r]; ++k)
@@ -1797,7 +1857,7 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
   // ---------------- factor + ADMM loop (osqp_solve) --------------------------------------------------------
   TMX_TICK(0);
 #if TMX_IS_DEVICE
-  const bool fast = TMX_UNI_B(!HBM && (NT == TMX_QP_NT) && (R <= 512) && dpart_supported(w, NT) && !TMX_HAS_PAIRS(w) && w.c_alist == nullptr && w.band == 0 && TMX_FAST_ALLOWED);
+  const bool fast = TMX_UNI_B(!HBM && (NT == TMX_QP_NT) && (R <= 512) && dpart_supported(w, NT) && !TMX_HAS_PAIRS(w) && w.c_alist == nullptr && w.band == 0 && w.pb == nullptr && TMX_FAST_ALLOWED);
 #else
   const bool fast = false;
 #endif
@@ -1857,6 +1917,14 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
 #endif
   {
 #if TMX_IS_DEVICE && TMX_ADMM_OUTLINED
+    if (ROWSK && w.pb != nullptr)
+    {
+      // function costs (piecewise QP kernels only): the loop runs inline on THIS descriptor - the out-of-line loop functions rebuild
+      // theirs without the dynamic objective blocks
+      qp_admm_generic_loop(w, P, info, iter, can_check, terminated, tid, NT, pc, tlast);
+    }
+    else
+    {
     // generic path: the same hand-over as above, to qp_admm_generic_nl
     QpShared* sh = reinterpret_cast<QpShared*>(w.wself);
     if (tid == 0)
@@ -1911,6 +1979,7 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
     can_check = sh->can_check != 0;
     iter = sh->iter;
     TMX_SYNC();
+    }
 #else
     qp_admm_generic_loop(w, P, info, iter, can_check, terminated, tid, NT, pc, tlast);
 #endif
@@ -1959,11 +2028,22 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
       wp.flg_bp = iq;
       iq += NX;
       wp.flg_ba = iq;
-      // inactive rows keep flag 0 (the solution store hashes every active flag; unset entries must not be garbage)
+      // inactive rows keep flag 0 (the solution store hashes every active flag; unset entries must not be garbage) and a ZERO
+      // multiplier: at_rows walks all slots of a waypoint and multiplies the (zero) coefficients of the inactive ones with dyr - in
+      // this region that is whatever the LDS held (the ADMM factors after the fast path: finite; anything, NaN patterns included,
+      // when a problem reserves the region without using it - function costs, round 5: polish "succeeded" with NaN in x)
       for (int r = tid; r < R; r += NT)
+      {
         wp.flg_r[r] = 0;
+        wp.dyr[r] = 0.0;
+      }
       for (int a = tid; a < P->NA; a += NT)
+      {
         wp.flg_ba[a] = 0;
+        wp.dxa[a] = 0.0;
+        wp.dyba[a] = 0.0;
+        wp.ta[a] = 0.0;
+      }
       TMX_SYNC();
     }
     for (int v = tid; v < NX; v += NT)
@@ -2396,7 +2476,8 @@ TMX_DEVFN void sqp_model_values(const DevProblem* P, const DevBatch* Bt, int b, 
       for (int e = tid; e < D * len; e += NT)
       {
         const int j = e / len, i = first + e % len;
-        const double dv = (pk >= 2) ? diff_value(xq, D, i, j, pk) : (pk ? xq[i * D + j] : (xq[(i + 1) * D + j] - xq[i * D + j]));
+        const double dv = vel_is_ifopt_kind(pk) ? 0.0 /* (trajopt_sqp flavour only: sqp2_update_block) */
+                                                : ((pk >= 2) ? diff_value(xq, D, i, j, pk) : (pk ? xq[i * D + j] : (xq[(i + 1) * D + j] - xq[i * D + j])));
         const double d = dv - P->vel_targets[v * TMX_MAX_DOF + j];
         vterm[(size_t)v * NX + e] = (d * d) * P->vel_coeffs[v * TMX_MAX_DOF + j];
       }
@@ -2847,7 +2928,32 @@ TMX_DEVFN void sqp2_model_values(const DevProblem* P, const DevBatch* Bt, int b,
       bool squared = false;
       if (k < P->n_costs)
         for (int v = 0; v < P->n_vel; ++v)
-          if (P->vel_cost[v] == k && P->vel_kind[v] == 0)
+          if (P->vel_cost[v] == k && vel_is_ifopt_kind(P->vel_kind[v]))
+          {
+            // QuadExprs::values of a JointAccelConstraint / JointJerkConstraint squared set, rows in order
+            squared = true;
+            const int first = P->vel_first[v], n = P->vel_last[v] - first + 1, ord = ifo_ord(P->vel_kind[v]);
+            for (int i = 0; i < n; ++i)
+              for (int j = 0; j < D; ++j)
+              {
+                const double w = P->vel_coeffs[v * TMX_MAX_DOF + j], targ = P->vel_targets[v * TMX_MAX_DOF + j];
+                const double a = ifo_row_a(x0 + first * D, D, n, ord, i, j, targ);
+                const double sr = 2.0 * (a * w), sw = sqrt(w);
+                const int a0 = ifo_start(n, ord, i);
+                double lin = ((diff_stencil(ord, 0) * -1) * sr) * xq[(first + a0) * D + j];
+                double tq = ((diff_stencil(ord, 0) * -1) * sw) * xq[(first + a0) * D + j];
+                for (int kk = 1; kk <= ord; ++kk)
+                {
+                  lin += ((diff_stencil(ord, kk) * -1) * sr) * xq[(first + a0 + kk) * D + j];
+                  tq += ((diff_stencil(ord, kk) * -1) * sw) * xq[(first + a0 + kk) * D + j];
+                }
+                double out = (a * a) * w;
+                out += 1.0 * lin;
+                out += tq * tq;
+                acc += out;
+              }
+          }
+          else if (P->vel_cost[v] == k && P->vel_kind[v] == 0)
           {
             // QuadExprs::values of the squared set, rows in order (expressions.cpp:123-170 on the output of AffExprs::square)
             squared = true;

@@ -994,10 +994,11 @@ TMX_DEVFN double fx_model_value(const double* H, const double* g, double cst, co
 
 // number of entries per joint of a squared joint cost minus (last_step - first_step): position 1, velocity 0, acc -1, jerk -2
 // (run-time in every instantiation: the banded structured path evaluates acceleration / jerk COSTS in the fused kernels too)
+TMX_DEVFN bool vel_is_ifopt_kind(int pk) { return pk == 4 || pk == 5; }  // (trajopt_ifopt accel / jerk sets: n rows per joint)
 template <bool ST>
 TMX_DEVFN int vel_len_adj(int pk)
 {
-  return (pk >= 2) ? 1 - pk : pk;
+  return vel_is_ifopt_kind(pk) ? 1 : ((pk >= 2) ? 1 - pk : pk);
 }
 // ---- finite-difference rows of order 2 / 3 (JointAcc / JointJerk, trajectory_costs.cpp:502-1016) ------------------------
 // order of a SLOT_JOINTVEL / SLOT_JOINTVEL_INEQ row: 1 (velocity: x[t], x[t+1]) unless slot_sub3 says 2 or 3
@@ -1030,6 +1031,37 @@ TMX_DEVFN double diff_value(const double* xv, int D, int i, int j, int ord)
     return d1 - d0;
   const double d2 = xv[(i + 3) * D + j] - xv[(i + 2) * D + j];
   return (d2 - d1) - (d1 - d0);
+}
+// ---- trajopt_ifopt JointAccelConstraint / JointJerkConstraint as squared cost sets of the trajopt_sqp flavour (vel_kind 4 / 5, round 5;
+// joint_acceleration_constraint.cpp:90-175, joint_jerk_constraint.cpp:90-180).  A set over n = last - first + 1 waypoints has n rows per
+// joint: row i takes the FORWARD stencil on waypoints i .. i + ord while i < n - ord and the BACKWARD one on i - ord .. i for the last
+// `ord` rows (which repeat the stencils of rows n - 2 ord .. n - ord - 1, with another order of the additions).
+TMX_DEVFN int ifo_ord(int pk) { return pk - 2; }
+TMX_DEVFN int ifo_start(int n, int ord, int i) { return (i < n - ord) ? i : i - ord; }  // first waypoint of row i's stencil (set-local)
+// getValues() of row (i, j): xs = the set's first waypoint
+TMX_DEVFN double ifo_value(const double* xs, int D, int n, int ord, int i, int j)
+{
+  if (ord == 2)
+  {
+    if (i < n - 2)
+      return (xs[(i + 2) * D + j] - 2.0 * xs[(i + 1) * D + j]) + xs[i * D + j];       // q2 - 2.0 * q1 + q0
+    return (xs[(i - 2) * D + j] - 2.0 * xs[(i - 1) * D + j]) + xs[i * D + j];         // (q2 = q_{i-2}, q1 = q_{i-1}, q0 = q_i)
+  }
+  if (i < n - 3)
+    return ((-xs[i * D + j] + 3.0 * xs[(i + 1) * D + j]) - 3.0 * xs[(i + 2) * D + j]) + xs[(i + 3) * D + j];  // -q0 + 3.0 * q1 - 3.0 * q2 + q3
+  return ((xs[i * D + j] - 3.0 * xs[(i - 1) * D + j]) + 3.0 * xs[(i - 2) * D + j]) - xs[(i - 3) * D + j];    // q0 - 3.0 * q1 + 3.0 * q2 - q3
+}
+// row (i, j) of the squared set at the convexification point x0 (AffExprs::create / square, expressions.cpp:28-112, as the JointVel set
+// below): a = target - (value - J x0), the row scale sr = 2 (a w); entries of the FLIPPED Jacobian in ascending columns: -stencil
+TMX_DEVFN double ifo_row_a(const double* xs0, int D, int n, int ord, int i, int j, double targ)
+{
+  const int a0 = ifo_start(n, ord, i);
+  double jx = diff_stencil(ord, 0) * xs0[a0 * D + j];
+  for (int k = 1; k <= ord; ++k)
+    jx += diff_stencil(ord, k) * xs0[(a0 + k) * D + j];
+  double cst = ifo_value(xs0, D, n, ord, i, j);
+  cst += -1.0 * jx;
+  return targ - cst;
 }
 
 
@@ -1367,7 +1399,8 @@ TMX_DEVFN void evaluate_terms(const DevProblem* P, const double* xv, double* cos
       // summation order: the reference's column-major Eigen array (joint-major) for trajopt_sco; row order of the constraint
       // set (segment-major) for the trajopt_sqp flavour (getExactCosts, trajopt_qp_problem.cpp:986-1001)
       const int j = (P->flavor == 1) ? e % D : e / len, i = first + ((P->flavor == 1) ? e / D : e % len);
-      const double dv = (pk >= 2) ? diff_value(xv, D, i, j, pk) : (pk ? xv[i * D + j] : (xv[(i + 1) * D + j] - xv[i * D + j]));
+      const double dv = vel_is_ifopt_kind(pk) ? ifo_value(xv + first * D, D, len, ifo_ord(pk), i - first, j)
+                                              : ((pk >= 2) ? diff_value(xv, D, i, j, pk) : (pk ? xv[i * D + j] : (xv[(i + 1) * D + j] - xv[i * D + j])));
       const double d = dv - P->vel_targets[v * TMX_MAX_DOF + j];
       vterm[(size_t)v * P->NX + e] = (d * d) * P->vel_coeffs[v * TMX_MAX_DOF + j];
     }
@@ -1624,10 +1657,26 @@ TMX_DEVFN void convexify_terms(const DevProblem* P, const double* xv, int* activ
       double acc = 0.0;
       for (int k = 0; k < P->n_vel; ++k)
       {
-        if (P->vel_kind[k] != 0)
-          continue;
         double part = 0.0;  // objective_linear_coeffs of this set, accumulated over its rows in row order
         const double w = P->vel_coeffs[k * TMX_MAX_DOF + j], targ = P->vel_targets[k * TMX_MAX_DOF + j];
+        if (vel_is_ifopt_kind(P->vel_kind[k]))
+        {
+          // JointAccelConstraint / JointJerkConstraint set: every row i whose stencil covers waypoint t, in row order
+          const int first = P->vel_first[k], n = P->vel_last[k] - first + 1, ord = ifo_ord(P->vel_kind[k]);
+          for (int i = 0; i < n; ++i)
+          {
+            const int a0 = ifo_start(n, ord, i);
+            if (t - first < a0 || t - first > a0 + ord)
+              continue;
+            const double a = ifo_row_a(xv + first * D, D, n, ord, i, j, targ);
+            const double sr = 2.0 * (a * w);
+            part += (diff_stencil(ord, t - first - a0) * -1) * sr;
+          }
+          acc += part;
+          continue;
+        }
+        if (P->vel_kind[k] != 0)
+          continue;
         for (int side = 1; side >= 0; --side)  // the row of segment t-1 (entry -1 at x1 = this var) comes before segment t's
         {
           const int i = side ? t - 1 : t;      // segment index
