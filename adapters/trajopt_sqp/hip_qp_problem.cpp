@@ -6,6 +6,7 @@
 #include <trajopt_ifopt/constraints/joint_velocity_constraint.h>
 #include <trajopt_ifopt/constraints/joint_acceleration_constraint.h>
 #include <trajopt_ifopt/constraints/joint_jerk_constraint.h>
+#include <trajopt_ifopt/constraints/cartesian_position_constraint.h>
 #include <trajopt_ifopt/constraints/collision/discrete_collision_constraint.h>
 #include <trajopt_ifopt/constraints/collision/discrete_collision_evaluators.h>
 #include <trajopt_ifopt/constraints/collision/continuous_collision_constraint.h>
@@ -111,6 +112,93 @@ void HipQPProblem::lowerSet(const trajopt_ifopt::ConstraintSet& set, bool is_cos
     t.first_step = static_cast<int32_t>(col / D);
     t.last_step = t.first_step + static_cast<int32_t>(set.getRows() / D);  // rows = n_dof * (n_vars - 1)
   }
+  else if (const auto* cp = dynamic_cast<const trajopt_ifopt::CartPosConstraint*>(&set))
+  {
+    // (round 5) CartPosConstraint of one waypoint, Type::kSourceActive: the source frame moves with the chain, the target is static.
+    // The device lowers it as its cart_pose rows (FK of the described chain's tool frame against a world target, forward-difference
+    // Jacobian, eps 1e-5 - cartesian_position_constraint.cpp:263-293 with use_numeric_differentiation, the default).  What the set does
+    // not expose (frames, offsets) is VERIFIED instead: the pose it reports for the current variable values must be the pose of the
+    // described chain's tool frame.
+    if (is_cost)
+      throw std::runtime_error(who + "CartPosConstraint is lowered as a constraint set only");
+    if (!cp->use_numeric_differentiation)
+      throw std::runtime_error(who + "CartPosConstraint is lowered with use_numeric_differentiation (the reference's default) only");
+    const std::vector<trajopt_ifopt::Bounds> b = set.getBounds();
+    const Eigen::VectorXd c = set.getCoefficients();
+    if (set.getRows() != 6 || b.size() != 6 || c.size() != 6)
+      throw std::runtime_error(who + "a CartPosConstraint with all six rows (no zero coefficient, no split range bounds) is expected");
+    for (std::size_t i = 0; i < 6; ++i)
+      if (b[i].getLower() != 0.0 || b[i].getUpper() != 0.0)
+        throw std::runtime_error(who + "only BoundZero rows are lowered by the device path");
+    const Eigen::Index col = firstColumn(set.getJacobian());
+    if (col < 0 || col % D != 0)
+      throw std::runtime_error(who + "cannot read the waypoint of the set off its Jacobian");
+    const Eigen::Index step = col / D;
+    // forward kinematics of the described chain at this waypoint (include/tmx.h: base, joints[k].origin / axis / type, tool: 3 x 4
+    // row-major transforms), in plain arithmetic
+    struct M34
+    {
+      double a[12];
+    };
+    auto mul = [](const M34& A, const M34& B) {
+      M34 C{};
+      for (int r = 0; r < 3; ++r)
+        for (int q = 0; q < 4; ++q)
+        {
+          double v = (q == 3) ? A.a[4 * r + 3] : 0.0;
+          for (int k = 0; k < 3; ++k)
+            v += A.a[4 * r + k] * B.a[4 * k + q];
+          C.a[4 * r + q] = v;
+        }
+      return C;
+    };
+    auto from12 = [](const double* p) {
+      M34 A{};
+      for (int i = 0; i < 12; ++i)
+        A.a[i] = p[i];
+      return A;
+    };
+    M34 T = from12(desc_->base);
+    for (Eigen::Index k = 0; k < D; ++k)
+    {
+      const double* ax = desc_->joints[k].axis;
+      const double qk = x_(step * D + k);
+      T = mul(T, from12(desc_->joints[k].origin));
+      M34 J{};
+      if (desc_->joints[k].type == 0)
+      {
+        const double cq = std::cos(qk), sq = std::sin(qk), vq = 1.0 - cq;  // Rodrigues
+        const double R[9] = { cq + ax[0] * ax[0] * vq,         ax[0] * ax[1] * vq - ax[2] * sq, ax[0] * ax[2] * vq + ax[1] * sq,
+                              ax[1] * ax[0] * vq + ax[2] * sq, cq + ax[1] * ax[1] * vq,         ax[1] * ax[2] * vq - ax[0] * sq,
+                              ax[2] * ax[0] * vq - ax[1] * sq, ax[2] * ax[1] * vq + ax[0] * sq, cq + ax[2] * ax[2] * vq };
+        for (int r = 0; r < 3; ++r)
+          for (int q = 0; q < 3; ++q)
+            J.a[4 * r + q] = R[3 * r + q];
+      }
+      else
+      {
+        J.a[0] = J.a[5] = J.a[10] = 1.0;
+        for (int r = 0; r < 3; ++r)
+          J.a[4 * r + 3] = qk * ax[r];
+      }
+      T = mul(T, J);
+    }
+    T = mul(T, from12(desc_->tool));
+    const Eigen::Isometry3d cur = cp->getCurrentPose();
+    for (int r = 0; r < 3; ++r)
+      for (int q = 0; q < 4; ++q)
+        if (std::fabs(T.a[4 * r + q] - cur(r, q)) > 1e-6)
+          throw std::runtime_error(who + "the source frame of the CartPosConstraint is not the tool frame of the described chain");
+    t.kind = TMX_TERM_CART_POSE;
+    t.is_constraint = 1;
+    t.first_step = t.last_step = static_cast<int32_t>(step);
+    for (int i = 0; i < 6; ++i)
+      t.coeffs[i] = c(i);
+    const Eigen::Isometry3d target = cp->getTargetPose();
+    for (int r = 0; r < 3; ++r)
+      for (int q = 0; q < 4; ++q)
+        t.target_pose[4 * r + q] = target(r, q);
+  }
   else if (dynamic_cast<const trajopt_ifopt::JointAccelConstraint*>(&set) != nullptr ||
            dynamic_cast<const trajopt_ifopt::JointJerkConstraint*>(&set) != nullptr)
   {
@@ -134,7 +222,7 @@ void HipQPProblem::lowerSet(const trajopt_ifopt::ConstraintSet& set, bool is_cos
     const auto* cc = dynamic_cast<const trajopt_ifopt::ContinuousCollisionConstraint*>(&set);
     if (dc == nullptr && cc == nullptr)
       throw std::runtime_error(who + "this ConstraintSet class is not lowered by the device path (JointPosConstraint, JointVelConstraint, "
-                                     "JointAccelConstraint, JointJerkConstraint, Discrete / ContinuousCollisionConstraint are); describe the problem with a lowered term table instead");
+                                     "JointAccelConstraint, JointJerkConstraint, CartPosConstraint, Discrete / ContinuousCollisionConstraint are); describe the problem with a lowered term table instead");
     if (is_cost && penalty_type != CostPenaltyType::kHinge)
       throw std::runtime_error(who + "collision sets as costs are lowered with CostPenaltyType::kHinge only");
     double margin = 0.0, coeff = 0.0, buffer = 0.0;

@@ -493,6 +493,17 @@ Sqp2Problem buildSqp2(const tmx_problem_desc& d, const double* x0)
         for (int t = tm.first_step; t <= tm.last_step; ++t)
           P.qp->addConstraintSet(std::make_shared<ifopt::JointPosConstraint>(targets, var(t), coeffs, "joint_pos_" + std::to_string(t)));
         break;
+      case TMX_TERM_CART_POSE:
+      {
+        // trajopt_ifopt::CartPosConstraint per step as a constraint set (numerical_ik_unit.cpp:107-110, cart_position_optimization_unit.cpp)
+        if (!tm.is_constraint)
+          throw std::runtime_error("the trajopt_sqp flavour lowers CartPosConstraint as a constraint set only");
+        const Tf target = tfFrom12(tm.target_pose);
+        const ifopt::Vec c6(tm.coeffs, tm.coeffs + 6);
+        for (int t = tm.first_step; t <= tm.last_step; ++t)
+          P.qp->addConstraintSet(std::make_shared<ifopt::CartPosConstraint>(var(t), chain, target, c6, "cart_pos_" + std::to_string(t)));
+        break;
+      }
       case TMX_TERM_JOINT_POS_EQ_COST:
         for (int t = tm.first_step; t <= tm.last_step; ++t)
           P.qp->addCostSet(std::make_shared<ifopt::JointPosConstraint>(targets, var(t), coeffs, "joint_pos_" + std::to_string(t)),

@@ -331,6 +331,59 @@ private:
   std::vector<Bounds> bounds_;
 };
 
+// cartesian_position_constraint.cpp:40-330 - CartPosConstraint of ONE waypoint, Type::kSourceActive (the source frame moves with the
+// chain, the target frame is a static link * offset): value = calcTransformError(target_tf, source_tf) rows `indices` (the rows whose
+// coefficient is not ~0), Jacobian by forward differences of calcJacobianTransformErrorDiff with eps = 1e-5 (use_numeric_differentiation
+// defaults to true, :131 of the header), bounds BoundZero.  The kinematics are those of the sco path's CartPoseErrCalculator /
+// CartPoseJacCalculator (oracle/trajprob.hpp CartPoseCalc: the same tesseract functions, kinematic_terms.cpp:250-263, :348-366).
+class CartPosConstraint : public ConstraintSet
+{
+public:
+  CartPosConstraint(Var position_var, std::shared_ptr<const Chain> chain, const Tf& target, const Vec& coeffs6, const std::string& name)
+    : ConstraintSet(name), var_(std::move(position_var))
+  {
+    if (coeffs6.size() != 6)
+      throw std::runtime_error("The number of coeffs should be six.");  // :69
+    calc_.chain = std::move(chain);
+    calc_.target = target;
+    for (int i = 0; i < 6; ++i)
+      if (!(std::fabs(coeffs6[static_cast<std::size_t>(i)]) <= 1e-6))  // !almostEqualRelativeAndAbs(coeffs(i), 0)  :95, :121
+      {
+        calc_.indices.push_back(i);
+        coeffs_.push_back(coeffs6[static_cast<std::size_t>(i)]);
+        bounds_.emplace_back(0.0, 0.0);
+      }
+  }
+  Vec getValues() const override
+  {
+    DblVec q(static_cast<std::size_t>(var_.n));
+    for (int k = 0; k < var_.n; ++k)
+      q[static_cast<std::size_t>(k)] = var_.at(k);
+    return calc_.err(q);
+  }
+  Jac getJacobian() const override
+  {
+    DblVec q(static_cast<std::size_t>(var_.n));
+    for (int k = 0; k < var_.n; ++k)
+      q[static_cast<std::size_t>(k)] = var_.at(k);
+    const Mat J0 = calc_.jac(q);
+    Jac j(getRows(), variables_->getRows());
+    for (int i = 0; i < getRows(); ++i)
+      for (int k = 0; k < var_.n; ++k)
+        j.insertBack(i, var_.index + k, J0(i, k));  // (every entry of the block is inserted, :283-293)
+    return j;
+  }
+  std::vector<Bounds> getBounds() const override { return bounds_; }
+  Vec getCoefficients() const override { return coeffs_; }
+  int getRows() const override { return static_cast<int>(bounds_.size()); }
+
+private:
+  Var var_;
+  CartPoseCalc calc_;
+  Vec coeffs_;
+  std::vector<Bounds> bounds_;
+};
+
 // joint_jerk_constraint.cpp:37-180 - forward stencil (-1, 3, -3, 1) on [0, n-4], backward on the last three; one row per (step, joint)
 class JointJerkConstraint : public ConstraintSet
 {

@@ -306,3 +306,116 @@ def test_ifopt_acceleration_and_jerk_cost_sets_on_device(gpu_ctx_factory, orc, o
     ctx = gpu_ctx_factory()
     _check_ifopt_difference_cost(ctx, orc, order)
     ctx.close()
+
+
+# ---- trajopt_ifopt CartPosConstraint as a constraint set (round 5) --------------------------------------------------------------------
+# The reference's trajopt_sqp/test/numerical_ik_unit.cpp:83-150: PR2 left arm, ONE node, start (0, 0, 0, -0.001, 0, -0.001, 0), a
+# CartPosConstraint of l_gripper_tool_frame against base_footprint * (xyz 0.4 0 0.8, wxyz 0 0 1 0); the test asserts the final tool pose
+# within 1e-3 of the goal entry by entry.  The chain and the base_footprint frame are the ones tests/test_numerical_ik_kat.py uses for
+# the trajopt_sco twin of this test (extracted from arm_around_table.urdf by tools/extract_pr2_chain.py).
+def _numerical_ik_sqp_problem():
+    from trajopt_amd.problem import BasicInfo, CartPoseTermInfo, ProblemConstructionInfo, pr2_base_footprint, pr2_left_arm
+    rob = pr2_left_arm()
+    pci = ProblemConstructionInfo(rob, BasicInfo(n_steps=1))
+    pci.flavor = 1
+    bf = np.vstack([pr2_base_footprint(), [0, 0, 0, 1]])      # chain base <- base_footprint
+    goal = np.eye(4)
+    goal[:3, 3] = (0.4, 0.0, 0.8)
+    goal[:3, :3] = np.diag([-1.0, 1.0, -1.0])                  # Quaterniond(0, 0, 1, 0): half turn about y
+    pci.cnt_infos.append(CartPoseTermInfo(timestep=0, target_pose=(bf @ goal)[:3, :], pos_coeffs=(1.0, 1.0, 1.0), rot_coeffs=(1.0, 1.0, 1.0),
+                                          is_constraint=True))
+    x0 = np.array([[[0.0, 0.0, 0.0, -0.001, 0.0, -0.001, 0.0]]])
+    return pci, rob, bf, goal, x0
+
+
+def _check_numerical_ik_sqp(ctx, orc):
+    pci, rob, bf, goal, x0 = _numerical_ik_sqp_problem()
+    desc = pci.to_desc()
+    st = configs.osqp_settings_config4()
+
+    def pose_ok(q):
+        final = np.linalg.inv(bf) @ rob.fk_tool(np.asarray(q))
+        return np.abs(final - goal).max() < 1e-3
+
+    o = orc.sqp2_batch(desc, x0, osqp=st)
+    assert o["status"][0] == abi.SQP_CONVERGED and pose_ok(o["x"][0, 0])            # the reference's assertion, on the oracle
+    ctx.upload(desc, abi.default_sqp_params(), st)
+    ctx.set_x0(x0)
+    cv, vv = ctx.evaluate()
+    ctx.convexify()
+    q = orc.sqp2_first_qp(desc, x0[0])
+    assert np.abs(vv[0] - q["exact_viols"]).max() <= 1e-12
+    e = ctx.export_csc(0)
+    assert (e["n"], e["m"]) == (q["nv"], q["nc"])
+    P, A = _dense_from_export(e)
+    assert np.abs(A - q["A"]).max() <= 1e-9 and np.abs(P - 2.0 * q["H"]).max() <= 1e-12
+    assert np.abs(np.clip(q["lower"], -1e30, 1e30) - e["l"]).max() <= 1e-9 and np.abs(np.clip(q["upper"], -1e30, 1e30) - e["u"]).max() <= 1e-9
+    ctx.set_x0(x0)
+    ctx.run(0)
+    r = ctx.results()
+    # 7 joints, 6 rows, no cost: which point of the one-dimensional solution set is returned is decided by round-off (see
+    # tests/test_numerical_ik_kat.py) - the reference asserts the pose only, and so do we, plus the outcome
+    assert r["status"][0] == abi.SQP_CONVERGED and pose_ok(r["x"][0, 0])
+
+
+def test_cart_pos_constraint_numerical_ik_on_host_build(hostemu_lib, orc):
+    ctx = runtime.Context(0, hostemu_lib)
+    _check_numerical_ik_sqp(ctx, orc)
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_cart_pos_constraint_numerical_ik_on_device(gpu_ctx_factory, orc):
+    ctx = gpu_ctx_factory()
+    _check_numerical_ik_sqp(ctx, orc)
+    ctx.close()
+
+
+# trajopt_sqp/test/cart_position_optimization_unit.cpp:75-140: PR2 right arm, ONE node started at zero, CartPosConstraint of the tool
+# frame against the pose the arm has at (0, 0, 0, -1, 0, -1, 0); asserted: translation isApprox(1e-4), quaternion isApprox(1e-5)
+def _check_cart_position_optimization(ctx, orc):
+    from trajopt_amd.problem import BasicInfo, CartPoseTermInfo, ProblemConstructionInfo
+    rob = configs.pr2_right_arm()
+    pci = ProblemConstructionInfo(rob, BasicInfo(n_steps=1))
+    pci.flavor = 1
+    target = rob.fk_tool(np.array([0.0, 0, 0, -1.0, 0, -1, -0.0]))
+    pci.cnt_infos.append(CartPoseTermInfo(timestep=0, target_pose=target[:3, :], pos_coeffs=(1.0, 1.0, 1.0), rot_coeffs=(1.0, 1.0, 1.0),
+                                          is_constraint=True))
+    x0 = np.zeros((1, 1, 7))
+    desc = pci.to_desc()
+    st = configs.osqp_settings_config4()
+
+    def quat(Rm):
+        from scipy.spatial.transform import Rotation
+        qv = Rotation.from_matrix(Rm).as_quat()
+        return qv if qv[3] >= 0 else -qv
+
+    def reached(q):
+        got = rob.fk_tool(np.asarray(q))
+        tp, gp = target[:3, 3], got[:3, 3]
+        tq, gq = quat(target[:3, :3]), quat(got[:3, :3])
+        # Eigen isApprox(a, b, p): |a - b| <= p * min(|a|, |b|)
+        return np.linalg.norm(tp - gp) <= 1e-4 * min(np.linalg.norm(tp), np.linalg.norm(gp)) and min(np.linalg.norm(tq - gq), np.linalg.norm(tq + gq)) <= 1e-5
+
+    o = orc.sqp2_batch(desc, x0, osqp=st)
+    assert o["status"][0] == abi.SQP_CONVERGED and reached(o["x"][0, 0])
+    ctx.upload(desc, abi.default_sqp_params(), st)
+    ctx.set_x0(x0)
+    ctx.run(0)
+    r = ctx.results()
+    assert r["status"][0] == abi.SQP_CONVERGED and reached(r["x"][0, 0])
+    # (the start point is an ordinary one here - no free direction is excited before the first steps: the histories agree)
+    assert r["n_qp_solves"][0] == o["n_qp_solves"][0] and np.abs(r["x"] - o["x"]).max() <= 1e-5
+
+
+def test_cart_pos_constraint_optimization_on_host_build(hostemu_lib, orc):
+    ctx = runtime.Context(0, hostemu_lib)
+    _check_cart_position_optimization(ctx, orc)
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_cart_pos_constraint_optimization_on_device(gpu_ctx_factory, orc):
+    ctx = gpu_ctx_factory()
+    _check_cart_position_optimization(ctx, orc)
+    ctx.close()

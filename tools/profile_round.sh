@@ -6,7 +6,13 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/kt -o out --output-format csv -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/kt.log
+# (round 5: the kernel-trace pass runs the DRIVER's command, so that the trace's average k_sqp_pool duration and the bench line's
+#  avg_launch_ms are over the same 20 launches; KT_ARGS overrides)
+KT_ARGS=${KT_ARGS:---steps 20 --warmup 5}
+if [ -z "$SKIP_KT" ]; then
+timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/kt -o out --output-format csv -- python $R/bench.py $KT_ARGS --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/kt.log
+fi
+[ -n "$SKIP_PMC" ] && exit 0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_MFMA_MOPS_F64"; do
   [ -n "$QUICK" ] && [ "$grp" != "FETCH_SIZE" ] && [ "$grp" != "WRITE_SIZE" ] && continue
   tag=$(echo $grp | tr ' ' '_' | cut -c1-48)
@@ -17,7 +23,7 @@ import csv, glob, json, collections, os
 out = "$OUT"
 lines = []
 for f in glob.glob(out + "/kt/*kernel_stats.csv"):
-    lines.append("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline")
+    lines.append("# rocprofv3 --kernel-trace --stats -- python bench.py " + os.environ.get("KT_ARGS", "--steps 20 --warmup 5") + " --no-cpu-baseline")
     lines.append(open(f).read())
 kt = glob.glob(out + "/kt/*kernel_trace.csv")
 if kt:

@@ -512,11 +512,21 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
           case TMX_TERM_JOINT_POS_EQ_CNT:
             want = 3;
             break;
+          case TMX_TERM_CART_POSE:  // trajopt_ifopt::CartPosConstraint as a (static) constraint set, round 5
+            if (!tm.is_constraint)
+            {
+              ctx->err = "TMX_FLAVOR_SQP: cart_pose is lowered as a constraint set (CartPosConstraint) only";
+              return TMX_ERR_UNSUPPORTED;
+            }
+            want = 3;
+            break;
           case TMX_TERM_COLLISION_CNT:
             want = 4;
             break;
           default:
-            ctx->err = "TMX_FLAVOR_SQP: term kind not part of the trajopt_sqp path";
+            ctx->err = "TMX_FLAVOR_SQP: this term kind is not lowered for the trajopt_sqp flavour (lowered: JointPosConstraint as constraint / "
+                       "absolute cost, JointVel / JointAccel / JointJerk constraint sets as squared costs, CartPosConstraint as constraint, the "
+                       "segment collision sets as hinge cost / constraint); not part of the trajopt_sqp path as built here";
             return TMX_ERR_UNSUPPORTED;
         }
         if ((tm.kind == TMX_TERM_COLLISION_COST || tm.kind == TMX_TERM_COLLISION_CNT) && tm.evaluator_type < 2)
@@ -1073,7 +1083,9 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
             int nr = 0;
             for (int i = 0; i < 6; ++i)
             {
-              const bool keep = std::fabs(tm.coeffs[i]) > 1e-5;  // problem_description.cpp:910-926
+              // problem_description.cpp:910-926; trajopt_ifopt::CartPosConstraint drops the rows whose coefficient is
+              // almostEqualRelativeAndAbs(c, 0) (cartesian_position_constraint.cpp:95, :121)
+              const bool keep = std::fabs(tm.coeffs[i]) > (flavor == TMX_FLAVOR_SQP ? 1e-6 : 1e-5);
               cp_idx.push_back(0);
               cp_coeff.push_back(0.0);
               if (keep)

@@ -2928,6 +2928,7 @@ TMX_DEVFN void sqp2_model_values(const DevProblem* P, const DevBatch* Bt, int b,
       bool squared = false;
       if (k < P->n_costs)
         for (int v = 0; v < P->n_vel; ++v)
+        {
           if (P->vel_cost[v] == k && vel_is_ifopt_kind(P->vel_kind[v]))
           {
             // QuadExprs::values of a JointAccelConstraint / JointJerkConstraint squared set, rows in order
@@ -2973,6 +2974,7 @@ TMX_DEVFN void sqp2_model_values(const DevProblem* P, const DevBatch* Bt, int b,
                 acc += out;
               }
           }
+        }
       if (!squared)
         for (int r = P->own_lo[k]; r <= P->own_hi[k]; ++r)
           if (keys[r] == k)

@@ -1356,7 +1356,8 @@ TMX_DEVFN void evaluate_terms(const DevProblem* P, const double* xv, double* cos
       const int ix = P->cp_idx[6 * c + i];
       const double e = (ix == 0) ? err[0] : (ix == 1) ? err[1] : (ix == 2) ? err[2] : (ix == 3) ? err[3] : (ix == 4) ? err[4] : err[5];
       const double cc = P->cp_coeff[6 * c + i];
-      scratch[s0 + i] = P->cp_iscnt[c] ? fabs(e * cc) : fabs(e) * cc;
+      // flavour 1: calcBoundsViolations of the row value against BoundZero, unweighted (getExactConstraintViolations)
+      scratch[s0 + i] = (P->flavor == 1) ? ((e != 0.0) ? fabs(e - 0.0) : 0.0) : (P->cp_iscnt[c] ? fabs(e * cc) : fabs(e) * cc);
     }
   }
   if constexpr (ST)
@@ -1762,8 +1763,23 @@ TMX_DEVFN void convexify_terms(const DevProblem* P, const double* xv, int* activ
     for (int k = 0; k < D; ++k)
       dot += Jr[k] * q[k];
     const double cc = P->cp_coeff[6 * c + i];
-    const double constant = (y - dot) * cc;
     const int r = P->cp_slot0[c] + i;
+#if TMX_LINK_ROWS
+    if (P->flavor == 1)
+    {
+      // trajopt_ifopt::CartPosConstraint row in TrajOptQPProblem::convexify (trajopt_qp_problem.cpp:752-792; round 5): the Jacobian
+      // block as the set returns it (forward differences / eps, unscaled), entries with |v| < 1e-7 stored as 0, constant = value - J x0
+      // with the UNPRUNED Jacobian, equality bounds 0 - constant; the coefficient weighs the slack pair only (aux_cost)
+      const double constant = y - dot;
+      for (int k = 0; k < D; ++k)
+        coef[r * D + k] = (fabs(Jr[k]) < TMX_CLEANUP_TOL) ? 0.0 : Jr[k];
+      rhs[r] = P->slot_aux1[r] - constant;
+      rowc[r] = constant;
+      active[r] = 1;
+      continue;
+    }
+#endif
+    const double constant = (y - dot) * cc;
     for (int k = 0; k < D; ++k)
     {
       const double jv = Jr[k];
