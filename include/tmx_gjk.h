@@ -547,6 +547,17 @@ TMX_GJK_FN int tmx_gjk_epa(const tmx_cvx* A, const tmx_cvx* B, double pa[3], dou
     if (full)
       break;
   }
+  /* The loop can also end with the face it chose already removed - the vertex / face caps, an empty horizon - and, at the face cap, with
+   * that face's slot reused by a new horizon face: take the closest face that is ALIVE now (the regular exit left through the
+   * convergence test before anything was removed: this selects the same face again). */
+  {
+    int alive_best = -1;
+    for (int f = 0; f < nf; ++f)
+      if (F[f].alive && (alive_best < 0 || F[f].dist < F[alive_best].dist))
+        alive_best = f;
+    if (alive_best >= 0)
+      bestf = alive_best;
+  }
   if (bestf < 0)
     bestf = 0;
   /* Witness points.  Depth and direction are those of the closest face (its plane supports the Minkowski difference: exact for

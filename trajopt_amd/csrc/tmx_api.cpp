@@ -960,7 +960,8 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
           const bool is_cost = tm.kind == TMX_TERM_JOINT_ACC_INEQ_COST || tm.kind == TMX_TERM_JOINT_JERK_INEQ_COST;
           if (flavor == TMX_FLAVOR_SQP)
           {
-            ctx->err = "TMX_FLAVOR_SQP: joint acceleration / jerk terms are not part of the trajopt_sqp path";
+            ctx->err = "TMX_FLAVOR_SQP: the ROW forms of the joint acceleration / jerk terms are not lowered for the trajopt_sqp flavour (their "
+                       "squared cost sets are); not part of the trajopt_sqp path as built here";
             return TMX_ERR_UNSUPPORTED;
           }
           if (tm.last_step - ord - tm.first_step < 0)
@@ -2891,14 +2892,21 @@ tmx_status tmx_best_trajectory(tmx_ctx* ctx, double* x_out, int32_t* owner_rank)
   if (comm && ncclCommUserRank(comm, &my_rank) != ncclSuccess)
     return TMX_ERR_NCCL;
 #endif
+  // The call is COLLECTIVE: every rank enters the broadcast whatever it finds locally - an owner whose winning index is not in its
+  // shard (global_offset of tmx_argmin inconsistent across ranks) sends a NaN trajectory instead of returning early and leaving the
+  // other ranks blocked in ncclBroadcast; every rank then reports TMX_ERR_STATE.
+  bool owner_bad = false;
   if (my_rank == ctx->best_owner)
   {
-    if (ctx->best_local < 0 || ctx->best_local >= (long long)ctx->hb.B)
+    owner_bad = ctx->best_local < 0 || ctx->best_local >= (long long)ctx->hb.B;
+    if (owner_bad)
     {
-      ctx->err = "tmx_best_trajectory: the winning index is not in this rank's shard (global_offset of tmx_argmin inconsistent across ranks)";
-      return TMX_ERR_STATE;
+      std::vector<double> nanv(NX, std::nan(""));
+      HIPCHK(hipMemcpyAsync(ctx->d_best, nanv.data(), sizeof(double) * NX, hipMemcpyHostToDevice, ctx->stream));
+      HIPCHK(hipStreamSynchronize(ctx->stream));  // (the staging vector dies with this scope)
     }
-    HIPCHK(hipMemcpyAsync(ctx->d_best, ctx->hb.x + (size_t)ctx->best_local * NX, sizeof(double) * NX, hipMemcpyDeviceToDevice, ctx->stream));
+    else
+      HIPCHK(hipMemcpyAsync(ctx->d_best, ctx->hb.x + (size_t)ctx->best_local * NX, sizeof(double) * NX, hipMemcpyDeviceToDevice, ctx->stream));
   }
 #ifndef TMX_HOST_EMU
   if (comm && ctx->best_nranks > 1 &&
@@ -2910,6 +2918,11 @@ tmx_status tmx_best_trajectory(tmx_ctx* ctx, double* x_out, int32_t* owner_rank)
 #endif
   HIPCHK(hipMemcpyAsync(x_out, ctx->d_best, sizeof(double) * NX, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (owner_bad || (NX > 0 && std::isnan(x_out[0])))
+  {
+    ctx->err = "tmx_best_trajectory: the winning index is not in the owner rank's shard (global_offset of tmx_argmin inconsistent across ranks)";
+    return TMX_ERR_STATE;
+  }
   return TMX_OK;
 }
 

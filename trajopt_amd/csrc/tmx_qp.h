@@ -846,7 +846,10 @@ TMX_DEVFN void kkt_factor(const QpWs& w, const DevProblem* P, int mode, double s
   // row r = list entry q + (l >> 4); B operand: coef_r[l & 15] of the same row; the rows enter in list order, as in the scalar
   // loop below, which problems with rows on two waypoints and the host build keep).  D layout: lane l, register q = entry
   // ((l >> 4) + 4 q, l & 15).
-  const bool mfma_blocks = D <= 16 && (NT & 63) == 0 && !TMX_HAS_PAIRS(w);
+#ifndef TMX_MFMA_ASSEMBLY
+#define TMX_MFMA_ASSEMBLY 1  // 0: the scalar list-order accumulation everywhere (diagnostic builds: isolates the matrix-core path)
+#endif
+  const bool mfma_blocks = TMX_MFMA_ASSEMBLY && D <= 16 && (NT & 63) == 0 && !TMX_HAS_PAIRS(w);
   if (mfma_blocks)
   {
     typedef double tmx_kf_v4d __attribute__((ext_vector_type(4)));

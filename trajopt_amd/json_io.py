@@ -260,11 +260,16 @@ def construct_problem(text_or_dict, env: Environment) -> ParsedProblem:
         pci.cost_infos.append(read_term(it, True))
     for it in v.get("constraints", []):
         pci.cnt_infos.append(read_term(it, False))
-    # ConstructProblem :415-452: a term uses time <=> basic_info.use_time
-    any_time = any((isinstance(ti, JointVelTermInfo) and ti.use_time) or isinstance(ti, TotalTimeTermInfo) for ti in pci.cost_infos + pci.cnt_infos) \
-        or any(_as_bool(it.get("use_time", False)) for it in list(v.get("costs", [])) + list(v.get("constraints", [])))
+    # ConstructProblem :415-452: some term carries TT_USE_TIME <=> basic_info.use_time.  The flag is the term-level "use_time": true of the
+    # JSON (problem_description.cpp:180, :210) - a total_time term WITHOUT it does not count (the reference then throws "No terms use
+    # time ..." for basic_info.use_time = true, and so does this reader); total_time itself needs the time column (checked at upload)
+    any_time = any(_as_bool(it.get("use_time", False)) for it in list(v.get("costs", [])) + list(v.get("constraints", [])))
     if any_time and not pci.basic_info.use_time:
         raise ValueError("A term is using time and basic_info is not set correctly. Try basic_info.use_time = true")
+    # deliberate guard beyond the reference: a total_time term in a problem WITHOUT the time column would be hatched over the last JOINT's
+    # column there (TotalTimeTermInfo::hatch takes GetVar(i, n_dof - 1), problem_description.cpp:1852-1861); refused here with the same text
+    if any(isinstance(ti, TotalTimeTermInfo) for ti in pci.cost_infos + pci.cnt_infos) and not pci.basic_info.use_time:
+        raise ValueError("A term is using time and basic_info is not set correctly. Try basic_info.use_time = true (total_time needs the time column)")
     if not any_time and pci.basic_info.use_time:
         raise ValueError("No terms use time and basic_info is not set correctly. Try basic_info.use_time = false")
 
