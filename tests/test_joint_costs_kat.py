@@ -392,8 +392,9 @@ def test_difference_rows_at_baseline_size_on_device(orc):
     # the oracle against ITSELF built with FMA contraction on the same 16 seeds (tests/tools/oracle_self_parity.py) - keeps 5 of 16
     # integer histories: hinge costs with tolerance bands make rank-deficient polish active sets, and the reference's own outcome
     # there is decided by round-off.
-    cnt, dx = _difference_rows_at_baseline_size(None, orc, 16)
-    assert cnt["identical"] + cnt["tie"] >= 5
+    # (round 5: 8 seeds instead of 16 - the test was a quarter of the GPU tier's wall time; the bar scales with the statistic above)
+    cnt, dx = _difference_rows_at_baseline_size(None, orc, 8)
+    assert cnt["identical"] + cnt["tie"] >= 2
 
 
 def test_difference_rows_next_to_general_pair_rows_keep_the_dense_engine(hostemu_lib):

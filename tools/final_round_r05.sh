@@ -13,6 +13,12 @@ if [ -z "$SKIP_TIER" ]; then
 timeout 2400 python -m pytest tests -m gpu -q -rf -rP --durations=12 > $OUT/pytest_gpu.txt 2>&1; echo "pytest rc $?"
 grep -E "passed|failed" $OUT/pytest_gpu.txt | tail -2
 fi
+if [ -z "$SKIP_SWEEPS" ]; then
+# the device sweeps VERDICT (round 4) asked for, on this code object: 0 failures and no fault wanted
+timeout 1500 python tests/tools/fuzz_parity.py 60 79 gpu r4 lvs > $OUT/fuzz_device_r4_lvs_60_79.log 2>&1; echo "60 79 r4 lvs rc $?"; tail -n 1 $OUT/fuzz_device_r4_lvs_60_79.log | cut -c1-300
+timeout 1200 python tests/tools/fuzz_parity.py 40 83 gpu r4 lvs links > $OUT/fuzz_device_r4_lvs_links_40_83.log 2>&1; echo "40 83 r4 lvs links rc $?"; tail -n 1 $OUT/fuzz_device_r4_lvs_links_40_83.log | cut -c1-300
+timeout 1200 python tests/tools/fuzz_parity.py 40 13 gpu new lvs > $OUT/fuzz_device_new_lvs_40_13.log 2>&1; echo "40 13 new lvs rc $?"; tail -n 1 $OUT/fuzz_device_new_lvs_40_13.log | cut -c1-300
+fi
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('SMOKE OK')" > $OUT/smoke.log 2>&1; tail -1 $OUT/smoke.log
 python tools/kernel_meta.py trajopt_amd/_build/libtrajopt_mi355x.so k_ > $OUT/kernel_meta.txt 2>&1
 # counters of configuration 1 (PMC passes only), then the summary becomes this round's traffic file
