@@ -215,3 +215,56 @@ def test_time_problems_whole_sqp_on_device(gpu_ctx_factory, orc, orc_fma, cid):
     ctx = gpu_ctx_factory()
     _history_check(ctx, orc, orc_fma, cid, 32 if cid == 50 else 8)   # (config 50 = the reference's arm_around_table with time: 32 seeds)
     ctx.close()
+
+
+# ---- function terms INSIDE a time-parameterised problem (round 5; refused until round 4) ----------------------------------------------
+# UserDefinedTermInfo::hatch hands the function prob.GetVarRow(s, 0, n_dof) (problem_description.cpp:611-660): the JOINT columns of the
+# waypoint - the time column is not one of its variables (zero Jacobian / Hessian entries there).
+def _time_problem_with_function_terms():
+    from trajopt_amd.problem import Ex, FuncConstraintTermInfo, FuncCostTermInfo, UserDefinedTermInfo, ex_cos, ex_sin, sq
+    pci, s, g = pc.cfg(53)   # rows-only time problem: structured solver; the function cost adds dynamic objective blocks (QpWs::pb)
+    n, D = pci.basic_info.n_steps, pci.robot.n_dof
+    x = [Ex.var(i) for i in range(D)]
+    # (no pair of variables without a coupling: an entry of the projected Hessian that is MATHEMATICALLY zero exists or not in P depending
+    #  on round-off - parity_checks' "csc-noise" - and would make every history part at its second QP)
+    f = 0.2 * sq(x[0] - 0.3 * x[1]) + 0.05 * ex_cos(x[2] + 0.5 * x[D - 1]) + 0.1 * sq(x[D - 1]) + 0.02 * x[0] * x[2] + 0.03 * x[1] * x[D - 1] + 0.01 * x[0] * x[D - 1] + 0.015 * x[1] * x[2]
+    pci.cost_infos.append(FuncCostTermInfo(f=f, first_step=1, last_step=n - 2, full_hessian=True, name="posture"))
+    pci.cost_infos.append(UserDefinedTermInfo(error_function=[ex_sin(x[0]) - 0.2 * x[1]], first_step=1, last_step=n - 2, coeff=[0.5],
+                                              cost_penalty_type=abi.PENALTY_ABS, name="shape"))
+    pci.cnt_infos.append(FuncConstraintTermInfo(g=[x[1] + 0.5 * x[2] - 0.1], first_step=n // 2, last_step=n // 2, ineq=True, name="half_plane"))
+    return pci, s, g
+
+
+def _check_time_problem_with_function_terms(ctx, orc, B):
+    pci, s, g = _time_problem_with_function_terms()
+    x0 = seeds_time(53, pci, s, g, B)
+    desc = pc.make_ctx_inputs(ctx, pci, x0)
+    pc.check_evaluate(ctx, orc, desc, x0, tol=1e-12)
+    for b in range(min(B, 2)):
+        pc.check_first_qp_structure(ctx, orc, desc, x0, b, val_tol=1e-9)
+    res = pc.check_first_qp_solve(ctx, orc, desc, x0, require_same_iters=False)
+    trace = []
+    classes, dx, _ = pc.sqp_history_classes(ctx, orc, desc, x0, trace=trace)
+    parted = {t["seed"]: t["first_qp"] for t in trace}
+    print(f"time problem + function terms: first QPs with the oracle's history {sum(sm for sm, _ in res)}/{B}, classes {classes}, "
+          f"parting QP {parted}, |dx| {np.round(dx, 8)}")
+    # these runs are ~100 QPs long with up to 15 rho updates per solve (bilinear rows, no TotalTime term to anchor the time column):
+    # the histories agree for the first tens of QPs and part at an ADMM-level integer (host build: QP 20 of 95 / 108 on both seeds).
+    # Required: nothing structural ever differs, and every run follows the oracle QP by QP through its first eight solves.
+    assert all(c in ("identical", "tie", "admm") for c in classes), classes
+    assert all(q >= 8 for q in parted.values()), parted
+
+
+def test_function_terms_in_a_time_problem_on_host_build(hostemu_lib, orc):
+    import os
+    os.environ.setdefault("TMX_DENSE_QP_MAX_N", "2000")
+    ctx = runtime.Context(0, hostemu_lib)
+    _check_time_problem_with_function_terms(ctx, orc, 2)
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_function_terms_in_a_time_problem_on_device(gpu_ctx_factory, orc):
+    ctx = gpu_ctx_factory()
+    _check_time_problem_with_function_terms(ctx, orc, 4)
+    ctx.close()

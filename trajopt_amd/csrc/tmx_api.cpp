@@ -713,9 +713,10 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
             ctx->err = "TMX_FLAVOR_SQP: function terms are not part of the trajopt_sqp path";
             return TMX_ERR_UNSUPPORTED;
           }
-          if (d->use_time)
+          if (d->use_time && builtin)
           {
-            ctx->err = "function terms (user-defined functions, AvoidSingularity, DynamicCartPose, CartPose with a tolerance band) are not lowered "
+            // (user-defined functions are: they see the joint columns of their waypoint, prob.GetVarRow(s, 0, n_dof) - round 5)
+            ctx->err = "the built-in kinematic function terms (AvoidSingularity, DynamicCartPose, CartPose with a tolerance band) are not lowered "
                        "for time-parameterised problems";
             return TMX_ERR_UNSUPPORTED;
           }

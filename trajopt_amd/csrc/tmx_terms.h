@@ -1486,25 +1486,46 @@ TMX_DEVFN void convexify_func_terms(const DevProblem* P, const double* xv, int* 
                                     double* fxc, double* fxW, int tid, int NT)
 {
   const int D = P->D;
+  // the function sees the JOINT values of its waypoint: prob.GetVarRow(s, 0, n_dof) (problem_description.cpp:611-660) - in a
+  // time-parameterised problem (D = DK + 1) the time column is not one of its variables: zero Jacobian / Hessian entries there (round 5)
+  const int KV = P->DK;
   for (int c = tid; c < P->n_fx; c += NT)
   {
     const double* q = xv + P->fx_t[c] * D;
     if (fx_is_quad(P->fx_kind[c]))
     {
       const int ci = P->fx_ci[c];
-      fx_convexify_cost(P, c, q, D, fxH + (size_t)ci * D * D, fxg + (size_t)ci * D, fxc + ci, fxW + (size_t)ci * 2 * D * D);
+      double* Hc = fxH + (size_t)ci * D * D;
+      double* gc = fxg + (size_t)ci * D;
+      fx_convexify_cost(P, c, q, KV, Hc, gc, fxc + ci, fxW + (size_t)ci * 2 * D * D);
+      if (KV < D)
+      {
+        // the KV x KV model in the D x D storage every consumer indexes: rows moved apart from the last entry down, padding zeroed
+        for (int i = KV - 1; i >= 0; --i)
+          for (int j = KV - 1; j >= 0; --j)
+            Hc[i * D + j] = Hc[i * KV + j];
+        for (int i = 0; i < D; ++i)
+          for (int j = 0; j < D; ++j)
+            if (i >= KV || j >= KV)
+              Hc[i * D + j] = 0.0;
+        for (int j = KV; j < D; ++j)
+          gc[j] = 0.0;
+      }
       continue;
     }
     double x[TMX_MAX_DOF], y[TMX_EXPR_MAX_OUT], yp[TMX_EXPR_MAX_OUT];
     double J[TMX_EXPR_MAX_OUT][TMX_MAX_DOF];
     for (int i = 0; i < D; ++i)
       x[i] = q[i];
+    for (int o = 0; o < TMX_EXPR_MAX_OUT; ++o)
+      for (int i = KV; i < D; ++i)
+        J[o][i] = 0.0;
     const int no = P->fx_nout[c];
     fx_eval(P, c, x, y);  // calcForwardNumJac evaluates f(x) first (num_diff.cpp:57), convex() once more for y (:252): same value
     if (P->fx_nops[c] < 0)
       fx_builtin_jac(P, c, x, J);  // the calculators' own dfdx (modeling_utils.cpp:171, :250)
     else
-      for (int i = 0; i < D; ++i)
+      for (int i = 0; i < KV; ++i)
       {
         const double xi = x[i];
         x[i] = xi + TMX_EPS_FD;
@@ -1519,7 +1540,7 @@ TMX_DEVFN void convexify_func_terms(const DevProblem* P, const double* xv, int* 
       if (!(P->slot_kind[r] == SLOT_FUNC && P->slot_sub2[r] == c && P->slot_sub[r] == o))
         continue;  // row dropped at upload (zero coefficient, :258-259)
       double dot = 0.0;
-      for (int k = 0; k < D; ++k)
+      for (int k = 0; k < KV; ++k)
         dot += J[o][k] * x[k];
       const double cc = P->slot_scale[r];
       const double constant = (y[o] - dot) * cc;
