@@ -1281,6 +1281,12 @@ TMX_DEVFN void qp_admm_generic_loop(QpWs& w, const DevProblem* P, QpInfo& info, 
 // one load + wait per term - with the additions in the same order (results bit-identical).
 // BAND = true: the instantiation for banded objectives (acceleration / jerk costs; never with pair rows).  Every other
 // instantiation keeps the literal band = 0 of qp_ws_carve: no banded code, no calls in the loops of configs 1 - 4.
+#ifndef TMX_D10_INSTANTIATION
+#define TMX_D10_INSTANTIATION 1  // block-size-10 instantiation of the pair-row loop for config 3 (10-DOF arm + positioner, HBM workspace): +21.6 %,
+                                 // bit-identical (profiles/r05/r05j_ab_d10_instantiation_cfg3.log).  Rounds 3 - 4 recorded it as "faulted in the
+                                 // 512-thread HBM kernel - memory access fault at address 0, not understood": the stale register of round 5's
+                                 // END_CF finding (trajopt_amd/csrc/Makefile)
+#endif
 template <bool HBM, bool PAIRS, int DC, bool BAND = false>
 __device__ __attribute__((noinline)) static void qp_admm_generic_nl(const DevProblem* P_in, const DevBatch* Bt_in, int b_in, unsigned lds_in,
                                                                   double* work_in, int chain_in_lds)
@@ -1945,15 +1951,18 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
       unsigned lds_off = (unsigned)(size_t)(HBM ? chain_lds : smem);
       TMX_ASM_OPAQUE_SGPR(lds_off);
     {
-      // instantiations: with / without pair rows; block size 7 (7-DOF arms: configs 2 and 4) as a compile-time constant.  (A D = 10
-      // instantiation for config 3 faulted in the 512-thread HBM kernel - memory access fault at address 0, not understood - and is
-      // not built.)
+      // instantiations: with / without pair rows; block size 7 (7-DOF arms: configs 2 and 4) and, for the HBM-workspace pair-row
+      // problems, 10 (config 3) as compile-time constants
       if (ROWSK && BANDK && P->band && P->n_link > 0)  // banded path with difference rows of order 2 / 3 (DevProblem::band_rows)
         qp_admm_generic_nl<HBM, true, 0, true>(P, Bt, b, lds_off, HBM ? smem : nullptr, chain_lds != nullptr ? 1 : 0);
       else if (P->n_link > 0)
       {
         if (P->D == 7)
           qp_admm_generic_nl<HBM, true, 7>(P, Bt, b, lds_off, HBM ? smem : nullptr, chain_lds != nullptr ? 1 : 0);
+#if TMX_D10_INSTANTIATION
+        else if (HBM && P->D == 10)  // config 3 (10-DOF arm + positioner, HBM workspace)
+          qp_admm_generic_nl<HBM, true, 10>(P, Bt, b, lds_off, HBM ? smem : nullptr, chain_lds != nullptr ? 1 : 0);
+#endif
         else
           qp_admm_generic_nl<HBM, true, 0>(P, Bt, b, lds_off, HBM ? smem : nullptr, chain_lds != nullptr ? 1 : 0);
       }
