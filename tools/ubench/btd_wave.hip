@@ -11,6 +11,8 @@
 //   fewer cycles than that (<= 3.0 k) at its best K to be worth a rewrite of the solver around it.
 //   RESULT (MI355X, profiles/r05/r05k_btd_wave_prototype.log): K = 1: 12 242, K = 2: 6 703, K = 4: 3 701, K = 8: 2 388 cycles per
 //   problem-iteration per CU (one wave alone: 11 963 cycles per iteration, i.e. ~180 per chain step); device = host to 2e-15.
+//   Factorisation on the wave (30 sequential 7 x 7 Gauss-Jordan inversions, a matrix row per lane): 58 k cycles alone, 14.2 k cycles per
+//   problem-factorisation per CU at K = 8.
 //
 // build: hipcc -O3 --offload-arch=gfx950 -Wno-unused-value -Wno-deprecated-declarations -o btd_wave btd_wave.hip      run: ./btd_wave [iters]
 #include <hip/hip_runtime.h>
@@ -61,7 +63,7 @@ __device__ __forceinline__ double red_x(double p)
   return swap32_add(p);
 }
 
-struct Params { const double *Fg, *Sg, *Ag, *ug, *qg; double* xout; long long* clk; int iters; double sigma, rho, alpha, bound; };
+struct Params { const double *Ag, *ug, *qg; double* xout; long long *clk, *clkf; int iters, nfac; double sigma, rho, alpha, bound, cvel; };
 
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_btd(Params P)
 {
@@ -71,12 +73,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   double* xt = v + LDS_V;            // x~_t
   double* zr = xt + LDS_V;           // zeros (addend of the lanes that do not inject)
   const int lane = threadIdx.x, a = lane >> 3, b = lane & 7, prob = blockIdx.x;
-  for (int k = lane; k < LDS_SINV; k += 64) Sinv[k] = P.Sg[k];
-  for (int k = lane; k < 3 * LDS_V; k += 64) v[k] = 0.0;
-  // chain matrices: one entry per lane and step, already negated and in the storage of the step (host)
-  double F[T - 1];
-#pragma unroll
-  for (int t = 0; t < T - 1; ++t) F[t] = P.Fg[t * 64 + lane];
+  for (int k = lane; k < LDS_SINV + 3 * LDS_V; k += 64) lds[k] = 0.0;
   // row-phase role: lane pair = waypoint, each lane RH rows and four variable slots (the fourth of the odd lane is padding)
   const int tw = min(lane >> 1, T - 1), h = lane & 1;
   double A[RH][D], z[RH], y[RH], u[RH], x[4], zb[4], yb[4], q[4];
@@ -97,6 +94,92 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     x[k] = 0.0; zb[k] = 0.0; yb[k] = 0.0;
   }
   const double sigma = P.sigma, rho = P.rho, rinv = 1.0 / P.rho, alpha = P.alpha, oma = 1.0 - P.alpha, B = P.bound;
+  // ---- factorisation on the one wave (repeated P.nfac times for the timer): (A) the diagonal blocks K_t = P_tt + sigma I + rho (A_t^T A_t + I),
+  // waypoint-parallel (lane pair: upper triangle over its ten rows), into the S^{-1} region; (B) the sequential part, one matrix ROW per
+  // lane (lanes 0..6), in-place Gauss-Jordan with v_readlane pivots: S_t = K_t - E S_{t-1}^{-1} E (E = -cvel I), S_t^{-1} back in place;
+  // (C) the chain registers F_t = E S_{t-1}^{-1} in the lane-grid storage of step t
+  __syncthreads();
+  const long long f0 = __builtin_readcyclecounter();
+  double F[T - 1];
+  for (int rep = 0; rep < P.nfac; ++rep)
+  {
+    {
+      double kk[D * (D + 1) / 2];
+      int idx = 0;
+#pragma unroll
+      for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = i; j < D; ++j)
+        {
+          double sacc = 0.0;
+#pragma unroll
+          for (int r = 0; r < RH; ++r) sacc = __builtin_fma(rho * A[r][i], A[r][j], sacc);
+          kk[idx++] = dpp_add<0xB1>(sacc);
+        }
+      const double dg = ((tw == 0 || tw == T - 1) ? 1.0 : 2.0) * P.cvel + 1e-3 + sigma + rho;
+      if (h == 0)
+      {
+        idx = 0;
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+          for (int j = i; j < D; ++j)
+          {
+            const double e = kk[idx++] + (i == j ? dg : 0.0);
+            Sinv[(tw * D + i) * 8 + j] = e;
+            Sinv[(tw * D + j) * 8 + i] = e;
+          }
+      }
+    }
+    __syncthreads();
+    {
+      const int il = min(lane, D - 1);
+      const double c2 = P.cvel * P.cvel;
+      double M[D], Sp[D];
+#pragma unroll
+      for (int j = 0; j < D; ++j) Sp[j] = 0.0;
+      for (int t = 0; t < T; ++t)
+      {
+#pragma unroll
+        for (int j = 0; j < D; ++j) M[j] = __builtin_fma(-c2, Sp[j], Sinv[(t * D + il) * 8 + j]);
+#pragma unroll
+        for (int c = 0; c < D; ++c)
+        {
+          double pr[D];
+#pragma unroll
+          for (int j = 0; j < D; ++j)
+            pr[j] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(M[j]), c), __builtin_amdgcn_readlane(__double2loint(M[j]), c));
+          const double inv = 1.0 / pr[c];
+          const double f = M[c] * inv;
+          const bool piv = (lane == c);
+#pragma unroll
+          for (int j = 0; j < D; ++j)
+          {
+            if (j == c) M[j] = piv ? inv : -f;
+            else M[j] = piv ? pr[j] * inv : __builtin_fma(-f, pr[j], M[j]);
+          }
+        }
+        if (lane < D)
+        {
+#pragma unroll
+          for (int j = 0; j < D; ++j) Sinv[(t * D + il) * 8 + j] = M[j];
+        }
+#pragma unroll
+        for (int j = 0; j < D; ++j) Sp[j] = M[j];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 1; t < T; ++t)
+    {
+      const int ia = min(a, D - 1), ib = min(b, D - 1);
+      const double sv = (t & 1) ? Sinv[((t - 1) * D + ia) * 8 + ib] : Sinv[((t - 1) * D + ib) * 8 + ia];
+      F[t - 1] = (a < D && b < D) ? P.cvel * sv : 0.0;    // -F_t = cvel S_{t-1}^{-1}
+    }
+    __syncthreads();
+  }
+  const long long f1 = __builtin_readcyclecounter();
+  if (lane == 0) P.clkf[prob] = f1 - f0;
   // per-lane LDS addresses of the chain (in doubles; the step adds t * 8 as an immediate)
   const int addA = (b == 0) ? (int)(v - lds) + a : (int)(zr - lds) + a;    // addend of a step that reduces over b (result by a)
   const int addB = (a == 0) ? (int)(v - lds) + b : (int)(zr - lds) + b;    // addend of a step that reduces over a (result by b)
@@ -277,15 +360,6 @@ int main(int argc, char** argv)
     }
     inv7(&S[t * D * D], &Si[t * D * D]);
   }
-  // device layouts
-  std::vector<double> Fg((size_t)(T - 1) * 64, 0.0), Sg((size_t)LDS_SINV, 0.0);
-  for (int t = 1; t < T; ++t)
-    for (int lane = 0; lane < 64; ++lane)
-    {
-      const int a = lane >> 3, b = lane & 7;
-      if (a < D && b < D) Fg[(t - 1) * 64 + lane] = -((t & 1) ? F[(t * D + a) * D + b] : F[(t * D + b) * D + a]);
-    }
-  for (int t = 0; t < T; ++t) for (int i = 0; i < D; ++i) for (int j = 0; j < D; ++j) Sg[(t * D + i) * 8 + j] = Si[(t * D + i) * D + j];
   // reference iteration (problem 0: q scale 1)
   auto reference = [&](int n_it, std::vector<double>& xo)
   {
@@ -345,18 +419,17 @@ int main(int argc, char** argv)
   hipDeviceProp_t prop; hipGetDeviceProperties(&prop, 0);
   const int n_cu = prop.multiProcessorCount;
   const double ghz = prop.clockRate * 1e-6;
-  double *dF, *dS, *dA, *du, *dq, *dx; long long* dclk;
+  double *dA, *du, *dq, *dx; long long *dclk, *dclkf;
   const int maxB = n_cu * 8;
-  hipMalloc(&dF, Fg.size() * 8); hipMalloc(&dS, Sg.size() * 8); hipMalloc(&dA, A.size() * 8); hipMalloc(&du, u.size() * 8); hipMalloc(&dq, q.size() * 8);
-  hipMalloc(&dx, (size_t)maxB * T * D * 8); hipMalloc(&dclk, (size_t)maxB * 8);
-  hipMemcpy(dF, Fg.data(), Fg.size() * 8, hipMemcpyHostToDevice); hipMemcpy(dS, Sg.data(), Sg.size() * 8, hipMemcpyHostToDevice);
+  hipMalloc(&dA, A.size() * 8); hipMalloc(&du, u.size() * 8); hipMalloc(&dq, q.size() * 8);
+  hipMalloc(&dx, (size_t)maxB * T * D * 8); hipMalloc(&dclk, (size_t)maxB * 8); hipMalloc(&dclkf, (size_t)maxB * 8);
   hipMemcpy(dA, A.data(), A.size() * 8, hipMemcpyHostToDevice); hipMemcpy(du, u.data(), u.size() * 8, hipMemcpyHostToDevice);
   hipMemcpy(dq, q.data(), q.size() * 8, hipMemcpyHostToDevice);
   hipFuncSetAttribute((const void*)k_btd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   printf("device %s, %d CUs, %.2f GHz; T = %d, D = %d, R = %d rows + %d bound rows per waypoint; LDS needed %zu B per problem\n", prop.name, n_cu, ghz, T, D, R, D,
          (size_t)LDS_DOUBLES * 8);
-  Params P{ dF, dS, dA, du, dq, dx, dclk, check_iters, sigma, rho, alpha, bound };
-  // correctness: problem 0 against the host iteration
+  Params P{ dA, du, dq, dx, dclk, dclkf, check_iters, 1, sigma, rho, alpha, bound, cvel };
+  // correctness: problem 0 (factorised on the device) against the host iteration on the host's factors
   {
     hipLaunchKernelGGL(k_btd, dim3(4), dim3(64), (size_t)LDS_DOUBLES * 8, 0, P);
     if (hipDeviceSynchronize() != hipSuccess) { printf("kernel failed\n"); return 1; }
@@ -366,12 +439,11 @@ int main(int argc, char** argv)
     printf("check after %d iterations: max |x_device - x_host| = %.3e (max |x| = %.3f) %s\n", check_iters, e, m, e < 1e-9 * std::max(1.0, m) ? "OK" : "MISMATCH");
     if (!(e < 1e-9 * std::max(1.0, m))) return 2;
   }
-  P.iters = iters;
-  printf("%-10s %-12s %-14s %-22s %-26s %-20s\n", "K per CU", "LDS request", "kernel ms", "cycles/iter per wave", "cycles per problem-iter/CU", "problem-iters/s/GPU");
-  for (int K : { 1, 2, 4, 8 })
+  auto run = [&](int K, int n_it, int n_fac, double& ms_best, double& cyc_loop, double& cyc_fac)
   {
     const size_t smem = std::max((size_t)LDS_DOUBLES * 8, (size_t)(160 * 1024 / K));
     const int grid = n_cu * K;
+    P.iters = n_it; P.nfac = n_fac;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     float best = 1e30f;
     for (int rep = 0; rep < 3; ++rep)
@@ -379,13 +451,29 @@ int main(int argc, char** argv)
       hipEventRecord(e0, 0);
       hipLaunchKernelGGL(k_btd, dim3(grid), dim3(64), smem, 0, P);
       hipEventRecord(e1, 0);
-      if (hipEventSynchronize(e1) != hipSuccess) { printf("kernel failed\n"); return 1; }
+      if (hipEventSynchronize(e1) != hipSuccess) { printf("kernel failed\n"); exit(1); }
       float ms; hipEventElapsedTime(&ms, e0, e1); best = std::min(best, ms);
     }
-    std::vector<long long> clk(grid); hipMemcpy(clk.data(), dclk, (size_t)grid * 8, hipMemcpyDeviceToHost);
-    double cavg = 0.0; for (long long c : clk) cavg += (double)c; cavg /= grid;
-    const double per_cu_cycles = best * 1e-3 * ghz * 1e9 / ((double)K * iters);
-    printf("%-10d %-12zu %-14.3f %-22.0f %-26.0f %-20.3e\n", K, smem, best, cavg / iters, per_cu_cycles, (double)grid * iters / (best * 1e-3));
+    std::vector<long long> clk(grid), clkf(grid);
+    hipMemcpy(clk.data(), dclk, (size_t)grid * 8, hipMemcpyDeviceToHost); hipMemcpy(clkf.data(), dclkf, (size_t)grid * 8, hipMemcpyDeviceToHost);
+    cyc_loop = 0.0; cyc_fac = 0.0;
+    for (int k = 0; k < grid; ++k) { cyc_loop += (double)clk[k]; cyc_fac += (double)clkf[k]; }
+    cyc_loop /= grid; cyc_fac /= grid; ms_best = best;
+  };
+  printf("ADMM loop (%d iterations after one factorisation)\n", iters);
+  printf("%-10s %-14s %-22s %-28s %-20s\n", "K per CU", "kernel ms", "cycles/iter per wave", "cycles per problem-iter per CU", "problem-iters/s/GPU");
+  for (int K : { 1, 2, 4, 8 })
+  {
+    double ms, cl, cf; run(K, iters, 1, ms, cl, cf);
+    printf("%-10d %-14.3f %-22.0f %-28.0f %-20.3e\n", K, ms, cl / iters, (ms * 1e-3 * ghz * 1e9 - cf) / ((double)K * iters), (double)n_cu * K * iters / (ms * 1e-3));
+  }
+  const int nfac = 40;
+  printf("factorisation alone (%d per problem, no iterations)\n", nfac);
+  printf("%-10s %-14s %-28s %-34s\n", "K per CU", "kernel ms", "cycles per factorisation, wave", "cycles per problem-factorisation per CU");
+  for (int K : { 1, 2, 4, 8 })
+  {
+    double ms, cl, cf; run(K, 0, nfac, ms, cl, cf);
+    printf("%-10d %-14.3f %-28.0f %-34.0f\n", K, ms, cf / nfac, ms * 1e-3 * ghz * 1e9 / ((double)K * nfac));
   }
   return 0;
 }
