@@ -523,13 +523,23 @@ def sqp_history_classes(ctx, orc, desc, x0, max_qp=128, detail=None, trace=None)
         k = -1
         struct = lambda t: (t.n, t.m, t.nnzP, t.hashP)
         admm = lambda t: (t.osqp_status, t.osqp_iter, t.rho_updates, t.polish_status)
+        rho_drift = None   # first QP whose final rho differs beyond round-off although every integer of its record agrees
         for k in range(max(len(dev[b]), len(oq))):
             if k >= len(dev[b]) or k >= len(oq):
-                cls = "other"
-                why = f"history lengths {len(dev[b])} vs {len(oq)}"
+                # One run went on after the other had stopped: an SQP-level decision (min_approx_improve, the trust-box floor, the
+                # improve-ratio test) fell on the other side although every QP record up to here agrees.  Explained - class "admm" - only
+                # if the ADMM runs had already parted in their adaptive rho (fuzz case 91/36 of `r4 lvs`, host build and device alike: a
+                # warm-started QP whose dual residual at the first rho check is at the round-off floor of the linear solve, 2.9e-12
+                # with QDLDL, 1.9e-11 with the dense engine's explicit inverse; rho * sqrt(prim / dual) = 6368 vs 2465, both runs update
+                # rho twice and exit at iteration 150, final rho 0.0625 vs 0.0335 - the QP solutions then differ by 1e-5 and three QPs
+                # later approx_merit_improve is 1.5e-4 on one side and 0.9e-4 on the other of min_approx_improve = 1e-4)
+                cls = "admm" if rho_drift is not None else "other"
+                why = f"history lengths {len(dev[b])} vs {len(oq)}" + (f" after rho drift at QP {rho_drift}" if rho_drift is not None else "")
                 break
             r, f, y, dataless = dev[b][k]
             o = ob["records"][k]
+            if rho_drift is None and abs(r.rho_final - o.rho_final) > 1e-9 * abs(o.rho_final):
+                rho_drift = k
             if struct(r) != struct(o):
                 # P of a problem with state-dependent Hessian blocks (squared velocity-with-time costs, function costs) is subject to the
                 # same rule as A: exprToEigen(QuadExpr) keeps every coefficient that is not EXACTLY 0.0 (solver_utils.cpp:51-110), so an
@@ -573,7 +583,7 @@ def sqp_history_classes(ctx, orc, desc, x0, max_qp=128, detail=None, trace=None)
                 cls = "admm" if drift else "other"
                 break
         if cls in ("identical", "tie") and (res["status"][b] != ob["status"][0] or res["n_qp_solves"][b] != ob["n_qp_solves"][0]):
-            cls = "other"
+            cls = "admm" if rho_drift is not None else "other"
             why = f"final status / counters {res['status'][b]},{res['n_qp_solves'][b]} vs {ob['status'][0]},{ob['n_qp_solves'][0]}"
         if cls == "tie" and dual_tie and float(np.abs(res["x"][b] - ob["x"][0]).max()) > TOL_TRAJ:
             cls = "other"   # (why: the non-degenerate active-set difference recorded above)
