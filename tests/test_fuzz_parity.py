@@ -95,6 +95,30 @@ def test_random_problems_on_device(orc):
     _sweep(40, 5, "gpu")     # D <= 8 and n_steps * D <= 256: the dense fast path of the QP solver
 
 
+def _one_case(n, seed, case, lib, *extra):
+    env = dict(os.environ, FUZZ_ONLY=str(case))
+    p = subprocess.run([sys.executable, TOOL, str(n), str(seed), lib, *extra], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
+    return p.stdout
+
+
+def test_rho_drift_without_an_integer_difference_is_class_admm(hostemu_lib, orc):
+    """Case 91/36 of `r4 lvs` (found by a device sweep of round 5, the same on the host build): seven identical QP records, then the
+    library solves an eighth QP.  The third QP's dual residual at its first rho check sits at the round-off floor of the linear solve
+    (QDLDL 2.9e-12, the dense engine's explicit inverse 1.9e-11), rho leaves at 6368 vs 2465 and ends at 0.0625 vs 0.0335 with every
+    integer of the record equal; three QPs later approx_merit_improve falls on either side of min_approx_improve.  The harness classes a run
+    that ends at another length AFTER such a drift as "admm" (DESIGN.md section 8, item 8); without drift it would stay "other" and fail."""
+    out = _one_case(60, 91, 36, hostemu_lib, "r4", "lvs")
+    assert "1 identical integer history" in out and "1 at an ADMM-level integer after rho drift" in out and "0 other" in out
+
+
+def test_identical_history_is_judged_against_the_oracles_own_fma_spread(hostemu_lib, orc):
+    """Case 23/24 of `wide` (6-DOF pose constraint over five waypoints): identical histories end 1.1e-5 apart - and the oracle ends 2.2e-5
+    from its own FMA build on the same seed; accepted within twice that spread, printed as a note"""
+    out = _one_case(30, 23, 24, hostemu_lib, "wide")
+    assert "within twice the oracle's own FMA spread" in out and "0 failures" in out
+
+
 @pytest.mark.parametrize("seed,case", [(2, 26), (2, 50), (2, 78), (2, 59), (2, 68), (2, 91)])
 def test_polish_regression_cases(hostemu_lib, orc, seed, case):
     """Random QPs on which the first device polish (1/delta row weights folded into the right-hand sides) lost 12 digits
