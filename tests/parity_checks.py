@@ -601,7 +601,13 @@ def sqp_history_classes(ctx, orc, desc, x0, max_qp=128, detail=None, trace=None)
         # variables 1e-4 apart (tests/tools/fuzz_parity.py 24 71 <host build> r4 lvs, case 15) - so it is compared at 1e-3
         dj = np.abs(res["x"][b] - ob["x"][0])
         if desc.use_time:
-            assert dj[:, desc.n_dof:].max() <= 1e-3 or cls not in ("identical", "tie"), f"time column of an identical history differs by {dj[:, desc.n_dof:].max()}"
+            dt_col = float(dj[:, desc.n_dof:].max())
+            if dt_col > 1e-3 and cls in ("identical", "tie"):
+                # the yardstick before the verdict (fuzz case 111/69 of `r4 lvs links`, host build: identical history, joints 1.3e-6 and time
+                # column 1.4e-3 from the oracle - which ends 1.3e-6 / 2.0e-3 from ITS OWN FMA build on that seed)
+                f = orc.variant("fma").sqp_batch(desc, x0[b:b + 1], nthreads=1)
+                dself = float(np.abs(ob["x"][0] - f["x"][0])[:, desc.n_dof:].max())
+                assert dt_col <= 2.0 * dself, f"time column of an identical history differs by {dt_col} (the oracle against its FMA build: {dself})"
             dj = dj[:, :desc.n_dof]
         dxs.append(float(dj.max()))
     return classes, np.array(dxs), res

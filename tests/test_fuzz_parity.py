@@ -119,6 +119,13 @@ def test_identical_history_is_judged_against_the_oracles_own_fma_spread(hostemu_
     assert "within twice the oracle's own FMA spread" in out and "0 failures" in out
 
 
+def test_time_column_of_an_identical_history_is_judged_against_the_oracles_own_fma_spread(hostemu_lib, orc):
+    """Case 111/69 of `r4 lvs links` (2-DOF time problem): identical history, joints 1.3e-6 and time column 1.4e-3 from the oracle, which ends
+    2.0e-3 from its own FMA build in that column (a flat direction of the QP; parity_checks.sqp_history_classes)"""
+    out = _one_case(80, 111, 69, hostemu_lib, "r4", "lvs", "links")
+    assert "0 failures" in out and "0 other" in out
+
+
 @pytest.mark.parametrize("seed,case", [(2, 26), (2, 50), (2, 78), (2, 59), (2, 68), (2, 91)])
 def test_polish_regression_cases(hostemu_lib, orc, seed, case):
     """Random QPs on which the first device polish (1/delta row weights folded into the right-hand sides) lost 12 digits
