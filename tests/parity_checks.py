@@ -546,15 +546,16 @@ def sqp_history_classes(ctx, orc, desc, x0, max_qp=128, detail=None, trace=None)
                 # entry that is mathematically zero exists or not depending on the last bits of x - from the second QP on only, and only
                 # a few entries (fuzz case 83/1 of `r4 lvs links`, host build and device alike: nnz(P) 92 vs 90 at QP 5, |dx| 8.6e-6)
                 noise = k > 0 and (r.n, r.m) == (o.n, o.m) and abs(r.nnzP - o.nnzP) <= 16 and r.nnzP != o.nnzP
-                cls = "csc-noise" if noise else "other"
-                why = f"QP structure {struct(r)} vs {struct(o)}"
+                # (after a rho drift the two runs convexify at iterates 1e-6 ... 1e-4 apart: a contact more or less, another slack count)
+                cls = "csc-noise" if noise else ("admm" if rho_drift is not None else "other")
+                why = f"QP structure {struct(r)} vs {struct(o)}" + (f" after rho drift at QP {rho_drift}" if rho_drift is not None else "")
                 break
             if (r.nnzA, r.hashA) != (o.nnzA, o.hashA):
-                cls = "csc-noise" if k > 0 and abs(r.nnzA - o.nnzA) <= 16 else "other"
+                cls = "csc-noise" if k > 0 and abs(r.nnzA - o.nnzA) <= 16 else ("admm" if rho_drift is not None else "other")
                 why = f"A: nnz {r.nnzA} vs {o.nnzA}"
                 break
             if r.warm_started != o.warm_started:
-                cls = "other"
+                cls = "admm" if rho_drift is not None else "other"
                 why = f"warm start {r.warm_started} vs {o.warm_started}"
                 break
             if admm(r) != admm(o):
@@ -568,7 +569,7 @@ def sqp_history_classes(ctx, orc, desc, x0, max_qp=128, detail=None, trace=None)
                     cls = "tie"
                     continue
                 # a non-degenerate active-set difference is only explained when the two ADMM runs already used different rho ...
-                drift = abs(r.rho_final - o.rho_final) > 1e-9 * abs(o.rho_final)   # round-off alone leaves rho equal to ~1e-13
+                drift = rho_drift is not None or abs(r.rho_final - o.rho_final) > 1e-9 * abs(o.rho_final)   # round-off alone leaves rho equal to ~1e-13
                 why = f"non-degenerate active-set difference, rho {r.rho_final!r} vs {o.rho_final!r}, records {admm(r)}"
                 if not drift and dataless:
                     # ... or when the DUALS are not unique: the row of a pose error inside its tolerance band has no data at all
