@@ -491,7 +491,28 @@ def sqp_history_classes(ctx, orc, desc, x0, max_qp=128, detail=None, trace=None)
             return len(owners) == 1 and dataless(owners[0])
         return all(ok(int(i)) for i in rows)
 
-    dev = [[] for _ in range(B)]   # per problem: list of (record, flags, y, differing rows are data-less equality rows)
+    def _dependent_rows(b, fdev, forc):
+        """True if the rows on which two polish active sets of problem b's CURRENT QP differ take part in a LINEAR DEPENDENCE of the rows that
+        either set calls active (bound rows included): the multipliers of such rows are not unique - two polishes return the same primal
+        point with the multipliers distributed differently over the dependent rows, non-vanishing on both sides (fuzz cases 137/72 of `new
+        lvs links` and 139/46 of `kin`, host build: same records, same rho, the runs end 4e-16 / 5e-7 rad apart)"""
+        e = ctx.export_csc(b)
+        _, A = csc_dense_ops(e)
+        Ar = A.tocsr()
+        m = e["m"]
+        act = np.nonzero((fdev[:m] != 0) | (forc[:m] != 0))[0]
+        diff = set(np.nonzero(fdev[:m] != forc[:m])[0].tolist())
+        if len(act) == 0 or not diff:
+            return False
+
+        def deficiency(rows):
+            if len(rows) == 0:
+                return 0
+            sv = np.linalg.svd(Ar[rows].toarray(), compute_uv=False)
+            return len(rows) - int((sv > 1e-9 * max(sv.max(initial=0.0), 1e-300)).sum())
+        return deficiency(act) > deficiency(np.array([r for r in act if r not in diff], dtype=np.int64))
+
+    dev = [[] for _ in range(B)]   # per problem: list of (record, flags, y, differing rows are data-less equality rows or linearly dependent)
     seen = np.zeros(B, np.int64)
     while True:
         na = ctx.run(1)
@@ -508,7 +529,7 @@ def sqp_history_classes(ctx, orc, desc, x0, max_qp=128, detail=None, trace=None)
                     same, only_ties = compare_active_sets(f, y, oq[k][0], oq[k][1])
                     if not same and not only_ties:
                         # (the QP of this step is still the one in HBM: the next convexification has not run yet)
-                        dataless = _dataless_rows(b, np.nonzero(f != oq[k][0])[0])
+                        dataless = _dataless_rows(b, np.nonzero(f != oq[k][0])[0]) or _dependent_rows(b, f, oq[k][0])
                 dev[b].append((r, f, y, dataless))
                 seen[b] = cnt[b]
         if na == 0:
