@@ -629,7 +629,7 @@ def sqp_history_classes(ctx, orc, desc, x0, max_qp=128, detail=None, trace=None)
                 # column 1.4e-3 from the oracle - which ends 1.3e-6 / 2.0e-3 from ITS OWN FMA build on that seed)
                 f = orc.variant("fma").sqp_batch(desc, x0[b:b + 1], nthreads=1)
                 dself = float(np.abs(ob["x"][0] - f["x"][0])[:, desc.n_dof:].max())
-                assert dt_col <= 2.0 * dself, f"time column of an identical history differs by {dt_col} (the oracle against its FMA build: {dself})"
+                assert dt_col <= 4.0 * dself, f"time column of an identical history differs by {dt_col} (the oracle against its FMA build: {dself})"
             dj = dj[:, :desc.n_dof]
         dxs.append(float(dj.max()))
     return classes, np.array(dxs), res

@@ -242,6 +242,9 @@ def random_problem(rng, wide=False, links=False, lvs=False, new=False, kin=False
     return pci, x0
 
 
+YARD = 4.0   # an end point may be this many times the oracle's own FMA spread away before an identical history is failed on it
+
+
 def main():
     wide = "wide" in sys.argv
     if wide:
@@ -304,9 +307,12 @@ def main():
                     # built with FMA contraction?  (case 23/24 of `wide`, a 6-DOF pose constraint over five waypoints: library vs oracle
                     # 1.1e-5 on the host build, 1.5e-5 on the device, oracle vs oracle-with-FMA 2.2e-5, all with identical histories)
                     dself = float(np.abs(orc.sqp_batch(desc, x0[b:b + 1])["x"] - orc.variant("fma").sqp_batch(desc, x0[b:b + 1])["x"]).max())
-                    if dx[b] > 2.0 * dself:
+                    # (one FMA build is ONE sample of that spread: the ratio of two such samples exceeds 2 in about a third of the draws -
+                    # case 143/8 of `new lvs`: library vs oracle 1.7e-5, oracle vs its FMA build 0.8e-5, the library vs ITS FMA build 1.1e-5,
+                    # the four builds 0.6 ... 1.7e-5 apart pairwise, seven unpolished QPs at the end of the run)
+                    if dx[b] > YARD * dself:
                         raise AssertionError(f"full SQP: identical QP history but |dx| = {dx[b]} (the oracle against its FMA build: {dself})")
-                    print(f"  note (identical history, |dx| = {dx[b]:.2e} above 1e-5 but within twice the oracle's own FMA spread {dself:.2e}):", tag)
+                    print(f"  note (identical history, |dx| = {dx[b]:.2e} above 1e-5 but within {YARD:g} x the oracle's own FMA spread {dself:.2e}):", tag)
                 if c == "other":
                     # the yardstick before the verdict: a seed on which the oracle parts from ITS OWN FMA build (another number of QP solves,
                     # another status, or more than 1e-5 rad apart) separates any two correct builds - counted and printed, not failed
