@@ -184,6 +184,8 @@ static inline int tmx_simt_dpp_src(int lane, int ctrl)
     return ((lane & 15) + (ctrl & 15) <= 15) ? lane + (ctrl & 15) : -1;
   if (ctrl >= 0x111 && ctrl <= 0x11F)  // row_shr n
     return ((lane & 15) >= (ctrl & 15)) ? lane - (ctrl & 15) : -1;
+  if (ctrl >= 0x121 && ctrl <= 0x12F)  // row_ror n: lane reads lane - n of its row, cyclically
+    return (lane & ~15) | (((lane & 15) - (ctrl & 15)) & 15);
   std::fprintf(stderr, "[tmx simt] DPP control 0x%x is not emulated\n", ctrl);
   std::abort();
 }
@@ -195,6 +197,31 @@ static inline int tmx_simt_mov_dpp(int v, int ctrl, const char* where, int line)
   tmx_simt_wait(TMX_SIMT_WAVE, where, line);
   const int s = tmx_simt_dpp_src(tid & 63, ctrl);
   const int r = (s < 0 || base + s >= b->NT) ? 0 : (int)(uint32_t)b->xa[base + s];
+  tmx_simt_wait(TMX_SIMT_WAVE, where, line);
+  return r;
+}
+// v_permlane16_swap / v_permlane32_swap (gfx950): the odd 16-lane rows of the first operand trade places with the even rows of the
+// second / the upper half of the first with the lower half of the second; returns both updated registers
+typedef unsigned tmx_simt_u2 __attribute__((ext_vector_type(2)));
+static inline tmx_simt_u2 tmx_simt_permlane_swap(unsigned a, unsigned b2, int wide, const char* where, int line)
+{
+  tmx_simt_block* b = tmx_simt_cur;
+  const int tid = b->cur, base = tid & ~63, lane = tid & 63;
+  b->xa[tid] = a;
+  b->xb[tid] = b2;
+  tmx_simt_wait(TMX_SIMT_WAVE, where, line);
+  tmx_simt_u2 r;
+  if (wide == 16)
+  {
+    const bool odd = (lane >> 4) & 1;
+    r[0] = odd ? (unsigned)b->xb[base + lane - 16] : a;
+    r[1] = !odd ? (unsigned)b->xa[base + lane + 16] : b2;
+  }
+  else
+  {
+    r[0] = lane >= 32 ? (unsigned)b->xb[base + lane - 32] : a;
+    r[1] = lane < 32 ? (unsigned)b->xa[base + lane + 32] : b2;
+  }
   tmx_simt_wait(TMX_SIMT_WAVE, where, line);
   return r;
 }
@@ -527,6 +554,8 @@ static inline int tmx_simt_readfirstlane(int v, const char* where, int line)
 #define __builtin_amdgcn_readlane(v, l) tmx_simt_readlane_i((v), (l), __FILE__, __LINE__)
 #define __builtin_amdgcn_mov_dpp(v, ctrl, rm, bm, bc) tmx_simt_mov_dpp((v), (ctrl), __FILE__, __LINE__)
 #define __builtin_amdgcn_ballot_w64(p) tmx_simt_ballot((p), __FILE__, __LINE__)
+#define __builtin_amdgcn_permlane16_swap(a, b, fi, bc) tmx_simt_permlane_swap((a), (b), 16, __FILE__, __LINE__)
+#define __builtin_amdgcn_permlane32_swap(a, b, fi, bc) tmx_simt_permlane_swap((a), (b), 32, __FILE__, __LINE__)
 #define __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, x, y, z) tmx_simt_mfma_f64_16x16x4((a), (b), (c), __FILE__, __LINE__)
 #define __builtin_amdgcn_rcp(a) (1.0 / (a))
 #define __builtin_amdgcn_fence(order, scope) __atomic_thread_fence(order)

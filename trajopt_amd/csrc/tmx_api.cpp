@@ -8,6 +8,8 @@
 #include <vector>
 
 #include "tmx_kernels.h"
+#include "tmx_wave_kernels.h"
+#include "tmx_wave_plan.h"
 
 #ifdef TMX_HOST_EMU
 #include <chrono>
@@ -62,6 +64,8 @@ struct tmx_ctx
   bool piecewise{ false };  // DevProblem::st: the piecewise driver runs optimize() (host loop) - dense problems and row-only function terms
   bool ws_in_hbm{ false };  // QP workspace > 160 KB of LDS: k_*_hbm kernels, workspace carved in HBM (long horizons)
   int mode{ 2 };  // optimize() driver: 0 = one launch chain per step, 1 = k_sqp_fused, 2 = k_sqp_pool (default)
+  bool wave{ false };      // DevProblem::wave_ok: optimize() and Model::optimize() run as one wave per problem (tmx_wave.h: k_sqp_wave / k_qp_solve_wave)
+  size_t smem_wave{ 0 };
   int pool_wgs{ 0 };  // resident workgroups of the pool kernel (0 = CUs x workgroups-per-CU)
   void* nccl{ nullptr };
   bool nccl_owned{ false };
@@ -1617,6 +1621,38 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
   }
   if (dyn_p && !qp_dense)
     P.coef_far |= 4;  // dynamic objective blocks behind the far region of the per-problem scratch (qp_dynp_offset)
+  // one wave per problem (tmx_wave.h): block-tridiagonal QPs with diagonal couplings whose row-slot template fits the lane plan
+  P.wave_ok = 0;
+  P.wv_gmax = 2;
+  P.wv_aux2 = 0;
+  P.wv_plan = nullptr;
+#if TMX_IS_DEVICE
+  {
+    const char* env = std::getenv("TMX_WAVE");  // "0": keep the one-workgroup-per-CU kernels (A/B runs, bisecting)
+    const bool allowed = !(env && env[0] == '0');
+    std::vector<int> plan(64 * TMX_WV_REC, 0);
+    int gmax = 2, aux2 = 0;
+    if (allowed && P.flavor == 0 && R2 == 0 && P.coef_far == 0 && !qp_dense && !P.st && !P.band && !P.use_time && P.n_fx == 0 &&
+        wave_plan_build(D, T, R, st.data(), naux.data(), plan.data(), &gmax, &aux2))
+    {
+      const size_t small_ints_w = 2 * (size_t)(P.n_max + 1) + 4 * (size_t)R + 2 + 16 + 16 + 512;
+      size_t small = std::max<size_t>((tmx_eval_scratch_doubles(R, D * T, (int)vel_first.size(), n_costs, n_cnts) + n_costs + n_cnts + 8) * sizeof(double),
+                                      small_ints_w * sizeof(int) + 64);
+      small = std::max<size_t>(small, tmx_cvx_scratch_doubles(P.n_cp, D) * sizeof(double));
+      const size_t lds = std::max(small, wave_lds_doubles(D, T, R) * sizeof(double));
+      if (lds <= 40 * 1024)  // four problems per CU
+      {
+        tmx_status rcw;
+        if ((rcw = upload(ctx, ctx->prob_allocs, &P.wv_plan, plan)) != TMX_OK)
+          return rcw;
+        P.wave_ok = 1;
+        P.wv_gmax = gmax;
+        P.wv_aux2 = aux2;
+        ctx->smem_wave = lds;
+      }
+    }
+  }
+#endif
   if (!ctx->dp)
   {
     void* p = nullptr;
@@ -1627,8 +1663,8 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
   // LDS budgets
   ctx->smem_qp = qp_smem_bytes(D, T, R, NA, R2, P.coef_far);
   if (std::getenv("TMX_VERBOSE"))
-    std::fprintf(stderr, "[tmx] problem: D %d (joints %d), T %d, row slots %d, aux %d, pair rows %d, workspace flags %d, band %d, dense %d, QP workspace %zu B\n", D, P.DK, T, R, NA, R2,
-                 P.coef_far, P.band, (int)P.qp_dense, ctx->smem_qp);
+    std::fprintf(stderr, "[tmx] problem: D %d (joints %d), T %d, row slots %d, aux %d, pair rows %d, workspace flags %d, band %d, dense %d, QP workspace %zu B, one wave per problem %d (LDS %zu B, largest lane group %d, second slack in row slots 0x%x)\n", D, P.DK, T, R, NA, R2,
+                 P.coef_far, P.band, (int)P.qp_dense, ctx->smem_qp, P.wave_ok, ctx->smem_wave, P.wv_gmax, P.wv_aux2);
   const size_t small_ints = 2 * (size_t)(P.n_max + 1) + 4 * (size_t)R + 2 + 16 + 16 + 512;  // qp_structure: tables, hash accumulators, chunk totals
   ctx->smem_small = std::max<size_t>((tmx_eval_scratch_doubles(R, D * T, (int)vel_first.size(), n_costs, n_cnts) + n_costs + n_cnts + 8) * sizeof(double),
                                      small_ints * sizeof(int) + 64);
@@ -1637,6 +1673,7 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
   ctx->piecewise = P.st != 0;
   ctx->band = P.band != 0;
   ctx->hull = P.n_ls_hull > 0;
+  ctx->wave = P.wave_ok != 0;
   ctx->tt_squared = std::find(tt_form.begin(), tt_form.end(), 0) != tt_form.end();
   if (ctx->dense)
   {
@@ -1873,6 +1910,8 @@ static tmx_status ensure_batch(tmx_ctx* ctx, int B)
     AL(tt_aff, b * (size_t)P.n_tt * (P.T + 1));
   H.tail_flag = ctx->h_tail;  // pinned host memory is device-accessible at the same address (unified addressing)
   H.qp_scratch_stride = (long long)qp_scratch_doubles(P.D, P.T, P.R, P.NA, P.n_link, P.coef_far);
+  if (P.wave_ok)  // the one-wave solver keeps the cold part of the workspace behind the far part (wave_ws_carve)
+    H.qp_scratch_stride = (long long)(((qp_far_doubles(P.D, P.T, P.R, P.NA, 0, P.coef_far) + 1) & ~(size_t)1) + qp_glb_doubles(P.D, P.T, P.R, P.NA, 0, P.coef_far) + 8);
   AL(qp_scratch, b * (size_t)H.qp_scratch_stride);
   H.ws_hbm_stride = ctx->ws_in_hbm ? (long long)((ctx->ws_bytes + 15) / 16 * 2) : 0;  // doubles, 16-byte aligned slices
   if (ctx->ws_in_hbm)  // stays nullptr otherwise: the kernels test the pointer
@@ -1984,7 +2023,7 @@ tmx_status tmx_sqp_launch(tmx_ctx* ctx)
     return TMX_ERR_UNSUPPORTED;  // the piecewise mode runs the loop on the host
   // only the pool kernel reports the start of its tail; the one-workgroup-per-problem kernels free CUs from their first
   // finished problem on, so for them the next batch may be enqueued at once
-  *ctx->h_tail = (!ctx->ws_in_hbm && ctx->mode == 2) ? 0 : 1;
+  *ctx->h_tail = (!ctx->ws_in_hbm && ctx->mode == 2) ? 0 : 1;  // (k_sqp_wave sets the word when its first problem finishes)
   if (!ctx->clock_started)
   {
     TMX_LAUNCH(k_mark_start, 1, 64, 0, ctx->stream, ctx->db);
@@ -1994,6 +2033,10 @@ tmx_status tmx_sqp_launch(tmx_ctx* ctx)
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
   if (ctx->ws_in_hbm)
     TMX_LAUNCH(k_sqp_fused_hbm, B, ctx->nt_qp > 1 ? TMX_HBM_NT : 1, ctx->smem_chain, ctx->stream, ctx->dp, ctx->db, 0);
+#if TMX_IS_DEVICE
+  else if (ctx->wave && ctx->mode == 2)
+    TMX_LAUNCH(k_sqp_wave, B, 64, ctx->smem_wave, ctx->stream, ctx->dp, ctx->db, 0);  // one wave per problem, all resident at B <= 4 x CUs
+#endif
   else if (ctx->mode == 2)
   {
     const int G = std::min(B, ctx->pool_wgs);
@@ -2054,7 +2097,7 @@ tmx_status tmx_sqp_wait(tmx_ctx* ctx, int32_t* n_active_out)
   // A run-to-completion launch must leave no problem unfinished.  The pool kernel retires workgroups that find nothing
   // ready; should the last workgroups ever leave with work undone, the scheduler words are rebuilt from the problem phases
   // (k_pool_sync) and the pool is started again - problems are independent, so the results do not depend on it.
-  for (int again = 0; tot[0] > 0 && again < 4 && !ctx->ws_in_hbm && ctx->mode == 2; ++again)
+  for (int again = 0; tot[0] > 0 && again < 4 && !ctx->ws_in_hbm && ctx->mode == 2 && !ctx->wave; ++again)
   {
     const int G = std::min(ctx->hb.B, ctx->pool_wgs);
     TMX_LAUNCH(k_pool_sync, 1, 256, 0, ctx->stream, ctx->db);
@@ -2156,6 +2199,10 @@ static tmx_status sqp_run_piecewise(tmx_ctx* ctx, int32_t max_steps, int32_t* n_
             TMX_LAUNCH(k_qp_solve_dense, B, ctx->nt_qp > 1 ? 256 : 1, ctx->smem_small, ctx->stream, ctx->dp, ctx->db, 0));
     else if (ctx->ws_in_hbm)
       TIMED(ctx->ms_admm, ctx->launches_admm++, TMX_LAUNCH(k_qp_solve_hbm, B, ctx->nt_qp > 1 ? TMX_HBM_NT : 1, ctx->smem_chain, ctx->stream, ctx->dp, ctx->db, 0));
+#if TMX_IS_DEVICE
+    else if (ctx->wave)
+      TIMED(ctx->ms_admm, ctx->launches_admm++, TMX_LAUNCH(k_qp_solve_wave, B, 64, ctx->smem_wave, ctx->stream, ctx->dp, ctx->db, 0));
+#endif
     else
       TIMED(ctx->ms_admm, ctx->launches_admm++,
             TMX_LAUNCH(k_qp_solve, B, ctx->nt_qp, ctx->smem_qp, ctx->stream, ctx->dp, ctx->db, 0));
@@ -2539,6 +2586,10 @@ tmx_status tmx_qp_solve(tmx_ctx* ctx, double* x_qp, int32_t* cvx_status, tmx_qp_
           TMX_LAUNCH(k_qp_solve_dense, ctx->hb.B, ctx->nt_qp > 1 ? 256 : 1, ctx->smem_small, ctx->stream, ctx->dp, ctx->db, 1));
   else if (ctx->ws_in_hbm)
     TIMED(ctx->ms_admm, ctx->launches_admm++, TMX_LAUNCH(k_qp_solve_hbm, ctx->hb.B, ctx->nt_qp > 1 ? TMX_HBM_NT : 1, ctx->smem_chain, ctx->stream, ctx->dp, ctx->db, 1));
+#if TMX_IS_DEVICE
+  else if (ctx->wave)
+    TIMED(ctx->ms_admm, ctx->launches_admm++, TMX_LAUNCH(k_qp_solve_wave, ctx->hb.B, 64, ctx->smem_wave, ctx->stream, ctx->dp, ctx->db, 1));
+#endif
   else
     TIMED(ctx->ms_admm, ctx->launches_admm++,
           TMX_LAUNCH(k_qp_solve, ctx->hb.B, ctx->nt_qp, ctx->smem_qp, ctx->stream, ctx->dp, ctx->db, 1));

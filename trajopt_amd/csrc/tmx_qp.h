@@ -524,7 +524,8 @@ TMX_DEVFN void qp_ws_chain_to_lds(QpWs& w, double* lds)
     w.Zp = p;
 }
 
-TMX_DEVFN void qp_ws_carve(QpWs& w, double* lds, double* glb, double* far, int D, int T, int R, int NA, int R2 = 0, int cf_flags = 0)
+// (dense_region = false: the one-wave solver of tmx_wave.h - no nested-dissection arrays G / Zs / sx / ty in the hot part)
+TMX_DEVFN void qp_ws_carve(QpWs& w, double* lds, double* glb, double* far, int D, int T, int R, int NA, int R2 = 0, int cf_flags = 0, bool dense_region = true)
 {
   const int cf = cf_flags & 1;
   w.D = D;
@@ -549,7 +550,7 @@ TMX_DEVFN void qp_ws_carve(QpWs& w, double* lds, double* glb, double* far, int D
   TAKE(Sinv, T * D * w.DS);  // first: 16-byte aligned for the double2 row loads
   w.G = w.Zs = w.sx = w.ty = nullptr;
   w.Gn = w.Gs = w.Zst = 0;
-  if (dpart_fits(D, T) && R2 == 0)
+  if (dense_region && dpart_fits(D, T) && R2 == 0)
   {
     DPart dp;
     dpart_make(T, dp);

@@ -139,6 +139,12 @@ struct DevProblem
   int n_tt;
   int *tt_owner, *tt_form, *tt_slot;
   double *tt_coeff, *tt_limit;
+  // ONE-WAVE SOLVER (tmx_wave.h): the problem runs as one wave per seed (k_sqp_wave); wv_plan = 64 x TMX_WV_REC ints, the row / variable
+  // role of every lane (waypoint, group size, position in the group, row slots); wv_gmax = the largest lane group (2 | 4 | 8)
+  int wave_ok;
+  int wv_gmax;
+  int wv_aux2;   // bit i: some lane's row slot i holds a row with two slack variables
+  int* wv_plan;
 };
 TMX_HOSTDEVFN int slot_is_diff(int kind) { return kind == SLOT_JOINTVEL || kind == SLOT_JOINTVEL_INEQ; }
 #define TMX_TV_REC 5  // DevBatch::tv_aff record of one segment: cleaned Jacobian entries on x[t][j], x[t+1][j], tau[t+1] (upper row), constants of the upper / lower row

@@ -1,0 +1,1475 @@
+// tmx_wave.h — ONE WAVE PER PROBLEM: the whole BasicTrustRegionSQP::optimize() of a seed on a single 64-lane wave, four problems per
+// CU (one wave per SIMD, the full 512-register file each, <= 40 KB of LDS each), no workgroup barrier and no hand-off anywhere.
+//
+// Which problems: block-tridiagonal QPs with diagonal couplings (no rows on two waypoints, no banded objective, no function costs),
+// D <= 8, T <= 32, and a row-slot template that fits the lane plan below (BASELINE config 1: 7-DOF x 30 waypoints, 304 row slots).
+// Everything else keeps the kernels of tmx_kernels.h.
+//
+// Model::optimize() (OSQP v1.0.0 as driven by trajopt_sco/src/osqp_interface.cpp:283-370, :440-615) here:
+//   * the reduced KKT matrix K = P + sigma I + A' diag(w) A (rows and their slack columns eliminated analytically, tmx_qp.h) is
+//     factored as a TWISTED block LDL': Schur complements from BOTH ends of the waypoint chain towards a middle block m,
+//       S_t = K_t - C_{t-1} S_{t-1}^{-1} C_{t-1} (t < m),  S_t = K_t - C_t S_{t+1}^{-1} C_t (t > m),
+//       S_m = K_m - C_{m-1} S_{m-1}^{-1} C_{m-1} - C_m S_{m+1}^{-1} C_m,       C_t = diag(po_t): coupling of blocks t, t + 1
+//     so that a solve is two INDEPENDENT half-chains that the one wave walks interleaved in one instruction stream (the chain step is
+//     bound by dependent-issue latency, the second chain fills the idle issue slots: tools/ubench/btd_twist.hip, 8.2 k instead of
+//     11.8 k cycles per iteration of a lone wave);
+//   * the chain matrices G_k = -C S^{-1} live in REGISTERS, one entry per lane of an 8 x 8 lane grid, stored alternately as G and G'
+//     so that the vector a step produces (a sum over the lane index it was multiplied along: DPP quad_perm / row_half_mirror / row_ror
+//     and gfx950's v_permlane16_swap / v_permlane32_swap) is already laid out as the next step's input;
+//   * everything off the chain is waypoint-parallel: a GROUP of 2 / 4 / 8 adjacent lanes owns a waypoint - its rows (TMX_WV_RL per
+//     lane, with their slack variables) and its D variables - with the iterate (x, z, y of rows, slack and bound rows) in registers
+//     for a whole burst of ADMM iterations;
+//   * setup (Ruiz), residual checks / certificates / adaptive rho, polish and the solution store are the row-structured device
+//     functions of tmx_qp.h / tmx_solve.h run by the one wave on a workspace whose cold part lives in the per-problem HBM scratch.
+#pragma once
+#include "tmx_solve.h"
+#include <type_traits>
+
+#include "tmx_wave_plan.h"
+
+#if TMX_IS_DEVICE
+typedef unsigned tmx_wv_u2 __attribute__((ext_vector_type(2)));
+// ---- cross-lane sums (tools/ubench/btd_wave.hip) -----------------------------------------------------------------------------
+template <int CTRL>
+TMX_DEVFN double wv_dpp(double p)
+{
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(p), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(p), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+// two independent values stage by stage: the instruction stream alternates between the two dependency chains
+template <int CTRL>
+TMX_DEVFN void wv_dpp_add2(double& p, double& q)
+{
+  const int plo = __double2loint(p), phi = __double2hiint(p), qlo = __double2loint(q), qhi = __double2hiint(q);
+  const int plo2 = __builtin_amdgcn_mov_dpp(plo, CTRL, 0xf, 0xf, false);
+  const int qlo2 = __builtin_amdgcn_mov_dpp(qlo, CTRL, 0xf, 0xf, false);
+  const int phi2 = __builtin_amdgcn_mov_dpp(phi, CTRL, 0xf, 0xf, false);
+  const int qhi2 = __builtin_amdgcn_mov_dpp(qhi, CTRL, 0xf, 0xf, false);
+  p += __hiloint2double(phi2, plo2);
+  q += __hiloint2double(qhi2, qlo2);
+}
+template <int WIDE>  // 16 | 32: x[lane] + x[lane ^ WIDE] of both values
+TMX_DEVFN void wv_swap_add2(double& p, double& q)
+{
+  const unsigned plo = (unsigned)__double2loint(p), phi = (unsigned)__double2hiint(p), qlo = (unsigned)__double2loint(q), qhi = (unsigned)__double2hiint(q);
+  tmx_wv_u2 pl, ql, ph, qh;
+  if (WIDE == 16)
+  {
+    pl = __builtin_amdgcn_permlane16_swap(plo, plo, false, false);
+    ql = __builtin_amdgcn_permlane16_swap(qlo, qlo, false, false);
+    ph = __builtin_amdgcn_permlane16_swap(phi, phi, false, false);
+    qh = __builtin_amdgcn_permlane16_swap(qhi, qhi, false, false);
+  }
+  else
+  {
+    pl = __builtin_amdgcn_permlane32_swap(plo, plo, false, false);
+    ql = __builtin_amdgcn_permlane32_swap(qlo, qlo, false, false);
+    ph = __builtin_amdgcn_permlane32_swap(phi, phi, false, false);
+    qh = __builtin_amdgcn_permlane32_swap(qhi, qhi, false, false);
+  }
+  p = __hiloint2double((int)ph[0], (int)pl[0]) + __hiloint2double((int)ph[1], (int)pl[1]);
+  q = __hiloint2double((int)qh[0], (int)ql[0]) + __hiloint2double((int)qh[1], (int)ql[1]);
+}
+// sums over the eight lanes of a grid row (lane & 7) / over the eight grid rows (lane >> 3); every lane ends with the sum
+TMX_DEVFN void wv_red_in2(double& p, double& q)
+{
+  wv_dpp_add2<0xB1>(p, q);   // quad_perm [1,0,3,2]
+  wv_dpp_add2<0x4E>(p, q);   // quad_perm [2,3,0,1]
+  wv_dpp_add2<0x141>(p, q);  // row_half_mirror
+}
+TMX_DEVFN void wv_red_x2(double& p, double& q)
+{
+  wv_dpp_add2<0x128>(p, q);  // row_ror:8
+  wv_swap_add2<16>(p, q);
+  wv_swap_add2<32>(p, q);
+}
+
+TMX_DEVFN WvLds wave_ws_carve(QpWs& w, const DevProblem* P, const DevBatch* Bt, int b, double* smem)
+{
+  double* scratch = Bt->qp_scratch + (size_t)b * Bt->qp_scratch_stride;
+  // cold part in the per-problem HBM scratch BEHIND the far part (which stays where the other kernels keep it: k_export_active reads
+  // the polish flags there); the hot pointers are then laid out as above
+  qp_ws_carve(w, smem, scratch + ((qp_far_doubles(P->D, P->T, P->R, P->NA, 0, P->coef_far) + 1) & ~(size_t)1), scratch, P->D, P->T, P->R, P->NA, 0, P->coef_far, false);
+#if TMX_LINK_ROWS
+  w.c2i = P->slot_c2;
+#endif
+  const int D = P->D, T = P->T, NX = P->NX, R = P->R;
+  WvLds L;
+  double* p = smem;
+  w.Sinv = p;
+  p += (size_t)T * D * 8;
+  w.po = p;
+  p += (NX + 1) & ~1;
+  w.wself = p;
+  p += QPWS_DOUBLES;
+  L.wv = p;
+  p += ((size_t)(T | 1) + 3) * 8;
+  L.wx = p;
+  p += ((size_t)(T | 1) + 3) * 8;
+  L.cfl = p;
+  w.tp = p;
+  p += wave_lds_tp_doubles(D, T);
+  w.hr = p;
+  p += wave_lds_hr_doubles(T, R);
+  w.gj = p;
+  p += ((size_t)D * D + 1) & ~(size_t)1;
+  w.red = p;
+  return L;
+}
+
+// ---- twisted factorisation of the chain: in: the diagonal blocks K_t in w.Sinv (kkt_factor); out: S_t^{-1} in place ---------------
+// (one matrix entry per lane, pivots through ds_bpermute, as part_invert_interior - whose arithmetic the ascending half repeats)
+TMX_DEVFN void wave_twist_invert(const QpWs& w, int m, int lane)
+{
+  const int D = w.D, DD = D * D, DS = w.DS, DDS = w.DDS, T = w.T;
+  const bool valid = lane < DD;
+  const int i = valid ? lane / D : 0, j = valid ? lane % D : 0;
+  auto gauss_jordan = [&](double s) {
+    for (int k = 0; k < D; ++k)
+    {
+      const double pkk = __shfl(s, k * D + k, 64);
+      const double rowk = __shfl(s, k * D + j, 64);
+      const double colk = __shfl(s, i * D + k, 64);
+      const double piv = fast_rcp(pkk);
+      if (i == k && j == k)
+        s = piv;
+      else if (i == k)
+        s = s * piv;
+      else if (j == k)
+        s = -colk * piv;
+      else
+        s = s - colk * rowk * piv;
+    }
+    return s;
+  };
+  double up = 0.0, dn = 0.0;
+  for (int t = 0; t < m; ++t)  // ascending half
+  {
+    double s = valid ? w.Sinv[t * DDS + i * DS + j] : 0.0;
+    if (t > 0 && valid)
+      s -= w.po[(t - 1) * D + i] * up * w.po[(t - 1) * D + j];
+    s = gauss_jordan(s);
+    if (valid)
+      w.Sinv[t * DDS + i * DS + j] = s;
+    up = s;
+  }
+  for (int t = T - 1; t > m; --t)  // descending half
+  {
+    double s = valid ? w.Sinv[t * DDS + i * DS + j] : 0.0;
+    if (t < T - 1 && valid)
+      s -= w.po[t * D + i] * dn * w.po[t * D + j];
+    s = gauss_jordan(s);
+    if (valid)
+      w.Sinv[t * DDS + i * DS + j] = s;
+    dn = s;
+  }
+  {
+    double s = valid ? w.Sinv[m * DDS + i * DS + j] : 0.0;
+    if (valid)
+    {
+      if (m > 0)
+        s -= w.po[(m - 1) * D + i] * up * w.po[(m - 1) * D + j];
+      if (m < T - 1)
+        s -= w.po[m * D + i] * dn * w.po[m * D + j];
+    }
+    s = gauss_jordan(s);
+    if (valid)
+      w.Sinv[m * DDS + i * DS + j] = s;
+  }
+  TMX_SYNC();
+}
+
+// ---- a burst of ADMM iterations with the iterate in registers -------------------------------------------------------------------
+// in / out: the iterate and the scaled problem data in the workspace arrays (x, z, y of rows / slack / bound rows; fac, dinv from
+// admm_cache_weights; S^{-1} from wave_twist_invert).  n_iter iterations; the last one leaves delta_x / delta_y (certificates).
+// The per-element operations are those of admm_phase_a / _b / _c (tmx_qp.h); what differs is the order of the sums of the A'e
+// gather (per lane, then across the lanes of the group) and the chain.
+// NC: the number of chain steps N as a compile-time constant (0: run time).  With a run-time N every `k <= N` of the unrolled sweeps
+// is a loop-invariant lane mask the compiler keeps in an SGPR pair (32 of them: spills, and two scalar instructions per branch)
+// DC: the block size D likewise (0: run time).
+template <int NC, int DC>
+TMX_DEVFN void wave_admm_burst(const QpWs& w, const DevProblem* P, const WvLds& L, int n_iter, int lane)
+{
+  constexpr int RL = TMX_WV_RL, NV = TMX_WV_NV, KM = TMX_WV_KMAX;
+  // (wave-uniform values as scalars: every `k <= N` below is a scalar branch, not an EXEC-masked region)
+  const int D = DC ? DC : TMX_UNI_I(w.D), T = TMX_UNI_I(w.T), DS = 8, DDS = 8 * D;
+  n_iter = TMX_UNI_I(n_iter);
+  const int TT = T | 1, N = NC ? NC : (TT - 1) / 2, m = N;  // both half chains: N steps, the last one is the contribution to the middle block m
+  const int ROW_TA = TT, ROW_TB = TT + 1, ROW_Z = TT + 2;
+  const int aux2 = TMX_UNI_I(P->wv_aux2), gmax = TMX_UNI_I(P->wv_gmax);
+  const int* pl = P->wv_plan + lane * TMX_WV_REC;
+  const int tw_raw = pl[0], gsize = pl[1], gpos = pl[2], nrow = pl[3];
+  const int tw = tw_raw < 0 ? 0 : tw_raw;
+  const int k0 = (gpos == 0) ? 0 : NV, nv = (tw_raw < 0 || gpos > 1) ? 0 : ((gpos == 0) ? (D < NV ? D : NV) : (D > NV ? D - NV : 0));
+  const double sigma = w.sigma, al = w.alpha, oma = 1.0 - w.alpha, rho = w.rho;
+  const double INF = TMX_OSQP_INFTY;
+  double* const wv = L.wv;
+  double* const wx = L.wx;
+  double* const cfl = L.cfl + lane;  // this lane's coefficients: cfl[(i D + d) 64]
+  // ---- row role: the iterate and the per-row constants in registers, the coefficients in LDS
+  double z[RL], y[RL], lo[RL], hi[RL], rr[RL], rri[RL], fac[RL];
+  double xa[RL][2], zba[RL][2], yba[RL][2], qa[RL][2], sa[RL][2], bba[RL][2], dnv[RL][2], sd[RL][2];
+  int rid[RL], aid[RL], nax[RL];
+#pragma unroll
+  for (int i = 0; i < RL; ++i)
+  {
+    const int r = i < nrow ? pl[4 + i] : 0;
+    const bool on = i < nrow && w.act[r] != 0;
+    rid[i] = on ? r : -1;
+    for (int d = 0; d < D; ++d)
+      cfl[(i * D + d) * 64] = on ? w.coef[r * D + d] : 0.0;
+    z[i] = on ? w.zr[r] : 0.0;
+    y[i] = on ? w.yr[r] : 0.0;
+    lo[i] = on ? w.lor[r] : -INF;
+    hi[i] = on ? w.hir[r] : INF;
+    rr[i] = on ? rho_of_type(w.typ_r[r], rho) : 1.0;
+    rri[i] = 1.0 / rr[i];
+    fac[i] = on ? w.fac[r] : 0.0;
+    nax[i] = on ? w.naux[r] : 0;
+    aid[i] = w.aoff[r];
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+    {
+      const bool has = k < nax[i];
+      const int a = has ? aid[i] + k : 0;
+      xa[i][k] = has ? w.xa[a] : 0.0;
+      zba[i][k] = has ? w.zba[a] : 0.0;
+      yba[i][k] = has ? w.yba[a] : 0.0;
+      qa[i][k] = has ? w.qa[a] : 0.0;
+      sa[i][k] = has ? w.sa[a] : 0.0;
+      bba[i][k] = has ? w.bba[a] : 0.0;
+      dnv[i][k] = has ? w.dinv[a] : 0.0;
+      sd[i][k] = sa[i][k] * dnv[i][k];
+    }
+  }
+  // bound rows of the slack variables: [0, INFTY * E) - type 0 for every admissible scaling, i.e. rho (checked by the caller)
+  const double rb = rho, rbi = 1.0 / rho;
+  // ---- variable role
+  double x[NV], zb[NV], yb[NV], q[NV], lb[NV], ub[NV], bb[NV], rv[NV], rvi[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j)
+  {
+    const bool has = j < nv;
+    const int v = has ? tw * D + k0 + j : 0;
+    x[j] = has ? w.xp[v] : 0.0;
+    zb[j] = has ? w.zbp[v] : 0.0;
+    yb[j] = has ? w.ybp[v] : 0.0;
+    q[j] = has ? w.qp[v] : 0.0;
+    lb[j] = has ? w.lbp[v] : -INF;
+    ub[j] = has ? w.ubp[v] : INF;
+    bb[j] = has ? w.bbp[v] : 0.0;
+    rv[j] = has ? rho_of_type(w.typ_bp[v], rho) : 1.0;
+    rvi[j] = 1.0 / rv[j];
+  }
+  // ---- grid role: chain registers.  Step k of chain A takes block k-1 to block k, step k of chain B block TT-k to block TT-1-k;
+  // odd steps hold M[a][b] (the product is summed over b), even steps M[b][a] (summed over a);  M = -C S^{-1}
+  const int ga = lane >> 3, gb = lane & 7;
+  const bool gin = ga < D && gb < D;
+  const int ia = ga < D ? ga : 0, ib = gb < D ? gb : 0;
+  double GA[KM], GB[KM];
+#pragma unroll
+  for (int k = 1; k <= KM; ++k)
+  {
+    GA[k - 1] = 0.0;
+    GB[k - 1] = 0.0;
+    if (k <= N)
+    {
+      const int ri = (k & 1) ? ia : ib, ci = (k & 1) ? ib : ia;
+      {
+        const int t = k - 1;
+        GA[k - 1] = gin ? -(w.po[t * D + ri] * w.Sinv[t * DDS + ri * DS + ci]) : 0.0;
+      }
+      const int t = TT - k, tc = TT - 1 - k;
+      if (t < T)  // (t == T: the dummy block of an even T - no coupling)
+        GB[k - 1] = gin ? -(w.po[tc * D + ri] * w.Sinv[t * DDS + ri * DS + ci]) : 0.0;
+    }
+  }
+  const bool selA = gb == 0, selB = ga == 0;  // the lanes that store component ga (sum over b) resp. gb (sum over a)
+  // Stores of the chain steps are unconditional: the lanes that do not hold the result write it into a dead row instead (no EXEC
+  // masking on the chain).  Forward sweeps: results into wv, the others into the same row of wx (dead until the backward sweeps).
+  // Backward sweeps: results into wx, the others into a row of wv that has been consumed - chain A (descending) the row above the one it
+  // reads, chain B (ascending) the row below.
+  double* const fstA = selA ? wv + ga : wx + ga;
+  double* const fstB = selB ? wv + gb : wx + gb;
+  double* const bsaA = selA ? wx + ga : wv + 8 + ga;   // chain A, result indexed by ga / gb
+  double* const bsaB = selB ? wx + gb : wv + 8 + gb;
+  double* const bsbA = selA ? wx + ga : wv - 8 + ga;   // chain B
+  double* const bsbB = selB ? wx + gb : wv - 8 + gb;
+  const bool own = tw_raw >= 0 && gpos == 0;
+  // Right-hand side of a chain step: EVERY lane of the eight that are summed adds one eighth of its component (wv holds the
+  // right-hand sides of both sweeps times 1/8 - exact scalings), so no lane select sits on the chain
+  auto inj = [&](bool sums_b, int row) -> double { return sums_b ? wv[row * 8 + ga] : wv[row * 8 + gb]; };
+  // Both chain vectors start as zeros: the dummy block and the zero row stay so, and so does the padding component of every row (lanes
+  // of the grid beyond D hold G = 0, but 0 x stale LDS contents may be 0 x NaN)
+  for (int e = lane; e < (TT + 3) * 8; e += 64)
+  {
+    wv[e] = 0.0;
+    wx[e] = 0.0;
+  }
+  TMX_SYNC();
+  // one ADMM iteration; KEEP: the last one of the burst, which leaves delta_x / delta_y for the certificates (a second instantiation
+  // of the body: with a run-time flag the stores sit in EXEC-masked regions of every iteration)
+  auto iterate = [&](auto keep_tag) {
+    constexpr bool keep = decltype(keep_tag)::value;
+    // ---- phase A: e_r = g_r - fac_r sum_k sa_k t_k dinv_k,  t_k = right-hand side of slack variable k
+    double e[RL], ta[RL][2], gsa[RL];
+#pragma unroll
+    for (int i = 0; i < RL; ++i)
+    {
+      const double g = __builtin_fma(rr[i], z[i], -y[i]);
+      double gs = 0.0;
+      ta[i][1] = 0.0;
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+        if (k == 0 || (aux2 >> i & 1))
+        {
+          const double gbk = __builtin_fma(rb, zba[i][k], -yba[i][k]);
+          const double t = __builtin_fma(bba[i][k], gbk, __builtin_fma(sa[i][k], g, __builtin_fma(sigma, xa[i][k], -qa[i][k])));
+          ta[i][k] = t;
+          gs = __builtin_fma(sd[i][k], t, gs);
+        }
+      gsa[i] = gs;
+      e[i] = __builtin_fma(-fac[i], gs, g);
+    }
+    // ---- phase B: reduced right-hand side sigma x - q + A'e + bound part, summed over the lanes of the group
+    double part[8];
+#pragma unroll
+    for (int d = 0; d < 8; ++d)
+      part[d] = 0.0;
+#pragma unroll
+    for (int i = 0; i < RL; ++i)
+#pragma unroll
+      for (int d = 0; d < 8; ++d)
+        if (d < D)
+          part[d] = __builtin_fma(cfl[(i * D + d) * 64], e[i], part[d]);
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+    {
+      const double gbv = __builtin_fma(rv[j], zb[j], -yb[j]);
+      const double o = __builtin_fma(bb[j], gbv, __builtin_fma(sigma, x[j], -q[j]));  // (absent variables: all zero)
+      if (gpos == 0)
+        part[j] += o;
+      else
+        part[NV + j] += o;
+    }
+    // (every stage runs under the full EXEC mask - a DPP read from a masked-off lane is not defined - and is selected per lane;
+    //  gmax is wave-uniform: problems whose groups are all pairs skip the wider stages)
+#pragma unroll
+    for (int d = 0; d < 8; ++d)
+    {
+      double s = part[d] + wv_dpp<0xB1>(part[d]);
+      if (gmax >= 4)
+      {
+        const double s4 = s + wv_dpp<0x4E>(s);
+        s = gsize >= 4 ? s4 : s;
+      }
+      if (gmax >= 8)
+      {
+        const double s8 = s + wv_dpp<0x141>(s);
+        s = gsize >= 8 ? s8 : s;
+      }
+      part[d] = s;
+    }
+    if (own)
+    {
+#pragma unroll
+      for (int d = 0; d < 8; ++d)
+        wv[tw * 8 + d] = 0.125 * part[d];
+    }
+    TMX_SYNC();
+#if defined(TMX_WAVE_DEBUG) && !TMX_IS_GCN
+    static thread_local double dbg_rhs[40 * 8];
+    if (lane == 0)
+      for (int e2 = 0; e2 < T * 8; ++e2)
+        dbg_rhs[e2] = 8.0 * wv[e2];
+    TMX_SYNC();
+#endif
+    // ---- the two forward half-chains in lockstep.  The right-hand sides are loaded two steps AHEAD of their use: a load placed behind
+    // a store of the other chain (unknown aliasing) would order the two chains.  The last step (k = N) has no right-hand side (the
+    // zero row) and leaves the contributions to the middle block in rows TT / TT + 1.
+    {
+      double ca = 8.0 * wv[gb], cb = 8.0 * wv[(TT - 1) * 8 + gb];
+      double ra0 = inj(true, 1 < N ? 1 : ROW_Z), rb0 = inj(true, 1 < N ? TT - 2 : ROW_Z);
+      double ra1 = inj(false, 2 < N ? 2 : ROW_Z), rb1 = inj(false, 2 < N ? TT - 3 : ROW_Z);
+#pragma unroll
+      for (int k = 1; k <= KM; ++k)
+        if (k <= N)
+        {
+          const double ra = ra0, rbk = rb0;
+          ra0 = ra1;
+          rb0 = rb1;
+          if (k + 2 <= KM)
+          {
+            ra1 = inj((k & 1) != 0, k + 2 < N ? k + 2 : ROW_Z);
+            rb1 = inj((k & 1) != 0, k + 2 < N ? TT - 3 - k : ROW_Z);
+          }
+          ca = __builtin_fma(GA[k - 1], ca, ra);
+          cb = __builtin_fma(GB[k - 1], cb, rbk);
+          if (k & 1)
+            wv_red_in2(ca, cb);
+          else
+            wv_red_x2(ca, cb);
+          double* const fst = (k & 1) ? fstA : fstB;
+          fst[(k < N ? k : ROW_TA) * 8] = ca;
+          fst[(k < N ? TT - 1 - k : ROW_TB) * 8] = cb;
+        }
+    }
+    TMX_SYNC();
+    if (lane < 8)
+      wv[m * 8 + lane] = (8.0 * wv[m * 8 + lane] + wv[ROW_TA * 8 + lane]) + wv[ROW_TB * 8 + lane];
+    TMX_SYNC();
+#if defined(TMX_WAVE_DEBUG) && !TMX_IS_GCN
+    static thread_local double dbg_y[40 * 8];
+    if (lane == 0)
+      for (int e2 = 0; e2 < T * 8; ++e2)
+        dbg_y[e2] = ((e2 >> 3) == 0 || (e2 >> 3) == TT - 1 ? 8.0 : 1.0) * wv[e2];
+    TMX_SYNC();
+#endif
+    // ---- g_t = S_t^{-1} y_t, waypoint-parallel (the first two lanes of a group; all lanes of the wave read before any writes)
+    {
+      double yy[8], g[NV];
+      const double ysc = (tw == 0 || tw == TT - 1) ? 8.0 : 1.0;  // (the end blocks the chains START from still hold their scaled right-hand sides)
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj)
+        yy[jj] = ysc * wv[tw * 8 + jj];
+#pragma unroll
+      for (int j = 0; j < NV; ++j)
+      {
+        const int d = (j < nv) ? k0 + j : 0;
+        double s = 0.0;
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj)
+          s = __builtin_fma(w.Sinv[tw * DDS + d * DS + jj], yy[jj], s);
+        g[j] = s;
+      }
+      __builtin_amdgcn_wave_barrier();  // (in place: every lane of the group has read y_t before any lane writes g_t)
+#pragma unroll
+      for (int j = 0; j < NV; ++j)
+        if (j < nv)
+        {
+          wv[tw * 8 + k0 + j] = 0.125 * g[j];
+          if (tw == m)
+            wx[tw * 8 + k0 + j] = g[j];
+        }
+    }
+    TMX_SYNC();
+    // ---- the two backward half-chains from the middle block outwards:  x_{k-1} = g_{k-1} + GA[k]' x_k,  x_{TT-k} = g_{TT-k} + GB[k]' x_{TT-1-k}
+    {
+      // x_m in the layout the first step (k = N) multiplies along: an odd step sums over a
+      const int moff = (N & 1) ? ga : gb;
+      double ca = wx[m * 8 + moff], cb = ca;
+      // right-hand sides of steps N and N - 1 (run-time parity), then two steps ahead inside the unrolled sequence
+      auto binj = [&](bool sums_a, int row) -> double { return sums_a ? wv[row * 8 + gb] : wv[row * 8 + ga]; };
+      double qa0 = binj((N & 1) != 0, N - 1), qb0 = binj((N & 1) != 0, TT - N);
+      double qa1 = binj((N & 1) == 0, N >= 2 ? N - 2 : ROW_Z), qb1 = binj((N & 1) == 0, N >= 2 ? TT - N + 1 : ROW_Z);
+#pragma unroll
+      for (int k = KM; k >= 1; --k)
+        if (k <= N)
+        {
+          const double ra = qa0, rbk = qb0;
+          qa0 = qa1;
+          qb0 = qb1;
+          if (k >= 3)
+          {
+            qa1 = binj((k & 1) != 0, k - 3);
+            qb1 = binj((k & 1) != 0, TT - k + 2);
+          }
+          ca = __builtin_fma(GA[k - 1], ca, ra);
+          cb = __builtin_fma(GB[k - 1], cb, rbk);
+          if (k & 1)
+            wv_red_x2(ca, cb);
+          else
+            wv_red_in2(ca, cb);
+          ((k & 1) ? bsaB : bsaA)[(k - 1) * 8] = ca;
+          ((k & 1) ? bsbB : bsbA)[(TT - k) * 8] = cb;
+        }
+    }
+    TMX_SYNC();
+#if defined(TMX_WAVE_DEBUG) && !TMX_IS_GCN
+    if (lane == 0)
+    {
+      // residual of the reduced system K x~ = rhs in operator form: K = diag(pd + sigma + rho_b bb^2) + couplings po + sum_r fac_r a_r a_r'
+      double worst = 0.0, rmax = 0.0;
+      int wt = -1, wd = -1;
+      for (int t = 0; t < T; ++t)
+        for (int d = 0; d < D; ++d)
+        {
+          const int v = t * D + d;
+          double acc = (w.pd[v] + sigma + rho_of_type(w.typ_bp[v], rho) * w.bbp[v] * w.bbp[v]) * wx[t * 8 + d];
+          if (t > 0)
+            acc += w.po[v - D] * wx[(t - 1) * 8 + d];
+          if (t < T - 1)
+            acc += w.po[v] * wx[(t + 1) * 8 + d];
+          for (int r = 0; r < w.R; ++r)
+            if (w.act[r] && w.slot_t[r] == t)
+            {
+              double dot = 0.0;
+              for (int jj = 0; jj < D; ++jj)
+                dot += w.coef[r * D + jj] * wx[t * 8 + jj];
+              acc += w.fac[r] * dot * w.coef[r * D + d];
+            }
+          const double res = acc - dbg_rhs[t * 8 + d];
+          static thread_local int dbg_calls = 0;
+          if (t == 0 && d == 0)
+            ++dbg_calls;
+          if (dbg_calls == 1)
+            { if (d == 0) std::printf("\n[wave dbg] t %2d res:", t); std::printf("%10.2e", res); }
+          rmax = fmax(rmax, fabs(dbg_rhs[t * 8 + d]));
+          if (fabs(res) > worst)
+          {
+            worst = fabs(res);
+            wt = t;
+            wd = d;
+          }
+        }
+      {
+        // serial replay of the twisted solve with the same factors
+        static thread_local double yy[40 * 8], gg[40 * 8], xs[40 * 8];
+        auto mv = [&](int t, const double* v, double* o) {
+          for (int i2 = 0; i2 < D; ++i2)
+          {
+            double a2 = 0.0;
+            for (int j2 = 0; j2 < D; ++j2)
+              a2 += w.Sinv[t * DDS + i2 * DS + j2] * v[j2];
+            o[i2] = a2;
+          }
+        };
+        double tmpv[8];
+        for (int t = 0; t < m; ++t)
+        {
+          for (int d = 0; d < D; ++d)
+            yy[t * 8 + d] = dbg_rhs[t * 8 + d];
+          if (t > 0)
+          {
+            mv(t - 1, &yy[(t - 1) * 8], tmpv);
+            for (int d = 0; d < D; ++d)
+              yy[t * 8 + d] -= w.po[(t - 1) * D + d] * tmpv[d];
+          }
+        }
+        for (int t = T - 1; t > m; --t)
+        {
+          for (int d = 0; d < D; ++d)
+            yy[t * 8 + d] = dbg_rhs[t * 8 + d];
+          if (t < T - 1)
+          {
+            mv(t + 1, &yy[(t + 1) * 8], tmpv);
+            for (int d = 0; d < D; ++d)
+              yy[t * 8 + d] -= w.po[t * D + d] * tmpv[d];
+          }
+        }
+        for (int d = 0; d < D; ++d)
+          yy[m * 8 + d] = dbg_rhs[m * 8 + d];
+        mv(m - 1, &yy[(m - 1) * 8], tmpv);
+        for (int d = 0; d < D; ++d)
+          yy[m * 8 + d] -= w.po[(m - 1) * D + d] * tmpv[d];
+        if (m < T - 1)
+        {
+          mv(m + 1, &yy[(m + 1) * 8], tmpv);
+          for (int d = 0; d < D; ++d)
+            yy[m * 8 + d] -= w.po[m * D + d] * tmpv[d];
+        }
+        for (int t = 0; t < T; ++t)
+          mv(t, &yy[t * 8], &gg[t * 8]);
+        for (int d = 0; d < D; ++d)
+          xs[m * 8 + d] = gg[m * 8 + d];
+        for (int t = m - 1; t >= 0; --t)
+        {
+          double u2[8];
+          for (int d = 0; d < D; ++d)
+            u2[d] = w.po[t * D + d] * xs[(t + 1) * 8 + d];
+          mv(t, u2, tmpv);
+          for (int d = 0; d < D; ++d)
+            xs[t * 8 + d] = gg[t * 8 + d] - tmpv[d];
+        }
+        for (int t = m + 1; t < T; ++t)
+        {
+          double u2[8];
+          for (int d = 0; d < D; ++d)
+            u2[d] = w.po[(t - 1) * D + d] * xs[(t - 1) * 8 + d];
+          mv(t, u2, tmpv);
+          for (int d = 0; d < D; ++d)
+            xs[t * 8 + d] = gg[t * 8 + d] - tmpv[d];
+        }
+        {
+          double ymax = 0.0;
+          int yt = -1;
+          for (int t = 0; t < T; ++t)
+            for (int d = 0; d < D; ++d)
+              if (fabs(yy[t * 8 + d] - dbg_y[t * 8 + d]) > ymax)
+              {
+                ymax = fabs(yy[t * 8 + d] - dbg_y[t * 8 + d]);
+                yt = t;
+              }
+          std::printf("\n[wave dbg] forward sweeps: max |dy| %.3e at t %d", ymax, yt);
+          for (int t = 0; t < T; ++t)
+          {
+            double e3 = 0.0;
+            for (int d = 0; d < D; ++d)
+              e3 = fmax(e3, fabs(yy[t * 8 + d] - dbg_y[t * 8 + d]));
+            std::printf("%s%.1e", t ? " " : "\n[wave dbg] |dy| by block: ", e3);
+          }
+        }
+        double dmax = 0.0;
+        int dt = -1;
+        for (int t = 0; t < T; ++t)
+          for (int d = 0; d < D; ++d)
+            if (fabs(xs[t * 8 + d] - wx[t * 8 + d]) > dmax)
+            {
+              dmax = fabs(xs[t * 8 + d] - wx[t * 8 + d]);
+              dt = t;
+            }
+        std::printf("\n[wave dbg] lane-grid chain vs serial twisted solve: max |dx| %.3e at t %d\n", dmax, dt);
+      }
+      std::printf("[wave dbg] reduced solve: max |K x - rhs| = %.3e at (t %d, d %d), max |rhs| %.3e\n", worst, wt, wd, rmax);
+    }
+    TMX_SYNC();
+#endif
+    // ---- phase C: slack recovery, z~, and the x / z / y updates
+    {
+      double xx[8];
+#pragma unroll
+      for (int d = 0; d < 8; ++d)
+        xx[d] = wx[tw * 8 + d];
+#pragma unroll
+      for (int i = 0; i < RL; ++i)
+      {
+        double dot = 0.0;
+#pragma unroll
+        for (int d = 0; d < 8; ++d)
+          if (d < D)
+            dot = __builtin_fma(cfl[(i * D + d) * 64], xx[d], dot);
+        double ax = dot;
+        // slack recovery.  With v_k = t_k - rho_r s_k dot and f = fac sum_k sd_k v_k (admm_phase_c):  sum_k sd_k v_k = gs - rho_r kappa dot
+        // and rho_r - fac rho_r kappa = fac, so  x~_k = (v_k - s_k f) dinv_k = (t_k - s_k h) dinv_k  with  h = fac (dot + gs)
+        const double h = fac[i] * (dot + gsa[i]);
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+          if (k == 0 || (aux2 >> i & 1))
+          {
+            const double xt = __builtin_fma(-sa[i][k], h, ta[i][k]) * dnv[i][k];
+            ax = __builtin_fma(sa[i][k], xt, ax);
+            const double xn = __builtin_fma(al, xt, oma * xa[i][k]);
+            [[maybe_unused]] const double dxa = xn - xa[i][k];
+            xa[i][k] = xn;
+            const double zt = bba[i][k] * xt;
+            const double zrl = __builtin_fma(al, zt, oma * zba[i][k]);
+            const double zn = fmax(__builtin_fma(rbi, yba[i][k], zrl), 0.0);  // (upper bound INFTY * E >= 1e26: never reached by a finite iterate)
+            const double dy = rb * (zrl - zn);
+            zba[i][k] = zn;
+            yba[i][k] += dy;
+            if (keep && k < nax[i])
+            {
+              w.dxa[aid[i] + k] = dxa;
+              w.dyba[aid[i] + k] = dy;
+            }
+          }
+        {
+          const double zrl = __builtin_fma(al, ax, oma * z[i]);
+          const double zn = clampd(__builtin_fma(rri[i], y[i], zrl), lo[i], hi[i]);
+          const double dy = rr[i] * (zrl - zn);
+          z[i] = zn;
+          y[i] += dy;
+          if (keep && rid[i] >= 0)
+            w.dyr[rid[i]] = dy;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < NV; ++j)
+      {
+        const double xt = wx[tw * 8 + ((j < nv) ? k0 + j : 0)];
+        const double xn = __builtin_fma(al, xt, oma * x[j]);
+        [[maybe_unused]] const double dx = xn - x[j];
+        x[j] = (j < nv) ? xn : 0.0;
+        const double zt = bb[j] * xt;
+        const double zrl = __builtin_fma(al, zt, oma * zb[j]);
+        const double zn = clampd(__builtin_fma(rvi[j], yb[j], zrl), lb[j], ub[j]);
+        const double dy = rv[j] * (zrl - zn);
+        zb[j] = (j < nv) ? zn : 0.0;
+        yb[j] = (j < nv) ? yb[j] + dy : 0.0;
+        if (keep && j < nv)
+        {
+          w.dxp[tw * D + k0 + j] = dx;
+          w.dybp[tw * D + k0 + j] = dy;
+        }
+      }
+    }
+    TMX_SYNC();
+  };
+  for (int it = 0; it + 1 < n_iter; ++it)
+    iterate(std::false_type{});
+  iterate(std::true_type{});
+  // ---- store the iterate
+#pragma unroll
+  for (int i = 0; i < RL; ++i)
+    if (rid[i] >= 0)
+    {
+      w.zr[rid[i]] = z[i];
+      w.yr[rid[i]] = y[i];
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+        if (k < nax[i])
+        {
+          w.xa[aid[i] + k] = xa[i][k];
+          w.zba[aid[i] + k] = zba[i][k];
+          w.yba[aid[i] + k] = yba[i][k];
+        }
+    }
+#pragma unroll
+  for (int j = 0; j < NV; ++j)
+    if (j < nv)
+    {
+      w.xp[tw * D + k0 + j] = x[j];
+      w.zbp[tw * D + k0 + j] = zb[j];
+      w.ybp[tw * D + k0 + j] = yb[j];
+    }
+  TMX_SYNC();
+}
+
+// ---- the ADMM loop of one QP as separately compiled functions (the nesting of qp_admm_fast_nl / qp_check_nl, tmx_solve.h) ----------
+TMX_DEVFN QpShared* wave_ws_rebuild(QpWs& w, const DevProblem* P, const DevBatch* Bt, int b, double* smem, WvLds* Lout = nullptr)
+{
+  const WvLds L = wave_ws_carve(w, P, Bt, b, smem);
+  if (Lout)
+    *Lout = L;
+  QpShared* sh = reinterpret_cast<QpShared*>(w.wself);
+  w.rho = sh->rho;
+  w.sigma = sh->sigma;
+  w.alpha = sh->alpha;
+  w.c = sh->c;
+  w.cinv = sh->cinv;
+  return sh;
+}
+// between two bursts (iteration `iter` just done): residuals, termination test, adaptive rho with re-factorisation; returns 1 when
+// the loop ends
+__device__ __attribute__((noinline)) static int wave_check_nl(const DevProblem* P_in, const DevBatch* Bt_in, int b_in, int iter_in, unsigned lds_in)
+{
+  constexpr int NT = 64;
+  const DevProblem* P = tmx_uniform_ptr(P_in);
+  const DevBatch* Bt = tmx_uniform_ptr(Bt_in);
+  const int b = __builtin_amdgcn_readfirstlane(b_in), iter = __builtin_amdgcn_readfirstlane(iter_in);
+  const int tid = threadIdx.x;
+  double* smem = (double*)(tmx_lds_d*)(size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)lds_in);
+  const tmx_osqp_settings& st = P->osqp;
+  QpWs w;
+  QpShared* sh = wave_ws_rebuild(w, P, Bt, b, smem);
+  QpInfo info = sh->info;
+  const bool can_check = st.check_termination && (iter % st.check_termination == 0);
+  const bool do_rho = st.adaptive_rho && st.adaptive_rho_interval && (iter % st.adaptive_rho_interval == 0);
+  int ended = 0;
+  if (can_check || do_rho)
+  {
+    info.iter = iter;
+    compute_residuals(w, P, w.xp, w.xa, w.yr, w.ybp, w.yba, 0, info, info.prim_res, info.dual_res, true, tid, NT);
+  }
+  if (can_check && TMX_UNI_B(check_termination(w, P, info, false, tid, NT)))
+    ended = 1;
+  double rho = w.rho;
+  if (!ended && do_rho)
+  {
+    const double rho_new = rho_estimate(w, info);
+    if (TMX_UNI_B((rho_new > w.rho * st.adaptive_rho_tolerance) || (rho_new < w.rho / st.adaptive_rho_tolerance)))
+    {
+      w.rho = fmin(fmax(rho_new, TMX_RHO_MIN), TMX_RHO_MAX);
+      rho = w.rho;
+      info.rho_updates += 1;
+      kkt_factor(w, P, 0, w.sigma, st.delta, tid, NT);
+      wave_twist_invert(w, ((w.T | 1) - 1) / 2, tid);
+      admm_cache_weights(w, tid, NT);
+    }
+  }
+  TMX_SYNC();
+  if (tid == 0)
+  {
+    sh->info = info;
+    sh->rho = rho;
+    sh->can_check = can_check ? 1 : 0;
+    sh->have_res = 0;
+  }
+  TMX_SYNC();
+  return ended;
+}
+// the whole ADMM loop of one QP (osqp_solve): in / out through the LDS record
+__device__ __attribute__((noinline)) static void wave_admm_nl(const DevProblem* P_in, const DevBatch* Bt_in, int b_in, unsigned lds_in)
+{
+  const DevProblem* P = tmx_uniform_ptr(P_in);
+  const DevBatch* Bt = tmx_uniform_ptr(Bt_in);
+  const int b = __builtin_amdgcn_readfirstlane(b_in);
+  const int tid = threadIdx.x;
+  const unsigned lds_off = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_in);
+  double* smem = (double*)(tmx_lds_d*)(size_t)lds_off;
+  const tmx_osqp_settings& st = P->osqp;
+  int iter = 0, ended = 0;
+  while (iter < st.max_iter)
+  {
+    // the next iteration at which something is looked at
+    int next = st.max_iter;
+    if (st.check_termination)
+      next = min(next, (iter / st.check_termination + 1) * st.check_termination);
+    if (st.adaptive_rho && st.adaptive_rho_interval)
+      next = min(next, (iter / st.adaptive_rho_interval + 1) * st.adaptive_rho_interval);
+    {
+      QpWs w;
+      WvLds L;
+      wave_ws_rebuild(w, P, Bt, b, smem, &L);
+      if (((w.T | 1) - 1) / 2 == 15 && w.D == 7)  // 7-DOF arm over 30 | 31 waypoints (BASELINE config 1)
+        wave_admm_burst<15, 7>(w, P, L, next - iter, tid);
+      else
+        wave_admm_burst<0, 0>(w, P, L, next - iter, tid);
+    }
+    iter = next;
+    ended = wave_check_nl(P, Bt, b, iter, lds_off);
+    if (ended)
+      break;
+  }
+  if (!ended)
+    iter = st.max_iter + 1;  // the loop `for (iter = 1; iter <= max_iter; ++iter)` ran out
+  QpWs w0;
+  QpShared* sh = wave_ws_rebuild(w0, P, Bt, b, smem);
+  if (tid == 0)
+  {
+    sh->terminated = ended;
+    sh->iter = iter;
+  }
+  TMX_SYNC();
+}
+
+// ---- K5 on one wave: Model::optimize() of problem b --------------------------------------------------------------------------------
+// The sequence of qp_solve_block (tmx_solve.h) - load, Ruiz, rho types, warm-start rule, factor, ADMM with the termination test every
+// check_termination iterations and adaptive rho, polish, store - without pair rows / bands / function costs; NT = 64.
+TMX_DEVFN void qp_solve_wave(const DevProblem* P, const DevBatch* Bt, int b, double* smem, int tid)
+{
+  constexpr int NT = 64;
+  const int D = P->D, T = P->T, NX = P->NX, R = P->R;
+  const tmx_osqp_settings& st = P->osqp;
+  QpWs w;
+  wave_ws_carve(w, P, Bt, b, smem);
+  const int m = ((T | 1) - 1) / 2;  // middle block of the twisted chain (wave_admm_burst)
+  const int* g_act = Bt->active + (size_t)b * R;
+  const double* g_coef = Bt->coef + (size_t)b * R * D;
+  const double* g_rhs = Bt->rhs + (size_t)b * R;
+  const double* g_x = Bt->x + (size_t)b * NX;
+  const double* g_merit = Bt->merit + (size_t)b * P->n_cnts;
+  const double trust = Bt->trust[b];
+  const int* dims = Bt->dims + 4 * b;
+  const unsigned long long* hs = Bt->hashes + 4 * b;
+  // ---------------- load (unscaled) --------------------------------------------------------------------
+  for (int r = tid; r < R; r += NT)
+  {
+    w.act[r] = g_act[r];
+    w.naux[r] = P->slot_naux[r];
+    w.aoff[r] = P->slot_aoff[r];
+    w.slot_t[r] = P->slot_t[r];
+    w.wp_list[r] = P->wp_list[r];
+    w.flg_r[r] = 0;
+    w.Er[r] = 1.0;
+    w.zr[r] = 0.0;
+    w.yr[r] = 0.0;
+    w.dyr[r] = 0.0;
+    w.lor[r] = P->slot_eq[r] ? g_rhs[r] : -TMX_OSQP_INFTY;
+    w.hir[r] = g_rhs[r];
+    for (int j = 0; j < D; ++j)
+      w.coef[r * D + j] = g_act[r] ? g_coef[r * D + j] : 0.0;
+    const double oc = aux_cost(P, g_merit, r);
+    for (int k = 0; k < P->slot_naux[r]; ++k)
+    {
+      const int a = P->slot_aoff[r] + k;
+      w.sa[a] = aux_sign(P->slot_naux[r], k);
+      w.qa[a] = oc;
+      w.bba[a] = 1.0;
+      w.Da[a] = 1.0;
+      w.Eba[a] = 1.0;
+      w.xa[a] = 0.0;
+      w.zba[a] = 0.0;
+      w.yba[a] = 0.0;
+      w.dxa[a] = 0.0;
+      w.dyba[a] = 0.0;
+      w.flg_ba[a] = 0;
+    }
+  }
+  for (int v = tid; v < NX; v += NT)
+  {
+    const int j = v % D;
+    const double xi = fmin(fmax(g_x[v], P->jl[j]), P->ju[j]);
+    const double lb = fmax(xi - trust, P->jl[j]), ub = fmin(xi + trust, P->ju[j]);
+    w.lbp[v] = fmax(lb, -TMX_OSQP_INFTY);
+    w.ubp[v] = fmin(ub, TMX_OSQP_INFTY);
+    w.qp[v] = primary_q(P, Bt->qdyn + (size_t)b * NX, v);
+    w.pd[v] = P->pd[v];
+    w.po[v] = (v < NX - D) ? P->po[v] : 0.0;
+    w.bbp[v] = 1.0;
+    w.Dp[v] = 1.0;
+    w.Ebp[v] = 1.0;
+    w.xp[v] = 0.0;
+    w.zbp[v] = 0.0;
+    w.ybp[v] = 0.0;
+    w.dxp[v] = 0.0;
+    w.dybp[v] = 0.0;
+    w.flg_bp[v] = 0;
+  }
+  for (int t = tid; t <= T; t += NT)
+    w.wp_start[t] = P->wp_start[t];
+  w.sigma = st.sigma;
+  w.alpha = st.alpha;
+  w.c = 1.0;
+  w.cinv = 1.0;
+  TMX_SYNC();
+  // position of every active row / of its aux vars in the reference-order solution vectors (exclusive prefix counts by chunks)
+  {
+    int* scan = reinterpret_cast<int*>(w.red);
+    const int C = (R + NT - 1) / NT;
+    const int r0 = tid * C < R ? tid * C : R, r1 = (tid + 1) * C < R ? (tid + 1) * C : R;
+    for (int pass = 0; pass < 2; ++pass)
+    {
+      int cnt = 0;
+      for (int r = r0; r < r1; ++r)
+        cnt += w.act[r] ? (pass == 0 ? 1 : w.naux[r]) : 0;
+      TMX_SYNC();
+      scan[tid] = cnt;
+      TMX_SYNC();
+      int off = 0;
+      for (int u = 0; u < tid; ++u)
+        off += scan[u];
+      for (int r = r0; r < r1; ++r)
+      {
+        if (pass == 0)
+          w.row_ref[r] = off;
+        else
+          w.aux_ref[r] = NX + off;
+        off += w.act[r] ? (pass == 0 ? 1 : w.naux[r]) : 0;
+      }
+    }
+    TMX_SYNC();
+  }
+  const int n = dims[0], mq = dims[1], mg = mq - n;
+  double* const t_ebp = w.dybp;
+  double* const t_eba = w.dyba;
+  double* const t_da = w.ta;
+  // ---------------- Ruiz equilibration (scale_data) ------------------------------------------------------
+  for (int it = 0; it < st.scaling; ++it)
+  {
+    for (int v = tid; v < NX; v += NT)
+    {
+      const int t = v / D, j = v % D;
+      double cn = fabs(w.pd[v]);
+      if (t > 0)
+        cn = fmax(cn, fabs(w.po[v - D]));
+      if (t < T - 1)
+        cn = fmax(cn, fabs(w.po[v]));
+      for (int q = w.wl_start[t]; q < w.wl_start[t + 1]; ++q)
+      {
+        const int r = w.wl_list[q];
+        if (w.act[r])
+          cn = fmax(cn, fabs(w.coef[r * D + j]));
+      }
+      cn = fmax(cn, fabs(w.bbp[v]));
+      w.tp[v] = 1.0 / sqrt(limit_scaling(cn));
+      t_ebp[v] = 1.0 / sqrt(limit_scaling(fabs(w.bbp[v])));
+    }
+    TMX_ROWS(w, r)
+    {
+      if (!w.act[r])
+        continue;
+      double rn = 0.0;
+      for (int j = 0; j < D; ++j)
+        rn = fmax(rn, fabs(w.coef[r * D + j]));
+      for (int k = 0; k < w.naux[r]; ++k)
+      {
+        const int a = w.aoff[r] + k;
+        rn = fmax(rn, fabs(w.sa[a]));
+        t_da[a] = 1.0 / sqrt(limit_scaling(fmax(fabs(w.sa[a]), fabs(w.bba[a]))));
+        t_eba[a] = 1.0 / sqrt(limit_scaling(fabs(w.bba[a])));
+      }
+      w.hr[r] = 1.0 / sqrt(limit_scaling(rn));
+    }
+    TMX_SYNC();
+    for (int v = tid; v < NX; v += NT)
+    {
+      w.pd[v] = (w.tp[v] * w.pd[v]) * w.tp[v];
+      if (v < NX - D)
+        w.po[v] = (w.tp[v] * w.po[v]) * w.tp[v + D];
+      w.bbp[v] = (t_ebp[v] * w.bbp[v]) * w.tp[v];
+      w.qp[v] *= w.tp[v];
+      w.Dp[v] *= w.tp[v];
+      w.Ebp[v] *= t_ebp[v];
+    }
+    TMX_ROWS(w, r)
+    {
+      if (!w.act[r])
+        continue;
+      const int t = w.slot_t[r];
+      for (int j = 0; j < D; ++j)
+        w.coef[r * D + j] = (w.hr[r] * w.coef[r * D + j]) * w.tp[t * D + j];
+      for (int k = 0; k < w.naux[r]; ++k)
+      {
+        const int a = w.aoff[r] + k;
+        w.sa[a] = (w.hr[r] * w.sa[a]) * t_da[a];
+        w.bba[a] = (t_eba[a] * w.bba[a]) * t_da[a];
+        w.qa[a] *= t_da[a];
+        w.Da[a] *= t_da[a];
+        w.Eba[a] *= t_eba[a];
+      }
+      w.Er[r] *= w.hr[r];
+    }
+    TMX_SYNC();
+    // cost normalisation: mean column inf-norm of P (aux columns are empty), ||q||_inf
+    double qmax = 0.0;
+    for (int v = tid; v < NX; v += NT)
+    {
+      const int t = v / D;
+      double cn = fabs(w.pd[v]);
+      if (t > 0)
+        cn = fmax(cn, fabs(w.po[v - D]));
+      if (t < T - 1)
+        cn = fmax(cn, fabs(w.po[v]));
+      w.tp[v] = cn;
+      qmax = fmax(qmax, fabs(w.qp[v]));
+    }
+    TMX_ROWS(w, r)
+      if (w.act[r])
+        for (int k = 0; k < w.naux[r]; ++k)
+          qmax = fmax(qmax, fabs(w.qa[w.aoff[r] + k]));
+    qmax = wave_allreduce<false>(qmax);
+    TMX_SYNC();
+    double csum = 0.0;
+    for (int v = tid; v < NX; v += NT)
+      csum += w.tp[v];
+    csum = wave_allreduce<true>(csum);
+    double c_temp = csum / (double)n;
+    c_temp = fmax(c_temp, limit_scaling(qmax));
+    c_temp = limit_scaling(c_temp);
+    const double ct = 1.0 / c_temp;
+    TMX_SYNC();
+    for (int v = tid; v < NX; v += NT)
+    {
+      w.pd[v] *= ct;
+      w.po[v] *= ct;
+      w.qp[v] *= ct;
+    }
+    TMX_ROWS(w, r)
+      if (w.act[r])
+        for (int k = 0; k < w.naux[r]; ++k)
+          w.qa[w.aoff[r] + k] *= ct;
+    w.c *= ct;
+    TMX_SYNC();
+  }
+  w.cinv = 1.0 / w.c;
+  for (int v = tid; v < NX; v += NT)
+  {
+    w.lbp[v] *= w.Ebp[v];
+    w.ubp[v] *= w.Ebp[v];
+    w.typ_bp[v] = constr_type(w.lbp[v], w.ubp[v]);
+  }
+  int bad_aux = 0;
+  TMX_ROWS(w, r)
+  {
+    if (!w.act[r])
+      continue;
+    w.lor[r] *= w.Er[r];
+    w.hir[r] *= w.Er[r];
+    w.typ_r[r] = constr_type(w.lor[r], w.hir[r]);
+    for (int k = 0; k < w.naux[r]; ++k)
+    {
+      w.typ_ba[w.aoff[r] + k] = constr_type(0.0, TMX_OSQP_INFTY * w.Eba[w.aoff[r] + k]);
+      bad_aux |= w.typ_ba[w.aoff[r] + k] != 0;
+    }
+  }
+  TMX_SYNC();
+  // (the burst takes rho itself for the slack bound rows; any other type would be a scaling outside [1e-4, 1e4])
+  const bool burst_ok = __builtin_amdgcn_ballot_w64(bad_aux != 0) == 0ULL;
+
+  // ---------------- warm start decision (createOrUpdateSolver, osqp_interface.cpp:283-370) -----------------
+  const int* pd4 = Bt->prev_dims + 4 * b;
+  const unsigned long long* pws = Bt->prev_ws + 2 * b;
+  bool warm = Bt->prev_ok[b] && st.warm_starting;
+  const bool P_eq = warm && pd4[0] == dims[0] && pd4[2] == dims[2] && pws[0] == hs[2];
+  const bool A_eq = P_eq && pd4[0] == dims[0] && pd4[1] == dims[1] && pd4[3] == dims[3] && pws[1] == hs[3];
+  warm = TMX_UNI_B(warm && P_eq && A_eq);
+  w.rho = warm ? Bt->prev_rho[b] : st.rho;
+  w.rho = fmin(fmax(w.rho, TMX_RHO_MIN), TMX_RHO_MAX);
+  if (warm)
+  {
+    const double* xq = Bt->xq + (size_t)b * P->n_max;
+    const double* yq = Bt->yq + (size_t)b * P->m_max;
+    for (int v = tid; v < NX; v += NT)
+    {
+      w.xp[v] = (1.0 / w.Dp[v]) * xq[v];
+      w.ybp[v] = ((1.0 / w.Ebp[v]) * yq[mg + v]) * w.c;
+    }
+    TMX_ROWS(w, r)
+      if (w.act[r])
+      {
+        w.yr[r] = ((1.0 / w.Er[r]) * yq[w.row_ref[r]]) * w.c;
+        for (int k = 0; k < w.naux[r]; ++k)
+        {
+          const int a = w.aoff[r] + k;
+          w.xa[a] = (1.0 / w.Da[a]) * xq[w.aux_ref[r] + k];
+          w.yba[a] = ((1.0 / w.Eba[a]) * yq[mg + w.aux_ref[r] + k]) * w.c;
+        }
+      }
+    TMX_SYNC();
+    for (int v = tid; v < NX; v += NT)
+      w.zbp[v] = w.bbp[v] * w.xp[v];
+    TMX_ROWS(w, r)
+      if (w.act[r])
+      {
+        const int t = w.slot_t[r];
+        double ax = 0.0;
+        for (int j = 0; j < D; ++j)
+          ax += w.coef[r * D + j] * w.xp[t * D + j];
+        for (int k = 0; k < w.naux[r]; ++k)
+        {
+          const int a = w.aoff[r] + k;
+          ax += w.sa[a] * w.xa[a];
+          w.zba[a] = w.bba[a] * w.xa[a];
+        }
+        w.zr[r] = ax;
+      }
+    TMX_SYNC();
+  }
+
+  // ---------------- factor + ADMM loop (osqp_solve) --------------------------------------------------------
+  kkt_factor(w, P, 0, w.sigma, st.delta, tid, NT);
+  wave_twist_invert(w, m, tid);
+  admm_cache_weights(w, tid, NT);
+  QpInfo info;
+  info.status = 11;  // OSQP_UNSOLVED
+  info.iter = 0;
+  info.rho_updates = 0;
+  info.polish_status = 0;
+  info.prim_res = info.dual_res = 0.0;
+  int iter = 0;
+  bool can_check = false, terminated = false;
+  (void)burst_ok;
+  {
+    // the ADMM loop is a function of its own (one function = one register allocation: tmx_solve.h, qp_admm_fast_nl); state crosses
+    // the call through the record in the descriptor slot of the LDS workspace
+    QpShared* sh = reinterpret_cast<QpShared*>(w.wself);
+    if (tid == 0)
+    {
+      sh->rho = w.rho;
+      sh->sigma = w.sigma;
+      sh->alpha = w.alpha;
+      sh->c = w.c;
+      sh->cinv = w.cinv;
+      sh->info = info;
+      sh->terminated = 0;
+      sh->can_check = 0;
+      sh->iter = 0;
+      sh->have_res = 0;
+    }
+    TMX_SYNC();
+    unsigned lds_off = (unsigned)(size_t)smem;
+    TMX_ASM_OPAQUE_SGPR(lds_off);
+    wave_admm_nl(P, Bt, b, lds_off);
+    info = sh->info;
+    w.rho = sh->rho;
+    terminated = sh->terminated != 0;
+    can_check = sh->can_check != 0;
+    iter = sh->iter;
+    TMX_SYNC();
+  }
+  const int exit_iter = terminated ? iter : iter - 1;
+  if (!can_check)
+  {
+    info.iter = exit_iter;
+    compute_residuals(w, P, w.xp, w.xa, w.yr, w.ybp, w.yba, 0, info, info.prim_res, info.dual_res, true, tid, NT);
+    check_termination(w, P, info, false, tid, NT);
+  }
+  if (info.status == 11)
+  {
+    if (!check_termination(w, P, info, true, tid, NT))
+      info.status = 7;  // OSQP_MAX_ITER_REACHED
+  }
+
+  // ---------------- polish (polish.c) ---------------------------------------------------------------------
+  if (TMX_UNI_B(st.polishing && info.status == 1))
+  {
+    const double delta = st.delta;
+    const QpWs& wp = w;
+    for (int v = tid; v < NX; v += NT)
+    {
+      int f = 0;
+      if (wp.zbp[v] - wp.lbp[v] < -wp.ybp[v])
+        f = -1;
+      else if (wp.ubp[v] - wp.zbp[v] < wp.ybp[v])
+        f = 1;
+      wp.flg_bp[v] = f;
+    }
+    TMX_ROWS(wp, r)
+    {
+      if (!wp.act[r])
+        continue;
+      int f = 0;
+      if (wp.zr[r] - wp.lor[r] < -wp.yr[r])
+        f = -1;
+      else if (wp.hir[r] - wp.zr[r] < wp.yr[r])
+        f = 1;
+      wp.flg_r[r] = f;
+      for (int k = 0; k < wp.naux[r]; ++k)
+      {
+        const int a = wp.aoff[r] + k;
+        int fa = 0;
+        if (wp.zba[a] - 0.0 < -wp.yba[a])
+          fa = -1;
+        else if (TMX_OSQP_INFTY * wp.Eba[a] - wp.zba[a] < wp.yba[a])
+          fa = 1;
+        wp.flg_ba[a] = fa;
+      }
+    }
+    TMX_SYNC();
+    kkt_factor(wp, P, 1, delta, delta, tid, NT);
+    kkt_invert_chain_wave0(wp, tid);
+    for (int pass = 0; pass <= st.polish_refine_iter; ++pass)
+    {
+      TMX_ROWS(wp, r)
+      {
+        double g = 0.0;
+        if (wp.act[r] && wp.flg_r[r] != 0)
+        {
+          double r2 = (wp.flg_r[r] < 0) ? wp.lor[r] : wp.hir[r];
+          if (pass > 0)
+          {
+            const int t = wp.slot_t[r];
+            double ax = 0.0;
+            for (int j = 0; j < D; ++j)
+              ax += wp.coef[r * D + j] * wp.dxp[t * D + j];
+            for (int k = 0; k < wp.naux[r]; ++k)
+              ax += wp.sa[wp.aoff[r] + k] * wp.dxa[wp.aoff[r] + k];
+            r2 -= ax;
+          }
+          g = r2;
+        }
+        wp.hr[r] = g;
+      }
+      TMX_SYNC();
+      for (int v = tid; v < NX; v += NT)
+      {
+        double r1 = -wp.qp[v];
+        double gb = 0.0;
+        if (wp.flg_bp[v] != 0)
+        {
+          double r2 = (wp.flg_bp[v] < 0) ? wp.lbp[v] : wp.ubp[v];
+          if (pass > 0)
+            r2 -= wp.bbp[v] * wp.dxp[v];
+          gb = r2 / delta;
+        }
+        if (pass > 0)
+          r1 -= p_times(wp, wp.dxp, v) + at_rows(wp, P, wp.dyr, v) + wp.bbp[v] * wp.dybp[v];
+        wp.tp[v] = r1 + wp.bbp[v] * gb;
+      }
+      TMX_ROWS(wp, r)
+        if (wp.act[r])
+          for (int k = 0; k < wp.naux[r]; ++k)
+          {
+            const int a = wp.aoff[r] + k;
+            double r1 = -wp.qa[a];
+            double gb = 0.0;
+            if (wp.flg_ba[a] != 0)
+            {
+              double r2 = (wp.flg_ba[a] < 0) ? 0.0 : TMX_OSQP_INFTY * wp.Eba[a];
+              if (pass > 0)
+                r2 -= wp.bba[a] * wp.dxa[a];
+              gb = r2 / delta;
+            }
+            if (pass > 0)
+              r1 -= wp.sa[a] * wp.dyr[r] + wp.bba[a] * wp.dyba[a];
+            wp.ta[a] = r1 + wp.bba[a] * gb;
+          }
+      TMX_SYNC();
+      kkt_solve(wp, P, 1, delta, delta, tid, NT);
+      TMX_ROWS(wp, r)
+      {
+        if (!wp.act[r])
+          continue;
+        const double dy = (wp.flg_r[r] != 0) ? wp.hr[r] : 0.0;
+        wp.zr[r] = dy;  // z_r is dead after the active-set guess: it carries this pass's dy_r
+      }
+      TMX_SYNC();
+      for (int v = tid; v < NX; v += NT)
+      {
+        double dyb = 0.0;
+        if (wp.flg_bp[v] != 0)
+        {
+          double r2 = (wp.flg_bp[v] < 0) ? wp.lbp[v] : wp.ubp[v];
+          if (pass > 0)
+            r2 -= wp.bbp[v] * wp.dxp[v];
+          dyb = (wp.bbp[v] * wp.tp[v] - r2) / delta;
+        }
+        if (pass == 0)
+        {
+          wp.dxp[v] = wp.tp[v];
+          wp.dybp[v] = dyb;
+        }
+        else
+        {
+          wp.dxp[v] += wp.tp[v];
+          wp.dybp[v] += dyb;
+        }
+      }
+      TMX_ROWS(wp, r)
+      {
+        if (!wp.act[r])
+          continue;
+        for (int k = 0; k < wp.naux[r]; ++k)
+        {
+          const int a = wp.aoff[r] + k;
+          double dyb = 0.0;
+          if (wp.flg_ba[a] != 0)
+          {
+            double r2 = (wp.flg_ba[a] < 0) ? 0.0 : TMX_OSQP_INFTY * wp.Eba[a];
+            if (pass > 0)
+              r2 -= wp.bba[a] * wp.dxa[a];
+            dyb = (wp.bba[a] * wp.ta[a] - r2) / delta;
+          }
+          if (pass == 0)
+          {
+            wp.dxa[a] = wp.ta[a];
+            wp.dyba[a] = dyb;
+          }
+          else
+          {
+            wp.dxa[a] += wp.ta[a];
+            wp.dyba[a] += dyb;
+          }
+        }
+        if (pass == 0)
+          wp.dyr[r] = wp.zr[r];
+        else
+          wp.dyr[r] += wp.zr[r];
+      }
+      TMX_SYNC();
+    }
+    QpInfo dummy = info;
+    double pprim = 0.0, pdual = 0.0;
+    compute_residuals(wp, P, wp.dxp, wp.dxa, wp.dyr, wp.dybp, wp.dyba, 1, dummy, pprim, pdual, false, tid, NT);
+    const bool ok = (pprim < info.prim_res && pdual < info.dual_res) || (pprim < info.prim_res && info.dual_res < 1e-10) ||
+                    (pdual < info.dual_res && info.prim_res < 1e-10);
+    if (ok)
+    {
+      info.polish_status = 1;
+      info.prim_res = pprim;
+      info.dual_res = pdual;
+      for (int v = tid; v < NX; v += NT)
+      {
+        wp.xp[v] = wp.dxp[v];
+        wp.ybp[v] = wp.dybp[v];
+      }
+      TMX_ROWS(wp, r)
+        if (wp.act[r])
+        {
+          wp.yr[r] = wp.dyr[r];
+          for (int k = 0; k < wp.naux[r]; ++k)
+          {
+            const int a = wp.aoff[r] + k;
+            wp.xa[a] = wp.dxa[a];
+            wp.yba[a] = wp.dyba[a];
+          }
+        }
+    }
+    else
+      info.polish_status = -1;
+    TMX_SYNC();
+  }
+
+  // ---------------- store solution (unscaled, reference order) + record -----------------------------------
+  const bool has_sol = !(info.status == 3 || info.status == 4 || info.status == 5 || info.status == 6 || info.status == 9);
+  double* xq = Bt->xq + (size_t)b * P->n_max;
+  double* yq = Bt->yq + (size_t)b * P->m_max;
+  const double nanv = NAN;
+  unsigned long long hact = 0ULL;
+  for (int v = tid; v < NX; v += NT)
+  {
+    xq[v] = has_sol ? w.Dp[v] * w.xp[v] : nanv;
+    yq[mg + v] = has_sol ? (w.cinv * w.Ebp[v]) * w.ybp[v] : nanv;
+    hact += tmx_hash_term((long long)w.flg_bp[v], (uint64_t)(mg + v), 5);
+  }
+  TMX_ROWS(w, r)
+    if (w.act[r])
+    {
+      yq[w.row_ref[r]] = has_sol ? (w.cinv * w.Er[r]) * w.yr[r] : nanv;
+      hact += tmx_hash_term((long long)w.flg_r[r], (uint64_t)w.row_ref[r], 5);
+      for (int k = 0; k < w.naux[r]; ++k)
+      {
+        const int a = w.aoff[r] + k;
+        xq[w.aux_ref[r] + k] = has_sol ? w.Da[a] * w.xa[a] : nanv;
+        yq[mg + w.aux_ref[r] + k] = has_sol ? (w.cinv * w.Eba[a]) * w.yba[a] : nanv;
+        hact += tmx_hash_term((long long)w.flg_ba[a], (uint64_t)(mg + w.aux_ref[r] + k), 5);
+      }
+    }
+  unsigned long long* hacc = reinterpret_cast<unsigned long long*>(w.red + 130);
+  if (tid == 0)
+    *hacc = 0ULL;
+  TMX_SYNC();
+  TMX_ATOMIC_ADD_U64(hacc, hact);
+  TMX_SYNC();
+  if (tid == 0)
+  {
+    info.iter = (info.iter == 0) ? exit_iter : info.iter;
+    tmx_qp_record rec;
+    rec.n = n;
+    rec.m = mq;
+    rec.nnzP = dims[2];
+    rec.nnzA = dims[3];
+    rec.warm_started = warm ? 1 : 0;
+    rec.osqp_status = info.status;
+    rec.osqp_iter = info.iter;
+    rec.rho_updates = info.rho_updates;
+    rec.polish_status = info.polish_status;
+    rec.pad_ = 0;
+    rec.hashP = hs[0];
+    rec.hashA = hs[1];
+    rec.hash_active = *hacc;
+    rec.rho_final = w.rho;
+    Bt->rec_last[b] = rec;
+    const int k = Bt->rec_count[b];
+    if (k < Bt->max_rec)
+      Bt->rec_log[(size_t)b * Bt->max_rec + k] = rec;
+    Bt->rec_count[b] = k + 1;
+    Bt->admm_iters[b] += info.iter;
+    Bt->cvx[b] = (info.status == 1 || info.status == 2) ? TMX_CVX_SOLVED : (has_sol ? TMX_CVX_FAILED : TMX_CVX_INFEASIBLE);
+    Bt->prev_ok[b] = (info.status == 1 || info.status == 2) ? 1 : 0;
+    Bt->prev_rho[b] = w.rho;
+    for (int q = 0; q < 4; ++q)
+      Bt->prev_dims[4 * b + q] = dims[q];
+    Bt->prev_ws[2 * b + 0] = hs[2];
+    Bt->prev_ws[2 * b + 1] = hs[3];
+  }
+  TMX_SYNC();
+}
+
+// One trust-region evaluation of problem b on one wave (sqp_step_block with the one-wave Model::optimize())
+TMX_DEVFN void sqp_step_wave(const DevProblem* P, const DevBatch* Bt, int b, double* smem, int tid)
+{
+  constexpr int NT = 64;
+  const int R = P->R, D = P->D, NX = P->NX;
+  int* act = Bt->active + (size_t)b * R;
+  double* coef = Bt->coef + (size_t)b * R * D;
+  double* rhs = Bt->rhs + (size_t)b * R;
+  double* x = Bt->x + (size_t)b * NX;
+  double* xn = Bt->xnew + (size_t)b * NX;
+  const double* xq = Bt->xq + (size_t)b * P->n_max;
+  if (P->sqp.max_time < 1e300)
+  {
+    if (tid == 0)
+      sqp_time_limit_check(P, Bt, b);
+    TMX_SYNC();
+    if (Bt->phase[b] == PHASE_DONE)
+      return;
+  }
+  if (Bt->phase[b] == PHASE_CONVEXIFY)
+  {
+    convexify_terms(P, x, act, coef, Bt->coef2, rhs, smem, tid, NT, Bt->rowc + (size_t)b * R, Bt->qdyn + (size_t)b * NX);
+    qp_structure(P, act, coef, Bt->coef2, rhs, x, Bt->trust[b], Bt->merit + (size_t)b * P->n_cnts, Bt->dims + 4 * b, Bt->hashes + 4 * b, nullptr,
+                 reinterpret_cast<int*>(smem), tid, NT, Bt->qdyn + (size_t)b * NX, nullptr);
+  }
+  TMX_SYNC();
+  qp_solve_wave(P, Bt, b, smem, tid);
+  for (int v = tid; v < NX; v += NT)
+    xn[v] = xq[v];
+  TMX_SYNC();
+  evaluate_terms(P, xn, Bt->new_cost_vals + (size_t)b * P->n_costs, Bt->new_cnt_viols + (size_t)b * P->n_cnts, smem, tid, NT);
+  sqp_update_block(P, Bt, b, smem, tid, NT);
+  TMX_SYNC();
+}
+#endif  // TMX_IS_DEVICE
