@@ -27,7 +27,44 @@
 
 #include "tmx_wave_plan.h"
 
+// phase profile of the one-wave solver (-DTMX_WAVE_PROF): shader-clock cycles of lane 0 per phase, accumulated in DevBatch::prof
+//   0 setup (load, Ruiz, warm start)  1 factorisations  2 bursts  3 checks (residuals, termination, rho)  4 polish  5 store
+//   6 convexify + QP structure  7 evaluate + SQP decision  8 ADMM iterations  9 bursts entered  10 QP solves
+#if defined(TMX_WAVE_PROF) && TMX_IS_GCN
+#define WV_CLK() ((long long)__builtin_readcyclecounter())
+#define WV_TICK(Bt, b, slot, t0)                                                                                      \
+  do                                                                                                                  \
+  {                                                                                                                   \
+    const long long now_ = WV_CLK();                                                                                  \
+    if (threadIdx.x == 0)                                                                                             \
+      (Bt)->prof[(size_t)(b) * 16 + (slot)] += now_ - (t0);                                                           \
+    (t0) = now_;                                                                                                      \
+  } while (0)
+#define WV_COUNT(Bt, b, slot, n)                                                                                      \
+  do                                                                                                                  \
+  {                                                                                                                   \
+    if (threadIdx.x == 0)                                                                                             \
+      (Bt)->prof[(size_t)(b) * 16 + (slot)] += (n);                                                                   \
+  } while (0)
+#else
+#define WV_CLK() 0LL
+#define WV_TICK(Bt, b, slot, t0) ((void)(t0))
+#define WV_COUNT(Bt, b, slot, n) ((void)0)
+#endif
+#if defined(TMX_WAVE_PROF_CHECK)
+#define WV_CTICK(slot) WV_TICK(Bt, b, slot, tbu)
+#else
+#define WV_CTICK(slot) ((void)0)
+#endif
+
 #if TMX_IS_DEVICE
+// the workspace arrays of the cold part live in the per-problem HBM scratch: addressed as GLOBAL memory inside the burst (a generic
+// pointer makes every access a FLAT one, which the compiler has to order against the LDS traffic of the chain)
+typedef __attribute__((address_space(1))) double wv_gd;
+typedef __attribute__((address_space(1))) int wv_gi;
+typedef __attribute__((address_space(1))) const int wv_cgi;
+#define WV_G(p) ((wv_gd*)(p))
+#define WV_GI(p) ((wv_gi*)(p))
 typedef unsigned tmx_wv_u2 __attribute__((ext_vector_type(2)));
 // ---- cross-lane sums (tools/ubench/btd_wave.hip) -----------------------------------------------------------------------------
 template <int CTRL>
@@ -98,15 +135,16 @@ TMX_DEVFN WvLds wave_ws_carve(QpWs& w, const DevProblem* P, const DevBatch* Bt, 
   WvLds L;
   double* p = smem;
   w.Sinv = p;
-  p += (size_t)T * D * 8;
+  w.DDS = D * 8 + TMX_WV_BPAD;  // (padded block stride: the waypoint-parallel reads of S^{-1} rows spread over the LDS banks)
+  p += (size_t)T * w.DDS;
   w.po = p;
   p += (NX + 1) & ~1;
   w.wself = p;
   p += QPWS_DOUBLES;
   L.wv = p;
-  p += ((size_t)(T | 1) + 3) * 8;
+  p += ((size_t)(T | 1) + 3) * TMX_WV_RS;
   L.wx = p;
-  p += ((size_t)(T | 1) + 3) * 8;
+  p += ((size_t)(T | 1) + 3) * TMX_WV_RS;
   L.cfl = p;
   w.tp = p;
   p += wave_lds_tp_doubles(D, T);
@@ -187,18 +225,19 @@ TMX_DEVFN void wave_twist_invert(const QpWs& w, int m, int lane)
 // gather (per lane, then across the lanes of the group) and the chain.
 // NC: the number of chain steps N as a compile-time constant (0: run time).  With a run-time N every `k <= N` of the unrolled sweeps
 // is a loop-invariant lane mask the compiler keeps in an SGPR pair (32 of them: spills, and two scalar instructions per branch)
-// DC: the block size D likewise (0: run time).
-template <int NC, int DC>
-TMX_DEVFN void wave_admm_burst(const QpWs& w, const DevProblem* P, const WvLds& L, int n_iter, int lane)
+// DC: the block size D likewise (0: run time).  AX2: the mask of the row slots that may hold a row with two slack variables (-1: run time):
+// the registers of the second slack variable of every other slot do not exist
+template <int NC, int DC, int AX2>
+TMX_DEVFN int wave_admm_burst(const QpWs& w, const DevProblem* P, const DevBatch* Bt, int b, const WvLds& L, QpShared* sh, int iter0, int lane)
 {
-  constexpr int RL = TMX_WV_RL, NV = TMX_WV_NV, KM = TMX_WV_KMAX;
+  constexpr int RL = TMX_WV_RL, NV = TMX_WV_NV, KM = TMX_WV_KMAX, RS = TMX_WV_RS;
+  [[maybe_unused]] long long tbu = WV_CLK();
   // (wave-uniform values as scalars: every `k <= N` below is a scalar branch, not an EXEC-masked region)
-  const int D = DC ? DC : TMX_UNI_I(w.D), T = TMX_UNI_I(w.T), DS = 8, DDS = 8 * D;
-  n_iter = TMX_UNI_I(n_iter);
+  const int D = DC ? DC : TMX_UNI_I(w.D), T = TMX_UNI_I(w.T), DS = 8, DDS = 8 * D + TMX_WV_BPAD;
   const int TT = T | 1, N = NC ? NC : (TT - 1) / 2, m = N;  // both half chains: N steps, the last one is the contribution to the middle block m
   const int ROW_TA = TT, ROW_TB = TT + 1, ROW_Z = TT + 2;
-  const int aux2 = TMX_UNI_I(P->wv_aux2), gmax = TMX_UNI_I(P->wv_gmax);
-  const int* pl = P->wv_plan + lane * TMX_WV_REC;
+  const int aux2 = AX2 >= 0 ? AX2 : TMX_UNI_I(P->wv_aux2), gmax = TMX_UNI_I(P->wv_gmax);
+  wv_cgi* pl = (wv_cgi*)(P->wv_plan + lane * TMX_WV_REC);
   const int tw_raw = pl[0], gsize = pl[1], gpos = pl[2], nrow = pl[3];
   const int tw = tw_raw < 0 ? 0 : tw_raw;
   const int k0 = (gpos == 0) ? 0 : NV, nv = (tw_raw < 0 || gpos > 1) ? 0 : ((gpos == 0) ? (D < NV ? D : NV) : (D > NV ? D - NV : 0));
@@ -208,59 +247,74 @@ TMX_DEVFN void wave_admm_burst(const QpWs& w, const DevProblem* P, const WvLds& 
   double* const wx = L.wx;
   double* const cfl = L.cfl + lane;  // this lane's coefficients: cfl[(i D + d) 64]
   // ---- row role: the iterate and the per-row constants in registers, the coefficients in LDS
-  double z[RL], y[RL], lo[RL], hi[RL], rr[RL], rri[RL], fac[RL];
+  double z[RL], y[RL], hi[RL], fac[RL];
+  int veqm = 0, vfrm = 0;            // the same two type masks for the variable slots
+  int reqm = 0, rfrm = 0, rlom = 0;  // bit i: row slot i is an equality row (rho x 1e3) / a free row (rho_min) / has a finite lower bound (= hi)
   double xa[RL][2], zba[RL][2], yba[RL][2], qa[RL][2], sa[RL][2], bba[RL][2], dnv[RL][2], sd[RL][2];
   int rid[RL], aid[RL], nax[RL];
 #pragma unroll
   for (int i = 0; i < RL; ++i)
   {
     const int r = i < nrow ? pl[4 + i] : 0;
-    const bool on = i < nrow && w.act[r] != 0;
+    const bool on = i < nrow && WV_GI(w.act)[r] != 0;
     rid[i] = on ? r : -1;
     for (int d = 0; d < D; ++d)
-      cfl[(i * D + d) * 64] = on ? w.coef[r * D + d] : 0.0;
-    z[i] = on ? w.zr[r] : 0.0;
-    y[i] = on ? w.yr[r] : 0.0;
-    lo[i] = on ? w.lor[r] : -INF;
-    hi[i] = on ? w.hir[r] : INF;
-    rr[i] = on ? rho_of_type(w.typ_r[r], rho) : 1.0;
-    rri[i] = 1.0 / rr[i];
-    fac[i] = on ? w.fac[r] : 0.0;
-    nax[i] = on ? w.naux[r] : 0;
-    aid[i] = w.aoff[r];
+      cfl[(i * D + d) * 64] = on ? WV_G(w.coef)[r * D + d] : 0.0;
+    z[i] = on ? WV_G(w.zr)[r] : 0.0;
+    y[i] = on ? WV_G(w.yr)[r] : 0.0;
+    hi[i] = on ? WV_G(w.hir)[r] : INF;
+    {
+      const int ty = on ? WV_GI(w.typ_r)[r] : 0;
+      reqm |= (ty == 1) << i;
+      rfrm |= (ty == -1) << i;
+      rlom |= (on && WV_G(w.lor)[r] > -INF) << i;  // (rows are `<= hi` or `== hi`: DevProblem::slot_eq)
+    }
+    fac[i] = on ? WV_G(w.fac)[r] : 0.0;
+    nax[i] = on ? WV_GI(w.naux)[r] : 0;
+    aid[i] = WV_GI(w.aoff)[r];
 #pragma unroll
     for (int k = 0; k < 2; ++k)
     {
       const bool has = k < nax[i];
       const int a = has ? aid[i] + k : 0;
-      xa[i][k] = has ? w.xa[a] : 0.0;
-      zba[i][k] = has ? w.zba[a] : 0.0;
-      yba[i][k] = has ? w.yba[a] : 0.0;
-      qa[i][k] = has ? w.qa[a] : 0.0;
-      sa[i][k] = has ? w.sa[a] : 0.0;
-      bba[i][k] = has ? w.bba[a] : 0.0;
-      dnv[i][k] = has ? w.dinv[a] : 0.0;
+      xa[i][k] = has ? WV_G(w.xa)[a] : 0.0;
+      zba[i][k] = has ? WV_G(w.zba)[a] : 0.0;
+      yba[i][k] = has ? WV_G(w.yba)[a] : 0.0;
+      qa[i][k] = has ? WV_G(w.qa)[a] : 0.0;
+      sa[i][k] = has ? WV_G(w.sa)[a] : 0.0;
+      bba[i][k] = has ? WV_G(w.bba)[a] : 0.0;
+      dnv[i][k] = has ? WV_G(w.dinv)[a] : 0.0;
       sd[i][k] = sa[i][k] * dnv[i][k];
     }
   }
   // bound rows of the slack variables: [0, INFTY * E) - type 0 for every admissible scaling, i.e. rho (checked by the caller)
   const double rb = rho, rbi = 1.0 / rho;
+  // rho of a row / bound row by its type: three wave-uniform values and two selects instead of two registers per row
+  const double rho_eq = TMX_RHO_EQ_OVER_INEQ * rho, rho_eqi = 1.0 / rho_eq, rho_fr = TMX_RHO_MIN, rho_fri = 1.0 / TMX_RHO_MIN;
+  auto RR = [&](int i) -> double { return (rfrm >> i & 1) ? rho_fr : ((reqm >> i & 1) ? rho_eq : rho); };
+  auto RRI = [&](int i) -> double { return (rfrm >> i & 1) ? rho_fri : ((reqm >> i & 1) ? rho_eqi : rbi); };
+  auto RV = [&](int j) -> double { return (vfrm >> j & 1) ? rho_fr : ((veqm >> j & 1) ? rho_eq : rho); };
+  auto RVI = [&](int j) -> double { return (vfrm >> j & 1) ? rho_fri : ((veqm >> j & 1) ? rho_eqi : rbi); };
+  auto LO = [&](int i) -> double { return (rlom >> i & 1) ? hi[i] : -INF; };
   // ---- variable role
-  double x[NV], zb[NV], yb[NV], q[NV], lb[NV], ub[NV], bb[NV], rv[NV], rvi[NV];
+  double x[NV], zb[NV], yb[NV], q[NV], lb[NV], ub[NV], bb[NV];
 #pragma unroll
   for (int j = 0; j < NV; ++j)
   {
     const bool has = j < nv;
     const int v = has ? tw * D + k0 + j : 0;
-    x[j] = has ? w.xp[v] : 0.0;
-    zb[j] = has ? w.zbp[v] : 0.0;
-    yb[j] = has ? w.ybp[v] : 0.0;
-    q[j] = has ? w.qp[v] : 0.0;
-    lb[j] = has ? w.lbp[v] : -INF;
-    ub[j] = has ? w.ubp[v] : INF;
-    bb[j] = has ? w.bbp[v] : 0.0;
-    rv[j] = has ? rho_of_type(w.typ_bp[v], rho) : 1.0;
-    rvi[j] = 1.0 / rv[j];
+    x[j] = has ? WV_G(w.xp)[v] : 0.0;
+    zb[j] = has ? WV_G(w.zbp)[v] : 0.0;
+    yb[j] = has ? WV_G(w.ybp)[v] : 0.0;
+    q[j] = has ? WV_G(w.qp)[v] : 0.0;
+    lb[j] = has ? WV_G(w.lbp)[v] : -INF;
+    ub[j] = has ? WV_G(w.ubp)[v] : INF;
+    bb[j] = has ? WV_G(w.bbp)[v] : 0.0;
+    {
+      const int ty = has ? WV_GI(w.typ_bp)[v] : 0;
+      veqm |= (ty == 1) << j;
+      vfrm |= (ty == -1) << j;
+    }
   }
   // ---- grid role: chain registers.  Step k of chain A takes block k-1 to block k, step k of chain B block TT-k to block TT-1-k;
   // odd steps hold M[a][b] (the product is summed over b), even steps M[b][a] (summed over a);  M = -C S^{-1}
@@ -268,6 +322,8 @@ TMX_DEVFN void wave_admm_burst(const QpWs& w, const DevProblem* P, const WvLds& 
   const bool gin = ga < D && gb < D;
   const int ia = ga < D ? ga : 0, ib = gb < D ? gb : 0;
   double GA[KM], GB[KM];
+  // (rebuilt at the start of every epoch: the chain registers are not live across the in-register check)
+  auto build_chain = [&]() {
 #pragma unroll
   for (int k = 1; k <= KM; ++k)
   {
@@ -285,6 +341,7 @@ TMX_DEVFN void wave_admm_burst(const QpWs& w, const DevProblem* P, const WvLds& 
         GB[k - 1] = gin ? -(w.po[tc * D + ri] * w.Sinv[t * DDS + ri * DS + ci]) : 0.0;
     }
   }
+  };
   const bool selA = gb == 0, selB = ga == 0;  // the lanes that store component ga (sum over b) resp. gb (sum over a)
   // Stores of the chain steps are unconditional: the lanes that do not hold the result write it into a dead row instead (no EXEC
   // masking on the chain).  Forward sweeps: results into wv, the others into the same row of wx (dead until the backward sweeps).
@@ -292,17 +349,17 @@ TMX_DEVFN void wave_admm_burst(const QpWs& w, const DevProblem* P, const WvLds& 
   // reads, chain B (ascending) the row below.
   double* const fstA = selA ? wv + ga : wx + ga;
   double* const fstB = selB ? wv + gb : wx + gb;
-  double* const bsaA = selA ? wx + ga : wv + 8 + ga;   // chain A, result indexed by ga / gb
-  double* const bsaB = selB ? wx + gb : wv + 8 + gb;
-  double* const bsbA = selA ? wx + ga : wv - 8 + ga;   // chain B
-  double* const bsbB = selB ? wx + gb : wv - 8 + gb;
+  double* const bsaA = selA ? wx + ga : wv + RS + ga;   // chain A, result indexed by ga / gb
+  double* const bsaB = selB ? wx + gb : wv + RS + gb;
+  double* const bsbA = selA ? wx + ga : wv - RS + ga;   // chain B
+  double* const bsbB = selB ? wx + gb : wv - RS + gb;
   const bool own = tw_raw >= 0 && gpos == 0;
   // Right-hand side of a chain step: EVERY lane of the eight that are summed adds one eighth of its component (wv holds the
   // right-hand sides of both sweeps times 1/8 - exact scalings), so no lane select sits on the chain
-  auto inj = [&](bool sums_b, int row) -> double { return sums_b ? wv[row * 8 + ga] : wv[row * 8 + gb]; };
+  auto inj = [&](bool sums_b, int row) -> double { return sums_b ? wv[row * RS + ga] : wv[row * RS + gb]; };
   // Both chain vectors start as zeros: the dummy block and the zero row stay so, and so does the padding component of every row (lanes
   // of the grid beyond D hold G = 0, but 0 x stale LDS contents may be 0 x NaN)
-  for (int e = lane; e < (TT + 3) * 8; e += 64)
+  for (int e = lane; e < (TT + 3) * RS; e += 64)
   {
     wv[e] = 0.0;
     wx[e] = 0.0;
@@ -310,6 +367,7 @@ TMX_DEVFN void wave_admm_burst(const QpWs& w, const DevProblem* P, const WvLds& 
   TMX_SYNC();
   // one ADMM iteration; KEEP: the last one of the burst, which leaves delta_x / delta_y for the certificates (a second instantiation
   // of the body: with a run-time flag the stores sit in EXEC-masked regions of every iteration)
+  double kd_dyr[RL], kd_dxa[RL][2], kd_dya[RL][2], kd_dxv[NV], kd_dyv[NV];  // deltas of the last iteration of an epoch
   auto iterate = [&](auto keep_tag) {
     constexpr bool keep = decltype(keep_tag)::value;
     // ---- phase A: e_r = g_r - fac_r sum_k sa_k t_k dinv_k,  t_k = right-hand side of slack variable k
@@ -317,7 +375,7 @@ TMX_DEVFN void wave_admm_burst(const QpWs& w, const DevProblem* P, const WvLds& 
 #pragma unroll
     for (int i = 0; i < RL; ++i)
     {
-      const double g = __builtin_fma(rr[i], z[i], -y[i]);
+      const double g = __builtin_fma(RR(i), z[i], -y[i]);
       double gs = 0.0;
       ta[i][1] = 0.0;
 #pragma unroll
@@ -346,7 +404,7 @@ TMX_DEVFN void wave_admm_burst(const QpWs& w, const DevProblem* P, const WvLds& 
 #pragma unroll
     for (int j = 0; j < NV; ++j)
     {
-      const double gbv = __builtin_fma(rv[j], zb[j], -yb[j]);
+      const double gbv = __builtin_fma(RV(j), zb[j], -yb[j]);
       const double o = __builtin_fma(bb[j], gbv, __builtin_fma(sigma, x[j], -q[j]));  // (absent variables: all zero)
       if (gpos == 0)
         part[j] += o;
@@ -375,21 +433,14 @@ TMX_DEVFN void wave_admm_burst(const QpWs& w, const DevProblem* P, const WvLds& 
     {
 #pragma unroll
       for (int d = 0; d < 8; ++d)
-        wv[tw * 8 + d] = 0.125 * part[d];
+        wv[tw * RS + d] = 0.125 * part[d];
     }
     TMX_SYNC();
-#if defined(TMX_WAVE_DEBUG) && !TMX_IS_GCN
-    static thread_local double dbg_rhs[40 * 8];
-    if (lane == 0)
-      for (int e2 = 0; e2 < T * 8; ++e2)
-        dbg_rhs[e2] = 8.0 * wv[e2];
-    TMX_SYNC();
-#endif
     // ---- the two forward half-chains in lockstep.  The right-hand sides are loaded two steps AHEAD of their use: a load placed behind
     // a store of the other chain (unknown aliasing) would order the two chains.  The last step (k = N) has no right-hand side (the
     // zero row) and leaves the contributions to the middle block in rows TT / TT + 1.
     {
-      double ca = 8.0 * wv[gb], cb = 8.0 * wv[(TT - 1) * 8 + gb];
+      double ca = 8.0 * wv[gb], cb = 8.0 * wv[(TT - 1) * RS + gb];
       double ra0 = inj(true, 1 < N ? 1 : ROW_Z), rb0 = inj(true, 1 < N ? TT - 2 : ROW_Z);
       double ra1 = inj(false, 2 < N ? 2 : ROW_Z), rb1 = inj(false, 2 < N ? TT - 3 : ROW_Z);
 #pragma unroll
@@ -411,28 +462,21 @@ TMX_DEVFN void wave_admm_burst(const QpWs& w, const DevProblem* P, const WvLds& 
           else
             wv_red_x2(ca, cb);
           double* const fst = (k & 1) ? fstA : fstB;
-          fst[(k < N ? k : ROW_TA) * 8] = ca;
-          fst[(k < N ? TT - 1 - k : ROW_TB) * 8] = cb;
+          fst[(k < N ? k : ROW_TA) * RS] = ca;
+          fst[(k < N ? TT - 1 - k : ROW_TB) * RS] = cb;
         }
     }
     TMX_SYNC();
     if (lane < 8)
-      wv[m * 8 + lane] = (8.0 * wv[m * 8 + lane] + wv[ROW_TA * 8 + lane]) + wv[ROW_TB * 8 + lane];
+      wv[m * RS + lane] = (8.0 * wv[m * RS + lane] + wv[ROW_TA * RS + lane]) + wv[ROW_TB * RS + lane];
     TMX_SYNC();
-#if defined(TMX_WAVE_DEBUG) && !TMX_IS_GCN
-    static thread_local double dbg_y[40 * 8];
-    if (lane == 0)
-      for (int e2 = 0; e2 < T * 8; ++e2)
-        dbg_y[e2] = ((e2 >> 3) == 0 || (e2 >> 3) == TT - 1 ? 8.0 : 1.0) * wv[e2];
-    TMX_SYNC();
-#endif
     // ---- g_t = S_t^{-1} y_t, waypoint-parallel (the first two lanes of a group; all lanes of the wave read before any writes)
     {
       double yy[8], g[NV];
       const double ysc = (tw == 0 || tw == TT - 1) ? 8.0 : 1.0;  // (the end blocks the chains START from still hold their scaled right-hand sides)
 #pragma unroll
       for (int jj = 0; jj < 8; ++jj)
-        yy[jj] = ysc * wv[tw * 8 + jj];
+        yy[jj] = ysc * wv[tw * RS + jj];
 #pragma unroll
       for (int j = 0; j < NV; ++j)
       {
@@ -448,9 +492,9 @@ TMX_DEVFN void wave_admm_burst(const QpWs& w, const DevProblem* P, const WvLds& 
       for (int j = 0; j < NV; ++j)
         if (j < nv)
         {
-          wv[tw * 8 + k0 + j] = 0.125 * g[j];
+          wv[tw * RS + k0 + j] = 0.125 * g[j];
           if (tw == m)
-            wx[tw * 8 + k0 + j] = g[j];
+            wx[tw * RS + k0 + j] = g[j];
         }
     }
     TMX_SYNC();
@@ -458,9 +502,9 @@ TMX_DEVFN void wave_admm_burst(const QpWs& w, const DevProblem* P, const WvLds& 
     {
       // x_m in the layout the first step (k = N) multiplies along: an odd step sums over a
       const int moff = (N & 1) ? ga : gb;
-      double ca = wx[m * 8 + moff], cb = ca;
+      double ca = wx[m * RS + moff], cb = ca;
       // right-hand sides of steps N and N - 1 (run-time parity), then two steps ahead inside the unrolled sequence
-      auto binj = [&](bool sums_a, int row) -> double { return sums_a ? wv[row * 8 + gb] : wv[row * 8 + ga]; };
+      auto binj = [&](bool sums_a, int row) -> double { return sums_a ? wv[row * RS + gb] : wv[row * RS + ga]; };
       double qa0 = binj((N & 1) != 0, N - 1), qb0 = binj((N & 1) != 0, TT - N);
       double qa1 = binj((N & 1) == 0, N >= 2 ? N - 2 : ROW_Z), qb1 = binj((N & 1) == 0, N >= 2 ? TT - N + 1 : ROW_Z);
 #pragma unroll
@@ -481,156 +525,17 @@ TMX_DEVFN void wave_admm_burst(const QpWs& w, const DevProblem* P, const WvLds& 
             wv_red_x2(ca, cb);
           else
             wv_red_in2(ca, cb);
-          ((k & 1) ? bsaB : bsaA)[(k - 1) * 8] = ca;
-          ((k & 1) ? bsbB : bsbA)[(TT - k) * 8] = cb;
+          ((k & 1) ? bsaB : bsaA)[(k - 1) * RS] = ca;
+          ((k & 1) ? bsbB : bsbA)[(TT - k) * RS] = cb;
         }
     }
     TMX_SYNC();
-#if defined(TMX_WAVE_DEBUG) && !TMX_IS_GCN
-    if (lane == 0)
-    {
-      // residual of the reduced system K x~ = rhs in operator form: K = diag(pd + sigma + rho_b bb^2) + couplings po + sum_r fac_r a_r a_r'
-      double worst = 0.0, rmax = 0.0;
-      int wt = -1, wd = -1;
-      for (int t = 0; t < T; ++t)
-        for (int d = 0; d < D; ++d)
-        {
-          const int v = t * D + d;
-          double acc = (w.pd[v] + sigma + rho_of_type(w.typ_bp[v], rho) * w.bbp[v] * w.bbp[v]) * wx[t * 8 + d];
-          if (t > 0)
-            acc += w.po[v - D] * wx[(t - 1) * 8 + d];
-          if (t < T - 1)
-            acc += w.po[v] * wx[(t + 1) * 8 + d];
-          for (int r = 0; r < w.R; ++r)
-            if (w.act[r] && w.slot_t[r] == t)
-            {
-              double dot = 0.0;
-              for (int jj = 0; jj < D; ++jj)
-                dot += w.coef[r * D + jj] * wx[t * 8 + jj];
-              acc += w.fac[r] * dot * w.coef[r * D + d];
-            }
-          const double res = acc - dbg_rhs[t * 8 + d];
-          static thread_local int dbg_calls = 0;
-          if (t == 0 && d == 0)
-            ++dbg_calls;
-          if (dbg_calls == 1)
-            { if (d == 0) std::printf("\n[wave dbg] t %2d res:", t); std::printf("%10.2e", res); }
-          rmax = fmax(rmax, fabs(dbg_rhs[t * 8 + d]));
-          if (fabs(res) > worst)
-          {
-            worst = fabs(res);
-            wt = t;
-            wd = d;
-          }
-        }
-      {
-        // serial replay of the twisted solve with the same factors
-        static thread_local double yy[40 * 8], gg[40 * 8], xs[40 * 8];
-        auto mv = [&](int t, const double* v, double* o) {
-          for (int i2 = 0; i2 < D; ++i2)
-          {
-            double a2 = 0.0;
-            for (int j2 = 0; j2 < D; ++j2)
-              a2 += w.Sinv[t * DDS + i2 * DS + j2] * v[j2];
-            o[i2] = a2;
-          }
-        };
-        double tmpv[8];
-        for (int t = 0; t < m; ++t)
-        {
-          for (int d = 0; d < D; ++d)
-            yy[t * 8 + d] = dbg_rhs[t * 8 + d];
-          if (t > 0)
-          {
-            mv(t - 1, &yy[(t - 1) * 8], tmpv);
-            for (int d = 0; d < D; ++d)
-              yy[t * 8 + d] -= w.po[(t - 1) * D + d] * tmpv[d];
-          }
-        }
-        for (int t = T - 1; t > m; --t)
-        {
-          for (int d = 0; d < D; ++d)
-            yy[t * 8 + d] = dbg_rhs[t * 8 + d];
-          if (t < T - 1)
-          {
-            mv(t + 1, &yy[(t + 1) * 8], tmpv);
-            for (int d = 0; d < D; ++d)
-              yy[t * 8 + d] -= w.po[t * D + d] * tmpv[d];
-          }
-        }
-        for (int d = 0; d < D; ++d)
-          yy[m * 8 + d] = dbg_rhs[m * 8 + d];
-        mv(m - 1, &yy[(m - 1) * 8], tmpv);
-        for (int d = 0; d < D; ++d)
-          yy[m * 8 + d] -= w.po[(m - 1) * D + d] * tmpv[d];
-        if (m < T - 1)
-        {
-          mv(m + 1, &yy[(m + 1) * 8], tmpv);
-          for (int d = 0; d < D; ++d)
-            yy[m * 8 + d] -= w.po[m * D + d] * tmpv[d];
-        }
-        for (int t = 0; t < T; ++t)
-          mv(t, &yy[t * 8], &gg[t * 8]);
-        for (int d = 0; d < D; ++d)
-          xs[m * 8 + d] = gg[m * 8 + d];
-        for (int t = m - 1; t >= 0; --t)
-        {
-          double u2[8];
-          for (int d = 0; d < D; ++d)
-            u2[d] = w.po[t * D + d] * xs[(t + 1) * 8 + d];
-          mv(t, u2, tmpv);
-          for (int d = 0; d < D; ++d)
-            xs[t * 8 + d] = gg[t * 8 + d] - tmpv[d];
-        }
-        for (int t = m + 1; t < T; ++t)
-        {
-          double u2[8];
-          for (int d = 0; d < D; ++d)
-            u2[d] = w.po[(t - 1) * D + d] * xs[(t - 1) * 8 + d];
-          mv(t, u2, tmpv);
-          for (int d = 0; d < D; ++d)
-            xs[t * 8 + d] = gg[t * 8 + d] - tmpv[d];
-        }
-        {
-          double ymax = 0.0;
-          int yt = -1;
-          for (int t = 0; t < T; ++t)
-            for (int d = 0; d < D; ++d)
-              if (fabs(yy[t * 8 + d] - dbg_y[t * 8 + d]) > ymax)
-              {
-                ymax = fabs(yy[t * 8 + d] - dbg_y[t * 8 + d]);
-                yt = t;
-              }
-          std::printf("\n[wave dbg] forward sweeps: max |dy| %.3e at t %d", ymax, yt);
-          for (int t = 0; t < T; ++t)
-          {
-            double e3 = 0.0;
-            for (int d = 0; d < D; ++d)
-              e3 = fmax(e3, fabs(yy[t * 8 + d] - dbg_y[t * 8 + d]));
-            std::printf("%s%.1e", t ? " " : "\n[wave dbg] |dy| by block: ", e3);
-          }
-        }
-        double dmax = 0.0;
-        int dt = -1;
-        for (int t = 0; t < T; ++t)
-          for (int d = 0; d < D; ++d)
-            if (fabs(xs[t * 8 + d] - wx[t * 8 + d]) > dmax)
-            {
-              dmax = fabs(xs[t * 8 + d] - wx[t * 8 + d]);
-              dt = t;
-            }
-        std::printf("\n[wave dbg] lane-grid chain vs serial twisted solve: max |dx| %.3e at t %d\n", dmax, dt);
-      }
-      std::printf("[wave dbg] reduced solve: max |K x - rhs| = %.3e at (t %d, d %d), max |rhs| %.3e\n", worst, wt, wd, rmax);
-    }
-    TMX_SYNC();
-#endif
     // ---- phase C: slack recovery, z~, and the x / z / y updates
     {
       double xx[8];
 #pragma unroll
       for (int d = 0; d < 8; ++d)
-        xx[d] = wx[tw * 8 + d];
+        xx[d] = wx[tw * RS + d];
 #pragma unroll
       for (int i = 0; i < RL; ++i)
       {
@@ -643,6 +548,11 @@ TMX_DEVFN void wave_admm_burst(const QpWs& w, const DevProblem* P, const WvLds& 
         // slack recovery.  With v_k = t_k - rho_r s_k dot and f = fac sum_k sd_k v_k (admm_phase_c):  sum_k sd_k v_k = gs - rho_r kappa dot
         // and rho_r - fac rho_r kappa = fac, so  x~_k = (v_k - s_k f) dinv_k = (t_k - s_k h) dinv_k  with  h = fac (dot + gs)
         const double h = fac[i] * (dot + gsa[i]);
+        if (keep)
+        {
+          kd_dxa[i][1] = 0.0;
+          kd_dya[i][1] = 0.0;
+        }
 #pragma unroll
         for (int k = 0; k < 2; ++k)
           if (k == 0 || (aux2 >> i & 1))
@@ -658,72 +568,367 @@ TMX_DEVFN void wave_admm_burst(const QpWs& w, const DevProblem* P, const WvLds& 
             const double dy = rb * (zrl - zn);
             zba[i][k] = zn;
             yba[i][k] += dy;
-            if (keep && k < nax[i])
+            if (keep)
             {
-              w.dxa[aid[i] + k] = dxa;
-              w.dyba[aid[i] + k] = dy;
+              kd_dxa[i][k] = dxa;
+              kd_dya[i][k] = dy;
             }
           }
         {
           const double zrl = __builtin_fma(al, ax, oma * z[i]);
-          const double zn = clampd(__builtin_fma(rri[i], y[i], zrl), lo[i], hi[i]);
-          const double dy = rr[i] * (zrl - zn);
+          const double zn = clampd(__builtin_fma(RRI(i), y[i], zrl), LO(i), hi[i]);
+          const double dy = RR(i) * (zrl - zn);
           z[i] = zn;
           y[i] += dy;
-          if (keep && rid[i] >= 0)
-            w.dyr[rid[i]] = dy;
+          if (keep)
+            kd_dyr[i] = dy;
         }
       }
 #pragma unroll
       for (int j = 0; j < NV; ++j)
       {
-        const double xt = wx[tw * 8 + ((j < nv) ? k0 + j : 0)];
+        const double xt = wx[tw * RS + ((j < nv) ? k0 + j : 0)];
         const double xn = __builtin_fma(al, xt, oma * x[j]);
         [[maybe_unused]] const double dx = xn - x[j];
         x[j] = (j < nv) ? xn : 0.0;
         const double zt = bb[j] * xt;
         const double zrl = __builtin_fma(al, zt, oma * zb[j]);
-        const double zn = clampd(__builtin_fma(rvi[j], yb[j], zrl), lb[j], ub[j]);
-        const double dy = rv[j] * (zrl - zn);
+        const double zn = clampd(__builtin_fma(RVI(j), yb[j], zrl), lb[j], ub[j]);
+        const double dy = RV(j) * (zrl - zn);
         zb[j] = (j < nv) ? zn : 0.0;
         yb[j] = (j < nv) ? yb[j] + dy : 0.0;
-        if (keep && j < nv)
+        if (keep)
         {
-          w.dxp[tw * D + k0 + j] = dx;
-          w.dybp[tw * D + k0 + j] = dy;
+          kd_dxv[j] = (j < nv) ? dx : 0.0;
+          kd_dyv[j] = (j < nv) ? dy : 0.0;
         }
       }
     }
     TMX_SYNC();
   };
-  for (int it = 0; it + 1 < n_iter; ++it)
-    iterate(std::false_type{});
-  iterate(std::true_type{});
-  // ---- store the iterate
+  // ---- EPOCHS: iterate to the next residual check, form - from registers - what the check would look at, and go on iterating while
+  // the check is CERTAINLY a no-op (not converged, both infeasibility certificates clearly negative, rho inside its band, iterations
+  // left); otherwise store the iterate and return: wave_check_nl then decides in full (the structure of admm_burst_core's epoch mode,
+  // tmx_part.h).  The 14 norms of update_info computed here are the residuals of this solve (handed over through the LDS record).
+  const tmx_osqp_settings& st = P->osqp;
+  const int max_iter = TMX_UNI_I(st.max_iter), chk = TMX_UNI_I(st.check_termination),
+            rint = (st.adaptive_rho && st.adaptive_rho_interval) ? TMX_UNI_I(st.adaptive_rho_interval) : 0;
+  const double eps_abs = st.eps_abs, eps_rel = st.eps_rel, eps_pinf = st.eps_prim_inf, eps_dinf = st.eps_dual_inf, rtol = st.adaptive_rho_tolerance;
+  const double cinv = w.cinv, cc = w.c;
+  int iter_done = TMX_UNI_I(iter0);
+  double nm[18];
+  WV_TICK(Bt, b, 11, tbu);
+  while (true)
+  {
+    int next = max_iter;
+    if (chk)
+      next = min(next, (iter_done / chk + 1) * chk);
+    if (rint)
+      next = min(next, (iter_done / rint + 1) * rint);
+    const int n = next - iter_done;
+    build_chain();
+    for (int it = 0; it + 1 < n; ++it)
+      iterate(std::false_type{});
+    if (n > 0)
+      iterate(std::true_type{});
+    iter_done = next;
+    WV_TICK(Bt, b, 14, tbu);
+    // ---- the scalings the norms are weighted with: ALL loads first (one exposed HBM latency per check, not one per value)
+    double cEr[RL], cEba[RL][2], cDa[RL][2], cEbp[NV], cDp[NV], cPd[NV];
+#pragma unroll
+    for (int i = 0; i < RL; ++i)
+    {
+      cEr[i] = WV_G(w.Er)[rid[i] >= 0 ? rid[i] : 0];
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+        if (k == 0 || (aux2 >> i & 1))
+        {
+          const int a = (k < nax[i]) ? aid[i] + k : 0;
+          cEba[i][k] = WV_G(w.Eba)[a];
+          cDa[i][k] = WV_G(w.Da)[a];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+    {
+      const int v = (j < nv) ? tw * D + k0 + j : 0;
+      cEbp[j] = WV_G(w.Ebp)[v];
+      cDp[j] = WV_G(w.Dp)[v];
+      cPd[j] = WV_G(w.pd)[v];
+    }
+    // ---- round 1: x with 8 slots per waypoint -> wx, A'y per waypoint -> wv; the norms of compute_residuals
+#pragma unroll
+    for (int k = 0; k < 18; ++k)
+      nm[k] = 0.0;
+    auto gather_to_wv = [&](const double (&rv)[RL]) {
+      double pt[8];
+#pragma unroll
+      for (int d = 0; d < 8; ++d)
+        pt[d] = 0.0;
+#pragma unroll
+      for (int i = 0; i < RL; ++i)
+#pragma unroll
+        for (int d = 0; d < 8; ++d)
+          if (d < D)
+            pt[d] = __builtin_fma(cfl[(i * D + d) * 64], rv[i], pt[d]);
+#pragma unroll
+      for (int d = 0; d < 8; ++d)
+      {
+        double s2 = pt[d] + wv_dpp<0xB1>(pt[d]);
+        if (gmax >= 4)
+        {
+          const double s4 = s2 + wv_dpp<0x4E>(s2);
+          s2 = gsize >= 4 ? s4 : s2;
+        }
+        if (gmax >= 8)
+        {
+          const double s8 = s2 + wv_dpp<0x141>(s2);
+          s2 = gsize >= 8 ? s8 : s2;
+        }
+        pt[d] = s2;
+      }
+      if (own)
+      {
+#pragma unroll
+        for (int d = 0; d < 8; ++d)
+          wv[tw * RS + d] = pt[d];
+      }
+    };
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+      if (j < nv)
+        wx[tw * RS + k0 + j] = x[j];
+    gather_to_wv(y);
+    TMX_SYNC();
+    WV_CTICK(3);
+    {
+      double xx[8];
+#pragma unroll
+      for (int d = 0; d < 8; ++d)
+        xx[d] = wx[tw * RS + d];
+#pragma unroll
+      for (int i = 0; i < RL; ++i)
+        if (rid[i] >= 0)
+        {
+          double ax = 0.0;
+#pragma unroll
+          for (int d = 0; d < 8; ++d)
+            if (d < D)
+              ax = __builtin_fma(cfl[(i * D + d) * 64], xx[d], ax);
+#pragma unroll
+          for (int k = 0; k < 2; ++k)
+            ax = __builtin_fma(sa[i][k], xa[i][k], ax);
+          const double einv = fast_rcp(cEr[i]);
+          nm[0] = fmax(nm[0], fabs(einv * (ax - z[i])));
+          nm[1] = fmax(nm[1], fabs(ax - z[i]));
+          nm[2] = fmax(nm[2], fabs(z[i]));
+          nm[3] = fmax(nm[3], fabs(ax));
+          nm[4] = fmax(nm[4], fabs(einv * z[i]));
+          nm[5] = fmax(nm[5], fabs(einv * ax));
+#pragma unroll
+          for (int k = 0; k < 2; ++k)
+            if ((k == 0 || (aux2 >> i & 1)) && k < nax[i])
+            {
+              const double axa = bba[i][k] * xa[i][k], za = zba[i][k];
+              const double ei = fast_rcp(cEba[i][k]);
+              nm[0] = fmax(nm[0], fabs(ei * (axa - za)));
+              nm[1] = fmax(nm[1], fabs(axa - za));
+              nm[2] = fmax(nm[2], fabs(za));
+              nm[3] = fmax(nm[3], fabs(axa));
+              nm[4] = fmax(nm[4], fabs(ei * za));
+              nm[5] = fmax(nm[5], fabs(ei * axa));
+              const double aty = sa[i][k] * y[i] + bba[i][k] * yba[i][k];
+              const double res = qa[i][k] + aty;
+              const double di = fast_rcp(cDa[i][k]);
+              nm[6] = fmax(nm[6], fabs(di * res));
+              nm[7] = fmax(nm[7], fabs(res));
+              nm[8] = fmax(nm[8], fabs(qa[i][k]));
+              nm[9] = fmax(nm[9], fabs(aty));
+              nm[11] = fmax(nm[11], fabs(di * qa[i][k]));
+              nm[12] = fmax(nm[12], fabs(di * aty));
+            }
+        }
+#pragma unroll
+      for (int j = 0; j < NV; ++j)
+        if (j < nv)
+        {
+          const int d = k0 + j, v = tw * D + d;
+          const double axv = bb[j] * x[j];
+          const double ei = fast_rcp(cEbp[j]);
+          nm[0] = fmax(nm[0], fabs(ei * (axv - zb[j])));
+          nm[1] = fmax(nm[1], fabs(axv - zb[j]));
+          nm[2] = fmax(nm[2], fabs(zb[j]));
+          nm[3] = fmax(nm[3], fabs(axv));
+          nm[4] = fmax(nm[4], fabs(ei * zb[j]));
+          nm[5] = fmax(nm[5], fabs(ei * axv));
+          double px = cPd[j] * x[j];
+          if (tw > 0)
+            px += w.po[v - D] * wx[(tw - 1) * RS + d];
+          if (tw < T - 1)
+            px += w.po[v] * wx[(tw + 1) * RS + d];
+          const double aty = wv[tw * RS + d] + bb[j] * yb[j];
+          const double res = (q[j] + px) + aty;
+          const double di = fast_rcp(cDp[j]);
+          nm[6] = fmax(nm[6], fabs(di * res));
+          nm[7] = fmax(nm[7], fabs(res));
+          nm[8] = fmax(nm[8], fabs(q[j]));
+          nm[9] = fmax(nm[9], fabs(aty));
+          nm[10] = fmax(nm[10], fabs(px));
+          nm[11] = fmax(nm[11], fabs(di * q[j]));
+          nm[12] = fmax(nm[12], fabs(di * aty));
+          nm[13] = fmax(nm[13], fabs(di * px));
+        }
+    }
+    TMX_SYNC();
+    WV_CTICK(4);
+    // ---- round 2: delta_x -> wx, A' (projected delta_y) -> wv; the norm tests of the two infeasibility certificates
+    //   nm[14] max |E dy_proj|   nm[15] max |(A' dy_proj) / D|   nm[16] max |D dx|   nm[17] max |(P dx) / D|
+    {
+      const double BIG = TMX_OSQP_INFTY * TMX_MIN_SCALING;
+      double pdy[RL], pda[RL][2], pdv[NV];
+#pragma unroll
+      for (int i = 0; i < RL; ++i)
+      {
+        double dy = kd_dyr[i];
+        if (hi[i] > BIG)
+          dy = (LO(i) < -BIG) ? 0.0 : fmin(dy, 0.0);
+        else if (LO(i) < -BIG)
+          dy = fmax(dy, 0.0);
+        pdy[i] = rid[i] >= 0 ? dy : 0.0;
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+          pda[i][k] = (k < nax[i]) ? fmin(kd_dya[i][k], 0.0) : 0.0;  // (upper bound INFTY * E: only the upper side is infinite)
+      }
+#pragma unroll
+      for (int j = 0; j < NV; ++j)
+      {
+        double dy = kd_dyv[j];
+        if (ub[j] > BIG)
+          dy = (lb[j] < -BIG) ? 0.0 : fmin(dy, 0.0);
+        else if (lb[j] < -BIG)
+          dy = fmax(dy, 0.0);
+        pdv[j] = (j < nv) ? dy : 0.0;
+      }
+#pragma unroll
+      for (int j = 0; j < NV; ++j)
+        if (j < nv)
+          wx[tw * RS + k0 + j] = kd_dxv[j];
+      gather_to_wv(pdy);
+      TMX_SYNC();
+#pragma unroll
+      for (int i = 0; i < RL; ++i)
+        if (rid[i] >= 0)
+        {
+          nm[14] = fmax(nm[14], fabs(cEr[i] * pdy[i]));
+#pragma unroll
+          for (int k = 0; k < 2; ++k)
+            if ((k == 0 || (aux2 >> i & 1)) && k < nax[i])
+            {
+              const double da = cDa[i][k];
+              nm[14] = fmax(nm[14], fabs(cEba[i][k] * pda[i][k]));
+              nm[15] = fmax(nm[15], fabs((sa[i][k] * pdy[i] + bba[i][k] * pda[i][k]) * fast_rcp(da)));
+              nm[16] = fmax(nm[16], fabs(da * kd_dxa[i][k]));
+            }
+        }
+#pragma unroll
+      for (int j = 0; j < NV; ++j)
+        if (j < nv)
+        {
+          const int d = k0 + j, v = tw * D + d;
+          const double dp = cDp[j], di = fast_rcp(dp);
+          nm[14] = fmax(nm[14], fabs(cEbp[j] * pdv[j]));
+          nm[15] = fmax(nm[15], fabs((wv[tw * RS + d] + bb[j] * pdv[j]) * di));
+          nm[16] = fmax(nm[16], fabs(dp * kd_dxv[j]));
+          double px = cPd[j] * kd_dxv[j];
+          if (tw > 0)
+            px += w.po[v - D] * wx[(tw - 1) * RS + d];
+          if (tw < T - 1)
+            px += w.po[v] * wx[(tw + 1) * RS + d];
+          nm[17] = fmax(nm[17], fabs(px * di));
+        }
+    }
+    WV_CTICK(5);
+#pragma unroll
+    for (int k = 0; k < 18; ++k)
+      nm[k] = wave_allreduce<false>(nm[k]);
+    TMX_SYNC();
+    WV_CTICK(6);
+    // ---- would wave_check_nl do anything?  (its tests in its order; anything not CERTAINLY a no-op leaves the loop)
+    bool go_on = iter_done < max_iter;
+    const bool can_check = chk && (iter_done % chk == 0);
+    const bool do_rho = rint && (iter_done % rint == 0);
+    if (go_on && can_check)
+    {
+      const double prim_res = nm[0], dual_res = cinv * nm[6];
+      if (!(prim_res <= TMX_OSQP_INFTY) || !(dual_res <= TMX_OSQP_INFTY))
+        go_on = false;
+      const bool prim_ok = prim_res < eps_abs + eps_rel * fmax(nm[4], nm[5]);
+      const bool dual_ok = dual_res < eps_abs + eps_rel * (cinv * fmax(fmax(nm[11], nm[12]), nm[13]));
+      if (prim_ok && dual_ok)
+        go_on = false;  // solved
+      if (!prim_ok)
+      {
+        const bool surely_not = !(nm[14] > TMX_DIVISION_TOL) || nm[15] > 2.0 * eps_pinf * nm[14];
+        go_on = go_on && surely_not;
+      }
+      if (!dual_ok)
+      {
+        const bool surely_not = !(nm[16] > TMX_DIVISION_TOL) || nm[17] > 2.0 * cc * eps_dinf * nm[16];
+        go_on = go_on && surely_not;
+      }
+    }
+    if (go_on && do_rho)
+    {
+      const double prim = nm[1] / (fmax(nm[2], nm[3]) + TMX_DIVISION_TOL);
+      const double dual = nm[7] / (fmax(fmax(nm[8], nm[9]), nm[10]) + TMX_DIVISION_TOL);
+      const double rho_new = fmin(fmax(rho * sqrt(prim / dual), TMX_RHO_MIN), TMX_RHO_MAX);
+      if (!((rho_new <= rho * rtol) && (rho_new >= rho / rtol)))
+        go_on = false;
+    }
+    go_on = TMX_UNI_B(go_on);
+    WV_TICK(Bt, b, 12, tbu);
+    if (!go_on)
+      break;
+  }
+  // ---- store the iterate, the deltas of the last iteration and the norms
 #pragma unroll
   for (int i = 0; i < RL; ++i)
     if (rid[i] >= 0)
     {
-      w.zr[rid[i]] = z[i];
-      w.yr[rid[i]] = y[i];
+      WV_G(w.zr)[rid[i]] = z[i];
+      WV_G(w.yr)[rid[i]] = y[i];
+      WV_G(w.dyr)[rid[i]] = kd_dyr[i];
 #pragma unroll
       for (int k = 0; k < 2; ++k)
         if (k < nax[i])
         {
-          w.xa[aid[i] + k] = xa[i][k];
-          w.zba[aid[i] + k] = zba[i][k];
-          w.yba[aid[i] + k] = yba[i][k];
+          WV_G(w.xa)[aid[i] + k] = xa[i][k];
+          WV_G(w.zba)[aid[i] + k] = zba[i][k];
+          WV_G(w.yba)[aid[i] + k] = yba[i][k];
+          WV_G(w.dxa)[aid[i] + k] = kd_dxa[i][k];
+          WV_G(w.dyba)[aid[i] + k] = kd_dya[i][k];
         }
     }
 #pragma unroll
   for (int j = 0; j < NV; ++j)
     if (j < nv)
     {
-      w.xp[tw * D + k0 + j] = x[j];
-      w.zbp[tw * D + k0 + j] = zb[j];
-      w.ybp[tw * D + k0 + j] = yb[j];
+      WV_G(w.xp)[tw * D + k0 + j] = x[j];
+      WV_G(w.zbp)[tw * D + k0 + j] = zb[j];
+      WV_G(w.ybp)[tw * D + k0 + j] = yb[j];
+      WV_G(w.dxp)[tw * D + k0 + j] = kd_dxv[j];
+      WV_G(w.dybp)[tw * D + k0 + j] = kd_dyv[j];
     }
+  if (lane == 0)
+  {
+#pragma unroll
+    for (int k = 0; k < 14; ++k)
+      sh->res[k] = nm[k];
+    sh->have_res = 1;
+  }
   TMX_SYNC();
+  WV_TICK(Bt, b, 13, tbu);
+  return iter_done;
 }
 
 // ---- the ADMM loop of one QP as separately compiled functions (the nesting of qp_admm_fast_nl / qp_check_nl, tmx_solve.h) ----------
@@ -754,13 +959,34 @@ __device__ __attribute__((noinline)) static int wave_check_nl(const DevProblem* 
   QpWs w;
   QpShared* sh = wave_ws_rebuild(w, P, Bt, b, smem);
   QpInfo info = sh->info;
+  [[maybe_unused]] long long tk = WV_CLK();
   const bool can_check = st.check_termination && (iter % st.check_termination == 0);
   const bool do_rho = st.adaptive_rho && st.adaptive_rho_interval && (iter % st.adaptive_rho_interval == 0);
   int ended = 0;
   if (can_check || do_rho)
   {
     info.iter = iter;
-    compute_residuals(w, P, w.xp, w.xa, w.yr, w.ybp, w.yba, 0, info, info.prim_res, info.dual_res, true, tid, NT);
+    if (sh->have_res)
+    {
+      // the burst left the norms: the assignments of compute_residuals
+      const double* m = sh->res;
+      info.prim_res = m[0];
+      info.dual_res = w.cinv * m[6];
+      info.s_prim = m[1];
+      info.s_z = m[2];
+      info.s_ax = m[3];
+      info.u_z = m[4];
+      info.u_ax = m[5];
+      info.s_dual = m[7];
+      info.s_q = m[8];
+      info.s_aty = m[9];
+      info.s_px = m[10];
+      info.u_q = m[11];
+      info.u_aty = m[12];
+      info.u_px = m[13];
+    }
+    else
+      compute_residuals(w, P, w.xp, w.xa, w.yr, w.ybp, w.yba, 0, info, info.prim_res, info.dual_res, true, tid, NT);
   }
   if (can_check && TMX_UNI_B(check_termination(w, P, info, false, tid, NT)))
     ended = 1;
@@ -773,12 +999,15 @@ __device__ __attribute__((noinline)) static int wave_check_nl(const DevProblem* 
       w.rho = fmin(fmax(rho_new, TMX_RHO_MIN), TMX_RHO_MAX);
       rho = w.rho;
       info.rho_updates += 1;
+      WV_TICK(Bt, b, 3, tk);
       kkt_factor(w, P, 0, w.sigma, st.delta, tid, NT);
       wave_twist_invert(w, ((w.T | 1) - 1) / 2, tid);
       admm_cache_weights(w, tid, NT);
+      WV_TICK(Bt, b, 1, tk);
     }
   }
   TMX_SYNC();
+  WV_TICK(Bt, b, 3, tk);
   if (tid == 0)
   {
     sh->info = info;
@@ -788,6 +1017,18 @@ __device__ __attribute__((noinline)) static int wave_check_nl(const DevProblem* 
   }
   TMX_SYNC();
   return ended;
+}
+// (the instantiation without compile-time sizes as a function of its own: the two bodies do not share a register allocation)
+__device__ __attribute__((noinline)) static int wave_burst_any_nl(const DevProblem* P_in, const DevBatch* Bt_in, int b_in, unsigned lds_in, int iter_in)
+{
+  const DevProblem* P = tmx_uniform_ptr(P_in);
+  const DevBatch* Bt = tmx_uniform_ptr(Bt_in);
+  const int b = __builtin_amdgcn_readfirstlane(b_in), iter = __builtin_amdgcn_readfirstlane(iter_in);
+  double* smem = (double*)(tmx_lds_d*)(size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)lds_in);
+  QpWs w;
+  WvLds L;
+  QpShared* sh = wave_ws_rebuild(w, P, Bt, b, smem, &L);
+  return wave_admm_burst<0, 0, -1>(w, P, Bt, b, L, sh, iter, threadIdx.x);
 }
 // the whole ADMM loop of one QP (osqp_solve): in / out through the LDS record
 __device__ __attribute__((noinline)) static void wave_admm_nl(const DevProblem* P_in, const DevBatch* Bt_in, int b_in, unsigned lds_in)
@@ -802,22 +1043,20 @@ __device__ __attribute__((noinline)) static void wave_admm_nl(const DevProblem* 
   int iter = 0, ended = 0;
   while (iter < st.max_iter)
   {
-    // the next iteration at which something is looked at
-    int next = st.max_iter;
-    if (st.check_termination)
-      next = min(next, (iter / st.check_termination + 1) * st.check_termination);
-    if (st.adaptive_rho && st.adaptive_rho_interval)
-      next = min(next, (iter / st.adaptive_rho_interval + 1) * st.adaptive_rho_interval);
     {
+      [[maybe_unused]] long long tb = WV_CLK();
       QpWs w;
       WvLds L;
-      wave_ws_rebuild(w, P, Bt, b, smem, &L);
-      if (((w.T | 1) - 1) / 2 == 15 && w.D == 7)  // 7-DOF arm over 30 | 31 waypoints (BASELINE config 1)
-        wave_admm_burst<15, 7>(w, P, L, next - iter, tid);
+      QpShared* sh = wave_ws_rebuild(w, P, Bt, b, smem, &L);
+      const int before = iter;
+      if (((w.T | 1) - 1) / 2 == 15 && w.D == 7 && P->wv_aux2 == 7)  // 7-DOF arm over 30 | 31 waypoints, two-slack rows in three row slots (BASELINE config 1)
+        iter = wave_admm_burst<15, 7, 7>(w, P, Bt, b, L, sh, iter, tid);
       else
-        wave_admm_burst<0, 0>(w, P, L, next - iter, tid);
+        iter = wave_burst_any_nl(P, Bt, b, lds_off, iter);
+      WV_TICK(Bt, b, 2, tb);
+      WV_COUNT(Bt, b, 8, iter - before);
+      WV_COUNT(Bt, b, 9, 1);
     }
-    iter = next;
     ended = wave_check_nl(P, Bt, b, iter, lds_off);
     if (ended)
       break;
@@ -845,6 +1084,8 @@ TMX_DEVFN void qp_solve_wave(const DevProblem* P, const DevBatch* Bt, int b, dou
   QpWs w;
   wave_ws_carve(w, P, Bt, b, smem);
   const int m = ((T | 1) - 1) / 2;  // middle block of the twisted chain (wave_admm_burst)
+  [[maybe_unused]] long long tq = WV_CLK();
+  WV_COUNT(Bt, b, 10, 1);
   const int* g_act = Bt->active + (size_t)b * R;
   const double* g_coef = Bt->coef + (size_t)b * R * D;
   const double* g_rhs = Bt->rhs + (size_t)b * R;
@@ -1129,9 +1370,11 @@ TMX_DEVFN void qp_solve_wave(const DevProblem* P, const DevBatch* Bt, int b, dou
   }
 
   // ---------------- factor + ADMM loop (osqp_solve) --------------------------------------------------------
+  WV_TICK(Bt, b, 0, tq);
   kkt_factor(w, P, 0, w.sigma, st.delta, tid, NT);
   wave_twist_invert(w, m, tid);
   admm_cache_weights(w, tid, NT);
+  WV_TICK(Bt, b, 1, tq);
   QpInfo info;
   info.status = 11;  // OSQP_UNSOLVED
   info.iter = 0;
@@ -1169,6 +1412,7 @@ TMX_DEVFN void qp_solve_wave(const DevProblem* P, const DevBatch* Bt, int b, dou
     iter = sh->iter;
     TMX_SYNC();
   }
+  tq = WV_CLK();
   const int exit_iter = terminated ? iter : iter - 1;
   if (!can_check)
   {
@@ -1373,6 +1617,7 @@ TMX_DEVFN void qp_solve_wave(const DevProblem* P, const DevBatch* Bt, int b, dou
   }
 
   // ---------------- store solution (unscaled, reference order) + record -----------------------------------
+  WV_TICK(Bt, b, 4, tq);
   const bool has_sol = !(info.status == 3 || info.status == 4 || info.status == 5 || info.status == 6 || info.status == 9);
   double* xq = Bt->xq + (size_t)b * P->n_max;
   double* yq = Bt->yq + (size_t)b * P->m_max;
@@ -1436,6 +1681,7 @@ TMX_DEVFN void qp_solve_wave(const DevProblem* P, const DevBatch* Bt, int b, dou
     Bt->prev_ws[2 * b + 1] = hs[3];
   }
   TMX_SYNC();
+  WV_TICK(Bt, b, 5, tq);
 }
 
 // One trust-region evaluation of problem b on one wave (sqp_step_block with the one-wave Model::optimize())
@@ -1449,6 +1695,7 @@ TMX_DEVFN void sqp_step_wave(const DevProblem* P, const DevBatch* Bt, int b, dou
   double* x = Bt->x + (size_t)b * NX;
   double* xn = Bt->xnew + (size_t)b * NX;
   const double* xq = Bt->xq + (size_t)b * P->n_max;
+  [[maybe_unused]] long long ts = WV_CLK();
   if (P->sqp.max_time < 1e300)
   {
     if (tid == 0)
@@ -1464,12 +1711,15 @@ TMX_DEVFN void sqp_step_wave(const DevProblem* P, const DevBatch* Bt, int b, dou
                  reinterpret_cast<int*>(smem), tid, NT, Bt->qdyn + (size_t)b * NX, nullptr);
   }
   TMX_SYNC();
+  WV_TICK(Bt, b, 6, ts);
   qp_solve_wave(P, Bt, b, smem, tid);
+  ts = WV_CLK();
   for (int v = tid; v < NX; v += NT)
     xn[v] = xq[v];
   TMX_SYNC();
   evaluate_terms(P, xn, Bt->new_cost_vals + (size_t)b * P->n_costs, Bt->new_cnt_viols + (size_t)b * P->n_cnts, smem, tid, NT);
   sqp_update_block(P, Bt, b, smem, tid, NT);
   TMX_SYNC();
+  WV_TICK(Bt, b, 7, ts);
 }
 #endif  // TMX_IS_DEVICE

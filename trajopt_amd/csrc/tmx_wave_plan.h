@@ -7,6 +7,8 @@
 #define TMX_WV_NV 4                    // variables per lane (the first two lanes of a group own the D <= 8 variables of the waypoint)
 #define TMX_WV_REC (4 + TMX_WV_RL)     // ints per lane of DevProblem::wv_plan: waypoint, group size, position in the group, number of rows, row slots
 #define TMX_WV_KMAX 16                 // steps per half chain: T <= 32
+#define TMX_WV_RS 10                   // row stride (doubles) of the chain vectors: 8 components + padding that spreads the waypoints over the LDS banks
+#define TMX_WV_BPAD 2                  // padding (doubles) behind every D x 8 block of S^{-1}, for the same reason
 
 // ---- lane plan (host, at upload): groups of 2 / 4 / 8 adjacent lanes per waypoint, aligned to their size ------------------------
 static inline bool wave_plan_build(int D, int T, int R, const int* slot_t, const int* slot_naux, int* plan, int* gmax_out, int* aux2_out)
@@ -96,7 +98,7 @@ struct WvLds
 TMX_HOSTDEVFN size_t wave_lds_fixed_doubles(int D, int T)
 {
   const size_t NX = (size_t)D * T;
-  return (size_t)T * D * 8 + ((NX + 1) & ~(size_t)1) + QPWS_DOUBLES + 2 * ((size_t)(T | 1) + 3) * 8;
+  return (size_t)T * (D * 8 + TMX_WV_BPAD) + ((NX + 1) & ~(size_t)1) + QPWS_DOUBLES + 2 * ((size_t)(T | 1) + 3) * TMX_WV_RS;
 }
 TMX_HOSTDEVFN size_t wave_lds_tp_doubles(int D, int T)
 {
