@@ -1,4 +1,4 @@
-"""One-wave-per-problem solver (trajopt_amd/csrc/tmx_wave.h) against the oracle and against the one-workgroup-per-CU kernels.
+"""Wave-pair solver (trajopt_amd/csrc/tmx_wave.h) against the oracle and against the one-workgroup-per-CU kernels.
 usage: python tools/wave_check.py [n_seeds] [cid]        (TMX_WAVE=0 in the environment switches the wave path off)"""
 import os
 import sys
@@ -7,6 +7,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import pyorc
+os.environ.setdefault("TMX_WAVE", "1")  # the wave-pair solver is opt-in
 from trajopt_amd import abi, configs, runtime
 
 

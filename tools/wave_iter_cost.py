@@ -1,4 +1,4 @@
-"""Cost of one register-resident ADMM iteration of the one-wave solver in situ (a -DTMX_WAVE_PROF build): one burst of N iterations per
+"""Cost of one register-resident ADMM iteration of the wave-pair solver in situ (a -DTMX_WAVE_PROF build): one burst of N iterations per
 QP solve (no termination test, no adaptive rho), first QP of B seeds of config 1.   usage: python tools/wave_iter_cost.py [B] [N]"""
 import ctypes as C
 import os
@@ -6,6 +6,7 @@ import sys
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("TMX_WAVE", "1")  # the wave-pair solver is opt-in
 from trajopt_amd import abi, configs, runtime
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024

@@ -1,4 +1,4 @@
-"""Phase profile of the one-wave solver (needs a -DTMX_WAVE_PROF build: make -C trajopt_amd/csrc EXTRA=-DTMX_WAVE_PROF).
+"""Phase profile of the wave-pair solver (needs a -DTMX_WAVE_PROF build: make -C trajopt_amd/csrc EXTRA=-DTMX_WAVE_PROF).
 usage: python tools/wave_prof.py [B]"""
 import ctypes as C
 import os
@@ -7,6 +7,7 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("TMX_WAVE", "1")  # the wave-pair solver is opt-in
 from trajopt_amd import abi, configs, runtime
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
@@ -33,5 +34,5 @@ tot = v[:8].sum()
 for k, nm in enumerate(names):
     print("  %-22s %8.0f cycles per ADMM iteration   %10.0f per QP solve   %5.1f %%" % (nm, v[k] / n_it, v[k] / n_qp, 100 * v[k] / tot))
 print("  inside the bursts: entry %.0f, iterations %.0f, in-register checks %.0f, exit %.0f cycles per ADMM iteration" % (v[11] / n_it, v[14] / n_it, v[12] / n_it, v[13] / n_it))
-print("  %-22s %8.0f cycles per ADMM iteration (one wave; x 1/4 per CU at four problems per CU)" % ("total", tot / n_it))
+print("  %-22s %8.0f cycles per ADMM iteration (one problem = one wave pair; x 1/4 per CU at four problems per CU)" % ("total", tot / n_it))
 ctx.close()

@@ -64,7 +64,7 @@ struct tmx_ctx
   bool piecewise{ false };  // DevProblem::st: the piecewise driver runs optimize() (host loop) - dense problems and row-only function terms
   bool ws_in_hbm{ false };  // QP workspace > 160 KB of LDS: k_*_hbm kernels, workspace carved in HBM (long horizons)
   int mode{ 2 };  // optimize() driver: 0 = one launch chain per step, 1 = k_sqp_fused, 2 = k_sqp_pool (default)
-  bool wave{ false };      // DevProblem::wave_ok: optimize() and Model::optimize() run as one wave per problem (tmx_wave.h: k_sqp_wave / k_qp_solve_wave)
+  bool wave{ false };      // DevProblem::wave_ok: optimize() and Model::optimize() run as a wave pair per problem (tmx_wave.h: k_sqp_wave / k_qp_solve_wave)
   size_t smem_wave{ 0 };
   int pool_wgs{ 0 };  // resident workgroups of the pool kernel (0 = CUs x workgroups-per-CU)
   void* nccl{ nullptr };
@@ -1621,19 +1621,22 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
   }
   if (dyn_p && !qp_dense)
     P.coef_far |= 4;  // dynamic objective blocks behind the far region of the per-problem scratch (qp_dynp_offset)
-  // one wave per problem (tmx_wave.h): block-tridiagonal QPs with diagonal couplings whose row-slot template fits the lane plan
+  // a wave pair per problem (tmx_wave.h): block-tridiagonal QPs with diagonal couplings whose row-slot template fits the lane plan
   P.wave_ok = 0;
   P.wv_gmax = 2;
   P.wv_aux2 = 0;
   P.wv_plan = nullptr;
 #if TMX_IS_DEVICE
   {
-    const char* env = std::getenv("TMX_WAVE");  // "0": keep the one-workgroup-per-CU kernels (A/B runs, bisecting)
-    const bool allowed = !(env && env[0] == '0');
-    std::vector<int> plan(64 * TMX_WV_REC, 0);
-    int gmax = 2, aux2 = 0;
+    // OPT-IN (TMX_WAVE=1): measured on MI355X (round 6, profiles/r06/) the wave-pair solver runs BASELINE config 1 at 101 k SQP it/s
+    // against the 118 k of k_sqp_pool - its ADMM iteration costs 4.6 k cycles per problem per CU where the stated bar was < 3 k - so
+    // the one-workgroup-per-CU kernels stay the default; DESIGN.md section 5
+    const char* env = std::getenv("TMX_WAVE");
+    const bool allowed = env && env[0] == '1';
+    std::vector<int> plan(TMX_WV_NT * TMX_WV_REC, 0);
+    int gmax = 4, aux2 = 0, n3 = 0;
     if (allowed && P.flavor == 0 && R2 == 0 && P.coef_far == 0 && !qp_dense && !P.st && !P.band && !P.use_time && P.n_fx == 0 &&
-        wave_plan_build(D, T, R, st.data(), naux.data(), plan.data(), &gmax, &aux2))
+        wave_plan_build(D, T, R, st.data(), naux.data(), plan.data(), &gmax, &aux2, &n3))
     {
       const size_t small_ints_w = 2 * (size_t)(P.n_max + 1) + 4 * (size_t)R + 2 + 16 + 16 + 512;
       size_t small = std::max<size_t>((tmx_eval_scratch_doubles(R, D * T, (int)vel_first.size(), n_costs, n_cnts) + n_costs + n_cnts + 8) * sizeof(double),
@@ -1663,7 +1666,7 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
   // LDS budgets
   ctx->smem_qp = qp_smem_bytes(D, T, R, NA, R2, P.coef_far);
   if (std::getenv("TMX_VERBOSE"))
-    std::fprintf(stderr, "[tmx] problem: D %d (joints %d), T %d, row slots %d, aux %d, pair rows %d, workspace flags %d, band %d, dense %d, QP workspace %zu B, one wave per problem %d (LDS %zu B, largest lane group %d, second slack in row slots 0x%x)\n", D, P.DK, T, R, NA, R2,
+    std::fprintf(stderr, "[tmx] problem: D %d (joints %d), T %d, row slots %d, aux %d, pair rows %d, workspace flags %d, band %d, dense %d, QP workspace %zu B, wave-pair solver %d (LDS %zu B, largest lane group %d, second slack in row slots 0x%x)\n", D, P.DK, T, R, NA, R2,
                  P.coef_far, P.band, (int)P.qp_dense, ctx->smem_qp, P.wave_ok, ctx->smem_wave, P.wv_gmax, P.wv_aux2);
   const size_t small_ints = 2 * (size_t)(P.n_max + 1) + 4 * (size_t)R + 2 + 16 + 16 + 512;  // qp_structure: tables, hash accumulators, chunk totals
   ctx->smem_small = std::max<size_t>((tmx_eval_scratch_doubles(R, D * T, (int)vel_first.size(), n_costs, n_cnts) + n_costs + n_cnts + 8) * sizeof(double),
@@ -2035,7 +2038,7 @@ tmx_status tmx_sqp_launch(tmx_ctx* ctx)
     TMX_LAUNCH(k_sqp_fused_hbm, B, ctx->nt_qp > 1 ? TMX_HBM_NT : 1, ctx->smem_chain, ctx->stream, ctx->dp, ctx->db, 0);
 #if TMX_IS_DEVICE
   else if (ctx->wave && ctx->mode == 2)
-    TMX_LAUNCH(k_sqp_wave, B, 64, ctx->smem_wave, ctx->stream, ctx->dp, ctx->db, 0);  // one wave per problem, all resident at B <= 4 x CUs
+    TMX_LAUNCH(k_sqp_wave, B, TMX_WV_NT, ctx->smem_wave, ctx->stream, ctx->dp, ctx->db, 0);  // a wave pair per problem, all resident at B <= 4 x CUs
 #endif
   else if (ctx->mode == 2)
   {
@@ -2201,7 +2204,7 @@ static tmx_status sqp_run_piecewise(tmx_ctx* ctx, int32_t max_steps, int32_t* n_
       TIMED(ctx->ms_admm, ctx->launches_admm++, TMX_LAUNCH(k_qp_solve_hbm, B, ctx->nt_qp > 1 ? TMX_HBM_NT : 1, ctx->smem_chain, ctx->stream, ctx->dp, ctx->db, 0));
 #if TMX_IS_DEVICE
     else if (ctx->wave)
-      TIMED(ctx->ms_admm, ctx->launches_admm++, TMX_LAUNCH(k_qp_solve_wave, B, 64, ctx->smem_wave, ctx->stream, ctx->dp, ctx->db, 0));
+      TIMED(ctx->ms_admm, ctx->launches_admm++, TMX_LAUNCH(k_qp_solve_wave, B, TMX_WV_NT, ctx->smem_wave, ctx->stream, ctx->dp, ctx->db, 0));
 #endif
     else
       TIMED(ctx->ms_admm, ctx->launches_admm++,
@@ -2588,7 +2591,7 @@ tmx_status tmx_qp_solve(tmx_ctx* ctx, double* x_qp, int32_t* cvx_status, tmx_qp_
     TIMED(ctx->ms_admm, ctx->launches_admm++, TMX_LAUNCH(k_qp_solve_hbm, ctx->hb.B, ctx->nt_qp > 1 ? TMX_HBM_NT : 1, ctx->smem_chain, ctx->stream, ctx->dp, ctx->db, 1));
 #if TMX_IS_DEVICE
   else if (ctx->wave)
-    TIMED(ctx->ms_admm, ctx->launches_admm++, TMX_LAUNCH(k_qp_solve_wave, ctx->hb.B, 64, ctx->smem_wave, ctx->stream, ctx->dp, ctx->db, 1));
+    TIMED(ctx->ms_admm, ctx->launches_admm++, TMX_LAUNCH(k_qp_solve_wave, ctx->hb.B, TMX_WV_NT, ctx->smem_wave, ctx->stream, ctx->dp, ctx->db, 1));
 #endif
   else
     TIMED(ctx->ms_admm, ctx->launches_admm++,

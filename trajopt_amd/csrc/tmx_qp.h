@@ -524,7 +524,7 @@ TMX_DEVFN void qp_ws_chain_to_lds(QpWs& w, double* lds)
     w.Zp = p;
 }
 
-// (dense_region = false: the one-wave solver of tmx_wave.h - no nested-dissection arrays G / Zs / sx / ty in the hot part)
+// (dense_region = false: the wave-pair solver of tmx_wave.h - no nested-dissection arrays G / Zs / sx / ty in the hot part)
 TMX_DEVFN void qp_ws_carve(QpWs& w, double* lds, double* glb, double* far, int D, int T, int R, int NA, int R2 = 0, int cf_flags = 0, bool dense_region = true)
 {
   const int cf = cf_flags & 1;

@@ -139,8 +139,8 @@ struct DevProblem
   int n_tt;
   int *tt_owner, *tt_form, *tt_slot;
   double *tt_coeff, *tt_limit;
-  // ONE-WAVE SOLVER (tmx_wave.h): the problem runs as one wave per seed (k_sqp_wave); wv_plan = 64 x TMX_WV_REC ints, the row / variable
-  // role of every lane (waypoint, group size, position in the group, row slots); wv_gmax = the largest lane group (2 | 4 | 8)
+  // WAVE-PAIR SOLVER (tmx_wave.h, opt-in: TMX_WAVE=1): the problem runs as two waves per seed (k_sqp_wave); wv_plan = 128 x TMX_WV_REC ints,
+  // the row / variable role of every lane (waypoint, group size, position in the group, row slots); wv_gmax = the largest lane group (4 | 8)
   int wave_ok;
   int wv_gmax;
   int wv_aux2;   // bit i: some lane's row slot i holds a row with two slack variables

@@ -1,11 +1,11 @@
-// tmx_wave.cpp — kernels of the one-wave-per-problem solver (tmx_wave.h).  Block = one wave, one wave per SIMD (the whole
-// 512-register file), <= 40 KB of dynamic LDS: four problems per CU.
+// tmx_wave.cpp — kernels of the wave-pair solver (tmx_wave.h).  Block = two waves, two waves per SIMD (256 registers each),
+// <= 40 KB of dynamic LDS: four problems per CU.
 #include "tmx_wave.h"
 #include "tmx_wave_kernels.h"
 
 #if TMX_IS_DEVICE
 #if TMX_IS_GCN
-#define TMX_WAVE_KERNEL __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
+#define TMX_WAVE_KERNEL __global__ void __launch_bounds__(TMX_WV_NT) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #else
 #define TMX_WAVE_KERNEL static void  // (the SIMT emulation of the CPU tier: tests/hostemu/tmx_simt.h)
 #endif
@@ -34,7 +34,7 @@ TMX_WAVE_KERNEL k_qp_solve_wave(const DevProblem* P, const DevBatch* Bt, int for
   qp_solve_wave(P, Bt, b, smem, tid);
   const double* xq = Bt->xq + (size_t)b * P->n_max;
   double* xn = Bt->xnew + (size_t)b * P->NX;
-  for (int v = tid; v < P->NX; v += 64)
+  for (int v = tid; v < P->NX; v += TMX_WV_NT)
     xn[v] = xq[v];
 }
 #endif

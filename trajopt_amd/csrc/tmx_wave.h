@@ -1,26 +1,28 @@
-// tmx_wave.h — ONE WAVE PER PROBLEM: the whole BasicTrustRegionSQP::optimize() of a seed on a single 64-lane wave, four problems per
-// CU (one wave per SIMD, the full 512-register file each, <= 40 KB of LDS each), no workgroup barrier and no hand-off anywhere.
+// tmx_wave.h — A WAVE PAIR PER PROBLEM: the whole BasicTrustRegionSQP::optimize() of a seed on two 64-lane waves (one 128-thread
+// workgroup), four problems per CU: two waves per SIMD (256 registers each), <= 40 KB of LDS per problem.
 //
 // Which problems: block-tridiagonal QPs with diagonal couplings (no rows on two waypoints, no banded objective, no function costs),
-// D <= 8, T <= 32, and a row-slot template that fits the lane plan below (BASELINE config 1: 7-DOF x 30 waypoints, 304 row slots).
-// Everything else keeps the kernels of tmx_kernels.h.
+// D <= 8, T <= 32, and a row-slot template that fits the lane plan (tmx_wave_plan.h; BASELINE config 1: 7-DOF x 30 waypoints, 304 row
+// slots).  Everything else keeps the kernels of tmx_kernels.h.
 //
 // Model::optimize() (OSQP v1.0.0 as driven by trajopt_sco/src/osqp_interface.cpp:283-370, :440-615) here:
 //   * the reduced KKT matrix K = P + sigma I + A' diag(w) A (rows and their slack columns eliminated analytically, tmx_qp.h) is
 //     factored as a TWISTED block LDL': Schur complements from BOTH ends of the waypoint chain towards a middle block m,
 //       S_t = K_t - C_{t-1} S_{t-1}^{-1} C_{t-1} (t < m),  S_t = K_t - C_t S_{t+1}^{-1} C_t (t > m),
 //       S_m = K_m - C_{m-1} S_{m-1}^{-1} C_{m-1} - C_m S_{m+1}^{-1} C_m,       C_t = diag(po_t): coupling of blocks t, t + 1
-//     so that a solve is two INDEPENDENT half-chains that the one wave walks interleaved in one instruction stream (the chain step is
-//     bound by dependent-issue latency, the second chain fills the idle issue slots: tools/ubench/btd_twist.hip, 8.2 k instead of
-//     11.8 k cycles per iteration of a lone wave);
+//     so that a solve is two INDEPENDENT half-chains: wave 0 walks the ascending one, wave 1 the descending one, side by side on
+//     different SIMDs; they meet at the middle block through LDS.  (History: tools/ubench/btd_wave.hip - one wave, one chain;
+//     btd_twist.hip - one wave, both chains interleaved; the one-wave product form of this file, git c206dfc .. : 14.5 k cycles per
+//     iteration at one wave per SIMD, every memory latency exposed, 512 registers not enough for the iterate + the residual check.)
 //   * the chain matrices G_k = -C S^{-1} live in REGISTERS, one entry per lane of an 8 x 8 lane grid, stored alternately as G and G'
 //     so that the vector a step produces (a sum over the lane index it was multiplied along: DPP quad_perm / row_half_mirror / row_ror
 //     and gfx950's v_permlane16_swap / v_permlane32_swap) is already laid out as the next step's input;
-//   * everything off the chain is waypoint-parallel: a GROUP of 2 / 4 / 8 adjacent lanes owns a waypoint - its rows (TMX_WV_RL per
-//     lane, with their slack variables) and its D variables - with the iterate (x, z, y of rows, slack and bound rows) in registers
-//     for a whole burst of ADMM iterations;
-//   * setup (Ruiz), residual checks / certificates / adaptive rho, polish and the solution store are the row-structured device
-//     functions of tmx_qp.h / tmx_solve.h run by the one wave on a workspace whose cold part lives in the per-problem HBM scratch.
+//   * everything off the chain is waypoint-parallel: a GROUP of 4 / 8 adjacent lanes of one wave owns a waypoint - its rows
+//     (TMX_WV_RL per lane, with their slack variables) and its D variables - with the iterate (x, z, y of rows, slack and bound rows)
+//     in registers for a whole burst of ADMM iterations, across the residual checks that change nothing;
+//   * setup (Ruiz), the authoritative residual checks / certificates / adaptive rho, polish and the solution store are the
+//     row-structured device functions of tmx_qp.h / tmx_solve.h run by the 128 threads on a workspace whose cold part lives in the
+//     per-problem HBM scratch.
 #pragma once
 #include "tmx_solve.h"
 #include <type_traits>
@@ -109,6 +111,27 @@ TMX_DEVFN void wv_swap_add2(double& p, double& q)
   q = __hiloint2double((int)qh[0], (int)ql[0]) + __hiloint2double((int)qh[1], (int)ql[1]);
 }
 // sums over the eight lanes of a grid row (lane & 7) / over the eight grid rows (lane >> 3); every lane ends with the sum
+TMX_DEVFN double wv_red_in(double p)
+{
+  p += wv_dpp<0xB1>(p);   // quad_perm [1,0,3,2]
+  p += wv_dpp<0x4E>(p);   // quad_perm [2,3,0,1]
+  return p + wv_dpp<0x141>(p);  // row_half_mirror
+}
+TMX_DEVFN double wv_red_x(double p)
+{
+  p += wv_dpp<0x128>(p);  // row_ror:8
+  {
+    const unsigned lo = (unsigned)__double2loint(p), hi = (unsigned)__double2hiint(p);
+    const tmx_wv_u2 l = __builtin_amdgcn_permlane16_swap(lo, lo, false, false), h = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    p = __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
+  }
+  {
+    const unsigned lo = (unsigned)__double2loint(p), hi = (unsigned)__double2hiint(p);
+    const tmx_wv_u2 l = __builtin_amdgcn_permlane32_swap(lo, lo, false, false), h = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    p = __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
+  }
+  return p;
+}
 TMX_DEVFN void wv_red_in2(double& p, double& q)
 {
   wv_dpp_add2<0xB1>(p, q);   // quad_perm [1,0,3,2]
@@ -145,6 +168,8 @@ TMX_DEVFN WvLds wave_ws_carve(QpWs& w, const DevProblem* P, const DevBatch* Bt, 
   p += ((size_t)(T | 1) + 3) * TMX_WV_RS;
   L.wx = p;
   p += ((size_t)(T | 1) + 3) * TMX_WV_RS;
+  L.wr = p;
+  p += TMX_WV_RED;
   L.cfl = p;
   w.tp = p;
   p += wave_lds_tp_doubles(D, T);
@@ -157,10 +182,12 @@ TMX_DEVFN WvLds wave_ws_carve(QpWs& w, const DevProblem* P, const DevBatch* Bt, 
 }
 
 // ---- twisted factorisation of the chain: in: the diagonal blocks K_t in w.Sinv (kkt_factor); out: S_t^{-1} in place ---------------
-// (one matrix entry per lane, pivots through ds_bpermute, as part_invert_interior - whose arithmetic the ascending half repeats)
-TMX_DEVFN void wave_twist_invert(const QpWs& w, int m, int lane)
+// Wave 0 the ascending half, wave 1 the descending half, side by side; then the middle block (wave 0).  One matrix entry per lane,
+// pivots through ds_bpermute, as part_invert_interior - whose arithmetic the ascending half repeats.
+TMX_DEVFN void wave_twist_invert(const QpWs& w, int m, int tid)
 {
   const int D = w.D, DD = D * D, DS = w.DS, DDS = w.DDS, T = w.T;
+  const int lane = tid & 63, wvi = TMX_UNI_I(tid >> 6);
   const bool valid = lane < DD;
   const int i = valid ? lane / D : 0, j = valid ? lane % D : 0;
   auto gauss_jordan = [&](double s) {
@@ -181,35 +208,44 @@ TMX_DEVFN void wave_twist_invert(const QpWs& w, int m, int lane)
     }
     return s;
   };
-  double up = 0.0, dn = 0.0;
-  for (int t = 0; t < m; ++t)  // ascending half
+  if (wvi == 0)
   {
-    double s = valid ? w.Sinv[t * DDS + i * DS + j] : 0.0;
-    if (t > 0 && valid)
-      s -= w.po[(t - 1) * D + i] * up * w.po[(t - 1) * D + j];
-    s = gauss_jordan(s);
-    if (valid)
-      w.Sinv[t * DDS + i * DS + j] = s;
-    up = s;
+    double up = 0.0;
+    for (int t = 0; t < m; ++t)  // ascending half
+    {
+      double s = valid ? w.Sinv[t * DDS + i * DS + j] : 0.0;
+      if (t > 0 && valid)
+        s -= w.po[(t - 1) * D + i] * up * w.po[(t - 1) * D + j];
+      s = gauss_jordan(s);
+      if (valid)
+        w.Sinv[t * DDS + i * DS + j] = s;
+      up = s;
+    }
   }
-  for (int t = T - 1; t > m; --t)  // descending half
+  else
   {
-    double s = valid ? w.Sinv[t * DDS + i * DS + j] : 0.0;
-    if (t < T - 1 && valid)
-      s -= w.po[t * D + i] * dn * w.po[t * D + j];
-    s = gauss_jordan(s);
-    if (valid)
-      w.Sinv[t * DDS + i * DS + j] = s;
-    dn = s;
+    double dn = 0.0;
+    for (int t = T - 1; t > m; --t)  // descending half
+    {
+      double s = valid ? w.Sinv[t * DDS + i * DS + j] : 0.0;
+      if (t < T - 1 && valid)
+        s -= w.po[t * D + i] * dn * w.po[t * D + j];
+      s = gauss_jordan(s);
+      if (valid)
+        w.Sinv[t * DDS + i * DS + j] = s;
+      dn = s;
+    }
   }
+  TMX_SYNC();
+  if (wvi == 0)
   {
     double s = valid ? w.Sinv[m * DDS + i * DS + j] : 0.0;
     if (valid)
     {
       if (m > 0)
-        s -= w.po[(m - 1) * D + i] * up * w.po[(m - 1) * D + j];
+        s -= w.po[(m - 1) * D + i] * w.Sinv[(m - 1) * DDS + i * DS + j] * w.po[(m - 1) * D + j];
       if (m < T - 1)
-        s -= w.po[m * D + i] * dn * w.po[m * D + j];
+        s -= w.po[m * D + i] * w.Sinv[(m + 1) * DDS + i * DS + j] * w.po[m * D + j];
     }
     s = gauss_jordan(s);
     if (valid)
@@ -220,46 +256,66 @@ TMX_DEVFN void wave_twist_invert(const QpWs& w, int m, int lane)
 
 // ---- a burst of ADMM iterations with the iterate in registers -------------------------------------------------------------------
 // in / out: the iterate and the scaled problem data in the workspace arrays (x, z, y of rows / slack / bound rows; fac, dinv from
-// admm_cache_weights; S^{-1} from wave_twist_invert).  n_iter iterations; the last one leaves delta_x / delta_y (certificates).
-// The per-element operations are those of admm_phase_a / _b / _c (tmx_qp.h); what differs is the order of the sums of the A'e
-// gather (per lane, then across the lanes of the group) and the chain.
+// admm_cache_weights; S^{-1} from wave_twist_invert).  The per-element operations are those of admm_phase_a / _b / _c (tmx_qp.h) in
+// fused-multiply-add form; what differs is the order of the sums of the A'e gather (per lane, then across the lanes of the group)
+// and the chain.  Returns the number of ADMM iterations done so far; leaves the iterate, the deltas of the last iteration and the 14
+// norms of update_info (QpShared::res).
 // NC: the number of chain steps N as a compile-time constant (0: run time).  With a run-time N every `k <= N` of the unrolled sweeps
-// is a loop-invariant lane mask the compiler keeps in an SGPR pair (32 of them: spills, and two scalar instructions per branch)
-// DC: the block size D likewise (0: run time).  AX2: the mask of the row slots that may hold a row with two slack variables (-1: run time):
-// the registers of the second slack variable of every other slot do not exist
+// is a loop-invariant lane mask the compiler keeps in an SGPR pair (32 of them: spills, and two scalar instructions per branch).
+// DC: the block size D likewise (0: run time).  AX2: the mask of the row slots that may hold a row with two slack variables (-1: run
+// time): the registers of the second slack variable of every other slot do not exist.
 template <int NC, int DC, int AX2>
-TMX_DEVFN int wave_admm_burst(const QpWs& w, const DevProblem* P, const DevBatch* Bt, int b, const WvLds& L, QpShared* sh, int iter0, int lane)
+TMX_DEVFN int wave_admm_burst(const QpWs& w, const DevProblem* P, const DevBatch* Bt, int b, const WvLds& L, QpShared* sh, int iter0, int tid)
 {
-  constexpr int RL = TMX_WV_RL, NV = TMX_WV_NV, KM = TMX_WV_KMAX, RS = TMX_WV_RS;
+  constexpr int RL = TMX_WV_RL, NV = TMX_WV_NV, KM = TMX_WV_KMAX, RS = TMX_WV_RS, NT = TMX_WV_NT;
   [[maybe_unused]] long long tbu = WV_CLK();
+  const int lane = tid & 63;
+  const int wvi = TMX_UNI_I(tid >> 6);  // 0: the ascending half chain (blocks 0 .. m), 1: the descending one (blocks TT-1 .. m)
   // (wave-uniform values as scalars: every `k <= N` below is a scalar branch, not an EXEC-masked region)
   const int D = DC ? DC : TMX_UNI_I(w.D), T = TMX_UNI_I(w.T), DS = 8, DDS = 8 * D + TMX_WV_BPAD;
   const int TT = T | 1, N = NC ? NC : (TT - 1) / 2, m = N;  // both half chains: N steps, the last one is the contribution to the middle block m
   const int ROW_TA = TT, ROW_TB = TT + 1, ROW_Z = TT + 2;
   const int aux2 = AX2 >= 0 ? AX2 : TMX_UNI_I(P->wv_aux2), gmax = TMX_UNI_I(P->wv_gmax);
-  wv_cgi* pl = (wv_cgi*)(P->wv_plan + lane * TMX_WV_REC);
-  const int tw_raw = pl[0], gsize = pl[1], gpos = pl[2], nrow = pl[3];
+  wv_cgi* pl = (wv_cgi*)(P->wv_plan + tid * TMX_WV_REC);
+  const int tw_raw = pl[0], gsize = pl[1], gpos = pl[2], nrow = pl[3], idx2 = pl[4];
   const int tw = tw_raw < 0 ? 0 : tw_raw;
-  const int k0 = (gpos == 0) ? 0 : NV, nv = (tw_raw < 0 || gpos > 1) ? 0 : ((gpos == 0) ? (D < NV ? D : NV) : (D > NV ? D - NV : 0));
-  const double sigma = w.sigma, al = w.alpha, oma = 1.0 - w.alpha, rho = w.rho;
+  const int k0 = (gpos < 4) ? NV * gpos : 0;
+  const int nv = (tw_raw < 0 || gpos > 3) ? 0 : (D - NV * gpos >= NV ? NV : (D - NV * gpos > 0 ? D - NV * gpos : 0));
+  // (wave-uniform doubles as scalars: they come out of the LDS record through vector loads)
+  auto uni_d = [](double v) -> double {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+  };
+  const double sigma = uni_d(w.sigma), al = uni_d(w.alpha), oma = 1.0 - al, rho = uni_d(w.rho);
   const double INF = TMX_OSQP_INFTY;
-  double* const wv = L.wv;
-  double* const wx = L.wx;
-  double* const cfl = L.cfl + lane;  // this lane's coefficients: cfl[(i D + d) 64]
+  // (LDS through 32-bit address-space-3 pointers: one base register per array and immediate offsets, not 64-bit generic addresses)
+  typedef tmx_lds_d ld;
+  ld* const wv = (ld*)L.wv;
+  ld* const wx = (ld*)L.wx;
+  ld* const wr = (ld*)L.wr;
+  ld* const Si = (ld*)w.Sinv;
+  ld* const po = (ld*)w.po;
+  // this lane's row coefficients: slots 0, 1 lane-major, slot 2 in the compact region (lanes without a third row share a zero column)
+  ld* const c01 = (ld*)L.cfl + tid;
+  ld* const c2 = (ld*)L.cfl + 2 * D * NT + idx2;
+  auto CF = [&](int i, int d) -> ld& { return i < 2 ? c01[(i * D + d) * NT] : c2[d * 64]; };
   // ---- row role: the iterate and the per-row constants in registers, the coefficients in LDS
   double z[RL], y[RL], hi[RL], fac[RL];
-  int veqm = 0, vfrm = 0;            // the same two type masks for the variable slots
-  int reqm = 0, rfrm = 0, rlom = 0;  // bit i: row slot i is an equality row (rho x 1e3) / a free row (rho_min) / has a finite lower bound (= hi)
-  double xa[RL][2], zba[RL][2], yba[RL][2], qa[RL][2], sa[RL][2], bba[RL][2], dnv[RL][2], sd[RL][2];
-  int rid[RL], aid[RL], nax[RL];
+  int veqm = 0, vfrm = 0;            // bit j: variable slot j is an equality bound row (rho x 1e3) / a free one (rho_min)
+  int reqm = 0, rfrm = 0, rlom = 0;  // bit i: row slot i is an equality row / a free row / has a finite lower bound (= hi)
+  // The two slack variables of an absolute-value row see the same numbers in every Ruiz pass (|+-1| scaled by the same row factor, equal
+  // bound rows, equal cost), so their constants are bit-identical up to the sign of the row entry: ONE set per row (checked below)
+  double xa[RL][2], zba[RL][2], yba[RL][2], qa[RL], sa[RL], bba[RL], dnv[RL];
+  int asym = 0;
+  int rid[RL], aid[RL];
+  int naxm = 0;  // bits 2i, 2i+1: the number of slack variables of row slot i
 #pragma unroll
   for (int i = 0; i < RL; ++i)
   {
-    const int r = i < nrow ? pl[4 + i] : 0;
+    const int r = i < nrow ? pl[5 + i] : 0;
     const bool on = i < nrow && WV_GI(w.act)[r] != 0;
     rid[i] = on ? r : -1;
     for (int d = 0; d < D; ++d)
-      cfl[(i * D + d) * 64] = on ? WV_G(w.coef)[r * D + d] : 0.0;
+      CF(i, d) = on ? WV_G(w.coef)[r * D + d] : 0.0;
     z[i] = on ? WV_G(w.zr)[r] : 0.0;
     y[i] = on ? WV_G(w.yr)[r] : 0.0;
     hi[i] = on ? WV_G(w.hir)[r] : INF;
@@ -270,23 +326,30 @@ TMX_DEVFN int wave_admm_burst(const QpWs& w, const DevProblem* P, const DevBatch
       rlom |= (on && WV_G(w.lor)[r] > -INF) << i;  // (rows are `<= hi` or `== hi`: DevProblem::slot_eq)
     }
     fac[i] = on ? WV_G(w.fac)[r] : 0.0;
-    nax[i] = on ? WV_GI(w.naux)[r] : 0;
+    const int nax_i = on ? WV_GI(w.naux)[r] : 0;
+    naxm |= nax_i << (2 * i);
     aid[i] = WV_GI(w.aoff)[r];
 #pragma unroll
     for (int k = 0; k < 2; ++k)
     {
-      const bool has = k < nax[i];
+      const bool has = k < nax_i;
       const int a = has ? aid[i] + k : 0;
       xa[i][k] = has ? WV_G(w.xa)[a] : 0.0;
       zba[i][k] = has ? WV_G(w.zba)[a] : 0.0;
       yba[i][k] = has ? WV_G(w.yba)[a] : 0.0;
-      qa[i][k] = has ? WV_G(w.qa)[a] : 0.0;
-      sa[i][k] = has ? WV_G(w.sa)[a] : 0.0;
-      bba[i][k] = has ? WV_G(w.bba)[a] : 0.0;
-      dnv[i][k] = has ? WV_G(w.dinv)[a] : 0.0;
-      sd[i][k] = sa[i][k] * dnv[i][k];
+      if (k == 0)
+      {
+        qa[i] = has ? WV_G(w.qa)[a] : 0.0;
+        sa[i] = has ? WV_G(w.sa)[a] : 0.0;
+        bba[i] = has ? WV_G(w.bba)[a] : 0.0;
+        dnv[i] = has ? WV_G(w.dinv)[a] : 0.0;
+      }
+      else if (has)
+        asym |= (WV_G(w.qa)[a] != qa[i]) || (WV_G(w.sa)[a] != -sa[i]) || (WV_G(w.bba)[a] != bba[i]) || (WV_G(w.dinv)[a] != dnv[i]);
     }
   }
+  if (asym)
+    __builtin_trap();  // (cannot happen: see above; loud rather than silently wrong)
   // bound rows of the slack variables: [0, INFTY * E) - type 0 for every admissible scaling, i.e. rho (checked by the caller)
   const double rb = rho, rbi = 1.0 / rho;
   // rho of a row / bound row by its type: three wave-uniform values and two selects instead of two registers per row
@@ -296,6 +359,12 @@ TMX_DEVFN int wave_admm_burst(const QpWs& w, const DevProblem* P, const DevBatch
   auto RV = [&](int j) -> double { return (vfrm >> j & 1) ? rho_fr : ((veqm >> j & 1) ? rho_eq : rho); };
   auto RVI = [&](int j) -> double { return (vfrm >> j & 1) ? rho_fri : ((veqm >> j & 1) ? rho_eqi : rbi); };
   auto LO = [&](int i) -> double { return (rlom >> i & 1) ? hi[i] : -INF; };
+  // constants of slack variable k of row slot i; the second one exists where the row has two (zeros otherwise, as for an absent row)
+  auto H1 = [&](int i) -> bool { return (naxm >> (2 * i) & 3) == 2; };
+  auto SA = [&](int i, int k) -> double { return k == 0 ? sa[i] : (H1(i) ? -sa[i] : 0.0); };
+  auto QA = [&](int i, int k) -> double { return k == 0 ? qa[i] : (H1(i) ? qa[i] : 0.0); };
+  auto BA = [&](int i, int k) -> double { return k == 0 ? bba[i] : (H1(i) ? bba[i] : 0.0); };
+  auto DN = [&](int i, int k) -> double { return k == 0 ? dnv[i] : (H1(i) ? dnv[i] : 0.0); };
   // ---- variable role
   double x[NV], zb[NV], yb[NV], q[NV], lb[NV], ub[NV], bb[NV];
 #pragma unroll
@@ -316,78 +385,76 @@ TMX_DEVFN int wave_admm_burst(const QpWs& w, const DevProblem* P, const DevBatch
       vfrm |= (ty == -1) << j;
     }
   }
-  // ---- grid role: chain registers.  Step k of chain A takes block k-1 to block k, step k of chain B block TT-k to block TT-1-k;
-  // odd steps hold M[a][b] (the product is summed over b), even steps M[b][a] (summed over a);  M = -C S^{-1}
+  // ---- grid role (lane of the wave): chain registers.  Step k of the ascending chain takes block k-1 to block k, step k of the
+  // descending chain block TT-k to block TT-1-k; odd steps hold M[a][b] (the product is summed over b), even steps M[b][a] (summed
+  // over a);  M = -C S^{-1}
   const int ga = lane >> 3, gb = lane & 7;
   const bool gin = ga < D && gb < D;
   const int ia = ga < D ? ga : 0, ib = gb < D ? gb : 0;
-  double GA[KM], GB[KM];
-  // (rebuilt at the start of every epoch: the chain registers are not live across the in-register check)
-  auto build_chain = [&]() {
-#pragma unroll
-  for (int k = 1; k <= KM; ++k)
-  {
-    GA[k - 1] = 0.0;
-    GB[k - 1] = 0.0;
-    if (k <= N)
-    {
-      const int ri = (k & 1) ? ia : ib, ci = (k & 1) ? ib : ia;
-      {
-        const int t = k - 1;
-        GA[k - 1] = gin ? -(w.po[t * D + ri] * w.Sinv[t * DDS + ri * DS + ci]) : 0.0;
-      }
-      const int t = TT - k, tc = TT - 1 - k;
-      if (t < T)  // (t == T: the dummy block of an even T - no coupling)
-        GB[k - 1] = gin ? -(w.po[tc * D + ri] * w.Sinv[t * DDS + ri * DS + ci]) : 0.0;
-    }
-  }
+  // The matrix entry of step k is read from LDS (S^{-1} entry and coupling) two steps ahead of its use: sixteen doubles per lane would
+  // not fit beside the iterate in the 256 registers of a wave
+  const double gmask = gin ? -1.0 : 0.0;
+  auto GXL = [&](int k) -> double {
+    const int ri = (k & 1) ? ia : ib, ci = (k & 1) ? ib : ia;
+    const int t = wvi ? TT - k : k - 1, tc = wvi ? TT - 1 - k : k - 1;
+    const int tl = t < T ? t : 0;  // (t == T: the dummy block of an even T - no coupling)
+    const double v = (gmask * po[(t < T ? tc : 0) * D + ri]) * Si[tl * DDS + ri * DS + ci];
+    return t < T ? v : 0.0;
   };
   const bool selA = gb == 0, selB = ga == 0;  // the lanes that store component ga (sum over b) resp. gb (sum over a)
   // Stores of the chain steps are unconditional: the lanes that do not hold the result write it into a dead row instead (no EXEC
   // masking on the chain).  Forward sweeps: results into wv, the others into the same row of wx (dead until the backward sweeps).
-  // Backward sweeps: results into wx, the others into a row of wv that has been consumed - chain A (descending) the row above the one it
-  // reads, chain B (ascending) the row below.
-  double* const fstA = selA ? wv + ga : wx + ga;
-  double* const fstB = selB ? wv + gb : wx + gb;
-  double* const bsaA = selA ? wx + ga : wv + RS + ga;   // chain A, result indexed by ga / gb
-  double* const bsaB = selB ? wx + gb : wv + RS + gb;
-  double* const bsbA = selA ? wx + ga : wv - RS + ga;   // chain B
-  double* const bsbB = selB ? wx + gb : wv - RS + gb;
+  // Backward sweeps: results into wx, the others into a row of wv that has been consumed - the ascending chain (now descending) the
+  // row above the one it reads, the other one the row below.
+  const int dump = wvi ? -RS : RS;
+  ld* const fstA = selA ? wv + ga : wx + ga;
+  ld* const fstB = selB ? wv + gb : wx + gb;
+  ld* const bstA = selA ? wx + ga : wv + dump + ga;
+  ld* const bstB = selB ? wx + gb : wv + dump + gb;
   const bool own = tw_raw >= 0 && gpos == 0;
   // Right-hand side of a chain step: EVERY lane of the eight that are summed adds one eighth of its component (wv holds the
   // right-hand sides of both sweeps times 1/8 - exact scalings), so no lane select sits on the chain
   auto inj = [&](bool sums_b, int row) -> double { return sums_b ? wv[row * RS + ga] : wv[row * RS + gb]; };
   // Both chain vectors start as zeros: the dummy block and the zero row stay so, and so does the padding component of every row (lanes
   // of the grid beyond D hold G = 0, but 0 x stale LDS contents may be 0 x NaN)
-  for (int e = lane; e < (TT + 3) * RS; e += 64)
+  for (int e = tid; e < (TT + 3) * RS; e += NT)
   {
     wv[e] = 0.0;
     wx[e] = 0.0;
   }
   TMX_SYNC();
-  // one ADMM iteration; KEEP: the last one of the burst, which leaves delta_x / delta_y for the certificates (a second instantiation
-  // of the body: with a run-time flag the stores sit in EXEC-masked regions of every iteration)
   double kd_dyr[RL], kd_dxa[RL][2], kd_dya[RL][2], kd_dxv[NV], kd_dyv[NV];  // deltas of the last iteration of an epoch
+  // sum of a per-lane partial over the lanes of the waypoint's group (4 or 8 adjacent lanes).  Every stage runs under the full EXEC
+  // mask (a DPP read from a masked-off lane is not defined) and the last one is selected per lane
+  auto group_sum = [&](double p8) -> double {
+    double s2 = p8 + wv_dpp<0xB1>(p8);
+    s2 += wv_dpp<0x4E>(s2);
+    if (gmax >= 8)
+    {
+      const double s8 = s2 + wv_dpp<0x141>(s2);
+      s2 = gsize >= 8 ? s8 : s2;
+    }
+    return s2;
+  };
+  // one ADMM iteration; KEEP: the last one of an epoch, which keeps delta_x / delta_y for the certificates (a second instantiation
+  // of the body)
   auto iterate = [&](auto keep_tag) {
     constexpr bool keep = decltype(keep_tag)::value;
-    // ---- phase A: e_r = g_r - fac_r sum_k sa_k t_k dinv_k,  t_k = right-hand side of slack variable k
-    double e[RL], ta[RL][2], gsa[RL];
+    // ---- phase A: e_r = g_r - fac_r sum_k sd_k t_k,  t_k = right-hand side of slack variable k
+    double e[RL];
 #pragma unroll
     for (int i = 0; i < RL; ++i)
     {
       const double g = __builtin_fma(RR(i), z[i], -y[i]);
       double gs = 0.0;
-      ta[i][1] = 0.0;
 #pragma unroll
       for (int k = 0; k < 2; ++k)
         if (k == 0 || (aux2 >> i & 1))
         {
           const double gbk = __builtin_fma(rb, zba[i][k], -yba[i][k]);
-          const double t = __builtin_fma(bba[i][k], gbk, __builtin_fma(sa[i][k], g, __builtin_fma(sigma, xa[i][k], -qa[i][k])));
-          ta[i][k] = t;
-          gs = __builtin_fma(sd[i][k], t, gs);
+          const double t = __builtin_fma(BA(i, k), gbk, __builtin_fma(SA(i, k), g, __builtin_fma(sigma, xa[i][k], -QA(i, k))));
+          gs = __builtin_fma(SA(i, k) * DN(i, k), t, gs);
         }
-      gsa[i] = gs;
       e[i] = __builtin_fma(-fac[i], gs, g);
     }
     // ---- phase B: reduced right-hand side sigma x - q + A'e + bound part, summed over the lanes of the group
@@ -400,35 +467,19 @@ TMX_DEVFN int wave_admm_burst(const QpWs& w, const DevProblem* P, const DevBatch
 #pragma unroll
       for (int d = 0; d < 8; ++d)
         if (d < D)
-          part[d] = __builtin_fma(cfl[(i * D + d) * 64], e[i], part[d]);
+          part[d] = __builtin_fma(CF(i, d), e[i], part[d]);
 #pragma unroll
     for (int j = 0; j < NV; ++j)
     {
       const double gbv = __builtin_fma(RV(j), zb[j], -yb[j]);
       const double o = __builtin_fma(bb[j], gbv, __builtin_fma(sigma, x[j], -q[j]));  // (absent variables: all zero)
-      if (gpos == 0)
-        part[j] += o;
-      else
-        part[NV + j] += o;
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4)
+        part[NV * g4 + j] += (gpos == g4) ? o : 0.0;
     }
-    // (every stage runs under the full EXEC mask - a DPP read from a masked-off lane is not defined - and is selected per lane;
-    //  gmax is wave-uniform: problems whose groups are all pairs skip the wider stages)
 #pragma unroll
     for (int d = 0; d < 8; ++d)
-    {
-      double s = part[d] + wv_dpp<0xB1>(part[d]);
-      if (gmax >= 4)
-      {
-        const double s4 = s + wv_dpp<0x4E>(s);
-        s = gsize >= 4 ? s4 : s;
-      }
-      if (gmax >= 8)
-      {
-        const double s8 = s + wv_dpp<0x141>(s);
-        s = gsize >= 8 ? s8 : s;
-      }
-      part[d] = s;
-    }
+      part[d] = group_sum(part[d]);
     if (own)
     {
 #pragma unroll
@@ -436,47 +487,41 @@ TMX_DEVFN int wave_admm_burst(const QpWs& w, const DevProblem* P, const DevBatch
         wv[tw * RS + d] = 0.125 * part[d];
     }
     TMX_SYNC();
-    // ---- the two forward half-chains in lockstep.  The right-hand sides are loaded two steps AHEAD of their use: a load placed behind
-    // a store of the other chain (unknown aliasing) would order the two chains.  The last step (k = N) has no right-hand side (the
-    // zero row) and leaves the contributions to the middle block in rows TT / TT + 1.
+    // ---- the forward half-chain of this wave.  The right-hand sides are loaded two steps AHEAD of their use.  The last step (k = N)
+    // has no right-hand side (the zero row) and leaves the contribution to the middle block in row TT / TT + 1.
     {
-      double ca = 8.0 * wv[gb], cb = 8.0 * wv[(TT - 1) * RS + gb];
-      double ra0 = inj(true, 1 < N ? 1 : ROW_Z), rb0 = inj(true, 1 < N ? TT - 2 : ROW_Z);
-      double ra1 = inj(false, 2 < N ? 2 : ROW_Z), rb1 = inj(false, 2 < N ? TT - 3 : ROW_Z);
+      double c = 8.0 * wv[(wvi ? TT - 1 : 0) * RS + gb];
+      double r0 = inj(true, 1 < N ? (wvi ? TT - 2 : 1) : ROW_Z);
+      double r1 = inj(false, 2 < N ? (wvi ? TT - 3 : 2) : ROW_Z);
+      double g0 = GXL(1), g1 = (2 <= N) ? GXL(2) : 0.0;
 #pragma unroll
       for (int k = 1; k <= KM; ++k)
         if (k <= N)
         {
-          const double ra = ra0, rbk = rb0;
-          ra0 = ra1;
-          rb0 = rb1;
+          const double r = r0, gk = g0;
+          r0 = r1;
+          g0 = g1;
           if (k + 2 <= KM)
           {
-            ra1 = inj((k & 1) != 0, k + 2 < N ? k + 2 : ROW_Z);
-            rb1 = inj((k & 1) != 0, k + 2 < N ? TT - 3 - k : ROW_Z);
+            r1 = inj((k & 1) != 0, k + 2 < N ? (wvi ? TT - 3 - k : k + 2) : ROW_Z);
+            g1 = (k + 2 <= N) ? GXL(k + 2) : 0.0;
           }
-          ca = __builtin_fma(GA[k - 1], ca, ra);
-          cb = __builtin_fma(GB[k - 1], cb, rbk);
-          if (k & 1)
-            wv_red_in2(ca, cb);
-          else
-            wv_red_x2(ca, cb);
-          double* const fst = (k & 1) ? fstA : fstB;
-          fst[(k < N ? k : ROW_TA) * RS] = ca;
-          fst[(k < N ? TT - 1 - k : ROW_TB) * RS] = cb;
+          c = __builtin_fma(gk, c, r);
+          c = (k & 1) ? wv_red_in(c) : wv_red_x(c);
+          ((k & 1) ? fstA : fstB)[(k < N ? (wvi ? TT - 1 - k : k) : (wvi ? ROW_TB : ROW_TA)) * RS] = c;
         }
     }
     TMX_SYNC();
-    if (lane < 8)
-      wv[m * RS + lane] = (8.0 * wv[m * RS + lane] + wv[ROW_TA * RS + lane]) + wv[ROW_TB * RS + lane];
-    TMX_SYNC();
-    // ---- g_t = S_t^{-1} y_t, waypoint-parallel (the first two lanes of a group; all lanes of the wave read before any writes)
+    // ---- g_t = S_t^{-1} y_t, waypoint-parallel (the first four lanes of a group; all lanes of the wave read before any writes).
+    // The middle block's y_m = b_m + the two contributions of the half chains is formed here by the lanes that need it.
     {
       double yy[8], g[NV];
-      const double ysc = (tw == 0 || tw == TT - 1) ? 8.0 : 1.0;  // (the end blocks the chains START from still hold their scaled right-hand sides)
+      // (the end blocks the chains START from and the middle block still hold their scaled right-hand sides)
+      const double ysc = (tw == 0 || tw == TT - 1 || tw == m) ? 8.0 : 1.0;
+      const int rta = (tw == m) ? ROW_TA : ROW_Z, rtb = (tw == m) ? ROW_TB : ROW_Z;
 #pragma unroll
       for (int jj = 0; jj < 8; ++jj)
-        yy[jj] = ysc * wv[tw * RS + jj];
+        yy[jj] = (ysc * wv[tw * RS + jj] + wv[rta * RS + jj]) + wv[rtb * RS + jj];
 #pragma unroll
       for (int j = 0; j < NV; ++j)
       {
@@ -484,7 +529,7 @@ TMX_DEVFN int wave_admm_burst(const QpWs& w, const DevProblem* P, const DevBatch
         double s = 0.0;
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj)
-          s = __builtin_fma(w.Sinv[tw * DDS + d * DS + jj], yy[jj], s);
+          s = __builtin_fma(Si[tw * DDS + d * DS + jj], yy[jj], s);
         g[j] = s;
       }
       __builtin_amdgcn_wave_barrier();  // (in place: every lane of the group has read y_t before any lane writes g_t)
@@ -498,56 +543,85 @@ TMX_DEVFN int wave_admm_burst(const QpWs& w, const DevProblem* P, const DevBatch
         }
     }
     TMX_SYNC();
-    // ---- the two backward half-chains from the middle block outwards:  x_{k-1} = g_{k-1} + GA[k]' x_k,  x_{TT-k} = g_{TT-k} + GB[k]' x_{TT-1-k}
+    // ---- the backward half-chain of this wave from the middle block outwards:  x_{k-1} = g_{k-1} + G_k' x_k  resp.
+    //      x_{TT-k} = g_{TT-k} + G_k' x_{TT-1-k}
     {
       // x_m in the layout the first step (k = N) multiplies along: an odd step sums over a
       const int moff = (N & 1) ? ga : gb;
-      double ca = wx[m * RS + moff], cb = ca;
-      // right-hand sides of steps N and N - 1 (run-time parity), then two steps ahead inside the unrolled sequence
+      double c = wx[m * RS + moff];
       auto binj = [&](bool sums_a, int row) -> double { return sums_a ? wv[row * RS + gb] : wv[row * RS + ga]; };
-      double qa0 = binj((N & 1) != 0, N - 1), qb0 = binj((N & 1) != 0, TT - N);
-      double qa1 = binj((N & 1) == 0, N >= 2 ? N - 2 : ROW_Z), qb1 = binj((N & 1) == 0, N >= 2 ? TT - N + 1 : ROW_Z);
+      // right-hand sides of steps N and N - 1 (run-time parity), then two steps ahead inside the unrolled sequence
+      double q0 = binj((N & 1) != 0, wvi ? TT - N : N - 1);
+      double q1 = binj((N & 1) == 0, N >= 2 ? (wvi ? TT - N + 1 : N - 2) : ROW_Z);
+      double g0 = 0.0, g1 = 0.0;
+      if (NC)
+      {
+        g0 = GXL(NC ? NC : 1);
+        g1 = (NC >= 2) ? GXL(NC >= 2 ? NC - 1 : 1) : 0.0;
+      }
 #pragma unroll
       for (int k = KM; k >= 1; --k)
         if (k <= N)
         {
-          const double ra = qa0, rbk = qb0;
-          qa0 = qa1;
-          qb0 = qb1;
+          if (!NC)  // (run-time N: the entry of this step is loaded here)
+            g0 = GXL(k);
+          const double r = q0, gk = g0;
+          q0 = q1;
+          g0 = g1;
           if (k >= 3)
           {
-            qa1 = binj((k & 1) != 0, k - 3);
-            qb1 = binj((k & 1) != 0, TT - k + 2);
+            q1 = binj((k & 1) != 0, wvi ? TT - k + 2 : k - 3);
+            if (NC)
+              g1 = GXL(k - 2);
           }
-          ca = __builtin_fma(GA[k - 1], ca, ra);
-          cb = __builtin_fma(GB[k - 1], cb, rbk);
-          if (k & 1)
-            wv_red_x2(ca, cb);
-          else
-            wv_red_in2(ca, cb);
-          ((k & 1) ? bsaB : bsaA)[(k - 1) * RS] = ca;
-          ((k & 1) ? bsbB : bsbA)[(TT - k) * RS] = cb;
+          c = __builtin_fma(gk, c, r);
+          c = (k & 1) ? wv_red_x(c) : wv_red_in(c);
+          ((k & 1) ? bstB : bstA)[(wvi ? TT - k : k - 1) * RS] = c;
         }
     }
     TMX_SYNC();
     // ---- phase C: slack recovery, z~, and the x / z / y updates
     {
-      double xx[8];
+      // (all dot products first: x~ of the waypoint is then dead while the rows are updated)
+      double dots[RL];
+      {
+        double xx[8];
 #pragma unroll
-      for (int d = 0; d < 8; ++d)
-        xx[d] = wx[tw * RS + d];
+        for (int d = 0; d < 8; ++d)
+          xx[d] = wx[tw * RS + d];
+#pragma unroll
+        for (int i = 0; i < RL; ++i)
+        {
+          double dot = 0.0;
+#pragma unroll
+          for (int d = 0; d < 8; ++d)
+            if (d < D)
+              dot = __builtin_fma(CF(i, d), xx[d], dot);
+          dots[i] = dot;
+        }
+      }
 #pragma unroll
       for (int i = 0; i < RL; ++i)
       {
-        double dot = 0.0;
-#pragma unroll
-        for (int d = 0; d < 8; ++d)
-          if (d < D)
-            dot = __builtin_fma(cfl[(i * D + d) * 64], xx[d], dot);
+        const double dot = dots[i];
         double ax = dot;
         // slack recovery.  With v_k = t_k - rho_r s_k dot and f = fac sum_k sd_k v_k (admm_phase_c):  sum_k sd_k v_k = gs - rho_r kappa dot
         // and rho_r - fac rho_r kappa = fac, so  x~_k = (v_k - s_k f) dinv_k = (t_k - s_k h) dinv_k  with  h = fac (dot + gs)
-        const double h = fac[i] * (dot + gsa[i]);
+        // (t_k and gs again, from the same - not yet updated - iterate: the values of phase A; keeping them across the chain costs more
+        //  registers than the wave has)
+        double ta[2] = { 0.0, 0.0 }, gs = 0.0;
+        {
+          const double g = __builtin_fma(RR(i), z[i], -y[i]);
+#pragma unroll
+          for (int k = 0; k < 2; ++k)
+            if (k == 0 || (aux2 >> i & 1))
+            {
+              const double gbk = __builtin_fma(rb, zba[i][k], -yba[i][k]);
+              ta[k] = __builtin_fma(BA(i, k), gbk, __builtin_fma(SA(i, k), g, __builtin_fma(sigma, xa[i][k], -QA(i, k))));
+              gs = __builtin_fma(SA(i, k) * DN(i, k), ta[k], gs);
+            }
+        }
+        const double h = fac[i] * (dot + gs);
         if (keep)
         {
           kd_dxa[i][1] = 0.0;
@@ -557,12 +631,12 @@ TMX_DEVFN int wave_admm_burst(const QpWs& w, const DevProblem* P, const DevBatch
         for (int k = 0; k < 2; ++k)
           if (k == 0 || (aux2 >> i & 1))
           {
-            const double xt = __builtin_fma(-sa[i][k], h, ta[i][k]) * dnv[i][k];
-            ax = __builtin_fma(sa[i][k], xt, ax);
+            const double xt = __builtin_fma(-SA(i, k), h, ta[k]) * DN(i, k);
+            ax = __builtin_fma(SA(i, k), xt, ax);
             const double xn = __builtin_fma(al, xt, oma * xa[i][k]);
             [[maybe_unused]] const double dxa = xn - xa[i][k];
             xa[i][k] = xn;
-            const double zt = bba[i][k] * xt;
+            const double zt = BA(i, k) * xt;
             const double zrl = __builtin_fma(al, zt, oma * zba[i][k]);
             const double zn = fmax(__builtin_fma(rbi, yba[i][k], zrl), 0.0);  // (upper bound INFTY * E >= 1e26: never reached by a finite iterate)
             const double dy = rb * (zrl - zn);
@@ -604,7 +678,8 @@ TMX_DEVFN int wave_admm_burst(const QpWs& w, const DevProblem* P, const DevBatch
         }
       }
     }
-    TMX_SYNC();
+    // (no barrier here: phase C reads x~ (wx) and nothing of what phases A / B of the next iteration write; the barrier behind phase
+    //  B separates the partner wave's reads of wx from the dump stores of the next forward sweep)
   };
   // ---- EPOCHS: iterate to the next residual check, form - from registers - what the check would look at, and go on iterating while
   // the check is CERTAINLY a no-op (not converged, both infeasibility certificates clearly negative, rho inside its band, iterations
@@ -613,8 +688,8 @@ TMX_DEVFN int wave_admm_burst(const QpWs& w, const DevProblem* P, const DevBatch
   const tmx_osqp_settings& st = P->osqp;
   const int max_iter = TMX_UNI_I(st.max_iter), chk = TMX_UNI_I(st.check_termination),
             rint = (st.adaptive_rho && st.adaptive_rho_interval) ? TMX_UNI_I(st.adaptive_rho_interval) : 0;
-  const double eps_abs = st.eps_abs, eps_rel = st.eps_rel, eps_pinf = st.eps_prim_inf, eps_dinf = st.eps_dual_inf, rtol = st.adaptive_rho_tolerance;
-  const double cinv = w.cinv, cc = w.c;
+  const double eps_abs = uni_d(st.eps_abs), eps_rel = uni_d(st.eps_rel), eps_pinf = uni_d(st.eps_prim_inf), eps_dinf = uni_d(st.eps_dual_inf), rtol = uni_d(st.adaptive_rho_tolerance);
+  const double cinv = uni_d(w.cinv), cc = uni_d(w.c);
   int iter_done = TMX_UNI_I(iter0);
   double nm[18];
   WV_TICK(Bt, b, 11, tbu);
@@ -626,36 +701,13 @@ TMX_DEVFN int wave_admm_burst(const QpWs& w, const DevProblem* P, const DevBatch
     if (rint)
       next = min(next, (iter_done / rint + 1) * rint);
     const int n = next - iter_done;
-    build_chain();
     for (int it = 0; it + 1 < n; ++it)
       iterate(std::false_type{});
     if (n > 0)
       iterate(std::true_type{});
     iter_done = next;
+    TMX_SYNC();
     WV_TICK(Bt, b, 14, tbu);
-    // ---- the scalings the norms are weighted with: ALL loads first (one exposed HBM latency per check, not one per value)
-    double cEr[RL], cEba[RL][2], cDa[RL][2], cEbp[NV], cDp[NV], cPd[NV];
-#pragma unroll
-    for (int i = 0; i < RL; ++i)
-    {
-      cEr[i] = WV_G(w.Er)[rid[i] >= 0 ? rid[i] : 0];
-#pragma unroll
-      for (int k = 0; k < 2; ++k)
-        if (k == 0 || (aux2 >> i & 1))
-        {
-          const int a = (k < nax[i]) ? aid[i] + k : 0;
-          cEba[i][k] = WV_G(w.Eba)[a];
-          cDa[i][k] = WV_G(w.Da)[a];
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < NV; ++j)
-    {
-      const int v = (j < nv) ? tw * D + k0 + j : 0;
-      cEbp[j] = WV_G(w.Ebp)[v];
-      cDp[j] = WV_G(w.Dp)[v];
-      cPd[j] = WV_G(w.pd)[v];
-    }
     // ---- round 1: x with 8 slots per waypoint -> wx, A'y per waypoint -> wv; the norms of compute_residuals
 #pragma unroll
     for (int k = 0; k < 18; ++k)
@@ -670,23 +722,10 @@ TMX_DEVFN int wave_admm_burst(const QpWs& w, const DevProblem* P, const DevBatch
 #pragma unroll
         for (int d = 0; d < 8; ++d)
           if (d < D)
-            pt[d] = __builtin_fma(cfl[(i * D + d) * 64], rv[i], pt[d]);
+            pt[d] = __builtin_fma(CF(i, d), rv[i], pt[d]);
 #pragma unroll
       for (int d = 0; d < 8; ++d)
-      {
-        double s2 = pt[d] + wv_dpp<0xB1>(pt[d]);
-        if (gmax >= 4)
-        {
-          const double s4 = s2 + wv_dpp<0x4E>(s2);
-          s2 = gsize >= 4 ? s4 : s2;
-        }
-        if (gmax >= 8)
-        {
-          const double s8 = s2 + wv_dpp<0x141>(s2);
-          s2 = gsize >= 8 ? s8 : s2;
-        }
-        pt[d] = s2;
-      }
+        pt[d] = group_sum(pt[d]);
       if (own)
       {
 #pragma unroll
@@ -700,7 +739,6 @@ TMX_DEVFN int wave_admm_burst(const QpWs& w, const DevProblem* P, const DevBatch
         wx[tw * RS + k0 + j] = x[j];
     gather_to_wv(y);
     TMX_SYNC();
-    WV_CTICK(3);
     {
       double xx[8];
 #pragma unroll
@@ -714,11 +752,12 @@ TMX_DEVFN int wave_admm_burst(const QpWs& w, const DevProblem* P, const DevBatch
 #pragma unroll
           for (int d = 0; d < 8; ++d)
             if (d < D)
-              ax = __builtin_fma(cfl[(i * D + d) * 64], xx[d], ax);
+              ax = __builtin_fma(CF(i, d), xx[d], ax);
 #pragma unroll
           for (int k = 0; k < 2; ++k)
-            ax = __builtin_fma(sa[i][k], xa[i][k], ax);
-          const double einv = fast_rcp(cEr[i]);
+            if (k == 0 || (aux2 >> i & 1))
+              ax = __builtin_fma(SA(i, k), xa[i][k], ax);
+          const double einv = fast_rcp(WV_G(w.Er)[rid[i]]);
           nm[0] = fmax(nm[0], fabs(einv * (ax - z[i])));
           nm[1] = fmax(nm[1], fabs(ax - z[i]));
           nm[2] = fmax(nm[2], fabs(z[i]));
@@ -727,24 +766,24 @@ TMX_DEVFN int wave_admm_burst(const QpWs& w, const DevProblem* P, const DevBatch
           nm[5] = fmax(nm[5], fabs(einv * ax));
 #pragma unroll
           for (int k = 0; k < 2; ++k)
-            if ((k == 0 || (aux2 >> i & 1)) && k < nax[i])
+            if ((k == 0 || (aux2 >> i & 1)) && k < (naxm >> (2 * i) & 3))
             {
-              const double axa = bba[i][k] * xa[i][k], za = zba[i][k];
-              const double ei = fast_rcp(cEba[i][k]);
+              const double axa = BA(i, k) * xa[i][k], za = zba[i][k];
+              const double ei = fast_rcp(WV_G(w.Eba)[aid[i] + k]);
               nm[0] = fmax(nm[0], fabs(ei * (axa - za)));
               nm[1] = fmax(nm[1], fabs(axa - za));
               nm[2] = fmax(nm[2], fabs(za));
               nm[3] = fmax(nm[3], fabs(axa));
               nm[4] = fmax(nm[4], fabs(ei * za));
               nm[5] = fmax(nm[5], fabs(ei * axa));
-              const double aty = sa[i][k] * y[i] + bba[i][k] * yba[i][k];
-              const double res = qa[i][k] + aty;
-              const double di = fast_rcp(cDa[i][k]);
+              const double aty = SA(i, k) * y[i] + BA(i, k) * yba[i][k];
+              const double res = QA(i, k) + aty;
+              const double di = fast_rcp(WV_G(w.Da)[aid[i] + k]);
               nm[6] = fmax(nm[6], fabs(di * res));
               nm[7] = fmax(nm[7], fabs(res));
-              nm[8] = fmax(nm[8], fabs(qa[i][k]));
+              nm[8] = fmax(nm[8], fabs(QA(i, k)));
               nm[9] = fmax(nm[9], fabs(aty));
-              nm[11] = fmax(nm[11], fabs(di * qa[i][k]));
+              nm[11] = fmax(nm[11], fabs(di * QA(i, k)));
               nm[12] = fmax(nm[12], fabs(di * aty));
             }
         }
@@ -754,21 +793,21 @@ TMX_DEVFN int wave_admm_burst(const QpWs& w, const DevProblem* P, const DevBatch
         {
           const int d = k0 + j, v = tw * D + d;
           const double axv = bb[j] * x[j];
-          const double ei = fast_rcp(cEbp[j]);
+          const double ei = fast_rcp(WV_G(w.Ebp)[v]);
           nm[0] = fmax(nm[0], fabs(ei * (axv - zb[j])));
           nm[1] = fmax(nm[1], fabs(axv - zb[j]));
           nm[2] = fmax(nm[2], fabs(zb[j]));
           nm[3] = fmax(nm[3], fabs(axv));
           nm[4] = fmax(nm[4], fabs(ei * zb[j]));
           nm[5] = fmax(nm[5], fabs(ei * axv));
-          double px = cPd[j] * x[j];
+          double px = WV_G(w.pd)[v] * x[j];
           if (tw > 0)
-            px += w.po[v - D] * wx[(tw - 1) * RS + d];
+            px += po[v - D] * wx[(tw - 1) * RS + d];
           if (tw < T - 1)
-            px += w.po[v] * wx[(tw + 1) * RS + d];
+            px += po[v] * wx[(tw + 1) * RS + d];
           const double aty = wv[tw * RS + d] + bb[j] * yb[j];
           const double res = (q[j] + px) + aty;
-          const double di = fast_rcp(cDp[j]);
+          const double di = fast_rcp(WV_G(w.Dp)[v]);
           nm[6] = fmax(nm[6], fabs(di * res));
           nm[7] = fmax(nm[7], fabs(res));
           nm[8] = fmax(nm[8], fabs(q[j]));
@@ -780,7 +819,6 @@ TMX_DEVFN int wave_admm_burst(const QpWs& w, const DevProblem* P, const DevBatch
         }
     }
     TMX_SYNC();
-    WV_CTICK(4);
     // ---- round 2: delta_x -> wx, A' (projected delta_y) -> wv; the norm tests of the two infeasibility certificates
     //   nm[14] max |E dy_proj|   nm[15] max |(A' dy_proj) / D|   nm[16] max |D dx|   nm[17] max |(P dx) / D|
     {
@@ -797,7 +835,7 @@ TMX_DEVFN int wave_admm_burst(const QpWs& w, const DevProblem* P, const DevBatch
         pdy[i] = rid[i] >= 0 ? dy : 0.0;
 #pragma unroll
         for (int k = 0; k < 2; ++k)
-          pda[i][k] = (k < nax[i]) ? fmin(kd_dya[i][k], 0.0) : 0.0;  // (upper bound INFTY * E: only the upper side is infinite)
+          pda[i][k] = ((k == 0 || (aux2 >> i & 1)) && k < (naxm >> (2 * i) & 3)) ? fmin(kd_dya[i][k], 0.0) : 0.0;  // (only the upper side is infinite)
       }
 #pragma unroll
       for (int j = 0; j < NV; ++j)
@@ -819,14 +857,14 @@ TMX_DEVFN int wave_admm_burst(const QpWs& w, const DevProblem* P, const DevBatch
       for (int i = 0; i < RL; ++i)
         if (rid[i] >= 0)
         {
-          nm[14] = fmax(nm[14], fabs(cEr[i] * pdy[i]));
+          nm[14] = fmax(nm[14], fabs(WV_G(w.Er)[rid[i]] * pdy[i]));
 #pragma unroll
           for (int k = 0; k < 2; ++k)
-            if ((k == 0 || (aux2 >> i & 1)) && k < nax[i])
+            if ((k == 0 || (aux2 >> i & 1)) && k < (naxm >> (2 * i) & 3))
             {
-              const double da = cDa[i][k];
-              nm[14] = fmax(nm[14], fabs(cEba[i][k] * pda[i][k]));
-              nm[15] = fmax(nm[15], fabs((sa[i][k] * pdy[i] + bba[i][k] * pda[i][k]) * fast_rcp(da)));
+              const double da = WV_G(w.Da)[aid[i] + k];
+              nm[14] = fmax(nm[14], fabs(WV_G(w.Eba)[aid[i] + k] * pda[i][k]));
+              nm[15] = fmax(nm[15], fabs((SA(i, k) * pdy[i] + BA(i, k) * pda[i][k]) * fast_rcp(da)));
               nm[16] = fmax(nm[16], fabs(da * kd_dxa[i][k]));
             }
         }
@@ -835,24 +873,33 @@ TMX_DEVFN int wave_admm_burst(const QpWs& w, const DevProblem* P, const DevBatch
         if (j < nv)
         {
           const int d = k0 + j, v = tw * D + d;
-          const double dp = cDp[j], di = fast_rcp(dp);
-          nm[14] = fmax(nm[14], fabs(cEbp[j] * pdv[j]));
+          const double dp = WV_G(w.Dp)[v], di = fast_rcp(dp);
+          nm[14] = fmax(nm[14], fabs(WV_G(w.Ebp)[v] * pdv[j]));
           nm[15] = fmax(nm[15], fabs((wv[tw * RS + d] + bb[j] * pdv[j]) * di));
           nm[16] = fmax(nm[16], fabs(dp * kd_dxv[j]));
-          double px = cPd[j] * kd_dxv[j];
+          double px = WV_G(w.pd)[v] * kd_dxv[j];
           if (tw > 0)
-            px += w.po[v - D] * wx[(tw - 1) * RS + d];
+            px += po[v - D] * wx[(tw - 1) * RS + d];
           if (tw < T - 1)
-            px += w.po[v] * wx[(tw + 1) * RS + d];
+            px += po[v] * wx[(tw + 1) * RS + d];
           nm[17] = fmax(nm[17], fabs(px * di));
         }
     }
-    WV_CTICK(5);
+    // maxima over the wave, then over the wave pair through LDS
 #pragma unroll
     for (int k = 0; k < 18; ++k)
       nm[k] = wave_allreduce<false>(nm[k]);
+    if (lane == 0)
+    {
+#pragma unroll
+      for (int k = 0; k < 18; ++k)
+        wr[wvi * 20 + k] = nm[k];
+    }
     TMX_SYNC();
-    WV_CTICK(6);
+#pragma unroll
+    for (int k = 0; k < 18; ++k)
+      nm[k] = fmax(wr[k], wr[20 + k]);
+    TMX_SYNC();
     // ---- would wave_check_nl do anything?  (its tests in its order; anything not CERTAINLY a no-op leaves the loop)
     bool go_on = iter_done < max_iter;
     const bool can_check = chk && (iter_done % chk == 0);
@@ -900,7 +947,7 @@ TMX_DEVFN int wave_admm_burst(const QpWs& w, const DevProblem* P, const DevBatch
       WV_G(w.dyr)[rid[i]] = kd_dyr[i];
 #pragma unroll
       for (int k = 0; k < 2; ++k)
-        if (k < nax[i])
+        if ((k == 0 || (aux2 >> i & 1)) && k < (naxm >> (2 * i) & 3))
         {
           WV_G(w.xa)[aid[i] + k] = xa[i][k];
           WV_G(w.zba)[aid[i] + k] = zba[i][k];
@@ -919,7 +966,7 @@ TMX_DEVFN int wave_admm_burst(const QpWs& w, const DevProblem* P, const DevBatch
       WV_G(w.dxp)[tw * D + k0 + j] = kd_dxv[j];
       WV_G(w.dybp)[tw * D + k0 + j] = kd_dyv[j];
     }
-  if (lane == 0)
+  if (tid == 0)
   {
 #pragma unroll
     for (int k = 0; k < 14; ++k)
@@ -949,7 +996,7 @@ TMX_DEVFN QpShared* wave_ws_rebuild(QpWs& w, const DevProblem* P, const DevBatch
 // the loop ends
 __device__ __attribute__((noinline)) static int wave_check_nl(const DevProblem* P_in, const DevBatch* Bt_in, int b_in, int iter_in, unsigned lds_in)
 {
-  constexpr int NT = 64;
+  constexpr int NT = TMX_WV_NT;
   const DevProblem* P = tmx_uniform_ptr(P_in);
   const DevBatch* Bt = tmx_uniform_ptr(Bt_in);
   const int b = __builtin_amdgcn_readfirstlane(b_in), iter = __builtin_amdgcn_readfirstlane(iter_in);
@@ -1049,8 +1096,8 @@ __device__ __attribute__((noinline)) static void wave_admm_nl(const DevProblem* 
       WvLds L;
       QpShared* sh = wave_ws_rebuild(w, P, Bt, b, smem, &L);
       const int before = iter;
-      if (((w.T | 1) - 1) / 2 == 15 && w.D == 7 && P->wv_aux2 == 7)  // 7-DOF arm over 30 | 31 waypoints, two-slack rows in three row slots (BASELINE config 1)
-        iter = wave_admm_burst<15, 7, 7>(w, P, Bt, b, L, sh, iter, tid);
+      if (((w.T | 1) - 1) / 2 == 15 && w.D == 7 && P->wv_aux2 == 3)  // 7-DOF arm over 30 | 31 waypoints, two-slack rows in two row slots (BASELINE config 1)
+        iter = wave_admm_burst<15, 7, 3>(w, P, Bt, b, L, sh, iter, tid);
       else
         iter = wave_burst_any_nl(P, Bt, b, lds_off, iter);
       WV_TICK(Bt, b, 2, tb);
@@ -1075,10 +1122,10 @@ __device__ __attribute__((noinline)) static void wave_admm_nl(const DevProblem* 
 
 // ---- K5 on one wave: Model::optimize() of problem b --------------------------------------------------------------------------------
 // The sequence of qp_solve_block (tmx_solve.h) - load, Ruiz, rho types, warm-start rule, factor, ADMM with the termination test every
-// check_termination iterations and adaptive rho, polish, store - without pair rows / bands / function costs; NT = 64.
+// check_termination iterations and adaptive rho, polish, store - without pair rows / bands / function costs; NT = 128.
 TMX_DEVFN void qp_solve_wave(const DevProblem* P, const DevBatch* Bt, int b, double* smem, int tid)
 {
-  constexpr int NT = 64;
+  constexpr int NT = TMX_WV_NT;
   const int D = P->D, T = P->T, NX = P->NX, R = P->R;
   const tmx_osqp_settings& st = P->osqp;
   QpWs w;
@@ -1270,12 +1317,17 @@ TMX_DEVFN void qp_solve_wave(const DevProblem* P, const DevBatch* Bt, int b, dou
       if (w.act[r])
         for (int k = 0; k < w.naux[r]; ++k)
           qmax = fmax(qmax, fabs(w.qa[w.aoff[r] + k]));
-    qmax = wave_allreduce<false>(qmax);
+    qmax = block_max1(qmax, w.red, tid, NT);
     TMX_SYNC();
     double csum = 0.0;
     for (int v = tid; v < NX; v += NT)
       csum += w.tp[v];
-    csum = wave_allreduce<true>(csum);
+    {
+      double cs[1] = { csum };
+      const bool issum[1] = { true };
+      block_reduce<1>(cs, issum, w.red, tid, NT);
+      csum = cs[0];
+    }
     double c_temp = csum / (double)n;
     c_temp = fmax(c_temp, limit_scaling(qmax));
     c_temp = limit_scaling(c_temp);
@@ -1317,7 +1369,7 @@ TMX_DEVFN void qp_solve_wave(const DevProblem* P, const DevBatch* Bt, int b, dou
   }
   TMX_SYNC();
   // (the burst takes rho itself for the slack bound rows; any other type would be a scaling outside [1e-4, 1e4])
-  const bool burst_ok = __builtin_amdgcn_ballot_w64(bad_aux != 0) == 0ULL;
+  const bool burst_ok = block_max1(bad_aux ? 1.0 : 0.0, w.red, tid, NT) == 0.0;
 
   // ---------------- warm start decision (createOrUpdateSolver, osqp_interface.cpp:283-370) -----------------
   const int* pd4 = Bt->prev_dims + 4 * b;
@@ -1687,7 +1739,7 @@ TMX_DEVFN void qp_solve_wave(const DevProblem* P, const DevBatch* Bt, int b, dou
 // One trust-region evaluation of problem b on one wave (sqp_step_block with the one-wave Model::optimize())
 TMX_DEVFN void sqp_step_wave(const DevProblem* P, const DevBatch* Bt, int b, double* smem, int tid)
 {
-  constexpr int NT = 64;
+  constexpr int NT = TMX_WV_NT;
   const int R = P->R, D = P->D, NX = P->NX;
   int* act = Bt->active + (size_t)b * R;
   double* coef = Bt->coef + (size_t)b * R * D;
