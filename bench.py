@@ -41,7 +41,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=0, help="seeds per GPU (default: the configuration's BASELINE batch per GPU)")
-    ap.add_argument("--depth", type=int, default=2, help="batches in flight (1 = strictly sequential steps, 2 = double-buffered contexts)")
+    ap.add_argument("--depth", type=int, default=None, help="batches in flight (1 = strictly sequential steps, 2 = double-buffered contexts); default 2, and 1 for the HBM-workspace configurations 2 / 3, whose launches are enqueued at once: with two in flight their HIP start event is recorded while the kernel still queues behind the other context, so the launch time would include queue wait and roofline.frac would not be a kernel figure")
     ap.add_argument("--config", type=int, default=1, choices=[1, 2, 3, 4], help="BASELINE.json configuration (default 1 = the metric's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -79,7 +79,7 @@ def main():
     # the persistent workgroups retire when nothing is left for them, and the next batch's kernel - enqueued on the other
     # context's stream - takes over their CUs.  Every step still is one complete optimize() of one batch; all of them start
     # and end inside the timed region.  --depth 1 runs them strictly one after the other.
-    depth = max(1, min(2, args.depth))
+    depth = max(1, min(2, args.depth if args.depth is not None else (1 if cid in (2, 3) else 2)))
     ctxs = []
     for _ in range(depth):
         c = runtime.Context(local_rank)
@@ -127,7 +127,7 @@ def main():
     t0 = time.perf_counter()
     tot_fe = tot_qp = tot_admm = 0
     conv = 0
-    last_r = None
+    last_r, last_best, last_k = None, None, None
     for k in range(args.warmup, min(nsteps, args.warmup + depth - 1)):
         issue(k)
     for k in range(args.warmup, nsteps):
@@ -142,7 +142,7 @@ def main():
                     time.sleep(0.0002)
             issue(k + depth - 1)
         r, best, c = finish(k)
-        last_r = r
+        last_r, last_best, last_k = r, best, k
         # trajopt_sqp counts QP solves only (SQPResults::overall_iteration): one trust-region evaluation each
         tot_fe += int(r["n_qp_solves"].sum()) if cid == 4 else int((r["n_func_evals"] - 1).sum())
         tot_qp += int(r["n_qp_solves"].sum())
@@ -217,7 +217,7 @@ def main():
             "kernel_time_share": {"admm_ms": stats["admm_ms"], "convexify_ms": stats["convexify_ms"],
                                   "evaluate_ms": stats["evaluate_ms"], "wall_ms": (t1 - t0) * 1e3},
         }
-        kernel_name = "k_sqp_fused_hbm" if ctx.workspace_in_hbm() else "k_sqp_pool"
+        kernel_name = "k_sqp_fused_hbm" if ctx.workspace_in_hbm() else ("k_sqp_wave" if (cid == 1 and os.environ.get("TMX_WAVE") == "1") else "k_sqp_pool")
         roofline["kernel"] = kernel_name
         if kernel_name == "k_sqp_fused_hbm":
             # QP workspace in HBM (configs 2 and 3): the rows and the block factor are streamed from the workgroup's HBM slice every
@@ -254,16 +254,15 @@ def main():
             except (OSError, ValueError, IndexError):
                 pass
             tried = []
-            # bounded: config 1 takes a few seconds per thread count; the long-horizon / pair-row configurations are timed on
-            # fewer thread counts and one problem per thread so that the whole leg stays within ~30 s
-            thread_counts = sorted({min(cores, 64), min(cores, 32), min(cores, 16), min(cores, 8)}, reverse=True) if cid == 1 else [min(cores, 32), min(cores, 16)]
-            for nthr in thread_counts:
-                # configs 2 / 3 / 4: at least 64 problems per thread count and at least 2 s of wall (a 0.1 s sample of 32 problems moved
-                # by 25 % between two runs): the sample is repeated until both hold, every repetition on fresh seeds of the workload
+            # Bounded (~15 - 25 s): a short probe picks the thread count, then THREE repetitions of >= 3.5 s each on fresh seeds of the
+            # workload at that count; `value` is their median, `min` / `max` their spread (VERDICT of round 5: a 1.5 s sample moved by
+            # 20 % between runs).  (Round-2 probe on the GPU box, tools/cpu_scaling.py: 16 threads 1.57 k, 64 threads 1.64 k, 256 threads
+            # 0.84 k SQP it/s: the box gives the container about 16 cores' worth of CPU time - a quota, reported below.)
+            def cpu_sample(nthr, min_s, lo0):
                 nsample = min(B, max(32, 2 * nthr)) if cid == 1 else min(B, max(64, 2 * nthr))
                 nit, nqp, nadmm, dt, done = 0.0, 0.0, 0.0, 0.0, 0
                 while True:
-                    lo = done % max(1, len(seeds_host) - nsample + 1)
+                    lo = (lo0 + done) % max(1, len(seeds_host) - nsample + 1)
                     xs = seeds_host[lo:lo + nsample]
                     tc0 = time.perf_counter()
                     o = pyorc.sqp2_batch(desc, xs, osqp=osqp_st, nthreads=nthr) if cid == 4 else pyorc.sqp_batch(desc, xs, nthreads=nthr)
@@ -272,16 +271,23 @@ def main():
                     nqp += float(o["n_qp_solves"].sum())
                     nadmm += float(o["admm_iters"]) if "admm_iters" in o else float("nan")
                     done += nsample
-                    if cid == 1 or dt >= 2.0 or dt > 20.0:
+                    if dt >= min_s or dt > 30.0:
                         break
-                tried.append((float(nit / dt), nthr, done, dt, nqp, nadmm))
-            best = max(tried, key=lambda t: t[0])
-            cpu = {"value": best[0], "unit": "SQP iters/s", "cores": best[1], "kind": "port",
-                   "sample": f"{best[2]} seeds of the same workload, one problem per OpenMP thread on {best[1]} of "
-                             f"{cores} hardware threads, {best[3]:.1f} s wall; restated reference CPU path (oracle/), "
-                             "not the upstream binary; tried " +
+                return (float(nit / dt), nthr, done, dt, nqp, nadmm)
+            thread_counts = sorted({min(cores, 64), min(cores, 32), min(cores, 16)}, reverse=True) if cid == 1 else [min(cores, 32), min(cores, 16)]
+            for nthr in thread_counts:
+                tried.append(cpu_sample(nthr, 0.8 if cid == 1 else 1.5, 0))
+            nbest = max(tried, key=lambda t: t[0])[1]
+            reps = [cpu_sample(nbest, 3.5, 64 * (i + 1)) for i in range(3)]
+            vals = sorted(t[0] for t in reps)
+            best = sorted(reps, key=lambda t: t[0])[1]   # the median repetition
+            cpu = {"value": vals[1], "unit": "SQP iters/s", "cores": best[1], "kind": "port",
+                   "min": vals[0], "max": vals[2], "repetitions": 3,
+                   "sample": f"3 x >= 3.5 s ({sum(t[2] for t in reps)} seeds of the same workload in all, {sum(t[3] for t in reps):.1f} s wall), one problem per "
+                             f"OpenMP thread on {best[1]} of {cores} hardware threads; median of the three, min / max beside it; restated reference "
+                             "CPU path (oracle/), not the upstream binary; thread-count probe: " +
                              ", ".join(f"{t[1]} thr -> {t[0]:.0f} it/s" for t in tried),
-                   "per_thread_value": best[0] / best[1], "host_threads": cores, "cgroup_cpu_quota_cores": quota,
+                   "per_thread_value": vals[1] / best[1], "host_threads": cores, "cgroup_cpu_quota_cores": quota,
                    "qp_solves_per_s": best[4] / best[3],
                    "admm_iters_per_s": (best[5] / best[3] if best[5] == best[5] else None)}
         # parity of THIS run's results (after the timed region; the oracle is the checker, never the thing measured): the first 64 problems
@@ -302,6 +308,22 @@ def main():
                       "same_n_qp_solves_frac": float((last_r["n_qp_solves"][:npar] == o["n_qp_solves"]).mean()),
                       "median_abs_dx": float(np.median(dxp)), "max_abs_dx": float(dxp.max()),
                       "what": "first %d problems of the last timed batch vs the oracle (oracle/, restated reference CPU path) on the same seeds" % npar}
+            # What the CONSUMER of a multi-seed run sees (VERDICT of round 5): tmx_argmin's winner of the last batch - index and cost -
+            # against the oracle.  The oracle cannot run all B seeds inside a bench (B x ~1.7 s of CPU): it runs the 32 seeds the device
+            # ranks best, and must (i) rank the same seed first among them, (ii) reproduce its cost; the full comparison (oracle on every
+            # seed of a 256-seed batch) is tests/test_gpu_parity.py::test_argmin_of_a_batch_matches_the_oracle.
+            if cid != 4 and last_best is not None and last_best[0] >= 0:
+                off = (rank * nsteps + last_k) * B
+                cost = np.where(last_r["status"] == conv_code, last_r["total_cost"], np.inf)
+                top = np.argsort(cost, kind="stable")[:32]
+                ot = pyorc.sqp_batch(desc, seeds_host[last_k * B + top], nthreads=min(os.cpu_count() or 1, 32))
+                ocost = np.where(ot["status"] == conv_code, ot["total_cost"], np.inf)
+                ow = int(top[int(np.argmin(ocost))])
+                parity["argmin"] = {"device_index": int(last_best[0] - off), "device_cost": float(last_best[1]),
+                                    "oracle_index_among_the_devices_best_32": ow, "oracle_cost": float(ocost.min()),
+                                    "same_winner": bool(ow == int(last_best[0] - off)),
+                                    "abs_cost_diff": float(abs(ocost.min() - last_best[1])),
+                                    "max_abs_cost_diff_over_the_32": float(np.abs(ocost - cost[top])[np.isfinite(ocost) & np.isfinite(cost[top])].max(initial=0.0))}
         line = {
             "metric": "SQP iters/s (+ QP solves/s), 7-DOF x 30-wp x 1024-batch glass_upright" if cid == 1 else
                       "SQP iters/s (+ QP solves/s), BASELINE config %d" % cid,

@@ -5,6 +5,7 @@ import os
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -102,14 +103,39 @@ def _one_case(n, seed, case, lib, *extra):
     return p.stdout
 
 
-def test_rho_drift_without_an_integer_difference_is_class_admm(hostemu_lib, orc):
+def test_dense_engine_refinement_keeps_the_oracles_history(hostemu_lib, orc):
     """Case 91/36 of `r4 lvs` (found by a device sweep of round 5, the same on the host build): seven identical QP records, then the
-    library solves an eighth QP.  The third QP's dual residual at its first rho check sits at the round-off floor of the linear solve
-    (QDLDL 2.9e-12, the dense engine's explicit inverse 1.9e-11), rho leaves at 6368 vs 2465 and ends at 0.0625 vs 0.0335 with every
-    integer of the record equal; three QPs later approx_merit_improve falls on either side of min_approx_improve.  The harness classes a run
-    that ends at another length AFTER such a drift as "admm" (DESIGN.md section 8, item 8); without drift it would stay "other" and fail."""
+    library solved an eighth QP.  The third QP's dual residual at its first rho check sits at the round-off floor of the linear solve
+    (QDLDL 2.9e-12, the dense engine's explicit inverse 1.9e-11), rho left at 6368 vs 2465 and ended at 0.0625 vs 0.0335 with every
+    integer of the record equal; three QPs later approx_merit_improve fell on either side of min_approx_improve.  Round 5 classed the run
+    ("admm after rho drift") and left the fix out of the product; round 6 landed it - one step of iterative refinement on the reduced
+    system (tmx_generic.h) - and the run now has the oracle's seven QPs: both seeds of the case in class identical."""
     out = _one_case(60, 91, 36, hostemu_lib, "r4", "lvs")
-    assert "1 identical integer history" in out and "1 at an ADMM-level integer after rho drift" in out and "0 other" in out
+    assert "2 identical integer history" in out and "0 other" in out and "0 failures" in out
+
+
+def test_a_systematic_warm_start_fault_blows_the_drift_budget(hostemu_lib, orc):
+    """The SQP-level leg of the harness can fail (VERDICT of round 5, item 2): with a fault seeded into the host build - the warm-start
+    starts of every run refused from its tenth Model::optimize() on (TMX_EMU_FAULT_WARM_QP=9, test scaffolding of tmx_solve.h) - every seed
+    parts from the oracle at a warm-start flag.  Rho has drifted by then on every seed (it always has: that is why the flag alone proves
+    nothing), so the seeds land in class "drift" - and eight of eight is far above the budget of one seed in 32."""
+    import parity_checks as pc
+    from trajopt_amd import configs, runtime
+    os.environ["TMX_EMU_FAULT_WARM_QP"] = "9"
+    try:
+        ctx = runtime.Context(0, hostemu_lib)
+        pci, s, g = pc.cfg(1)
+        x0 = configs.seeds_for(1, pci, s, g, 8)
+        desc = pc.make_ctx_inputs(ctx, pci, x0)
+        trace = []
+        classes, dx, _ = pc.sqp_history_classes(ctx, orc, desc, x0, trace=trace)
+        ctx.close()
+    finally:
+        del os.environ["TMX_EMU_FAULT_WARM_QP"]
+    hit = [t for t in trace if "warm start" in t["why"]]
+    print("seeded fault: classes", classes, "|dx|", np.round(dx, 7))
+    assert len(hit) >= 6, trace                                 # the fault shows as what it is on (nearly) every seed
+    assert classes.count("drift") + classes.count("other") > pc.drift_budget(len(classes))   # ... and the tier goes red on it
 
 
 def test_identical_history_is_judged_against_the_oracles_own_fma_spread(hostemu_lib, orc):

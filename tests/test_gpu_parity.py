@@ -112,15 +112,20 @@ def test_config1_history_classes_256_seeds(gpu, orc, orc_fma):
         if cnt[c]:
             assert dx[cl == c].max() <= pc.TOL_TRAJ, f"{c} history but |dx| = {dx[cl == c].max()}"
     out = set(np.nonzero(dx > pc.TOL_TRAJ)[0].tolist())
-    assert all(cl[b] in ("admm", "csc-noise") for b in out)
-    # the yardstick: the same seeds on two builds of the oracle itself
+    assert all(cl[b] in ("admm", "csc-noise", "drift") for b in out)
+    # the yardstick: the same seeds on two builds of the oracle itself - end points and class histogram
     a = orc.sqp_batch(desc, x0)
     f = orc_fma.sqp_batch(desc, x0)
     dself = np.abs(a["x"] - f["x"]).reshape(B, -1).max(axis=1)
     fragile = set(np.nonzero(dself > pc.TOL_TRAJ)[0].tolist())
+    own = pc.oracle_self_classes(orc, orc_fma, desc, x0)
     print(f"config 1 x {B}: within 1e-5 rad {(dx <= pc.TOL_TRAJ).sum()} / {B}; outside: device vs oracle {sorted(out)}, "
-          f"oracle vs oracle-with-FMA {sorted(fragile)}")
-    assert len(out) <= len(fragile) + max(2, B // 32), (sorted(out), sorted(fragile))
+          f"oracle vs oracle-with-FMA {sorted(fragile)}; classes of the oracle against its FMA build: {dict(Counter(own))}")
+    # round 6: runs that part at a structure / warm-start / run-length difference after their rho had drifted are a class of their own,
+    # bounded by what the oracle shows against itself (parity_checks.drift_budget); the 1e-5 bar as in rounds 3 - 4 (ADVICE, round 5)
+    assert cnt["drift"] <= pc.drift_budget(B, own), (cnt["drift"], Counter(own), [t for t in trace if t["cls"] == "drift"])
+    assert cnt["admm"] + cnt["drift"] <= Counter(own)["admm"] + Counter(own)["drift"] + max(2, B // 16), (dict(cnt), dict(Counter(own)))
+    assert len(out) <= max(len(fragile), B // 32), (sorted(out), sorted(fragile))
     assert (dx <= pc.TOL_TRAJ).sum() >= int(0.92 * B)          # rounds 3 - 4 on 64 seeds: 61 - 62 (95 - 97 %)
     assert cnt["identical"] + cnt["tie"] >= int(0.75 * B)      # rounds 3 - 4 on 64 seeds: 55 - 58
 
@@ -171,7 +176,8 @@ def _history_classes(gpu, orc, cid, B, sigma=None):
         if cnt[c]:
             assert dx[cl == c].max() <= pc.TOL_TRAJ, f"{c} history but |dx| = {dx[cl == c].max()}"
     out = set(np.nonzero(dx > pc.TOL_TRAJ)[0].tolist())
-    assert all(cl[b] in ("admm", "csc-noise") for b in out), (sorted(out), [cl[b] for b in sorted(out)])
+    assert all(cl[b] in ("admm", "csc-noise", "drift") for b in out), (sorted(out), [cl[b] for b in sorted(out)])
+    assert cnt["drift"] <= pc.drift_budget(B), dict(cnt)
     return cnt, dx
 
 
@@ -321,3 +327,26 @@ def test_two_batches_in_flight_give_the_sequential_results(orc):
     finally:
         for c in ctxs:
             c.close()
+
+
+def test_argmin_of_a_batch_matches_the_oracle(gpu, orc):
+    """What the consumer of a multi-seed run sees (VERDICT of round 5, item 2 (e)): 256 seeds of config 1 end to end, then tmx_argmin
+    - the converged seed of least total cost - against the arg-min of the oracle's runs on the same 256 seeds.  Individual seeds part
+    from the oracle at ADMM-level integers (history classes above); the winner and its cost must not: same seed, cost to 1e-6
+    relative - or, where two seeds tie within that, a cost that the oracle's winner reproduces to the same tolerance."""
+    pci, s, g = _cfg(1)
+    B = 256
+    x0 = configs.seeds_for(1, pci, s, g, B)
+    desc = pc.make_ctx_inputs(gpu, pci, x0)
+    gpu.run(0)
+    r = gpu.results()
+    bi, bc = gpu.argmin(0)
+    o = orc.sqp_batch(desc, x0)
+    ocost = np.where(o["status"] == abi.OPT_CONVERGED, o["total_cost"], np.inf)
+    ow = int(np.argmin(ocost))
+    print(f"argmin over {B} seeds: device seed {bi} cost {bc!r}; oracle seed {ow} cost {ocost[ow]!r}; device cost of the oracle's winner "
+          f"{r['total_cost'][ow]!r}, status {r['status'][ow]}")
+    assert bi >= 0
+    tol = 1e-6 * max(1.0, abs(ocost[ow]))
+    assert abs(bc - ocost[ow]) <= tol, (bi, bc, ow, ocost[ow])
+    assert bi == ow or abs(ocost[bi] - ocost[ow]) <= tol, (bi, ow, ocost[bi], ocost[ow])

@@ -375,6 +375,7 @@ def _difference_rows_at_baseline_size(lib_path, orc, B):
     print(f"config 1 + acc limits + jerk hinge x {B}: {dict(cnt)}, worst |dx| of the identical / tie histories "
           f"{max([dx[i] for i in range(B) if classes[i] in ('identical', 'tie')], default=0.0):.2e}")
     assert cnt["other"] == 0, [t for t in trace if t["cls"] == "other"]
+    assert cnt["drift"] <= pc.drift_budget(B), [t for t in trace if t["cls"] == "drift"]
     for c in ("identical", "tie"):
         if cnt[c]:
             assert dx[cl == c].max() <= 1e-5, f"{c} history but |dx| = {dx[cl == c].max()}"

@@ -137,6 +137,7 @@ def _history_check(ctx, orc, orc_fma, cid, B):
     good = sum(c in ("identical", "tie") for c in classes)
     print(f"config {cid}: classes {classes}, |dx| {np.round(dx, 7)}, oracle vs FMA oracle same on {same_builds}/{B}")
     assert "other" not in classes and "csc-noise" not in classes
+    assert classes.count("drift") <= pc.drift_budget(B, pc.oracle_self_classes(orc, orc_fma, desc, x0)), classes
     assert good >= max(1, same_builds - 1)
     return classes
 
@@ -251,7 +252,8 @@ def _check_time_problem_with_function_terms(ctx, orc, B):
     # these runs are ~100 QPs long with up to 15 rho updates per solve (bilinear rows, no TotalTime term to anchor the time column):
     # the histories agree for the first tens of QPs and part at an ADMM-level integer (host build: QP 20 of 95 / 108 on both seeds).
     # Required: nothing structural ever differs, and every run follows the oracle QP by QP through its first eight solves.
-    assert all(c in ("identical", "tie", "admm") for c in classes), classes
+    assert all(c in ("identical", "tie", "admm", "drift") for c in classes), classes
+    assert classes.count("drift") <= pc.drift_budget(B), classes
     assert all(q >= 8 for q in parted.values()), parted
 
 

@@ -27,7 +27,7 @@ o = orc.sqp_batch(desc, x0)
 same = (r["status"] == o["status"]) & (r["n_qp_solves"] == o["n_qp_solves"])
 print(f"B={B}: classes {dict(Counter(classes))}; same status+QP count {same.sum()}/{B}; same status {(r['status'] == o['status']).sum()}/{B}; "
       f"|dx|<=1e-5: {(dx <= 1e-5).sum()}/{B}; |dx|<=1e-8: {(dx <= 1e-8).sum()}/{B}; median {np.median(dx):.2e} max {dx.max():.2e}")
-for c in ("identical", "tie", "admm", "csc-noise", "other"):
+for c in ("identical", "tie", "admm", "csc-noise", "drift", "other"):
     m = np.array([k == c for k in classes])
     if m.any():
         print(f"  {c}: {m.sum()} seeds, max |dx| {dx[m].max():.2e}")

@@ -271,8 +271,9 @@ def main():
     gpu_lib = lib[4:] if lib.startswith("gpu:") else None
     if (new or kin or r4) and not on_gpu:
         os.environ.setdefault("TMX_DENSE_QP_MAX_N", "2000")   # the host build has the time; on the GPU the library's limit stays
-    fails, soft, refused, fragile = 0, 0, 0, 0
-    counts = {"identical": 0, "tie": 0, "admm": 0, "csc-noise": 0, "other": 0}
+    fails, soft, refused = 0, 0, 0
+    counts = {"identical": 0, "tie": 0, "admm": 0, "csc-noise": 0, "drift": 0, "other": 0}
+    n_seeds = 0
     worst = {k: 0.0 for k in counts}
     redraw = {}   # case -> attempt: a case the library refuses (dense-engine size limit) is drawn again, so n cases test n problems
     k = -1
@@ -300,6 +301,7 @@ def main():
             # whole SQP, QP by QP (pc.sqp_history_classes): identical integer history -> |dx| <= 1e-5 is REQUIRED; a run that
             # parts at a degenerate polish tie is counted; anything else is a failure
             classes, dx, r = pc.sqp_history_classes(ctx, orc, desc, x0)
+            n_seeds += len(classes)
             for b, c in enumerate(classes):
                 counts[c] += 1
                 if c == "identical" and dx[b] > pc.TOL_TRAJ:
@@ -314,15 +316,13 @@ def main():
                         raise AssertionError(f"full SQP: identical QP history but |dx| = {dx[b]} (the oracle against its FMA build: {dself})")
                     print(f"  note (identical history, |dx| = {dx[b]:.2e} above 1e-5 but within {YARD:g} x the oracle's own FMA spread {dself:.2e}):", tag)
                 if c == "other":
-                    # the yardstick before the verdict: a seed on which the oracle parts from ITS OWN FMA build (another number of QP solves,
-                    # another status, or more than 1e-5 rad apart) separates any two correct builds - counted and printed, not failed
-                    oa, of = orc.sqp_batch(desc, x0[b:b + 1]), orc.variant("fma").sqp_batch(desc, x0[b:b + 1])
-                    dself = float(np.abs(oa["x"] - of["x"])[..., :pci.robot.n_dof].max())
-                    if oa["n_qp_solves"][0] == of["n_qp_solves"][0] and oa["status"][0] == of["status"][0] and dself <= pc.TOL_TRAJ:
-                        raise AssertionError(f"full SQP: seed {b} parts from the oracle at a non-degenerate comparison")
-                    fragile += 1
-                    print(f"  note (seed {b} parts from the oracle at a non-degenerate comparison - the oracle parts from its own FMA build there too: "
-                          f"QP solves {oa['n_qp_solves'][0]} vs {of['n_qp_solves'][0]}, |dx| {dself:.1e}):", tag)
+                    # (round 6: no yardstick escape here any more - a structural / warm-start / run-length difference WITHOUT rho drift, or
+                    #  a non-degenerate active-set difference at equal rho, is a failure: fixed in the product, or red)
+                    raise AssertionError(f"full SQP: seed {b} parts from the oracle at a non-degenerate comparison")
+                if c == "drift":
+                    # structure / warm-start / run-length difference after the two runs' rho had parted: counted against the sweep's budget
+                    # (parity_checks.drift_budget: one seed in 32, at least one) - checked when the sweep ends
+                    print(f"  note (seed {b}: class drift, |dx| = {dx[b]:.2e}):", tag)
                 worst[c] = max(worst[c], dx[b])
                 if r["status"][b] == abi.OPT_CONVERGED:
                     cv, vv = ctx.evaluate()
@@ -345,10 +345,14 @@ def main():
             ctx.close()
     if refused:
         print(f"{refused} draws refused (dense-engine size limit) and drawn again")
-    print(f"{n} cases, {fails} failures, {soft} first QPs with differing history; SQP runs: {counts['identical']} identical integer history "
+    print(f"{n} cases, {fails} failures, {soft} first QPs with differing history; SQP runs ({n_seeds} seeds): {counts['identical']} identical integer history "
           f"(max |dx| {worst['identical']:.1e}), {counts['tie']} parted at a degenerate polish tie (max |dx| {worst['tie']:.1e}), "
-          f"{counts['admm']} at an ADMM-level integer after rho drift (max |dx| {worst['admm']:.1e}), {counts['csc-noise']} at a round-off entry of A "
-          f"(max |dx| {worst['csc-noise']:.1e}), {counts['other']} other" + (f" ({fragile} of them on seeds where the oracle parts from its own FMA build)" if fragile else ""))
+          f"{counts['admm']} at an ADMM-level integer (max |dx| {worst['admm']:.1e}), {counts['csc-noise']} at a round-off entry of A "
+          f"(max |dx| {worst['csc-noise']:.1e}), {counts['drift']} at a structure / warm-start / run-length difference after rho drift "
+          f"(max |dx| {worst['drift']:.1e}; budget {pc.drift_budget(n_seeds)}), {counts['other']} other")
+    if counts["drift"] > pc.drift_budget(n_seeds):
+        fails += 1
+        print(f"FAIL class histogram: {counts['drift']} seeds of {n_seeds} in class drift, budget {pc.drift_budget(n_seeds)}")
     sys.exit(1 if fails else 0)
 
 

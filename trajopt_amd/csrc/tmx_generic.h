@@ -479,6 +479,27 @@ TMX_DEVFN void qp_generic_block(const GenQp& g, const GenData& d, const tmx_osqp
     TMX_SYNC();
     gen_matvec(Ad, m, n, xt, zt, tid, NT);
     TMX_SYNC();
+    // One step of iterative refinement on the reduced system (round 6; OSQP refines its quasi-definite solves as well, SURVEY.md
+    // Appendix B).  The explicit inverse Ki leaves a residual floor ~7 x QDLDL's; where a warm-started QP's dual residual sits at that
+    // floor at its first rho check, rho sqrt(prim / dual) comes out 2.6 x the reference's and the run parts three QPs later (fuzz
+    // case 91/36 of `r4 lvs`, round 5: the library solved an eighth QP; with this step the history is the oracle's - DESIGN.md section 3).
+    //   r = rhs - (P xt + sigma xt + A' (rho . A xt)),   xt += Ki r,   then zt = A xt
+    for (int i = tid; i < m; i += NT)
+      tm[i] = rho[i] * zt[i];
+    TMX_SYNC();
+    gen_matTvec(Ad, m, n, tm, Aty, tid, NT);
+    gen_matvec(Pd, n, n, xt, Px, tid, NT);
+    TMX_SYNC();
+    for (int j = tid; j < n; j += NT)
+      Px[j] = tn[j] - ((Px[j] + st.sigma * xt[j]) + Aty[j]);
+    TMX_SYNC();
+    gen_matvec(Ki, n, n, Px, Aty, tid, NT);
+    TMX_SYNC();
+    for (int j = tid; j < n; j += NT)
+      xt[j] += Aty[j];
+    TMX_SYNC();
+    gen_matvec(Ad, m, n, xt, zt, tid, NT);
+    TMX_SYNC();
     for (int j = tid; j < n; j += NT)
     {
       x[j] = st.alpha * xt[j] + (1.0 - st.alpha) * xprev[j];

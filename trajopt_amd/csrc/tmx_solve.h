@@ -1805,6 +1805,12 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
   const bool P_eq = warm && pd4[0] == dims[0] && pd4[2] == dims[2] && pws[0] == hs[2];
   const bool A_eq = P_eq && pd4[0] == dims[0] && pd4[1] == dims[1] && pd4[3] == dims[3] && pws[1] == hs[3];
   warm = TMX_UNI_B(warm && P_eq && A_eq);
+#if defined(TMX_HOST_EMU) && !defined(TMX_EMU_SIMT)
+  // TEST SCAFFOLDING (host build only): a seeded fault for the parity harness - the warm starts of every run refused from its n-th Model::optimize() on (tests/test_fuzz_parity.py::test_a_systematic_warm_start_fault_blows_the_drift_budget)
+  if (const char* fq = std::getenv("TMX_EMU_FAULT_WARM_QP"))
+    if (Bt->rec_count[b] >= std::atoi(fq) && warm)
+      warm = false;  // (from the n-th solve on, a warm start the reference would take is refused: cold start, the record says so)
+#endif
   if (P->flavor == 1)
   {
     // OSQPEigenSolver protocol (osqp_eigen_solver.cpp:96-109, :277-326; trust_region_sqp_solver.cpp:214-244): with warm
