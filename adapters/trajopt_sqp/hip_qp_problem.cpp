@@ -194,7 +194,47 @@ void HipQPProblem::lowerSet(const trajopt_ifopt::ConstraintSet& set, bool is_cos
     t.first_step = t.last_step = static_cast<int32_t>(step);
     for (int i = 0; i < 6; ++i)
       t.coeffs[i] = c(i);
+    // getTargetPose() is the target frame OFFSET only (cartesian_position_constraint.cpp:391), the world target is
+    // transforms[target_frame] * offset (:267), and the error is taken target -> source for Type::kSourceActive only (:177; the other
+    // way round for kTargetActive, :144).  Neither the frame nor the type is exposed, so both are VERIFIED through the values: what the
+    // set reports at the current variables must be calcTransformError(target, FK of the described tool) - translation of
+    // target^-1 * tool, then the rotation vector of its rotation part - with the offset taken as the world target.  A static target
+    // frame with a non-identity transform, a kTargetActive or a kBothActive set all fail here instead of being lowered wrongly.
     const Eigen::Isometry3d target = cp->getTargetPose();
+    {
+      // pose_err = target^-1 * tool in plain arithmetic: R = Rt' Rs, p = Rt' (ps - pt)
+      double Rm[9], expected[6];
+      for (int r = 0; r < 3; ++r)
+      {
+        for (int q = 0; q < 3; ++q)
+        {
+          double v = 0.0;
+          for (int k = 0; k < 3; ++k)
+            v += target(k, r) * T.a[4 * k + q];
+          Rm[3 * r + q] = v;
+        }
+        double v = 0.0;
+        for (int k = 0; k < 3; ++k)
+          v += target(k, r) * (T.a[4 * k + 3] - target(k, 3));
+        expected[r] = v;
+      }
+      // rotation vector: angle = atan2(|v|, trace - 1) with v = (R32 - R23, R13 - R31, R21 - R12) = 2 sin(angle) axis
+      const double vx = Rm[7] - Rm[5], vy = Rm[2] - Rm[6], vz = Rm[3] - Rm[1];
+      const double vn = std::sqrt(vx * vx + vy * vy + vz * vz);
+      const double angle = std::atan2(vn, Rm[0] + Rm[4] + Rm[8] - 1.0);
+      const double scale = vn > 1e-12 ? angle / vn : 0.5;
+      expected[3] = scale * vx;
+      expected[4] = scale * vy;
+      expected[5] = scale * vz;
+      const Eigen::VectorXd reported = set.getValues();
+      bool same = reported.size() == 6;
+      // (at a half turn v vanishes and the axis is not read off it: the translation part alone decides there)
+      for (int i = 0; same && i < (angle > 3.1415 ? 3 : 6); ++i)
+        same = std::fabs(reported(i) - expected[i]) <= 1e-6;
+      if (!same)
+        throw std::runtime_error(who + "the values of the CartPosConstraint are not calcTransformError(getTargetPose(), tool frame): "
+                                       "its target frame is not the root frame of the described chain, or the set is not Type::kSourceActive");
+    }
     for (int r = 0; r < 3; ++r)
       for (int q = 0; q < 4; ++q)
         t.target_pose[4 * r + q] = target(r, q);

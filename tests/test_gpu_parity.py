@@ -350,3 +350,32 @@ def test_argmin_of_a_batch_matches_the_oracle(gpu, orc):
     tol = 1e-6 * max(1.0, abs(ocost[ow]))
     assert abs(bc - ocost[ow]) <= tol, (bi, bc, ow, ocost[ow])
     assert bi == ow or abs(ocost[bi] - ocost[ow]) <= tol, (bi, ow, ocost[bi], ocost[ow])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cid", [0, 1])
+def test_mfma_block_assembly_against_the_scalar_loop(gpu, cid):
+    """the D x D diagonal blocks of the reduced KKT matrix come from v_mfma_f64_16x16x4_f64 (tmx_qp.h kkt_factor: A' diag(fac) A, four
+    rows per instruction, rows in list order); DevProblem::dbg_flags bit 0 switches the SAME library to the scalar list-order loop.
+    The first Model::optimize() of 16 seeds both ways: every integer of the record the same (status, iterations, rho updates, polish
+    status, active-set hash) and the solutions equal to round-off of one ADMM run (the two sums associate differently, so not bit for bit)."""
+    import ctypes as C
+    fn = gpu.lib.tmx_debug_set_flags
+    fn.argtypes, fn.restype = [C.c_void_p, C.c_int], C.c_int
+    pci, s, g = pc.cfg(cid)
+    x0 = configs.seeds_for(cid, pci, s, g, 16)
+    pc.make_ctx_inputs(gpu, pci, x0)
+    out = []
+    for flags in (0, 1):
+        assert fn(gpu.h, flags) == 0
+        gpu.set_x0(x0)
+        gpu.convexify()
+        xq, cvx, rec = gpu.qp_solve()
+        out.append((xq.copy(), [(r.osqp_status, r.osqp_iter, r.rho_updates, r.polish_status, r.hash_active) for r in rec]))
+    assert fn(gpu.h, 0) == 0
+    same = sum(a == b for a, b in zip(out[0][1], out[1][1]))
+    dx = np.abs(out[0][0] - out[1][0]).max(axis=1)
+    print("cfg %d: MFMA vs scalar block assembly: %d / 16 identical integer records, max |dx| %.3e" % (cid, same, dx.max()))
+    assert same == 16
+    assert dx.max() <= 1e-9
+

@@ -394,8 +394,10 @@ def test_difference_rows_at_baseline_size_on_device(orc):
     # integer histories: hinge costs with tolerance bands make rank-deficient polish active sets, and the reference's own outcome
     # there is decided by round-off.
     # (round 5: 8 seeds instead of 16 - the test was a quarter of the GPU tier's wall time; the bar scales with the statistic above)
-    cnt, dx = _difference_rows_at_baseline_size(None, orc, 8)
-    assert cnt["identical"] + cnt["tie"] >= 2
+    # (round 6: the proportional bar of round 4 again - at least 5 of 16 seeds, rounded up)
+    B = 8
+    cnt, dx = _difference_rows_at_baseline_size(None, orc, B)
+    assert cnt["identical"] + cnt["tie"] >= (5 * B + 15) // 16
 
 
 def test_difference_rows_next_to_general_pair_rows_keep_the_dense_engine(hostemu_lib):

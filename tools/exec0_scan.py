@@ -10,20 +10,47 @@ once EXEC is restored (round 5: the zero voffset of a global_load in k_sqp_pool,
 
   python tools/exec0_scan.py lib.so|code_object.co [more ...]     exit code 1 if any site is found
 """
-import os, re, subprocess, sys, tempfile
-
-LLVM = "/opt/rocm/lib/llvm/bin"
+import os, re, shutil, subprocess, sys, tempfile
 
 
-def code_object(path):
+def llvm_bin():
+    """the LLVM tools of the ROCm toolchain that built the library: $TMX_LLVM_BIN, else beside $HIPCC / $ROCM_PATH, else /opt/rocm"""
+    cands = []
+    if os.environ.get("TMX_LLVM_BIN"):
+        cands.append(os.environ["TMX_LLVM_BIN"])
+    hipcc = os.environ.get("HIPCC") or shutil.which("hipcc")
+    if hipcc:
+        cands.append(os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(hipcc))), "lib", "llvm", "bin"))
+    if os.environ.get("ROCM_PATH"):
+        cands.append(os.path.join(os.environ["ROCM_PATH"], "lib", "llvm", "bin"))
+    cands.append("/opt/rocm/lib/llvm/bin")
+    for c in cands:
+        if os.path.exists(os.path.join(c, "llvm-objdump")):
+            return c
+    raise SystemExit("exec0_scan: no llvm-objdump found (set TMX_LLVM_BIN)")
+
+
+LLVM = llvm_bin()
+MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
+
+
+def code_objects(path, tmp):
+    """every gfx950 code object of the library: one offload bundle per translation unit in .hip_fatbin"""
     if path.endswith(".co") or path.endswith(".s"):
-        return path
-    tmp = tempfile.mkdtemp()
-    fat, co = os.path.join(tmp, "fat.bin"), os.path.join(tmp, "dev.co")
+        return [path]
+    fat = os.path.join(tmp, "fat.bin")
     subprocess.check_call([f"{LLVM}/llvm-objcopy", "--dump-section", ".hip_fatbin=" + fat, path, os.path.join(tmp, "discard.so")])
-    subprocess.check_call([f"{LLVM}/clang-offload-bundler", "--unbundle", "--type=o", "--input=" + fat,
-                           "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co], stderr=subprocess.DEVNULL)
-    return co
+    blob = open(fat, "rb").read()
+    starts = [m.start() for m in re.finditer(re.escape(MAGIC), blob)]
+    out = []
+    for k, a in enumerate(starts):
+        b = starts[k + 1] if k + 1 < len(starts) else len(blob)
+        part, co = os.path.join(tmp, f"bundle{k}.bin"), os.path.join(tmp, f"dev{k}.co")
+        open(part, "wb").write(blob[a:b])
+        subprocess.check_call([f"{LLVM}/clang-offload-bundler", "--unbundle", "--type=o", "--input=" + part,
+                               "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co], stderr=subprocess.DEVNULL)
+        out.append(co)
+    return out
 
 
 def disasm(path):
@@ -33,12 +60,23 @@ def disasm(path):
 
 
 INS = re.compile(r"^\s+(\S+)\s*(.*?)\s*//\s*([0-9A-Fa-f]+):")
-TGT = re.compile(r"<([^>+]+)\+0x([0-9a-f]+)>\s*$")
+TGT = re.compile(r"<([^>+]+)(?:\+0x([0-9a-f]+))?>\s*$")
 FUNC = re.compile(r"^([0-9a-f]+) <(.*)>:")
 
 
 def scan(path):
-    lines = disasm(code_object(path))
+    """every code object of the library on its own (the objects of two translation units overlap in their addresses); returns the
+    sites and the names of the functions looked at"""
+    sites, names = [], []
+    with tempfile.TemporaryDirectory() as tmp:
+        for co in code_objects(path, tmp):
+            s, n = scan_lines(disasm(co))
+            sites += s
+            names += n
+    return sites, names
+
+
+def scan_lines(lines):
     funcs, cur = [], None
     for ln in lines:
         m = FUNC.match(ln)
@@ -58,7 +96,7 @@ def scan(path):
             if op.startswith("s_cbranch") or op == "s_branch":
                 m = TGT.search(ln)
                 if m:
-                    preds.setdefault(f["base"] + int(m.group(2), 16), []).append(op)
+                    preds.setdefault(f["base"] + int(m.group(2) or "0", 16), []).append(op)
         for t, ops in preds.items():
             if t not in index or any(o != "s_cbranch_execz" for o in ops):
                 continue
@@ -83,13 +121,22 @@ def scan(path):
                 if re.match(r"(v_|ds_|global_|flat_|scratch_|buffer_)", op) and not op.startswith(("v_readlane", "v_readfirstlane", "v_writelane")):
                     sites.append((f["name"], a - f["base"], op + " " + args))
                 j += 1
-    return sites
+    return sites, [f["name"] for f in funcs]
 
 
 def main():
     bad = 0
     for p in sys.argv[1:]:
-        s = scan(p)
+        s, names = scan(p)
+        kernels = set()
+        for n in names:
+            m = re.match(r"_Z(\d+)(k_\w+)", n)  # Itanium: _Z <length> <name> <parameter types>
+            if m:
+                kernels.add(m.group(2)[:int(m.group(1))])
+            elif n.startswith("k_"):
+                kernels.add(n)
+        kernels = sorted(kernels)
+        print(f"{p}: {len(names)} function(s) scanned, kernels: " + " ".join(kernels))
         print(f"{p}: {len(s)} vector instruction(s) that can only run with EXEC = 0")
         for name, off, txt in s:
             print(f"   {name[:60]}+0x{off:x}: {txt}")

@@ -1,9 +1,9 @@
 #!/bin/bash
-# end-of-round evidence of round 5 (gpurun -- bash tools/final_round_r05.sh r05z):
+# end-of-round evidence of round 6 (gpurun -- bash tools/final_round_r06.sh r06z):
 #   code-object id, the whole GPU tier, smoke; counters of configuration 1 FIRST (so that the bench line's traffic_source is this round's
 #   collection), the driver's bench command, the kernel trace at the driver's command; then per configuration 2 / 3 / 4: counters, then the
 #   bench line at --steps 10
-TAG=${1:-r05z}
+TAG=${1:-r06z}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
@@ -13,7 +13,7 @@ if [ -z "$SKIP_TIER" ]; then
 timeout 2400 python -m pytest tests -m gpu -q -rf -rP --durations=12 > $OUT/pytest_gpu.txt 2>&1; echo "pytest rc $?"
 grep -E "passed|failed" $OUT/pytest_gpu.txt | tail -2
 fi
-if [ -z "$SKIP_SWEEPS" ]; then
+if [ -n "$RUN_SWEEPS" ]; then
 # the device sweeps VERDICT (round 4) asked for, on this code object: 0 failures and no fault wanted
 timeout 1500 python tests/tools/fuzz_parity.py 60 79 gpu r4 lvs > $OUT/fuzz_device_r4_lvs_60_79.log 2>&1; echo "60 79 r4 lvs rc $?"; tail -n 1 $OUT/fuzz_device_r4_lvs_60_79.log | cut -c1-300
 timeout 1200 python tests/tools/fuzz_parity.py 40 83 gpu r4 lvs links > $OUT/fuzz_device_r4_lvs_links_40_83.log 2>&1; echo "40 83 r4 lvs links rc $?"; tail -n 1 $OUT/fuzz_device_r4_lvs_links_40_83.log | cut -c1-300
@@ -24,7 +24,7 @@ python tools/kernel_meta.py trajopt_amd/_build/libtrajopt_mi355x.so k_ > $OUT/ke
 # counters of configuration 1 (PMC passes only), then the summary becomes this round's traffic file
 SKIP_KT=1 bash tools/profile_round.sh $TAG > $OUT/profile_pmc.log 2>&1
 cd $R
-[ -f $OUT/pmc_traffic.json ] && cp $OUT/pmc_traffic.json profiles/r05_pmc_traffic.json
+[ -f $OUT/pmc_traffic.json ] && cp $OUT/pmc_traffic.json profiles/r06_pmc_traffic.json
 timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_n1_steps20.log 2> $OUT/bench_n1_steps20.err
 grep "^{" $OUT/bench_n1_steps20.log | cut -c1-300
 # kernel trace + stats at the driver's command (summary is rewritten with both parts)
@@ -55,7 +55,7 @@ PY
 for c in ${CFGS:-2 3 4}; do
   bash tools/profile_cfg.sh $TAG $c > $OUT/profile_cfg$c.log 2>&1
   cd $R
-  [ -f $OUT/pmc_traffic_cfg$c.json ] && cp $OUT/pmc_traffic_cfg$c.json profiles/r05_pmc_traffic_cfg$c.json
+  [ -f $OUT/pmc_traffic_cfg$c.json ] && cp $OUT/pmc_traffic_cfg$c.json profiles/r06_pmc_traffic_cfg$c.json
   timeout 900 python bench.py --config $c --steps 10 --warmup 2 > $OUT/bench_cfg$c.json 2> $OUT/bench_cfg$c.err
   grep "^{" $OUT/bench_cfg$c.json | cut -c1-260
 done

@@ -1,5 +1,5 @@
 #!/bin/bash
-# end-of-round evidence of round 3: gpurun -- bash tools/final_round_r03.sh r03f
+# end-of-round evidence of round 3: gpurun -- bash tools/history/final_round_r03.sh r03f
 TAG=${1:-r03f}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/$TAG

@@ -1,5 +1,5 @@
 #!/bin/bash
-# end-of-round evidence on the last commit of round 3: gpurun -- bash tools/final_round_r03b.sh r03x
+# end-of-round evidence on the last commit of round 3: gpurun -- bash tools/history/final_round_r03b.sh r03x
 TAG=${1:-r03x}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/$TAG

@@ -1,5 +1,5 @@
 #!/bin/bash
-# end-of-round evidence of round 4 (gpurun -- bash tools/final_round_r04.sh r04x [quick]):
+# end-of-round evidence of round 4 (gpurun -- bash tools/history/final_round_r04.sh r04x [quick]):
 #   GPU tier, smoke, the driver's bench command, rocprofv3 kernel trace + ALL counter groups of configuration 1 (tools/profile_round.sh),
 #   bench lines + traffic counters of configurations 2 / 3 / 4 (tools/profile_cfg.sh), phase tables on a -DTMX_PROFILE build.
 TAG=${1:-r04x}

@@ -1,5 +1,5 @@
 #!/bin/bash
-# refresh of the configuration 2 / 3 / 4 evidence after the last generic-path commits (tools/final_round_r03.sh layout)
+# refresh of the configuration 2 / 3 / 4 evidence after the last generic-path commits (tools/history/final_round_r03.sh layout)
 TAG=r03h
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/$TAG

@@ -3,6 +3,7 @@
 // the batched SQP (convexify -> QP solve -> exact re-evaluation -> decisions) as a short chain of kernel launches per
 // trust-region evaluation on one HIP stream; the host only reads back one "problems still running" counter.
 #include <algorithm>
+#include <cstddef>
 #include <limits>
 #include <string>
 #include <vector>
@@ -75,7 +76,7 @@ struct tmx_ctx
   // owner (global index - the owner's global_offset; valid on the owner only), the rank count it was reduced over
   int best_owner{ -1 }, best_nranks{ 1 };
   long long best_local{ -1 }, best_global{ -1 };
-  double* d_best{ nullptr };   // T * D doubles: the broadcast buffer of tmx_best_trajectory
+  double* d_best{ nullptr };   // T * D + 1 doubles: the broadcast buffer of tmx_best_trajectory (trajectory, status word)
   size_t best_cap{ 0 };
   int max_rec{ 128 };
 };
@@ -1622,6 +1623,7 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
   if (dyn_p && !qp_dense)
     P.coef_far |= 4;  // dynamic objective blocks behind the far region of the per-problem scratch (qp_dynp_offset)
   // a wave pair per problem (tmx_wave.h): block-tridiagonal QPs with diagonal couplings whose row-slot template fits the lane plan
+  P.dbg_flags = 0;
   P.wave_ok = 0;
   P.wv_gmax = 2;
   P.wv_aux2 = 0;
@@ -2931,15 +2933,17 @@ tmx_status tmx_best_trajectory(tmx_ctx* ctx, double* x_out, int32_t* owner_rank)
   }
   HIPCHK(hipSetDevice(ctx->device));
   const size_t NX = (size_t)ctx->hp.NX;
-  if (ctx->best_cap < NX)
+  if (ctx->best_cap < NX + 1)
   {
     if (ctx->d_best)
       (void)hipFree(ctx->d_best);
     ctx->d_best = nullptr;
+    ctx->best_cap = 0;
     void* p = nullptr;
-    HIPCHK(hipMalloc(&p, sizeof(double) * NX));
+    HIPCHK(hipMalloc(&p, sizeof(double) * (NX + 1)));
+    HIPCHK(hipMemset(p, 0xFF, sizeof(double) * (NX + 1)));  // (a status word that was never written reads as not-valid)
     ctx->d_best = static_cast<double*>(p);
-    ctx->best_cap = NX;
+    ctx->best_cap = NX + 1;
   }
   int my_rank = 0;
 #ifndef TMX_HOST_EMU
@@ -2947,33 +2951,42 @@ tmx_status tmx_best_trajectory(tmx_ctx* ctx, double* x_out, int32_t* owner_rank)
   if (comm && ncclCommUserRank(comm, &my_rank) != ncclSuccess)
     return TMX_ERR_NCCL;
 #endif
-  // The call is COLLECTIVE: every rank enters the broadcast whatever it finds locally - an owner whose winning index is not in its
-  // shard (global_offset of tmx_argmin inconsistent across ranks) sends a NaN trajectory instead of returning early and leaving the
-  // other ranks blocked in ncclBroadcast; every rank then reports TMX_ERR_STATE.
-  bool owner_bad = false;
+  // The call is COLLECTIVE: every rank enters the broadcast whatever it finds locally.  The message is the trajectory plus ONE status
+  // word behind it (0 = valid, 1 = the owner's winning index is not in its shard: global_offset of tmx_argmin inconsistent across
+  // ranks) - an owner that cannot send the trajectory still takes part, so no rank is left blocked in ncclBroadcast, and every rank
+  // reads the same verdict from the word, not from the payload.
+  // (a device error on the owner before the broadcast is kept in owner_err and returned AFTER the collective, for the same reason)
+  hipError_t owner_err = hipSuccess;
   if (my_rank == ctx->best_owner)
   {
-    owner_bad = ctx->best_local < 0 || ctx->best_local >= (long long)ctx->hb.B;
-    if (owner_bad)
-    {
-      std::vector<double> nanv(NX, std::nan(""));
-      HIPCHK(hipMemcpyAsync(ctx->d_best, nanv.data(), sizeof(double) * NX, hipMemcpyHostToDevice, ctx->stream));
-      HIPCHK(hipStreamSynchronize(ctx->stream));  // (the staging vector dies with this scope)
-    }
-    else
-      HIPCHK(hipMemcpyAsync(ctx->d_best, ctx->hb.x + (size_t)ctx->best_local * NX, sizeof(double) * NX, hipMemcpyDeviceToDevice, ctx->stream));
+    const bool owner_bad = ctx->best_local < 0 || ctx->best_local >= (long long)ctx->hb.B;
+    const double word = owner_bad ? 1.0 : 0.0;
+    owner_err = owner_bad ? hipMemsetAsync(ctx->d_best, 0, sizeof(double) * NX, ctx->stream) :
+                            hipMemcpyAsync(ctx->d_best, ctx->hb.x + (size_t)ctx->best_local * NX, sizeof(double) * NX, hipMemcpyDeviceToDevice, ctx->stream);
+    if (owner_err == hipSuccess)
+      owner_err = hipMemcpyAsync(ctx->d_best + NX, &word, sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+    const hipError_t se = hipStreamSynchronize(ctx->stream);  // (the staging word dies with this scope)
+    if (owner_err == hipSuccess)
+      owner_err = se;
   }
 #ifndef TMX_HOST_EMU
   if (comm && ctx->best_nranks > 1 &&
-      ncclBroadcast(ctx->d_best, ctx->d_best, NX, ncclDouble, ctx->best_owner, comm, ctx->stream) != ncclSuccess)
+      ncclBroadcast(ctx->d_best, ctx->d_best, NX + 1, ncclDouble, ctx->best_owner, comm, ctx->stream) != ncclSuccess)
   {
     ctx->err = "ncclBroadcast failed";
     return TMX_ERR_NCCL;
   }
 #endif
+  if (owner_err != hipSuccess)
+  {
+    ctx->err = std::string("tmx_best_trajectory: ") + hipGetErrorString(owner_err);
+    return TMX_ERR_DEVICE;
+  }
+  double word_in = 1.0;
   HIPCHK(hipMemcpyAsync(x_out, ctx->d_best, sizeof(double) * NX, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(&word_in, ctx->d_best + NX, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  if (owner_bad || (NX > 0 && std::isnan(x_out[0])))
+  if (word_in != 0.0)
   {
     ctx->err = "tmx_best_trajectory: the winning index is not in the owner rank's shard (global_offset of tmx_argmin inconsistent across ranks)";
     return TMX_ERR_STATE;
@@ -3111,6 +3124,19 @@ __attribute__((visibility("default"))) tmx_status tmx_debug_admm_iters(tmx_ctx* 
   static_assert(sizeof(long long) == sizeof(int64_t), "");
   if (hipMemcpy(out, ctx->hb.admm_iters, sizeof(int64_t) * ctx->hb.B, hipMemcpyDeviceToHost) != hipSuccess)
     return TMX_ERR_DEVICE;
+  return TMX_OK;
+}
+
+// debug hook (not in include/tmx.h): diagnostic switches of the uploaded problem (DevProblem::dbg_flags); bit 0 = scalar assembly of the
+// diagonal KKT blocks instead of the MFMA one
+__attribute__((visibility("default"))) tmx_status tmx_debug_set_flags(tmx_ctx* ctx, int flags)
+{
+  if (!ctx || !ctx->have_problem || !ctx->dp)
+    return TMX_ERR_INVALID;
+  TMX_REFUSE_WHILE_PENDING(ctx);
+  HIPCHK(hipSetDevice(ctx->device));
+  ctx->hp.dbg_flags = flags;
+  HIPCHK(hipMemcpy(reinterpret_cast<char*>(ctx->dp) + offsetof(DevProblem, dbg_flags), &flags, sizeof(int), hipMemcpyHostToDevice));
   return TMX_OK;
 }
 

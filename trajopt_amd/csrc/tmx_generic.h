@@ -11,6 +11,9 @@
 // the explicit inverse of the quasi-definite [P + delta I, Aact'; Aact, -delta I].  Meant for small / medium QPs
 // (n + m up to a few thousand); the trajectory QPs of the SQP path never come here (qp_solve_block).
 #pragma once
+#ifndef TMX_DENSE_REFINE
+#define TMX_DENSE_REFINE 1  // one step of iterative refinement per ADMM linear solve of the dense engine (0: none, the round-5 arithmetic)
+#endif
 #include "tmx_qp.h"
 
 struct GenQp  // device view of one problem (offsets into the packed arrays)
@@ -484,6 +487,7 @@ TMX_DEVFN void qp_generic_block(const GenQp& g, const GenData& d, const tmx_osqp
     // floor at its first rho check, rho sqrt(prim / dual) comes out 2.6 x the reference's and the run parts three QPs later (fuzz
     // case 91/36 of `r4 lvs`, round 5: the library solved an eighth QP; with this step the history is the oracle's - DESIGN.md section 3).
     //   r = rhs - (P xt + sigma xt + A' (rho . A xt)),   xt += Ki r,   then zt = A xt
+#if TMX_DENSE_REFINE
     for (int i = tid; i < m; i += NT)
       tm[i] = rho[i] * zt[i];
     TMX_SYNC();
@@ -500,6 +504,7 @@ TMX_DEVFN void qp_generic_block(const GenQp& g, const GenData& d, const tmx_osqp
     TMX_SYNC();
     gen_matvec(Ad, m, n, xt, zt, tid, NT);
     TMX_SYNC();
+#endif
     for (int j = tid; j < n; j += NT)
     {
       x[j] = st.alpha * xt[j] + (1.0 - st.alpha) * xprev[j];

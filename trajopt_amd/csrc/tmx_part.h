@@ -138,11 +138,8 @@ TMX_DEVFN void dpart_map(const QpWs& w, const DPart& p, int tid, DMap& m)
 }
 
 typedef double tmx_d2 __attribute__((ext_vector_type(2) TMX_D2_MEM_ALIGN));
-#include "tmx_gjm.h"
-// block Gauss-Jordan on the f64 matrix cores (tmx_gjm.h) for the two inversion stages of dpart_factor; 0: the row versions below
-#ifndef TMX_GJM
-#define TMX_GJM 0  // bit 0: interiors, bit 1: separator Schur complement.  OFF by default: measured on MI355X (config 1, same box, tools/bench_libs.py): 119.0 k against 126.3 k QP solves/s - four pivots per step cost ~5 k cycles (the 4 x 4 pivot inverse alone 1.7 k: ~140 dependent-ish fp64 instructions at one wave per SIMD), no better per pivot than the row version, and the kernel body spills more (private segment 2 956 -> 3 648 B).  Kept as a build switch with its micro-benchmark (tools/ubench/gjm_test.hip)
-#endif
+// (a block Gauss-Jordan of these two stages on the f64 matrix cores was measured in round 5 - 119.0 k against 126.3 k QP solves/s - and
+// removed in round 6 with its header; the numbers are in docs/history/)
 
 // Register-resident Gauss-Jordan inversion of `nmat` SPD matrices held in LDS with a common row stride.
 // Thread role (m, i, seg): wn <= W consecutive entries [seg*wn, seg*wn + wn) of row i of matrix m stay in registers for
@@ -284,18 +281,6 @@ TMX_DEVFN void dpart_factor(const QpWs& w, int tid, int NT, long long* pc, long 
   }
   TMX_SYNC();
   // 2. explicit inverses of all interiors at once: one thread per matrix row (scratch: the Zs region, not yet built)
-  // (TMX_GJM) two interiors per wave, four pivots per step, rank-4 updates on the matrix cores; scratch: the Zs region as well
-  if ((TMX_GJM & 1) && NT == 256 && Gn <= 32 && 4 * TMX_GJM_WAVE_DOUBLES(2) <= ns * Zst)
-  {
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int mi[2] = { 2 * wv, 2 * wv + 1 };
-    const int nn[2] = { 2 * wv < p.P ? dpart_len(w.T, p.P, 2 * wv) * D : 0, 2 * wv + 1 < p.P ? dpart_len(w.T, p.P, 2 * wv + 1) * D : 0 };
-    tmx_gjm_lds* Gl = (tmx_gjm_lds*)(size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)w.G);
-    tmx_gjm_lds* Wl = (tmx_gjm_lds*)(size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)w.Zs);
-    gjm_wave2<2>(Gl, Gn * Gs, Gs, mi, nn, Wl + wv * TMX_GJM_WAVE_DOUBLES(2), tid & 63);
-    TMX_SYNC();
-  }
-  else
   {
     const int m = tid / Gn, i = tid % Gn;
     const bool active = m < p.P && i < dpart_len(w.T, p.P, m) * D;
@@ -331,15 +316,7 @@ TMX_DEVFN void dpart_factor(const QpWs& w, int tid, int NT, long long* pc, long 
     w.Zs[e] = val;
   }
   TMX_SYNC();
-  // 4. its dense inverse (SPD).  (TMX_GJM) block Gauss-Jordan of the workgroup on the matrix cores; scratch: the block-factor
-  //    region Sinv, whose diagonal blocks have all been consumed above (the fast path does not use the block chain)
-  if ((TMX_GJM & 2) && NT == 256 && ns <= 64 && (size_t)TMX_GJM_BLOCK64_DOUBLES <= (size_t)w.T * D * DS)
-  {
-    tmx_gjm_lds* Zl = (tmx_gjm_lds*)(size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)w.Zs);
-    tmx_gjm_lds* Wl = (tmx_gjm_lds*)(size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)w.Sinv);
-    gjm_block64(Zl, Zst, ns, Wl, tid);
-  }
-  else
+  // 4. its dense inverse (SPD)
   // lane = row, wave = column quarter (scratch: the separator exchange vectors)
   {
     const int i = tid & 63, seg = (tid >> 6) & 3;

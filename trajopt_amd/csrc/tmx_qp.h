@@ -850,7 +850,7 @@ TMX_DEVFN void kkt_factor(const QpWs& w, const DevProblem* P, int mode, double s
 #ifndef TMX_MFMA_ASSEMBLY
 #define TMX_MFMA_ASSEMBLY 1  // 0: the scalar list-order accumulation everywhere (diagnostic builds: isolates the matrix-core path)
 #endif
-  const bool mfma_blocks = TMX_MFMA_ASSEMBLY && D <= 16 && (NT & 63) == 0 && !TMX_HAS_PAIRS(w);
+  const bool mfma_blocks = TMX_MFMA_ASSEMBLY && !(P->dbg_flags & 1) && D <= 16 && (NT & 63) == 0 && !TMX_HAS_PAIRS(w);
   if (mfma_blocks)
   {
     typedef double tmx_kf_v4d __attribute__((ext_vector_type(4)));

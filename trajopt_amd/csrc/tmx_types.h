@@ -145,6 +145,9 @@ struct DevProblem
   int wv_gmax;
   int wv_aux2;   // bit i: some lane's row slot i holds a row with two slack variables
   int* wv_plan;
+  // diagnostic switches (tmx_debug_set_flags, not part of include/tmx.h): bit 0 = the D x D diagonal blocks of the reduced KKT matrix by
+  // the scalar list-order loop instead of v_mfma_f64_16x16x4_f64 (tests/test_gpu_parity.py compares the two on the same QP)
+  int dbg_flags;
 };
 TMX_HOSTDEVFN int slot_is_diff(int kind) { return kind == SLOT_JOINTVEL || kind == SLOT_JOINTVEL_INEQ; }
 #define TMX_TV_REC 5  // DevBatch::tv_aff record of one segment: cleaned Jacobian entries on x[t][j], x[t+1][j], tau[t+1] (upper row), constants of the upper / lower row
