@@ -98,6 +98,32 @@ def cfg(cid, T=None):
         ti = CartVelTermInfo(first_step=1, last_step=n - 2, max_displacement=0.07, is_constraint=(cid == 23))
         (pci.cnt_infos if cid == 23 else pci.cost_infos).append(ti)
         return pci, s, g
+    if cid in (54, 55, 56):
+        # round 6: the BUILT-IN kinematic function terms inside a time-parameterised problem (refused until round 5).  Base = config 50
+        # (velocity limits with time as INEQ constraints + TotalTime cost, 4-DOF test arm: fewer joints than Jacobian rows, so a zero
+        # time column in the decomposed Jacobian would make the smallest singular value 0).  54: AvoidSingularity ABS cost over the
+        # problem's joint group; 55: the DynamicCartPose ABS cost of 43 (tolerance band) in place of the static via point; 56: the static
+        # via point with the tolerance band of 42 + AvoidSingularity over the joint subset 1 .. 3 as INEQ constraint
+        from trajopt_amd.problem import AvoidSingularityTermInfo, CartPoseTermInfo, DynamicCartPoseTermInfo
+        pci, s, g = cfg(50, T)
+        D, n = pci.robot.n_dof, pci.basic_info.n_steps
+        if cid == 54:
+            pci.cost_infos.append(AvoidSingularityTermInfo(link=D - 1, first_step=1, last_step=n - 2, coeffs=[2.0], lambda_=0.1, name="sing"))
+        elif cid == 55:
+            pci.cnt_infos = [ti for ti in pci.cnt_infos if not isinstance(ti, CartPoseTermInfo)]
+            qv = 0.5 * (s + g) + np.array([0.1, -0.15, 0.2, 0.1])
+            off = (np.linalg.inv(pci.robot.fk_links(qv)[1]) @ pci.robot.fk_tool(qv))[:3, :]
+            pci.cost_infos.insert(0, DynamicCartPoseTermInfo(timestep=n // 2, target_link=1, target_frame_offset=off, pos_coeffs=(2, 1, 1.5),
+                                                             rot_coeffs=(0.5, 0.25, 1.0), is_constraint=False, lower_tolerance=[-0.03, -0.02, -0.01, -0.2, -0.1, -0.05],
+                                                             upper_tolerance=[0.02, 0.03, 0.04, 0.1, 0.2, 0.3]))
+        else:
+            for ti in pci.cnt_infos:
+                if isinstance(ti, CartPoseTermInfo):
+                    ti.lower_tolerance = [-0.02, -0.01, -0.03, 0, 0, 0]
+                    ti.upper_tolerance = [0.01, 0.02, 0.0, 0, 0, 0]
+            pci.cnt_infos.append(AvoidSingularityTermInfo(link=3, first_step=1, last_step=n - 2, coeffs=[1.0], lambda_=0.05, subset_first=1,
+                                                          is_constraint=True, name="sing"))
+        return pci, s, g
     if cid in (48, 49, 50, 51, 52, 53):
         # TIME-PARAMETERISED problems (BasicInfo::use_time: one 1/dt variable per waypoint; problem_description.cpp:1244-1325, :1852-1890)
         # on the 4-DOF test arm (53: glass_upright): 48 JointVel-with-time SQUARED cost + TotalTime HINGE cost; 49 velocity limits as a

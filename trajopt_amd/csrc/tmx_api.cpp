@@ -718,13 +718,9 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
             ctx->err = "TMX_FLAVOR_SQP: function terms are not part of the trajopt_sqp path";
             return TMX_ERR_UNSUPPORTED;
           }
-          if (d->use_time && builtin)
-          {
-            // (user-defined functions are: they see the joint columns of their waypoint, prob.GetVarRow(s, 0, n_dof) - round 5)
-            ctx->err = "the built-in kinematic function terms (AvoidSingularity, DynamicCartPose, CartPose with a tolerance band) are not lowered "
-                       "for time-parameterised problems";
-            return TMX_ERR_UNSUPPORTED;
-          }
+          // (time-parameterised problems: user-defined functions see the joint columns of their waypoint, prob.GetVarRow(s, 0, n_dof) -
+          //  round 5; the built-in kinematic functions likewise since round 6: the time column is a prismatic joint with a zero axis
+          //  for the FK, a zero Jacobian column, and no column of the Jacobian AvoidSingularity decomposes - tmx_terms.h)
           if (!builtin && tmx_expr_check(tm.expr, DK) != 0)
           {
             ctx->err = "function term: malformed tmx_expr program (opcode, index, stack discipline or outputs)";

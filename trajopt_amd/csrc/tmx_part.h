@@ -1412,18 +1412,30 @@ TMX_DEVFN int admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, bo
     if (certs_ok)
       publish_deltas();
     TMX_SYNC();
+#if defined(TMX_FINE) && TMX_FINE == 2  // (-DTMX_PROFILE -DTMX_FINE=2: the in-register check split over slots 13 publish / 14 norms / 15 certificates / 6 reduction)
+    TMX_TICK(13);
+#endif
 #pragma unroll
     for (int k = 0; k < 22; ++k)
       m[k] = 0.0;
     norms14(m);
+#if defined(TMX_FINE) && TMX_FINE == 2
+    TMX_TICK(14);
+#endif
     if (certs_ok)
       certs8(m);
+#if defined(TMX_FINE) && TMX_FINE == 2
+    TMX_TICK(15);
+#endif
     double m18[18];
 #pragma unroll
     for (int k = 0; k < 18; ++k)
       m18[k] = m[k];
     const bool sall[18] = { false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false };
     block_reduce<18>(m18, sall, w.red, tid, TMX_QP_NT);  // ends with every thread holding all values; its barriers free the buffers
+#if defined(TMX_FINE) && TMX_FINE == 2
+    TMX_TICK(6);
+#endif
 #pragma unroll
     for (int k = 0; k < 18; ++k)
       m[k] = m18[k];

@@ -1880,7 +1880,24 @@ TMX_DEVFN void band_solve(const QpWs& w, int tid, int NT)
 
 // ---- KKT solve: in: tp (primary rhs r1 + A'W r2 part), ta (aux rhs); out: tp = x_p, ta = x_a, hr = (A x)_r --------
 // (mode 1, polish: other conventions for the row terms, see the first branch)
-TMX_DEVFN void kkt_solve(const QpWs& w, const DevProblem* P, int mode, double sig, double delta, int tid, int NT)
+// (-DTMX_PROFILE -DTMX_FINE=1: the polish solves split over slots 13 row phase / 14 gather / 15 chain / 6 recovery - tools/prof_phases.py,
+//  subtract a plain -DTMX_PROFILE run)
+#if TMX_IS_DEVICE && defined(TMX_PROFILE) && defined(TMX_FINE)
+#define TMX_FTICK(f, slot)                                                                                            \
+  do                                                                                                                  \
+  {                                                                                                                   \
+    if (TMX_FINE == (f) && fpc != nullptr)                                                                            \
+    {                                                                                                                 \
+      const long long now_ = TMX_CLK();                                                                               \
+      fpc[slot] += now_ - *ftl;                                                                                       \
+      *ftl = now_;                                                                                                    \
+    }                                                                                                                 \
+  } while (0)
+#else
+#define TMX_FTICK(f, slot) ((void)0)
+#endif
+TMX_DEVFN void kkt_solve(const QpWs& w, const DevProblem* P, int mode, double sig, double delta, int tid, int NT,
+                         [[maybe_unused]] long long* fpc = nullptr, [[maybe_unused]] long long* ftl = nullptr)
 {
   const int D = w.D, T = w.T, DS = w.DS, DDS = w.DDS;
   if (mode == 1)
@@ -1922,6 +1939,7 @@ TMX_DEVFN void kkt_solve(const QpWs& w, const DevProblem* P, int mode, double si
       w.hr[r] = c;
     }
     TMX_SYNC();
+    TMX_FTICK(1, 13);
     for (int v = tid; v < w.NX; v += NT)
     {
       const int t = v / D, j = v % D;
@@ -1938,6 +1956,7 @@ TMX_DEVFN void kkt_solve(const QpWs& w, const DevProblem* P, int mode, double si
       w.tp[v] += s;
     }
     TMX_SYNC();
+    TMX_FTICK(1, 14);
   }
   else
   {
@@ -2126,6 +2145,7 @@ TMX_DEVFN void kkt_solve(const QpWs& w, const DevProblem* P, int mode, double si
   // 3. aux recovery and (A x)_r   (polish: hr = nu_r, the multiplier itself - (A dx - r2) / delta would cancel again)
   if (mode == 1)
   {
+    TMX_FTICK(1, 15);
     TMX_ROWS(w, r)
     {
       if (!w.act[r])
@@ -2169,6 +2189,7 @@ TMX_DEVFN void kkt_solve(const QpWs& w, const DevProblem* P, int mode, double si
       w.hr[r] = nu;
     }
     TMX_SYNC();
+    TMX_FTICK(1, 6);
     return;
   }
   // 3. aux recovery and (A x)_r

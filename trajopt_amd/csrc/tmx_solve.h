@@ -2094,8 +2094,17 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
     TMX_SYNC();
     // (difference rows of order 2 / 3: the banded factorisation and its solves in double-double arithmetic, tmx_qp.h)
     wp.polish_dd = (TMX_POLISH_DD && wp.band_rows > 0 && wp.bk != nullptr) ? 1 : 0;
+#ifdef TMX_POLISH_SPLIT
+    TMX_TICK(7);
+#endif
     kkt_factor(wp, P, 1, delta, delta, tid, NT);
+#ifdef TMX_POLISH_SPLIT
+    TMX_TICK(13);
+#endif
     kkt_invert(wp, false, tid, NT, pc, tlast);
+#ifdef TMX_POLISH_SPLIT
+    TMX_TICK(14);
+#endif
     // polished iterate lives in (dxp, dxa | dyr, dybp, dyba)
     for (int pass = 0; pass <= st.polish_refine_iter; ++pass)
     {
@@ -2158,7 +2167,17 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
             wp.ta[a] = r1 + wp.bba[a] * gb;
           }
       TMX_SYNC();
+#if defined(TMX_POLISH_SPLIT) || defined(TMX_FINE)
+      TMX_TICK(7);
+#endif
+#if defined(TMX_PROFILE) && defined(TMX_FINE)
+      kkt_solve(wp, P, 1, delta, delta, tid, NT, pc, &tlast);
+#else
       kkt_solve(wp, P, 1, delta, delta, tid, NT);
+#endif
+#ifdef TMX_POLISH_SPLIT
+      TMX_TICK(15);
+#endif
 #if defined(TMX_HOST_EMU) && defined(TMX_DEBUG_KKT)
       {
         double mx = 0.0;
@@ -2230,10 +2249,16 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
       }
       TMX_SYNC();
     }
+#ifdef TMX_POLISH_SPLIT
+    TMX_TICK(7);
+#endif
     // residuals at the polished point (z = clip(A x))
     QpInfo dummy = info;
     double pprim = 0.0, pdual = 0.0;
     compute_residuals(wp, P, wp.dxp, wp.dxa, wp.dyr, wp.dybp, wp.dyba, 1, dummy, pprim, pdual, false, tid, NT);
+#ifdef TMX_POLISH_SPLIT
+    TMX_TICK(6);  // (slot 6, "residuals + rho", is nearly empty on the fast path)
+#endif
 #if defined(TMX_HOST_EMU) && defined(TMX_DEBUG_KKT)
     std::printf("[dbg] polish: prim %.3e (admm %.3e)  dual %.3e (admm %.3e)\n", pprim, info.prim_res, pdual, info.dual_res);
 #endif

@@ -710,9 +710,11 @@ TMX_DEVFN int sing_jacobian(const DevProblem* P, const double* q, int link, int 
 {
   const int D = P->D;
   link_jacobian6(P, q, link, J);
-  if (j0p1 == 0)
+  if (j0p1 == 0 && P->DK == D)
     return D;
-  const int j0 = j0p1 - 1, nc = link - j0 + 1;
+  // (a time-parameterised problem, D = DK + 1: the time column is no joint of the group - the 6 x DK matrix the reference
+  //  decomposes, not one with a zero column behind it, whose smallest singular value would be 0 for DK < 6)
+  const int j0 = j0p1 ? j0p1 - 1 : 0, nc = j0p1 ? link - j0 + 1 : P->DK;
   for (int r = 0; r < 6; ++r)  // compaction in place: (r, c) moves down to a smaller index
     for (int c = 0; c < nc; ++c)
       J[r * nc + c] = J[r * D + j0 + c];
@@ -784,7 +786,7 @@ TMX_DEVFN void fx_builtin_jac(const DevProblem* P, int inst, double* x, double (
     const double sv = smallest_singular(J0, nc, u, v);
     const double lambda = par[0];
     const double scale = -1.0 / ((sv + lambda) * (sv + lambda));
-    const int k0 = j0p1 ? j0p1 - 1 : 0, k1 = j0p1 ? link : D - 1;
+    const int k0 = j0p1 ? j0p1 - 1 : 0, k1 = j0p1 ? link : P->DK - 1;  // (the time column of a time-parameterised problem: zero)
     for (int k = 0; k < D; ++k)
     {
       if (k < k0 || k > k1)
