@@ -1880,6 +1880,85 @@ TMX_DEVFN void band_solve(const QpWs& w, int tid, int NT)
 
 // ---- KKT solve: in: tp (primary rhs r1 + A'W r2 part), ta (aux rhs); out: tp = x_p, ta = x_a, hr = (A x)_r --------
 // (mode 1, polish: other conventions for the row terms, see the first branch)
+#if TMX_IS_DEVICE
+// ---- one-wave block substitution of the DIAGONAL-coupling chain, running vector in registers (round 6) ------------------------------
+//   forward   v_t = b_t - c_{t-1} o (S_{t-1}^-1 v_{t-1}),  t = 1 .. T-1         backward  x_t = S_t^-1 (v_t - c_t o x_{t+1}),  t = T-1 .. 0
+// Lane i < D owns component i; the other components come by v_readlane instead of an LDS store + fence + load per block, and the matrix
+// row, right-hand side and coupling of the NEXT block are loaded while the current one is summed (they do not depend on the chain).
+// The arithmetic is that of the LDS-exchange walk it replaces - two FMA accumulators over the even / odd columns, then (a0 + a1), the
+// coupling product, the subtraction - so the results are bit-identical.  Measured before (profiles/r06/r06f_*): 1.28 k cycles per block
+// step, 303 k cycles per polish (four solves) = 5.6 % of k_sqp_pool.
+typedef __attribute__((address_space(3))) const double tmx_dsw_clds;
+typedef __attribute__((address_space(3))) double tmx_dsw_lds;
+template <int DC, class MP, class CP, class VP>
+TMX_DEVFN void chain_diag_sweep(MP Sinv, CP cpl, VP tp, int D_in, int DS, int DDS, int T, int lane)
+{
+  const int D = DC ? DC : D_in;
+  const bool live = lane < D;
+  const int i = live ? lane : 0;
+  double m[8], mn[8];
+  auto row_load = [&](int t, double (&r)[8]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      r[j] = (j < D) ? Sinv[t * DDS + i * DS + j] : 0.0;
+  };
+  auto row_dot = [&](const double (&r)[8], double u) __attribute__((always_inline)) -> double {
+    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+    for (int j = 0; j < 8; j += 2)
+    {
+      if (j < D)
+        a0 = __builtin_fma(r[j], tmx_readlane_d(u, j), a0);
+      if (j + 1 < D)
+        a1 = __builtin_fma(r[j + 1], tmx_readlane_d(u, j + 1), a1);
+    }
+    return a0 + a1;
+  };
+  // ---- forward
+  double v = tp[i];
+  row_load(0, m);
+  double bn = (T > 1) ? tp[D + i] : 0.0, cn = (T > 1) ? cpl[i] : 0.0;
+  for (int t = 1; t < T; ++t)
+  {
+    const int tn = (t + 1 < T) ? t : t - 1;  // (clamped prefetch: the last pass reloads valid addresses)
+    row_load(tn, mn);
+    const double bnn = tp[(tn + 1) * D + i], cnn = cpl[tn * D + i];
+    const double acc = row_dot(m, v);
+    v = bn - cn * acc;
+    if (live)
+      tp[t * D + i] = v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      m[j] = mn[j];
+    bn = bnn;
+    cn = cnn;
+  }
+  // ---- backward (v = v_{T-1} of this lane)
+  row_load(T - 1, m);
+  double u = v;
+  for (int t = T - 1; t >= 0; --t)
+  {
+    const int tn = t > 0 ? t - 1 : 0;
+    row_load(tn, mn);
+    const double vn = tp[tn * D + i], cnn = cpl[tn * D + i];   // v_{t-1} of the forward sweep (overwritten by x_{t-1} only in the next pass)
+    const double x = row_dot(m, u);
+    if (live)
+      tp[t * D + i] = x;
+    u = vn - cnn * x;  // the next pass's  v_{t-1} - c_{t-1} o x_t
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      m[j] = mn[j];
+  }
+}
+template <class MP, class CP, class VP>
+TMX_DEVFN void chain_diag_sweep_d(MP Sinv, CP cpl, VP tp, int D, int DS, int DDS, int T, int lane)
+{
+  if (D == 7)
+    chain_diag_sweep<7>(Sinv, cpl, tp, D, DS, DDS, T, lane);
+  else
+    chain_diag_sweep<0>(Sinv, cpl, tp, D, DS, DDS, T, lane);
+}
+#endif
 // (-DTMX_PROFILE -DTMX_FINE=1: the polish solves split over slots 13 row phase / 14 gather / 15 chain / 6 recovery - tools/prof_phases.py,
 //  subtract a plain -DTMX_PROFILE run)
 #if TMX_IS_DEVICE && defined(TMX_PROFILE) && defined(TMX_FINE)
@@ -2013,52 +2092,14 @@ TMX_DEVFN void kkt_solve(const QpWs& w, const DevProblem* P, int mode, double si
     lpart_solve(w, tid, NT);  // long horizon: 4 interior chains side by side + separator system + spike correction
   else if (D <= 8 && NT >= 64)
   {
-    // one wave walks the chain with wave-synchronous LDS exchange: 2T-1 dependent steps without a workgroup barrier each
+    // one wave walks the chain, the running vector in registers (chain_diag_sweep): 2T-1 dependent steps without a barrier, an LDS
+    // round trip or a fence each
     if (tid < 64)
     {
-      const int i = tid < D ? tid : 0;
-      const bool live = tid < D;
-      for (int t = 1; t < T; ++t)
-      {
-        const double* S = w.Sinv + (t - 1) * DDS + i * DS;
-        const double* vp = w.tp + (t - 1) * D;
-        double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-        for (int j = 0; j < 8; j += 2)
-        {
-          if (j < D)
-            a0 = __builtin_fma(S[j], vp[j], a0);
-          if (j + 1 < D)
-            a1 = __builtin_fma(S[j + 1], vp[j + 1], a1);
-        }
-        if (live)
-          w.tp[t * D + i] -= TMX_PC(w)[(t - 1) * D + i] * (a0 + a1);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-      }
-      for (int t = T - 1; t >= 0; --t)
-      {
-        const double* S = w.Sinv + t * DDS + i * DS;
-        double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-          if (j < D)
-          {
-            double vj = w.tp[t * D + j];
-            if (t < T - 1)
-              vj -= TMX_PC(w)[t * D + j] * w.tp[(t + 1) * D + j];
-            if (j & 1)
-              a1 = __builtin_fma(S[j], vj, a1);
-            else
-              a0 = __builtin_fma(S[j], vj, a0);
-          }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        if (live)
-          w.tp[t * D + i] = a0 + a1;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-      }
+      if (tmx_in_lds(w.Sinv) && tmx_in_lds(w.tp) && tmx_in_lds(TMX_PC(w)))
+        chain_diag_sweep_d((tmx_dsw_clds*)w.Sinv, (tmx_dsw_clds*)TMX_PC(w), (tmx_dsw_lds*)w.tp, D, DS, DDS, T, tid);
+      else
+        chain_diag_sweep_d((const double*)w.Sinv, (const double*)TMX_PC(w), w.tp, D, DS, DDS, T, tid);
     }
     TMX_SYNC();
   }
