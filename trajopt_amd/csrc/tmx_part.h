@@ -150,7 +150,10 @@ typedef double tmx_d2 __attribute__((ext_vector_type(2) TMX_D2_MEM_ALIGN));
 //   M   : matrix m at M + m*mslot, row stride `stride` (even, rows 16-byte aligned, wn even)
 //   n   : dimension of this thread's matrix (role inactive: active = false)
 //   buf : 2 * nmat * (stride + 2) doubles of LDS scratch, followed by >= W readable doubles
-template <int W, bool INDEXED>
+// NK > 0: the number of elimination steps as a compile-time constant (= nmax): the step loop is fully unrolled, and with a literal j0 the
+// position of the pivot column in the register row is a constant per step - the W selects of the pivot-column fix-up and of the
+// next-pivot extraction fold away (round 6: 1.96 k cycles per step of the 21 x 21 interior inverses before)
+template <int W, bool INDEXED, int NK = 0>
 TMX_DEVFN void gj_rows(double* M, int mslot, int stride, int nmat, int nmax, bool active, int m, int i, int j0, int wn, int n, double* buf)
 {
   // j0 (first column of this thread's segment) must be wave-uniform: the pivot-column fix-up and the next-pivot
@@ -178,7 +181,8 @@ TMX_DEVFN void gj_rows(double* M, int mslot, int stride, int nmat, int nmax, boo
       rb[stride] = fast_rcp(val[0]);
   }
   TMX_SYNC();
-  for (int k = 0; k < nmax; ++k)
+#pragma unroll(NK ? NK : 1)
+  for (int k = 0; k < (NK ? NK : nmax); ++k)
   {
     const int par = k & 1;
     const int kk = __builtin_amdgcn_readfirstlane(k - j0);  // position of the pivot column in this wave's segment
@@ -262,24 +266,34 @@ TMX_DEVFN void dpart_factor(const QpWs& w, int tid, int NT, long long* pc, long 
   DPart p;
   dpart_make(w.T, p);
   const int ns = (p.P - 1) * D;
-  // 1. interior diagonal sub-matrices (block tridiagonal with diagonal coupling blocks), zero padded
-  for (int e = tid; e < p.P * Gn * Gs; e += NT)
+  // 1. interior diagonal sub-matrices (block tridiagonal with diagonal coupling blocks), zero padded.  One thread per matrix ROW: zero
+  //    fill, then the D entries of the diagonal block and the (at most two) coupling entries - no index division per entry (round 6: the
+  //    entry-per-thread loop paid eight 32-bit divisions / remainders per entry, 9.8 k cycles per factorisation; same values)
   {
-    const int k = e / (Gn * Gs), rem = e % (Gn * Gs), r = rem / Gs, c = rem % Gs, n = dpart_len(w.T, p.P, k) * D;
-    double val = 0.0;
-    if (r < n && c < n)
+    const float rGn = 1.0f / (float)Gn, rD = 1.0f / (float)D;
+    for (int row = tid; row < p.P * Gn; row += NT)
     {
-      const int tb = r / D, i = r % D, tc = c / D, j = c % D, t = dpart_first(w.T, p.P, k) + tb;
-      if (tb == tc)
-        val = w.Sinv[t * DDS + i * DS + j];
-      else if (tc == tb + 1 && i == j)
-        val = w.po[t * D + i];
-      else if (tb == tc + 1 && i == j)
-        val = w.po[(t - 1) * D + i];
+      const int k = tmx_fdiv(row, rGn), r = row - k * Gn, n = dpart_len(w.T, p.P, k) * D;
+      double* Gr = w.G + (size_t)row * Gs;
+      for (int c = 0; c < Gs; ++c)
+        Gr[c] = 0.0;
+      if (r < n)
+      {
+        const int tb = tmx_fdiv(r, rD), i = r - tb * D, t = dpart_first(w.T, p.P, k) + tb;
+        const double* Sr = w.Sinv + t * DDS + i * DS;
+        for (int j = 0; j < D; ++j)
+          Gr[tb * D + j] = Sr[j];
+        if (r + D < n)
+          Gr[r + D] = w.po[t * D + i];        // block column tb + 1, entry (i, i)
+        if (tb > 0)
+          Gr[r - D] = w.po[(t - 1) * D + i];  // block column tb - 1
+      }
     }
-    w.G[e] = val;
   }
   TMX_SYNC();
+#if defined(TMX_FINE) && TMX_FINE == 3  // (-DTMX_PROFILE -DTMX_FINE=3: the two assembly stages of the factorisation in slots 6 / 3)
+  TMX_TICK(6);
+#endif
   // 2. explicit inverses of all interiors at once: one thread per matrix row (scratch: the Zs region, not yet built)
   {
     const int m = tid / Gn, i = tid % Gn;
@@ -287,35 +301,56 @@ TMX_DEVFN void dpart_factor(const QpWs& w, int tid, int NT, long long* pc, long 
     const int n = active ? dpart_len(w.T, p.P, m) * D : 0;
     if (Gs <= 16)
       gj_rows<16, false>(w.G, Gn * Gs, Gs, p.P, Gn, active, active ? m : 0, i, 0, Gs, n, w.Zs);
+    else if (Gs <= 24 && Gn == 21)  // (three blocks of 7: BASELINE configuration 1)
+      gj_rows<24, false, 21>(w.G, Gn * Gs, Gs, p.P, Gn, active, active ? m : 0, i, 0, Gs, n, w.Zs);
     else if (Gs <= 24)
       gj_rows<24, false>(w.G, Gn * Gs, Gs, p.P, Gn, active, active ? m : 0, i, 0, Gs, n, w.Zs);
     else
       gj_rows<34, false>(w.G, Gn * Gs, Gs, p.P, Gn, active, active ? m : 0, i, 0, Gs, n, w.Zs);
   }
   TMX_TICK(14);
-  // 3. Schur complement on the separators (block tridiagonal, (P-1) blocks of D)
-  for (int e = tid; e < ns * Zst; e += NT)
+  // 3. Schur complement on the separators (block tridiagonal, (P-1) blocks of D).  Four threads per matrix row: thread q < 3 computes the
+  //    D entries of block column kr - 1 + q, all four zero-fill the rest of the row a quarter each (round 6: was one entry per thread and
+  //    pass with its index divisions, 11.6 k cycles per factorisation; same values)
   {
-    const int rI = e / Zst, cI = e % Zst;
-    double val = 0.0;
-    if (cI < ns)
+    const float rD = 1.0f / (float)D;
+    const int zq = Zst >> 2;  // (Zst is a multiple of 8)
+    for (int rq = tid; rq < 4 * ns; rq += NT)
     {
-      const int kr = rI / D, i = rI % D, kc = cI / D, j = cI % D, sb = dpart_sep(w.T, p.P, kr);
-      const double* GL = w.G + kr * Gn * Gs;        // interior left of separator kr
-      const double* GR = w.G + (kr + 1) * Gn * Gs;  // interior right of it
-      const int nL = dpart_len(w.T, p.P, kr) * D, nR = dpart_len(w.T, p.P, kr + 1) * D;
-      const double cl_i = w.po[(sb - 1) * D + i], cr_i = w.po[sb * D + i];
-      if (kr == kc)
-        val = w.Sinv[sb * DDS + i * DS + j] - cl_i * GL[(nL - D + i) * Gs + (nL - D + j)] * w.po[(sb - 1) * D + j] -
-              cr_i * GR[i * Gs + j] * w.po[sb * D + j];
-      else if (kc == kr + 1)
-        val = -cr_i * GR[i * Gs + (nR - D + j)] * w.po[(dpart_sep(w.T, p.P, kc) - 1) * D + j];
-      else if (kc + 1 == kr)
-        val = -cl_i * GL[(nL - D + i) * Gs + j] * w.po[dpart_sep(w.T, p.P, kc) * D + j];
+      const int rI = rq >> 2, q = rq & 3;
+      const int kr = tmx_fdiv(rI, rD), i = rI - kr * D, kc = kr - 1 + q;
+      double* Zr = w.Zs + (size_t)rI * Zst;
+      const int c_lo = (kr - 1) * D, c_hi = (kr + 2) * D < ns ? (kr + 2) * D : ns;  // columns [c_lo, c_hi) belong to the three blocks
+      for (int c = q * zq; c < (q + 1) * zq; ++c)
+        if (c < c_lo || c >= c_hi)
+          Zr[c] = 0.0;
+      if (q < 3 && kc >= 0 && kc < p.P - 1)
+      {
+        const int sb = dpart_sep(w.T, p.P, kr);
+        const double* GL = w.G + kr * Gn * Gs;        // interior left of separator kr
+        const double* GR = w.G + (kr + 1) * Gn * Gs;  // interior right of it
+        const int nL = dpart_len(w.T, p.P, kr) * D, nR = dpart_len(w.T, p.P, kr + 1) * D;
+        const double cl_i = w.po[(sb - 1) * D + i], cr_i = w.po[sb * D + i];
+        const int sc = dpart_sep(w.T, p.P, kc);
+        for (int j = 0; j < D; ++j)
+        {
+          double val;
+          if (q == 1)
+            val = w.Sinv[sb * DDS + i * DS + j] - cl_i * GL[(nL - D + i) * Gs + (nL - D + j)] * w.po[(sb - 1) * D + j] -
+                  cr_i * GR[i * Gs + j] * w.po[sb * D + j];
+          else if (q == 2)
+            val = -cr_i * GR[i * Gs + (nR - D + j)] * w.po[(sc - 1) * D + j];
+          else
+            val = -cl_i * GL[(nL - D + i) * Gs + j] * w.po[sc * D + j];
+          Zr[kc * D + j] = val;
+        }
+      }
     }
-    w.Zs[e] = val;
   }
   TMX_SYNC();
+#if defined(TMX_FINE) && TMX_FINE == 3
+  TMX_TICK(3);
+#endif
   // 4. its dense inverse (SPD)
   // lane = row, wave = column quarter (scratch: the separator exchange vectors)
   {
