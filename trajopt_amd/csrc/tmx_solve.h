@@ -1581,6 +1581,9 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
     TMX_SYNC();
   }
 
+#if defined(TMX_FINE) && TMX_FINE == 4  // (-DTMX_PROFILE -DTMX_FINE=4: setup split - load 13, Ruiz 15, the rest stays in slot 0)
+  TMX_TICK(13);
+#endif
   // ---------------- Ruiz equilibration (scale_data) ------------------------------------------------------
   // temporaries: D_temp_p -> tp, D_temp_a -> ta, E_temp_r -> hr, E_temp_bp -> dybp, E_temp_ba -> dyba
   for (int it = 0; it < st.scaling; ++it)
@@ -1798,6 +1801,9 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
   }
   TMX_SYNC();
 
+#if defined(TMX_FINE) && TMX_FINE == 4
+  TMX_TICK(15);
+#endif
   // ---------------- warm start decision (createOrUpdateSolver, osqp_interface.cpp:283-370) -----------------
   const int* pd4 = Bt->prev_dims + 4 * b;
   const unsigned long long* pws = Bt->prev_ws + 2 * b;
