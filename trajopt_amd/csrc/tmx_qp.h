@@ -2023,11 +2023,27 @@ TMX_DEVFN void kkt_solve(const QpWs& w, const DevProblem* P, int mode, double si
     {
       const int t = v / D, j = v % D;
       double s = 0.0;
-      for (int q = w.wl_start[t]; q < w.wl_start[t + 1]; ++q)
       {
-        const int r = w.wl_list[q];
-        if (w.act[r])
-          s += w.hr[r] * w.coef[r * D + j];
+        // (groups of four entries loaded together, added in list order: the same sum)
+        const int q1 = w.wl_start[t + 1];
+        int q = w.wl_start[t];
+        for (; q + 4 <= q1; q += 4)
+        {
+          const int r0 = w.wl_list[q], r1 = w.wl_list[q + 1], r2 = w.wl_list[q + 2], r3 = w.wl_list[q + 3];
+          const int a0 = w.act[r0], a1 = w.act[r1], a2 = w.act[r2], a3 = w.act[r3];
+          const double h0 = w.hr[r0], h1 = w.hr[r1], h2 = w.hr[r2], h3 = w.hr[r3];
+          const double c0 = w.coef[r0 * D + j], c1 = w.coef[r1 * D + j], c2 = w.coef[r2 * D + j], c3 = w.coef[r3 * D + j];
+          s = a0 ? s + h0 * c0 : s;
+          s = a1 ? s + h1 * c1 : s;
+          s = a2 ? s + h2 * c2 : s;
+          s = a3 ? s + h3 * c3 : s;
+        }
+        for (; q < q1; ++q)
+        {
+          const int r = w.wl_list[q];
+          if (w.act[r])
+            s += w.hr[r] * w.coef[r * D + j];
+        }
       }
 #if TMX_LINK_ROWS
       s += link_gather(w, w.hr, t, j);

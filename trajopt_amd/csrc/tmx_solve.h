@@ -1601,11 +1601,27 @@ TMX_DEVFN void qp_solve_block(const DevProblem* P, const DevBatch* Bt, int b, do
       if (w.pb != nullptr)
         for (int i = 0; i < D; ++i)
           cn = fmax(cn, fabs(w.pb[(size_t)t * D * D + i * D + j]));
-      for (int q = w.wl_start[t]; q < w.wl_start[t + 1]; ++q)
       {
-        const int r = w.wl_list[q];
-        if (w.act[r])
-          cn = fmax(cn, fabs(w.coef[r * D + j]));
+        // (groups of four: the three dependent loads per list entry - slot, active flag, coefficient - of four entries are in flight
+        //  together; a maximum does not depend on the order.  The coefficient of an inactive slot may be uninitialised: selected away)
+        const int q1 = w.wl_start[t + 1];
+        int q = w.wl_start[t];
+        for (; q + 4 <= q1; q += 4)
+        {
+          const int r0 = w.wl_list[q], r1 = w.wl_list[q + 1], r2 = w.wl_list[q + 2], r3 = w.wl_list[q + 3];
+          const int a0 = w.act[r0], a1 = w.act[r1], a2 = w.act[r2], a3 = w.act[r3];
+          const double c0 = w.coef[r0 * D + j], c1 = w.coef[r1 * D + j], c2 = w.coef[r2 * D + j], c3 = w.coef[r3 * D + j];
+          cn = a0 ? fmax(cn, fabs(c0)) : cn;
+          cn = a1 ? fmax(cn, fabs(c1)) : cn;
+          cn = a2 ? fmax(cn, fabs(c2)) : cn;
+          cn = a3 ? fmax(cn, fabs(c3)) : cn;
+        }
+        for (; q < q1; ++q)
+        {
+          const int r = w.wl_list[q];
+          if (w.act[r])
+            cn = fmax(cn, fabs(w.coef[r * D + j]));
+        }
       }
 #if TMX_LINK_ROWS
       if (w.n_link > 0 && t > 0)
