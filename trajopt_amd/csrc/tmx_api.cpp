@@ -1624,6 +1624,52 @@ tmx_status tmx_problem_upload(tmx_ctx* ctx, const tmx_problem_desc* d, const tmx
   P.wv_gmax = 2;
   P.wv_aux2 = 0;
   P.wv_plan = nullptr;
+  P.row_perm = nullptr;
+  {
+    // ROW -> THREAD assignment of the register-resident bursts (DevProblem::row_perm, tmx_part.h).  With R > 256 row slots the last
+    // R - 256 threads carry two rows.  In slot order those threads got the LAST slots - for config 1 the 65 abs rows (two slack
+    // variables each): one wave ran two rows x (row + two slacks) = six dependent chains per thread in phases A / C of every ADMM
+    // iteration while the other three ran two, and waited (tools/prof_loop.py: 2.0 k of the iteration's 4.7 k cycles).  Here the
+    // two-row threads (and the single-row threads of their waves) take one-slack rows, the two-slack rows go to single-row threads of
+    // the waves below, top down: at most four chains per thread anywhere.  TMX_ROW_PERM=0 keeps the slot order.
+    const char* env = std::getenv("TMX_ROW_PERM");
+    const int NT = TMX_QP_NT;
+    if (!(env && env[0] == '0') && R <= 2 * NT && TMX_QP_NT == 256)
+    {
+      std::vector<int> perm(2 * (size_t)NT, -1), cheap, heavy;
+      for (int r = 0; r < R; ++r)
+        (naux[r] > 1 ? heavy : cheap).push_back(r);
+      const int extra = std::max(0, R - NT), two_first = NT - extra;
+      const int prot_first = extra > 0 ? (two_first / 64) * 64 : NT;  // single-row threads [prot_first, two_first) share a wave with two-row threads
+      std::vector<int> pool(cheap);
+      pool.insert(pool.end(), heavy.begin(), heavy.end());  // (two-slack rows only if the one-slack rows run out)
+      size_t take = 0;
+      for (int q = 0; q < 2; ++q)
+        for (int i = 0; i < extra; ++i)
+          perm[(size_t)q * NT + two_first + i] = pool[take++];
+      for (int tdx = prot_first; tdx < two_first && take < pool.size(); ++tdx)
+        perm[tdx] = pool[take++];
+      // the rest on the threads below: one-slack rows bottom up in slot order, two-slack rows top down (as few waves as possible run the
+      // two-slot instantiation)
+      const int n_free = std::min(prot_first, two_first);
+      const size_t n_cheap_left = take < cheap.size() ? cheap.size() - take : 0, n_left = pool.size() - take, n_heavy_left = n_left - n_cheap_left;
+      if ((int)n_left > n_free)  // (cannot happen: R - 2 extra - (two_first - prot_first) <= prot_first; kept as a guard)
+        perm.clear();
+      else
+      {
+        for (size_t i = 0; i < n_cheap_left; ++i)
+          perm[i] = pool[take + i];
+        for (size_t i = 0; i < n_heavy_left; ++i)
+          perm[(size_t)n_free - n_heavy_left + i] = pool[take + n_cheap_left + i];
+      }
+      if (!perm.empty())
+      {
+        tmx_status rcp;
+        if ((rcp = upload(ctx, ctx->prob_allocs, &P.row_perm, perm)) != TMX_OK)
+          return rcp;
+      }
+    }
+  }
 #if TMX_IS_DEVICE
   {
     // OPT-IN (TMX_WAVE=1): measured on MI355X (round 6, profiles/r06/) the wave-pair solver runs BASELINE config 1 at 101 k SQP it/s

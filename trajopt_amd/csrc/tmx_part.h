@@ -565,6 +565,28 @@ TMX_DEVFN double dpart_separator_row_rc(const HotLds& h, const DMap& m, const do
     r[p] = yr[p];
   }
   double s[4] = { 0.0, 0.0, 0.0, 0.0 };
+#ifndef TMX_SEP_DIFF_FIRST
+#define TMX_SEP_DIFF_FIRST 1  // 0: difference and product of a column back to back (rounds 2 - 5; same bits; A/B switch)
+#endif
+#if TMX_SEP_DIFF_FIRST
+  // all sixteen differences, THEN the products (round 6): left alone the scheduler emitted sixteen (v_add_f64 -> dependent v_fmac_f64)
+  // pairs through one temporary register - sixteen dependent-issue stalls in the phase every other wave waits for
+  double df[2 * TMX_RC_ZP];
+#pragma unroll
+  for (int p = 0; p < TMX_RC_ZP; ++p)
+  {
+    df[2 * p] = l[p].x - r[p].x;
+    df[2 * p + 1] = l[p].y - r[p].y;
+  }
+  TMX_SCHED_FENCE();
+#pragma unroll
+  for (int p = 0; p < TMX_RC_ZP; ++p)
+  {
+    const int u = p & 3;
+    s[(2 * u) & 3] = __builtin_fma(zq[2 * p], df[2 * p], s[(2 * u) & 3]);
+    s[(2 * u + 1) & 3] = __builtin_fma(zq[2 * p + 1], df[2 * p + 1], s[(2 * u + 1) & 3]);
+  }
+#else
 #pragma unroll
   for (int p = 0; p < TMX_RC_ZP; ++p)
   {
@@ -572,6 +594,7 @@ TMX_DEVFN double dpart_separator_row_rc(const HotLds& h, const DMap& m, const do
     s[(2 * u) & 3] = __builtin_fma(zq[2 * p], l[p].x - r[p].x, s[(2 * u) & 3]);
     s[(2 * u + 1) & 3] = __builtin_fma(zq[2 * p + 1], l[p].y - r[p].y, s[(2 * u + 1) & 3]);
   }
+#endif
   return quad_sum((s[0] + s[1]) + (s[2] + s[3]));
 }
 TMX_DEVFN double dpart_correct_rc(const HotLds& h, const DMap& m, double y, const double (&gr)[2 * TMX_RC_GP], const double (&gc)[8])
@@ -830,6 +853,242 @@ TMX_DEVFN void row_phase_c(RowRegsT<NA>& g, double alpha, double rho_b, double r
   }
 }
 
+// ---- LOCK-STEP rows (round 6) --------------------------------------------------------------------------------------------------
+// The wave that carries the rows beyond NT (config 1: 48 of 304 rows, wave 3) runs phases A and C for TWO rows per thread.  The two
+// chains are independent, but row_phase_c sat behind `if (act)` - one exec-masked region per row - and the row_phase_a tails were sunk
+// into the regions of the conditional e stores, so the ISA was row 0's whole dependent chain (~24 fp64 operations at the dependent-issue
+// latency of a lone wave) and THEN row 1's, while the three other waves waited at the barrier.  Here both rows advance one operation at
+// a time: after every operation an empty volatile asm takes the two results as read-write operands, so neither the IR passes nor the
+// machine scheduler can pull one chain ahead of the other (and nothing can be sunk behind a branch).  Inactive rows are computed too -
+// their registers hold zeros (row_load), every product stays zero and nothing of them is stored.  Same operations in the same order
+// per row as row_phase_a / row_phase_c: bit-identical results.
+// pin(...): the values become opaque read-write operands of ONE empty volatile asm - they must all exist before it and nothing that
+// depends on its outputs can start before it.  Up to six doubles (two rows x (row + two aux vars)).
+TMX_DEVFN void pin(double& a)
+{
+#if TMX_IS_GCN
+  asm volatile("" : "+v"(a));
+#endif
+}
+TMX_DEVFN void pin(double& a, double& b)
+{
+#if TMX_IS_GCN
+  asm volatile("" : "+v"(a), "+v"(b));
+#endif
+}
+TMX_DEVFN void pin(double& a, double& b, double& c)
+{
+#if TMX_IS_GCN
+  asm volatile("" : "+v"(a), "+v"(b), "+v"(c));
+#endif
+}
+TMX_DEVFN void pin(double& a, double& b, double& c, double& d)
+{
+#if TMX_IS_GCN
+  asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+#endif
+}
+TMX_DEVFN void pin(double& a, double& b, double& c, double& d, double& e, double& f)
+{
+#if TMX_IS_GCN
+  asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f));
+#endif
+}
+template <int NR>
+TMX_DEVFN void lockstep(double (&s)[NR])
+{
+  if constexpr (NR == 1)
+    pin(s[0]);
+  else
+    pin(s[0], s[1]);
+}
+template <int NR, int NA>
+TMX_DEVFN void lockstep(double (&a)[NR][NA])
+{
+  if constexpr (NR == 1 && NA == 1)
+    pin(a[0][0]);
+  else if constexpr (NR == 1)
+    pin(a[0][0], a[0][1]);
+  else if constexpr (NA == 1)
+    pin(a[0][0], a[1][0]);
+  else
+    pin(a[0][0], a[0][1], a[1][0], a[1][1]);
+}
+// the row value and the values of its aux vars at the same depth of their (independent) chains
+template <int NR, int NA>
+TMX_DEVFN void lockstep(double (&s)[NR], double (&a)[NR][NA])
+{
+  if constexpr (NR == 1 && NA == 1)
+    pin(s[0], a[0][0]);
+  else if constexpr (NR == 1)
+    pin(s[0], a[0][0], a[0][1]);
+  else if constexpr (NA == 1)
+    pin(s[0], a[0][0], s[1], a[1][0]);
+  else
+    pin(s[0], a[0][0], a[0][1], s[1], a[1][0], a[1][1]);
+}
+template <int NR, int NA>
+TMX_DEVFN void rows_phase_a(const RowRegsT<NA> (&g)[NR], double sigma, double rho_b, double (&ta)[NR][NA], double (&e)[NR])
+{
+  double gg[NR], gb[NR][NA], bq[NR][NA], in[NR][NA], gs[NR];
+#pragma unroll
+  for (int q = 0; q < NR; ++q)
+  {
+    gg[q] = __builtin_fma(g[q].rr, g[q].z, -g[q].y);
+#pragma unroll
+    for (int k = 0; k < NA; ++k)
+    {
+      gb[q][k] = __builtin_fma(rho_b, g[q].za[k], -g[q].ya[k]);
+      bq[q][k] = __builtin_fma(sigma, g[q].xa[k], -g[q].qa[k]);
+    }
+  }
+  lockstep(gg, gb);
+  lockstep(bq);
+#pragma unroll
+  for (int q = 0; q < NR; ++q)
+#pragma unroll
+    for (int k = 0; k < NA; ++k)
+      in[q][k] = __builtin_fma(g[q].sa[k], gg[q], bq[q][k]);
+  lockstep(in);
+#pragma unroll
+  for (int q = 0; q < NR; ++q)
+#pragma unroll
+    for (int k = 0; k < NA; ++k)
+      ta[q][k] = __builtin_fma(g[q].bb[k], gb[q][k], in[q][k]);
+  lockstep(ta);
+#pragma unroll
+  for (int q = 0; q < NR; ++q)
+    gs[q] = (g[q].sa[0] * g[q].di[0]) * ta[q][0];
+  lockstep(gs);
+  if constexpr (NA > 1)
+  {
+#pragma unroll
+    for (int q = 0; q < NR; ++q)
+      gs[q] = __builtin_fma(g[q].sa[1] * g[q].di[1], ta[q][1], gs[q]);
+    lockstep(gs);
+  }
+#pragma unroll
+  for (int q = 0; q < NR; ++q)
+    e[q] = g[q].act ? __builtin_fma(-g[q].fac, gs[q], gg[q]) : 0.0;
+  lockstep(e);
+}
+template <int NR, int NA>
+TMX_DEVFN void rows_phase_c(RowRegsT<NA> (&g)[NR], double alpha, double rho_b, double rhoi_b, const double (&dot)[NR], const double (&ta)[NR][NA],
+                            double (&dyr)[NR], double (&dxa)[NR][NA], double (&dya)[NR][NA])
+{
+  const double om = 1.0 - alpha;
+  double v[NR][NA], xt[NR][NA], gs[NR], f[NR], ax[NR], zr[NR], zn[NR], t1[NR][NA];
+#pragma unroll
+  for (int q = 0; q < NR; ++q)
+#pragma unroll
+    for (int k = 0; k < NA; ++k)
+      v[q][k] = __builtin_fma(-(g[q].rr * g[q].sa[k]), dot[q], ta[q][k]);
+  lockstep(v);
+#pragma unroll
+  for (int q = 0; q < NR; ++q)
+    gs[q] = (g[q].sa[0] * g[q].di[0]) * v[q][0];
+  lockstep(gs);
+  if constexpr (NA > 1)
+  {
+#pragma unroll
+    for (int q = 0; q < NR; ++q)
+      gs[q] = __builtin_fma(g[q].sa[1] * g[q].di[1], v[q][1], gs[q]);
+    lockstep(gs);
+  }
+#pragma unroll
+  for (int q = 0; q < NR; ++q)
+    f[q] = g[q].fac * gs[q];
+  lockstep(f);
+#pragma unroll
+  for (int q = 0; q < NR; ++q)
+#pragma unroll
+    for (int k = 0; k < NA; ++k)
+      t1[q][k] = __builtin_fma(-g[q].sa[k], f[q], v[q][k]);
+  lockstep(t1);
+#pragma unroll
+  for (int q = 0; q < NR; ++q)
+#pragma unroll
+    for (int k = 0; k < NA; ++k)
+      xt[q][k] = t1[q][k] * g[q].di[k];
+  lockstep(xt);
+  // from here on the aux vars' own updates run beside the rest of the row's chain (they only need xt)
+  double xn[NR][NA], zra[NR][NA], zna[NR][NA], ua[NR][NA], u[NR];
+#pragma unroll
+  for (int q = 0; q < NR; ++q)
+  {
+    ax[q] = __builtin_fma(g[q].sa[0], xt[q][0], dot[q]);
+#pragma unroll
+    for (int k = 0; k < NA; ++k)
+    {
+      xn[q][k] = __builtin_fma(alpha, xt[q][k], om * g[q].xa[k]);
+      zra[q][k] = __builtin_fma(alpha * g[q].bb[k], xt[q][k], om * g[q].za[k]);
+    }
+  }
+  lockstep(ax, zra);
+  lockstep(xn);
+  if constexpr (NA > 1)
+  {
+#pragma unroll
+    for (int q = 0; q < NR; ++q)
+      ax[q] = __builtin_fma(g[q].sa[1], xt[q][1], ax[q]);
+  }
+#pragma unroll
+  for (int q = 0; q < NR; ++q)
+#pragma unroll
+    for (int k = 0; k < NA; ++k)
+      ua[q][k] = __builtin_fma(rhoi_b, g[q].ya[k], zra[q][k]);
+  lockstep(ax, ua);
+#pragma unroll
+  for (int q = 0; q < NR; ++q)
+  {
+    zr[q] = __builtin_fma(alpha, ax[q], om * g[q].z);
+#pragma unroll
+    for (int k = 0; k < NA; ++k)
+      zna[q][k] = clampd(ua[q][k], 0.0, g[q].ub[k]);
+  }
+  lockstep(zr, zna);
+#pragma unroll
+  for (int q = 0; q < NR; ++q)
+  {
+    u[q] = __builtin_fma(g[q].rri, g[q].y, zr[q]);
+#pragma unroll
+    for (int k = 0; k < NA; ++k)
+      ua[q][k] = zra[q][k] - zna[q][k];
+  }
+  lockstep(u, ua);
+#pragma unroll
+  for (int q = 0; q < NR; ++q)
+  {
+    zn[q] = clampd(u[q], g[q].lo, g[q].hi);
+#pragma unroll
+    for (int k = 0; k < NA; ++k)
+      dya[q][k] = rho_b * ua[q][k];
+  }
+  lockstep(zn, dya);
+#pragma unroll
+  for (int q = 0; q < NR; ++q)
+    u[q] = zr[q] - zn[q];
+  lockstep(u);
+#pragma unroll
+  for (int q = 0; q < NR; ++q)
+    dyr[q] = g[q].rr * u[q];
+  lockstep(dyr);
+#pragma unroll
+  for (int q = 0; q < NR; ++q)
+  {
+    g[q].z = zn[q];
+    g[q].y += dyr[q];
+#pragma unroll
+    for (int k = 0; k < NA; ++k)
+    {
+      dxa[q][k] = xn[q][k] - g[q].xa[k];
+      g[q].xa[k] = xn[q][k];
+      g[q].za[k] = zna[q][k];
+      g[q].ya[k] += dya[q][k];
+    }
+  }
+}
+
 // Runs n_iter ADMM iterations without any residual check; the iterate is loaded from / stored to the workspace around
 // the burst.  `keep_last` stores delta_x / delta_y of the final iteration (needed by the termination test).
 // Thread tid owns the constraint rows tid + q*NT (NROW = 512 / NT of them, with their aux vars); the primary variables
@@ -840,7 +1099,10 @@ struct TmxTag
   static constexpr bool value = V;
 };
 #define TMX_NROW (512 / TMX_QP_NT)
-#if defined(TMX_PROFILE) && defined(TMX_PROFILE_LOOP)
+#ifndef TMX_ROWS_LOCKSTEP
+#define TMX_ROWS_LOCKSTEP 3  // lock-step phases A / C: 1 in every instantiation, 2 in the two-row ones, 3 in the two-row and the two-slack ones; 0: the row-after-row code of rounds 2 - 5 (same bits; A/B switch)
+#endif
+#if defined(TMX_PROFILE) && defined(TMX_PROFILE_LOOP) && TMX_PROFILE_LOOP != 2
 #define TMX_LTICK(s) TMX_TICK(s)
 #else
 #define TMX_LTICK(s) ((void)0)  // per-phase ticks inside the iteration perturb it (~100 cycles each): opt-in
@@ -902,6 +1164,14 @@ TMX_DEVFN int admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, bo
     const int first = TMX_QP_NT - extra;    // first thread that takes one
     rowi[q] = (extra > 0 && tid >= first) ? q * TMX_QP_NT + (tid - first) : -1;
   }
+  // (round 6) the assignment built at upload (DevProblem::row_perm): same rows, spread so that the two-row threads hold one-slack rows;
+  // which thread holds a row changes no operation on it
+  if (const int* rperm = P->row_perm)
+  {
+#pragma unroll
+    for (int q = 0; q < NR; ++q)
+      rowi[q] = rperm[q * TMX_QP_NT + tid];
+  }
   RowRegsT<NAX> g[NR];
 #pragma unroll
   for (int q = 0; q < NR; ++q)
@@ -961,11 +1231,12 @@ TMX_DEVFN int admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, bo
   // to a loop for the remainder)
   double cj[16];
 #ifndef TMX_CJX
-#define TMX_CJX 0  // extra cached pairs beyond 16 (config 1's goal waypoint has 17 rows: 7 goal + 2 upright + 8 collision)
+#define TMX_CJX 1  // extra cached pairs beyond 16 (config 1's goal waypoint has 17 rows: 7 goal + 2 upright + 8 collision; its seven threads ran a
+                  // dependent index -> coefficient -> product loop in phase B of every iteration: + 180 cycles for their whole wave, tools/prof_loop.py)
 #endif
-#if TMX_CJX
-  double cjx[2 * TMX_CJX];
-#endif
+  [[maybe_unused]] double cjx[TMX_CJX ? 2 * TMX_CJX : 1];
+  // entry k of the cached column (k a literal after unrolling): the first sixteen in cj, the extra pairs in cjx
+  auto cjv = [&](int k) __attribute__((always_inline)) { return k < 16 ? cj[k < 16 ? k : 0] : cjx[(TMX_CJX && k >= 16) ? k - 16 : 0]; };
   int e0off = 0, q_rest = 0, q_end = 0;
   {
     const int t = vt, j = vj;
@@ -1043,14 +1314,28 @@ TMX_DEVFN int admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, bo
   auto iteration = [&](auto keep_tag) __attribute__((always_inline)) {
     constexpr bool keep = decltype(keep_tag)::value;
     double ta[NR][NAX];
-#pragma unroll
-    for (int q = 0; q < NR; ++q)
+    if constexpr (TMX_ROWS_LOCKSTEP == 1 || (TMX_ROWS_LOCKSTEP >= 2 && NR >= 2) || (TMX_ROWS_LOCKSTEP == 3 && NAX >= 2))
     {
-      const double e = row_phase_a(g[q], sigma, rho_b, ta[q]);
-      if (has[q])
-        h.hr[epos[q]] = e;
+      double e[NR];
+      rows_phase_a<NR, NAX>(g, sigma, rho_b, ta, e);
+#pragma unroll
+      for (int q = 0; q < NR; ++q)
+        if (has[q])
+          h.hr[epos[q]] = e[q];
     }
+    else
+    {
+#pragma unroll
+      for (int q = 0; q < NR; ++q)
+      {
+        const double e = row_phase_a(g[q], sigma, rho_b, ta[q]);
+        if (has[q])
+          h.hr[epos[q]] = e;
+      }
+    }
+    TMX_LT(0);
     TMX_SYNC();
+    TMX_LT(2);
     if (pv)
     {
       const double gb = __builtin_fma(rbp, zb, -yb);
@@ -1086,22 +1371,40 @@ TMX_DEVFN int admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, bo
       }
       h.ty[mp.slot] = __builtin_fma(bb, gb, __builtin_fma(sigma, xp, -qv) + ate);
     }
+    TMX_LT(3);
     TMX_SYNC();
+    TMX_LT(5);
     TMX_LTICK(2);
     // dense nested-dissection solve: interiors -> separators (4 lanes per variable) -> correction
     double yint = 0.0;
     if (INTW && interior)
     {
+#ifndef TMX_BSEP_EARLY
+#define TMX_BSEP_EARLY 1  // 0: b_sep is read inside the conditional store, after the dot (rounds 2 - 5; same bits; A/B switch)
+#endif
+#if TMX_BSEP_EARLY
+      // b_sep of the separator row this thread completes: requested WITH the right-hand side of the dot product (an unconditional load
+      // at a clamped index), not after it inside the conditional store - one LDS round trip less on the path the separator phase waits for
+      const double bsl = RC ? bsep[wr_yl ? i_yl : 0] : 0.0;
+#endif
       if constexpr (RC && INTW)
         yint = dpart_interior_rc(h, mp, gr);
       else
         yint = dpart_interior(h, mp);
+#if TMX_BSEP_EARLY
+      const double outl = RC ? bsl - cnext * yint : cnext * yint;  // RC: b_sep - C y_left in one slot
+      if (wr_yl)
+        h.sx[i_yl] = outl;
+#else
       if (wr_yl)
         h.sx[i_yl] = RC ? bsep[i_yl] - cnext * yint : cnext * yint;  // RC: b_sep - C y_left in one slot
+#endif
       if (wr_yr)
         h.sx[i_yr] = cprev * yint;
     }
+    TMX_LT(6);
     TMX_SYNC();
+    TMX_LT(7);
     TMX_LTICK(3);
     if (tid < 256)
     {
@@ -1117,7 +1420,9 @@ TMX_DEVFN int admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, bo
         h.sx[192 + qsp] = qcnext * xs;
       }
     }
+    TMX_LT(8);
     TMX_SYNC();
+    TMX_LT(9);
     if (INTW && interior)
     {
       if constexpr (RC && INTW)
@@ -1125,10 +1430,91 @@ TMX_DEVFN int admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, bo
       else
         h.tp[vp] = dpart_correct(h, mp, yint);
     }
+    TMX_LT(10);
     TMX_SYNC();
+    TMX_LT(13);
     TMX_LTICK(4);
     // phase C
     const double xtv = h.tp[vp];
+    if constexpr (TMX_ROWS_LOCKSTEP == 1 || (TMX_ROWS_LOCKSTEP >= 2 && NR >= 2) || (TMX_ROWS_LOCKSTEP == 3 && NAX >= 2))
+    {
+      // x~ of both rows' waypoints first (eight 16-byte loads in flight), then the two dots and the two chains in lock-step
+      tmx_d2 x2[NR][4];
+#pragma unroll
+      for (int q = 0; q < NR; ++q)
+      {
+        const tmx_lds_d2* xb = reinterpret_cast<const tmx_lds_d2*>(h.tp + tb[q]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          x2[q][j] = xb[j];
+      }
+      double d0[NR], p0[NR], p1[NR], p2[NR], p3[NR];
+#pragma unroll
+      for (int q = 0; q < NR; ++q)
+      {
+        p0[q] = g[q].c[0] * x2[q][0].x;
+        p1[q] = g[q].c[1] * x2[q][0].y;
+        p2[q] = g[q].c[2] * x2[q][1].x;
+        p3[q] = g[q].c[3] * x2[q][1].y;
+      }
+      lockstep(p0);
+      lockstep(p1);
+      lockstep(p2);
+      lockstep(p3);
+#pragma unroll
+      for (int q = 0; q < NR; ++q)
+      {
+        p0[q] = __builtin_fma(g[q].c[4], x2[q][2].x, p0[q]);
+        p1[q] = __builtin_fma(g[q].c[5], x2[q][2].y, p1[q]);
+        p2[q] = __builtin_fma(g[q].c[6], x2[q][3].x, p2[q]);
+        p3[q] = __builtin_fma(g[q].c[7], x2[q][3].y, p3[q]);
+      }
+      lockstep(p0);
+      lockstep(p1);
+      lockstep(p2);
+      lockstep(p3);
+#pragma unroll
+      for (int q = 0; q < NR; ++q)
+      {
+        p0[q] = p0[q] + p1[q];
+        p2[q] = p2[q] + p3[q];
+      }
+      lockstep(p0);
+      lockstep(p2);
+#pragma unroll
+      for (int q = 0; q < NR; ++q)
+        d0[q] = p0[q] + p2[q];
+      lockstep(d0);
+      double dyr0[NR], dxa0[NR][NAX], dya0[NR][NAX];
+      rows_phase_c<NR, NAX>(g, alpha, rho_b, rhoi_b, d0, ta, dyr0, dxa0, dya0);
+#pragma unroll
+      for (int q = 0; q < NR; ++q)
+      {
+        const RowRegsT<NAX>& gq = g[q];
+        if (keep && gq.act)
+        {
+          const int r = rowi[q];
+          w.dyr[r] = dyr0[q];
+          for (int k = 0; k < gq.na; ++k)
+          {
+            w.dxa[w.aoff[r] + k] = dxa0[q][k];
+            w.dyba[w.aoff[r] + k] = dya0[q][k];
+          }
+        }
+        if constexpr (keep)
+        {
+          kd_dyr[q] = gq.act ? dyr0[q] : 0.0;
+#pragma unroll
+          for (int k = 0; k < NAX; ++k)
+          {
+            const bool ok = gq.act && k < gq.na;
+            kd_dya[q][k] = ok ? dya0[q][k] : 0.0;
+            kd_dxa[q][k] = ok ? dxa0[q][k] : 0.0;
+          }
+        }
+      }
+    }
+    else
 #pragma unroll
     for (int q = 0; q < NR; ++q)
     {
@@ -1193,6 +1579,7 @@ TMX_DEVFN int admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, bo
       yb += dy;
     }
     TMX_LTICK(5);
+    TMX_LT(14);
     // the next iteration's phase A only touches registers; its hr stores are ordered after every thread's tp reads by
     // the barrier that follows them, and tp is rewritten only after that barrier
   };
@@ -1293,10 +1680,10 @@ TMX_DEVFN int admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, bo
       {
         const tmx_lds_d2* ep = reinterpret_cast<const tmx_lds_d2*>(h.hr + e0off);
   #pragma unroll
-        for (int k2 = 0; k2 < 8; ++k2)
+        for (int k2 = 0; k2 < 8 + TMX_CJX; ++k2)
         {
           const tmx_d2 e2 = ep[k2];
-          const double p0 = cj[2 * k2] * e2.x, p1 = cj[2 * k2 + 1] * e2.y;
+          const double p0 = cjv(2 * k2) * e2.x, p1 = cjv(2 * k2 + 1) * e2.y;
           // entries 2 k2 and 2 k2 + 1: partial sum (k & 3) inside the groups of four, the first one in the remainder
           const int ka = 2 * k2, kb = 2 * k2 + 1;
           if ((ka & 3) == 0)
@@ -1418,11 +1805,11 @@ TMX_DEVFN int admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, bo
       {
         const tmx_lds_d2* ep = reinterpret_cast<const tmx_lds_d2*>(h.sx + e0off);
 #pragma unroll
-        for (int k2 = 0; k2 < 8; ++k2)
+        for (int k2 = 0; k2 < 8 + TMX_CJX; ++k2)
         {
           const tmx_d2 e2 = ep[k2];
-          s0 = __builtin_fma(cj[2 * k2], e2.x, s0);
-          s1 = __builtin_fma(cj[2 * k2 + 1], e2.y, s1);
+          s0 = __builtin_fma(cjv(2 * k2), e2.x, s0);
+          s1 = __builtin_fma(cjv(2 * k2 + 1), e2.y, s1);
         }
       }
       for (int q = q_rest; q < q_end; ++q)
@@ -1529,8 +1916,18 @@ TMX_DEVFN int admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, bo
 #pragma unroll
     for (int k = 0; k < 18; ++k)
       m18[k] = m[k];
-    const bool sall[18] = { false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false };
+    [[maybe_unused]] const bool sall[18] = { false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false };
+#ifndef TMX_CHECK_REDUCE_ROWS
+#define TMX_CHECK_REDUCE_ROWS 1  // 0: the value-by-value block_reduce of rounds 2 - 5 (same bits; A/B switch)
+#endif
+#if TMX_CHECK_REDUCE_ROWS
+    static_assert(TMX_QP_NT == 256, "block_max_rows: 16 rows of 16 lanes");
+    // scratch: the partials in sx (read by certs8 before the routine's first barrier, re-zeroed below after its last), the results in
+    // tp (free between iterations; the loop needs its never-written slots finite, which maxima of finite norms are)
+    block_max_rows<18>(m18, h.sx, h.tp, tid);
+#else
     block_reduce<18>(m18, sall, w.red, tid, TMX_QP_NT);  // ends with every thread holding all values; its barriers free the buffers
+#endif
 #if defined(TMX_FINE) && TMX_FINE == 2
     TMX_TICK(6);
 #endif
@@ -1584,7 +1981,7 @@ TMX_DEVFN int admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, bo
     }
     go_on = __builtin_amdgcn_readfirstlane(go_on ? 1 : 0) != 0;
     TMX_TICK(9);
-#ifdef TMX_PROFILE
+#if defined(TMX_PROFILE) && !(defined(TMX_PROFILE_LOOP) && TMX_PROFILE_LOOP == 2)
     pc[5] += 1 + (go_on ? (1LL << 20) : 0);  // diagnostic: checks, and checks after which the burst went on (slot 5 is unused on this path)
 #endif
     if (!go_on)
@@ -1646,12 +2043,21 @@ TMX_DEVFN int admm_run_fast(const QpWs& w, const DevProblem* P, int n_iter, bool
   const bool intw = wave0 < w.NX - (dp.P - 1) * w.D;
   // does any row of this wave carry two aux vars (abs rows)?  Hinge-only waves run the one-slot instantiation
   bool my2 = false;
+  const int* rperm = P->row_perm;
   {
-    const int r0 = tid;
-    if (r0 < w.R && w.act[r0] && w.naux[r0] > 1)
+    const int r0 = rperm ? rperm[tid] : tid;
+    if (r0 >= 0 && r0 < w.R && w.act[r0] && w.naux[r0] > 1)
       my2 = true;
+    if (rperm != nullptr && TMX_NROW > 1)
+    {
+      const int r1 = rperm[TMX_QP_NT + tid];
+      if (r1 >= 0 && r1 < w.R && w.act[r1] && w.naux[r1] > 1)
+        my2 = true;
+    }
   }
-  const bool aux2 = two || __builtin_amdgcn_ballot_w64(my2) != 0ULL;
+  // (without the upload-time assignment the rows beyond NT are the LAST slots - abs rows in every problem seen so far - and the
+  //  two-row waves run the two-slot instantiation unasked, as in rounds 2 - 5)
+  const bool aux2 = (two && rperm == nullptr) || __builtin_amdgcn_ballot_w64(my2) != 0ULL;
 #ifdef TMX_BURST_NOINLINE
   QpWs* wsh = reinterpret_cast<QpWs*>(w.wself);
   if (tid == 0)
@@ -1667,12 +2073,19 @@ TMX_DEVFN int admm_run_fast(const QpWs& w, const DevProblem* P, int n_iter, bool
   int done;
   if (!rc)
     done = TMX_BURST_CALL(false, TMX_NROW, true);
-  else if (two)
+  else if (two && aux2)
   {
     if (intw)
       done = TMX_BURST_CALL(true, TMX_NROW, true);
     else
       done = TMX_BURST_CALL(true, TMX_NROW, false);
+  }
+  else if (two)
+  {
+    if (intw)
+      done = TMX_BURST_CALL1(true, TMX_NROW, true);
+    else
+      done = TMX_BURST_CALL1(true, TMX_NROW, false);
   }
   else if (aux2)
   {

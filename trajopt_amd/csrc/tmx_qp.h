@@ -36,7 +36,24 @@
 #else
 #define TMX_CLK() 0LL  // the profiler is opt-in (-DTMX_PROFILE): s_memtime costs ~100 cycles per tick
 #endif
-#if TMX_IS_DEVICE && defined(TMX_PROFILE)
+#if TMX_IS_DEVICE && defined(TMX_PROFILE) && defined(TMX_PROFILE_LOOP) && TMX_PROFILE_LOOP == 2
+// LOOP-ONLY profile (-DTMX_PROFILE -DTMX_PROFILE_LOOP=2 [-DTMX_PROF_TID=<thread>]): the phase ticks only restart the clock, and the
+// eleven TMX_LT points inside the ADMM iteration - before and after each of its five barriers and at its end - own the slots, seen by
+// thread TMX_PROF_TID (default 0; 192 = the wave that carries the second rows): compute and barrier wait of every phase per wave
+// (tools/prof_loop.py)
+#define TMX_TICK(slot)                                                                                                \
+  do                                                                                                                  \
+  {                                                                                                                   \
+    tlast = TMX_CLK();                                                                                                \
+  } while (0)
+#define TMX_LT(slot)                                                                                                  \
+  do                                                                                                                  \
+  {                                                                                                                   \
+    const long long now_ = TMX_CLK();                                                                                 \
+    pc[slot] += now_ - tlast;                                                                                         \
+    tlast = now_;                                                                                                     \
+  } while (0)
+#elif TMX_IS_DEVICE && defined(TMX_PROFILE)
 #define TMX_TICK(slot)                                                                                                \
   do                                                                                                                  \
   {                                                                                                                   \
@@ -44,8 +61,13 @@
     pc[slot] += now_ - tlast;                                                                                         \
     tlast = now_;                                                                                                     \
   } while (0)
+#define TMX_LT(slot) ((void)0)
 #else
 #define TMX_TICK(slot) ((void)0)
+#define TMX_LT(slot) ((void)0)
+#endif
+#ifndef TMX_PROF_TID
+#define TMX_PROF_TID 0
 #endif
 // one extra split point inside a phase (slot 5 is unused on the fast path): -DTMX_PROFILE -DTMX_PROFILE_POINT=<n>
 #if TMX_IS_DEVICE && defined(TMX_PROFILE) && defined(TMX_PROFILE_POINT)
@@ -122,6 +144,93 @@ TMX_DEVFN void block_reduce(double (&v)[K], const bool (&is_sum)[K], double* red
       v[k] = x;
     }
   }
+}
+// ---- K maxima over a 256-thread workgroup, LEVEL-MAJOR (round 6) ---------------------------------------------------------------
+// block_reduce above reduces value after value, and under the register pressure of the burst function the scheduler keeps that order:
+// the ISA was 18 strictly sequential chains of 4 x (two DPP moves -> canonicalising v_max -> v_max) followed by eight v_readlane whose
+// scalars were spilled to VGPR lanes - 8.2 k cycles per call for 18 values (profiles/r06/r06f_prof_phases_check_split.txt).  Here every
+// butterfly level is written for all K values at once and fenced with sched_barrier, so the K chains are interleaved (independent
+// instructions back to back instead of one dependent chain after another); the four row maxima of a wave go to LDS directly (no
+// v_readlane, no scalar registers), and the 16 partials of each value are combined by ONE more 16-lane DPP butterfly - value k in
+// row k of the workgroup - instead of 4 loads + 3 maxima per value and thread.  A maximum does not depend on the order of its operands,
+// and v_max_f64 on operands that are results of arithmetic (never signalling NaNs) is fmax without the canonicalising copies: every
+// thread ends with the same bits as block_reduce's.
+//   part : >= 256 + 16 * (K - 16) doubles of LDS scratch (readable up to 288), fin : >= K doubles; NT = 256; K <= 18
+TMX_DEVFN double raw_max_f64(double a, double b)
+{
+#if TMX_IS_GCN
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+#else
+  return fmax(a, b);
+#endif
+}
+#if TMX_IS_GCN
+#define TMX_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define TMX_SCHED_FENCE() ((void)0)
+#endif
+template <int CTRL>
+TMX_DEVFN double dpp_mov_f64(double x)
+{
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+template <int K, int CTRL>
+TMX_DEVFN void row_max_level(double (&v)[K])
+{
+  double o[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k)
+    o[k] = dpp_mov_f64<CTRL>(v[k]);
+  TMX_SCHED_FENCE();
+#pragma unroll
+  for (int k = 0; k < K; ++k)
+    v[k] = raw_max_f64(v[k], o[k]);
+  TMX_SCHED_FENCE();
+}
+template <int K>
+TMX_DEVFN void row_max16(double (&v)[K])
+{
+  row_max_level<K, 0xB1>(v);   // quad_perm [1,0,3,2]
+  row_max_level<K, 0x4E>(v);   // quad_perm [2,3,0,1]
+  row_max_level<K, 0x141>(v);  // row_half_mirror
+  row_max_level<K, 0x140>(v);  // row_mirror: every lane of a 16-lane row holds the row maximum
+}
+template <int K, class PP, class PF>
+TMX_DEVFN void block_max_rows(double (&v)[K], PP part, PF fin, int tid)
+{
+  static_assert(K <= 18, "two butterfly registers: values 0..15 in the 16 rows of the workgroup, 16 and 17 in rows 0 and 1 again");
+  constexpr int K2 = K > 16 ? K - 16 : 0;
+  row_max16<K>(v);
+  TMX_SYNC();  // the callers' readers of `part` are done
+  if ((tid & 15) == 0)
+  {
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+      part[k * 16 + (tid >> 4)] = v[k];
+  }
+  TMX_SYNC();
+  {
+    double x[K2 ? 2 : 1];
+    x[0] = part[tid];  // value tid >> 4, partial tid & 15 (rows >= K: finite scratch, never stored)
+    if (K2)
+      x[K2 ? 1 : 0] = part[256 + (tid < 16 * K2 ? tid : 0)];
+    row_max16<(K2 ? 2 : 1)>(x);
+    if ((tid & 15) == 0)
+    {
+      if ((tid >> 4) < K)
+        fin[tid >> 4] = x[0];
+      if (K2 && tid < 16 * K2)
+        fin[16 + (tid >> 4)] = x[K2 ? 1 : 0];
+    }
+  }
+  TMX_SYNC();
+#pragma unroll
+  for (int k = 0; k < K; ++k)
+    v[k] = fin[k];
 }
 #else
 template <int K>

@@ -1002,7 +1002,7 @@ struct QpShared
 #define TMX_PROF_LEAVE(sh)                                                                                            \
   do                                                                                                                  \
   {                                                                                                                   \
-    if (threadIdx.x == 0)                                                                                             \
+    if (threadIdx.x == TMX_PROF_TID)                                                                                  \
       for (int q_ = 0; q_ < 16; ++q_)                                                                                 \
       {                                                                                                               \
         Bt->prof[(size_t)b * 16 + q_] += pc[q_];                                                                      \

@@ -145,6 +145,11 @@ struct DevProblem
   int wv_gmax;
   int wv_aux2;   // bit i: some lane's row slot i holds a row with two slack variables
   int* wv_plan;
+  // ROW -> THREAD assignment of the register-resident ADMM bursts (tmx_part.h; round 6): row_perm[q * 256 + tid] = row slot held by thread
+  // tid as its q-th row (-1: none), built at upload from the slack counts of the slots (build_row_perm): the rows beyond 256 pair up
+  // ONE-slack rows on the last threads and the two-slack rows sit on single-row threads of other waves, so that no wave runs two rows
+  // with two slack variables each per thread.  nullptr: thread tid holds row tid, the rows beyond 256 sit on the last threads
+  int* row_perm;
   // diagnostic switches (tmx_debug_set_flags, not part of include/tmx.h): bit 0 = the D x D diagonal blocks of the reduced KKT matrix by
   // the scalar list-order loop instead of v_mfma_f64_16x16x4_f64 (tests/test_gpu_parity.py compares the two on the same QP)
   int dbg_flags;
