@@ -862,37 +862,39 @@ TMX_DEVFN void row_phase_c(RowRegsT<NA>& g, double alpha, double rho_b, double r
 // machine scheduler can pull one chain ahead of the other (and nothing can be sunk behind a branch).  Inactive rows are computed too -
 // their registers hold zeros (row_load), every product stays zero and nothing of them is stored.  Same operations in the same order
 // per row as row_phase_a / row_phase_c: bit-identical results.
-// pin(...): the values become opaque read-write operands of ONE empty volatile asm - they must all exist before it and nothing that
-// depends on its outputs can start before it.  Up to six doubles (two rows x (row + two aux vars)).
+// pin(...): a stage boundary of the lock-step chains.  TMX_PIN_ASM=1 (default): the values become opaque read-write operands of ONE
+// empty volatile asm - they must all exist before it and nothing that depends on its outputs can start before it (holds against IR
+// passes and the machine scheduler alike).  0: a scheduling barrier only; 2: nothing (source order alone).  Measured same-box with the
+// s_waitcnt repair below in place: 150.1 k / 148.5 k QP solves/s (1 / 0), profiles/r06/r06j_ab5_*.
+#ifndef TMX_PIN_ASM
+#define TMX_PIN_ASM 1
+#endif
+#if TMX_IS_GCN && TMX_PIN_ASM == 1
+#define TMX_PIN_BODY(...) asm volatile("" : __VA_ARGS__)
+#elif TMX_IS_GCN && TMX_PIN_ASM == 0
+#define TMX_PIN_BODY(...) __builtin_amdgcn_sched_barrier(0)
+#else
+#define TMX_PIN_BODY(...) ((void)0)
+#endif
 TMX_DEVFN void pin(double& a)
 {
-#if TMX_IS_GCN
-  asm volatile("" : "+v"(a));
-#endif
+  TMX_PIN_BODY("+v"(a));
 }
 TMX_DEVFN void pin(double& a, double& b)
 {
-#if TMX_IS_GCN
-  asm volatile("" : "+v"(a), "+v"(b));
-#endif
+  TMX_PIN_BODY("+v"(a), "+v"(b));
 }
 TMX_DEVFN void pin(double& a, double& b, double& c)
 {
-#if TMX_IS_GCN
-  asm volatile("" : "+v"(a), "+v"(b), "+v"(c));
-#endif
+  TMX_PIN_BODY("+v"(a), "+v"(b), "+v"(c));
 }
 TMX_DEVFN void pin(double& a, double& b, double& c, double& d)
 {
-#if TMX_IS_GCN
-  asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
-#endif
+  TMX_PIN_BODY("+v"(a), "+v"(b), "+v"(c), "+v"(d));
 }
 TMX_DEVFN void pin(double& a, double& b, double& c, double& d, double& e, double& f)
 {
-#if TMX_IS_GCN
-  asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f));
-#endif
+  TMX_PIN_BODY("+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f));
 }
 template <int NR>
 TMX_DEVFN void lockstep(double (&s)[NR])
@@ -1128,6 +1130,18 @@ struct BurstCtl
   int iter;  // in: ADMM iterations done so far
   int n_checks{ 0 }, n_continued{ 0 };
 };
+// s_waitcnt vmcnt(0) in front of the iteration loop (round 6).  The peeled last iteration of a burst stores its deltas through the
+// generic pointers of QpWs - FLAT stores, which count on vmcnt as well as lgkmcnt.  Nothing in the loop ever waits for vmcnt, and the
+// backend's s_waitcnt insertion treats a flat operation that is still pending on EITHER counter as "LDS results may arrive out of order":
+// every first wait after a batch of LDS loads in the loop became lgkmcnt(0) - all twelve loads of a dot product back before its first
+// FMA.  Rounds 2 - 5 were saved by accident: a spill reload (scratch_load + s_waitcnt vmcnt(0)) sat between the stores and the loop; when
+// this round's changes removed spills, the conservative waits appeared in EVERY instantiation (ISA bisection: the count of
+// `lgkmcnt(0)` in qp_admm_fast_nl 854 -> 1042).  The explicit wait is the modelled event that clears the flag.
+#if TMX_IS_GCN
+#define TMX_RETIRE_FLAT() __builtin_amdgcn_s_waitcnt(0x0F70)  // vmcnt(0) expcnt(7) lgkmcnt(15)
+#else
+#define TMX_RETIRE_FLAT() ((void)0)
+#endif
 template <bool RC, int NR, bool INTW, int NAX = 2>
 TMX_DEVFN int admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, bool keep_last, int tid, long long* pc, long long& tlast,
                                double* res14 = nullptr, BurstCtl* ctl = nullptr)
@@ -1829,6 +1843,7 @@ TMX_DEVFN int admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, bo
   if (ctl == nullptr)
   {
     const int n_plain = keep_last ? n_iter - 1 : n_iter;
+    TMX_RETIRE_FLAT();
     for (int it = 0; it < n_plain; ++it)
       iteration(TmxTag<false>{});
     if (keep_last && n_iter > 0)
@@ -1886,6 +1901,7 @@ TMX_DEVFN int admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, bo
       next = min(next, (iter_done / rint + 1) * rint);
     const int n = next - iter_done;
     load_matrix_rows();
+    TMX_RETIRE_FLAT();
     for (int it = 0; it < n - 1; ++it)
       iteration(TmxTag<false>{});
     if (n > 0)

@@ -158,7 +158,10 @@ TMX_DEVFN void block_reduce(double (&v)[K], const bool (&is_sum)[K], double* red
 //   part : >= 256 + 16 * (K - 16) doubles of LDS scratch (readable up to 288), fin : >= K doubles; NT = 256; K <= 18
 TMX_DEVFN double raw_max_f64(double a, double b)
 {
-#if TMX_IS_GCN
+#ifndef TMX_RAW_MAX_ASM
+#define TMX_RAW_MAX_ASM 1
+#endif
+#if TMX_IS_GCN && TMX_RAW_MAX_ASM
   double r;
   asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
   return r;
@@ -166,7 +169,7 @@ TMX_DEVFN double raw_max_f64(double a, double b)
   return fmax(a, b);
 #endif
 }
-#if TMX_IS_GCN
+#if TMX_IS_GCN && !defined(TMX_NO_SCHED_FENCE)
 #define TMX_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #else
 #define TMX_SCHED_FENCE() ((void)0)
