@@ -173,10 +173,11 @@ TMX_DEVFN void gj_rows(double* M, int mslot, int stride, int nmat, int nmax, boo
   if (active && i == 0)
   {
     double* rb = buf + m * bs;
+    // (wn and j0 are even and the row buffers 16-byte aligned - the step loop reads them as pairs: pairs are written too, round 6)
 #pragma unroll
-    for (int c = 0; c < W; ++c)
+    for (int c = 0; c < W; c += 2)
       if (c < wn)
-        rb[j0 + c] = val[c];
+        *reinterpret_cast<tmx_d2*>(rb + j0 + c) = tmx_d2{ val[c], val[c + 1] };
     if (j0 == 0)
       rb[stride] = fast_rcp(val[0]);
   }
@@ -211,7 +212,9 @@ TMX_DEVFN void gj_rows(double* M, int mslot, int stride, int nmat, int nmax, boo
       {
         // the index is clamped BEFORE use: the compiler hoists the indexed register write above the range test (it
         // writes a copy and selects afterwards), and an out-of-range M0 index would clobber unrelated registers
-        const int kc = kk < 0 ? 0 : (kk >= W ? W - 1 : kk);
+        // (round 6: the clamp of the scalar kk is emitted as v_med3_i32 - a VECTOR register - and an index in a vector register makes
+        //  every indexed access a waterfall loop, four of them per elimination step; handed back as a scalar it is one s_set_gpr_idx)
+        const int kc = TMX_UNI_I(kk < 0 ? 0 : (kk >= W ? W - 1 : kk));
         const double keep = val[kc];
         val[kc] = (kk >= 0 && kk < wn) ? pc : keep;
       }
@@ -225,15 +228,15 @@ TMX_DEVFN void gj_rows(double* M, int mslot, int stride, int nmat, int nmax, boo
       {
         double* rb = buf + ((par ^ 1) * nmat + m) * bs;
 #pragma unroll
-        for (int c = 0; c < W; ++c)
+        for (int c = 0; c < W; c += 2)
           if (c < wn)
-            rb[j0 + c] = val[c];
+            *reinterpret_cast<tmx_d2*>(rb + j0 + c) = tmx_d2{ val[c], val[c + 1] };
         // next pivot = M[k+1][k+1]: lives in the segment that contains column k+1
         {
           double pvn;
           if (INDEXED)
           {
-            const int kn = kk + 1 < 0 ? 0 : (kk + 1 >= W ? W - 1 : kk + 1);
+            const int kn = TMX_UNI_I(kk + 1 < 0 ? 0 : (kk + 1 >= W ? W - 1 : kk + 1));
             pvn = val[kn];
           }
           else
