@@ -1613,6 +1613,84 @@ TMX_DEVFN int admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, bo
     if (pv)
       h.tp[vp] = xp;
   };
+  // ---- the scaling reciprocals of the check (round 6).  norms14 / certs8 divide by E and D of this thread's rows, slack variables and
+  // primary variable: seven fast_rcp (a load, v_rcp_f64 and four dependent FMAs each) that stood one after the other inside the
+  // per-row regions, recomputed by certs8.  Formed here ONCE per check, all loads first and the Newton steps of all of them stage by
+  // stage (lock-step), then read from registers.  Same function on the same operands: same bits.
+#ifndef TMX_CHECK_RCP_BATCH
+#define TMX_CHECK_RCP_BATCH 1  // 0: fast_rcp where the quotient is used (rounds 2 - 6a; same bits; A/B switch)
+#endif
+  [[maybe_unused]] double rc_er[NR], rc_eba[NR][NAX], rc_da[NR][NAX], rc_pv[2];
+  auto check_rcps = [&]() __attribute__((always_inline)) {
+    double x_er[NR], x_eba[NR][NAX], x_da[NR][NAX], x_pv[2];
+#pragma unroll
+    for (int q = 0; q < NR; ++q)
+    {
+      const bool ok = g[q].act;
+      const int r = ok ? rowi[q] : 0;
+      x_er[q] = ok ? w.Er[r] : 1.0;
+#pragma unroll
+      for (int k = 0; k < NAX; ++k)
+      {
+        const bool oka = ok && k < g[q].na;
+        const int a = oka ? w.aoff[r] + k : 0;
+        x_eba[q][k] = oka ? w.Eba[a] : 1.0;
+        x_da[q][k] = oka ? w.Da[a] : 1.0;
+      }
+    }
+    x_pv[0] = pv ? w.Ebp[v] : 1.0;
+    x_pv[1] = pv ? w.Dp[v] : 1.0;
+#if TMX_IS_GCN
+    // fast_rcp, stage by stage over all operands
+    double e_er[NR], e_eba[NR][NAX], e_da[NR][NAX], e_pv[2];
+#define TMX_RCP_ALL(EXPR)                                                                                             \
+  do                                                                                                                  \
+  {                                                                                                                   \
+    _Pragma("unroll") for (int q = 0; q < NR; ++q)                                                                    \
+    {                                                                                                                 \
+      { double& X = x_er[q]; double& R = rc_er[q]; double& E = e_er[q]; EXPR; }                                       \
+      _Pragma("unroll") for (int k = 0; k < NAX; ++k)                                                                 \
+      {                                                                                                               \
+        { double& X = x_eba[q][k]; double& R = rc_eba[q][k]; double& E = e_eba[q][k]; EXPR; }                         \
+        { double& X = x_da[q][k]; double& R = rc_da[q][k]; double& E = e_da[q][k]; EXPR; }                            \
+      }                                                                                                               \
+    }                                                                                                                 \
+    _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                                     \
+    {                                                                                                                 \
+      double& X = x_pv[u]; double& R = rc_pv[u]; double& E = e_pv[u]; EXPR;                                           \
+    }                                                                                                                 \
+    lockstep(rc_er, rc_eba);                                                                                          \
+    lockstep(rc_da);                                                                                                  \
+    pin(rc_pv[0], rc_pv[1]);                                                                                          \
+  } while (0)
+    TMX_RCP_ALL((void)E; R = __builtin_amdgcn_rcp(X));
+    TMX_RCP_ALL((void)R; E = __builtin_fma(-X, R, 1.0));
+    lockstep(e_er, e_eba);
+    lockstep(e_da);
+    pin(e_pv[0], e_pv[1]);
+    TMX_RCP_ALL(R = __builtin_fma(E, R, R));
+    TMX_RCP_ALL((void)R; E = __builtin_fma(-X, R, 1.0));
+    lockstep(e_er, e_eba);
+    lockstep(e_da);
+    pin(e_pv[0], e_pv[1]);
+    TMX_RCP_ALL(R = __builtin_fma(E, R, R));
+#undef TMX_RCP_ALL
+#else
+#pragma unroll
+    for (int q = 0; q < NR; ++q)
+    {
+      rc_er[q] = fast_rcp(x_er[q]);
+#pragma unroll
+      for (int k = 0; k < NAX; ++k)
+      {
+        rc_eba[q][k] = fast_rcp(x_eba[q][k]);
+        rc_da[q][k] = fast_rcp(x_da[q][k]);
+      }
+    }
+    rc_pv[0] = fast_rcp(x_pv[0]);
+    rc_pv[1] = fast_rcp(x_pv[1]);
+#endif
+  };
   auto norms14 = [&](double (&m)[22]) __attribute__((always_inline)) {
   #pragma unroll
     for (int q = 0; q < NR; ++q)
@@ -1642,7 +1720,7 @@ TMX_DEVFN int admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, bo
           if (k < gq.na)
             ax = ax + gq.sa[k] * gq.xa[k];
         {
-          const double z = gq.z, einv = fast_rcp(w.Er[r]);
+          const double z = gq.z, einv = TMX_CHECK_RCP_BATCH ? rc_er[q] : fast_rcp(w.Er[r]);
           m[0] = fmax(m[0], fabs(einv * (ax - z)));
           m[1] = fmax(m[1], fabs(ax - z));
           m[2] = fmax(m[2], fabs(z));
@@ -1655,7 +1733,7 @@ TMX_DEVFN int admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, bo
           if (k < gq.na)
           {
             const int a = w.aoff[r] + k;
-            const double axa = gq.bb[k] * gq.xa[k], z = gq.za[k], einv = fast_rcp(w.Eba[a]);
+            const double axa = gq.bb[k] * gq.xa[k], z = gq.za[k], einv = TMX_CHECK_RCP_BATCH ? rc_eba[q][k] : fast_rcp(w.Eba[a]);
             m[0] = fmax(m[0], fabs(einv * (axa - z)));
             m[1] = fmax(m[1], fabs(axa - z));
             m[2] = fmax(m[2], fabs(z));
@@ -1664,7 +1742,7 @@ TMX_DEVFN int admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, bo
             m[5] = fmax(m[5], fabs(einv * axa));
             const double aty = gq.sa[k] * gq.y + gq.bb[k] * gq.ya[k];
             const double res = gq.qa[k] + aty;
-            const double dinv = fast_rcp(w.Da[a]);
+            const double dinv = TMX_CHECK_RCP_BATCH ? rc_da[q][k] : fast_rcp(w.Da[a]);
             m[6] = fmax(m[6], fabs(dinv * res));
             m[7] = fmax(m[7], fabs(res));
             m[8] = fmax(m[8], fabs(gq.qa[k]));
@@ -1677,7 +1755,7 @@ TMX_DEVFN int admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, bo
     if (pv)
     {
       {
-        const double ax = bb * xp, z = zb, einv = fast_rcp(w.Ebp[v]);
+        const double ax = bb * xp, z = zb, einv = TMX_CHECK_RCP_BATCH ? rc_pv[0] : fast_rcp(w.Ebp[v]);
         m[0] = fmax(m[0], fabs(einv * (ax - z)));
         m[1] = fmax(m[1], fabs(ax - z));
         m[2] = fmax(m[2], fabs(z));
@@ -1736,7 +1814,7 @@ TMX_DEVFN int admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, bo
       }
       const double aty = ((s0 + s1) + (s2 + s3)) + bb * yb;
       const double res = (qv + px) + aty;
-      const double dinv = fast_rcp(w.Dp[v]);
+      const double dinv = TMX_CHECK_RCP_BATCH ? rc_pv[1] : fast_rcp(w.Dp[v]);
       m[6] = fmax(m[6], fabs(dinv * res));
       m[7] = fmax(m[7], fabs(res));
       m[8] = fmax(m[8], fabs(qv));
@@ -1806,7 +1884,7 @@ TMX_DEVFN int admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, bo
             const int a = w.aoff[r] + k;
             const double da = kp_dya[q][k];
             m[14] = fmax(m[14], fabs(w.Eba[a] * da));
-            const double dinv = fast_rcp(w.Da[a]);
+            const double dinv = TMX_CHECK_RCP_BATCH ? rc_da[q][k] : fast_rcp(w.Da[a]);
             m[15] = fmax(m[15], fabs((gq.sa[k] * dy + gq.bb[k] * da) * dinv));
             m[16] = fmax(m[16], fabs(w.Da[a] * kd_dxa[q][k]));
           }
@@ -1831,7 +1909,7 @@ TMX_DEVFN int admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, bo
       }
       for (int q = q_rest; q < q_end; ++q)
         s0 += w.coef[w.wp_list[q] * D + vj] * h.sx[e0off + (q - q0v)];
-      const double dinv = fast_rcp(w.Dp[v]);
+      const double dinv = TMX_CHECK_RCP_BATCH ? rc_pv[1] : fast_rcp(w.Dp[v]);
       m[15] = fmax(m[15], fabs(((s0 + s1) + bb * dy) * dinv));
       m[16] = fmax(m[16], fabs(w.Dp[v] * kd_dxp));
       double px = w.pd[v] * kd_dxp;
@@ -1873,6 +1951,8 @@ TMX_DEVFN int admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, bo
 #pragma unroll
       for (int k = 0; k < 22; ++k)
         m[k] = 0.0;
+      if (TMX_CHECK_RCP_BATCH)
+        check_rcps();
       norms14(m);
       double m14[14];
 #pragma unroll
@@ -1922,6 +2002,8 @@ TMX_DEVFN int admm_burst_core(const QpWs& w, const DevProblem* P, int n_iter, bo
 #pragma unroll
     for (int k = 0; k < 22; ++k)
       m[k] = 0.0;
+    if (TMX_CHECK_RCP_BATCH)
+      check_rcps();
     norms14(m);
 #if defined(TMX_FINE) && TMX_FINE == 2
     TMX_TICK(14);
