@@ -379,3 +379,29 @@ def test_mfma_block_assembly_against_the_scalar_loop(gpu, cid):
     assert same == 16
     assert dx.max() <= 1e-9
 
+
+
+@pytest.mark.gpu
+def test_row_to_thread_assignment_changes_no_bit(gpu_ctx_factory):
+    """round 6: which thread of the register-resident ADMM burst holds which constraint row is decided at upload (DevProblem::row_perm,
+    tmx_api.cpp: the two-row threads take one-slack rows).  The assignment must not change a single operation: BASELINE config 1, 64 seeds,
+    whole optimize() with the assignment and with TMX_ROW_PERM=0 (row r on thread r) - status, QP counts and trajectories byte for byte."""
+    import os
+    pci, s, g = pc.cfg(1)
+    x0 = configs.seeds_for(1, pci, s, g, 64)
+    sig = []
+    for env in (None, "0"):
+        if env is None:
+            os.environ.pop("TMX_ROW_PERM", None)
+        else:
+            os.environ["TMX_ROW_PERM"] = env
+        try:
+            ctx = gpu_ctx_factory()
+            pc.make_ctx_inputs(ctx, pci, x0)   # the switch is read at upload
+            ctx.run(0)
+            r = ctx.results()
+            sig.append((r["status"].tobytes(), r["n_qp_solves"].tobytes(), r["x"].tobytes()))
+            ctx.close()
+        finally:
+            os.environ.pop("TMX_ROW_PERM", None)
+    assert sig[0] == sig[1]

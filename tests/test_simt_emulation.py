@@ -169,3 +169,28 @@ def test_random_problems_on_the_fast_path(simt_lib, orc):
     """a slice of the device tier's own sweep (seed 5: D <= 8, n_steps * D <= 256)"""
     from test_fuzz_parity import _sweep
     _sweep(5, 5, simt_lib)
+
+
+def test_row_to_thread_assignment_changes_no_bit(simt_lib):
+    """round 6 (tmx_api.cpp, DevProblem::row_perm): the upload-time row -> thread assignment of the register-resident burst against
+    TMX_ROW_PERM=0 (row r on thread r) on the emulation: the first Model::optimize() of BASELINE config 1 (304 row slots: 48 threads carry
+    two rows) byte for byte - solution, status, iterations, rho updates, polish status."""
+    pci, s, g = pc.cfg(1)
+    x0 = configs.seeds_for(1, pci, s, g, 2, sigma=0.05)
+    out = []
+    for env in (None, "0"):
+        if env is None:
+            os.environ.pop("TMX_ROW_PERM", None)
+        else:
+            os.environ["TMX_ROW_PERM"] = env
+        try:
+            ctx = runtime.Context(0, simt_lib)
+            pc.make_ctx_inputs(ctx, pci, x0)
+            ctx.convexify()
+            xq, cvx, rec = ctx.qp_solve()
+            out.append((xq.tobytes(), [(r.osqp_status, r.osqp_iter, r.rho_updates, r.polish_status, r.hash_active) for r in rec]))
+            ctx.close()
+        finally:
+            os.environ.pop("TMX_ROW_PERM", None)
+    assert out[0][1] == out[1][1]
+    assert out[0][0] == out[1][0]
